@@ -1,0 +1,305 @@
+/*
+ * mmx.h -- C ABI of the MI355X-native batched inverse-kinematics hot path.
+ *
+ * This is the drop-in boundary for ONE path of facebookresearch/momentum: the
+ * per-iteration  FK -> Jacobian/residual assembly -> (JtJ + lambda I) d = Jtr
+ * -> theta update  loop, batched over independent characters.  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference
+ * checkout).  Plain pointers and sizes only; no C++/torch types; status-code
+ * returns, no exceptions across the ABI (the C++ shell in
+ * include/momentum_amd/ converts non-zero into std::runtime_error to match
+ * MT_CHECK/MT_THROW, momentum/common/checks.h:36-45, exception.h:24-66).
+ *
+ * Conventions shared with the reference:
+ *   - quaternions are (x,y,z,w) (Eigen storage order; tensor API
+ *     pymomentum/tensor_ik/tensor_error_function_utility.h:58-66),
+ *   - joint parameter order per joint is tx,ty,tz,rx,ry,rz,scale
+ *     (momentum/character/types.h:21-27, kParametersPerJoint = 7),
+ *   - joints are listed parent-before-child (momentum/character/skeleton.cpp:16-22),
+ *   - the dense Jacobian of one instance is COLUMN-MAJOR M x P
+ *     (Eigen default; momentum/math/resizeable_matrix.h:18,32-34), rows ordered
+ *     [position block (3 rows / constraint)] then [orientation block (9 rows /
+ *     constraint)] = order of addErrorFunction
+ *     (momentum/character_solver/skeleton_solver_function.cpp:217-261).
+ *
+ * Threading: one handle = one device + caller-provided stream; calls on one
+ * handle must be serialised by the caller (the reference's solver objects are
+ * not thread-safe either, momentum/math/resizeable_matrix.h:36-38).
+ */
+#ifndef MMX_H_
+#define MMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMX_ABI_VERSION 1
+#define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
+#define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
+#define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
+
+typedef enum mmx_status {
+  MMX_OK = 0,
+  MMX_ERR_INVALID_ARGUMENT = 1, /* MT_CHECK failure class */
+  MMX_ERR_SIZE_MISMATCH = 2, /* solver.cpp:77, parameter_transform.cpp:112-121 */
+  MMX_ERR_DEVICE = 3, /* HIP runtime error (message in mmx_last_error) */
+  MMX_ERR_UNSUPPORTED = 4, /* shape outside what the kernels were built for */
+  MMX_ERR_OUT_OF_MEMORY = 5,
+  MMX_ERR_NO_DEVICE = 6 /* no gfx950 device: the product path never falls back to CPU */
+} mmx_status;
+
+/* Per-instance solve status (mmx_solve: status[B]). */
+#define MMX_SOLVE_OK 0
+#define MMX_SOLVE_NONFINITE 1 /* NaN/Inf result -> theta reverted to theta_init
+                                 (pymomentum/tensor_ik/tensor_ik.cpp:168-173) */
+#define MMX_SOLVE_NOT_PD 2 /* non-positive Cholesky pivot seen (dense LLT result is
+                              unchecked in the reference, gauss_newton_solver.cpp:251) */
+
+/* Where the caller's bulk arrays live. */
+#define MMX_MEM_HOST 0
+#define MMX_MEM_DEVICE 1
+
+/* Jacobian layouts of mmx_eval_jacobian. */
+#define MMX_LAYOUT_COL_MAJOR 0 /* J[b][p*M + i]   (the reference's layout) */
+#define MMX_LAYOUT_ROW_MAJOR 1 /* J[b][i*P + p] */
+
+/* Solver step rule. */
+#define MMX_STEP_GN_FIXED_LAMBDA 0 /* GaussNewtonSolverT, constant regularization
+                                      (momentum/solver/gauss_newton_solver.cpp:224-280) */
+#define MMX_STEP_LM_SCHEDULE 1 /* gain-ratio lambda schedule, lambda-form of
+                                  momentum/character_solver/trust_region_qr.cpp:244-268
+                                  (no direct reference implementation) */
+
+/*
+ * Static rig = Skeleton + ParameterTransform of a momentum::Character
+ * (momentum/character/character.h:32-125; only .skeleton and
+ * .parameterTransform are read on this path,
+ * skeleton_solver_function.cpp:30-33).  All pointers are HOST pointers and are
+ * copied by mmx_rig_create.
+ */
+typedef struct mmx_rig_desc {
+  int32_t num_joints; /* J  = skeleton.joints.size() */
+  int32_t num_params; /* P  = parameterTransform.numAllModelParameters() */
+  const int32_t* parent; /* [J]  Joint::parent, -1 for kInvalidIndex (joint.h:18-36) */
+  const float* pre_rotation; /* [J][4] Joint::preRotation (x,y,z,w) */
+  const float* translation_offset; /* [J][3] Joint::translationOffset */
+  /* ParameterTransform::transform, SparseRowMatrix 7J x P == CSR
+     (momentum/character/parameter_transform.h:62-95, math/types.h:191) */
+  const int32_t* pt_outer; /* [7J+1] outerIndexPtr */
+  const int32_t* pt_inner; /* [nnz]  innerIndexPtr (column = model parameter) */
+  const float* pt_value; /* [nnz]  valuePtr */
+  const float* pt_offsets; /* [7J]   ParameterTransform::offsets (may be NULL = zeros) */
+} mmx_rig_desc;
+
+/*
+ * Per-instance constraint payload = the std::vector<PositionDataT>/
+ * <OrientationDataT> of one PositionErrorFunction + one OrientationErrorFunction
+ * per batch element (momentum/character_solver/position_error_function.h:16-29,
+ * orientation_error_function.h:16-36, error_function_types.h:34-44).  The parent
+ * joint of each constraint is shared by the batch and fixed at
+ * mmx_problem_create.  Orientation quaternions are normalised on ingest like the
+ * OrientationDataT constructor does (orientation_error_function.h:33-35).
+ */
+typedef struct mmx_constraint_data {
+  const float* pos_offset; /* [B][Kp][3] */
+  const float* pos_target; /* [B][Kp][3] */
+  const float* pos_weight; /* [B][Kp]    ConstraintData::weight */
+  const float* ori_offset; /* [B][Ko][4] (x,y,z,w) */
+  const float* ori_target; /* [B][Ko][4] (x,y,z,w) */
+  const float* ori_weight; /* [B][Ko] */
+  float pos_function_weight; /* SkeletonErrorFunction::weight_ of the position block
+                                (skeleton_error_function.h:44-141, setWeight) */
+  float ori_function_weight; /* ... of the orientation block */
+  int32_t memory; /* MMX_MEM_HOST: copied; MMX_MEM_DEVICE: borrowed, caller keeps alive */
+} mmx_constraint_data;
+
+/*
+ * POD mirror of SolverOptions + GaussNewtonSolverOptions
+ * (momentum/solver/solver.h:19-34, gauss_newton_solver.h:17-59).
+ */
+typedef struct mmx_gn_options {
+  int32_t min_iterations; /* SolverOptions::minIterations (default 1) */
+  int32_t max_iterations; /* SolverOptions::maxIterations (default 2) */
+  float threshold; /* SolverOptions::threshold (default 1): converged when
+                      |e_prev-e|/(|e|+FLT_MIN) <= threshold*FLT_EPSILON, solver.cpp:98-99 */
+  float regularization; /* GaussNewtonSolverBaseOptions::regularization (default 0.05) */
+  int32_t do_line_search; /* GaussNewtonSolverBaseOptions::doLineSearch (default 0);
+                             Armijo backtracking gauss_newton_solver.cpp:283-313 */
+  int32_t step_rule; /* MMX_STEP_* */
+  /* LM schedule knobs (only read when step_rule == MMX_STEP_LM_SCHEDULE) */
+  float lm_lambda_min; /* default 1e-6 */
+  float lm_lambda_max; /* default 1e6 */
+  float lm_up; /* lambda *= lm_up   when rho < 0.25 or the step is rejected (default 4) */
+  float lm_down; /* lambda *= lm_down when rho > 0.75 (default 0.5) */
+} mmx_gn_options;
+
+typedef struct mmx_rig mmx_rig; /* opaque: device-resident rig constants */
+typedef struct mmx_problem mmx_problem; /* opaque: one batch of B instances on one device */
+
+/* Sensible defaults == the reference's struct initialisers cited above. */
+void mmx_gn_options_default(mmx_gn_options* opt);
+
+/* ABI / build info. */
+int32_t mmx_abi_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* mmx_last_error(void);
+/* Number of visible HIP devices (0 when there is none; never throws). */
+int32_t mmx_device_count(void);
+
+/*
+ * Replaces: constructing Skeleton + ParameterTransform for
+ * SkeletonSolverFunctionT (skeleton_solver_function.cpp:25-39).  Validates the
+ * parent-before-child invariant (skeleton.cpp:16-22) and CSR bounds, uploads the
+ * rig and its derived integer tables to `device`.
+ */
+int32_t mmx_rig_create(const mmx_rig_desc* desc, int32_t device, mmx_rig** out);
+void mmx_rig_destroy(mmx_rig* rig);
+int32_t mmx_rig_num_joints(const mmx_rig* rig);
+int32_t mmx_rig_num_params(const mmx_rig* rig);
+
+/*
+ * Replaces: one SkeletonSolverFunctionT + PositionErrorFunctionT +
+ * OrientationErrorFunctionT per batch element, as built per task in
+ * pymomentum/tensor_ik/tensor_ik.cpp:136-141.  pos_parent / ori_parent are HOST
+ * arrays of joint indices (ConstraintData::parent).  All device scratch is sized
+ * here, once.
+ */
+int32_t mmx_problem_create(
+    mmx_rig* rig,
+    int32_t batch,
+    int32_t num_pos,
+    const int32_t* pos_parent,
+    int32_t num_ori,
+    const int32_t* ori_parent,
+    mmx_problem** out);
+void mmx_problem_destroy(mmx_problem* problem);
+
+/* M = 3*Kp + 9*Ko (JointErrorFunctionT::getJacobianSize, joint_error_function-inl.h:300-302). */
+int32_t mmx_problem_num_rows(const mmx_problem* problem);
+int32_t mmx_problem_batch(const mmx_problem* problem);
+
+/*
+ * Replaces SolverT::setEnabledParameters -> SkeletonSolverFunctionT::
+ * setEnabledParameters (solver.cpp:40-47, skeleton_solver_function.cpp:45-61):
+ * enabled[P] (HOST, 0/1) is the ParameterSet; derives activeJointParams
+ * (parameter_transform.cpp:97-107) and the compacted enabled list
+ * (gauss_newton_solver.cpp:57-66).  Default after create: all enabled.
+ */
+int32_t mmx_problem_set_enabled(mmx_problem* problem, const uint8_t* enabled);
+
+/* Replaces PositionErrorFunctionT::setConstraints / OrientationErrorFunctionT::
+ * setConstraints + setWeight for every batch element. */
+int32_t mmx_problem_set_constraints(
+    mmx_problem* problem,
+    const mmx_constraint_data* data,
+    void* stream);
+
+/*
+ * The graded kernel and the parity hook.  Replaces, per batch element,
+ * SkeletonSolverFunctionT::initializeJacobianComputation + computeJacobianBlock
+ * for both blocks (skeleton_solver_function.cpp:200-261 ->
+ * joint_error_function-inl.h:179-297) into a pre-zeroed dense Jacobian
+ * (gauss_newton_solver.cpp:166).  theta_dev [B][P], jac_dev [B][M*P] in `layout`,
+ * res_dev [B][M], err_dev [B] (double, may be NULL) are DEVICE pointers.
+ * Every element of jac_dev is written (zeros included).
+ */
+int32_t mmx_eval_jacobian(
+    mmx_problem* problem,
+    const float* theta_dev,
+    float* jac_dev,
+    float* res_dev,
+    double* err_dev,
+    int32_t layout,
+    void* stream);
+
+/*
+ * Forward pass only.  Replaces SkeletonStateT<T>(params, skeleton)
+ * (skeleton_state.cpp:22-28,87-121).  state_dev [B][J][8] =
+ * (tx,ty,tz, qx,qy,qz,qw, s) world transforms (the layout of
+ * pymomentum's skel_state tensors).
+ */
+int32_t mmx_eval_skeleton_state(
+    mmx_problem* problem,
+    const float* theta_dev,
+    float* state_dev,
+    void* stream);
+
+/*
+ * Normal equations of one GN step without solving them: H = J[:,E]^T J[:,E]
+ * (full symmetric n x n, n = |E| enabled parameters, row-major == col-major),
+ * g = J[:,E]^T r.  Replaces GaussNewtonSolverT::computeJtJFromJacobianBlocks
+ * (gauss_newton_solver.cpp:110-221).  jtj_dev [B][n*n], jtr_dev [B][n].
+ */
+int32_t mmx_eval_normal_equations(
+    mmx_problem* problem,
+    const float* theta_dev,
+    float* jtj_dev,
+    float* jtr_dev,
+    double* err_dev,
+    void* stream);
+
+/*
+ * Replaces, for every batch element, SolverT::solve with a GaussNewtonSolverT
+ * (solver.cpp:50-128, gauss_newton_solver.cpp:224-313) exactly as the batched
+ * driver does per task (tensor_ik.cpp:127-177), including its NaN/Inf revert.
+ * theta_dev [B][P] in/out (DEVICE).  Optional DEVICE outputs (NULL to skip):
+ *   final_error[B]   double  the value solve() returns (error at the theta
+ *                            before the last step, solver.cpp:126-127)
+ *   iterations[B]    int32   errorHistory_.size()
+ *   status[B]        int32   MMX_SOLVE_*
+ *   error_history    double [B][max_iterations] (unused tail = 0)
+ */
+int32_t mmx_solve(
+    mmx_problem* problem,
+    const mmx_gn_options* options,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    void* stream);
+
+/* Host-buffer convenience wrappers (the reference's boundary hands over host
+ * memory): copy in, run on the handle's stream, copy out, synchronise. */
+int32_t mmx_solve_host(
+    mmx_problem* problem,
+    const mmx_gn_options* options,
+    float* theta_host,
+    double* final_error_host,
+    int32_t* iterations_host,
+    int32_t* status_host);
+int32_t mmx_eval_jacobian_host(
+    mmx_problem* problem,
+    const float* theta_host,
+    float* jac_host,
+    float* res_host,
+    double* err_host,
+    int32_t layout);
+
+/*
+ * Host-side integer bookkeeping, exposed so that it can be checked bit-exactly
+ * without a GPU (north_star: "bit-exact on joint-index bookkeeping").
+ * All outputs are HOST arrays owned by the caller.
+ *   level[J]            depth of each joint (root = 0)
+ *   tin[J], tout[J]     DFS pre-order interval: a is an ancestor-or-self of j
+ *                       iff tin[a] <= tin[j] < tout[a]
+ *   active_joint_params[7J]  ParameterTransformT::computeActiveJointParams(enabled)
+ *   enabled_list[P], *num_enabled  GaussNewtonSolverT::updateEnabledParameters
+ */
+int32_t mmx_host_tables(
+    const mmx_rig_desc* desc,
+    const uint8_t* enabled,
+    int32_t* level,
+    int32_t* tin,
+    int32_t* tout,
+    uint8_t* active_joint_params,
+    int32_t* enabled_list,
+    int32_t* num_enabled);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* MMX_H_ */

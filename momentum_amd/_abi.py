@@ -1,0 +1,111 @@
+"""ctypes mirrors of the POD structs in include/mmx.h (the C-ABI boundary).
+
+Pure plumbing: no compute here.  Field order and types must match include/mmx.h exactly;
+tests/test_abi.py checks sizes and that the built library exports every declared symbol.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+MMX_ABI_VERSION = 1
+MMX_OK = 0
+MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
+MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
+MMX_LAYOUT_COL_MAJOR, MMX_LAYOUT_ROW_MAJOR = 0, 1
+MMX_STEP_GN_FIXED_LAMBDA, MMX_STEP_LM_SCHEDULE = 0, 1
+
+
+class RigDesc(C.Structure):
+    _fields_ = [
+        ("num_joints", C.c_int32),
+        ("num_params", C.c_int32),
+        ("parent", c_int32_p),
+        ("pre_rotation", c_float_p),
+        ("translation_offset", c_float_p),
+        ("pt_outer", c_int32_p),
+        ("pt_inner", c_int32_p),
+        ("pt_value", c_float_p),
+        ("pt_offsets", c_float_p),
+    ]
+
+
+class ConstraintData(C.Structure):
+    _fields_ = [
+        ("pos_offset", C.c_void_p),
+        ("pos_target", C.c_void_p),
+        ("pos_weight", C.c_void_p),
+        ("ori_offset", C.c_void_p),
+        ("ori_target", C.c_void_p),
+        ("ori_weight", C.c_void_p),
+        ("pos_function_weight", C.c_float),
+        ("ori_function_weight", C.c_float),
+        ("memory", C.c_int32),
+    ]
+
+
+class GnOptions(C.Structure):
+    """POD mirror of SolverOptions + GaussNewtonSolverOptions
+    (momentum/solver/solver.h:19-34, gauss_newton_solver.h:17-59)."""
+
+    _fields_ = [
+        ("min_iterations", C.c_int32),
+        ("max_iterations", C.c_int32),
+        ("threshold", C.c_float),
+        ("regularization", C.c_float),
+        ("do_line_search", C.c_int32),
+        ("step_rule", C.c_int32),
+        ("lm_lambda_min", C.c_float),
+        ("lm_lambda_max", C.c_float),
+        ("lm_up", C.c_float),
+        ("lm_down", C.c_float),
+    ]
+
+    @classmethod
+    def make(
+        cls,
+        min_iterations=1,
+        max_iterations=2,
+        threshold=1.0,
+        regularization=0.05,
+        do_line_search=False,
+        step_rule=MMX_STEP_GN_FIXED_LAMBDA,
+        lm_lambda_min=1e-6,
+        lm_lambda_max=1e6,
+        lm_up=4.0,
+        lm_down=0.5,
+    ) -> "GnOptions":
+        return cls(
+            int(min_iterations),
+            int(max_iterations),
+            float(threshold),
+            float(regularization),
+            int(bool(do_line_search)),
+            int(step_rule),
+            float(lm_lambda_min),
+            float(lm_lambda_max),
+            float(lm_up),
+            float(lm_down),
+        )
+
+
+def as_ptr(a: np.ndarray, ctype):
+    """Typed pointer to a C-contiguous numpy array (caller keeps `a` alive)."""
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def void_p(a) -> C.c_void_p:
+    """void* of a numpy array, a raw device address (int) or None."""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(int(a))

@@ -1,0 +1,798 @@
+// mmx_oracle.hpp -- CPU ORACLE (test infrastructure, NOT a product path).
+//
+// A from-scratch C++17 restatement of the reference algorithm for the batched-IK
+// hot path of facebookresearch/momentum, with no third-party dependencies.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+// it.  The product path (momentum_amd/csrc) never includes or links this file.
+//
+// Pinning status: the reference itself cannot be compiled or imported in the
+// build container (it needs Eigen >=5.0, MS-GSL, fmt, spdlog, dispenso, none of
+// which is installed or vendored).  The oracle is pinned
+// against the golden vectors and known-answer tests the reference's own test
+// suite holds for this path (tests/test_oracle_golden.py):
+//   - FK golden value       momentum/test/character/forward_kinematics_test.cpp:49,80-86
+//   - JointState algebra    momentum/test/character/joint_state_test.cpp:65-216
+//   - Jacobian vs finite differences, |r|^2 == error, 2 J^T r == gradient
+//                           momentum/test/character_solver/error_function_helpers.cpp:169-281
+//   - GN known answers      momentum/test/solver/gauss_newton_solver_test.cpp:263-285
+//   - IK end-to-end         momentum/test/character_solver/inverse_kinematics_test.cpp:60-121
+// Eigen's summation order (LLT blocking, GEMM kernels) is NOT bit-pinned by any
+// reference test; parity is therefore "pinned at the reference tests' own
+// tolerances, unpinned at the bit level".
+//
+// Every function cites the reference file:line it follows (paths relative to
+// the reference checkout).
+#pragma once
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace mmx_oracle {
+
+constexpr int kParametersPerJoint = 7; // momentum/character/types.h:21
+
+// ---------------------------------------------------------------------------------------------
+// tiny fixed-size algebra with Eigen's formulas
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct V3 {
+  T x, y, z;
+  T operator[](int i) const {
+    return i == 0 ? x : (i == 1 ? y : z);
+  }
+};
+template <class T>
+inline V3<T> operator+(const V3<T>& a, const V3<T>& b) {
+  return {a.x + b.x, a.y + b.y, a.z + b.z};
+}
+template <class T>
+inline V3<T> operator-(const V3<T>& a, const V3<T>& b) {
+  return {a.x - b.x, a.y - b.y, a.z - b.z};
+}
+template <class T>
+inline V3<T> operator*(T s, const V3<T>& a) {
+  return {s * a.x, s * a.y, s * a.z};
+}
+template <class T>
+inline V3<T> cross(const V3<T>& a, const V3<T>& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class T>
+inline T dot(const V3<T>& a, const V3<T>& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+
+template <class T>
+struct Quat { // Eigen storage order (x,y,z,w)
+  T x, y, z, w;
+};
+
+// Eigen::Quaternion product (Eigen/src/Geometry/Quaternion.h, quat_product)
+template <class T>
+inline Quat<T> qmul(const Quat<T>& a, const Quat<T>& b) {
+  return {
+      a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+      a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+      a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x,
+      a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+
+// Eigen::QuaternionBase::_transformVector: v + w*uv + vec x uv with uv = 2 (vec x v)
+template <class T>
+inline V3<T> qrot(const Quat<T>& q, const V3<T>& v) {
+  const V3<T> qv{q.x, q.y, q.z};
+  V3<T> uv = cross(qv, v);
+  uv = uv + uv;
+  return v + q.w * uv + cross(qv, uv);
+}
+
+// Eigen::QuaternionBase::toRotationMatrix; m[r][c]
+template <class T>
+struct M3 {
+  T m[3][3];
+  V3<T> col(int c) const {
+    return {m[0][c], m[1][c], m[2][c]};
+  }
+};
+template <class T>
+inline M3<T> qmat(const Quat<T>& q) {
+  const T tx = T(2) * q.x, ty = T(2) * q.y, tz = T(2) * q.z;
+  const T twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const T txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const T tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  M3<T> r;
+  r.m[0][0] = T(1) - (tyy + tzz);
+  r.m[0][1] = txy - twz;
+  r.m[0][2] = txz + twy;
+  r.m[1][0] = txy + twz;
+  r.m[1][1] = T(1) - (txx + tzz);
+  r.m[1][2] = tyz - twx;
+  r.m[2][0] = txz - twy;
+  r.m[2][1] = tyz + twx;
+  r.m[2][2] = T(1) - (txx + tyy);
+  return r;
+}
+
+// Eigen: Quaternion(AngleAxis(angle, unit axis `axis`))
+template <class T>
+inline Quat<T> qaxis(T angle, int axis) {
+  const T ha = T(0.5) * angle;
+  const T s = std::sin(ha), c = std::cos(ha);
+  Quat<T> q{0, 0, 0, c};
+  (axis == 0 ? q.x : (axis == 1 ? q.y : q.z)) = s;
+  return q;
+}
+
+template <class T>
+inline Quat<T> qnormalized(const Quat<T>& q) { // Eigen normalized(): q / sqrt(squaredNorm)
+  const T n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  if (n2 > T(0)) {
+    const T n = std::sqrt(n2);
+    return {q.x / n, q.y / n, q.z / n, q.w / n};
+  }
+  return q;
+}
+
+// TransformT (momentum/math/transform.h:36-42)
+template <class T>
+struct Xf {
+  V3<T> t{0, 0, 0};
+  Quat<T> q{0, 0, 0, 1};
+  T s{1};
+};
+// TransformT::operator* (transform.h:124-129)
+template <class T>
+inline Xf<T> xmul(const Xf<T>& a, const Xf<T>& b) {
+  Xf<T> r;
+  r.t = a.t + qrot(a.q, a.s * b.t);
+  r.q = qmul(a.q, b.q);
+  r.s = a.s * b.s;
+  return r;
+}
+// TransformT::transformPoint (transform.h:193)
+template <class T>
+inline V3<T> xpoint(const Xf<T>& a, const V3<T>& p) {
+  return a.t + qrot(a.q, a.s * p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rig = Skeleton + ParameterTransform (constants are fp32 in the reference even for T=double:
+// momentum/character/skeleton.h:25, skeleton_state.cpp:89, skeleton_error_function.h:145)
+// ---------------------------------------------------------------------------------------------
+struct Rig {
+  int J = 0, P = 0;
+  std::vector<int32_t> parent; // [J], -1 = kInvalidIndex
+  std::vector<float> preRot; // [J][4] xyzw
+  std::vector<float> offset; // [J][3]
+  std::vector<int32_t> outer, inner; // CSR 7J x P
+  std::vector<float> value;
+  std::vector<float> ptOffsets; // [7J]
+};
+
+// JointStateT (momentum/character/joint_state.h:50-74)
+template <class T>
+struct JointState {
+  Xf<T> local, world;
+  M3<T> translationAxis; // columns = d world / d t_d
+  M3<T> rotationAxis; // column i = world axis of local rotation i
+};
+
+// ParameterTransformT::apply (momentum/character/parameter_transform.cpp:110-124):
+// jointParams = transform * theta + offsets, row-major sparse product
+template <class T>
+inline void applyParameterTransform(const Rig& rig, const T* theta, T* jp) {
+  for (int r = 0; r < kParametersPerJoint * rig.J; ++r) {
+    T acc = T(0);
+    for (int k = rig.outer[r]; k < rig.outer[r + 1]; ++k) {
+      acc += T(rig.value[k]) * theta[rig.inner[k]];
+    }
+    jp[r] = acc + T(rig.ptOffsets[r]);
+  }
+}
+
+// ParameterTransformT::computeActiveJointParams (parameter_transform.cpp:97-107)
+inline void computeActiveJointParams(const Rig& rig, const uint8_t* enabled, uint8_t* active) {
+  for (int r = 0; r < kParametersPerJoint * rig.J; ++r) {
+    active[r] = 0;
+    for (int k = rig.outer[r]; k < rig.outer[r + 1]; ++k) {
+      if (enabled[rig.inner[k]]) {
+        active[r] = 1;
+      }
+    }
+  }
+}
+
+// JointStateT<T>::set (momentum/character/joint_state.cpp:22-65)
+template <class T>
+inline void
+setJointState(JointState<T>& js, const Rig& rig, int j, const T* p7, const JointState<T>* parentState) {
+  Xf<T> parent; // identity
+  if (parentState != nullptr) {
+    parent = parentState->world;
+  }
+  // :36-42 translationAxis = parent.toLinear() (= R(q_p) * s_p, transform.h:165) or identity
+  if (parentState != nullptr) {
+    const M3<T> R = qmat(parent.q);
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        js.translationAxis.m[r][c] = R.m[r][c] * parent.s;
+      }
+    }
+  } else {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        js.translationAxis.m[r][c] = (r == c) ? T(1) : T(0);
+      }
+    }
+  }
+  // :44 local translation
+  js.local.t = {
+      T(rig.offset[3 * j + 0]) + p7[0], T(rig.offset[3 * j + 1]) + p7[1], T(rig.offset[3 * j + 2]) + p7[2]};
+  // :46 local rotation starts as the pre-rotation
+  js.local.q = {
+      T(rig.preRot[4 * j + 0]), T(rig.preRot[4 * j + 1]), T(rig.preRot[4 * j + 2]), T(rig.preRot[4 * j + 3])};
+  // :51-58 rotations applied in order Z, Y, X; the axis of rotation i is the parent rotation
+  // composed with the partially accumulated local rotation
+  for (int index = 2; index >= 0; --index) {
+    const Quat<T> pq = qmul(parent.q, js.local.q);
+    V3<T> e{0, 0, 0};
+    (index == 0 ? e.x : (index == 1 ? e.y : e.z)) = T(1);
+    const V3<T> ax = qrot(pq, e);
+    js.rotationAxis.m[0][index] = ax.x;
+    js.rotationAxis.m[1][index] = ax.y;
+    js.rotationAxis.m[2][index] = ax.z;
+    js.local.q = qmul(js.local.q, qaxis<T>(p7[3 + index], index));
+  }
+  // :62 scale = exp2(p6)
+  js.local.s = std::exp2(p7[6]);
+  // :64 world = parent * local
+  js.world = xmul(parent, js.local);
+}
+
+// SkeletonStateT<T>::set (momentum/character/skeleton_state.cpp:87-121)
+template <class T>
+inline void setSkeletonState(const Rig& rig, const T* jp, std::vector<JointState<T>>& st) {
+  st.resize(rig.J);
+  for (int j = 0; j < rig.J; ++j) {
+    const int par = rig.parent[j];
+    setJointState<T>(st[j], rig, j, jp + kParametersPerJoint * j, par < 0 ? nullptr : &st[par]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// constraints (momentum/character_solver/error_function_types.h:34-44,
+// position_error_function.h:16-29, orientation_error_function.h:16-36)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Constraints {
+  int Kp = 0, Ko = 0;
+  const int32_t* posParent = nullptr; // [Kp]
+  const float* posOffset = nullptr; // [Kp][3]
+  const float* posTarget = nullptr; // [Kp][3]
+  const float* posWeight = nullptr; // [Kp]
+  const int32_t* oriParent = nullptr; // [Ko]
+  const float* oriOffset = nullptr; // [Ko][4] xyzw (normalised on use like the ctor, :33-35)
+  const float* oriTarget = nullptr; // [Ko][4]
+  const float* oriWeight = nullptr; // [Ko]
+  float posFunctionWeight = 1.f; // SkeletonErrorFunction::weight_
+  float oriFunctionWeight = 1.f;
+  int rows() const {
+    return 3 * Kp + 9 * Ko;
+  }
+};
+
+template <class T>
+inline T ln2() { // momentum/math/constants.h:30,40
+  return T(0.693147180559945309417232121458176568);
+}
+
+// GeneralizedLossT L2 branch (momentum/math/generalized_loss.cpp:25-32): value = s/c^2, deriv = 1/c^2, c = 1
+template <class T>
+inline T lossValue(T s) {
+  return s;
+}
+template <class T>
+inline T lossDeriv(T) {
+  return T(1);
+}
+
+// The generic ancestor walk of JointErrorFunctionT::getJacobian
+// (momentum/character_solver/joint_error_function-inl.h:228-294) for one constraint:
+// FuncDim rows starting at `row`, NumVec vectors v[k] with dfdv[k] = I3 placed at rows 3k..3k+2
+// (position: NumVec=1, NumPos=1; orientation: NumVec=3, NumPos=0).
+template <class T>
+inline void ancestorWalk(
+    const Rig& rig,
+    const std::vector<JointState<T>>& st,
+    const uint8_t* active,
+    const uint8_t* enabled,
+    int parentJoint,
+    int numVec,
+    int numPos,
+    const V3<T>* v,
+    T derivScale,
+    int row,
+    T* jac, // column-major, leading dimension ld
+    int ld) {
+  int jnt = parentJoint;
+  while (jnt >= 0) {
+    const JointState<T>& js = st[jnt];
+    const int base = jnt * kParametersPerJoint;
+    for (int k = 0; k < numVec; ++k) {
+      const bool isPoint = k < numPos;
+      const V3<T> off = isPoint ? (v[k] - js.world.t) : v[k]; // :240-245
+      auto scatter = [&](int jp, const V3<T>& g) {
+        // jc = derivScale * dfdv * g ; jac.col(inner) += jc * value (:254-260)
+        const V3<T> jc = derivScale * g;
+        for (int idx = rig.outer[jp]; idx < rig.outer[jp + 1]; ++idx) {
+          const int col = rig.inner[idx];
+          if (enabled[col]) {
+            const T w = T(rig.value[idx]);
+            T* c = jac + size_t(col) * ld + row + 3 * k;
+            c[0] += jc.x * w;
+            c[1] += jc.y * w;
+            c[2] += jc.z * w;
+          }
+        }
+      };
+      if (isPoint) { // translational dofs only affect points (:248-262)
+        for (int d = 0; d < 3; ++d) {
+          if (active[base + d]) {
+            scatter(base + d, js.translationAxis.col(d)); // getTranslationDerivative, joint_state.cpp:74-77
+          }
+        }
+      }
+      for (int d = 0; d < 3; ++d) { // rotational dofs (:265-278)
+        if (active[base + 3 + d]) {
+          scatter(base + 3 + d, cross(js.rotationAxis.col(d), off)); // getRotationDerivative :68-71
+        }
+      }
+      if (isPoint && active[base + 6]) { // scale dof (:281-291)
+        scatter(base + 6, ln2<T>() * off); // getScaleDerivative :80-82
+      }
+    }
+    jnt = rig.parent[jnt];
+  }
+}
+
+// isApprox(derivScale, 0, Eps(1e-9, 1e-16)) of joint_error_function-inl.h:216
+template <class T>
+inline bool derivScaleIsZero(T s) {
+  const T eps = std::is_same<T, float>::value ? T(1e-9) : T(1e-16);
+  return std::fabs(s) <= eps;
+}
+
+// PositionErrorFunctionT::evalFunction (position_error_function.cpp:15-27) +
+// OrientationErrorFunctionT::evalFunction (orientation_error_function.cpp:15-40) driven through
+// JointErrorFunctionT::getJacobian (joint_error_function-inl.h:179-297).  jac (M x P column-major,
+// must be pre-zeroed like gauss_newton_solver.cpp:166) and res (M) may be null => error only
+// (JointErrorFunctionT::getError, :35-54).  Returns sum of block errors (double, like the reference).
+template <class T>
+inline double evalErrorFunctions(
+    const Rig& rig,
+    const std::vector<JointState<T>>& st,
+    const Constraints<T>& cs,
+    const uint8_t* active,
+    const uint8_t* enabled,
+    T* jac,
+    T* res) {
+  const int M = cs.rows();
+  double total = 0.0;
+  // ---- position block (rows 3c..3c+2).  A block whose function weight is <= 0 is skipped
+  // (skeleton_solver_function.cpp:77,223-231,250-253); its rows stay zero.
+  if (cs.posFunctionWeight > 0.f) {
+    double error = 0.0;
+    for (int c = 0; c < cs.Kp; ++c) {
+      const T cw = T(cs.posWeight[c]);
+      if (cw == T(0)) {
+        continue; // :197-199
+      }
+      const Xf<T>& X = st[cs.posParent[c]].world;
+      const V3<T> off{T(cs.posOffset[3 * c]), T(cs.posOffset[3 * c + 1]), T(cs.posOffset[3 * c + 2])};
+      const V3<T> tgt{T(cs.posTarget[3 * c]), T(cs.posTarget[3 * c + 1]), T(cs.posTarget[3 * c + 2])};
+      const V3<T> v = xpoint(X, off);
+      const V3<T> f = v - tgt;
+      const T sqr = dot(f, f);
+      const T w = cw * T(cs.posFunctionWeight);
+      if (jac == nullptr) {
+        error += double(cw * lossValue(sqr)); // getError: weight_ applied after the loop (:50-53)
+        continue;
+      }
+      error += double(w * lossValue(sqr)); // :207
+      const T derivScale = std::sqrt(w * lossDeriv(sqr)); // :208
+      const int row = 3 * c;
+      res[row + 0] = derivScale * f.x; // :212-213
+      res[row + 1] = derivScale * f.y;
+      res[row + 2] = derivScale * f.z;
+      if (derivScaleIsZero(derivScale)) {
+        continue; // :216
+      }
+      ancestorWalk<T>(rig, st, active, enabled, cs.posParent[c], 1, 1, &v, derivScale, row, jac, M);
+    }
+    total += (jac == nullptr) ? double(cs.posFunctionWeight) * error : error;
+  }
+  // ---- orientation block (rows 3Kp + 9c .. +8)
+  if (cs.oriFunctionWeight > 0.f) {
+    double error = 0.0;
+    for (int c = 0; c < cs.Ko; ++c) {
+      const T cw = T(cs.oriWeight[c]);
+      if (cw == T(0)) {
+        continue;
+      }
+      const Quat<T> qo = qnormalized(Quat<T>{
+          T(cs.oriOffset[4 * c]), T(cs.oriOffset[4 * c + 1]), T(cs.oriOffset[4 * c + 2]), T(cs.oriOffset[4 * c + 3])});
+      const Quat<T> qt = qnormalized(Quat<T>{
+          T(cs.oriTarget[4 * c]), T(cs.oriTarget[4 * c + 1]), T(cs.oriTarget[4 * c + 2]), T(cs.oriTarget[4 * c + 3])});
+      const Quat<T>& qw = st[cs.oriParent[c]].world.q;
+      const M3<T> Ro = qmat(qo);
+      const M3<T> Rt = qmat(qt);
+      V3<T> v[3];
+      T f[9];
+      T sqr = T(0);
+      for (int k = 0; k < 3; ++k) {
+        v[k] = qrot(qw, Ro.col(k)); // :24-26
+        const V3<T> d = v[k] - Rt.col(k); // :28-33 column-stacked
+        f[3 * k + 0] = d.x;
+        f[3 * k + 1] = d.y;
+        f[3 * k + 2] = d.z;
+      }
+      for (int i = 0; i < 9; ++i) {
+        sqr += f[i] * f[i];
+      }
+      const T w = cw * T(cs.oriFunctionWeight);
+      if (jac == nullptr) {
+        error += double(cw * lossValue(sqr));
+        continue;
+      }
+      error += double(w * lossValue(sqr));
+      const T derivScale = std::sqrt(w * lossDeriv(sqr));
+      const int row = 3 * cs.Kp + 9 * c;
+      for (int i = 0; i < 9; ++i) {
+        res[row + i] = derivScale * f[i];
+      }
+      if (derivScaleIsZero(derivScale)) {
+        continue;
+      }
+      ancestorWalk<T>(rig, st, active, enabled, cs.oriParent[c], 3, 0, v, derivScale, row, jac, M);
+    }
+    total += (jac == nullptr) ? double(cs.oriFunctionWeight) * error : error;
+  }
+  return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SkeletonSolverFunctionT (momentum/character_solver/skeleton_solver_function.cpp)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct SolverFunction {
+  const Rig& rig;
+  Constraints<T> cs;
+  std::vector<uint8_t> enabled; // ParameterSet
+  std::vector<uint8_t> active; // activeJointParams_
+  std::vector<T> jp;
+  std::vector<JointState<T>> state;
+
+  SolverFunction(const Rig& r, const Constraints<T>& c) : rig(r), cs(c) {
+    enabled.assign(rig.P, 1);
+    active.resize(size_t(kParametersPerJoint) * rig.J);
+    computeActiveJointParams(rig, enabled.data(), active.data());
+    jp.resize(size_t(kParametersPerJoint) * rig.J);
+  }
+  int numParams() const {
+    return rig.P;
+  }
+  int numRows() const {
+    return cs.rows();
+  }
+  int firstBlockRows() const {
+    return 3 * cs.Kp;
+  }
+  // :45-61
+  void setEnabledParameters(const uint8_t* en) {
+    enabled.assign(en, en + rig.P);
+    computeActiveJointParams(rig, enabled.data(), active.data());
+  }
+  // :64-83 -- NB the result is rounded through float (:82)
+  double getError(const T* theta) {
+    applyParameterTransform<T>(rig, theta, jp.data());
+    setSkeletonState<T>(rig, jp.data(), state);
+    const double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
+    return double(float(e));
+  }
+  // :200-261 (initializeJacobianComputation + computeJacobianBlock for both blocks).  Blocks with
+  // weight <= 0 have size 0 in the reference (:223-231); the oracle keeps their rows as zeros so
+  // that the row layout of the C ABI stays fixed -- JtJ / Jtr are unaffected.
+  double getJacobian(const T* theta, T* jac, T* res) {
+    applyParameterTransform<T>(rig, theta, jp.data());
+    setSkeletonState<T>(rig, jp.data(), state);
+    const int M = cs.rows();
+    std::fill(jac, jac + size_t(M) * rig.P, T(0));
+    std::fill(res, res + M, T(0));
+    return evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// dense linear algebra the reference delegates to Eigen (third-party, Eigen >=5.0,<5.1 per
+// pixi.toml:45; call sites gauss_newton_solver.cpp:215-216,251).  Mathematically specified
+// operations: lower Cholesky LL^T, two triangular solves, J^T J lower triangle, J^T r.
+// ---------------------------------------------------------------------------------------------
+// dot product with 8 independent partial sums (deterministic, vectorisable without -ffast-math)
+template <class T>
+inline T dot8(const T* a, const T* b, int n) {
+  T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    for (int k = 0; k < 8; ++k) {
+      s[k] += a[i + k] * b[i + k];
+    }
+  }
+  T tail = T(0);
+  for (; i < n; ++i) {
+    tail += a[i] * b[i];
+  }
+  return ((s[0] + s[4]) + (s[1] + s[5])) + ((s[2] + s[6]) + (s[3] + s[7])) + tail;
+}
+
+// H (n x n column-major, lower triangle) += Jc^T Jc ; g += Jc^T r   with Jc = M x n column-major
+template <class T>
+inline void accumulateNormalEquations(const T* Jc, const T* r, int M, int ld, int n, T* H, T* g) {
+  for (int j = 0; j < n; ++j) {
+    const T* cj = Jc + size_t(j) * ld;
+    for (int i = j; i < n; ++i) {
+      H[size_t(j) * n + i] += dot8(Jc + size_t(i) * ld, cj, M);
+    }
+    g[j] += dot8(cj, r, M);
+  }
+}
+
+// Eigen::LLT<MatrixX<T>>::compute on the lower triangle, restated after Eigen's
+// llt_inplace<Lower>::unblocked (Eigen/src/Cholesky/LLT.h): bordered / left-looking, and -- like
+// Eigen -- it STOPS at the first non-positive pivot (info() = NumericalIssue), leaving the
+// remaining columns unfactored; LLT::solve then runs on whatever is stored, which is what the
+// reference does because it never checks info() (gauss_newton_solver.cpp:251).  Returns false in
+// that case.  (Eigen switches to a blocked variant for n >= 32: same mathematics, different
+// summation order; not bit-pinned by any reference test.)
+template <class T>
+inline bool choleskyLower(T* H, int n) {
+  for (int k = 0; k < n; ++k) {
+    T d = H[size_t(k) * n + k];
+    for (int p = 0; p < k; ++p) {
+      const T l = H[size_t(p) * n + k];
+      d -= l * l;
+    }
+    if (!(d > T(0))) {
+      return false;
+    }
+    const T lkk = std::sqrt(d);
+    H[size_t(k) * n + k] = lkk;
+    for (int i = k + 1; i < n; ++i) {
+      T s = H[size_t(k) * n + i];
+      for (int p = 0; p < k; ++p) {
+        s -= H[size_t(p) * n + i] * H[size_t(p) * n + k];
+      }
+      H[size_t(k) * n + i] = s / lkk;
+    }
+  }
+  return true;
+}
+
+// LLT::solve: L y = b, L^T x = y (in place)
+template <class T>
+inline void choleskySolve(const T* L, int n, T* b) {
+  for (int i = 0; i < n; ++i) {
+    T s = b[i];
+    for (int p = 0; p < i; ++p) {
+      s -= L[size_t(p) * n + i] * b[p];
+    }
+    b[i] = s / L[size_t(i) * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    T s = b[i];
+    for (int p = i + 1; p < n; ++p) {
+      s -= L[size_t(i) * n + p] * b[p];
+    }
+    b[i] = s / L[size_t(i) * n + i];
+  }
+}
+
+// MockSolverFunction of the reference's solver tests (identity Jacobian, residual = theta,
+// error = |theta|^2): momentum/test/solver/gauss_newton_solver_test.cpp:19-106
+template <class T>
+struct MockSolverFunction {
+  int P;
+  std::vector<uint8_t> enabled;
+  explicit MockSolverFunction(int p) : P(p), enabled(size_t(p), 1) {}
+  int numParams() const {
+    return P;
+  }
+  int numRows() const {
+    return P;
+  }
+  int firstBlockRows() const {
+    return P;
+  }
+  double getError(const T* theta) {
+    double e = 0;
+    for (int i = 0; i < P; ++i) {
+      e += double(theta[i]) * double(theta[i]);
+    }
+    return e;
+  }
+  double getJacobian(const T* theta, T* jac, T* res) {
+    std::fill(jac, jac + size_t(P) * P, T(0));
+    for (int i = 0; i < P; ++i) {
+      jac[size_t(i) * P + i] = T(1);
+      res[i] = theta[i];
+    }
+    return getError(theta);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// SolverOptions / GaussNewtonSolverOptions (momentum/solver/solver.h:19-34,
+// gauss_newton_solver.h:17-59) + the build's LM schedule knobs
+// ---------------------------------------------------------------------------------------------
+struct Options {
+  int minIterations = 1;
+  int maxIterations = 2;
+  float threshold = 1.f;
+  float regularization = 0.05f;
+  bool doLineSearch = false;
+  bool useBlockJtJ = false;
+  int stepRule = 0; // 0 = fixed lambda (reference), 1 = LM gain-ratio schedule (build's own)
+  float lmLambdaMin = 1e-6f, lmLambdaMax = 1e6f, lmUp = 4.f, lmDown = 0.5f;
+};
+
+template <class T>
+struct SolveResult {
+  double error = 0.0; // what SolverT::solve returns (stale by one step, solver.cpp:126-127)
+  int iterations = 0; // errorHistory_.size()
+  bool notPD = false;
+  std::vector<double> errorHistory;
+  std::vector<T> lastJtJ, lastJtr; // compacted system of the last iteration (for parity hooks)
+};
+
+// GaussNewtonSolverT<T> + SolverT<T>::solve
+// (momentum/solver/gauss_newton_solver.cpp:57-313, momentum/solver/solver.cpp:50-128)
+template <class T, class Fn>
+inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
+  const int P = fn.numParams();
+  const int M = fn.numRows();
+  SolveResult<T> out;
+  // updateEnabledParameters (:57-66)
+  std::vector<int> E;
+  for (int i = 0; i < P; ++i) {
+    if (fn.enabled[i]) {
+      E.push_back(i);
+    }
+  }
+  const int n = int(E.size());
+  std::vector<T> params(theta, theta + P);
+  std::vector<T> jac(size_t(M) * P), res(M), H(size_t(n) * n), g(n), delta(P), trial(P);
+  double error = std::numeric_limits<double>::max(); // solver.cpp:84-85
+  double lastError = std::numeric_limits<double>::max();
+  T lambda = T(opt.regularization);
+
+  int it = 0;
+  for (; it < opt.maxIterations; ++it) { // solver.cpp:89
+    // ---- doIteration (:224) / computeJtJFromJacobianBlocks (:110-221)
+    error = fn.getJacobian(params.data(), jac.data(), res.data());
+    // column compaction to the enabled subset (:204-209), in place
+    for (int s = 0; s < n; ++s) {
+      if (E[s] > s) {
+        std::memcpy(jac.data() + size_t(s) * M, jac.data() + size_t(E[s]) * M, sizeof(T) * M);
+      }
+    }
+    std::fill(H.begin(), H.end(), T(0));
+    std::fill(g.begin(), g.end(), T(0));
+    if (!opt.useBlockJtJ) {
+      accumulateNormalEquations<T>(jac.data(), res.data(), M, M, n, H.data(), g.data()); // :215-216
+    } else {
+      // SolverFunctionT::getJtJR default (solver_function.cpp:74-121): one rank update per block
+      // (= per error function), then compaction (:69-107) -- mathematically the same system,
+      // accumulated block by block.
+      const int r0 = fn.firstBlockRows();
+      if (r0 > 0) {
+        accumulateNormalEquations<T>(jac.data(), res.data(), r0, M, n, H.data(), g.data());
+      }
+      if (M - r0 > 0) {
+        accumulateNormalEquations<T>(jac.data() + r0, res.data() + r0, M - r0, M, n, H.data(), g.data());
+      }
+    }
+    out.lastJtJ = H;
+    out.lastJtr = g;
+
+    if (opt.stepRule == 0) {
+      // ---- dense GN step (:241-257)
+      for (int i = 0; i < n; ++i) {
+        H[size_t(i) * n + i] += T(opt.regularization); // :248
+      }
+      if (!choleskyLower<T>(H.data(), n)) {
+        out.notPD = true;
+      }
+      choleskySolve<T>(H.data(), n, g.data()); // :251
+      std::fill(delta.begin(), delta.end(), T(0));
+      for (int s = 0; s < n; ++s) {
+        delta[E[s]] = g[s]; // :254-257
+      }
+      // ---- updateParameters (:283-313)
+      if (!opt.doLineSearch) {
+        for (int i = 0; i < P; ++i) {
+          params[i] -= delta[i]; // skeleton_solver_function.cpp:158
+        }
+      } else {
+        const T kC1 = T(1e-3), kTau = T(0.5);
+        const T scaledError = kC1 * T(error);
+        const std::vector<T> orig = params;
+        T scale = T(1);
+        for (int ls = 0; ls < 10 && std::isnormal(scale); ++ls) {
+          for (int i = 0; i < P; ++i) {
+            params[i] = orig[i] - scale * delta[i];
+          }
+          const double errorNew = fn.getError(params.data());
+          if ((error - errorNew) >= double(scale * scaledError)) {
+            break;
+          }
+          scale *= kTau;
+        }
+      }
+    } else {
+      // ---- LM gain-ratio schedule: the lambda-form of TrustRegionQRT's radius rule
+      // (momentum/character_solver/trust_region_qr.cpp:244-268): rho = actual/predicted decrease;
+      // rho < 0.25 -> lambda *= up; rho > 0.75 -> lambda *= down; rho <= 0 -> reject the step.
+      // One trial step per iteration (a rejected step still consumes the iteration).
+      std::vector<T> Hl = H;
+      std::vector<T> d = g;
+      for (int i = 0; i < n; ++i) {
+        Hl[size_t(i) * n + i] += lambda;
+      }
+      if (!choleskyLower<T>(Hl.data(), n)) {
+        out.notPD = true;
+      }
+      choleskySolve<T>(Hl.data(), n, d.data());
+      // predicted decrease of |r - J d|^2 = 2 d^T g - d^T H d = d^T g + lambda d^T d
+      // (using (H + lambda I) d = g)
+      T dg = T(0), dd = T(0);
+      for (int s = 0; s < n; ++s) {
+        dg += d[s] * g[s];
+        dd += d[s] * d[s];
+      }
+      const T predicted = dg + lambda * dd;
+      trial = params;
+      for (int s = 0; s < n; ++s) {
+        trial[E[s]] -= d[s];
+      }
+      const double errorNew = fn.getError(trial.data());
+      const T rho = predicted > T(0) ? T((error - errorNew) / double(predicted)) : T(-1);
+      if (rho > T(0)) {
+        params = trial;
+      }
+      if (!(rho >= T(0.25))) {
+        lambda = std::min(lambda * T(opt.lmUp), T(opt.lmLambdaMax));
+      } else if (rho > T(0.75)) {
+        lambda = std::max(lambda * T(opt.lmDown), T(opt.lmLambdaMin));
+      }
+    }
+
+    out.errorHistory.push_back(error); // solver.cpp:92
+    // convergence (solver.cpp:96-115)
+    const bool converged = std::fabs(lastError - error) / (std::fabs(error) + double(FLT_MIN)) <=
+        double(opt.threshold) * double(FLT_EPSILON);
+    if (it >= opt.minIterations && converged) {
+      break;
+    }
+    lastError = error;
+  }
+  std::copy(params.begin(), params.end(), theta);
+  out.error = error;
+  out.iterations = int(out.errorHistory.size());
+  return out;
+}
+
+} // namespace mmx_oracle

@@ -1,0 +1,259 @@
+"""ctypes wrapper of the CPU ORACLE (oracle/libmmx_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package momentum_amd (tests/test_no_oracle_in_product.py
+enforces that).  See oracle/mmx_oracle.hpp for the pinning statement and reference citations.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+from momentum_amd._abi import ConstraintData, GnOptions, MMX_MEM_HOST, as_ptr, void_p
+from momentum_amd.rigs import Rig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmmx_oracle.so")
+_lib: Optional[C.CDLL] = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with oracle/Makefile (gcc only)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _np(dtype):
+    return np.float32 if dtype in ("f32", np.float32) else np.float64
+
+
+def _suf(dtype) -> str:
+    return "f32" if _np(dtype) is np.float32 else "f64"
+
+
+def _ct(dtype):
+    return C.c_float if _np(dtype) is np.float32 else C.c_double
+
+
+class Constraints:
+    """One instance's (or a batch's) constraint payload, numpy-backed."""
+
+    def __init__(
+        self,
+        pos_parent,
+        pos_offset,
+        pos_target,
+        pos_weight,
+        ori_parent,
+        ori_offset,
+        ori_target,
+        ori_weight,
+        pos_function_weight: float = 1.0,
+        ori_function_weight: float = 1.0,
+    ):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        self.pos_parent = np.ascontiguousarray(pos_parent, dtype=np.int32).reshape(-1)
+        self.ori_parent = np.ascontiguousarray(ori_parent, dtype=np.int32).reshape(-1)
+        self.Kp = int(self.pos_parent.shape[0])
+        self.Ko = int(self.ori_parent.shape[0])
+        self.pos_offset, self.pos_target, self.pos_weight = f(pos_offset), f(pos_target), f(pos_weight)
+        self.ori_offset, self.ori_target, self.ori_weight = f(ori_offset), f(ori_target), f(ori_weight)
+        self.pos_function_weight = float(pos_function_weight)
+        self.ori_function_weight = float(ori_function_weight)
+
+    @property
+    def rows(self) -> int:
+        return 3 * self.Kp + 9 * self.Ko
+
+    def data(self) -> ConstraintData:
+        return ConstraintData(
+            void_p(self.pos_offset if self.Kp else None),
+            void_p(self.pos_target if self.Kp else None),
+            void_p(self.pos_weight if self.Kp else None),
+            void_p(self.ori_offset if self.Ko else None),
+            void_p(self.ori_target if self.Ko else None),
+            void_p(self.ori_weight if self.Ko else None),
+            self.pos_function_weight,
+            self.ori_function_weight,
+            MMX_MEM_HOST,
+        )
+
+    def instance(self, b: int) -> "Constraints":
+        """Slice instance b out of a batched payload ([B,K,...] arrays)."""
+        return Constraints(
+            self.pos_parent,
+            self.pos_offset.reshape(-1, self.Kp, 3)[b] if self.Kp else self.pos_offset,
+            self.pos_target.reshape(-1, self.Kp, 3)[b] if self.Kp else self.pos_target,
+            self.pos_weight.reshape(-1, self.Kp)[b] if self.Kp else self.pos_weight,
+            self.ori_parent,
+            self.ori_offset.reshape(-1, self.Ko, 4)[b] if self.Ko else self.ori_offset,
+            self.ori_target.reshape(-1, self.Ko, 4)[b] if self.Ko else self.ori_target,
+            self.ori_weight.reshape(-1, self.Ko)[b] if self.Ko else self.ori_weight,
+            self.pos_function_weight,
+            self.ori_function_weight,
+        )
+
+
+def _enabled_ptr(enabled, P):
+    if enabled is None:
+        return None, C.POINTER(C.c_uint8)()
+    e = np.ascontiguousarray(enabled, dtype=np.uint8).reshape(-1)
+    assert e.shape[0] == P
+    return e, as_ptr(e, C.c_uint8)
+
+
+def skeleton_state(rig: Rig, theta, dtype="f64"):
+    """A1+A2: returns dict(world[J,8], local[J,8], trans_axis[J,3,3], rot_axis[J,3,3], joint_params[7J])."""
+    T = _np(dtype)
+    J = rig.num_joints
+    th = np.ascontiguousarray(theta, dtype=T).reshape(-1)
+    assert th.shape[0] == rig.num_params
+    world = np.zeros((J, 8), T)
+    local = np.zeros((J, 8), T)
+    ta = np.zeros((J, 3, 3), T)
+    ra = np.zeros((J, 3, 3), T)
+    jp = np.zeros(7 * J, T)
+    d = rig.desc()
+    ct = _ct(dtype)
+    fn = getattr(lib(), f"orc_skeleton_state_{_suf(dtype)}")
+    rc = fn(C.byref(d), as_ptr(th, ct), as_ptr(world, ct), as_ptr(local, ct), as_ptr(ta, ct), as_ptr(ra, ct), as_ptr(jp, ct))
+    assert rc == 0
+    return dict(world=world, local=local, trans_axis=ta, rot_axis=ra, joint_params=jp)
+
+
+def eval_jacobian(rig: Rig, cons: Constraints, theta, enabled=None, dtype="f64"):
+    """Returns (J [M,P] (numpy view of the column-major buffer, i.e. J[i,p]), r [M], error)."""
+    T = _np(dtype)
+    M, P = cons.rows, rig.num_params
+    th = np.ascontiguousarray(theta, dtype=T).reshape(-1)
+    jac = np.zeros((P, M), T)  # column-major M x P == C-order [P][M]
+    res = np.zeros(M, T)
+    err = C.c_double(0)
+    d, cd = rig.desc(), cons.data()
+    ekeep, eptr = _enabled_ptr(enabled, P)
+    ct = _ct(dtype)
+    fn = getattr(lib(), f"orc_eval_jacobian_{_suf(dtype)}")
+    rc = fn(
+        C.byref(d), cons.Kp, as_ptr(cons.pos_parent, C.c_int32), cons.Ko, as_ptr(cons.ori_parent, C.c_int32),
+        C.byref(cd), eptr, as_ptr(th, ct), as_ptr(jac, ct), as_ptr(res, ct), C.byref(err),
+    )  # fmt: skip
+    assert rc == 0
+    return jac.T, res, err.value
+
+
+def get_error(rig: Rig, cons: Constraints, theta, dtype="f64") -> float:
+    T = _np(dtype)
+    th = np.ascontiguousarray(theta, dtype=T).reshape(-1)
+    err = C.c_double(0)
+    d, cd = rig.desc(), cons.data()
+    fn = getattr(lib(), f"orc_get_error_{_suf(dtype)}")
+    rc = fn(
+        C.byref(d), cons.Kp, as_ptr(cons.pos_parent, C.c_int32), cons.Ko, as_ptr(cons.ori_parent, C.c_int32),
+        C.byref(cd), as_ptr(th, _ct(dtype)), C.byref(err),
+    )  # fmt: skip
+    assert rc == 0
+    return err.value
+
+
+def solve(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f64", use_block_jtj=False):
+    """SolverT::solve with GaussNewtonSolverT for one instance.  Returns dict(theta, error,
+    iterations, status, error_history, jtj, jtr) (jtj/jtr = compacted system of the last iteration)."""
+    T = _np(dtype)
+    P = rig.num_params
+    th = np.array(theta0, dtype=T).reshape(-1).copy()
+    ekeep, eptr = _enabled_ptr(enabled, P)
+    n = P if enabled is None else int(np.count_nonzero(ekeep))
+    err = C.c_double(0)
+    iters = C.c_int32(0)
+    status = C.c_int32(0)
+    hist = np.zeros(max(1, options.max_iterations), np.float64)
+    jtj = np.zeros((n, n), T)
+    jtr = np.zeros(n, T)
+    d, cd = rig.desc(), cons.data()
+    ct = _ct(dtype)
+    fn = getattr(lib(), f"orc_solve_{_suf(dtype)}")
+    rc = fn(
+        C.byref(d), cons.Kp, as_ptr(cons.pos_parent, C.c_int32), cons.Ko, as_ptr(cons.ori_parent, C.c_int32),
+        C.byref(cd), eptr, C.byref(options), int(use_block_jtj), as_ptr(th, ct), C.byref(err), C.byref(iters),
+        C.byref(status), as_ptr(hist, C.c_double), as_ptr(jtj, ct), as_ptr(jtr, ct),
+    )  # fmt: skip
+    assert rc == 0
+    # the oracle stores the lower triangle column-major: element (i,j), i>=j at [j*n+i]; as a C-order
+    # numpy array that is the upper triangle -> mirror to a full symmetric matrix
+    full = np.triu(jtj) + np.triu(jtj, 1).T
+    return dict(
+        theta=th, error=err.value, iterations=iters.value, status=status.value,
+        error_history=hist[: iters.value].copy(), jtj=full, jtr=jtr,
+    )  # fmt: skip
+
+
+def solve_batch(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f32", nthreads=1, use_block_jtj=False):
+    """The reference's batched driver shape (pymomentum/tensor_ik/tensor_ik.cpp:127-177): one
+    independent solver per instance, `nthreads` std::threads.  cons arrays are [B,K,...]."""
+    T = _np(dtype)
+    P = rig.num_params
+    th = np.array(theta0, dtype=T).reshape(-1, P).copy()
+    B = th.shape[0]
+    ekeep, eptr = _enabled_ptr(enabled, P)
+    err = np.zeros(B, np.float64)
+    iters = np.zeros(B, np.int32)
+    status = np.zeros(B, np.int32)
+    hist = np.zeros((B, max(1, options.max_iterations)), np.float64)
+    d, cd = rig.desc(), cons.data()
+    ct = _ct(dtype)
+    fn = getattr(lib(), f"orc_solve_batch_{_suf(dtype)}")
+    rc = fn(
+        C.byref(d), B, cons.Kp, as_ptr(cons.pos_parent, C.c_int32), cons.Ko, as_ptr(cons.ori_parent, C.c_int32),
+        C.byref(cd), eptr, C.byref(options), int(use_block_jtj), as_ptr(th, ct), as_ptr(err, C.c_double),
+        as_ptr(iters, C.c_int32), as_ptr(status, C.c_int32), as_ptr(hist, C.c_double), int(nthreads),
+    )  # fmt: skip
+    assert rc == 0
+    return dict(theta=th, error=err, iterations=iters, status=status, error_history=hist)
+
+
+def mock_solve(P: int, theta0, options: GnOptions, enabled=None, dtype="f64", use_block_jtj=False):
+    """GaussNewtonSolverT on MockSolverFunction (J = I, r = theta);
+    momentum/test/solver/gauss_newton_solver_test.cpp:19-106."""
+    T = _np(dtype)
+    th = np.array(theta0, dtype=T).reshape(-1).copy()
+    ekeep, eptr = _enabled_ptr(enabled, P)
+    err = C.c_double(0)
+    iters = C.c_int32(0)
+    hist = np.zeros(max(1, options.max_iterations), np.float64)
+    fn = getattr(lib(), f"orc_mock_solve_{_suf(dtype)}")
+    rc = fn(P, eptr, C.byref(options), int(use_block_jtj), as_ptr(th, _ct(dtype)), C.byref(err), C.byref(iters), as_ptr(hist, C.c_double))
+    assert rc == 0
+    return dict(theta=th, error=err.value, iterations=iters.value, error_history=hist[: iters.value].copy())
+
+
+def ancestor_matrix(rig: Rig) -> np.ndarray:
+    J = rig.num_joints
+    out = np.zeros((J, J), np.uint8)
+    d = rig.desc()
+    assert lib().orc_ancestor_matrix(C.byref(d), as_ptr(out, C.c_uint8)) == 0
+    return out
+
+
+def active_joint_params(rig: Rig, enabled) -> np.ndarray:
+    e = np.ascontiguousarray(enabled, dtype=np.uint8)
+    out = np.zeros(7 * rig.num_joints, np.uint8)
+    d = rig.desc()
+    assert lib().orc_active_joint_params(C.byref(d), as_ptr(e, C.c_uint8), as_ptr(out, C.c_uint8)) == 0
+    return out
+
+
+def hardware_threads() -> int:
+    return int(lib().orc_hardware_threads())

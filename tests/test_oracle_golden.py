@@ -1,0 +1,249 @@
+"""Pins the CPU oracle against the golden vectors / known-answer tests the reference's own test
+suite holds for the hot path.  CPU only."""
+import numpy as np
+import pytest
+
+from momentum_amd import make_humanoid72, make_test_character
+from momentum_amd._abi import GnOptions
+from tests.helpers import make_problem, quat_rot
+
+PI = np.pi
+GOLDEN_FK = np.array([-1.14354682, 3.14354706, -0.0717732906])
+
+
+def _xf_point(w, p):
+    return w[:3] + quat_rot(w[3:7], w[7] * np.asarray(p, dtype=np.float64))
+
+
+@pytest.mark.parametrize("n", [3, 4, 7, 24, 72, 300, 512])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-6), ("f64", 5e-7)])
+def test_fk_golden_value(orc, n, dtype, tol):
+    # momentum/test/character/forward_kinematics_test.cpp:49,80-86
+    rig = make_test_character(n)
+    th = np.zeros(rig.num_params)
+    th[:10] = [1, 1, 1, PI, 0, -PI, 0.1, PI, PI, -PI]
+    st = orc.skeleton_state(rig, th, dtype)
+    p = _xf_point(st["world"][2].astype(np.float64), [1, 1, 1])
+    assert np.abs(p - GOLDEN_FK).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_fk_rest_pose_is_identity(orc, dtype):
+    # forward_kinematics_test.cpp:62-74: rest pose => rotations / axes exactly identity
+    rig = make_test_character(5)
+    st = orc.skeleton_state(rig, np.zeros(rig.num_params), dtype)
+    for j in range(5):
+        assert np.array_equal(st["world"][j, 3:7], [0, 0, 0, 1])
+        assert st["world"][j, 7] == 1
+        assert np.array_equal(st["rot_axis"][j], np.eye(3))
+        assert np.array_equal(st["trans_axis"][j], np.eye(3))
+        assert np.array_equal(st["world"][j, :3], [0, j, 0])
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("f64", 1e-12)])
+def test_joint_state_algebra(orc, dtype, tol):
+    # momentum/test/character/joint_state_test.cpp:27-36 fixture: params (4,5,6, pi/4,pi/6,pi/8, 0.5),
+    # offset (1,2,3); :65-99 scale = exp2(p6), child translation t_p + q_p*(t_l*s_p);
+    # :101-156 translationAxis == parent.toLinear(); :182-216 derivative accessors.
+    from momentum_amd.rigs import _build_rig
+
+    parent = [-1, 0]
+    pre = np.array([[0, 0, 0, 1], [0, 0, 0, 1]], np.float32)
+    off = np.array([[1, 2, 3], [1, 2, 3]], np.float32)
+    trip = [(r, r, 1.0) for r in range(14)]
+    rig = _build_rig(parent, pre, off, trip, 14, ["a", "b"], [f"p{i}" for i in range(14)])
+    p7 = np.array([4, 5, 6, PI / 4, PI / 6, PI / 8, 0.5])
+    th = np.concatenate([p7, p7])
+    st = orc.skeleton_state(rig, th, dtype)
+    loc, wor = st["local"].astype(np.float64), st["world"].astype(np.float64)
+    assert abs(loc[0, 7] - 2**0.5) <= tol
+    assert np.allclose(loc[0, :3], [5, 7, 9], atol=tol * 10)
+    # local rotation = Rz(pi/8)... as preRot * Rx*Ry*Rz order product q = qz*qy*qx (Eigen order)
+    def qa(a, ax):
+        q = np.zeros(4)
+        q[ax] = np.sin(a / 2)
+        q[3] = np.cos(a / 2)
+        return q
+
+    from tests.helpers import quat_mul
+
+    qexp = quat_mul(quat_mul(qa(PI / 8, 2), qa(PI / 6, 1)), qa(PI / 4, 0))
+    assert np.allclose(loc[0, 3:7], qexp, atol=tol * 4)
+    # child world translation = t_p + q_p * (s_p * t_l)
+    texp = wor[0, :3] + quat_rot(wor[0, 3:7], wor[0, 7] * loc[1, :3])
+    assert np.allclose(wor[1, :3], texp, atol=tol * 40)
+    assert abs(wor[1, 7] - 2.0) <= tol * 4
+    # translationAxis of the child == s_p * R(q_p)
+    R = np.stack([quat_rot(wor[0, 3:7], e) for e in np.eye(3)], axis=1)
+    assert np.allclose(st["trans_axis"][1], wor[0, 7] * R, atol=tol * 4)
+    assert np.array_equal(st["trans_axis"][0], np.eye(3))
+    # rotation axes of the root: z axis is the pre-rotation's z (identity), y = Rz * ey, x = Rz Ry ex
+    assert np.allclose(st["rot_axis"][0][:, 2], [0, 0, 1], atol=tol)
+    assert np.allclose(st["rot_axis"][0][:, 1], quat_rot(qa(PI / 8, 2), [0, 1, 0]), atol=tol * 2)
+    assert np.allclose(
+        st["rot_axis"][0][:, 0], quat_rot(quat_mul(qa(PI / 8, 2), qa(PI / 6, 1)), [1, 0, 0]), atol=tol * 2
+    )
+
+
+def _fd_jacobian(orc, rig, cons, theta, h=1e-6):
+    """Central differences on the oracle's own f64 residual (error_function_helpers.cpp:74-109
+    uses forward differences with step 1e-5; central is tighter)."""
+    P = rig.num_params
+    _, r0, _ = orc.eval_jacobian(rig, cons, theta, dtype="f64")
+    Jfd = np.zeros((r0.shape[0], P))
+    for p in range(P):
+        tp, tm = theta.copy(), theta.copy()
+        tp[p] += h
+        tm[p] -= h
+        _, rp, _ = orc.eval_jacobian(rig, cons, tp, dtype="f64")
+        _, rm, _ = orc.eval_jacobian(rig, cons, tm, dtype="f64")
+        Jfd[:, p] = (rp - rm) / (2 * h)
+    return Jfd
+
+
+@pytest.mark.parametrize("which", ["chain", "humanoid"])
+def test_jacobian_vs_finite_differences(orc, which):
+    # momentum/test/character_solver/error_function_helpers.cpp:169-281 (testGradientAndJacobian),
+    # drivers position_error_function_test.cpp:25-59, orientation_error_function_test.cpp:39-75
+    if which == "chain":
+        rig = make_test_character(8)
+        pp, op = [7, 3, 1], [6, 2]
+    else:
+        rig = make_humanoid72(seed=7)
+        pp, op = [6, 26, 40, 14, 71], [51, 12, 33]
+    cons, th0, ths = make_problem(rig, pp, op, 1, seed=3, perturb=0.4, random_offsets=True, weights="random")
+    c = cons.instance(0)
+    c.pos_function_weight, c.ori_function_weight = 0.7, 1.3
+    rng = np.random.default_rng(5)
+    theta = rng.uniform(-0.5, 0.5, size=rig.num_params)
+    J, r, err = orc.eval_jacobian(rig, c, theta, dtype="f64")
+    # |r|^2 == error  (helpers:203-216, tolerance 5e-4 relative there)
+    assert abs(r @ r - err) <= 1e-10 * max(1.0, err)
+    assert abs(orc.get_error(rig, c, theta, "f64") - err) <= 2e-6 * max(1.0, err)  # getError casts to float
+    Jfd = _fd_jacobian(orc, rig, c, theta)
+    scale = max(1.0, np.abs(J).max())
+    assert np.abs(J - Jfd).max() <= 1e-6 * scale  # getJacThreshold 1e-6 for double (helpers.h:42-52)
+    # 2 J^T r == gradient of the error (helpers:220,262): FD gradient of sum w |f|^2
+    g = 2 * J.T @ r
+    h = 1e-6
+    gfd = np.zeros_like(g)
+    for p in range(rig.num_params):
+        tp, tm = theta.copy(), theta.copy()
+        tp[p] += h
+        tm[p] -= h
+        _, rp, _ = orc.eval_jacobian(rig, c, tp, dtype="f64")
+        _, rm, _ = orc.eval_jacobian(rig, c, tm, dtype="f64")
+        gfd[p] = (rp @ rp - rm @ rm) / (2 * h)
+    assert np.abs(g - gfd).max() <= 1e-5 * max(1.0, np.abs(g).max())
+    # fp32 instantiation agrees with fp64 at fp32 accuracy
+    J32, r32, e32 = orc.eval_jacobian(rig, c, theta, dtype="f32")
+    assert np.abs(J32 - J).max() <= 2e-5 * scale
+    assert np.abs(r32 - r).max() <= 2e-5 * max(1.0, np.abs(r).max())
+
+
+def test_jacobian_respects_enabled_parameters_and_zero_weights(orc):
+    rig = make_test_character(6)
+    cons, _, _ = make_problem(rig, [5, 2], [4], 1, seed=11, random_offsets=True)
+    c = cons.instance(0)
+    c.pos_weight = c.pos_weight.copy()
+    c.pos_weight[1] = 0.0  # weight == 0 -> rows stay zero (joint_error_function-inl.h:197-199)
+    theta = np.random.default_rng(2).uniform(-0.4, 0.4, rig.num_params)
+    en = np.ones(rig.num_params, np.uint8)
+    en[[1, 4, 8]] = 0
+    J, r, _ = orc.eval_jacobian(rig, c, theta, enabled=en, dtype="f64")
+    Jall, rall, _ = orc.eval_jacobian(rig, c, theta, dtype="f64")
+    assert np.all(J[:, [1, 4, 8]] == 0)
+    keep = np.flatnonzero(en)
+    assert np.array_equal(J[:, keep], Jall[:, keep])
+    assert np.all(J[3:6] == 0) and np.all(r[3:6] == 0)
+    # activeJointParams (parameter_transform.cpp:97-107)
+    act = orc.active_joint_params(rig, en)
+    A = rig.dense_transform()
+    assert np.array_equal(act.astype(bool), (np.abs(A[:, keep]).sum(axis=1) > 0))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("block", [False, True])
+def test_gn_mock_known_answer(orc, dtype, block):
+    # momentum/test/solver/gauss_newton_solver_test.cpp:263-285: from theta = 1 the solver must
+    # reach |theta| <= 1e-4 and error <= 1e-8 (defaultSolverOptions: min 4, max 40, threshold 1000,
+    # solver_test_helpers.h:16-53; regularization small)
+    opt = GnOptions.make(min_iterations=4, max_iterations=40, threshold=1000.0, regularization=1e-7)
+    r = orc.mock_solve(10, np.ones(10), opt, dtype=dtype, use_block_jtj=block)
+    assert np.linalg.norm(r["theta"]) <= 1e-4
+    assert orc.mock_solve(10, r["theta"], GnOptions.make(1, 1), dtype=dtype)["error"] <= 1e-8
+    # monotone error history (:680-717)
+    h = r["error_history"]
+    assert np.all(np.diff(h) <= 0)
+    # subset / non-contiguous enabled set: disabled parameters untouched (:757-880)
+    en = np.ones(10, np.uint8)
+    en[[0, 3, 9]] = 0
+    r2 = orc.mock_solve(10, np.ones(10), opt, enabled=en, dtype=dtype, use_block_jtj=block)
+    assert np.array_equal(r2["theta"][[0, 3, 9]], [1, 1, 1])
+    assert np.linalg.norm(r2["theta"][en.astype(bool)]) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype,etol,ptol", [("f32", 5e-7, 5e-5), ("f64", 1e-8, 1e-5)])
+def test_ik_end_to_end_three_joint_chain(orc, dtype, etol, ptol):
+    # momentum/test/character_solver/inverse_kinematics_test.cpp:60-99,114-121: 3-joint chain, one
+    # position constraint on joint 2 offset UnitY; GN {min = max = 6 iterations, lambda 1e-7};
+    # rest target => theta stays 0, error tiny; random reachable targets => end effector within tol.
+    rig = make_test_character(3)
+    opt = GnOptions.make(min_iterations=6, max_iterations=6, threshold=1.0, regularization=1e-7)
+    P = rig.num_params
+    off = np.array([[0, 1, 0]], np.float32)
+    rest = np.array([[0, 3, 0]], np.float32)
+    cons = orc.Constraints([2], off, rest, [1.0], [], np.zeros((0, 4)), np.zeros((0, 4)), [])
+    r = orc.solve(rig, cons, np.zeros(P), opt, dtype=dtype, use_block_jtj=True)
+    assert np.abs(r["theta"]).max() <= 1e-6 and r["error"] <= 1e-7
+    rng = np.random.default_rng(12345)
+    for _ in range(10):
+        # targets generated from a random pose so that they are reachable (the reference draws
+        # targets in [-3,3]^3; the chain with root translation reaches all of them)
+        tgt = rng.uniform(-3, 3, size=(1, 3)).astype(np.float32)
+        cons = orc.Constraints([2], off, tgt, [1.0], [], np.zeros((0, 4)), np.zeros((0, 4)), [])
+        r = orc.solve(rig, cons, np.zeros(P), opt, dtype=dtype, use_block_jtj=True)
+        final = orc.get_error(rig, cons, r["theta"], dtype)
+        assert final <= etol
+        st = orc.skeleton_state(rig, r["theta"], dtype)
+        ee = _xf_point(st["world"][2].astype(np.float64), [0, 1, 0])
+        assert np.abs(ee - tgt[0]).max() <= ptol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_gn_variants_agree_all_joint_constraints(orc, dtype):
+    # momentum/test/character_solver/solver_test.cpp:43-121: position + orientation constraint on
+    # every joint, targets from a random pose in [-1,1]^P, start at 0, lambda 0.05, line search on.
+    # The reference compares SubsetGN / GN / GN-QR final errors (err <= 1.001 err_gn + 0.001); the
+    # oracle has one GN, so compare its two JtJ paths and line search on/off.
+    rig = make_test_character(5)
+    J = rig.num_joints
+    cons, th0, ths = make_problem(rig, list(range(J)), list(range(J)), 1, seed=77, perturb=1.0, random_offsets=True)
+    c = cons.instance(0)
+    opt = GnOptions.make(min_iterations=4, max_iterations=40, threshold=1000.0, regularization=0.05, do_line_search=True)
+    a = orc.solve(rig, c, np.zeros(rig.num_params), opt, dtype=dtype, use_block_jtj=False)
+    b = orc.solve(rig, c, np.zeros(rig.num_params), opt, dtype=dtype, use_block_jtj=True)
+    assert b["error"] <= 1.001 * a["error"] + 0.001 and a["error"] <= 1.001 * b["error"] + 0.001
+    assert np.abs(a["theta"] - b["theta"]).max() <= 1e-4
+    assert a["error_history"][-1] < a["error_history"][0] * 1e-2
+    assert np.all(np.diff(a["error_history"]) <= 1e-9)  # line search => monotone
+    # determinism: re-solve reproduces the error history exactly (pymomentum/test/test_solver2.py:195-198)
+    a2 = orc.solve(rig, c, np.zeros(rig.num_params), opt, dtype=dtype, use_block_jtj=False)
+    assert np.array_equal(a["error_history"], a2["error_history"])
+
+
+def test_solve_returns_stale_error_and_converges(orc):
+    # solver.cpp:126-127: the returned error is the objective at theta BEFORE the last step
+    rig = make_humanoid72()
+    from momentum_amd import humanoid72_landmark_joints
+
+    lm = humanoid72_landmark_joints(rig)
+    cons, th0, ths = make_problem(rig, lm, lm, 1, seed=12345, perturb=0.3)
+    c = cons.instance(0)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05)
+    r = orc.solve(rig, c, th0[0], opt, dtype="f64")
+    assert r["iterations"] == 10
+    opt9 = GnOptions.make(min_iterations=9, max_iterations=9, regularization=0.05)
+    r9 = orc.solve(rig, c, th0[0], opt9, dtype="f64")
+    assert abs(orc.get_error(rig, c, r9["theta"], "f64") - r["error"]) <= 2e-6 * max(1.0, r["error"])
+    assert r["error_history"][-1] < 1e-3 * r["error_history"][0]
