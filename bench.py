@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- character IK solves/sec on MI355X (BASELINE.json metric) + J-assembly HBM roofline.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--config cfg2|cfg2_all|cfg3]
+
+One "step" = one pass of the hot path over one batch: a full batched solve (10 Gauss-Newton
+iterations: FK -> Jacobian/residual -> JtJ/Jtr -> Cholesky (+1 refinement) -> theta update) of
+B independent 72-joint humanoid instances per GPU, inputs resident in HBM.  For N > 1 the driver
+launches one rank per GPU (torch.distributed.run); instances are sharded (weak scaling: B per GPU
+fixed) and the only collective is one all-reduce of the per-batch residual norms per solve.
+
+Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit/... plus
+  "roofline":     achieved algorithmic HBM GB/s of the J-assembly kernel (mmx_eval_jacobian),
+                  timed live with HIP events on the launch stream
+  "cpu_baseline": the CPU oracle (restatement of momentum's algorithm, kind "port") timed on
+                  this box's host cores on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X datasheet (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+UNIT = 0.01  # rig offsets "U[2,30] cm" expressed in metres
+
+CONFIGS = {
+    # name: (rig variant, constraint joints, default batch per GPU, step rule, description)
+    "cfg2": ("p128", "landmarks", 4096, 0, "BASELINE configs[1]: B x 72-joint humanoid (P=128), position+orientation on 16 landmark joints (M=192), GN lambda=0.05, 10 iterations"),
+    "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
+}
+
+
+def algorithmic_bytes_per_instance(M: int, P: int, Kp: int, Ko: int) -> int:
+    """write J (M*P) and r (M), read theta (P), constraint payload and
+    parent indices; fp32; rig constants are batch-shared and excluded."""
+    return 4 * (M * P + M) + 4 * P + 4 * (7 * Kp + 9 * Ko) + 4 * (Kp + Ko)
+
+
+def make_device_problem(rig, parents, B, device_index, seed):
+    """Synthetic batch generated ON the GPU: theta* = U[-0.3,0.3]^P, targets = FK(theta*) through the
+    product's own FK kernel, theta0 = 0."""
+    from momentum_amd import capi
+
+    rh = capi.RigHandle(rig, device_index)
+    pb = capi.Problem(rh, B, parents, parents)
+    dev = pb.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    P, K = rig.num_params, len(parents)
+    theta_star = (torch.rand((B, P), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * 0.3
+    st = pb.skeleton_state(theta_star)  # [B,J,8]
+    idx = torch.as_tensor(np.asarray(parents, dtype=np.int64), device=dev)
+    world = st[:, idx, :]  # [B,K,8]
+    pos_offset = torch.zeros((B, K, 3), device=dev)
+    pos_target = world[:, :, 0:3].contiguous()
+    ori_offset = torch.zeros((B, K, 4), device=dev)
+    ori_offset[..., 3] = 1.0
+    ori_target = world[:, :, 3:7].contiguous()
+    w = torch.ones((B, K), device=dev)
+    pb.set_constraints(pos_offset, pos_target, w, ori_offset, ori_target, w.clone(), 1.0, 1.0)
+    theta0 = torch.zeros((B, P), device=dev, dtype=torch.float32)
+    return rh, pb, theta0, theta_star
+
+
+def cpu_baseline(rig, parents, sample, seed, options):
+    """The CPU oracle timed on the host cores (bounded sample of the same workload)."""
+    from oracle import oracle as orc
+    from tests.helpers import make_problem
+
+    cores = os.cpu_count() or 1
+    cons, th0, _ = make_problem(rig, parents, parents, sample, seed=seed, perturb=0.3)
+    orc.solve_batch(rig, cons, th0[: min(sample, 2 * cores)], options, dtype="f32", nthreads=cores)  # warm
+    t0 = time.perf_counter()
+    orc.solve_batch(rig, cons, th0, options, dtype="f32", nthreads=cores)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    n1 = max(1, min(sample, 64))
+    one = orc.Constraints(
+        cons.pos_parent, cons.pos_offset[:n1], cons.pos_target[:n1], cons.pos_weight[:n1],
+        cons.ori_parent, cons.ori_offset[:n1], cons.ori_target[:n1], cons.ori_weight[:n1],
+    )  # fmt: skip
+    orc.solve_batch(rig, one, th0[:n1], options, dtype="f32", nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": sample / dt,
+        "unit": "solves/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{sample} instances of the same workload, fp32, one solver per task over {cores} std::threads (mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
+        "single_thread_value": n1 / dt1,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's)")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--iterations", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--jac-launches", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL behind the "nccl" backend on ROCm
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from momentum_amd import humanoid72_landmark_joints, make_humanoid72
+    from momentum_amd._abi import GnOptions
+
+    variant, which, defB, step_rule, desc = CONFIGS[args.config]
+    B = args.batch if args.batch > 0 else defB
+    rig = make_humanoid72(seed=12345, variant=variant, unit=UNIT)
+    parents = humanoid72_landmark_joints(rig) if which == "landmarks" else np.arange(rig.num_joints, dtype=np.int32)
+    seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
+    rh, pb, theta0, theta_star = make_device_problem(rig, parents, B, local_rank, seed)
+    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule)
+    dev = pb.device
+    theta = theta0.clone()
+    outputs = dict(
+        error=torch.empty((B,), dtype=torch.float64, device=dev),
+        iterations=torch.empty((B,), dtype=torch.int32, device=dev),
+        status=torch.empty((B,), dtype=torch.int32, device=dev),
+    )
+    norms = torch.zeros(3, dtype=torch.float64, device=dev)
+
+    def step():
+        theta.copy_(theta0)
+        pb.solve(theta, opt, outputs=outputs)
+        # the path's only exchange: per-batch residual norms (sum error, sum iterations, #failed)
+        norms[0] = outputs["error"].sum()
+        norms[1] = outputs["iterations"].sum()
+        norms[2] = (outputs["status"] != 0).sum()
+        if dist is not None:
+            dist.all_reduce(norms)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    total_err, total_it, failed = [float(x) for x in norms.tolist()]
+
+    # ---- roofline of the J-assembly kernel (mmx_eval_jacobian): HIP events on the launch stream
+    M, P, K = pb.M, pb.P, len(parents)
+    jac = torch.empty((B, P, M), dtype=torch.float32, device=dev)
+    res = torch.empty((B, M), dtype=torch.float32, device=dev)
+    err = torch.empty((B,), dtype=torch.float64, device=dev)
+    for _ in range(3):
+        pb.eval_jacobian(theta_star, jac, res, err)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.jac_launches)]
+    for a, b in evs:
+        a.record()
+        pb.eval_jacobian(theta_star, jac, res, err)
+        b.record()
+    torch.cuda.synchronize()
+    jac_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    bytes_per_launch = B * algorithmic_bytes_per_instance(M, P, K, K)
+    achieved = bytes_per_launch / (jac_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_jacobian.json")
+    if os.path.exists(pmc_path):
+        try:
+            pm = json.load(open(pmc_path))
+            if pm.get("batch") == B and pm.get("config") == args.config:
+                traffic = pm.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    del jac
+
+    if rank == 0:
+        solves = float(B) * world * args.steps
+        line = {
+            "metric": "character IK solves/sec (72-joint, 10 GN iters)",
+            "value": solves / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": desc,
+                "batch_per_gpu": B,
+                "global_batch": B * world,
+                "joints": rig.num_joints,
+                "params": P,
+                "rows": M,
+                "gn_iterations": args.iterations,
+                "regularization": 0.05,
+                "sharding": f"{world} x {B} independent instances, one all-reduce of residual norms per solve",
+            },
+            "check": {"sum_final_error": total_err, "sum_iterations": total_it, "failed_instances": failed},
+            "roofline": {
+                "kernel": "fkJacobianKernel<true> (mmx_eval_jacobian: FK + dense J/r assembly)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_launch": bytes_per_launch,
+                "ms_per_launch": jac_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(rig, parents, min(args.cpu_sample, B), 12345, opt)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

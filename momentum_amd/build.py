@@ -1,0 +1,57 @@
+"""Builds momentum_amd/libmmx_hip.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc.
+
+In-tree artefact: the .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmmx_hip.so")
+SOURCES = ["mmx_kernels.hip", "mmx_capi.hip", "mmx_host_tables.cpp"]
+HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build the gfx950 kernels)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,277 @@
+"""ctypes binding of momentum_amd/libmmx_hip.so (the C ABI of include/mmx.h).
+
+Plumbing only: torch owns device memory and streams, the HIP library does all compute.  There is
+no CPU fallback -- loading fails loudly if the library is missing, and every compute call raises
+MmxError if the device path cannot run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _abi
+from ._abi import ConstraintData, GnOptions, RigDesc, as_ptr
+from .rigs import Rig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmx_hip.so")
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/mmx.h declares (tests/test_abi.py checks the header against this list and
+# the built library against both)
+SYMBOLS = [
+    "mmx_gn_options_default", "mmx_abi_version", "mmx_last_error", "mmx_device_count",
+    "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
+    "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
+    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_eval_jacobian",
+    "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_host",
+    "mmx_eval_jacobian_host", "mmx_host_tables",
+]  # fmt: skip
+
+
+class MmxError(RuntimeError):
+    """Non-zero status from the C ABI (the C++ shell maps it to std::runtime_error like MT_CHECK)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mmx error {code}: {msg}")
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Loads libmmx_hip.so.  torch is imported first so that both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmxError(-1, f"{LIB_PATH} is missing: build it with `python -m momentum_amd.build` (no CPU fallback exists)")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first; same soname, one runtime)
+    except Exception:  # pragma: no cover - torch is plumbing, the library also works without it
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.mmx_last_error.restype = C.c_char_p
+    L.mmx_gn_options_default.restype = None
+    L.mmx_gn_options_default.argtypes = [C.POINTER(GnOptions)]
+    L.mmx_rig_create.argtypes = [C.POINTER(RigDesc), i32, C.POINTER(vp)]
+    L.mmx_rig_destroy.argtypes = [vp]
+    L.mmx_rig_destroy.restype = None
+    L.mmx_rig_num_joints.argtypes = [vp]
+    L.mmx_rig_num_params.argtypes = [vp]
+    L.mmx_problem_create.argtypes = [vp, i32, i32, _abi.c_int32_p, i32, _abi.c_int32_p, C.POINTER(vp)]
+    L.mmx_problem_destroy.argtypes = [vp]
+    L.mmx_problem_destroy.restype = None
+    L.mmx_problem_num_rows.argtypes = [vp]
+    L.mmx_problem_batch.argtypes = [vp]
+    L.mmx_problem_set_enabled.argtypes = [vp, _abi.c_uint8_p]
+    L.mmx_problem_set_constraints.argtypes = [vp, C.POINTER(ConstraintData), vp]
+    L.mmx_eval_jacobian.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.mmx_eval_skeleton_state.argtypes = [vp, vp, vp, vp]
+    L.mmx_eval_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.mmx_solve.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
+    L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
+    L.mmx_eval_jacobian_host.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.mmx_host_tables.argtypes = [
+        C.POINTER(RigDesc), _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p,
+        _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p,
+    ]  # fmt: skip
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise MmxError(rc, lib().mmx_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return int(lib().mmx_device_count())
+
+
+def host_tables(rig: Rig, enabled=None) -> dict:
+    """Integer bookkeeping of the path, computed by the library's host code (no GPU needed)."""
+    J, P = rig.num_joints, rig.num_params
+    level, tin, tout = (np.zeros(J, np.int32) for _ in range(3))
+    active = np.zeros(7 * J, np.uint8)
+    elist = np.zeros(P, np.int32)
+    n = C.c_int32(0)
+    d = rig.desc()
+    if enabled is None:
+        eptr = _abi.c_uint8_p()
+    else:
+        e = np.ascontiguousarray(enabled, dtype=np.uint8)
+        eptr = as_ptr(e, C.c_uint8)
+    _check(
+        lib().mmx_host_tables(
+            C.byref(d), eptr, as_ptr(level, C.c_int32), as_ptr(tin, C.c_int32), as_ptr(tout, C.c_int32),
+            as_ptr(active, C.c_uint8), as_ptr(elist, C.c_int32), C.byref(n),
+        )
+    )  # fmt: skip
+    return dict(level=level, tin=tin, tout=tout, active_joint_params=active, enabled_list=elist[: n.value].copy())
+
+
+def _stream_ptr() -> C.c_void_p:
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class RigHandle:
+    """Device-resident Skeleton + ParameterTransform (mmx_rig)."""
+
+    def __init__(self, rig: Rig, device: int = 0):
+        self.rig = rig
+        self.device = int(device)
+        self._h = C.c_void_p(0)
+        d = rig.desc()
+        _check(lib().mmx_rig_create(C.byref(d), self.device, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().mmx_rig_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Problem:
+    """One batch of independent IK instances on one GPU (mmx_problem): the batched counterpart of
+    one SkeletonSolverFunction + GaussNewtonSolver per element
+    (pymomentum/tensor_ik/tensor_ik.cpp:127-177)."""
+
+    def __init__(self, rig_handle: RigHandle, batch: int, pos_parent, ori_parent):
+        import torch
+
+        self.rh = rig_handle
+        self.B = int(batch)
+        self.P = rig_handle.rig.num_params
+        self.J = rig_handle.rig.num_joints
+        self.pos_parent = np.ascontiguousarray(pos_parent, dtype=np.int32).reshape(-1)
+        self.ori_parent = np.ascontiguousarray(ori_parent, dtype=np.int32).reshape(-1)
+        self.Kp, self.Ko = len(self.pos_parent), len(self.ori_parent)
+        self.M = 3 * self.Kp + 9 * self.Ko
+        self.n = self.P
+        self.device = torch.device("cuda", rig_handle.device)
+        self._h = C.c_void_p(0)
+        self._keep = []
+        _check(
+            lib().mmx_problem_create(
+                rig_handle._h, self.B, self.Kp, as_ptr(self.pos_parent, C.c_int32), self.Ko,
+                as_ptr(self.ori_parent, C.c_int32), C.byref(self._h),
+            )
+        )  # fmt: skip
+
+    def close(self) -> None:
+        if self._h:
+            lib().mmx_problem_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- SolverT::setEnabledParameters
+    def set_enabled(self, enabled) -> None:
+        e = np.ascontiguousarray(enabled, dtype=np.uint8).reshape(-1)
+        assert e.shape[0] == self.P
+        _check(lib().mmx_problem_set_enabled(self._h, as_ptr(e, C.c_uint8)))
+        self.n = int(np.count_nonzero(e))
+
+    # -- setConstraints for every batch element; device tensors are borrowed, numpy arrays copied
+    def set_constraints(
+        self, pos_offset, pos_target, pos_weight, ori_offset, ori_target, ori_weight,
+        pos_function_weight: float = 1.0, ori_function_weight: float = 1.0,
+    ) -> None:  # fmt: skip
+        import torch
+
+        arrs = [pos_offset, pos_target, pos_weight, ori_offset, ori_target, ori_weight]
+        shapes = [(self.B, self.Kp, 3), (self.B, self.Kp, 3), (self.B, self.Kp), (self.B, self.Ko, 4), (self.B, self.Ko, 4), (self.B, self.Ko)]
+        on_dev = all(isinstance(a, torch.Tensor) for a in arrs)
+        keep, ptrs = [], []
+        for a, shp in zip(arrs, shapes):
+            if on_dev:
+                assert a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and tuple(a.shape) == shp, (a.shape, shp)
+                keep.append(a)
+                ptrs.append(C.c_void_p(a.data_ptr() if a.numel() else 0))
+            else:
+                x = np.ascontiguousarray(a, dtype=np.float32).reshape(shp)
+                keep.append(x)
+                ptrs.append(C.c_void_p(x.ctypes.data if x.size else 0))
+        cd = ConstraintData(*ptrs, float(pos_function_weight), float(ori_function_weight), _abi.MMX_MEM_DEVICE if on_dev else _abi.MMX_MEM_HOST)
+        _check(lib().mmx_problem_set_constraints(self._h, C.byref(cd), _stream_ptr()))
+        self._keep = keep if on_dev else []
+
+    def _theta(self, theta):
+        import torch
+
+        assert isinstance(theta, torch.Tensor) and theta.is_cuda and theta.dtype == torch.float32
+        assert theta.is_contiguous() and tuple(theta.shape) == (self.B, self.P), theta.shape
+        return theta
+
+    # -- the graded kernel: dense column-major Jacobian + residual (+ error)
+    def eval_jacobian(self, theta, jac=None, res=None, err=None, want_err: bool = True):
+        """Returns (jac [B,P,M] (jac[b].T is the M x P Jacobian), res [B,M], err [B] float64)."""
+        import torch
+
+        theta = self._theta(theta)
+        if jac is None:
+            jac = torch.empty((self.B, self.P, self.M), dtype=torch.float32, device=self.device)
+        if res is None:
+            res = torch.empty((self.B, self.M), dtype=torch.float32, device=self.device)
+        if err is None and want_err:
+            err = torch.empty((self.B,), dtype=torch.float64, device=self.device)
+        _check(lib().mmx_eval_jacobian(self._h, _dev(theta), _dev(jac), _dev(res), _dev(err), _abi.MMX_LAYOUT_COL_MAJOR, _stream_ptr()))
+        return jac, res, err
+
+    def skeleton_state(self, theta):
+        import torch
+
+        theta = self._theta(theta)
+        st = torch.empty((self.B, self.J, 8), dtype=torch.float32, device=self.device)
+        _check(lib().mmx_eval_skeleton_state(self._h, _dev(theta), _dev(st), _stream_ptr()))
+        return st
+
+    def normal_equations(self, theta):
+        import torch
+
+        theta = self._theta(theta)
+        jtj = torch.empty((self.B, self.n, self.n), dtype=torch.float32, device=self.device)
+        jtr = torch.empty((self.B, self.n), dtype=torch.float32, device=self.device)
+        err = torch.empty((self.B,), dtype=torch.float64, device=self.device)
+        _check(lib().mmx_eval_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), _dev(err), _stream_ptr()))
+        return jtj, jtr, err
+
+    def solve(self, theta, options: GnOptions, want_history: bool = False, outputs=None):
+        """In-place batched SolverT::solve.  Returns dict(theta, error, iterations, status[, error_history])."""
+        import torch
+
+        theta = self._theta(theta)
+        if outputs is None:
+            outputs = dict(
+                error=torch.empty((self.B,), dtype=torch.float64, device=self.device),
+                iterations=torch.empty((self.B,), dtype=torch.int32, device=self.device),
+                status=torch.empty((self.B,), dtype=torch.int32, device=self.device),
+            )
+            if want_history:
+                outputs["error_history"] = torch.empty((self.B, max(1, options.max_iterations)), dtype=torch.float64, device=self.device)
+        _check(
+            lib().mmx_solve(
+                self._h, C.byref(options), _dev(theta), _dev(outputs["error"]), _dev(outputs["iterations"]),
+                _dev(outputs["status"]), _dev(outputs.get("error_history")), _stream_ptr(),
+            )
+        )  # fmt: skip
+        outputs["theta"] = theta
+        return outputs

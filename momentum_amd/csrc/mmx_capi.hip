@@ -1,0 +1,733 @@
+// mmx_capi.hip -- implementation of the C ABI declared in include/mmx.h.
+// Host-side glue only: handle ownership, device buffers, table upload, kernel sequencing.
+// No compute happens on the host and there is no CPU fallback: without a HIP device every compute
+// entry point returns MMX_ERR_NO_DEVICE / MMX_ERR_DEVICE.
+#include "../../include/mmx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mmx_host_tables.hpp"
+#include "mmx_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int32_t fail(int32_t code, const std::string& msg) {
+  g_lastError = msg;
+  return code;
+}
+
+#define MMX_HIP(call)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      return fail(                                                                                \
+          e_ == hipErrorOutOfMemory ? MMX_ERR_OUT_OF_MEMORY : MMX_ERR_DEVICE,                     \
+          std::string(#call) + ": " + hipGetErrorString(e_));                                     \
+    }                                                                                             \
+  } while (0)
+
+// RAII device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() {
+    release();
+  }
+  void release() {
+    if (p != nullptr) {
+      (void)hipFree(p);
+      p = nullptr;
+      bytes = 0;
+    }
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes && p != nullptr) {
+      return hipSuccess;
+    }
+    release();
+    if (n == 0) {
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) {
+      bytes = n;
+    } else {
+      p = nullptr;
+    }
+    return e;
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+template <class T>
+hipError_t upload(DevBuf& buf, const std::vector<T>& v) {
+  hipError_t e = buf.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (e != hipSuccess || v.empty()) {
+    return e;
+  }
+  return hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+} // namespace
+
+struct mmx_rig {
+  int32_t device = 0;
+  int32_t J = 0, P = 0;
+  // host copy of the descriptor (needed to rebuild tables when the enabled set changes)
+  std::vector<int32_t> parent, ptOuter, ptInner;
+  std::vector<float> preRot, offset, ptValue, ptOffsets;
+  mmx::HostTables topo; // built with all parameters enabled
+  DevBuf dParent, dPreRot, dOffset, dPtOuter, dPtInner, dPtValue, dPtOffsets, dLevelOrder, dLevelStart;
+  mmx::RigDev dev{};
+
+  mmx_rig_desc desc() const {
+    mmx_rig_desc d{};
+    d.num_joints = J;
+    d.num_params = P;
+    d.parent = parent.data();
+    d.pre_rotation = preRot.data();
+    d.translation_offset = offset.data();
+    d.pt_outer = ptOuter.data();
+    d.pt_inner = ptInner.data();
+    d.pt_value = ptValue.data();
+    d.pt_offsets = ptOffsets.data();
+    return d;
+  }
+};
+
+struct mmx_problem {
+  mmx_rig* rig = nullptr;
+  int32_t B = 0, Kp = 0, Ko = 0, U = 0, M = 0;
+  std::vector<int32_t> posParent, oriParent;
+  mmx::HostTables tables; // for the current enabled set
+  DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList;
+  // constraint payload: owned copies (host ingest) or borrowed device pointers
+  DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight;
+  bool haveConstraints = false;
+  mmx::ProblemDev dev{};
+  // scratch
+  DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
+  DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist;
+};
+
+namespace {
+
+int32_t uploadProblemTables(mmx_problem* pb) {
+  const mmx_rig* rig = pb->rig;
+  MMX_HIP(hipSetDevice(rig->device));
+  const mmx::HostTables& t = pb->tables;
+  std::vector<int32_t> unitJoint(size_t(std::max(pb->U, 1))), unitTin(size_t(std::max(pb->U, 1)));
+  for (int32_t c = 0; c < pb->Kp; ++c) {
+    unitJoint[c] = pb->posParent[c];
+  }
+  for (int32_t c = 0; c < pb->Ko; ++c) {
+    for (int k = 0; k < 3; ++k) {
+      unitJoint[pb->Kp + 3 * c + k] = pb->oriParent[c];
+    }
+  }
+  for (int32_t u = 0; u < pb->U; ++u) {
+    unitTin[u] = t.tin[unitJoint[u]];
+  }
+  static_assert(sizeof(mmx::ColumnSource) == sizeof(mmx::ColumnSourceDev), "ColumnSource layouts must match");
+  MMX_HIP(upload(pb->dUnitJoint, unitJoint));
+  MMX_HIP(upload(pb->dUnitTin, unitTin));
+  MMX_HIP(upload(pb->dColStart, t.colStart));
+  MMX_HIP(upload(pb->dColSources, t.colSources));
+  MMX_HIP(upload(pb->dEnabledList, t.enabledList));
+  mmx::ProblemDev& d = pb->dev;
+  d.B = pb->B;
+  d.Kp = pb->Kp;
+  d.Ko = pb->Ko;
+  d.U = pb->U;
+  d.M = pb->M;
+  d.n = int32_t(t.enabledList.size());
+  d.unitJoint = pb->dUnitJoint.as<int32_t>();
+  d.unitTin = pb->dUnitTin.as<int32_t>();
+  d.colStart = pb->dColStart.as<int32_t>();
+  d.colSources = pb->dColSources.as<mmx::ColumnSourceDev>();
+  d.enabledList = pb->dEnabledList.as<int32_t>();
+  return MMX_OK;
+}
+
+int32_t checkProblem(const mmx_problem* pb, bool needConstraints) {
+  if (pb == nullptr || pb->rig == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "problem handle is null");
+  }
+  if (needConstraints && !pb->haveConstraints && pb->U > 0) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_problem_set_constraints has not been called");
+  }
+  return MMX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void mmx_gn_options_default(mmx_gn_options* o) {
+  if (o == nullptr) {
+    return;
+  }
+  o->min_iterations = 1; // SolverOptions (momentum/solver/solver.h:19-34)
+  o->max_iterations = 2;
+  o->threshold = 1.0f;
+  o->regularization = 0.05f; // GaussNewtonSolverBaseOptions (gauss_newton_solver.h:17-33)
+  o->do_line_search = 0;
+  o->step_rule = MMX_STEP_GN_FIXED_LAMBDA;
+  o->lm_lambda_min = 1e-6f;
+  o->lm_lambda_max = 1e6f;
+  o->lm_up = 4.0f;
+  o->lm_down = 0.5f;
+}
+
+int32_t mmx_abi_version(void) {
+  return MMX_ABI_VERSION;
+}
+
+const char* mmx_last_error(void) {
+  return g_lastError.c_str();
+}
+
+int32_t mmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int32_t mmx_host_tables(
+    const mmx_rig_desc* desc,
+    const uint8_t* enabled,
+    int32_t* level,
+    int32_t* tin,
+    int32_t* tout,
+    uint8_t* active_joint_params,
+    int32_t* enabled_list,
+    int32_t* num_enabled) {
+  mmx::HostTables t;
+  std::string err;
+  const int32_t rc = mmx::buildHostTables(desc, enabled, t, err);
+  if (rc != MMX_OK) {
+    return fail(rc, err);
+  }
+  if (level) {
+    std::memcpy(level, t.level.data(), sizeof(int32_t) * t.J);
+  }
+  if (tin) {
+    std::memcpy(tin, t.tin.data(), sizeof(int32_t) * t.J);
+  }
+  if (tout) {
+    std::memcpy(tout, t.tout.data(), sizeof(int32_t) * t.J);
+  }
+  if (active_joint_params) {
+    std::memcpy(active_joint_params, t.activeJointParams.data(), t.activeJointParams.size());
+  }
+  if (enabled_list) {
+    std::memcpy(enabled_list, t.enabledList.data(), sizeof(int32_t) * t.enabledList.size());
+  }
+  if (num_enabled) {
+    *num_enabled = int32_t(t.enabledList.size());
+  }
+  return MMX_OK;
+}
+
+int32_t mmx_rig_create(const mmx_rig_desc* d, int32_t device, mmx_rig** out) {
+  if (out == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "out is null");
+  }
+  *out = nullptr;
+  mmx::HostTables topo;
+  std::string err;
+  int32_t rc = mmx::buildHostTables(d, nullptr, topo, err);
+  if (rc != MMX_OK) {
+    return fail(rc, err);
+  }
+  const int ndev = mmx_device_count();
+  if (ndev <= 0) {
+    return fail(MMX_ERR_NO_DEVICE, "no HIP device visible; the MI355X path has no CPU fallback");
+  }
+  if (device < 0 || device >= ndev) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "device index out of range");
+  }
+  mmx_rig* r = new (std::nothrow) mmx_rig();
+  if (r == nullptr) {
+    return fail(MMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  }
+  r->device = device;
+  r->J = d->num_joints;
+  r->P = d->num_params;
+  const int32_t R = MMX_PARAMS_PER_JOINT * r->J;
+  r->parent.assign(d->parent, d->parent + r->J);
+  r->preRot.assign(d->pre_rotation, d->pre_rotation + 4 * r->J);
+  r->offset.assign(d->translation_offset, d->translation_offset + 3 * r->J);
+  r->ptOuter.assign(d->pt_outer, d->pt_outer + R + 1);
+  const int32_t nnz = r->ptOuter[R];
+  r->ptInner.assign(d->pt_inner, d->pt_inner + nnz);
+  r->ptValue.assign(d->pt_value, d->pt_value + nnz);
+  if (d->pt_offsets != nullptr) {
+    r->ptOffsets.assign(d->pt_offsets, d->pt_offsets + R);
+  } else {
+    r->ptOffsets.assign(R, 0.f);
+  }
+  r->topo = std::move(topo);
+  auto cleanup = [&](int32_t code) {
+    delete r;
+    return code;
+  };
+  if (hipSetDevice(device) != hipSuccess) {
+    return cleanup(fail(MMX_ERR_DEVICE, "hipSetDevice failed"));
+  }
+#define UP(buf, vec)                                                             \
+  do {                                                                           \
+    hipError_t e_ = upload(buf, vec);                                            \
+    if (e_ != hipSuccess) {                                                      \
+      return cleanup(fail(MMX_ERR_DEVICE, std::string("rig upload: ") + hipGetErrorString(e_))); \
+    }                                                                            \
+  } while (0)
+  UP(r->dParent, r->parent);
+  UP(r->dPreRot, r->preRot);
+  UP(r->dOffset, r->offset);
+  UP(r->dPtOuter, r->ptOuter);
+  UP(r->dPtInner, r->ptInner);
+  UP(r->dPtValue, r->ptValue);
+  UP(r->dPtOffsets, r->ptOffsets);
+  UP(r->dLevelOrder, r->topo.levelOrder);
+  UP(r->dLevelStart, r->topo.levelStart);
+#undef UP
+  mmx::RigDev& dv = r->dev;
+  dv.J = r->J;
+  dv.P = r->P;
+  dv.R = R;
+  dv.numLevels = int32_t(r->topo.levelStart.size()) - 1;
+  dv.parent = r->dParent.as<int32_t>();
+  dv.preRot = r->dPreRot.as<float>();
+  dv.offset = r->dOffset.as<float>();
+  dv.ptOuter = r->dPtOuter.as<int32_t>();
+  dv.ptInner = r->dPtInner.as<int32_t>();
+  dv.ptValue = r->dPtValue.as<float>();
+  dv.ptOffsets = r->dPtOffsets.as<float>();
+  dv.levelOrder = r->dLevelOrder.as<int32_t>();
+  dv.levelStart = r->dLevelStart.as<int32_t>();
+  *out = r;
+  return MMX_OK;
+}
+
+void mmx_rig_destroy(mmx_rig* rig) {
+  if (rig != nullptr) {
+    (void)hipSetDevice(rig->device);
+    delete rig;
+  }
+}
+
+int32_t mmx_rig_num_joints(const mmx_rig* rig) {
+  return rig ? rig->J : 0;
+}
+int32_t mmx_rig_num_params(const mmx_rig* rig) {
+  return rig ? rig->P : 0;
+}
+
+int32_t mmx_problem_create(
+    mmx_rig* rig,
+    int32_t batch,
+    int32_t num_pos,
+    const int32_t* pos_parent,
+    int32_t num_ori,
+    const int32_t* ori_parent,
+    mmx_problem** out) {
+  if (out == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "out is null");
+  }
+  *out = nullptr;
+  if (rig == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "rig handle is null");
+  }
+  if (batch <= 0 || num_pos < 0 || num_ori < 0) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "batch must be > 0 and constraint counts >= 0");
+  }
+  if ((num_pos > 0 && pos_parent == nullptr) || (num_ori > 0 && ori_parent == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "constraint parent array is null");
+  }
+  for (int32_t c = 0; c < num_pos; ++c) {
+    // MT_CHECK(jntIndex < skeleton_.joints.size()) (joint_error_function-inl.h:230)
+    if (pos_parent[c] < 0 || pos_parent[c] >= rig->J) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "position constraint parent joint out of range");
+    }
+  }
+  for (int32_t c = 0; c < num_ori; ++c) {
+    if (ori_parent[c] < 0 || ori_parent[c] >= rig->J) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "orientation constraint parent joint out of range");
+    }
+  }
+  mmx_problem* pb = new (std::nothrow) mmx_problem();
+  if (pb == nullptr) {
+    return fail(MMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  }
+  pb->rig = rig;
+  pb->B = batch;
+  pb->Kp = num_pos;
+  pb->Ko = num_ori;
+  pb->U = num_pos + 3 * num_ori;
+  pb->M = 3 * pb->U;
+  if (num_pos > 0) {
+    pb->posParent.assign(pos_parent, pos_parent + num_pos);
+  }
+  if (num_ori > 0) {
+    pb->oriParent.assign(ori_parent, ori_parent + num_ori);
+  }
+  pb->tables = rig->topo; // all parameters enabled
+  pb->dev.wPos = 1.f;
+  pb->dev.wOri = 1.f;
+  const int32_t rc = uploadProblemTables(pb);
+  if (rc != MMX_OK) {
+    delete pb;
+    return rc;
+  }
+  *out = pb;
+  return MMX_OK;
+}
+
+void mmx_problem_destroy(mmx_problem* pb) {
+  if (pb != nullptr) {
+    if (pb->rig != nullptr) {
+      (void)hipSetDevice(pb->rig->device);
+    }
+    delete pb;
+  }
+}
+
+int32_t mmx_problem_num_rows(const mmx_problem* pb) {
+  return pb ? pb->M : 0;
+}
+int32_t mmx_problem_batch(const mmx_problem* pb) {
+  return pb ? pb->B : 0;
+}
+
+int32_t mmx_problem_set_enabled(mmx_problem* pb, const uint8_t* enabled) {
+  int32_t rc = checkProblem(pb, false);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (enabled == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "enabled is null");
+  }
+  const mmx_rig_desc d = pb->rig->desc();
+  std::string err;
+  mmx::HostTables t;
+  rc = mmx::buildHostTables(&d, enabled, t, err);
+  if (rc != MMX_OK) {
+    return fail(rc, err);
+  }
+  pb->tables = std::move(t);
+  return uploadProblemTables(pb);
+}
+
+int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* c, void* stream) {
+  int32_t rc = checkProblem(pb, false);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (c == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "constraint data is null");
+  }
+  if (pb->Kp > 0 && (!c->pos_offset || !c->pos_target || !c->pos_weight)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "position constraint arrays are null");
+  }
+  if (pb->Ko > 0 && (!c->ori_offset || !c->ori_target || !c->ori_weight)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "orientation constraint arrays are null");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  mmx::ProblemDev& d = pb->dev;
+  const size_t B = size_t(pb->B);
+  if (c->memory == MMX_MEM_DEVICE) {
+    d.posOffset = c->pos_offset;
+    d.posTarget = c->pos_target;
+    d.posWeight = c->pos_weight;
+    d.oriOffset = c->ori_offset;
+    d.oriTarget = c->ori_target;
+    d.oriWeight = c->ori_weight;
+  } else if (c->memory == MMX_MEM_HOST) {
+    auto ingest = [&](DevBuf& buf, const float* src, size_t count, const float*& dst) -> hipError_t {
+      if (count == 0) {
+        dst = nullptr;
+        return hipSuccess;
+      }
+      hipError_t e = buf.ensure(count * sizeof(float));
+      if (e != hipSuccess) {
+        return e;
+      }
+      dst = buf.as<float>();
+      return hipMemcpyAsync(buf.p, src, count * sizeof(float), hipMemcpyHostToDevice, s);
+    };
+    MMX_HIP(ingest(pb->oPosOffset, c->pos_offset, B * pb->Kp * 3, d.posOffset));
+    MMX_HIP(ingest(pb->oPosTarget, c->pos_target, B * pb->Kp * 3, d.posTarget));
+    MMX_HIP(ingest(pb->oPosWeight, c->pos_weight, B * pb->Kp, d.posWeight));
+    MMX_HIP(ingest(pb->oOriOffset, c->ori_offset, B * pb->Ko * 4, d.oriOffset));
+    MMX_HIP(ingest(pb->oOriTarget, c->ori_target, B * pb->Ko * 4, d.oriTarget));
+    MMX_HIP(ingest(pb->oOriWeight, c->ori_weight, B * pb->Ko, d.oriWeight));
+    MMX_HIP(hipStreamSynchronize(s)); // the caller may free its host arrays on return
+  } else {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "constraint data: unknown memory space");
+  }
+  d.wPos = c->pos_function_weight;
+  d.wOri = c->ori_function_weight;
+  pb->haveConstraints = true;
+  return MMX_OK;
+}
+
+int32_t mmx_eval_jacobian(
+    mmx_problem* pb,
+    const float* theta_dev,
+    float* jac_dev,
+    float* res_dev,
+    double* err_dev,
+    int32_t layout,
+    void* stream) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta is null");
+  }
+  if (layout != MMX_LAYOUT_COL_MAJOR) {
+    return fail(MMX_ERR_UNSUPPORTED, "only MMX_LAYOUT_COL_MAJOR (the reference's layout) is implemented");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  MMX_HIP(mmx::launchFkJacobian(
+      pb->rig->dev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, static_cast<hipStream_t>(stream)));
+  return MMX_OK;
+}
+
+int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* state_dev, void* stream) {
+  int32_t rc = checkProblem(pb, false);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_dev == nullptr || state_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta / state is null");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  MMX_HIP(mmx::launchFkJacobian(
+      pb->rig->dev, pb->dev, theta_dev, nullptr, nullptr, nullptr, state_dev, nullptr, static_cast<hipStream_t>(stream)));
+  return MMX_OK;
+}
+
+namespace {
+int32_t ensureStepScratch(mmx_problem* pb) {
+  const size_t B = size_t(pb->B), M = size_t(pb->M), P = size_t(pb->rig->P), n = size_t(pb->dev.n);
+  MMX_HIP(pb->sJac.ensure(B * M * P * sizeof(float)));
+  MMX_HIP(pb->sRes.ensure(B * std::max<size_t>(M, 1) * sizeof(float)));
+  MMX_HIP(pb->sErr.ensure(B * sizeof(double)));
+  MMX_HIP(pb->sJtj.ensure(B * n * n * sizeof(float)));
+  MMX_HIP(pb->sJtr.ensure(B * n * sizeof(float)));
+  return MMX_OK;
+}
+} // namespace
+
+int32_t mmx_eval_normal_equations(
+    mmx_problem* pb,
+    const float* theta_dev,
+    float* jtj_dev,
+    float* jtr_dev,
+    double* err_dev,
+    void* stream) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_dev == nullptr || jtj_dev == nullptr || jtr_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta / jtj / jtr is null");
+  }
+  if (pb->dev.n > 512) {
+    return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = ensureStepScratch(pb);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  MMX_HIP(mmx::launchFkJacobian(
+      pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), err_dev, nullptr, nullptr, s));
+  MMX_HIP(mmx::launchNormalEquations(
+      pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), jtj_dev, jtr_dev, nullptr, s));
+  return MMX_OK;
+}
+
+int32_t mmx_solve(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    void* stream) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (o == nullptr || theta_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "options / theta is null");
+  }
+  if (o->max_iterations < 0 || o->min_iterations < 0) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "iteration counts must be >= 0");
+  }
+  if (o->do_line_search != 0) {
+    return fail(MMX_ERR_UNSUPPORTED, "doLineSearch is not implemented on the GPU path yet");
+  }
+  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA) {
+    return fail(MMX_ERR_UNSUPPORTED, "only MMX_STEP_GN_FIXED_LAMBDA is implemented yet");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
+  const int n = pb->dev.n;
+  if (mmx::choleskyStepLdsBytes(n, pb->M) > 160 * 1024) {
+    return fail(MMX_ERR_UNSUPPORTED, "enabled-parameter count too large for the in-LDS Cholesky of this build");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = ensureStepScratch(pb);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  MMX_HIP(pb->sThetaInit.ensure(B * P * sizeof(float)));
+  MMX_HIP(pb->sDone.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sLastErr.ensure(B * sizeof(double)));
+  MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
+  mmx::SolveStateDev st{};
+  st.done = pb->sDone.as<int32_t>();
+  st.iterations = iterations != nullptr ? iterations : pb->sIters.as<int32_t>();
+  st.status = status != nullptr ? status : pb->sStatus.as<int32_t>();
+  st.lastError = pb->sLastErr.as<double>();
+  st.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
+  st.errorHistory = error_history;
+  if (error_history != nullptr && o->max_iterations > 0) {
+    MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+  }
+  MMX_HIP(hipMemcpyAsync(pb->sThetaInit.p, theta_dev, B * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+  MMX_HIP(mmx::launchSolveInit(st, pb->B, s));
+  mmx::StepParams sp{};
+  sp.lambda = o->regularization;
+  sp.threshold = o->threshold;
+  sp.minIterations = o->min_iterations;
+  sp.maxIterations = o->max_iterations;
+  sp.refine = 1;
+  for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
+    sp.iteration = it;
+    MMX_HIP(mmx::launchFkJacobian(
+        pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
+    MMX_HIP(mmx::launchNormalEquations(
+        pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, s));
+    MMX_HIP(mmx::launchCholeskyStep(
+        pb->dev,
+        pb->rig->P,
+        pb->sJac.as<float>(),
+        pb->sRes.as<float>(),
+        pb->sJtj.as<float>(),
+        pb->sJtr.as<float>(),
+        pb->sErr.as<double>(),
+        theta_dev,
+        st,
+        sp,
+        s));
+  }
+  MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
+  return MMX_OK;
+}
+
+int32_t mmx_solve_host(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_host,
+    double* final_error_host,
+    int32_t* iterations_host,
+    int32_t* status_host) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_host == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta is null");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  MMX_HIP(pb->sTheta.ensure(B * P * sizeof(float)));
+  MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
+  MMX_HIP(hipMemcpy(pb->sTheta.p, theta_host, B * P * sizeof(float), hipMemcpyHostToDevice));
+  rc = mmx_solve(pb, o, pb->sTheta.as<float>(), pb->sFinalErr.as<double>(), pb->sIters.as<int32_t>(), pb->sStatus.as<int32_t>(), nullptr, nullptr);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  MMX_HIP(hipDeviceSynchronize());
+  MMX_HIP(hipMemcpy(theta_host, pb->sTheta.p, B * P * sizeof(float), hipMemcpyDeviceToHost));
+  if (final_error_host) {
+    MMX_HIP(hipMemcpy(final_error_host, pb->sFinalErr.p, B * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (iterations_host) {
+    MMX_HIP(hipMemcpy(iterations_host, pb->sIters.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  if (status_host) {
+    MMX_HIP(hipMemcpy(status_host, pb->sStatus.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return MMX_OK;
+}
+
+int32_t mmx_eval_jacobian_host(
+    mmx_problem* pb,
+    const float* theta_host,
+    float* jac_host,
+    float* res_host,
+    double* err_host,
+    int32_t layout) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_host == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta is null");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P), M = size_t(pb->M);
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  MMX_HIP(pb->sTheta.ensure(B * P * sizeof(float)));
+  MMX_HIP(pb->sJac.ensure(B * M * P * sizeof(float)));
+  MMX_HIP(pb->sRes.ensure(B * std::max<size_t>(M, 1) * sizeof(float)));
+  MMX_HIP(pb->sErr.ensure(B * sizeof(double)));
+  MMX_HIP(hipMemcpy(pb->sTheta.p, theta_host, B * P * sizeof(float), hipMemcpyHostToDevice));
+  rc = mmx_eval_jacobian(pb, pb->sTheta.as<float>(), pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), layout, nullptr);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  MMX_HIP(hipDeviceSynchronize());
+  if (jac_host) {
+    MMX_HIP(hipMemcpy(jac_host, pb->sJac.p, B * M * P * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  if (res_host) {
+    MMX_HIP(hipMemcpy(res_host, pb->sRes.p, B * M * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  if (err_host) {
+    MMX_HIP(hipMemcpy(err_host, pb->sErr.p, B * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return MMX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,298 @@
+// mmx_device.hpp -- device-side building blocks of the batched-IK kernels (gfx950, wave64).
+//
+// Data layout in LDS for ONE skeleton instance (all fp32):
+//   jp[10*J]  per joint: tx,ty,tz, sin(rx/2),cos(rx/2), sin(ry/2),cos(ry/2), sin(rz/2),cos(rz/2), exp2(sc)
+//   js[20*J]  per joint: world t(3) q(4, xyzw) s(1) | rotationAxis columns x,y,z (3x3) | pad(3)
+// Math follows momentum's JointStateT::set (momentum/character/joint_state.cpp:22-65),
+// TransformT::operator* (momentum/math/transform.h:124-129) and the Position / Orientation
+// evalFunction + ancestor walk (momentum/character_solver/position_error_function.cpp:15-27,
+// orientation_error_function.cpp:15-40, joint_error_function-inl.h:179-297), re-organised so that a
+// 64-lane wavefront works on one instance: lanes = joints during FK, lanes = constraint vectors
+// ("units", 3 Jacobian rows each) during assembly, and every Jacobian column is GATHERED from the
+// column's (joint, dof, weight) source list instead of scattered by an ancestor walk.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mmx {
+
+constexpr int kJp = 10; // floats per joint in jp[]
+constexpr int kJs = 20; // floats per joint in js[]
+constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
+
+struct F3 {
+  float x, y, z;
+};
+struct Q4 { // Eigen storage order
+  float x, y, z, w;
+};
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) {
+  return F3{x, y, z};
+}
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) {
+  return F3{a.x + b.x, a.y + b.y, a.z + b.z};
+}
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) {
+  return F3{a.x - b.x, a.y - b.y, a.z - b.z};
+}
+__device__ __forceinline__ F3 operator*(float s, F3 a) {
+  return F3{s * a.x, s * a.y, s * a.z};
+}
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+  return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float dot(F3 a, F3 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+// Eigen quaternion product
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return Q4{
+      a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+      a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+      a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x,
+      a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+// Eigen _transformVector: v + w*uv + qv x uv, uv = 2 (qv x v)
+__device__ __forceinline__ F3 qrot(Q4 q, F3 v) {
+  const F3 qv{q.x, q.y, q.z};
+  F3 uv = cross(qv, v);
+  uv = uv + uv;
+  return v + q.w * uv + cross(qv, uv);
+}
+// column c of Eigen toRotationMatrix
+__device__ __forceinline__ F3 qmatCol(Q4 q, int c) {
+  const float tx = 2.f * q.x, ty = 2.f * q.y, tz = 2.f * q.z;
+  const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const float txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const float tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  if (c == 0) {
+    return F3{1.f - (tyy + tzz), txy + twz, txz - twy};
+  }
+  if (c == 1) {
+    return F3{txy - twz, 1.f - (txx + tzz), tyz + twx};
+  }
+  return F3{txz + twy, tyz - twx, 1.f - (txx + tyy)};
+}
+__device__ __forceinline__ Q4 qnormalized(Q4 q) { // Eigen normalized(): q / sqrt(|q|^2)
+  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  if (n2 > 0.f) {
+    const float n = sqrtf(n2);
+    return Q4{q.x / n, q.y / n, q.z / n, q.w / n};
+  }
+  return q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device views of the rig / problem tables (all pointers are device memory)
+// ---------------------------------------------------------------------------------------------
+struct ColumnSourceDev { // mirrors mmx::ColumnSource (mmx_host_tables.hpp), 24 bytes
+  int32_t joint, dof, tin, tout, parent;
+  float weight;
+};
+
+struct RigDev {
+  int32_t J, P, R, numLevels;
+  const int32_t* parent; // [J]
+  const float* preRot; // [J][4]
+  const float* offset; // [J][3]
+  const int32_t* ptOuter; // [R+1]
+  const int32_t* ptInner; // [nnz]
+  const float* ptValue; // [nnz]
+  const float* ptOffsets; // [R]
+  const int32_t* levelOrder; // [J]
+  const int32_t* levelStart; // [numLevels+1]
+};
+
+struct ProblemDev {
+  int32_t B, Kp, Ko, U, M, n; // U = Kp + 3 Ko constraint vectors, M = 3 U rows, n = #enabled
+  const int32_t* unitJoint; // [U] parent joint of the unit's constraint
+  const int32_t* unitTin; // [U] tin[unitJoint]
+  const int32_t* colStart; // [P+1]
+  const ColumnSourceDev* colSources;
+  const int32_t* enabledList; // [n]
+  const float* posOffset; // [B][Kp][3]
+  const float* posTarget; // [B][Kp][3]
+  const float* posWeight; // [B][Kp]
+  const float* oriOffset; // [B][Ko][4]
+  const float* oriTarget; // [B][Ko][4]
+  const float* oriWeight; // [B][Ko]
+  float wPos, wOri; // SkeletonErrorFunction::weight_ of the two blocks
+};
+
+// ---------------------------------------------------------------------------------------------
+// phase 1: joint parameters = transform * theta + offsets (ParameterTransformT::apply,
+// momentum/character/parameter_transform.cpp:110-124), then the per-joint transcendental work
+// (half-angle sin/cos of Quaternion(AngleAxis), exp2 of the scale; joint_state.cpp:56-57,62)
+// with lanes = joint-parameter rows so all 64 lanes are busy.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void
+jointParamsPhase(const RigDev& rig, const float* __restrict__ theta, float* jp, int lane, int nlanes) {
+  for (int r = lane; r < rig.R; r += nlanes) {
+    float acc = 0.f;
+    const int k1 = rig.ptOuter[r + 1];
+    for (int k = rig.ptOuter[r]; k < k1; ++k) {
+      acc += rig.ptValue[k] * theta[rig.ptInner[k]];
+    }
+    acc += rig.ptOffsets[r];
+    const int j = r / 7, d = r - 7 * j;
+    float* o = jp + kJp * j;
+    if (d < 3) {
+      o[d] = acc;
+    } else if (d < 6) {
+      float s, c;
+      sincosf(0.5f * acc, &s, &c);
+      o[3 + 2 * (d - 3)] = s;
+      o[4 + 2 * (d - 3)] = c;
+    } else {
+      o[9] = exp2f(acc);
+    }
+  }
+}
+
+// phase 2 body: JointStateT::set for joint j, parent already final in js[] (joint_state.cpp:22-65)
+__device__ __forceinline__ void fkJoint(const RigDev& rig, int j, const float* jp, float* js) {
+  const int par = rig.parent[j];
+  F3 tp{0.f, 0.f, 0.f};
+  Q4 qp{0.f, 0.f, 0.f, 1.f};
+  float sp = 1.f;
+  if (par >= 0) {
+    const float* p = js + kJs * par;
+    tp = F3{p[0], p[1], p[2]};
+    qp = Q4{p[3], p[4], p[5], p[6]};
+    sp = p[7];
+  }
+  const float* a = jp + kJp * j;
+  const float* pre = rig.preRot + 4 * j;
+  Q4 ql{pre[0], pre[1], pre[2], pre[3]};
+  float* o = js + kJs * j;
+  // index 2 (z): axis = (q_p * q_l) * ez, then q_l *= Qz
+  {
+    const F3 ax = qrot(qmul(qp, ql), F3{0.f, 0.f, 1.f});
+    o[14] = ax.x, o[15] = ax.y, o[16] = ax.z;
+    ql = qmul(ql, Q4{0.f, 0.f, a[7], a[8]});
+  }
+  {
+    const F3 ax = qrot(qmul(qp, ql), F3{0.f, 1.f, 0.f});
+    o[11] = ax.x, o[12] = ax.y, o[13] = ax.z;
+    ql = qmul(ql, Q4{0.f, a[5], 0.f, a[6]});
+  }
+  {
+    const F3 ax = qrot(qmul(qp, ql), F3{1.f, 0.f, 0.f});
+    o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
+    ql = qmul(ql, Q4{a[3], 0.f, 0.f, a[4]});
+  }
+  const float* off = rig.offset + 3 * j;
+  const F3 tl{off[0] + a[0], off[1] + a[1], off[2] + a[2]};
+  // world = parent * local (transform.h:124-129)
+  const F3 t = tp + qrot(qp, sp * tl);
+  const Q4 q = qmul(qp, ql);
+  o[0] = t.x, o[1] = t.y, o[2] = t.z;
+  o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
+  o[7] = sp * a[9];
+}
+
+// One constraint vector ("unit") = 3 Jacobian rows 3u..3u+2.  Position constraint c -> unit c
+// (a point); orientation constraint c -> units Kp+3c+k, k = 0..2 (directions = columns of
+// R(world) * R(offset)).
+struct Unit {
+  F3 v; // world point / direction (v[k] of evalFunction)
+  F3 f; // residual rows before scaling
+  float sigma; // sqrt(w * loss'(.)) with the L2 loss (generalized_loss.cpp:25-32) = sqrt(w)
+  float werr; // this unit's share of the block error: w * |f|^2
+  int tin; // DFS index of the constraint's joint
+  bool isPoint;
+  bool valid;
+};
+
+__device__ __forceinline__ Unit evalUnit(const ProblemDev& pb, const float* js, int b, int u) {
+  Unit un;
+  un.valid = u < pb.U;
+  un.v = F3{0.f, 0.f, 0.f};
+  un.f = un.v;
+  un.sigma = 0.f;
+  un.werr = 0.f;
+  un.tin = -1;
+  un.isPoint = u < pb.Kp;
+  if (!un.valid) {
+    return un;
+  }
+  const int j = pb.unitJoint[u];
+  un.tin = pb.unitTin[u];
+  const float* w = js + kJs * j;
+  const F3 t{w[0], w[1], w[2]};
+  const Q4 q{w[3], w[4], w[5], w[6]};
+  const float s = w[7];
+  float cw, fw;
+  if (un.isPoint) {
+    // PositionErrorFunctionT::evalFunction (position_error_function.cpp:23-26)
+    const size_t c = size_t(b) * pb.Kp + u;
+    const float* po = pb.posOffset + 3 * c;
+    const float* pt = pb.posTarget + 3 * c;
+    un.v = t + qrot(q, s * F3{po[0], po[1], po[2]});
+    un.f = un.v - F3{pt[0], pt[1], pt[2]};
+    cw = pb.posWeight[c];
+    fw = pb.wPos;
+  } else {
+    // OrientationErrorFunctionT::evalFunction (orientation_error_function.cpp:23-39)
+    const int uo = u - pb.Kp;
+    const int co = uo / 3, k = uo - 3 * co;
+    const size_t c = size_t(b) * pb.Ko + co;
+    const float* oo = pb.oriOffset + 4 * c;
+    const float* ot = pb.oriTarget + 4 * c;
+    const Q4 qo = qnormalized(Q4{oo[0], oo[1], oo[2], oo[3]}); // ctor normalises (:33-35)
+    const Q4 qt = qnormalized(Q4{ot[0], ot[1], ot[2], ot[3]});
+    un.v = qrot(q, qmatCol(qo, k));
+    un.f = un.v - qmatCol(qt, k);
+    cw = pb.oriWeight[c];
+    fw = pb.wOri;
+  }
+  // joint_error_function-inl.h:197-213 ; a block with weight_ <= 0 is skipped entirely
+  // (skeleton_solver_function.cpp:223-231) and a constraint with weight == 0 keeps zero rows
+  if (cw != 0.f && fw > 0.f) {
+    const float wgt = cw * fw;
+    un.werr = wgt * dot(un.f, un.f);
+    un.sigma = sqrtf(wgt);
+  }
+  return un;
+}
+
+// d(unit vector)/d(joint-parameter row (a,dof)) for a source term of a column; the three
+// formulas of joint_error_function-inl.h:248-291 with joint_state.cpp:68-82.
+__device__ __forceinline__ F3 sourceDerivative(const ColumnSourceDev& s, const float* js, const Unit& un, bool& applies) {
+  const bool anc = (s.tin <= un.tin) && (un.tin < s.tout);
+  const float* a = js + kJs * s.joint;
+  if (s.dof >= 3 && s.dof < 6) { // rotation: axis x (v - t_a) for points, axis x v for directions
+    const float* ax = a + 8 + 3 * (s.dof - 3);
+    const F3 off = un.isPoint ? un.v - F3{a[0], a[1], a[2]} : un.v;
+    applies = anc;
+    return cross(F3{ax[0], ax[1], ax[2]}, off);
+  }
+  applies = anc && un.isPoint;
+  if (s.dof < 3) { // translation: column dof of parent.toLinear() = R(q_p) * s_p; identity for a root
+    if (s.parent < 0) {
+      return F3{s.dof == 0 ? 1.f : 0.f, s.dof == 1 ? 1.f : 0.f, s.dof == 2 ? 1.f : 0.f};
+    }
+    const float* p = js + kJs * s.parent;
+    const F3 c = qmatCol(Q4{p[3], p[4], p[5], p[6]}, s.dof);
+    return F3{c.x * p[7], c.y * p[7], c.z * p[7]};
+  }
+  return kLn2 * (un.v - F3{a[0], a[1], a[2]}); // scale: (v - t_a) * ln2
+}
+
+__device__ __forceinline__ double waveReduceSum(double v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    v += __shfl_xor(v, off, 64);
+  }
+  return v;
+}
+__device__ __forceinline__ float waveReduceSumF(float v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    v += __shfl_xor(v, off, 64);
+  }
+  return v;
+}
+
+} // namespace mmx

@@ -1,0 +1,179 @@
+// mmx_host_tables.cpp -- see mmx_host_tables.hpp.  Pure host C++17, integer bookkeeping only.
+#include "mmx_host_tables.hpp"
+
+#include <algorithm>
+
+namespace mmx {
+
+int32_t validateRigDesc(const mmx_rig_desc* d, std::string& err) {
+  if (d == nullptr) {
+    err = "rig descriptor is null";
+    return MMX_ERR_INVALID_ARGUMENT;
+  }
+  const int32_t J = d->num_joints, P = d->num_params;
+  if (J <= 0 || P <= 0) {
+    err = "rig needs at least one joint and one model parameter";
+    return MMX_ERR_INVALID_ARGUMENT;
+  }
+  if (P > MMX_MAX_MODEL_PARAMS) {
+    err = "num_params exceeds kMaxModelParams (2048)";
+    return MMX_ERR_INVALID_ARGUMENT;
+  }
+  if (!d->parent || !d->pre_rotation || !d->translation_offset || !d->pt_outer || !d->pt_inner || !d->pt_value) {
+    err = "rig descriptor has a null array";
+    return MMX_ERR_INVALID_ARGUMENT;
+  }
+  for (int32_t j = 0; j < J; ++j) {
+    // Skeleton invariant (momentum/character/skeleton.cpp:16-22): parents precede children
+    if (d->parent[j] != MMX_INVALID_PARENT && (d->parent[j] < 0 || d->parent[j] >= j)) {
+      err = "joint " + std::to_string(j) + " has parent " + std::to_string(d->parent[j]) +
+          ": joints must be listed parent-before-child";
+      return MMX_ERR_INVALID_ARGUMENT;
+    }
+  }
+  const int32_t R = MMX_PARAMS_PER_JOINT * J;
+  if (d->pt_outer[0] != 0) {
+    err = "pt_outer[0] must be 0";
+    return MMX_ERR_SIZE_MISMATCH;
+  }
+  for (int32_t r = 0; r < R; ++r) {
+    if (d->pt_outer[r + 1] < d->pt_outer[r]) {
+      err = "pt_outer must be non-decreasing";
+      return MMX_ERR_SIZE_MISMATCH;
+    }
+  }
+  const int32_t nnz = d->pt_outer[R];
+  for (int32_t k = 0; k < nnz; ++k) {
+    if (d->pt_inner[k] < 0 || d->pt_inner[k] >= P) {
+      err = "parameter-transform column index out of range (transform.cols() != num_params)";
+      return MMX_ERR_SIZE_MISMATCH;
+    }
+  }
+  return MMX_OK;
+}
+
+int32_t buildHostTables(const mmx_rig_desc* d, const uint8_t* enabled, HostTables& t, std::string& err) {
+  const int32_t rc = validateRigDesc(d, err);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  const int32_t J = d->num_joints, P = d->num_params, R = MMX_PARAMS_PER_JOINT * J;
+  t.J = J;
+  t.P = P;
+
+  // ---- levels (parents precede children, so one forward sweep suffices)
+  t.level.assign(J, 0);
+  int32_t maxLevel = 0;
+  for (int32_t j = 0; j < J; ++j) {
+    t.level[j] = d->parent[j] < 0 ? 0 : t.level[d->parent[j]] + 1;
+    maxLevel = std::max(maxLevel, t.level[j]);
+  }
+  t.levelStart.assign(maxLevel + 2, 0);
+  for (int32_t j = 0; j < J; ++j) {
+    t.levelStart[t.level[j] + 1]++;
+  }
+  for (int32_t l = 0; l <= maxLevel; ++l) {
+    t.levelStart[l + 1] += t.levelStart[l];
+  }
+  t.levelOrder.assign(J, 0);
+  {
+    std::vector<int32_t> cursor(t.levelStart.begin(), t.levelStart.end() - 1);
+    for (int32_t j = 0; j < J; ++j) { // ascending j keeps (level, index) order
+      t.levelOrder[cursor[t.level[j]]++] = j;
+    }
+  }
+
+  // ---- DFS pre-order intervals.  Subtree sizes by a backward sweep, then tin by a forward sweep
+  // that hands each child the next free slot of its parent (children in index order).
+  std::vector<int32_t> size(J, 1), nextSlot(J, 0);
+  for (int32_t j = J - 1; j >= 0; --j) {
+    if (d->parent[j] >= 0) {
+      size[d->parent[j]] += size[j];
+    }
+  }
+  t.tin.assign(J, 0);
+  t.tout.assign(J, 0);
+  int32_t rootCursor = 0;
+  for (int32_t j = 0; j < J; ++j) {
+    const int32_t p = d->parent[j];
+    if (p < 0) {
+      t.tin[j] = rootCursor;
+      rootCursor += size[j];
+    } else {
+      t.tin[j] = nextSlot[p];
+    }
+    nextSlot[j] = t.tin[j] + 1;
+    if (p >= 0) {
+      nextSlot[p] = t.tin[j] + size[j];
+    }
+    t.tout[j] = t.tin[j] + size[j];
+  }
+
+  // ---- enabled set
+  t.enabled.assign(P, 1);
+  if (enabled != nullptr) {
+    for (int32_t p = 0; p < P; ++p) {
+      t.enabled[p] = enabled[p] ? 1 : 0;
+    }
+  }
+  // GaussNewtonSolverT::updateEnabledParameters (gauss_newton_solver.cpp:57-66)
+  t.enabledList.clear();
+  t.fullToSubset.assign(P, -1);
+  for (int32_t p = 0; p < P; ++p) {
+    if (t.enabled[p]) {
+      t.fullToSubset[p] = int32_t(t.enabledList.size());
+      t.enabledList.push_back(p);
+    }
+  }
+  // ParameterTransformT::computeActiveJointParams (parameter_transform.cpp:97-107)
+  t.activeJointParams.assign(R, 0);
+  for (int32_t r = 0; r < R; ++r) {
+    for (int32_t k = d->pt_outer[r]; k < d->pt_outer[r + 1]; ++k) {
+      if (t.enabled[d->pt_inner[k]]) {
+        t.activeJointParams[r] = 1;
+      }
+    }
+  }
+
+  // ---- CSC view of the enabled entries: column p lists its (joint, dof, weight) sources in
+  // ascending joint-parameter row order.  A zero stored value is kept (the reference multiplies by
+  // it too).  Rows of a disabled column are dropped here, which is the
+  // enabledParameters_.test(inner[k]) test of joint_error_function-inl.h:257,273,286.
+  std::vector<int32_t> count(P + 1, 0);
+  for (int32_t r = 0; r < R; ++r) {
+    for (int32_t k = d->pt_outer[r]; k < d->pt_outer[r + 1]; ++k) {
+      if (t.enabled[d->pt_inner[k]]) {
+        count[d->pt_inner[k] + 1]++;
+      }
+    }
+  }
+  t.colStart.assign(P + 1, 0);
+  for (int32_t p = 0; p < P; ++p) {
+    t.colStart[p + 1] = t.colStart[p] + count[p + 1];
+  }
+  t.colSources.assign(t.colStart[P], ColumnSource{});
+  std::vector<int32_t> cursor(t.colStart.begin(), t.colStart.end() - 1);
+  for (int32_t r = 0; r < R; ++r) {
+    const int32_t joint = r / MMX_PARAMS_PER_JOINT, dof = r % MMX_PARAMS_PER_JOINT;
+    for (int32_t k = d->pt_outer[r]; k < d->pt_outer[r + 1]; ++k) {
+      const int32_t p = d->pt_inner[k];
+      if (!t.enabled[p]) {
+        continue;
+      }
+      ColumnSource& s = t.colSources[cursor[p]++];
+      s.joint = joint;
+      s.dof = dof;
+      s.tin = t.tin[joint];
+      s.tout = t.tout[joint];
+      s.parent = d->parent[joint];
+      s.weight = d->pt_value[k];
+    }
+  }
+  t.maxColSources = 0;
+  for (int32_t p = 0; p < P; ++p) {
+    t.maxColSources = std::max(t.maxColSources, t.colStart[p + 1] - t.colStart[p]);
+  }
+  return MMX_OK;
+}
+
+} // namespace mmx

@@ -1,0 +1,57 @@
+// mmx_host_tables.hpp -- host-side integer bookkeeping of the batched-IK path (no HIP here, so it
+// is unit-testable bit-exactly without a GPU).  Everything in this file is index arithmetic:
+// tree levels and DFS intervals of the Skeleton, the enabled-parameter list of
+// GaussNewtonSolverT::updateEnabledParameters (momentum/solver/gauss_newton_solver.cpp:57-66),
+// ParameterTransformT::computeActiveJointParams (momentum/character/parameter_transform.cpp:97-107)
+// and a column-wise (CSC) view of the enabled part of the parameter transform, which is what lets
+// the kernels GATHER a Jacobian column instead of scattering like the reference's ancestor walk
+// (momentum/character_solver/joint_error_function-inl.h:228-294).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mmx.h"
+
+namespace mmx {
+
+// One source term of a Jacobian column p: joint-parameter row (joint, dof) of the parameter
+// transform with weight w = transform(7*joint+dof, p).  tin/tout = DFS interval of `joint`:
+// the term contributes to a constraint on joint j iff tin <= tin[j] < tout (joint is j or one of
+// its ancestors -- exactly the set the reference's while(jntIndex != kInvalidIndex) loop visits).
+struct ColumnSource {
+  int32_t joint;
+  int32_t dof; // 0..2 translation, 3..5 rotation, 6 scale
+  int32_t tin;
+  int32_t tout;
+  int32_t parent; // parent joint of `joint` (-1 for a root): translationAxis = parent.toLinear()
+  float weight;
+};
+
+struct HostTables {
+  int32_t J = 0, P = 0;
+  // --- skeleton topology
+  std::vector<int32_t> level; // [J] depth, root = 0
+  std::vector<int32_t> levelOrder; // [J] joints sorted by (level, index)
+  std::vector<int32_t> levelStart; // [numLevels+1] offsets into levelOrder
+  std::vector<int32_t> tin, tout; // [J] DFS pre-order interval
+  // --- enabled-parameter dependent
+  std::vector<uint8_t> enabled; // [P]
+  std::vector<uint8_t> activeJointParams; // [7J]
+  std::vector<int32_t> enabledList; // [n] ascending
+  std::vector<int32_t> fullToSubset; // [P] index into enabledList or -1
+  std::vector<int32_t> colStart; // [P+1] offsets into colSources (disabled columns are empty)
+  std::vector<ColumnSource> colSources;
+  int32_t maxColSources = 0;
+};
+
+// Validates the descriptor the way the reference's constructors / MT_CHECKs do
+// (skeleton.cpp:16-22 parent-before-child; parameter_transform.cpp:112-121 sizes).
+// Returns MMX_OK or an error code with a message in `err`.
+int32_t validateRigDesc(const mmx_rig_desc* d, std::string& err);
+
+// Builds all tables.  `enabled` may be null (= all parameters enabled).
+int32_t buildHostTables(const mmx_rig_desc* d, const uint8_t* enabled, HostTables& out, std::string& err);
+
+} // namespace mmx

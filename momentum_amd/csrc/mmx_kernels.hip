@@ -1,0 +1,577 @@
+// mmx_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the batched-IK hot path.
+//
+//   fkJacobianKernel       one wavefront per skeleton instance: ParameterTransform apply -> FK by
+//                          tree level in LDS -> residual rows -> dense Jacobian, every column
+//                          gathered and written with coalesced 768-byte wave stores (the graded,
+//                          HBM-write-bound kernel: mmx_eval_jacobian).
+//   normalEquationsKernel  H = J[:,E]^T J[:,E], g = J[:,E]^T r from the dense Jacobian.
+//   choleskyStepKernel     (H + lambda I) d = g by in-LDS Cholesky, one corrected-seminormal
+//                          refinement step through J, theta -= d, convergence bookkeeping.
+//
+// Reference semantics: see the citations in mmx_device.hpp and at each kernel.
+#include "mmx_device.hpp"
+#include "mmx_kernels.hpp"
+
+#include <cfloat>
+
+namespace mmx {
+
+// =============================================================================================
+// Kernel 1: FK + residual + Jacobian assembly.  grid = B, block = 64 (one wavefront = one
+// instance), dynamic LDS = (kJp + kJs) * J floats.
+//
+// Replaces SkeletonSolverFunctionT::initializeJacobianComputation + computeJacobianBlock
+// (momentum/character_solver/skeleton_solver_function.cpp:200-261) -> JointErrorFunctionT::
+// getJacobian (joint_error_function-inl.h:179-297) for the position and orientation blocks.
+// Output layout: column-major M x P per instance (the reference's Eigen layout), rows 3u..3u+2 of
+// unit u.  Lane u owns three consecutive floats of every column, so one wave store covers 768
+// contiguous bytes; every element is written (structural zeros included), no read-modify-write.
+// =============================================================================================
+template <bool kWriteJac>
+__global__ void __launch_bounds__(64) fkJacobianKernel(
+    RigDev rig,
+    ProblemDev pb,
+    const float* __restrict__ theta, // [B][P]
+    float* __restrict__ jac, // [B][M*P] column-major, or null
+    float* __restrict__ res, // [B][M] or null
+    double* __restrict__ err, // [B] or null
+    float* __restrict__ state, // [B][J][8] or null
+    const int32_t* __restrict__ done) { // [B] or null: skip finished instances
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* jp = smem;
+  float* js = smem + kJp * rig.J;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (done != nullptr && done[b] != 0) {
+    return;
+  }
+  const float* th = theta + size_t(b) * rig.P;
+
+  jointParamsPhase(rig, th, jp, lane, 64);
+  __syncthreads();
+  // SkeletonStateT::set (skeleton_state.cpp:104-118): parents first.  Joints of one tree level are
+  // independent -> lanes = joints of the level; arithmetic per joint is the reference's
+  // parent * local in the reference's order.
+  for (int l = 0; l < rig.numLevels; ++l) {
+    const int i1 = rig.levelStart[l + 1];
+    for (int i = rig.levelStart[l] + lane; i < i1; i += 64) {
+      fkJoint(rig, rig.levelOrder[i], jp, js);
+    }
+    __syncthreads();
+  }
+  if (state != nullptr) {
+    float* so = state + size_t(b) * rig.J * 8;
+    for (int i = lane; i < rig.J * 8; i += 64) {
+      so[i] = js[kJs * (i >> 3) + (i & 7)];
+    }
+  }
+  if (!kWriteJac && res == nullptr && err == nullptr) {
+    return;
+  }
+
+  double errAcc = 0.0;
+  const size_t M = size_t(pb.M);
+  for (int u0 = 0; u0 < pb.U; u0 += 64) {
+    const int u = u0 + lane;
+    const Unit un = evalUnit(pb, js, b, u);
+    errAcc += double(un.werr);
+    if (res != nullptr && un.valid) {
+      float* r = res + size_t(b) * M + 3 * size_t(u);
+      r[0] = un.sigma * un.f.x;
+      r[1] = un.sigma * un.f.y;
+      r[2] = un.sigma * un.f.z;
+    }
+    if (kWriteJac) {
+      float* jb = jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(u);
+      for (int p = 0; p < rig.P; ++p) {
+        F3 acc{0.f, 0.f, 0.f};
+        const int e1 = pb.colStart[p + 1];
+        for (int e = pb.colStart[p]; e < e1; ++e) {
+          const ColumnSourceDev s = pb.colSources[e]; // wave-uniform
+          bool applies;
+          const F3 g = sourceDerivative(s, js, un, applies);
+          // jc = derivScale * dfdv * g ; jac.col(p) += jc * value (joint_error_function-inl.h:253-259)
+          const float w = applies ? s.weight : 0.f;
+          acc.x += (un.sigma * g.x) * w;
+          acc.y += (un.sigma * g.y) * w;
+          acc.z += (un.sigma * g.z) * w;
+        }
+        if (un.valid) {
+          float* o = jb + size_t(p) * M;
+          o[0] = acc.x;
+          o[1] = acc.y;
+          o[2] = acc.z;
+        }
+      }
+    }
+  }
+  if (err != nullptr) {
+    const double e = waveReduceSum(errAcc);
+    if (lane == 0) {
+      err[b] = e;
+    }
+  }
+}
+
+// =============================================================================================
+// Kernel 2: normal equations from the dense Jacobian.  grid = B, block = 256.
+// H = J[:,E]^T J[:,E] (full symmetric n x n), g = J[:,E]^T r, E = enabled parameter list.
+// Replaces the column compaction + `H.triangularView<Lower>() += J^T J; JtR += J^T r` of
+// GaussNewtonSolverT::computeJtJFromJacobianBlocks (momentum/solver/gauss_newton_solver.cpp:204-216).
+// Row chunks of J are staged in LDS ([k][s], padded); each thread accumulates 4x4 tiles of the
+// lower triangle in registers over ALL rows (tile loop outside, chunk loop inside would re-stage J,
+// so tiles are kept in a small register set and the matrix is swept once per tile batch).
+// =============================================================================================
+constexpr int kNeChunk = 32; // rows of J staged per step
+constexpr int kNeTilesPerThread = 4; // 4x4 tiles held per thread -> n <= 4*sqrt(2*256*4) ~ 180
+
+__global__ void __launch_bounds__(256) normalEquationsKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jac, // [B][M*P] column-major
+    const float* __restrict__ res, // [B][M]
+    float* __restrict__ jtj, // [B][n*n]
+    float* __restrict__ jtr, // [B][n]
+    const int32_t* __restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (done != nullptr && done[b] != 0) {
+    return;
+  }
+  const int n = pb.n, M = pb.M;
+  const int nT = (n + 3) >> 2; // tiles per dimension
+  const int ld = 4 * nT + 4; // padded row length of the staged chunk (multiple of 4 for b128 reads)
+  float* Jc = smem; // [kNeChunk][ld]
+  float* rc = smem + kNeChunk * ld; // [kNeChunk]
+  const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
+  const float* rb = res + size_t(b) * size_t(M);
+  const int numTiles = nT * (nT + 1) / 2;
+
+  for (int base = 0; base < numTiles; base += 256 * kNeTilesPerThread) {
+    float acc[kNeTilesPerThread][16];
+    int ti[kNeTilesPerThread], tj[kNeTilesPerThread];
+#pragma unroll
+    for (int q = 0; q < kNeTilesPerThread; ++q) {
+      // tile index -> (ti >= tj) of the lower triangle, row-major enumeration
+      const int t = base + q * 256 + tid;
+      int i = 0;
+      if (t < numTiles) {
+        i = int((sqrtf(8.f * float(t) + 1.f) - 1.f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= t) {
+          ++i;
+        }
+        while (i * (i + 1) / 2 > t) {
+          --i;
+        }
+      }
+      ti[q] = i;
+      tj[q] = t < numTiles ? t - i * (i + 1) / 2 : 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc[q][e] = 0.f;
+      }
+    }
+    float gacc[2] = {0.f, 0.f}; // threads accumulate g[tid], g[tid+256] (first tile batch only)
+    for (int k0 = 0; k0 < M; k0 += kNeChunk) {
+      const int kc = min(kNeChunk, M - k0);
+      __syncthreads();
+      // stage rows k0..k0+kc of the compacted Jacobian: element (k, s) = J[k0+k + E[s]*M]
+      for (int idx = tid; idx < kNeChunk * 4 * nT; idx += 256) {
+        const int k = idx % kNeChunk, s = idx / kNeChunk;
+        float v = 0.f;
+        if (k < kc && s < n) {
+          v = Jb[size_t(pb.enabledList[s]) * M + k0 + k];
+        }
+        Jc[k * ld + s] = v;
+      }
+      if (tid < kNeChunk) {
+        rc[tid] = tid < kc ? rb[k0 + tid] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kNeTilesPerThread; ++q) {
+        if (base + q * 256 + tid < numTiles) {
+          const float* pa = Jc + 4 * ti[q];
+          const float* pbb = Jc + 4 * tj[q];
+          for (int k = 0; k < kNeChunk; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(pa + k * ld);
+            const float4 c = *reinterpret_cast<const float4*>(pbb + k * ld);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+#pragma unroll
+              for (int y = 0; y < 4; ++y) {
+                acc[q][4 * x + y] += av[x] * cv[y];
+              }
+            }
+          }
+        }
+      }
+      if (base == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int s = tid + 256 * h;
+          if (s < n) {
+            for (int k = 0; k < kNeChunk; ++k) {
+              gacc[h] += Jc[k * ld + s] * rc[k];
+            }
+          }
+        }
+      }
+    }
+    // write tiles (both triangles)
+    float* Hb = jtj + size_t(b) * size_t(n) * size_t(n);
+#pragma unroll
+    for (int q = 0; q < kNeTilesPerThread; ++q) {
+      if (base + q * 256 + tid < numTiles) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+#pragma unroll
+          for (int y = 0; y < 4; ++y) {
+            const int i = 4 * ti[q] + x, j = 4 * tj[q] + y;
+            if (i < n && j < n) {
+              Hb[size_t(i) * n + j] = acc[q][4 * x + y];
+              Hb[size_t(j) * n + i] = acc[q][4 * x + y];
+            }
+          }
+        }
+      }
+    }
+    if (base == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (tid + 256 * h < n) {
+          jtr[size_t(b) * n + tid + 256 * h] = gacc[h];
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// Kernel 3: dense GN step.  grid = B, block = 256, dynamic LDS = n*(n+1) + 3n + M + 4 floats.
+//   H diag += lambda ; L L^T = H ; d0 = solve(g)                 (gauss_newton_solver.cpp:248-251)
+//   rho = J^T (r - J d0) - lambda d0 ; d = d0 + solve(rho)        (one refinement step, fp32: the
+//        corrected seminormal equations -- brings the fp32 step to ~1e-6 of the reference's
+//        double-precision solve, DESIGN.md "Numerics")
+//   theta[E] -= d                                                 (skeleton_solver_function.cpp:158)
+//   convergence / history bookkeeping of SolverT::solve           (solver.cpp:92-119)
+// =============================================================================================
+__device__ __forceinline__ void
+triangularSolves(const float* A, int ld, int n, float* x, int tid) {
+  // single wavefront, no barriers: lane owns rows lane, lane+64, ...; the pivot row's value is
+  // broadcast with a wave shuffle.  Forward L y = b then backward L^T x = y, in place.
+  if (tid >= 64) {
+    return;
+  }
+  constexpr int kMaxRowsPerLane = 8; // n <= 512
+  float v[kMaxRowsPerLane];
+#pragma unroll
+  for (int q = 0; q < kMaxRowsPerLane; ++q) {
+    const int i = tid + 64 * q;
+    v[q] = i < n ? x[i] : 0.f;
+  }
+  for (int k = 0; k < n; ++k) {
+    const int owner = k & 63, slot = k >> 6;
+    float mine = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMaxRowsPerLane; ++q) {
+      if (q == slot) {
+        mine = v[q];
+      }
+    }
+    const float yk = __shfl(mine, owner, 64) / A[k * ld + k];
+#pragma unroll
+    for (int q = 0; q < kMaxRowsPerLane; ++q) {
+      const int i = tid + 64 * q;
+      if (i == k) {
+        v[q] = yk;
+      } else if (i > k && i < n) {
+        v[q] -= A[k * ld + i] * yk; // L(i,k), column-major
+      }
+    }
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    const int owner = k & 63, slot = k >> 6;
+    float mine = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMaxRowsPerLane; ++q) {
+      if (q == slot) {
+        mine = v[q];
+      }
+    }
+    const float xk = __shfl(mine, owner, 64) / A[k * ld + k];
+#pragma unroll
+    for (int q = 0; q < kMaxRowsPerLane; ++q) {
+      const int i = tid + 64 * q;
+      if (i == k) {
+        v[q] = xk;
+      } else if (i < k) {
+        v[q] -= A[i * ld + k] * xk; // L^T(i,k) = L(k,i)
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kMaxRowsPerLane; ++q) {
+    const int i = tid + 64 * q;
+    if (i < n) {
+      x[i] = v[q];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) choleskyStepKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jac, // [B][M*P]
+    const float* __restrict__ res, // [B][M]
+    const float* __restrict__ jtj, // [B][n*n]
+    const float* __restrict__ jtr, // [B][n]
+    const double* __restrict__ errIter, // [B] error at the theta used to build J
+    float* __restrict__ theta, // [B][P] in/out
+    SolveStateDev st,
+    StepParams sp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (st.done[b] != 0) {
+    return;
+  }
+  const int n = pb.n, M = pb.M;
+  const int ld = n + 1; // odd-ish stride: conflict-free column walks
+  float* A = smem; // [n][ld] column-major: A[j*ld + i] = H(i,j)
+  float* g = A + n * ld; // [n]
+  float* d0 = g + n; // [n]
+  float* rho = d0 + n; // [n]
+  float* w = rho + n; // [M]
+  int* notPdPtr = reinterpret_cast<int*>(w + M); // all LDS scratch lives in the dynamic region
+  if (tid == 0) {
+    *notPdPtr = 0;
+  }
+  const float* Hb = jtj + size_t(b) * n * n;
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx % n, j = idx / n;
+    float v = Hb[idx];
+    if (i == j) {
+      v += sp.lambda;
+    }
+    A[j * ld + i] = v;
+  }
+  for (int i = tid; i < n; i += 256) {
+    g[i] = jtr[size_t(b) * n + i];
+    d0[i] = g[i];
+  }
+  __syncthreads();
+  // right-looking Cholesky, lower, in place
+  for (int k = 0; k < n; ++k) {
+    const float akk = A[k * ld + k];
+    if (!(akk > 0.f)) { // Eigen's LLT stops here with NumericalIssue; flag and stop factorising
+      if (tid == 0) {
+        *notPdPtr = 1;
+      }
+      break;
+    }
+    const float lkk = sqrtf(akk);
+    __syncthreads();
+    for (int i = k + tid; i < n; i += 256) {
+      A[k * ld + i] = (i == k) ? lkk : A[k * ld + i] / lkk;
+    }
+    __syncthreads();
+    // trailing update: column j (thread) -= L(j,k) * L(:,k)
+    for (int j = k + 1 + tid; j < n; j += 256) {
+      const float ljk = A[k * ld + j];
+      for (int i = j; i < n; ++i) {
+        A[j * ld + i] -= A[k * ld + i] * ljk;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool bad = *notPdPtr != 0;
+  if (!bad) {
+    triangularSolves(A, ld, n, d0, tid);
+  }
+  __syncthreads();
+  if (!bad && sp.refine) {
+    // w = r - J d0   (rows over threads, coalesced down each column)
+    const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
+    const float* rb = res + size_t(b) * size_t(M);
+    for (int k = tid; k < M; k += 256) {
+      float acc = rb[k];
+      for (int s = 0; s < n; ++s) {
+        acc -= Jb[size_t(pb.enabledList[s]) * M + k] * d0[s];
+      }
+      w[k] = acc;
+    }
+    __syncthreads();
+    // rho = J^T w - lambda d0  (one wavefront per column, coalesced, shuffle reduction)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int s = wave; s < n; s += 4) {
+      const float* col = Jb + size_t(pb.enabledList[s]) * M;
+      float acc = 0.f;
+      for (int k = lane; k < M; k += 64) {
+        acc += col[k] * w[k];
+      }
+      acc = waveReduceSumF(acc);
+      if (lane == 0) {
+        rho[s] = acc - sp.lambda * d0[s];
+      }
+    }
+    __syncthreads();
+    triangularSolves(A, ld, n, rho, tid);
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      d0[i] += rho[i];
+    }
+    __syncthreads();
+  }
+  // theta -= delta (scatter to the full parameter space, gauss_newton_solver.cpp:254-257)
+  if (!bad) {
+    float* th = theta + size_t(b) * P;
+    for (int s = tid; s < n; s += 256) {
+      th[pb.enabledList[s]] -= d0[s];
+    }
+  }
+  // SolverT::solve bookkeeping (solver.cpp:92-119)
+  if (tid == 0) {
+    const double e = errIter[b];
+    const double last = st.lastError[b];
+    if (st.errorHistory != nullptr) {
+      st.errorHistory[size_t(b) * sp.maxIterations + sp.iteration] = e;
+    }
+    st.iterations[b] = sp.iteration + 1;
+    st.finalError[b] = e;
+    if (bad) {
+      st.status[b] = 2; // MMX_SOLVE_NOT_PD
+    }
+    const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
+    if (sp.iteration >= sp.minIterations && converged) {
+      st.done[b] = 1;
+    }
+    st.lastError[b] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small bookkeeping kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void solveInitKernel(SolveStateDev st, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    st.done[b] = 0;
+    st.iterations[b] = 0;
+    st.status[b] = 0;
+    st.lastError[b] = DBL_MAX; // solver.cpp:84-85
+    st.finalError[b] = DBL_MAX;
+  }
+}
+
+// NaN/Inf guard of the batched driver: revert to the initial parameters
+// (pymomentum/tensor_ik/tensor_ik.cpp:168-173).  One wavefront per instance.
+__global__ void __launch_bounds__(64)
+solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaInit, int P, SolveStateDev st) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float* th = theta + size_t(b) * P;
+  const float* ti = thetaInit + size_t(b) * P;
+  int bad = 0;
+  for (int i = lane; i < P; i += 64) {
+    if (!isfinite(th[i])) {
+      bad = 1;
+    }
+  }
+  bad = __any(bad);
+  if (bad) {
+    for (int i = lane; i < P; i += 64) {
+      th[i] = ti[i];
+    }
+    if (lane == 0) {
+      st.status[b] = 1; // MMX_SOLVE_NONFINITE
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launchers (declared in mmx_kernels.hpp)
+// ---------------------------------------------------------------------------------------------
+size_t fkJacobianLdsBytes(int J) {
+  return size_t(kJp + kJs) * size_t(J) * sizeof(float);
+}
+
+hipError_t launchFkJacobian(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const float* theta,
+    float* jac,
+    float* res,
+    double* err,
+    float* state,
+    const int32_t* done,
+    hipStream_t stream) {
+  const size_t lds = fkJacobianLdsBytes(rig.J);
+  if (jac != nullptr) {
+    hipLaunchKernelGGL(fkJacobianKernel<true>, dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+  } else {
+    hipLaunchKernelGGL(fkJacobianKernel<false>, dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+  }
+  return hipGetLastError();
+}
+
+size_t normalEquationsLdsBytes(int n) {
+  const int nT = (n + 3) >> 2;
+  return size_t(kNeChunk) * size_t(4 * nT + 4) * sizeof(float) + kNeChunk * sizeof(float);
+}
+
+hipError_t launchNormalEquations(
+    const ProblemDev& pb,
+    int P,
+    const float* jac,
+    const float* res,
+    float* jtj,
+    float* jtr,
+    const int32_t* done,
+    hipStream_t stream) {
+  hipLaunchKernelGGL(
+      normalEquationsKernel, dim3(pb.B), dim3(256), normalEquationsLdsBytes(pb.n), stream, pb, P, jac, res, jtj, jtr, done);
+  return hipGetLastError();
+}
+
+size_t choleskyStepLdsBytes(int n, int M) {
+  return (size_t(n) * size_t(n + 1) + 3 * size_t(n) + size_t(M) + 4) * sizeof(float);
+}
+
+hipError_t launchCholeskyStep(
+    const ProblemDev& pb,
+    int P,
+    const float* jac,
+    const float* res,
+    const float* jtj,
+    const float* jtr,
+    const double* errIter,
+    float* theta,
+    const SolveStateDev& st,
+    const StepParams& sp,
+    hipStream_t stream) {
+  const size_t lds = choleskyStepLdsBytes(pb.n, pb.M);
+  if (lds > 64 * 1024) {
+    hipError_t rc = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(choleskyStepKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+  }
+  hipLaunchKernelGGL(
+      choleskyStepKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, errIter, theta, st, sp);
+  return hipGetLastError();
+}
+
+hipError_t launchSolveInit(const SolveStateDev& st, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(solveInitKernel, dim3((B + 255) / 256), dim3(256), 0, stream, st, B);
+  return hipGetLastError();
+}
+
+hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(solveFinalizeKernel, dim3(B), dim3(64), 0, stream, theta, thetaInit, P, st);
+  return hipGetLastError();
+}
+
+} // namespace mmx

@@ -1,0 +1,73 @@
+// mmx_kernels.hpp -- host-visible launch interface of mmx_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "mmx_device.hpp"
+
+namespace mmx {
+
+// per-instance state of SolverT::solve kept on the device (solver.cpp:84-119)
+struct SolveStateDev {
+  int32_t* done; // [B] 1 once the convergence test fired (instance idles afterwards)
+  int32_t* iterations; // [B] errorHistory_.size()
+  int32_t* status; // [B] MMX_SOLVE_*
+  double* lastError; // [B] lastError_
+  double* finalError; // [B] error_ (what solve() returns)
+  double* errorHistory; // [B][maxIterations] or null
+};
+
+struct StepParams {
+  float lambda; // regularization added to the diagonal of the compacted system
+  float threshold; // SolverOptions::threshold
+  int32_t iteration; // iteration_ (0-based)
+  int32_t minIterations;
+  int32_t maxIterations;
+  int32_t refine; // 1 = one corrected-seminormal refinement step through J
+};
+
+size_t fkJacobianLdsBytes(int J);
+size_t normalEquationsLdsBytes(int n);
+size_t choleskyStepLdsBytes(int n, int M);
+
+hipError_t launchFkJacobian(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const float* theta,
+    float* jac,
+    float* res,
+    double* err,
+    float* state,
+    const int32_t* done,
+    hipStream_t stream);
+
+hipError_t launchNormalEquations(
+    const ProblemDev& pb,
+    int P,
+    const float* jac,
+    const float* res,
+    float* jtj,
+    float* jtr,
+    const int32_t* done,
+    hipStream_t stream);
+
+hipError_t launchCholeskyStep(
+    const ProblemDev& pb,
+    int P,
+    const float* jac,
+    const float* res,
+    const float* jtj,
+    const float* jtr,
+    const double* errIter,
+    float* theta,
+    const SolveStateDev& st,
+    const StepParams& sp,
+    hipStream_t stream);
+
+hipError_t launchSolveInit(const SolveStateDev& st, int B, hipStream_t stream);
+hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream);
+
+} // namespace mmx

@@ -190,9 +190,9 @@ def make_humanoid72(seed: int = 12345, variant: str = "p128", unit: float = 1.0)
     spine 4 + neck + head + jaw/eyes 3; 2 x leg 6; 2 x (arm 4 + forearm twist 1 + 5 fingers x 4);
     depth 12.  Offsets U[2,30] (cm, times `unit`) along limb axes, pre-rotations random <= 0.3 rad.
 
-    variant "p128": root 6 DOF + scale_global + 3 rotations on articulated joints, finger curls
-                    shared across joints and four shared parameters (fist_l, fist_r,
-                    spine_twist, spine_bend) like the fixture's shared_rz  -> P = 128
+    variant "p128": root 6 DOF + scale_global + rotations on articulated joints, a jaw
+                    translation, finger curls shared across joints and three shared parameters
+                    (fist_l, fist_r, spine_twist) like the fixture's shared_rz  -> P = 128
     variant "p219": 6 root DOF + 3 rotations on all 71 non-root joints      -> P = 219
     """
     rng = np.random.default_rng(seed)
@@ -232,29 +232,38 @@ def make_humanoid72(seed: int = 12345, variant: str = "p128", unit: float = 1.0)
         for d, nm in enumerate(("tx", "ty", "tz", "rx", "ry", "rz")):
             add_param(f"root_{nm}", [("pelvis", d, 1.0)])
         add_param("scale_global", [("pelvis", SC, 1.0)])
-        full3 = ["spine1", "spine2", "spine3", "spine4", "neck", "head", "jaw", "eye_l", "eye_r"]
-        for s in ("l", "r"):
-            full3 += [f"hip_{s}", f"knee_{s}", f"ankle_{s}", f"ball_{s}", f"toe_{s}"]
-        for s in ("l", "r"):
-            full3 += [f"clavicle_{s}", f"shoulder_{s}", f"elbow_{s}", f"wrist_{s}"]
-        for n in full3:
-            for d, nm in ((RX, "rx"), (RY, "ry"), (RZ, "rz")):
+        def rot3(n, dofs=((RX, "rx"), (RY, "ry"), (RZ, "rz"))):
+            for d, nm in dofs:
                 add_param(f"{n}_{nm}", [(n, d, 1.0)])
+
+        # spine: rx/rz everywhere, ry individually on spine1/spine4 only; spine2/spine3 twist is
+        # driven ONLY by the shared spine_twist parameter (no exactly-redundant parameters: a
+        # redundant direction is a null space of J that fp32 noise / lambda drifts along)
+        rot3("spine1")
+        rot3("spine2", ((RX, "rx"), (RZ, "rz")))
+        rot3("spine3", ((RX, "rx"), (RZ, "rz")))
+        rot3("spine4")
+        add_param("spine_twist", [("spine2", RY, 0.5), ("spine3", RY, 0.5)])
+        for n in ("neck", "head", "jaw", "eye_l", "eye_r"):
+            rot3(n)
+        add_param("jaw_tz", [("jaw", TZ, 1.0)])  # a translation DOF below a non-root parent
         for s in ("l", "r"):
-            add_param(f"forearm_twist_{s}_rx", [(f"forearm_twist_{s}", RX, 1.0)])
+            for n in (f"hip_{s}", f"knee_{s}", f"ankle_{s}", f"ball_{s}", f"toe_{s}"):
+                rot3(n)
+        for s in ("l", "r"):
+            for n in (f"clavicle_{s}", f"shoulder_{s}", f"elbow_{s}", f"wrist_{s}"):
+                rot3(n)
+            rot3(f"forearm_twist_{s}", ((RX, "rx"), (RY, "ry")))
         for s in ("l", "r"):
             for f in ("thumb", "index", "middle", "ring", "pinky"):
                 dofs = ((RX, "rx"), (RY, "ry"), (RZ, "rz")) if f in ("thumb", "index") else ((RX, "rx"), (RZ, "rz"))
-                for d, nm in dofs:
-                    add_param(f"{f}0_{s}_{nm}", [(f"{f}0_{s}", d, 1.0)])
+                rot3(f"{f}0_{s}", dofs)
                 add_param(f"{f}_{s}_curl", [(f"{f}1_{s}", RZ, 0.6), (f"{f}2_{s}", RZ, 0.4)])
         for s in ("l", "r"):
             ent: List[Tuple[str, int, float]] = []
             for f in ("thumb", "index", "middle", "ring", "pinky"):
                 ent += [(f"{f}0_{s}", RZ, 0.3), (f"{f}1_{s}", RZ, 0.2), (f"{f}2_{s}", RZ, 0.2)]
             add_param(f"fist_{s}", ent)
-        add_param("spine_twist", [(f"spine{k}", RY, 0.25) for k in (1, 2, 3, 4)])
-        add_param("spine_bend", [(f"spine{k}", RX, 0.25) for k in (1, 2, 3, 4)])
         assert len(pnames) == 128, len(pnames)
     else:
         raise ValueError(f"unknown variant {variant!r}")

@@ -1,0 +1,106 @@
+"""CPU checks of the C-ABI boundary: the built library loads, exports every symbol include/mmx.h
+declares, struct layouts match the ctypes mirrors, and the product path fails LOUDLY without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from momentum_amd import _abi, make_test_character
+from momentum_amd import build as mbuild
+from momentum_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mmx.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    mbuild.build()
+    return capi.lib()
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_match_binding_list():
+    assert _declared_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(L):
+    for name in _declared_symbols():
+        assert hasattr(L, name), f"libmmx_hip.so does not export {name}"
+    assert L.mmx_abi_version() == _abi.MMX_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    prog = r"""
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "mmx.h"
+    int main(void) {
+      printf("%zu %zu %zu\n", sizeof(mmx_rig_desc), sizeof(mmx_constraint_data), sizeof(mmx_gn_options));
+      printf("%zu %zu %zu\n", offsetof(mmx_rig_desc, pt_offsets), offsetof(mmx_constraint_data, memory), offsetof(mmx_gn_options, lm_down));
+      return 0;
+    }"""
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [int(x) for x in out]
+    assert sizes[:3] == [C.sizeof(_abi.RigDesc), C.sizeof(_abi.ConstraintData), C.sizeof(_abi.GnOptions)]
+    assert sizes[3:] == [_abi.RigDesc.pt_offsets.offset, _abi.ConstraintData.memory.offset, _abi.GnOptions.lm_down.offset]
+
+
+def test_default_options_match_reference_structs(L):
+    # SolverOptions{1,2,1} (solver.h:19-34), GaussNewtonSolverBaseOptions{0.05,false} (gauss_newton_solver.h:17-33)
+    o = _abi.GnOptions()
+    L.mmx_gn_options_default(C.byref(o))
+    assert (o.min_iterations, o.max_iterations, o.threshold, o.do_line_search, o.step_rule) == (1, 2, 1.0, 0, 0)
+    assert abs(o.regularization - 0.05) < 1e-9
+
+
+def test_invalid_rig_is_rejected_like_mt_check(L):
+    rig = make_test_character(4)
+    rig.parent[2] = 3  # child before parent violates the Skeleton invariant (skeleton.cpp:16-22)
+    with pytest.raises(capi.MmxError) as ei:
+        capi.host_tables(rig)
+    assert "parent-before-child" in str(ei.value)
+    rig = make_test_character(4)
+    rig.pt_inner[0] = 99  # column index beyond numAllModelParameters
+    with pytest.raises(capi.MmxError):
+        capi.host_tables(rig)
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(L):
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(capi.MmxError) as ei:
+        capi.RigHandle(make_test_character(3))
+    assert ei.value.code == 6  # MMX_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under momentum_amd/ (nor include/) may import,
+    include or link it."""
+    bad = []
+    for base in ("momentum_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                    txt = open(os.path.join(dp, fn), errors="replace").read()
+                    if re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle|libmmx_oracle", txt, flags=re.M):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    out = subprocess.check_output(["readelf", "-d", capi.LIB_PATH]).decode()
+    assert "oracle" not in out

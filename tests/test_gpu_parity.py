@@ -1,0 +1,220 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Tolerances: bit-exact for integer outputs; floating point within north_star's 1e-5 relative on pose
+parameters (stated at each assert)."""
+import numpy as np
+import pytest
+
+from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
+from momentum_amd._abi import GnOptions
+from tests.helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+
+UNIT = 0.01  # humanoid offsets U[2,30] cm expressed in metres
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU (run with -m gpu on the MI355X box)")
+    return torch
+
+
+def _gpu_problem(torch, rig, cons, B):
+    from momentum_amd import capi
+
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    dev = pb.device
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(dev)
+    pb.set_constraints(
+        t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+        t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+        cons.pos_function_weight, cons.ori_function_weight,
+    )  # fmt: skip
+    return rh, pb
+
+
+CASES = {
+    # name: (rig factory, pos parents, ori parents, batch)
+    "chain24_cfg1": (lambda: make_test_character(24), [23, 12, 5], [], 3),
+    "chain8_mixed": (lambda: make_test_character(8), [7, 3, 1], [6, 2], 5),
+    "humanoid72_cfg2": (lambda: make_humanoid72(unit=UNIT), "lm", "lm", 6),
+    "humanoid72_ori_only": (lambda: make_humanoid72(unit=UNIT), [], [6, 26, 51, 12], 2),
+    "humanoid72_many_units": (lambda: make_humanoid72(unit=UNIT), list(range(0, 72, 2)), list(range(1, 72, 3)), 2),
+}
+
+
+def _case(name):
+    mk, pp, op, B = CASES[name]
+    rig = mk()
+    if pp == "lm":
+        pp = humanoid72_landmark_joints(rig)
+    if op == "lm":
+        op = humanoid72_landmark_joints(rig)
+    return rig, pp, op, B
+
+
+def test_skeleton_state_matches_oracle(torch_cuda, orc):
+    torch = torch_cuda
+    for name in ("chain24_cfg1", "humanoid72_cfg2"):
+        rig, pp, op, B = _case(name)
+        cons, th0, ths = make_problem(rig, pp, op, B, seed=21, perturb=0.5)
+        rh, pb = _gpu_problem(torch, rig, cons, B)
+        st = pb.skeleton_state(torch.from_numpy(ths).to(pb.device)).cpu().numpy()
+        for b in range(B):
+            ref = orc.skeleton_state(rig, ths[b].astype(np.float64), "f64")["world"]
+            scale = max(1.0, np.abs(ref[:, :3]).max())
+            assert np.abs(st[b, :, :3] - ref[:, :3]).max() <= 5e-6 * scale  # fp32 FK chain of depth <= 24
+            assert np.abs(st[b, :, 3:] - ref[:, 3:]).max() <= 5e-6
+    # the reference's FK golden value (forward_kinematics_test.cpp:80-86) through the GPU path
+    rig = make_test_character(24)
+    cons, _, _ = make_problem(rig, [2], [], 1)
+    rh, pb = _gpu_problem(torch, rig, cons, 1)
+    th = np.zeros((1, rig.num_params), np.float32)
+    th[0, :10] = [1, 1, 1, np.pi, 0, -np.pi, 0.1, np.pi, np.pi, -np.pi]
+    w = pb.skeleton_state(torch.from_numpy(th).to(pb.device)).cpu().numpy()[0, 2].astype(np.float64)
+    from tests.helpers import quat_rot
+
+    p = w[:3] + quat_rot(w[3:7], w[7] * np.ones(3))
+    assert np.abs(p - [-1.14354682, 3.14354706, -0.0717732906]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_jacobian_residual_error_match_oracle(torch_cuda, orc, name):
+    torch = torch_cuda
+    rig, pp, op, B = _case(name)
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=100, perturb=0.4, random_offsets=True, weights="random")
+    cons.pos_function_weight, cons.ori_function_weight = 0.8, 1.25
+    if cons.Kp:
+        cons.pos_weight[0, 0] = 0.0  # a zero-weight constraint keeps zero rows
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    rng = np.random.default_rng(9)
+    theta = rng.uniform(-0.4, 0.4, size=(B, rig.num_params)).astype(np.float32)
+    jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
+    jac, res, err = jac.cpu().numpy(), res.cpu().numpy(), err.cpu().numpy()
+    for b in range(B):
+        J, r, e = orc.eval_jacobian(rig, cons.instance(b), theta[b].astype(np.float64), dtype="f64")
+        Jg = jac[b].T  # [M,P]
+        scale = max(1.0, np.abs(J).max())
+        assert np.abs(Jg - J).max() <= 2e-5 * scale, (name, b)
+        assert np.array_equal(Jg == 0, np.abs(J) == 0) or np.abs(Jg[np.abs(J) == 0]).max() == 0  # structural zeros are exact zeros
+        assert np.abs(res[b] - r).max() <= 2e-5 * max(1.0, np.abs(r).max())
+        assert abs(err[b] - e) <= 2e-5 * max(1.0, e)
+
+
+def test_jacobian_with_disabled_parameters(torch_cuda, orc):
+    torch = torch_cuda
+    rig, pp, op, B = _case("humanoid72_cfg2")
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=5, perturb=0.3)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    rng = np.random.default_rng(1)
+    en = (rng.uniform(size=rig.num_params) < 0.7).astype(np.uint8)
+    pb.set_enabled(en)
+    theta = ths
+    jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
+    jac = jac.cpu().numpy()
+    for b in range(B):
+        J, r, e = orc.eval_jacobian(rig, cons.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
+        assert np.abs(jac[b].T - J).max() <= 2e-5 * max(1.0, np.abs(J).max())
+        assert np.all(jac[b].T[:, en == 0] == 0)
+    # normal equations of the compacted system (validateIdentical compares JtJ / Jtr, error_function_helpers.cpp:347-368)
+    jtj, jtr, _ = pb.normal_equations(torch.from_numpy(theta).to(pb.device))
+    jtj, jtr = jtj.cpu().numpy(), jtr.cpu().numpy()
+    keep = np.flatnonzero(en)
+    for b in range(B):
+        J, r, e = orc.eval_jacobian(rig, cons.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
+        H = J[:, keep].T @ J[:, keep]
+        g = J[:, keep].T @ r
+        assert np.abs(jtj[b] - H).max() <= 5e-5 * max(1.0, np.abs(H).max())
+        assert np.abs(jtr[b] - g).max() <= 5e-5 * max(1.0, np.abs(g).max())
+        assert np.array_equal(jtj[b], jtj[b].T)
+
+
+@pytest.mark.parametrize("name", ["chain24_cfg1", "chain8_mixed", "humanoid72_cfg2", "humanoid72_many_units"])
+def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
+    """north_star: pose parameters within 1e-5 relative of momentum's CPU solver (here: the oracle's
+    GaussNewtonSolverT<double> restatement) after 10 GN iterations, lambda = 0.05."""
+    torch = torch_cuda
+    rig, pp, op, B = _case(name)
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=12345, perturb=0.3)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
+    theta = torch.from_numpy(th0.copy()).to(pb.device)
+    out = pb.solve(theta, opt, want_history=True)
+    th = out["theta"].cpu().numpy()
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel.max() <= 1e-5, rel
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])  # integer bookkeeping: exact
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    e, eref = out["error"].cpu().numpy(), ref["error"]
+    assert np.abs(e - eref).max() <= 1e-4 * np.maximum(1e-3, np.abs(eref)).max()
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+
+
+def test_solve_convergence_bookkeeping_and_determinism(torch_cuda, orc):
+    torch = torch_cuda
+    rig, pp, op, B = _case("chain8_mixed")
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=3, perturb=0.2)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    # loose threshold => instances stop early, each at its own iteration (solver.cpp:98-115)
+    opt = GnOptions.make(min_iterations=2, max_iterations=30, threshold=1e5, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    it, itref = out["iterations"].cpu().numpy(), ref["iterations"]
+    assert np.all(it >= 3) and np.all(it <= 30)
+    assert np.abs(it - itref).max() <= 1  # the stop test compares fp32-level error differences
+    th = out["theta"].cpu().numpy()
+    same = it == itref
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel[same].max() <= 1e-5
+    # run-to-run determinism (pymomentum/test/test_solver2.py:195-198)
+    out2 = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert torch.equal(out["theta"], out2["theta"]) and torch.equal(out["error_history"], out2["error_history"])
+
+
+def test_nonfinite_input_reverts_to_initial_parameters(torch_cuda):
+    # pymomentum/tensor_ik/tensor_ik.cpp:168-173
+    torch = torch_cuda
+    rig, pp, op, B = _case("chain8_mixed")
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=3)
+    cons.pos_target[1, 0, 0] = np.nan
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=3, max_iterations=3)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)
+    st = out["status"].cpu().numpy()
+    assert st[1] != 0 and np.all(np.delete(st, 1) == 0)
+    assert np.array_equal(out["theta"].cpu().numpy()[1], th0[1])
+    assert np.isfinite(out["theta"].cpu().numpy()).all()
+
+
+def test_full_size_batch_properties(torch_cuda):
+    """BASELINE config 2 at full size (B = 4096): size-independent properties -- every instance
+    reduces its error by orders of magnitude, duplicates of one instance give bit-identical
+    results wherever they sit in the batch, and |r|^2 == error."""
+    torch = torch_cuda
+    rig = make_humanoid72(unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    Bs = 16
+    cons, th0, ths = make_problem(rig, lm, lm, Bs, seed=12345, perturb=0.3)
+    B = 4096
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (B // Bs,) + (1,) * (a.ndim - 1)))
+    from oracle import oracle as o
+
+    big = o.Constraints(cons.pos_parent, rep(cons.pos_offset), rep(cons.pos_target), rep(cons.pos_weight),
+                        cons.ori_parent, rep(cons.ori_offset), rep(cons.ori_target), rep(cons.ori_weight))  # fmt: skip
+    rh, pb = _gpu_problem(torch, rig, big, B)
+    theta0 = torch.from_numpy(rep(th0)).to(pb.device)
+    jac, res, err = pb.eval_jacobian(theta0)
+    assert torch.allclose((res.double() ** 2).sum(dim=1), err, rtol=1e-5, atol=1e-9)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05)
+    out = pb.solve(theta0.clone(), opt, want_history=True)
+    th = out["theta"].view(B // Bs, Bs, -1)
+    assert torch.equal(th[0].expand_as(th), th)  # position in the batch does not matter
+    h = out["error_history"]
+    assert torch.all(h[:, -1] < 1e-3 * h[:, 0])
+    assert torch.all(out["status"] == 0) and torch.all(out["iterations"] == 10)
