@@ -262,6 +262,23 @@ int32_t mmx_solve(
     double* error_history,
     void* stream);
 
+/*
+ * Parity hook of the fused solve kernel: its normal equations at theta (first iteration), over
+ * the kernel's SOLVE list = enabled parameters whose Jacobian column is not structurally zero
+ * (the others get an exact zero step, like in the reference where H row/col and g vanish).
+ * jtj_dev [B][n*n] (J^T J without lambda), jtr_dev [B][n]; solve_list_host [<= P] receives the
+ * parameter index of each compacted column, *num_solved = n.  Pass null device pointers to query
+ * n / the list only.  theta is not modified.
+ */
+int32_t mmx_debug_fused_normal_equations(
+    mmx_problem* problem,
+    const float* theta_dev,
+    float* jtj_dev,
+    float* jtr_dev,
+    int32_t* solve_list_host,
+    int32_t* num_solved,
+    void* stream);
+
 /* Host-buffer convenience wrappers (the reference's boundary hands over host
  * memory): copy in, run on the handle's stream, copy out, synchronise. */
 int32_t mmx_solve_host(

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmx_hip.so")
-SOURCES = ["mmx_kernels.hip", "mmx_capi.hip", "mmx_host_tables.cpp"]
+SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_host_tables.cpp"]
 HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
 ARCH = "gfx950"
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_eval_jacobian",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_host",
-    "mmx_eval_jacobian_host", "mmx_host_tables",
+    "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
 ]  # fmt: skip
 
 
@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
     L.mmx_solve.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
     L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_eval_jacobian_host.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.mmx_debug_fused_normal_equations.argtypes = [vp, vp, vp, vp, _abi.c_int32_p, _abi.c_int32_p, vp]
     L.mmx_host_tables.argtypes = [
         C.POINTER(RigDesc), _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p,
         _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p,
@@ -253,6 +254,20 @@ class Problem:
         err = torch.empty((self.B,), dtype=torch.float64, device=self.device)
         _check(lib().mmx_eval_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), _dev(err), _stream_ptr()))
         return jtj, jtr, err
+
+    def fused_normal_equations(self, theta):
+        """Parity hook: (solve_list [n], JtJ [B,n,n], Jtr [B,n]) as the fused kernel builds them."""
+        import torch
+
+        theta = self._theta(theta)
+        lst = np.zeros(self.P, np.int32)
+        n = C.c_int32(0)
+        _check(lib().mmx_debug_fused_normal_equations(self._h, None, None, None, as_ptr(lst, C.c_int32), C.byref(n), None))
+        n = n.value
+        jtj = torch.zeros((self.B, n, n), dtype=torch.float32, device=self.device)
+        jtr = torch.zeros((self.B, n), dtype=torch.float32, device=self.device)
+        _check(lib().mmx_debug_fused_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), as_ptr(lst, C.c_int32), C.byref(C.c_int32(0)), _stream_ptr()))
+        return lst[:n].copy(), jtj, jtr
 
     def solve(self, theta, options: GnOptions, want_history: bool = False, outputs=None):
         """In-place batched SolverT::solve.  Returns dict(theta, error, iterations, status[, error_history])."""

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -114,7 +115,10 @@ struct mmx_problem {
   int32_t B = 0, Kp = 0, Ko = 0, U = 0, M = 0;
   std::vector<int32_t> posParent, oriParent;
   mmx::HostTables tables; // for the current enabled set
+  mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList;
+  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs;
+  mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight;
   bool haveConstraints = false;
@@ -160,7 +164,49 @@ int32_t uploadProblemTables(mmx_problem* pb) {
   d.colStart = pb->dColStart.as<int32_t>();
   d.colSources = pb->dColSources.as<mmx::ColumnSourceDev>();
   d.enabledList = pb->dEnabledList.as<int32_t>();
+  // tables of the fused solve kernel
+  {
+    const mmx_rig_desc rd = rig->desc();
+    std::string err;
+    const int32_t rc = mmx::buildFusedTables(
+        &rd, t, pb->Kp, pb->posParent.data(), pb->Ko, pb->oriParent.data(), pb->fused, err);
+    if (rc != MMX_OK) {
+      return fail(rc, err);
+    }
+    const mmx::FusedTables& f = pb->fused;
+    MMX_HIP(upload(pb->dSubSize, f.subSize));
+    MMX_HIP(upload(pb->dPosUnitStart, f.posUnitStart));
+    MMX_HIP(upload(pb->dPosUnits, f.posUnits));
+    MMX_HIP(upload(pb->dSolveList, f.solveList));
+    MMX_HIP(upload(pb->dSrcStart, f.srcStart));
+    MMX_HIP(upload(pb->dSrcs, f.srcs));
+    mmx::FusedDev& fd = pb->fdev;
+    fd.U = pb->U;
+    fd.Kp = pb->Kp;
+    fd.n = int32_t(f.solveList.size());
+    fd.nsrc = int32_t(f.srcs.size());
+    fd.subSize = pb->dSubSize.as<int32_t>();
+    fd.unitJoint = pb->dUnitJoint.as<int32_t>();
+    fd.posUnitStart = pb->dPosUnitStart.as<int32_t>();
+    fd.posUnits = pb->dPosUnits.as<int32_t>();
+    fd.solveList = pb->dSolveList.as<int32_t>();
+    fd.srcStart = pb->dSrcStart.as<int32_t>();
+    fd.srcs = pb->dSrcs.as<mmx::ColumnSourceDev>();
+  }
   return MMX_OK;
+}
+
+bool fusedUsable(const mmx_problem* pb) {
+  const int nb = mmx::fusedBlocksFor(pb->fdev.n);
+  if (nb < 0) {
+    return false;
+  }
+  return mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc) <= 160 * 1024;
+}
+
+bool wantLegacySolver() {
+  const char* e = getenv("MMX_SOLVER");
+  return e != nullptr && std::string(e) == "v1";
 }
 
 int32_t checkProblem(const mmx_problem* pb, bool needConstraints) {
@@ -597,11 +643,35 @@ int32_t mmx_solve(
   }
   const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
   const int n = pb->dev.n;
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (fusedUsable(pb) && !wantLegacySolver()) {
+    // fused path: the whole SolverT::solve loop in one launch, one workgroup per instance
+    MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
+    MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+    MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
+    mmx::SolveStateDev fst{};
+    fst.done = nullptr;
+    fst.iterations = iterations != nullptr ? iterations : pb->sIters.as<int32_t>();
+    fst.status = status != nullptr ? status : pb->sStatus.as<int32_t>();
+    fst.lastError = nullptr;
+    fst.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
+    fst.errorHistory = error_history;
+    if (error_history != nullptr && o->max_iterations > 0) {
+      MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+    }
+    mmx::FusedParams fp{};
+    fp.lambda = o->regularization;
+    fp.threshold = o->threshold;
+    fp.minIterations = o->min_iterations;
+    fp.maxIterations = o->max_iterations;
+    fp.refine = 1;
+    MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, s));
+    return MMX_OK;
+  }
   if (mmx::choleskyStepLdsBytes(n, pb->M) > 160 * 1024) {
     return fail(MMX_ERR_UNSUPPORTED, "enabled-parameter count too large for the in-LDS Cholesky of this build");
   }
-  MMX_HIP(hipSetDevice(pb->rig->device));
-  hipStream_t s = static_cast<hipStream_t>(stream);
   rc = ensureStepScratch(pb);
   if (rc != MMX_OK) {
     return rc;
@@ -650,6 +720,53 @@ int32_t mmx_solve(
         s));
   }
   MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
+  return MMX_OK;
+}
+
+int32_t mmx_debug_fused_normal_equations(
+    mmx_problem* pb,
+    const float* theta_dev,
+    float* jtj_dev,
+    float* jtr_dev,
+    int32_t* solve_list_host,
+    int32_t* num_solved,
+    void* stream) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  const int n = pb->fdev.n;
+  if (num_solved != nullptr) {
+    *num_solved = n;
+  }
+  if (solve_list_host != nullptr) {
+    std::memcpy(solve_list_host, pb->fused.solveList.data(), sizeof(int32_t) * size_t(n));
+  }
+  if (theta_dev == nullptr || jtj_dev == nullptr || jtr_dev == nullptr) {
+    return MMX_OK; // size query only
+  }
+  if (!fusedUsable(pb)) {
+    return fail(MMX_ERR_UNSUPPORTED, "problem shape outside the fused kernel's instantiations");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MMX_HIP(pb->sTheta.ensure(B * P * sizeof(float)));
+  MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
+  MMX_HIP(hipMemcpyAsync(pb->sTheta.p, theta_dev, B * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+  mmx::SolveStateDev fst{};
+  fst.iterations = pb->sIters.as<int32_t>();
+  fst.status = pb->sStatus.as<int32_t>();
+  fst.finalError = pb->sFinalErr.as<double>();
+  mmx::FusedParams fp{};
+  fp.lambda = 0.05f;
+  fp.threshold = 1.f;
+  fp.minIterations = 1;
+  fp.maxIterations = 1;
+  fp.refine = 0;
+  MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, pb->sTheta.as<float>(), fst, fp, jtj_dev, jtr_dev, s));
   return MMX_OK;
 }
 

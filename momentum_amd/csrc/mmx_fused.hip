@@ -1,0 +1,808 @@
+// mmx_fused.hip -- the fused batched Gauss-Newton solve kernel (gfx950 / CDNA4, wave64).
+//
+// One workgroup (4 wavefronts) owns one skeleton instance for the WHOLE solve: all iterations of
+// SolverT::solve (momentum/solver/solver.cpp:50-128) with GaussNewtonSolverT::doIteration
+// (momentum/solver/gauss_newton_solver.cpp:224-280) run inside one launch, theta and every
+// intermediate live in LDS / registers, and the dense Jacobian is never formed:
+//
+//   A  joint parameters = transform * theta + offsets, half-angle sin/cos, exp2       (parameter_transform.cpp:110-124)
+//   B  forward kinematics by tree level                                               (joint_state.cpp:22-65)
+//   C  constraint vectors ("units"): residual rows, sigma, error                      (position/orientation evalFunction)
+//   D  per-joint SUBTREE sums of the units' moments (joints in DFS order => a subtree is a range)
+//   E  per column source (joint, dof): alpha/B of d(unit)/d(dof) and its moment contractions
+//   F  g = J^T r from the first-order sums (adjoint pass)
+//   G  H = J^T J + lambda I from the second-order sums, each 16x16 tile computed straight into
+//      the MFMA accumulator registers of the wave that owns it (O(1) work per entry, independent
+//      of the number of constraint rows)
+//   H  blocked right-looking Cholesky on 16x16 tiles: tiles stay in registers, finished L panels
+//      go to LDS; trailing updates are v_mfma_f32_16x16x4_f32
+//   I  forward / backward substitution with the LDS-resident factor
+//   J  one refinement step of the corrected seminormal equations, rho = J^T (r - J d) - lambda d,
+//      with J d by a tangent pass down the tree and J^T w by the adjoint pass (never forming J);
+//      this makes the fp32 step agree with the reference's double-precision solve to ~1e-7
+//   K  theta -= delta, error history, convergence test
+//
+// The formulas of D-G and J are derived and validated against the explicit Jacobian in
+// tests/tree_algebra_np.py / tests/test_tree_algebra.py.
+#include "mmx_device.hpp"
+#include "mmx_kernels.hpp"
+
+#include <cfloat>
+
+namespace mmx {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kCh = 24; // moment channels per joint
+// channel map: 0 m0 | 1-3 m1 | 4-9 M2 (xx xy xz yy yz zz) | 10-15 M2 of directions | 16-18 F | 19-21 N | 22 D | 23 pad
+constexpr int kSrc = 16; // floats per column source: G0(3) AX(3) TR(1) AL(3) BV(3) BS(1) GJ(1) pad(1)
+constexpr int kTan = 8; // tangent-pass floats per joint: C(3) W(3) S(1) pad
+
+// swizzled address of element (row, col) inside a 16x16 fp32 tile (row-major, 16-byte chunks
+// XOR-ed with the row group so that b128 reads of one chunk column hit distinct banks)
+__device__ __forceinline__ int tileAddr(int row, int col) {
+  return row * 16 + ((((col >> 2) ^ (row >> 2)) & 3) << 2) + (col & 3);
+}
+__device__ __forceinline__ int tileIndex(int I, int Jc) { // I >= Jc
+  return I * (I + 1) / 2 + Jc;
+}
+__device__ __forceinline__ void tileDecode(int t, int& I, int& Jc) {
+  int i = int((sqrtf(8.f * float(t) + 1.f) - 1.f) * 0.5f);
+  while ((i + 1) * (i + 2) / 2 <= t) {
+    ++i;
+  }
+  while (i * (i + 1) / 2 > t) {
+    --i;
+  }
+  I = i;
+  Jc = t - i * (i + 1) / 2;
+}
+
+__device__ __forceinline__ float readLaneF(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// translationAxis column d of joint a = column d of parent.toLinear() (joint_state.cpp:36-42)
+__device__ __forceinline__ F3 transAxisCol(const float* js, int parent, int d) {
+  if (parent < 0) {
+    return F3{d == 0 ? 1.f : 0.f, d == 1 ? 1.f : 0.f, d == 2 ? 1.f : 0.f};
+  }
+  const float* p = js + kJs * parent;
+  const F3 c = qmatCol(Q4{p[3], p[4], p[5], p[6]}, d);
+  return F3{c.x * p[7], c.y * p[7], c.z * p[7]};
+}
+
+struct FusedLds {
+  float* th; // [Ppad] theta (full parameter space)
+  float* jp; // [10 J]
+  float* js; // [20 J]
+  float* up; // [3 U] unit world vector
+  float* ur; // [3 U] scaled residual rows r
+  float* uy; // [3 U] sigma * (r or w): input of the adjoint pass
+  float* us; // [U]   sigma
+  float* own; // [kCh J] per DFS position: sums over the joint's own units
+  float* sub; // [kCh J] per DFS position: sums over the joint's subtree
+  float* srcT; // [kSrc nsrc]
+  float* g; // [NP]
+  float* d0; // [NP]
+  float* rho; // [NP]
+  float* dfull; // [Ppad]
+  float* jd; // [7 J]
+  float* tanOwn; // [kTan J]
+  float* tanPre; // [kTan J]
+  float* L; // [T][256] tiles; diagonal slots hold the INVERSE of the diagonal Cholesky block
+  double* red; // [8]
+  int* flags; // [4]
+};
+
+__device__ __forceinline__ size_t alignUp4(size_t x) {
+  return (x + 3) & ~size_t(3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint machinery: own sums -> subtree sums over channels [c0, c1)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ownSums(const FusedDev& fd, const FusedLds& s, int J, int tid, bool second) {
+  // thread per DFS position: loop over the joint's units, ascending unit index
+  for (int k = tid; k < J; k += 256) {
+    float a[kCh];
+#pragma unroll
+    for (int c = 0; c < kCh; ++c) {
+      a[c] = 0.f;
+    }
+    const int e1 = fd.posUnitStart[k + 1];
+    for (int e = fd.posUnitStart[k]; e < e1; ++e) {
+      const int u = fd.posUnits[e];
+      const float px = s.up[3 * u], py = s.up[3 * u + 1], pz = s.up[3 * u + 2];
+      const float yx = s.uy[3 * u], yy = s.uy[3 * u + 1], yz = s.uy[3 * u + 2];
+      const bool point = u < fd.Kp;
+      // N += p x y (points and directions share the channel: only the sum enters, see jt_times)
+      a[19] += py * yz - pz * yy;
+      a[20] += pz * yx - px * yz;
+      a[21] += px * yy - py * yx;
+      if (point) {
+        a[16] += yx;
+        a[17] += yy;
+        a[18] += yz;
+        a[22] += px * yx + py * yy + pz * yz;
+      }
+      if (second) {
+        const float sg = s.us[u];
+        const float s2 = sg * sg;
+        const int o = point ? 4 : 10;
+        a[o + 0] += s2 * px * px;
+        a[o + 1] += s2 * px * py;
+        a[o + 2] += s2 * px * pz;
+        a[o + 3] += s2 * py * py;
+        a[o + 4] += s2 * py * pz;
+        a[o + 5] += s2 * pz * pz;
+        if (point) {
+          a[0] += s2;
+          a[1] += s2 * px;
+          a[2] += s2 * py;
+          a[3] += s2 * pz;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kCh; ++c) {
+      s.own[kCh * k + c] = a[c];
+    }
+  }
+}
+
+__device__ __forceinline__ void subtreeSums(const FusedDev& fd, const FusedLds& s, int J, int tid, int c0, int c1) {
+  const int nc = c1 - c0;
+  for (int idx = tid; idx < J * nc; idx += 256) {
+    const int k = idx / nc, c = c0 + (idx - k * nc);
+    const int k1 = k + fd.subSize[k];
+    float acc = 0.f;
+    for (int m = k; m < k1; ++m) {
+      acc += s.own[kCh * m + c];
+    }
+    s.sub[kCh * k + c] = acc;
+  }
+}
+
+// J^T y component of one column source from the first-order subtree sums (tests/tree_algebra_np.py jt_times)
+__device__ __forceinline__ float sourceGradient(const ColumnSourceDev& cs, const float* js, const float* sb) {
+  const float* a = js + kJs * cs.joint;
+  const F3 ta{a[0], a[1], a[2]};
+  const F3 Fv{sb[16], sb[17], sb[18]};
+  if (cs.dof < 3) {
+    return dot(transAxisCol(js, cs.parent, cs.dof), Fv);
+  }
+  if (cs.dof < 6) {
+    const float* ax = a + 8 + 3 * (cs.dof - 3);
+    const F3 Nv{sb[19], sb[20], sb[21]};
+    return dot(F3{ax[0], ax[1], ax[2]}, Nv - cross(ta, Fv));
+  }
+  return kLn2 * (sb[22] - dot(ta, Fv));
+}
+
+// ---------------------------------------------------------------------------------------------
+// blocked triangular solves with the factor in LDS (diagonal slots = inverse diagonal blocks)
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
+  // forward: L y = b
+  for (int k = 0; k < NB; ++k) {
+    const float* Dk = L + 256 * tileIndex(k, k);
+    float yk = 0.f;
+    if (tid < 16) {
+      for (int c = 0; c <= tid; ++c) {
+        yk += Dk[tileAddr(tid, c)] * x[16 * k + c];
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      x[16 * k + tid] = yk;
+    }
+    __syncthreads();
+    const int r = 16 * (k + 1) + tid;
+    if (r < 16 * NB) {
+      const float* T = L + 256 * tileIndex(r >> 4, k);
+      float acc = x[r];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        acc -= T[tileAddr(r & 15, c)] * x[16 * k + c];
+      }
+      x[r] = acc;
+    }
+    __syncthreads();
+  }
+  // backward: L^T x = y
+  for (int k = NB - 1; k >= 0; --k) {
+    const float* Dk = L + 256 * tileIndex(k, k);
+    float xk = 0.f;
+    if (tid < 16) {
+      for (int c = tid; c < 16; ++c) {
+        xk += Dk[tileAddr(c, tid)] * x[16 * k + c];
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      x[16 * k + tid] = xk;
+    }
+    __syncthreads();
+    const int r = tid;
+    if (r < 16 * k) {
+      const float* T = L + 256 * tileIndex(k, r >> 4);
+      float acc = x[r];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        acc -= T[tileAddr(c, r & 15)] * x[16 * k + c];
+      }
+      x[r] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256) fusedSolveKernel(
+    RigDev rig,
+    ProblemDev pb,
+    FusedDev fd,
+    float* __restrict__ theta, // [B][P] in/out
+    SolveStateDev st,
+    FusedParams fp,
+    float* __restrict__ dbgH, // [B][n*n] or null: H = J^T J (no lambda) of the FIRST iteration
+    float* __restrict__ dbgG) { // [B][n] or null
+  constexpr int T = NB * (NB + 1) / 2; // lower-triangle tiles
+  constexpr int TPW = (T + 3) / 4; // tiles per wave
+  constexpr int NP = 16 * NB; // padded system size
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
+
+  // ---- LDS carve (every offset a multiple of 4 floats)
+  FusedLds s;
+  {
+    float* p = smem;
+    auto take = [&](size_t count) {
+      float* r = p;
+      p += alignUp4(count);
+      return r;
+    };
+    s.th = take(P);
+    s.jp = take(size_t(kJp) * J);
+    s.js = take(size_t(kJs) * J);
+    s.up = take(3 * size_t(U));
+    s.ur = take(3 * size_t(U));
+    s.uy = take(3 * size_t(U));
+    s.us = take(U);
+    s.own = take(size_t(kCh) * J);
+    s.sub = take(size_t(kCh) * J);
+    s.srcT = take(size_t(kSrc) * nsrc);
+    s.g = take(NP);
+    s.d0 = take(NP);
+    s.rho = take(NP);
+    s.dfull = take(P);
+    s.jd = take(7 * size_t(J));
+    s.tanOwn = take(size_t(kTan) * J);
+    s.tanPre = take(size_t(kTan) * J);
+    s.L = take(size_t(T) * 256);
+    s.red = reinterpret_cast<double*>(take(16));
+    s.flags = reinterpret_cast<int*>(take(4));
+  }
+
+  float* thg = theta + size_t(b) * P;
+  for (int i = tid; i < P; i += 256) {
+    s.th[i] = thg[i];
+  }
+  if (tid == 0) {
+    s.flags[0] = 0; // stop
+    s.flags[1] = 0; // not positive definite (this iteration)
+    s.flags[2] = 0; // status
+  }
+  double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
+  double curError = DBL_MAX;
+  int itersDone = 0;
+  __syncthreads();
+
+  for (int it = 0; it < fp.maxIterations; ++it) {
+    // ================= A: joint parameters
+    jointParamsPhase(rig, s.th, s.jp, tid, 256);
+    __syncthreads();
+    // ================= B: forward kinematics by level
+    for (int l = 0; l < rig.numLevels; ++l) {
+      const int i1 = rig.levelStart[l + 1];
+      for (int i = rig.levelStart[l] + tid; i < i1; i += 256) {
+        fkJoint(rig, rig.levelOrder[i], s.jp, s.js);
+      }
+      __syncthreads();
+    }
+    // ================= C: units
+    {
+      double e = 0.0;
+      for (int u = tid; u < U; u += 256) {
+        const Unit un = evalUnit(pb, s.js, b, u);
+        s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
+        const float rx = un.sigma * un.f.x, ry = un.sigma * un.f.y, rz = un.sigma * un.f.z;
+        s.ur[3 * u] = rx, s.ur[3 * u + 1] = ry, s.ur[3 * u + 2] = rz;
+        s.uy[3 * u] = un.sigma * rx, s.uy[3 * u + 1] = un.sigma * ry, s.uy[3 * u + 2] = un.sigma * rz;
+        s.us[u] = un.sigma;
+        e += double(un.werr);
+      }
+      e = waveReduceSum(e);
+      if (lane == 0) {
+        s.red[wave] = e;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+    }
+    // ================= D: own + subtree sums (all channels)
+    ownSums(fd, s, J, tid, true);
+    __syncthreads();
+    subtreeSums(fd, s, J, tid, 0, 23);
+    __syncthreads();
+    // ================= E: column-source tables
+    for (int e = tid; e < nsrc; e += 256) {
+      const ColumnSourceDev cs = fd.srcs[e];
+      const float* a = s.js + kJs * cs.joint;
+      const float* sb = s.sub + kCh * cs.tin;
+      const F3 ta{a[0], a[1], a[2]};
+      const float m0 = sb[0];
+      const F3 m1{sb[1], sb[2], sb[3]};
+      F3 al, bv{0.f, 0.f, 0.f}, g0, ax;
+      float bs = 0.f, tr;
+      if (cs.dof < 3) {
+        al = transAxisCol(s.js, cs.parent, cs.dof);
+        g0 = m0 * al;
+        ax = cross(m1, al);
+        tr = dot(al, m1);
+      } else if (cs.dof < 6) {
+        const float* w = a + 8 + 3 * (cs.dof - 3);
+        const F3 om{w[0], w[1], w[2]};
+        al = F3{0.f, 0.f, 0.f} - cross(om, ta);
+        bv = om;
+        g0 = m0 * al + cross(om, m1);
+        // axial([om]x M) = tr(M) om - M om, for the point and the direction second moments
+        const float t2 = (sb[4] + sb[7] + sb[9]) + (sb[10] + sb[13] + sb[15]);
+        const F3 Mo{
+            (sb[4] + sb[10]) * om.x + (sb[5] + sb[11]) * om.y + (sb[6] + sb[12]) * om.z,
+            (sb[5] + sb[11]) * om.x + (sb[7] + sb[13]) * om.y + (sb[8] + sb[14]) * om.z,
+            (sb[6] + sb[12]) * om.x + (sb[8] + sb[14]) * om.y + (sb[9] + sb[15]) * om.z};
+        ax = cross(m1, al) + (t2 * om - Mo);
+        tr = dot(al, m1);
+      } else {
+        al = F3{0.f, 0.f, 0.f} - kLn2 * ta;
+        bs = kLn2;
+        g0 = m0 * al + kLn2 * m1;
+        ax = cross(m1, al);
+        tr = dot(al, m1) + kLn2 * (sb[4] + sb[7] + sb[9]);
+      }
+      float* o = s.srcT + kSrc * e;
+      o[0] = g0.x, o[1] = g0.y, o[2] = g0.z;
+      o[3] = ax.x, o[4] = ax.y, o[5] = ax.z;
+      o[6] = tr;
+      o[7] = al.x, o[8] = al.y, o[9] = al.z;
+      o[10] = bv.x, o[11] = bv.y, o[12] = bv.z;
+      o[13] = bs;
+      o[14] = sourceGradient(cs, s.js, sb);
+      o[15] = 0.f;
+    }
+    __syncthreads();
+    // ================= F: g = J^T r (compacted), padded with zeros
+    for (int c = tid; c < NP; c += 256) {
+      float acc = 0.f;
+      if (c < n) {
+        const int e1 = fd.srcStart[c + 1];
+        for (int e = fd.srcStart[c]; e < e1; ++e) {
+          acc += fd.srcs[e].weight * s.srcT[kSrc * e + 14];
+        }
+      }
+      s.g[c] = acc;
+      s.d0[c] = acc;
+    }
+    // ================= G: H tiles into the owning wave's accumulator registers
+    v4f acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int t = 4 * q + wave;
+      acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (t < T) {
+        int I, Jc;
+        tileDecode(t, I, Jc);
+        const int col = 16 * Jc + (lane & 15);
+        const int cs0 = col < n ? fd.srcStart[col] : 0;
+        const int cs1 = col < n ? fd.srcStart[col + 1] : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + 4 * (lane >> 4) + r;
+          float h = 0.f;
+          if (row < n && col < n) {
+            const int rs1 = fd.srcStart[row + 1];
+            for (int er = fd.srcStart[row]; er < rs1; ++er) {
+              const ColumnSourceDev a = fd.srcs[er];
+              for (int ec = cs0; ec < cs1; ++ec) {
+                const ColumnSourceDev c = fd.srcs[ec];
+                int deep, anc;
+                if (c.tin <= a.tin && a.tin < c.tout) { // c's joint is a's joint or an ancestor
+                  deep = er, anc = ec;
+                } else if (a.tin <= c.tin && c.tin < a.tout) {
+                  deep = ec, anc = er;
+                } else {
+                  continue;
+                }
+                const float* dp = s.srcT + kSrc * deep;
+                const float* ap = s.srcT + kSrc * anc;
+                const float hj = dp[0] * ap[7] + dp[1] * ap[8] + dp[2] * ap[9] + dp[3] * ap[10] + dp[4] * ap[11] +
+                    dp[5] * ap[12] + dp[6] * ap[13];
+                h += (a.weight * c.weight) * hj;
+              }
+            }
+          }
+          if (dbgH != nullptr && it == 0 && row < n && col < n) {
+            dbgH[size_t(b) * n * n + size_t(row) * n + col] = h;
+            dbgH[size_t(b) * n * n + size_t(col) * n + row] = h;
+          }
+          if (row == col) {
+            h = row < n ? h + fp.lambda : 1.f; // padding rows: identity
+          }
+          acc[q][r] = h;
+        }
+      }
+    }
+    if (dbgG != nullptr && it == 0) {
+      for (int c = tid; c < n; c += 256) {
+        dbgG[size_t(b) * n + c] = s.g[c];
+      }
+    }
+    if (tid == 0) {
+      s.flags[1] = 0;
+    }
+    __syncthreads();
+
+    // ================= H: blocked Cholesky, tiles in registers, L panels in LDS
+    for (int k = 0; k < NB; ++k) {
+      // (a) owners publish the tiles of block column k
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int t = 4 * q + wave;
+        if (t < T) {
+          int I, Jc;
+          tileDecode(t, I, Jc);
+          if (Jc == k) {
+            float* Tl = s.L + 256 * t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Tl[tileAddr(4 * (lane >> 4) + r, lane & 15)] = acc[q][r];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // (b) wave 0: Cholesky of the 16x16 diagonal block and its inverse, rows/columns per lane,
+      //     cross-lane traffic by v_readlane (no LDS round trips inside the 16 dependent steps)
+      if (wave == 0) {
+        float* Dk = s.L + 256 * tileIndex(k, k);
+        const int i = lane & 15;
+        float a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          a[c] = Dk[tileAddr(i, c)];
+        }
+        float invd = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float djj = readLaneF(a[j], j);
+          bad = bad || !(djj > 0.f);
+          const float ljj = sqrtf(djj);
+          const float inv = 1.f / ljj;
+          a[j] = (i == j) ? ljj : a[j] * inv;
+          if (i == j) {
+            invd = inv;
+          }
+#pragma unroll
+          for (int c = j + 1; c < 16; ++c) {
+            const float lcj = readLaneF(a[j], c);
+            a[c] -= a[j] * lcj;
+          }
+        }
+        // inverse: lane c computes column c of X = L^-1 by forward substitution
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sum = (r == i) ? 1.f : 0.f;
+#pragma unroll
+          for (int m = 0; m < r; ++m) {
+            sum -= readLaneF(a[m], r) * x[m];
+          }
+          x[r] = sum * readLaneF(invd, r);
+        }
+        if (lane < 16) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            Dk[tileAddr(r, i)] = x[r];
+          }
+          if (bad) {
+            s.flags[1] = 1;
+          }
+        }
+      }
+      __syncthreads();
+      // (c) panel: X = A * L_kk^-T, one thread per row of the panel below the diagonal block
+      {
+        const int r = 16 * (k + 1) + tid;
+        if (r < NP) {
+          float* Tl = s.L + 256 * tileIndex(r >> 4, k);
+          const float* Dk = s.L + 256 * tileIndex(k, k);
+          float arow[16], xrow[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            arow[c] = Tl[tileAddr(r & 15, c)];
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c <= j; ++c) {
+              sum += arow[c] * Dk[tileAddr(j, c)];
+            }
+            xrow[j] = sum;
+          }
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            Tl[tileAddr(r & 15, c)] = xrow[c];
+          }
+        }
+      }
+      __syncthreads();
+      // (d) trailing update of the tiles this wave owns: acc(I,J) -= L(I,k) L(J,k)^T  (MFMA)
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int t = 4 * q + wave;
+        if (t < T) {
+          int I, Jc;
+          tileDecode(t, I, Jc);
+          if (Jc > k) {
+            const float* Ta = s.L + 256 * tileIndex(I, k);
+            const float* Tb = s.L + 256 * tileIndex(Jc, k);
+            const int row = lane & 15, chunk = lane >> 4;
+            const int off = row * 16 + (((chunk ^ (row >> 2)) & 3) << 2);
+            const float4 av = *reinterpret_cast<const float4*>(Ta + off);
+            const float4 bv = *reinterpret_cast<const float4*>(Tb + off);
+            v4f c = acc[q];
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
+            acc[q] = c;
+          }
+        }
+      }
+      // no barrier needed here: step k+1 publishes into other LDS tiles, and its (a)->(b) barrier
+      // orders everything else
+    }
+    __syncthreads();
+    const bool notPd = s.flags[1] != 0;
+
+    // ================= I: d0 = (L L^T)^-1 g
+    if (!notPd) {
+      solveLLt<NB>(s.L, s.d0, tid);
+    }
+    // ================= J: one refinement step through the tree (tangent + adjoint passes)
+    if (!notPd && fp.refine) {
+      // full-space delta
+      for (int i = tid; i < P; i += 256) {
+        s.dfull[i] = 0.f;
+      }
+      __syncthreads();
+      for (int c = tid; c < n; c += 256) {
+        s.dfull[fd.solveList[c]] = s.d0[c];
+      }
+      __syncthreads();
+      // joint-parameter delta jd = transform * delta
+      for (int r = tid; r < rig.R; r += 256) {
+        float a = 0.f;
+        const int k1 = rig.ptOuter[r + 1];
+        for (int k = rig.ptOuter[r]; k < k1; ++k) {
+          a += rig.ptValue[k] * s.dfull[rig.ptInner[k]];
+        }
+        s.jd[r] = a;
+      }
+      __syncthreads();
+      // per joint: C = T - Om x t - ln2 sd t ; W = Om ; S = sd
+      for (int a = tid; a < J; a += 256) {
+        const float* ja = s.js + kJs * a;
+        const float* d = s.jd + 7 * a;
+        const F3 ta{ja[0], ja[1], ja[2]};
+        F3 Tv{0.f, 0.f, 0.f};
+        if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+          const int par = rig.parent[a];
+          Tv = d[0] * transAxisCol(s.js, par, 0) + d[1] * transAxisCol(s.js, par, 1) + d[2] * transAxisCol(s.js, par, 2);
+        }
+        const F3 Om = d[3] * F3{ja[8], ja[9], ja[10]} + d[4] * F3{ja[11], ja[12], ja[13]} + d[5] * F3{ja[14], ja[15], ja[16]};
+        const F3 C = Tv - cross(Om, ta) - (kLn2 * d[6]) * ta;
+        float* o = s.tanOwn + kTan * a;
+        o[0] = C.x, o[1] = C.y, o[2] = C.z, o[3] = Om.x, o[4] = Om.y, o[5] = Om.z, o[6] = d[6];
+      }
+      __syncthreads();
+      // prefix over ancestors (walk the parent chain; root-first order of summation is not needed)
+      for (int a = tid; a < J; a += 256) {
+        float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int q = a;
+        while (q >= 0) {
+          const float* o = s.tanOwn + kTan * q;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) {
+            v[c] += o[c];
+          }
+          q = rig.parent[q];
+        }
+        float* o = s.tanPre + kTan * a;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          o[c] = v[c];
+        }
+      }
+      __syncthreads();
+      // units: w = r - J d0 ; y = sigma w
+      for (int u = tid; u < U; u += 256) {
+        const float* pre = s.tanPre + kTan * fd.unitJoint[u];
+        const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+        const F3 W{pre[3], pre[4], pre[5]};
+        F3 v = cross(W, p);
+        if (u < fd.Kp) {
+          v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
+        }
+        const float sg = s.us[u];
+        const float wx = s.ur[3 * u] - sg * v.x, wy = s.ur[3 * u + 1] - sg * v.y, wz = s.ur[3 * u + 2] - sg * v.z;
+        s.uy[3 * u] = sg * wx, s.uy[3 * u + 1] = sg * wy, s.uy[3 * u + 2] = sg * wz;
+      }
+      __syncthreads();
+      ownSums(fd, s, J, tid, false);
+      __syncthreads();
+      subtreeSums(fd, s, J, tid, 16, 23);
+      __syncthreads();
+      for (int c = tid; c < NP; c += 256) {
+        float a = 0.f;
+        if (c < n) {
+          const int e1 = fd.srcStart[c + 1];
+          for (int e = fd.srcStart[c]; e < e1; ++e) {
+            const ColumnSourceDev cs = fd.srcs[e];
+            a += cs.weight * sourceGradient(cs, s.js, s.sub + kCh * cs.tin);
+          }
+          a -= fp.lambda * s.d0[c];
+        }
+        s.rho[c] = a;
+      }
+      __syncthreads();
+      solveLLt<NB>(s.L, s.rho, tid);
+      for (int c = tid; c < n; c += 256) {
+        s.d0[c] += s.rho[c];
+      }
+      __syncthreads();
+    }
+    // ================= K: theta -= delta ; bookkeeping of SolverT::solve (solver.cpp:92-119)
+    if (!notPd) {
+      for (int c = tid; c < n; c += 256) {
+        s.th[fd.solveList[c]] -= s.d0[c]; // skeleton_solver_function.cpp:158
+      }
+    }
+    if (tid == 0) {
+      const double e = curError;
+      if (st.errorHistory != nullptr) {
+        st.errorHistory[size_t(b) * fp.maxIterations + it] = e;
+      }
+      itersDone = it + 1;
+      if (notPd) {
+        s.flags[2] = 2; // MMX_SOLVE_NOT_PD
+      }
+      const bool converged = fabs(lastError - e) / (fabs(e) + double(FLT_MIN)) <= double(fp.threshold) * double(FLT_EPSILON);
+      s.flags[0] = (it >= fp.minIterations && converged) ? 1 : 0;
+      lastError = e;
+    }
+    __syncthreads();
+    if (s.flags[0] != 0) {
+      break;
+    }
+  }
+
+  // NaN/Inf guard of the batched driver (pymomentum/tensor_ik/tensor_ik.cpp:168-173): theta in
+  // global memory still holds the initial parameters, so "revert" = do not write
+  int bad = 0;
+  for (int i = tid; i < P; i += 256) {
+    if (!isfinite(s.th[i])) {
+      bad = 1;
+    }
+  }
+  bad = __syncthreads_or(bad);
+  if (!bad) {
+    for (int i = tid; i < P; i += 256) {
+      thg[i] = s.th[i];
+    }
+  }
+  if (tid == 0) {
+    st.iterations[b] = itersDone;
+    st.finalError[b] = curError;
+    st.status[b] = bad ? 1 : s.flags[2];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc) {
+  const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
+  auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
+  size_t f = a4(P) + a4(size_t(kJp) * J) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kCh) * J) +
+      a4(size_t(kSrc) * nsrc) + 3 * a4(NP) + a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J) + T * 256 + 16 + 4;
+  return f * sizeof(float);
+}
+
+template <int NB>
+static hipError_t launchFusedNB(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    float* theta,
+    const SolveStateDev& st,
+    const FusedParams& fp,
+    float* dbgH,
+    float* dbgG,
+    hipStream_t stream) {
+  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc);
+  if (lds > 160 * 1024) {
+    return hipErrorInvalidValue;
+  }
+  static size_t attrBytes = 64 * 1024; // default dynamic-LDS limit; raised on demand
+  if (lds > attrBytes) {
+    hipError_t rc = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(fusedSolveKernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    attrBytes = lds;
+  }
+  hipLaunchKernelGGL(fusedSolveKernel<NB>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG);
+  return hipGetLastError();
+}
+
+int fusedBlocksFor(int n) {
+  const int nb = (n + 15) / 16;
+  const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14};
+  for (int a : avail) {
+    if (nb <= a) {
+      return a;
+    }
+  }
+  return -1;
+}
+
+hipError_t launchFusedSolve(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    float* theta,
+    const SolveStateDev& st,
+    const FusedParams& fp,
+    float* dbgH,
+    float* dbgG,
+    hipStream_t stream) {
+  switch (fusedBlocksFor(fd.n)) {
+#define MMX_CASE(NB_) \
+  case NB_:           \
+    return launchFusedNB<NB_>(rig, pb, fd, theta, st, fp, dbgH, dbgG, stream);
+    MMX_CASE(1)
+    MMX_CASE(2)
+    MMX_CASE(3)
+    MMX_CASE(4)
+    MMX_CASE(5)
+    MMX_CASE(6)
+    MMX_CASE(7)
+    MMX_CASE(8)
+    MMX_CASE(10)
+    MMX_CASE(12)
+    MMX_CASE(14)
+#undef MMX_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+} // namespace mmx

@@ -176,4 +176,96 @@ int32_t buildHostTables(const mmx_rig_desc* d, const uint8_t* enabled, HostTable
   return MMX_OK;
 }
 
+int32_t buildFusedTables(
+    const mmx_rig_desc* d,
+    const HostTables& t,
+    int32_t Kp,
+    const int32_t* posParent,
+    int32_t Ko,
+    const int32_t* oriParent,
+    FusedTables& f,
+    std::string& err) {
+  const int32_t J = t.J, P = t.P;
+  f.U = Kp + 3 * Ko;
+  f.dfsJoint.assign(J, 0);
+  f.subSize.assign(J, 1);
+  for (int32_t j = 0; j < J; ++j) {
+    f.dfsJoint[t.tin[j]] = j;
+    f.subSize[t.tin[j]] = t.tout[j] - t.tin[j];
+  }
+  f.maxDepth = 0;
+  for (int32_t j = 0; j < J; ++j) {
+    f.maxDepth = std::max(f.maxDepth, t.level[j]);
+  }
+  f.unitJoint.assign(size_t(std::max(f.U, 1)), 0);
+  for (int32_t c = 0; c < Kp; ++c) {
+    f.unitJoint[c] = posParent[c];
+  }
+  for (int32_t c = 0; c < Ko; ++c) {
+    for (int k = 0; k < 3; ++k) {
+      f.unitJoint[Kp + 3 * c + k] = oriParent[c];
+    }
+  }
+  // units per DFS position (ascending unit index within a joint: deterministic summation order)
+  f.posUnitStart.assign(J + 1, 0);
+  for (int32_t u = 0; u < f.U; ++u) {
+    f.posUnitStart[t.tin[f.unitJoint[u]] + 1]++;
+  }
+  for (int32_t k = 0; k < J; ++k) {
+    f.posUnitStart[k + 1] += f.posUnitStart[k];
+  }
+  f.posUnits.assign(size_t(std::max(f.U, 1)), 0);
+  {
+    std::vector<int32_t> cur(f.posUnitStart.begin(), f.posUnitStart.end() - 1);
+    for (int32_t u = 0; u < f.U; ++u) {
+      f.posUnits[cur[t.tin[f.unitJoint[u]]]++] = u;
+    }
+  }
+  // a joint is "loaded" if some unit sits in its subtree
+  std::vector<uint8_t> loaded(J, 0);
+  for (int32_t u = 0; u < f.U; ++u) {
+    int32_t a = f.unitJoint[u];
+    while (a >= 0 && !loaded[a]) {
+      loaded[a] = 1;
+      a = d->parent[a];
+    }
+  }
+  // Orientation constraints only see rotation dofs, position constraints see all: a column is
+  // structurally non-zero iff it has a source (a,dof) with a unit below a that the dof acts on.
+  std::vector<uint8_t> hasPoint(J, 0);
+  for (int32_t c = 0; c < Kp; ++c) {
+    int32_t a = posParent[c];
+    while (a >= 0 && !hasPoint[a]) {
+      hasPoint[a] = 1;
+      a = d->parent[a];
+    }
+  }
+  f.solveList.clear();
+  f.srcStart.assign(1, 0);
+  f.srcs.clear();
+  for (int32_t p = 0; p < P; ++p) {
+    if (!t.enabled[p]) {
+      continue;
+    }
+    bool nz = false;
+    for (int32_t e = t.colStart[p]; e < t.colStart[p + 1]; ++e) {
+      const ColumnSource& s = t.colSources[e];
+      const bool rot = s.dof >= 3 && s.dof < 6;
+      if (rot ? loaded[s.joint] : hasPoint[s.joint]) {
+        nz = true;
+      }
+    }
+    if (!nz) {
+      continue;
+    }
+    f.solveList.push_back(p);
+    for (int32_t e = t.colStart[p]; e < t.colStart[p + 1]; ++e) {
+      f.srcs.push_back(t.colSources[e]);
+    }
+    f.srcStart.push_back(int32_t(f.srcs.size()));
+  }
+  (void)err;
+  return MMX_OK;
+}
+
 } // namespace mmx

@@ -46,6 +46,36 @@ struct HostTables {
   int32_t maxColSources = 0;
 };
 
+// Tables of the fused solve kernel, for one (rig, constraint topology, enabled set):
+//  - joints in DFS pre-order, so that the subtree of a joint is a contiguous index range
+//  - the constraint vectors ("units", 3 Jacobian rows each) attached to each joint
+//  - the SOLVE list: enabled parameters whose Jacobian column is not structurally zero, i.e. that
+//    drive at least one joint with a constrained joint in its subtree.  A structurally zero column
+//    has H row/col = 0 and g = 0, so the reference's step for it is exactly 0 / (0 + lambda) = 0
+//    (gauss_newton_solver.cpp:248-257); dropping it from the dense system changes nothing.
+struct FusedTables {
+  int32_t U = 0; // units = Kp + 3 Ko
+  std::vector<int32_t> dfsJoint; // [J] joint at DFS position k
+  std::vector<int32_t> subSize; // [J] subtree size of the joint at DFS position k
+  std::vector<int32_t> unitJoint; // [U]
+  std::vector<int32_t> posUnitStart; // [J+1] CSR over DFS positions -> units attached to that joint
+  std::vector<int32_t> posUnits; // [U]
+  std::vector<int32_t> solveList; // [n] parameter index of compacted column s (ascending)
+  std::vector<int32_t> srcStart; // [n+1] offsets into srcs per compacted column
+  std::vector<ColumnSource> srcs;
+  int32_t maxDepth = 0;
+};
+
+int32_t buildFusedTables(
+    const mmx_rig_desc* d,
+    const HostTables& t,
+    int32_t Kp,
+    const int32_t* posParent,
+    int32_t Ko,
+    const int32_t* oriParent,
+    FusedTables& out,
+    std::string& err);
+
 // Validates the descriptor the way the reference's constructors / MT_CHECKs do
 // (skeleton.cpp:16-22 parent-before-child; parameter_transform.cpp:112-121 sizes).
 // Returns MMX_OK or an error code with a message in `err`.

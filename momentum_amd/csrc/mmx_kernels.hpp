@@ -29,6 +29,39 @@ struct StepParams {
   int32_t refine; // 1 = one corrected-seminormal refinement step through J
 };
 
+// device view of mmx::FusedTables (mmx_host_tables.hpp)
+struct FusedDev {
+  int32_t U, Kp, n, nsrc; // units, position constraints, solved parameters, column sources
+  const int32_t* subSize; // [J] by DFS position
+  const int32_t* unitJoint; // [U]
+  const int32_t* posUnitStart; // [J+1] by DFS position
+  const int32_t* posUnits; // [U]
+  const int32_t* solveList; // [n]
+  const int32_t* srcStart; // [n+1]
+  const ColumnSourceDev* srcs; // [nsrc]
+};
+
+struct FusedParams {
+  float lambda;
+  float threshold;
+  int32_t minIterations;
+  int32_t maxIterations;
+  int32_t refine;
+};
+
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc);
+int fusedBlocksFor(int n); // number of 16-wide blocks the fused kernel is instantiated for, or -1
+hipError_t launchFusedSolve(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    float* theta,
+    const SolveStateDev& st,
+    const FusedParams& fp,
+    float* dbgH,
+    float* dbgG,
+    hipStream_t stream);
+
 size_t fkJacobianLdsBytes(int J);
 size_t normalEquationsLdsBytes(int n);
 size_t choleskyStepLdsBytes(int n, int M);

@@ -133,6 +133,35 @@ def test_jacobian_with_disabled_parameters(torch_cuda, orc):
         assert np.array_equal(jtj[b], jtj[b].T)
 
 
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("subset", [False, True])
+def test_fused_kernel_normal_equations_match_oracle(torch_cuda, orc, name, subset):
+    """The fused solve kernel never forms J: its J^T J (from per-joint subtree moments) and J^T r
+    (adjoint pass) must equal the oracle's J^T J / J^T r on the kernel's solve list, and every
+    parameter it drops from the dense system must have a structurally zero Jacobian column."""
+    torch = torch_cuda
+    rig, pp, op, B = _case(name)
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=100, perturb=0.4, random_offsets=True, weights="random")
+    cons.pos_function_weight, cons.ori_function_weight = 0.8, 1.25
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    rng = np.random.default_rng(9)
+    en = None
+    if subset:
+        en = (rng.uniform(size=rig.num_params) < 0.7).astype(np.uint8)
+        pb.set_enabled(en)
+    theta = rng.uniform(-0.4, 0.4, size=(B, rig.num_params)).astype(np.float32)
+    lst, jtj, jtr = pb.fused_normal_equations(torch.from_numpy(theta).to(pb.device))
+    jtj, jtr = jtj.cpu().numpy(), jtr.cpu().numpy()
+    for b in range(B):
+        J, r, e = orc.eval_jacobian(rig, cons.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
+        dropped = np.setdiff1d(np.arange(rig.num_params), lst)
+        assert np.all(J[:, dropped] == 0)  # integer bookkeeping: exact
+        H = J[:, lst].T @ J[:, lst]
+        g = J[:, lst].T @ r
+        assert np.abs(jtj[b] - H).max() <= 2e-5 * max(1.0, np.abs(H).max()), (name, b)
+        assert np.abs(jtr[b] - g).max() <= 2e-5 * max(1.0, np.abs(g).max()), (name, b)
+
+
 def _sensitivity(orc, rig, cons, th0, opt, ref, eps=1e-7):
     """Relative change of the oracle's double-precision solution under an eps-sized perturbation of
     theta0 (fp32 epsilon): the conditioning of the whole 10-iteration map, per instance."""
