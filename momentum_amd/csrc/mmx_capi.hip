@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -117,7 +118,7 @@ struct mmx_problem {
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList;
-  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs;
+  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTermStart, dTermPack, dTermW;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight;
@@ -125,7 +126,7 @@ struct mmx_problem {
   mmx::ProblemDev dev{};
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
-  DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist;
+  DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk;
 };
 
 namespace {
@@ -192,6 +193,70 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     fd.solveList = pb->dSolveList.as<int32_t>();
     fd.srcStart = pb->dSrcStart.as<int32_t>();
     fd.srcs = pb->dSrcs.as<mmx::ColumnSourceDev>();
+    // Structural term lists of H in the kernel's register layout (integer bookkeeping): entry
+    // (row, col) of the compacted system receives one term per pair (source a of row, source c
+    // of col) whose joints are in an ancestor relation; the deeper source supplies the moment
+    // contractions, the other one alpha / B (mmx_fused.hip phase G).
+    const int nb = std::max(mmx::fusedBlocksFor(fd.n), 1);
+    const int T = nb * (nb + 1) / 2, TPW = (T + 3) / 4;
+    std::vector<int32_t> termStart(size_t(4) * TPW * 64 + 1, 0);
+    std::vector<uint32_t> termPack;
+    std::vector<float> termW;
+    for (int wave = 0; wave < 4; ++wave) {
+      for (int q = 0; q < TPW; ++q) {
+        const int t = 4 * q + wave;
+        int I = 0, Jc = 0;
+        if (t < T) {
+          while ((I + 1) * (I + 2) / 2 <= t) {
+            ++I;
+          }
+          Jc = t - I * (I + 1) / 2;
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+          const size_t slot = (size_t(wave) * TPW + q) * 64 + lane;
+          termStart[slot] = int32_t(termPack.size());
+          if (t >= T) {
+            continue;
+          }
+          const int col = 16 * Jc + (lane & 15);
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + 4 * (lane >> 4) + r;
+            if (row >= fd.n || col >= fd.n) {
+              continue;
+            }
+            for (int32_t er = f.srcStart[row]; er < f.srcStart[row + 1]; ++er) {
+              for (int32_t ec = f.srcStart[col]; ec < f.srcStart[col + 1]; ++ec) {
+                const mmx::ColumnSource &sa = f.srcs[er], &sc = f.srcs[ec];
+                int32_t deep, anc;
+                if (sc.tin <= sa.tin && sa.tin < sc.tout) {
+                  deep = er, anc = ec;
+                } else if (sa.tin <= sc.tin && sc.tin < sa.tout) {
+                  deep = ec, anc = er;
+                } else {
+                  continue;
+                }
+                termPack.push_back(uint32_t(deep) | (uint32_t(anc) << 14) | (uint32_t(r) << 28));
+                termW.push_back(sa.weight * sc.weight);
+              }
+            }
+          }
+        }
+      }
+    }
+    termStart.back() = int32_t(termPack.size());
+    if (fd.nsrc >= (1 << 14)) {
+      return fail(MMX_ERR_UNSUPPORTED, "more than 16383 column sources");
+    }
+    if (termPack.empty()) {
+      termPack.push_back(0);
+      termW.push_back(0.f);
+    }
+    MMX_HIP(upload(pb->dTermStart, termStart));
+    MMX_HIP(upload(pb->dTermPack, termPack));
+    MMX_HIP(upload(pb->dTermW, termW));
+    fd.termStart = pb->dTermStart.as<int32_t>();
+    fd.termPack = pb->dTermPack.as<uint32_t>();
+    fd.termW = pb->dTermW.as<float>();
   }
   return MMX_OK;
 }
@@ -666,7 +731,28 @@ int32_t mmx_solve(
     fp.minIterations = o->min_iterations;
     fp.maxIterations = o->max_iterations;
     fp.refine = 1;
-    MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, s));
+    long long* clk = nullptr;
+    if (getenv("MMX_PHASE_CLOCKS") != nullptr) { // profiling aid: per-phase cycles of block 0
+      MMX_HIP(pb->sClk.ensure(16 * sizeof(long long)));
+      MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 16 * sizeof(long long), s));
+      clk = pb->sClk.as<long long>();
+    }
+    MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, s));
+    if (clk != nullptr) {
+      long long h[16];
+      MMX_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, s));
+      MMX_HIP(hipStreamSynchronize(s));
+      static const char* names[11] = {"A jointParams", "B fk", "C units", "D sums", "E srcTables", "F g", "G H-assembly",
+                                      "H cholesky", "I solve", "J refine", "K update"};
+      long long tot = 0;
+      for (int i = 0; i < 11; ++i) {
+        tot += h[i];
+      }
+      fprintf(stderr, "[mmx phase clocks, block 0, all iterations] total %lld\n", tot);
+      for (int i = 0; i < 11; ++i) {
+        fprintf(stderr, "  %-16s %10lld  %5.1f%%\n", names[i], h[i], 100.0 * double(h[i]) / double(tot > 0 ? tot : 1));
+      }
+    }
     return MMX_OK;
   }
   if (mmx::choleskyStepLdsBytes(n, pb->M) > 160 * 1024) {
@@ -766,7 +852,7 @@ int32_t mmx_debug_fused_normal_equations(
   fp.minIterations = 1;
   fp.maxIterations = 1;
   fp.refine = 0;
-  MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, pb->sTheta.as<float>(), fst, fp, jtj_dev, jtr_dev, s));
+  MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, pb->sTheta.as<float>(), fst, fp, jtj_dev, jtr_dev, nullptr, s));
   return MMX_OK;
 }
 

@@ -33,8 +33,6 @@ namespace mmx {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kCh = 24; // moment channels per joint
-// channel map: 0 m0 | 1-3 m1 | 4-9 M2 (xx xy xz yy yz zz) | 10-15 M2 of directions | 16-18 F | 19-21 N | 22 D | 23 pad
 constexpr int kSrc = 16; // floats per column source: G0(3) AX(3) TR(1) AL(3) BV(3) BS(1) GJ(1) pad(1)
 constexpr int kTan = 8; // tangent-pass floats per joint: C(3) W(3) S(1) pad
 
@@ -72,43 +70,59 @@ __device__ __forceinline__ F3 transAxisCol(const float* js, int parent, int d) {
   return F3{c.x * p[7], c.y * p[7], c.z * p[7]};
 }
 
+constexpr int kC2 = 16; // second-order channels per joint: m0 | m1(3) | M2 (xx xy xz yy yz zz) | M2 of directions (6)
+constexpr int kC1 = 8; // first-order channels per joint: F(3) | N(3) | D | pad
+constexpr int kLoc = 16; // local transform per joint: t(3) s(1) | q_l(4) | q1(4) | q2(4)
+
 struct FusedLds {
-  float* th; // [Ppad] theta (full parameter space)
-  float* jp; // [10 J]
-  float* js; // [20 J]
+  // ---- loaded once per launch
+  int* mStart; // [NP+1] column -> first source (padded columns are empty)
+  int* mTin; // [nsrc]
+  int* mTout; // [nsrc]
+  float* mW; // [nsrc]
+  // ---- per iteration
+  float* th; // [P] theta (full parameter space)
+  float* js; // [20 J] world t(3) q(4) s(1) | rotation axes (9) | pad
   float* up; // [3 U] unit world vector
   float* ur; // [3 U] scaled residual rows r
   float* uy; // [3 U] sigma * (r or w): input of the adjoint pass
   float* us; // [U]   sigma
-  float* own; // [kCh J] per DFS position: sums over the joint's own units
-  float* sub; // [kCh J] per DFS position: sums over the joint's subtree
-  float* srcT; // [kSrc nsrc]
+  float* own1; // [kC1 J] first-order sums over the joint's own units (by DFS position)
+  float* sub1; // [kC1 J] ... over the joint's subtree
   float* g; // [NP]
   float* d0; // [NP]
   float* rho; // [NP]
-  float* dfull; // [Ppad]
+  float* dfull; // [P]
   float* jd; // [7 J]
   float* tanOwn; // [kTan J]
   float* tanPre; // [kTan J]
-  float* L; // [T][256] tiles; diagonal slots hold the INVERSE of the diagonal Cholesky block
   double* red; // [8]
   int* flags; // [4]
+  // ---- one region, two lives: assembly scratch (phases A-G), then the Cholesky factor (H-J)
+  float* loc; // [kLoc J]
+  float* own2; // [kC2 J]
+  float* sub2; // [kC2 J]
+  float* srcT; // [kSrc nsrc]
+  float* L; // [T][256] tiles; diagonal slots hold the INVERSE of the diagonal Cholesky block
 };
 
-__device__ __forceinline__ size_t alignUp4(size_t x) {
+__host__ __device__ __forceinline__ size_t alignUp4(size_t x) {
   return (x + 3) & ~size_t(3);
 }
 
 // ---------------------------------------------------------------------------------------------
-// adjoint machinery: own sums -> subtree sums over channels [c0, c1)
+// adjoint machinery: sums over a joint's own units, then over its subtree (= a DFS index range)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ownSums(const FusedDev& fd, const FusedLds& s, int J, int tid, bool second) {
-  // thread per DFS position: loop over the joint's units, ascending unit index
   for (int k = tid; k < J; k += 256) {
-    float a[kCh];
+    float a1[kC1], a2[kC2];
 #pragma unroll
-    for (int c = 0; c < kCh; ++c) {
-      a[c] = 0.f;
+    for (int c = 0; c < kC1; ++c) {
+      a1[c] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < kC2; ++c) {
+      a2[c] = 0.f;
     }
     const int e1 = fd.posUnitStart[k + 1];
     for (int e = fd.posUnitStart[k]; e < e1; ++e) {
@@ -117,81 +131,110 @@ __device__ __forceinline__ void ownSums(const FusedDev& fd, const FusedLds& s, i
       const float yx = s.uy[3 * u], yy = s.uy[3 * u + 1], yz = s.uy[3 * u + 2];
       const bool point = u < fd.Kp;
       // N += p x y (points and directions share the channel: only the sum enters, see jt_times)
-      a[19] += py * yz - pz * yy;
-      a[20] += pz * yx - px * yz;
-      a[21] += px * yy - py * yx;
+      a1[3] += py * yz - pz * yy;
+      a1[4] += pz * yx - px * yz;
+      a1[5] += px * yy - py * yx;
       if (point) {
-        a[16] += yx;
-        a[17] += yy;
-        a[18] += yz;
-        a[22] += px * yx + py * yy + pz * yz;
+        a1[0] += yx;
+        a1[1] += yy;
+        a1[2] += yz;
+        a1[6] += px * yx + py * yy + pz * yz;
       }
       if (second) {
         const float sg = s.us[u];
         const float s2 = sg * sg;
         const int o = point ? 4 : 10;
-        a[o + 0] += s2 * px * px;
-        a[o + 1] += s2 * px * py;
-        a[o + 2] += s2 * px * pz;
-        a[o + 3] += s2 * py * py;
-        a[o + 4] += s2 * py * pz;
-        a[o + 5] += s2 * pz * pz;
+        a2[o + 0] += s2 * px * px;
+        a2[o + 1] += s2 * px * py;
+        a2[o + 2] += s2 * px * pz;
+        a2[o + 3] += s2 * py * py;
+        a2[o + 4] += s2 * py * pz;
+        a2[o + 5] += s2 * pz * pz;
         if (point) {
-          a[0] += s2;
-          a[1] += s2 * px;
-          a[2] += s2 * py;
-          a[3] += s2 * pz;
+          a2[0] += s2;
+          a2[1] += s2 * px;
+          a2[2] += s2 * py;
+          a2[3] += s2 * pz;
         }
       }
     }
 #pragma unroll
-    for (int c = 0; c < kCh; ++c) {
-      s.own[kCh * k + c] = a[c];
+    for (int c = 0; c < kC1; ++c) {
+      s.own1[kC1 * k + c] = a1[c];
+    }
+    if (second) {
+#pragma unroll
+      for (int c = 0; c < kC2; ++c) {
+        s.own2[kC2 * k + c] = a2[c];
+      }
     }
   }
 }
 
-__device__ __forceinline__ void subtreeSums(const FusedDev& fd, const FusedLds& s, int J, int tid, int c0, int c1) {
-  const int nc = c1 - c0;
-  for (int idx = tid; idx < J * nc; idx += 256) {
-    const int k = idx / nc, c = c0 + (idx - k * nc);
+// sub[k][c] = sum_{m in [k, k + subSize[k])} own[m][c]; four independent partial sums so that the
+// LDS loads pipeline (the summation order is fixed => deterministic)
+template <int NC>
+__device__ __forceinline__ void subtreeSums(const FusedDev& fd, const float* own, float* sub, int J, int tid) {
+  for (int idx = tid; idx < J * NC; idx += 256) {
+    const int k = idx / NC, c = idx - k * NC;
     const int k1 = k + fd.subSize[k];
-    float acc = 0.f;
-    for (int m = k; m < k1; ++m) {
-      acc += s.own[kCh * m + c];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int m = k;
+    for (; m + 4 <= k1; m += 4) {
+      a0 += own[NC * m + c];
+      a1 += own[NC * (m + 1) + c];
+      a2 += own[NC * (m + 2) + c];
+      a3 += own[NC * (m + 3) + c];
     }
-    s.sub[kCh * k + c] = acc;
+    for (; m < k1; ++m) {
+      a0 += own[NC * m + c];
+    }
+    sub[NC * k + c] = (a0 + a1) + (a2 + a3);
   }
 }
 
-// J^T y component of one column source from the first-order subtree sums (tests/tree_algebra_np.py jt_times)
-__device__ __forceinline__ float sourceGradient(const ColumnSourceDev& cs, const float* js, const float* sb) {
-  const float* a = js + kJs * cs.joint;
+// J^T y component of one (joint, dof) from the first-order subtree sums (tests/tree_algebra_np.py jt_times)
+__device__ __forceinline__ float sourceGradient(int joint, int dof, int parent, const float* js, const float* sb) {
+  const float* a = js + kJs * joint;
   const F3 ta{a[0], a[1], a[2]};
-  const F3 Fv{sb[16], sb[17], sb[18]};
-  if (cs.dof < 3) {
-    return dot(transAxisCol(js, cs.parent, cs.dof), Fv);
+  const F3 Fv{sb[0], sb[1], sb[2]};
+  if (dof < 3) {
+    return dot(transAxisCol(js, parent, dof), Fv);
   }
-  if (cs.dof < 6) {
-    const float* ax = a + 8 + 3 * (cs.dof - 3);
-    const F3 Nv{sb[19], sb[20], sb[21]};
+  if (dof < 6) {
+    const float* ax = a + 8 + 3 * (dof - 3);
+    const F3 Nv{sb[3], sb[4], sb[5]};
     return dot(F3{ax[0], ax[1], ax[2]}, Nv - cross(ta, Fv));
   }
-  return kLn2 * (sb[22] - dot(ta, Fv));
+  return kLn2 * (sb[6] - dot(ta, Fv));
+}
+
+__device__ __forceinline__ float4 ldsRow4(const float* tile, int row, int chunk) { // 4 consecutive columns
+  return *reinterpret_cast<const float4*>(tile + row * 16 + (((chunk ^ (row >> 2)) & 3) << 2));
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
+  acc += a.x * b.x;
+  acc += a.y * b.y;
+  acc += a.z * b.z;
+  acc += a.w * b.w;
+  return acc;
 }
 
 // ---------------------------------------------------------------------------------------------
-// blocked triangular solves with the factor in LDS (diagonal slots = inverse diagonal blocks)
+// blocked triangular solves with the factor in LDS (diagonal slots = inverse diagonal blocks,
+// stored as full 16x16 tiles with an exactly-zero upper triangle, so no loop needs a bound)
 // ---------------------------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
   // forward: L y = b
   for (int k = 0; k < NB; ++k) {
     const float* Dk = L + 256 * tileIndex(k, k);
+    const float4* xb = reinterpret_cast<const float4*>(x + 16 * k);
     float yk = 0.f;
     if (tid < 16) {
-      for (int c = 0; c <= tid; ++c) {
-        yk += Dk[tileAddr(tid, c)] * x[16 * k + c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        yk = dot4(ldsRow4(Dk, tid, q), xb[q], yk);
       }
     }
     __syncthreads();
@@ -201,13 +244,13 @@ __device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
     __syncthreads();
     const int r = 16 * (k + 1) + tid;
     if (r < 16 * NB) {
-      const float* T = L + 256 * tileIndex(r >> 4, k);
-      float acc = x[r];
+      const float* Tl = L + 256 * tileIndex(r >> 4, k);
+      float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        acc -= T[tileAddr(r & 15, c)] * x[16 * k + c];
+      for (int q = 0; q < 4; ++q) {
+        acc = dot4(ldsRow4(Tl, r & 15, q), xb[q], acc);
       }
-      x[r] = acc;
+      x[r] -= acc;
     }
     __syncthreads();
   }
@@ -216,7 +259,8 @@ __device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
     const float* Dk = L + 256 * tileIndex(k, k);
     float xk = 0.f;
     if (tid < 16) {
-      for (int c = tid; c < 16; ++c) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
         xk += Dk[tileAddr(c, tid)] * x[16 * k + c];
       }
     }
@@ -227,20 +271,20 @@ __device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
     __syncthreads();
     const int r = tid;
     if (r < 16 * k) {
-      const float* T = L + 256 * tileIndex(k, r >> 4);
-      float acc = x[r];
+      const float* Tl = L + 256 * tileIndex(k, r >> 4);
+      float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        acc -= T[tileAddr(c, r & 15)] * x[16 * k + c];
+        acc += Tl[tileAddr(c, r & 15)] * x[16 * k + c];
       }
-      x[r] = acc;
+      x[r] -= acc;
     }
     __syncthreads();
   }
 }
 
 template <int NB>
-__global__ void __launch_bounds__(256) fusedSolveKernel(
+__global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
@@ -248,16 +292,24 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
     SolveStateDev st,
     FusedParams fp,
     float* __restrict__ dbgH, // [B][n*n] or null: H = J^T J (no lambda) of the FIRST iteration
-    float* __restrict__ dbgG) { // [B][n] or null
+    float* __restrict__ dbgG, // [B][n] or null
+    long long* __restrict__ dbgClk) { // [16] or null: per-phase cycle counts of block 0 (profiling aid)
   constexpr int T = NB * (NB + 1) / 2; // lower-triangle tiles
   constexpr int TPW = (T + 3) / 4; // tiles per wave
   constexpr int NP = 16 * NB; // padded system size
+  long long clkLast = 0;
+#define MMX_CLK(slot)                                             \
+  if (dbgClk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { \
+    const long long now_ = clock64();                             \
+    dbgClk[slot] += now_ - clkLast;                               \
+    clkLast = now_;                                               \
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
 
-  // ---- LDS carve (every offset a multiple of 4 floats)
+  // ---- LDS carve (every offset a multiple of 4 floats); must match fusedLdsBytes()
   FusedLds s;
   {
     float* p = smem;
@@ -266,16 +318,18 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
       p += alignUp4(count);
       return r;
     };
+    s.mStart = reinterpret_cast<int*>(take(NP + 1));
+    s.mTin = reinterpret_cast<int*>(take(nsrc));
+    s.mTout = reinterpret_cast<int*>(take(nsrc));
+    s.mW = take(nsrc);
     s.th = take(P);
-    s.jp = take(size_t(kJp) * J);
     s.js = take(size_t(kJs) * J);
     s.up = take(3 * size_t(U));
     s.ur = take(3 * size_t(U));
     s.uy = take(3 * size_t(U));
     s.us = take(U);
-    s.own = take(size_t(kCh) * J);
-    s.sub = take(size_t(kCh) * J);
-    s.srcT = take(size_t(kSrc) * nsrc);
+    s.own1 = take(size_t(kC1) * J);
+    s.sub1 = take(size_t(kC1) * J);
     s.g = take(NP);
     s.d0 = take(NP);
     s.rho = take(NP);
@@ -283,14 +337,28 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
     s.jd = take(7 * size_t(J));
     s.tanOwn = take(size_t(kTan) * J);
     s.tanPre = take(size_t(kTan) * J);
-    s.L = take(size_t(T) * 256);
     s.red = reinterpret_cast<double*>(take(16));
     s.flags = reinterpret_cast<int*>(take(4));
+    float* region = p;
+    s.loc = take(size_t(kLoc) * J);
+    s.own2 = take(size_t(kC2) * J);
+    s.sub2 = take(size_t(kC2) * J);
+    s.srcT = take(size_t(kSrc) * nsrc);
+    s.L = region;
   }
 
   float* thg = theta + size_t(b) * P;
   for (int i = tid; i < P; i += 256) {
     s.th[i] = thg[i];
+  }
+  for (int c = tid; c <= NP; c += 256) {
+    s.mStart[c] = fd.srcStart[c < n ? c : n];
+  }
+  for (int e = tid; e < nsrc; e += 256) {
+    const ColumnSourceDev cs = fd.srcs[e];
+    s.mTin[e] = cs.tin;
+    s.mTout[e] = cs.tout;
+    s.mW[e] = cs.weight;
   }
   if (tid == 0) {
     s.flags[0] = 0; // stop
@@ -302,19 +370,89 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
   int itersDone = 0;
   __syncthreads();
 
+  if (dbgClk != nullptr) {
+    clkLast = clock64();
+  }
   for (int it = 0; it < fp.maxIterations; ++it) {
-    // ================= A: joint parameters
-    jointParamsPhase(rig, s.th, s.jp, tid, 256);
+    // ================= A: per joint: joint parameters (transform * theta + offsets,
+    // parameter_transform.cpp:110-124), local transform and the partial rotations q1 = pre*Qz,
+    // q2 = pre*Qz*Qy (joint_state.cpp:44-62)
+    for (int j = tid; j < J; j += 256) {
+      float jpv[7];
+#pragma unroll
+      for (int d = 0; d < 7; ++d) {
+        const int r = 7 * j + d;
+        float acc = 0.f;
+        const int k1 = rig.ptOuter[r + 1];
+        for (int k = rig.ptOuter[r]; k < k1; ++k) {
+          acc += rig.ptValue[k] * s.th[rig.ptInner[k]];
+        }
+        jpv[d] = acc + rig.ptOffsets[r];
+      }
+      float sx, cx, sy, cy, sz, cz;
+      sincosf(0.5f * jpv[3], &sx, &cx);
+      sincosf(0.5f * jpv[4], &sy, &cy);
+      sincosf(0.5f * jpv[5], &sz, &cz);
+      const float* pre = rig.preRot + 4 * j;
+      const float* off = rig.offset + 3 * j;
+      const Q4 q0{pre[0], pre[1], pre[2], pre[3]};
+      const Q4 q1 = qmul(q0, Q4{0.f, 0.f, sz, cz});
+      const Q4 q2 = qmul(q1, Q4{0.f, sy, 0.f, cy});
+      const Q4 ql = qmul(q2, Q4{sx, 0.f, 0.f, cx});
+      float* o = s.loc + kLoc * j;
+      o[0] = off[0] + jpv[0], o[1] = off[1] + jpv[1], o[2] = off[2] + jpv[2];
+      o[3] = exp2f(jpv[6]);
+      o[4] = ql.x, o[5] = ql.y, o[6] = ql.z, o[7] = ql.w;
+      o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w;
+      o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
+    }
     __syncthreads();
-    // ================= B: forward kinematics by level
+    MMX_CLK(0)
+    // ================= B: world = parent * local by tree level (transform.h:124-129), then the
+    // rotation axes (q_p * q_partial) * e_index for all joints at once
     for (int l = 0; l < rig.numLevels; ++l) {
       const int i1 = rig.levelStart[l + 1];
       for (int i = rig.levelStart[l] + tid; i < i1; i += 256) {
-        fkJoint(rig, rig.levelOrder[i], s.jp, s.js);
+        const int j = rig.levelOrder[i];
+        const int par = rig.parent[j];
+        F3 tp{0.f, 0.f, 0.f};
+        Q4 qp{0.f, 0.f, 0.f, 1.f};
+        float sp = 1.f;
+        if (par >= 0) {
+          const float* p = s.js + kJs * par;
+          tp = F3{p[0], p[1], p[2]};
+          qp = Q4{p[3], p[4], p[5], p[6]};
+          sp = p[7];
+        }
+        const float* lo = s.loc + kLoc * j;
+        const F3 t = tp + qrot(qp, sp * F3{lo[0], lo[1], lo[2]});
+        const Q4 q = qmul(qp, Q4{lo[4], lo[5], lo[6], lo[7]});
+        float* o = s.js + kJs * j;
+        o[0] = t.x, o[1] = t.y, o[2] = t.z;
+        o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
+        o[7] = sp * lo[3];
       }
       __syncthreads();
     }
-    // ================= C: units
+    for (int j = tid; j < J; j += 256) {
+      const int par = rig.parent[j];
+      Q4 qp{0.f, 0.f, 0.f, 1.f};
+      if (par >= 0) {
+        const float* p = s.js + kJs * par;
+        qp = Q4{p[3], p[4], p[5], p[6]};
+      }
+      const float* pre = rig.preRot + 4 * j;
+      const float* lo = s.loc + kLoc * j;
+      const F3 az = qrot(qmul(qp, Q4{pre[0], pre[1], pre[2], pre[3]}), F3{0.f, 0.f, 1.f});
+      const F3 ay = qrot(qmul(qp, Q4{lo[8], lo[9], lo[10], lo[11]}), F3{0.f, 1.f, 0.f});
+      const F3 ax = qrot(qmul(qp, Q4{lo[12], lo[13], lo[14], lo[15]}), F3{1.f, 0.f, 0.f});
+      float* o = s.js + kJs * j;
+      o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
+      o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
+      o[14] = az.x, o[15] = az.y, o[16] = az.z;
+    }
+    MMX_CLK(1)
+    // ================= C: units (need only the world transforms, not the axes)
     {
       double e = 0.0;
       for (int u = tid; u < U; u += 256) {
@@ -335,16 +473,19 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
     if (tid == 0) {
       curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
     }
-    // ================= D: own + subtree sums (all channels)
+    MMX_CLK(2)
+    // ================= D: own + subtree sums
     ownSums(fd, s, J, tid, true);
     __syncthreads();
-    subtreeSums(fd, s, J, tid, 0, 23);
+    subtreeSums<kC1>(fd, s.own1, s.sub1, J, tid);
+    subtreeSums<kC2>(fd, s.own2, s.sub2, J, tid);
     __syncthreads();
+    MMX_CLK(3)
     // ================= E: column-source tables
     for (int e = tid; e < nsrc; e += 256) {
       const ColumnSourceDev cs = fd.srcs[e];
       const float* a = s.js + kJs * cs.joint;
-      const float* sb = s.sub + kCh * cs.tin;
+      const float* sb = s.sub2 + kC2 * cs.tin;
       const F3 ta{a[0], a[1], a[2]};
       const float m0 = sb[0];
       const F3 m1{sb[1], sb[2], sb[3]};
@@ -383,22 +524,22 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
       o[7] = al.x, o[8] = al.y, o[9] = al.z;
       o[10] = bv.x, o[11] = bv.y, o[12] = bv.z;
       o[13] = bs;
-      o[14] = sourceGradient(cs, s.js, sb);
+      o[14] = sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
       o[15] = 0.f;
     }
     __syncthreads();
+    MMX_CLK(4)
     // ================= F: g = J^T r (compacted), padded with zeros
     for (int c = tid; c < NP; c += 256) {
       float acc = 0.f;
-      if (c < n) {
-        const int e1 = fd.srcStart[c + 1];
-        for (int e = fd.srcStart[c]; e < e1; ++e) {
-          acc += fd.srcs[e].weight * s.srcT[kSrc * e + 14];
-        }
+      const int e1 = s.mStart[c + 1];
+      for (int e = s.mStart[c]; e < e1; ++e) {
+        acc += s.mW[e] * s.srcT[kSrc * e + 14];
       }
       s.g[c] = acc;
       s.d0[c] = acc;
     }
+    MMX_CLK(5)
     // ================= G: H tiles into the owning wave's accumulator registers
     v4f acc[TPW];
 #pragma unroll
@@ -409,42 +550,43 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
         int I, Jc;
         tileDecode(t, I, Jc);
         const int col = 16 * Jc + (lane & 15);
-        const int cs0 = col < n ? fd.srcStart[col] : 0;
-        const int cs1 = col < n ? fd.srcStart[col + 1] : 0;
+        {
+          // the structural term list of this lane's 4 entries (host-built, mmx_capi.hip)
+          const int slot = (wave * TPW + q) * 64 + lane;
+          const int e1 = fd.termStart[slot + 1];
+          float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+          for (int e = fd.termStart[slot]; e < e1; ++e) {
+            const uint32_t pk = fd.termPack[e];
+            const float w = fd.termW[e];
+            const int deep = pk & 0x3fff, anc = (pk >> 14) & 0x3fff, r = pk >> 28;
+            const float4 d0v = *reinterpret_cast<const float4*>(s.srcT + kSrc * deep);
+            const float4 d1v = *reinterpret_cast<const float4*>(s.srcT + kSrc * deep + 4);
+            const float4 a1v = *reinterpret_cast<const float4*>(s.srcT + kSrc * anc + 4);
+            const float4 a2v = *reinterpret_cast<const float4*>(s.srcT + kSrc * anc + 8);
+            const float4 a3v = *reinterpret_cast<const float4*>(s.srcT + kSrc * anc + 12);
+            // G0.AL + AX.BV + TR*BS   (G0 = d0v.xyz, AX = d0v.w d1v.xy, TR = d1v.z;
+            //                          AL = a1v.w a2v.xy, BV = a2v.zw a3v.x, BS = a3v.y)
+            const float hj = d0v.x * a1v.w + d0v.y * a2v.x + d0v.z * a2v.y + d0v.w * a2v.z + d1v.x * a2v.w +
+                d1v.y * a3v.x + d1v.z * a3v.y;
+            const float v = w * hj;
+            h0 += r == 0 ? v : 0.f;
+            h1 += r == 1 ? v : 0.f;
+            h2 += r == 2 ? v : 0.f;
+            h3 += r == 3 ? v : 0.f;
+          }
+          acc[q] = v4f{h0, h1, h2, h3};
+        }
+        // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * I + 4 * (lane >> 4) + r;
-          float h = 0.f;
-          if (row < n && col < n) {
-            const int rs1 = fd.srcStart[row + 1];
-            for (int er = fd.srcStart[row]; er < rs1; ++er) {
-              const ColumnSourceDev a = fd.srcs[er];
-              for (int ec = cs0; ec < cs1; ++ec) {
-                const ColumnSourceDev c = fd.srcs[ec];
-                int deep, anc;
-                if (c.tin <= a.tin && a.tin < c.tout) { // c's joint is a's joint or an ancestor
-                  deep = er, anc = ec;
-                } else if (a.tin <= c.tin && c.tin < a.tout) {
-                  deep = ec, anc = er;
-                } else {
-                  continue;
-                }
-                const float* dp = s.srcT + kSrc * deep;
-                const float* ap = s.srcT + kSrc * anc;
-                const float hj = dp[0] * ap[7] + dp[1] * ap[8] + dp[2] * ap[9] + dp[3] * ap[10] + dp[4] * ap[11] +
-                    dp[5] * ap[12] + dp[6] * ap[13];
-                h += (a.weight * c.weight) * hj;
-              }
-            }
-          }
           if (dbgH != nullptr && it == 0 && row < n && col < n) {
-            dbgH[size_t(b) * n * n + size_t(row) * n + col] = h;
-            dbgH[size_t(b) * n * n + size_t(col) * n + row] = h;
+            dbgH[size_t(b) * n * n + size_t(row) * n + col] = acc[q][r];
+            dbgH[size_t(b) * n * n + size_t(col) * n + row] = acc[q][r];
           }
           if (row == col) {
-            h = row < n ? h + fp.lambda : 1.f; // padding rows: identity
+            acc[q][r] = row < n ? acc[q][r] + fp.lambda : 1.f;
           }
-          acc[q][r] = h;
         }
       }
     }
@@ -456,7 +598,8 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
     if (tid == 0) {
       s.flags[1] = 0;
     }
-    __syncthreads();
+    __syncthreads(); // srcT / moments are dead from here on: the region becomes the factor
+    MMX_CLK(6)
 
     // ================= H: blocked Cholesky, tiles in registers, L panels in LDS
     for (int k = 0; k < NB; ++k) {
@@ -477,15 +620,17 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
         }
       }
       __syncthreads();
-      // (b) wave 0: Cholesky of the 16x16 diagonal block and its inverse, rows/columns per lane,
-      //     cross-lane traffic by v_readlane (no LDS round trips inside the 16 dependent steps)
+      // (b) wave 0: Cholesky of the 16x16 diagonal block and its inverse, one row / column per
+      //     lane, cross-lane traffic by v_readlane (no LDS round trips inside the dependent steps).
+      //     Only the inverse is kept: the panel solve and the substitutions multiply by it.
       if (wave == 0) {
         float* Dk = s.L + 256 * tileIndex(k, k);
         const int i = lane & 15;
         float a[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          a[c] = Dk[tileAddr(i, c)];
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = ldsRow4(Dk, i, q);
+          a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
         }
         float invd = 0.f;
         bool bad = false;
@@ -493,16 +638,14 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
         for (int j = 0; j < 16; ++j) {
           const float djj = readLaneF(a[j], j);
           bad = bad || !(djj > 0.f);
-          const float ljj = sqrtf(djj);
-          const float inv = 1.f / ljj;
-          a[j] = (i == j) ? ljj : a[j] * inv;
+          const float inv = __builtin_amdgcn_rsqf(djj); // 1/l_jj; l_jj = d_jj * inv
+          a[j] *= inv;
           if (i == j) {
             invd = inv;
           }
 #pragma unroll
           for (int c = j + 1; c < 16; ++c) {
-            const float lcj = readLaneF(a[j], c);
-            a[c] -= a[j] * lcj;
+            a[c] -= a[j] * readLaneF(a[j], c);
           }
         }
         // inverse: lane c computes column c of X = L^-1 by forward substitution
@@ -533,17 +676,20 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
         if (r < NP) {
           float* Tl = s.L + 256 * tileIndex(r >> 4, k);
           const float* Dk = s.L + 256 * tileIndex(k, k);
-          float arow[16], xrow[16];
+          float4 ar[4];
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            arow[c] = Tl[tileAddr(r & 15, c)];
+          for (int q = 0; q < 4; ++q) {
+            ar[q] = ldsRow4(Tl, r & 15, q);
           }
+          float xrow[16];
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c <= j; ++c) {
-              sum += arow[c] * Dk[tileAddr(j, c)];
+            for (int q = 0; q < 4; ++q) {
+              if (4 * q <= j) { // the inverse is lower triangular
+                sum = dot4(ar[q], ldsRow4(Dk, j, q), sum);
+              }
             }
             xrow[j] = sum;
           }
@@ -562,12 +708,8 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
           int I, Jc;
           tileDecode(t, I, Jc);
           if (Jc > k) {
-            const float* Ta = s.L + 256 * tileIndex(I, k);
-            const float* Tb = s.L + 256 * tileIndex(Jc, k);
-            const int row = lane & 15, chunk = lane >> 4;
-            const int off = row * 16 + (((chunk ^ (row >> 2)) & 3) << 2);
-            const float4 av = *reinterpret_cast<const float4*>(Ta + off);
-            const float4 bv = *reinterpret_cast<const float4*>(Tb + off);
+            const float4 av = ldsRow4(s.L + 256 * tileIndex(I, k), lane & 15, lane >> 4);
+            const float4 bv = ldsRow4(s.L + 256 * tileIndex(Jc, k), lane & 15, lane >> 4);
             v4f c = acc[q];
             c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
@@ -582,11 +724,13 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
     }
     __syncthreads();
     const bool notPd = s.flags[1] != 0;
+    MMX_CLK(7)
 
     // ================= I: d0 = (L L^T)^-1 g
     if (!notPd) {
       solveLLt<NB>(s.L, s.d0, tid);
     }
+    MMX_CLK(8)
     // ================= J: one refinement step through the tree (tangent + adjoint passes)
     if (!notPd && fp.refine) {
       // full-space delta
@@ -624,7 +768,7 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
         o[0] = C.x, o[1] = C.y, o[2] = C.z, o[3] = Om.x, o[4] = Om.y, o[5] = Om.z, o[6] = d[6];
       }
       __syncthreads();
-      // prefix over ancestors (walk the parent chain; root-first order of summation is not needed)
+      // prefix over ancestors (walk the parent chain)
       for (int a = tid; a < J; a += 256) {
         float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int q = a;
@@ -659,15 +803,15 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
       __syncthreads();
       ownSums(fd, s, J, tid, false);
       __syncthreads();
-      subtreeSums(fd, s, J, tid, 16, 23);
+      subtreeSums<kC1>(fd, s.own1, s.sub1, J, tid);
       __syncthreads();
       for (int c = tid; c < NP; c += 256) {
         float a = 0.f;
         if (c < n) {
-          const int e1 = fd.srcStart[c + 1];
-          for (int e = fd.srcStart[c]; e < e1; ++e) {
+          const int e1 = s.mStart[c + 1];
+          for (int e = s.mStart[c]; e < e1; ++e) {
             const ColumnSourceDev cs = fd.srcs[e];
-            a += cs.weight * sourceGradient(cs, s.js, s.sub + kCh * cs.tin);
+            a += cs.weight * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
           }
           a -= fp.lambda * s.d0[c];
         }
@@ -680,6 +824,7 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
       }
       __syncthreads();
     }
+    MMX_CLK(9)
     // ================= K: theta -= delta ; bookkeeping of SolverT::solve (solver.cpp:92-119)
     if (!notPd) {
       for (int c = tid; c < n; c += 256) {
@@ -700,6 +845,7 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
       lastError = e;
     }
     __syncthreads();
+    MMX_CLK(10)
     if (s.flags[0] != 0) {
       break;
     }
@@ -730,9 +876,11 @@ __global__ void __launch_bounds__(256) fusedSolveKernel(
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc) {
   const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
-  size_t f = a4(P) + a4(size_t(kJp) * J) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kCh) * J) +
-      a4(size_t(kSrc) * nsrc) + 3 * a4(NP) + a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J) + T * 256 + 16 + 4;
-  return f * sizeof(float);
+  const size_t fixed = a4(NP + 1) + 3 * a4(nsrc) + a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) +
+      2 * a4(size_t(kC1) * J) + 3 * a4(NP) + a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J) + 16 + 4;
+  const size_t scratch = a4(size_t(kLoc) * J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kSrc) * nsrc);
+  const size_t region = scratch > T * 256 ? scratch : T * 256;
+  return (fixed + region) * sizeof(float);
 }
 
 template <int NB>
@@ -745,6 +893,7 @@ static hipError_t launchFusedNB(
     const FusedParams& fp,
     float* dbgH,
     float* dbgG,
+    long long* dbgClk,
     hipStream_t stream) {
   const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc);
   if (lds > 160 * 1024) {
@@ -759,7 +908,7 @@ static hipError_t launchFusedNB(
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL(fusedSolveKernel<NB>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG);
+  hipLaunchKernelGGL(fusedSolveKernel<NB>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
   return hipGetLastError();
 }
 
@@ -783,11 +932,12 @@ hipError_t launchFusedSolve(
     const FusedParams& fp,
     float* dbgH,
     float* dbgG,
+    long long* dbgClk,
     hipStream_t stream) {
   switch (fusedBlocksFor(fd.n)) {
 #define MMX_CASE(NB_) \
   case NB_:           \
-    return launchFusedNB<NB_>(rig, pb, fd, theta, st, fp, dbgH, dbgG, stream);
+    return launchFusedNB<NB_>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
     MMX_CASE(1)
     MMX_CASE(2)
     MMX_CASE(3)

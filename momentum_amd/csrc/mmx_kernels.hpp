@@ -39,6 +39,12 @@ struct FusedDev {
   const int32_t* solveList; // [n]
   const int32_t* srcStart; // [n+1]
   const ColumnSourceDev* srcs; // [nsrc]
+  // Structural term lists of H = J^T J in the fused kernel's register layout (integer bookkeeping
+  // done on the host): slot = (wave * TPW + q) * 64 + lane owns 4 entries (r = 0..3) of tile
+  // 4q + wave; terms [termStart[slot], termStart[slot+1]) are its non-zero (deep, anc) source pairs.
+  const int32_t* termStart; // [4 * TPW * 64 + 1]
+  const uint32_t* termPack; // deep | anc << 14 | r << 28
+  const float* termW; // weight(deep's column source) * weight(anc's column source)
 };
 
 struct FusedParams {
@@ -60,6 +66,7 @@ hipError_t launchFusedSolve(
     const FusedParams& fp,
     float* dbgH,
     float* dbgG,
+    long long* dbgClk,
     hipStream_t stream);
 
 size_t fkJacobianLdsBytes(int J);
