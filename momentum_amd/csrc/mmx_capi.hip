@@ -117,7 +117,7 @@ struct mmx_problem {
   std::vector<int32_t> posParent, oriParent;
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
-  DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList;
+  DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
   DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTermStart, dTermPack, dTermW;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
@@ -165,6 +165,16 @@ int32_t uploadProblemTables(mmx_problem* pb) {
   d.colStart = pb->dColStart.as<int32_t>();
   d.colSources = pb->dColSources.as<mmx::ColumnSourceDev>();
   d.enabledList = pb->dEnabledList.as<int32_t>();
+  static_assert(sizeof(mmx::JacRec) == sizeof(mmx::JacRecDev) && sizeof(mmx::JacRec) == 32, "JacRec layouts must match");
+  MMX_HIP(upload(pb->dJacRecs, t.jacRecs));
+  MMX_HIP(upload(pb->dMultiCols, t.multiCols));
+  MMX_HIP(upload(pb->dZeroCols, t.zeroCols));
+  d.jacRecs = pb->dJacRecs.as<mmx::JacRecDev>();
+  d.multiCols = pb->dMultiCols.as<int32_t>();
+  d.zeroCols = pb->dZeroCols.as<int32_t>();
+  d.numJacRecs = int32_t(t.jacRecs.size());
+  d.numMultiCols = int32_t(t.multiCols.size());
+  d.numZeroCols = int32_t(t.zeroCols.size());
   // tables of the fused solve kernel
   {
     const mmx_rig_desc rd = rig->desc();

@@ -20,6 +20,7 @@ namespace mmx {
 
 constexpr int kJp = 10; // floats per joint in jp[]
 constexpr int kJs = 20; // floats per joint in js[]
+constexpr int kLoc = 16; // local transform per joint: t(3) s(1) | q_l(4) | q1 = pre*Qz (4) | q2 = pre*Qz*Qy (4)
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {
@@ -93,6 +94,12 @@ struct ColumnSourceDev { // mirrors mmx::ColumnSource (mmx_host_tables.hpp), 24 
   float weight;
 };
 
+struct JacRecDev { // mirrors mmx::JacRec, 32 bytes
+  int32_t joint, dof, col, tin, tout, parent;
+  float weight;
+  int32_t valid;
+};
+
 struct RigDev {
   int32_t J, P, R, numLevels;
   const int32_t* parent; // [J]
@@ -113,6 +120,10 @@ struct ProblemDev {
   const int32_t* colStart; // [P+1]
   const ColumnSourceDev* colSources;
   const int32_t* enabledList; // [n]
+  const JacRecDev* jacRecs; // [numJacRecs] single-source columns grouped by joint (multiple of 4)
+  const int32_t* multiCols; // [numMultiCols]
+  const int32_t* zeroCols; // [numZeroCols]
+  int32_t numJacRecs, numMultiCols, numZeroCols;
   const float* posOffset; // [B][Kp][3]
   const float* posTarget; // [B][Kp][3]
   const float* posWeight; // [B][Kp]
@@ -192,6 +203,128 @@ __device__ __forceinline__ void fkJoint(const RigDev& rig, int j, const float* j
   o[0] = t.x, o[1] = t.y, o[2] = t.z;
   o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
   o[7] = sp * a[9];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same forward kinematics split into its parallel and its serial part: every joint's local
+// transform and partial rotations need only theta (all joints at once), the tree levels only
+// compose world = parent * local, and the rotation axes again need only the parent's world
+// rotation (all joints at once).  Arithmetic per joint is identical to fkJoint / the reference.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fkLocalTo(const RigDev& rig, int j, const float* __restrict__ theta, float* o) {
+  float jpv[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) {
+    const int r = 7 * j + d;
+    float acc = 0.f;
+    const int k1 = rig.ptOuter[r + 1];
+    for (int k = rig.ptOuter[r]; k < k1; ++k) {
+      acc += rig.ptValue[k] * theta[rig.ptInner[k]];
+    }
+    jpv[d] = acc + rig.ptOffsets[r];
+  }
+  float sx, cx, sy, cy, sz, cz;
+  sincosf(0.5f * jpv[3], &sx, &cx);
+  sincosf(0.5f * jpv[4], &sy, &cy);
+  sincosf(0.5f * jpv[5], &sz, &cz);
+  const float* pre = rig.preRot + 4 * j;
+  const float* off = rig.offset + 3 * j;
+  const Q4 q0{pre[0], pre[1], pre[2], pre[3]};
+  const Q4 q1 = qmul(q0, Q4{0.f, 0.f, sz, cz});
+  const Q4 q2 = qmul(q1, Q4{0.f, sy, 0.f, cy});
+  const Q4 ql = qmul(q2, Q4{sx, 0.f, 0.f, cx});
+  o[0] = off[0] + jpv[0], o[1] = off[1] + jpv[1], o[2] = off[2] + jpv[2];
+  o[3] = exp2f(jpv[6]);
+  o[4] = ql.x, o[5] = ql.y, o[6] = ql.z, o[7] = ql.w;
+  o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w;
+  o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
+}
+
+__device__ __forceinline__ void fkLocal(const RigDev& rig, int j, const float* __restrict__ theta, float* loc) {
+  fkLocalTo(rig, j, theta, loc + kLoc * j);
+}
+
+__device__ __forceinline__ void fkCompose(const RigDev& rig, int j, const float* loc, float* js) {
+  const int par = rig.parent[j];
+  F3 tp{0.f, 0.f, 0.f};
+  Q4 qp{0.f, 0.f, 0.f, 1.f};
+  float sp = 1.f;
+  if (par >= 0) {
+    const float* p = js + kJs * par;
+    tp = F3{p[0], p[1], p[2]};
+    qp = Q4{p[3], p[4], p[5], p[6]};
+    sp = p[7];
+  }
+  const float* lo = loc + kLoc * j;
+  const F3 t = tp + qrot(qp, sp * F3{lo[0], lo[1], lo[2]});
+  const Q4 q = qmul(qp, Q4{lo[4], lo[5], lo[6], lo[7]});
+  float* o = js + kJs * j;
+  o[0] = t.x, o[1] = t.y, o[2] = t.z;
+  o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
+  o[7] = sp * lo[3];
+}
+
+__device__ __forceinline__ void fkAxes(const RigDev& rig, int j, const float* loc, float* js) {
+  const int par = rig.parent[j];
+  Q4 qp{0.f, 0.f, 0.f, 1.f};
+  if (par >= 0) {
+    const float* p = js + kJs * par;
+    qp = Q4{p[3], p[4], p[5], p[6]};
+  }
+  const float* pre = rig.preRot + 4 * j;
+  const float* lo = loc + kLoc * j;
+  const F3 az = qrot(qmul(qp, Q4{pre[0], pre[1], pre[2], pre[3]}), F3{0.f, 0.f, 1.f});
+  const F3 ay = qrot(qmul(qp, Q4{lo[8], lo[9], lo[10], lo[11]}), F3{0.f, 1.f, 0.f});
+  const F3 ax = qrot(qmul(qp, Q4{lo[12], lo[13], lo[14], lo[15]}), F3{1.f, 0.f, 0.f});
+  float* o = js + kJs * j;
+  o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
+  o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
+  o[14] = az.x, o[15] = az.y, o[16] = az.z;
+}
+
+// In-place variants: one 20-float slot per joint.  [0..7] holds the local (t, s, q_l) until the
+// joint's level is composed, then the world (t, q, s); [8..15] holds q1, q2 until the axes pass
+// replaces them by the rotation axes [8..16].  Each slot is rewritten only by the lane that owns
+// the joint, and parents are final before children read them (level barrier).
+__device__ __forceinline__ void fkLocalInPlace(const RigDev& rig, int j, const float* __restrict__ theta, float* js) {
+  fkLocalTo(rig, j, theta, js + kJs * j);
+}
+
+__device__ __forceinline__ void fkComposeInPlace(const RigDev& rig, int j, float* js) {
+  const int par = rig.parent[j];
+  F3 tp{0.f, 0.f, 0.f};
+  Q4 qp{0.f, 0.f, 0.f, 1.f};
+  float sp = 1.f;
+  if (par >= 0) {
+    const float* p = js + kJs * par;
+    tp = F3{p[0], p[1], p[2]};
+    qp = Q4{p[3], p[4], p[5], p[6]};
+    sp = p[7];
+  }
+  float* o = js + kJs * j;
+  const F3 t = tp + qrot(qp, sp * F3{o[0], o[1], o[2]});
+  const Q4 q = qmul(qp, Q4{o[4], o[5], o[6], o[7]});
+  const float sc = sp * o[3];
+  o[0] = t.x, o[1] = t.y, o[2] = t.z;
+  o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
+  o[7] = sc;
+}
+
+__device__ __forceinline__ void fkAxesInPlace(const RigDev& rig, int j, float* js) {
+  const int par = rig.parent[j];
+  Q4 qp{0.f, 0.f, 0.f, 1.f};
+  if (par >= 0) {
+    const float* p = js + kJs * par;
+    qp = Q4{p[3], p[4], p[5], p[6]};
+  }
+  const float* pre = rig.preRot + 4 * j;
+  float* o = js + kJs * j;
+  const F3 az = qrot(qmul(qp, Q4{pre[0], pre[1], pre[2], pre[3]}), F3{0.f, 0.f, 1.f});
+  const F3 ay = qrot(qmul(qp, Q4{o[8], o[9], o[10], o[11]}), F3{0.f, 1.f, 0.f});
+  const F3 ax = qrot(qmul(qp, Q4{o[12], o[13], o[14], o[15]}), F3{1.f, 0.f, 0.f});
+  o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
+  o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
+  o[14] = az.x, o[15] = az.y, o[16] = az.z;
 }
 
 // One constraint vector ("unit") = 3 Jacobian rows 3u..3u+2.  Position constraint c -> unit c

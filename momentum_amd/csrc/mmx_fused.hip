@@ -72,7 +72,6 @@ __device__ __forceinline__ F3 transAxisCol(const float* js, int parent, int d) {
 
 constexpr int kC2 = 16; // second-order channels per joint: m0 | m1(3) | M2 (xx xy xz yy yz zz) | M2 of directions (6)
 constexpr int kC1 = 8; // first-order channels per joint: F(3) | N(3) | D | pad
-constexpr int kLoc = 16; // local transform per joint: t(3) s(1) | q_l(4) | q1(4) | q2(4)
 
 struct FusedLds {
   // ---- loaded once per launch
@@ -378,33 +377,7 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     // parameter_transform.cpp:110-124), local transform and the partial rotations q1 = pre*Qz,
     // q2 = pre*Qz*Qy (joint_state.cpp:44-62)
     for (int j = tid; j < J; j += 256) {
-      float jpv[7];
-#pragma unroll
-      for (int d = 0; d < 7; ++d) {
-        const int r = 7 * j + d;
-        float acc = 0.f;
-        const int k1 = rig.ptOuter[r + 1];
-        for (int k = rig.ptOuter[r]; k < k1; ++k) {
-          acc += rig.ptValue[k] * s.th[rig.ptInner[k]];
-        }
-        jpv[d] = acc + rig.ptOffsets[r];
-      }
-      float sx, cx, sy, cy, sz, cz;
-      sincosf(0.5f * jpv[3], &sx, &cx);
-      sincosf(0.5f * jpv[4], &sy, &cy);
-      sincosf(0.5f * jpv[5], &sz, &cz);
-      const float* pre = rig.preRot + 4 * j;
-      const float* off = rig.offset + 3 * j;
-      const Q4 q0{pre[0], pre[1], pre[2], pre[3]};
-      const Q4 q1 = qmul(q0, Q4{0.f, 0.f, sz, cz});
-      const Q4 q2 = qmul(q1, Q4{0.f, sy, 0.f, cy});
-      const Q4 ql = qmul(q2, Q4{sx, 0.f, 0.f, cx});
-      float* o = s.loc + kLoc * j;
-      o[0] = off[0] + jpv[0], o[1] = off[1] + jpv[1], o[2] = off[2] + jpv[2];
-      o[3] = exp2f(jpv[6]);
-      o[4] = ql.x, o[5] = ql.y, o[6] = ql.z, o[7] = ql.w;
-      o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w;
-      o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
+      fkLocal(rig, j, s.th, s.loc);
     }
     __syncthreads();
     MMX_CLK(0)
@@ -413,43 +386,12 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     for (int l = 0; l < rig.numLevels; ++l) {
       const int i1 = rig.levelStart[l + 1];
       for (int i = rig.levelStart[l] + tid; i < i1; i += 256) {
-        const int j = rig.levelOrder[i];
-        const int par = rig.parent[j];
-        F3 tp{0.f, 0.f, 0.f};
-        Q4 qp{0.f, 0.f, 0.f, 1.f};
-        float sp = 1.f;
-        if (par >= 0) {
-          const float* p = s.js + kJs * par;
-          tp = F3{p[0], p[1], p[2]};
-          qp = Q4{p[3], p[4], p[5], p[6]};
-          sp = p[7];
-        }
-        const float* lo = s.loc + kLoc * j;
-        const F3 t = tp + qrot(qp, sp * F3{lo[0], lo[1], lo[2]});
-        const Q4 q = qmul(qp, Q4{lo[4], lo[5], lo[6], lo[7]});
-        float* o = s.js + kJs * j;
-        o[0] = t.x, o[1] = t.y, o[2] = t.z;
-        o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
-        o[7] = sp * lo[3];
+        fkCompose(rig, rig.levelOrder[i], s.loc, s.js);
       }
       __syncthreads();
     }
     for (int j = tid; j < J; j += 256) {
-      const int par = rig.parent[j];
-      Q4 qp{0.f, 0.f, 0.f, 1.f};
-      if (par >= 0) {
-        const float* p = s.js + kJs * par;
-        qp = Q4{p[3], p[4], p[5], p[6]};
-      }
-      const float* pre = rig.preRot + 4 * j;
-      const float* lo = s.loc + kLoc * j;
-      const F3 az = qrot(qmul(qp, Q4{pre[0], pre[1], pre[2], pre[3]}), F3{0.f, 0.f, 1.f});
-      const F3 ay = qrot(qmul(qp, Q4{lo[8], lo[9], lo[10], lo[11]}), F3{0.f, 1.f, 0.f});
-      const F3 ax = qrot(qmul(qp, Q4{lo[12], lo[13], lo[14], lo[15]}), F3{1.f, 0.f, 0.f});
-      float* o = s.js + kJs * j;
-      o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
-      o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
-      o[14] = az.x, o[15] = az.y, o[16] = az.z;
+      fkAxes(rig, j, s.loc, s.js);
     }
     MMX_CLK(1)
     // ================= C: units (need only the world transforms, not the axes)

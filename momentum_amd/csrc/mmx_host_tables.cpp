@@ -173,6 +173,32 @@ int32_t buildHostTables(const mmx_rig_desc* d, const uint8_t* enabled, HostTable
   for (int32_t p = 0; p < P; ++p) {
     t.maxColSources = std::max(t.maxColSources, t.colStart[p + 1] - t.colStart[p]);
   }
+  // column program of the J-assembly kernel: single-source ROTATION columns (the bulk of any rig)
+  // go to the record list grouped by joint; every other non-empty column takes the generic path
+  t.jacRecs.clear();
+  t.multiCols.clear();
+  t.zeroCols.clear();
+  for (int32_t p = 0; p < P; ++p) {
+    const int32_t cnt = t.colStart[p + 1] - t.colStart[p];
+    if (cnt == 0) {
+      t.zeroCols.push_back(p);
+      continue;
+    }
+    const ColumnSource& s = t.colSources[t.colStart[p]];
+    if (cnt == 1 && s.dof >= 3 && s.dof < 6) {
+      t.jacRecs.push_back(JacRec{s.joint, s.dof, p, s.tin, s.tout, s.parent, s.weight, 1});
+    } else {
+      t.multiCols.push_back(p);
+    }
+  }
+  std::stable_sort(t.jacRecs.begin(), t.jacRecs.end(), [](const JacRec& a, const JacRec& b) {
+    return a.joint != b.joint ? a.joint < b.joint : a.dof < b.dof;
+  });
+  // pad to a multiple of 4 with copies of the last record (re-writing a column with the same
+  // values is idempotent)
+  while (!t.jacRecs.empty() && t.jacRecs.size() % 4 != 0) {
+    t.jacRecs.push_back(t.jacRecs.back());
+  }
   return MMX_OK;
 }
 

@@ -29,6 +29,16 @@ struct ColumnSource {
   float weight;
 };
 
+// One record of the J-assembly kernel's column program: a Jacobian column with exactly ONE
+// source that is a ROTATION dof -- the overwhelmingly common case -- listed grouped by joint so
+// that the kernel computes the ancestor test and v - t_joint once per joint.
+// 32 bytes = one s_load_dwordx8.
+struct JacRec {
+  int32_t joint, dof, col, tin, tout, parent;
+  float weight;
+  int32_t valid; // unused (padding records are copies of the last real record)
+};
+
 struct HostTables {
   int32_t J = 0, P = 0;
   // --- skeleton topology
@@ -44,6 +54,10 @@ struct HostTables {
   std::vector<int32_t> colStart; // [P+1] offsets into colSources (disabled columns are empty)
   std::vector<ColumnSource> colSources;
   int32_t maxColSources = 0;
+  // column program of the J-assembly kernel
+  std::vector<JacRec> jacRecs; // single-source rotation columns, grouped by joint, padded to a multiple of 4
+  std::vector<int32_t> multiCols; // all other non-empty columns (generic gather path)
+  std::vector<int32_t> zeroCols; // columns without sources (disabled parameters): written as zeros
 };
 
 // Tables of the fused solve kernel, for one (rig, constraint topology, enabled set):

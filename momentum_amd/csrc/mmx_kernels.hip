@@ -18,7 +18,7 @@ namespace mmx {
 
 // =============================================================================================
 // Kernel 1: FK + residual + Jacobian assembly.  grid = B, block = 64 (one wavefront = one
-// instance), dynamic LDS = (kJp + kJs) * J floats.
+// instance), dynamic LDS = kJs * J floats.
 //
 // Replaces SkeletonSolverFunctionT::initializeJacobianComputation + computeJacobianBlock
 // (momentum/character_solver/skeleton_solver_function.cpp:200-261) -> JointErrorFunctionT::
@@ -38,8 +38,9 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
     float* __restrict__ state, // [B][J][8] or null
     const int32_t* __restrict__ done) { // [B] or null: skip finished instances
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* jp = smem;
-  float* js = smem + kJp * rig.J;
+  // one 20-float slot per joint, used in place: [0..7] local t,s,q -> world t,q,s ; [8..15] partial
+  // rotations q1,q2 -> [8..16] rotation axes
+  float* js = smem;
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (done != nullptr && done[b] != 0) {
@@ -47,15 +48,23 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
   }
   const float* th = theta + size_t(b) * rig.P;
 
-  jointParamsPhase(rig, th, jp, lane, 64);
+  // local transforms of all joints at once (ParameterTransformT::apply + the theta-only part of
+  // JointStateT::set), then SkeletonStateT::set's parent-before-child sweep as a sweep over tree
+  // levels that only composes world = parent * local, then the rotation axes of all joints at once
+  for (int j = lane; j < rig.J; j += 64) {
+    fkLocalInPlace(rig, j, th, js);
+  }
   __syncthreads();
-  // SkeletonStateT::set (skeleton_state.cpp:104-118): parents first.  Joints of one tree level are
-  // independent -> lanes = joints of the level; arithmetic per joint is the reference's
-  // parent * local in the reference's order.
   for (int l = 0; l < rig.numLevels; ++l) {
     const int i1 = rig.levelStart[l + 1];
     for (int i = rig.levelStart[l] + lane; i < i1; i += 64) {
-      fkJoint(rig, rig.levelOrder[i], jp, js);
+      fkComposeInPlace(rig, rig.levelOrder[i], js);
+    }
+    __syncthreads();
+  }
+  if (kWriteJac) {
+    for (int j = lane; j < rig.J; j += 64) {
+      fkAxesInPlace(rig, j, js);
     }
     __syncthreads();
   }
@@ -83,14 +92,48 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
     }
     if (kWriteJac) {
       float* jb = jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(u);
-      for (int p = 0; p < rig.P; ++p) {
+      // (1) single-source rotation columns, grouped by joint: four records (one 128-byte run of
+      //     scalar loads) per trip; ancestor test and v - t_joint refreshed when the joint changes.
+      //     jc = derivScale * dfdv * (axis x off) ; jac.col(p) = jc * value
+      //     (joint_error_function-inl.h:265-278, joint_state.cpp:68-71)
+      int curJoint = -1;
+      bool anc = false;
+      F3 off{0.f, 0.f, 0.f};
+      for (int i0 = 0; i0 < pb.numJacRecs; i0 += 4) {
+        JacRecDev rec[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          rec[k] = pb.jacRecs[i0 + k]; // wave-uniform
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const JacRecDev& r = rec[k];
+          const float* a = js + kJs * r.joint;
+          if (r.joint != curJoint) {
+            curJoint = r.joint;
+            anc = (r.tin <= un.tin) && (un.tin < r.tout);
+            off = un.isPoint ? un.v - F3{a[0], a[1], a[2]} : un.v;
+          }
+          const float* ax = a + 8 + 3 * (r.dof - 3);
+          const F3 g = cross(F3{ax[0], ax[1], ax[2]}, off);
+          const float w = anc ? r.weight : 0.f;
+          if (un.valid) {
+            float* o = jb + size_t(r.col) * M;
+            o[0] = (un.sigma * g.x) * w;
+            o[1] = (un.sigma * g.y) * w;
+            o[2] = (un.sigma * g.z) * w;
+          }
+        }
+      }
+      // (2) every other non-empty column (shared parameters, translation / scale dofs): generic gather
+      for (int i = 0; i < pb.numMultiCols; ++i) {
+        const int p = pb.multiCols[i];
         F3 acc{0.f, 0.f, 0.f};
         const int e1 = pb.colStart[p + 1];
         for (int e = pb.colStart[p]; e < e1; ++e) {
           const ColumnSourceDev s = pb.colSources[e]; // wave-uniform
           bool applies;
           const F3 g = sourceDerivative(s, js, un, applies);
-          // jc = derivScale * dfdv * g ; jac.col(p) += jc * value (joint_error_function-inl.h:253-259)
           const float w = applies ? s.weight : 0.f;
           acc.x += (un.sigma * g.x) * w;
           acc.y += (un.sigma * g.y) * w;
@@ -101,6 +144,15 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
           o[0] = acc.x;
           o[1] = acc.y;
           o[2] = acc.z;
+        }
+      }
+      // (3) columns without sources (disabled parameters): zeros, every element of J is written
+      for (int i = 0; i < pb.numZeroCols; ++i) {
+        if (un.valid) {
+          float* o = jb + size_t(pb.zeroCols[i]) * M;
+          o[0] = 0.f;
+          o[1] = 0.f;
+          o[2] = 0.f;
         }
       }
     }
@@ -494,7 +546,7 @@ solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaIn
 // host-callable launchers (declared in mmx_kernels.hpp)
 // ---------------------------------------------------------------------------------------------
 size_t fkJacobianLdsBytes(int J) {
-  return size_t(kJp + kJs) * size_t(J) * sizeof(float);
+  return size_t(kJs) * size_t(J) * sizeof(float);
 }
 
 hipError_t launchFkJacobian(
