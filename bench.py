@@ -114,21 +114,16 @@ def main() -> None:
     ap.add_argument("--jac-launches", type=int, default=20)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from momentum_amd import distributed as D
+
+    rank, world, local_rank = D.env_rank()
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # RCCL behind the "nccl" backend on ROCm
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dist = D.init("nccl")  # RCCL behind the "nccl" backend on ROCm; None when world == 1
 
     from momentum_amd import humanoid72_landmark_joints, make_humanoid72
     from momentum_amd._abi import GnOptions
@@ -156,8 +151,7 @@ def main() -> None:
         norms[0] = outputs["error"].sum()
         norms[1] = outputs["iterations"].sum()
         norms[2] = (outputs["status"] != 0).sum()
-        if dist is not None:
-            dist.all_reduce(norms)
+        D.reduce_norms(dist, norms)
 
     def fence():
         if dist is not None:
@@ -172,10 +166,7 @@ def main() -> None:
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = D.reduce_max(dist, elapsed, dev)
     total_err, total_it, failed = [float(x) for x in norms.tolist()]
 
     # ---- roofline of the J-assembly kernel (mmx_eval_jacobian): HIP events on the launch stream
