@@ -1,0 +1,362 @@
+// momentum_amd.hpp -- header-only C++17 shell over the C ABI (include/mmx.h) that keeps momentum's
+// Character / Skeleton / SkeletonSolverFunction / GaussNewtonSolver surface for the batched IK
+// path, so that code written against momentum's classes switches to the MI355X path by changing
+// the namespace and the solver type.  Host-side glue only; all compute is in libmmx_hip.so.
+//
+// Mirrors (reference file:line):
+//   Joint / Skeleton                 momentum/character/joint.h:18-36, skeleton.h:22-25
+//   ParameterTransform               momentum/character/parameter_transform.h:62-95 (CSR = SparseRowMatrix)
+//   Character                        momentum/character/character.h:32-125 (skeleton + parameterTransform only)
+//   PositionData / OrientationData   momentum/character_solver/position_error_function.h:16-29,
+//                                    orientation_error_function.h:16-36
+//   SolverOptions                    momentum/solver/solver.h:19-34
+//   GaussNewtonSolverOptions         momentum/solver/gauss_newton_solver.h:17-59
+//   SkeletonSolverFunction           momentum/character_solver/skeleton_solver_function.h:21-95
+//   GaussNewtonSolver::solve         momentum/solver/solver.cpp:50-128 (one per batch element, as
+//                                    pymomentum/tensor_ik/tensor_ik.cpp:127-177 does)
+// Errors: every non-zero status becomes std::runtime_error with the library's message, the
+// OSS behaviour of MT_CHECK / MT_THROW (momentum/common/checks.h:36-45, exception.h:24-66).
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../mmx.h"
+
+namespace momentum_amd {
+
+inline constexpr size_t kInvalidIndex = std::numeric_limits<size_t>::max(); // character/types.h:182
+inline constexpr size_t kParametersPerJoint = 7; // character/types.h:21
+
+using Vector3f = std::array<float, 3>;
+using Quaternionf = std::array<float, 4>; // (x, y, z, w), Eigen storage order
+using ParameterSet = std::vector<bool>; // momentum: std::bitset<kMaxModelParams>
+
+inline void check(int32_t rc) {
+  if (rc != MMX_OK) {
+    throw std::runtime_error(std::string("momentum_amd: ") + mmx_last_error());
+  }
+}
+
+struct Joint {
+  std::string name;
+  size_t parent = kInvalidIndex;
+  Quaternionf preRotation{0.f, 0.f, 0.f, 1.f};
+  Vector3f translationOffset{0.f, 0.f, 0.f};
+};
+
+struct Skeleton {
+  std::vector<Joint> joints;
+};
+
+// Row-major sparse 7J x P transform + offsets.  `addEntry` keeps rows sorted by column.
+struct ParameterTransform {
+  std::vector<std::string> name; // model parameter names; size = numAllModelParameters()
+  std::vector<int32_t> outer{0}, inner;
+  std::vector<float> value;
+  std::vector<float> offsets;
+
+  size_t numAllModelParameters() const {
+    return name.size();
+  }
+  // build from (row, col, value) triplets like Eigen's setFromTriplets
+  struct Triplet {
+    int32_t row, col;
+    float value;
+  };
+  void setFromTriplets(size_t numJoints, const std::vector<Triplet>& triplets) {
+    const size_t rows = kParametersPerJoint * numJoints;
+    std::vector<std::vector<std::pair<int32_t, float>>> r(rows);
+    for (const auto& t : triplets) {
+      if (t.row < 0 || size_t(t.row) >= rows || t.col < 0 || size_t(t.col) >= name.size()) {
+        throw std::runtime_error("ParameterTransform triplet out of range");
+      }
+      bool merged = false;
+      for (auto& e : r[t.row]) {
+        if (e.first == t.col) {
+          e.second += t.value;
+          merged = true;
+        }
+      }
+      if (!merged) {
+        r[t.row].push_back({t.col, t.value});
+      }
+    }
+    outer.assign(1, 0);
+    inner.clear();
+    value.clear();
+    for (auto& row : r) {
+      for (size_t i = 1; i < row.size(); ++i) { // insertion sort by column
+        for (size_t j = i; j > 0 && row[j].first < row[j - 1].first; --j) {
+          std::swap(row[j], row[j - 1]);
+        }
+      }
+      for (const auto& e : row) {
+        inner.push_back(e.first);
+        value.push_back(e.second);
+      }
+      outer.push_back(int32_t(inner.size()));
+    }
+    offsets.assign(rows, 0.f);
+  }
+};
+
+struct Character {
+  Skeleton skeleton;
+  ParameterTransform parameterTransform;
+};
+
+struct PositionData {
+  Vector3f offset{0.f, 0.f, 0.f};
+  Vector3f target{0.f, 0.f, 0.f};
+  size_t parent = 0;
+  float weight = 1.f;
+};
+
+struct OrientationData {
+  Quaternionf offset{0.f, 0.f, 0.f, 1.f};
+  Quaternionf target{0.f, 0.f, 0.f, 1.f};
+  size_t parent = 0;
+  float weight = 1.f;
+};
+
+struct SolverOptions {
+  size_t minIterations = 1;
+  size_t maxIterations = 2;
+  float threshold = 1.0f;
+  bool verbose = false;
+  virtual ~SolverOptions() = default;
+};
+
+struct GaussNewtonSolverOptions : SolverOptions {
+  float regularization = 0.05f;
+  bool doLineSearch = false;
+  bool useBlockJtJ = false; // accepted for source compatibility: both settings build the same system
+  GaussNewtonSolverOptions() = default;
+  explicit GaussNewtonSolverOptions(const SolverOptions& base) : SolverOptions(base) {}
+};
+
+// Device-resident Skeleton + ParameterTransform.
+class DeviceCharacter {
+ public:
+  explicit DeviceCharacter(const Character& c, int device = 0) : numJoints_(c.skeleton.joints.size()) {
+    const size_t J = numJoints_;
+    std::vector<int32_t> parent(J);
+    std::vector<float> pre(4 * J), off(3 * J);
+    for (size_t j = 0; j < J; ++j) {
+      const Joint& jt = c.skeleton.joints[j];
+      parent[j] = jt.parent == kInvalidIndex ? MMX_INVALID_PARENT : int32_t(jt.parent);
+      for (int k = 0; k < 4; ++k) {
+        pre[4 * j + k] = jt.preRotation[k];
+      }
+      for (int k = 0; k < 3; ++k) {
+        off[3 * j + k] = jt.translationOffset[k];
+      }
+    }
+    const ParameterTransform& pt = c.parameterTransform;
+    if (pt.outer.size() != kParametersPerJoint * J + 1) {
+      throw std::runtime_error("momentum_amd: parameter transform has the wrong number of rows");
+    }
+    mmx_rig_desc d{};
+    d.num_joints = int32_t(J);
+    d.num_params = int32_t(pt.numAllModelParameters());
+    d.parent = parent.data();
+    d.pre_rotation = pre.data();
+    d.translation_offset = off.data();
+    d.pt_outer = pt.outer.data();
+    d.pt_inner = pt.inner.data();
+    d.pt_value = pt.value.data();
+    d.pt_offsets = pt.offsets.empty() ? nullptr : pt.offsets.data();
+    numParams_ = pt.numAllModelParameters();
+    mmx_rig* h = nullptr;
+    check(mmx_rig_create(&d, device, &h));
+    handle_.reset(h, [](mmx_rig* p) { mmx_rig_destroy(p); });
+  }
+  mmx_rig* handle() const {
+    return handle_.get();
+  }
+  size_t numParameters() const {
+    return numParams_;
+  }
+  size_t numJoints() const {
+    return numJoints_;
+  }
+
+ private:
+  std::shared_ptr<mmx_rig> handle_;
+  size_t numJoints_ = 0, numParams_ = 0;
+};
+
+// One SkeletonSolverFunction + PositionErrorFunction + OrientationErrorFunction per batch element.
+// The constraint parents are shared by the batch; offsets / targets / weights are per element.
+class BatchedSkeletonSolverFunction {
+ public:
+  BatchedSkeletonSolverFunction(
+      const DeviceCharacter& character,
+      size_t batch,
+      const std::vector<size_t>& positionParents,
+      const std::vector<size_t>& orientationParents)
+      : character_(character), batch_(batch), kp_(positionParents.size()), ko_(orientationParents.size()) {
+    std::vector<int32_t> pp(positionParents.begin(), positionParents.end());
+    std::vector<int32_t> op(orientationParents.begin(), orientationParents.end());
+    mmx_problem* h = nullptr;
+    check(mmx_problem_create(
+        character.handle(), int32_t(batch), int32_t(kp_), pp.data(), int32_t(ko_), op.data(), &h));
+    handle_.reset(h, [](mmx_problem* p) { mmx_problem_destroy(p); });
+    posOffset_.assign(batch * kp_ * 3, 0.f);
+    posTarget_.assign(batch * kp_ * 3, 0.f);
+    posWeight_.assign(batch * kp_, 1.f);
+    oriOffset_.assign(batch * ko_ * 4, 0.f);
+    oriTarget_.assign(batch * ko_ * 4, 0.f);
+    for (size_t i = 0; i < batch * ko_; ++i) {
+      oriOffset_[4 * i + 3] = 1.f;
+      oriTarget_[4 * i + 3] = 1.f;
+    }
+    oriWeight_.assign(batch * ko_, 1.f);
+  }
+  BatchedSkeletonSolverFunction(const BatchedSkeletonSolverFunction&) = delete; // like the reference (:29-32)
+  BatchedSkeletonSolverFunction& operator=(const BatchedSkeletonSolverFunction&) = delete;
+
+  size_t getNumParameters() const {
+    return character_.numParameters();
+  }
+  size_t batchSize() const {
+    return batch_;
+  }
+  // PositionErrorFunction::setConstraints of batch element b (parents must match the shared list)
+  void setPositionConstraints(size_t b, const std::vector<PositionData>& c) {
+    if (b >= batch_ || c.size() != kp_) {
+      throw std::runtime_error("momentum_amd: position constraint count / batch index mismatch");
+    }
+    for (size_t i = 0; i < kp_; ++i) {
+      for (int k = 0; k < 3; ++k) {
+        posOffset_[(b * kp_ + i) * 3 + k] = c[i].offset[k];
+        posTarget_[(b * kp_ + i) * 3 + k] = c[i].target[k];
+      }
+      posWeight_[b * kp_ + i] = c[i].weight;
+    }
+    dirty_ = true;
+  }
+  void setOrientationConstraints(size_t b, const std::vector<OrientationData>& c) {
+    if (b >= batch_ || c.size() != ko_) {
+      throw std::runtime_error("momentum_amd: orientation constraint count / batch index mismatch");
+    }
+    for (size_t i = 0; i < ko_; ++i) {
+      for (int k = 0; k < 4; ++k) {
+        oriOffset_[(b * ko_ + i) * 4 + k] = c[i].offset[k];
+        oriTarget_[(b * ko_ + i) * 4 + k] = c[i].target[k];
+      }
+      oriWeight_[b * ko_ + i] = c[i].weight;
+    }
+    dirty_ = true;
+  }
+  void setWeights(float positionWeight, float orientationWeight) { // SkeletonErrorFunction::setWeight
+    wPos_ = positionWeight;
+    wOri_ = orientationWeight;
+    dirty_ = true;
+  }
+  void setEnabledParameters(const ParameterSet& ps) {
+    std::vector<uint8_t> e(character_.numParameters(), 0);
+    for (size_t i = 0; i < e.size() && i < ps.size(); ++i) {
+      e[i] = ps[i] ? 1 : 0;
+    }
+    check(mmx_problem_set_enabled(handle_.get(), e.data()));
+  }
+  // uploads the constraint payload if it changed
+  void sync() {
+    if (!dirty_) {
+      return;
+    }
+    mmx_constraint_data d{};
+    d.pos_offset = posOffset_.data();
+    d.pos_target = posTarget_.data();
+    d.pos_weight = posWeight_.data();
+    d.ori_offset = oriOffset_.data();
+    d.ori_target = oriTarget_.data();
+    d.ori_weight = oriWeight_.data();
+    d.pos_function_weight = wPos_;
+    d.ori_function_weight = wOri_;
+    d.memory = MMX_MEM_HOST;
+    check(mmx_problem_set_constraints(handle_.get(), &d, nullptr));
+    dirty_ = false;
+  }
+  // SolverFunctionT::getJacobian for every element: column-major M x P per element, residual M
+  void getJacobian(const std::vector<float>& parameters, std::vector<float>& jacobian, std::vector<float>& residual, std::vector<double>& error) {
+    sync();
+    const size_t M = size_t(mmx_problem_num_rows(handle_.get())), P = getNumParameters();
+    if (parameters.size() != batch_ * P) {
+      throw std::runtime_error("momentum_amd: parameters.size() != batch * numParameters"); // solver.cpp:77
+    }
+    jacobian.resize(batch_ * M * P);
+    residual.resize(batch_ * M);
+    error.resize(batch_);
+    check(mmx_eval_jacobian_host(handle_.get(), parameters.data(), jacobian.data(), residual.data(), error.data(), MMX_LAYOUT_COL_MAJOR));
+  }
+  mmx_problem* handle() const {
+    return handle_.get();
+  }
+
+ private:
+  const DeviceCharacter& character_; // non-owning, like the reference (:87-88)
+  size_t batch_, kp_, ko_;
+  std::shared_ptr<mmx_problem> handle_;
+  std::vector<float> posOffset_, posTarget_, posWeight_, oriOffset_, oriTarget_, oriWeight_;
+  float wPos_ = 1.f, wOri_ = 1.f;
+  bool dirty_ = true;
+};
+
+// GaussNewtonSolverT<float> for every element of the batch at once.
+class BatchedGaussNewtonSolver {
+ public:
+  BatchedGaussNewtonSolver(const SolverOptions& options, BatchedSkeletonSolverFunction* function) : fn_(function) {
+    setOptions(options);
+  }
+  std::string getName() const {
+    return "GaussNewton";
+  }
+  void setOptions(const SolverOptions& options) { // gauss_newton_solver.cpp:37-46
+    mmx_gn_options_default(&opt_);
+    opt_.min_iterations = int32_t(options.minIterations);
+    opt_.max_iterations = int32_t(options.maxIterations);
+    opt_.threshold = options.threshold;
+    if (const auto* d = dynamic_cast<const GaussNewtonSolverOptions*>(&options)) {
+      opt_.regularization = d->regularization;
+      opt_.do_line_search = d->doLineSearch ? 1 : 0;
+    }
+  }
+  void setEnabledParameters(const ParameterSet& ps) {
+    fn_->setEnabledParameters(ps);
+  }
+  // parameters [batch * P] in/out; returns the value SolverT::solve returns, per element
+  std::vector<double> solve(std::vector<float>& parameters) {
+    fn_->sync();
+    const size_t B = fn_->batchSize(), P = fn_->getNumParameters();
+    if (parameters.size() != B * P) {
+      throw std::runtime_error("momentum_amd: parameters.size() != batch * numParameters"); // solver.cpp:77
+    }
+    std::vector<double> err(B);
+    iterations_.assign(B, 0);
+    status_.assign(B, 0);
+    check(mmx_solve_host(fn_->handle(), &opt_, parameters.data(), err.data(), iterations_.data(), status_.data()));
+    return err;
+  }
+  const std::vector<int32_t>& getIterations() const {
+    return iterations_;
+  }
+  const std::vector<int32_t>& getStatus() const {
+    return status_;
+  }
+
+ private:
+  BatchedSkeletonSolverFunction* fn_; // raw pointer like SolverT::solverFunction_ (solver.h:106)
+  mmx_gn_options opt_{};
+  std::vector<int32_t> iterations_, status_;
+};
+
+} // namespace momentum_amd

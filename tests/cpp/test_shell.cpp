@@ -1,0 +1,97 @@
+// GPU smoke test of the C++ shell (include/momentum_amd/momentum_amd.hpp): builds momentum's test
+// fixture createTestCharacter(24) (momentum/test/character/character_helpers.cpp:38-55,106-149),
+// solves a batch of 3-position-constraint IK problems (BASELINE configs[0] shape) on the GPU and
+// checks that the error collapses and that bad input throws std::runtime_error like MT_CHECK.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "momentum_amd/momentum_amd.hpp"
+
+using namespace momentum_amd;
+
+static Character createTestCharacter(size_t n) {
+  Character c;
+  Joint j;
+  j.name = "root";
+  c.skeleton.joints.push_back(j);
+  for (size_t i = 1; i < n; ++i) {
+    j.name = "joint" + std::to_string(i);
+    j.parent = i - 1;
+    j.translationOffset = {0.f, 1.f, 0.f};
+    c.skeleton.joints.push_back(j);
+  }
+  auto& pt = c.parameterTransform;
+  pt.name = {"root_tx", "root_ty", "root_tz", "root_rx", "root_ry", "root_rz", "scale_global", "joint1_rx", "shared_rz"};
+  const int rxStart = int(pt.name.size());
+  for (size_t i = 2; i < n; ++i) {
+    pt.name.push_back("joint" + std::to_string(i) + "_rx");
+  }
+  std::vector<ParameterTransform::Triplet> t;
+  for (int d = 0; d < 7; ++d) {
+    t.push_back({d, d, 1.f});
+  }
+  t.push_back({1 * 7 + 3, 7, 1.f});
+  t.push_back({1 * 7 + 5, 8, 0.5f});
+  t.push_back({2 * 7 + 5, 8, 0.5f});
+  for (size_t i = 2; i < n; ++i) {
+    t.push_back({int(i * 7 + 3), rxStart + int(i) - 2, 1.f});
+  }
+  pt.setFromTriplets(n, t);
+  return c;
+}
+
+int main() {
+  const size_t n = 24, B = 8;
+  const Character character = createTestCharacter(n);
+  if (character.parameterTransform.numAllModelParameters() != 31) {
+    std::printf("FAIL: expected 31 parameters\n");
+    return 1;
+  }
+  DeviceCharacter dev(character, 0);
+  BatchedSkeletonSolverFunction fn(dev, B, {23, 12, 5}, {});
+  std::mt19937 rng(12345);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  for (size_t b = 0; b < B; ++b) {
+    std::vector<PositionData> cons(3);
+    const size_t parents[3] = {23, 12, 5};
+    for (int i = 0; i < 3; ++i) {
+      cons[i].parent = parents[i];
+      cons[i].offset = {0.f, 0.f, 0.f};
+      cons[i].target = {0.5f * U(rng), float(parents[i]) * 0.9f + 0.3f * U(rng), 0.5f * U(rng)}; // near the rest pose
+      cons[i].weight = 1.f;
+    }
+    fn.setPositionConstraints(b, cons);
+  }
+  GaussNewtonSolverOptions opt;
+  opt.minIterations = 10;
+  opt.maxIterations = 10;
+  opt.regularization = 0.05f;
+  BatchedGaussNewtonSolver solver(opt, &fn);
+  const size_t P = fn.getNumParameters();
+  std::vector<float> theta(B * P, 0.f);
+  std::vector<float> jac, res;
+  std::vector<double> e0;
+  fn.getJacobian(theta, jac, res, e0);
+  const std::vector<double> e = solver.solve(theta);
+  int bad = 0;
+  for (size_t b = 0; b < B; ++b) {
+    std::printf("instance %zu: error %.6g -> %.3g, iterations %d, status %d\n", b, e0[b], e[b], solver.getIterations()[b], solver.getStatus()[b]);
+    if (!(e[b] < 1e-3 * e0[b]) || solver.getIterations()[b] != 10 || solver.getStatus()[b] != 0) {
+      ++bad;
+    }
+  }
+  // size mismatch must throw like MT_CHECK(params.size() == numParameters_) (solver.cpp:77)
+  bool threw = false;
+  try {
+    std::vector<float> wrong(P);
+    solver.solve(wrong);
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  if (!threw) {
+    ++bad;
+  }
+  std::printf(bad == 0 ? "OK\n" : "FAIL\n");
+  return bad == 0 ? 0 : 1;
+}
