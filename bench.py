@@ -36,6 +36,7 @@ UNIT = 0.01  # rig offsets "U[2,30] cm" expressed in metres
 CONFIGS = {
     # name: (rig variant, constraint joints, default batch per GPU, step rule, description)
     "cfg2": ("p128", "landmarks", 4096, 0, "BASELINE configs[1]: B x 72-joint humanoid (P=128), position+orientation on 16 landmark joints (M=192), GN lambda=0.05, 10 iterations"),
+    "cfg3": ("p128", "landmarks", 65536, 1, "BASELINE configs[2]: 65536 x 72-joint humanoid (P=128, M=192), LM gain-ratio damping schedule (lambda0=0.05), 10 iterations"),
     "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
 }
 

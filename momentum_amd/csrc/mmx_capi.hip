@@ -710,11 +710,8 @@ int32_t mmx_solve(
   if (o->max_iterations < 0 || o->min_iterations < 0) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "iteration counts must be >= 0");
   }
-  if (o->do_line_search != 0) {
-    return fail(MMX_ERR_UNSUPPORTED, "doLineSearch is not implemented on the GPU path yet");
-  }
-  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA) {
-    return fail(MMX_ERR_UNSUPPORTED, "only MMX_STEP_GN_FIXED_LAMBDA is implemented yet");
+  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown step_rule");
   }
   const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
   const int n = pb->dev.n;
@@ -741,6 +738,12 @@ int32_t mmx_solve(
     fp.minIterations = o->min_iterations;
     fp.maxIterations = o->max_iterations;
     fp.refine = 1;
+    fp.doLineSearch = o->do_line_search;
+    fp.stepRule = o->step_rule;
+    fp.lmLambdaMin = o->lm_lambda_min;
+    fp.lmLambdaMax = o->lm_lambda_max;
+    fp.lmUp = o->lm_up;
+    fp.lmDown = o->lm_down;
     long long* clk = nullptr;
     if (getenv("MMX_PHASE_CLOCKS") != nullptr) { // profiling aid: per-phase cycles of block 0
       MMX_HIP(pb->sClk.ensure(16 * sizeof(long long)));
@@ -764,6 +767,9 @@ int32_t mmx_solve(
       }
     }
     return MMX_OK;
+  }
+  if (o->do_line_search != 0 || o->step_rule != MMX_STEP_GN_FIXED_LAMBDA) {
+    return fail(MMX_ERR_UNSUPPORTED, "line search / LM schedule need the fused solver (<= 224 solved parameters)");
   }
   if (mmx::choleskyStepLdsBytes(n, pb->M) > 160 * 1024) {
     return fail(MMX_ERR_UNSUPPORTED, "enabled-parameter count too large for the in-LDS Cholesky of this build");

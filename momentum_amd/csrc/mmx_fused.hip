@@ -208,6 +208,54 @@ __device__ __forceinline__ float sourceGradient(int joint, int dof, int parent, 
   return kLn2 * (sb[6] - dot(ta, Fv));
 }
 
+// SkeletonSolverFunctionT::getError (skeleton_solver_function.cpp:64-83) of the parameters in
+// `th`: FK without derivatives + sum of w * |f|^2, rounded through float like the reference (:82).
+// Every thread returns the same value.  Clobbers loc / js / red.
+__device__ __forceinline__ double blockError(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    const FusedLds& s,
+    const float* th,
+    int b,
+    int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < rig.J; j += 256) {
+    fkLocal(rig, j, th, s.loc);
+  }
+  __syncthreads();
+  for (int l = 0; l < rig.numLevels; ++l) {
+    const int i1 = rig.levelStart[l + 1];
+    for (int i = rig.levelStart[l] + tid; i < i1; i += 256) {
+      fkCompose(rig, rig.levelOrder[i], s.loc, s.js);
+    }
+    __syncthreads();
+  }
+  double e = 0.0;
+  for (int u = tid; u < fd.U; u += 256) {
+    e += double(evalUnit(pb, s.js, b, u).werr);
+  }
+  e = waveReduceSum(e);
+  if (lane == 0) {
+    s.red[wave] = e;
+  }
+  __syncthreads();
+  const double tot = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+  __syncthreads();
+  return double(float(tot));
+}
+
+__device__ __forceinline__ float blockSumF(const FusedLds& s, float v, int tid) {
+  v = waveReduceSumF(v);
+  if ((tid & 63) == 0) {
+    s.red[4 + (tid >> 6)] = double(v);
+  }
+  __syncthreads();
+  const float tot = float((s.red[4] + s.red[5]) + (s.red[6] + s.red[7]));
+  __syncthreads();
+  return tot;
+}
+
 __device__ __forceinline__ float4 ldsRow4(const float* tile, int row, int chunk) { // 4 consecutive columns
   return *reinterpret_cast<const float4*>(tile + row * 16 + (((chunk ^ (row >> 2)) & 3) << 2));
 }
@@ -365,6 +413,7 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     s.flags[2] = 0; // status
   }
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
+  float lambda = fp.lambda; // constant for GaussNewtonSolverT, adapted by the LM schedule
   double curError = DBL_MAX;
   int itersDone = 0;
   __syncthreads();
@@ -412,9 +461,7 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
-    }
+    curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); // every thread: the same value
     MMX_CLK(2)
     // ================= D: own + subtree sums
     ownSums(fd, s, J, tid, true);
@@ -527,7 +574,7 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
             dbgH[size_t(b) * n * n + size_t(col) * n + row] = acc[q][r];
           }
           if (row == col) {
-            acc[q][r] = row < n ? acc[q][r] + fp.lambda : 1.f;
+            acc[q][r] = row < n ? acc[q][r] + lambda : 1.f;
           }
         }
       }
@@ -755,7 +802,7 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
             const ColumnSourceDev cs = fd.srcs[e];
             a += cs.weight * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
           }
-          a -= fp.lambda * s.d0[c];
+          a -= lambda * s.d0[c];
         }
         s.rho[c] = a;
       }
@@ -768,7 +815,61 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     }
     MMX_CLK(9)
     // ================= K: theta -= delta ; bookkeeping of SolverT::solve (solver.cpp:92-119)
-    if (!notPd) {
+    if (!notPd && fp.stepRule == 1) {
+      // ---- LM gain-ratio schedule, the lambda form of TrustRegionQRT's radius rule
+      // (momentum/character_solver/trust_region_qr.cpp:244-268); identical to the oracle's
+      // restatement (oracle/mmx_oracle.hpp solveGaussNewton, stepRule 1)
+      float part = 0.f;
+      for (int c = tid; c < n; c += 256) {
+        part += s.d0[c] * s.g[c] + lambda * s.d0[c] * s.d0[c];
+      }
+      const float predicted = blockSumF(s, part, tid); // decrease of |r - J d|^2 = d.g + lambda d.d
+      for (int i = tid; i < P; i += 256) {
+        s.dfull[i] = s.th[i];
+      }
+      __syncthreads();
+      for (int c = tid; c < n; c += 256) {
+        s.dfull[fd.solveList[c]] -= s.d0[c];
+      }
+      __syncthreads();
+      const double eNew = blockError(rig, pb, fd, s, s.dfull, b, tid);
+      const float rho = predicted > 0.f ? float((curError - eNew) / double(predicted)) : -1.f;
+      if (rho > 0.f) {
+        for (int i = tid; i < P; i += 256) {
+          s.th[i] = s.dfull[i];
+        }
+      }
+      if (!(rho >= 0.25f)) {
+        lambda = fminf(lambda * fp.lmUp, fp.lmLambdaMax);
+      } else if (rho > 0.75f) {
+        lambda = fmaxf(lambda * fp.lmDown, fp.lmLambdaMin);
+      }
+    } else if (notPd && fp.stepRule == 1) {
+      lambda = fminf(lambda * fp.lmUp, fp.lmLambdaMax);
+    } else if (!notPd && fp.doLineSearch) {
+      // ---- GaussNewtonSolverT::updateParameters with doLineSearch (gauss_newton_solver.cpp:283-313):
+      // Armijo backtracking, c1 = 1e-3, tau = 0.5, at most 10 trial steps; the last trial stays
+      const float scaledError = 1e-3f * float(curError);
+      float scale = 1.f;
+      for (int ls = 0; ls < 10; ++ls) {
+        for (int i = tid; i < P; i += 256) {
+          s.dfull[i] = s.th[i];
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += 256) {
+          s.dfull[fd.solveList[c]] -= scale * s.d0[c];
+        }
+        __syncthreads();
+        const double eNew = blockError(rig, pb, fd, s, s.dfull, b, tid);
+        if ((curError - eNew) >= double(scale * scaledError)) {
+          break;
+        }
+        scale *= 0.5f;
+      }
+      for (int i = tid; i < P; i += 256) {
+        s.th[i] = s.dfull[i];
+      }
+    } else if (!notPd) {
       for (int c = tid; c < n; c += 256) {
         s.th[fd.solveList[c]] -= s.d0[c]; // skeleton_solver_function.cpp:158
       }

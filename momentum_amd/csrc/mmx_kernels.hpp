@@ -53,6 +53,9 @@ struct FusedParams {
   int32_t minIterations;
   int32_t maxIterations;
   int32_t refine;
+  int32_t doLineSearch; // GaussNewtonSolverT::updateParameters backtracking (gauss_newton_solver.cpp:283-313)
+  int32_t stepRule; // MMX_STEP_*
+  float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
 };
 
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc);

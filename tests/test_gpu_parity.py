@@ -204,6 +204,33 @@ def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
 
 
+@pytest.mark.parametrize("mode", ["line_search", "lm_schedule"])
+def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode):
+    """GaussNewtonSolverT with doLineSearch (gauss_newton_solver.cpp:283-313) and the LM gain-ratio
+    schedule of BASELINE configs[2] (the lambda form of trust_region_qr.cpp:244-268; no direct
+    reference implementation, so parity is against the build's own oracle restatement)."""
+    from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
+
+    torch = torch_cuda
+    rig, pp, op, B = _case("humanoid72_cfg2")
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=4242, perturb=0.3)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    if mode == "line_search":
+        opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, do_line_search=True)
+    else:
+        opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel.max() <= 1e-5, rel
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+    if mode == "line_search":
+        assert np.all(np.diff(h, axis=1) <= 1e-6 * np.abs(h[:, :-1]) + 1e-12)  # monotone
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+
+
 def test_solve_convergence_bookkeeping_and_determinism(torch_cuda, orc):
     torch = torch_cuda
     rig, pp, op, B = _case("chain8_mixed")
