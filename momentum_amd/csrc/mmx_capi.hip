@@ -118,7 +118,7 @@ struct mmx_problem {
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
-  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTermStart, dTermPack, dTermW;
+  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight;
@@ -196,6 +196,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     fd.Kp = pb->Kp;
     fd.n = int32_t(f.solveList.size());
     fd.nsrc = int32_t(f.srcs.size());
+    fd.nnz = rig->ptOuter.back();
     fd.subSize = pb->dSubSize.as<int32_t>();
     fd.unitJoint = pb->dUnitJoint.as<int32_t>();
     fd.posUnitStart = pb->dPosUnitStart.as<int32_t>();
@@ -203,70 +204,96 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     fd.solveList = pb->dSolveList.as<int32_t>();
     fd.srcStart = pb->dSrcStart.as<int32_t>();
     fd.srcs = pb->dSrcs.as<mmx::ColumnSourceDev>();
-    // Structural term lists of H in the kernel's register layout (integer bookkeeping): entry
-    // (row, col) of the compacted system receives one term per pair (source a of row, source c
-    // of col) whose joints are in an ancestor relation; the deeper source supplies the moment
-    // contractions, the other one alpha / B (mmx_fused.hip phase G).
-    const int nb = std::max(mmx::fusedBlocksFor(fd.n), 1);
-    const int T = nb * (nb + 1) / 2, TPW = (T + 3) / 4;
-    std::vector<int32_t> termStart(size_t(4) * TPW * 64 + 1, 0);
-    std::vector<uint32_t> termPack;
-    std::vector<float> termW;
-    for (int wave = 0; wave < 4; ++wave) {
-      for (int q = 0; q < TPW; ++q) {
-        const int t = 4 * q + wave;
-        int I = 0, Jc = 0;
-        if (t < T) {
-          while ((I + 1) * (I + 2) / 2 <= t) {
-            ++I;
+    // Structural term records of H (integer bookkeeping): entry (row, col), row >= col, of the
+    // compacted system receives one term per pair (source a of row, source c of col) whose joints
+    // are in an ancestor relation; the deeper source supplies the moment contractions, the other
+    // one alpha / B (mmx_fused.hip phase G).  Entries are dealt to the 256 threads of a workgroup
+    // in contiguous runs of roughly equal term count; a thread's records are stored interleaved
+    // (record k of thread t at [k * 256 + t]) so that a wave reads them coalesced.
+    {
+      const int nb = std::max(mmx::fusedBlocksFor(fd.n), 1);
+      struct Term {
+        uint32_t deep, anc;
+        float w;
+      };
+      struct Entry {
+        int32_t dest;
+        std::vector<Term> terms;
+      };
+      std::vector<Entry> entries;
+      size_t totalTerms = 0;
+      for (int32_t row = 0; row < fd.n; ++row) {
+        for (int32_t col = 0; col <= row; ++col) {
+          Entry en;
+          for (int32_t er = f.srcStart[row]; er < f.srcStart[row + 1]; ++er) {
+            for (int32_t ec = f.srcStart[col]; ec < f.srcStart[col + 1]; ++ec) {
+              const mmx::ColumnSource &sa = f.srcs[er], &sc = f.srcs[ec];
+              int32_t deep, anc;
+              if (sc.tin <= sa.tin && sa.tin < sc.tout) {
+                deep = er, anc = ec;
+              } else if (sa.tin <= sc.tin && sc.tin < sa.tout) {
+                deep = ec, anc = er;
+              } else {
+                continue;
+              }
+              en.terms.push_back(Term{uint32_t(deep), uint32_t(anc), sa.weight * sc.weight});
+            }
           }
-          Jc = t - I * (I + 1) / 2;
-        }
-        for (int lane = 0; lane < 64; ++lane) {
-          const size_t slot = (size_t(wave) * TPW + q) * 64 + lane;
-          termStart[slot] = int32_t(termPack.size());
-          if (t >= T) {
+          if (en.terms.empty()) {
             continue;
           }
-          const int col = 16 * Jc + (lane & 15);
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * I + 4 * (lane >> 4) + r;
-            if (row >= fd.n || col >= fd.n) {
-              continue;
-            }
-            for (int32_t er = f.srcStart[row]; er < f.srcStart[row + 1]; ++er) {
-              for (int32_t ec = f.srcStart[col]; ec < f.srcStart[col + 1]; ++ec) {
-                const mmx::ColumnSource &sa = f.srcs[er], &sc = f.srcs[ec];
-                int32_t deep, anc;
-                if (sc.tin <= sa.tin && sa.tin < sc.tout) {
-                  deep = er, anc = ec;
-                } else if (sa.tin <= sc.tin && sc.tin < sa.tout) {
-                  deep = ec, anc = er;
-                } else {
-                  continue;
-                }
-                termPack.push_back(uint32_t(deep) | (uint32_t(anc) << 14) | (uint32_t(r) << 28));
-                termW.push_back(sa.weight * sc.weight);
-              }
-            }
+          const int I = row >> 4, Jc = col >> 4, r = row & 15, c = col & 15;
+          const int t = I * (I + 1) / 2 + Jc;
+          en.dest = t * 256 + r * 16 + ((((c >> 2) ^ (r >> 2)) & 3) << 2) + (c & 3); // tileAddr()
+          totalTerms += en.terms.size();
+          entries.push_back(std::move(en));
+        }
+      }
+      (void)nb;
+      if (fd.nsrc >= (1 << 12)) {
+        return fail(MMX_ERR_UNSUPPORTED, "more than 4095 column sources");
+      }
+      // greedy contiguous partition: close a thread's run once it reaches the running target
+      std::vector<std::vector<uint32_t>> recs(256); // 4 words per record
+      size_t done = 0;
+      int thread = 0;
+      for (const Entry& en : entries) {
+        const size_t target = (totalTerms * size_t(thread + 1) + 255) / 256;
+        if (thread < 255 && done >= target) {
+          ++thread;
+        }
+        for (size_t i = 0; i < en.terms.size(); ++i) {
+          const Term& tm = en.terms[i];
+          uint32_t x = tm.deep | (tm.anc << 12) | (1u << 26);
+          if (i == 0) {
+            x |= 1u << 24;
+          }
+          if (i + 1 == en.terms.size()) {
+            x |= 1u << 25;
+          }
+          uint32_t wbits;
+          std::memcpy(&wbits, &tm.w, 4);
+          recs[thread].insert(recs[thread].end(), {x, uint32_t(en.dest), wbits, 0u});
+        }
+        done += en.terms.size();
+      }
+      size_t rounds = 0;
+      for (const auto& r : recs) {
+        rounds = std::max(rounds, r.size() / 4);
+      }
+      rounds = (rounds + 7) & ~size_t(7); // the kernel consumes 8 records per trip
+      std::vector<uint32_t> inter(std::max<size_t>(rounds, 8) * 256 * 4, 0u);
+      for (int t = 0; t < 256; ++t) {
+        for (size_t k = 0; k < recs[t].size() / 4; ++k) {
+          for (int w = 0; w < 4; ++w) {
+            inter[(k * 256 + size_t(t)) * 4 + w] = recs[t][4 * k + w];
           }
         }
       }
+      MMX_HIP(upload(pb->dTerms, inter));
+      fd.gTerms = pb->dTerms.as<uint4>();
+      fd.termRounds = int32_t(rounds);
     }
-    termStart.back() = int32_t(termPack.size());
-    if (fd.nsrc >= (1 << 14)) {
-      return fail(MMX_ERR_UNSUPPORTED, "more than 16383 column sources");
-    }
-    if (termPack.empty()) {
-      termPack.push_back(0);
-      termW.push_back(0.f);
-    }
-    MMX_HIP(upload(pb->dTermStart, termStart));
-    MMX_HIP(upload(pb->dTermPack, termPack));
-    MMX_HIP(upload(pb->dTermW, termW));
-    fd.termStart = pb->dTermStart.as<int32_t>();
-    fd.termPack = pb->dTermPack.as<uint32_t>();
-    fd.termW = pb->dTermW.as<float>();
   }
   return MMX_OK;
 }
@@ -276,7 +303,8 @@ bool fusedUsable(const mmx_problem* pb) {
   if (nb < 0) {
     return false;
   }
-  return mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc) <= 160 * 1024;
+  return pb->rig->J < 4096 &&
+      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rig->dev.numLevels) <= 160 * 1024;
 }
 
 bool wantLegacySolver() {
@@ -755,14 +783,15 @@ int32_t mmx_solve(
       long long h[16];
       MMX_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, s));
       MMX_HIP(hipStreamSynchronize(s));
-      static const char* names[11] = {"A jointParams", "B fk", "C units", "D sums", "E srcTables", "F g", "G H-assembly",
-                                      "H cholesky", "I solve", "J refine", "K update"};
+      static const char* names[15] = {"A jointParams", "B fk", "C units", "D sums", "E srcTables", "F g", "G H-assembly",
+                                      "H cholesky(tail)", "I solve", "J refine", "K update", "H.a publish", "H.b potrf+inv",
+                                      "H.c panel", "H.d mfma"};
       long long tot = 0;
-      for (int i = 0; i < 11; ++i) {
+      for (int i = 0; i < 15; ++i) {
         tot += h[i];
       }
       fprintf(stderr, "[mmx phase clocks, block 0, all iterations] total %lld\n", tot);
-      for (int i = 0; i < 11; ++i) {
+      for (int i = 0; i < 15; ++i) {
         fprintf(stderr, "  %-16s %10lld  %5.1f%%\n", names[i], h[i], 100.0 * double(h[i]) / double(tot > 0 ? tot : 1));
       }
     }

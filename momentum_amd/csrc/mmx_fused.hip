@@ -74,10 +74,10 @@ constexpr int kC2 = 16; // second-order channels per joint: m0 | m1(3) | M2 (xx 
 constexpr int kC1 = 8; // first-order channels per joint: F(3) | N(3) | D | pad
 
 struct FusedLds {
-  // ---- loaded once per launch
+  // ---- loaded once per launch (batch-shared integer tables and the parameter-transform CSR)
   int* mStart; // [NP+1] column -> first source (padded columns are empty)
-  int* mTin; // [nsrc]
-  int* mTout; // [nsrc]
+  int* mTin; // [nsrc] DFS position of the source's joint
+  int* mInfo; // [nsrc] joint | dof << 12 | (parent + 1) << 16
   float* mW; // [nsrc]
   // ---- per iteration
   float* th; // [P] theta (full parameter space)
@@ -91,6 +91,7 @@ struct FusedLds {
   float* g; // [NP]
   float* d0; // [NP]
   float* rho; // [NP]
+  float* invDiag; // [NP] 1 / L(i,i)
   float* dfull; // [P]
   float* jd; // [7 J]
   float* tanOwn; // [kTan J]
@@ -101,8 +102,9 @@ struct FusedLds {
   float* loc; // [kLoc J]
   float* own2; // [kC2 J]
   float* sub2; // [kC2 J]
-  float* srcT; // [kSrc nsrc]
   float* L; // [T][256] tiles; diagonal slots hold the INVERSE of the diagonal Cholesky block
+  // ---- aliases the refinement scratch (dfull, jd, tanOwn, tanPre): dead before phase J starts
+  float* srcT; // [kSrc nsrc]
 };
 
 __host__ __device__ __forceinline__ size_t alignUp4(size_t x) {
@@ -268,30 +270,41 @@ __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// blocked triangular solves with the factor in LDS (diagonal slots = inverse diagonal blocks,
-// stored as full 16x16 tiles with an exactly-zero upper triangle, so no loop needs a bound)
+// blocked triangular solves with the factor in LDS.  Diagonal tiles hold L_kk (lower triangle,
+// exact zeros above), invDiag[i] = 1 / L(i,i).  The 16x16 diagonal solves run in wave 0 with one
+// row (forward) / one column (backward) of L_kk per lane and v_readlane broadcasts; the
+// off-diagonal updates use one thread per row.
 // ---------------------------------------------------------------------------------------------
 template <int NB>
-__device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
+__device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, float* x, int tid) {
+  const int lane = tid & 63;
+  const int i = lane & 15;
   // forward: L y = b
   for (int k = 0; k < NB; ++k) {
     const float* Dk = L + 256 * tileIndex(k, k);
-    const float4* xb = reinterpret_cast<const float4*>(x + 16 * k);
-    float yk = 0.f;
-    if (tid < 16) {
+    if (tid < 64) {
+      float a[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        yk = dot4(ldsRow4(Dk, tid, q), xb[q], yk);
+        const float4 v = ldsRow4(Dk, i, q);
+        a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
       }
-    }
-    __syncthreads();
-    if (tid < 16) {
-      x[16 * k + tid] = yk;
+      float bi = x[16 * k + i];
+      const float invd = invDiag[16 * k + i];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float yj = readLaneF(bi, j) * readLaneF(invd, j);
+        bi = (i == j) ? yj : bi - a[j] * yj; // lanes i < j already hold their final y_i: a[j] = 0 there
+      }
+      if (lane < 16) {
+        x[16 * k + i] = bi;
+      }
     }
     __syncthreads();
     const int r = 16 * (k + 1) + tid;
     if (r < 16 * NB) {
       const float* Tl = L + 256 * tileIndex(r >> 4, k);
+      const float4* xb = reinterpret_cast<const float4*>(x + 16 * k);
       float acc = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -304,16 +317,22 @@ __device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
   // backward: L^T x = y
   for (int k = NB - 1; k >= 0; --k) {
     const float* Dk = L + 256 * tileIndex(k, k);
-    float xk = 0.f;
-    if (tid < 16) {
+    if (tid < 64) {
+      float at[16]; // column i of L_kk: at[c] = L(c, i)
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        xk += Dk[tileAddr(c, tid)] * x[16 * k + c];
+        at[c] = Dk[tileAddr(c, i)];
       }
-    }
-    __syncthreads();
-    if (tid < 16) {
-      x[16 * k + tid] = xk;
+      float bi = x[16 * k + i];
+      const float invd = invDiag[16 * k + i];
+#pragma unroll
+      for (int j = 15; j >= 0; --j) {
+        const float xj = readLaneF(bi, j) * readLaneF(invd, j);
+        bi = (i == j) ? xj : bi - at[j] * xj; // lanes i > j: at[j] = L(j,i) = 0, value already final
+      }
+      if (lane < 16) {
+        x[16 * k + i] = bi;
+      }
     }
     __syncthreads();
     const int r = tid;
@@ -331,7 +350,7 @@ __device__ __forceinline__ void solveLLt(const float* L, float* x, int tid) {
 }
 
 template <int NB>
-__global__ void __launch_bounds__(256, 2) fusedSolveKernel(
+__global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
@@ -358,6 +377,8 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
 
   // ---- LDS carve (every offset a multiple of 4 floats); must match fusedLdsBytes()
   FusedLds s;
+  int *lParent, *lLevelOrder, *lLevelStart, *lPtOuter, *lPtInner, *lSubSize, *lPosUnitStart, *lPosUnits, *lUnitJoint, *lSolveList;
+  float* lPtValue;
   {
     float* p = smem;
     auto take = [&](size_t count) {
@@ -367,8 +388,19 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     };
     s.mStart = reinterpret_cast<int*>(take(NP + 1));
     s.mTin = reinterpret_cast<int*>(take(nsrc));
-    s.mTout = reinterpret_cast<int*>(take(nsrc));
+    s.mInfo = reinterpret_cast<int*>(take(nsrc));
     s.mW = take(nsrc);
+    lParent = reinterpret_cast<int*>(take(J));
+    lLevelOrder = reinterpret_cast<int*>(take(J));
+    lLevelStart = reinterpret_cast<int*>(take(rig.numLevels + 1));
+    lPtOuter = reinterpret_cast<int*>(take(rig.R + 1));
+    lPtInner = reinterpret_cast<int*>(take(fd.nnz));
+    lPtValue = take(fd.nnz);
+    lSubSize = reinterpret_cast<int*>(take(J));
+    lPosUnitStart = reinterpret_cast<int*>(take(J + 1));
+    lPosUnits = reinterpret_cast<int*>(take(U));
+    lUnitJoint = reinterpret_cast<int*>(take(U));
+    lSolveList = reinterpret_cast<int*>(take(n));
     s.th = take(P);
     s.js = take(size_t(kJs) * J);
     s.up = take(3 * size_t(U));
@@ -380,17 +412,25 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     s.g = take(NP);
     s.d0 = take(NP);
     s.rho = take(NP);
+    s.invDiag = take(NP);
+    s.red = reinterpret_cast<double*>(take(16));
+    s.flags = reinterpret_cast<int*>(take(4));
+    float* blockJ = p; // srcT (phases E-G)  |  dfull, jd, tanOwn, tanPre (phases J-K)
     s.dfull = take(P);
     s.jd = take(7 * size_t(J));
     s.tanOwn = take(size_t(kTan) * J);
     s.tanPre = take(size_t(kTan) * J);
-    s.red = reinterpret_cast<double*>(take(16));
-    s.flags = reinterpret_cast<int*>(take(4));
+    s.srcT = blockJ;
+    {
+      float* endSrc = blockJ + alignUp4(size_t(kSrc) * nsrc);
+      if (endSrc > p) {
+        p = endSrc;
+      }
+    }
     float* region = p;
     s.loc = take(size_t(kLoc) * J);
     s.own2 = take(size_t(kC2) * J);
     s.sub2 = take(size_t(kC2) * J);
-    s.srcT = take(size_t(kSrc) * nsrc);
     s.L = region;
   }
 
@@ -404,8 +444,49 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
   for (int e = tid; e < nsrc; e += 256) {
     const ColumnSourceDev cs = fd.srcs[e];
     s.mTin[e] = cs.tin;
-    s.mTout[e] = cs.tout;
+    s.mInfo[e] = cs.joint | (cs.dof << 12) | ((cs.parent + 1) << 16);
     s.mW[e] = cs.weight;
+  }
+  for (int i = tid; i < J; i += 256) {
+    lParent[i] = rig.parent[i];
+    lLevelOrder[i] = rig.levelOrder[i];
+    lSubSize[i] = fd.subSize[i];
+  }
+  for (int i = tid; i <= rig.numLevels; i += 256) {
+    lLevelStart[i] = rig.levelStart[i];
+  }
+  for (int i = tid; i <= rig.R; i += 256) {
+    lPtOuter[i] = rig.ptOuter[i];
+  }
+  for (int i = tid; i < fd.nnz; i += 256) {
+    lPtInner[i] = rig.ptInner[i];
+    lPtValue[i] = rig.ptValue[i];
+  }
+  for (int i = tid; i <= J; i += 256) {
+    lPosUnitStart[i] = fd.posUnitStart[i];
+  }
+  for (int i = tid; i < U; i += 256) {
+    lPosUnits[i] = fd.posUnits[i];
+    lUnitJoint[i] = fd.unitJoint[i];
+  }
+  for (int i = tid; i < n; i += 256) {
+    lSolveList[i] = fd.solveList[i];
+  }
+  // from here on the kernel reads the batch-shared tables through these LDS-backed views
+  {
+    RigDev& r = const_cast<RigDev&>(rig);
+    r.parent = lParent;
+    r.levelOrder = lLevelOrder;
+    r.levelStart = lLevelStart;
+    r.ptOuter = lPtOuter;
+    r.ptInner = lPtInner;
+    r.ptValue = lPtValue;
+    FusedDev& f = const_cast<FusedDev&>(fd);
+    f.subSize = lSubSize;
+    f.posUnitStart = lPosUnitStart;
+    f.posUnits = lPosUnits;
+    f.unitJoint = lUnitJoint;
+    f.solveList = lSolveList;
   }
   if (tid == 0) {
     s.flags[0] = 0; // stop
@@ -472,7 +553,14 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
     MMX_CLK(3)
     // ================= E: column-source tables
     for (int e = tid; e < nsrc; e += 256) {
-      const ColumnSourceDev cs = fd.srcs[e];
+      ColumnSourceDev cs;
+      {
+        const int info = s.mInfo[e];
+        cs.joint = info & 0xfff;
+        cs.dof = (info >> 12) & 7;
+        cs.parent = (info >> 16) - 1;
+        cs.tin = s.mTin[e];
+      }
       const float* a = s.js + kJs * cs.joint;
       const float* sb = s.sub2 + kC2 * cs.tin;
       const F3 ta{a[0], a[1], a[2]};
@@ -529,25 +617,27 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
       s.d0[c] = acc;
     }
     MMX_CLK(5)
-    // ================= G: H tiles into the owning wave's accumulator registers
-    v4f acc[TPW];
+    // ================= G: H = J^T J from the moment contractions.  The structurally non-zero
+    // terms are host-built records dealt evenly to the 256 threads; each thread accumulates the
+    // terms of an entry (consecutive records) and stores the entry into the LDS tile region, which
+    // the owning waves then pull into their MFMA accumulator registers.
+    for (int i = tid; i < T * 64; i += 256) {
+      reinterpret_cast<float4*>(s.L)[i] = float4{0.f, 0.f, 0.f, 0.f}; // loc / moments are dead (barrier after E)
+    }
+    __syncthreads();
+    {
+      float h = 0.f;
+      for (int k0 = 0; k0 < fd.termRounds; k0 += 8) {
+        uint4 rec[8];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      const int t = 4 * q + wave;
-      acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (t < T) {
-        int I, Jc;
-        tileDecode(t, I, Jc);
-        const int col = 16 * Jc + (lane & 15);
-        {
-          // the structural term list of this lane's 4 entries (host-built, mmx_capi.hip)
-          const int slot = (wave * TPW + q) * 64 + lane;
-          const int e1 = fd.termStart[slot + 1];
-          float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
-          for (int e = fd.termStart[slot]; e < e1; ++e) {
-            const uint32_t pk = fd.termPack[e];
-            const float w = fd.termW[e];
-            const int deep = pk & 0x3fff, anc = (pk >> 14) & 0x3fff, r = pk >> 28;
+        for (int k = 0; k < 8; ++k) {
+          rec[k] = fd.gTerms[(k0 + k) * 256 + tid];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t x = rec[k].x;
+          if (x & (1u << 26)) {
+            const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
             const float4 d0v = *reinterpret_cast<const float4*>(s.srcT + kSrc * deep);
             const float4 d1v = *reinterpret_cast<const float4*>(s.srcT + kSrc * deep + 4);
             const float4 a1v = *reinterpret_cast<const float4*>(s.srcT + kSrc * anc + 4);
@@ -557,25 +647,44 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
             //                          AL = a1v.w a2v.xy, BV = a2v.zw a3v.x, BS = a3v.y)
             const float hj = d0v.x * a1v.w + d0v.y * a2v.x + d0v.z * a2v.y + d0v.w * a2v.z + d1v.x * a2v.w +
                 d1v.y * a3v.x + d1v.z * a3v.y;
-            const float v = w * hj;
-            h0 += r == 0 ? v : 0.f;
-            h1 += r == 1 ? v : 0.f;
-            h2 += r == 2 ? v : 0.f;
-            h3 += r == 3 ? v : 0.f;
+            const float v = __uint_as_float(rec[k].z) * hj;
+            h = (x & (1u << 24)) ? v : h + v;
+            if (x & (1u << 25)) {
+              s.L[rec[k].y] = h;
+            }
           }
-          acc[q] = v4f{h0, h1, h2, h3};
         }
+      }
+    }
+    __syncthreads();
+    v4f acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int t = 4 * q + wave;
+      acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (t < T) {
+        int I, Jc;
+        tileDecode(t, I, Jc);
+        const int col = 16 * Jc + (lane & 15);
+        const float* Tl = s.L + 256 * t;
         // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * I + 4 * (lane >> 4) + r;
+          float h;
+          if (I == Jc && row < col) {
+            h = Tl[tileAddr(col & 15, row & 15)]; // upper part of a diagonal tile: mirror
+          } else {
+            h = Tl[tileAddr(row & 15, col & 15)];
+          }
           if (dbgH != nullptr && it == 0 && row < n && col < n) {
-            dbgH[size_t(b) * n * n + size_t(row) * n + col] = acc[q][r];
-            dbgH[size_t(b) * n * n + size_t(col) * n + row] = acc[q][r];
+            dbgH[size_t(b) * n * n + size_t(row) * n + col] = h;
+            dbgH[size_t(b) * n * n + size_t(col) * n + row] = h;
           }
           if (row == col) {
-            acc[q][r] = row < n ? acc[q][r] + lambda : 1.f;
+            h = row < n ? h + lambda : 1.f;
           }
+          acc[q][r] = h;
         }
       }
     }
@@ -609,27 +718,35 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
         }
       }
       __syncthreads();
-      // (b) wave 0: Cholesky of the 16x16 diagonal block and its inverse, one row / column per
-      //     lane, cross-lane traffic by v_readlane (no LDS round trips inside the dependent steps).
-      //     Only the inverse is kept: the panel solve and the substitutions multiply by it.
-      if (wave == 0) {
+      MMX_CLK(11)
+      // (b+c) panel factorisation: every wave holds the 16 rows of the diagonal block in lanes
+      //     0..15 (redundantly) and 48 rows of the panel below it in lanes 16..63, one row of 16
+      //     values per lane.  Sixteen elimination steps factor the diagonal block AND solve the
+      //     panel rows against it at the same time; the pivot row's entries are broadcast with
+      //     v_readlane, so there is no LDS round trip and no barrier inside the dependent chain.
+      {
         float* Dk = s.L + 256 * tileIndex(k, k);
-        const int i = lane & 15;
+        const bool diagLane = lane < 16;
+        const int prow = 16 * (k + 1) + 48 * wave + (lane - 16); // panel row of lanes 16..63
+        const bool active = diagLane || prow < NP;
+        float* Tl = diagLane ? Dk : s.L + 256 * tileIndex((active ? prow : 16 * k) >> 4, k);
+        const int trow = diagLane ? lane : (prow & 15);
         float a[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 v = ldsRow4(Dk, i, q);
+          const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
           a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
         }
+        __syncthreads(); // every wave has read the diagonal block before wave 0 overwrites it
         float invd = 0.f;
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const float djj = readLaneF(a[j], j);
           bad = bad || !(djj > 0.f);
-          const float inv = __builtin_amdgcn_rsqf(djj); // 1/l_jj; l_jj = d_jj * inv
+          const float inv = __builtin_amdgcn_rsqf(djj); // 1 / l_jj ; l_jj = d_jj * inv
           a[j] *= inv;
-          if (i == j) {
+          if (lane == j) {
             invd = inv;
           }
 #pragma unroll
@@ -637,58 +754,52 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
             a[c] -= a[j] * readLaneF(a[j], c);
           }
         }
-        // inverse: lane c computes column c of X = L^-1 by forward substitution
-        float x[16];
+        if (diagLane) {
+          if (wave == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float sum = (r == i) ? 1.f : 0.f;
-#pragma unroll
-          for (int m = 0; m < r; ++m) {
-            sum -= readLaneF(a[m], r) * x[m];
+            for (int c = 0; c < 16; ++c) {
+              Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
+            }
+            s.invDiag[16 * k + lane] = invd;
+            if (bad) {
+              s.flags[1] = 1;
+            }
           }
-          x[r] = sum * readLaneF(invd, r);
-        }
-        if (lane < 16) {
+        } else if (active) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            Dk[tileAddr(r, i)] = x[r];
-          }
-          if (bad) {
-            s.flags[1] = 1;
+          for (int c = 0; c < 16; ++c) {
+            Tl[tileAddr(trow, c)] = a[c];
           }
         }
-      }
-      __syncthreads();
-      // (c) panel: X = A * L_kk^-T, one thread per row of the panel below the diagonal block
-      {
-        const int r = 16 * (k + 1) + tid;
-        if (r < NP) {
-          float* Tl = s.L + 256 * tileIndex(r >> 4, k);
-          const float* Dk = s.L + 256 * tileIndex(k, k);
-          float4 ar[4];
+        __syncthreads();
+        // panels taller than 4 x 48 rows: the remaining rows solve against the finished L_kk
+        for (int r = 16 * (k + 1) + 192 + tid; r < NP; r += 256) {
+          float* Tr = s.L + 256 * tileIndex(r >> 4, k);
+          float x[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            ar[q] = ldsRow4(Tl, r & 15, q);
+            const float4 v = ldsRow4(Tr, r & 15, q);
+            x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
           }
-          float xrow[16];
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            float sum = 0.f;
+            float sum = x[j];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (4 * q <= j) { // the inverse is lower triangular
-                sum = dot4(ar[q], ldsRow4(Dk, j, q), sum);
-              }
+            for (int c = 0; c < j; ++c) {
+              sum -= x[c] * Dk[tileAddr(j, c)];
             }
-            xrow[j] = sum;
+            x[j] = sum * s.invDiag[16 * k + j];
           }
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
-            Tl[tileAddr(r & 15, c)] = xrow[c];
+            Tr[tileAddr(r & 15, c)] = x[c];
           }
         }
+        if (NP - 16 * (k + 1) > 192) {
+          __syncthreads();
+        }
       }
-      __syncthreads();
+      MMX_CLK(13)
       // (d) trailing update of the tiles this wave owns: acc(I,J) -= L(I,k) L(J,k)^T  (MFMA)
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
@@ -710,6 +821,7 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
       }
       // no barrier needed here: step k+1 publishes into other LDS tiles, and its (a)->(b) barrier
       // orders everything else
+      MMX_CLK(14)
     }
     __syncthreads();
     const bool notPd = s.flags[1] != 0;
@@ -717,11 +829,12 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
 
     // ================= I: d0 = (L L^T)^-1 g
     if (!notPd) {
-      solveLLt<NB>(s.L, s.d0, tid);
+      solveLLt<NB>(s.L, s.invDiag, s.d0, tid);
     }
     MMX_CLK(8)
     // ================= J: one refinement step through the tree (tangent + adjoint passes)
-    if (!notPd && fp.refine) {
+    const int nRefine = (!notPd && fp.refine) ? (lambda < 0.01f ? 2 : 1) : 0; // small lambda: worse conditioning
+    for (int rf = 0; rf < nRefine; ++rf) {
       // full-space delta
       for (int i = tid; i < P; i += 256) {
         s.dfull[i] = 0.f;
@@ -799,15 +912,15 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
         if (c < n) {
           const int e1 = s.mStart[c + 1];
           for (int e = s.mStart[c]; e < e1; ++e) {
-            const ColumnSourceDev cs = fd.srcs[e];
-            a += cs.weight * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
+            const int info = s.mInfo[e];
+            a += s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
           }
           a -= lambda * s.d0[c];
         }
         s.rho[c] = a;
       }
       __syncthreads();
-      solveLLt<NB>(s.L, s.rho, tid);
+      solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
       for (int c = tid; c < n; c += 256) {
         s.d0[c] += s.rho[c];
       }
@@ -916,14 +1029,17 @@ __global__ void __launch_bounds__(256, 2) fusedSolveKernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc) {
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels) {
   const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
-  const size_t fixed = a4(NP + 1) + 3 * a4(nsrc) + a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) +
-      2 * a4(size_t(kC1) * J) + 3 * a4(NP) + a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J) + 16 + 4;
-  const size_t scratch = a4(size_t(kLoc) * J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kSrc) * nsrc);
+  const size_t meta = a4(NP + 1) + 3 * a4(nsrc) + 2 * a4(J) + a4(numLevels + 1) + a4(7 * size_t(J) + 1) + 2 * a4(nnz) + a4(J) +
+      a4(J + 1) + 2 * a4(U) + a4(n);
+  const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 4;
+  const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
+  const size_t blockJ = refine > a4(size_t(kSrc) * nsrc) ? refine : a4(size_t(kSrc) * nsrc);
+  const size_t scratch = a4(size_t(kLoc) * J) + 2 * a4(size_t(kC2) * J);
   const size_t region = scratch > T * 256 ? scratch : T * 256;
-  return (fixed + region) * sizeof(float);
+  return (meta + fixed + blockJ + region) * sizeof(float);
 }
 
 template <int NB>
@@ -938,7 +1054,7 @@ static hipError_t launchFusedNB(
     float* dbgG,
     long long* dbgClk,
     hipStream_t stream) {
-  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc);
+  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.nnz, rig.numLevels);
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }

@@ -31,7 +31,7 @@ struct StepParams {
 
 // device view of mmx::FusedTables (mmx_host_tables.hpp)
 struct FusedDev {
-  int32_t U, Kp, n, nsrc; // units, position constraints, solved parameters, column sources
+  int32_t U, Kp, n, nsrc, nnz; // units, position constraints, solved parameters, column sources, CSR entries
   const int32_t* subSize; // [J] by DFS position
   const int32_t* unitJoint; // [U]
   const int32_t* posUnitStart; // [J+1] by DFS position
@@ -39,12 +39,12 @@ struct FusedDev {
   const int32_t* solveList; // [n]
   const int32_t* srcStart; // [n+1]
   const ColumnSourceDev* srcs; // [nsrc]
-  // Structural term lists of H = J^T J in the fused kernel's register layout (integer bookkeeping
-  // done on the host): slot = (wave * TPW + q) * 64 + lane owns 4 entries (r = 0..3) of tile
-  // 4q + wave; terms [termStart[slot], termStart[slot+1]) are its non-zero (deep, anc) source pairs.
-  const int32_t* termStart; // [4 * TPW * 64 + 1]
-  const uint32_t* termPack; // deep | anc << 14 | r << 28
-  const float* termW; // weight(deep's column source) * weight(anc's column source)
+  // Structural term records of H = J^T J (integer bookkeeping done on the host, mmx_capi.hip):
+  // thread t of the workgroup processes records gTerms[k * 256 + t], k = 0..termRounds-1; the
+  // non-zero terms of one H entry are consecutive records of ONE thread, balanced over threads.
+  const uint4* gTerms; // x: deep | anc << 12 | first << 24 | last << 25 | valid << 26 ; y: LDS address
+                       // of the entry inside the tile region ; z: weight product (float bits)
+  int32_t termRounds;
 };
 
 struct FusedParams {
@@ -58,7 +58,7 @@ struct FusedParams {
   float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
 };
 
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc);
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels);
 int fusedBlocksFor(int n); // number of 16-wide blocks the fused kernel is instantiated for, or -1
 hipError_t launchFusedSolve(
     const RigDev& rig,

@@ -223,7 +223,13 @@ def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode):
     ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
     th = out["theta"].cpu().numpy()
     rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
-    assert rel.max() <= 1e-5, rel
+    tol = np.full(B, 1e-5)
+    if mode == "lm_schedule":
+        # the schedule shrinks lambda (0.05 -> ~1e-4 after ten good steps), which raises the
+        # conditioning of the late steps: bound by the measured sensitivity of the oracle's own
+        # double solve to an fp32-epsilon input perturbation, like the chain fixtures
+        tol = np.maximum(tol, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
+    assert np.all(rel <= tol), (rel, tol)
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     if mode == "line_search":
