@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -118,7 +119,7 @@ struct mmx_problem {
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
-  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms;
+  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight;
@@ -253,29 +254,69 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       if (fd.nsrc >= (1 << 12)) {
         return fail(MMX_ERR_UNSUPPORTED, "more than 4095 column sources");
       }
-      // greedy contiguous partition: close a thread's run once it reaches the running target
-      std::vector<std::vector<uint32_t>> recs(256); // 4 words per record
-      size_t done = 0;
-      int thread = 0;
-      for (const Entry& en : entries) {
-        const size_t target = (totalTerms * size_t(thread + 1) + 255) / 256;
-        if (thread < 255 && done >= target) {
-          ++thread;
+      // Entries with many terms (shared parameters with many sources) are split into chunks of at
+      // most kCap terms: chunk 0 stores to the entry itself, every further chunk to a private
+      // partial cell that one thread adds to the entry afterwards, in a fixed order.
+      constexpr size_t kCap = 16;
+      struct Run {
+        int32_t dest; // >= 0: float offset in the tile region ; < 0: -(cell + 1) partial cell
+        size_t entry, first, count;
+      };
+      std::vector<Run> runs;
+      std::vector<int32_t> combDest, combFirst, combCount;
+      int32_t numCells = 0;
+      for (size_t e = 0; e < entries.size(); ++e) {
+        const size_t nt = entries[e].terms.size();
+        const size_t chunks = (nt + kCap - 1) / kCap;
+        for (size_t c = 0; c < chunks; ++c) {
+          const size_t first = c * kCap, count = std::min(kCap, nt - first);
+          runs.push_back(Run{c == 0 ? entries[e].dest : -(numCells + int32_t(c)), e, first, count});
         }
-        for (size_t i = 0; i < en.terms.size(); ++i) {
-          const Term& tm = en.terms[i];
+        if (chunks > 1) {
+          combDest.push_back(entries[e].dest);
+          combFirst.push_back(numCells);
+          combCount.push_back(int32_t(chunks - 1));
+          numCells += int32_t(chunks - 1);
+        }
+      }
+      // (chunk c >= 1 of an entry uses partial cell combFirst + c - 1)
+      // longest-processing-time-first assignment of runs to the 256 threads (deterministic)
+      std::vector<size_t> order(runs.size());
+      for (size_t i = 0; i < order.size(); ++i) {
+        order[i] = i;
+      }
+      std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return runs[x].count > runs[y].count; });
+      std::vector<std::vector<uint32_t>> recs(256); // 4 words per record
+      std::vector<size_t> load(256, 0);
+      for (size_t oi : order) {
+        const Run& rn = runs[oi];
+        int thread = 0;
+        for (int t = 1; t < 256; ++t) {
+          if (load[t] < load[thread]) {
+            thread = t;
+          }
+        }
+        const Entry& en = entries[rn.entry];
+        uint32_t destWord;
+        if (rn.dest >= 0) {
+          destWord = uint32_t(rn.dest);
+        } else {
+          destWord = (1u << 30) | uint32_t(-rn.dest - 1);
+        }
+        for (size_t i = 0; i < rn.count; ++i) {
+          const Term& tm = en.terms[rn.first + i];
           uint32_t x = tm.deep | (tm.anc << 12) | (1u << 26);
           if (i == 0) {
             x |= 1u << 24;
           }
-          if (i + 1 == en.terms.size()) {
+          if (i + 1 == rn.count) {
             x |= 1u << 25;
           }
           uint32_t wbits;
           std::memcpy(&wbits, &tm.w, 4);
-          recs[thread].insert(recs[thread].end(), {x, uint32_t(en.dest), wbits, 0u});
+          recs[thread].insert(recs[thread].end(), {x, destWord, wbits, 0u});
         }
-        done += en.terms.size();
+        load[thread] += rn.count;
       }
       size_t rounds = 0;
       for (const auto& r : recs) {
@@ -290,6 +331,18 @@ int32_t uploadProblemTables(mmx_problem* pb) {
           }
         }
       }
+      if (numCells > 8 * rig->J) {
+        return fail(MMX_ERR_UNSUPPORTED, "too many split H entries for the partial-cell scratch");
+      }
+      std::vector<int32_t> comb;
+      for (size_t i = 0; i < combDest.size(); ++i) {
+        comb.push_back(combDest[i]);
+        comb.push_back(combFirst[i]);
+        comb.push_back(combCount[i]);
+      }
+      MMX_HIP(upload(pb->dComb, comb));
+      fd.comb = pb->dComb.as<int32_t>();
+      fd.numComb = int32_t(combDest.size());
       MMX_HIP(upload(pb->dTerms, inter));
       fd.gTerms = pb->dTerms.as<uint4>();
       fd.termRounds = int32_t(rounds);

@@ -650,13 +650,26 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
             const float v = __uint_as_float(rec[k].z) * hj;
             h = (x & (1u << 24)) ? v : h + v;
             if (x & (1u << 25)) {
-              s.L[rec[k].y] = h;
+              const uint32_t y = rec[k].y;
+              float* dst = (y & (1u << 30)) ? s.own1 + (y & 0xffff) : s.L + y; // own1 is free during G
+              *dst = h;
             }
           }
         }
       }
     }
     __syncthreads();
+    if (fd.numComb > 0) { // entries that were split into chunks: add the partial cells, fixed order
+      for (int i = tid; i < fd.numComb; i += 256) {
+        const int dest = fd.comb[3 * i], first = fd.comb[3 * i + 1], cnt = fd.comb[3 * i + 2];
+        float v = s.L[dest];
+        for (int c = 0; c < cnt; ++c) {
+          v += s.own1[first + c];
+        }
+        s.L[dest] = v;
+      }
+      __syncthreads();
+    }
     v4f acc[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
