@@ -211,7 +211,8 @@ __device__ __forceinline__ void fkJoint(const RigDev& rig, int j, const float* j
 // compose world = parent * local, and the rotation axes again need only the parent's world
 // rotation (all joints at once).  Arithmetic per joint is identical to fkJoint / the reference.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fkLocalTo(const RigDev& rig, int j, const float* __restrict__ theta, float* o) {
+template <class RigT>
+__device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* __restrict__ theta, float* o) {
   float jpv[7];
 #pragma unroll
   for (int d = 0; d < 7; ++d) {
@@ -240,11 +241,13 @@ __device__ __forceinline__ void fkLocalTo(const RigDev& rig, int j, const float*
   o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
 }
 
-__device__ __forceinline__ void fkLocal(const RigDev& rig, int j, const float* __restrict__ theta, float* loc) {
+template <class RigT>
+__device__ __forceinline__ void fkLocal(const RigT& rig, int j, const float* __restrict__ theta, float* loc) {
   fkLocalTo(rig, j, theta, loc + kLoc * j);
 }
 
-__device__ __forceinline__ void fkCompose(const RigDev& rig, int j, const float* loc, float* js) {
+template <class RigT>
+__device__ __forceinline__ void fkCompose(const RigT& rig, int j, const float* loc, float* js) {
   const int par = rig.parent[j];
   F3 tp{0.f, 0.f, 0.f};
   Q4 qp{0.f, 0.f, 0.f, 1.f};
@@ -264,7 +267,8 @@ __device__ __forceinline__ void fkCompose(const RigDev& rig, int j, const float*
   o[7] = sp * lo[3];
 }
 
-__device__ __forceinline__ void fkAxes(const RigDev& rig, int j, const float* loc, float* js) {
+template <class RigT>
+__device__ __forceinline__ void fkAxes(const RigT& rig, int j, const float* loc, float* js) {
   const int par = rig.parent[j];
   Q4 qp{0.f, 0.f, 0.f, 1.f};
   if (par >= 0) {
@@ -286,11 +290,13 @@ __device__ __forceinline__ void fkAxes(const RigDev& rig, int j, const float* lo
 // joint's level is composed, then the world (t, q, s); [8..15] holds q1, q2 until the axes pass
 // replaces them by the rotation axes [8..16].  Each slot is rewritten only by the lane that owns
 // the joint, and parents are final before children read them (level barrier).
-__device__ __forceinline__ void fkLocalInPlace(const RigDev& rig, int j, const float* __restrict__ theta, float* js) {
+template <class RigT>
+__device__ __forceinline__ void fkLocalInPlace(const RigT& rig, int j, const float* __restrict__ theta, float* js) {
   fkLocalTo(rig, j, theta, js + kJs * j);
 }
 
-__device__ __forceinline__ void fkComposeInPlace(const RigDev& rig, int j, float* js) {
+template <class RigT>
+__device__ __forceinline__ void fkComposeInPlace(const RigT& rig, int j, float* js) {
   const int par = rig.parent[j];
   F3 tp{0.f, 0.f, 0.f};
   Q4 qp{0.f, 0.f, 0.f, 1.f};
@@ -310,7 +316,8 @@ __device__ __forceinline__ void fkComposeInPlace(const RigDev& rig, int j, float
   o[7] = sc;
 }
 
-__device__ __forceinline__ void fkAxesInPlace(const RigDev& rig, int j, float* js) {
+template <class RigT>
+__device__ __forceinline__ void fkAxesInPlace(const RigT& rig, int j, float* js) {
   const int par = rig.parent[j];
   Q4 qp{0.f, 0.f, 0.f, 1.f};
   if (par >= 0) {

@@ -107,6 +107,30 @@ struct FusedLds {
   float* srcT; // [kSrc nsrc]
 };
 
+// Views of the batch-shared tables after they were copied into LDS.  Plain local structs whose
+// pointers come straight from the LDS carve, so the compiler keeps the LDS address space (ds_read)
+// instead of falling back to flat loads.
+struct RigView {
+  int32_t J, P, R, numLevels;
+  const int32_t* parent;
+  const float* preRot; // stays in global memory (read once per joint per iteration)
+  const float* offset; // "
+  const int32_t* ptOuter;
+  const int32_t* ptInner;
+  const float* ptValue;
+  const float* ptOffsets; // "
+  const int32_t* levelOrder;
+  const int32_t* levelStart;
+};
+struct FusedView {
+  int32_t U, Kp;
+  const int32_t* subSize;
+  const int32_t* unitJoint;
+  const int32_t* posUnitStart;
+  const int32_t* posUnits;
+  const int32_t* solveList;
+};
+
 __host__ __device__ __forceinline__ size_t alignUp4(size_t x) {
   return (x + 3) & ~size_t(3);
 }
@@ -114,7 +138,7 @@ __host__ __device__ __forceinline__ size_t alignUp4(size_t x) {
 // ---------------------------------------------------------------------------------------------
 // adjoint machinery: sums over a joint's own units, then over its subtree (= a DFS index range)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ownSums(const FusedDev& fd, const FusedLds& s, int J, int tid, bool second) {
+__device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, int J, int tid, bool second) {
   for (int k = tid; k < J; k += 256) {
     float a1[kC1], a2[kC2];
 #pragma unroll
@@ -175,7 +199,7 @@ __device__ __forceinline__ void ownSums(const FusedDev& fd, const FusedLds& s, i
 // sub[k][c] = sum_{m in [k, k + subSize[k])} own[m][c]; four independent partial sums so that the
 // LDS loads pipeline (the summation order is fixed => deterministic)
 template <int NC>
-__device__ __forceinline__ void subtreeSums(const FusedDev& fd, const float* own, float* sub, int J, int tid) {
+__device__ __forceinline__ void subtreeSums(const FusedView& fd, const float* own, float* sub, int J, int tid) {
   for (int idx = tid; idx < J * NC; idx += 256) {
     const int k = idx / NC, c = idx - k * NC;
     const int k1 = k + fd.subSize[k];
@@ -214,9 +238,9 @@ __device__ __forceinline__ float sourceGradient(int joint, int dof, int parent, 
 // `th`: FK without derivatives + sum of w * |f|^2, rounded through float like the reference (:82).
 // Every thread returns the same value.  Clobbers loc / js / red.
 __device__ __forceinline__ double blockError(
-    const RigDev& rig,
+    const RigView& rig,
     const ProblemDev& pb,
-    const FusedDev& fd,
+    const FusedView& fd,
     const FusedLds& s,
     const float* th,
     int b,
@@ -473,25 +497,30 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     lSolveList[i] = fd.solveList[i];
   }
   // from here on the kernel reads the batch-shared tables through these LDS-backed views
-  {
-    RigDev& r = const_cast<RigDev&>(rig);
-    r.parent = lParent;
-    r.levelOrder = lLevelOrder;
-    r.levelStart = lLevelStart;
-    r.ptOuter = lPtOuter;
-    r.ptInner = lPtInner;
-    r.ptValue = lPtValue;
-    FusedDev& f = const_cast<FusedDev&>(fd);
-    f.subSize = lSubSize;
-    f.posUnitStart = lPosUnitStart;
-    f.posUnits = lPosUnits;
-    f.unitJoint = lUnitJoint;
-    f.solveList = lSolveList;
-  }
+  RigView rv;
+  rv.J = J, rv.P = P, rv.R = rig.R, rv.numLevels = rig.numLevels;
+  rv.parent = lParent, rv.preRot = rig.preRot, rv.offset = rig.offset;
+  rv.ptOuter = lPtOuter, rv.ptInner = lPtInner, rv.ptValue = lPtValue, rv.ptOffsets = rig.ptOffsets;
+  rv.levelOrder = lLevelOrder, rv.levelStart = lLevelStart;
+  FusedView fv;
+  fv.U = U, fv.Kp = fd.Kp;
+  fv.subSize = lSubSize, fv.unitJoint = lUnitJoint, fv.posUnitStart = lPosUnitStart, fv.posUnits = lPosUnits;
+  fv.solveList = lSolveList;
   if (tid == 0) {
     s.flags[0] = 0; // stop
     s.flags[1] = 0; // not positive definite (this iteration)
     s.flags[2] = 0; // status
+  }
+  // (I, J) of the tiles this wave owns: wave-uniform, decoded once
+  int tI[TPW], tJ[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    int I = 0, Jc = 0;
+    if (4 * q + wave < T) {
+      tileDecode(4 * q + wave, I, Jc);
+    }
+    tI[q] = __builtin_amdgcn_readfirstlane(I);
+    tJ[q] = __builtin_amdgcn_readfirstlane(Jc);
   }
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
   float lambda = fp.lambda; // constant for GaussNewtonSolverT, adapted by the LM schedule
@@ -507,21 +536,21 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     // parameter_transform.cpp:110-124), local transform and the partial rotations q1 = pre*Qz,
     // q2 = pre*Qz*Qy (joint_state.cpp:44-62)
     for (int j = tid; j < J; j += 256) {
-      fkLocal(rig, j, s.th, s.loc);
+      fkLocal(rv, j, s.th, s.loc);
     }
     __syncthreads();
     MMX_CLK(0)
     // ================= B: world = parent * local by tree level (transform.h:124-129), then the
     // rotation axes (q_p * q_partial) * e_index for all joints at once
-    for (int l = 0; l < rig.numLevels; ++l) {
-      const int i1 = rig.levelStart[l + 1];
-      for (int i = rig.levelStart[l] + tid; i < i1; i += 256) {
-        fkCompose(rig, rig.levelOrder[i], s.loc, s.js);
+    for (int l = 0; l < rv.numLevels; ++l) {
+      const int i1 = rv.levelStart[l + 1];
+      for (int i = rv.levelStart[l] + tid; i < i1; i += 256) {
+        fkCompose(rv, rv.levelOrder[i], s.loc, s.js);
       }
       __syncthreads();
     }
     for (int j = tid; j < J; j += 256) {
-      fkAxes(rig, j, s.loc, s.js);
+      fkAxes(rv, j, s.loc, s.js);
     }
     MMX_CLK(1)
     // ================= C: units (need only the world transforms, not the axes)
@@ -545,10 +574,10 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); // every thread: the same value
     MMX_CLK(2)
     // ================= D: own + subtree sums
-    ownSums(fd, s, J, tid, true);
+    ownSums(fv, s, J, tid, true);
     __syncthreads();
-    subtreeSums<kC1>(fd, s.own1, s.sub1, J, tid);
-    subtreeSums<kC2>(fd, s.own2, s.sub2, J, tid);
+    subtreeSums<kC1>(fv, s.own1, s.sub1, J, tid);
+    subtreeSums<kC2>(fv, s.own2, s.sub2, J, tid);
     __syncthreads();
     MMX_CLK(3)
     // ================= E: column-source tables
@@ -625,6 +654,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       reinterpret_cast<float4*>(s.L)[i] = float4{0.f, 0.f, 0.f, 0.f}; // loc / moments are dead (barrier after E)
     }
     __syncthreads();
+    MMX_CLK(5)
     {
       float h = 0.f;
       for (int k0 = 0; k0 < fd.termRounds; k0 += 8) {
@@ -659,6 +689,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
     }
     __syncthreads();
+    MMX_CLK(12)
     if (fd.numComb > 0) { // entries that were split into chunks: add the partial cells, fixed order
       for (int i = tid; i < fd.numComb; i += 256) {
         const int dest = fd.comb[3 * i], first = fd.comb[3 * i + 1], cnt = fd.comb[3 * i + 2];
@@ -676,8 +707,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       const int t = 4 * q + wave;
       acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
       if (t < T) {
-        int I, Jc;
-        tileDecode(t, I, Jc);
+        const int I = tI[q], Jc = tJ[q];
         const int col = 16 * Jc + (lane & 15);
         const float* Tl = s.L + 256 * t;
         // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block
@@ -719,8 +749,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       for (int q = 0; q < TPW; ++q) {
         const int t = 4 * q + wave;
         if (t < T) {
-          int I, Jc;
-          tileDecode(t, I, Jc);
+          const int Jc = tJ[q];
           if (Jc == k) {
             float* Tl = s.L + 256 * t;
 #pragma unroll
@@ -818,8 +847,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       for (int q = 0; q < TPW; ++q) {
         const int t = 4 * q + wave;
         if (t < T) {
-          int I, Jc;
-          tileDecode(t, I, Jc);
+          const int I = tI[q], Jc = tJ[q];
           if (Jc > k) {
             const float4 av = ldsRow4(s.L + 256 * tileIndex(I, k), lane & 15, lane >> 4);
             const float4 bv = ldsRow4(s.L + 256 * tileIndex(Jc, k), lane & 15, lane >> 4);
@@ -854,15 +882,15 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
       __syncthreads();
       for (int c = tid; c < n; c += 256) {
-        s.dfull[fd.solveList[c]] = s.d0[c];
+        s.dfull[fv.solveList[c]] = s.d0[c];
       }
       __syncthreads();
       // joint-parameter delta jd = transform * delta
-      for (int r = tid; r < rig.R; r += 256) {
+      for (int r = tid; r < rv.R; r += 256) {
         float a = 0.f;
-        const int k1 = rig.ptOuter[r + 1];
-        for (int k = rig.ptOuter[r]; k < k1; ++k) {
-          a += rig.ptValue[k] * s.dfull[rig.ptInner[k]];
+        const int k1 = rv.ptOuter[r + 1];
+        for (int k = rv.ptOuter[r]; k < k1; ++k) {
+          a += rv.ptValue[k] * s.dfull[rv.ptInner[k]];
         }
         s.jd[r] = a;
       }
@@ -874,7 +902,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         const F3 ta{ja[0], ja[1], ja[2]};
         F3 Tv{0.f, 0.f, 0.f};
         if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
-          const int par = rig.parent[a];
+          const int par = rv.parent[a];
           Tv = d[0] * transAxisCol(s.js, par, 0) + d[1] * transAxisCol(s.js, par, 1) + d[2] * transAxisCol(s.js, par, 2);
         }
         const F3 Om = d[3] * F3{ja[8], ja[9], ja[10]} + d[4] * F3{ja[11], ja[12], ja[13]} + d[5] * F3{ja[14], ja[15], ja[16]};
@@ -893,7 +921,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           for (int c = 0; c < 7; ++c) {
             v[c] += o[c];
           }
-          q = rig.parent[q];
+          q = rv.parent[q];
         }
         float* o = s.tanPre + kTan * a;
 #pragma unroll
@@ -904,7 +932,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       __syncthreads();
       // units: w = r - J d0 ; y = sigma w
       for (int u = tid; u < U; u += 256) {
-        const float* pre = s.tanPre + kTan * fd.unitJoint[u];
+        const float* pre = s.tanPre + kTan * fv.unitJoint[u];
         const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
         const F3 W{pre[3], pre[4], pre[5]};
         F3 v = cross(W, p);
@@ -916,9 +944,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         s.uy[3 * u] = sg * wx, s.uy[3 * u + 1] = sg * wy, s.uy[3 * u + 2] = sg * wz;
       }
       __syncthreads();
-      ownSums(fd, s, J, tid, false);
+      ownSums(fv, s, J, tid, false);
       __syncthreads();
-      subtreeSums<kC1>(fd, s.own1, s.sub1, J, tid);
+      subtreeSums<kC1>(fv, s.own1, s.sub1, J, tid);
       __syncthreads();
       for (int c = tid; c < NP; c += 256) {
         float a = 0.f;
@@ -955,10 +983,10 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
       __syncthreads();
       for (int c = tid; c < n; c += 256) {
-        s.dfull[fd.solveList[c]] -= s.d0[c];
+        s.dfull[fv.solveList[c]] -= s.d0[c];
       }
       __syncthreads();
-      const double eNew = blockError(rig, pb, fd, s, s.dfull, b, tid);
+      const double eNew = blockError(rv, pb, fv, s, s.dfull, b, tid);
       const float rho = predicted > 0.f ? float((curError - eNew) / double(predicted)) : -1.f;
       if (rho > 0.f) {
         for (int i = tid; i < P; i += 256) {
@@ -983,10 +1011,10 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         }
         __syncthreads();
         for (int c = tid; c < n; c += 256) {
-          s.dfull[fd.solveList[c]] -= scale * s.d0[c];
+          s.dfull[fv.solveList[c]] -= scale * s.d0[c];
         }
         __syncthreads();
-        const double eNew = blockError(rig, pb, fd, s, s.dfull, b, tid);
+        const double eNew = blockError(rv, pb, fv, s, s.dfull, b, tid);
         if ((curError - eNew) >= double(scale * scaledError)) {
           break;
         }
@@ -997,7 +1025,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
     } else if (!notPd) {
       for (int c = tid; c < n; c += 256) {
-        s.th[fd.solveList[c]] -= s.d0[c]; // skeleton_solver_function.cpp:158
+        s.th[fv.solveList[c]] -= s.d0[c]; // skeleton_solver_function.cpp:158
       }
     }
     if (tid == 0) {
