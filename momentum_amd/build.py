@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmx_hip.so")
 SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_host_tables.cpp"]
+FUSED_GROUPS = 4  # mmx_fused.hip is compiled once per group of template instantiations, in parallel
 HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
 ARCH = "gfx950"
 
@@ -35,17 +36,29 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    objs = []
+    jobs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
-        if src.endswith(".cpp"):
-            cmd.insert(1, "-x")
-            cmd.insert(2, "hip")
+        groups = range(FUSED_GROUPS) if src == "mmx_fused.hip" else [None]
+        for g in groups:
+            stem = os.path.splitext(src)[0] + ("" if g is None else f"_g{g}")
+            obj = os.path.join(CSRC, stem + ".o")
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+            if g is not None:
+                cmd.insert(1, f"-DMMX_FUSED_GROUP={g}")
+            if src.endswith(".cpp"):
+                cmd.insert(1, "-x")
+                cmd.insert(2, "hip")
+            jobs.append((cmd, obj))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print(" ".join(job[0]), file=sys.stderr)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -373,7 +373,8 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
   }
 }
 
-template <int NB>
+// MODE 0: production; 1: also dump H / g of the first iteration (parity hook); 2: per-phase clocks
+template <int NB, int MODE>
 __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   constexpr int NP = 16 * NB; // padded system size
   long long clkLast = 0;
 #define MMX_CLK(slot)                                             \
-  if (dbgClk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { \
+  if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) {         \
     const long long now_ = clock64();                             \
     dbgClk[slot] += now_ - clkLast;                               \
     clkLast = now_;                                               \
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   int itersDone = 0;
   __syncthreads();
 
-  if (dbgClk != nullptr) {
+  if (MODE == 2) {
     clkLast = clock64();
   }
   for (int it = 0; it < fp.maxIterations; ++it) {
@@ -665,6 +666,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+          __builtin_amdgcn_sched_barrier(0); // keep one record's LDS operands live at a time
           const uint32_t x = rec[k].x;
           if (x & (1u << 26)) {
             const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
@@ -720,7 +722,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           } else {
             h = Tl[tileAddr(row & 15, col & 15)];
           }
-          if (dbgH != nullptr && it == 0 && row < n && col < n) {
+          if (MODE == 1 && it == 0 && row < n && col < n) {
             dbgH[size_t(b) * n * n + size_t(row) * n + col] = h;
             dbgH[size_t(b) * n * n + size_t(col) * n + row] = h;
           }
@@ -731,7 +733,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         }
       }
     }
-    if (dbgG != nullptr && it == 0) {
+    if (MODE == 1 && it == 0) {
       for (int c = tid; c < n; c += 256) {
         dbgG[size_t(b) * n + c] = s.g[c];
       }
@@ -1070,6 +1072,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+#if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels) {
   const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
@@ -1082,9 +1085,10 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
   const size_t region = scratch > T * 256 ? scratch : T * 256;
   return (meta + fixed + blockJ + region) * sizeof(float);
 }
+#endif
 
-template <int NB>
-static hipError_t launchFusedNB(
+template <int NB, int MODE>
+static hipError_t launchFusedMode(
     const RigDev& rig,
     const ProblemDev& pb,
     const FusedDev& fd,
@@ -1102,16 +1106,85 @@ static hipError_t launchFusedNB(
   static size_t attrBytes = 64 * 1024; // default dynamic-LDS limit; raised on demand
   if (lds > attrBytes) {
     hipError_t rc = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(fusedSolveKernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (rc != hipSuccess) {
       return rc;
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL(fusedSolveKernel<NB>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
   return hipGetLastError();
 }
 
+template <int NB>
+static hipError_t launchFusedNB(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    float* theta,
+    const SolveStateDev& st,
+    const FusedParams& fp,
+    float* dbgH,
+    float* dbgG,
+    long long* dbgClk,
+    hipStream_t stream) {
+  if (dbgClk != nullptr) {
+    return launchFusedMode<NB, 2>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+  }
+  if (dbgH != nullptr || dbgG != nullptr) {
+    return launchFusedMode<NB, 1>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+  }
+  return launchFusedMode<NB, 0>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+}
+
+// The instantiations are split over four translation units (build.py compiles this file once per
+// MMX_FUSED_GROUP, in parallel): group g provides launchFusedGroup<g>() for its block counts.
+#ifndef MMX_FUSED_GROUP
+#define MMX_FUSED_GROUP 0
+#endif
+
+#define MMX_FUSED_ARGS \
+  const RigDev &rig, const ProblemDev &pb, const FusedDev &fd, float *theta, const SolveStateDev &st, const FusedParams &fp, \
+      float *dbgH, float *dbgG, long long *dbgClk, hipStream_t stream
+#define MMX_FUSED_PASS rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream
+
+hipError_t launchFusedGroup0(int nb, MMX_FUSED_ARGS);
+hipError_t launchFusedGroup1(int nb, MMX_FUSED_ARGS);
+hipError_t launchFusedGroup2(int nb, MMX_FUSED_ARGS);
+hipError_t launchFusedGroup3(int nb, MMX_FUSED_ARGS);
+
+#define MMX_CASE(NB_) \
+  case NB_:           \
+    return launchFusedNB<NB_>(MMX_FUSED_PASS);
+
+#if MMX_FUSED_GROUP == 0
+hipError_t launchFusedGroup0(int nb, MMX_FUSED_ARGS) {
+  switch (nb) {
+    MMX_CASE(1) MMX_CASE(2) MMX_CASE(3) default : return hipErrorInvalidValue;
+  }
+}
+#elif MMX_FUSED_GROUP == 1
+hipError_t launchFusedGroup1(int nb, MMX_FUSED_ARGS) {
+  switch (nb) {
+    MMX_CASE(4) MMX_CASE(5) MMX_CASE(6) default : return hipErrorInvalidValue;
+  }
+}
+#elif MMX_FUSED_GROUP == 2
+hipError_t launchFusedGroup2(int nb, MMX_FUSED_ARGS) {
+  switch (nb) {
+    MMX_CASE(7) MMX_CASE(8) MMX_CASE(10) default : return hipErrorInvalidValue;
+  }
+}
+#else
+hipError_t launchFusedGroup3(int nb, MMX_FUSED_ARGS) {
+  switch (nb) {
+    MMX_CASE(12) MMX_CASE(14) default : return hipErrorInvalidValue;
+  }
+}
+#endif
+#undef MMX_CASE
+
+#if MMX_FUSED_GROUP == 0
 int fusedBlocksFor(int n) {
   const int nb = (n + 15) / 16;
   const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14};
@@ -1123,36 +1196,22 @@ int fusedBlocksFor(int n) {
   return -1;
 }
 
-hipError_t launchFusedSolve(
-    const RigDev& rig,
-    const ProblemDev& pb,
-    const FusedDev& fd,
-    float* theta,
-    const SolveStateDev& st,
-    const FusedParams& fp,
-    float* dbgH,
-    float* dbgG,
-    long long* dbgClk,
-    hipStream_t stream) {
-  switch (fusedBlocksFor(fd.n)) {
-#define MMX_CASE(NB_) \
-  case NB_:           \
-    return launchFusedNB<NB_>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
-    MMX_CASE(1)
-    MMX_CASE(2)
-    MMX_CASE(3)
-    MMX_CASE(4)
-    MMX_CASE(5)
-    MMX_CASE(6)
-    MMX_CASE(7)
-    MMX_CASE(8)
-    MMX_CASE(10)
-    MMX_CASE(12)
-    MMX_CASE(14)
-#undef MMX_CASE
-    default:
-      return hipErrorInvalidValue;
+hipError_t launchFusedSolve(MMX_FUSED_ARGS) {
+  const int nb = fusedBlocksFor(fd.n);
+  if (nb < 0) {
+    return hipErrorInvalidValue;
   }
+  if (nb <= 3) {
+    return launchFusedGroup0(nb, MMX_FUSED_PASS);
+  }
+  if (nb <= 6) {
+    return launchFusedGroup1(nb, MMX_FUSED_PASS);
+  }
+  if (nb <= 10) {
+    return launchFusedGroup2(nb, MMX_FUSED_PASS);
+  }
+  return launchFusedGroup3(nb, MMX_FUSED_PASS);
 }
+#endif
 
 } // namespace mmx
