@@ -119,7 +119,7 @@ struct mmx_problem {
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
-  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb;
+  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb, dDfsJoint, dLoadedPos;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight;
@@ -187,6 +187,14 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     }
     const mmx::FusedTables& f = pb->fused;
     MMX_HIP(upload(pb->dSubSize, f.subSize));
+    MMX_HIP(upload(pb->dDfsJoint, f.dfsJoint));
+    std::vector<int32_t> loadedPos;
+    for (int32_t k = 0; k < rig->J; ++k) {
+      if (f.posUnitStart[k + 1] > f.posUnitStart[k]) {
+        loadedPos.push_back(k);
+      }
+    }
+    MMX_HIP(upload(pb->dLoadedPos, loadedPos));
     MMX_HIP(upload(pb->dPosUnitStart, f.posUnitStart));
     MMX_HIP(upload(pb->dPosUnits, f.posUnits));
     MMX_HIP(upload(pb->dSolveList, f.solveList));
@@ -199,6 +207,9 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     fd.nsrc = int32_t(f.srcs.size());
     fd.nnz = rig->ptOuter.back();
     fd.subSize = pb->dSubSize.as<int32_t>();
+    fd.dfsJoint = pb->dDfsJoint.as<int32_t>();
+    fd.loadedPos = pb->dLoadedPos.as<int32_t>();
+    fd.numLoaded = int32_t(loadedPos.size());
     fd.unitJoint = pb->dUnitJoint.as<int32_t>();
     fd.posUnitStart = pb->dPosUnitStart.as<int32_t>();
     fd.posUnits = pb->dPosUnits.as<int32_t>();
@@ -357,7 +368,7 @@ bool fusedUsable(const mmx_problem* pb) {
     return false;
   }
   return pb->rig->J < 4096 &&
-      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rig->dev.numLevels) <= 160 * 1024;
+      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rig->dev.numLevels) + size_t(8) * size_t(pb->rig->J + pb->rig->P) <= 160 * 1024;
 }
 
 bool wantLegacySolver() {
@@ -818,7 +829,7 @@ int32_t mmx_solve(
     fp.threshold = o->threshold;
     fp.minIterations = o->min_iterations;
     fp.maxIterations = o->max_iterations;
-    fp.refine = 1;
+    fp.refine = getenv("MMX_NO_REFINE") != nullptr ? 0 : 1; // experiment switch; parity needs the refinement
     fp.doLineSearch = o->do_line_search;
     fp.stepRule = o->step_rule;
     fp.lmLambdaMin = o->lm_lambda_min;
@@ -827,24 +838,25 @@ int32_t mmx_solve(
     fp.lmDown = o->lm_down;
     long long* clk = nullptr;
     if (getenv("MMX_PHASE_CLOCKS") != nullptr) { // profiling aid: per-phase cycles of block 0
-      MMX_HIP(pb->sClk.ensure(16 * sizeof(long long)));
-      MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 16 * sizeof(long long), s));
+      MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
+      MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
       clk = pb->sClk.as<long long>();
     }
     MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, s));
     if (clk != nullptr) {
-      long long h[16];
+      long long h[32];
       MMX_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, s));
       MMX_HIP(hipStreamSynchronize(s));
-      static const char* names[15] = {"A jointParams", "B fk", "C units", "D sums", "E srcTables", "F g", "G H-assembly",
-                                      "H cholesky(tail)", "I solve", "J refine", "K update", "H.a publish", "H.b potrf+inv",
-                                      "H.c panel", "H.d mfma"};
+      static const char* names[21] = {"A jointParams", "B fk", "C units", "D subtree sums", "E srcTables", "F g + zero tiles",
+                                      "G combine + pull", "H cholesky(tail)", "I solve", "J tail (d0 += rho)", "K update",
+                                      "H.a publish", "G term records", "H.bc panel", "H.d mfma", "D own sums", "J jd",
+                                      "J tangent+own", "J subtree", "J rho", "J solve"};
       long long tot = 0;
-      for (int i = 0; i < 15; ++i) {
+      for (int i = 0; i < 21; ++i) {
         tot += h[i];
       }
       fprintf(stderr, "[mmx phase clocks, block 0, all iterations] total %lld\n", tot);
-      for (int i = 0; i < 15; ++i) {
+      for (int i = 0; i < 21; ++i) {
         fprintf(stderr, "  %-16s %10lld  %5.1f%%\n", names[i], h[i], 100.0 * double(h[i]) / double(tot > 0 ? tot : 1));
       }
     }

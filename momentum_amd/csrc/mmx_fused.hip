@@ -125,6 +125,10 @@ struct RigView {
 struct FusedView {
   int32_t U, Kp;
   const int32_t* subSize;
+  const int32_t* dfsJoint;
+  const int32_t* loadedPos;
+  int32_t numLoaded;
+  const int32_t* colToSolve; // [P] compacted index of a parameter or -1
   const int32_t* unitJoint;
   const int32_t* posUnitStart;
   const int32_t* posUnits;
@@ -196,23 +200,29 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
   }
 }
 
-// sub[k][c] = sum_{m in [k, k + subSize[k])} own[m][c]; four independent partial sums so that the
-// LDS loads pipeline (the summation order is fixed => deterministic)
+// sub[k][c] = sum of own[m][c] over the DFS positions m in [k, k + subSize[k]) that carry units
+// (only those have non-zero own sums); the loaded positions are listed ascending, four
+// independent partial sums keep the LDS loads pipelined (fixed order => deterministic)
 template <int NC>
 __device__ __forceinline__ void subtreeSums(const FusedView& fd, const float* own, float* sub, int J, int tid) {
+  const int nl = fd.numLoaded;
   for (int idx = tid; idx < J * NC; idx += 256) {
     const int k = idx / NC, c = idx - k * NC;
     const int k1 = k + fd.subSize[k];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int m = k;
-    for (; m + 4 <= k1; m += 4) {
-      a0 += own[NC * m + c];
-      a1 += own[NC * (m + 1) + c];
-      a2 += own[NC * (m + 2) + c];
-      a3 += own[NC * (m + 3) + c];
+    int m = 0;
+    for (; m + 4 <= nl; m += 4) {
+      const int p0 = fd.loadedPos[m], p1 = fd.loadedPos[m + 1], p2 = fd.loadedPos[m + 2], p3 = fd.loadedPos[m + 3];
+      const float v0 = own[NC * p0 + c], v1 = own[NC * p1 + c], v2 = own[NC * p2 + c], v3 = own[NC * p3 + c];
+      a0 += (p0 >= k && p0 < k1) ? v0 : 0.f;
+      a1 += (p1 >= k && p1 < k1) ? v1 : 0.f;
+      a2 += (p2 >= k && p2 < k1) ? v2 : 0.f;
+      a3 += (p3 >= k && p3 < k1) ? v3 : 0.f;
     }
-    for (; m < k1; ++m) {
-      a0 += own[NC * m + c];
+    for (; m < nl; ++m) {
+      const int p0 = fd.loadedPos[m];
+      const float v0 = own[NC * p0 + c];
+      a0 += (p0 >= k && p0 < k1) ? v0 : 0.f;
     }
     sub[NC * k + c] = (a0 + a1) + (a2 + a3);
   }
@@ -384,7 +394,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     FusedParams fp,
     float* __restrict__ dbgH, // [B][n*n] or null: H = J^T J (no lambda) of the FIRST iteration
     float* __restrict__ dbgG, // [B][n] or null
-    long long* __restrict__ dbgClk) { // [16] or null: per-phase cycle counts of block 0 (profiling aid)
+    long long* __restrict__ dbgClk) { // [32] or null: per-phase cycle counts of block 0 (profiling aid)
   constexpr int T = NB * (NB + 1) / 2; // lower-triangle tiles
   constexpr int TPW = (T + 3) / 4; // tiles per wave
   constexpr int NP = 16 * NB; // padded system size
@@ -402,7 +412,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
 
   // ---- LDS carve (every offset a multiple of 4 floats); must match fusedLdsBytes()
   FusedLds s;
-  int *lParent, *lLevelOrder, *lLevelStart, *lPtOuter, *lPtInner, *lSubSize, *lPosUnitStart, *lPosUnits, *lUnitJoint, *lSolveList;
+  int *lParent, *lLevelOrder, *lLevelStart, *lPtOuter, *lPtInner, *lSubSize, *lPosUnitStart, *lPosUnits, *lUnitJoint, *lSolveList, *lDfsJoint, *lLoadedPos, *lColToSolve;
   float* lPtValue;
   {
     float* p = smem;
@@ -426,6 +436,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     lPosUnits = reinterpret_cast<int*>(take(U));
     lUnitJoint = reinterpret_cast<int*>(take(U));
     lSolveList = reinterpret_cast<int*>(take(n));
+    lDfsJoint = reinterpret_cast<int*>(take(J));
+    lLoadedPos = reinterpret_cast<int*>(take(J));
+    lColToSolve = reinterpret_cast<int*>(take(P));
     s.th = take(P);
     s.js = take(size_t(kJs) * J);
     s.up = take(3 * size_t(U));
@@ -497,6 +510,17 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   for (int i = tid; i < n; i += 256) {
     lSolveList[i] = fd.solveList[i];
   }
+  for (int i = tid; i < J; i += 256) {
+    lDfsJoint[i] = fd.dfsJoint[i];
+    lLoadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
+  }
+  for (int i = tid; i < P; i += 256) {
+    lColToSolve[i] = -1;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    lColToSolve[fd.solveList[i]] = i;
+  }
   // from here on the kernel reads the batch-shared tables through these LDS-backed views
   RigView rv;
   rv.J = J, rv.P = P, rv.R = rig.R, rv.numLevels = rig.numLevels;
@@ -505,6 +529,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   rv.levelOrder = lLevelOrder, rv.levelStart = lLevelStart;
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp;
+  fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = fd.numLoaded, fv.colToSolve = lColToSolve;
   fv.subSize = lSubSize, fv.unitJoint = lUnitJoint, fv.posUnitStart = lPosUnitStart, fv.posUnits = lPosUnits;
   fv.solveList = lSolveList;
   if (tid == 0) {
@@ -577,6 +602,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     // ================= D: own + subtree sums
     ownSums(fv, s, J, tid, true);
     __syncthreads();
+    MMX_CLK(15)
     subtreeSums<kC1>(fv, s.own1, s.sub1, J, tid);
     subtreeSums<kC2>(fv, s.own2, s.sub2, J, tid);
     __syncthreads();
@@ -878,78 +904,74 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     // ================= J: one refinement step through the tree (tangent + adjoint passes)
     const int nRefine = (!notPd && fp.refine) ? (lambda < 0.01f ? 2 : 1) : 0; // small lambda: worse conditioning
     for (int rf = 0; rf < nRefine; ++rf) {
-      // full-space delta
-      for (int i = tid; i < P; i += 256) {
-        s.dfull[i] = 0.f;
-      }
-      __syncthreads();
-      for (int c = tid; c < n; c += 256) {
-        s.dfull[fv.solveList[c]] = s.d0[c];
-      }
-      __syncthreads();
-      // joint-parameter delta jd = transform * delta
+      // joint-parameter delta jd = transform * delta (delta gathered through the solve map)
       for (int r = tid; r < rv.R; r += 256) {
         float a = 0.f;
         const int k1 = rv.ptOuter[r + 1];
         for (int k = rv.ptOuter[r]; k < k1; ++k) {
-          a += rv.ptValue[k] * s.dfull[rv.ptInner[k]];
+          const int cs = fv.colToSolve[rv.ptInner[k]];
+          a += rv.ptValue[k] * (cs >= 0 ? s.d0[cs] : 0.f);
         }
         s.jd[r] = a;
       }
       __syncthreads();
-      // per joint: C = T - Om x t - ln2 sd t ; W = Om ; S = sd
-      for (int a = tid; a < J; a += 256) {
-        const float* ja = s.js + kJs * a;
-        const float* d = s.jd + 7 * a;
-        const F3 ta{ja[0], ja[1], ja[2]};
-        F3 Tv{0.f, 0.f, 0.f};
-        if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
-          const int par = rv.parent[a];
-          Tv = d[0] * transAxisCol(s.js, par, 0) + d[1] * transAxisCol(s.js, par, 1) + d[2] * transAxisCol(s.js, par, 2);
-        }
-        const F3 Om = d[3] * F3{ja[8], ja[9], ja[10]} + d[4] * F3{ja[11], ja[12], ja[13]} + d[5] * F3{ja[14], ja[15], ja[16]};
-        const F3 C = Tv - cross(Om, ta) - (kLn2 * d[6]) * ta;
-        float* o = s.tanOwn + kTan * a;
-        o[0] = C.x, o[1] = C.y, o[2] = C.z, o[3] = Om.x, o[4] = Om.y, o[5] = Om.z, o[6] = d[6];
-      }
-      __syncthreads();
-      // prefix over ancestors (walk the parent chain)
-      for (int a = tid; a < J; a += 256) {
-        float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int q = a;
-        while (q >= 0) {
-          const float* o = s.tanOwn + kTan * q;
-#pragma unroll
-          for (int c = 0; c < 7; ++c) {
-            v[c] += o[c];
+      MMX_CLK(16)
+      // One thread per joint (in DFS order), no barrier inside: tangent pass = sum over the joint's
+      // ancestor chain of C = T - Om x t - ln2 sd t, W = Om, S = sd; then for the joint's own
+      // units w = r - J d and y = sigma w, accumulated straight into the first-order own sums.
+      for (int k = tid; k < J; k += 256) {
+        const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
+        float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (e1 > e0) {
+          float pre[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          int q = fv.dfsJoint[k];
+          while (q >= 0) {
+            const float* ja = s.js + kJs * q;
+            const float* d = s.jd + 7 * q;
+            const int par = rv.parent[q];
+            const F3 ta{ja[0], ja[1], ja[2]};
+            F3 Tv{0.f, 0.f, 0.f};
+            if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+              Tv = d[0] * transAxisCol(s.js, par, 0) + d[1] * transAxisCol(s.js, par, 1) + d[2] * transAxisCol(s.js, par, 2);
+            }
+            const F3 Om = d[3] * F3{ja[8], ja[9], ja[10]} + d[4] * F3{ja[11], ja[12], ja[13]} + d[5] * F3{ja[14], ja[15], ja[16]};
+            const F3 C = Tv - cross(Om, ta) - (kLn2 * d[6]) * ta;
+            pre[0] += C.x, pre[1] += C.y, pre[2] += C.z;
+            pre[3] += Om.x, pre[4] += Om.y, pre[5] += Om.z;
+            pre[6] += d[6];
+            q = par;
           }
-          q = rv.parent[q];
+          for (int e = e0; e < e1; ++e) {
+            const int u = fv.posUnits[e];
+            const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+            const bool point = u < fv.Kp;
+            F3 v = cross(F3{pre[3], pre[4], pre[5]}, p);
+            if (point) {
+              v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
+            }
+            const float sg = s.us[u];
+            const float yx = sg * (s.ur[3 * u] - sg * v.x), yy = sg * (s.ur[3 * u + 1] - sg * v.y), yz = sg * (s.ur[3 * u + 2] - sg * v.z);
+            a1[3] += p.y * yz - p.z * yy;
+            a1[4] += p.z * yx - p.x * yz;
+            a1[5] += p.x * yy - p.y * yx;
+            if (point) {
+              a1[0] += yx;
+              a1[1] += yy;
+              a1[2] += yz;
+              a1[6] += p.x * yx + p.y * yy + p.z * yz;
+            }
+          }
         }
-        float* o = s.tanPre + kTan * a;
 #pragma unroll
-        for (int c = 0; c < 7; ++c) {
-          o[c] = v[c];
+        for (int c = 0; c < kC1; ++c) {
+          s.own1[kC1 * k + c] = a1[c];
         }
       }
       __syncthreads();
-      // units: w = r - J d0 ; y = sigma w
-      for (int u = tid; u < U; u += 256) {
-        const float* pre = s.tanPre + kTan * fv.unitJoint[u];
-        const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
-        const F3 W{pre[3], pre[4], pre[5]};
-        F3 v = cross(W, p);
-        if (u < fd.Kp) {
-          v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
-        }
-        const float sg = s.us[u];
-        const float wx = s.ur[3 * u] - sg * v.x, wy = s.ur[3 * u + 1] - sg * v.y, wz = s.ur[3 * u + 2] - sg * v.z;
-        s.uy[3 * u] = sg * wx, s.uy[3 * u + 1] = sg * wy, s.uy[3 * u + 2] = sg * wz;
-      }
-      __syncthreads();
-      ownSums(fv, s, J, tid, false);
-      __syncthreads();
+      MMX_CLK(17)
       subtreeSums<kC1>(fv, s.own1, s.sub1, J, tid);
       __syncthreads();
+      MMX_CLK(18)
       for (int c = tid; c < NP; c += 256) {
         float a = 0.f;
         if (c < n) {
@@ -963,7 +985,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         s.rho[c] = a;
       }
       __syncthreads();
+      MMX_CLK(19)
       solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
+      MMX_CLK(20)
       for (int c = tid; c < n; c += 256) {
         s.d0[c] += s.rho[c];
       }
@@ -1077,7 +1101,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
   const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
   const size_t meta = a4(NP + 1) + 3 * a4(nsrc) + 2 * a4(J) + a4(numLevels + 1) + a4(7 * size_t(J) + 1) + 2 * a4(nnz) + a4(J) +
-      a4(J + 1) + 2 * a4(U) + a4(n);
+      a4(J + 1) + 2 * a4(U) + a4(n) + 2 * a4(J) + a4(P);
   const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 4;
   const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
   const size_t blockJ = refine > a4(size_t(kSrc) * nsrc) ? refine : a4(size_t(kSrc) * nsrc);

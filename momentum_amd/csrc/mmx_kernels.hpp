@@ -33,6 +33,9 @@ struct StepParams {
 struct FusedDev {
   int32_t U, Kp, n, nsrc, nnz; // units, position constraints, solved parameters, column sources, CSR entries
   const int32_t* subSize; // [J] by DFS position
+  const int32_t* dfsJoint; // [J] joint at DFS position k
+  const int32_t* loadedPos; // [numLoaded] DFS positions of the joints that carry constraint units, ascending
+  int32_t numLoaded;
   const int32_t* unitJoint; // [U]
   const int32_t* posUnitStart; // [J+1] by DFS position
   const int32_t* posUnits; // [U]
