@@ -27,8 +27,10 @@ namespace mmx {
 // unit u.  Lane u owns three consecutive floats of every column, so one wave store covers 768
 // contiguous bytes; every element is written (structural zeros included), no read-modify-write.
 // =============================================================================================
-template <bool kWriteJac>
-__global__ void __launch_bounds__(64) fkJacobianKernel(
+// WPI = wavefronts per instance: 1 (block = 64) for large batches, 4 (block = 256: FK over 256
+// threads, the column program dealt to the four waves) when the batch alone cannot fill the chip.
+template <bool kWriteJac, int WPI>
+__global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     RigDev rig,
     ProblemDev pb,
     const float* __restrict__ theta, // [B][P]
@@ -42,7 +44,10 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
   // rotations q1,q2 -> [8..16] rotation axes
   float* js = smem;
   const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform on purpose: it indexes the column program, which must stay on the scalar unit
+  const int wave = WPI == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NT = 64 * WPI;
   if (done != nullptr && done[b] != 0) {
     return;
   }
@@ -51,26 +56,26 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
   // local transforms of all joints at once (ParameterTransformT::apply + the theta-only part of
   // JointStateT::set), then SkeletonStateT::set's parent-before-child sweep as a sweep over tree
   // levels that only composes world = parent * local, then the rotation axes of all joints at once
-  for (int j = lane; j < rig.J; j += 64) {
+  for (int j = tid; j < rig.J; j += NT) {
     fkLocalInPlace(rig, j, th, js);
   }
   __syncthreads();
   for (int l = 0; l < rig.numLevels; ++l) {
     const int i1 = rig.levelStart[l + 1];
-    for (int i = rig.levelStart[l] + lane; i < i1; i += 64) {
+    for (int i = rig.levelStart[l] + tid; i < i1; i += NT) {
       fkComposeInPlace(rig, rig.levelOrder[i], js);
     }
     __syncthreads();
   }
   if (kWriteJac) {
-    for (int j = lane; j < rig.J; j += 64) {
+    for (int j = tid; j < rig.J; j += NT) {
       fkAxesInPlace(rig, j, js);
     }
     __syncthreads();
   }
   if (state != nullptr) {
     float* so = state + size_t(b) * rig.J * 8;
-    for (int i = lane; i < rig.J * 8; i += 64) {
+    for (int i = tid; i < rig.J * 8; i += NT) {
       so[i] = js[kJs * (i >> 3) + (i & 7)];
     }
   }
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
     const int u = u0 + lane;
     const Unit un = evalUnit(pb, js, b, u);
     errAcc += double(un.werr);
-    if (res != nullptr && un.valid) {
+    if (res != nullptr && un.valid && wave == 0) {
       float* r = res + size_t(b) * M + 3 * size_t(u);
       r[0] = un.sigma * un.f.x;
       r[1] = un.sigma * un.f.y;
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
       int curJoint = -1;
       bool anc = false;
       F3 off{0.f, 0.f, 0.f};
-      for (int i0 = 0; i0 < pb.numJacRecs; i0 += 4) {
+      for (int i0 = 4 * wave; i0 < pb.numJacRecs; i0 += 4 * WPI) {
         JacRecDev rec[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
         }
       }
       // (2) every other non-empty column (shared parameters, translation / scale dofs): generic gather
-      for (int i = 0; i < pb.numMultiCols; ++i) {
+      for (int i = wave; i < pb.numMultiCols; i += WPI) {
         const int p = pb.multiCols[i];
         F3 acc{0.f, 0.f, 0.f};
         const int e1 = pb.colStart[p + 1];
@@ -147,7 +152,7 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
         }
       }
       // (3) columns without sources (disabled parameters): zeros, every element of J is written
-      for (int i = 0; i < pb.numZeroCols; ++i) {
+      for (int i = wave; i < pb.numZeroCols; i += WPI) {
         if (un.valid) {
           float* o = jb + size_t(pb.zeroCols[i]) * M;
           o[0] = 0.f;
@@ -159,7 +164,7 @@ __global__ void __launch_bounds__(64) fkJacobianKernel(
   }
   if (err != nullptr) {
     const double e = waveReduceSum(errAcc);
-    if (lane == 0) {
+    if (tid == 0) {
       err[b] = e;
     }
   }
@@ -560,10 +565,21 @@ hipError_t launchFkJacobian(
     const int32_t* done,
     hipStream_t stream) {
   const size_t lds = fkJacobianLdsBytes(rig.J);
+  // one wave per instance fills the chip once B >> 256 CUs x ~24 resident waves; below that, four
+  // waves per instance shorten the per-instance critical path
+  const bool wide = pb.B < 2048; // measured: at B = 4096 one wave per instance (3.8 TB/s) beats four (3.2 TB/s)
   if (jac != nullptr) {
-    hipLaunchKernelGGL(fkJacobianKernel<true>, dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+    if (wide) {
+      hipLaunchKernelGGL((fkJacobianKernel<true, 4>), dim3(pb.B), dim3(256), lds, stream, rig, pb, theta, jac, res, err, state, done);
+    } else {
+      hipLaunchKernelGGL((fkJacobianKernel<true, 1>), dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+    }
   } else {
-    hipLaunchKernelGGL(fkJacobianKernel<false>, dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+    if (wide) {
+      hipLaunchKernelGGL((fkJacobianKernel<false, 4>), dim3(pb.B), dim3(256), lds, stream, rig, pb, theta, jac, res, err, state, done);
+    } else {
+      hipLaunchKernelGGL((fkJacobianKernel<false, 1>), dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+    }
   }
   return hipGetLastError();
 }
