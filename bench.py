@@ -111,7 +111,7 @@ def main() -> None:
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--jac-launches", type=int, default=20)
     args = ap.parse_args()
 
@@ -238,7 +238,7 @@ def main() -> None:
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(rig, parents, min(args.cpu_sample, B), 12345, opt)
+            line["cpu_baseline"] = cpu_baseline(rig, parents, args.cpu_sample, 12345, opt)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,72 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the
+double-precision oracle): the oracle must keep reproducing them (CPU), and the HIP path must match
+them through the C ABI (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from momentum_amd import make_humanoid72, make_test_character
+from momentum_amd._abi import GnOptions
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {
+    "cfg1_chain24.npz": lambda: make_test_character(24),
+    "cfg2_humanoid72.npz": lambda: make_humanoid72(seed=12345, variant="p128", unit=0.01),
+}
+OPT = dict(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
+
+
+def _cons(orc, g):
+    return orc.Constraints(g["pos_parent"], g["pos_offset"], g["pos_target"], g["pos_weight"],
+                           g["ori_parent"], g["ori_offset"], g["ori_target"], g["ori_weight"])  # fmt: skip
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_reproduces_fixture(orc, name):
+    g = np.load(os.path.join(HERE, name))
+    rig = CASES[name]()
+    cons = _cons(orc, g)
+    ref = orc.solve_batch(rig, cons, g["theta0"], GnOptions.make(**OPT), dtype="f64")
+    assert np.abs(ref["theta"] - g["theta_final"]).max() <= 1e-10
+    assert np.array_equal(ref["iterations"], g["iterations"])
+    assert np.abs(ref["error_history"] - g["error_history"]).max() <= 1e-9 * max(1.0, np.abs(g["error_history"]).max())
+    J0, r0, e0 = orc.eval_jacobian(rig, cons.instance(0), g["theta0"][0].astype(np.float64), dtype="f64")
+    assert np.abs(J0 - g["jac0"]).max() <= 1e-6 * max(1.0, np.abs(J0).max())  # stored as fp32
+    assert np.abs(r0 - g["res0"]).max() <= 1e-12 * max(1.0, np.abs(r0).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_hip_path_matches_fixture(orc, name):
+    import torch
+
+    from momentum_amd import capi
+
+    g = np.load(os.path.join(HERE, name))
+    rig = CASES[name]()
+    B = g["theta0"].shape[0]
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, g["pos_parent"], g["ori_parent"])
+    dev = pb.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    Kp, Ko = len(g["pos_parent"]), len(g["ori_parent"])
+    pb.set_constraints(t(g["pos_offset"]).reshape(B, Kp, 3), t(g["pos_target"]).reshape(B, Kp, 3), t(g["pos_weight"]).reshape(B, Kp),
+                       t(g["ori_offset"]).reshape(B, Ko, 4), t(g["ori_target"]).reshape(B, Ko, 4), t(g["ori_weight"]).reshape(B, Ko))  # fmt: skip
+    # world transforms at theta*
+    st = pb.skeleton_state(t(g["theta_star"])).cpu().numpy()[0]
+    assert np.abs(st - g["state_star0"]).max() <= 5e-6 * max(1.0, np.abs(g["state_star0"]).max())
+    # dense Jacobian / residual at theta0 of instance 0
+    jac, res, err = pb.eval_jacobian(t(g["theta0"]))
+    assert np.abs(jac[0].cpu().numpy().T - g["jac0"]).max() <= 2e-5 * max(1.0, np.abs(g["jac0"]).max())
+    assert np.abs(res[0].cpu().numpy() - g["res0"]).max() <= 2e-5 * max(1.0, np.abs(g["res0"]).max())
+    assert abs(err[0].item() - float(g["err0"])) <= 2e-5 * max(1.0, float(g["err0"]))
+    # ten Gauss-Newton iterations
+    out = pb.solve(t(g["theta0"].copy()), GnOptions.make(**OPT), want_history=True)
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - g["theta_final"], axis=1) / np.linalg.norm(g["theta_final"], axis=1)
+    tol = 1e-5 if name.startswith("cfg2") else 5e-5  # the chain fixture is ill-conditioned (tests/test_gpu_parity.py)
+    assert rel.max() <= tol, rel
+    assert np.array_equal(out["iterations"].cpu().numpy(), g["iterations"])
+    h = out["error_history"].cpu().numpy()
+    assert np.abs(h - g["error_history"]).max() <= 1e-4 * max(1.0, np.abs(g["error_history"]).max())
