@@ -200,31 +200,44 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
   }
 }
 
-// sub[k][c] = sum of own[m][c] over the DFS positions m in [k, k + subSize[k]) that carry units
-// (only those have non-zero own sums); the loaded positions are listed ascending, four
-// independent partial sums keep the LDS loads pipelined (fixed order => deterministic)
-template <int NC>
-__device__ __forceinline__ void subtreeSums(const FusedView& fd, const float* own, float* sub, int J, int tid) {
-  const int nl = fd.numLoaded;
-  for (int idx = tid; idx < J * NC; idx += 256) {
-    const int k = idx / NC, c = idx - k * NC;
-    const int k1 = k + fd.subSize[k];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int m = 0;
-    for (; m + 4 <= nl; m += 4) {
-      const int p0 = fd.loadedPos[m], p1 = fd.loadedPos[m + 1], p2 = fd.loadedPos[m + 2], p3 = fd.loadedPos[m + 3];
-      const float v0 = own[NC * p0 + c], v1 = own[NC * p1 + c], v2 = own[NC * p2 + c], v3 = own[NC * p3 + c];
-      a0 += (p0 >= k && p0 < k1) ? v0 : 0.f;
-      a1 += (p1 >= k && p1 < k1) ? v1 : 0.f;
-      a2 += (p2 >= k && p2 < k1) ? v2 : 0.f;
-      a3 += (p3 >= k && p3 < k1) ? v3 : 0.f;
+// Tree sums as tiny exact-fp32 MFMA products with a 0/1 mask matrix built on the fly (joints are
+// indexed by DFS position, so "m is in the subtree of k" is k <= m < k + subSize[k]):
+//   kSubtree = true :  out[k][c] = sum over the loaded positions m in the subtree of k of in[m][c]
+//                      (adjoint pass: subtree sums; only joints that carry units have non-zero rows)
+//   kSubtree = false:  out[k][c] = sum over the ancestors-or-self a of k of in[a][c]
+//                      (tangent pass: prefix sums along the parent chain)
+// v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (exact products by 0/1), hence deterministic.
+// Tiles of 16 rows x 16 channels are dealt to the four waves.
+template <int NC, bool kSubtree>
+__device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, float* out, int J, int wave, int lane) {
+  const int K = kSubtree ? fd.numLoaded : J;
+  const int rowTiles = (J + 15) >> 4;
+  constexpr int colTiles = (NC + 15) / 16;
+  const int i = lane & 15, g = lane >> 4;
+  for (int t = wave; t < rowTiles * colTiles; t += 4) {
+    const int rt = t / colTiles, ct = t - rt * colTiles;
+    const int r = 16 * rt + i; // row of the A operand this lane feeds
+    const int rsz = r < J ? fd.subSize[r] : 0;
+    const int c = 16 * ct + i; // column of the B operand this lane feeds
+    v4f acc{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const int kk = k0 + g;
+      float av = 0.f, bv = 0.f;
+      if (kk < K) {
+        const int p = kSubtree ? fd.loadedPos[kk] : kk;
+        const bool m = kSubtree ? (p >= r && p < r + rsz) : (r < J && p <= r && r < p + fd.subSize[p]);
+        av = m ? 1.f : 0.f;
+        bv = c < NC ? in[NC * p + c] : 0.f;
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
-    for (; m < nl; ++m) {
-      const int p0 = fd.loadedPos[m];
-      const float v0 = own[NC * p0 + c];
-      a0 += (p0 >= k && p0 < k1) ? v0 : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int orow = 16 * rt + 4 * g + q, ocol = 16 * ct + i;
+      if (orow < J && ocol < NC) {
+        out[NC * orow + ocol] = acc[q];
+      }
     }
-    sub[NC * k + c] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -603,8 +616,8 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     ownSums(fv, s, J, tid, true);
     __syncthreads();
     MMX_CLK(15)
-    subtreeSums<kC1>(fv, s.own1, s.sub1, J, tid);
-    subtreeSums<kC2>(fv, s.own2, s.sub2, J, tid);
+    treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
+    treeSum<kC2, true>(fv, s.own2, s.sub2, J, wave, lane);
     __syncthreads();
     MMX_CLK(3)
     // ================= E: column-source tables
@@ -916,31 +929,32 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
       __syncthreads();
       MMX_CLK(16)
-      // One thread per joint (in DFS order), no barrier inside: tangent pass = sum over the joint's
-      // ancestor chain of C = T - Om x t - ln2 sd t, W = Om, S = sd; then for the joint's own
-      // units w = r - J d and y = sigma w, accumulated straight into the first-order own sums.
+      // tangent pass: per joint (stored by DFS position) C = T - Om x t - ln2 sd t, W = Om, S = sd
+      for (int k = tid; k < J; k += 256) {
+        const int q = fv.dfsJoint[k];
+        const float* ja = s.js + kJs * q;
+        const float* d = s.jd + 7 * q;
+        const F3 ta{ja[0], ja[1], ja[2]};
+        F3 Tv{0.f, 0.f, 0.f};
+        if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+          const int par = rv.parent[q];
+          Tv = d[0] * transAxisCol(s.js, par, 0) + d[1] * transAxisCol(s.js, par, 1) + d[2] * transAxisCol(s.js, par, 2);
+        }
+        const F3 Om = d[3] * F3{ja[8], ja[9], ja[10]} + d[4] * F3{ja[11], ja[12], ja[13]} + d[5] * F3{ja[14], ja[15], ja[16]};
+        const F3 C = Tv - cross(Om, ta) - (kLn2 * d[6]) * ta;
+        float* o = s.tanOwn + kTan * k;
+        o[0] = C.x, o[1] = C.y, o[2] = C.z, o[3] = Om.x, o[4] = Om.y, o[5] = Om.z, o[6] = d[6], o[7] = 0.f;
+      }
+      __syncthreads();
+      // ... summed over each joint's ancestor chain (prefix sums down the tree)
+      treeSum<kTan, false>(fv, s.tanOwn, s.tanPre, J, wave, lane);
+      __syncthreads();
+      // per joint with units: w = r - J d, y = sigma w, accumulated straight into the first-order own sums
       for (int k = tid; k < J; k += 256) {
         const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
         float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (e1 > e0) {
-          float pre[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          int q = fv.dfsJoint[k];
-          while (q >= 0) {
-            const float* ja = s.js + kJs * q;
-            const float* d = s.jd + 7 * q;
-            const int par = rv.parent[q];
-            const F3 ta{ja[0], ja[1], ja[2]};
-            F3 Tv{0.f, 0.f, 0.f};
-            if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
-              Tv = d[0] * transAxisCol(s.js, par, 0) + d[1] * transAxisCol(s.js, par, 1) + d[2] * transAxisCol(s.js, par, 2);
-            }
-            const F3 Om = d[3] * F3{ja[8], ja[9], ja[10]} + d[4] * F3{ja[11], ja[12], ja[13]} + d[5] * F3{ja[14], ja[15], ja[16]};
-            const F3 C = Tv - cross(Om, ta) - (kLn2 * d[6]) * ta;
-            pre[0] += C.x, pre[1] += C.y, pre[2] += C.z;
-            pre[3] += Om.x, pre[4] += Om.y, pre[5] += Om.z;
-            pre[6] += d[6];
-            q = par;
-          }
+          const float* pre = s.tanPre + kTan * k;
           for (int e = e0; e < e1; ++e) {
             const int u = fv.posUnits[e];
             const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
@@ -969,7 +983,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
       __syncthreads();
       MMX_CLK(17)
-      subtreeSums<kC1>(fv, s.own1, s.sub1, J, tid);
+      treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
       __syncthreads();
       MMX_CLK(18)
       for (int c = tid; c < NP; c += 256) {
