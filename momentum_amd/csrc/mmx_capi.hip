@@ -865,8 +865,8 @@ int32_t mmx_solve(
   if (o->do_line_search != 0 || o->step_rule != MMX_STEP_GN_FIXED_LAMBDA) {
     return fail(MMX_ERR_UNSUPPORTED, "line search / LM schedule need the fused solver (<= 224 solved parameters)");
   }
-  if (mmx::choleskyStepLdsBytes(n, pb->M) > 160 * 1024) {
-    return fail(MMX_ERR_UNSUPPORTED, "enabled-parameter count too large for the in-LDS Cholesky of this build");
+  if (n > 512) {
+    return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
   }
   rc = ensureStepScratch(pb);
   if (rc != MMX_OK) {

@@ -422,6 +422,47 @@ __device__ __forceinline__ F3 sourceDerivative(const ColumnSourceDev& s, const f
   return kLn2 * (un.v - F3{a[0], a[1], a[2]}); // scale: (v - t_a) * ln2
 }
 
+// ---- 16x16 fp32 tile helpers shared by the fused solver and the large-system Cholesky
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kSrc = 16; // floats per column source: G0(3) AX(3) TR(1) AL(3) BV(3) BS(1) GJ(1) pad(1)
+constexpr int kTan = 8; // tangent-pass floats per joint: C(3) W(3) S(1) pad
+
+// swizzled address of element (row, col) inside a 16x16 fp32 tile (row-major, 16-byte chunks
+// XOR-ed with the row group so that b128 reads of one chunk column hit distinct banks)
+__device__ __forceinline__ int tileAddr(int row, int col) {
+  return row * 16 + ((((col >> 2) ^ (row >> 2)) & 3) << 2) + (col & 3);
+}
+__device__ __forceinline__ int tileIndex(int I, int Jc) { // I >= Jc
+  return I * (I + 1) / 2 + Jc;
+}
+__device__ __forceinline__ void tileDecode(int t, int& I, int& Jc) {
+  int i = int((sqrtf(8.f * float(t) + 1.f) - 1.f) * 0.5f);
+  while ((i + 1) * (i + 2) / 2 <= t) {
+    ++i;
+  }
+  while (i * (i + 1) / 2 > t) {
+    --i;
+  }
+  I = i;
+  Jc = t - i * (i + 1) / 2;
+}
+
+__device__ __forceinline__ float readLaneF(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float4 ldsRow4(const float* tile, int row, int chunk) { // 4 consecutive columns
+  return *reinterpret_cast<const float4*>(tile + row * 16 + (((chunk ^ (row >> 2)) & 3) << 2));
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
+  acc += a.x * b.x;
+  acc += a.y * b.y;
+  acc += a.z * b.z;
+  acc += a.w * b.w;
+  return acc;
+}
+
 __device__ __forceinline__ double waveReduceSum(double v) {
   for (int off = 32; off > 0; off >>= 1) {
     v += __shfl_xor(v, off, 64);

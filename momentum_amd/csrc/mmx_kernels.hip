@@ -509,6 +509,341 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
   }
 }
 
+// =============================================================================================
+// Kernel 3b: dense GN step for LARGE systems (n up to 512 solved parameters, e.g. the 300-joint
+// rig of BASELINE configs[4]): the same step as choleskyStepKernel, but H / L stay in global
+// memory (the jtj scratch, factored in place) and only one 16-column panel lives in LDS at a time.
+// grid = B, block = 256.  Blocked right-looking Cholesky on 16x16 tiles:
+//   - every tile (I,J) of the lower triangle is always handled by the same wave (owner = tile index
+//     mod 4), so a wave only ever re-reads global data it wrote itself; panels are exchanged
+//     through LDS,
+//   - panel factorisation = the lane-per-row elimination with v_readlane broadcasts of the fused
+//     kernel, trailing updates = v_mfma_f32_16x16x4_f32 with operands from the LDS panel,
+//   - substitutions read L from global memory after one agent-scope fence.
+// dynamic LDS = NP*16 (panel) + 4*NP + M + 8 floats.
+// =============================================================================================
+__global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jac, // [B][M*P]
+    const float* __restrict__ res, // [B][M]
+    float* __restrict__ jtj, // [B][n*n] in: H ; out: L (lower), garbage above the diagonal blocks
+    const float* __restrict__ jtr, // [B][n]
+    const double* __restrict__ errIter,
+    float* __restrict__ theta,
+    SolveStateDev st,
+    StepParams sp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (st.done[b] != 0) {
+    return;
+  }
+  const int n = pb.n, M = pb.M;
+  const int NP = (n + 15) & ~15, NB = NP >> 4;
+  float* pan = smem; // [NB - k tiles][256] swizzled tiles of the current block column
+  float* g = pan + size_t(NP) * 16;
+  float* d0 = g + NP;
+  float* rho = d0 + NP;
+  float* invDiag = rho + NP;
+  float* w = invDiag + NP; // [M]
+  int* flags = reinterpret_cast<int*>(w + M);
+  float* H = jtj + size_t(b) * n * n;
+  auto Hget = [&](int r, int c) -> float { // padded rows / columns form an identity block
+    if (r < n && c < n) {
+      const float v = H[size_t(r) * n + c];
+      return r == c ? v + sp.lambda : v;
+    }
+    return r == c ? 1.f : 0.f;
+  };
+  if (tid == 0) {
+    flags[0] = 0;
+  }
+  for (int i = tid; i < NP; i += 256) {
+    const float v = i < n ? jtr[size_t(b) * n + i] : 0.f;
+    g[i] = v;
+    d0[i] = v;
+  }
+  // lambda is added when a diagonal element is first read; every element of the lower triangle is
+  // read from H exactly once before being overwritten with its Schur-complement value, EXCEPT that
+  // updated values are re-read -> keep a "lambda already applied" convention: apply it up front.
+  for (int i = tid; i < n; i += 256) {
+    H[size_t(i) * n + i] += sp.lambda;
+  }
+  __threadfence();
+  __syncthreads();
+  auto Hval = [&](int r, int c) -> float {
+    if (r < n && c < n) {
+      return H[size_t(r) * n + c];
+    }
+    return r == c ? 1.f : 0.f;
+  };
+  (void)Hget;
+
+  for (int k = 0; k < NB; ++k) {
+    const int nt = NB - k; // tiles in this block column
+    // (a) owners load their tiles of block column k into the LDS panel
+    for (int I = k; I < NB; ++I) {
+      if ((tileIndex(I, k) & 3) == wave) {
+        float* Tl = pan + 256 * (I - k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * I + 4 * (lane >> 4) + q, c = 16 * k + (lane & 15);
+          Tl[tileAddr(r & 15, c & 15)] = Hval(r, c);
+        }
+      }
+    }
+    __syncthreads();
+    // (b) panel factorisation (see mmx_fused.hip phase H for the scheme)
+    {
+      float* Dk = pan;
+      const bool diagLane = lane < 16;
+      const int prow = 16 + 48 * wave + (lane - 16); // row inside the panel (0..15 = diagonal block)
+      const bool active = diagLane || prow < 16 * nt;
+      float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
+      const int trow = diagLane ? lane : (prow & 15);
+      float a[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+        a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+      }
+      __syncthreads();
+      float invd = 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float djj = readLaneF(a[j], j);
+        bad = bad || !(djj > 0.f);
+        const float inv = __builtin_amdgcn_rsqf(djj);
+        a[j] *= inv;
+        if (lane == j) {
+          invd = inv;
+        }
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+          a[c] -= a[j] * readLaneF(a[j], c);
+        }
+      }
+      if (diagLane) {
+        if (wave == 0) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
+          }
+          invDiag[16 * k + lane] = invd;
+          if (bad) {
+            flags[0] = 1;
+          }
+        }
+      } else if (active) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          Tl[tileAddr(trow, c)] = a[c];
+        }
+      }
+      __syncthreads();
+      for (int pr = 16 + 192 + tid; pr < 16 * nt; pr += 256) { // rows beyond 4 x 48: substitution
+        float* Tr = pan + 256 * (pr >> 4);
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = ldsRow4(Tr, pr & 15, q);
+          x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float sum = x[j];
+#pragma unroll
+          for (int c = 0; c < j; ++c) {
+            sum -= x[c] * Dk[tileAddr(j, c)];
+          }
+          x[j] = sum * invDiag[16 * k + j];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          Tr[tileAddr(pr & 15, c)] = x[c];
+        }
+      }
+      __syncthreads();
+    }
+    // (c) owners write the factored tiles back (L) and update their trailing tiles
+    for (int I = k; I < NB; ++I) {
+      if ((tileIndex(I, k) & 3) == wave) {
+        const float* Tl = pan + 256 * (I - k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * I + 4 * (lane >> 4) + q, c = 16 * k + (lane & 15);
+          if (r < n && c < n) {
+            H[size_t(r) * n + c] = Tl[tileAddr(r & 15, c & 15)];
+          }
+        }
+      }
+    }
+    for (int Jc = k + 1; Jc < NB; ++Jc) {
+      for (int I = Jc; I < NB; ++I) {
+        if ((tileIndex(I, Jc) & 3) != wave) {
+          continue;
+        }
+        const float4 av = ldsRow4(pan + 256 * (I - k), lane & 15, lane >> 4);
+        const float4 bv = ldsRow4(pan + 256 * (Jc - k), lane & 15, lane >> 4);
+        v4f c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          c[q] = Hval(16 * I + 4 * (lane >> 4) + q, 16 * Jc + (lane & 15));
+        }
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * I + 4 * (lane >> 4) + q, cc = 16 * Jc + (lane & 15);
+          if (r < n && cc < n) {
+            H[size_t(r) * n + cc] = c[q];
+          }
+        }
+      }
+    }
+    __syncthreads(); // the panel buffer is reused by the next block column
+  }
+  __threadfence(); // L was written by four waves; the substitutions read it from any thread
+  __syncthreads();
+  const bool bad = flags[0] != 0;
+
+  // L y = b ; L^T x = y with L in global memory: diagonal blocks through the LDS panel buffer
+  auto solve = [&](float* x) {
+    for (int k = 0; k < NB; ++k) { // forward
+      for (int i = tid; i < 256; i += 256) {
+        const int r = 16 * k + (i >> 4), c = 16 * k + (i & 15);
+        pan[tileAddr(i >> 4, i & 15)] = c <= r ? Hval(r, c) : 0.f;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int i = lane & 15;
+        float a[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = ldsRow4(pan, i, q);
+          a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+        }
+        float bi = x[16 * k + i];
+        const float invd = invDiag[16 * k + i];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float yj = readLaneF(bi, j) * readLaneF(invd, j);
+          bi = (i == j) ? yj : bi - a[j] * yj;
+        }
+        if (lane < 16) {
+          x[16 * k + i] = bi;
+        }
+      }
+      __syncthreads();
+      for (int r = 16 * (k + 1) + tid; r < NP; r += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          acc += Hval(r, 16 * k + c) * x[16 * k + c];
+        }
+        x[r] -= acc;
+      }
+      __syncthreads();
+    }
+    for (int k = NB - 1; k >= 0; --k) { // backward
+      for (int i = tid; i < 256; i += 256) {
+        const int r = 16 * k + (i >> 4), c = 16 * k + (i & 15);
+        pan[tileAddr(i >> 4, i & 15)] = c <= r ? Hval(r, c) : 0.f;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int i = lane & 15;
+        float at[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          at[c] = pan[tileAddr(c, i)];
+        }
+        float bi = x[16 * k + i];
+        const float invd = invDiag[16 * k + i];
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+          const float xj = readLaneF(bi, j) * readLaneF(invd, j);
+          bi = (i == j) ? xj : bi - at[j] * xj;
+        }
+        if (lane < 16) {
+          x[16 * k + i] = bi;
+        }
+      }
+      __syncthreads();
+      for (int r = tid; r < 16 * k; r += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          acc += Hval(16 * k + c, r) * x[16 * k + c];
+        }
+        x[r] -= acc;
+      }
+      __syncthreads();
+    }
+  };
+  if (!bad) {
+    solve(d0);
+  }
+  if (!bad && sp.refine) {
+    const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
+    const float* rb = res + size_t(b) * size_t(M);
+    for (int kk = tid; kk < M; kk += 256) {
+      float acc = rb[kk];
+      for (int s2 = 0; s2 < n; ++s2) {
+        acc -= Jb[size_t(pb.enabledList[s2]) * M + kk] * d0[s2];
+      }
+      w[kk] = acc;
+    }
+    __syncthreads();
+    for (int s2 = wave; s2 < NP; s2 += 4) {
+      float acc = 0.f;
+      if (s2 < n) {
+        const float* col = Jb + size_t(pb.enabledList[s2]) * M;
+        for (int kk = lane; kk < M; kk += 64) {
+          acc += col[kk] * w[kk];
+        }
+        acc = waveReduceSumF(acc);
+      }
+      if (lane == 0) {
+        rho[s2] = s2 < n ? acc - sp.lambda * d0[s2] : 0.f;
+      }
+    }
+    __syncthreads();
+    solve(rho);
+    for (int i = tid; i < n; i += 256) {
+      d0[i] += rho[i];
+    }
+    __syncthreads();
+  }
+  if (!bad) {
+    float* th = theta + size_t(b) * P;
+    for (int s2 = tid; s2 < n; s2 += 256) {
+      th[pb.enabledList[s2]] -= d0[s2];
+    }
+  }
+  if (tid == 0) {
+    const double e = errIter[b];
+    const double last = st.lastError[b];
+    if (st.errorHistory != nullptr) {
+      st.errorHistory[size_t(b) * sp.maxIterations + sp.iteration] = e;
+    }
+    st.iterations[b] = sp.iteration + 1;
+    st.finalError[b] = e;
+    if (bad) {
+      st.status[b] = 2;
+    }
+    const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
+    if (sp.iteration >= sp.minIterations && converged) {
+      st.done[b] = 1;
+    }
+    st.lastError[b] = e;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // small bookkeeping kernels
 // ---------------------------------------------------------------------------------------------
@@ -619,7 +954,21 @@ hipError_t launchCholeskyStep(
     const SolveStateDev& st,
     const StepParams& sp,
     hipStream_t stream) {
-  const size_t lds = choleskyStepLdsBytes(pb.n, pb.M);
+  size_t lds = choleskyStepLdsBytes(pb.n, pb.M);
+  if (lds > 160 * 1024) { // large system: factor in global memory, one LDS panel at a time
+    const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
+    lds = (NP * 16 + 4 * NP + size_t(pb.M) + 8) * sizeof(float);
+    if (lds > 64 * 1024) {
+      hipError_t rc = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(choleskyStepGlobalKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (rc != hipSuccess) {
+        return rc;
+      }
+    }
+    hipLaunchKernelGGL(
+        choleskyStepGlobalKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, const_cast<float*>(jtj), jtr, errIter, theta, st, sp);
+    return hipGetLastError();
+  }
   if (lds > 64 * 1024) {
     hipError_t rc = hipFuncSetAttribute(
         reinterpret_cast<const void*>(choleskyStepKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

@@ -300,3 +300,32 @@ def test_full_size_batch_properties(torch_cuda):
     h = out["error_history"]
     assert torch.all(h[:, -1] < 1e-3 * h[:, 0])
     assert torch.all(out["status"] == 0) and torch.all(out["iterations"] == 10)
+
+
+def test_large_rig_config5_solve_matches_oracle(torch_cuda, orc):
+    """BASELINE configs[4] shape: 300-joint hand+body rig, P = 300, 150 position + 50 orientation
+    constraints (M = 900).  More than 224 solved parameters: the solve takes the three-kernel path
+    with the factor in global memory (choleskyStepGlobalKernel)."""
+    from momentum_amd import make_rig300
+
+    torch = torch_cuda
+    rig = make_rig300(seed=12345, unit=UNIT)
+    rng = np.random.default_rng(77)
+    pp = rng.choice(rig.num_joints, size=150, replace=False)
+    op = rng.choice(rig.num_joints, size=50, replace=False)
+    B = 3
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=555, perturb=0.2)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
+    jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
+    J, r, e = orc.eval_jacobian(rig, cons.instance(0), theta[0].astype(np.float64), dtype="f64")
+    assert np.abs(jac[0].cpu().numpy().T - J).max() <= 2e-5 * max(1.0, np.abs(J).max())
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
+    assert np.all(rel <= tol), (rel, tol)
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
