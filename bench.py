@@ -37,6 +37,7 @@ CONFIGS = {
     # name: (rig variant, constraint joints, default batch per GPU, step rule, description)
     "cfg2": ("p128", "landmarks", 4096, 0, "BASELINE configs[1]: B x 72-joint humanoid (P=128), position+orientation on 16 landmark joints (M=192), GN lambda=0.05, 10 iterations"),
     "cfg3": ("p128", "landmarks", 65536, 1, "BASELINE configs[2]: 65536 x 72-joint humanoid (P=128, M=192), LM gain-ratio damping schedule (lambda0=0.05), 10 iterations"),
+    "cfg5": ("rig300", "cfg5", 8192, 0, "BASELINE configs[4]: 8192 x 300-joint hand+body rig (P=300), 150 position + 50 orientation constraints (M=900), GN lambda=0.05, 10 iterations"),
     "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
 }
 
@@ -52,23 +53,23 @@ def make_device_problem(rig, parents, B, device_index, seed):
     product's own FK kernel, theta0 = 0."""
     from momentum_amd import capi
 
+    pos_parents, ori_parents = parents if isinstance(parents, tuple) else (parents, parents)
     rh = capi.RigHandle(rig, device_index)
-    pb = capi.Problem(rh, B, parents, parents)
+    pb = capi.Problem(rh, B, pos_parents, ori_parents)
     dev = pb.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    P, K = rig.num_params, len(parents)
+    P, Kp, Ko = rig.num_params, len(pos_parents), len(ori_parents)
     theta_star = (torch.rand((B, P), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * 0.3
     st = pb.skeleton_state(theta_star)  # [B,J,8]
-    idx = torch.as_tensor(np.asarray(parents, dtype=np.int64), device=dev)
-    world = st[:, idx, :]  # [B,K,8]
-    pos_offset = torch.zeros((B, K, 3), device=dev)
-    pos_target = world[:, :, 0:3].contiguous()
-    ori_offset = torch.zeros((B, K, 4), device=dev)
+    pidx = torch.as_tensor(np.asarray(pos_parents, dtype=np.int64), device=dev)
+    oidx = torch.as_tensor(np.asarray(ori_parents, dtype=np.int64), device=dev)
+    pos_offset = torch.zeros((B, Kp, 3), device=dev)
+    pos_target = st[:, pidx, 0:3].contiguous()
+    ori_offset = torch.zeros((B, Ko, 4), device=dev)
     ori_offset[..., 3] = 1.0
-    ori_target = world[:, :, 3:7].contiguous()
-    w = torch.ones((B, K), device=dev)
-    pb.set_constraints(pos_offset, pos_target, w, ori_offset, ori_target, w.clone(), 1.0, 1.0)
+    ori_target = st[:, oidx, 3:7].contiguous()
+    pb.set_constraints(pos_offset, pos_target, torch.ones((B, Kp), device=dev), ori_offset, ori_target, torch.ones((B, Ko), device=dev), 1.0, 1.0)
     theta0 = torch.zeros((B, P), device=dev, dtype=torch.float32)
     return rh, pb, theta0, theta_star
 
@@ -79,7 +80,8 @@ def cpu_baseline(rig, parents, sample, seed, options):
     from tests.helpers import make_problem
 
     cores = os.cpu_count() or 1
-    cons, th0, _ = make_problem(rig, parents, parents, sample, seed=seed, perturb=0.3)
+    pos_parents, ori_parents = parents if isinstance(parents, tuple) else (parents, parents)
+    cons, th0, _ = make_problem(rig, pos_parents, ori_parents, sample, seed=seed, perturb=0.3)
     orc.solve_batch(rig, cons, th0[: min(sample, 2 * cores)], options, dtype="f32", nthreads=cores)  # warm
     t0 = time.perf_counter()
     orc.solve_batch(rig, cons, th0, options, dtype="f32", nthreads=cores)
@@ -131,8 +133,21 @@ def main() -> None:
 
     variant, which, defB, step_rule, desc = CONFIGS[args.config]
     B = args.batch if args.batch > 0 else defB
-    rig = make_humanoid72(seed=12345, variant=variant, unit=UNIT)
-    parents = humanoid72_landmark_joints(rig) if which == "landmarks" else np.arange(rig.num_joints, dtype=np.int32)
+    if variant == "rig300":
+        from momentum_amd import make_rig300
+
+        rig = make_rig300(seed=12345, unit=UNIT)
+    else:
+        rig = make_humanoid72(seed=12345, variant=variant, unit=UNIT)
+    if which == "landmarks":
+        pos_parents = ori_parents = humanoid72_landmark_joints(rig)
+    elif which == "cfg5":
+        prng = np.random.default_rng(77)
+        pos_parents = prng.choice(rig.num_joints, size=150, replace=False).astype(np.int32)
+        ori_parents = prng.choice(rig.num_joints, size=50, replace=False).astype(np.int32)
+    else:
+        pos_parents = ori_parents = np.arange(rig.num_joints, dtype=np.int32)
+    parents = (pos_parents, ori_parents)
     seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
     rh, pb, theta0, theta_star = make_device_problem(rig, parents, B, local_rank, seed)
     opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule)
@@ -171,7 +186,8 @@ def main() -> None:
     total_err, total_it, failed = [float(x) for x in norms.tolist()]
 
     # ---- roofline of the J-assembly kernel (mmx_eval_jacobian): HIP events on the launch stream
-    M, P, K = pb.M, pb.P, len(parents)
+    M, P = pb.M, pb.P
+    Kp_, Ko_ = len(parents[0]), len(parents[1])
     jac = torch.empty((B, P, M), dtype=torch.float32, device=dev)
     res = torch.empty((B, M), dtype=torch.float32, device=dev)
     err = torch.empty((B,), dtype=torch.float64, device=dev)
@@ -185,7 +201,7 @@ def main() -> None:
         b.record()
     torch.cuda.synchronize()
     jac_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    bytes_per_launch = B * algorithmic_bytes_per_instance(M, P, K, K)
+    bytes_per_launch = B * algorithmic_bytes_per_instance(M, P, Kp_, Ko_)
     achieved = bytes_per_launch / (jac_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_jacobian.json")
