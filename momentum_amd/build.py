@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmx_hip.so")
 SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_host_tables.cpp"]
 FUSED_GROUPS = 4  # mmx_fused.hip is compiled once per group of template instantiations, in parallel
-HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
+HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_tree.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
 ARCH = "gfx950"
 
 

@@ -26,23 +26,11 @@
 // tests/tree_algebra_np.py / tests/test_tree_algebra.py.
 #include "mmx_device.hpp"
 #include "mmx_kernels.hpp"
+#include "mmx_tree.hpp"
 
 #include <cfloat>
 
 namespace mmx {
-
-// translationAxis column d of joint a = column d of parent.toLinear() (joint_state.cpp:36-42)
-__device__ __forceinline__ F3 transAxisCol(const float* js, int parent, int d) {
-  if (parent < 0) {
-    return F3{d == 0 ? 1.f : 0.f, d == 1 ? 1.f : 0.f, d == 2 ? 1.f : 0.f};
-  }
-  const float* p = js + kJs * parent;
-  const F3 c = qmatCol(Q4{p[3], p[4], p[5], p[6]}, d);
-  return F3{c.x * p[7], c.y * p[7], c.z * p[7]};
-}
-
-constexpr int kC2 = 16; // second-order channels per joint: m0 | m1(3) | M2 (xx xy xz yy yz zz) | M2 of directions (6)
-constexpr int kC1 = 8; // first-order channels per joint: F(3) | N(3) | D | pad
 
 struct FusedLds {
   // ---- loaded once per launch (batch-shared integer tables and the parameter-transform CSR)
@@ -171,61 +159,9 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
   }
 }
 
-// Tree sums as tiny exact-fp32 MFMA products with a 0/1 mask matrix built on the fly (joints are
-// indexed by DFS position, so "m is in the subtree of k" is k <= m < k + subSize[k]):
-//   kSubtree = true :  out[k][c] = sum over the loaded positions m in the subtree of k of in[m][c]
-//                      (adjoint pass: subtree sums; only joints that carry units have non-zero rows)
-//   kSubtree = false:  out[k][c] = sum over the ancestors-or-self a of k of in[a][c]
-//                      (tangent pass: prefix sums along the parent chain)
-// v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (exact products by 0/1), hence deterministic.
-// Tiles of 16 rows x 16 channels are dealt to the four waves.
 template <int NC, bool kSubtree>
 __device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, float* out, int J, int wave, int lane) {
-  const int K = kSubtree ? fd.numLoaded : J;
-  const int rowTiles = (J + 15) >> 4;
-  constexpr int colTiles = (NC + 15) / 16;
-  const int i = lane & 15, g = lane >> 4;
-  for (int t = wave; t < rowTiles * colTiles; t += 4) {
-    const int rt = t / colTiles, ct = t - rt * colTiles;
-    const int r = 16 * rt + i; // row of the A operand this lane feeds
-    const int rsz = r < J ? fd.subSize[r] : 0;
-    const int c = 16 * ct + i; // column of the B operand this lane feeds
-    v4f acc{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const int kk = k0 + g;
-      float av = 0.f, bv = 0.f;
-      if (kk < K) {
-        const int p = kSubtree ? fd.loadedPos[kk] : kk;
-        const bool m = kSubtree ? (p >= r && p < r + rsz) : (r < J && p <= r && r < p + fd.subSize[p]);
-        av = m ? 1.f : 0.f;
-        bv = c < NC ? in[NC * p + c] : 0.f;
-      }
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int orow = 16 * rt + 4 * g + q, ocol = 16 * ct + i;
-      if (orow < J && ocol < NC) {
-        out[NC * orow + ocol] = acc[q];
-      }
-    }
-  }
-}
-
-// J^T y component of one (joint, dof) from the first-order subtree sums (tests/tree_algebra_np.py jt_times)
-__device__ __forceinline__ float sourceGradient(int joint, int dof, int parent, const float* js, const float* sb) {
-  const float* a = js + kJs * joint;
-  const F3 ta{a[0], a[1], a[2]};
-  const F3 Fv{sb[0], sb[1], sb[2]};
-  if (dof < 3) {
-    return dot(transAxisCol(js, parent, dof), Fv);
-  }
-  if (dof < 6) {
-    const float* ax = a + 8 + 3 * (dof - 3);
-    const F3 Nv{sb[3], sb[4], sb[5]};
-    return dot(F3{ax[0], ax[1], ax[2]}, Nv - cross(ta, Fv));
-  }
-  return kLn2 * (sb[6] - dot(ta, Fv));
+  treeSumT<NC, kSubtree>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
 }
 
 // SkeletonSolverFunctionT::getError (skeleton_solver_function.cpp:64-83) of the parameters in
