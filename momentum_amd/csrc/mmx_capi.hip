@@ -94,7 +94,7 @@ struct mmx_rig {
   std::vector<int32_t> parent, ptOuter, ptInner;
   std::vector<float> preRot, offset, ptValue, ptOffsets;
   mmx::HostTables topo; // built with all parameters enabled
-  DevBuf dParent, dPreRot, dOffset, dPtOuter, dPtInner, dPtValue, dPtOffsets, dLevelOrder, dLevelStart;
+  DevBuf dParent, dPreRot, dOffset, dPtOuter, dPtInner, dPtValue, dPtOffsets, dLevelOrder, dLevelStart, dPtEll, dJumpParent;
   mmx::RigDev dev{};
 
   mmx_rig_desc desc() const {
@@ -521,8 +521,41 @@ int32_t mmx_rig_create(const mmx_rig_desc* d, int32_t device, mmx_rig** out) {
   UP(r->dPtOffsets, r->ptOffsets);
   UP(r->dLevelOrder, r->topo.levelOrder);
   UP(r->dLevelStart, r->topo.levelStart);
+  // two-slot ELL copy of the parameter transform (one 16-byte record per joint-parameter row) and
+  // the packed level/parent table of the J-assembly kernel
+  std::vector<int32_t> ell(size_t(R) * 4, 0), jumpParent(size_t(r->J));
+  bool ellOk = true;
+  for (int32_t row = 0; row < R; ++row) {
+    const int32_t k0 = r->ptOuter[row], k1 = r->ptOuter[row + 1];
+    if (k1 - k0 > 2) {
+      ellOk = false;
+      break;
+    }
+    for (int s = 0; s < 2; ++s) {
+      int32_t idx = -1, bits = 0;
+      if (k0 + s < k1) {
+        idx = r->ptInner[k0 + s];
+        std::memcpy(&bits, &r->ptValue[k0 + s], 4);
+      }
+      ell[4 * size_t(row) + 2 * s] = idx;
+      ell[4 * size_t(row) + 2 * s + 1] = bits;
+    }
+  }
+  for (int32_t j = 0; j < r->J; ++j) {
+    jumpParent[j] = ((r->parent[j] + 1) << 16) | (r->parent[j] + 1);
+  }
+  if (ellOk) {
+    UP(r->dPtEll, ell);
+  }
+  UP(r->dJumpParent, jumpParent);
 #undef UP
   mmx::RigDev& dv = r->dev;
+  dv.ptEll = ellOk ? r->dPtEll.as<int4>() : nullptr;
+  dv.jumpParent = r->dJumpParent.as<int32_t>();
+  dv.jumpRounds = 0;
+  while ((1 << dv.jumpRounds) < int32_t(r->topo.levelStart.size()) - 1) {
+    ++dv.jumpRounds;
+  }
   dv.J = r->J;
   dv.P = r->P;
   dv.R = R;

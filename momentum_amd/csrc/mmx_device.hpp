@@ -20,7 +20,7 @@ namespace mmx {
 
 constexpr int kJp = 10; // floats per joint in jp[]
 constexpr int kJs = 20; // floats per joint in js[]
-constexpr int kLoc = 16; // local transform per joint: t(3) s(1) | q_l(4) | q1 = pre*Qz (4) | q2 = pre*Qz*Qy (4)
+constexpr int kLoc = 16; // local transform per joint: t(3) q_l(4) s(1) | q1 = pre*Qz (4) | q2 = pre*Qz*Qy (4)
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {
@@ -111,6 +111,11 @@ struct RigDev {
   const float* ptOffsets; // [R]
   const int32_t* levelOrder; // [J]
   const int32_t* levelStart; // [numLevels+1]
+  // two (parameter index, value bits) pairs per joint-parameter row, index -1 = unused slot; null
+  // when some row of the transform has more than two entries (then the CSR arrays are walked)
+  const int4* ptEll; // [R]
+  const int32_t* jumpParent; // [J] (parent + 1) << 16 | (parent + 1): parent and initial jump target
+  int32_t jumpRounds; // ceil(log2(numLevels)): pointer-jumping rounds that finish every joint
 };
 
 struct ProblemDev {
@@ -211,6 +216,24 @@ __device__ __forceinline__ void fkJoint(const RigDev& rig, int j, const float* j
 // compose world = parent * local, and the rotation axes again need only the parent's world
 // rotation (all joints at once).  Arithmetic per joint is identical to fkJoint / the reference.
 // ---------------------------------------------------------------------------------------------
+// local transform (t, q, s: the layout of a world transform) + partial rotations q1 = pre*Qz,
+// q2 = pre*Qz*Qy from the 7 joint parameters (joint_state.cpp:44-62)
+__device__ __forceinline__ void fkLocalFromParams(const float* jpv, const float* pre, const float* off, float* o) {
+  float sx, cx, sy, cy, sz, cz;
+  sincosf(0.5f * jpv[3], &sx, &cx);
+  sincosf(0.5f * jpv[4], &sy, &cy);
+  sincosf(0.5f * jpv[5], &sz, &cz);
+  const Q4 q0{pre[0], pre[1], pre[2], pre[3]};
+  const Q4 q1 = qmul(q0, Q4{0.f, 0.f, sz, cz});
+  const Q4 q2 = qmul(q1, Q4{0.f, sy, 0.f, cy});
+  const Q4 ql = qmul(q2, Q4{sx, 0.f, 0.f, cx});
+  o[0] = off[0] + jpv[0], o[1] = off[1] + jpv[1], o[2] = off[2] + jpv[2];
+  o[3] = ql.x, o[4] = ql.y, o[5] = ql.z, o[6] = ql.w;
+  o[7] = exp2f(jpv[6]);
+  o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w;
+  o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
+}
+
 template <class RigT>
 __device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* __restrict__ theta, float* o) {
   float jpv[7];
@@ -224,21 +247,28 @@ __device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* _
     }
     jpv[d] = acc + rig.ptOffsets[r];
   }
-  float sx, cx, sy, cy, sz, cz;
-  sincosf(0.5f * jpv[3], &sx, &cx);
-  sincosf(0.5f * jpv[4], &sy, &cy);
-  sincosf(0.5f * jpv[5], &sz, &cz);
-  const float* pre = rig.preRot + 4 * j;
-  const float* off = rig.offset + 3 * j;
-  const Q4 q0{pre[0], pre[1], pre[2], pre[3]};
-  const Q4 q1 = qmul(q0, Q4{0.f, 0.f, sz, cz});
-  const Q4 q2 = qmul(q1, Q4{0.f, sy, 0.f, cy});
-  const Q4 ql = qmul(q2, Q4{sx, 0.f, 0.f, cx});
-  o[0] = off[0] + jpv[0], o[1] = off[1] + jpv[1], o[2] = off[2] + jpv[2];
-  o[3] = exp2f(jpv[6]);
-  o[4] = ql.x, o[5] = ql.y, o[6] = ql.z, o[7] = ql.w;
-  o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w;
-  o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
+  fkLocalFromParams(jpv, rig.preRot + 4 * j, rig.offset + 3 * j, o);
+}
+
+// fkLocalTo with the joint's seven transform rows already in registers (RigDev::ptEll) and theta
+// in LDS: one round of independent global loads instead of the outer -> inner -> theta chain.
+// Same products in the same order as the CSR walk (parameter_transform.cpp:124).
+__device__ __forceinline__ void
+fkLocalFromRows(const RigDev& rig, int j, const int4* rows, const float* ptOff, const float* thetaLds, float* o) {
+  float jpv[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) {
+    const int4 e = rows[d];
+    float acc = 0.f;
+    if (e.x >= 0) {
+      acc += __int_as_float(e.y) * thetaLds[e.x];
+    }
+    if (e.z >= 0) {
+      acc += __int_as_float(e.w) * thetaLds[e.z];
+    }
+    jpv[d] = acc + ptOff[d];
+  }
+  fkLocalFromParams(jpv, rig.preRot + 4 * j, rig.offset + 3 * j, o);
 }
 
 template <class RigT>
@@ -260,11 +290,11 @@ __device__ __forceinline__ void fkCompose(const RigT& rig, int j, const float* l
   }
   const float* lo = loc + kLoc * j;
   const F3 t = tp + qrot(qp, sp * F3{lo[0], lo[1], lo[2]});
-  const Q4 q = qmul(qp, Q4{lo[4], lo[5], lo[6], lo[7]});
+  const Q4 q = qmul(qp, Q4{lo[3], lo[4], lo[5], lo[6]});
   float* o = js + kJs * j;
   o[0] = t.x, o[1] = t.y, o[2] = t.z;
   o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
-  o[7] = sp * lo[3];
+  o[7] = sp * lo[7];
 }
 
 template <class RigT>
@@ -295,9 +325,7 @@ __device__ __forceinline__ void fkLocalInPlace(const RigT& rig, int j, const flo
   fkLocalTo(rig, j, theta, js + kJs * j);
 }
 
-template <class RigT>
-__device__ __forceinline__ void fkComposeInPlace(const RigT& rig, int j, float* js) {
-  const int par = rig.parent[j];
+__device__ __forceinline__ void fkComposeInPlaceP(int j, int par, float* js) {
   F3 tp{0.f, 0.f, 0.f};
   Q4 qp{0.f, 0.f, 0.f, 1.f};
   float sp = 1.f;
@@ -309,16 +337,19 @@ __device__ __forceinline__ void fkComposeInPlace(const RigT& rig, int j, float* 
   }
   float* o = js + kJs * j;
   const F3 t = tp + qrot(qp, sp * F3{o[0], o[1], o[2]});
-  const Q4 q = qmul(qp, Q4{o[4], o[5], o[6], o[7]});
-  const float sc = sp * o[3];
+  const Q4 q = qmul(qp, Q4{o[3], o[4], o[5], o[6]});
+  const float sc = sp * o[7];
   o[0] = t.x, o[1] = t.y, o[2] = t.z;
   o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
   o[7] = sc;
 }
+template <class RigT>
+__device__ __forceinline__ void fkComposeInPlace(const RigT& rig, int j, float* js) {
+  fkComposeInPlaceP(j, rig.parent[j], js);
+}
 
 template <class RigT>
-__device__ __forceinline__ void fkAxesInPlace(const RigT& rig, int j, float* js) {
-  const int par = rig.parent[j];
+__device__ __forceinline__ void fkAxesInPlaceP(const RigT& rig, int j, int par, float* js) {
   Q4 qp{0.f, 0.f, 0.f, 1.f};
   if (par >= 0) {
     const float* p = js + kJs * par;
@@ -332,6 +363,10 @@ __device__ __forceinline__ void fkAxesInPlace(const RigT& rig, int j, float* js)
   o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
   o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
   o[14] = az.x, o[15] = az.y, o[16] = az.z;
+}
+template <class RigT>
+__device__ __forceinline__ void fkAxesInPlace(const RigT& rig, int j, float* js) {
+  fkAxesInPlaceP(rig, j, rig.parent[j], js);
 }
 
 // One constraint vector ("unit") = 3 Jacobian rows 3u..3u+2.  Position constraint c -> unit c
@@ -347,7 +382,44 @@ struct Unit {
   bool valid;
 };
 
-__device__ __forceinline__ Unit evalUnit(const ProblemDev& pb, const float* js, int b, int u) {
+// the global-memory part of a unit: issued before FK so that the HBM latency hides behind it
+struct UnitInput {
+  int joint, tin;
+  float a[4]; // position: offset (3) ; orientation: offset quaternion
+  float t[4]; // position: target (3) ; orientation: target quaternion
+  float cw; // constraint weight
+};
+
+__device__ __forceinline__ UnitInput loadUnitInput(const ProblemDev& pb, int b, int u) {
+  UnitInput in;
+  in.joint = 0, in.tin = -1, in.cw = 0.f;
+  in.a[0] = in.a[1] = in.a[2] = in.a[3] = 0.f;
+  in.t[0] = in.t[1] = in.t[2] = in.t[3] = 0.f;
+  if (u >= pb.U) {
+    return in;
+  }
+  in.joint = pb.unitJoint[u];
+  in.tin = pb.unitTin[u];
+  if (u < pb.Kp) {
+    const size_t c = size_t(b) * pb.Kp + u;
+    const float* po = pb.posOffset + 3 * c;
+    const float* pt = pb.posTarget + 3 * c;
+    in.a[0] = po[0], in.a[1] = po[1], in.a[2] = po[2];
+    in.t[0] = pt[0], in.t[1] = pt[1], in.t[2] = pt[2];
+    in.cw = pb.posWeight[c];
+  } else {
+    const int co = (u - pb.Kp) / 3;
+    const size_t c = size_t(b) * pb.Ko + co;
+    const float* oo = pb.oriOffset + 4 * c; // caller-owned pointers: no alignment assumed
+    const float* ot = pb.oriTarget + 4 * c;
+    in.a[0] = oo[0], in.a[1] = oo[1], in.a[2] = oo[2], in.a[3] = oo[3];
+    in.t[0] = ot[0], in.t[1] = ot[1], in.t[2] = ot[2], in.t[3] = ot[3];
+    in.cw = pb.oriWeight[c];
+  }
+  return in;
+}
+
+__device__ __forceinline__ Unit evalUnitFrom(const ProblemDev& pb, const UnitInput& in, const float* js, int u) {
   Unit un;
   un.valid = u < pb.U;
   un.v = F3{0.f, 0.f, 0.f};
@@ -359,44 +431,39 @@ __device__ __forceinline__ Unit evalUnit(const ProblemDev& pb, const float* js, 
   if (!un.valid) {
     return un;
   }
-  const int j = pb.unitJoint[u];
-  un.tin = pb.unitTin[u];
-  const float* w = js + kJs * j;
+  un.tin = in.tin;
+  const float* w = js + kJs * in.joint;
   const F3 t{w[0], w[1], w[2]};
   const Q4 q{w[3], w[4], w[5], w[6]};
   const float s = w[7];
-  float cw, fw;
+  float fw;
   if (un.isPoint) {
     // PositionErrorFunctionT::evalFunction (position_error_function.cpp:23-26)
-    const size_t c = size_t(b) * pb.Kp + u;
-    const float* po = pb.posOffset + 3 * c;
-    const float* pt = pb.posTarget + 3 * c;
-    un.v = t + qrot(q, s * F3{po[0], po[1], po[2]});
-    un.f = un.v - F3{pt[0], pt[1], pt[2]};
-    cw = pb.posWeight[c];
+    un.v = t + qrot(q, s * F3{in.a[0], in.a[1], in.a[2]});
+    un.f = un.v - F3{in.t[0], in.t[1], in.t[2]};
     fw = pb.wPos;
   } else {
     // OrientationErrorFunctionT::evalFunction (orientation_error_function.cpp:23-39)
     const int uo = u - pb.Kp;
-    const int co = uo / 3, k = uo - 3 * co;
-    const size_t c = size_t(b) * pb.Ko + co;
-    const float* oo = pb.oriOffset + 4 * c;
-    const float* ot = pb.oriTarget + 4 * c;
-    const Q4 qo = qnormalized(Q4{oo[0], oo[1], oo[2], oo[3]}); // ctor normalises (:33-35)
-    const Q4 qt = qnormalized(Q4{ot[0], ot[1], ot[2], ot[3]});
+    const int k = uo - 3 * (uo / 3);
+    const Q4 qo = qnormalized(Q4{in.a[0], in.a[1], in.a[2], in.a[3]}); // ctor normalises (:33-35)
+    const Q4 qt = qnormalized(Q4{in.t[0], in.t[1], in.t[2], in.t[3]});
     un.v = qrot(q, qmatCol(qo, k));
     un.f = un.v - qmatCol(qt, k);
-    cw = pb.oriWeight[c];
     fw = pb.wOri;
   }
   // joint_error_function-inl.h:197-213 ; a block with weight_ <= 0 is skipped entirely
   // (skeleton_solver_function.cpp:223-231) and a constraint with weight == 0 keeps zero rows
-  if (cw != 0.f && fw > 0.f) {
-    const float wgt = cw * fw;
+  if (in.cw != 0.f && fw > 0.f) {
+    const float wgt = in.cw * fw;
     un.werr = wgt * dot(un.f, un.f);
     un.sigma = sqrtf(wgt);
   }
   return un;
+}
+
+__device__ __forceinline__ Unit evalUnit(const ProblemDev& pb, const float* js, int b, int u) {
+  return evalUnitFrom(pb, loadUnitInput(pb, b, u), js, u);
 }
 
 // d(unit vector)/d(joint-parameter row (a,dof)) for a source term of a column; the three

@@ -708,17 +708,22 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         const bool diagLane = lane < 16;
         const int prow = 16 * (k + 1) + 48 * wave + (lane - 16); // panel row of lanes 16..63
         const bool active = diagLane || prow < NP;
+        // waves whose 48 panel rows all lie beyond the matrix only wait (wave-uniform branch)
+        const bool waveWorks = wave == 0 || 16 * (k + 1) + 48 * wave < NP;
         float* Tl = diagLane ? Dk : s.L + 256 * tileIndex((active ? prow : 16 * k) >> 4, k);
         const int trow = diagLane ? lane : (prow & 15);
         float a[16];
+        if (waveWorks) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
-          a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+            a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+          }
         }
         __syncthreads(); // every wave has read the diagonal block before wave 0 overwrites it
         float invd = 0.f;
         bool bad = false;
+        if (waveWorks) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const float djj = readLaneF(a[j], j);
@@ -749,6 +754,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           for (int c = 0; c < 16; ++c) {
             Tl[tileAddr(trow, c)] = a[c];
           }
+        }
         }
         __syncthreads();
         // panels taller than 4 x 48 rows: the remaining rows solve against the finished L_kk

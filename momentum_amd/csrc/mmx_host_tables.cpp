@@ -15,6 +15,10 @@ int32_t validateRigDesc(const mmx_rig_desc* d, std::string& err) {
     err = "rig needs at least one joint and one model parameter";
     return MMX_ERR_INVALID_ARGUMENT;
   }
+  if (J > 32767) {
+    err = "num_joints exceeds 32767 (joint and level indices are packed into 16 bits on the device)";
+    return MMX_ERR_INVALID_ARGUMENT;
+  }
   if (P > MMX_MAX_MODEL_PARAMS) {
     err = "num_params exceeds kMaxModelParams (2048)";
     return MMX_ERR_INVALID_ARGUMENT;

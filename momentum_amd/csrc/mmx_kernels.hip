@@ -43,6 +43,8 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   // one 20-float slot per joint, used in place: [0..7] local t,s,q -> world t,q,s ; [8..15] partial
   // rotations q1,q2 -> [8..16] rotation axes
   float* js = smem;
+  float* thL = js + ((kJs * rig.J + 3) & ~3); // [P] theta of this instance
+  int* jl = reinterpret_cast<int*>(thL + ((rig.P + 3) & ~3)); // [J] (parent + 1) << 16 | (jump target + 1)
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform on purpose: it indexes the column program, which must stay on the scalar unit
@@ -53,23 +55,95 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   }
   const float* th = theta + size_t(b) * rig.P;
 
+  // Everything the instance needs from global memory is requested up front, in ONE round of
+  // independent loads: theta and the level/parent table (-> LDS), the first joint's transform
+  // rows and the constraint payload of the first 64 units (-> registers).  FK then runs on LDS.
+  const bool ell = rig.ptEll != nullptr;
+  int4 rows[7];
+  float ptOff[7];
+  if (ell && tid < rig.J) {
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+      rows[d] = rig.ptEll[7 * tid + d];
+      ptOff[d] = rig.ptOffsets[7 * tid + d];
+    }
+  }
+  const bool needUnits = kWriteJac || res != nullptr || err != nullptr;
+  UnitInput uin0 = loadUnitInput(pb, b, needUnits ? lane : pb.U);
+  for (int i = tid; i < rig.P; i += NT) {
+    thL[i] = th[i];
+  }
+  for (int i = tid; i < rig.J; i += NT) {
+    jl[i] = rig.jumpParent[i];
+  }
+  __syncthreads();
   // local transforms of all joints at once (ParameterTransformT::apply + the theta-only part of
   // JointStateT::set), then SkeletonStateT::set's parent-before-child sweep as a sweep over tree
   // levels that only composes world = parent * local, then the rotation axes of all joints at once
-  for (int j = tid; j < rig.J; j += NT) {
-    fkLocalInPlace(rig, j, th, js);
+  if (ell) {
+    if (tid < rig.J) {
+      fkLocalFromRows(rig, tid, rows, ptOff, thL, js + kJs * tid);
+    }
+    for (int j = tid + NT; j < rig.J; j += NT) {
+#pragma unroll
+      for (int d = 0; d < 7; ++d) {
+        rows[d] = rig.ptEll[7 * j + d];
+        ptOff[d] = rig.ptOffsets[7 * j + d];
+      }
+      fkLocalFromRows(rig, j, rows, ptOff, thL, js + kJs * j);
+    }
+  } else {
+    for (int j = tid; j < rig.J; j += NT) {
+      fkLocalInPlace(rig, j, thL, js);
+    }
   }
   __syncthreads();
-  for (int l = 0; l < rig.numLevels; ++l) {
-    const int i1 = rig.levelStart[l + 1];
-    for (int i = rig.levelStart[l] + tid; i < i1; i += NT) {
-      fkComposeInPlace(rig, rig.levelOrder[i], js);
+  // World transforms by pointer jumping instead of a sweep over the tree levels: in every round
+  // each joint composes its partial product with the one of its current jump target and inherits
+  // that joint's target, T_j <- T_a * T_j, a_j <- a_a (parent-before-child composition of
+  // SkeletonStateT::set, skeleton_state.cpp:100-121, re-associated).  ceil(log2(depth)) rounds with
+  // every lane busy replace `depth` rounds with a handful of lanes each.  A joint may read a
+  // target that was already advanced in the same round: (T_a, a_a) are always read as a
+  // consistent pair, which keeps the invariant "T_j = product of the locals on the path
+  // (a_j, j]" -- within one wave by program order, across waves by the two barriers.
+  for (int r = 0; r < rig.jumpRounds; ++r) {
+    for (int j0 = 0; j0 < rig.J; j0 += NT) {
+      const int j = j0 + tid;
+      const int mine = j < rig.J ? jl[j] : 0;
+      const int a = (mine & 0xffff) - 1;
+      float* o = js + kJs * (j < rig.J ? j : 0);
+      F3 t{0.f, 0.f, 0.f};
+      Q4 q{0.f, 0.f, 0.f, 1.f};
+      float sc = 1.f;
+      int next = 0;
+      if (a >= 0) {
+        const float* p = js + kJs * a;
+        const F3 tp{p[0], p[1], p[2]};
+        const Q4 qp{p[3], p[4], p[5], p[6]};
+        const float sp = p[7];
+        next = jl[a] & 0xffff;
+        t = tp + qrot(qp, sp * F3{o[0], o[1], o[2]}); // transform.h:124-129
+        q = qmul(qp, Q4{o[3], o[4], o[5], o[6]});
+        sc = sp * o[7];
+      }
+      if (WPI > 1) {
+        __syncthreads();
+      }
+      if (a >= 0) {
+        o[0] = t.x, o[1] = t.y, o[2] = t.z;
+        o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
+        o[7] = sc;
+        jl[j] = (mine & ~0xffff) | next;
+      }
+      if (WPI > 1) {
+        __syncthreads();
+      }
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (kWriteJac) {
     for (int j = tid; j < rig.J; j += NT) {
-      fkAxesInPlace(rig, j, js);
+      fkAxesInPlaceP(rig, j, (jl[j] >> 16) - 1, js);
     }
     __syncthreads();
   }
@@ -87,7 +161,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   const size_t M = size_t(pb.M);
   for (int u0 = 0; u0 < pb.U; u0 += 64) {
     const int u = u0 + lane;
-    const Unit un = evalUnit(pb, js, b, u);
+    const Unit un = evalUnitFrom(pb, u0 == 0 ? uin0 : loadUnitInput(pb, b, u), js, u);
     errAcc += double(un.werr);
     if (res != nullptr && un.valid && wave == 0) {
       float* r = res + size_t(b) * M + 3 * size_t(u);
@@ -885,8 +959,8 @@ solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaIn
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (declared in mmx_kernels.hpp)
 // ---------------------------------------------------------------------------------------------
-size_t fkJacobianLdsBytes(int J) {
-  return size_t(kJs) * size_t(J) * sizeof(float);
+size_t fkJacobianLdsBytes(int J, int P) {
+  return (((size_t(kJs) * size_t(J) + 3) & ~size_t(3)) + ((size_t(P) + 3) & ~size_t(3)) + size_t(J)) * sizeof(float);
 }
 
 hipError_t launchFkJacobian(
@@ -899,7 +973,7 @@ hipError_t launchFkJacobian(
     float* state,
     const int32_t* done,
     hipStream_t stream) {
-  const size_t lds = fkJacobianLdsBytes(rig.J);
+  const size_t lds = fkJacobianLdsBytes(rig.J, rig.P);
   // one wave per instance fills the chip once B >> 256 CUs x ~24 resident waves; below that, four
   // waves per instance shorten the per-instance critical path
   const bool wide = pb.B < 2048; // measured: at B = 4096 one wave per instance (3.8 TB/s) beats four (3.2 TB/s)

@@ -77,7 +77,7 @@ hipError_t launchFusedSolve(
     long long* dbgClk,
     hipStream_t stream);
 
-size_t fkJacobianLdsBytes(int J);
+size_t fkJacobianLdsBytes(int J, int P);
 size_t normalEquationsLdsBytes(int n);
 size_t choleskyStepLdsBytes(int n, int M);
 
