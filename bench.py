@@ -213,6 +213,36 @@ def main() -> None:
         except Exception:
             traffic = None
     del jac
+    # context for the roofline: (i) the same kernel at the weak-scaling shard size of BASELINE
+    # configs[3] (32768 instances per GPU), where launch ramp-up and the FK prologue are amortised,
+    # (ii) what a plain write-only fill of the same byte count reaches on this box
+    extra = {}
+    if rank == 0 and world == 1:
+        def timed(fn, n):
+            for _ in range(2):
+                fn()
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for a, b in pairs:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize()
+            return float(np.mean([a.elapsed_time(b) for a, b in pairs]))
+
+        fill = torch.empty(bytes_per_launch // 4, dtype=torch.float32, device=dev)
+        fill_ms = timed(lambda: fill.zero_(), 5)
+        extra["fill_same_bytes_gbs"] = bytes_per_launch / (fill_ms * 1e-3) / 1e9
+        del fill
+        BL = 32768
+        if args.config == "cfg2" and B < BL:
+            rhL, pbL, _, thetaL = make_device_problem(rig, parents, BL, local_rank, seed + 1)
+            jacL = torch.empty((BL, P, M), dtype=torch.float32, device=dev)
+            resL = torch.empty((BL, M), dtype=torch.float32, device=dev)
+            errL = torch.empty((BL,), dtype=torch.float64, device=dev)
+            msL = timed(lambda: pbL.eval_jacobian(thetaL, jacL, resL, errL), 5)
+            gbsL = BL * algorithmic_bytes_per_instance(M, P, Kp_, Ko_) / (msL * 1e-3) / 1e9
+            extra["at_batch_32768"] = {"achieved": gbsL, "frac": gbsL / HBM_PEAK_GBS, "ms_per_launch": msL}
+            del jacL, resL, errL, pbL, rhL
 
     if rank == 0:
         solves = float(B) * world * args.steps
@@ -251,6 +281,8 @@ def main() -> None:
                 "traffic": traffic,
                 "bytes_per_launch": bytes_per_launch,
                 "ms_per_launch": jac_ms,
+                "batch": B,
+                **extra,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
