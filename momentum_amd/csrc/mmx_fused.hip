@@ -61,7 +61,7 @@ struct FusedLds {
   float* loc; // [kLoc J]
   float* own2; // [kC2 J]
   float* sub2; // [kC2 J]
-  float* L; // [T][256] tiles; diagonal slots hold the INVERSE of the diagonal Cholesky block
+  float* L; // [T][256] tiles; a diagonal tile holds L_kk (lower triangle) and L_kk^-T (strict upper triangle)
   // ---- aliases the refinement scratch (dfull, jd, tanOwn, tanPre): dead before phase J starts
   float* srcT; // [kSrc nsrc]
 };
@@ -213,83 +213,92 @@ __device__ __forceinline__ float blockSumF(const FusedLds& s, float v, int tid) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// blocked triangular solves with the factor in LDS.  Diagonal tiles hold L_kk (lower triangle,
-// exact zeros above), invDiag[i] = 1 / L(i,i).  The 16x16 diagonal solves run in wave 0 with one
-// row (forward) / one column (backward) of L_kk per lane and v_readlane broadcasts; the
-// off-diagonal updates use one thread per row.
+// (L L^T) x = b with the factor in LDS, by wave 0 alone and without a single workgroup barrier
+// inside.  Off-diagonal tiles hold L_jk; a diagonal tile holds L_kk in its lower triangle and the
+// strict upper triangle of L_kk^-T above it (written by the panel factorisation), invDiag[i] =
+// 1 / L(i,i) = the diagonal of L_kk^-T.  With the inverse of the diagonal blocks at hand a block
+// step is two short dot products instead of a 16-step substitution chain:
+//   forward :  y_k = L_kk^-1 (b_k - sum_{j<k} L_kj y_j)        backward:  x_k = L_kk^-T (y_k - sum_{j>k} L_jk^T x_j)
+// Lane 4 i + g owns row i of the current block and a quarter g of every dot product; quarters are
+// added with quad-permute DPP moves; the 16 right-hand sides of a block are exchanged through x
+// itself (LDS operations of one wave execute in program order).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float quadSum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); // lanes ^ 1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); // lanes ^ 2
+  return v;
+}
+
 template <int NB>
 __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, float* x, int tid) {
-  const int lane = tid & 63;
-  const int i = lane & 15;
-  // forward: L y = b
-  for (int k = 0; k < NB; ++k) {
-    const float* Dk = L + 256 * tileIndex(k, k);
-    if (tid < 64) {
-      float a[16];
+  if (tid < 64) {
+    const int i = tid >> 2, g = tid & 3;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = ldsRow4(Dk, i, q);
-        a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
-      }
-      float bi = x[16 * k + i];
-      const float invd = invDiag[16 * k + i];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float yj = readLaneF(bi, j) * readLaneF(invd, j);
-        bi = (i == j) ? yj : bi - a[j] * yj; // lanes i < j already hold their final y_i: a[j] = 0 there
-      }
-      if (lane < 16) {
-        x[16 * k + i] = bi;
-      }
-    }
-    __syncthreads();
-    const int r = 16 * (k + 1) + tid;
-    if (r < 16 * NB) {
-      const float* Tl = L + 256 * tileIndex(r >> 4, k);
-      const float4* xb = reinterpret_cast<const float4*>(x + 16 * k);
+    for (int k = 0; k < NB; ++k) { // forward
       float acc = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc = dot4(ldsRow4(Tl, r & 15, q), xb[q], acc);
+      for (int j = 0; j < k; ++j) {
+        acc = dot4(ldsRow4(L + 256 * tileIndex(k, j), i, g), *reinterpret_cast<const float4*>(x + 16 * j + 4 * g), acc);
       }
-      x[r] -= acc;
-    }
-    __syncthreads();
-  }
-  // backward: L^T x = y
-  for (int k = NB - 1; k >= 0; --k) {
-    const float* Dk = L + 256 * tileIndex(k, k);
-    if (tid < 64) {
-      float at[16]; // column i of L_kk: at[c] = L(c, i)
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        at[c] = Dk[tileAddr(c, i)];
-      }
-      float bi = x[16 * k + i];
+      acc = quadSum(acc);
+      float* xk = x + 16 * k;
+      const float rhs = xk[i] - acc;
       const float invd = invDiag[16 * k + i];
+      if (g == 0) {
+        xk[i] = rhs;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const float* Dk = L + 256 * tileIndex(k, k);
+      float p = 0.f;
 #pragma unroll
-      for (int j = 15; j >= 0; --j) {
-        const float xj = readLaneF(bi, j) * readLaneF(invd, j);
-        bi = (i == j) ? xj : bi - at[j] * xj; // lanes i > j: at[j] = L(j,i) = 0, value already final
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g; // L_kk^-1 (i, c) = L_kk^-T (c, i)
+        const float m = Dk[tileAddr(c, i)];
+        p += (c < i ? m : (c == i ? invd : 0.f)) * xk[c];
       }
-      if (lane < 16) {
-        x[16 * k + i] = bi;
+      p = quadSum(p);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (g == 0) {
+        xk[i] = p;
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    __syncthreads();
-    const int r = tid;
-    if (r < 16 * k) {
-      const float* Tl = L + 256 * tileIndex(k, r >> 4);
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k) { // backward
       float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        acc += Tl[tileAddr(c, r & 15)] * x[16 * k + c];
+      for (int j = k + 1; j < NB; ++j) {
+        const float* Tj = L + 256 * tileIndex(j, k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int c = 4 * t + g;
+          acc += Tj[tileAddr(c, i)] * x[16 * j + c]; // L(16 j + c, 16 k + i)
+        }
       }
-      x[r] -= acc;
+      acc = quadSum(acc);
+      float* xk = x + 16 * k;
+      const float rhs = xk[i] - acc;
+      const float invd = invDiag[16 * k + i];
+      if (g == 0) {
+        xk[i] = rhs;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const float4 row = ldsRow4(L + 256 * tileIndex(k, k), i, g); // L_kk^-T (i, 4g..4g+3)
+      const float4 rv = *reinterpret_cast<const float4*>(xk + 4 * g);
+      const int c0 = 4 * g;
+      float p = (c0 > i ? row.x : (c0 == i ? invd : 0.f)) * rv.x;
+      p += (c0 + 1 > i ? row.y : (c0 + 1 == i ? invd : 0.f)) * rv.y;
+      p += (c0 + 2 > i ? row.z : (c0 + 2 == i ? invd : 0.f)) * rv.z;
+      p += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * rv.w;
+      p = quadSum(p);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (g == 0) {
+        xk[i] = p;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    __syncthreads();
   }
+  __syncthreads();
 }
 
 // MODE 0: production; 1: also dump H / g of the first iteration (parity hook); 2: per-phase clocks
@@ -705,19 +714,30 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       //     v_readlane, so there is no LDS round trip and no barrier inside the dependent chain.
       {
         float* Dk = s.L + 256 * tileIndex(k, k);
+        // lanes 16..63 of the four waves enumerate "virtual" panel rows: the first 16 are rows of
+        // the identity, which the elimination turns into L_kk^-T (used by solveLLt), then come
+        // the real rows below the diagonal block
         const bool diagLane = lane < 16;
-        const int prow = 16 * (k + 1) + 48 * wave + (lane - 16); // panel row of lanes 16..63
-        const bool active = diagLane || prow < NP;
-        // waves whose 48 panel rows all lie beyond the matrix only wait (wave-uniform branch)
-        const bool waveWorks = wave == 0 || 16 * (k + 1) + 48 * wave < NP;
-        float* Tl = diagLane ? Dk : s.L + 256 * tileIndex((active ? prow : 16 * k) >> 4, k);
-        const int trow = diagLane ? lane : (prow & 15);
+        const int vrow = 48 * wave + (lane - 16);
+        const bool identLane = !diagLane && vrow < 16;
+        const int prow = 16 * k + vrow; // = 16 (k + 1) + (vrow - 16)
+        const bool panelLane = !diagLane && !identLane && prow < NP;
+        // waves whose 48 virtual rows all lie beyond the matrix only wait (wave-uniform branch)
+        const bool waveWorks = wave == 0 || 16 * k + 48 * wave < NP;
+        float* Tl = panelLane ? s.L + 256 * tileIndex(prow >> 4, k) : Dk;
+        const int trow = diagLane ? lane : (panelLane ? (prow & 15) : vrow);
         float a[16];
         if (waveWorks) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+            const float4 v = (diagLane || panelLane) ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
             a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+          }
+          if (identLane) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              a[c] = c == vrow ? 1.f : 0.f;
+            }
           }
         }
         __syncthreads(); // every wave has read the diagonal block before wave 0 overwrites it
@@ -725,40 +745,39 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         bool bad = false;
         if (waveWorks) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float djj = readLaneF(a[j], j);
-          bad = bad || !(djj > 0.f);
-          const float inv = __builtin_amdgcn_rsqf(djj); // 1 / l_jj ; l_jj = d_jj * inv
-          a[j] *= inv;
-          if (lane == j) {
-            invd = inv;
-          }
-#pragma unroll
-          for (int c = j + 1; c < 16; ++c) {
-            a[c] -= a[j] * readLaneF(a[j], c);
-          }
-        }
-        if (diagLane) {
-          if (wave == 0) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-              Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
+          for (int j = 0; j < 16; ++j) {
+            const float djj = readLaneF(a[j], j);
+            bad = bad || !(djj > 0.f);
+            const float inv = __builtin_amdgcn_rsqf(djj); // 1 / l_jj ; l_jj = d_jj * inv
+            a[j] *= inv;
+            if (lane == j) {
+              invd = inv;
             }
+#pragma unroll
+            for (int c = j + 1; c < 16; ++c) {
+              a[c] -= a[j] * readLaneF(a[j], c);
+            }
+          }
+          // one store loop for the three kinds of lanes: columns lo..hi of the lane's row
+          //   diagonal rows (wave 0): 0..row = L_kk ; identity rows: row+1..15 = L_kk^-T ; panel rows: all
+          const int lo = identLane ? vrow + 1 : ((diagLane && wave != 0) || !(diagLane || panelLane) ? 16 : 0);
+          const int hi = diagLane ? lane : 15;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (c >= lo && c <= hi) {
+              Tl[tileAddr(trow, c)] = a[c];
+            }
+          }
+          if (diagLane && wave == 0) {
             s.invDiag[16 * k + lane] = invd;
             if (bad) {
               s.flags[1] = 1;
             }
           }
-        } else if (active) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            Tl[tileAddr(trow, c)] = a[c];
-          }
-        }
         }
         __syncthreads();
-        // panels taller than 4 x 48 rows: the remaining rows solve against the finished L_kk
-        for (int r = 16 * (k + 1) + 192 + tid; r < NP; r += 256) {
+        // panels taller than the 176 rows of one pass: the remaining rows solve against the finished L_kk
+        for (int r = 16 * (k + 1) + 176 + tid; r < NP; r += 256) {
           float* Tr = s.L + 256 * tileIndex(r >> 4, k);
           float x[16];
 #pragma unroll
@@ -780,7 +799,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
             Tr[tileAddr(r & 15, c)] = x[c];
           }
         }
-        if (NP - 16 * (k + 1) > 192) {
+        if (NP - 16 * (k + 1) > 176) {
           __syncthreads();
         }
       }
