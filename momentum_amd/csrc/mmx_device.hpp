@@ -218,7 +218,8 @@ __device__ __forceinline__ void fkJoint(const RigDev& rig, int j, const float* j
 // ---------------------------------------------------------------------------------------------
 // local transform (t, q, s: the layout of a world transform) + partial rotations q1 = pre*Qz,
 // q2 = pre*Qz*Qy from the 7 joint parameters (joint_state.cpp:44-62)
-__device__ __forceinline__ void fkLocalFromParams(const float* jpv, const float* pre, const float* off, float* o) {
+__device__ __forceinline__ void
+fkLocalFromParams(const float* jpv, const float* pre, const float* off, float* o, float* oq) {
   float sx, cx, sy, cy, sz, cz;
   sincosf(0.5f * jpv[3], &sx, &cx);
   sincosf(0.5f * jpv[4], &sy, &cy);
@@ -230,12 +231,13 @@ __device__ __forceinline__ void fkLocalFromParams(const float* jpv, const float*
   o[0] = off[0] + jpv[0], o[1] = off[1] + jpv[1], o[2] = off[2] + jpv[2];
   o[3] = ql.x, o[4] = ql.y, o[5] = ql.z, o[6] = ql.w;
   o[7] = exp2f(jpv[6]);
-  o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w;
-  o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
+  oq[0] = q1.x, oq[1] = q1.y, oq[2] = q1.z, oq[3] = q1.w;
+  oq[4] = q2.x, oq[5] = q2.y, oq[6] = q2.z, oq[7] = q2.w;
 }
 
 template <class RigT>
-__device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* __restrict__ theta, float* o) {
+__device__ __forceinline__ void
+fkLocalSplit(const RigT& rig, int j, const float* __restrict__ theta, float* o, float* oq) {
   float jpv[7];
 #pragma unroll
   for (int d = 0; d < 7; ++d) {
@@ -247,7 +249,52 @@ __device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* _
     }
     jpv[d] = acc + rig.ptOffsets[r];
   }
-  fkLocalFromParams(jpv, rig.preRot + 4 * j, rig.offset + 3 * j, o);
+  fkLocalFromParams(jpv, rig.preRot + 4 * j, rig.offset + 3 * j, o, oq);
+}
+template <class RigT>
+__device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* __restrict__ theta, float* o) {
+  fkLocalSplit(rig, j, theta, o, o + 8);
+}
+
+// World transforms of all joints by double-buffered pointer jumping (see fkJacobianKernel for the
+// single-buffer form): `rounds` = ceil(log2(depth)) rounds, one workgroup barrier each.  Buffers:
+// js (stride kJs) and alt (stride 8), jump targets (+1) in jlA / jlB.  Precondition (barrier
+// done): the local transforms and the initial targets (= parents) are in js / jlA when `rounds`
+// is even, in alt / jlB when it is odd; the result always ends up in js.
+__device__ __forceinline__ void
+fkJumpRounds(float* js, float* alt, int* jlA, int* jlB, int J, int rounds, int tid, int nthreads) {
+  for (int r = 0; r < rounds; ++r) {
+    const bool fromJs = ((rounds - r) & 1) == 0;
+    const float* src = fromJs ? js : alt;
+    float* dst = fromJs ? alt : js;
+    const int ss = fromJs ? kJs : 8, ds = fromJs ? 8 : kJs;
+    const int* jlS = fromJs ? jlA : jlB;
+    int* jlD = fromJs ? jlB : jlA;
+    for (int j = tid; j < J; j += nthreads) {
+      const int a = jlS[j] - 1;
+      const float* o = src + ss * j;
+      F3 t{o[0], o[1], o[2]};
+      Q4 q{o[3], o[4], o[5], o[6]};
+      float sc = o[7];
+      int next = 0;
+      if (a >= 0) {
+        const float* p = src + ss * a;
+        const F3 tp{p[0], p[1], p[2]};
+        const Q4 qp{p[3], p[4], p[5], p[6]};
+        const float sp = p[7];
+        next = jlS[a];
+        t = tp + qrot(qp, sp * t); // transform.h:124-129
+        q = qmul(qp, q);
+        sc = sp * sc;
+      }
+      float* w = dst + ds * j;
+      w[0] = t.x, w[1] = t.y, w[2] = t.z;
+      w[3] = q.x, w[4] = q.y, w[5] = q.z, w[6] = q.w;
+      w[7] = sc;
+      jlD[j] = next;
+    }
+    __syncthreads();
+  }
 }
 
 // fkLocalTo with the joint's seven transform rows already in registers (RigDev::ptEll) and theta
@@ -268,7 +315,7 @@ fkLocalFromRows(const RigDev& rig, int j, const int4* rows, const float* ptOff, 
     }
     jpv[d] = acc + ptOff[d];
   }
-  fkLocalFromParams(jpv, rig.preRot + 4 * j, rig.offset + 3 * j, o);
+  fkLocalFromParams(jpv, rig.preRot + 4 * j, rig.offset + 3 * j, o, o + 8);
 }
 
 template <class RigT>

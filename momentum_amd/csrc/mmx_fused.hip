@@ -58,7 +58,9 @@ struct FusedLds {
   double* red; // [8]
   int* flags; // [4]
   // ---- one region, two lives: assembly scratch (phases A-G), then the Cholesky factor (H-J)
-  float* loc; // [kLoc J]
+  float* alt; // [8 J] second transform buffer of the pointer-jumping FK
+  int* jlA; // [J] jump targets (+1), double-buffered
+  int* jlB;
   float* own2; // [kC2 J]
   float* sub2; // [kC2 J]
   float* L; // [T][256] tiles; a diagonal tile holds L_kk (lower triangle) and L_kk^-T (strict upper triangle)
@@ -70,7 +72,7 @@ struct FusedLds {
 // pointers come straight from the LDS carve, so the compiler keeps the LDS address space (ds_read)
 // instead of falling back to flat loads.
 struct RigView {
-  int32_t J, P, R, numLevels;
+  int32_t J, P, R, numLevels, jumpRounds;
   const int32_t* parent;
   const float* preRot; // stays in global memory (read once per joint per iteration)
   const float* offset; // "
@@ -164,9 +166,31 @@ __device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, fl
   treeSumT<NC, kSubtree>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
 }
 
+// Forward kinematics of the whole skeleton from the parameters in `th` into s.js: local transforms
+// of all joints at once (parameter_transform.cpp:110-124, joint_state.cpp:44-62), world transforms
+// by pointer jumping (skeleton_state.cpp:100-121 re-associated), optionally the rotation axes.
+// Ends with a barrier.  Clobbers alt / jlA / jlB (assembly scratch = the Cholesky region).
+__device__ __forceinline__ void
+blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes) {
+  const bool odd = (rig.jumpRounds & 1) != 0;
+  for (int j = tid; j < rig.J; j += 256) {
+    float* slot = s.js + kJs * j;
+    fkLocalSplit(rig, j, th, odd ? s.alt + 8 * j : slot, slot + 8);
+    (odd ? s.jlB : s.jlA)[j] = rig.parent[j] + 1;
+  }
+  __syncthreads();
+  fkJumpRounds(s.js, s.alt, s.jlA, s.jlB, rig.J, rig.jumpRounds, tid, 256);
+  if (withAxes) {
+    for (int j = tid; j < rig.J; j += 256) {
+      fkAxesInPlaceP(rig, j, rig.parent[j], s.js);
+    }
+    __syncthreads();
+  }
+}
+
 // SkeletonSolverFunctionT::getError (skeleton_solver_function.cpp:64-83) of the parameters in
 // `th`: FK without derivatives + sum of w * |f|^2, rounded through float like the reference (:82).
-// Every thread returns the same value.  Clobbers loc / js / red.
+// Every thread returns the same value.  Clobbers the FK scratch / js / red.
 __device__ __forceinline__ double blockError(
     const RigView& rig,
     const ProblemDev& pb,
@@ -176,17 +200,7 @@ __device__ __forceinline__ double blockError(
     int b,
     int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  for (int j = tid; j < rig.J; j += 256) {
-    fkLocal(rig, j, th, s.loc);
-  }
-  __syncthreads();
-  for (int l = 0; l < rig.numLevels; ++l) {
-    const int i1 = rig.levelStart[l + 1];
-    for (int i = rig.levelStart[l] + tid; i < i1; i += 256) {
-      fkCompose(rig, rig.levelOrder[i], s.loc, s.js);
-    }
-    __syncthreads();
-  }
+  blockFk(rig, s, th, tid, false);
   double e = 0.0;
   for (int u = tid; u < fd.U; u += 256) {
     e += double(evalUnit(pb, s.js, b, u).werr);
@@ -384,7 +398,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
     }
     float* region = p;
-    s.loc = take(size_t(kLoc) * J);
+    s.alt = take(8 * size_t(J));
+    s.jlA = reinterpret_cast<int*>(take(J));
+    s.jlB = reinterpret_cast<int*>(take(J));
     s.own2 = take(size_t(kC2) * J);
     s.sub2 = take(size_t(kC2) * J);
     s.L = region;
@@ -441,7 +457,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   }
   // from here on the kernel reads the batch-shared tables through these LDS-backed views
   RigView rv;
-  rv.J = J, rv.P = P, rv.R = rig.R, rv.numLevels = rig.numLevels;
+  rv.J = J, rv.P = P, rv.R = rig.R, rv.numLevels = rig.numLevels, rv.jumpRounds = rig.jumpRounds;
   rv.parent = lParent, rv.preRot = rig.preRot, rv.offset = rig.offset;
   rv.ptOuter = lPtOuter, rv.ptInner = lPtInner, rv.ptValue = lPtValue, rv.ptOffsets = rig.ptOffsets;
   rv.levelOrder = lLevelOrder, rv.levelStart = lLevelStart;
@@ -476,26 +492,8 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     clkLast = clock64();
   }
   for (int it = 0; it < fp.maxIterations; ++it) {
-    // ================= A: per joint: joint parameters (transform * theta + offsets,
-    // parameter_transform.cpp:110-124), local transform and the partial rotations q1 = pre*Qz,
-    // q2 = pre*Qz*Qy (joint_state.cpp:44-62)
-    for (int j = tid; j < J; j += 256) {
-      fkLocal(rv, j, s.th, s.loc);
-    }
-    __syncthreads();
-    MMX_CLK(0)
-    // ================= B: world = parent * local by tree level (transform.h:124-129), then the
-    // rotation axes (q_p * q_partial) * e_index for all joints at once
-    for (int l = 0; l < rv.numLevels; ++l) {
-      const int i1 = rv.levelStart[l + 1];
-      for (int i = rv.levelStart[l] + tid; i < i1; i += 256) {
-        fkCompose(rv, rv.levelOrder[i], s.loc, s.js);
-      }
-      __syncthreads();
-    }
-    for (int j = tid; j < J; j += 256) {
-      fkAxes(rv, j, s.loc, s.js);
-    }
+    // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
+    blockFk(rv, s, s.th, tid, true);
     MMX_CLK(1)
     // ================= C: units (need only the world transforms, not the axes)
     {
@@ -1040,7 +1038,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
   const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 4;
   const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
   const size_t blockJ = refine > a4(size_t(kSrc) * nsrc) ? refine : a4(size_t(kSrc) * nsrc);
-  const size_t scratch = a4(size_t(kLoc) * J) + 2 * a4(size_t(kC2) * J);
+  const size_t scratch = a4(8 * size_t(J)) + 2 * a4(J) + 2 * a4(size_t(kC2) * J);
   const size_t region = scratch > T * 256 ? scratch : T * 256;
   return (meta + fixed + blockJ + region) * sizeof(float);
 }
