@@ -21,7 +21,7 @@ import csv, glob, json
 vals = {}
 for f in glob.glob("$O/pmc/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "fkJacobianKernel<true>" in r["Kernel_Name"]:
+        if "fkJacobianKernel<true" in r["Kernel_Name"]:
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in vals.items()}
 # WRITE_SIZE / FETCH_SIZE are in KiB; on gfx950 FETCH_SIZE under-counts wide streaming reads by 2x
