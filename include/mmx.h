@@ -103,6 +103,24 @@ typedef struct mmx_rig_desc {
  * mmx_problem_create.  Orientation quaternions are normalised on ingest like the
  * OrientationDataT constructor does (orientation_error_function.h:33-35).
  */
+/*
+ * One entry of Character::parameterLimits restricted to the limit types that act on MODEL
+ * parameters (momentum/character/parameter_limits.h:20-31,33-99,125-136): the rows of
+ * LimitErrorFunctionT that need no joint state.
+ */
+#define MMX_LIMIT_MINMAX 0 /* LimitType::MinMax    : index0 = parameterIndex ; v = {min, max} */
+#define MMX_LIMIT_LINEAR 3 /* LimitType::Linear    : index0 = referenceIndex, index1 = targetIndex ;
+                              v = {scale, offset, rangeMin, rangeMax}  (p_ref = scale * p_target - offset) */
+#define MMX_LIMIT_HALFPLANE 6 /* LimitType::HalfPlane : index0 = param1, index1 = param2 ;
+                                 v = {normal[0], normal[1], offset} */
+typedef struct mmx_parameter_limit {
+  int32_t type; /* MMX_LIMIT_* (values of momentum::LimitType) */
+  int32_t index0;
+  int32_t index1;
+  float weight; /* ParameterLimit::weight */
+  float v[4];
+} mmx_parameter_limit;
+
 typedef struct mmx_constraint_data {
   const float* pos_offset; /* [B][Kp][3] */
   const float* pos_target; /* [B][Kp][3] */
@@ -114,6 +132,17 @@ typedef struct mmx_constraint_data {
                                 (skeleton_error_function.h:44-141, setWeight) */
   float ori_function_weight; /* ... of the orientation block */
   int32_t memory; /* MMX_MEM_HOST: copied; MMX_MEM_DEVICE: borrowed, caller keeps alive */
+  /* ---- optional parameter-space blocks (all zero / NULL = absent); rows follow the
+     orientation rows: [3 Kp][9 Ko][num_limits][P if model_target != NULL] */
+  /* ModelParametersErrorFunctionT::setTargetParameters (model_parameters_error_function.h:48-51) */
+  const float* model_target; /* [B][P] targetParameters_, same memory kind as above */
+  const float* model_weights; /* [B][P] targetWeights_ */
+  float model_function_weight; /* weight_ of that block */
+  /* LimitErrorFunctionT::setLimits (limit_error_function.h:88-89): batch-shared, ALWAYS a host
+     pointer (copied) */
+  int32_t num_limits;
+  const mmx_parameter_limit* limits; /* [num_limits] */
+  float limit_function_weight; /* weight_ of that block */
 } mmx_constraint_data;
 
 /*

@@ -36,6 +36,43 @@ class RigDesc(C.Structure):
     ]
 
 
+MMX_LIMIT_MINMAX = 0  # momentum::LimitType values (character/parameter_limits.h:20-31)
+MMX_LIMIT_LINEAR = 3
+MMX_LIMIT_HALFPLANE = 6
+
+
+class ParameterLimit(C.Structure):
+    """mmx_parameter_limit: one model-parameter entry of Character::parameterLimits."""
+
+    _fields_ = [
+        ("type", C.c_int32),
+        ("index0", C.c_int32),
+        ("index1", C.c_int32),
+        ("weight", C.c_float),
+        ("v", C.c_float * 4),
+    ]
+
+    @classmethod
+    def minmax(cls, param, lo, hi, weight=1.0):
+        return cls(MMX_LIMIT_MINMAX, int(param), 0, float(weight), (C.c_float * 4)(lo, hi, 0.0, 0.0))
+
+    @classmethod
+    def linear(cls, reference, target, scale, offset, range_min=0.0, range_max=0.0, weight=1.0):
+        return cls(MMX_LIMIT_LINEAR, int(reference), int(target), float(weight), (C.c_float * 4)(scale, offset, range_min, range_max))
+
+    @classmethod
+    def halfplane(cls, param1, param2, n0, n1, offset, weight=1.0):
+        return cls(MMX_LIMIT_HALFPLANE, int(param1), int(param2), float(weight), (C.c_float * 4)(n0, n1, offset, 0.0))
+
+
+def limit_array(limits):
+    """ctypes array (kept alive by the caller) of ParameterLimit."""
+    arr = (ParameterLimit * max(len(limits), 1))()
+    for i, l in enumerate(limits):
+        arr[i] = l
+    return arr
+
+
 class ConstraintData(C.Structure):
     _fields_ = [
         ("pos_offset", C.c_void_p),
@@ -47,6 +84,13 @@ class ConstraintData(C.Structure):
         ("pos_function_weight", C.c_float),
         ("ori_function_weight", C.c_float),
         ("memory", C.c_int32),
+        # optional parameter-space blocks
+        ("model_target", C.c_void_p),
+        ("model_weights", C.c_void_p),
+        ("model_function_weight", C.c_float),
+        ("num_limits", C.c_int32),
+        ("limits", C.c_void_p),
+        ("limit_function_weight", C.c_float),
     ]
 
 

@@ -32,6 +32,8 @@
 #include <limits>
 #include <vector>
 
+#include "../include/mmx.h" // mmx_parameter_limit (descriptor types shared with the product ABI)
+
 namespace mmx_oracle {
 
 constexpr int kParametersPerJoint = 7; // momentum/character/types.h:21
@@ -281,10 +283,29 @@ struct Constraints {
   const float* oriWeight = nullptr; // [Ko]
   float posFunctionWeight = 1.f; // SkeletonErrorFunction::weight_
   float oriFunctionWeight = 1.f;
-  int rows() const {
+  // parameter-space blocks
+  int P = 0; // model parameters (needed for the row count of the model-parameter block)
+  int NL = 0; // LimitErrorFunctionT, limit types on model parameters (parameter_limits.h:20-31)
+  const mmx_parameter_limit* limits = nullptr; // [NL]
+  float limFunctionWeight = 0.f;
+  const float* mpTarget = nullptr; // [P] ModelParametersErrorFunctionT::targetParameters_
+  const float* mpWeights = nullptr; // [P] targetWeights_
+  float mpFunctionWeight = 0.f;
+  int jointRows() const {
     return 3 * Kp + 9 * Ko;
   }
+  int rows() const {
+    return jointRows() + NL + (mpTarget != nullptr ? P : 0);
+  }
 };
+
+// isInRange (momentum/character/parameter_limits.cpp:105-113)
+inline bool limitInRange(const mmx_parameter_limit& l, float value) {
+  if (l.v[2] == 0 && l.v[3] == 0) {
+    return true;
+  }
+  return value >= l.v[2] && value < l.v[3];
+}
 
 template <class T>
 inline T ln2() { // momentum/math/constants.h:30,40
@@ -465,6 +486,125 @@ inline double evalErrorFunctions(
   return total;
 }
 
+// LimitErrorFunctionT with the L2 loss, limit types MinMax / Linear / HalfPlane
+// (momentum/character_solver/limit_error_function.cpp: getErrorImpl :820-868 with
+// computeMinMaxError :32-60, computeLinearError :98-116, computeHalfPlaneError :148-168;
+// getJacobianImpl :992-1122 with computeMinMaxJacobian :460-503, computeLinearJacobian :561-595,
+// computeHalfPlaneJacobian :659-695) and ModelParametersErrorFunctionT
+// (model_parameters_error_function.cpp: getError :43-62, getJacobian :95-131).
+// Rows: rowBase + l for limit l, then the model-parameter rows compacted like the reference.
+template <class T>
+inline double evalParameterRows(const Constraints<T>& cs, const T* theta, const uint8_t* enabled, T* jac, T* res) {
+  const int M = cs.rows();
+  double total = 0.0;
+  int row = cs.jointRows();
+  if (cs.NL > 0 && cs.limFunctionWeight > 0.f) {
+    const float kLimitWeight = 1e+1f; // limit_error_function.h:91
+    const T tWeight = T(kLimitWeight * cs.limFunctionWeight); // :1007 (invC2 = 1)
+    double error = 0.0;
+    for (int l = 0; l < cs.NL; ++l) {
+      const mmx_parameter_limit& lm = cs.limits[l];
+      const T limitWeight = T(lm.weight);
+      const T wgt = std::sqrt(tWeight * limitWeight); // :1018-1021
+      const int r = row + l;
+      if (lm.type == MMX_LIMIT_MINMAX) {
+        const int p = lm.index0;
+        if (!enabled[p]) {
+          continue;
+        }
+        T val = T(0);
+        bool hit = false;
+        if (theta[p] < T(lm.v[0])) {
+          val = theta[p] - T(lm.v[0]);
+          hit = true;
+        }
+        if (theta[p] > T(lm.v[1])) { // the second test wins when both fire (:472,486)
+          val = theta[p] - T(lm.v[1]);
+          hit = true;
+        }
+        if (!hit) {
+          continue;
+        }
+        const T sqr = val * val;
+        if (jac == nullptr) {
+          error += double(limitWeight * sqr);
+        } else {
+          jac[size_t(p) * M + r] = wgt;
+          res[r] = val * wgt;
+          error += double(tWeight * limitWeight * sqr);
+        }
+      } else if (lm.type == MMX_LIMIT_LINEAR) {
+        const int ref = lm.index0, tgt = lm.index1;
+        if ((!enabled[tgt] && !enabled[ref]) || !limitInRange(lm, float(theta[tgt]))) {
+          continue;
+        }
+        const T rs = theta[tgt] * T(lm.v[0]) - T(lm.v[1]) - theta[ref];
+        const T sqr = rs * rs;
+        if (jac == nullptr) {
+          error += double(limitWeight * sqr);
+        } else {
+          res[r] = rs * wgt;
+          if (enabled[tgt]) {
+            jac[size_t(tgt) * M + r] = T(lm.v[0]) * wgt;
+          }
+          if (enabled[ref]) {
+            jac[size_t(ref) * M + r] = -wgt;
+          }
+          error += double(tWeight * limitWeight * sqr);
+        }
+      } else if (lm.type == MMX_LIMIT_HALFPLANE) {
+        const int p1 = lm.index0, p2 = lm.index1;
+        if (!enabled[p1] && !enabled[p2]) {
+          continue;
+        }
+        const T rs = theta[p1] * T(lm.v[0]) + theta[p2] * T(lm.v[1]) - T(lm.v[2]);
+        if (rs >= T(0)) {
+          continue;
+        }
+        const T sqr = rs * rs;
+        if (jac == nullptr) {
+          error += double(limitWeight * sqr);
+        } else {
+          res[r] = rs * wgt;
+          if (enabled[p1]) {
+            jac[size_t(p1) * M + r] = T(lm.v[0]) * wgt;
+          }
+          if (enabled[p2]) {
+            jac[size_t(p2) * M + r] = T(lm.v[1]) * wgt;
+          }
+          error += double(tWeight * limitWeight * sqr);
+        }
+      }
+    }
+    total += (jac == nullptr) ? error * double(kLimitWeight) * double(cs.limFunctionWeight) : error;
+  }
+  row += cs.NL;
+  if (cs.mpTarget != nullptr && cs.mpFunctionWeight > 0.f) {
+    const T kMotionWeight = T(1e-1); // model_parameters_error_function.h:61
+    const T weight = T(cs.mpFunctionWeight);
+    const float sWeight = std::sqrt(float(weight * kMotionWeight)); // :109 (a float in both instantiations)
+    double error = 0.0;
+    int out = 0;
+    for (int i = 0; i < cs.P; ++i) {
+      if (!enabled[i]) {
+        continue;
+      }
+      const T tw = T(cs.mpWeights[i]);
+      const T pdiff = tw * (theta[i] - T(cs.mpTarget[i]));
+      if (jac == nullptr) {
+        error += double(pdiff * pdiff); // getError sums every enabled parameter (:54-58)
+      } else if (tw > T(0)) {
+        error += double(pdiff * pdiff);
+        res[row + out] = pdiff * T(sWeight);
+        jac[size_t(i) * M + row + out] = T(sWeight) * tw;
+        ++out;
+      }
+    }
+    total += error * double(weight) * double(kMotionWeight);
+  }
+  return total;
+}
+
 // ---------------------------------------------------------------------------------------------
 // SkeletonSolverFunctionT (momentum/character_solver/skeleton_solver_function.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -501,7 +641,8 @@ struct SolverFunction {
   double getError(const T* theta) {
     applyParameterTransform<T>(rig, theta, jp.data());
     setSkeletonState<T>(rig, jp.data(), state);
-    const double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
+    double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
+    e += evalParameterRows<T>(cs, theta, enabled.data(), nullptr, nullptr);
     return double(float(e));
   }
   // :200-261 (initializeJacobianComputation + computeJacobianBlock for both blocks).  Blocks with
@@ -513,7 +654,9 @@ struct SolverFunction {
     const int M = cs.rows();
     std::fill(jac, jac + size_t(M) * rig.P, T(0));
     std::fill(res, res + M, T(0));
-    return evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
+    double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
+    e += evalParameterRows<T>(cs, theta, enabled.data(), jac, res);
+    return e;
   }
 };
 

@@ -40,7 +40,8 @@ Constraints<T> makeConstraints(
     int Ko,
     const int32_t* oriParent,
     const mmx_constraint_data* c,
-    size_t b) {
+    size_t b,
+    int P) {
   Constraints<T> cs;
   cs.Kp = Kp;
   cs.Ko = Ko;
@@ -54,6 +55,13 @@ Constraints<T> makeConstraints(
   cs.oriWeight = c->ori_weight ? c->ori_weight + b * Ko : nullptr;
   cs.posFunctionWeight = c->pos_function_weight;
   cs.oriFunctionWeight = c->ori_function_weight;
+  cs.P = P;
+  cs.NL = c->num_limits;
+  cs.limits = c->limits;
+  cs.limFunctionWeight = c->limit_function_weight;
+  cs.mpTarget = c->model_target ? c->model_target + b * size_t(P) : nullptr;
+  cs.mpWeights = c->model_weights ? c->model_weights + b * size_t(P) : nullptr;
+  cs.mpFunctionWeight = c->model_function_weight;
   return cs;
 }
 
@@ -130,7 +138,7 @@ int evalJacobian(
     T* res,
     double* err) {
   const Rig rig = makeRig(d);
-  SolverFunction<T> fn(rig, makeConstraints<T>(Kp, posParent, Ko, oriParent, c, 0));
+  SolverFunction<T> fn(rig, makeConstraints<T>(Kp, posParent, Ko, oriParent, c, 0, d->num_params));
   if (enabled) {
     fn.setEnabledParameters(enabled);
   }
@@ -152,7 +160,7 @@ int getError(
     const T* theta,
     double* err) {
   const Rig rig = makeRig(d);
-  SolverFunction<T> fn(rig, makeConstraints<T>(Kp, posParent, Ko, oriParent, c, 0));
+  SolverFunction<T> fn(rig, makeConstraints<T>(Kp, posParent, Ko, oriParent, c, 0, d->num_params));
   *err = fn.getError(theta);
   return 0;
 }
@@ -242,7 +250,7 @@ int solveBatch(
       }
       solveOne<T>(
           rig,
-          makeConstraints<T>(Kp, posParent, Ko, oriParent, c, size_t(b)),
+          makeConstraints<T>(Kp, posParent, Ko, oriParent, c, size_t(b), d->num_params),
           enabled,
           opt,
           theta + size_t(b) * rig.P,
@@ -344,7 +352,7 @@ extern "C" {
     const Rig rig = makeRig(d);                                                                          \
     return solveOne<T>(                                                                                  \
         rig,                                                                                             \
-        makeConstraints<T>(Kp, pp, Ko, op, c, 0),                                                        \
+        makeConstraints<T>(Kp, pp, Ko, op, c, 0, d->num_params),                                                        \
         en,                                                                                              \
         makeOptions(o, useBlockJtJ),                                                                     \
         theta,                                                                                           \

@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from momentum_amd._abi import ConstraintData, GnOptions, MMX_MEM_HOST, as_ptr, void_p
+from momentum_amd._abi import ConstraintData, GnOptions, MMX_MEM_HOST, as_ptr, limit_array, void_p
 from momentum_amd.rigs import Rig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -63,6 +63,11 @@ class Constraints:
         ori_weight,
         pos_function_weight: float = 1.0,
         ori_function_weight: float = 1.0,
+        limits=None,
+        limit_function_weight: float = 1.0,
+        model_target=None,
+        model_weights=None,
+        model_function_weight: float = 1.0,
     ):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         self.pos_parent = np.ascontiguousarray(pos_parent, dtype=np.int32).reshape(-1)
@@ -73,10 +78,22 @@ class Constraints:
         self.ori_offset, self.ori_target, self.ori_weight = f(ori_offset), f(ori_target), f(ori_weight)
         self.pos_function_weight = float(pos_function_weight)
         self.ori_function_weight = float(ori_function_weight)
+        # parameter-space blocks: a list of momentum_amd._abi.ParameterLimit (batch-shared) and the
+        # ModelParametersErrorFunction targets / weights ([P] or [B,P])
+        self.limits = list(limits) if limits else []
+        self._limit_array = limit_array(self.limits)
+        self.limit_function_weight = float(limit_function_weight)
+        self.model_target = None if model_target is None else f(model_target)
+        self.model_weights = None if model_weights is None else f(model_weights)
+        self.model_function_weight = float(model_function_weight)
+
+    @property
+    def P(self) -> int:
+        return 0 if self.model_target is None else int(self.model_target.shape[-1])
 
     @property
     def rows(self) -> int:
-        return 3 * self.Kp + 9 * self.Ko
+        return 3 * self.Kp + 9 * self.Ko + len(self.limits) + self.P
 
     def data(self) -> ConstraintData:
         return ConstraintData(
@@ -89,6 +106,12 @@ class Constraints:
             self.pos_function_weight,
             self.ori_function_weight,
             MMX_MEM_HOST,
+            void_p(self.model_target),
+            void_p(self.model_weights),
+            self.model_function_weight,
+            len(self.limits),
+            C.cast(self._limit_array, C.c_void_p) if self.limits else None,
+            self.limit_function_weight,
         )
 
     def instance(self, b: int) -> "Constraints":
@@ -104,6 +127,11 @@ class Constraints:
             self.ori_weight.reshape(-1, self.Ko)[b] if self.Ko else self.ori_weight,
             self.pos_function_weight,
             self.ori_function_weight,
+            self.limits,
+            self.limit_function_weight,
+            None if self.model_target is None else self.model_target.reshape(-1, self.P)[b if self.model_target.ndim > 1 else 0],
+            None if self.model_weights is None else self.model_weights.reshape(-1, self.P)[b if self.model_weights.ndim > 1 else 0],
+            self.model_function_weight,
         )
 
 
