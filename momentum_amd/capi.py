@@ -195,11 +195,19 @@ class Problem:
     def set_constraints(
         self, pos_offset, pos_target, pos_weight, ori_offset, ori_target, ori_weight,
         pos_function_weight: float = 1.0, ori_function_weight: float = 1.0,
+        limits=None, limit_function_weight: float = 1.0,
+        model_target=None, model_weights=None, model_function_weight: float = 1.0,
     ) -> None:  # fmt: skip
+        """limits: list of _abi.ParameterLimit (batch-shared, LimitErrorFunction);
+        model_target / model_weights: [B,P] (ModelParametersErrorFunction), same memory kind as the
+        constraint arrays.  Adds len(limits) + (P if model_target is given) rows to J / r."""
         import torch
 
         arrs = [pos_offset, pos_target, pos_weight, ori_offset, ori_target, ori_weight]
         shapes = [(self.B, self.Kp, 3), (self.B, self.Kp, 3), (self.B, self.Kp), (self.B, self.Ko, 4), (self.B, self.Ko, 4), (self.B, self.Ko)]
+        if model_target is not None:
+            arrs += [model_target, model_weights]
+            shapes += [(self.B, self.P), (self.B, self.P)]
         on_dev = all(isinstance(a, torch.Tensor) for a in arrs)
         keep, ptrs = [], []
         for a, shp in zip(arrs, shapes):
@@ -211,9 +219,17 @@ class Problem:
                 x = np.ascontiguousarray(a, dtype=np.float32).reshape(shp)
                 keep.append(x)
                 ptrs.append(C.c_void_p(x.ctypes.data if x.size else 0))
-        cd = ConstraintData(*ptrs, float(pos_function_weight), float(ori_function_weight), _abi.MMX_MEM_DEVICE if on_dev else _abi.MMX_MEM_HOST)
+        if model_target is None:
+            ptrs += [C.c_void_p(0), C.c_void_p(0)]
+        limits = list(limits) if limits else []
+        larr = _abi.limit_array(limits)
+        cd = ConstraintData(
+            *ptrs[:6], float(pos_function_weight), float(ori_function_weight), _abi.MMX_MEM_DEVICE if on_dev else _abi.MMX_MEM_HOST,
+            ptrs[6], ptrs[7], float(model_function_weight), len(limits), C.cast(larr, C.c_void_p) if limits else None, float(limit_function_weight),
+        )  # fmt: skip
         _check(lib().mmx_problem_set_constraints(self._h, C.byref(cd), _stream_ptr()))
         self._keep = keep if on_dev else []
+        self.M = int(lib().mmx_problem_num_rows(self._h))
 
     def _theta(self, theta):
         import torch

@@ -122,7 +122,8 @@ struct mmx_problem {
   DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb, dDfsJoint, dLoadedPos;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
-  DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight;
+  DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight, oMpTarget, oMpWeights, dLimits, dEnabledMask;
+  std::vector<mmx_parameter_limit> limits; // host copy (solve-list bookkeeping)
   bool haveConstraints = false;
   mmx::ProblemDev dev{};
   // scratch
@@ -166,6 +167,15 @@ int32_t uploadProblemTables(mmx_problem* pb) {
   d.colStart = pb->dColStart.as<int32_t>();
   d.colSources = pb->dColSources.as<mmx::ColumnSourceDev>();
   d.enabledList = pb->dEnabledList.as<int32_t>();
+  {
+    std::vector<uint8_t> mask(size_t(rig->P), 0);
+    for (int32_t p : t.enabledList) {
+      mask[size_t(p)] = 1;
+    }
+    MMX_HIP(upload(pb->dEnabledMask, mask));
+    d.enabledMask = pb->dEnabledMask.as<uint8_t>();
+    d.rowsJoint = 3 * pb->U;
+  }
   static_assert(sizeof(mmx::JacRec) == sizeof(mmx::JacRecDev) && sizeof(mmx::JacRec) == 32, "JacRec layouts must match");
   MMX_HIP(upload(pb->dJacRecs, t.jacRecs));
   MMX_HIP(upload(pb->dMultiCols, t.multiCols));
@@ -366,6 +376,9 @@ bool fusedUsable(const mmx_problem* pb) {
   const int nb = mmx::fusedBlocksFor(pb->fdev.n);
   if (nb < 0) {
     return false;
+  }
+  if (pb->M != 3 * pb->U) {
+    return false; // limit / model-parameter rows: three-kernel path
   }
   return pb->rig->J < 4096 &&
       mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rig->dev.numLevels) + size_t(8) * size_t(pb->rig->J + pb->rig->P) <= 160 * 1024;
@@ -732,6 +745,51 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   }
   d.wPos = c->pos_function_weight;
   d.wOri = c->ori_function_weight;
+  // ---- optional parameter-space blocks
+  const int32_t P = pb->rig->P;
+  if (c->num_limits < 0 || (c->num_limits > 0 && c->limits == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "limits: negative count or null array");
+  }
+  if ((c->model_target == nullptr) != (c->model_weights == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "model_target and model_weights must be given together");
+  }
+  for (int32_t l = 0; l < c->num_limits; ++l) {
+    const mmx_parameter_limit& lm = c->limits[l];
+    const bool two = lm.type == MMX_LIMIT_LINEAR || lm.type == MMX_LIMIT_HALFPLANE;
+    if (lm.type != MMX_LIMIT_MINMAX && !two) {
+      return fail(
+          MMX_ERR_UNSUPPORTED,
+          "limit " + std::to_string(l) + ": only the model-parameter limit types MinMax, Linear and HalfPlane are implemented");
+    }
+    if (lm.index0 < 0 || lm.index0 >= P || (two && (lm.index1 < 0 || lm.index1 >= P))) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "limit " + std::to_string(l) + ": parameter index out of range"); // MT_CHECK :574-575
+    }
+  }
+  pb->limits.assign(c->limits, c->limits + c->num_limits);
+  static_assert(sizeof(mmx_parameter_limit) == sizeof(mmx::LimitDev) && sizeof(mmx::LimitDev) == 32, "limit layouts must match");
+  MMX_HIP(upload(pb->dLimits, pb->limits));
+  d.NL = c->num_limits;
+  d.limits = pb->dLimits.as<mmx::LimitDev>();
+  d.wLimit = c->limit_function_weight;
+  d.hasModel = c->model_target != nullptr ? 1 : 0;
+  d.wModel = c->model_function_weight;
+  if (d.hasModel) {
+    if (c->memory == MMX_MEM_DEVICE) {
+      d.mpTarget = c->model_target;
+      d.mpWeights = c->model_weights;
+    } else {
+      MMX_HIP(pb->oMpTarget.ensure(B * P * sizeof(float)));
+      MMX_HIP(pb->oMpWeights.ensure(B * P * sizeof(float)));
+      MMX_HIP(hipMemcpy(pb->oMpTarget.p, c->model_target, B * P * sizeof(float), hipMemcpyHostToDevice));
+      MMX_HIP(hipMemcpy(pb->oMpWeights.p, c->model_weights, B * P * sizeof(float), hipMemcpyHostToDevice));
+      d.mpTarget = pb->oMpTarget.as<float>();
+      d.mpWeights = pb->oMpWeights.as<float>();
+    }
+  } else {
+    d.mpTarget = d.mpWeights = nullptr;
+  }
+  pb->M = 3 * pb->U + d.NL + (d.hasModel ? P : 0);
+  d.M = pb->M;
   pb->haveConstraints = true;
   return MMX_OK;
 }

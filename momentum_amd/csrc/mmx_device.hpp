@@ -118,6 +118,13 @@ struct RigDev {
   int32_t jumpRounds; // ceil(log2(numLevels)): pointer-jumping rounds that finish every joint
 };
 
+// == mmx_parameter_limit (include/mmx.h)
+struct LimitDev {
+  int32_t type, index0, index1;
+  float weight;
+  float v[4];
+};
+
 struct ProblemDev {
   int32_t B, Kp, Ko, U, M, n; // U = Kp + 3 Ko constraint vectors, M = 3 U rows, n = #enabled
   const int32_t* unitJoint; // [U] parent joint of the unit's constraint
@@ -136,6 +143,16 @@ struct ProblemDev {
   const float* oriTarget; // [B][Ko][4]
   const float* oriWeight; // [B][Ko]
   float wPos, wOri; // SkeletonErrorFunction::weight_ of the two blocks
+  // ---- parameter-space blocks (rows rowsJoint .. M-1): LimitErrorFunctionT on model parameters,
+  // ModelParametersErrorFunctionT.  M = rowsJoint + NL + (hasModel ? P : 0).
+  int32_t rowsJoint; // 3 U
+  int32_t NL; // limits (one row each)
+  int32_t hasModel; // model-parameter block present (P rows, used rows compacted to the top)
+  const LimitDev* limits; // [NL]
+  float wLimit, wModel; // weight_ of the two blocks
+  const float* mpTarget; // [B][P]
+  const float* mpWeights; // [B][P]
+  const uint8_t* enabledMask; // [P]
 };
 
 // ---------------------------------------------------------------------------------------------

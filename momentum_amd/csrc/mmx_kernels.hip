@@ -245,6 +245,207 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
 }
 
 // =============================================================================================
+// Kernel 1b: the parameter-space rows of J / r (rows rowsJoint .. M-1 of every column) and their
+// error.  grid = B, block = 256.  Launched after fkJacobianKernel when the problem carries limits
+// or model-parameter targets; adds its error to err[b].
+//
+// Replaces LimitErrorFunctionT::getJacobian for the model-parameter limit types with the L2 loss
+// (momentum/character_solver/limit_error_function.cpp:992-1122: computeMinMaxJacobian :460-503,
+// computeLinearJacobian :561-595, computeHalfPlaneJacobian :659-695; kLimitWeight
+// limit_error_function.h:91) and ModelParametersErrorFunctionT::getJacobian
+// (model_parameters_error_function.cpp:95-131; used rows compacted like `out` there).
+// =============================================================================================
+struct LimitRow {
+  int ia, ib; // model parameters with a non-zero entry (-1: none)
+  float ca, cb; // the entries
+  float r; // residual entry
+  float err; // this row's error term
+};
+
+__device__ __forceinline__ LimitRow evalLimit(const LimitDev& lm, const float* th, const uint8_t* enabled, float tWeight) {
+  LimitRow o;
+  o.ia = o.ib = -1;
+  o.ca = o.cb = o.r = o.err = 0.f;
+  const float wgt = sqrtf(tWeight * lm.weight); // :1018-1021
+  if (lm.type == 0) { // MinMax
+    const int p = lm.index0;
+    if (!enabled[p]) {
+      return o;
+    }
+    float val = 0.f;
+    bool hit = false;
+    if (th[p] < lm.v[0]) {
+      val = th[p] - lm.v[0];
+      hit = true;
+    }
+    if (th[p] > lm.v[1]) {
+      val = th[p] - lm.v[1];
+      hit = true;
+    }
+    if (hit) {
+      o.ia = p;
+      o.ca = wgt;
+      o.r = val * wgt;
+      o.err = tWeight * lm.weight * (val * val);
+    }
+  } else if (lm.type == 3) { // Linear: p_ref = scale * p_tgt - offset
+    const int ref = lm.index0, tgt = lm.index1;
+    const bool inRange = (lm.v[2] == 0.f && lm.v[3] == 0.f) || (th[tgt] >= lm.v[2] && th[tgt] < lm.v[3]); // parameter_limits.cpp:105-113
+    if ((!enabled[tgt] && !enabled[ref]) || !inRange) {
+      return o;
+    }
+    const float rs = th[tgt] * lm.v[0] - lm.v[1] - th[ref];
+    o.r = rs * wgt;
+    if (enabled[tgt]) {
+      o.ia = tgt;
+      o.ca = lm.v[0] * wgt;
+    }
+    if (enabled[ref]) {
+      o.ib = ref;
+      o.cb = -wgt;
+    }
+    o.err = tWeight * lm.weight * (rs * rs);
+  } else if (lm.type == 6) { // HalfPlane: (p1, p2) . normal - offset >= 0
+    const int p1 = lm.index0, p2 = lm.index1;
+    if (!enabled[p1] && !enabled[p2]) {
+      return o;
+    }
+    const float rs = th[p1] * lm.v[0] + th[p2] * lm.v[1] - lm.v[2];
+    if (rs >= 0.f) {
+      return o;
+    }
+    o.r = rs * wgt;
+    if (enabled[p1]) {
+      o.ia = p1;
+      o.ca = lm.v[0] * wgt;
+    }
+    if (enabled[p2]) {
+      o.ib = p2;
+      o.cb = lm.v[1] * wgt;
+    }
+    o.err = tWeight * lm.weight * (rs * rs);
+  }
+  return o;
+}
+
+__global__ void __launch_bounds__(256) parameterRowsKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ theta,
+    float* __restrict__ jac, // or null
+    float* __restrict__ res, // or null
+    double* __restrict__ err, // or null: err[b] += error of these blocks
+    const int32_t* __restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (done != nullptr && done[b] != 0) {
+    return;
+  }
+  const int NL = pb.NL, R0 = pb.rowsJoint;
+  const int Pm = pb.hasModel ? P : 0;
+  int* outOf = reinterpret_cast<int*>(smem); // [P] compacted model row of parameter i, or -1
+  int* ia = outOf + P; // [NL]
+  int* ib = ia + NL;
+  float* ca = reinterpret_cast<float*>(ib + NL);
+  float* cb = ca + NL;
+  double* red = reinterpret_cast<double*>(smem + ((P + 4 * NL + 1) & ~1)); // [4]
+  __shared__ int numUsed;
+  const float* th = theta + size_t(b) * P;
+  const size_t M = size_t(pb.M);
+  float* rb = res != nullptr ? res + size_t(b) * M : nullptr;
+  double e = 0.0;
+  // ---- limits: one thread per limit
+  const bool limOn = pb.wLimit > 0.f; // a block with weight_ <= 0 is skipped (skeleton_solver_function.cpp:228,250)
+  const float tWeight = 1e+1f * pb.wLimit;
+  for (int l = tid; l < NL; l += 256) {
+    LimitRow o;
+    o.ia = o.ib = -1;
+    o.ca = o.cb = o.r = o.err = 0.f;
+    if (limOn) {
+      o = evalLimit(pb.limits[l], th, pb.enabledMask, tWeight);
+    }
+    ia[l] = o.ia, ib[l] = o.ib, ca[l] = o.ca, cb[l] = o.cb;
+    if (rb != nullptr) {
+      rb[R0 + l] = o.r;
+    }
+    e += double(o.err);
+  }
+  // ---- model-parameter rows: compaction map by wave 0 (ballot prefix), then one thread per parameter
+  const bool mpOn = Pm > 0 && pb.wModel > 0.f;
+  const float* tp = Pm > 0 ? pb.mpTarget + size_t(b) * P : nullptr;
+  const float* tw = Pm > 0 ? pb.mpWeights + size_t(b) * P : nullptr;
+  if (Pm > 0 && wave == 0) {
+    int base = 0;
+    for (int i0 = 0; i0 < P; i0 += 64) {
+      const int i = i0 + lane;
+      const bool f = mpOn && i < P && pb.enabledMask[i] != 0 && tw[i] > 0.f;
+      const unsigned long long m = __ballot(f);
+      if (i < P) {
+        outOf[i] = f ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+      }
+      base += __popcll(m);
+    }
+    if (lane == 0) {
+      numUsed = base;
+    }
+  }
+  __syncthreads();
+  if (Pm > 0) {
+    const float sWeight = sqrtf(pb.wModel * 1e-1f); // kMotionWeight, model_parameters_error_function.h:61
+    double em = 0.0;
+    for (int i = tid; i < P; i += 256) {
+      const int out = outOf[i];
+      if (out >= 0) {
+        const float pdiff = tw[i] * (th[i] - tp[i]);
+        em += double(pdiff * pdiff);
+        if (rb != nullptr) {
+          rb[R0 + NL + out] = pdiff * sWeight;
+        }
+      }
+    }
+    e += em * double(pb.wModel) * double(1e-1f);
+    if (rb != nullptr) {
+      for (int r = numUsed + tid; r < P; r += 256) {
+        rb[R0 + NL + r] = 0.f;
+      }
+    }
+  }
+  if (err != nullptr) {
+    e = waveReduceSum(e);
+    if (lane == 0) {
+      red[wave] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      err[b] += (red[0] + red[1]) + (red[2] + red[3]);
+    }
+  }
+  // ---- the Jacobian rows: column p = a wave, rows = lanes; every element is written
+  if (jac != nullptr) {
+    const int R = NL + Pm;
+    const float sWeight = Pm > 0 ? sqrtf(pb.wModel * 1e-1f) : 0.f;
+    for (int p = wave; p < P; p += 4) {
+      float* col = jac + size_t(b) * M * size_t(P) + size_t(p) * M + R0;
+      const int mine = Pm > 0 ? outOf[p] : -1;
+      const float mval = mine >= 0 ? sWeight * tw[p] : 0.f;
+      for (int rr = lane; rr < R; rr += 64) {
+        float v = 0.f;
+        if (rr < NL) {
+          v = (ia[rr] == p ? ca[rr] : 0.f) + (ib[rr] == p ? cb[rr] : 0.f);
+        } else if (rr - NL == mine) {
+          v = mval;
+        }
+        col[rr] = v;
+      }
+    }
+  }
+}
+
+size_t parameterRowsLdsBytes(int P, int NL) {
+  return (size_t((P + 4 * NL + 1) & ~1) + 8) * sizeof(float);
+}
+
+// =============================================================================================
 // Kernel 2: normal equations from the dense Jacobian.  grid = B, block = 256.
 // H = J[:,E]^T J[:,E] (full symmetric n x n), g = J[:,E]^T r, E = enabled parameter list.
 // Replaces the column compaction + `H.triangularView<Lower>() += J^T J; JtR += J^T r` of
@@ -989,6 +1190,10 @@ hipError_t launchFkJacobian(
     } else {
       hipLaunchKernelGGL((fkJacobianKernel<false, 1>), dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
     }
+  }
+  if (pb.M > pb.rowsJoint && (jac != nullptr || res != nullptr || err != nullptr)) {
+    hipLaunchKernelGGL(
+        parameterRowsKernel, dim3(pb.B), dim3(256), parameterRowsLdsBytes(rig.P, pb.NL), stream, pb, rig.P, theta, jac, res, err, done);
   }
   return hipGetLastError();
 }
