@@ -12,6 +12,7 @@
 #include <cstring>
 #include <algorithm>
 #include <new>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -120,6 +121,7 @@ struct mmx_problem {
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
   DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb, dDfsJoint, dLoadedPos;
+  DevBuf dLimStart, dLimOf, dPairDest, dPairStart, dPairLim;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight, oMpTarget, oMpWeights, dLimits, dEnabledMask;
@@ -190,8 +192,16 @@ int32_t uploadProblemTables(mmx_problem* pb) {
   {
     const mmx_rig_desc rd = rig->desc();
     std::string err;
+    // parameters touched by a limit or (all of them) by the model-parameter block stay in the solve list
+    std::vector<uint8_t> force(size_t(rig->P), pb->dev.hasModel ? 1 : 0);
+    for (const mmx_parameter_limit& lm : pb->limits) {
+      force[size_t(lm.index0)] = 1;
+      if (lm.type != MMX_LIMIT_MINMAX) {
+        force[size_t(lm.index1)] = 1;
+      }
+    }
     const int32_t rc = mmx::buildFusedTables(
-        &rd, t, pb->Kp, pb->posParent.data(), pb->Ko, pb->oriParent.data(), pb->fused, err);
+        &rd, t, pb->Kp, pb->posParent.data(), pb->Ko, pb->oriParent.data(), force.data(), pb->fused, err);
     if (rc != MMX_OK) {
       return fail(rc, err);
     }
@@ -368,6 +378,53 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       fd.gTerms = pb->dTerms.as<uint4>();
       fd.termRounds = int32_t(rounds);
     }
+    // limits per solve column, and the limits that share an off-diagonal entry of H
+    {
+      std::vector<int32_t> colOf(size_t(rig->P), -1);
+      for (int32_t c = 0; c < fd.n; ++c) {
+        colOf[size_t(f.solveList[c])] = c;
+      }
+      std::vector<std::vector<int32_t>> per(size_t(std::max(fd.n, 1)));
+      std::map<int32_t, std::vector<int32_t>> pairs; // tile-region offset -> limits
+      for (size_t l = 0; l < pb->limits.size(); ++l) {
+        const mmx_parameter_limit& lm = pb->limits[l];
+        const int32_t c0 = colOf[size_t(lm.index0)];
+        const int32_t c1 = lm.type != MMX_LIMIT_MINMAX ? colOf[size_t(lm.index1)] : -1;
+        if (c0 >= 0) {
+          per[size_t(c0)].push_back(int32_t(l));
+        }
+        if (c1 >= 0 && c1 != c0) {
+          per[size_t(c1)].push_back(int32_t(l));
+        }
+        if (c0 >= 0 && c1 >= 0 && c0 != c1) {
+          const int32_t row = std::max(c0, c1), col = std::min(c0, c1);
+          const int I = row >> 4, Jc = col >> 4, r = row & 15, c = col & 15;
+          pairs[(I * (I + 1) / 2 + Jc) * 256 + r * 16 + ((((c >> 2) ^ (r >> 2)) & 3) << 2) + (c & 3)].push_back(int32_t(l));
+        }
+      }
+      std::vector<int32_t> limStart(1, 0), limOf, pairDest, pairStart(1, 0), pairLim;
+      for (int32_t c = 0; c < fd.n; ++c) {
+        limOf.insert(limOf.end(), per[size_t(c)].begin(), per[size_t(c)].end());
+        limStart.push_back(int32_t(limOf.size()));
+      }
+      for (const auto& kv : pairs) {
+        pairDest.push_back(kv.first);
+        pairLim.insert(pairLim.end(), kv.second.begin(), kv.second.end());
+        pairStart.push_back(int32_t(pairLim.size()));
+      }
+      MMX_HIP(upload(pb->dLimStart, limStart));
+      MMX_HIP(upload(pb->dLimOf, limOf));
+      MMX_HIP(upload(pb->dPairDest, pairDest));
+      MMX_HIP(upload(pb->dPairStart, pairStart));
+      MMX_HIP(upload(pb->dPairLim, pairLim));
+      fd.numLimits = int32_t(pb->limits.size());
+      fd.limStart = pb->dLimStart.as<int32_t>();
+      fd.limOf = pb->dLimOf.as<int32_t>();
+      fd.numPairDests = int32_t(pairDest.size());
+      fd.pairDest = pb->dPairDest.as<int32_t>();
+      fd.pairStart = pb->dPairStart.as<int32_t>();
+      fd.pairLim = pb->dPairLim.as<int32_t>();
+    }
   }
   return MMX_OK;
 }
@@ -376,9 +433,6 @@ bool fusedUsable(const mmx_problem* pb) {
   const int nb = mmx::fusedBlocksFor(pb->fdev.n);
   if (nb < 0) {
     return false;
-  }
-  if (pb->M != 3 * pb->U) {
-    return false; // limit / model-parameter rows: three-kernel path
   }
   return pb->rig->J < 4096 &&
       mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rig->dev.numLevels) + size_t(8) * size_t(pb->rig->J + pb->rig->P) <= 160 * 1024;
@@ -765,6 +819,8 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
       return fail(MMX_ERR_INVALID_ARGUMENT, "limit " + std::to_string(l) + ": parameter index out of range"); // MT_CHECK :574-575
     }
   }
+  const bool structureChanged = (c->model_target != nullptr) != (d.hasModel != 0) || size_t(c->num_limits) != pb->limits.size() ||
+      (c->num_limits > 0 && std::memcmp(c->limits, pb->limits.data(), size_t(c->num_limits) * sizeof(mmx_parameter_limit)) != 0);
   pb->limits.assign(c->limits, c->limits + c->num_limits);
   static_assert(sizeof(mmx_parameter_limit) == sizeof(mmx::LimitDev) && sizeof(mmx::LimitDev) == 32, "limit layouts must match");
   MMX_HIP(upload(pb->dLimits, pb->limits));
@@ -790,6 +846,12 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   }
   pb->M = 3 * pb->U + d.NL + (d.hasModel ? P : 0);
   d.M = pb->M;
+  if (structureChanged) { // the fused kernel's solve list and limit tables depend on it
+    rc = uploadProblemTables(pb);
+    if (rc != MMX_OK) {
+      return rc;
+    }
+  }
   pb->haveConstraints = true;
   return MMX_OK;
 }

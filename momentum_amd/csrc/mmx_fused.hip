@@ -166,6 +166,89 @@ __device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, fl
   treeSumT<NC, kSubtree>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// parameter-space rows (LimitErrorFunctionT on model parameters, ModelParametersErrorFunctionT):
+// they need no joint state, so their contributions to the error, to g / H and to the refinement
+// are evaluated on the fly from theta -- no extra LDS, nothing stored per row.
+// ---------------------------------------------------------------------------------------------
+// this thread's share of the blocks' error at the parameters `th`.  kJacobianRows: the value
+// getJacobian returns (model rows with weight <= 0 are skipped, model_parameters_error_function.cpp:113),
+// else the one getError returns (:54-58).
+template <bool kJacobianRows>
+__device__ __forceinline__ double paramRowsError(const ProblemDev& pb, int P, const float* th, int b, int tid) {
+  double e = 0.0;
+  if (pb.NL > 0 && pb.wLimit > 0.f) {
+    const float tWeight = 1e+1f * pb.wLimit;
+    for (int l = tid; l < pb.NL; l += 256) {
+      e += double(evalLimit(pb.limits[l], th, pb.enabledMask, tWeight).err);
+    }
+  }
+  if (pb.hasModel && pb.wModel > 0.f) {
+    const float* tp = pb.mpTarget + size_t(b) * P;
+    const float* tw = pb.mpWeights + size_t(b) * P;
+    double em = 0.0;
+    for (int i = tid; i < P; i += 256) {
+      if (pb.enabledMask[i] != 0) {
+        const float w = tw[i];
+        if (!kJacobianRows || w > 0.f) {
+          const float pd = w * (th[i] - tp[i]);
+          em += double(pd * pd);
+        }
+      }
+    }
+    e += em * double(pb.wModel) * double(1e-1f);
+  }
+  return e;
+}
+
+struct ParamCol {
+  float g, h;
+};
+
+// contributions of the rows to solve column c = parameter p: g_c = sum_l J(l,c) r_l and
+// H_cc = sum_l J(l,c)^2.  With a step `d0` the residual is replaced by r - J d0 (refinement).
+__device__ __forceinline__ ParamCol paramRowsColumn(
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    const float* th,
+    const float* d0,
+    const int* colToSolve,
+    int P,
+    int b,
+    int c,
+    int p) {
+  ParamCol o{0.f, 0.f};
+  if (fd.numLimits > 0 && pb.wLimit > 0.f) {
+    const float tWeight = 1e+1f * pb.wLimit;
+    const int k1 = fd.limStart[c + 1];
+    for (int k = fd.limStart[c]; k < k1; ++k) {
+      const LimitRow row = evalLimit(pb.limits[fd.limOf[k]], th, pb.enabledMask, tWeight);
+      const float coef = (row.ia == p ? row.ca : 0.f) + (row.ib == p ? row.cb : 0.f);
+      float rr = row.r;
+      if (d0 != nullptr) {
+        const int sa = row.ia >= 0 ? colToSolve[row.ia] : -1, sb = row.ib >= 0 ? colToSolve[row.ib] : -1;
+        rr -= row.ca * (sa >= 0 ? d0[sa] : 0.f) + row.cb * (sb >= 0 ? d0[sb] : 0.f);
+      }
+      o.g += coef * rr;
+      o.h += coef * coef;
+    }
+  }
+  if (pb.hasModel && pb.wModel > 0.f) {
+    const float w = pb.mpWeights[size_t(b) * P + p];
+    if (w > 0.f) {
+      const float sWeight = sqrtf(pb.wModel * 1e-1f);
+      const float a = sWeight * w;
+      float rr = (w * (th[p] - pb.mpTarget[size_t(b) * P + p])) * sWeight;
+      if (d0 != nullptr) {
+        rr -= a * d0[c];
+      }
+      o.g += a * rr;
+      o.h += a * a;
+    }
+  }
+  return o;
+}
+
 // Forward kinematics of the whole skeleton from the parameters in `th` into s.js: local transforms
 // of all joints at once (parameter_transform.cpp:110-124, joint_state.cpp:44-62), world transforms
 // by pointer jumping (skeleton_state.cpp:100-121 re-associated), optionally the rotation axes.
@@ -204,6 +287,9 @@ __device__ __forceinline__ double blockError(
   double e = 0.0;
   for (int u = tid; u < fd.U; u += 256) {
     e += double(evalUnit(pb, s.js, b, u).werr);
+  }
+  if (pb.M > pb.rowsJoint) {
+    e += paramRowsError<false>(pb, rig.P, th, b, tid);
   }
   e = waveReduceSum(e);
   if (lane == 0) {
@@ -482,6 +568,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     tI[q] = __builtin_amdgcn_readfirstlane(I);
     tJ[q] = __builtin_amdgcn_readfirstlane(Jc);
   }
+  const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
   float lambda = fp.lambda; // constant for GaussNewtonSolverT, adapted by the LM schedule
   double curError = DBL_MAX;
@@ -506,6 +593,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         s.uy[3 * u] = un.sigma * rx, s.uy[3 * u + 1] = un.sigma * ry, s.uy[3 * u + 2] = un.sigma * rz;
         s.us[u] = un.sigma;
         e += double(un.werr);
+      }
+      if (hasParamRows) {
+        e += paramRowsError<true>(pb, P, s.th, b, tid);
       }
       e = waveReduceSum(e);
       if (lane == 0) {
@@ -585,6 +675,11 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       for (int e = s.mStart[c]; e < e1; ++e) {
         acc += s.mW[e] * s.srcT[kSrc * e + 14];
       }
+      if (hasParamRows && c < n) {
+        const ParamCol pc = paramRowsColumn(pb, fd, s.th, nullptr, lColToSolve, P, b, c, lSolveList[c]);
+        acc += pc.g;
+        s.rho[c] = pc.h; // parked until the tiles of H exist (phase G)
+      }
       s.g[c] = acc;
       s.d0[c] = acc;
     }
@@ -642,6 +737,26 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           v += s.own1[first + c];
         }
         s.L[dest] = v;
+      }
+      __syncthreads();
+    }
+    if (hasParamRows) { // J^T J of the parameter-space rows: diagonal entries, then the shared off-diagonal ones
+      for (int c = tid; c < n; c += 256) {
+        s.L[256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15)] += s.rho[c];
+      }
+      if (pb.wLimit > 0.f) {
+        const float tWeight = 1e+1f * pb.wLimit;
+        for (int d = tid; d < fd.numPairDests; d += 256) {
+          float accp = 0.f;
+          const int k1 = fd.pairStart[d + 1];
+          for (int k = fd.pairStart[d]; k < k1; ++k) {
+            const LimitRow row = evalLimit(pb.limits[fd.pairLim[k]], s.th, pb.enabledMask, tWeight);
+            if (row.ia >= 0 && row.ib >= 0) {
+              accp += row.ca * row.cb;
+            }
+          }
+          s.L[fd.pairDest[d]] += accp;
+        }
       }
       __syncthreads();
     }
@@ -912,6 +1027,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           for (int e = s.mStart[c]; e < e1; ++e) {
             const int info = s.mInfo[e];
             a += s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
+          }
+          if (hasParamRows) {
+            a += paramRowsColumn(pb, fd, s.th, s.d0, lColToSolve, P, b, c, lSolveList[c]).g;
           }
           a -= lambda * s.d0[c];
         }

@@ -213,6 +213,7 @@ int32_t buildFusedTables(
     const int32_t* posParent,
     int32_t Ko,
     const int32_t* oriParent,
+    const uint8_t* forceSolve,
     FusedTables& f,
     std::string& err) {
   const int32_t J = t.J, P = t.P;
@@ -285,11 +286,11 @@ int32_t buildFusedTables(
         nz = true;
       }
     }
-    if (!nz) {
+    if (!nz && !(forceSolve != nullptr && forceSolve[p] != 0)) {
       continue;
     }
     f.solveList.push_back(p);
-    for (int32_t e = t.colStart[p]; e < t.colStart[p + 1]; ++e) {
+    for (int32_t e = t.colStart[p]; nz && e < t.colStart[p + 1]; ++e) {
       f.srcs.push_back(t.colSources[e]);
     }
     f.srcStart.push_back(int32_t(f.srcs.size()));

@@ -87,6 +87,8 @@ int32_t buildFusedTables(
     const int32_t* posParent,
     int32_t Ko,
     const int32_t* oriParent,
+    const uint8_t* forceSolve, // [P] or null: enabled parameters to keep in the solve list although
+                               // no joint constraint reaches them (limit / model-parameter rows)
     FusedTables& out,
     std::string& err);
 

@@ -255,79 +255,6 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
 // limit_error_function.h:91) and ModelParametersErrorFunctionT::getJacobian
 // (model_parameters_error_function.cpp:95-131; used rows compacted like `out` there).
 // =============================================================================================
-struct LimitRow {
-  int ia, ib; // model parameters with a non-zero entry (-1: none)
-  float ca, cb; // the entries
-  float r; // residual entry
-  float err; // this row's error term
-};
-
-__device__ __forceinline__ LimitRow evalLimit(const LimitDev& lm, const float* th, const uint8_t* enabled, float tWeight) {
-  LimitRow o;
-  o.ia = o.ib = -1;
-  o.ca = o.cb = o.r = o.err = 0.f;
-  const float wgt = sqrtf(tWeight * lm.weight); // :1018-1021
-  if (lm.type == 0) { // MinMax
-    const int p = lm.index0;
-    if (!enabled[p]) {
-      return o;
-    }
-    float val = 0.f;
-    bool hit = false;
-    if (th[p] < lm.v[0]) {
-      val = th[p] - lm.v[0];
-      hit = true;
-    }
-    if (th[p] > lm.v[1]) {
-      val = th[p] - lm.v[1];
-      hit = true;
-    }
-    if (hit) {
-      o.ia = p;
-      o.ca = wgt;
-      o.r = val * wgt;
-      o.err = tWeight * lm.weight * (val * val);
-    }
-  } else if (lm.type == 3) { // Linear: p_ref = scale * p_tgt - offset
-    const int ref = lm.index0, tgt = lm.index1;
-    const bool inRange = (lm.v[2] == 0.f && lm.v[3] == 0.f) || (th[tgt] >= lm.v[2] && th[tgt] < lm.v[3]); // parameter_limits.cpp:105-113
-    if ((!enabled[tgt] && !enabled[ref]) || !inRange) {
-      return o;
-    }
-    const float rs = th[tgt] * lm.v[0] - lm.v[1] - th[ref];
-    o.r = rs * wgt;
-    if (enabled[tgt]) {
-      o.ia = tgt;
-      o.ca = lm.v[0] * wgt;
-    }
-    if (enabled[ref]) {
-      o.ib = ref;
-      o.cb = -wgt;
-    }
-    o.err = tWeight * lm.weight * (rs * rs);
-  } else if (lm.type == 6) { // HalfPlane: (p1, p2) . normal - offset >= 0
-    const int p1 = lm.index0, p2 = lm.index1;
-    if (!enabled[p1] && !enabled[p2]) {
-      return o;
-    }
-    const float rs = th[p1] * lm.v[0] + th[p2] * lm.v[1] - lm.v[2];
-    if (rs >= 0.f) {
-      return o;
-    }
-    o.r = rs * wgt;
-    if (enabled[p1]) {
-      o.ia = p1;
-      o.ca = lm.v[0] * wgt;
-    }
-    if (enabled[p2]) {
-      o.ib = p2;
-      o.cb = lm.v[1] * wgt;
-    }
-    o.err = tWeight * lm.weight * (rs * rs);
-  }
-  return o;
-}
-
 __global__ void __launch_bounds__(256) parameterRowsKernel(
     ProblemDev pb,
     int P,

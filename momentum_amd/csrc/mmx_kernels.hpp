@@ -50,6 +50,15 @@ struct FusedDev {
   int32_t termRounds;
   const int32_t* comb; // [numComb][3] (tile-region offset, first partial cell, cell count) of split entries
   int32_t numComb;
+  // parameter-space rows (limits on model parameters, model-parameter targets): which limits touch
+  // a solve column, and which share an off-diagonal H entry
+  int32_t numLimits;
+  const int32_t* limStart; // [n+1]
+  const int32_t* limOf; // limit indices per solve column
+  int32_t numPairDests;
+  const int32_t* pairDest; // [numPairDests] float offset of the H entry inside the tile region
+  const int32_t* pairStart; // [numPairDests+1]
+  const int32_t* pairLim; // limit indices per destination
 };
 
 struct FusedParams {
