@@ -119,6 +119,30 @@ struct PositionData {
   float weight = 1.f;
 };
 
+// momentum::ParameterLimit restricted to the limit types that act on model parameters
+// (momentum/character/parameter_limits.h:20-31,33-99,125-136)
+enum LimitType { MinMax = MMX_LIMIT_MINMAX, Linear = MMX_LIMIT_LINEAR, HalfPlane = MMX_LIMIT_HALFPLANE };
+struct ParameterLimit {
+  LimitType type = MinMax;
+  float weight = 1.f;
+  // MinMax: parameterIndex, limits = {min, max}
+  // Linear: referenceIndex, targetIndex, {scale, offset, rangeMin, rangeMax}
+  // HalfPlane: param1, param2, {normal[0], normal[1], offset}
+  size_t index0 = 0, index1 = 0;
+  std::array<float, 4> values{0.f, 0.f, 0.f, 0.f};
+  static ParameterLimit minMax(size_t parameterIndex, float lo, float hi, float weight = 1.f) {
+    return ParameterLimit{MinMax, weight, parameterIndex, 0, {lo, hi, 0.f, 0.f}};
+  }
+  static ParameterLimit
+  linear(size_t referenceIndex, size_t targetIndex, float scale, float offset, float rangeMin = 0.f, float rangeMax = 0.f, float weight = 1.f) {
+    return ParameterLimit{Linear, weight, referenceIndex, targetIndex, {scale, offset, rangeMin, rangeMax}};
+  }
+  static ParameterLimit halfPlane(size_t param1, size_t param2, float n0, float n1, float offset, float weight = 1.f) {
+    return ParameterLimit{HalfPlane, weight, param1, param2, {n0, n1, offset, 0.f}};
+  }
+};
+using ParameterLimits = std::vector<ParameterLimit>;
+
 struct OrientationData {
   Quaternionf offset{0.f, 0.f, 0.f, 1.f};
   Quaternionf target{0.f, 0.f, 0.f, 1.f};
@@ -261,6 +285,38 @@ class BatchedSkeletonSolverFunction {
     wOri_ = orientationWeight;
     dirty_ = true;
   }
+  // LimitErrorFunctionT::setLimits (limit_error_function.h:88) for every element, with its weight_
+  void setLimits(const ParameterLimits& limits, float weight = 1.f) {
+    limits_.clear();
+    for (const ParameterLimit& l : limits) {
+      mmx_parameter_limit m{};
+      m.type = int32_t(l.type);
+      m.index0 = int32_t(l.index0);
+      m.index1 = int32_t(l.index1);
+      m.weight = l.weight;
+      for (int k = 0; k < 4; ++k) {
+        m.v[k] = l.values[size_t(k)];
+      }
+      limits_.push_back(m);
+    }
+    wLimit_ = weight;
+    dirty_ = true;
+  }
+  // ModelParametersErrorFunctionT::setTargetParameters (model_parameters_error_function.h:48-51) of element b
+  void setTargetParameters(size_t b, const std::vector<float>& params, const std::vector<float>& weights, float weight = 1.f) {
+    const size_t P = getNumParameters();
+    if (b >= batch_ || params.size() != P || weights.size() != P) {
+      throw std::runtime_error("momentum_amd: target parameter count / batch index mismatch");
+    }
+    if (mpTarget_.empty()) {
+      mpTarget_.assign(batch_ * P, 0.f);
+      mpWeights_.assign(batch_ * P, 0.f);
+    }
+    std::copy(params.begin(), params.end(), mpTarget_.begin() + b * P);
+    std::copy(weights.begin(), weights.end(), mpWeights_.begin() + b * P);
+    wModel_ = weight;
+    dirty_ = true;
+  }
   void setEnabledParameters(const ParameterSet& ps) {
     std::vector<uint8_t> e(character_.numParameters(), 0);
     for (size_t i = 0; i < e.size() && i < ps.size(); ++i) {
@@ -283,6 +339,12 @@ class BatchedSkeletonSolverFunction {
     d.pos_function_weight = wPos_;
     d.ori_function_weight = wOri_;
     d.memory = MMX_MEM_HOST;
+    d.num_limits = int32_t(limits_.size());
+    d.limits = limits_.empty() ? nullptr : limits_.data();
+    d.limit_function_weight = wLimit_;
+    d.model_target = mpTarget_.empty() ? nullptr : mpTarget_.data();
+    d.model_weights = mpWeights_.empty() ? nullptr : mpWeights_.data();
+    d.model_function_weight = wModel_;
     check(mmx_problem_set_constraints(handle_.get(), &d, nullptr));
     dirty_ = false;
   }
@@ -307,7 +369,9 @@ class BatchedSkeletonSolverFunction {
   size_t batch_, kp_, ko_;
   std::shared_ptr<mmx_problem> handle_;
   std::vector<float> posOffset_, posTarget_, posWeight_, oriOffset_, oriTarget_, oriWeight_;
-  float wPos_ = 1.f, wOri_ = 1.f;
+  std::vector<mmx_parameter_limit> limits_;
+  std::vector<float> mpTarget_, mpWeights_;
+  float wPos_ = 1.f, wOri_ = 1.f, wLimit_ = 1.f, wModel_ = 1.f;
   bool dirty_ = true;
 };
 

@@ -92,6 +92,27 @@ int main() {
   if (!threw) {
     ++bad;
   }
+  // parameter limits + model-parameter prior (LimitErrorFunction / ModelParametersErrorFunction):
+  // a MinMax limit on parameter 3 must pull the solution into (or close to) its range
+  {
+    fn.setLimits({ParameterLimit::minMax(3, -0.01f, 0.01f, 100.f), ParameterLimit::linear(4, 5, 1.f, 0.f)}, 1.f);
+    for (size_t b = 0; b < B; ++b) {
+      fn.setTargetParameters(b, std::vector<float>(P, 0.f), std::vector<float>(P, 0.1f), 1.f);
+    }
+    std::vector<float> th2(B * P, 0.f);
+    std::vector<double> e1;
+    fn.getJacobian(th2, jac, res, e1);
+    if (jac.size() != B * (9 + 2 + P) * P) {
+      ++bad;
+    }
+    solver.solve(th2);
+    for (size_t b = 0; b < B; ++b) {
+      std::printf("instance %zu with limits: theta[3] %.4f -> %.4f, theta[4]-theta[5] %.4f\n", b, theta[b * P + 3], th2[b * P + 3], th2[b * P + 4] - th2[b * P + 5]);
+      if (std::fabs(th2[b * P + 3]) > std::fabs(theta[b * P + 3]) + 1e-6f || std::fabs(th2[b * P + 3]) > 0.05f) {
+        ++bad;
+      }
+    }
+  }
   std::printf(bad == 0 ? "OK\n" : "FAIL\n");
   return bad == 0 ? 0 : 1;
 }
