@@ -1,0 +1,135 @@
+"""Edge cases of the C ABI on the GPU: empty constraint sets, empty enabled set, single joint,
+single instance, parameter-space rows only -- compared with the oracle where there is something to
+compare, otherwise checked for the reference's documented behaviour."""
+import numpy as np
+import pytest
+
+from momentum_amd import make_test_character
+from momentum_amd._abi import GnOptions, ParameterLimit
+from tests.helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU (run with -m gpu on the MI355X box)")
+    return torch
+
+
+def _upload(torch, pb, cons, B, **kw):
+    dev = pb.device
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(dev)
+    pb.set_constraints(
+        t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+        t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+        cons.pos_function_weight, cons.ori_function_weight, **kw,
+    )  # fmt: skip
+
+
+@pytest.mark.parametrize("solver", ["fused", "v1"])
+def test_no_enabled_parameters_keeps_theta(torch_cuda, orc, solver, monkeypatch):
+    # SolverT::setEnabledParameters with an empty set: the compacted system has size 0, theta is unchanged
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    if solver == "v1":
+        monkeypatch.setenv("MMX_SOLVER", "v1")
+    rig = make_test_character(6)
+    B = 3
+    cons, th0, _ = make_problem(rig, [5, 2], [4], B, seed=1, theta0_scale=0.2)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, B)
+    pb.set_enabled(np.zeros(rig.num_params, np.uint8))
+    opt = GnOptions.make(min_iterations=3, max_iterations=3, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)
+    assert np.array_equal(out["theta"].cpu().numpy(), th0)
+    ref = orc.solve_batch(rig, cons, th0, opt, enabled=np.zeros(rig.num_params, np.uint8), dtype="f64")
+    assert np.abs(out["error"].cpu().numpy() - ref["error"]).max() <= 1e-5 * max(1.0, np.abs(ref["error"]).max())
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+
+
+def test_single_joint_single_instance(torch_cuda, orc):
+    from momentum_amd import capi
+    from momentum_amd.rigs import Rig
+
+    torch = torch_cuda
+    full = make_test_character(3)
+    # a rig of one joint: root with its 6 rigid parameters + scale (first joint of the test character)
+    J, P = 1, 7
+    outer = np.arange(8, dtype=np.int32)
+    rig = Rig(
+        parent=np.array([-1], np.int32), pre_rotation=np.array([[0, 0, 0, 1]], np.float32),
+        translation_offset=np.zeros((1, 3), np.float32), pt_outer=outer, pt_inner=np.arange(7, dtype=np.int32),
+        pt_value=np.ones(7, np.float32), pt_offsets=np.zeros(7, np.float32), num_params=P,
+        joint_names=["root"], param_names=[f"p{i}" for i in range(7)],
+    )  # fmt: skip
+    assert rig.num_joints == J
+    cons, th0, ths = make_problem(rig, [0, 0], [0], 1, seed=5, perturb=0.3, random_offsets=True)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, 1, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, 1)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    rel = np.linalg.norm(out["theta"].cpu().numpy() - ref["theta"]) / np.linalg.norm(ref["theta"])
+    assert rel <= 1e-5, rel
+    del full
+
+
+@pytest.mark.parametrize("solver", ["fused", "v1"])
+def test_parameter_rows_only_no_joint_constraints(torch_cuda, orc, solver, monkeypatch):
+    # Kp = Ko = 0: only the limit and model-parameter blocks; the solution of the regularised
+    # quadratic is the oracle's
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    if solver == "v1":
+        monkeypatch.setenv("MMX_SOLVER", "v1")
+    rig = make_test_character(5)
+    P, B = rig.num_params, 2
+    cons, _, _ = make_problem(rig, [], [], B, seed=2)
+    rng = np.random.default_rng(8)
+    limits = [ParameterLimit.minmax(1, -0.05, 0.05, 2.0), ParameterLimit.linear(2, 6, 0.5, 0.1), ParameterLimit.halfplane(3, 4, 0.6, 0.8, 0.3)]
+    mt = rng.uniform(-0.3, 0.3, (B, P)).astype(np.float32)
+    mw = rng.uniform(0.2, 1.5, (B, P)).astype(np.float32)
+    full = orc.Constraints(
+        cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset, cons.ori_target, cons.ori_weight,
+        limits=limits, limit_function_weight=1.0, model_target=mt, model_weights=mw, model_function_weight=1.0,
+    )  # fmt: skip
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    dev = pb.device
+    _upload(torch, pb, cons, B, limits=limits, model_target=torch.from_numpy(mt).to(dev), model_weights=torch.from_numpy(mw).to(dev))
+    assert pb.M == len(limits) + P
+    th0 = rng.uniform(-0.5, 0.5, (B, P)).astype(np.float32)
+    opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(dev), opt, want_history=True)
+    ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+    rel = np.linalg.norm(out["theta"].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert np.all(rel <= 1e-5), rel
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+
+
+def test_unsupported_limit_type_is_a_loud_error(torch_cuda):
+    from momentum_amd import capi
+    from momentum_amd._abi import ParameterLimit as PL
+
+    torch = torch_cuda
+    rig = make_test_character(4)
+    cons, _, _ = make_problem(rig, [3], [], 1, seed=3)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, 1, cons.pos_parent, cons.ori_parent)
+    bad = PL.minmax(0, -1, 1)
+    bad.type = 1  # LimitType::MinMaxJoint needs joint state: not implemented
+    with pytest.raises(capi.MmxError) as ei:
+        _upload(torch, pb, cons, 1, limits=[bad])
+    assert "MinMax" in str(ei.value)
+    oob = PL.linear(0, rig.num_params, 1.0, 0.0)
+    with pytest.raises(capi.MmxError):
+        _upload(torch, pb, cons, 1, limits=[oob])
