@@ -444,6 +444,10 @@ bool wantLegacySolver() {
 }
 
 int32_t checkProblem(const mmx_problem* pb, bool needConstraints) {
+  // hipGetLastError() is per thread and shared with every other user of the runtime in this
+  // process (torch probes devices / pointers and leaves benign errors behind): start clean so that
+  // the launchers below only ever report their own failures
+  (void)hipGetLastError();
   if (pb == nullptr || pb->rig == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "problem handle is null");
   }

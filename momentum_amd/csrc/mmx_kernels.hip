@@ -509,6 +509,217 @@ __global__ void __launch_bounds__(256) normalEquationsKernel(
 }
 
 // =============================================================================================
+// Kernel 2b: normal equations from the dense Jacobian on the matrix cores (wide systems:
+// BASELINE configs[4], P = 300).  grid = B, block = 256 (one wave per SIMD, one workgroup per CU).
+// Same contract as normalEquationsKernel.
+//
+// The compacted J^T (n x M) is consumed in chunks of 32 rows of J: a chunk (all n columns) is
+// staged in LDS column-major with a padded column stride, double-buffered so that the global
+// loads of chunk c+1 are in flight while chunk c is multiplied.  H is cut into 16x16 tiles of the
+// lower triangle; tile t belongs to wave t & 3 and stays in that wave's accumulator registers for
+// the whole sweep over M, so J is read from HBM exactly once (one pass holds 4 * TPW tiles; wider
+// systems take several passes).  Per tile and 16 rows: two 16-byte LDS reads and four
+// v_mfma_f32_16x16x4_f32 (the k index is permuted identically in both operands, which a
+// contraction does not see).
+// =============================================================================================
+constexpr int kMfKc = 32; // rows of J per chunk
+constexpr int kMfLd = 36; // LDS column stride in floats: 16-byte aligned, b128 reads of 16 columns conflict-free
+
+template <int TPW>
+__global__ void __launch_bounds__(256, 1) normalEquationsMfmaKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jac, // [B][M*P] column-major
+    const float* __restrict__ res, // [B][M]
+    float* __restrict__ jtj, // [B][n*n]
+    float* __restrict__ jtr, // [B][n]
+    const int32_t* __restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (done != nullptr && done[b] != 0) {
+    return;
+  }
+  const int n = pb.n, M = pb.M;
+  const int NB = (n + 15) >> 4, NP = 16 * NB;
+  const int T = NB * (NB + 1) / 2;
+  const size_t bufFloats = size_t(NP) * kMfLd;
+  float* buf0 = smem;
+  float* buf1 = smem + bufFloats;
+  float* rc = buf1 + bufFloats; // [2][kMfKc]
+  int* tileIJ = reinterpret_cast<int*>(rc + 2 * kMfKc); // [T] I << 16 | J
+  const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
+  const float* rb = res + size_t(b) * size_t(M);
+  const bool vec = (M & 3) == 0 && (reinterpret_cast<uintptr_t>(jac) & 15) == 0; // 16-byte column pieces
+  for (int t = tid; t < T; t += 256) {
+    int I, Jc;
+    tileDecode(t, I, Jc);
+    tileIJ[t] = (I << 16) | Jc;
+  }
+  const int pieces = NP * (kMfKc / 4); // 16-byte pieces of a chunk
+  const int numChunks = (M + kMfKc - 1) / kMfKc;
+  constexpr int kMaxPieces = 12; // per thread: covers n <= 384 per pass of the staging loop
+  float4 stage[kMaxPieces];
+  float rstage = 0.f;
+  // global -> registers for chunk c (zeros beyond M and for the padding columns)
+  auto fetch = [&](int c) {
+    const int k0 = c * kMfKc;
+#pragma unroll
+    for (int q = 0; q < kMaxPieces; ++q) {
+      const int e = tid + 256 * q;
+      float4 v{0.f, 0.f, 0.f, 0.f};
+      if (e < pieces) {
+        const int col = e >> 3, kk = k0 + 4 * (e & 7); // 8 pieces per column
+        if (col < n && kk < M) {
+          const float* src = Jb + size_t(pb.enabledList[col]) * M + kk;
+          if (vec) {
+            v = *reinterpret_cast<const float4*>(src); // M % 4 == 0: the piece never straddles M
+          } else {
+            v.x = src[0];
+            v.y = kk + 1 < M ? src[1] : 0.f;
+            v.z = kk + 2 < M ? src[2] : 0.f;
+            v.w = kk + 3 < M ? src[3] : 0.f;
+          }
+        }
+      }
+      stage[q] = v;
+    }
+    rstage = (tid < kMfKc && k0 + tid < M) ? rb[k0 + tid] : 0.f;
+  };
+  auto commit = [&](float* buf, int slot) {
+#pragma unroll
+    for (int q = 0; q < kMaxPieces; ++q) {
+      const int e = tid + 256 * q;
+      if (e < pieces) {
+        *reinterpret_cast<float4*>(buf + (e >> 3) * kMfLd + 4 * (e & 7)) = stage[q];
+      }
+    }
+    if (tid < kMfKc) {
+      rc[slot * kMfKc + tid] = rstage;
+    }
+  };
+  const int col16 = lane & 15, g = lane >> 4;
+  float* Hb = jtj + size_t(b) * size_t(n) * size_t(n);
+  for (int base = 0; base < T; base += 4 * TPW) { // one pass holds 4 * TPW tiles
+    v4f acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    float gacc[2] = {0.f, 0.f};
+    __syncthreads(); // the previous pass is done with the buffers; tileIJ is visible
+    fetch(0);
+    commit(buf0, 0);
+    __syncthreads();
+    for (int c = 0; c < numChunks; ++c) {
+      const float* cur = (c & 1) ? buf1 : buf0;
+      const float* rcur = rc + (c & 1) * kMfKc;
+      if (c + 1 < numChunks) {
+        fetch(c + 1); // in flight while this chunk is multiplied
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < TPW; q0 += 4) {
+        if (base + 4 * q0 + wave < T) {
+          // four tiles at a time: operands of both 16-row halves, then the MFMAs interleaved
+          // across the tiles (independent accumulators back to back)
+          float4 a[4][2], bb[4][2];
+          bool on[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = base + 4 * (q0 + u) + wave;
+            on[u] = t < T;
+            const int ij = __builtin_amdgcn_readfirstlane(tileIJ[on[u] ? t : 0]);
+            const float* pa = cur + (16 * (ij >> 16) + col16) * kMfLd + 4 * g;
+            const float* pbv = cur + (16 * (ij & 0xffff) + col16) * kMfLd + 4 * g;
+            a[u][0] = *reinterpret_cast<const float4*>(pa);
+            a[u][1] = *reinterpret_cast<const float4*>(pa + 16);
+            bb[u][0] = *reinterpret_cast<const float4*>(pbv);
+            bb[u][1] = *reinterpret_cast<const float4*>(pbv + 16);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (on[u]) {
+                acc[q0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][h].x, bb[u][h].x, acc[q0 + u], 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (on[u]) {
+                acc[q0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][h].y, bb[u][h].y, acc[q0 + u], 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (on[u]) {
+                acc[q0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][h].z, bb[u][h].z, acc[q0 + u], 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (on[u]) {
+                acc[q0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][h].w, bb[u][h].w, acc[q0 + u], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      if (base == 0) { // g = J^T r rides along on the first pass
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int sIdx = tid + 256 * h;
+          if (sIdx < n) {
+            const float4* colp = reinterpret_cast<const float4*>(cur + sIdx * kMfLd);
+            const float4* rp = reinterpret_cast<const float4*>(rcur);
+            float accg = gacc[h];
+#pragma unroll
+            for (int k4 = 0; k4 < kMfKc / 4; ++k4) {
+              accg = dot4(colp[k4], rp[k4], accg);
+            }
+            gacc[h] = accg;
+          }
+        }
+      }
+      if (c + 1 < numChunks) {
+        commit((c & 1) ? buf0 : buf1, (c + 1) & 1); // the other buffer: last read two barriers ago
+      }
+      __syncthreads();
+    }
+    // write the tiles of this pass (both triangles; C layout: col = lane & 15, row = 4 (lane >> 4) + r)
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int t = base + 4 * q + wave;
+      if (t < T) {
+        const int ij = tileIJ[t];
+        const int I = ij >> 16, Jc = ij & 0xffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + 4 * g + r, j = 16 * Jc + col16;
+          if (i < n && j < n) {
+            Hb[size_t(i) * n + j] = acc[q][r];
+            Hb[size_t(j) * n + i] = acc[q][r];
+          }
+        }
+      }
+    }
+    if (base == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (tid + 256 * h < n) {
+          jtr[size_t(b) * n + tid + 256 * h] = gacc[h];
+        }
+      }
+    }
+  }
+}
+
+size_t normalEquationsMfmaLdsBytes(int n) {
+  const size_t NB = size_t(n + 15) >> 4, NP = 16 * NB, T = NB * (NB + 1) / 2;
+  return (2 * NP * kMfLd + 2 * kMfKc + T) * sizeof(float);
+}
+
+// =============================================================================================
 // Kernel 3: dense GN step.  grid = B, block = 256, dynamic LDS = n*(n+1) + 3n + M + 4 floats.
 //   H diag += lambda ; L L^T = H ; d0 = solve(g)                 (gauss_newton_solver.cpp:248-251)
 //   rho = J^T (r - J d0) - lambda d0 ; d = d0 + solve(rho)        (one refinement step, fp32: the
@@ -1139,6 +1350,33 @@ hipError_t launchNormalEquations(
     float* jtr,
     const int32_t* done,
     hipStream_t stream) {
+  // wide systems go to the matrix cores; the staging loop of that kernel covers n <= 384, g <= 512 columns
+  if (pb.n >= 32 && pb.n <= 384) {
+    const size_t lds = normalEquationsMfmaLdsBytes(pb.n);
+    const int NB = (pb.n + 15) >> 4, T = NB * (NB + 1) / 2;
+#define MMX_NE_LAUNCH(TPW_)                                                                                             \
+  do {                                                                                                                  \
+    static bool attr = false;                                                                                           \
+    if (!attr && lds > 64 * 1024) {                                                                                     \
+      hipError_t rc = hipFuncSetAttribute(                                                                              \
+          reinterpret_cast<const void*>(normalEquationsMfmaKernel<TPW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
+      if (rc != hipSuccess) {                                                                                           \
+        return rc;                                                                                                      \
+      }                                                                                                                 \
+      attr = true;                                                                                                      \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(normalEquationsMfmaKernel<TPW_>, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, done); \
+  } while (0)
+    if (T <= 16) {
+      MMX_NE_LAUNCH(4);
+    } else if (T <= 64) {
+      MMX_NE_LAUNCH(16);
+    } else {
+      MMX_NE_LAUNCH(48);
+    }
+#undef MMX_NE_LAUNCH
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(
       normalEquationsKernel, dim3(pb.B), dim3(256), normalEquationsLdsBytes(pb.n), stream, pb, P, jac, res, jtj, jtr, done);
   return hipGetLastError();

@@ -320,6 +320,11 @@ def test_large_rig_config5_solve_matches_oracle(torch_cuda, orc):
     jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
     J, r, e = orc.eval_jacobian(rig, cons.instance(0), theta[0].astype(np.float64), dtype="f64")
     assert np.abs(jac[0].cpu().numpy().T - J).max() <= 2e-5 * max(1.0, np.abs(J).max())
+    # the matrix-core normal equations (normalEquationsMfmaKernel, 190 tiles in one pass)
+    jtj, jtr, _ = pb.normal_equations(torch.from_numpy(theta).to(pb.device))
+    H, g = J.T @ J, J.T @ r
+    assert np.abs(jtj[0].cpu().numpy() - H).max() <= 5e-5 * max(1.0, np.abs(H).max())
+    assert np.abs(jtr[0].cpu().numpy() - g).max() <= 5e-5 * max(1.0, np.abs(g).max())
     opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05)
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
