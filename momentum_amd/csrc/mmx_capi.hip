@@ -936,7 +936,7 @@ int32_t mmx_eval_normal_equations(
   MMX_HIP(mmx::launchFkJacobian(
       pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), err_dev, nullptr, nullptr, s));
   MMX_HIP(mmx::launchNormalEquations(
-      pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), jtj_dev, jtr_dev, nullptr, s));
+      pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), jtj_dev, jtr_dev, nullptr, false, s));
   return MMX_OK;
 }
 
@@ -1058,7 +1058,8 @@ int32_t mmx_solve(
     MMX_HIP(mmx::launchFkJacobian(
         pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
     MMX_HIP(mmx::launchNormalEquations(
-        pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, s));
+        pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done,
+        mmx::choleskyStepLdsBytes(pb->dev.n, pb->dev.M) > 160 * 1024 /* the in-HBM factorisation reads the lower triangle only */, s));
     MMX_HIP(mmx::launchCholeskyStep(
         pb->dev,
         pb->rig->P,

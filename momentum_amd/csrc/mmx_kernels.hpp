@@ -109,6 +109,7 @@ hipError_t launchNormalEquations(
     float* jtj,
     float* jtr,
     const int32_t* done,
+    bool lowerOnly, // the caller only reads the lower triangle of jtj (wide systems skip the mirror stores)
     hipStream_t stream);
 
 hipError_t launchCholeskyStep(
