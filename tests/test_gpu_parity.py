@@ -334,3 +334,33 @@ def test_large_rig_config5_solve_matches_oracle(torch_cuda, orc):
     assert np.all(rel <= tol), (rel, tol)
     assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
     assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+
+
+def test_config3_full_size_lm_schedule_properties(torch_cuda, orc):
+    """BASELINE configs[2] at its full size (65 536 instances, LM damping schedule): the first
+    instances are compared with the oracle, the rest through size-independent properties (a tiled
+    batch gives bit-identical results wherever an instance sits; every instance ends finite with a
+    decreased error and a full iteration count)."""
+    from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
+    from oracle import oracle as o
+
+    torch = torch_cuda
+    rig = make_humanoid72(unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    Bs, B = 32, 65536
+    cons, th0, ths = make_problem(rig, lm, lm, Bs, seed=777, perturb=0.3)
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (B // Bs,) + (1,) * (a.ndim - 1)))
+    big = o.Constraints(cons.pos_parent, rep(cons.pos_offset), rep(cons.pos_target), rep(cons.pos_weight),
+                        cons.ori_parent, rep(cons.ori_offset), rep(cons.ori_target), rep(cons.ori_weight))  # fmt: skip
+    rh, pb = _gpu_problem(torch, rig, big, B)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
+    out = pb.solve(torch.from_numpy(rep(th0)).to(pb.device), opt, want_history=True)
+    th = out["theta"].view(B // Bs, Bs, -1)
+    assert torch.equal(th[0].expand_as(th), th)
+    assert torch.isfinite(out["theta"]).all() and torch.all(out["status"] == 0) and torch.all(out["iterations"] == 10)
+    h = out["error_history"]
+    assert torch.all(h[:, -1] < 1e-3 * h[:, 0])
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    rel = np.linalg.norm(th[0].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
+    assert np.all(rel <= tol), (rel, tol)
