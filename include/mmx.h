@@ -113,6 +113,8 @@ typedef struct mmx_rig_desc {
                               v = {scale, offset, rangeMin, rangeMax}  (p_ref = scale * p_target - offset) */
 #define MMX_LIMIT_HALFPLANE 6 /* LimitType::HalfPlane : index0 = param1, index1 = param2 ;
                                  v = {normal[0], normal[1], offset} */
+#define MMX_LOSS_WELSCH (-3.402823466e+38f) /* GeneralizedLossT::kWelsch = numeric_limits<float>::lowest() */
+
 typedef struct mmx_parameter_limit {
   int32_t type; /* MMX_LIMIT_* (values of momentum::LimitType) */
   int32_t index0;
@@ -143,6 +145,13 @@ typedef struct mmx_constraint_data {
   int32_t num_limits;
   const mmx_parameter_limit* limits; /* [num_limits] */
   float limit_function_weight; /* weight_ of that block */
+  /* ---- robust loss of the two joint-constraint blocks: GeneralizedLossT(alpha, c)
+     (momentum/math/generalized_loss.h:46-101; constructor arguments lossAlpha / lossC of
+     PositionErrorFunctionT / OrientationErrorFunctionT, position_error_function.h:41-48).
+     alpha = 2: L2, 1: L1 / pseudo-Huber, 0: Cauchy, MMX_LOSS_WELSCH: Welsch, other: Barron's
+     general form.  c <= 0 (e.g. a zero-initialised struct) selects the default L2 loss with c = 1. */
+  float pos_loss_alpha, pos_loss_c;
+  float ori_loss_alpha, ori_loss_c;
 } mmx_constraint_data;
 
 /*

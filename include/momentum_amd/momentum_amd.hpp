@@ -317,6 +317,13 @@ class BatchedSkeletonSolverFunction {
     wModel_ = weight;
     dirty_ = true;
   }
+  // GeneralizedLoss(alpha, c) of the position / orientation blocks: the lossAlpha / lossC constructor
+  // arguments of PositionErrorFunctionT / OrientationErrorFunctionT (position_error_function.h:41-48)
+  void setLoss(float positionAlpha, float positionC, float orientationAlpha, float orientationC) {
+    lossPos_[0] = positionAlpha, lossPos_[1] = positionC;
+    lossOri_[0] = orientationAlpha, lossOri_[1] = orientationC;
+    dirty_ = true;
+  }
   void setEnabledParameters(const ParameterSet& ps) {
     std::vector<uint8_t> e(character_.numParameters(), 0);
     for (size_t i = 0; i < e.size() && i < ps.size(); ++i) {
@@ -345,6 +352,8 @@ class BatchedSkeletonSolverFunction {
     d.model_target = mpTarget_.empty() ? nullptr : mpTarget_.data();
     d.model_weights = mpWeights_.empty() ? nullptr : mpWeights_.data();
     d.model_function_weight = wModel_;
+    d.pos_loss_alpha = lossPos_[0], d.pos_loss_c = lossPos_[1];
+    d.ori_loss_alpha = lossOri_[0], d.ori_loss_c = lossOri_[1];
     check(mmx_problem_set_constraints(handle_.get(), &d, nullptr));
     dirty_ = false;
   }
@@ -372,6 +381,7 @@ class BatchedSkeletonSolverFunction {
   std::vector<mmx_parameter_limit> limits_;
   std::vector<float> mpTarget_, mpWeights_;
   float wPos_ = 1.f, wOri_ = 1.f, wLimit_ = 1.f, wModel_ = 1.f;
+  float lossPos_[2] = {2.f, 1.f}, lossOri_[2] = {2.f, 1.f};
   bool dirty_ = true;
 };
 

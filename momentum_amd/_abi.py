@@ -36,6 +36,7 @@ class RigDesc(C.Structure):
     ]
 
 
+MMX_LOSS_WELSCH = float(np.finfo(np.float32).min)  # GeneralizedLossT::kWelsch
 MMX_LIMIT_MINMAX = 0  # momentum::LimitType values (character/parameter_limits.h:20-31)
 MMX_LIMIT_LINEAR = 3
 MMX_LIMIT_HALFPLANE = 6
@@ -91,6 +92,11 @@ class ConstraintData(C.Structure):
         ("num_limits", C.c_int32),
         ("limits", C.c_void_p),
         ("limit_function_weight", C.c_float),
+        # GeneralizedLoss(alpha, c) of the position / orientation blocks; c <= 0 = default L2
+        ("pos_loss_alpha", C.c_float),
+        ("pos_loss_c", C.c_float),
+        ("ori_loss_alpha", C.c_float),
+        ("ori_loss_c", C.c_float),
     ]
 
 

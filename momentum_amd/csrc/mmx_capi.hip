@@ -700,6 +700,8 @@ int32_t mmx_problem_create(
   pb->Ko = num_ori;
   pb->U = num_pos + 3 * num_ori;
   pb->M = 3 * pb->U;
+  pb->dev.lossPos = mmx::LossDev{0, 2.f, 1.f};
+  pb->dev.lossOri = mmx::LossDev{0, 2.f, 1.f};
   if (num_pos > 0) {
     pb->posParent.assign(pos_parent, pos_parent + num_pos);
   }
@@ -803,6 +805,28 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   }
   d.wPos = c->pos_function_weight;
   d.wOri = c->ori_function_weight;
+  auto makeLoss = [](float alpha, float cc) { // GeneralizedLossT ctor (generalized_loss.cpp:81-101), kEps = 1e-9
+    mmx::LossDev l{0, 2.f, 1.f};
+    if (cc > 0.f) {
+      l.alpha = alpha;
+      l.invC2 = 1.f / (cc * cc);
+      const float kEps = 1e-9f;
+      if (alpha >= 2.f - kEps && alpha <= 2.f + kEps) {
+        l.type = 0;
+      } else if (alpha >= 1.f - kEps && alpha <= 1.f + kEps) {
+        l.type = 1;
+      } else if (alpha >= -kEps && alpha <= kEps) {
+        l.type = 2;
+      } else if (alpha == MMX_LOSS_WELSCH) {
+        l.type = 3;
+      } else {
+        l.type = 4;
+      }
+    }
+    return l;
+  };
+  d.lossPos = makeLoss(c->pos_loss_alpha, c->pos_loss_c);
+  d.lossOri = makeLoss(c->ori_loss_alpha, c->ori_loss_c);
   // ---- optional parameter-space blocks
   const int32_t P = pb->rig->P;
   if (c->num_limits < 0 || (c->num_limits > 0 && c->limits == nullptr)) {

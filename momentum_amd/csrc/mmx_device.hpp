@@ -118,6 +118,42 @@ struct RigDev {
   int32_t jumpRounds; // ceil(log2(numLevels)): pointer-jumping rounds that finish every joint
 };
 
+// GeneralizedLossT(alpha, c) (momentum/math/generalized_loss.h:46-101, .cpp:20-155)
+struct LossDev {
+  int32_t type; // 0 L2, 1 L1 / pseudo-Huber, 2 Cauchy, 3 Welsch, 4 Barron's general form
+  float alpha, invC2;
+};
+__device__ __forceinline__ float lossValue(const LossDev& l, float s) {
+  const float q = s * l.invC2;
+  switch (l.type) {
+    case 0:
+      return q;
+    case 1:
+      return sqrtf(q + 1.f) - 1.f;
+    case 2:
+      return logf(0.5f * q + 1.f);
+    case 3:
+      return 1.f - expf(-0.5f * q);
+    default:
+      return (powf(q / fabsf(l.alpha - 2.f) + 1.f, 0.5f * l.alpha) - 1.f) * fabsf(l.alpha - 2.f) / l.alpha;
+  }
+}
+__device__ __forceinline__ float lossDeriv(const LossDev& l, float s) {
+  const float q = s * l.invC2;
+  switch (l.type) {
+    case 0:
+      return l.invC2;
+    case 1:
+      return 0.5f * l.invC2 / sqrtf(q + 1.f);
+    case 2:
+      return l.invC2 / (l.invC2 * s + 2.f);
+    case 3:
+      return 0.5f * l.invC2 * expf(-0.5f * q);
+    default:
+      return 0.5f * l.invC2 * powf(q / fabsf(l.alpha - 2.f) + 1.f, 0.5f * l.alpha - 1.f);
+  }
+}
+
 // == mmx_parameter_limit (include/mmx.h)
 struct LimitDev {
   int32_t type, index0, index1;
@@ -143,6 +179,7 @@ struct ProblemDev {
   const float* oriTarget; // [B][Ko][4]
   const float* oriWeight; // [B][Ko]
   float wPos, wOri; // SkeletonErrorFunction::weight_ of the two blocks
+  LossDev lossPos, lossOri; // JointErrorFunctionT::loss_ of the two blocks
   // ---- parameter-space blocks (rows rowsJoint .. M-1): LimitErrorFunctionT on model parameters,
   // ModelParametersErrorFunctionT.  M = rowsJoint + NL + (hasModel ? P : 0).
   int32_t rowsJoint; // 3 U
@@ -501,11 +538,16 @@ __device__ __forceinline__ Unit evalUnitFrom(const ProblemDev& pb, const UnitInp
   const Q4 q{w[3], w[4], w[5], w[6]};
   const float s = w[7];
   float fw;
+  float sqr; // |f|^2 of the whole CONSTRAINT (the argument of the loss)
+  bool first = true; // the unit that reports the constraint's error
+  int ltype;
   if (un.isPoint) {
     // PositionErrorFunctionT::evalFunction (position_error_function.cpp:23-26)
     un.v = t + qrot(q, s * F3{in.a[0], in.a[1], in.a[2]});
     un.f = un.v - F3{in.t[0], in.t[1], in.t[2]};
     fw = pb.wPos;
+    sqr = dot(un.f, un.f);
+    ltype = pb.lossPos.type;
   } else {
     // OrientationErrorFunctionT::evalFunction (orientation_error_function.cpp:23-39)
     const int uo = u - pb.Kp;
@@ -515,13 +557,31 @@ __device__ __forceinline__ Unit evalUnitFrom(const ProblemDev& pb, const UnitInp
     un.v = qrot(q, qmatCol(qo, k));
     un.f = un.v - qmatCol(qt, k);
     fw = pb.wOri;
+    sqr = dot(un.f, un.f);
+    ltype = pb.lossOri.type;
+    if (ltype != 0) { // a robust loss sees all nine rows of the constraint: add the two other columns
+      first = k == 0;
+      for (int kk = 0; kk < 3; ++kk) {
+        if (kk != k) {
+          const F3 fo = qrot(q, qmatCol(qo, kk)) - qmatCol(qt, kk);
+          sqr += dot(fo, fo);
+        }
+      }
+    }
   }
   // joint_error_function-inl.h:197-213 ; a block with weight_ <= 0 is skipped entirely
   // (skeleton_solver_function.cpp:223-231) and a constraint with weight == 0 keeps zero rows
   if (in.cw != 0.f && fw > 0.f) {
     const float wgt = in.cw * fw;
-    un.werr = wgt * dot(un.f, un.f);
-    un.sigma = sqrtf(wgt);
+    if (ltype == 0) { // L2 (the hot path): error and scale split per unit, invC2 folded in
+      const float ic = un.isPoint ? pb.lossPos.invC2 : pb.lossOri.invC2;
+      un.werr = wgt * (sqr * ic);
+      un.sigma = sqrtf(wgt * ic);
+    } else {
+      const LossDev& ls = un.isPoint ? pb.lossPos : pb.lossOri;
+      un.werr = first ? wgt * lossValue(ls, sqr) : 0.f; // :207, once per constraint
+      un.sigma = sqrtf(wgt * lossDeriv(ls, sqr)); // :208
+    }
   }
   return un;
 }

@@ -949,7 +949,12 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     }
     MMX_CLK(8)
     // ================= J: one refinement step through the tree (tangent + adjoint passes)
-    const int nRefine = (!notPd && fp.refine) ? (lambda < 0.01f ? 2 : 1) : 0; // small lambda: worse conditioning
+    // One step is enough when lambda dominates the rounding of H (the BASELINE metric); with a
+    // small lambda, heavy weights or a robust loss (rows scaled by 1/c^2) the fp32 factor is a
+    // weaker preconditioner, so a further step is taken while the last correction was still
+    // larger than 1e-3 of the step (error after k steps ~ ratio^(k+1)).  The test is on block-wide
+    // sums, hence uniform.
+    const int nRefine = (!notPd && fp.refine) ? 3 : 0;
     for (int rf = 0; rf < nRefine; ++rf) {
       // joint-parameter delta jd = transform * delta (delta gathered through the solve map)
       for (int r = tid; r < rv.R; r += 256) {
@@ -1039,10 +1044,26 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       MMX_CLK(19)
       solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
       MMX_CLK(20)
+      float c2 = 0.f, d2 = 0.f;
       for (int c = tid; c < n; c += 256) {
-        s.d0[c] += s.rho[c];
+        const float cr = s.rho[c], dn = s.d0[c] + cr;
+        s.d0[c] = dn;
+        c2 += cr * cr;
+        d2 += dn * dn;
+      }
+      c2 = waveReduceSumF(c2);
+      d2 = waveReduceSumF(d2);
+      if (lane == 0) {
+        s.red[4 + wave] = double(c2);
+        s.red[wave] = double(d2); // (the error sums of phase C were consumed long ago)
       }
       __syncthreads();
+      const float corr2 = float((s.red[4] + s.red[5]) + (s.red[6] + s.red[7]));
+      const float step2 = float((s.red[0] + s.red[1]) + (s.red[2] + s.red[3]));
+      __syncthreads();
+      if (!(corr2 > 1e-6f * step2)) {
+        break;
+      }
     }
     MMX_CLK(9)
     // ================= K: theta -= delta ; bookkeeping of SolverT::solve (solver.cpp:92-119)

@@ -863,7 +863,9 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     triangularSolves(A, ld, n, d0, tid);
   }
   __syncthreads();
-  if (!bad && sp.refine) {
+  // up to three refinement steps: a further one only while the last correction exceeded 1e-3 of the
+  // step (same rule as the fused kernel; one step is the normal case)
+  for (int rf = 0; rf < 3 && !bad && sp.refine && n > 0; ++rf) {
     // w = r - J d0   (rows over threads, coalesced down each column)
     const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
     const float* rb = res + size_t(b) * size_t(M);
@@ -891,10 +893,26 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     __syncthreads();
     triangularSolves(A, ld, n, rho, tid);
     __syncthreads();
+    float c2 = 0.f, d2 = 0.f;
     for (int i = tid; i < n; i += 256) {
-      d0[i] += rho[i];
+      const float cr = rho[i], dn = d0[i] + cr;
+      d0[i] = dn;
+      c2 += cr * cr;
+      d2 += dn * dn;
+    }
+    c2 = waveReduceSumF(c2);
+    d2 = waveReduceSumF(d2);
+    __syncthreads();
+    if (lane == 0) {
+      rho[wave] = c2; // rho / w are free until the next step
+      rho[4 + wave] = d2;
     }
     __syncthreads();
+    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > 1e-6f * (rho[4] + rho[5] + rho[6] + rho[7]);
+    __syncthreads();
+    if (!again) {
+      break;
+    }
   }
   // theta -= delta (scatter to the full parameter space, gauss_newton_solver.cpp:254-257)
   if (!bad) {
@@ -1202,7 +1220,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
   if (!bad) {
     solve(d0);
   }
-  if (!bad && sp.refine) {
+  for (int rf = 0; rf < 3 && !bad && sp.refine; ++rf) { // see choleskyStepKernel
     const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
     const float* rb = res + size_t(b) * size_t(M);
     for (int kk = tid; kk < M; kk += 256) {
@@ -1228,10 +1246,26 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
     }
     __syncthreads();
     solve(rho);
+    float c2 = 0.f, d2 = 0.f;
     for (int i = tid; i < n; i += 256) {
-      d0[i] += rho[i];
+      const float cr = rho[i], dn = d0[i] + cr;
+      d0[i] = dn;
+      c2 += cr * cr;
+      d2 += dn * dn;
+    }
+    c2 = waveReduceSumF(c2);
+    d2 = waveReduceSumF(d2);
+    __syncthreads();
+    if (lane == 0) {
+      rho[wave] = c2;
+      rho[4 + wave] = d2;
     }
     __syncthreads();
+    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > 1e-6f * (rho[4] + rho[5] + rho[6] + rho[7]);
+    __syncthreads();
+    if (!again) {
+      break;
+    }
   }
   if (!bad) {
     float* th = theta + size_t(b) * P;
@@ -1396,7 +1430,7 @@ hipError_t launchNormalEquations(
 }
 
 size_t choleskyStepLdsBytes(int n, int M) {
-  return (size_t(n) * size_t(n + 1) + 3 * size_t(n) + size_t(M) + 4) * sizeof(float);
+  return (size_t(n) * size_t(n + 1) + 3 * size_t(n) + size_t(M) + 12) * sizeof(float);
 }
 
 hipError_t launchCholeskyStep(

@@ -266,6 +266,61 @@ inline void setSkeletonState(const Rig& rig, const T* jp, std::vector<JointState
   }
 }
 
+// GeneralizedLossT (momentum/math/generalized_loss.h:46-101, .cpp:20-155): a robust loss on the
+// squared residual; alpha selects the closed form (2 = L2, 1 = L1 / pseudo-Huber, 0 = Cauchy,
+// lowest() = Welsch, anything else = Barron's general form), c is the scale.
+template <class T>
+struct Loss {
+  enum Type { L2, L1, Cauchy, Welsch, General };
+  T alpha = T(2), invC2 = T(1);
+  Type type = L2;
+  Loss() = default;
+  Loss(T a, T c) : alpha(a), invC2(T(1) / (c * c)) { // ctor :81-101 (kEps = 1e-9, generalized_loss.h:101)
+    const T kEps = T(1e-9);
+    if (alpha >= T(2) - kEps && alpha <= T(2) + kEps) {
+      type = L2;
+    } else if (alpha >= T(1) - kEps && alpha <= T(1) + kEps) {
+      type = L1;
+    } else if (alpha >= T(0) - kEps && alpha <= T(0) + kEps) {
+      type = Cauchy;
+    } else if (alpha == std::numeric_limits<T>::lowest()) {
+      type = Welsch;
+    } else {
+      type = General;
+    }
+  }
+  T value(T s) const { // :104-134
+    const T q = s * invC2;
+    switch (type) {
+      case L2:
+        return q;
+      case L1:
+        return std::sqrt(q + T(1)) - T(1);
+      case Cauchy:
+        return std::log(T(0.5) * q + T(1));
+      case Welsch:
+        return T(1) - std::exp(T(-0.5) * q);
+      default:
+        return (std::pow(q / std::abs(alpha - T(2)) + T(1), T(0.5) * alpha) - T(1)) * std::abs(alpha - T(2)) / alpha;
+    }
+  }
+  T deriv(T s) const { // :136-155
+    const T q = s * invC2;
+    switch (type) {
+      case L2:
+        return invC2;
+      case L1:
+        return T(0.5) * invC2 / std::sqrt(q + T(1));
+      case Cauchy:
+        return invC2 / (invC2 * s + T(2));
+      case Welsch:
+        return T(0.5) * invC2 * std::exp(T(-0.5) * q);
+      default:
+        return T(0.5) * invC2 * std::pow(q / std::abs(alpha - T(2)) + T(1), T(0.5) * alpha - T(1));
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // constraints (momentum/character_solver/error_function_types.h:34-44,
 // position_error_function.h:16-29, orientation_error_function.h:16-36)
@@ -283,6 +338,7 @@ struct Constraints {
   const float* oriWeight = nullptr; // [Ko]
   float posFunctionWeight = 1.f; // SkeletonErrorFunction::weight_
   float oriFunctionWeight = 1.f;
+  Loss<T> posLoss, oriLoss; // JointErrorFunctionT::loss_ of the two blocks (default L2, c = 1)
   // parameter-space blocks
   int P = 0; // model parameters (needed for the row count of the model-parameter block)
   int NL = 0; // LimitErrorFunctionT, limit types on model parameters (parameter_limits.h:20-31)
@@ -310,16 +366,6 @@ inline bool limitInRange(const mmx_parameter_limit& l, float value) {
 template <class T>
 inline T ln2() { // momentum/math/constants.h:30,40
   return T(0.693147180559945309417232121458176568);
-}
-
-// GeneralizedLossT L2 branch (momentum/math/generalized_loss.cpp:25-32): value = s/c^2, deriv = 1/c^2, c = 1
-template <class T>
-inline T lossValue(T s) {
-  return s;
-}
-template <class T>
-inline T lossDeriv(T) {
-  return T(1);
 }
 
 // The generic ancestor walk of JointErrorFunctionT::getJacobian
@@ -421,11 +467,11 @@ inline double evalErrorFunctions(
       const T sqr = dot(f, f);
       const T w = cw * T(cs.posFunctionWeight);
       if (jac == nullptr) {
-        error += double(cw * lossValue(sqr)); // getError: weight_ applied after the loop (:50-53)
+        error += double(cw * cs.posLoss.value(sqr)); // getError: weight_ applied after the loop (:50-53)
         continue;
       }
-      error += double(w * lossValue(sqr)); // :207
-      const T derivScale = std::sqrt(w * lossDeriv(sqr)); // :208
+      error += double(w * cs.posLoss.value(sqr)); // :207
+      const T derivScale = std::sqrt(w * cs.posLoss.deriv(sqr)); // :208
       const int row = 3 * c;
       res[row + 0] = derivScale * f.x; // :212-213
       res[row + 1] = derivScale * f.y;
@@ -467,11 +513,11 @@ inline double evalErrorFunctions(
       }
       const T w = cw * T(cs.oriFunctionWeight);
       if (jac == nullptr) {
-        error += double(cw * lossValue(sqr));
+        error += double(cw * cs.oriLoss.value(sqr));
         continue;
       }
-      error += double(w * lossValue(sqr));
-      const T derivScale = std::sqrt(w * lossDeriv(sqr));
+      error += double(w * cs.oriLoss.value(sqr));
+      const T derivScale = std::sqrt(w * cs.oriLoss.deriv(sqr));
       const int row = 3 * cs.Kp + 9 * c;
       for (int i = 0; i < 9; ++i) {
         res[row + i] = derivScale * f[i];

@@ -55,6 +55,12 @@ Constraints<T> makeConstraints(
   cs.oriWeight = c->ori_weight ? c->ori_weight + b * Ko : nullptr;
   cs.posFunctionWeight = c->pos_function_weight;
   cs.oriFunctionWeight = c->ori_function_weight;
+  if (c->pos_loss_c > 0.f) {
+    cs.posLoss = Loss<T>(c->pos_loss_alpha == MMX_LOSS_WELSCH ? std::numeric_limits<T>::lowest() : T(c->pos_loss_alpha), T(c->pos_loss_c));
+  }
+  if (c->ori_loss_c > 0.f) {
+    cs.oriLoss = Loss<T>(c->ori_loss_alpha == MMX_LOSS_WELSCH ? std::numeric_limits<T>::lowest() : T(c->ori_loss_alpha), T(c->ori_loss_c));
+  }
   cs.P = P;
   cs.NL = c->num_limits;
   cs.limits = c->limits;

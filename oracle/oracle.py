@@ -68,6 +68,8 @@ class Constraints:
         model_target=None,
         model_weights=None,
         model_function_weight: float = 1.0,
+        pos_loss=(2.0, 1.0),
+        ori_loss=(2.0, 1.0),
     ):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         self.pos_parent = np.ascontiguousarray(pos_parent, dtype=np.int32).reshape(-1)
@@ -86,6 +88,8 @@ class Constraints:
         self.model_target = None if model_target is None else f(model_target)
         self.model_weights = None if model_weights is None else f(model_weights)
         self.model_function_weight = float(model_function_weight)
+        self.pos_loss = (float(pos_loss[0]), float(pos_loss[1]))  # GeneralizedLoss (alpha, c)
+        self.ori_loss = (float(ori_loss[0]), float(ori_loss[1]))
 
     @property
     def P(self) -> int:
@@ -112,6 +116,10 @@ class Constraints:
             len(self.limits),
             C.cast(self._limit_array, C.c_void_p) if self.limits else None,
             self.limit_function_weight,
+            self.pos_loss[0],
+            self.pos_loss[1],
+            self.ori_loss[0],
+            self.ori_loss[1],
         )
 
     def instance(self, b: int) -> "Constraints":
@@ -132,6 +140,8 @@ class Constraints:
             None if self.model_target is None else self.model_target.reshape(-1, self.P)[b if self.model_target.ndim > 1 else 0],
             None if self.model_weights is None else self.model_weights.reshape(-1, self.P)[b if self.model_weights.ndim > 1 else 0],
             self.model_function_weight,
+            self.pos_loss,
+            self.ori_loss,
         )
 
 
