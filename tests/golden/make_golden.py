@@ -25,8 +25,35 @@ from tests.helpers import make_problem  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def dump(name, rig, pos_parent, ori_parent, batch, seed, perturb):
+def limits_to_array(limits):
+    """[N,8] float64 rows (type, index0, index1, weight, v0..v3) of _abi.ParameterLimit"""
+    return np.array([[l.type, l.index0, l.index1, l.weight, *list(l.v)] for l in limits], dtype=np.float64).reshape(-1, 8)
+
+
+def dump(name, rig, pos_parent, ori_parent, batch, seed, perturb, extras=False):
     cons, th0, ths = make_problem(rig, pos_parent, ori_parent, batch, seed=seed, perturb=perturb)
+    extra = {}
+    if extras:
+        # parameter limits, a model-parameter prior and a Cauchy loss on the position block
+        from momentum_amd._abi import ParameterLimit
+
+        P = rig.num_params
+        rng = np.random.default_rng(seed + 99)
+        limits = [
+            ParameterLimit.minmax(7, -0.05, 0.05, 2.0),
+            ParameterLimit.minmax(20, -0.1, 0.02, 1.0),
+            ParameterLimit.linear(9, 12, 0.5, 0.05, weight=1.5),
+            ParameterLimit.linear(30, 31, 1.0, -0.1, -0.1, float(np.finfo(np.float32).max), weight=0.5),
+            ParameterLimit.halfplane(15, 16, 0.6, 0.8, 0.05, 1.0),
+        ]
+        mt = rng.uniform(-0.1, 0.1, size=(batch, P)).astype(np.float32)
+        mw = rng.uniform(-0.2, 1.0, size=(batch, P)).astype(np.float32)
+        cons = orc.Constraints(
+            cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset, cons.ori_target, cons.ori_weight,
+            limits=limits, limit_function_weight=0.8, model_target=mt, model_weights=mw, model_function_weight=1.2, pos_loss=(0.0, 0.1),
+        )  # fmt: skip
+        extra = dict(limits=limits_to_array(limits), limit_function_weight=0.8, model_target=mt, model_weights=mw,
+                     model_function_weight=1.2, pos_loss=np.array([0.0, 0.1]), ori_loss=np.array([2.0, 1.0]))  # fmt: skip
     opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
     ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
     J0, r0, e0 = orc.eval_jacobian(rig, cons.instance(0), th0[0].astype(np.float64), dtype="f64")
@@ -37,7 +64,7 @@ def dump(name, rig, pos_parent, ori_parent, batch, seed, perturb):
         pos_offset=cons.pos_offset, pos_target=cons.pos_target, pos_weight=cons.pos_weight,
         ori_offset=cons.ori_offset, ori_target=cons.ori_target, ori_weight=cons.ori_weight,
         theta0=th0, theta_star=ths, theta_final=ref["theta"], final_error=ref["error"], error_history=ref["error_history"],
-        iterations=ref["iterations"], jac0=J0.astype(np.float32), res0=r0, err0=np.float64(e0), state_star0=st0,
+        iterations=ref["iterations"], jac0=J0.astype(np.float32), res0=r0, err0=np.float64(e0), state_star0=st0, **extra,
     )  # fmt: skip
     print(name, "batch", batch, "final error", ref["error"])
 
@@ -49,3 +76,5 @@ if __name__ == "__main__":
     rig = make_humanoid72(seed=12345, variant="p128", unit=0.01)
     lm = humanoid72_landmark_joints(rig)
     dump("cfg2_humanoid72.npz", rig, lm, lm, 4, 12345, 0.3)
+    # the same with parameter limits, a model-parameter prior and a robust loss
+    dump("cfg2_limits_prior_cauchy.npz", rig, lm, lm, 4, 4321, 0.3, extras=True)

@@ -13,13 +13,31 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = {
     "cfg1_chain24.npz": lambda: make_test_character(24),
     "cfg2_humanoid72.npz": lambda: make_humanoid72(seed=12345, variant="p128", unit=0.01),
+    "cfg2_limits_prior_cauchy.npz": lambda: make_humanoid72(seed=12345, variant="p128", unit=0.01),
 }
 OPT = dict(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
 
 
+def _extras(g):
+    """keyword arguments of the optional blocks stored in a fixture (limits, model prior, losses)"""
+    if "limits" not in g.files:
+        return {}
+    from momentum_amd._abi import ParameterLimit
+
+    limits = []
+    for row in g["limits"]:
+        l = ParameterLimit(int(row[0]), int(row[1]), int(row[2]), float(row[3]))
+        for k in range(4):
+            l.v[k] = float(row[4 + k])
+        limits.append(l)
+    return dict(limits=limits, limit_function_weight=float(g["limit_function_weight"]), model_target=g["model_target"],
+                model_weights=g["model_weights"], model_function_weight=float(g["model_function_weight"]),
+                pos_loss=tuple(g["pos_loss"]), ori_loss=tuple(g["ori_loss"]))  # fmt: skip
+
+
 def _cons(orc, g):
     return orc.Constraints(g["pos_parent"], g["pos_offset"], g["pos_target"], g["pos_weight"],
-                           g["ori_parent"], g["ori_offset"], g["ori_target"], g["ori_weight"])  # fmt: skip
+                           g["ori_parent"], g["ori_offset"], g["ori_target"], g["ori_weight"], **_extras(g))  # fmt: skip
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -51,8 +69,11 @@ def test_hip_path_matches_fixture(orc, name):
     dev = pb.device
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
     Kp, Ko = len(g["pos_parent"]), len(g["ori_parent"])
+    ex = _extras(g)
+    if ex:
+        ex["model_target"], ex["model_weights"] = t(ex["model_target"]), t(ex["model_weights"])
     pb.set_constraints(t(g["pos_offset"]).reshape(B, Kp, 3), t(g["pos_target"]).reshape(B, Kp, 3), t(g["pos_weight"]).reshape(B, Kp),
-                       t(g["ori_offset"]).reshape(B, Ko, 4), t(g["ori_target"]).reshape(B, Ko, 4), t(g["ori_weight"]).reshape(B, Ko))  # fmt: skip
+                       t(g["ori_offset"]).reshape(B, Ko, 4), t(g["ori_target"]).reshape(B, Ko, 4), t(g["ori_weight"]).reshape(B, Ko), **ex)  # fmt: skip
     # world transforms at theta*
     st = pb.skeleton_state(t(g["theta_star"])).cpu().numpy()[0]
     assert np.abs(st - g["state_star0"]).max() <= 5e-6 * max(1.0, np.abs(g["state_star0"]).max())
