@@ -1349,8 +1349,10 @@ hipError_t launchFkJacobian(
     hipStream_t stream) {
   const size_t lds = fkJacobianLdsBytes(rig.J, rig.P);
   // one wave per instance fills the chip once B >> 256 CUs x ~24 resident waves; below that, four
-  // waves per instance shorten the per-instance critical path
-  const bool wide = pb.B < 2048; // measured: at B = 4096 one wave per instance (3.8 TB/s) beats four (3.2 TB/s)
+  // waves per instance shorten the per-instance critical path.  Large rigs are LDS-bound (a
+  // 300-joint instance needs 25 KB: six single-wave workgroups per CU), so they also take four
+  // waves per instance, which share one copy of the joint states.
+  const bool wide = pb.B < 2048 || lds > 12 * 1024; // measured: at B = 4096, J = 72 one wave per instance beats four
   if (jac != nullptr) {
     if (wide) {
       hipLaunchKernelGGL((fkJacobianKernel<true, 4>), dim3(pb.B), dim3(256), lds, stream, rig, pb, theta, jac, res, err, state, done);
