@@ -364,3 +364,35 @@ def test_config3_full_size_lm_schedule_properties(torch_cuda, orc):
     rel = np.linalg.norm(th[0].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
     tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
     assert np.all(rel <= tol), (rel, tol)
+
+
+def test_tensor_ik_default_options(torch_cuda, orc):
+    """The batch driver's defaults (pymomentum/tensor_ik/solver_options.h:28-37): levmar_lambda =
+    0.01, minIter = 4, maxIter = 50, threshold = 10, lineSearch = true (its default linear solver,
+    QR, solves the same regularised normal equations as the Cholesky path).  Instances stop at
+    their own iteration; the converged poses must agree with the oracle's double solve."""
+    torch = torch_cuda
+    rig, pp, op, B = _case("humanoid72_cfg2")
+    B = 8
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=2024, perturb=0.3)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=4, max_iterations=50, threshold=10.0, regularization=0.01, do_line_search=True)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    it, itref = out["iterations"].cpu().numpy(), ref["iterations"]
+    assert np.all(it >= 5) and np.all(it <= 50)
+    # the stop test compares relative error changes of ~1e-6: fp32 may fire an iteration or two apart
+    assert np.abs(it - itref).max() <= 3, (it, itref)
+    th = out["theta"].cpu().numpy()
+    # all instances are converged, so a different stopping iteration moves theta by less than the
+    # last step; compare the poses through the joint world positions like test_solver2.py:135-200
+    st = pb.skeleton_state(out["theta"]).cpu().numpy()
+    for b in range(B):
+        sref = orc.skeleton_state(rig, ref["theta"][b], "f64")["world"]
+        assert np.abs(st[b][:, :3] - sref[:, :3]).max() <= 1e-4
+    e, eref = out["error"].cpu().numpy(), ref["error"]
+    assert np.all(np.abs(e - eref) <= 1e-3 * eref + 1e-9), (e, eref)
+    h = out["error_history"].cpu().numpy()
+    assert np.all(np.diff(h[:, : it.min()], axis=1) <= 1e-6 * np.abs(h[:, : it.min() - 1]) + 1e-12)  # line search: monotone
+    assert np.all(out["status"].cpu().numpy() == 0)
+    del th
