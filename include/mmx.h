@@ -104,11 +104,17 @@ typedef struct mmx_rig_desc {
  * OrientationDataT constructor does (orientation_error_function.h:33-35).
  */
 /*
- * One entry of Character::parameterLimits restricted to the limit types that act on MODEL
- * parameters (momentum/character/parameter_limits.h:20-31,33-99,125-136): the rows of
- * LimitErrorFunctionT that need no joint state.
+ * One entry of Character::parameterLimits restricted to the limit types that act on model or
+ * joint PARAMETERS (momentum/character/parameter_limits.h:20-31,33-99,125-136): the rows of
+ * LimitErrorFunctionT that need no joint transforms.  Ellipsoid limits and
+ * the passive MinMaxJointPassive type are not handled here.
  */
 #define MMX_LIMIT_MINMAX 0 /* LimitType::MinMax    : index0 = parameterIndex ; v = {min, max} */
+#define MMX_LIMIT_MINMAX_JOINT 1 /* LimitType::MinMaxJoint : index0 = 7 * jointIndex + jointParameter (a row of the
+                                    parameter transform) ; v = {min, max} on that JOINT parameter */
+#define MMX_LIMIT_LINEAR_JOINT 4 /* LimitType::LinearJoint : index0 = 7 * referenceJointIndex + referenceJointParameter,
+                                    index1 = 7 * targetJointIndex + targetJointParameter ;
+                                    v = {scale, offset, rangeMin, rangeMax} */
 #define MMX_LIMIT_LINEAR 3 /* LimitType::Linear    : index0 = referenceIndex, index1 = targetIndex ;
                               v = {scale, offset, rangeMin, rangeMax}  (p_ref = scale * p_target - offset) */
 #define MMX_LIMIT_HALFPLANE 6 /* LimitType::HalfPlane : index0 = param1, index1 = param2 ;

@@ -121,7 +121,7 @@ struct mmx_problem {
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
   DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb, dDfsJoint, dLoadedPos;
-  DevBuf dLimStart, dLimOf, dPairDest, dPairStart, dPairLim;
+  DevBuf dLimStart, dLimOf, dPairDest, dPairStart, dPairLim, dPairCols;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight, oMpTarget, oMpWeights, dLimits, dEnabledMask;
@@ -134,6 +134,41 @@ struct mmx_problem {
 };
 
 namespace {
+
+// model parameters that can carry a non-zero Jacobian entry of a limit row
+std::vector<int32_t> limitParameters(const mmx_rig* rig, const mmx_parameter_limit& lm) {
+  std::vector<int32_t> out;
+  auto add = [&](int32_t p) {
+    if (std::find(out.begin(), out.end(), p) == out.end()) {
+      out.push_back(p);
+    }
+  };
+  auto addRow = [&](int32_t row) {
+    for (int32_t k = rig->ptOuter[size_t(row)]; k < rig->ptOuter[size_t(row) + 1]; ++k) {
+      add(rig->ptInner[size_t(k)]);
+    }
+  };
+  switch (lm.type) {
+    case MMX_LIMIT_MINMAX:
+      add(lm.index0);
+      break;
+    case MMX_LIMIT_LINEAR:
+    case MMX_LIMIT_HALFPLANE:
+      add(lm.index0);
+      add(lm.index1);
+      break;
+    case MMX_LIMIT_MINMAX_JOINT:
+      addRow(lm.index0);
+      break;
+    case MMX_LIMIT_LINEAR_JOINT:
+      addRow(lm.index1);
+      addRow(lm.index0);
+      break;
+    default:
+      break;
+  }
+  return out;
+}
 
 int32_t uploadProblemTables(mmx_problem* pb) {
   const mmx_rig* rig = pb->rig;
@@ -195,9 +230,8 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     // parameters touched by a limit or (all of them) by the model-parameter block stay in the solve list
     std::vector<uint8_t> force(size_t(rig->P), pb->dev.hasModel ? 1 : 0);
     for (const mmx_parameter_limit& lm : pb->limits) {
-      force[size_t(lm.index0)] = 1;
-      if (lm.type != MMX_LIMIT_MINMAX) {
-        force[size_t(lm.index1)] = 1;
+      for (int32_t p : limitParameters(rig, lm)) {
+        force[size_t(p)] = 1;
       }
     }
     const int32_t rc = mmx::buildFusedTables(
@@ -386,20 +420,25 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       }
       std::vector<std::vector<int32_t>> per(size_t(std::max(fd.n, 1)));
       std::map<int32_t, std::vector<int32_t>> pairs; // tile-region offset -> limits
+      std::map<int32_t, std::pair<int32_t, int32_t>> pairColumns;
       for (size_t l = 0; l < pb->limits.size(); ++l) {
-        const mmx_parameter_limit& lm = pb->limits[l];
-        const int32_t c0 = colOf[size_t(lm.index0)];
-        const int32_t c1 = lm.type != MMX_LIMIT_MINMAX ? colOf[size_t(lm.index1)] : -1;
-        if (c0 >= 0) {
-          per[size_t(c0)].push_back(int32_t(l));
+        std::vector<int32_t> cols;
+        for (int32_t p : limitParameters(rig, pb->limits[l])) {
+          if (colOf[size_t(p)] >= 0) {
+            cols.push_back(colOf[size_t(p)]);
+          }
         }
-        if (c1 >= 0 && c1 != c0) {
-          per[size_t(c1)].push_back(int32_t(l));
+        for (int32_t c : cols) {
+          per[size_t(c)].push_back(int32_t(l));
         }
-        if (c0 >= 0 && c1 >= 0 && c0 != c1) {
-          const int32_t row = std::max(c0, c1), col = std::min(c0, c1);
-          const int I = row >> 4, Jc = col >> 4, r = row & 15, c = col & 15;
-          pairs[(I * (I + 1) / 2 + Jc) * 256 + r * 16 + ((((c >> 2) ^ (r >> 2)) & 3) << 2) + (c & 3)].push_back(int32_t(l));
+        for (size_t x = 0; x < cols.size(); ++x) {
+          for (size_t y = x + 1; y < cols.size(); ++y) {
+            const int32_t row = std::max(cols[x], cols[y]), col = std::min(cols[x], cols[y]);
+            const int I = row >> 4, Jc = col >> 4, r = row & 15, c = col & 15;
+            const int32_t dest = (I * (I + 1) / 2 + Jc) * 256 + r * 16 + ((((c >> 2) ^ (r >> 2)) & 3) << 2) + (c & 3);
+            pairs[dest].push_back(int32_t(l));
+            pairColumns[dest] = {row, col};
+          }
         }
       }
       std::vector<int32_t> limStart(1, 0), limOf, pairDest, pairStart(1, 0), pairLim;
@@ -407,11 +446,16 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         limOf.insert(limOf.end(), per[size_t(c)].begin(), per[size_t(c)].end());
         limStart.push_back(int32_t(limOf.size()));
       }
+      std::vector<int32_t> pairCols;
       for (const auto& kv : pairs) {
         pairDest.push_back(kv.first);
+        pairCols.push_back(pairColumns[kv.first].first);
+        pairCols.push_back(pairColumns[kv.first].second);
         pairLim.insert(pairLim.end(), kv.second.begin(), kv.second.end());
         pairStart.push_back(int32_t(pairLim.size()));
       }
+      MMX_HIP(upload(pb->dPairCols, pairCols));
+      fd.pairCols = pb->dPairCols.as<int32_t>();
       MMX_HIP(upload(pb->dLimStart, limStart));
       MMX_HIP(upload(pb->dLimOf, limOf));
       MMX_HIP(upload(pb->dPairDest, pairDest));
@@ -837,14 +881,21 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   }
   for (int32_t l = 0; l < c->num_limits; ++l) {
     const mmx_parameter_limit& lm = c->limits[l];
-    const bool two = lm.type == MMX_LIMIT_LINEAR || lm.type == MMX_LIMIT_HALFPLANE;
-    if (lm.type != MMX_LIMIT_MINMAX && !two) {
+    const bool model = lm.type == MMX_LIMIT_MINMAX || lm.type == MMX_LIMIT_LINEAR || lm.type == MMX_LIMIT_HALFPLANE;
+    const bool joint = lm.type == MMX_LIMIT_MINMAX_JOINT || lm.type == MMX_LIMIT_LINEAR_JOINT;
+    const bool two = lm.type == MMX_LIMIT_LINEAR || lm.type == MMX_LIMIT_HALFPLANE || lm.type == MMX_LIMIT_LINEAR_JOINT;
+    if (!model && !joint) {
       return fail(
           MMX_ERR_UNSUPPORTED,
-          "limit " + std::to_string(l) + ": only the model-parameter limit types MinMax, Linear and HalfPlane are implemented");
+          "limit " + std::to_string(l) +
+              ": only MinMax, MinMaxJoint, Linear, LinearJoint and HalfPlane limits are implemented (no Ellipsoid / passive limits)");
     }
-    if (lm.index0 < 0 || lm.index0 >= P || (two && (lm.index1 < 0 || lm.index1 >= P))) {
-      return fail(MMX_ERR_INVALID_ARGUMENT, "limit " + std::to_string(l) + ": parameter index out of range"); // MT_CHECK :574-575
+    const int32_t bound = joint ? MMX_PARAMS_PER_JOINT * pb->rig->J : P;
+    if (lm.index0 < 0 || lm.index0 >= bound || (two && (lm.index1 < 0 || lm.index1 >= bound))) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "limit " + std::to_string(l) + ": parameter index out of range"); // MT_CHECK :574-575,:611-612
+    }
+    if (limitParameters(pb->rig, lm).size() > 4) {
+      return fail(MMX_ERR_UNSUPPORTED, "limit " + std::to_string(l) + ": more than four model parameters drive the limited joint parameters");
     }
   }
   const bool structureChanged = (c->model_target != nullptr) != (d.hasModel != 0) || size_t(c->num_limits) != pb->limits.size() ||

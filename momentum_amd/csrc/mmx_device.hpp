@@ -613,20 +613,60 @@ __device__ __forceinline__ F3 sourceDerivative(const ColumnSourceDev& s, const f
   return kLn2 * (un.v - F3{a[0], a[1], a[2]}); // scale: (v - t_a) * ln2
 }
 
-// One row of LimitErrorFunctionT::getJacobian for a model-parameter limit with the L2 loss
-// (momentum/character_solver/limit_error_function.cpp: computeMinMaxJacobian :460-503,
-// computeLinearJacobian :561-595, computeHalfPlaneJacobian :659-695).
+// One row of LimitErrorFunctionT::getJacobian with the L2 loss for the limit types that act on
+// model or joint parameters (momentum/character_solver/limit_error_function.cpp:
+// computeMinMaxJacobian :460-503, computeMinMaxJointJacobian :503-558, computeLinearJacobian
+// :561-595, computeLinearJointJacobian :597-656, computeHalfPlaneJacobian :659-695).
+constexpr int kLimitEntries = 4; // non-zero Jacobian entries of a row (joint limits: <= 2 per transform row)
 struct LimitRow {
-  int ia, ib; // model parameters with a non-zero entry (-1: none)
-  float ca, cb; // the entries
+  int idx[kLimitEntries]; // model parameters with a non-zero entry (-1: unused)
+  float coef[kLimitEntries]; // the entries
   float r; // residual entry
   float err; // this row's error term
 };
 
-__device__ __forceinline__ LimitRow evalLimit(const LimitDev& lm, const float* th, const uint8_t* enabled, float tWeight) {
+// joint parameter `row` of the parameter transform: value (transform * theta + offsets) and
+// whether the row has an enabled column (activeJointParams, parameter_transform.cpp:97-107)
+__device__ __forceinline__ float limitJointParam(const RigDev& rig, const float* th, const uint8_t* enabled, int row, bool& active) {
+  float v = rig.ptOffsets[row];
+  active = false;
+  const int k1 = rig.ptOuter[row + 1];
+  for (int k = rig.ptOuter[row]; k < k1; ++k) {
+    const int p = rig.ptInner[k];
+    v += rig.ptValue[k] * th[p];
+    active = active || enabled[p] != 0;
+  }
+  return v;
+}
+
+// adds weight * T[row, :] to the entries (jacobian_jointParams_to_modelParams, error_function_utils.h:77-91:
+// every column of the transform row, enabled or not; duplicates of a parameter add up)
+__device__ __forceinline__ void limitScatterRow(const RigDev& rig, LimitRow& o, int row, float weight) {
+  const int k1 = rig.ptOuter[row + 1];
+  for (int k = rig.ptOuter[row]; k < k1; ++k) {
+    const int p = rig.ptInner[k];
+    const float c = weight * rig.ptValue[k];
+    bool placed = false;
+#pragma unroll
+    for (int e = 0; e < kLimitEntries; ++e) {
+      if (!placed && (o.idx[e] == p || o.idx[e] < 0)) {
+        o.coef[e] = o.idx[e] == p ? o.coef[e] + c : c;
+        o.idx[e] = p;
+        placed = true;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ LimitRow
+evalLimit(const RigDev& rig, const LimitDev& lm, const float* th, const uint8_t* enabled, float tWeight) {
   LimitRow o;
-  o.ia = o.ib = -1;
-  o.ca = o.cb = o.r = o.err = 0.f;
+#pragma unroll
+  for (int e = 0; e < kLimitEntries; ++e) {
+    o.idx[e] = -1;
+    o.coef[e] = 0.f;
+  }
+  o.r = o.err = 0.f;
   const float wgt = sqrtf(tWeight * lm.weight); // :1018-1021
   if (lm.type == 0) { // MinMax
     const int p = lm.index0;
@@ -644,8 +684,28 @@ __device__ __forceinline__ LimitRow evalLimit(const LimitDev& lm, const float* t
       hit = true;
     }
     if (hit) {
-      o.ia = p;
-      o.ca = wgt;
+      o.idx[0] = p;
+      o.coef[0] = wgt;
+      o.r = val * wgt;
+      o.err = tWeight * lm.weight * (val * val);
+    }
+  } else if (lm.type == 1) { // MinMaxJoint: limits on the joint parameter index0
+    bool active;
+    const float jp = limitJointParam(rig, th, enabled, lm.index0, active);
+    if (!active) {
+      return o;
+    }
+    float val = 0.f;
+    bool hit = false;
+    if (jp < lm.v[0]) {
+      val = jp - lm.v[0];
+      hit = true;
+    } else if (jp > lm.v[1]) {
+      val = jp - lm.v[1];
+      hit = true;
+    }
+    if (hit) {
+      limitScatterRow(rig, o, lm.index0, wgt);
       o.r = val * wgt;
       o.err = tWeight * lm.weight * (val * val);
     }
@@ -658,15 +718,33 @@ __device__ __forceinline__ LimitRow evalLimit(const LimitDev& lm, const float* t
     const float rs = th[tgt] * lm.v[0] - lm.v[1] - th[ref];
     o.r = rs * wgt;
     if (enabled[tgt]) {
-      o.ia = tgt;
-      o.ca = lm.v[0] * wgt;
+      o.idx[0] = tgt;
+      o.coef[0] = lm.v[0] * wgt;
     }
     if (enabled[ref]) {
-      o.ib = ref;
-      o.cb = -wgt;
+      o.idx[1] = ref;
+      o.coef[1] = -wgt;
     }
-    if (o.ia == o.ib) {
-      o.ia = -1; // jacobian(row, ref) = ... is assigned after (row, tgt) and overwrites it (:590-594)
+    if (o.idx[0] == o.idx[1]) {
+      o.idx[0] = -1; // jacobian(row, ref) = ... is assigned after (row, tgt) and overwrites it (:590-594)
+      o.coef[0] = 0.f;
+    }
+    o.err = tWeight * lm.weight * (rs * rs);
+  } else if (lm.type == 4) { // LinearJoint: the same relation between two joint parameters
+    bool actRef, actTgt;
+    const float jr = limitJointParam(rig, th, enabled, lm.index0, actRef);
+    const float jt = limitJointParam(rig, th, enabled, lm.index1, actTgt);
+    const bool inRange = (lm.v[2] == 0.f && lm.v[3] == 0.f) || (jt >= lm.v[2] && jt < lm.v[3]);
+    if ((!actRef && !actTgt) || !inRange) {
+      return o;
+    }
+    const float rs = jt * lm.v[0] - lm.v[1] - jr;
+    o.r = rs * wgt;
+    if (actTgt) {
+      limitScatterRow(rig, o, lm.index1, lm.v[0] * wgt);
+    }
+    if (actRef) {
+      limitScatterRow(rig, o, lm.index0, -wgt);
     }
     o.err = tWeight * lm.weight * (rs * rs);
   } else if (lm.type == 6) { // HalfPlane: (p1, p2) . normal - offset >= 0
@@ -680,21 +758,21 @@ __device__ __forceinline__ LimitRow evalLimit(const LimitDev& lm, const float* t
     }
     o.r = rs * wgt;
     if (enabled[p1]) {
-      o.ia = p1;
-      o.ca = lm.v[0] * wgt;
+      o.idx[0] = p1;
+      o.coef[0] = lm.v[0] * wgt;
     }
     if (enabled[p2]) {
-      o.ib = p2;
-      o.cb = lm.v[1] * wgt;
+      o.idx[1] = p2;
+      o.coef[1] = lm.v[1] * wgt;
     }
-    if (o.ia == o.ib) {
-      o.ia = -1; // (:689-694)
+    if (o.idx[0] == o.idx[1]) {
+      o.idx[0] = -1; // (:689-694)
+      o.coef[0] = 0.f;
     }
     o.err = tWeight * lm.weight * (rs * rs);
   }
   return o;
 }
-
 
 // ---- 16x16 fp32 tile helpers shared by the fused solver and the large-system Cholesky
 typedef float v4f __attribute__((ext_vector_type(4)));

@@ -175,12 +175,12 @@ __device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, fl
 // getJacobian returns (model rows with weight <= 0 are skipped, model_parameters_error_function.cpp:113),
 // else the one getError returns (:54-58).
 template <bool kJacobianRows>
-__device__ __forceinline__ double paramRowsError(const ProblemDev& pb, int P, const float* th, int b, int tid) {
+__device__ __forceinline__ double paramRowsError(const RigDev& rig, const ProblemDev& pb, int P, const float* th, int b, int tid) {
   double e = 0.0;
   if (pb.NL > 0 && pb.wLimit > 0.f) {
     const float tWeight = 1e+1f * pb.wLimit;
     for (int l = tid; l < pb.NL; l += 256) {
-      e += double(evalLimit(pb.limits[l], th, pb.enabledMask, tWeight).err);
+      e += double(evalLimit(rig, pb.limits[l], th, pb.enabledMask, tWeight).err);
     }
   }
   if (pb.hasModel && pb.wModel > 0.f) {
@@ -208,6 +208,7 @@ struct ParamCol {
 // contributions of the rows to solve column c = parameter p: g_c = sum_l J(l,c) r_l and
 // H_cc = sum_l J(l,c)^2.  With a step `d0` the residual is replaced by r - J d0 (refinement).
 __device__ __forceinline__ ParamCol paramRowsColumn(
+    const RigDev& rig,
     const ProblemDev& pb,
     const FusedDev& fd,
     const float* th,
@@ -222,12 +223,15 @@ __device__ __forceinline__ ParamCol paramRowsColumn(
     const float tWeight = 1e+1f * pb.wLimit;
     const int k1 = fd.limStart[c + 1];
     for (int k = fd.limStart[c]; k < k1; ++k) {
-      const LimitRow row = evalLimit(pb.limits[fd.limOf[k]], th, pb.enabledMask, tWeight);
-      const float coef = (row.ia == p ? row.ca : 0.f) + (row.ib == p ? row.cb : 0.f);
-      float rr = row.r;
-      if (d0 != nullptr) {
-        const int sa = row.ia >= 0 ? colToSolve[row.ia] : -1, sb = row.ib >= 0 ? colToSolve[row.ib] : -1;
-        rr -= row.ca * (sa >= 0 ? d0[sa] : 0.f) + row.cb * (sb >= 0 ? d0[sb] : 0.f);
+      const LimitRow row = evalLimit(rig, pb.limits[fd.limOf[k]], th, pb.enabledMask, tWeight);
+      float coef = 0.f, rr = row.r;
+#pragma unroll
+      for (int e = 0; e < kLimitEntries; ++e) {
+        coef += row.idx[e] == p ? row.coef[e] : 0.f;
+        if (d0 != nullptr) {
+          const int sc = row.idx[e] >= 0 ? colToSolve[row.idx[e]] : -1;
+          rr -= row.coef[e] * (sc >= 0 ? d0[sc] : 0.f); // parameters outside the solve list do not move
+        }
       }
       o.g += coef * rr;
       o.h += coef * coef;
@@ -275,6 +279,7 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
 // `th`: FK without derivatives + sum of w * |f|^2, rounded through float like the reference (:82).
 // Every thread returns the same value.  Clobbers the FK scratch / js / red.
 __device__ __forceinline__ double blockError(
+    const RigDev& rigDev,
     const RigView& rig,
     const ProblemDev& pb,
     const FusedView& fd,
@@ -289,7 +294,7 @@ __device__ __forceinline__ double blockError(
     e += double(evalUnit(pb, s.js, b, u).werr);
   }
   if (pb.M > pb.rowsJoint) {
-    e += paramRowsError<false>(pb, rig.P, th, b, tid);
+    e += paramRowsError<false>(rigDev, pb, rig.P, th, b, tid);
   }
   e = waveReduceSum(e);
   if (lane == 0) {
@@ -595,7 +600,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         e += double(un.werr);
       }
       if (hasParamRows) {
-        e += paramRowsError<true>(pb, P, s.th, b, tid);
+        e += paramRowsError<true>(rig, pb, P, s.th, b, tid);
       }
       e = waveReduceSum(e);
       if (lane == 0) {
@@ -676,7 +681,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         acc += s.mW[e] * s.srcT[kSrc * e + 14];
       }
       if (hasParamRows && c < n) {
-        const ParamCol pc = paramRowsColumn(pb, fd, s.th, nullptr, lColToSolve, P, b, c, lSolveList[c]);
+        const ParamCol pc = paramRowsColumn(rig, pb, fd, s.th, nullptr, lColToSolve, P, b, c, lSolveList[c]);
         acc += pc.g;
         s.rho[c] = pc.h; // parked until the tiles of H exist (phase G)
       }
@@ -750,10 +755,15 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           float accp = 0.f;
           const int k1 = fd.pairStart[d + 1];
           for (int k = fd.pairStart[d]; k < k1; ++k) {
-            const LimitRow row = evalLimit(pb.limits[fd.pairLim[k]], s.th, pb.enabledMask, tWeight);
-            if (row.ia >= 0 && row.ib >= 0) {
-              accp += row.ca * row.cb;
+            const LimitRow row = evalLimit(rig, pb.limits[fd.pairLim[k]], s.th, pb.enabledMask, tWeight);
+            float ca = 0.f, cb = 0.f; // the row's entries in the two columns of this H entry
+#pragma unroll
+            for (int e = 0; e < kLimitEntries; ++e) {
+              const int sc = row.idx[e] >= 0 ? lColToSolve[row.idx[e]] : -1;
+              ca += sc == fd.pairCols[2 * d] ? row.coef[e] : 0.f;
+              cb += sc == fd.pairCols[2 * d + 1] ? row.coef[e] : 0.f;
             }
+            accp += ca * cb;
           }
           s.L[fd.pairDest[d]] += accp;
         }
@@ -1034,7 +1044,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
             a += s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
           }
           if (hasParamRows) {
-            a += paramRowsColumn(pb, fd, s.th, s.d0, lColToSolve, P, b, c, lSolveList[c]).g;
+            a += paramRowsColumn(rig, pb, fd, s.th, s.d0, lColToSolve, P, b, c, lSolveList[c]).g;
           }
           a -= lambda * s.d0[c];
         }
@@ -1084,7 +1094,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         s.dfull[fv.solveList[c]] -= s.d0[c];
       }
       __syncthreads();
-      const double eNew = blockError(rv, pb, fv, s, s.dfull, b, tid);
+      const double eNew = blockError(rig, rv, pb, fv, s, s.dfull, b, tid);
       const float rho = predicted > 0.f ? float((curError - eNew) / double(predicted)) : -1.f;
       if (rho > 0.f) {
         for (int i = tid; i < P; i += 256) {
@@ -1112,7 +1122,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           s.dfull[fv.solveList[c]] -= scale * s.d0[c];
         }
         __syncthreads();
-        const double eNew = blockError(rv, pb, fv, s, s.dfull, b, tid);
+        const double eNew = blockError(rig, rv, pb, fv, s, s.dfull, b, tid);
         if ((curError - eNew) >= double(scale * scaledError)) {
           break;
         }

@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
 // (model_parameters_error_function.cpp:95-131; used rows compacted like `out` there).
 // =============================================================================================
 __global__ void __launch_bounds__(256) parameterRowsKernel(
+    RigDev rig,
     ProblemDev pb,
     int P,
     const float* __restrict__ theta,
@@ -271,11 +272,9 @@ __global__ void __launch_bounds__(256) parameterRowsKernel(
   const int NL = pb.NL, R0 = pb.rowsJoint;
   const int Pm = pb.hasModel ? P : 0;
   int* outOf = reinterpret_cast<int*>(smem); // [P] compacted model row of parameter i, or -1
-  int* ia = outOf + P; // [NL]
-  int* ib = ia + NL;
-  float* ca = reinterpret_cast<float*>(ib + NL);
-  float* cb = ca + NL;
-  double* red = reinterpret_cast<double*>(smem + ((P + 4 * NL + 1) & ~1)); // [4]
+  int* eidx = outOf + P; // [kLimitEntries][NL] non-zero entries of the limit rows
+  float* ecoef = reinterpret_cast<float*>(eidx + kLimitEntries * NL);
+  double* red = reinterpret_cast<double*>(smem + ((P + 2 * kLimitEntries * NL + 1) & ~1)); // [4]
   __shared__ int numUsed;
   const float* th = theta + size_t(b) * P;
   const size_t M = size_t(pb.M);
@@ -286,12 +285,20 @@ __global__ void __launch_bounds__(256) parameterRowsKernel(
   const float tWeight = 1e+1f * pb.wLimit;
   for (int l = tid; l < NL; l += 256) {
     LimitRow o;
-    o.ia = o.ib = -1;
-    o.ca = o.cb = o.r = o.err = 0.f;
-    if (limOn) {
-      o = evalLimit(pb.limits[l], th, pb.enabledMask, tWeight);
+#pragma unroll
+    for (int e = 0; e < kLimitEntries; ++e) {
+      o.idx[e] = -1;
+      o.coef[e] = 0.f;
     }
-    ia[l] = o.ia, ib[l] = o.ib, ca[l] = o.ca, cb[l] = o.cb;
+    o.r = o.err = 0.f;
+    if (limOn) {
+      o = evalLimit(rig, pb.limits[l], th, pb.enabledMask, tWeight);
+    }
+#pragma unroll
+    for (int e = 0; e < kLimitEntries; ++e) {
+      eidx[e * NL + l] = o.idx[e];
+      ecoef[e * NL + l] = o.coef[e];
+    }
     if (rb != nullptr) {
       rb[R0 + l] = o.r;
     }
@@ -358,7 +365,10 @@ __global__ void __launch_bounds__(256) parameterRowsKernel(
       for (int rr = lane; rr < R; rr += 64) {
         float v = 0.f;
         if (rr < NL) {
-          v = (ia[rr] == p ? ca[rr] : 0.f) + (ib[rr] == p ? cb[rr] : 0.f);
+#pragma unroll
+          for (int e = 0; e < kLimitEntries; ++e) {
+            v += eidx[e * NL + rr] == p ? ecoef[e * NL + rr] : 0.f;
+          }
         } else if (rr - NL == mine) {
           v = mval;
         }
@@ -369,7 +379,7 @@ __global__ void __launch_bounds__(256) parameterRowsKernel(
 }
 
 size_t parameterRowsLdsBytes(int P, int NL) {
-  return (size_t((P + 4 * NL + 1) & ~1) + 8) * sizeof(float);
+  return (size_t((P + 2 * kLimitEntries * NL + 1) & ~1) + 8) * sizeof(float);
 }
 
 // =============================================================================================
@@ -1368,7 +1378,7 @@ hipError_t launchFkJacobian(
   }
   if (pb.M > pb.rowsJoint && (jac != nullptr || res != nullptr || err != nullptr)) {
     hipLaunchKernelGGL(
-        parameterRowsKernel, dim3(pb.B), dim3(256), parameterRowsLdsBytes(rig.P, pb.NL), stream, pb, rig.P, theta, jac, res, err, done);
+        parameterRowsKernel, dim3(pb.B), dim3(256), parameterRowsLdsBytes(rig.P, pb.NL), stream, rig, pb, rig.P, theta, jac, res, err, done);
   }
   return hipGetLastError();
 }

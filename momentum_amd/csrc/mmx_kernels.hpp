@@ -57,6 +57,7 @@ struct FusedDev {
   const int32_t* limOf; // limit indices per solve column
   int32_t numPairDests;
   const int32_t* pairDest; // [numPairDests] float offset of the H entry inside the tile region
+  const int32_t* pairCols; // [numPairDests][2] the two solve columns of that entry
   const int32_t* pairStart; // [numPairDests+1]
   const int32_t* pairLim; // limit indices per destination
 };

@@ -540,7 +540,22 @@ inline double evalErrorFunctions(
 // (model_parameters_error_function.cpp: getError :43-62, getJacobian :95-131).
 // Rows: rowBase + l for limit l, then the model-parameter rows compacted like the reference.
 template <class T>
-inline double evalParameterRows(const Constraints<T>& cs, const T* theta, const uint8_t* enabled, T* jac, T* res) {
+inline double evalParameterRows(
+    const Rig& rig,
+    const Constraints<T>& cs,
+    const T* theta,
+    const T* jp, // joint parameters = transform * theta + offsets (state.jointParameters)
+    const uint8_t* active, // activeJointParams
+    const uint8_t* enabled,
+    T* jac,
+    T* res) {
+  // jacobian_jointParams_to_modelParams (error_function_utils.h:77-91): adds weight * T[row, :] to
+  // the Jacobian row -- every column of the transform row, enabled or not
+  auto scatterRow = [&](T weight, int jpRow, int r) {
+    for (int k = rig.outer[jpRow]; k < rig.outer[jpRow + 1]; ++k) {
+      jac[size_t(rig.inner[k]) * cs.rows() + r] += weight * T(rig.value[k]);
+    }
+  };
   const int M = cs.rows();
   double total = 0.0;
   int row = cs.jointRows();
@@ -595,6 +610,50 @@ inline double evalParameterRows(const Constraints<T>& cs, const T* theta, const 
           }
           if (enabled[ref]) {
             jac[size_t(ref) * M + r] = -wgt;
+          }
+          error += double(tWeight * limitWeight * sqr);
+        }
+      } else if (lm.type == MMX_LIMIT_MINMAX_JOINT) { // computeMinMaxJointError :63-96 / ...Jacobian :503-558
+        const int jr = lm.index0;
+        if (!active[jr]) {
+          continue;
+        }
+        T val = T(0);
+        bool hit = false;
+        if (jp[jr] < T(lm.v[0])) {
+          val = jp[jr] - T(lm.v[0]);
+          hit = true;
+        } else if (jp[jr] > T(lm.v[1])) { // the Jacobian version returns after the first branch (:538)
+          val = jp[jr] - T(lm.v[1]);
+          hit = true;
+        }
+        if (!hit) {
+          continue;
+        }
+        const T sqr = val * val;
+        if (jac == nullptr) {
+          error += double(limitWeight * sqr);
+        } else {
+          scatterRow(wgt, jr, r);
+          res[r] = val * wgt;
+          error += double(tWeight * limitWeight * sqr);
+        }
+      } else if (lm.type == MMX_LIMIT_LINEAR_JOINT) { // computeLinearJointError :118-145 / ...Jacobian :597-656
+        const int ref = lm.index0, tgt = lm.index1;
+        if ((!active[ref] && !active[tgt]) || !limitInRange(lm, float(jp[tgt]))) {
+          continue;
+        }
+        const T rs = jp[tgt] * T(lm.v[0]) - T(lm.v[1]) - jp[ref];
+        const T sqr = rs * rs;
+        if (jac == nullptr) {
+          error += double(limitWeight * sqr);
+        } else {
+          res[r] = rs * wgt;
+          if (active[tgt]) {
+            scatterRow(T(lm.v[0]) * wgt, tgt, r);
+          }
+          if (active[ref]) {
+            scatterRow(-wgt, ref, r);
           }
           error += double(tWeight * limitWeight * sqr);
         }
@@ -688,7 +747,7 @@ struct SolverFunction {
     applyParameterTransform<T>(rig, theta, jp.data());
     setSkeletonState<T>(rig, jp.data(), state);
     double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
-    e += evalParameterRows<T>(cs, theta, enabled.data(), nullptr, nullptr);
+    e += evalParameterRows<T>(rig, cs, theta, jp.data(), active.data(), enabled.data(), nullptr, nullptr);
     return double(float(e));
   }
   // :200-261 (initializeJacobianComputation + computeJacobianBlock for both blocks).  Blocks with
@@ -701,7 +760,7 @@ struct SolverFunction {
     std::fill(jac, jac + size_t(M) * rig.P, T(0));
     std::fill(res, res + M, T(0));
     double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
-    e += evalParameterRows<T>(cs, theta, enabled.data(), jac, res);
+    e += evalParameterRows<T>(rig, cs, theta, jp.data(), active.data(), enabled.data(), jac, res);
     return e;
   }
 };

@@ -126,10 +126,10 @@ def test_unsupported_limit_type_is_a_loud_error(torch_cuda):
     rh = capi.RigHandle(rig, 0)
     pb = capi.Problem(rh, 1, cons.pos_parent, cons.ori_parent)
     bad = PL.minmax(0, -1, 1)
-    bad.type = 1  # LimitType::MinMaxJoint needs joint state: not implemented
+    bad.type = 5  # LimitType::Ellipsoid needs joint transforms: not implemented
     with pytest.raises(capi.MmxError) as ei:
         _upload(torch, pb, cons, 1, limits=[bad])
-    assert "MinMax" in str(ei.value)
+    assert "Ellipsoid" in str(ei.value)
     oob = PL.linear(0, rig.num_params, 1.0, 0.0)
     with pytest.raises(capi.MmxError):
         _upload(torch, pb, cons, 1, limits=[oob])

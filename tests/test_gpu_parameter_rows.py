@@ -21,10 +21,10 @@ def torch_cuda():
     return torch
 
 
-def _limits(P, rng, count):
+def _limits(P, rng, count, rig=None):
     out = []
     for k in range(count):
-        kind = k % 4
+        kind = k % (6 if rig is not None else 4)
         a, b = rng.choice(P, size=2, replace=False)
         if kind == 0:
             out.append(ParameterLimit.minmax(a, -0.08, 0.12, rng.uniform(0.5, 2.0)))
@@ -32,10 +32,18 @@ def _limits(P, rng, count):
             out.append(ParameterLimit.linear(a, b, rng.uniform(-1, 1), rng.uniform(-0.2, 0.2), weight=rng.uniform(0.5, 2.0)))
         elif kind == 2:
             out.append(ParameterLimit.linear(a, b, 1.0, -0.1, -0.1, FLT_MAX, weight=0.5))  # piecewise: applies above -0.1 only
-        else:
+        elif kind == 3:
             n = rng.normal(size=2)
             n /= np.linalg.norm(n)
             out.append(ParameterLimit.halfplane(a, b, n[0], n[1], 0.1, rng.uniform(0.5, 2.0)))
+        else:
+            # joint-parameter limits on rotation rows that are driven by at least one model parameter
+            rows = [r for r in range(7 * rig.num_joints) if r % 7 in (3, 4, 5) and rig.pt_outer[r + 1] > rig.pt_outer[r]]
+            r0, r1 = rng.choice(rows, size=2, replace=False)
+            if kind == 4:
+                out.append(ParameterLimit.minmax_joint(r0 // 7, r0 % 7, -0.05, 0.08, rng.uniform(0.5, 2.0)))
+            else:
+                out.append(ParameterLimit.linear_joint(r0 // 7, r0 % 7, r1 // 7, r1 % 7, rng.uniform(-1, 1), 0.05, weight=rng.uniform(0.5, 2.0)))
     return out
 
 
@@ -45,7 +53,7 @@ def _problem(torch, orc, rig, pp, op, B, seed, with_limits=True, with_model=True
     cons, th0, ths = make_problem(rig, pp, op, B, seed=seed, perturb=0.3)
     P = rig.num_params
     rng = np.random.default_rng(seed + 7)
-    limits = _limits(P, rng, 13) if with_limits else []
+    limits = _limits(P, rng, 19, rig) if with_limits else []
     mt = rng.uniform(-0.2, 0.2, size=(B, P)).astype(np.float32) if with_model else None
     mw = rng.uniform(-0.3, 1.5, size=(B, P)).astype(np.float32) if with_model else None  # some weights <= 0: rows dropped
     full = orc.Constraints(

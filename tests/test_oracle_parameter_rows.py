@@ -158,3 +158,48 @@ def test_blocks_combine_with_joint_constraints_and_enabled_set():
     out = orc.solve(rig, full, np.zeros(P), opt, dtype="f64")
     hist = out["error_history"]
     assert np.all(np.diff(hist) <= 1e-9) and hist[-1] < hist[0]
+
+
+def test_limit_minmax_joint_and_linear_joint():
+    # limit_error_function_test.cpp:62-81 (MinMaxJoint on joint 2, parameter 5, limits +-0.1) and
+    # :170-196 (piecewise LinearJoint between joint 0 tz and joint 1 rz, driven by shared_rz)
+    rig = make_test_character(5)
+    cons = _cons(rig, [ParameterLimit.minmax_joint(2, 5, -0.1, 0.1, 1.0)])
+    _check(rig, cons, np.zeros(rig.num_params))
+    rng = np.random.default_rng(11)
+    hits = 0
+    for _ in range(10):
+        theta = rng.uniform(-1, 1, rig.num_params)
+        J, r, err = _check(rig, cons, theta)
+        hits += int(err > 0)
+    assert hits > 0
+    lims = [
+        ParameterLimit.linear_joint(0, 2, 1, 5, 1.0, -4.0, -FLT_MAX, 0.0, weight=0.75),
+        ParameterLimit.linear_joint(0, 2, 1, 5, -1.0, -4.0, 0.0, 2.0, weight=0.75),
+        ParameterLimit.linear_joint(0, 2, 1, 5, 1.0, 0.0, 2.0, FLT_MAX, weight=0.75),
+    ]
+    cons = _cons(rig, lims)
+    rz = rig.param_names.index("shared_rz")
+    for test_pos in (-4.0, 0.0, 4.0):
+        errs = []
+        for d in (-0.001, 0.001):
+            theta = np.zeros(rig.num_params)
+            theta[rz] = np.float32(test_pos + d)
+            _check(rig, cons, theta, fd_tol=1e-5)
+            errs.append(orc.get_error(rig, cons, theta, "f64"))
+        assert abs(errs[0] - errs[1]) < 0.03  # C0 continuity across the pieces (:216-221)
+    # a joint limit writes every column of the transform row, enabled or not
+    # (jacobian_jointParams_to_modelParams, error_function_utils.h:77-91), and is skipped only when
+    # no column of the row is enabled
+    theta = rng.uniform(-1, 1, rig.num_params)
+    cons = _cons(rig, [ParameterLimit.minmax_joint(1, 5, -0.01, 0.01, 1.0)])
+    J, r, err = orc.eval_jacobian(rig, cons, theta, dtype="f64")
+    cols = np.flatnonzero(J[0])
+    assert len(cols) >= 1
+    en = np.ones(rig.num_params, np.uint8)
+    en[cols[0]] = 0
+    J2, _, _ = orc.eval_jacobian(rig, cons, theta, enabled=en, dtype="f64")
+    if len(cols) > 1:
+        assert np.array_equal(J2, J)
+    else:
+        assert not J2.any()
