@@ -48,6 +48,8 @@ def test_struct_layouts_match_header():
     int main(void) {
       printf("%zu %zu %zu\n", sizeof(mmx_rig_desc), sizeof(mmx_constraint_data), sizeof(mmx_gn_options));
       printf("%zu %zu %zu\n", offsetof(mmx_rig_desc, pt_offsets), offsetof(mmx_constraint_data, memory), offsetof(mmx_gn_options, lm_down));
+      printf("%zu %zu %zu %zu\n", sizeof(mmx_parameter_limit), offsetof(mmx_constraint_data, limits), offsetof(mmx_constraint_data, model_weights),
+             offsetof(mmx_constraint_data, ori_loss_c));
       return 0;
     }"""
     with tempfile.TemporaryDirectory() as td:
@@ -58,7 +60,9 @@ def test_struct_layouts_match_header():
         out = subprocess.check_output([exe]).decode().split()
     sizes = [int(x) for x in out]
     assert sizes[:3] == [C.sizeof(_abi.RigDesc), C.sizeof(_abi.ConstraintData), C.sizeof(_abi.GnOptions)]
-    assert sizes[3:] == [_abi.RigDesc.pt_offsets.offset, _abi.ConstraintData.memory.offset, _abi.GnOptions.lm_down.offset]
+    assert sizes[3:6] == [_abi.RigDesc.pt_offsets.offset, _abi.ConstraintData.memory.offset, _abi.GnOptions.lm_down.offset]
+    assert sizes[6:] == [C.sizeof(_abi.ParameterLimit), _abi.ConstraintData.limits.offset, _abi.ConstraintData.model_weights.offset,
+                         _abi.ConstraintData.ori_loss_c.offset]  # fmt: skip
 
 
 def test_default_options_match_reference_structs(L):
