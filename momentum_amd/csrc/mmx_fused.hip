@@ -419,7 +419,6 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     float* __restrict__ dbgG, // [B][n] or null
     long long* __restrict__ dbgClk) { // [32] or null: per-phase cycle counts of block 0 (profiling aid)
   constexpr int T = NB * (NB + 1) / 2; // lower-triangle tiles
-  constexpr int TPW = (T + 3) / 4; // tiles per wave
   constexpr int NP = 16 * NB; // padded system size
   long long clkLast = 0;
 #define MMX_CLK(slot)                                             \
@@ -561,17 +560,6 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     s.flags[0] = 0; // stop
     s.flags[1] = 0; // not positive definite (this iteration)
     s.flags[2] = 0; // status
-  }
-  // (I, J) of the tiles this wave owns: wave-uniform, decoded once
-  int tI[TPW], tJ[TPW];
-#pragma unroll
-  for (int q = 0; q < TPW; ++q) {
-    int I = 0, Jc = 0;
-    if (4 * q + wave < T) {
-      tileDecode(4 * q + wave, I, Jc);
-    }
-    tI[q] = __builtin_amdgcn_readfirstlane(I);
-    tJ[q] = __builtin_amdgcn_readfirstlane(Jc);
   }
   const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
@@ -770,35 +758,18 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
       __syncthreads();
     }
-    v4f acc[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      const int t = 4 * q + wave;
-      acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (t < T) {
-        const int I = tI[q], Jc = tJ[q];
-        const int col = 16 * Jc + (lane & 15);
-        const float* Tl = s.L + 256 * t;
-        // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + 4 * (lane >> 4) + r;
-          float h;
-          if (I == Jc && row < col) {
-            h = Tl[tileAddr(col & 15, row & 15)]; // upper part of a diagonal tile: mirror
-          } else {
-            h = Tl[tileAddr(row & 15, col & 15)];
-          }
-          if (MODE == 1 && it == 0 && row < n && col < n) {
-            dbgH[size_t(b) * n * n + size_t(row) * n + col] = h;
-            dbgH[size_t(b) * n * n + size_t(col) * n + row] = h;
-          }
-          if (row == col) {
-            h = row < n ? h + lambda : 1.f;
-          }
-          acc[q][r] = h;
-        }
+    if (MODE == 1 && it == 0) { // parity hook: H = J^T J without lambda, both triangles
+      for (int e = tid; e < n * n; e += 256) {
+        const int row = e / n, col = e - row * n;
+        const int hi = row > col ? row : col, lo = row > col ? col : row;
+        dbgH[size_t(b) * n * n + e] = s.L[256 * tileIndex(hi >> 4, lo >> 4) + tileAddr(hi & 15, lo & 15)];
       }
+      __syncthreads();
+    }
+    // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block
+    for (int c = tid; c < NP; c += 256) {
+      float* dg = s.L + 256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15);
+      *dg = c < n ? *dg + lambda : 1.f;
     }
     if (MODE == 1 && it == 0) {
       for (int c = tid; c < n; c += 256) {
@@ -811,25 +782,8 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     __syncthreads(); // srcT / moments are dead from here on: the region becomes the factor
     MMX_CLK(6)
 
-    // ================= H: blocked Cholesky, tiles in registers, L panels in LDS
+    // ================= H: blocked right-looking Cholesky on the LDS-resident tiles
     for (int k = 0; k < NB; ++k) {
-      // (a) owners publish the tiles of block column k
-#pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const int t = 4 * q + wave;
-        if (t < T) {
-          const int Jc = tJ[q];
-          if (Jc == k) {
-            float* Tl = s.L + 256 * t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              Tl[tileAddr(4 * (lane >> 4) + r, lane & 15)] = acc[q][r];
-            }
-          }
-        }
-      }
-      __syncthreads();
-      MMX_CLK(11)
       // (b+c) panel factorisation: every wave holds the 16 rows of the diagonal block in lanes
       //     0..15 (redundantly) and 48 rows of the panel below it in lanes 16..63, one row of 16
       //     values per lane.  Sixteen elimination steps factor the diagonal block AND solve the
@@ -927,26 +881,34 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         }
       }
       MMX_CLK(13)
-      // (d) trailing update of the tiles this wave owns: acc(I,J) -= L(I,k) L(J,k)^T  (MFMA)
+      // (d) trailing update tile(I,J) -= L(I,k) L(J,k)^T for k < J <= I, tiles dealt to the waves;
+      //     a tile is read, updated with four MFMAs and written back by one wave
+      {
+        const int nt = NB - 1 - k; // the trailing matrix has nt x nt tiles (lower triangle)
+        const int count = nt * (nt + 1) / 2;
+        for (int m = wave; m < count; m += 4) {
+          int ti, tj;
+          tileDecode(m, ti, tj);
+          const int I = __builtin_amdgcn_readfirstlane(k + 1 + ti), Jc = __builtin_amdgcn_readfirstlane(k + 1 + tj);
+          float* Tc = s.L + 256 * tileIndex(I, Jc);
+          const float4 av = ldsRow4(s.L + 256 * tileIndex(I, k), lane & 15, lane >> 4);
+          const float4 bv = ldsRow4(s.L + 256 * tileIndex(Jc, k), lane & 15, lane >> 4);
+          v4f c;
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const int t = 4 * q + wave;
-        if (t < T) {
-          const int I = tI[q], Jc = tJ[q];
-          if (Jc > k) {
-            const float4 av = ldsRow4(s.L + 256 * tileIndex(I, k), lane & 15, lane >> 4);
-            const float4 bv = ldsRow4(s.L + 256 * tileIndex(Jc, k), lane & 15, lane >> 4);
-            v4f c = acc[q];
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
-            acc[q] = c;
+          for (int r = 0; r < 4; ++r) {
+            c[r] = Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)];
+          }
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)] = c[r];
           }
         }
+        __syncthreads(); // block column k + 1 is final before its panel pass reads it
       }
-      // no barrier needed here: step k+1 publishes into other LDS tiles, and its (a)->(b) barrier
-      // orders everything else
       MMX_CLK(14)
     }
     __syncthreads();
