@@ -1127,7 +1127,7 @@ int32_t mmx_solve(
   sp.threshold = o->threshold;
   sp.minIterations = o->min_iterations;
   sp.maxIterations = o->max_iterations;
-  sp.refine = 1;
+  sp.refine = getenv("MMX_NO_REFINE") != nullptr ? 0 : 1;
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
     MMX_HIP(mmx::launchFkJacobian(
