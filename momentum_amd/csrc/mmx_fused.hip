@@ -62,6 +62,7 @@ struct FusedLds {
   int* jlA; // [J] jump targets (+1), double-buffered
   int* jlB;
   float* own2; // [kC2 J]
+  float* umom; // [(kC1 + kC2) U] per-unit moment contributions (phase D only)
   float* sub2; // [kC2 J]
   float* L; // [T][256] tiles; a diagonal tile holds L_kk (lower triangle) and L_kk^-T (strict upper triangle)
   // ---- aliases the refinement scratch (dfull, jd, tanOwn, tanPre): dead before phase J starts
@@ -90,7 +91,7 @@ struct FusedView {
   const int32_t* loadedPos;
   int32_t numLoaded;
   const int32_t* colToSolve; // [P] compacted index of a parameter or -1
-  const int32_t* unitJoint;
+  const int32_t* unitPos; // [U] DFS position of the joint a unit hangs on
   const int32_t* posUnitStart;
   const int32_t* posUnits;
   const int32_t* solveList;
@@ -103,62 +104,71 @@ __host__ __device__ __forceinline__ size_t alignUp4(size_t x) {
 // ---------------------------------------------------------------------------------------------
 // adjoint machinery: sums over a joint's own units, then over its subtree (= a DFS index range)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, int J, int tid, bool second) {
-  for (int k = tid; k < J; k += 256) {
-    float a1[kC1], a2[kC2];
-#pragma unroll
-    for (int c = 0; c < kC1; ++c) {
-      a1[c] = 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < kC2; ++c) {
-      a2[c] = 0.f;
-    }
+// Two steps, both fully parallel: (1) one thread per unit writes the unit's moment contributions
+// (NCH floats: kC1 first-order, then kC2 second-order channels) to a scratch array; (2) one thread per
+// (loaded joint, channel) adds up the few units of that joint, in ascending unit order.  Joints
+// without units are never read by the subtree sums (treeSumT walks loadedPos), so they are skipped.
+__device__ __forceinline__ void firstOrderMoments(float* o, F3 p, float yx, float yy, float yz, bool point) {
+  // N += p x y (points and directions share the channel: only the sum enters, see jt_times)
+  o[3] = p.y * yz - p.z * yy;
+  o[4] = p.z * yx - p.x * yz;
+  o[5] = p.x * yy - p.y * yx;
+  o[0] = point ? yx : 0.f;
+  o[1] = point ? yy : 0.f;
+  o[2] = point ? yz : 0.f;
+  o[6] = point ? p.x * yx + p.y * yy + p.z * yz : 0.f;
+  o[7] = 0.f;
+}
+
+template <int NCH>
+__device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLds& s, const float* umom, int tid) {
+  for (int item = tid; item < fd.numLoaded * NCH; item += 256) {
+    const int li = item / NCH, c = item - li * NCH;
+    const int k = fd.loadedPos[li];
+    float acc = 0.f;
     const int e1 = fd.posUnitStart[k + 1];
     for (int e = fd.posUnitStart[k]; e < e1; ++e) {
-      const int u = fd.posUnits[e];
-      const float px = s.up[3 * u], py = s.up[3 * u + 1], pz = s.up[3 * u + 2];
-      const float yx = s.uy[3 * u], yy = s.uy[3 * u + 1], yz = s.uy[3 * u + 2];
-      const bool point = u < fd.Kp;
-      // N += p x y (points and directions share the channel: only the sum enters, see jt_times)
-      a1[3] += py * yz - pz * yy;
-      a1[4] += pz * yx - px * yz;
-      a1[5] += px * yy - py * yx;
-      if (point) {
-        a1[0] += yx;
-        a1[1] += yy;
-        a1[2] += yz;
-        a1[6] += px * yx + py * yy + pz * yz;
-      }
-      if (second) {
-        const float sg = s.us[u];
-        const float s2 = sg * sg;
-        const int o = point ? 4 : 10;
-        a2[o + 0] += s2 * px * px;
-        a2[o + 1] += s2 * px * py;
-        a2[o + 2] += s2 * px * pz;
-        a2[o + 3] += s2 * py * py;
-        a2[o + 4] += s2 * py * pz;
-        a2[o + 5] += s2 * pz * pz;
-        if (point) {
-          a2[0] += s2;
-          a2[1] += s2 * px;
-          a2[2] += s2 * py;
-          a2[3] += s2 * pz;
-        }
-      }
+      acc += umom[NCH * fd.posUnits[e] + c];
     }
-#pragma unroll
-    for (int c = 0; c < kC1; ++c) {
-      s.own1[kC1 * k + c] = a1[c];
-    }
-    if (second) {
-#pragma unroll
-      for (int c = 0; c < kC2; ++c) {
-        s.own2[kC2 * k + c] = a2[c];
-      }
+    if (c < kC1) {
+      s.own1[kC1 * k + c] = acc;
+    } else {
+      s.own2[kC2 * k + (c - kC1)] = acc;
     }
   }
+}
+
+// phase D: first- and second-order own sums from up / uy / us
+__device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, float* umom, int U, int tid) {
+  constexpr int NCH = kC1 + kC2;
+  for (int u = tid; u < U; u += 256) {
+    const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+    const bool point = u < fd.Kp;
+    float* o = umom + NCH * u;
+    firstOrderMoments(o, p, s.uy[3 * u], s.uy[3 * u + 1], s.uy[3 * u + 2], point);
+    const float sg = s.us[u];
+    const float s2 = sg * sg;
+    float* o2 = o + kC1;
+#pragma unroll
+    for (int c = 0; c < kC2; ++c) {
+      o2[c] = 0.f;
+    }
+    const int q = point ? 4 : 10;
+    o2[q + 0] = s2 * p.x * p.x;
+    o2[q + 1] = s2 * p.x * p.y;
+    o2[q + 2] = s2 * p.x * p.z;
+    o2[q + 3] = s2 * p.y * p.y;
+    o2[q + 4] = s2 * p.y * p.z;
+    o2[q + 5] = s2 * p.z * p.z;
+    if (point) {
+      o2[0] = s2;
+      o2[1] = s2 * p.x;
+      o2[2] = s2 * p.y;
+      o2[3] = s2 * p.z;
+    }
+  }
+  __syncthreads();
+  gatherOwnSums<NCH>(fd, s, umom, tid);
 }
 
 template <int NC, bool kSubtree>
@@ -493,6 +503,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     s.jlB = reinterpret_cast<int*>(take(J));
     s.own2 = take(size_t(kC2) * J);
     s.sub2 = take(size_t(kC2) * J);
+    s.umom = take(size_t(kC1 + kC2) * U);
     s.L = region;
   }
 
@@ -529,7 +540,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   }
   for (int i = tid; i < U; i += 256) {
     lPosUnits[i] = fd.posUnits[i];
-    lUnitJoint[i] = fd.unitJoint[i];
+    lUnitJoint[i] = pb.unitTin[i]; // DFS position of the unit's joint
   }
   for (int i = tid; i < n; i += 256) {
     lSolveList[i] = fd.solveList[i];
@@ -554,7 +565,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp;
   fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = fd.numLoaded, fv.colToSolve = lColToSolve;
-  fv.subSize = lSubSize, fv.unitJoint = lUnitJoint, fv.posUnitStart = lPosUnitStart, fv.posUnits = lPosUnits;
+  fv.subSize = lSubSize, fv.unitPos = lUnitJoint, fv.posUnitStart = lPosUnitStart, fv.posUnits = lPosUnits;
   fv.solveList = lSolveList;
   if (tid == 0) {
     s.flags[0] = 0; // stop
@@ -572,6 +583,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     clkLast = clock64();
   }
   for (int it = 0; it < fp.maxIterations; ++it) {
+    // the constraint payload of this thread's unit is requested before FK so that its HBM latency
+    // hides behind it (one round trip per iteration instead of two)
+    const UnitInput uin0 = loadUnitInput(pb, b, tid < U ? tid : U);
     // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
     blockFk(rv, s, s.th, tid, true);
     MMX_CLK(1)
@@ -579,7 +593,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     {
       double e = 0.0;
       for (int u = tid; u < U; u += 256) {
-        const Unit un = evalUnit(pb, s.js, b, u);
+        const Unit un = evalUnitFrom(pb, u == tid ? uin0 : loadUnitInput(pb, b, u), s.js, u);
         s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
         const float rx = un.sigma * un.f.x, ry = un.sigma * un.f.y, rz = un.sigma * un.f.z;
         s.ur[3 * u] = rx, s.ur[3 * u + 1] = ry, s.ur[3 * u + 2] = rz;
@@ -599,7 +613,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); // every thread: the same value
     MMX_CLK(2)
     // ================= D: own + subtree sums
-    ownSums(fv, s, J, tid, true);
+    ownSums(fv, s, s.umom, U, tid);
     __syncthreads();
     MMX_CLK(15)
     treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
@@ -960,36 +974,50 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       // ... summed over each joint's ancestor chain (prefix sums down the tree)
       treeSum<kTan, false>(fv, s.tanOwn, s.tanPre, J, wave, lane);
       __syncthreads();
-      // per joint with units: w = r - J d, y = sigma w, accumulated straight into the first-order own sums
-      for (int k = tid; k < J; k += 256) {
-        const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
-        float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (e1 > e0) {
-          const float* pre = s.tanPre + kTan * k;
-          for (int e = e0; e < e1; ++e) {
-            const int u = fv.posUnits[e];
-            const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
-            const bool point = u < fv.Kp;
-            F3 v = cross(F3{pre[3], pre[4], pre[5]}, p);
-            if (point) {
-              v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
-            }
-            const float sg = s.us[u];
-            const float yx = sg * (s.ur[3 * u] - sg * v.x), yy = sg * (s.ur[3 * u + 1] - sg * v.y), yz = sg * (s.ur[3 * u + 2] - sg * v.z);
-            a1[3] += p.y * yz - p.z * yy;
-            a1[4] += p.z * yx - p.x * yz;
-            a1[5] += p.x * yy - p.y * yx;
-            if (point) {
-              a1[0] += yx;
-              a1[1] += yy;
-              a1[2] += yz;
-              a1[6] += p.x * yx + p.y * yy + p.z * yz;
+      // w = r - J d, y = sigma w per unit, then the first-order own sums.  sub1 (free until the
+      // subtree sums are written) holds the per-unit contributions when it is large enough.
+      if (U <= J) {
+        for (int u = tid; u < U; u += 256) {
+          const float* pre = s.tanPre + kTan * fv.unitPos[u];
+          const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+          const bool point = u < fv.Kp;
+          F3 v = cross(F3{pre[3], pre[4], pre[5]}, p);
+          if (point) {
+            v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
+          }
+          const float sg = s.us[u];
+          firstOrderMoments(
+              s.sub1 + kC1 * u, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
+        }
+        __syncthreads();
+        gatherOwnSums<kC1>(fv, s, s.sub1, tid);
+      } else {
+        for (int k = tid; k < J; k += 256) {
+          const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
+          float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (e1 > e0) {
+            const float* pre = s.tanPre + kTan * k;
+            for (int e = e0; e < e1; ++e) {
+              const int u = fv.posUnits[e];
+              const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+              const bool point = u < fv.Kp;
+              F3 v = cross(F3{pre[3], pre[4], pre[5]}, p);
+              if (point) {
+                v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
+              }
+              const float sg = s.us[u];
+              float o[kC1];
+              firstOrderMoments(o, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
+#pragma unroll
+              for (int c = 0; c < kC1; ++c) {
+                a1[c] += o[c];
+              }
             }
           }
-        }
 #pragma unroll
-        for (int c = 0; c < kC1; ++c) {
-          s.own1[kC1 * k + c] = a1[c];
+          for (int c = 0; c < kC1; ++c) {
+            s.own1[kC1 * k + c] = a1[c];
+          }
         }
       }
       __syncthreads();
@@ -1149,7 +1177,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
   const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 4;
   const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
   const size_t blockJ = refine > a4(size_t(kSrc) * nsrc) ? refine : a4(size_t(kSrc) * nsrc);
-  const size_t scratch = a4(8 * size_t(J)) + 2 * a4(J) + 2 * a4(size_t(kC2) * J);
+  const size_t scratch = a4(8 * size_t(J)) + 2 * a4(J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kC1 + kC2) * U);
   const size_t region = scratch > T * 256 ? scratch : T * 256;
   return (meta + fixed + blockJ + region) * sizeof(float);
 }
