@@ -522,7 +522,6 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   }
   for (int i = tid; i < J; i += 256) {
     lParent[i] = rig.parent[i];
-    lLevelOrder[i] = rig.levelOrder[i];
     lSubSize[i] = fd.subSize[i];
   }
   for (int i = tid; i <= rig.numLevels; i += 256) {
@@ -555,6 +554,20 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
     lColToSolve[fd.solveList[i]] = i;
+  }
+  // parentPos[k] = DFS position of the parent of the joint at DFS position k (-1 for a root), built
+  // through a joint -> position scratch map (alt is free until the first FK)
+  int* lParentPos = lLevelOrder;
+  {
+    int* posOf = reinterpret_cast<int*>(s.alt);
+    for (int k = tid; k < J; k += 256) {
+      posOf[fd.dfsJoint[k]] = k;
+    }
+    __syncthreads();
+    for (int k = tid; k < J; k += 256) {
+      const int par = rig.parent[fd.dfsJoint[k]];
+      lParentPos[k] = par >= 0 ? posOf[par] : -1;
+    }
   }
   // from here on the kernel reads the batch-shared tables through these LDS-backed views
   RigView rv;
@@ -972,8 +985,50 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       }
       __syncthreads();
       // ... summed over each joint's ancestor chain (prefix sums down the tree)
-      treeSum<kTan, false>(fv, s.tanOwn, s.tanPre, J, wave, lane);
-      __syncthreads();
+      if (J <= 256) {
+        // pointer jumping with the running sum and the jump target in registers: per round a thread
+        // reads its target's sum and target (slot 7 of the row), then every thread publishes its own
+        float acc[7];
+        int target = -1;
+        if (tid < J) {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) {
+            acc[c] = s.tanOwn[kTan * tid + c];
+          }
+          target = lParentPos[tid];
+          s.tanPre[kTan * tid + 7] = __int_as_float(target);
+#pragma unroll
+          for (int c = 0; c < 7; ++c) {
+            s.tanPre[kTan * tid + c] = acc[c];
+          }
+        }
+        __syncthreads();
+        for (int r = 0; r < rv.jumpRounds; ++r) {
+          int next = -1;
+          if (target >= 0) {
+            const float* t = s.tanPre + kTan * target;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+              acc[c] += t[c];
+            }
+            next = __float_as_int(t[7]);
+          }
+          __syncthreads();
+          if (target >= 0) {
+            float* o = s.tanPre + kTan * tid;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+              o[c] = acc[c];
+            }
+            o[7] = __int_as_float(next);
+          }
+          target = next;
+          __syncthreads();
+        }
+      } else {
+        treeSum<kTan, false>(fv, s.tanOwn, s.tanPre, J, wave, lane);
+        __syncthreads();
+      }
       // w = r - J d, y = sigma w per unit, then the first-order own sums.  sub1 (free until the
       // subtree sums are written) holds the per-unit contributions when it is large enough.
       if (U <= J) {
