@@ -1080,13 +1080,26 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
       treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
       __syncthreads();
       MMX_CLK(18)
+      // J^T w per column source in parallel (tanOwn is free again), then per column the sum of its sources
+      const bool perSource = nsrc <= kTan * J;
+      if (perSource) {
+        for (int e = tid; e < nsrc; e += 256) {
+          const int info = s.mInfo[e];
+          s.tanOwn[e] = s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
+        }
+        __syncthreads();
+      }
       for (int c = tid; c < NP; c += 256) {
         float a = 0.f;
         if (c < n) {
           const int e1 = s.mStart[c + 1];
           for (int e = s.mStart[c]; e < e1; ++e) {
-            const int info = s.mInfo[e];
-            a += s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
+            if (perSource) {
+              a += s.tanOwn[e];
+            } else {
+              const int info = s.mInfo[e];
+              a += s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
+            }
           }
           if (hasParamRows) {
             a += paramRowsColumn(rig, pb, fd, s.th, s.d0, lColToSolve, P, b, c, lSolveList[c]).g;
