@@ -809,8 +809,41 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     __syncthreads(); // srcT / moments are dead from here on: the region becomes the factor
     MMX_CLK(6)
 
-    // ================= H: blocked right-looking Cholesky on the LDS-resident tiles
+    // ================= H: blocked left-looking Cholesky on the LDS-resident tiles
     for (int k = 0; k < NB; ++k) {
+      // (u) bring block column k up to date: tile(I,k) -= sum_{j<k} L(I,j) L(k,j)^T.  A tile is
+      //     read once, takes all its 4 k MFMAs (two accumulators: even / odd j) and is written once.
+      if (k > 0) {
+        for (int I = k + wave; I < NB; I += 4) {
+          float* Tc = s.L + 256 * tileIndex(I, k);
+          v4f c0, c1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            c0[r] = Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)];
+          }
+          for (int j = 0; j < k; ++j) {
+            const float4 av = ldsRow4(s.L + 256 * tileIndex(I, j), lane & 15, lane >> 4);
+            const float4 bv = ldsRow4(s.L + 256 * tileIndex(k, j), lane & 15, lane >> 4);
+            if (j & 1) {
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c1, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c1, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c1, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c1, 0, 0, 0);
+            } else {
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c0, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c0, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c0, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c0, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)] = c0[r] + c1[r];
+          }
+        }
+        __syncthreads();
+      }
+      MMX_CLK(14)
       // (b+c) panel factorisation: every wave holds the 16 rows of the diagonal block in lanes
       //     0..15 (redundantly) and 48 rows of the panel below it in lanes 16..63, one row of 16
       //     values per lane.  Sixteen elimination steps factor the diagonal block AND solve the
@@ -908,35 +941,6 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         }
       }
       MMX_CLK(13)
-      // (d) trailing update tile(I,J) -= L(I,k) L(J,k)^T for k < J <= I, tiles dealt to the waves;
-      //     a tile is read, updated with four MFMAs and written back by one wave
-      {
-        const int nt = NB - 1 - k; // the trailing matrix has nt x nt tiles (lower triangle)
-        const int count = nt * (nt + 1) / 2;
-        for (int m = wave; m < count; m += 4) {
-          int ti, tj;
-          tileDecode(m, ti, tj);
-          const int I = __builtin_amdgcn_readfirstlane(k + 1 + ti), Jc = __builtin_amdgcn_readfirstlane(k + 1 + tj);
-          float* Tc = s.L + 256 * tileIndex(I, Jc);
-          const float4 av = ldsRow4(s.L + 256 * tileIndex(I, k), lane & 15, lane >> 4);
-          const float4 bv = ldsRow4(s.L + 256 * tileIndex(Jc, k), lane & 15, lane >> 4);
-          v4f c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            c[r] = Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)];
-          }
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)] = c[r];
-          }
-        }
-        __syncthreads(); // block column k + 1 is final before its panel pass reads it
-      }
-      MMX_CLK(14)
     }
     __syncthreads();
     const bool notPd = s.flags[1] != 0;
