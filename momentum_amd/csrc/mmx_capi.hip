@@ -1079,16 +1079,16 @@ int32_t mmx_solve(
       long long h[32];
       MMX_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, s));
       MMX_HIP(hipStreamSynchronize(s));
-      static const char* names[21] = {"A jointParams", "B fk", "C units", "D subtree sums", "E srcTables", "F g + zero tiles",
+      static const char* names[24] = {"A jointParams", "B fk", "C units", "D subtree sums", "E srcTables", "F g + zero tiles",
                                       "G combine + pull", "H cholesky(tail)", "I solve", "J tail (d0 += rho)", "K update",
                                       "H.a publish", "G term records", "H.bc panel", "H.d mfma", "D own sums", "J jd",
-                                      "J tangent+own", "J subtree", "J rho", "J solve"};
+                                      "J tangent+own", "J subtree", "J rho", "J solve", "(unused)", "H.b load+barrier", "H.b chain"};
       long long tot = 0;
-      for (int i = 0; i < 21; ++i) {
+      for (int i = 0; i < 24; ++i) {
         tot += h[i];
       }
       fprintf(stderr, "[mmx phase clocks, block 0, all iterations] total %lld\n", tot);
-      for (int i = 0; i < 21; ++i) {
+      for (int i = 0; i < 24; ++i) {
         fprintf(stderr, "  %-16s %10lld  %5.1f%%\n", names[i], h[i], 100.0 * double(h[i]) / double(tot > 0 ? tot : 1));
       }
     }

@@ -878,6 +878,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
           }
         }
         __syncthreads(); // every wave has read the diagonal block before wave 0 overwrites it
+        MMX_CLK(22)
         float invd = 0.f;
         bool bad = false;
         if (waveWorks) {
@@ -895,14 +896,23 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
               a[c] -= a[j] * readLaneF(a[j], c);
             }
           }
-          // one store loop for the three kinds of lanes: columns lo..hi of the lane's row
-          //   diagonal rows (wave 0): 0..row = L_kk ; identity rows: row+1..15 = L_kk^-T ; panel rows: all
-          const int lo = identLane ? vrow + 1 : ((diagLane && wave != 0) || !(diagLane || panelLane) ? 16 : 0);
-          const int hi = diagLane ? lane : 15;
+          MMX_CLK(23)
+          // Stores.  The diagonal tile takes L_kk (columns <= row) from the diagonal lane of a row and
+          // L_kk^-T (columns > row) from the identity lane of the same row, 16 lanes further up:
+          // ds_swizzle (xor 16) brings the partner's value over, so that the diagonal lane writes the
+          // whole row and every row leaves as four unpredicated 16-byte stores.
+          const bool stores = panelLane || (diagLane && wave == 0);
+          float v[16];
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
-            if (c >= lo && c <= hi) {
-              Tl[tileAddr(trow, c)] = a[c];
+            const float partner = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a[c]), 0x401F));
+            v[c] = (diagLane && c > lane) ? partner : a[c];
+          }
+          if (stores) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              *reinterpret_cast<float4*>(Tl + trow * 16 + (((q ^ (trow >> 2)) & 3) << 2)) =
+                  float4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
             }
           }
           if (diagLane && wave == 0) {
