@@ -115,6 +115,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--jac-launches", type=int, default=20)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
     args = ap.parse_args()
 
     from momentum_amd import distributed as D
@@ -125,8 +126,11 @@ def main() -> None:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    # one rank per GPU; --backend gloo with fewer GPUs than ranks is only for the plumbing test
+    # (tests/test_bench_two_ranks.py), where the ranks share a device
+    local_rank = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
-    dist = D.init("nccl")  # RCCL behind the "nccl" backend on ROCm; None when world == 1
+    dist = D.init(args.backend)  # RCCL behind the "nccl" backend on ROCm; None when world == 1
 
     from momentum_amd import humanoid72_landmark_joints, make_humanoid72
     from momentum_amd._abi import GnOptions

@@ -44,7 +44,12 @@ def reduce_norms(dist, norms: torch.Tensor) -> torch.Tensor:
     """In-place sum all-reduce of the residual-norm vector (<= 64 bytes: latency bound; called
     once per solve, never per iteration)."""
     if dist is not None:
-        dist.all_reduce(norms)
+        if norms.is_cuda and dist.get_backend() == "gloo":  # CPU rendezvous of the tests: stage through the host
+            host = norms.cpu()
+            dist.all_reduce(host)
+            norms.copy_(host)
+        else:
+            dist.all_reduce(norms)
     return norms
 
 
@@ -52,6 +57,6 @@ def reduce_max(dist, value: float, device) -> float:
     """Max over ranks of a host scalar (the timed region of the bench)."""
     if dist is None:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
