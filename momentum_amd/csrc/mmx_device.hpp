@@ -18,9 +18,7 @@
 
 namespace mmx {
 
-constexpr int kJp = 10; // floats per joint in jp[]
 constexpr int kJs = 20; // floats per joint in js[]
-constexpr int kLoc = 16; // local transform per joint: t(3) q_l(4) s(1) | q1 = pre*Qz (4) | q2 = pre*Qz*Qy (4)
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {
@@ -193,82 +191,10 @@ struct ProblemDev {
 };
 
 // ---------------------------------------------------------------------------------------------
-// phase 1: joint parameters = transform * theta + offsets (ParameterTransformT::apply,
-// momentum/character/parameter_transform.cpp:110-124), then the per-joint transcendental work
-// (half-angle sin/cos of Quaternion(AngleAxis), exp2 of the scale; joint_state.cpp:56-57,62)
-// with lanes = joint-parameter rows so all 64 lanes are busy.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void
-jointParamsPhase(const RigDev& rig, const float* __restrict__ theta, float* jp, int lane, int nlanes) {
-  for (int r = lane; r < rig.R; r += nlanes) {
-    float acc = 0.f;
-    const int k1 = rig.ptOuter[r + 1];
-    for (int k = rig.ptOuter[r]; k < k1; ++k) {
-      acc += rig.ptValue[k] * theta[rig.ptInner[k]];
-    }
-    acc += rig.ptOffsets[r];
-    const int j = r / 7, d = r - 7 * j;
-    float* o = jp + kJp * j;
-    if (d < 3) {
-      o[d] = acc;
-    } else if (d < 6) {
-      float s, c;
-      sincosf(0.5f * acc, &s, &c);
-      o[3 + 2 * (d - 3)] = s;
-      o[4 + 2 * (d - 3)] = c;
-    } else {
-      o[9] = exp2f(acc);
-    }
-  }
-}
-
-// phase 2 body: JointStateT::set for joint j, parent already final in js[] (joint_state.cpp:22-65)
-__device__ __forceinline__ void fkJoint(const RigDev& rig, int j, const float* jp, float* js) {
-  const int par = rig.parent[j];
-  F3 tp{0.f, 0.f, 0.f};
-  Q4 qp{0.f, 0.f, 0.f, 1.f};
-  float sp = 1.f;
-  if (par >= 0) {
-    const float* p = js + kJs * par;
-    tp = F3{p[0], p[1], p[2]};
-    qp = Q4{p[3], p[4], p[5], p[6]};
-    sp = p[7];
-  }
-  const float* a = jp + kJp * j;
-  const float* pre = rig.preRot + 4 * j;
-  Q4 ql{pre[0], pre[1], pre[2], pre[3]};
-  float* o = js + kJs * j;
-  // index 2 (z): axis = (q_p * q_l) * ez, then q_l *= Qz
-  {
-    const F3 ax = qrot(qmul(qp, ql), F3{0.f, 0.f, 1.f});
-    o[14] = ax.x, o[15] = ax.y, o[16] = ax.z;
-    ql = qmul(ql, Q4{0.f, 0.f, a[7], a[8]});
-  }
-  {
-    const F3 ax = qrot(qmul(qp, ql), F3{0.f, 1.f, 0.f});
-    o[11] = ax.x, o[12] = ax.y, o[13] = ax.z;
-    ql = qmul(ql, Q4{0.f, a[5], 0.f, a[6]});
-  }
-  {
-    const F3 ax = qrot(qmul(qp, ql), F3{1.f, 0.f, 0.f});
-    o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
-    ql = qmul(ql, Q4{a[3], 0.f, 0.f, a[4]});
-  }
-  const float* off = rig.offset + 3 * j;
-  const F3 tl{off[0] + a[0], off[1] + a[1], off[2] + a[2]};
-  // world = parent * local (transform.h:124-129)
-  const F3 t = tp + qrot(qp, sp * tl);
-  const Q4 q = qmul(qp, ql);
-  o[0] = t.x, o[1] = t.y, o[2] = t.z;
-  o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
-  o[7] = sp * a[9];
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same forward kinematics split into its parallel and its serial part: every joint's local
-// transform and partial rotations need only theta (all joints at once), the tree levels only
-// compose world = parent * local, and the rotation axes again need only the parent's world
-// rotation (all joints at once).  Arithmetic per joint is identical to fkJoint / the reference.
+// Forward kinematics split into its parallel and its serial part: every joint's local transform
+// and partial rotations need only theta (all joints at once), the world transforms compose
+// parent * local (pointer jumping), and the rotation axes again need only the parent's world
+// rotation (all joints at once).  Arithmetic per joint is the reference's (joint_state.cpp:22-65).
 // ---------------------------------------------------------------------------------------------
 // local transform (t, q, s: the layout of a world transform) + partial rotations q1 = pre*Qz,
 // q2 = pre*Qz*Qy from the 7 joint parameters (joint_state.cpp:44-62)
@@ -372,55 +298,9 @@ fkLocalFromRows(const RigDev& rig, int j, const int4* rows, const float* ptOff, 
   fkLocalFromParams(jpv, rig.preRot + 4 * j, rig.offset + 3 * j, o, o + 8);
 }
 
-template <class RigT>
-__device__ __forceinline__ void fkLocal(const RigT& rig, int j, const float* __restrict__ theta, float* loc) {
-  fkLocalTo(rig, j, theta, loc + kLoc * j);
-}
-
-template <class RigT>
-__device__ __forceinline__ void fkCompose(const RigT& rig, int j, const float* loc, float* js) {
-  const int par = rig.parent[j];
-  F3 tp{0.f, 0.f, 0.f};
-  Q4 qp{0.f, 0.f, 0.f, 1.f};
-  float sp = 1.f;
-  if (par >= 0) {
-    const float* p = js + kJs * par;
-    tp = F3{p[0], p[1], p[2]};
-    qp = Q4{p[3], p[4], p[5], p[6]};
-    sp = p[7];
-  }
-  const float* lo = loc + kLoc * j;
-  const F3 t = tp + qrot(qp, sp * F3{lo[0], lo[1], lo[2]});
-  const Q4 q = qmul(qp, Q4{lo[3], lo[4], lo[5], lo[6]});
-  float* o = js + kJs * j;
-  o[0] = t.x, o[1] = t.y, o[2] = t.z;
-  o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
-  o[7] = sp * lo[7];
-}
-
-template <class RigT>
-__device__ __forceinline__ void fkAxes(const RigT& rig, int j, const float* loc, float* js) {
-  const int par = rig.parent[j];
-  Q4 qp{0.f, 0.f, 0.f, 1.f};
-  if (par >= 0) {
-    const float* p = js + kJs * par;
-    qp = Q4{p[3], p[4], p[5], p[6]};
-  }
-  const float* pre = rig.preRot + 4 * j;
-  const float* lo = loc + kLoc * j;
-  const F3 az = qrot(qmul(qp, Q4{pre[0], pre[1], pre[2], pre[3]}), F3{0.f, 0.f, 1.f});
-  const F3 ay = qrot(qmul(qp, Q4{lo[8], lo[9], lo[10], lo[11]}), F3{0.f, 1.f, 0.f});
-  const F3 ax = qrot(qmul(qp, Q4{lo[12], lo[13], lo[14], lo[15]}), F3{1.f, 0.f, 0.f});
-  float* o = js + kJs * j;
-  o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
-  o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
-  o[14] = az.x, o[15] = az.y, o[16] = az.z;
-}
-
-// In-place variants: one 20-float slot per joint.  [0..7] holds the local (t, s, q_l) until the
-// joint's level is composed, then the world (t, q, s); [8..15] holds q1, q2 until the axes pass
-// replaces them by the rotation axes [8..16].  Each slot is rewritten only by the lane that owns
-// the joint, and parents are final before children read them (level barrier).
+// One 20-float slot per joint, used in place: [0..7] holds the local (t, q_l, s) until the joint is
+// composed with its ancestors, then the world (t, q, s); [8..15] holds q1, q2 until the axes pass
+// replaces them by the rotation axes [8..16].
 template <class RigT>
 __device__ __forceinline__ void fkLocalInPlace(const RigT& rig, int j, const float* __restrict__ theta, float* js) {
   fkLocalTo(rig, j, theta, js + kJs * j);
@@ -444,10 +324,6 @@ __device__ __forceinline__ void fkComposeInPlaceP(int j, int par, float* js) {
   o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w;
   o[7] = sc;
 }
-template <class RigT>
-__device__ __forceinline__ void fkComposeInPlace(const RigT& rig, int j, float* js) {
-  fkComposeInPlaceP(j, rig.parent[j], js);
-}
 
 template <class RigT>
 __device__ __forceinline__ void fkAxesInPlaceP(const RigT& rig, int j, int par, float* js) {
@@ -465,10 +341,7 @@ __device__ __forceinline__ void fkAxesInPlaceP(const RigT& rig, int j, int par, 
   o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
   o[14] = az.x, o[15] = az.y, o[16] = az.z;
 }
-template <class RigT>
-__device__ __forceinline__ void fkAxesInPlace(const RigT& rig, int j, float* js) {
-  fkAxesInPlaceP(rig, j, rig.parent[j], js);
-}
+
 
 // One constraint vector ("unit") = 3 Jacobian rows 3u..3u+2.  Position constraint c -> unit c
 // (a point); orientation constraint c -> units Kp+3c+k, k = 0..2 (directions = columns of

@@ -991,13 +991,6 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
   float* w = invDiag + NP; // [M]
   int* flags = reinterpret_cast<int*>(w + M);
   float* H = jtj + size_t(b) * n * n;
-  auto Hget = [&](int r, int c) -> float { // padded rows / columns form an identity block
-    if (r < n && c < n) {
-      const float v = H[size_t(r) * n + c];
-      return r == c ? v + sp.lambda : v;
-    }
-    return r == c ? 1.f : 0.f;
-  };
   if (tid == 0) {
     flags[0] = 0;
   }
@@ -1020,7 +1013,6 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
     }
     return r == c ? 1.f : 0.f;
   };
-  (void)Hget;
 
   for (int k = 0; k < NB; ++k) {
     const int nt = NB - k; // tiles in this block column

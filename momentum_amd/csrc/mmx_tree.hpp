@@ -1,5 +1,4 @@
-// mmx_tree.hpp -- device helpers of the tree-structured normal equations (shared by the fused
-// solver, mmx_fused.hip, and the wave-per-instance pipeline, mmx_pipeline.hip).  The formulas are
+// mmx_tree.hpp -- device helpers of the tree-structured normal equations (mmx_fused.hip).  The formulas are
 // derived and validated against the explicit Jacobian in tests/tree_algebra_np.py.
 #pragma once
 
@@ -84,64 +83,6 @@ __device__ __forceinline__ float sourceGradient(int joint, int dof, int parent, 
     return dot(F3{ax[0], ax[1], ax[2]}, Nv - cross(ta, Fv));
   }
   return kLn2 * (sb[6] - dot(ta, Fv));
-}
-
-// The 16 floats the H assembly needs from one column source (joint, dof) (phase E of the fused
-// kernel): G0(3) AX(3) TR(1) | AL(3) BV(3) BS(1) | GJ(1) pad(1).  m2 = the joint's second-order
-// subtree sums (kC2 floats), m1 = its first-order subtree sums (kC1 floats).
-__device__ __forceinline__ void
-sourceTable(int joint, int dof, int parent, const float* js, const float* m2, const float* m1s, float* o) {
-  const float* a = js + kJs * joint;
-  const F3 ta{a[0], a[1], a[2]};
-  const float m0 = m2[0];
-  const F3 m1{m2[1], m2[2], m2[3]};
-  F3 al, bv{0.f, 0.f, 0.f}, g0, ax;
-  float bs = 0.f, tr;
-  if (dof < 3) {
-    al = transAxisCol(js, parent, dof);
-    g0 = m0 * al;
-    ax = cross(m1, al);
-    tr = dot(al, m1);
-  } else if (dof < 6) {
-    const float* w = a + 8 + 3 * (dof - 3);
-    const F3 om{w[0], w[1], w[2]};
-    al = F3{0.f, 0.f, 0.f} - cross(om, ta);
-    bv = om;
-    g0 = m0 * al + cross(om, m1);
-    // axial([om]x M) = tr(M) om - M om, for the point and the direction second moments
-    const float t2 = (m2[4] + m2[7] + m2[9]) + (m2[10] + m2[13] + m2[15]);
-    const F3 Mo{
-        (m2[4] + m2[10]) * om.x + (m2[5] + m2[11]) * om.y + (m2[6] + m2[12]) * om.z,
-        (m2[5] + m2[11]) * om.x + (m2[7] + m2[13]) * om.y + (m2[8] + m2[14]) * om.z,
-        (m2[6] + m2[12]) * om.x + (m2[8] + m2[14]) * om.y + (m2[9] + m2[15]) * om.z};
-    ax = cross(m1, al) + (t2 * om - Mo);
-    tr = dot(al, m1);
-  } else {
-    al = F3{0.f, 0.f, 0.f} - kLn2 * ta;
-    bs = kLn2;
-    g0 = m0 * al + kLn2 * m1;
-    ax = cross(m1, al);
-    tr = dot(al, m1) + kLn2 * (m2[4] + m2[7] + m2[9]);
-  }
-  o[0] = g0.x, o[1] = g0.y, o[2] = g0.z;
-  o[3] = ax.x, o[4] = ax.y, o[5] = ax.z;
-  o[6] = tr;
-  o[7] = al.x, o[8] = al.y, o[9] = al.z;
-  o[10] = bv.x, o[11] = bv.y, o[12] = bv.z;
-  o[13] = bs;
-  o[14] = sourceGradient(joint, dof, parent, js, m1s);
-  o[15] = 0.f;
-}
-
-// contraction of a (deep, anc) source pair: G0.AL + AX.BV + TR*BS
-__device__ __forceinline__ float sourcePairTerm(const float* srcT, int deep, int anc) {
-  const float4 d0v = *reinterpret_cast<const float4*>(srcT + kSrc * deep);
-  const float4 d1v = *reinterpret_cast<const float4*>(srcT + kSrc * deep + 4);
-  const float4 a1v = *reinterpret_cast<const float4*>(srcT + kSrc * anc + 4);
-  const float4 a2v = *reinterpret_cast<const float4*>(srcT + kSrc * anc + 8);
-  const float4 a3v = *reinterpret_cast<const float4*>(srcT + kSrc * anc + 12);
-  // (G0 = d0v.xyz, AX = d0v.w d1v.xy, TR = d1v.z ; AL = a1v.w a2v.xy, BV = a2v.zw a3v.x, BS = a3v.y)
-  return d0v.x * a1v.w + d0v.y * a2v.x + d0v.z * a2v.y + d0v.w * a2v.z + d1v.x * a2v.w + d1v.y * a3v.x + d1v.z * a3v.y;
 }
 
 } // namespace mmx
