@@ -335,8 +335,8 @@ __device__ __forceinline__ float blockSumF(const FusedLds& s, float v, int tid) 
 // step is two short dot products instead of a 16-step substitution chain:
 //   forward :  y_k = L_kk^-1 (b_k - sum_{j<k} L_kj y_j)        backward:  x_k = L_kk^-T (y_k - sum_{j>k} L_jk^T x_j)
 // Lane 4 i + g owns row i of the current block and a quarter g of every dot product; quarters are
-// added with quad-permute DPP moves; the 16 right-hand sides of a block are exchanged through x
-// itself (LDS operations of one wave execute in program order).
+// added with quad-permute DPP moves; the 16 right-hand sides of a block are gathered from their
+// quads with ds_bpermute (one LDS-crossbar trip instead of a store and a load).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float quadSum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); // lanes ^ 1
@@ -357,22 +357,18 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
       }
       acc = quadSum(acc);
       float* xk = x + 16 * k;
-      const float rhs = xk[i] - acc;
+      const float rhs = xk[i] - acc; // the same value in the four lanes of quad i
       const float invd = invDiag[16 * k + i];
-      if (g == 0) {
-        xk[i] = rhs;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const float* Dk = L + 256 * tileIndex(k, k);
       float p = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int c = 4 * t + g; // L_kk^-1 (i, c) = L_kk^-T (c, i)
         const float m = Dk[tileAddr(c, i)];
-        p += (c < i ? m : (c == i ? invd : 0.f)) * xk[c];
+        const float rc = __shfl(rhs, 4 * c, 64); // right-hand side of row c straight from its quad
+        p += (c < i ? m : (c == i ? invd : 0.f)) * rc;
       }
       p = quadSum(p);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (g == 0) {
         xk[i] = p;
       }
@@ -394,19 +390,13 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
       float* xk = x + 16 * k;
       const float rhs = xk[i] - acc;
       const float invd = invDiag[16 * k + i];
-      if (g == 0) {
-        xk[i] = rhs;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const float4 row = ldsRow4(L + 256 * tileIndex(k, k), i, g); // L_kk^-T (i, 4g..4g+3)
-      const float4 rv = *reinterpret_cast<const float4*>(xk + 4 * g);
       const int c0 = 4 * g;
-      float p = (c0 > i ? row.x : (c0 == i ? invd : 0.f)) * rv.x;
-      p += (c0 + 1 > i ? row.y : (c0 + 1 == i ? invd : 0.f)) * rv.y;
-      p += (c0 + 2 > i ? row.z : (c0 + 2 == i ? invd : 0.f)) * rv.z;
-      p += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * rv.w;
+      float p = (c0 > i ? row.x : (c0 == i ? invd : 0.f)) * __shfl(rhs, 4 * c0, 64);
+      p += (c0 + 1 > i ? row.y : (c0 + 1 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 1), 64);
+      p += (c0 + 2 > i ? row.z : (c0 + 2 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 2), 64);
+      p += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 3), 64);
       p = quadSum(p);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (g == 0) {
         xk[i] = p;
       }
