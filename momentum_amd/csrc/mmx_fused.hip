@@ -348,16 +348,17 @@ template <int NB>
 __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, float* x, int tid) {
   if (tid < 64) {
     const int i = tid >> 2, g = tid & 3;
+    // Right-looking inside the wave: as soon as a block of the solution is known it is folded into
+    // the partial sums of all blocks still to come (acc[m]: row i of block m, quarter g).  Only the
+    // newest contribution sits on the dependent chain; the older ones fill its LDS wait slots.
+    float acc[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) { // forward
-      float acc = 0.f;
+    for (int m = 0; m < NB; ++m) {
+      acc[m] = 0.f;
+    }
 #pragma unroll
-      for (int j = 0; j < k; ++j) {
-        acc = dot4(ldsRow4(L + 256 * tileIndex(k, j), i, g), *reinterpret_cast<const float4*>(x + 16 * j + 4 * g), acc);
-      }
-      acc = quadSum(acc);
-      float* xk = x + 16 * k;
-      const float rhs = xk[i] - acc; // the same value in the four lanes of quad i
+    for (int k = 0; k < NB; ++k) { // forward: y_k = L_kk^-1 (b_k - sum_{j<k} L_kj y_j)
+      const float rhs = x[16 * k + i] - quadSum(acc[k]); // the same value in the four lanes of quad i
       const float invd = invDiag[16 * k + i];
       const float* Dk = L + 256 * tileIndex(k, k);
       float p = 0.f;
@@ -369,26 +370,23 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
         p += (c < i ? m : (c == i ? invd : 0.f)) * rc;
       }
       p = quadSum(p);
-      if (g == 0) {
-        xk[i] = p;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
+      if (k + 1 < NB) {
+        const float4 yq{__shfl(p, 16 * g, 64), __shfl(p, 16 * g + 4, 64), __shfl(p, 16 * g + 8, 64), __shfl(p, 16 * g + 12, 64)}; // y_k[4g..4g+3]
 #pragma unroll
-    for (int k = NB - 1; k >= 0; --k) { // backward
-      float acc = 0.f;
-#pragma unroll
-      for (int j = k + 1; j < NB; ++j) {
-        const float* Tj = L + 256 * tileIndex(j, k);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int c = 4 * t + g;
-          acc += Tj[tileAddr(c, i)] * x[16 * j + c]; // L(16 j + c, 16 k + i)
+        for (int m = k + 1; m < NB; ++m) {
+          acc[m] = dot4(ldsRow4(L + 256 * tileIndex(m, k), i, g), yq, acc[m]);
         }
       }
-      acc = quadSum(acc);
-      float* xk = x + 16 * k;
-      const float rhs = xk[i] - acc;
+      acc[k] = p; // block k of y, kept for the backward sweep (every lane of quad i holds y_{16k+i})
+    }
+    float bacc[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      bacc[m] = 0.f;
+    }
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k) { // backward: x_k = L_kk^-T (y_k - sum_{j>k} L_jk^T x_j)
+      const float rhs = acc[k] - quadSum(bacc[k]);
       const float invd = invDiag[16 * k + i];
       const float4 row = ldsRow4(L + 256 * tileIndex(k, k), i, g); // L_kk^-T (i, 4g..4g+3)
       const int c0 = 4 * g;
@@ -398,9 +396,20 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
       p += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 3), 64);
       p = quadSum(p);
       if (g == 0) {
-        xk[i] = p;
+        x[16 * k + i] = p;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (k > 0) {
+        // x_k[4t + g] for t = 0..3: the rows this lane pairs with L(16k + 4t + g, 16m + i)
+        const float xq[4] = {__shfl(p, 4 * g, 64), __shfl(p, 4 * (4 + g), 64), __shfl(p, 4 * (8 + g), 64), __shfl(p, 4 * (12 + g), 64)};
+#pragma unroll
+        for (int m = 0; m < k; ++m) {
+          const float* Tk = L + 256 * tileIndex(k, m);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            bacc[m] += Tk[tileAddr(4 * t + g, i)] * xq[t]; // L(16 k + c, 16 m + i)
+          }
+        }
+      }
     }
   }
   __syncthreads();
