@@ -344,8 +344,72 @@ __device__ __forceinline__ float quadSum(float v) {
   return v;
 }
 
+// left-looking form (one partial sum, the tiles of block row k read when block k is due): for the
+// wide systems, where NB accumulators per direction and NB^2 / 2 unrolled tile products do not pay
 template <int NB>
-__device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, float* x, int tid) {
+__device__ __forceinline__ void solveLLtLeft(const float* L, const float* invDiag, float* x, int tid) {
+  if (tid < 64) {
+    const int i = tid >> 2, g = tid & 3;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { // forward
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < k; ++j) {
+        acc = dot4(ldsRow4(L + 256 * tileIndex(k, j), i, g), *reinterpret_cast<const float4*>(x + 16 * j + 4 * g), acc);
+      }
+      acc = quadSum(acc);
+      float* xk = x + 16 * k;
+      const float rhs = xk[i] - acc; // the same value in the four lanes of quad i
+      const float invd = invDiag[16 * k + i];
+      const float* Dk = L + 256 * tileIndex(k, k);
+      float p = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g; // L_kk^-1 (i, c) = L_kk^-T (c, i)
+        const float m = Dk[tileAddr(c, i)];
+        const float rc = __shfl(rhs, 4 * c, 64); // right-hand side of row c straight from its quad
+        p += (c < i ? m : (c == i ? invd : 0.f)) * rc;
+      }
+      p = quadSum(p);
+      if (g == 0) {
+        xk[i] = p;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k) { // backward
+      float acc = 0.f;
+#pragma unroll
+      for (int j = k + 1; j < NB; ++j) {
+        const float* Tj = L + 256 * tileIndex(j, k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int c = 4 * t + g;
+          acc += Tj[tileAddr(c, i)] * x[16 * j + c]; // L(16 j + c, 16 k + i)
+        }
+      }
+      acc = quadSum(acc);
+      float* xk = x + 16 * k;
+      const float rhs = xk[i] - acc;
+      const float invd = invDiag[16 * k + i];
+      const float4 row = ldsRow4(L + 256 * tileIndex(k, k), i, g); // L_kk^-T (i, 4g..4g+3)
+      const int c0 = 4 * g;
+      float p = (c0 > i ? row.x : (c0 == i ? invd : 0.f)) * __shfl(rhs, 4 * c0, 64);
+      p += (c0 + 1 > i ? row.y : (c0 + 1 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 1), 64);
+      p += (c0 + 2 > i ? row.z : (c0 + 2 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 2), 64);
+      p += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 3), 64);
+      p = quadSum(p);
+      if (g == 0) {
+        xk[i] = p;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  __syncthreads();
+}
+
+template <int NB>
+__device__ __forceinline__ void solveLLtRight(const float* L, const float* invDiag, float* x, int tid) {
   if (tid < 64) {
     const int i = tid >> 2, g = tid & 3;
     // Right-looking inside the wave: as soon as a block of the solution is known it is folded into
@@ -413,6 +477,15 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
     }
   }
   __syncthreads();
+}
+
+template <int NB>
+__device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, float* x, int tid) {
+  if (NB <= 8) {
+    solveLLtRight<NB>(L, invDiag, x, tid);
+  } else {
+    solveLLtLeft<NB>(L, invDiag, x, tid);
+  }
 }
 
 // MODE 0: production; 1: also dump H / g of the first iteration (parity hook); 2: per-phase clocks
