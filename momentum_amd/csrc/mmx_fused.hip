@@ -949,7 +949,6 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
             }
           }
         }
-        __syncthreads(); // every wave has read the diagonal block before wave 0 overwrites it
         MMX_CLK(22)
         float invd = 0.f;
         bool bad = false;
@@ -968,6 +967,9 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
               a[c] -= a[j] * readLaneF(a[j], c);
             }
           }
+        }
+        __syncthreads(); // every wave has read the diagonal block (long ago) before wave 0 overwrites it
+        if (waveWorks) {
           MMX_CLK(23)
           // Stores.  The diagonal tile takes L_kk (columns <= row) from the diagonal lane of a row and
           // L_kk^-T (columns > row) from the identity lane of the same row, 16 lanes further up:
