@@ -1,0 +1,131 @@
+"""Randomised rigs on the GPU: random trees (chains, stars, bushy), parameter transforms with shared
+parameters, translation / scale dofs, rows with three entries (no two-slot ELL copy -> CSR walk),
+non-zero transform offsets, random constraint sets, weights and enabled masks -- J / r / error and a
+short solve against the CPU oracle.  Catches indexing mistakes in the host-built tables (DFS
+intervals, column sources, term records, limit tables) that the fixed fixtures cannot."""
+import numpy as np
+import pytest
+
+from momentum_amd._abi import GnOptions, ParameterLimit
+from momentum_amd.rigs import _build_rig
+from tests.helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU (run with -m gpu on the MI355X box)")
+    return torch
+
+
+def random_rig(rng, J, shape):
+    parent = [-1]
+    for j in range(1, J):
+        if shape == "chain":
+            parent.append(j - 1)
+        elif shape == "star":
+            parent.append(0 if rng.uniform() < 0.7 else int(rng.integers(0, j)))
+        else:
+            parent.append(int(rng.integers(max(0, j - 6), j)))
+    pre = np.zeros((J, 4), np.float32)
+    for j in range(J):
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        ang = rng.uniform(-0.4, 0.4)
+        pre[j] = [*(np.sin(ang / 2) * ax), np.cos(ang / 2)]
+    off = rng.uniform(-0.3, 0.3, size=(J, 3)).astype(np.float32)
+    trip, names = [], []
+
+    def new_param(name):
+        names.append(name)
+        return len(names) - 1
+
+    for d in range(6):  # root: rigid motion
+        trip.append((d, new_param(f"root{d}"), 1.0))
+    trip.append((6, new_param("scale"), 1.0))
+    for j in range(1, J):
+        for d in (3, 4, 5):
+            if rng.uniform() < 0.75:
+                trip.append((7 * j + d, new_param(f"j{j}r{d}"), float(rng.uniform(0.5, 1.5))))
+        if rng.uniform() < 0.15:
+            trip.append((7 * j + int(rng.integers(0, 3)), new_param(f"j{j}t"), 1.0))
+        if rng.uniform() < 0.1:
+            trip.append((7 * j + 6, new_param(f"j{j}s"), 0.5))
+    # shared parameters: each drives one rotation dof of several joints (some rows end up with 2-3 entries)
+    for s in range(max(1, J // 6)):
+        p = new_param(f"shared{s}")
+        for j in rng.choice(np.arange(1, J), size=min(J - 1, int(rng.integers(2, 6))), replace=False):
+            trip.append((7 * int(j) + int(rng.integers(3, 6)), p, float(rng.uniform(-1.0, 1.0))))
+    rig = _build_rig(parent, pre, off, trip, len(names), [f"j{j}" for j in range(J)], names)
+    rig.pt_offsets[:] = (rng.uniform(-0.05, 0.05, size=7 * J) * (rng.uniform(size=7 * J) < 0.2)).astype(np.float32)
+    return rig
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    if seed % 4 == 3:
+        monkeypatch.setenv("MMX_SOLVER", "v1")  # every fourth rig through the three-kernel path
+    rng = np.random.default_rng(1000 + seed)
+    J = int(rng.integers(2, 48))
+    rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
+    P = rig.num_params
+    Kp, Ko = int(rng.integers(0, 9)), int(rng.integers(0, 6))
+    if Kp + Ko == 0:
+        Kp = 1
+    pp = rng.integers(0, J, size=Kp).astype(np.int32)
+    op = rng.integers(0, J, size=Ko).astype(np.int32)
+    B = 3
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=seed, perturb=0.25, random_offsets=True, weights="random")
+    limits = []
+    if seed % 2 == 0 and P >= 4:
+        a, b2 = rng.choice(P, size=2, replace=False)
+        limits = [ParameterLimit.minmax(int(a), -0.05, 0.05, 1.5), ParameterLimit.linear(int(a), int(b2), 0.7, 0.02)]
+        rows = [r for r in range(7 * J) if rig.pt_outer[r + 1] - rig.pt_outer[r] in (1, 2)]
+        if rows:
+            r0 = int(rng.choice(rows))
+            limits.append(ParameterLimit.minmax_joint(r0 // 7, r0 % 7, -0.02, 0.03, 1.0))
+    full = orc.Constraints(
+        cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset, cons.ori_target, cons.ori_weight,
+        pos_function_weight=0.9, ori_function_weight=1.1, limits=limits, limit_function_weight=0.5,
+    )  # fmt: skip
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, pp, op)
+    dev = pb.device
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(dev)
+    pb.set_constraints(
+        t(cons.pos_offset, (B, Kp, 3)), t(cons.pos_target, (B, Kp, 3)), t(cons.pos_weight, (B, Kp)),
+        t(cons.ori_offset, (B, Ko, 4)), t(cons.ori_target, (B, Ko, 4)), t(cons.ori_weight, (B, Ko)),
+        0.9, 1.1, limits=limits, limit_function_weight=0.5,
+    )  # fmt: skip
+    en = (rng.uniform(size=P) < 0.8).astype(np.uint8)
+    en[:3] = 1
+    pb.set_enabled(en)
+    theta = rng.uniform(-0.3, 0.3, size=(B, P)).astype(np.float32)
+    jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(dev))
+    jac, res, err = jac.cpu().numpy(), res.cpu().numpy(), err.cpu().numpy()
+    for b in range(B):
+        Jo, ro, eo = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
+        scale = max(1.0, np.abs(Jo).max())
+        assert np.abs(jac[b].T - Jo).max() <= 3e-5 * scale, (seed, b)
+        assert np.abs(res[b] - ro).max() <= 3e-5 * max(1.0, np.abs(ro).max())
+        assert abs(err[b] - eo) <= 3e-5 * max(1.0, eo)
+    # a short, well regularised solve (lambda = 0.5 keeps even the degenerate random rigs conditioned)
+    opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.5)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(dev), opt, want_history=True)
+    ref = orc.solve_batch(rig, full, th0, opt, enabled=en, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    dnorm = np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / dnorm
+    assert np.all(rel <= 2e-5), (seed, rel)
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+    assert np.all(th[:, en == 0] == th0[:, en == 0])  # disabled parameters are never touched
