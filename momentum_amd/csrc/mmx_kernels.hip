@@ -27,9 +27,22 @@ namespace mmx {
 // unit u.  Lane u owns three consecutive floats of every column, so one wave store covers 768
 // contiguous bytes; every element is written (structural zeros included), no read-modify-write.
 // =============================================================================================
+// the lane's three rows of a column.  Streaming (non-temporal) stores measured against plain ones
+// on the 72-joint workload: 111 -> 104 us at B = 4096, 371 -> 330 us at B = 16384, but 1290 -> 1325 us
+// at B = 65536 -- so they are used up to 40 000 instances per launch.
+__device__ __forceinline__ void store3(float* o, float x, float y, float z, bool nt) {
+  if (nt) {
+    __builtin_nontemporal_store(x, o);
+    __builtin_nontemporal_store(y, o + 1);
+    __builtin_nontemporal_store(z, o + 2);
+  } else {
+    o[0] = x, o[1] = y, o[2] = z;
+  }
+}
+
 // WPI = wavefronts per instance: 1 (block = 64) for large batches, 4 (block = 256: FK over 256
 // threads, the column program dealt to the four waves) when the batch alone cannot fill the chip.
-template <bool kWriteJac, int WPI>
+template <bool kWriteJac, int WPI, bool kStream>
 __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     RigDev rig,
     ProblemDev pb,
@@ -159,6 +172,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
 
   double errAcc = 0.0;
   const size_t M = size_t(pb.M);
+  constexpr bool nt = kStream;
   for (int u0 = 0; u0 < pb.U; u0 += 64) {
     const int u = u0 + lane;
     const Unit un = evalUnitFrom(pb, u0 == 0 ? uin0 : loadUnitInput(pb, b, u), js, u);
@@ -198,9 +212,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
           const float w = anc ? r.weight : 0.f;
           if (un.valid) {
             float* o = jb + size_t(r.col) * M;
-            o[0] = (un.sigma * g.x) * w;
-            o[1] = (un.sigma * g.y) * w;
-            o[2] = (un.sigma * g.z) * w;
+            store3(o, (un.sigma * g.x) * w, (un.sigma * g.y) * w, (un.sigma * g.z) * w, nt);
           }
         }
       }
@@ -219,19 +231,13 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
           acc.z += (un.sigma * g.z) * w;
         }
         if (un.valid) {
-          float* o = jb + size_t(p) * M;
-          o[0] = acc.x;
-          o[1] = acc.y;
-          o[2] = acc.z;
+          store3(jb + size_t(p) * M, acc.x, acc.y, acc.z, nt);
         }
       }
       // (3) columns without sources (disabled parameters): zeros, every element of J is written
       for (int i = wave; i < pb.numZeroCols; i += WPI) {
         if (un.valid) {
-          float* o = jb + size_t(pb.zeroCols[i]) * M;
-          o[0] = 0.f;
-          o[1] = 0.f;
-          o[2] = 0.f;
+          store3(jb + size_t(pb.zeroCols[i]) * M, 0.f, 0.f, 0.f, nt);
         }
       }
     }
@@ -1376,19 +1382,31 @@ hipError_t launchFkJacobian(
   // 300-joint instance needs 25 KB: six single-wave workgroups per CU), so they also take four
   // waves per instance, which share one copy of the joint states.
   const bool wide = pb.B < 2048 || lds > 12 * 1024; // measured: at B = 4096, J = 72 one wave per instance beats four
+  const bool streaming = pb.B <= 40000; // non-temporal column stores: see store3()
+#define MMX_FKJ(W_, WPI_, S_)                                                                                                  \
+  hipLaunchKernelGGL((fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, rig, pb, theta, jac, res, err, state, done)
   if (jac != nullptr) {
     if (wide) {
-      hipLaunchKernelGGL((fkJacobianKernel<true, 4>), dim3(pb.B), dim3(256), lds, stream, rig, pb, theta, jac, res, err, state, done);
+      if (streaming) {
+        MMX_FKJ(true, 4, true);
+      } else {
+        MMX_FKJ(true, 4, false);
+      }
     } else {
-      hipLaunchKernelGGL((fkJacobianKernel<true, 1>), dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+      if (streaming) {
+        MMX_FKJ(true, 1, true);
+      } else {
+        MMX_FKJ(true, 1, false);
+      }
     }
   } else {
     if (wide) {
-      hipLaunchKernelGGL((fkJacobianKernel<false, 4>), dim3(pb.B), dim3(256), lds, stream, rig, pb, theta, jac, res, err, state, done);
+      MMX_FKJ(false, 4, false);
     } else {
-      hipLaunchKernelGGL((fkJacobianKernel<false, 1>), dim3(pb.B), dim3(64), lds, stream, rig, pb, theta, jac, res, err, state, done);
+      MMX_FKJ(false, 1, false);
     }
   }
+#undef MMX_FKJ
   if (pb.M > pb.rowsJoint && (jac != nullptr || res != nullptr || err != nullptr)) {
     hipLaunchKernelGGL(
         parameterRowsKernel, dim3(pb.B), dim3(256), parameterRowsLdsBytes(rig.P, pb.NL), stream, rig, pb, rig.P, theta, jac, res, err, done);
