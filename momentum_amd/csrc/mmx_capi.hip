@@ -240,6 +240,42 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       return fail(rc, err);
     }
     const mmx::FusedTables& f = pb->fused;
+    // Column program of the J-assembly kernel, specialised to this problem: a column whose sources
+    // have no constraint vector below them (or that is disabled) is structurally zero -- it moves
+    // to the zero list, which the kernel writes BEFORE forward kinematics (those stores overlap the
+    // FK prologue and cost no arithmetic); the rest as in buildHostTables.
+    {
+      std::vector<mmx::JacRec> recs;
+      std::vector<int32_t> multi, zero;
+      for (int32_t p = 0; p < rig->P; ++p) {
+        const int32_t cnt = t.colStart[size_t(p) + 1] - t.colStart[size_t(p)];
+        if (cnt == 0 || !f.structNonZero[size_t(p)]) {
+          zero.push_back(p);
+          continue;
+        }
+        const mmx::ColumnSource& cs = t.colSources[size_t(t.colStart[size_t(p)])];
+        if (cnt == 1 && cs.dof >= 3 && cs.dof < 6) {
+          recs.push_back(mmx::JacRec{cs.joint, cs.dof, p, cs.tin, cs.tout, cs.parent, cs.weight, 1});
+        } else {
+          multi.push_back(p);
+        }
+      }
+      std::stable_sort(recs.begin(), recs.end(), [](const mmx::JacRec& a, const mmx::JacRec& b) {
+        return a.joint != b.joint ? a.joint < b.joint : a.dof < b.dof;
+      });
+      while (!recs.empty() && recs.size() % 4 != 0) {
+        recs.push_back(recs.back());
+      }
+      MMX_HIP(upload(pb->dJacRecs, recs));
+      MMX_HIP(upload(pb->dMultiCols, multi));
+      MMX_HIP(upload(pb->dZeroCols, zero));
+      d.jacRecs = pb->dJacRecs.as<mmx::JacRecDev>();
+      d.multiCols = pb->dMultiCols.as<int32_t>();
+      d.zeroCols = pb->dZeroCols.as<int32_t>();
+      d.numJacRecs = int32_t(recs.size());
+      d.numMultiCols = int32_t(multi.size());
+      d.numZeroCols = int32_t(zero.size());
+    }
     MMX_HIP(upload(pb->dSubSize, f.subSize));
     MMX_HIP(upload(pb->dDfsJoint, f.dfsJoint));
     std::vector<int32_t> loadedPos;

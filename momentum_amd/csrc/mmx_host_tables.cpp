@@ -274,6 +274,7 @@ int32_t buildFusedTables(
   f.solveList.clear();
   f.srcStart.assign(1, 0);
   f.srcs.clear();
+  f.structNonZero.assign(size_t(P), 0);
   for (int32_t p = 0; p < P; ++p) {
     if (!t.enabled[p]) {
       continue;
@@ -286,6 +287,7 @@ int32_t buildFusedTables(
         nz = true;
       }
     }
+    f.structNonZero[size_t(p)] = nz ? 1 : 0;
     if (!nz && !(forceSolve != nullptr && forceSolve[p] != 0)) {
       continue;
     }

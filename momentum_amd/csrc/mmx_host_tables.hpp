@@ -74,6 +74,7 @@ struct FusedTables {
   std::vector<int32_t> unitJoint; // [U]
   std::vector<int32_t> posUnitStart; // [J+1] CSR over DFS positions -> units attached to that joint
   std::vector<int32_t> posUnits; // [U]
+  std::vector<uint8_t> structNonZero; // [P] the parameter's column of the joint-constraint rows can be non-zero
   std::vector<int32_t> solveList; // [n] parameter index of compacted column s (ascending)
   std::vector<int32_t> srcStart; // [n+1] offsets into srcs per compacted column
   std::vector<ColumnSource> srcs;

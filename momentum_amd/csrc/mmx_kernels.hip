@@ -89,6 +89,20 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   for (int i = tid; i < rig.J; i += NT) {
     jl[i] = rig.jumpParent[i];
   }
+  if (kWriteJac) {
+    // structurally zero columns (disabled parameters, and parameters none of whose joints carries a
+    // constraint below it): they need no kinematics, so they are written first -- every element of J
+    // is written, and these stores are in flight while FK runs
+    float* jz = jac + size_t(b) * size_t(pb.M) * size_t(rig.P);
+    for (int u0 = 0; u0 < pb.U; u0 += 64) {
+      const int u = u0 + lane;
+      if (u < pb.U) {
+        for (int i = wave; i < pb.numZeroCols; i += WPI) {
+          store3(jz + size_t(pb.zeroCols[i]) * size_t(pb.M) + 3 * size_t(u), 0.f, 0.f, 0.f, kStream);
+        }
+      }
+    }
+  }
   __syncthreads();
   // local transforms of all joints at once (ParameterTransformT::apply + the theta-only part of
   // JointStateT::set), then SkeletonStateT::set's parent-before-child sweep as a sweep over tree
@@ -232,12 +246,6 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
         }
         if (un.valid) {
           store3(jb + size_t(p) * M, acc.x, acc.y, acc.z, nt);
-        }
-      }
-      // (3) columns without sources (disabled parameters): zeros, every element of J is written
-      for (int i = wave; i < pb.numZeroCols; i += WPI) {
-        if (un.valid) {
-          store3(jb + size_t(pb.zeroCols[i]) * M, 0.f, 0.f, 0.f, nt);
         }
       }
     }
