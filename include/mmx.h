@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 2
+#define MMX_ABI_VERSION 3
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
@@ -129,6 +129,45 @@ typedef struct mmx_parameter_limit {
   float v[4];
 } mmx_parameter_limit;
 
+/*
+ * The other JointErrorFunctionT specialisations: one block = one error
+ * function object with `count` constraints per batch element.  FuncDim rows per constraint.
+ *   type                      reference (momentum/character_solver/...)            rows  payload used
+ *   MMX_JC_PLANE              PlaneErrorFunctionT(above=false) plane_error_function.cpp:52-71   1  local_point=offset, global=normal (normalised), plane_d
+ *   MMX_JC_HALF_PLANE         PlaneErrorFunctionT(above=true)  (f clamped to <= 0, :63-70)      1  as above
+ *   MMX_JC_AIM_DIST           AimDistErrorFunctionT aim_error_function.cpp:15-36                3  local_point, local_dir (normalised), global=globalTarget
+ *   MMX_JC_AIM_DIR            AimDirErrorFunctionT  aim_error_function.cpp:39-67                3  as above
+ *   MMX_JC_FIXED_AXIS_DIFF    FixedAxisDiffErrorFunctionT  fixed_axis_error_function.cpp:15-26  3  local_dir=localAxis, global=globalAxis (both normalised)
+ *   MMX_JC_FIXED_AXIS_COS     FixedAxisCosErrorFunctionT   :28-39                               1  as above
+ *   MMX_JC_FIXED_AXIS_ANGLE   FixedAxisAngleErrorFunctionT :41-66                               1  as above
+ *   MMX_JC_NORMAL             NormalErrorFunctionT normal_error_function.cpp:14-31              1  local_point, local_dir=localNormal (normalised), global=globalPoint
+ * Vectors are normalised on ingest exactly where the reference's data constructors do
+ * (plane_error_function.h:30, aim_error_function.h:34, fixed_axis_error_function.h:29-30,
+ * normal_error_function.h:34).
+ */
+#define MMX_JC_PLANE 0
+#define MMX_JC_HALF_PLANE 1
+#define MMX_JC_AIM_DIST 2
+#define MMX_JC_AIM_DIR 3
+#define MMX_JC_FIXED_AXIS_DIFF 4
+#define MMX_JC_FIXED_AXIS_COS 5
+#define MMX_JC_FIXED_AXIS_ANGLE 6
+#define MMX_JC_NORMAL 7
+#define MMX_MAX_JOINT_BLOCKS 8
+
+typedef struct mmx_joint_constraint_block {
+  int32_t type; /* MMX_JC_* */
+  int32_t count; /* constraints per batch element */
+  const int32_t* parent; /* [count] HOST, batch-shared: ConstraintData::parent */
+  const float* local_point; /* [B][count][3] or NULL when the type has no point */
+  const float* local_dir; /* [B][count][3] or NULL when the type has no direction */
+  const float* global; /* [B][count][3] */
+  const float* plane_d; /* [B][count] (plane types only) */
+  const float* weight; /* [B][count] ConstraintData::weight */
+  float function_weight; /* SkeletonErrorFunction::weight_ */
+  float loss_alpha, loss_c; /* GeneralizedLossT(alpha, c); c <= 0: default L2, c = 1 */
+} mmx_joint_constraint_block;
+
 typedef struct mmx_constraint_data {
   const float* pos_offset; /* [B][Kp][3] */
   const float* pos_target; /* [B][Kp][3] */
@@ -158,6 +197,13 @@ typedef struct mmx_constraint_data {
      general form.  c <= 0 (e.g. a zero-initialised struct) selects the default L2 loss with c = 1. */
   float pos_loss_alpha, pos_loss_c;
   float ori_loss_alpha, ori_loss_c;
+  /* ---- optional further joint-constraint blocks (see mmx_joint_constraint_block); their rows
+     follow the orientation rows and precede the limit rows:
+     [3 Kp][9 Ko][block 0]...[block n-1][num_limits][P if model_target != NULL].
+     `joint_blocks` is a HOST array (copied); the payload arrays inside follow `memory`.
+     Problems with such blocks are solved by the explicit-Jacobian kernels. */
+  int32_t num_joint_blocks; /* <= MMX_MAX_JOINT_BLOCKS */
+  const mmx_joint_constraint_block* joint_blocks;
 } mmx_constraint_data;
 
 /*
@@ -221,7 +267,8 @@ int32_t mmx_problem_create(
     mmx_problem** out);
 void mmx_problem_destroy(mmx_problem* problem);
 
-/* M = 3*Kp + 9*Ko (JointErrorFunctionT::getJacobianSize, joint_error_function-inl.h:300-302). */
+/* M = 3*Kp + 9*Ko + rows of the further blocks and parameter-space blocks
+ * (JointErrorFunctionT::getJacobianSize, joint_error_function-inl.h:300-302). */
 int32_t mmx_problem_num_rows(const mmx_problem* problem);
 int32_t mmx_problem_batch(const mmx_problem* problem);
 

@@ -14,7 +14,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-MMX_ABI_VERSION = 2
+MMX_ABI_VERSION = 3
 MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
@@ -85,6 +85,99 @@ def limit_array(limits):
     return arr
 
 
+MMX_JC_PLANE, MMX_JC_HALF_PLANE, MMX_JC_AIM_DIST, MMX_JC_AIM_DIR = 0, 1, 2, 3
+MMX_JC_FIXED_AXIS_DIFF, MMX_JC_FIXED_AXIS_COS, MMX_JC_FIXED_AXIS_ANGLE, MMX_JC_NORMAL = 4, 5, 6, 7
+MMX_MAX_JOINT_BLOCKS = 8
+
+
+def jc_func_dim(type_: int) -> int:
+    """FuncDim of the block's error function (rows per constraint)."""
+    return 3 if type_ in (MMX_JC_AIM_DIST, MMX_JC_AIM_DIR, MMX_JC_FIXED_AXIS_DIFF) else 1
+
+
+class JointConstraintBlock(C.Structure):
+    """mmx_joint_constraint_block."""
+
+    _fields_ = [
+        ("type", C.c_int32),
+        ("count", C.c_int32),
+        ("parent", C.c_void_p),
+        ("local_point", C.c_void_p),
+        ("local_dir", C.c_void_p),
+        ("global_", C.c_void_p),
+        ("plane_d", C.c_void_p),
+        ("weight", C.c_void_p),
+        ("function_weight", C.c_float),
+        ("loss_alpha", C.c_float),
+        ("loss_c", C.c_float),
+    ]
+
+
+class JointBlock:
+    """Python-side description of one further joint-constraint block (Plane / Aim / FixedAxis /
+    Normal error function).  Payload arrays are numpy ([K,..] for one instance or [B,K,..]) or,
+    for the device path, contiguous float32 cuda tensors [B,K,..]."""
+
+    FIELDS = (("local_point", 3), ("local_dir", 3), ("global_", 3), ("plane_d", 0), ("weight", 0))
+
+    def __init__(self, type, parent, weight, global_, local_point=None, local_dir=None, plane_d=None,
+                 function_weight: float = 1.0, loss=(2.0, 1.0)):  # fmt: skip
+        self.type = int(type)
+        self.parent = np.ascontiguousarray(parent, dtype=np.int32).reshape(-1)
+        self.count = int(self.parent.shape[0])
+        self.weight, self.global_ = weight, global_
+        self.local_point, self.local_dir, self.plane_d = local_point, local_dir, plane_d
+        self.function_weight = float(function_weight)
+        self.loss = (float(loss[0]), float(loss[1]))
+
+    @property
+    def rows(self) -> int:
+        return jc_func_dim(self.type) * self.count
+
+    def instance(self, b: int) -> "JointBlock":
+        def cut(a, d):
+            if a is None:
+                return None
+            a = np.asarray(a, dtype=np.float32)
+            shp = (-1, self.count, d) if d else (-1, self.count)
+            return a.reshape(shp)[b]
+
+        return JointBlock(self.type, self.parent, cut(self.weight, 0), cut(self.global_, 3), cut(self.local_point, 3),
+                          cut(self.local_dir, 3), cut(self.plane_d, 0), self.function_weight, self.loss)  # fmt: skip
+
+    def struct(self, keep: list, batch=None, device: bool = False) -> JointConstraintBlock:
+        """ctypes struct; arrays it points to are appended to `keep`.  batch = B checks [B,K,..] shapes."""
+        ptrs = {}
+        for name, d in self.FIELDS:
+            a = getattr(self, name)
+            if a is None:
+                ptrs[name] = None
+                continue
+            if device:
+                shp = (batch, self.count, d) if d else (batch, self.count)
+                assert a.is_cuda and a.is_contiguous() and tuple(a.shape) == shp, (name, tuple(a.shape), shp)
+                keep.append(a)
+                ptrs[name] = C.c_void_p(a.data_ptr() if a.numel() else 0)
+            else:
+                x = np.ascontiguousarray(a, dtype=np.float32)
+                if batch is not None:
+                    x = x.reshape((batch, self.count, d) if d else (batch, self.count))
+                keep.append(x)
+                ptrs[name] = C.c_void_p(x.ctypes.data if x.size else 0)
+        keep.append(self.parent)
+        return JointConstraintBlock(
+            self.type, self.count, C.c_void_p(self.parent.ctypes.data if self.count else 0), ptrs["local_point"], ptrs["local_dir"],
+            ptrs["global_"], ptrs["plane_d"], ptrs["weight"], self.function_weight, self.loss[0], self.loss[1],
+        )  # fmt: skip
+
+
+def joint_block_array(blocks, keep: list, batch=None, device: bool = False):
+    arr = (JointConstraintBlock * max(len(blocks), 1))()
+    for i, blk in enumerate(blocks):
+        arr[i] = blk.struct(keep, batch, device)
+    return arr
+
+
 class ConstraintData(C.Structure):
     _fields_ = [
         ("pos_offset", C.c_void_p),
@@ -108,6 +201,9 @@ class ConstraintData(C.Structure):
         ("pos_loss_c", C.c_float),
         ("ori_loss_alpha", C.c_float),
         ("ori_loss_c", C.c_float),
+        # further joint-constraint blocks (host array of JointConstraintBlock)
+        ("num_joint_blocks", C.c_int32),
+        ("joint_blocks", C.c_void_p),
     ]
 
 

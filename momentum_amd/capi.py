@@ -197,13 +197,15 @@ class Problem:
         pos_function_weight: float = 1.0, ori_function_weight: float = 1.0,
         limits=None, limit_function_weight: float = 1.0,
         model_target=None, model_weights=None, model_function_weight: float = 1.0,
-        pos_loss=(2.0, 1.0), ori_loss=(2.0, 1.0),
+        pos_loss=(2.0, 1.0), ori_loss=(2.0, 1.0), joint_blocks=None,
     ) -> None:  # fmt: skip
         """limits: list of _abi.ParameterLimit (batch-shared, LimitErrorFunction);
         model_target / model_weights: [B,P] (ModelParametersErrorFunction), same memory kind as the
         constraint arrays.  Adds len(limits) + (P if model_target is given) rows to J / r.
         pos_loss / ori_loss: GeneralizedLoss (alpha, c) of the two joint-constraint blocks
-        (alpha 2 = L2, 1 = L1, 0 = Cauchy, _abi.MMX_LOSS_WELSCH = Welsch, else Barron's general form)."""
+        (alpha 2 = L2, 1 = L1, 0 = Cauchy, _abi.MMX_LOSS_WELSCH = Welsch, else Barron's general form).
+        joint_blocks: list of _abi.JointBlock (Plane / Aim / FixedAxis / Normal error functions), payload
+        of the same memory kind as the constraint arrays; their rows follow the orientation rows."""
         import torch
 
         arrs = [pos_offset, pos_target, pos_weight, ori_offset, ori_target, ori_weight]
@@ -226,13 +228,17 @@ class Problem:
             ptrs += [C.c_void_p(0), C.c_void_p(0)]
         limits = list(limits) if limits else []
         larr = _abi.limit_array(limits)
+        blocks = list(joint_blocks) if joint_blocks else []
+        bkeep: list = []
+        barr = _abi.joint_block_array(blocks, bkeep, self.B, on_dev)
         cd = ConstraintData(
             *ptrs[:6], float(pos_function_weight), float(ori_function_weight), _abi.MMX_MEM_DEVICE if on_dev else _abi.MMX_MEM_HOST,
             ptrs[6], ptrs[7], float(model_function_weight), len(limits), C.cast(larr, C.c_void_p) if limits else None, float(limit_function_weight),
             float(pos_loss[0]), float(pos_loss[1]), float(ori_loss[0]), float(ori_loss[1]),
+            len(blocks), C.cast(barr, C.c_void_p) if blocks else None,
         )  # fmt: skip
         _check(lib().mmx_problem_set_constraints(self._h, C.byref(cd), _stream_ptr()))
-        self._keep = keep if on_dev else []
+        self._keep = keep + bkeep if on_dev else []
         self.M = int(lib().mmx_problem_num_rows(self._h))
 
     def _theta(self, theta):

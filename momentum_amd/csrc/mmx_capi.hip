@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <new>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -126,11 +127,21 @@ struct mmx_problem {
   // constraint payload: owned copies (host ingest) or borrowed device pointers
   DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight, oMpTarget, oMpWeights, dLimits, dEnabledMask;
   std::vector<mmx_parameter_limit> limits; // host copy (solve-list bookkeeping)
+  // further joint-constraint blocks: host copy of the descriptors (payload pointers cleared) and parents
+  struct JointBlockHost {
+    int32_t type = 0, count = 0;
+    std::vector<int32_t> parent;
+    DevBuf oLocalPoint, oLocalDir, oGlobal, oPlaneD, oWeight; // owned copies of a host payload
+  };
+  std::vector<std::unique_ptr<JointBlockHost>> blocks;
+  std::vector<mmx::JointBlockDev> blockDev;
+  DevBuf dBlocks, dGenJoint, dGenTin, dGenBlock;
+  int32_t genRows = 0;
   bool haveConstraints = false;
   mmx::ProblemDev dev{};
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
-  DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk;
+  DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
 };
 
 namespace {
@@ -189,6 +200,26 @@ int32_t uploadProblemTables(mmx_problem* pb) {
   static_assert(sizeof(mmx::ColumnSource) == sizeof(mmx::ColumnSourceDev), "ColumnSource layouts must match");
   MMX_HIP(upload(pb->dUnitJoint, unitJoint));
   MMX_HIP(upload(pb->dUnitTin, unitTin));
+  {
+    std::vector<int32_t> gj, gt, gb;
+    for (size_t i = 0; i < pb->blocks.size(); ++i) {
+      for (int32_t j : pb->blocks[i]->parent) {
+        gj.push_back(j);
+        gt.push_back(t.tin[size_t(j)]);
+        gb.push_back(int32_t(i));
+      }
+    }
+    MMX_HIP(upload(pb->dGenJoint, gj));
+    MMX_HIP(upload(pb->dGenTin, gt));
+    MMX_HIP(upload(pb->dGenBlock, gb));
+    MMX_HIP(upload(pb->dBlocks, pb->blockDev));
+    pb->dev.numBlocks = int32_t(pb->blocks.size());
+    pb->dev.G = int32_t(gj.size());
+    pb->dev.blocks = pb->dBlocks.as<mmx::JointBlockDev>();
+    pb->dev.genJoint = pb->dGenJoint.as<int32_t>();
+    pb->dev.genTin = pb->dGenTin.as<int32_t>();
+    pb->dev.genBlock = pb->dGenBlock.as<int32_t>();
+  }
   MMX_HIP(upload(pb->dColStart, t.colStart));
   MMX_HIP(upload(pb->dColSources, t.colSources));
   MMX_HIP(upload(pb->dEnabledList, t.enabledList));
@@ -211,7 +242,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     }
     MMX_HIP(upload(pb->dEnabledMask, mask));
     d.enabledMask = pb->dEnabledMask.as<uint8_t>();
-    d.rowsJoint = 3 * pb->U;
+    d.rowsJoint = 3 * pb->U + pb->genRows;
   }
   static_assert(sizeof(mmx::JacRec) == sizeof(mmx::JacRecDev) && sizeof(mmx::JacRec) == 32, "JacRec layouts must match");
   MMX_HIP(upload(pb->dJacRecs, t.jacRecs));
@@ -511,7 +542,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
 
 bool fusedUsable(const mmx_problem* pb) {
   const int nb = mmx::fusedBlocksFor(pb->fdev.n);
-  if (nb < 0) {
+  if (nb < 0 || pb->dev.G > 0) { // the further joint-constraint blocks live in the explicit-Jacobian kernels
     return false;
   }
   return pb->rig->J < 4096 &&
@@ -934,7 +965,94 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
       return fail(MMX_ERR_UNSUPPORTED, "limit " + std::to_string(l) + ": more than four model parameters drive the limited joint parameters");
     }
   }
-  const bool structureChanged = (c->model_target != nullptr) != (d.hasModel != 0) || size_t(c->num_limits) != pb->limits.size() ||
+  // ---- further joint-constraint blocks
+  if (c->num_joint_blocks < 0 || c->num_joint_blocks > MMX_MAX_JOINT_BLOCKS || (c->num_joint_blocks > 0 && c->joint_blocks == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "joint_blocks: count out of range or null array");
+  }
+  bool blocksChanged = size_t(c->num_joint_blocks) != pb->blocks.size();
+  int32_t genRows = 0, genCount = 0;
+  for (int32_t i = 0; i < c->num_joint_blocks; ++i) {
+    const mmx_joint_constraint_block& jb = c->joint_blocks[i];
+    const std::string tag = "joint block " + std::to_string(i);
+    if (jb.type < MMX_JC_PLANE || jb.type > MMX_JC_NORMAL) {
+      return fail(MMX_ERR_UNSUPPORTED, tag + ": unknown error-function type");
+    }
+    if (jb.count < 0 || (jb.count > 0 && (jb.parent == nullptr || jb.global == nullptr || jb.weight == nullptr))) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, tag + ": negative count or null parent / global / weight array");
+    }
+    const bool plane = jb.type == MMX_JC_PLANE || jb.type == MMX_JC_HALF_PLANE;
+    const bool fixedAxis = jb.type == MMX_JC_FIXED_AXIS_DIFF || jb.type == MMX_JC_FIXED_AXIS_COS || jb.type == MMX_JC_FIXED_AXIS_ANGLE;
+    if (jb.count > 0 && ((!fixedAxis && jb.local_point == nullptr) || (!plane && jb.local_dir == nullptr) || (plane && jb.plane_d == nullptr))) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, tag + ": a payload array its error function needs is null");
+    }
+    for (int32_t k = 0; k < jb.count; ++k) {
+      if (jb.parent[k] < 0 || jb.parent[k] >= pb->rig->J) {
+        return fail(MMX_ERR_INVALID_ARGUMENT, tag + ": parent joint out of range"); // MT_CHECK joint_error_function-inl.h:230
+      }
+    }
+    const bool three = jb.type == MMX_JC_AIM_DIST || jb.type == MMX_JC_AIM_DIR || jb.type == MMX_JC_FIXED_AXIS_DIFF;
+    genRows += (three ? 3 : 1) * jb.count;
+    genCount += jb.count;
+    if (!blocksChanged) {
+      const mmx_problem::JointBlockHost& h = *pb->blocks[size_t(i)];
+      blocksChanged = h.type != jb.type || h.count != jb.count || !std::equal(h.parent.begin(), h.parent.end(), jb.parent);
+    }
+  }
+  if (genCount > 1024) {
+    return fail(MMX_ERR_UNSUPPORTED, "more than 1024 constraints in the further joint-constraint blocks");
+  }
+  if (blocksChanged) {
+    pb->blocks.clear();
+    for (int32_t i = 0; i < c->num_joint_blocks; ++i) {
+      auto h = std::make_unique<mmx_problem::JointBlockHost>();
+      h->type = c->joint_blocks[i].type;
+      h->count = c->joint_blocks[i].count;
+      h->parent.assign(c->joint_blocks[i].parent, c->joint_blocks[i].parent + h->count);
+      pb->blocks.push_back(std::move(h));
+    }
+  }
+  pb->blockDev.assign(size_t(c->num_joint_blocks), mmx::JointBlockDev{});
+  {
+    int32_t first = 0, row = 3 * pb->U;
+    for (int32_t i = 0; i < c->num_joint_blocks; ++i) {
+      const mmx_joint_constraint_block& jb = c->joint_blocks[i];
+      mmx_problem::JointBlockHost& h = *pb->blocks[size_t(i)];
+      mmx::JointBlockDev& k = pb->blockDev[size_t(i)];
+      k.type = jb.type;
+      k.count = jb.count;
+      k.first = first;
+      k.rowStart = row;
+      k.fw = jb.function_weight;
+      k.loss = makeLoss(jb.loss_alpha, jb.loss_c);
+      const size_t cnt = B * size_t(jb.count);
+      auto bring = [&](DevBuf& buf, const float* src, size_t count, const float*& dst) -> hipError_t {
+        if (src == nullptr || count == 0) {
+          dst = nullptr;
+          return hipSuccess;
+        }
+        if (c->memory == MMX_MEM_DEVICE) {
+          dst = src;
+          return hipSuccess;
+        }
+        hipError_t e = buf.ensure(count * sizeof(float));
+        if (e != hipSuccess) {
+          return e;
+        }
+        dst = buf.as<float>();
+        return hipMemcpy(buf.p, src, count * sizeof(float), hipMemcpyHostToDevice);
+      };
+      MMX_HIP(bring(h.oLocalPoint, jb.local_point, 3 * cnt, k.localPoint));
+      MMX_HIP(bring(h.oLocalDir, jb.local_dir, 3 * cnt, k.localDir));
+      MMX_HIP(bring(h.oGlobal, jb.global, 3 * cnt, k.global));
+      MMX_HIP(bring(h.oPlaneD, jb.plane_d, cnt, k.planeD));
+      MMX_HIP(bring(h.oWeight, jb.weight, cnt, k.weight));
+      const bool three = jb.type == MMX_JC_AIM_DIST || jb.type == MMX_JC_AIM_DIR || jb.type == MMX_JC_FIXED_AXIS_DIFF;
+      first += jb.count;
+      row += (three ? 3 : 1) * jb.count;
+    }
+  }
+  pb->genRows = genRows;
+  const bool structureChanged = blocksChanged || (c->model_target != nullptr) != (d.hasModel != 0) || size_t(c->num_limits) != pb->limits.size() ||
       (c->num_limits > 0 && std::memcmp(c->limits, pb->limits.data(), size_t(c->num_limits) * sizeof(mmx_parameter_limit)) != 0);
   pb->limits.assign(c->limits, c->limits + c->num_limits);
   static_assert(sizeof(mmx_parameter_limit) == sizeof(mmx::LimitDev) && sizeof(mmx::LimitDev) == 32, "limit layouts must match");
@@ -959,8 +1077,13 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   } else {
     d.mpTarget = d.mpWeights = nullptr;
   }
-  pb->M = 3 * pb->U + d.NL + (d.hasModel ? P : 0);
+  pb->M = 3 * pb->U + pb->genRows + d.NL + (d.hasModel ? P : 0);
   d.M = pb->M;
+  d.rowsJoint = 3 * pb->U + pb->genRows;
+  if (!structureChanged) { // payload pointers / weights / losses of the blocks may still have changed
+    MMX_HIP(upload(pb->dBlocks, pb->blockDev));
+    d.blocks = pb->dBlocks.as<mmx::JointBlockDev>();
+  }
   if (structureChanged) { // the fused kernel's solve list and limit tables depend on it
     rc = uploadProblemTables(pb);
     if (rc != MMX_OK) {
@@ -1130,9 +1253,6 @@ int32_t mmx_solve(
     }
     return MMX_OK;
   }
-  if (o->do_line_search != 0 || o->step_rule != MMX_STEP_GN_FIXED_LAMBDA) {
-    return fail(MMX_ERR_UNSUPPORTED, "line search / LM schedule need the fused solver (<= 224 solved parameters)");
-  }
   if (n > 512) {
     return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
   }
@@ -1157,13 +1277,32 @@ int32_t mmx_solve(
     MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
   }
   MMX_HIP(hipMemcpyAsync(pb->sThetaInit.p, theta_dev, B * P * sizeof(float), hipMemcpyDeviceToDevice, s));
-  MMX_HIP(mmx::launchSolveInit(st, pb->B, s));
+  const bool deferred = o->do_line_search != 0 || o->step_rule == MMX_STEP_LM_SCHEDULE;
+  const bool schedule = o->step_rule == MMX_STEP_LM_SCHEDULE;
+  if (deferred) {
+    MMX_HIP(pb->sDelta.ensure(B * size_t(std::max(n, 1)) * sizeof(float)));
+    MMX_HIP(pb->sStepIter.ensure(B * sizeof(int32_t)));
+    MMX_HIP(hipMemsetAsync(pb->sStepIter.p, 0, B * sizeof(int32_t), s));
+  }
+  if (schedule) {
+    MMX_HIP(pb->sLambda.ensure(B * sizeof(float)));
+  }
+  MMX_HIP(mmx::launchSolveInit(st, pb->B, schedule ? pb->sLambda.as<float>() : nullptr, o->regularization, s));
   mmx::StepParams sp{};
   sp.lambda = o->regularization;
   sp.threshold = o->threshold;
   sp.minIterations = o->min_iterations;
   sp.maxIterations = o->max_iterations;
   sp.refine = getenv("MMX_NO_REFINE") != nullptr ? 0 : 1;
+  sp.delta = deferred ? pb->sDelta.as<float>() : nullptr;
+  sp.stepIter = deferred ? pb->sStepIter.as<int32_t>() : nullptr;
+  sp.lambdaPer = schedule ? pb->sLambda.as<float>() : nullptr;
+  sp.doLineSearch = o->do_line_search;
+  sp.stepRule = o->step_rule;
+  sp.lmLambdaMin = o->lm_lambda_min;
+  sp.lmLambdaMax = o->lm_lambda_max;
+  sp.lmUp = o->lm_up;
+  sp.lmDown = o->lm_down;
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
     MMX_HIP(mmx::launchFkJacobian(
@@ -1183,6 +1322,9 @@ int32_t mmx_solve(
         st,
         sp,
         s));
+    if (deferred) {
+      MMX_HIP(mmx::launchStepUpdate(pb->rig->dev, pb->dev, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
+    }
   }
   MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
   return MMX_OK;

@@ -16,6 +16,8 @@
 
 #include <cstdint>
 
+#include "../../include/mmx.h"
+
 namespace mmx {
 
 constexpr int kJs = 20; // floats per joint in js[]
@@ -159,6 +161,21 @@ struct LimitDev {
   float v[4];
 };
 
+// == mmx_joint_constraint_block (include/mmx.h) for the device: one further JointErrorFunctionT
+// specialisation (Plane / Aim / FixedAxis / Normal) with `count` constraints per instance
+struct JointBlockDev {
+  int32_t type, count;
+  int32_t first; // index of the block's first constraint in the flattened list (genJoint, genTin, genBlock)
+  int32_t rowStart; // first row of the block in J / r
+  const float* localPoint; // [B][count][3] or null
+  const float* localDir; // [B][count][3] or null
+  const float* global; // [B][count][3]
+  const float* planeD; // [B][count] or null
+  const float* weight; // [B][count]
+  float fw; // SkeletonErrorFunction::weight_
+  LossDev loss;
+};
+
 struct ProblemDev {
   int32_t B, Kp, Ko, U, M, n; // U = Kp + 3 Ko constraint vectors, M = 3 U rows, n = #enabled
   const int32_t* unitJoint; // [U] parent joint of the unit's constraint
@@ -180,7 +197,13 @@ struct ProblemDev {
   LossDev lossPos, lossOri; // JointErrorFunctionT::loss_ of the two blocks
   // ---- parameter-space blocks (rows rowsJoint .. M-1): LimitErrorFunctionT on model parameters,
   // ModelParametersErrorFunctionT.  M = rowsJoint + NL + (hasModel ? P : 0).
-  int32_t rowsJoint; // 3 U
+  int32_t rowsJoint; // 3 U + rows of the further joint-constraint blocks
+  // ---- further joint-constraint blocks (rows 3 U .. rowsJoint-1), explicit-Jacobian path only
+  int32_t numBlocks, G; // blocks, constraints of all blocks
+  const JointBlockDev* blocks; // [numBlocks]
+  const int32_t* genJoint; // [G] parent joint
+  const int32_t* genTin; // [G] tin[genJoint]
+  const int32_t* genBlock; // [G] block of the constraint
   int32_t NL; // limits (one row each)
   int32_t hasModel; // model-parameter block present (P rows, used rows compacted to the top)
   const LimitDev* limits; // [NL]
@@ -486,6 +509,141 @@ __device__ __forceinline__ F3 sourceDerivative(const ColumnSourceDev& s, const f
   return kLn2 * (un.v - F3{a[0], a[1], a[2]}); // scale: (v - t_a) * ln2
 }
 
+// ---------------------------------------------------------------------------------------------
+// evalFunction of the further JointErrorFunctionT specialisations + the weighting of
+// JointErrorFunctionT::getJacobian (joint_error_function-inl.h:197-226): one constraint with up to
+// one point v_p (NumPos) and one direction v_n, FuncDim = nrows in {1, 3}, df/dv_p = dp, df/dv_n = dn
+// (row-major, rows >= nrows zero).
+// ---------------------------------------------------------------------------------------------
+struct JointEval {
+  F3 vp, vn;
+  float dp[9], dn[9];
+  float f[3];
+  float sigma; // derivScale = sqrt(w * loss'(|f|^2)) ; 0 when the rows stay zero
+  float werr; // w * loss(|f|^2)
+  int nrows;
+  bool hasPoint, hasDir;
+};
+
+__device__ __forceinline__ F3 normalizedOrSame(const F3& a) { // Eigen normalized(): unchanged when the norm is zero
+  const float n2 = dot(a, a);
+  return n2 > 0.f ? (1.f / sqrtf(n2)) * a : a;
+}
+
+__device__ __forceinline__ int jointBlockFuncDim(int type) {
+  return (type == MMX_JC_AIM_DIST || type == MMX_JC_AIM_DIR || type == MMX_JC_FIXED_AXIS_DIFF) ? 3 : 1;
+}
+
+__device__ __forceinline__ JointEval evalJointConstraint(const JointBlockDev& k, const float* js, int joint, size_t c) {
+  JointEval o;
+  o.vp = o.vn = F3{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    o.dp[i] = o.dn[i] = 0.f;
+  }
+  o.f[0] = o.f[1] = o.f[2] = 0.f;
+  o.sigma = o.werr = 0.f;
+  o.nrows = jointBlockFuncDim(k.type);
+  o.hasPoint = k.type != MMX_JC_FIXED_AXIS_DIFF && k.type != MMX_JC_FIXED_AXIS_COS && k.type != MMX_JC_FIXED_AXIS_ANGLE;
+  o.hasDir = k.type != MMX_JC_PLANE && k.type != MMX_JC_HALF_PLANE;
+  const float* w = js + kJs * joint;
+  const F3 t{w[0], w[1], w[2]};
+  const Q4 q{w[3], w[4], w[5], w[6]};
+  const float s = w[7];
+  auto vec = [&](const float* a) { return F3{a[3 * c], a[3 * c + 1], a[3 * c + 2]}; };
+  auto setRow = [](float* m, const F3& a, float sc) { m[0] = sc * a.x, m[1] = sc * a.y, m[2] = sc * a.z; };
+  auto addOuter = [](float* m, const F3& a, const F3& b, float sc) { // m += sc * a b^T
+    m[0] += sc * a.x * b.x, m[1] += sc * a.x * b.y, m[2] += sc * a.x * b.z;
+    m[3] += sc * a.y * b.x, m[4] += sc * a.y * b.y, m[5] += sc * a.y * b.z;
+    m[6] += sc * a.z * b.x, m[7] += sc * a.z * b.y, m[8] += sc * a.z * b.z;
+  };
+  const F3 gl = vec(k.global);
+  if (o.hasPoint) {
+    o.vp = t + qrot(q, s * vec(k.localPoint)); // state.transform * point
+  }
+  if (o.hasDir) {
+    o.vn = qrot(q, normalizedOrSame(vec(k.localDir))); // state.rotation() * dir, normalised by the data ctor
+  }
+  switch (k.type) {
+    case MMX_JC_PLANE:
+    case MMX_JC_HALF_PLANE: { // plane_error_function.cpp:52-71
+      const F3 n = normalizedOrSame(gl);
+      float val = dot(o.vp, n) - k.planeD[c];
+      const bool half = k.type == MMX_JC_HALF_PLANE;
+      if (half && val > 0.f) {
+        val = 0.f;
+      }
+      o.f[0] = val;
+      if (!half || val < 0.f) {
+        setRow(o.dp, n, 1.f);
+      }
+      break;
+    }
+    case MMX_JC_AIM_DIST: { // aim_error_function.cpp:15-36
+      const F3 tgt = gl - o.vp;
+      const float proj = dot(o.vn, tgt);
+      const F3 r = proj * o.vn - tgt;
+      o.f[0] = r.x, o.f[1] = r.y, o.f[2] = r.z;
+      o.dp[0] = o.dp[4] = o.dp[8] = 1.f;
+      addOuter(o.dp, o.vn, o.vn, -1.f);
+      addOuter(o.dn, o.vn, tgt, 1.f);
+      o.dn[0] += proj, o.dn[4] += proj, o.dn[8] += proj;
+      break;
+    }
+    case MMX_JC_AIM_DIR: { // aim_error_function.cpp:39-67
+      const F3 tgt = gl - o.vp;
+      const float nrm = sqrtf(dot(tgt, tgt));
+      F3 dir{0.f, 0.f, 0.f};
+      if (nrm > 1e-16f) {
+        dir = (1.f / nrm) * tgt;
+        addOuter(o.dp, dir, dir, -1.f / nrm);
+        o.dp[0] += 1.f / nrm, o.dp[4] += 1.f / nrm, o.dp[8] += 1.f / nrm;
+      }
+      const F3 r = o.vn - dir;
+      o.f[0] = r.x, o.f[1] = r.y, o.f[2] = r.z;
+      o.dn[0] = o.dn[4] = o.dn[8] = 1.f;
+      break;
+    }
+    case MMX_JC_FIXED_AXIS_DIFF: { // fixed_axis_error_function.cpp:15-26
+      const F3 r = o.vn - normalizedOrSame(gl);
+      o.f[0] = r.x, o.f[1] = r.y, o.f[2] = r.z;
+      o.dn[0] = o.dn[4] = o.dn[8] = 1.f;
+      break;
+    }
+    case MMX_JC_FIXED_AXIS_COS: { // :28-39
+      const F3 ga = normalizedOrSame(gl);
+      o.f[0] = 1.f - dot(o.vn, ga);
+      setRow(o.dn, ga, -1.f);
+      break;
+    }
+    case MMX_JC_FIXED_AXIS_ANGLE: { // :41-66
+      const F3 ga = normalizedOrSame(gl);
+      const float d = dot(o.vn, ga);
+      o.f[0] = acosf(fminf(fmaxf(d, -1.f), 1.f));
+      const float sine = sqrtf(1.f - d * d);
+      if (sine > 1e-9f) {
+        setRow(o.dn, ga, -1.f / sine);
+      }
+      break;
+    }
+    default: { // MMX_JC_NORMAL, normal_error_function.cpp:14-31
+      const F3 dist = o.vp - gl;
+      o.f[0] = dot(o.vn, dist);
+      setRow(o.dp, o.vn, 1.f);
+      setRow(o.dn, dist, 1.f);
+      break;
+    }
+  }
+  const float cw = k.weight[c];
+  if (cw != 0.f && k.fw > 0.f) { // :197-199 ; blocks with weight_ <= 0 are skipped (skeleton_solver_function.cpp:223-231)
+    const float sqr = o.f[0] * o.f[0] + o.f[1] * o.f[1] + o.f[2] * o.f[2];
+    const float wgt = cw * k.fw;
+    o.werr = wgt * lossValue(k.loss, sqr); // :207
+    o.sigma = sqrtf(wgt * lossDeriv(k.loss, sqr)); // :208
+  }
+  return o;
+}
+
 // One row of LimitErrorFunctionT::getJacobian with the L2 loss for the limit types that act on
 // model or joint parameters (momentum/character_solver/limit_error_function.cpp:
 // computeMinMaxJacobian :460-503, computeMinMaxJointJacobian :503-558, computeLinearJacobian
@@ -700,5 +858,36 @@ __device__ __forceinline__ float waveReduceSumF(float v) {
   }
   return v;
 }
+
+// this thread's share of the blocks' error at the parameters `th`.  kJacobianRows: the value
+// getJacobian returns (model rows with weight <= 0 are skipped, model_parameters_error_function.cpp:113),
+// else the one getError returns (:54-58).
+template <bool kJacobianRows>
+__device__ __forceinline__ double paramRowsError(const RigDev& rig, const ProblemDev& pb, int P, const float* th, int b, int tid) {
+  double e = 0.0;
+  if (pb.NL > 0 && pb.wLimit > 0.f) {
+    const float tWeight = 1e+1f * pb.wLimit;
+    for (int l = tid; l < pb.NL; l += 256) {
+      e += double(evalLimit(rig, pb.limits[l], th, pb.enabledMask, tWeight).err);
+    }
+  }
+  if (pb.hasModel && pb.wModel > 0.f) {
+    const float* tp = pb.mpTarget + size_t(b) * P;
+    const float* tw = pb.mpWeights + size_t(b) * P;
+    double em = 0.0;
+    for (int i = tid; i < P; i += 256) {
+      if (pb.enabledMask[i] != 0) {
+        const float w = tw[i];
+        if (!kJacobianRows || w > 0.f) {
+          const float pd = w * (th[i] - tp[i]);
+          em += double(pd * pd);
+        }
+      }
+    }
+    e += em * double(pb.wModel) * double(1e-1f);
+  }
+  return e;
+}
+
 
 } // namespace mmx

@@ -181,36 +181,6 @@ __device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, fl
 // they need no joint state, so their contributions to the error, to g / H and to the refinement
 // are evaluated on the fly from theta -- no extra LDS, nothing stored per row.
 // ---------------------------------------------------------------------------------------------
-// this thread's share of the blocks' error at the parameters `th`.  kJacobianRows: the value
-// getJacobian returns (model rows with weight <= 0 are skipped, model_parameters_error_function.cpp:113),
-// else the one getError returns (:54-58).
-template <bool kJacobianRows>
-__device__ __forceinline__ double paramRowsError(const RigDev& rig, const ProblemDev& pb, int P, const float* th, int b, int tid) {
-  double e = 0.0;
-  if (pb.NL > 0 && pb.wLimit > 0.f) {
-    const float tWeight = 1e+1f * pb.wLimit;
-    for (int l = tid; l < pb.NL; l += 256) {
-      e += double(evalLimit(rig, pb.limits[l], th, pb.enabledMask, tWeight).err);
-    }
-  }
-  if (pb.hasModel && pb.wModel > 0.f) {
-    const float* tp = pb.mpTarget + size_t(b) * P;
-    const float* tw = pb.mpWeights + size_t(b) * P;
-    double em = 0.0;
-    for (int i = tid; i < P; i += 256) {
-      if (pb.enabledMask[i] != 0) {
-        const float w = tw[i];
-        if (!kJacobianRows || w > 0.f) {
-          const float pd = w * (th[i] - tp[i]);
-          em += double(pd * pd);
-        }
-      }
-    }
-    e += em * double(pb.wModel) * double(1e-1f);
-  }
-  return e;
-}
-
 struct ParamCol {
   float g, h;
 };

@@ -397,6 +397,190 @@ size_t parameterRowsLdsBytes(int P, int NL) {
 }
 
 // =============================================================================================
+// Kernel 1c: the rows of the further joint-constraint blocks (Plane / HalfPlane / AimDist / AimDir /
+// FixedAxisDiff / Cos / Angle / Normal error functions; rows 3 U .. rowsJoint-1 of every column),
+// their residual and error.  grid = B, block = 256.  Launched after fkJacobianKernel when the
+// problem carries such blocks; adds its error to err[b].
+//
+// Replaces JointErrorFunctionT<T, Data, FuncDim, NumVec, NumPos>::getJacobian
+// (momentum/character_solver/joint_error_function-inl.h:179-297) for general df/dv: the kernel
+// repeats forward kinematics for its instance in LDS (cheap next to the rows it writes), evaluates
+// every constraint once (one thread each; sigma * df/dv staged in LDS), then one thread per
+// (constraint, column) gathers the column's sources -- the ancestor walk turned inside out, as in
+// fkJacobianKernel -- and writes FuncDim rows.  Every element of those rows is written.
+// =============================================================================================
+constexpr int kEvWords = 27; // vp(3) vn(3) sigma*dp(9) sigma*dn(9) tin row nrows|flags ; odd stride: conflict-free
+
+struct SideLds {
+  float* js; // [J][kJs]
+  float* alt; // [J][8]
+  int* jlA; // [J]
+  int* jlB; // [J]
+};
+
+__device__ __forceinline__ SideLds carveSideLds(float* smem, int J, float** next) {
+  SideLds s;
+  s.js = smem;
+  s.alt = s.js + ((kJs * J + 3) & ~3);
+  s.jlA = reinterpret_cast<int*>(s.alt + 8 * J);
+  s.jlB = s.jlA + J;
+  *next = reinterpret_cast<float*>(s.jlB + J);
+  return s;
+}
+
+size_t sideFkLdsFloats(int J) {
+  return size_t((kJs * J + 3) & ~3) + 10 * size_t(J);
+}
+
+// forward kinematics of one instance by 256 threads: local transforms of all joints at once,
+// pointer-jumping composition, optionally the rotation axes (see fkJacobianKernel)
+__device__ __forceinline__ void sideFk(const RigDev& rig, const SideLds& s, const float* th, int tid, bool withAxes) {
+  const bool odd = (rig.jumpRounds & 1) != 0;
+  for (int j = tid; j < rig.J; j += 256) {
+    float* slot = s.js + kJs * j;
+    fkLocalSplit(rig, j, th, odd ? s.alt + 8 * j : slot, slot + 8);
+    (odd ? s.jlB : s.jlA)[j] = rig.parent[j] + 1;
+  }
+  __syncthreads();
+  fkJumpRounds(s.js, s.alt, s.jlA, s.jlB, rig.J, rig.jumpRounds, tid, 256);
+  if (withAxes) {
+    for (int j = tid; j < rig.J; j += 256) {
+      fkAxesInPlaceP(rig, j, rig.parent[j], s.js);
+    }
+    __syncthreads();
+  }
+}
+
+template <bool kWriteJac>
+__global__ void __launch_bounds__(256) jointBlocksKernel(
+    RigDev rig,
+    ProblemDev pb,
+    const float* __restrict__ theta,
+    float* __restrict__ jac, // or null
+    float* __restrict__ res, // or null
+    double* __restrict__ err, // or null: err[b] += error of these blocks
+    const int32_t* __restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ double red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (done != nullptr && done[b] != 0) {
+    return;
+  }
+  const int P = rig.P, G = pb.G;
+  float* thL;
+  const SideLds sl = carveSideLds(smem, rig.J, &thL);
+  float* ev = thL + ((P + 3) & ~3);
+  int* evi = reinterpret_cast<int*>(ev);
+  for (int i = tid; i < P; i += 256) {
+    thL[i] = theta[size_t(b) * P + i];
+  }
+  __syncthreads();
+  sideFk(rig, sl, thL, tid, kWriteJac);
+  const float* js = sl.js;
+  const size_t M = size_t(pb.M);
+  double e = 0.0;
+  for (int g = tid; g < G; g += 256) {
+    const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+    const int i = g - k.first;
+    const JointEval o = evalJointConstraint(k, js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(i));
+    const int row = k.rowStart + o.nrows * i;
+    e += double(o.werr);
+    if (res != nullptr) {
+      float* r = res + size_t(b) * M + row;
+      for (int q = 0; q < o.nrows; ++q) {
+        r[q] = o.sigma * o.f[q];
+      }
+    }
+    if (kWriteJac) {
+      const float sg = fabsf(o.sigma) <= 1e-9f ? 0.f : o.sigma; // early termination (:216): the rows stay zero
+      float* w = ev + kEvWords * g;
+      w[0] = o.vp.x, w[1] = o.vp.y, w[2] = o.vp.z;
+      w[3] = o.vn.x, w[4] = o.vn.y, w[5] = o.vn.z;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        w[6 + q] = sg * o.dp[q];
+        w[15 + q] = sg * o.dn[q];
+      }
+      evi[kEvWords * g + 24] = pb.genTin[g];
+      evi[kEvWords * g + 25] = row;
+      evi[kEvWords * g + 26] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0);
+    }
+  }
+  if (err != nullptr) {
+    e = waveReduceSum(e);
+    if (lane == 0) {
+      red[wave] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      err[b] += (red[0] + red[1]) + (red[2] + red[3]);
+    }
+  }
+  if (!kWriteJac) {
+    return;
+  }
+  __syncthreads();
+  float* jb = jac + size_t(b) * M * size_t(P);
+  const int items = G * P;
+  for (int item = tid; item < items; item += 256) {
+    const int p = item / G, g = item - p * G; // constraints fastest: neighbouring threads write neighbouring rows
+    const float* w = ev + kEvWords * g;
+    const int tin = evi[kEvWords * g + 24], row = evi[kEvWords * g + 25], fl = evi[kEvWords * g + 26];
+    const int nrows = fl & 15;
+    const bool hasPoint = (fl & 16) != 0, hasDir = (fl & 32) != 0;
+    const F3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
+    float acc[3] = {0.f, 0.f, 0.f};
+    const int e1 = pb.colStart[p + 1];
+    for (int ei = pb.colStart[p]; ei < e1; ++ei) {
+      const ColumnSourceDev s = pb.colSources[ei];
+      if (!((s.tin <= tin) && (tin < s.tout))) {
+        continue; // the source's joint is not an ancestor of the constraint's joint
+      }
+      const float* a = js + kJs * s.joint;
+      F3 gp{0.f, 0.f, 0.f}, gn{0.f, 0.f, 0.f};
+      if (s.dof >= 3 && s.dof < 6) { // rotation: axis x (v - t_a) for points, axis x v for directions (:265-278)
+        const float* ax = a + 8 + 3 * (s.dof - 3);
+        const F3 axis{ax[0], ax[1], ax[2]};
+        if (hasPoint) {
+          gp = cross(axis, vp - F3{a[0], a[1], a[2]});
+        }
+        if (hasDir) {
+          gn = cross(axis, vn);
+        }
+      } else if (hasPoint) {
+        if (s.dof < 3) { // translation (:248-262): column dof of parent.toLinear(), identity for a root
+          if (s.parent < 0) {
+            gp = F3{s.dof == 0 ? 1.f : 0.f, s.dof == 1 ? 1.f : 0.f, s.dof == 2 ? 1.f : 0.f};
+          } else {
+            const float* pp = js + kJs * s.parent;
+            const F3 c = qmatCol(Q4{pp[3], pp[4], pp[5], pp[6]}, s.dof);
+            gp = F3{c.x * pp[7], c.y * pp[7], c.z * pp[7]};
+          }
+        } else { // scale (:281-291)
+          gp = kLn2 * (vp - F3{a[0], a[1], a[2]});
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float jc = (w[6 + 3 * q] * gp.x + w[7 + 3 * q] * gp.y + w[8 + 3 * q] * gp.z) +
+            (w[15 + 3 * q] * gn.x + w[16 + 3 * q] * gn.y + w[17 + 3 * q] * gn.z);
+        acc[q] += jc * s.weight;
+      }
+    }
+    float* col = jb + size_t(p) * M + row;
+    col[0] = acc[0];
+    if (nrows == 3) {
+      col[1] = acc[1];
+      col[2] = acc[2];
+    }
+  }
+}
+
+size_t jointBlocksLdsBytes(int J, int P, int G) {
+  return (sideFkLdsFloats(J) + size_t((P + 3) & ~3) + size_t(kEvWords) * size_t(G)) * sizeof(float);
+}
+
+// =============================================================================================
 // Kernel 2: normal equations from the dense Jacobian.  grid = B, block = 256.
 // H = J[:,E]^T J[:,E] (full symmetric n x n), g = J[:,E]^T r, E = enabled parameter list.
 // Replaces the column compaction + `H.triangularView<Lower>() += J^T J; JtR += J^T r` of
@@ -833,6 +1017,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     return;
   }
   const int n = pb.n, M = pb.M;
+  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
   const int ld = n + 1; // odd-ish stride: conflict-free column walks
   float* A = smem; // [n][ld] column-major: A[j*ld + i] = H(i,j)
   float* g = A + n * ld; // [n]
@@ -848,7 +1033,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     const int i = idx % n, j = idx / n;
     float v = Hb[idx];
     if (i == j) {
-      v += sp.lambda;
+      v += lambda;
     }
     A[j * ld + i] = v;
   }
@@ -911,7 +1096,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
       }
       acc = waveReduceSumF(acc);
       if (lane == 0) {
-        rho[s] = acc - sp.lambda * d0[s];
+        rho[s] = acc - lambda * d0[s];
       }
     }
     __syncthreads();
@@ -939,7 +1124,14 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     }
   }
   // theta -= delta (scatter to the full parameter space, gauss_newton_solver.cpp:254-257)
-  if (!bad) {
+  if (sp.delta != nullptr) { // line search / damping schedule: stepUpdateKernel applies the step
+    for (int s = tid; s < n; s += 256) {
+      sp.delta[size_t(b) * n + s] = bad ? 0.f : d0[s];
+    }
+    if (tid == 0) {
+      sp.stepIter[b] = bad ? -(sp.iteration + 1) : sp.iteration + 1;
+    }
+  } else if (!bad) {
     float* th = theta + size_t(b) * P;
     for (int s = tid; s < n; s += 256) {
       th[pb.enabledList[s]] -= d0[s];
@@ -996,6 +1188,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
     return;
   }
   const int n = pb.n, M = pb.M;
+  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
   const int NP = (n + 15) & ~15, NB = NP >> 4;
   float* pan = smem; // [NB - k tiles][256] swizzled tiles of the current block column
   float* g = pan + size_t(NP) * 16;
@@ -1017,7 +1210,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
   // read from H exactly once before being overwritten with its Schur-complement value, EXCEPT that
   // updated values are re-read -> keep a "lambda already applied" convention: apply it up front.
   for (int i = tid; i < n; i += 256) {
-    H[size_t(i) * n + i] += sp.lambda;
+    H[size_t(i) * n + i] += lambda;
   }
   __threadfence();
   __syncthreads();
@@ -1278,7 +1471,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
         acc = waveReduceSumF(acc);
       }
       if (lane == 0) {
-        rho[s2] = s2 < n ? acc - sp.lambda * d0[s2] : 0.f;
+        rho[s2] = s2 < n ? acc - lambda * d0[s2] : 0.f;
       }
     }
     __syncthreads();
@@ -1304,7 +1497,14 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
       break;
     }
   }
-  if (!bad) {
+  if (sp.delta != nullptr) {
+    for (int s2 = tid; s2 < n; s2 += 256) {
+      sp.delta[size_t(b) * n + s2] = bad ? 0.f : d0[s2];
+    }
+    if (tid == 0) {
+      sp.stepIter[b] = bad ? -(sp.iteration + 1) : sp.iteration + 1;
+    }
+  } else if (!bad) {
     float* th = theta + size_t(b) * P;
     for (int s2 = tid; s2 < n; s2 += 256) {
       th[pb.enabledList[s2]] -= d0[s2];
@@ -1329,12 +1529,133 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
   }
 }
 
+// =============================================================================================
+// Kernel 4: the parameter update of an iteration when it needs trial evaluations of the error --
+// GaussNewtonSolverT::updateParameters with doLineSearch (momentum/solver/gauss_newton_solver.cpp:
+// 283-313: Armijo backtracking, c1 = 1e-3, tau = 0.5, <= 10 trial steps, the last trial stays) or the
+// LM gain-ratio schedule (the lambda form of TrustRegionQRT's radius rule, trust_region_qr.cpp:244-268;
+// same arithmetic as fusedSolveKernel phase K and the oracle's stepRule 1).  grid = B, block = 256.
+// A trial = SkeletonSolverFunctionT::getError (skeleton_solver_function.cpp:64-83): forward
+// kinematics without derivatives + the error of every block, rounded through float (:82).
+// =============================================================================================
+__global__ void __launch_bounds__(256) stepUpdateKernel(
+    RigDev rig,
+    ProblemDev pb,
+    float* __restrict__ theta, // [B][P] in/out
+    const float* __restrict__ jtr, // [B][n] (LM: predicted decrease)
+    const double* __restrict__ errIter, // [B] error at the theta the step was computed at
+    StepParams sp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ double red[4];
+  __shared__ float redF[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mark = sp.stepIter[b];
+  if (mark != sp.iteration + 1 && mark != -(sp.iteration + 1)) {
+    return; // the instance had converged before this iteration
+  }
+  float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
+  if (mark < 0) { // H was not positive definite: no step; the schedule raises the damping
+    if (sp.stepRule == MMX_STEP_LM_SCHEDULE && tid == 0) {
+      sp.lambdaPer[b] = fminf(lambda * sp.lmUp, sp.lmLambdaMax);
+    }
+    return;
+  }
+  const int P = rig.P, n = pb.n;
+  float* thL;
+  const SideLds sl = carveSideLds(smem, rig.J, &thL);
+  float* thT = thL + ((P + 3) & ~3);
+  float* th = theta + size_t(b) * P;
+  const float* dl = sp.delta + size_t(b) * n;
+  for (int i = tid; i < P; i += 256) {
+    thL[i] = th[i];
+  }
+  const double curError = errIter[b];
+  // every thread returns the error at thT
+  auto trialError = [&]() -> double {
+    sideFk(rig, sl, thT, tid, false);
+    double e = 0.0;
+    for (int u = tid; u < pb.U; u += 256) {
+      e += double(evalUnit(pb, sl.js, b, u).werr);
+    }
+    for (int g = tid; g < pb.G; g += 256) {
+      const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+      e += double(evalJointConstraint(k, sl.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(g - k.first)).werr);
+    }
+    if (pb.M > pb.rowsJoint) {
+      e += paramRowsError<false>(rig, pb, P, thT, b, tid);
+    }
+    e = waveReduceSum(e);
+    __syncthreads();
+    if (lane == 0) {
+      red[wave] = e;
+    }
+    __syncthreads();
+    return double(float((red[0] + red[1]) + (red[2] + red[3])));
+  };
+  auto makeTrial = [&](float scale) {
+    __syncthreads();
+    for (int i = tid; i < P; i += 256) {
+      thT[i] = thL[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += 256) {
+      thT[pb.enabledList[c]] -= scale * dl[c];
+    }
+    __syncthreads();
+  };
+  if (sp.stepRule == MMX_STEP_LM_SCHEDULE) {
+    float part = 0.f;
+    for (int c = tid; c < n; c += 256) {
+      part += dl[c] * jtr[size_t(b) * n + c] + lambda * dl[c] * dl[c];
+    }
+    part = waveReduceSumF(part);
+    if (lane == 0) {
+      redF[wave] = part;
+    }
+    __syncthreads();
+    const float predicted = float((double(redF[0]) + double(redF[1])) + (double(redF[2]) + double(redF[3]))); // d.g + lambda d.d
+    makeTrial(1.f);
+    const double eNew = trialError();
+    const float rho = predicted > 0.f ? float((curError - eNew) / double(predicted)) : -1.f;
+    if (rho > 0.f) {
+      for (int i = tid; i < P; i += 256) {
+        th[i] = thT[i];
+      }
+    }
+    if (tid == 0) {
+      if (!(rho >= 0.25f)) {
+        lambda = fminf(lambda * sp.lmUp, sp.lmLambdaMax);
+      } else if (rho > 0.75f) {
+        lambda = fmaxf(lambda * sp.lmDown, sp.lmLambdaMin);
+      }
+      sp.lambdaPer[b] = lambda;
+    }
+    return;
+  }
+  const float scaledError = 1e-3f * float(curError);
+  float scale = 1.f;
+  for (int ls = 0; ls < 10; ++ls) {
+    makeTrial(scale);
+    const double eNew = trialError();
+    if ((curError - eNew) >= double(scale * scaledError)) {
+      break;
+    }
+    scale *= 0.5f;
+  }
+  for (int i = tid; i < P; i += 256) {
+    th[i] = thT[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // small bookkeeping kernels
 // ---------------------------------------------------------------------------------------------
-__global__ void solveInitKernel(SolveStateDev st, int B) {
+__global__ void solveInitKernel(SolveStateDev st, int B, float* lambdaPer, float lambda0) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) {
+    if (lambdaPer != nullptr) {
+      lambdaPer[b] = lambda0;
+    }
     st.done[b] = 0;
     st.iterations[b] = 0;
     st.status[b] = 0;
@@ -1415,6 +1736,23 @@ hipError_t launchFkJacobian(
     }
   }
 #undef MMX_FKJ
+  if (pb.G > 0 && (jac != nullptr || res != nullptr || err != nullptr)) {
+    const size_t jl = jointBlocksLdsBytes(rig.J, rig.P, pb.G);
+    if (jl > 64 * 1024) {
+      hipError_t rc = hipFuncSetAttribute(
+          jac != nullptr ? reinterpret_cast<const void*>(jointBlocksKernel<true>) : reinterpret_cast<const void*>(jointBlocksKernel<false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize,
+          int(jl));
+      if (rc != hipSuccess) {
+        return rc;
+      }
+    }
+    if (jac != nullptr) {
+      hipLaunchKernelGGL(jointBlocksKernel<true>, dim3(pb.B), dim3(256), jl, stream, rig, pb, theta, jac, res, err, done);
+    } else {
+      hipLaunchKernelGGL(jointBlocksKernel<false>, dim3(pb.B), dim3(256), jl, stream, rig, pb, theta, jac, res, err, done);
+    }
+  }
   if (pb.M > pb.rowsJoint && (jac != nullptr || res != nullptr || err != nullptr)) {
     hipLaunchKernelGGL(
         parameterRowsKernel, dim3(pb.B), dim3(256), parameterRowsLdsBytes(rig.P, pb.NL), stream, rig, pb, rig.P, theta, jac, res, err, done);
@@ -1523,8 +1861,27 @@ hipError_t launchCholeskyStep(
   return hipGetLastError();
 }
 
-hipError_t launchSolveInit(const SolveStateDev& st, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(solveInitKernel, dim3((B + 255) / 256), dim3(256), 0, stream, st, B);
+hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream) {
+  hipLaunchKernelGGL(solveInitKernel, dim3((B + 255) / 256), dim3(256), 0, stream, st, B, lambdaPer, lambda0);
+  return hipGetLastError();
+}
+
+hipError_t launchStepUpdate(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    float* theta,
+    const float* jtr,
+    const double* errIter,
+    const StepParams& sp,
+    hipStream_t stream) {
+  const size_t lds = (sideFkLdsFloats(rig.J) + 2 * size_t((rig.P + 3) & ~3)) * sizeof(float);
+  if (lds > 64 * 1024) {
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(stepUpdateKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+  }
+  hipLaunchKernelGGL(stepUpdateKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, theta, jtr, errIter, sp);
   return hipGetLastError();
 }
 

@@ -27,6 +27,14 @@ struct StepParams {
   int32_t minIterations;
   int32_t maxIterations;
   int32_t refine; // 1 = one corrected-seminormal refinement step through J
+  // ---- line search / damping schedule of the explicit-Jacobian path: the Cholesky kernel leaves
+  // the step in `delta` and stepUpdateKernel applies it (all null / 0: theta -= delta in place)
+  float* delta; // [B][n] step of this iteration
+  int32_t* stepIter; // [B] iteration + 1 when `delta` holds a step, -(iteration + 1) when H was not positive definite
+  float* lambdaPer; // [B] per-instance damping (LM schedule) or null: `lambda` for everyone
+  int32_t doLineSearch; // GaussNewtonSolverOptions::doLineSearch
+  int32_t stepRule; // MMX_STEP_*
+  float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
 };
 
 // device view of mmx::FusedTables (mmx_host_tables.hpp)
@@ -126,7 +134,18 @@ hipError_t launchCholeskyStep(
     const StepParams& sp,
     hipStream_t stream);
 
-hipError_t launchSolveInit(const SolveStateDev& st, int B, hipStream_t stream);
+// applies the deferred step of the iteration: Armijo backtracking (GaussNewtonSolverT::updateParameters,
+// gauss_newton_solver.cpp:283-313) or the LM gain-ratio schedule (see fusedSolveKernel phase K)
+hipError_t launchStepUpdate(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    float* theta,
+    const float* jtr,
+    const double* errIter,
+    const StepParams& sp,
+    hipStream_t stream);
+
+hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream);
 hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream);
 
 } // namespace mmx

@@ -325,9 +325,30 @@ struct Loss {
 // constraints (momentum/character_solver/error_function_types.h:34-44,
 // position_error_function.h:16-29, orientation_error_function.h:16-36)
 // ---------------------------------------------------------------------------------------------
+// One further JointErrorFunctionT specialisation with its constraints (== mmx_joint_constraint_block
+// for one batch element); FuncDim / NumVec / NumPos per type as in the reference headers:
+// plane_error_function.h:47 (1,1,1), aim_error_function.h:44,83 (3,2,1),
+// fixed_axis_error_function.h:38,72,108 (3|1,1,0), normal_error_function.h:42 (1,2,1).
+template <class T>
+struct JointBlock {
+  int type = 0, count = 0;
+  const int32_t* parent = nullptr; // [count]
+  const float* localPoint = nullptr; // [count][3]
+  const float* localDir = nullptr; // [count][3]
+  const float* global = nullptr; // [count][3]
+  const float* planeD = nullptr; // [count]
+  const float* weight = nullptr; // [count]
+  float functionWeight = 1.f;
+  Loss<T> loss;
+  int funcDim() const {
+    return (type == MMX_JC_AIM_DIST || type == MMX_JC_AIM_DIR || type == MMX_JC_FIXED_AXIS_DIFF) ? 3 : 1;
+  }
+};
+
 template <class T>
 struct Constraints {
   int Kp = 0, Ko = 0;
+  std::vector<JointBlock<T>> blocks; // rows follow the orientation rows
   const int32_t* posParent = nullptr; // [Kp]
   const float* posOffset = nullptr; // [Kp][3]
   const float* posTarget = nullptr; // [Kp][3]
@@ -348,7 +369,11 @@ struct Constraints {
   const float* mpWeights = nullptr; // [P] targetWeights_
   float mpFunctionWeight = 0.f;
   int jointRows() const {
-    return 3 * Kp + 9 * Ko;
+    int r = 3 * Kp + 9 * Ko;
+    for (const JointBlock<T>& blk : blocks) {
+      r += blk.funcDim() * blk.count;
+    }
+    return r;
   }
   int rows() const {
     return jointRows() + NL + (mpTarget != nullptr ? P : 0);
@@ -432,6 +457,253 @@ template <class T>
 inline bool derivScaleIsZero(T s) {
   const T eps = std::is_same<T, float>::value ? T(1e-9) : T(1e-16);
   return std::fabs(s) <= eps;
+}
+
+// The same walk for an error function with general df/dv (joint_error_function-inl.h:228-294):
+// dfdv[k] is FuncDim x 3, row-major in a 3x3 buffer (rows >= FuncDim unused); a vector whose dfdv is
+// all zero is skipped (:236-238).
+template <class T>
+inline void ancestorWalkGeneral(
+    const Rig& rig,
+    const std::vector<JointState<T>>& st,
+    const uint8_t* active,
+    const uint8_t* enabled,
+    int parentJoint,
+    int funcDim,
+    int numVec,
+    int numPos,
+    const V3<T>* v,
+    const T (*dfdv)[9],
+    T derivScale,
+    int row,
+    T* jac,
+    int ld) {
+  bool zero[2] = {true, true};
+  for (int k = 0; k < numVec; ++k) {
+    for (int i = 0; i < 3 * funcDim; ++i) {
+      zero[k] = zero[k] && dfdv[k][i] == T(0);
+    }
+  }
+  int jnt = parentJoint;
+  while (jnt >= 0) {
+    const JointState<T>& js = st[jnt];
+    const int base = jnt * kParametersPerJoint;
+    for (int k = 0; k < numVec; ++k) {
+      if (zero[k]) {
+        continue;
+      }
+      const bool isPoint = k < numPos;
+      const V3<T> off = isPoint ? (v[k] - js.world.t) : v[k];
+      auto scatter = [&](int jp, const V3<T>& g) {
+        T jc[3];
+        for (int r = 0; r < funcDim; ++r) { // jc = derivScale * dfdv * g
+          jc[r] = (derivScale * dfdv[k][3 * r]) * g.x + (derivScale * dfdv[k][3 * r + 1]) * g.y + (derivScale * dfdv[k][3 * r + 2]) * g.z;
+        }
+        for (int idx = rig.outer[jp]; idx < rig.outer[jp + 1]; ++idx) {
+          const int col = rig.inner[idx];
+          if (enabled[col]) {
+            const T w = T(rig.value[idx]);
+            T* c = jac + size_t(col) * ld + row;
+            for (int r = 0; r < funcDim; ++r) {
+              c[r] += jc[r] * w;
+            }
+          }
+        }
+      };
+      if (isPoint) {
+        for (int d = 0; d < 3; ++d) {
+          if (active[base + d]) {
+            scatter(base + d, js.translationAxis.col(d));
+          }
+        }
+      }
+      for (int d = 0; d < 3; ++d) {
+        if (active[base + 3 + d]) {
+          scatter(base + 3 + d, cross(js.rotationAxis.col(d), off));
+        }
+      }
+      if (isPoint && active[base + 6]) {
+        scatter(base + 6, ln2<T>() * off);
+      }
+    }
+    jnt = rig.parent[jnt];
+  }
+}
+
+template <class T>
+inline V3<T> v3normalized(const V3<T>& a) { // Eigen normalized(): unchanged when the norm is zero
+  const T n2 = dot(a, a);
+  return n2 > T(0) ? (T(1) / std::sqrt(n2)) * a : a;
+}
+
+// evalFunction of the block's error function for constraint c: fills f[FuncDim], v[NumVec] and
+// dfdv[NumVec] (row-major FuncDim x 3 in a 9 buffer); returns {NumVec, NumPos} through the out args.
+template <class T>
+inline void evalJointBlockFunction(
+    const JointBlock<T>& blk,
+    int c,
+    const JointState<T>& js,
+    T* f,
+    V3<T>* v,
+    T (*dfdv)[9],
+    int& numVec,
+    int& numPos) {
+  auto vec = [&](const float* a) { return V3<T>{T(a[3 * c]), T(a[3 * c + 1]), T(a[3 * c + 2])}; };
+  for (int k = 0; k < 2; ++k) {
+    for (int i = 0; i < 9; ++i) {
+      dfdv[k][i] = T(0);
+    }
+  }
+  f[0] = f[1] = f[2] = T(0);
+  auto setIdentity = [](T* m, T s) { m[0] = m[4] = m[8] = s; };
+  auto addOuter = [](T* m, const V3<T>& a, const V3<T>& b, T s) { // m += s * a b^T
+    const T av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+    for (int r = 0; r < 3; ++r) {
+      for (int q = 0; q < 3; ++q) {
+        m[3 * r + q] += s * av[r] * bv[q];
+      }
+    }
+  };
+  auto setRow = [](T* m, const V3<T>& a, T s) { m[0] = s * a.x, m[1] = s * a.y, m[2] = s * a.z; };
+  switch (blk.type) {
+    case MMX_JC_PLANE:
+    case MMX_JC_HALF_PLANE: { // plane_error_function.cpp:52-71
+      const V3<T> n = v3normalized(vec(blk.global)); // PlaneDataT ctor, plane_error_function.h:30
+      numVec = 1, numPos = 1;
+      v[0] = xpoint(js.world, vec(blk.localPoint));
+      T val = dot(v[0], n) - T(blk.planeD[c]);
+      const bool half = blk.type == MMX_JC_HALF_PLANE;
+      if (half && val > T(0)) {
+        val = T(0);
+      }
+      f[0] = val;
+      if (!half || val < T(0)) {
+        setRow(dfdv[0], n, T(1));
+      }
+      break;
+    }
+    case MMX_JC_AIM_DIST: { // aim_error_function.cpp:15-36
+      numVec = 2, numPos = 1;
+      v[0] = xpoint(js.world, vec(blk.localPoint));
+      v[1] = qrot(js.world.q, v3normalized(vec(blk.localDir))); // AimDataT ctor, aim_error_function.h:34
+      const V3<T> tgt = vec(blk.global) - v[0];
+      const T proj = dot(v[1], tgt);
+      const V3<T> r = proj * v[1] - tgt;
+      f[0] = r.x, f[1] = r.y, f[2] = r.z;
+      setIdentity(dfdv[0], T(1));
+      addOuter(dfdv[0], v[1], v[1], T(-1));
+      addOuter(dfdv[1], v[1], tgt, T(1));
+      dfdv[1][0] += proj, dfdv[1][4] += proj, dfdv[1][8] += proj;
+      break;
+    }
+    case MMX_JC_AIM_DIR: { // aim_error_function.cpp:39-67
+      numVec = 2, numPos = 1;
+      v[0] = xpoint(js.world, vec(blk.localPoint));
+      v[1] = qrot(js.world.q, v3normalized(vec(blk.localDir)));
+      const V3<T> tgt = vec(blk.global) - v[0];
+      const T nrm = std::sqrt(dot(tgt, tgt));
+      V3<T> dir{T(0), T(0), T(0)};
+      if (nrm > T(1e-16)) {
+        dir = (T(1) / nrm) * tgt;
+      }
+      const V3<T> r = v[1] - dir;
+      f[0] = r.x, f[1] = r.y, f[2] = r.z;
+      if (nrm > T(1e-16)) {
+        addOuter(dfdv[0], dir, dir, T(-1) / nrm);
+        dfdv[0][0] += T(1) / nrm, dfdv[0][4] += T(1) / nrm, dfdv[0][8] += T(1) / nrm;
+      }
+      setIdentity(dfdv[1], T(1));
+      break;
+    }
+    case MMX_JC_FIXED_AXIS_DIFF:
+    case MMX_JC_FIXED_AXIS_COS:
+    case MMX_JC_FIXED_AXIS_ANGLE: { // fixed_axis_error_function.cpp:15-66 ; ctor fixed_axis_error_function.h:29-30
+      numVec = 1, numPos = 0;
+      const V3<T> ga = v3normalized(vec(blk.global));
+      v[0] = qrot(js.world.q, v3normalized(vec(blk.localDir)));
+      if (blk.type == MMX_JC_FIXED_AXIS_DIFF) {
+        const V3<T> r = v[0] - ga;
+        f[0] = r.x, f[1] = r.y, f[2] = r.z;
+        setIdentity(dfdv[0], T(1));
+      } else if (blk.type == MMX_JC_FIXED_AXIS_COS) {
+        f[0] = T(1) - dot(v[0], ga);
+        setRow(dfdv[0], ga, T(-1));
+      } else {
+        const T d = dot(v[0], ga);
+        f[0] = std::acos(std::min(std::max(d, T(-1)), T(1)));
+        const T sine = std::sqrt(T(1) - d * d);
+        if (sine > T(1e-9)) {
+          setRow(dfdv[0], ga, T(-1) / sine);
+        }
+      }
+      break;
+    }
+    default: { // MMX_JC_NORMAL, normal_error_function.cpp:14-31 ; ctor normal_error_function.h:34
+      numVec = 2, numPos = 1;
+      v[0] = xpoint(js.world, vec(blk.localPoint));
+      v[1] = qrot(js.world.q, v3normalized(vec(blk.localDir)));
+      const V3<T> dist = v[0] - vec(blk.global);
+      f[0] = dot(v[1], dist);
+      setRow(dfdv[0], v[1], T(1));
+      setRow(dfdv[1], dist, T(1));
+      break;
+    }
+  }
+}
+
+// JointErrorFunctionT::getJacobian / getError (joint_error_function-inl.h:35-54,179-297) for the
+// further blocks; rows start at rowBase (after the orientation rows).
+template <class T>
+inline double evalJointBlocks(
+    const Rig& rig,
+    const std::vector<JointState<T>>& st,
+    const Constraints<T>& cs,
+    const uint8_t* active,
+    const uint8_t* enabled,
+    T* jac,
+    T* res) {
+  const int M = cs.rows();
+  double total = 0.0;
+  int rowBase = 3 * cs.Kp + 9 * cs.Ko;
+  for (const JointBlock<T>& blk : cs.blocks) {
+    const int fd = blk.funcDim();
+    if (blk.functionWeight > 0.f) {
+      double error = 0.0;
+      for (int c = 0; c < blk.count; ++c) {
+        const T cw = T(blk.weight[c]);
+        if (cw == T(0)) {
+          continue;
+        }
+        T f[3];
+        V3<T> v[2];
+        T dfdv[2][9];
+        int numVec = 0, numPos = 0;
+        evalJointBlockFunction<T>(blk, c, st[blk.parent[c]], f, v, dfdv, numVec, numPos);
+        T sqr = T(0);
+        for (int r = 0; r < fd; ++r) {
+          sqr += f[r] * f[r];
+        }
+        if (jac == nullptr) {
+          error += double(cw * blk.loss.value(sqr));
+          continue;
+        }
+        const T w = cw * T(blk.functionWeight);
+        error += double(w * blk.loss.value(sqr));
+        const T derivScale = std::sqrt(w * blk.loss.deriv(sqr));
+        const int row = rowBase + fd * c;
+        for (int r = 0; r < fd; ++r) {
+          res[row + r] = derivScale * f[r];
+        }
+        if (derivScaleIsZero(derivScale)) {
+          continue;
+        }
+        ancestorWalkGeneral<T>(rig, st, active, enabled, blk.parent[c], fd, numVec, numPos, v, dfdv, derivScale, row, jac, M);
+      }
+      total += (jac == nullptr) ? double(blk.functionWeight) * error : error;
+    }
+    rowBase += fd * blk.count;
+  }
+  return total;
 }
 
 // PositionErrorFunctionT::evalFunction (position_error_function.cpp:15-27) +
@@ -747,6 +1019,7 @@ struct SolverFunction {
     applyParameterTransform<T>(rig, theta, jp.data());
     setSkeletonState<T>(rig, jp.data(), state);
     double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
+    e += evalJointBlocks<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
     e += evalParameterRows<T>(rig, cs, theta, jp.data(), active.data(), enabled.data(), nullptr, nullptr);
     return double(float(e));
   }
@@ -760,6 +1033,7 @@ struct SolverFunction {
     std::fill(jac, jac + size_t(M) * rig.P, T(0));
     std::fill(res, res + M, T(0));
     double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
+    e += evalJointBlocks<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
     e += evalParameterRows<T>(rig, cs, theta, jp.data(), active.data(), enabled.data(), jac, res);
     return e;
   }

@@ -61,6 +61,24 @@ Constraints<T> makeConstraints(
   if (c->ori_loss_c > 0.f) {
     cs.oriLoss = Loss<T>(c->ori_loss_alpha == MMX_LOSS_WELSCH ? std::numeric_limits<T>::lowest() : T(c->ori_loss_alpha), T(c->ori_loss_c));
   }
+  for (int32_t i = 0; i < c->num_joint_blocks; ++i) {
+    const mmx_joint_constraint_block& jb = c->joint_blocks[i];
+    JointBlock<T> blk;
+    blk.type = jb.type;
+    blk.count = jb.count;
+    blk.parent = jb.parent;
+    const size_t o = b * size_t(jb.count);
+    blk.localPoint = jb.local_point ? jb.local_point + 3 * o : nullptr;
+    blk.localDir = jb.local_dir ? jb.local_dir + 3 * o : nullptr;
+    blk.global = jb.global ? jb.global + 3 * o : nullptr;
+    blk.planeD = jb.plane_d ? jb.plane_d + o : nullptr;
+    blk.weight = jb.weight + o;
+    blk.functionWeight = jb.function_weight;
+    if (jb.loss_c > 0.f) {
+      blk.loss = Loss<T>(jb.loss_alpha == MMX_LOSS_WELSCH ? std::numeric_limits<T>::lowest() : T(jb.loss_alpha), T(jb.loss_c));
+    }
+    cs.blocks.push_back(blk);
+  }
   cs.P = P;
   cs.NL = c->num_limits;
   cs.limits = c->limits;

@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from momentum_amd._abi import ConstraintData, GnOptions, MMX_MEM_HOST, as_ptr, limit_array, void_p
+from momentum_amd._abi import ConstraintData, GnOptions, MMX_MEM_HOST, as_ptr, joint_block_array, limit_array, void_p
 from momentum_amd.rigs import Rig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -70,6 +70,7 @@ class Constraints:
         model_function_weight: float = 1.0,
         pos_loss=(2.0, 1.0),
         ori_loss=(2.0, 1.0),
+        joint_blocks=None,
     ):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         self.pos_parent = np.ascontiguousarray(pos_parent, dtype=np.int32).reshape(-1)
@@ -90,6 +91,7 @@ class Constraints:
         self.model_function_weight = float(model_function_weight)
         self.pos_loss = (float(pos_loss[0]), float(pos_loss[1]))  # GeneralizedLoss (alpha, c)
         self.ori_loss = (float(ori_loss[0]), float(ori_loss[1]))
+        self.joint_blocks = list(joint_blocks) if joint_blocks else []  # momentum_amd._abi.JointBlock
 
     @property
     def P(self) -> int:
@@ -97,9 +99,11 @@ class Constraints:
 
     @property
     def rows(self) -> int:
-        return 3 * self.Kp + 9 * self.Ko + len(self.limits) + self.P
+        return 3 * self.Kp + 9 * self.Ko + sum(b.rows for b in self.joint_blocks) + len(self.limits) + self.P
 
     def data(self) -> ConstraintData:
+        self._keep = []
+        self._block_array = joint_block_array(self.joint_blocks, self._keep)
         return ConstraintData(
             void_p(self.pos_offset if self.Kp else None),
             void_p(self.pos_target if self.Kp else None),
@@ -120,6 +124,8 @@ class Constraints:
             self.pos_loss[1],
             self.ori_loss[0],
             self.ori_loss[1],
+            len(self.joint_blocks),
+            C.cast(self._block_array, C.c_void_p) if self.joint_blocks else None,
         )
 
     def instance(self, b: int) -> "Constraints":
@@ -142,6 +148,7 @@ class Constraints:
             self.model_function_weight,
             self.pos_loss,
             self.ori_loss,
+            [blk.instance(b) for blk in self.joint_blocks],
         )
 
 

@@ -204,14 +204,17 @@ def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
 
 
+@pytest.mark.parametrize("path", ["fused", "three_kernel"])
 @pytest.mark.parametrize("mode", ["line_search", "lm_schedule"])
-def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode):
+def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, monkeypatch):
     """GaussNewtonSolverT with doLineSearch (gauss_newton_solver.cpp:283-313) and the LM gain-ratio
     schedule of BASELINE configs[2] (the lambda form of trust_region_qr.cpp:244-268; no direct
     reference implementation, so parity is against the build's own oracle restatement)."""
     from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
 
     torch = torch_cuda
+    if path == "three_kernel":  # explicit J -> J^T J -> Cholesky step -> stepUpdateKernel
+        monkeypatch.setenv("MMX_SOLVER", "v1")
     rig, pp, op, B = _case("humanoid72_cfg2")
     cons, th0, ths = make_problem(rig, pp, op, B, seed=4242, perturb=0.3)
     rh, pb = _gpu_problem(torch, rig, cons, B)
@@ -334,6 +337,13 @@ def test_large_rig_config5_solve_matches_oracle(torch_cuda, orc):
     assert np.all(rel <= tol), (rel, tol)
     assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
     assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    # the driver's default doLineSearch on the large system: Cholesky step in HBM + stepUpdateKernel
+    opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=True)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    rel = np.linalg.norm(out["theta"].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert np.all(rel <= np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))), rel
+    assert np.abs(out["error_history"].cpu().numpy() - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
 
 
 def test_config3_full_size_lm_schedule_properties(torch_cuda, orc):
