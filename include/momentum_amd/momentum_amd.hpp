@@ -121,7 +121,13 @@ struct PositionData {
 
 // momentum::ParameterLimit restricted to the limit types that act on model parameters
 // (momentum/character/parameter_limits.h:20-31,33-99,125-136)
-enum LimitType { MinMax = MMX_LIMIT_MINMAX, Linear = MMX_LIMIT_LINEAR, HalfPlane = MMX_LIMIT_HALFPLANE };
+enum LimitType {
+  MinMax = MMX_LIMIT_MINMAX,
+  MinMaxJoint = MMX_LIMIT_MINMAX_JOINT, // index0 = 7 * jointIndex + jointParameter
+  Linear = MMX_LIMIT_LINEAR,
+  LinearJoint = MMX_LIMIT_LINEAR_JOINT,
+  HalfPlane = MMX_LIMIT_HALFPLANE
+};
 struct ParameterLimit {
   LimitType type = MinMax;
   float weight = 1.f;
@@ -215,6 +221,47 @@ class DeviceCharacter {
  private:
   std::shared_ptr<mmx_rig> handle_;
   size_t numJoints_ = 0, numParams_ = 0;
+};
+
+// Constraint data of the further JointErrorFunction specialisations; vectors are normalised where
+// the reference's constructors do (plane_error_function.h:16-31, aim_error_function.h:17-37,
+// fixed_axis_error_function.h:17-31, normal_error_function.h:17-36).
+struct PlaneData {
+  Vector3f offset{0.f, 0.f, 0.f};
+  Vector3f normal{0.f, 1.f, 0.f};
+  float d = 0.f;
+  size_t parent = 0;
+  float weight = 1.f;
+};
+struct AimData {
+  Vector3f localPoint{0.f, 0.f, 0.f};
+  Vector3f localDir{0.f, 0.f, 1.f};
+  Vector3f globalTarget{0.f, 0.f, 0.f};
+  size_t parent = 0;
+  float weight = 1.f;
+};
+struct FixedAxisData {
+  Vector3f localAxis{0.f, 0.f, 1.f};
+  Vector3f globalAxis{0.f, 0.f, 1.f};
+  size_t parent = 0;
+  float weight = 1.f;
+};
+struct NormalData {
+  Vector3f localPoint{0.f, 0.f, 0.f};
+  Vector3f localNormal{0.f, 0.f, 1.f};
+  Vector3f globalPoint{0.f, 0.f, 0.f};
+  size_t parent = 0;
+  float weight = 1.f;
+};
+enum class JointErrorFunctionType {
+  Plane = MMX_JC_PLANE, // PlaneErrorFunction(above = false)
+  HalfPlane = MMX_JC_HALF_PLANE, // PlaneErrorFunction(above = true)
+  AimDist = MMX_JC_AIM_DIST,
+  AimDir = MMX_JC_AIM_DIR,
+  FixedAxisDiff = MMX_JC_FIXED_AXIS_DIFF,
+  FixedAxisCos = MMX_JC_FIXED_AXIS_COS,
+  FixedAxisAngle = MMX_JC_FIXED_AXIS_ANGLE,
+  Normal = MMX_JC_NORMAL
 };
 
 // One SkeletonSolverFunction + PositionErrorFunction + OrientationErrorFunction per batch element.
@@ -324,6 +371,54 @@ class BatchedSkeletonSolverFunction {
     lossOri_[0] = orientationAlpha, lossOri_[1] = orientationC;
     dirty_ = true;
   }
+  // SkeletonSolverFunction::addErrorFunction for one of the further joint error functions
+  // (Plane / Aim / FixedAxis / Normal); parents are shared by the batch.  Returns the block's index.
+  size_t addJointErrorFunction(JointErrorFunctionType type, const std::vector<size_t>& parents, float lossAlpha = 2.f, float lossC = 1.f) {
+    if (blocks_.size() >= MMX_MAX_JOINT_BLOCKS) {
+      throw std::runtime_error("momentum_amd: too many joint error functions");
+    }
+    Block k;
+    k.type = int32_t(type);
+    k.parent.assign(parents.begin(), parents.end());
+    const size_t cnt = batch_ * parents.size();
+    k.localPoint.assign(3 * cnt, 0.f);
+    k.localDir.assign(3 * cnt, 0.f);
+    k.global.assign(3 * cnt, 0.f);
+    k.planeD.assign(cnt, 0.f);
+    k.weight.assign(cnt, 0.f); // constraints not set yet carry weight 0 (skipped, joint_error_function-inl.h:197-199)
+    k.loss[0] = lossAlpha, k.loss[1] = lossC;
+    blocks_.push_back(std::move(k));
+    dirty_ = true;
+    return blocks_.size() - 1;
+  }
+  void setWeight(size_t block, float weight) { // SkeletonErrorFunction::setWeight of that error function
+    blockAt(block).fw = weight;
+    dirty_ = true;
+  }
+  void setConstraints(size_t block, size_t b, const std::vector<PlaneData>& c) {
+    Block& k = expect(block, b, c.size(), MMX_JC_PLANE, MMX_JC_HALF_PLANE);
+    for (size_t i = 0; i < c.size(); ++i) {
+      put(k, b, i, c[i].offset.data(), nullptr, c[i].normal.data(), c[i].d, c[i].weight);
+    }
+  }
+  void setConstraints(size_t block, size_t b, const std::vector<AimData>& c) {
+    Block& k = expect(block, b, c.size(), MMX_JC_AIM_DIST, MMX_JC_AIM_DIR);
+    for (size_t i = 0; i < c.size(); ++i) {
+      put(k, b, i, c[i].localPoint.data(), c[i].localDir.data(), c[i].globalTarget.data(), 0.f, c[i].weight);
+    }
+  }
+  void setConstraints(size_t block, size_t b, const std::vector<FixedAxisData>& c) {
+    Block& k = expect(block, b, c.size(), MMX_JC_FIXED_AXIS_DIFF, MMX_JC_FIXED_AXIS_ANGLE);
+    for (size_t i = 0; i < c.size(); ++i) {
+      put(k, b, i, nullptr, c[i].localAxis.data(), c[i].globalAxis.data(), 0.f, c[i].weight);
+    }
+  }
+  void setConstraints(size_t block, size_t b, const std::vector<NormalData>& c) {
+    Block& k = expect(block, b, c.size(), MMX_JC_NORMAL, MMX_JC_NORMAL);
+    for (size_t i = 0; i < c.size(); ++i) {
+      put(k, b, i, c[i].localPoint.data(), c[i].localNormal.data(), c[i].globalPoint.data(), 0.f, c[i].weight);
+    }
+  }
   void setEnabledParameters(const ParameterSet& ps) {
     std::vector<uint8_t> e(character_.numParameters(), 0);
     for (size_t i = 0; i < e.size() && i < ps.size(); ++i) {
@@ -354,6 +449,22 @@ class BatchedSkeletonSolverFunction {
     d.model_function_weight = wModel_;
     d.pos_loss_alpha = lossPos_[0], d.pos_loss_c = lossPos_[1];
     d.ori_loss_alpha = lossOri_[0], d.ori_loss_c = lossOri_[1];
+    std::vector<mmx_joint_constraint_block> jb(blocks_.size());
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+      const Block& k = blocks_[i];
+      jb[i].type = k.type;
+      jb[i].count = int32_t(k.parent.size());
+      jb[i].parent = k.parent.data();
+      jb[i].local_point = k.localPoint.data();
+      jb[i].local_dir = k.localDir.data();
+      jb[i].global = k.global.data();
+      jb[i].plane_d = k.planeD.data();
+      jb[i].weight = k.weight.data();
+      jb[i].function_weight = k.fw;
+      jb[i].loss_alpha = k.loss[0], jb[i].loss_c = k.loss[1];
+    }
+    d.num_joint_blocks = int32_t(jb.size());
+    d.joint_blocks = jb.empty() ? nullptr : jb.data();
     check(mmx_problem_set_constraints(handle_.get(), &d, nullptr));
     dirty_ = false;
   }
@@ -374,6 +485,38 @@ class BatchedSkeletonSolverFunction {
   }
 
  private:
+  struct Block {
+    int32_t type = 0;
+    std::vector<int32_t> parent;
+    std::vector<float> localPoint, localDir, global, planeD, weight;
+    float fw = 1.f;
+    float loss[2] = {2.f, 1.f};
+  };
+  Block& blockAt(size_t block) {
+    if (block >= blocks_.size()) {
+      throw std::runtime_error("momentum_amd: joint error function index out of range");
+    }
+    return blocks_[block];
+  }
+  Block& expect(size_t block, size_t b, size_t count, int32_t typeLo, int32_t typeHi) {
+    Block& k = blockAt(block);
+    if (b >= batch_ || count != k.parent.size() || k.type < typeLo || k.type > typeHi) {
+      throw std::runtime_error("momentum_amd: constraint data does not match the joint error function (type / count / batch index)");
+    }
+    dirty_ = true;
+    return k;
+  }
+  void put(Block& k, size_t b, size_t i, const float* lp, const float* ld, const float* gl, float d, float w) {
+    const size_t c = b * k.parent.size() + i;
+    for (int q = 0; q < 3; ++q) {
+      k.localPoint[3 * c + q] = lp != nullptr ? lp[q] : 0.f;
+      k.localDir[3 * c + q] = ld != nullptr ? ld[q] : 0.f;
+      k.global[3 * c + q] = gl[q];
+    }
+    k.planeD[c] = d;
+    k.weight[c] = w;
+  }
+  std::vector<Block> blocks_;
   const DeviceCharacter& character_; // non-owning, like the reference (:87-88)
   size_t batch_, kp_, ko_;
   std::shared_ptr<mmx_problem> handle_;

@@ -113,6 +113,53 @@ int main() {
       }
     }
   }
+  // a further joint error function: half-plane "floor" constraints y >= 2 on joints 3 and 10 of the
+  // chain (PlaneErrorFunction(above = true)) + a fixed-axis constraint; the solve must lift both joints
+  // to the plane and the error of the block must vanish
+  {
+    BatchedSkeletonSolverFunction fn2(dev, B, {23}, {});
+    const size_t floor = fn2.addJointErrorFunction(JointErrorFunctionType::HalfPlane, {3, 10});
+    const size_t axis = fn2.addJointErrorFunction(JointErrorFunctionType::FixedAxisDiff, {12});
+    fn2.setWeight(axis, 0.5f);
+    for (size_t b = 0; b < B; ++b) {
+      std::vector<PositionData> pc(1);
+      pc[0].parent = 23;
+      pc[0].target = {0.f, 25.f, 0.f};
+      pc[0].weight = 1e-3f;
+      fn2.setPositionConstraints(b, pc);
+      std::vector<PlaneData> fl(2);
+      fl[0].parent = 3, fl[1].parent = 10;
+      fl[0].normal = fl[1].normal = {0.f, 2.f, 0.f}; // normalised on ingest
+      fl[0].d = 5.f, fl[1].d = 12.f;
+      fn2.setConstraints(floor, b, fl);
+      std::vector<FixedAxisData> fa(1);
+      fa[0].parent = 12;
+      fa[0].localAxis = {0.f, 1.f, 0.f};
+      fa[0].globalAxis = {0.f, 1.f, 0.f};
+      fn2.setConstraints(axis, b, fa);
+    }
+    BatchedGaussNewtonSolver solver2(opt, &fn2);
+    std::vector<float> th3(B * P, 0.f);
+    std::vector<double> e2;
+    fn2.getJacobian(th3, jac, res, e2);
+    if (jac.size() != B * (3 + 2 + 3) * P) {
+      ++bad;
+    }
+    const std::vector<double> e3 = solver2.solve(th3);
+    std::printf("floor constraints: error %.4g -> %.4g\n", e2[0], e3[0]);
+    if (!(e2[0] > 1.0) || !(e3[0] < 1e-2 * e2[0])) {
+      ++bad;
+    }
+    bool threw2 = false;
+    try {
+      fn2.setConstraints(floor, 0, std::vector<AimData>(2)); // wrong data type for the block
+    } catch (const std::runtime_error&) {
+      threw2 = true;
+    }
+    if (!threw2) {
+      ++bad;
+    }
+  }
   std::printf(bad == 0 ? "OK\n" : "FAIL\n");
   return bad == 0 ? 0 : 1;
 }

@@ -30,9 +30,37 @@ def limits_to_array(limits):
     return np.array([[l.type, l.index0, l.index1, l.weight, *list(l.v)] for l in limits], dtype=np.float64).reshape(-1, 8)
 
 
-def dump(name, rig, pos_parent, ori_parent, batch, seed, perturb, extras=False):
+def blocks_to_dict(blocks):
+    """flat npz entries jb<i>_<field> of a list of _abi.JointBlock"""
+    out = {"num_joint_blocks": np.int64(len(blocks))}
+    for i, b in enumerate(blocks):
+        out[f"jb{i}_type"] = np.int64(b.type)
+        out[f"jb{i}_parent"] = b.parent
+        out[f"jb{i}_fw_loss"] = np.array([b.function_weight, b.loss[0], b.loss[1]], np.float64)
+        for f in ("weight", "global_", "local_point", "local_dir", "plane_d"):
+            a = getattr(b, f)
+            if a is not None:
+                out[f"jb{i}_{f}"] = np.asarray(a, np.float32)
+    return out
+
+
+def dump(name, rig, pos_parent, ori_parent, batch, seed, perturb, extras=False, joint_blocks=False):
     cons, th0, ths = make_problem(rig, pos_parent, ori_parent, batch, seed=seed, perturb=perturb)
     extra = {}
+    if joint_blocks:
+        # one block of every further JointErrorFunction specialisation (SURVEY 8f rank 3)
+        from tests.test_oracle_joint_blocks import TYPES, make_block
+
+        rng = np.random.default_rng(seed + 5)
+        blocks = []
+        for i, ty in enumerate(TYPES.values()):
+            loss = (0.0, 0.5) if i == 2 else (2.0, 1.0)
+            blocks.append(make_block(ty, rng.choice(rig.num_joints, size=3), rng, weight=1.0, batch=batch, function_weight=0.5 + 0.1 * i, loss=loss))
+        cons = orc.Constraints(
+            cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset, cons.ori_target, cons.ori_weight,
+            joint_blocks=blocks,
+        )  # fmt: skip
+        extra = blocks_to_dict(blocks)
     if extras:
         # parameter limits, a model-parameter prior and a Cauchy loss on the position block
         from momentum_amd._abi import ParameterLimit
@@ -78,3 +106,5 @@ if __name__ == "__main__":
     dump("cfg2_humanoid72.npz", rig, lm, lm, 4, 12345, 0.3)
     # the same with parameter limits, a model-parameter prior and a robust loss
     dump("cfg2_limits_prior_cauchy.npz", rig, lm, lm, 4, 4321, 0.3, extras=True)
+    # the same with Plane / HalfPlane / Aim / FixedAxis / Normal constraint blocks (explicit-Jacobian path)
+    dump("cfg2_joint_blocks.npz", rig, lm, lm, 4, 2468, 0.3, joint_blocks=True)

@@ -14,12 +14,23 @@ CASES = {
     "cfg1_chain24.npz": lambda: make_test_character(24),
     "cfg2_humanoid72.npz": lambda: make_humanoid72(seed=12345, variant="p128", unit=0.01),
     "cfg2_limits_prior_cauchy.npz": lambda: make_humanoid72(seed=12345, variant="p128", unit=0.01),
+    "cfg2_joint_blocks.npz": lambda: make_humanoid72(seed=12345, variant="p128", unit=0.01),
 }
 OPT = dict(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
 
 
 def _extras(g):
     """keyword arguments of the optional blocks stored in a fixture (limits, model prior, losses)"""
+    if "num_joint_blocks" in g.files:
+        from momentum_amd._abi import JointBlock
+
+        blocks = []
+        for i in range(int(g["num_joint_blocks"])):
+            opt = lambda f: g[f"jb{i}_{f}"] if f"jb{i}_{f}" in g.files else None
+            fw, la, lc = g[f"jb{i}_fw_loss"]
+            blocks.append(JointBlock(int(g[f"jb{i}_type"]), g[f"jb{i}_parent"], opt("weight"), opt("global_"), opt("local_point"),
+                                     opt("local_dir"), opt("plane_d"), float(fw), (float(la), float(lc))))  # fmt: skip
+        return dict(joint_blocks=blocks)
     if "limits" not in g.files:
         return {}
     from momentum_amd._abi import ParameterLimit
@@ -70,8 +81,14 @@ def test_hip_path_matches_fixture(orc, name):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
     Kp, Ko = len(g["pos_parent"]), len(g["ori_parent"])
     ex = _extras(g)
-    if ex:
+    if "model_target" in ex:
         ex["model_target"], ex["model_weights"] = t(ex["model_target"]), t(ex["model_weights"])
+    if "joint_blocks" in ex:
+        from momentum_amd._abi import JointBlock
+
+        d = lambda a: None if a is None else t(a)
+        ex["joint_blocks"] = [JointBlock(k.type, k.parent, d(k.weight), d(k.global_), d(k.local_point), d(k.local_dir), d(k.plane_d),
+                                         k.function_weight, k.loss) for k in ex["joint_blocks"]]  # fmt: skip
     pb.set_constraints(t(g["pos_offset"]).reshape(B, Kp, 3), t(g["pos_target"]).reshape(B, Kp, 3), t(g["pos_weight"]).reshape(B, Kp),
                        t(g["ori_offset"]).reshape(B, Ko, 4), t(g["ori_target"]).reshape(B, Ko, 4), t(g["ori_weight"]).reshape(B, Ko), **ex)  # fmt: skip
     # world transforms at theta*
@@ -87,6 +104,11 @@ def test_hip_path_matches_fixture(orc, name):
     th = out["theta"].cpu().numpy()
     rel = np.linalg.norm(th - g["theta_final"], axis=1) / np.linalg.norm(g["theta_final"], axis=1)
     tol = 1e-5 if name.startswith("cfg2") else 5e-5  # the chain fixture is ill-conditioned (tests/test_gpu_parity.py)
+    if "joint_blocks" in name:
+        # large-residual problem (final error 2..4.6: planes / aims that cannot all be met), so the
+        # solution moves with dJ^T r and the fp32 storage of the dense J bounds parity: the oracle's
+        # own float instantiation is 2e-5..9e-5 from its double one on this fixture
+        tol = 1e-4
     assert rel.max() <= tol, rel
     assert np.array_equal(out["iterations"].cpu().numpy(), g["iterations"])
     h = out["error_history"].cpu().numpy()
