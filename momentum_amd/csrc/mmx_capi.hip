@@ -139,6 +139,9 @@ struct mmx_problem {
   int32_t genRows = 0;
   bool haveConstraints = false;
   mmx::ProblemDev dev{};
+  // the same problem with the structurally zero columns dropped from the solve (explicit-Jacobian solver)
+  int32_t solveN = 0;
+  DevBuf dSolveListV1; // [solveN]
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
@@ -537,6 +540,57 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       fd.pairLim = pb->dPairLim.as<int32_t>();
     }
   }
+  // Solve list of the explicit-Jacobian solver: an enabled parameter none of whose joint-parameter
+  // rows has a constraint below it has a zero column in J, so its step is 0 (H_pp = lambda, g_p = 0)
+  // and it can leave the dense system -- exactly, like the fused kernel's solve list.  Parameters
+  // touched by a limit or the model-parameter prior stay.  (Integer bookkeeping on the host.)
+  {
+    const size_t J = size_t(rig->J);
+    std::vector<uint8_t> anyBelow(J, 0), pointBelow(J, 0); // a constraint vector / a constraint POINT in the joint's subtree
+    auto mark = [&](int32_t joint, bool point) {
+      for (int32_t a = joint; a >= 0; a = rig->parent[size_t(a)]) {
+        anyBelow[size_t(a)] = 1;
+        if (point) {
+          pointBelow[size_t(a)] = 1;
+        }
+      }
+    };
+    for (int32_t c = 0; c < pb->Kp; ++c) {
+      mark(pb->posParent[size_t(c)], true);
+    }
+    for (int32_t c = 0; c < pb->Ko; ++c) {
+      mark(pb->oriParent[size_t(c)], false);
+    }
+    for (const auto& h : pb->blocks) {
+      const bool fixedAxis = h->type == MMX_JC_FIXED_AXIS_DIFF || h->type == MMX_JC_FIXED_AXIS_COS || h->type == MMX_JC_FIXED_AXIS_ANGLE;
+      for (int32_t j : h->parent) {
+        mark(j, !fixedAxis);
+      }
+    }
+    std::vector<uint8_t> keep(size_t(rig->P), pb->dev.hasModel ? 1 : 0);
+    for (const mmx_parameter_limit& lm : pb->limits) {
+      for (int32_t p : limitParameters(rig, lm)) {
+        keep[size_t(p)] = 1;
+      }
+    }
+    std::vector<int32_t> list;
+    for (int32_t p : t.enabledList) {
+      bool nz = keep[size_t(p)] != 0;
+      for (int32_t e = t.colStart[size_t(p)]; !nz && e < t.colStart[size_t(p) + 1]; ++e) {
+        const mmx::ColumnSource& cs = t.colSources[size_t(e)];
+        nz = (cs.dof >= 3 && cs.dof < 6) ? anyBelow[size_t(cs.joint)] != 0 : pointBelow[size_t(cs.joint)] != 0;
+      }
+      if (nz) {
+        list.push_back(p);
+      }
+    }
+    if (list.empty()) {
+      list = t.enabledList; // nothing to solve for: keep the plain system (all steps are zero)
+    }
+    MMX_HIP(upload(pb->dSolveListV1, list));
+    pb->solveN = int32_t(list.size());
+  }
+
   return MMX_OK;
 }
 
@@ -1197,7 +1251,10 @@ int32_t mmx_solve(
     return fail(MMX_ERR_INVALID_ARGUMENT, "unknown step_rule");
   }
   const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
-  const int n = pb->dev.n;
+  mmx::ProblemDev ds = pb->dev; // the explicit-Jacobian solver's view: structurally zero columns dropped
+  ds.n = pb->solveN;
+  ds.enabledList = pb->dSolveListV1.as<int32_t>();
+  const int n = ds.n;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (fusedUsable(pb) && !wantLegacySolver()) {
@@ -1308,10 +1365,10 @@ int32_t mmx_solve(
     MMX_HIP(mmx::launchFkJacobian(
         pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
     MMX_HIP(mmx::launchNormalEquations(
-        pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done,
-        mmx::choleskyStepLdsBytes(pb->dev.n, pb->dev.M) > 160 * 1024 /* the in-HBM factorisation reads the lower triangle only */, s));
+        ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done,
+        mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 /* the in-HBM factorisation reads the lower triangle only */, s));
     MMX_HIP(mmx::launchCholeskyStep(
-        pb->dev,
+        ds,
         pb->rig->P,
         pb->sJac.as<float>(),
         pb->sRes.as<float>(),
@@ -1323,7 +1380,7 @@ int32_t mmx_solve(
         sp,
         s));
     if (deferred) {
-      MMX_HIP(mmx::launchStepUpdate(pb->rig->dev, pb->dev, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
+      MMX_HIP(mmx::launchStepUpdate(pb->rig->dev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
     }
   }
   MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));

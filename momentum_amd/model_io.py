@@ -1,0 +1,370 @@
+"""Rig ingestion: momentum's text formats for the two Character members the
+solver reads, into the C-ABI rig descriptor (`Rig`) and `mmx_parameter_limit` entries.
+
+* `.model` text ("Momentum Model Definition V1.0"): sections [ParameterTransform], [Limits]
+  ([ParameterSets] / [PoseConstraints] are read as raw text) -- momentum/io/skeleton/
+  parameter_transform_io.cpp:40-125 (sections; duplicate sections are concatenated),
+  :157-240,311-372 (channel expressions `joint.attr = w*param + w*joint.attr + const`),
+  parameter_limits_io.cpp:296-343 (minmax, minmax_passive), :345-445 (piecewise `linear`),
+  :447-545 (`linear` on joint parameters), :558-578 (`halfplane`, normalised), :622-690 (dispatch).
+* legacy JSON skeleton ("Skeleton" / "BodySkeleton" / "skeleton" -> "Bones": Name, Parent,
+  PreRotation (x,y,z,w), TranslationOffset) -- momentum/io/legacy_json/legacy_json_io.cpp:82-86,
+  121-156,591.
+
+Host-side text handling only.  `ellipsoid` limits parse into a record the GPU path does not take
+(kept in the returned list as a dict so that a caller sees them; `limits_for_solver` drops them and
+the passive type, which LimitErrorFunction itself ignores: limit_error_function.cpp:1136-1150).
+"""
+from __future__ import annotations
+
+import json
+import math
+import re
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from ._abi import MMX_LIMIT_HALFPLANE, MMX_LIMIT_LINEAR, MMX_LIMIT_LINEAR_JOINT, MMX_LIMIT_MINMAX, MMX_LIMIT_MINMAX_JOINT, ParameterLimit
+from .rigs import Rig
+
+JOINT_PARAMETER_NAMES = ("tx", "ty", "tz", "rx", "ry", "rz", "sc")  # character/types.h:24
+KNOWN_SECTIONS = ("ParameterTransform", "ParameterSets", "PoseConstraints", "Limits")
+FLT_MAX = float(np.finfo(np.float32).max)
+HEADER = "Momentum Model Definition V1.0"
+
+
+class ModelFormatError(RuntimeError):
+    """MT_THROW of the reference's parsers."""
+
+
+def _strip(line: str) -> str:
+    return line.split("#", 1)[0].strip()
+
+
+def load_momentum_model(text: str) -> Dict[str, str]:
+    """loadMomentumModelCommon: {section name: content}; a repeated section is concatenated."""
+    lines = text.splitlines()
+    i = 0
+    while i < len(lines):
+        s = _strip(lines[i])
+        i += 1
+        if not s:
+            continue
+        if s == HEADER:
+            break
+        raise ModelFormatError(f"Invalid model definition file; expected '{HEADER}', got {s}")
+    out: Dict[str, str] = {}
+    name = ""
+    for raw in lines[i:]:
+        s = _strip(raw)
+        if not s:
+            continue
+        m = re.fullmatch(r"\[(\w+)\]", s)
+        if m:
+            name = m.group(1)
+        elif name in KNOWN_SECTIONS:
+            out[name] = out.get(name, "") + s + "\n"
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# [ParameterTransform]
+# ---------------------------------------------------------------------------------------------
+def parse_parameter_transform(text: str, joint_names: Sequence[str]):
+    """parseParameterTransform: (parameter names, triplets [(row, col, value)], offsets [7J])."""
+    J = len(joint_names)
+    jid = {n: k for k, n in enumerate(joint_names)}
+    names: List[str] = []
+    triplets: List[Tuple[int, int, float]] = []
+    offsets = np.zeros(7 * J, np.float32)
+    for ln, raw in enumerate(text.splitlines(), 1):
+        line = raw.split("#", 1)[0]
+        if not line.strip():
+            continue
+        if line.startswith("limit") or line.startswith("parameterset") or line.startswith("poseconstraints"):
+            continue  # old single-section files mix these lines in; their own parsers read them
+        sides = line.split("=")
+        if len(sides) != 2:
+            continue  # "Ignoring invalid line" in the reference
+        lhs = sides[0].strip().split(".")
+        if len(lhs) != 2:
+            raise ModelFormatError(f"Unknown joint name in expression at line {ln}: {line}")
+        joint, attr = lhs[0].strip(), lhs[1].strip()
+        if joint not in jid:
+            raise ModelFormatError(f"Unknown joint name in expression at line {ln}: {line}")
+        if attr not in JOINT_PARAMETER_NAMES:
+            raise ModelFormatError(f"Unknown channel name in expression at line {ln}: {line}")
+        row = 7 * jid[joint] + JOINT_PARAMETER_NAMES.index(attr)
+        for term in sides[1].split("+"):
+            parts = term.split("*")
+            if len(parts) == 1:
+                if parts[0].strip():
+                    offsets[row] = np.float32(float(parts[0]))  # additional constant
+                continue
+            if len(parts) != 2:
+                continue
+            weight = float(np.float32(float(parts[0])))
+            pname = parts[1].strip()
+            ref_joint = pname.split(".", 1)[0]
+            ref_attr = pname.split(".", 1)[1] if "." in pname else ""
+            if pname in names:
+                triplets.append((row, names.index(pname), weight))
+            elif ref_joint in jid and ref_attr in JOINT_PARAMETER_NAMES:
+                # reference to an earlier joint channel: copy its parameters, scaled (:213-226)
+                ref = 7 * jid[ref_joint] + JOINT_PARAMETER_NAMES.index(ref_attr)
+                for r, c, v in list(triplets):
+                    if r == ref:
+                        triplets.append((row, c, float(np.float32(v * weight))))
+            elif ref_joint in jid:
+                raise ModelFormatError(f"Could not parse channel expression : {line}")
+            else:
+                names.append(pname)
+                triplets.append((row, len(names) - 1, weight))
+    triplets = [t for t in triplets if t[2] != 0.0]
+    return names, triplets, offsets
+
+
+def _csr(triplets, rows: int):
+    """Eigen setFromTriplets into a row-major matrix: duplicates add up, columns ascending per row."""
+    acc: Dict[Tuple[int, int], float] = {}
+    for r, c, v in triplets:
+        acc[(r, c)] = float(np.float32(acc.get((r, c), 0.0) + v))
+    outer = np.zeros(rows + 1, np.int32)
+    inner, value = [], []
+    for r, c in sorted(acc):
+        outer[r + 1] += 1
+        inner.append(c)
+        value.append(acc[(r, c)])
+    return np.cumsum(outer).astype(np.int32), np.array(inner, np.int32), np.array(value, np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# [Limits]
+# ---------------------------------------------------------------------------------------------
+_TOKEN = re.compile(r"\s*(?:(\[)|(\])|(,)|([A-Za-z_][A-Za-z0-9_.]*)|([-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?))")
+
+
+class _Tokens:
+    def __init__(self, line: str, ln: int):
+        self.line, self.ln, self.toks = line, ln, []
+        pos = 0
+        while pos < len(line):
+            if not line[pos:].strip():
+                break
+            m = _TOKEN.match(line, pos)
+            if not m:
+                raise ModelFormatError(f"Unexpected token at character {pos} of line {ln}: {line}")
+            kind = "[" if m.group(1) else "]" if m.group(2) else "," if m.group(3) else "id" if m.group(4) else "num"
+            self.toks.append((kind, m.group(m.lastindex)))
+            pos = m.end()
+        self.i = 0
+
+    def eof(self) -> bool:
+        return self.i >= len(self.toks)
+
+    def peek(self) -> str:
+        return "eof" if self.eof() else self.toks[self.i][0]
+
+    def take(self, kind: str) -> str:
+        if self.peek() != kind:
+            raise ModelFormatError(f"Expected {kind} in line {self.ln}: {self.line}")
+        self.i += 1
+        return self.toks[self.i - 1][1]
+
+    def number(self) -> float:
+        return float(np.float32(float(self.take("num"))))
+
+    def vec(self) -> List[float]:
+        self.take("[")
+        out = [self.number()]
+        while self.peek() == ",":
+            self.take(",")
+            out.append(self.number())
+        self.take("]")
+        return out
+
+
+def parse_parameter_limits(text: str, joint_names: Sequence[str], param_names: Sequence[str]) -> list:
+    """parseParameterLimits: list of ParameterLimit (+ dicts for the types the GPU path does not take)."""
+    jid = {n: k for k, n in enumerate(joint_names)}
+
+    def model_index(name: str, t: _Tokens) -> int:
+        if name not in param_names:
+            raise ModelFormatError(f"Unknown parameter name {name} in line {t.ln}: {t.line}")
+        return list(param_names).index(name)
+
+    def joint_row(name: str, t: _Tokens) -> Tuple[int, int]:
+        j, _, a = name.partition(".")
+        if j not in jid or a not in JOINT_PARAMETER_NAMES:
+            raise ModelFormatError(f"Unknown joint parameter {name} in line {t.ln}: {t.line}")
+        return jid[j], JOINT_PARAMETER_NAMES.index(a)
+
+    out: list = []
+    for ln, raw in enumerate(text.splitlines(), 1):
+        line = raw.split("#", 1)[0]
+        if not line.strip() or not line.startswith("limit"):
+            continue
+        t = _Tokens(line, ln)
+        t.take("id")  # "limit"
+        pname, kind = t.take("id"), t.take("id")
+        if kind in ("minmax", "minmax_passive"):
+            lo, hi = t.vec()
+            w = 1.0 if t.eof() else t.number()
+            if kind == "minmax" and "." not in pname:
+                out.append(ParameterLimit.minmax(model_index(pname, t), lo, hi, w))
+            else:
+                j, a = joint_row(pname, t)
+                lim = ParameterLimit.minmax_joint(j, a, lo, hi, w)
+                out.append(lim if kind == "minmax" else dict(type="minmax_passive", joint=j, joint_parameter=a, limits=(lo, hi), weight=w))
+        elif kind == "linear":
+            on_joint = "." in pname
+            target = t.take("id")
+            segs = []
+            prev = -FLT_MAX
+            while t.peek() == "[":
+                seg = t.vec()
+                if len(seg) not in (2, 3):
+                    raise ModelFormatError(f"Expected 2 or 3 values for linear segment in line {ln}: {line}")
+                if prev == FLT_MAX and len(seg) == 3:
+                    raise ModelFormatError(f"Only the last linear segment can have unrestricted range in line {ln}: {line}")
+                cur = seg[2] if len(seg) == 3 else FLT_MAX
+                segs.append((seg[0], seg[1], prev, cur))
+                prev = cur
+            if not segs:
+                raise ModelFormatError(f"Expected [ in line {ln}: {line}")
+            for (s0, o0, _, hi0), (s1, o1, _, _) in zip(segs, segs[1:]):
+                if abs((s0 * hi0 - o0) - (s1 * hi0 - o1)) > 1e-3:
+                    raise ModelFormatError(f"Mismatch between function values between two linear segments in line {ln}: {line}")
+            w = 1.0 if t.eof() else t.number()
+            for sc, off, lo, hi in segs:
+                rng = (lo, hi)  # a single unrestricted segment gets (-FLT_MAX, FLT_MAX) like the reference (:376,398)
+                if on_joint:
+                    (rj, ra), (tj, ta) = joint_row(pname, t), joint_row(target, t)
+                    out.append(ParameterLimit.linear_joint(rj, ra, tj, ta, sc, off, rng[0], rng[1], w))
+                else:
+                    out.append(ParameterLimit.linear(model_index(pname, t), model_index(target, t), sc, off, rng[0], rng[1], w))
+        elif kind == "halfplane":
+            p2 = t.take("id")
+            n = t.vec()
+            off = t.number()
+            ln2 = math.hypot(n[0], n[1])
+            w = 1.0 if t.eof() else t.number()
+            out.append(ParameterLimit.halfplane(model_index(pname, t), model_index(p2, t), n[0] / ln2, n[1] / ln2, off / ln2, w))
+        elif kind in ("ellipsoid", "elipsoid"):
+            rest = [tok[1] for tok in t.toks[t.i :]]
+            t.i = len(t.toks)
+            out.append(dict(type="ellipsoid", joint=pname, tokens=rest))
+        else:
+            raise ModelFormatError(f"Unexpected parameter limit type {kind} in line {ln}: {line}")
+        if not t.eof():
+            raise ModelFormatError(f"Unexpected token in line {ln}: {line}")
+    return out
+
+
+def limits_for_solver(limits: list) -> List[ParameterLimit]:
+    """the entries LimitErrorFunction evaluates on the GPU path (mmx_parameter_limit)"""
+    return [l for l in limits if isinstance(l, ParameterLimit)]
+
+
+def _num(x: float) -> str:
+    return repr(float(np.float32(x)))
+
+
+def write_parameter_limits(limits: Sequence, joint_names: Sequence[str], param_names: Sequence[str]) -> str:
+    """writeParameterLimits for the types above; consecutive Linear entries of one (reference,
+    target) pair whose ranges chain are written as one piecewise line like the reference does."""
+    jp = lambda row: f"{joint_names[row // 7]}.{JOINT_PARAMETER_NAMES[row % 7]}"
+    out = []
+    i = 0
+    limits = list(limits)
+    while i < len(limits):
+        l = limits[i]
+        if not isinstance(l, ParameterLimit):
+            i += 1
+            continue
+        v = list(l.v)
+        if l.type == MMX_LIMIT_MINMAX:
+            out.append(f"limit {param_names[l.index0]} minmax [{_num(v[0])}, {_num(v[1])}] {_num(l.weight)}")
+        elif l.type == MMX_LIMIT_MINMAX_JOINT:
+            out.append(f"limit {jp(l.index0)} minmax [{_num(v[0])}, {_num(v[1])}] {_num(l.weight)}")
+        elif l.type == MMX_LIMIT_HALFPLANE:
+            out.append(f"limit {param_names[l.index0]} halfplane {param_names[l.index1]} [{_num(v[0])}, {_num(v[1])}] {_num(v[2])} {_num(l.weight)}")
+        elif l.type in (MMX_LIMIT_LINEAR, MMX_LIMIT_LINEAR_JOINT):
+            name = (lambda k: param_names[k]) if l.type == MMX_LIMIT_LINEAR else jp
+            segs = [l]
+            while (i + 1 < len(limits) and isinstance(limits[i + 1], ParameterLimit) and limits[i + 1].type == l.type
+                   and (limits[i + 1].index0, limits[i + 1].index1) == (l.index0, l.index1)
+                   and not (segs[-1].v[2] == 0 and segs[-1].v[3] == 0) and limits[i + 1].v[2] == segs[-1].v[3]):  # fmt: skip
+                i += 1
+                segs.append(limits[i])
+            body = " ".join(
+                f"[{_num(s.v[0])}, {_num(s.v[1])}]" if (s.v[2] == 0 and s.v[3] == 0) or s.v[3] >= FLT_MAX else f"[{_num(s.v[0])}, {_num(s.v[1])}, {_num(s.v[3])}]"
+                for s in segs
+            )
+            out.append(f"limit {name(l.index0)} linear {name(l.index1)} {body} {_num(l.weight)}")
+        i += 1
+    return "\n".join(out) + ("\n" if out else "")
+
+
+# ---------------------------------------------------------------------------------------------
+# skeleton (legacy JSON) and the assembled rig
+# ---------------------------------------------------------------------------------------------
+def parse_legacy_skeleton(doc) -> Tuple[List[str], np.ndarray, np.ndarray, np.ndarray]:
+    """legacySkeletonToMomentum: (names, parent [-1 = root], pre_rotation [J,4] xyzw, translation_offset [J,3])."""
+    if isinstance(doc, str):
+        doc = json.loads(doc)
+    for key in ("Skeleton", "BodySkeleton", "skeleton"):
+        if key in doc:
+            doc = doc[key]
+            break
+    if "Bones" not in doc:
+        raise ModelFormatError("Legacy skeleton JSON missing 'Bones' field")
+    bones = doc["Bones"]
+    J = len(bones)
+    names = [b["Name"] for b in bones]
+    parent = np.array([int(b["Parent"]) if 0 <= int(b["Parent"]) < J else -1 for b in bones], np.int32)  # kInvalidIndex = SIZE_MAX
+    pre = np.array([b.get("PreRotation", [0.0, 0.0, 0.0, 1.0]) for b in bones], np.float32).reshape(J, 4)
+    off = np.array([b.get("TranslationOffset", [0.0, 0.0, 0.0]) for b in bones], np.float32).reshape(J, 3)
+    return names, parent, pre, off
+
+
+def skeleton_to_legacy_json(rig: Rig) -> dict:
+    """momentumSkeletonToLegacy (legacy_json_io.cpp:158-190)."""
+    bones = []
+    for j in range(rig.num_joints):
+        bones.append({
+            "Name": rig.joint_names[j] if rig.joint_names else f"joint{j}",
+            "Parent": int(rig.parent[j]) if rig.parent[j] >= 0 else 2**64 - 1,
+            "PreRotation": [float(x) for x in rig.pre_rotation[j]],
+            "TranslationOffset": [float(x) for x in rig.translation_offset[j]],
+            "JointType": "Root" if rig.parent[j] < 0 else "Limb",
+            "RotationOrder": "XYZ",
+        })  # fmt: skip
+    return {"Skeleton": {"Bones": bones}}
+
+
+def write_parameter_transform(rig: Rig) -> str:
+    """one channel expression per driven joint parameter (writeParameterTransform's shape)"""
+    lines = []
+    for r in range(7 * rig.num_joints):
+        terms = [f"{_num(rig.pt_value[k])}*{rig.param_names[rig.pt_inner[k]]}" for k in range(rig.pt_outer[r], rig.pt_outer[r + 1])]
+        if rig.pt_offsets[r] != 0:
+            terms.append(_num(rig.pt_offsets[r]))
+        if terms:
+            lines.append(f"{rig.joint_names[r // 7]}.{JOINT_PARAMETER_NAMES[r % 7]} = " + " + ".join(terms))
+    return "\n".join(lines) + "\n"
+
+
+def load_character(skeleton_json, model_text: str) -> Tuple[Rig, list]:
+    """(Rig, parameter limits) from a legacy JSON skeleton and a `.model` definition: what
+    loadCharacter + loadModelDefinition hand to the solver (character_io.cpp, parameter_transform_io.cpp:126-155)."""
+    names, parent, pre, off = parse_legacy_skeleton(skeleton_json)
+    for j, p in enumerate(parent):
+        if p >= j:
+            raise ModelFormatError("skeleton joints must be stored parent-before-child")  # skeleton.cpp:16-22
+    sections = load_momentum_model(model_text)
+    pnames, triplets, offsets = parse_parameter_transform(sections.get("ParameterTransform", ""), names)
+    outer, inner, value = _csr(triplets, 7 * len(names))
+    rig = Rig(parent, pre, off, outer, inner, value, offsets, len(pnames), list(names), list(pnames))
+    limits = parse_parameter_limits(sections.get("Limits", ""), names, pnames)
+    return rig, limits

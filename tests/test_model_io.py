@@ -1,0 +1,145 @@
+"""Rig ingestion (momentum_amd/model_io.py) against the reference's own parser
+tests: section handling of io_model_parser_test.cpp:16-117 (duplicate sections are concatenated),
+the write -> parse round trip of io_parameter_limits_test.cpp (createCharacterWithLimits: MinMax,
+MinMaxJoint, Linear, the four-segment piecewise Linear, LinearJoint), the documented piecewise
+example of parameter_limits_io.cpp:355-365, and a whole-character round trip of createTestCharacter."""
+import json
+
+import numpy as np
+import pytest
+
+from momentum_amd import make_test_character, model_io
+from momentum_amd._abi import ParameterLimit
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def _same(a: ParameterLimit, b: ParameterLimit) -> bool:
+    return (a.type, a.index0, a.index1) == (b.type, b.index0, b.index1) and a.weight == pytest.approx(b.weight) and list(a.v) == pytest.approx(list(b.v))
+
+
+def test_duplicate_sections_are_concatenated():
+    text = """Momentum Model Definition V1.0
+
+[Limits]
+limit param1 minmax [-1.0, 1.0] 1.0
+
+[ParameterTransform]
+# Some parameter transforms
+root.tx = 1.0 * param1
+
+[Limits]
+# Second set of limits
+limit param2 minmax [-2.0, 2.0] 1.0
+
+[PoseConstraints]
+poseconstraints tpose param1=0.0
+
+[Limits]
+limit param3 minmax [-3.0, 3.0] 1.0
+"""
+    sec = model_io.load_momentum_model(text)
+    assert "Limits" in sec
+    for k in (1, 2, 3):
+        assert f"limit param{k} minmax" in sec["Limits"]
+    assert sec["ParameterTransform"].strip() == "root.tx = 1.0 * param1"
+    with pytest.raises(model_io.ModelFormatError):
+        model_io.load_momentum_model("Not a model file\n[Limits]\n")
+
+
+def test_channel_expressions():
+    joints = ["root", "child", "leaf"]
+    text = """
+root.tx = 1.0*tx
+root.rz = 0.5*shared + 0.25
+child.rz = 0.5*shared + 2.0*twist
+leaf.rx = 0.5*child.rz          # copies child.rz's parameters, scaled
+leaf.ry = 0.0*unused_zero
+"""
+    names, trip, offsets = model_io.parse_parameter_transform(text, joints)
+    assert names == ["tx", "shared", "twist", "unused_zero"]
+    A = np.zeros((21, 4))
+    for r, c, v in trip:
+        A[r, c] += v
+    assert A[0, 0] == 1 and A[5, 1] == 0.5 and offsets[5] == np.float32(0.25)
+    assert A[7 + 5, 1] == 0.5 and A[7 + 5, 2] == 2.0
+    assert A[14 + 3, 1] == 0.25 and A[14 + 3, 2] == 1.0
+    assert not A[:, 3].any()  # zero weights are dropped (:361-366) but the parameter exists
+    with pytest.raises(model_io.ModelFormatError):
+        model_io.parse_parameter_transform("nojoint.rx = 1.0*a", joints)
+    with pytest.raises(model_io.ModelFormatError):
+        model_io.parse_parameter_transform("root.qq = 1.0*a", joints)
+
+
+def test_documented_piecewise_linear_example():
+    lim = model_io.parse_parameter_limits("limit param1 linear param2 [-1, 3, -3] [1, -3, 0] [-2, -3] 4.0\n", [], ["param1", "param2"])
+    assert len(lim) == 3 and all(l.weight == 4.0 and (l.index0, l.index1) == (0, 1) for l in lim)
+    assert [list(l.v) for l in lim] == [[-1, 3, -FLT_MAX, -3], [1, -3, -3, 0], [-2, -3, 0, FLT_MAX]]
+    with pytest.raises(model_io.ModelFormatError):  # segments must be continuous (:414-436)
+        model_io.parse_parameter_limits("limit param1 linear param2 [-1, 3, -3] [1, 5, 0] [-2, -3]\n", [], ["param1", "param2"])
+    with pytest.raises(model_io.ModelFormatError):
+        model_io.parse_parameter_limits("limit param1 bogus [0, 1]\n", [], ["param1"])
+    hp = model_io.parse_parameter_limits("limit a halfplane b [3, 4] 10 2.0\n", [], ["a", "b"])[0]
+    assert list(hp.v)[:3] == pytest.approx([0.6, 0.8, 2.0]) and hp.weight == 2.0  # normalised (:568-571)
+
+
+def test_limits_write_parse_round_trip_like_the_reference_test():
+    rig = make_test_character(5)
+    P = rig.param_names
+    limits = [
+        ParameterLimit.minmax(1, -0.2, 0.1, 1.5),
+        ParameterLimit.minmax_joint(1, 2, -0.3, 0.0, 2.0),
+        ParameterLimit.linear(2, 1, 3.0, 2.0, -FLT_MAX, FLT_MAX, 2.0),
+        # f(x) = -x-3 (x<-3) ; x+3 (-3<=x<0) ; -2x+3 (0<=x<3) ; 0.5x-4.5 (x>=3)   [io_parameter_limits_test.cpp]
+        ParameterLimit.linear(2, 1, -1.0, 3.0, -FLT_MAX, -3.0, 2.5),
+        ParameterLimit.linear(2, 1, 1.0, -3.0, -3.0, 0.0, 2.5),
+        ParameterLimit.linear(2, 1, -2.0, -3.0, 0.0, 3.0, 2.5),
+        ParameterLimit.linear(2, 1, 0.5, 4.5, 3.0, FLT_MAX, 2.5),
+        ParameterLimit.linear(2, 1, 1.2, 0.3, -FLT_MAX, FLT_MAX, 2.5),
+        ParameterLimit.linear_joint(2, 3, 1, 0, 1.0, 0.0, -FLT_MAX, 0.0, 2.5),
+        ParameterLimit.linear_joint(2, 3, 1, 0, 2.0, 0.0, 0.0, FLT_MAX, 2.5),
+        ParameterLimit.halfplane(0, 3, 0.6, 0.8, 0.25, 1.0),
+    ]
+    text = model_io.write_parameter_limits(limits, rig.joint_names, P)
+    assert text.count("\n") == 7  # the piecewise entries share one line each
+    back = model_io.limits_for_solver(model_io.parse_parameter_limits(text, rig.joint_names, P))
+    assert len(back) == len(limits)
+    for a, b in zip(limits, back):
+        assert _same(a, b), (a.type, list(a.v), list(b.v))
+    passive = model_io.parse_parameter_limits(f"limit {rig.joint_names[2]}.ry minmax_passive [0, 0.5] 2.0\n", rig.joint_names, P)
+    assert isinstance(passive[0], dict) and model_io.limits_for_solver(passive) == []
+
+
+@pytest.mark.parametrize("n", [3, 24])
+def test_character_round_trip(n):
+    rig = make_test_character(n)
+    doc = json.dumps(model_io.skeleton_to_legacy_json(rig))
+    model = "Momentum Model Definition V1.0\n\n[ParameterTransform]\n" + model_io.write_parameter_transform(rig) + "\n[Limits]\nlimit root_rx minmax [-1, 1]\n"
+    back, limits = model_io.load_character(doc, model)
+    assert back.num_params == rig.num_params and back.param_names == rig.param_names and back.joint_names == rig.joint_names
+    for f in ("parent", "pre_rotation", "translation_offset", "pt_outer", "pt_inner", "pt_value", "pt_offsets"):
+        assert np.array_equal(getattr(back, f), getattr(rig, f)), f
+    assert len(limits) == 1 and limits[0].index0 == rig.param_names.index("root_rx") and limits[0].weight == 1.0
+
+
+@pytest.mark.gpu
+def test_loaded_character_solves_like_the_original(orc):
+    import torch
+
+    from momentum_amd import capi
+    from momentum_amd._abi import GnOptions
+    from tests.helpers import make_problem
+
+    rig = make_test_character(8)
+    back, _ = model_io.load_character(
+        model_io.skeleton_to_legacy_json(rig), "Momentum Model Definition V1.0\n[ParameterTransform]\n" + model_io.write_parameter_transform(rig)
+    )
+    cons, th0, _ = make_problem(rig, [7, 3], [6], 4, seed=5, perturb=0.3)
+    opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05)
+    out = []
+    for r in (rig, back):
+        pb = capi.Problem(capi.RigHandle(r, 0), 4, cons.pos_parent, cons.ori_parent)
+        pb.set_constraints(cons.pos_offset.reshape(4, 2, 3), cons.pos_target.reshape(4, 2, 3), cons.pos_weight.reshape(4, 2),
+                           cons.ori_offset.reshape(4, 1, 4), cons.ori_target.reshape(4, 1, 4), cons.ori_weight.reshape(4, 1))  # fmt: skip
+        out.append(pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)["theta"].cpu().numpy())
+    assert np.array_equal(out[0], out[1])
