@@ -1360,6 +1360,11 @@ int32_t mmx_solve(
   sp.lmLambdaMax = o->lm_lambda_max;
   sp.lmUp = o->lm_up;
   sp.lmDown = o->lm_down;
+  if (getenv("MMX_PHASE_CLOCKS") != nullptr) {
+    MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
+    MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
+    sp.clk = pb->sClk.as<long long>();
+  }
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
     MMX_HIP(mmx::launchFkJacobian(
@@ -1384,6 +1389,16 @@ int32_t mmx_solve(
     }
   }
   MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
+  if (sp.clk != nullptr) {
+    long long h[8];
+    MMX_HIP(hipMemcpyAsync(h, sp.clk, sizeof(h), hipMemcpyDeviceToHost, s));
+    MMX_HIP(hipStreamSynchronize(s));
+    static const char* names[6] = {"load H", "factor", "solve", "refine: w = r - J d", "refine: rho = J^T w", "refine: solve"};
+    fprintf(stderr, "[mmx phase clocks, choleskyStepKernel block 0, all iterations] n = %d\n", n);
+    for (int i = 0; i < 6; ++i) {
+      fprintf(stderr, "  %-22s %10lld\n", names[i], h[i]);
+    }
+  }
   return MMX_OK;
 }
 

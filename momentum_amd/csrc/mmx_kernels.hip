@@ -937,66 +937,116 @@ size_t normalEquationsMfmaLdsBytes(int n) {
 //   theta[E] -= d                                                 (skeleton_solver_function.cpp:158)
 //   convergence / history bookkeeping of SolverT::solve           (solver.cpp:92-119)
 // =============================================================================================
-__device__ __forceinline__ void
-triangularSolves(const float* A, int ld, int n, float* x, int tid) {
-  // single wavefront, no barriers: lane owns rows lane, lane+64, ...; the pivot row's value is
-  // broadcast with a wave shuffle.  Forward L y = b then backward L^T x = y, in place.
-  if (tid >= 64) {
-    return;
-  }
-  constexpr int kMaxRowsPerLane = 8; // n <= 512
-  float v[kMaxRowsPerLane];
+// (L L^T) x = b in place, L in LDS (column-major, leading dimension ld, the RECIPROCAL of the diagonal
+// stored on the diagonal).  One wavefront, no barriers: lane owns rows lane + 64 q; per step the
+// pivot value is broadcast with v_readlane (k is wave-uniform) and the next column / row of L is
+// already in flight (software pipelining), so a step costs a readlane, two multiplies and an fma
+// instead of an LDS round trip.  Forward L y = b walks columns, backward L^T x = y walks rows.
+template <int R>
+__device__ __forceinline__ void triangularSolvesT(const float* A, int ld, int n, float* x, int lane) {
+  float v[R], cur[R], nxt[R];
 #pragma unroll
-  for (int q = 0; q < kMaxRowsPerLane; ++q) {
-    const int i = tid + 64 * q;
+  for (int q = 0; q < R; ++q) {
+    const int i = lane + 64 * q;
     v[q] = i < n ? x[i] : 0.f;
+    cur[q] = i < n ? A[i] : 0.f; // column 0
+    nxt[q] = 0.f;
   }
   for (int k = 0; k < n; ++k) {
+    if (k + 1 < n) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int i = lane + 64 * q;
+        nxt[q] = i < n ? A[(k + 1) * ld + i] : 0.f;
+      }
+    }
     const int owner = k & 63, slot = k >> 6;
-    float mine = 0.f;
+    float mine = v[0], diag = cur[0];
 #pragma unroll
-    for (int q = 0; q < kMaxRowsPerLane; ++q) {
-      if (q == slot) {
-        mine = v[q];
+    for (int q = 1; q < R; ++q) {
+      if (slot == q) {
+        mine = v[q], diag = cur[q];
       }
     }
-    const float yk = __shfl(mine, owner, 64) / A[k * ld + k];
+    const float yk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), owner)) *
+        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(diag), owner));
 #pragma unroll
-    for (int q = 0; q < kMaxRowsPerLane; ++q) {
-      const int i = tid + 64 * q;
-      if (i == k) {
-        v[q] = yk;
-      } else if (i > k && i < n) {
-        v[q] -= A[k * ld + i] * yk; // L(i,k), column-major
-      }
+    for (int q = 0; q < R; ++q) {
+      const int i = lane + 64 * q;
+      v[q] = i == k ? yk : (i > k ? v[q] - cur[q] * yk : v[q]);
+      cur[q] = nxt[q];
     }
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int i = lane + 64 * q;
+    cur[q] = i < n ? A[i * ld + (n - 1)] : 0.f; // row n-1 of L = column n-1 of L^T
   }
   for (int k = n - 1; k >= 0; --k) {
-    const int owner = k & 63, slot = k >> 6;
-    float mine = 0.f;
+    if (k > 0) {
 #pragma unroll
-    for (int q = 0; q < kMaxRowsPerLane; ++q) {
-      if (q == slot) {
+      for (int q = 0; q < R; ++q) {
+        const int i = lane + 64 * q;
+        nxt[q] = i < k ? A[i * ld + (k - 1)] : 0.f;
+      }
+    }
+    const int owner = k & 63, slot = k >> 6;
+    float mine = v[0];
+#pragma unroll
+    for (int q = 1; q < R; ++q) {
+      if (slot == q) {
         mine = v[q];
       }
     }
-    const float xk = __shfl(mine, owner, 64) / A[k * ld + k];
+    const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), owner)) * A[k * ld + k];
 #pragma unroll
-    for (int q = 0; q < kMaxRowsPerLane; ++q) {
-      const int i = tid + 64 * q;
-      if (i == k) {
-        v[q] = xk;
-      } else if (i < k) {
-        v[q] -= A[i * ld + k] * xk; // L^T(i,k) = L(k,i)
-      }
+    for (int q = 0; q < R; ++q) {
+      const int i = lane + 64 * q;
+      v[q] = i == k ? xk : (i < k ? v[q] - cur[q] * xk : v[q]);
+      cur[q] = nxt[q];
     }
   }
 #pragma unroll
-  for (int q = 0; q < kMaxRowsPerLane; ++q) {
-    const int i = tid + 64 * q;
+  for (int q = 0; q < R; ++q) {
+    const int i = lane + 64 * q;
     if (i < n) {
       x[i] = v[q];
     }
+  }
+}
+
+__device__ __forceinline__ void triangularSolves(const float* A, int ld, int n, float* x, int tid) {
+  if (tid >= 64) {
+    return;
+  }
+  if (n <= 64) {
+    triangularSolvesT<1>(A, ld, n, x, tid);
+  } else if (n <= 128) {
+    triangularSolvesT<2>(A, ld, n, x, tid);
+  } else if (n <= 192) {
+    triangularSolvesT<3>(A, ld, n, x, tid);
+  } else {
+    triangularSolvesT<8>(A, ld, n, x, tid);
+  }
+}
+
+__device__ __forceinline__ void
+columnAxpy(float* __restrict__ dst, const float* __restrict__ src, float a, int begin, int end, int step) {
+  int i = begin;
+  for (; i + 3 * step < end; i += 4 * step) { // all loads of a trip before its stores
+    float sv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sv[u] = src[i + u * step];
+      dv[u] = dst[i + u * step];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      dst[i + u * step] = dv[u] + a * sv[u];
+    }
+  }
+  for (; i < end; i += step) {
+    dst[i] += a * src[i];
   }
 }
 
@@ -1018,7 +1068,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
   }
   const int n = pb.n, M = pb.M;
   const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
-  const int ld = n + 1; // odd-ish stride: conflict-free column walks
+  const int ld = (n + 1) | 1; // odd stride: the column walks of neighbouring threads hit different LDS banks
   float* A = smem; // [n][ld] column-major: A[j*ld + i] = H(i,j)
   float* g = A + n * ld; // [n]
   float* d0 = g + n; // [n]
@@ -1027,6 +1077,16 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
   int* notPdPtr = reinterpret_cast<int*>(w + M); // all LDS scratch lives in the dynamic region
   if (tid == 0) {
     *notPdPtr = 0;
+  }
+  long long tclk = clock64();
+#define MMX_SCLK(slot)                                   \
+  if (sp.clk != nullptr && b == 0) {                     \
+    __syncthreads();                                     \
+    if (tid == 0) {                                      \
+      const long long now = clock64();                   \
+      sp.clk[slot] += now - tclk;                        \
+      tclk = now;                                        \
+    }                                                    \
   }
   const float* Hb = jtj + size_t(b) * n * n;
   for (int idx = tid; idx < n * n; idx += 256) {
@@ -1042,7 +1102,10 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     d0[i] = g[i];
   }
   __syncthreads();
-  // right-looking Cholesky, lower, in place
+  MMX_SCLK(0)
+  // right-looking Cholesky, lower, in place, ONE barrier per column: the columns stay unscaled
+  // while the factorisation runs (a_ik = L_ik * L_kk; the trailing update a_ij -= a_ik a_jk / a_kk is
+  // the same rank-1 update), and one parallel pass scales them at the end
   for (int k = 0; k < n; ++k) {
     const float akk = A[k * ld + k];
     if (!(akk > 0.f)) { // Eigen's LLT stops here with NumericalIssue; flag and stop factorising
@@ -1051,27 +1114,39 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
       }
       break;
     }
-    const float lkk = sqrtf(akk);
-    __syncthreads();
-    for (int i = k + tid; i < n; i += 256) {
-      A[k * ld + i] = (i == k) ? lkk : A[k * ld + i] / lkk;
-    }
-    __syncthreads();
-    // trailing update: column j (thread) -= L(j,k) * L(:,k)
-    for (int j = k + 1 + tid; j < n; j += 256) {
-      const float ljk = A[k * ld + j];
-      for (int i = j; i < n; ++i) {
-        A[j * ld + i] -= A[k * ld + i] * ljk;
+    const float inva = __builtin_amdgcn_rcpf(akk); // 1 ulp; the refinement step absorbs it
+    // the rows of a column are dealt to as many threads (a power of two: shifts, no division) as
+    // the shrinking trailing block leaves free; source and destination columns never overlap,
+    // which lets the loads run ahead of the stores
+    const int cols = n - k - 1;
+    if (cols > 0) {
+      const int sh = cols > 128 ? 0 : 31 - __clz(256 / cols); // log2(threads per column)
+      const int tpc = 1 << sh;
+      for (int c = tid >> sh; c < cols; c += 256 >> sh) {
+        const int j = k + 1 + c;
+        columnAxpy(A + j * ld, A + k * ld, -A[k * ld + j] * inva, j + (tid & (tpc - 1)), n, tpc);
       }
     }
     __syncthreads();
   }
   __syncthreads();
+  if (*notPdPtr == 0) { // L(:,k) = a(:,k) / sqrt(a_kk); the diagonal keeps 1 / L(k,k) for triangularSolvesT
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int k = wv; k < n; k += 4) {
+      const float inv = 1.f / sqrtf(A[k * ld + k]);
+      for (int i = k + ln; i < n; i += 64) {
+        A[k * ld + i] = i == k ? inv : A[k * ld + i] * inv;
+      }
+    }
+  }
+  __syncthreads();
   const bool bad = *notPdPtr != 0;
+  MMX_SCLK(1)
   if (!bad) {
     triangularSolves(A, ld, n, d0, tid);
   }
   __syncthreads();
+  MMX_SCLK(2)
   // up to three refinement steps: a further one only while the last correction exceeded 1e-3 of the
   // step (same rule as the fused kernel; one step is the normal case)
   for (int rf = 0; rf < 3 && !bad && sp.refine && n > 0; ++rf) {
@@ -1080,28 +1155,54 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     const float* rb = res + size_t(b) * size_t(M);
     for (int k = tid; k < M; k += 256) {
       float acc = rb[k];
-      for (int s = 0; s < n; ++s) {
+      int s = 0;
+      for (; s + 8 <= n; s += 8) { // eight independent loads in flight per trip
+        float jv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          jv[u] = Jb[size_t(pb.enabledList[s + u]) * M + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc -= jv[u] * d0[s + u];
+        }
+      }
+      for (; s < n; ++s) {
         acc -= Jb[size_t(pb.enabledList[s]) * M + k] * d0[s];
       }
       w[k] = acc;
     }
     __syncthreads();
+    MMX_SCLK(3)
     // rho = J^T w - lambda d0  (one wavefront per column, coalesced, shuffle reduction)
     const int wave = tid >> 6, lane = tid & 63;
-    for (int s = wave; s < n; s += 4) {
-      const float* col = Jb + size_t(pb.enabledList[s]) * M;
-      float acc = 0.f;
-      for (int k = lane; k < M; k += 64) {
-        acc += col[k] * w[k];
+    for (int s0 = 4 * wave; s0 < n; s0 += 16) { // four columns per trip: their loads overlap
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* col[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        col[u] = Jb + size_t(pb.enabledList[s0 + u < n ? s0 + u : s0]) * M;
       }
-      acc = waveReduceSumF(acc);
-      if (lane == 0) {
-        rho[s] = acc - lambda * d0[s];
+      for (int k = lane; k < M; k += 64) {
+        const float wk = w[k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[u] += col[u][k] * wk;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float t = waveReduceSumF(acc[u]);
+        if (lane == 0 && s0 + u < n) {
+          rho[s0 + u] = t - lambda * d0[s0 + u];
+        }
       }
     }
     __syncthreads();
+    MMX_SCLK(4)
     triangularSolves(A, ld, n, rho, tid);
     __syncthreads();
+    MMX_SCLK(5)
     float c2 = 0.f, d2 = 0.f;
     for (int i = tid; i < n; i += 256) {
       const float cr = rho[i], dn = d0[i] + cr;
@@ -1819,7 +1920,7 @@ hipError_t launchNormalEquations(
 }
 
 size_t choleskyStepLdsBytes(int n, int M) {
-  return (size_t(n) * size_t(n + 1) + 3 * size_t(n) + size_t(M) + 12) * sizeof(float);
+  return (size_t(n) * size_t((n + 1) | 1) + 3 * size_t(n) + size_t(M) + 12) * sizeof(float);
 }
 
 hipError_t launchCholeskyStep(

@@ -35,6 +35,7 @@ struct StepParams {
   int32_t doLineSearch; // GaussNewtonSolverOptions::doLineSearch
   int32_t stepRule; // MMX_STEP_*
   float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
+  long long* clk; // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
 };
 
 // device view of mmx::FusedTables (mmx_host_tables.hpp)
