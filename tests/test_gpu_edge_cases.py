@@ -133,3 +133,42 @@ def test_unsupported_limit_type_is_a_loud_error(torch_cuda):
     oob = PL.linear(0, rig.num_params, 1.0, 0.0)
     with pytest.raises(capi.MmxError):
         _upload(torch, pb, cons, 1, limits=[oob])
+
+
+@pytest.mark.parametrize("count", [1, 15, 16, 17, 33, 100, 176, 191, 192, 200, 219])
+def test_three_kernel_path_system_sizes(torch_cuda, orc, count, monkeypatch):
+    """Explicit-Jacobian solver over the sizes of the dense system: partial 16-blocks of the blocked
+    LDS Cholesky (panel rows / MFMA tiles beyond n), the 48-rows-per-wave limit of its panel (n <= 208),
+    and the hand-over to the in-HBM factorisation once the factor no longer fits LDS."""
+    from momentum_amd import capi, make_humanoid72
+    torch = torch_cuda
+    monkeypatch.setenv("MMX_SOLVER", "v1")
+    rig = make_humanoid72(seed=12345, variant="p219", unit=0.01)
+    P, J = rig.num_params, rig.num_joints
+    assert P == 219
+    allj = np.arange(J, dtype=np.int32)
+    B = 2
+    cons, th0, _ = make_problem(rig, allj, allj, B, seed=40 + count, perturb=0.25)
+    rng = np.random.default_rng(count)
+    en = np.zeros(P, np.uint8)
+    en[rng.choice(P, size=count, replace=False)] = 1
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, allj, allj)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(t(cons.pos_offset, (B, J, 3)), t(cons.pos_target, (B, J, 3)), t(cons.pos_weight, (B, J)),
+                       t(cons.ori_offset, (B, J, 4)), t(cons.ori_target, (B, J, 4)), t(cons.ori_weight, (B, J)))  # fmt: skip
+    pb.set_enabled(en)
+    for ls in (False, True):
+        opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.05, do_line_search=ls)
+        out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+        ref = orc.solve_batch(rig, cons, th0, opt, enabled=en, dtype="f64")
+        th = out["theta"].cpu().numpy()
+        assert np.array_equal(th[:, en == 0], th0[:, en == 0])  # disabled parameters never move
+        rel = np.linalg.norm(th - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-12)
+        # conditioning of the whole map: the oracle's own answer under an fp32-epsilon perturbation of theta0
+        pert = orc.solve_batch(rig, cons, th0.astype(np.float64) + 1e-7 * rng.normal(size=th0.shape) * en, opt, enabled=en, dtype="f64")
+        sens = np.linalg.norm(pert["theta"] - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-12)
+        tol = np.maximum(1e-5, 3.0 * sens)
+        assert (rel <= tol).all(), (count, ls, rel, tol)
+        assert (out["status"].cpu().numpy() == 0).all()
+        h = out["error_history"].cpu().numpy()
+        assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
