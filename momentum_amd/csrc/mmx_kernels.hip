@@ -955,12 +955,15 @@ __device__ __forceinline__ void triangularSolves(const float* A, int ld, int n, 
     const int k0 = 16 * k;
     if (tid < 64) {
       const int i = lane & 15, row = k0 + i;
+      const int rowc = min(row, n - 1); // clamped: the reads are unconditional (a branch per read serialises them)
       float a[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        a[c] = (c <= i && row < n) ? A[(k0 + c) * ld + row] : 0.f;
+        const float v = A[min(k0 + c, n - 1) * ld + rowc];
+        a[c] = (c <= i && row < n) ? v : 0.f;
       }
-      float bi = row < n ? x[row] : 0.f, invd = 0.f;
+      const float xr = x[rowc];
+      float bi = row < n ? xr : 0.f, invd = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         invd = c == i ? a[c] : invd; // 1 / L(row,row)
@@ -979,7 +982,9 @@ __device__ __forceinline__ void triangularSolves(const float* A, int ld, int n, 
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        acc += (k0 + c < n) ? A[(k0 + c) * ld + r] * x[k0 + c] : 0.f;
+        const int cc = min(k0 + c, n - 1);
+        const float t = A[cc * ld + r] * x[cc];
+        acc += (k0 + c < n) ? t : 0.f;
       }
       x[r] -= acc;
     }
@@ -989,12 +994,15 @@ __device__ __forceinline__ void triangularSolves(const float* A, int ld, int n, 
     const int k0 = 16 * k;
     if (tid < 64) {
       const int i = lane & 15, row = k0 + i;
+      const int rowc = min(row, n - 1);
       float at[16]; // column i of the diagonal block of L^T = row entries L(k0 + c, k0 + i), c >= i
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        at[c] = (c >= i && k0 + c < n) ? A[row * ld + k0 + c] : 0.f;
+        const float v = A[rowc * ld + min(k0 + c, n - 1)];
+        at[c] = (c >= i && k0 + c < n && row < n) ? v : 0.f;
       }
-      float bi = row < n ? x[row] : 0.f, invd = 0.f;
+      const float xr = x[rowc];
+      float bi = row < n ? xr : 0.f, invd = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         invd = c == i ? at[c] : invd;
@@ -1013,7 +1021,9 @@ __device__ __forceinline__ void triangularSolves(const float* A, int ld, int n, 
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        acc += (k0 + c < n) ? A[r * ld + k0 + c] * x[k0 + c] : 0.f;
+        const int cc = min(k0 + c, n - 1);
+        const float t = A[r * ld + cc] * x[cc];
+        acc += (k0 + c < n) ? t : 0.f;
       }
       x[r] -= acc;
     }
