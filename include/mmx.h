@@ -307,6 +307,22 @@ int32_t mmx_eval_jacobian(
     void* stream);
 
 /*
+ * Profiling aid: mmx_eval_jacobian with a pair of HIP events attached to the dispatch packet of the
+ * J-assembly kernel itself (hipExtLaunchKernelGGL): *kernel_ms receives the duration of that kernel
+ * on `stream`, without launch latency or the gap to neighbouring dispatches -- the quantity a
+ * rocprofv3 kernel trace reports.  Synchronises the stream.  bench.py's roofline uses it.
+ */
+int32_t mmx_eval_jacobian_timed(
+    mmx_problem* problem,
+    const float* theta_dev,
+    float* jac_dev,
+    float* res_dev,
+    double* err_dev,
+    int32_t layout,
+    void* stream,
+    float* kernel_ms);
+
+/*
  * Forward pass only.  Replaces SkeletonStateT<T>(params, skeleton)
  * (skeleton_state.cpp:22-28,87-121).  state_dev [B][J][8] =
  * (tx,ty,tz, qx,qy,qz,qw, s) world transforms (the layout of

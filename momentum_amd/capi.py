@@ -26,7 +26,7 @@ SYMBOLS = [
     "mmx_gn_options_default", "mmx_abi_version", "mmx_last_error", "mmx_device_count",
     "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
-    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_eval_jacobian",
+    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_eval_jacobian", "mmx_eval_jacobian_timed",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
 ]  # fmt: skip
@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
     L.mmx_problem_set_enabled.argtypes = [vp, _abi.c_uint8_p]
     L.mmx_problem_set_constraints.argtypes = [vp, C.POINTER(ConstraintData), vp]
     L.mmx_eval_jacobian.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.mmx_eval_jacobian_timed.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(C.c_float)]
     L.mmx_eval_skeleton_state.argtypes = [vp, vp, vp, vp]
     L.mmx_eval_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mmx_solve.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
@@ -262,6 +263,15 @@ class Problem:
             err = torch.empty((self.B,), dtype=torch.float64, device=self.device)
         _check(lib().mmx_eval_jacobian(self._h, _dev(theta), _dev(jac), _dev(res), _dev(err), _abi.MMX_LAYOUT_COL_MAJOR, _stream_ptr()))
         return jac, res, err
+
+    def eval_jacobian_kernel_ms(self, theta, jac, res, err=None) -> float:
+        """Duration (ms) of the J-assembly kernel itself: events attached to its dispatch packet
+        (mmx_eval_jacobian_timed); what a rocprofv3 kernel trace reports for it."""
+        theta = self._theta(theta)
+        ms = C.c_float(0.0)
+        _check(lib().mmx_eval_jacobian_timed(self._h, _dev(theta), _dev(jac), _dev(res), _dev(err), _abi.MMX_LAYOUT_COL_MAJOR,
+                                             _stream_ptr(), C.byref(ms)))  # fmt: skip
+        return float(ms.value)
 
     def skeleton_state(self, theta):
         import torch

@@ -1172,6 +1172,47 @@ int32_t mmx_eval_jacobian(
   return MMX_OK;
 }
 
+int32_t mmx_eval_jacobian_timed(
+    mmx_problem* pb,
+    const float* theta_dev,
+    float* jac_dev,
+    float* res_dev,
+    double* err_dev,
+    int32_t layout,
+    void* stream,
+    float* kernel_ms) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_dev == nullptr || jac_dev == nullptr || kernel_ms == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta / jac / kernel_ms is null");
+  }
+  if (layout != MMX_LAYOUT_COL_MAJOR) {
+    return fail(MMX_ERR_UNSUPPORTED, "only MMX_LAYOUT_COL_MAJOR (the reference's layout) is implemented");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  MMX_HIP(hipEventCreate(&e0));
+  hipError_t err = hipEventCreate(&e1);
+  if (err == hipSuccess) {
+    err = mmx::launchFkJacobian(
+        pb->rig->dev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, static_cast<hipStream_t>(stream), e0, e1);
+  }
+  if (err == hipSuccess) {
+    err = hipEventSynchronize(e1);
+  }
+  if (err == hipSuccess) {
+    err = hipEventElapsedTime(kernel_ms, e0, e1);
+  }
+  hipEventDestroy(e0);
+  if (e1 != nullptr) {
+    hipEventDestroy(e1);
+  }
+  MMX_HIP(err);
+  return MMX_OK;
+}
+
 int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* state_dev, void* stream) {
   int32_t rc = checkProblem(pb, false);
   if (rc != MMX_OK) {

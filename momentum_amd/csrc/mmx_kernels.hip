@@ -9,6 +9,8 @@
 //                          refinement step through J, theta -= d, convergence bookkeeping.
 //
 // Reference semantics: see the citations in mmx_device.hpp and at each kernel.
+#include <hip/hip_ext.h>
+
 #include "mmx_device.hpp"
 #include "mmx_kernels.hpp"
 
@@ -1834,7 +1836,9 @@ hipError_t launchFkJacobian(
     double* err,
     float* state,
     const int32_t* done,
-    hipStream_t stream) {
+    hipStream_t stream,
+    hipEvent_t startEvent,
+    hipEvent_t stopEvent) {
   const size_t lds = fkJacobianLdsBytes(rig.J, rig.P);
   // one wave per instance fills the chip once B >> 256 CUs x ~24 resident waves; below that, four
   // waves per instance shorten the per-instance critical path.  Large rigs are LDS-bound (a
@@ -1843,7 +1847,8 @@ hipError_t launchFkJacobian(
   const bool wide = pb.B < 2048 || lds > 12 * 1024; // measured: at B = 4096, J = 72 one wave per instance beats four
   const bool streaming = pb.B <= 40000; // non-temporal column stores: see store3()
 #define MMX_FKJ(W_, WPI_, S_)                                                                                                  \
-  hipLaunchKernelGGL((fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, rig, pb, theta, jac, res, err, state, done)
+  hipExtLaunchKernelGGL(                                                                                                       \
+      (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done)
   if (jac != nullptr) {
     if (wide) {
       if (streaming) {

@@ -109,7 +109,9 @@ hipError_t launchFkJacobian(
     double* err,
     float* state,
     const int32_t* done,
-    hipStream_t stream);
+    hipStream_t stream,
+    hipEvent_t startEvent = nullptr, // attached to the J-assembly dispatch itself (hipExtLaunchKernelGGL)
+    hipEvent_t stopEvent = nullptr);
 
 hipError_t launchNormalEquations(
     const ProblemDev& pb,
