@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel summary (calls / total / avg / min / max / %) from a rocprofv3 rocpd sqlite database
-or a *_kernel_trace.csv.  Used to produce the text summaries committed under profiles/."""
+or a *_kernel_trace.csv.  Used to produce the text summaries committed under profiles/.  Launches of
+one kernel with different grid sizes are different workloads (bench.py also runs the J-assembly
+kernel at the 32768-instance shard size for context), so a CSV trace is summarised per
+(kernel, workgroups) pair."""
 import csv
 import sqlite3
 import sys
@@ -19,7 +22,11 @@ def from_db(path):
 def from_csv(path):
     rows = []
     for r in csv.DictReader(open(path)):
-        rows.append((r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        name = r["Kernel_Name"]
+        if name.startswith("void mmx::") or name.startswith("mmx::"):
+            wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+            name = f"[{wg} wg] " + name
+        rows.append((name, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     return rows
 
 
