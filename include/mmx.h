@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 3
+#define MMX_ABI_VERSION 4
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
@@ -130,6 +130,25 @@ typedef struct mmx_parameter_limit {
 } mmx_parameter_limit;
 
 /*
+ * LimitType::Ellipsoid of Character::parameterLimits (momentum/character/parameter_limits.h:77-84):
+ * the point `offset` of joint `parent` is pulled onto the ellipsoid (unit sphere mapped by `ellipsoid`)
+ * defined in the frame of joint `ellipsoid_parent`.  Three rows per entry, evaluated like
+ * computeEllipsoidError / computeEllipsoidJacobian (limit_error_function.cpp:173-195,702-790): the
+ * Jacobian walks parent -> ellipsoid_parent (exclusive) and treats the projected point as constant,
+ * weight kLimitWeight * weight_ * kPositionWeight(1e-4) * weight.  Affine maps are 3 x 4 row-major
+ * [linear | translation].  Batch-shared, HOST array.  NB: no test of the reference exercises this
+ * limit type, so parity for it rests on the restatement alone.
+ */
+typedef struct mmx_ellipsoid_limit {
+  float ellipsoid[12]; /* LimitEllipsoid::ellipsoid */
+  float ellipsoid_inv[12]; /* LimitEllipsoid::ellipsoidInv (its inverse) */
+  float offset[3]; /* LimitEllipsoid::offset */
+  float weight; /* ParameterLimit::weight */
+  int32_t ellipsoid_parent;
+  int32_t parent;
+} mmx_ellipsoid_limit;
+
+/*
  * The other JointErrorFunctionT specialisations: one block = one error
  * function object with `count` constraints per batch element.  FuncDim rows per constraint.
  *   type                      reference (momentum/character_solver/...)            rows  payload used
@@ -204,6 +223,11 @@ typedef struct mmx_constraint_data {
      Problems with such blocks are solved by the explicit-Jacobian kernels. */
   int32_t num_joint_blocks; /* <= MMX_MAX_JOINT_BLOCKS */
   const mmx_joint_constraint_block* joint_blocks;
+  /* ---- Ellipsoid entries of the limit block (same weight_ = limit_function_weight as `limits`);
+     three rows each, placed between the joint-block rows and the other limit rows:
+     [3 Kp][9 Ko][blocks][3 num_ellipsoid_limits][num_limits][P].  HOST array (copied). */
+  int32_t num_ellipsoid_limits;
+  const mmx_ellipsoid_limit* ellipsoid_limits;
 } mmx_constraint_data;
 
 /*

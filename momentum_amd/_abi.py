@@ -14,7 +14,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-MMX_ABI_VERSION = 3
+MMX_ABI_VERSION = 4
 MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
@@ -82,6 +82,49 @@ def limit_array(limits):
     arr = (ParameterLimit * max(len(limits), 1))()
     for i, l in enumerate(limits):
         arr[i] = l
+    return arr
+
+
+class EllipsoidLimit(C.Structure):
+    """mmx_ellipsoid_limit: LimitType::Ellipsoid entry (character/parameter_limits.h:77-84)."""
+
+    _fields_ = [
+        ("ellipsoid", C.c_float * 12),
+        ("ellipsoid_inv", C.c_float * 12),
+        ("offset", C.c_float * 3),
+        ("weight", C.c_float),
+        ("ellipsoid_parent", C.c_int32),
+        ("parent", C.c_int32),
+    ]
+
+    @classmethod
+    def make(cls, parent, offset, ellipsoid_parent, translation, euler_zyx_deg, scale, weight=1.0):
+        """The text form's arguments (parseEllipsoid, io/skeleton/parameter_limits_io.cpp:580-610):
+        linear part = R(extrinsic XYZ of the reversed, radian angles) * diag(scale)."""
+        ez = np.radians(np.asarray(euler_zyx_deg, np.float32).astype(np.float64))
+        ax, ay, az = ez[2], ez[1], ez[0]
+        cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        R = np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx],
+                      [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                      [-sy, cy * sx, cy * cx]])  # Rz Ry Rx = eulerXYZToRotationMatrix(., Extrinsic), math/utility.cpp:315-380
+        A = np.eye(4)
+        A[:3, :3] = R @ np.diag(np.asarray(scale, np.float64))
+        A[:3, 3] = np.asarray(translation, np.float64)
+        return cls.from_affine(parent, offset, ellipsoid_parent, A[:3], weight)
+
+    @classmethod
+    def from_affine(cls, parent, offset, ellipsoid_parent, affine34, weight=1.0):
+        A = np.eye(4)
+        A[:3] = np.asarray(affine34, np.float64).reshape(3, 4)
+        Ai = np.linalg.inv(A)
+        f12 = lambda m: (C.c_float * 12)(*[float(x) for x in np.asarray(m[:3], np.float32).reshape(-1)])
+        return cls(f12(A), f12(Ai), (C.c_float * 3)(*[float(x) for x in offset]), float(weight), int(ellipsoid_parent), int(parent))
+
+
+def ellipsoid_array(items):
+    arr = (EllipsoidLimit * max(len(items), 1))()
+    for i, e in enumerate(items):
+        arr[i] = e
     return arr
 
 
@@ -204,6 +247,9 @@ class ConstraintData(C.Structure):
         # further joint-constraint blocks (host array of JointConstraintBlock)
         ("num_joint_blocks", C.c_int32),
         ("joint_blocks", C.c_void_p),
+        # Ellipsoid entries of the limit block (host array of EllipsoidLimit)
+        ("num_ellipsoid_limits", C.c_int32),
+        ("ellipsoid_limits", C.c_void_p),
     ]
 
 

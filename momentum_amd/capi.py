@@ -198,7 +198,7 @@ class Problem:
         pos_function_weight: float = 1.0, ori_function_weight: float = 1.0,
         limits=None, limit_function_weight: float = 1.0,
         model_target=None, model_weights=None, model_function_weight: float = 1.0,
-        pos_loss=(2.0, 1.0), ori_loss=(2.0, 1.0), joint_blocks=None,
+        pos_loss=(2.0, 1.0), ori_loss=(2.0, 1.0), joint_blocks=None, ellipsoid_limits=None,
     ) -> None:  # fmt: skip
         """limits: list of _abi.ParameterLimit (batch-shared, LimitErrorFunction);
         model_target / model_weights: [B,P] (ModelParametersErrorFunction), same memory kind as the
@@ -232,11 +232,14 @@ class Problem:
         blocks = list(joint_blocks) if joint_blocks else []
         bkeep: list = []
         barr = _abi.joint_block_array(blocks, bkeep, self.B, on_dev)
+        ells = list(ellipsoid_limits) if ellipsoid_limits else []  # _abi.EllipsoidLimit, batch-shared
+        earr = _abi.ellipsoid_array(ells)
         cd = ConstraintData(
             *ptrs[:6], float(pos_function_weight), float(ori_function_weight), _abi.MMX_MEM_DEVICE if on_dev else _abi.MMX_MEM_HOST,
             ptrs[6], ptrs[7], float(model_function_weight), len(limits), C.cast(larr, C.c_void_p) if limits else None, float(limit_function_weight),
             float(pos_loss[0]), float(pos_loss[1]), float(ori_loss[0]), float(ori_loss[1]),
             len(blocks), C.cast(barr, C.c_void_p) if blocks else None,
+            len(ells), C.cast(earr, C.c_void_p) if ells else None,
         )  # fmt: skip
         _check(lib().mmx_problem_set_constraints(self._h, C.byref(cd), _stream_ptr()))
         self._keep = keep + bkeep if on_dev else []

@@ -135,6 +135,8 @@ struct mmx_problem {
   };
   std::vector<std::unique_ptr<JointBlockHost>> blocks;
   std::vector<mmx::JointBlockDev> blockDev;
+  std::vector<mmx_ellipsoid_limit> ellipsoids; // host copy
+  DevBuf dEllipsoids;
   DevBuf dBlocks, dGenJoint, dGenTin, dGenBlock;
   int32_t genRows = 0;
   bool haveConstraints = false;
@@ -222,6 +224,18 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     pb->dev.genJoint = pb->dGenJoint.as<int32_t>();
     pb->dev.genTin = pb->dGenTin.as<int32_t>();
     pb->dev.genBlock = pb->dGenBlock.as<int32_t>();
+    std::vector<mmx::EllipsoidDev> ed(pb->ellipsoids.size());
+    for (size_t i = 0; i < ed.size(); ++i) {
+      const mmx_ellipsoid_limit& e = pb->ellipsoids[i];
+      static_assert(sizeof(mmx_ellipsoid_limit) == 30 * 4 && sizeof(mmx::EllipsoidDev) == 32 * 4, "ellipsoid layouts");
+      std::memcpy(&ed[i], &e, sizeof(e));
+      ed[i].tinParent = t.tin[size_t(e.parent)];
+      const bool onChain = t.tin[size_t(e.ellipsoid_parent)] <= t.tin[size_t(e.parent)] && t.tin[size_t(e.parent)] < t.tout[size_t(e.ellipsoid_parent)];
+      ed[i].tinStop = onChain ? t.tin[size_t(e.ellipsoid_parent)] : -1;
+    }
+    MMX_HIP(upload(pb->dEllipsoids, ed));
+    pb->dev.NE = int32_t(ed.size());
+    pb->dev.ellipsoids = pb->dEllipsoids.as<mmx::EllipsoidDev>();
   }
   MMX_HIP(upload(pb->dColStart, t.colStart));
   MMX_HIP(upload(pb->dColSources, t.colSources));
@@ -245,7 +259,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     }
     MMX_HIP(upload(pb->dEnabledMask, mask));
     d.enabledMask = pb->dEnabledMask.as<uint8_t>();
-    d.rowsJoint = 3 * pb->U + pb->genRows;
+    d.rowsJoint = 3 * pb->U + pb->genRows + 3 * int32_t(pb->ellipsoids.size());
   }
   static_assert(sizeof(mmx::JacRec) == sizeof(mmx::JacRecDev) && sizeof(mmx::JacRec) == 32, "JacRec layouts must match");
   MMX_HIP(upload(pb->dJacRecs, t.jacRecs));
@@ -567,6 +581,9 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         mark(j, !fixedAxis);
       }
     }
+    for (const mmx_ellipsoid_limit& e : pb->ellipsoids) {
+      mark(e.parent, true);
+    }
     std::vector<uint8_t> keep(size_t(rig->P), pb->dev.hasModel ? 1 : 0);
     for (const mmx_parameter_limit& lm : pb->limits) {
       for (int32_t p : limitParameters(rig, lm)) {
@@ -596,7 +613,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
 
 bool fusedUsable(const mmx_problem* pb) {
   const int nb = mmx::fusedBlocksFor(pb->fdev.n);
-  if (nb < 0 || pb->dev.G > 0) { // the further joint-constraint blocks live in the explicit-Jacobian kernels
+  if (nb < 0 || pb->dev.G > 0 || pb->dev.NE > 0) { // the further joint-constraint blocks and ellipsoid limits live in the explicit-Jacobian kernels
     return false;
   }
   return pb->rig->J < 4096 &&
@@ -1106,7 +1123,21 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
     }
   }
   pb->genRows = genRows;
-  const bool structureChanged = blocksChanged || (c->model_target != nullptr) != (d.hasModel != 0) || size_t(c->num_limits) != pb->limits.size() ||
+  // ---- Ellipsoid entries of the limit block
+  if (c->num_ellipsoid_limits < 0 || c->num_ellipsoid_limits > 256 || (c->num_ellipsoid_limits > 0 && c->ellipsoid_limits == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "ellipsoid_limits: count out of range or null array");
+  }
+  for (int32_t i = 0; i < c->num_ellipsoid_limits; ++i) {
+    const mmx_ellipsoid_limit& e = c->ellipsoid_limits[i];
+    if (e.parent < 0 || e.parent >= pb->rig->J || e.ellipsoid_parent < 0 || e.ellipsoid_parent >= pb->rig->J) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "ellipsoid limit " + std::to_string(i) + ": joint index out of range");
+    }
+  }
+  const bool ellipsoidsChanged = size_t(c->num_ellipsoid_limits) != pb->ellipsoids.size() ||
+      (c->num_ellipsoid_limits > 0 &&
+       std::memcmp(c->ellipsoid_limits, pb->ellipsoids.data(), size_t(c->num_ellipsoid_limits) * sizeof(mmx_ellipsoid_limit)) != 0);
+  pb->ellipsoids.assign(c->ellipsoid_limits, c->ellipsoid_limits + c->num_ellipsoid_limits);
+  const bool structureChanged = blocksChanged || ellipsoidsChanged || (c->model_target != nullptr) != (d.hasModel != 0) || size_t(c->num_limits) != pb->limits.size() ||
       (c->num_limits > 0 && std::memcmp(c->limits, pb->limits.data(), size_t(c->num_limits) * sizeof(mmx_parameter_limit)) != 0);
   pb->limits.assign(c->limits, c->limits + c->num_limits);
   static_assert(sizeof(mmx_parameter_limit) == sizeof(mmx::LimitDev) && sizeof(mmx::LimitDev) == 32, "limit layouts must match");
@@ -1131,9 +1162,10 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   } else {
     d.mpTarget = d.mpWeights = nullptr;
   }
-  pb->M = 3 * pb->U + pb->genRows + d.NL + (d.hasModel ? P : 0);
+  const int32_t rowsE = 3 * int32_t(pb->ellipsoids.size());
+  pb->M = 3 * pb->U + pb->genRows + rowsE + d.NL + (d.hasModel ? P : 0);
   d.M = pb->M;
-  d.rowsJoint = 3 * pb->U + pb->genRows;
+  d.rowsJoint = 3 * pb->U + pb->genRows + rowsE;
   if (!structureChanged) { // payload pointers / weights / losses of the blocks may still have changed
     MMX_HIP(upload(pb->dBlocks, pb->blockDev));
     d.blocks = pb->dBlocks.as<mmx::JointBlockDev>();

@@ -176,6 +176,14 @@ struct JointBlockDev {
   LossDev loss;
 };
 
+// == mmx_ellipsoid_limit (include/mmx.h) + the DFS indices the kernels test ancestry with
+struct EllipsoidDev {
+  float ellipsoid[12], ellipsoidInv[12], offset[3], weight;
+  int32_t ellipsoidParent, parent;
+  int32_t tinParent; // tin[parent]
+  int32_t tinStop; // tin[ellipsoidParent] when that joint is an ancestor-or-self of `parent` (the walk stops there), else -1
+};
+
 struct ProblemDev {
   int32_t B, Kp, Ko, U, M, n; // U = Kp + 3 Ko constraint vectors, M = 3 U rows, n = #enabled
   const int32_t* unitJoint; // [U] parent joint of the unit's constraint
@@ -197,13 +205,16 @@ struct ProblemDev {
   LossDev lossPos, lossOri; // JointErrorFunctionT::loss_ of the two blocks
   // ---- parameter-space blocks (rows rowsJoint .. M-1): LimitErrorFunctionT on model parameters,
   // ModelParametersErrorFunctionT.  M = rowsJoint + NL + (hasModel ? P : 0).
-  int32_t rowsJoint; // 3 U + rows of the further joint-constraint blocks
+  int32_t rowsJoint; // 3 U + rows of the further joint-constraint blocks + 3 NE: first parameter-space row
   // ---- further joint-constraint blocks (rows 3 U .. rowsJoint-1), explicit-Jacobian path only
   int32_t numBlocks, G; // blocks, constraints of all blocks
   const JointBlockDev* blocks; // [numBlocks]
   const int32_t* genJoint; // [G] parent joint
   const int32_t* genTin; // [G] tin[genJoint]
   const int32_t* genBlock; // [G] block of the constraint
+  // ---- LimitType::Ellipsoid entries of the limit block: rows 3 U + block rows .. rowsJoint-1, three each
+  int32_t NE;
+  const EllipsoidDev* ellipsoids; // [NE]
   int32_t NL; // limits (one row each)
   int32_t hasModel; // model-parameter block present (P rows, used rows compacted to the top)
   const LimitDev* limits; // [NL]
@@ -641,6 +652,33 @@ __device__ __forceinline__ JointEval evalJointConstraint(const JointBlockDev& k,
     o.werr = wgt * lossValue(k.loss, sqr); // :207
     o.sigma = sqrtf(wgt * lossDeriv(k.loss, sqr)); // :208
   }
+  return o;
+}
+
+// computeEllipsoidError / the point and weights of computeEllipsoidJacobian
+// (momentum/character_solver/limit_error_function.cpp:173-195,702-737): position of the constrained
+// point, its offset from the projection onto the ellipsoid, jwgt = sqrt(tWeight * 1e-4 * weight).
+struct EllipsoidEval {
+  F3 position, diff;
+  float jwgt, werr;
+};
+__device__ __forceinline__ F3 affineApply(const float* a, const F3& p) { // 3 x 4 row-major
+  return F3{a[0] * p.x + a[1] * p.y + a[2] * p.z + a[3], a[4] * p.x + a[5] * p.y + a[6] * p.z + a[7], a[8] * p.x + a[9] * p.y + a[10] * p.z + a[11]};
+}
+__device__ __forceinline__ EllipsoidEval evalEllipsoid(const EllipsoidDev& ct, const float* js, float tWeight) {
+  const float* wp = js + kJs * ct.parent;
+  const float* we = js + kJs * ct.ellipsoidParent;
+  const F3 te{we[0], we[1], we[2]};
+  const Q4 qe{we[3], we[4], we[5], we[6]};
+  EllipsoidEval o;
+  o.position = F3{wp[0], wp[1], wp[2]} + qrot(Q4{wp[3], wp[4], wp[5], wp[6]}, wp[7] * F3{ct.offset[0], ct.offset[1], ct.offset[2]});
+  const F3 local = (1.f / we[7]) * qrot(Q4{-qe.x, -qe.y, -qe.z, qe.w}, o.position - te); // transform.inverse() * position
+  const F3 nrm = normalizedOrSame(affineApply(ct.ellipsoidInv, local));
+  const F3 proj = affineApply(ct.ellipsoid, nrm);
+  o.diff = o.position - (te + qrot(qe, we[7] * proj));
+  const float w = tWeight * 1e-4f * ct.weight; // kLimitWeight * weight_ * kPositionWeight * limit.weight
+  o.werr = w * dot(o.diff, o.diff);
+  o.jwgt = sqrtf(w);
   return o;
 }
 

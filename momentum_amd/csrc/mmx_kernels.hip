@@ -411,7 +411,7 @@ size_t parameterRowsLdsBytes(int P, int NL) {
 // (constraint, column) gathers the column's sources -- the ancestor walk turned inside out, as in
 // fkJacobianKernel -- and writes FuncDim rows.  Every element of those rows is written.
 // =============================================================================================
-constexpr int kEvWords = 27; // vp(3) vn(3) sigma*dp(9) sigma*dn(9) tin row nrows|flags ; odd stride: conflict-free
+constexpr int kEvWords = 29; // vp(3) vn(3) sigma*dp(9) sigma*dn(9) tin row nrows|flags tinStop pad ; odd stride: conflict-free
 
 struct SideLds {
   float* js; // [J][kJs]
@@ -506,6 +506,37 @@ __global__ void __launch_bounds__(256) jointBlocksKernel(
       evi[kEvWords * g + 24] = pb.genTin[g];
       evi[kEvWords * g + 25] = row;
       evi[kEvWords * g + 26] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0);
+      evi[kEvWords * g + 27] = -1;
+    }
+  }
+  // LimitType::Ellipsoid entries: a point constraint whose target (the projection onto the ellipsoid)
+  // is held constant and whose walk stops at ellipsoidParent (limit_error_function.cpp:702-790)
+  const float tWeightE = 1e+1f * pb.wLimit;
+  for (int q = tid; q < pb.NE; q += 256) {
+    const EllipsoidDev ct = pb.ellipsoids[q];
+    const int row = pb.rowsJoint - 3 * pb.NE + 3 * q, g = G + q;
+    EllipsoidEval o = evalEllipsoid(ct, js, tWeightE);
+    if (!(pb.wLimit > 0.f)) { // a block with weight_ <= 0 is skipped; its rows stay zero
+      o.jwgt = o.werr = 0.f;
+    }
+    e += double(o.werr);
+    if (res != nullptr) {
+      float* r = res + size_t(b) * M + row;
+      r[0] = o.diff.x * o.jwgt, r[1] = o.diff.y * o.jwgt, r[2] = o.diff.z * o.jwgt;
+    }
+    if (kWriteJac) {
+      float* w = ev + kEvWords * g;
+      w[0] = o.position.x, w[1] = o.position.y, w[2] = o.position.z;
+      w[3] = w[4] = w[5] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        w[6 + k] = (k == 0 || k == 4 || k == 8) ? o.jwgt : 0.f;
+        w[15 + k] = 0.f;
+      }
+      evi[kEvWords * g + 24] = ct.tinParent;
+      evi[kEvWords * g + 25] = row;
+      evi[kEvWords * g + 26] = 3 | 16;
+      evi[kEvWords * g + 27] = ct.tinStop;
     }
   }
   if (err != nullptr) {
@@ -523,11 +554,13 @@ __global__ void __launch_bounds__(256) jointBlocksKernel(
   }
   __syncthreads();
   float* jb = jac + size_t(b) * M * size_t(P);
-  const int items = G * P;
+  const int GT = G + pb.NE;
+  const int items = GT * P;
   for (int item = tid; item < items; item += 256) {
-    const int p = item / G, g = item - p * G; // constraints fastest: neighbouring threads write neighbouring rows
+    const int p = item / GT, g = item - p * GT; // constraints fastest: neighbouring threads write neighbouring rows
     const float* w = ev + kEvWords * g;
     const int tin = evi[kEvWords * g + 24], row = evi[kEvWords * g + 25], fl = evi[kEvWords * g + 26];
+    const int tinStop = evi[kEvWords * g + 27];
     const int nrows = fl & 15;
     const bool hasPoint = (fl & 16) != 0, hasDir = (fl & 32) != 0;
     const F3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
@@ -537,6 +570,9 @@ __global__ void __launch_bounds__(256) jointBlocksKernel(
       const ColumnSourceDev s = pb.colSources[ei];
       if (!((s.tin <= tin) && (tin < s.tout))) {
         continue; // the source's joint is not an ancestor of the constraint's joint
+      }
+      if (tinStop >= 0 && s.tin <= tinStop && tinStop < s.tout) {
+        continue; // ellipsoid limit: the walk stopped before this joint
       }
       const float* a = js + kJs * s.joint;
       F3 gp{0.f, 0.f, 0.f}, gn{0.f, 0.f, 0.f};
@@ -578,7 +614,7 @@ __global__ void __launch_bounds__(256) jointBlocksKernel(
   }
 }
 
-size_t jointBlocksLdsBytes(int J, int P, int G) {
+size_t jointBlocksLdsBytes(int J, int P, int G) { // G = constraints of the blocks + ellipsoid limits
   return (sideFkLdsFloats(J) + size_t((P + 3) & ~3) + size_t(kEvWords) * size_t(G)) * sizeof(float);
 }
 
@@ -1713,6 +1749,11 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
       const JointBlockDev k = pb.blocks[pb.genBlock[g]];
       e += double(evalJointConstraint(k, sl.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(g - k.first)).werr);
     }
+    if (pb.wLimit > 0.f) {
+      for (int q = tid; q < pb.NE; q += 256) {
+        e += double(evalEllipsoid(pb.ellipsoids[q], sl.js, 1e+1f * pb.wLimit).werr);
+      }
+    }
     if (pb.M > pb.rowsJoint) {
       e += paramRowsError<false>(rig, pb, P, thT, b, tid);
     }
@@ -1871,8 +1912,8 @@ hipError_t launchFkJacobian(
     }
   }
 #undef MMX_FKJ
-  if (pb.G > 0 && (jac != nullptr || res != nullptr || err != nullptr)) {
-    const size_t jl = jointBlocksLdsBytes(rig.J, rig.P, pb.G);
+  if (pb.G + pb.NE > 0 && (jac != nullptr || res != nullptr || err != nullptr)) {
+    const size_t jl = jointBlocksLdsBytes(rig.J, rig.P, pb.G + pb.NE);
     if (jl > 64 * 1024) {
       hipError_t rc = hipFuncSetAttribute(
           jac != nullptr ? reinterpret_cast<const void*>(jointBlocksKernel<true>) : reinterpret_cast<const void*>(jointBlocksKernel<false>),

@@ -11,9 +11,9 @@ solver reads, into the C-ABI rig descriptor (`Rig`) and `mmx_parameter_limit` en
   PreRotation (x,y,z,w), TranslationOffset) -- momentum/io/legacy_json/legacy_json_io.cpp:82-86,
   121-156,591.
 
-Host-side text handling only.  `ellipsoid` limits parse into a record the GPU path does not take
-(kept in the returned list as a dict so that a caller sees them; `limits_for_solver` drops them and
-the passive type, which LimitErrorFunction itself ignores: limit_error_function.cpp:1136-1150).
+Host-side text handling only.  `ellipsoid` lines become `EllipsoidLimit` (mmx_ellipsoid_limit);
+`minmax_passive` entries are kept as dicts so that a caller sees them -- LimitErrorFunction itself
+ignores that type (limit_error_function.cpp:1136-1150) and `limits_for_solver` drops it.
 """
 from __future__ import annotations
 
@@ -24,7 +24,9 @@ from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 
-from ._abi import MMX_LIMIT_HALFPLANE, MMX_LIMIT_LINEAR, MMX_LIMIT_LINEAR_JOINT, MMX_LIMIT_MINMAX, MMX_LIMIT_MINMAX_JOINT, ParameterLimit
+from ._abi import (
+    MMX_LIMIT_HALFPLANE, MMX_LIMIT_LINEAR, MMX_LIMIT_LINEAR_JOINT, MMX_LIMIT_MINMAX, MMX_LIMIT_MINMAX_JOINT, EllipsoidLimit, ParameterLimit,
+)  # fmt: skip
 from .rigs import Rig
 
 JOINT_PARAMETER_NAMES = ("tx", "ty", "tz", "rx", "ry", "rz", "sc")  # character/types.h:24
@@ -250,10 +252,16 @@ def parse_parameter_limits(text: str, joint_names: Sequence[str], param_names: S
             ln2 = math.hypot(n[0], n[1])
             w = 1.0 if t.eof() else t.number()
             out.append(ParameterLimit.halfplane(model_index(pname, t), model_index(p2, t), n[0] / ln2, n[1] / ln2, off / ln2, w))
-        elif kind in ("ellipsoid", "elipsoid"):
-            rest = [tok[1] for tok in t.toks[t.i :]]
-            t.i = len(t.toks)
-            out.append(dict(type="ellipsoid", joint=pname, tokens=rest))
+        elif kind in ("ellipsoid", "elipsoid"):  # "[offset] parent [translation] [rotation zyx, degrees] [scale] <weight>" (:580-610)
+            if pname not in jid:
+                raise ModelFormatError(f"Unknown joint name {pname} in line {ln}: {line}")
+            offset = t.vec()
+            ep = t.take("id")
+            if ep not in jid:
+                raise ModelFormatError(f"Unknown joint name {ep} in line {ln}: {line}")
+            translation, euler_zyx, scale = t.vec(), t.vec(), t.vec()
+            w = 1.0 if t.eof() else t.number()
+            out.append(EllipsoidLimit.make(jid[pname], offset, jid[ep], translation, euler_zyx, scale, w))
         else:
             raise ModelFormatError(f"Unexpected parameter limit type {kind} in line {ln}: {line}")
         if not t.eof():
@@ -262,8 +270,13 @@ def parse_parameter_limits(text: str, joint_names: Sequence[str], param_names: S
 
 
 def limits_for_solver(limits: list) -> List[ParameterLimit]:
-    """the entries LimitErrorFunction evaluates on the GPU path (mmx_parameter_limit)"""
+    """the parameter-space entries LimitErrorFunction evaluates (mmx_parameter_limit)"""
     return [l for l in limits if isinstance(l, ParameterLimit)]
+
+
+def ellipsoids_for_solver(limits: list) -> List[EllipsoidLimit]:
+    """the LimitType::Ellipsoid entries (mmx_ellipsoid_limit)"""
+    return [l for l in limits if isinstance(l, EllipsoidLimit)]
 
 
 def _num(x: float) -> str:

@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _abi
-from ._abi import GnOptions, JointBlock, ParameterLimit
+from ._abi import EllipsoidLimit, GnOptions, JointBlock, ParameterLimit
 from .rigs import Rig
 
 
@@ -273,7 +273,8 @@ class NormalErrorFunction(_BlockErrorFunction):
 
 class LimitErrorFunction(SkeletonErrorFunction):
     """LimitErrorFunctionT on the character's parameter limits (limit_error_function.h:45-110);
-    limit types MinMax / MinMaxJoint / Linear / LinearJoint / HalfPlane."""
+    limit types MinMax / MinMaxJoint / Linear / LinearJoint / HalfPlane (ParameterLimit) and Ellipsoid
+    (EllipsoidLimit) in one list, like Character::parameterLimits."""
 
     def __init__(self, character: Character, limits: Optional[Sequence[ParameterLimit]] = None, weight: float = 1.0):
         super().__init__(character, weight)
@@ -375,14 +376,16 @@ class SkeletonSolverFunction(SolverFunction):
                 self._cache[1].close()
             self._cache = (key, capi.Problem(self.character.handle(), B, pp, op))
         pb = self._cache[1]
-        limits, wl = [], 1.0
+        limits, ells, wl = [], [], 1.0
         mt = mw = None
         wm = 1.0
         for e in self._efs:
             if isinstance(e, LimitErrorFunction):
-                if limits:
+                if limits or ells:
                     raise RuntimeError("only one LimitErrorFunction per solver function")
-                limits, wl = e.limits, e.weight
+                limits = [l for l in e.limits if isinstance(l, ParameterLimit)]
+                ells = [l for l in e.limits if isinstance(l, EllipsoidLimit)]
+                wl = e.weight
             elif isinstance(e, ModelParametersErrorFunction):
                 if mt is not None:
                     raise RuntimeError("only one ModelParametersErrorFunction per solver function")
@@ -393,7 +396,8 @@ class SkeletonSolverFunction(SolverFunction):
             elif not isinstance(e, _JointErrorFunction):
                 raise RuntimeError(f"{type(e).__name__} is not available on the GPU path")
         pb.set_constraints(po, pt, pw, oo, ot, ow, 1.0, 1.0, limits=limits, limit_function_weight=wl, model_target=mt,
-                           model_weights=mw, model_function_weight=wm, pos_loss=ploss, ori_loss=oloss, joint_blocks=blocks)  # fmt: skip
+                           model_weights=mw, model_function_weight=wm, pos_loss=ploss, ori_loss=oloss, joint_blocks=blocks,
+                           ellipsoid_limits=ells)  # fmt: skip
         return pb, torch
 
     def _params(self, model_parameters):

@@ -368,12 +368,17 @@ struct Constraints {
   const float* mpTarget = nullptr; // [P] ModelParametersErrorFunctionT::targetParameters_
   const float* mpWeights = nullptr; // [P] targetWeights_
   float mpFunctionWeight = 0.f;
-  int jointRows() const {
+  int NE = 0; // LimitType::Ellipsoid entries of the limit block (three rows each, before the other limit rows)
+  const mmx_ellipsoid_limit* ellipsoids = nullptr;
+  int blockRows() const {
     int r = 3 * Kp + 9 * Ko;
     for (const JointBlock<T>& blk : blocks) {
       r += blk.funcDim() * blk.count;
     }
     return r;
+  }
+  int jointRows() const { // rows that need joint transforms = everything before the parameter-space rows
+    return blockRows() + 3 * NE;
   }
   int rows() const {
     return jointRows() + NL + (mpTarget != nullptr ? P : 0);
@@ -706,6 +711,86 @@ inline double evalJointBlocks(
   return total;
 }
 
+// LimitType::Ellipsoid rows of LimitErrorFunctionT (L2): computeEllipsoidError / computeEllipsoidJacobian
+// (momentum/character_solver/limit_error_function.cpp:173-195,702-790; kPositionWeight :21,
+// kLimitWeight limit_error_function.h:91).  The walk goes parent -> ellipsoidParent (exclusive) and
+// scatters through every column of the transform row (no enabled-parameter test, :745-776); columns of
+// disabled parameters are left zero here like everywhere else in this oracle (the solver never reads them).
+template <class T>
+inline double evalEllipsoidRows(
+    const Rig& rig,
+    const std::vector<JointState<T>>& st,
+    const Constraints<T>& cs,
+    const uint8_t* active,
+    const uint8_t* enabled,
+    T* jac,
+    T* res) {
+  if (cs.NE == 0 || !(cs.limFunctionWeight > 0.f)) {
+    return 0.0;
+  }
+  const int M = cs.rows();
+  const T tWeight = T(10) * T(cs.limFunctionWeight);
+  const T kPositionWeight = T(1e-4f);
+  double error = 0.0;
+  auto apply = [](const float* a, const V3<T>& p) { // 3 x 4 row-major affine
+    return V3<T>{
+        T(a[0]) * p.x + T(a[1]) * p.y + T(a[2]) * p.z + T(a[3]),
+        T(a[4]) * p.x + T(a[5]) * p.y + T(a[6]) * p.z + T(a[7]),
+        T(a[8]) * p.x + T(a[9]) * p.y + T(a[10]) * p.z + T(a[11])};
+  };
+  for (int e = 0; e < cs.NE; ++e) {
+    const mmx_ellipsoid_limit& ct = cs.ellipsoids[e];
+    const Xf<T>& Xp = st[ct.parent].world;
+    const Xf<T>& Xe = st[ct.ellipsoid_parent].world;
+    const V3<T> position = xpoint(Xp, V3<T>{T(ct.offset[0]), T(ct.offset[1]), T(ct.offset[2])});
+    // transform.inverse() * position for a TRS transform: q^-1 (p - t) / s
+    const Quat<T> qi{-Xe.q.x, -Xe.q.y, -Xe.q.z, Xe.q.w};
+    const V3<T> local = (T(1) / Xe.s) * qrot(qi, position - Xe.t);
+    const V3<T> ell = apply(ct.ellipsoid_inv, local);
+    const V3<T> nrm = v3normalized(ell);
+    const V3<T> proj = apply(ct.ellipsoid, nrm);
+    const V3<T> diff = position - xpoint(Xe, proj);
+    const T sqr = dot(diff, diff);
+    const T limitWeight = T(ct.weight);
+    error += double(tWeight * kPositionWeight * limitWeight * sqr);
+    if (jac == nullptr) {
+      continue;
+    }
+    const T jwgt = std::sqrt(tWeight * kPositionWeight * limitWeight);
+    const int row = cs.blockRows() + 3 * e;
+    res[row] = diff.x * jwgt, res[row + 1] = diff.y * jwgt, res[row + 2] = diff.z * jwgt;
+    int jnt = ct.parent;
+    while (jnt != ct.ellipsoid_parent && jnt >= 0) {
+      const JointState<T>& js = st[jnt];
+      const int base = jnt * kParametersPerJoint;
+      const V3<T> posd = position - js.world.t;
+      auto scatter = [&](int jp, const V3<T>& g) {
+        for (int idx = rig.outer[jp]; idx < rig.outer[jp + 1]; ++idx) {
+          const int col = rig.inner[idx];
+          if (enabled[col]) {
+            const T w = T(rig.value[idx]);
+            T* c = jac + size_t(col) * M + row;
+            c[0] += (g.x * jwgt) * w, c[1] += (g.y * jwgt) * w, c[2] += (g.z * jwgt) * w;
+          }
+        }
+      };
+      for (int d = 0; d < 3; ++d) {
+        if (active[base + d]) {
+          scatter(base + d, js.translationAxis.col(d));
+        }
+        if (active[base + 3 + d]) {
+          scatter(base + 3 + d, cross(js.rotationAxis.col(d), posd));
+        }
+      }
+      if (active[base + 6]) {
+        scatter(base + 6, ln2<T>() * posd);
+      }
+      jnt = rig.parent[jnt];
+    }
+  }
+  return error;
+}
+
 // PositionErrorFunctionT::evalFunction (position_error_function.cpp:15-27) +
 // OrientationErrorFunctionT::evalFunction (orientation_error_function.cpp:15-40) driven through
 // JointErrorFunctionT::getJacobian (joint_error_function-inl.h:179-297).  jac (M x P column-major,
@@ -1020,6 +1105,7 @@ struct SolverFunction {
     setSkeletonState<T>(rig, jp.data(), state);
     double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
     e += evalJointBlocks<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
+    e += evalEllipsoidRows<T>(rig, state, cs, active.data(), enabled.data(), nullptr, nullptr);
     e += evalParameterRows<T>(rig, cs, theta, jp.data(), active.data(), enabled.data(), nullptr, nullptr);
     return double(float(e));
   }
@@ -1034,6 +1120,7 @@ struct SolverFunction {
     std::fill(res, res + M, T(0));
     double e = evalErrorFunctions<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
     e += evalJointBlocks<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
+    e += evalEllipsoidRows<T>(rig, state, cs, active.data(), enabled.data(), jac, res);
     e += evalParameterRows<T>(rig, cs, theta, jp.data(), active.data(), enabled.data(), jac, res);
     return e;
   }

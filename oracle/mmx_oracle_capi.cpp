@@ -79,6 +79,8 @@ Constraints<T> makeConstraints(
     }
     cs.blocks.push_back(blk);
   }
+  cs.NE = c->num_ellipsoid_limits;
+  cs.ellipsoids = c->ellipsoid_limits;
   cs.P = P;
   cs.NL = c->num_limits;
   cs.limits = c->limits;

@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from momentum_amd._abi import ConstraintData, GnOptions, MMX_MEM_HOST, as_ptr, joint_block_array, limit_array, void_p
+from momentum_amd._abi import ConstraintData, GnOptions, MMX_MEM_HOST, as_ptr, ellipsoid_array, joint_block_array, limit_array, void_p
 from momentum_amd.rigs import Rig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -71,6 +71,7 @@ class Constraints:
         pos_loss=(2.0, 1.0),
         ori_loss=(2.0, 1.0),
         joint_blocks=None,
+        ellipsoid_limits=None,
     ):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         self.pos_parent = np.ascontiguousarray(pos_parent, dtype=np.int32).reshape(-1)
@@ -92,6 +93,8 @@ class Constraints:
         self.pos_loss = (float(pos_loss[0]), float(pos_loss[1]))  # GeneralizedLoss (alpha, c)
         self.ori_loss = (float(ori_loss[0]), float(ori_loss[1]))
         self.joint_blocks = list(joint_blocks) if joint_blocks else []  # momentum_amd._abi.JointBlock
+        self.ellipsoid_limits = list(ellipsoid_limits) if ellipsoid_limits else []  # momentum_amd._abi.EllipsoidLimit (batch-shared)
+        self._ellipsoid_array = ellipsoid_array(self.ellipsoid_limits)
 
     @property
     def P(self) -> int:
@@ -99,7 +102,7 @@ class Constraints:
 
     @property
     def rows(self) -> int:
-        return 3 * self.Kp + 9 * self.Ko + sum(b.rows for b in self.joint_blocks) + len(self.limits) + self.P
+        return 3 * self.Kp + 9 * self.Ko + sum(b.rows for b in self.joint_blocks) + 3 * len(self.ellipsoid_limits) + len(self.limits) + self.P
 
     def data(self) -> ConstraintData:
         self._keep = []
@@ -126,6 +129,8 @@ class Constraints:
             self.ori_loss[1],
             len(self.joint_blocks),
             C.cast(self._block_array, C.c_void_p) if self.joint_blocks else None,
+            len(self.ellipsoid_limits),
+            C.cast(self._ellipsoid_array, C.c_void_p) if self.ellipsoid_limits else None,
         )
 
     def instance(self, b: int) -> "Constraints":
@@ -149,6 +154,7 @@ class Constraints:
             self.pos_loss,
             self.ori_loss,
             [blk.instance(b) for blk in self.joint_blocks],
+            self.ellipsoid_limits,
         )
 
 

@@ -1,0 +1,98 @@
+"""GPU parity of the LimitType::Ellipsoid rows (mmx_ellipsoid_limit) against the CPU oracle: J / r /
+error next to the other limit types and joint constraints, and Gauss-Newton / line-search solves
+(explicit-Jacobian kernels: jointBlocksKernel, stepUpdateKernel)."""
+import numpy as np
+import pytest
+
+from momentum_amd import _abi, humanoid72_landmark_joints, make_humanoid72, make_test_character
+from momentum_amd._abi import EllipsoidLimit, GnOptions, ParameterLimit
+from tests.helpers import make_problem
+from tests.test_gpu_joint_blocks import _device_block
+from tests.test_oracle_joint_blocks import make_block
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(torch, orc, which, B, seed, with_blocks):
+    from momentum_amd import capi
+
+    if which == "chain8":
+        rig, pp, op = make_test_character(8), [7, 3], [6]
+        ells = [EllipsoidLimit.make(6, [0.1, 0.2, -0.1], 2, [0.0, 0.5, 0.0], [10.0, 20.0, 30.0], [0.6, 1.2, 0.8], 3.0),
+                EllipsoidLimit.make(3, [0.0, 0.1, 0.0], 5, [0.1, 0.0, 0.2], [0.0, 0.0, 45.0], [1.0, 0.5, 0.7], 1.0)]  # fmt: skip
+    else:
+        rig = make_humanoid72(unit=0.01)
+        lm = humanoid72_landmark_joints(rig)
+        pp, op = lm, lm
+        rng0 = np.random.default_rng(seed)
+        ells = []
+        for _ in range(5):
+            parent = int(rng0.integers(1, rig.num_joints))
+            chain = [parent]
+            while rig.parent[chain[-1]] >= 0:
+                chain.append(int(rig.parent[chain[-1]]))
+            ep = int(rng0.choice(chain[1:])) if len(chain) > 1 and rng0.uniform() < 0.7 else int(rng0.integers(0, rig.num_joints))
+            ells.append(EllipsoidLimit.make(parent, rng0.uniform(-0.05, 0.05, 3), ep, rng0.uniform(-0.1, 0.1, 3), rng0.uniform(-90, 90, 3),
+                                            rng0.uniform(0.05, 0.3, 3), float(rng0.uniform(0.5, 4.0))))  # fmt: skip
+    cons, th0, _ = make_problem(rig, pp, op, B, seed=seed, perturb=0.3)
+    rng = np.random.default_rng(seed + 1)
+    limits = [ParameterLimit.minmax(3, -0.05, 0.05, 1.0), ParameterLimit.linear(4, 5, 1.0, 0.0, weight=0.5)]
+    blocks = [make_block(_abi.MMX_JC_HALF_PLANE, rng.choice(rig.num_joints, size=3), rng, weight=1.0, batch=B)] if with_blocks else []
+    wl = 25.0  # ellipsoid rows carry kPositionWeight = 1e-4: a visible weight for the test
+    full = orc.Constraints(cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset,
+                           cons.ori_target, cons.ori_weight, limits=limits, limit_function_weight=wl, joint_blocks=blocks,
+                           ellipsoid_limits=ells)  # fmt: skip
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, cons.pos_parent, cons.ori_parent)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+                       t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+                       limits=limits, limit_function_weight=wl, joint_blocks=[_device_block(torch, k, pb.device) for k in blocks],
+                       ellipsoid_limits=ells)  # fmt: skip
+    assert pb.M == full.rows
+    return rig, pb, full, th0
+
+
+@pytest.mark.parametrize("which", ["chain8", "humanoid72"])
+@pytest.mark.parametrize("with_blocks", [False, True])
+def test_ellipsoid_rows_match_oracle(orc, which, with_blocks):
+    import torch
+
+    B = 3
+    rig, pb, full, th0 = _setup(torch, orc, which, B, 17, with_blocks)
+    rng = np.random.default_rng(5)
+    theta = rng.uniform(-0.4, 0.4, size=(B, rig.num_params)).astype(np.float32)
+    en = np.ones(rig.num_params, np.uint8)
+    en[[2, 6]] = 0
+    for enabled in (None, en):
+        if enabled is not None:
+            pb.set_enabled(enabled)
+        jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
+        jac, res, err = jac.cpu().numpy(), res.cpu().numpy(), err.cpu().numpy()
+        for b in range(B):
+            J, r, e = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), enabled=enabled, dtype="f64")
+            assert np.abs(jac[b].T - J).max() <= 3e-5 * max(1.0, np.abs(J).max())
+            assert np.abs(res[b] - r).max() <= 3e-5 * max(1.0, np.abs(r).max())
+            assert abs(err[b] - e) <= 3e-5 * max(1.0, e)
+            nE = 3 * len(full.ellipsoid_limits)
+            rowsE = slice(full.rows - len(full.limits) - nE, full.rows - len(full.limits))
+            assert np.abs(J[rowsE]).max() > 0  # the rows under test are not trivially zero
+
+
+@pytest.mark.parametrize("which", ["chain8", "humanoid72"])
+@pytest.mark.parametrize("line_search", [False, True])
+def test_solve_with_ellipsoid_limits_matches_oracle(orc, which, line_search):
+    import torch
+
+    from tests.test_gpu_parity import _sensitivity
+
+    B = 4
+    rig, pb, full, th0 = _setup(torch, orc, which, B, 23, False)
+    opt = GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05, do_line_search=line_search)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+    rel = np.linalg.norm(out["theta"].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    tol = np.maximum(3e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
+    assert (rel <= tol).all(), (rel, tol)
+    h = out["error_history"].cpu().numpy()
+    assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
+    assert (out["status"].cpu().numpy() == 0).all()
