@@ -52,6 +52,7 @@ def test_struct_layouts_match_header():
              offsetof(mmx_constraint_data, ori_loss_c));
       printf("%zu %zu %zu %zu\n", sizeof(mmx_joint_constraint_block), offsetof(mmx_joint_constraint_block, plane_d),
              offsetof(mmx_joint_constraint_block, loss_c), offsetof(mmx_constraint_data, joint_blocks));
+      printf("%zu %zu %zu\n", sizeof(mmx_ellipsoid_limit), offsetof(mmx_ellipsoid_limit, parent), offsetof(mmx_constraint_data, ellipsoid_limits));
       return 0;
     }"""
     with tempfile.TemporaryDirectory() as td:
@@ -63,7 +64,8 @@ def test_struct_layouts_match_header():
     sizes = [int(x) for x in out]
     assert sizes[:3] == [C.sizeof(_abi.RigDesc), C.sizeof(_abi.ConstraintData), C.sizeof(_abi.GnOptions)]
     assert sizes[3:6] == [_abi.RigDesc.pt_offsets.offset, _abi.ConstraintData.memory.offset, _abi.GnOptions.lm_down.offset]
-    assert sizes[10:] == [C.sizeof(_abi.JointConstraintBlock), _abi.JointConstraintBlock.plane_d.offset,
+    assert sizes[14:] == [C.sizeof(_abi.EllipsoidLimit), _abi.EllipsoidLimit.parent.offset, _abi.ConstraintData.ellipsoid_limits.offset]
+    assert sizes[10:14] == [C.sizeof(_abi.JointConstraintBlock), _abi.JointConstraintBlock.plane_d.offset,
                           _abi.JointConstraintBlock.loss_c.offset, _abi.ConstraintData.joint_blocks.offset]  # fmt: skip
     assert sizes[6:10] == [C.sizeof(_abi.ParameterLimit), _abi.ConstraintData.limits.offset, _abi.ConstraintData.model_weights.offset,
                          _abi.ConstraintData.ori_loss_c.offset]  # fmt: skip
