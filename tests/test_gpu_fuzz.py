@@ -129,3 +129,58 @@ def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     assert np.all(th[:, en == 0] == th0[:, en == 0])  # disabled parameters are never touched
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
+    """The same random rigs with the further joint error functions and Ellipsoid limits: exercises the
+    host tables of the explicit-Jacobian kernels (flattened constraint lists, DFS indices, the stop
+    index of the ellipsoid walk, the compacted solve list) on arbitrary trees."""
+    from momentum_amd import capi
+    from momentum_amd._abi import EllipsoidLimit
+    from tests.test_oracle_joint_blocks import TYPES, make_block
+
+    torch = torch_cuda
+    rng = np.random.default_rng(5000 + seed)
+    J = int(rng.integers(2, 40))
+    rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
+    P = rig.num_params
+    Kp = int(rng.integers(0, 5))
+    pp = rng.integers(0, J, size=Kp).astype(np.int32)
+    op = np.zeros(0, np.int32)
+    B = 3
+    cons, th0, _ = make_problem(rig, pp, op, B, seed=seed, perturb=0.25, random_offsets=True, weights="random")
+    types = list(TYPES.values())
+    blocks = [make_block(types[int(k)], rng.integers(0, J, size=int(rng.integers(1, 4))), rng, weight=1.0, batch=B,
+                         function_weight=float(rng.uniform(0.3, 1.2)), loss=(2.0, 1.0) if rng.uniform() < 0.7 else (0.0, 0.8))
+              for k in rng.choice(len(types), size=int(rng.integers(1, 4)), replace=False)]  # fmt: skip
+    ells = [EllipsoidLimit.make(int(rng.integers(0, J)), rng.uniform(-0.2, 0.2, 3), int(rng.integers(0, J)), rng.uniform(-0.2, 0.2, 3),
+                                rng.uniform(-180, 180, 3), rng.uniform(0.1, 0.6, 3), float(rng.uniform(0.5, 2.0)))
+            for _ in range(int(rng.integers(0, 3)))]  # fmt: skip
+    wl = 50.0
+    full = orc.Constraints(cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset,
+                           cons.ori_target, cons.ori_weight, joint_blocks=blocks, ellipsoid_limits=ells, limit_function_weight=wl)  # fmt: skip
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, pp, op)
+    f = lambda a, shp: np.ascontiguousarray(a, np.float32).reshape(shp)
+    pb.set_constraints(f(cons.pos_offset, (B, Kp, 3)), f(cons.pos_target, (B, Kp, 3)), f(cons.pos_weight, (B, Kp)), f(cons.ori_offset, (B, 0, 4)),
+                       f(cons.ori_target, (B, 0, 4)), f(cons.ori_weight, (B, 0)), joint_blocks=blocks, ellipsoid_limits=ells,
+                       limit_function_weight=wl)  # fmt: skip  (host payload: copied by the library)
+    assert pb.M == full.rows
+    en = (rng.uniform(size=P) < 0.85).astype(np.uint8)
+    en[:3] = 1
+    pb.set_enabled(en)
+    theta = rng.uniform(-0.3, 0.3, size=(B, P)).astype(np.float32)
+    jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
+    jac, res, err = jac.cpu().numpy(), res.cpu().numpy(), err.cpu().numpy()
+    for b in range(B):
+        Jo, ro, eo = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
+        assert np.abs(jac[b].T - Jo).max() <= 5e-5 * max(1.0, np.abs(Jo).max()), (seed, b)
+        assert np.abs(res[b] - ro).max() <= 5e-5 * max(1.0, np.abs(ro).max())
+        assert abs(err[b] - eo) <= 5e-5 * max(1.0, eo)
+    opt = GnOptions.make(min_iterations=4, max_iterations=4, regularization=0.5, do_line_search=bool(seed % 2))
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, full, th0, opt, enabled=en, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
+    assert np.all(rel <= 1e-4), (seed, rel)
+    assert np.all(th[:, en == 0] == th0[:, en == 0])
