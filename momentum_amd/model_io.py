@@ -10,6 +10,8 @@ solver reads, into the C-ABI rig descriptor (`Rig`) and `mmx_parameter_limit` en
 * legacy JSON skeleton ("Skeleton" / "BodySkeleton" / "skeleton" -> "Bones": Name, Parent,
   PreRotation (x,y,z,w), TranslationOffset) -- momentum/io/legacy_json/legacy_json_io.cpp:82-86,
   121-156,591.
+* glTF / GLB: joints from the node hierarchy, parameter transform and limits from the FB_momentum
+  extension (see `load_gltf` at the end of this file).
 
 Host-side text handling only.  `ellipsoid` lines become `EllipsoidLimit` (mmx_ellipsoid_limit);
 `minmax_passive` entries are kept as dicts so that a caller sees them -- LimitErrorFunction itself
@@ -381,3 +383,238 @@ def load_character(skeleton_json, model_text: str) -> Tuple[Rig, list]:
     rig = Rig(parent, pre, off, outer, inner, value, offsets, len(pnames), list(names), list(pnames))
     limits = parse_parameter_limits(sections.get("Limits", ""), names, pnames)
     return rig, limits
+
+
+# ---------------------------------------------------------------------------------------------
+# glTF / GLB characters (skeleton from the node hierarchy, parameter transform and limits from the
+# FB_momentum extension) -- momentum/io/gltf/gltf_skeleton_io.cpp:79-175 (loadHierarchyRecursive),
+# :267-278 (createJoint, isHierarchyNode), :280-384 (gatherSkeletonRoots), :389-418 (loadHierarchy);
+# gltf_io.cpp:57-80 (loadGlobalExtensions); io/common/json_utils.cpp:204-285 (parameterTransformFromJson),
+# :519-674 (limits).  Lengths in the file are metres, momentum works in centimetres
+# (gltf/utils/coordinate_utils.h:13-26); matrices are stored as lists of columns (json_utils.h:30-41).
+# ---------------------------------------------------------------------------------------------
+_M_TO_CM = 100.0
+
+
+def _gltf_document(data) -> dict:
+    if isinstance(data, dict):
+        return data
+    if isinstance(data, str):
+        return json.loads(data)
+    b = bytes(data)
+    if b[:4] != b"glTF":
+        return json.loads(b.decode("utf-8"))
+    import struct
+
+    version, _ = struct.unpack("<II", b[4:12])
+    if version != 2:
+        raise ModelFormatError(f"unsupported GLB version {version}")
+    clen, ctype = struct.unpack("<I4s", b[12:20])
+    if ctype != b"JSON":
+        raise ModelFormatError("GLB: first chunk is not JSON")
+    return json.loads(b[20 : 20 + clen].decode("utf-8"))
+
+
+def _momentum_ext(obj: dict) -> dict:
+    return obj.get("extensions", {}).get("FB_momentum", {}) if isinstance(obj, dict) else {}
+
+
+def _gltf_skeleton_roots(doc: dict) -> List[List[int]]:
+    nodes = doc.get("nodes", [])
+    scene = doc["scenes"][doc.get("scene", 0)]
+    if not doc.get("meshes") or not doc.get("skins"):
+        return [list(scene.get("nodes", []))]
+    parent = [-1] * len(nodes)
+    stack = list(scene.get("nodes", []))
+    while stack:
+        nxt = []
+        for n in stack:
+            for c in nodes[n].get("children", []):
+                parent[c] = n
+                nxt.append(c)
+        stack = nxt
+
+    def ancestors(n):
+        out = []
+        while n != -1:
+            out.append(n)
+            n = parent[n]
+        return out[::-1]
+
+    def common(a, b2):
+        ca = -1
+        for x, y in zip(ancestors(a), ancestors(b2)):
+            if x != y:
+                break
+            ca = x
+        return ca
+
+    per_skin = []
+    for skin in doc["skins"]:
+        roots: List[int] = []
+        for j in skin["joints"]:
+            if parent[j] not in skin["joints"]:
+                for k, r in enumerate(roots):
+                    ca = common(j, r)
+                    if ca != -1:
+                        roots[k] = ca
+                        break
+                else:
+                    roots.append(j)
+        per_skin.append(roots)
+    result = []
+    for i, roots in enumerate(per_skin):
+        if len(roots) > 1:
+            result.append(roots)
+            continue
+        anc = ancestors(roots[0])
+        if not any(k != i and len(o) == 1 and o[0] in anc for k, o in enumerate(per_skin)):
+            result.append([roots[0]])
+    return result
+
+
+def load_gltf(data) -> Tuple[Rig, list]:
+    """(Rig, parameter limits) of the first skeleton in a glTF / GLB document (bytes, str or dict)."""
+    doc = _gltf_document(data)
+    nodes = doc.get("nodes", [])
+    if not nodes:
+        raise ModelFormatError("No valid node found in the gltf file.")
+    use_ext = "FB_momentum" in doc.get("extensions", {})
+    names: List[str] = []
+    parents: List[int] = []
+    pre: List[List[float]] = []
+    off: List[List[float]] = []
+
+    def walk(nid: int, pj: int) -> None:
+        if nid < 0 or nid >= len(nodes):
+            raise ModelFormatError(f"Invalid node id found in the gltf hierarchy: {nid}")
+        node = nodes[nid]
+        if "skin" in node or "camera" in node:  # isHierarchyNode
+            return
+        typ = _momentum_ext(node).get("type", "")
+        npj = pj
+        if typ in ("collision_capsule", "collision_ellipsoid", "collision_box", "locator"):
+            pass  # end nodes the solver path does not read
+        elif (not use_ext and "mesh" not in node) or typ == "skeleton_joint":
+            names.append(node.get("name", ""))
+            parents.append(pj)
+            pre.append(list(node.get("rotation", [0.0, 0.0, 0.0, 1.0])))
+            off.append([_M_TO_CM * float(x) for x in node.get("translation", [0.0, 0.0, 0.0])])
+            npj = len(names) - 1
+        for c in node.get("children", []):
+            walk(c, npj)
+
+    roots = _gltf_skeleton_roots(doc)
+    if len(roots) != 1:
+        raise ModelFormatError(f"expected one skeleton in the file, found {len(roots)}")
+    for r in roots[0]:
+        walk(r, -1)
+        if names:
+            break
+    J = len(names)
+    jid = {n: k for k, n in enumerate(names)}
+    ext = _momentum_ext(doc)
+    pnames: List[str] = []
+    triplets: List[Tuple[int, int, float]] = []
+    if "transform" in ext:
+        tj = ext["transform"]
+        if "parameters" not in tj or "joints" not in tj:
+            raise ModelFormatError("No 'parameters' / 'joints' found in parameter transform.")
+        pnames = list(tj["parameters"])
+        for jn, attrs in tj["joints"].items():
+            if jn not in jid:
+                raise ModelFormatError(f"Unknown joint name in expression : {jn}")
+            for an, terms in attrs.items():
+                if an not in JOINT_PARAMETER_NAMES:
+                    raise ModelFormatError(f"Unknown channel name in expression : {an}")
+                for pn, w in terms.items():
+                    if pn not in pnames:
+                        raise ModelFormatError(f"Unknown parameter name in expression : {pn}")
+                    triplets.append((7 * jid[jn] + JOINT_PARAMETER_NAMES.index(an), pnames.index(pn), float(np.float32(w))))
+    outer, inner, value = _csr(triplets, 7 * J)
+    rig = Rig(np.array(parents, np.int32), np.array(pre, np.float32).reshape(J, 4), np.array(off, np.float32).reshape(J, 3),
+              outer, inner, value, np.zeros(7 * J, np.float32), len(pnames), names, pnames)  # fmt: skip
+    limits: list = []
+    pid = lambda n: pnames.index(n)
+    for el in ext.get("parameterLimits", []):
+        t, w = el.get("type", ""), float(el.get("weight", 0.0))
+        if t == "minmax":
+            limits.append(ParameterLimit.minmax(pid(el["parameter"]), el["limits"][0], el["limits"][1], w))
+        elif t in ("minmax_joint", "minmax_joint_passive"):
+            j, a = jid[el["jointIndex"]], JOINT_PARAMETER_NAMES.index(el["jointParameter"])
+            lim = ParameterLimit.minmax_joint(j, a, el["limits"][0], el["limits"][1], w)
+            limits.append(lim if t == "minmax_joint" else dict(type="minmax_passive", joint=j, joint_parameter=a, limits=tuple(el["limits"]), weight=w))
+        elif t == "linear":
+            limits.append(ParameterLimit.linear(pid(el["referenceParameter"]), pid(el["targetParameter"]), el["scale"], el["offset"],
+                                                el.get("rangeMin", -FLT_MAX), el.get("rangeMax", FLT_MAX), w))  # fmt: skip
+        elif t == "linear_joint":
+            limits.append(ParameterLimit.linear_joint(jid[el["referenceJoint"]], int(el["referenceJointParameter"]), jid[el["targetJoint"]],
+                                                      int(el["targetJointParameter"]), el["scale"], el["offset"],
+                                                      el.get("rangeMin", -FLT_MAX), el.get("rangeMax", FLT_MAX), w))  # fmt: skip
+        elif t == "half_plane":
+            limits.append(ParameterLimit.halfplane(pid(el["param1"]), pid(el["param2"]), el["normal"][0], el["normal"][1], el["offset"], w))
+        elif t in ("ellipsoid", "elipsoid"):
+            A = np.array(el[t], np.float64).reshape(4, 4).T  # list of columns
+            A[:3, 3] *= _M_TO_CM
+            epk = "ellipsoidParent" if t == "ellipsoid" else "elipsoidParent"
+            limits.append(EllipsoidLimit.from_affine(jid[el["parent"]], [_M_TO_CM * float(x) for x in el["offset"]], jid[el[epk]], A[:3], w))
+        else:
+            raise ModelFormatError(f"Unknown parameter limit type '{t}'")
+    return rig, limits
+
+
+def write_gltf(rig: Rig, limits: Sequence = ()) -> dict:
+    """glTF document (dict) with the FB_momentum extension: joints as `skeleton_joint` nodes in the
+    hierarchy, `transform` (parameterTransformToJson, json_utils.cpp:168-200) and `parameterLimits`."""
+    J = rig.num_joints
+    nodes = []
+    for j in range(J):
+        nodes.append({"name": rig.joint_names[j], "rotation": [float(x) for x in rig.pre_rotation[j]],
+                      "translation": [float(x) / _M_TO_CM for x in rig.translation_offset[j]],
+                      "extensions": {"FB_momentum": {"type": "skeleton_joint"}}})  # fmt: skip
+    for j in range(J):
+        p = int(rig.parent[j])
+        if p >= 0:
+            nodes[p].setdefault("children", []).append(j)
+    joints: Dict[str, dict] = {}
+    for r in range(7 * J):
+        for k in range(rig.pt_outer[r], rig.pt_outer[r + 1]):
+            joints.setdefault(rig.joint_names[r // 7], {}).setdefault(JOINT_PARAMETER_NAMES[r % 7], {})[rig.param_names[rig.pt_inner[k]]] = float(rig.pt_value[k])
+    lj = []
+    for l in limits:
+        if isinstance(l, EllipsoidLimit):
+            A = np.eye(4)
+            A[:3] = np.array(list(l.ellipsoid)).reshape(3, 4)
+            A[:3, 3] /= _M_TO_CM
+            lj.append({"type": "ellipsoid", "weight": l.weight, "parent": rig.joint_names[l.parent], "ellipsoidParent": rig.joint_names[l.ellipsoid_parent],
+                       "offset": [float(x) / _M_TO_CM for x in l.offset], "ellipsoid": [[float(A[r2, c]) for r2 in range(4)] for c in range(4)]})  # fmt: skip
+        elif isinstance(l, ParameterLimit):
+            v = list(l.v)
+            if l.type == MMX_LIMIT_MINMAX:
+                lj.append({"type": "minmax", "weight": l.weight, "parameter": rig.param_names[l.index0], "limits": v[:2]})
+            elif l.type == MMX_LIMIT_MINMAX_JOINT:
+                lj.append({"type": "minmax_joint", "weight": l.weight, "jointIndex": rig.joint_names[l.index0 // 7],
+                           "jointParameter": JOINT_PARAMETER_NAMES[l.index0 % 7], "limits": v[:2]})  # fmt: skip
+            elif l.type == MMX_LIMIT_LINEAR:
+                lj.append({"type": "linear", "weight": l.weight, "referenceParameter": rig.param_names[l.index0],
+                           "targetParameter": rig.param_names[l.index1], "scale": v[0], "offset": v[1], "rangeMin": v[2], "rangeMax": v[3]})  # fmt: skip
+            elif l.type == MMX_LIMIT_LINEAR_JOINT:
+                lj.append({"type": "linear_joint", "weight": l.weight, "referenceJoint": rig.joint_names[l.index0 // 7],
+                           "referenceJointParameter": l.index0 % 7, "targetJoint": rig.joint_names[l.index1 // 7],
+                           "targetJointParameter": l.index1 % 7, "scale": v[0], "offset": v[1], "rangeMin": v[2], "rangeMax": v[3]})  # fmt: skip
+            elif l.type == MMX_LIMIT_HALFPLANE:
+                lj.append({"type": "half_plane", "weight": l.weight, "param1": rig.param_names[l.index0], "param2": rig.param_names[l.index1],
+                           "normal": v[:2], "offset": v[2]})  # fmt: skip
+    roots = [j for j in range(J) if rig.parent[j] < 0]
+    return {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": roots}], "nodes": nodes,
+            "extensionsUsed": ["FB_momentum"],
+            "extensions": {"FB_momentum": {"transform": {"parameters": list(rig.param_names), "joints": joints}, "parameterLimits": lj}}}  # fmt: skip
+
+
+def to_glb(doc: dict) -> bytes:
+    """GLB container with only a JSON chunk."""
+    import struct
+
+    payload = json.dumps(doc).encode("utf-8")
+    payload += b" " * ((4 - len(payload) % 4) % 4)
+    return b"glTF" + struct.pack("<II", 2, 12 + 8 + len(payload)) + struct.pack("<I4s", len(payload), b"JSON") + payload

@@ -143,3 +143,70 @@ def test_loaded_character_solves_like_the_original(orc):
                            cons.ori_offset.reshape(4, 1, 4), cons.ori_target.reshape(4, 1, 4), cons.ori_weight.reshape(4, 1))  # fmt: skip
         out.append(pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)["theta"].cpu().numpy())
     assert np.array_equal(out[0], out[1])
+
+
+def test_gltf_round_trip_with_momentum_extension():
+    """Character -> glTF (FB_momentum extension: skeleton_joint nodes, transform, parameterLimits) -> GLB
+    container -> Character: arrays identical (lengths travel in metres), limits identical."""
+    from momentum_amd._abi import EllipsoidLimit
+
+    rig = make_test_character(7)
+    limits = [
+        ParameterLimit.minmax(1, -0.2, 0.1, 1.5),
+        ParameterLimit.minmax_joint(1, 2, -0.3, 0.0, 2.0),
+        ParameterLimit.linear(2, 1, 3.0, 2.0, -FLT_MAX, FLT_MAX, 2.0),
+        ParameterLimit.linear_joint(2, 3, 1, 0, 1.0, 0.0, -FLT_MAX, 0.0, 2.5),
+        ParameterLimit.halfplane(0, 3, 0.6, 0.8, 0.25, 1.0),
+        EllipsoidLimit.make(5, [1.0, 2.0, 3.0], 2, [2.0, 3.0, 4.0], [-60.0, 45.0, 90.0], [0.8, 0.9, 1.3], 4.0),
+    ]
+    glb = model_io.to_glb(model_io.write_gltf(rig, limits))
+    assert glb[:4] == b"glTF"
+    back, lim2 = model_io.load_gltf(glb)
+    assert back.joint_names == rig.joint_names and back.param_names == rig.param_names
+    for f in ("parent", "pre_rotation", "pt_outer", "pt_inner", "pt_value", "pt_offsets"):
+        assert np.array_equal(getattr(back, f), getattr(rig, f)), f
+    assert np.abs(back.translation_offset - rig.translation_offset).max() <= 1e-6  # cm -> m -> cm
+    assert len(lim2) == len(limits)
+    for a, b in zip(limits[:-1], lim2[:-1]):
+        assert _same(a, b)
+    ea, eb = limits[-1], lim2[-1]
+    assert (ea.parent, ea.ellipsoid_parent, ea.weight) == (eb.parent, eb.ellipsoid_parent, eb.weight)
+    assert np.abs(np.array(list(ea.ellipsoid)) - np.array(list(eb.ellipsoid))).max() <= 1e-5
+    assert np.abs(np.array(list(ea.offset)) - np.array(list(eb.offset))).max() <= 1e-5
+
+
+def test_gltf_without_extension_every_unskinned_node_is_a_joint():
+    """No FB_momentum extension: every hierarchy node without a mesh becomes a joint, in depth-first
+    order, translations converted from metres (gltf_skeleton_io.cpp:79-175,267-274)."""
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+        "nodes": [
+            {"name": "root", "children": [1, 3], "translation": [0.0, 1.0, 0.0]},
+            {"name": "spine", "children": [2], "rotation": [0.0, 0.0, 0.7071068, 0.7071068], "translation": [0.0, 0.25, 0.0]},
+            {"name": "head", "translation": [0.0, 0.1, 0.0]},
+            {"name": "body_mesh", "mesh": 0},
+            {"name": "unreachable"},
+        ],
+        "meshes": [{"primitives": []}],
+    }  # fmt: skip
+    rig, limits = model_io.load_gltf(json.dumps(doc))
+    assert rig.joint_names == ["root", "spine", "head"] and list(rig.parent) == [-1, 0, 1] and limits == []
+    assert np.allclose(rig.translation_offset, [[0, 100, 0], [0, 25, 0], [0, 10, 0]])
+    assert np.allclose(rig.pre_rotation[1], [0, 0, 0.7071068, 0.7071068]) and np.allclose(rig.pre_rotation[0], [0, 0, 0, 1])
+    assert rig.num_params == 0
+
+
+@pytest.mark.parametrize("name,joints", [("blender_simple_armature.glb", None), ("skeleton_non_joint_root.glb", None), ("sort_joints.glb", None)])
+def test_reference_glb_resources_load(name, joints):
+    """The reference's own GLB test resources (read in place when the checkout is present; they carry
+    no FB_momentum extension): a parent-before-child skeleton with unit pre-rotations comes out."""
+    import os
+
+    path = os.path.join("/root/reference/momentum/test/resources", name)
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    rig, limits = model_io.load_gltf(open(path, "rb").read())
+    assert rig.num_joints >= 2 and limits == []
+    assert rig.parent[0] == -1 and all(rig.parent[j] < j for j in range(rig.num_joints))
+    assert np.allclose(np.linalg.norm(rig.pre_rotation, axis=1), 1.0, atol=1e-4)
+    assert len(set(rig.joint_names)) == rig.num_joints
