@@ -311,6 +311,23 @@ fkJumpRounds(float* js, float* alt, int* jlA, int* jlB, int J, int rounds, int t
   }
 }
 
+// the seven joint parameters of a joint from its two-slot ELL transform rows (in registers) and theta
+// in LDS.  Same products in the same order as the CSR walk (parameter_transform.cpp:124).
+__device__ __forceinline__ void jointParamsFromRows(const int4* rows, const float* ptOff, const float* thetaLds, float* jpv) {
+#pragma unroll
+  for (int d = 0; d < 7; ++d) {
+    const int4 e = rows[d];
+    float acc = 0.f;
+    if (e.x >= 0) {
+      acc += __int_as_float(e.y) * thetaLds[e.x];
+    }
+    if (e.z >= 0) {
+      acc += __int_as_float(e.w) * thetaLds[e.z];
+    }
+    jpv[d] = acc + ptOff[d];
+  }
+}
+
 // fkLocalTo with the joint's seven transform rows already in registers (RigDev::ptEll) and theta
 // in LDS: one round of independent global loads instead of the outer -> inner -> theta chain.
 // Same products in the same order as the CSR walk (parameter_transform.cpp:124).
@@ -359,14 +376,13 @@ __device__ __forceinline__ void fkComposeInPlaceP(int j, int par, float* js) {
   o[7] = sc;
 }
 
-template <class RigT>
-__device__ __forceinline__ void fkAxesInPlaceP(const RigT& rig, int j, int par, float* js) {
+// rotation axes of joint j with its pre-rotation `pre` (x,y,z,w) handed in (registers)
+__device__ __forceinline__ void fkAxesInPlaceQ(const float* pre, int j, int par, float* js) {
   Q4 qp{0.f, 0.f, 0.f, 1.f};
   if (par >= 0) {
     const float* p = js + kJs * par;
     qp = Q4{p[3], p[4], p[5], p[6]};
   }
-  const float* pre = rig.preRot + 4 * j;
   float* o = js + kJs * j;
   const F3 az = qrot(qmul(qp, Q4{pre[0], pre[1], pre[2], pre[3]}), F3{0.f, 0.f, 1.f});
   const F3 ay = qrot(qmul(qp, Q4{o[8], o[9], o[10], o[11]}), F3{0.f, 1.f, 0.f});
@@ -374,6 +390,10 @@ __device__ __forceinline__ void fkAxesInPlaceP(const RigT& rig, int j, int par, 
   o[8] = ax.x, o[9] = ax.y, o[10] = ax.z;
   o[11] = ay.x, o[12] = ay.y, o[13] = ay.z;
   o[14] = az.x, o[15] = az.y, o[16] = az.z;
+}
+template <class RigT>
+__device__ __forceinline__ void fkAxesInPlaceP(const RigT& rig, int j, int par, float* js) {
+  fkAxesInPlaceQ(rig.preRot + 4 * j, j, par, js);
 }
 
 

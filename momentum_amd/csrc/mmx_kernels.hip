@@ -15,6 +15,7 @@
 #include "mmx_kernels.hpp"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace mmx {
 
@@ -29,11 +30,12 @@ namespace mmx {
 // unit u.  Lane u owns three consecutive floats of every column, so one wave store covers 768
 // contiguous bytes; every element is written (structural zeros included), no read-modify-write.
 // =============================================================================================
-// the lane's three rows of a column.  Streaming (non-temporal) stores measured against plain ones
-// on the 72-joint workload: 111 -> 104 us at B = 4096, 371 -> 330 us at B = 16384, but 1290 -> 1325 us
-// at B = 65536 -- so they are used up to 40 000 instances per launch.
-__device__ __forceinline__ void store3(float* o, float x, float y, float z, bool nt) {
-  if (nt) {
+// the lane's three rows of a column.  kNt = streaming (non-temporal) stores.  A template parameter on
+// purpose: with a run-time `bool nt` argument the optimiser merged the two branches of the helper
+// before inlining it and dropped the nontemporal flag (no `global_store ... nt` was ever emitted).
+template <bool kNt>
+__device__ __forceinline__ void store3(float* o, float x, float y, float z) {
+  if constexpr (kNt) {
     __builtin_nontemporal_store(x, o);
     __builtin_nontemporal_store(y, o + 1);
     __builtin_nontemporal_store(z, o + 2);
@@ -42,10 +44,90 @@ __device__ __forceinline__ void store3(float* o, float x, float y, float z, bool
   }
 }
 
+// vmcnt counts loads and stores in ONE in-order counter, so a wait for a load that is placed after a
+// store drains every store issued in between.  MMX_ARRIVED ties the registers of earlier loads to a
+// value the following stores depend on (`dep`, e.g. the zero they write): the compiler has to wait
+// for those loads before the first store, and knows afterwards that they have arrived.  Not
+// `volatile`: a volatile asm counts as a write to unknown memory, which turns every wave-uniform
+// table load after it from a scalar load into a vector load.
+#define MMX_ARRIVED4(dep_, a_, b_, c_, d_) asm("" : "+v"(dep_) : "v"(a_), "v"(b_), "v"(c_), "v"(d_))
+
+// the structurally zero columns of an instance: lane = unit u writes rows 3u..3u+2 of each
+// (the columns are dealt to the waves w0 .. w0 + nw - 1 of the workgroup)
+template <bool kNt>
+__device__ __forceinline__ void writeZeroColumns(const ProblemDev& pb, float* jz, float zero, int lane, int wave, int w0, int nw) {
+  if (wave < w0) {
+    return;
+  }
+  for (int u0 = 0; u0 < pb.U; u0 += 64) {
+    const int u = u0 + lane;
+    if (u < pb.U) {
+      for (int i = wave - w0; i < pb.numZeroCols; i += nw) {
+        store3<kNt>(jz + size_t(pb.zeroCols[i]) * size_t(pb.M) + 3 * size_t(u), zero, zero, zero);
+      }
+    }
+  }
+}
+
+// The column program of one unit (lane = unit u, rows 3u..3u+2 of every non-zero column).
+template <int WPI, bool kNt>
+__device__ __forceinline__ void
+writeUnitColumns(const ProblemDev& pb, const float* js, const Unit& un, float* jb, size_t M, int wave) {
+  // (1) single-source rotation columns, grouped by joint: four records (one 128-byte run of
+  //     scalar loads) per trip; ancestor test and v - t_joint refreshed when the joint changes.
+  //     jc = derivScale * dfdv * (axis x off) ; jac.col(p) = jc * value
+  //     (joint_error_function-inl.h:265-278, joint_state.cpp:68-71)
+  int curJoint = -1;
+  bool anc = false;
+  F3 off{0.f, 0.f, 0.f};
+  for (int i0 = 4 * wave; i0 < pb.numJacRecs; i0 += 4 * WPI) {
+    JacRecDev rec[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rec[k] = pb.jacRecs[i0 + k]; // wave-uniform
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const JacRecDev& r = rec[k];
+      const float* a = js + kJs * r.joint;
+      if (r.joint != curJoint) {
+        curJoint = r.joint;
+        anc = (r.tin <= un.tin) && (un.tin < r.tout);
+        off = un.isPoint ? un.v - F3{a[0], a[1], a[2]} : un.v;
+      }
+      const float* ax = a + 8 + 3 * (r.dof - 3);
+      const F3 g = cross(F3{ax[0], ax[1], ax[2]}, off);
+      const float w = anc ? r.weight : 0.f;
+      if (un.valid) {
+        float* o = jb + size_t(r.col) * M;
+        store3<kNt>(o, (un.sigma * g.x) * w, (un.sigma * g.y) * w, (un.sigma * g.z) * w);
+      }
+    }
+  }
+  // (2) every other non-empty column (shared parameters, translation / scale dofs): generic gather
+  for (int i = wave; i < pb.numMultiCols; i += WPI) {
+    const int p = pb.multiCols[i];
+    F3 acc{0.f, 0.f, 0.f};
+    const int e1 = pb.colStart[p + 1];
+    for (int e = pb.colStart[p]; e < e1; ++e) {
+      const ColumnSourceDev s = pb.colSources[e]; // wave-uniform
+      bool applies;
+      const F3 g = sourceDerivative(s, js, un, applies);
+      const float w = applies ? s.weight : 0.f;
+      acc.x += (un.sigma * g.x) * w;
+      acc.y += (un.sigma * g.y) * w;
+      acc.z += (un.sigma * g.z) * w;
+    }
+    if (un.valid) {
+      store3<kNt>(jb + size_t(p) * M, acc.x, acc.y, acc.z);
+    }
+  }
+}
+
 // WPI = wavefronts per instance: 1 (block = 64) for large batches, 4 (block = 256: FK over 256
 // threads, the column program dealt to the four waves) when the batch alone cannot fill the chip.
 template <bool kWriteJac, int WPI, bool kStream>
-__global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
+__global__ void __launch_bounds__(64 * WPI) __attribute__((amdgpu_waves_per_eu(5))) fkJacobianKernel(
     RigDev rig,
     ProblemDev pb,
     const float* __restrict__ theta, // [B][P]
@@ -53,7 +135,8 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     float* __restrict__ res, // [B][M] or null
     double* __restrict__ err, // [B] or null
     float* __restrict__ state, // [B][J][8] or null
-    const int32_t* __restrict__ done) { // [B] or null: skip finished instances
+    const int32_t* __restrict__ done, // [B] or null: skip finished instances
+    int zeroPhase) { // when the structurally zero columns are written: 0 first, 1 alternating, 2 last
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // one 20-float slot per joint, used in place: [0..7] local t,s,q -> world t,q,s ; [8..15] partial
   // rotations q1,q2 -> [8..16] rotation axes
@@ -68,19 +151,44 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   if (done != nullptr && done[b] != 0) {
     return;
   }
+  // workgroups go round-robin to the 8 XCDs and then to an XCD's CUs: bits 3.. pick the CU, bits 8..
+  // the slot on it -- both kinds of instance on every CU, alternating between neighbouring CUs
+  const bool zeroLast = zeroPhase == 2 || (zeroPhase == 1 && (((b >> 3) ^ (b >> 8)) & 1) != 0);
   const float* th = theta + size_t(b) * rig.P;
 
   // Everything the instance needs from global memory is requested up front, in ONE round of
   // independent loads: theta and the level/parent table (-> LDS), the first joint's transform
-  // rows and the constraint payload of the first 64 units (-> registers).  FK then runs on LDS.
+  // rows, the pre-rotations of the thread's first two joints and the constraint payload of the
+  // first 64 units (-> registers).  FK then runs on LDS, and -- when J is written -- nothing is
+  // loaded from global memory any more until the last column store has been issued: vmcnt is ONE
+  // in-order counter for loads and stores, so any wait for a load after the first store would
+  // drain all the stores issued before it (measured: the zero-column stores used to be waited for
+  // in full before FK began).
   const bool ell = rig.ptEll != nullptr;
   int4 rows[7];
   float ptOff[7];
-  if (ell && tid < rig.J) {
+  float preA[4] = {0.f, 0.f, 0.f, 1.f}, preB[4] = {0.f, 0.f, 0.f, 1.f}, offA[3] = {0.f, 0.f, 0.f};
+  if (tid < rig.J) {
+    if (ell) {
 #pragma unroll
-    for (int d = 0; d < 7; ++d) {
-      rows[d] = rig.ptEll[7 * tid + d];
-      ptOff[d] = rig.ptOffsets[7 * tid + d];
+      for (int d = 0; d < 7; ++d) {
+        rows[d] = rig.ptEll[7 * tid + d];
+        ptOff[d] = rig.ptOffsets[7 * tid + d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      preA[d] = rig.preRot[4 * tid + d];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      offA[d] = rig.offset[3 * tid + d];
+    }
+  }
+  if (tid + NT < rig.J) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      preB[d] = rig.preRot[4 * (tid + NT) + d];
     }
   }
   const bool needUnits = kWriteJac || res != nullptr || err != nullptr;
@@ -91,27 +199,15 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   for (int i = tid; i < rig.J; i += NT) {
     jl[i] = rig.jumpParent[i];
   }
-  if (kWriteJac) {
-    // structurally zero columns (disabled parameters, and parameters none of whose joints carries a
-    // constraint below it): they need no kinematics, so they are written first -- every element of J
-    // is written, and these stores are in flight while FK runs
-    float* jz = jac + size_t(b) * size_t(pb.M) * size_t(rig.P);
-    for (int u0 = 0; u0 < pb.U; u0 += 64) {
-      const int u = u0 + lane;
-      if (u < pb.U) {
-        for (int i = wave; i < pb.numZeroCols; i += WPI) {
-          store3(jz + size_t(pb.zeroCols[i]) * size_t(pb.M) + 3 * size_t(u), 0.f, 0.f, 0.f, kStream);
-        }
-      }
-    }
-  }
   __syncthreads();
   // local transforms of all joints at once (ParameterTransformT::apply + the theta-only part of
-  // JointStateT::set), then SkeletonStateT::set's parent-before-child sweep as a sweep over tree
-  // levels that only composes world = parent * local, then the rotation axes of all joints at once
+  // JointStateT::set); SkeletonStateT::set's parent-before-child sweep follows as pointer jumping
+  // that only composes world = parent * local, then the rotation axes of all joints at once
   if (ell) {
     if (tid < rig.J) {
-      fkLocalFromRows(rig, tid, rows, ptOff, thL, js + kJs * tid);
+      float jpv[7];
+      jointParamsFromRows(rows, ptOff, thL, jpv);
+      fkLocalFromParams(jpv, preA, offA, js + kJs * tid, js + kJs * tid + 8);
     }
     for (int j = tid + NT; j < rig.J; j += NT) {
 #pragma unroll
@@ -124,6 +220,28 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   } else {
     for (int j = tid; j < rig.J; j += NT) {
       fkLocalInPlace(rig, j, thL, js);
+    }
+  }
+  if (kWriteJac) {
+    // every load above has to have arrived before the first store (see the top of the kernel)
+    float zero = 0.f;
+    MMX_ARRIVED4(zero, preA[0], preA[1], preA[2], preA[3]);
+    MMX_ARRIVED4(zero, preB[0], preB[1], preB[2], preB[3]);
+    MMX_ARRIVED4(zero, uin0.a[0], uin0.a[1], uin0.a[2], uin0.a[3]);
+    MMX_ARRIVED4(zero, uin0.t[0], uin0.t[1], uin0.t[2], uin0.t[3]);
+    MMX_ARRIVED4(zero, uin0.joint, uin0.tin, uin0.cw, uin0.cw);
+    // structurally zero columns (disabled parameters, and parameters none of whose joints carries a
+    // constraint below it) need no kinematics (every element of J is still written).  Half of the
+    // instances write them right here, so that their stores keep HBM busy while FK runs; the
+    // other half writes them last: a wave cannot run ahead of the stores it has issued by more
+    // than the depth of the CU's store path, so if every wave began with these stores they would
+    // all sit here until the stores have drained and then all run FK with HBM idle.
+    // With several waves per instance the waves that hold no joint (72 joints: waves 2 and 3 of 4)
+    // write them while the others run FK.
+    if (!zeroLast) {
+      const int fkWaves = (rig.J + 63) >> 6;
+      const int w0 = (WPI > fkWaves && zeroPhase != 3) ? fkWaves : 0;
+      writeZeroColumns<kStream>(pb, jac + size_t(b) * size_t(pb.M) * size_t(rig.P), zero, lane, wave, w0, WPI - w0);
     }
   }
   __syncthreads();
@@ -171,7 +289,13 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   }
   __syncthreads();
   if (kWriteJac) {
-    for (int j = tid; j < rig.J; j += NT) {
+    if (tid < rig.J) {
+      fkAxesInPlaceQ(preA, tid, (jl[tid] >> 16) - 1, js);
+    }
+    if (tid + NT < rig.J) {
+      fkAxesInPlaceQ(preB, tid + NT, (jl[tid + NT] >> 16) - 1, js);
+    }
+    for (int j = tid + 2 * NT; j < rig.J; j += NT) { // rigs beyond 2 joints per thread: loads (and waits) here
       fkAxesInPlaceP(rig, j, (jl[j] >> 16) - 1, js);
     }
     __syncthreads();
@@ -188,69 +312,31 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
 
   double errAcc = 0.0;
   const size_t M = size_t(pb.M);
-  constexpr bool nt = kStream;
-  for (int u0 = 0; u0 < pb.U; u0 += 64) {
-    const int u = u0 + lane;
-    const Unit un = evalUnitFrom(pb, u0 == 0 ? uin0 : loadUnitInput(pb, b, u), js, u);
+  // the first 64 units are peeled out of the loop: their payload is already in registers, so there
+  // is no load -- hence no vmcnt wait -- between the zero-column stores and the column stores
+  {
+    const Unit un = evalUnitFrom(pb, uin0, js, lane);
     errAcc += double(un.werr);
     if (res != nullptr && un.valid && wave == 0) {
-      float* r = res + size_t(b) * M + 3 * size_t(u);
-      r[0] = un.sigma * un.f.x;
-      r[1] = un.sigma * un.f.y;
-      r[2] = un.sigma * un.f.z;
+      store3<false>(res + size_t(b) * M + 3 * size_t(lane), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
     }
     if (kWriteJac) {
-      float* jb = jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(u);
-      // (1) single-source rotation columns, grouped by joint: four records (one 128-byte run of
-      //     scalar loads) per trip; ancestor test and v - t_joint refreshed when the joint changes.
-      //     jc = derivScale * dfdv * (axis x off) ; jac.col(p) = jc * value
-      //     (joint_error_function-inl.h:265-278, joint_state.cpp:68-71)
-      int curJoint = -1;
-      bool anc = false;
-      F3 off{0.f, 0.f, 0.f};
-      for (int i0 = 4 * wave; i0 < pb.numJacRecs; i0 += 4 * WPI) {
-        JacRecDev rec[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          rec[k] = pb.jacRecs[i0 + k]; // wave-uniform
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const JacRecDev& r = rec[k];
-          const float* a = js + kJs * r.joint;
-          if (r.joint != curJoint) {
-            curJoint = r.joint;
-            anc = (r.tin <= un.tin) && (un.tin < r.tout);
-            off = un.isPoint ? un.v - F3{a[0], a[1], a[2]} : un.v;
-          }
-          const float* ax = a + 8 + 3 * (r.dof - 3);
-          const F3 g = cross(F3{ax[0], ax[1], ax[2]}, off);
-          const float w = anc ? r.weight : 0.f;
-          if (un.valid) {
-            float* o = jb + size_t(r.col) * M;
-            store3(o, (un.sigma * g.x) * w, (un.sigma * g.y) * w, (un.sigma * g.z) * w, nt);
-          }
-        }
-      }
-      // (2) every other non-empty column (shared parameters, translation / scale dofs): generic gather
-      for (int i = wave; i < pb.numMultiCols; i += WPI) {
-        const int p = pb.multiCols[i];
-        F3 acc{0.f, 0.f, 0.f};
-        const int e1 = pb.colStart[p + 1];
-        for (int e = pb.colStart[p]; e < e1; ++e) {
-          const ColumnSourceDev s = pb.colSources[e]; // wave-uniform
-          bool applies;
-          const F3 g = sourceDerivative(s, js, un, applies);
-          const float w = applies ? s.weight : 0.f;
-          acc.x += (un.sigma * g.x) * w;
-          acc.y += (un.sigma * g.y) * w;
-          acc.z += (un.sigma * g.z) * w;
-        }
-        if (un.valid) {
-          store3(jb + size_t(p) * M, acc.x, acc.y, acc.z, nt);
-        }
-      }
+      writeUnitColumns<WPI, kStream>(pb, js, un, jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(lane), M, wave);
     }
+  }
+  for (int u0 = 64; u0 < pb.U; u0 += 64) {
+    const int u = u0 + lane;
+    const Unit un = evalUnitFrom(pb, loadUnitInput(pb, b, u), js, u);
+    errAcc += double(un.werr);
+    if (res != nullptr && un.valid && wave == 0) {
+      store3<false>(res + size_t(b) * M + 3 * size_t(u), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
+    }
+    if (kWriteJac) {
+      writeUnitColumns<WPI, kStream>(pb, js, un, jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(u), M, wave);
+    }
+  }
+  if (kWriteJac && zeroLast) {
+    writeZeroColumns<kStream>(pb, jac + size_t(b) * M * size_t(rig.P), 0.f, lane, wave, 0, WPI);
   }
   if (err != nullptr) {
     const double e = waveReduceSum(errAcc);
@@ -1881,31 +1967,44 @@ hipError_t launchFkJacobian(
     hipEvent_t startEvent,
     hipEvent_t stopEvent) {
   const size_t lds = fkJacobianLdsBytes(rig.J, rig.P);
-  // one wave per instance fills the chip once B >> 256 CUs x ~24 resident waves; below that, four
-  // waves per instance shorten the per-instance critical path.  Large rigs are LDS-bound (a
-  // 300-joint instance needs 25 KB: six single-wave workgroups per CU), so they also take four
-  // waves per instance, which share one copy of the joint states.
-  const bool wide = pb.B < 2048 || lds > 12 * 1024; // measured: at B = 4096, J = 72 one wave per instance beats four
-  const bool streaming = pb.B <= 40000; // non-temporal column stores: see store3()
+  // Wavefronts per instance.  J-assembly: four waves share one instance (FK over 256 threads, the
+  // column program dealt to the waves) up to 40 000 instances per launch -- fewer instances are then
+  // in flight at a time (5 workgroups per CU instead of 20), and write bandwidth on this part
+  // falls with the footprint of the concurrently written regions (scripts/store_k.hip: 6.7 TB/s
+  // when a workgroup writes 4 KB and ends, 5.4 TB/s at 96 KB per workgroup).  Measured, same box:
+  // B = 4096: 95 -> 88 us, 16384: 335 -> 309 us, 32768: 632 -> 617 us, 65536: 1232 -> 1245 us;
+  // eight waves leave too few workgroups per CU to overlap FK with stores (4096: 113 us).
+  // Large rigs are LDS-bound (a 300-joint instance needs 25 KB), so they take four waves too.
+  // FK only (no J): one wave per instance from 2048 instances on (16 vs 23 us at 4096).
+  int wpi = (pb.B < 2048 || lds > 12 * 1024 || (jac != nullptr && pb.B <= 40000)) ? 4 : 1;
+  if (const char* e = getenv("MMX_JAC_WPI")) { // experiment switch: 1 or 4
+    wpi = e[0] == '4' ? 4 : 1;
+  }
+  bool streaming = true; // non-temporal column stores (measured better at every batch size once they were really emitted: see store3())
+  int zeroPhase = wpi == 1 ? 1 : 0; // one wave per instance: alternate; several: the waves without joints write them first
+  if (const char* e = getenv("MMX_JAC_NT")) { // experiment switches
+    streaming = e[0] == '1';
+  }
+  if (const char* e = getenv("MMX_JAC_ZERO_PHASE")) {
+    zeroPhase = e[0] - '0';
+  }
 #define MMX_FKJ(W_, WPI_, S_)                                                                                                  \
   hipExtLaunchKernelGGL(                                                                                                       \
-      (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done)
+      (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done, zeroPhase)
   if (jac != nullptr) {
-    if (wide) {
-      if (streaming) {
-        MMX_FKJ(true, 4, true);
-      } else {
+    if (!streaming) {
+      if (wpi == 4) {
         MMX_FKJ(true, 4, false);
-      }
-    } else {
-      if (streaming) {
-        MMX_FKJ(true, 1, true);
       } else {
         MMX_FKJ(true, 1, false);
       }
+    } else if (wpi == 4) {
+      MMX_FKJ(true, 4, true);
+    } else {
+      MMX_FKJ(true, 1, true);
     }
   } else {
-    if (wide) {
+    if (wpi == 4) {
       MMX_FKJ(false, 4, false);
     } else {
       MMX_FKJ(false, 1, false);
