@@ -52,6 +52,93 @@ __device__ __forceinline__ void store3(float* o, float x, float y, float z) {
 // table load after it from a scalar load into a vector load.
 #define MMX_ARRIVED4(dep_, a_, b_, c_, d_) asm("" : "+v"(dep_) : "v"(a_), "v"(b_), "v"(c_), "v"(d_))
 
+// The column program for rigs with more units than lanes: a lane carries up to kChunks units
+// (u = u0 + 64 c + lane) and a column is written chunk after chunk, back to back, so that the
+// pieces of a column (M * 4 bytes, not a multiple of a 128-byte line in general: 3600 B at cfg5)
+// meet in the write-combining L2 instead of reaching HBM as partial lines.  Plain stores for the
+// same reason.  Measured on the bare store pattern at cfg5 (scripts/store_cfg5.hip): chunk-outer
+// 3.1 TB/s (3.3 streaming), column-outer 5.6 TB/s (4.3 streaming).
+constexpr int kChunks = 6;
+struct UnitLite {
+  F3 v;
+  float sigma;
+  int tin;
+  bool isPoint, valid;
+};
+template <int WPI>
+__device__ __forceinline__ void
+writeUnitColumnsMulti(const ProblemDev& pb, const float* js, const UnitLite* un, float* jb, size_t M, int wave) {
+  int curJoint = -1;
+  bool anc[kChunks];
+  F3 off[kChunks];
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    anc[c] = false;
+    off[c] = F3{0.f, 0.f, 0.f};
+  }
+  for (int i0 = 4 * wave; i0 < pb.numJacRecs; i0 += 4 * WPI) {
+    JacRecDev rec[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rec[k] = pb.jacRecs[i0 + k]; // wave-uniform
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const JacRecDev& r = rec[k];
+      const float* a = js + kJs * r.joint;
+      if (r.joint != curJoint) {
+        curJoint = r.joint;
+        const F3 t{a[0], a[1], a[2]};
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+          anc[c] = (r.tin <= un[c].tin) && (un[c].tin < r.tout);
+          off[c] = un[c].isPoint ? un[c].v - t : un[c].v;
+        }
+      }
+      const float* axp = a + 8 + 3 * (r.dof - 3);
+      const F3 ax{axp[0], axp[1], axp[2]};
+      float* o = jb + size_t(r.col) * M;
+#pragma unroll
+      for (int c = 0; c < kChunks; ++c) {
+        const F3 g = cross(ax, off[c]);
+        const float w = anc[c] ? r.weight : 0.f;
+        if (un[c].valid) {
+          store3<false>(o + 192 * c, (un[c].sigma * g.x) * w, (un[c].sigma * g.y) * w, (un[c].sigma * g.z) * w);
+        }
+      }
+    }
+  }
+  for (int i = wave; i < pb.numMultiCols; i += WPI) {
+    const int p = pb.multiCols[i];
+    F3 acc[kChunks];
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+      acc[c] = F3{0.f, 0.f, 0.f};
+    }
+    const int e1 = pb.colStart[p + 1];
+    for (int e = pb.colStart[p]; e < e1; ++e) {
+      const ColumnSourceDev s = pb.colSources[e]; // wave-uniform
+#pragma unroll
+      for (int c = 0; c < kChunks; ++c) {
+        Unit u1;
+        u1.v = un[c].v, u1.tin = un[c].tin, u1.isPoint = un[c].isPoint;
+        bool applies;
+        const F3 g = sourceDerivative(s, js, u1, applies);
+        const float w = applies ? s.weight : 0.f;
+        acc[c].x += (un[c].sigma * g.x) * w;
+        acc[c].y += (un[c].sigma * g.y) * w;
+        acc[c].z += (un[c].sigma * g.z) * w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+      if (un[c].valid) {
+        store3<false>(jb + size_t(p) * M + 192 * c, acc[c].x, acc[c].y, acc[c].z);
+      }
+    }
+  }
+}
+
 // the structurally zero columns of an instance: lane = unit u writes rows 3u..3u+2 of each
 // (the columns are dealt to the waves w0 .. w0 + nw - 1 of the workgroup)
 template <bool kNt>
@@ -127,7 +214,7 @@ writeUnitColumns(const ProblemDev& pb, const float* js, const Unit& un, float* j
 // WPI = wavefronts per instance: 1 (block = 64) for large batches, 4 (block = 256: FK over 256
 // threads, the column program dealt to the four waves) when the batch alone cannot fill the chip.
 template <bool kWriteJac, int WPI, bool kStream>
-__global__ void __launch_bounds__(64 * WPI) __attribute__((amdgpu_waves_per_eu(5))) fkJacobianKernel(
+__global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     RigDev rig,
     ProblemDev pb,
     const float* __restrict__ theta, // [B][P]
@@ -143,6 +230,7 @@ __global__ void __launch_bounds__(64 * WPI) __attribute__((amdgpu_waves_per_eu(5
   float* js = smem;
   float* thL = js + ((kJs * rig.J + 3) & ~3); // [P] theta of this instance
   int* jl = reinterpret_cast<int*>(thL + ((rig.P + 3) & ~3)); // [J] (parent + 1) << 16 | (jump target + 1)
+  float* ul = reinterpret_cast<float*>(jl + ((rig.J + 3) & ~3)); // [U][5] evaluated units (v, sigma, tin), only when U > 64 and J is written
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform on purpose: it indexes the column program, which must stay on the scalar unit
@@ -153,6 +241,7 @@ __global__ void __launch_bounds__(64 * WPI) __attribute__((amdgpu_waves_per_eu(5
   }
   // workgroups go round-robin to the 8 XCDs and then to an XCD's CUs: bits 3.. pick the CU, bits 8..
   // the slot on it -- both kinds of instance on every CU, alternating between neighbouring CUs
+  const bool manyUnits = kWriteJac && pb.U > 64; // several 64-unit chunks: see the unit loop
   const bool zeroLast = zeroPhase == 2 || (zeroPhase == 1 && (((b >> 3) ^ (b >> 8)) & 1) != 0);
   const float* th = theta + size_t(b) * rig.P;
 
@@ -238,7 +327,7 @@ __global__ void __launch_bounds__(64 * WPI) __attribute__((amdgpu_waves_per_eu(5
     // all sit here until the stores have drained and then all run FK with HBM idle.
     // With several waves per instance the waves that hold no joint (72 joints: waves 2 and 3 of 4)
     // write them while the others run FK.
-    if (!zeroLast) {
+    if (!zeroLast && !manyUnits) {
       const int fkWaves = (rig.J + 63) >> 6;
       const int w0 = (WPI > fkWaves && zeroPhase != 3) ? fkWaves : 0;
       writeZeroColumns<kStream>(pb, jac + size_t(b) * size_t(pb.M) * size_t(rig.P), zero, lane, wave, w0, WPI - w0);
@@ -312,8 +401,61 @@ __global__ void __launch_bounds__(64 * WPI) __attribute__((amdgpu_waves_per_eu(5
 
   double errAcc = 0.0;
   const size_t M = size_t(pb.M);
-  // the first 64 units are peeled out of the loop: their payload is already in registers, so there
-  // is no load -- hence no vmcnt wait -- between the zero-column stores and the column stores
+  if (manyUnits) {
+    // More units than lanes (cfg5: 300): every unit is evaluated BEFORE the first column store --
+    // one unit per thread and trip, the result (v, sigma, DFS index) stashed in LDS -- so that the
+    // payload loads of the later chunks do not sit between column stores (each wait for one would
+    // drain the stores issued so far).  Then zero columns and column program per 64-unit chunk.
+    for (int u = tid; u < pb.U; u += NT) {
+      const Unit un = evalUnitFrom(pb, u == lane ? uin0 : loadUnitInput(pb, b, u), js, u);
+      errAcc += double(un.werr);
+      if (res != nullptr) {
+        store3<false>(res + size_t(b) * M + 3 * size_t(u), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
+      }
+      float* o = ul + 5 * u;
+      o[0] = un.v.x, o[1] = un.v.y, o[2] = un.v.z, o[3] = un.sigma, o[4] = __int_as_float(un.tin);
+    }
+    __syncthreads();
+    float* jz = jac + size_t(b) * M * size_t(rig.P);
+    // zero columns, column-outer as well (plain stores: see writeUnitColumnsMulti)
+    for (int i = wave; i < pb.numZeroCols; i += WPI) {
+      float* o = jz + size_t(pb.zeroCols[i]) * M;
+      for (int u = lane; u < pb.U; u += 64) {
+        store3<false>(o + 3 * size_t(u), 0.f, 0.f, 0.f);
+      }
+    }
+    for (int u0 = 0; u0 < pb.U; u0 += 64 * kChunks) {
+      UnitLite un[kChunks];
+#pragma unroll
+      for (int c = 0; c < kChunks; ++c) {
+        const int u = u0 + 64 * c + lane;
+        un[c].valid = u < pb.U;
+        un[c].isPoint = u < pb.Kp;
+        const float* o = ul + 5 * (un[c].valid ? u : 0);
+        un[c].v = F3{o[0], o[1], o[2]};
+        un[c].sigma = un[c].valid ? o[3] : 0.f;
+        un[c].tin = un[c].valid ? __float_as_int(o[4]) : -1;
+      }
+      writeUnitColumnsMulti<WPI>(pb, js, un, jz + 3 * size_t(u0 + lane), M, wave);
+    }
+    if (WPI > 1) { // the per-thread error shares are summed over the workgroup through LDS
+      __syncthreads();
+      const double e = waveReduceSum(errAcc);
+      double* red = reinterpret_cast<double*>(ul);
+      if (lane == 0) {
+        red[wave] = e;
+      }
+      __syncthreads();
+      errAcc = 0.0;
+      if (tid == 0) {
+        for (int w = 0; w < WPI; ++w) {
+          errAcc += red[w];
+        }
+      }
+    }
+  } else {
+  // the first 64 units: their payload is already in registers, so there is no load -- hence no
+  // vmcnt wait -- between the zero-column stores and the column stores
   {
     const Unit un = evalUnitFrom(pb, uin0, js, lane);
     errAcc += double(un.werr);
@@ -324,18 +466,16 @@ __global__ void __launch_bounds__(64 * WPI) __attribute__((amdgpu_waves_per_eu(5
       writeUnitColumns<WPI, kStream>(pb, js, un, jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(lane), M, wave);
     }
   }
-  for (int u0 = 64; u0 < pb.U; u0 += 64) {
+  for (int u0 = 64; u0 < pb.U; u0 += 64) { // (only without J: residual / error of the further chunks)
     const int u = u0 + lane;
     const Unit un = evalUnitFrom(pb, loadUnitInput(pb, b, u), js, u);
     errAcc += double(un.werr);
     if (res != nullptr && un.valid && wave == 0) {
       store3<false>(res + size_t(b) * M + 3 * size_t(u), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
     }
-    if (kWriteJac) {
-      writeUnitColumns<WPI, kStream>(pb, js, un, jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(u), M, wave);
-    }
   }
-  if (kWriteJac && zeroLast) {
+  }
+  if (kWriteJac && zeroLast && !manyUnits) {
     writeZeroColumns<kStream>(pb, jac + size_t(b) * M * size_t(rig.P), 0.f, lane, wave, 0, WPI);
   }
   if (err != nullptr) {
@@ -1950,8 +2090,9 @@ solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaIn
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (declared in mmx_kernels.hpp)
 // ---------------------------------------------------------------------------------------------
-size_t fkJacobianLdsBytes(int J, int P) {
-  return (((size_t(kJs) * size_t(J) + 3) & ~size_t(3)) + ((size_t(P) + 3) & ~size_t(3)) + size_t(J)) * sizeof(float);
+size_t fkJacobianLdsBytes(int J, int P, int U) {
+  const size_t unitStash = U > 64 ? 5 * size_t(U) : 0; // evaluated units of the multi-chunk J path
+  return (((size_t(kJs) * size_t(J) + 3) & ~size_t(3)) + ((size_t(P) + 3) & ~size_t(3)) + ((size_t(J) + 3) & ~size_t(3)) + unitStash) * sizeof(float);
 }
 
 hipError_t launchFkJacobian(
@@ -1966,7 +2107,7 @@ hipError_t launchFkJacobian(
     hipStream_t stream,
     hipEvent_t startEvent,
     hipEvent_t stopEvent) {
-  const size_t lds = fkJacobianLdsBytes(rig.J, rig.P);
+  const size_t lds = fkJacobianLdsBytes(rig.J, rig.P, pb.U);
   // Wavefronts per instance.  J-assembly: four waves share one instance (FK over 256 threads, the
   // column program dealt to the waves) up to 40 000 instances per launch -- fewer instances are then
   // in flight at a time (5 workgroups per CU instead of 20), and write bandwidth on this part

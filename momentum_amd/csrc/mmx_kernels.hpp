@@ -96,7 +96,7 @@ hipError_t launchFusedSolve(
     long long* dbgClk,
     hipStream_t stream);
 
-size_t fkJacobianLdsBytes(int J, int P);
+size_t fkJacobianLdsBytes(int J, int P, int U);
 size_t normalEquationsLdsBytes(int n);
 size_t choleskyStepLdsBytes(int n, int M);
 
