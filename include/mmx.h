@@ -234,14 +234,28 @@ typedef struct mmx_constraint_data {
  * POD mirror of SolverOptions + GaussNewtonSolverOptions
  * (momentum/solver/solver.h:19-34, gauss_newton_solver.h:17-59).
  */
+/*
+ * Backtracking rules of the reference's Gauss-Newton solvers (tau = 0.5, at most 10 trial steps, the
+ * last trial stays when none passes):
+ *   MMX_LINE_SEARCH_GAUSS_NEWTON  GaussNewtonSolverT::updateParameters (gauss_newton_solver.cpp:283-313):
+ *                                 accept when  e - e(alpha) >= alpha * 1e-3 * e
+ *   MMX_LINE_SEARCH_DIRECTIONAL   SubsetGaussNewtonSolverT::doIteration (subset_gauss_newton_solver.cpp:
+ *                                 117-142) and GaussNewtonSolverQRT::doIteration (gauss_newton_solver_qr.cpp:
+ *                                 126-149) -- the two solvers the batched driver builds
+ *                                 (pymomentum/tensor_ik/tensor_ik.cpp:142-158): accept when
+ *                                 e - e(alpha) >= 1e-4 * alpha * (J^T r . delta)
+ */
+#define MMX_LINE_SEARCH_NONE 0
+#define MMX_LINE_SEARCH_GAUSS_NEWTON 1
+#define MMX_LINE_SEARCH_DIRECTIONAL 2
+
 typedef struct mmx_gn_options {
   int32_t min_iterations; /* SolverOptions::minIterations (default 1) */
   int32_t max_iterations; /* SolverOptions::maxIterations (default 2) */
   float threshold; /* SolverOptions::threshold (default 1): converged when
                       |e_prev-e|/(|e|+FLT_MIN) <= threshold*FLT_EPSILON, solver.cpp:98-99 */
   float regularization; /* GaussNewtonSolverBaseOptions::regularization (default 0.05) */
-  int32_t do_line_search; /* GaussNewtonSolverBaseOptions::doLineSearch (default 0);
-                             Armijo backtracking gauss_newton_solver.cpp:283-313 */
+  int32_t do_line_search; /* MMX_LINE_SEARCH_* (default 0 = GaussNewtonSolverBaseOptions::doLineSearch false) */
   int32_t step_rule; /* MMX_STEP_* */
   /* LM schedule knobs (only read when step_rule == MMX_STEP_LM_SCHEDULE) */
   float lm_lambda_min; /* default 1e-6 */

@@ -164,12 +164,31 @@ struct SolverOptions {
   virtual ~SolverOptions() = default;
 };
 
-struct GaussNewtonSolverOptions : SolverOptions {
+// gauss_newton_solver.h:17-33
+struct GaussNewtonSolverBaseOptions : SolverOptions {
   float regularization = 0.05f;
   bool doLineSearch = false;
+  GaussNewtonSolverBaseOptions() = default;
+  /* implicit */ GaussNewtonSolverBaseOptions(const SolverOptions& base) : SolverOptions(base) {}
+};
+
+struct GaussNewtonSolverOptions : GaussNewtonSolverBaseOptions {
   bool useBlockJtJ = false; // accepted for source compatibility: both settings build the same system
   GaussNewtonSolverOptions() = default;
-  explicit GaussNewtonSolverOptions(const SolverOptions& base) : SolverOptions(base) {}
+  explicit GaussNewtonSolverOptions(const SolverOptions& base) : GaussNewtonSolverBaseOptions(base) {}
+};
+
+// subset_gauss_newton_solver.h:19-26 and gauss_newton_solver_qr.h:20-25: the two solvers the batched
+// driver builds (pymomentum/tensor_ik/tensor_ik.cpp:142-158).  Same normal equations as
+// GaussNewtonSolverT; their line search tests against the directional derivative
+// (MMX_LINE_SEARCH_DIRECTIONAL).
+struct SubsetGaussNewtonSolverOptions : GaussNewtonSolverBaseOptions {
+  SubsetGaussNewtonSolverOptions() = default;
+  /* implicit */ SubsetGaussNewtonSolverOptions(const SolverOptions& base) : GaussNewtonSolverBaseOptions(base) {}
+};
+struct GaussNewtonSolverQROptions : GaussNewtonSolverBaseOptions {
+  GaussNewtonSolverQROptions() = default;
+  /* implicit */ GaussNewtonSolverQROptions(const SolverOptions& base) : GaussNewtonSolverBaseOptions(base) {}
 };
 
 // Device-resident Skeleton + ParameterTransform.
@@ -534,7 +553,8 @@ class BatchedGaussNewtonSolver {
   BatchedGaussNewtonSolver(const SolverOptions& options, BatchedSkeletonSolverFunction* function) : fn_(function) {
     setOptions(options);
   }
-  std::string getName() const {
+  virtual ~BatchedGaussNewtonSolver() = default;
+  virtual std::string getName() const {
     return "GaussNewton";
   }
   void setOptions(const SolverOptions& options) { // gauss_newton_solver.cpp:37-46
@@ -542,9 +562,9 @@ class BatchedGaussNewtonSolver {
     opt_.min_iterations = int32_t(options.minIterations);
     opt_.max_iterations = int32_t(options.maxIterations);
     opt_.threshold = options.threshold;
-    if (const auto* d = dynamic_cast<const GaussNewtonSolverOptions*>(&options)) {
+    if (const auto* d = dynamic_cast<const GaussNewtonSolverBaseOptions*>(&options)) {
       opt_.regularization = d->regularization;
-      opt_.do_line_search = d->doLineSearch ? 1 : 0;
+      opt_.do_line_search = d->doLineSearch ? lineSearchRule() : MMX_LINE_SEARCH_NONE;
     }
   }
   void setEnabledParameters(const ParameterSet& ps) {
@@ -570,10 +590,42 @@ class BatchedGaussNewtonSolver {
     return status_;
   }
 
+ protected:
+  virtual int32_t lineSearchRule() const { // gauss_newton_solver.cpp:283-313
+    return MMX_LINE_SEARCH_GAUSS_NEWTON;
+  }
+
  private:
   BatchedSkeletonSolverFunction* fn_; // raw pointer like SolverT::solverFunction_ (solver.h:106)
   mmx_gn_options opt_{};
   std::vector<int32_t> iterations_, status_;
+};
+
+// SubsetGaussNewtonSolverT<float> / GaussNewtonSolverQRT<float> for every element of the batch: the
+// regularised normal equations of GaussNewtonSolverT (the QR solver factors [J; sqrt(lambda) I],
+// gauss_newton_solver_qr.cpp:75-77, which is the same least-squares problem), with the directional
+// line search both share (subset_gauss_newton_solver.cpp:117-142, gauss_newton_solver_qr.cpp:126-149).
+class BatchedSubsetGaussNewtonSolver : public BatchedGaussNewtonSolver {
+ public:
+  BatchedSubsetGaussNewtonSolver(const SolverOptions& options, BatchedSkeletonSolverFunction* function)
+      : BatchedGaussNewtonSolver(SolverOptions(options), function) {
+    setOptions(options); // the base constructor ran with the base class's rule
+  }
+  std::string getName() const override {
+    return "SubsetGaussNewton";
+  }
+
+ protected:
+  int32_t lineSearchRule() const override {
+    return MMX_LINE_SEARCH_DIRECTIONAL;
+  }
+};
+class BatchedGaussNewtonSolverQR : public BatchedSubsetGaussNewtonSolver {
+ public:
+  using BatchedSubsetGaussNewtonSolver::BatchedSubsetGaussNewtonSolver;
+  std::string getName() const override {
+    return "GaussNewtonQR";
+  }
 };
 
 } // namespace momentum_amd

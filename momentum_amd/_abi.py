@@ -289,7 +289,7 @@ class GnOptions(C.Structure):
             int(max_iterations),
             float(threshold),
             float(regularization),
-            int(bool(do_line_search)),
+            int(do_line_search),  # MMX_LINE_SEARCH_*: False/0 none, True/1 GaussNewtonSolverT rule, 2 SubsetGN / GN-QR rule
             int(step_rule),
             float(lm_lambda_min),
             float(lm_lambda_max),

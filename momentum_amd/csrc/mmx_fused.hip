@@ -1227,7 +1227,17 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
     } else if (!notPd && fp.doLineSearch) {
       // ---- GaussNewtonSolverT::updateParameters with doLineSearch (gauss_newton_solver.cpp:283-313):
       // Armijo backtracking, c1 = 1e-3, tau = 0.5, at most 10 trial steps; the last trial stays
+      // or SubsetGaussNewtonSolverT / GaussNewtonSolverQRT (subset_gauss_newton_solver.cpp:117-142,
+      // gauss_newton_solver_qr.cpp:126-149): c_1 = 1e-4 against the directional derivative J^T r . delta
       const float scaledError = 1e-3f * float(curError);
+      double gd = 0.0;
+      if (fp.doLineSearch == 2) {
+        float part = 0.f;
+        for (int c = tid; c < n; c += 256) {
+          part += s.g[c] * s.d0[c];
+        }
+        gd = double(blockSumF(s, part, tid));
+      }
       float scale = 1.f;
       for (int ls = 0; ls < 10; ++ls) {
         for (int i = tid; i < P; i += 256) {
@@ -1239,7 +1249,7 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
         }
         __syncthreads();
         const double eNew = blockError(rig, rv, pb, fv, s, s.dfull, b, tid);
-        if ((curError - eNew) >= double(scale * scaledError)) {
+        if ((curError - eNew) >= (fp.doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale * scaledError))) {
           break;
         }
         scale *= 0.5f;

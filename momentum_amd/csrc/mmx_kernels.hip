@@ -2032,11 +2032,24 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
     return;
   }
   const float scaledError = 1e-3f * float(curError);
+  double gd = 0.0; // SubsetGaussNewtonSolverT / GaussNewtonSolverQRT rule: J^T r . delta
+  if (sp.doLineSearch == 2) {
+    float part = 0.f;
+    for (int c = tid; c < n; c += 256) {
+      part += dl[c] * jtr[size_t(b) * n + c];
+    }
+    part = waveReduceSumF(part);
+    if (lane == 0) {
+      redF[wave] = part;
+    }
+    __syncthreads();
+    gd = (double(redF[0]) + double(redF[1])) + (double(redF[2]) + double(redF[3]));
+  }
   float scale = 1.f;
   for (int ls = 0; ls < 10; ++ls) {
     makeTrial(scale);
     const double eNew = trialError();
-    if ((curError - eNew) >= double(scale * scaledError)) {
+    if ((curError - eNew) >= (sp.doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale * scaledError))) {
       break;
     }
     scale *= 0.5f;

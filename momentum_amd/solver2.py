@@ -459,7 +459,18 @@ class GaussNewtonSolverOptions(GaussNewtonSolverBaseOptions):
         self.sparse_matrix_threshold = 200
 
 
+class GaussNewtonSolverQROptions(GaussNewtonSolverBaseOptions):
+    """character_solver/gauss_newton_solver_qr.h:20-25"""
+
+
+class SubsetGaussNewtonSolverOptions(GaussNewtonSolverBaseOptions):
+    """solver/subset_gauss_newton_solver.h:19-26"""
+
+
 class Solver:
+    #: MMX_LINE_SEARCH_* rule used when options.do_line_search is set
+    _line_search_rule = 1  # GaussNewtonSolverT::updateParameters (gauss_newton_solver.cpp:283-313)
+
     def __init__(self, solver_function: SkeletonSolverFunction, options: Optional[SolverOptions] = None):
         self.solver_function = solver_function
         self.options = options if options is not None else GaussNewtonSolverOptions()
@@ -484,7 +495,7 @@ class Solver:
         pb.set_enabled(self._enabled if self._enabled is not None else np.ones(fn.get_num_parameters(), np.uint8))
         o = self.options
         opt = GnOptions.make(min_iterations=o.min_iterations, max_iterations=o.max_iterations, threshold=o.threshold,
-                             regularization=getattr(o, "regularization", 0.05), do_line_search=bool(getattr(o, "do_line_search", False)))  # fmt: skip
+                             regularization=getattr(o, "regularization", 0.05), do_line_search=self._line_search_rule if getattr(o, "do_line_search", False) else 0)  # fmt: skip
         out = pb.solve(torch.from_numpy(mp.copy()).to(pb.device), opt, want_history=True)
         it = out["iterations"].cpu().numpy()
         h = out["error_history"].cpu().numpy()
@@ -499,11 +510,17 @@ class GaussNewtonSolver(Solver):
 
 
 class GaussNewtonSolverQR(Solver):
-    """Solves the same regularised normal equations as GaussNewtonSolverQRT
-    (character_solver/gauss_newton_solver_qr.cpp:50-150) -- on the GPU by the refined Cholesky step."""
+    """Solves the same regularised least-squares problem as GaussNewtonSolverQRT
+    (character_solver/gauss_newton_solver_qr.cpp:50-150: QR of [J; sqrt(lambda) I]) -- on the GPU by
+    the refined Cholesky step -- with that solver's line search (:126-149, against the directional
+    derivative J^T r . delta, c_1 = 1e-4)."""
+
+    _line_search_rule = 2
 
 
 class SubsetGaussNewtonSolver(Solver):
-    """The Gauss-Newton step of SubsetGaussNewtonSolverT (solver/subset_gauss_newton_solver.cpp:72-145)
-    on the subset given to `set_enabled_parameters` (same normal equations; the line search is
-    GaussNewtonSolverT's)."""
+    """SubsetGaussNewtonSolverT (solver/subset_gauss_newton_solver.cpp:72-145) on the subset given to
+    `set_enabled_parameters`: same normal equations as GaussNewtonSolverT, line search against the
+    directional derivative (:117-142)."""
+
+    _line_search_rule = 2

@@ -1252,7 +1252,7 @@ struct Options {
   int maxIterations = 2;
   float threshold = 1.f;
   float regularization = 0.05f;
-  bool doLineSearch = false;
+  int doLineSearch = 0; // 0 none, 1 GaussNewtonSolverT rule, 2 SubsetGaussNewtonSolverT / GaussNewtonSolverQRT rule
   bool useBlockJtJ = false;
   int stepRule = 0; // 0 = fixed lambda (reference), 1 = LM gain-ratio schedule (build's own)
   float lmLambdaMin = 1e-6f, lmLambdaMax = 1e6f, lmUp = 4.f, lmDown = 0.5f;
@@ -1334,6 +1334,28 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
       if (!opt.doLineSearch) {
         for (int i = 0; i < P; ++i) {
           params[i] -= delta[i]; // skeleton_solver_function.cpp:158
+        }
+      } else if (opt.doLineSearch == 2) {
+        // SubsetGaussNewtonSolverT::doIteration (subset_gauss_newton_solver.cpp:117-142) ==
+        // GaussNewtonSolverQRT::doIteration (gauss_newton_solver_qr.cpp:126-149): sufficient decrease
+        // against the true directional derivative, float c_1 / tau / alpha
+        T gd = T(0);
+        for (int s = 0; s < n; ++s) {
+          gd += out.lastJtr[s] * g[s]; // subsetGradient_ . subsetDelta_  (g holds the solved step here)
+        }
+        const double innerProd = -double(gd);
+        const float c1 = 1e-4f, tau = 0.5f;
+        float alpha = 1.0f;
+        const std::vector<T> orig = params;
+        for (int ls = 0; ls < 10 && std::fpclassify(alpha) == FP_NORMAL; ++ls) {
+          for (int i = 0; i < P; ++i) {
+            params[i] = orig[i] - T(alpha) * delta[i];
+          }
+          const double errorNew = fn.getError(params.data());
+          if ((error - errorNew) >= c1 * alpha * -innerProd) {
+            break;
+          }
+          alpha = alpha * tau;
         }
       } else {
         const T kC1 = T(1e-3), kTau = T(0.5);

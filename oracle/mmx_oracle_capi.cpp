@@ -97,7 +97,7 @@ Options makeOptions(const mmx_gn_options* o, int useBlockJtJ) {
   r.maxIterations = o->max_iterations;
   r.threshold = o->threshold;
   r.regularization = o->regularization;
-  r.doLineSearch = o->do_line_search != 0;
+  r.doLineSearch = o->do_line_search;
   r.useBlockJtJ = useBlockJtJ != 0;
   r.stepRule = o->step_rule;
   r.lmLambdaMin = o->lm_lambda_min;

@@ -160,6 +160,21 @@ int main() {
       ++bad;
     }
   }
+  // the two solvers the batched driver builds (tensor_ik.cpp:142-158), with their line search
+  {
+    SubsetGaussNewtonSolverOptions so(opt);
+    so.doLineSearch = true;
+    BatchedSubsetGaussNewtonSolver subset(so, &fn);
+    GaussNewtonSolverQROptions qo(opt);
+    qo.doLineSearch = true;
+    BatchedGaussNewtonSolverQR qr(qo, &fn);
+    std::vector<float> ta(B * P, 0.f), tb(B * P, 0.f);
+    const std::vector<double> ea = subset.solve(ta), eb = qr.solve(tb);
+    std::printf("%s / %s with line search: error %.3g / %.3g\n", subset.getName().c_str(), qr.getName().c_str(), ea[0], eb[0]);
+    if (subset.getName() != "SubsetGaussNewton" || qr.getName() != "GaussNewtonQR" || ta != tb || !(ea[0] < 1e-3 * e0[0])) {
+      ++bad;
+    }
+  }
   std::printf(bad == 0 ? "OK\n" : "FAIL\n");
   return bad == 0 ? 0 : 1;
 }

@@ -205,7 +205,7 @@ def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
 
 
 @pytest.mark.parametrize("path", ["fused", "three_kernel"])
-@pytest.mark.parametrize("mode", ["line_search", "lm_schedule"])
+@pytest.mark.parametrize("mode", ["line_search", "line_search_directional", "lm_schedule"])
 def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, monkeypatch):
     """GaussNewtonSolverT with doLineSearch (gauss_newton_solver.cpp:283-313) and the LM gain-ratio
     schedule of BASELINE configs[2] (the lambda form of trust_region_qr.cpp:244-268; no direct
@@ -220,6 +220,8 @@ def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, m
     rh, pb = _gpu_problem(torch, rig, cons, B)
     if mode == "line_search":
         opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, do_line_search=True)
+    elif mode == "line_search_directional":  # SubsetGaussNewtonSolverT / GaussNewtonSolverQRT rule
+        opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, do_line_search=2)
     else:
         opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
@@ -235,9 +237,45 @@ def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, m
     assert np.all(rel <= tol), (rel, tol)
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
-    if mode == "line_search":
+    if mode.startswith("line_search"):
         assert np.all(np.diff(h, axis=1) <= 1e-6 * np.abs(h[:, :-1]) + 1e-12)  # monotone
     assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+
+
+@pytest.mark.parametrize("path", ["fused", "three_kernel"])
+@pytest.mark.parametrize("rule", [1, 2])
+def test_line_search_backtracking_matches_oracle(torch_cuda, orc, rule, path, monkeypatch):
+    """Starts from which the full Gauss-Newton step overshoots (3 rad away, lambda = 0.01): the
+    backtracking itself -- trial errors, accept tests of GaussNewtonSolverT (rule 1,
+    gauss_newton_solver.cpp:283-313) and of SubsetGaussNewtonSolverT / GaussNewtonSolverQRT (rule 2,
+    subset_gauss_newton_solver.cpp:117-142) -- against the oracle.  An accept test is a branch on a
+    difference of errors: where the oracle's own float build takes another branch than its double
+    build the instance is only required to have decreased its error."""
+    torch = torch_cuda
+    if path == "three_kernel":
+        monkeypatch.setenv("MMX_SOLVER", "v1")
+    rig, pp, op, _ = _case("humanoid72_cfg2")
+    B = 48
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=4242, perturb=3.0)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=3, max_iterations=3, regularization=0.01, do_line_search=rule)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    ref32 = orc.solve_batch(rig, cons, th0, opt, dtype="f32")
+    plain = orc.solve_batch(rig, cons, th0, GnOptions.make(min_iterations=3, max_iterations=3, regularization=0.01), dtype="f64")
+    th = out["theta"].cpu().numpy()
+    scale = np.maximum(1.0, np.abs(ref["theta"]).max(axis=1))
+    d = np.abs(th - ref["theta"]).max(axis=1) / scale
+    stable = np.abs(ref32["theta"] - ref["theta"]).max(axis=1) / scale <= 1e-3  # same branches in float and double
+    backtracked = np.abs(plain["theta"] - ref["theta"]).max(axis=1) > 1e-6
+    assert np.count_nonzero(stable & backtracked) >= 8  # the case does exercise the backtracking
+    # lambda = 0.01 and steps of several radians: bounded by the float oracle's own distance
+    tol = np.maximum(2e-4, 4.0 * np.abs(ref32["theta"] - ref["theta"]).max(axis=1) / scale)
+    assert np.all(d[stable] <= tol[stable]), (d[stable], tol[stable])
+    h = out["error_history"].cpu().numpy()
+    assert np.all(h[:, -1] <= h[:, 0])
+    e_gpu = np.array([orc.get_error(rig, cons.instance(b), th[b], "f64") for b in range(B)])
+    assert np.all(e_gpu[~stable] <= h[~stable, 0])
 
 
 def test_solve_convergence_bookkeeping_and_determinism(torch_cuda, orc):
@@ -387,15 +425,17 @@ def test_config3_full_size_lm_schedule_properties(torch_cuda, orc):
 
 def test_tensor_ik_default_options(torch_cuda, orc):
     """The batch driver's defaults (pymomentum/tensor_ik/solver_options.h:28-37): levmar_lambda =
-    0.01, minIter = 4, maxIter = 50, threshold = 10, lineSearch = true (its default linear solver,
-    QR, solves the same regularised normal equations as the Cholesky path).  Instances stop at
+    0.01, minIter = 4, maxIter = 50, threshold = 10, lineSearch = true.  Its default linear solver,
+    QR (GaussNewtonSolverQRT), solves the same regularised normal equations as the Cholesky choice
+    (SubsetGaussNewtonSolverT), and both use the directional line search (tensor_ik.cpp:142-158;
+    MMX_LINE_SEARCH_DIRECTIONAL).  Instances stop at
     their own iteration; the converged poses must agree with the oracle's double solve."""
     torch = torch_cuda
     rig, pp, op, B = _case("humanoid72_cfg2")
     B = 8
     cons, th0, ths = make_problem(rig, pp, op, B, seed=2024, perturb=0.3)
     rh, pb = _gpu_problem(torch, rig, cons, B)
-    opt = GnOptions.make(min_iterations=4, max_iterations=50, threshold=10.0, regularization=0.01, do_line_search=True)
+    opt = GnOptions.make(min_iterations=4, max_iterations=50, threshold=10.0, regularization=0.01, do_line_search=2)
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
     it, itref = out["iterations"].cpu().numpy(), ref["iterations"]

@@ -232,6 +232,51 @@ def test_gn_variants_agree_all_joint_constraints(orc, dtype):
     assert np.array_equal(a["error_history"], a2["error_history"])
 
 
+def test_subset_and_qr_solver_line_search_rule(orc):
+    """MMX_LINE_SEARCH_DIRECTIONAL = the backtracking of SubsetGaussNewtonSolverT / GaussNewtonSolverQRT
+    (subset_gauss_newton_solver.cpp:117-142, gauss_newton_solver_qr.cpp:126-149; the solvers the batched
+    driver builds, tensor_ik.cpp:142-158): accept alpha when e - e(alpha) >= 1e-4 * alpha * (J^T r . delta).
+    One iteration of the oracle against an independent numpy restatement built from the oracle's own
+    J / r / error evaluations, on starts where the full step overshoots."""
+    from momentum_amd import humanoid72_landmark_joints
+
+    rig = make_humanoid72()
+    lm = humanoid72_landmark_joints(rig)
+    B = 8
+    cons, th0, ths = make_problem(rig, lm, lm, B, seed=4242, perturb=0.8)
+    lam = 1e-3
+    iters = 3
+    opt1 = GnOptions.make(min_iterations=iters, max_iterations=iters, regularization=lam, do_line_search=2)
+    backtracked = 0
+    for b in range(B):
+        c = cons.instance(b)
+        th = th0[b].astype(np.float64)
+        for _ in range(iters):
+            Jm, r, e0 = orc.eval_jacobian(rig, c, th, dtype="f64")
+            Jm, r = np.asarray(Jm, np.float64), np.asarray(r, np.float64)
+            g = Jm.T @ r
+            delta = np.linalg.solve(Jm.T @ Jm + lam * np.eye(Jm.shape[1]), g)
+            gd = float(g @ delta)
+            alpha = np.float32(1.0)
+            for k in range(10):
+                trial = th - float(alpha) * delta
+                if e0 - orc.get_error(rig, c, trial, "f64") >= float(np.float32(1e-4) * alpha) * gd:
+                    break
+                alpha = np.float32(alpha * np.float32(0.5))
+            backtracked += int(alpha < 1.0)
+            th = trial
+        got = orc.solve(rig, c, th0[b], opt1, dtype="f64")  # (in f32 the accept decisions of such starts may flip)
+        assert np.abs(got["theta"] - th).max() <= 1e-5 * max(1.0, np.abs(th).max()), b  # (lambda = 1e-3: cond ~ 1e6)
+    assert backtracked >= 3  # the case does exercise the backtracking
+    # the three rules end at comparable errors (momentum/test/character_solver/solver_test.cpp:105-120
+    # compares SubsetGN / GN / GN-QR this way)
+    errs = []
+    for rule in (1, 2):
+        o = GnOptions.make(min_iterations=4, max_iterations=40, threshold=1000.0, regularization=0.05, do_line_search=rule)
+        errs.append(orc.solve_batch(rig, cons, th0, o, dtype="f64")["error"])
+    assert np.all(errs[1] <= 1.001 * errs[0] + 0.001) and np.all(errs[0] <= 1.001 * errs[1] + 0.001)
+
+
 def test_solve_returns_stale_error_and_converges(orc):
     # solver.cpp:126-127: the returned error is the objective at theta BEFORE the last step
     rig = make_humanoid72()
