@@ -241,6 +241,12 @@ def main() -> None:
         fill = torch.empty(bytes_per_launch // 4, dtype=torch.float32, device=dev)
         fill_ms = timed(lambda: fill.zero_(), 5)
         extra["fill_same_bytes_gbs"] = bytes_per_launch / (fill_ms * 1e-3) / 1e9
+        # the same stores (layout, workgroup shape, width) without any kinematics: what the write
+        # pattern of a column-major J per instance allows on this box
+        for _ in range(2):
+            pb.store_pattern_kernel_ms(fill)
+        sp_ms = float(np.mean([pb.store_pattern_kernel_ms(fill) for _ in range(5)]))
+        extra["store_pattern_gbs"] = B * 4 * M * P / (sp_ms * 1e-3) / 1e9
         del fill
         BL = 32768
         if args.config == "cfg2" and B < BL:

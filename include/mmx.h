@@ -361,6 +361,15 @@ int32_t mmx_eval_jacobian_timed(
     float* kernel_ms);
 
 /*
+ * Profiling aid: the store pattern of the J-assembly kernel on its own -- every element of
+ * jac_dev [B][M*P] is written with the same stores, workgroup shape and column-major layout, but no
+ * kinematics.  *kernel_ms = duration of that kernel (events on its dispatch packet).  The bandwidth
+ * it reaches is what the write pattern allows on the box at hand; bench.py reports it next to the
+ * J-assembly figure (roofline.store_pattern_gbs).  Problems with position / orientation rows only.
+ */
+int32_t mmx_debug_store_pattern(mmx_problem* problem, float* jac_dev, void* stream, float* kernel_ms);
+
+/*
  * Forward pass only.  Replaces SkeletonStateT<T>(params, skeleton)
  * (skeleton_state.cpp:22-28,87-121).  state_dev [B][J][8] =
  * (tx,ty,tz, qx,qy,qz,qw, s) world transforms (the layout of

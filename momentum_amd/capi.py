@@ -26,7 +26,7 @@ SYMBOLS = [
     "mmx_gn_options_default", "mmx_abi_version", "mmx_last_error", "mmx_device_count",
     "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
-    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_eval_jacobian", "mmx_eval_jacobian_timed",
+    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
 ]  # fmt: skip
@@ -70,6 +70,7 @@ def lib() -> C.CDLL:
     L.mmx_problem_set_constraints.argtypes = [vp, C.POINTER(ConstraintData), vp]
     L.mmx_eval_jacobian.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.mmx_eval_jacobian_timed.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(C.c_float)]
+    L.mmx_debug_store_pattern.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
     L.mmx_eval_skeleton_state.argtypes = [vp, vp, vp, vp]
     L.mmx_eval_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mmx_solve.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
@@ -274,6 +275,12 @@ class Problem:
         ms = C.c_float(0.0)
         _check(lib().mmx_eval_jacobian_timed(self._h, _dev(theta), _dev(jac), _dev(res), _dev(err), _abi.MMX_LAYOUT_COL_MAJOR,
                                              _stream_ptr(), C.byref(ms)))  # fmt: skip
+        return float(ms.value)
+
+    def store_pattern_kernel_ms(self, jac) -> float:
+        """Duration (ms) of the store-only counterpart of the J-assembly kernel (mmx_debug_store_pattern)."""
+        ms = C.c_float(0.0)
+        _check(lib().mmx_debug_store_pattern(self._h, _dev(jac), _stream_ptr(), C.byref(ms)))
         return float(ms.value)
 
     def skeleton_state(self, theta):

@@ -1237,9 +1237,41 @@ int32_t mmx_eval_jacobian_timed(
   if (err == hipSuccess) {
     err = hipEventElapsedTime(kernel_ms, e0, e1);
   }
-  hipEventDestroy(e0);
+  (void)hipEventDestroy(e0);
   if (e1 != nullptr) {
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e1);
+  }
+  MMX_HIP(err);
+  return MMX_OK;
+}
+
+int32_t mmx_debug_store_pattern(mmx_problem* pb, float* jac_dev, void* stream, float* kernel_ms) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (jac_dev == nullptr || kernel_ms == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "jac / kernel_ms is null");
+  }
+  if (pb->dev.M != pb->dev.rowsJoint || pb->dev.M != 3 * pb->dev.U) {
+    return fail(MMX_ERR_UNSUPPORTED, "store pattern: position / orientation rows only");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  MMX_HIP(hipEventCreate(&e0));
+  hipError_t err = hipEventCreate(&e1);
+  if (err == hipSuccess) {
+    err = mmx::launchStorePattern(jac_dev, pb->B, pb->dev.M, pb->rig->dev.P, static_cast<hipStream_t>(stream), e0, e1);
+  }
+  if (err == hipSuccess) {
+    err = hipEventSynchronize(e1);
+  }
+  if (err == hipSuccess) {
+    err = hipEventElapsedTime(kernel_ms, e0, e1);
+  }
+  (void)hipEventDestroy(e0);
+  if (e1 != nullptr) {
+    (void)hipEventDestroy(e1);
   }
   MMX_HIP(err);
   return MMX_OK;

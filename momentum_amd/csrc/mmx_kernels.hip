@@ -2103,6 +2103,34 @@ solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaIn
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (declared in mmx_kernels.hpp)
 // ---------------------------------------------------------------------------------------------
+// Profiling aid: the store pattern of J-assembly without any kinematics -- one workgroup of `waves`
+// wavefronts per instance writes the instance's column-major M x P block column by column, lane u the
+// rows 3u..3u+2 (the same 12-byte stores, streaming when the unit count fits one chunk, plain and
+// chunk after chunk otherwise, like fkJacobianKernel).  What this reaches is the ceiling the write
+// pattern itself sets for the graded kernel on the box at hand (bench.py: roofline.store_pattern_gbs).
+template <bool kNt>
+__global__ void __launch_bounds__(256) storePatternKernel(float* __restrict__ jac, int M, int P, int waves) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* jb = jac + size_t(blockIdx.x) * size_t(M) * size_t(P);
+  const float v = float(blockIdx.x);
+  const int U = M / 3;
+  for (int c = wave; c < P; c += waves) {
+    for (int u = lane; u < U; u += 64) {
+      store3<kNt>(jb + size_t(c) * M + 3 * size_t(u), v, v, v);
+    }
+  }
+}
+
+hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent) {
+  const int waves = B <= 40000 ? 4 : 1; // launchFkJacobian's choice for J-assembly
+  if (M / 3 <= 64) {
+    hipExtLaunchKernelGGL((storePatternKernel<true>), dim3(B), dim3(64 * waves), 0, stream, startEvent, stopEvent, 0, jac, M, P, waves);
+  } else {
+    hipExtLaunchKernelGGL((storePatternKernel<false>), dim3(B), dim3(256), 0, stream, startEvent, stopEvent, 0, jac, M, P, 4);
+  }
+  return hipGetLastError();
+}
+
 size_t fkJacobianLdsBytes(int J, int P, int U) {
   const size_t unitStash = U > 64 ? 5 * size_t(U) : 0; // evaluated units of the multi-chunk J path
   return (((size_t(kJs) * size_t(J) + 3) & ~size_t(3)) + ((size_t(P) + 3) & ~size_t(3)) + ((size_t(J) + 3) & ~size_t(3)) + unitStash) * sizeof(float);

@@ -97,6 +97,8 @@ hipError_t launchFusedSolve(
     hipStream_t stream);
 
 size_t fkJacobianLdsBytes(int J, int P, int U);
+// store-only counterpart of the J-assembly kernel (profiling aid; see storePatternKernel)
+hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent);
 size_t normalEquationsLdsBytes(int n);
 size_t choleskyStepLdsBytes(int n, int M);
 
