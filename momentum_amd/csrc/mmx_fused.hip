@@ -637,7 +637,16 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
   if (MODE == 2) {
     clkLast = clock64();
   }
+  const int tidOuter = tid;
   for (int it = 0; it < fp.maxIterations; ++it) {
+    // Opaque per-iteration copies of the thread index: everything derived from them (tile
+    // addresses, row assignments, run boundaries ...) is recomputed where it is used instead of
+    // being hoisted out of the iteration loop, where those per-thread invariants overflowed the
+    // register budget of three workgroups per CU and were reloaded from scratch at ~140 sites.
+    int tid = tidOuter;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the constraint payload of this thread's unit is requested before FK so that its HBM latency
     // hides behind it (one round trip per iteration instead of two)
     const UnitInput uin0 = loadUnitInput(pb, b, tid < U ? tid : U);
@@ -913,9 +922,13 @@ __global__ void __launch_bounds__(256, 3) fusedSolveKernel(
             a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
           }
           if (identLane) {
+            // (the opaque copy keeps the compiler from hoisting these sixteen per-lane constants out
+            // of the iteration loop, where they ended up in scratch and were reloaded for every panel)
+            int vr = vrow;
+            asm volatile("" : "+v"(vr));
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-              a[c] = c == vrow ? 1.f : 0.f;
+              a[c] = c == vr ? 1.f : 0.f;
             }
           }
         }
