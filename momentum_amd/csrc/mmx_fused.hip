@@ -459,8 +459,10 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
 }
 
 // MODE 0: production; 1: also dump H / g of the first iteration (parity hook); 2: per-phase clocks
+// Workgroups per CU follow the LDS footprint (tiles: 1 KB each): three up to NB = 6, two up to NB = 8,
+// one beyond -- the register budget is set to match, so the wide systems do not spill.
 template <int NB, int MODE>
-__global__ void __launch_bounds__(256, 3) fusedSolveKernel(
+__global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
