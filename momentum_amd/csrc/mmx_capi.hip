@@ -1498,10 +1498,10 @@ int32_t mmx_solve(
     long long h[8];
     MMX_HIP(hipMemcpyAsync(h, sp.clk, sizeof(h), hipMemcpyDeviceToHost, s));
     MMX_HIP(hipStreamSynchronize(s));
-    static const char* names[6] = {"load H", "factor", "solve", "refine: w = r - J d", "refine: rho = J^T w", "refine: solve"};
+    static const char* names[8] = {"load H / fence", "factor (in-HBM: write-back + trailing)", "solve", "refine: w = r - J d", "refine: rho = J^T w", "refine: solve", "factor: panel load (in-HBM)", "factor: panel chain (in-HBM)"};
     fprintf(stderr, "[mmx phase clocks, choleskyStepKernel block 0, all iterations] n = %d\n", n);
-    for (int i = 0; i < 6; ++i) {
-      fprintf(stderr, "  %-22s %10lld\n", names[i], h[i]);
+    for (int i = 0; i < 8; ++i) {
+      fprintf(stderr, "  %-40s %10lld\n", names[i], h[i]);
     }
   }
   return MMX_OK;

@@ -1610,6 +1610,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
   }
   __threadfence();
   __syncthreads();
+  long long tclk = clock64();
   auto Hval = [&](int r, int c) -> float { // the padded matrix; the load itself is unconditional
     const float v = H[size_t(min(r, n - 1)) * n + min(c, n - 1)]; // (clamped: independent loads stay in flight together)
     return (r < n && c < n) ? v : (r == c ? 1.f : 0.f);
@@ -1629,6 +1630,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
       }
     }
     __syncthreads();
+    MMX_SCLK(6)
     // (b) panel factorisation (see mmx_fused.hip phase H for the scheme)
     {
       float* Dk = pan;
@@ -1702,6 +1704,7 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
       }
       __syncthreads();
     }
+    MMX_SCLK(7)
     // (c) owners write the factored tiles back (L) and update their trailing tiles
     for (int I = k; I < NB; ++I) {
       if ((tileIndex(I, k) & 3) == wave) {
@@ -1715,32 +1718,74 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
         }
       }
     }
-    for (int Jc = k + 1; Jc < NB; ++Jc) {
-      for (int I = Jc; I < NB; ++I) {
-        if ((tileIndex(I, Jc) & 3) != wave) {
-          continue;
-        }
-        const float4 av = ldsRow4(pan + 256 * (I - k), lane & 15, lane >> 4);
-        const float4 bv = ldsRow4(pan + 256 * (Jc - k), lane & 15, lane >> 4);
-        v4f c;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          c[q] = Hval(16 * I + 4 * (lane >> 4) + q, 16 * Jc + (lane & 15));
-        }
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 16 * I + 4 * (lane >> 4) + q, cc = 16 * Jc + (lane & 15);
-          if (r < n && cc < n) {
-            H[size_t(r) * n + cc] = c[q];
+    // Trailing update C_IJ -= L_Ik L_Jk^T of the wave's own tiles, eight tiles per trip: the loads of
+    // the eight go out together, then the MFMAs, then the stores.  One tile per trip made every trip
+    // a full global round trip, and -- vmcnt being one in-order counter for loads and stores -- the
+    // wait for a tile's loads also waited for the previous tile's stores to be acknowledged.
+    {
+      // next trailing tile (row-major over the lower triangle, columns > k) that this wave owns
+      auto nextOwned = [&](int& I, int& Jc) {
+        do {
+          if (++Jc > I) {
+            ++I;
+            Jc = k + 1;
           }
+        } while (I < NB && (tileIndex(I, Jc) & 3) != wave);
+      };
+      constexpr int kTb = 8;
+      int I0 = k + 1, J0 = k;
+      nextOwned(I0, J0);
+      while (I0 < NB) {
+        int tI[kTb], tJ[kTb];
+        tI[0] = I0, tJ[0] = J0;
+#pragma unroll
+        for (int t = 1; t < kTb; ++t) {
+          tI[t] = tI[t - 1], tJ[t] = tJ[t - 1];
+          if (tI[t] < NB) {
+            nextOwned(tI[t], tJ[t]);
+          }
+        }
+        v4f c[kTb];
+#pragma unroll
+        for (int t = 0; t < kTb; ++t) {
+          if (tI[t] < NB) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              c[t][q] = Hval(16 * tI[t] + 4 * (lane >> 4) + q, 16 * tJ[t] + (lane & 15));
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < kTb; ++t) {
+          if (tI[t] < NB) {
+            const float4 av = ldsRow4(pan + 256 * (tI[t] - k), lane & 15, lane >> 4);
+            const float4 bv = ldsRow4(pan + 256 * (tJ[t] - k), lane & 15, lane >> 4);
+            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c[t], 0, 0, 0);
+            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c[t], 0, 0, 0);
+            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c[t], 0, 0, 0);
+            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c[t], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < kTb; ++t) {
+          if (tI[t] < NB) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = 16 * tI[t] + 4 * (lane >> 4) + q, cc = 16 * tJ[t] + (lane & 15);
+              if (r < n && cc < n) {
+                H[size_t(r) * n + cc] = c[t][q];
+              }
+            }
+          }
+        }
+        I0 = tI[kTb - 1], J0 = tJ[kTb - 1];
+        if (I0 < NB) {
+          nextOwned(I0, J0);
         }
       }
     }
     __syncthreads(); // the panel buffer is reused by the next block column
+    MMX_SCLK(1)
   }
   __threadfence(); // L was written by four waves; the substitutions read it from any thread
   __syncthreads();
@@ -1820,9 +1865,11 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
       __syncthreads();
     }
   };
+  MMX_SCLK(0)
   if (!bad) {
     solve(d0);
   }
+  MMX_SCLK(2)
   for (int rf = 0; rf < 3 && !bad && sp.refine; ++rf) { // see choleskyStepKernel
     const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
     const float* rb = res + size_t(b) * size_t(M);
@@ -1831,13 +1878,32 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
     const bool vec4 = (M & 3) == 0 && (reinterpret_cast<uintptr_t>(jac) & 15) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0;
     if (vec4) {
       for (int k4 = tid; k4 < (M >> 2); k4 += 256) {
-        float4 acc = *reinterpret_cast<const float4*>(rb + 4 * k4);
-        for (int s2 = 0; s2 < n; ++s2) {
-          const float4 jv = *reinterpret_cast<const float4*>(Jb + size_t(pb.enabledList[s2]) * M + 4 * k4);
-          const float d = d0[s2];
-          acc.x -= jv.x * d, acc.y -= jv.y * d, acc.z -= jv.z * d, acc.w -= jv.w * d;
+        // w = r - J d cancels (|w| << |r| near the solution) and it bounds what the refinement can
+        // recover: the n-term sums are kept in double (four FMAs per 16-byte load -- the pass is
+        // bound by its loads)
+        const float4 r4 = *reinterpret_cast<const float4*>(rb + 4 * k4);
+        double ax = r4.x, ay = r4.y, az = r4.z, aw = r4.w;
+        // sixteen columns per trip: the loads are independent and go out together (one column
+        // per trip was one dependent HBM round trip per column: 260 in a row at cfg5)
+        int s2 = 0;
+        for (; s2 + 16 <= n; s2 += 16) {
+          float4 jv[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            jv[t] = *reinterpret_cast<const float4*>(Jb + size_t(pb.enabledList[s2 + t]) * M + 4 * k4);
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const double d = double(d0[s2 + t]);
+            ax -= double(jv[t].x) * d, ay -= double(jv[t].y) * d, az -= double(jv[t].z) * d, aw -= double(jv[t].w) * d;
+          }
         }
-        *reinterpret_cast<float4*>(w + 4 * k4) = acc;
+        for (; s2 < n; ++s2) {
+          const float4 jv = *reinterpret_cast<const float4*>(Jb + size_t(pb.enabledList[s2]) * M + 4 * k4);
+          const double d = double(d0[s2]);
+          ax -= double(jv.x) * d, ay -= double(jv.y) * d, az -= double(jv.z) * d, aw -= double(jv.w) * d;
+        }
+        *reinterpret_cast<float4*>(w + 4 * k4) = float4{float(ax), float(ay), float(az), float(aw)};
       }
     } else {
       for (int kk = tid; kk < M; kk += 256) {
@@ -1849,7 +1915,48 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
       }
     }
     __syncthreads();
-    for (int s2 = wave; s2 < NP; s2 += 4) {
+    MMX_SCLK(3)
+    if (vec4) {
+      // four columns per wave and trip: their loads are in flight together, then four reductions
+      for (int s0 = 4 * wave; s0 < NP; s0 += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* col[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          col[t] = Jb + size_t(pb.enabledList[min(s0 + t, n - 1)]) * M;
+        }
+        const int M4 = M >> 2;
+        for (int k0 = lane; k0 < M4; k0 += 256) { // four row groups x four columns = sixteen loads in flight
+          float4 jv[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k4 = min(k0 + 64 * u, M4 - 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              jv[u][t] = *reinterpret_cast<const float4*>(col[t] + 4 * k4);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (k0 + 64 * u < M4) {
+              const float4 wv = *reinterpret_cast<const float4*>(w + 4 * (k0 + 64 * u));
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                acc[t] = dot4(jv[u][t], wv, acc[t]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float a = waveReduceSumF(acc[t]);
+          if (lane == 0 && s0 + t < NP) {
+            rho[s0 + t] = s0 + t < n ? a - lambda * d0[s0 + t] : 0.f;
+          }
+        }
+      }
+    }
+    for (int s2 = wave; s2 < NP && !vec4; s2 += 4) {
       float acc = 0.f;
       if (s2 < n) {
         const float* col = Jb + size_t(pb.enabledList[s2]) * M;
@@ -1869,7 +1976,9 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
       }
     }
     __syncthreads();
+    MMX_SCLK(4)
     solve(rho);
+    MMX_SCLK(5)
     float c2 = 0.f, d2 = 0.f;
     for (int i = tid; i < n; i += 256) {
       const float cr = rho[i], dn = d0[i] + cr;
