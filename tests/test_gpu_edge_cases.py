@@ -172,3 +172,29 @@ def test_three_kernel_path_system_sizes(torch_cuda, orc, count, monkeypatch):
         assert (out["status"].cpu().numpy() == 0).all()
         h = out["error_history"].cpu().numpy()
         assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
+
+
+@pytest.mark.parametrize("case", ["one_chunk", "many_units"])
+def test_store_pattern_probe_writes_every_element(torch_cuda, case):
+    """mmx_debug_store_pattern (the J-assembly kernel's stores without kinematics, bench.py's
+    roofline.store_pattern_gbs): every element of the [B][P][M] block is written, for the one-chunk
+    layout (<= 64 units, streaming stores) and the chunked one (plain stores, column-outer); problems
+    with further row blocks are refused."""
+    from momentum_amd import capi, make_humanoid72
+    from momentum_amd import humanoid72_landmark_joints
+
+    torch = torch_cuda
+    rig = make_humanoid72(unit=0.01)
+    joints = humanoid72_landmark_joints(rig) if case == "one_chunk" else np.arange(rig.num_joints, dtype=np.int32)
+    B = 5
+    cons, _, _ = make_problem(rig, joints, joints, B, seed=1, perturb=0.1)
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, joints, joints)
+    _upload(torch, pb, cons, B)
+    M, P = pb.M, rig.num_params
+    assert (M // 3 <= 64) == (case == "one_chunk")
+    buf = torch.full((B, P, M), float("nan"), dtype=torch.float32, device=pb.device)
+    ms = pb.store_pattern_kernel_ms(buf)
+    assert ms > 0.0
+    got = buf.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert np.array_equal(got, np.broadcast_to(np.arange(B, dtype=np.float32)[:, None, None], got.shape))
