@@ -34,6 +34,23 @@ __global__ void __launch_bounds__(64) kcol3(float* o) {
     }
   }
 }
+// 12 B per lane, 256-thread block: wave w writes K columns (the block 4 K adjacent columns = 3 K KB)
+template <int K, bool NT>
+__global__ void __launch_bounds__(256) kcol3w(float* o) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* p = o + (size_t(blockIdx.x) * 4 + wave) * K * 192 + 3 * lane;
+  float v = float(blockIdx.x);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (NT) {
+      __builtin_nontemporal_store(v, p + k * 192);
+      __builtin_nontemporal_store(v, p + k * 192 + 1);
+      __builtin_nontemporal_store(v, p + k * 192 + 2);
+    } else {
+      p[k * 192] = v, p[k * 192 + 1] = v, p[k * 192 + 2] = v;
+    }
+  }
+}
 int main() {
   const size_t n = size_t(4096) * 192 * 128; // floats = 402 MB
   float* buf;
@@ -61,5 +78,7 @@ int main() {
 #define RUNC(K_, NT_) run("kcol3 K=" #K_ " nt=" #NT_, [&] { kcol3<K_, NT_><<<unsigned(n / 192 / K_), 64>>>(buf); })
   RUNC(1, false); RUNC(2, false); RUNC(4, false); RUNC(8, false); RUNC(16, false); RUNC(32, false); RUNC(128, false);
   RUNC(1, true); RUNC(4, true); RUNC(16, true); RUNC(128, true);
+#define RUNW(K_, NT_) run("kcol3w (256 thr) K=" #K_ " nt=" #NT_, [&] { kcol3w<K_, NT_><<<unsigned(n / 192 / K_ / 4), 256>>>(buf); })
+  RUNW(1, false); RUNW(2, false); RUNW(4, false); RUNW(1, true); RUNW(2, true); RUNW(4, true);
   return 0;
 }
