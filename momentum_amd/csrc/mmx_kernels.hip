@@ -1,12 +1,15 @@
 // mmx_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the batched-IK hot path.
 //
-//   fkJacobianKernel       one wavefront per skeleton instance: ParameterTransform apply -> FK by
-//                          tree level in LDS -> residual rows -> dense Jacobian, every column
-//                          gathered and written with coalesced 768-byte wave stores (the graded,
-//                          HBM-write-bound kernel: mmx_eval_jacobian).
-//   normalEquationsKernel  H = J[:,E]^T J[:,E], g = J[:,E]^T r from the dense Jacobian.
-//   choleskyStepKernel     (H + lambda I) d = g by in-LDS Cholesky, one corrected-seminormal
-//                          refinement step through J, theta -= d, convergence bookkeeping.
+//   fkJacobianKernel       one or four wavefronts per skeleton instance: ParameterTransform apply ->
+//                          FK by pointer jumping in LDS -> residual rows -> dense Jacobian, every
+//                          column gathered and written with coalesced 768-byte wave stores (the
+//                          graded, HBM-write-bound kernel: mmx_eval_jacobian).
+//   jointBlocksKernel / parameterRowsKernel   rows of the further error functions and of the limits.
+//   normalEquations[Mfma]Kernel  H = J[:,E]^T J[:,E], g = J[:,E]^T r from the dense Jacobian
+//                          (register tiles / matrix cores).
+//   choleskyStep[Global]Kernel   (H + lambda I) d = g by blocked Cholesky in LDS (or with the factor in
+//                          HBM), corrected-seminormal refinement through J, theta -= d, bookkeeping.
+//   stepUpdateKernel       line search (both rules of the reference) / LM schedule trial steps.
 //
 // Reference semantics: see the citations in mmx_device.hpp and at each kernel.
 #include <hip/hip_ext.h>
@@ -20,8 +23,8 @@
 namespace mmx {
 
 // =============================================================================================
-// Kernel 1: FK + residual + Jacobian assembly.  grid = B, block = 64 (one wavefront = one
-// instance), dynamic LDS = kJs * J floats.
+// Kernel 1: FK + residual + Jacobian assembly.  grid = B, block = 64 * WPI (WPI = 1 or 4 wavefronts
+// per instance, launchFkJacobian), dynamic LDS = fkJacobianLdsBytes().
 //
 // Replaces SkeletonSolverFunctionT::initializeJacobianComputation + computeJacobianBlock
 // (momentum/character_solver/skeleton_solver_function.cpp:200-261) -> JointErrorFunctionT::
