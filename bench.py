@@ -115,6 +115,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--jac-launches", type=int, default=20)
+    ap.add_argument("--line-search", type=int, default=0, choices=[0, 1, 2], help="MMX_LINE_SEARCH_*: 0 none (the BASELINE metric), 1 GaussNewtonSolverT's rule, 2 the rule of the batched driver's solvers (SubsetGN / GN-QR)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
     args = ap.parse_args()
 
@@ -154,7 +155,7 @@ def main() -> None:
     parents = (pos_parents, ori_parents)
     seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
     rh, pb, theta0, theta_star = make_device_problem(rig, parents, B, local_rank, seed)
-    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule)
+    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=args.line_search)
     dev = pb.device
     theta = theta0.clone()
     outputs = dict(
@@ -284,6 +285,7 @@ def main() -> None:
                 "params": P,
                 "rows": M,
                 "gn_iterations": args.iterations,
+                "line_search": args.line_search,
                 "regularization": 0.05,
                 "sharding": f"{world} x {B} independent instances, one all-reduce of residual norms per solve",
             },
