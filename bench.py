@@ -74,12 +74,29 @@ def make_device_problem(rig, parents, B, device_index, seed):
     return rh, pb, theta0, theta_star
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a container can see 256 logical CPUs and be allowed a dozen)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(rig, parents, sample, seed, options):
     """The CPU oracle timed on the host cores (bounded sample of the same workload)."""
     from oracle import oracle as orc
     from tests.helpers import make_problem
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     pos_parents, ori_parents = parents if isinstance(parents, tuple) else (parents, parents)
     cons, th0, _ = make_problem(rig, pos_parents, ori_parents, sample, seed=seed, perturb=0.3)
     orc.solve_batch(rig, cons, th0[: min(sample, 2 * cores)], options, dtype="f32", nthreads=cores)  # warm
@@ -99,7 +116,7 @@ def cpu_baseline(rig, parents, sample, seed, options):
         "unit": "solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{sample} instances of the same workload, fp32, one solver per task over {cores} std::threads (mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
+        "sample": f"{sample} instances of the same workload, fp32, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
         "single_thread_value": n1 / dt1,
     }
 
