@@ -1148,15 +1148,72 @@ inline T dot8(const T* a, const T* b, int n) {
   return ((s[0] + s[4]) + (s[1] + s[5])) + ((s[2] + s[6]) + (s[3] + s[7])) + tail;
 }
 
-// H (n x n column-major, lower triangle) += Jc^T Jc ; g += Jc^T r   with Jc = M x n column-major
+// H (n x n column-major, lower triangle) += Jc^T Jc ; g += Jc^T r   with Jc = M x n column-major.
+// Register-blocked like a GEMM micro-kernel (4 x 2 entries of H per sweep over the rows, every entry
+// with the same 8 partial sums and the same summation order as dot8): the reference gets this
+// product from Eigen's blocked kernels (gauss_newton_solver.cpp:215), so the timed CPU baseline
+// should not re-read every column of J once per entry either.  Results are identical to the
+// entry-at-a-time form.
 template <class T>
 inline void accumulateNormalEquations(const T* Jc, const T* r, int M, int ld, int n, T* H, T* g) {
-  for (int j = 0; j < n; ++j) {
-    const T* cj = Jc + size_t(j) * ld;
-    for (int i = j; i < n; ++i) {
-      H[size_t(j) * n + i] += dot8(Jc + size_t(i) * ld, cj, M);
+  constexpr int BI = 4, BJ = 2;
+  const int M8 = M & ~7;
+  for (int j0 = 0; j0 < n; j0 += BJ) {
+    const int nj = std::min(BJ, n - j0);
+    for (int i0 = j0; i0 < n; i0 += BI) {
+      const int ni = std::min(BI, n - i0);
+      if (ni == BI && nj == BJ) {
+        T acc[BJ][BI][8];
+        for (int jj = 0; jj < BJ; ++jj) {
+          for (int ii = 0; ii < BI; ++ii) {
+            for (int l = 0; l < 8; ++l) {
+              acc[jj][ii][l] = T(0);
+            }
+          }
+        }
+        const T* cj0 = Jc + size_t(j0) * ld;
+        const T* cj1 = cj0 + ld;
+        const T* ci[BI];
+        for (int ii = 0; ii < BI; ++ii) {
+          ci[ii] = Jc + size_t(i0 + ii) * ld;
+        }
+        for (int k = 0; k < M8; k += 8) {
+          for (int ii = 0; ii < BI; ++ii) {
+            for (int l = 0; l < 8; ++l) {
+              const T a = ci[ii][k + l];
+              acc[0][ii][l] += a * cj0[k + l];
+              acc[1][ii][l] += a * cj1[k + l];
+            }
+          }
+        }
+        for (int jj = 0; jj < BJ; ++jj) {
+          const T* cj = jj == 0 ? cj0 : cj1;
+          for (int ii = 0; ii < BI; ++ii) {
+            if (i0 + ii < j0 + jj) {
+              continue; // above the diagonal (only inside the diagonal block)
+            }
+            const T* s = acc[jj][ii];
+            T tail = T(0);
+            for (int k = M8; k < M; ++k) {
+              tail += ci[ii][k] * cj[k];
+            }
+            H[size_t(j0 + jj) * n + i0 + ii] += ((s[0] + s[4]) + (s[1] + s[5])) + ((s[2] + s[6]) + (s[3] + s[7])) + tail;
+          }
+        }
+      } else {
+        for (int jj = 0; jj < nj; ++jj) {
+          const T* cj = Jc + size_t(j0 + jj) * ld;
+          for (int ii = 0; ii < ni; ++ii) {
+            if (i0 + ii >= j0 + jj) {
+              H[size_t(j0 + jj) * n + i0 + ii] += dot8(Jc + size_t(i0 + ii) * ld, cj, M);
+            }
+          }
+        }
+      }
     }
-    g[j] += dot8(cj, r, M);
+    for (int jj = 0; jj < nj; ++jj) {
+      g[j0 + jj] += dot8(Jc + size_t(j0 + jj) * ld, r, M);
+    }
   }
 }
 
@@ -1169,23 +1226,30 @@ inline void accumulateNormalEquations(const T* Jc, const T* r, int M, int ld, in
 // summation order; not bit-pinned by any reference test.)
 template <class T>
 inline bool choleskyLower(T* H, int n) {
+  // column k takes the contributions of the finished columns p = 0..k-1 one after the other (each
+  // a contiguous axpy over the rows k..n-1): the same sums in the same order as the textbook
+  // "s -= L(i,p) L(k,p) for p < k", walked along the storage instead of across it
+  std::vector<T> col(static_cast<size_t>(n));
   for (int k = 0; k < n; ++k) {
-    T d = H[size_t(k) * n + k];
-    for (int p = 0; p < k; ++p) {
-      const T l = H[size_t(p) * n + k];
-      d -= l * l;
+    T* ck = H + size_t(k) * n;
+    for (int i = k; i < n; ++i) {
+      col[i] = ck[i];
     }
+    for (int p = 0; p < k; ++p) {
+      const T* cp = H + size_t(p) * n;
+      const T l = cp[k];
+      for (int i = k; i < n; ++i) {
+        col[i] -= cp[i] * l;
+      }
+    }
+    const T d = col[k];
     if (!(d > T(0))) {
-      return false;
+      return false; // column k and everything after it stay as they were (see above)
     }
     const T lkk = std::sqrt(d);
-    H[size_t(k) * n + k] = lkk;
+    ck[k] = lkk;
     for (int i = k + 1; i < n; ++i) {
-      T s = H[size_t(k) * n + i];
-      for (int p = 0; p < k; ++p) {
-        s -= H[size_t(p) * n + i] * H[size_t(p) * n + k];
-      }
-      H[size_t(k) * n + i] = s / lkk;
+      ck[i] = col[i] / lkk;
     }
   }
   return true;
@@ -1194,12 +1258,13 @@ inline bool choleskyLower(T* H, int n) {
 // LLT::solve: L y = b, L^T x = y (in place)
 template <class T>
 inline void choleskySolve(const T* L, int n, T* b) {
-  for (int i = 0; i < n; ++i) {
-    T s = b[i];
-    for (int p = 0; p < i; ++p) {
-      s -= L[size_t(p) * n + i] * b[p];
+  for (int p = 0; p < n; ++p) { // forward, column-oriented: b(i) -= L(i,p) y(p) in the order p = 0..i-1
+    const T* cp = L + size_t(p) * n;
+    const T y = b[p] / cp[p];
+    b[p] = y;
+    for (int i = p + 1; i < n; ++i) {
+      b[i] -= cp[i] * y;
     }
-    b[i] = s / L[size_t(i) * n + i];
   }
   for (int i = n - 1; i >= 0; --i) {
     T s = b[i];
