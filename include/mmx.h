@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 4
+#define MMX_ABI_VERSION 5 /* 5: MMX_LINE_SEARCH_DIRECTIONAL, mmx_debug_store_pattern (additive) */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
