@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- character IK solves/sec on MI355X (BASELINE.json metric) + J-assembly HBM roofline.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--config cfg2|cfg2_all|cfg3]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--config cfg2|cfg2_all|cfg3|cfg5]
 
 One "step" = one pass of the hot path over one batch: a full batched solve (10 Gauss-Newton
 iterations: FK -> Jacobian/residual -> JtJ/Jtr -> Cholesky (+1 refinement) -> theta update) of
@@ -10,10 +10,19 @@ launches one rank per GPU (torch.distributed.run); instances are sharded (weak s
 fixed) and the only collective is one all-reduce of the per-batch residual norms per solve.
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit/... plus
-  "roofline":     achieved algorithmic HBM GB/s of the J-assembly kernel (mmx_eval_jacobian),
-                  timed live with HIP events on the launch stream
-  "cpu_baseline": the CPU oracle (restatement of momentum's algorithm, kind "port") timed on
-                  this box's host cores on a bounded sample of the same workload
+  "check":          parity of THIS batch: the first --check-instances (default 1024) DISTINCT instances of
+                    the timed batch re-solved by the CPU oracle in double precision; max / median
+                    relative pose-parameter difference (north_star bound: 1e-5)
+  "roofline":       achieved algorithmic HBM GB/s of the J-assembly kernel (mmx_eval_jacobian),
+                    timed live with HIP events on the launch stream
+  "roofline_fused": the headline kernel (fusedSolveKernel): dense-equivalent TFLOP/s of the timed solve
+                    and its PMC utilisation figures from the committed profile
+  "cpu_baseline":   the CPU oracle (restatement of momentum's algorithm, kind "port") timed on
+                    this box's host cores on a bounded sample of the SAME instances
+  "configs":        (N = 1 only) every other BASELINE.json configuration that fits one GPU -- the north-star
+                    target 65536 x 72 (cfg3, LM schedule), the weak-scaling shard 32768 x 72, the wide-J
+                    300-joint rig (cfg5), the batched driver's default line search -- each with its own
+                    solves/s, cpu_baseline and parity check
 """
 from __future__ import annotations
 
@@ -31,7 +40,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X datasheet (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 UNIT = 0.01  # rig offsets "U[2,30] cm" expressed in metres
+PARITY_BOUND = 1e-5  # BASELINE.json north_star: relative difference on pose parameters
 
 CONFIGS = {
     # name: (rig variant, constraint joints, default batch per GPU, step rule, description)
@@ -41,6 +52,14 @@ CONFIGS = {
     "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
 }
 
+# what the default single-GPU run reports besides the headline: (key, config, batch, line_search, timed steps, CPU sample)
+EXTRA_RUNS = [
+    ("cfg3@65536", "cfg3", 65536, 0, 4, 8192),
+    ("cfg2@32768", "cfg2", 32768, 0, 6, 8192),
+    ("cfg2@4096 line_search=2", "cfg2", 4096, 2, 10, 4096),
+    ("cfg5@8192", "cfg5", 8192, 0, 3, 1024),
+]
+
 
 def algorithmic_bytes_per_instance(M: int, P: int, Kp: int, Ko: int) -> int:
     """write J (M*P) and r (M), read theta (P), constraint payload and
@@ -48,30 +67,81 @@ def algorithmic_bytes_per_instance(M: int, P: int, Kp: int, Ko: int) -> int:
     return 4 * (M * P + M) + 4 * P + 4 * (7 * Kp + 9 * Ko) + 4 * (Kp + Ko)
 
 
-def make_device_problem(rig, parents, B, device_index, seed):
-    """Synthetic batch generated ON the GPU: theta* = U[-0.3,0.3]^P, targets = FK(theta*) through the
-    product's own FK kernel, theta0 = 0."""
-    from momentum_amd import capi
+def dense_equivalent_flops_per_iteration(M: int, n: int, J: int) -> float:
+    """what a dense implementation of one GN iteration executes per instance --
+    J^T J (lower triangle, M n^2 MACs = 2 flops each, half of it by symmetry), J^T r, Cholesky n^3/3,
+    two triangular solves, FK.  The fused kernel never forms J and exploits the tree sparsity, so it
+    executes far fewer; this is the denominator a dense GPU/CPU implementation would be priced against."""
+    return float(M) * n * n + 2.0 * M * n + n**3 / 3.0 + 2.0 * n * n + 150.0 * J
 
+
+def build_rig(config: str):
+    from momentum_amd import humanoid72_landmark_joints, make_humanoid72
+
+    variant, which, defB, step_rule, desc = CONFIGS[config]
+    if variant == "rig300":
+        from momentum_amd import make_rig300
+
+        rig = make_rig300(seed=12345, unit=UNIT)
+    else:
+        rig = make_humanoid72(seed=12345, variant=variant, unit=UNIT)
+    if which == "landmarks":
+        pos_parents = ori_parents = humanoid72_landmark_joints(rig)
+    elif which == "cfg5":
+        prng = np.random.default_rng(77)
+        pos_parents = prng.choice(rig.num_joints, size=150, replace=False).astype(np.int32)
+        ori_parents = prng.choice(rig.num_joints, size=50, replace=False).astype(np.int32)
+    else:
+        pos_parents = ori_parents = np.arange(rig.num_joints, dtype=np.int32)
+    return rig, (np.asarray(pos_parents, np.int32), np.asarray(ori_parents, np.int32)), defB, step_rule, desc
+
+
+class DeviceBatch:
+    """Synthetic batch generated ON the GPU: theta* = U[-0.3,0.3]^P, targets = FK(theta*) through the
+    product's own FK kernel, theta0 = 0.  Every instance is distinct."""
+
+    def __init__(self, rig, parents, B, device_index, seed):
+        from momentum_amd import capi
+
+        self.rig, self.parents, self.B = rig, parents, B
+        pos_parents, ori_parents = parents
+        self.rh = capi.RigHandle(rig, device_index)
+        self.pb = pb = capi.Problem(self.rh, B, pos_parents, ori_parents)
+        dev = pb.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        P, Kp, Ko = rig.num_params, len(pos_parents), len(ori_parents)
+        self.theta_star = (torch.rand((B, P), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * 0.3
+        st = pb.skeleton_state(self.theta_star)  # [B,J,8]
+        pidx = torch.as_tensor(np.asarray(pos_parents, dtype=np.int64), device=dev)
+        oidx = torch.as_tensor(np.asarray(ori_parents, dtype=np.int64), device=dev)
+        self.pos_offset = torch.zeros((B, Kp, 3), device=dev)
+        self.pos_target = st[:, pidx, 0:3].contiguous()
+        self.ori_offset = torch.zeros((B, Ko, 4), device=dev)
+        self.ori_offset[..., 3] = 1.0
+        self.ori_target = st[:, oidx, 3:7].contiguous()
+        self.pos_weight = torch.ones((B, Kp), device=dev)
+        self.ori_weight = torch.ones((B, Ko), device=dev)
+        pb.set_constraints(self.pos_offset, self.pos_target, self.pos_weight, self.ori_offset, self.ori_target, self.ori_weight, 1.0, 1.0)
+        self.theta0 = torch.zeros((B, P), device=dev, dtype=torch.float32)
+
+    def host_constraints(self, n):
+        """The first n instances of this very batch as the oracle's input (host copies)."""
+        from oracle import oracle as orc
+
+        c = lambda t: t[:n].cpu().numpy()
+        return orc.Constraints(
+            self.parents[0], c(self.pos_offset), c(self.pos_target), c(self.pos_weight),
+            self.parents[1], c(self.ori_offset), c(self.ori_target), c(self.ori_weight),
+        )  # fmt: skip
+
+
+def make_device_problem(rig, parents, B, device_index, seed):
+    """(kept for scripts/): rig handle, problem, theta0, theta* of a DeviceBatch."""
     pos_parents, ori_parents = parents if isinstance(parents, tuple) else (parents, parents)
-    rh = capi.RigHandle(rig, device_index)
-    pb = capi.Problem(rh, B, pos_parents, ori_parents)
-    dev = pb.device
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    P, Kp, Ko = rig.num_params, len(pos_parents), len(ori_parents)
-    theta_star = (torch.rand((B, P), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * 0.3
-    st = pb.skeleton_state(theta_star)  # [B,J,8]
-    pidx = torch.as_tensor(np.asarray(pos_parents, dtype=np.int64), device=dev)
-    oidx = torch.as_tensor(np.asarray(ori_parents, dtype=np.int64), device=dev)
-    pos_offset = torch.zeros((B, Kp, 3), device=dev)
-    pos_target = st[:, pidx, 0:3].contiguous()
-    ori_offset = torch.zeros((B, Ko, 4), device=dev)
-    ori_offset[..., 3] = 1.0
-    ori_target = st[:, oidx, 3:7].contiguous()
-    pb.set_constraints(pos_offset, pos_target, torch.ones((B, Kp), device=dev), ori_offset, ori_target, torch.ones((B, Ko), device=dev), 1.0, 1.0)
-    theta0 = torch.zeros((B, P), device=dev, dtype=torch.float32)
-    return rh, pb, theta0, theta_star
+    db = DeviceBatch(rig, (np.asarray(pos_parents, np.int32), np.asarray(ori_parents, np.int32)), B, device_index, seed)
+    make_device_problem.keep = db
+    return db.rh, db.pb, db.theta0, db.theta_star
 
 
 def usable_cores() -> int:
@@ -91,90 +161,66 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(rig, parents, sample, seed, options):
-    """The CPU oracle timed on the host cores (bounded sample of the same workload)."""
+def parity_check(db: DeviceBatch, theta_gpu, options, n):
+    """Re-solves the first n (distinct) instances of the timed batch with the CPU oracle in double
+    precision and compares the pose parameters (outside the timed region; the oracle is the checker)."""
     from oracle import oracle as orc
-    from tests.helpers import make_problem
+
+    n = int(min(n, db.B))
+    if n <= 0:
+        return None
+    cons = db.host_constraints(n)
+    th0 = db.theta0[:n].cpu().numpy()
+    ref = orc.solve_batch(db.rig, cons, th0, options, dtype="f64", nthreads=usable_cores())
+    th = theta_gpu[:n].cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-30)
+    return {
+        "instances": n,
+        "distinct": True,
+        "reference": "CPU oracle, double precision (oracle/, kind port), same inputs",
+        "max_rel_theta_vs_oracle_f64": float(rel.max()),
+        "median_rel_theta_vs_oracle_f64": float(np.median(rel)),
+        "p99_rel_theta_vs_oracle_f64": float(np.quantile(rel, 0.99)),
+        "num_above_bound": int((rel > PARITY_BOUND).sum()),
+        "bound": PARITY_BOUND,
+        "pass": bool(rel.max() <= PARITY_BOUND),
+    }
+
+
+def cpu_baseline(db: DeviceBatch, sample, options):
+    """The CPU oracle timed on the host cores, fp32, on the first `sample` instances of the SAME batch."""
+    from oracle import oracle as orc
 
     cores = usable_cores()
-    pos_parents, ori_parents = parents if isinstance(parents, tuple) else (parents, parents)
-    cons, th0, _ = make_problem(rig, pos_parents, ori_parents, sample, seed=seed, perturb=0.3)
-    orc.solve_batch(rig, cons, th0[: min(sample, 2 * cores)], options, dtype="f32", nthreads=cores)  # warm
+    sample = int(min(sample, db.B))
+    cons = db.host_constraints(sample)
+    th0 = db.theta0[:sample].cpu().numpy()
+    warm = min(sample, 2 * cores)
+    orc.solve_batch(db.rig, db.host_constraints(warm), th0[:warm], options, dtype="f32", nthreads=cores)
     t0 = time.perf_counter()
-    orc.solve_batch(rig, cons, th0, options, dtype="f32", nthreads=cores)
+    orc.solve_batch(db.rig, cons, th0, options, dtype="f32", nthreads=cores)
     dt = time.perf_counter() - t0
+    n1 = max(1, min(sample, 32 if db.rig.num_joints > 100 else 64))
     t1 = time.perf_counter()
-    n1 = max(1, min(sample, 64))
-    one = orc.Constraints(
-        cons.pos_parent, cons.pos_offset[:n1], cons.pos_target[:n1], cons.pos_weight[:n1],
-        cons.ori_parent, cons.ori_offset[:n1], cons.ori_target[:n1], cons.ori_weight[:n1],
-    )  # fmt: skip
-    orc.solve_batch(rig, one, th0[:n1], options, dtype="f32", nthreads=1)
+    orc.solve_batch(db.rig, db.host_constraints(n1), th0[:n1], options, dtype="f32", nthreads=1)
     dt1 = time.perf_counter() - t1
     return {
         "value": sample / dt,
         "unit": "solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{sample} instances of the same workload, fp32, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
+        "sample": f"the first {sample} instances of the timed batch, fp32, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
         "single_thread_value": n1 / dt1,
     }
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's)")
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--iterations", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8192)
-    ap.add_argument("--jac-launches", type=int, default=20)
-    ap.add_argument("--line-search", type=int, default=0, choices=[0, 1, 2], help="MMX_LINE_SEARCH_*: 0 none (the BASELINE metric), 1 GaussNewtonSolverT's rule, 2 the rule of the batched driver's solvers (SubsetGN / GN-QR)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
-    args = ap.parse_args()
-
+def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None):
+    """W untimed + K timed batched solves; returns (elapsed seconds (max over ranks), theta of the last solve,
+    reduced norms)."""
     from momentum_amd import distributed as D
 
-    rank, world, local_rank = D.env_rank()
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
-    # one rank per GPU; --backend gloo with fewer GPUs than ranks is only for the plumbing test
-    # (tests/test_bench_two_ranks.py), where the ranks share a device
-    local_rank = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
-    torch.cuda.set_device(local_rank)
-    dist = D.init(args.backend)  # RCCL behind the "nccl" backend on ROCm; None when world == 1
-
-    from momentum_amd import humanoid72_landmark_joints, make_humanoid72
-    from momentum_amd._abi import GnOptions
-
-    variant, which, defB, step_rule, desc = CONFIGS[args.config]
-    B = args.batch if args.batch > 0 else defB
-    if variant == "rig300":
-        from momentum_amd import make_rig300
-
-        rig = make_rig300(seed=12345, unit=UNIT)
-    else:
-        rig = make_humanoid72(seed=12345, variant=variant, unit=UNIT)
-    if which == "landmarks":
-        pos_parents = ori_parents = humanoid72_landmark_joints(rig)
-    elif which == "cfg5":
-        prng = np.random.default_rng(77)
-        pos_parents = prng.choice(rig.num_joints, size=150, replace=False).astype(np.int32)
-        ori_parents = prng.choice(rig.num_joints, size=50, replace=False).astype(np.int32)
-    else:
-        pos_parents = ori_parents = np.arange(rig.num_joints, dtype=np.int32)
-    parents = (pos_parents, ori_parents)
-    seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
-    rh, pb, theta0, theta_star = make_device_problem(rig, parents, B, local_rank, seed)
-    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=args.line_search)
-    dev = pb.device
-    theta = theta0.clone()
+    pb, dev, B = db.pb, db.pb.device, db.B
+    theta = db.theta0.clone()
     outputs = dict(
         error=torch.empty((B,), dtype=torch.float64, device=dev),
         iterations=torch.empty((B,), dtype=torch.int32, device=dev),
@@ -183,7 +229,7 @@ def main() -> None:
     norms = torch.zeros(3, dtype=torch.float64, device=dev)
 
     def step():
-        theta.copy_(theta0)
+        theta.copy_(db.theta0)
         pb.solve(theta, opt, outputs=outputs)
         # the path's only exchange: per-batch residual norms (sum error, sum iterations, #failed)
         norms[0] = outputs["error"].sum()
@@ -196,16 +242,110 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = D.reduce_max(dist, elapsed, dev)
-    total_err, total_it, failed = [float(x) for x in norms.tolist()]
+    return elapsed, theta, [float(x) for x in norms.tolist()]
+
+
+def solved_parameters(pb) -> int:
+    """Size of the dense system the solver factors (enabled parameters whose column is not structurally zero)."""
+    import ctypes as C
+
+    from momentum_amd import capi
+
+    buf = np.zeros(pb.P, np.int32)
+    n = C.c_int32(0)
+    capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(n), None))
+    return int(n.value)
+
+
+def fused_pmc():
+    """PMC figures of the headline kernel from the committed profile (profiles/pmc_fused.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_fused.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu):
+    from momentum_amd._abi import GnOptions
+
+    rig, parents, _, step_rule, desc = build_rig(config)
+    db = DeviceBatch(rig, parents, B, device_index, 424242)
+    opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=line_search)
+    elapsed, theta, norms = solve_loop(db, opt, steps, 1)
+    out = {
+        "workload": desc,
+        "batch": B,
+        "line_search": line_search,
+        "step_rule": "lm_schedule" if step_rule == 1 else "gn_fixed_lambda",
+        "solves_per_s": B * steps / elapsed,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "steps": steps,
+        "failed_instances": norms[2],
+        "check": parity_check(db, theta, opt, check_n),
+    }
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(db, cpu_sample, opt)
+        out["gpu_over_cpu"] = out["solves_per_s"] / out["cpu_baseline"]["value"]
+    del db
+    torch.cuda.empty_cache()
+    return out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's)")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--iterations", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--check-instances", type=int, default=1024, help="distinct instances of the timed batch re-solved by the oracle (0 = skip)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the other BASELINE configurations (N = 1 default run reports them)")
+    ap.add_argument("--jac-launches", type=int, default=20)
+    ap.add_argument("--line-search", type=int, default=0, choices=[0, 1, 2], help="MMX_LINE_SEARCH_*: 0 none (the BASELINE metric), 1 GaussNewtonSolverT's rule, 2 the rule of the batched driver's solvers (SubsetGN / GN-QR)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
+    args = ap.parse_args()
+
+    from momentum_amd import distributed as D
+
+    rank, world, local_rank = D.env_rank()
+    if args.gpus != world:
+        raise SystemExit(
+            f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 with torch.distributed.run, one rank per GPU "
+            "(python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...)"
+        )
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    # one rank per GPU; --backend gloo with fewer GPUs than ranks is only for the plumbing test
+    # (tests/test_bench_two_ranks.py), where the ranks share a device
+    local_rank = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(local_rank)
+    dist = D.init(args.backend)  # RCCL behind the "nccl" backend on ROCm; None when world == 1
+
+    from momentum_amd._abi import GnOptions
+
+    rig, parents, defB, step_rule, desc = build_rig(args.config)
+    B = args.batch if args.batch > 0 else defB
+    seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
+    db = DeviceBatch(rig, parents, B, local_rank, seed)
+    pb, theta_star = db.pb, db.theta_star
+    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=args.line_search)
+    dev = pb.device
+    elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist)
 
     # ---- roofline of the J-assembly kernel (mmx_eval_jacobian): HIP events on the launch stream
     M, P = pb.M, pb.P
@@ -268,21 +408,25 @@ def main() -> None:
         del fill
         BL = 32768
         if args.config == "cfg2" and B < BL:
-            rhL, pbL, _, thetaL = make_device_problem(rig, parents, BL, local_rank, seed + 1)
+            dbL = DeviceBatch(rig, parents, BL, local_rank, seed + 1)
             jacL = torch.empty((BL, P, M), dtype=torch.float32, device=dev)
             resL = torch.empty((BL, M), dtype=torch.float32, device=dev)
             errL = torch.empty((BL,), dtype=torch.float64, device=dev)
             for _ in range(2):
-                pbL.eval_jacobian(thetaL, jacL, resL, errL)
-            msL = float(np.mean([pbL.eval_jacobian_kernel_ms(thetaL, jacL, resL, errL) for _ in range(5)]))
+                dbL.pb.eval_jacobian(dbL.theta_star, jacL, resL, errL)
+            msL = float(np.mean([dbL.pb.eval_jacobian_kernel_ms(dbL.theta_star, jacL, resL, errL) for _ in range(5)]))
             gbsL = BL * algorithmic_bytes_per_instance(M, P, Kp_, Ko_) / (msL * 1e-3) / 1e9
             extra["at_batch_32768"] = {"achieved": gbsL, "frac": gbsL / HBM_PEAK_GBS, "ms_per_launch": msL}
-            del jacL, resL, errL, pbL, rhL
+            del jacL, resL, errL, dbL
+            torch.cuda.empty_cache()
 
     if rank == 0:
         solves = float(B) * world * args.steps
+        n_solved = solved_parameters(pb)
+        dense_flops = dense_equivalent_flops_per_iteration(M, n_solved, rig.num_joints) * args.iterations
+        per_gpu_solves_per_s = float(B) * args.steps / elapsed
         line = {
-            "metric": "character IK solves/sec (72-joint, 10 GN iters)",
+            "metric": f"character IK solves/sec ({rig.num_joints}-joint, {args.iterations} GN iters)",
             "value": solves / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
@@ -301,6 +445,7 @@ def main() -> None:
                 "joints": rig.num_joints,
                 "params": P,
                 "rows": M,
+                "solved_parameters": n_solved,
                 "gn_iterations": args.iterations,
                 "line_search": args.line_search,
                 "regularization": 0.05,
@@ -322,9 +467,31 @@ def main() -> None:
                 "batch": B,
                 **extra,
             },
+            "roofline_fused": {
+                "kernel": "fusedSolveKernel (mmx_solve: the kernel `value` times; the Jacobian is never formed)",
+                "bound": "latency (LDS round trips / barriers of one workgroup per instance); priced against the fp32 peak of a dense implementation",
+                "dense_equivalent_flops_per_solve": dense_flops,
+                "achieved": per_gpu_solves_per_s * dense_flops / 1e12,
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s (dense-equivalent, per GPU)",
+                "frac": per_gpu_solves_per_s * dense_flops / 1e12 / FP32_PEAK_TFLOPS,
+                "pmc": fused_pmc(),
+            },
         }
+        if args.check_instances > 0:
+            line["check"].update(parity_check(db, theta_final, opt, args.check_instances))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(rig, parents, args.cpu_sample, 12345, opt)
+            line["cpu_baseline"] = cpu_baseline(db, args.cpu_sample, opt)
+        default_run = world == 1 and args.config == "cfg2" and args.batch == 0 and args.line_search == 0
+        if default_run and not args.no_extra_configs:
+            del db, pb
+            torch.cuda.empty_cache()
+            line["configs"] = {}
+            for key, cfg, eb, ls, steps, sample in EXTRA_RUNS:
+                try:
+                    line["configs"][key] = run_extra(key, cfg, eb, ls, steps, sample, local_rank, args.iterations, args.check_instances, not args.no_cpu_baseline)
+                except Exception as ex:  # a failing side configuration must not lose the headline line
+                    line["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

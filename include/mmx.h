@@ -64,7 +64,8 @@ typedef enum mmx_status {
 
 /* Jacobian layouts of mmx_eval_jacobian. */
 #define MMX_LAYOUT_COL_MAJOR 0 /* J[b][p*M + i]   (the reference's layout) */
-#define MMX_LAYOUT_ROW_MAJOR 1 /* J[b][i*P + p] */
+#define MMX_LAYOUT_ROW_MAJOR 1 /* J[b][i*P + p]   (torch-style [B][M][P]; assembled column-major, then transposed:
+                                  one extra read + write of J; mmx_eval_jacobian[_host] only) */
 
 /* Solver step rule. */
 #define MMX_STEP_GN_FIXED_LAMBDA 0 /* GaussNewtonSolverT, constant regularization
@@ -106,12 +107,15 @@ typedef struct mmx_rig_desc {
 /*
  * One entry of Character::parameterLimits restricted to the limit types that act on model or
  * joint PARAMETERS (momentum/character/parameter_limits.h:20-31,33-99,125-136): the rows of
- * LimitErrorFunctionT that need no joint transforms.  Ellipsoid limits and
- * the passive MinMaxJointPassive type are not handled here.
+ * LimitErrorFunctionT that need no joint transforms.  Ellipsoid limits travel in
+ * mmx_ellipsoid_limit; the passive MinMaxJointPassive type is accepted and ignored like in the reference.
  */
 #define MMX_LIMIT_MINMAX 0 /* LimitType::MinMax    : index0 = parameterIndex ; v = {min, max} */
 #define MMX_LIMIT_MINMAX_JOINT 1 /* LimitType::MinMaxJoint : index0 = 7 * jointIndex + jointParameter (a row of the
                                     parameter transform) ; v = {min, max} on that JOINT parameter */
+#define MMX_LIMIT_MINMAX_JOINT_PASSIVE 2 /* LimitType::MinMaxJointPassive: accepted and IGNORED -- LimitErrorFunctionT gives it
+                                            neither an error term nor a Jacobian row (limit_error_function.cpp:836-837,
+                                            1051-1052); such entries do not count in mmx_problem_num_rows */
 #define MMX_LIMIT_LINEAR_JOINT 4 /* LimitType::LinearJoint : index0 = 7 * referenceJointIndex + referenceJointParameter,
                                     index1 = 7 * targetJointIndex + targetJointParameter ;
                                     v = {scale, offset, rangeMin, rangeMax} */

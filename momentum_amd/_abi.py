@@ -39,6 +39,7 @@ class RigDesc(C.Structure):
 MMX_LOSS_WELSCH = float(np.finfo(np.float32).min)  # GeneralizedLossT::kWelsch
 MMX_LIMIT_MINMAX = 0  # momentum::LimitType values (character/parameter_limits.h:20-31)
 MMX_LIMIT_MINMAX_JOINT = 1
+MMX_LIMIT_MINMAX_JOINT_PASSIVE = 2  # accepted and ignored, like LimitErrorFunctionT does
 MMX_LIMIT_LINEAR = 3
 MMX_LIMIT_LINEAR_JOINT = 4
 MMX_LIMIT_HALFPLANE = 6
@@ -66,6 +67,10 @@ class ParameterLimit(C.Structure):
     @classmethod
     def minmax_joint(cls, joint, joint_parameter, lo, hi, weight=1.0):
         return cls(MMX_LIMIT_MINMAX_JOINT, 7 * int(joint) + int(joint_parameter), 0, float(weight), (C.c_float * 4)(lo, hi, 0.0, 0.0))
+
+    @classmethod
+    def minmax_joint_passive(cls, joint, joint_parameter, lo, hi, weight=1.0):
+        return cls(MMX_LIMIT_MINMAX_JOINT_PASSIVE, 7 * int(joint) + int(joint_parameter), 0, float(weight), (C.c_float * 4)(lo, hi, 0.0, 0.0))
 
     @classmethod
     def linear_joint(cls, ref_joint, ref_parameter, tgt_joint, tgt_parameter, scale, offset, range_min=0.0, range_max=0.0, weight=1.0):

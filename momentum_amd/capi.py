@@ -254,18 +254,19 @@ class Problem:
         return theta
 
     # -- the graded kernel: dense column-major Jacobian + residual (+ error)
-    def eval_jacobian(self, theta, jac=None, res=None, err=None, want_err: bool = True):
-        """Returns (jac [B,P,M] (jac[b].T is the M x P Jacobian), res [B,M], err [B] float64)."""
+    def eval_jacobian(self, theta, jac=None, res=None, err=None, want_err: bool = True, row_major: bool = False):
+        """Returns (jac [B,P,M] (jac[b].T is the M x P Jacobian; [B,M,P] with row_major), res [B,M], err [B] float64)."""
         import torch
 
         theta = self._theta(theta)
         if jac is None:
-            jac = torch.empty((self.B, self.P, self.M), dtype=torch.float32, device=self.device)
+            jac = torch.empty((self.B, self.M, self.P) if row_major else (self.B, self.P, self.M), dtype=torch.float32, device=self.device)
         if res is None:
             res = torch.empty((self.B, self.M), dtype=torch.float32, device=self.device)
         if err is None and want_err:
             err = torch.empty((self.B,), dtype=torch.float64, device=self.device)
-        _check(lib().mmx_eval_jacobian(self._h, _dev(theta), _dev(jac), _dev(res), _dev(err), _abi.MMX_LAYOUT_COL_MAJOR, _stream_ptr()))
+        layout = _abi.MMX_LAYOUT_ROW_MAJOR if row_major else _abi.MMX_LAYOUT_COL_MAJOR
+        _check(lib().mmx_eval_jacobian(self._h, _dev(theta), _dev(jac), _dev(res), _dev(err), layout, _stream_ptr()))
         return jac, res, err
 
     def eval_jacobian_kernel_ms(self, theta, jac, res, err=None) -> float:

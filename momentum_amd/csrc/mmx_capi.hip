@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +40,54 @@ int32_t fail(int32_t code, const std::string& msg) {
           std::string(#call) + ": " + hipGetErrorString(e_));                                     \
     }                                                                                             \
   } while (0)
+
+// ---- profiling zones: roctx ranges around the ABI entry points and the phases of the explicit-Jacobian
+// iteration, named after the reference's MT_PROFILE_EVENT zones of this path
+// (momentum/solver/gauss_newton_solver.cpp:70,225,241,264,285,290; solver.cpp:51).  The roctx library is
+// looked up at run time (librocprofiler-sdk-roctx.so, then libroctx64.so) so that libmmx_hip.so has no
+// link-time dependency on a profiler; without it, or with MMX_NO_ROCTX set, a zone costs one branch.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (getenv("MMX_NO_ROCTX") != nullptr) {
+      return;
+    }
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
+      if (h != nullptr) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push != nullptr && pop != nullptr) {
+          return;
+        }
+        push = nullptr, pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+struct Zone {
+  bool open;
+  explicit Zone(const char* name) : open(roctx().push != nullptr) {
+    if (open) {
+      roctx().push(name);
+    }
+  }
+  Zone(const Zone&) = delete;
+  Zone& operator=(const Zone&) = delete;
+  ~Zone() {
+    if (open) {
+      roctx().pop();
+    }
+  }
+};
+#define MMX_ZONE_CAT2(a, b) a##b
+#define MMX_ZONE_CAT(a, b) MMX_ZONE_CAT2(a, b)
+#define MMX_ZONE(name) Zone MMX_ZONE_CAT(zone_, __LINE__)(name)
 
 // RAII device buffer
 struct DevBuf {
@@ -140,12 +190,14 @@ struct mmx_problem {
   DevBuf dBlocks, dGenJoint, dGenTin, dGenBlock;
   int32_t genRows = 0;
   bool haveConstraints = false;
+  bool tablesDirty = false; // blocks / ellipsoids / limits changed and uploadProblemTables has not succeeded since
   mmx::ProblemDev dev{};
   // the same problem with the structurally zero columns dropped from the solve (explicit-Jacobian solver)
   int32_t solveN = 0;
   DevBuf dSolveListV1; // [solveN]
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
+  DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
 };
 
@@ -713,6 +765,7 @@ int32_t mmx_host_tables(
 }
 
 int32_t mmx_rig_create(const mmx_rig_desc* d, int32_t device, mmx_rig** out) {
+  MMX_ZONE("mmx_rig_create");
   if (out == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "out is null");
   }
@@ -848,6 +901,7 @@ int32_t mmx_problem_create(
     int32_t num_ori,
     const int32_t* ori_parent,
     mmx_problem** out) {
+  MMX_ZONE("mmx_problem_create");
   if (out == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "out is null");
   }
@@ -919,6 +973,7 @@ int32_t mmx_problem_batch(const mmx_problem* pb) {
 }
 
 int32_t mmx_problem_set_enabled(mmx_problem* pb, const uint8_t* enabled) {
+  MMX_ZONE("mmx_problem_set_enabled");
   int32_t rc = checkProblem(pb, false);
   if (rc != MMX_OK) {
     return rc;
@@ -938,6 +993,7 @@ int32_t mmx_problem_set_enabled(mmx_problem* pb, const uint8_t* enabled) {
 }
 
 int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* c, void* stream) {
+  MMX_ZONE("mmx_problem_set_constraints");
   int32_t rc = checkProblem(pb, false);
   if (rc != MMX_OK) {
     return rc;
@@ -955,38 +1011,9 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   mmx::ProblemDev& d = pb->dev;
   const size_t B = size_t(pb->B);
-  if (c->memory == MMX_MEM_DEVICE) {
-    d.posOffset = c->pos_offset;
-    d.posTarget = c->pos_target;
-    d.posWeight = c->pos_weight;
-    d.oriOffset = c->ori_offset;
-    d.oriTarget = c->ori_target;
-    d.oriWeight = c->ori_weight;
-  } else if (c->memory == MMX_MEM_HOST) {
-    auto ingest = [&](DevBuf& buf, const float* src, size_t count, const float*& dst) -> hipError_t {
-      if (count == 0) {
-        dst = nullptr;
-        return hipSuccess;
-      }
-      hipError_t e = buf.ensure(count * sizeof(float));
-      if (e != hipSuccess) {
-        return e;
-      }
-      dst = buf.as<float>();
-      return hipMemcpyAsync(buf.p, src, count * sizeof(float), hipMemcpyHostToDevice, s);
-    };
-    MMX_HIP(ingest(pb->oPosOffset, c->pos_offset, B * pb->Kp * 3, d.posOffset));
-    MMX_HIP(ingest(pb->oPosTarget, c->pos_target, B * pb->Kp * 3, d.posTarget));
-    MMX_HIP(ingest(pb->oPosWeight, c->pos_weight, B * pb->Kp, d.posWeight));
-    MMX_HIP(ingest(pb->oOriOffset, c->ori_offset, B * pb->Ko * 4, d.oriOffset));
-    MMX_HIP(ingest(pb->oOriTarget, c->ori_target, B * pb->Ko * 4, d.oriTarget));
-    MMX_HIP(ingest(pb->oOriWeight, c->ori_weight, B * pb->Ko, d.oriWeight));
-    MMX_HIP(hipStreamSynchronize(s)); // the caller may free its host arrays on return
-  } else {
+  if (c->memory != MMX_MEM_DEVICE && c->memory != MMX_MEM_HOST) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "constraint data: unknown memory space");
   }
-  d.wPos = c->pos_function_weight;
-  d.wOri = c->ori_function_weight;
   auto makeLoss = [](float alpha, float cc) { // GeneralizedLossT ctor (generalized_loss.cpp:81-101), kEps = 1e-9
     mmx::LossDev l{0, 2.f, 1.f};
     if (cc > 0.f) {
@@ -1007,8 +1034,6 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
     }
     return l;
   };
-  d.lossPos = makeLoss(c->pos_loss_alpha, c->pos_loss_c);
-  d.lossOri = makeLoss(c->ori_loss_alpha, c->ori_loss_c);
   // ---- optional parameter-space blocks
   const int32_t P = pb->rig->P;
   if (c->num_limits < 0 || (c->num_limits > 0 && c->limits == nullptr)) {
@@ -1022,11 +1047,15 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
     const bool model = lm.type == MMX_LIMIT_MINMAX || lm.type == MMX_LIMIT_LINEAR || lm.type == MMX_LIMIT_HALFPLANE;
     const bool joint = lm.type == MMX_LIMIT_MINMAX_JOINT || lm.type == MMX_LIMIT_LINEAR_JOINT;
     const bool two = lm.type == MMX_LIMIT_LINEAR || lm.type == MMX_LIMIT_HALFPLANE || lm.type == MMX_LIMIT_LINEAR_JOINT;
+    if (lm.type == MMX_LIMIT_MINMAX_JOINT_PASSIVE) {
+      continue; // LimitErrorFunctionT skips the passive type: no error, no row (limit_error_function.cpp:836-837,1051-1052)
+    }
     if (!model && !joint) {
       return fail(
           MMX_ERR_UNSUPPORTED,
           "limit " + std::to_string(l) +
-              ": only MinMax, MinMaxJoint, Linear, LinearJoint and HalfPlane limits are implemented (no Ellipsoid / passive limits)");
+              ": MinMax, MinMaxJoint, MinMaxJointPassive (ignored like in the reference), Linear, LinearJoint and HalfPlane go here; "
+              "Ellipsoid limits travel in mmx_constraint_data::ellipsoid_limits");
     }
     const int32_t bound = joint ? MMX_PARAMS_PER_JOINT * pb->rig->J : P;
     if (lm.index0 < 0 || lm.index0 >= bound || (two && (lm.index1 < 0 || lm.index1 >= bound))) {
@@ -1072,7 +1101,52 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
   if (genCount > 1024) {
     return fail(MMX_ERR_UNSUPPORTED, "more than 1024 constraints in the further joint-constraint blocks");
   }
+  // ---- Ellipsoid entries of the limit block
+  if (c->num_ellipsoid_limits < 0 || c->num_ellipsoid_limits > 256 || (c->num_ellipsoid_limits > 0 && c->ellipsoid_limits == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "ellipsoid_limits: count out of range or null array");
+  }
+  for (int32_t i = 0; i < c->num_ellipsoid_limits; ++i) {
+    const mmx_ellipsoid_limit& e = c->ellipsoid_limits[i];
+    if (e.parent < 0 || e.parent >= pb->rig->J || e.ellipsoid_parent < 0 || e.ellipsoid_parent >= pb->rig->J) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "ellipsoid limit " + std::to_string(i) + ": joint index out of range");
+    }
+  }
+  // ---- everything above only validated; from here on the problem is modified.  Should a device
+  // call fail half-way, tablesDirty keeps the derived tables from being trusted by the next call.
+  if (c->memory == MMX_MEM_DEVICE) {
+    d.posOffset = c->pos_offset;
+    d.posTarget = c->pos_target;
+    d.posWeight = c->pos_weight;
+    d.oriOffset = c->ori_offset;
+    d.oriTarget = c->ori_target;
+    d.oriWeight = c->ori_weight;
+  } else if (c->memory == MMX_MEM_HOST) {
+    auto ingest = [&](DevBuf& buf, const float* src, size_t count, const float*& dst) -> hipError_t {
+      if (count == 0) {
+        dst = nullptr;
+        return hipSuccess;
+      }
+      hipError_t e = buf.ensure(count * sizeof(float));
+      if (e != hipSuccess) {
+        return e;
+      }
+      dst = buf.as<float>();
+      return hipMemcpyAsync(buf.p, src, count * sizeof(float), hipMemcpyHostToDevice, s);
+    };
+    MMX_HIP(ingest(pb->oPosOffset, c->pos_offset, B * pb->Kp * 3, d.posOffset));
+    MMX_HIP(ingest(pb->oPosTarget, c->pos_target, B * pb->Kp * 3, d.posTarget));
+    MMX_HIP(ingest(pb->oPosWeight, c->pos_weight, B * pb->Kp, d.posWeight));
+    MMX_HIP(ingest(pb->oOriOffset, c->ori_offset, B * pb->Ko * 4, d.oriOffset));
+    MMX_HIP(ingest(pb->oOriTarget, c->ori_target, B * pb->Ko * 4, d.oriTarget));
+    MMX_HIP(ingest(pb->oOriWeight, c->ori_weight, B * pb->Ko, d.oriWeight));
+    MMX_HIP(hipStreamSynchronize(s)); // the caller may free its host arrays on return
+  }
+  d.wPos = c->pos_function_weight;
+  d.wOri = c->ori_function_weight;
+  d.lossPos = makeLoss(c->pos_loss_alpha, c->pos_loss_c);
+  d.lossOri = makeLoss(c->ori_loss_alpha, c->ori_loss_c);
   if (blocksChanged) {
+    pb->tablesDirty = true;
     pb->blocks.clear();
     for (int32_t i = 0; i < c->num_joint_blocks; ++i) {
       auto h = std::make_unique<mmx_problem::JointBlockHost>();
@@ -1123,26 +1197,23 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
     }
   }
   pb->genRows = genRows;
-  // ---- Ellipsoid entries of the limit block
-  if (c->num_ellipsoid_limits < 0 || c->num_ellipsoid_limits > 256 || (c->num_ellipsoid_limits > 0 && c->ellipsoid_limits == nullptr)) {
-    return fail(MMX_ERR_INVALID_ARGUMENT, "ellipsoid_limits: count out of range or null array");
-  }
-  for (int32_t i = 0; i < c->num_ellipsoid_limits; ++i) {
-    const mmx_ellipsoid_limit& e = c->ellipsoid_limits[i];
-    if (e.parent < 0 || e.parent >= pb->rig->J || e.ellipsoid_parent < 0 || e.ellipsoid_parent >= pb->rig->J) {
-      return fail(MMX_ERR_INVALID_ARGUMENT, "ellipsoid limit " + std::to_string(i) + ": joint index out of range");
-    }
-  }
   const bool ellipsoidsChanged = size_t(c->num_ellipsoid_limits) != pb->ellipsoids.size() ||
       (c->num_ellipsoid_limits > 0 &&
        std::memcmp(c->ellipsoid_limits, pb->ellipsoids.data(), size_t(c->num_ellipsoid_limits) * sizeof(mmx_ellipsoid_limit)) != 0);
   pb->ellipsoids.assign(c->ellipsoid_limits, c->ellipsoid_limits + c->num_ellipsoid_limits);
-  const bool structureChanged = blocksChanged || ellipsoidsChanged || (c->model_target != nullptr) != (d.hasModel != 0) || size_t(c->num_limits) != pb->limits.size() ||
-      (c->num_limits > 0 && std::memcmp(c->limits, pb->limits.data(), size_t(c->num_limits) * sizeof(mmx_parameter_limit)) != 0);
-  pb->limits.assign(c->limits, c->limits + c->num_limits);
+  std::vector<mmx_parameter_limit> kept; // the limits that produce a row (the passive type does not)
+  for (int32_t l = 0; l < c->num_limits; ++l) {
+    if (c->limits[l].type != MMX_LIMIT_MINMAX_JOINT_PASSIVE) {
+      kept.push_back(c->limits[l]);
+    }
+  }
+  const bool structureChanged = pb->tablesDirty || blocksChanged || ellipsoidsChanged || (c->model_target != nullptr) != (d.hasModel != 0) || kept.size() != pb->limits.size() ||
+      (!kept.empty() && std::memcmp(kept.data(), pb->limits.data(), kept.size() * sizeof(mmx_parameter_limit)) != 0);
+  pb->tablesDirty = pb->tablesDirty || structureChanged;
+  pb->limits = std::move(kept);
   static_assert(sizeof(mmx_parameter_limit) == sizeof(mmx::LimitDev) && sizeof(mmx::LimitDev) == 32, "limit layouts must match");
   MMX_HIP(upload(pb->dLimits, pb->limits));
-  d.NL = c->num_limits;
+  d.NL = int32_t(pb->limits.size());
   d.limits = pb->dLimits.as<mmx::LimitDev>();
   d.wLimit = c->limit_function_weight;
   d.hasModel = c->model_target != nullptr ? 1 : 0;
@@ -1175,6 +1246,7 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
     if (rc != MMX_OK) {
       return rc;
     }
+    pb->tablesDirty = false;
   }
   pb->haveConstraints = true;
   return MMX_OK;
@@ -1188,6 +1260,7 @@ int32_t mmx_eval_jacobian(
     double* err_dev,
     int32_t layout,
     void* stream) {
+  MMX_ZONE("mmx_eval_jacobian (initializeJacobianComputation + computeJacobianBlock)");
   int32_t rc = checkProblem(pb, true);
   if (rc != MMX_OK) {
     return rc;
@@ -1195,12 +1268,20 @@ int32_t mmx_eval_jacobian(
   if (theta_dev == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "theta is null");
   }
-  if (layout != MMX_LAYOUT_COL_MAJOR) {
-    return fail(MMX_ERR_UNSUPPORTED, "only MMX_LAYOUT_COL_MAJOR (the reference's layout) is implemented");
+  if (layout != MMX_LAYOUT_COL_MAJOR && layout != MMX_LAYOUT_ROW_MAJOR) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown Jacobian layout");
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
-  MMX_HIP(mmx::launchFkJacobian(
-      pb->rig->dev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, static_cast<hipStream_t>(stream)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (layout == MMX_LAYOUT_ROW_MAJOR && jac_dev != nullptr) {
+    // assembled column-major (the layout the kernel's coalesced column stores are built for) into the
+    // problem's scratch, then transposed per instance: one extra read + write of J
+    MMX_HIP(pb->sJacColMajor.ensure(size_t(pb->B) * size_t(pb->M) * size_t(pb->rig->P) * sizeof(float)));
+    MMX_HIP(mmx::launchFkJacobian(pb->rig->dev, pb->dev, theta_dev, pb->sJacColMajor.as<float>(), res_dev, err_dev, nullptr, nullptr, s));
+    MMX_HIP(mmx::launchTransposeJacobian(pb->sJacColMajor.as<float>(), jac_dev, pb->B, pb->M, pb->rig->P, s));
+    return MMX_OK;
+  }
+  MMX_HIP(mmx::launchFkJacobian(pb->rig->dev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, s));
   return MMX_OK;
 }
 
@@ -1278,6 +1359,7 @@ int32_t mmx_debug_store_pattern(mmx_problem* pb, float* jac_dev, void* stream, f
 }
 
 int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* state_dev, void* stream) {
+  MMX_ZONE("mmx_eval_skeleton_state (SkeletonState::set)");
   int32_t rc = checkProblem(pb, false);
   if (rc != MMX_OK) {
     return rc;
@@ -1310,6 +1392,7 @@ int32_t mmx_eval_normal_equations(
     float* jtr_dev,
     double* err_dev,
     void* stream) {
+  MMX_ZONE("mmx_eval_normal_equations (Get JtJ and JtR)");
   int32_t rc = checkProblem(pb, true);
   if (rc != MMX_OK) {
     return rc;
@@ -1342,6 +1425,7 @@ int32_t mmx_solve(
     int32_t* status,
     double* error_history,
     void* stream) {
+  MMX_ZONE("mmx_solve (SolverT::solve)");
   int32_t rc = checkProblem(pb, true);
   if (rc != MMX_OK) {
     return rc;
@@ -1354,6 +1438,10 @@ int32_t mmx_solve(
   }
   if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "unknown step_rule");
+  }
+  if (o->do_line_search != MMX_LINE_SEARCH_NONE && o->do_line_search != MMX_LINE_SEARCH_GAUSS_NEWTON &&
+      o->do_line_search != MMX_LINE_SEARCH_DIRECTIONAL) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown do_line_search rule");
   }
   const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
   mmx::ProblemDev ds = pb->dev; // the explicit-Jacobian solver's view: structurally zero columns dropped
@@ -1395,7 +1483,10 @@ int32_t mmx_solve(
       MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
       clk = pb->sClk.as<long long>();
     }
-    MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, s));
+    {
+      MMX_ZONE("fused solve: all iterations of GaussNewtonSolverT::doIteration in one launch");
+      MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, s));
+    }
     if (clk != nullptr) {
       long long h[32];
       MMX_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -1472,24 +1563,23 @@ int32_t mmx_solve(
   }
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
-    MMX_HIP(mmx::launchFkJacobian(
-        pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
-    MMX_HIP(mmx::launchNormalEquations(
-        ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done,
-        mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 /* the in-HBM factorisation reads the lower triangle only */, s));
-    MMX_HIP(mmx::launchCholeskyStep(
-        ds,
-        pb->rig->P,
-        pb->sJac.as<float>(),
-        pb->sRes.as<float>(),
-        pb->sJtj.as<float>(),
-        pb->sJtr.as<float>(),
-        pb->sErr.as<double>(),
-        theta_dev,
-        st,
-        sp,
-        s));
+    MMX_ZONE("GaussNewtonSolverT::doIteration");
+    {
+      MMX_ZONE("Get JtJ and JtR");
+      MMX_HIP(mmx::launchFkJacobian(
+          pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
+      MMX_HIP(mmx::launchNormalEquations(
+          ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done,
+          mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 /* the in-HBM factorisation reads the lower triangle only */, s));
+    }
+    {
+      MMX_ZONE("Dense gauss newton step");
+      MMX_HIP(mmx::launchCholeskyStep(
+          ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), pb->sErr.as<double>(),
+          theta_dev, st, sp, s));
+    }
     if (deferred) {
+      MMX_ZONE("Line search");
       MMX_HIP(mmx::launchStepUpdate(pb->rig->dev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
     }
   }
@@ -1561,6 +1651,7 @@ int32_t mmx_solve_host(
     double* final_error_host,
     int32_t* iterations_host,
     int32_t* status_host) {
+  MMX_ZONE("mmx_solve_host");
   int32_t rc = checkProblem(pb, true);
   if (rc != MMX_OK) {
     return rc;
@@ -1600,6 +1691,7 @@ int32_t mmx_eval_jacobian_host(
     float* res_host,
     double* err_host,
     int32_t layout) {
+  MMX_ZONE("mmx_eval_jacobian_host");
   int32_t rc = checkProblem(pb, true);
   if (rc != MMX_OK) {
     return rc;

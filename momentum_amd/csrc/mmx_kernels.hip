@@ -2243,6 +2243,42 @@ hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t strea
   return hipGetLastError();
 }
 
+// =============================================================================================
+// MMX_LAYOUT_ROW_MAJOR: J[b][i * P + p] from the column-major J[b][p * M + i] the assembly kernel writes
+// (the reference's own layout, math/resizeable_matrix.h:18,32-34; row-major is offered for callers that
+// hold torch-style [B][M][P] tensors, pymomentum/tensor_ik/tensor_error_function.cpp).  A 32 x 32 tile
+// per workgroup through LDS (stride 33: conflict-free both ways), reads and writes both in 128-byte runs.
+// =============================================================================================
+__global__ void __launch_bounds__(256) transposeJacobianKernel(const float* __restrict__ colMajor, float* __restrict__ rowMajor, int M, int P) {
+  __shared__ float tile[32][33];
+  const size_t base = size_t(blockIdx.z) * size_t(M) * size_t(P);
+  const int i0 = 32 * blockIdx.x, p0 = 32 * blockIdx.y; // rows i, columns p
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) { // column p0 + k, rows i0 + tx (contiguous in the column-major source)
+    const int p = p0 + k, i = i0 + tx;
+    tile[k][tx] = (p < P && i < M) ? colMajor[base + size_t(p) * M + i] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) { // row i0 + k, columns p0 + tx (contiguous in the row-major destination)
+    const int i = i0 + k, p = p0 + tx;
+    if (i < M && p < P) {
+      rowMajor[base + size_t(i) * P + p] = tile[tx][k];
+    }
+  }
+}
+
+hipError_t launchTransposeJacobian(const float* colMajor, float* rowMajor, int B, int M, int P, hipStream_t stream) {
+  if (B <= 0 || M <= 0 || P <= 0) {
+    return hipSuccess;
+  }
+  for (int b0 = 0; b0 < B; b0 += 65535) { // gridDim.z limit
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    const size_t off = size_t(b0) * size_t(M) * size_t(P);
+    hipLaunchKernelGGL(transposeJacobianKernel, dim3((M + 31) / 32, (P + 31) / 32, nb), dim3(256), 0, stream, colMajor + off, rowMajor + off, M, P);
+  }
+  return hipGetLastError();
+}
+
 size_t fkJacobianLdsBytes(int J, int P, int U) {
   const size_t unitStash = U > 64 ? 5 * size_t(U) : 0; // evaluated units of the multi-chunk J path
   return (((size_t(kJs) * size_t(J) + 3) & ~size_t(3)) + ((size_t(P) + 3) & ~size_t(3)) + ((size_t(J) + 3) & ~size_t(3)) + unitStash) * sizeof(float);

@@ -99,6 +99,8 @@ hipError_t launchFusedSolve(
 size_t fkJacobianLdsBytes(int J, int P, int U);
 // store-only counterpart of the J-assembly kernel (profiling aid; see storePatternKernel)
 hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent);
+// column-major [B][P][M] -> row-major [B][M][P] (MMX_LAYOUT_ROW_MAJOR)
+hipError_t launchTransposeJacobian(const float* colMajor, float* rowMajor, int B, int M, int P, hipStream_t stream);
 size_t normalEquationsLdsBytes(int n);
 size_t choleskyStepLdsBytes(int n, int M);
 

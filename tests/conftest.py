@@ -19,3 +19,12 @@ def orc():
 
     o.build()
     return o
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU (run with -m gpu on the MI355X box)")
+    return torch

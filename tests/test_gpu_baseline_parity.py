@@ -1,0 +1,94 @@
+"""Parity on the BASELINE.json workloads themselves, at the north_star bound: pose parameters of >= 1024
+DISTINCT instances of the very batches bench.py times (generated on the GPU, theta* = U[-0.3, 0.3]^P,
+targets = FK(theta*)) against the CPU oracle's double-precision solve of the same inputs -- 1e-5 relative,
+no sensitivity escape.  (The reference compares solver outputs the same way:
+momentum/test/character_solver/error_function_helpers.cpp:283-370 compares, it does not self-check.)"""
+import numpy as np
+import pytest
+
+import bench
+from momentum_amd._abi import GnOptions
+
+pytestmark = pytest.mark.gpu
+
+BOUND = 1e-5
+
+
+def _solve_and_check(torch, config, B, n_check, line_search=0, step_rule=None, iterations=10):
+    rig, parents, _, cfg_rule, _ = bench.build_rig(config)
+    rule = cfg_rule if step_rule is None else step_rule
+    db = bench.DeviceBatch(rig, parents, B, 0, 20240611)
+    opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=0.05, step_rule=rule, do_line_search=line_search)
+    out = db.pb.solve(db.theta0.clone(), opt)
+    torch.cuda.synchronize()
+    assert int((out["status"] != 0).sum()) == 0
+    assert int((out["iterations"] != iterations).sum()) == 0
+    chk = bench.parity_check(db, out["theta"], opt, n_check)
+    return chk, out, db
+
+
+@pytest.mark.parametrize(
+    "config,B,n_check,line_search",
+    [
+        ("cfg2", 4096, 4096, 0),  # BASELINE configs[1]: EVERY instance of the batch is checked
+        ("cfg2", 4096, 1024, 2),  # the batched driver's default line search (SubsetGN / GN-QR rule)
+        ("cfg2", 4096, 1024, 1),  # GaussNewtonSolverT's own line search
+        ("cfg2_all", 2048, 1024, 0),  # P = 219, M = 864 (NB = 14 instantiation)
+        ("cfg5", 1024, 1024, 0),  # 300-joint rig, wide J: MFMA normal equations + in-HBM Cholesky
+    ],
+)
+def test_baseline_workloads_within_1e5_of_the_oracle(torch_cuda, orc, config, B, n_check, line_search):
+    chk, _, _ = _solve_and_check(torch_cuda, config, B, n_check, line_search)
+    assert chk["instances"] == n_check and chk["distinct"]
+    assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
+
+
+def test_config3_gauss_newton_part_at_full_size(torch_cuda, orc):
+    """BASELINE configs[2]'s batch (65 536 x 72 joints) under the fixed-lambda rule: 2048 distinct instances
+    spread over the whole batch (first, middle, last blocks) at 1e-5."""
+    torch = torch_cuda
+    rig, parents, _, _, _ = bench.build_rig("cfg3")
+    B = 65536
+    db = bench.DeviceBatch(rig, parents, B, 0, 777)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
+    out = db.pb.solve(db.theta0.clone(), opt)
+    torch.cuda.synchronize()
+    assert int((out["status"] != 0).sum()) == 0
+    from oracle import oracle as o
+
+    idx = np.concatenate([np.arange(0, 683), np.arange(B // 2, B // 2 + 683), np.arange(B - 682, B)])
+    sel = torch.as_tensor(idx, device=db.pb.device)
+    c = lambda t: t[sel].cpu().numpy()
+    cons = o.Constraints(parents[0], c(db.pos_offset), c(db.pos_target), c(db.pos_weight), parents[1], c(db.ori_offset), c(db.ori_target), c(db.ori_weight))
+    ref = o.solve_batch(rig, cons, np.zeros((len(idx), rig.num_params), np.float32), opt, dtype="f64", nthreads=bench.usable_cores())
+    th = out["theta"][sel].cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert len(idx) == 2048 and rel.max() <= BOUND, (rel.max(), int((rel > BOUND).sum()))
+
+
+def test_config3_lm_schedule_distinct_instances(torch_cuda, orc):
+    """The LM gain-ratio schedule on 1024 distinct instances of the cfg3 batch.  The schedule takes discrete
+    decisions (rho against 0 / 0.25 / 0.75); an instance whose gain ratio sits on a threshold goes a
+    different -- equally valid -- way in single and in double precision (the oracle's own float
+    instantiation does, too).  So: every instance whose decisions agree with the double solve (same error
+    history to 1e-4) is held to 1e-5, and the others must be few and still be good solutions."""
+    torch = torch_cuda
+    from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
+    from oracle import oracle as o
+
+    rig, parents, _, _, _ = bench.build_rig("cfg3")
+    B, n = 8192, 1024
+    db = bench.DeviceBatch(rig, parents, B, 0, 99)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
+    out = db.pb.solve(db.theta0.clone(), opt, want_history=True)
+    torch.cuda.synchronize()
+    cons = db.host_constraints(n)
+    ref = o.solve_batch(rig, cons, np.zeros((n, rig.num_params), np.float32), opt, dtype="f64", nthreads=bench.usable_cores())
+    th = out["theta"][:n].cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    h, href = out["error_history"][:n].cpu().numpy(), ref["error_history"]
+    same_path = np.abs(h - href).max(axis=1) <= 1e-4 * np.maximum(1e-9, np.abs(href).max(axis=1))
+    assert same_path.mean() >= 0.97, same_path.mean()
+    assert rel[same_path].max() <= BOUND, (rel[same_path].max(), int((rel[same_path] > BOUND).sum()))
+    # the instances that took another branch still converged
+    assert np.all(h[:, -1] <= 1e-3 * h[:, 0])

@@ -198,3 +198,63 @@ def test_store_pattern_probe_writes_every_element(torch_cuda, case):
     got = buf.cpu().numpy()
     assert not np.isnan(got).any()
     assert np.array_equal(got, np.broadcast_to(np.arange(B, dtype=np.float32)[:, None, None], got.shape))
+
+
+def test_passive_limits_are_ignored_like_in_the_reference(torch_cuda, orc):
+    """LimitType::MinMaxJointPassive gets neither an error term nor a row from LimitErrorFunctionT
+    (limit_error_function.cpp:836-837,1051-1052): a limit list with passive entries gives the J / r / error
+    and the solve of the same list without them (rows compacted)."""
+    from momentum_amd import capi
+    from momentum_amd._abi import ParameterLimit as PL
+    from oracle import oracle as o
+
+    torch = torch_cuda
+    rig = make_test_character(8)
+    B = 3
+    cons, th0, _ = make_problem(rig, [7, 3], [6], B, seed=11, theta0_scale=0.3)
+    active = [PL.minmax(1, -0.1, 0.1, 2.0), PL.minmax_joint(2, 4, -0.05, 0.05), PL.linear(3, 4, 0.5, 0.1)]
+    passive = PL.minmax_joint_passive(1, 3, -0.01, 0.01, 5.0)
+    mixed = [passive, active[0], active[1], passive, active[2]]
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, B, limits=mixed, limit_function_weight=0.7)
+    assert pb.M == 3 * 2 + 9 + len(active)
+    full = o.Constraints(cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset, cons.ori_target, cons.ori_weight,
+                         limits=active, limit_function_weight=0.7)  # fmt: skip
+    theta = np.random.default_rng(5).uniform(-0.4, 0.4, size=(B, rig.num_params)).astype(np.float32)
+    jac, res, err = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
+    for b in range(B):
+        J, r, e = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), dtype="f64")
+        assert np.abs(jac[b].cpu().numpy().T - J).max() <= 2e-5 * max(1.0, np.abs(J).max())
+        assert np.abs(res[b].cpu().numpy() - r).max() <= 2e-5 * max(1.0, np.abs(r).max())
+        assert abs(float(err[b]) - e) <= 2e-5 * max(1.0, e)
+    opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)
+    ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+    assert np.abs(out["error"].cpu().numpy() - ref["error"]).max() <= 1e-4 * max(1.0, np.abs(ref["error"]).max())
+
+
+def test_row_major_jacobian_is_the_transpose(torch_cuda):
+    """MMX_LAYOUT_ROW_MAJOR: J[b][i * P + p], bit-identical to the transposed column-major result (sizes
+    that are not multiples of the 32 x 32 transposition tile; limits add rows after the joint rows)."""
+    from momentum_amd import capi
+    from momentum_amd._abi import ParameterLimit as PL
+
+    torch = torch_cuda
+    rig = make_test_character(9)
+    B = 5
+    cons, th0, _ = make_problem(rig, [8, 3, 5], [6, 2], B, seed=21, theta0_scale=0.3)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, B, limits=[PL.minmax(1, -0.1, 0.1, 2.0)])
+    theta = torch.from_numpy(th0.copy()).to(pb.device)
+    jc, rc, ec = pb.eval_jacobian(theta)
+    jr, rr, er = pb.eval_jacobian(theta, row_major=True)
+    assert tuple(jr.shape) == (B, pb.M, pb.P)
+    assert torch.equal(jr, jc.transpose(1, 2).contiguous()) and torch.equal(rc, rr) and torch.equal(ec, er)
+    # host-buffer entry point with the row-major layout
+    import ctypes as C
+
+    jh = np.zeros((B, pb.M, pb.P), np.float32)
+    capi._check(capi.lib().mmx_eval_jacobian_host(pb._h, th0.ctypes.data_as(C.c_void_p), jh.ctypes.data_as(C.c_void_p), None, None, 1))
+    assert np.array_equal(jh, jr.cpu().numpy())

@@ -152,3 +152,37 @@ def test_solve_with_blocks_matches_oracle(torch_cuda, orc, which, mode):
     assert (rel <= tol).all(), (rel, tol)
     hist = out["error_history"].cpu().numpy()
     assert np.abs(hist - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
+
+
+def test_failed_set_constraints_does_not_poison_the_next_call(torch_cuda, orc):
+    """A set_constraints call that fails its validation (here: an ellipsoid limit with a joint index out of
+    range, next to NEW joint blocks) must leave the problem usable: nothing is modified before everything
+    has been validated, so the retry with valid data rebuilds the block tables and J / r match the oracle."""
+    from momentum_amd import capi
+    from momentum_amd._abi import EllipsoidLimit
+
+    torch = torch_cuda
+    rig = make_humanoid72(unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    B = 2
+    rng = np.random.default_rng(9)
+    blk = make_block(TYPES["plane"] if "plane" in TYPES else list(TYPES.values())[0], rng.choice(rig.num_joints, size=7), rng, weight=1.1, batch=B, function_weight=0.9)
+    cons, th0, _ = make_problem(rig, lm[:4], lm[4:6], B, seed=5, perturb=0.3)
+    full = orc.Constraints(cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset, cons.ori_target, cons.ori_weight,
+                           joint_blocks=[blk])  # fmt: skip
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    dev = pb.device
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(dev)
+    args = (t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+            t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)), 1.0, 1.0)  # fmt: skip
+    gb = [_device_block(torch, blk, dev)]
+    bad = EllipsoidLimit.make(rig.num_joints + 3, (0.0, 0.1, 0.0), 0, (0, 0, 0), (0, 0, 0), (1, 1, 1))
+    rows_before = pb.M
+    with pytest.raises(capi.MmxError):
+        pb.set_constraints(*args, joint_blocks=gb, ellipsoid_limits=[bad])
+    assert int(capi.lib().mmx_problem_num_rows(pb._h)) == rows_before  # nothing was modified
+    pb.set_constraints(*args, joint_blocks=gb)
+    assert pb.M == full.rows
+    theta = rng.uniform(-0.3, 0.3, size=(B, rig.num_params)).astype(np.float32)
+    _compare_jacobian(torch, orc, rig, pb, full, theta)
