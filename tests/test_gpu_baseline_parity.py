@@ -86,9 +86,17 @@ def test_config3_lm_schedule_distinct_instances(torch_cuda, orc):
     ref = o.solve_batch(rig, cons, np.zeros((n, rig.num_params), np.float32), opt, dtype="f64", nthreads=bench.usable_cores())
     th = out["theta"][:n].cpu().numpy().astype(np.float64)
     rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
-    h, href = out["error_history"][:n].cpu().numpy(), ref["error_history"]
-    same_path = np.abs(h - href).max(axis=1) <= 1e-4 * np.maximum(1e-9, np.abs(href).max(axis=1))
-    assert same_path.mean() >= 0.97, same_path.mean()
+    # same decisions <=> the same error at EVERY iterate, the final one included (relative, per entry: the
+    # late errors are 1e4 times smaller than the first one, so a difference there hides in a max-norm over
+    # the history).  The error of the final iterate is entry 10 of the same (deterministic) solve run for
+    # eleven iterations.
+    opt11 = GnOptions.make(min_iterations=11, max_iterations=11, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
+    out11 = db.pb.solve(db.theta0.clone(), opt11, want_history=True)
+    ref11 = o.solve_batch(rig, cons, np.zeros((n, rig.num_params), np.float32), opt11, dtype="f64", nthreads=bench.usable_cores())
+    h, href = out11["error_history"][:n].cpu().numpy(), ref11["error_history"]
+    assert np.array_equal(h[:, :10], out["error_history"][:n].cpu().numpy())
+    same_path = np.all(np.abs(h - href) <= 1e-3 * np.abs(href) + 1e-12, axis=1)
+    assert same_path.mean() >= 0.95, same_path.mean()
     assert rel[same_path].max() <= BOUND, (rel[same_path].max(), int((rel[same_path] > BOUND).sum()))
     # the instances that took another branch still converged
     assert np.all(h[:, -1] <= 1e-3 * h[:, 0])
