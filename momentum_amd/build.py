@@ -11,7 +11,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libmmx_hip.so")
+# A/B experiments on one GPU box: MMX_BUILD_VARIANT=name builds momentum_amd/libmmx_hip_<name>.so with
+# -DMMX_EXP_<NAME> (objects kept apart); MMX_LIB=<path> makes capi.py load that library instead.
+VARIANT = os.environ.get("MMX_BUILD_VARIANT", "")
+LIB = os.path.join(HERE, f"libmmx_hip_{VARIANT}.so" if VARIANT else "libmmx_hip.so")
 SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_host_tables.cpp"]
 FUSED_GROUPS = 4  # mmx_fused.hip is compiled once per group of template instantiations, in parallel
 HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_tree.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
@@ -41,8 +44,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         groups = range(FUSED_GROUPS) if src == "mmx_fused.hip" else [None]
         for g in groups:
             stem = os.path.splitext(src)[0] + ("" if g is None else f"_g{g}")
-            obj = os.path.join(CSRC, stem + ".o")
+            obj = os.path.join(CSRC, stem + (f".{VARIANT}" if VARIANT else "") + ".o")
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+            if VARIANT:
+                cmd.insert(1, f"-DMMX_EXP_{VARIANT.upper()}")
             if g is not None:
                 cmd.insert(1, f"-DMMX_FUSED_GROUP={g}")
             if src.endswith(".cpp"):

@@ -17,7 +17,7 @@ from ._abi import ConstraintData, GnOptions, RigDesc, as_ptr
 from .rigs import Rig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmx_hip.so")
+LIB_PATH = os.environ.get("MMX_LIB") or os.path.join(_HERE, "libmmx_hip.so")  # MMX_LIB: A/B experiment builds (momentum_amd/build.py)
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/mmx.h declares (tests/test_abi.py checks the header against this list and

@@ -388,13 +388,50 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     MMX_HIP(upload(pb->dPosUnitStart, f.posUnitStart));
     MMX_HIP(upload(pb->dPosUnits, f.posUnits));
     MMX_HIP(upload(pb->dSolveList, f.solveList));
-    MMX_HIP(upload(pb->dSrcStart, f.srcStart));
-    MMX_HIP(upload(pb->dSrcs, f.srcs));
+    // Source SLOTS of the fused kernel.  Column c of the compacted system keeps its first source in slot c
+    // (the "primary" source: with it alone the slot index IS the column index, so the 16 x 16 tiles of
+    // H = J^T J come straight out of matrix-core products of the per-slot moment contractions, phase G);
+    // slots n .. NP-1 pad the last block (weight 0); the further sources of multi-source columns (shared
+    // parameters) follow from slot NP on, in column order: extras of column c = slots
+    // NP + xStart[c] .. NP + xStart[c+1] - 1.  (Integer bookkeeping, host side.)
+    const int nbFused = mmx::fusedBlocksFor(int32_t(f.solveList.size())); // -1: beyond the fused instantiations (tables unused then)
+    const int nbSlots = nbFused > 0 ? nbFused : std::max((int32_t(f.solveList.size()) + 15) / 16, 1);
+    const int32_t NPs = 16 * nbSlots;
+    std::vector<mmx::ColumnSource> slots(size_t(NPs), mmx::ColumnSource{0, 3, 0, 0, -1, 0.f});
+    std::vector<int32_t> xStart(size_t(NPs) + 1, 0);
+    std::vector<int32_t> slotOf(f.srcs.size(), -1), slotColumn; // source e -> slot ; slot -> column
+    {
+      const int32_t ncol = int32_t(f.solveList.size());
+      slotColumn.assign(size_t(NPs), -1);
+      for (int32_t c = 0; c < ncol; ++c) {
+        xStart[size_t(c)] = int32_t(slots.size()) - NPs;
+        for (int32_t e = f.srcStart[size_t(c)]; e < f.srcStart[size_t(c) + 1]; ++e) {
+          if (e == f.srcStart[size_t(c)]) {
+            slots[size_t(c)] = f.srcs[size_t(e)];
+            slotOf[size_t(e)] = c;
+            slotColumn[size_t(c)] = c;
+          } else {
+            slotOf[size_t(e)] = int32_t(slots.size());
+            slotColumn.push_back(c);
+            slots.push_back(f.srcs[size_t(e)]);
+          }
+        }
+      }
+      for (int32_t c = ncol; c <= NPs; ++c) {
+        xStart[size_t(c)] = int32_t(slots.size()) - NPs;
+      }
+      while (slots.size() % 4 != 0) {
+        slots.push_back(mmx::ColumnSource{0, 3, 0, 0, -1, 0.f});
+        slotColumn.push_back(-1);
+      }
+    }
+    MMX_HIP(upload(pb->dSrcStart, xStart));
+    MMX_HIP(upload(pb->dSrcs, slots));
     mmx::FusedDev& fd = pb->fdev;
     fd.U = pb->U;
     fd.Kp = pb->Kp;
     fd.n = int32_t(f.solveList.size());
-    fd.nsrc = int32_t(f.srcs.size());
+    fd.nsrc = int32_t(slots.size());
     fd.nnz = rig->ptOuter.back();
     fd.subSize = pb->dSubSize.as<int32_t>();
     fd.dfsJoint = pb->dDfsJoint.as<int32_t>();
@@ -406,14 +443,14 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     fd.solveList = pb->dSolveList.as<int32_t>();
     fd.srcStart = pb->dSrcStart.as<int32_t>();
     fd.srcs = pb->dSrcs.as<mmx::ColumnSourceDev>();
-    // Structural term records of H (integer bookkeeping): entry (row, col), row >= col, of the
-    // compacted system receives one term per pair (source a of row, source c of col) whose joints
-    // are in an ancestor relation; the deeper source supplies the moment contractions, the other
-    // one alpha / B (mmx_fused.hip phase G).  Entries are dealt to the 256 threads of a workgroup
-    // in contiguous runs of roughly equal term count; a thread's records are stored interleaved
+    // Structural term records of H for the pairs the matrix-core pass does not cover: entry (row, col),
+    // row >= col, receives one term per pair (source a of row, source c of col) whose joints are in an
+    // ancestor relation AND of which at least one is an extra source; the deeper source supplies the
+    // moment contractions, the other one alpha / B (mmx_fused.hip phase G; weights are folded into the
+    // per-slot tables, the record's weight word stays 1).  Entries are dealt to the 256 threads of a
+    // workgroup in contiguous runs of roughly equal term count; a thread's records are stored interleaved
     // (record k of thread t at [k * 256 + t]) so that a wave reads them coalesced.
     {
-      const int nb = std::max(mmx::fusedBlocksFor(fd.n), 1);
       struct Term {
         uint32_t deep, anc;
         float w;
@@ -423,22 +460,24 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         std::vector<Term> terms;
       };
       std::vector<Entry> entries;
-      size_t totalTerms = 0;
       for (int32_t row = 0; row < fd.n; ++row) {
         for (int32_t col = 0; col <= row; ++col) {
           Entry en;
           for (int32_t er = f.srcStart[row]; er < f.srcStart[row + 1]; ++er) {
             for (int32_t ec = f.srcStart[col]; ec < f.srcStart[col + 1]; ++ec) {
+              if (er == f.srcStart[row] && ec == f.srcStart[col]) {
+                continue; // primary x primary: the matrix-core pass
+              }
               const mmx::ColumnSource &sa = f.srcs[er], &sc = f.srcs[ec];
               int32_t deep, anc;
               if (sc.tin <= sa.tin && sa.tin < sc.tout) {
-                deep = er, anc = ec;
+                deep = slotOf[size_t(er)], anc = slotOf[size_t(ec)];
               } else if (sa.tin <= sc.tin && sc.tin < sa.tout) {
-                deep = ec, anc = er;
+                deep = slotOf[size_t(ec)], anc = slotOf[size_t(er)];
               } else {
                 continue;
               }
-              en.terms.push_back(Term{uint32_t(deep), uint32_t(anc), sa.weight * sc.weight});
+              en.terms.push_back(Term{uint32_t(deep), uint32_t(anc), 1.f});
             }
           }
           if (en.terms.empty()) {
@@ -447,18 +486,16 @@ int32_t uploadProblemTables(mmx_problem* pb) {
           const int I = row >> 4, Jc = col >> 4, r = row & 15, c = col & 15;
           const int t = I * (I + 1) / 2 + Jc;
           en.dest = t * 256 + r * 16 + ((((c >> 2) ^ (r >> 2)) & 3) << 2) + (c & 3); // tileAddr()
-          totalTerms += en.terms.size();
           entries.push_back(std::move(en));
         }
       }
-      (void)nb;
       if (fd.nsrc >= (1 << 12)) {
         return fail(MMX_ERR_UNSUPPORTED, "more than 4095 column sources");
       }
-      // Entries with many terms (shared parameters with many sources) are split into chunks of at
+      // Entries with many terms (pairs of shared parameters with many sources) are split into chunks of at
       // most kCap terms: chunk 0 stores to the entry itself, every further chunk to a private
       // partial cell that one thread adds to the entry afterwards, in a fixed order.
-      constexpr size_t kCap = 16;
+      constexpr size_t kCap = 8; // = the records one trip of the kernel's loop consumes
       struct Run {
         int32_t dest; // >= 0: float offset in the tile region ; < 0: -(cell + 1) partial cell
         size_t entry, first, count;
@@ -1493,16 +1530,17 @@ int32_t mmx_solve(
       MMX_HIP(hipStreamSynchronize(s));
       static const char* names[24] = {"A jointParams", "B fk", "C units", "D subtree sums", "E srcTables", "F g + zero tiles",
                                       "G combine + pull", "H cholesky(tail)", "I solve", "J tail (d0 += rho)", "K update",
-                                      "H.a publish", "G term records", "H.bc panel", "H.d mfma", "D own sums", "J jd",
-                                      "J tangent+own", "J subtree", "J rho", "J solve", "(unused)", "H.b load+barrier", "H.b chain"};
-      long long tot = 0;
+                                      "G extras: records", "G term records", "H.bc panel", "H.d mfma", "D own sums", "J jd",
+                                      "J tangent+own", "J subtree", "J rho", "J solve", "G extras: loads", "H.b load+barrier", "H.b chain"};
+      long long tot = h[24] + h[25];
       for (int i = 0; i < 24; ++i) {
         tot += h[i];
       }
-      fprintf(stderr, "[mmx phase clocks, block 0, all iterations] total %lld\n", tot);
+      fprintf(stderr, "[mmx phase clocks, block 0, all iterations] total %lld  (termRounds %d, numComb %d, nsrc %d, n %d)\n", tot, pb->fdev.termRounds, pb->fdev.numComb, pb->fdev.nsrc, pb->fdev.n);
       for (int i = 0; i < 24; ++i) {
         fprintf(stderr, "  %-16s %10lld  %5.1f%%\n", names[i], h[i], 100.0 * double(h[i]) / double(tot > 0 ? tot : 1));
       }
+      fprintf(stderr, "  (of B fk: local transforms %lld, pointer jumping %lld, axes = the rest of B)\n", h[24], h[25]);
     }
     return MMX_OK;
   }

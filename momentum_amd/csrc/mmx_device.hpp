@@ -20,7 +20,8 @@
 
 namespace mmx {
 
-constexpr int kJs = 20; // floats per joint in js[]
+constexpr int kJs = 21; // floats per joint in js[]: 17 used, odd stride (lanes = joints read a field without LDS bank conflicts)
+constexpr int kAlt = 9; // floats per joint in the second pointer-jumping buffer: 8 used, odd stride
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {
@@ -272,7 +273,7 @@ __device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* _
 
 // World transforms of all joints by double-buffered pointer jumping (see fkJacobianKernel for the
 // single-buffer form): `rounds` = ceil(log2(depth)) rounds, one workgroup barrier each.  Buffers:
-// js (stride kJs) and alt (stride 8), jump targets (+1) in jlA / jlB.  Precondition (barrier
+// js (stride kJs) and alt (stride kAlt), jump targets (+1) in jlA / jlB.  Precondition (barrier
 // done): the local transforms and the initial targets (= parents) are in js / jlA when `rounds`
 // is even, in alt / jlB when it is odd; the result always ends up in js.
 __device__ __forceinline__ void
@@ -281,7 +282,7 @@ fkJumpRounds(float* js, float* alt, int* jlA, int* jlB, int J, int rounds, int t
     const bool fromJs = ((rounds - r) & 1) == 0;
     const float* src = fromJs ? js : alt;
     float* dst = fromJs ? alt : js;
-    const int ss = fromJs ? kJs : 8, ds = fromJs ? 8 : kJs;
+    const int ss = fromJs ? kJs : kAlt, ds = fromJs ? kAlt : kJs;
     const int* jlS = fromJs ? jlA : jlB;
     int* jlD = fromJs ? jlB : jlA;
     for (int j = tid; j < J; j += nthreads) {
@@ -866,8 +867,7 @@ evalLimit(const RigDev& rig, const LimitDev& lm, const float* th, const uint8_t*
 // ---- 16x16 fp32 tile helpers shared by the fused solver and the large-system Cholesky
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kSrc = 16; // floats per column source: G0(3) AX(3) TR(1) AL(3) BV(3) BS(1) GJ(1) pad(1)
-constexpr int kTan = 8; // tangent-pass floats per joint: C(3) W(3) S(1) pad
+constexpr int kTan = 9; // tangent-pass floats per joint: C(3) W(3) S(1) jump target (odd stride)
 
 // swizzled address of element (row, col) inside a 16x16 fp32 tile (row-major, 16-byte chunks
 // XOR-ed with the row group so that b128 reads of one chunk column hit distinct banks)

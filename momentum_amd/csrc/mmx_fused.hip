@@ -34,8 +34,10 @@ namespace mmx {
 
 struct FusedLds {
   // ---- loaded once per launch (batch-shared integer tables and the parameter-transform CSR)
-  int* mStart; // [NP+1] column -> first source (padded columns are empty)
-  int* mTin; // [nsrc] DFS position of the source's joint
+  // source SLOTS: slot c < NP is the primary source of column c (pad columns: weight 0), slots >= NP are
+  // the further sources of multi-source columns: extras of column c = NP + mStart[c] .. NP + mStart[c+1] - 1
+  int* mStart; // [NP+1] column -> number of extra slots before it
+  int* mTin; // [nsrc] DFS interval of the slot's joint: tin | tout << 16
   int* mInfo; // [nsrc] joint | dof << 12 | (parent + 1) << 16
   float* mW; // [nsrc]
   // ---- per iteration
@@ -58,15 +60,15 @@ struct FusedLds {
   double* red; // [8]
   int* flags; // [4]
   // ---- one region, two lives: assembly scratch (phases A-G), then the Cholesky factor (H-J)
-  float* alt; // [8 J] second transform buffer of the pointer-jumping FK
+  float* alt; // [kAlt J] second transform buffer of the pointer-jumping FK
   int* jlA; // [J] jump targets (+1), double-buffered
   int* jlB;
   float* own2; // [kC2 J]
-  float* umom; // [(kC1 + kC2) U] per-unit moment contributions (phase D only)
+  float* umom; // [kUmom U] per-unit moment contributions (phase D only)
   float* sub2; // [kC2 J]
   float* L; // [T][256] tiles; a diagonal tile holds L_kk (lower triangle) and L_kk^-T (strict upper triangle)
   // ---- aliases the refinement scratch (dfull, jd, tanOwn, tanPre): dead before phase J starts
-  float* srcT; // [kSrc nsrc]
+  float* srcT; // [15][srcStride]: weighted D (7 channels) | weighted A (7) | weighted J^T r share (1), channel-major
 };
 
 // Views of the batch-shared tables after they were copied into LDS.  Plain local structs whose
@@ -100,6 +102,13 @@ struct FusedView {
 __host__ __device__ __forceinline__ size_t alignUp4(size_t x) {
   return (x + 3) & ~size_t(3);
 }
+// channel stride of the per-slot tables: >= nsrc and = 16 mod 32, so that the 16 slots x 2 channels a
+// 32-lane group reads as MFMA operands (phase G) fall into 32 different banks
+__host__ __device__ __forceinline__ int srcStrideFor(int nsrc) {
+  int x = (nsrc + 15) & ~15;
+  return (x & 31) == 16 ? x : x + 16;
+}
+constexpr int kSrcCh = 15; // D(7) | A(7) | g share
 
 // ---------------------------------------------------------------------------------------------
 // adjoint machinery: sums over a joint's own units, then over its subtree (= a DFS index range)
@@ -117,10 +126,10 @@ __device__ __forceinline__ void firstOrderMoments(float* o, F3 p, float yx, floa
   o[1] = point ? yy : 0.f;
   o[2] = point ? yz : 0.f;
   o[6] = point ? p.x * yx + p.y * yy + p.z * yz : 0.f;
-  o[7] = 0.f;
 }
 
-template <int NCH>
+// NCH channels per unit (kC1 first-order, then kC2Used second-order ones), stored with stride STRIDE (odd)
+template <int NCH, int STRIDE>
 __device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLds& s, const float* umom, int tid) {
   for (int item = tid; item < fd.numLoaded * NCH; item += 256) {
     const int li = item / NCH, c = item - li * NCH;
@@ -128,7 +137,7 @@ __device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLd
     float acc = 0.f;
     const int e1 = fd.posUnitStart[k + 1];
     for (int e = fd.posUnitStart[k]; e < e1; ++e) {
-      acc += umom[NCH * fd.posUnits[e] + c];
+      acc += umom[STRIDE * fd.posUnits[e] + c];
     }
     if (c < kC1) {
       s.own1[kC1 * k + c] = acc;
@@ -137,20 +146,21 @@ __device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLd
     }
   }
 }
+constexpr int kUmom = 25; // stride of the per-unit moment scratch: 7 + 16 channels, odd
 
 // phase D: first- and second-order own sums from up / uy / us
 __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, float* umom, int U, int tid) {
-  constexpr int NCH = kC1 + kC2;
+  constexpr int NCH = kC1 + kC2Used;
   for (int u = tid; u < U; u += 256) {
     const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
     const bool point = u < fd.Kp;
-    float* o = umom + NCH * u;
+    float* o = umom + kUmom * u;
     firstOrderMoments(o, p, s.uy[3 * u], s.uy[3 * u + 1], s.uy[3 * u + 2], point);
     const float sg = s.us[u];
     const float s2 = sg * sg;
     float* o2 = o + kC1;
 #pragma unroll
-    for (int c = 0; c < kC2; ++c) {
+    for (int c = 0; c < kC2Used; ++c) {
       o2[c] = 0.f;
     }
     const int q = point ? 4 : 10;
@@ -168,12 +178,12 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
     }
   }
   __syncthreads();
-  gatherOwnSums<NCH>(fd, s, umom, tid);
+  gatherOwnSums<NCH, kUmom>(fd, s, umom, tid);
 }
 
-template <int NC, bool kSubtree>
+template <int NC, bool kSubtree, int STRIDE = NC>
 __device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, float* out, int J, int wave, int lane) {
-  treeSumT<NC, kSubtree>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
+  treeSumT<NC, kSubtree, STRIDE>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -238,15 +248,24 @@ __device__ __forceinline__ ParamCol paramRowsColumn(
 // by pointer jumping (skeleton_state.cpp:100-121 re-associated), optionally the rotation axes.
 // Ends with a barrier.  Clobbers alt / jlA / jlB (assembly scratch = the Cholesky region).
 __device__ __forceinline__ void
-blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes) {
+blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes, long long* clk = nullptr, long long* clkLast = nullptr) {
+  auto stamp = [&](int slot) { // profiling aid (MMX_PHASE_CLOCKS): sub-phases of FK
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+      const long long now = clock64();
+      clk[slot] += now - *clkLast;
+      *clkLast = now;
+    }
+  };
   const bool odd = (rig.jumpRounds & 1) != 0;
   for (int j = tid; j < rig.J; j += 256) {
     float* slot = s.js + kJs * j;
-    fkLocalSplit(rig, j, th, odd ? s.alt + 8 * j : slot, slot + 8);
+    fkLocalSplit(rig, j, th, odd ? s.alt + kAlt * j : slot, slot + 8);
     (odd ? s.jlB : s.jlA)[j] = rig.parent[j] + 1;
   }
   __syncthreads();
+  stamp(24);
   fkJumpRounds(s.js, s.alt, s.jlA, s.jlB, rig.J, rig.jumpRounds, tid, 256);
+  stamp(25);
   if (withAxes) {
     for (int j = tid; j < rig.J; j += 256) {
       fkAxesInPlaceP(rig, j, rig.parent[j], s.js);
@@ -484,7 +503,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+#ifdef MMX_EXP_STATIC // experiment: every size a compile-time constant (cfg2), so that every LDS address is a literal
+  constexpr int J = 72, P = 128, U = 64, n = 96, nsrc = 112, kR = 504, kNnz = 167, kLevels = 13;
+#else
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
+  const int kR = rig.R, kNnz = fd.nnz, kLevels = rig.numLevels;
+#endif
 
   // ---- LDS carve (every offset a multiple of 4 floats); must match fusedLdsBytes()
   FusedLds s;
@@ -503,10 +527,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     s.mW = take(nsrc);
     lParent = reinterpret_cast<int*>(take(J));
     lLevelOrder = reinterpret_cast<int*>(take(J));
-    lLevelStart = reinterpret_cast<int*>(take(rig.numLevels + 1));
-    lPtOuter = reinterpret_cast<int*>(take(rig.R + 1));
-    lPtInner = reinterpret_cast<int*>(take(fd.nnz));
-    lPtValue = take(fd.nnz);
+    lLevelStart = reinterpret_cast<int*>(take(kLevels + 1));
+    lPtOuter = reinterpret_cast<int*>(take(kR + 1));
+    lPtInner = reinterpret_cast<int*>(take(kNnz));
+    lPtValue = take(kNnz);
     lSubSize = reinterpret_cast<int*>(take(J));
     lPosUnitStart = reinterpret_cast<int*>(take(J + 1));
     lPosUnits = reinterpret_cast<int*>(take(U));
@@ -536,18 +560,18 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     s.tanPre = take(size_t(kTan) * J);
     s.srcT = blockJ;
     {
-      float* endSrc = blockJ + alignUp4(size_t(kSrc) * nsrc);
+      float* endSrc = blockJ + size_t(kSrcCh) * srcStrideFor(nsrc);
       if (endSrc > p) {
         p = endSrc;
       }
     }
     float* region = p;
-    s.alt = take(8 * size_t(J));
+    s.alt = take(size_t(kAlt) * J);
     s.jlA = reinterpret_cast<int*>(take(J));
     s.jlB = reinterpret_cast<int*>(take(J));
     s.own2 = take(size_t(kC2) * J);
     s.sub2 = take(size_t(kC2) * J);
-    s.umom = take(size_t(kC1 + kC2) * U);
+    s.umom = take(size_t(kUmom) * U);
     s.L = region;
   }
 
@@ -556,11 +580,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     s.th[i] = thg[i];
   }
   for (int c = tid; c <= NP; c += 256) {
-    s.mStart[c] = fd.srcStart[c < n ? c : n];
+    s.mStart[c] = fd.srcStart[c];
   }
   for (int e = tid; e < nsrc; e += 256) {
     const ColumnSourceDev cs = fd.srcs[e];
-    s.mTin[e] = cs.tin;
+    s.mTin[e] = cs.tin | (cs.tout << 16);
     s.mInfo[e] = cs.joint | (cs.dof << 12) | ((cs.parent + 1) << 16);
     s.mW[e] = cs.weight;
   }
@@ -568,13 +592,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     lParent[i] = rig.parent[i];
     lSubSize[i] = fd.subSize[i];
   }
-  for (int i = tid; i <= rig.numLevels; i += 256) {
+  for (int i = tid; i <= kLevels; i += 256) {
     lLevelStart[i] = rig.levelStart[i];
   }
-  for (int i = tid; i <= rig.R; i += 256) {
+  for (int i = tid; i <= kR; i += 256) {
     lPtOuter[i] = rig.ptOuter[i];
   }
-  for (int i = tid; i < fd.nnz; i += 256) {
+  for (int i = tid; i < kNnz; i += 256) {
     lPtInner[i] = rig.ptInner[i];
     lPtValue[i] = rig.ptValue[i];
   }
@@ -615,7 +639,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
   }
   // from here on the kernel reads the batch-shared tables through these LDS-backed views
   RigView rv;
-  rv.J = J, rv.P = P, rv.R = rig.R, rv.numLevels = rig.numLevels, rv.jumpRounds = rig.jumpRounds;
+  rv.J = J, rv.P = P, rv.R = kR, rv.numLevels = kLevels, rv.jumpRounds = rig.jumpRounds;
   rv.parent = lParent, rv.preRot = rig.preRot, rv.offset = rig.offset;
   rv.ptOuter = lPtOuter, rv.ptInner = lPtInner, rv.ptValue = lPtValue, rv.ptOffsets = rig.ptOffsets;
   rv.levelOrder = lLevelOrder, rv.levelStart = lLevelStart;
@@ -653,7 +677,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     // hides behind it (one round trip per iteration instead of two)
     const UnitInput uin0 = loadUnitInput(pb, b, tid < U ? tid : U);
     // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
-    blockFk(rv, s, s.th, tid, true);
+    blockFk(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast);
     MMX_CLK(1)
     // ================= C: units (need only the world transforms, not the axes)
     {
@@ -683,10 +707,14 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     __syncthreads();
     MMX_CLK(15)
     treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
-    treeSum<kC2, true>(fv, s.own2, s.sub2, J, wave, lane);
+    treeSum<kC2Used, true, kC2>(fv, s.own2, s.sub2, J, wave, lane);
     __syncthreads();
     MMX_CLK(3)
-    // ================= E: column-source tables
+    // ================= E: per-slot tables (weight folded in), channel-major
+    const int sst = srcStrideFor(nsrc);
+    float* srcD = s.srcT; // [7][sst]  G0(3) AX(3) TR
+    float* srcA = s.srcT + 7 * sst; // [7][sst]  AL(3) BV(3) BS
+    float* srcG = s.srcT + 14 * sst; // [sst]     the slot's share of g = J^T r
     for (int e = tid; e < nsrc; e += 256) {
       ColumnSourceDev cs;
       {
@@ -694,7 +722,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
         cs.joint = info & 0xfff;
         cs.dof = (info >> 12) & 7;
         cs.parent = (info >> 16) - 1;
-        cs.tin = s.mTin[e];
+        cs.tin = s.mTin[e] & 0xffff;
       }
       const float* a = s.js + kJs * cs.joint;
       const float* sb = s.sub2 + kC2 * cs.tin;
@@ -729,24 +757,25 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
         ax = cross(m1, al);
         tr = dot(al, m1) + kLn2 * (sb[4] + sb[7] + sb[9]);
       }
-      float* o = s.srcT + kSrc * e;
-      o[0] = g0.x, o[1] = g0.y, o[2] = g0.z;
-      o[3] = ax.x, o[4] = ax.y, o[5] = ax.z;
-      o[6] = tr;
-      o[7] = al.x, o[8] = al.y, o[9] = al.z;
-      o[10] = bv.x, o[11] = bv.y, o[12] = bv.z;
-      o[13] = bs;
-      o[14] = sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
-      o[15] = 0.f;
+      const float w = s.mW[e]; // pad slots: 0
+      float* d = srcD + e;
+      d[0] = w * g0.x, d[sst] = w * g0.y, d[2 * sst] = w * g0.z;
+      d[3 * sst] = w * ax.x, d[4 * sst] = w * ax.y, d[5 * sst] = w * ax.z;
+      d[6 * sst] = w * tr;
+      float* o = srcA + e;
+      o[0] = w * al.x, o[sst] = w * al.y, o[2 * sst] = w * al.z;
+      o[3 * sst] = w * bv.x, o[4 * sst] = w * bv.y, o[5 * sst] = w * bv.z;
+      o[6 * sst] = w * bs;
+      srcG[e] = w * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
     }
     __syncthreads();
     MMX_CLK(4)
     // ================= F: g = J^T r (compacted), padded with zeros
     for (int c = tid; c < NP; c += 256) {
-      float acc = 0.f;
-      const int e1 = s.mStart[c + 1];
-      for (int e = s.mStart[c]; e < e1; ++e) {
-        acc += s.mW[e] * s.srcT[kSrc * e + 14];
+      float acc = srcG[c]; // pad columns: weight 0
+      const int e1 = NP + s.mStart[c + 1];
+      for (int e = NP + s.mStart[c]; e < e1; ++e) {
+        acc += srcG[e];
       }
       if (hasParamRows && c < n) {
         const ParamCol pc = paramRowsColumn(rig, pb, fd, s.th, nullptr, lColToSolve, P, b, c, lSolveList[c]);
@@ -757,57 +786,126 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
       s.d0[c] = acc;
     }
     MMX_CLK(5)
-    // ================= G: H = J^T J from the moment contractions.  The structurally non-zero
-    // terms are host-built records dealt evenly to the 256 threads; each thread accumulates the
-    // terms of an entry (consecutive records) and stores the entry into the LDS tile region, which
-    // the owning waves then pull into their MFMA accumulator registers.
-    for (int i = tid; i < T * 64; i += 256) {
-      reinterpret_cast<float4*>(s.L)[i] = float4{0.f, 0.f, 0.f, 0.f}; // loc / moments are dead (barrier after E)
-    }
-    __syncthreads();
-    MMX_CLK(5)
+    // ================= G: H = J^T J from the moment contractions.  Entry (r, c) of the primary slots is
+    //   w_r w_c (G0.AL + AX.BV + TR BS)(deep, ancestor),   deep = the slot whose joint lies below the other's,
+    // i.e. one of the two 7-term products D_r . A_c or A_r . D_c, selected by the DFS intervals -- so every
+    // 16 x 16 tile is two matrix-core products (K = 7 padded to 8: two v_mfma_f32_16x16x4_f32 each) of the
+    // channel-major slot tables, masked, and stored straight into the LDS tile (O(1) work per entry,
+    // independent of the number of constraint rows; the scratch region became free at the barrier after
+    // E).  The pairs that involve an extra source of a multi-source column are added afterwards from
+    // host-built term records.
     {
-      float h = 0.f;
-      for (int k0 = 0; k0 < fd.termRounds; k0 += 8) {
-        uint4 rec[8];
+      const int i = lane & 15, gq = lane >> 4;
+      const int k1 = gq < 3 ? 4 + gq : 6; // second MFMA: channel 4 + gq; channel 7 is zero (clamped address, value dropped)
+      // operands of a tile: rows of block I on the A side, rows of block Jc on the B side
+      struct TileOps {
+        float dI0, aI0, dJ0, aJ0, dI1, aI1, dJ1, aJ1;
+        int spanC, spanR[4];
+      };
+      auto loadOps = [&](int I, int Jc) {
+        TileOps o;
+        const int ri = 16 * I + i, ci = 16 * Jc + i;
+        o.dI0 = srcD[gq * sst + ri], o.aI0 = srcA[gq * sst + ri];
+        o.dJ0 = srcD[gq * sst + ci], o.aJ0 = srcA[gq * sst + ci];
+        o.dI1 = srcD[k1 * sst + ri], o.aI1 = srcA[k1 * sst + ri];
+        o.dJ1 = srcD[k1 * sst + ci], o.aJ1 = srcA[k1 * sst + ci];
+        o.spanC = s.mTin[ci];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          rec[k] = fd.gTerms[(k0 + k) * 256 + tid];
+        for (int q = 0; q < 4; ++q) {
+          o.spanR[q] = s.mTin[16 * I + 4 * gq + q];
         }
+        return o;
+      };
+      // the wave's tiles t = wave, wave + 4, ... in (I, Jc) form, advanced without a square root
+      int I = 0, Jc = wave;
+      auto normalise = [&]() {
+        while (Jc > I) {
+          Jc -= I + 1;
+          ++I;
+        }
+      };
+      normalise();
+      TileOps cur = loadOps(I < NB ? I : 0, I < NB ? Jc : 0);
+      for (int t = wave; t < T; t += 4) {
+        const int tI = I, tJ = Jc;
+        Jc += 4;
+        normalise();
+        const bool more = t + 4 < T; // wave-uniform
+        TileOps nxt = loadOps(more ? I : tI, more ? Jc : tJ); // the next tile's LDS reads fly while this one multiplies
+        const float z = gq == 3 ? 0.f : 1.f;
+        v4f P{0.f, 0.f, 0.f, 0.f}, Q{0.f, 0.f, 0.f, 0.f};
+        P = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dI0, cur.aJ0, P, 0, 0, 0); // P[r][c] = D_r . A_c : row slot deep
+        Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aI0, cur.dJ0, Q, 0, 0, 0); // Q[r][c] = A_r . D_c : column slot deep
+        P = __builtin_amdgcn_mfma_f32_16x16x4f32(z * cur.dI1, cur.aJ1, P, 0, 0, 0);
+        Q = __builtin_amdgcn_mfma_f32_16x16x4f32(z * cur.aI1, cur.dJ1, Q, 0, 0, 0);
+        const int tinC = cur.spanC & 0xffff, toutC = cur.spanC >> 16;
+        float* Tc = s.L + 256 * tileIndex(tI, tJ);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          __builtin_amdgcn_sched_barrier(0); // keep one record's LDS operands live at a time
-          const uint32_t x = rec[k].x;
-          if (x & (1u << 26)) {
-            const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
-            const float4 d0v = *reinterpret_cast<const float4*>(s.srcT + kSrc * deep);
-            const float4 d1v = *reinterpret_cast<const float4*>(s.srcT + kSrc * deep + 4);
-            const float4 a1v = *reinterpret_cast<const float4*>(s.srcT + kSrc * anc + 4);
-            const float4 a2v = *reinterpret_cast<const float4*>(s.srcT + kSrc * anc + 8);
-            const float4 a3v = *reinterpret_cast<const float4*>(s.srcT + kSrc * anc + 12);
-            // G0.AL + AX.BV + TR*BS   (G0 = d0v.xyz, AX = d0v.w d1v.xy, TR = d1v.z;
-            //                          AL = a1v.w a2v.xy, BV = a2v.zw a3v.x, BS = a3v.y)
-            const float hj = d0v.x * a1v.w + d0v.y * a2v.x + d0v.z * a2v.y + d0v.w * a2v.z + d1v.x * a2v.w +
-                d1v.y * a3v.x + d1v.z * a3v.y;
-            const float v = __uint_as_float(rec[k].z) * hj;
-            h = (x & (1u << 24)) ? v : h + v;
-            if (x & (1u << 25)) {
-              const uint32_t y = rec[k].y;
-              float* dst = (y & (1u << 30)) ? s.own1 + (y & 0xffff) : s.L + y; // own1 is free during G
-              *dst = h;
-            }
-          }
+        for (int q = 0; q < 4; ++q) {
+          const int tinR = cur.spanR[q] & 0xffff, toutR = cur.spanR[q] >> 16;
+          const bool rowDeep = tinC <= tinR && tinR < toutC; // the column's joint is the row's joint or above it
+          const bool colDeep = tinR <= tinC && tinC < toutR;
+          Tc[tileAddr(4 * gq + q, i)] = rowDeep ? P[q] : (colDeep ? Q[q] : 0.f);
         }
+        cur = nxt;
       }
     }
     __syncthreads();
     MMX_CLK(12)
+#ifdef MMX_EXP_NOREC
+    if (false) {
+#else
+    if (fd.termRounds > 0) {
+#endif
+      float h = 0.f;
+      for (int k0 = 0; k0 < fd.termRounds; k0 += 8) {
+        uint2 rec[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint4* rp = fd.gTerms + (k0 + k) * 256 + tid;
+          rec[k] = *reinterpret_cast<const uint2*>(rp); // x: deep | anc << 12 | flags ; y: destination
+        }
+        if (MODE == 2) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          MMX_CLK(21)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t x = rec[k].x;
+          if (x & (1u << 26)) {
+            const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
+            float dv[7], av[7]; // all fourteen reads in flight together: one LDS round trip per record
+#pragma unroll
+            for (int ch = 0; ch < 7; ++ch) {
+              dv[ch] = srcD[ch * sst + deep];
+              av[ch] = srcA[ch * sst + anc];
+            }
+            float hj = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 7; ++ch) {
+              hj += dv[ch] * av[ch];
+            }
+            h = (x & (1u << 24)) ? hj : h + hj;
+            if (x & (1u << 25)) {
+              const uint32_t y = rec[k].y;
+              if (y & (1u << 30)) {
+                s.sub1[y & 0xffff] = h; // partial cell of a split entry (sub1 is free between E and the refinement)
+              } else {
+                s.L[y] += h; // one thread per entry
+              }
+            }
+          }
+        }
+        MMX_CLK(11)
+      }
+      __syncthreads();
+    }
     if (fd.numComb > 0) { // entries that were split into chunks: add the partial cells, fixed order
       for (int i = tid; i < fd.numComb; i += 256) {
         const int dest = fd.comb[3 * i], first = fd.comb[3 * i + 1], cnt = fd.comb[3 * i + 2];
         float v = s.L[dest];
         for (int c = 0; c < cnt; ++c) {
-          v += s.own1[first + c];
+          v += s.sub1[first + c];
         }
         s.L[dest] = v;
       }
@@ -1099,7 +1197,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
           __syncthreads();
         }
       } else {
-        treeSum<kTan, false>(fv, s.tanOwn, s.tanPre, J, wave, lane);
+        treeSum<7, false, kTan>(fv, s.tanOwn, s.tanPre, J, wave, lane);
         __syncthreads();
       }
       // w = r - J d, y = sigma w per unit, then the first-order own sums.  sub1 (free until the
@@ -1118,11 +1216,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
               s.sub1 + kC1 * u, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
         }
         __syncthreads();
-        gatherOwnSums<kC1>(fv, s, s.sub1, tid);
+        gatherOwnSums<kC1, kC1>(fv, s, s.sub1, tid);
       } else {
         for (int k = tid; k < J; k += 256) {
           const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
-          float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           if (e1 > e0) {
             const float* pre = s.tanPre + kTan * k;
             for (int e = e0; e < e1; ++e) {
@@ -1153,26 +1251,29 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
       treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
       __syncthreads();
       MMX_CLK(18)
-      // J^T w per column source in parallel (tanOwn is free again), then per column the sum of its sources
+      // J^T w per slot in parallel (tanOwn is free again), then per column the sum of its slots
       const bool perSource = nsrc <= kTan * J;
       if (perSource) {
         for (int e = tid; e < nsrc; e += 256) {
           const int info = s.mInfo[e];
-          s.tanOwn[e] = s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
+          s.tanOwn[e] = s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * (s.mTin[e] & 0xffff));
         }
         __syncthreads();
       }
       for (int c = tid; c < NP; c += 256) {
         float a = 0.f;
         if (c < n) {
-          const int e1 = s.mStart[c + 1];
-          for (int e = s.mStart[c]; e < e1; ++e) {
+          auto slotShare = [&](int sl) {
             if (perSource) {
-              a += s.tanOwn[e];
-            } else {
-              const int info = s.mInfo[e];
-              a += s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * s.mTin[e]);
+              return s.tanOwn[sl];
             }
+            const int info = s.mInfo[sl];
+            return s.mW[sl] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * (s.mTin[sl] & 0xffff));
+          };
+          a = slotShare(c); // the primary slot, then the extras
+          const int e1 = NP + s.mStart[c + 1];
+          for (int e = NP + s.mStart[c]; e < e1; ++e) {
+            a += slotShare(e);
           }
           if (hasParamRows) {
             a += paramRowsColumn(rig, pb, fd, s.th, s.d0, lColToSolve, P, b, c, lSolveList[c]).g;
@@ -1327,8 +1428,9 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
       a4(J + 1) + 2 * a4(U) + a4(n) + 2 * a4(J) + a4(P);
   const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 4;
   const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
-  const size_t blockJ = refine > a4(size_t(kSrc) * nsrc) ? refine : a4(size_t(kSrc) * nsrc);
-  const size_t scratch = a4(8 * size_t(J)) + 2 * a4(J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kC1 + kC2) * U);
+  const size_t srcT = size_t(kSrcCh) * size_t(srcStrideFor(nsrc));
+  const size_t blockJ = refine > srcT ? refine : srcT;
+  const size_t scratch = a4(size_t(kAlt) * J) + 2 * a4(J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kUmom) * U);
   const size_t region = scratch > T * 256 ? scratch : T * 256;
   return (meta + fixed + blockJ + region) * sizeof(float);
 }

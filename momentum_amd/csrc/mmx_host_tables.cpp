@@ -292,8 +292,15 @@ int32_t buildFusedTables(
       continue;
     }
     f.solveList.push_back(p);
+    // only the sources that can move a unit: a rotation dof with a unit in its joint's subtree, a
+    // translation / scale dof with a POINT there (the others have zero moments below them, so every term
+    // they take part in is exactly zero)
     for (int32_t e = t.colStart[p]; nz && e < t.colStart[p + 1]; ++e) {
-      f.srcs.push_back(t.colSources[e]);
+      const ColumnSource& s = t.colSources[e];
+      const bool rot = s.dof >= 3 && s.dof < 6;
+      if (rot ? loaded[s.joint] : hasPoint[s.joint]) {
+        f.srcs.push_back(s);
+      }
     }
     f.srcStart.push_back(int32_t(f.srcs.size()));
   }

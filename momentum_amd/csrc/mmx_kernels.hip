@@ -644,7 +644,7 @@ constexpr int kEvWords = 29; // vp(3) vn(3) sigma*dp(9) sigma*dn(9) tin row nrow
 
 struct SideLds {
   float* js; // [J][kJs]
-  float* alt; // [J][8]
+  float* alt; // [J][kAlt]
   int* jlA; // [J]
   int* jlB; // [J]
 };
@@ -653,14 +653,14 @@ __device__ __forceinline__ SideLds carveSideLds(float* smem, int J, float** next
   SideLds s;
   s.js = smem;
   s.alt = s.js + ((kJs * J + 3) & ~3);
-  s.jlA = reinterpret_cast<int*>(s.alt + 8 * J);
+  s.jlA = reinterpret_cast<int*>(s.alt + kAlt * J);
   s.jlB = s.jlA + J;
   *next = reinterpret_cast<float*>(s.jlB + J);
   return s;
 }
 
 size_t sideFkLdsFloats(int J) {
-  return size_t((kJs * J + 3) & ~3) + 10 * size_t(J);
+  return size_t((kJs * J + 3) & ~3) + size_t(kAlt + 2) * size_t(J);
 }
 
 // forward kinematics of one instance by 256 threads: local transforms of all joints at once,
@@ -669,7 +669,7 @@ __device__ __forceinline__ void sideFk(const RigDev& rig, const SideLds& s, cons
   const bool odd = (rig.jumpRounds & 1) != 0;
   for (int j = tid; j < rig.J; j += 256) {
     float* slot = s.js + kJs * j;
-    fkLocalSplit(rig, j, th, odd ? s.alt + 8 * j : slot, slot + 8);
+    fkLocalSplit(rig, j, th, odd ? s.alt + kAlt * j : slot, slot + 8);
     (odd ? s.jlB : s.jlA)[j] = rig.parent[j] + 1;
   }
   __syncthreads();

@@ -16,8 +16,9 @@ __device__ __forceinline__ F3 transAxisCol(const float* js, int parent, int d) {
   return F3{c.x * p[7], c.y * p[7], c.z * p[7]};
 }
 
-constexpr int kC2 = 16; // second-order channels per joint: m0 | m1(3) | M2 (xx xy xz yy yz zz) | M2 of directions (6)
-constexpr int kC1 = 8; // first-order channels per joint: F(3) | N(3) | D | pad
+constexpr int kC2 = 17; // second-order channels per joint: m0 | m1(3) | M2 (xx xy xz yy yz zz) | M2 of directions (6) | pad (odd stride)
+constexpr int kC2Used = 16;
+constexpr int kC1 = 7; // first-order channels per joint: F(3) | N(3) | D (odd stride)
 
 // Tree sums as tiny exact-fp32 MFMA products with a 0/1 mask matrix built on the fly (joints are
 // indexed by DFS position, so "m is in the subtree of k" is k <= m < k + subSize[k]):
@@ -27,7 +28,7 @@ constexpr int kC1 = 8; // first-order channels per joint: F(3) | N(3) | D | pad
 //                      (tangent pass: prefix sums along the parent chain)
 // v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (exact products by 0/1), hence deterministic.
 // Tiles of 16 rows x 16 channels are dealt to the four waves.
-template <int NC, bool kSubtree>
+template <int NC, bool kSubtree, int STRIDE = NC> // NC channels per row, rows STRIDE floats apart
 __device__ __forceinline__ void treeSumT(
     const int32_t* subSize,
     const int32_t* loadedPos,
@@ -55,7 +56,7 @@ __device__ __forceinline__ void treeSumT(
         const int p = kSubtree ? loadedPos[kk] : kk;
         const bool m = kSubtree ? (p >= r && p < r + rsz) : (r < J && p <= r && r < p + subSize[p]);
         av = m ? 1.f : 0.f;
-        bv = c < NC ? in[NC * p + c] : 0.f;
+        bv = c < NC ? in[STRIDE * p + c] : 0.f;
       }
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
@@ -63,7 +64,7 @@ __device__ __forceinline__ void treeSumT(
     for (int q = 0; q < 4; ++q) {
       const int orow = 16 * rt + 4 * g + q, ocol = 16 * ct + i;
       if (orow < J && ocol < NC) {
-        out[NC * orow + ocol] = acc[q];
+        out[STRIDE * orow + ocol] = acc[q];
       }
     }
   }

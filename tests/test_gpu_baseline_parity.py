@@ -95,7 +95,8 @@ def test_config3_lm_schedule_distinct_instances(torch_cuda, orc):
     ref11 = o.solve_batch(rig, cons, np.zeros((n, rig.num_params), np.float32), opt11, dtype="f64", nthreads=bench.usable_cores())
     h, href = out11["error_history"][:n].cpu().numpy(), ref11["error_history"]
     assert np.array_equal(h[:, :10], out["error_history"][:n].cpu().numpy())
-    same_path = np.all(np.abs(h - href) <= 1e-3 * np.abs(href) + 1e-12, axis=1)
+    # (errors below 1e-7 of the initial one are the fp32 noise floor of a converged fit, not a decision)
+    same_path = np.all(np.abs(h - href) <= 1e-3 * np.abs(href) + 1e-7 * href[:, :1], axis=1)
     assert same_path.mean() >= 0.95, same_path.mean()
     assert rel[same_path].max() <= BOUND, (rel[same_path].max(), int((rel[same_path] > BOUND).sum()))
     # the instances that took another branch still converged
