@@ -1532,7 +1532,7 @@ int32_t mmx_solve(
                                       "G combine + pull", "H cholesky(tail)", "I solve", "J tail (d0 += rho)", "K update",
                                       "G extras: records", "G term records", "H.bc panel", "H.d mfma", "D own sums", "J jd",
                                       "J tangent+own", "J subtree", "J rho", "J solve", "G extras: loads", "H.b load+barrier", "H.b chain"};
-      long long tot = h[24] + h[25];
+      long long tot = h[24] + h[25] + h[26];
       for (int i = 0; i < 24; ++i) {
         tot += h[i];
       }
@@ -1540,7 +1540,7 @@ int32_t mmx_solve(
       for (int i = 0; i < 24; ++i) {
         fprintf(stderr, "  %-16s %10lld  %5.1f%%\n", names[i], h[i], 100.0 * double(h[i]) / double(tot > 0 ? tot : 1));
       }
-      fprintf(stderr, "  (of B fk: local transforms %lld, pointer jumping %lld, axes = the rest of B)\n", h[24], h[25]);
+      fprintf(stderr, "  (of B fk: joint parameters %lld, local transforms %lld, pointer jumping %lld, axes = the rest of B)\n", h[26], h[24], h[25]);
     }
     return MMX_OK;
   }

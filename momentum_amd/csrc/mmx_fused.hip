@@ -257,9 +257,40 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
     }
   };
   const bool odd = (rig.jumpRounds & 1) != 0;
+  // joint parameters = transform * theta + offsets, one transform ROW per thread (parameter_transform.cpp:
+  // 110-124; the same products in the same order as a per-joint walk): 7 J independent short CSR walks
+  // instead of seven dependent ones per joint.  They land in the refinement scratch (jd), which is dead
+  // whenever FK runs.
+  for (int r = tid; r < rig.R; r += 256) {
+    const float off = rig.ptOffsets[r];
+    float acc = 0.f;
+    const int k1 = rig.ptOuter[r + 1];
+    for (int k = rig.ptOuter[r]; k < k1; ++k) {
+      acc += rig.ptValue[k] * th[rig.ptInner[k]];
+    }
+    s.jd[r] = acc + off;
+  }
+  // the joint's constants are requested before the barrier, so that their L2 round trip overlaps it
+  float pre[4] = {0.f, 0.f, 0.f, 1.f}, off3[3] = {0.f, 0.f, 0.f};
+  if (tid < rig.J) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      pre[d] = rig.preRot[4 * tid + d];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      off3[d] = rig.offset[3 * tid + d];
+    }
+  }
+  __syncthreads();
+  stamp(26);
   for (int j = tid; j < rig.J; j += 256) {
     float* slot = s.js + kJs * j;
-    fkLocalSplit(rig, j, th, odd ? s.alt + kAlt * j : slot, slot + 8);
+    if (j == tid) {
+      fkLocalFromParams(s.jd + 7 * j, pre, off3, odd ? s.alt + kAlt * j : slot, slot + 8);
+    } else {
+      fkLocalFromParams(s.jd + 7 * j, rig.preRot + 4 * j, rig.offset + 3 * j, odd ? s.alt + kAlt * j : slot, slot + 8);
+    }
     (odd ? s.jlB : s.jlA)[j] = rig.parent[j] + 1;
   }
   __syncthreads();
