@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 5 /* 5: MMX_LINE_SEARCH_DIRECTIONAL, mmx_debug_store_pattern (additive) */
+#define MMX_ABI_VERSION 6 /* 6: per-instance characters and constraint parents, MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J (additive) */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
@@ -100,8 +100,8 @@ typedef struct mmx_rig_desc {
  * <OrientationDataT> of one PositionErrorFunction + one OrientationErrorFunction
  * per batch element (momentum/character_solver/position_error_function.h:16-29,
  * orientation_error_function.h:16-36, error_function_types.h:34-44).  The parent
- * joint of each constraint is shared by the batch and fixed at
- * mmx_problem_create.  Orientation quaternions are normalised on ingest like the
+ * joint of each constraint is given at mmx_problem_create (batch-shared) or per
+ * element with mmx_problem_set_instance_parents.  Orientation quaternions are normalised on ingest like the
  * OrientationDataT constructor does (orientation_error_function.h:33-35).
  */
 /*
@@ -308,6 +308,39 @@ int32_t mmx_problem_create(
     const int32_t* ori_parent,
     mmx_problem** out);
 void mmx_problem_destroy(mmx_problem* problem);
+
+/*
+ * Per-instance characters of the same topology: the batched driver solves element iBatch on
+ * *characters[iBatch] (pymomentum/tensor_ik/tensor_ik.cpp:129,140), in practice one skeleton scaled per
+ * subject -- same parents and parameter transform, different Joint::translationOffset / preRotation.
+ * translation_offset [B][J][3], pre_rotation [B][J][4] (x,y,z,w); either may be NULL (= the rig's own
+ * values for every element); both NULL restores the shared rig.  `memory`: MMX_MEM_HOST (copied) or
+ * MMX_MEM_DEVICE (borrowed, caller keeps alive).  Every entry point of the problem (FK, J assembly,
+ * solve) then reads element b's constants.
+ */
+int32_t mmx_problem_set_instance_rig(
+    mmx_problem* problem,
+    const float* translation_offset,
+    const float* pre_rotation,
+    int32_t memory,
+    void* stream);
+
+/*
+ * Per-instance constraint parents: ConstraintData::parent of element iBatch's constraint k, the way the
+ * tensor error functions read `parents` per batch element (pymomentum/tensor_ik/
+ * tensor_marker_error_function.cpp:97-98,186).  pos_parent [B][Kp], ori_parent [B][Ko] (joint indices);
+ * either may be NULL (= the batch-shared list given at mmx_problem_create); both NULL restores the
+ * shared lists.  `memory` as above.  The integer bookkeeping that depends on where constraints sit
+ * (structurally zero columns, the solve list) is rebuilt for the UNION of the batch's parents -- a column
+ * that is zero for one element only gets an exact zero step there, as in the reference.
+ * Joint indices are validated (MT_CHECK joint_error_function-inl.h:230).
+ */
+int32_t mmx_problem_set_instance_parents(
+    mmx_problem* problem,
+    const int32_t* pos_parent,
+    const int32_t* ori_parent,
+    int32_t memory,
+    void* stream);
 
 /* M = 3*Kp + 9*Ko + rows of the further blocks and parameter-space blocks
  * (JointErrorFunctionT::getJacobianSize, joint_error_function-inl.h:300-302). */

@@ -26,7 +26,7 @@ SYMBOLS = [
     "mmx_gn_options_default", "mmx_abi_version", "mmx_last_error", "mmx_device_count",
     "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
-    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
+    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
 ]  # fmt: skip
@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
     L.mmx_problem_batch.argtypes = [vp]
     L.mmx_problem_set_enabled.argtypes = [vp, _abi.c_uint8_p]
     L.mmx_problem_set_constraints.argtypes = [vp, C.POINTER(ConstraintData), vp]
+    L.mmx_problem_set_instance_rig.argtypes = [vp, vp, vp, i32, vp]
+    L.mmx_problem_set_instance_parents.argtypes = [vp, vp, vp, i32, vp]
     L.mmx_eval_jacobian.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.mmx_eval_jacobian_timed.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(C.c_float)]
     L.mmx_debug_store_pattern.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
@@ -245,6 +247,42 @@ class Problem:
         _check(lib().mmx_problem_set_constraints(self._h, C.byref(cd), _stream_ptr()))
         self._keep = keep + bkeep if on_dev else []
         self.M = int(lib().mmx_problem_num_rows(self._h))
+
+    # -- per-instance characters of one topology (characters[iBatch] of solveTensorIKProblem)
+    def set_instance_rig(self, translation_offset=None, pre_rotation=None) -> None:
+        """translation_offset [B,J,3], pre_rotation [B,J,4] (x,y,z,w): float32 cuda tensors (borrowed) or
+        numpy arrays (copied); None = the rig's own values.  Both None restores the shared rig."""
+        self._keep_rig = self._instance_call(
+            lib().mmx_problem_set_instance_rig, [(translation_offset, (self.B, self.J, 3)), (pre_rotation, (self.B, self.J, 4))], "float32"
+        )
+
+    # -- per-instance ConstraintData::parent
+    def set_instance_parents(self, pos_parent=None, ori_parent=None) -> None:
+        """pos_parent [B,Kp], ori_parent [B,Ko]: int32 cuda tensors (borrowed) or numpy arrays (copied);
+        None = the batch-shared list of the constructor."""
+        self._keep_parents = self._instance_call(
+            lib().mmx_problem_set_instance_parents, [(pos_parent, (self.B, self.Kp)), (ori_parent, (self.B, self.Ko))], "int32"
+        )
+
+    def _instance_call(self, fn, arrays, dtype):
+        import torch
+
+        given = [a for a, _ in arrays if a is not None]
+        on_dev = bool(given) and all(isinstance(a, torch.Tensor) for a in given)
+        keep, ptrs = [], []
+        for a, shp in arrays:
+            if a is None:
+                ptrs.append(C.c_void_p(0))
+            elif on_dev:
+                assert a.is_cuda and str(a.dtype) == "torch." + dtype and a.is_contiguous() and tuple(a.shape) == shp, (a.shape, shp, a.dtype)
+                keep.append(a)
+                ptrs.append(C.c_void_p(a.data_ptr() if a.numel() else 0))
+            else:
+                x = np.ascontiguousarray(a, dtype=dtype).reshape(shp)
+                keep.append(x)
+                ptrs.append(C.c_void_p(x.ctypes.data if x.size else 0))
+        _check(fn(self._h, ptrs[0], ptrs[1], _abi.MMX_MEM_DEVICE if on_dev else _abi.MMX_MEM_HOST, _stream_ptr()))
+        return keep if on_dev else []
 
     def _theta(self, theta):
         import torch

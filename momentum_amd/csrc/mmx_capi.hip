@@ -168,6 +168,11 @@ struct mmx_problem {
   mmx_rig* rig = nullptr;
   int32_t B = 0, Kp = 0, Ko = 0, U = 0, M = 0;
   std::vector<int32_t> posParent, oriParent;
+  // per-instance characters / constraint parents (mmx_problem_set_instance_rig / _parents)
+  mmx::RigDev rigDev{}; // the rig as this problem's kernels see it: rig->dev + the per-instance pointers
+  DevBuf oInstOffset, oInstPreRot, oInstPosParent, oInstOriParent, dJointTin;
+  std::vector<int32_t> unionPos, unionOri; // joints that carry a position / orientation constraint in some element
+  bool instPos = false, instOri = false;
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
@@ -257,6 +262,8 @@ int32_t uploadProblemTables(mmx_problem* pb) {
   static_assert(sizeof(mmx::ColumnSource) == sizeof(mmx::ColumnSourceDev), "ColumnSource layouts must match");
   MMX_HIP(upload(pb->dUnitJoint, unitJoint));
   MMX_HIP(upload(pb->dUnitTin, unitTin));
+  MMX_HIP(upload(pb->dJointTin, t.tin));
+  pb->dev.jointTin = pb->dJointTin.as<int32_t>();
   {
     std::vector<int32_t> gj, gt, gb;
     for (size_t i = 0; i < pb->blocks.size(); ++i) {
@@ -335,7 +342,8 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       }
     }
     const int32_t rc = mmx::buildFusedTables(
-        &rd, t, pb->Kp, pb->posParent.data(), pb->Ko, pb->oriParent.data(), force.data(), pb->fused, err);
+        &rd, t, pb->Kp, pb->posParent.data(), pb->Ko, pb->oriParent.data(), force.data(), pb->instPos ? &pb->unionPos : nullptr,
+        pb->instOri ? &pb->unionOri : nullptr, pb->fused, err);
     if (rc != MMX_OK) {
       return fail(rc, err);
     }
@@ -664,6 +672,16 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     for (int32_t c = 0; c < pb->Ko; ++c) {
       mark(pb->oriParent[size_t(c)], false);
     }
+    if (pb->instPos) {
+      for (int32_t j : pb->unionPos) {
+        mark(j, true);
+      }
+    }
+    if (pb->instOri) {
+      for (int32_t j : pb->unionOri) {
+        mark(j, false);
+      }
+    }
     for (const auto& h : pb->blocks) {
       const bool fixedAxis = h->type == MMX_JC_FIXED_AXIS_DIFF || h->type == MMX_JC_FIXED_AXIS_COS || h->type == MMX_JC_FIXED_AXIS_ANGLE;
       for (int32_t j : h->parent) {
@@ -706,7 +724,7 @@ bool fusedUsable(const mmx_problem* pb) {
     return false;
   }
   return pb->rig->J < 4096 &&
-      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rig->dev.numLevels) + size_t(8) * size_t(pb->rig->J + pb->rig->P) <= 160 * 1024;
+      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rigDev.numLevels) + size_t(8) * size_t(pb->rig->J + pb->rig->P) <= 160 * 1024;
 }
 
 bool wantLegacySolver() {
@@ -982,6 +1000,7 @@ int32_t mmx_problem_create(
     pb->oriParent.assign(ori_parent, ori_parent + num_ori);
   }
   pb->tables = rig->topo; // all parameters enabled
+  pb->rigDev = rig->dev;
   pb->dev.wPos = 1.f;
   pb->dev.wOri = 1.f;
   const int32_t rc = uploadProblemTables(pb);
@@ -1027,6 +1046,130 @@ int32_t mmx_problem_set_enabled(mmx_problem* pb, const uint8_t* enabled) {
   }
   pb->tables = std::move(t);
   return uploadProblemTables(pb);
+}
+
+int32_t mmx_problem_set_instance_rig(mmx_problem* pb, const float* translation_offset, const float* pre_rotation, int32_t memory, void* stream) {
+  MMX_ZONE("mmx_problem_set_instance_rig");
+  int32_t rc = checkProblem(pb, false);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (memory != MMX_MEM_HOST && memory != MMX_MEM_DEVICE) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "instance rig: unknown memory space");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t B = size_t(pb->B), J = size_t(pb->rig->J);
+  auto bring = [&](DevBuf& buf, const float* src, size_t count, const float*& dst) -> hipError_t {
+    if (src == nullptr) {
+      dst = nullptr;
+      return hipSuccess;
+    }
+    if (memory == MMX_MEM_DEVICE) {
+      dst = src;
+      return hipSuccess;
+    }
+    hipError_t e = buf.ensure(count * sizeof(float));
+    if (e != hipSuccess) {
+      return e;
+    }
+    dst = buf.as<float>();
+    return hipMemcpyAsync(buf.p, src, count * sizeof(float), hipMemcpyHostToDevice, s);
+  };
+  const float *off = nullptr, *pre = nullptr;
+  MMX_HIP(bring(pb->oInstOffset, translation_offset, B * J * 3, off));
+  MMX_HIP(bring(pb->oInstPreRot, pre_rotation, B * J * 4, pre));
+  if (memory == MMX_MEM_HOST) {
+    MMX_HIP(hipStreamSynchronize(s)); // the caller may free its host arrays on return
+  }
+  pb->rigDev.instOffset = off;
+  pb->rigDev.instPreRot = pre;
+  return MMX_OK;
+}
+
+int32_t mmx_problem_set_instance_parents(mmx_problem* pb, const int32_t* pos_parent, const int32_t* ori_parent, int32_t memory, void* stream) {
+  MMX_ZONE("mmx_problem_set_instance_parents");
+  int32_t rc = checkProblem(pb, false);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (memory != MMX_MEM_HOST && memory != MMX_MEM_DEVICE) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "instance parents: unknown memory space");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t B = size_t(pb->B);
+  // host view of the lists (device input is read back: the integer bookkeeping is host work)
+  std::vector<int32_t> hp, ho;
+  auto fetch = [&](const int32_t* src, size_t count, std::vector<int32_t>& dst) -> hipError_t {
+    dst.clear();
+    if (src == nullptr || count == 0) {
+      return hipSuccess;
+    }
+    dst.resize(count);
+    if (memory == MMX_MEM_HOST) {
+      std::memcpy(dst.data(), src, count * sizeof(int32_t));
+      return hipSuccess;
+    }
+    hipError_t e = hipMemcpyAsync(dst.data(), src, count * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+  };
+  MMX_HIP(fetch(pos_parent, B * size_t(pb->Kp), hp));
+  MMX_HIP(fetch(ori_parent, B * size_t(pb->Ko), ho));
+  // validate everything before anything is modified (MT_CHECK joint_error_function-inl.h:230)
+  std::vector<uint8_t> seenP(size_t(pb->rig->J), 0), seenO(size_t(pb->rig->J), 0);
+  for (int32_t j : hp) {
+    if (j < 0 || j >= pb->rig->J) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "instance parents: position constraint parent joint out of range");
+    }
+    seenP[size_t(j)] = 1;
+  }
+  for (int32_t j : ho) {
+    if (j < 0 || j >= pb->rig->J) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "instance parents: orientation constraint parent joint out of range");
+    }
+    seenO[size_t(j)] = 1;
+  }
+  auto place = [&](DevBuf& buf, const int32_t* src, const std::vector<int32_t>& host, const int32_t*& dst) -> hipError_t {
+    if (host.empty()) {
+      dst = nullptr;
+      return hipSuccess;
+    }
+    if (memory == MMX_MEM_DEVICE) {
+      dst = src;
+      return hipSuccess;
+    }
+    hipError_t e = buf.ensure(host.size() * sizeof(int32_t));
+    if (e != hipSuccess) {
+      return e;
+    }
+    dst = buf.as<int32_t>();
+    return hipMemcpy(buf.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  };
+  const int32_t *dp = nullptr, *dq = nullptr;
+  MMX_HIP(place(pb->oInstPosParent, pos_parent, hp, dp));
+  MMX_HIP(place(pb->oInstOriParent, ori_parent, ho, dq));
+  pb->tablesDirty = true;
+  pb->dev.instPosParent = dp;
+  pb->dev.instOriParent = dq;
+  pb->instPos = dp != nullptr;
+  pb->instOri = dq != nullptr;
+  pb->unionPos.clear();
+  pb->unionOri.clear();
+  for (int32_t j = 0; j < pb->rig->J; ++j) {
+    if (seenP[size_t(j)]) {
+      pb->unionPos.push_back(j);
+    }
+    if (seenO[size_t(j)]) {
+      pb->unionOri.push_back(j);
+    }
+  }
+  rc = uploadProblemTables(pb); // solve list, structurally zero columns: over the union of the batch
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  pb->tablesDirty = false;
+  return MMX_OK;
 }
 
 int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* c, void* stream) {
@@ -1314,11 +1457,11 @@ int32_t mmx_eval_jacobian(
     // assembled column-major (the layout the kernel's coalesced column stores are built for) into the
     // problem's scratch, then transposed per instance: one extra read + write of J
     MMX_HIP(pb->sJacColMajor.ensure(size_t(pb->B) * size_t(pb->M) * size_t(pb->rig->P) * sizeof(float)));
-    MMX_HIP(mmx::launchFkJacobian(pb->rig->dev, pb->dev, theta_dev, pb->sJacColMajor.as<float>(), res_dev, err_dev, nullptr, nullptr, s));
+    MMX_HIP(mmx::launchFkJacobian(pb->rigDev, pb->dev, theta_dev, pb->sJacColMajor.as<float>(), res_dev, err_dev, nullptr, nullptr, s));
     MMX_HIP(mmx::launchTransposeJacobian(pb->sJacColMajor.as<float>(), jac_dev, pb->B, pb->M, pb->rig->P, s));
     return MMX_OK;
   }
-  MMX_HIP(mmx::launchFkJacobian(pb->rig->dev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, s));
+  MMX_HIP(mmx::launchFkJacobian(pb->rigDev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, s));
   return MMX_OK;
 }
 
@@ -1347,7 +1490,7 @@ int32_t mmx_eval_jacobian_timed(
   hipError_t err = hipEventCreate(&e1);
   if (err == hipSuccess) {
     err = mmx::launchFkJacobian(
-        pb->rig->dev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, static_cast<hipStream_t>(stream), e0, e1);
+        pb->rigDev, pb->dev, theta_dev, jac_dev, res_dev, err_dev, nullptr, nullptr, static_cast<hipStream_t>(stream), e0, e1);
   }
   if (err == hipSuccess) {
     err = hipEventSynchronize(e1);
@@ -1406,7 +1549,7 @@ int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* 
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
   MMX_HIP(mmx::launchFkJacobian(
-      pb->rig->dev, pb->dev, theta_dev, nullptr, nullptr, nullptr, state_dev, nullptr, static_cast<hipStream_t>(stream)));
+      pb->rigDev, pb->dev, theta_dev, nullptr, nullptr, nullptr, state_dev, nullptr, static_cast<hipStream_t>(stream)));
   return MMX_OK;
 }
 
@@ -1447,7 +1590,7 @@ int32_t mmx_eval_normal_equations(
     return rc;
   }
   MMX_HIP(mmx::launchFkJacobian(
-      pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), err_dev, nullptr, nullptr, s));
+      pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), err_dev, nullptr, nullptr, s));
   MMX_HIP(mmx::launchNormalEquations(
       pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), jtj_dev, jtr_dev, nullptr, false, s));
   return MMX_OK;
@@ -1522,7 +1665,7 @@ int32_t mmx_solve(
     }
     {
       MMX_ZONE("fused solve: all iterations of GaussNewtonSolverT::doIteration in one launch");
-      MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, s));
+      MMX_HIP(mmx::launchFusedSolve(pb->rigDev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, s));
     }
     if (clk != nullptr) {
       long long h[32];
@@ -1605,7 +1748,7 @@ int32_t mmx_solve(
     {
       MMX_ZONE("Get JtJ and JtR");
       MMX_HIP(mmx::launchFkJacobian(
-          pb->rig->dev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
+          pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
       MMX_HIP(mmx::launchNormalEquations(
           ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done,
           mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 /* the in-HBM factorisation reads the lower triangle only */, s));
@@ -1618,7 +1761,7 @@ int32_t mmx_solve(
     }
     if (deferred) {
       MMX_ZONE("Line search");
-      MMX_HIP(mmx::launchStepUpdate(pb->rig->dev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
+      MMX_HIP(mmx::launchStepUpdate(pb->rigDev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
     }
   }
   MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
@@ -1678,7 +1821,7 @@ int32_t mmx_debug_fused_normal_equations(
   fp.minIterations = 1;
   fp.maxIterations = 1;
   fp.refine = 0;
-  MMX_HIP(mmx::launchFusedSolve(pb->rig->dev, pb->dev, pb->fdev, pb->sTheta.as<float>(), fst, fp, jtj_dev, jtr_dev, nullptr, s));
+  MMX_HIP(mmx::launchFusedSolve(pb->rigDev, pb->dev, pb->fdev, pb->sTheta.as<float>(), fst, fp, jtj_dev, jtr_dev, nullptr, s));
   return MMX_OK;
 }
 

@@ -117,7 +117,21 @@ struct RigDev {
   const int4* ptEll; // [R]
   const int32_t* jumpParent; // [J] (parent + 1) << 16 | (parent + 1): parent and initial jump target
   int32_t jumpRounds; // ceil(log2(numLevels)): pointer-jumping rounds that finish every joint
+  // per-instance characters of the same topology (mmx_problem_set_instance_rig): [B][J][4] / [B][J][3] or null
+  const float* instPreRot;
+  const float* instOffset;
 };
+
+// element b's view of the rig: the per-instance constants replace the shared ones (a kernel calls this
+// once on its by-value copy of the descriptor)
+__device__ __forceinline__ void selectInstanceRig(RigDev& rig, int b) {
+  if (rig.instPreRot != nullptr) {
+    rig.preRot = rig.instPreRot + size_t(b) * 4 * size_t(rig.J);
+  }
+  if (rig.instOffset != nullptr) {
+    rig.offset = rig.instOffset + size_t(b) * 3 * size_t(rig.J);
+  }
+}
 
 // GeneralizedLossT(alpha, c) (momentum/math/generalized_loss.h:46-101, .cpp:20-155)
 struct LossDev {
@@ -223,6 +237,11 @@ struct ProblemDev {
   const float* mpTarget; // [B][P]
   const float* mpWeights; // [B][P]
   const uint8_t* enabledMask; // [P]
+  // per-instance constraint parents (mmx_problem_set_instance_parents): [B][Kp] / [B][Ko] or null, and
+  // the joint -> DFS position table they are looked up in
+  const int32_t* instPosParent;
+  const int32_t* instOriParent;
+  const int32_t* jointTin; // [J]
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -431,6 +450,10 @@ __device__ __forceinline__ UnitInput loadUnitInput(const ProblemDev& pb, int b, 
   in.tin = pb.unitTin[u];
   if (u < pb.Kp) {
     const size_t c = size_t(b) * pb.Kp + u;
+    if (pb.instPosParent != nullptr) { // ConstraintData::parent of THIS element
+      in.joint = pb.instPosParent[c];
+      in.tin = pb.jointTin[in.joint];
+    }
     const float* po = pb.posOffset + 3 * c;
     const float* pt = pb.posTarget + 3 * c;
     in.a[0] = po[0], in.a[1] = po[1], in.a[2] = po[2];
@@ -439,6 +462,10 @@ __device__ __forceinline__ UnitInput loadUnitInput(const ProblemDev& pb, int b, 
   } else {
     const int co = (u - pb.Kp) / 3;
     const size_t c = size_t(b) * pb.Ko + co;
+    if (pb.instOriParent != nullptr) {
+      in.joint = pb.instOriParent[c];
+      in.tin = pb.jointTin[in.joint];
+    }
     const float* oo = pb.oriOffset + 4 * c; // caller-owned pointers: no alignment assumed
     const float* ot = pb.oriTarget + 4 * c;
     in.a[0] = oo[0], in.a[1] = oo[1], in.a[2] = oo[2], in.a[3] = oo[3];

@@ -534,6 +534,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+  selectInstanceRig(rig, b);
 #ifdef MMX_EXP_STATIC // experiment: every size a compile-time constant (cfg2), so that every LDS address is a literal
   constexpr int J = 72, P = 128, U = 64, n = 96, nsrc = 112, kR = 504, kNnz = 167, kLevels = 13;
 #else
@@ -654,6 +655,55 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
   for (int i = tid; i < n; i += 256) {
     lColToSolve[fd.solveList[i]] = i;
   }
+  // Per-instance constraint parents (mmx_problem_set_instance_parents): the tables that say which units
+  // hang on which joint are built here, per element, instead of copied from the batch-shared ones --
+  // units sorted by (DFS position of their joint, unit index) with a counting rank, so the summation
+  // order of the own sums is the same deterministic one as in the shared case.  Once per solve.
+  int numLoadedInst = fd.numLoaded;
+  if (pb.instPosParent != nullptr || pb.instOriParent != nullptr) {
+    __syncthreads();
+    for (int u = tid; u < U; u += 256) {
+      int joint;
+      if (u < fd.Kp) {
+        joint = pb.instPosParent != nullptr ? pb.instPosParent[size_t(b) * fd.Kp + u] : fd.unitJoint[u];
+      } else {
+        const int co = (u - fd.Kp) / 3;
+        joint = pb.instOriParent != nullptr ? pb.instOriParent[size_t(b) * pb.Ko + co] : fd.unitJoint[u];
+      }
+      lUnitJoint[u] = pb.jointTin[joint];
+    }
+    __syncthreads();
+    for (int k = tid; k <= J; k += 256) { // units on positions before k
+      int cnt = 0;
+      for (int u = 0; u < U; ++u) {
+        cnt += lUnitJoint[u] < k ? 1 : 0;
+      }
+      lPosUnitStart[k] = cnt;
+    }
+    for (int u = tid; u < U; u += 256) {
+      const int pu = lUnitJoint[u];
+      int rank = 0;
+      for (int v = 0; v < U; ++v) {
+        const int pv = lUnitJoint[v];
+        rank += (pv < pu || (pv == pu && v < u)) ? 1 : 0;
+      }
+      lPosUnits[rank] = u;
+    }
+    __syncthreads();
+    for (int k = tid; k < J; k += 256) { // loaded positions, ascending
+      if (lPosUnitStart[k + 1] > lPosUnitStart[k]) {
+        int rank = 0;
+        for (int q = 0; q < k; ++q) {
+          rank += lPosUnitStart[q + 1] > lPosUnitStart[q] ? 1 : 0;
+        }
+        lLoadedPos[rank] = k;
+      }
+    }
+    numLoadedInst = 0; // their number: every thread computes the same value
+    for (int k = 0; k < J; ++k) {
+      numLoadedInst += lPosUnitStart[k + 1] > lPosUnitStart[k] ? 1 : 0;
+    }
+  }
   // parentPos[k] = DFS position of the parent of the joint at DFS position k (-1 for a root), built
   // through a joint -> position scratch map (alt is free until the first FK)
   int* lParentPos = lLevelOrder;
@@ -676,7 +726,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
   rv.levelOrder = lLevelOrder, rv.levelStart = lLevelStart;
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp;
-  fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = fd.numLoaded, fv.colToSolve = lColToSolve;
+  fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = numLoadedInst, fv.colToSolve = lColToSolve;
   fv.subSize = lSubSize, fv.unitPos = lUnitJoint, fv.posUnitStart = lPosUnitStart, fv.posUnits = lPosUnits;
   fv.solveList = lSolveList;
   if (tid == 0) {

@@ -214,6 +214,8 @@ int32_t buildFusedTables(
     int32_t Ko,
     const int32_t* oriParent,
     const uint8_t* forceSolve,
+    const std::vector<int32_t>* unionPos,
+    const std::vector<int32_t>* unionOri,
     FusedTables& f,
     std::string& err) {
   const int32_t J = t.J, P = t.P;
@@ -252,23 +254,40 @@ int32_t buildFusedTables(
       f.posUnits[cur[t.tin[f.unitJoint[u]]]++] = u;
     }
   }
-  // a joint is "loaded" if some unit sits in its subtree
+  // a joint is "loaded" if some unit sits in its subtree (in some element of the batch, when the
+  // constraint parents are per instance)
   std::vector<uint8_t> loaded(J, 0);
-  for (int32_t u = 0; u < f.U; ++u) {
-    int32_t a = f.unitJoint[u];
+  auto markLoaded = [&](int32_t a) {
     while (a >= 0 && !loaded[a]) {
       loaded[a] = 1;
       a = d->parent[a];
+    }
+  };
+  for (int32_t u = 0; u < f.U; ++u) {
+    markLoaded(f.unitJoint[u]);
+  }
+  for (const std::vector<int32_t>* lst : {unionPos, unionOri}) {
+    if (lst != nullptr) {
+      for (int32_t j : *lst) {
+        markLoaded(j);
+      }
     }
   }
   // Orientation constraints only see rotation dofs, position constraints see all: a column is
   // structurally non-zero iff it has a source (a,dof) with a unit below a that the dof acts on.
   std::vector<uint8_t> hasPoint(J, 0);
-  for (int32_t c = 0; c < Kp; ++c) {
-    int32_t a = posParent[c];
+  auto markPoint = [&](int32_t a) {
     while (a >= 0 && !hasPoint[a]) {
       hasPoint[a] = 1;
       a = d->parent[a];
+    }
+  };
+  for (int32_t c = 0; c < Kp; ++c) {
+    markPoint(posParent[c]);
+  }
+  if (unionPos != nullptr) {
+    for (int32_t j : *unionPos) {
+      markPoint(j);
     }
   }
   f.solveList.clear();

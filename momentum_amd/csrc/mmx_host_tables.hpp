@@ -90,6 +90,8 @@ int32_t buildFusedTables(
     const int32_t* oriParent,
     const uint8_t* forceSolve, // [P] or null: enabled parameters to keep in the solve list although
                                // no joint constraint reaches them (limit / model-parameter rows)
+    const std::vector<int32_t>* unionPos, // or null: with per-instance constraint parents, every joint that
+    const std::vector<int32_t>* unionOri, // carries a position / an orientation constraint in SOME element
     FusedTables& out,
     std::string& err);
 

@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   float* ul = reinterpret_cast<float*>(jl + ((rig.J + 3) & ~3)); // [U][5] evaluated units (v, sigma, tin), only when U > 64 and J is written
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
+  selectInstanceRig(rig, b);
   // wave-uniform on purpose: it indexes the column program, which must stay on the scalar unit
   const int wave = WPI == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NT = 64 * WPI;
@@ -694,6 +695,7 @@ __global__ void __launch_bounds__(256) jointBlocksKernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ double red[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  selectInstanceRig(rig, b);
   if (done != nullptr && done[b] != 0) {
     return;
   }
@@ -2055,6 +2057,7 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
   __shared__ double red[4];
   __shared__ float redF[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  selectInstanceRig(rig, b);
   const int mark = sp.stepIter[b];
   if (mark != sp.iteration + 1 && mark != -(sp.iteration + 1)) {
     return; // the instance had converged before this iteration
