@@ -18,6 +18,7 @@
 // OSS behaviour of MT_CHECK / MT_THROW (momentum/common/checks.h:36-45, exception.h:24-66).
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstddef>
 #include <cstdint>
@@ -223,6 +224,7 @@ class DeviceCharacter {
     d.pt_value = pt.value.data();
     d.pt_offsets = pt.offsets.empty() ? nullptr : pt.offsets.data();
     numParams_ = pt.numAllModelParameters();
+    parents_ = parent;
     mmx_rig* h = nullptr;
     check(mmx_rig_create(&d, device, &h));
     handle_.reset(h, [](mmx_rig* p) { mmx_rig_destroy(p); });
@@ -236,10 +238,14 @@ class DeviceCharacter {
   size_t numJoints() const {
     return numJoints_;
   }
+  int32_t parentOf(size_t joint) const { // MMX_INVALID_PARENT for a root
+    return parents_[joint];
+  }
 
  private:
   std::shared_ptr<mmx_rig> handle_;
   size_t numJoints_ = 0, numParams_ = 0;
+  std::vector<int32_t> parents_;
 };
 
 // Constraint data of the further JointErrorFunction specialisations; vectors are normalised where
@@ -284,7 +290,10 @@ enum class JointErrorFunctionType {
 };
 
 // One SkeletonSolverFunction + PositionErrorFunction + OrientationErrorFunction per batch element.
-// The constraint parents are shared by the batch; offsets / targets / weights are per element.
+// The parent lists of the constructor are the default of every element; an element whose constraints name
+// other parents (ConstraintData::parent) gets its own list, and setCharacters() gives every element its own
+// Character of the same topology -- what solveTensorIKProblem does with characters[iBatch]
+// (pymomentum/tensor_ik/tensor_ik.cpp:129-141).
 class BatchedSkeletonSolverFunction {
  public:
   BatchedSkeletonSolverFunction(
@@ -309,6 +318,14 @@ class BatchedSkeletonSolverFunction {
       oriTarget_[4 * i + 3] = 1.f;
     }
     oriWeight_.assign(batch * ko_, 1.f);
+    posParent_.resize(batch * kp_);
+    oriParent_.resize(batch * ko_);
+    for (size_t b = 0; b < batch; ++b) {
+      std::copy(pp.begin(), pp.end(), posParent_.begin() + b * kp_);
+      std::copy(op.begin(), op.end(), oriParent_.begin() + b * ko_);
+    }
+    sharedPos_ = pp;
+    sharedOri_ = op;
   }
   BatchedSkeletonSolverFunction(const BatchedSkeletonSolverFunction&) = delete; // like the reference (:29-32)
   BatchedSkeletonSolverFunction& operator=(const BatchedSkeletonSolverFunction&) = delete;
@@ -319,12 +336,47 @@ class BatchedSkeletonSolverFunction {
   size_t batchSize() const {
     return batch_;
   }
-  // PositionErrorFunction::setConstraints of batch element b (parents must match the shared list)
+  // One Character per batch element, all of the topology of the DeviceCharacter (same parents and
+  // parameter transform; translationOffset / preRotation differ, e.g. per-subject bone lengths).  An
+  // empty list goes back to the shared character.
+  void setCharacters(const std::vector<const Character*>& characters) {
+    if (characters.empty()) {
+      check(mmx_problem_set_instance_rig(handle_.get(), nullptr, nullptr, MMX_MEM_HOST, nullptr));
+      return;
+    }
+    const size_t J = character_.numJoints();
+    if (characters.size() != batch_) {
+      throw std::runtime_error("momentum_amd: one character per batch element expected");
+    }
+    std::vector<float> off(batch_ * J * 3), pre(batch_ * J * 4);
+    for (size_t b = 0; b < batch_; ++b) {
+      const Character& c = *characters[b];
+      if (c.skeleton.joints.size() != J || c.parameterTransform.numAllModelParameters() != character_.numParameters()) {
+        throw std::runtime_error("momentum_amd: per-element characters must share the topology of the device character");
+      }
+      for (size_t j = 0; j < J; ++j) {
+        const Joint& jt = c.skeleton.joints[j];
+        const int32_t par = jt.parent == kInvalidIndex ? MMX_INVALID_PARENT : int32_t(jt.parent);
+        if (par != character_.parentOf(j)) {
+          throw std::runtime_error("momentum_amd: per-element characters must share the topology of the device character");
+        }
+        for (int k = 0; k < 3; ++k) {
+          off[(b * J + j) * 3 + k] = jt.translationOffset[k];
+        }
+        for (int k = 0; k < 4; ++k) {
+          pre[(b * J + j) * 4 + k] = jt.preRotation[k];
+        }
+      }
+    }
+    check(mmx_problem_set_instance_rig(handle_.get(), off.data(), pre.data(), MMX_MEM_HOST, nullptr));
+  }
+  // PositionErrorFunction::setConstraints of batch element b (ConstraintData::parent per constraint)
   void setPositionConstraints(size_t b, const std::vector<PositionData>& c) {
     if (b >= batch_ || c.size() != kp_) {
       throw std::runtime_error("momentum_amd: position constraint count / batch index mismatch");
     }
     for (size_t i = 0; i < kp_; ++i) {
+      posParent_[b * kp_ + i] = int32_t(c[i].parent);
       for (int k = 0; k < 3; ++k) {
         posOffset_[(b * kp_ + i) * 3 + k] = c[i].offset[k];
         posTarget_[(b * kp_ + i) * 3 + k] = c[i].target[k];
@@ -338,6 +390,7 @@ class BatchedSkeletonSolverFunction {
       throw std::runtime_error("momentum_amd: orientation constraint count / batch index mismatch");
     }
     for (size_t i = 0; i < ko_; ++i) {
+      oriParent_[b * ko_ + i] = int32_t(c[i].parent);
       for (int k = 0; k < 4; ++k) {
         oriOffset_[(b * ko_ + i) * 4 + k] = c[i].offset[k];
         oriTarget_[(b * ko_ + i) * 4 + k] = c[i].target[k];
@@ -485,6 +538,20 @@ class BatchedSkeletonSolverFunction {
     d.num_joint_blocks = int32_t(jb.size());
     d.joint_blocks = jb.empty() ? nullptr : jb.data();
     check(mmx_problem_set_constraints(handle_.get(), &d, nullptr));
+    // per-element parent lists only when some element departs from the constructor's lists
+    auto departs = [&](const std::vector<int32_t>& all, const std::vector<int32_t>& shared) {
+      for (size_t b = 0; b < batch_; ++b) {
+        if (!std::equal(shared.begin(), shared.end(), all.begin() + b * shared.size())) {
+          return true;
+        }
+      }
+      return false;
+    };
+    const bool ip = departs(posParent_, sharedPos_), io = departs(oriParent_, sharedOri_);
+    if (ip || io || instanceParents_) {
+      check(mmx_problem_set_instance_parents(handle_.get(), ip ? posParent_.data() : nullptr, io ? oriParent_.data() : nullptr, MMX_MEM_HOST, nullptr));
+      instanceParents_ = ip || io;
+    }
     dirty_ = false;
   }
   // SolverFunctionT::getJacobian for every element: column-major M x P per element, residual M
@@ -540,6 +607,8 @@ class BatchedSkeletonSolverFunction {
   size_t batch_, kp_, ko_;
   std::shared_ptr<mmx_problem> handle_;
   std::vector<float> posOffset_, posTarget_, posWeight_, oriOffset_, oriTarget_, oriWeight_;
+  std::vector<int32_t> posParent_, oriParent_, sharedPos_, sharedOri_; // [batch * K] per element ; the constructor's lists
+  bool instanceParents_ = false;
   std::vector<mmx_parameter_limit> limits_;
   std::vector<float> mpTarget_, mpWeights_;
   float wPos_ = 1.f, wOri_ = 1.f, wLimit_ = 1.f, wModel_ = 1.f;

@@ -12,12 +12,26 @@ SRC = os.path.join(ROOT, "tests", "cpp", "test_shell.cpp")
 EXE = os.path.join(ROOT, "tests", "cpp", "test_shell")
 
 
-def _compile():
+PARITY_SRC = os.path.join(ROOT, "tests", "cpp", "test_shell_parity.cpp")
+PARITY_EXE = os.path.join(ROOT, "tests", "cpp", "test_shell_parity")
+GOLDEN_INC = os.path.join(ROOT, "tests", "cpp", "golden_cfg2.inc")
+
+
+def _compile(src=SRC, exe=EXE):
     mbuild.build()
     libdir = os.path.join(ROOT, "momentum_amd")
-    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-L", libdir, "-lmmx_hip",
-           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]  # fmt: skip
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir, "-lmmx_hip",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]  # fmt: skip
     subprocess.check_call(cmd)
+
+
+def _compile_parity():
+    # the committed golden fixture (inputs + the oracle's double-precision answers) as a C++ include
+    import sys
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "cpp", "make_golden_header.py"),
+                           os.path.join(ROOT, "tests", "golden", "cfg2_humanoid72.npz"), GOLDEN_INC])  # fmt: skip
+    _compile(PARITY_SRC, PARITY_EXE)
 
 
 def test_cpp_shell_compiles_and_links():
@@ -31,3 +45,19 @@ def test_cpp_shell_solves_on_gpu():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("OK")
+
+
+def test_cpp_shell_parity_program_compiles_and_links():
+    _compile_parity()
+    assert os.path.exists(PARITY_EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_shell_matches_golden_fixture_on_gpu():
+    """Character -> DeviceCharacter -> BatchedSkeletonSolverFunction -> BatchedGaussNewtonSolver on the
+    numbers of tests/golden/cfg2_humanoid72.npz: 1e-5 on the pose parameters against the oracle's stored
+    double-precision solve; per-element characters / parents reproduce it bit for bit."""
+    _compile_parity()
+    out = subprocess.run([PARITY_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK"), out.stdout
