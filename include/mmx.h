@@ -70,9 +70,17 @@ typedef enum mmx_status {
 /* Solver step rule. */
 #define MMX_STEP_GN_FIXED_LAMBDA 0 /* GaussNewtonSolverT, constant regularization
                                       (momentum/solver/gauss_newton_solver.cpp:224-280) */
-#define MMX_STEP_LM_SCHEDULE 1 /* gain-ratio lambda schedule, lambda-form of
+#define MMX_STEP_LM_SCHEDULE 1 /* gain-ratio lambda schedule, a lambda-form of
                                   momentum/character_solver/trust_region_qr.cpp:244-268
-                                  (no direct reference implementation) */
+                                  (BASELINE configs[2]; no direct reference implementation) */
+#define MMX_STEP_TRUST_REGION 2 /* TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:
+                                   52-270; LinearSolverType::TrustRegionQR of the batched driver, tensor_ik.cpp:
+                                   150-152): per iteration up to ten trial steps, each after up to three Newton
+                                   updates of the damping that pull |step| towards the trust radius (:180-231),
+                                   gain ratio against the quadratic model (:246-247), radius x 0.25 / x 2 (cap 10)
+                                   (:256-262), a step with rho <= 0 is rejected (:265-269).  Every change of the
+                                   damping costs a factorisation (the reference appends rows to its QR).  Fused
+                                   solver only; do_line_search and regularization are not read by this rule. */
 
 /*
  * Static rig = Skeleton + ParameterTransform of a momentum::Character
@@ -266,6 +274,8 @@ typedef struct mmx_gn_options {
   float lm_lambda_max; /* default 1e6 */
   float lm_up; /* lambda *= lm_up   when rho < 0.25 or the step is rejected (default 4) */
   float lm_down; /* lambda *= lm_down when rho > 0.75 (default 0.5) */
+  /* trust region (only read when step_rule == MMX_STEP_TRUST_REGION) */
+  float trust_region_radius; /* TrustRegionQROptions::trustRegionRadius_ (default 1; <= 0 selects the default) */
 } mmx_gn_options;
 
 typedef struct mmx_rig mmx_rig; /* opaque: device-resident rig constants */

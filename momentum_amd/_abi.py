@@ -19,7 +19,7 @@ MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
 MMX_LAYOUT_COL_MAJOR, MMX_LAYOUT_ROW_MAJOR = 0, 1
-MMX_STEP_GN_FIXED_LAMBDA, MMX_STEP_LM_SCHEDULE = 0, 1
+MMX_STEP_GN_FIXED_LAMBDA, MMX_STEP_LM_SCHEDULE, MMX_STEP_TRUST_REGION = 0, 1, 2
 
 
 class RigDesc(C.Structure):
@@ -273,6 +273,7 @@ class GnOptions(C.Structure):
         ("lm_lambda_max", C.c_float),
         ("lm_up", C.c_float),
         ("lm_down", C.c_float),
+        ("trust_region_radius", C.c_float),
     ]
 
     @classmethod
@@ -288,6 +289,7 @@ class GnOptions(C.Structure):
         lm_lambda_max=1e6,
         lm_up=4.0,
         lm_down=0.5,
+        trust_region_radius=1.0,
     ) -> "GnOptions":
         return cls(
             int(min_iterations),
@@ -300,6 +302,7 @@ class GnOptions(C.Structure):
             float(lm_lambda_max),
             float(lm_up),
             float(lm_down),
+            float(trust_region_radius),
         )
 
 

@@ -764,6 +764,7 @@ void mmx_gn_options_default(mmx_gn_options* o) {
   o->lm_lambda_max = 1e6f;
   o->lm_up = 4.0f;
   o->lm_down = 0.5f;
+  o->trust_region_radius = 1.0f; // TrustRegionQROptions::trustRegionRadius_ (trust_region_qr.h:24)
 }
 
 int32_t mmx_abi_version(void) {
@@ -1616,7 +1617,7 @@ int32_t mmx_solve(
   if (o->max_iterations < 0 || o->min_iterations < 0) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "iteration counts must be >= 0");
   }
-  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE) {
+  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE && o->step_rule != MMX_STEP_TRUST_REGION) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "unknown step_rule");
   }
   if (o->do_line_search != MMX_LINE_SEARCH_NONE && o->do_line_search != MMX_LINE_SEARCH_GAUSS_NEWTON &&
@@ -1657,6 +1658,7 @@ int32_t mmx_solve(
     fp.lmLambdaMax = o->lm_lambda_max;
     fp.lmUp = o->lm_up;
     fp.lmDown = o->lm_down;
+    fp.trustRadius = o->trust_region_radius > 0.f ? o->trust_region_radius : 1.f;
     long long* clk = nullptr;
     if (getenv("MMX_PHASE_CLOCKS") != nullptr) { // profiling aid: per-phase cycles of block 0
       MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
@@ -1686,6 +1688,9 @@ int32_t mmx_solve(
       fprintf(stderr, "  (of B fk: joint parameters %lld, local transforms %lld, pointer jumping %lld, axes = the rest of B)\n", h[26], h[24], h[25]);
     }
     return MMX_OK;
+  }
+  if (o->step_rule == MMX_STEP_TRUST_REGION) {
+    return fail(MMX_ERR_UNSUPPORTED, "MMX_STEP_TRUST_REGION lives in the fused solver: not available for problems that take the explicit-Jacobian kernels (further joint blocks, ellipsoid limits, MMX_SOLVER=v1, systems beyond the fused instantiations)");
   }
   if (n > 512) {
     return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");

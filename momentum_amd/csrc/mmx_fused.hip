@@ -511,7 +511,8 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
 // MODE 0: production; 1: also dump H / g of the first iteration (parity hook); 2: per-phase clocks
 // Workgroups per CU follow the LDS footprint (tiles: 1 KB each): three up to NB = 6, two up to NB = 8,
 // one beyond -- the register budget is set to match, so the wide systems do not spill.
-template <int NB, int MODE>
+// kTR: the TrustRegionQRT step rule (its re-solve loops are compiled into that instantiation only)
+template <int NB, int MODE, bool kTR>
 __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
@@ -737,6 +738,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
   const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
   float lambda = fp.lambda; // constant for GaussNewtonSolverT, adapted by the LM schedule
+  float trRadius = fp.trustRadius; // TrustRegionQRT::curTrustRegionRadius_ (initializeSolver, trust_region_qr.cpp:38-41)
   double curError = DBL_MAX;
   int itersDone = 0;
   __syncthreads();
@@ -757,6 +759,22 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     // the constraint payload of this thread's unit is requested before FK so that its HBM latency
     // hides behind it (one round trip per iteration instead of two)
     const UnitInput uin0 = loadUnitInput(pb, b, tid < U ? tid : U);
+    // TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270) wraps what follows
+    // in up to ten trial steps (:157); every other step rule passes through once.
+    float trLambda = 1e-10f; // :86, only grows within an iteration (:213-224)
+    int trustStep = 0;
+    bool trNoStep = false; // the step is not worth taking (:164) or could not be computed: the parameters stay
+    float trDn2 = 0.f, trDg = 0.f, trMu = 0.f; // |step|^2, step . J^T r, damping of the step on the table
+    bool notPd = false;
+    for (;;) {
+    int tidT = tid;
+    if (kTR) { // (no per-thread invariant of the body is to live across the re-solve loops either)
+      asm volatile("" : "+v"(tidT));
+    }
+    {
+    const int tid = tidT;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
     blockFk(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast);
     MMX_CLK(1)
@@ -783,6 +801,19 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     __syncthreads();
     curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); // every thread: the same value
     MMX_CLK(2)
+    int newtonIter = 0, pdRetries = 0;
+    for (;;) { // one pass per value of the damping (the trust region's Newton updates change it, :180-231)
+    int tidS = tid;
+    if (kTR) {
+      asm volatile("" : "+v"(tidS));
+    }
+    {
+    const int tid = tidS;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the reference seeds R with lambda ON its diagonal (online_householder_qr.cpp:133-140) and appends
+    // sqrt(lambda_new - lambda) I rows: R^T R = J^T J + (1e-20 + lambda - 1e-10) I
+    const float mu = kTR ? 1e-20f + (trLambda - 1e-10f) : lambda;
     // ================= D: own + subtree sums
     ownSums(fv, s, s.umom, U, tid);
     __syncthreads();
@@ -1025,10 +1056,23 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
       }
       __syncthreads();
     }
-    // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block
+    // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block.  The trust
+    // region starts from (almost) no damping, which the reference's QR of J can take and an fp32 Cholesky
+    // of J^T J cannot when J is rank deficient: the FACTOR is damped by at least 1e-6 of the mean diagonal,
+    // the refinement (which measures its residual with the true mu through J) moves the step towards the
+    // undamped one wherever J determines it.
+    float muFactor = mu;
+    if (kTR) {
+      float tr = 0.f;
+      for (int c = tid; c < n; c += 256) {
+        tr += s.L[256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15)];
+      }
+      tr = blockSumF(s, tr, tid);
+      muFactor = fmaxf(mu, 1e-6f * tr / float(n > 0 ? n : 1));
+    }
     for (int c = tid; c < NP; c += 256) {
       float* dg = s.L + 256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15);
-      *dg = c < n ? *dg + lambda : 1.f;
+      *dg = c < n ? *dg + muFactor : 1.f;
     }
     if (MODE == 1 && it == 0) {
       for (int c = tid; c < n; c += 256) {
@@ -1191,7 +1235,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
       MMX_CLK(13)
     }
     __syncthreads();
-    const bool notPd = s.flags[1] != 0;
+    notPd = s.flags[1] != 0;
     MMX_CLK(7)
 
     // ================= I: d0 = (L L^T)^-1 g
@@ -1359,7 +1403,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
           if (hasParamRows) {
             a += paramRowsColumn(rig, pb, fd, s.th, s.d0, lColToSolve, P, b, c, lSolveList[c]).g;
           }
-          a -= lambda * s.d0[c];
+          a -= mu * s.d0[c];
         }
         s.rho[c] = a;
       }
@@ -1389,7 +1433,92 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
       }
     }
     MMX_CLK(9)
+    if (!kTR) {
+      break;
+    }
+    // ---- trust region: is this step the one to try, or does the damping have to grow first?
+    if (notPd) { // (cannot happen in the reference's QR) more damping, a bounded number of times
+      trLambda = fmaxf(4.f * trLambda, 1e-6f);
+      if (++pdRetries > 16) {
+        trNoStep = true;
+        break;
+      }
+      continue;
+    }
+    {
+      float p0 = 0.f, p1 = 0.f;
+      for (int c = tid; c < n; c += 256) {
+        p0 += s.d0[c] * s.d0[c];
+        p1 += s.d0[c] * s.g[c];
+      }
+      trDn2 = blockSumF(s, p0, tid);
+      trDg = blockSumF(s, p1, tid);
+      trMu = mu;
+    }
+    if (newtonIter == 0 && 2.f * trDg < FLT_EPSILON * (1.f + float(curError))) { // :164 (gradientSub_ = 2 J^T r)
+      trNoStep = true;
+      break;
+    }
+    if (newtonIter < 3 && sqrtf(trDn2) >= 1.05f * trRadius) { // :180-181
+      // Newton step on lambda (Nocedal & Wright eq. 4.44, :191-204): p_l = -(step), |q_l|^2 = p_l^T (R^T R)^-1 p_l
+      for (int c = tid; c < NP; c += 256) {
+        s.rho[c] = c < n ? s.d0[c] : 0.f;
+      }
+      __syncthreads();
+      solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
+      float pq = 0.f;
+      for (int c = tid; c < n; c += 256) {
+        pq += s.d0[c] * s.rho[c];
+      }
+      const float q2 = blockSumF(s, pq, tid);
+      if (q2 >= FLT_EPSILON) { // :198
+        const float pn = sqrtf(trDn2);
+        const float deltaLambda = (trDn2 / q2) * ((pn - trRadius) / trRadius);
+        if (deltaLambda > 0.f) { // :207: lambda only ever grows
+          trLambda += deltaLambda;
+          ++newtonIter;
+          continue; // factor and solve again with the larger damping (the reference appends rows to its QR)
+        }
+      }
+    }
+    break;
+    }
+    } // linear solves
     // ================= K: theta -= delta ; bookkeeping of SolverT::solve (solver.cpp:92-119)
+    if (kTR) {
+      if (trNoStep) {
+        break;
+      }
+      // trial step, gain ratio against the quadratic model e - 2 g.p + p^T (J^T J + 1e-20 I) p, where
+      // p^T J^T J p = g.p - mu |p|^2 because (J^T J + mu I) p = g  (:240-247)
+      for (int i = tid; i < P; i += 256) {
+        s.dfull[i] = s.th[i];
+      }
+      __syncthreads();
+      for (int c = tid; c < n; c += 256) {
+        s.dfull[fv.solveList[c]] -= s.d0[c];
+      }
+      __syncthreads();
+      const double eNew = blockError(rig, rv, pb, fv, s, s.dfull, b, tid);
+      const float predicted = trDg + (trMu - 1e-20f) * trDn2; // e - model
+      const float rho = float((curError - eNew) / double(predicted));
+      if (rho < 0.25f) { // :256-262 (lambda > 0 always holds: it starts at 1e-10)
+        trRadius = 0.25f * trRadius;
+      } else if (rho > 0.75f) {
+        trRadius = fminf(2.f * trRadius, 10.f);
+      }
+      if (rho > 0.f) { // :265
+        for (int i = tid; i < P; i += 256) {
+          s.th[i] = s.dfull[i];
+        }
+        break;
+      }
+      if (++trustStep >= 10) { // :157: every trial rejected, the parameters stay (:268-269)
+        break;
+      }
+      __syncthreads();
+      continue; // the trial evaluation overwrote the joint states and the factor: this theta once more
+    }
     if (!notPd && fp.stepRule == 1) {
       // ---- LM gain-ratio schedule, the lambda form of TrustRegionQRT's radius rule
       // (momentum/character_solver/trust_region_qr.cpp:244-268); identical to the oracle's
@@ -1459,6 +1588,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
         s.th[fv.solveList[c]] -= s.d0[c]; // skeleton_solver_function.cpp:158
       }
     }
+    break;
+    }
+    } // trust steps
     if (tid == 0) {
       const double e = curError;
       if (st.errorHistory != nullptr) {
@@ -1517,7 +1649,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
 }
 #endif
 
-template <int NB, int MODE>
+template <int NB, int MODE, bool kTR>
 static hipError_t launchFusedMode(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -1536,13 +1668,13 @@ static hipError_t launchFusedMode(
   static size_t attrBytes = 64 * 1024; // default dynamic-LDS limit; raised on demand
   if (lds > attrBytes) {
     hipError_t rc = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (rc != hipSuccess) {
       return rc;
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
   return hipGetLastError();
 }
 
@@ -1558,13 +1690,16 @@ static hipError_t launchFusedNB(
     float* dbgG,
     long long* dbgClk,
     hipStream_t stream) {
+  if (fp.stepRule == 2) { // MMX_STEP_TRUST_REGION: its own instantiation (no clocks / parity dump in it)
+    return launchFusedMode<NB, 0, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+  }
   if (dbgClk != nullptr) {
-    return launchFusedMode<NB, 2>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+    return launchFusedMode<NB, 2, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
   }
   if (dbgH != nullptr || dbgG != nullptr) {
-    return launchFusedMode<NB, 1>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+    return launchFusedMode<NB, 1, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
   }
-  return launchFusedMode<NB, 0>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+  return launchFusedMode<NB, 0, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
 }
 
 // The instantiations are split over four translation units (build.py compiles this file once per

@@ -80,6 +80,7 @@ struct FusedParams {
   int32_t doLineSearch; // GaussNewtonSolverT::updateParameters backtracking (gauss_newton_solver.cpp:283-313)
   int32_t stepRule; // MMX_STEP_*
   float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
+  float trustRadius; // TrustRegionQROptions::trustRegionRadius_
 };
 
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels);

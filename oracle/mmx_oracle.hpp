@@ -1319,8 +1319,9 @@ struct Options {
   float regularization = 0.05f;
   int doLineSearch = 0; // 0 none, 1 GaussNewtonSolverT rule, 2 SubsetGaussNewtonSolverT / GaussNewtonSolverQRT rule
   bool useBlockJtJ = false;
-  int stepRule = 0; // 0 = fixed lambda (reference), 1 = LM gain-ratio schedule (build's own)
+  int stepRule = 0; // 0 = fixed lambda (reference), 1 = LM gain-ratio schedule (build's own), 2 = TrustRegionQRT (reference)
   float lmLambdaMin = 1e-6f, lmLambdaMax = 1e6f, lmUp = 4.f, lmDown = 0.5f;
+  float trustRegionRadius = 1.f; // TrustRegionQROptions::trustRegionRadius_ (trust_region_qr.h:24)
 };
 
 template <class T>
@@ -1330,6 +1331,116 @@ struct SolveResult {
   bool notPD = false;
   std::vector<double> errorHistory;
   std::vector<T> lastJtJ, lastJtr; // compacted system of the last iteration (for parity hooks)
+};
+
+// OnlineHouseholderQR<T> (momentum/math/online_householder_qr.h:146-215, .cpp:128-243): R starts as
+// seed * I (reset(n, lambda) puts `lambda` itself on the diagonal, .cpp:133-140), every add() reduces a block
+// of rows (A, b) against the current R with Householder reflections, y accumulates the rotated right-hand
+// side; result() = R^-1 y, At_times_b() = R^T y.  R is n x n upper triangular, row-major here.
+template <class T>
+struct OnlineQR {
+  int n = 0;
+  std::vector<T> R, y;
+  void reset(int n_, T seed) {
+    n = n_;
+    R.assign(size_t(n) * n, T(0));
+    y.assign(size_t(n), T(0));
+    for (int i = 0; i < n; ++i) {
+      R[size_t(i) * n + i] = seed;
+    }
+  }
+  // A: rows x n column-major (column j at A + j * lda), b: rows.  Both are destroyed ("addMutating").
+  void addMutating(T* A, int rows, int lda, T* b) {
+    for (int j = 0; j < n; ++j) {
+      T norm2 = R[size_t(j) * n + j] * R[size_t(j) * n + j];
+      T* aj = A + size_t(j) * lda;
+      for (int i = 0; i < rows; ++i) {
+        norm2 += aj[i] * aj[i];
+      }
+      if (norm2 == T(0)) {
+        continue;
+      }
+      const T rjj = R[size_t(j) * n + j];
+      const T alpha = rjj > T(0) ? -std::sqrt(norm2) : std::sqrt(norm2);
+      const T v0 = rjj - alpha; // v = (v0, a_j) ; H = I - 2 v v^T / (v^T v)
+      const T vtv = v0 * v0 + (norm2 - rjj * rjj);
+      if (vtv == T(0)) {
+        continue;
+      }
+      const T beta = T(2) / vtv;
+      for (int k = j + 1; k < n; ++k) {
+        T* ak = A + size_t(k) * lda;
+        T dot = v0 * R[size_t(j) * n + k];
+        for (int i = 0; i < rows; ++i) {
+          dot += aj[i] * ak[i];
+        }
+        const T f = beta * dot;
+        R[size_t(j) * n + k] -= f * v0;
+        for (int i = 0; i < rows; ++i) {
+          ak[i] -= f * aj[i];
+        }
+      }
+      {
+        T dot = v0 * y[j];
+        for (int i = 0; i < rows; ++i) {
+          dot += aj[i] * b[i];
+        }
+        const T f = beta * dot;
+        y[j] -= f * v0;
+        for (int i = 0; i < rows; ++i) {
+          b[i] -= f * aj[i];
+        }
+      }
+      R[size_t(j) * n + j] = alpha;
+      for (int i = 0; i < rows; ++i) {
+        aj[i] = T(0);
+      }
+    }
+  }
+  // appends y * I rows with a zero right-hand side (trust_region_qr.cpp:209-217)
+  void addScaledIdentity(T yv) {
+    std::vector<T> D(size_t(n) * n, T(0)), z(size_t(n), T(0));
+    for (int i = 0; i < n; ++i) {
+      D[size_t(i) * n + i] = yv;
+    }
+    addMutating(D.data(), n, n, z.data());
+  }
+  std::vector<T> solveUpper(const std::vector<T>& rhs) const { // R x = rhs ; 0 / 0 -> 0 like Eigen's triangular solve (.cpp:236-242)
+    std::vector<T> x(rhs);
+    for (int i = n - 1; i >= 0; --i) {
+      T sum = x[i];
+      for (int k = i + 1; k < n; ++k) {
+        sum -= R[size_t(i) * n + k] * x[k];
+      }
+      const T d = R[size_t(i) * n + i];
+      x[i] = d != T(0) ? sum / d : T(0);
+    }
+    return x;
+  }
+  std::vector<T> solveUpperTransposed(const std::vector<T>& rhs) const { // R^T x = rhs
+    std::vector<T> x(rhs);
+    for (int i = 0; i < n; ++i) {
+      T sum = x[i];
+      for (int k = 0; k < i; ++k) {
+        sum -= R[size_t(k) * n + i] * x[k];
+      }
+      const T d = R[size_t(i) * n + i];
+      x[i] = d != T(0) ? sum / d : T(0);
+    }
+    return x;
+  }
+  std::vector<T> result() const {
+    return solveUpper(y);
+  }
+  std::vector<T> AtTimesB() const {
+    std::vector<T> g(size_t(n), T(0));
+    for (int k = 0; k < n; ++k) {
+      for (int i = k; i < n; ++i) {
+        g[i] += R[size_t(k) * n + i] * y[k];
+      }
+    }
+    return g;
+  }
 };
 
 // GaussNewtonSolverT<T> + SolverT<T>::solve
@@ -1352,6 +1463,8 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
   double error = std::numeric_limits<double>::max(); // solver.cpp:84-85
   double lastError = std::numeric_limits<double>::max();
   T lambda = T(opt.regularization);
+  T curTrustRegionRadius = T(opt.trustRegionRadius); // TrustRegionQRT::initializeSolver (trust_region_qr.cpp:38-41)
+  const T maxTrustRegionRadius = T(10); // trust_region_qr.h:83
 
   int it = 0;
   for (; it < opt.maxIterations; ++it) { // solver.cpp:89
@@ -1382,7 +1495,96 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
     out.lastJtJ = H;
     out.lastJtr = g;
 
-    if (opt.stepRule == 0) {
+    if (opt.stepRule == 2) {
+      // ---- TrustRegionQRT<T>::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270).  jac
+      // holds the compacted enabled columns (ColumnIndexedMatrix, :110-114); all error functions form one
+      // block here (the QR of stacked blocks is the QR of the whole matrix up to signs).
+      OnlineQR<T> qr;
+      T lam = T(1e-10); // :86: "a tiny lambda just to make sure we don't divide by zero"
+      qr.reset(n, lam); // :87 -- seeds the diagonal of R with lambda itself
+      {
+        std::vector<T> A(jac.begin(), jac.begin() + size_t(M) * n), b(res.begin(), res.end());
+        qr.addMutating(A.data(), M, M, b.data()); // :110-114
+      }
+      std::vector<T> gradientSub = qr.AtTimesB(); // :121: 2 J^T r
+      for (T& v : gradientSub) {
+        v *= T(2);
+      }
+      const std::vector<T> R0 = qr.R; // :124
+      auto evalQuadraticModel = [&](const std::vector<T>& p) { // :136-144
+        T result = T(error);
+        for (int s = 0; s < n; ++s) {
+          result -= gradientSub[s] * p[s];
+        }
+        T sq = T(0);
+        for (int i = 0; i < n; ++i) {
+          T row = T(0);
+          for (int k = i; k < n; ++k) {
+            row += R0[size_t(i) * n + k] * p[k];
+          }
+          sq += row * row;
+        }
+        return result + sq;
+      };
+      const T nu = T(0); // :155
+      for (int iTrustStep = 0; iTrustStep < 10; ++iTrustStep) { // :157
+        std::vector<T> searchDir = qr.result(); // :158
+        T sg = T(0);
+        for (int s = 0; s < n; ++s) {
+          sg += searchDir[s] * gradientSub[s];
+        }
+        if (sg < T(FLT_EPSILON) * (T(1) + T(error))) { // :164
+          break;
+        }
+        auto norm = [&](const std::vector<T>& v) {
+          T a = T(0);
+          for (T x : v) {
+            a += x * x;
+          }
+          return a;
+        };
+        for (int iIter = 0; iIter < 3; ++iIter) { // :180
+          if (std::sqrt(norm(searchDir)) < T(1.05) * curTrustRegionRadius) { // :181
+            break;
+          }
+          std::vector<T> rhs(static_cast<size_t>(n), T(0));
+          for (int s = 0; s < n; ++s) {
+            rhs[s] = -T(0.5) * gradientSub[s];
+          }
+          const std::vector<T> p_l = qr.solveUpper(qr.solveUpperTransposed(rhs)); // :191-192
+          const std::vector<T> q_l = qr.solveUpperTransposed(p_l); // :193
+          const T p2 = norm(p_l), q2 = norm(q_l);
+          if (q2 < T(FLT_EPSILON)) { // :198
+            break;
+          }
+          const T pn = std::sqrt(p2);
+          const T deltaLambda = (p2 / q2) * ((pn - curTrustRegionRadius) / curTrustRegionRadius); // :203-204
+          if (deltaLambda <= T(0)) { // :207
+            break;
+          }
+          const T lambdaNew = lam + deltaLambda;
+          qr.addScaledIdentity(std::sqrt(lambdaNew - lam)); // :215-224
+          lam = lambdaNew;
+          searchDir = qr.result(); // :229
+        }
+        const std::vector<T> orig = params; // :240
+        for (int s = 0; s < n; ++s) {
+          params[E[s]] -= searchDir[s]; // :241, skeleton_solver_function.cpp:158
+        }
+        const double errorNew = fn.getError(params.data()); // :242
+        const T quadraticModelEval = evalQuadraticModel(searchDir); // :246
+        const T rho = T((error - errorNew) / (error - double(quadraticModelEval))); // :247
+        if (rho < T(0.25)) { // :256
+          curTrustRegionRadius = T(0.25) * curTrustRegionRadius;
+        } else if (rho > T(0.75) && lam > T(0)) { // :259
+          curTrustRegionRadius = std::min(T(2) * curTrustRegionRadius, maxTrustRegionRadius);
+        }
+        if (rho > nu) { // :265
+          break;
+        }
+        params = orig; // :268-269
+      }
+    } else if (opt.stepRule == 0) {
       // ---- dense GN step (:241-257)
       for (int i = 0; i < n; ++i) {
         H[size_t(i) * n + i] += T(opt.regularization); // :248
@@ -1439,7 +1641,7 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
         }
       }
     } else {
-      // ---- LM gain-ratio schedule: the lambda-form of TrustRegionQRT's radius rule
+      // ---- LM gain-ratio schedule (the build's own): a lambda-form of TrustRegionQRT's radius rule
       // (momentum/character_solver/trust_region_qr.cpp:244-268): rho = actual/predicted decrease;
       // rho < 0.25 -> lambda *= up; rho > 0.75 -> lambda *= down; rho <= 0 -> reject the step.
       // One trial step per iteration (a rejected step still consumes the iteration).

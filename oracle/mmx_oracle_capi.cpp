@@ -104,6 +104,7 @@ Options makeOptions(const mmx_gn_options* o, int useBlockJtJ) {
   r.lmLambdaMax = o->lm_lambda_max;
   r.lmUp = o->lm_up;
   r.lmDown = o->lm_down;
+  r.trustRegionRadius = o->trust_region_radius > 0.f ? o->trust_region_radius : 1.f;
   return r;
 }
 

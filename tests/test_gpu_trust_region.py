@@ -1,0 +1,95 @@
+"""MMX_STEP_TRUST_REGION = TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270)
+in the fused kernel, against the oracle's line-by-line restatement (pinned by the reference's own
+TrustRegionTest shapes in tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+
+from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
+from momentum_amd._abi import MMX_STEP_TRUST_REGION, GnOptions
+from tests.helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+UNIT = 0.01
+
+
+def _gpu(torch, rig, cons, B):
+    from momentum_amd import capi
+
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(
+        t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+        t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)), 1.0, 1.0,
+    )  # fmt: skip
+    return rh, pb
+
+
+@pytest.mark.parametrize("radius", [1.0, 0.3])
+def test_trust_region_matches_oracle_on_the_reference_fixture(torch_cuda, orc, radius):
+    """The reference's TrustRegionTest.SanityCheck shape (solver_test.cpp:178-230): position + orientation
+    constraint on every joint of createTestCharacter, targets from a random pose in [-1, 1]^P, start at 0.
+    J has full column rank there, so the (almost) undamped steps are well defined in single precision:
+    the error history follows the oracle's double-precision run (same trial decisions) and the pose
+    parameters agree to 1e-4 after 12 iterations (the Newton updates of lambda divide two fp32 quadratic
+    forms, which is where single and double precision part beyond 1e-5)."""
+    torch = torch_cuda
+    rig = make_test_character(5)
+    J = rig.num_joints
+    B = 16
+    cons, th0, ths = make_problem(rig, list(range(J)), list(range(J)), B, seed=900, perturb=1.0)
+    rh, pb = _gpu(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=12, max_iterations=12, threshold=1000.0, step_rule=MMX_STEP_TRUST_REGION, trust_region_radius=radius)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"]) and np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    same = np.all(np.abs(h - href) <= 2e-3 * np.abs(href) + 1e-6 * href[:, :1], axis=1)
+    assert same.mean() >= 0.8, (same.mean(), np.abs(h - href).max(axis=1))
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel[same].max() <= 1e-4, rel
+    # whatever path an element took, it is a good solution: the reference's own acceptance bound against GN
+    gn = orc.solve_batch(rig, cons, th0, GnOptions.make(min_iterations=12, max_iterations=12, threshold=1000.0, regularization=0.05), dtype="f64")
+    for b in range(B):
+        e_tr = orc.get_error(rig, cons.instance(b), th[b].astype(np.float64), "f64")
+        e_gn = orc.get_error(rig, cons.instance(b), gn["theta"][b], "f64")
+        assert e_tr <= 1.001 * e_gn + 0.001, (b, e_tr, e_gn)
+
+
+def test_trust_region_on_the_humanoid_does_at_least_as_well_as_gauss_newton(torch_cuda, orc):
+    """BASELINE configs[1]'s rig has redundant rotation dofs (J^T J is singular), where the reference's
+    undamped first steps are defined by rounding; parity there is the reference's own criterion
+    (solver_test.cpp:228: err_tr <= 1.001 err_gn + 0.001), every element, plus determinism."""
+    torch = torch_cuda
+    rig = make_humanoid72(unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    B = 64
+    cons, th0, ths = make_problem(rig, lm, lm, B, seed=31, perturb=0.3)
+    rh, pb = _gpu(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, step_rule=MMX_STEP_TRUST_REGION)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    out2 = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert torch.equal(out["theta"], out2["theta"]) and torch.equal(out["error_history"], out2["error_history"])
+    assert int((out["status"] != 0).sum()) == 0
+    th = out["theta"].cpu().numpy()
+    gn = orc.solve_batch(rig, cons, th0, GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05), dtype="f64")
+    h = out["error_history"].cpu().numpy()
+    assert np.all(np.diff(h, axis=1) <= 1e-6 * np.abs(h[:, :-1]) + 1e-12)  # accepted steps only ever decrease the error
+    for b in range(B):
+        e_tr = orc.get_error(rig, cons.instance(b), th[b].astype(np.float64), "f64")
+        e_gn = orc.get_error(rig, cons.instance(b), gn["theta"][b], "f64")
+        assert e_tr <= 1.001 * e_gn + 0.001, (b, e_tr, e_gn)
+
+
+def test_trust_region_needs_the_fused_solver(torch_cuda, monkeypatch):
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    rig = make_test_character(5)
+    cons, th0, _ = make_problem(rig, [4], [3], 2, seed=1)
+    rh, pb = _gpu(torch, rig, cons, 2)
+    monkeypatch.setenv("MMX_SOLVER", "v1")
+    with pytest.raises(capi.MmxError) as ei:
+        pb.solve(torch.from_numpy(th0.copy()).to(pb.device), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION))
+    assert "fused" in str(ei.value)

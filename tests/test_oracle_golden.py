@@ -292,3 +292,105 @@ def test_solve_returns_stale_error_and_converges(orc):
     r9 = orc.solve(rig, c, th0[0], opt9, dtype="f64")
     assert abs(orc.get_error(rig, c, r9["theta"], "f64") - r["error"]) <= 2e-6 * max(1.0, r["error"])
     assert r["error_history"][-1] < 1e-3 * r["error_history"][0]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_trust_region_sanity_check(orc, dtype):
+    """momentum/test/character_solver/solver_test.cpp:178-230 (TrustRegionTest.SanityCheck): position +
+    orientation constraint on every joint of the test character, targets from a random pose in [-1,1]^P,
+    start at 0, defaultSolverOptions (minIter 4, maxIter 40, threshold 1000): the trust-region solver must
+    do at least as well as Gauss-Newton: err_tr <= 1.001 err_gn + 0.001 -- ten frames like the reference."""
+    from momentum_amd._abi import MMX_STEP_TRUST_REGION
+
+    rig = make_test_character(5)
+    J = rig.num_joints
+    for frame in range(10):
+        cons, th0, ths = make_problem(rig, list(range(J)), list(range(J)), 1, seed=900 + frame, perturb=1.0)
+        c = cons.instance(0)
+        kw = dict(min_iterations=4, max_iterations=40, threshold=1000.0)
+        tr = orc.solve(rig, c, np.zeros(rig.num_params), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION, **kw), dtype=dtype)
+        gn = orc.solve(rig, c, np.zeros(rig.num_params), GnOptions.make(regularization=0.05, **kw), dtype=dtype, use_block_jtj=True)
+        err_tr = orc.get_error(rig, c, tr["theta"], dtype)
+        err_gn = orc.get_error(rig, c, gn["theta"], dtype)
+        assert err_tr <= 1.001 * err_gn + 0.001, (frame, err_tr, err_gn)
+        assert tr["error_history"][-1] <= tr["error_history"][0]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_trust_region_perfect_quadratic(orc, dtype):
+    """solver_test.cpp:131-175 (TrustRegionTest.PerfectQuadratic): a ModelParametersErrorFunction alone is an
+    exactly quadratic objective; trust region <= 1.001 Gauss-Newton + 0.001, and both reach the target on the
+    weighted parameters."""
+    from momentum_amd._abi import MMX_STEP_TRUST_REGION
+
+    rig = make_test_character(5)
+    P = rig.num_params
+    rng = np.random.default_rng(12345)
+    for frame in range(10):
+        target = rng.uniform(-1, 1, size=(1, P)).astype(np.float32)
+        weights = np.abs(rng.uniform(-1, 1, size=(1, P))).astype(np.float32)
+        empty = np.zeros((1, 0, 3), np.float32)
+        c = orc.Constraints([], empty, empty, np.zeros((1, 0), np.float32), [], np.zeros((1, 0, 4), np.float32), np.zeros((1, 0, 4), np.float32),
+                            np.zeros((1, 0), np.float32), model_target=target, model_weights=weights).instance(0)  # fmt: skip
+        kw = dict(min_iterations=4, max_iterations=40, threshold=1000.0)
+        tr = orc.solve(rig, c, np.zeros(P), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION, **kw), dtype=dtype)
+        gn = orc.solve(rig, c, np.zeros(P), GnOptions.make(regularization=0.05, **kw), dtype=dtype)
+        err_tr = orc.get_error(rig, c, tr["theta"], dtype)
+        err_gn = orc.get_error(rig, c, gn["theta"], dtype)
+        assert err_tr <= 1.001 * err_gn + 0.001, (frame, err_tr, err_gn)
+        # undamped (1e-20) steps inside the radius solve the quadratic exactly once the radius has grown
+        assert err_tr <= 1e-6 if dtype == "f64" else err_tr <= 1e-4
+
+
+def test_trust_region_first_iteration_against_a_numpy_restatement(orc):
+    """One iteration of TrustRegionQRT::doIteration (trust_region_qr.cpp:52-270) restated independently with
+    numpy on the oracle's own J / r: normal equations with damping mu = 1e-20 + (lambda - 1e-10) (the QR is
+    seeded with lambda = 1e-10 ON the diagonal of R and grows by sqrt(dlambda) I rows), <= 3 Newton updates of
+    lambda towards |step| = radius (Nocedal & Wright eq. 4.44), gain ratio against e - g.p + p^T J^T J p,
+    accept iff rho > 0."""
+    from momentum_amd._abi import MMX_STEP_TRUST_REGION
+
+    rig = make_test_character(6)
+    J = rig.num_joints
+    cons, th0, ths = make_problem(rig, list(range(J)), list(range(J)), 1, seed=4711, perturb=1.0)
+    c = cons.instance(0)
+    P = rig.num_params
+    theta = np.zeros(P)
+    Jm, r, e = orc.eval_jacobian(rig, c, theta, dtype="f64")
+    H, g = Jm.T @ Jm, Jm.T @ r
+    lam, radius = 1e-10, 1.0
+    expected = None
+    for trust_step in range(10):
+        mu = 1e-20 + (lam - 1e-10)
+        step = np.linalg.solve(H + mu * np.eye(P), g)
+        if step @ (2 * g) < np.finfo(np.float32).eps * (1 + e):
+            expected = theta
+            break
+        for it in range(3):
+            if np.linalg.norm(step) < 1.05 * radius:
+                break
+            A = H + mu * np.eye(P)
+            p = -np.linalg.solve(A, g)
+            q2 = p @ np.linalg.solve(A, p)
+            if q2 < np.finfo(np.float32).eps:
+                break
+            dl = (p @ p) / q2 * ((np.linalg.norm(p) - radius) / radius)
+            if dl <= 0:
+                break
+            lam += dl
+            mu = 1e-20 + (lam - 1e-10)
+            step = np.linalg.solve(H + mu * np.eye(P), g)
+        trial = theta - step
+        e_new = orc.get_error(rig, c, trial, "f64")
+        model = e - (2 * g) @ step + step @ (H + 1e-20 * np.eye(P)) @ step
+        rho = (e - e_new) / (e - model)
+        if rho < 0.25:
+            radius *= 0.25
+        elif rho > 0.75:
+            radius = min(2 * radius, 10.0)
+        if rho > 0:
+            expected = trial
+            break
+    assert expected is not None
+    got = orc.solve(rig, c, theta, GnOptions.make(min_iterations=1, max_iterations=1, step_rule=MMX_STEP_TRUST_REGION), dtype="f64")
+    assert np.abs(got["theta"] - expected).max() <= 1e-8 * max(1.0, np.abs(expected).max())
