@@ -214,9 +214,10 @@ def cpu_baseline(db: DeviceBatch, sample, options):
     }
 
 
-def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None):
+def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None, comm=None):
     """W untimed + K timed batched solves; returns (elapsed seconds (max over ranks), theta of the last solve,
-    reduced norms)."""
+    reduced norms).  comm: the direct RCCL communicator (momentum_amd.capi.Comm) when there is one."""
+    from momentum_amd import capi
     from momentum_amd import distributed as D
 
     pb, dev, B = db.pb, db.pb.device, db.B
@@ -231,11 +232,13 @@ def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None):
     def step():
         theta.copy_(db.theta0)
         pb.solve(theta, opt, outputs=outputs)
-        # the path's only exchange: per-batch residual norms (sum error, sum iterations, #failed)
-        norms[0] = outputs["error"].sum()
-        norms[1] = outputs["iterations"].sum()
-        norms[2] = (outputs["status"] != 0).sum()
-        D.reduce_norms(dist, norms)
+        # the path's only exchange: per-batch residual norms (sum error, sum iterations, #failed), reduced by
+        # RCCL called from the C ABI (mmx_comm_all_reduce_norms); gloo only in the one-GPU plumbing test
+        capi.residual_norms(outputs, norms)
+        if comm is not None:
+            comm.all_reduce_norms(norms)
+        else:
+            D.reduce_norms(dist, norms)
 
     def fence():
         if dist is not None:
@@ -335,6 +338,17 @@ def main() -> None:
     local_rank = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     dist = D.init(args.backend)  # RCCL behind the "nccl" backend on ROCm; None when world == 1
+    comm = None
+    if dist is not None and args.backend == "nccl":
+        # the data path's exchange goes through the library's own RCCL communicator; torch.distributed only
+        # carries the 128-byte id to the other ranks and the barrier of the timing contract
+        from momentum_amd import capi
+
+        idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        comm = capi.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
 
     from momentum_amd._abi import GnOptions
 
@@ -345,7 +359,7 @@ def main() -> None:
     pb, theta_star = db.pb, db.theta_star
     opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=args.line_search)
     dev = pb.device
-    elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist)
+    elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist, comm)
 
     # ---- roofline of the J-assembly kernel (mmx_eval_jacobian): HIP events on the launch stream
     M, P = pb.M, pb.P
@@ -450,6 +464,7 @@ def main() -> None:
                 "line_search": args.line_search,
                 "regularization": 0.05,
                 "sharding": f"{world} x {B} independent instances, one all-reduce of residual norms per solve",
+                "exchange": ("RCCL all-reduce of 3 doubles per solve, called from the C ABI (mmx_comm_all_reduce_norms), ranks seen by RCCL: " + str(comm.world_size)) if comm is not None else ("none (one GPU)" if world == 1 else "gloo (plumbing test)"),
             },
             "check": {"sum_final_error": total_err, "sum_iterations": total_it, "failed_instances": failed},
             "roofline": {
@@ -493,6 +508,8 @@ def main() -> None:
                 except Exception as ex:  # a failing side configuration must not lose the headline line
                     line["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 6 /* 6: per-instance characters and constraint parents, MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J (additive) */
+#define MMX_ABI_VERSION 6 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
+                             trust_region_radius), mmx_comm_* (RCCL), MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
@@ -496,6 +497,34 @@ int32_t mmx_eval_jacobian_host(
     float* res_host,
     double* err_host,
     int32_t layout);
+
+/*
+ * Multi-GPU: instances are independent, so a batch shards into contiguous blocks, one problem handle per
+ * GPU, with NO collective on the data path (the reference runs one independent task per element,
+ * pymomentum/tensor_ik/tensor_ik.cpp:127-177).  The one exchange is the per-batch residual norms -- (sum of
+ * final errors, sum of iterations, number of failed instances), three doubles -- all-reduced once per solve
+ * with RCCL over xGMI.  The communicator below is that all-reduce and nothing else; RCCL is called directly
+ * (librccl is looked up at run time, so a single-GPU process never loads it).
+ *   multi-process (one rank per GPU):  rank 0 calls mmx_comm_unique_id and hands the 128 bytes to the other
+ *     ranks (any side channel: a torch.distributed / MPI broadcast, a file); every rank calls mmx_comm_create.
+ *   single process (one host thread per GPU):  mmx_comm_create_all fills one communicator per device; the
+ *     threads then call mmx_comm_all_reduce_norms concurrently (the C++ shell's BatchedMultiGpuSolver).
+ */
+#define MMX_COMM_ID_BYTES 128 /* NCCL_UNIQUE_ID_BYTES */
+typedef struct mmx_comm mmx_comm;
+int32_t mmx_comm_unique_id(uint8_t id[MMX_COMM_ID_BYTES]);
+int32_t mmx_comm_create(const uint8_t id[MMX_COMM_ID_BYTES], int32_t world_size, int32_t rank, int32_t device, mmx_comm** out);
+int32_t mmx_comm_create_all(int32_t num_devices, const int32_t* devices, mmx_comm** out /* [num_devices] */);
+int32_t mmx_comm_world_size(const mmx_comm* comm);
+int32_t mmx_comm_rank(const mmx_comm* comm);
+/* In-place sum over the ranks of norms_dev[3] (DEVICE doubles) on `stream`; asynchronous like any kernel. */
+int32_t mmx_comm_all_reduce_norms(mmx_comm* comm, double* norms_dev, void* stream);
+/* The same for three HOST doubles: staged through a device buffer and a stream the communicator owns;
+ * returns when norms_host holds the sums.  (Callers without device code, e.g. the C++ shell's threads.) */
+int32_t mmx_comm_all_reduce_norms_host(mmx_comm* comm, double norms_host[3]);
+/* (sum final_error, sum iterations, #status != 0) of a solve's outputs -> norms_dev[3], on `stream`. */
+int32_t mmx_residual_norms(int32_t batch, const double* final_error, const int32_t* iterations, const int32_t* status, double* norms_dev, void* stream);
+void mmx_comm_destroy(mmx_comm* comm);
 
 /*
  * Host-side integer bookkeeping, exposed so that it can be checked bit-exactly

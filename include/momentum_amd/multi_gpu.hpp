@@ -1,0 +1,161 @@
+// multi_gpu.hpp -- the batched solver over several GPUs of one node, in C++ over the C ABI (include/mmx.h).
+//
+// The reference solves a batch as one independent task per element (pymomentum/tensor_ik/tensor_ik.cpp:
+// 127-177).  Here the batch is cut into contiguous shards, one per device; each device gets its own
+// DeviceCharacter / BatchedSkeletonSolverFunction / solver (momentum_amd.hpp) and its own host thread, and
+// NO data crosses devices during a solve.  The one exchange is the per-batch residual norms -- (sum of final
+// errors, sum of iterations, number of failed elements) -- all-reduced once per solve by RCCL over xGMI
+// (mmx_comm_*), so that every shard's owner sees the batch totals.
+#pragma once
+
+#include <array>
+#include <exception>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "momentum_amd.hpp"
+
+namespace momentum_amd {
+
+// contiguous shard [begin, end) of rank `rank` out of `world`: ceil(total / world) elements per rank, the
+// last ranks may be short or empty
+inline std::pair<size_t, size_t> shardRange(size_t total, size_t rank, size_t world) {
+  const size_t per = (total + world - 1) / world;
+  const size_t begin = std::min(rank * per, total);
+  return {begin, std::min(begin + per, total)};
+}
+
+class BatchedMultiGpuSolver {
+ public:
+  // One shard per entry of `devices` (HIP device indices).  SolverT: BatchedGaussNewtonSolver or one of its
+  // subclasses (the line-search rule differs).
+  BatchedMultiGpuSolver(
+      const Character& character,
+      const std::vector<int>& devices,
+      size_t batch,
+      const std::vector<size_t>& positionParents,
+      const std::vector<size_t>& orientationParents,
+      const SolverOptions& options)
+      : batch_(batch), numParams_(character.parameterTransform.numAllModelParameters()) {
+    if (devices.empty()) {
+      throw std::runtime_error("momentum_amd: no device given");
+    }
+    for (size_t i = 0; i < devices.size(); ++i) {
+      const auto range = shardRange(batch, i, devices.size());
+      Shard sh;
+      sh.begin = range.first, sh.end = range.second, sh.device = devices[i];
+      sh.character = std::make_unique<DeviceCharacter>(character, devices[i]);
+      if (sh.end > sh.begin) {
+        sh.function = std::make_unique<BatchedSkeletonSolverFunction>(*sh.character, sh.end - sh.begin, positionParents, orientationParents);
+        sh.solver = std::make_unique<BatchedGaussNewtonSolver>(options, sh.function.get());
+      }
+      shards_.push_back(std::move(sh));
+    }
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    std::vector<mmx_comm*> comms(devices.size(), nullptr);
+    check(mmx_comm_create_all(int32_t(devs.size()), devs.data(), comms.data()));
+    for (size_t i = 0; i < comms.size(); ++i) {
+      shards_[i].comm.reset(comms[i], [](mmx_comm* c) { mmx_comm_destroy(c); });
+    }
+  }
+
+  size_t numShards() const {
+    return shards_.size();
+  }
+  size_t batchSize() const {
+    return batch_;
+  }
+  // the shard that owns batch element b, and b's index inside it
+  std::pair<size_t, size_t> locate(size_t b) const {
+    for (size_t i = 0; i < shards_.size(); ++i) {
+      if (b >= shards_[i].begin && b < shards_[i].end) {
+        return {i, b - shards_[i].begin};
+      }
+    }
+    throw std::runtime_error("momentum_amd: batch index out of range");
+  }
+  BatchedSkeletonSolverFunction& function(size_t shard) {
+    return *shards_.at(shard).function;
+  }
+  void setPositionConstraints(size_t b, const std::vector<PositionData>& c) {
+    const auto at = locate(b);
+    shards_[at.first].function->setPositionConstraints(at.second, c);
+  }
+  void setOrientationConstraints(size_t b, const std::vector<OrientationData>& c) {
+    const auto at = locate(b);
+    shards_[at.first].function->setOrientationConstraints(at.second, c);
+  }
+
+  // parameters [batch * P] in/out.  Returns SolverT::solve's value per element.  Afterwards norms() holds the
+  // batch totals (identical on every shard: they come out of the all-reduce).
+  std::vector<double> solve(std::vector<float>& parameters) {
+    if (parameters.size() != batch_ * numParams_) {
+      throw std::runtime_error("momentum_amd: parameters.size() != batch * numParameters"); // solver.cpp:77
+    }
+    std::vector<double> errors(batch_, 0.0);
+    std::vector<std::exception_ptr> failures(shards_.size());
+    std::vector<std::array<double, 3>> reduced(shards_.size());
+    std::vector<std::thread> threads;
+    for (size_t i = 0; i < shards_.size(); ++i) {
+      threads.emplace_back([&, i]() {
+        Shard& sh = shards_[i];
+        std::array<double, 3> local{0.0, 0.0, 0.0};
+        try {
+          if (sh.end > sh.begin) {
+            std::vector<float> slice(parameters.begin() + sh.begin * numParams_, parameters.begin() + sh.end * numParams_);
+            const std::vector<double> err = sh.solver->solve(slice);
+            std::copy(slice.begin(), slice.end(), parameters.begin() + sh.begin * numParams_);
+            std::copy(err.begin(), err.end(), errors.begin() + sh.begin);
+            for (size_t k = 0; k < err.size(); ++k) {
+              local[0] += err[k];
+              local[1] += double(sh.solver->getIterations()[k]);
+              local[2] += sh.solver->getStatus()[k] != 0 ? 1.0 : 0.0;
+            }
+          }
+        } catch (...) {
+          failures[i] = std::current_exception(); // rethrown after the join, like the reference (tensor_ik.cpp:179-186)
+        }
+        // every rank joins the collective, also after a failure: a missing rank would hang the others
+        if (mmx_comm_all_reduce_norms_host(sh.comm.get(), local.data()) != MMX_OK && !failures[i]) {
+          failures[i] = std::make_exception_ptr(std::runtime_error(std::string("momentum_amd: ") + mmx_last_error()));
+        }
+        reduced[i] = local;
+      });
+    }
+    for (std::thread& t : threads) {
+      t.join();
+    }
+    for (const std::exception_ptr& f : failures) {
+      if (f) {
+        std::rethrow_exception(f);
+      }
+    }
+    norms_ = reduced[0];
+    for (const auto& r : reduced) {
+      if (r != norms_) {
+        throw std::runtime_error("momentum_amd: ranks disagree on the reduced residual norms");
+      }
+    }
+    return errors;
+  }
+  // (sum of the returned errors, sum of iterations, number of failed elements) over the whole batch
+  const std::array<double, 3>& norms() const {
+    return norms_;
+  }
+
+ private:
+  struct Shard {
+    size_t begin = 0, end = 0;
+    int device = 0;
+    std::unique_ptr<DeviceCharacter> character;
+    std::unique_ptr<BatchedSkeletonSolverFunction> function;
+    std::unique_ptr<BatchedGaussNewtonSolver> solver;
+    std::shared_ptr<mmx_comm> comm;
+  };
+  size_t batch_, numParams_;
+  std::vector<Shard> shards_;
+  std::array<double, 3> norms_{0.0, 0.0, 0.0};
+};
+
+} // namespace momentum_amd

@@ -29,6 +29,8 @@ SYMBOLS = [
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
+    "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
+    "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
 ]  # fmt: skip
 
 
@@ -79,6 +81,16 @@ def lib() -> C.CDLL:
     L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_eval_jacobian_host.argtypes = [vp, vp, vp, vp, vp, i32]
     L.mmx_debug_fused_normal_equations.argtypes = [vp, vp, vp, vp, _abi.c_int32_p, _abi.c_int32_p, vp]
+    L.mmx_comm_unique_id.argtypes = [vp]
+    L.mmx_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.mmx_comm_create_all.argtypes = [i32, _abi.c_int32_p, C.POINTER(vp)]
+    L.mmx_comm_world_size.argtypes = [vp]
+    L.mmx_comm_rank.argtypes = [vp]
+    L.mmx_comm_all_reduce_norms.argtypes = [vp, vp, vp]
+    L.mmx_comm_all_reduce_norms_host.argtypes = [vp, vp]
+    L.mmx_residual_norms.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.mmx_comm_destroy.argtypes = [vp]
+    L.mmx_comm_destroy.restype = None
     L.mmx_host_tables.argtypes = [
         C.POINTER(RigDesc), _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p,
         _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p,
@@ -375,3 +387,55 @@ class Problem:
         )  # fmt: skip
         outputs["theta"] = theta
         return outputs
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """The path's one multi-GPU exchange (mmx_comm): an RCCL all-reduce of the three residual norms per solve,
+    one rank per GPU.  Rank 0 makes the id with Comm.unique_id() and hands the 128 bytes to the other ranks
+    through any side channel (bench.py: a torch.distributed broadcast)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib().mmx_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, comm_id: bytes, world_size: int, rank: int, device: int):
+        assert len(comm_id) == COMM_ID_BYTES
+        self._h = C.c_void_p(0)
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id)
+        _check(lib().mmx_comm_create(C.cast(buf, C.c_void_p), int(world_size), int(rank), int(device), C.byref(self._h)))
+
+    @property
+    def world_size(self) -> int:
+        return int(lib().mmx_comm_world_size(self._h))
+
+    @property
+    def rank(self) -> int:
+        return int(lib().mmx_comm_rank(self._h))
+
+    def all_reduce_norms(self, norms) -> None:
+        """In-place sum over the ranks of a float64[3] cuda tensor, on torch's current stream."""
+        assert norms.is_cuda and str(norms.dtype) == "torch.float64" and norms.numel() == 3 and norms.is_contiguous()
+        _check(lib().mmx_comm_all_reduce_norms(self._h, _dev(norms), _stream_ptr()))
+
+    def close(self) -> None:
+        if self._h:
+            lib().mmx_comm_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def residual_norms(outputs: dict, norms) -> None:
+    """(sum final error, sum iterations, #failed) of a solve's outputs -> norms (float64[3] cuda tensor): one
+    small kernel on torch's current stream, fixed summation order."""
+    e, it, st = outputs["error"], outputs["iterations"], outputs["status"]
+    _check(lib().mmx_residual_norms(int(e.numel()), _dev(e), _dev(it), _dev(st), _dev(norms), _stream_ptr()))

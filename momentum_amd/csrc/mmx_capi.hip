@@ -139,6 +139,12 @@ hipError_t upload(DevBuf& buf, const std::vector<T>& v) {
 
 } // namespace
 
+namespace mmx {
+int32_t failWith(int32_t code, const std::string& msg) { // for the other translation units of the C ABI
+  return fail(code, msg);
+}
+} // namespace mmx
+
 struct mmx_rig {
   int32_t device = 0;
   int32_t J = 0, P = 0;

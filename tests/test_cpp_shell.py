@@ -25,6 +25,26 @@ def _compile(src=SRC, exe=EXE):
     subprocess.check_call(cmd)
 
 
+MULTI_SRC = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu.cpp")
+MULTI_EXE = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu")
+
+
+def _golden_header():
+    import sys
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "cpp", "make_golden_header.py"),
+                           os.path.join(ROOT, "tests", "golden", "cfg2_humanoid72.npz"), GOLDEN_INC])  # fmt: skip
+
+
+def _compile_multi():
+    _golden_header()
+    mbuild.build()
+    libdir = os.path.join(ROOT, "momentum_amd")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"), MULTI_SRC, "-L", libdir, "-lmmx_hip",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", MULTI_EXE]  # fmt: skip
+    subprocess.check_call(cmd)
+
+
 def _compile_parity():
     # the committed golden fixture (inputs + the oracle's double-precision answers) as a C++ include
     import sys
@@ -59,5 +79,20 @@ def test_cpp_shell_matches_golden_fixture_on_gpu():
     double-precision solve; per-element characters / parents reproduce it bit for bit."""
     _compile_parity()
     out = subprocess.run([PARITY_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK"), out.stdout
+
+
+def test_cpp_multi_gpu_program_compiles_and_links():
+    _compile_multi()
+    assert os.path.exists(MULTI_EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_multi_gpu_solver_on_every_visible_gpu():
+    """BatchedMultiGpuSolver: one host thread + one RCCL rank per visible device (one on the test box, eight
+    on a full node), ragged shards, per-element parity with the golden fixture, all-reduced residual norms."""
+    _compile_multi()
+    out = subprocess.run([MULTI_EXE], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("OK"), out.stdout

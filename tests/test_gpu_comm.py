@@ -1,0 +1,68 @@
+"""The path's one multi-GPU exchange, RCCL called from the C ABI (mmx_comm_*): a communicator of one rank on
+the test box (the arithmetic of an all-reduce over one rank is the identity, but RCCL initialises, enqueues on
+the stream and completes), the residual-norm kernel against numpy, and -- when the box has two or more GPUs --
+bench.py with two ranks over RCCL exactly as the driver launches it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_residual_norms_and_single_rank_all_reduce(torch_cuda):
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    B = 4099
+    err = rng.uniform(0, 1, size=B)
+    it = rng.integers(1, 11, size=B).astype(np.int32)
+    st = (rng.uniform(size=B) < 0.01).astype(np.int32) * 2
+    out = dict(error=torch.from_numpy(err).to(dev), iterations=torch.from_numpy(it).to(dev), status=torch.from_numpy(st).to(dev))
+    norms = torch.zeros(3, dtype=torch.float64, device=dev)
+    capi.residual_norms(out, norms)
+    torch.cuda.synchronize()
+    got = norms.cpu().numpy()
+    assert abs(got[0] - err.sum()) <= 1e-12 * err.sum() and got[1] == it.sum() and got[2] == (st != 0).sum()
+    comm = capi.Comm(capi.Comm.unique_id(), 1, 0, 0)
+    assert comm.world_size == 1 and comm.rank == 0
+    comm.all_reduce_norms(norms)
+    torch.cuda.synchronize()
+    assert np.array_equal(norms.cpu().numpy(), got)
+    # deterministic: the same reduction twice gives the same bits
+    n2 = torch.zeros(3, dtype=torch.float64, device=dev)
+    capi.residual_norms(out, n2)
+    torch.cuda.synchronize()
+    assert np.array_equal(n2.cpu().numpy(), got)
+    comm.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(torch_cuda):
+    torch = torch_cuda
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the two-rank RCCL run needs two (the gloo plumbing test covers the sharding)")
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "1024", "--no-cpu-baseline", "--check-instances", "64"]  # fmt: skip
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "ranks seen by RCCL: 2" in d["config"]["exchange"]
+    assert d["check"]["sum_iterations"] == 2 * 1024 * 10 and d["check"]["failed_instances"] == 0
