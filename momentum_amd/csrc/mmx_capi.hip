@@ -181,7 +181,8 @@ struct mmx_problem {
   bool instPos = false, instOri = false;
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
-  DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
+  DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols, dColDesc;
+  DevBuf sJaJs, sJaUnits, sJaCols; // hand-over scratch of the two-kernel J assembly
   DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb, dDfsJoint, dLoadedPos;
   DevBuf dLimStart, dLimOf, dPairDest, dPairStart, dPairLim, dPairCols;
   mmx::FusedDev fdev{};
@@ -373,6 +374,21 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         } else {
           multi.push_back(p);
         }
+      }
+      // per-column descriptors of the two-kernel form (jacobianColumnsKernel)
+      {
+        std::vector<int32_t> desc(size_t(rig->P) * 4, 0);
+        for (const mmx::JacRec& rc1 : recs) {
+          int32_t wbits;
+          std::memcpy(&wbits, &rc1.weight, 4);
+          int32_t* o = desc.data() + size_t(rc1.col) * 4;
+          o[0] = 1, o[1] = rc1.joint | (rc1.dof << 16), o[2] = rc1.tin | (rc1.tout << 16), o[3] = wbits;
+        }
+        for (int32_t p : multi) {
+          desc[size_t(p) * 4] = 2;
+        }
+        MMX_HIP(upload(pb->dColDesc, desc));
+        d.colDesc = pb->rig->J < 65536 ? pb->dColDesc.as<int4>() : nullptr;
       }
       std::stable_sort(recs.begin(), recs.end(), [](const mmx::JacRec& a, const mmx::JacRec& b) {
         return a.joint != b.joint ? a.joint < b.joint : a.dof < b.dof;
@@ -736,6 +752,18 @@ bool fusedUsable(const mmx_problem* pb) {
 bool wantLegacySolver() {
   const char* e = getenv("MMX_SOLVER");
   return e != nullptr && std::string(e) == "v1";
+}
+
+// hand-over scratch of the two-kernel J assembly (4 (kJs J + 5 U + 8 P) bytes per instance)
+int32_t ensureJacobianScratch(mmx_problem* pb) {
+  const size_t B = size_t(pb->B);
+  MMX_HIP(pb->sJaJs.ensure(B * size_t(pb->rig->J) * mmx::kJs * sizeof(float)));
+  MMX_HIP(pb->sJaUnits.ensure(B * 5 * size_t(std::max(pb->U, 1)) * sizeof(float)));
+  pb->dev.jaJs = pb->sJaJs.as<float>();
+  MMX_HIP(pb->sJaCols.ensure(B * size_t(pb->rig->P) * 8 * sizeof(float)));
+  pb->dev.jaUnits = pb->sJaUnits.as<float>();
+  pb->dev.jaCols = pb->sJaCols.as<float>();
+  return MMX_OK;
 }
 
 int32_t checkProblem(const mmx_problem* pb, bool needConstraints) {
@@ -1460,6 +1488,12 @@ int32_t mmx_eval_jacobian(
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (jac_dev != nullptr) {
+    rc = ensureJacobianScratch(pb);
+    if (rc != MMX_OK) {
+      return rc;
+    }
+  }
   if (layout == MMX_LAYOUT_ROW_MAJOR && jac_dev != nullptr) {
     // assembled column-major (the layout the kernel's coalesced column stores are built for) into the
     // problem's scratch, then transposed per instance: one extra read + write of J
@@ -1492,6 +1526,10 @@ int32_t mmx_eval_jacobian_timed(
     return fail(MMX_ERR_UNSUPPORTED, "only MMX_LAYOUT_COL_MAJOR (the reference's layout) is implemented");
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
+  rc = ensureJacobianScratch(pb);
+  if (rc != MMX_OK) {
+    return rc;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   MMX_HIP(hipEventCreate(&e0));
   hipError_t err = hipEventCreate(&e1);
@@ -1562,6 +1600,10 @@ int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* 
 
 namespace {
 int32_t ensureStepScratch(mmx_problem* pb) {
+  const int32_t rcj = ensureJacobianScratch(pb);
+  if (rcj != MMX_OK) {
+    return rcj;
+  }
   const size_t B = size_t(pb->B), M = size_t(pb->M), P = size_t(pb->rig->P), n = size_t(pb->dev.n);
   MMX_HIP(pb->sJac.ensure(B * M * P * sizeof(float)));
   MMX_HIP(pb->sRes.ensure(B * std::max<size_t>(M, 1) * sizeof(float)));

@@ -242,6 +242,12 @@ struct ProblemDev {
   const int32_t* instPosParent;
   const int32_t* instOriParent;
   const int32_t* jointTin; // [J]
+  // ---- two-kernel J assembly: per-column descriptors and the hand-over scratch of the problem
+  // colDesc[p] = {kind (0 zero, 1 one rotation source, 2 generic gather), joint | dof << 16, tin | tout << 16, weight bits}
+  const int4* colDesc; // [P]
+  float* jaJs; // [B][J][kJs] joint states written by fkJacobianKernel<false>, read by jacobianColumnsKernel (or null)
+  float* jaUnits; // [B][5][U] evaluated units (v, sigma, DFS index) (or null)
+  float* jaCols; // [B][P][8] one record per column: joint translation, rotation axis, weight, DFS interval (or null)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -226,7 +226,10 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     double* __restrict__ err, // [B] or null
     float* __restrict__ state, // [B][J][8] or null
     const int32_t* __restrict__ done, // [B] or null: skip finished instances
-    int zeroPhase) { // when the structurally zero columns are written: 0 first, 1 alternating, 2 last
+    int zeroPhase, // when the structurally zero columns are written: 0 first, 1 alternating, 2 last
+    float* __restrict__ jsOut, // [B][J][kJs] or null: the joint states (world transforms + rotation axes) ...
+    float* __restrict__ unitOut, // [B][5][U] or null: ... the evaluated units (v, sigma, DFS index) ...
+    float* __restrict__ colOut) { // [B][P][8] or null: ... and one record per column (see jacobianColumnsKernel)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // one 20-float slot per joint, used in place: [0..7] local t,s,q -> world t,q,s ; [8..15] partial
   // rotations q1,q2 -> [8..16] rotation axes
@@ -284,7 +287,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
       preB[d] = rig.preRot[4 * (tid + NT) + d];
     }
   }
-  const bool needUnits = kWriteJac || res != nullptr || err != nullptr;
+  const bool needUnits = kWriteJac || res != nullptr || err != nullptr || unitOut != nullptr;
   UnitInput uin0 = loadUnitInput(pb, b, needUnits ? lane : pb.U);
   for (int i = tid; i < rig.P; i += NT) {
     thL[i] = th[i];
@@ -381,7 +384,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     }
   }
   __syncthreads();
-  if (kWriteJac) {
+  if (kWriteJac || jsOut != nullptr || colOut != nullptr) {
     if (tid < rig.J) {
       fkAxesInPlaceQ(preA, tid, (jl[tid] >> 16) - 1, js);
     }
@@ -399,9 +402,43 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
       so[i] = js[kJs * (i >> 3) + (i & 7)];
     }
   }
-  if (!kWriteJac && res == nullptr && err == nullptr) {
+  if (jsOut != nullptr) { // hand-over to the column kernel: 4 * kJs * J bytes per instance (6 % of J at cfg2)
+    float* jo = jsOut + size_t(b) * size_t(rig.J) * kJs;
+    for (int i = tid; i < rig.J * kJs; i += NT) {
+      jo[i] = js[i];
+    }
+  }
+  if (colOut != nullptr) {
+    // one 32-byte record per column, so that the column kernel needs ONE round of loads whose addresses do
+    // not depend on any table: joint translation (3), rotation axis (3), weight, tin | tout << 16.
+    // Structurally zero columns: weight 0 and an empty interval; generic columns: interval 0xffff / 0xffff.
+    float* co = colOut + size_t(b) * size_t(rig.P) * 8;
+    for (int p = tid; p < rig.P; p += NT) {
+      const int4 d = pb.colDesc[p];
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (d.x == 1) {
+        const float* a = js + kJs * (d.y & 0xffff);
+        const float* axp = a + 8 + 3 * ((d.y >> 16) - 3);
+        o[0] = a[0], o[1] = a[1], o[2] = a[2], o[3] = axp[0], o[4] = axp[1], o[5] = axp[2];
+        o[6] = __int_as_float(d.w);
+        o[7] = __int_as_float(d.z);
+      } else if (d.x == 2) {
+        o[7] = __int_as_float(-1);
+      }
+      float4* dst = reinterpret_cast<float4*>(co + 8 * size_t(p));
+      dst[0] = float4{o[0], o[1], o[2], o[3]};
+      dst[1] = float4{o[4], o[5], o[6], o[7]};
+    }
+  }
+  if (!kWriteJac && res == nullptr && err == nullptr && unitOut == nullptr) {
     return;
   }
+  auto dumpUnit = [&](const Unit& un, int u) {
+    if (unitOut != nullptr && un.valid) {
+      float* uo = unitOut + size_t(b) * 5 * size_t(pb.U) + u;
+      uo[0] = un.v.x, uo[pb.U] = un.v.y, uo[2 * size_t(pb.U)] = un.v.z, uo[3 * size_t(pb.U)] = un.sigma, uo[4 * size_t(pb.U)] = __int_as_float(un.tin);
+    }
+  };
 
   double errAcc = 0.0;
   const size_t M = size_t(pb.M);
@@ -466,6 +503,9 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     if (res != nullptr && un.valid && wave == 0) {
       store3<false>(res + size_t(b) * M + 3 * size_t(lane), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
     }
+    if (wave == 0) {
+      dumpUnit(un, lane);
+    }
     if (kWriteJac) {
       writeUnitColumns<WPI, kStream>(pb, js, un, jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(lane), M, wave);
     }
@@ -477,6 +517,9 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     if (res != nullptr && un.valid && wave == 0) {
       store3<false>(res + size_t(b) * M + 3 * size_t(u), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
     }
+    if (wave == 0) {
+      dumpUnit(un, u);
+    }
   }
   }
   if (kWriteJac && zeroLast && !manyUnits) {
@@ -487,6 +530,96 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     if (tid == 0) {
       err[b] = e;
     }
+  }
+}
+
+// =============================================================================================
+// Kernel 1': the columns of J from the handed-over joint states and units (two-kernel J assembly).
+// fkJacobianKernel<false> runs FK once per instance and leaves 4 (kJs J + 5 U) bytes per instance behind (the
+// joint states and the evaluated units: ~6 % of J's bytes at cfg2, L2 / Infinity-Cache resident); this kernel
+// writes the columns: one 256-thread workgroup = four ADJACENT columns of one instance (one column per wave,
+// lane u = rows 3u..3u+2, one 12-byte streaming store per lane and 64-unit chunk) and ends.  Write bandwidth
+// on this part falls with the footprint a workgroup writes before it ends (scripts/store_k.hip: 3 KB per
+// workgroup reach 5.8-6.1 TB/s with the dependent loads in place, the 96 KB of a whole column-major J per
+// workgroup 5.1-5.3), which is what the one-kernel form could not get around.  Workgroups go
+// round-robin to the 8 XCDs, so the index is decoded such that all workgroups of an instance land on one
+// XCD and its hand-over record is fetched into one L2 only.
+// Values: exactly writeUnitColumns' arithmetic (same operands, same order).
+// =============================================================================================
+// everything the kernel reads, in ONE small by-value struct: the workgroup lives for ~1 us, so its first
+// instruction fetches all arguments at once instead of walking the big ProblemDev field by field (five
+// dependent scalar-cache round trips in the first version: 145 us instead of 70 at B = 4096)
+struct ColumnArgs {
+  const float* unitIn; // [B][5][U]
+  const float* colIn; // [B][P][8]
+  const float* jsIn; // [B][J][kJs] (generic columns only)
+  float* jac; // [B][P][M]
+  const int32_t* done; // [B] or null
+  const int32_t* colStart; // generic columns: CSC of the enabled transform
+  const ColumnSourceDev* colSources;
+  int32_t B, U, M, Kp, P, J, numGroups;
+};
+template <bool kNt>
+__global__ void __launch_bounds__(256) jacobianColumnsKernel(ColumnArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+  const int cg = r % a.numGroups, b = (r / a.numGroups) * 8 + x;
+  const int p = 4 * cg + wave;
+  const bool active = b < a.B && p < a.P; // wave-uniform
+  const int bb = active ? b : 0, pp = active ? p : 0;
+  const int U = a.U;
+  // ONE round of independent loads, issued before any branch: the column's record (wave-uniform), the lane's
+  // first unit, the instance's done flag
+  const float4* rec = reinterpret_cast<const float4*>(a.colIn + (size_t(bb) * size_t(a.P) + size_t(pp)) * 8);
+  const float4 r0 = rec[0], r1 = rec[1];
+  const float* ub = a.unitIn + size_t(bb) * 5 * size_t(U);
+  const int u0 = lane < U ? lane : 0;
+  float vx = ub[u0], vy = ub[U + u0], vz = ub[2 * size_t(U) + u0], sigma = ub[3 * size_t(U) + u0];
+  int utin = __float_as_int(ub[4 * size_t(U) + u0]);
+  const int doneFlag = a.done != nullptr ? a.done[bb] : 0;
+  if (!active || doneFlag != 0) {
+    return;
+  }
+  const size_t M = size_t(a.M);
+  float* col = a.jac + (size_t(b) * size_t(a.P) + size_t(p)) * M;
+  const int span = __float_as_int(r1.w);
+  if (span != -1) { // one rotation source (or a structurally zero column: weight 0, empty interval)
+    const F3 t{r0.x, r0.y, r0.z}, ax{r0.w, r1.x, r1.y};
+    const float weight = r1.z;
+    const int tin = span & 0xffff, tout = int(unsigned(span) >> 16);
+    for (int u = lane; u < U; u += 64) {
+      if (u != lane) {
+        vx = ub[u], vy = ub[U + u], vz = ub[2 * size_t(U) + u], sigma = ub[3 * size_t(U) + u];
+        utin = __float_as_int(ub[4 * size_t(U) + u]);
+      }
+      const F3 v{vx, vy, vz};
+      const F3 off = u < a.Kp ? v - t : v;
+      const F3 g = cross(ax, off);
+      const float w = (tin <= utin && utin < tout) ? weight : 0.f;
+      store3<kNt>(col + 3 * size_t(u), (sigma * g.x) * w, (sigma * g.y) * w, (sigma * g.z) * w);
+    }
+    return;
+  }
+  // every other non-empty column (shared parameters, translation / scale dofs): generic gather from the joint states
+  const float* js = a.jsIn + size_t(b) * size_t(a.J) * kJs;
+  const int e0 = a.colStart[p], e1 = a.colStart[p + 1];
+  for (int u = lane; u < U; u += 64) {
+    Unit un;
+    un.v = F3{ub[u], ub[U + u], ub[2 * size_t(U) + u]};
+    un.sigma = ub[3 * size_t(U) + u];
+    un.tin = __float_as_int(ub[4 * size_t(U) + u]);
+    un.isPoint = u < a.Kp;
+    F3 acc{0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; ++e) {
+      const ColumnSourceDev s = a.colSources[e]; // wave-uniform
+      bool applies;
+      const F3 g = sourceDerivative(s, js, un, applies);
+      const float w = applies ? s.weight : 0.f;
+      acc.x += (un.sigma * g.x) * w;
+      acc.y += (un.sigma * g.y) * w;
+      acc.z += (un.sigma * g.z) * w;
+    }
+    store3<kNt>(col + 3 * size_t(u), acc.x, acc.y, acc.z);
   }
 }
 
@@ -2323,7 +2456,42 @@ hipError_t launchFkJacobian(
   }
 #define MMX_FKJ(W_, WPI_, S_)                                                                                                  \
   hipExtLaunchKernelGGL(                                                                                                       \
-      (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done, zeroPhase)
+      (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done, zeroPhase, \
+      static_cast<float*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr))
+  // Two-kernel J assembly (MMX_JAC_TWO_KERNEL=1; an experiment that did NOT pay, kept for the record and
+  // covered by a parity test): FK + units once per instance, handed over through pb.jaJs / jaUnits / jaCols,
+  // then four adjacent columns per workgroup (jacobianColumnsKernel).  The store pattern alone reaches
+  // 6.1 TB/s with synthetic, L2-warm inputs (scripts/store_k.hip, 66 us at B = 4096), but the real second
+  // kernel needs 95 us on warm and 150 us on freshly written hand-over data (the L2s are written back and
+  // invalidated between the two kernels, so every workgroup's first loads miss; its ~1.5 us lifetime then
+  // caps the stores in flight) against 86 us for the one-kernel form.  The events bracket BOTH dispatches.
+  const bool oneKernel = getenv("MMX_JAC_TWO_KERNEL") == nullptr;
+  if (jac != nullptr && pb.jaJs != nullptr && pb.jaUnits != nullptr && pb.jaCols != nullptr && pb.colDesc != nullptr && !oneKernel) {
+    static const char* wpiEnv = getenv("MMX_JAC_K1_WPI");
+    const int wpiK1 = wpiEnv != nullptr ? (wpiEnv[0] == '1' ? 1 : 4) : ((pb.B < 2048 || lds > 12 * 1024) ? 4 : 1);
+    static const bool skipK1 = getenv("MMX_JAC_SKIP_K1") != nullptr; // experiment: time the column kernel on the previous launch's hand-over data
+    if (skipK1) {
+    } else if (wpiK1 == 4) {
+      hipExtLaunchKernelGGL(
+          (fkJacobianKernel<false, 4, false>), dim3(pb.B), dim3(256), lds, stream, startEvent, nullptr, 0, rig, pb, theta, static_cast<float*>(nullptr), res,
+          err, state, done, 0, pb.numMultiCols > 0 ? pb.jaJs : nullptr, pb.jaUnits, pb.jaCols);
+    } else {
+      hipExtLaunchKernelGGL(
+          (fkJacobianKernel<false, 1, false>), dim3(pb.B), dim3(64), lds, stream, startEvent, nullptr, 0, rig, pb, theta, static_cast<float*>(nullptr), res,
+          err, state, done, 0, pb.numMultiCols > 0 ? pb.jaJs : nullptr, pb.jaUnits, pb.jaCols);
+    }
+    const int groups = (rig.P + 3) / 4;
+    const unsigned blocks = unsigned(((pb.B + 7) / 8) * 8) * unsigned(groups);
+    ColumnArgs ca{};
+    ca.unitIn = pb.jaUnits, ca.colIn = pb.jaCols, ca.jsIn = pb.jaJs, ca.jac = jac, ca.done = done;
+    ca.colStart = pb.colStart, ca.colSources = pb.colSources;
+    ca.B = pb.B, ca.U = pb.U, ca.M = pb.M, ca.Kp = pb.Kp, ca.P = rig.P, ca.J = rig.J, ca.numGroups = groups;
+    if (streaming) {
+      hipExtLaunchKernelGGL((jacobianColumnsKernel<true>), dim3(blocks), dim3(256), 0, stream, skipK1 ? startEvent : nullptr, stopEvent, 0, ca);
+    } else {
+      hipExtLaunchKernelGGL((jacobianColumnsKernel<false>), dim3(blocks), dim3(256), 0, stream, nullptr, stopEvent, 0, ca);
+    }
+  } else
   if (jac != nullptr) {
     if (!streaming) {
       if (wpi == 4) {

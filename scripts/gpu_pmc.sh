@@ -18,7 +18,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
-    if "fusedSolve" in k or "fkJacobian" in k:
+    if "fusedSolve" in k or "fkJacobian" in k or "jacobianColumns" in k:
         print(k)
         for c,vals in sorted(v.items()): print("   %-28s n=%d avg=%.4g" % (c,len(vals),sum(vals)/len(vals)))
 PY

@@ -51,6 +51,87 @@ __global__ void __launch_bounds__(256) kcol3w(float* o) {
     }
   }
 }
+// the two-kernel J-assembly's second kernel in miniature: a 256-thread block = 4 adjacent columns of one
+// instance; every lane first loads its unit (5 floats from a 1.3 KB per-instance record that a first kernel
+// would have written), every wave its column's joint state (8 floats, uniform address), then one 12-byte
+// store per lane.  What bandwidth survives the dependent loads?
+template <bool NT>
+__global__ void __launch_bounds__(256) kcol3w_dep(float* o, const float* __restrict__ ub, const float* __restrict__ sb) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x >> 5, col = 4 * (blockIdx.x & 31) + wave;
+  const float* u = ub + (size_t(b) * 64 + lane) * 5;
+  const float vx = u[0], vy = u[1], vz = u[2], sg = u[3];
+  const int tin = __float_as_int(u[4]);
+  const float* st = sb + (size_t(b) * 72 + (col * 37) % 72) * 8; // wave-uniform
+  const float tx = st[0], ty = st[1], tz = st[2], ax = st[3], ay = st[4], az = st[5];
+  const float w = (tin & 1) ? 1.f : 0.f;
+  const float ox = vx - tx, oy = vy - ty, oz = vz - tz;
+  float* p = o + (size_t(b) * 128 + col) * 192 + 3 * lane;
+  const float gx = sg * (ay * oz - az * oy) * w, gy = sg * (az * ox - ax * oz) * w, gz = sg * (ax * oy - ay * ox) * w;
+  if (NT) {
+    __builtin_nontemporal_store(gx, p);
+    __builtin_nontemporal_store(gy, p + 1);
+    __builtin_nontemporal_store(gz, p + 2);
+  } else {
+    p[0] = gx, p[1] = gy, p[2] = gz;
+  }
+}
+// the same with 8 columns per block (2 per wave): half the blocks, the loads amortised over two stores
+template <bool NT>
+__global__ void __launch_bounds__(256) kcol3w_dep2(float* o, const float* __restrict__ ub, const float* __restrict__ sb) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x >> 4, col0 = 8 * (blockIdx.x & 15) + 2 * wave;
+  const float* u = ub + (size_t(b) * 64 + lane) * 5;
+  const float vx = u[0], vy = u[1], vz = u[2], sg = u[3];
+  const int tin = __float_as_int(u[4]);
+  const float w = (tin & 1) ? 1.f : 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int col = col0 + k;
+    const float* st = sb + (size_t(b) * 72 + (col * 37) % 72) * 8;
+    const float tx = st[0], ty = st[1], tz = st[2], ax = st[3], ay = st[4], az = st[5];
+    const float ox = vx - tx, oy = vy - ty, oz = vz - tz;
+    float* p = o + (size_t(b) * 128 + col) * 192 + 3 * lane;
+    const float gx = sg * (ay * oz - az * oy) * w, gy = sg * (az * ox - ax * oz) * w, gz = sg * (ax * oy - ay * ox) * w;
+    if (NT) {
+      __builtin_nontemporal_store(gx, p);
+      __builtin_nontemporal_store(gy, p + 1);
+      __builtin_nontemporal_store(gz, p + 2);
+    } else {
+      p[0] = gx, p[1] = gy, p[2] = gz;
+    }
+  }
+}
+// general shape: WPB waves per block, CPW columns per wave (block = WPB * CPW adjacent columns of one instance)
+template <int WPB, int CPW, bool XCD>
+__global__ void __launch_bounds__(64 * WPB) kcol3w_shape(float* o, const float* __restrict__ ub, const float* __restrict__ sb) {
+  constexpr int CPB = WPB * CPW, G = 128 / CPB;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int b, cg;
+  if (XCD) { // all blocks of an instance on one XCD (blocks go round-robin to the 8 XCDs)
+    const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+    cg = r % G;
+    b = (r / G) * 8 + x;
+  } else {
+    b = blockIdx.x / G, cg = blockIdx.x % G;
+  }
+  const int col0 = CPB * cg + CPW * wave;
+  const float* u = ub + (size_t(b) * 64 + lane) * 5;
+  const float vx = u[0], vy = u[1], vz = u[2], sg = u[3];
+  const int tin = __float_as_int(u[4]);
+  const float w = (tin & 1) ? 1.f : 0.f;
+#pragma unroll
+  for (int k = 0; k < CPW; ++k) {
+    const int col = col0 + k;
+    const float* st = sb + (size_t(b) * 72 + (col * 37) % 72) * 8;
+    const float tx = st[0], ty = st[1], tz = st[2], ax = st[3], ay = st[4], az = st[5];
+    const float ox = vx - tx, oy = vy - ty, oz = vz - tz;
+    float* p = o + (size_t(b) * 128 + col) * 192 + 3 * lane;
+    __builtin_nontemporal_store(sg * (ay * oz - az * oy) * w, p);
+    __builtin_nontemporal_store(sg * (az * ox - ax * oz) * w, p + 1);
+    __builtin_nontemporal_store(sg * (ax * oy - ay * ox) * w, p + 2);
+  }
+}
 int main() {
   const size_t n = size_t(4096) * 192 * 128; // floats = 402 MB
   float* buf;
@@ -80,5 +161,17 @@ int main() {
   RUNC(1, true); RUNC(4, true); RUNC(16, true); RUNC(128, true);
 #define RUNW(K_, NT_) run("kcol3w (256 thr) K=" #K_ " nt=" #NT_, [&] { kcol3w<K_, NT_><<<unsigned(n / 192 / K_ / 4), 256>>>(buf); })
   RUNW(1, false); RUNW(2, false); RUNW(4, false); RUNW(1, true); RUNW(2, true); RUNW(4, true);
+  float *ub, *sb;
+  hipMalloc(&ub, size_t(4096) * 64 * 5 * 4);
+  hipMalloc(&sb, size_t(4096) * 72 * 8 * 4);
+  hipMemset(ub, 0x3f, size_t(4096) * 64 * 5 * 4); // 0x3f3f3f3f = 0.747f, odd as an int: non-zero data, w = 1
+  hipMemset(sb, 0x3e, size_t(4096) * 72 * 8 * 4);
+  run("kcol3w_dep (4 cols/block)", [&] { kcol3w_dep<false><<<4096 * 32, 256>>>(buf, ub, sb); });
+  run("kcol3w_dep nt (4 cols/block)", [&] { kcol3w_dep<true><<<4096 * 32, 256>>>(buf, ub, sb); });
+  run("kcol3w_dep2 (8 cols/block)", [&] { kcol3w_dep2<false><<<4096 * 16, 256>>>(buf, ub, sb); });
+  run("kcol3w_dep2 nt (8 cols/block)", [&] { kcol3w_dep2<true><<<4096 * 16, 256>>>(buf, ub, sb); });
+#define RUNS(WPB_, CPW_, X_) run("shape wpb=" #WPB_ " cpw=" #CPW_ " xcd=" #X_, [&] { kcol3w_shape<WPB_, CPW_, X_><<<4096 * (128 / (WPB_ * CPW_)), 64 * WPB_>>>(buf, ub, sb); })
+  RUNS(4, 1, false); RUNS(4, 1, true); RUNS(4, 2, false); RUNS(4, 2, true); RUNS(4, 4, false); RUNS(4, 4, true); RUNS(4, 8, true);
+  RUNS(2, 2, true); RUNS(2, 4, true); RUNS(2, 8, true); RUNS(1, 4, true); RUNS(1, 8, true); RUNS(1, 16, true); RUNS(8, 1, true); RUNS(8, 2, true);
   return 0;
 }

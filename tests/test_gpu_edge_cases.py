@@ -258,3 +258,38 @@ def test_row_major_jacobian_is_the_transpose(torch_cuda):
     jh = np.zeros((B, pb.M, pb.P), np.float32)
     capi._check(capi.lib().mmx_eval_jacobian_host(pb._h, th0.ctypes.data_as(C.c_void_p), jh.ctypes.data_as(C.c_void_p), None, None, 1))
     assert np.array_equal(jh, jr.cpu().numpy())
+
+
+def test_two_kernel_jacobian_assembly_experiment_matches_the_default(torch_cuda, monkeypatch):
+    """MMX_JAC_TWO_KERNEL=1 (FK once per instance + a column kernel of four adjacent columns per workgroup, an
+    experiment DESIGN.md 4.1 reports as slower) must still write the same Jacobian: single-source, generic and
+    structurally zero columns, more units than lanes, a disabled parameter."""
+    from momentum_amd import capi, humanoid72_landmark_joints, make_humanoid72
+
+    torch = torch_cuda
+    for case in ("humanoid", "many_units"):
+        if case == "humanoid":
+            rig = make_humanoid72(unit=0.01)
+            lm = humanoid72_landmark_joints(rig)
+            pp, op, B = lm, lm, 9
+        else:
+            rig = make_test_character(12)
+            pp, op, B = list(range(12)) * 5, list(range(12)) * 3, 3  # 60 + 108 units
+        cons, th0, _ = make_problem(rig, pp, op, B, seed=17, theta0_scale=0.3, random_offsets=True, weights="random")
+        rh = capi.RigHandle(rig, 0)
+        pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+        _upload(torch, pb, cons, B)
+        en = np.ones(rig.num_params, np.uint8)
+        en[3] = 0
+        pb.set_enabled(en)
+        theta = torch.from_numpy(th0.copy()).to(pb.device)
+        monkeypatch.delenv("MMX_JAC_TWO_KERNEL", raising=False)
+        j1, r1, e1 = pb.eval_jacobian(theta)
+        monkeypatch.setenv("MMX_JAC_TWO_KERNEL", "1")
+        j2, r2, e2 = pb.eval_jacobian(theta)
+        monkeypatch.delenv("MMX_JAC_TWO_KERNEL", raising=False)
+        # (the two forms are different instantiations: fma contraction may differ in the last bit)
+        assert float((r1 - r2).abs().max()) <= 2e-6 * max(1.0, float(r1.abs().max())) and float((e1 - e2).abs().max()) <= 1e-6 * max(1.0, float(e1.abs().max()))
+        scale = float(j1.abs().max())
+        assert float((j1 - j2).abs().max()) <= 2e-6 * scale  # (fma contraction may differ between the two kernels)
+        assert torch.equal(j1 == 0, j2 == 0)  # the same structural zeros
