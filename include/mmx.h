@@ -465,6 +465,26 @@ int32_t mmx_solve(
     void* stream);
 
 /*
+ * mmx_solve with SolverT::setStoreHistory(true) (momentum/solver/solver.cpp:53-72,101-110): additionally
+ *   parameter_history  float [B][max_iterations][P]  iterationHistory_["parameters"]: the parameters after
+ *                      iteration i; rows from an element's iteration count on stay zero (setZero(), :70)
+ * (error_history is iterationHistory_["error"], `iterations` iterationHistory_["iterations"]).  The "jtj"
+ * history of GaussNewtonSolverT (gauss_newton_solver.cpp:265-278) is not stored -- n^2 floats per element and
+ * iteration --; it is J^T J at the parameters BEFORE iteration i, which mmx_eval_normal_equations returns for
+ * row i-1 of parameter_history (theta_init for i = 0).
+ */
+int32_t mmx_solve_with_history(
+    mmx_problem* problem,
+    const mmx_gn_options* options,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    void* stream);
+
+/*
  * Parity hook of the fused solve kernel: its normal equations at theta (first iteration), over
  * the kernel's SOLVE list = enabled parameters whose Jacobian column is not structurally zero
  * (the others get an exact zero step, like in the reference where H row/col and g vanish).

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
-    "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_host",
+    "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
     "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
@@ -78,6 +78,7 @@ def lib() -> C.CDLL:
     L.mmx_eval_skeleton_state.argtypes = [vp, vp, vp, vp]
     L.mmx_eval_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mmx_solve.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
+    L.mmx_solve_with_history.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp, vp]
     L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_eval_jacobian_host.argtypes = [vp, vp, vp, vp, vp, i32]
     L.mmx_debug_fused_normal_equations.argtypes = [vp, vp, vp, vp, _abi.c_int32_p, _abi.c_int32_p, vp]
@@ -366,8 +367,9 @@ class Problem:
         _check(lib().mmx_debug_fused_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), as_ptr(lst, C.c_int32), C.byref(C.c_int32(0)), _stream_ptr()))
         return lst[:n].copy(), jtj, jtr
 
-    def solve(self, theta, options: GnOptions, want_history: bool = False, outputs=None):
-        """In-place batched SolverT::solve.  Returns dict(theta, error, iterations, status[, error_history])."""
+    def solve(self, theta, options: GnOptions, want_history: bool = False, outputs=None, want_parameter_history: bool = False):
+        """In-place batched SolverT::solve.  Returns dict(theta, error, iterations, status[, error_history]
+        [, parameter_history [B, max_iterations, P]])."""
         import torch
 
         theta = self._theta(theta)
@@ -379,6 +381,17 @@ class Problem:
             )
             if want_history:
                 outputs["error_history"] = torch.empty((self.B, max(1, options.max_iterations)), dtype=torch.float64, device=self.device)
+        if want_parameter_history and "parameter_history" not in outputs:
+            outputs["parameter_history"] = torch.empty((self.B, max(1, options.max_iterations), self.P), dtype=torch.float32, device=self.device)
+        if outputs.get("parameter_history") is not None:
+            _check(
+                lib().mmx_solve_with_history(
+                    self._h, C.byref(options), _dev(theta), _dev(outputs["error"]), _dev(outputs["iterations"]),
+                    _dev(outputs["status"]), _dev(outputs.get("error_history")), _dev(outputs["parameter_history"]), _stream_ptr(),
+                )
+            )  # fmt: skip
+            outputs["theta"] = theta
+            return outputs
         _check(
             lib().mmx_solve(
                 self._h, C.byref(options), _dev(theta), _dev(outputs["error"]), _dev(outputs["iterations"]),

@@ -1645,6 +1645,17 @@ int32_t mmx_eval_normal_equations(
   return MMX_OK;
 }
 
+static int32_t solveImpl(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    void* stream);
+
 int32_t mmx_solve(
     mmx_problem* pb,
     const mmx_gn_options* o,
@@ -1653,6 +1664,32 @@ int32_t mmx_solve(
     int32_t* iterations,
     int32_t* status,
     double* error_history,
+    void* stream) {
+  return solveImpl(pb, o, theta_dev, final_error, iterations, status, error_history, nullptr, stream);
+}
+
+int32_t mmx_solve_with_history(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    void* stream) {
+  return solveImpl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, stream);
+}
+
+static int32_t solveImpl(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
     void* stream) {
   MMX_ZONE("mmx_solve (SolverT::solve)");
   int32_t rc = checkProblem(pb, true);
@@ -1691,8 +1728,12 @@ int32_t mmx_solve(
     fst.lastError = nullptr;
     fst.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
     fst.errorHistory = error_history;
+    fst.paramHistory = parameter_history;
     if (error_history != nullptr && o->max_iterations > 0) {
       MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+    }
+    if (parameter_history != nullptr && o->max_iterations > 0) {
+      MMX_HIP(hipMemsetAsync(parameter_history, 0, B * size_t(o->max_iterations) * P * sizeof(float), s));
     }
     mmx::FusedParams fp{};
     fp.lambda = o->regularization;
@@ -1760,6 +1801,7 @@ int32_t mmx_solve(
   st.lastError = pb->sLastErr.as<double>();
   st.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
   st.errorHistory = error_history;
+  st.paramHistory = nullptr; // (explicit-Jacobian path: the history is copied after every iteration, below)
   if (error_history != nullptr && o->max_iterations > 0) {
     MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
   }
@@ -1816,6 +1858,14 @@ int32_t mmx_solve(
       MMX_ZONE("Line search");
       MMX_HIP(mmx::launchStepUpdate(pb->rigDev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
     }
+    if (parameter_history != nullptr) { // parameters after iteration `it`, every element (rows past an element's last iteration are zeroed at the end)
+      MMX_HIP(hipMemcpy2DAsync(
+          parameter_history + size_t(it) * P, size_t(o->max_iterations) * P * sizeof(float), theta_dev, P * sizeof(float), P * sizeof(float), B,
+          hipMemcpyDeviceToDevice, s));
+    }
+  }
+  if (parameter_history != nullptr) {
+    MMX_HIP(mmx::launchParamHistoryFinalize(parameter_history, st.iterations, pb->B, o->max_iterations, pb->rig->P, s));
   }
   MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
   if (sp.clk != nullptr) {

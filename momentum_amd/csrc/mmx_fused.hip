@@ -1591,6 +1591,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     break;
     }
     } // trust steps
+    if (st.paramHistory != nullptr) { // iterationHistory_["parameters"].col(iteration_) = parameters_ (solver.cpp:101-106)
+      float* ph = st.paramHistory + (size_t(b) * fp.maxIterations + it) * size_t(P);
+      for (int i = tid; i < P; i += 256) {
+        ph[i] = s.th[i];
+      }
+    }
     if (tid == 0) {
       const double e = curError;
       if (st.errorHistory != nullptr) {

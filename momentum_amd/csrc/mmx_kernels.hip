@@ -2671,6 +2671,22 @@ hipError_t launchStepUpdate(
   return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) paramHistoryFinalizeKernel(float* __restrict__ hist, const int32_t* __restrict__ iterations, int maxIterations, int P) {
+  const int b = blockIdx.x;
+  const size_t rows = size_t(maxIterations) * size_t(P);
+  for (size_t i = size_t(iterations[b]) * size_t(P) + threadIdx.x; i < rows; i += 256) {
+    hist[size_t(b) * rows + i] = 0.f;
+  }
+}
+
+hipError_t launchParamHistoryFinalize(float* paramHistory, const int32_t* iterations, int B, int maxIterations, int P, hipStream_t stream) {
+  if (paramHistory == nullptr || B <= 0 || maxIterations <= 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(paramHistoryFinalizeKernel, dim3(B), dim3(256), 0, stream, paramHistory, iterations, maxIterations, P);
+  return hipGetLastError();
+}
+
 hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream) {
   hipLaunchKernelGGL(solveFinalizeKernel, dim3(B), dim3(64), 0, stream, theta, thetaInit, P, st);
   return hipGetLastError();

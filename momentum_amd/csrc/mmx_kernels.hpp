@@ -18,6 +18,7 @@ struct SolveStateDev {
   double* lastError; // [B] lastError_
   double* finalError; // [B] error_ (what solve() returns)
   double* errorHistory; // [B][maxIterations] or null
+  float* paramHistory; // [B][maxIterations][P] or null: the parameters after iteration i (iterationHistory_["parameters"], solver.cpp:101-106)
 };
 
 struct StepParams {
@@ -154,6 +155,8 @@ hipError_t launchStepUpdate(
     hipStream_t stream);
 
 hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream);
+// zeroes the rows of paramHistory [B][maxIterations][P] from iterations[b] on (the reference leaves them at setZero())
+hipError_t launchParamHistoryFinalize(float* paramHistory, const int32_t* iterations, int B, int maxIterations, int P, hipStream_t stream);
 hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream);
 
 } // namespace mmx

@@ -293,3 +293,38 @@ def test_two_kernel_jacobian_assembly_experiment_matches_the_default(torch_cuda,
         scale = float(j1.abs().max())
         assert float((j1 - j2).abs().max()) <= 2e-6 * scale  # (fma contraction may differ between the two kernels)
         assert torch.equal(j1 == 0, j2 == 0)  # the same structural zeros
+
+
+@pytest.mark.parametrize("solver", ["fused", "v1"])
+def test_parameter_history_matches_the_iterates(torch_cuda, orc, solver, monkeypatch):
+    """SolverT::setStoreHistory(true) (solver.cpp:53-72,101-110): iterationHistory_["parameters"].col(i) is the
+    parameter vector after iteration i, untouched columns stay zero.  Checked against solves truncated at i + 1
+    iterations (the solve is deterministic) and, for an element that converges early, against the zero rows."""
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    if solver == "v1":
+        monkeypatch.setenv("MMX_SOLVER", "v1")
+    rig = make_test_character(8)
+    B = 4
+    cons, th0, _ = make_problem(rig, [7, 3], [6], B, seed=5, theta0_scale=0.2)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, B)
+    opt = GnOptions.make(min_iterations=2, max_iterations=6, threshold=1e9, regularization=0.05)  # huge threshold: stops after min_iterations + 1
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True, want_parameter_history=True)
+    hist = out["parameter_history"].cpu().numpy()
+    iters = out["iterations"].cpu().numpy()
+    th = out["theta"].cpu().numpy()
+    assert hist.shape == (B, 6, rig.num_params) and iters.min() >= 3 and iters.min() < 6  # some element stops early
+    for b in range(B):
+        assert np.array_equal(hist[b, iters[b] - 1], th[b])
+        assert np.all(hist[b, iters[b]:] == 0)
+    for i in range(2):
+        o2 = GnOptions.make(min_iterations=i + 1, max_iterations=i + 1, threshold=1e9, regularization=0.05)
+        ti = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), o2)["theta"].cpu().numpy()
+        assert np.array_equal(hist[:, i], ti)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    assert np.array_equal(iters, ref["iterations"])
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel.max() <= 5e-5
