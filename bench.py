@@ -187,8 +187,8 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n):
     }
 
 
-def cpu_baseline(db: DeviceBatch, sample, options):
-    """The CPU oracle timed on the host cores, fp32, on the first `sample` instances of the SAME batch."""
+def cpu_baseline(db: DeviceBatch, sample, options, dtype="f32"):
+    """The CPU oracle timed on the host cores (same precision as the GPU run) on the first `sample` instances of the SAME batch."""
     from oracle import oracle as orc
 
     cores = usable_cores()
@@ -196,32 +196,33 @@ def cpu_baseline(db: DeviceBatch, sample, options):
     cons = db.host_constraints(sample)
     th0 = db.theta0[:sample].cpu().numpy()
     warm = min(sample, 2 * cores)
-    orc.solve_batch(db.rig, db.host_constraints(warm), th0[:warm], options, dtype="f32", nthreads=cores)
+    orc.solve_batch(db.rig, db.host_constraints(warm), th0[:warm], options, dtype=dtype, nthreads=cores)
     t0 = time.perf_counter()
-    orc.solve_batch(db.rig, cons, th0, options, dtype="f32", nthreads=cores)
+    orc.solve_batch(db.rig, cons, th0, options, dtype=dtype, nthreads=cores)
     dt = time.perf_counter() - t0
     n1 = max(1, min(sample, 32 if db.rig.num_joints > 100 else 64))
     t1 = time.perf_counter()
-    orc.solve_batch(db.rig, db.host_constraints(n1), th0[:n1], options, dtype="f32", nthreads=1)
+    orc.solve_batch(db.rig, db.host_constraints(n1), th0[:n1], options, dtype=dtype, nthreads=1)
     dt1 = time.perf_counter() - t1
     return {
         "value": sample / dt,
         "unit": "solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"the first {sample} instances of the timed batch, fp32, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
+        "sample": f"the first {sample} instances of the timed batch, {dtype}, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
         "single_thread_value": n1 / dt1,
     }
 
 
-def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None, comm=None):
+def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None, comm=None, dtype="f32"):
     """W untimed + K timed batched solves; returns (elapsed seconds (max over ranks), theta of the last solve,
     reduced norms).  comm: the direct RCCL communicator (momentum_amd.capi.Comm) when there is one."""
     from momentum_amd import capi
     from momentum_amd import distributed as D
 
     pb, dev, B = db.pb, db.pb.device, db.B
-    theta = db.theta0.clone()
+    theta0 = db.theta0 if dtype == "f32" else db.theta0.double()
+    theta = theta0.clone()
     outputs = dict(
         error=torch.empty((B,), dtype=torch.float64, device=dev),
         iterations=torch.empty((B,), dtype=torch.int32, device=dev),
@@ -230,8 +231,11 @@ def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None, comm=None):
     norms = torch.zeros(3, dtype=torch.float64, device=dev)
 
     def step():
-        theta.copy_(db.theta0)
-        pb.solve(theta, opt, outputs=outputs)
+        theta.copy_(theta0)
+        if dtype == "f32":
+            pb.solve(theta, opt, outputs=outputs)
+        else:
+            outputs.update(pb.solve_f64(theta, opt))
         # the path's only exchange: per-batch residual norms (sum error, sum iterations, #failed), reduced by
         # RCCL called from the C ABI (mmx_comm_all_reduce_norms); gloo only in the one-GPU plumbing test
         capi.residual_norms(outputs, norms)
@@ -320,6 +324,7 @@ def main() -> None:
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the other BASELINE configurations (N = 1 default run reports them)")
     ap.add_argument("--jac-launches", type=int, default=20)
     ap.add_argument("--line-search", type=int, default=0, choices=[0, 1, 2], help="MMX_LINE_SEARCH_*: 0 none (the BASELINE metric), 1 GaussNewtonSolverT's rule, 2 the rule of the batched driver's solvers (SubsetGN / GN-QR)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64: mmx_solve_f64 (SolverT<double>; built for exactness, see DESIGN.md)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
     args = ap.parse_args()
 
@@ -359,7 +364,7 @@ def main() -> None:
     pb, theta_star = db.pb, db.theta_star
     opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=args.line_search)
     dev = pb.device
-    elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist, comm)
+    elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist, comm, args.dtype)
 
     # ---- roofline of the J-assembly kernel (mmx_eval_jacobian): HIP events on the launch stream
     M, P = pb.M, pb.P
@@ -450,7 +455,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": desc,
@@ -496,8 +501,8 @@ def main() -> None:
         if args.check_instances > 0:
             line["check"].update(parity_check(db, theta_final, opt, args.check_instances))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(db, args.cpu_sample, opt)
-        default_run = world == 1 and args.config == "cfg2" and args.batch == 0 and args.line_search == 0
+            line["cpu_baseline"] = cpu_baseline(db, args.cpu_sample, opt, args.dtype)
+        default_run = world == 1 and args.config == "cfg2" and args.batch == 0 and args.line_search == 0 and args.dtype == "f32"
         if default_run and not args.no_extra_configs:
             del db, pb
             torch.cuda.empty_cache()

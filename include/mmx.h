@@ -465,6 +465,27 @@ int32_t mmx_solve(
     void* stream);
 
 /*
+ * The double instantiation: SolverT<double>::solve with GaussNewtonSolverT<double> for every element
+ * (momentum/solver/gauss_newton_solver.cpp:315-316; solveTensorIKProblem is templated on T,
+ * pymomentum/tensor_ik/tensor_ik.cpp:95-103).  theta_dev is DOUBLE [B][P]; the constraint payload and the joint
+ * constants stay float (Joint is float in the reference even for double solves, skeleton_state.cpp:89) and are
+ * widened per use; every other argument as in mmx_solve.  Normal equations from the explicit Jacobian, LL^T and
+ * two substitutions in double: agrees with the reference's double solver to rounding (tests: 1e-10 against the
+ * oracle), no refinement step.  Built for exactness, not for the roofline: position / orientation
+ * constraints with their losses, per-instance characters and parents, fixed lambda or the LM schedule, both
+ * line-search rules; other blocks return MMX_ERR_UNSUPPORTED.
+ */
+int32_t mmx_solve_f64(
+    mmx_problem* problem,
+    const mmx_gn_options* options,
+    double* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    void* stream);
+
+/*
  * mmx_solve with SolverT::setStoreHistory(true) (momentum/solver/solver.cpp:53-72,101-110): additionally
  *   parameter_history  float [B][max_iterations][P]  iterationHistory_["parameters"]: the parameters after
  *                      iteration i; rows from an element's iteration count on stay zero (setZero(), :70)
@@ -507,6 +528,13 @@ int32_t mmx_solve_host(
     mmx_problem* problem,
     const mmx_gn_options* options,
     float* theta_host,
+    double* final_error_host,
+    int32_t* iterations_host,
+    int32_t* status_host);
+int32_t mmx_solve_f64_host(
+    mmx_problem* problem,
+    const mmx_gn_options* options,
+    double* theta_host,
     double* final_error_host,
     int32_t* iterations_host,
     int32_t* status_host);

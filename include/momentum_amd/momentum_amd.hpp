@@ -652,6 +652,20 @@ class BatchedGaussNewtonSolver {
     check(mmx_solve_host(fn_->handle(), &opt_, parameters.data(), err.data(), iterations_.data(), status_.data()));
     return err;
   }
+  // SolverT<double>::solve with GaussNewtonSolverT<double> for every element (the reference instantiates its
+  // solvers for float and double, gauss_newton_solver.cpp:315-316): parameters [batch * P] in double
+  std::vector<double> solve(std::vector<double>& parameters) {
+    fn_->sync();
+    const size_t B = fn_->batchSize(), P = fn_->getNumParameters();
+    if (parameters.size() != B * P) {
+      throw std::runtime_error("momentum_amd: parameters.size() != batch * numParameters"); // solver.cpp:77
+    }
+    std::vector<double> err(B);
+    iterations_.assign(B, 0);
+    status_.assign(B, 0);
+    check(mmx_solve_f64_host(fn_->handle(), &opt_, parameters.data(), err.data(), iterations_.data(), status_.data()));
+    return err;
+  }
   const std::vector<int32_t>& getIterations() const {
     return iterations_;
   }

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 # -DMMX_EXP_<NAME> (objects kept apart); MMX_LIB=<path> makes capi.py load that library instead.
 VARIANT = os.environ.get("MMX_BUILD_VARIANT", "")
 LIB = os.path.join(HERE, f"libmmx_hip_{VARIANT}.so" if VARIANT else "libmmx_hip.so")
-SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_comm.hip", "mmx_host_tables.cpp"]
+SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_comm.hip", "mmx_f64.hip", "mmx_host_tables.cpp"]
 FUSED_GROUPS = 4  # mmx_fused.hip is compiled once per group of template instantiations, in parallel
 HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_tree.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
 ARCH = "gfx950"

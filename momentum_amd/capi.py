@@ -27,7 +27,7 @@ SYMBOLS = [
     "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
-    "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_host",
+    "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
     "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
@@ -79,7 +79,9 @@ def lib() -> C.CDLL:
     L.mmx_eval_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mmx_solve.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
     L.mmx_solve_with_history.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp, vp]
+    L.mmx_solve_f64.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
     L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
+    L.mmx_solve_f64_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_eval_jacobian_host.argtypes = [vp, vp, vp, vp, vp, i32]
     L.mmx_debug_fused_normal_equations.argtypes = [vp, vp, vp, vp, _abi.c_int32_p, _abi.c_int32_p, vp]
     L.mmx_comm_unique_id.argtypes = [vp]
@@ -366,6 +368,23 @@ class Problem:
         jtr = torch.zeros((self.B, n), dtype=torch.float32, device=self.device)
         _check(lib().mmx_debug_fused_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), as_ptr(lst, C.c_int32), C.byref(C.c_int32(0)), _stream_ptr()))
         return lst[:n].copy(), jtj, jtr
+
+    def solve_f64(self, theta, options: GnOptions, want_history: bool = False):
+        """In-place batched SolverT<double>::solve (mmx_solve_f64); theta: float64 cuda tensor [B, P]."""
+        import torch
+
+        assert isinstance(theta, torch.Tensor) and theta.is_cuda and theta.dtype == torch.float64 and theta.is_contiguous() and tuple(theta.shape) == (self.B, self.P)
+        out = dict(
+            error=torch.empty((self.B,), dtype=torch.float64, device=self.device),
+            iterations=torch.empty((self.B,), dtype=torch.int32, device=self.device),
+            status=torch.empty((self.B,), dtype=torch.int32, device=self.device),
+        )
+        if want_history:
+            out["error_history"] = torch.empty((self.B, max(1, options.max_iterations)), dtype=torch.float64, device=self.device)
+        _check(lib().mmx_solve_f64(self._h, C.byref(options), _dev(theta), _dev(out["error"]), _dev(out["iterations"]), _dev(out["status"]),
+                                   _dev(out.get("error_history")), _stream_ptr()))  # fmt: skip
+        out["theta"] = theta
+        return out
 
     def solve(self, theta, options: GnOptions, want_history: bool = False, outputs=None, want_parameter_history: bool = False):
         """In-place batched SolverT::solve.  Returns dict(theta, error, iterations, status[, error_history]

@@ -210,6 +210,7 @@ struct mmx_problem {
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
+  DevBuf sJacF64, sHessF64; // scratch of the double-precision solve
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
 };
 
@@ -1881,6 +1882,73 @@ static int32_t solveImpl(
   return MMX_OK;
 }
 
+int32_t mmx_solve_f64(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    double* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    void* stream) {
+  MMX_ZONE("mmx_solve_f64 (SolverT<double>::solve)");
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (o == nullptr || theta_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "options / theta is null");
+  }
+  if (o->max_iterations < 0 || o->min_iterations < 0) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "iteration counts must be >= 0");
+  }
+  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE) {
+    return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: step rules MMX_STEP_GN_FIXED_LAMBDA and MMX_STEP_LM_SCHEDULE");
+  }
+  if (o->do_line_search != MMX_LINE_SEARCH_NONE && o->do_line_search != MMX_LINE_SEARCH_GAUSS_NEWTON &&
+      o->do_line_search != MMX_LINE_SEARCH_DIRECTIONAL) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown do_line_search rule");
+  }
+  if (pb->dev.G > 0 || pb->dev.NE > 0 || pb->M > 3 * pb->U) {
+    return fail(
+        MMX_ERR_UNSUPPORTED,
+        "mmx_solve_f64: position / orientation constraints only (the further joint error functions, limits and the model-parameter prior are single precision)");
+  }
+  const size_t B = size_t(pb->B), n = size_t(pb->solveN), M = size_t(3 * pb->U);
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN) > 160 * 1024) {
+    return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: rig beyond the kernel's LDS budget");
+  }
+  MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));
+  MMX_HIP(pb->sHessF64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));
+  MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
+  mmx::SolveStateDev st{};
+  st.iterations = iterations != nullptr ? iterations : pb->sIters.as<int32_t>();
+  st.status = status != nullptr ? status : pb->sStatus.as<int32_t>();
+  st.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
+  st.errorHistory = error_history;
+  if (error_history != nullptr && o->max_iterations > 0) {
+    MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+  }
+  mmx::FusedParams fp{};
+  fp.lambda = o->regularization;
+  fp.threshold = o->threshold;
+  fp.minIterations = o->min_iterations;
+  fp.maxIterations = o->max_iterations;
+  fp.doLineSearch = o->do_line_search;
+  fp.stepRule = o->step_rule;
+  fp.lmLambdaMin = o->lm_lambda_min;
+  fp.lmLambdaMax = o->lm_lambda_max;
+  fp.lmUp = o->lm_up;
+  fp.lmDown = o->lm_down;
+  MMX_HIP(mmx::launchSolveF64(
+      pb->rigDev, pb->dev, pb->dSolveListV1.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), s));
+  return MMX_OK;
+}
+
 int32_t mmx_debug_fused_normal_equations(
     mmx_problem* pb,
     const float* theta_dev,
@@ -1956,6 +2024,46 @@ int32_t mmx_solve_host(
   }
   MMX_HIP(hipDeviceSynchronize());
   MMX_HIP(hipMemcpy(theta_host, pb->sTheta.p, B * P * sizeof(float), hipMemcpyDeviceToHost));
+  if (final_error_host) {
+    MMX_HIP(hipMemcpy(final_error_host, pb->sFinalErr.p, B * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (iterations_host) {
+    MMX_HIP(hipMemcpy(iterations_host, pb->sIters.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  if (status_host) {
+    MMX_HIP(hipMemcpy(status_host, pb->sStatus.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return MMX_OK;
+}
+
+int32_t mmx_solve_f64_host(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    double* theta_host,
+    double* final_error_host,
+    int32_t* iterations_host,
+    int32_t* status_host) {
+  MMX_ZONE("mmx_solve_f64_host");
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_host == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta is null");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  MMX_HIP(pb->sTheta.ensure(B * P * sizeof(double)));
+  MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
+  MMX_HIP(hipMemcpy(pb->sTheta.p, theta_host, B * P * sizeof(double), hipMemcpyHostToDevice));
+  rc = mmx_solve_f64(pb, o, pb->sTheta.as<double>(), pb->sFinalErr.as<double>(), pb->sIters.as<int32_t>(), pb->sStatus.as<int32_t>(), nullptr, nullptr);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  MMX_HIP(hipDeviceSynchronize());
+  MMX_HIP(hipMemcpy(theta_host, pb->sTheta.p, B * P * sizeof(double), hipMemcpyDeviceToHost));
   if (final_error_host) {
     MMX_HIP(hipMemcpy(final_error_host, pb->sFinalErr.p, B * sizeof(double), hipMemcpyDeviceToHost));
   }

@@ -1,0 +1,640 @@
+// mmx_f64.hip -- the double-precision instantiation of the solve: GaussNewtonSolverT<double> + SolverT<double>::solve
+// (momentum/solver/gauss_newton_solver.cpp:315-316 instantiates both; pymomentum/tensor_ik/tensor_ik.cpp is
+// templated on T) for every element of the batch, behind mmx_solve_f64.
+//
+// Written for exactness and brevity, not for the roofline: one workgroup per instance, forward kinematics by
+// tree level in double, the dense J (solved columns only), H = J^T J + lambda I and its Cholesky factor in a
+// global scratch of the problem (L2-resident per workgroup), everything the reference's double solver does in
+// the reference's order of operations (normal equations from the explicit Jacobian, LL^T, two substitutions,
+// theta -= delta, both backtracking rules, the LM schedule).  No refinement step is needed here: the factor is
+// exact to double rounding.  Joint constants stay float like in the reference (JointT is float even for double
+// solves, skeleton_state.cpp:89) and are widened per use.
+//
+// Scope: position and orientation constraints with their GeneralizedLoss, per-instance characters and constraint
+// parents, enabled-parameter sets.  The parameter-space rows (limits, model-parameter prior) and the further joint
+// error functions are single-precision only for now (mmx_solve_f64 returns MMX_ERR_UNSUPPORTED for them).
+#include "mmx_device.hpp"
+#include "mmx_kernels.hpp"
+
+#include <cfloat>
+
+namespace mmx {
+
+namespace {
+
+struct D3 {
+  double x, y, z;
+};
+struct DQ {
+  double x, y, z, w;
+};
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) {
+  return D3{a.x + b.x, a.y + b.y, a.z + b.z};
+}
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) {
+  return D3{a.x - b.x, a.y - b.y, a.z - b.z};
+}
+__device__ __forceinline__ D3 operator*(double s, D3 a) {
+  return D3{s * a.x, s * a.y, s * a.z};
+}
+__device__ __forceinline__ D3 dcross(D3 a, D3 b) {
+  return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double ddot(D3 a, D3 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+__device__ __forceinline__ DQ dqmul(DQ a, DQ b) { // Eigen quaternion product
+  return DQ{
+      a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+      a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+      a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x,
+      a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+__device__ __forceinline__ D3 dqrot(DQ q, D3 v) { // Eigen _transformVector
+  const D3 qv{q.x, q.y, q.z};
+  D3 uv = dcross(qv, v);
+  uv = uv + uv;
+  return v + q.w * uv + dcross(qv, uv);
+}
+__device__ __forceinline__ D3 dqmatCol(DQ q, int c) { // column c of Eigen toRotationMatrix
+  const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  if (c == 0) {
+    return D3{1.0 - (tyy + tzz), txy + twz, txz - twy};
+  }
+  if (c == 1) {
+    return D3{txy - twz, 1.0 - (txx + tzz), tyz + twx};
+  }
+  return D3{txz + twy, tyz - twx, 1.0 - (txx + tyy)};
+}
+__device__ __forceinline__ DQ dqnormalized(DQ q) {
+  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  if (n2 > 0.0) {
+    const double n = sqrt(n2);
+    return DQ{q.x / n, q.y / n, q.z / n, q.w / n};
+  }
+  return q;
+}
+__device__ __forceinline__ double dlossValue(const LossDev& l, double s) { // generalized_loss.cpp:104-140
+  const double ic = double(l.invC2), q = s * ic;
+  switch (l.type) {
+    case 0:
+      return q;
+    case 1:
+      return sqrt(q + 1.0) - 1.0;
+    case 2:
+      return log(0.5 * q + 1.0);
+    case 3:
+      return 1.0 - exp(-0.5 * q);
+    default: {
+      const double a = double(l.alpha);
+      return (pow(q / fabs(a - 2.0) + 1.0, 0.5 * a) - 1.0) * fabs(a - 2.0) / a;
+    }
+  }
+}
+__device__ __forceinline__ double dlossDeriv(const LossDev& l, double s) {
+  const double ic = double(l.invC2), q = s * ic;
+  switch (l.type) {
+    case 0:
+      return ic;
+    case 1:
+      return 0.5 * ic / sqrt(q + 1.0);
+    case 2:
+      return ic / (ic * s + 2.0);
+    case 3:
+      return 0.5 * ic * exp(-0.5 * q);
+    default: {
+      const double a = double(l.alpha);
+      return 0.5 * ic * pow(q / fabs(a - 2.0) + 1.0, 0.5 * a - 1.0);
+    }
+  }
+}
+
+constexpr int kDs = 17; // doubles per joint: world t(3) q(4) s(1) | rotation axes x, y, z (9)
+
+struct F64Lds {
+  double* th; // [P]
+  double* trial; // [P]
+  double* jp; // [7 J]
+  double* js; // [kDs J]
+  double* uv; // [3 U] unit world vector
+  double* ur; // [3 U] scaled residual rows
+  double* us; // [U] derivScale
+  int* utin; // [U]
+  double* g; // [n]
+  double* d; // [n]
+  double* red; // [8]
+  int* flags; // [4]
+  double* jl; // [n][rc + 1] a chunk of J's rows, column-major (normal equations)
+};
+
+// ParameterTransformT<double>::apply + SkeletonStateT<double>::set (parameter_transform.cpp:110-124,
+// skeleton_state.cpp:87-121, joint_state.cpp:22-65): joint parameters one transform row per thread, then one
+// tree level per barrier (parents before children), then the rotation axes of all joints at once.
+__device__ void fkF64(const RigDev& rig, const F64Lds& s, const double* th, int tid, bool withAxes) {
+  for (int r = tid; r < rig.R; r += 256) {
+    double acc = 0.0;
+    const int k1 = rig.ptOuter[r + 1];
+    for (int k = rig.ptOuter[r]; k < k1; ++k) {
+      acc += double(rig.ptValue[k]) * th[rig.ptInner[k]];
+    }
+    s.jp[r] = acc + double(rig.ptOffsets[r]);
+  }
+  __syncthreads();
+  for (int lvl = 0; lvl < rig.numLevels; ++lvl) {
+    const int i1 = rig.levelStart[lvl + 1];
+    for (int i = rig.levelStart[lvl] + tid; i < i1; i += 256) {
+      const int j = rig.levelOrder[i];
+      const double* p = s.jp + 7 * j;
+      const float* pre = rig.preRot + 4 * j;
+      const float* off = rig.offset + 3 * j;
+      const DQ q0{double(pre[0]), double(pre[1]), double(pre[2]), double(pre[3])};
+      const DQ q1 = dqmul(q0, DQ{0.0, 0.0, sin(0.5 * p[5]), cos(0.5 * p[5])});
+      const DQ q2 = dqmul(q1, DQ{0.0, sin(0.5 * p[4]), 0.0, cos(0.5 * p[4])});
+      const DQ ql = dqmul(q2, DQ{sin(0.5 * p[3]), 0.0, 0.0, cos(0.5 * p[3])});
+      D3 t{double(off[0]) + p[0], double(off[1]) + p[1], double(off[2]) + p[2]};
+      DQ q = ql;
+      double sc = exp2(p[6]);
+      DQ qp{0.0, 0.0, 0.0, 1.0};
+      const int par = rig.parent[j];
+      if (par >= 0) {
+        const double* w = s.js + kDs * par;
+        const D3 tp{w[0], w[1], w[2]};
+        qp = DQ{w[3], w[4], w[5], w[6]};
+        t = tp + dqrot(qp, w[7] * t); // transform.h:124-129
+        q = dqmul(qp, ql);
+        sc = w[7] * sc;
+      }
+      double* o = s.js + kDs * j;
+      o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w, o[7] = sc;
+      if (withAxes) { // rotationAxis.col(i) = (q_parent * q_partial) * e_i (joint_state.cpp:53-54)
+        const D3 az = dqrot(dqmul(qp, q0), D3{0.0, 0.0, 1.0});
+        const D3 ay = dqrot(dqmul(qp, q1), D3{0.0, 1.0, 0.0});
+        const D3 ax = dqrot(dqmul(qp, q2), D3{1.0, 0.0, 0.0});
+        o[8] = ax.x, o[9] = ax.y, o[10] = ax.z, o[11] = ay.x, o[12] = ay.y, o[13] = ay.z, o[14] = az.x, o[15] = az.y, o[16] = az.z;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Position / Orientation evalFunction + the weighting of JointErrorFunctionT::getJacobian
+// (position_error_function.cpp:15-27, orientation_error_function.cpp:15-40, joint_error_function-inl.h:197-213)
+// for unit u of instance b; returns the unit's share of the error (w * loss(|f|^2), once per constraint).
+__device__ double evalUnitF64(const ProblemDev& pb, const F64Lds& s, int b, int u, bool store) {
+  const UnitInput in = loadUnitInput(pb, b, u);
+  const double* w = s.js + kDs * in.joint;
+  const D3 t{w[0], w[1], w[2]};
+  const DQ q{w[3], w[4], w[5], w[6]};
+  const bool isPoint = u < pb.Kp;
+  D3 v, f;
+  double sqr, fw;
+  bool first = true;
+  const LossDev& ls = isPoint ? pb.lossPos : pb.lossOri;
+  if (isPoint) {
+    v = t + dqrot(q, w[7] * D3{double(in.a[0]), double(in.a[1]), double(in.a[2])});
+    f = v - D3{double(in.t[0]), double(in.t[1]), double(in.t[2])};
+    sqr = ddot(f, f);
+    fw = double(pb.wPos);
+  } else {
+    const int uo = u - pb.Kp, k = uo - 3 * (uo / 3);
+    // OrientationDataT<double>'s constructor normalises in double (orientation_error_function.h:33-35)
+    const DQ qo = dqnormalized(DQ{double(in.a[0]), double(in.a[1]), double(in.a[2]), double(in.a[3])});
+    const DQ qt = dqnormalized(DQ{double(in.t[0]), double(in.t[1]), double(in.t[2]), double(in.t[3])});
+    v = dqrot(q, dqmatCol(qo, k));
+    f = v - dqmatCol(qt, k);
+    sqr = 0.0;
+    for (int kk = 0; kk < 3; ++kk) { // the loss sees all nine rows of the constraint
+      const D3 fo = dqrot(q, dqmatCol(qo, kk)) - dqmatCol(qt, kk);
+      sqr += ddot(fo, fo);
+    }
+    first = k == 0;
+    fw = double(pb.wOri);
+  }
+  double sigma = 0.0, werr = 0.0;
+  if (in.cw != 0.f && fw > 0.0) {
+    const double wgt = double(in.cw) * fw;
+    werr = first ? wgt * dlossValue(ls, sqr) : 0.0;
+    sigma = sqrt(wgt * dlossDeriv(ls, sqr));
+  }
+  if (store) {
+    s.uv[3 * u] = v.x, s.uv[3 * u + 1] = v.y, s.uv[3 * u + 2] = v.z;
+    s.ur[3 * u] = sigma * f.x, s.ur[3 * u + 1] = sigma * f.y, s.ur[3 * u + 2] = sigma * f.z;
+    s.us[u] = sigma;
+    s.utin[u] = in.tin;
+  }
+  return werr;
+}
+
+__device__ double blockSumF64(const F64Lds& s, double v, int tid) {
+  for (int off = 32; off > 0; off >>= 1) {
+    v += __shfl_xor(v, off, 64);
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    s.red[tid >> 6] = v;
+  }
+  __syncthreads();
+  return (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+}
+
+// SkeletonSolverFunctionT<double>::getError (skeleton_solver_function.cpp:64-83; rounded through float, :82)
+__device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds& s, const double* th, int b, int tid) {
+  fkF64(rig, s, th, tid, false);
+  double e = 0.0;
+  for (int u = tid; u < pb.U; u += 256) {
+    e += evalUnitF64(pb, s, b, u, false);
+  }
+  return double(float(blockSumF64(s, e, tid)));
+}
+
+// d(unit vector) / d(joint parameter (joint, dof)) (joint_error_function-inl.h:248-291, joint_state.cpp:68-82)
+__device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, const double* js, D3 v, int utin, bool isPoint, bool& applies) {
+  const bool anc = c.tin <= utin && utin < c.tout;
+  const double* a = js + kDs * c.joint;
+  if (c.dof >= 3 && c.dof < 6) {
+    const double* ax = a + 8 + 3 * (c.dof - 3);
+    applies = anc;
+    return dcross(D3{ax[0], ax[1], ax[2]}, isPoint ? v - D3{a[0], a[1], a[2]} : v);
+  }
+  applies = anc && isPoint;
+  if (c.dof < 3) {
+    if (c.parent < 0) {
+      return D3{c.dof == 0 ? 1.0 : 0.0, c.dof == 1 ? 1.0 : 0.0, c.dof == 2 ? 1.0 : 0.0};
+    }
+    const double* p = js + kDs * c.parent;
+    return p[7] * dqmatCol(DQ{p[3], p[4], p[5], p[6]}, c.dof);
+  }
+  return 0.693147180559945309417232121458176568 * (v - D3{a[0], a[1], a[2]});
+}
+
+__global__ void __launch_bounds__(256) solveF64Kernel(
+    RigDev rig,
+    ProblemDev pb,
+    const int32_t* __restrict__ solveList, // [n] parameters of the dense system (enabled, structurally non-zero)
+    int n,
+    double* __restrict__ theta, // [B][P] in/out
+    SolveStateDev st,
+    FusedParams fp,
+    double* __restrict__ Jg, // [B][n][M] scratch: the dense Jacobian (solved columns, column-major)
+    double* __restrict__ Hg, // [B][n][n] scratch: H, then its Cholesky factor (lower triangle, column-major)
+    int rc) { // rows of J staged in LDS at a time
+  extern __shared__ __attribute__((aligned(16))) double dmem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  selectInstanceRig(rig, b);
+  const int J = rig.J, P = rig.P, U = pb.U, M = 3 * U;
+  F64Lds s;
+  {
+    double* p = dmem;
+    auto take = [&](size_t c) {
+      double* r = p;
+      p += (c + 1) & ~size_t(1);
+      return r;
+    };
+    s.th = take(P), s.trial = take(P), s.jp = take(7 * size_t(J)), s.js = take(size_t(kDs) * J);
+    s.uv = take(3 * size_t(U)), s.ur = take(3 * size_t(U)), s.us = take(U);
+    s.g = take(n), s.d = take(n), s.red = take(8);
+    s.utin = reinterpret_cast<int*>(take((U + 1) / 2 + 1));
+    s.flags = reinterpret_cast<int*>(take(2));
+    s.jl = take(size_t(n) * size_t(rc + 1));
+  }
+  double* thg = theta + size_t(b) * P;
+  double* Jb = Jg + size_t(b) * size_t(n) * size_t(M);
+  double* Hb = Hg + size_t(b) * size_t(n) * size_t(n);
+  for (int i = tid; i < P; i += 256) {
+    s.th[i] = thg[i];
+  }
+  if (tid == 0) {
+    s.flags[0] = 0, s.flags[1] = 0, s.flags[2] = 0;
+  }
+  __syncthreads();
+  double lastError = DBL_MAX, curError = DBL_MAX; // solver.cpp:84-85
+  double lambda = double(fp.lambda);
+  int itersDone = 0;
+  for (int it = 0; it < fp.maxIterations; ++it) {
+    // ---- SkeletonSolverFunctionT::getJacobian: state, residual, Jacobian (skeleton_solver_function.cpp:200-261)
+    fkF64(rig, s, s.th, tid, true);
+    double e = 0.0;
+    for (int u = tid; u < U; u += 256) {
+      e += evalUnitF64(pb, s, b, u, true);
+    }
+    curError = blockSumF64(s, e, tid); // (not rounded: the value getJacobian returns)
+    for (int item = tid; item < n * U; item += 256) {
+      const int c = item / U, u = item - c * U;
+      const int p = solveList[c];
+      const D3 v{s.uv[3 * u], s.uv[3 * u + 1], s.uv[3 * u + 2]};
+      D3 acc{0.0, 0.0, 0.0};
+      const int e1 = pb.colStart[p + 1];
+      for (int k = pb.colStart[p]; k < e1; ++k) {
+        const ColumnSourceDev cs = pb.colSources[k];
+        bool applies;
+        const D3 gq = sourceDerivativeF64(cs, s.js, v, s.utin[u], u < pb.Kp, applies);
+        if (applies) { // jac.col(p) += derivScale * dfdv * jc * value (joint_error_function-inl.h:254-289)
+          const double w = double(cs.weight);
+          acc.x += (s.us[u] * gq.x) * w, acc.y += (s.us[u] * gq.y) * w, acc.z += (s.us[u] * gq.z) * w;
+        }
+      }
+      double* o = Jb + size_t(c) * M + 3 * u;
+      o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- H.triangularView<Lower>() += J^T J ; Jtr += J^T r ; diagonal += regularization (gauss_newton_solver.cpp:215-216,248)
+    // J is staged through LDS in chunks of `rc` rows (read from the scratch once per iteration instead of once
+    // per entry of H: 4096 x 10 x 14 MB of re-reads made the first version HBM-bound); a thread owns 4 x 4
+    // blocks of the lower triangle and adds a chunk's contribution to the scratch block by block.
+    {
+      const int nb4 = (n + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2, ldj = rc + 1;
+      for (int c = tid; c < n; c += 256) {
+        s.g[c] = 0.0;
+      }
+      for (int r0 = 0; r0 < M; r0 += rc) {
+        const int rows = M - r0 < rc ? M - r0 : rc;
+        __syncthreads();
+        for (int idx = tid; idx < n * rows; idx += 256) {
+          const int c = idx / rows, r = idx - c * rows;
+          s.jl[c * ldj + r] = Jb[size_t(c) * M + r0 + r];
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += 256) {
+          double acc = s.g[c];
+          for (int r = 0; r < rows; ++r) {
+            acc += s.jl[c * ldj + r] * s.ur[r0 + r];
+          }
+          s.g[c] = acc;
+        }
+        for (int q = tid; q < nblk; q += 256) {
+          int bi = int((sqrt(8.0 * double(q) + 1.0) - 1.0) * 0.5); // q = bi (bi + 1) / 2 + bj, bj <= bi
+          while ((bi + 1) * (bi + 2) / 2 <= q) {
+            ++bi;
+          }
+          while (bi * (bi + 1) / 2 > q) {
+            --bi;
+          }
+          const int bj = q - bi * (bi + 1) / 2;
+          double acc[4][4] = {};
+          const double* ci[4];
+          const double* cj[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { // (columns beyond n read column n - 1: their entries are never stored)
+            ci[k] = s.jl + (4 * bi + k < n ? 4 * bi + k : n - 1) * ldj;
+            cj[k] = s.jl + (4 * bj + k < n ? 4 * bj + k : n - 1) * ldj;
+          }
+          for (int r = 0; r < rows; ++r) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              av[k] = ci[k][r], bv[k] = cj[k][r];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+#pragma unroll
+              for (int y = 0; y < 4; ++y) {
+                acc[x][y] += av[x] * bv[y];
+              }
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+              const int i = 4 * bi + x, j = 4 * bj + y;
+              if (i < n && j <= i) {
+                double* h = Hb + size_t(j) * n + i;
+                *h = (r0 == 0 ? (i == j ? lambda : 0.0) : *h) + acc[x][y];
+              }
+            }
+          }
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- llt_.compute(H) (Eigen::LLT, lower): right-looking, one column per step; a non-positive pivot is
+    // recorded (the reference never checks LLT::info(), gauss_newton_solver.cpp:251)
+    bool notPd = false;
+    for (int k = 0; k < n; ++k) {
+      const double dkk = Hb[size_t(k) * n + k];
+      if (!(dkk > 0.0)) {
+        notPd = true; // every thread reads the same value
+        break;
+      }
+      const double lkk = sqrt(dkk);
+      __syncthreads();
+      for (int i = k + tid; i < n; i += 256) {
+        Hb[size_t(k) * n + i] = i == k ? lkk : Hb[size_t(k) * n + i] / lkk;
+      }
+      __threadfence_block();
+      __syncthreads();
+      const int rem = n - k - 1;
+      for (int item = tid; item < rem * (rem + 1) / 2; item += 256) {
+        int ii = int((sqrt(8.0 * double(item) + 1.0) - 1.0) * 0.5);
+        while ((ii + 1) * (ii + 2) / 2 <= item) {
+          ++ii;
+        }
+        while (ii * (ii + 1) / 2 > item) {
+          --ii;
+        }
+        const int jj = item - ii * (ii + 1) / 2;
+        const int i = k + 1 + ii, j = k + 1 + jj;
+        Hb[size_t(j) * n + i] -= Hb[size_t(k) * n + i] * Hb[size_t(k) * n + j];
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    // ---- delta = llt_.solve(Jtr): wave 0, lanes over the already known entries
+    if (!notPd) {
+      for (int c = tid; c < n; c += 256) {
+        s.d[c] = s.g[c];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        for (int k = 0; k < n; ++k) { // L y = g
+          double part = 0.0;
+          for (int j = tid; j < k; j += 64) {
+            part += Hb[size_t(j) * n + k] * s.d[j];
+          }
+          for (int off = 32; off > 0; off >>= 1) {
+            part += __shfl_xor(part, off, 64);
+          }
+          if (tid == 0) {
+            s.d[k] = (s.d[k] - part) / Hb[size_t(k) * n + k];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        for (int k = n - 1; k >= 0; --k) { // L^T x = y
+          double part = 0.0;
+          for (int j = k + 1 + tid; j < n; j += 64) {
+            part += Hb[size_t(k) * n + j] * s.d[j];
+          }
+          for (int off = 32; off > 0; off >>= 1) {
+            part += __shfl_xor(part, off, 64);
+          }
+          if (tid == 0) {
+            s.d[k] = (s.d[k] - part) / Hb[size_t(k) * n + k];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+      }
+      __syncthreads();
+    }
+    // ---- updateParameters (gauss_newton_solver.cpp:283-313; subset_gauss_newton_solver.cpp:117-142) / LM schedule
+    auto makeTrial = [&](double scale) {
+      for (int i = tid; i < P; i += 256) {
+        s.trial[i] = s.th[i];
+      }
+      __syncthreads();
+      for (int c = tid; c < n; c += 256) {
+        s.trial[solveList[c]] -= scale * s.d[c];
+      }
+      __syncthreads();
+    };
+    auto acceptTrial = [&]() {
+      for (int i = tid; i < P; i += 256) {
+        s.th[i] = s.trial[i];
+      }
+      __syncthreads();
+    };
+    if (!notPd && fp.stepRule == 1) {
+      double part = 0.0;
+      for (int c = tid; c < n; c += 256) {
+        part += s.d[c] * s.g[c] + lambda * s.d[c] * s.d[c];
+      }
+      const double predicted = blockSumF64(s, part, tid);
+      makeTrial(1.0);
+      const double eNew = errorF64(rig, pb, s, s.trial, b, tid);
+      const double rho = predicted > 0.0 ? (curError - eNew) / predicted : -1.0;
+      if (rho > 0.0) {
+        acceptTrial();
+      }
+      if (!(rho >= 0.25)) {
+        lambda = fmin(lambda * double(fp.lmUp), double(fp.lmLambdaMax));
+      } else if (rho > 0.75) {
+        lambda = fmax(lambda * double(fp.lmDown), double(fp.lmLambdaMin));
+      }
+    } else if (notPd && fp.stepRule == 1) {
+      lambda = fmin(lambda * double(fp.lmUp), double(fp.lmLambdaMax));
+    } else if (!notPd && fp.doLineSearch == 2) {
+      double part = 0.0;
+      for (int c = tid; c < n; c += 256) {
+        part += s.g[c] * s.d[c];
+      }
+      const double gd = blockSumF64(s, part, tid);
+      float alpha = 1.0f; // the reference keeps c_1 / tau / alpha in float (:118-142)
+      for (int ls = 0; ls < 10; ++ls) {
+        makeTrial(double(alpha));
+        const double eNew = errorF64(rig, pb, s, s.trial, b, tid);
+        if ((curError - eNew) >= double(1e-4f * alpha) * gd) {
+          break;
+        }
+        alpha *= 0.5f;
+      }
+      acceptTrial();
+    } else if (!notPd && fp.doLineSearch == 1) {
+      const double scaledError = 1e-3 * curError;
+      double scale = 1.0;
+      for (int ls = 0; ls < 10; ++ls) {
+        makeTrial(scale);
+        const double eNew = errorF64(rig, pb, s, s.trial, b, tid);
+        if ((curError - eNew) >= scale * scaledError) {
+          break;
+        }
+        scale *= 0.5;
+      }
+      acceptTrial();
+    } else if (!notPd) {
+      for (int c = tid; c < n; c += 256) {
+        s.th[solveList[c]] -= s.d[c]; // skeleton_solver_function.cpp:158
+      }
+    }
+    if (tid == 0) { // solver.cpp:92-119
+      if (st.errorHistory != nullptr) {
+        st.errorHistory[size_t(b) * fp.maxIterations + it] = curError;
+      }
+      itersDone = it + 1;
+      if (notPd) {
+        s.flags[2] = 2;
+      }
+      const bool converged = fabs(lastError - curError) / (fabs(curError) + double(FLT_MIN)) <= double(fp.threshold) * double(FLT_EPSILON);
+      s.flags[0] = (it >= fp.minIterations && converged) ? 1 : 0;
+      lastError = curError;
+    }
+    __syncthreads();
+    if (s.flags[0] != 0) {
+      break;
+    }
+  }
+  // NaN / Inf: revert to the initial parameters (tensor_ik.cpp:168-173) = do not write
+  int bad = 0;
+  for (int i = tid; i < P; i += 256) {
+    if (!isfinite(s.th[i])) {
+      bad = 1;
+    }
+  }
+  bad = __syncthreads_or(bad);
+  if (!bad) {
+    for (int i = tid; i < P; i += 256) {
+      thg[i] = s.th[i];
+    }
+  }
+  if (tid == 0) {
+    st.iterations[b] = itersDone;
+    st.finalError[b] = curError;
+    st.status[b] = bad ? 1 : s.flags[2];
+  }
+}
+
+} // namespace
+
+static size_t solveF64BaseDoubles(int J, int P, int U, int n) {
+  auto e = [](size_t c) { return (c + 1) & ~size_t(1); };
+  return 2 * e(P) + e(7 * size_t(J)) + e(size_t(kDs) * J) + 2 * e(3 * size_t(U)) + e(U) + 2 * e(n) + e(8) + e((U + 1) / 2 + 1) + e(2);
+}
+// rows of J staged per chunk: as many as fit next to the fixed part (at most 64, at least 4), leaving room for two
+// workgroups per CU when the system is small
+static int solveF64ChunkRows(int J, int P, int U, int n) {
+  const size_t base = solveF64BaseDoubles(J, P, U, n) * sizeof(double);
+  const size_t budget = base < 60 * 1024 ? 78 * 1024 : 158 * 1024;
+  if (base + size_t(n > 0 ? n : 1) * 5 * sizeof(double) > budget) {
+    return 0;
+  }
+  size_t rows = (budget - base) / (size_t(n > 0 ? n : 1) * sizeof(double)) - 1;
+  return int(rows > 64 ? 64 : rows);
+}
+size_t solveF64LdsBytes(int J, int P, int U, int n) {
+  const int rc = solveF64ChunkRows(J, P, U, n);
+  if (rc < 4) {
+    return size_t(1) << 30; // does not fit
+  }
+  return (solveF64BaseDoubles(J, P, U, n) + ((size_t(n) * size_t(rc + 1) + 1) & ~size_t(1))) * sizeof(double);
+}
+
+hipError_t launchSolveF64(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const int32_t* solveList,
+    int n,
+    double* theta,
+    const SolveStateDev& st,
+    const FusedParams& fp,
+    double* Jg,
+    double* Hg,
+    hipStream_t stream) {
+  const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n);
+  if (lds > 160 * 1024) {
+    return hipErrorInvalidValue;
+  }
+  if (lds > 64 * 1024) {
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(solveF64Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+  }
+  hipLaunchKernelGGL(
+      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, solveF64ChunkRows(rig.J, rig.P, pb.U, n));
+  return hipGetLastError();
+}
+
+} // namespace mmx

@@ -98,6 +98,20 @@ hipError_t launchFusedSolve(
     long long* dbgClk,
     hipStream_t stream);
 
+// double-precision solve (mmx_f64.hip)
+size_t solveF64LdsBytes(int J, int P, int U, int n);
+hipError_t launchSolveF64(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const int32_t* solveList,
+    int n,
+    double* theta,
+    const SolveStateDev& st,
+    const FusedParams& fp,
+    double* Jg,
+    double* Hg,
+    hipStream_t stream);
+
 size_t fkJacobianLdsBytes(int J, int P, int U);
 // store-only counterpart of the J-assembly kernel (profiling aid; see storePatternKernel)
 hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent);

@@ -106,6 +106,27 @@ int main() {
   }
   std::printf("shared character: max relative pose-parameter difference vs golden %.3e\n", worst);
 
+  // ---- the double instantiation through the same classes: 1e-10 against the golden double solve
+  {
+    std::vector<double> thd(size_t(kB) * kP);
+    for (size_t i = 0; i < thd.size(); ++i) {
+      thd[i] = double(k_theta0[i]);
+    }
+    solver.solve(thd);
+    for (int b = 0; b < kB; ++b) {
+      double num = 0.0, den = 0.0;
+      for (int p = 0; p < kP; ++p) {
+        const double d = thd[size_t(b) * kP + p] - k_theta_final[b * kP + p];
+        num += d * d, den += k_theta_final[b * kP + p] * k_theta_final[b * kP + p];
+      }
+      if (!(std::sqrt(num / den) <= 1e-10)) {
+        std::printf("FAIL: double solve, element %d differs from the golden double solve by %.3e (> 1e-10)\n", b, std::sqrt(num / den));
+        return 1;
+      }
+    }
+    std::printf("double instantiation: within 1e-10 of the golden double solve\n");
+  }
+
   // ---- the driver's solver classes on the same problem: SubsetGaussNewton / GaussNewtonQR with the line
   // search on must still land on the golden pose (the full step passes the Armijo test on this fixture)
   {

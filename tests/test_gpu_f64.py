@@ -1,0 +1,102 @@
+"""mmx_solve_f64 = SolverT<double>::solve with GaussNewtonSolverT<double> per element (gauss_newton_solver.cpp:
+315-316): against the oracle's double instantiation at 1e-10 relative on the pose parameters -- both run the
+same algorithm in the same precision, so what separates them is summation order only."""
+import numpy as np
+import pytest
+
+from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
+from momentum_amd._abi import MMX_STEP_LM_SCHEDULE, GnOptions
+from tests.helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+UNIT = 0.01
+
+
+def _gpu(torch, rig, cons, B, **kw):
+    from momentum_amd import capi
+
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(
+        t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+        t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+        cons.pos_function_weight, cons.ori_function_weight, **kw,
+    )  # fmt: skip
+    return rh, pb
+
+
+@pytest.mark.parametrize("mode", ["gn", "line_search_gn", "line_search_directional", "lm_schedule"])
+@pytest.mark.parametrize("which", ["humanoid72", "chain24"])
+def test_f64_solve_matches_oracle_double(torch_cuda, orc, which, mode):
+    torch = torch_cuda
+    if which == "humanoid72":
+        rig = make_humanoid72(unit=UNIT)
+        pp = op = humanoid72_landmark_joints(rig)
+        B, perturb = 24, 0.3
+    else:
+        rig = make_test_character(24)
+        pp, op, B, perturb = [23, 12, 5], [20], 8, 0.5
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=77, perturb=perturb, random_offsets=True, weights="random")
+    rh, pb = _gpu(torch, rig, cons, B)
+    kw = dict(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
+    if mode == "line_search_gn":
+        kw["do_line_search"] = 1
+    elif mode == "line_search_directional":
+        kw["do_line_search"] = 2
+    elif mode == "lm_schedule":
+        kw["step_rule"] = MMX_STEP_LM_SCHEDULE
+    opt = GnOptions.make(**kw)
+    theta = torch.from_numpy(th0.astype(np.float64)).to(pb.device)
+    out = pb.solve_f64(theta, opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    # the under-determined chain fixture amplifies rounding-order differences (cond ~ 1e4): 1e-8 there
+    assert rel.max() <= (1e-10 if which == "humanoid72" else 1e-8), rel
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]) and np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-9 * max(1.0, np.abs(href).max())
+    assert np.abs(out["error"].cpu().numpy() - ref["error"]).max() <= 1e-9 * max(1.0, np.abs(ref["error"]).max())
+
+
+def test_f64_solve_with_robust_loss_disabled_parameters_and_per_instance_parents(torch_cuda, orc):
+    torch = torch_cuda
+    rig = make_humanoid72(unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    B = 6
+    rng = np.random.default_rng(8)
+    pos_parents = [rng.choice(rig.num_joints, size=10).astype(np.int32) for _ in range(B)]
+    conss = [make_problem(rig, pos_parents[b], lm[:6], 1, seed=50 + b, perturb=0.3, weights="random")[0] for b in range(B)]
+    cat = lambda f: np.concatenate([getattr(c, f) for c in conss], axis=0)
+    cons = orc.Constraints(pos_parents[0], cat("pos_offset"), cat("pos_target"), cat("pos_weight"), lm[:6], cat("ori_offset"), cat("ori_target"), cat("ori_weight"),
+                           pos_function_weight=0.7, ori_function_weight=1.3, pos_loss=(0.0, 0.5), ori_loss=(1.0, 2.0))  # fmt: skip
+    rh, pb = _gpu(torch, rig, cons, B, pos_loss=(0.0, 0.5), ori_loss=(1.0, 2.0))
+    pb.set_instance_parents(np.stack(pos_parents), None)
+    en = np.ones(rig.num_params, np.uint8)
+    en[[2, 9, 30]] = 0
+    pb.set_enabled(en)
+    opt = GnOptions.make(min_iterations=8, max_iterations=8, threshold=1.0, regularization=0.05)
+    th0 = np.zeros((B, rig.num_params))
+    out = pb.solve_f64(torch.from_numpy(th0.copy()).to(pb.device), opt)
+    th = out["theta"].cpu().numpy()
+    for b in range(B):
+        c = orc.Constraints(pos_parents[b], cons.pos_offset[b], cons.pos_target[b], cons.pos_weight[b], lm[:6], cons.ori_offset[b], cons.ori_target[b],
+                            cons.ori_weight[b], pos_function_weight=0.7, ori_function_weight=1.3, pos_loss=(0.0, 0.5), ori_loss=(1.0, 2.0))  # fmt: skip
+        ref = orc.solve(rig, c, th0[b], opt, enabled=en, dtype="f64")
+        rel = np.linalg.norm(th[b] - ref["theta"]) / np.linalg.norm(ref["theta"])
+        assert rel <= 1e-10, (b, rel)
+        assert np.all(th[b][[2, 9, 30]] == 0)
+
+
+def test_f64_refuses_blocks_it_does_not_cover(torch_cuda):
+    from momentum_amd import capi
+    from momentum_amd._abi import ParameterLimit as PL
+
+    torch = torch_cuda
+    rig = make_test_character(5)
+    cons, th0, _ = make_problem(rig, [4], [3], 2, seed=1)
+    rh, pb = _gpu(torch, rig, cons, 2, limits=[PL.minmax(1, -0.1, 0.1)])
+    with pytest.raises(capi.MmxError) as ei:
+        pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), GnOptions.make())
+    assert "single precision" in str(ei.value)
