@@ -207,6 +207,7 @@ struct mmx_problem {
   // the same problem with the structurally zero columns dropped from the solve (explicit-Jacobian solver)
   int32_t solveN = 0;
   DevBuf dSolveListV1; // [solveN]
+  std::vector<int32_t> solveListV1; // host copy
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
@@ -600,7 +601,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
           }
         }
       }
-      if (numCells > 8 * rig->J) {
+      if (numCells > 7 * rig->J) { // the kernels park the cells in a first-moment array: kC1 (= 7) floats per joint
         return fail(MMX_ERR_UNSUPPORTED, "too many split H entries for the partial-cell scratch");
       }
       std::vector<int32_t> comb;
@@ -736,6 +737,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     }
     MMX_HIP(upload(pb->dSolveListV1, list));
     pb->solveN = int32_t(list.size());
+    pb->solveListV1 = list;
   }
 
   return MMX_OK;
@@ -748,6 +750,18 @@ bool fusedUsable(const mmx_problem* pb) {
   }
   return pb->rig->J < 4096 &&
       mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rigDev.numLevels) + size_t(8) * size_t(pb->rig->J + pb->rig->P) <= 160 * 1024;
+}
+
+// H and g of the explicit-Jacobian solver from the tree moments instead of the dense J (treeNormalEquationsKernel):
+// position / orientation rows with batch-shared parents only, the same solve list on both sides
+bool treeNormalEquationsUsable(const mmx_problem* pb) {
+  const char* e = getenv("MMX_TREE_NE");
+  if (e != nullptr && e[0] == '0') {
+    return false;
+  }
+  return !pb->instPos && !pb->instOri && pb->dev.G == 0 && pb->dev.NE == 0 && pb->M == 3 * pb->U && pb->U > 0 && pb->fdev.n > 0 &&
+      pb->fdev.n <= 512 && pb->fdev.nsrc < 4096 && pb->fused.solveList == pb->solveListV1 &&
+      mmx::treeNormalEquationsLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc) <= 160 * 1024 - 64;
 }
 
 bool wantLegacySolver() {
@@ -1641,6 +1655,17 @@ int32_t mmx_eval_normal_equations(
   }
   MMX_HIP(mmx::launchFkJacobian(
       pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), err_dev, nullptr, nullptr, s));
+  {
+    const char* e = getenv("MMX_TREE_NE"); // parity hook: "force" = the tree-moment kernel (lower triangle of the solve-list system)
+    if (e != nullptr && std::string(e) == "force") {
+      if (!treeNormalEquationsUsable(pb) || pb->solveN != pb->dev.n) {
+        return fail(MMX_ERR_UNSUPPORTED, "MMX_TREE_NE=force: problem outside the tree-moment kernel's scope (or structurally zero columns present)");
+      }
+      MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
+      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, s));
+      return MMX_OK;
+    }
+  }
   MMX_HIP(mmx::launchNormalEquations(
       pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), jtj_dev, jtr_dev, nullptr, false, s));
   return MMX_OK;
@@ -1838,6 +1863,7 @@ static int32_t solveImpl(
     MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
     sp.clk = pb->sClk.as<long long>();
   }
+  const bool treeFromMoments = treeNormalEquationsUsable(pb);
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
     MMX_ZONE("GaussNewtonSolverT::doIteration");
@@ -1845,9 +1871,15 @@ static int32_t solveImpl(
       MMX_ZONE("Get JtJ and JtR");
       MMX_HIP(mmx::launchFkJacobian(
           pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
-      MMX_HIP(mmx::launchNormalEquations(
-          ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done,
-          mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 /* the in-HBM factorisation reads the lower triangle only */, s));
+      const bool lowerOnly = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024; // the in-HBM factorisation reads the lower triangle only
+      if (lowerOnly && treeFromMoments) {
+        // wide systems: H and g from the tree moments, O(n^2) per instance, J not read (J itself is still
+        // assembled above: the Cholesky step's refinement streams it)
+        MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, s));
+      } else {
+        MMX_HIP(mmx::launchNormalEquations(
+            ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, lowerOnly, s));
+      }
     }
     {
       MMX_ZONE("Dense gauss newton step");

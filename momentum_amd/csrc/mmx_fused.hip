@@ -1639,6 +1639,280 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
 }
 
 // ---------------------------------------------------------------------------------------------
+// treeNormalEquationsKernel: H = J^T J and g = J^T r of ONE Gauss-Newton iteration from the tree moments
+// (phases A-G of fusedSolveKernel: same formulas, same slot tables, same matrix-core tile products), written to
+// HBM for the explicit-Jacobian solver's Cholesky step -- for systems beyond the fused kernel's LDS budget
+// (BASELINE configs[4]: n = 260, 153 tiles).  O(n^2) work per instance instead of the M n^2 of the product
+// J^T J (normalEquationsMfmaKernel: 7.0 ms per 8192 instances at cfg5), and J is not read.  One workgroup per
+// instance, the batch-shared integer tables straight from L2 (no LDS copies: one workgroup per CU at this
+// size anyway).  Position / orientation constraints with batch-shared parents; anything else keeps the dense
+// kernel (launchTreeNormalEquations returns false).
+// Output: H[i * n + j] for i >= j (what choleskyStepGlobalKernel reads), no lambda; g[n].
+// ---------------------------------------------------------------------------------------------
+#if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
+struct TreeNeLds {
+  float *th, *js, *alt, *up, *uy, *us, *own1, *own2, *sub1, *sub2, *umom, *jd, *srcT;
+  int *jlA, *jlB, *span; // span[slot] = tin | tout << 16
+  double* red;
+};
+
+__host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc, TreeNeLds* out, float* base) {
+  size_t off = 0;
+  auto take = [&](size_t count) {
+    const size_t o = off;
+    off += alignUp4(count);
+    return o;
+  };
+  const size_t oTh = take(P), oJs = take(size_t(kJs) * J), oAlt = take(size_t(kAlt) * J), oJl = take(2 * size_t(J));
+  const size_t oUp = take(3 * size_t(U)), oUy = take(3 * size_t(U)), oUs = take(U);
+  const size_t oOwn1 = take(size_t(kC1) * J), oOwn2 = take(size_t(kC2) * J);
+  // one region, two lives: joint parameters (FK) and the per-unit moments (D), then the subtree sums
+  const size_t life1 = alignUp4(7 * size_t(J)) > alignUp4(size_t(kUmom) * U) ? alignUp4(7 * size_t(J)) : alignUp4(size_t(kUmom) * U);
+  const size_t life2 = alignUp4(size_t(kC1) * J) + alignUp4(size_t(kC2) * J);
+  const size_t oR = take(life1 > life2 ? life1 : life2);
+  const size_t oSrc = take(size_t(kSrcCh) * size_t(srcStrideFor(nsrc)));
+  const size_t oSpan = take(nsrc);
+  const size_t oRed = take(16);
+  if (out != nullptr) {
+    out->span = reinterpret_cast<int*>(base + oSpan);
+    out->th = base + oTh, out->js = base + oJs, out->alt = base + oAlt;
+    out->jlA = reinterpret_cast<int*>(base + oJl), out->jlB = out->jlA + J;
+    out->up = base + oUp, out->uy = base + oUy, out->us = base + oUs;
+    out->own1 = base + oOwn1, out->own2 = base + oOwn2;
+    out->jd = base + oR, out->umom = base + oR;
+    out->sub1 = base + oR, out->sub2 = base + oR + alignUp4(size_t(kC1) * J);
+    out->srcT = base + oSrc;
+    out->red = reinterpret_cast<double*>(base + oRed);
+  }
+  return off;
+}
+
+__global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
+    RigDev rig,
+    ProblemDev pb,
+    FusedDev fd,
+    const float* __restrict__ theta, // [B][P]
+    float* __restrict__ jtj, // [B][n*n], lower triangle written
+    float* __restrict__ jtr, // [B][n]
+    const int32_t* __restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (done != nullptr && done[b] != 0) {
+    return;
+  }
+  selectInstanceRig(rig, b);
+  const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
+  const int NB = (n + 15) >> 4, NP = 16 * NB, T = NB * (NB + 1) / 2;
+  TreeNeLds t;
+  treeNeLdsFloats(J, P, U, nsrc, &t, smem);
+  // the fused kernel's helpers work on these views; here the tables stay where they are (L2)
+  FusedLds s{};
+  s.th = t.th, s.js = t.js, s.alt = t.alt, s.jlA = t.jlA, s.jlB = t.jlB, s.jd = t.jd;
+  s.up = t.up, s.uy = t.uy, s.us = t.us, s.own1 = t.own1, s.own2 = t.own2, s.sub1 = t.sub1, s.sub2 = t.sub2, s.umom = t.umom;
+  s.srcT = t.srcT, s.red = t.red;
+  RigView rv;
+  rv.J = J, rv.P = P, rv.R = rig.R, rv.numLevels = rig.numLevels, rv.jumpRounds = rig.jumpRounds;
+  rv.parent = rig.parent, rv.preRot = rig.preRot, rv.offset = rig.offset;
+  rv.ptOuter = rig.ptOuter, rv.ptInner = rig.ptInner, rv.ptValue = rig.ptValue, rv.ptOffsets = rig.ptOffsets;
+  rv.levelOrder = rig.levelOrder, rv.levelStart = rig.levelStart;
+  FusedView fv;
+  fv.U = U, fv.Kp = fd.Kp, fv.subSize = fd.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = fd.loadedPos, fv.numLoaded = fd.numLoaded;
+  fv.colToSolve = nullptr, fv.unitPos = pb.unitTin, fv.posUnitStart = fd.posUnitStart, fv.posUnits = fd.posUnits, fv.solveList = fd.solveList;
+  for (int i = tid; i < P; i += 256) {
+    s.th[i] = theta[size_t(b) * P + i];
+  }
+  for (int e = tid; e < nsrc; e += 256) {
+    t.span[e] = fd.srcs[e].tin | (fd.srcs[e].tout << 16);
+  }
+  __syncthreads();
+  // ---- A, B: forward kinematics with rotation axes
+  blockFk(rv, s, s.th, tid, true);
+  // ---- C: units
+  for (int u = tid; u < U; u += 256) {
+    const Unit un = evalUnit(pb, s.js, b, u);
+    s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
+    const float sg2 = un.sigma * un.sigma;
+    s.uy[3 * u] = sg2 * un.f.x, s.uy[3 * u + 1] = sg2 * un.f.y, s.uy[3 * u + 2] = sg2 * un.f.z;
+    s.us[u] = un.sigma;
+  }
+  __syncthreads();
+  // ---- D: own sums (per-unit moments -> per-joint sums), then subtree sums (the moments' scratch is dead by then)
+  ownSums(fv, s, s.umom, U, tid);
+  __syncthreads();
+  treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
+  treeSum<kC2Used, true, kC2>(fv, s.own2, s.sub2, J, wave, lane);
+  __syncthreads();
+  // ---- E: per-slot tables (see fusedSolveKernel phase E)
+  const int sst = srcStrideFor(nsrc);
+  float* srcD = s.srcT;
+  float* srcA = s.srcT + 7 * sst;
+  float* srcG = s.srcT + 14 * sst;
+  for (int e = tid; e < nsrc; e += 256) {
+    const ColumnSourceDev cs = fd.srcs[e];
+    const float* a = s.js + kJs * cs.joint;
+    const float* sb = s.sub2 + kC2 * cs.tin;
+    const F3 ta{a[0], a[1], a[2]};
+    const float m0 = sb[0];
+    const F3 m1{sb[1], sb[2], sb[3]};
+    F3 al, bv{0.f, 0.f, 0.f}, g0, ax;
+    float bs = 0.f, tr;
+    if (cs.dof < 3) {
+      al = transAxisCol(s.js, cs.parent, cs.dof);
+      g0 = m0 * al;
+      ax = cross(m1, al);
+      tr = dot(al, m1);
+    } else if (cs.dof < 6) {
+      const float* w = a + 8 + 3 * (cs.dof - 3);
+      const F3 om{w[0], w[1], w[2]};
+      al = F3{0.f, 0.f, 0.f} - cross(om, ta);
+      bv = om;
+      g0 = m0 * al + cross(om, m1);
+      const float t2 = (sb[4] + sb[7] + sb[9]) + (sb[10] + sb[13] + sb[15]);
+      const F3 Mo{
+          (sb[4] + sb[10]) * om.x + (sb[5] + sb[11]) * om.y + (sb[6] + sb[12]) * om.z,
+          (sb[5] + sb[11]) * om.x + (sb[7] + sb[13]) * om.y + (sb[8] + sb[14]) * om.z,
+          (sb[6] + sb[12]) * om.x + (sb[8] + sb[14]) * om.y + (sb[9] + sb[15]) * om.z};
+      ax = cross(m1, al) + (t2 * om - Mo);
+      tr = dot(al, m1);
+    } else {
+      al = F3{0.f, 0.f, 0.f} - kLn2 * ta;
+      bs = kLn2;
+      g0 = m0 * al + kLn2 * m1;
+      ax = cross(m1, al);
+      tr = dot(al, m1) + kLn2 * (sb[4] + sb[7] + sb[9]);
+    }
+    const float w = cs.weight;
+    float* d = srcD + e;
+    d[0] = w * g0.x, d[sst] = w * g0.y, d[2 * sst] = w * g0.z;
+    d[3 * sst] = w * ax.x, d[4 * sst] = w * ax.y, d[5 * sst] = w * ax.z;
+    d[6 * sst] = w * tr;
+    float* o = srcA + e;
+    o[0] = w * al.x, o[sst] = w * al.y, o[2 * sst] = w * al.z;
+    o[3 * sst] = w * bv.x, o[4 * sst] = w * bv.y, o[5 * sst] = w * bv.z;
+    o[6 * sst] = w * bs;
+    srcG[e] = w * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
+  }
+  __syncthreads();
+  // ---- F: g
+  for (int c = tid; c < n; c += 256) {
+    float acc = srcG[c];
+    const int e1 = NP + fd.srcStart[c + 1];
+    for (int e = NP + fd.srcStart[c]; e < e1; ++e) {
+      acc += srcG[e];
+    }
+    jtr[size_t(b) * n + c] = acc;
+  }
+  // ---- G: the tiles of the lower triangle, two masked matrix-core products each, straight to HBM
+  float* Hb = jtj + size_t(b) * size_t(n) * size_t(n);
+  {
+    const int i = lane & 15, gq = lane >> 4;
+    const int k1 = gq < 3 ? 4 + gq : 6;
+    const float z = gq == 3 ? 0.f : 1.f;
+    for (int tt = wave; tt < T; tt += 4) {
+      int I, Jc;
+      tileDecode(tt, I, Jc);
+      const int ri = 16 * I + i, ci = 16 * Jc + i;
+      const float dI0 = srcD[gq * sst + ri], aI0 = srcA[gq * sst + ri], dJ0 = srcD[gq * sst + ci], aJ0 = srcA[gq * sst + ci];
+      const float dI1 = z * srcD[k1 * sst + ri], aI1 = z * srcA[k1 * sst + ri], dJ1 = srcD[k1 * sst + ci], aJ1 = srcA[k1 * sst + ci];
+      const int spanC = t.span[ci];
+      const int tinC = spanC & 0xffff, toutC = spanC >> 16;
+      v4f Pm{0.f, 0.f, 0.f, 0.f}, Qm{0.f, 0.f, 0.f, 0.f};
+      Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(dI0, aJ0, Pm, 0, 0, 0);
+      Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(aI0, dJ0, Qm, 0, 0, 0);
+      Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(dI1, aJ1, Pm, 0, 0, 0);
+      Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(aI1, dJ1, Qm, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * I + 4 * gq + q, col = ci;
+        const int spanR = t.span[row];
+        const int tinR = spanR & 0xffff, toutR = spanR >> 16;
+        const bool rowDeep = tinC <= tinR && tinR < toutC;
+        const bool colDeep = tinR <= tinC && tinC < toutR;
+        if (row < n && col <= row) {
+          Hb[size_t(row) * n + col] = rowDeep ? Pm[q] : (colDeep ? Qm[q] : 0.f);
+        }
+      }
+    }
+  }
+  // ---- the pairs that involve an extra source of a shared parameter: term records, one thread per entry run
+  if (fd.termRounds > 0) {
+    __threadfence_block();
+    __syncthreads();
+    float h = 0.f;
+    auto entryAddr = [&](uint32_t y) { // tile-region offset of the fused kernel -> (row, col) of H
+      int I, Jc;
+      tileDecode(int(y >> 8), I, Jc);
+      const int r = (y >> 4) & 15, c = int(((((y >> 2) & 3) ^ (r >> 2)) & 3) << 2) | int(y & 3);
+      return Hb + size_t(16 * I + r) * n + (16 * Jc + c);
+    };
+    for (int k = 0; k < fd.termRounds; ++k) {
+      const uint4* rp = fd.gTerms + size_t(k) * 256 + tid;
+      const uint2 rec = *reinterpret_cast<const uint2*>(rp);
+      const uint32_t x = rec.x;
+      if (x & (1u << 26)) {
+        const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
+        float hj = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch) {
+          hj += srcD[ch * sst + deep] * srcA[ch * sst + anc];
+        }
+        h = (x & (1u << 24)) ? hj : h + hj;
+        if (x & (1u << 25)) {
+          const uint32_t y = rec.y;
+          if (y & (1u << 30)) {
+            s.own1[y & 0xffff] = h; // partial cell of a split entry (the own sums are dead)
+          } else {
+            *entryAddr(y) += h;
+          }
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < fd.numComb; i += 256) {
+      const int dest = fd.comb[3 * i], first = fd.comb[3 * i + 1], cnt = fd.comb[3 * i + 2];
+      float* hp = entryAddr(uint32_t(dest));
+      float v = *hp;
+      for (int c = 0; c < cnt; ++c) {
+        v += s.own1[first + c];
+      }
+      *hp = v;
+    }
+  }
+}
+
+size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc) {
+  return treeNeLdsFloats(J, P, U, nsrc, nullptr, nullptr) * sizeof(float);
+}
+
+hipError_t launchTreeNormalEquations(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    const float* theta,
+    float* jtj,
+    float* jtr,
+    const int32_t* done,
+    hipStream_t stream) {
+  const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc);
+  if (lds > 160 * 1024 - 64) {
+    return hipErrorInvalidValue;
+  }
+  static size_t attrBytes = 64 * 1024;
+  if (lds > attrBytes) {
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(treeNormalEquationsKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    attrBytes = lds;
+  }
+  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done);
+  return hipGetLastError();
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 #if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels) {
   const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);

@@ -85,6 +85,17 @@ struct FusedParams {
 };
 
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels);
+// H = J^T J, g = J^T r from the tree moments for the explicit-Jacobian solver (mmx_fused.hip, treeNormalEquationsKernel)
+size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc);
+hipError_t launchTreeNormalEquations(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    const float* theta,
+    float* jtj,
+    float* jtr,
+    const int32_t* done,
+    hipStream_t stream);
 int fusedBlocksFor(int n); // number of 16-wide blocks the fused kernel is instantiated for, or -1
 hipError_t launchFusedSolve(
     const RigDev& rig,

@@ -483,3 +483,56 @@ def test_tensor_ik_default_options(torch_cuda, orc):
     assert np.all(np.diff(h[:, : it.min()], axis=1) <= 1e-6 * np.abs(h[:, : it.min() - 1]) + 1e-12)  # line search: monotone
     assert np.all(out["status"].cpu().numpy() == 0)
     del th
+
+
+def test_tree_moment_normal_equations_match_the_dense_product_on_the_wide_rig(torch_cuda, orc, monkeypatch):
+    """BASELINE configs[4] shape (300 joints, 150 position + 50 orientation constraints): H = J^T J and g = J^T r
+    built from the tree moments (treeNormalEquationsKernel, what the explicit-Jacobian solver uses for wide
+    systems) against the matrix-core product of the dense J (normalEquationsMfmaKernel) and against the oracle's
+    double J; then the solve through either, same pose parameters."""
+    from momentum_amd import make_rig300
+
+    torch = torch_cuda
+    rig = make_rig300(seed=12345, unit=UNIT)
+    rng = np.random.default_rng(77)
+    pp = rng.choice(rig.num_joints, size=150, replace=False)
+    op = rng.choice(rig.num_joints, size=50, replace=False)
+    B = 3
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=555, perturb=0.2, weights="random")
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    import ctypes as C
+
+    from momentum_amd import capi
+
+    buf = np.zeros(rig.num_params, np.int32)
+    nn = C.c_int32(0)
+    capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(nn), None))
+    lst = buf[: nn.value]
+    en = np.zeros(rig.num_params, np.uint8)
+    en[lst] = 1  # only structurally non-zero columns enabled: the enabled system IS the solve-list system
+    pb.set_enabled(en)
+    theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
+    td = torch.from_numpy(theta).to(pb.device)
+    monkeypatch.delenv("MMX_TREE_NE", raising=False)
+    Hd, gd, _ = pb.normal_equations(td)
+    monkeypatch.setenv("MMX_TREE_NE", "force")
+    Ht, gt, _ = pb.normal_equations(td)
+    monkeypatch.delenv("MMX_TREE_NE", raising=False)
+    Hd, Ht, gd, gt = Hd.cpu().numpy(), Ht.cpu().numpy(), gd.cpu().numpy(), gt.cpu().numpy()
+    for b in range(B):
+        Jm, r, e = orc.eval_jacobian(rig, cons.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
+        Je = Jm[:, lst]
+        H, g = Je.T @ Je, Je.T @ r
+        scale = max(1.0, np.abs(H).max())
+        assert np.abs(np.tril(Ht[b]) - np.tril(H)).max() <= 5e-5 * scale, np.abs(np.tril(Ht[b]) - np.tril(H)).max() / scale
+        assert np.abs(np.tril(Hd[b]) - np.tril(H)).max() <= 5e-5 * scale
+        assert np.abs(gt[b] - g).max() <= 5e-5 * max(1.0, np.abs(g).max())
+    opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05)
+    out_tree = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)["theta"].cpu().numpy()
+    monkeypatch.setenv("MMX_TREE_NE", "0")
+    out_dense = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)["theta"].cpu().numpy()
+    monkeypatch.delenv("MMX_TREE_NE", raising=False)
+    ref = orc.solve_batch(rig, cons, th0, opt, enabled=en, dtype="f64")
+    for th in (out_tree, out_dense):
+        rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+        assert rel.max() <= 2e-5, rel
