@@ -209,7 +209,7 @@ struct mmx_problem {
   DevBuf dSolveListV1; // [solveN]
   std::vector<int32_t> solveListV1; // host copy
   // scratch
-  DevBuf sJac, sRes, sErr, sJtj, sJtr, sThetaInit, sTheta;
+  DevBuf sJac, sRes, sErr, sJtj, sJtr, sFactor, sThetaInit, sTheta;
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
   DevBuf sJacF64, sHessF64; // scratch of the double-precision solve
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
@@ -1864,6 +1864,11 @@ static int32_t solveImpl(
     sp.clk = pb->sClk.as<long long>();
   }
   const bool treeFromMoments = treeNormalEquationsUsable(pb);
+  float* factorScratch = nullptr; // wide systems: the left-looking Cholesky step keeps L in its own tile-major scratch
+  if (mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 && !(getenv("MMX_CHOL_RIGHT_LOOKING") != nullptr && getenv("MMX_CHOL_RIGHT_LOOKING")[0] == '1')) {
+    MMX_HIP(pb->sFactor.ensure(size_t(B) * mmx::choleskyFactorFloats(ds.n) * sizeof(float)));
+    factorScratch = pb->sFactor.as<float>();
+  }
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
     MMX_ZONE("GaussNewtonSolverT::doIteration");
@@ -1885,7 +1890,7 @@ static int32_t solveImpl(
       MMX_ZONE("Dense gauss newton step");
       MMX_HIP(mmx::launchCholeskyStep(
           ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), pb->sErr.as<double>(),
-          theta_dev, st, sp, s));
+          theta_dev, st, sp, factorScratch, s));
     }
     if (deferred) {
       MMX_ZONE("Line search");

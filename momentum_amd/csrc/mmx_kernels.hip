@@ -18,6 +18,7 @@
 #include "mmx_kernels.hpp"
 
 #include <cfloat>
+#include <type_traits>
 #include <cstdlib>
 
 namespace mmx {
@@ -2171,6 +2172,477 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
 }
 
 // =============================================================================================
+// Kernel 3c: the large-system GN step, left-looking.  Same step as choleskyStepGlobalKernel, which it
+// replaces (that one stays as the MMX_CHOL_RIGHT_LOOKING=1 cross-check); what changed is the order of
+// the memory traffic:
+//   - H is read once and never written: block column k of the factor is
+//       C(I,k) = H(I,k) [+ lambda] - sum_{j<k} L(I,j) L(k,j)^T
+//     with ALL operand loads independent of each other (finished tiles only), so they go out in batches
+//     of twenty 16-byte requests per lane; no load ever waits for a store (the right-looking form re-read
+//     every trailing tile right after writing it: ~40 dependent round trips per block column),
+//   - L goes to its own tile-major scratch ([tile (I,j)][16][16] row-major, tile (I,j) at I(I+1)/2 + j):
+//     a lane's MFMA operand is one aligned 16-byte load whatever n is, a row block is one contiguous run,
+//   - the forward substitution of g rides along with the factorisation (y_k from row block k, which is
+//     complete when column k is), so the first solve is the backward sweep only,
+//   - both sweeps prefetch the next block's tiles before the 16-step chain of the current one,
+//   - the refinement reads J ONCE: `chunkRows` rows at a time through LDS, w = r - J d (double sums) for
+//     those rows, then their contribution to rho = J^T w; the next chunk's loads are in flight meanwhile.
+// dynamic LDS = max(NP*16, n*(chunkRows+1)) + 4*NP + chunkRows + 2*256 + 8 floats.
+// =============================================================================================
+constexpr int kJb = 4; // finished block columns per trip of the tile products (4 tiles x kJb + kJb 16-byte loads in flight per lane)
+constexpr int kChunkLoads = 10; // 16-byte loads a thread keeps in flight for the next J chunk (n * chunkRows / 4 <= 256 * 10)
+
+__global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jac, // [B][M*P]
+    const float* __restrict__ res, // [B][M]
+    const float* __restrict__ jtj, // [B][n*n] H, lower triangle, read only
+    const float* __restrict__ jtr, // [B][n]
+    float* __restrict__ factor, // [B][NB(NB+1)/2][256] L, tile-major
+    const double* __restrict__ errIter,
+    float* __restrict__ theta,
+    SolveStateDev st,
+    StepParams sp,
+    int chunkRows) { // 16 or 32
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (st.done[b] != 0) {
+    return;
+  }
+  const int n = pb.n, M = pb.M;
+  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
+  const int NP = (n + 15) & ~15, NB = NP >> 4;
+  const int cs = chunkRows + 1; // LDS stride of one J column inside a chunk (odd)
+  const int panFloats = max(NP * 16, n * cs);
+  float* pan = smem; // block column being factored (swizzled tiles) / J chunk [n][cs]
+  float* g = pan + ((panFloats + 3) & ~3); // g, then y = L^-1 g
+  float* d0 = g + NP;
+  float* rho = d0 + NP;
+  float* invDiag = rho + NP;
+  float* wch = invDiag + NP; // [chunkRows] w of the current chunk
+  double* part = reinterpret_cast<double*>(wch + ((chunkRows + 1) & ~1)); // [256] partial sums of w
+  int* flags = reinterpret_cast<int*>(part + 256);
+  const float* H = jtj + size_t(b) * n * n;
+  float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+  if (tid == 0) {
+    flags[0] = 0;
+  }
+  for (int i = tid; i < NP; i += 256) {
+    g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
+  }
+  __syncthreads();
+  long long tclk = clock64();
+  const int lrow = lane & 15, lkg = lane >> 4; // operand layout of v_mfma_f32_16x16x4_f32: row, k group
+  const int opOff = lrow * 16 + 4 * lkg; // a lane's 16 bytes inside a row-major tile
+
+  for (int k = 0; k < NB; ++k) {
+    const int nt = NB - k;
+    // (a) the wave's tiles of block column k (I = k + wave, + 4, ...), four per trip
+    for (int I0 = k + wave; I0 < NB; I0 += 16) {
+      v4f c[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int I = I0 + 4 * t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * I + 4 * lkg + q, cc = 16 * k + lrow;
+          const float v = H[size_t(min(r, n - 1)) * n + min(cc, n - 1)]; // clamped: unconditional, independent loads
+          c[t][q] = (r < n && cc < n) ? (r > cc ? v : (r == cc ? v + lambda : 0.f)) : (r == cc ? 1.f : 0.f);
+        }
+      }
+      for (int j0 = 0; j0 < k; j0 += kJb) {
+        float4 bv[kJb], av[4][kJb];
+#pragma unroll
+        for (int u = 0; u < kJb; ++u) {
+          const int j = min(j0 + u, k - 1);
+          bv[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(k, j)) * 256 + opOff);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            av[t][u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(min(I0 + 4 * t, NB - 1), j)) * 256 + opOff);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kJb; ++u) {
+          if (j0 + u < k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[t][u].x, bv[u].x, c[t], 0, 0, 0);
+              c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[t][u].y, bv[u].y, c[t], 0, 0, 0);
+              c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[t][u].z, bv[u].z, c[t], 0, 0, 0);
+              c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[t][u].w, bv[u].w, c[t], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int I = I0 + 4 * t;
+        if (I < NB) {
+          float* Tl = pan + 256 * (I - k);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Tl[tileAddr(4 * lkg + q, lrow)] = c[t][q];
+          }
+        }
+      }
+    }
+    // the forward substitution rides along: s_k = g_k - sum_{j<k} L(k,j) y_j (the wave with the fewest tiles)
+    if (wave == 3 && k > 0) {
+      float acc = 0.f;
+      for (int j0 = 0; j0 < k; j0 += 8) {
+        float4 lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          lv[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(k, min(j0 + u, k - 1))) * 256 + opOff);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (j0 + u < k) {
+            acc = dot4(lv[u], *reinterpret_cast<const float4*>(g + 16 * (j0 + u) + 4 * lkg), acc);
+          }
+        }
+      }
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      if (lane < 16) {
+        g[16 * k + lane] -= acc;
+      }
+    }
+    __syncthreads();
+    MMX_SCLK(6)
+    // (b) panel factorisation (mmx_fused.hip phase H): lanes 0-15 of every wave the diagonal block,
+    // redundantly; lanes 16-63 forty-eight rows below it; pivots by v_readlane
+    {
+      float* Dk = pan;
+      const bool diagLane = lane < 16;
+      const int prow = 16 + 48 * wave + (lane - 16);
+      const bool active = diagLane || prow < 16 * nt;
+      float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
+      const int trow = diagLane ? lane : (prow & 15);
+      float a[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+        a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+      }
+      float bi = g[16 * k + lrow]; // s_k
+      __syncthreads();
+      float invd = 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float djj = readLaneF(a[j], j);
+        bad = bad || !(djj > 0.f);
+        const float inv = __builtin_amdgcn_rsqf(djj);
+        a[j] *= inv;
+        if (lane == j) {
+          invd = inv;
+        }
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+          a[c] -= a[j] * readLaneF(a[j], c);
+        }
+      }
+      if (diagLane) {
+        if (wave == 0) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
+          }
+          invDiag[16 * k + lane] = invd;
+          if (bad) {
+            flags[0] = 1;
+          }
+        }
+      } else if (active) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          Tl[tileAddr(trow, c)] = a[c];
+        }
+      }
+      if (wave == 0) { // L_kk y_k = s_k with the rows still in registers
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float yj = readLaneF(bi, j) * readLaneF(invd, j);
+          bi = (lane == j) ? yj : (j < lane ? bi - a[j] * yj : bi);
+        }
+        if (lane < 16) {
+          g[16 * k + lane] = bi;
+        }
+      }
+      __syncthreads();
+      for (int pr = 16 + 192 + tid; pr < 16 * nt; pr += 256) { // rows beyond 4 x 48: substitution
+        float* Tr = pan + 256 * (pr >> 4);
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = ldsRow4(Tr, pr & 15, q);
+          x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float sum = x[j];
+#pragma unroll
+          for (int c = 0; c < j; ++c) {
+            sum -= x[c] * Dk[tileAddr(j, c)];
+          }
+          x[j] = sum * invDiag[16 * k + j];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          Tr[tileAddr(pr & 15, c)] = x[c];
+        }
+      }
+      if (16 * nt > 16 + 192) {
+        __syncthreads();
+      }
+    }
+    MMX_SCLK(7)
+    // (c) every finished tile is written once
+    for (int I = k + wave; I < NB; I += 4) {
+      *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k)) * 256 + opOff) = ldsRow4(pan + 256 * (I - k), lrow, lkg);
+    }
+    __syncthreads(); // the panel buffer is reused; the tiles are visible to the workgroup
+    MMX_SCLK(1)
+  }
+  const bool bad = flags[0] != 0;
+
+  // substitutions on the tile-major factor.  forward: L y = x, column by column (after y_k every row below
+  // subtracts block k's sixteen columns); backward: L^T z = y, row block by row block.  The tiles of the
+  // NEXT step are requested before the sixteen-step chain of the current one.
+  auto sweep = [&](float* x, auto direction) {
+    constexpr bool forward = decltype(direction)::value;
+    float dg[16] = {}, dgNext[16] = {}, pv[2][16] = {}, pvNext[2][16] = {};
+    auto request = [&](int k, float (&dgo)[16], float (&pvo)[2][16]) {
+      if (k < 0 || k >= NB) {
+        return;
+      }
+      const float* Dt = L + size_t(tileIndex(k, k)) * 256;
+      if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { // forward: row `lrow` of the diagonal tile; backward: its column
+          dgo[c] = forward ? Dt[lrow * 16 + c] : Dt[c * 16 + lrow];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (forward) {
+          const int r = 16 * (k + 1) + tid + 256 * m;
+          const float* Tr = L + size_t(tileIndex(min(r, NP - 1) >> 4, k)) * 256 + (r & 15) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(Tr + 4 * q);
+            pvo[m][4 * q] = v.x, pvo[m][4 * q + 1] = v.y, pvo[m][4 * q + 2] = v.z, pvo[m][4 * q + 3] = v.w;
+          }
+        } else {
+          const int cidx = min(tid + 256 * m, max(16 * k - 1, 0));
+          const float* Tc = L + size_t(tileIndex(k, cidx >> 4)) * 256 + (cidx & 15);
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            pvo[m][rr] = Tc[rr * 16];
+          }
+        }
+      }
+    };
+    const int kFirst = forward ? 0 : NB - 1, kStep = forward ? 1 : -1;
+    request(kFirst, dg, pv);
+    for (int k = kFirst; k >= 0 && k < NB; k += kStep) {
+      request(k + kStep, dgNext, pvNext);
+      if (wave == 0) {
+        float bi = x[16 * k + lrow];
+        const float invd = invDiag[16 * k + lrow];
+        if (forward) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float yj = readLaneF(bi, j) * readLaneF(invd, j);
+            bi = (lrow == j) ? yj : bi - dg[j] * yj; // dg[j] = 0 above the diagonal
+          }
+        } else {
+#pragma unroll
+          for (int j = 15; j >= 0; --j) {
+            const float xj = readLaneF(bi, j) * readLaneF(invd, j);
+            bi = (lrow == j) ? xj : bi - dg[j] * xj;
+          }
+        }
+        if (lane < 16) {
+          x[16 * k + lane] = bi;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int idx = tid + 256 * m;
+        const int target = forward ? 16 * (k + 1) + idx : idx;
+        if (forward ? target < NP : target < 16 * k) {
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            acc += pv[m][c] * x[16 * k + c];
+          }
+          x[target] -= acc;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        dg[c] = dgNext[c], pv[0][c] = pvNext[0][c], pv[1][c] = pvNext[1][c];
+      }
+    }
+  };
+  for (int i = tid; i < NP; i += 256) {
+    d0[i] = g[i];
+  }
+  __syncthreads();
+  MMX_SCLK(0)
+  if (!bad) {
+    sweep(d0, std::false_type{});
+  }
+  MMX_SCLK(2)
+  for (int rf = 0; rf < 3 && !bad && sp.refine; ++rf) { // see choleskyStepKernel
+    const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
+    const float* rb = res + size_t(b) * size_t(M);
+    const bool vec4 = (M & 3) == 0 && (reinterpret_cast<uintptr_t>(jac) & 15) == 0;
+    const int rowShift = chunkRows == 32 ? 5 : 4, quadShift = rowShift - 2, quadMask = (1 << quadShift) - 1;
+    const int items = n << quadShift; // (column, 16-byte row group) pairs of one chunk
+    const int slices = 256 >> rowShift, wRow = tid & (chunkRows - 1), wSlice = tid >> rowShift;
+    float4 nx[kChunkLoads];
+    float rNext = 0.f;
+    auto requestChunk = [&](int m0) {
+#pragma unroll
+      for (int i = 0; i < kChunkLoads; ++i) {
+        const int it = tid + 256 * i;
+        if (it < items) {
+          const int col = it >> quadShift, row = m0 + 4 * (it & quadMask);
+          const float* src = Jb + size_t(pb.enabledList[col]) * M;
+          if (vec4) {
+            nx[i] = row < M ? *reinterpret_cast<const float4*>(src + row) : float4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            nx[i].x = row < M ? src[row] : 0.f;
+            nx[i].y = row + 1 < M ? src[row + 1] : 0.f;
+            nx[i].z = row + 2 < M ? src[row + 2] : 0.f;
+            nx[i].w = row + 3 < M ? src[row + 3] : 0.f;
+          }
+        }
+      }
+      if (tid < chunkRows) {
+        rNext = m0 + tid < M ? rb[m0 + tid] : 0.f;
+      }
+    };
+    float racc[2] = {0.f, 0.f};
+    requestChunk(0);
+    for (int m0 = 0; m0 < M; m0 += chunkRows) {
+#pragma unroll
+      for (int i = 0; i < kChunkLoads; ++i) {
+        const int it = tid + 256 * i;
+        if (it < items) {
+          float* dst = pan + (it >> quadShift) * cs + 4 * (it & quadMask);
+          dst[0] = nx[i].x, dst[1] = nx[i].y, dst[2] = nx[i].z, dst[3] = nx[i].w;
+        }
+      }
+      const float rCur = rNext;
+      __syncthreads();
+      if (m0 + chunkRows < M) {
+        requestChunk(m0 + chunkRows);
+      }
+      // w = r - J d for the chunk's rows: the n-term sums cancel near the solution and bound what the
+      // refinement can recover -- double
+      {
+        double acc = 0.0;
+        for (int s2 = wSlice; s2 < n; s2 += slices) {
+          acc += double(pan[s2 * cs + wRow]) * double(d0[s2]);
+        }
+        part[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < chunkRows) {
+        double acc = double(rCur);
+        for (int s2 = 0; s2 < slices; ++s2) {
+          acc -= part[s2 * chunkRows + tid];
+        }
+        wch[tid] = m0 + tid < M ? float(acc) : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int col = tid + 256 * m;
+        if (col < n) {
+          float acc = racc[m];
+          for (int rr = 0; rr < chunkRows; ++rr) {
+            acc += pan[col * cs + rr] * wch[rr];
+          }
+          racc[m] = acc;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int col = tid + 256 * m;
+      if (col < NP) {
+        rho[col] = col < n ? racc[m] - lambda * d0[col] : 0.f;
+      }
+    }
+    __syncthreads();
+    MMX_SCLK(3)
+    sweep(rho, std::true_type{});
+    sweep(rho, std::false_type{});
+    MMX_SCLK(5)
+    float c2 = 0.f, d2 = 0.f;
+    for (int i = tid; i < n; i += 256) {
+      const float cr = rho[i], dn = d0[i] + cr;
+      d0[i] = dn;
+      c2 += cr * cr;
+      d2 += dn * dn;
+    }
+    c2 = waveReduceSumF(c2);
+    d2 = waveReduceSumF(d2);
+    __syncthreads();
+    if (lane == 0) {
+      rho[wave] = c2;
+      rho[4 + wave] = d2;
+    }
+    __syncthreads();
+    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
+    __syncthreads();
+    if (!again) {
+      break;
+    }
+  }
+  if (sp.delta != nullptr) {
+    for (int s2 = tid; s2 < n; s2 += 256) {
+      sp.delta[size_t(b) * n + s2] = bad ? 0.f : d0[s2];
+    }
+    if (tid == 0) {
+      sp.stepIter[b] = bad ? -(sp.iteration + 1) : sp.iteration + 1;
+    }
+  } else if (!bad) {
+    float* th = theta + size_t(b) * P;
+    for (int s2 = tid; s2 < n; s2 += 256) {
+      th[pb.enabledList[s2]] -= d0[s2];
+    }
+  }
+  if (tid == 0) { // SolverT::solve bookkeeping (solver.cpp:92-119)
+    const double e = errIter[b];
+    const double last = st.lastError[b];
+    if (st.errorHistory != nullptr) {
+      st.errorHistory[size_t(b) * sp.maxIterations + sp.iteration] = e;
+    }
+    st.iterations[b] = sp.iteration + 1;
+    st.finalError[b] = e;
+    if (bad) {
+      st.status[b] = 2;
+    }
+    const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
+    if (sp.iteration >= sp.minIterations && converged) {
+      st.done[b] = 1;
+    }
+    st.lastError[b] = e;
+  }
+}
+
+// =============================================================================================
 // Kernel 4: the parameter update of an iteration when it needs trial evaluations of the error --
 // GaussNewtonSolverT::updateParameters with doLineSearch (momentum/solver/gauss_newton_solver.cpp:
 // 283-313: Armijo backtracking, c1 = 1e-3, tau = 0.5, <= 10 trial steps, the last trial stays) or the
@@ -2619,9 +3091,32 @@ hipError_t launchCholeskyStep(
     float* theta,
     const SolveStateDev& st,
     const StepParams& sp,
+    float* factor,
     hipStream_t stream) {
   size_t lds = choleskyStepLdsBytes(pb.n, pb.M);
-  if (lds > 160 * 1024) { // large system: factor in global memory, one LDS panel at a time
+  if (lds > 160 * 1024 && factor != nullptr) { // large system: left-looking factor in its own tile-major scratch
+    const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
+    // rows of J per refinement chunk: 32 (every column contributes one full 128-byte line per chunk) while the
+    // chunk's loads fit the prefetch registers, else 16
+    static const int chunkPref = [] {
+      const char* e = getenv("MMX_CHOL_CHUNK_ROWS");
+      return e != nullptr ? atoi(e) : 32;
+    }();
+    const int chunkRows = chunkPref == 32 && size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
+    const size_t panFloats = (std::max(NP * 16, size_t(pb.n) * size_t(chunkRows + 1)) + 3) & ~size_t(3);
+    lds = (panFloats + 4 * NP + size_t(chunkRows) + 2 + 512 + 8) * sizeof(float);
+    if (lds > 64 * 1024) {
+      hipError_t rc = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(choleskyStepTiledKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (rc != hipSuccess) {
+        return rc;
+      }
+    }
+    hipLaunchKernelGGL(
+        choleskyStepTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, factor, errIter, theta, st, sp, chunkRows);
+    return hipGetLastError();
+  }
+  if (lds > 160 * 1024) { // the right-looking form, factored in place (MMX_CHOL_RIGHT_LOOKING=1)
     const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
     lds = (NP * 16 + 4 * NP + size_t(pb.M) + 8) * sizeof(float);
     if (lds > 64 * 1024) {

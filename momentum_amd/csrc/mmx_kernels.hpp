@@ -166,7 +166,12 @@ hipError_t launchCholeskyStep(
     float* theta,
     const SolveStateDev& st,
     const StepParams& sp,
+    float* factor, // wide systems: [B][choleskyFactorFloats(n)] scratch for the tile-major factor (null: factor H in place)
     hipStream_t stream);
+inline size_t choleskyFactorFloats(int n) {
+  const size_t nb = (size_t(n) + 15) / 16;
+  return nb * (nb + 1) / 2 * 256;
+}
 
 // applies the deferred step of the iteration: Armijo backtracking (GaussNewtonSolverT::updateParameters,
 // gauss_newton_solver.cpp:283-313) or the LM gain-ratio schedule (see fusedSolveKernel phase K)
