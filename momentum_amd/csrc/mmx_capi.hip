@@ -210,6 +210,7 @@ struct mmx_problem {
   std::vector<int32_t> solveListV1; // host copy
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sFactor, sThetaInit, sTheta;
+  DevBuf sTreeState, sDvec, sRhoVec, sRefState; // wide systems refined through the tree (no dense J)
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
   DevBuf sJacF64, sHessF64; // scratch of the double-precision solve
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
@@ -1614,13 +1615,15 @@ int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* 
 }
 
 namespace {
-int32_t ensureStepScratch(mmx_problem* pb) {
+int32_t ensureStepScratch(mmx_problem* pb, bool needJacobian = true) {
   const int32_t rcj = ensureJacobianScratch(pb);
   if (rcj != MMX_OK) {
     return rcj;
   }
   const size_t B = size_t(pb->B), M = size_t(pb->M), P = size_t(pb->rig->P), n = size_t(pb->dev.n);
-  MMX_HIP(pb->sJac.ensure(B * M * P * sizeof(float)));
+  if (needJacobian) {
+    MMX_HIP(pb->sJac.ensure(B * M * P * sizeof(float)));
+  }
   MMX_HIP(pb->sRes.ensure(B * std::max<size_t>(M, 1) * sizeof(float)));
   MMX_HIP(pb->sErr.ensure(B * sizeof(double)));
   MMX_HIP(pb->sJtj.ensure(B * n * n * sizeof(float)));
@@ -1662,7 +1665,7 @@ int32_t mmx_eval_normal_equations(
         return fail(MMX_ERR_UNSUPPORTED, "MMX_TREE_NE=force: problem outside the tree-moment kernel's scope (or structurally zero columns present)");
       }
       MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
-      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, s));
+      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, s));
       return MMX_OK;
     }
   }
@@ -1810,7 +1813,14 @@ static int32_t solveImpl(
   if (n > 512) {
     return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
   }
-  rc = ensureStepScratch(pb);
+  // Wide systems (the in-LDS Cholesky step does not fit) whose rows are position / orientation constraints only:
+  // normal equations from the tree moments, left-looking factor in HBM, refinement through the tree.  No dense J is
+  // written or read (MMX_TREE_REFINE=0: the refinement streams a dense J instead; MMX_TREE_NE=0: the dense product too).
+  const bool wide = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024;
+  const bool rightLooking = getenv("MMX_CHOL_RIGHT_LOOKING") != nullptr && getenv("MMX_CHOL_RIGHT_LOOKING")[0] == '1';
+  const bool treeFromMoments = treeNormalEquationsUsable(pb);
+  const bool treeRefine = wide && treeFromMoments && !rightLooking && !(getenv("MMX_TREE_REFINE") != nullptr && getenv("MMX_TREE_REFINE")[0] == '0');
+  rc = ensureStepScratch(pb, !treeRefine);
   if (rc != MMX_OK) {
     return rc;
   }
@@ -1863,34 +1873,63 @@ static int32_t solveImpl(
     MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
     sp.clk = pb->sClk.as<long long>();
   }
-  const bool treeFromMoments = treeNormalEquationsUsable(pb);
   float* factorScratch = nullptr; // wide systems: the left-looking Cholesky step keeps L in its own tile-major scratch
-  if (mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 && !(getenv("MMX_CHOL_RIGHT_LOOKING") != nullptr && getenv("MMX_CHOL_RIGHT_LOOKING")[0] == '1')) {
+  if (wide && !rightLooking) {
     MMX_HIP(pb->sFactor.ensure(size_t(B) * mmx::choleskyFactorFloats(ds.n) * sizeof(float)));
     factorScratch = pb->sFactor.as<float>();
+  }
+  const size_t NPs = (size_t(n) + 15) & ~size_t(15);
+  if (treeRefine) {
+    MMX_HIP(pb->sTreeState.ensure(size_t(B) * mmx::treeStateFloats(pb->rig->J, pb->fdev.U) * sizeof(float)));
+    MMX_HIP(pb->sDvec.ensure(size_t(B) * NPs * sizeof(float)));
+    MMX_HIP(pb->sRhoVec.ensure(size_t(B) * NPs * sizeof(float)));
+    MMX_HIP(pb->sRefState.ensure(size_t(B) * sizeof(int32_t)));
   }
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
     MMX_ZONE("GaussNewtonSolverT::doIteration");
-    {
-      MMX_ZONE("Get JtJ and JtR");
-      MMX_HIP(mmx::launchFkJacobian(
-          pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
-      const bool lowerOnly = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024; // the in-HBM factorisation reads the lower triangle only
-      if (lowerOnly && treeFromMoments) {
-        // wide systems: H and g from the tree moments, O(n^2) per instance, J not read (J itself is still
-        // assembled above: the Cholesky step's refinement streams it)
-        MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, s));
-      } else {
-        MMX_HIP(mmx::launchNormalEquations(
-            ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, lowerOnly, s));
+    if (treeRefine) {
+      {
+        MMX_ZONE("Get JtJ and JtR");
+        MMX_HIP(mmx::launchTreeNormalEquations(
+            pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, pb->sErr.as<double>(),
+            pb->sTreeState.as<float>(), s));
       }
-    }
-    {
       MMX_ZONE("Dense gauss newton step");
-      MMX_HIP(mmx::launchCholeskyStep(
-          ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), pb->sErr.as<double>(),
-          theta_dev, st, sp, factorScratch, s));
+      MMX_HIP(mmx::launchCholeskyFactorTiled(
+          ds, pb->rig->P, pb->sJtj.as<float>(), pb->sJtr.as<float>(), factorScratch, pb->sDvec.as<float>(), pb->sRefState.as<int32_t>(),
+          pb->sErr.as<double>(), theta_dev, st, sp, s));
+      // up to three refinement rounds; an instance whose correction fell below 1e-3 of its step applies the step and
+      // sits out the remaining rounds (its workgroups return at once)
+      for (int round = 0; round < 3 && sp.refine; ++round) {
+        MMX_HIP(mmx::launchTreeRefine(
+            pb->rigDev, pb->dev, pb->fdev, pb->sTreeState.as<float>(), pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
+            sp.lambda, sp.lambdaPer, s));
+        MMX_HIP(mmx::launchCholeskyFinishTiled(
+            ds, pb->rig->P, factorScratch, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(), pb->sErr.as<double>(),
+            theta_dev, st, sp, round, s));
+      }
+    } else {
+      {
+        MMX_ZONE("Get JtJ and JtR");
+        MMX_HIP(mmx::launchFkJacobian(
+            pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
+        if (wide && treeFromMoments) {
+          // H and g from the tree moments, O(n^2) per instance, J not read (J itself is still assembled above: the
+          // Cholesky step's refinement streams it)
+          MMX_HIP(mmx::launchTreeNormalEquations(
+              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, s));
+        } else {
+          MMX_HIP(mmx::launchNormalEquations(
+              ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, wide, s));
+        }
+      }
+      {
+        MMX_ZONE("Dense gauss newton step");
+        MMX_HIP(mmx::launchCholeskyStep(
+            ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), pb->sErr.as<double>(),
+            theta_dev, st, sp, factorScratch, s));
+      }
     }
     if (deferred) {
       MMX_ZONE("Line search");

@@ -1650,6 +1650,20 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
 // Output: H[i * n + j] for i >= j (what choleskyStepGlobalKernel reads), no lambda; g[n].
 // ---------------------------------------------------------------------------------------------
 #if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
+// what treeNormalEquationsKernel hands to treeRefineKernel, per instance: js | up | ur | us
+struct TreeStateLayout {
+  size_t js, up, ur, us, total;
+};
+__host__ __device__ inline TreeStateLayout treeStateLayout(int J, int U) {
+  TreeStateLayout l;
+  l.js = 0;
+  l.up = alignUp4(size_t(kJs) * J);
+  l.ur = l.up + alignUp4(3 * size_t(U));
+  l.us = l.ur + alignUp4(3 * size_t(U));
+  l.total = l.us + alignUp4(size_t(U));
+  return l;
+}
+
 struct TreeNeLds {
   float *th, *js, *alt, *up, *uy, *us, *own1, *own2, *sub1, *sub2, *umom, *jd, *srcT;
   int *jlA, *jlB, *span; // span[slot] = tin | tout << 16
@@ -1694,7 +1708,9 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     const float* __restrict__ theta, // [B][P]
     float* __restrict__ jtj, // [B][n*n], lower triangle written
     float* __restrict__ jtr, // [B][n]
-    const int32_t* __restrict__ done) {
+    const int32_t* __restrict__ done,
+    double* __restrict__ errOut, // [B] error at theta (SkeletonSolverFunctionT::getJacobian's return value), or null
+    float* __restrict__ state) { // [B][treeStateFloats] joint states and units for treeRefineKernel, or null
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1729,14 +1745,42 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   // ---- A, B: forward kinematics with rotation axes
   blockFk(rv, s, s.th, tid, true);
   // ---- C: units
-  for (int u = tid; u < U; u += 256) {
-    const Unit un = evalUnit(pb, s.js, b, u);
-    s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
-    const float sg2 = un.sigma * un.sigma;
-    s.uy[3 * u] = sg2 * un.f.x, s.uy[3 * u + 1] = sg2 * un.f.y, s.uy[3 * u + 2] = sg2 * un.f.z;
-    s.us[u] = un.sigma;
+  {
+    const TreeStateLayout sl = treeStateLayout(J, U);
+    float* stb = state != nullptr ? state + size_t(b) * sl.total : nullptr;
+    double e = 0.0;
+    for (int u = tid; u < U; u += 256) {
+      const Unit un = evalUnit(pb, s.js, b, u);
+      s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
+      const float sg2 = un.sigma * un.sigma;
+      s.uy[3 * u] = sg2 * un.f.x, s.uy[3 * u + 1] = sg2 * un.f.y, s.uy[3 * u + 2] = sg2 * un.f.z;
+      s.us[u] = un.sigma;
+      e += double(un.werr);
+      if (stb != nullptr) {
+        float* o = stb + sl.ur + 3 * u;
+        o[0] = un.sigma * un.f.x, o[1] = un.sigma * un.f.y, o[2] = un.sigma * un.f.z;
+      }
+    }
+    e = waveReduceSum(e);
+    if (lane == 0) {
+      s.red[wave] = e;
+    }
+    __syncthreads();
+    if (errOut != nullptr && tid == 0) {
+      errOut[b] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+    }
+    if (stb != nullptr) {
+      for (int i = tid; i < kJs * J; i += 256) {
+        stb[sl.js + i] = s.js[i];
+      }
+      for (int i = tid; i < 3 * U; i += 256) {
+        stb[sl.up + i] = s.up[i];
+      }
+      for (int i = tid; i < U; i += 256) {
+        stb[sl.us + i] = s.us[i];
+      }
+    }
   }
-  __syncthreads();
   // ---- D: own sums (per-unit moments -> per-joint sums), then subtree sums (the moments' scratch is dead by then)
   ownSums(fv, s, s.umom, U, tid);
   __syncthreads();
@@ -1894,6 +1938,8 @@ hipError_t launchTreeNormalEquations(
     float* jtj,
     float* jtr,
     const int32_t* done,
+    double* errOut,
+    float* state,
     hipStream_t stream) {
   const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc);
   if (lds > 160 * 1024 - 64) {
@@ -1907,7 +1953,219 @@ hipError_t launchTreeNormalEquations(
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done);
+  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// The refinement residual of the wide explicit solve through the tree: rho = J^T (r - J d) - lambda d from the
+// joint states and units treeNormalEquationsKernel left in `state` -- the tangent pass down the tree and the
+// adjoint pass up (fusedSolveKernel phase J with its tables read from global memory).  No dense J anywhere:
+// with this kernel the wide path neither writes nor reads one.  grid = B, block = 256.
+// =============================================================================================
+struct TreeRefLds {
+  float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0;
+  int* col;
+};
+__host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base) {
+  size_t off = 0;
+  auto take = [&](size_t count) {
+    const size_t o = off;
+    off += alignUp4(count);
+    return o;
+  };
+  const size_t NP = (size_t(n) + 15) & ~size_t(15);
+  const size_t oJs = take(size_t(kJs) * J), oUp = take(3 * size_t(U)), oUr = take(3 * size_t(U)), oUs = take(U);
+  const size_t r1 = size_t(kC1) * (U > J ? U : J); // jd (7 J), then the per-unit contributions / the subtree sums
+  const size_t oR1 = take(r1 > 7 * size_t(J) ? r1 : 7 * size_t(J));
+  const size_t oR2 = take(size_t(kTan > kC1 ? kTan : kC1) * J); // tanOwn, then the own sums
+  const size_t oPre = take(size_t(kTan) * J);
+  const size_t oD = take(NP), oCol = take(P);
+  if (out != nullptr) {
+    out->js = base + oJs, out->up = base + oUp, out->ur = base + oUr, out->us = base + oUs;
+    out->jd = base + oR1, out->sub1 = base + oR1, out->tanOwn = base + oR2, out->own1 = base + oR2, out->tanPre = base + oPre;
+    out->d0 = base + oD;
+    out->col = reinterpret_cast<int*>(base + oCol);
+  }
+  return off;
+}
+
+__global__ void __launch_bounds__(256, 2) treeRefineKernel(
+    RigDev rig,
+    ProblemDev pb,
+    FusedDev fd,
+    const float* __restrict__ state, // [B][treeStateFloats]
+    const float* __restrict__ dvec, // [B][NP] the step
+    float* __restrict__ rhoVec, // [B][NP]
+    const int32_t* __restrict__ refState, // [B] 0: this instance is waiting for a refinement round
+    float lambdaAll,
+    const float* __restrict__ lambdaPer) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (refState[b] != 0) {
+    return;
+  }
+  const int J = rig.J, P = rig.P, U = fd.U, n = fd.n;
+  const int NP = (n + 15) & ~15;
+  const float lambda = lambdaPer != nullptr ? lambdaPer[b] : lambdaAll;
+  TreeRefLds t;
+  treeRefineLdsFloats(J, P, U, n, &t, smem);
+  FusedLds s{};
+  s.js = t.js, s.up = t.up, s.ur = t.ur, s.us = t.us, s.own1 = t.own1, s.sub1 = t.sub1, s.jd = t.jd, s.tanOwn = t.tanOwn, s.tanPre = t.tanPre, s.d0 = t.d0;
+  FusedView fv;
+  fv.U = U, fv.Kp = fd.Kp, fv.subSize = fd.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = fd.loadedPos, fv.numLoaded = fd.numLoaded;
+  fv.colToSolve = t.col, fv.unitPos = pb.unitTin, fv.posUnitStart = fd.posUnitStart, fv.posUnits = fd.posUnits, fv.solveList = fd.solveList;
+  {
+    const TreeStateLayout sl = treeStateLayout(J, U);
+    const float* stb = state + size_t(b) * sl.total;
+    for (int i = tid; i < kJs * J; i += 256) {
+      s.js[i] = stb[sl.js + i];
+    }
+    for (int i = tid; i < 3 * U; i += 256) {
+      s.up[i] = stb[sl.up + i];
+      s.ur[i] = stb[sl.ur + i];
+    }
+    for (int i = tid; i < U; i += 256) {
+      s.us[i] = stb[sl.us + i];
+    }
+    for (int i = tid; i < NP; i += 256) {
+      s.d0[i] = i < n ? dvec[size_t(b) * NP + i] : 0.f;
+    }
+    for (int i = tid; i < P; i += 256) {
+      t.col[i] = -1;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < n; c += 256) {
+    t.col[fd.solveList[c]] = c;
+  }
+  __syncthreads();
+  // joint-parameter delta jd = transform * delta
+  for (int r = tid; r < rig.R; r += 256) {
+    float a = 0.f;
+    const int k1 = rig.ptOuter[r + 1];
+    for (int k = rig.ptOuter[r]; k < k1; ++k) {
+      const int cs = t.col[rig.ptInner[k]];
+      a += rig.ptValue[k] * (cs >= 0 ? s.d0[cs] : 0.f);
+    }
+    s.jd[r] = a;
+  }
+  __syncthreads();
+  // tangent pass: per joint (by DFS position) C = T - Om x t - ln2 sd t, W = Om, S = sd ...
+  for (int k = tid; k < J; k += 256) {
+    const int q = fd.dfsJoint[k];
+    const float* ja = s.js + kJs * q;
+    const float* d = s.jd + 7 * q;
+    const F3 ta{ja[0], ja[1], ja[2]};
+    F3 Tv{0.f, 0.f, 0.f};
+    if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+      const int par = rig.parent[q];
+      Tv = d[0] * transAxisCol(s.js, par, 0) + d[1] * transAxisCol(s.js, par, 1) + d[2] * transAxisCol(s.js, par, 2);
+    }
+    const F3 Om = d[3] * F3{ja[8], ja[9], ja[10]} + d[4] * F3{ja[11], ja[12], ja[13]} + d[5] * F3{ja[14], ja[15], ja[16]};
+    const F3 C = Tv - cross(Om, ta) - (kLn2 * d[6]) * ta;
+    float* o = s.tanOwn + kTan * k;
+    o[0] = C.x, o[1] = C.y, o[2] = C.z, o[3] = Om.x, o[4] = Om.y, o[5] = Om.z, o[6] = d[6], o[7] = 0.f;
+  }
+  __syncthreads();
+  // ... summed over each joint's ancestor chain
+  treeSum<7, false, kTan>(fv, s.tanOwn, s.tanPre, J, wave, lane);
+  __syncthreads();
+  // w = r - J d, y = sigma w per unit, then the first-order own sums
+  if (U <= J) {
+    for (int u = tid; u < U; u += 256) {
+      const float* pre = s.tanPre + kTan * fv.unitPos[u];
+      const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+      const bool point = u < fv.Kp;
+      F3 v = cross(F3{pre[3], pre[4], pre[5]}, p);
+      if (point) {
+        v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
+      }
+      const float sg = s.us[u];
+      firstOrderMoments(s.sub1 + kC1 * u, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
+    }
+    __syncthreads();
+    gatherOwnSums<kC1, kC1>(fv, s, s.sub1, tid);
+  } else {
+    for (int k = tid; k < J; k += 256) {
+      const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
+      float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (e1 > e0) {
+        const float* pre = s.tanPre + kTan * k;
+        for (int e = e0; e < e1; ++e) {
+          const int u = fv.posUnits[e];
+          const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+          const bool point = u < fv.Kp;
+          F3 v = cross(F3{pre[3], pre[4], pre[5]}, p);
+          if (point) {
+            v = F3{pre[0], pre[1], pre[2]} + v + (kLn2 * pre[6]) * p;
+          }
+          const float sg = s.us[u];
+          float o[kC1];
+          firstOrderMoments(o, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
+#pragma unroll
+          for (int c = 0; c < kC1; ++c) {
+            a1[c] += o[c];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < kC1; ++c) {
+        s.own1[kC1 * k + c] = a1[c];
+      }
+    }
+  }
+  __syncthreads();
+  treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
+  __syncthreads();
+  // J^T w per column: the primary source slot, then the extras (slot numbering of phase F)
+  for (int c = tid; c < NP; c += 256) {
+    float a = 0.f;
+    if (c < n) {
+      auto slotShare = [&](int e) {
+        const ColumnSourceDev cs = fd.srcs[e];
+        return cs.weight * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
+      };
+      a = slotShare(c);
+      const int e1 = NP + fd.srcStart[c + 1];
+      for (int e = NP + fd.srcStart[c]; e < e1; ++e) {
+        a += slotShare(e);
+      }
+      a -= lambda * s.d0[c];
+    }
+    rhoVec[size_t(b) * NP + c] = a;
+  }
+}
+
+size_t treeStateFloats(int J, int U) {
+  return treeStateLayout(J, U).total;
+}
+
+hipError_t launchTreeRefine(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    const float* state,
+    const float* dvec,
+    float* rhoVec,
+    const int32_t* refState,
+    float lambda,
+    const float* lambdaPer,
+    hipStream_t stream) {
+  const size_t lds = treeRefineLdsFloats(rig.J, rig.P, fd.U, fd.n, nullptr, nullptr) * sizeof(float);
+  if (lds > 160 * 1024 - 64) {
+    return hipErrorInvalidValue;
+  }
+  static size_t attrBytes = 64 * 1024;
+  if (lds > attrBytes) {
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(treeRefineKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    attrBytes = lds;
+  }
+  hipLaunchKernelGGL(treeRefineKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, state, dvec, rhoVec, refState, lambda, lambdaPer);
   return hipGetLastError();
 }
 #endif

@@ -2192,51 +2192,38 @@ __global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
 constexpr int kJb = 4; // finished block columns per trip of the tile products (4 tiles x kJb + kJb 16-byte loads in flight per lane)
 constexpr int kChunkLoads = 10; // 16-byte loads a thread keeps in flight for the next J chunk (n * chunkRows / 4 <= 256 * 10)
 
-__global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
-    ProblemDev pb,
-    int P,
-    const float* __restrict__ jac, // [B][M*P]
-    const float* __restrict__ res, // [B][M]
-    const float* __restrict__ jtj, // [B][n*n] H, lower triangle, read only
-    const float* __restrict__ jtr, // [B][n]
-    float* __restrict__ factor, // [B][NB(NB+1)/2][256] L, tile-major
-    const double* __restrict__ errIter,
-    float* __restrict__ theta,
-    SolveStateDev st,
-    StepParams sp,
-    int chunkRows) { // 16 or 32
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
+struct TiledLds { // the LDS carve of the tiled step's kernels
+  float *pan, *g, *d0, *rho, *invDiag, *wch;
+  double* part;
+  int* flags;
+};
+__host__ __device__ inline size_t tiledLdsFloats(int n, int chunkRows, TiledLds* out, float* base) {
+  const size_t NP = (size_t(n) + 15) & ~size_t(15);
+  const size_t chunk = chunkRows > 0 ? size_t(n) * size_t(chunkRows + 1) : 0;
+  const size_t panFloats = ((NP * 16 > chunk ? NP * 16 : chunk) + 3) & ~size_t(3);
+  const size_t oG = panFloats, oD = oG + NP, oRho = oD + NP, oInv = oRho + NP, oW = oInv + NP;
+  const size_t oPart = oW + ((size_t(chunkRows) + 3) & ~size_t(3)); // doubles: even float offset
+  const size_t oFlags = oPart + (chunkRows > 0 ? 512 : 16);
+  if (out != nullptr) {
+    out->pan = base, out->g = base + oG, out->d0 = base + oD, out->rho = base + oRho, out->invDiag = base + oInv, out->wch = base + oW;
+    out->part = reinterpret_cast<double*>(base + oPart);
+    out->flags = reinterpret_cast<int*>(base + oFlags);
+  }
+  return oFlags + 8;
+}
+
+// Left-looking blocked Cholesky of H + lambda I (H: [n][n], lower triangle, read only) into the tile-major L;
+// t.g holds g on entry and y = L^-1 g on exit; t.flags[0] = 1 when a pivot was not positive.
+__device__ __forceinline__ void tiledFactor(
+    const float* __restrict__ H, float* __restrict__ L, int n, float lambda, const TiledLds& t, const StepParams& sp, int b, int tid, long long& tclk) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (st.done[b] != 0) {
-    return;
-  }
-  const int n = pb.n, M = pb.M;
-  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
   const int NP = (n + 15) & ~15, NB = NP >> 4;
-  const int cs = chunkRows + 1; // LDS stride of one J column inside a chunk (odd)
-  const int panFloats = max(NP * 16, n * cs);
-  float* pan = smem; // block column being factored (swizzled tiles) / J chunk [n][cs]
-  float* g = pan + ((panFloats + 3) & ~3); // g, then y = L^-1 g
-  float* d0 = g + NP;
-  float* rho = d0 + NP;
-  float* invDiag = rho + NP;
-  float* wch = invDiag + NP; // [chunkRows] w of the current chunk
-  double* part = reinterpret_cast<double*>(wch + ((chunkRows + 1) & ~1)); // [256] partial sums of w
-  int* flags = reinterpret_cast<int*>(part + 256);
-  const float* H = jtj + size_t(b) * n * n;
-  float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
-  if (tid == 0) {
-    flags[0] = 0;
-  }
-  for (int i = tid; i < NP; i += 256) {
-    g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
-  }
-  __syncthreads();
-  long long tclk = clock64();
+  float* pan = t.pan;
+  float* g = t.g;
+  float* invDiag = t.invDiag;
+  int* flags = t.flags;
   const int lrow = lane & 15, lkg = lane >> 4; // operand layout of v_mfma_f32_16x16x4_f32: row, k group
   const int opOff = lrow * 16 + 4 * lkg; // a lane's 16 bytes inside a row-major tile
-
   for (int k = 0; k < NB; ++k) {
     const int nt = NB - k;
     // (a) the wave's tiles of block column k (I = k + wave, + 4, ...), four per trip
@@ -2407,15 +2394,19 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
     __syncthreads(); // the panel buffer is reused; the tiles are visible to the workgroup
     MMX_SCLK(1)
   }
-  const bool bad = flags[0] != 0;
+}
 
-  // substitutions on the tile-major factor.  forward: L y = x, column by column (after y_k every row below
-  // subtracts block k's sixteen columns); backward: L^T z = y, row block by row block.  The tiles of the
-  // NEXT step are requested before the sixteen-step chain of the current one.
-  auto sweep = [&](float* x, auto direction) {
-    constexpr bool forward = decltype(direction)::value;
+// Substitutions on the tile-major factor.  forward: L y = x, column by column (after y_k every row below
+// subtracts block k's sixteen columns); backward: L^T z = y, row block by row block.  The tiles of the NEXT
+// step are requested before the sixteen-step chain of the current one.  x: LDS, NP floats, in place.
+template <bool forward>
+__device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, float* x, int tid) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NP = 16 * NB, lrow = lane & 15;
+  {
     float dg[16] = {}, dgNext[16] = {}, pv[2][16] = {}, pvNext[2][16] = {};
-    auto request = [&](int k, float (&dgo)[16], float (&pvo)[2][16]) {
+    float di = 1.f, diNext = 1.f; // L(i,i) of the lane's row / column of the diagonal tile
+    auto request = [&](int k, float (&dgo)[16], float (&pvo)[2][16], float& dio) {
       if (k < 0 || k >= NB) {
         return;
       }
@@ -2425,6 +2416,7 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
         for (int c = 0; c < 16; ++c) { // forward: row `lrow` of the diagonal tile; backward: its column
           dgo[c] = forward ? Dt[lrow * 16 + c] : Dt[c * 16 + lrow];
         }
+        dio = Dt[lrow * 17];
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -2447,12 +2439,12 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
       }
     };
     const int kFirst = forward ? 0 : NB - 1, kStep = forward ? 1 : -1;
-    request(kFirst, dg, pv);
+    request(kFirst, dg, pv, di);
     for (int k = kFirst; k >= 0 && k < NB; k += kStep) {
-      request(k + kStep, dgNext, pvNext);
+      request(k + kStep, dgNext, pvNext, diNext);
       if (wave == 0) {
         float bi = x[16 * k + lrow];
-        const float invd = invDiag[16 * k + lrow];
+        const float invd = 1.f / di;
         if (forward) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
@@ -2489,15 +2481,95 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
       for (int c = 0; c < 16; ++c) {
         dg[c] = dgNext[c], pv[0][c] = pvNext[0][c], pv[1][c] = pvNext[1][c];
       }
+      di = diNext;
     }
-  };
+  }
+}
+
+// theta -= delta (or the step handed to stepUpdateKernel) and SolverT::solve's bookkeeping (solver.cpp:92-119)
+__device__ __forceinline__ void applyStepAndBook(
+    const ProblemDev& pb, int P, int b, const float* d0, bool bad, const double* errIter, float* theta, const SolveStateDev& st, const StepParams& sp, int tid) {
+  const int n = pb.n;
+  if (sp.delta != nullptr) {
+    for (int s2 = tid; s2 < n; s2 += 256) {
+      sp.delta[size_t(b) * n + s2] = bad ? 0.f : d0[s2];
+    }
+    if (tid == 0) {
+      sp.stepIter[b] = bad ? -(sp.iteration + 1) : sp.iteration + 1;
+    }
+  } else if (!bad) {
+    float* th = theta + size_t(b) * P;
+    for (int s2 = tid; s2 < n; s2 += 256) {
+      th[pb.enabledList[s2]] -= d0[s2];
+    }
+  }
+  if (tid == 0) { // SolverT::solve bookkeeping (solver.cpp:92-119)
+    const double e = errIter[b];
+    const double last = st.lastError[b];
+    if (st.errorHistory != nullptr) {
+      st.errorHistory[size_t(b) * sp.maxIterations + sp.iteration] = e;
+    }
+    st.iterations[b] = sp.iteration + 1;
+    st.finalError[b] = e;
+    if (bad) {
+      st.status[b] = 2;
+    }
+    const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
+    if (sp.iteration >= sp.minIterations && converged) {
+      st.done[b] = 1;
+    }
+    st.lastError[b] = e;
+  }
+}
+
+__global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jac, // [B][M*P]
+    const float* __restrict__ res, // [B][M]
+    const float* __restrict__ jtj, // [B][n*n] H, lower triangle, read only
+    const float* __restrict__ jtr, // [B][n]
+    float* __restrict__ factor, // [B][NB(NB+1)/2][256] L, tile-major
+    const double* __restrict__ errIter,
+    float* __restrict__ theta,
+    SolveStateDev st,
+    StepParams sp,
+    int chunkRows) { // 16 or 32
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (st.done[b] != 0) {
+    return;
+  }
+  const int n = pb.n, M = pb.M;
+  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
+  const int NP = (n + 15) & ~15, NB = NP >> 4;
+  const int cs = chunkRows + 1; // LDS stride of one J column inside a chunk (odd)
+  TiledLds t;
+  tiledLdsFloats(n, chunkRows, &t, smem);
+  float* pan = t.pan; // block column being factored (swizzled tiles) / J chunk [n][cs]
+  float* d0 = t.d0;
+  float* rho = t.rho;
+  float* wch = t.wch; // [chunkRows] w of the current chunk
+  double* part = t.part; // [256] partial sums of w
+  float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+  if (tid == 0) {
+    t.flags[0] = 0;
+  }
   for (int i = tid; i < NP; i += 256) {
-    d0[i] = g[i];
+    t.g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
+  }
+  __syncthreads();
+  long long tclk = clock64();
+  tiledFactor(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
+  const bool bad = t.flags[0] != 0;
+  for (int i = tid; i < NP; i += 256) {
+    d0[i] = t.g[i];
   }
   __syncthreads();
   MMX_SCLK(0)
   if (!bad) {
-    sweep(d0, std::false_type{});
+    tiledSweep<false>(L, NB, d0, tid);
   }
   MMX_SCLK(2)
   for (int rf = 0; rf < 3 && !bad && sp.refine; ++rf) { // see choleskyStepKernel
@@ -2586,8 +2658,8 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
     }
     __syncthreads();
     MMX_SCLK(3)
-    sweep(rho, std::true_type{});
-    sweep(rho, std::false_type{});
+    tiledSweep<true>(L, NB, rho, tid);
+    tiledSweep<false>(L, NB, rho, tid);
     MMX_SCLK(5)
     float c2 = 0.f, d2 = 0.f;
     for (int i = tid; i < n; i += 256) {
@@ -2610,35 +2682,126 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
       break;
     }
   }
-  if (sp.delta != nullptr) {
-    for (int s2 = tid; s2 < n; s2 += 256) {
-      sp.delta[size_t(b) * n + s2] = bad ? 0.f : d0[s2];
-    }
+  applyStepAndBook(pb, P, b, d0, bad, errIter, theta, st, sp, tid);
+}
+
+// The same step for systems whose refinement goes through the tree (treeRefineKernel, mmx_fused.hip) instead of a
+// dense J: stage 1 factors and solves (d0 to `dvec`), stage 2 -- once per refinement round, after treeRefineKernel
+// left rho = J^T (r - J d) - lambda d in `rhoVec` -- solves for the correction and, when it was the last one,
+// applies the step.  refState[b]: 0 = a refinement round is due, 1 = the iteration's step has been applied.
+__global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jtj,
+    const float* __restrict__ jtr,
+    float* __restrict__ factor,
+    float* __restrict__ dvec, // [B][NP]
+    int32_t* __restrict__ refState, // [B]
+    const double* __restrict__ errIter,
+    float* __restrict__ theta,
+    SolveStateDev st,
+    StepParams sp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (st.done[b] != 0) {
     if (tid == 0) {
-      sp.stepIter[b] = bad ? -(sp.iteration + 1) : sp.iteration + 1;
+      refState[b] = 1;
     }
-  } else if (!bad) {
-    float* th = theta + size_t(b) * P;
-    for (int s2 = tid; s2 < n; s2 += 256) {
-      th[pb.enabledList[s2]] -= d0[s2];
-    }
+    return;
   }
-  if (tid == 0) { // SolverT::solve bookkeeping (solver.cpp:92-119)
-    const double e = errIter[b];
-    const double last = st.lastError[b];
-    if (st.errorHistory != nullptr) {
-      st.errorHistory[size_t(b) * sp.maxIterations + sp.iteration] = e;
+  const int n = pb.n;
+  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
+  const int NP = (n + 15) & ~15, NB = NP >> 4;
+  TiledLds t;
+  tiledLdsFloats(n, 0, &t, smem);
+  float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+  if (tid == 0) {
+    t.flags[0] = 0;
+  }
+  for (int i = tid; i < NP; i += 256) {
+    t.g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
+  }
+  __syncthreads();
+  long long tclk = clock64();
+  tiledFactor(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
+  const bool bad = t.flags[0] != 0;
+  float* d0 = t.g; // y = L^-1 g, solved in place
+  MMX_SCLK(0)
+  if (!bad) {
+    tiledSweep<false>(L, NB, d0, tid);
+  }
+  MMX_SCLK(2)
+  if (bad || !sp.refine) {
+    applyStepAndBook(pb, P, b, d0, bad, errIter, theta, st, sp, tid);
+    if (tid == 0) {
+      refState[b] = 1;
     }
-    st.iterations[b] = sp.iteration + 1;
-    st.finalError[b] = e;
-    if (bad) {
-      st.status[b] = 2;
+    return;
+  }
+  for (int i = tid; i < NP; i += 256) {
+    dvec[size_t(b) * NP + i] = d0[i];
+  }
+  if (tid == 0) {
+    refState[b] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ factor,
+    float* __restrict__ dvec, // [B][NP] in: d ; out: d + correction when another round follows
+    const float* __restrict__ rhoVec, // [B][NP]
+    int32_t* __restrict__ refState,
+    const double* __restrict__ errIter,
+    float* __restrict__ theta,
+    SolveStateDev st,
+    StepParams sp,
+    int round) { // 0, 1, 2: the last round applies the step whatever the correction was
+  __shared__ __attribute__((aligned(16))) float d0[512 + 16];
+  __shared__ __attribute__((aligned(16))) float rho[512 + 16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (refState[b] != 0) {
+    return;
+  }
+  const int n = pb.n;
+  const int NP = (n + 15) & ~15, NB = NP >> 4;
+  const float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+  for (int i = tid; i < NP; i += 256) {
+    d0[i] = dvec[size_t(b) * NP + i];
+    rho[i] = rhoVec[size_t(b) * NP + i];
+  }
+  __syncthreads();
+  long long tclk = clock64();
+  tiledSweep<true>(L, NB, rho, tid);
+  tiledSweep<false>(L, NB, rho, tid);
+  MMX_SCLK(5)
+  float c2 = 0.f, d2 = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const float cr = rho[i], dn = d0[i] + cr;
+    d0[i] = dn;
+    c2 += cr * cr;
+    d2 += dn * dn;
+  }
+  c2 = waveReduceSumF(c2);
+  d2 = waveReduceSumF(d2);
+  __syncthreads();
+  if (lane == 0) {
+    rho[wave] = c2;
+    rho[4 + wave] = d2;
+  }
+  __syncthreads();
+  const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
+  if (again && round < 2) {
+    for (int i = tid; i < NP; i += 256) {
+      dvec[size_t(b) * NP + i] = d0[i];
     }
-    const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
-    if (sp.iteration >= sp.minIterations && converged) {
-      st.done[b] = 1;
-    }
-    st.lastError[b] = e;
+    return;
+  }
+  applyStepAndBook(pb, P, b, d0, false, errIter, theta, st, sp, tid);
+  if (tid == 0) {
+    refState[b] = 1;
   }
 }
 
@@ -3103,8 +3266,7 @@ hipError_t launchCholeskyStep(
       return e != nullptr ? atoi(e) : 32;
     }();
     const int chunkRows = chunkPref == 32 && size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
-    const size_t panFloats = (std::max(NP * 16, size_t(pb.n) * size_t(chunkRows + 1)) + 3) & ~size_t(3);
-    lds = (panFloats + 4 * NP + size_t(chunkRows) + 2 + 512 + 8) * sizeof(float);
+    lds = tiledLdsFloats(pb.n, chunkRows, nullptr, nullptr) * sizeof(float);
     if (lds > 64 * 1024) {
       hipError_t rc = hipFuncSetAttribute(
           reinterpret_cast<const void*>(choleskyStepTiledKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -3139,6 +3301,44 @@ hipError_t launchCholeskyStep(
   }
   hipLaunchKernelGGL(
       choleskyStepKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, errIter, theta, st, sp);
+  return hipGetLastError();
+}
+
+hipError_t launchCholeskyFactorTiled(
+    const ProblemDev& pb,
+    int P,
+    const float* jtj,
+    const float* jtr,
+    float* factor,
+    float* dvec,
+    int32_t* refState,
+    const double* errIter,
+    float* theta,
+    const SolveStateDev& st,
+    const StepParams& sp,
+    hipStream_t stream) {
+  if (pb.n > 512) {
+    return hipErrorInvalidValue;
+  }
+  const size_t lds = tiledLdsFloats(pb.n, 0, nullptr, nullptr) * sizeof(float);
+  hipLaunchKernelGGL(choleskyFactorTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp);
+  return hipGetLastError();
+}
+
+hipError_t launchCholeskyFinishTiled(
+    const ProblemDev& pb,
+    int P,
+    const float* factor,
+    float* dvec,
+    const float* rhoVec,
+    int32_t* refState,
+    const double* errIter,
+    float* theta,
+    const SolveStateDev& st,
+    const StepParams& sp,
+    int round,
+    hipStream_t stream) {
+  hipLaunchKernelGGL(choleskyFinishTiledKernel, dim3(pb.B), dim3(256), 0, stream, pb, P, factor, dvec, rhoVec, refState, errIter, theta, st, sp, round);
   return hipGetLastError();
 }
 

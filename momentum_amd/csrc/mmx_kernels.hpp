@@ -95,6 +95,21 @@ hipError_t launchTreeNormalEquations(
     float* jtj,
     float* jtr,
     const int32_t* done,
+    double* errOut, // [B] error at theta, or null
+    float* state, // [B][treeStateFloats(J, U)] hand-over to launchTreeRefine, or null
+    hipStream_t stream);
+size_t treeStateFloats(int J, int U);
+// rho = J^T (r - J d) - lambda d through the tree, for the instances with refState[b] == 0 (dvec / rhoVec: [B][NP])
+hipError_t launchTreeRefine(
+    const RigDev& rig,
+    const ProblemDev& pb,
+    const FusedDev& fd,
+    const float* state,
+    const float* dvec,
+    float* rhoVec,
+    const int32_t* refState,
+    float lambda,
+    const float* lambdaPer,
     hipStream_t stream);
 int fusedBlocksFor(int n); // number of 16-wide blocks the fused kernel is instantiated for, or -1
 hipError_t launchFusedSolve(
@@ -167,6 +182,34 @@ hipError_t launchCholeskyStep(
     const SolveStateDev& st,
     const StepParams& sp,
     float* factor, // wide systems: [B][choleskyFactorFloats(n)] scratch for the tile-major factor (null: factor H in place)
+    hipStream_t stream);
+// the same step when the refinement goes through the tree (launchTreeRefine): factor + first solve, then one call per
+// refinement round.  dvec / rhoVec: [B][NP] (NP = n rounded up to 16), refState: [B].
+hipError_t launchCholeskyFactorTiled(
+    const ProblemDev& pb,
+    int P,
+    const float* jtj,
+    const float* jtr,
+    float* factor,
+    float* dvec,
+    int32_t* refState,
+    const double* errIter,
+    float* theta,
+    const SolveStateDev& st,
+    const StepParams& sp,
+    hipStream_t stream);
+hipError_t launchCholeskyFinishTiled(
+    const ProblemDev& pb,
+    int P,
+    const float* factor,
+    float* dvec,
+    const float* rhoVec,
+    int32_t* refState,
+    const double* errIter,
+    float* theta,
+    const SolveStateDev& st,
+    const StepParams& sp,
+    int round,
     hipStream_t stream);
 inline size_t choleskyFactorFloats(int n) {
   const size_t nb = (size_t(n) + 15) / 16;
