@@ -1665,7 +1665,7 @@ int32_t mmx_eval_normal_equations(
         return fail(MMX_ERR_UNSUPPORTED, "MMX_TREE_NE=force: problem outside the tree-moment kernel's scope (or structurally zero columns present)");
       }
       MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
-      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, s));
+      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, s));
       return MMX_OK;
     }
   }
@@ -1893,7 +1893,7 @@ static int32_t solveImpl(
         MMX_ZONE("Get JtJ and JtR");
         MMX_HIP(mmx::launchTreeNormalEquations(
             pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, pb->sErr.as<double>(),
-            pb->sTreeState.as<float>(), s));
+            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, s));
       }
       MMX_ZONE("Dense gauss newton step");
       MMX_HIP(mmx::launchCholeskyFactorTiled(
@@ -1918,7 +1918,7 @@ static int32_t solveImpl(
           // H and g from the tree moments, O(n^2) per instance, J not read (J itself is still assembled above: the
           // Cholesky step's refinement streams it)
           MMX_HIP(mmx::launchTreeNormalEquations(
-              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, s));
+              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, nullptr, s));
         } else {
           MMX_HIP(mmx::launchNormalEquations(
               ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, wide, s));
@@ -1946,13 +1946,20 @@ static int32_t solveImpl(
   }
   MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
   if (sp.clk != nullptr) {
-    long long h[8];
+    long long h[16];
     MMX_HIP(hipMemcpyAsync(h, sp.clk, sizeof(h), hipMemcpyDeviceToHost, s));
     MMX_HIP(hipStreamSynchronize(s));
     static const char* names[8] = {"load H / fence", "factor (in-HBM: write-back + trailing)", "solve", "refine: w = r - J d", "refine: rho = J^T w", "refine: solve", "factor: panel load (in-HBM)", "factor: panel chain (in-HBM)"};
     fprintf(stderr, "[mmx phase clocks, choleskyStepKernel block 0, all iterations] n = %d\n", n);
     for (int i = 0; i < 8; ++i) {
       fprintf(stderr, "  %-40s %10lld\n", names[i], h[i]);
+    }
+    if (treeRefine) {
+      static const char* tnames[8] = {"tree NE: load", "tree NE: A, B forward kinematics", "tree NE: C units + hand-over", "tree NE: D own sums",
+                                      "tree NE: D subtree sums", "tree NE: E slot tables", "tree NE: F, G tiles", "tree NE: G extras"};
+      for (int i = 0; i < 8; ++i) {
+        fprintf(stderr, "  %-40s %10lld\n", tnames[i], h[8 + i]);
+      }
     }
   }
   return MMX_OK;

@@ -181,9 +181,10 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
   gatherOwnSums<NCH, kUmom>(fd, s, umom, tid);
 }
 
-template <int NC, bool kSubtree, int STRIDE = NC>
+constexpr int kFusedTreeUn = 4; // k-steps per trip of the tree sums (measured on BASELINE configs[1]: 1 -> 1.575e6, 4 -> 1.60e6, 8 -> 1.54e6 solves/s)
+template <int NC, bool kSubtree, int STRIDE = NC, int UN = kFusedTreeUn>
 __device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, float* out, int J, int wave, int lane) {
-  treeSumT<NC, kSubtree, STRIDE>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
+  treeSumT<NC, kSubtree, STRIDE, UN>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1667,6 +1668,7 @@ __host__ __device__ inline TreeStateLayout treeStateLayout(int J, int U) {
 struct TreeNeLds {
   float *th, *js, *alt, *up, *uy, *us, *own1, *own2, *sub1, *sub2, *umom, *jd, *srcT;
   int *jlA, *jlB, *span; // span[slot] = tin | tout << 16
+  int *subSize, *loadedPos; // copies of the tables the subtree sums walk (read once per inner step)
   double* red;
 };
 
@@ -1686,9 +1688,11 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   const size_t oR = take(life1 > life2 ? life1 : life2);
   const size_t oSrc = take(size_t(kSrcCh) * size_t(srcStrideFor(nsrc)));
   const size_t oSpan = take(nsrc);
+  const size_t oSub = take(J), oLoaded = take(J);
   const size_t oRed = take(16);
   if (out != nullptr) {
     out->span = reinterpret_cast<int*>(base + oSpan);
+    out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->th = base + oTh, out->js = base + oJs, out->alt = base + oAlt;
     out->jlA = reinterpret_cast<int*>(base + oJl), out->jlB = out->jlA + J;
     out->up = base + oUp, out->uy = base + oUy, out->us = base + oUs;
@@ -1710,7 +1714,8 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     float* __restrict__ jtr, // [B][n]
     const int32_t* __restrict__ done,
     double* __restrict__ errOut, // [B] error at theta (SkeletonSolverFunctionT::getJacobian's return value), or null
-    float* __restrict__ state) { // [B][treeStateFloats] joint states and units for treeRefineKernel, or null
+    float* __restrict__ state, // [B][treeStateFloats] joint states and units for treeRefineKernel, or null
+    long long* __restrict__ clk) { // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1722,6 +1727,16 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   const int NB = (n + 15) >> 4, NP = 16 * NB, T = NB * (NB + 1) / 2;
   TreeNeLds t;
   treeNeLdsFloats(J, P, U, nsrc, &t, smem);
+  long long tclk = clock64();
+#define MMX_TCLK(slot)                 \
+  if (clk != nullptr && b == 0) {      \
+    __syncthreads();                   \
+    if (tid == 0) {                    \
+      const long long now = clock64(); \
+      clk[slot] += now - tclk;         \
+      tclk = now;                      \
+    }                                  \
+  }
   // the fused kernel's helpers work on these views; here the tables stay where they are (L2)
   FusedLds s{};
   s.th = t.th, s.js = t.js, s.alt = t.alt, s.jlA = t.jlA, s.jlB = t.jlB, s.jd = t.jd;
@@ -1733,17 +1748,23 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   rv.ptOuter = rig.ptOuter, rv.ptInner = rig.ptInner, rv.ptValue = rig.ptValue, rv.ptOffsets = rig.ptOffsets;
   rv.levelOrder = rig.levelOrder, rv.levelStart = rig.levelStart;
   FusedView fv;
-  fv.U = U, fv.Kp = fd.Kp, fv.subSize = fd.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = fd.loadedPos, fv.numLoaded = fd.numLoaded;
+  fv.U = U, fv.Kp = fd.Kp, fv.subSize = t.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = t.loadedPos, fv.numLoaded = fd.numLoaded;
   fv.colToSolve = nullptr, fv.unitPos = pb.unitTin, fv.posUnitStart = fd.posUnitStart, fv.posUnits = fd.posUnits, fv.solveList = fd.solveList;
   for (int i = tid; i < P; i += 256) {
     s.th[i] = theta[size_t(b) * P + i];
+  }
+  for (int i = tid; i < J; i += 256) {
+    t.subSize[i] = fd.subSize[i];
+    t.loadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
   }
   for (int e = tid; e < nsrc; e += 256) {
     t.span[e] = fd.srcs[e].tin | (fd.srcs[e].tout << 16);
   }
   __syncthreads();
+  MMX_TCLK(0)
   // ---- A, B: forward kinematics with rotation axes
   blockFk(rv, s, s.th, tid, true);
+  MMX_TCLK(1)
   // ---- C: units
   {
     const TreeStateLayout sl = treeStateLayout(J, U);
@@ -1781,12 +1802,15 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       }
     }
   }
+  MMX_TCLK(2)
   // ---- D: own sums (per-unit moments -> per-joint sums), then subtree sums (the moments' scratch is dead by then)
   ownSums(fv, s, s.umom, U, tid);
   __syncthreads();
-  treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
-  treeSum<kC2Used, true, kC2>(fv, s.own2, s.sub2, J, wave, lane);
+  MMX_TCLK(3)
+  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane);
+  treeSum<kC2Used, true, kC2, 8>(fv, s.own2, s.sub2, J, wave, lane);
   __syncthreads();
+  MMX_TCLK(4)
   // ---- E: per-slot tables (see fusedSolveKernel phase E)
   const int sst = srcStrideFor(nsrc);
   float* srcD = s.srcT;
@@ -1838,6 +1862,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     srcG[e] = w * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
   }
   __syncthreads();
+  MMX_TCLK(5)
   // ---- F: g
   for (int c = tid; c < n; c += 256) {
     float acc = srcG[c];
@@ -1879,6 +1904,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       }
     }
   }
+  MMX_TCLK(6)
   // ---- the pairs that involve an extra source of a shared parameter: term records, one thread per entry run
   if (fd.termRounds > 0) {
     __threadfence_block();
@@ -1924,6 +1950,8 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       *hp = v;
     }
   }
+  MMX_TCLK(7)
+#undef MMX_TCLK
 }
 
 size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc) {
@@ -1940,6 +1968,7 @@ hipError_t launchTreeNormalEquations(
     const int32_t* done,
     double* errOut,
     float* state,
+    long long* clk,
     hipStream_t stream) {
   const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc);
   if (lds > 160 * 1024 - 64) {
@@ -1953,7 +1982,7 @@ hipError_t launchTreeNormalEquations(
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state);
+  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk);
   return hipGetLastError();
 }
 
@@ -1965,7 +1994,7 @@ hipError_t launchTreeNormalEquations(
 // =============================================================================================
 struct TreeRefLds {
   float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0;
-  int* col;
+  int *col, *subSize, *loadedPos;
 };
 __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base) {
   size_t off = 0;
@@ -1980,8 +2009,9 @@ __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n
   const size_t oR1 = take(r1 > 7 * size_t(J) ? r1 : 7 * size_t(J));
   const size_t oR2 = take(size_t(kTan > kC1 ? kTan : kC1) * J); // tanOwn, then the own sums
   const size_t oPre = take(size_t(kTan) * J);
-  const size_t oD = take(NP), oCol = take(P);
+  const size_t oD = take(NP), oCol = take(P), oSub = take(J), oLoaded = take(J);
   if (out != nullptr) {
+    out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->js = base + oJs, out->up = base + oUp, out->ur = base + oUr, out->us = base + oUs;
     out->jd = base + oR1, out->sub1 = base + oR1, out->tanOwn = base + oR2, out->own1 = base + oR2, out->tanPre = base + oPre;
     out->d0 = base + oD;
@@ -2014,7 +2044,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   FusedLds s{};
   s.js = t.js, s.up = t.up, s.ur = t.ur, s.us = t.us, s.own1 = t.own1, s.sub1 = t.sub1, s.jd = t.jd, s.tanOwn = t.tanOwn, s.tanPre = t.tanPre, s.d0 = t.d0;
   FusedView fv;
-  fv.U = U, fv.Kp = fd.Kp, fv.subSize = fd.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = fd.loadedPos, fv.numLoaded = fd.numLoaded;
+  fv.U = U, fv.Kp = fd.Kp, fv.subSize = t.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = t.loadedPos, fv.numLoaded = fd.numLoaded;
   fv.colToSolve = t.col, fv.unitPos = pb.unitTin, fv.posUnitStart = fd.posUnitStart, fv.posUnits = fd.posUnits, fv.solveList = fd.solveList;
   {
     const TreeStateLayout sl = treeStateLayout(J, U);
@@ -2034,6 +2064,10 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     }
     for (int i = tid; i < P; i += 256) {
       t.col[i] = -1;
+    }
+    for (int i = tid; i < J; i += 256) {
+      t.subSize[i] = fd.subSize[i];
+      t.loadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
     }
   }
   __syncthreads();
@@ -2070,7 +2104,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   }
   __syncthreads();
   // ... summed over each joint's ancestor chain
-  treeSum<7, false, kTan>(fv, s.tanOwn, s.tanPre, J, wave, lane);
+  treeSum<7, false, kTan, 8>(fv, s.tanOwn, s.tanPre, J, wave, lane);
   __syncthreads();
   // w = r - J d, y = sigma w per unit, then the first-order own sums
   if (U <= J) {
@@ -2117,7 +2151,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     }
   }
   __syncthreads();
-  treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
+  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane);
   __syncthreads();
   // J^T w per column: the primary source slot, then the extras (slot numbering of phase F)
   for (int c = tid; c < NP; c += 256) {

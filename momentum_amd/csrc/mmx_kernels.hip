@@ -2689,7 +2689,7 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
 // dense J: stage 1 factors and solves (d0 to `dvec`), stage 2 -- once per refinement round, after treeRefineKernel
 // left rho = J^T (r - J d) - lambda d in `rhoVec` -- solves for the correction and, when it was the last one,
 // applies the step.  refState[b]: 0 = a refinement round is due, 1 = the iteration's step has been applied.
-__global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
+__global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
     ProblemDev pb,
     int P,
     const float* __restrict__ jtj,

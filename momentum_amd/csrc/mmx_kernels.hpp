@@ -97,6 +97,7 @@ hipError_t launchTreeNormalEquations(
     const int32_t* done,
     double* errOut, // [B] error at theta, or null
     float* state, // [B][treeStateFloats(J, U)] hand-over to launchTreeRefine, or null
+    long long* clk, // profiling aid: eight per-phase cycle counters of block 0, or null
     hipStream_t stream);
 size_t treeStateFloats(int J, int U);
 // rho = J^T (r - J d) - lambda d through the tree, for the instances with refState[b] == 0 (dvec / rhoVec: [B][NP])

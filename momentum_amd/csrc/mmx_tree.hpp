@@ -28,7 +28,9 @@ constexpr int kC1 = 7; // first-order channels per joint: F(3) | N(3) | D (odd s
 //                      (tangent pass: prefix sums along the parent chain)
 // v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (exact products by 0/1), hence deterministic.
 // Tiles of 16 rows x 16 channels are dealt to the four waves.
-template <int NC, bool kSubtree, int STRIDE = NC> // NC channels per row, rows STRIDE floats apart
+// UN: k-steps per trip -- their table and value reads go out together, then the chained MFMAs (pays for long k ranges:
+// hundreds of joints; the 72-joint fused solve is faster with 1)
+template <int NC, bool kSubtree, int STRIDE = NC, int UN = 1> // NC channels per row, rows STRIDE floats apart
 __device__ __forceinline__ void treeSumT(
     const int32_t* subSize,
     const int32_t* loadedPos,
@@ -49,16 +51,28 @@ __device__ __forceinline__ void treeSumT(
     const int rsz = r < J ? subSize[r] : 0;
     const int c = 16 * ct + i; // column of the B operand this lane feeds
     v4f acc{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const int kk = k0 + g;
-      float av = 0.f, bv = 0.f;
-      if (kk < K) {
-        const int p = kSubtree ? loadedPos[kk] : kk;
-        const bool m = kSubtree ? (p >= r && p < r + rsz) : (r < J && p <= r && r < p + subSize[p]);
-        av = m ? 1.f : 0.f;
-        bv = c < NC ? in[STRIDE * p + c] : 0.f;
+    // prefix sums: only positions up to the tile's last row can be ancestors of its rows
+    const int kEnd = kSubtree ? K : (K < 16 * rt + 16 ? K : 16 * rt + 16);
+    for (int k0 = 0; k0 < kEnd; k0 += 4 * UN) {
+      int pp[UN], sz[UN];
+      float bv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int kk = k0 + 4 * u + g;
+        pp[u] = kSubtree ? loadedPos[kk < kEnd ? kk : 0] : kk;
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int kk = k0 + 4 * u + g;
+        sz[u] = kSubtree ? 0 : subSize[kk < kEnd ? pp[u] : 0];
+        bv[u] = (kk < kEnd && c < NC) ? in[STRIDE * pp[u] + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int kk = k0 + 4 * u + g, p = pp[u];
+        const bool m = kSubtree ? (p >= r && p < r + rsz) : (r < J && p <= r && r < p + sz[u]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((kk < kEnd && m) ? 1.f : 0.f, bv[u], acc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
