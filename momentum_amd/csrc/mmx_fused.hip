@@ -244,10 +244,46 @@ __device__ __forceinline__ ParamCol paramRowsColumn(
   return o;
 }
 
+// y = A x for a CSR matrix whose tables live in GLOBAL memory (the wide kernels; the fused solve keeps them in LDS):
+// four rows per trip with their row bounds, then their first entries, requested together -- a row's walk is a chain
+// of dependent L2 round trips otherwise.  Same products in the same order as the plain walk.
+template <typename Gather, typename Store>
+__device__ __forceinline__ void csrRowsPrefetched(const int32_t* outer, const int32_t* inner, const float* value, int R, int tid, Gather x, Store out) {
+  for (int r0 = tid; r0 < R; r0 += 4 * 256) {
+    int ka[4], kb[4], in0[4];
+    float v0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = min(r0 + 256 * i, R - 1);
+      ka[i] = outer[r], kb[i] = outer[r + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool has = kb[i] > ka[i];
+      in0[i] = has ? inner[ka[i]] : 0, v0[i] = has ? value[ka[i]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + 256 * i;
+      if (r < R) {
+        float acc = 0.f;
+        if (kb[i] > ka[i]) {
+          acc += v0[i] * x(in0[i]);
+          for (int k = ka[i] + 1; k < kb[i]; ++k) {
+            acc += value[k] * x(inner[k]);
+          }
+        }
+        out(r, acc);
+      }
+    }
+  }
+}
+
 // Forward kinematics of the whole skeleton from the parameters in `th` into s.js: local transforms
 // of all joints at once (parameter_transform.cpp:110-124, joint_state.cpp:44-62), world transforms
 // by pointer jumping (skeleton_state.cpp:100-121 re-associated), optionally the rotation axes.
 // Ends with a barrier.  Clobbers alt / jlA / jlB (assembly scratch = the Cholesky region).
+template <bool kGlobalTables = false> // the rig's CSR tables are read from global memory (prefetching walk)
 __device__ __forceinline__ void
 blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes, long long* clk = nullptr, long long* clkLast = nullptr) {
   auto stamp = [&](int slot) { // profiling aid (MMX_PHASE_CLOCKS): sub-phases of FK
@@ -262,14 +298,19 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   // 110-124; the same products in the same order as a per-joint walk): 7 J independent short CSR walks
   // instead of seven dependent ones per joint.  They land in the refinement scratch (jd), which is dead
   // whenever FK runs.
-  for (int r = tid; r < rig.R; r += 256) {
-    const float off = rig.ptOffsets[r];
-    float acc = 0.f;
-    const int k1 = rig.ptOuter[r + 1];
-    for (int k = rig.ptOuter[r]; k < k1; ++k) {
-      acc += rig.ptValue[k] * th[rig.ptInner[k]];
+  if (kGlobalTables) {
+    csrRowsPrefetched(
+        rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + rig.ptOffsets[r]; });
+  } else {
+    for (int r = tid; r < rig.R; r += 256) {
+      const float off = rig.ptOffsets[r];
+      float acc = 0.f;
+      const int k1 = rig.ptOuter[r + 1];
+      for (int k = rig.ptOuter[r]; k < k1; ++k) {
+        acc += rig.ptValue[k] * th[rig.ptInner[k]];
+      }
+      s.jd[r] = acc + off;
     }
-    s.jd[r] = acc + off;
   }
   // the joint's constants are requested before the barrier, so that their L2 round trip overlaps it
   float pre[4] = {0.f, 0.f, 0.f, 1.f}, off3[3] = {0.f, 0.f, 0.f};
@@ -1669,6 +1710,7 @@ struct TreeNeLds {
   float *th, *js, *alt, *up, *uy, *us, *own1, *own2, *sub1, *sub2, *umom, *jd, *srcT;
   int *jlA, *jlB, *span; // span[slot] = tin | tout << 16
   int *subSize, *loadedPos; // copies of the tables the subtree sums walk (read once per inner step)
+  int *posUnitStart, *posUnits; // ... and of the units-per-joint lists the own sums walk
   double* red;
 };
 
@@ -1688,10 +1730,11 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   const size_t oR = take(life1 > life2 ? life1 : life2);
   const size_t oSrc = take(size_t(kSrcCh) * size_t(srcStrideFor(nsrc)));
   const size_t oSpan = take(nsrc);
-  const size_t oSub = take(J), oLoaded = take(J);
+  const size_t oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U);
   const size_t oRed = take(16);
   if (out != nullptr) {
     out->span = reinterpret_cast<int*>(base + oSpan);
+    out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->th = base + oTh, out->js = base + oJs, out->alt = base + oAlt;
     out->jlA = reinterpret_cast<int*>(base + oJl), out->jlB = out->jlA + J;
@@ -1749,7 +1792,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   rv.levelOrder = rig.levelOrder, rv.levelStart = rig.levelStart;
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp, fv.subSize = t.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = t.loadedPos, fv.numLoaded = fd.numLoaded;
-  fv.colToSolve = nullptr, fv.unitPos = pb.unitTin, fv.posUnitStart = fd.posUnitStart, fv.posUnits = fd.posUnits, fv.solveList = fd.solveList;
+  fv.colToSolve = nullptr, fv.unitPos = pb.unitTin, fv.posUnitStart = t.posUnitStart, fv.posUnits = t.posUnits, fv.solveList = fd.solveList;
   for (int i = tid; i < P; i += 256) {
     s.th[i] = theta[size_t(b) * P + i];
   }
@@ -1757,13 +1800,19 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     t.subSize[i] = fd.subSize[i];
     t.loadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
   }
+  for (int i = tid; i <= J; i += 256) {
+    t.posUnitStart[i] = fd.posUnitStart[i];
+  }
+  for (int i = tid; i < U; i += 256) {
+    t.posUnits[i] = fd.posUnits[i];
+  }
   for (int e = tid; e < nsrc; e += 256) {
     t.span[e] = fd.srcs[e].tin | (fd.srcs[e].tout << 16);
   }
   __syncthreads();
   MMX_TCLK(0)
   // ---- A, B: forward kinematics with rotation axes
-  blockFk(rv, s, s.th, tid, true);
+  blockFk<true>(rv, s, s.th, tid, true);
   MMX_TCLK(1)
   // ---- C: units
   {
@@ -1994,7 +2043,7 @@ hipError_t launchTreeNormalEquations(
 // =============================================================================================
 struct TreeRefLds {
   float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0;
-  int *col, *subSize, *loadedPos;
+  int *col, *subSize, *loadedPos, *posUnitStart, *posUnits;
 };
 __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base) {
   size_t off = 0;
@@ -2009,8 +2058,9 @@ __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n
   const size_t oR1 = take(r1 > 7 * size_t(J) ? r1 : 7 * size_t(J));
   const size_t oR2 = take(size_t(kTan > kC1 ? kTan : kC1) * J); // tanOwn, then the own sums
   const size_t oPre = take(size_t(kTan) * J);
-  const size_t oD = take(NP), oCol = take(P), oSub = take(J), oLoaded = take(J);
+  const size_t oD = take(NP), oCol = take(P), oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U);
   if (out != nullptr) {
+    out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->js = base + oJs, out->up = base + oUp, out->ur = base + oUr, out->us = base + oUs;
     out->jd = base + oR1, out->sub1 = base + oR1, out->tanOwn = base + oR2, out->own1 = base + oR2, out->tanPre = base + oPre;
@@ -2045,7 +2095,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   s.js = t.js, s.up = t.up, s.ur = t.ur, s.us = t.us, s.own1 = t.own1, s.sub1 = t.sub1, s.jd = t.jd, s.tanOwn = t.tanOwn, s.tanPre = t.tanPre, s.d0 = t.d0;
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp, fv.subSize = t.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = t.loadedPos, fv.numLoaded = fd.numLoaded;
-  fv.colToSolve = t.col, fv.unitPos = pb.unitTin, fv.posUnitStart = fd.posUnitStart, fv.posUnits = fd.posUnits, fv.solveList = fd.solveList;
+  fv.colToSolve = t.col, fv.unitPos = pb.unitTin, fv.posUnitStart = t.posUnitStart, fv.posUnits = t.posUnits, fv.solveList = fd.solveList;
   {
     const TreeStateLayout sl = treeStateLayout(J, U);
     const float* stb = state + size_t(b) * sl.total;
@@ -2069,6 +2119,12 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
       t.subSize[i] = fd.subSize[i];
       t.loadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
     }
+    for (int i = tid; i <= J; i += 256) {
+      t.posUnitStart[i] = fd.posUnitStart[i];
+    }
+    for (int i = tid; i < U; i += 256) {
+      t.posUnits[i] = fd.posUnits[i];
+    }
   }
   __syncthreads();
   for (int c = tid; c < n; c += 256) {
@@ -2076,15 +2132,13 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   }
   __syncthreads();
   // joint-parameter delta jd = transform * delta
-  for (int r = tid; r < rig.R; r += 256) {
-    float a = 0.f;
-    const int k1 = rig.ptOuter[r + 1];
-    for (int k = rig.ptOuter[r]; k < k1; ++k) {
-      const int cs = t.col[rig.ptInner[k]];
-      a += rig.ptValue[k] * (cs >= 0 ? s.d0[cs] : 0.f);
-    }
-    s.jd[r] = a;
-  }
+  csrRowsPrefetched(
+      rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid,
+      [&](int c) {
+        const int cs = t.col[c];
+        return cs >= 0 ? s.d0[cs] : 0.f;
+      },
+      [&](int r, float a) { s.jd[r] = a; });
   __syncthreads();
   // tangent pass: per joint (by DFS position) C = T - Om x t - ln2 sd t, W = Om, S = sd ...
   for (int k = tid; k < J; k += 256) {

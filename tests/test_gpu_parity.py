@@ -536,3 +536,46 @@ def test_tree_moment_normal_equations_match_the_dense_product_on_the_wide_rig(to
     for th in (out_tree, out_dense):
         rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
         assert rel.max() <= 2e-5, rel
+
+
+@pytest.mark.parametrize(
+    "variant",
+    [
+        {},  # tree normal equations + left-looking factor + refinement through the tree (no dense J)
+        {"MMX_TREE_REFINE": "0"},  # ... refinement streaming the dense J (choleskyStepTiledKernel)
+        {"MMX_CHOL_RIGHT_LOOKING": "1"},  # ... right-looking factor in place (choleskyStepGlobalKernel)
+        {"MMX_TREE_NE": "0", "MMX_TREE_REFINE": "0"},  # dense J^T J on the matrix cores
+    ],
+    ids=["tree", "dense_refine", "right_looking", "dense_product"],
+)
+def test_wide_solve_variants_agree_with_the_oracle(torch_cuda, orc, variant, monkeypatch):
+    """The four routes of the wide explicit solve (300-joint rig) under the LM schedule and with elements that
+    converge at different iterations: same pose parameters, iteration counts and statuses as the oracle."""
+    from momentum_amd import make_rig300
+    from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
+
+    torch = torch_cuda
+    for k, v in variant.items():
+        monkeypatch.setenv(k, v)
+    rig = make_rig300(seed=12345, unit=UNIT)
+    rng = np.random.default_rng(78)
+    pp = rng.choice(rig.num_joints, size=150, replace=False)
+    op = rng.choice(rig.num_joints, size=50, replace=False)
+    B = 4
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=556, perturb=0.2)
+    th0[1] = ths[1]  # starts at its solution: converges at once, sits out the other elements' iterations
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    for opt in (
+        GnOptions.make(min_iterations=1, max_iterations=8, threshold=1e3, regularization=0.05),
+        GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE),
+    ):
+        out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+        ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+        th = out["theta"].cpu().numpy()
+        den = np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
+        rel = np.linalg.norm(th - ref["theta"], axis=1) / den
+        tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
+        assert np.all(rel <= tol), (variant, rel, tol)
+        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        if opt.step_rule != MMX_STEP_LM_SCHEDULE:
+            assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]), (out["iterations"], ref["iterations"])
