@@ -50,6 +50,9 @@ CONFIGS = {
     "cfg3": ("p128", "landmarks", 65536, 1, "BASELINE configs[2]: 65536 x 72-joint humanoid (P=128, M=192), LM gain-ratio damping schedule (lambda0=0.05), 10 iterations"),
     "cfg5": ("rig300", "cfg5", 8192, 0, "BASELINE configs[4]: 8192 x 300-joint hand+body rig (P=300), 150 position + 50 orientation constraints (M=900), GN lambda=0.05, 10 iterations"),
     "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
+    # production-shaped: what marker_tracker.cpp:916-960 adds to the marker constraints -- a plane block (8 floor contacts,
+    # PlaneErrorFunction) and MinMax limits on 16 parameters (LimitErrorFunction); takes the fused solve's general rows
+    "cfg2_tracker": ("p128", "landmarks+tracker", 4096, 0, "BASELINE configs[1] + PlaneErrorFunction (8 constraints) + 16 MinMax parameter limits (M=192+8+16)"),
 }
 
 # what the default single-GPU run reports besides the headline: (key, config, batch, line_search, timed steps, CPU sample)
@@ -58,6 +61,7 @@ EXTRA_RUNS = [
     ("cfg2@32768", "cfg2", 32768, 0, 6, 8192),
     ("cfg2@4096 line_search=2", "cfg2", 4096, 2, 10, 4096),
     ("cfg5@8192", "cfg5", 8192, 0, 3, 1024),
+    ("cfg2_tracker@4096", "cfg2_tracker", 4096, 0, 10, 4096),
 ]
 
 
@@ -85,7 +89,7 @@ def build_rig(config: str):
         rig = make_rig300(seed=12345, unit=UNIT)
     else:
         rig = make_humanoid72(seed=12345, variant=variant, unit=UNIT)
-    if which == "landmarks":
+    if which.startswith("landmarks"):
         pos_parents = ori_parents = humanoid72_landmark_joints(rig)
     elif which == "cfg5":
         prng = np.random.default_rng(77)
@@ -100,8 +104,8 @@ class DeviceBatch:
     """Synthetic batch generated ON the GPU: theta* = U[-0.3,0.3]^P, targets = FK(theta*) through the
     product's own FK kernel, theta0 = 0.  Every instance is distinct."""
 
-    def __init__(self, rig, parents, B, device_index, seed):
-        from momentum_amd import capi
+    def __init__(self, rig, parents, B, device_index, seed, tracker=False):
+        from momentum_amd import _abi, capi
 
         self.rig, self.parents, self.B = rig, parents, B
         pos_parents, ori_parents = parents
@@ -122,17 +126,34 @@ class DeviceBatch:
         self.ori_target = st[:, oidx, 3:7].contiguous()
         self.pos_weight = torch.ones((B, Kp), device=dev)
         self.ori_weight = torch.ones((B, Ko), device=dev)
-        pb.set_constraints(self.pos_offset, self.pos_target, self.pos_weight, self.ori_offset, self.ori_target, self.ori_weight, 1.0, 1.0)
+        self.blocks, self.limits = [], []
+        if tracker:
+            # planes through the solution's joint positions (random unit normals), MinMax limits that the solution respects
+            pj = np.asarray(pos_parents[:8], np.int32)
+            nrm = torch.randn((B, len(pj), 3), generator=g, device=dev, dtype=torch.float32)
+            nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+            pstar = st[:, torch.as_tensor(pj.astype(np.int64), device=dev), 0:3]
+            d = (nrm * pstar).sum(-1).contiguous()
+            self.blocks = [_abi.JointBlock(_abi.MMX_JC_PLANE, pj, torch.ones((B, len(pj)), device=dev), nrm.contiguous(),
+                                           local_point=torch.zeros((B, len(pj), 3), device=dev), plane_d=d)]  # fmt: skip
+            self.limits = [_abi.ParameterLimit.minmax(int(p), -0.35, 0.35, 1.0) for p in range(6, 22)]
+        pb.set_constraints(self.pos_offset, self.pos_target, self.pos_weight, self.ori_offset, self.ori_target, self.ori_weight, 1.0, 1.0,
+                           joint_blocks=self.blocks or None, limits=self.limits or None)  # fmt: skip
         self.theta0 = torch.zeros((B, P), device=dev, dtype=torch.float32)
 
     def host_constraints(self, n):
         """The first n instances of this very batch as the oracle's input (host copies)."""
         from oracle import oracle as orc
 
+        from momentum_amd import _abi
+
         c = lambda t: t[:n].cpu().numpy()
+        blocks = [_abi.JointBlock(k.type, k.parent, c(k.weight), c(k.global_), c(k.local_point), None, c(k.plane_d), k.function_weight, k.loss)
+                  for k in self.blocks]  # fmt: skip
         return orc.Constraints(
             self.parents[0], c(self.pos_offset), c(self.pos_target), c(self.pos_weight),
             self.parents[1], c(self.ori_offset), c(self.ori_target), c(self.ori_weight),
+            joint_blocks=blocks, limits=list(self.limits),
         )  # fmt: skip
 
 
@@ -288,7 +309,7 @@ def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iter
     from momentum_amd._abi import GnOptions
 
     rig, parents, _, step_rule, desc = build_rig(config)
-    db = DeviceBatch(rig, parents, B, device_index, 424242)
+    db = DeviceBatch(rig, parents, B, device_index, 424242, tracker=CONFIGS[config][1].endswith("+tracker"))
     opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=line_search)
     elapsed, theta, norms = solve_loop(db, opt, steps, 1)
     out = {
@@ -360,7 +381,7 @@ def main() -> None:
     rig, parents, defB, step_rule, desc = build_rig(args.config)
     B = args.batch if args.batch > 0 else defB
     seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
-    db = DeviceBatch(rig, parents, B, local_rank, seed)
+    db = DeviceBatch(rig, parents, B, local_rank, seed, tracker=CONFIGS[args.config][1].endswith("+tracker"))
     pb, theta_star = db.pb, db.theta_star
     opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=args.line_search)
     dev = pb.device
@@ -420,10 +441,11 @@ def main() -> None:
         extra["fill_same_bytes_gbs"] = bytes_per_launch / (fill_ms * 1e-3) / 1e9
         # the same stores (layout, workgroup shape, width) without any kinematics: what the write
         # pattern of a column-major J per instance allows on this box
-        for _ in range(2):
-            pb.store_pattern_kernel_ms(fill)
-        sp_ms = float(np.mean([pb.store_pattern_kernel_ms(fill) for _ in range(5)]))
-        extra["store_pattern_gbs"] = B * 4 * M * P / (sp_ms * 1e-3) / 1e9
+        if M == 3 * (Kp_ + 3 * Ko_):  # (the probe replays the stores of position / orientation rows only)
+            for _ in range(2):
+                pb.store_pattern_kernel_ms(fill)
+            sp_ms = float(np.mean([pb.store_pattern_kernel_ms(fill) for _ in range(5)]))
+            extra["store_pattern_gbs"] = B * 4 * M * P / (sp_ms * 1e-3) / 1e9
         del fill
         BL = 32768
         if args.config == "cfg2" and B < BL:

@@ -351,9 +351,27 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         force[size_t(p)] = 1;
       }
     }
+    // joints that carry a further joint error function or an ellipsoid limit count like constrained joints for the
+    // structure (solve list, source slots): point-like ones see every dof above them, fixed-axis ones rotations only
+    std::vector<int32_t> structPos, structOri;
+    if (pb->instPos) {
+      structPos = pb->unionPos;
+    }
+    if (pb->instOri) {
+      structOri = pb->unionOri;
+    }
+    for (const auto& h : pb->blocks) {
+      const bool fixedAxis = h->type == MMX_JC_FIXED_AXIS_DIFF || h->type == MMX_JC_FIXED_AXIS_COS || h->type == MMX_JC_FIXED_AXIS_ANGLE;
+      for (int32_t j : h->parent) {
+        (fixedAxis ? structOri : structPos).push_back(j);
+      }
+    }
+    for (const mmx_ellipsoid_limit& e : pb->ellipsoids) {
+      structPos.push_back(e.parent);
+    }
     const int32_t rc = mmx::buildFusedTables(
-        &rd, t, pb->Kp, pb->posParent.data(), pb->Ko, pb->oriParent.data(), force.data(), pb->instPos ? &pb->unionPos : nullptr,
-        pb->instOri ? &pb->unionOri : nullptr, pb->fused, err);
+        &rd, t, pb->Kp, pb->posParent.data(), pb->Ko, pb->oriParent.data(), force.data(), structPos.empty() ? nullptr : &structPos,
+        structOri.empty() ? nullptr : &structOri, pb->fused, err);
     if (rc != MMX_OK) {
       return fail(rc, err);
     }
@@ -675,6 +693,8 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       fd.pairStart = pb->dPairStart.as<int32_t>();
       fd.pairLim = pb->dPairLim.as<int32_t>();
     }
+    pb->fdev.GT = pb->dev.G + int32_t(pb->ellipsoids.size());
+    pb->fdev.genRows = pb->fdev.GT > 0 ? pb->dev.rowsJoint - 3 * pb->U : 0;
   }
   // Solve list of the explicit-Jacobian solver: an enabled parameter none of whose joint-parameter
   // rows has a constraint below it has a zero column in J, so its step is 0 (H_pp = lambda, g_p = 0)
@@ -746,11 +766,18 @@ int32_t uploadProblemTables(mmx_problem* pb) {
 
 bool fusedUsable(const mmx_problem* pb) {
   const int nb = mmx::fusedBlocksFor(pb->fdev.n);
-  if (nb < 0 || pb->dev.G > 0 || pb->dev.NE > 0) { // the further joint-constraint blocks and ellipsoid limits live in the explicit-Jacobian kernels
+  if (nb < 0) {
+    return false;
+  }
+  // (the further joint-constraint blocks and ellipsoid limits ride along as a dense block of rows in LDS -- fdev.GT /
+  // genRows -- while they fit; MMX_FUSED_GENERAL=0 sends them to the explicit-Jacobian kernels)
+  if (pb->fdev.GT > 0 && getenv("MMX_FUSED_GENERAL") != nullptr && getenv("MMX_FUSED_GENERAL")[0] == '0') {
     return false;
   }
   return pb->rig->J < 4096 &&
-      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rigDev.numLevels) + size_t(8) * size_t(pb->rig->J + pb->rig->P) <= 160 * 1024;
+      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rigDev.numLevels, pb->fdev.GT, pb->fdev.genRows) +
+          size_t(8) * size_t(pb->rig->J + pb->rig->P) <=
+      160 * 1024;
 }
 
 // H and g of the explicit-Jacobian solver from the tree moments instead of the dense J (treeNormalEquationsKernel):
@@ -1745,7 +1772,7 @@ static int32_t solveImpl(
   const int n = ds.n;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (fusedUsable(pb) && !wantLegacySolver()) {
+  if (fusedUsable(pb) && !wantLegacySolver() && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION)) {
     // fused path: the whole SolverT::solve loop in one launch, one workgroup per instance
     MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
     MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));

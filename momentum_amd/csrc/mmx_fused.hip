@@ -59,6 +59,11 @@ struct FusedLds {
   float* tanPre; // [kTan J]
   double* red; // [8]
   int* flags; // [4]
+  // ---- rows of the further joint error functions and ellipsoid limits (kGen instantiations): dense in LDS
+  float* gEv; // [GT][kGenEv] per constraint: vp(3) vn(3) sigma*dp(9) sigma*dn(9) tin row flags tinStop
+  float* gRes; // [rowsGp] residual rows
+  float* gW; // [rowsGp] r - J d of the refinement
+  float* gJ; // [rowsGp][gst] their Jacobian rows over the solve columns (pad rows / columns zero)
   // ---- one region, two lives: assembly scratch (phases A-G), then the Cholesky factor (H-J)
   float* alt; // [kAlt J] second transform buffer of the pointer-jumping FK
   int* jlA; // [J] jump targets (+1), double-buffered
@@ -347,9 +352,28 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   }
 }
 
+constexpr int kGenEv = 29; // words per constraint record (odd stride)
+
+// error of the further joint error functions + ellipsoid limits at the joint states in js (this thread's share)
+__device__ __forceinline__ double generalRowsError(const ProblemDev& pb, const float* js, int b, int tid) {
+  double e = 0.0;
+  for (int g = tid; g < pb.G; g += 256) {
+    const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+    e += double(evalJointConstraint(k, js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(g - k.first)).werr);
+  }
+  if (pb.wLimit > 0.f) {
+    const float tWeightE = 1e+1f * pb.wLimit;
+    for (int q = tid; q < pb.NE; q += 256) {
+      e += double(evalEllipsoid(pb.ellipsoids[q], js, tWeightE).werr);
+    }
+  }
+  return e;
+}
+
 // SkeletonSolverFunctionT::getError (skeleton_solver_function.cpp:64-83) of the parameters in
 // `th`: FK without derivatives + sum of w * |f|^2, rounded through float like the reference (:82).
 // Every thread returns the same value.  Clobbers the FK scratch / js / red.
+template <bool kGen = false>
 __device__ __forceinline__ double blockError(
     const RigDev& rigDev,
     const RigView& rig,
@@ -367,6 +391,9 @@ __device__ __forceinline__ double blockError(
   }
   if (pb.M > pb.rowsJoint) {
     e += paramRowsError<false>(rigDev, pb, rig.P, th, b, tid);
+  }
+  if (kGen) {
+    e += generalRowsError(pb, s.js, b, tid);
   }
   e = waveReduceSum(e);
   if (lane == 0) {
@@ -554,8 +581,11 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
 // Workgroups per CU follow the LDS footprint (tiles: 1 KB each): three up to NB = 6, two up to NB = 8,
 // one beyond -- the register budget is set to match, so the wide systems do not spill.
 // kTR: the TrustRegionQRT step rule (its re-solve loops are compiled into that instantiation only)
-template <int NB, int MODE, bool kTR>
-__global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
+// kGen: rows of the further joint error functions (plane / aim / fixed axis / normal / ...) and of the ellipsoid limits:
+// evaluated per iteration into a small dense block J_g (LDS), added to g, H (matrix-core rank-k update of the tiles),
+// the refinement residual and the trial errors.  More LDS, so at most two workgroups per CU.
+template <int NB, int MODE, bool kTR, bool kGen = false>
+__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
@@ -628,6 +658,14 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     s.invDiag = take(NP);
     s.red = reinterpret_cast<double*>(take(16));
     s.flags = reinterpret_cast<int*>(take(4));
+    s.gEv = s.gRes = s.gW = s.gJ = nullptr;
+    if (kGen) {
+      const int rowsGp = (fd.genRows + 3) & ~3;
+      s.gEv = take(size_t(kGenEv) * size_t(fd.GT));
+      s.gRes = take(rowsGp);
+      s.gW = take(rowsGp);
+      s.gJ = take(size_t(rowsGp) * size_t(srcStrideFor(NP)));
+    }
     float* blockJ = p; // srcT (phases E-G)  |  dfull, jd, tanOwn, tanPre (phases J-K)
     s.dfull = take(P);
     s.jd = take(7 * size_t(J));
@@ -693,6 +731,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
   }
   for (int i = tid; i < P; i += 256) {
     lColToSolve[i] = -1;
+  }
+  if (kGen) { // pad rows / pad columns of J_g stay zero for the whole launch
+    const int rowsGp = (fd.genRows + 3) & ~3;
+    for (int i = tid; i < rowsGp * srcStrideFor(NP); i += 256) {
+      s.gJ[i] = 0.f;
+    }
+    for (int i = tid; i < rowsGp; i += 256) {
+      s.gRes[i] = 0.f;
+      s.gW[i] = 0.f;
+    }
   }
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
@@ -835,6 +883,55 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
       if (hasParamRows) {
         e += paramRowsError<true>(rig, pb, P, s.th, b, tid);
       }
+      if (kGen) { // the further joint error functions and the ellipsoid limits: records for the rows of J_g, residual rows
+        int* evi = reinterpret_cast<int*>(s.gEv);
+        for (int g = tid; g < pb.G; g += 256) {
+          const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+          const int i = g - k.first;
+          const JointEval o = evalJointConstraint(k, s.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(i));
+          const int row = k.rowStart + o.nrows * i - 3 * U;
+          e += double(o.werr);
+          for (int q = 0; q < o.nrows; ++q) {
+            s.gRes[row + q] = o.sigma * o.f[q];
+          }
+          const float sg = fabsf(o.sigma) <= 1e-9f ? 0.f : o.sigma; // early termination (joint_error_function-inl.h:216): the rows stay zero
+          float* w = s.gEv + kGenEv * g;
+          w[0] = o.vp.x, w[1] = o.vp.y, w[2] = o.vp.z;
+          w[3] = o.vn.x, w[4] = o.vn.y, w[5] = o.vn.z;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            w[6 + q] = sg * o.dp[q];
+            w[15 + q] = sg * o.dn[q];
+          }
+          evi[kGenEv * g + 24] = pb.genTin[g];
+          evi[kGenEv * g + 25] = row;
+          evi[kGenEv * g + 26] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0);
+          evi[kGenEv * g + 27] = -1;
+        }
+        const float tWeightE = 1e+1f * pb.wLimit;
+        for (int q = tid; q < pb.NE; q += 256) { // LimitType::Ellipsoid (limit_error_function.cpp:702-790), see jointBlocksKernel
+          const EllipsoidDev ct = pb.ellipsoids[q];
+          const int row = pb.rowsJoint - 3 * pb.NE + 3 * q - 3 * U, g = pb.G + q;
+          EllipsoidEval o = evalEllipsoid(ct, s.js, tWeightE);
+          if (!(pb.wLimit > 0.f)) {
+            o.jwgt = o.werr = 0.f;
+          }
+          e += double(o.werr);
+          s.gRes[row] = o.diff.x * o.jwgt, s.gRes[row + 1] = o.diff.y * o.jwgt, s.gRes[row + 2] = o.diff.z * o.jwgt;
+          float* w = s.gEv + kGenEv * g;
+          w[0] = o.position.x, w[1] = o.position.y, w[2] = o.position.z;
+          w[3] = w[4] = w[5] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            w[6 + k] = (k == 0 || k == 4 || k == 8) ? o.jwgt : 0.f;
+            w[15 + k] = 0.f;
+          }
+          evi[kGenEv * g + 24] = ct.tinParent;
+          evi[kGenEv * g + 25] = row;
+          evi[kGenEv * g + 26] = 3 | 16;
+          evi[kGenEv * g + 27] = ct.tinStop;
+        }
+      }
       e = waveReduceSum(e);
       if (lane == 0) {
         s.red[wave] = e;
@@ -842,6 +939,64 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
     }
     __syncthreads();
     curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); // every thread: the same value
+    if (kGen) {
+      // J_g: entry (row of constraint g, solve column c) gathered from the column's source slots, the walk of
+      // joint_error_function-inl.h:228-294 turned around as in jointBlocksKernel (constraints fastest)
+      const int gst = srcStrideFor(NP), GT = fd.GT;
+      const int* evi = reinterpret_cast<const int*>(s.gEv);
+      for (int item = tid; item < GT * n; item += 256) {
+        const int c = item / GT, g = item - c * GT;
+        const float* w = s.gEv + kGenEv * g;
+        const int tin = evi[kGenEv * g + 24], row = evi[kGenEv * g + 25], fl = evi[kGenEv * g + 26], tinStop = evi[kGenEv * g + 27];
+        const bool hasPoint = (fl & 16) != 0, hasDir = (fl & 32) != 0;
+        const F3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
+        float acc[3] = {0.f, 0.f, 0.f};
+        auto addSlot = [&](int e) {
+          const int span = s.mTin[e];
+          const int stin = span & 0xffff, stout = span >> 16;
+          if (!(stin <= tin && tin < stout)) {
+            return; // the slot's joint is not an ancestor of the constraint's joint
+          }
+          if (tinStop >= 0 && stin <= tinStop && tinStop < stout) {
+            return; // ellipsoid limit: the walk stopped before this joint
+          }
+          const int info = s.mInfo[e];
+          const int joint = info & 0xfff, dof = (info >> 12) & 7, parent = (info >> 16) - 1;
+          const float* a = s.js + kJs * joint;
+          F3 gp{0.f, 0.f, 0.f}, gn{0.f, 0.f, 0.f};
+          if (dof >= 3 && dof < 6) {
+            const float* ax = a + 8 + 3 * (dof - 3);
+            const F3 axis{ax[0], ax[1], ax[2]};
+            if (hasPoint) {
+              gp = cross(axis, vp - F3{a[0], a[1], a[2]});
+            }
+            if (hasDir) {
+              gn = cross(axis, vn);
+            }
+          } else if (hasPoint) {
+            gp = dof < 3 ? transAxisCol(s.js, parent, dof) : kLn2 * (vp - F3{a[0], a[1], a[2]});
+          }
+          const float wgt = s.mW[e];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const float jc = (w[6 + 3 * q] * gp.x + w[7 + 3 * q] * gp.y + w[8 + 3 * q] * gp.z) +
+                (w[15 + 3 * q] * gn.x + w[16 + 3 * q] * gn.y + w[17 + 3 * q] * gn.z);
+            acc[q] += jc * wgt;
+          }
+        };
+        addSlot(c);
+        const int e1 = NP + s.mStart[c + 1];
+        for (int e = NP + s.mStart[c]; e < e1; ++e) {
+          addSlot(e);
+        }
+        s.gJ[row * gst + c] = acc[0];
+        if ((fl & 15) == 3) {
+          s.gJ[(row + 1) * gst + c] = acc[1];
+          s.gJ[(row + 2) * gst + c] = acc[2];
+        }
+      }
+      __syncthreads();
+    }
     MMX_CLK(2)
     int newtonIter = 0, pdRetries = 0;
     for (;;) { // one pass per value of the damping (the trust region's Newton updates change it, :180-231)
@@ -935,6 +1090,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
         const ParamCol pc = paramRowsColumn(rig, pb, fd, s.th, nullptr, lColToSolve, P, b, c, lSolveList[c]);
         acc += pc.g;
         s.rho[c] = pc.h; // parked until the tiles of H exist (phase G)
+      }
+      if (kGen && c < n) {
+        const int gst = srcStrideFor(NP);
+        for (int r = 0; r < fd.genRows; ++r) {
+          acc += s.gJ[r * gst + c] * s.gRes[r];
+        }
       }
       s.g[c] = acc;
       s.d0[c] = acc;
@@ -1086,6 +1247,25 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
             accp += ca * cb;
           }
           s.L[fd.pairDest[d]] += accp;
+        }
+      }
+      __syncthreads();
+    }
+    if (kGen) { // + J_g^T J_g: a rank-genRows update of every tile on the matrix cores (operands straight from J_g)
+      const int i = lane & 15, gq = lane >> 4;
+      const int gst = srcStrideFor(NP), steps = (fd.genRows + 3) >> 2;
+      for (int t = wave; t < T; t += 4) {
+        int I, Jc;
+        tileDecode(t, I, Jc);
+        v4f acc{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < steps; ++k) {
+          const float* rowp = s.gJ + (4 * k + gq) * gst;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowp[16 * I + i], rowp[16 * Jc + i], acc, 0, 0, 0);
+        }
+        float* Tc = s.L + 256 * t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Tc[tileAddr(4 * gq + q, i)] += acc[q];
         }
       }
       __syncthreads();
@@ -1305,6 +1485,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
       }
       __syncthreads();
       MMX_CLK(16)
+      if (kGen) { // w_g = r_g - J_g d (consumed by the rho loop below, several barriers later)
+        const int gst = srcStrideFor(NP);
+        for (int r = tid; r < fd.genRows; r += 256) {
+          float a = s.gRes[r];
+          for (int c = 0; c < n; ++c) {
+            a -= s.gJ[r * gst + c] * s.d0[c];
+          }
+          s.gW[r] = a;
+        }
+      }
       // tangent pass: per joint (stored by DFS position) C = T - Om x t - ln2 sd t, W = Om, S = sd
       for (int k = tid; k < J; k += 256) {
         const int q = fv.dfsJoint[k];
@@ -1445,6 +1635,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
           if (hasParamRows) {
             a += paramRowsColumn(rig, pb, fd, s.th, s.d0, lColToSolve, P, b, c, lSolveList[c]).g;
           }
+          if (kGen) {
+            const int gst = srcStrideFor(NP);
+            for (int r = 0; r < fd.genRows; ++r) {
+              a += s.gJ[r * gst + c] * s.gW[r];
+            }
+          }
           a -= mu * s.d0[c];
         }
         s.rho[c] = a;
@@ -1541,7 +1737,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
         s.dfull[fv.solveList[c]] -= s.d0[c];
       }
       __syncthreads();
-      const double eNew = blockError(rig, rv, pb, fv, s, s.dfull, b, tid);
+      const double eNew = blockError<kGen>(rig, rv, pb, fv, s, s.dfull, b, tid);
       const float predicted = trDg + (trMu - 1e-20f) * trDn2; // e - model
       const float rho = float((curError - eNew) / double(predicted));
       if (rho < 0.25f) { // :256-262 (lambda > 0 always holds: it starts at 1e-10)
@@ -1578,7 +1774,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
         s.dfull[fv.solveList[c]] -= s.d0[c];
       }
       __syncthreads();
-      const double eNew = blockError(rig, rv, pb, fv, s, s.dfull, b, tid);
+      const double eNew = blockError<kGen>(rig, rv, pb, fv, s, s.dfull, b, tid);
       const float rho = predicted > 0.f ? float((curError - eNew) / double(predicted)) : -1.f;
       if (rho > 0.f) {
         for (int i = tid; i < P; i += 256) {
@@ -1616,7 +1812,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 ? 3 : (NB <= 8 ? 2 : 1))) fusedS
           s.dfull[fv.solveList[c]] -= scale * s.d0[c];
         }
         __syncthreads();
-        const double eNew = blockError(rig, rv, pb, fv, s, s.dfull, b, tid);
+        const double eNew = blockError<kGen>(rig, rv, pb, fv, s, s.dfull, b, tid);
         if ((curError - eNew) >= (fp.doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale * scaledError))) {
           break;
         }
@@ -2260,7 +2456,7 @@ hipError_t launchTreeRefine(
 
 // ---------------------------------------------------------------------------------------------
 #if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels) {
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels, int GT, int genRows) {
   const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
   const size_t meta = a4(NP + 1) + 3 * a4(nsrc) + 2 * a4(J) + a4(numLevels + 1) + a4(7 * size_t(J) + 1) + 2 * a4(nnz) + a4(J) +
@@ -2271,11 +2467,13 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
   const size_t blockJ = refine > srcT ? refine : srcT;
   const size_t scratch = a4(size_t(kAlt) * J) + 2 * a4(J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kUmom) * U);
   const size_t region = scratch > T * 256 ? scratch : T * 256;
-  return (meta + fixed + blockJ + region) * sizeof(float);
+  const size_t rowsGp = (size_t(genRows) + 3) & ~size_t(3);
+  const size_t gen = GT > 0 ? a4(size_t(kGenEv) * GT) + 2 * a4(rowsGp) + a4(rowsGp * size_t(srcStrideFor(int(NP)))) : 0;
+  return (meta + fixed + gen + blockJ + region) * sizeof(float);
 }
 #endif
 
-template <int NB, int MODE, bool kTR>
+template <int NB, int MODE, bool kTR, bool kGen = false>
 static hipError_t launchFusedMode(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -2287,20 +2485,20 @@ static hipError_t launchFusedMode(
     float* dbgG,
     long long* dbgClk,
     hipStream_t stream) {
-  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.nnz, rig.numLevels);
+  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.nnz, rig.numLevels, kGen ? fd.GT : 0, kGen ? fd.genRows : 0);
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }
   static size_t attrBytes = 64 * 1024; // default dynamic-LDS limit; raised on demand
   if (lds > attrBytes) {
     hipError_t rc = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (rc != hipSuccess) {
       return rc;
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
   return hipGetLastError();
 }
 
@@ -2316,6 +2514,15 @@ static hipError_t launchFusedNB(
     float* dbgG,
     long long* dbgClk,
     hipStream_t stream) {
+  if (fd.GT > 0) { // further joint error functions / ellipsoid limits: the production and the parity-dump instantiations only
+    if (fp.stepRule == 2) {
+      return hipErrorInvalidValue;
+    }
+    if (dbgH != nullptr || dbgG != nullptr) {
+      return launchFusedMode<NB, 1, false, true>(rig, pb, fd, theta, st, fp, dbgH, dbgG, nullptr, stream);
+    }
+    return launchFusedMode<NB, 0, false, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+  }
   if (fp.stepRule == 2) { // MMX_STEP_TRUST_REGION: its own instantiation (no clocks / parity dump in it)
     return launchFusedMode<NB, 0, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
   }

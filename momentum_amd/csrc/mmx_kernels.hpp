@@ -70,6 +70,9 @@ struct FusedDev {
   const int32_t* pairCols; // [numPairDests][2] the two solve columns of that entry
   const int32_t* pairStart; // [numPairDests+1]
   const int32_t* pairLim; // limit indices per destination
+  // rows of the further joint error functions + ellipsoid limits handled inside the fused solve (kGen instantiations):
+  // GT = constraints (ProblemDev::G + NE), genRows = their Jacobian rows (rowsJoint - 3 U); 0 / 0: none
+  int32_t GT, genRows;
 };
 
 struct FusedParams {
@@ -84,7 +87,7 @@ struct FusedParams {
   float trustRadius; // TrustRegionQROptions::trustRegionRadius_
 };
 
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels);
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels, int GT = 0, int genRows = 0);
 // H = J^T J, g = J^T r from the tree moments for the explicit-Jacobian solver (mmx_fused.hip, treeNormalEquationsKernel)
 size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc);
 hipError_t launchTreeNormalEquations(

@@ -96,3 +96,53 @@ def test_solve_with_ellipsoid_limits_matches_oracle(orc, which, line_search):
     h = out["error_history"].cpu().numpy()
     assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
     assert (out["status"].cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize("which", ["chain8", "humanoid72"])
+def test_fused_solve_carries_blocks_and_ellipsoids(orc, which, monkeypatch):
+    """The one-launch solve with a half-plane block, ellipsoid limits and parameter limits next to the position /
+    orientation constraints (the marker tracker's shape, marker_tracker.cpp:916-960): its normal equations
+    (parity hook of the fused kernel -- only answered when the problem takes the fused path) against the oracle's
+    J^T J / J^T r in double, then the solve under three step rules against the oracle and against the
+    explicit-Jacobian kernels (MMX_FUSED_GENERAL=0)."""
+    import torch
+
+    from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
+    from tests.test_gpu_parity import _sensitivity
+
+    B = 4
+    monkeypatch.delenv("MMX_FUSED_GENERAL", raising=False)
+    rig, pb, full, th0 = _setup(torch, orc, which, B, 29, True)
+    rng = np.random.default_rng(6)
+    theta = rng.uniform(-0.4, 0.4, size=(B, rig.num_params)).astype(np.float32)
+    lst, jtj, jtr = pb.fused_normal_equations(torch.from_numpy(theta).to(pb.device))
+    jtj, jtr = jtj.cpu().numpy(), jtr.cpu().numpy()
+    for b in range(B):
+        J, r, e = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), dtype="f64")
+        Je = J[:, lst]
+        H, g = Je.T @ Je, Je.T @ r
+        assert np.abs(jtj[b] - H).max() <= 5e-5 * max(1.0, np.abs(H).max()), np.abs(jtj[b] - H).max() / np.abs(H).max()
+        assert np.abs(jtr[b] - g).max() <= 5e-5 * max(1.0, np.abs(g).max())
+        other = np.setdiff1d(np.arange(rig.num_params), lst)
+        if other.size:  # what left the solve list is structurally zero
+            assert np.abs(J[: full.rows - len(full.limits), other]).max() == 0.0
+    for opt in (
+        GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05),
+        GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05, do_line_search=2),
+        GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE),
+    ):
+        ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+        tol = np.maximum(3e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
+        outs = []
+        for general in ("1", "0"):
+            monkeypatch.setenv("MMX_FUSED_GENERAL", general)
+            out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+            th = out["theta"].cpu().numpy()
+            rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+            assert (rel <= tol).all(), (general, rel, tol)
+            assert (out["status"].cpu().numpy() == 0).all()
+            h = out["error_history"].cpu().numpy()
+            assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
+            outs.append(th)
+        monkeypatch.delenv("MMX_FUSED_GENERAL", raising=False)
+        assert not np.array_equal(outs[0], outs[1])  # two different routes really ran (fp32 rounding differs)

@@ -1,6 +1,7 @@
 """GPU parity of the further JointErrorFunctionT specialisations (Plane / HalfPlane / AimDist / AimDir /
 FixedAxisDiff / Cos / Angle / Normal) against the CPU oracle, through the C ABI.
-Problems with such blocks take the explicit-Jacobian kernels (J assembly -> J^T J -> Cholesky step)."""
+While they fit the fused solve carries these rows as a small dense block (kGen instantiations of fusedSolveKernel);
+MMX_FUSED_GENERAL=0 or larger problems take the explicit-Jacobian kernels (J assembly -> J^T J -> Cholesky step)."""
 import numpy as np
 import pytest
 
