@@ -1115,6 +1115,17 @@ int32_t mmx_problem_set_enabled(mmx_problem* pb, const uint8_t* enabled) {
   if (enabled == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "enabled is null");
   }
+  // an unchanged mask leaves every table as it is (callers like Solver.solve set it before every solve; the rebuild
+  // is host bookkeeping plus some thirty synchronous uploads)
+  if (!pb->tablesDirty && pb->tables.enabled.size() == size_t(pb->rig->P)) {
+    bool same = true;
+    for (size_t p = 0; p < pb->tables.enabled.size() && same; ++p) {
+      same = (pb->tables.enabled[p] != 0) == (enabled[p] != 0);
+    }
+    if (same) {
+      return MMX_OK;
+    }
+  }
   const mmx_rig_desc d = pb->rig->desc();
   std::string err;
   mmx::HostTables t;

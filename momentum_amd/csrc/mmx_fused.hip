@@ -608,12 +608,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   selectInstanceRig(rig, b);
-#ifdef MMX_EXP_STATIC // experiment: every size a compile-time constant (cfg2), so that every LDS address is a literal
-  constexpr int J = 72, P = 128, U = 64, n = 96, nsrc = 112, kR = 504, kNnz = 167, kLevels = 13;
-#else
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int kR = rig.R, kNnz = fd.nnz, kLevels = rig.numLevels;
-#endif
 
   // ---- LDS carve (every offset a multiple of 4 floats); must match fusedLdsBytes()
   FusedLds s;
@@ -1167,11 +1163,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     }
     __syncthreads();
     MMX_CLK(12)
-#ifdef MMX_EXP_NOREC
-    if (false) {
-#else
     if (fd.termRounds > 0) {
-#endif
       float h = 0.f;
       for (int k0 = 0; k0 < fd.termRounds; k0 += 8) {
         uint2 rec[8];

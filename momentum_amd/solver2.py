@@ -346,7 +346,7 @@ class SkeletonSolverFunction(SolverFunction):
     def _merged(self, cls, B: int, width: int):
         """all error functions of class `cls` as one constraint list; the function weight is folded
         into the constraint weights (w = c.weight * weight_, joint_error_function-inl.h:205)"""
-        fns = [e for e in self._efs if type(e) is cls]
+        fns = [e for e in self._efs if isinstance(e, cls) and not isinstance(e, _BlockErrorFunction)]  # user subclasses included
         if len({(e.alpha, e.c) for e in fns}) > 1:
             raise RuntimeError(f"{cls.__name__}: error functions with different losses cannot share a problem")
         parents, weights, offs, tgts = [], [], [], []
@@ -415,7 +415,13 @@ class SkeletonSolverFunction(SolverFunction):
         return float(e[0]) if single else e
 
     def get_jacobian(self, model_parameters):
-        """(residual [.., M], jacobian [.., M, P]) like SolverFunctionT::getJacobian."""
+        """(residual [.., M], jacobian [.., M, P]) like SolverFunctionT::getJacobian.
+
+        Row order: all position constraints (3 rows each, in the order their error functions were added), all
+        orientation constraints (9 rows each), the further joint error functions block by block, ellipsoid limits,
+        parameter limits, model-parameter rows -- grouped by kind, NOT interleaved in add_error_function order like the
+        reference's per-function offsets (skeleton_solver_function.cpp:97-133).  J^T J, J^T r and the solve do not
+        depend on the row order."""
         single, mp = self._params(model_parameters)
         pb, torch = self.lower(mp.shape[0])
         jac, res, _ = pb.eval_jacobian(torch.from_numpy(mp).to(pb.device))
