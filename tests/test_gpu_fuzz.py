@@ -134,8 +134,9 @@ def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
 @pytest.mark.parametrize("seed", range(16))
 def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
     """The same random rigs with the further joint error functions and Ellipsoid limits: exercises the
-    host tables of the explicit-Jacobian kernels (flattened constraint lists, DFS indices, the stop
-    index of the ellipsoid walk, the compacted solve list) on arbitrary trees."""
+    host tables (flattened constraint lists, DFS indices, the stop index of the ellipsoid walk, the compacted
+    solve list) on arbitrary trees -- J / r through the explicit-Jacobian kernels, the solve through the fused
+    kernel's general rows."""
     from momentum_amd import capi
     from momentum_amd._abi import EllipsoidLimit
     from tests.test_oracle_joint_blocks import TYPES, make_block
@@ -181,6 +182,13 @@ def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     ref = orc.solve_batch(rig, full, th0, opt, enabled=en, dtype="f64")
     th = out["theta"].cpu().numpy()
-    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
-    assert np.all(rel <= 1e-4), (seed, rel)
+    den = np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / den
+    # acos-type blocks (fixed-axis angle) amplify single-precision rounding: the bound follows what the oracle's own
+    # float instantiation loses on the same instance (seed 15: 5.5e-5; explicit-Jacobian kernels 7e-5, fused solve 1.2e-4)
+    ref32 = orc.solve_batch(rig, full, th0, opt, enabled=en, dtype="f32")
+    tol = np.maximum(1e-4, 3.0 * np.linalg.norm(ref32["theta"] - ref["theta"], axis=1) / den)
+    assert np.all(rel <= tol), (seed, rel, tol)
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     assert np.all(th[:, en == 0] == th0[:, en == 0])
