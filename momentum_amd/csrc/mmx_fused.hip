@@ -188,8 +188,8 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
 
 constexpr int kFusedTreeUn = 4; // k-steps per trip of the tree sums (measured on BASELINE configs[1]: 1 -> 1.575e6, 4 -> 1.60e6, 8 -> 1.54e6 solves/s)
 template <int NC, bool kSubtree, int STRIDE = NC, int UN = kFusedTreeUn>
-__device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, float* out, int J, int wave, int lane) {
-  treeSumT<NC, kSubtree, STRIDE, UN>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane);
+__device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, float* out, int J, int wave, int lane, const int32_t* kRange = nullptr) {
+  treeSumT<NC, kSubtree, STRIDE, UN>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane, kRange);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1899,6 +1899,7 @@ struct TreeNeLds {
   int *jlA, *jlB, *span; // span[slot] = tin | tout << 16
   int *subSize, *loadedPos; // copies of the tables the subtree sums walk (read once per inner step)
   int *posUnitStart, *posUnits; // ... and of the units-per-joint lists the own sums walk
+  int* kRange; // [2 rowTiles] treeSumRanges
   double* red;
 };
 
@@ -1918,10 +1919,11 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   const size_t oR = take(life1 > life2 ? life1 : life2);
   const size_t oSrc = take(size_t(kSrcCh) * size_t(srcStrideFor(nsrc)));
   const size_t oSpan = take(nsrc);
-  const size_t oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U);
+  const size_t oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U), oKr = take(2 * ((size_t(J) + 15) / 16));
   const size_t oRed = take(16);
   if (out != nullptr) {
     out->span = reinterpret_cast<int*>(base + oSpan);
+    out->kRange = reinterpret_cast<int*>(base + oKr);
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->th = base + oTh, out->js = base + oJs, out->alt = base + oAlt;
@@ -1998,6 +2000,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     t.span[e] = fd.srcs[e].tin | (fd.srcs[e].tout << 16);
   }
   __syncthreads();
+  treeSumRanges(t.subSize, t.loadedPos, fd.numLoaded, J, tid, t.kRange); // (barriers follow before the first tree sum)
   MMX_TCLK(0)
   // ---- A, B: forward kinematics with rotation axes
   blockFk<true>(rv, s, s.th, tid, true);
@@ -2044,8 +2047,8 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   ownSums(fv, s, s.umom, U, tid);
   __syncthreads();
   MMX_TCLK(3)
-  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane);
-  treeSum<kC2Used, true, kC2, 8>(fv, s.own2, s.sub2, J, wave, lane);
+  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane, t.kRange);
+  treeSum<kC2Used, true, kC2, 8>(fv, s.own2, s.sub2, J, wave, lane, t.kRange);
   __syncthreads();
   MMX_TCLK(4)
   // ---- E: per-slot tables (see fusedSolveKernel phase E)
@@ -2231,7 +2234,7 @@ hipError_t launchTreeNormalEquations(
 // =============================================================================================
 struct TreeRefLds {
   float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0;
-  int *col, *subSize, *loadedPos, *posUnitStart, *posUnits;
+  int *col, *subSize, *loadedPos, *posUnitStart, *posUnits, *kRange;
 };
 __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base) {
   size_t off = 0;
@@ -2247,7 +2250,9 @@ __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n
   const size_t oR2 = take(size_t(kTan > kC1 ? kTan : kC1) * J); // tanOwn, then the own sums
   const size_t oPre = take(size_t(kTan) * J);
   const size_t oD = take(NP), oCol = take(P), oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U);
+  const size_t oKr = take(2 * ((size_t(J) + 15) / 16));
   if (out != nullptr) {
+    out->kRange = reinterpret_cast<int*>(base + oKr);
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->js = base + oJs, out->up = base + oUp, out->ur = base + oUr, out->us = base + oUs;
@@ -2315,6 +2320,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     }
   }
   __syncthreads();
+  treeSumRanges(t.subSize, t.loadedPos, fd.numLoaded, J, tid, t.kRange);
   for (int c = tid; c < n; c += 256) {
     t.col[fd.solveList[c]] = c;
   }
@@ -2393,7 +2399,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     }
   }
   __syncthreads();
-  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane);
+  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane, t.kRange);
   __syncthreads();
   // J^T w per column: the primary source slot, then the extras (slot numbering of phase F)
   for (int c = tid; c < NP; c += 256) {

@@ -30,6 +30,8 @@ constexpr int kC1 = 7; // first-order channels per joint: F(3) | N(3) | D (odd s
 // Tiles of 16 rows x 16 channels are dealt to the four waves.
 // UN: k-steps per trip -- their table and value reads go out together, then the chained MFMAs (pays for long k ranges:
 // hundreds of joints; the 72-joint fused solve is faster with 1)
+// kRange (subtree sums, optional): per row tile the range [lo, hi) of loaded-position indices that can fall into a
+// subtree of one of the tile's rows (treeSumRanges below); everything outside multiplies by an exact zero.
 template <int NC, bool kSubtree, int STRIDE = NC, int UN = 1> // NC channels per row, rows STRIDE floats apart
 __device__ __forceinline__ void treeSumT(
     const int32_t* subSize,
@@ -40,7 +42,8 @@ __device__ __forceinline__ void treeSumT(
     int J,
     int wave,
     int numWaves,
-    int lane) {
+    int lane,
+    const int32_t* kRange = nullptr) {
   const int K = kSubtree ? numLoaded : J;
   const int rowTiles = (J + 15) >> 4;
   constexpr int colTiles = (NC + 15) / 16;
@@ -52,8 +55,9 @@ __device__ __forceinline__ void treeSumT(
     const int c = 16 * ct + i; // column of the B operand this lane feeds
     v4f acc{0.f, 0.f, 0.f, 0.f};
     // prefix sums: only positions up to the tile's last row can be ancestors of its rows
-    const int kEnd = kSubtree ? K : (K < 16 * rt + 16 ? K : 16 * rt + 16);
-    for (int k0 = 0; k0 < kEnd; k0 += 4 * UN) {
+    const int kEnd = kSubtree ? (kRange != nullptr ? kRange[2 * rt + 1] : K) : (K < 16 * rt + 16 ? K : 16 * rt + 16);
+    const int kBegin = kSubtree && kRange != nullptr ? kRange[2 * rt] : 0;
+    for (int k0 = kBegin; k0 < kEnd; k0 += 4 * UN) {
       int pp[UN], sz[UN];
       float bv[UN];
 #pragma unroll
@@ -81,6 +85,33 @@ __device__ __forceinline__ void treeSumT(
         out[STRIDE * orow + ocol] = acc[q];
       }
     }
+  }
+}
+
+// kRange of treeSumT: row tile rt covers DFS positions 16 rt .. 16 rt + 15; a loaded position p contributes to one of its
+// rows r iff r <= p < r + subSize[r], hence 16 rt <= p < max_r (r + subSize[r]).  One thread per row tile, two binary
+// searches in the ascending loadedPos.  Call by >= (J + 15) / 16 threads; barrier afterwards.
+__device__ __forceinline__ void treeSumRanges(const int32_t* subSize, const int32_t* loadedPos, int numLoaded, int J, int tid, int32_t* kRange) {
+  const int rowTiles = (J + 15) >> 4;
+  if (tid < rowTiles) {
+    int hi = 0;
+    for (int r = 16 * tid; r < 16 * tid + 16 && r < J; ++r) {
+      hi = max(hi, r + subSize[r]);
+    }
+    auto lowerBound = [&](int v) { // first index with loadedPos[index] >= v
+      int a = 0, b = numLoaded;
+      while (a < b) {
+        const int m = (a + b) >> 1;
+        if (loadedPos[m] < v) {
+          a = m + 1;
+        } else {
+          b = m;
+        }
+      }
+      return a;
+    };
+    kRange[2 * tid] = lowerBound(16 * tid);
+    kRange[2 * tid + 1] = lowerBound(hi);
   }
 }
 
