@@ -1703,7 +1703,7 @@ int32_t mmx_eval_normal_equations(
         return fail(MMX_ERR_UNSUPPORTED, "MMX_TREE_NE=force: problem outside the tree-moment kernel's scope (or structurally zero columns present)");
       }
       MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
-      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, s));
+      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, false, s));
       return MMX_OK;
     }
   }
@@ -1931,7 +1931,7 @@ static int32_t solveImpl(
         MMX_ZONE("Get JtJ and JtR");
         MMX_HIP(mmx::launchTreeNormalEquations(
             pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, pb->sErr.as<double>(),
-            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, s));
+            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, true, s));
       }
       MMX_ZONE("Dense gauss newton step");
       MMX_HIP(mmx::launchCholeskyFactorTiled(
@@ -1956,7 +1956,7 @@ static int32_t solveImpl(
           // H and g from the tree moments, O(n^2) per instance, J not read (J itself is still assembled above: the
           // Cholesky step's refinement streams it)
           MMX_HIP(mmx::launchTreeNormalEquations(
-              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, nullptr, s));
+              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, nullptr, false, s));
         } else {
           MMX_HIP(mmx::launchNormalEquations(
               ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, wide, s));

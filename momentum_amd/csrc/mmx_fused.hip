@@ -1948,7 +1948,8 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     const int32_t* __restrict__ done,
     double* __restrict__ errOut, // [B] error at theta (SkeletonSolverFunctionT::getJacobian's return value), or null
     float* __restrict__ state, // [B][treeStateFloats] joint states and units for treeRefineKernel, or null
-    long long* __restrict__ clk) { // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
+    long long* __restrict__ clk, // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
+    int tileMajor) { // 0: jtj = [n][n] row-major, lower triangle; 1: [tile (I,J) at I(I+1)/2 + J][col][row] (what the tiled factor reads) // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -2114,6 +2115,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   }
   // ---- G: the tiles of the lower triangle, two masked matrix-core products each, straight to HBM
   float* Hb = jtj + size_t(b) * size_t(n) * size_t(n);
+  float* Ht = jtj + size_t(b) * size_t(T) * 256;
   {
     const int i = lane & 15, gq = lane >> 4;
     const int k1 = gq < 3 ? 4 + gq : 6;
@@ -2131,6 +2133,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(aI0, dJ0, Qm, 0, 0, 0);
       Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(dI1, aJ1, Pm, 0, 0, 0);
       Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(aI1, dJ1, Qm, 0, 0, 0);
+      float hv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = 16 * I + 4 * gq + q, col = ci;
@@ -2138,9 +2141,13 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
         const int tinR = spanR & 0xffff, toutR = spanR >> 16;
         const bool rowDeep = tinC <= tinR && tinR < toutC;
         const bool colDeep = tinR <= tinC && tinC < toutR;
-        if (row < n && col <= row) {
-          Hb[size_t(row) * n + col] = rowDeep ? Pm[q] : (colDeep ? Qm[q] : 0.f);
+        hv[q] = rowDeep ? Pm[q] : (colDeep ? Qm[q] : 0.f);
+        if (!tileMajor && row < n && col <= row) {
+          Hb[size_t(row) * n + col] = hv[q];
         }
+      }
+      if (tileMajor) { // [col][row] inside the tile: the lane's four rows are one 16-byte store, the wave's a contiguous KB
+        *reinterpret_cast<float4*>(Ht + size_t(tt) * 256 + i * 16 + 4 * gq) = float4{hv[0], hv[1], hv[2], hv[3]};
       }
     }
   }
@@ -2154,7 +2161,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       int I, Jc;
       tileDecode(int(y >> 8), I, Jc);
       const int r = (y >> 4) & 15, c = int(((((y >> 2) & 3) ^ (r >> 2)) & 3) << 2) | int(y & 3);
-      return Hb + size_t(16 * I + r) * n + (16 * Jc + c);
+      return tileMajor ? Ht + size_t(y >> 8) * 256 + c * 16 + r : Hb + size_t(16 * I + r) * n + (16 * Jc + c);
     };
     for (int k = 0; k < fd.termRounds; ++k) {
       const uint4* rp = fd.gTerms + size_t(k) * 256 + tid;
@@ -2209,6 +2216,7 @@ hipError_t launchTreeNormalEquations(
     double* errOut,
     float* state,
     long long* clk,
+    bool tileMajor,
     hipStream_t stream) {
   const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc);
   if (lds > 160 * 1024 - 64) {
@@ -2222,7 +2230,7 @@ hipError_t launchTreeNormalEquations(
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk);
+  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, tileMajor ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -2214,6 +2214,7 @@ __host__ __device__ inline size_t tiledLdsFloats(int n, int chunkRows, TiledLds*
 
 // Left-looking blocked Cholesky of H + lambda I (H: [n][n], lower triangle, read only) into the tile-major L;
 // t.g holds g on entry and y = L^-1 g on exit; t.flags[0] = 1 when a pivot was not positive.
+template <bool kTileMajorH> // H as [tile][col][row] (treeNormalEquationsKernel's tile-major output) instead of [n][n]
 __device__ __forceinline__ void tiledFactor(
     const float* __restrict__ H, float* __restrict__ L, int n, float lambda, const TiledLds& t, const StepParams& sp, int b, int tid, long long& tclk) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2232,10 +2233,15 @@ __device__ __forceinline__ void tiledFactor(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int I = I0 + 4 * t;
+        float hq[4];
+        if (kTileMajorH) {
+          const float4 hv = *reinterpret_cast<const float4*>(H + size_t(tileIndex(min(I, NB - 1), k)) * 256 + opOff);
+          hq[0] = hv.x, hq[1] = hv.y, hq[2] = hv.z, hq[3] = hv.w;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = 16 * I + 4 * lkg + q, cc = 16 * k + lrow;
-          const float v = H[size_t(min(r, n - 1)) * n + min(cc, n - 1)]; // clamped: unconditional, independent loads
+          const float v = kTileMajorH ? hq[q] : H[size_t(min(r, n - 1)) * n + min(cc, n - 1)]; // clamped: unconditional, independent loads
           c[t][q] = (r < n && cc < n) ? (r > cc ? v : (r == cc ? v + lambda : 0.f)) : (r == cc ? 1.f : 0.f);
         }
       }
@@ -2561,7 +2567,7 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledFactor(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
+  tiledFactor<false>(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
   const bool bad = t.flags[0] != 0;
   for (int i = tid; i < NP; i += 256) {
     d0[i] = t.g[i];
@@ -2723,7 +2729,7 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledFactor(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
+  tiledFactor<true>(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
   const bool bad = t.flags[0] != 0;
   float* d0 = t.g; // y = L^-1 g, solved in place
   MMX_SCLK(0)

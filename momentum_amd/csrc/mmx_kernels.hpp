@@ -101,6 +101,7 @@ hipError_t launchTreeNormalEquations(
     double* errOut, // [B] error at theta, or null
     float* state, // [B][treeStateFloats(J, U)] hand-over to launchTreeRefine, or null
     long long* clk, // profiling aid: eight per-phase cycle counters of block 0, or null
+    bool tileMajor, // jtj as [tile (I,J) at I(I+1)/2 + J][col][row] (launchCholeskyFactorTiled reads that) instead of [n][n]
     hipStream_t stream);
 size_t treeStateFloats(int J, int U);
 // rho = J^T (r - J d) - lambda d through the tree, for the instances with refState[b] == 0 (dvec / rhoVec: [B][NP])
@@ -192,7 +193,7 @@ hipError_t launchCholeskyStep(
 hipError_t launchCholeskyFactorTiled(
     const ProblemDev& pb,
     int P,
-    const float* jtj,
+    const float* jtj, // tile-major (launchTreeNormalEquations with tileMajor)
     const float* jtr,
     float* factor,
     float* dvec,
