@@ -2200,7 +2200,8 @@ struct TiledLds { // the LDS carve of the tiled step's kernels
 __host__ __device__ inline size_t tiledLdsFloats(int n, int chunkRows, TiledLds* out, float* base) {
   const size_t NP = (size_t(n) + 15) & ~size_t(15);
   const size_t chunk = chunkRows > 0 ? size_t(n) * size_t(chunkRows + 1) : 0;
-  const size_t panFloats = ((NP * 16 > chunk ? NP * 16 : chunk) + 3) & ~size_t(3);
+  const size_t panels = chunkRows > 0 ? NP * 16 : 2 * NP * 16; // (chunkRows = 0: the factor stage alone, two panels)
+  const size_t panFloats = ((panels > chunk ? panels : chunk) + 3) & ~size_t(3);
   const size_t oG = panFloats, oD = oG + NP, oRho = oD + NP, oInv = oRho + NP, oW = oInv + NP;
   const size_t oPart = oW + ((size_t(chunkRows) + 3) & ~size_t(3)); // doubles: even float offset
   const size_t oFlags = oPart + (chunkRows > 0 ? 512 : 16);
@@ -2398,6 +2399,256 @@ __device__ __forceinline__ void tiledFactor(
       *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k)) * 256 + opOff) = ldsRow4(pan + 256 * (I - k), lrow, lkg);
     }
     __syncthreads(); // the panel buffer is reused; the tiles are visible to the workgroup
+    MMX_SCLK(1)
+  }
+}
+
+// The same factorisation two block columns at a time (tile-major H only): the tiles L(I, j < k) are loaded ONCE for
+// the columns k and k + 1 -- the finished-tile reads, which are what the factor stage's HBM traffic consists of, halve.
+// Column k + 1 lacks its j = k term after that pass; it gets it from the LDS panel of column k once that is factored.
+// LDS: two panels (2 NP * 16 floats).
+__device__ __forceinline__ void tiledFactorPairs(
+    const float* __restrict__ H, float* __restrict__ L, int n, float lambda, const TiledLds& t, const StepParams& sp, int b, int tid, long long& tclk) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NP = (n + 15) & ~15, NB = NP >> 4;
+  float* g = t.g;
+  float* invDiag = t.invDiag;
+  int* flags = t.flags;
+  const int lrow = lane & 15, lkg = lane >> 4;
+  const int opOff = lrow * 16 + 4 * lkg;
+  auto loadH = [&](int I, int k) { // tile (I, k) of H + lambda I, padded with the identity, strict upper part of a diagonal tile zero
+    const float4 hv = *reinterpret_cast<const float4*>(H + size_t(tileIndex(min(max(I, k), NB - 1), min(k, NB - 1))) * 256 + opOff);
+    const float hq[4] = {hv.x, hv.y, hv.z, hv.w};
+    v4f c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 16 * I + 4 * lkg + q, cc = 16 * k + lrow;
+      c[q] = (r < n && cc < n) ? (r > cc ? hq[q] : (r == cc ? hq[q] + lambda : 0.f)) : (r == cc ? 1.f : 0.f);
+    }
+    return c;
+  };
+  // panel factorisation of block column k whose nt tiles sit in `pan` (mmx_fused.hip phase H): lanes 0-15 of every
+  // wave the diagonal block, redundantly; lanes 16-63 forty-eight rows below it; pivots by v_readlane.  Wave 0 also
+  // finishes y_k (L_kk y_k = s_k with the rows still in registers).  Ends with the panel complete and a barrier.
+  auto factorPanel = [&](float* pan, int nt, int k) {
+    float* Dk = pan;
+    const bool diagLane = lane < 16;
+    const int prow = 16 + 48 * wave + (lane - 16);
+    const bool active = diagLane || prow < 16 * nt;
+    float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
+    const int trow = diagLane ? lane : (prow & 15);
+    float a[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+      a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+    }
+    float bi = g[16 * k + lrow]; // s_k
+    __syncthreads();
+    float invd = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float djj = readLaneF(a[j], j);
+      bad = bad || !(djj > 0.f);
+      const float inv = __builtin_amdgcn_rsqf(djj);
+      a[j] *= inv;
+      if (lane == j) {
+        invd = inv;
+      }
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) {
+        a[c] -= a[j] * readLaneF(a[j], c);
+      }
+    }
+    if (diagLane) {
+      if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
+        }
+        invDiag[16 * k + lane] = invd;
+        if (bad) {
+          flags[0] = 1;
+        }
+      }
+    } else if (active) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        Tl[tileAddr(trow, c)] = a[c];
+      }
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float yj = readLaneF(bi, j) * readLaneF(invd, j);
+        bi = (lane == j) ? yj : (j < lane ? bi - a[j] * yj : bi);
+      }
+      if (lane < 16) {
+        g[16 * k + lane] = bi;
+      }
+    }
+    __syncthreads();
+    if (16 * nt > 16 + 192) { // rows beyond 4 x 48: substitution against the finished diagonal block
+      for (int pr = 16 + 192 + tid; pr < 16 * nt; pr += 256) {
+        float* Tr = pan + 256 * (pr >> 4);
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = ldsRow4(Tr, pr & 15, q);
+          x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float sum = x[j];
+#pragma unroll
+          for (int c = 0; c < j; ++c) {
+            sum -= x[c] * Dk[tileAddr(j, c)];
+          }
+          x[j] = sum * invDiag[16 * k + j];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          Tr[tileAddr(pr & 15, c)] = x[c];
+        }
+      }
+      __syncthreads();
+    }
+  };
+  float* pan0 = t.pan;
+  float* pan1 = t.pan + size_t(NP) * 16;
+  for (int k = 0; k < NB; k += 2) {
+    const bool two = k + 1 < NB; // (uniform)
+    // (a) the wave's tiles I = k + wave, + 4, ... of BOTH columns, two rows of tiles per trip
+    for (int I0 = k + wave; I0 < NB; I0 += 8) {
+      v4f c0[2], c1[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        c0[tt] = loadH(I0 + 4 * tt, k);
+        c1[tt] = loadH(I0 + 4 * tt, k + 1); // (meaningless for I = k or without a second column: not stored)
+      }
+      for (int j0 = 0; j0 < k; j0 += kJb) {
+        float4 b0[kJb], b1[kJb], av[2][kJb];
+#pragma unroll
+        for (int u = 0; u < kJb; ++u) {
+          const int j = min(j0 + u, k - 1);
+          b0[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(k, j)) * 256 + opOff);
+          b1[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(min(k + 1, NB - 1), j)) * 256 + opOff);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            av[tt][u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(min(I0 + 4 * tt, NB - 1), j)) * 256 + opOff);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kJb; ++u) {
+          if (j0 + u < k) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].x, b0[u].x, c0[tt], 0, 0, 0);
+              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].y, b0[u].y, c0[tt], 0, 0, 0);
+              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].z, b0[u].z, c0[tt], 0, 0, 0);
+              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].w, b0[u].w, c0[tt], 0, 0, 0);
+              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].x, b1[u].x, c1[tt], 0, 0, 0);
+              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].y, b1[u].y, c1[tt], 0, 0, 0);
+              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].z, b1[u].z, c1[tt], 0, 0, 0);
+              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].w, b1[u].w, c1[tt], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int I = I0 + 4 * tt;
+        if (I < NB) {
+          float* T0 = pan0 + 256 * (I - k);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            T0[tileAddr(4 * lkg + q, lrow)] = c0[tt][q];
+          }
+          if (two && I > k) {
+            float* T1 = pan1 + 256 * (I - k - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              T1[tileAddr(4 * lkg + q, lrow)] = c1[tt][q];
+            }
+          }
+        }
+      }
+    }
+    // the forward substitution rides along: s = g - sum_{j<k} L(.,j) y_j for the rows of both columns
+    if (wave == 3 && k > 0) {
+      float acc0 = 0.f, acc1 = 0.f;
+      for (int j0 = 0; j0 < k; j0 += 4) {
+        float4 l0[4], l1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = min(j0 + u, k - 1);
+          l0[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(k, j)) * 256 + opOff);
+          l1[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(min(k + 1, NB - 1), j)) * 256 + opOff);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j0 + u < k) {
+            const float4 yv = *reinterpret_cast<const float4*>(g + 16 * (j0 + u) + 4 * lkg);
+            acc0 = dot4(l0[u], yv, acc0);
+            acc1 = dot4(l1[u], yv, acc1);
+          }
+        }
+      }
+      acc0 += __shfl_xor(acc0, 16, 64);
+      acc0 += __shfl_xor(acc0, 32, 64);
+      acc1 += __shfl_xor(acc1, 16, 64);
+      acc1 += __shfl_xor(acc1, 32, 64);
+      if (lane < 16) {
+        g[16 * k + lane] -= acc0;
+        if (two) {
+          g[16 * (k + 1) + lane] -= acc1;
+        }
+      }
+    }
+    __syncthreads();
+    MMX_SCLK(6)
+    factorPanel(pan0, NB - k, k);
+    if (two) {
+      // the missing term of column k + 1: C(I, k+1) -= L(I,k) L(k+1,k)^T, operands from column k's LDS panel
+      for (int I = k + 1 + wave; I < NB; I += 4) {
+        float* T1 = pan1 + 256 * (I - k - 1);
+        v4f c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          c[q] = T1[tileAddr(4 * lkg + q, lrow)];
+        }
+        const float4 av = ldsRow4(pan0 + 256 * (I - k), lrow, lkg);
+        const float4 bv = ldsRow4(pan0 + 256, lrow, lkg);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          T1[tileAddr(4 * lkg + q, lrow)] = c[q];
+        }
+      }
+      if (wave == 3 && lane < 16) { // ... and of s_{k+1}: - L(k+1,k) y_k
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc = dot4(ldsRow4(pan0 + 256, lane, q), *reinterpret_cast<const float4*>(g + 16 * k + 4 * q), acc);
+        }
+        g[16 * (k + 1) + lane] -= acc;
+      }
+      __syncthreads();
+      factorPanel(pan1, NB - k - 1, k + 1);
+    }
+    MMX_SCLK(7)
+    // (c) every finished tile is written once
+    for (int I = k + wave; I < NB; I += 4) {
+      *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k)) * 256 + opOff) = ldsRow4(pan0 + 256 * (I - k), lrow, lkg);
+      if (two && I > k) {
+        *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k + 1)) * 256 + opOff) = ldsRow4(pan1 + 256 * (I - k - 1), lrow, lkg);
+      }
+    }
+    __syncthreads(); // the panel buffers are reused; the tiles are visible to the workgroup
     MMX_SCLK(1)
   }
 }
@@ -2706,7 +2957,8 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
     const double* __restrict__ errIter,
     float* __restrict__ theta,
     SolveStateDev st,
-    StepParams sp) {
+    StepParams sp,
+    int pairs) { // two block columns per step (tiledFactorPairs)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (st.done[b] != 0) {
@@ -2729,7 +2981,11 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledFactor<true>(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
+  if (pairs) {
+    tiledFactorPairs(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
+  } else {
+    tiledFactor<true>(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
+  }
   const bool bad = t.flags[0] != 0;
   float* d0 = t.g; // y = L^-1 g, solved in place
   MMX_SCLK(0)
@@ -3327,7 +3583,11 @@ hipError_t launchCholeskyFactorTiled(
     return hipErrorInvalidValue;
   }
   const size_t lds = tiledLdsFloats(pb.n, 0, nullptr, nullptr) * sizeof(float);
-  hipLaunchKernelGGL(choleskyFactorTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp);
+  static const int pairs = [] {
+    const char* e = getenv("MMX_CHOL_PAIRS");
+    return e != nullptr && e[0] == '0' ? 0 : 1;
+  }();
+  hipLaunchKernelGGL(choleskyFactorTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp, pairs);
   return hipGetLastError();
 }
 
