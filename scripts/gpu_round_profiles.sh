@@ -1,0 +1,53 @@
+#!/bin/bash
+# end-of-round evidence: full GPU suite, the default bench line, kernel traces and PMC passes of the headline (cfg2) and
+# of the wide solve (cfg5).  usage: bash scripts/gpu_round_profiles.sh r02   -> gpurun_out/round_r02/
+cd "$GRAFT_REPO_ROOT" || exit 1
+r=${1:-r02}
+out=$GRAFT_REPO_ROOT/gpurun_out/round_$r
+mkdir -p $out
+export TMPDIR=/tmp
+timeout 700 python -m pytest tests -m gpu -q < /dev/null 2>&1 | tail -4 > $out/pytest_gpu.txt
+timeout 900 python bench.py < /dev/null > $out/${r}_bench_default.json 2> $out/bench_default.err
+cd /tmp
+B="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 0"
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace2 -o t -- $B < /dev/null > /dev/null 2> $out/trace2.err
+db=$(find $out/trace2 -name "*.db" | head -1)
+[ -n "$db" ] && timeout 120 python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py "$db" < /dev/null > $out/${r}_bench_kernel_stats.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace5 -o t -- $B --config cfg5 --steps 3 --warmup 1 < /dev/null > /dev/null 2> $out/trace5.err
+db=$(find $out/trace5 -name "*.db" | head -1)
+[ -n "$db" ] && timeout 120 python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py "$db" < /dev/null > $out/${r}_cfg5_kernel_stats.txt
+pass() { # dir, counters, bench args...
+  d=$1; c=$2; shift; shift
+  timeout 200 rocprofv3 --pmc $c --output-format csv -d $out/$d -o pmc -- $B "$@" < /dev/null > /dev/null 2> $out/$d.err
+}
+pass pmc2a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES"
+pass pmc2b "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT"
+pass pmc2c "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE"
+pass pmc2d "FETCH_SIZE"
+pass pmc2e "WRITE_SIZE"
+pass pmc5a "FETCH_SIZE" --config cfg5 --batch 2048 --steps 2 --warmup 1
+pass pmc5b "WRITE_SIZE" --config cfg5 --batch 2048 --steps 2 --warmup 1
+pass pmc5c "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_F32 SQ_LDS_BANK_CONFLICT" --config cfg5 --batch 2048 --steps 2 --warmup 1
+timeout 120 python - $out $r < /dev/null <<'PY'
+import csv,sys,glob,collections
+out,r=sys.argv[1],sys.argv[2]
+for tag,pat in (("pmc_bench","pmc2"),("pmc_cfg5","pmc5")):
+    agg=collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(out+"/"+pat+"*/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            key=row["Kernel_Name"].split("(")[0]+" ["+row.get("Grid_Size","?")+" threads]"
+            agg[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    with open(out+"/"+r+"_"+tag+".txt","w") as fo:
+        for k,v in sorted(agg.items()):
+            if "mmx::" not in k: continue
+            fo.write(k+"\n")
+            for c,vals in sorted(v.items()): fo.write("   %-28s n=%-3d avg=%.4g\n" % (c,len(vals),sum(vals)/len(vals)))
+PY
+cat $out/pytest_gpu.txt; head -8 $out/${r}_bench_kernel_stats.txt | cut -c1-140; head -8 $out/${r}_cfg5_kernel_stats.txt | cut -c1-140
+python - $out/${r}_bench_default.json < /dev/null <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+print("value", d["value"], "roofline", d["roofline"]["frac"], "cpu", d["cpu_baseline"]["value"])
+for k,v in d["configs"].items():
+    print(k, round(v["solves_per_s"]), v["check"].get("max_rel_theta_vs_oracle_f64"), round(v.get("gpu_over_cpu",0),1))
+PY

@@ -40,15 +40,9 @@ def _solve_and_check(torch, config, B, n_check, line_search=0, step_rule=None, i
 def test_baseline_workloads_within_1e5_of_the_oracle(torch_cuda, orc, config, B, n_check, line_search):
     chk, _, _ = _solve_and_check(torch_cuda, config, B, n_check, line_search)
     assert chk["instances"] == n_check and chk["distinct"]
-    if config == "cfg5":
-        # 300 joints, chains of depth 20+: single-precision forward kinematics alone leaves ~1e-7 on the
-        # residuals, which the weakest direction of the worst of a thousand instances amplifies to the bound
-        # itself (measured over code-generation variants of the same arithmetic: 6.8e-6 ... 1.3e-5 on ONE
-        # instance of 1024, p99 4.8e-6, median 1.8e-6).  The bound is asserted where it is robust (99.5 % of the
-        # instances), the worst instance at 2e-5.
-        assert chk["p99_rel_theta_vs_oracle_f64"] <= BOUND and chk["num_above_bound"] <= n_check // 200, chk
-        assert chk["max_rel_theta_vs_oracle_f64"] <= 2e-5, chk
-        return
+    # (cfg5, 300 joints: with the dense-J refinement of round 1 the worst of 1024 instances sat AT the bound -- fp32 forward
+    # kinematics amplified by the weakest direction, 6.8e-6 ... 1.3e-5 over code-generation variants; the refinement through
+    # the tree brought it to 5.6e-6, so the plain bound holds here too)
     assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
 
 
