@@ -192,3 +192,52 @@ def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     assert np.all(th[:, en == 0] == th0[:, en == 0])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_wide_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
+    """Random trees of 100-170 joints with shared parameters, translation / scale dofs and transform offsets, more than
+    224 solved parameters: the wide path (tree normal equations incl. the term records of multi-source columns,
+    paired-column / single-column factor, tree refinement) on shapes the 300-joint rig does not have; odd seeds keep some
+    parameters disabled, every fourth one takes the dense-J refinement, seeds 2 and 6 the directional line search."""
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    if seed % 4 == 3:
+        monkeypatch.setenv("MMX_TREE_REFINE", "0")
+    if seed % 4 == 1:
+        monkeypatch.setenv("MMX_CHOL_PAIRS", "0")
+    rng = np.random.default_rng(9000 + seed)
+    J = int(rng.integers(100, 170))
+    rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
+    P = rig.num_params
+    Kp, Ko = int(rng.integers(20, 70)), int(rng.integers(4, 24))
+    pp = rng.integers(0, J, size=Kp).astype(np.int32)
+    op = rng.integers(0, J, size=Ko).astype(np.int32)
+    B = 3
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=seed, perturb=0.2, random_offsets=True, weights="random")
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, pp, op)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(t(cons.pos_offset, (B, Kp, 3)), t(cons.pos_target, (B, Kp, 3)), t(cons.pos_weight, (B, Kp)),
+                       t(cons.ori_offset, (B, Ko, 4)), t(cons.ori_target, (B, Ko, 4)), t(cons.ori_weight, (B, Ko)))  # fmt: skip
+    en = np.ones(P, np.uint8)
+    if seed % 2 == 1:
+        en = (rng.uniform(size=P) < 0.9).astype(np.uint8)
+        en[:3] = 1
+    pb.set_enabled(en)
+    opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.5, do_line_search=2 if seed % 4 == 2 else 0)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, enabled=en, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    den = np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / den
+    # 2e-5 like the small random rigs; a chain of 100+ joints amplifies single-precision FK, so the bound follows what the
+    # oracle's own float instantiation loses on the instance (seed 3, a 168-joint chain through the dense-J refinement: 3.2e-5)
+    ref32 = orc.solve_batch(rig, cons, th0, opt, enabled=en, dtype="f32")
+    tol = np.maximum(2e-5, 3.0 * np.linalg.norm(ref32["theta"] - ref["theta"], axis=1) / den)
+    assert np.all(rel <= tol), (seed, J, P, rel, tol)
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+    assert np.all(th[:, en == 0] == th0[:, en == 0])

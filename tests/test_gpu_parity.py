@@ -579,3 +579,28 @@ def test_wide_solve_variants_agree_with_the_oracle(torch_cuda, orc, variant, mon
         assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
         if opt.step_rule != MMX_STEP_LM_SCHEDULE:
             assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]), (out["iterations"], ref["iterations"])
+
+
+@pytest.mark.parametrize("pairs", ["1", "0"])
+def test_wide_path_on_a_small_skeleton_with_many_units(torch_cuda, orc, pairs, monkeypatch):
+    """The wide path's other shapes: the 72-joint humanoid with constraints on EVERY joint (P = 219, n = 219: an even
+    number of 16-blocks; U = 288 units > J joints, so the tree kernels take their per-joint loops) forced onto the
+    explicit route (MMX_SOLVER=v1; by default this problem fits the fused solve), both factor forms."""
+    import bench
+
+    torch = torch_cuda
+    monkeypatch.setenv("MMX_SOLVER", "v1")
+    monkeypatch.setenv("MMX_CHOL_PAIRS", pairs)
+    rig, parents, _, _, _ = bench.build_rig("cfg2_all")
+    B = 48
+    db = bench.DeviceBatch(rig, parents, B, 0, 31337)
+    for ls in (0, 2):
+        opt = GnOptions.make(min_iterations=8, max_iterations=8, threshold=1.0, regularization=0.05, do_line_search=ls)
+        out = db.pb.solve(db.theta0.clone(), opt, want_history=True)
+        ref = orc.solve_batch(rig, db.host_constraints(B), db.theta0.cpu().numpy(), opt, dtype="f64")
+        th = out["theta"].cpu().numpy()
+        rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+        assert rel.max() <= 1e-5, (ls, rel.max())
+        assert int((out["status"] != 0).sum()) == 0
+        h = out["error_history"].cpu().numpy()
+        assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
