@@ -2120,25 +2120,51 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     const int i = lane & 15, gq = lane >> 4;
     const int k1 = gq < 3 ? 4 + gq : 6;
     const float z = gq == 3 ? 0.f : 1.f;
-    for (int tt = wave; tt < T; tt += 4) {
-      int I, Jc;
-      tileDecode(tt, I, Jc);
+    struct TileOps { // operands of a tile (fusedSolveKernel phase G): rows of block I on the A side, of block Jc on the B side
+      float dI0, aI0, dJ0, aJ0, dI1, aI1, dJ1, aJ1;
+      int spanC, spanR[4];
+    };
+    auto loadOps = [&](int I, int Jc) {
+      TileOps o;
       const int ri = 16 * I + i, ci = 16 * Jc + i;
-      const float dI0 = srcD[gq * sst + ri], aI0 = srcA[gq * sst + ri], dJ0 = srcD[gq * sst + ci], aJ0 = srcA[gq * sst + ci];
-      const float dI1 = z * srcD[k1 * sst + ri], aI1 = z * srcA[k1 * sst + ri], dJ1 = srcD[k1 * sst + ci], aJ1 = srcA[k1 * sst + ci];
-      const int spanC = t.span[ci];
-      const int tinC = spanC & 0xffff, toutC = spanC >> 16;
+      o.dI0 = srcD[gq * sst + ri], o.aI0 = srcA[gq * sst + ri];
+      o.dJ0 = srcD[gq * sst + ci], o.aJ0 = srcA[gq * sst + ci];
+      o.dI1 = srcD[k1 * sst + ri], o.aI1 = srcA[k1 * sst + ri];
+      o.dJ1 = srcD[k1 * sst + ci], o.aJ1 = srcA[k1 * sst + ci];
+      o.spanC = t.span[ci];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o.spanR[q] = t.span[16 * I + 4 * gq + q];
+      }
+      return o;
+    };
+    // the wave's tiles tt = wave, wave + 4, ... in (I, Jc) form, advanced without a square root
+    int I = 0, Jc = wave;
+    auto normalise = [&]() {
+      while (Jc > I) {
+        Jc -= I + 1;
+        ++I;
+      }
+    };
+    normalise();
+    TileOps cur = loadOps(I < NB ? I : 0, I < NB ? Jc : 0);
+    for (int tt = wave; tt < T; tt += 4) {
+      const int tI = I, tJ = Jc;
+      Jc += 4;
+      normalise();
+      const bool more = tt + 4 < T; // wave-uniform
+      const TileOps nxt = loadOps(more ? I : tI, more ? Jc : tJ); // the next tile's LDS reads fly while this one multiplies
       v4f Pm{0.f, 0.f, 0.f, 0.f}, Qm{0.f, 0.f, 0.f, 0.f};
-      Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(dI0, aJ0, Pm, 0, 0, 0);
-      Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(aI0, dJ0, Qm, 0, 0, 0);
-      Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(dI1, aJ1, Pm, 0, 0, 0);
-      Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(aI1, dJ1, Qm, 0, 0, 0);
+      Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dI0, cur.aJ0, Pm, 0, 0, 0);
+      Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aI0, cur.dJ0, Qm, 0, 0, 0);
+      Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(z * cur.dI1, cur.aJ1, Pm, 0, 0, 0);
+      Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(z * cur.aI1, cur.dJ1, Qm, 0, 0, 0);
+      const int tinC = cur.spanC & 0xffff, toutC = cur.spanC >> 16;
       float hv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = 16 * I + 4 * gq + q, col = ci;
-        const int spanR = t.span[row];
-        const int tinR = spanR & 0xffff, toutR = spanR >> 16;
+        const int row = 16 * tI + 4 * gq + q, col = 16 * tJ + i;
+        const int tinR = cur.spanR[q] & 0xffff, toutR = cur.spanR[q] >> 16;
         const bool rowDeep = tinC <= tinR && tinR < toutC;
         const bool colDeep = tinR <= tinC && tinC < toutR;
         hv[q] = rowDeep ? Pm[q] : (colDeep ? Qm[q] : 0.f);
@@ -2149,6 +2175,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       if (tileMajor) { // [col][row] inside the tile: the lane's four rows are one 16-byte store, the wave's a contiguous KB
         *reinterpret_cast<float4*>(Ht + size_t(tt) * 256 + i * 16 + 4 * gq) = float4{hv[0], hv[1], hv[2], hv[3]};
       }
+      cur = nxt;
     }
   }
   MMX_TCLK(6)
