@@ -50,6 +50,7 @@ CONFIGS = {
     "cfg3": ("p128", "landmarks", 65536, 1, "BASELINE configs[2]: 65536 x 72-joint humanoid (P=128, M=192), LM gain-ratio damping schedule (lambda0=0.05), 10 iterations"),
     "cfg5": ("rig300", "cfg5", 8192, 0, "BASELINE configs[4]: 8192 x 300-joint hand+body rig (P=300), 150 position + 50 orientation constraints (M=900), GN lambda=0.05, 10 iterations"),
     "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
+    "cfg2_p219": ("p219", "landmarks", 4096, 0, "P=219 parameter set, position+orientation on the 16 landmark joints (route selection probe)"),
     # production-shaped: what marker_tracker.cpp:916-960 adds to the marker constraints -- a plane block (8 floor contacts,
     # PlaneErrorFunction) and MinMax limits on 16 parameters (LimitErrorFunction); takes the fused solve's general rows
     "cfg2_tracker": ("p128", "landmarks+tracker", 4096, 0, "BASELINE configs[1] + PlaneErrorFunction (8 constraints) + 16 MinMax parameter limits (M=192+8+16)"),

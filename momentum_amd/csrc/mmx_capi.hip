@@ -1783,7 +1783,12 @@ static int32_t solveImpl(
   const int n = ds.n;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (fusedUsable(pb) && !wantLegacySolver() && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION)) {
+  // Systems of 193-224 solved parameters fit the fused solve only with one workgroup per CU (105 KB of tiles): when the wide
+  // path's tree kernels cover the problem it is the faster route (P = 219 on the 72-joint humanoid: 3.1e5 against 2.3e5
+  // solves/s).  MMX_PREFER_FUSED=1 keeps the one-launch solve.
+  const bool preferWide = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 && mmx::fusedBlocksFor(pb->fdev.n) >= 14 &&
+      o->step_rule != MMX_STEP_TRUST_REGION && treeNormalEquationsUsable(pb) && getenv("MMX_PREFER_FUSED") == nullptr;
+  if (fusedUsable(pb) && !wantLegacySolver() && !preferWide && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION)) {
     // fused path: the whole SolverT::solve loop in one launch, one workgroup per instance
     MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
     MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));

@@ -33,7 +33,7 @@ def _solve_and_check(torch, config, B, n_check, line_search=0, step_rule=None, i
         ("cfg2", 4096, 4096, 0),  # BASELINE configs[1]: EVERY instance of the batch is checked
         ("cfg2", 4096, 1024, 2),  # the batched driver's default line search (SubsetGN / GN-QR rule)
         ("cfg2", 4096, 1024, 1),  # GaussNewtonSolverT's own line search
-        ("cfg2_all", 2048, 1024, 0),  # P = 219, M = 864 (NB = 14 instantiation)
+        ("cfg2_all", 2048, 1024, 0),  # P = 219, M = 864: the wide path (preferred over the fused NB = 14 instantiation)
         ("cfg5", 1024, 1024, 0),  # 300-joint rig, wide J: MFMA normal equations + in-HBM Cholesky
     ],
 )
@@ -43,6 +43,14 @@ def test_baseline_workloads_within_1e5_of_the_oracle(torch_cuda, orc, config, B,
     # (cfg5, 300 joints: with the dense-J refinement of round 1 the worst of 1024 instances sat AT the bound -- fp32 forward
     # kinematics amplified by the weakest direction, 6.8e-6 ... 1.3e-5 over code-generation variants; the refinement through
     # the tree brought it to 5.6e-6, so the plain bound holds here too)
+    assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
+
+
+def test_cfg2_all_through_the_fused_instantiation(torch_cuda, orc, monkeypatch):
+    """P = 219 fits the one-launch solve with one workgroup per CU (NB = 14); the wide path is the default route for it
+    because it is faster -- this keeps the fused instantiation covered."""
+    monkeypatch.setenv("MMX_PREFER_FUSED", "1")
+    chk, _, _ = _solve_and_check(torch_cuda, "cfg2_all", 1024, 512)
     assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
 
 
