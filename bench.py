@@ -51,6 +51,7 @@ CONFIGS = {
     "cfg5": ("rig300", "cfg5", 8192, 0, "BASELINE configs[4]: 8192 x 300-joint hand+body rig (P=300), 150 position + 50 orientation constraints (M=900), GN lambda=0.05, 10 iterations"),
     "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
     "cfg2_p219": ("p219", "landmarks", 4096, 0, "P=219 parameter set, position+orientation on the 16 landmark joints (route selection probe)"),
+    "cfg2_half": ("p219", "half", 4096, 0, "P=219 parameter set, position+orientation on every other joint (route selection probe)"),
     # production-shaped: what marker_tracker.cpp:916-960 adds to the marker constraints -- a plane block (8 floor contacts,
     # PlaneErrorFunction) and MinMax limits on 16 parameters (LimitErrorFunction); takes the fused solve's general rows
     "cfg2_tracker": ("p128", "landmarks+tracker", 4096, 0, "BASELINE configs[1] + PlaneErrorFunction (8 constraints) + 16 MinMax parameter limits (M=192+8+16)"),
@@ -96,6 +97,8 @@ def build_rig(config: str):
         prng = np.random.default_rng(77)
         pos_parents = prng.choice(rig.num_joints, size=150, replace=False).astype(np.int32)
         ori_parents = prng.choice(rig.num_joints, size=50, replace=False).astype(np.int32)
+    elif which == "half":
+        pos_parents = ori_parents = np.arange(0, rig.num_joints, 2, dtype=np.int32)
     else:
         pos_parents = ori_parents = np.arange(rig.num_joints, dtype=np.int32)
     return rig, (np.asarray(pos_parents, np.int32), np.asarray(ori_parents, np.int32)), defB, step_rule, desc

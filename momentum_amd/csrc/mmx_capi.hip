@@ -1783,11 +1783,13 @@ static int32_t solveImpl(
   const int n = ds.n;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // Systems of 193-224 solved parameters fit the fused solve only with one workgroup per CU (105 KB of tiles): when the wide
-  // path's tree kernels cover the problem it is the faster route (P = 219 on the 72-joint humanoid: 3.1e5 against 2.3e5
-  // solves/s).  MMX_PREFER_FUSED=1 keeps the one-launch solve.
-  const bool preferWide = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024 && mmx::fusedBlocksFor(pb->fdev.n) >= 14 &&
-      o->step_rule != MMX_STEP_TRUST_REGION && treeNormalEquationsUsable(pb) && getenv("MMX_PREFER_FUSED") == nullptr;
+  // Systems of 161-224 solved parameters fit the fused solve only with one workgroup per CU (78-105 KB of tiles): when the
+  // wide path's tree kernels cover the problem it is the faster route (72-joint humanoid, measured with scripts/gpu_route.sh:
+  // n = 189: 4.2e5 against 3.2e5 solves/s, n = 219: 3.1e5 against 2.3e5; n = 126: 7.2e5 against 1.0e6, n = 96: 9.2e5 against
+  // 1.57e6 -- below twelve 16-blocks the fused solve stays).  MMX_PREFER_FUSED=1 keeps the one-launch solve.
+  const bool forceWide = getenv("MMX_FORCE_WIDE") != nullptr; // measurement switch: the wide path for any size its tree kernels cover
+  const bool preferWide = (forceWide || mmx::fusedBlocksFor(pb->fdev.n) >= 12) && o->step_rule != MMX_STEP_TRUST_REGION &&
+      treeNormalEquationsUsable(pb) && getenv("MMX_PREFER_FUSED") == nullptr;
   if (fusedUsable(pb) && !wantLegacySolver() && !preferWide && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION)) {
     // fused path: the whole SolverT::solve loop in one launch, one workgroup per instance
     MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
@@ -1859,10 +1861,10 @@ static int32_t solveImpl(
   // Wide systems (the in-LDS Cholesky step does not fit) whose rows are position / orientation constraints only:
   // normal equations from the tree moments, left-looking factor in HBM, refinement through the tree.  No dense J is
   // written or read (MMX_TREE_REFINE=0: the refinement streams a dense J instead; MMX_TREE_NE=0: the dense product too).
-  const bool wide = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024;
+  const bool wide = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024; // (the in-LDS Cholesky step does not fit)
   const bool rightLooking = getenv("MMX_CHOL_RIGHT_LOOKING") != nullptr && getenv("MMX_CHOL_RIGHT_LOOKING")[0] == '1';
   const bool treeFromMoments = treeNormalEquationsUsable(pb);
-  const bool treeRefine = wide && treeFromMoments && !rightLooking && !(getenv("MMX_TREE_REFINE") != nullptr && getenv("MMX_TREE_REFINE")[0] == '0');
+  const bool treeRefine = (wide || preferWide) && treeFromMoments && !rightLooking && !(getenv("MMX_TREE_REFINE") != nullptr && getenv("MMX_TREE_REFINE")[0] == '0');
   rc = ensureStepScratch(pb, !treeRefine);
   if (rc != MMX_OK) {
     return rc;
@@ -1917,7 +1919,7 @@ static int32_t solveImpl(
     sp.clk = pb->sClk.as<long long>();
   }
   float* factorScratch = nullptr; // wide systems: the left-looking Cholesky step keeps L in its own tile-major scratch
-  if (wide && !rightLooking) {
+  if ((wide && !rightLooking) || treeRefine) {
     MMX_HIP(pb->sFactor.ensure(size_t(B) * mmx::choleskyFactorFloats(ds.n) * sizeof(float)));
     factorScratch = pb->sFactor.as<float>();
   }
