@@ -171,3 +171,27 @@ def test_per_instance_constraint_parents(torch_cuda, orc, solver, which, monkeyp
         pb.set_instance_parents(bad, None)
     jac2, _, _ = pb.eval_jacobian(torch.from_numpy(theta).to(pb.device))
     assert torch.equal(jac, jac2)
+
+
+def test_per_instance_characters_on_the_wide_path(torch_cuda, orc):
+    """Per-element rig constants on a problem that takes the wide path (P = 219, constraints on every joint: tree normal
+    equations -> tiled factor -> tree refinement): every element against the oracle on its own character, with and
+    without the line search (whose trial errors re-run FK on the element's constants)."""
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    rig = make_humanoid72(variant="p219", unit=UNIT)
+    allj = np.arange(rig.num_joints, dtype=np.int32)
+    B = 4
+    rng = np.random.default_rng(37)
+    off, pre, rigs = _variants(rig, B, rng, scale=0.15)
+    conss = [make_problem(rigs[b], allj, allj, 1, seed=200 + b, perturb=0.25)[0] for b in range(B)]
+    cat = lambda f: np.concatenate([getattr(c, f) for c in conss], axis=0)
+    cons = orc.Constraints(allj, cat("pos_offset"), cat("pos_target"), cat("pos_weight"), allj, cat("ori_offset"), cat("ori_target"), cat("ori_weight"))
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, allj, allj)
+    _upload(torch, pb, cons, B)
+    pb.set_instance_rig(torch.from_numpy(off).to(pb.device), torch.from_numpy(pre).to(pb.device))
+    parents = [allj] * B
+    th0 = np.zeros((B, rig.num_params), np.float32)
+    _check_solve(torch, orc, pb, rigs, cons, th0, parents, parents, GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05))
+    _check_solve(torch, orc, pb, rigs, cons, th0, parents, parents, GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=2))
