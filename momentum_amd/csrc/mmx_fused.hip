@@ -373,7 +373,10 @@ __device__ __forceinline__ double generalRowsError(const ProblemDev& pb, const f
 // SkeletonSolverFunctionT::getError (skeleton_solver_function.cpp:64-83) of the parameters in
 // `th`: FK without derivatives + sum of w * |f|^2, rounded through float like the reference (:82).
 // Every thread returns the same value.  Clobbers the FK scratch / js / red.
-template <bool kGen = false>
+// kStore: the evaluation also leaves everything phases A-C of an iteration would leave for `th` (rotation axes, the
+// units' vectors / residuals / weights) and reports the unrounded sum -- when the trial is accepted, the next iteration
+// starts from it instead of repeating forward kinematics and the unit evaluation.
+template <bool kGen = false, bool kStore = false>
 __device__ __forceinline__ double blockError(
     const RigDev& rigDev,
     const RigView& rig,
@@ -382,12 +385,21 @@ __device__ __forceinline__ double blockError(
     const FusedLds& s,
     const float* th,
     int b,
-    int tid) {
+    int tid,
+    double* unrounded = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
-  blockFk(rig, s, th, tid, false);
+  blockFk(rig, s, th, tid, kStore);
   double e = 0.0;
   for (int u = tid; u < fd.U; u += 256) {
-    e += double(evalUnit(pb, s.js, b, u).werr);
+    const Unit un = evalUnit(pb, s.js, b, u);
+    if (kStore) {
+      s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
+      const float rx = un.sigma * un.f.x, ry = un.sigma * un.f.y, rz = un.sigma * un.f.z;
+      s.ur[3 * u] = rx, s.ur[3 * u + 1] = ry, s.ur[3 * u + 2] = rz;
+      s.uy[3 * u] = un.sigma * rx, s.uy[3 * u + 1] = un.sigma * ry, s.uy[3 * u + 2] = un.sigma * rz;
+      s.us[u] = un.sigma;
+    }
+    e += double(un.werr);
   }
   if (pb.M > pb.rowsJoint) {
     e += paramRowsError<false>(rigDev, pb, rig.P, th, b, tid);
@@ -402,6 +414,9 @@ __device__ __forceinline__ double blockError(
   __syncthreads();
   const double tot = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
   __syncthreads();
+  if (unrounded != nullptr) {
+    *unrounded = tot;
+  }
   return double(float(tot));
 }
 
@@ -827,6 +842,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   float trRadius = fp.trustRadius; // TrustRegionQRT::curTrustRegionRadius_ (initializeSolver, trust_region_qr.cpp:38-41)
   double curError = DBL_MAX;
   int itersDone = 0;
+  // the joint states / units in LDS already belong to s.th (left by an accepted trial of the line search or the LM
+  // schedule, blockError<kStore>); stateError = the error an evaluation of phases A-C would report for it
+  // (measured: line search 1.39 -> 1.52e6, LM schedule 1.41 -> 1.53e6 solves/s at cfg2 / cfg3)
+  constexpr bool kReuse = !kGen && !kTR;
+  bool stateValid = false;
+  double stateError = 0.0;
   __syncthreads();
 
   if (MODE == 2) {
@@ -861,6 +882,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     const int tid = tidT;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (kReuse && stateValid) {
+      curError = stateError;
+    } else {
     // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
     blockFk(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast);
     MMX_CLK(1)
@@ -935,6 +959,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     }
     __syncthreads();
     curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); // every thread: the same value
+    } // (phases A-C)
     if (kGen) {
       // J_g: entry (row of constraint g, solve column c) gathered from the column's source slots, the walk of
       // joint_error_function-inl.h:228-294 turned around as in jointBlocksKernel (constraints fastest)
@@ -1766,12 +1791,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         s.dfull[fv.solveList[c]] -= s.d0[c];
       }
       __syncthreads();
-      const double eNew = blockError<kGen>(rig, rv, pb, fv, s, s.dfull, b, tid);
+      double eFull = 0.0;
+      const double eNew = blockError<kGen, kReuse>(rig, rv, pb, fv, s, s.dfull, b, tid, &eFull);
       const float rho = predicted > 0.f ? float((curError - eNew) / double(predicted)) : -1.f;
+      stateValid = false; // (a rejected trial leaves the trial's joint states behind: this theta is evaluated again)
       if (rho > 0.f) {
         for (int i = tid; i < P; i += 256) {
           s.th[i] = s.dfull[i];
         }
+        stateValid = kReuse && !hasParamRows;
+        stateError = eFull;
       }
       if (!(rho >= 0.25f)) {
         lambda = fminf(lambda * fp.lmUp, fp.lmLambdaMax);
@@ -1804,7 +1833,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           s.dfull[fv.solveList[c]] -= scale * s.d0[c];
         }
         __syncthreads();
-        const double eNew = blockError<kGen>(rig, rv, pb, fv, s, s.dfull, b, tid);
+        const double eNew = blockError<kGen, kReuse>(rig, rv, pb, fv, s, s.dfull, b, tid, &stateError);
         if ((curError - eNew) >= (fp.doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale * scaledError))) {
           break;
         }
@@ -1813,10 +1842,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       for (int i = tid; i < P; i += 256) {
         s.th[i] = s.dfull[i];
       }
+      stateValid = kReuse && !hasParamRows; // the last trial evaluated IS the new theta
     } else if (!notPd) {
       for (int c = tid; c < n; c += 256) {
         s.th[fv.solveList[c]] -= s.d0[c]; // skeleton_solver_function.cpp:158
       }
+      stateValid = false;
     }
     break;
     }
