@@ -6,7 +6,7 @@ r=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/round_$r
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 700 python -m pytest tests -m gpu -q < /dev/null 2>&1 | tail -4 > $out/pytest_gpu.txt
+timeout 700 python -m pytest tests -m gpu -q < /dev/null 2>&1 | grep -E "passed|failed|FAILED|rror" | tail -6 > $out/pytest_gpu.txt
 timeout 900 python bench.py < /dev/null > $out/${r}_bench_default.json 2> $out/bench_default.err
 cd /tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 0"
