@@ -787,9 +787,10 @@ bool treeNormalEquationsUsable(const mmx_problem* pb) {
   if (e != nullptr && e[0] == '0') {
     return false;
   }
-  return !pb->instPos && !pb->instOri && pb->dev.G == 0 && pb->dev.NE == 0 && pb->M == 3 * pb->U && pb->U > 0 && pb->fdev.n > 0 &&
+  // (limit / model-parameter rows ride along: evaluated on the fly from theta like in the fused solve)
+  return !pb->instPos && !pb->instOri && pb->dev.G == 0 && pb->dev.NE == 0 && pb->dev.rowsJoint == 3 * pb->U && pb->U > 0 && pb->fdev.n > 0 &&
       pb->fdev.n <= 512 && pb->fdev.nsrc < 4096 && pb->fused.solveList == pb->solveListV1 &&
-      mmx::treeNormalEquationsLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc) <= 160 * 1024 - 64;
+      mmx::treeNormalEquationsLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n) <= 160 * 1024 - 64;
 }
 
 bool wantLegacySolver() {
@@ -1948,7 +1949,7 @@ static int32_t solveImpl(
       // sits out the remaining rounds (its workgroups return at once)
       for (int round = 0; round < 3 && sp.refine; ++round) {
         MMX_HIP(mmx::launchTreeRefine(
-            pb->rigDev, pb->dev, pb->fdev, pb->sTreeState.as<float>(), pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
+            pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sTreeState.as<float>(), pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
             sp.lambda, sp.lambdaPer, s));
         MMX_HIP(mmx::launchCholeskyFinishTiled(
             ds, pb->rig->P, factorScratch, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(), pb->sErr.as<double>(),

@@ -1931,10 +1931,12 @@ struct TreeNeLds {
   int *subSize, *loadedPos; // copies of the tables the subtree sums walk (read once per inner step)
   int *posUnitStart, *posUnits; // ... and of the units-per-joint lists the own sums walk
   int* kRange; // [2 rowTiles] treeSumRanges
+  int* col; // [P] parameter -> solve column or -1 (parameter-space rows)
+  float* pdiag; // [NP] diagonal contributions of the parameter-space rows
   double* red;
 };
 
-__host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc, TreeNeLds* out, float* base) {
+__host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc, TreeNeLds* out, float* base, int n = 0) {
   size_t off = 0;
   auto take = [&](size_t count) {
     const size_t o = off;
@@ -1951,10 +1953,12 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   const size_t oSrc = take(size_t(kSrcCh) * size_t(srcStrideFor(nsrc)));
   const size_t oSpan = take(nsrc);
   const size_t oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U), oKr = take(2 * ((size_t(J) + 15) / 16));
+  const size_t oCol = take(P), oPd = take((size_t(n) + 15) & ~size_t(15));
   const size_t oRed = take(16);
   if (out != nullptr) {
     out->span = reinterpret_cast<int*>(base + oSpan);
     out->kRange = reinterpret_cast<int*>(base + oKr);
+    out->col = reinterpret_cast<int*>(base + oCol), out->pdiag = base + oPd;
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->th = base + oTh, out->js = base + oJs, out->alt = base + oAlt;
@@ -1991,7 +1995,8 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int NB = (n + 15) >> 4, NP = 16 * NB, T = NB * (NB + 1) / 2;
   TreeNeLds t;
-  treeNeLdsFloats(J, P, U, nsrc, &t, smem);
+  treeNeLdsFloats(J, P, U, nsrc, &t, smem, n);
+  const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   long long tclk = clock64();
 #define MMX_TCLK(slot)                 \
   if (clk != nullptr && b == 0) {      \
@@ -2031,7 +2036,13 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   for (int e = tid; e < nsrc; e += 256) {
     t.span[e] = fd.srcs[e].tin | (fd.srcs[e].tout << 16);
   }
+  for (int i = tid; i < P; i += 256) {
+    t.col[i] = -1;
+  }
   __syncthreads();
+  for (int c = tid; c < n; c += 256) {
+    t.col[fd.solveList[c]] = c;
+  }
   treeSumRanges(t.subSize, t.loadedPos, fd.numLoaded, J, tid, t.kRange); // (barriers follow before the first tree sum)
   MMX_TCLK(0)
   // ---- A, B: forward kinematics with rotation axes
@@ -2053,6 +2064,9 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
         float* o = stb + sl.ur + 3 * u;
         o[0] = un.sigma * un.f.x, o[1] = un.sigma * un.f.y, o[2] = un.sigma * un.f.z;
       }
+    }
+    if (hasParamRows) {
+      e += paramRowsError<true>(rig, pb, P, s.th, b, tid);
     }
     e = waveReduceSum(e);
     if (lane == 0) {
@@ -2141,6 +2155,11 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     const int e1 = NP + fd.srcStart[c + 1];
     for (int e = NP + fd.srcStart[c]; e < e1; ++e) {
       acc += srcG[e];
+    }
+    if (hasParamRows) { // limit / model-parameter rows: evaluated on the fly from theta (fusedSolveKernel phase F)
+      const ParamCol pc = paramRowsColumn(rig, pb, fd, s.th, nullptr, t.col, P, b, c, fd.solveList[c]);
+      acc += pc.g;
+      t.pdiag[c] = pc.h; // parked until the tiles of H are in place
     }
     jtr[size_t(b) * n + c] = acc;
   }
@@ -2255,12 +2274,41 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       *hp = v;
     }
   }
+  if (hasParamRows) { // J^T J of the parameter-space rows: diagonal entries, then the shared off-diagonal ones
+    __threadfence_block();
+    __syncthreads();
+    auto hEntry = [&](int row, int col) { // row >= col
+      return tileMajor ? Ht + size_t(tileIndex(row >> 4, col >> 4)) * 256 + (col & 15) * 16 + (row & 15) : Hb + size_t(row) * n + col;
+    };
+    for (int c = tid; c < n; c += 256) {
+      *hEntry(c, c) += t.pdiag[c];
+    }
+    if (pb.wLimit > 0.f) {
+      const float tWeight = 1e+1f * pb.wLimit;
+      for (int d = tid; d < fd.numPairDests; d += 256) {
+        float accp = 0.f;
+        const int k1 = fd.pairStart[d + 1];
+        for (int k = fd.pairStart[d]; k < k1; ++k) {
+          const LimitRow row = evalLimit(rig, pb.limits[fd.pairLim[k]], s.th, pb.enabledMask, tWeight);
+          float ca = 0.f, cb = 0.f; // the row's entries in the two columns of this H entry
+#pragma unroll
+          for (int e = 0; e < kLimitEntries; ++e) {
+            const int sc = row.idx[e] >= 0 ? t.col[row.idx[e]] : -1;
+            ca += sc == fd.pairCols[2 * d] ? row.coef[e] : 0.f;
+            cb += sc == fd.pairCols[2 * d + 1] ? row.coef[e] : 0.f;
+          }
+          accp += ca * cb;
+        }
+        *hEntry(fd.pairCols[2 * d], fd.pairCols[2 * d + 1]) += accp;
+      }
+    }
+  }
   MMX_TCLK(7)
 #undef MMX_TCLK
 }
 
-size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc) {
-  return treeNeLdsFloats(J, P, U, nsrc, nullptr, nullptr) * sizeof(float);
+size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n) {
+  return treeNeLdsFloats(J, P, U, nsrc, nullptr, nullptr, n) * sizeof(float);
 }
 
 hipError_t launchTreeNormalEquations(
@@ -2276,7 +2324,7 @@ hipError_t launchTreeNormalEquations(
     long long* clk,
     bool tileMajor,
     hipStream_t stream) {
-  const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc);
+  const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc, fd.n);
   if (lds > 160 * 1024 - 64) {
     return hipErrorInvalidValue;
   }
@@ -2299,7 +2347,7 @@ hipError_t launchTreeNormalEquations(
 // with this kernel the wide path neither writes nor reads one.  grid = B, block = 256.
 // =============================================================================================
 struct TreeRefLds {
-  float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0;
+  float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0, *th;
   int *col, *subSize, *loadedPos, *posUnitStart, *posUnits, *kRange;
 };
 __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base) {
@@ -2316,9 +2364,10 @@ __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n
   const size_t oR2 = take(size_t(kTan > kC1 ? kTan : kC1) * J); // tanOwn, then the own sums
   const size_t oPre = take(size_t(kTan) * J);
   const size_t oD = take(NP), oCol = take(P), oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U);
-  const size_t oKr = take(2 * ((size_t(J) + 15) / 16));
+  const size_t oKr = take(2 * ((size_t(J) + 15) / 16)), oTh = take(P);
   if (out != nullptr) {
     out->kRange = reinterpret_cast<int*>(base + oKr);
+    out->th = base + oTh;
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->js = base + oJs, out->up = base + oUp, out->ur = base + oUr, out->us = base + oUs;
@@ -2333,6 +2382,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
+    const float* __restrict__ theta, // [B][P] the parameters the normal equations were built at
     const float* __restrict__ state, // [B][treeStateFloats]
     const float* __restrict__ dvec, // [B][NP] the step
     float* __restrict__ rhoVec, // [B][NP]
@@ -2373,6 +2423,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     }
     for (int i = tid; i < P; i += 256) {
       t.col[i] = -1;
+      t.th[i] = theta[size_t(b) * P + i];
     }
     for (int i = tid; i < J; i += 256) {
       t.subSize[i] = fd.subSize[i];
@@ -2480,6 +2531,9 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
       for (int e = NP + fd.srcStart[c]; e < e1; ++e) {
         a += slotShare(e);
       }
+      if (pb.M > pb.rowsJoint) { // limit / model-parameter rows, residual r - J d (fusedSolveKernel phase J)
+        a += paramRowsColumn(rig, pb, fd, t.th, s.d0, t.col, P, b, c, fd.solveList[c]).g;
+      }
       a -= lambda * s.d0[c];
     }
     rhoVec[size_t(b) * NP + c] = a;
@@ -2494,6 +2548,7 @@ hipError_t launchTreeRefine(
     const RigDev& rig,
     const ProblemDev& pb,
     const FusedDev& fd,
+    const float* theta,
     const float* state,
     const float* dvec,
     float* rhoVec,
@@ -2513,7 +2568,7 @@ hipError_t launchTreeRefine(
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL(treeRefineKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, state, dvec, rhoVec, refState, lambda, lambdaPer);
+  hipLaunchKernelGGL(treeRefineKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, state, dvec, rhoVec, refState, lambda, lambdaPer);
   return hipGetLastError();
 }
 #endif

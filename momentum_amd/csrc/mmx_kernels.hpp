@@ -89,7 +89,7 @@ struct FusedParams {
 
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels, int GT = 0, int genRows = 0);
 // H = J^T J, g = J^T r from the tree moments for the explicit-Jacobian solver (mmx_fused.hip, treeNormalEquationsKernel)
-size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc);
+size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n);
 hipError_t launchTreeNormalEquations(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -109,6 +109,7 @@ hipError_t launchTreeRefine(
     const RigDev& rig,
     const ProblemDev& pb,
     const FusedDev& fd,
+    const float* theta,
     const float* state,
     const float* dvec,
     float* rhoVec,

@@ -144,3 +144,57 @@ def test_solve_with_limits_and_model_prior_matches_oracle(torch_cuda, orc, which
     assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+
+
+@pytest.mark.parametrize("route", ["tree", "dense"])
+def test_wide_solve_with_limits_and_the_model_prior(torch_cuda, orc, route, monkeypatch):
+    """The 300-joint rig (wide path) with parameter limits of every type and the model-parameter prior next to its
+    position / orientation constraints: the tree kernels evaluate these rows on the fly from theta (normal equations:
+    g, diagonal and shared off-diagonal entries of H; refinement residual), the dense route assembles them into J."""
+    from momentum_amd import make_rig300
+
+    torch = torch_cuda
+    if route == "dense":
+        monkeypatch.setenv("MMX_TREE_NE", "0")
+        monkeypatch.setenv("MMX_TREE_REFINE", "0")
+    rig = make_rig300(seed=12345, unit=UNIT)
+    rng = np.random.default_rng(79)
+    pp = rng.choice(rig.num_joints, size=120, replace=False)
+    op = rng.choice(rig.num_joints, size=40, replace=False)
+    B = 3
+    rh, pb, full, th0 = _problem(torch, orc, rig, pp, op, B, 91)
+    if route == "tree":  # the tree-moment normal equations with the parameter-space rows against the oracle's J^T J / J^T r
+        import ctypes as C
+
+        from momentum_amd import capi
+
+        buf, nn = np.zeros(rig.num_params, np.int32), C.c_int32(0)
+        capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(nn), None))
+        lst = buf[: nn.value]
+        assert nn.value == rig.num_params  # the model prior keeps every parameter in the solve list
+        theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
+        monkeypatch.setenv("MMX_TREE_NE", "force")
+        Ht, gt, _ = pb.normal_equations(torch.from_numpy(theta).to(pb.device))
+        monkeypatch.delenv("MMX_TREE_NE", raising=False)
+        Ht, gt = Ht.cpu().numpy(), gt.cpu().numpy()
+        for b in range(B):
+            Jm, r, e = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), dtype="f64")
+            Je = Jm[:, lst]
+            H, g = Je.T @ Je, Je.T @ r
+            assert np.abs(np.tril(Ht[b]) - np.tril(H)).max() <= 5e-5 * max(1.0, np.abs(H).max())
+            assert np.abs(gt[b] - g).max() <= 5e-5 * max(1.0, np.abs(g).max())
+    from tests.test_gpu_parity import _sensitivity
+
+    for opt in (
+        GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05),
+        GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=2),
+    ):
+        out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+        ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+        th = out["theta"].cpu().numpy()
+        rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+        tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
+        assert np.all(rel <= tol), (route, rel, tol)
+        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        h = out["error_history"].cpu().numpy()
+        assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
