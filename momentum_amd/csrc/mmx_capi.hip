@@ -210,7 +210,7 @@ struct mmx_problem {
   std::vector<int32_t> solveListV1; // host copy
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sFactor, sThetaInit, sTheta;
-  DevBuf sTreeState, sDvec, sRhoVec, sRefState; // wide systems refined through the tree (no dense J)
+  DevBuf sTreeState, sDvec, sRhoVec, sRefState, sGenState; // wide systems refined through the tree (no dense J)
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
   DevBuf sJacF64, sHessF64; // scratch of the double-precision solve
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
@@ -787,10 +787,12 @@ bool treeNormalEquationsUsable(const mmx_problem* pb) {
   if (e != nullptr && e[0] == '0') {
     return false;
   }
-  // (limit / model-parameter rows ride along: evaluated on the fly from theta like in the fused solve)
-  return !pb->instPos && !pb->instOri && pb->dev.G == 0 && pb->dev.NE == 0 && pb->dev.rowsJoint == 3 * pb->U && pb->U > 0 && pb->fdev.n > 0 &&
-      pb->fdev.n <= 512 && pb->fdev.nsrc < 4096 && pb->fused.solveList == pb->solveListV1 &&
-      mmx::treeNormalEquationsLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n) <= 160 * 1024 - 64;
+  // (limit / model-parameter rows ride along: evaluated on the fly from theta like in the fused solve; the further joint
+  // error functions and ellipsoid limits as a dense block of rows in LDS while it fits)
+  return !pb->instPos && !pb->instOri && pb->U > 0 && pb->fdev.n > 0 && pb->fdev.n <= 512 && pb->fdev.nsrc < 4096 &&
+      pb->fused.solveList == pb->solveListV1 &&
+      mmx::treeNormalEquationsLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.GT, pb->fdev.genRows) <= 160 * 1024 - 64 &&
+      mmx::treeRefineLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.n, pb->fdev.genRows) <= 160 * 1024 - 64;
 }
 
 bool wantLegacySolver() {
@@ -1704,7 +1706,7 @@ int32_t mmx_eval_normal_equations(
         return fail(MMX_ERR_UNSUPPORTED, "MMX_TREE_NE=force: problem outside the tree-moment kernel's scope (or structurally zero columns present)");
       }
       MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
-      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, false, s));
+      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, nullptr, false, s));
       return MMX_OK;
     }
   }
@@ -1925,11 +1927,16 @@ static int32_t solveImpl(
     factorScratch = pb->sFactor.as<float>();
   }
   const size_t NPs = (size_t(n) + 15) & ~size_t(15);
+  float* genState = nullptr; // J_g of the further joint error functions / ellipsoid limits, tree kernels' hand-over
   if (treeRefine) {
     MMX_HIP(pb->sTreeState.ensure(size_t(B) * mmx::treeStateFloats(pb->rig->J, pb->fdev.U) * sizeof(float)));
     MMX_HIP(pb->sDvec.ensure(size_t(B) * NPs * sizeof(float)));
     MMX_HIP(pb->sRhoVec.ensure(size_t(B) * NPs * sizeof(float)));
     MMX_HIP(pb->sRefState.ensure(size_t(B) * sizeof(int32_t)));
+    if (pb->fdev.GT > 0) {
+      MMX_HIP(pb->sGenState.ensure(size_t(B) * mmx::treeGenStateFloats(pb->fdev.n, pb->fdev.genRows) * sizeof(float)));
+      genState = pb->sGenState.as<float>();
+    }
   }
   for (int it = 0; it < o->max_iterations; ++it) { // solver.cpp:89
     sp.iteration = it;
@@ -1939,7 +1946,7 @@ static int32_t solveImpl(
         MMX_ZONE("Get JtJ and JtR");
         MMX_HIP(mmx::launchTreeNormalEquations(
             pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, pb->sErr.as<double>(),
-            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, true, s));
+            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, genState, true, s));
       }
       MMX_ZONE("Dense gauss newton step");
       MMX_HIP(mmx::launchCholeskyFactorTiled(
@@ -1949,7 +1956,7 @@ static int32_t solveImpl(
       // sits out the remaining rounds (its workgroups return at once)
       for (int round = 0; round < 3 && sp.refine; ++round) {
         MMX_HIP(mmx::launchTreeRefine(
-            pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sTreeState.as<float>(), pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
+            pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sTreeState.as<float>(), genState, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
             sp.lambda, sp.lambdaPer, s));
         MMX_HIP(mmx::launchCholeskyFinishTiled(
             ds, pb->rig->P, factorScratch, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(), pb->sErr.as<double>(),
@@ -1964,7 +1971,7 @@ static int32_t solveImpl(
           // H and g from the tree moments, O(n^2) per instance, J not read (J itself is still assembled above: the
           // Cholesky step's refinement streams it)
           MMX_HIP(mmx::launchTreeNormalEquations(
-              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, nullptr, false, s));
+              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, nullptr, nullptr, false, s));
         } else {
           MMX_HIP(mmx::launchNormalEquations(
               ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, wide, s));

@@ -370,6 +370,121 @@ __device__ __forceinline__ double generalRowsError(const ProblemDev& pb, const f
   return e;
 }
 
+// The further joint error functions and the ellipsoid limits at the joint states in js: per constraint a record
+// (v_p, v_n, sigma df/dv_p, sigma df/dv_n, DFS position, first row, flags, stop position) in gEv, the residual rows in
+// gRes (rows counted from the first row after the 3 U position / orientation rows); returns this thread's error share.
+__device__ __forceinline__ double generalRowsEvaluate(const ProblemDev& pb, const float* js, int b, int U, int tid, float* gEv, float* gRes) {
+  double e = 0.0;
+  int* evi = reinterpret_cast<int*>(gEv);
+  for (int g = tid; g < pb.G; g += 256) {
+    const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+    const int i = g - k.first;
+    const JointEval o = evalJointConstraint(k, js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(i));
+    const int row = k.rowStart + o.nrows * i - 3 * U;
+    e += double(o.werr);
+    for (int q = 0; q < o.nrows; ++q) {
+      gRes[row + q] = o.sigma * o.f[q];
+    }
+    const float sg = fabsf(o.sigma) <= 1e-9f ? 0.f : o.sigma; // early termination (joint_error_function-inl.h:216): the rows stay zero
+    float* w = gEv + kGenEv * g;
+    w[0] = o.vp.x, w[1] = o.vp.y, w[2] = o.vp.z;
+    w[3] = o.vn.x, w[4] = o.vn.y, w[5] = o.vn.z;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      w[6 + q] = sg * o.dp[q];
+      w[15 + q] = sg * o.dn[q];
+    }
+    evi[kGenEv * g + 24] = pb.genTin[g];
+    evi[kGenEv * g + 25] = row;
+    evi[kGenEv * g + 26] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0);
+    evi[kGenEv * g + 27] = -1;
+  }
+  const float tWeightE = 1e+1f * pb.wLimit;
+  for (int q = tid; q < pb.NE; q += 256) { // LimitType::Ellipsoid (limit_error_function.cpp:702-790), see jointBlocksKernel
+    const EllipsoidDev ct = pb.ellipsoids[q];
+    const int row = pb.rowsJoint - 3 * pb.NE + 3 * q - 3 * U, g = pb.G + q;
+    EllipsoidEval o = evalEllipsoid(ct, js, tWeightE);
+    if (!(pb.wLimit > 0.f)) {
+      o.jwgt = o.werr = 0.f;
+    }
+    e += double(o.werr);
+    gRes[row] = o.diff.x * o.jwgt, gRes[row + 1] = o.diff.y * o.jwgt, gRes[row + 2] = o.diff.z * o.jwgt;
+    float* w = gEv + kGenEv * g;
+    w[0] = o.position.x, w[1] = o.position.y, w[2] = o.position.z;
+    w[3] = w[4] = w[5] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      w[6 + k] = (k == 0 || k == 4 || k == 8) ? o.jwgt : 0.f;
+      w[15 + k] = 0.f;
+    }
+    evi[kGenEv * g + 24] = ct.tinParent;
+    evi[kGenEv * g + 25] = row;
+    evi[kGenEv * g + 26] = 3 | 16;
+    evi[kGenEv * g + 27] = ct.tinStop;
+  }
+  return e;
+}
+
+// J_g: entry (row of constraint g, solve column c) gathered from the column's source slots -- the walk of
+// joint_error_function-inl.h:228-294 turned around as in jointBlocksKernel (constraints fastest).  slot(e): the slot's
+// DFS interval, joint, dof, parent and weight; extras(c, e0, e1): the extra slots of column c besides its primary slot c.
+struct GenSlot {
+  int tin, tout, joint, dof, parent;
+  float weight;
+};
+template <typename SlotFn, typename ExtrasFn>
+__device__ __forceinline__ void generalRowsGather(const float* js, const float* gEv, float* gJ, int gst, int GT, int n, int tid, SlotFn slot, ExtrasFn extras) {
+  const int* evi = reinterpret_cast<const int*>(gEv);
+  for (int item = tid; item < GT * n; item += 256) {
+    const int c = item / GT, g = item - c * GT;
+    const float* w = gEv + kGenEv * g;
+    const int tin = evi[kGenEv * g + 24], row = evi[kGenEv * g + 25], fl = evi[kGenEv * g + 26], tinStop = evi[kGenEv * g + 27];
+    const bool hasPoint = (fl & 16) != 0, hasDir = (fl & 32) != 0;
+    const F3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
+    float acc[3] = {0.f, 0.f, 0.f};
+    auto addSlot = [&](int e) {
+      const GenSlot sl = slot(e);
+      if (!(sl.tin <= tin && tin < sl.tout)) {
+        return; // the slot's joint is not an ancestor of the constraint's joint
+      }
+      if (tinStop >= 0 && sl.tin <= tinStop && tinStop < sl.tout) {
+        return; // ellipsoid limit: the walk stopped before this joint
+      }
+      const float* a = js + kJs * sl.joint;
+      F3 gp{0.f, 0.f, 0.f}, gn{0.f, 0.f, 0.f};
+      if (sl.dof >= 3 && sl.dof < 6) {
+        const float* ax = a + 8 + 3 * (sl.dof - 3);
+        const F3 axis{ax[0], ax[1], ax[2]};
+        if (hasPoint) {
+          gp = cross(axis, vp - F3{a[0], a[1], a[2]});
+        }
+        if (hasDir) {
+          gn = cross(axis, vn);
+        }
+      } else if (hasPoint) {
+        gp = sl.dof < 3 ? transAxisCol(js, sl.parent, sl.dof) : kLn2 * (vp - F3{a[0], a[1], a[2]});
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float jc = (w[6 + 3 * q] * gp.x + w[7 + 3 * q] * gp.y + w[8 + 3 * q] * gp.z) +
+            (w[15 + 3 * q] * gn.x + w[16 + 3 * q] * gn.y + w[17 + 3 * q] * gn.z);
+        acc[q] += jc * sl.weight;
+      }
+    };
+    addSlot(c);
+    int e0, e1;
+    extras(c, e0, e1);
+    for (int e = e0; e < e1; ++e) {
+      addSlot(e);
+    }
+    gJ[row * gst + c] = acc[0];
+    if ((fl & 15) == 3) {
+      gJ[(row + 1) * gst + c] = acc[1];
+      gJ[(row + 2) * gst + c] = acc[2];
+    }
+  }
+}
+
 // SkeletonSolverFunctionT::getError (skeleton_solver_function.cpp:64-83) of the parameters in
 // `th`: FK without derivatives + sum of w * |f|^2, rounded through float like the reference (:82).
 // Every thread returns the same value.  Clobbers the FK scratch / js / red.
@@ -904,53 +1019,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         e += paramRowsError<true>(rig, pb, P, s.th, b, tid);
       }
       if (kGen) { // the further joint error functions and the ellipsoid limits: records for the rows of J_g, residual rows
-        int* evi = reinterpret_cast<int*>(s.gEv);
-        for (int g = tid; g < pb.G; g += 256) {
-          const JointBlockDev k = pb.blocks[pb.genBlock[g]];
-          const int i = g - k.first;
-          const JointEval o = evalJointConstraint(k, s.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(i));
-          const int row = k.rowStart + o.nrows * i - 3 * U;
-          e += double(o.werr);
-          for (int q = 0; q < o.nrows; ++q) {
-            s.gRes[row + q] = o.sigma * o.f[q];
-          }
-          const float sg = fabsf(o.sigma) <= 1e-9f ? 0.f : o.sigma; // early termination (joint_error_function-inl.h:216): the rows stay zero
-          float* w = s.gEv + kGenEv * g;
-          w[0] = o.vp.x, w[1] = o.vp.y, w[2] = o.vp.z;
-          w[3] = o.vn.x, w[4] = o.vn.y, w[5] = o.vn.z;
-#pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            w[6 + q] = sg * o.dp[q];
-            w[15 + q] = sg * o.dn[q];
-          }
-          evi[kGenEv * g + 24] = pb.genTin[g];
-          evi[kGenEv * g + 25] = row;
-          evi[kGenEv * g + 26] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0);
-          evi[kGenEv * g + 27] = -1;
-        }
-        const float tWeightE = 1e+1f * pb.wLimit;
-        for (int q = tid; q < pb.NE; q += 256) { // LimitType::Ellipsoid (limit_error_function.cpp:702-790), see jointBlocksKernel
-          const EllipsoidDev ct = pb.ellipsoids[q];
-          const int row = pb.rowsJoint - 3 * pb.NE + 3 * q - 3 * U, g = pb.G + q;
-          EllipsoidEval o = evalEllipsoid(ct, s.js, tWeightE);
-          if (!(pb.wLimit > 0.f)) {
-            o.jwgt = o.werr = 0.f;
-          }
-          e += double(o.werr);
-          s.gRes[row] = o.diff.x * o.jwgt, s.gRes[row + 1] = o.diff.y * o.jwgt, s.gRes[row + 2] = o.diff.z * o.jwgt;
-          float* w = s.gEv + kGenEv * g;
-          w[0] = o.position.x, w[1] = o.position.y, w[2] = o.position.z;
-          w[3] = w[4] = w[5] = 0.f;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            w[6 + k] = (k == 0 || k == 4 || k == 8) ? o.jwgt : 0.f;
-            w[15 + k] = 0.f;
-          }
-          evi[kGenEv * g + 24] = ct.tinParent;
-          evi[kGenEv * g + 25] = row;
-          evi[kGenEv * g + 26] = 3 | 16;
-          evi[kGenEv * g + 27] = ct.tinStop;
-        }
+        e += generalRowsEvaluate(pb, s.js, b, U, tid, s.gEv, s.gRes);
       }
       e = waveReduceSum(e);
       if (lane == 0) {
@@ -961,61 +1030,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); // every thread: the same value
     } // (phases A-C)
     if (kGen) {
-      // J_g: entry (row of constraint g, solve column c) gathered from the column's source slots, the walk of
-      // joint_error_function-inl.h:228-294 turned around as in jointBlocksKernel (constraints fastest)
-      const int gst = srcStrideFor(NP), GT = fd.GT;
-      const int* evi = reinterpret_cast<const int*>(s.gEv);
-      for (int item = tid; item < GT * n; item += 256) {
-        const int c = item / GT, g = item - c * GT;
-        const float* w = s.gEv + kGenEv * g;
-        const int tin = evi[kGenEv * g + 24], row = evi[kGenEv * g + 25], fl = evi[kGenEv * g + 26], tinStop = evi[kGenEv * g + 27];
-        const bool hasPoint = (fl & 16) != 0, hasDir = (fl & 32) != 0;
-        const F3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
-        float acc[3] = {0.f, 0.f, 0.f};
-        auto addSlot = [&](int e) {
-          const int span = s.mTin[e];
-          const int stin = span & 0xffff, stout = span >> 16;
-          if (!(stin <= tin && tin < stout)) {
-            return; // the slot's joint is not an ancestor of the constraint's joint
-          }
-          if (tinStop >= 0 && stin <= tinStop && tinStop < stout) {
-            return; // ellipsoid limit: the walk stopped before this joint
-          }
-          const int info = s.mInfo[e];
-          const int joint = info & 0xfff, dof = (info >> 12) & 7, parent = (info >> 16) - 1;
-          const float* a = s.js + kJs * joint;
-          F3 gp{0.f, 0.f, 0.f}, gn{0.f, 0.f, 0.f};
-          if (dof >= 3 && dof < 6) {
-            const float* ax = a + 8 + 3 * (dof - 3);
-            const F3 axis{ax[0], ax[1], ax[2]};
-            if (hasPoint) {
-              gp = cross(axis, vp - F3{a[0], a[1], a[2]});
-            }
-            if (hasDir) {
-              gn = cross(axis, vn);
-            }
-          } else if (hasPoint) {
-            gp = dof < 3 ? transAxisCol(s.js, parent, dof) : kLn2 * (vp - F3{a[0], a[1], a[2]});
-          }
-          const float wgt = s.mW[e];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            const float jc = (w[6 + 3 * q] * gp.x + w[7 + 3 * q] * gp.y + w[8 + 3 * q] * gp.z) +
-                (w[15 + 3 * q] * gn.x + w[16 + 3 * q] * gn.y + w[17 + 3 * q] * gn.z);
-            acc[q] += jc * wgt;
-          }
-        };
-        addSlot(c);
-        const int e1 = NP + s.mStart[c + 1];
-        for (int e = NP + s.mStart[c]; e < e1; ++e) {
-          addSlot(e);
-        }
-        s.gJ[row * gst + c] = acc[0];
-        if ((fl & 15) == 3) {
-          s.gJ[(row + 1) * gst + c] = acc[1];
-          s.gJ[(row + 2) * gst + c] = acc[2];
-        }
-      }
+      generalRowsGather(
+          s.js, s.gEv, s.gJ, srcStrideFor(NP), fd.GT, n, tid,
+          [&](int e) {
+            const int span = s.mTin[e], info = s.mInfo[e];
+            return GenSlot{span & 0xffff, span >> 16, info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.mW[e]};
+          },
+          [&](int c, int& e0, int& e1) { e0 = NP + s.mStart[c], e1 = NP + s.mStart[c + 1]; });
       __syncthreads();
     }
     MMX_CLK(2)
@@ -1931,12 +1952,10 @@ struct TreeNeLds {
   int *subSize, *loadedPos; // copies of the tables the subtree sums walk (read once per inner step)
   int *posUnitStart, *posUnits; // ... and of the units-per-joint lists the own sums walk
   int* kRange; // [2 rowTiles] treeSumRanges
-  int* col; // [P] parameter -> solve column or -1 (parameter-space rows)
-  float* pdiag; // [NP] diagonal contributions of the parameter-space rows
   double* red;
 };
 
-__host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc, TreeNeLds* out, float* base, int n = 0) {
+__host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc, TreeNeLds* out, float* base) {
   size_t off = 0;
   auto take = [&](size_t count) {
     const size_t o = off;
@@ -1953,12 +1972,10 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   const size_t oSrc = take(size_t(kSrcCh) * size_t(srcStrideFor(nsrc)));
   const size_t oSpan = take(nsrc);
   const size_t oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U), oKr = take(2 * ((size_t(J) + 15) / 16));
-  const size_t oCol = take(P), oPd = take((size_t(n) + 15) & ~size_t(15));
   const size_t oRed = take(16);
   if (out != nullptr) {
     out->span = reinterpret_cast<int*>(base + oSpan);
     out->kRange = reinterpret_cast<int*>(base + oKr);
-    out->col = reinterpret_cast<int*>(base + oCol), out->pdiag = base + oPd;
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
     out->th = base + oTh, out->js = base + oJs, out->alt = base + oAlt;
@@ -1973,6 +1990,25 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   return off;
 }
 
+// LDS of the kExtraRows instantiation, carved behind the tables above (kept out of TreeNeLds: the plain kernel's carve
+// stays the small all-in-registers struct it was)
+struct TreeNeExtraLds {
+  int* col; // [P] parameter -> solve column or -1 (parameter-space rows)
+  float* pdiag; // [NP] diagonal contributions of the parameter-space rows
+  float *gEv, *gRes, *gJ; // rows of the further joint error functions / ellipsoid limits (fusedSolveKernel kGen)
+};
+__host__ __device__ inline size_t treeNeExtraLdsFloats(int P, int n, int GT, int genRows, TreeNeExtraLds* out, float* base) {
+  const size_t NP = (size_t(n) + 15) & ~size_t(15), rowsGp = (size_t(genRows) + 3) & ~size_t(3);
+  const size_t oCol = 0, oPd = oCol + alignUp4(P), oGev = oPd + NP, oGres = oGev + alignUp4(size_t(kGenEv) * GT), oGj = oGres + rowsGp;
+  if (out != nullptr) {
+    out->col = reinterpret_cast<int*>(base + oCol), out->pdiag = base + oPd, out->gEv = base + oGev, out->gRes = base + oGres, out->gJ = base + oGj;
+  }
+  return oGj + rowsGp * size_t(srcStrideFor(int(NP)));
+}
+
+// kExtraRows: the instantiation for problems with parameter-space rows (limits, model prior) and / or further joint error
+// functions / ellipsoid limits; the plain one carries none of that code
+template <bool kExtraRows>
 __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     RigDev rig,
     ProblemDev pb,
@@ -1984,6 +2020,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     double* __restrict__ errOut, // [B] error at theta (SkeletonSolverFunctionT::getJacobian's return value), or null
     float* __restrict__ state, // [B][treeStateFloats] joint states and units for treeRefineKernel, or null
     long long* __restrict__ clk, // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
+    float* __restrict__ genState, // [B][treeGenStateFloats] J_g and its residual rows for treeRefineKernel, or null
     int tileMajor) { // 0: jtj = [n][n] row-major, lower triangle; 1: [tile (I,J) at I(I+1)/2 + J][col][row] (what the tiled factor reads) // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -1995,8 +2032,22 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int NB = (n + 15) >> 4, NP = 16 * NB, T = NB * (NB + 1) / 2;
   TreeNeLds t;
-  treeNeLdsFloats(J, P, U, nsrc, &t, smem, n);
-  const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
+  const size_t baseFloats = treeNeLdsFloats(J, P, U, nsrc, &t, smem);
+  TreeNeExtraLds x{};
+  if (kExtraRows) {
+    treeNeExtraLdsFloats(P, n, fd.GT, fd.genRows, &x, smem + baseFloats);
+  }
+  const bool hasParamRows = kExtraRows && pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
+  const bool hasGen = kExtraRows && fd.GT > 0; // further joint error functions / ellipsoid limits: a dense block of rows J_g in LDS
+  const int gst = srcStrideFor(NP), rowsGp = (fd.genRows + 3) & ~3;
+  if (hasGen) {
+    for (int i = tid; i < rowsGp * gst; i += 256) {
+      x.gJ[i] = 0.f;
+    }
+    for (int i = tid; i < rowsGp; i += 256) {
+      x.gRes[i] = 0.f;
+    }
+  }
   long long tclk = clock64();
 #define MMX_TCLK(slot)                 \
   if (clk != nullptr && b == 0) {      \
@@ -2036,12 +2087,16 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   for (int e = tid; e < nsrc; e += 256) {
     t.span[e] = fd.srcs[e].tin | (fd.srcs[e].tout << 16);
   }
-  for (int i = tid; i < P; i += 256) {
-    t.col[i] = -1;
+  if (kExtraRows) {
+    for (int i = tid; i < P; i += 256) {
+      x.col[i] = -1;
+    }
   }
   __syncthreads();
-  for (int c = tid; c < n; c += 256) {
-    t.col[fd.solveList[c]] = c;
+  if (kExtraRows) {
+    for (int c = tid; c < n; c += 256) {
+      x.col[fd.solveList[c]] = c;
+    }
   }
   treeSumRanges(t.subSize, t.loadedPos, fd.numLoaded, J, tid, t.kRange); // (barriers follow before the first tree sum)
   MMX_TCLK(0)
@@ -2068,11 +2123,23 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     if (hasParamRows) {
       e += paramRowsError<true>(rig, pb, P, s.th, b, tid);
     }
+    if (hasGen) {
+      e += generalRowsEvaluate(pb, s.js, b, U, tid, x.gEv, x.gRes);
+    }
     e = waveReduceSum(e);
     if (lane == 0) {
       s.red[wave] = e;
     }
     __syncthreads();
+    if (hasGen) { // J_g from the slots' table in global memory (slot numbering of phase F); its barrier: phase D's
+      generalRowsGather(
+          s.js, x.gEv, x.gJ, gst, fd.GT, n, tid,
+          [&](int e2) {
+            const ColumnSourceDev cs = fd.srcs[e2];
+            return GenSlot{cs.tin, cs.tout, cs.joint, cs.dof, cs.parent, cs.weight};
+          },
+          [&](int c, int& e0, int& e1) { e0 = NP + fd.srcStart[c], e1 = NP + fd.srcStart[c + 1]; });
+    }
     if (errOut != nullptr && tid == 0) {
       errOut[b] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
     }
@@ -2157,11 +2224,25 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       acc += srcG[e];
     }
     if (hasParamRows) { // limit / model-parameter rows: evaluated on the fly from theta (fusedSolveKernel phase F)
-      const ParamCol pc = paramRowsColumn(rig, pb, fd, s.th, nullptr, t.col, P, b, c, fd.solveList[c]);
+      const ParamCol pc = paramRowsColumn(rig, pb, fd, s.th, nullptr, x.col, P, b, c, fd.solveList[c]);
       acc += pc.g;
-      t.pdiag[c] = pc.h; // parked until the tiles of H are in place
+      x.pdiag[c] = pc.h; // parked until the tiles of H are in place
+    }
+    if (hasGen) {
+      for (int r = 0; r < fd.genRows; ++r) {
+        acc += x.gJ[r * gst + c] * x.gRes[r];
+      }
     }
     jtr[size_t(b) * n + c] = acc;
+  }
+  if (hasGen && genState != nullptr) { // hand-over to the refinement: J_g (rows x gst), then the residual rows
+    float* gs = genState + size_t(b) * (size_t(rowsGp) * gst + rowsGp);
+    for (int i = tid; i < rowsGp * gst; i += 256) {
+      gs[i] = x.gJ[i];
+    }
+    for (int i = tid; i < rowsGp; i += 256) {
+      gs[size_t(rowsGp) * gst + i] = x.gRes[i];
+    }
   }
   // ---- G: the tiles of the lower triangle, two masked matrix-core products each, straight to HBM
   float* Hb = jtj + size_t(b) * size_t(n) * size_t(n);
@@ -2210,6 +2291,13 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(z * cur.dI1, cur.aJ1, Pm, 0, 0, 0);
       Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(z * cur.aI1, cur.dJ1, Qm, 0, 0, 0);
       const int tinC = cur.spanC & 0xffff, toutC = cur.spanC >> 16;
+      v4f Gm{0.f, 0.f, 0.f, 0.f}; // + J_g^T J_g: a rank-genRows update on the matrix cores, operands straight from J_g
+      if (hasGen) {
+        for (int k = 0; k < (rowsGp >> 2); ++k) {
+          const float* rowp = x.gJ + (4 * k + gq) * gst;
+          Gm = __builtin_amdgcn_mfma_f32_16x16x4f32(rowp[16 * tI + i], rowp[16 * tJ + i], Gm, 0, 0, 0);
+        }
+      }
       float hv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -2218,6 +2306,9 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
         const bool rowDeep = tinC <= tinR && tinR < toutC;
         const bool colDeep = tinR <= tinC && tinC < toutR;
         hv[q] = rowDeep ? Pm[q] : (colDeep ? Qm[q] : 0.f);
+        if (kExtraRows) {
+          hv[q] += Gm[q];
+        }
         if (!tileMajor && row < n && col <= row) {
           Hb[size_t(row) * n + col] = hv[q];
         }
@@ -2281,7 +2372,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       return tileMajor ? Ht + size_t(tileIndex(row >> 4, col >> 4)) * 256 + (col & 15) * 16 + (row & 15) : Hb + size_t(row) * n + col;
     };
     for (int c = tid; c < n; c += 256) {
-      *hEntry(c, c) += t.pdiag[c];
+      *hEntry(c, c) += x.pdiag[c];
     }
     if (pb.wLimit > 0.f) {
       const float tWeight = 1e+1f * pb.wLimit;
@@ -2293,7 +2384,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
           float ca = 0.f, cb = 0.f; // the row's entries in the two columns of this H entry
 #pragma unroll
           for (int e = 0; e < kLimitEntries; ++e) {
-            const int sc = row.idx[e] >= 0 ? t.col[row.idx[e]] : -1;
+            const int sc = row.idx[e] >= 0 ? x.col[row.idx[e]] : -1;
             ca += sc == fd.pairCols[2 * d] ? row.coef[e] : 0.f;
             cb += sc == fd.pairCols[2 * d + 1] ? row.coef[e] : 0.f;
           }
@@ -2307,8 +2398,12 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
 #undef MMX_TCLK
 }
 
-size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n) {
-  return treeNeLdsFloats(J, P, U, nsrc, nullptr, nullptr, n) * sizeof(float);
+size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n, int GT, int genRows) {
+  return (treeNeLdsFloats(J, P, U, nsrc, nullptr, nullptr) + treeNeExtraLdsFloats(P, n, GT, genRows, nullptr, nullptr)) * sizeof(float);
+}
+size_t treeGenStateFloats(int n, int genRows) {
+  const size_t rowsGp = (size_t(genRows) + 3) & ~size_t(3);
+  return rowsGp * size_t(srcStrideFor((n + 15) & ~15)) + rowsGp;
 }
 
 hipError_t launchTreeNormalEquations(
@@ -2322,21 +2417,29 @@ hipError_t launchTreeNormalEquations(
     double* errOut,
     float* state,
     long long* clk,
+    float* genState,
     bool tileMajor,
     hipStream_t stream) {
-  const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc, fd.n);
+  const size_t lds = treeNormalEquationsLdsBytes(rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.GT, fd.genRows);
   if (lds > 160 * 1024 - 64) {
     return hipErrorInvalidValue;
   }
-  static size_t attrBytes = 64 * 1024;
-  if (lds > attrBytes) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(treeNormalEquationsKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  const bool extra = pb.M > pb.rowsJoint || fd.GT > 0;
+  static size_t attrBytes[2] = {64 * 1024, 64 * 1024};
+  if (lds > attrBytes[extra ? 1 : 0]) {
+    hipError_t rc = hipFuncSetAttribute(
+        extra ? reinterpret_cast<const void*>(treeNormalEquationsKernel<true>) : reinterpret_cast<const void*>(treeNormalEquationsKernel<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (rc != hipSuccess) {
       return rc;
     }
-    attrBytes = lds;
+    attrBytes[extra ? 1 : 0] = lds;
   }
-  hipLaunchKernelGGL(treeNormalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, tileMajor ? 1 : 0);
+  if (extra) {
+    hipLaunchKernelGGL(treeNormalEquationsKernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(treeNormalEquationsKernel<false>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
+  }
   return hipGetLastError();
 }
 
@@ -2347,10 +2450,10 @@ hipError_t launchTreeNormalEquations(
 // with this kernel the wide path neither writes nor reads one.  grid = B, block = 256.
 // =============================================================================================
 struct TreeRefLds {
-  float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0, *th;
+  float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0, *th, *gJ, *gRes;
   int *col, *subSize, *loadedPos, *posUnitStart, *posUnits, *kRange;
 };
-__host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base) {
+__host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base, int genRows = 0) {
   size_t off = 0;
   auto take = [&](size_t count) {
     const size_t o = off;
@@ -2365,7 +2468,10 @@ __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n
   const size_t oPre = take(size_t(kTan) * J);
   const size_t oD = take(NP), oCol = take(P), oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U);
   const size_t oKr = take(2 * ((size_t(J) + 15) / 16)), oTh = take(P);
+  const size_t rowsGp = (size_t(genRows) + 3) & ~size_t(3);
+  const size_t oGj = take(rowsGp * size_t(srcStrideFor(int(NP)))), oGres = take(rowsGp);
   if (out != nullptr) {
+    out->gJ = base + oGj, out->gRes = base + oGres;
     out->kRange = reinterpret_cast<int*>(base + oKr);
     out->th = base + oTh;
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
@@ -2384,6 +2490,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     FusedDev fd,
     const float* __restrict__ theta, // [B][P] the parameters the normal equations were built at
     const float* __restrict__ state, // [B][treeStateFloats]
+    const float* __restrict__ genState, // [B][treeGenStateFloats] J_g and its residual rows (problems with such rows), or null
     const float* __restrict__ dvec, // [B][NP] the step
     float* __restrict__ rhoVec, // [B][NP]
     const int32_t* __restrict__ refState, // [B] 0: this instance is waiting for a refinement round
@@ -2399,7 +2506,9 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   const int NP = (n + 15) & ~15;
   const float lambda = lambdaPer != nullptr ? lambdaPer[b] : lambdaAll;
   TreeRefLds t;
-  treeRefineLdsFloats(J, P, U, n, &t, smem);
+  treeRefineLdsFloats(J, P, U, n, &t, smem, fd.genRows);
+  const bool hasGen = fd.GT > 0 && genState != nullptr;
+  const int gst = srcStrideFor(NP), rowsGp = (fd.genRows + 3) & ~3;
   FusedLds s{};
   s.js = t.js, s.up = t.up, s.ur = t.ur, s.us = t.us, s.own1 = t.own1, s.sub1 = t.sub1, s.jd = t.jd, s.tanOwn = t.tanOwn, s.tanPre = t.tanPre, s.d0 = t.d0;
   FusedView fv;
@@ -2425,6 +2534,15 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
       t.col[i] = -1;
       t.th[i] = theta[size_t(b) * P + i];
     }
+    if (hasGen) {
+      const float* gs = genState + size_t(b) * (size_t(rowsGp) * gst + rowsGp);
+      for (int i = tid; i < rowsGp * gst; i += 256) {
+        t.gJ[i] = gs[i];
+      }
+      for (int i = tid; i < rowsGp; i += 256) {
+        t.gRes[i] = gs[size_t(rowsGp) * gst + i];
+      }
+    }
     for (int i = tid; i < J; i += 256) {
       t.subSize[i] = fd.subSize[i];
       t.loadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
@@ -2440,6 +2558,15 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   treeSumRanges(t.subSize, t.loadedPos, fd.numLoaded, J, tid, t.kRange);
   for (int c = tid; c < n; c += 256) {
     t.col[fd.solveList[c]] = c;
+  }
+  if (hasGen) { // w_g = r_g - J_g d, in place (each row by one thread; consumed by the rho loop, several barriers later)
+    for (int r = tid; r < fd.genRows; r += 256) {
+      float a = t.gRes[r];
+      for (int c = 0; c < n; ++c) {
+        a -= t.gJ[r * gst + c] * s.d0[c];
+      }
+      t.gRes[r] = a;
+    }
   }
   __syncthreads();
   // joint-parameter delta jd = transform * delta
@@ -2534,6 +2661,11 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
       if (pb.M > pb.rowsJoint) { // limit / model-parameter rows, residual r - J d (fusedSolveKernel phase J)
         a += paramRowsColumn(rig, pb, fd, t.th, s.d0, t.col, P, b, c, fd.solveList[c]).g;
       }
+      if (hasGen) {
+        for (int r = 0; r < fd.genRows; ++r) {
+          a += t.gJ[r * gst + c] * t.gRes[r];
+        }
+      }
       a -= lambda * s.d0[c];
     }
     rhoVec[size_t(b) * NP + c] = a;
@@ -2543,6 +2675,9 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
 size_t treeStateFloats(int J, int U) {
   return treeStateLayout(J, U).total;
 }
+size_t treeRefineLdsBytes(int J, int P, int U, int n, int genRows) {
+  return treeRefineLdsFloats(J, P, U, n, nullptr, nullptr, genRows) * sizeof(float);
+}
 
 hipError_t launchTreeRefine(
     const RigDev& rig,
@@ -2550,13 +2685,14 @@ hipError_t launchTreeRefine(
     const FusedDev& fd,
     const float* theta,
     const float* state,
+    const float* genState,
     const float* dvec,
     float* rhoVec,
     const int32_t* refState,
     float lambda,
     const float* lambdaPer,
     hipStream_t stream) {
-  const size_t lds = treeRefineLdsFloats(rig.J, rig.P, fd.U, fd.n, nullptr, nullptr) * sizeof(float);
+  const size_t lds = treeRefineLdsBytes(rig.J, rig.P, fd.U, fd.n, fd.genRows);
   if (lds > 160 * 1024 - 64) {
     return hipErrorInvalidValue;
   }
@@ -2568,7 +2704,7 @@ hipError_t launchTreeRefine(
     }
     attrBytes = lds;
   }
-  hipLaunchKernelGGL(treeRefineKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, state, dvec, rhoVec, refState, lambda, lambdaPer);
+  hipLaunchKernelGGL(treeRefineKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, state, genState, dvec, rhoVec, refState, lambda, lambdaPer);
   return hipGetLastError();
 }
 #endif

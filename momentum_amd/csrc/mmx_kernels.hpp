@@ -89,7 +89,9 @@ struct FusedParams {
 
 size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels, int GT = 0, int genRows = 0);
 // H = J^T J, g = J^T r from the tree moments for the explicit-Jacobian solver (mmx_fused.hip, treeNormalEquationsKernel)
-size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n);
+size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n, int GT = 0, int genRows = 0);
+size_t treeRefineLdsBytes(int J, int P, int U, int n, int genRows);
+size_t treeGenStateFloats(int n, int genRows); // per instance: J_g and its residual rows, handed from the tree normal equations to the tree refinement
 hipError_t launchTreeNormalEquations(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -101,6 +103,7 @@ hipError_t launchTreeNormalEquations(
     double* errOut, // [B] error at theta, or null
     float* state, // [B][treeStateFloats(J, U)] hand-over to launchTreeRefine, or null
     long long* clk, // profiling aid: eight per-phase cycle counters of block 0, or null
+    float* genState, // [B][treeGenStateFloats] (problems with further joint error functions / ellipsoid limits), or null
     bool tileMajor, // jtj as [tile (I,J) at I(I+1)/2 + J][col][row] (launchCholeskyFactorTiled reads that) instead of [n][n]
     hipStream_t stream);
 size_t treeStateFloats(int J, int U);
@@ -111,6 +114,7 @@ hipError_t launchTreeRefine(
     const FusedDev& fd,
     const float* theta,
     const float* state,
+    const float* genState,
     const float* dvec,
     float* rhoVec,
     const int32_t* refState,

@@ -146,3 +146,84 @@ def test_fused_solve_carries_blocks_and_ellipsoids(orc, which, monkeypatch):
             outs.append(th)
         monkeypatch.delenv("MMX_FUSED_GENERAL", raising=False)
         assert not np.array_equal(outs[0], outs[1])  # two different routes really ran (fp32 rounding differs)
+
+
+@pytest.mark.parametrize("route", ["tree", "dense"])
+def test_wide_solve_carries_blocks_and_ellipsoids(orc, route, monkeypatch):
+    """The 300-joint rig (wide path) with a half-plane block, an aim block, a fixed-axis block, ellipsoid limits and
+    parameter limits next to 160 position / orientation constraints: the tree kernels keep those rows as a dense block
+    J_g (tree normal equations: g, rank-k update of the tiles; tree refinement: r_g - J_g d), the dense route assembles
+    them into J (jointBlocksKernel)."""
+    import ctypes as C
+
+    import torch
+
+    from momentum_amd import capi, make_rig300
+    from tests.test_gpu_parity import _sensitivity
+
+    if route == "dense":
+        monkeypatch.setenv("MMX_TREE_NE", "0")
+        monkeypatch.setenv("MMX_TREE_REFINE", "0")
+    rig = make_rig300(seed=12345, unit=0.01)
+    rng = np.random.default_rng(83)
+    J, B = rig.num_joints, 3
+    pp = rng.choice(J, size=120, replace=False)
+    op = rng.choice(J, size=40, replace=False)
+    cons, th0, _ = make_problem(rig, pp, op, B, seed=97, perturb=0.2)
+    blocks = [
+        make_block(_abi.MMX_JC_HALF_PLANE, rng.choice(J, size=6), rng, weight=1.0, batch=B),
+        make_block(_abi.MMX_JC_AIM_DIST, rng.choice(J, size=1), rng, weight=0.5, batch=B),
+        make_block(_abi.MMX_JC_FIXED_AXIS_DIFF, rng.choice(J, size=1), rng, weight=0.5, batch=B, function_weight=0.7),
+    ]  # (15 rows with the ellipsoid limit: what fits next to this rig's 125 KB of tree tables in LDS; more rows take the dense route)
+    ells = []
+    for _ in range(1):
+        parent = int(rng.integers(1, J))
+        chain = [parent]
+        while rig.parent[chain[-1]] >= 0:
+            chain.append(int(rig.parent[chain[-1]]))
+        ep = int(rng.choice(chain[1:])) if len(chain) > 1 else 0
+        ells.append(EllipsoidLimit.make(parent, rng.uniform(-0.05, 0.05, 3), ep, rng.uniform(-0.1, 0.1, 3), rng.uniform(-90, 90, 3),
+                                        rng.uniform(0.05, 0.3, 3), float(rng.uniform(0.5, 4.0))))  # fmt: skip
+    limits = [ParameterLimit.minmax(3, -0.05, 0.05, 1.0), ParameterLimit.linear(4, 5, 1.0, 0.0, weight=0.5)]
+    wl = 25.0
+    full = orc.Constraints(cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset,
+                           cons.ori_target, cons.ori_weight, limits=limits, limit_function_weight=wl, joint_blocks=blocks,
+                           ellipsoid_limits=ells)  # fmt: skip
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, cons.pos_parent, cons.ori_parent)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+                       t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+                       limits=limits, limit_function_weight=wl, joint_blocks=[_device_block(torch, k, pb.device) for k in blocks],
+                       ellipsoid_limits=ells)  # fmt: skip
+    assert pb.M == full.rows
+    if route == "tree":  # the tree normal equations with J_g against the oracle's J^T J / J^T r (parity hook)
+        buf, nn = np.zeros(rig.num_params, np.int32), C.c_int32(0)
+        capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(nn), None))
+        lst = buf[: nn.value]
+        en = np.zeros(rig.num_params, np.uint8)
+        en[lst] = 1
+        pb.set_enabled(en)  # only structurally non-zero columns: the enabled system IS the solve-list system
+        theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
+        monkeypatch.setenv("MMX_TREE_NE", "force")
+        Ht, gt, _ = pb.normal_equations(torch.from_numpy(theta).to(pb.device))
+        monkeypatch.delenv("MMX_TREE_NE", raising=False)
+        Ht, gt = Ht.cpu().numpy(), gt.cpu().numpy()
+        for b in range(B):
+            Jm, r, e = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
+            Je = Jm[:, lst]
+            H, g = Je.T @ Je, Je.T @ r
+            assert np.abs(np.tril(Ht[b]) - np.tril(H)).max() <= 5e-5 * max(1.0, np.abs(H).max())
+            assert np.abs(gt[b] - g).max() <= 5e-5 * max(1.0, np.abs(g).max())
+        pb.set_enabled(np.ones(rig.num_params, np.uint8))
+    for opt in (
+        GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05),
+        GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=2),
+    ):
+        out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+        ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+        rel = np.linalg.norm(out["theta"].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+        tol = np.maximum(3e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
+        assert (rel <= tol).all(), (route, rel, tol)
+        assert (out["status"].cpu().numpy() == 0).all()
+        h = out["error_history"].cpu().numpy()
+        assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
