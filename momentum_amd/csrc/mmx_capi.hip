@@ -781,7 +781,7 @@ bool fusedUsable(const mmx_problem* pb) {
 }
 
 // H and g of the explicit-Jacobian solver from the tree moments instead of the dense J (treeNormalEquationsKernel):
-// position / orientation rows with batch-shared parents only, the same solve list on both sides
+// the same solve list on both sides, everything within the kernels' LDS
 bool treeNormalEquationsUsable(const mmx_problem* pb) {
   const char* e = getenv("MMX_TREE_NE");
   if (e != nullptr && e[0] == '0') {
@@ -789,7 +789,7 @@ bool treeNormalEquationsUsable(const mmx_problem* pb) {
   }
   // (limit / model-parameter rows ride along: evaluated on the fly from theta like in the fused solve; the further joint
   // error functions and ellipsoid limits as a dense block of rows in LDS while it fits)
-  return !pb->instPos && !pb->instOri && pb->U > 0 && pb->fdev.n > 0 && pb->fdev.n <= 512 && pb->fdev.nsrc < 4096 &&
+  return pb->U > 0 && pb->fdev.n > 0 && pb->fdev.n <= 512 && pb->fdev.nsrc < 4096 &&
       pb->fused.solveList == pb->solveListV1 &&
       mmx::treeNormalEquationsLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.GT, pb->fdev.genRows) <= 160 * 1024 - 64 &&
       mmx::treeRefineLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.n, pb->fdev.genRows) <= 160 * 1024 - 64;

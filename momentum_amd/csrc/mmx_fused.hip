@@ -707,6 +707,57 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
   }
 }
 
+// Per-instance constraint parents (mmx_problem_set_instance_parents): the tables that say which units hang on which
+// joint, built per element instead of copied from the batch-shared ones -- units sorted by (DFS position of their joint,
+// unit index) with a counting rank, so that the own sums add in the same deterministic order as in the shared case.
+// All four tables in LDS; returns the number of loaded positions (the same value in every thread); ends with a barrier.
+__device__ __forceinline__ int buildInstanceUnitTables(
+    const ProblemDev& pb, const FusedDev& fd, int b, int J, int U, int tid, int* unitPos, int* posUnitStart, int* posUnits, int* loadedPos) {
+  for (int u = tid; u < U; u += 256) {
+    int joint;
+    if (u < fd.Kp) {
+      joint = pb.instPosParent != nullptr ? pb.instPosParent[size_t(b) * fd.Kp + u] : fd.unitJoint[u];
+    } else {
+      const int co = (u - fd.Kp) / 3;
+      joint = pb.instOriParent != nullptr ? pb.instOriParent[size_t(b) * pb.Ko + co] : fd.unitJoint[u];
+    }
+    unitPos[u] = pb.jointTin[joint];
+  }
+  __syncthreads();
+  for (int k = tid; k <= J; k += 256) { // units on positions before k
+    int cnt = 0;
+    for (int u = 0; u < U; ++u) {
+      cnt += unitPos[u] < k ? 1 : 0;
+    }
+    posUnitStart[k] = cnt;
+  }
+  for (int u = tid; u < U; u += 256) {
+    const int pu = unitPos[u];
+    int rank = 0;
+    for (int v = 0; v < U; ++v) {
+      const int pv = unitPos[v];
+      rank += (pv < pu || (pv == pu && v < u)) ? 1 : 0;
+    }
+    posUnits[rank] = u;
+  }
+  __syncthreads();
+  for (int k = tid; k < J; k += 256) { // loaded positions, ascending
+    if (posUnitStart[k + 1] > posUnitStart[k]) {
+      int rank = 0;
+      for (int q = 0; q < k; ++q) {
+        rank += posUnitStart[q + 1] > posUnitStart[q] ? 1 : 0;
+      }
+      loadedPos[rank] = k;
+    }
+  }
+  int numLoaded = 0; // every thread computes the same value
+  for (int k = 0; k < J; ++k) {
+    numLoaded += posUnitStart[k + 1] > posUnitStart[k] ? 1 : 0;
+  }
+  __syncthreads();
+  return numLoaded;
+}
+
 // MODE 0: production; 1: also dump H / g of the first iteration (parity hook); 2: per-phase clocks
 // Workgroups per CU follow the LDS footprint (tiles: 1 KB each): three up to NB = 6, two up to NB = 8,
 // one beyond -- the register budget is set to match, so the wide systems do not spill.
@@ -879,47 +930,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   int numLoadedInst = fd.numLoaded;
   if (pb.instPosParent != nullptr || pb.instOriParent != nullptr) {
     __syncthreads();
-    for (int u = tid; u < U; u += 256) {
-      int joint;
-      if (u < fd.Kp) {
-        joint = pb.instPosParent != nullptr ? pb.instPosParent[size_t(b) * fd.Kp + u] : fd.unitJoint[u];
-      } else {
-        const int co = (u - fd.Kp) / 3;
-        joint = pb.instOriParent != nullptr ? pb.instOriParent[size_t(b) * pb.Ko + co] : fd.unitJoint[u];
-      }
-      lUnitJoint[u] = pb.jointTin[joint];
-    }
-    __syncthreads();
-    for (int k = tid; k <= J; k += 256) { // units on positions before k
-      int cnt = 0;
-      for (int u = 0; u < U; ++u) {
-        cnt += lUnitJoint[u] < k ? 1 : 0;
-      }
-      lPosUnitStart[k] = cnt;
-    }
-    for (int u = tid; u < U; u += 256) {
-      const int pu = lUnitJoint[u];
-      int rank = 0;
-      for (int v = 0; v < U; ++v) {
-        const int pv = lUnitJoint[v];
-        rank += (pv < pu || (pv == pu && v < u)) ? 1 : 0;
-      }
-      lPosUnits[rank] = u;
-    }
-    __syncthreads();
-    for (int k = tid; k < J; k += 256) { // loaded positions, ascending
-      if (lPosUnitStart[k + 1] > lPosUnitStart[k]) {
-        int rank = 0;
-        for (int q = 0; q < k; ++q) {
-          rank += lPosUnitStart[q + 1] > lPosUnitStart[q] ? 1 : 0;
-        }
-        lLoadedPos[rank] = k;
-      }
-    }
-    numLoadedInst = 0; // their number: every thread computes the same value
-    for (int k = 0; k < J; ++k) {
-      numLoadedInst += lPosUnitStart[k + 1] > lPosUnitStart[k] ? 1 : 0;
-    }
+    numLoadedInst = buildInstanceUnitTables(pb, fd, b, J, U, tid, lUnitJoint, lPosUnitStart, lPosUnits, lLoadedPos);
   }
   // parentPos[k] = DFS position of the parent of the joint at DFS position k (-1 for a root), built
   // through a joint -> position scratch map (alt is free until the first FK)
@@ -1996,14 +2007,19 @@ struct TreeNeExtraLds {
   int* col; // [P] parameter -> solve column or -1 (parameter-space rows)
   float* pdiag; // [NP] diagonal contributions of the parameter-space rows
   float *gEv, *gRes, *gJ; // rows of the further joint error functions / ellipsoid limits (fusedSolveKernel kGen)
+  int* unitPos; // [U] DFS position of each unit's joint (per-instance constraint parents)
 };
-__host__ __device__ inline size_t treeNeExtraLdsFloats(int P, int n, int GT, int genRows, TreeNeExtraLds* out, float* base) {
+__host__ __device__ inline size_t treeNeExtraLdsFloats(int P, int n, int GT, int genRows, int U, TreeNeExtraLds* out, float* base) {
   const size_t NP = (size_t(n) + 15) & ~size_t(15), rowsGp = (size_t(genRows) + 3) & ~size_t(3);
   const size_t oCol = 0, oPd = oCol + alignUp4(P), oGev = oPd + NP, oGres = oGev + alignUp4(size_t(kGenEv) * GT), oGj = oGres + rowsGp;
   if (out != nullptr) {
     out->col = reinterpret_cast<int*>(base + oCol), out->pdiag = base + oPd, out->gEv = base + oGev, out->gRes = base + oGres, out->gJ = base + oGj;
   }
-  return oGj + rowsGp * size_t(srcStrideFor(int(NP)));
+  const size_t oUp = oGj + rowsGp * size_t(srcStrideFor(int(NP)));
+  if (out != nullptr) {
+    out->unitPos = reinterpret_cast<int*>(base + oUp);
+  }
+  return oUp + alignUp4(U);
 }
 
 // kExtraRows: the instantiation for problems with parameter-space rows (limits, model prior) and / or further joint error
@@ -2035,7 +2051,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   const size_t baseFloats = treeNeLdsFloats(J, P, U, nsrc, &t, smem);
   TreeNeExtraLds x{};
   if (kExtraRows) {
-    treeNeExtraLdsFloats(P, n, fd.GT, fd.genRows, &x, smem + baseFloats);
+    treeNeExtraLdsFloats(P, n, fd.GT, fd.genRows, U, &x, smem + baseFloats);
   }
   const bool hasParamRows = kExtraRows && pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   const bool hasGen = kExtraRows && fd.GT > 0; // further joint error functions / ellipsoid limits: a dense block of rows J_g in LDS
@@ -2097,8 +2113,12 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     for (int c = tid; c < n; c += 256) {
       x.col[fd.solveList[c]] = c;
     }
+    if (pb.instPosParent != nullptr || pb.instOriParent != nullptr) { // per-instance constraint parents: this element's unit lists
+      fv.numLoaded = buildInstanceUnitTables(pb, fd, b, J, U, tid, x.unitPos, t.posUnitStart, t.posUnits, t.loadedPos);
+      fv.unitPos = x.unitPos;
+    }
   }
-  treeSumRanges(t.subSize, t.loadedPos, fd.numLoaded, J, tid, t.kRange); // (barriers follow before the first tree sum)
+  treeSumRanges(t.subSize, t.loadedPos, fv.numLoaded, J, tid, t.kRange); // (barriers follow before the first tree sum)
   MMX_TCLK(0)
   // ---- A, B: forward kinematics with rotation axes
   blockFk<true>(rv, s, s.th, tid, true);
@@ -2399,7 +2419,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
 }
 
 size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n, int GT, int genRows) {
-  return (treeNeLdsFloats(J, P, U, nsrc, nullptr, nullptr) + treeNeExtraLdsFloats(P, n, GT, genRows, nullptr, nullptr)) * sizeof(float);
+  return (treeNeLdsFloats(J, P, U, nsrc, nullptr, nullptr) + treeNeExtraLdsFloats(P, n, GT, genRows, U, nullptr, nullptr)) * sizeof(float);
 }
 size_t treeGenStateFloats(int n, int genRows) {
   const size_t rowsGp = (size_t(genRows) + 3) & ~size_t(3);
@@ -2424,7 +2444,7 @@ hipError_t launchTreeNormalEquations(
   if (lds > 160 * 1024 - 64) {
     return hipErrorInvalidValue;
   }
-  const bool extra = pb.M > pb.rowsJoint || fd.GT > 0;
+  const bool extra = pb.M > pb.rowsJoint || fd.GT > 0 || pb.instPosParent != nullptr || pb.instOriParent != nullptr;
   static size_t attrBytes[2] = {64 * 1024, 64 * 1024};
   if (lds > attrBytes[extra ? 1 : 0]) {
     hipError_t rc = hipFuncSetAttribute(
@@ -2451,7 +2471,7 @@ hipError_t launchTreeNormalEquations(
 // =============================================================================================
 struct TreeRefLds {
   float *js, *up, *ur, *us, *jd, *tanOwn, *tanPre, *own1, *sub1, *d0, *th, *gJ, *gRes;
-  int *col, *subSize, *loadedPos, *posUnitStart, *posUnits, *kRange;
+  int *col, *subSize, *loadedPos, *posUnitStart, *posUnits, *kRange, *unitPos;
 };
 __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n, TreeRefLds* out, float* base, int genRows = 0) {
   size_t off = 0;
@@ -2469,9 +2489,10 @@ __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n
   const size_t oD = take(NP), oCol = take(P), oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U);
   const size_t oKr = take(2 * ((size_t(J) + 15) / 16)), oTh = take(P);
   const size_t rowsGp = (size_t(genRows) + 3) & ~size_t(3);
-  const size_t oGj = take(rowsGp * size_t(srcStrideFor(int(NP)))), oGres = take(rowsGp);
+  const size_t oGj = take(rowsGp * size_t(srcStrideFor(int(NP)))), oGres = take(rowsGp), oUpos = take(U);
   if (out != nullptr) {
     out->gJ = base + oGj, out->gRes = base + oGres;
+    out->unitPos = reinterpret_cast<int*>(base + oUpos);
     out->kRange = reinterpret_cast<int*>(base + oKr);
     out->th = base + oTh;
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
@@ -2555,7 +2576,11 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     }
   }
   __syncthreads();
-  treeSumRanges(t.subSize, t.loadedPos, fd.numLoaded, J, tid, t.kRange);
+  if (pb.instPosParent != nullptr || pb.instOriParent != nullptr) { // per-instance constraint parents: this element's unit lists
+    fv.numLoaded = buildInstanceUnitTables(pb, fd, b, J, U, tid, t.unitPos, t.posUnitStart, t.posUnits, t.loadedPos);
+    fv.unitPos = t.unitPos;
+  }
+  treeSumRanges(t.subSize, t.loadedPos, fv.numLoaded, J, tid, t.kRange);
   for (int c = tid; c < n; c += 256) {
     t.col[fd.solveList[c]] = c;
   }

@@ -195,3 +195,31 @@ def test_per_instance_characters_on_the_wide_path(torch_cuda, orc):
     th0 = np.zeros((B, rig.num_params), np.float32)
     _check_solve(torch, orc, pb, rigs, cons, th0, parents, parents, GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05))
     _check_solve(torch, orc, pb, rigs, cons, th0, parents, parents, GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=2))
+
+
+@pytest.mark.parametrize("route", ["tree", "dense"])
+def test_per_instance_constraint_parents_on_the_wide_path(torch_cuda, orc, route, monkeypatch):
+    """Per-element constraint parents on a problem of 219 solved parameters (wide path): every element constrains its own
+    60 + 30 joints; the tree kernels build the element's units-per-joint lists in LDS like the fused solve does
+    (buildInstanceUnitTables), the dense route reads the per-element parents in the J assembly."""
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    if route == "dense":
+        monkeypatch.setenv("MMX_TREE_NE", "0")
+        monkeypatch.setenv("MMX_TREE_REFINE", "0")
+    rig = make_humanoid72(variant="p219", unit=UNIT)
+    J, B, Kp, Ko = rig.num_joints, 4, 60, 30
+    rng = np.random.default_rng(59)
+    pos_parents = [rng.choice(J, size=Kp, replace=True).astype(np.int32) for _ in range(B)]
+    ori_parents = [rng.choice(J, size=Ko, replace=True).astype(np.int32) for _ in range(B)]
+    conss = [make_problem(rig, pos_parents[b], ori_parents[b], 1, seed=400 + b, perturb=0.25, random_offsets=True, weights="random")[0] for b in range(B)]
+    cat = lambda f: np.concatenate([getattr(c, f) for c in conss], axis=0)
+    cons = orc.Constraints(pos_parents[0], cat("pos_offset"), cat("pos_target"), cat("pos_weight"), ori_parents[0], cat("ori_offset"), cat("ori_target"), cat("ori_weight"))
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, pos_parents[0], ori_parents[0])
+    _upload(torch, pb, cons, B)
+    pb.set_instance_parents(torch.from_numpy(np.stack(pos_parents)).to(pb.device), torch.from_numpy(np.stack(ori_parents)).to(pb.device))
+    rigs = [rig] * B
+    th0 = np.zeros((B, rig.num_params), np.float32)
+    _check_solve(torch, orc, pb, rigs, cons, th0, pos_parents, ori_parents, GnOptions.make(min_iterations=8, max_iterations=8, regularization=0.05), 2e-5)
+    _check_solve(torch, orc, pb, rigs, cons, th0, pos_parents, ori_parents, GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=2), 2e-5)
