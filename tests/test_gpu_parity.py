@@ -604,3 +604,10 @@ def test_wide_path_on_a_small_skeleton_with_many_units(torch_cuda, orc, pairs, m
         assert int((out["status"] != 0).sum()) == 0
         h = out["error_history"].cpu().numpy()
         assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
+    # iterationHistory_["parameters"] on this route: row i = the parameters after iteration i (the solve is deterministic)
+    opt = GnOptions.make(min_iterations=3, max_iterations=3, threshold=1.0, regularization=0.05)
+    out = db.pb.solve(db.theta0.clone(), opt, want_parameter_history=True)
+    hist = out["parameter_history"].cpu().numpy()
+    assert np.array_equal(hist[:, 2], out["theta"].cpu().numpy())
+    o2 = GnOptions.make(min_iterations=2, max_iterations=2, threshold=1.0, regularization=0.05)
+    assert np.array_equal(hist[:, 1], db.pb.solve(db.theta0.clone(), o2)["theta"].cpu().numpy())
