@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- character IK solves/sec on MI355X (BASELINE.json metric) + J-assembly HBM roofline.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--config cfg2|cfg2_all|cfg3|cfg5]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--config cfg2|cfg2_all|cfg3|cfg5|cfg2_tracker|...]
 
 One "step" = one pass of the hot path over one batch: a full batched solve (10 Gauss-Newton
 iterations: FK -> Jacobian/residual -> JtJ/Jtr -> Cholesky (+1 refinement) -> theta update) of
@@ -21,8 +21,8 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit/... pl
                     this box's host cores on a bounded sample of the SAME instances
   "configs":        (N = 1 only) every other BASELINE.json configuration that fits one GPU -- the north-star
                     target 65536 x 72 (cfg3, LM schedule), the weak-scaling shard 32768 x 72, the wide-J
-                    300-joint rig (cfg5), the batched driver's default line search -- each with its own
-                    solves/s, cpu_baseline and parity check
+                    300-joint rig (cfg5), the batched driver's default line search, a tracker-shaped problem (cfg2 +
+                    plane block + parameter limits) -- each with its own solves/s, cpu_baseline and parity check
 """
 from __future__ import annotations
 
