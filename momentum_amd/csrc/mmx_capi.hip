@@ -483,6 +483,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     fd.Kp = pb->Kp;
     fd.n = int32_t(f.solveList.size());
     fd.nsrc = int32_t(slots.size());
+    fd.slotBase = NPs;
     fd.nnz = rig->ptOuter.back();
     fd.subSize = pb->dSubSize.as<int32_t>();
     fd.dfsJoint = pb->dDfsJoint.as<int32_t>();
@@ -1946,7 +1947,7 @@ static int32_t solveImpl(
         MMX_ZONE("Get JtJ and JtR");
         MMX_HIP(mmx::launchTreeNormalEquations(
             pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, pb->sErr.as<double>(),
-            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, genState, true, s));
+            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, genState, getenv("MMX_TREE_ROWMAJOR") == nullptr, s));
       }
       MMX_ZONE("Dense gauss newton step");
       MMX_HIP(mmx::launchCholeskyFactorTiled(

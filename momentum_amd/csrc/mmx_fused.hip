@@ -2158,7 +2158,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
             const ColumnSourceDev cs = fd.srcs[e2];
             return GenSlot{cs.tin, cs.tout, cs.joint, cs.dof, cs.parent, cs.weight};
           },
-          [&](int c, int& e0, int& e1) { e0 = NP + fd.srcStart[c], e1 = NP + fd.srcStart[c + 1]; });
+          [&](int c, int& e0, int& e1) { e0 = fd.slotBase + fd.srcStart[c], e1 = fd.slotBase + fd.srcStart[c + 1]; });
     }
     if (errOut != nullptr && tid == 0) {
       errOut[b] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
@@ -2239,8 +2239,8 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   // ---- F: g
   for (int c = tid; c < n; c += 256) {
     float acc = srcG[c];
-    const int e1 = NP + fd.srcStart[c + 1];
-    for (int e = NP + fd.srcStart[c]; e < e1; ++e) {
+    const int e1 = fd.slotBase + fd.srcStart[c + 1];
+    for (int e = fd.slotBase + fd.srcStart[c]; e < e1; ++e) {
       acc += srcG[e];
     }
     if (hasParamRows) { // limit / model-parameter rows: evaluated on the fly from theta (fusedSolveKernel phase F)
@@ -2679,8 +2679,8 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
         return cs.weight * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
       };
       a = slotShare(c);
-      const int e1 = NP + fd.srcStart[c + 1];
-      for (int e = NP + fd.srcStart[c]; e < e1; ++e) {
+      const int e1 = fd.slotBase + fd.srcStart[c + 1];
+      for (int e = fd.slotBase + fd.srcStart[c]; e < e1; ++e) {
         a += slotShare(e);
       }
       if (pb.M > pb.rowsJoint) { // limit / model-parameter rows, residual r - J d (fusedSolveKernel phase J)

@@ -2981,7 +2981,9 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  if (pairs) {
+  if (pairs == 2) { // cross-check switch (MMX_TREE_ROWMAJOR=1): H as [n][n] rows, single-column factor
+    tiledFactor<false>(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
+  } else if (pairs) {
     tiledFactorPairs(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
   } else {
     tiledFactor<true>(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
@@ -3523,10 +3525,8 @@ hipError_t launchCholeskyStep(
     const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
     // rows of J per refinement chunk: 32 (every column contributes one full 128-byte line per chunk) while the
     // chunk's loads fit the prefetch registers, else 16
-    static const int chunkPref = [] {
-      const char* e = getenv("MMX_CHOL_CHUNK_ROWS");
-      return e != nullptr ? atoi(e) : 32;
-    }();
+    const char* ce = getenv("MMX_CHOL_CHUNK_ROWS");
+    const int chunkPref = ce != nullptr ? atoi(ce) : 32;
     const int chunkRows = chunkPref == 32 && size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
     lds = tiledLdsFloats(pb.n, chunkRows, nullptr, nullptr) * sizeof(float);
     if (lds > 64 * 1024) {
@@ -3583,10 +3583,8 @@ hipError_t launchCholeskyFactorTiled(
     return hipErrorInvalidValue;
   }
   const size_t lds = tiledLdsFloats(pb.n, 0, nullptr, nullptr) * sizeof(float);
-  static const int pairs = [] {
-    const char* e = getenv("MMX_CHOL_PAIRS");
-    return e != nullptr && e[0] == '0' ? 0 : 1;
-  }();
+  const char* pe = getenv("MMX_CHOL_PAIRS"); // (read per call: the tests switch it inside one process)
+  const int pairs = getenv("MMX_TREE_ROWMAJOR") != nullptr ? 2 : (pe != nullptr && pe[0] == '0' ? 0 : 1);
   hipLaunchKernelGGL(choleskyFactorTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp, pairs);
   return hipGetLastError();
 }

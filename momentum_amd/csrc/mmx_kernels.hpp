@@ -42,6 +42,7 @@ struct StepParams {
 // device view of mmx::FusedTables (mmx_host_tables.hpp)
 struct FusedDev {
   int32_t U, Kp, n, nsrc, nnz; // units, position constraints, solved parameters, column sources, CSR entries
+  int32_t slotBase; // first extra source slot = number of primary slots (16 x the fused instantiation's blocks when there is one, else n rounded up to 16)
   const int32_t* subSize; // [J] by DFS position
   const int32_t* dfsJoint; // [J] joint at DFS position k
   const int32_t* loadedPos; // [numLoaded] DFS positions of the joints that carry constraint units, ascending
