@@ -243,3 +243,76 @@ def test_random_wide_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     assert np.all(th[:, en == 0] == th0[:, en == 0])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MMX_FUZZ_WIDE_SEEDS", "32")) // 2))
+def test_random_wide_rig_with_extra_rows(torch_cuda, orc, seed):
+    """The wide path's generalisations on random trees: parameter limits (every seed), the model-parameter prior (every
+    second), a plane block of a few rows (two of three), per-element constraint parents (every fourth) -- the tree kernels'
+    extra-rows instantiation against the oracle."""
+    from momentum_amd import _abi, capi
+    from tests.test_oracle_joint_blocks import make_block
+
+    torch = torch_cuda
+    rng = np.random.default_rng(11000 + seed)
+    J = int(rng.integers(100, 160))
+    rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
+    P = rig.num_params
+    Kp, Ko = int(rng.integers(20, 60)), int(rng.integers(4, 20))
+    B = 3
+    inst = seed % 4 == 3
+    pos_parents = [rng.integers(0, J, size=Kp).astype(np.int32) for _ in range(B if inst else 1)]
+    ori_parents = [rng.integers(0, J, size=Ko).astype(np.int32) for _ in range(B if inst else 1)]
+    if inst:
+        conss = [make_problem(rig, pos_parents[b], ori_parents[b], 1, seed=seed * 7 + b, perturb=0.2, random_offsets=True, weights="random") for b in range(B)]
+        cat = lambda f: np.concatenate([getattr(c[0], f) for c in conss], axis=0)
+        th0 = np.concatenate([c[1] for c in conss], axis=0)
+        base = dict(pos_offset=cat("pos_offset"), pos_target=cat("pos_target"), pos_weight=cat("pos_weight"),
+                    ori_offset=cat("ori_offset"), ori_target=cat("ori_target"), ori_weight=cat("ori_weight"))
+    else:
+        c0, th0, _ = make_problem(rig, pos_parents[0], ori_parents[0], B, seed=seed, perturb=0.2, random_offsets=True, weights="random")
+        base = dict(pos_offset=c0.pos_offset, pos_target=c0.pos_target, pos_weight=c0.pos_weight,
+                    ori_offset=c0.ori_offset, ori_target=c0.ori_target, ori_weight=c0.ori_weight)
+    a, b2 = rng.choice(P, size=2, replace=False)
+    limits = [ParameterLimit.minmax(int(a), -0.05, 0.05, 1.5), ParameterLimit.linear(int(a), int(b2), 0.7, 0.02)]
+    rows = [r for r in range(7 * J) if rig.pt_outer[r + 1] - rig.pt_outer[r] in (1, 2)]
+    r0 = int(rng.choice(rows))
+    limits.append(ParameterLimit.minmax_joint(r0 // 7, r0 % 7, -0.02, 0.03, 1.0))
+    mt = mw = None
+    if seed % 2 == 0:
+        mt = rng.uniform(-0.2, 0.2, size=(B, P)).astype(np.float32)
+        mw = rng.uniform(-0.3, 1.0, size=(B, P)).astype(np.float32)
+    blocks = [make_block(_abi.MMX_JC_PLANE, rng.integers(0, J, size=int(rng.integers(2, 6))), rng, weight=1.0, batch=B)] if seed % 3 != 2 else []
+
+    def constraints(b=None):
+        s = (lambda x: x) if b is None else (lambda x: x[b])
+        return orc.Constraints(pos_parents[0 if b is None or not inst else b], s(base["pos_offset"]), s(base["pos_target"]), s(base["pos_weight"]),
+                               ori_parents[0 if b is None or not inst else b], s(base["ori_offset"]), s(base["ori_target"]), s(base["ori_weight"]),
+                               limits=limits, limit_function_weight=0.5, model_target=None if mt is None else s(mt), model_weights=None if mw is None else s(mw),
+                               model_function_weight=0.8, joint_blocks=blocks if b is None else [k.instance(b) for k in blocks])  # fmt: skip
+
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, pos_parents[0], ori_parents[0])
+    t = lambda x, shp: torch.from_numpy(np.ascontiguousarray(x, np.float32).reshape(shp)).to(pb.device)
+    gb = [_abi.JointBlock(k.type, k.parent, t(k.weight, (B, k.count)), t(k.global_, (B, k.count, 3)), t(k.local_point, (B, k.count, 3)), None,
+                          t(k.plane_d, (B, k.count)), k.function_weight, k.loss) for k in blocks]  # fmt: skip
+    pb.set_constraints(t(base["pos_offset"], (B, Kp, 3)), t(base["pos_target"], (B, Kp, 3)), t(base["pos_weight"], (B, Kp)),
+                       t(base["ori_offset"], (B, Ko, 4)), t(base["ori_target"], (B, Ko, 4)), t(base["ori_weight"], (B, Ko)),
+                       limits=limits, limit_function_weight=0.5, model_target=None if mt is None else t(mt, (B, P)),
+                       model_weights=None if mw is None else t(mw, (B, P)), model_function_weight=0.8, joint_blocks=gb or None)  # fmt: skip
+    if inst:
+        pb.set_instance_parents(np.stack(pos_parents), np.stack(ori_parents))
+    opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.5, do_line_search=2 if seed % 5 == 4 else 0)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    th = out["theta"].cpu().numpy()
+    for b in range(B):
+        cb = constraints(b)
+        ref = orc.solve(rig, cb, th0[b], opt, dtype="f64")
+        r32 = orc.solve(rig, cb, th0[b], opt, dtype="f32")
+        den = max(np.linalg.norm(ref["theta"]), 1e-3)
+        rel = np.linalg.norm(th[b] - ref["theta"]) / den
+        tol = max(2e-5, 3.0 * np.linalg.norm(r32["theta"] - ref["theta"]) / den)
+        assert rel <= tol, (seed, b, J, P, rel, tol)
+        assert int(out["iterations"][b]) == ref["iterations"] and int(out["status"][b]) == ref["status"]
+        href = np.asarray(ref["error_history"])
+        h = out["error_history"][b].cpu().numpy()[: len(href)]
+        assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
