@@ -67,7 +67,7 @@ def random_rig(rng, J, shape):
     return rig
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MMX_FUZZ_SEEDS", "48"))))
 def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
     from momentum_amd import capi
 
@@ -75,7 +75,7 @@ def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
     if seed % 4 == 3:
         monkeypatch.setenv("MMX_SOLVER", "v1")  # every fourth rig through the three-kernel path
     rng = np.random.default_rng(1000 + seed)
-    J = int(rng.integers(2, 48))
+    J = int(rng.integers(2, int(os.environ.get("MMX_FUZZ_JMAX", "48"))))  # (MMX_FUZZ_JMAX=100: the mid-size instantiations and the route switch)
     rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
     P = rig.num_params
     Kp, Ko = int(rng.integers(0, 9)), int(rng.integers(0, 6))
@@ -119,7 +119,8 @@ def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
         assert np.abs(res[b] - ro).max() <= 3e-5 * max(1.0, np.abs(ro).max())
         assert abs(err[b] - eo) <= 3e-5 * max(1.0, eo)
     # a short, well regularised solve (lambda = 0.5 keeps even the degenerate random rigs conditioned)
-    opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.5)
+    # (every fifth rig with a line search: the trial evaluation hands its joint states to the next iteration)
+    opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.5, do_line_search=(1 + seed % 2) if seed % 5 == 4 else 0)
     out = pb.solve(torch.from_numpy(th0.copy()).to(dev), opt, want_history=True)
     ref = orc.solve_batch(rig, full, th0, opt, enabled=en, dtype="f64")
     th = out["theta"].cpu().numpy()
@@ -133,7 +134,7 @@ def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
     assert np.all(th[:, en == 0] == th0[:, en == 0])  # disabled parameters are never touched
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MMX_FUZZ_SEEDS", "48")) // 3))
 def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
     """The same random rigs with the further joint error functions and Ellipsoid limits: exercises the
     host tables (flattened constraint lists, DFS indices, the stop index of the ellipsoid walk, the compacted
@@ -145,7 +146,7 @@ def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
 
     torch = torch_cuda
     rng = np.random.default_rng(5000 + seed)
-    J = int(rng.integers(2, 40))
+    J = int(rng.integers(2, int(os.environ.get("MMX_FUZZ_JMAX", "40"))))
     rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
     P = rig.num_params
     Kp = int(rng.integers(0, 5))
