@@ -1930,6 +1930,8 @@ static int32_t solveImpl(
   const size_t NPs = (size_t(n) + 15) & ~size_t(15);
   float* genState = nullptr; // J_g of the further joint error functions / ellipsoid limits, tree kernels' hand-over
   if (treeRefine) {
+    // (H travels tile-major on this route: NB (NB + 1) / 2 tiles of 256 floats, more than n^2 for small systems)
+    MMX_HIP(pb->sJtj.ensure(std::max(size_t(B) * size_t(pb->dev.n) * size_t(pb->dev.n), size_t(B) * mmx::choleskyFactorFloats(ds.n)) * sizeof(float)));
     MMX_HIP(pb->sTreeState.ensure(size_t(B) * mmx::treeStateFloats(pb->rig->J, pb->fdev.U) * sizeof(float)));
     MMX_HIP(pb->sDvec.ensure(size_t(B) * NPs * sizeof(float)));
     MMX_HIP(pb->sRhoVec.ensure(size_t(B) * NPs * sizeof(float)));
