@@ -317,3 +317,37 @@ def test_random_wide_rig_with_extra_rows(torch_cuda, orc, seed):
         href = np.asarray(ref["error_history"])
         h = out["error_history"][b].cpu().numpy()[: len(href)]
         assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MMX_FUZZ_SEEDS", "48")) // 3))
+def test_random_rig_double_solve_matches_oracle(torch_cuda, orc, seed):
+    """mmx_solve_f64 on the random rigs (shared parameters, translation / scale dofs, transform offsets, enabled masks,
+    every third with a line search): the oracle's double instantiation at 1e-8 (both run the same algorithm in the
+    same precision; lambda = 0.5 keeps the degenerate rigs conditioned)."""
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    rng = np.random.default_rng(13000 + seed)
+    J = int(rng.integers(2, int(os.environ.get("MMX_FUZZ_JMAX", "48"))))
+    rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
+    P = rig.num_params
+    Kp, Ko = int(rng.integers(1, 9)), int(rng.integers(0, 6))
+    pp = rng.integers(0, J, size=Kp).astype(np.int32)
+    op = rng.integers(0, J, size=Ko).astype(np.int32)
+    B = 3
+    cons, th0, _ = make_problem(rig, pp, op, B, seed=seed, perturb=0.25, random_offsets=True, weights="random")
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, pp, op)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(t(cons.pos_offset, (B, Kp, 3)), t(cons.pos_target, (B, Kp, 3)), t(cons.pos_weight, (B, Kp)),
+                       t(cons.ori_offset, (B, Ko, 4)), t(cons.ori_target, (B, Ko, 4)), t(cons.ori_weight, (B, Ko)))  # fmt: skip
+    en = (rng.uniform(size=P) < 0.85).astype(np.uint8)
+    en[:3] = 1
+    pb.set_enabled(en)
+    opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.5, do_line_search=(1 + seed % 2) if seed % 3 == 2 else 0)
+    out = pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, enabled=en, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
+    assert np.all(rel <= 1e-8), (seed, J, P, rel)
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]) and np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.all(th[:, en == 0] == th0[:, en == 0].astype(np.float64))
