@@ -302,13 +302,19 @@ def test_random_wide_rig_with_extra_rows(torch_cuda, orc, seed):
                        model_weights=None if mw is None else t(mw, (B, P)), model_function_weight=0.8, joint_blocks=gb or None)  # fmt: skip
     if inst:
         pb.set_instance_parents(np.stack(pos_parents), np.stack(ori_parents))
+    rigs = [rig] * B
+    if seed % 4 == 1:  # per-element rig constants (bone lengths, pre-rotations) on top
+        from tests.test_gpu_per_instance import _variants
+
+        off, pre, rigs = _variants(rig, B, rng, scale=0.1)
+        pb.set_instance_rig(off, pre)
     opt = GnOptions.make(min_iterations=5, max_iterations=5, regularization=0.5, do_line_search=2 if seed % 5 == 4 else 0)
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     th = out["theta"].cpu().numpy()
     for b in range(B):
         cb = constraints(b)
-        ref = orc.solve(rig, cb, th0[b], opt, dtype="f64")
-        r32 = orc.solve(rig, cb, th0[b], opt, dtype="f32")
+        ref = orc.solve(rigs[b], cb, th0[b], opt, dtype="f64")
+        r32 = orc.solve(rigs[b], cb, th0[b], opt, dtype="f32")
         den = max(np.linalg.norm(ref["theta"]), 1e-3)
         rel = np.linalg.norm(th[b] - ref["theta"]) / den
         tol = max(2e-5, 3.0 * np.linalg.norm(r32["theta"] - ref["theta"]) / den)
