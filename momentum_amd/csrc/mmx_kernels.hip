@@ -3583,6 +3583,12 @@ hipError_t launchCholeskyFactorTiled(
     return hipErrorInvalidValue;
   }
   const size_t lds = tiledLdsFloats(pb.n, 0, nullptr, nullptr) * sizeof(float);
+  if (lds > 64 * 1024) { // two panels of a 450-512-parameter system: beyond the default dynamic LDS limit
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(choleskyFactorTiledKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+  }
   const char* pe = getenv("MMX_CHOL_PAIRS"); // (read per call: the tests switch it inside one process)
   const int pairs = getenv("MMX_TREE_ROWMAJOR") != nullptr ? 2 : (pe != nullptr && pe[0] == '0' ? 0 : 1);
   hipLaunchKernelGGL(choleskyFactorTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp, pairs);

@@ -16,5 +16,5 @@ run() { # tag, env..., -- pytest args
 run fuzz_small MMX_FUZZ_SEEDS=300 -- tests/test_gpu_fuzz.py -k "not wide"
 run fuzz_mid MMX_FUZZ_SEEDS=300 MMX_FUZZ_JMAX=110 -- tests/test_gpu_fuzz.py -k "not wide"
 run fuzz_mid_forced_wide MMX_FORCE_WIDE=1 MMX_FUZZ_SEEDS=300 MMX_FUZZ_JMAX=110 -- tests/test_gpu_fuzz.py -k "not wide"
-run fuzz_wide MMX_FUZZ_WIDE_SEEDS=128 -- tests/test_gpu_fuzz.py -k "wide"
+run fuzz_wide MMX_FUZZ_WIDE_SEEDS=128 MMX_FUZZ_WIDE_JMAX=195 -- tests/test_gpu_fuzz.py -k "wide"
 run suite_forced_wide MMX_FORCE_WIDE=1 -- tests -m gpu
