@@ -2445,15 +2445,13 @@ hipError_t launchTreeNormalEquations(
     return hipErrorInvalidValue;
   }
   const bool extra = pb.M > pb.rowsJoint || fd.GT > 0 || pb.instPosParent != nullptr || pb.instOriParent != nullptr;
-  static size_t attrBytes[2] = {64 * 1024, 64 * 1024};
-  if (lds > attrBytes[extra ? 1 : 0]) {
-    hipError_t rc = hipFuncSetAttribute(
-        extra ? reinterpret_cast<const void*>(treeNormalEquationsKernel<true>) : reinterpret_cast<const void*>(treeNormalEquationsKernel<false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  static LdsLimitCache ldsLimit[2];
+  {
+    hipError_t rc = ldsLimit[extra ? 1 : 0].ensure(
+        extra ? reinterpret_cast<const void*>(treeNormalEquationsKernel<true>) : reinterpret_cast<const void*>(treeNormalEquationsKernel<false>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
-    attrBytes[extra ? 1 : 0] = lds;
   }
   if (extra) {
     hipLaunchKernelGGL(treeNormalEquationsKernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
@@ -2721,13 +2719,12 @@ hipError_t launchTreeRefine(
   if (lds > 160 * 1024 - 64) {
     return hipErrorInvalidValue;
   }
-  static size_t attrBytes = 64 * 1024;
-  if (lds > attrBytes) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(treeRefineKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  static LdsLimitCache ldsLimit;
+  {
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(treeRefineKernel), lds);
     if (rc != hipSuccess) {
       return rc;
     }
-    attrBytes = lds;
   }
   hipLaunchKernelGGL(treeRefineKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, state, genState, dvec, rhoVec, refState, lambda, lambdaPer);
   return hipGetLastError();
@@ -2769,14 +2766,12 @@ static hipError_t launchFusedMode(
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }
-  static size_t attrBytes = 64 * 1024; // default dynamic-LDS limit; raised on demand
-  if (lds > attrBytes) {
-    hipError_t rc = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  static LdsLimitCache ldsLimit; // (one per instantiation)
+  {
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
-    attrBytes = lds;
   }
   hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
   return hipGetLastError();

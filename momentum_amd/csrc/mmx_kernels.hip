@@ -3456,14 +3456,12 @@ hipError_t launchNormalEquations(
     const int NB = (pb.n + 15) >> 4, T = NB * (NB + 1) / 2;
 #define MMX_NE_LAUNCH_V(TPW_, V_)                                                                                       \
   do {                                                                                                                  \
-    static bool attr = false;                                                                                           \
-    if (!attr && lds > 64 * 1024) {                                                                                     \
-      hipError_t rc = hipFuncSetAttribute(                                                                              \
-          reinterpret_cast<const void*>(normalEquationsMfmaKernel<TPW_, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
+    static LdsLimitCache ldsLimit;                                                                                      \
+    if (lds > 64 * 1024) {                                                                                              \
+      hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(normalEquationsMfmaKernel<TPW_, V_>), 160 * 1024 - 64); \
       if (rc != hipSuccess) {                                                                                           \
         return rc;                                                                                                      \
       }                                                                                                                 \
-      attr = true;                                                                                                      \
     }                                                                                                                   \
     hipLaunchKernelGGL((normalEquationsMfmaKernel<TPW_, V_>), dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, done, lowerOnly ? 0 : 1); \
   } while (0)

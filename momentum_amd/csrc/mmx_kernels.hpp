@@ -1,6 +1,8 @@
 // mmx_kernels.hpp -- host-visible launch interface of mmx_kernels.hip.
 #pragma once
 
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -19,6 +21,34 @@ struct SolveStateDev {
   double* finalError; // [B] error_ (what solve() returns)
   double* errorHistory; // [B][maxIterations] or null
   float* paramHistory; // [B][maxIterations][P] or null: the parameters after iteration i (iterationHistory_["parameters"], solver.cpp:101-106)
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: the largest value requested so far is
+// remembered per device (one process may drive several GPUs from several threads: BatchedMultiGpuSolver), so that the
+// attribute is set once per (kernel, device, size class) and not once per launch.
+struct LdsLimitCache {
+  std::atomic<size_t> bytes[64];
+  LdsLimitCache() {
+    for (auto& b : bytes) {
+      b.store(64 * 1024); // default dynamic-LDS limit
+    }
+  }
+  hipError_t ensure(const void* kernel, size_t lds) {
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    std::atomic<size_t>& slot = bytes[dev & 63];
+    if (lds > slot.load(std::memory_order_relaxed)) {
+      rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (rc != hipSuccess) {
+        return rc;
+      }
+      slot.store(lds, std::memory_order_relaxed);
+    }
+    return hipSuccess;
+  }
 };
 
 struct StepParams {
