@@ -191,6 +191,12 @@ struct GaussNewtonSolverQROptions : GaussNewtonSolverBaseOptions {
   GaussNewtonSolverQROptions() = default;
   /* implicit */ GaussNewtonSolverQROptions(const SolverOptions& base) : GaussNewtonSolverBaseOptions(base) {}
 };
+// trust_region_qr.h:22-33: the third solver the batched driver builds (tensor_ik.cpp:150-152)
+struct TrustRegionQROptions : SolverOptions {
+  float trustRegionRadius_ = 1.0f;
+  TrustRegionQROptions() = default;
+  /* implicit */ TrustRegionQROptions(const SolverOptions& base) : SolverOptions(base) {}
+};
 
 // Device-resident Skeleton + ParameterTransform.
 class DeviceCharacter {
@@ -635,6 +641,7 @@ class BatchedGaussNewtonSolver {
       opt_.regularization = d->regularization;
       opt_.do_line_search = d->doLineSearch ? lineSearchRule() : MMX_LINE_SEARCH_NONE;
     }
+    applyDerivedOptions(options, opt_);
   }
   void setEnabledParameters(const ParameterSet& ps) {
     fn_->setEnabledParameters(ps);
@@ -677,6 +684,7 @@ class BatchedGaussNewtonSolver {
   virtual int32_t lineSearchRule() const { // gauss_newton_solver.cpp:283-313
     return MMX_LINE_SEARCH_GAUSS_NEWTON;
   }
+  virtual void applyDerivedOptions(const SolverOptions&, mmx_gn_options&) const {}
 
  private:
   BatchedSkeletonSolverFunction* fn_; // raw pointer like SolverT::solverFunction_ (solver.h:106)
@@ -708,6 +716,30 @@ class BatchedGaussNewtonSolverQR : public BatchedSubsetGaussNewtonSolver {
   using BatchedSubsetGaussNewtonSolver::BatchedSubsetGaussNewtonSolver;
   std::string getName() const override {
     return "GaussNewtonQR";
+  }
+};
+
+// TrustRegionQRT<float> for every element of the batch (trust_region_qr.cpp:52-270): the step rule
+// MMX_STEP_TRUST_REGION of the fused solve -- radius, up to ten trust steps per iteration, Newton updates of the
+// damping, gain-ratio radius update.  Position / orientation constraints, limits and the model prior;
+// problems beyond the fused solve throw (MMX_ERR_UNSUPPORTED).
+class BatchedTrustRegionQR : public BatchedGaussNewtonSolver {
+ public:
+  BatchedTrustRegionQR(const SolverOptions& options, BatchedSkeletonSolverFunction* function)
+      : BatchedGaussNewtonSolver(SolverOptions(options), function) {
+    setOptions(options); // the base constructor ran without this class's hook
+  }
+  std::string getName() const override {
+    return "TrustRegionQR";
+  }
+
+ protected:
+  void applyDerivedOptions(const SolverOptions& options, mmx_gn_options& o) const override {
+    o.step_rule = MMX_STEP_TRUST_REGION;
+    o.do_line_search = MMX_LINE_SEARCH_NONE;
+    if (const auto* d = dynamic_cast<const TrustRegionQROptions*>(&options)) {
+      o.trust_region_radius = d->trustRegionRadius_;
+    }
   }
 };
 

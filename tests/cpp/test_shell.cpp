@@ -175,6 +175,43 @@ int main() {
       ++bad;
     }
   }
+  // the third one: TrustRegionQR (same function: position constraints + limits + prior).  What the step rule computes
+  // is pinned against the oracle in tests/test_gpu_trust_region.py; here: the class selects it (a result that is not
+  // Gauss-Newton's, every element far down from the start) and trustRegionRadius_ reaches the kernel (three iterations
+  // of radius 0.05 from the rest pose cannot get as far as three of radius 1)
+  {
+    GaussNewtonSolverOptions go(opt);
+    go.minIterations = go.maxIterations = 20;
+    BatchedGaussNewtonSolver gn(go, &fn);
+    TrustRegionQROptions to(go);
+    to.trustRegionRadius_ = 1.0f;
+    BatchedTrustRegionQR tr(to, &fn);
+    std::vector<float> ta(B * P, 0.f), tb(B * P, 0.f);
+    std::vector<double> es;
+    fn.getJacobian(ta, jac, res, es);
+    const std::vector<double> eg = gn.solve(ta), et = tr.solve(tb);
+    std::printf("%s: error %.4g -> %.3g (GaussNewton %.3g)\n", tr.getName().c_str(), es[0], et[0], eg[0]);
+    bool differs = false;
+    for (size_t b = 0; b < B; ++b) {
+      if (!(et[b] < 0.1 * es[b]) || tr.getStatus()[b] != 0) {
+        std::printf("  instance %zu: %.4g vs %.4g (start %.4g), status %d\n", b, et[b], eg[b], es[b], tr.getStatus()[b]);
+        ++bad;
+      }
+      differs = differs || et[b] != eg[b];
+    }
+    TrustRegionQROptions small(to), wide(to);
+    small.minIterations = small.maxIterations = wide.minIterations = wide.maxIterations = 3;
+    small.trustRegionRadius_ = 0.05f;
+    std::vector<float> tc(B * P, 0.f), td(B * P, 0.f);
+    tr.setOptions(small);
+    const std::vector<double> e_small = tr.solve(tc);
+    tr.setOptions(wide);
+    const std::vector<double> e_wide = tr.solve(td);
+    std::printf("  three iterations: radius 0.05 %.4g, radius 1 %.4g\n", e_small[0], e_wide[0]);
+    if (!differs || !(e_small[0] > e_wide[0]) || tr.getName() != "TrustRegionQR") {
+      ++bad;
+    }
+  }
   std::printf(bad == 0 ? "OK\n" : "FAIL\n");
   return bad == 0 ? 0 : 1;
 }
