@@ -1,0 +1,27 @@
+#!/bin/bash
+# Explicit-inverse experiment (MMX_BUILD_VARIANT=inverse): headline bench of the variant against the default library on one
+# box (each run carries its own parity check against the CPU oracle), then the variant's phase clocks.
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+run() { # tag lib extra bench args...
+  tag=$1; lib=$2; shift 2
+  MMX_LIB=$GRAFT_REPO_ROOT/momentum_amd/$lib timeout 60 python bench.py --steps 30 --warmup 5 --no-extra-configs --no-cpu-baseline --check-instances 256 "$@" < /dev/null > gpurun_out/inv_$tag.json 2> gpurun_out/inv_$tag.err
+  python - "$tag" "gpurun_out/inv_$tag.json" < /dev/null <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[2]))
+    print("%-14s value %.4g solves/s  ms/step %.3f  parity max %.3g  failed %s" % (sys.argv[1], d["value"], d["ms_per_step"], d["check"].get("max_rel_theta_vs_oracle_f64",-1), d["check"]["failed_instances"]))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+}
+run inverse_1 libmmx_hip_inverse.so
+run main_1 libmmx_hip.so
+if [ -n "$INV_MORE" ]; then
+  run inverse_2 libmmx_hip_inverse.so
+  run inverse_ls libmmx_hip_inverse.so --line-search 2
+  run main_ls libmmx_hip.so --line-search 2
+  MMX_LIB=$GRAFT_REPO_ROOT/momentum_amd/libmmx_hip_inverse.so timeout 60 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q < /dev/null 2>&1 | grep -E "passed|failed|^FAILED|Error" | cut -c1-200 | tail -4
+fi
+bash scripts/gpu_clocks.sh invclk inverse 2>&1 | grep -E "total|H cholesky|I solve|J solve|H.bc|H.b chain|H.d"
