@@ -958,6 +958,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     long long* __restrict__ dbgClk) { // [32] or null: per-phase cycle counts of block 0 (profiling aid)
   constexpr int T = NB * (NB + 1) / 2; // lower-triangle tiles
   constexpr int NP = 16 * NB; // padded system size
+#ifdef MMX_EXP_LOOKAHEAD
+  // experiment: the left-looking updates of block column k + 1 by the columns before k ride under panel k's elimination
+  // chain (waves without a panel row); NB <= 8: wave 3 never holds one
+  constexpr bool kLook = NB <= 8;
+#else
+  constexpr bool kLook = false;
+#endif
 #ifdef MMX_EXP_INVERSE
   constexpr bool kInv = !kTR && NB <= 8; // experiment: solves through an explicit L^-1 (invertFactorTiles)
 #else
@@ -1545,6 +1552,45 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     for (int k = 0; k < NB; ++k) {
       // (u) bring block column k up to date: tile(I,k) -= sum_{j<k} L(I,j) L(k,j)^T.  A tile is
       //     read once, takes all its 4 k MFMAs (two accumulators: even / odd j) and is written once.
+#ifdef MMX_EXP_LOOKAHEAD
+      // tile (I, kc) -= sum_{j0 <= j < j1} L(I,j) L(kc,j)^T
+      auto updateTile = [&](int I, int kc, int j0, int j1) {
+        float* Tc = s.L + 256 * tileIndex(I, kc);
+        v4f c0, c1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c0[r] = Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)];
+        }
+        for (int j = j0; j < j1; ++j) {
+          const float4 av = ldsRow4(s.L + 256 * tileIndex(I, j), lane & 15, lane >> 4);
+          const float4 bv = ldsRow4(s.L + 256 * tileIndex(kc, j), lane & 15, lane >> 4);
+          if (j & 1) {
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c1, 0, 0, 0);
+          } else {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c0, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)] = c0[r] + c1[r];
+        }
+      };
+      if (k > 0) {
+        // (lookahead experiment: the contributions of the block columns before k - 1 were taken during panel k - 1 by the
+        // waves that had no panel row, see below -- only column k - 1's is left)
+        const int jFirst = (kLook && k >= 2) ? k - 1 : 0;
+        for (int I = k + wave; I < NB; I += 4) {
+          updateTile(I, k, jFirst, k);
+        }
+        __syncthreads();
+      }
+#else
       if (k > 0) {
         for (int I = k + wave; I < NB; I += 4) {
           float* Tc = s.L + 256 * tileIndex(I, k);
@@ -1575,6 +1621,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         }
         __syncthreads();
       }
+#endif
       MMX_CLK(14)
       // (b+c) panel factorisation: every wave holds the 16 rows of the diagonal block in lanes
       //     0..15 (redundantly) and 48 rows of the panel below it in lanes 16..63, one row of 16
@@ -1614,6 +1661,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           }
         }
         MMX_CLK(22)
+#ifdef MMX_EXP_LOOKAHEAD
+        if (kLook && !waveWorks && k >= 1 && k + 1 < NB) {
+          // lookahead: the waves without a panel row bring block column k + 1 up to date with the finished columns
+          // j < k while the others run the elimination chain (disjoint tiles: column k is the chain's)
+          const int firstIdle = (NP - 16 * k + 47) / 48; // waves 0 .. firstIdle - 1 hold the virtual rows
+          for (int I = k + 1 + (wave - firstIdle); I < NB; I += 4 - firstIdle) {
+            updateTile(I, k + 1, 0, k);
+          }
+        }
+#endif
         float invd = 0.f;
         bool bad = false;
         if (waveWorks) {
