@@ -965,6 +965,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
 #else
   constexpr bool kLook = false;
 #endif
+#ifdef MMX_EXP_MFMAPANEL
+  constexpr bool kMp = NB <= 8; // experiment: panel rows beyond wave 0's by a matrix-core product with L_kk^-T
+#endif
 #ifdef MMX_EXP_INVERSE
   constexpr bool kInv = !kTR && NB <= 8; // experiment: solves through an explicit L^-1 (invertFactorTiles)
 #else
@@ -1639,7 +1642,14 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         const int prow = 16 * k + vrow; // = 16 (k + 1) + (vrow - 16)
         const bool panelLane = !diagLane && !identLane && prow < NP;
         // waves whose 48 virtual rows all lie beyond the matrix only wait (wave-uniform branch)
+#ifdef MMX_EXP_MFMAPANEL
+        // experiment: only wave 0 runs the elimination chain (the diagonal block, the identity rows and the first 32 panel
+        // rows); the block rows from k + 3 on are multiplied by L_kk^-T on the matrix cores afterwards (below) -- six
+        // wave-chains of ~580 VALU instructions per iteration instead of nine at cfg2
+        const bool waveWorks = kMp ? wave == 0 : (wave == 0 || 16 * k + 48 * wave < NP);
+#else
         const bool waveWorks = wave == 0 || 16 * k + 48 * wave < NP;
+#endif
         float* Tl = panelLane ? s.L + 256 * tileIndex(prow >> 4, k) : Dk;
         const int trow = diagLane ? lane : (panelLane ? (prow & 15) : vrow);
         float a[16];
@@ -1718,6 +1728,32 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           }
         }
         __syncthreads();
+#ifdef MMX_EXP_MFMAPANEL
+        if (kMp && k + 3 < NB) { // X = T L_kk^-T for the tiles the chain did not take, one product per tile
+          const int q = lane & 15, g = lane >> 4;
+          for (int I = k + 3 + wave; I < NB; I += 4) {
+            float* Tc = s.L + 256 * tileIndex(I, k);
+            const float4 av = ldsRow4(Tc, q, g); // A[i' = q][kk = 4 g + e]
+            // B[kk][j' = q] = L_kk^-T (kk, q): the packed diagonal tile right of its diagonal, 1 / l_kk on it
+            const float4 ivd = *reinterpret_cast<const float4*>(s.invDiag + 16 * k + 4 * g);
+            const int k0 = 4 * g;
+            const float b0 = q > k0 ? Dk[tileAddr(k0, q)] : (q == k0 ? ivd.x : 0.f);
+            const float b1 = q > k0 + 1 ? Dk[tileAddr(k0 + 1, q)] : (q == k0 + 1 ? ivd.y : 0.f);
+            const float b2 = q > k0 + 2 ? Dk[tileAddr(k0 + 2, q)] : (q == k0 + 2 ? ivd.z : 0.f);
+            const float b3 = q > k0 + 3 ? Dk[tileAddr(k0 + 3, q)] : (q == k0 + 3 ? ivd.w : 0.f);
+            v4f c{0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b3, c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Tc[tileAddr(4 * g + r, q)] = c[r]; // X[4 g + r][q]
+            }
+          }
+          __syncthreads();
+        }
+#endif
         // panels taller than the 176 rows of one pass: the remaining rows solve against the finished L_kk
         for (int r = 16 * (k + 1) + 176 + tid; r < NP; r += 256) {
           float* Tr = s.L + 256 * tileIndex(r >> 4, k);

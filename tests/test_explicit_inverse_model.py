@@ -40,3 +40,36 @@ def test_every_block_has_exactly_one_wave(NB):
         tiles = sorted(i for w in range(4) for i in m.column_tiles_of_wave(NB, j, w))
         assert tiles == list(range(j + 1, NB)), (j, tiles)
         assert max(len(m.column_tiles_of_wave(NB, j, w)) for w in range(4)) <= 2
+
+
+def test_panel_tile_times_inverse_transpose_of_the_packed_diagonal_block():
+    """MMX_EXP_MFMAPANEL: X = T L_kk^-T for a panel tile, operands as the kernel reads them (A: a row chunk of T,
+    B: the packed diagonal tile right of its diagonal / invDiag), result stored in place."""
+    rng = np.random.default_rng(7)
+    A = rng.normal(size=(40, 32))
+    L = np.linalg.cholesky(A.T @ A + 0.1 * np.eye(32))
+    lds, inv_diag = m.store_factor(L, 2)
+    # tile (1, 0) still holds H's block: put a random one there and solve it against L_00
+    T = rng.normal(size=(16, 16))
+    base = 256 * m.tile_index(1, 0)
+    for r in range(16):
+        for c in range(16):
+            lds[base + m.tile_addr(r, c)] = T[r, c]
+    dk = 256 * m.tile_index(0, 0)
+    a = np.zeros((4, 64))
+    b = np.zeros((4, 64))
+    for l in range(64):
+        q, g = l & 15, l >> 4
+        a[:, l] = m.lds_row4(lds, base, q, g)
+        for e in range(4):
+            kk = 4 * g + e
+            b[e, l] = lds[dk + m.tile_addr(kk, q)] if q > kk else (inv_diag[kk] if q == kk else 0.0)
+    acc = np.zeros((64, 4))
+    for e in range(4):
+        m.mfma(a[e], b[e], acc)
+    for l in range(64):
+        q, g = l & 15, l >> 4
+        for r in range(4):
+            lds[base + m.tile_addr(4 * g + r, q)] = acc[l, r]
+    got = np.array([[lds[base + m.tile_addr(r, c)] for c in range(16)] for r in range(16)])
+    assert np.allclose(got, T @ np.linalg.inv(L[:16, :16]).T, rtol=1e-10, atol=1e-12)
