@@ -707,186 +707,6 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Experiment (build variant MMX_EXP_INVERSE, scripts/gpu_ab.sh): the solves through an explicit L^-1.
-// solveLLt above is one wave walking 2 NB dependent block steps per solve, two to four solves per iteration.  Here the
-// off-diagonal tiles are turned into the tiles of X = L^-1 once per factorisation, in place, block column by block column
-// from the right (X L = I:  X_ij = -(sum_{k=j+1..i} X_ik L_kj) L_jj^-1; the columns right of j are inverted already, column
-// j still holds L), as matrix-core products in transposed form so that an accumulator is the next product's B operand
-// as it stands:   S^T = sum_k L_kj^T X_ik^T ,   X_ij^T = -(L_jj^-1)^T S^T .
-// A solve is then y = X b, x = X^T y: two triangular mat-vecs dealt to the four waves by block rows / block columns.
-// Lane-level model with the same storage, operand lanes and work split: tests/explicit_inverse_np.py.
-// ---------------------------------------------------------------------------------------------
-template <int NB>
-__device__ __forceinline__ void invertFactorTiles(float* L, const float* invDiag, int wave, int lane) {
-  static_assert(NB <= 8, "two tiles per wave and block column at most");
-  const int q = lane & 15, g = lane >> 4;
-  // k index of a lane's operand in matrix-core step s: kk = 4 s + g -- as rows of a tile column (A: L_kj[kk][i']) and as
-  // columns of a tile row (B: X_ik[j'][kk]) both patterns put the 64 lanes on 64 different banks
-  const int colOff[4] = {tileAddr(g, q), tileAddr(4 + g, q), tileAddr(8 + g, q), tileAddr(12 + g, q)};
-  const int rowOff[4] = {tileAddr(q, g), tileAddr(q, 4 + g), tileAddr(q, 8 + g), tileAddr(q, 12 + g)};
-  // the four lowest tiles of a column (the longest sums) one per wave, the others to the waves with the shortest
-  const int ti[2] = {NB - 1 - wave, NB - 8 + wave};
-#pragma unroll 1
-  for (int j = NB - 2; j >= 0; --j) {
-    v4f res[2];
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      const int i = ti[sl];
-      res[sl] = v4f{0.f, 0.f, 0.f, 0.f};
-      if ((sl == 0 || NB >= 6) && i >= j + 1) { // wave-uniform
-        const float* Ti = L + 256 * ((i * (i + 1)) >> 1); // block row i
-        // operands of the k = i term (X_ii = L_ii^-1 from the packed diagonal tile: (j', kk) sits at (kk, j') above the
-        // diagonal), of the closing product and of the first k < i term: all in flight together
-        float ad[4], md[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ad[e] = Ti[256 * j + colOff[e]];
-          md[e] = Ti[256 * i + colOff[e]];
-        }
-        const float invd = invDiag[16 * i + q];
-        const float4 row = ldsRow4(L + 256 * tileIndex(j, j), q, g);
-        const float4 ivd = *reinterpret_cast<const float4*>(invDiag + 16 * j + 4 * g);
-        const float* Ta = L + 256 * tileIndex(j + 1, j); // L_kj, k = j + 1 (always a tile of the factor)
-        const float* Tb = Ti + 256 * (j + 1); // X_ik (inside the factor's storage whatever i is)
-        float ca[4], cb[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ca[e] = Ta[colOff[e]];
-          cb[e] = Tb[rowOff[e]];
-        }
-        v4f c0{0.f, 0.f, 0.f, 0.f}, c1{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int kk = 4 * e + g;
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ad[e], kk < q ? md[e] : (kk == q ? invd : 0.f), c0, 0, 0, 0);
-        }
-#pragma unroll 1
-        for (int k = j + 1; k < i; ++k) {
-          // the next term's operands are requested before this term's products are issued
-          Ta += 256 * (k + 1);
-          Tb += 256;
-          float na[4], nb[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            na[e] = Ta[colOff[e]]; // (one step past the sum: L_ij again / the diagonal tile -- never used)
-            nb[e] = Tb[rowOff[e]];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[e], cb[e], c1, 0, 0, 0);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ca[e] = na[e];
-            cb[e] = nb[e];
-          }
-        }
-        // slot r of c0 + c1 = S^T[4 g + r][j'] = the B operand of kk = 4 g + r.  A[i'][kk] = -(L_jj^-1)[kk][i']: row i' of
-        // the packed diagonal tile right of the diagonal
-        const int k0 = 4 * g;
-        const float n0 = q < k0 ? row.x : (q == k0 ? ivd.x : 0.f);
-        const float n1 = q < k0 + 1 ? row.y : (q == k0 + 1 ? ivd.y : 0.f);
-        const float n2 = q < k0 + 2 ? row.z : (q == k0 + 2 ? ivd.z : 0.f);
-        const float n3 = q < k0 + 3 ? row.w : (q == k0 + 3 ? ivd.w : 0.f);
-        v4f r{0.f, 0.f, 0.f, 0.f};
-        r = __builtin_amdgcn_mfma_f32_16x16x4f32(-n0, c0[0] + c1[0], r, 0, 0, 0);
-        r = __builtin_amdgcn_mfma_f32_16x16x4f32(-n1, c0[1] + c1[1], r, 0, 0, 0);
-        r = __builtin_amdgcn_mfma_f32_16x16x4f32(-n2, c0[2] + c1[2], r, 0, 0, 0);
-        r = __builtin_amdgcn_mfma_f32_16x16x4f32(-n3, c0[3] + c1[3], r, 0, 0, 0);
-        res[sl] = r; // X_ij[j'][4 g + r]
-      }
-    }
-    __syncthreads(); // every wave has read its L_kj of this column
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      const int i = ti[sl];
-      if ((sl == 0 || NB >= 6) && i >= j + 1) {
-        *reinterpret_cast<float4*>(L + 256 * tileIndex(i, j) + q * 16 + (((g ^ (q >> 2)) & 3) << 2)) = float4{res[sl][0], res[sl][1], res[sl][2], res[sl][3]};
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// x := (L L^T)^-1 x with the tiles invertFactorTiles left behind; tmp [16 NB] holds y = L^-1 b between the sweeps.
-// Block row I of X has I + 1 tiles, block column J has NB - J: heaviest four one per wave, the others to the lightest.
-// Straight-line code: every tile a wave could own is read (the addresses stay inside the factor's storage) and the
-// ones beyond its block are dropped by a select, so that all reads of a sweep are in flight together.
-template <int NB>
-__device__ __forceinline__ void solveWithInverse(const float* L, const float* invDiag, float* x, float* tmp, int wave, int lane) {
-  static_assert(NB <= 8, "two blocks per wave at most");
-  const int i = lane >> 2, g = lane & 3;
-  const int rb[2] = {NB - 1 - wave, NB - 8 + wave};
-  const int colOff[4] = {tileAddr(g, i), tileAddr(4 + g, i), tileAddr(8 + g, i), tileAddr(12 + g, i)};
-  {
-    float4 xq[NB > 1 ? NB - 1 : 1];
-#pragma unroll
-    for (int Jc = 0; Jc < NB - 1; ++Jc) {
-      xq[Jc] = *reinterpret_cast<const float4*>(x + 16 * Jc + 4 * g);
-    }
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) { // y_I = sum_{J <= I} X_IJ b_J
-      const int I = rb[sl];
-      if ((sl == 0 || NB >= 5) && I >= 0) {
-        const float* Ti = L + 256 * ((I * (I + 1)) >> 1);
-        constexpr int kMaxJ = NB - 1; // slot 1: I <= NB - 5
-        float acc = 0.f;
-#pragma unroll
-        for (int Jc = 0; Jc < kMaxJ; ++Jc) {
-          if (sl == 0 || Jc < NB - 5) {
-            const float t = dot4(ldsRow4(Ti + 256 * Jc, i, g), xq[Jc], 0.f);
-            acc += Jc < I ? t : 0.f;
-          }
-        }
-        const float* DI = Ti + 256 * I;
-        const float invd = invDiag[16 * I + i];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int c = 4 * t + g; // L_II^-1 (i, c) = L_II^-T (c, i)
-          const float m = DI[colOff[t]];
-          acc += (c < i ? m : (c == i ? invd : 0.f)) * x[16 * I + c];
-        }
-        acc = quadSum(acc);
-        if (g == 0) {
-          tmp[16 * I + i] = acc;
-        }
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int sl = 0; sl < 2; ++sl) { // x_J = sum_{I >= J} X_IJ^T y_I
-    if ((sl == 0 || NB >= 5) && rb[sl] >= 0) {
-      const int Jc = NB - 1 - rb[sl];
-      float acc = 0.f;
-#pragma unroll
-      for (int d = 1; d < NB; ++d) {
-        if (sl == 0 || d <= NB - 5) { // slot 1: J >= 4
-          const int I = Jc + d, Ic = I < NB ? I : NB - 1;
-          const float* Tij = L + 256 * (((Ic * (Ic + 1)) >> 1) + Jc);
-          const float* yv = tmp + 16 * Ic + g;
-          const float t = (Tij[colOff[0]] * yv[0] + Tij[colOff[1]] * yv[4]) + (Tij[colOff[2]] * yv[8] + Tij[colOff[3]] * yv[12]); // X(16 I + c, 16 J + i), c = 4 t + g
-          acc += I < NB ? t : 0.f;
-        }
-      }
-      const float4 row = ldsRow4(L + 256 * tileIndex(Jc, Jc), i, g); // L_JJ^-T (i, 4g..4g+3)
-      const float4 yd = *reinterpret_cast<const float4*>(tmp + 16 * Jc + 4 * g);
-      const float invd = invDiag[16 * Jc + i];
-      const int c0 = 4 * g;
-      acc += (c0 > i ? row.x : (c0 == i ? invd : 0.f)) * yd.x;
-      acc += (c0 + 1 > i ? row.y : (c0 + 1 == i ? invd : 0.f)) * yd.y;
-      acc += (c0 + 2 > i ? row.z : (c0 + 2 == i ? invd : 0.f)) * yd.z;
-      acc += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * yd.w;
-      acc = quadSum(acc);
-      if (g == 0) {
-        x[16 * Jc + i] = acc;
-      }
-    }
-  }
-  __syncthreads();
-}
-
 // Per-instance constraint parents (mmx_problem_set_instance_parents): the tables that say which units hang on which
 // joint, built per element instead of copied from the batch-shared ones -- units sorted by (DFS position of their joint,
 // unit index) with a counting rank, so that the own sums add in the same deterministic order as in the shared case.
@@ -964,14 +784,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   constexpr bool kLook = NB <= 8;
 #else
   constexpr bool kLook = false;
-#endif
-#ifdef MMX_EXP_MFMAPANEL
-  constexpr bool kMp = NB <= 8; // experiment: panel rows beyond wave 0's by a matrix-core product with L_kk^-T
-#endif
-#ifdef MMX_EXP_INVERSE
-  constexpr bool kInv = !kTR && NB <= 8; // experiment: solves through an explicit L^-1 (invertFactorTiles)
-#else
-  constexpr bool kInv = false;
 #endif
   long long clkLast = 0;
 #define MMX_CLK(slot)                                             \
@@ -1642,14 +1454,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         const int prow = 16 * k + vrow; // = 16 (k + 1) + (vrow - 16)
         const bool panelLane = !diagLane && !identLane && prow < NP;
         // waves whose 48 virtual rows all lie beyond the matrix only wait (wave-uniform branch)
-#ifdef MMX_EXP_MFMAPANEL
-        // experiment: only wave 0 runs the elimination chain (the diagonal block, the identity rows and the first 32 panel
-        // rows); the block rows from k + 3 on are multiplied by L_kk^-T on the matrix cores afterwards (below) -- six
-        // wave-chains of ~580 VALU instructions per iteration instead of nine at cfg2
-        const bool waveWorks = kMp ? wave == 0 : (wave == 0 || 16 * k + 48 * wave < NP);
-#else
         const bool waveWorks = wave == 0 || 16 * k + 48 * wave < NP;
-#endif
         float* Tl = panelLane ? s.L + 256 * tileIndex(prow >> 4, k) : Dk;
         const int trow = diagLane ? lane : (panelLane ? (prow & 15) : vrow);
         float a[16];
@@ -1728,32 +1533,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           }
         }
         __syncthreads();
-#ifdef MMX_EXP_MFMAPANEL
-        if (kMp && k + 3 < NB) { // X = T L_kk^-T for the tiles the chain did not take, one product per tile
-          const int q = lane & 15, g = lane >> 4;
-          for (int I = k + 3 + wave; I < NB; I += 4) {
-            float* Tc = s.L + 256 * tileIndex(I, k);
-            const float4 av = ldsRow4(Tc, q, g); // A[i' = q][kk = 4 g + e]
-            // B[kk][j' = q] = L_kk^-T (kk, q): the packed diagonal tile right of its diagonal, 1 / l_kk on it
-            const float4 ivd = *reinterpret_cast<const float4*>(s.invDiag + 16 * k + 4 * g);
-            const int k0 = 4 * g;
-            const float b0 = q > k0 ? Dk[tileAddr(k0, q)] : (q == k0 ? ivd.x : 0.f);
-            const float b1 = q > k0 + 1 ? Dk[tileAddr(k0 + 1, q)] : (q == k0 + 1 ? ivd.y : 0.f);
-            const float b2 = q > k0 + 2 ? Dk[tileAddr(k0 + 2, q)] : (q == k0 + 2 ? ivd.z : 0.f);
-            const float b3 = q > k0 + 3 ? Dk[tileAddr(k0 + 3, q)] : (q == k0 + 3 ? ivd.w : 0.f);
-            v4f c{0.f, 0.f, 0.f, 0.f};
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b3, c, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              Tc[tileAddr(4 * g + r, q)] = c[r]; // X[4 g + r][q]
-            }
-          }
-          __syncthreads();
-        }
-#endif
         // panels taller than the 176 rows of one pass: the remaining rows solve against the finished L_kk
         for (int r = 16 * (k + 1) + 176 + tid; r < NP; r += 256) {
           float* Tr = s.L + 256 * tileIndex(r >> 4, k);
@@ -1785,20 +1564,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     }
     __syncthreads();
     notPd = s.flags[1] != 0;
-    if constexpr (kInv) {
-      if (!notPd) {
-        invertFactorTiles<NB>(s.L, s.invDiag, wave, lane);
-      }
-    }
     MMX_CLK(7)
 
     // ================= I: d0 = (L L^T)^-1 g
     if (!notPd) {
-      if constexpr (kInv) {
-        solveWithInverse<NB>(s.L, s.invDiag, s.d0, s.jd, wave, lane); // (jd: free until the refinement writes it)
-      } else {
-        solveLLt<NB>(s.L, s.invDiag, s.d0, tid);
-      }
+      solveLLt<NB>(s.L, s.invDiag, s.d0, tid);
     }
     MMX_CLK(8)
     // ================= J: one refinement step through the tree (tangent + adjoint passes)
@@ -1983,11 +1753,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       }
       __syncthreads();
       MMX_CLK(19)
-      if constexpr (kInv) {
-        solveWithInverse<NB>(s.L, s.invDiag, s.rho, s.jd, wave, lane); // (jd was consumed by the tangent pass)
-      } else {
-        solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
-      }
+      solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
       MMX_CLK(20)
       float c2 = 0.f, d2 = 0.f;
       for (int c = tid; c < n; c += 256) {
