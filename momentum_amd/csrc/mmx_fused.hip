@@ -1455,6 +1455,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         const bool panelLane = !diagLane && !identLane && prow < NP;
         // waves whose 48 virtual rows all lie beyond the matrix only wait (wave-uniform branch)
         const bool waveWorks = wave == 0 || 16 * k + 48 * wave < NP;
+#ifdef MMX_EXP_LOOKAHEAD
+        if (kLook && !waveWorks && k >= 1 && k + 1 < NB) {
+          // lookahead: the waves without a panel row bring block column k + 1 up to date with the finished columns
+          // j < k while the others run the elimination chain (disjoint tiles: column k is the chain's)
+          const int firstIdle = (NP - 16 * k + 47) / 48; // waves 0 .. firstIdle - 1 hold the virtual rows
+          for (int I = k + 1 + (wave - firstIdle); I < NB; I += 4 - firstIdle) {
+            updateTile(I, k + 1, 0, k);
+          }
+        }
+#endif
         float* Tl = panelLane ? s.L + 256 * tileIndex(prow >> 4, k) : Dk;
         const int trow = diagLane ? lane : (panelLane ? (prow & 15) : vrow);
         float a[16];
@@ -1476,16 +1486,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           }
         }
         MMX_CLK(22)
-#ifdef MMX_EXP_LOOKAHEAD
-        if (kLook && !waveWorks && k >= 1 && k + 1 < NB) {
-          // lookahead: the waves without a panel row bring block column k + 1 up to date with the finished columns
-          // j < k while the others run the elimination chain (disjoint tiles: column k is the chain's)
-          const int firstIdle = (NP - 16 * k + 47) / 48; // waves 0 .. firstIdle - 1 hold the virtual rows
-          for (int I = k + 1 + (wave - firstIdle); I < NB; I += 4 - firstIdle) {
-            updateTile(I, k + 1, 0, k);
-          }
-        }
-#endif
         float invd = 0.f;
         bool bad = false;
         if (waveWorks) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of one build variant (VAR=name, default: the explicit-inverse experiment, MMX_BUILD_VARIANT=inverse): headline bench of the variant against the default library on one
+# A/B of one build variant (VAR=name of MMX_BUILD_VARIANT, e.g. lookahead): headline bench of the variant against the default library on one
 # box (each run carries its own parity check against the CPU oracle), then the variant's phase clocks.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
@@ -16,12 +16,12 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 }
-run ${VAR:-inverse}_1 libmmx_hip_${VAR:-inverse}.so
+run ${VAR:-lookahead}_1 libmmx_hip_${VAR:-lookahead}.so
 run main_1 libmmx_hip.so
 if [ -n "$INV_MORE" ]; then
-  run ${VAR:-inverse}_2 libmmx_hip_${VAR:-inverse}.so
-  run inverse_ls libmmx_hip_${VAR:-inverse}.so --line-search 2
+  run ${VAR:-lookahead}_2 libmmx_hip_${VAR:-lookahead}.so
+  run inverse_ls libmmx_hip_${VAR:-lookahead}.so --line-search 2
   run main_ls libmmx_hip.so --line-search 2
-  MMX_LIB=$GRAFT_REPO_ROOT/momentum_amd/libmmx_hip_${VAR:-inverse}.so timeout 60 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q < /dev/null 2>&1 | grep -E "passed|failed|^FAILED|Error" | cut -c1-200 | tail -4
+  MMX_LIB=$GRAFT_REPO_ROOT/momentum_amd/libmmx_hip_${VAR:-lookahead}.so timeout 60 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q < /dev/null 2>&1 | grep -E "passed|failed|^FAILED|Error" | cut -c1-200 | tail -4
 fi
-bash scripts/gpu_clocks.sh ${VAR:-inverse}clk ${VAR:-inverse} 2>&1 | grep -E "total|H cholesky|I solve|J solve|H.bc|H.b |H.d"
+[ -n "$SKIP_CLOCKS" ] || bash scripts/gpu_clocks.sh ${VAR:-lookahead}clk ${VAR:-lookahead} 2>&1 | grep -E "total|H cholesky|I solve|J solve|H.bc|H.b |H.d"
