@@ -20,7 +20,7 @@ run ${VAR:-lookahead}_1 libmmx_hip_${VAR:-lookahead}.so
 run main_1 libmmx_hip.so
 if [ -n "$INV_MORE" ]; then
   run ${VAR:-lookahead}_2 libmmx_hip_${VAR:-lookahead}.so
-  run inverse_ls libmmx_hip_${VAR:-lookahead}.so --line-search 2
+  run ${VAR:-lookahead}_ls libmmx_hip_${VAR:-lookahead}.so --line-search 2
   run main_ls libmmx_hip.so --line-search 2
   MMX_LIB=$GRAFT_REPO_ROOT/momentum_amd/libmmx_hip_${VAR:-lookahead}.so timeout 60 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q < /dev/null 2>&1 | grep -E "passed|failed|^FAILED|Error" | cut -c1-200 | tail -4
 fi
