@@ -782,8 +782,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   // experiment: the left-looking updates of block column k + 1 by the columns before k ride under panel k's elimination
   // chain (waves without a panel row); NB <= 8: wave 3 never holds one
   constexpr bool kLook = NB <= 8;
-#else
-  constexpr bool kLook = false;
 #endif
   long long clkLast = 0;
 #define MMX_CLK(slot)                                             \
