@@ -29,6 +29,7 @@
 #include "mmx_tree.hpp"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace mmx {
 
@@ -765,7 +766,11 @@ __device__ __forceinline__ int buildInstanceUnitTables(
 // kGen: rows of the further joint error functions (plane / aim / fixed axis / normal / ...) and of the ellipsoid limits:
 // evaluated per iteration into a small dense block J_g (LDS), added to g, H (matrix-core rank-k update of the tiles),
 // the refinement residual and the trial errors.  More LDS, so at most two workgroups per CU.
-template <int NB, int MODE, bool kTR, bool kGen = false>
+// kPlain: the instantiation for GaussNewtonSolverT without a line search (step rule 0, do_line_search 0 -- the BASELINE
+// metric): the LM schedule and the backtracking loops with their trial evaluations (a second and third copy of phases A-C)
+// are compiled out together with the state they carry from iteration to iteration.  Launched only with
+// MMX_FUSED_PLAIN=1 until it has been through the GPU suite (launchFusedNB).
+template <int NB, int MODE, bool kTR, bool kGen = false, bool kPlain = false>
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
@@ -976,7 +981,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   // the joint states / units in LDS already belong to s.th (left by an accepted trial of the line search or the LM
   // schedule, blockError<kStore>); stateError = the error an evaluation of phases A-C would report for it
   // (measured: line search 1.39 -> 1.52e6, LM schedule 1.41 -> 1.53e6 solves/s at cfg2 / cfg3)
-  constexpr bool kReuse = !kGen && !kTR;
+  constexpr bool kReuse = !kGen && !kTR && !kPlain;
+  const int stepRule = kPlain ? 0 : fp.stepRule, doLineSearch = kPlain ? 0 : fp.doLineSearch;
   bool stateValid = false;
   double stateError = 0.0;
   __syncthreads();
@@ -1861,7 +1867,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       __syncthreads();
       continue; // the trial evaluation overwrote the joint states and the factor: this theta once more
     }
-    if (!notPd && fp.stepRule == 1) {
+    if (!notPd && stepRule == 1) {
       // ---- LM gain-ratio schedule, the lambda form of TrustRegionQRT's radius rule
       // (momentum/character_solver/trust_region_qr.cpp:244-268); identical to the oracle's
       // restatement (oracle/mmx_oracle.hpp solveGaussNewton, stepRule 1)
@@ -1894,16 +1900,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       } else if (rho > 0.75f) {
         lambda = fmaxf(lambda * fp.lmDown, fp.lmLambdaMin);
       }
-    } else if (notPd && fp.stepRule == 1) {
+    } else if (notPd && stepRule == 1) {
       lambda = fminf(lambda * fp.lmUp, fp.lmLambdaMax);
-    } else if (!notPd && fp.doLineSearch) {
+    } else if (!notPd && doLineSearch) {
       // ---- GaussNewtonSolverT::updateParameters with doLineSearch (gauss_newton_solver.cpp:283-313):
       // Armijo backtracking, c1 = 1e-3, tau = 0.5, at most 10 trial steps; the last trial stays
       // or SubsetGaussNewtonSolverT / GaussNewtonSolverQRT (subset_gauss_newton_solver.cpp:117-142,
       // gauss_newton_solver_qr.cpp:126-149): c_1 = 1e-4 against the directional derivative J^T r . delta
       const float scaledError = 1e-3f * float(curError);
       double gd = 0.0;
-      if (fp.doLineSearch == 2) {
+      if (doLineSearch == 2) {
         float part = 0.f;
         for (int c = tid; c < n; c += 256) {
           part += s.g[c] * s.d0[c];
@@ -1921,7 +1927,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         }
         __syncthreads();
         const double eNew = blockError<kGen, kReuse>(rig, rv, pb, fv, s, s.dfull, b, tid, &stateError);
-        if ((curError - eNew) >= (fp.doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale * scaledError))) {
+        if ((curError - eNew) >= (doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale * scaledError))) {
           break;
         }
         scale *= 0.5f;
@@ -2805,7 +2811,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
 }
 #endif
 
-template <int NB, int MODE, bool kTR, bool kGen = false>
+template <int NB, int MODE, bool kTR, bool kGen = false, bool kPlain = false>
 static hipError_t launchFusedMode(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -2823,12 +2829,12 @@ static hipError_t launchFusedMode(
   }
   static LdsLimitCache ldsLimit; // (one per instantiation)
   {
-    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen>), lds);
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen, kPlain>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
   }
-  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kPlain>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
   return hipGetLastError();
 }
 
@@ -2861,6 +2867,12 @@ static hipError_t launchFusedNB(
   }
   if (dbgH != nullptr || dbgG != nullptr) {
     return launchFusedMode<NB, 1, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+  }
+  if (fp.stepRule == 0 && fp.doLineSearch == 0) { // plain Gauss-Newton: the instantiation without the trial-evaluation code
+    const char* e = getenv("MMX_FUSED_PLAIN");
+    if (e != nullptr && e[0] == '1') {
+      return launchFusedMode<NB, 0, false, false, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+    }
   }
   return launchFusedMode<NB, 0, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
 }

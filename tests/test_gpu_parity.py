@@ -204,6 +204,32 @@ def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
 
 
+@pytest.mark.parametrize("name", ["chain24_cfg1", "humanoid72_cfg2", "humanoid72_many_units"])
+def test_plain_gauss_newton_instantiation_matches_the_general_one(torch_cuda, orc, name, monkeypatch):
+    """MMX_FUSED_PLAIN=1 launches the fused kernel's instantiation for GaussNewtonSolverT without a line search (the
+    LM schedule and the backtracking loops compiled out): the same arithmetic on the same path, so the same iterates as
+    the general instantiation up to the compiler's scheduling, and the same parity with the oracle."""
+    torch = torch_cuda
+    rig, pp, op, B = _case(name)
+    cons, th0, ths = make_problem(rig, pp, op, B, seed=777, perturb=0.3)
+    rh, pb = _gpu_problem(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
+    general = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    monkeypatch.setenv("MMX_FUSED_PLAIN", "1")
+    plain = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    plain2 = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert torch.equal(plain["theta"], plain2["theta"])  # deterministic
+    assert torch.equal(plain["iterations"], general["iterations"]) and torch.equal(plain["status"], general["status"])
+    a, b = plain["theta"].cpu().numpy(), general["theta"].cpu().numpy()
+    assert (np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)).max() <= 5e-6
+    h, hg = plain["error_history"].cpu().numpy(), general["error_history"].cpu().numpy()
+    assert np.abs(h - hg).max() <= 1e-5 * max(1.0, np.abs(hg).max())
+    if name.startswith("humanoid"):
+        ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+        rel = np.linalg.norm(a - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+        assert rel.max() <= 1e-5, rel
+
+
 @pytest.mark.parametrize("path", ["fused", "three_kernel"])
 @pytest.mark.parametrize("mode", ["line_search", "line_search_directional", "lm_schedule"])
 def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, monkeypatch):
