@@ -766,11 +766,13 @@ __device__ __forceinline__ int buildInstanceUnitTables(
 // kGen: rows of the further joint error functions (plane / aim / fixed axis / normal / ...) and of the ellipsoid limits:
 // evaluated per iteration into a small dense block J_g (LDS), added to g, H (matrix-core rank-k update of the tiles),
 // the refinement residual and the trial errors.  More LDS, so at most two workgroups per CU.
-// kPlain: the instantiation for GaussNewtonSolverT without a line search (step rule 0, do_line_search 0 -- the BASELINE
-// metric): the LM schedule and the backtracking loops with their trial evaluations (a second and third copy of phases A-C)
-// are compiled out together with the state they carry from iteration to iteration.  Launched only with
-// MMX_FUSED_PLAIN=1 until it has been through the GPU suite (launchFusedNB).
-template <int NB, int MODE, bool kTR, bool kGen = false, bool kPlain = false>
+// kRule: -1 = the step rule and the line search are run-time options (one instantiation for all of them); 0 / 1 = the
+// instantiation for GaussNewtonSolverT without a line search (the BASELINE metric) / for the LM schedule: the other rules'
+// branches -- each inlines a whole trial evaluation, a further copy of phases A-C -- are compiled out together with the
+// state they carry from iteration to iteration.  (2 = a line search only: compiles, but spills more than the generic
+// instantiation -- 68 against 36 vector registers at cfg2 -- and is not instantiated.)  Launched only with
+// MMX_FUSED_PLAIN=1 until they have been through the GPU suite (launchFusedNB).
+template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     RigDev rig,
     ProblemDev pb,
@@ -981,8 +983,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   // the joint states / units in LDS already belong to s.th (left by an accepted trial of the line search or the LM
   // schedule, blockError<kStore>); stateError = the error an evaluation of phases A-C would report for it
   // (measured: line search 1.39 -> 1.52e6, LM schedule 1.41 -> 1.53e6 solves/s at cfg2 / cfg3)
-  constexpr bool kReuse = !kGen && !kTR && !kPlain;
-  const int stepRule = kPlain ? 0 : fp.stepRule, doLineSearch = kPlain ? 0 : fp.doLineSearch;
+  constexpr bool kReuse = !kGen && !kTR && kRule != 0;
+  const int stepRule = kRule < 0 ? fp.stepRule : (kRule == 1 ? 1 : 0);
+  const int doLineSearch = kRule < 0 || kRule == 2 ? fp.doLineSearch : 0;
   bool stateValid = false;
   double stateError = 0.0;
   __syncthreads();
@@ -2811,7 +2814,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
 }
 #endif
 
-template <int NB, int MODE, bool kTR, bool kGen = false, bool kPlain = false>
+template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
 static hipError_t launchFusedMode(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -2829,12 +2832,12 @@ static hipError_t launchFusedMode(
   }
   static LdsLimitCache ldsLimit; // (one per instantiation)
   {
-    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen, kPlain>), lds);
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen, kRule>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
   }
-  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kPlain>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
   return hipGetLastError();
 }
 
@@ -2868,10 +2871,15 @@ static hipError_t launchFusedNB(
   if (dbgH != nullptr || dbgG != nullptr) {
     return launchFusedMode<NB, 1, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
   }
-  if (fp.stepRule == 0 && fp.doLineSearch == 0) { // plain Gauss-Newton: the instantiation without the trial-evaluation code
-    const char* e = getenv("MMX_FUSED_PLAIN");
+  {
+    const char* e = getenv("MMX_FUSED_PLAIN"); // the instantiations per step rule (kRule)
     if (e != nullptr && e[0] == '1') {
-      return launchFusedMode<NB, 0, false, false, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+      if (fp.stepRule == 0 && fp.doLineSearch == 0) {
+        return launchFusedMode<NB, 0, false, false, 0>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+      }
+      if (fp.stepRule == 1) {
+        return launchFusedMode<NB, 0, false, false, 1>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+      }
     }
   }
   return launchFusedMode<NB, 0, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);

@@ -230,7 +230,7 @@ def test_plain_gauss_newton_instantiation_matches_the_general_one(torch_cuda, or
         assert rel.max() <= 1e-5, rel
 
 
-@pytest.mark.parametrize("path", ["fused", "three_kernel"])
+@pytest.mark.parametrize("path", ["fused", "three_kernel", "fused_per_rule"])
 @pytest.mark.parametrize("mode", ["line_search", "line_search_directional", "lm_schedule"])
 def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, monkeypatch):
     """GaussNewtonSolverT with doLineSearch (gauss_newton_solver.cpp:283-313) and the LM gain-ratio
@@ -241,6 +241,8 @@ def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, m
     torch = torch_cuda
     if path == "three_kernel":  # explicit J -> J^T J -> Cholesky step -> stepUpdateKernel
         monkeypatch.setenv("MMX_SOLVER", "v1")
+    if path == "fused_per_rule":  # the fused kernel's instantiation for the LM schedule alone (line searches: the general one)
+        monkeypatch.setenv("MMX_FUSED_PLAIN", "1")
     rig, pp, op, B = _case("humanoid72_cfg2")
     cons, th0, ths = make_problem(rig, pp, op, B, seed=4242, perturb=0.3)
     rh, pb = _gpu_problem(torch, rig, cons, B)
