@@ -513,6 +513,8 @@ def main() -> None:
                 "regularization": 0.05,
                 "sharding": f"{world} x {B} independent instances, one all-reduce of residual norms per solve",
                 "exchange": ("RCCL all-reduce of 3 doubles per solve, called from the C ABI (mmx_comm_all_reduce_norms), ranks seen by RCCL: " + str(comm.world_size)) if comm is not None else ("none (one GPU)" if world == 1 else "gloo (plumbing test)"),
+                # experiment switches in force (none in a default run): a number measured with one of them says so
+                "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMX_")},
             },
             "check": {"sum_final_error": total_err, "sum_iterations": total_it, "failed_instances": failed},
             "roofline": {
