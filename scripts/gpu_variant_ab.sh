@@ -18,6 +18,13 @@ PY
 }
 run ${VAR:-lookahead}_1 libmmx_hip_${VAR:-lookahead}.so
 run main_1 libmmx_hip.so
+# the per-rule instantiations (MMX_FUSED_PLAIN=1) on both libraries: plain Gauss-Newton, then the LM schedule of cfg3
+export MMX_FUSED_PLAIN=1
+run main_plain libmmx_hip.so
+run ${VAR:-lookahead}_plain libmmx_hip_${VAR:-lookahead}.so
+run main_lm_perrule libmmx_hip.so --config cfg3
+unset MMX_FUSED_PLAIN
+run main_lm libmmx_hip.so --config cfg3
 if [ -n "$INV_MORE" ]; then
   run ${VAR:-lookahead}_2 libmmx_hip_${VAR:-lookahead}.so
   run ${VAR:-lookahead}_ls libmmx_hip_${VAR:-lookahead}.so --line-search 2
