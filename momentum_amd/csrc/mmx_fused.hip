@@ -766,12 +766,14 @@ __device__ __forceinline__ int buildInstanceUnitTables(
 // kGen: rows of the further joint error functions (plane / aim / fixed axis / normal / ...) and of the ellipsoid limits:
 // evaluated per iteration into a small dense block J_g (LDS), added to g, H (matrix-core rank-k update of the tiles),
 // the refinement residual and the trial errors.  More LDS, so at most two workgroups per CU.
-// kRule: -1 = the step rule and the line search are run-time options (one instantiation for all of them); 0 / 1 = the
-// instantiation for GaussNewtonSolverT without a line search (the BASELINE metric) / for the LM schedule: the other rules'
-// branches -- each inlines a whole trial evaluation, a further copy of phases A-C -- are compiled out together with the
-// state they carry from iteration to iteration.  (2 = a line search only: compiles, but spills more than the generic
-// instantiation -- 68 against 36 vector registers at cfg2 -- and is not instantiated.)  Launched only with
-// MMX_FUSED_PLAIN=1 until they have been through the GPU suite (launchFusedNB).
+// kRule: -1 = the step rule, the line search and the parameter-space rows are run-time options (one instantiation for all
+// of them); 0 / 1 = the instantiation for GaussNewtonSolverT without a line search (the BASELINE metric) / for the LM
+// schedule, both for problems without limit / model-parameter rows: the other rules' branches -- each inlines a whole
+// trial evaluation, a further copy of phases A-C --, the on-the-fly evaluation of the parameter-space rows and the state
+// they carry from iteration to iteration are compiled out (cfg2: 15.0 k / 19.1 k instead of 27.0 k instructions, 6 / 9
+// instead of 36 spilled vector registers, 352 / 380 instead of 456 spilled scalar registers).  (2 = a line search only:
+// compiles, but spills MORE than the generic instantiation -- 68 vector registers -- and is not instantiated.)
+// Launched only with MMX_FUSED_PLAIN=1 until they have been through the GPU suite (launchFusedNB).
 template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     RigDev rig,
@@ -974,7 +976,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     s.flags[1] = 0; // not positive definite (this iteration)
     s.flags[2] = 0; // status
   }
-  const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
+  const bool hasParamRows = kRule >= 0 ? false : (pb.M > pb.rowsJoint); // limit / model-parameter rows present (uniform)
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
   float lambda = fp.lambda; // constant for GaussNewtonSolverT, adapted by the LM schedule
   float trRadius = fp.trustRadius; // TrustRegionQRT::curTrustRegionRadius_ (initializeSolver, trust_region_qr.cpp:38-41)
@@ -2872,8 +2874,8 @@ static hipError_t launchFusedNB(
     return launchFusedMode<NB, 1, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
   }
   {
-    const char* e = getenv("MMX_FUSED_PLAIN"); // the instantiations per step rule (kRule)
-    if (e != nullptr && e[0] == '1') {
+    const char* e = getenv("MMX_FUSED_PLAIN"); // the instantiations per step rule (kRule): no parameter-space rows
+    if (e != nullptr && e[0] == '1' && pb.M == pb.rowsJoint) {
       if (fp.stepRule == 0 && fp.doLineSearch == 0) {
         return launchFusedMode<NB, 0, false, false, 0>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
       }
