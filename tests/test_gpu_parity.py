@@ -204,11 +204,22 @@ def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
 
 
+def _staged():
+    """The per-rule instantiations of the fused kernel (MMX_FUSED_PLAIN=1) were written after the round's GPU budget was
+    spent: their tests run on request (MMX_TEST_STAGED=1, scripts/gpu_variant_suite.sh) until they have passed on a GPU
+    once and the instantiations become the default."""
+    import os
+
+    if os.environ.get("MMX_TEST_STAGED") != "1":
+        pytest.skip("staged code path, not yet run on a GPU: MMX_TEST_STAGED=1 runs it")
+
+
 @pytest.mark.parametrize("name", ["chain24_cfg1", "humanoid72_cfg2", "humanoid72_many_units"])
 def test_plain_gauss_newton_instantiation_matches_the_general_one(torch_cuda, orc, name, monkeypatch):
     """MMX_FUSED_PLAIN=1 launches the fused kernel's instantiation for GaussNewtonSolverT without a line search (the
     LM schedule and the backtracking loops compiled out): the same arithmetic on the same path, so the same iterates as
     the general instantiation up to the compiler's scheduling, and the same parity with the oracle."""
+    _staged()
     torch = torch_cuda
     rig, pp, op, B = _case(name)
     cons, th0, ths = make_problem(rig, pp, op, B, seed=777, perturb=0.3)
@@ -242,6 +253,7 @@ def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, m
     if path == "three_kernel":  # explicit J -> J^T J -> Cholesky step -> stepUpdateKernel
         monkeypatch.setenv("MMX_SOLVER", "v1")
     if path == "fused_per_rule":  # the fused kernel's instantiation for the LM schedule alone (line searches: the general one)
+        _staged()
         monkeypatch.setenv("MMX_FUSED_PLAIN", "1")
     rig, pp, op, B = _case("humanoid72_cfg2")
     cons, th0, ths = make_problem(rig, pp, op, B, seed=4242, perturb=0.3)
