@@ -135,9 +135,9 @@ __device__ __forceinline__ void firstOrderMoments(float* o, F3 p, float yx, floa
 }
 
 // NCH channels per unit (kC1 first-order, then kC2Used second-order ones), stored with stride STRIDE (odd)
-template <int NCH, int STRIDE>
+template <int NCH, int STRIDE, int kT = 256>
 __device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLds& s, const float* umom, int tid) {
-  for (int item = tid; item < fd.numLoaded * NCH; item += 256) {
+  for (int item = tid; item < fd.numLoaded * NCH; item += kT) {
     const int li = item / NCH, c = item - li * NCH;
     const int k = fd.loadedPos[li];
     float acc = 0.f;
@@ -155,9 +155,10 @@ __device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLd
 constexpr int kUmom = 25; // stride of the per-unit moment scratch: 7 + 16 channels, odd
 
 // phase D: first- and second-order own sums from up / uy / us
+template <int kT = 256>
 __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, float* umom, int U, int tid) {
   constexpr int NCH = kC1 + kC2Used;
-  for (int u = tid; u < U; u += 256) {
+  for (int u = tid; u < U; u += kT) {
     const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
     const bool point = u < fd.Kp;
     float* o = umom + kUmom * u;
@@ -184,7 +185,7 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
     }
   }
   __syncthreads();
-  gatherOwnSums<NCH, kUmom>(fd, s, umom, tid);
+  gatherOwnSums<NCH, kUmom, kT>(fd, s, umom, tid);
 }
 
 constexpr int kFusedTreeUn = 4; // k-steps per trip of the tree sums (measured on BASELINE configs[1]: 1 -> 1.575e6, 4 -> 1.60e6, 8 -> 1.54e6 solves/s)
@@ -253,14 +254,14 @@ __device__ __forceinline__ ParamCol paramRowsColumn(
 // y = A x for a CSR matrix whose tables live in GLOBAL memory (the wide kernels; the fused solve keeps them in LDS):
 // four rows per trip with their row bounds, then their first entries, requested together -- a row's walk is a chain
 // of dependent L2 round trips otherwise.  Same products in the same order as the plain walk.
-template <typename Gather, typename Store>
+template <int kT = 256, typename Gather, typename Store> // kT: threads of the workgroup
 __device__ __forceinline__ void csrRowsPrefetched(const int32_t* outer, const int32_t* inner, const float* value, int R, int tid, Gather x, Store out) {
-  for (int r0 = tid; r0 < R; r0 += 4 * 256) {
+  for (int r0 = tid; r0 < R; r0 += 4 * kT) {
     int ka[4], kb[4], in0[4];
     float v0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = min(r0 + 256 * i, R - 1);
+      const int r = min(r0 + kT * i, R - 1);
       ka[i] = outer[r], kb[i] = outer[r + 1];
     }
 #pragma unroll
@@ -270,7 +271,7 @@ __device__ __forceinline__ void csrRowsPrefetched(const int32_t* outer, const in
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = r0 + 256 * i;
+      const int r = r0 + kT * i;
       if (r < R) {
         float acc = 0.f;
         if (kb[i] > ka[i]) {
@@ -289,7 +290,7 @@ __device__ __forceinline__ void csrRowsPrefetched(const int32_t* outer, const in
 // of all joints at once (parameter_transform.cpp:110-124, joint_state.cpp:44-62), world transforms
 // by pointer jumping (skeleton_state.cpp:100-121 re-associated), optionally the rotation axes.
 // Ends with a barrier.  Clobbers alt / jlA / jlB (assembly scratch = the Cholesky region).
-template <bool kGlobalTables = false> // the rig's CSR tables are read from global memory (prefetching walk)
+template <bool kGlobalTables = false, int kT = 256> // the rig's CSR tables are read from global memory (prefetching walk); kT threads
 __device__ __forceinline__ void
 blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes, long long* clk = nullptr, long long* clkLast = nullptr) {
   auto stamp = [&](int slot) { // profiling aid (MMX_PHASE_CLOCKS): sub-phases of FK
@@ -305,10 +306,10 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   // instead of seven dependent ones per joint.  They land in the refinement scratch (jd), which is dead
   // whenever FK runs.
   if (kGlobalTables) {
-    csrRowsPrefetched(
+    csrRowsPrefetched<kT>(
         rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + rig.ptOffsets[r]; });
   } else {
-    for (int r = tid; r < rig.R; r += 256) {
+    for (int r = tid; r < rig.R; r += kT) {
       const float off = rig.ptOffsets[r];
       float acc = 0.f;
       const int k1 = rig.ptOuter[r + 1];
@@ -332,7 +333,7 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   }
   __syncthreads();
   stamp(26);
-  for (int j = tid; j < rig.J; j += 256) {
+  for (int j = tid; j < rig.J; j += kT) {
     float* slot = s.js + kJs * j;
     if (j == tid) {
       fkLocalFromParams(s.jd + 7 * j, pre, off3, odd ? s.alt + kAlt * j : slot, slot + 8);
@@ -343,10 +344,10 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   }
   __syncthreads();
   stamp(24);
-  fkJumpRounds(s.js, s.alt, s.jlA, s.jlB, rig.J, rig.jumpRounds, tid, 256);
+  fkJumpRounds(s.js, s.alt, s.jlA, s.jlB, rig.J, rig.jumpRounds, tid, kT);
   stamp(25);
   if (withAxes) {
-    for (int j = tid; j < rig.J; j += 256) {
+    for (int j = tid; j < rig.J; j += kT) {
       fkAxesInPlaceP(rig, j, rig.parent[j], s.js);
     }
     __syncthreads();
@@ -2090,8 +2091,11 @@ __host__ __device__ inline size_t treeNeExtraLdsFloats(int P, int n, int GT, int
 
 // kExtraRows: the instantiation for problems with parameter-space rows (limits, model prior) and / or further joint error
 // functions / ellipsoid limits; the plain one carries none of that code
-template <bool kExtraRows>
-__global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
+// kWaves: wavefronts of the workgroup (4; 8 = staged, MMX_TREE_NE_WAVES=8, for the instantiation without extra rows: one
+// workgroup per CU is all the LDS allows, so four waves are ONE per SIMD -- eight give every phase that deals work by thread
+// or by wave twice the lanes and each SIMD a second wave to switch to; the term records stay with the first 256 threads)
+template <bool kExtraRows, int kWaves = 4>
+__global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
@@ -2105,6 +2109,8 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     float* __restrict__ genState, // [B][treeGenStateFloats] J_g and its residual rows for treeRefineKernel, or null
     int tileMajor) { // 0: jtj = [n][n] row-major, lower triangle; 1: [tile (I,J) at I(I+1)/2 + J][col][row] (what the tiled factor reads) // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(kWaves == 4 || (kWaves == 8 && !kExtraRows), "the helpers of the extra rows are written for 256 threads");
+  constexpr int kT = 64 * kWaves;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   if (done != nullptr && done[b] != 0) {
@@ -2153,20 +2159,20 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp, fv.subSize = t.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = t.loadedPos, fv.numLoaded = fd.numLoaded;
   fv.colToSolve = nullptr, fv.unitPos = pb.unitTin, fv.posUnitStart = t.posUnitStart, fv.posUnits = t.posUnits, fv.solveList = fd.solveList;
-  for (int i = tid; i < P; i += 256) {
+  for (int i = tid; i < P; i += kT) {
     s.th[i] = theta[size_t(b) * P + i];
   }
-  for (int i = tid; i < J; i += 256) {
+  for (int i = tid; i < J; i += kT) {
     t.subSize[i] = fd.subSize[i];
     t.loadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
   }
-  for (int i = tid; i <= J; i += 256) {
+  for (int i = tid; i <= J; i += kT) {
     t.posUnitStart[i] = fd.posUnitStart[i];
   }
-  for (int i = tid; i < U; i += 256) {
+  for (int i = tid; i < U; i += kT) {
     t.posUnits[i] = fd.posUnits[i];
   }
-  for (int e = tid; e < nsrc; e += 256) {
+  for (int e = tid; e < nsrc; e += kT) {
     t.span[e] = fd.srcs[e].tin | (fd.srcs[e].tout << 16);
   }
   if (kExtraRows) {
@@ -2187,14 +2193,14 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   treeSumRanges(t.subSize, t.loadedPos, fv.numLoaded, J, tid, t.kRange); // (barriers follow before the first tree sum)
   MMX_TCLK(0)
   // ---- A, B: forward kinematics with rotation axes
-  blockFk<true>(rv, s, s.th, tid, true);
+  blockFk<true, kT>(rv, s, s.th, tid, true);
   MMX_TCLK(1)
   // ---- C: units
   {
     const TreeStateLayout sl = treeStateLayout(J, U);
     float* stb = state != nullptr ? state + size_t(b) * sl.total : nullptr;
     double e = 0.0;
-    for (int u = tid; u < U; u += 256) {
+    for (int u = tid; u < U; u += kT) {
       const Unit un = evalUnit(pb, s.js, b, u);
       s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
       const float sg2 = un.sigma * un.sigma;
@@ -2227,27 +2233,27 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
           [&](int c, int& e0, int& e1) { e0 = fd.slotBase + fd.srcStart[c], e1 = fd.slotBase + fd.srcStart[c + 1]; });
     }
     if (errOut != nullptr && tid == 0) {
-      errOut[b] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+      errOut[b] = kWaves == 4 ? (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]) : ((s.red[0] + s.red[1]) + (s.red[2] + s.red[3])) + ((s.red[4] + s.red[5]) + (s.red[6] + s.red[7]));
     }
     if (stb != nullptr) {
-      for (int i = tid; i < kJs * J; i += 256) {
+      for (int i = tid; i < kJs * J; i += kT) {
         stb[sl.js + i] = s.js[i];
       }
-      for (int i = tid; i < 3 * U; i += 256) {
+      for (int i = tid; i < 3 * U; i += kT) {
         stb[sl.up + i] = s.up[i];
       }
-      for (int i = tid; i < U; i += 256) {
+      for (int i = tid; i < U; i += kT) {
         stb[sl.us + i] = s.us[i];
       }
     }
   }
   MMX_TCLK(2)
   // ---- D: own sums (per-unit moments -> per-joint sums), then subtree sums (the moments' scratch is dead by then)
-  ownSums(fv, s, s.umom, U, tid);
+  ownSums<kT>(fv, s, s.umom, U, tid);
   __syncthreads();
   MMX_TCLK(3)
-  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane, t.kRange);
-  treeSum<kC2Used, true, kC2, 8>(fv, s.own2, s.sub2, J, wave, lane, t.kRange);
+  treeSumT<kC1, true, kC1, 8>(fv.subSize, fv.loadedPos, fv.numLoaded, s.own1, s.sub1, J, wave, kWaves, lane, t.kRange);
+  treeSumT<kC2Used, true, kC2, 8>(fv.subSize, fv.loadedPos, fv.numLoaded, s.own2, s.sub2, J, wave, kWaves, lane, t.kRange);
   __syncthreads();
   MMX_TCLK(4)
   // ---- E: per-slot tables (see fusedSolveKernel phase E)
@@ -2255,7 +2261,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   float* srcD = s.srcT;
   float* srcA = s.srcT + 7 * sst;
   float* srcG = s.srcT + 14 * sst;
-  for (int e = tid; e < nsrc; e += 256) {
+  for (int e = tid; e < nsrc; e += kT) {
     const ColumnSourceDev cs = fd.srcs[e];
     const float* a = s.js + kJs * cs.joint;
     const float* sb = s.sub2 + kC2 * cs.tin;
@@ -2303,7 +2309,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
   __syncthreads();
   MMX_TCLK(5)
   // ---- F: g
-  for (int c = tid; c < n; c += 256) {
+  for (int c = tid; c < n; c += kT) {
     float acc = srcG[c];
     const int e1 = fd.slotBase + fd.srcStart[c + 1];
     for (int e = fd.slotBase + fd.srcStart[c]; e < e1; ++e) {
@@ -2365,11 +2371,11 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     };
     normalise();
     TileOps cur = loadOps(I < NB ? I : 0, I < NB ? Jc : 0);
-    for (int tt = wave; tt < T; tt += 4) {
+    for (int tt = wave; tt < T; tt += kWaves) {
       const int tI = I, tJ = Jc;
-      Jc += 4;
+      Jc += kWaves;
       normalise();
-      const bool more = tt + 4 < T; // wave-uniform
+      const bool more = tt + kWaves < T; // wave-uniform
       const TileOps nxt = loadOps(more ? I : tI, more ? Jc : tJ); // the next tile's LDS reads fly while this one multiplies
       v4f Pm{0.f, 0.f, 0.f, 0.f}, Qm{0.f, 0.f, 0.f, 0.f};
       Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dI0, cur.aJ0, Pm, 0, 0, 0);
@@ -2418,10 +2424,10 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
       return tileMajor ? Ht + size_t(y >> 8) * 256 + c * 16 + r : Hb + size_t(16 * I + r) * n + (16 * Jc + c);
     };
     for (int k = 0; k < fd.termRounds; ++k) {
-      const uint4* rp = fd.gTerms + size_t(k) * 256 + tid;
+      const uint4* rp = fd.gTerms + size_t(k) * 256 + (kWaves == 4 ? tid : (tid & 255)); // (dealt to 256 threads by the host)
       const uint2 rec = *reinterpret_cast<const uint2*>(rp);
       const uint32_t x = rec.x;
-      if (x & (1u << 26)) {
+      if ((kWaves == 4 || tid < 256) && (x & (1u << 26))) {
         const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
         float hj = 0.f;
 #pragma unroll
@@ -2441,7 +2447,7 @@ __global__ void __launch_bounds__(256, 1) treeNormalEquationsKernel(
     }
     __threadfence_block();
     __syncthreads();
-    for (int i = tid; i < fd.numComb; i += 256) {
+    for (int i = tid; i < fd.numComb; i += kT) {
       const int dest = fd.comb[3 * i], first = fd.comb[3 * i + 1], cnt = fd.comb[3 * i + 2];
       float* hp = entryAddr(uint32_t(dest));
       float v = *hp;
@@ -2517,6 +2523,18 @@ hipError_t launchTreeNormalEquations(
         extra ? reinterpret_cast<const void*>(treeNormalEquationsKernel<true>) : reinterpret_cast<const void*>(treeNormalEquationsKernel<false>), lds);
     if (rc != hipSuccess) {
       return rc;
+    }
+  }
+  if (!extra) { // staged: eight waves per workgroup (MMX_TREE_NE_WAVES=8), not the default until it has run on a GPU
+    const char* we = getenv("MMX_TREE_NE_WAVES");
+    if (we != nullptr && we[0] == '8') {
+      static LdsLimitCache ldsLimit8;
+      hipError_t rc = ldsLimit8.ensure(reinterpret_cast<const void*>(treeNormalEquationsKernel<false, 8>), lds);
+      if (rc != hipSuccess) {
+        return rc;
+      }
+      hipLaunchKernelGGL((treeNormalEquationsKernel<false, 8>), dim3(pb.B), dim3(512), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
+      return hipGetLastError();
     }
   }
   if (extra) {

@@ -25,8 +25,10 @@ run ${VAR:-lookahead}_plain libmmx_hip_${VAR:-lookahead}.so
 run main_lm_perrule libmmx_hip.so --config cfg3
 unset MMX_FUSED_PLAIN
 run main_lm libmmx_hip.so --config cfg3
-# the lean factor kernel of the wide path (MMX_CHOL_LEAN=1) on cfg5
+# the staged kernels of the wide path (MMX_CHOL_LEAN=1, MMX_TREE_NE_WAVES=8) on cfg5
 MMX_CHOL_LEAN=1 run main_cfg5_lean libmmx_hip.so --config cfg5 --steps 5 --warmup 2
+MMX_TREE_NE_WAVES=8 run main_cfg5_ne8 libmmx_hip.so --config cfg5 --steps 5 --warmup 2
+MMX_CHOL_LEAN=1 MMX_TREE_NE_WAVES=8 run main_cfg5_both libmmx_hip.so --config cfg5 --steps 5 --warmup 2
 run main_cfg5 libmmx_hip.so --config cfg5 --steps 5 --warmup 2
 if [ -n "$INV_MORE" ]; then
   run ${VAR:-lookahead}_2 libmmx_hip_${VAR:-lookahead}.so

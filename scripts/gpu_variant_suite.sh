@@ -13,6 +13,6 @@ export MMX_TEST_STAGED=1 # the tests of the staged per-rule instantiations too
 timeout 400 python -m pytest tests -q -m gpu < /dev/null > gpurun_out/variant_${VAR}_suite.txt 2>&1
 grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/variant_${VAR}_suite.txt | cut -c1-200 | tail -8
 MMX_FUZZ_SEEDS=200 MMX_FUZZ_JMAX=110 timeout 300 python -m pytest tests/test_gpu_fuzz.py -q -k "not wide" < /dev/null 2>&1 | grep -E "passed|failed|^FAILED" | cut -c1-200 | tail -4
-MMX_FUSED_PLAIN=1 MMX_CHOL_LEAN=1 timeout 400 python -m pytest tests -q -m gpu < /dev/null 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" | cut -c1-200 | tail -8
+MMX_FUSED_PLAIN=1 MMX_CHOL_LEAN=1 MMX_TREE_NE_WAVES=8 timeout 400 python -m pytest tests -q -m gpu < /dev/null 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" | cut -c1-200 | tail -8
 unset MMX_LIB
 INV_MORE=1 VAR=$VAR timeout 200 bash scripts/gpu_variant_ab.sh

@@ -586,8 +586,9 @@ def test_tree_moment_normal_equations_match_the_dense_product_on_the_wide_rig(to
         {"MMX_CHOL_RIGHT_LOOKING": "1"},  # ... right-looking factor in place (choleskyStepGlobalKernel)
         {"MMX_TREE_NE": "0", "MMX_TREE_REFINE": "0"},  # dense J^T J on the matrix cores
         {"MMX_CHOL_LEAN": "1"},  # the factor kernel with the production form alone (staged: MMX_TEST_STAGED=1)
+        {"MMX_TREE_NE_WAVES": "8"},  # tree normal equations by eight waves per workgroup (staged likewise)
     ],
-    ids=["tree", "dense_refine", "right_looking", "dense_product", "lean_factor"],
+    ids=["tree", "dense_refine", "right_looking", "dense_product", "lean_factor", "tree_8_waves"],
 )
 def test_wide_solve_variants_agree_with_the_oracle(torch_cuda, orc, variant, monkeypatch):
     """The four routes of the wide explicit solve (300-joint rig) under the LM schedule and with elements that
@@ -595,7 +596,7 @@ def test_wide_solve_variants_agree_with_the_oracle(torch_cuda, orc, variant, mon
     from momentum_amd import make_rig300
     from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
 
-    if "MMX_CHOL_LEAN" in variant:
+    if "MMX_CHOL_LEAN" in variant or "MMX_TREE_NE_WAVES" in variant:
         _staged()
     torch = torch_cuda
     for k, v in variant.items():
