@@ -36,8 +36,10 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 6 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
-                             trust_region_radius), mmx_comm_* (RCCL), MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J */
+#define MMX_ABI_VERSION 7 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
+                             trust_region_radius), mmx_comm_* (RCCL), MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J
+                             7: mmx_tuning / mmx_problem_set_tuning / mmx_problem_last_route (replace the MMX_* environment
+                             switches of earlier builds: the library reads no environment variable on the solve path) */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
@@ -352,6 +354,30 @@ int32_t mmx_problem_set_instance_parents(
     const int32_t* ori_parent,
     int32_t memory,
     void* stream);
+
+/*
+ * Which kernels mmx_solve runs.  The library picks by problem size (MMX_ROUTE_AUTO); a caller -- in practice a parity
+ * test that wants every route exercised on the same inputs, or a benchmark -- can pin the route per problem handle.
+ * A pinned route the problem does not fit makes mmx_solve return MMX_ERR_UNSUPPORTED; it never falls through silently.
+ *   MMX_ROUTE_FUSED              one launch, one workgroup per instance, the system in LDS (<= 224 solved parameters)
+ *   MMX_ROUTE_WIDE               normal equations from the tree moments, left-looking Cholesky with the factor in HBM,
+ *                                refinement through the tree (<= 512 solved parameters; the default from 177 on)
+ *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores) -> Cholesky step; the route for problems
+ *                                outside the tree kernels' scope
+ * Nothing here changes WHAT is computed (same algorithm, same refinement); results of different routes agree to
+ * rounding (tests/test_gpu_weak_damping.py, tests/test_gpu_fuzz.py).
+ */
+#define MMX_ROUTE_AUTO 0
+#define MMX_ROUTE_FUSED 1
+#define MMX_ROUTE_WIDE 2
+#define MMX_ROUTE_EXPLICIT_JACOBIAN 3
+typedef struct mmx_tuning {
+  int32_t route; /* MMX_ROUTE_* */
+  int32_t reserved[7]; /* must be zero */
+} mmx_tuning;
+int32_t mmx_problem_set_tuning(mmx_problem* problem, const mmx_tuning* tuning);
+/* MMX_ROUTE_* the last mmx_solve / mmx_solve_with_history on this handle took (MMX_ROUTE_AUTO before the first). */
+int32_t mmx_problem_last_route(const mmx_problem* problem);
 
 /* M = 3*Kp + 9*Ko + rows of the further blocks and parameter-space blocks
  * (JointErrorFunctionT::getJacobianSize, joint_error_function-inl.h:300-302). */

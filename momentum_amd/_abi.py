@@ -14,7 +14,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-MMX_ABI_VERSION = 6
+MMX_ABI_VERSION = 7
 MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
@@ -304,6 +304,15 @@ class GnOptions(C.Structure):
             float(lm_down),
             float(trust_region_radius),
         )
+
+
+ROUTES = {"auto": 0, "fused": 1, "wide": 2, "explicit_jacobian": 3}  # MMX_ROUTE_*
+
+
+class Tuning(C.Structure):
+    """mmx_tuning: which kernels mmx_solve runs (include/mmx.h)."""
+
+    _fields_ = [("route", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 def as_ptr(a: np.ndarray, ctype):

@@ -26,6 +26,7 @@ SYMBOLS = [
     "mmx_gn_options_default", "mmx_abi_version", "mmx_last_error", "mmx_device_count",
     "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
+    "mmx_problem_set_tuning", "mmx_problem_last_route",
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
@@ -69,6 +70,8 @@ def lib() -> C.CDLL:
     L.mmx_problem_num_rows.argtypes = [vp]
     L.mmx_problem_batch.argtypes = [vp]
     L.mmx_problem_set_enabled.argtypes = [vp, _abi.c_uint8_p]
+    L.mmx_problem_set_tuning.argtypes = [vp, C.POINTER(_abi.Tuning)]
+    L.mmx_problem_last_route.argtypes = [vp]
     L.mmx_problem_set_constraints.argtypes = [vp, C.POINTER(ConstraintData), vp]
     L.mmx_problem_set_instance_rig.argtypes = [vp, vp, vp, i32, vp]
     L.mmx_problem_set_instance_parents.argtypes = [vp, vp, vp, i32, vp]
@@ -202,6 +205,16 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+    # -- which kernels mmx_solve runs (mmx_tuning): "auto" | "fused" | "wide" | "explicit_jacobian"
+    def set_route(self, route: str) -> None:
+        t = _abi.Tuning()
+        t.route = _abi.ROUTES[route]
+        _check(lib().mmx_problem_set_tuning(self._h, C.byref(t)))
+
+    def last_route(self) -> str:
+        r = int(lib().mmx_problem_last_route(self._h))
+        return {v: k for k, v in _abi.ROUTES.items()}[r]
 
     # -- SolverT::setEnabledParameters
     def set_enabled(self, enabled) -> None:

@@ -214,6 +214,8 @@ struct mmx_problem {
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
   DevBuf sJacF64, sHessF64; // scratch of the double-precision solve
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
+  mmx_tuning tuning{}; // mmx_problem_set_tuning
+  int32_t lastRoute = MMX_ROUTE_AUTO;
 };
 
 namespace {
@@ -1110,6 +1112,30 @@ int32_t mmx_problem_batch(const mmx_problem* pb) {
   return pb ? pb->B : 0;
 }
 
+int32_t mmx_problem_set_tuning(mmx_problem* pb, const mmx_tuning* tuning) {
+  int32_t rc = checkProblem(pb, false);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (tuning == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "tuning is null");
+  }
+  if (tuning->route < MMX_ROUTE_AUTO || tuning->route > MMX_ROUTE_EXPLICIT_JACOBIAN) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_tuning::route: unknown MMX_ROUTE_* value");
+  }
+  for (int32_t r : tuning->reserved) {
+    if (r != 0) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_tuning::reserved must be zero");
+    }
+  }
+  pb->tuning = *tuning;
+  return MMX_OK;
+}
+
+int32_t mmx_problem_last_route(const mmx_problem* pb) {
+  return pb != nullptr ? pb->lastRoute : MMX_ROUTE_AUTO;
+}
+
 int32_t mmx_problem_set_enabled(mmx_problem* pb, const uint8_t* enabled) {
   MMX_ZONE("mmx_problem_set_enabled");
   int32_t rc = checkProblem(pb, false);
@@ -1791,10 +1817,21 @@ static int32_t solveImpl(
   // wide path's tree kernels cover the problem it is the faster route (72-joint humanoid, measured with scripts/gpu_route.sh:
   // n = 189: 4.2e5 against 3.2e5 solves/s, n = 219: 3.1e5 against 2.3e5; n = 126: 7.2e5 against 1.0e6, n = 96: 9.2e5 against
   // 1.57e6 -- below twelve 16-blocks the fused solve stays).  MMX_PREFER_FUSED=1 keeps the one-launch solve.
-  const bool forceWide = getenv("MMX_FORCE_WIDE") != nullptr; // measurement switch: the wide path for any size its tree kernels cover
+  const int32_t route = pb->tuning.route;
+  const bool forceWide = route == MMX_ROUTE_WIDE || (route == MMX_ROUTE_AUTO && getenv("MMX_FORCE_WIDE") != nullptr);
   const bool preferWide = (forceWide || mmx::fusedBlocksFor(pb->fdev.n) >= 12) && o->step_rule != MMX_STEP_TRUST_REGION &&
-      treeNormalEquationsUsable(pb) && getenv("MMX_PREFER_FUSED") == nullptr;
-  if (fusedUsable(pb) && !wantLegacySolver() && !preferWide && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION)) {
+      treeNormalEquationsUsable(pb) && route != MMX_ROUTE_FUSED && route != MMX_ROUTE_EXPLICIT_JACOBIAN &&
+      (route != MMX_ROUTE_AUTO || getenv("MMX_PREFER_FUSED") == nullptr);
+  const bool legacy = route == MMX_ROUTE_EXPLICIT_JACOBIAN || (route == MMX_ROUTE_AUTO && wantLegacySolver());
+  const bool takeFused = fusedUsable(pb) && !legacy && !preferWide && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION);
+  if (route == MMX_ROUTE_FUSED && !takeFused) {
+    return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_FUSED: the problem does not fit the one-launch solve (more than 224 solved parameters, or its tables beyond the LDS budget)");
+  }
+  if (route == MMX_ROUTE_WIDE && !preferWide) {
+    return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_WIDE: the problem is outside the tree kernels' scope (or the step rule is MMX_STEP_TRUST_REGION)");
+  }
+  if (takeFused) {
+    pb->lastRoute = MMX_ROUTE_FUSED;
     // fused path: the whole SolverT::solve loop in one launch, one workgroup per instance
     MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
     MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
@@ -1868,7 +1905,11 @@ static int32_t solveImpl(
   const bool wide = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024; // (the in-LDS Cholesky step does not fit)
   const bool rightLooking = getenv("MMX_CHOL_RIGHT_LOOKING") != nullptr && getenv("MMX_CHOL_RIGHT_LOOKING")[0] == '1';
   const bool treeFromMoments = treeNormalEquationsUsable(pb);
-  const bool treeRefine = (wide || preferWide) && treeFromMoments && !rightLooking && !(getenv("MMX_TREE_REFINE") != nullptr && getenv("MMX_TREE_REFINE")[0] == '0');
+  const bool treeRefine = (wide || preferWide) && treeFromMoments && !rightLooking && route != MMX_ROUTE_EXPLICIT_JACOBIAN && !(getenv("MMX_TREE_REFINE") != nullptr && getenv("MMX_TREE_REFINE")[0] == '0');
+  if (route == MMX_ROUTE_WIDE && !treeRefine) {
+    return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_WIDE: the tree-refined wide solve is not available for this problem");
+  }
+  pb->lastRoute = treeRefine ? MMX_ROUTE_WIDE : MMX_ROUTE_EXPLICIT_JACOBIAN;
   rc = ensureStepScratch(pb, !treeRefine);
   if (rc != MMX_OK) {
     return rc;
