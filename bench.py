@@ -213,19 +213,20 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n):
     if options.step_rule == 1 and out["num_above_bound"] > 0:
         # The LM gain-ratio schedule shrinks lambda towards 1e-4 and takes discrete decisions (rho against 0 / 0.25 / 0.75): on a
         # few instances single precision itself cannot hold the bound -- a gain ratio on a threshold goes the other (equally valid)
-        # way, or a weakly constrained direction amplifies the rounding of the late, barely damped steps.  The check for this rule:
-        # at least 99 % of the instances within the bound, and on EVERY instance above it the oracle's own float instantiation is
-        # above it too while the solve still converged (tests/test_gpu_baseline_parity.py::test_config3_lm_schedule_distinct_instances
+        # way, or a weakly constrained direction amplifies the rounding of the late, barely damped steps.  Reported beside the
+        # strict `pass` (pass_relaxed): at least 99 % of the instances within the bound, and on EVERY instance above it the
+        # oracle's own float instantiation is above it too while the solve still converged (tests/test_gpu_baseline_parity.py::test_config3_lm_schedule_distinct_instances
         # classifies by decisions instead).
         idx = np.nonzero(rel > PARITY_BOUND)[0]
-        sub = orc.Constraints(cons.pos_parent, cons.pos_offset[idx], cons.pos_target[idx], cons.pos_weight[idx], cons.ori_parent,
-                              cons.ori_offset[idx], cons.ori_target[idx], cons.ori_weight[idx])  # fmt: skip
+        sub = cons.subset(idx)  # (the same problem: joint blocks / limits / prior travel with the instances)
         r32 = orc.solve_batch(db.rig, sub, th0[idx], options, dtype="f32", nthreads=usable_cores())
         rel32 = np.linalg.norm(r32["theta"] - ref["theta"][idx], axis=1) / np.maximum(np.linalg.norm(ref["theta"][idx], axis=1), 1e-30)
         out["above_bound_float_oracle_rel"] = [float(x) for x in rel32]
         out["above_bound_float_oracle_also_above"] = bool(np.all(rel32 > PARITY_BOUND))
-        out["pass"] = bool(out["num_above_bound"] <= n // 100 and out["above_bound_float_oracle_also_above"])
-        out["pass_rule"] = ">= 99 % within the bound; every instance above it is above it in the oracle's float instantiation too"
+        # `pass` stays the strict bound; the rule for this schedule is reported beside it
+        out["pass_relaxed"] = bool(out["num_above_bound"] <= n // 100 and out["above_bound_float_oracle_also_above"])
+        out["pass_relaxed_rule"] = ">= 99 % within the bound; every instance above it is above it in the oracle's float instantiation too"
+        out["within_bound"] = f"{n - out['num_above_bound']}/{n}"
     return out
 
 
@@ -251,7 +252,7 @@ def cpu_baseline(db: DeviceBatch, sample, options, dtype="f32"):
         "unit": "solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"the first {sample} instances of the timed batch, {dtype}, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
+        "sample": f"the first {sample} instances of the timed batch, {dtype}, oracle built -O3 -march=native on {orc.host_cpu()}, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
         "single_thread_value": n1 / dt1,
     }
 

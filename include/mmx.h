@@ -58,8 +58,13 @@ typedef enum mmx_status {
 #define MMX_SOLVE_OK 0
 #define MMX_SOLVE_NONFINITE 1 /* NaN/Inf result -> theta reverted to theta_init
                                  (pymomentum/tensor_ik/tensor_ik.cpp:168-173) */
-#define MMX_SOLVE_NOT_PD 2 /* non-positive Cholesky pivot seen (dense LLT result is
-                              unchecked in the reference, gauss_newton_solver.cpp:251) */
+#define MMX_SOLVE_NOT_PD 2 /* a Cholesky pivot came out non-positive in single precision (J rank deficient and
+                              lambda below the rounding of J^T J).  Informational: the pivot is floored at 2^-20 of
+                              its row's H_jj + lambda, the factorisation completes and the step IS taken -- like the
+                              reference, which never checks LLT::info() (gauss_newton_solver.cpp:251); its double
+                              instantiation does not meet such pivots, its float instantiation hands Eigen's aborted
+                              factor to solve().  The refinement step pulls the step back to the true lambda wherever
+                              J determines it. */
 
 /* Where the caller's bulk arrays live. */
 #define MMX_MEM_HOST 0
@@ -547,6 +552,14 @@ int32_t mmx_debug_fused_normal_equations(
     int32_t* solve_list_host,
     int32_t* num_solved,
     void* stream);
+
+/*
+ * Parity hook of the wide route's first stage: H = J^T J (LOWER triangle of the n x n system written, the rest zero)
+ * and g = J^T r from the tree moments (treeNormalEquationsKernel), in the layout of mmx_eval_normal_equations, so that
+ * the two can be compared entry by entry.  Problems without structurally zero columns, inside the tree kernels' scope;
+ * MMX_ERR_UNSUPPORTED otherwise.
+ */
+int32_t mmx_debug_tree_normal_equations(mmx_problem* problem, const float* theta_dev, float* jtj_dev, float* jtr_dev, void* stream);
 
 /* Host-buffer convenience wrappers (the reference's boundary hands over host
  * memory): copy in, run on the handle's stream, copy out, synchronise. */

@@ -29,7 +29,7 @@ SYMBOLS = [
     "mmx_problem_set_tuning", "mmx_problem_last_route",
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
-    "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations",
+    "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations", "mmx_debug_tree_normal_equations",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
     "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
 ]  # fmt: skip
@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
     L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_solve_f64_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_eval_jacobian_host.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.mmx_debug_tree_normal_equations.argtypes = [vp, vp, vp, vp, vp]
     L.mmx_debug_fused_normal_equations.argtypes = [vp, vp, vp, vp, _abi.c_int32_p, _abi.c_int32_p, vp]
     L.mmx_comm_unique_id.argtypes = [vp]
     L.mmx_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
@@ -168,6 +169,11 @@ class RigHandle:
             pass
 
 
+# Route every Problem created from here on starts with ("auto" | "fused" | "wide" | "explicit_jacobian"): the parity tests
+# set it (monkeypatch.setattr) to send whole test bodies through one route; Problem.set_route changes it per handle.
+default_route = "auto"
+
+
 class Problem:
     """One batch of independent IK instances on one GPU (mmx_problem): the batched counterpart of
     one SkeletonSolverFunction + GaussNewtonSolver per element
@@ -194,6 +200,8 @@ class Problem:
                 as_ptr(self.ori_parent, C.c_int32), C.byref(self._h),
             )
         )  # fmt: skip
+        if default_route != "auto":
+            self.set_route(default_route)
 
     def close(self) -> None:
         if self._h:
@@ -367,6 +375,16 @@ class Problem:
         err = torch.empty((self.B,), dtype=torch.float64, device=self.device)
         _check(lib().mmx_eval_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), _dev(err), _stream_ptr()))
         return jtj, jtr, err
+
+    def tree_normal_equations(self, theta):
+        """Parity hook: (JtJ [B,n,n] lower triangle, Jtr [B,n]) from the tree moments (the wide route's first stage)."""
+        import torch
+
+        theta = self._theta(theta)
+        jtj = torch.empty((self.B, self.n, self.n), dtype=torch.float32, device=self.device)
+        jtr = torch.empty((self.B, self.n), dtype=torch.float32, device=self.device)
+        _check(lib().mmx_debug_tree_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), _stream_ptr()))
+        return jtj, jtr
 
     def fused_normal_equations(self, theta):
         """Parity hook: (solve_list [n], JtJ [B,n,n], Jtr [B,n]) as the fused kernel builds them."""

@@ -181,8 +181,7 @@ struct mmx_problem {
   bool instPos = false, instOri = false;
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
-  DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols, dColDesc;
-  DevBuf sJaJs, sJaUnits, sJaCols; // hand-over scratch of the two-kernel J assembly
+  DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
   DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb, dDfsJoint, dLoadedPos;
   DevBuf dLimStart, dLimOf, dPairDest, dPairStart, dPairLim, dPairCols;
   mmx::FusedDev fdev{};
@@ -397,21 +396,6 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         } else {
           multi.push_back(p);
         }
-      }
-      // per-column descriptors of the two-kernel form (jacobianColumnsKernel)
-      {
-        std::vector<int32_t> desc(size_t(rig->P) * 4, 0);
-        for (const mmx::JacRec& rc1 : recs) {
-          int32_t wbits;
-          std::memcpy(&wbits, &rc1.weight, 4);
-          int32_t* o = desc.data() + size_t(rc1.col) * 4;
-          o[0] = 1, o[1] = rc1.joint | (rc1.dof << 16), o[2] = rc1.tin | (rc1.tout << 16), o[3] = wbits;
-        }
-        for (int32_t p : multi) {
-          desc[size_t(p) * 4] = 2;
-        }
-        MMX_HIP(upload(pb->dColDesc, desc));
-        d.colDesc = pb->rig->J < 65536 ? pb->dColDesc.as<int4>() : nullptr;
       }
       std::stable_sort(recs.begin(), recs.end(), [](const mmx::JacRec& a, const mmx::JacRec& b) {
         return a.joint != b.joint ? a.joint < b.joint : a.dof < b.dof;
@@ -773,10 +757,7 @@ bool fusedUsable(const mmx_problem* pb) {
     return false;
   }
   // (the further joint-constraint blocks and ellipsoid limits ride along as a dense block of rows in LDS -- fdev.GT /
-  // genRows -- while they fit; MMX_FUSED_GENERAL=0 sends them to the explicit-Jacobian kernels)
-  if (pb->fdev.GT > 0 && getenv("MMX_FUSED_GENERAL") != nullptr && getenv("MMX_FUSED_GENERAL")[0] == '0') {
-    return false;
-  }
+  // genRows -- while they fit; MMX_ROUTE_EXPLICIT_JACOBIAN sends them to the explicit-Jacobian kernels)
   return pb->rig->J < 4096 &&
       mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rigDev.numLevels, pb->fdev.GT, pb->fdev.genRows) +
           size_t(8) * size_t(pb->rig->J + pb->rig->P) <=
@@ -786,10 +767,6 @@ bool fusedUsable(const mmx_problem* pb) {
 // H and g of the explicit-Jacobian solver from the tree moments instead of the dense J (treeNormalEquationsKernel):
 // the same solve list on both sides, everything within the kernels' LDS
 bool treeNormalEquationsUsable(const mmx_problem* pb) {
-  const char* e = getenv("MMX_TREE_NE");
-  if (e != nullptr && e[0] == '0') {
-    return false;
-  }
   // (limit / model-parameter rows ride along: evaluated on the fly from theta like in the fused solve; the further joint
   // error functions and ellipsoid limits as a dense block of rows in LDS while it fits)
   return pb->U > 0 && pb->fdev.n > 0 && pb->fdev.n <= 512 && pb->fdev.nsrc < 4096 &&
@@ -798,21 +775,12 @@ bool treeNormalEquationsUsable(const mmx_problem* pb) {
       mmx::treeRefineLdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->fdev.n, pb->fdev.genRows) <= 160 * 1024 - 64;
 }
 
-bool wantLegacySolver() {
-  const char* e = getenv("MMX_SOLVER");
-  return e != nullptr && std::string(e) == "v1";
-}
-
-// hand-over scratch of the two-kernel J assembly (4 (kJs J + 5 U + 8 P) bytes per instance)
-int32_t ensureJacobianScratch(mmx_problem* pb) {
-  const size_t B = size_t(pb->B);
-  MMX_HIP(pb->sJaJs.ensure(B * size_t(pb->rig->J) * mmx::kJs * sizeof(float)));
-  MMX_HIP(pb->sJaUnits.ensure(B * 5 * size_t(std::max(pb->U, 1)) * sizeof(float)));
-  pb->dev.jaJs = pb->sJaJs.as<float>();
-  MMX_HIP(pb->sJaCols.ensure(B * size_t(pb->rig->P) * 8 * sizeof(float)));
-  pb->dev.jaUnits = pb->sJaUnits.as<float>();
-  pb->dev.jaCols = pb->sJaCols.as<float>();
-  return MMX_OK;
+// profiling aid (one of the library's two environment reads; the other is MMX_NO_ROCTX, the marker switch): per-phase cycle
+// counters of workgroup 0, printed to stderr after the solve.  Not on any product path: the clocked instantiation is a
+// separate kernel.
+bool phaseClocksWanted() {
+  static const bool wanted = getenv("MMX_PHASE_CLOCKS") != nullptr;
+  return wanted;
 }
 
 int32_t checkProblem(const mmx_problem* pb, bool needConstraints) {
@@ -1572,12 +1540,6 @@ int32_t mmx_eval_jacobian(
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (jac_dev != nullptr) {
-    rc = ensureJacobianScratch(pb);
-    if (rc != MMX_OK) {
-      return rc;
-    }
-  }
   if (layout == MMX_LAYOUT_ROW_MAJOR && jac_dev != nullptr) {
     // assembled column-major (the layout the kernel's coalesced column stores are built for) into the
     // problem's scratch, then transposed per instance: one extra read + write of J
@@ -1610,10 +1572,6 @@ int32_t mmx_eval_jacobian_timed(
     return fail(MMX_ERR_UNSUPPORTED, "only MMX_LAYOUT_COL_MAJOR (the reference's layout) is implemented");
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
-  rc = ensureJacobianScratch(pb);
-  if (rc != MMX_OK) {
-    return rc;
-  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   MMX_HIP(hipEventCreate(&e0));
   hipError_t err = hipEventCreate(&e1);
@@ -1684,10 +1642,6 @@ int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* 
 
 namespace {
 int32_t ensureStepScratch(mmx_problem* pb, bool needJacobian = true) {
-  const int32_t rcj = ensureJacobianScratch(pb);
-  if (rcj != MMX_OK) {
-    return rcj;
-  }
   const size_t B = size_t(pb->B), M = size_t(pb->M), P = size_t(pb->rig->P), n = size_t(pb->dev.n);
   if (needJacobian) {
     MMX_HIP(pb->sJac.ensure(B * M * P * sizeof(float)));
@@ -1726,19 +1680,27 @@ int32_t mmx_eval_normal_equations(
   }
   MMX_HIP(mmx::launchFkJacobian(
       pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), err_dev, nullptr, nullptr, s));
-  {
-    const char* e = getenv("MMX_TREE_NE"); // parity hook: "force" = the tree-moment kernel (lower triangle of the solve-list system)
-    if (e != nullptr && std::string(e) == "force") {
-      if (!treeNormalEquationsUsable(pb) || pb->solveN != pb->dev.n) {
-        return fail(MMX_ERR_UNSUPPORTED, "MMX_TREE_NE=force: problem outside the tree-moment kernel's scope (or structurally zero columns present)");
-      }
-      MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
-      MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, nullptr, false, s));
-      return MMX_OK;
-    }
-  }
   MMX_HIP(mmx::launchNormalEquations(
       pb->dev, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), jtj_dev, jtr_dev, nullptr, false, s));
+  return MMX_OK;
+}
+
+int32_t mmx_debug_tree_normal_equations(mmx_problem* pb, const float* theta_dev, float* jtj_dev, float* jtr_dev, void* stream) {
+  MMX_ZONE("mmx_debug_tree_normal_equations");
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_dev == nullptr || jtj_dev == nullptr || jtr_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta / jtj / jtr is null");
+  }
+  if (!treeNormalEquationsUsable(pb) || pb->solveN != pb->dev.n) {
+    return fail(MMX_ERR_UNSUPPORTED, "mmx_debug_tree_normal_equations: problem outside the tree-moment kernel's scope (or structurally zero columns present)");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
+  MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, nullptr, false, s));
   return MMX_OK;
 }
 
@@ -1816,13 +1778,12 @@ static int32_t solveImpl(
   // Systems of 161-224 solved parameters fit the fused solve only with one workgroup per CU (78-105 KB of tiles): when the
   // wide path's tree kernels cover the problem it is the faster route (72-joint humanoid, measured with scripts/gpu_route.sh:
   // n = 189: 4.2e5 against 3.2e5 solves/s, n = 219: 3.1e5 against 2.3e5; n = 126: 7.2e5 against 1.0e6, n = 96: 9.2e5 against
-  // 1.57e6 -- below twelve 16-blocks the fused solve stays).  MMX_PREFER_FUSED=1 keeps the one-launch solve.
+  // 1.57e6 -- below twelve 16-blocks the fused solve stays).  mmx_tuning::route pins either.
   const int32_t route = pb->tuning.route;
-  const bool forceWide = route == MMX_ROUTE_WIDE || (route == MMX_ROUTE_AUTO && getenv("MMX_FORCE_WIDE") != nullptr);
+  const bool forceWide = route == MMX_ROUTE_WIDE;
   const bool preferWide = (forceWide || mmx::fusedBlocksFor(pb->fdev.n) >= 12) && o->step_rule != MMX_STEP_TRUST_REGION &&
-      treeNormalEquationsUsable(pb) && route != MMX_ROUTE_FUSED && route != MMX_ROUTE_EXPLICIT_JACOBIAN &&
-      (route != MMX_ROUTE_AUTO || getenv("MMX_PREFER_FUSED") == nullptr);
-  const bool legacy = route == MMX_ROUTE_EXPLICIT_JACOBIAN || (route == MMX_ROUTE_AUTO && wantLegacySolver());
+      treeNormalEquationsUsable(pb) && route != MMX_ROUTE_FUSED && route != MMX_ROUTE_EXPLICIT_JACOBIAN;
+  const bool legacy = route == MMX_ROUTE_EXPLICIT_JACOBIAN;
   const bool takeFused = fusedUsable(pb) && !legacy && !preferWide && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION);
   if (route == MMX_ROUTE_FUSED && !takeFused) {
     return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_FUSED: the problem does not fit the one-launch solve (more than 224 solved parameters, or its tables beyond the LDS budget)");
@@ -1855,7 +1816,7 @@ static int32_t solveImpl(
     fp.threshold = o->threshold;
     fp.minIterations = o->min_iterations;
     fp.maxIterations = o->max_iterations;
-    fp.refine = getenv("MMX_NO_REFINE") != nullptr ? 0 : 1; // experiment switch; parity needs the refinement
+    fp.refine = 1;
     fp.doLineSearch = o->do_line_search;
     fp.stepRule = o->step_rule;
     fp.lmLambdaMin = o->lm_lambda_min;
@@ -1864,7 +1825,7 @@ static int32_t solveImpl(
     fp.lmDown = o->lm_down;
     fp.trustRadius = o->trust_region_radius > 0.f ? o->trust_region_radius : 1.f;
     long long* clk = nullptr;
-    if (getenv("MMX_PHASE_CLOCKS") != nullptr) { // profiling aid: per-phase cycles of block 0
+    if (phaseClocksWanted()) { // profiling aid: per-phase cycles of block 0
       MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
       MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
       clk = pb->sClk.as<long long>();
@@ -1894,18 +1855,17 @@ static int32_t solveImpl(
     return MMX_OK;
   }
   if (o->step_rule == MMX_STEP_TRUST_REGION) {
-    return fail(MMX_ERR_UNSUPPORTED, "MMX_STEP_TRUST_REGION lives in the fused solver: not available for problems that take the explicit-Jacobian kernels (further joint blocks, ellipsoid limits, MMX_SOLVER=v1, systems beyond the fused instantiations)");
+    return fail(MMX_ERR_UNSUPPORTED, "MMX_STEP_TRUST_REGION lives in the fused solver: not available for problems that take the explicit-Jacobian kernels (further joint blocks, ellipsoid limits, MMX_ROUTE_EXPLICIT_JACOBIAN, systems beyond the fused instantiations)");
   }
   if (n > 512) {
     return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
   }
-  // Wide systems (the in-LDS Cholesky step does not fit) whose rows are position / orientation constraints only:
-  // normal equations from the tree moments, left-looking factor in HBM, refinement through the tree.  No dense J is
-  // written or read (MMX_TREE_REFINE=0: the refinement streams a dense J instead; MMX_TREE_NE=0: the dense product too).
+  // Wide systems (the in-LDS Cholesky step does not fit) inside the tree kernels' scope: normal equations from the tree
+  // moments, left-looking factor in HBM, refinement through the tree.  No dense J is written or read.
+  // MMX_ROUTE_EXPLICIT_JACOBIAN (and problems outside the tree kernels' scope): dense J, J^T J on the matrix cores,
+  // the refinement streams J.
   const bool wide = mmx::choleskyStepLdsBytes(ds.n, ds.M) > 160 * 1024; // (the in-LDS Cholesky step does not fit)
-  const bool rightLooking = getenv("MMX_CHOL_RIGHT_LOOKING") != nullptr && getenv("MMX_CHOL_RIGHT_LOOKING")[0] == '1';
-  const bool treeFromMoments = treeNormalEquationsUsable(pb);
-  const bool treeRefine = (wide || preferWide) && treeFromMoments && !rightLooking && route != MMX_ROUTE_EXPLICIT_JACOBIAN && !(getenv("MMX_TREE_REFINE") != nullptr && getenv("MMX_TREE_REFINE")[0] == '0');
+  const bool treeRefine = (wide || preferWide) && treeNormalEquationsUsable(pb) && route != MMX_ROUTE_EXPLICIT_JACOBIAN;
   if (route == MMX_ROUTE_WIDE && !treeRefine) {
     return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_WIDE: the tree-refined wide solve is not available for this problem");
   }
@@ -1948,7 +1908,7 @@ static int32_t solveImpl(
   sp.threshold = o->threshold;
   sp.minIterations = o->min_iterations;
   sp.maxIterations = o->max_iterations;
-  sp.refine = getenv("MMX_NO_REFINE") != nullptr ? 0 : 1;
+  sp.refine = 1;
   sp.delta = deferred ? pb->sDelta.as<float>() : nullptr;
   sp.stepIter = deferred ? pb->sStepIter.as<int32_t>() : nullptr;
   sp.lambdaPer = schedule ? pb->sLambda.as<float>() : nullptr;
@@ -1958,13 +1918,13 @@ static int32_t solveImpl(
   sp.lmLambdaMax = o->lm_lambda_max;
   sp.lmUp = o->lm_up;
   sp.lmDown = o->lm_down;
-  if (getenv("MMX_PHASE_CLOCKS") != nullptr) {
+  if (phaseClocksWanted()) {
     MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
     MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
     sp.clk = pb->sClk.as<long long>();
   }
   float* factorScratch = nullptr; // wide systems: the left-looking Cholesky step keeps L in its own tile-major scratch
-  if ((wide && !rightLooking) || treeRefine) {
+  if (wide || treeRefine) {
     MMX_HIP(pb->sFactor.ensure(size_t(B) * mmx::choleskyFactorFloats(ds.n) * sizeof(float)));
     factorScratch = pb->sFactor.as<float>();
   }
@@ -1990,7 +1950,7 @@ static int32_t solveImpl(
         MMX_ZONE("Get JtJ and JtR");
         MMX_HIP(mmx::launchTreeNormalEquations(
             pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, pb->sErr.as<double>(),
-            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, genState, getenv("MMX_TREE_ROWMAJOR") == nullptr, s));
+            pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, genState, true, s));
       }
       MMX_ZONE("Dense gauss newton step");
       MMX_HIP(mmx::launchCholeskyFactorTiled(
@@ -2011,15 +1971,8 @@ static int32_t solveImpl(
         MMX_ZONE("Get JtJ and JtR");
         MMX_HIP(mmx::launchFkJacobian(
             pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
-        if (wide && treeFromMoments) {
-          // H and g from the tree moments, O(n^2) per instance, J not read (J itself is still assembled above: the
-          // Cholesky step's refinement streams it)
-          MMX_HIP(mmx::launchTreeNormalEquations(
-              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, nullptr, nullptr, nullptr, nullptr, false, s));
-        } else {
-          MMX_HIP(mmx::launchNormalEquations(
-              ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, wide, s));
-        }
+        MMX_HIP(mmx::launchNormalEquations(
+            ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, wide, s));
       }
       {
         MMX_ZONE("Dense gauss newton step");

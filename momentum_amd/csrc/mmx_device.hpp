@@ -22,6 +22,16 @@ namespace mmx {
 
 constexpr int kJs = 21; // floats per joint in js[]: 17 used, odd stride (lanes = joints read a field without LDS bank conflicts)
 constexpr int kAlt = 9; // floats per joint in the second pointer-jumping buffer: 8 used, odd stride
+// Pivot floor of every single-precision Cholesky in this library: column j's pivot d_jj = (H_jj + lambda) - sum_k l_jk^2 is
+// replaced by max(d_jj, kPivotFloor * (H_jj + lambda)).  In exact arithmetic d_jj >= lambda > 0; in fp32 the subtraction
+// leaves a rounding error of ~ sqrt(n) * 6e-8 * H_jj, so when J is rank deficient or nearly so and lambda is small (the
+// reference's own IK test runs lambda = 1e-7, inverse_kinematics_test.cpp:114) the computed pivot is noise of either sign.
+// The reference's double instantiation never sees that; its float instantiation hands Eigen's aborted factor to solve()
+// unchecked (gauss_newton_solver.cpp:251).  With the floor the factor is that of H + lambda I + E, E >= 0 diagonal and
+// only non-zero in the directions J does not determine; the refinement step measures its residual with the true lambda
+// through J and moves the step back wherever J determines it.  Pivots above the floor -- every problem whose H + lambda I
+// is numerically positive definite -- are untouched bit for bit.  16 ulp.
+constexpr float kPivotFloor = 9.5367431640625e-7f; // 2^-20
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {
@@ -242,12 +252,6 @@ struct ProblemDev {
   const int32_t* instPosParent;
   const int32_t* instOriParent;
   const int32_t* jointTin; // [J]
-  // ---- two-kernel J assembly: per-column descriptors and the hand-over scratch of the problem
-  // colDesc[p] = {kind (0 zero, 1 one rotation source, 2 generic gather), joint | dof << 16, tin | tout << 16, weight bits}
-  const int4* colDesc; // [P]
-  float* jaJs; // [B][J][kJs] joint states written by fkJacobianKernel<false>, read by jacobianColumnsKernel (or null)
-  float* jaUnits; // [B][5][U] evaluated units (v, sigma, DFS index) (or null)
-  float* jaCols; // [B][P][8] one record per column: joint translation, rotation axis, weight, DFS interval (or null)
 };
 
 // ---------------------------------------------------------------------------------------------

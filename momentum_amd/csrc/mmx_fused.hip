@@ -774,7 +774,7 @@ __device__ __forceinline__ int buildInstanceUnitTables(
 // they carry from iteration to iteration are compiled out (cfg2: 15.0 k / 19.1 k instead of 27.0 k instructions, 6 / 9
 // instead of 36 spilled vector registers, 352 / 380 instead of 456 spilled scalar registers).  (2 = a line search only:
 // compiles, but spills MORE than the generic instantiation -- 68 vector registers -- and is not instantiated.)
-// Launched only with MMX_FUSED_PLAIN=1 until they have been through the GPU suite (launchFusedNB).
+// Round 3, one box: plain Gauss-Newton +2.1 %, LM schedule +2.5 % over the generic instantiation; parity unchanged.
 template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     RigDev rig,
@@ -788,11 +788,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     long long* __restrict__ dbgClk) { // [32] or null: per-phase cycle counts of block 0 (profiling aid)
   constexpr int T = NB * (NB + 1) / 2; // lower-triangle tiles
   constexpr int NP = 16 * NB; // padded system size
-#ifdef MMX_EXP_LOOKAHEAD
-  // experiment: the left-looking updates of block column k + 1 by the columns before k ride under panel k's elimination
-  // chain (waves without a panel row); NB <= 8: wave 3 never holds one
+  // lookahead: the left-looking updates of block column k + 1 by the columns before k ride under panel k's elimination
+  // chain (waves without a panel row); NB <= 8: wave 3 never holds one (round 3, measured on one box: +2.2 % on cfg2)
   constexpr bool kLook = NB <= 8;
-#endif
   long long clkLast = 0;
 #define MMX_CLK(slot)                                             \
   if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) {         \
@@ -1015,7 +1013,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     int trustStep = 0;
     bool trNoStep = false; // the step is not worth taking (:164) or could not be computed: the parameters stay
     float trDn2 = 0.f, trDg = 0.f, trMu = 0.f; // |step|^2, step . J^T r, damping of the step on the table
-    bool notPd = false;
+    bool notPd = false; // (kept false since the pivot floor: the factorisation always completes and the step is always taken, as in
+                        // the reference, which never looks at LLT::info(); the branches it guards are dead code the compiler removes)
+    bool badPivot = false; // a raw pivot was not positive: reported as MMX_SOLVE_NOT_PD
     for (;;) {
     int tidT = tid;
     if (kTR) { // (no per-thread invariant of the body is to live across the re-solve loops either)
@@ -1360,7 +1360,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     }
     for (int c = tid; c < NP; c += 256) {
       float* dg = s.L + 256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15);
-      *dg = c < n ? *dg + muFactor : 1.f;
+      const float hd = c < n ? *dg + muFactor : 1.f;
+      *dg = hd;
+      s.invDiag[c] = kPivotFloor * hd; // the row's pivot floor until the panel pass of its block leaves 1 / l_cc here
     }
     if (MODE == 1 && it == 0) {
       for (int c = tid; c < n; c += 256) {
@@ -1377,7 +1379,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     for (int k = 0; k < NB; ++k) {
       // (u) bring block column k up to date: tile(I,k) -= sum_{j<k} L(I,j) L(k,j)^T.  A tile is
       //     read once, takes all its 4 k MFMAs (two accumulators: even / odd j) and is written once.
-#ifdef MMX_EXP_LOOKAHEAD
       // tile (I, kc) -= sum_{j0 <= j < j1} L(I,j) L(kc,j)^T
       auto updateTile = [&](int I, int kc, int j0, int j1) {
         float* Tc = s.L + 256 * tileIndex(I, kc);
@@ -1407,7 +1408,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         }
       };
       if (k > 0) {
-        // (lookahead experiment: the contributions of the block columns before k - 1 were taken during panel k - 1 by the
+        // (lookahead: the contributions of the block columns before k - 1 were taken during panel k - 1 by the
         // waves that had no panel row, see below -- only column k - 1's is left)
         const int jFirst = (kLook && k >= 2) ? k - 1 : 0;
         for (int I = k + wave; I < NB; I += 4) {
@@ -1415,38 +1416,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         }
         __syncthreads();
       }
-#else
-      if (k > 0) {
-        for (int I = k + wave; I < NB; I += 4) {
-          float* Tc = s.L + 256 * tileIndex(I, k);
-          v4f c0, c1{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            c0[r] = Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)];
-          }
-          for (int j = 0; j < k; ++j) {
-            const float4 av = ldsRow4(s.L + 256 * tileIndex(I, j), lane & 15, lane >> 4);
-            const float4 bv = ldsRow4(s.L + 256 * tileIndex(k, j), lane & 15, lane >> 4);
-            if (j & 1) {
-              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c1, 0, 0, 0);
-              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c1, 0, 0, 0);
-              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c1, 0, 0, 0);
-              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c1, 0, 0, 0);
-            } else {
-              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c0, 0, 0, 0);
-              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c0, 0, 0, 0);
-              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c0, 0, 0, 0);
-              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c0, 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            Tc[tileAddr(4 * (lane >> 4) + r, lane & 15)] = c0[r] + c1[r];
-          }
-        }
-        __syncthreads();
-      }
-#endif
       MMX_CLK(14)
       // (b+c) panel factorisation: every wave holds the 16 rows of the diagonal block in lanes
       //     0..15 (redundantly) and 48 rows of the panel below it in lanes 16..63, one row of 16
@@ -1465,7 +1434,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         const bool panelLane = !diagLane && !identLane && prow < NP;
         // waves whose 48 virtual rows all lie beyond the matrix only wait (wave-uniform branch)
         const bool waveWorks = wave == 0 || 16 * k + 48 * wave < NP;
-#ifdef MMX_EXP_LOOKAHEAD
         if (kLook && !waveWorks && k >= 1 && k + 1 < NB) {
           // lookahead: the waves without a panel row bring block column k + 1 up to date with the finished columns
           // j < k while the others run the elimination chain (disjoint tiles: column k is the chain's)
@@ -1474,7 +1442,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
             updateTile(I, k + 1, 0, k);
           }
         }
-#endif
         float* Tl = panelLane ? s.L + 256 * tileIndex(prow >> 4, k) : Dk;
         const int trow = diagLane ? lane : (panelLane ? (prow & 15) : vrow);
         float a[16];
@@ -1499,10 +1466,14 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         float invd = 0.f;
         bool bad = false;
         if (waveWorks) {
+          const float floorRow = s.invDiag[16 * k + (lane & 15)]; // kPivotFloor * (H_rr + lambda) of the diagonal lanes' rows
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            const float djj = readLaneF(a[j], j);
-            bad = bad || !(djj > 0.f);
+            const float draw = readLaneF(a[j], j);
+            bad = bad || !(draw > 0.f);
+            // pivot floor (see kPivotFloor): off the dependent chain except for the one v_max
+            const float djj = fmaxf(draw, readLaneF(floorRow, j));
+            a[j] = lane == j ? djj : a[j];
             const float inv = __builtin_amdgcn_rsqf(djj); // 1 / l_jj ; l_jj = d_jj * inv
             a[j] *= inv;
             if (lane == j) {
@@ -1573,7 +1544,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       MMX_CLK(13)
     }
     __syncthreads();
-    notPd = s.flags[1] != 0;
+    badPivot = s.flags[1] != 0;
     MMX_CLK(7)
 
     // ================= I: d0 = (L L^T)^-1 g
@@ -1963,7 +1934,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         st.errorHistory[size_t(b) * fp.maxIterations + it] = e;
       }
       itersDone = it + 1;
-      if (notPd) {
+      if (badPivot) {
         s.flags[2] = 2; // MMX_SOLVE_NOT_PD
       }
       const bool converged = fabs(lastError - e) / (fabs(e) + double(FLT_MIN)) <= double(fp.threshold) * double(FLT_EPSILON);
@@ -2517,31 +2488,24 @@ hipError_t launchTreeNormalEquations(
     return hipErrorInvalidValue;
   }
   const bool extra = pb.M > pb.rowsJoint || fd.GT > 0 || pb.instPosParent != nullptr || pb.instOriParent != nullptr;
-  static LdsLimitCache ldsLimit[2];
+  if (!extra) { // eight waves per workgroup (one workgroup per CU either way: the LDS footprint decides); cfg5: +12 %
+    static LdsLimitCache ldsLimit8;
+    hipError_t rc = ldsLimit8.ensure(reinterpret_cast<const void*>(treeNormalEquationsKernel<false, 8>), lds);
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    hipLaunchKernelGGL((treeNormalEquationsKernel<false, 8>), dim3(pb.B), dim3(512), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
+    return hipGetLastError();
+  }
+  // parameter-space rows, further joint blocks or per-instance parents: four waves (their helpers stride by 256 threads)
+  static LdsLimitCache ldsLimit;
   {
-    hipError_t rc = ldsLimit[extra ? 1 : 0].ensure(
-        extra ? reinterpret_cast<const void*>(treeNormalEquationsKernel<true>) : reinterpret_cast<const void*>(treeNormalEquationsKernel<false>), lds);
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(treeNormalEquationsKernel<true>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
   }
-  if (!extra) { // staged: eight waves per workgroup (MMX_TREE_NE_WAVES=8), not the default until it has run on a GPU
-    const char* we = getenv("MMX_TREE_NE_WAVES");
-    if (we != nullptr && we[0] == '8') {
-      static LdsLimitCache ldsLimit8;
-      hipError_t rc = ldsLimit8.ensure(reinterpret_cast<const void*>(treeNormalEquationsKernel<false, 8>), lds);
-      if (rc != hipSuccess) {
-        return rc;
-      }
-      hipLaunchKernelGGL((treeNormalEquationsKernel<false, 8>), dim3(pb.B), dim3(512), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
-      return hipGetLastError();
-    }
-  }
-  if (extra) {
-    hipLaunchKernelGGL(treeNormalEquationsKernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
-  } else {
-    hipLaunchKernelGGL(treeNormalEquationsKernel<false>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
-  }
+  hipLaunchKernelGGL(treeNormalEquationsKernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -2891,15 +2855,12 @@ static hipError_t launchFusedNB(
   if (dbgH != nullptr || dbgG != nullptr) {
     return launchFusedMode<NB, 1, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
   }
-  {
-    const char* e = getenv("MMX_FUSED_PLAIN"); // the instantiations per step rule (kRule): no parameter-space rows
-    if (e != nullptr && e[0] == '1' && pb.M == pb.rowsJoint) {
-      if (fp.stepRule == 0 && fp.doLineSearch == 0) {
-        return launchFusedMode<NB, 0, false, false, 0>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
-      }
-      if (fp.stepRule == 1) {
-        return launchFusedMode<NB, 0, false, false, 1>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
-      }
+  if (pb.M == pb.rowsJoint) { // no parameter-space rows: the instantiations per step rule (kRule)
+    if (fp.stepRule == 0 && fp.doLineSearch == 0) {
+      return launchFusedMode<NB, 0, false, false, 0>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+    }
+    if (fp.stepRule == 1) {
+      return launchFusedMode<NB, 0, false, false, 1>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
     }
   }
   return launchFusedMode<NB, 0, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);

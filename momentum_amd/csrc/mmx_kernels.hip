@@ -227,10 +227,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     double* __restrict__ err, // [B] or null
     float* __restrict__ state, // [B][J][8] or null
     const int32_t* __restrict__ done, // [B] or null: skip finished instances
-    int zeroPhase, // when the structurally zero columns are written: 0 first, 1 alternating, 2 last
-    float* __restrict__ jsOut, // [B][J][kJs] or null: the joint states (world transforms + rotation axes) ...
-    float* __restrict__ unitOut, // [B][5][U] or null: ... the evaluated units (v, sigma, DFS index) ...
-    float* __restrict__ colOut) { // [B][P][8] or null: ... and one record per column (see jacobianColumnsKernel)
+    int zeroPhase) { // when the structurally zero columns are written: 0 first, 1 alternating, 2 last
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // one 20-float slot per joint, used in place: [0..7] local t,s,q -> world t,q,s ; [8..15] partial
   // rotations q1,q2 -> [8..16] rotation axes
@@ -288,7 +285,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
       preB[d] = rig.preRot[4 * (tid + NT) + d];
     }
   }
-  const bool needUnits = kWriteJac || res != nullptr || err != nullptr || unitOut != nullptr;
+  const bool needUnits = kWriteJac || res != nullptr || err != nullptr;
   UnitInput uin0 = loadUnitInput(pb, b, needUnits ? lane : pb.U);
   for (int i = tid; i < rig.P; i += NT) {
     thL[i] = th[i];
@@ -385,7 +382,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     }
   }
   __syncthreads();
-  if (kWriteJac || jsOut != nullptr || colOut != nullptr) {
+  if (kWriteJac) {
     if (tid < rig.J) {
       fkAxesInPlaceQ(preA, tid, (jl[tid] >> 16) - 1, js);
     }
@@ -403,43 +400,9 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
       so[i] = js[kJs * (i >> 3) + (i & 7)];
     }
   }
-  if (jsOut != nullptr) { // hand-over to the column kernel: 4 * kJs * J bytes per instance (6 % of J at cfg2)
-    float* jo = jsOut + size_t(b) * size_t(rig.J) * kJs;
-    for (int i = tid; i < rig.J * kJs; i += NT) {
-      jo[i] = js[i];
-    }
-  }
-  if (colOut != nullptr) {
-    // one 32-byte record per column, so that the column kernel needs ONE round of loads whose addresses do
-    // not depend on any table: joint translation (3), rotation axis (3), weight, tin | tout << 16.
-    // Structurally zero columns: weight 0 and an empty interval; generic columns: interval 0xffff / 0xffff.
-    float* co = colOut + size_t(b) * size_t(rig.P) * 8;
-    for (int p = tid; p < rig.P; p += NT) {
-      const int4 d = pb.colDesc[p];
-      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (d.x == 1) {
-        const float* a = js + kJs * (d.y & 0xffff);
-        const float* axp = a + 8 + 3 * ((d.y >> 16) - 3);
-        o[0] = a[0], o[1] = a[1], o[2] = a[2], o[3] = axp[0], o[4] = axp[1], o[5] = axp[2];
-        o[6] = __int_as_float(d.w);
-        o[7] = __int_as_float(d.z);
-      } else if (d.x == 2) {
-        o[7] = __int_as_float(-1);
-      }
-      float4* dst = reinterpret_cast<float4*>(co + 8 * size_t(p));
-      dst[0] = float4{o[0], o[1], o[2], o[3]};
-      dst[1] = float4{o[4], o[5], o[6], o[7]};
-    }
-  }
-  if (!kWriteJac && res == nullptr && err == nullptr && unitOut == nullptr) {
+  if (!kWriteJac && res == nullptr && err == nullptr) {
     return;
   }
-  auto dumpUnit = [&](const Unit& un, int u) {
-    if (unitOut != nullptr && un.valid) {
-      float* uo = unitOut + size_t(b) * 5 * size_t(pb.U) + u;
-      uo[0] = un.v.x, uo[pb.U] = un.v.y, uo[2 * size_t(pb.U)] = un.v.z, uo[3 * size_t(pb.U)] = un.sigma, uo[4 * size_t(pb.U)] = __int_as_float(un.tin);
-    }
-  };
 
   double errAcc = 0.0;
   const size_t M = size_t(pb.M);
@@ -504,9 +467,6 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     if (res != nullptr && un.valid && wave == 0) {
       store3<false>(res + size_t(b) * M + 3 * size_t(lane), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
     }
-    if (wave == 0) {
-      dumpUnit(un, lane);
-    }
     if (kWriteJac) {
       writeUnitColumns<WPI, kStream>(pb, js, un, jac + size_t(b) * M * size_t(rig.P) + 3 * size_t(lane), M, wave);
     }
@@ -518,9 +478,6 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     if (res != nullptr && un.valid && wave == 0) {
       store3<false>(res + size_t(b) * M + 3 * size_t(u), un.sigma * un.f.x, un.sigma * un.f.y, un.sigma * un.f.z);
     }
-    if (wave == 0) {
-      dumpUnit(un, u);
-    }
   }
   }
   if (kWriteJac && zeroLast && !manyUnits) {
@@ -531,96 +488,6 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
     if (tid == 0) {
       err[b] = e;
     }
-  }
-}
-
-// =============================================================================================
-// Kernel 1': the columns of J from the handed-over joint states and units (two-kernel J assembly).
-// fkJacobianKernel<false> runs FK once per instance and leaves 4 (kJs J + 5 U) bytes per instance behind (the
-// joint states and the evaluated units: ~6 % of J's bytes at cfg2, L2 / Infinity-Cache resident); this kernel
-// writes the columns: one 256-thread workgroup = four ADJACENT columns of one instance (one column per wave,
-// lane u = rows 3u..3u+2, one 12-byte streaming store per lane and 64-unit chunk) and ends.  Write bandwidth
-// on this part falls with the footprint a workgroup writes before it ends (scripts/store_k.hip: 3 KB per
-// workgroup reach 5.8-6.1 TB/s with the dependent loads in place, the 96 KB of a whole column-major J per
-// workgroup 5.1-5.3), which is what the one-kernel form could not get around.  Workgroups go
-// round-robin to the 8 XCDs, so the index is decoded such that all workgroups of an instance land on one
-// XCD and its hand-over record is fetched into one L2 only.
-// Values: exactly writeUnitColumns' arithmetic (same operands, same order).
-// =============================================================================================
-// everything the kernel reads, in ONE small by-value struct: the workgroup lives for ~1 us, so its first
-// instruction fetches all arguments at once instead of walking the big ProblemDev field by field (five
-// dependent scalar-cache round trips in the first version: 145 us instead of 70 at B = 4096)
-struct ColumnArgs {
-  const float* unitIn; // [B][5][U]
-  const float* colIn; // [B][P][8]
-  const float* jsIn; // [B][J][kJs] (generic columns only)
-  float* jac; // [B][P][M]
-  const int32_t* done; // [B] or null
-  const int32_t* colStart; // generic columns: CSC of the enabled transform
-  const ColumnSourceDev* colSources;
-  int32_t B, U, M, Kp, P, J, numGroups;
-};
-template <bool kNt>
-__global__ void __launch_bounds__(256) jacobianColumnsKernel(ColumnArgs a) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
-  const int cg = r % a.numGroups, b = (r / a.numGroups) * 8 + x;
-  const int p = 4 * cg + wave;
-  const bool active = b < a.B && p < a.P; // wave-uniform
-  const int bb = active ? b : 0, pp = active ? p : 0;
-  const int U = a.U;
-  // ONE round of independent loads, issued before any branch: the column's record (wave-uniform), the lane's
-  // first unit, the instance's done flag
-  const float4* rec = reinterpret_cast<const float4*>(a.colIn + (size_t(bb) * size_t(a.P) + size_t(pp)) * 8);
-  const float4 r0 = rec[0], r1 = rec[1];
-  const float* ub = a.unitIn + size_t(bb) * 5 * size_t(U);
-  const int u0 = lane < U ? lane : 0;
-  float vx = ub[u0], vy = ub[U + u0], vz = ub[2 * size_t(U) + u0], sigma = ub[3 * size_t(U) + u0];
-  int utin = __float_as_int(ub[4 * size_t(U) + u0]);
-  const int doneFlag = a.done != nullptr ? a.done[bb] : 0;
-  if (!active || doneFlag != 0) {
-    return;
-  }
-  const size_t M = size_t(a.M);
-  float* col = a.jac + (size_t(b) * size_t(a.P) + size_t(p)) * M;
-  const int span = __float_as_int(r1.w);
-  if (span != -1) { // one rotation source (or a structurally zero column: weight 0, empty interval)
-    const F3 t{r0.x, r0.y, r0.z}, ax{r0.w, r1.x, r1.y};
-    const float weight = r1.z;
-    const int tin = span & 0xffff, tout = int(unsigned(span) >> 16);
-    for (int u = lane; u < U; u += 64) {
-      if (u != lane) {
-        vx = ub[u], vy = ub[U + u], vz = ub[2 * size_t(U) + u], sigma = ub[3 * size_t(U) + u];
-        utin = __float_as_int(ub[4 * size_t(U) + u]);
-      }
-      const F3 v{vx, vy, vz};
-      const F3 off = u < a.Kp ? v - t : v;
-      const F3 g = cross(ax, off);
-      const float w = (tin <= utin && utin < tout) ? weight : 0.f;
-      store3<kNt>(col + 3 * size_t(u), (sigma * g.x) * w, (sigma * g.y) * w, (sigma * g.z) * w);
-    }
-    return;
-  }
-  // every other non-empty column (shared parameters, translation / scale dofs): generic gather from the joint states
-  const float* js = a.jsIn + size_t(b) * size_t(a.J) * kJs;
-  const int e0 = a.colStart[p], e1 = a.colStart[p + 1];
-  for (int u = lane; u < U; u += 64) {
-    Unit un;
-    un.v = F3{ub[u], ub[U + u], ub[2 * size_t(U) + u]};
-    un.sigma = ub[3 * size_t(U) + u];
-    un.tin = __float_as_int(ub[4 * size_t(U) + u]);
-    un.isPoint = u < a.Kp;
-    F3 acc{0.f, 0.f, 0.f};
-    for (int e = e0; e < e1; ++e) {
-      const ColumnSourceDev s = a.colSources[e]; // wave-uniform
-      bool applies;
-      const F3 g = sourceDerivative(s, js, un, applies);
-      const float w = applies ? s.weight : 0.f;
-      acc.x += (un.sigma * g.x) * w;
-      acc.y += (un.sigma * g.y) * w;
-      acc.z += (un.sigma * g.z) * w;
-    }
-    store3<kNt>(col + 3 * size_t(u), acc.x, acc.y, acc.z);
   }
 }
 
@@ -1484,6 +1351,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
   for (int i = tid; i < n; i += 256) {
     g[i] = jtr[size_t(b) * n + i];
     d0[i] = g[i];
+    rho[i] = kPivotFloor * (Hb[size_t(i) * n + i] + lambda); // the row's pivot floor (rho is free until the refinement)
   }
   __syncthreads();
   MMX_SCLK(0)
@@ -1514,12 +1382,15 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
           // a diagonal-block row needs its upper part too: element (r, c), c > r, mirrored from (c, r)
           a[c] = (diagLane && c > lane) ? Aval(k0 + c, prow) : Aval(prow, k0 + c);
         }
+        const float floorRow = k0 + (lane & 15) < n ? rho[k0 + (lane & 15)] : 0.f;
         __syncthreads(); // every wave has read the diagonal block before wave 0 overwrites it
         float invd = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
-          const float djj = readLaneF(a[jj], jj);
-          notPd |= !(djj > 0.f) ? 1 : 0;
+          const float draw = readLaneF(a[jj], jj);
+          notPd |= !(draw > 0.f) ? 1 : 0;
+          const float djj = fmaxf(draw, readLaneF(floorRow, jj)); // pivot floor, see kPivotFloor
+          a[jj] = lane == jj ? djj : a[jj];
           const float inv = __builtin_amdgcn_rsqf(djj);
           a[jj] *= inv;
           if (lane == jj) {
@@ -1569,12 +1440,13 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
       }
       __syncthreads();
     }
-    if (notPd != 0) { // Eigen's LLT stops with NumericalIssue; the step is skipped
+    if (notPd != 0) { // a raw pivot was not positive (Eigen's LLT would stop with NumericalIssue): reported, the step is taken
       *notPdPtr = 1;
     }
   }
   __syncthreads();
-  const bool bad = *notPdPtr != 0;
+  const bool badPivot = *notPdPtr != 0;
+  constexpr bool bad = false; // (since the pivot floor the factorisation always completes; the reference never skips a step either)
   MMX_SCLK(1)
   if (!bad) {
     triangularSolves(A, ld, n, d0, tid);
@@ -1681,7 +1553,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     }
     st.iterations[b] = sp.iteration + 1;
     st.finalError[b] = e;
-    if (bad) {
+    if (badPivot) {
       st.status[b] = 2; // MMX_SOLVE_NOT_PD
     }
     const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
@@ -1693,488 +1565,10 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
 }
 
 // =============================================================================================
-// Kernel 3b: dense GN step for LARGE systems (n up to 512 solved parameters, e.g. the 300-joint
-// rig of BASELINE configs[4]): the same step as choleskyStepKernel, but H / L stay in global
-// memory (the jtj scratch, factored in place) and only one 16-column panel lives in LDS at a time.
-// grid = B, block = 256.  Blocked right-looking Cholesky on 16x16 tiles:
-//   - every tile (I,J) of the lower triangle is always handled by the same wave (owner = tile index
-//     mod 4), so a wave only ever re-reads global data it wrote itself; panels are exchanged
-//     through LDS,
-//   - panel factorisation = the lane-per-row elimination with v_readlane broadcasts of the fused
-//     kernel, trailing updates = v_mfma_f32_16x16x4_f32 with operands from the LDS panel,
-//   - substitutions read L from global memory after one agent-scope fence.
-// dynamic LDS = NP*16 (panel) + 4*NP + M + 8 floats.
-// =============================================================================================
-__global__ void __launch_bounds__(256) choleskyStepGlobalKernel(
-    ProblemDev pb,
-    int P,
-    const float* __restrict__ jac, // [B][M*P]
-    const float* __restrict__ res, // [B][M]
-    float* __restrict__ jtj, // [B][n*n] in: H ; out: L (lower), garbage above the diagonal blocks
-    const float* __restrict__ jtr, // [B][n]
-    const double* __restrict__ errIter,
-    float* __restrict__ theta,
-    SolveStateDev st,
-    StepParams sp) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (st.done[b] != 0) {
-    return;
-  }
-  const int n = pb.n, M = pb.M;
-  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
-  const int NP = (n + 15) & ~15, NB = NP >> 4;
-  float* pan = smem; // [NB - k tiles][256] swizzled tiles of the current block column
-  float* g = pan + size_t(NP) * 16;
-  float* d0 = g + NP;
-  float* rho = d0 + NP;
-  float* invDiag = rho + NP;
-  float* w = invDiag + NP; // [M]
-  int* flags = reinterpret_cast<int*>(w + M);
-  float* H = jtj + size_t(b) * n * n;
-  if (tid == 0) {
-    flags[0] = 0;
-  }
-  for (int i = tid; i < NP; i += 256) {
-    const float v = i < n ? jtr[size_t(b) * n + i] : 0.f;
-    g[i] = v;
-    d0[i] = v;
-  }
-  // lambda is added when a diagonal element is first read; every element of the lower triangle is
-  // read from H exactly once before being overwritten with its Schur-complement value, EXCEPT that
-  // updated values are re-read -> keep a "lambda already applied" convention: apply it up front.
-  for (int i = tid; i < n; i += 256) {
-    H[size_t(i) * n + i] += lambda;
-  }
-  __threadfence();
-  __syncthreads();
-  long long tclk = clock64();
-  auto Hval = [&](int r, int c) -> float { // the padded matrix; the load itself is unconditional
-    const float v = H[size_t(min(r, n - 1)) * n + min(c, n - 1)]; // (clamped: independent loads stay in flight together)
-    return (r < n && c < n) ? v : (r == c ? 1.f : 0.f);
-  };
-
-  for (int k = 0; k < NB; ++k) {
-    const int nt = NB - k; // tiles in this block column
-    // (a) owners load their tiles of block column k into the LDS panel
-    for (int I = k; I < NB; ++I) {
-      if ((tileIndex(I, k) & 3) == wave) {
-        float* Tl = pan + 256 * (I - k);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 16 * I + 4 * (lane >> 4) + q, c = 16 * k + (lane & 15);
-          Tl[tileAddr(r & 15, c & 15)] = Hval(r, c);
-        }
-      }
-    }
-    __syncthreads();
-    MMX_SCLK(6)
-    // (b) panel factorisation (see mmx_fused.hip phase H for the scheme)
-    {
-      float* Dk = pan;
-      const bool diagLane = lane < 16;
-      const int prow = 16 + 48 * wave + (lane - 16); // row inside the panel (0..15 = diagonal block)
-      const bool active = diagLane || prow < 16 * nt;
-      float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
-      const int trow = diagLane ? lane : (prow & 15);
-      float a[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
-        a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
-      }
-      __syncthreads();
-      float invd = 0.f;
-      bool bad = false;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float djj = readLaneF(a[j], j);
-        bad = bad || !(djj > 0.f);
-        const float inv = __builtin_amdgcn_rsqf(djj);
-        a[j] *= inv;
-        if (lane == j) {
-          invd = inv;
-        }
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-          a[c] -= a[j] * readLaneF(a[j], c);
-        }
-      }
-      if (diagLane) {
-        if (wave == 0) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
-          }
-          invDiag[16 * k + lane] = invd;
-          if (bad) {
-            flags[0] = 1;
-          }
-        }
-      } else if (active) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          Tl[tileAddr(trow, c)] = a[c];
-        }
-      }
-      __syncthreads();
-      for (int pr = 16 + 192 + tid; pr < 16 * nt; pr += 256) { // rows beyond 4 x 48: substitution
-        float* Tr = pan + 256 * (pr >> 4);
-        float x[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = ldsRow4(Tr, pr & 15, q);
-          x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float sum = x[j];
-#pragma unroll
-          for (int c = 0; c < j; ++c) {
-            sum -= x[c] * Dk[tileAddr(j, c)];
-          }
-          x[j] = sum * invDiag[16 * k + j];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          Tr[tileAddr(pr & 15, c)] = x[c];
-        }
-      }
-      __syncthreads();
-    }
-    MMX_SCLK(7)
-    // (c) owners write the factored tiles back (L) and update their trailing tiles
-    for (int I = k; I < NB; ++I) {
-      if ((tileIndex(I, k) & 3) == wave) {
-        const float* Tl = pan + 256 * (I - k);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 16 * I + 4 * (lane >> 4) + q, c = 16 * k + (lane & 15);
-          if (r < n && c < n) {
-            H[size_t(r) * n + c] = Tl[tileAddr(r & 15, c & 15)];
-          }
-        }
-      }
-    }
-    // Trailing update C_IJ -= L_Ik L_Jk^T of the wave's own tiles, eight tiles per trip: the loads of
-    // the eight go out together, then the MFMAs, then the stores.  One tile per trip made every trip
-    // a full global round trip, and -- vmcnt being one in-order counter for loads and stores -- the
-    // wait for a tile's loads also waited for the previous tile's stores to be acknowledged.
-    {
-      // next trailing tile (row-major over the lower triangle, columns > k) that this wave owns
-      auto nextOwned = [&](int& I, int& Jc) {
-        do {
-          if (++Jc > I) {
-            ++I;
-            Jc = k + 1;
-          }
-        } while (I < NB && (tileIndex(I, Jc) & 3) != wave);
-      };
-      constexpr int kTb = 8;
-      int I0 = k + 1, J0 = k;
-      nextOwned(I0, J0);
-      while (I0 < NB) {
-        int tI[kTb], tJ[kTb];
-        tI[0] = I0, tJ[0] = J0;
-#pragma unroll
-        for (int t = 1; t < kTb; ++t) {
-          tI[t] = tI[t - 1], tJ[t] = tJ[t - 1];
-          if (tI[t] < NB) {
-            nextOwned(tI[t], tJ[t]);
-          }
-        }
-        v4f c[kTb];
-#pragma unroll
-        for (int t = 0; t < kTb; ++t) {
-          if (tI[t] < NB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              c[t][q] = Hval(16 * tI[t] + 4 * (lane >> 4) + q, 16 * tJ[t] + (lane & 15));
-            }
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < kTb; ++t) {
-          if (tI[t] < NB) {
-            const float4 av = ldsRow4(pan + 256 * (tI[t] - k), lane & 15, lane >> 4);
-            const float4 bv = ldsRow4(pan + 256 * (tJ[t] - k), lane & 15, lane >> 4);
-            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c[t], 0, 0, 0);
-            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c[t], 0, 0, 0);
-            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c[t], 0, 0, 0);
-            c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c[t], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < kTb; ++t) {
-          if (tI[t] < NB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int r = 16 * tI[t] + 4 * (lane >> 4) + q, cc = 16 * tJ[t] + (lane & 15);
-              if (r < n && cc < n) {
-                H[size_t(r) * n + cc] = c[t][q];
-              }
-            }
-          }
-        }
-        I0 = tI[kTb - 1], J0 = tJ[kTb - 1];
-        if (I0 < NB) {
-          nextOwned(I0, J0);
-        }
-      }
-    }
-    __syncthreads(); // the panel buffer is reused by the next block column
-    MMX_SCLK(1)
-  }
-  __threadfence(); // L was written by four waves; the substitutions read it from any thread
-  __syncthreads();
-  const bool bad = flags[0] != 0;
-
-  // L y = b ; L^T x = y with L in global memory: diagonal blocks through the LDS panel buffer
-  auto solve = [&](float* x) {
-    for (int k = 0; k < NB; ++k) { // forward
-      for (int i = tid; i < 256; i += 256) {
-        const int r = 16 * k + (i >> 4), c = 16 * k + (i & 15);
-        pan[tileAddr(i >> 4, i & 15)] = c <= r ? Hval(r, c) : 0.f;
-      }
-      __syncthreads();
-      if (tid < 64) {
-        const int i = lane & 15;
-        float a[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = ldsRow4(pan, i, q);
-          a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
-        }
-        float bi = x[16 * k + i];
-        const float invd = invDiag[16 * k + i];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float yj = readLaneF(bi, j) * readLaneF(invd, j);
-          bi = (i == j) ? yj : bi - a[j] * yj;
-        }
-        if (lane < 16) {
-          x[16 * k + i] = bi;
-        }
-      }
-      __syncthreads();
-      for (int r = 16 * (k + 1) + tid; r < NP; r += 256) {
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          acc += Hval(r, 16 * k + c) * x[16 * k + c];
-        }
-        x[r] -= acc;
-      }
-      __syncthreads();
-    }
-    for (int k = NB - 1; k >= 0; --k) { // backward
-      for (int i = tid; i < 256; i += 256) {
-        const int r = 16 * k + (i >> 4), c = 16 * k + (i & 15);
-        pan[tileAddr(i >> 4, i & 15)] = c <= r ? Hval(r, c) : 0.f;
-      }
-      __syncthreads();
-      if (tid < 64) {
-        const int i = lane & 15;
-        float at[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          at[c] = pan[tileAddr(c, i)];
-        }
-        float bi = x[16 * k + i];
-        const float invd = invDiag[16 * k + i];
-#pragma unroll
-        for (int j = 15; j >= 0; --j) {
-          const float xj = readLaneF(bi, j) * readLaneF(invd, j);
-          bi = (i == j) ? xj : bi - at[j] * xj;
-        }
-        if (lane < 16) {
-          x[16 * k + i] = bi;
-        }
-      }
-      __syncthreads();
-      for (int r = tid; r < 16 * k; r += 256) {
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          acc += Hval(16 * k + c, r) * x[16 * k + c];
-        }
-        x[r] -= acc;
-      }
-      __syncthreads();
-    }
-  };
-  MMX_SCLK(0)
-  if (!bad) {
-    solve(d0);
-  }
-  MMX_SCLK(2)
-  for (int rf = 0; rf < 3 && !bad && sp.refine; ++rf) { // see choleskyStepKernel
-    const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
-    const float* rb = res + size_t(b) * size_t(M);
-    // w = r - J d0 and rho = J^T w - lambda d0 stream the dense J twice; with M a multiple of 4 (and
-    // an aligned J) a thread moves 16 bytes per load and keeps four independent sums
-    const bool vec4 = (M & 3) == 0 && (reinterpret_cast<uintptr_t>(jac) & 15) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0;
-    if (vec4) {
-      for (int k4 = tid; k4 < (M >> 2); k4 += 256) {
-        // w = r - J d cancels (|w| << |r| near the solution) and it bounds what the refinement can
-        // recover: the n-term sums are kept in double (four FMAs per 16-byte load -- the pass is
-        // bound by its loads)
-        const float4 r4 = *reinterpret_cast<const float4*>(rb + 4 * k4);
-        double ax = r4.x, ay = r4.y, az = r4.z, aw = r4.w;
-        // sixteen columns per trip: the loads are independent and go out together (one column
-        // per trip was one dependent HBM round trip per column: 260 in a row at cfg5)
-        int s2 = 0;
-        for (; s2 + 16 <= n; s2 += 16) {
-          float4 jv[16];
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            jv[t] = *reinterpret_cast<const float4*>(Jb + size_t(pb.enabledList[s2 + t]) * M + 4 * k4);
-          }
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const double d = double(d0[s2 + t]);
-            ax -= double(jv[t].x) * d, ay -= double(jv[t].y) * d, az -= double(jv[t].z) * d, aw -= double(jv[t].w) * d;
-          }
-        }
-        for (; s2 < n; ++s2) {
-          const float4 jv = *reinterpret_cast<const float4*>(Jb + size_t(pb.enabledList[s2]) * M + 4 * k4);
-          const double d = double(d0[s2]);
-          ax -= double(jv.x) * d, ay -= double(jv.y) * d, az -= double(jv.z) * d, aw -= double(jv.w) * d;
-        }
-        *reinterpret_cast<float4*>(w + 4 * k4) = float4{float(ax), float(ay), float(az), float(aw)};
-      }
-    } else {
-      for (int kk = tid; kk < M; kk += 256) {
-        float acc = rb[kk];
-        for (int s2 = 0; s2 < n; ++s2) {
-          acc -= Jb[size_t(pb.enabledList[s2]) * M + kk] * d0[s2];
-        }
-        w[kk] = acc;
-      }
-    }
-    __syncthreads();
-    MMX_SCLK(3)
-    if (vec4) {
-      // four columns per wave and trip: their loads are in flight together, then four reductions
-      for (int s0 = 4 * wave; s0 < NP; s0 += 16) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* col[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          col[t] = Jb + size_t(pb.enabledList[min(s0 + t, n - 1)]) * M;
-        }
-        const int M4 = M >> 2;
-        for (int k0 = lane; k0 < M4; k0 += 256) { // four row groups x four columns = sixteen loads in flight
-          float4 jv[4][4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int k4 = min(k0 + 64 * u, M4 - 1);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              jv[u][t] = *reinterpret_cast<const float4*>(col[t] + 4 * k4);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (k0 + 64 * u < M4) {
-              const float4 wv = *reinterpret_cast<const float4*>(w + 4 * (k0 + 64 * u));
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                acc[t] = dot4(jv[u][t], wv, acc[t]);
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float a = waveReduceSumF(acc[t]);
-          if (lane == 0 && s0 + t < NP) {
-            rho[s0 + t] = s0 + t < n ? a - lambda * d0[s0 + t] : 0.f;
-          }
-        }
-      }
-    }
-    for (int s2 = wave; s2 < NP && !vec4; s2 += 4) {
-      float acc = 0.f;
-      if (s2 < n) {
-        const float* col = Jb + size_t(pb.enabledList[s2]) * M;
-        if (vec4) {
-          for (int k4 = lane; k4 < (M >> 2); k4 += 64) {
-            acc = dot4(*reinterpret_cast<const float4*>(col + 4 * k4), *reinterpret_cast<const float4*>(w + 4 * k4), acc);
-          }
-        } else {
-          for (int kk = lane; kk < M; kk += 64) {
-            acc += col[kk] * w[kk];
-          }
-        }
-        acc = waveReduceSumF(acc);
-      }
-      if (lane == 0) {
-        rho[s2] = s2 < n ? acc - lambda * d0[s2] : 0.f;
-      }
-    }
-    __syncthreads();
-    MMX_SCLK(4)
-    solve(rho);
-    MMX_SCLK(5)
-    float c2 = 0.f, d2 = 0.f;
-    for (int i = tid; i < n; i += 256) {
-      const float cr = rho[i], dn = d0[i] + cr;
-      d0[i] = dn;
-      c2 += cr * cr;
-      d2 += dn * dn;
-    }
-    c2 = waveReduceSumF(c2);
-    d2 = waveReduceSumF(d2);
-    __syncthreads();
-    if (lane == 0) {
-      rho[wave] = c2;
-      rho[4 + wave] = d2;
-    }
-    __syncthreads();
-    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
-    __syncthreads();
-    if (!again) {
-      break;
-    }
-  }
-  if (sp.delta != nullptr) {
-    for (int s2 = tid; s2 < n; s2 += 256) {
-      sp.delta[size_t(b) * n + s2] = bad ? 0.f : d0[s2];
-    }
-    if (tid == 0) {
-      sp.stepIter[b] = bad ? -(sp.iteration + 1) : sp.iteration + 1;
-    }
-  } else if (!bad) {
-    float* th = theta + size_t(b) * P;
-    for (int s2 = tid; s2 < n; s2 += 256) {
-      th[pb.enabledList[s2]] -= d0[s2];
-    }
-  }
-  if (tid == 0) {
-    const double e = errIter[b];
-    const double last = st.lastError[b];
-    if (st.errorHistory != nullptr) {
-      st.errorHistory[size_t(b) * sp.maxIterations + sp.iteration] = e;
-    }
-    st.iterations[b] = sp.iteration + 1;
-    st.finalError[b] = e;
-    if (bad) {
-      st.status[b] = 2;
-    }
-    const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
-    if (sp.iteration >= sp.minIterations && converged) {
-      st.done[b] = 1;
-    }
-    st.lastError[b] = e;
-  }
-}
-
-// =============================================================================================
-// Kernel 3c: the large-system GN step, left-looking.  Same step as choleskyStepGlobalKernel, which it
-// replaces (that one stays as the MMX_CHOL_RIGHT_LOOKING=1 cross-check); what changed is the order of
-// the memory traffic:
+// Kernel 3c: the large-system GN step (n up to 512 solved parameters), left-looking: the same step as
+// choleskyStepKernel with H and the factor in HBM.  (Round 1's right-looking form, factored in place, re-read
+// every trailing tile right after writing it -- ~40 dependent round trips per block column -- and was removed in
+// round 3.)  The order of the memory traffic:
 //   - H is read once and never written: block column k of the factor is
 //       C(I,k) = H(I,k) [+ lambda] - sum_{j<k} L(I,j) L(k,j)^T
 //     with ALL operand loads independent of each other (finished tiles only), so they go out in batches
@@ -2215,7 +1609,6 @@ __host__ __device__ inline size_t tiledLdsFloats(int n, int chunkRows, TiledLds*
 
 // Left-looking blocked Cholesky of H + lambda I (H: [n][n], lower triangle, read only) into the tile-major L;
 // t.g holds g on entry and y = L^-1 g on exit; t.flags[0] = 1 when a pivot was not positive.
-template <bool kTileMajorH> // H as [tile][col][row] (treeNormalEquationsKernel's tile-major output) instead of [n][n]
 __device__ __forceinline__ void tiledFactor(
     const float* __restrict__ H, float* __restrict__ L, int n, float lambda, const TiledLds& t, const StepParams& sp, int b, int tid, long long& tclk) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2234,15 +1627,10 @@ __device__ __forceinline__ void tiledFactor(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int I = I0 + 4 * t;
-        float hq[4];
-        if (kTileMajorH) {
-          const float4 hv = *reinterpret_cast<const float4*>(H + size_t(tileIndex(min(I, NB - 1), k)) * 256 + opOff);
-          hq[0] = hv.x, hq[1] = hv.y, hq[2] = hv.z, hq[3] = hv.w;
-        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = 16 * I + 4 * lkg + q, cc = 16 * k + lrow;
-          const float v = kTileMajorH ? hq[q] : H[size_t(min(r, n - 1)) * n + min(cc, n - 1)]; // clamped: unconditional, independent loads
+          const float v = H[size_t(min(r, n - 1)) * n + min(cc, n - 1)]; // clamped: unconditional, independent loads
           c[t][q] = (r < n && cc < n) ? (r > cc ? v : (r == cc ? v + lambda : 0.f)) : (r == cc ? 1.f : 0.f);
         }
       }
@@ -2322,13 +1710,17 @@ __device__ __forceinline__ void tiledFactor(
         a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
       }
       float bi = g[16 * k + lrow]; // s_k
+      const int frow = 16 * k + lrow;
+      const float floorRow = frow < n ? kPivotFloor * (H[size_t(frow) * n + frow] + lambda) : 0.f; // see kPivotFloor
       __syncthreads();
       float invd = 0.f;
       bool bad = false;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float djj = readLaneF(a[j], j);
-        bad = bad || !(djj > 0.f);
+        const float draw = readLaneF(a[j], j);
+        bad = bad || !(draw > 0.f);
+        const float djj = fmaxf(draw, readLaneF(floorRow, j));
+        a[j] = lane == j ? djj : a[j];
         const float inv = __builtin_amdgcn_rsqf(djj);
         a[j] *= inv;
         if (lane == j) {
@@ -2444,13 +1836,17 @@ __device__ __forceinline__ void tiledFactorPairs(
       a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
     }
     float bi = g[16 * k + lrow]; // s_k
+    // the row's pivot floor (kPivotFloor) from the original diagonal: tile (k, k) of the tile-major H, [col][row] inside
+    const float floorRow = 16 * k + lrow < n ? kPivotFloor * (H[size_t(tileIndex(k, k)) * 256 + lrow * 17] + lambda) : 0.f;
     __syncthreads();
     float invd = 0.f;
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float djj = readLaneF(a[j], j);
-      bad = bad || !(djj > 0.f);
+      const float draw = readLaneF(a[j], j);
+      bad = bad || !(draw > 0.f);
+      const float djj = fmaxf(draw, readLaneF(floorRow, j));
+      a[j] = lane == j ? djj : a[j];
       const float inv = __builtin_amdgcn_rsqf(djj);
       a[j] *= inv;
       if (lane == j) {
@@ -2745,16 +2141,16 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
 
 // theta -= delta (or the step handed to stepUpdateKernel) and SolverT::solve's bookkeeping (solver.cpp:92-119)
 __device__ __forceinline__ void applyStepAndBook(
-    const ProblemDev& pb, int P, int b, const float* d0, bool bad, const double* errIter, float* theta, const SolveStateDev& st, const StepParams& sp, int tid) {
+    const ProblemDev& pb, int P, int b, const float* d0, bool badPivot, const double* errIter, float* theta, const SolveStateDev& st, const StepParams& sp, int tid) {
   const int n = pb.n;
   if (sp.delta != nullptr) {
     for (int s2 = tid; s2 < n; s2 += 256) {
-      sp.delta[size_t(b) * n + s2] = bad ? 0.f : d0[s2];
+      sp.delta[size_t(b) * n + s2] = d0[s2];
     }
     if (tid == 0) {
-      sp.stepIter[b] = bad ? -(sp.iteration + 1) : sp.iteration + 1;
+      sp.stepIter[b] = sp.iteration + 1;
     }
-  } else if (!bad) {
+  } else {
     float* th = theta + size_t(b) * P;
     for (int s2 = tid; s2 < n; s2 += 256) {
       th[pb.enabledList[s2]] -= d0[s2];
@@ -2768,7 +2164,7 @@ __device__ __forceinline__ void applyStepAndBook(
     }
     st.iterations[b] = sp.iteration + 1;
     st.finalError[b] = e;
-    if (bad) {
+    if (badPivot) { // a raw pivot was not positive; floored (kPivotFloor), the step taken
       st.status[b] = 2;
     }
     const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
@@ -2818,8 +2214,9 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledFactor<false>(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
-  const bool bad = t.flags[0] != 0;
+  tiledFactor(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
+  const bool badPivot = t.flags[0] != 0;
+  constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
   for (int i = tid; i < NP; i += 256) {
     d0[i] = t.g[i];
   }
@@ -2939,81 +2336,15 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
       break;
     }
   }
-  applyStepAndBook(pb, P, b, d0, bad, errIter, theta, st, sp, tid);
+  applyStepAndBook(pb, P, b, d0, badPivot, errIter, theta, st, sp, tid);
 }
 
 // The same step for systems whose refinement goes through the tree (treeRefineKernel, mmx_fused.hip) instead of a
 // dense J: stage 1 factors and solves (d0 to `dvec`), stage 2 -- once per refinement round, after treeRefineKernel
 // left rho = J^T (r - J d) - lambda d in `rhoVec` -- solves for the correction and, when it was the last one,
 // applies the step.  refState[b]: 0 = a refinement round is due, 1 = the iteration's step has been applied.
+// (Two block columns per step on the tile-major hand-over of treeNormalEquationsKernel: tiledFactorPairs.)
 __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
-    ProblemDev pb,
-    int P,
-    const float* __restrict__ jtj,
-    const float* __restrict__ jtr,
-    float* __restrict__ factor,
-    float* __restrict__ dvec, // [B][NP]
-    int32_t* __restrict__ refState, // [B]
-    const double* __restrict__ errIter,
-    float* __restrict__ theta,
-    SolveStateDev st,
-    StepParams sp,
-    int pairs) { // two block columns per step (tiledFactorPairs)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (st.done[b] != 0) {
-    if (tid == 0) {
-      refState[b] = 1;
-    }
-    return;
-  }
-  const int n = pb.n;
-  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
-  const int NP = (n + 15) & ~15, NB = NP >> 4;
-  TiledLds t;
-  tiledLdsFloats(n, 0, &t, smem);
-  float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
-  if (tid == 0) {
-    t.flags[0] = 0;
-  }
-  for (int i = tid; i < NP; i += 256) {
-    t.g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
-  }
-  __syncthreads();
-  long long tclk = clock64();
-  if (pairs == 2) { // cross-check switch (MMX_TREE_ROWMAJOR=1): H as [n][n] rows, single-column factor
-    tiledFactor<false>(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
-  } else if (pairs) {
-    tiledFactorPairs(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
-  } else {
-    tiledFactor<true>(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
-  }
-  const bool bad = t.flags[0] != 0;
-  float* d0 = t.g; // y = L^-1 g, solved in place
-  MMX_SCLK(0)
-  if (!bad) {
-    tiledSweep<false>(L, NB, d0, tid);
-  }
-  MMX_SCLK(2)
-  if (bad || !sp.refine) {
-    applyStepAndBook(pb, P, b, d0, bad, errIter, theta, st, sp, tid);
-    if (tid == 0) {
-      refState[b] = 1;
-    }
-    return;
-  }
-  for (int i = tid; i < NP; i += 256) {
-    dvec[size_t(b) * NP + i] = d0[i];
-  }
-  if (tid == 0) {
-    refState[b] = 0;
-  }
-}
-
-// choleskyFactorTiledKernel with the production form of the factorisation alone (two block columns per step on the
-// tile-major hand-over; the single-column and the row-major cross-check forms are not compiled in): 4.5 k instead of
-// 8.9 k instructions, no scratch.  Staged: launched with MMX_CHOL_LEAN=1 until it has been through the GPU suite.
-__global__ void __launch_bounds__(256, 4) choleskyFactorTiledLeanKernel(
     ProblemDev pb,
     int P,
     const float* __restrict__ jtj,
@@ -3048,7 +2379,8 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledLeanKernel(
   __syncthreads();
   long long tclk = clock64();
   tiledFactorPairs(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
-  const bool bad = t.flags[0] != 0;
+  const bool badPivot = t.flags[0] != 0;
+  constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
   float* d0 = t.g; // y = L^-1 g, solved in place
   MMX_SCLK(0)
   if (!bad) {
@@ -3056,7 +2388,7 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledLeanKernel(
   }
   MMX_SCLK(2)
   if (bad || !sp.refine) {
-    applyStepAndBook(pb, P, b, d0, bad, errIter, theta, st, sp, tid);
+    applyStepAndBook(pb, P, b, d0, badPivot, errIter, theta, st, sp, tid);
     if (tid == 0) {
       refState[b] = 1;
     }
@@ -3067,6 +2399,9 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledLeanKernel(
   }
   if (tid == 0) {
     refState[b] = 0;
+    if (badPivot) { // (the finish stage books the iteration; the floored pivot is reported from here)
+      st.status[b] = 2;
+    }
   }
 }
 
@@ -3401,64 +2736,18 @@ hipError_t launchFkJacobian(
   // eight waves leave too few workgroups per CU to overlap FK with stores (4096: 113 us).
   // Large rigs are LDS-bound (a 300-joint instance needs 25 KB), so they take four waves too.
   // FK only (no J): one wave per instance from 2048 instances on (16 vs 23 us at 4096).
-  int wpi = (pb.B < 2048 || lds > 12 * 1024 || (jac != nullptr && pb.B <= 40000)) ? 4 : 1;
-  if (const char* e = getenv("MMX_JAC_WPI")) { // experiment switch: 1 or 4
-    wpi = e[0] == '4' ? 4 : 1;
-  }
-  bool streaming = true; // non-temporal column stores (measured better at every batch size once they were really emitted: see store3())
-  int zeroPhase = wpi == 1 ? 1 : 0; // one wave per instance: alternate; several: the waves without joints write them first
-  if (const char* e = getenv("MMX_JAC_NT")) { // experiment switches
-    streaming = e[0] == '1';
-  }
-  if (const char* e = getenv("MMX_JAC_ZERO_PHASE")) {
-    zeroPhase = e[0] - '0';
-  }
+  const int wpi = (pb.B < 2048 || lds > 12 * 1024 || (jac != nullptr && pb.B <= 40000)) ? 4 : 1;
+  // non-temporal column stores throughout (measured better at every batch size once they were really emitted: see store3());
+  // the structurally zero columns: one wave per instance alternates their position, several waves: those without joints write them first
+  const int zeroPhase = wpi == 1 ? 1 : 0;
+  // (A two-kernel form -- FK + units once per instance handed over through HBM, then four adjacent columns per short-lived
+  // workgroup -- was built and measured in round 2: 95-150 us against 86 us for this one at B = 4096, because the L2s are
+  // written back between the two kernels and every column workgroup's first loads miss.  Removed in round 3)
 #define MMX_FKJ(W_, WPI_, S_)                                                                                                  \
   hipExtLaunchKernelGGL(                                                                                                       \
-      (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done, zeroPhase, \
-      static_cast<float*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr))
-  // Two-kernel J assembly (MMX_JAC_TWO_KERNEL=1; an experiment that did NOT pay, kept for the record and
-  // covered by a parity test): FK + units once per instance, handed over through pb.jaJs / jaUnits / jaCols,
-  // then four adjacent columns per workgroup (jacobianColumnsKernel).  The store pattern alone reaches
-  // 6.1 TB/s with synthetic, L2-warm inputs (scripts/store_k.hip, 66 us at B = 4096), but the real second
-  // kernel needs 95 us on warm and 150 us on freshly written hand-over data (the L2s are written back and
-  // invalidated between the two kernels, so every workgroup's first loads miss; its ~1.5 us lifetime then
-  // caps the stores in flight) against 86 us for the one-kernel form.  The events bracket BOTH dispatches.
-  const bool oneKernel = getenv("MMX_JAC_TWO_KERNEL") == nullptr;
-  if (jac != nullptr && pb.jaJs != nullptr && pb.jaUnits != nullptr && pb.jaCols != nullptr && pb.colDesc != nullptr && !oneKernel) {
-    static const char* wpiEnv = getenv("MMX_JAC_K1_WPI");
-    const int wpiK1 = wpiEnv != nullptr ? (wpiEnv[0] == '1' ? 1 : 4) : ((pb.B < 2048 || lds > 12 * 1024) ? 4 : 1);
-    static const bool skipK1 = getenv("MMX_JAC_SKIP_K1") != nullptr; // experiment: time the column kernel on the previous launch's hand-over data
-    if (skipK1) {
-    } else if (wpiK1 == 4) {
-      hipExtLaunchKernelGGL(
-          (fkJacobianKernel<false, 4, false>), dim3(pb.B), dim3(256), lds, stream, startEvent, nullptr, 0, rig, pb, theta, static_cast<float*>(nullptr), res,
-          err, state, done, 0, pb.numMultiCols > 0 ? pb.jaJs : nullptr, pb.jaUnits, pb.jaCols);
-    } else {
-      hipExtLaunchKernelGGL(
-          (fkJacobianKernel<false, 1, false>), dim3(pb.B), dim3(64), lds, stream, startEvent, nullptr, 0, rig, pb, theta, static_cast<float*>(nullptr), res,
-          err, state, done, 0, pb.numMultiCols > 0 ? pb.jaJs : nullptr, pb.jaUnits, pb.jaCols);
-    }
-    const int groups = (rig.P + 3) / 4;
-    const unsigned blocks = unsigned(((pb.B + 7) / 8) * 8) * unsigned(groups);
-    ColumnArgs ca{};
-    ca.unitIn = pb.jaUnits, ca.colIn = pb.jaCols, ca.jsIn = pb.jaJs, ca.jac = jac, ca.done = done;
-    ca.colStart = pb.colStart, ca.colSources = pb.colSources;
-    ca.B = pb.B, ca.U = pb.U, ca.M = pb.M, ca.Kp = pb.Kp, ca.P = rig.P, ca.J = rig.J, ca.numGroups = groups;
-    if (streaming) {
-      hipExtLaunchKernelGGL((jacobianColumnsKernel<true>), dim3(blocks), dim3(256), 0, stream, skipK1 ? startEvent : nullptr, stopEvent, 0, ca);
-    } else {
-      hipExtLaunchKernelGGL((jacobianColumnsKernel<false>), dim3(blocks), dim3(256), 0, stream, nullptr, stopEvent, 0, ca);
-    }
-  } else
+      (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done, zeroPhase)
   if (jac != nullptr) {
-    if (!streaming) {
-      if (wpi == 4) {
-        MMX_FKJ(true, 4, false);
-      } else {
-        MMX_FKJ(true, 1, false);
-      }
-    } else if (wpi == 4) {
+    if (wpi == 4) {
       MMX_FKJ(true, 4, true);
     } else {
       MMX_FKJ(true, 1, true);
@@ -3583,9 +2872,7 @@ hipError_t launchCholeskyStep(
     const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
     // rows of J per refinement chunk: 32 (every column contributes one full 128-byte line per chunk) while the
     // chunk's loads fit the prefetch registers, else 16
-    const char* ce = getenv("MMX_CHOL_CHUNK_ROWS");
-    const int chunkPref = ce != nullptr ? atoi(ce) : 32;
-    const int chunkRows = chunkPref == 32 && size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
+    const int chunkRows = size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
     lds = tiledLdsFloats(pb.n, chunkRows, nullptr, nullptr) * sizeof(float);
     if (lds > 64 * 1024) {
       hipError_t rc = hipFuncSetAttribute(
@@ -3598,19 +2885,8 @@ hipError_t launchCholeskyStep(
         choleskyStepTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, factor, errIter, theta, st, sp, chunkRows);
     return hipGetLastError();
   }
-  if (lds > 160 * 1024) { // the right-looking form, factored in place (MMX_CHOL_RIGHT_LOOKING=1)
-    const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
-    lds = (NP * 16 + 4 * NP + size_t(pb.M) + 8) * sizeof(float);
-    if (lds > 64 * 1024) {
-      hipError_t rc = hipFuncSetAttribute(
-          reinterpret_cast<const void*>(choleskyStepGlobalKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      if (rc != hipSuccess) {
-        return rc;
-      }
-    }
-    hipLaunchKernelGGL(
-        choleskyStepGlobalKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, const_cast<float*>(jtj), jtr, errIter, theta, st, sp);
-    return hipGetLastError();
+  if (lds > 160 * 1024) {
+    return hipErrorInvalidValue; // (large systems need the factor scratch)
   }
   if (lds > 64 * 1024) {
     hipError_t rc = hipFuncSetAttribute(
@@ -3647,20 +2923,7 @@ hipError_t launchCholeskyFactorTiled(
       return rc;
     }
   }
-  const char* pe = getenv("MMX_CHOL_PAIRS"); // (read per call: the tests switch it inside one process)
-  const int pairs = getenv("MMX_TREE_ROWMAJOR") != nullptr ? 2 : (pe != nullptr && pe[0] == '0' ? 0 : 1);
-  const char* le = getenv("MMX_CHOL_LEAN");
-  if (pairs == 1 && le != nullptr && le[0] == '1') {
-    if (lds > 64 * 1024) {
-      hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(choleskyFactorTiledLeanKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      if (rc != hipSuccess) {
-        return rc;
-      }
-    }
-    hipLaunchKernelGGL(choleskyFactorTiledLeanKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp);
-    return hipGetLastError();
-  }
-  hipLaunchKernelGGL(choleskyFactorTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp, pairs);
+  hipLaunchKernelGGL(choleskyFactorTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp);
   return hipGetLastError();
 }
 

@@ -21,10 +21,47 @@ _LIB_PATH = os.path.join(_HERE, "libmmx_oracle.so")
 _lib: Optional[C.CDLL] = None
 
 
+_STAMP = os.path.join(_HERE, ".built_for")
+
+
+def host_cpu() -> str:
+    """Model name + the widest vector ISA of the CPU this process runs on (the oracle is compiled -march=native)."""
+    model, flags = "unknown", set()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = set(line.split(":", 1)[1].split())
+            if model != "unknown" and flags:
+                break
+    except OSError:
+        pass
+    isa = "avx512" if "avx512f" in flags else ("avx2" if "avx2" in flags else "sse")
+    return f"{model} ({isa})"
+
+
 def build(force: bool = False) -> str:
-    """Compile the oracle with oracle/Makefile (gcc only)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    """Compile the oracle with oracle/Makefile (gcc only, -march=native).  A library built on another host (it travels
+    with the snapshot) is rebuilt for this one: the CPU baseline must use the ISA of the cores it is timed on."""
+    cpu = host_cpu()
+    try:
+        stamp = open(_STAMP).read().strip()
+    except OSError:
+        stamp = ""
+    if force or not os.path.exists(_LIB_PATH) or stamp != cpu:
+        import fcntl
+
+        with open(os.path.join(_HERE, ".build_lock"), "w") as lock:  # two ranks of one test may get here together
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                stamp = open(_STAMP).read().strip()
+            except OSError:
+                stamp = ""
+            if force or not os.path.exists(_LIB_PATH) or stamp != cpu:
+                subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+                with open(_STAMP, "w") as f:
+                    f.write(cpu + "\n")
     return _LIB_PATH
 
 
@@ -156,6 +193,14 @@ class Constraints:
             [blk.instance(b) for blk in self.joint_blocks],
             self.ellipsoid_limits,
         )
+
+
+def _subset(self, idx) -> "Constraints":
+    """Instances idx (an index array) of a batched payload, every block of it (joint blocks, limits, prior) included."""
+    return self.instance(np.asarray(idx, dtype=np.int64))
+
+
+Constraints.subset = _subset
 
 
 def _enabled_ptr(enabled, P):

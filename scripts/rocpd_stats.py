@@ -10,24 +10,45 @@ import sys
 from collections import defaultdict
 
 
+def _label(name, grid_x, wg_x):
+    """Launches of one kernel with different grids are different workloads: one line per (kernel, workgroups)."""
+    if "mmx" in name:  # (the sqlite database holds mangled names: _ZN3mmx...)
+        return f"[{int(grid_x) // max(int(wg_x), 1)} wg] " + name
+    return name
+
+
 def from_db(path):
     db = sqlite3.connect(path)
     cur = db.cursor()
-    rows = cur.execute(
-        "select s.kernel_name, d.end - d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id"
-    ).fetchall()
-    return rows
+    # rocprofv3's rocpd schema suffixes its tables with the run's GUID; views without the suffix exist in newer versions
+    tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table', 'view')")]
+    disp = next((t for t in tables if t == "rocpd_kernel_dispatch"), None) or next(t for t in tables if t.startswith("rocpd_kernel_dispatch"))
+    sym = next((t for t in tables if t == "rocpd_info_kernel_symbol"), None) or next(t for t in tables if t.startswith("rocpd_info_kernel_symbol"))
+    cols = {r[1] for r in cur.execute(f"pragma table_info({disp})")}
+    grid = "d.grid_size_x" if "grid_size_x" in cols else ("d.grid_x" if "grid_x" in cols else "0")
+    wg = "d.workgroup_size_x" if "workgroup_size_x" in cols else ("d.workgroup_x" if "workgroup_x" in cols else "1")
+    rows = cur.execute(f"select s.kernel_name, d.end - d.start, {grid}, {wg} from {disp} d join {sym} s on d.kernel_id = s.id").fetchall()
+    return [(_label(name, g, w), dur) for name, dur, g, w in rows]
 
 
 def from_csv(path):
     rows = []
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"]
-        if name.startswith("void mmx::") or name.startswith("mmx::"):
-            wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
-            name = f"[{wg} wg] " + name
+        name = _label(r["Kernel_Name"], r["Grid_Size_X"], r["Workgroup_Size_X"])
         rows.append((name, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     return rows
+
+
+def demangle(names):
+    import shutil
+    import subprocess
+
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([tool], input="\n".join(n.replace(".kd", "") for n in names), capture_output=True, text=True, check=True).stdout.split("\n")
+        return dict(zip(names, out))
+    except Exception:
+        return {n: n for n in names}
 
 
 def main():
@@ -36,6 +57,8 @@ def main():
     agg = defaultdict(list)
     for name, dur in rows:
         agg[name].append(dur)
+    pretty = demangle([n.split("] ", 1)[-1] for n in agg])
+    agg = {(n.split("] ", 1)[0] + "] " if "] " in n else "") + pretty[n.split("] ", 1)[-1]]: v for n, v in agg.items()}
     total = sum(sum(v) for v in agg.values())
     print(f"{'kernel':<70} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}")
     for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):

@@ -6,6 +6,8 @@ momentum/test/character_solver/error_function_helpers.cpp:283-370 compares, it d
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 import bench
 from momentum_amd._abi import GnOptions
 
@@ -49,7 +51,7 @@ def test_baseline_workloads_within_1e5_of_the_oracle(torch_cuda, orc, config, B,
 def test_cfg2_all_through_the_fused_instantiation(torch_cuda, orc, monkeypatch):
     """P = 219 fits the one-launch solve with one workgroup per CU (NB = 14); the wide path is the default route for it
     because it is faster -- this keeps the fused instantiation covered."""
-    monkeypatch.setenv("MMX_PREFER_FUSED", "1")
+    monkeypatch.setattr(capi, "default_route", "fused")
     chk, _, _ = _solve_and_check(torch_cuda, "cfg2_all", 1024, 512)
     assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
 

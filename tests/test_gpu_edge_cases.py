@@ -4,6 +4,8 @@ compare, otherwise checked for the reference's documented behaviour."""
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd import make_test_character
 from momentum_amd._abi import GnOptions, ParameterLimit
 from tests.helpers import make_problem
@@ -33,11 +35,10 @@ def _upload(torch, pb, cons, B, **kw):
 @pytest.mark.parametrize("solver", ["fused", "v1"])
 def test_no_enabled_parameters_keeps_theta(torch_cuda, orc, solver, monkeypatch):
     # SolverT::setEnabledParameters with an empty set: the compacted system has size 0, theta is unchanged
-    from momentum_amd import capi
 
     torch = torch_cuda
     if solver == "v1":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_test_character(6)
     B = 3
     cons, th0, _ = make_problem(rig, [5, 2], [4], B, seed=1, theta0_scale=0.2)
@@ -54,7 +55,6 @@ def test_no_enabled_parameters_keeps_theta(torch_cuda, orc, solver, monkeypatch)
 
 
 def test_single_joint_single_instance(torch_cuda, orc):
-    from momentum_amd import capi
     from momentum_amd.rigs import Rig
 
     torch = torch_cuda
@@ -85,11 +85,10 @@ def test_single_joint_single_instance(torch_cuda, orc):
 def test_parameter_rows_only_no_joint_constraints(torch_cuda, orc, solver, monkeypatch):
     # Kp = Ko = 0: only the limit and model-parameter blocks; the solution of the regularised
     # quadratic is the oracle's
-    from momentum_amd import capi
 
     torch = torch_cuda
     if solver == "v1":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_test_character(5)
     P, B = rig.num_params, 2
     cons, _, _ = make_problem(rig, [], [], B, seed=2)
@@ -117,7 +116,6 @@ def test_parameter_rows_only_no_joint_constraints(torch_cuda, orc, solver, monke
 
 
 def test_unsupported_limit_type_is_a_loud_error(torch_cuda):
-    from momentum_amd import capi
     from momentum_amd._abi import ParameterLimit as PL
 
     torch = torch_cuda
@@ -140,9 +138,9 @@ def test_three_kernel_path_system_sizes(torch_cuda, orc, count, monkeypatch):
     """Explicit-Jacobian solver over the sizes of the dense system: partial 16-blocks of the blocked
     LDS Cholesky (panel rows / MFMA tiles beyond n), the 48-rows-per-wave limit of its panel (n <= 208),
     and the hand-over to the in-HBM factorisation once the factor no longer fits LDS."""
-    from momentum_amd import capi, make_humanoid72
+    from momentum_amd import make_humanoid72
     torch = torch_cuda
-    monkeypatch.setenv("MMX_SOLVER", "v1")
+    monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_humanoid72(seed=12345, variant="p219", unit=0.01)
     P, J = rig.num_params, rig.num_joints
     assert P == 219
@@ -180,7 +178,7 @@ def test_store_pattern_probe_writes_every_element(torch_cuda, case):
     roofline.store_pattern_gbs): every element of the [B][P][M] block is written, for the one-chunk
     layout (<= 64 units, streaming stores) and the chunked one (plain stores, column-outer); problems
     with further row blocks are refused."""
-    from momentum_amd import capi, make_humanoid72
+    from momentum_amd import make_humanoid72
     from momentum_amd import humanoid72_landmark_joints
 
     torch = torch_cuda
@@ -204,7 +202,6 @@ def test_passive_limits_are_ignored_like_in_the_reference(torch_cuda, orc):
     """LimitType::MinMaxJointPassive gets neither an error term nor a row from LimitErrorFunctionT
     (limit_error_function.cpp:836-837,1051-1052): a limit list with passive entries gives the J / r / error
     and the solve of the same list without them (rows compacted)."""
-    from momentum_amd import capi
     from momentum_amd._abi import ParameterLimit as PL
     from oracle import oracle as o
 
@@ -237,7 +234,6 @@ def test_passive_limits_are_ignored_like_in_the_reference(torch_cuda, orc):
 def test_row_major_jacobian_is_the_transpose(torch_cuda):
     """MMX_LAYOUT_ROW_MAJOR: J[b][i * P + p], bit-identical to the transposed column-major result (sizes
     that are not multiples of the 32 x 32 transposition tile; limits add rows after the joint rows)."""
-    from momentum_amd import capi
     from momentum_amd._abi import ParameterLimit as PL
 
     torch = torch_cuda
@@ -260,51 +256,15 @@ def test_row_major_jacobian_is_the_transpose(torch_cuda):
     assert np.array_equal(jh, jr.cpu().numpy())
 
 
-def test_two_kernel_jacobian_assembly_experiment_matches_the_default(torch_cuda, monkeypatch):
-    """MMX_JAC_TWO_KERNEL=1 (FK once per instance + a column kernel of four adjacent columns per workgroup, an
-    experiment DESIGN.md 4.1 reports as slower) must still write the same Jacobian: single-source, generic and
-    structurally zero columns, more units than lanes, a disabled parameter."""
-    from momentum_amd import capi, humanoid72_landmark_joints, make_humanoid72
-
-    torch = torch_cuda
-    for case in ("humanoid", "many_units"):
-        if case == "humanoid":
-            rig = make_humanoid72(unit=0.01)
-            lm = humanoid72_landmark_joints(rig)
-            pp, op, B = lm, lm, 9
-        else:
-            rig = make_test_character(12)
-            pp, op, B = list(range(12)) * 5, list(range(12)) * 3, 3  # 60 + 108 units
-        cons, th0, _ = make_problem(rig, pp, op, B, seed=17, theta0_scale=0.3, random_offsets=True, weights="random")
-        rh = capi.RigHandle(rig, 0)
-        pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
-        _upload(torch, pb, cons, B)
-        en = np.ones(rig.num_params, np.uint8)
-        en[3] = 0
-        pb.set_enabled(en)
-        theta = torch.from_numpy(th0.copy()).to(pb.device)
-        monkeypatch.delenv("MMX_JAC_TWO_KERNEL", raising=False)
-        j1, r1, e1 = pb.eval_jacobian(theta)
-        monkeypatch.setenv("MMX_JAC_TWO_KERNEL", "1")
-        j2, r2, e2 = pb.eval_jacobian(theta)
-        monkeypatch.delenv("MMX_JAC_TWO_KERNEL", raising=False)
-        # (the two forms are different instantiations: fma contraction may differ in the last bit)
-        assert float((r1 - r2).abs().max()) <= 2e-6 * max(1.0, float(r1.abs().max())) and float((e1 - e2).abs().max()) <= 1e-6 * max(1.0, float(e1.abs().max()))
-        scale = float(j1.abs().max())
-        assert float((j1 - j2).abs().max()) <= 2e-6 * scale  # (fma contraction may differ between the two kernels)
-        assert torch.equal(j1 == 0, j2 == 0)  # the same structural zeros
-
-
 @pytest.mark.parametrize("solver", ["fused", "v1"])
 def test_parameter_history_matches_the_iterates(torch_cuda, orc, solver, monkeypatch):
     """SolverT::setStoreHistory(true) (solver.cpp:53-72,101-110): iterationHistory_["parameters"].col(i) is the
     parameter vector after iteration i, untouched columns stay zero.  Checked against solves truncated at i + 1
     iterations (the solve is deterministic) and, for an element that converges early, against the zero rows."""
-    from momentum_amd import capi
 
     torch = torch_cuda
     if solver == "v1":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_test_character(8)
     B = 4
     cons, th0, _ = make_problem(rig, [7, 3], [6], B, seed=5, theta0_scale=0.2)

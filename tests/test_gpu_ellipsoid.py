@@ -4,6 +4,8 @@ error next to the other limit types and joint constraints, and Gauss-Newton / li
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd import _abi, humanoid72_landmark_joints, make_humanoid72, make_test_character
 from momentum_amd._abi import EllipsoidLimit, GnOptions, ParameterLimit
 from tests.helpers import make_problem
@@ -14,7 +16,6 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(torch, orc, which, B, seed, with_blocks):
-    from momentum_amd import capi
 
     if which == "chain8":
         rig, pp, op = make_test_character(8), [7, 3], [6]
@@ -104,14 +105,13 @@ def test_fused_solve_carries_blocks_and_ellipsoids(orc, which, monkeypatch):
     orientation constraints (the marker tracker's shape, marker_tracker.cpp:916-960): its normal equations
     (parity hook of the fused kernel -- only answered when the problem takes the fused path) against the oracle's
     J^T J / J^T r in double, then the solve under three step rules against the oracle and against the
-    explicit-Jacobian kernels (MMX_FUSED_GENERAL=0)."""
+    explicit-Jacobian kernels (MMX_ROUTE_EXPLICIT_JACOBIAN)."""
     import torch
 
     from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
     from tests.test_gpu_parity import _sensitivity
 
     B = 4
-    monkeypatch.delenv("MMX_FUSED_GENERAL", raising=False)
     rig, pb, full, th0 = _setup(torch, orc, which, B, 29, True)
     rng = np.random.default_rng(6)
     theta = rng.uniform(-0.4, 0.4, size=(B, rig.num_params)).astype(np.float32)
@@ -134,8 +134,8 @@ def test_fused_solve_carries_blocks_and_ellipsoids(orc, which, monkeypatch):
         ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
         tol = np.maximum(3e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
         outs = []
-        for general in ("1", "0"):
-            monkeypatch.setenv("MMX_FUSED_GENERAL", general)
+        for general in ("fused", "explicit_jacobian"):
+            pb.set_route(general)
             out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
             th = out["theta"].cpu().numpy()
             rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
@@ -143,8 +143,9 @@ def test_fused_solve_carries_blocks_and_ellipsoids(orc, which, monkeypatch):
             assert (out["status"].cpu().numpy() == 0).all()
             h = out["error_history"].cpu().numpy()
             assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
+            assert pb.last_route() == general
             outs.append(th)
-        monkeypatch.delenv("MMX_FUSED_GENERAL", raising=False)
+        pb.set_route("auto")
         assert not np.array_equal(outs[0], outs[1])  # two different routes really ran (fp32 rounding differs)
 
 
@@ -158,12 +159,11 @@ def test_wide_solve_carries_blocks_and_ellipsoids(orc, route, monkeypatch):
 
     import torch
 
-    from momentum_amd import capi, make_rig300
+    from momentum_amd import make_rig300
     from tests.test_gpu_parity import _sensitivity
 
     if route == "dense":
-        monkeypatch.setenv("MMX_TREE_NE", "0")
-        monkeypatch.setenv("MMX_TREE_REFINE", "0")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_rig300(seed=12345, unit=0.01)
     rng = np.random.default_rng(83)
     J, B = rig.num_joints, 3
@@ -204,9 +204,7 @@ def test_wide_solve_carries_blocks_and_ellipsoids(orc, route, monkeypatch):
         en[lst] = 1
         pb.set_enabled(en)  # only structurally non-zero columns: the enabled system IS the solve-list system
         theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
-        monkeypatch.setenv("MMX_TREE_NE", "force")
-        Ht, gt, _ = pb.normal_equations(torch.from_numpy(theta).to(pb.device))
-        monkeypatch.delenv("MMX_TREE_NE", raising=False)
+        Ht, gt = pb.tree_normal_equations(torch.from_numpy(theta).to(pb.device))
         Ht, gt = Ht.cpu().numpy(), gt.cpu().numpy()
         for b in range(B):
             Jm, r, e = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")

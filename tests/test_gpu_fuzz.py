@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd._abi import GnOptions, ParameterLimit
 from momentum_amd.rigs import _build_rig
 from tests.helpers import make_problem
@@ -69,11 +71,10 @@ def random_rig(rng, J, shape):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MMX_FUZZ_SEEDS", "48"))))
 def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
-    from momentum_amd import capi
 
     torch = torch_cuda
     if seed % 4 == 3:
-        monkeypatch.setenv("MMX_SOLVER", "v1")  # every fourth rig through the three-kernel path
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")  # every fourth rig through the three-kernel path
     rng = np.random.default_rng(1000 + seed)
     J = int(rng.integers(2, int(os.environ.get("MMX_FUZZ_JMAX", "48"))))  # (MMX_FUZZ_JMAX=100: the mid-size instantiations and the route switch)
     rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
@@ -145,7 +146,6 @@ def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
     host tables (flattened constraint lists, DFS indices, the stop index of the ellipsoid walk, the compacted
     solve list) on arbitrary trees -- J / r through the explicit-Jacobian kernels, the solve through the fused
     kernel's general rows."""
-    from momentum_amd import capi
     from momentum_amd._abi import EllipsoidLimit
     from tests.test_oracle_joint_blocks import TYPES, make_block
 
@@ -206,15 +206,13 @@ def test_random_rig_with_joint_blocks_and_ellipsoids(torch_cuda, orc, seed):
 def test_random_wide_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
     """Random trees of 100-170 joints with shared parameters, translation / scale dofs and transform offsets, more than
     224 solved parameters: the wide path (tree normal equations incl. the term records of multi-source columns,
-    paired-column / single-column factor, tree refinement) on shapes the 300-joint rig does not have; odd seeds keep some
-    parameters disabled, every fourth one takes the dense-J refinement, seeds 2 and 6 the directional line search."""
-    from momentum_amd import capi
+    paired-column factor, tree refinement) on shapes the 300-joint rig does not have; odd seeds keep some
+    parameters disabled, every fourth one takes the explicit-Jacobian route (dense J^T J on the matrix cores, the
+    refinement streaming J), seeds 2 and 6 the directional line search."""
 
     torch = torch_cuda
     if seed % 4 == 3:
-        monkeypatch.setenv("MMX_TREE_REFINE", "0")
-    if seed % 4 == 1:
-        monkeypatch.setenv("MMX_CHOL_PAIRS", "0")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rng = np.random.default_rng(9000 + seed)
     J = int(rng.integers(100, int(os.environ.get("MMX_FUZZ_WIDE_JMAX", "170"))))  # (MMX_FUZZ_WIDE_JMAX=195: up to the 512-parameter limit)
     rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
@@ -258,7 +256,7 @@ def test_random_wide_rig_with_extra_rows(torch_cuda, orc, seed):
     """The wide path's generalisations on random trees: parameter limits (every seed), the model-parameter prior (every
     second), a plane block of a few rows (two of three), per-element constraint parents (every fourth) -- the tree kernels'
     extra-rows instantiation against the oracle."""
-    from momentum_amd import _abi, capi
+    from momentum_amd import _abi
     from tests.test_oracle_joint_blocks import make_block
 
     torch = torch_cuda
@@ -337,7 +335,6 @@ def test_random_rig_double_solve_matches_oracle(torch_cuda, orc, seed):
     """mmx_solve_f64 on the random rigs (shared parameters, translation / scale dofs, transform offsets, enabled masks,
     every third with a line search): the oracle's double instantiation at 1e-8 (both run the same algorithm in the
     same precision; lambda = 0.5 keeps the degenerate rigs conditioned)."""
-    from momentum_amd import capi
 
     torch = torch_cuda
     rng = np.random.default_rng(13000 + seed)

@@ -3,6 +3,8 @@ CPU oracle, through the C ABI: J / r / error elementwise and the solve (fused an
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
 from momentum_amd._abi import GnOptions, MMX_LOSS_WELSCH
 from tests.helpers import make_problem
@@ -22,7 +24,6 @@ def torch_cuda():
 
 
 def _setup(torch, rig, pp, op, B, seed, loss, perturb):
-    from momentum_amd import capi
 
     cons, th0, ths = make_problem(rig, pp, op, B, seed=seed, perturb=perturb, random_offsets=True, weights="random")
     cons.pos_loss, cons.ori_loss = loss, (loss[0], 2 * loss[1])
@@ -62,7 +63,7 @@ def test_solve_with_robust_loss_matches_oracle(torch_cuda, orc, name, solver, mo
 
     torch = torch_cuda
     if solver == "v1":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_humanoid72(unit=UNIT)
     lm = humanoid72_landmark_joints(rig)
     B = 4

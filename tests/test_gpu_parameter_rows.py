@@ -3,6 +3,8 @@ ModelParametersErrorFunction) against the CPU oracle, throu
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
 from momentum_amd._abi import GnOptions, ParameterLimit
 from tests.helpers import make_problem
@@ -48,7 +50,6 @@ def _limits(P, rng, count, rig=None):
 
 
 def _problem(torch, orc, rig, pp, op, B, seed, with_limits=True, with_model=True):
-    from momentum_amd import capi
 
     cons, th0, ths = make_problem(rig, pp, op, B, seed=seed, perturb=0.3)
     P = rig.num_params
@@ -109,7 +110,7 @@ def test_parameter_rows_of_jacobian_match_oracle(torch_cuda, orc, which, blocks)
 @pytest.mark.parametrize("mode", ["gn", "line_search", "lm_schedule", "three_kernel"])
 def test_solve_with_limits_and_model_prior_matches_oracle(torch_cuda, orc, which, mode, monkeypatch):
     """The fused kernel folds the rows into g / H / the refinement / the line-search error on the fly;
-    MMX_SOLVER=v1 (three_kernel) goes through the dense J instead -- both must match the oracle."""
+    MMX_ROUTE_EXPLICIT_JACOBIAN (three_kernel) goes through the dense J instead -- both must match the oracle."""
     from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
     from tests.test_gpu_parity import _sensitivity
 
@@ -121,7 +122,7 @@ def test_solve_with_limits_and_model_prior_matches_oracle(torch_cuda, orc, which
         pp = op = humanoid72_landmark_joints(rig)
         B = 4
     if mode == "three_kernel":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rh, pb, full, th0 = _problem(torch, orc, rig, pp, op, B, 12345)
     kw = dict(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
     if mode == "line_search":
@@ -155,8 +156,7 @@ def test_wide_solve_with_limits_and_the_model_prior(torch_cuda, orc, route, monk
 
     torch = torch_cuda
     if route == "dense":
-        monkeypatch.setenv("MMX_TREE_NE", "0")
-        monkeypatch.setenv("MMX_TREE_REFINE", "0")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_rig300(seed=12345, unit=UNIT)
     rng = np.random.default_rng(79)
     pp = rng.choice(rig.num_joints, size=120, replace=False)
@@ -166,16 +166,13 @@ def test_wide_solve_with_limits_and_the_model_prior(torch_cuda, orc, route, monk
     if route == "tree":  # the tree-moment normal equations with the parameter-space rows against the oracle's J^T J / J^T r
         import ctypes as C
 
-        from momentum_amd import capi
 
         buf, nn = np.zeros(rig.num_params, np.int32), C.c_int32(0)
         capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(nn), None))
         lst = buf[: nn.value]
         assert nn.value == rig.num_params  # the model prior keeps every parameter in the solve list
         theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
-        monkeypatch.setenv("MMX_TREE_NE", "force")
-        Ht, gt, _ = pb.normal_equations(torch.from_numpy(theta).to(pb.device))
-        monkeypatch.delenv("MMX_TREE_NE", raising=False)
+        Ht, gt = pb.tree_normal_equations(torch.from_numpy(theta).to(pb.device))
         Ht, gt = Ht.cpu().numpy(), gt.cpu().numpy()
         for b in range(B):
             Jm, r, e = orc.eval_jacobian(rig, full.instance(b), theta[b].astype(np.float64), dtype="f64")

@@ -4,6 +4,8 @@ parameters (stated at each assert)."""
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
 from momentum_amd._abi import GnOptions
 from tests.helpers import make_problem
@@ -23,7 +25,6 @@ def torch_cuda():
 
 
 def _gpu_problem(torch, rig, cons, B):
-    from momentum_amd import capi
 
     rh = capi.RigHandle(rig, 0)
     pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
@@ -204,31 +205,42 @@ def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
 
 
-def _staged():
-    """The per-rule instantiations of the fused kernel (MMX_FUSED_PLAIN=1) were written after the round's GPU budget was
-    spent: their tests run on request (MMX_TEST_STAGED=1, scripts/gpu_variant_suite.sh) until they have passed on a GPU
-    once and the instantiations become the default."""
-    import os
+def _vacuous_limit():
+    """A MinMax limit that is never active (no error, zero Jacobian row): a problem that carries it has a parameter-space
+    row, so the fused solve takes its GENERAL instantiation instead of the one compiled per step rule."""
+    from momentum_amd._abi import ParameterLimit
 
-    if os.environ.get("MMX_TEST_STAGED") != "1":
-        pytest.skip("staged code path, not yet run on a GPU: MMX_TEST_STAGED=1 runs it")
+    return [ParameterLimit.minmax(0, -1e9, 1e9, 1.0)]
+
+
+def _gpu_problem_with_vacuous_limit(torch, rig, cons, B):
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(
+        t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+        t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+        cons.pos_function_weight, cons.ori_function_weight, limits=_vacuous_limit(),
+    )  # fmt: skip
+    return rh, pb
 
 
 @pytest.mark.parametrize("name", ["chain24_cfg1", "humanoid72_cfg2", "humanoid72_many_units"])
-def test_plain_gauss_newton_instantiation_matches_the_general_one(torch_cuda, orc, name, monkeypatch):
-    """MMX_FUSED_PLAIN=1 launches the fused kernel's instantiation for GaussNewtonSolverT without a line search (the
-    LM schedule and the backtracking loops compiled out): the same arithmetic on the same path, so the same iterates as
-    the general instantiation up to the compiler's scheduling, and the same parity with the oracle."""
-    _staged()
+def test_plain_gauss_newton_instantiation_matches_the_general_one(torch_cuda, orc, name):
+    """Problems without parameter-space rows run the fused kernel's instantiation per step rule (for GaussNewtonSolverT
+    without a line search: the LM schedule, the backtracking loops and the on-the-fly limit rows compiled out); with a
+    (vacuous) limit row the same problem runs the general instantiation.  The same arithmetic on the same path: the same
+    iterates up to the compiler's scheduling, and the same parity with the oracle."""
     torch = torch_cuda
     rig, pp, op, B = _case(name)
     cons, th0, ths = make_problem(rig, pp, op, B, seed=777, perturb=0.3)
     rh, pb = _gpu_problem(torch, rig, cons, B)
+    rhg, pbg = _gpu_problem_with_vacuous_limit(torch, rig, cons, B)
     opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
-    general = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
-    monkeypatch.setenv("MMX_FUSED_PLAIN", "1")
+    general = pbg.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     plain = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     plain2 = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert pb.last_route() == "fused" and pbg.last_route() == "fused"
     assert torch.equal(plain["theta"], plain2["theta"])  # deterministic
     assert torch.equal(plain["iterations"], general["iterations"]) and torch.equal(plain["status"], general["status"])
     a, b = plain["theta"].cpu().numpy(), general["theta"].cpu().numpy()
@@ -237,11 +249,12 @@ def test_plain_gauss_newton_instantiation_matches_the_general_one(torch_cuda, or
     if name.startswith("humanoid"):  # (the under-determined chain amplifies a rounding difference beyond any fixed bound)
         assert (np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)).max() <= 5e-6
         ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
-        rel = np.linalg.norm(a - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
-        assert rel.max() <= 1e-5, rel
+        for x in (a, b):
+            rel = np.linalg.norm(x - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+            assert rel.max() <= 1e-5, rel
 
 
-@pytest.mark.parametrize("path", ["fused", "three_kernel", "fused_per_rule"])
+@pytest.mark.parametrize("path", ["fused", "three_kernel", "fused_general"])
 @pytest.mark.parametrize("mode", ["line_search", "line_search_directional", "lm_schedule"])
 def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, monkeypatch):
     """GaussNewtonSolverT with doLineSearch (gauss_newton_solver.cpp:283-313) and the LM gain-ratio
@@ -251,13 +264,13 @@ def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, m
 
     torch = torch_cuda
     if path == "three_kernel":  # explicit J -> J^T J -> Cholesky step -> stepUpdateKernel
-        monkeypatch.setenv("MMX_SOLVER", "v1")
-    if path == "fused_per_rule":  # the fused kernel's instantiation for the LM schedule alone (line searches: the general one)
-        _staged()
-        monkeypatch.setenv("MMX_FUSED_PLAIN", "1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig, pp, op, B = _case("humanoid72_cfg2")
     cons, th0, ths = make_problem(rig, pp, op, B, seed=4242, perturb=0.3)
-    rh, pb = _gpu_problem(torch, rig, cons, B)
+    if path == "fused_general":  # (path "fused": the LM schedule runs the instantiation compiled for it alone; here the general one)
+        rh, pb = _gpu_problem_with_vacuous_limit(torch, rig, cons, B)
+    else:
+        rh, pb = _gpu_problem(torch, rig, cons, B)
     if mode == "line_search":
         opt = GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, do_line_search=True)
     elif mode == "line_search_directional":  # SubsetGaussNewtonSolverT / GaussNewtonSolverQRT rule
@@ -293,7 +306,7 @@ def test_line_search_backtracking_matches_oracle(torch_cuda, orc, rule, path, mo
     build the instance is only required to have decreased its error."""
     torch = torch_cuda
     if path == "three_kernel":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig, pp, op, _ = _case("humanoid72_cfg2")
     B = 48
     cons, th0, ths = make_problem(rig, pp, op, B, seed=4242, perturb=3.0)
@@ -542,7 +555,6 @@ def test_tree_moment_normal_equations_match_the_dense_product_on_the_wide_rig(to
     rh, pb = _gpu_problem(torch, rig, cons, B)
     import ctypes as C
 
-    from momentum_amd import capi
 
     buf = np.zeros(rig.num_params, np.int32)
     nn = C.c_int32(0)
@@ -553,11 +565,8 @@ def test_tree_moment_normal_equations_match_the_dense_product_on_the_wide_rig(to
     pb.set_enabled(en)
     theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
     td = torch.from_numpy(theta).to(pb.device)
-    monkeypatch.delenv("MMX_TREE_NE", raising=False)
     Hd, gd, _ = pb.normal_equations(td)
-    monkeypatch.setenv("MMX_TREE_NE", "force")
-    Ht, gt, _ = pb.normal_equations(td)
-    monkeypatch.delenv("MMX_TREE_NE", raising=False)
+    Ht, gt = pb.tree_normal_equations(td)
     Hd, Ht, gd, gt = Hd.cpu().numpy(), Ht.cpu().numpy(), gd.cpu().numpy(), gt.cpu().numpy()
     for b in range(B):
         Jm, r, e = orc.eval_jacobian(rig, cons.instance(b), theta[b].astype(np.float64), enabled=en, dtype="f64")
@@ -569,38 +578,27 @@ def test_tree_moment_normal_equations_match_the_dense_product_on_the_wide_rig(to
         assert np.abs(gt[b] - g).max() <= 5e-5 * max(1.0, np.abs(g).max())
     opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05)
     out_tree = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)["theta"].cpu().numpy()
-    monkeypatch.setenv("MMX_TREE_NE", "0")
+    assert pb.last_route() == "wide"
+    pb.set_route("explicit_jacobian")
     out_dense = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)["theta"].cpu().numpy()
-    monkeypatch.delenv("MMX_TREE_NE", raising=False)
+    assert pb.last_route() == "explicit_jacobian"
     ref = orc.solve_batch(rig, cons, th0, opt, enabled=en, dtype="f64")
     for th in (out_tree, out_dense):
         rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
         assert rel.max() <= 2e-5, rel
 
 
-@pytest.mark.parametrize(
-    "variant",
-    [
-        {},  # tree normal equations + left-looking factor + refinement through the tree (no dense J)
-        {"MMX_TREE_REFINE": "0"},  # ... refinement streaming the dense J (choleskyStepTiledKernel)
-        {"MMX_CHOL_RIGHT_LOOKING": "1"},  # ... right-looking factor in place (choleskyStepGlobalKernel)
-        {"MMX_TREE_NE": "0", "MMX_TREE_REFINE": "0"},  # dense J^T J on the matrix cores
-        {"MMX_CHOL_LEAN": "1"},  # the factor kernel with the production form alone (staged: MMX_TEST_STAGED=1)
-        {"MMX_TREE_NE_WAVES": "8"},  # tree normal equations by eight waves per workgroup (staged likewise)
-    ],
-    ids=["tree", "dense_refine", "right_looking", "dense_product", "lean_factor", "tree_8_waves"],
-)
+@pytest.mark.parametrize("variant", ["wide", "explicit_jacobian"])
 def test_wide_solve_variants_agree_with_the_oracle(torch_cuda, orc, variant, monkeypatch):
-    """The four routes of the wide explicit solve (300-joint rig) under the LM schedule and with elements that
-    converge at different iterations: same pose parameters, iteration counts and statuses as the oracle."""
+    """The two routes of a wide solve (300-joint rig) -- tree normal equations + left-looking factor + refinement through
+    the tree (no dense J), and the explicit-Jacobian kernels (dense J^T J on the matrix cores, the refinement streaming
+    J) -- under the LM schedule and with elements that converge at different iterations: same pose parameters, iteration
+    counts and statuses as the oracle."""
     from momentum_amd import make_rig300
     from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
 
-    if "MMX_CHOL_LEAN" in variant or "MMX_TREE_NE_WAVES" in variant:
-        _staged()
     torch = torch_cuda
-    for k, v in variant.items():
-        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(capi, "default_route", variant)
     rig = make_rig300(seed=12345, unit=UNIT)
     rng = np.random.default_rng(78)
     pp = rng.choice(rig.num_joints, size=150, replace=False)
@@ -625,16 +623,14 @@ def test_wide_solve_variants_agree_with_the_oracle(torch_cuda, orc, variant, mon
             assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]), (out["iterations"], ref["iterations"])
 
 
-@pytest.mark.parametrize("pairs", ["1", "0"])
-def test_wide_path_on_a_small_skeleton_with_many_units(torch_cuda, orc, pairs, monkeypatch):
+def test_wide_path_on_a_small_skeleton_with_many_units(torch_cuda, orc, monkeypatch):
     """The wide path's other shapes: the 72-joint humanoid with constraints on EVERY joint (P = 219, n = 219: an even
-    number of 16-blocks; U = 288 units > J joints, so the tree kernels take their per-joint loops) forced onto the
-    explicit route (MMX_SOLVER=v1; by default this problem fits the fused solve), both factor forms."""
+    number of 16-blocks; U = 288 units > J joints, so the tree kernels take their per-joint loops) pinned to the
+    wide route (MMX_ROUTE_WIDE)."""
     import bench
 
     torch = torch_cuda
-    monkeypatch.setenv("MMX_SOLVER", "v1")
-    monkeypatch.setenv("MMX_CHOL_PAIRS", pairs)
+    monkeypatch.setattr(capi, "default_route", "wide")
     rig, parents, _, _, _ = bench.build_rig("cfg2_all")
     B = 48
     db = bench.DeviceBatch(rig, parents, B, 0, 31337)

@@ -8,6 +8,8 @@ import copy
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
 from momentum_amd._abi import GnOptions
 from tests.helpers import make_problem
@@ -76,11 +78,10 @@ def _check_solve(torch, orc, pb, rigs, cons, th0, pos_parents, ori_parents, opt,
 @pytest.mark.parametrize("solver", ["fused", "v1"])
 @pytest.mark.parametrize("memory", ["device", "host"])
 def test_per_instance_characters(torch_cuda, orc, solver, memory, monkeypatch):
-    from momentum_amd import capi
 
     torch = torch_cuda
     if solver == "v1":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_humanoid72(unit=UNIT)
     lm = humanoid72_landmark_joints(rig)
     B = 6
@@ -123,11 +124,10 @@ def test_per_instance_characters(torch_cuda, orc, solver, memory, monkeypatch):
 @pytest.mark.parametrize("solver", ["fused", "v1"])
 @pytest.mark.parametrize("which", ["humanoid72", "chain9"])
 def test_per_instance_constraint_parents(torch_cuda, orc, solver, which, monkeypatch):
-    from momentum_amd import capi
 
     torch = torch_cuda
     if solver == "v1":
-        monkeypatch.setenv("MMX_SOLVER", "v1")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rng = np.random.default_rng(57)
     if which == "humanoid72":
         rig = make_humanoid72(unit=UNIT)
@@ -177,7 +177,6 @@ def test_per_instance_characters_on_the_wide_path(torch_cuda, orc):
     """Per-element rig constants on a problem that takes the wide path (P = 219, constraints on every joint: tree normal
     equations -> tiled factor -> tree refinement): every element against the oracle on its own character, with and
     without the line search (whose trial errors re-run FK on the element's constants)."""
-    from momentum_amd import capi
 
     torch = torch_cuda
     rig = make_humanoid72(variant="p219", unit=UNIT)
@@ -202,12 +201,10 @@ def test_per_instance_constraint_parents_on_the_wide_path(torch_cuda, orc, route
     """Per-element constraint parents on a problem of 219 solved parameters (wide path): every element constrains its own
     60 + 30 joints; the tree kernels build the element's units-per-joint lists in LDS like the fused solve does
     (buildInstanceUnitTables), the dense route reads the per-element parents in the J assembly."""
-    from momentum_amd import capi
 
     torch = torch_cuda
     if route == "dense":
-        monkeypatch.setenv("MMX_TREE_NE", "0")
-        monkeypatch.setenv("MMX_TREE_REFINE", "0")
+        monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     rig = make_humanoid72(variant="p219", unit=UNIT)
     J, B, Kp, Ko = rig.num_joints, 4, 60, 30
     rng = np.random.default_rng(59)

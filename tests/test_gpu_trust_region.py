@@ -4,6 +4,8 @@ TrustRegionTest shapes in tests/test_oracle_golden.py)."""
 import numpy as np
 import pytest
 
+from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
+
 from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
 from momentum_amd._abi import MMX_STEP_TRUST_REGION, GnOptions
 from tests.helpers import make_problem
@@ -13,7 +15,6 @@ UNIT = 0.01
 
 
 def _gpu(torch, rig, cons, B):
-    from momentum_amd import capi
 
     rh = capi.RigHandle(rig, 0)
     pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
@@ -83,13 +84,12 @@ def test_trust_region_on_the_humanoid_does_at_least_as_well_as_gauss_newton(torc
 
 
 def test_trust_region_needs_the_fused_solver(torch_cuda, monkeypatch):
-    from momentum_amd import capi
 
     torch = torch_cuda
     rig = make_test_character(5)
     cons, th0, _ = make_problem(rig, [4], [3], 2, seed=1)
     rh, pb = _gpu(torch, rig, cons, 2)
-    monkeypatch.setenv("MMX_SOLVER", "v1")
+    monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
     with pytest.raises(capi.MmxError) as ei:
         pb.solve(torch.from_numpy(th0.copy()).to(pb.device), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION))
     assert "fused" in str(ei.value)

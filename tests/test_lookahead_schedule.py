@@ -1,4 +1,4 @@
-"""Schedule of the fused solve's lookahead experiment (mmx_fused.hip, MMX_EXP_LOOKAHEAD), block level: during panel k's
+"""Schedule of the fused solve's lookahead (mmx_fused.hip, phase H: kLook), block level: during panel k's
 elimination the waves without a panel row take the contributions of the block columns j < k to block column k + 1, so
 that the left-looking update in front of panel k + 1 is left with column k's alone.  Checked here: the schedule computes
 the Cholesky factor, and a wave without a panel row exists at every step it is used at (NB <= 8)."""
