@@ -252,7 +252,7 @@ def cpu_baseline(db: DeviceBatch, sample, options, dtype="f32"):
         "unit": "solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"the first {sample} instances of the timed batch, {dtype}, oracle built -O3 -march=native on {orc.host_cpu()}, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
+        "sample": f"the first {sample} instances of the timed batch, {dtype}, oracle build: {orc.build_info()}, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
         "single_thread_value": n1 / dt1,
     }
 

@@ -59,12 +59,14 @@ typedef enum mmx_status {
 #define MMX_SOLVE_NONFINITE 1 /* NaN/Inf result -> theta reverted to theta_init
                                  (pymomentum/tensor_ik/tensor_ik.cpp:168-173) */
 #define MMX_SOLVE_NOT_PD 2 /* a Cholesky pivot came out non-positive in single precision (J rank deficient and
-                              lambda below the rounding of J^T J).  Informational: the pivot is floored at 2^-20 of
-                              its row's H_jj + lambda, the factorisation completes and the step IS taken -- like the
+                              lambda below the rounding of J^T J).  Informational: a pivot at or below 2^-18 of its
+                              row's H_jj + lambda drops that column from the iteration's step (zero step in that
+                              parameter, the others solve the reduced system) and the step IS taken -- like the
                               reference, which never checks LLT::info() (gauss_newton_solver.cpp:251); its double
                               instantiation does not meet such pivots, its float instantiation hands Eigen's aborted
-                              factor to solve().  The refinement step pulls the step back to the true lambda wherever
-                              J determines it. */
+                              factor to solve().  The objective converges like the reference's; the components of
+                              theta that J does not determine differ from the double solver's minimum-norm ones
+                              (tests/test_gpu_weak_damping.py). */
 
 /* Where the caller's bulk arrays live. */
 #define MMX_MEM_HOST 0
@@ -248,6 +250,17 @@ typedef struct mmx_constraint_data {
      [3 Kp][9 Ko][blocks][3 num_ellipsoid_limits][num_limits][P].  HOST array (copied). */
   int32_t num_ellipsoid_limits;
   const mmx_ellipsoid_limit* ellipsoid_limits;
+  /* ---- per-element error-function weights = errorFunctionWeights[iBatch][weightsMap[iErr]] of the batched driver
+     (pymomentum/tensor_ik/tensor_ik.cpp:100-101,137-138; tensor_ik_utility.cpp:162-177: every error function of
+     element iBatch gets setWeight(that entry)).  NULL = none.  [B][num_function_weights] floats, same memory kind as
+     the constraint arrays (device: borrowed), columns:
+        0 position block   1 orientation block   2 limit block (parameter + ellipsoid limits)
+        3 model-parameter block   4 + i joint block i        (columns past num_function_weights count as 1)
+     Element b's weight_ of a block = the block's scalar function weight above x function_weights[b][column]; the
+     driver's weights go here with the scalars left at 1.  A product <= 0 switches the block off for that element
+     (skeleton_solver_function.cpp:223-231), like weightsMap[iErr] < 0 does (weight 0, tensor_ik_utility.cpp:176). */
+  const float* function_weights;
+  int32_t num_function_weights;
 } mmx_constraint_data;
 
 /*
@@ -369,7 +382,7 @@ int32_t mmx_problem_set_instance_parents(
  *                                refinement through the tree (<= 512 solved parameters; the default from 177 on)
  *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores) -> Cholesky step; the route for problems
  *                                outside the tree kernels' scope
- * Nothing here changes WHAT is computed (same algorithm, same refinement); results of different routes agree to
+ * The route does not change WHAT is computed (same algorithm, same refinement); results of different routes agree to
  * rounding (tests/test_gpu_weak_damping.py, tests/test_gpu_fuzz.py).
  */
 #define MMX_ROUTE_AUTO 0
@@ -378,7 +391,11 @@ int32_t mmx_problem_set_instance_parents(
 #define MMX_ROUTE_EXPLICIT_JACOBIAN 3
 typedef struct mmx_tuning {
   int32_t route; /* MMX_ROUTE_* */
-  int32_t reserved[7]; /* must be zero */
+  int32_t max_refinement_steps; /* iterative-refinement steps a solve may take per iteration on top of the fp32 Cholesky
+                                   solve (each measures its residual through J itself): 0 = the default, up to three (a
+                                   further one only while the last correction exceeded 1e-3 of the step); 1..3 = at most
+                                   that many; -1 = none (a measurement switch: north_star's 1e-5 needs the refinement) */
+  int32_t reserved[6]; /* must be zero */
 } mmx_tuning;
 int32_t mmx_problem_set_tuning(mmx_problem* problem, const mmx_tuning* tuning);
 /* MMX_ROUTE_* the last mmx_solve / mmx_solve_with_history on this handle took (MMX_ROUTE_AUTO before the first). */

@@ -410,6 +410,18 @@ class BatchedSkeletonSolverFunction {
     wOri_ = orientationWeight;
     dirty_ = true;
   }
+  // Per-element error-function weights: errorFunctionWeights[iBatch][weightsMap[iErr]] of solveTensorIKProblem
+  // (pymomentum/tensor_ik/tensor_ik.cpp:100-101,137-138; every error function of element iBatch gets setWeight(entry),
+  // tensor_ik_utility.cpp:162-177).  weights: [batch][columns] row-major, columns = position, orientation, limits,
+  // model parameters, joint block 0, 1, ... (mmx_constraint_data::function_weights); an empty vector removes them.
+  void setErrorFunctionWeights(const std::vector<float>& weights, size_t columns) {
+    if (!weights.empty() && (columns == 0 || weights.size() != batch_ * columns)) {
+      throw std::runtime_error("momentum_amd: error-function weights must be [batch][columns]");
+    }
+    fnWeights_ = weights;
+    fnCols_ = weights.empty() ? 0 : columns;
+    dirty_ = true;
+  }
   // LimitErrorFunctionT::setLimits (limit_error_function.h:88) for every element, with its weight_
   void setLimits(const ParameterLimits& limits, float weight = 1.f) {
     limits_.clear();
@@ -543,6 +555,8 @@ class BatchedSkeletonSolverFunction {
     }
     d.num_joint_blocks = int32_t(jb.size());
     d.joint_blocks = jb.empty() ? nullptr : jb.data();
+    d.function_weights = fnWeights_.empty() ? nullptr : fnWeights_.data();
+    d.num_function_weights = int32_t(fnCols_);
     check(mmx_problem_set_constraints(handle_.get(), &d, nullptr));
     // per-element parent lists only when some element departs from the constructor's lists
     auto departs = [&](const std::vector<int32_t>& all, const std::vector<int32_t>& shared) {
@@ -618,6 +632,8 @@ class BatchedSkeletonSolverFunction {
   std::vector<mmx_parameter_limit> limits_;
   std::vector<float> mpTarget_, mpWeights_;
   float wPos_ = 1.f, wOri_ = 1.f, wLimit_ = 1.f, wModel_ = 1.f;
+  std::vector<float> fnWeights_; // [batch][fnCols_] per-element error-function weights, or empty
+  size_t fnCols_ = 0;
   float lossPos_[2] = {2.f, 1.f}, lossOri_[2] = {2.f, 1.f};
   bool dirty_ = true;
 };

@@ -255,6 +255,9 @@ class ConstraintData(C.Structure):
         # Ellipsoid entries of the limit block (host array of EllipsoidLimit)
         ("num_ellipsoid_limits", C.c_int32),
         ("ellipsoid_limits", C.c_void_p),
+        # per-element error-function weights [B][num_function_weights] (columns: position, orientation, limits, model, blocks...)
+        ("function_weights", C.c_void_p),
+        ("num_function_weights", C.c_int32),
     ]
 
 
@@ -312,7 +315,7 @@ ROUTES = {"auto": 0, "fused": 1, "wide": 2, "explicit_jacobian": 3}  # MMX_ROUTE
 class Tuning(C.Structure):
     """mmx_tuning: which kernels mmx_solve runs (include/mmx.h)."""
 
-    _fields_ = [("route", C.c_int32), ("reserved", C.c_int32 * 7)]
+    _fields_ = [("route", C.c_int32), ("max_refinement_steps", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 def as_ptr(a: np.ndarray, ctype):

@@ -215,9 +215,10 @@ class Problem:
             pass
 
     # -- which kernels mmx_solve runs (mmx_tuning): "auto" | "fused" | "wide" | "explicit_jacobian"
-    def set_route(self, route: str) -> None:
+    def set_route(self, route: str, max_refinement_steps: int = 0) -> None:
         t = _abi.Tuning()
         t.route = _abi.ROUTES[route]
+        t.max_refinement_steps = int(max_refinement_steps)  # 0 default (up to three), -1 none, 1..3
         _check(lib().mmx_problem_set_tuning(self._h, C.byref(t)))
 
     def last_route(self) -> str:
@@ -237,7 +238,7 @@ class Problem:
         pos_function_weight: float = 1.0, ori_function_weight: float = 1.0,
         limits=None, limit_function_weight: float = 1.0,
         model_target=None, model_weights=None, model_function_weight: float = 1.0,
-        pos_loss=(2.0, 1.0), ori_loss=(2.0, 1.0), joint_blocks=None, ellipsoid_limits=None,
+        pos_loss=(2.0, 1.0), ori_loss=(2.0, 1.0), joint_blocks=None, ellipsoid_limits=None, function_weights=None,
     ) -> None:  # fmt: skip
         """limits: list of _abi.ParameterLimit (batch-shared, LimitErrorFunction);
         model_target / model_weights: [B,P] (ModelParametersErrorFunction), same memory kind as the
@@ -245,7 +246,9 @@ class Problem:
         pos_loss / ori_loss: GeneralizedLoss (alpha, c) of the two joint-constraint blocks
         (alpha 2 = L2, 1 = L1, 0 = Cauchy, _abi.MMX_LOSS_WELSCH = Welsch, else Barron's general form).
         joint_blocks: list of _abi.JointBlock (Plane / Aim / FixedAxis / Normal error functions), payload
-        of the same memory kind as the constraint arrays; their rows follow the orientation rows."""
+        of the same memory kind as the constraint arrays; their rows follow the orientation rows.
+        function_weights: [B, C] per-element error-function weights (errorFunctionWeights of solveTensorIKProblem), columns
+        position, orientation, limits, model parameters, joint block 0, ...; same memory kind as the constraint arrays."""
         import torch
 
         arrs = [pos_offset, pos_target, pos_weight, ori_offset, ori_target, ori_weight]
@@ -266,6 +269,16 @@ class Problem:
                 ptrs.append(C.c_void_p(x.ctypes.data if x.size else 0))
         if model_target is None:
             ptrs += [C.c_void_p(0), C.c_void_p(0)]
+        fw_ptr, fw_cols = C.c_void_p(0), 0
+        if function_weights is not None:
+            if on_dev:
+                assert function_weights.is_cuda and function_weights.dtype == torch.float32 and function_weights.is_contiguous() and function_weights.shape[0] == self.B
+                keep.append(function_weights)
+                fw_ptr, fw_cols = C.c_void_p(function_weights.data_ptr()), int(function_weights.shape[1])
+            else:
+                fwh = np.ascontiguousarray(function_weights, dtype=np.float32).reshape(self.B, -1)
+                keep.append(fwh)
+                fw_ptr, fw_cols = C.c_void_p(fwh.ctypes.data), int(fwh.shape[1])
         limits = list(limits) if limits else []
         larr = _abi.limit_array(limits)
         blocks = list(joint_blocks) if joint_blocks else []
@@ -279,6 +292,7 @@ class Problem:
             float(pos_loss[0]), float(pos_loss[1]), float(ori_loss[0]), float(ori_loss[1]),
             len(blocks), C.cast(barr, C.c_void_p) if blocks else None,
             len(ells), C.cast(earr, C.c_void_p) if ells else None,
+            fw_ptr, fw_cols,
         )  # fmt: skip
         _check(lib().mmx_problem_set_constraints(self._h, C.byref(cd), _stream_ptr()))
         self._keep = keep + bkeep if on_dev else []

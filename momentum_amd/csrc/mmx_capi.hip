@@ -178,6 +178,8 @@ struct mmx_problem {
   mmx::RigDev rigDev{}; // the rig as this problem's kernels see it: rig->dev + the per-instance pointers
   DevBuf oInstOffset, oInstPreRot, oInstPosParent, oInstOriParent, dJointTin;
   std::vector<int32_t> unionPos, unionOri; // joints that carry a position / orientation constraint in some element
+  std::vector<int32_t> instPosHost, instOriHost; // the lists of the last mmx_problem_set_instance_parents call (host copies)
+  bool instParentsFromHost = false;
   bool instPos = false, instOri = false;
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
@@ -186,7 +188,7 @@ struct mmx_problem {
   DevBuf dLimStart, dLimOf, dPairDest, dPairStart, dPairLim, dPairCols;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
-  DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight, oMpTarget, oMpWeights, dLimits, dEnabledMask;
+  DevBuf oPosOffset, oPosTarget, oPosWeight, oOriOffset, oOriTarget, oOriWeight, oMpTarget, oMpWeights, dLimits, dEnabledMask, oFnWeights;
   std::vector<mmx_parameter_limit> limits; // host copy (solve-list bookkeeping)
   // further joint-constraint blocks: host copy of the descriptors (payload pointers cleared) and parents
   struct JointBlockHost {
@@ -778,6 +780,12 @@ bool treeNormalEquationsUsable(const mmx_problem* pb) {
 // profiling aid (one of the library's two environment reads; the other is MMX_NO_ROCTX, the marker switch): per-phase cycle
 // counters of workgroup 0, printed to stderr after the solve.  Not on any product path: the clocked instantiation is a
 // separate kernel.
+// refinement steps a solve may take per iteration (mmx_tuning::max_refinement_steps: 0 = the default, three; -1 = none)
+int32_t refineSteps(const mmx_problem* pb) {
+  const int32_t m = pb->tuning.max_refinement_steps;
+  return m == 0 ? 3 : (m < 0 ? 0 : (m > 3 ? 3 : m));
+}
+
 bool phaseClocksWanted() {
   static const bool wanted = getenv("MMX_PHASE_CLOCKS") != nullptr;
   return wanted;
@@ -1091,6 +1099,9 @@ int32_t mmx_problem_set_tuning(mmx_problem* pb, const mmx_tuning* tuning) {
   if (tuning->route < MMX_ROUTE_AUTO || tuning->route > MMX_ROUTE_EXPLICIT_JACOBIAN) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_tuning::route: unknown MMX_ROUTE_* value");
   }
+  if (tuning->max_refinement_steps < -1 || tuning->max_refinement_steps > 3) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_tuning::max_refinement_steps: -1 (none), 0 (default) or 1..3");
+  }
   for (int32_t r : tuning->reserved) {
     if (r != 0) {
       return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_tuning::reserved must be zero");
@@ -1217,6 +1228,10 @@ int32_t mmx_problem_set_instance_parents(mmx_problem* pb, const int32_t* pos_par
     }
     seenO[size_t(j)] = 1;
   }
+  // unchanged lists (the C++ shell re-sends them with every constraint update): nothing to do
+  if (memory == MMX_MEM_HOST && !pb->tablesDirty && pb->instParentsFromHost && hp == pb->instPosHost && ho == pb->instOriHost) {
+    return MMX_OK;
+  }
   auto place = [&](DevBuf& buf, const int32_t* src, const std::vector<int32_t>& host, const int32_t*& dst) -> hipError_t {
     if (host.empty()) {
       dst = nullptr;
@@ -1231,26 +1246,38 @@ int32_t mmx_problem_set_instance_parents(mmx_problem* pb, const int32_t* pos_par
       return e;
     }
     dst = buf.as<int32_t>();
-    return hipMemcpy(buf.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    // on the caller's stream: ordered after the kernels in flight there that still read the previous lists
+    e = hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
   };
   const int32_t *dp = nullptr, *dq = nullptr;
   MMX_HIP(place(pb->oInstPosParent, pos_parent, hp, dp));
   MMX_HIP(place(pb->oInstOriParent, ori_parent, ho, dq));
-  pb->tablesDirty = true;
+  std::vector<int32_t> unionPos, unionOri;
+  for (int32_t j = 0; j < pb->rig->J; ++j) {
+    if (seenP[size_t(j)]) {
+      unionPos.push_back(j);
+    }
+    if (seenO[size_t(j)]) {
+      unionOri.push_back(j);
+    }
+  }
+  // the integer bookkeeping (solve list, structurally zero columns) depends on the UNION of the batch's parents only:
+  // new lists over the same joints need no rebuild -- the kernels read the lists themselves
+  const bool sameTables = !pb->tablesDirty && (dp != nullptr) == pb->instPos && (dq != nullptr) == pb->instOri && unionPos == pb->unionPos && unionOri == pb->unionOri;
   pb->dev.instPosParent = dp;
   pb->dev.instOriParent = dq;
   pb->instPos = dp != nullptr;
   pb->instOri = dq != nullptr;
-  pb->unionPos.clear();
-  pb->unionOri.clear();
-  for (int32_t j = 0; j < pb->rig->J; ++j) {
-    if (seenP[size_t(j)]) {
-      pb->unionPos.push_back(j);
-    }
-    if (seenO[size_t(j)]) {
-      pb->unionOri.push_back(j);
-    }
+  pb->instParentsFromHost = memory == MMX_MEM_HOST;
+  pb->instPosHost = std::move(hp);
+  pb->instOriHost = std::move(ho);
+  if (sameTables) {
+    return MMX_OK;
   }
+  pb->tablesDirty = true;
+  pb->unionPos = std::move(unionPos);
+  pb->unionOri = std::move(unionOri);
   rc = uploadProblemTables(pb); // solve list, structurally zero columns: over the union of the batch
   if (rc != MMX_OK) {
     return rc;
@@ -1332,6 +1359,9 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
       return fail(MMX_ERR_UNSUPPORTED, "limit " + std::to_string(l) + ": more than four model parameters drive the limited joint parameters");
     }
   }
+  if (c->num_function_weights < 0 || c->num_function_weights > 4 + MMX_MAX_JOINT_BLOCKS) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "num_function_weights out of range (columns: position, orientation, limits, model parameters, joint blocks)");
+  }
   // ---- further joint-constraint blocks
   if (c->num_joint_blocks < 0 || c->num_joint_blocks > MMX_MAX_JOINT_BLOCKS || (c->num_joint_blocks > 0 && c->joint_blocks == nullptr)) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "joint_blocks: count out of range or null array");
@@ -1406,7 +1436,20 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
     MMX_HIP(ingest(pb->oOriOffset, c->ori_offset, B * pb->Ko * 4, d.oriOffset));
     MMX_HIP(ingest(pb->oOriTarget, c->ori_target, B * pb->Ko * 4, d.oriTarget));
     MMX_HIP(ingest(pb->oOriWeight, c->ori_weight, B * pb->Ko, d.oriWeight));
+    if (c->function_weights != nullptr && c->num_function_weights > 0) {
+      MMX_HIP(ingest(pb->oFnWeights, c->function_weights, B * size_t(c->num_function_weights), d.fnWeights));
+    }
     MMX_HIP(hipStreamSynchronize(s)); // the caller may free its host arrays on return
+  }
+  // per-element error-function weights (errorFunctionWeights[iBatch][...] of the batched driver)
+  if (c->function_weights != nullptr && c->num_function_weights > 0) {
+    if (c->memory == MMX_MEM_DEVICE) {
+      d.fnWeights = c->function_weights;
+    }
+    d.fnCols = c->num_function_weights;
+  } else {
+    d.fnWeights = nullptr;
+    d.fnCols = 0;
   }
   d.wPos = c->pos_function_weight;
   d.wOri = c->ori_function_weight;
@@ -1816,7 +1859,7 @@ static int32_t solveImpl(
     fp.threshold = o->threshold;
     fp.minIterations = o->min_iterations;
     fp.maxIterations = o->max_iterations;
-    fp.refine = 1;
+    fp.refine = refineSteps(pb);
     fp.doLineSearch = o->do_line_search;
     fp.stepRule = o->step_rule;
     fp.lmLambdaMin = o->lm_lambda_min;
@@ -1908,7 +1951,7 @@ static int32_t solveImpl(
   sp.threshold = o->threshold;
   sp.minIterations = o->min_iterations;
   sp.maxIterations = o->max_iterations;
-  sp.refine = 1;
+  sp.refine = refineSteps(pb);
   sp.delta = deferred ? pb->sDelta.as<float>() : nullptr;
   sp.stepIter = deferred ? pb->sStepIter.as<int32_t>() : nullptr;
   sp.lambdaPer = schedule ? pb->sLambda.as<float>() : nullptr;
@@ -1958,7 +2001,7 @@ static int32_t solveImpl(
           pb->sErr.as<double>(), theta_dev, st, sp, s));
       // up to three refinement rounds; an instance whose correction fell below 1e-3 of its step applies the step and
       // sits out the remaining rounds (its workgroups return at once)
-      for (int round = 0; round < 3 && sp.refine; ++round) {
+      for (int round = 0; round < sp.refine; ++round) {
         MMX_HIP(mmx::launchTreeRefine(
             pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sTreeState.as<float>(), genState, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
             sp.lambda, sp.lambdaPer, s));

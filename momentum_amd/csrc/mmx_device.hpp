@@ -22,16 +22,25 @@ namespace mmx {
 
 constexpr int kJs = 21; // floats per joint in js[]: 17 used, odd stride (lanes = joints read a field without LDS bank conflicts)
 constexpr int kAlt = 9; // floats per joint in the second pointer-jumping buffer: 8 used, odd stride
-// Pivot floor of every single-precision Cholesky in this library: column j's pivot d_jj = (H_jj + lambda) - sum_k l_jk^2 is
-// replaced by max(d_jj, kPivotFloor * (H_jj + lambda)).  In exact arithmetic d_jj >= lambda > 0; in fp32 the subtraction
-// leaves a rounding error of ~ sqrt(n) * 6e-8 * H_jj, so when J is rank deficient or nearly so and lambda is small (the
-// reference's own IK test runs lambda = 1e-7, inverse_kinematics_test.cpp:114) the computed pivot is noise of either sign.
-// The reference's double instantiation never sees that; its float instantiation hands Eigen's aborted factor to solve()
-// unchecked (gauss_newton_solver.cpp:251).  With the floor the factor is that of H + lambda I + E, E >= 0 diagonal and
-// only non-zero in the directions J does not determine; the refinement step measures its residual with the true lambda
-// through J and moves the step back wherever J determines it.  Pivots above the floor -- every problem whose H + lambda I
-// is numerically positive definite -- are untouched bit for bit.  16 ulp.
-constexpr float kPivotFloor = 9.5367431640625e-7f; // 2^-20
+// Pivot threshold of every single-precision Cholesky in this library: when column j's pivot
+// d_jj = (H_jj + lambda) - sum_k l_jk^2 comes out at or below kPivotFloor * (H_jj + lambda), column j is DROPPED from this
+// iteration's step -- 1 / l_jj := 0, so l_ij = 0 below it and parameter j's step is exactly 0, as if the column were
+// linearly dependent on the ones before it; every other parameter solves the reduced system.
+// In exact arithmetic d_jj >= lambda > 0; in fp32 the subtraction leaves a rounding error of a few 1e-7 H_jj, so when J
+// is rank deficient (or nearly) and lambda is small (the reference's own IK test runs lambda = 1e-7,
+// inverse_kinematics_test.cpp:114) the computed pivot is noise of either sign.  The reference's double instantiation never
+// sees that; its float instantiation hands Eigen's aborted factor to solve() unchecked (gauss_newton_solver.cpp:251).
+// Measured on the GPU (round 3): FLOORING such pivots instead keeps noise / floor ~ O(1) steps in the directions J does
+// not determine -- a scale parameter that takes one turns the next forward pass into 2^90 -- while dropping them gives a
+// basic least-squares step: the objective converges like the reference's (its 3-joint known-answer test passes at its
+// float tolerances), only the undetermined components of theta differ from the double solver's minimum-norm ones.
+// Pivots above the threshold -- every problem whose H + lambda I is numerically positive definite -- are untouched bit
+// for bit.  2^-18 = 64 ulp: a kept pivot amplifies the rounding of its column by at most ~1 / 64.
+#ifdef MMX_EXP_NOFLOOR // A/B build variant (MMX_BUILD_VARIANT=nofloor): what the threshold costs, what it changes
+constexpr float kPivotFloor = 0.f;
+#else
+constexpr float kPivotFloor = 3.814697265625e-6f; // 2^-18
+#endif
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {
@@ -252,7 +261,30 @@ struct ProblemDev {
   const int32_t* instPosParent;
   const int32_t* instOriParent;
   const int32_t* jointTin; // [J]
+  // per-element error-function weights (mmx_constraint_data::function_weights): [B][fnCols] or null
+  const float* fnWeights;
+  int32_t fnCols;
 };
+
+// element b's view of the problem: its error-function weights folded into the block weights of the kernel's by-value
+// copy of the descriptor (a kernel calls this once, like selectInstanceRig); weight_ = scalar x per-element entry
+__device__ __forceinline__ void selectInstanceWeights(ProblemDev& pb, int b) {
+  if (pb.fnWeights != nullptr) {
+    const float* w = pb.fnWeights + size_t(b) * size_t(pb.fnCols);
+    pb.wPos *= pb.fnCols > 0 ? w[0] : 1.f;
+    pb.wOri *= pb.fnCols > 1 ? w[1] : 1.f;
+    pb.wLimit *= pb.fnCols > 2 ? w[2] : 1.f;
+    pb.wModel *= pb.fnCols > 3 ? w[3] : 1.f;
+  }
+}
+// joint block i as element b sees it (column 4 + i of the per-element weights)
+__device__ __forceinline__ JointBlockDev jointBlockOf(const ProblemDev& pb, int b, int i) {
+  JointBlockDev k = pb.blocks[i];
+  if (pb.fnWeights != nullptr && 4 + i < pb.fnCols) {
+    k.fw *= pb.fnWeights[size_t(b) * size_t(pb.fnCols) + size_t(4 + i)];
+  }
+  return k;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Forward kinematics split into its parallel and its serial part: every joint's local transform

@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
   extern __shared__ __attribute__((aligned(16))) double dmem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   selectInstanceRig(rig, b);
+  selectInstanceWeights(pb, b);
   const int J = rig.J, P = rig.P, U = pb.U, M = 3 * U;
   F64Lds s;
   {

@@ -360,7 +360,7 @@ constexpr int kGenEv = 29; // words per constraint record (odd stride)
 __device__ __forceinline__ double generalRowsError(const ProblemDev& pb, const float* js, int b, int tid) {
   double e = 0.0;
   for (int g = tid; g < pb.G; g += 256) {
-    const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+    const JointBlockDev k = jointBlockOf(pb, b, pb.genBlock[g]);
     e += double(evalJointConstraint(k, js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(g - k.first)).werr);
   }
   if (pb.wLimit > 0.f) {
@@ -379,7 +379,7 @@ __device__ __forceinline__ double generalRowsEvaluate(const ProblemDev& pb, cons
   double e = 0.0;
   int* evi = reinterpret_cast<int*>(gEv);
   for (int g = tid; g < pb.G; g += 256) {
-    const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+    const JointBlockDev k = jointBlockOf(pb, b, pb.genBlock[g]);
     const int i = g - k.first;
     const JointEval o = evalJointConstraint(k, js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(i));
     const int row = k.rowStart + o.nrows * i - 3 * U;
@@ -802,6 +802,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   selectInstanceRig(rig, b);
+  selectInstanceWeights(pb, b);
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int kR = rig.R, kNnz = fd.nnz, kLevels = rig.numLevels;
 
@@ -1469,12 +1470,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           const float floorRow = s.invDiag[16 * k + (lane & 15)]; // kPivotFloor * (H_rr + lambda) of the diagonal lanes' rows
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            const float draw = readLaneF(a[j], j);
-            bad = bad || !(draw > 0.f);
-            // pivot floor (see kPivotFloor): off the dependent chain except for the one v_max
-            const float djj = fmaxf(draw, readLaneF(floorRow, j));
-            a[j] = lane == j ? djj : a[j];
-            const float inv = __builtin_amdgcn_rsqf(djj); // 1 / l_jj ; l_jj = d_jj * inv
+            const float djj = readLaneF(a[j], j);
+            bad = bad || !(djj > 0.f);
+            // a pivot at rounding level drops its column from this iteration's step (see kPivotFloor): 1 / l_jj = 0
+            const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // 1 / l_jj ; l_jj = d_jj * inv
             a[j] *= inv;
             if (lane == j) {
               invd = inv;
@@ -1558,7 +1557,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     // weaker preconditioner, so a further step is taken while the last correction was still
     // larger than 1e-3 of the step (error after k steps ~ ratio^(k+1)).  The test is on block-wide
     // sums, hence uniform.
-    const int nRefine = (!notPd && fp.refine) ? 3 : 0;
+    const int nRefine = !notPd ? fp.refine : 0; // refinement steps allowed (default 3, mmx_tuning::max_refinement_steps)
+    float prevCorr2 = FLT_MAX;
     for (int rf = 0; rf < nRefine; ++rf) {
       // joint-parameter delta jd = transform * delta (delta gathered through the solve map)
       for (int r = tid; r < rv.R; r += 256) {
@@ -1753,6 +1753,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       const float corr2 = float((s.red[4] + s.red[5]) + (s.red[6] + s.red[7]));
       const float step2 = float((s.red[0] + s.red[1]) + (s.red[2] + s.red[3]));
       __syncthreads();
+      // a correction is only taken when it is a contraction (kRefineMax2, mmx_kernels.hip: where the fp32 factor is no
+      // preconditioner any more -- pivots at rounding level -- the refinement diverges): undo it and stop
+      if (corr2 > 0.25f * step2 || corr2 > prevCorr2) {
+        for (int c = tid; c < n; c += 256) {
+          s.d0[c] -= s.rho[c];
+        }
+        __syncthreads();
+        break;
+      }
+      prevCorr2 = corr2;
       if (!(corr2 > 1e-6f * step2)) {
         break;
       }
@@ -2088,6 +2098,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
     return;
   }
   selectInstanceRig(rig, b);
+  selectInstanceWeights(pb, b);
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int NB = (n + 15) >> 4, NP = 16 * NB, T = NB * (NB + 1) / 2;
   TreeNeLds t;
@@ -2569,6 +2580,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   if (refState[b] != 0) {
     return;
   }
+  selectInstanceWeights(pb, b);
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n;
   const int NP = (n + 15) & ~15;
   const float lambda = lambdaPer != nullptr ? lambdaPer[b] : lambdaAll;

@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   selectInstanceRig(rig, b);
+  selectInstanceWeights(pb, b);
   // wave-uniform on purpose: it indexes the column program, which must stay on the scalar unit
   const int wave = WPI == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NT = 64 * WPI;
@@ -516,6 +517,7 @@ __global__ void __launch_bounds__(256) parameterRowsKernel(
   if (done != nullptr && done[b] != 0) {
     return;
   }
+  selectInstanceWeights(pb, b);
   const int NL = pb.NL, R0 = pb.rowsJoint;
   const int Pm = pb.hasModel ? P : 0;
   int* outOf = reinterpret_cast<int*>(smem); // [P] compacted model row of parameter i, or -1
@@ -697,6 +699,7 @@ __global__ void __launch_bounds__(256) jointBlocksKernel(
   __shared__ double red[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   selectInstanceRig(rig, b);
+  selectInstanceWeights(pb, b);
   if (done != nullptr && done[b] != 0) {
     return;
   }
@@ -714,7 +717,7 @@ __global__ void __launch_bounds__(256) jointBlocksKernel(
   const size_t M = size_t(pb.M);
   double e = 0.0;
   for (int g = tid; g < G; g += 256) {
-    const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+    const JointBlockDev k = jointBlockOf(pb, b, pb.genBlock[g]);
     const int i = g - k.first;
     const JointEval o = evalJointConstraint(k, js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(i));
     const int row = k.rowStart + o.nrows * i;
@@ -862,6 +865,13 @@ size_t jointBlocksLdsBytes(int J, int P, int G) { // G = constraints of the bloc
 constexpr int kNeChunk = 32; // rows of J staged per step
 // a further refinement step is taken while |correction|^2 > kRefineTol2 |step|^2 (at most three steps)
 constexpr float kRefineTol2 = 1e-6f;
+// ... and a correction is only TAKEN when it is a contraction: |correction|^2 <= kRefineMax2 |step|^2, and not larger than
+// the correction before it.  With a well-conditioned factor the first correction is 1e-3 ... 1e-5 of the step; where the
+// fp32 factor is no preconditioner any more (pivots at rounding level: rank-deficient J with lambda ~ 1e-7) the
+// iteration d += M^-1 (g - A d) diverges -- measured in round 3: cfg2 at lambda = 1e-7 ended at a median error of 74 with
+// the unguarded refinement, 6 without any (the double solver: 5e-6 ... 16) -- so such a correction is undone and the
+// refinement stops.
+constexpr float kRefineMax2 = 0.25f;
 constexpr int kNeTilesPerThread = 4; // 4x4 tiles held per thread -> n <= 4*sqrt(2*256*4) ~ 180
 
 __global__ void __launch_bounds__(256) normalEquationsKernel(
@@ -1387,11 +1397,9 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
         float invd = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
-          const float draw = readLaneF(a[jj], jj);
-          notPd |= !(draw > 0.f) ? 1 : 0;
-          const float djj = fmaxf(draw, readLaneF(floorRow, jj)); // pivot floor, see kPivotFloor
-          a[jj] = lane == jj ? djj : a[jj];
-          const float inv = __builtin_amdgcn_rsqf(djj);
+          const float djj = readLaneF(a[jj], jj);
+          notPd |= !(djj > 0.f) ? 1 : 0;
+          const float inv = djj > readLaneF(floorRow, jj) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
           a[jj] *= inv;
           if (lane == jj) {
             invd = inv;
@@ -1455,7 +1463,8 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
   MMX_SCLK(2)
   // up to three refinement steps: a further one only while the last correction exceeded 1e-3 of the
   // step (same rule as the fused kernel; one step is the normal case)
-  for (int rf = 0; rf < 3 && !bad && sp.refine && n > 0; ++rf) {
+  float prevCorr2 = FLT_MAX;
+  for (int rf = 0; rf < sp.refine && !bad && n > 0; ++rf) {
     // w = r - J d0   (rows over threads, coalesced down each column)
     const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
     const float* rb = res + size_t(b) * size_t(M);
@@ -1520,13 +1529,21 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     d2 = waveReduceSumF(d2);
     __syncthreads();
     if (lane == 0) {
-      rho[wave] = c2; // rho / w are free until the next step
-      rho[4 + wave] = d2;
+      w[wave] = c2; // w is free between the refinement steps (M >= 8 or the rows pad: see choleskyStepLdsBytes' + 12)
+      w[4 + wave] = d2;
     }
     __syncthreads();
-    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
+    const float corr2 = w[0] + w[1] + w[2] + w[3], step2 = w[4] + w[5] + w[6] + w[7];
     __syncthreads();
-    if (!again) {
+    if (corr2 > kRefineMax2 * step2 || corr2 > prevCorr2) { // not a contraction: undo, stop (kRefineMax2)
+      for (int i = tid; i < n; i += 256) {
+        d0[i] -= rho[i];
+      }
+      __syncthreads();
+      break;
+    }
+    prevCorr2 = corr2;
+    if (!(corr2 > kRefineTol2 * step2)) {
       break;
     }
   }
@@ -1717,11 +1734,9 @@ __device__ __forceinline__ void tiledFactor(
       bool bad = false;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float draw = readLaneF(a[j], j);
-        bad = bad || !(draw > 0.f);
-        const float djj = fmaxf(draw, readLaneF(floorRow, j));
-        a[j] = lane == j ? djj : a[j];
-        const float inv = __builtin_amdgcn_rsqf(djj);
+        const float djj = readLaneF(a[j], j);
+        bad = bad || !(djj > 0.f);
+        const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
         a[j] *= inv;
         if (lane == j) {
           invd = inv;
@@ -1843,11 +1858,9 @@ __device__ __forceinline__ void tiledFactorPairs(
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float draw = readLaneF(a[j], j);
-      bad = bad || !(draw > 0.f);
-      const float djj = fmaxf(draw, readLaneF(floorRow, j));
-      a[j] = lane == j ? djj : a[j];
-      const float inv = __builtin_amdgcn_rsqf(djj);
+      const float djj = readLaneF(a[j], j);
+      bad = bad || !(djj > 0.f);
+      const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
       a[j] *= inv;
       if (lane == j) {
         invd = inv;
@@ -2097,7 +2110,7 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
       request(k + kStep, dgNext, pvNext, diNext);
       if (wave == 0) {
         float bi = x[16 * k + lrow];
-        const float invd = 1.f / di;
+        const float invd = di > 0.f ? 1.f / di : 0.f; // (a dropped column has l_jj = 0: zero step, see kPivotFloor)
         if (forward) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
@@ -2226,7 +2239,8 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
     tiledSweep<false>(L, NB, d0, tid);
   }
   MMX_SCLK(2)
-  for (int rf = 0; rf < 3 && !bad && sp.refine; ++rf) { // see choleskyStepKernel
+  float prevCorr2 = FLT_MAX;
+  for (int rf = 0; rf < sp.refine && !bad; ++rf) { // see choleskyStepKernel
     const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
     const float* rb = res + size_t(b) * size_t(M);
     const bool vec4 = (M & 3) == 0 && (reinterpret_cast<uintptr_t>(jac) & 15) == 0;
@@ -2326,13 +2340,21 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
     d2 = waveReduceSumF(d2);
     __syncthreads();
     if (lane == 0) {
-      rho[wave] = c2;
-      rho[4 + wave] = d2;
+      wch[wave] = c2; // (the chunk's w is consumed: chunkRows >= 16 floats)
+      wch[4 + wave] = d2;
     }
     __syncthreads();
-    const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
+    const float corr2 = wch[0] + wch[1] + wch[2] + wch[3], step2 = wch[4] + wch[5] + wch[6] + wch[7];
     __syncthreads();
-    if (!again) {
+    if (corr2 > kRefineMax2 * step2 || corr2 > prevCorr2) { // not a contraction: undo, stop (kRefineMax2)
+      for (int i = tid; i < n; i += 256) {
+        d0[i] -= rho[i];
+      }
+      __syncthreads();
+      break;
+    }
+    prevCorr2 = corr2;
+    if (!(corr2 > kRefineTol2 * step2)) {
       break;
     }
   }
@@ -2416,7 +2438,7 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
     float* __restrict__ theta,
     SolveStateDev st,
     StepParams sp,
-    int round) { // 0, 1, 2: the last round applies the step whatever the correction was
+    int round) { // 0 .. sp.refine - 1: the last round applies the step whatever the correction was
   __shared__ __attribute__((aligned(16))) float d0[512 + 16];
   __shared__ __attribute__((aligned(16))) float rho[512 + 16];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -2445,14 +2467,22 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
   }
   c2 = waveReduceSumF(c2);
   d2 = waveReduceSumF(d2);
-  __syncthreads();
+  __shared__ float sums[8];
   if (lane == 0) {
-    rho[wave] = c2;
-    rho[4 + wave] = d2;
+    sums[wave] = c2;
+    sums[4 + wave] = d2;
   }
   __syncthreads();
-  const bool again = (rho[0] + rho[1] + rho[2] + rho[3]) > kRefineTol2 * (rho[4] + rho[5] + rho[6] + rho[7]);
-  if (again && round < 2) {
+  const float corr2 = sums[0] + sums[1] + sums[2] + sums[3], step2 = sums[4] + sums[5] + sums[6] + sums[7];
+  bool again = corr2 > kRefineTol2 * step2;
+  if (corr2 > kRefineMax2 * step2) { // not a contraction (kRefineMax2): undo this correction, the step is the one before it
+    for (int i = tid; i < n; i += 256) {
+      d0[i] -= rho[i];
+    }
+    __syncthreads();
+    again = false;
+  }
+  if (again && round + 1 < sp.refine) {
     for (int i = tid; i < NP; i += 256) {
       dvec[size_t(b) * NP + i] = d0[i];
     }
@@ -2485,6 +2515,7 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
   __shared__ float redF[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   selectInstanceRig(rig, b);
+  selectInstanceWeights(pb, b);
   const int mark = sp.stepIter[b];
   if (mark != sp.iteration + 1 && mark != -(sp.iteration + 1)) {
     return; // the instance had converged before this iteration
@@ -2514,7 +2545,7 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
       e += double(evalUnit(pb, sl.js, b, u).werr);
     }
     for (int g = tid; g < pb.G; g += 256) {
-      const JointBlockDev k = pb.blocks[pb.genBlock[g]];
+      const JointBlockDev k = jointBlockOf(pb, b, pb.genBlock[g]);
       e += double(evalJointConstraint(k, sl.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(g - k.first)).werr);
     }
     if (pb.wLimit > 0.f) {

@@ -57,7 +57,7 @@ struct StepParams {
   int32_t iteration; // iteration_ (0-based)
   int32_t minIterations;
   int32_t maxIterations;
-  int32_t refine; // 1 = one corrected-seminormal refinement step through J
+  int32_t refine; // refinement steps through J allowed per iteration (0..3)
   // ---- line search / damping schedule of the explicit-Jacobian path: the Cholesky kernel leaves
   // the step in `delta` and stepUpdateKernel applies it (all null / 0: theta -= delta in place)
   float* delta; // [B][n] step of this iteration

@@ -1319,6 +1319,7 @@ struct Options {
   float regularization = 0.05f;
   int doLineSearch = 0; // 0 none, 1 GaussNewtonSolverT rule, 2 SubsetGaussNewtonSolverT / GaussNewtonSolverQRT rule
   bool useBlockJtJ = false;
+  bool useQR = false; // stepRule 0 only: GaussNewtonSolverQRT (Householder QR of [J; sqrt(lambda) I]) instead of the Cholesky of the normal equations
   int stepRule = 0; // 0 = fixed lambda (reference), 1 = LM gain-ratio schedule (build's own), 2 = TrustRegionQRT (reference)
   float lmLambdaMin = 1e-6f, lmLambdaMax = 1e6f, lmUp = 4.f, lmDown = 0.5f;
   float trustRegionRadius = 1.f; // TrustRegionQROptions::trustRegionRadius_ (trust_region_qr.h:24)
@@ -1583,6 +1584,49 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
           break;
         }
         params = orig; // :268-269
+      }
+    } else if (opt.stepRule == 0 && opt.useQR) {
+      // ---- GaussNewtonSolverQRT<T>::doIteration (momentum/character_solver/gauss_newton_solver_qr.cpp:50-150): the
+      // solver `solve_ik` builds by default (pymomentum/tensor_ik/solver_options.h:28-37, tensor_ik.cpp:142-158).
+      // "momentum solves the problem (J^T J + lambda I) x = J^T r; the QR solver wants the square root of that
+      // lambda" (:75-77): R starts as sqrt(lambda) I, the enabled columns of every Jacobian block are reduced
+      // into it (:81-107; one block here: the QR of stacked blocks is the QR of the whole matrix up to signs),
+      // delta = R^-1 y (:116).  jac holds the compacted enabled columns (ColumnIndexedMatrix, :103-106).
+      OnlineQR<T> qr;
+      qr.reset(n, std::sqrt(T(opt.regularization))); // :77
+      {
+        std::vector<T> A(jac.begin(), jac.begin() + size_t(M) * n), b2(res.begin(), res.end());
+        qr.addMutating(A.data(), M, M, b2.data()); // :103-106
+      }
+      const std::vector<T> subsetDelta = qr.result(); // :116
+      std::fill(delta.begin(), delta.end(), T(0));
+      for (int s = 0; s < n; ++s) {
+        delta[E[s]] = subsetDelta[s]; // :118-122
+      }
+      if (opt.doLineSearch) { // :124-146 (the QR solver has ONE backtracking rule, the directional one)
+        const std::vector<T> atb = qr.AtTimesB();
+        T dotp = T(0);
+        for (int s = 0; s < n; ++s) {
+          dotp += atb[s] * subsetDelta[s];
+        }
+        const double innerProd = -double(dotp); // :125
+        const float c1 = 1e-4f, tau = 0.5f;
+        float alpha = 1.0f;
+        const std::vector<T> orig = params;
+        for (int ls = 0; ls < 10 && std::fpclassify(alpha) == FP_NORMAL; ++ls) { // :133
+          for (int i = 0; i < P; ++i) {
+            params[i] = orig[i] - T(alpha) * delta[i]; // :135-136
+          }
+          const double errorNew = fn.getError(params.data()); // :138
+          if ((error - errorNew) >= c1 * alpha * -innerProd) { // :140
+            break;
+          }
+          alpha = alpha * tau; // :145
+        }
+      } else {
+        for (int i = 0; i < P; ++i) {
+          params[i] -= delta[i]; // :148, skeleton_solver_function.cpp:158
+        }
       }
     } else if (opt.stepRule == 0) {
       // ---- dense GN step (:241-257)

@@ -53,8 +53,13 @@ Constraints<T> makeConstraints(
   cs.oriOffset = c->ori_offset ? c->ori_offset + b * Ko * 4 : nullptr;
   cs.oriTarget = c->ori_target ? c->ori_target + b * Ko * 4 : nullptr;
   cs.oriWeight = c->ori_weight ? c->ori_weight + b * Ko : nullptr;
-  cs.posFunctionWeight = c->pos_function_weight;
-  cs.oriFunctionWeight = c->ori_function_weight;
+  // per-element error-function weights: buildMomentumErrorFunctions gives every error function of element iBatch
+  // setWeight(errorFunctionWeights[iBatch][weightsMap[iErr]]) (pymomentum/tensor_ik/tensor_ik_utility.cpp:162-177)
+  auto fnw = [&](int col) {
+    return (c->function_weights != nullptr && col < c->num_function_weights) ? c->function_weights[b * size_t(c->num_function_weights) + size_t(col)] : 1.f;
+  };
+  cs.posFunctionWeight = c->pos_function_weight * fnw(0);
+  cs.oriFunctionWeight = c->ori_function_weight * fnw(1);
   if (c->pos_loss_c > 0.f) {
     cs.posLoss = Loss<T>(c->pos_loss_alpha == MMX_LOSS_WELSCH ? std::numeric_limits<T>::lowest() : T(c->pos_loss_alpha), T(c->pos_loss_c));
   }
@@ -73,7 +78,7 @@ Constraints<T> makeConstraints(
     blk.global = jb.global ? jb.global + 3 * o : nullptr;
     blk.planeD = jb.plane_d ? jb.plane_d + o : nullptr;
     blk.weight = jb.weight + o;
-    blk.functionWeight = jb.function_weight;
+    blk.functionWeight = jb.function_weight * fnw(4 + i);
     if (jb.loss_c > 0.f) {
       blk.loss = Loss<T>(jb.loss_alpha == MMX_LOSS_WELSCH ? std::numeric_limits<T>::lowest() : T(jb.loss_alpha), T(jb.loss_c));
     }
@@ -84,10 +89,10 @@ Constraints<T> makeConstraints(
   cs.P = P;
   cs.NL = c->num_limits;
   cs.limits = c->limits;
-  cs.limFunctionWeight = c->limit_function_weight;
+  cs.limFunctionWeight = c->limit_function_weight * fnw(2);
   cs.mpTarget = c->model_target ? c->model_target + b * size_t(P) : nullptr;
   cs.mpWeights = c->model_weights ? c->model_weights + b * size_t(P) : nullptr;
-  cs.mpFunctionWeight = c->model_function_weight;
+  cs.mpFunctionWeight = c->model_function_weight * fnw(3);
   return cs;
 }
 
@@ -98,7 +103,8 @@ Options makeOptions(const mmx_gn_options* o, int useBlockJtJ) {
   r.threshold = o->threshold;
   r.regularization = o->regularization;
   r.doLineSearch = o->do_line_search;
-  r.useBlockJtJ = useBlockJtJ != 0;
+  r.useBlockJtJ = (useBlockJtJ & 1) != 0; // bit 0: SolverFunctionT::getJtJR block accumulation; bit 1: GaussNewtonSolverQRT
+  r.useQR = (useBlockJtJ & 2) != 0;
   r.stepRule = o->step_rule;
   r.lmLambdaMin = o->lm_lambda_min;
   r.lmLambdaMax = o->lm_lambda_max;

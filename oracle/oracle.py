@@ -22,10 +22,17 @@ _lib: Optional[C.CDLL] = None
 
 
 _STAMP = os.path.join(_HERE, ".built_for")
+# ISA candidates of the CPU baseline.  SURVEY.md 8d asks for the host's own ISA (-march=native); with this compiler
+# (gcc 11) the 512-bit code it generates for the oracle's short inner loops is SLOWER than the AVX2 build on both hosts
+# this has run on (Cooper Lake: 295 vs 438 solves/s/thread; EPYC 9575F: 195 vs 706), so build() compiles every
+# candidate, times a fixed single-thread workload with each, and keeps the fastest: the baseline is the best this
+# code does on the box at hand, and cpu_baseline.sample says which flags won.
+_CANDIDATES = ["-march=native", "-march=native -mprefer-vector-width=256", "-march=x86-64-v3 -mtune=native"]
+_BASE_FLAGS = "-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter"
 
 
 def host_cpu() -> str:
-    """Model name + the widest vector ISA of the CPU this process runs on (the oracle is compiled -march=native)."""
+    """Model name + the widest vector ISA of the CPU this process runs on."""
     model, flags = "unknown", set()
     try:
         for line in open("/proc/cpuinfo"):
@@ -41,27 +48,65 @@ def host_cpu() -> str:
     return f"{model} ({isa})"
 
 
-def build(force: bool = False) -> str:
-    """Compile the oracle with oracle/Makefile (gcc only, -march=native).  A library built on another host (it travels
-    with the snapshot) is rebuilt for this one: the CPU baseline must use the ISA of the cores it is timed on."""
-    cpu = host_cpu()
+def build_info() -> str:
+    """What the library in use was built with ("<cpu> | <flags> | timings of the candidates")."""
     try:
-        stamp = open(_STAMP).read().strip()
+        return open(_STAMP).read().strip()
     except OSError:
-        stamp = ""
-    if force or not os.path.exists(_LIB_PATH) or stamp != cpu:
+        return "unknown"
+
+
+def _selftime() -> float:
+    """Seconds for a fixed single-thread workload (32 x 72-joint solves, 10 iterations, float) with the library on disk;
+    run in a fresh interpreter so that every candidate is loaded from scratch."""
+    import sys
+
+    code = (
+        "import sys,time;sys.path.insert(0,%r);import numpy as np;"
+        "from oracle import oracle as o;o._lib=__import__('ctypes').CDLL(o._LIB_PATH);"
+        "from momentum_amd import humanoid72_landmark_joints as lj, make_humanoid72 as mk;from momentum_amd._abi import GnOptions as G;"
+        "r=mk(seed=12345,variant='p128',unit=0.01);l=lj(r);rng=np.random.default_rng(0);B=32;"
+        "z=np.zeros;c=o.Constraints(l,z((B,16,3)),rng.uniform(-1,1,(B,16,3)),np.ones((B,16)),l,np.tile([0,0,0,1.],(B,16,1)),np.tile([0,0,0,1.],(B,16,1)),np.ones((B,16)));"
+        "op=G.make(10,10);th=z((B,r.num_params),np.float32);o.solve_batch(r,c,th[:4],op,dtype='f32');"
+        "t=time.perf_counter();o.solve_batch(r,c,th,op,dtype='f32');print(time.perf_counter()-t)"
+    ) % os.path.dirname(_HERE)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip().split("\n")[-1]
+    return float(out)
+
+
+def _make(flags: str) -> None:
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", f"CXXFLAGS={_BASE_FLAGS} {flags}"])
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with oracle/Makefile (gcc only).  A library built on another host (it travels with the snapshot)
+    is rebuilt for this one, with the fastest of the ISA candidates above."""
+    cpu = host_cpu()
+    stamp = build_info()
+    if force or not os.path.exists(_LIB_PATH) or not stamp.startswith(cpu + " | "):
         import fcntl
 
         with open(os.path.join(_HERE, ".build_lock"), "w") as lock:  # two ranks of one test may get here together
             fcntl.flock(lock, fcntl.LOCK_EX)
-            try:
-                stamp = open(_STAMP).read().strip()
-            except OSError:
-                stamp = ""
-            if force or not os.path.exists(_LIB_PATH) or stamp != cpu:
-                subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+            stamp = build_info()
+            if force or not os.path.exists(_LIB_PATH) or not stamp.startswith(cpu + " | "):
+                timings = []
+                for flags in _CANDIDATES:
+                    try:
+                        _make(flags)
+                        timings.append((_selftime(), flags))
+                    except Exception:  # a candidate this compiler / CPU does not take
+                        continue
+                if not timings:
+                    _make("-march=x86-64-v3")
+                    best, note = "-march=x86-64-v3", "no candidate could be timed"
+                else:
+                    best = min(timings)[1]
+                    note = "; ".join(f"{f}: {32 / t:.0f} solves/s/thread" for t, f in timings)
+                    if best != timings[-1][1]:
+                        _make(best)
                 with open(_STAMP, "w") as f:
-                    f.write(cpu + "\n")
+                    f.write(f"{cpu} | {_BASE_FLAGS.split()[0]} {best} | {note}\n")
     return _LIB_PATH
 
 
@@ -109,8 +154,12 @@ class Constraints:
         ori_loss=(2.0, 1.0),
         joint_blocks=None,
         ellipsoid_limits=None,
+        function_weights=None,
     ):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        # per-element error-function weights [B, C] (errorFunctionWeights[iBatch][weightsMap[iErr]] of solveTensorIKProblem):
+        # columns position, orientation, limits, model parameters, joint block 0, ...
+        self.function_weights = None if function_weights is None else np.ascontiguousarray(function_weights, dtype=np.float32).reshape(-1, np.asarray(function_weights).shape[-1])
         self.pos_parent = np.ascontiguousarray(pos_parent, dtype=np.int32).reshape(-1)
         self.ori_parent = np.ascontiguousarray(ori_parent, dtype=np.int32).reshape(-1)
         self.Kp = int(self.pos_parent.shape[0])
@@ -168,6 +217,8 @@ class Constraints:
             C.cast(self._block_array, C.c_void_p) if self.joint_blocks else None,
             len(self.ellipsoid_limits),
             C.cast(self._ellipsoid_array, C.c_void_p) if self.ellipsoid_limits else None,
+            void_p(self.function_weights),
+            0 if self.function_weights is None else int(self.function_weights.shape[1]),
         )
 
     def instance(self, b: int) -> "Constraints":
@@ -192,6 +243,7 @@ class Constraints:
             self.ori_loss,
             [blk.instance(b) for blk in self.joint_blocks],
             self.ellipsoid_limits,
+            None if self.function_weights is None else self.function_weights[b],
         )
 
 
@@ -264,9 +316,11 @@ def get_error(rig: Rig, cons: Constraints, theta, dtype="f64") -> float:
     return err.value
 
 
-def solve(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f64", use_block_jtj=False):
+def solve(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f64", use_block_jtj=False, use_qr=False):
     """SolverT::solve with GaussNewtonSolverT for one instance.  Returns dict(theta, error,
-    iterations, status, error_history, jtj, jtr) (jtj/jtr = compacted system of the last iteration)."""
+    iterations, status, error_history, jtj, jtr) (jtj/jtr = compacted system of the last iteration).
+    use_qr: GaussNewtonSolverQRT (gauss_newton_solver_qr.cpp:50-150) instead of GaussNewtonSolverT's Cholesky; a line search,
+    when asked for, is then the directional rule whatever do_line_search says (the QR solver has no other)."""
     T = _np(dtype)
     P = rig.num_params
     th = np.array(theta0, dtype=T).reshape(-1).copy()
@@ -283,7 +337,7 @@ def solve(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None,
     fn = getattr(lib(), f"orc_solve_{_suf(dtype)}")
     rc = fn(
         C.byref(d), cons.Kp, as_ptr(cons.pos_parent, C.c_int32), cons.Ko, as_ptr(cons.ori_parent, C.c_int32),
-        C.byref(cd), eptr, C.byref(options), int(use_block_jtj), as_ptr(th, ct), C.byref(err), C.byref(iters),
+        C.byref(cd), eptr, C.byref(options), int(bool(use_block_jtj)) | (2 if use_qr else 0), as_ptr(th, ct), C.byref(err), C.byref(iters),
         C.byref(status), as_ptr(hist, C.c_double), as_ptr(jtj, ct), as_ptr(jtr, ct),
     )  # fmt: skip
     assert rc == 0
@@ -296,7 +350,7 @@ def solve(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None,
     )  # fmt: skip
 
 
-def solve_batch(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f32", nthreads=1, use_block_jtj=False):
+def solve_batch(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f32", nthreads=1, use_block_jtj=False, use_qr=False):
     """The reference's batched driver shape (pymomentum/tensor_ik/tensor_ik.cpp:127-177): one
     independent solver per instance, `nthreads` std::threads.  cons arrays are [B,K,...]."""
     T = _np(dtype)
@@ -313,7 +367,7 @@ def solve_batch(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled
     fn = getattr(lib(), f"orc_solve_batch_{_suf(dtype)}")
     rc = fn(
         C.byref(d), B, cons.Kp, as_ptr(cons.pos_parent, C.c_int32), cons.Ko, as_ptr(cons.ori_parent, C.c_int32),
-        C.byref(cd), eptr, C.byref(options), int(use_block_jtj), as_ptr(th, ct), as_ptr(err, C.c_double),
+        C.byref(cd), eptr, C.byref(options), int(bool(use_block_jtj)) | (2 if use_qr else 0), as_ptr(th, ct), as_ptr(err, C.c_double),
         as_ptr(iters, C.c_int32), as_ptr(status, C.c_int32), as_ptr(hist, C.c_double), int(nthreads),
     )  # fmt: skip
     assert rc == 0

@@ -89,7 +89,7 @@ def test_trust_region_needs_the_fused_solver(torch_cuda, monkeypatch):
     rig = make_test_character(5)
     cons, th0, _ = make_problem(rig, [4], [3], 2, seed=1)
     rh, pb = _gpu(torch, rig, cons, 2)
-    monkeypatch.setattr(capi, "default_route", "explicit_jacobian")
+    pb.set_route("explicit_jacobian")
     with pytest.raises(capi.MmxError) as ei:
         pb.solve(torch.from_numpy(th0.copy()).to(pb.device), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION))
     assert "fused" in str(ei.value)

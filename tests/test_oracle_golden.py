@@ -394,3 +394,51 @@ def test_trust_region_first_iteration_against_a_numpy_restatement(orc):
     assert expected is not None
     got = orc.solve(rig, c, theta, GnOptions.make(min_iterations=1, max_iterations=1, step_rule=MMX_STEP_TRUST_REGION), dtype="f64")
     assert np.abs(got["theta"] - expected).max() <= 1e-8 * max(1.0, np.abs(expected).max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_gauss_newton_qr_solver_agrees_with_the_normal_equations(orc, dtype):
+    """GaussNewtonSolverQRT restated (gauss_newton_solver_qr.cpp:50-150: Householder QR of [J; sqrt(lambda) I], :75-77)
+    against GaussNewtonSolverT (Cholesky of J^T J + lambda I) the way the reference compares its own solvers,
+    momentum/test/character_solver/solver_test.cpp:43-121: position + orientation constraint on every joint, targets
+    from a random pose in [-1,1]^P, start at 0, lambda 0.05, line search on; err_qr <= 1.001 err_gn + 0.001 and the
+    other way round.  Both solve the same least-squares problem per iteration, so in double the iterates agree to
+    rounding -- which is what pins `mmx_solve` (normal equations) as a drop-in for solve_ik's DEFAULT linear solver
+    (pymomentum/tensor_ik/solver_options.h:28-37)."""
+    rig = make_test_character(5)
+    J = rig.num_joints
+    cons, th0, ths = make_problem(rig, list(range(J)), list(range(J)), 1, seed=77, perturb=1.0, random_offsets=True)
+    c = cons.instance(0)
+    zero = np.zeros(rig.num_params)
+    opt = GnOptions.make(min_iterations=4, max_iterations=40, threshold=1000.0, regularization=0.05, do_line_search=2)
+    gn = orc.solve(rig, c, zero, opt, dtype=dtype)
+    qr = orc.solve(rig, c, zero, opt, dtype=dtype, use_qr=True)
+    assert qr["error"] <= 1.001 * gn["error"] + 0.001 and gn["error"] <= 1.001 * qr["error"] + 0.001  # solver_test.cpp:110-118
+    assert qr["error_history"][-1] < qr["error_history"][0] * 1e-2
+    assert np.all(np.diff(qr["error_history"]) <= 1e-9)  # line search => monotone
+    if dtype == "f64":
+        # fixed iteration count, so a stop one iteration apart cannot hide a difference: the same iterates to rounding,
+        # at solve_ik's default lambda and at pymomentum's test_solver2.py value
+        for lam in (0.01, 1e-5):
+            for ls in (0, 2):
+                o = GnOptions.make(min_iterations=8, max_iterations=8, threshold=1.0, regularization=lam, do_line_search=ls)
+                a = orc.solve(rig, c, zero, o, dtype="f64")
+                b = orc.solve(rig, c, zero, o, dtype="f64", use_qr=True)
+                assert np.abs(a["theta"] - b["theta"]).max() <= 1e-9 * max(1.0, np.abs(a["theta"]).max()), (lam, ls)
+                assert np.allclose(a["error_history"], b["error_history"], rtol=1e-9, atol=1e-18)
+
+
+def test_gauss_newton_qr_seeds_sqrt_lambda(orc):
+    """The sqrt(lambda) seeding (gauss_newton_solver_qr.cpp:75-77): one iteration of the QR solver equals the step of the
+    regularised normal equations computed independently in numpy from the oracle's J and r."""
+    rig = make_test_character(6)
+    J = rig.num_joints
+    cons, th0, ths = make_problem(rig, list(range(J)), [1, 3], 1, seed=5, perturb=0.5, random_offsets=True)
+    c = cons.instance(0)
+    th = np.random.default_rng(3).uniform(-0.3, 0.3, rig.num_params)
+    for lam in (0.05, 1e-5):
+        Jm, r, _ = orc.eval_jacobian(rig, c, th, dtype="f64")
+        Jm, r = np.asarray(Jm, np.float64), np.asarray(r, np.float64)
+        step = np.linalg.solve(Jm.T @ Jm + np.float64(np.float32(lam)) * np.eye(Jm.shape[1]), Jm.T @ r)
+        out = orc.solve(rig, c, th, GnOptions.make(min_iterations=1, max_iterations=1, regularization=lam), dtype="f64", use_qr=True)
+        assert np.abs((th - out["theta"]) - step).max() <= 1e-9 * max(1.0, np.abs(step).max())
