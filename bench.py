@@ -397,6 +397,8 @@ def main() -> None:
             idt.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         comm = capi.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+        if comm.world_size != world:  # (what RCCL itself counts: ncclCommCount)
+            raise SystemExit(f"RCCL sees {comm.world_size} ranks, --gpus says {world}")
 
     from momentum_amd._abi import GnOptions
 

@@ -11,6 +11,7 @@
 #include <array>
 #include <exception>
 #include <memory>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -26,17 +27,49 @@ inline std::pair<size_t, size_t> shardRange(size_t total, size_t rank, size_t wo
   return {begin, std::min(begin + per, total)};
 }
 
-class BatchedMultiGpuSolver {
+// The exchange of the multi-GPU solver: one communicator per shard, created together, that sums three doubles over
+// the shards.  The default is RCCL through the C ABI (mmx_comm_*); the policy exists so that the shard routing, the
+// ragged / empty shards and the failure protocol of BatchedMultiGpuSolverT can be exercised on a host without several
+// GPUs (tests/cpp/test_multi_gpu_stub.cpp: RCCL cannot take one device twice).
+struct RcclNormsComm {
+  using Handle = std::shared_ptr<mmx_comm>;
+  static std::vector<Handle> createAll(const std::vector<int>& devices) {
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    std::vector<mmx_comm*> comms(devices.size(), nullptr);
+    check(mmx_comm_create_all(int32_t(devs.size()), devs.data(), comms.data()));
+    std::vector<Handle> out;
+    for (mmx_comm* c : comms) {
+      out.emplace_back(c, [](mmx_comm* p) { mmx_comm_destroy(p); });
+    }
+    return out;
+  }
+  static size_t worldSize(const Handle& h) {
+    return size_t(mmx_comm_world_size(h.get()));
+  }
+  // in-place sum over the shards; false + message on failure
+  static bool allReduce(const Handle& h, double v[3], std::string& error) {
+    if (mmx_comm_all_reduce_norms_host(h.get(), v) != MMX_OK) {
+      error = mmx_last_error();
+      return false;
+    }
+    return true;
+  }
+};
+
+// SolverT: BatchedGaussNewtonSolver or one of its subclasses (the line-search rule / step rule differs) -- anything with
+// SolverT(options, FunctionT*), solve(std::vector<float>&) -> std::vector<double>, getIterations(), getStatus().
+template <class SolverT = BatchedGaussNewtonSolver, class FunctionT = BatchedSkeletonSolverFunction, class CharacterT = DeviceCharacter, class CommT = RcclNormsComm>
+class BatchedMultiGpuSolverT {
  public:
-  // One shard per entry of `devices` (HIP device indices).  SolverT: BatchedGaussNewtonSolver or one of its
-  // subclasses (the line-search rule differs).
-  BatchedMultiGpuSolver(
+  // One shard per entry of `devices` (HIP device indices).
+  template <class OptionsT>
+  BatchedMultiGpuSolverT(
       const Character& character,
       const std::vector<int>& devices,
       size_t batch,
       const std::vector<size_t>& positionParents,
       const std::vector<size_t>& orientationParents,
-      const SolverOptions& options)
+      const OptionsT& options)
       : batch_(batch), numParams_(character.parameterTransform.numAllModelParameters()) {
     if (devices.empty()) {
       throw std::runtime_error("momentum_amd: no device given");
@@ -45,18 +78,19 @@ class BatchedMultiGpuSolver {
       const auto range = shardRange(batch, i, devices.size());
       Shard sh;
       sh.begin = range.first, sh.end = range.second, sh.device = devices[i];
-      sh.character = std::make_unique<DeviceCharacter>(character, devices[i]);
+      sh.character = std::make_unique<CharacterT>(character, devices[i]);
       if (sh.end > sh.begin) {
-        sh.function = std::make_unique<BatchedSkeletonSolverFunction>(*sh.character, sh.end - sh.begin, positionParents, orientationParents);
-        sh.solver = std::make_unique<BatchedGaussNewtonSolver>(options, sh.function.get());
+        sh.function = std::make_unique<FunctionT>(*sh.character, sh.end - sh.begin, positionParents, orientationParents);
+        sh.solver = std::make_unique<SolverT>(options, sh.function.get());
       }
       shards_.push_back(std::move(sh));
     }
-    std::vector<int32_t> devs(devices.begin(), devices.end());
-    std::vector<mmx_comm*> comms(devices.size(), nullptr);
-    check(mmx_comm_create_all(int32_t(devs.size()), devs.data(), comms.data()));
+    std::vector<typename CommT::Handle> comms = CommT::createAll(devices);
+    if (comms.size() != shards_.size()) {
+      throw std::runtime_error("momentum_amd: one communicator per shard expected");
+    }
     for (size_t i = 0; i < comms.size(); ++i) {
-      shards_[i].comm.reset(comms[i], [](mmx_comm* c) { mmx_comm_destroy(c); });
+      shards_[i].comm = comms[i];
     }
   }
 
@@ -75,8 +109,18 @@ class BatchedMultiGpuSolver {
     }
     throw std::runtime_error("momentum_amd: batch index out of range");
   }
-  BatchedSkeletonSolverFunction& function(size_t shard) {
+  FunctionT& function(size_t shard) {
     return *shards_.at(shard).function;
+  }
+  SolverT& solver(size_t shard) {
+    return *shards_.at(shard).solver;
+  }
+  std::pair<size_t, size_t> shardBounds(size_t shard) const {
+    return {shards_.at(shard).begin, shards_.at(shard).end};
+  }
+  // ranks the exchange sees (RCCL: ncclCommCount): must equal numShards()
+  size_t commWorldSize() const {
+    return CommT::worldSize(shards_.front().comm);
   }
   void setPositionConstraints(size_t b, const std::vector<PositionData>& c) {
     const auto at = locate(b);
@@ -117,8 +161,9 @@ class BatchedMultiGpuSolver {
           failures[i] = std::current_exception(); // rethrown after the join, like the reference (tensor_ik.cpp:179-186)
         }
         // every rank joins the collective, also after a failure: a missing rank would hang the others
-        if (mmx_comm_all_reduce_norms_host(sh.comm.get(), local.data()) != MMX_OK && !failures[i]) {
-          failures[i] = std::make_exception_ptr(std::runtime_error(std::string("momentum_amd: ") + mmx_last_error()));
+        std::string commError;
+        if (!CommT::allReduce(sh.comm, local.data(), commError) && !failures[i]) {
+          failures[i] = std::make_exception_ptr(std::runtime_error("momentum_amd: " + commError));
         }
         reduced[i] = local;
       });
@@ -148,14 +193,16 @@ class BatchedMultiGpuSolver {
   struct Shard {
     size_t begin = 0, end = 0;
     int device = 0;
-    std::unique_ptr<DeviceCharacter> character;
-    std::unique_ptr<BatchedSkeletonSolverFunction> function;
-    std::unique_ptr<BatchedGaussNewtonSolver> solver;
-    std::shared_ptr<mmx_comm> comm;
+    std::unique_ptr<CharacterT> character;
+    std::unique_ptr<FunctionT> function;
+    std::unique_ptr<SolverT> solver;
+    typename CommT::Handle comm;
   };
   size_t batch_, numParams_;
   std::vector<Shard> shards_;
   std::array<double, 3> norms_{0.0, 0.0, 0.0};
 };
+
+using BatchedMultiGpuSolver = BatchedMultiGpuSolverT<>; // Gauss-Newton, fixed lambda, no line search: the BASELINE metric
 
 } // namespace momentum_amd

@@ -30,6 +30,7 @@ struct Rccl {
   int (*commInitAll)(ncclComm_t*, int, const int*) = nullptr;
   int (*allReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*commDestroy)(ncclComm_t) = nullptr;
+  int (*commCount)(ncclComm_t, int*) = nullptr; // optional
   const char* (*getErrorString)(int) = nullptr;
   std::string why;
   Rccl() {
@@ -51,6 +52,7 @@ struct Rccl {
     allReduce = reinterpret_cast<decltype(allReduce)>(sym("ncclAllReduce"));
     commDestroy = reinterpret_cast<decltype(commDestroy)>(sym("ncclCommDestroy"));
     getErrorString = reinterpret_cast<decltype(getErrorString)>(sym("ncclGetErrorString"));
+    commCount = reinterpret_cast<decltype(commCount)>(sym("ncclCommCount"));
     if (!getUniqueId || !commInitRank || !commInitAll || !allReduce || !commDestroy) {
       why = "librccl.so lacks an expected entry point";
       getUniqueId = nullptr;
@@ -167,17 +169,28 @@ int32_t mmx_comm_create_all(int32_t num_devices, const int32_t* devices, mmx_com
   if (!rccl().ok()) {
     return mmx::failWith(MMX_ERR_UNSUPPORTED, rccl().why);
   }
+  // the handles first: a failed host allocation must not leave RCCL communicators behind
+  std::vector<mmx_comm*> objs(static_cast<size_t>(num_devices), nullptr);
+  for (int32_t i = 0; i < num_devices; ++i) {
+    objs[static_cast<size_t>(i)] = new (std::nothrow) mmx_comm();
+    if (objs[static_cast<size_t>(i)] == nullptr) {
+      for (mmx_comm* c : objs) {
+        delete c;
+      }
+      return mmx::failWith(MMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+  }
   std::vector<ncclComm_t> comms(static_cast<size_t>(num_devices), nullptr);
   std::vector<int> devs(devices, devices + num_devices);
   const int rc = rccl().commInitAll(comms.data(), num_devices, devs.data());
   if (rc != 0) {
+    for (mmx_comm* c : objs) {
+      delete c;
+    }
     return ncclFail(rc, "ncclCommInitAll");
   }
   for (int32_t i = 0; i < num_devices; ++i) {
-    mmx_comm* c = new (std::nothrow) mmx_comm();
-    if (c == nullptr) {
-      return mmx::failWith(MMX_ERR_OUT_OF_MEMORY, "host allocation failed");
-    }
+    mmx_comm* c = objs[static_cast<size_t>(i)];
     c->comm = comms[static_cast<size_t>(i)];
     c->world = num_devices, c->rank = i, c->device = devices[i];
     out[i] = c;
@@ -186,7 +199,17 @@ int32_t mmx_comm_create_all(int32_t num_devices, const int32_t* devices, mmx_com
 }
 
 int32_t mmx_comm_world_size(const mmx_comm* comm) {
-  return comm != nullptr ? comm->world : 0;
+  if (comm == nullptr) {
+    return 0;
+  }
+  // what RCCL itself counts (ncclCommCount) when the library exports it: bench.py asserts it equals --gpus
+  if (comm->comm != nullptr && rccl().ok() && rccl().commCount != nullptr) {
+    int n = 0;
+    if (rccl().commCount(comm->comm, &n) == 0) {
+      return n;
+    }
+  }
+  return comm->world;
 }
 int32_t mmx_comm_rank(const mmx_comm* comm) {
   return comm != nullptr ? comm->rank : -1;

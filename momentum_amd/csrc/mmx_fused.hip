@@ -1446,7 +1446,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         float* Tl = panelLane ? s.L + 256 * tileIndex(prow >> 4, k) : Dk;
         const int trow = diagLane ? lane : (panelLane ? (prow & 15) : vrow);
         float a[16];
-        if (waveWorks) {
+        auto loadRows = [&]() {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float4 v = (diagLane || panelLane) ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
@@ -1462,27 +1462,49 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
               a[c] = c == vr ? 1.f : 0.f;
             }
           }
+        };
+        if (waveWorks) {
+          loadRows();
         }
         MMX_CLK(22)
         float invd = 0.f;
         bool bad = false;
         if (waveWorks) {
+          // the sixteen elimination steps; kGuard: a pivot at rounding level drops its column from this iteration's step
+          // (see kPivotFloor): 1 / l_jj = 0
+          auto chain = [&](const bool kGuard, const float floorRow) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const float djj = readLaneF(a[j], j);
+              bad = bad || !(djj > 0.f);
+              float inv = __builtin_amdgcn_rsqf(djj); // 1 / l_jj ; l_jj = d_jj * inv
+              if (kGuard) {
+                inv = djj > readLaneF(floorRow, j) ? inv : 0.f;
+              }
+              a[j] *= inv;
+              if (lane == j) {
+                invd = inv;
+              }
+#pragma unroll
+              for (int c = j + 1; c < 16; ++c) {
+                a[c] -= a[j] * readLaneF(a[j], c);
+              }
+            }
+          };
+          // The threshold costs three instructions per step on the kernel's longest dependent chain (measured: 3 % of the
+          // headline), and it only ever acts on rank-deficient systems with a lambda below the rounding of H: so the chain
+          // runs unguarded, every diagonal lane then checks ITS pivot from the 1 / l_jj it kept (d_jj = 1 / invd^2; a
+          // non-positive pivot left a NaN there), and only a panel that fails is reloaded (its tiles are still untouched
+          // in LDS) and eliminated again with the guard.  Every wave factors the diagonal block redundantly from the same
+          // values, so all of them take the same branch.
+          chain(false, 0.f);
+#ifndef MMX_EXP_NOPIVOT // (A/B build variant: no threshold at all)
           const float floorRow = s.invDiag[16 * k + (lane & 15)]; // kPivotFloor * (H_rr + lambda) of the diagonal lanes' rows
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float djj = readLaneF(a[j], j);
-            bad = bad || !(djj > 0.f);
-            // a pivot at rounding level drops its column from this iteration's step (see kPivotFloor): 1 / l_jj = 0
-            const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // 1 / l_jj ; l_jj = d_jj * inv
-            a[j] *= inv;
-            if (lane == j) {
-              invd = inv;
-            }
-#pragma unroll
-            for (int c = j + 1; c < 16; ++c) {
-              a[c] -= a[j] * readLaneF(a[j], c);
-            }
+          if (__any(diagLane && !(floorRow * invd * invd < 1.f))) {
+            loadRows();
+            chain(true, floorRow);
           }
+#endif
         }
         __syncthreads(); // every wave has read the diagonal block (long ago) before wave 0 overwrites it
         if (waveWorks) {

@@ -102,6 +102,51 @@ int main() {
     std::printf("FAIL: reduced norms (%.9g, %g, %g), expected (%.9g, %g, 0)\n", n[0], n[1], n[2], sumErr, double(B) * kIterations);
     return 1;
   }
-  std::printf("%d device(s), %zu elements in %zu shards, RCCL ranks: %zu\nOK\n", ndev, B, solver.numShards(), solver.numShards());
+  if (solver.commWorldSize() != solver.numShards()) {
+    std::printf("FAIL: RCCL counts %zu ranks for %zu shards\n", solver.commWorldSize(), solver.numShards());
+    return 1;
+  }
+  // the same batch through the driver's default solver type (GaussNewtonSolverQR: directional line search) on every device
+  {
+    GaussNewtonSolverQROptions qo;
+    qo.minIterations = qo.maxIterations = size_t(kIterations);
+    qo.threshold = 1.f;
+    qo.regularization = 0.05f;
+    qo.doLineSearch = true;
+    BatchedMultiGpuSolverT<BatchedGaussNewtonSolverQR> qr(character, devices, B, pp, op, qo);
+    std::vector<float> th2(B * kP, 0.f);
+    for (size_t b = 0; b < B; ++b) {
+      const int g = int(b % size_t(kB));
+      std::vector<PositionData> pc(kKp);
+      for (int i = 0; i < kKp; ++i) {
+        const int e = g * kKp + i;
+        pc[i].parent = size_t(k_pos_parent[i]);
+        pc[i].offset = {k_pos_offset[3 * e], k_pos_offset[3 * e + 1], k_pos_offset[3 * e + 2]};
+        pc[i].target = {k_pos_target[3 * e], k_pos_target[3 * e + 1], k_pos_target[3 * e + 2]};
+        pc[i].weight = k_pos_weight[e];
+      }
+      qr.setPositionConstraints(b, pc);
+      std::vector<OrientationData> oc(kKo);
+      for (int i = 0; i < kKo; ++i) {
+        const int e = g * kKo + i;
+        oc[i].parent = size_t(k_ori_parent[i]);
+        oc[i].offset = {k_ori_offset[4 * e], k_ori_offset[4 * e + 1], k_ori_offset[4 * e + 2], k_ori_offset[4 * e + 3]};
+        oc[i].target = {k_ori_target[4 * e], k_ori_target[4 * e + 1], k_ori_target[4 * e + 2], k_ori_target[4 * e + 3]};
+        oc[i].weight = k_ori_weight[e];
+      }
+      qr.setOrientationConstraints(b, oc);
+      for (int p = 0; p < kP; ++p) {
+        th2[b * kP + p] = k_theta0[g * kP + p];
+      }
+    }
+    const std::vector<double> e2 = qr.solve(th2);
+    for (size_t b = 0; b < B; ++b) { // a line search only ever lowers the error of the plain step's run
+      if (!(e2[b] <= err[b] * 1.001 + 1e-6) || !std::isfinite(double(th2[b * kP]))) {
+        std::printf("FAIL: line-search solver on %zu shards, element %zu: error %.6g against %.6g\n", qr.numShards(), b, e2[b], err[b]);
+        return 1;
+      }
+    }
+  }
+  std::printf("%d device(s), %zu elements in %zu shards, RCCL ranks: %zu\nOK\n", ndev, B, solver.numShards(), solver.commWorldSize());
   return 0;
 }

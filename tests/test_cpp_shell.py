@@ -83,6 +83,24 @@ def test_cpp_shell_matches_golden_fixture_on_gpu():
     assert out.stdout.strip().endswith("OK"), out.stdout
 
 
+STUB_SRC = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu_stub.cpp")
+STUB_EXE = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu_stub")
+
+
+def test_cpp_multi_gpu_host_logic_with_a_stubbed_exchange():
+    """BatchedMultiGpuSolverT with stub device classes and an in-process all-reduce (no GPU): shard routing of
+    per-element calls over 1 ... 8 ranks, ragged and empty shards, the reduced norms, a failing rank (the others finish,
+    every rank still joins the collective, the exception is rethrown after the join) -- the host logic of the N > 1 path,
+    which the one-GPU box can only ever run with a single rank."""
+    mbuild.build()
+    libdir = os.path.join(ROOT, "momentum_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"), STUB_SRC, "-L", libdir,
+                           "-lmmx_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", STUB_EXE])  # fmt: skip
+    out = subprocess.run([STUB_EXE], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK"), out.stdout
+
+
 def test_cpp_multi_gpu_program_compiles_and_links():
     _compile_multi()
     assert os.path.exists(MULTI_EXE)
