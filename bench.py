@@ -57,13 +57,17 @@ CONFIGS = {
     "cfg2_tracker": ("p128", "landmarks+tracker", 4096, 0, "BASELINE configs[1] + PlaneErrorFunction (8 constraints) + 16 MinMax parameter limits (M=192+8+16)"),
 }
 
-# what the default single-GPU run reports besides the headline: (key, config, batch, line_search, timed steps, CPU sample)
+# what the default single-GPU run reports besides the headline: (key, config, batch, line_search, timed steps, CPU sample, lambda)
 EXTRA_RUNS = [
-    ("cfg3@65536", "cfg3", 65536, 0, 4, 8192),
-    ("cfg2@32768", "cfg2", 32768, 0, 6, 8192),
-    ("cfg2@4096 line_search=2", "cfg2", 4096, 2, 10, 4096),
-    ("cfg5@8192", "cfg5", 8192, 0, 3, 1024),
-    ("cfg2_tracker@4096", "cfg2_tracker", 4096, 0, 10, 4096),
+    ("cfg3@65536", "cfg3", 65536, 0, 4, 8192, 0.05),
+    ("cfg2@32768", "cfg2", 32768, 0, 6, 8192, 0.05),
+    ("cfg2@4096 line_search=2", "cfg2", 4096, 2, 10, 4096, 0.05),
+    ("cfg5@8192", "cfg5", 8192, 0, 3, 1024, 0.05),
+    ("cfg2_tracker@4096", "cfg2_tracker", 4096, 0, 10, 4096, 0.05),
+    # weak damping (pymomentum's test_solver2.py value) with the batched driver's line search: on this shape -- as many
+    # independent rows as solved parameters -- no single-precision Cholesky solver holds 1e-5 on theta (check.pass is
+    # false by construction, the float oracle's figures stand beside it); tests/test_gpu_weak_damping.py has the table
+    ("cfg2@4096 lambda=1e-5 line_search=2", "cfg2", 4096, 2, 10, 2048, 1e-5),
 ]
 
 
@@ -210,23 +214,27 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n):
         "bound": PARITY_BOUND,
         "pass": bool(rel.max() <= PARITY_BOUND),
     }
-    if options.step_rule == 1 and out["num_above_bound"] > 0:
-        # The LM gain-ratio schedule shrinks lambda towards 1e-4 and takes discrete decisions (rho against 0 / 0.25 / 0.75): on a
-        # few instances single precision itself cannot hold the bound -- a gain ratio on a threshold goes the other (equally valid)
-        # way, or a weakly constrained direction amplifies the rounding of the late, barely damped steps.  Reported beside the
-        # strict `pass` (pass_relaxed): at least 99 % of the instances within the bound, and on EVERY instance above it the
-        # oracle's own float instantiation is above it too while the solve still converged (tests/test_gpu_baseline_parity.py::test_config3_lm_schedule_distinct_instances
-        # classifies by decisions instead).
+    if out["num_above_bound"] > 0:
+        # `pass` is the strict bound.  Beside it, for the instances above the bound: what the oracle's own FLOAT instantiation
+        # (the restatement of the reference's SolverT<float>) loses on them.  Three things put an instance there without any
+        # defect of the kernels: the LM schedule's discrete decisions (rho against 0 / 0.25 / 0.75: a gain ratio on a threshold
+        # goes the other, equally valid, way in single precision), a Gauss-Newton run that has not converged (no line search,
+        # a start from which the undamped step overshoots: the iteration amplifies every last-bit difference), and a weak
+        # lambda on a rank-deficient J (tests/test_gpu_weak_damping.py).  pass_relaxed: at least 99 % of the instances within
+        # the bound and every instance above it above it in the float oracle too.
         idx = np.nonzero(rel > PARITY_BOUND)[0]
         sub = cons.subset(idx)  # (the same problem: joint blocks / limits / prior travel with the instances)
-        r32 = orc.solve_batch(db.rig, sub, th0[idx], options, dtype="f32", nthreads=usable_cores())
-        rel32 = np.linalg.norm(r32["theta"] - ref["theta"][idx], axis=1) / np.maximum(np.linalg.norm(ref["theta"][idx], axis=1), 1e-30)
-        out["above_bound_float_oracle_rel"] = [float(x) for x in rel32]
-        out["above_bound_float_oracle_also_above"] = bool(np.all(rel32 > PARITY_BOUND))
-        # `pass` stays the strict bound; the rule for this schedule is reported beside it
+        with np.errstate(all="ignore"):
+            r32 = orc.solve_batch(db.rig, sub, th0[idx], options, dtype="f32", nthreads=usable_cores())
+            rel32 = np.linalg.norm(r32["theta"] - ref["theta"][idx], axis=1) / np.maximum(np.linalg.norm(ref["theta"][idx], axis=1), 1e-30)
+        out["above_bound_instances"] = [int(i) for i in idx[:16]]
+        out["above_bound_rel"] = [float(x) for x in rel[idx][:16]]
+        out["above_bound_float_oracle_rel"] = [float(x) for x in rel32[:16]]
+        out["above_bound_float_oracle_also_above"] = bool(np.all(~(rel32 <= PARITY_BOUND)))
+        out["above_bound_final_error_double"] = [float(x) for x in ref["error"][idx][:16]]
         out["pass_relaxed"] = bool(out["num_above_bound"] <= n // 100 and out["above_bound_float_oracle_also_above"])
         out["pass_relaxed_rule"] = ">= 99 % within the bound; every instance above it is above it in the oracle's float instantiation too"
-        out["within_bound"] = f"{n - out['num_above_bound']}/{n}"
+    out["within_bound"] = f"{n - out['num_above_bound']}/{n}"
     return out
 
 
@@ -327,15 +335,16 @@ def fused_pmc():
         return None
 
 
-def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu):
+def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu, regularization=0.05):
     from momentum_amd._abi import GnOptions
 
     rig, parents, _, step_rule, desc = build_rig(config)
     db = DeviceBatch(rig, parents, B, device_index, 424242, tracker=CONFIGS[config][1].endswith("+tracker"))
-    opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=line_search)
+    opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=regularization, step_rule=step_rule, do_line_search=line_search)
     elapsed, theta, norms = solve_loop(db, opt, steps, 1)
     out = {
         "workload": desc,
+        "regularization": regularization,
         "batch": B,
         "line_search": line_search,
         "step_rule": "lm_schedule" if step_rule == 1 else "gn_fixed_lambda",
@@ -555,9 +564,9 @@ def main() -> None:
             del db, pb
             torch.cuda.empty_cache()
             line["configs"] = {}
-            for key, cfg, eb, ls, steps, sample in EXTRA_RUNS:
+            for key, cfg, eb, ls, steps, sample, lam in EXTRA_RUNS:
                 try:
-                    line["configs"][key] = run_extra(key, cfg, eb, ls, steps, sample, local_rank, args.iterations, args.check_instances, not args.no_cpu_baseline)
+                    line["configs"][key] = run_extra(key, cfg, eb, ls, steps, sample, local_rank, args.iterations, args.check_instances, not args.no_cpu_baseline, lam)
                 except Exception as ex:  # a failing side configuration must not lose the headline line
                     line["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(line), flush=True)

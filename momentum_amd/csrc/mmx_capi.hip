@@ -2085,10 +2085,10 @@ int32_t mmx_solve_f64(
       o->do_line_search != MMX_LINE_SEARCH_DIRECTIONAL) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "unknown do_line_search rule");
   }
-  if (pb->dev.G > 0 || pb->dev.NE > 0 || pb->M > 3 * pb->U) {
+  if (pb->dev.G > 0 || pb->dev.NE > 0) {
     return fail(
         MMX_ERR_UNSUPPORTED,
-        "mmx_solve_f64: position / orientation constraints only (the further joint error functions, limits and the model-parameter prior are single precision)");
+        "mmx_solve_f64: position / orientation constraints, parameter limits and the model-parameter prior (the further joint error functions and ellipsoid limits are single precision)");
   }
   const size_t B = size_t(pb->B), n = size_t(pb->solveN), M = size_t(3 * pb->U);
   MMX_HIP(hipSetDevice(pb->rig->device));

@@ -777,22 +777,31 @@ __device__ __forceinline__ EllipsoidEval evalEllipsoid(const EllipsoidDev& ct, c
 // computeMinMaxJacobian :460-503, computeMinMaxJointJacobian :503-558, computeLinearJacobian
 // :561-595, computeLinearJointJacobian :597-656, computeHalfPlaneJacobian :659-695).
 constexpr int kLimitEntries = 4; // non-zero Jacobian entries of a row (joint limits: <= 2 per transform row)
-struct LimitRow {
+template <class T> // float: the single-precision kernels; double: mmx_solve_f64 (LimitErrorFunctionT<double>)
+struct LimitRowT {
   int idx[kLimitEntries]; // model parameters with a non-zero entry (-1: unused)
-  float coef[kLimitEntries]; // the entries
-  float r; // residual entry
-  float err; // this row's error term
+  T coef[kLimitEntries]; // the entries
+  T r; // residual entry
+  T err; // this row's error term
 };
+using LimitRow = LimitRowT<float>;
+__device__ __forceinline__ float limitSqrt(float x) {
+  return sqrtf(x);
+}
+__device__ __forceinline__ double limitSqrt(double x) {
+  return sqrt(x);
+}
 
 // joint parameter `row` of the parameter transform: value (transform * theta + offsets) and
 // whether the row has an enabled column (activeJointParams, parameter_transform.cpp:97-107)
-__device__ __forceinline__ float limitJointParam(const RigDev& rig, const float* th, const uint8_t* enabled, int row, bool& active) {
-  float v = rig.ptOffsets[row];
+template <class T>
+__device__ __forceinline__ T limitJointParam(const RigDev& rig, const T* th, const uint8_t* enabled, int row, bool& active) {
+  T v = T(rig.ptOffsets[row]);
   active = false;
   const int k1 = rig.ptOuter[row + 1];
   for (int k = rig.ptOuter[row]; k < k1; ++k) {
     const int p = rig.ptInner[k];
-    v += rig.ptValue[k] * th[p];
+    v += T(rig.ptValue[k]) * th[p];
     active = active || enabled[p] != 0;
   }
   return v;
@@ -800,11 +809,12 @@ __device__ __forceinline__ float limitJointParam(const RigDev& rig, const float*
 
 // adds weight * T[row, :] to the entries (jacobian_jointParams_to_modelParams, error_function_utils.h:77-91:
 // every column of the transform row, enabled or not; duplicates of a parameter add up)
-__device__ __forceinline__ void limitScatterRow(const RigDev& rig, LimitRow& o, int row, float weight) {
+template <class T>
+__device__ __forceinline__ void limitScatterRow(const RigDev& rig, LimitRowT<T>& o, int row, T weight) {
   const int k1 = rig.ptOuter[row + 1];
   for (int k = rig.ptOuter[row]; k < k1; ++k) {
     const int p = rig.ptInner[k];
-    const float c = weight * rig.ptValue[k];
+    const T c = weight * T(rig.ptValue[k]);
     bool placed = false;
 #pragma unroll
     for (int e = 0; e < kLimitEntries; ++e) {
@@ -817,68 +827,69 @@ __device__ __forceinline__ void limitScatterRow(const RigDev& rig, LimitRow& o, 
   }
 }
 
-__device__ __forceinline__ LimitRow
-evalLimit(const RigDev& rig, const LimitDev& lm, const float* th, const uint8_t* enabled, float tWeight) {
-  LimitRow o;
+template <class T>
+__device__ __forceinline__ LimitRowT<T> evalLimit(const RigDev& rig, const LimitDev& lm, const T* th, const uint8_t* enabled, T tWeight) {
+  LimitRowT<T> o;
 #pragma unroll
   for (int e = 0; e < kLimitEntries; ++e) {
     o.idx[e] = -1;
-    o.coef[e] = 0.f;
+    o.coef[e] = T(0);
   }
-  o.r = o.err = 0.f;
-  const float wgt = sqrtf(tWeight * lm.weight); // :1018-1021
+  o.r = o.err = T(0);
+  const T wgt = limitSqrt(tWeight * T(lm.weight)); // :1018-1021
   if (lm.type == 0) { // MinMax
     const int p = lm.index0;
     if (!enabled[p]) {
       return o;
     }
-    float val = 0.f;
+    T val = T(0);
     bool hit = false;
-    if (th[p] < lm.v[0]) {
-      val = th[p] - lm.v[0];
+    if (th[p] < T(lm.v[0])) {
+      val = th[p] - T(lm.v[0]);
       hit = true;
     }
-    if (th[p] > lm.v[1]) {
-      val = th[p] - lm.v[1];
+    if (th[p] > T(lm.v[1])) {
+      val = th[p] - T(lm.v[1]);
       hit = true;
     }
     if (hit) {
       o.idx[0] = p;
       o.coef[0] = wgt;
       o.r = val * wgt;
-      o.err = tWeight * lm.weight * (val * val);
+      o.err = tWeight * T(lm.weight) * (val * val);
     }
   } else if (lm.type == 1) { // MinMaxJoint: limits on the joint parameter index0
     bool active;
-    const float jp = limitJointParam(rig, th, enabled, lm.index0, active);
+    const T jp = limitJointParam(rig, th, enabled, lm.index0, active);
     if (!active) {
       return o;
     }
-    float val = 0.f;
+    T val = T(0);
     bool hit = false;
-    if (jp < lm.v[0]) {
-      val = jp - lm.v[0];
+    if (jp < T(lm.v[0])) {
+      val = jp - T(lm.v[0]);
       hit = true;
-    } else if (jp > lm.v[1]) {
-      val = jp - lm.v[1];
+    } else if (jp > T(lm.v[1])) {
+      val = jp - T(lm.v[1]);
       hit = true;
     }
     if (hit) {
       limitScatterRow(rig, o, lm.index0, wgt);
       o.r = val * wgt;
-      o.err = tWeight * lm.weight * (val * val);
+      o.err = tWeight * T(lm.weight) * (val * val);
     }
   } else if (lm.type == 3) { // Linear: p_ref = scale * p_tgt - offset
     const int ref = lm.index0, tgt = lm.index1;
-    const bool inRange = (lm.v[2] == 0.f && lm.v[3] == 0.f) || (th[tgt] >= lm.v[2] && th[tgt] < lm.v[3]); // parameter_limits.cpp:105-113
+    const float tgtF = float(th[tgt]); // isInRange takes a float (parameter_limits.cpp:105-113)
+    const bool inRange = (lm.v[2] == 0.f && lm.v[3] == 0.f) || (tgtF >= lm.v[2] && tgtF < lm.v[3]);
     if ((!enabled[tgt] && !enabled[ref]) || !inRange) {
       return o;
     }
-    const float rs = th[tgt] * lm.v[0] - lm.v[1] - th[ref];
+    const T rs = th[tgt] * T(lm.v[0]) - T(lm.v[1]) - th[ref];
     o.r = rs * wgt;
     if (enabled[tgt]) {
       o.idx[0] = tgt;
-      o.coef[0] = lm.v[0] * wgt;
+      o.coef[0] = T(lm.v[0]) * wgt;
     }
     if (enabled[ref]) {
       o.idx[1] = ref;
@@ -886,49 +897,50 @@ evalLimit(const RigDev& rig, const LimitDev& lm, const float* th, const uint8_t*
     }
     if (o.idx[0] == o.idx[1]) {
       o.idx[0] = -1; // jacobian(row, ref) = ... is assigned after (row, tgt) and overwrites it (:590-594)
-      o.coef[0] = 0.f;
+      o.coef[0] = T(0);
     }
-    o.err = tWeight * lm.weight * (rs * rs);
+    o.err = tWeight * T(lm.weight) * (rs * rs);
   } else if (lm.type == 4) { // LinearJoint: the same relation between two joint parameters
     bool actRef, actTgt;
-    const float jr = limitJointParam(rig, th, enabled, lm.index0, actRef);
-    const float jt = limitJointParam(rig, th, enabled, lm.index1, actTgt);
-    const bool inRange = (lm.v[2] == 0.f && lm.v[3] == 0.f) || (jt >= lm.v[2] && jt < lm.v[3]);
+    const T jr = limitJointParam(rig, th, enabled, lm.index0, actRef);
+    const T jt = limitJointParam(rig, th, enabled, lm.index1, actTgt);
+    const float jtF = float(jt);
+    const bool inRange = (lm.v[2] == 0.f && lm.v[3] == 0.f) || (jtF >= lm.v[2] && jtF < lm.v[3]);
     if ((!actRef && !actTgt) || !inRange) {
       return o;
     }
-    const float rs = jt * lm.v[0] - lm.v[1] - jr;
+    const T rs = jt * T(lm.v[0]) - T(lm.v[1]) - jr;
     o.r = rs * wgt;
     if (actTgt) {
-      limitScatterRow(rig, o, lm.index1, lm.v[0] * wgt);
+      limitScatterRow(rig, o, lm.index1, T(lm.v[0]) * wgt);
     }
     if (actRef) {
       limitScatterRow(rig, o, lm.index0, -wgt);
     }
-    o.err = tWeight * lm.weight * (rs * rs);
+    o.err = tWeight * T(lm.weight) * (rs * rs);
   } else if (lm.type == 6) { // HalfPlane: (p1, p2) . normal - offset >= 0
     const int p1 = lm.index0, p2 = lm.index1;
     if (!enabled[p1] && !enabled[p2]) {
       return o;
     }
-    const float rs = th[p1] * lm.v[0] + th[p2] * lm.v[1] - lm.v[2];
-    if (rs >= 0.f) {
+    const T rs = th[p1] * T(lm.v[0]) + th[p2] * T(lm.v[1]) - T(lm.v[2]);
+    if (rs >= T(0)) {
       return o;
     }
     o.r = rs * wgt;
     if (enabled[p1]) {
       o.idx[0] = p1;
-      o.coef[0] = lm.v[0] * wgt;
+      o.coef[0] = T(lm.v[0]) * wgt;
     }
     if (enabled[p2]) {
       o.idx[1] = p2;
-      o.coef[1] = lm.v[1] * wgt;
+      o.coef[1] = T(lm.v[1]) * wgt;
     }
     if (o.idx[0] == o.idx[1]) {
       o.idx[0] = -1; // (:689-694)
-      o.coef[0] = 0.f;
+      o.coef[0] = T(0);
     }
-    o.err = tWeight * lm.weight * (rs * rs);
+    o.err = tWeight * T(lm.weight) * (rs * rs);
   }
   return o;
 }

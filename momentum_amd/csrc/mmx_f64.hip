@@ -11,8 +11,10 @@
 // solves, skeleton_state.cpp:89) and are widened per use.
 //
 // Scope: position and orientation constraints with their GeneralizedLoss, per-instance characters and constraint
-// parents, enabled-parameter sets.  The parameter-space rows (limits, model-parameter prior) and the further joint
-// error functions are single-precision only for now (mmx_solve_f64 returns MMX_ERR_UNSUPPORTED for them).
+// parents, enabled-parameter sets, per-element error-function weights, and the parameter-space rows -- LimitErrorFunctionT
+// <double> for the limit types on model / joint parameters and ModelParametersErrorFunctionT<double> -- whose few
+// non-zeros per row go straight into H and g (the products J^T J would form from them, in double).  The further joint
+// error functions and ellipsoid limits are single-precision only (mmx_solve_f64 returns MMX_ERR_UNSUPPORTED for them).
 #include "mmx_device.hpp"
 #include "mmx_kernels.hpp"
 
@@ -127,6 +129,7 @@ struct F64Lds {
   double* d; // [n]
   double* red; // [8]
   int* flags; // [4]
+  int* colOf; // [P] solve column of a model parameter, or -1
   double* jl; // [n][rc + 1] a chunk of J's rows, column-major (normal equations)
 };
 
@@ -240,6 +243,37 @@ __device__ double blockSumF64(const F64Lds& s, double v, int tid) {
   return (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
 }
 
+// this thread's share of the error of the parameter-space blocks at `th`: LimitErrorFunctionT<double> (the limit types
+// on model / joint parameters, limit_error_function.cpp:992-1122) and ModelParametersErrorFunctionT<double>
+// (model_parameters_error_function.cpp:44-131).  kJacobianRows: the value getJacobian returns (model rows with weight
+// <= 0 are skipped, :113), else the one getError returns (:54-58).
+template <bool kJacobianRows>
+__device__ double paramRowsErrorF64(const RigDev& rig, const ProblemDev& pb, const double* th, int b, int tid) {
+  double e = 0.0;
+  if (pb.NL > 0 && pb.wLimit > 0.f) {
+    const double tWeight = double(1e+1f * pb.wLimit); // kLimitWeight * weight_ (a float product in both instantiations)
+    for (int l = tid; l < pb.NL; l += 256) {
+      e += evalLimit<double>(rig, pb.limits[l], th, pb.enabledMask, tWeight).err;
+    }
+  }
+  if (pb.hasModel && pb.wModel > 0.f) {
+    const float* tp = pb.mpTarget + size_t(b) * rig.P;
+    const float* tw = pb.mpWeights + size_t(b) * rig.P;
+    double em = 0.0;
+    for (int i = tid; i < rig.P; i += 256) {
+      if (pb.enabledMask[i] != 0) {
+        const double w = double(tw[i]);
+        if (!kJacobianRows || w > 0.0) {
+          const double pd = w * (th[i] - double(tp[i]));
+          em += pd * pd;
+        }
+      }
+    }
+    e += em * double(pb.wModel) * 1e-1; // kMotionWeight (T(1e-1), model_parameters_error_function.h:61)
+  }
+  return e;
+}
+
 // SkeletonSolverFunctionT<double>::getError (skeleton_solver_function.cpp:64-83; rounded through float, :82)
 __device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds& s, const double* th, int b, int tid) {
   fkF64(rig, s, th, tid, false);
@@ -247,6 +281,7 @@ __device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds
   for (int u = tid; u < pb.U; u += 256) {
     e += evalUnitF64(pb, s, b, u, false);
   }
+  e += paramRowsErrorF64<false>(rig, pb, th, b, tid);
   return double(float(blockSumF64(s, e, tid)));
 }
 
@@ -299,6 +334,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     s.g = take(n), s.d = take(n), s.red = take(8);
     s.utin = reinterpret_cast<int*>(take((U + 1) / 2 + 1));
     s.flags = reinterpret_cast<int*>(take(2));
+    s.colOf = reinterpret_cast<int*>(take((size_t(P) + 1) / 2));
     s.jl = take(size_t(n) * size_t(rc + 1));
   }
   double* thg = theta + size_t(b) * P;
@@ -310,6 +346,14 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
   if (tid == 0) {
     s.flags[0] = 0, s.flags[1] = 0, s.flags[2] = 0;
   }
+  for (int i = tid; i < P; i += 256) {
+    s.colOf[i] = -1;
+  }
+  __syncthreads();
+  for (int c = tid; c < n; c += 256) {
+    s.colOf[solveList[c]] = c;
+  }
+  const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   __syncthreads();
   double lastError = DBL_MAX, curError = DBL_MAX; // solver.cpp:84-85
   double lambda = double(fp.lambda);
@@ -320,6 +364,9 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     double e = 0.0;
     for (int u = tid; u < U; u += 256) {
       e += evalUnitF64(pb, s, b, u, true);
+    }
+    if (hasParamRows) {
+      e += paramRowsErrorF64<true>(rig, pb, s.th, b, tid);
     }
     curError = blockSumF64(s, e, tid); // (not rounded: the value getJacobian returns)
     for (int item = tid; item < n * U; item += 256) {
@@ -413,6 +460,60 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     }
     __threadfence_block();
     __syncthreads();
+    if (M == 0) { // no joint-constraint rows at all (parameter-space rows only): H starts as lambda I
+      for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx % n, j = idx / n;
+        if (j <= i) {
+          Hb[size_t(j) * n + i] = i == j ? lambda : 0.0;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (hasParamRows) {
+      // the rows of the parameter-space blocks have at most kLimitEntries non-zeros: what J^T J and J^T r would take
+      // from them goes straight into H and g.  Limits one after the other by one thread (several may share an entry of
+      // H: a fixed order keeps the solve deterministic), the model prior's diagonal rows over the threads.
+      if (tid == 0 && pb.NL > 0 && pb.wLimit > 0.f) {
+        const double tWeight = double(1e+1f * pb.wLimit);
+        for (int l = 0; l < pb.NL; ++l) {
+          const LimitRowT<double> row = evalLimit<double>(rig, pb.limits[l], s.th, pb.enabledMask, tWeight);
+          for (int x = 0; x < kLimitEntries; ++x) {
+            const int cx = row.idx[x] >= 0 ? s.colOf[row.idx[x]] : -1;
+            if (cx < 0) {
+              continue;
+            }
+            s.g[cx] += row.coef[x] * row.r;
+            for (int y = 0; y <= x; ++y) {
+              const int cy = row.idx[y] >= 0 ? s.colOf[row.idx[y]] : -1;
+              if (cy < 0) {
+                continue;
+              }
+              const int hi = cx > cy ? cx : cy, lo = cx > cy ? cy : cx;
+              Hb[size_t(lo) * n + hi] += row.coef[x] * row.coef[y]; // (a row's parameters are distinct: limitScatterRow merges)
+            }
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (pb.hasModel && pb.wModel > 0.f) {
+        const float* tp = pb.mpTarget + size_t(b) * P;
+        const float* tw = pb.mpWeights + size_t(b) * P;
+        const double sW = double(sqrtf(pb.wModel * 1e-1f)); // sWeight: a float in both instantiations (:109)
+        for (int c = tid; c < n; c += 256) {
+          const int p = solveList[c];
+          const double w = double(tw[p]);
+          if (pb.enabledMask[p] != 0 && w > 0.0) {
+            const double jw = sW * w, r = (w * (s.th[p] - double(tp[p]))) * sW;
+            Hb[size_t(c) * n + c] += jw * jw;
+            s.g[c] += jw * r;
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
     // ---- llt_.compute(H) (Eigen::LLT, lower): right-looking, one column per step; a non-positive pivot is
     // recorded (the reference never checks LLT::info(), gauss_newton_solver.cpp:251)
     bool notPd = false;
@@ -591,7 +692,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
 
 static size_t solveF64BaseDoubles(int J, int P, int U, int n) {
   auto e = [](size_t c) { return (c + 1) & ~size_t(1); };
-  return 2 * e(P) + e(7 * size_t(J)) + e(size_t(kDs) * J) + 2 * e(3 * size_t(U)) + e(U) + 2 * e(n) + e(8) + e((U + 1) / 2 + 1) + e(2);
+  return 2 * e(P) + e(7 * size_t(J)) + e(size_t(kDs) * J) + 2 * e(3 * size_t(U)) + e(U) + 2 * e(n) + e(8) + e((U + 1) / 2 + 1) + e(2) + e((size_t(P) + 1) / 2);
 }
 // rows of J staged per chunk: as many as fit next to the fixed part (at most 64, at least 4), leaving room for two
 // workgroups per CU when the system is small

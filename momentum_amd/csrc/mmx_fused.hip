@@ -2053,7 +2053,7 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   const size_t oSrc = take(size_t(kSrcCh) * size_t(srcStrideFor(nsrc)));
   const size_t oSpan = take(nsrc);
   const size_t oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U), oKr = take(2 * ((size_t(J) + 15) / 16));
-  const size_t oRed = take(16);
+  const size_t oRed = take(32); // one double per wave (up to sixteen)
   if (out != nullptr) {
     out->span = reinterpret_cast<int*>(base + oSpan);
     out->kRange = reinterpret_cast<int*>(base + oKr);
@@ -2094,9 +2094,9 @@ __host__ __device__ inline size_t treeNeExtraLdsFloats(int P, int n, int GT, int
 
 // kExtraRows: the instantiation for problems with parameter-space rows (limits, model prior) and / or further joint error
 // functions / ellipsoid limits; the plain one carries none of that code
-// kWaves: wavefronts of the workgroup (4; 8 = staged, MMX_TREE_NE_WAVES=8, for the instantiation without extra rows: one
-// workgroup per CU is all the LDS allows, so four waves are ONE per SIMD -- eight give every phase that deals work by thread
-// or by wave twice the lanes and each SIMD a second wave to switch to; the term records stay with the first 256 threads)
+// kWaves: wavefronts of the workgroup (4; 16 for the instantiation without extra rows: one workgroup per CU is all the
+// LDS allows, so four waves are ONE per SIMD -- sixteen give every phase that deals work by thread or by wave four times
+// the lanes and each SIMD three more waves to switch to; the term records stay with the first 256 threads)
 template <bool kExtraRows, int kWaves = 4>
 __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
     RigDev rig,
@@ -2112,7 +2112,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
     float* __restrict__ genState, // [B][treeGenStateFloats] J_g and its residual rows for treeRefineKernel, or null
     int tileMajor) { // 0: jtj = [n][n] row-major, lower triangle; 1: [tile (I,J) at I(I+1)/2 + J][col][row] (what the tiled factor reads) // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  static_assert(kWaves == 4 || (kWaves == 8 && !kExtraRows), "the helpers of the extra rows are written for 256 threads");
+  static_assert(kWaves == 4 || ((kWaves == 8 || kWaves == 16) && !kExtraRows), "the helpers of the extra rows are written for 256 threads");
   constexpr int kT = 64 * kWaves;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -2237,7 +2237,11 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
           [&](int c, int& e0, int& e1) { e0 = fd.slotBase + fd.srcStart[c], e1 = fd.slotBase + fd.srcStart[c + 1]; });
     }
     if (errOut != nullptr && tid == 0) {
-      errOut[b] = kWaves == 4 ? (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]) : ((s.red[0] + s.red[1]) + (s.red[2] + s.red[3])) + ((s.red[4] + s.red[5]) + (s.red[6] + s.red[7]));
+      double eSum = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+      for (int w0 = 4; w0 < kWaves; w0 += 4) {
+        eSum += (s.red[w0] + s.red[w0 + 1]) + (s.red[w0 + 2] + s.red[w0 + 3]);
+      }
+      errOut[b] = eSum;
     }
     if (stb != nullptr) {
       for (int i = tid; i < kJs * J; i += kT) {
@@ -2521,13 +2525,16 @@ hipError_t launchTreeNormalEquations(
     return hipErrorInvalidValue;
   }
   const bool extra = pb.M > pb.rowsJoint || fd.GT > 0 || pb.instPosParent != nullptr || pb.instOriParent != nullptr;
-  if (!extra) { // eight waves per workgroup (one workgroup per CU either way: the LDS footprint decides); cfg5: +12 %
+  if (!extra) { // many waves per workgroup (one workgroup per CU either way: the LDS footprint decides)
+    // sixteen waves = four per SIMD (93 VGPRs: no spill under the 128 of that occupancy).  cfg5, one box, solves/s:
+    // four waves 1.476e5, eight 1.626e5, sixteen 1.704e5 (round 3)
+    constexpr int kNeWaves = 16;
     static LdsLimitCache ldsLimit8;
-    hipError_t rc = ldsLimit8.ensure(reinterpret_cast<const void*>(treeNormalEquationsKernel<false, 8>), lds);
+    hipError_t rc = ldsLimit8.ensure(reinterpret_cast<const void*>(treeNormalEquationsKernel<false, kNeWaves>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
-    hipLaunchKernelGGL((treeNormalEquationsKernel<false, 8>), dim3(pb.B), dim3(512), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
+    hipLaunchKernelGGL((treeNormalEquationsKernel<false, kNeWaves>), dim3(pb.B), dim3(64 * kNeWaves), lds, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
     return hipGetLastError();
   }
   // parameter-space rows, further joint blocks or per-instance parents: four waves (their helpers stride by 256 threads)

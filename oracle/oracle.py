@@ -22,12 +22,21 @@ _lib: Optional[C.CDLL] = None
 
 
 _STAMP = os.path.join(_HERE, ".built_for")
-# ISA candidates of the CPU baseline.  SURVEY.md 8d asks for the host's own ISA (-march=native); with this compiler
-# (gcc 11) the 512-bit code it generates for the oracle's short inner loops is SLOWER than the AVX2 build on both hosts
-# this has run on (Cooper Lake: 295 vs 438 solves/s/thread; EPYC 9575F: 195 vs 706), so build() compiles every
-# candidate, times a fixed single-thread workload with each, and keeps the fastest: the baseline is the best this
-# code does on the box at hand, and cpu_baseline.sample says which flags won.
-_CANDIDATES = ["-march=native", "-march=native -mprefer-vector-width=256", "-march=x86-64-v3 -mtune=native"]
+# ISA / tuning candidates of the CPU baseline.  SURVEY.md 8d asks for the host's own ISA (-march=native); with this
+# compiler (gcc 11) that is not the fastest build of the oracle on either host this has run on, and on one it is
+# disastrous -- measured, solves/s/thread, float, 72-joint humanoid:
+#   Cooper Lake (this container): -march=native 320 | native, 256-bit vectors 457 | x86-64-v3 438
+#   EPYC 9575F (the MI355X box):  -march=native 208 | -march=znver3 167 | x86-64-v3 -mtune=native 166 | x86-64-v3 746-775
+# (gcc 11 does not know Zen 5: `native` resolves to a znver tuning whose cost model wrecks the oracle's short inner
+# loops, with or without AVX-512).  So build() compiles every candidate below, times a fixed single-thread workload with
+# each, and keeps the fastest: the baseline is the best this code does on the box at hand, and cpu_baseline.sample says
+# which flags won and what the others reached.
+_CANDIDATES = [
+    "-march=native",
+    "-march=native -mtune=generic",
+    "-march=native -mtune=generic -mprefer-vector-width=256",
+    "-march=x86-64-v3",
+]
 _BASE_FLAGS = "-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter"
 
 

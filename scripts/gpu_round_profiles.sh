@@ -43,6 +43,34 @@ for tag,pat in (("pmc_bench","pmc2"),("pmc_cfg5","pmc5")):
             fo.write(k+"\n")
             for c,vals in sorted(v.items()): fo.write("   %-28s n=%-3d avg=%.4g\n" % (c,len(vals),sum(vals)/len(vals)))
 PY
+# two-line derivation of the roofline fractions from the kernel traces alone: algorithmic bytes per instance (bench.py's
+# algorithmic_bytes_per_instance: write J and r, read theta / constraint payload / parents) x instances per launch
+# / average duration of the J-assembly kernel at that grid / 8 TB/s
+timeout 60 python - $out $r < /dev/null <<'PY'
+import re,sys
+out,r=sys.argv[1],sys.argv[2]
+def avg_us(path, wg):
+    for line in open(path):
+        if line.startswith(f"[{wg} wg]") and "fkJacobianKernel<true" in line:
+            f=line.split()
+            # columns: ... calls total_ms avg_us min_us max_us pct (from the right)
+            return int(f[-6]), float(f[-4])
+    return None
+rows=[]
+for tag,path,wg,M,P,Kp,Ko in (("cfg2 (BASELINE configs[1], B = 4096)", f"{out}/{r}_bench_kernel_stats.txt", 4096, 192, 128, 16, 16),
+                            ("cfg5 (BASELINE configs[4], B = 8192)", f"{out}/{r}_cfg5_kernel_stats.txt", 8192, 900, 300, 150, 50)):
+    try:
+        got=avg_us(path, wg)
+    except OSError:
+        got=None
+    if not got: continue
+    calls,us=got
+    bpi=4*(M*P+M)+4*P+4*(7*Kp+9*Ko)+4*(Kp+Ko)
+    gbs=bpi*wg/(us*1e-6)/1e9
+    rows.append(f"{tag}: fkJacobianKernel<true,4,true> at {wg} workgroups: {calls} launches, average {us:.2f} us; {bpi} B per instance x {wg} = {bpi*wg} B per launch -> {gbs:.0f} GB/s = {gbs/8000:.3f} of the 8 TB/s HBM peak")
+open(f"{out}/{r}_roofline.txt","w").write("\n".join(rows)+"\n")
+print("\n".join(rows))
+PY
 cat $out/pytest_gpu.txt; head -8 $out/${r}_bench_kernel_stats.txt | cut -c1-140; head -8 $out/${r}_cfg5_kernel_stats.txt | cut -c1-140
 python - $out/${r}_bench_default.json < /dev/null <<'PY'
 import json,sys

@@ -89,14 +89,79 @@ def test_f64_solve_with_robust_loss_disabled_parameters_and_per_instance_parents
         assert np.all(th[b][[2, 9, 30]] == 0)
 
 
-def test_f64_refuses_blocks_it_does_not_cover(torch_cuda):
+@pytest.mark.parametrize("mode", ["gn", "line_search_directional", "lm_schedule"])
+@pytest.mark.parametrize("which", ["chain8", "humanoid72"])
+def test_f64_solve_with_limits_and_the_model_prior(torch_cuda, orc, which, mode):
+    """LimitErrorFunctionT<double> (every limit type on model / joint parameters) and ModelParametersErrorFunctionT<double>
+    next to the joint constraints, some parameters disabled, per-element error-function weights: the double instantiation
+    against the oracle's at 1e-10 (the reference instantiates everything for double, gauss_newton_solver.cpp:315-316)."""
+    from tests.test_gpu_parameter_rows import _problem
+
+    torch = torch_cuda
+    if which == "chain8":
+        rig, pp, op, B = make_test_character(8), [7, 3], [6], 4
+    else:
+        rig = make_humanoid72(unit=UNIT)
+        pp = op = humanoid72_landmark_joints(rig)
+        B = 5
+    rh, pb, full, th0 = _problem(torch, orc, rig, pp, op, B, 300, True, True)
+    en = np.ones(rig.num_params, np.uint8)
+    en[[2, 5]] = 0
+    pb.set_enabled(en)
+    kw = dict(min_iterations=8, max_iterations=8, threshold=1.0, regularization=0.05)
+    if mode == "line_search_directional":
+        kw["do_line_search"] = 2
+    elif mode == "lm_schedule":
+        kw["step_rule"] = MMX_STEP_LM_SCHEDULE
+    opt = GnOptions.make(**kw)
+    out = pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, full, th0, opt, enabled=en, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel.max() <= (1e-10 if which == "humanoid72" else 1e-8), rel
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]) and np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-9 * max(1.0, np.abs(href).max())
+    assert np.all(th[:, [2, 5]] == th0[:, [2, 5]])
+
+
+def test_f64_solve_with_parameter_rows_only(torch_cuda, orc):
+    """No joint constraint at all: limits and the model prior alone drive the double solve (H starts as lambda I)."""
     from momentum_amd import capi
     from momentum_amd._abi import ParameterLimit as PL
 
     torch = torch_cuda
+    rig = make_test_character(6)
+    B, P = 3, rig.num_params
+    rng = np.random.default_rng(4)
+    limits = [PL.minmax(1, -0.1, 0.1, 2.0), PL.linear(3, 4, 0.5, 0.1, weight=1.5), PL.halfplane(5, 6, 0.6, 0.8, 0.2)]
+    mt = rng.uniform(-0.3, 0.3, size=(B, P)).astype(np.float32)
+    mw = rng.uniform(0.1, 1.0, size=(B, P)).astype(np.float32)
+    th0 = rng.uniform(-0.5, 0.5, size=(B, P))
+    z = lambda *shape: np.zeros(shape, np.float32)
+    full = orc.Constraints([], z(B, 0, 3), z(B, 0, 3), z(B, 0), [], z(B, 0, 4), z(B, 0, 4), z(B, 0), limits=limits, limit_function_weight=0.8,
+                           model_target=mt, model_weights=mw, model_function_weight=1.2)  # fmt: skip
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, [], [])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(pb.device)
+    pb.set_constraints(t(z(B, 0, 3)), t(z(B, 0, 3)), t(z(B, 0)), t(z(B, 0, 4)), t(z(B, 0, 4)), t(z(B, 0)), limits=limits, limit_function_weight=0.8,
+                       model_target=t(mt), model_weights=t(mw), model_function_weight=1.2)  # fmt: skip
+    opt = GnOptions.make(min_iterations=5, max_iterations=5, threshold=1.0, regularization=0.05)
+    out = pb.solve_f64(torch.from_numpy(th0.copy()).to(pb.device), opt)
+    ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+    rel = np.linalg.norm(out["theta"].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel.max() <= 1e-10, rel
+
+
+def test_f64_refuses_blocks_it_does_not_cover(torch_cuda):
+    from momentum_amd import _abi, capi
+    from tests.test_gpu_joint_blocks import _device_block
+    from tests.test_oracle_joint_blocks import make_block
+
+    torch = torch_cuda
     rig = make_test_character(5)
     cons, th0, _ = make_problem(rig, [4], [3], 2, seed=1)
-    rh, pb = _gpu(torch, rig, cons, 2, limits=[PL.minmax(1, -0.1, 0.1)])
+    blk = _device_block(torch, make_block(_abi.MMX_JC_PLANE, [2], np.random.default_rng(0), weight=1.0, batch=2), torch.device("cuda", 0))
+    rh, pb = _gpu(torch, rig, cons, 2, joint_blocks=[blk])
     with pytest.raises(capi.MmxError) as ei:
         pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), GnOptions.make())
     assert "single precision" in str(ei.value)
