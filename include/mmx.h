@@ -89,8 +89,13 @@ typedef enum mmx_status {
                                    updates of the damping that pull |step| towards the trust radius (:180-231),
                                    gain ratio against the quadratic model (:246-247), radius x 0.25 / x 2 (cap 10)
                                    (:256-262), a step with rho <= 0 is rejected (:265-269).  Every change of the
-                                   damping costs a factorisation (the reference appends rows to its QR).  Fused
-                                   solver only; do_line_search and regularization are not read by this rule. */
+                                   damping costs a factorisation (the reference appends rows to its QR).  Runs
+                                   inside the one-launch solve where the problem fits it (<= 224 solved parameters,
+                                   position / orientation constraints, limits, model prior) and on the wide route
+                                   otherwise (driven from the host: factor / decide / trial kernels per trust step;
+                                   larger systems, further joint error functions, ellipsoid limits); not on
+                                   MMX_ROUTE_EXPLICIT_JACOBIAN and not in mmx_solve_f64.  do_line_search and
+                                   regularization are not read by this rule. */
 
 /*
  * Static rig = Skeleton + ParameterTransform of a momentum::Character

@@ -214,7 +214,7 @@ struct mmx_problem {
   DevBuf sTreeState, sDvec, sRhoVec, sRefState, sGenState; // wide systems refined through the tree (no dense J)
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
   DevBuf sJacF64, sHessF64; // scratch of the double-precision solve
-  DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda;
+  DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda, sTrust;
   mmx_tuning tuning{}; // mmx_problem_set_tuning
   int32_t lastRoute = MMX_ROUTE_AUTO;
 };
@@ -1824,7 +1824,12 @@ static int32_t solveImpl(
   // 1.57e6 -- below twelve 16-blocks the fused solve stays).  mmx_tuning::route pins either.
   const int32_t route = pb->tuning.route;
   const bool forceWide = route == MMX_ROUTE_WIDE;
-  const bool preferWide = (forceWide || mmx::fusedBlocksFor(pb->fdev.n) >= 12) && o->step_rule != MMX_STEP_TRUST_REGION &&
+  const bool trust = o->step_rule == MMX_STEP_TRUST_REGION;
+  // (the trust region's re-solve loops live in the one-launch solve; the wide route drives them from the host, several
+  // small kernels per trust step: it takes the rule only where the fused solve cannot -- more than 224 solved
+  // parameters, further joint error functions / ellipsoid limits -- or when pinned)
+  const bool trustNeedsWide = trust && (!fusedUsable(pb) || pb->fdev.GT > 0);
+  const bool preferWide = (forceWide || trustNeedsWide || (!trust && mmx::fusedBlocksFor(pb->fdev.n) >= 12)) &&
       treeNormalEquationsUsable(pb) && route != MMX_ROUTE_FUSED && route != MMX_ROUTE_EXPLICIT_JACOBIAN;
   const bool legacy = route == MMX_ROUTE_EXPLICIT_JACOBIAN;
   const bool takeFused = fusedUsable(pb) && !legacy && !preferWide && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION);
@@ -1832,7 +1837,7 @@ static int32_t solveImpl(
     return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_FUSED: the problem does not fit the one-launch solve (more than 224 solved parameters, or its tables beyond the LDS budget)");
   }
   if (route == MMX_ROUTE_WIDE && !preferWide) {
-    return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_WIDE: the problem is outside the tree kernels' scope (or the step rule is MMX_STEP_TRUST_REGION)");
+    return fail(MMX_ERR_UNSUPPORTED, "MMX_ROUTE_WIDE: the problem is outside the tree kernels' scope");
   }
   if (takeFused) {
     pb->lastRoute = MMX_ROUTE_FUSED;
@@ -1897,8 +1902,8 @@ static int32_t solveImpl(
     }
     return MMX_OK;
   }
-  if (o->step_rule == MMX_STEP_TRUST_REGION) {
-    return fail(MMX_ERR_UNSUPPORTED, "MMX_STEP_TRUST_REGION lives in the fused solver: not available for problems that take the explicit-Jacobian kernels (further joint blocks, ellipsoid limits, MMX_ROUTE_EXPLICIT_JACOBIAN, systems beyond the fused instantiations)");
+  if (trust && !(preferWide && treeNormalEquationsUsable(pb) && route != MMX_ROUTE_EXPLICIT_JACOBIAN)) {
+    return fail(MMX_ERR_UNSUPPORTED, "MMX_STEP_TRUST_REGION: available in the one-launch solve and on the wide route (tree kernels); this problem takes neither (MMX_ROUTE_EXPLICIT_JACOBIAN, or outside the tree kernels' scope)");
   }
   if (n > 512) {
     return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
@@ -1935,8 +1940,8 @@ static int32_t solveImpl(
     MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
   }
   MMX_HIP(hipMemcpyAsync(pb->sThetaInit.p, theta_dev, B * P * sizeof(float), hipMemcpyDeviceToDevice, s));
-  const bool deferred = o->do_line_search != 0 || o->step_rule == MMX_STEP_LM_SCHEDULE;
-  const bool schedule = o->step_rule == MMX_STEP_LM_SCHEDULE;
+  const bool deferred = trust || o->do_line_search != 0 || o->step_rule == MMX_STEP_LM_SCHEDULE;
+  const bool schedule = trust || o->step_rule == MMX_STEP_LM_SCHEDULE; // per-instance damping
   if (deferred) {
     MMX_HIP(pb->sDelta.ensure(B * size_t(std::max(n, 1)) * sizeof(float)));
     MMX_HIP(pb->sStepIter.ensure(B * sizeof(int32_t)));
@@ -1955,8 +1960,20 @@ static int32_t solveImpl(
   sp.delta = deferred ? pb->sDelta.as<float>() : nullptr;
   sp.stepIter = deferred ? pb->sStepIter.as<int32_t>() : nullptr;
   sp.lambdaPer = schedule ? pb->sLambda.as<float>() : nullptr;
-  sp.doLineSearch = o->do_line_search;
+  sp.doLineSearch = trust ? 0 : o->do_line_search; // (the trust region reads neither do_line_search nor regularization)
   sp.stepRule = o->step_rule;
+  if (trust) {
+    MMX_HIP(pb->sTrust.ensure(B * 6 * sizeof(int32_t) + 16));
+    char* base = static_cast<char*>(pb->sTrust.p);
+    sp.tr.lambda = reinterpret_cast<float*>(base);
+    sp.tr.radius = reinterpret_cast<float*>(base + B * 4);
+    sp.tr.phase = reinterpret_cast<int32_t*>(base + B * 8);
+    sp.tr.newton = reinterpret_cast<int32_t*>(base + B * 12);
+    sp.tr.step = reinterpret_cast<int32_t*>(base + B * 16);
+    sp.tr.mask = reinterpret_cast<int32_t*>(base + B * 20);
+    sp.tr.active = reinterpret_cast<int32_t*>(base + B * 24);
+    MMX_HIP(mmx::launchTrustInit(sp.tr, pb->B, o->trust_region_radius > 0.f ? o->trust_region_radius : 1.f, s));
+  }
   sp.lmLambdaMin = o->lm_lambda_min;
   sp.lmLambdaMax = o->lm_lambda_max;
   sp.lmUp = o->lm_up;
@@ -1996,18 +2013,52 @@ static int32_t solveImpl(
             pb->sTreeState.as<float>(), sp.clk != nullptr ? sp.clk + 8 : nullptr, genState, true, s));
       }
       MMX_ZONE("Dense gauss newton step");
-      MMX_HIP(mmx::launchCholeskyFactorTiled(
-          ds, pb->rig->P, pb->sJtj.as<float>(), pb->sJtr.as<float>(), factorScratch, pb->sDvec.as<float>(), pb->sRefState.as<int32_t>(),
-          pb->sErr.as<double>(), theta_dev, st, sp, s));
-      // up to three refinement rounds; an instance whose correction fell below 1e-3 of its step applies the step and
-      // sits out the remaining rounds (its workgroups return at once)
-      for (int round = 0; round < sp.refine; ++round) {
-        MMX_HIP(mmx::launchTreeRefine(
-            pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sTreeState.as<float>(), genState, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
-            sp.lambda, sp.lambdaPer, s));
-        MMX_HIP(mmx::launchCholeskyFinishTiled(
-            ds, pb->rig->P, factorScratch, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(), pb->sErr.as<double>(),
-            theta_dev, st, sp, round, s));
+      // factor + first solve, then up to three refinement rounds; an instance whose correction fell below 1e-3 of its step
+      // applies the step and sits out the remaining rounds (its workgroups return at once)
+      auto linearSolve = [&](const mmx::SolveStateDev& who) -> int32_t {
+        MMX_HIP(mmx::launchCholeskyFactorTiled(
+            ds, pb->rig->P, pb->sJtj.as<float>(), pb->sJtr.as<float>(), factorScratch, pb->sDvec.as<float>(), pb->sRefState.as<int32_t>(),
+            pb->sErr.as<double>(), theta_dev, who, sp, s));
+        for (int round = 0; round < sp.refine; ++round) {
+          MMX_HIP(mmx::launchTreeRefine(
+              pb->rigDev, pb->dev, pb->fdev, theta_dev, pb->sTreeState.as<float>(), genState, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(),
+              sp.lambda, sp.lambdaPer, s));
+          MMX_HIP(mmx::launchCholeskyFinishTiled(
+              ds, pb->rig->P, factorScratch, pb->sDvec.as<float>(), pb->sRhoVec.as<float>(), pb->sRefState.as<int32_t>(), pb->sErr.as<double>(),
+              theta_dev, who, sp, round, s));
+        }
+        return MMX_OK;
+      };
+      if (trust) {
+        // TrustRegionQRT::doIteration (trust_region_qr.cpp:52-270) from the host: per pass, the instances whose damping
+        // changed factor and solve, every instance with a step on the table decides (try it, or a Newton update of lambda
+        // first), the ready ones run their trial.  At most ten trust steps of up to four solves each; the loop ends as
+        // soon as no instance is left in the iteration (one 4-byte read-back per pass).
+        MMX_ZONE("TrustRegionQR: trust steps");
+        MMX_HIP(mmx::launchTrustBegin(sp.tr, st, sp.lambdaPer, pb->B, s));
+        mmx::SolveStateDev masked = st;
+        masked.done = sp.tr.mask;
+        for (int pass = 0; pass < 40; ++pass) {
+          rc = linearSolve(masked);
+          if (rc != MMX_OK) {
+            return rc;
+          }
+          MMX_HIP(mmx::launchTrustDecide(ds, factorScratch, pb->sJtr.as<float>(), pb->sErr.as<double>(), st, sp, s));
+          MMX_HIP(hipMemsetAsync(sp.tr.active, 0, sizeof(int32_t), s));
+          MMX_HIP(mmx::launchStepUpdate(pb->rigDev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
+          int32_t active = 0;
+          MMX_HIP(hipMemcpyAsync(&active, sp.tr.active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+          MMX_HIP(hipStreamSynchronize(s));
+          if (active == 0) {
+            break;
+          }
+        }
+        MMX_HIP(mmx::launchTrustEnd(st, sp, pb->sErr.as<double>(), pb->B, s));
+      } else {
+        rc = linearSolve(st);
+        if (rc != MMX_OK) {
+          return rc;
+        }
       }
     } else {
       {
@@ -2024,7 +2075,7 @@ static int32_t solveImpl(
             theta_dev, st, sp, factorScratch, s));
       }
     }
-    if (deferred) {
+    if (deferred && !trust) {
       MMX_ZONE("Line search");
       MMX_HIP(mmx::launchStepUpdate(pb->rigDev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
     }

@@ -2169,6 +2169,12 @@ __device__ __forceinline__ void applyStepAndBook(
       th[pb.enabledList[s2]] -= d0[s2];
     }
   }
+  if (sp.stepRule == MMX_STEP_TRUST_REGION) { // several linear solves per iteration: trustEndKernel books it once
+    if (tid == 0 && badPivot) {
+      st.status[b] = 2;
+    }
+    return;
+  }
   if (tid == 0) { // SolverT::solve bookkeeping (solver.cpp:92-119)
     const double e = errIter[b];
     const double last = st.lastError[b];
@@ -2387,7 +2393,7 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
     return;
   }
   const int n = pb.n;
-  const float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
+  float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
   const int NP = (n + 15) & ~15, NB = NP >> 4;
   TiledLds t;
   tiledLdsFloats(n, 0, &t, smem);
@@ -2397,6 +2403,23 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
   }
   for (int i = tid; i < NP; i += 256) {
     t.g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
+  }
+  if (sp.stepRule == MMX_STEP_TRUST_REGION) {
+    // The trust region starts from (almost) no damping, which the reference's QR of J can take and an fp32 Cholesky of
+    // J^T J cannot when J is rank deficient: the FACTOR is damped by at least 1e-6 of the mean diagonal (as in
+    // fusedSolveKernel), the refinement measures its residual with the true damping through J.
+    float tr = 0.f;
+    const float* Hd = jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+    for (int i = tid; i < n; i += 256) {
+      tr += Hd[size_t(tileIndex(i >> 4, i >> 4)) * 256 + (i & 15) * 17];
+    }
+    tr = waveReduceSumF(tr);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+      t.rho[tid >> 6] = tr;
+    }
+    __syncthreads();
+    lambda = fmaxf(lambda, 1e-6f * ((t.rho[0] + t.rho[1]) + (t.rho[2] + t.rho[3])) / float(n > 0 ? n : 1));
   }
   __syncthreads();
   long long tclk = clock64();
@@ -2516,17 +2539,27 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   selectInstanceRig(rig, b);
   selectInstanceWeights(pb, b);
-  const int mark = sp.stepIter[b];
-  if (mark != sp.iteration + 1 && mark != -(sp.iteration + 1)) {
-    return; // the instance had converged before this iteration
+  if (sp.stepRule == MMX_STEP_TRUST_REGION) { // only the instances whose step is the one to try (phase 2)
+    const int ph = sp.tr.phase[b];
+    if (ph != 2) {
+      if (tid == 0 && ph != 3) {
+        atomicAdd(sp.tr.active, 1);
+      }
+      return;
+    }
+  } else {
+    const int mark = sp.stepIter[b];
+    if (mark != sp.iteration + 1 && mark != -(sp.iteration + 1)) {
+      return; // the instance had converged before this iteration
+    }
+    if (mark < 0) { // H was not positive definite: no step; the schedule raises the damping
+      if (sp.stepRule == MMX_STEP_LM_SCHEDULE && tid == 0) {
+        sp.lambdaPer[b] = fminf((sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda) * sp.lmUp, sp.lmLambdaMax);
+      }
+      return;
+    }
   }
   float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
-  if (mark < 0) { // H was not positive definite: no step; the schedule raises the damping
-    if (sp.stepRule == MMX_STEP_LM_SCHEDULE && tid == 0) {
-      sp.lambdaPer[b] = fminf(lambda * sp.lmUp, sp.lmLambdaMax);
-    }
-    return;
-  }
   const int P = rig.P, n = pb.n;
   float* thL;
   const SideLds sl = carveSideLds(smem, rig.J, &thL);
@@ -2575,6 +2608,57 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
     }
     __syncthreads();
   };
+  if (sp.stepRule == MMX_STEP_TRUST_REGION) {
+    // TrustRegionQRT::doIteration, the trial (trust_region_qr.cpp:240-269; fusedSolveKernel phase K): gain ratio against
+    // the quadratic model e - 2 g.p + p^T (J^T J + 1e-20 I) p, where p^T J^T J p = g.p - mu |p|^2 because
+    // (J^T J + mu I) p = g; radius x 0.25 / x 2 (cap 10); a step with rho <= 0 is rejected.
+    float p0 = 0.f, p1 = 0.f;
+    for (int c = tid; c < n; c += 256) {
+      p0 += dl[c] * dl[c];
+      p1 += dl[c] * jtr[size_t(b) * n + c];
+    }
+    p0 = waveReduceSumF(p0);
+    p1 = waveReduceSumF(p1);
+    __shared__ float redT[8];
+    if (lane == 0) {
+      redT[wave] = p0;
+      redT[4 + wave] = p1;
+    }
+    __syncthreads();
+    const float dn2 = (redT[0] + redT[1]) + (redT[2] + redT[3]), dg = (redT[4] + redT[5]) + (redT[6] + redT[7]);
+    makeTrial(1.f);
+    const double eNew = trialError();
+    const float predicted = dg + (lambda - 1e-20f) * dn2; // e - model (lambdaPer holds mu = 1e-20 + (lambda_TR - 1e-10))
+    const float rho = float((curError - eNew) / double(predicted));
+    float radius = sp.tr.radius[b];
+    if (rho < 0.25f) { // :256-262
+      radius = 0.25f * radius;
+    } else if (rho > 0.75f) {
+      radius = fminf(2.f * radius, 10.f);
+    }
+    if (rho > 0.f) { // :265
+      for (int i = tid; i < P; i += 256) {
+        th[i] = thT[i];
+      }
+    }
+    if (tid == 0) {
+      sp.tr.radius[b] = radius;
+      if (rho > 0.f) {
+        sp.tr.phase[b] = 3;
+      } else {
+        const int tried = sp.tr.step[b] + 1;
+        sp.tr.step[b] = tried;
+        if (tried >= 10) { // :157: every trial rejected, the parameters stay (:268-269)
+          sp.tr.phase[b] = 3;
+        } else { // the same step against the smaller radius: decide again (a Newton update of lambda follows)
+          sp.tr.phase[b] = 1;
+          sp.tr.newton[b] = 0;
+          atomicAdd(sp.tr.active, 1);
+        }
+      }
+    }
+    return;
+  }
   if (sp.stepRule == MMX_STEP_LM_SCHEDULE) {
     float part = 0.f;
     for (int c = tid; c < n; c += 256) {
@@ -2630,6 +2714,140 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
   for (int i = tid; i < P; i += 256) {
     th[i] = thT[i];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TrustRegionQRT on the wide route (momentum/character_solver/trust_region_qr.cpp:52-270): the control flow that
+// fusedSolveKernel runs inside one launch, as per-instance state + small kernels between the linear solves.
+// ---------------------------------------------------------------------------------------------
+__global__ void trustInitKernel(TrustStateDev tr, int B, float radius0) { // initializeSolver (:38-41)
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    tr.radius[b] = radius0;
+  }
+}
+
+// start of an iteration: lambda = 1e-10 ("a tiny lambda just to make sure we don't divide by zero", :86), the first
+// trust step; converged instances sit the iteration out
+__global__ void trustBeginKernel(TrustStateDev tr, SolveStateDev st, float* lambdaPer, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    const bool idle = st.done[b] != 0;
+    tr.lambda[b] = 1e-10f;
+    lambdaPer[b] = 1e-20f; // mu = 1e-20 + (lambda - 1e-10): R is seeded with lambda ON its diagonal (online_householder_qr.cpp:133-140)
+    tr.phase[b] = idle ? 3 : 0;
+    tr.newton[b] = 0;
+    tr.step[b] = 0;
+    tr.mask[b] = idle ? 1 : 0;
+  }
+}
+
+// after a linear solve (or after a rejected trial shrank the radius): is the step on the table the one to try (:164,
+// :180-181), or does lambda take a Newton update first (Nocedal & Wright eq. 4.44, :191-224: p_l = -(step),
+// |q_l|^2 = p_l^T (R^T R)^-1 p_l = |L^-1 p_l|^2 with the factor at hand)?  grid = B, block = 256.
+__global__ void __launch_bounds__(256) trustDecideKernel(
+    ProblemDev pb, const float* __restrict__ factor, const float* __restrict__ jtr, const double* __restrict__ errIter, SolveStateDev st, StepParams sp) {
+  __shared__ __attribute__((aligned(16))) float x[512 + 16];
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ph = sp.tr.phase[b];
+  if (st.done[b] != 0 || (ph != 0 && ph != 1)) {
+    return;
+  }
+  const int n = pb.n, NP = (n + 15) & ~15, NB = NP >> 4;
+  const float* dl = sp.delta + size_t(b) * n;
+  float p0 = 0.f, p1 = 0.f;
+  for (int c = tid; c < NP; c += 256) {
+    const float d = c < n ? dl[c] : 0.f;
+    x[c] = d;
+    p0 += d * d;
+    p1 += c < n ? d * jtr[size_t(b) * n + c] : 0.f;
+  }
+  p0 = waveReduceSumF(p0);
+  p1 = waveReduceSumF(p1);
+  if (lane == 0) {
+    red[wave] = p0;
+    red[4 + wave] = p1;
+  }
+  __syncthreads();
+  const float dn2 = (red[0] + red[1]) + (red[2] + red[3]), dg = (red[4] + red[5]) + (red[6] + red[7]);
+  const int newton = sp.tr.newton[b];
+  int next = 2; // the step is the one to try
+  if (newton == 0 && 2.f * dg < FLT_EPSILON * (1.f + float(errIter[b]))) { // :164 (gradientSub_ = 2 J^T r): not worth a step
+    next = 3;
+  } else if (newton < 3 && sqrtf(dn2) >= 1.05f * sp.tr.radius[b]) { // :180-181
+    const float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+    tiledSweep<true>(L, NB, x, tid); // x = L^-1 p_l
+    __syncthreads();
+    float q = 0.f;
+    for (int c = tid; c < n; c += 256) {
+      q += x[c] * x[c];
+    }
+    q = waveReduceSumF(q);
+    __syncthreads();
+    if (lane == 0) {
+      red[wave] = q;
+    }
+    __syncthreads();
+    const float q2 = (red[0] + red[1]) + (red[2] + red[3]);
+    if (q2 >= FLT_EPSILON) { // :198
+      const float pn = sqrtf(dn2), radius = sp.tr.radius[b];
+      const float deltaLambda = (dn2 / q2) * ((pn - radius) / radius);
+      if (deltaLambda > 0.f) { // :207: lambda only ever grows
+        next = 0; // factor and solve again with the larger damping (the reference appends rows to its QR)
+        if (tid == 0) {
+          const float lam = sp.tr.lambda[b] + deltaLambda;
+          sp.tr.lambda[b] = lam;
+          sp.lambdaPer[b] = 1e-20f + (lam - 1e-10f);
+          sp.tr.newton[b] = newton + 1;
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    sp.tr.phase[b] = next;
+    sp.tr.mask[b] = next == 0 ? 0 : 1;
+  }
+}
+
+// end of an iteration: SolverT::solve's bookkeeping (solver.cpp:92-119), once per instance that took part
+__global__ void trustEndKernel(SolveStateDev st, StepParams sp, const double* __restrict__ errIter, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || st.done[b] != 0) {
+    return;
+  }
+  const double e = errIter[b];
+  const double last = st.lastError[b];
+  if (st.errorHistory != nullptr) {
+    st.errorHistory[size_t(b) * sp.maxIterations + sp.iteration] = e;
+  }
+  st.iterations[b] = sp.iteration + 1;
+  st.finalError[b] = e;
+  const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
+  if (sp.iteration >= sp.minIterations && converged) {
+    st.done[b] = 1;
+  }
+  st.lastError[b] = e;
+}
+
+hipError_t launchTrustInit(const TrustStateDev& tr, int B, float radius0, hipStream_t stream) {
+  hipLaunchKernelGGL(trustInitKernel, dim3((B + 255) / 256), dim3(256), 0, stream, tr, B, radius0);
+  return hipGetLastError();
+}
+hipError_t launchTrustBegin(const TrustStateDev& tr, const SolveStateDev& st, float* lambdaPer, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(trustBeginKernel, dim3((B + 255) / 256), dim3(256), 0, stream, tr, st, lambdaPer, B);
+  return hipGetLastError();
+}
+hipError_t launchTrustDecide(const ProblemDev& pb, const float* factor, const float* jtr, const double* errIter, const SolveStateDev& st, const StepParams& sp, hipStream_t stream) {
+  if (pb.n > 512) {
+    return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(trustDecideKernel, dim3(pb.B), dim3(256), 0, stream, pb, factor, jtr, errIter, st, sp);
+  return hipGetLastError();
+}
+hipError_t launchTrustEnd(const SolveStateDev& st, const StepParams& sp, const double* errIter, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(trustEndKernel, dim3((B + 255) / 256), dim3(256), 0, stream, st, sp, errIter, B);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -51,6 +51,19 @@ struct LdsLimitCache {
   }
 };
 
+// TrustRegionQRT on the wide route (several kernels per trust step, driven from the host): per-instance state.
+// phase: 0 the damping changed (or the trust step begins): factor + solve, 1 a step is on the table and the radius
+// changed: decide again, 2 the step is the one to try, 3 the iteration is over for this instance.
+struct TrustStateDev {
+  float* lambda; // [B] TrustRegionQRT's lambda (starts at 1e-10 every iteration, only grows within it)
+  float* radius; // [B] curTrustRegionRadius_ (lives across iterations)
+  int32_t* phase; // [B]
+  int32_t* newton; // [B] Newton updates of lambda taken in the current trust step (<= 3)
+  int32_t* step; // [B] trust steps tried in the current iteration (<= 10)
+  int32_t* mask; // [B] 1 = the factor kernels skip this instance (phase != 0, or converged)
+  int32_t* active; // [1] instances whose iteration is not over (phase != 3), counted by the trial kernel
+};
+
 struct StepParams {
   float lambda; // regularization added to the diagonal of the compacted system
   float threshold; // SolverOptions::threshold
@@ -62,7 +75,8 @@ struct StepParams {
   // the step in `delta` and stepUpdateKernel applies it (all null / 0: theta -= delta in place)
   float* delta; // [B][n] step of this iteration
   int32_t* stepIter; // [B] iteration + 1 when `delta` holds a step, -(iteration + 1) when H was not positive definite
-  float* lambdaPer; // [B] per-instance damping (LM schedule) or null: `lambda` for everyone
+  float* lambdaPer; // [B] per-instance damping (LM schedule, trust region) or null: `lambda` for everyone
+  TrustStateDev tr; // MMX_STEP_TRUST_REGION on the wide route (all null otherwise)
   int32_t doLineSearch; // GaussNewtonSolverOptions::doLineSearch
   int32_t stepRule; // MMX_STEP_*
   float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
@@ -269,6 +283,12 @@ hipError_t launchStepUpdate(
     hipStream_t stream);
 
 hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream);
+// TrustRegionQRT on the wide route: state of a solve / of an iteration, the decision after a linear solve (is the step
+// within the radius, or does lambda take a Newton update first), the bookkeeping at the end of an iteration
+hipError_t launchTrustInit(const TrustStateDev& tr, int B, float radius0, hipStream_t stream);
+hipError_t launchTrustBegin(const TrustStateDev& tr, const SolveStateDev& st, float* lambdaPer, int B, hipStream_t stream);
+hipError_t launchTrustDecide(const ProblemDev& pb, const float* factor, const float* jtr, const double* errIter, const SolveStateDev& st, const StepParams& sp, hipStream_t stream);
+hipError_t launchTrustEnd(const SolveStateDev& st, const StepParams& sp, const double* errIter, int B, hipStream_t stream);
 // zeroes the rows of paramHistory [B][maxIterations][P] from iterations[b] on (the reference leaves them at setZero())
 hipError_t launchParamHistoryFinalize(float* paramHistory, const int32_t* iterations, int B, int maxIterations, int P, hipStream_t stream);
 hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream);
