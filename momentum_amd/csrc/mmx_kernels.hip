@@ -2975,7 +2975,17 @@ hipError_t launchFkJacobian(
     hipStream_t stream,
     hipEvent_t startEvent,
     hipEvent_t stopEvent) {
-  const size_t lds = fkJacobianLdsBytes(rig.J, rig.P, pb.U);
+  size_t lds = fkJacobianLdsBytes(rig.J, rig.P, pb.U);
+#if defined(MMX_EXP_JACOCC4) || defined(MMX_EXP_JACOCC3) // A/B build variants: resident workgroups per CU forced through the LDS request
+#ifdef MMX_EXP_JACOCC4
+  constexpr size_t kOcc = 4;
+#else
+  constexpr size_t kOcc = 3;
+#endif
+  if (jac != nullptr && lds < (160 * 1024 / kOcc) - 1024) {
+    lds = (160 * 1024 / kOcc) - 1024;
+  }
+#endif
   // Wavefronts per instance.  J-assembly: four waves share one instance (FK over 256 threads, the
   // column program dealt to the waves) up to 40 000 instances per launch -- fewer instances are then
   // in flight at a time (5 workgroups per CU instead of 20), and write bandwidth on this part
