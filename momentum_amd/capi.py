@@ -171,6 +171,8 @@ class RigHandle:
 
 # Route every Problem created from here on starts with ("auto" | "fused" | "wide" | "explicit_jacobian"): the parity tests
 # set it (monkeypatch.setattr) to send whole test bodies through one route; Problem.set_route changes it per handle.
+# "prefer_wide" (sweeps: MMX_TEST_ROUTE=prefer_wide, tests/conftest.py): every solve tries the wide route first and falls
+# back to the library's own choice where the problem is outside the tree kernels' scope.
 default_route = "auto"
 
 
@@ -200,7 +202,8 @@ class Problem:
                 as_ptr(self.ori_parent, C.c_int32), C.byref(self._h),
             )
         )  # fmt: skip
-        if default_route != "auto":
+        self._prefer_wide = default_route == "prefer_wide"
+        if default_route not in ("auto", "prefer_wide"):
             self.set_route(default_route)
 
     def close(self) -> None:
@@ -437,6 +440,21 @@ class Problem:
         import torch
 
         theta = self._theta(theta)
+        if getattr(self, "_prefer_wide", False):  # sweeps (MMX_TEST_ROUTE=prefer_wide): the wide route wherever it applies
+            self._prefer_wide = False
+            keep = theta.clone()
+            try:
+                self.set_route("wide")
+                return self.solve(theta, options, want_history, outputs, want_parameter_history)
+            except MmxError as e:
+                if e.code != 4:  # MMX_ERR_UNSUPPORTED: outside the tree kernels' scope -> the library's own choice
+                    raise
+                theta.copy_(keep)
+                self.set_route("auto")
+            finally:
+                self._prefer_wide = True
+                if self.last_route() == "wide":
+                    self.set_route("auto")
         if outputs is None:
             outputs = dict(
                 error=torch.empty((self.B,), dtype=torch.float64, device=self.device),

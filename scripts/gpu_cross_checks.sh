@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-off cross-checks beyond the suite (run on the GPU box): large seed sweeps of the randomised tests, also with every
-# solve forced through the wide path, and the whole GPU suite under MMX_FORCE_WIDE=1 (expected there: only the two
-# tests that compare the fused route with the explicit one fail, because both runs take the wide path).
+# solve sent through the wide route where it applies (MMX_TEST_ROUTE=prefer_wide, tests/conftest.py), and the whole GPU suite
+# that way (expected there: only tests that pin or compare routes themselves can differ).
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -15,6 +15,6 @@ run() { # tag, env..., -- pytest args
 }
 run fuzz_small MMX_FUZZ_SEEDS=300 -- tests/test_gpu_fuzz.py -k "not wide"
 run fuzz_mid MMX_FUZZ_SEEDS=300 MMX_FUZZ_JMAX=110 -- tests/test_gpu_fuzz.py -k "not wide"
-run fuzz_mid_forced_wide MMX_FORCE_WIDE=1 MMX_FUZZ_SEEDS=300 MMX_FUZZ_JMAX=110 -- tests/test_gpu_fuzz.py -k "not wide"
+run fuzz_mid_forced_wide MMX_TEST_ROUTE=prefer_wide MMX_FUZZ_SEEDS=300 MMX_FUZZ_JMAX=110 -- tests/test_gpu_fuzz.py -k "not wide"
 run fuzz_wide MMX_FUZZ_WIDE_SEEDS=128 MMX_FUZZ_WIDE_JMAX=195 -- tests/test_gpu_fuzz.py -k "wide"
-run suite_forced_wide MMX_FORCE_WIDE=1 -- tests -m gpu
+run suite_forced_wide MMX_TEST_ROUTE=prefer_wide -- tests -m gpu

@@ -43,6 +43,7 @@ for tag,pat in (("pmc_bench","pmc2"),("pmc_cfg5","pmc5")):
             fo.write(k+"\n")
             for c,vals in sorted(v.items()): fo.write("   %-28s n=%-3d avg=%.4g\n" % (c,len(vals),sum(vals)/len(vals)))
 PY
+timeout 60 python $GRAFT_REPO_ROOT/scripts/pmc_json.py $out $r < /dev/null
 # two-line derivation of the roofline fractions from the kernel traces alone: algorithmic bytes per instance (bench.py's
 # algorithmic_bytes_per_instance: write J and r, read theta / constraint payload / parents) x instances per launch
 # / average duration of the J-assembly kernel at that grid / 8 TB/s

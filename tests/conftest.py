@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # sweeps (scripts/gpu_cross_checks.sh): MMX_TEST_ROUTE=prefer_wide | fused | wide | explicit_jacobian sends every problem the
+    # tests create through that route (a test-side variable: the library itself reads no environment on the solve path)
+    route = os.environ.get("MMX_TEST_ROUTE")
+    if route:
+        from momentum_amd import capi
+
+        capi.default_route = route
 
 
 @pytest.fixture(scope="session")
