@@ -384,7 +384,7 @@ int32_t mmx_problem_set_instance_parents(
  * A pinned route the problem does not fit makes mmx_solve return MMX_ERR_UNSUPPORTED; it never falls through silently.
  *   MMX_ROUTE_FUSED              one launch, one workgroup per instance, the system in LDS (<= 224 solved parameters)
  *   MMX_ROUTE_WIDE               normal equations from the tree moments, left-looking Cholesky with the factor in HBM,
- *                                refinement through the tree (<= 512 solved parameters; the default from 177 on)
+ *                                refinement through the tree (<= 512 solved parameters; the default from 161 on)
  *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores) -> Cholesky step; the route for problems
  *                                outside the tree kernels' scope
  * The route does not change WHAT is computed (same algorithm, same refinement); results of different routes agree to
