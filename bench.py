@@ -324,6 +324,17 @@ def solved_parameters(pb) -> int:
     return int(n.value)
 
 
+def factor_structure(pb):
+    """Route of the last solve and, on the wide route, the tile structure its factor ran with (mmx_problem_tile_structure)."""
+    route = pb.last_route()
+    out = {"route": route, "solved_parameters": solved_parameters(pb)}
+    if route == "wide":
+        ts = pb.tile_structure()
+        out["factor_tiles"] = f"{ts['tiles']} of {ts['dense_tiles']} 16x16 tiles structurally non-zero (columns in elimination order)"
+        out["factor_tile_products"] = f"{ts['products']} of {ts['dense_products']}"
+    return out
+
+
 def fused_pmc():
     """PMC figures of the headline kernel from the committed profile (profiles/pmc_fused.json), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_fused.json")
@@ -353,6 +364,7 @@ def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iter
         "steps": steps,
         "failed_instances": norms[2],
         "check": parity_check(db, theta, opt, check_n),
+        "solver": factor_structure(db.pb),
     }
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(db, cpu_sample, opt)
@@ -520,6 +532,7 @@ def main() -> None:
                 "params": P,
                 "rows": M,
                 "solved_parameters": n_solved,
+                "solver": factor_structure(pb),
                 "gn_iterations": args.iterations,
                 "line_search": args.line_search,
                 "regularization": 0.05,

@@ -36,10 +36,12 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 7 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
+#define MMX_ABI_VERSION 8 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
                              trust_region_radius), mmx_comm_* (RCCL), MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J
                              7: mmx_tuning / mmx_problem_set_tuning / mmx_problem_last_route (replace the MMX_* environment
-                             switches of earlier builds: the library reads no environment variable on the solve path) */
+                             switches of earlier builds: the library reads no environment variable on the solve path)
+                             8: columns in elimination order + tile-sparse factor on the wide route
+                                (mmx_host_elimination_order, mmx_host_tile_structure, mmx_problem_tile_structure) */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
@@ -577,8 +579,10 @@ int32_t mmx_debug_fused_normal_equations(
 
 /*
  * Parity hook of the wide route's first stage: H = J^T J (LOWER triangle of the n x n system written, the rest zero)
- * and g = J^T r from the tree moments (treeNormalEquationsKernel), in the layout of mmx_eval_normal_equations, so that
- * the two can be compared entry by entry.  Problems without structurally zero columns, inside the tree kernels' scope;
+ * and g = J^T r from the tree moments (treeNormalEquationsKernel), in the layout of mmx_eval_normal_equations but with
+ * the columns in the solvers' ELIMINATION order (the solve list mmx_debug_fused_normal_equations reports: the enabled
+ * parameters, every subtree's ahead of those of the joints above it), so that the two can be compared entry by entry
+ * after that permutation.  Problems without structurally zero columns, inside the tree kernels' scope;
  * MMX_ERR_UNSUPPORTED otherwise.
  */
 int32_t mmx_debug_tree_normal_equations(mmx_problem* problem, const float* theta_dev, float* jtj_dev, float* jtr_dev, void* stream);
@@ -654,6 +658,25 @@ int32_t mmx_host_tables(
     uint8_t* active_joint_params,
     int32_t* enabled_list,
     int32_t* num_enabled);
+
+/*
+ * The solvers' column order and the tile structure of their factor (host-side integer bookkeeping, no GPU needed).
+ * The reference factors a dense J (QR); the step it computes does not depend on a column order, so the solvers here
+ * number the columns of (J^T J + lambda I) in an ELIMINATION order: the enabled parameters sorted by the post-order
+ * position (children before their parent, smaller subtrees first) of the last joint each drives.  Two columns of J
+ * overlap only when a joint of the one is an ancestor-or-self of a joint of the other, so in that order the Cholesky
+ * factor has no fill outside that pattern, and the blocked solvers of the wide route skip its all-zero 16 x 16 tiles.
+ *   mmx_host_elimination_order: order[P] receives the enabled parameters in that order, *num_enabled their count.
+ *   mmx_host_tile_structure: symbolic factorisation on the tile grid for an n x n pattern (related[n*n], row-major,
+ *     entry (row, col), row > col, non-zero = H(row, col) can be non-zero; n <= 512): row_mask[32] (bit J of word I:
+ *     tile (I, J <= I) of the factor is structurally non-zero), col_mask[32] (bit I of word k: tile (I >= k, k) is),
+ *     *products = tile products L(I,j) L(k,j)^T the masked factorisation performs.
+ *   mmx_problem_tile_structure: the masks the problem's wide route runs with (all ones when it keeps the dense
+ *     structure: further joint error functions / ellipsoid limits present, or outside the tree kernels' scope).
+ */
+int32_t mmx_host_elimination_order(const mmx_rig_desc* desc, const uint8_t* enabled, int32_t* order, int32_t* num_enabled);
+int32_t mmx_host_tile_structure(int32_t n, const uint8_t* related, uint32_t* row_mask, uint32_t* col_mask, int64_t* products);
+int32_t mmx_problem_tile_structure(mmx_problem* problem, uint32_t* row_mask, uint32_t* col_mask, int32_t* num_blocks, int32_t* num_tiles, int64_t* products);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -14,7 +14,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-MMX_ABI_VERSION = 7
+MMX_ABI_VERSION = 8
 MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1

@@ -30,6 +30,7 @@ SYMBOLS = [
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations", "mmx_debug_tree_normal_equations",
+    "mmx_host_elimination_order", "mmx_host_tile_structure", "mmx_problem_tile_structure",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
     "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
 ]  # fmt: skip
@@ -102,6 +103,10 @@ def lib() -> C.CDLL:
         C.POINTER(RigDesc), _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p,
         _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p,
     ]  # fmt: skip
+    u32p, i64p = C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
+    L.mmx_host_elimination_order.argtypes = [C.POINTER(RigDesc), _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p]
+    L.mmx_host_tile_structure.argtypes = [i32, _abi.c_uint8_p, u32p, u32p, i64p]
+    L.mmx_problem_tile_structure.argtypes = [vp, u32p, u32p, _abi.c_int32_p, _abi.c_int32_p, i64p]
     _lib = L
     return L
 
@@ -134,7 +139,22 @@ def host_tables(rig: Rig, enabled=None) -> dict:
             as_ptr(active, C.c_uint8), as_ptr(elist, C.c_int32), C.byref(n),
         )
     )  # fmt: skip
-    return dict(level=level, tin=tin, tout=tout, active_joint_params=active, enabled_list=elist[: n.value].copy())
+    order = np.zeros(P, np.int32)
+    _check(lib().mmx_host_elimination_order(C.byref(d), eptr, as_ptr(order, C.c_int32), C.byref(n)))
+    return dict(level=level, tin=tin, tout=tout, active_joint_params=active, enabled_list=elist[: n.value].copy(),
+                elimination_order=order[: n.value].copy())  # fmt: skip
+
+
+def host_tile_structure(related: np.ndarray):
+    """Symbolic factorisation on the 16 x 16 tile grid (mmx_host_tile_structure): related [n, n] (lower triangle used)
+    -> dict(row_mask [32], col_mask [32], products)."""
+    rel = np.ascontiguousarray(related, dtype=np.uint8)
+    n = rel.shape[0]
+    assert rel.shape == (n, n)
+    row, col = np.zeros(32, np.uint32), np.zeros(32, np.uint32)
+    prod = C.c_int64(0)
+    _check(lib().mmx_host_tile_structure(C.c_int32(n), as_ptr(rel, C.c_uint8), as_ptr(row, C.c_uint32), as_ptr(col, C.c_uint32), C.byref(prod)))
+    return dict(row_mask=row, col_mask=col, products=prod.value)
 
 
 def _stream_ptr() -> C.c_void_p:
@@ -401,7 +421,25 @@ class Problem:
         jtj = torch.empty((self.B, self.n, self.n), dtype=torch.float32, device=self.device)
         jtr = torch.empty((self.B, self.n), dtype=torch.float32, device=self.device)
         _check(lib().mmx_debug_tree_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), _stream_ptr()))
-        return jtj, jtr
+        # the kernels number the columns in elimination order (mmx_host_tables.hpp); hand back the enabled-list order of
+        # mmx_eval_normal_equations
+        lst = np.zeros(self.P, np.int32)
+        n = C.c_int32(0)
+        _check(lib().mmx_debug_fused_normal_equations(self._h, None, None, None, as_ptr(lst, C.c_int32), C.byref(n), None))
+        assert n.value == self.n
+        order = torch.from_numpy(np.argsort(lst[: self.n], kind="stable")).to(self.device)
+        full = jtj + jtj.transpose(1, 2) - torch.diag_embed(torch.diagonal(jtj, dim1=1, dim2=2))
+        return torch.tril(full[:, order][:, :, order]).contiguous(), jtr[:, order].contiguous()
+
+    def tile_structure(self):
+        """The tile structure the wide route factors with (mmx_problem_tile_structure): dict(row_mask, col_mask, blocks,
+        tiles, products, dense_tiles, dense_products)."""
+        row, col = np.zeros(32, np.uint32), np.zeros(32, np.uint32)
+        nb, nt, prod = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        _check(lib().mmx_problem_tile_structure(self._h, as_ptr(row, C.c_uint32), as_ptr(col, C.c_uint32), C.byref(nb), C.byref(nt), C.byref(prod)))
+        NB = nb.value
+        return dict(row_mask=row, col_mask=col, blocks=NB, tiles=nt.value, products=prod.value, dense_tiles=NB * (NB + 1) // 2,
+                    dense_products=NB * (NB * NB - 1) // 6)  # fmt: skip
 
     def fused_normal_equations(self, theta):
         """Parity hook: (solve_list [n], JtJ [B,n,n], Jtr [B,n]) as the fused kernel builds them."""

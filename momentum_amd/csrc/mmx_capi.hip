@@ -208,6 +208,10 @@ struct mmx_problem {
   // the same problem with the structurally zero columns dropped from the solve (explicit-Jacobian solver)
   int32_t solveN = 0;
   DevBuf dSolveListV1; // [solveN]
+  DevBuf dSolveListF64; // [solveN] the same parameters in index order: the double instantiation follows the reference's column order
+  std::vector<std::pair<int32_t, int32_t>> limitPairs; // (row, col) solve columns of the off-diagonal H entries limits add
+  DevBuf dTileMasks, dTileList; // tile structure of the factor in elimination order (mmx::TileMasks): [64] masks, the non-zero tiles
+  mmx::TileMasks tileMasks;
   std::vector<int32_t> solveListV1; // host copy
   // scratch
   DevBuf sJac, sRes, sErr, sJtj, sJtr, sFactor, sThetaInit, sTheta;
@@ -626,6 +630,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       fd.termRounds = int32_t(rounds);
     }
     // limits per solve column, and the limits that share an off-diagonal entry of H
+    pb->limitPairs.clear();
     {
       std::vector<int32_t> colOf(size_t(rig->P), -1);
       for (int32_t c = 0; c < fd.n; ++c) {
@@ -664,6 +669,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         pairDest.push_back(kv.first);
         pairCols.push_back(pairColumns[kv.first].first);
         pairCols.push_back(pairColumns[kv.first].second);
+        pb->limitPairs.push_back(pairColumns[kv.first]);
         pairLim.insert(pairLim.end(), kv.second.begin(), kv.second.end());
         pairStart.push_back(int32_t(pairLim.size()));
       }
@@ -732,7 +738,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       }
     }
     std::vector<int32_t> list;
-    for (int32_t p : t.enabledList) {
+    for (int32_t p : t.eliminationList) {
       bool nz = keep[size_t(p)] != 0;
       for (int32_t e = t.colStart[size_t(p)]; !nz && e < t.colStart[size_t(p) + 1]; ++e) {
         const mmx::ColumnSource& cs = t.colSources[size_t(e)];
@@ -743,11 +749,67 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       }
     }
     if (list.empty()) {
-      list = t.enabledList; // nothing to solve for: keep the plain system (all steps are zero)
+      list = t.eliminationList; // nothing to solve for: keep the plain system (all steps are zero)
     }
     MMX_HIP(upload(pb->dSolveListV1, list));
     pb->solveN = int32_t(list.size());
     pb->solveListV1 = list;
+    std::sort(list.begin(), list.end());
+    MMX_HIP(upload(pb->dSolveListF64, list));
+  }
+  // Tile structure of the wide solve's factor (HostTables::eliminationList): entry (row, col) of H can be non-zero when
+  // a source joint of the one column is an ancestor-or-self of a source joint of the other (their columns of J overlap
+  // only then) or when a limit couples the two parameters.  The further joint error functions / ellipsoid limits (rows
+  // over two joint chains) and systems the tree kernels do not take keep the dense structure.
+  {
+    const mmx::FusedTables& f = pb->fused;
+    const int32_t n = int32_t(f.solveList.size());
+#ifdef MMX_EXP_DENSE
+    const bool dense = true;
+#else
+    const bool dense = f.solveList != pb->solveListV1 || n > 512 || pb->fdev.GT > 0 || n == 0;
+#endif
+    std::vector<uint8_t> related;
+    if (!dense) {
+      const size_t J = size_t(rig->J);
+      std::vector<uint8_t> reach(size_t(n) * J, 0); // joints in an ancestor relation with some source joint of column c
+      for (int32_t c = 0; c < n; ++c) {
+        uint8_t* rc = reach.data() + size_t(c) * J;
+        for (int32_t e = f.srcStart[size_t(c)]; e < f.srcStart[size_t(c) + 1]; ++e) {
+          const mmx::ColumnSource& cs = f.srcs[size_t(e)];
+          for (int32_t k = cs.tin; k < cs.tout; ++k) {
+            rc[size_t(f.dfsJoint[size_t(k)])] = 1;
+          }
+          for (int32_t a = cs.parent; a >= 0; a = rig->parent[size_t(a)]) {
+            rc[size_t(a)] = 1;
+          }
+        }
+      }
+      related.assign(size_t(n) * size_t(n), 0);
+      for (int32_t row = 0; row < n; ++row) {
+        for (int32_t col = 0; col < row; ++col) {
+          const uint8_t* rc = reach.data() + size_t(col) * J;
+          bool any = false;
+          for (int32_t e = f.srcStart[size_t(row)]; !any && e < f.srcStart[size_t(row) + 1]; ++e) {
+            any = rc[size_t(f.srcs[size_t(e)].joint)] != 0;
+          }
+          related[size_t(row) * size_t(n) + size_t(col)] = any ? 1 : 0;
+        }
+      }
+      for (const auto& rcPair : pb->limitPairs) {
+        related[size_t(rcPair.first) * size_t(n) + size_t(rcPair.second)] = 1;
+      }
+    }
+    pb->tileMasks = mmx::eliminationTileMasks(std::min(n, 512), related, dense);
+    std::vector<uint32_t> masks(64, 0u);
+    for (int i = 0; i < 32; ++i) {
+      masks[size_t(i)] = pb->tileMasks.rowMask[i];
+      masks[size_t(32 + i)] = pb->tileMasks.colMask[i];
+    }
+    MMX_HIP(upload(pb->dTileMasks, masks));
+    MMX_HIP(upload(pb->dTileList, pb->tileMasks.tiles));
+    pb->fdev.tileList = pb->dTileList.as<int32_t>();
+    pb->fdev.numTiles = int32_t(pb->tileMasks.tiles.size());
   }
 
   return MMX_OK;
@@ -875,6 +937,67 @@ int32_t mmx_host_tables(
   }
   if (num_enabled) {
     *num_enabled = int32_t(t.enabledList.size());
+  }
+  return MMX_OK;
+}
+
+int32_t mmx_host_elimination_order(const mmx_rig_desc* desc, const uint8_t* enabled, int32_t* order, int32_t* num_enabled) {
+  mmx::HostTables t;
+  std::string err;
+  const int32_t rc = mmx::buildHostTables(desc, enabled, t, err);
+  if (rc != MMX_OK) {
+    return fail(rc, err);
+  }
+  if (order) {
+    std::memcpy(order, t.eliminationList.data(), sizeof(int32_t) * t.eliminationList.size());
+  }
+  if (num_enabled) {
+    *num_enabled = int32_t(t.eliminationList.size());
+  }
+  return MMX_OK;
+}
+
+int32_t mmx_host_tile_structure(int32_t n, const uint8_t* related, uint32_t* row_mask, uint32_t* col_mask, int64_t* products) {
+  if (n < 0 || n > 512 || (n > 0 && related == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_host_tile_structure: n outside 0..512 or related is null");
+  }
+  const std::vector<uint8_t> rel(related, related + size_t(n) * size_t(n));
+  const mmx::TileMasks m = mmx::eliminationTileMasks(n, rel, false);
+  for (int i = 0; i < 32; ++i) {
+    if (row_mask) {
+      row_mask[i] = m.rowMask[i];
+    }
+    if (col_mask) {
+      col_mask[i] = m.colMask[i];
+    }
+  }
+  if (products) {
+    *products = m.products;
+  }
+  return MMX_OK;
+}
+
+int32_t mmx_problem_tile_structure(mmx_problem* pb, uint32_t* row_mask, uint32_t* col_mask, int32_t* num_blocks, int32_t* num_tiles, int64_t* products) {
+  if (pb == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "problem is null");
+  }
+  const mmx::TileMasks& m = pb->tileMasks;
+  for (int i = 0; i < 32; ++i) {
+    if (row_mask) {
+      row_mask[i] = m.rowMask[i];
+    }
+    if (col_mask) {
+      col_mask[i] = m.colMask[i];
+    }
+  }
+  if (num_blocks) {
+    *num_blocks = m.NB;
+  }
+  if (num_tiles) {
+    *num_tiles = int32_t(m.tiles.size());
+  }
+  if (products) {
+    *products = m.products;
   }
   return MMX_OK;
 }
@@ -1957,6 +2080,7 @@ static int32_t solveImpl(
   sp.minIterations = o->min_iterations;
   sp.maxIterations = o->max_iterations;
   sp.refine = refineSteps(pb);
+  sp.tileMasks = pb->dTileMasks.as<uint32_t>();
   sp.delta = deferred ? pb->sDelta.as<float>() : nullptr;
   sp.stepIter = deferred ? pb->sStepIter.as<int32_t>() : nullptr;
   sp.lambdaPer = schedule ? pb->sLambda.as<float>() : nullptr;
@@ -2172,7 +2296,7 @@ int32_t mmx_solve_f64(
   fp.lmUp = o->lm_up;
   fp.lmDown = o->lm_down;
   MMX_HIP(mmx::launchSolveF64(
-      pb->rigDev, pb->dev, pb->dSolveListV1.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), s));
+      pb->rigDev, pb->dev, pb->dSolveListF64.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), s));
   return MMX_OK;
 }
 

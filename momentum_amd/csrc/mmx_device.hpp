@@ -41,6 +41,16 @@ constexpr float kPivotFloor = 0.f;
 #else
 constexpr float kPivotFloor = 3.814697265625e-6f; // 2^-18
 #endif
+// Damping floor of every single-precision FACTOR in this library: what is factored is J^T J + max(lambda, kFactorDamping *
+// mean diag(J^T J)) I.  1e-5 ~ n eps: the level at which the pivots of an fp32 Cholesky of a rank-deficient J^T J are
+// rounding noise -- above it the factorisation completes whatever the column order (with the columns in elimination
+// order, mmx_host_tables.hpp, the column-drop rule above would otherwise remove the ROOT's columns instead of the
+// leaves': a basic step of far worse quality), below it nothing changes bit for bit (lambda = 0.05 on every BASELINE
+// configuration: 1e-2 ... 1e-3 of the mean diagonal).  The STEP is still the one for the caller's lambda wherever J
+// determines it: the refinement measures its residual with the true lambda through J and moves the step there; in the
+// directions J does not determine the step is the more damped one (the reference's QR returns the minimum-norm-like
+// step there, the objective decreases the same).  The trust-region solver used the same device from the start.
+constexpr float kFactorDamping = 1e-5f;
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {

@@ -1345,19 +1345,19 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       }
       __syncthreads();
     }
-    // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block.  The trust
-    // region starts from (almost) no damping, which the reference's QR of J can take and an fp32 Cholesky
-    // of J^T J cannot when J is rank deficient: the FACTOR is damped by at least 1e-6 of the mean diagonal,
-    // the refinement (which measures its residual with the true mu through J) moves the step towards the
-    // undamped one wherever J determines it.
+    // diagonal: + lambda (gauss_newton_solver.cpp:248); padded rows/cols form an identity block.  The FACTOR is damped
+    // by at least kFactorDamping of the mean diagonal (mmx_device.hpp): weak damping -- the trust region starts from
+    // (almost) none -- is something the reference's QR of J can take and an fp32 Cholesky of J^T J cannot when J is rank
+    // deficient; the refinement (which measures its residual with the true mu through J) moves the step towards the
+    // weakly damped one wherever J determines it.
     float muFactor = mu;
-    if (kTR) {
+    {
       float tr = 0.f;
       for (int c = tid; c < n; c += 256) {
         tr += s.L[256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15)];
       }
       tr = blockSumF(s, tr, tid);
-      muFactor = fmaxf(mu, 1e-6f * tr / float(n > 0 ? n : 1));
+      muFactor = fmaxf(mu, kFactorDamping * tr / float(n > 0 ? n : 1));
     }
     for (int c = tid; c < NP; c += 256) {
       float* dg = s.L + 256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15);
@@ -2369,22 +2369,27 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
       }
       return o;
     };
-    // the wave's tiles tt = wave, wave + 4, ... in (I, Jc) form, advanced without a square root
-    int I = 0, Jc = wave;
-    auto normalise = [&]() {
-      while (Jc > I) {
-        Jc -= I + 1;
-        ++I;
+    // the wave's tiles: entries wave, wave + kWaves, ... of the list of structurally non-zero tiles (tile-major hand-over:
+    // the tiled factor reads exactly those, mmx::TileMasks) or of all T tiles (row-major: every entry is written)
+    const int numT = tileMajor ? fd.numTiles : T;
+    auto tileAt = [&](int ti, int& I, int& Jc) { // (wave-uniform)
+      if (tileMajor) {
+        const int code = fd.tileList[ti < numT ? ti : 0];
+        I = code & 0xff, Jc = code >> 8;
+      } else {
+        tileDecode(ti < numT ? ti : 0, I, Jc);
       }
     };
-    normalise();
-    TileOps cur = loadOps(I < NB ? I : 0, I < NB ? Jc : 0);
-    for (int tt = wave; tt < T; tt += kWaves) {
-      const int tI = I, tJ = Jc;
-      Jc += kWaves;
-      normalise();
-      const bool more = tt + kWaves < T; // wave-uniform
-      const TileOps nxt = loadOps(more ? I : tI, more ? Jc : tJ); // the next tile's LDS reads fly while this one multiplies
+    int I, Jc;
+    tileAt(wave, I, Jc);
+    TileOps cur = loadOps(I, Jc);
+    for (int ti = wave; ti < numT; ti += kWaves) {
+      const int tI = I, tJ = Jc, tt = tileIndex(tI, tJ);
+      const bool more = ti + kWaves < numT; // wave-uniform
+      if (more) {
+        tileAt(ti + kWaves, I, Jc);
+      }
+      const TileOps nxt = loadOps(I, Jc); // the next tile's LDS reads fly while this one multiplies
       v4f Pm{0.f, 0.f, 0.f, 0.f}, Qm{0.f, 0.f, 0.f, 0.f};
       Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dI0, cur.aJ0, Pm, 0, 0, 0);
       Qm = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aI0, cur.dJ0, Qm, 0, 0, 0);

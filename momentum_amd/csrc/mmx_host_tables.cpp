@@ -129,6 +129,43 @@ int32_t buildHostTables(const mmx_rig_desc* d, const uint8_t* enabled, HostTable
       t.enabledList.push_back(p);
     }
   }
+  // ---- elimination order: joints in post-order (children before their parent, smaller subtrees first, ties by index);
+  // a parameter sits where the LAST of the joints it drives does (a shared parameter joins the highest of its joints)
+  {
+    std::vector<std::vector<int32_t>> children(J);
+    std::vector<int32_t> roots;
+    for (int32_t j = 0; j < J; ++j) {
+      (d->parent[j] >= 0 ? children[d->parent[j]] : roots).push_back(j);
+    }
+    auto bySize = [&](int32_t a, int32_t b) { return size[a] != size[b] ? size[a] < size[b] : a < b; };
+    std::stable_sort(roots.begin(), roots.end(), bySize);
+    for (auto& c : children) {
+      std::stable_sort(c.begin(), c.end(), bySize);
+    }
+    std::vector<int32_t> postPos(J, 0), stack, cursor(J, 0);
+    int32_t next = 0;
+    for (int32_t r : roots) {
+      stack.push_back(r);
+      while (!stack.empty()) {
+        const int32_t j = stack.back();
+        if (cursor[j] < int32_t(children[j].size())) {
+          stack.push_back(children[j][cursor[j]++]);
+        } else {
+          postPos[j] = next++;
+          stack.pop_back();
+        }
+      }
+    }
+    std::vector<int32_t> key(P, J); // parameters that drive no joint: last, by index
+    for (int32_t r = 0; r < R; ++r) {
+      for (int32_t k = d->pt_outer[r]; k < d->pt_outer[r + 1]; ++k) {
+        const int32_t p = d->pt_inner[k], pos = postPos[r / MMX_PARAMS_PER_JOINT];
+        key[p] = key[p] == J ? pos : std::max(key[p], pos);
+      }
+    }
+    t.eliminationList = t.enabledList;
+    std::stable_sort(t.eliminationList.begin(), t.eliminationList.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  }
   // ParameterTransformT::computeActiveJointParams (parameter_transform.cpp:97-107)
   t.activeJointParams.assign(R, 0);
   for (int32_t r = 0; r < R; ++r) {
@@ -294,10 +331,7 @@ int32_t buildFusedTables(
   f.srcStart.assign(1, 0);
   f.srcs.clear();
   f.structNonZero.assign(size_t(P), 0);
-  for (int32_t p = 0; p < P; ++p) {
-    if (!t.enabled[p]) {
-      continue;
-    }
+  for (int32_t p : t.eliminationList) {
     bool nz = false;
     for (int32_t e = t.colStart[p]; e < t.colStart[p + 1]; ++e) {
       const ColumnSource& s = t.colSources[e];
@@ -325,6 +359,50 @@ int32_t buildFusedTables(
   }
   (void)err;
   return MMX_OK;
+}
+
+TileMasks eliminationTileMasks(int32_t n, const std::vector<uint8_t>& related, bool dense) {
+  TileMasks m;
+  const int32_t NB = (n + 15) / 16;
+  m.NB = NB;
+  if (NB > 32) {
+    return m;
+  }
+  for (int32_t I = 0; I < NB; ++I) {
+    m.rowMask[I] = dense ? (I == 31 ? 0xffffffffu : ((1u << (I + 1)) - 1u)) : (1u << I);
+  }
+  if (!dense) {
+    for (int32_t row = 0; row < n; ++row) {
+      for (int32_t col = 0; col < row; ++col) {
+        if (related[size_t(row) * size_t(n) + size_t(col)]) {
+          m.rowMask[row >> 4] |= 1u << (col >> 4);
+        }
+      }
+    }
+    for (int32_t k = 0; k < NB; ++k) { // fill: the rows that hold a tile in column k become mutually coupled
+      for (int32_t a = k + 1; a < NB; ++a) {
+        if (!(m.rowMask[a] >> k & 1u)) {
+          continue;
+        }
+        for (int32_t bb = k + 1; bb <= a; ++bb) {
+          if (m.rowMask[bb] >> k & 1u) {
+            m.rowMask[a] |= 1u << bb;
+          }
+        }
+      }
+    }
+  }
+  for (int32_t I = 0; I < NB; ++I) {
+    for (int32_t k = 0; k <= I; ++k) {
+      if (m.rowMask[I] >> k & 1u) {
+        m.colMask[k] |= 1u << I;
+        m.tiles.push_back(I | (k << 8));
+        const uint32_t below = k == 0 ? 0u : ((1u << k) - 1u);
+        m.products += __builtin_popcount(m.rowMask[I] & m.rowMask[k] & below);
+      }
+    }
+  }
+  return m;
 }
 
 } // namespace mmx

@@ -51,6 +51,13 @@ struct HostTables {
   std::vector<uint8_t> activeJointParams; // [7J]
   std::vector<int32_t> enabledList; // [n] ascending
   std::vector<int32_t> fullToSubset; // [P] index into enabledList or -1
+  // the enabled parameters in ELIMINATION order (a permutation of enabledList): the order in which the solvers number
+  // the columns of their normal equations.  Two columns of J overlap only when a joint of the one is an ancestor of a
+  // joint of the other, so with every subtree's parameters ahead of those of the joints above it (a post-order of the
+  // skeleton, small subtrees first) the Cholesky factor of J^T J fills in next to nothing outside that ancestor pattern
+  // -- the blocked solvers skip the 16 x 16 tiles that stay zero (eliminationTileMasks).  The reference's dense QR has
+  // no such order; the step it computes does not depend on one.
+  std::vector<int32_t> eliminationList;
   std::vector<int32_t> colStart; // [P+1] offsets into colSources (disabled columns are empty)
   std::vector<ColumnSource> colSources;
   int32_t maxColSources = 0;
@@ -75,7 +82,7 @@ struct FusedTables {
   std::vector<int32_t> posUnitStart; // [J+1] CSR over DFS positions -> units attached to that joint
   std::vector<int32_t> posUnits; // [U]
   std::vector<uint8_t> structNonZero; // [P] the parameter's column of the joint-constraint rows can be non-zero
-  std::vector<int32_t> solveList; // [n] parameter index of compacted column s (ascending)
+  std::vector<int32_t> solveList; // [n] parameter index of compacted column s (in HostTables::eliminationList order)
   std::vector<int32_t> srcStart; // [n+1] offsets into srcs per compacted column
   std::vector<ColumnSource> srcs;
   int32_t maxDepth = 0;
@@ -94,6 +101,20 @@ int32_t buildFusedTables(
     const std::vector<int32_t>* unionOri, // carries a position / an orientation constraint in SOME element
     FusedTables& out,
     std::string& err);
+
+// Tile structure of the Cholesky factor of H = J^T J + (parameter-space rows) for a solve list in elimination order:
+// `related(row, col)` (row > col) says whether entry (row, col) of H can be non-zero.  Symbolic factorisation on the
+// 16 x 16 tile grid (tile (I, J) of L is non-zero when it is in H or when two tiles (I, k), (J, k), k < J, are).
+// rowMask[I]: bit J set = tile (I, J <= I) of L is structurally non-zero; colMask[k]: bit I set = tile (I >= k, k) is.
+// n <= 512 (32 blocks).  Integer bookkeeping, unit-tested on the CPU.
+struct TileMasks {
+  int32_t NB = 0;
+  uint32_t rowMask[32] = {};
+  uint32_t colMask[32] = {};
+  std::vector<int32_t> tiles; // the non-zero tiles, I | J << 8, in tile-index order (I (I + 1) / 2 + J ascending)
+  int64_t products = 0; // tile products L(I,j) L(k,j)^T of the masked factorisation (dense: NB (NB^2 - 1) / 6)
+};
+TileMasks eliminationTileMasks(int32_t n, const std::vector<uint8_t>& related /* [n][n], lower triangle used */, bool dense);
 
 // Validates the descriptor the way the reference's constructors / MT_CHECKs do
 // (skeleton.cpp:16-22 parent-before-child; parameter_transform.cpp:112-121 sizes).

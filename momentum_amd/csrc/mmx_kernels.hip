@@ -1350,18 +1350,28 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     }                                                    \
   }
   const float* Hb = jtj + size_t(b) * n * n;
+  // damping of the FACTOR: at least kFactorDamping of the mean diagonal (mmx_device.hpp; every wave sums the trace for
+  // itself); the refinement below measures its residual with the caller's lambda
+  float lambdaF;
+  {
+    float tr = 0.f;
+    for (int i = tid & 63; i < n; i += 64) {
+      tr += Hb[size_t(i) * n + i];
+    }
+    lambdaF = fmaxf(lambda, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
+  }
   for (int idx = tid; idx < n * n; idx += 256) {
     const int i = idx % n, j = idx / n;
     float v = Hb[idx];
     if (i == j) {
-      v += lambda;
+      v += lambdaF;
     }
     A[j * ld + i] = v;
   }
   for (int i = tid; i < n; i += 256) {
     g[i] = jtr[size_t(b) * n + i];
     d0[i] = g[i];
-    rho[i] = kPivotFloor * (Hb[size_t(i) * n + i] + lambda); // the row's pivot floor (rho is free until the refinement)
+    rho[i] = kPivotFloor * (Hb[size_t(i) * n + i] + lambdaF); // the row's pivot floor (rho is free until the refinement)
   }
   __syncthreads();
   MMX_SCLK(0)
@@ -1600,6 +1610,11 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
 //     those rows, then their contribution to rho = J^T w; the next chunk's loads are in flight meanwhile.
 // dynamic LDS = max(NP*16, n*(chunkRows+1)) + 4*NP + chunkRows + 2*256 + 8 floats.
 // =============================================================================================
+#ifdef MMX_EXP_KJM4
+constexpr int kJm = 4;
+#else
+constexpr int kJm = 2; // ... of the masked (tile-sparse) products: the lists are short
+#endif
 constexpr int kJb = 4; // finished block columns per trip of the tile products (4 tiles x kJb + kJb 16-byte loads in flight per lane)
 constexpr int kChunkLoads = 10; // 16-byte loads a thread keeps in flight for the next J chunk (n * chunkRows / 4 <= 256 * 10)
 
@@ -1926,81 +1941,129 @@ __device__ __forceinline__ void tiledFactorPairs(
   };
   float* pan0 = t.pan;
   float* pan1 = t.pan + size_t(NP) * 16;
+  // tile structure (mmx::TileMasks): only the structurally non-zero tiles are computed, kept in the panels (compacted: a
+  // panel holds column k's non-zero tiles in row order) and written; all of it wave-uniform integer work
+  // (the 2 x 32 mask words live in the lanes of two registers: a v_readlane picks one)
+  const uint32_t vRowMask = sp.tileMasks[lane & 31], vColMask = sp.tileMasks[32 + (lane & 31)];
+  auto rowMask = [&](int I) { return uint32_t(__builtin_amdgcn_readlane(int(vRowMask), I)); };
+  auto colMask = [&](int kk) { return uint32_t(__builtin_amdgcn_readlane(int(vColMask), kk)); };
+  auto below = [](int i) { return (1u << i) - 1u; }; // bits 0 .. i-1 (i <= 31)
+  auto tileL = [&](int I, int j) { return L + size_t(tileIndex(I, j)) * 256 + opOff; };
   for (int k = 0; k < NB; k += 2) {
     const bool two = k + 1 < NB; // (uniform)
-    // (a) the wave's tiles I = k + wave, + 4, ... of BOTH columns, two rows of tiles per trip
-    for (int I0 = k + wave; I0 < NB; I0 += 8) {
-      v4f c0[2], c1[2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        c0[tt] = loadH(I0 + 4 * tt, k);
-        c1[tt] = loadH(I0 + 4 * tt, k + 1); // (meaningless for I = k or without a second column: not stored)
-      }
-      for (int j0 = 0; j0 < k; j0 += kJb) {
-        float4 b0[kJb], b1[kJb], av[2][kJb];
-#pragma unroll
-        for (int u = 0; u < kJb; ++u) {
-          const int j = min(j0 + u, k - 1);
-          b0[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(k, j)) * 256 + opOff);
-          b1[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(min(k + 1, NB - 1), j)) * 256 + opOff);
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            av[tt][u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(min(I0 + 4 * tt, NB - 1), j)) * 256 + opOff);
-          }
+    const uint32_t cm0 = colMask(k), cm1 = two ? colMask(k + 1) : 0u; // rows of the two columns (bits >= k / >= k + 1)
+    const uint32_t rk0 = rowMask(k) & below(k), rk1 = two ? rowMask(k + 1) & below(k) : 0u; // finished columns j < k they reach
+    // (a) the wave's tiles of BOTH columns: every fourth row of the union, one row (two tiles) per trip
+    {
+      uint32_t rem = cm0 | cm1;
+      for (int idx = 0; rem != 0u; ++idx) {
+        const int I = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        if ((idx & 3) != wave) {
+          continue;
         }
+        const bool in0 = (cm0 >> I & 1u) != 0u, in1 = (cm1 >> I & 1u) != 0u;
+        const uint32_t rI = rowMask(I);
+        const uint32_t m0 = in0 ? rI & rk0 : 0u, m1 = in1 ? rI & rk1 : 0u;
+        v4f c0{0.f, 0.f, 0.f, 0.f}, c1{0.f, 0.f, 0.f, 0.f};
+        if (in0) {
+          c0 = loadH(I, k);
+        }
+        if (in1) {
+          c1 = loadH(I, k + 1);
+        }
+        uint32_t mm = m0 | m1;
+        while (mm != 0u) {
+          int jj[kJm];
+          bool use0[kJm], use1[kJm];
 #pragma unroll
-        for (int u = 0; u < kJb; ++u) {
-          if (j0 + u < k) {
+          for (int u = 0; u < kJm; ++u) {
+            const bool have = mm != 0u;
+            jj[u] = have ? __builtin_ctz(mm) : 0;
+            use0[u] = have && (m0 >> jj[u] & 1u) != 0u;
+            use1[u] = have && (m1 >> jj[u] & 1u) != 0u;
+            mm = have ? mm & (mm - 1u) : 0u;
+          }
+          float4 b0[kJm], b1[kJm], av[kJm];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].x, b0[u].x, c0[tt], 0, 0, 0);
-              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].y, b0[u].y, c0[tt], 0, 0, 0);
-              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].z, b0[u].z, c0[tt], 0, 0, 0);
-              c0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].w, b0[u].w, c0[tt], 0, 0, 0);
-              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].x, b1[u].x, c1[tt], 0, 0, 0);
-              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].y, b1[u].y, c1[tt], 0, 0, 0);
-              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].z, b1[u].z, c1[tt], 0, 0, 0);
-              c1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[tt][u].w, b1[u].w, c1[tt], 0, 0, 0);
+          for (int u = 0; u < kJm; ++u) {
+            if (use0[u] || use1[u]) {
+              av[u] = *reinterpret_cast<const float4*>(tileL(I, jj[u]));
+            }
+            if (use0[u]) {
+              b0[u] = *reinterpret_cast<const float4*>(tileL(k, jj[u]));
+            }
+            if (use1[u]) {
+              b1[u] = *reinterpret_cast<const float4*>(tileL(k + 1, jj[u]));
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kJm; ++u) {
+            if (use0[u]) {
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].x, b0[u].x, c0, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].y, b0[u].y, c0, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].z, b0[u].z, c0, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].w, b0[u].w, c0, 0, 0, 0);
+            }
+            if (use1[u]) {
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].x, b1[u].x, c1, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].y, b1[u].y, c1, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].z, b1[u].z, c1, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].w, b1[u].w, c1, 0, 0, 0);
             }
           }
         }
-      }
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int I = I0 + 4 * tt;
-        if (I < NB) {
-          float* T0 = pan0 + 256 * (I - k);
+        if (in0) {
+          float* T0 = pan0 + 256 * __builtin_popcount(cm0 & below(I));
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            T0[tileAddr(4 * lkg + q, lrow)] = c0[tt][q];
+            T0[tileAddr(4 * lkg + q, lrow)] = c0[q];
           }
-          if (two && I > k) {
-            float* T1 = pan1 + 256 * (I - k - 1);
+        }
+        if (in1) {
+          float* T1 = pan1 + 256 * __builtin_popcount(cm1 & below(I));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              T1[tileAddr(4 * lkg + q, lrow)] = c1[tt][q];
-            }
+          for (int q = 0; q < 4; ++q) {
+            T1[tileAddr(4 * lkg + q, lrow)] = c1[q];
           }
         }
       }
     }
     // the forward substitution rides along: s = g - sum_{j<k} L(.,j) y_j for the rows of both columns
-    if (wave == 3 && k > 0) {
+    if (wave == 3 && (rk0 | rk1) != 0u) {
       float acc0 = 0.f, acc1 = 0.f;
-      for (int j0 = 0; j0 < k; j0 += 4) {
+      uint32_t mm = rk0 | rk1;
+      while (mm != 0u) {
+        int jj[4];
+        bool use0[4], use1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool have = mm != 0u;
+          jj[u] = have ? __builtin_ctz(mm) : 0;
+          use0[u] = have && (rk0 >> jj[u] & 1u) != 0u;
+          use1[u] = have && (rk1 >> jj[u] & 1u) != 0u;
+          mm = have ? mm & (mm - 1u) : 0u;
+        }
         float4 l0[4], l1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int j = min(j0 + u, k - 1);
-          l0[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(k, j)) * 256 + opOff);
-          l1[u] = *reinterpret_cast<const float4*>(L + size_t(tileIndex(min(k + 1, NB - 1), j)) * 256 + opOff);
+          if (use0[u]) {
+            l0[u] = *reinterpret_cast<const float4*>(tileL(k, jj[u]));
+          }
+          if (use1[u]) {
+            l1[u] = *reinterpret_cast<const float4*>(tileL(k + 1, jj[u]));
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          if (j0 + u < k) {
-            const float4 yv = *reinterpret_cast<const float4*>(g + 16 * (j0 + u) + 4 * lkg);
-            acc0 = dot4(l0[u], yv, acc0);
-            acc1 = dot4(l1[u], yv, acc1);
+          if (use0[u] || use1[u]) {
+            const float4 yv = *reinterpret_cast<const float4*>(g + 16 * jj[u] + 4 * lkg);
+            if (use0[u]) {
+              acc0 = dot4(l0[u], yv, acc0);
+            }
+            if (use1[u]) {
+              acc1 = dot4(l1[u], yv, acc1);
+            }
           }
         }
       }
@@ -2017,44 +2080,65 @@ __device__ __forceinline__ void tiledFactorPairs(
     }
     __syncthreads();
     MMX_SCLK(6)
-    factorPanel(pan0, NB - k, k);
+    factorPanel(pan0, __builtin_popcount(cm0), k);
     if (two) {
-      // the missing term of column k + 1: C(I, k+1) -= L(I,k) L(k+1,k)^T, operands from column k's LDS panel
-      for (int I = k + 1 + wave; I < NB; I += 4) {
-        float* T1 = pan1 + 256 * (I - k - 1);
-        v4f c;
+      // the missing term of column k + 1: C(I, k+1) -= L(I,k) L(k+1,k)^T, operands from column k's LDS panel -- when
+      // L(k+1,k) is structurally non-zero (it is the second tile of column k's panel then), for the rows both columns hold
+      if ((cm0 >> (k + 1) & 1u) != 0u) {
+        uint32_t rem = cm0 & cm1;
+        for (int idx = 0; rem != 0u; ++idx) {
+          const int I = __builtin_ctz(rem);
+          rem &= rem - 1u;
+          if ((idx & 3) != wave) {
+            continue;
+          }
+          float* T1 = pan1 + 256 * __builtin_popcount(cm1 & below(I));
+          v4f c;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          c[q] = T1[tileAddr(4 * lkg + q, lrow)];
-        }
-        const float4 av = ldsRow4(pan0 + 256 * (I - k), lrow, lkg);
-        const float4 bv = ldsRow4(pan0 + 256, lrow, lkg);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
+          for (int q = 0; q < 4; ++q) {
+            c[q] = T1[tileAddr(4 * lkg + q, lrow)];
+          }
+          const float4 av = ldsRow4(pan0 + 256 * __builtin_popcount(cm0 & below(I)), lrow, lkg);
+          const float4 bv = ldsRow4(pan0 + 256, lrow, lkg);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.w, bv.w, c, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          T1[tileAddr(4 * lkg + q, lrow)] = c[q];
+          for (int q = 0; q < 4; ++q) {
+            T1[tileAddr(4 * lkg + q, lrow)] = c[q];
+          }
         }
+        if (wave == 3 && lane < 16) { // ... and of s_{k+1}: - L(k+1,k) y_k
+          float acc = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc = dot4(ldsRow4(pan0 + 256, lane, q), *reinterpret_cast<const float4*>(g + 16 * k + 4 * q), acc);
+          }
+          g[16 * (k + 1) + lane] -= acc;
+        }
+        __syncthreads();
       }
-      if (wave == 3 && lane < 16) { // ... and of s_{k+1}: - L(k+1,k) y_k
-        float acc = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc = dot4(ldsRow4(pan0 + 256, lane, q), *reinterpret_cast<const float4*>(g + 16 * k + 4 * q), acc);
-        }
-        g[16 * (k + 1) + lane] -= acc;
-      }
-      __syncthreads();
-      factorPanel(pan1, NB - k - 1, k + 1);
+      factorPanel(pan1, __builtin_popcount(cm1), k + 1);
     }
     MMX_SCLK(7)
     // (c) every finished tile is written once
-    for (int I = k + wave; I < NB; I += 4) {
-      *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k)) * 256 + opOff) = ldsRow4(pan0 + 256 * (I - k), lrow, lkg);
-      if (two && I > k) {
-        *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k + 1)) * 256 + opOff) = ldsRow4(pan1 + 256 * (I - k - 1), lrow, lkg);
+    {
+      uint32_t rem = cm0;
+      for (int idx = 0; rem != 0u; ++idx) {
+        const int I = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        if ((idx & 3) == wave) {
+          *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k)) * 256 + opOff) = ldsRow4(pan0 + 256 * idx, lrow, lkg);
+        }
+      }
+      rem = cm1;
+      for (int idx = 0; rem != 0u; ++idx) {
+        const int I = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        if ((idx & 3) == wave) {
+          *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k + 1)) * 256 + opOff) = ldsRow4(pan1 + 256 * idx, lrow, lkg);
+        }
       }
     }
     __syncthreads(); // the panel buffers are reused; the tiles are visible to the workgroup
@@ -2065,10 +2149,12 @@ __device__ __forceinline__ void tiledFactorPairs(
 // Substitutions on the tile-major factor.  forward: L y = x, column by column (after y_k every row below
 // subtracts block k's sixteen columns); backward: L^T z = y, row block by row block.  The tiles of the NEXT
 // step are requested before the sixteen-step chain of the current one.  x: LDS, NP floats, in place.
+// masks: the factor's tile structure (mmx::TileMasks; tiles outside it were never written and are not read), or null: dense
 template <bool forward>
-__device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, float* x, int tid) {
+__device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, float* x, int tid, const uint32_t* __restrict__ masks = nullptr) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NP = 16 * NB, lrow = lane & 15;
+  const uint32_t vMask = masks != nullptr ? masks[(forward ? 32 : 0) + (lane & 31)] : 0xffffffffu; // (lane i: block i's word)
   {
     float dg[16] = {}, dgNext[16] = {}, pv[2][16] = {}, pvNext[2][16] = {};
     float di = 1.f, diNext = 1.f; // L(i,i) of the lane's row / column of the diagonal tile
@@ -2084,22 +2170,27 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
         }
         dio = Dt[lrow * 17];
       }
+      // column k's tiles below the diagonal (forward) / row k's tiles left of it (backward) that are structurally non-zero
+      const uint32_t present = uint32_t(__builtin_amdgcn_readlane(int(vMask), k));
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         if (forward) {
           const int r = 16 * (k + 1) + tid + 256 * m;
-          const float* Tr = L + size_t(tileIndex(min(r, NP - 1) >> 4, k)) * 256 + (r & 15) * 16;
+          const int rb = min(r, NP - 1) >> 4;
+          const float* Tr = L + size_t(tileIndex(rb, k)) * 256 + (r & 15) * 16;
+          const bool have = (present >> rb & 1u) != 0u;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(Tr + 4 * q);
+            const float4 v = have ? *reinterpret_cast<const float4*>(Tr + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
             pvo[m][4 * q] = v.x, pvo[m][4 * q + 1] = v.y, pvo[m][4 * q + 2] = v.z, pvo[m][4 * q + 3] = v.w;
           }
         } else {
           const int cidx = min(tid + 256 * m, max(16 * k - 1, 0));
           const float* Tc = L + size_t(tileIndex(k, cidx >> 4)) * 256 + (cidx & 15);
+          const bool have = (present >> (cidx >> 4) & 1u) != 0u;
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) {
-            pvo[m][rr] = Tc[rr * 16];
+            pvo[m][rr] = have ? Tc[rr * 16] : 0.f;
           }
         }
       }
@@ -2233,7 +2324,16 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledFactor(jtj + size_t(b) * n * n, L, n, lambda, t, sp, b, tid, tclk);
+  float lambdaF; // damping of the FACTOR (kFactorDamping, mmx_device.hpp); the refinement keeps the caller's lambda
+  {
+    const float* Hb = jtj + size_t(b) * n * n;
+    float tr = 0.f;
+    for (int i = tid & 63; i < n; i += 64) {
+      tr += Hb[size_t(i) * n + i];
+    }
+    lambdaF = fmaxf(lambda, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
+  }
+  tiledFactor(jtj + size_t(b) * n * n, L, n, lambdaF, t, sp, b, tid, tclk);
   const bool badPivot = t.flags[0] != 0;
   constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
   for (int i = tid; i < NP; i += 256) {
@@ -2372,7 +2472,12 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
 // left rho = J^T (r - J d) - lambda d in `rhoVec` -- solves for the correction and, when it was the last one,
 // applies the step.  refState[b]: 0 = a refinement round is due, 1 = the iteration's step has been applied.
 // (Two block columns per step on the tile-major hand-over of treeNormalEquationsKernel: tiledFactorPairs.)
-__global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
+#ifdef MMX_EXP_OCC4
+#define MMX_FACTOR_WG 4
+#else
+#define MMX_FACTOR_WG 3 // (the masked products' integer work does not fit the 128 registers of four: 56 spilled, 13 % slower)
+#endif
+__global__ void __launch_bounds__(256, MMX_FACTOR_WG) choleskyFactorTiledKernel(
     ProblemDev pb,
     int P,
     const float* __restrict__ jtj,
@@ -2404,10 +2509,9 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
   for (int i = tid; i < NP; i += 256) {
     t.g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
   }
-  if (sp.stepRule == MMX_STEP_TRUST_REGION) {
-    // The trust region starts from (almost) no damping, which the reference's QR of J can take and an fp32 Cholesky of
-    // J^T J cannot when J is rank deficient: the FACTOR is damped by at least 1e-6 of the mean diagonal (as in
-    // fusedSolveKernel), the refinement measures its residual with the true damping through J.
+  {
+    // the FACTOR is damped by at least kFactorDamping of the mean diagonal (mmx_device.hpp; as in fusedSolveKernel); the
+    // refinement measures its residual with the true damping through J
     float tr = 0.f;
     const float* Hd = jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
     for (int i = tid; i < n; i += 256) {
@@ -2419,7 +2523,7 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
       t.rho[tid >> 6] = tr;
     }
     __syncthreads();
-    lambda = fmaxf(lambda, 1e-6f * ((t.rho[0] + t.rho[1]) + (t.rho[2] + t.rho[3])) / float(n > 0 ? n : 1));
+    lambda = fmaxf(lambda, kFactorDamping * ((t.rho[0] + t.rho[1]) + (t.rho[2] + t.rho[3])) / float(n > 0 ? n : 1));
   }
   __syncthreads();
   long long tclk = clock64();
@@ -2429,7 +2533,7 @@ __global__ void __launch_bounds__(256, 4) choleskyFactorTiledKernel(
   float* d0 = t.g; // y = L^-1 g, solved in place
   MMX_SCLK(0)
   if (!bad) {
-    tiledSweep<false>(L, NB, d0, tid);
+    tiledSweep<false>(L, NB, d0, tid, sp.tileMasks);
   }
   MMX_SCLK(2)
   if (bad || !sp.refine) {
@@ -2478,8 +2582,8 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledSweep<true>(L, NB, rho, tid);
-  tiledSweep<false>(L, NB, rho, tid);
+  tiledSweep<true>(L, NB, rho, tid, sp.tileMasks);
+  tiledSweep<false>(L, NB, rho, tid, sp.tileMasks);
   MMX_SCLK(5)
   float c2 = 0.f, d2 = 0.f;
   for (int i = tid; i < n; i += 256) {
@@ -2497,7 +2601,14 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
   }
   __syncthreads();
   const float corr2 = sums[0] + sums[1] + sums[2] + sums[3], step2 = sums[4] + sums[5] + sums[6] + sums[7];
-  bool again = corr2 > kRefineTol2 * step2;
+#if defined(MMX_EXP_TOL7)
+  constexpr float kTolWide2 = 1e-7f;
+#elif defined(MMX_EXP_TOL8)
+  constexpr float kTolWide2 = 1e-8f;
+#else
+  constexpr float kTolWide2 = kRefineTol2;
+#endif
+  bool again = corr2 > kTolWide2 * step2;
   if (corr2 > kRefineMax2 * step2) { // not a contraction (kRefineMax2): undo this correction, the step is the one before it
     for (int i = tid; i < n; i += 256) {
       d0[i] -= rho[i];
@@ -2777,7 +2888,7 @@ __global__ void __launch_bounds__(256) trustDecideKernel(
     next = 3;
   } else if (newton < 3 && sqrtf(dn2) >= 1.05f * sp.tr.radius[b]) { // :180-181
     const float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
-    tiledSweep<true>(L, NB, x, tid); // x = L^-1 p_l
+    tiledSweep<true>(L, NB, x, tid, sp.tileMasks); // x = L^-1 p_l
     __syncthreads();
     float q = 0.f;
     for (int c = tid; c < n; c += 256) {

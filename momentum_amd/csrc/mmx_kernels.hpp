@@ -81,6 +81,9 @@ struct StepParams {
   int32_t stepRule; // MMX_STEP_*
   float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
   long long* clk; // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
+  // tile structure of the tile-major factor (mmx::TileMasks): [0..31] rowMask, [32..63] colMask.  The tiled factor, its
+  // sweeps and treeNormalEquationsKernel touch only the tiles named here; the others are never written nor read.
+  const uint32_t* tileMasks;
 };
 
 // device view of mmx::FusedTables (mmx_host_tables.hpp)
@@ -118,6 +121,9 @@ struct FusedDev {
   // rows of the further joint error functions + ellipsoid limits handled inside the fused solve (kGen instantiations):
   // GT = constraints (ProblemDev::G + NE), genRows = their Jacobian rows (rowsJoint - 3 U); 0 / 0: none
   int32_t GT, genRows;
+  // the structurally non-zero tiles of the factor (and of H) in elimination order: I | J << 8 (mmx::TileMasks::tiles)
+  const int32_t* tileList;
+  int32_t numTiles;
 };
 
 struct FusedParams {

@@ -199,7 +199,7 @@ def test_wide_solve_carries_blocks_and_ellipsoids(orc, route, monkeypatch):
     if route == "tree":  # the tree normal equations with J_g against the oracle's J^T J / J^T r (parity hook)
         buf, nn = np.zeros(rig.num_params, np.int32), C.c_int32(0)
         capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(nn), None))
-        lst = buf[: nn.value]
+        lst = np.sort(buf[: nn.value])  # (elimination order -> parameter order, which tree_normal_equations reports in)
         en = np.zeros(rig.num_params, np.uint8)
         en[lst] = 1
         pb.set_enabled(en)  # only structurally non-zero columns: the enabled system IS the solve-list system

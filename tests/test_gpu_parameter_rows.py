@@ -169,7 +169,7 @@ def test_wide_solve_with_limits_and_the_model_prior(torch_cuda, orc, route, monk
 
         buf, nn = np.zeros(rig.num_params, np.int32), C.c_int32(0)
         capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(nn), None))
-        lst = buf[: nn.value]
+        lst = np.sort(buf[: nn.value])  # (elimination order -> parameter order, which tree_normal_equations reports in)
         assert nn.value == rig.num_params  # the model prior keeps every parameter in the solve list
         theta = rng.uniform(-0.2, 0.2, size=(B, rig.num_params)).astype(np.float32)
         Ht, gt = pb.tree_normal_equations(torch.from_numpy(theta).to(pb.device))

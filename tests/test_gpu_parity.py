@@ -559,7 +559,7 @@ def test_tree_moment_normal_equations_match_the_dense_product_on_the_wide_rig(to
     buf = np.zeros(rig.num_params, np.int32)
     nn = C.c_int32(0)
     capi._check(capi.lib().mmx_debug_fused_normal_equations(pb._h, None, None, None, capi.as_ptr(buf, C.c_int32), C.byref(nn), None))
-    lst = buf[: nn.value]
+    lst = np.sort(buf[: nn.value])  # (the solve list is in elimination order; the hooks below report in parameter order)
     en = np.zeros(rig.num_params, np.uint8)
     en[lst] = 1  # only structurally non-zero columns enabled: the enabled system IS the solve-list system
     pb.set_enabled(en)

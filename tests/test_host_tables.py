@@ -53,3 +53,107 @@ def test_humanoid_shapes():
     assert (r.num_joints, r.num_params) == (300, 300) and int(r.depth().max()) <= 16
     r = make_test_character(24)
     assert (r.num_joints, r.num_params) == (24, 31)
+
+
+# ---- the solvers' column order and the tile structure of their factor (mmx_host_elimination_order / _tile_structure)
+def _param_joints(rig, en=None):
+    """joints each (enabled) parameter drives, from the parameter transform's CSR rows."""
+    out = [set() for _ in range(rig.num_params)]
+    for r in range(7 * rig.num_joints):
+        for k in range(rig.pt_outer[r], rig.pt_outer[r + 1]):
+            out[int(rig.pt_inner[k])].add(r // 7)
+    return out
+
+
+def _related(rig, order, anc):
+    """H(row, col) can be non-zero iff a joint of the one parameter is an ancestor-or-self of a joint of the other."""
+    pj = _param_joints(rig)
+    n = len(order)
+    rel = np.zeros((n, n), np.uint8)
+    for a in range(n):
+        for b in range(a):
+            rel[a, b] = any(anc[x, y] or anc[y, x] for x in pj[order[a]] for y in pj[order[b]])
+    return rel
+
+
+@pytest.mark.parametrize("name", list(RIGS))
+def test_elimination_order_is_a_post_order_of_the_enabled_parameters(orc, name):
+    rig = RIGS[name]()
+    rng = np.random.default_rng(8)
+    anc = orc.ancestor_matrix(rig).astype(bool)
+    pj = _param_joints(rig)
+    for trial in range(2):
+        en = (rng.uniform(size=rig.num_params) < (1.0 if trial == 0 else 0.7)).astype(np.uint8)
+        t = capi.host_tables(rig, en)
+        order = t["elimination_order"]
+        assert sorted(order.tolist()) == np.flatnonzero(en).tolist()  # a permutation of the enabled list
+        # children before parents: a parameter that drives ONE joint never precedes a single-joint parameter of a
+        # strict descendant of that joint
+        single = [p for p in order if len(pj[p]) == 1]
+        pos = {int(p): i for i, p in enumerate(order)}
+        for p in single:
+            (a,) = pj[p]
+            for q in single:
+                (b,) = pj[q]
+                if a != b and anc[a, b]:  # a strict ancestor of b
+                    assert pos[int(q)] < pos[int(p)], (p, q)
+
+
+def _numeric_fill(rel, seed=0):
+    """Pattern of the Cholesky factor of a random SPD matrix with the given pattern (dense double arithmetic)."""
+    n = rel.shape[0]
+    rng = np.random.default_rng(seed)
+    A = np.tril(rel, -1) * rng.uniform(0.5, 1.0, size=(n, n))
+    A = A + A.T + np.eye(n) * (n + 1.0)
+    L = np.linalg.cholesky(A)
+    return np.abs(np.tril(L)) > 1e-14
+
+
+@pytest.mark.parametrize("name", ["humanoid72", "humanoid72_p219", "rig300"])
+def test_tile_structure_covers_the_numerical_factor_and_is_sparse_in_elimination_order(orc, name):
+    rig = RIGS[name]()
+    anc = orc.ancestor_matrix(rig).astype(bool)
+    t = capi.host_tables(rig)
+    dense_products = lambda NB: NB * (NB * NB - 1) // 6
+    results = {}
+    for label, order in (("elimination", t["elimination_order"]), ("parameter", t["enabled_list"])):
+        rel = _related(rig, [int(p) for p in order], anc)
+        n = rel.shape[0]
+        NB = (n + 15) // 16
+        ts = capi.host_tile_structure(rel)
+        Lnz = _numeric_fill(rel)
+        tiles = 0
+        for I in range(NB):
+            for Jc in range(I + 1):
+                has = bool(Lnz[16 * I : 16 * I + 16, 16 * Jc : 16 * Jc + 16].any())
+                bit = bool(ts["row_mask"][I] >> Jc & 1)
+                assert bit or not has, (label, I, Jc)  # every numerically non-zero tile is in the structure
+                assert bit == bool(ts["col_mask"][Jc] >> I & 1)
+                tiles += bit
+        # the products the masked factorisation performs, recounted from the masks
+        prod = sum(
+            bin(int(ts["row_mask"][I]) & int(ts["row_mask"][k]) & ((1 << k) - 1)).count("1")
+            for I in range(NB)
+            for k in range(I + 1)
+            if ts["row_mask"][I] >> k & 1
+        )
+        assert prod == ts["products"]
+        results[label] = (tiles, ts["products"], NB)
+    (te, pe, NB), (tp, pp, _) = results["elimination"], results["parameter"]
+    assert pp == dense_products(NB) and tp == NB * (NB + 1) // 2  # root first: the factor fills completely
+    assert 3 * pe <= pp and te < tp, results  # leaves first: at most a third of the tile products
+
+
+def test_tile_structure_fill_in():
+    """An arrow pattern pointing the wrong way (first row block coupled to all) fills completely; the same arrow with the
+    hub last has no fill at all."""
+    n = 96
+    rel = np.zeros((n, n), np.uint8)
+    rel[16:, :16] = 1  # every later parameter coupled to the first block
+    ts = capi.host_tile_structure(rel)
+    assert all(int(ts["row_mask"][I]) == (1 << (I + 1)) - 1 for I in range(6))
+    rel = np.zeros((n, n), np.uint8)
+    rel[80:, :80] = 1  # the hub last
+    ts = capi.host_tile_structure(rel)
+    assert [int(ts["row_mask"][I]) for I in range(6)] == [1, 2, 4, 8, 16, 63]
+    assert ts["products"] == 5  # the hub's diagonal tile: one product per earlier column
