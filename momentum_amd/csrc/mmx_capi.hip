@@ -184,7 +184,7 @@ struct mmx_problem {
   mmx::HostTables tables; // for the current enabled set
   mmx::FusedTables fused;
   DevBuf dUnitJoint, dUnitTin, dColStart, dColSources, dEnabledList, dJacRecs, dMultiCols, dZeroCols;
-  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dComb, dDfsJoint, dLoadedPos;
+  DevBuf dSubSize, dPosUnitStart, dPosUnits, dSolveList, dSrcStart, dSrcs, dTerms, dTerms16, dComb, dDfsJoint, dLoadedPos;
   DevBuf dLimStart, dLimOf, dPairDest, dPairStart, dPairLim, dPairCols;
   mmx::FusedDev fdev{};
   // constraint payload: owned copies (host ingest) or borrowed device pointers
@@ -562,57 +562,64 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         }
       }
       // (chunk c >= 1 of an entry uses partial cell combFirst + c - 1)
-      // longest-processing-time-first assignment of runs to the 256 threads (deterministic)
+      // longest-processing-time-first assignment of runs to the threads of a workgroup (deterministic): 256 for the
+      // one-launch solve and the four-wave tree kernels, 1024 for the sixteen-wave treeNormalEquationsKernel
       std::vector<size_t> order(runs.size());
       for (size_t i = 0; i < order.size(); ++i) {
         order[i] = i;
       }
       std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return runs[x].count > runs[y].count; });
-      std::vector<std::vector<uint32_t>> recs(256); // 4 words per record
-      std::vector<size_t> load(256, 0);
-      for (size_t oi : order) {
-        const Run& rn = runs[oi];
-        int thread = 0;
-        for (int t = 1; t < 256; ++t) {
-          if (load[t] < load[thread]) {
-            thread = t;
+      auto deal = [&](int threads, std::vector<uint32_t>& inter) -> size_t {
+        const size_t nThreads = size_t(threads);
+        std::vector<std::vector<uint32_t>> recs(nThreads); // 4 words per record
+        std::vector<size_t> load(nThreads, 0);
+        for (size_t oi : order) {
+          const Run& rn = runs[oi];
+          int thread = 0;
+          for (int t = 1; t < threads; ++t) {
+            if (load[size_t(t)] < load[size_t(thread)]) {
+              thread = t;
+            }
+          }
+          const Entry& en = entries[rn.entry];
+          uint32_t destWord;
+          if (rn.dest >= 0) {
+            destWord = uint32_t(rn.dest);
+          } else {
+            destWord = (1u << 30) | uint32_t(-rn.dest - 1);
+          }
+          for (size_t i = 0; i < rn.count; ++i) {
+            const Term& tm = en.terms[rn.first + i];
+            uint32_t x = tm.deep | (tm.anc << 12) | (1u << 26);
+            if (i == 0) {
+              x |= 1u << 24;
+            }
+            if (i + 1 == rn.count) {
+              x |= 1u << 25;
+            }
+            uint32_t wbits;
+            std::memcpy(&wbits, &tm.w, 4);
+            recs[size_t(thread)].insert(recs[size_t(thread)].end(), {x, destWord, wbits, 0u});
+          }
+          load[size_t(thread)] += rn.count;
+        }
+        size_t rounds = 0;
+        for (const auto& r : recs) {
+          rounds = std::max(rounds, r.size() / 4);
+        }
+        rounds = (rounds + 7) & ~size_t(7); // the kernels consume 8 records per trip
+        inter.assign(std::max<size_t>(rounds, 8) * size_t(threads) * 4, 0u);
+        for (int t = 0; t < threads; ++t) {
+          for (size_t k = 0; k < recs[size_t(t)].size() / 4; ++k) {
+            for (int w = 0; w < 4; ++w) {
+              inter[(k * size_t(threads) + size_t(t)) * 4 + size_t(w)] = recs[size_t(t)][4 * k + size_t(w)];
+            }
           }
         }
-        const Entry& en = entries[rn.entry];
-        uint32_t destWord;
-        if (rn.dest >= 0) {
-          destWord = uint32_t(rn.dest);
-        } else {
-          destWord = (1u << 30) | uint32_t(-rn.dest - 1);
-        }
-        for (size_t i = 0; i < rn.count; ++i) {
-          const Term& tm = en.terms[rn.first + i];
-          uint32_t x = tm.deep | (tm.anc << 12) | (1u << 26);
-          if (i == 0) {
-            x |= 1u << 24;
-          }
-          if (i + 1 == rn.count) {
-            x |= 1u << 25;
-          }
-          uint32_t wbits;
-          std::memcpy(&wbits, &tm.w, 4);
-          recs[thread].insert(recs[thread].end(), {x, destWord, wbits, 0u});
-        }
-        load[thread] += rn.count;
-      }
-      size_t rounds = 0;
-      for (const auto& r : recs) {
-        rounds = std::max(rounds, r.size() / 4);
-      }
-      rounds = (rounds + 7) & ~size_t(7); // the kernel consumes 8 records per trip
-      std::vector<uint32_t> inter(std::max<size_t>(rounds, 8) * 256 * 4, 0u);
-      for (int t = 0; t < 256; ++t) {
-        for (size_t k = 0; k < recs[t].size() / 4; ++k) {
-          for (int w = 0; w < 4; ++w) {
-            inter[(k * 256 + size_t(t)) * 4 + w] = recs[t][4 * k + w];
-          }
-        }
-      }
+        return rounds;
+      };
+      std::vector<uint32_t> inter, inter16;
+      const size_t rounds = deal(256, inter), rounds16 = deal(1024, inter16);
       if (numCells > 7 * rig->J) { // the kernels park the cells in a first-moment array: kC1 (= 7) floats per joint
         return fail(MMX_ERR_UNSUPPORTED, "too many split H entries for the partial-cell scratch");
       }
@@ -628,6 +635,9 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       MMX_HIP(upload(pb->dTerms, inter));
       fd.gTerms = pb->dTerms.as<uint4>();
       fd.termRounds = int32_t(rounds);
+      MMX_HIP(upload(pb->dTerms16, inter16));
+      fd.gTerms16 = pb->dTerms16.as<uint4>();
+      fd.termRounds16 = int32_t(rounds16);
     }
     // limits per solve column, and the limits that share an off-diagonal entry of H
     pb->limitPairs.clear();

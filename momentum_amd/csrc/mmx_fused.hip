@@ -1351,13 +1351,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     // deficient; the refinement (which measures its residual with the true mu through J) moves the step towards the
     // weakly damped one wherever J determines it.
     float muFactor = mu;
-    {
+    { // (every wave sums the trace for itself: no barrier, no LDS round trip)
       float tr = 0.f;
-      for (int c = tid; c < n; c += 256) {
+      for (int c = tid & 63; c < n; c += 64) {
         tr += s.L[256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15)];
       }
-      tr = blockSumF(s, tr, tid);
-      muFactor = fmaxf(mu, kFactorDamping * tr / float(n > 0 ? n : 1));
+      muFactor = fmaxf(mu, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
     }
     for (int c = tid; c < NP; c += 256) {
       float* dg = s.L + 256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15);
@@ -2436,24 +2435,34 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
       const int r = (y >> 4) & 15, c = int(((((y >> 2) & 3) ^ (r >> 2)) & 3) << 2) | int(y & 3);
       return tileMajor ? Ht + size_t(y >> 8) * 256 + c * 16 + r : Hb + size_t(16 * I + r) * n + (16 * Jc + c);
     };
-    for (int k = 0; k < fd.termRounds; ++k) {
-      const uint4* rp = fd.gTerms + size_t(k) * 256 + (kWaves == 4 ? tid : (tid & 255)); // (dealt to 256 threads by the host)
-      const uint2 rec = *reinterpret_cast<const uint2*>(rp);
-      const uint32_t x = rec.x;
-      if ((kWaves == 4 || tid < 256) && (x & (1u << 26))) {
-        const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
-        float hj = 0.f;
+    // (the host deals the records to 256 threads and to 1024: the sixteen-wave instantiation takes the latter, the
+    // others keep their first 256 threads on the former)
+    const int rounds = kWaves == 16 ? fd.termRounds16 : fd.termRounds; // (a multiple of 8)
+    for (int k0 = 0; k0 < rounds; k0 += 8) {
+      uint2 recs[8]; // the trip's records are requested together (one round trip, not eight)
 #pragma unroll
-        for (int ch = 0; ch < 7; ++ch) {
-          hj += srcD[ch * sst + deep] * srcA[ch * sst + anc];
-        }
-        h = (x & (1u << 24)) ? hj : h + hj;
-        if (x & (1u << 25)) {
-          const uint32_t y = rec.y;
-          if (y & (1u << 30)) {
-            s.own1[y & 0xffff] = h; // partial cell of a split entry (the own sums are dead)
-          } else {
-            *entryAddr(y) += h;
+      for (int u = 0; u < 8; ++u) {
+        const uint4* rp = kWaves == 16 ? fd.gTerms16 + size_t(k0 + u) * 1024 + tid : fd.gTerms + size_t(k0 + u) * 256 + (tid & 255);
+        recs[u] = *reinterpret_cast<const uint2*>(rp);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t x = recs[u].x;
+        if ((kWaves != 8 || tid < 256) && (x & (1u << 26))) {
+          const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
+          float hj = 0.f;
+#pragma unroll
+          for (int ch = 0; ch < 7; ++ch) {
+            hj += srcD[ch * sst + deep] * srcA[ch * sst + anc];
+          }
+          h = (x & (1u << 24)) ? hj : h + hj;
+          if (x & (1u << 25)) {
+            const uint32_t y = recs[u].y;
+            if (y & (1u << 30)) {
+              s.own1[y & 0xffff] = h; // partial cell of a split entry (the own sums are dead)
+            } else {
+              *entryAddr(y) += h; // (an atomic without return instead was measured slower: 25 k against 18 k cycles for the phase)
+            }
           }
         }
       }

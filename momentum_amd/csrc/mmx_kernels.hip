@@ -1825,12 +1825,20 @@ __device__ __forceinline__ void tiledFactor(
   }
 }
 
+// The 2 x 32 mask words of mmx::TileMasks in the lanes of two registers (lane i, i + 32: block i's word): a v_readlane picks one.
+struct TileMaskLanes {
+  uint32_t row, col;
+};
+__device__ __forceinline__ TileMaskLanes loadTileMaskLanes(const uint32_t* __restrict__ masks, int tid) {
+  return TileMaskLanes{masks[tid & 31], masks[32 + (tid & 31)]};
+}
+
 // The same factorisation two block columns at a time (tile-major H only): the tiles L(I, j < k) are loaded ONCE for
 // the columns k and k + 1 -- the finished-tile reads, which are what the factor stage's HBM traffic consists of, halve.
 // Column k + 1 lacks its j = k term after that pass; it gets it from the LDS panel of column k once that is factored.
 // LDS: two panels (2 NP * 16 floats).
 __device__ __forceinline__ void tiledFactorPairs(
-    const float* __restrict__ H, float* __restrict__ L, int n, float lambda, const TiledLds& t, const StepParams& sp, int b, int tid, long long& tclk) {
+    const float* __restrict__ H, float* __restrict__ L, int n, float lambda, const TiledLds& t, const StepParams& sp, int b, int tid, long long& tclk, const TileMaskLanes& ml) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NP = (n + 15) & ~15, NB = NP >> 4;
   float* g = t.g;
@@ -1944,7 +1952,7 @@ __device__ __forceinline__ void tiledFactorPairs(
   // tile structure (mmx::TileMasks): only the structurally non-zero tiles are computed, kept in the panels (compacted: a
   // panel holds column k's non-zero tiles in row order) and written; all of it wave-uniform integer work
   // (the 2 x 32 mask words live in the lanes of two registers: a v_readlane picks one)
-  const uint32_t vRowMask = sp.tileMasks[lane & 31], vColMask = sp.tileMasks[32 + (lane & 31)];
+  const uint32_t vRowMask = ml.row, vColMask = ml.col;
   auto rowMask = [&](int I) { return uint32_t(__builtin_amdgcn_readlane(int(vRowMask), I)); };
   auto colMask = [&](int kk) { return uint32_t(__builtin_amdgcn_readlane(int(vColMask), kk)); };
   auto below = [](int i) { return (1u << i) - 1u; }; // bits 0 .. i-1 (i <= 31)
@@ -2150,11 +2158,16 @@ __device__ __forceinline__ void tiledFactorPairs(
 // subtracts block k's sixteen columns); backward: L^T z = y, row block by row block.  The tiles of the NEXT
 // step are requested before the sixteen-step chain of the current one.  x: LDS, NP floats, in place.
 // masks: the factor's tile structure (mmx::TileMasks; tiles outside it were never written and are not read), or null: dense
-template <bool forward>
-__device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, float* x, int tid, const uint32_t* __restrict__ masks = nullptr) {
+// vMask: the mask words in the lanes of a register (lane i: block i's word; colMask for the forward sweep, rowMask for
+// the backward one; TileMaskLanes below), loaded by the caller ahead of time
+// kSkip: how a lane whose tile is structurally zero stays away from it -- true: its loads are skipped (divergent; what the
+// factor kernel's sweep over the tiles it has just written wants: 1.53 against 1.95 ms for the stage on cfg5), false: it reads
+// the diagonal tile instead (in cache) and takes zeros (uniform control flow; what the finish kernel's sweeps over a factor
+// coming from HBM want: 0.53 against 0.67 ms)
+template <bool forward, bool kSkip = false>
+__device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, float* x, int tid, uint32_t vMask = 0xffffffffu) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NP = 16 * NB, lrow = lane & 15;
-  const uint32_t vMask = masks != nullptr ? masks[(forward ? 32 : 0) + (lane & 31)] : 0xffffffffu; // (lane i: block i's word)
   {
     float dg[16] = {}, dgNext[16] = {}, pv[2][16] = {}, pvNext[2][16] = {};
     float di = 1.f, diNext = 1.f; // L(i,i) of the lane's row / column of the diagonal tile
@@ -2177,20 +2190,27 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
         if (forward) {
           const int r = 16 * (k + 1) + tid + 256 * m;
           const int rb = min(r, NP - 1) >> 4;
-          const float* Tr = L + size_t(tileIndex(rb, k)) * 256 + (r & 15) * 16;
           const bool have = (present >> rb & 1u) != 0u;
+          const float* Tr = L + size_t(tileIndex(kSkip || have ? rb : k, k)) * 256 + (r & 15) * 16;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 v = have ? *reinterpret_cast<const float4*>(Tr + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
-            pvo[m][4 * q] = v.x, pvo[m][4 * q + 1] = v.y, pvo[m][4 * q + 2] = v.z, pvo[m][4 * q + 3] = v.w;
+            float4 v{0.f, 0.f, 0.f, 0.f};
+            if (!kSkip || have) {
+              v = *reinterpret_cast<const float4*>(Tr + 4 * q);
+            }
+            pvo[m][4 * q] = have ? v.x : 0.f, pvo[m][4 * q + 1] = have ? v.y : 0.f, pvo[m][4 * q + 2] = have ? v.z : 0.f, pvo[m][4 * q + 3] = have ? v.w : 0.f;
           }
         } else {
           const int cidx = min(tid + 256 * m, max(16 * k - 1, 0));
-          const float* Tc = L + size_t(tileIndex(k, cidx >> 4)) * 256 + (cidx & 15);
           const bool have = (present >> (cidx >> 4) & 1u) != 0u;
+          const float* Tc = L + size_t(tileIndex(k, kSkip || have ? cidx >> 4 : k)) * 256 + (cidx & 15);
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) {
-            pvo[m][rr] = have ? Tc[rr * 16] : 0.f;
+            float v = 0.f;
+            if (!kSkip || have) {
+              v = Tc[rr * 16];
+            }
+            pvo[m][rr] = have ? v : 0.f;
           }
         }
       }
@@ -2498,6 +2518,7 @@ __global__ void __launch_bounds__(256, MMX_FACTOR_WG) choleskyFactorTiledKernel(
     return;
   }
   const int n = pb.n;
+  const TileMaskLanes ml = loadTileMaskLanes(sp.tileMasks, tid);
   float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
   const int NP = (n + 15) & ~15, NB = NP >> 4;
   TiledLds t;
@@ -2527,13 +2548,13 @@ __global__ void __launch_bounds__(256, MMX_FACTOR_WG) choleskyFactorTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledFactorPairs(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk);
+  tiledFactorPairs(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk, ml);
   const bool badPivot = t.flags[0] != 0;
   constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
   float* d0 = t.g; // y = L^-1 g, solved in place
   MMX_SCLK(0)
   if (!bad) {
-    tiledSweep<false>(L, NB, d0, tid, sp.tileMasks);
+    tiledSweep<false, true>(L, NB, d0, tid, ml.row);
   }
   MMX_SCLK(2)
   if (bad || !sp.refine) {
@@ -2574,6 +2595,7 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
     return;
   }
   const int n = pb.n;
+  const TileMaskLanes ml = loadTileMaskLanes(sp.tileMasks, tid);
   const int NP = (n + 15) & ~15, NB = NP >> 4;
   const float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
   for (int i = tid; i < NP; i += 256) {
@@ -2582,8 +2604,8 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
   }
   __syncthreads();
   long long tclk = clock64();
-  tiledSweep<true>(L, NB, rho, tid, sp.tileMasks);
-  tiledSweep<false>(L, NB, rho, tid, sp.tileMasks);
+  tiledSweep<true>(L, NB, rho, tid, ml.col);
+  tiledSweep<false>(L, NB, rho, tid, ml.row);
   MMX_SCLK(5)
   float c2 = 0.f, d2 = 0.f;
   for (int i = tid; i < n; i += 256) {
@@ -2866,6 +2888,7 @@ __global__ void __launch_bounds__(256) trustDecideKernel(
     return;
   }
   const int n = pb.n, NP = (n + 15) & ~15, NB = NP >> 4;
+  const TileMaskLanes ml = loadTileMaskLanes(sp.tileMasks, tid);
   const float* dl = sp.delta + size_t(b) * n;
   float p0 = 0.f, p1 = 0.f;
   for (int c = tid; c < NP; c += 256) {
@@ -2888,7 +2911,7 @@ __global__ void __launch_bounds__(256) trustDecideKernel(
     next = 3;
   } else if (newton < 3 && sqrtf(dn2) >= 1.05f * sp.tr.radius[b]) { // :180-181
     const float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
-    tiledSweep<true>(L, NB, x, tid, sp.tileMasks); // x = L^-1 p_l
+    tiledSweep<true>(L, NB, x, tid, ml.col); // x = L^-1 p_l
     __syncthreads();
     float q = 0.f;
     for (int c = tid; c < n; c += 256) {

@@ -106,6 +106,8 @@ struct FusedDev {
   const uint4* gTerms; // x: deep | anc << 12 | first << 24 | last << 25 | valid << 26 ; y: LDS address
                        // of the entry inside the tile region ; z: weight product (float bits)
   int32_t termRounds;
+  const uint4* gTerms16; // the same records dealt to 1024 threads (the sixteen-wave treeNormalEquationsKernel): [k * 1024 + t]
+  int32_t termRounds16;
   const int32_t* comb; // [numComb][3] (tile-region offset, first partial cell, cell count) of split entries
   int32_t numComb;
   // parameter-space rows (limits on model parameters, model-parameter targets): which limits touch
