@@ -995,17 +995,41 @@ __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
   return acc;
 }
 
-__device__ __forceinline__ double waveReduceSum(double v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    v += __shfl_xor(v, off, 64);
-  }
-  return v;
+// Sum over the 64 lanes of a wave, the same value in every lane (in an SGPR): four DPP steps inside each row of sixteen
+// lanes (lanes ^ 1, lanes ^ 2, half-row mirror, row mirror: no LDS crossbar trip, unlike __shfl_xor = ds_bpermute), then the
+// four row sums by v_readlane.  Measured on the headline kernel (cfg2): a six-step __shfl_xor butterfly costs ~ 1 k cycles
+// on a wave's critical path, this ~ 100.
+template <int kCtrl>
+__device__ __forceinline__ float dppMoveF(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float waveReduceSumF(float v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    v += __shfl_xor(v, off, 64);
-  }
-  return v;
+  v += dppMoveF<0xB1>(v); // quad_perm [1,0,3,2]
+  v += dppMoveF<0x4E>(v); // quad_perm [2,3,0,1]
+  v += dppMoveF<0x141>(v); // row_half_mirror
+  v += dppMoveF<0x140>(v); // row_mirror: every lane of a row holds the row's sum
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+template <int kCtrl>
+__device__ __forceinline__ double dppMoveD(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, int(b), kCtrl, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, int(b >> 32), kCtrl, 0xF, 0xF, true);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<long long>(static_cast<unsigned int>(lo)));
+}
+__device__ __forceinline__ double waveReduceSum(double v) {
+  v += dppMoveD<0xB1>(v);
+  v += dppMoveD<0x4E>(v);
+  v += dppMoveD<0x141>(v);
+  v += dppMoveD<0x140>(v);
+  const long long b = __double_as_longlong(v);
+  auto row = [&](int lane) {
+    const int lo = __builtin_amdgcn_readlane(int(b), lane), hi = __builtin_amdgcn_readlane(int(b >> 32), lane);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<long long>(static_cast<unsigned int>(lo)));
+  };
+  return (row(0) + row(16)) + (row(32) + row(48));
 }
 
 // this thread's share of the blocks' error at the parameters `th`.  kJacobianRows: the value
