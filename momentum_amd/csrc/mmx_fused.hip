@@ -1351,9 +1351,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     // deficient; the refinement (which measures its residual with the true mu through J) moves the step towards the
     // weakly damped one wherever J determines it.
     float muFactor = mu;
-#ifdef MMX_EXP_NOTRACE
-    if (kTR)
-#endif
     { // (every wave sums the trace for itself: no barrier, no LDS round trip)
       float tr = 0.f;
       for (int c = tid & 63; c < n; c += 64) {

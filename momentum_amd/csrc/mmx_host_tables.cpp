@@ -164,9 +164,7 @@ int32_t buildHostTables(const mmx_rig_desc* d, const uint8_t* enabled, HostTable
       }
     }
     t.eliminationList = t.enabledList;
-#ifndef MMX_EXP_NATURAL
     std::stable_sort(t.eliminationList.begin(), t.eliminationList.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
-#endif
   }
   // ParameterTransformT::computeActiveJointParams (parameter_transform.cpp:97-107)
   t.activeJointParams.assign(R, 0);

@@ -1610,11 +1610,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
 //     those rows, then their contribution to rho = J^T w; the next chunk's loads are in flight meanwhile.
 // dynamic LDS = max(NP*16, n*(chunkRows+1)) + 4*NP + chunkRows + 2*256 + 8 floats.
 // =============================================================================================
-#ifdef MMX_EXP_KJM4
-constexpr int kJm = 4;
-#else
-constexpr int kJm = 2; // ... of the masked (tile-sparse) products: the lists are short
-#endif
+constexpr int kJm = 2; // ... of the masked (tile-sparse) products: the lists are short (four: spills, cfg5 -6 %)
 constexpr int kJb = 4; // finished block columns per trip of the tile products (4 tiles x kJb + kJb 16-byte loads in flight per lane)
 constexpr int kChunkLoads = 10; // 16-byte loads a thread keeps in flight for the next J chunk (n * chunkRows / 4 <= 256 * 10)
 
@@ -2492,12 +2488,9 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
 // left rho = J^T (r - J d) - lambda d in `rhoVec` -- solves for the correction and, when it was the last one,
 // applies the step.  refState[b]: 0 = a refinement round is due, 1 = the iteration's step has been applied.
 // (Two block columns per step on the tile-major hand-over of treeNormalEquationsKernel: tiledFactorPairs.)
-#ifdef MMX_EXP_OCC4
-#define MMX_FACTOR_WG 4
-#else
-#define MMX_FACTOR_WG 3 // (the masked products' integer work does not fit the 128 registers of four: 56 spilled, 13 % slower)
-#endif
-__global__ void __launch_bounds__(256, MMX_FACTOR_WG) choleskyFactorTiledKernel(
+// (three workgroups per CU: the masked products' integer work does not fit the 128 registers of four -- 56 spilled, the
+// stage 13 % slower on cfg5)
+__global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
     ProblemDev pb,
     int P,
     const float* __restrict__ jtj,
@@ -2623,14 +2616,7 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
   }
   __syncthreads();
   const float corr2 = sums[0] + sums[1] + sums[2] + sums[3], step2 = sums[4] + sums[5] + sums[6] + sums[7];
-#if defined(MMX_EXP_TOL7)
-  constexpr float kTolWide2 = 1e-7f;
-#elif defined(MMX_EXP_TOL8)
-  constexpr float kTolWide2 = 1e-8f;
-#else
-  constexpr float kTolWide2 = kRefineTol2;
-#endif
-  bool again = corr2 > kTolWide2 * step2;
+  bool again = corr2 > kRefineTol2 * step2;
   if (corr2 > kRefineMax2 * step2) { // not a contraction (kRefineMax2): undo this correction, the step is the one before it
     for (int i = tid; i < n; i += 256) {
       d0[i] -= rho[i];
