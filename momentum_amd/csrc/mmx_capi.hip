@@ -811,10 +811,13 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       }
     }
     pb->tileMasks = mmx::eliminationTileMasks(std::min(n, 512), related, dense);
-    std::vector<uint32_t> masks(64, 0u);
+    std::vector<uint32_t> masks(96, 0u);
+    uint32_t base = 0;
     for (int i = 0; i < 32; ++i) {
       masks[size_t(i)] = pb->tileMasks.rowMask[i];
       masks[size_t(32 + i)] = pb->tileMasks.colMask[i];
+      masks[size_t(64 + i)] = base; // first slot of block column i in the column-compact numbering
+      base += uint32_t(__builtin_popcount(pb->tileMasks.colMask[i]));
     }
     MMX_HIP(upload(pb->dTileMasks, masks));
     MMX_HIP(upload(pb->dTileList, pb->tileMasks.tiles));
@@ -2091,6 +2094,7 @@ static int32_t solveImpl(
   sp.maxIterations = o->max_iterations;
   sp.refine = refineSteps(pb);
   sp.tileMasks = pb->dTileMasks.as<uint32_t>();
+  sp.numTiles = int32_t(pb->tileMasks.tiles.size());
   sp.delta = deferred ? pb->sDelta.as<float>() : nullptr;
   sp.stepIter = deferred ? pb->sStepIter.as<int32_t>() : nullptr;
   sp.lambdaPer = schedule ? pb->sLambda.as<float>() : nullptr;

@@ -1821,6 +1821,94 @@ __device__ __forceinline__ void tiledFactor(
   }
 }
 
+// Panel factorisation of block column k whose nt tiles sit contiguously in `pan` (LDS; mmx_fused.hip phase H): lanes 0-15 of
+// every wave the diagonal block, redundantly; lanes 16-63 forty-eight rows below it; pivots by v_readlane.  Wave 0 also
+// finishes y_k (L_kk y_k = s_k with the rows still in registers).  floorRow: the pivot floor of row 16 k + (lane & 15)
+// (kPivotFloor x the original diagonal).  Ends with the panel complete and a barrier.  256 threads.
+__device__ __forceinline__ void tiledPanelFactor(float* pan, int nt, int k, float* g, float* invDiag, int* flags, float floorRow, int tid) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15;
+  float* Dk = pan;
+  const bool diagLane = lane < 16;
+  const int prow = 16 + 48 * wave + (lane - 16);
+  const bool active = diagLane || prow < 16 * nt;
+  float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
+  const int trow = diagLane ? lane : (prow & 15);
+  float a[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+    a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+  }
+  float bi = g[16 * k + lrow]; // s_k
+  __syncthreads();
+  float invd = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float djj = readLaneF(a[j], j);
+    bad = bad || !(djj > 0.f);
+    const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
+    a[j] *= inv;
+    if (lane == j) {
+      invd = inv;
+    }
+    // L_kk y_k = s_k rides along (lanes 0-15: row j's entry is final once column j is scaled; the other lanes carry a dummy)
+    const float yj = readLaneF(bi, j) * inv;
+    bi = (lane == j) ? yj : (lane > j ? bi - a[j] * yj : bi); // (a row's entries right of the diagonal are scratch)
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) {
+      a[c] -= a[j] * readLaneF(a[j], c);
+    }
+  }
+  if (diagLane) {
+    if (wave == 0) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
+      }
+      invDiag[16 * k + lane] = invd;
+      if (bad) {
+        flags[0] = 1;
+      }
+    }
+  } else if (active) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      Tl[tileAddr(trow, c)] = a[c];
+    }
+  }
+  if (wave == 0 && lane < 16) {
+    g[16 * k + lane] = bi;
+  }
+  __syncthreads();
+  if (16 * nt > 16 + 192) { // rows beyond 4 x 48: substitution against the finished diagonal block
+    for (int pr = 16 + 192 + tid; pr < 16 * nt; pr += 256) {
+      float* Tr = pan + 256 * (pr >> 4);
+      float x[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = ldsRow4(Tr, pr & 15, q);
+        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float sum = x[j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) {
+          sum -= x[c] * Dk[tileAddr(j, c)];
+        }
+        x[j] = sum * invDiag[16 * k + j];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        Tr[tileAddr(pr & 15, c)] = x[c];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // The 2 x 32 mask words of mmx::TileMasks in the lanes of two registers (lane i, i + 32: block i's word): a v_readlane picks one.
 struct TileMaskLanes {
   uint32_t row, col;
@@ -1853,95 +1941,10 @@ __device__ __forceinline__ void tiledFactorPairs(
     }
     return c;
   };
-  // panel factorisation of block column k whose nt tiles sit in `pan` (mmx_fused.hip phase H): lanes 0-15 of every
-  // wave the diagonal block, redundantly; lanes 16-63 forty-eight rows below it; pivots by v_readlane.  Wave 0 also
-  // finishes y_k (L_kk y_k = s_k with the rows still in registers).  Ends with the panel complete and a barrier.
   auto factorPanel = [&](float* pan, int nt, int k) {
-    float* Dk = pan;
-    const bool diagLane = lane < 16;
-    const int prow = 16 + 48 * wave + (lane - 16);
-    const bool active = diagLane || prow < 16 * nt;
-    float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
-    const int trow = diagLane ? lane : (prow & 15);
-    float a[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
-      a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
-    }
-    float bi = g[16 * k + lrow]; // s_k
     // the row's pivot floor (kPivotFloor) from the original diagonal: tile (k, k) of the tile-major H, [col][row] inside
     const float floorRow = 16 * k + lrow < n ? kPivotFloor * (H[size_t(tileIndex(k, k)) * 256 + lrow * 17] + lambda) : 0.f;
-    __syncthreads();
-    float invd = 0.f;
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float djj = readLaneF(a[j], j);
-      bad = bad || !(djj > 0.f);
-      const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
-      a[j] *= inv;
-      if (lane == j) {
-        invd = inv;
-      }
-#pragma unroll
-      for (int c = j + 1; c < 16; ++c) {
-        a[c] -= a[j] * readLaneF(a[j], c);
-      }
-    }
-    if (diagLane) {
-      if (wave == 0) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
-        }
-        invDiag[16 * k + lane] = invd;
-        if (bad) {
-          flags[0] = 1;
-        }
-      }
-    } else if (active) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        Tl[tileAddr(trow, c)] = a[c];
-      }
-    }
-    if (wave == 0) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float yj = readLaneF(bi, j) * readLaneF(invd, j);
-        bi = (lane == j) ? yj : (j < lane ? bi - a[j] * yj : bi);
-      }
-      if (lane < 16) {
-        g[16 * k + lane] = bi;
-      }
-    }
-    __syncthreads();
-    if (16 * nt > 16 + 192) { // rows beyond 4 x 48: substitution against the finished diagonal block
-      for (int pr = 16 + 192 + tid; pr < 16 * nt; pr += 256) {
-        float* Tr = pan + 256 * (pr >> 4);
-        float x[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = ldsRow4(Tr, pr & 15, q);
-          x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float sum = x[j];
-#pragma unroll
-          for (int c = 0; c < j; ++c) {
-            sum -= x[c] * Dk[tileAddr(j, c)];
-          }
-          x[j] = sum * invDiag[16 * k + j];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          Tr[tileAddr(pr & 15, c)] = x[c];
-        }
-      }
-      __syncthreads();
-    }
+    tiledPanelFactor(pan, nt, k, g, invDiag, flags, floorRow, tid);
   };
   float* pan0 = t.pan;
   float* pan1 = t.pan + size_t(NP) * 16;
@@ -2551,6 +2554,312 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
   }
   MMX_SCLK(2)
   if (bad || !sp.refine) {
+    applyStepAndBook(pb, P, b, d0, badPivot, errIter, theta, st, sp, tid);
+    if (tid == 0) {
+      refState[b] = 1;
+    }
+    return;
+  }
+  for (int i = tid; i < NP; i += 256) {
+    dvec[size_t(b) * NP + i] = d0[i];
+  }
+  if (tid == 0) {
+    refState[b] = 0;
+    if (badPivot) { // (the finish stage books the iteration; the floored pivot is reported from here)
+      st.status[b] = 2;
+    }
+  }
+}
+
+// The factor stage of the wide route with the whole (tile-sparse) factor RESIDENT in LDS -- for systems whose structurally
+// non-zero tiles (mmx::TileMasks) fit half a CU (<= 75 tiles of 1 KB + the vectors: two workgroups per CU; cfg5 has 71).
+// Same contract as choleskyFactorTiledKernel.  H's tiles are read from HBM ONCE, straight into the slots the factor's
+// tiles will occupy (column-compact: tile (I, k) at colBase[k] + rank of I in column k, so a block column's panel is
+// contiguous and tiledPanelFactor works on it in place); the left-looking update takes its operands L(I,j), L(k,j) from
+// LDS (~100 cycles instead of a dependent HBM round trip per column), every finished column is stored to the tile-major
+// factor in HBM without anybody waiting for it (the finish stage and the trust region read it there), and the backward
+// substitution of the first solve runs on the resident tiles.
+__global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
+    ProblemDev pb,
+    int P,
+    const float* __restrict__ jtj,
+    const float* __restrict__ jtr,
+    float* __restrict__ factor,
+    float* __restrict__ dvec, // [B][NP]
+    int32_t* __restrict__ refState, // [B]
+    const double* __restrict__ errIter,
+    float* __restrict__ theta,
+    SolveStateDev st,
+    StepParams sp,
+    int numTiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (st.done[b] != 0) {
+    if (tid == 0) {
+      refState[b] = 1;
+    }
+    return;
+  }
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lkg = lane >> 4, opOff = lrow * 16 + 4 * lkg;
+  const int n = pb.n, NP = (n + 15) & ~15, NB = NP >> 4;
+  // mask words and the columns' first slots in the lanes of three registers (lane i: block i's word)
+  const uint32_t vRowMask = sp.tileMasks[lane & 31], vColMask = sp.tileMasks[32 + (lane & 31)], vColBase = sp.tileMasks[64 + (lane & 31)];
+  auto rowMask = [&](int I) { return uint32_t(__builtin_amdgcn_readlane(int(vRowMask), I)); };
+  auto colMask = [&](int kk) { return uint32_t(__builtin_amdgcn_readlane(int(vColMask), kk)); };
+  auto colBase = [&](int kk) { return __builtin_amdgcn_readlane(int(vColBase), kk); };
+  auto below = [](int i) { return (1u << i) - 1u; }; // bits 0 .. i-1 (i <= 31)
+  float* tiles = smem; // [numTiles][256], swizzled (tileAddr)
+  float* g = tiles + size_t(numTiles) * 256; // [NP] g, then y, then the step
+  float* invDiag = g + NP; // [NP]
+  float* floorAll = invDiag + NP; // [NP] the rows' pivot floors: kPivotFloor x the original diagonal (incl. the damping)
+  float* red = floorAll + NP; // [4]
+  int* flags = reinterpret_cast<int*>(red + 4); // [4]
+  uint32_t* maskWords = reinterpret_cast<uint32_t*>(flags + 4); // [96] the same words for per-lane lookups (a v_readlane needs a uniform index)
+  auto tileAt = [&](int I, int j) { return tiles + 256 * (colBase(j) + __builtin_popcount(colMask(j) & below(I))); }; // (uniform)
+  const float* H = jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+  float* L = factor + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+  float lambda = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
+  if (tid == 0) {
+    flags[0] = 0;
+  }
+  if (tid < 96) {
+    maskWords[tid] = sp.tileMasks[tid];
+  }
+  for (int i = tid; i < NP; i += 256) {
+    g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
+  }
+  long long tclk = clock64();
+  // ---- H into the slots: the wave's tiles (every fourth slot), ALL its requests in flight together -- one HBM round trip
+  // for the whole matrix (kLd x 4 waves >= the tiles that fit the kernel's LDS budget)
+  {
+    constexpr int kLd = 20;
+    int k = 0;
+    uint32_t rem = colMask(0);
+    int slot = 0; // running slot of the (k, I) enumeration = colBase[k] + rank
+    auto next = [&](int& I, int& kk, int& sl) { // the next tile of the enumeration, or false (uniform)
+      while (rem == 0u) {
+        if (++k >= NB) {
+          return false;
+        }
+        rem = colMask(k);
+      }
+      I = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      kk = k;
+      sl = slot++;
+      return true;
+    };
+    bool more = true;
+    while (more) {
+      float4 hv[kLd];
+      int tI[kLd], tK[kLd], tS[kLd];
+#pragma unroll
+      for (int u = 0; u < kLd; ++u) {
+        tI[u] = tK[u] = 0, tS[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kLd; ++u) {
+        int I = 0, kk = 0, sl = 0;
+        bool have = false;
+        while (more) { // advance to the wave's next tile
+          more = next(I, kk, sl);
+          if (more && (sl & 3) == wave) {
+            have = true;
+            break;
+          }
+        }
+        if (have) {
+          tI[u] = I, tK[u] = kk, tS[u] = sl;
+          hv[u] = *reinterpret_cast<const float4*>(H + size_t(tileIndex(I, kk)) * 256 + opOff);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kLd; ++u) {
+        if (tS[u] >= 0) {
+          const float hq[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
+          float* T = tiles + 256 * tS[u];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { // padded with the identity, strict upper part of a diagonal tile zero (tiledFactorPairs::loadH)
+            const int r = 16 * tI[u] + 4 * lkg + q, cc = 16 * tK[u] + lrow;
+            T[tileAddr(4 * lkg + q, lrow)] = (r < n && cc < n) ? (r >= cc ? hq[q] : 0.f) : (r == cc ? 1.f : 0.f);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  { // damping of the FACTOR: at least kFactorDamping of the mean diagonal (mmx_device.hpp), from the resident diagonal
+    // tiles; then the diagonal gets it and every row its pivot floor
+    float tr = 0.f;
+    for (int i = tid; i < n; i += 256) {
+      tr += tiles[256 * int(maskWords[64 + (i >> 4)]) + tileAddr(i & 15, i & 15)];
+    }
+    tr = waveReduceSumF(tr);
+    if (lane == 0) {
+      red[wave] = tr;
+    }
+    __syncthreads();
+    lambda = fmaxf(lambda, kFactorDamping * ((red[0] + red[1]) + (red[2] + red[3])) / float(n > 0 ? n : 1));
+    for (int i = tid; i < NP; i += 256) {
+      float* dg = tiles + 256 * int(maskWords[64 + (i >> 4)]) + tileAddr(i & 15, i & 15);
+      const float hd = i < n ? *dg + lambda : 1.f;
+      *dg = hd;
+      floorAll[i] = i < n ? kPivotFloor * hd : 0.f;
+    }
+  }
+  __syncthreads();
+  MMX_SCLK(6)
+  // ---- left-looking factorisation, one block column at a time, everything in LDS
+  for (int k = 0; k < NB; ++k) {
+    const uint32_t cm = colMask(k), rk = rowMask(k) & below(k);
+    float* pan = tiles + 256 * colBase(k);
+    if (rk != 0u) {
+      uint32_t rem = cm;
+      for (int idx = 0; rem != 0u; ++idx) {
+        const int I = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        uint32_t m = rowMask(I) & rk;
+        if ((idx & 3) != wave || m == 0u) {
+          continue;
+        }
+        float* Tc = pan + 256 * idx;
+        v4f c0, c1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          c0[q] = Tc[tileAddr(4 * lkg + q, lrow)];
+        }
+        while (m != 0u) { // four products per trip: their eight operand reads are in flight together
+          float4 av[4], bv[4];
+          bool use[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            use[u] = m != 0u;
+            const int j = use[u] ? __builtin_ctz(m) : 0;
+            m = use[u] ? m & (m - 1u) : 0u;
+            if (use[u]) {
+              av[u] = ldsRow4(tileAt(I, j), lrow, lkg);
+              bv[u] = ldsRow4(tileAt(k, j), lrow, lkg);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (use[u]) {
+              if (u & 1) { // (two accumulators: consecutive products do not wait for each other)
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].x, bv[u].x, c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].y, bv[u].y, c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].z, bv[u].z, c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].w, bv[u].w, c1, 0, 0, 0);
+              } else {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].x, bv[u].x, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].y, bv[u].y, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].z, bv[u].z, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[u].w, bv[u].w, c0, 0, 0, 0);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Tc[tileAddr(4 * lkg + q, lrow)] = c0[q] + c1[q];
+        }
+      }
+      // the forward substitution rides along: s_k = g_k - sum_{j<k} L(k,j) y_j (wave 3)
+      if (wave == 3) {
+        float acc = 0.f;
+        uint32_t m = rk;
+        while (m != 0u) { // four blocks per trip, reads in flight together
+          float4 lv[4], yv[4];
+          bool use[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            use[u] = m != 0u;
+            const int j = use[u] ? __builtin_ctz(m) : 0;
+            m = use[u] ? m & (m - 1u) : 0u;
+            if (use[u]) {
+              lv[u] = ldsRow4(tileAt(k, j), lrow, lkg);
+              yv[u] = *reinterpret_cast<const float4*>(g + 16 * j + 4 * lkg);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (use[u]) {
+              acc = dot4(lv[u], yv[u], acc);
+            }
+          }
+        }
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < 16) {
+          g[16 * k + lane] -= acc;
+        }
+      }
+      __syncthreads();
+    }
+    MMX_SCLK(7)
+    {
+      tiledPanelFactor(pan, __builtin_popcount(cm), k, g, invDiag, flags, floorAll[16 * k + lrow], tid);
+    }
+    MMX_SCLK(1)
+  }
+  const bool badPivot = flags[0] != 0;
+  float* d0 = g; // y = L^-1 g; solved in place: L^T d = y on the resident tiles
+  MMX_SCLK(0)
+  for (int k = NB - 1; k >= 0; --k) {
+    const float* Dk = tiles + 256 * colBase(k);
+    if (wave == 0) { // x_k = L_kk^-T x_k: sixteen steps, the lane's column of the diagonal tile in registers
+      float dgc[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        dgc[c] = Dk[tileAddr(c, lrow)]; // L(16k + c, 16k + lrow): zero above the diagonal
+      }
+      float bi = d0[16 * k + lrow];
+      const float invd = invDiag[16 * k + lrow]; // 1 / l_jj (0 for a dropped column)
+#pragma unroll
+      for (int j = 15; j >= 0; --j) {
+        const float xj = readLaneF(bi, j) * readLaneF(invd, j);
+        bi = (lrow == j) ? xj : bi - dgc[j] * xj;
+      }
+      if (lane < 16) {
+        d0[16 * k + lane] = bi;
+      }
+    }
+    __syncthreads();
+    const uint32_t present = rowMask(k) & below(k); // row block k's tiles left of the diagonal
+    // x[c] -= sum_r L(16k + r, c) x_k[r] for the columns c < 16 k whose tile (k, c >> 4) exists: a thread per column
+    if (present != 0u) {
+      for (int c = tid; c < 16 * k; c += 256) {
+        const int jb = c >> 4;
+        if ((present >> jb & 1u) == 0u) {
+          continue;
+        }
+        const float* T = tiles + 256 * (int(maskWords[64 + jb]) + __builtin_popcount(maskWords[32 + jb] & below(k))); // tile (k, jb)
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc += T[tileAddr(r, c & 15)] * d0[16 * k + r];
+        }
+        d0[c] -= acc;
+      }
+      __syncthreads();
+    }
+  }
+  MMX_SCLK(2)
+  // the factor goes to its tile-major home in HBM (the finish stage and the trust region read it there) -- only now: a
+  // __syncthreads() waits for every outstanding global store of the wave, so stores issued per finished column would put
+  // an HBM round trip into each of the barriers above (measured: 4.6 k cycles per panel instead of 2.5 k)
+  for (int k = 0; k < NB; ++k) {
+    uint32_t rem = colMask(k);
+    const float* pan = tiles + 256 * colBase(k);
+    for (int idx = 0; rem != 0u; ++idx) {
+      const int I = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      if ((idx & 3) == wave) {
+        *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k)) * 256 + opOff) = ldsRow4(pan + 256 * idx, lrow, lkg);
+      }
+    }
+  }
+  if (!sp.refine) {
     applyStepAndBook(pb, P, b, d0, badPivot, errIter, theta, st, sp, tid);
     if (tid == 0) {
       refState[b] = 1;
@@ -3294,6 +3603,25 @@ hipError_t launchCholeskyFactorTiled(
     hipStream_t stream) {
   if (pb.n > 512) {
     return hipErrorInvalidValue;
+  }
+  // the factor resident in LDS when its structurally non-zero tiles + the vectors fit half a CU (two workgroups per CU)
+  {
+    const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
+    const size_t resident = (size_t(sp.numTiles) * 256 + 3 * NP + 8 + 96) * sizeof(float);
+#ifdef MMX_EXP_NORESIDENT // A/B build variant (MMX_BUILD_VARIANT=noresident): the in-HBM pairs form for every system
+    const bool useResident = false;
+#else
+    const bool useResident = sp.numTiles > 0 && resident <= 80 * 1024 - 64;
+#endif
+    if (useResident) {
+      static LdsLimitCache ldsLimit;
+      hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(choleskyFactorResidentKernel), resident);
+      if (rc != hipSuccess) {
+        return rc;
+      }
+      hipLaunchKernelGGL(choleskyFactorResidentKernel, dim3(pb.B), dim3(256), resident, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp, int(sp.numTiles));
+      return hipGetLastError();
+    }
   }
   const size_t lds = tiledLdsFloats(pb.n, 0, nullptr, nullptr) * sizeof(float);
   if (lds > 64 * 1024) { // two panels of a 450-512-parameter system: beyond the default dynamic LDS limit
