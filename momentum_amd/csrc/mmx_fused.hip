@@ -2605,7 +2605,11 @@ __host__ __device__ inline size_t treeRefineLdsFloats(int J, int P, int U, int n
   return off;
 }
 
-__global__ void __launch_bounds__(256, 2) treeRefineKernel(
+// kWaves: wavefronts of the workgroup -- 4 for problems with parameter rows / further joint blocks / per-instance parents
+// (their helpers stride by 256 threads), 8 for the plain problem: the kernel holds ~71 KB of LDS on the 300-joint rig (two
+// workgroups per CU), so four waves are ONE per SIMD and every tree pass a chain of exposed LDS round trips
+template <int kWaves>
+__global__ void __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) treeRefineKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
@@ -2618,6 +2622,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     float lambdaAll,
     const float* __restrict__ lambdaPer) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kT = 64 * kWaves;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   if (refState[b] != 0) {
@@ -2639,40 +2644,40 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   {
     const TreeStateLayout sl = treeStateLayout(J, U);
     const float* stb = state + size_t(b) * sl.total;
-    for (int i = tid; i < kJs * J; i += 256) {
+    for (int i = tid; i < kJs * J; i += kT) {
       s.js[i] = stb[sl.js + i];
     }
-    for (int i = tid; i < 3 * U; i += 256) {
+    for (int i = tid; i < 3 * U; i += kT) {
       s.up[i] = stb[sl.up + i];
       s.ur[i] = stb[sl.ur + i];
     }
-    for (int i = tid; i < U; i += 256) {
+    for (int i = tid; i < U; i += kT) {
       s.us[i] = stb[sl.us + i];
     }
-    for (int i = tid; i < NP; i += 256) {
+    for (int i = tid; i < NP; i += kT) {
       s.d0[i] = i < n ? dvec[size_t(b) * NP + i] : 0.f;
     }
-    for (int i = tid; i < P; i += 256) {
+    for (int i = tid; i < P; i += kT) {
       t.col[i] = -1;
       t.th[i] = theta[size_t(b) * P + i];
     }
     if (hasGen) {
       const float* gs = genState + size_t(b) * (size_t(rowsGp) * gst + rowsGp);
-      for (int i = tid; i < rowsGp * gst; i += 256) {
+      for (int i = tid; i < rowsGp * gst; i += kT) {
         t.gJ[i] = gs[i];
       }
-      for (int i = tid; i < rowsGp; i += 256) {
+      for (int i = tid; i < rowsGp; i += kT) {
         t.gRes[i] = gs[size_t(rowsGp) * gst + i];
       }
     }
-    for (int i = tid; i < J; i += 256) {
+    for (int i = tid; i < J; i += kT) {
       t.subSize[i] = fd.subSize[i];
       t.loadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
     }
-    for (int i = tid; i <= J; i += 256) {
+    for (int i = tid; i <= J; i += kT) {
       t.posUnitStart[i] = fd.posUnitStart[i];
     }
-    for (int i = tid; i < U; i += 256) {
+    for (int i = tid; i < U; i += kT) {
       t.posUnits[i] = fd.posUnits[i];
     }
   }
@@ -2682,11 +2687,11 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     fv.unitPos = t.unitPos;
   }
   treeSumRanges(t.subSize, t.loadedPos, fv.numLoaded, J, tid, t.kRange);
-  for (int c = tid; c < n; c += 256) {
+  for (int c = tid; c < n; c += kT) {
     t.col[fd.solveList[c]] = c;
   }
   if (hasGen) { // w_g = r_g - J_g d, in place (each row by one thread; consumed by the rho loop, several barriers later)
-    for (int r = tid; r < fd.genRows; r += 256) {
+    for (int r = tid; r < fd.genRows; r += kT) {
       float a = t.gRes[r];
       for (int c = 0; c < n; ++c) {
         a -= t.gJ[r * gst + c] * s.d0[c];
@@ -2696,7 +2701,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   }
   __syncthreads();
   // joint-parameter delta jd = transform * delta
-  csrRowsPrefetched(
+  csrRowsPrefetched<kT>(
       rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid,
       [&](int c) {
         const int cs = t.col[c];
@@ -2705,7 +2710,7 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
       [&](int r, float a) { s.jd[r] = a; });
   __syncthreads();
   // tangent pass: per joint (by DFS position) C = T - Om x t - ln2 sd t, W = Om, S = sd ...
-  for (int k = tid; k < J; k += 256) {
+  for (int k = tid; k < J; k += kT) {
     const int q = fd.dfsJoint[k];
     const float* ja = s.js + kJs * q;
     const float* d = s.jd + 7 * q;
@@ -2722,11 +2727,11 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
   }
   __syncthreads();
   // ... summed over each joint's ancestor chain
-  treeSum<7, false, kTan, 8>(fv, s.tanOwn, s.tanPre, J, wave, lane);
+  treeSumT<7, false, kTan, 8>(fv.subSize, fv.loadedPos, fv.numLoaded, s.tanOwn, s.tanPre, J, wave, kWaves, lane);
   __syncthreads();
   // w = r - J d, y = sigma w per unit, then the first-order own sums
   if (U <= J) {
-    for (int u = tid; u < U; u += 256) {
+    for (int u = tid; u < U; u += kT) {
       const float* pre = s.tanPre + kTan * fv.unitPos[u];
       const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
       const bool point = u < fv.Kp;
@@ -2738,9 +2743,9 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
       firstOrderMoments(s.sub1 + kC1 * u, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
     }
     __syncthreads();
-    gatherOwnSums<kC1, kC1>(fv, s, s.sub1, tid);
+    gatherOwnSums<kC1, kC1, kT>(fv, s, s.sub1, tid);
   } else {
-    for (int k = tid; k < J; k += 256) {
+    for (int k = tid; k < J; k += kT) {
       const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
       float a1[kC1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (e1 > e0) {
@@ -2769,10 +2774,10 @@ __global__ void __launch_bounds__(256, 2) treeRefineKernel(
     }
   }
   __syncthreads();
-  treeSum<kC1, true, kC1, 8>(fv, s.own1, s.sub1, J, wave, lane, t.kRange);
+  treeSumT<kC1, true, kC1, 8>(fv.subSize, fv.loadedPos, fv.numLoaded, s.own1, s.sub1, J, wave, kWaves, lane, t.kRange);
   __syncthreads();
   // J^T w per column: the primary source slot, then the extras (slot numbering of phase F)
-  for (int c = tid; c < NP; c += 256) {
+  for (int c = tid; c < NP; c += kT) {
     float a = 0.f;
     if (c < n) {
       auto slotShare = [&](int e) {
@@ -2822,14 +2827,25 @@ hipError_t launchTreeRefine(
   if (lds > 160 * 1024 - 64) {
     return hipErrorInvalidValue;
   }
+  const bool extra = pb.M > pb.rowsJoint || fd.GT > 0 || pb.instPosParent != nullptr || pb.instOriParent != nullptr;
+  if (!extra) { // (cfg5, one box, per launch: four waves 0.83 ms, eight 0.64 ms, sixteen 0.80 ms)
+    constexpr int kRefWaves = 8;
+    static LdsLimitCache ldsLimitWide;
+    hipError_t rc = ldsLimitWide.ensure(reinterpret_cast<const void*>(treeRefineKernel<kRefWaves>), lds);
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    hipLaunchKernelGGL((treeRefineKernel<kRefWaves>), dim3(pb.B), dim3(64 * kRefWaves), lds, stream, rig, pb, fd, theta, state, genState, dvec, rhoVec, refState, lambda, lambdaPer);
+    return hipGetLastError();
+  }
   static LdsLimitCache ldsLimit;
   {
-    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(treeRefineKernel), lds);
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(treeRefineKernel<4>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
   }
-  hipLaunchKernelGGL(treeRefineKernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, state, genState, dvec, rhoVec, refState, lambda, lambdaPer);
+  hipLaunchKernelGGL(treeRefineKernel<4>, dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, state, genState, dvec, rhoVec, refState, lambda, lambdaPer);
   return hipGetLastError();
 }
 #endif
