@@ -68,7 +68,10 @@ typedef enum mmx_status {
                               instantiation does not meet such pivots, its float instantiation hands Eigen's aborted
                               factor to solve().  The objective converges like the reference's; the components of
                               theta that J does not determine differ from the double solver's minimum-norm ones
-                              (tests/test_gpu_weak_damping.py). */
+                              (tests/test_gpu_weak_damping.py).  Since ABI 8 every single-precision
+                              FACTOR is damped by at least 1e-5 of the mean diagonal of J^T J (the refinement measures
+                              its residual with the caller's lambda through J, so the step is the caller's wherever J
+                              determines it): the drop rule is the last resort and this status is rare. */
 
 /* Where the caller's bulk arrays live. */
 #define MMX_MEM_HOST 0
@@ -97,7 +100,15 @@ typedef enum mmx_status {
                                    otherwise (driven from the host: factor / decide / trial kernels per trust step;
                                    larger systems, further joint error functions, ellipsoid limits); not on
                                    MMX_ROUTE_EXPLICIT_JACOBIAN and not in mmx_solve_f64.  do_line_search and
-                                   regularization are not read by this rule. */
+                                   regularization are not read by this rule.
+                                   DEVIATION from TrustRegionQRT: the reference's Householder QR of J takes the rule's
+                                   (almost) zero damping on rank-deficient / under-determined J; an fp32 Cholesky of
+                                   J^T J cannot, so the factor is damped by at least 1e-5 of the mean diagonal of J^T J
+                                   (the refinement keeps the rule's damping): in the directions J does not determine
+                                   the step is the more damped one -- the trust-region logic (radius, gain ratio,
+                                   accept / reject) runs on that step; objective and iteration counts follow the
+                                   oracle's on the reference's fixtures (tests/test_gpu_trust_region.py), the
+                                   undetermined components of theta need not. */
 
 /*
  * Static rig = Skeleton + ParameterTransform of a momentum::Character
@@ -386,7 +397,7 @@ int32_t mmx_problem_set_instance_parents(
  * A pinned route the problem does not fit makes mmx_solve return MMX_ERR_UNSUPPORTED; it never falls through silently.
  *   MMX_ROUTE_FUSED              one launch, one workgroup per instance, the system in LDS (<= 224 solved parameters)
  *   MMX_ROUTE_WIDE               normal equations from the tree moments, left-looking Cholesky with the factor in HBM,
- *                                refinement through the tree (<= 512 solved parameters; the default from 161 on)
+ *                                refinement through the tree (<= 512 solved parameters; the default from 129 on)
  *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores) -> Cholesky step; the route for problems
  *                                outside the tree kernels' scope
  * The route does not change WHAT is computed (same algorithm, same refinement); results of different routes agree to

@@ -1954,10 +1954,12 @@ static int32_t solveImpl(
   const int n = ds.n;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // Systems of 161-224 solved parameters fit the fused solve only with one workgroup per CU (78-105 KB of tiles): when the
-  // wide path's tree kernels cover the problem it is the faster route (72-joint humanoid, measured with scripts/gpu_route.sh:
-  // n = 189: 4.2e5 against 3.2e5 solves/s, n = 219: 3.1e5 against 2.3e5; n = 126: 7.2e5 against 1.0e6, n = 96: 9.2e5 against
-  // 1.57e6 -- below twelve 16-blocks the fused solve stays).  mmx_tuning::route pins either.
+  // Systems of 129-224 solved parameters fit the fused solve only with one workgroup per CU (its instantiations for ten,
+  // twelve and fourteen 16-blocks: 55-105 KB of tiles): when the wide path's tree kernels cover the problem it is the
+  // faster route since its factor is tile-sparse (72-joint humanoid with 219 parameters, random enabled subsets, B = 4096,
+  // scripts/route_crossover.py, wide against fused solves/s: n = 105: 5.0e5 / 5.0e5, 126: 4.6e5 / 4.6e5, 136: 4.5e5 / 3.7e5,
+  // 154: 4.2e5 / 3.7e5, 166: 3.9e5 / 2.8e5, 183: 3.5e5 / 2.7e5, 219: 3.3e5 / 2.2e5) -- up to eight blocks (two or three
+  // workgroups per CU) the fused solve stays.  mmx_tuning::route pins either.
   const int32_t route = pb->tuning.route;
   const bool forceWide = route == MMX_ROUTE_WIDE;
   const bool trust = o->step_rule == MMX_STEP_TRUST_REGION;
@@ -1965,7 +1967,7 @@ static int32_t solveImpl(
   // small kernels per trust step: it takes the rule only where the fused solve cannot -- more than 224 solved
   // parameters, further joint error functions / ellipsoid limits -- or when pinned)
   const bool trustNeedsWide = trust && (!fusedUsable(pb) || pb->fdev.GT > 0);
-  const bool preferWide = (forceWide || trustNeedsWide || (!trust && mmx::fusedBlocksFor(pb->fdev.n) >= 12)) &&
+  const bool preferWide = (forceWide || trustNeedsWide || (!trust && mmx::fusedBlocksFor(pb->fdev.n) >= 10)) &&
       treeNormalEquationsUsable(pb) && route != MMX_ROUTE_FUSED && route != MMX_ROUTE_EXPLICIT_JACOBIAN;
   const bool legacy = route == MMX_ROUTE_EXPLICIT_JACOBIAN;
   const bool takeFused = fusedUsable(pb) && !legacy && !preferWide && !(pb->fdev.GT > 0 && o->step_rule == MMX_STEP_TRUST_REGION);
