@@ -819,6 +819,13 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       masks[size_t(64 + i)] = base; // first slot of block column i in the column-compact numbering
       base += uint32_t(__builtin_popcount(pb->tileMasks.colMask[i]));
     }
+    for (int k = 0; k < pb->tileMasks.NB && k < 32; ++k) { // [96 + slot]: the tile in that slot, I | k << 8 (the resident kernels' load lists)
+      for (int I = k; I < 32; ++I) {
+        if (pb->tileMasks.colMask[k] >> I & 1u) {
+          masks.push_back(uint32_t(I) | uint32_t(k) << 8);
+        }
+      }
+    }
     MMX_HIP(upload(pb->dTileMasks, masks));
     MMX_HIP(upload(pb->dTileList, pb->tileMasks.tiles));
     pb->fdev.tileList = pb->dTileList.as<int32_t>();

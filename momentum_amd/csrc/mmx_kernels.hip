@@ -2571,6 +2571,63 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
   }
 }
 
+constexpr int kResidentLoads = 20; // 16-byte requests a lane of the resident kernels keeps in flight while a matrix comes in
+
+// Substitutions on a factor whose structurally non-zero tiles are resident in LDS (column-compact slots, swizzled tiles:
+// choleskyFactorResidentKernel).  maskWords: the 96 words of StepParams::tileMasks in LDS (per-lane lookups), vRowMask /
+// vColMask / vColBase: the same words in the lanes of registers (uniform lookups by v_readlane).  invDiag: 1 / l_jj per
+// row (LDS) or null: taken from the diagonal tiles.  x: LDS, in place.  256 threads.
+__device__ __forceinline__ void residentSweepBackward(
+    const float* tiles, const uint32_t* maskWords, uint32_t vRowMask, uint32_t vColBase, int NB, float* x, const float* invDiag, int tid) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 15;
+  auto below = [](int i) { return (1u << i) - 1u; };
+  for (int k = NB - 1; k >= 0; --k) {
+    const float* Dk = tiles + 256 * __builtin_amdgcn_readlane(int(vColBase), k);
+    if (wave == 0) { // x_k = L_kk^-T x_k: sixteen steps, the lane's column of the diagonal tile in registers
+      float dgc[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        dgc[c] = Dk[tileAddr(c, lrow)]; // L(16k + c, 16k + lrow): zero above the diagonal
+      }
+      float bi = x[16 * k + lrow];
+      float invd; // 1 / l_jj (0 for a dropped column)
+      if (invDiag != nullptr) {
+        invd = invDiag[16 * k + lrow];
+      } else {
+        const float dd = Dk[tileAddr(lrow, lrow)];
+        invd = dd > 0.f ? 1.f / dd : 0.f;
+      }
+#pragma unroll
+      for (int j = 15; j >= 0; --j) {
+        const float xj = readLaneF(bi, j) * readLaneF(invd, j);
+        bi = (lrow == j) ? xj : bi - dgc[j] * xj;
+      }
+      if (lane < 16) {
+        x[16 * k + lane] = bi;
+      }
+    }
+    __syncthreads();
+    const uint32_t present = uint32_t(__builtin_amdgcn_readlane(int(vRowMask), k)) & below(k); // row block k's tiles left of the diagonal
+    // x[c] -= sum_r L(16k + r, c) x_k[r] for the columns c < 16 k whose tile (k, c >> 4) exists: a thread per column
+    if (present != 0u) {
+      for (int c = tid; c < 16 * k; c += 256) {
+        const int jb = c >> 4;
+        if ((present >> jb & 1u) == 0u) {
+          continue;
+        }
+        const float* T = tiles + 256 * (int(maskWords[64 + jb]) + __builtin_popcount(maskWords[32 + jb] & below(k))); // tile (k, jb)
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc += T[tileAddr(r, c & 15)] * x[16 * k + r];
+        }
+        x[c] -= acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // The factor stage of the wide route with the whole (tile-sparse) factor RESIDENT in LDS -- for systems whose structurally
 // non-zero tiles (mmx::TileMasks) fit half a CU (<= 75 tiles of 1 KB + the vectors: two workgroups per CU; cfg5 has 71).
 // Same contract as choleskyFactorTiledKernel.  H's tiles are read from HBM ONCE, straight into the slots the factor's
@@ -2631,59 +2688,27 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   }
   long long tclk = clock64();
   // ---- H into the slots: the wave's tiles (every fourth slot), ALL its requests in flight together -- one HBM round trip
-  // for the whole matrix (kLd x 4 waves >= the tiles that fit the kernel's LDS budget)
-  {
-    constexpr int kLd = 20;
-    int k = 0;
-    uint32_t rem = colMask(0);
-    int slot = 0; // running slot of the (k, I) enumeration = colBase[k] + rank
-    auto next = [&](int& I, int& kk, int& sl) { // the next tile of the enumeration, or false (uniform)
-      while (rem == 0u) {
-        if (++k >= NB) {
-          return false;
-        }
-        rem = colMask(k);
-      }
-      I = __builtin_ctz(rem);
-      rem &= rem - 1u;
-      kk = k;
-      sl = slot++;
-      return true;
-    };
-    bool more = true;
-    while (more) {
-      float4 hv[kLd];
-      int tI[kLd], tK[kLd], tS[kLd];
+  // for the whole matrix (4 x kResidentLoads >= the tiles that fit the kernel's LDS budget)
+  for (int s0 = 0; s0 < numTiles; s0 += 4 * kResidentLoads) {
+    float4 hv[kResidentLoads];
 #pragma unroll
-      for (int u = 0; u < kLd; ++u) {
-        tI[u] = tK[u] = 0, tS[u] = -1;
-      }
+    for (int u = 0; u < kResidentLoads; ++u) {
+      const int sl = min(s0 + 4 * u + wave, numTiles - 1); // (clamped: unconditional, independent requests)
+      const int code = int(sp.tileMasks[96 + sl]); // I | k << 8 (uniform)
+      hv[u] = *reinterpret_cast<const float4*>(H + size_t(tileIndex(code & 0xff, code >> 8)) * 256 + opOff);
+    }
 #pragma unroll
-      for (int u = 0; u < kLd; ++u) {
-        int I = 0, kk = 0, sl = 0;
-        bool have = false;
-        while (more) { // advance to the wave's next tile
-          more = next(I, kk, sl);
-          if (more && (sl & 3) == wave) {
-            have = true;
-            break;
-          }
-        }
-        if (have) {
-          tI[u] = I, tK[u] = kk, tS[u] = sl;
-          hv[u] = *reinterpret_cast<const float4*>(H + size_t(tileIndex(I, kk)) * 256 + opOff);
-        }
-      }
+    for (int u = 0; u < kResidentLoads; ++u) {
+      const int sl = s0 + 4 * u + wave;
+      if (sl < numTiles) {
+        const int code = int(sp.tileMasks[96 + sl]);
+        const int tI = code & 0xff, tK = code >> 8;
+        const float hq[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
+        float* T = tiles + 256 * sl;
 #pragma unroll
-      for (int u = 0; u < kLd; ++u) {
-        if (tS[u] >= 0) {
-          const float hq[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
-          float* T = tiles + 256 * tS[u];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { // padded with the identity, strict upper part of a diagonal tile zero (tiledFactorPairs::loadH)
-            const int r = 16 * tI[u] + 4 * lkg + q, cc = 16 * tK[u] + lrow;
-            T[tileAddr(4 * lkg + q, lrow)] = (r < n && cc < n) ? (r >= cc ? hq[q] : 0.f) : (r == cc ? 1.f : 0.f);
-          }
+        for (int q = 0; q < 4; ++q) { // padded with the identity, strict upper part of a diagonal tile zero (tiledFactorPairs::loadH)
+          const int r = 16 * tI + 4 * lkg + q, cc = 16 * tK + lrow;
+          T[tileAddr(4 * lkg + q, lrow)] = (r < n && cc < n) ? (r >= cc ? hq[q] : 0.f) : (r == cc ? 1.f : 0.f);
         }
       }
     }
@@ -2805,45 +2830,7 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   const bool badPivot = flags[0] != 0;
   float* d0 = g; // y = L^-1 g; solved in place: L^T d = y on the resident tiles
   MMX_SCLK(0)
-  for (int k = NB - 1; k >= 0; --k) {
-    const float* Dk = tiles + 256 * colBase(k);
-    if (wave == 0) { // x_k = L_kk^-T x_k: sixteen steps, the lane's column of the diagonal tile in registers
-      float dgc[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        dgc[c] = Dk[tileAddr(c, lrow)]; // L(16k + c, 16k + lrow): zero above the diagonal
-      }
-      float bi = d0[16 * k + lrow];
-      const float invd = invDiag[16 * k + lrow]; // 1 / l_jj (0 for a dropped column)
-#pragma unroll
-      for (int j = 15; j >= 0; --j) {
-        const float xj = readLaneF(bi, j) * readLaneF(invd, j);
-        bi = (lrow == j) ? xj : bi - dgc[j] * xj;
-      }
-      if (lane < 16) {
-        d0[16 * k + lane] = bi;
-      }
-    }
-    __syncthreads();
-    const uint32_t present = rowMask(k) & below(k); // row block k's tiles left of the diagonal
-    // x[c] -= sum_r L(16k + r, c) x_k[r] for the columns c < 16 k whose tile (k, c >> 4) exists: a thread per column
-    if (present != 0u) {
-      for (int c = tid; c < 16 * k; c += 256) {
-        const int jb = c >> 4;
-        if ((present >> jb & 1u) == 0u) {
-          continue;
-        }
-        const float* T = tiles + 256 * (int(maskWords[64 + jb]) + __builtin_popcount(maskWords[32 + jb] & below(k))); // tile (k, jb)
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc += T[tileAddr(r, c & 15)] * d0[16 * k + r];
-        }
-        d0[c] -= acc;
-      }
-      __syncthreads();
-    }
-  }
+  residentSweepBackward(tiles, maskWords, vRowMask, vColBase, NB, d0, invDiag, tid);
   MMX_SCLK(2)
   // the factor goes to its tile-major home in HBM (the finish stage and the trust region read it there) -- only now: a
   // __syncthreads() waits for every outstanding global store of the wave, so stores issued per finished column would put
@@ -3647,6 +3634,8 @@ hipError_t launchCholeskyFinishTiled(
     const StepParams& sp,
     int round,
     hipStream_t stream) {
+  // (the sweeps on a factor brought into LDS in one round trip -- the form choleskyFactorResidentKernel's first solve uses --
+  // were built for this stage too and measured slower: 0.61 against 0.53 ms on cfg5; two workgroups per CU instead of four)
   hipLaunchKernelGGL(choleskyFinishTiledKernel, dim3(pb.B), dim3(256), 0, stream, pb, P, factor, dvec, rhoVec, refState, errIter, theta, st, sp, round);
   return hipGetLastError();
 }

@@ -82,7 +82,8 @@ struct StepParams {
   float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
   long long* clk; // profiling aid (MMX_PHASE_CLOCKS): per-phase cycles of block 0, or null
   // tile structure of the tile-major factor (mmx::TileMasks): [0..31] rowMask, [32..63] colMask, [64..95] colBase (tiles
-  // in the columns before block column k: the column-compact slot numbering of the LDS-resident factor).  The tiled
+  // in the columns before block column k: the column-compact slot numbering of the LDS-resident factor), [96 + slot]:
+  // the tile in that slot, I | k << 8.  The tiled
   // factor, its sweeps and treeNormalEquationsKernel touch only the tiles named here; the others are never written nor read.
   const uint32_t* tileMasks;
   int32_t numTiles; // structurally non-zero tiles
