@@ -19,7 +19,7 @@ for f in sorted(glob.glob(sys.argv[1]+"/*.txt")):
         if m and cur is not None: cur[m.group(1)]=int(m.group(2))
 names=[r["name"] for r in rows]
 dem=subprocess.run([__import__("shutil").which("c++filt") or "c++filt"],input="\n".join(names),capture_output=True,text=True).stdout.split("\n")
-want=("fusedSolveKernel<6, 0,","fusedSolveKernel<6, 2,","fusedSolveKernel<4, 0, false, false, 0","treeNormalEquationsKernel","treeRefineKernel","fkJacobianKernel<true","choleskyFactorTiledKernel","choleskyFinishTiledKernel","choleskyStepKernel","choleskyStepTiledKernel","stepUpdateKernel","normalEquationsMfmaKernel","trustDecideKernel")
+want=("fusedSolveKernel<6, 0,","fusedSolveKernel<6, 2,","fusedSolveKernel<4, 0, false, false, 0","treeNormalEquationsKernel","treeRefineKernel","fkJacobianKernel<true","choleskyFactorTiledKernel","choleskyFactorResidentKernel","choleskyFinishTiledKernel","choleskyStepKernel","choleskyStepTiledKernel","stepUpdateKernel","normalEquationsMfmaKernel","trustDecideKernel")
 print("kernel resource usage (hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage)")
 print(f"{'kernel':<78} {'VGPR':>5} {'SGPR':>5} {'vspill':>6} {'sspill':>6} {'scratch B':>9} {'waves/SIMD':>10}")
 for r,d in zip(rows,dem):
