@@ -1194,8 +1194,8 @@ int32_t mmx_problem_create(
   pb->Ko = num_ori;
   pb->U = num_pos + 3 * num_ori;
   pb->M = 3 * pb->U;
-  pb->dev.lossPos = mmx::LossDev{0, 2.f, 1.f};
-  pb->dev.lossOri = mmx::LossDev{0, 2.f, 1.f};
+  pb->dev.lossPos = mmx::LossDev{0, 2.f, 1.f, 1.f};
+  pb->dev.lossOri = mmx::LossDev{0, 2.f, 1.f, 1.f};
   if (num_pos > 0) {
     pb->posParent.assign(pos_parent, pos_parent + num_pos);
   }
@@ -1452,10 +1452,11 @@ int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* 
     return fail(MMX_ERR_INVALID_ARGUMENT, "constraint data: unknown memory space");
   }
   auto makeLoss = [](float alpha, float cc) { // GeneralizedLossT ctor (generalized_loss.cpp:81-101), kEps = 1e-9
-    mmx::LossDev l{0, 2.f, 1.f};
+    mmx::LossDev l{0, 2.f, 1.f, 1.f};
     if (cc > 0.f) {
       l.alpha = alpha;
       l.invC2 = 1.f / (cc * cc);
+      l.c = cc;
       const float kEps = 1e-9f;
       if (alpha >= 2.f - kEps && alpha <= 2.f + kEps) {
         l.type = 0;
@@ -2283,15 +2284,16 @@ int32_t mmx_solve_f64(
       o->do_line_search != MMX_LINE_SEARCH_DIRECTIONAL) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "unknown do_line_search rule");
   }
-  if (pb->dev.G > 0 || pb->dev.NE > 0) {
+  if (pb->dev.NE > 0) {
     return fail(
         MMX_ERR_UNSUPPORTED,
-        "mmx_solve_f64: position / orientation constraints, parameter limits and the model-parameter prior (the further joint error functions and ellipsoid limits are single precision)");
+        "mmx_solve_f64: position / orientation constraints, the further joint error functions, parameter limits and the model-parameter prior (ellipsoid limits are single precision)");
   }
-  const size_t B = size_t(pb->B), n = size_t(pb->solveN), M = size_t(3 * pb->U);
+  const size_t B = size_t(pb->B), n = size_t(pb->solveN), M = size_t(pb->dev.rowsJoint);
+  const int genRowsF64 = pb->dev.rowsJoint - 3 * pb->U;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN) > 160 * 1024) {
+  if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G, genRowsF64) > 160 * 1024) {
     return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: rig beyond the kernel's LDS budget");
   }
   MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));

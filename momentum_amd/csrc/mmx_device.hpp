@@ -166,6 +166,7 @@ __device__ __forceinline__ void selectInstanceRig(RigDev& rig, int b) {
 struct LossDev {
   int32_t type; // 0 L2, 1 L1 / pseudo-Huber, 2 Cauchy, 3 Welsch, 4 Barron's general form
   float alpha, invC2;
+  float c; // the scale as given (1 when none was): GeneralizedLossT<double> forms 1 / c^2 in double (mmx_f64.hip)
 };
 __device__ __forceinline__ float lossValue(const LossDev& l, float s) {
   const float q = s * l.invC2;

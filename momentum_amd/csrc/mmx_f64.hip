@@ -80,7 +80,7 @@ __device__ __forceinline__ DQ dqnormalized(DQ q) {
   return q;
 }
 __device__ __forceinline__ double dlossValue(const LossDev& l, double s) { // generalized_loss.cpp:104-140
-  const double ic = double(l.invC2), q = s * ic;
+  const double ic = 1.0 / (double(l.c) * double(l.c)), q = s * ic; // (GeneralizedLossT<double>: 1 / c^2 in double)
   switch (l.type) {
     case 0:
       return q;
@@ -97,7 +97,7 @@ __device__ __forceinline__ double dlossValue(const LossDev& l, double s) { // ge
   }
 }
 __device__ __forceinline__ double dlossDeriv(const LossDev& l, double s) {
-  const double ic = double(l.invC2), q = s * ic;
+  const double ic = 1.0 / (double(l.c) * double(l.c)), q = s * ic; // (GeneralizedLossT<double>: 1 / c^2 in double)
   switch (l.type) {
     case 0:
       return ic;
@@ -122,7 +122,7 @@ struct F64Lds {
   double* jp; // [7 J]
   double* js; // [kDs J]
   double* uv; // [3 U] unit world vector
-  double* ur; // [3 U] scaled residual rows
+  double* ur; // [M] scaled residual rows: 3 U of the position / orientation blocks, then the further joint error functions'
   double* us; // [U] derivScale
   int* utin; // [U]
   double* g; // [n]
@@ -131,6 +131,7 @@ struct F64Lds {
   int* flags; // [4]
   int* colOf; // [P] solve column of a model parameter, or -1
   double* jl; // [n][rc + 1] a chunk of J's rows, column-major (normal equations)
+  double* gev; // [G][kGevD] the further joint error functions' evaluations (JointEvalD, rows scaled by sigma)
 };
 
 // ParameterTransformT<double>::apply + SkeletonStateT<double>::set (parameter_transform.cpp:110-124,
@@ -275,6 +276,143 @@ __device__ double paramRowsErrorF64(const RigDev& rig, const ProblemDev& pb, con
 }
 
 // SkeletonSolverFunctionT<double>::getError (skeleton_solver_function.cpp:64-83; rounded through float, :82)
+// The further JointErrorFunctionT<double> specialisations (Plane / HalfPlane, AimDist / AimDir, FixedAxisDiff / Cos /
+// Angle, Normal): evalFunction + the weighting of getJacobian in double -- evalJointConstraint of mmx_device.hpp with T =
+// double (the constraint data stay float like the reference's tensors; joint_error_function-inl.h:197-226).
+struct JointEvalD {
+  D3 vp, vn;
+  double dp[9], dn[9];
+  double f[3];
+  double sigma, werr;
+  int nrows;
+  bool hasPoint, hasDir;
+};
+constexpr int kGevD = 26; // doubles per constraint in LDS: vp(3) vn(3) sigma dp(9) sigma dn(9) | tin, row | flags, -
+
+__device__ __forceinline__ D3 dnormalizedOrSame(D3 a) { // Eigen normalized(): unchanged when the norm is zero
+  const double n2 = ddot(a, a);
+  return n2 > 0.0 ? (1.0 / sqrt(n2)) * a : a;
+}
+
+__device__ JointEvalD evalJointConstraintF64(const JointBlockDev& k, const double* js, int joint, size_t c) {
+  JointEvalD o;
+  o.vp = o.vn = D3{0.0, 0.0, 0.0};
+  for (int i = 0; i < 9; ++i) {
+    o.dp[i] = o.dn[i] = 0.0;
+  }
+  o.f[0] = o.f[1] = o.f[2] = 0.0;
+  o.sigma = o.werr = 0.0;
+  o.nrows = jointBlockFuncDim(k.type);
+  o.hasPoint = k.type != MMX_JC_FIXED_AXIS_DIFF && k.type != MMX_JC_FIXED_AXIS_COS && k.type != MMX_JC_FIXED_AXIS_ANGLE;
+  o.hasDir = k.type != MMX_JC_PLANE && k.type != MMX_JC_HALF_PLANE;
+  const double* w = js + kDs * joint;
+  const D3 t{w[0], w[1], w[2]};
+  const DQ q{w[3], w[4], w[5], w[6]};
+  const double sc = w[7];
+  auto vec = [&](const float* a) { return D3{double(a[3 * c]), double(a[3 * c + 1]), double(a[3 * c + 2])}; };
+  auto setRow = [](double* m, D3 a, double f) { m[0] = f * a.x, m[1] = f * a.y, m[2] = f * a.z; };
+  auto addOuter = [](double* m, D3 a, D3 b, double f) { // m += f * a b^T
+    m[0] += f * a.x * b.x, m[1] += f * a.x * b.y, m[2] += f * a.x * b.z;
+    m[3] += f * a.y * b.x, m[4] += f * a.y * b.y, m[5] += f * a.y * b.z;
+    m[6] += f * a.z * b.x, m[7] += f * a.z * b.y, m[8] += f * a.z * b.z;
+  };
+  const D3 gl = vec(k.global);
+  if (o.hasPoint) {
+    o.vp = t + dqrot(q, sc * vec(k.localPoint)); // state.transform * point
+  }
+  if (o.hasDir) {
+    o.vn = dqrot(q, dnormalizedOrSame(vec(k.localDir))); // state.rotation() * dir, normalised by the data ctor
+  }
+  switch (k.type) {
+    case MMX_JC_PLANE:
+    case MMX_JC_HALF_PLANE: { // plane_error_function.cpp:52-71
+      const D3 nrm = dnormalizedOrSame(gl);
+      double val = ddot(o.vp, nrm) - double(k.planeD[c]);
+      const bool half = k.type == MMX_JC_HALF_PLANE;
+      if (half && val > 0.0) {
+        val = 0.0;
+      }
+      o.f[0] = val;
+      if (!half || val < 0.0) {
+        setRow(o.dp, nrm, 1.0);
+      }
+      break;
+    }
+    case MMX_JC_AIM_DIST: { // aim_error_function.cpp:15-36
+      const D3 tgt = gl - o.vp;
+      const double proj = ddot(o.vn, tgt);
+      const D3 r = proj * o.vn - tgt;
+      o.f[0] = r.x, o.f[1] = r.y, o.f[2] = r.z;
+      o.dp[0] = o.dp[4] = o.dp[8] = 1.0;
+      addOuter(o.dp, o.vn, o.vn, -1.0);
+      addOuter(o.dn, o.vn, tgt, 1.0);
+      o.dn[0] += proj, o.dn[4] += proj, o.dn[8] += proj;
+      break;
+    }
+    case MMX_JC_AIM_DIR: { // aim_error_function.cpp:39-67
+      const D3 tgt = gl - o.vp;
+      const double nrm = sqrt(ddot(tgt, tgt));
+      D3 dir{0.0, 0.0, 0.0};
+      if (nrm > 1e-16) {
+        dir = (1.0 / nrm) * tgt;
+        addOuter(o.dp, dir, dir, -1.0 / nrm);
+        o.dp[0] += 1.0 / nrm, o.dp[4] += 1.0 / nrm, o.dp[8] += 1.0 / nrm;
+      }
+      const D3 r = o.vn - dir;
+      o.f[0] = r.x, o.f[1] = r.y, o.f[2] = r.z;
+      o.dn[0] = o.dn[4] = o.dn[8] = 1.0;
+      break;
+    }
+    case MMX_JC_FIXED_AXIS_DIFF: { // fixed_axis_error_function.cpp:15-26
+      const D3 r = o.vn - dnormalizedOrSame(gl);
+      o.f[0] = r.x, o.f[1] = r.y, o.f[2] = r.z;
+      o.dn[0] = o.dn[4] = o.dn[8] = 1.0;
+      break;
+    }
+    case MMX_JC_FIXED_AXIS_COS: { // :28-39
+      const D3 ga = dnormalizedOrSame(gl);
+      o.f[0] = 1.0 - ddot(o.vn, ga);
+      setRow(o.dn, ga, -1.0);
+      break;
+    }
+    case MMX_JC_FIXED_AXIS_ANGLE: { // :41-66
+      const D3 ga = dnormalizedOrSame(gl);
+      const double d = ddot(o.vn, ga);
+      o.f[0] = acos(fmin(fmax(d, -1.0), 1.0));
+      const double sine = sqrt(1.0 - d * d);
+      if (sine > 1e-9) {
+        setRow(o.dn, ga, -1.0 / sine);
+      }
+      break;
+    }
+    default: { // MMX_JC_NORMAL, normal_error_function.cpp:14-31
+      const D3 dist = o.vp - gl;
+      o.f[0] = ddot(o.vn, dist);
+      setRow(o.dp, o.vn, 1.0);
+      setRow(o.dn, dist, 1.0);
+      break;
+    }
+  }
+  const double cw = double(k.weight[c]);
+  if (cw != 0.0 && k.fw > 0.f) { // :197-199 ; blocks with weight_ <= 0 are skipped (skeleton_solver_function.cpp:223-231)
+    const double sqr = o.f[0] * o.f[0] + o.f[1] * o.f[1] + o.f[2] * o.f[2];
+    const double wgt = cw * double(k.fw);
+    o.werr = wgt * dlossValue(k.loss, sqr); // :207
+    o.sigma = sqrt(wgt * dlossDeriv(k.loss, sqr)); // :208
+  }
+  return o;
+}
+
+// this thread's share of the further joint error functions' error at the state in s.js
+__device__ double jointBlocksErrorF64(const ProblemDev& pb, const F64Lds& s, int b, int tid) {
+  double e = 0.0;
+  for (int g = tid; g < pb.G; g += 256) {
+    const JointBlockDev k = jointBlockOf(pb, b, pb.genBlock[g]);
+    e += evalJointConstraintF64(k, s.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(g - k.first)).werr;
+  }
+  return e;
+}
+
 __device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds& s, const double* th, int b, int tid) {
   fkF64(rig, s, th, tid, false);
   double e = 0.0;
@@ -282,6 +420,7 @@ __device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds
     e += evalUnitF64(pb, s, b, u, false);
   }
   e += paramRowsErrorF64<false>(rig, pb, th, b, tid);
+  e += jointBlocksErrorF64(pb, s, b, tid);
   return double(float(blockSumF64(s, e, tid)));
 }
 
@@ -320,7 +459,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
   const int b = blockIdx.x, tid = threadIdx.x;
   selectInstanceRig(rig, b);
   selectInstanceWeights(pb, b);
-  const int J = rig.J, P = rig.P, U = pb.U, M = 3 * U;
+  const int J = rig.J, P = rig.P, U = pb.U, G = pb.G, M = pb.rowsJoint; // (rowsJoint = 3 U + rows of the further joint error functions)
   F64Lds s;
   {
     double* p = dmem;
@@ -330,12 +469,13 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       return r;
     };
     s.th = take(P), s.trial = take(P), s.jp = take(7 * size_t(J)), s.js = take(size_t(kDs) * J);
-    s.uv = take(3 * size_t(U)), s.ur = take(3 * size_t(U)), s.us = take(U);
+    s.uv = take(3 * size_t(U)), s.ur = take(size_t(M)), s.us = take(U);
     s.g = take(n), s.d = take(n), s.red = take(8);
     s.utin = reinterpret_cast<int*>(take((U + 1) / 2 + 1));
     s.flags = reinterpret_cast<int*>(take(2));
     s.colOf = reinterpret_cast<int*>(take((size_t(P) + 1) / 2));
     s.jl = take(size_t(n) * size_t(rc + 1));
+    s.gev = take(size_t(kGevD) * size_t(G));
   }
   double* thg = theta + size_t(b) * P;
   double* Jb = Jg + size_t(b) * size_t(n) * size_t(M);
@@ -368,6 +508,25 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     if (hasParamRows) {
       e += paramRowsErrorF64<true>(rig, pb, s.th, b, tid);
     }
+    for (int g = tid; g < G; g += 256) { // the further joint error functions: residual rows, evaluation record for the Jacobian
+      const JointBlockDev k = jointBlockOf(pb, b, pb.genBlock[g]);
+      const int i = g - k.first;
+      const JointEvalD o = evalJointConstraintF64(k, s.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(i));
+      const int row = k.rowStart + o.nrows * i;
+      e += o.werr;
+      for (int q = 0; q < o.nrows; ++q) {
+        s.ur[row + q] = o.sigma * o.f[q];
+      }
+      const double sg = fabs(o.sigma) <= 1e-9 ? 0.0 : o.sigma; // early termination (joint_error_function-inl.h:216): the rows stay zero
+      double* w = s.gev + kGevD * g;
+      w[0] = o.vp.x, w[1] = o.vp.y, w[2] = o.vp.z, w[3] = o.vn.x, w[4] = o.vn.y, w[5] = o.vn.z;
+      for (int q = 0; q < 9; ++q) {
+        w[6 + q] = sg * o.dp[q];
+        w[15 + q] = sg * o.dn[q];
+      }
+      int* wi = reinterpret_cast<int*>(w + 24);
+      wi[0] = pb.genTin[g], wi[1] = row, wi[2] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0), wi[3] = 0;
+    }
     curError = blockSumF64(s, e, tid); // (not rounded: the value getJacobian returns)
     for (int item = tid; item < n * U; item += 256) {
       const int c = item / U, u = item - c * U;
@@ -386,6 +545,47 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       }
       double* o = Jb + size_t(c) * M + 3 * u;
       o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+    }
+    for (int item = tid; item < n * G; item += 256) { // rows of the further joint error functions (jointBlocksKernel in double)
+      const int c = item / G, g = item - c * G;
+      const int p = solveList[c];
+      const double* w = s.gev + kGevD * g;
+      const int* wi = reinterpret_cast<const int*>(w + 24);
+      const int tin = wi[0], row = wi[1], nrows = wi[2] & 15;
+      const bool hasPoint = (wi[2] & 16) != 0, hasDir = (wi[2] & 32) != 0;
+      const D3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
+      double acc[3] = {0.0, 0.0, 0.0};
+      const int e1 = pb.colStart[p + 1];
+      for (int k = pb.colStart[p]; k < e1; ++k) {
+        const ColumnSourceDev cs = pb.colSources[k];
+        if (!(cs.tin <= tin && tin < cs.tout)) {
+          continue; // the source's joint is not an ancestor of the constraint's joint
+        }
+        bool ap;
+        D3 gp{0.0, 0.0, 0.0}, gn{0.0, 0.0, 0.0};
+        if (hasPoint) {
+          gp = sourceDerivativeF64(cs, s.js, vp, tin, true, ap);
+          if (!ap) {
+            gp = D3{0.0, 0.0, 0.0};
+          }
+        }
+        if (hasDir) {
+          gn = sourceDerivativeF64(cs, s.js, vn, tin, false, ap);
+          if (!ap) {
+            gn = D3{0.0, 0.0, 0.0};
+          }
+        }
+        const double wt = double(cs.weight);
+        for (int q = 0; q < 3; ++q) {
+          const double jc = (w[6 + 3 * q] * gp.x + w[7 + 3 * q] * gp.y + w[8 + 3 * q] * gp.z) +
+              (w[15 + 3 * q] * gn.x + w[16 + 3 * q] * gn.y + w[17 + 3 * q] * gn.z);
+          acc[q] += jc * wt;
+        }
+      }
+      double* o = Jb + size_t(c) * M + row;
+      for (int q = 0; q < nrows; ++q) {
+        o[q] = acc[q];
+      }
     }
     __threadfence_block();
     __syncthreads();
@@ -690,14 +890,15 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
 
 } // namespace
 
-static size_t solveF64BaseDoubles(int J, int P, int U, int n) {
+static size_t solveF64BaseDoubles(int J, int P, int U, int n, int G, int genRows) {
   auto e = [](size_t c) { return (c + 1) & ~size_t(1); };
-  return 2 * e(P) + e(7 * size_t(J)) + e(size_t(kDs) * J) + 2 * e(3 * size_t(U)) + e(U) + 2 * e(n) + e(8) + e((U + 1) / 2 + 1) + e(2) + e((size_t(P) + 1) / 2);
+  return 2 * e(P) + e(7 * size_t(J)) + e(size_t(kDs) * J) + e(3 * size_t(U)) + e(3 * size_t(U) + size_t(genRows)) + e(U) + 2 * e(n) + e(8) +
+      e((U + 1) / 2 + 1) + e(2) + e((size_t(P) + 1) / 2) + e(size_t(kGevD) * size_t(G));
 }
 // rows of J staged per chunk: as many as fit next to the fixed part (at most 64, at least 4), leaving room for two
 // workgroups per CU when the system is small
-static int solveF64ChunkRows(int J, int P, int U, int n) {
-  const size_t base = solveF64BaseDoubles(J, P, U, n) * sizeof(double);
+static int solveF64ChunkRows(int J, int P, int U, int n, int G, int genRows) {
+  const size_t base = solveF64BaseDoubles(J, P, U, n, G, genRows) * sizeof(double);
   const size_t budget = base < 60 * 1024 ? 78 * 1024 : 158 * 1024;
   if (base + size_t(n > 0 ? n : 1) * 5 * sizeof(double) > budget) {
     return 0;
@@ -705,12 +906,12 @@ static int solveF64ChunkRows(int J, int P, int U, int n) {
   size_t rows = (budget - base) / (size_t(n > 0 ? n : 1) * sizeof(double)) - 1;
   return int(rows > 64 ? 64 : rows);
 }
-size_t solveF64LdsBytes(int J, int P, int U, int n) {
-  const int rc = solveF64ChunkRows(J, P, U, n);
+size_t solveF64LdsBytes(int J, int P, int U, int n, int G, int genRows) {
+  const int rc = solveF64ChunkRows(J, P, U, n, G, genRows);
   if (rc < 4) {
     return size_t(1) << 30; // does not fit
   }
-  return (solveF64BaseDoubles(J, P, U, n) + ((size_t(n) * size_t(rc + 1) + 1) & ~size_t(1))) * sizeof(double);
+  return (solveF64BaseDoubles(J, P, U, n, G, genRows) + ((size_t(n) * size_t(rc + 1) + 1) & ~size_t(1))) * sizeof(double);
 }
 
 hipError_t launchSolveF64(
@@ -724,7 +925,8 @@ hipError_t launchSolveF64(
     double* Jg,
     double* Hg,
     hipStream_t stream) {
-  const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n);
+  const int genRows = pb.rowsJoint - 3 * pb.U;
+  const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n, pb.G, genRows);
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }
@@ -735,7 +937,7 @@ hipError_t launchSolveF64(
     }
   }
   hipLaunchKernelGGL(
-      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, solveF64ChunkRows(rig.J, rig.P, pb.U, n));
+      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G, genRows));
   return hipGetLastError();
 }
 

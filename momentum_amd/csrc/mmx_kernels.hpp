@@ -191,7 +191,7 @@ hipError_t launchFusedSolve(
     hipStream_t stream);
 
 // double-precision solve (mmx_f64.hip)
-size_t solveF64LdsBytes(int J, int P, int U, int n);
+size_t solveF64LdsBytes(int J, int P, int U, int n, int G = 0, int genRows = 0);
 hipError_t launchSolveF64(
     const RigDev& rig,
     const ProblemDev& pb,

@@ -152,16 +152,77 @@ def test_f64_solve_with_parameter_rows_only(torch_cuda, orc):
     assert rel.max() <= 1e-10, rel
 
 
-def test_f64_refuses_blocks_it_does_not_cover(torch_cuda):
+@pytest.mark.parametrize("mode", ["gn", "line_search_directional", "lm_schedule"])
+@pytest.mark.parametrize("which", ["chain8", "humanoid72"])
+def test_f64_solve_with_the_further_joint_error_functions(torch_cuda, orc, which, mode):
+    """PlaneErrorFunctionT<double> (plane and half plane), AimDist / AimDir, FixedAxisDiff / Cos / Angle and
+    NormalErrorFunctionT<double> next to the position / orientation constraints, one block with a robust loss, one with a
+    function weight, per-element error-function weights on top: the double instantiation against the oracle's at 1e-10
+    (skeleton_solver_function.cpp:200-261 with T = double; evalJointConstraintF64 in mmx_f64.hip)."""
     from momentum_amd import _abi, capi
     from tests.test_gpu_joint_blocks import _device_block
     from tests.test_oracle_joint_blocks import make_block
 
     torch = torch_cuda
-    rig = make_test_character(5)
-    cons, th0, _ = make_problem(rig, [4], [3], 2, seed=1)
-    blk = _device_block(torch, make_block(_abi.MMX_JC_PLANE, [2], np.random.default_rng(0), weight=1.0, batch=2), torch.device("cuda", 0))
-    rh, pb = _gpu(torch, rig, cons, 2, joint_blocks=[blk])
+    rng = np.random.default_rng(21)
+    if which == "chain8":
+        rig, pp, op, B = make_test_character(8), [7, 3], [6], 4
+    else:
+        rig = make_humanoid72(unit=UNIT)
+        pp = op = humanoid72_landmark_joints(rig)
+        B = 5
+    J = rig.num_joints
+    cons, th0, _ = make_problem(rig, pp, op, B, seed=31, perturb=0.3, weights="random")
+    pick = lambda k: rng.choice(np.arange(1, J), size=k, replace=False)
+    blocks = [
+        make_block(_abi.MMX_JC_PLANE, pick(3), rng, weight=1.0, batch=B),
+        make_block(_abi.MMX_JC_HALF_PLANE, pick(2), rng, weight=2.0, batch=B),
+        make_block(_abi.MMX_JC_AIM_DIST, pick(2), rng, weight=0.5, batch=B, function_weight=1.7),
+        make_block(_abi.MMX_JC_AIM_DIR, pick(2), rng, weight=0.8, batch=B),
+        make_block(_abi.MMX_JC_FIXED_AXIS_DIFF, pick(2), rng, weight=1.2, batch=B, loss=(1.0, 0.3)),
+        make_block(_abi.MMX_JC_FIXED_AXIS_COS, pick(2), rng, weight=1.0, batch=B),
+        make_block(_abi.MMX_JC_FIXED_AXIS_ANGLE, pick(2), rng, weight=0.7, batch=B),
+        make_block(_abi.MMX_JC_NORMAL, pick(3), rng, weight=1.5, batch=B),
+    ]
+    fw = rng.uniform(0.5, 2.0, size=(B, 4 + len(blocks))).astype(np.float32)
+    fw[1, 4] = 0.0  # element 1: the plane block switched off
+    full = orc.Constraints(cons.pos_parent, cons.pos_offset, cons.pos_target, cons.pos_weight, cons.ori_parent, cons.ori_offset, cons.ori_target,
+                           cons.ori_weight, joint_blocks=blocks, function_weights=fw)  # fmt: skip
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, cons.pos_parent, cons.ori_parent)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+                       t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+                       joint_blocks=[_device_block(torch, k, pb.device) for k in blocks], function_weights=t(fw, fw.shape))  # fmt: skip
+    kw = dict(min_iterations=8, max_iterations=8, threshold=1.0, regularization=0.05)
+    if mode == "line_search_directional":
+        kw["do_line_search"] = 2
+    elif mode == "lm_schedule":
+        kw["step_rule"] = MMX_STEP_LM_SCHEDULE
+    opt = GnOptions.make(**kw)
+    out = pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    # (summation order only separates the two: 1e-12 measured.  With the loss scale's 1 / c^2 formed in float instead of
+    # double -- the first version -- the error values differed in the ninth digit and theta by 2e-10 / 4.5e-8.)
+    assert rel.max() <= (1e-10 if which == "humanoid72" else 1e-8), rel
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]) and np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-9 * max(1.0, np.abs(href).max())
+    # the blocks matter: without them the answer differs
+    plain = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    assert np.abs(plain["theta"] - ref["theta"]).max() > 1e-3
+
+
+def test_f64_refuses_ellipsoid_limits(torch_cuda):
+    from momentum_amd import capi
+    from momentum_amd._abi import EllipsoidLimit
+
+    torch = torch_cuda
+    rig = make_test_character(8)
+    cons, th0, _ = make_problem(rig, [7], [3], 2, seed=1)
+    ell = EllipsoidLimit.make(6, [0.1, 0.2, -0.1], 2, [0.0, 0.5, 0.0], [10.0, 20.0, 30.0], [0.6, 1.2, 0.8], 3.0)
+    rh, pb = _gpu(torch, rig, cons, 2, ellipsoid_limits=[ell])
     with pytest.raises(capi.MmxError) as ei:
         pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), GnOptions.make())
     assert "single precision" in str(ei.value)
