@@ -538,9 +538,9 @@ int32_t mmx_solve(
  * widened per use; every other argument as in mmx_solve.  Normal equations from the explicit Jacobian, LL^T and
  * two substitutions in double: agrees with the reference's double solver to rounding (tests: 1e-10 against the
  * oracle), no refinement step.  Built for exactness, not for the roofline: position / orientation
- * constraints and the further joint error functions (mmx_joint_constraint_block) with their losses, parameter limits,
- * the model-parameter prior, per-element error-function weights, per-instance characters and parents, fixed lambda or
- * the LM schedule, both line-search rules; ellipsoid limits and MMX_STEP_TRUST_REGION return MMX_ERR_UNSUPPORTED.
+ * constraints and the further joint error functions (mmx_joint_constraint_block) with their losses, parameter limits
+ * incl. ellipsoid limits, the model-parameter prior, per-element error-function weights, per-instance characters and
+ * parents, fixed lambda or the LM schedule, both line-search rules; MMX_STEP_TRUST_REGION returns MMX_ERR_UNSUPPORTED.
  */
 int32_t mmx_solve_f64(
     mmx_problem* problem,

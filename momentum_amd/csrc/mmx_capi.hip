@@ -2284,16 +2284,11 @@ int32_t mmx_solve_f64(
       o->do_line_search != MMX_LINE_SEARCH_DIRECTIONAL) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "unknown do_line_search rule");
   }
-  if (pb->dev.NE > 0) {
-    return fail(
-        MMX_ERR_UNSUPPORTED,
-        "mmx_solve_f64: position / orientation constraints, the further joint error functions, parameter limits and the model-parameter prior (ellipsoid limits are single precision)");
-  }
   const size_t B = size_t(pb->B), n = size_t(pb->solveN), M = size_t(pb->dev.rowsJoint);
   const int genRowsF64 = pb->dev.rowsJoint - 3 * pb->U;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G, genRowsF64) > 160 * 1024) {
+  if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64) > 160 * 1024) {
     return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: rig beyond the kernel's LDS budget");
   }
   MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));

@@ -403,12 +403,47 @@ __device__ JointEvalD evalJointConstraintF64(const JointBlockDev& k, const doubl
   return o;
 }
 
+// computeEllipsoidError / the point and weight of computeEllipsoidJacobian in double (evalEllipsoid of mmx_device.hpp;
+// limit_error_function.cpp:173-195,702-737)
+struct EllipsoidEvalD {
+  D3 position, diff;
+  double jwgt, werr;
+};
+__device__ EllipsoidEvalD evalEllipsoidF64(const EllipsoidDev& ct, const double* js, float wLimit) {
+  const double* wp = js + kDs * ct.parent;
+  const double* we = js + kDs * ct.ellipsoidParent;
+  const D3 te{we[0], we[1], we[2]};
+  const DQ qe{we[3], we[4], we[5], we[6]};
+  auto affine = [](const float* a, D3 p) { // 3 x 4 row-major
+    return D3{
+        double(a[0]) * p.x + double(a[1]) * p.y + double(a[2]) * p.z + double(a[3]),
+        double(a[4]) * p.x + double(a[5]) * p.y + double(a[6]) * p.z + double(a[7]),
+        double(a[8]) * p.x + double(a[9]) * p.y + double(a[10]) * p.z + double(a[11])};
+  };
+  EllipsoidEvalD o;
+  o.position = D3{wp[0], wp[1], wp[2]} + dqrot(DQ{wp[3], wp[4], wp[5], wp[6]}, wp[7] * D3{double(ct.offset[0]), double(ct.offset[1]), double(ct.offset[2])});
+  const D3 local = (1.0 / we[7]) * dqrot(DQ{-qe.x, -qe.y, -qe.z, qe.w}, o.position - te); // transform.inverse() * position
+  const D3 nrm = dnormalizedOrSame(affine(ct.ellipsoidInv, local));
+  const D3 proj = affine(ct.ellipsoid, nrm);
+  o.diff = o.position - (te + dqrot(qe, we[7] * proj));
+  o.jwgt = o.werr = 0.0;
+  if (wLimit > 0.f) { // a block with weight_ <= 0 is skipped; its rows stay zero
+    const double w = (10.0 * double(wLimit)) * double(1e-4f) * double(ct.weight); // kLimitWeight * weight_ * kPositionWeight * limit.weight
+    o.werr = w * ddot(o.diff, o.diff);
+    o.jwgt = sqrt(w);
+  }
+  return o;
+}
+
 // this thread's share of the further joint error functions' error at the state in s.js
 __device__ double jointBlocksErrorF64(const ProblemDev& pb, const F64Lds& s, int b, int tid) {
   double e = 0.0;
   for (int g = tid; g < pb.G; g += 256) {
     const JointBlockDev k = jointBlockOf(pb, b, pb.genBlock[g]);
     e += evalJointConstraintF64(k, s.js, pb.genJoint[g], size_t(b) * size_t(k.count) + size_t(g - k.first)).werr;
+  }
+  for (int q = tid; q < pb.NE; q += 256) { // LimitType::Ellipsoid entries of the limit block
+    e += evalEllipsoidF64(pb.ellipsoids[q], s.js, pb.wLimit).werr;
   }
   return e;
 }
@@ -459,7 +494,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
   const int b = blockIdx.x, tid = threadIdx.x;
   selectInstanceRig(rig, b);
   selectInstanceWeights(pb, b);
-  const int J = rig.J, P = rig.P, U = pb.U, G = pb.G, M = pb.rowsJoint; // (rowsJoint = 3 U + rows of the further joint error functions)
+  const int J = rig.J, P = rig.P, U = pb.U, G = pb.G, M = pb.rowsJoint; // (rowsJoint = 3 U + rows of the further joint error functions + 3 NE)
   F64Lds s;
   {
     double* p = dmem;
@@ -475,7 +510,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     s.flags = reinterpret_cast<int*>(take(2));
     s.colOf = reinterpret_cast<int*>(take((size_t(P) + 1) / 2));
     s.jl = take(size_t(n) * size_t(rc + 1));
-    s.gev = take(size_t(kGevD) * size_t(G));
+    s.gev = take(size_t(kGevD) * size_t(G + pb.NE));
   }
   double* thg = theta + size_t(b) * P;
   double* Jb = Jg + size_t(b) * size_t(n) * size_t(M);
@@ -525,7 +560,22 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
         w[15 + q] = sg * o.dn[q];
       }
       int* wi = reinterpret_cast<int*>(w + 24);
-      wi[0] = pb.genTin[g], wi[1] = row, wi[2] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0), wi[3] = 0;
+      wi[0] = pb.genTin[g], wi[1] = row, wi[2] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0), wi[3] = -1;
+    }
+    for (int q = tid; q < pb.NE; q += 256) { // ellipsoid limits: a point constraint whose walk stops at ellipsoidParent
+      const EllipsoidDev ct = pb.ellipsoids[q];
+      const EllipsoidEvalD o = evalEllipsoidF64(ct, s.js, pb.wLimit);
+      const int row = pb.rowsJoint - 3 * pb.NE + 3 * q;
+      e += o.werr;
+      s.ur[row] = o.diff.x * o.jwgt, s.ur[row + 1] = o.diff.y * o.jwgt, s.ur[row + 2] = o.diff.z * o.jwgt;
+      double* w = s.gev + kGevD * (G + q);
+      w[0] = o.position.x, w[1] = o.position.y, w[2] = o.position.z, w[3] = w[4] = w[5] = 0.0;
+      for (int k = 0; k < 9; ++k) {
+        w[6 + k] = (k == 0 || k == 4 || k == 8) ? o.jwgt : 0.0;
+        w[15 + k] = 0.0;
+      }
+      int* wi = reinterpret_cast<int*>(w + 24);
+      wi[0] = ct.tinParent, wi[1] = row, wi[2] = 3 | 16, wi[3] = ct.tinStop;
     }
     curError = blockSumF64(s, e, tid); // (not rounded: the value getJacobian returns)
     for (int item = tid; item < n * U; item += 256) {
@@ -546,12 +596,13 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       double* o = Jb + size_t(c) * M + 3 * u;
       o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
     }
-    for (int item = tid; item < n * G; item += 256) { // rows of the further joint error functions (jointBlocksKernel in double)
-      const int c = item / G, g = item - c * G;
+    const int GT = G + pb.NE;
+    for (int item = tid; item < n * GT; item += 256) { // rows of the further joint error functions / ellipsoid limits (jointBlocksKernel in double)
+      const int c = item / GT, g = item - c * GT;
       const int p = solveList[c];
       const double* w = s.gev + kGevD * g;
       const int* wi = reinterpret_cast<const int*>(w + 24);
-      const int tin = wi[0], row = wi[1], nrows = wi[2] & 15;
+      const int tin = wi[0], row = wi[1], nrows = wi[2] & 15, tinStop = wi[3];
       const bool hasPoint = (wi[2] & 16) != 0, hasDir = (wi[2] & 32) != 0;
       const D3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
       double acc[3] = {0.0, 0.0, 0.0};
@@ -560,6 +611,9 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
         const ColumnSourceDev cs = pb.colSources[k];
         if (!(cs.tin <= tin && tin < cs.tout)) {
           continue; // the source's joint is not an ancestor of the constraint's joint
+        }
+        if (tinStop >= 0 && cs.tin <= tinStop && tinStop < cs.tout) {
+          continue; // ellipsoid limit: the walk stopped before this joint
         }
         bool ap;
         D3 gp{0.0, 0.0, 0.0}, gn{0.0, 0.0, 0.0};
@@ -926,7 +980,7 @@ hipError_t launchSolveF64(
     double* Hg,
     hipStream_t stream) {
   const int genRows = pb.rowsJoint - 3 * pb.U;
-  const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n, pb.G, genRows);
+  const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }
@@ -937,7 +991,7 @@ hipError_t launchSolveF64(
     }
   }
   hipLaunchKernelGGL(
-      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G, genRows));
+      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows));
   return hipGetLastError();
 }
 

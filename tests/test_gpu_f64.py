@@ -214,15 +214,44 @@ def test_f64_solve_with_the_further_joint_error_functions(torch_cuda, orc, which
     assert np.abs(plain["theta"] - ref["theta"]).max() > 1e-3
 
 
-def test_f64_refuses_ellipsoid_limits(torch_cuda):
+@pytest.mark.parametrize("mode", ["gn", "line_search_directional"])
+@pytest.mark.parametrize("which", ["chain8", "humanoid72"])
+def test_f64_solve_with_ellipsoid_limits(torch_cuda, orc, which, mode):
+    """LimitType::Ellipsoid entries of LimitErrorFunctionT<double> (limit_error_function.cpp:173-195,702-790: the walk from
+    the constrained joint stops at the ellipsoid's joint) next to parameter limits and a half-plane block: the double
+    instantiation against the oracle's at 1e-10."""
+    from tests.test_gpu_ellipsoid import _setup
+
+    torch = torch_cuda
+    B = 4
+    rig, pb, full, th0 = _setup(torch, orc, which, B, 17, True)
+    kw = dict(min_iterations=8, max_iterations=8, threshold=1.0, regularization=0.05)
+    if mode == "line_search_directional":
+        kw["do_line_search"] = 2
+    opt = GnOptions.make(**kw)
+    out = pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel.max() <= (1e-10 if which == "humanoid72" else 1e-8), rel
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]) and np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-9 * max(1.0, np.abs(href).max())
+    # the ellipsoid rows matter: without them the answer differs
+    plain = orc.Constraints(full.pos_parent, full.pos_offset, full.pos_target, full.pos_weight, full.ori_parent, full.ori_offset, full.ori_target,
+                            full.ori_weight, limits=full.limits, limit_function_weight=25.0, joint_blocks=full.joint_blocks)  # fmt: skip
+    ref0 = orc.solve_batch(rig, plain, th0, opt, dtype="f64")
+    assert np.abs(ref0["theta"] - ref["theta"]).max() > 1e-4
+
+
+def test_f64_refuses_the_trust_region(torch_cuda):
     from momentum_amd import capi
-    from momentum_amd._abi import EllipsoidLimit
+    from momentum_amd._abi import MMX_STEP_TRUST_REGION
 
     torch = torch_cuda
     rig = make_test_character(8)
     cons, th0, _ = make_problem(rig, [7], [3], 2, seed=1)
-    ell = EllipsoidLimit.make(6, [0.1, 0.2, -0.1], 2, [0.0, 0.5, 0.0], [10.0, 20.0, 30.0], [0.6, 1.2, 0.8], 3.0)
-    rh, pb = _gpu(torch, rig, cons, 2, ellipsoid_limits=[ell])
+    rh, pb = _gpu(torch, rig, cons, 2)
     with pytest.raises(capi.MmxError) as ei:
-        pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), GnOptions.make())
-    assert "single precision" in str(ei.value)
+        pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION))
+    assert "MMX_STEP_GN_FIXED_LAMBDA" in str(ei.value)
