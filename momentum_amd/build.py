@@ -14,6 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 # A/B experiments on one GPU box: MMX_BUILD_VARIANT=name builds momentum_amd/libmmx_hip_<name>.so with
 # -DMMX_EXP_<NAME> (objects kept apart); MMX_LIB=<path> makes capi.py load that library instead.
 VARIANT = os.environ.get("MMX_BUILD_VARIANT", "")
+# ... and MMX_BUILD_FLAGS="..." appends compiler flags to such a variant build (e.g. -mllvm -amdgpu-sched-strategy=max-ilp)
+VARIANT_FLAGS = os.environ.get("MMX_BUILD_FLAGS", "").split() if VARIANT else []
 LIB = os.path.join(HERE, f"libmmx_hip_{VARIANT}.so" if VARIANT else "libmmx_hip.so")
 SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_comm.hip", "mmx_f64.hip", "mmx_host_tables.cpp"]
 FUSED_GROUPS = 4  # mmx_fused.hip is compiled once per group of template instantiations, in parallel
@@ -48,6 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
             if VARIANT:
                 cmd.insert(1, f"-DMMX_EXP_{VARIANT.upper()}")
+                cmd[1:1] = VARIANT_FLAGS
             if g is not None:
                 cmd.insert(1, f"-DMMX_FUSED_GROUP={g}")
             if src.endswith(".cpp"):
