@@ -99,8 +99,9 @@ typedef enum mmx_status {
                                    position / orientation constraints, limits, model prior) and on the wide route
                                    otherwise (driven from the host: factor / decide / trial kernels per trust step;
                                    larger systems, further joint error functions, ellipsoid limits); not on
-                                   MMX_ROUTE_EXPLICIT_JACOBIAN and not in mmx_solve_f64.  do_line_search and
-                                   regularization are not read by this rule.
+                                   MMX_ROUTE_EXPLICIT_JACOBIAN.  mmx_solve_f64 runs the rule in double (one LL^T of
+                                   J^T J + damping per value of the damping; 1e-7 on the oracle's double run where J
+                                   has full column rank).  do_line_search and regularization are not read by this rule.
                                    DEVIATION from TrustRegionQRT: the reference's Householder QR of J takes the rule's
                                    (almost) zero damping on rank-deficient / under-determined J; an fp32 Cholesky of
                                    J^T J cannot, so the factor is damped by at least 1e-5 of the mean diagonal of J^T J
@@ -540,7 +541,7 @@ int32_t mmx_solve(
  * oracle), no refinement step.  Built for exactness, not for the roofline: position / orientation
  * constraints and the further joint error functions (mmx_joint_constraint_block) with their losses, parameter limits
  * incl. ellipsoid limits, the model-parameter prior, per-element error-function weights, per-instance characters and
- * parents, fixed lambda or the LM schedule, both line-search rules; MMX_STEP_TRUST_REGION returns MMX_ERR_UNSUPPORTED.
+ * parents, fixed lambda, the LM schedule or the trust region (MMX_STEP_TRUST_REGION), both line-search rules.
  */
 int32_t mmx_solve_f64(
     mmx_problem* problem,

@@ -208,6 +208,7 @@ struct mmx_problem {
   // the same problem with the structurally zero columns dropped from the solve (explicit-Jacobian solver)
   int32_t solveN = 0;
   DevBuf dSolveListV1; // [solveN]
+  DevBuf sHess2F64; // mmx_solve_f64 under MMX_STEP_TRUST_REGION: J^T J without damping
   DevBuf dSolveListF64; // [solveN] the same parameters in index order: the double instantiation follows the reference's column order
   std::vector<std::pair<int32_t, int32_t>> limitPairs; // (row, col) solve columns of the off-diagonal H entries limits add
   DevBuf dTileMasks, dTileList; // tile structure of the factor in elimination order (mmx::TileMasks): [64] masks, the non-zero tiles
@@ -2277,8 +2278,8 @@ int32_t mmx_solve_f64(
   if (o->max_iterations < 0 || o->min_iterations < 0) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "iteration counts must be >= 0");
   }
-  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE) {
-    return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: step rules MMX_STEP_GN_FIXED_LAMBDA and MMX_STEP_LM_SCHEDULE");
+  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE && o->step_rule != MMX_STEP_TRUST_REGION) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown step_rule");
   }
   if (o->do_line_search != MMX_LINE_SEARCH_NONE && o->do_line_search != MMX_LINE_SEARCH_GAUSS_NEWTON &&
       o->do_line_search != MMX_LINE_SEARCH_DIRECTIONAL) {
@@ -2293,6 +2294,10 @@ int32_t mmx_solve_f64(
   }
   MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));
   MMX_HIP(pb->sHessF64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));
+  const bool trustF64 = o->step_rule == MMX_STEP_TRUST_REGION;
+  if (trustF64) {
+    MMX_HIP(pb->sHess2F64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));
+  }
   MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
   MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
   MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
@@ -2315,8 +2320,9 @@ int32_t mmx_solve_f64(
   fp.lmLambdaMax = o->lm_lambda_max;
   fp.lmUp = o->lm_up;
   fp.lmDown = o->lm_down;
+  fp.trustRadius = o->trust_region_radius > 0.f ? o->trust_region_radius : 1.f;
   MMX_HIP(mmx::launchSolveF64(
-      pb->rigDev, pb->dev, pb->dSolveListF64.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), s));
+      pb->rigDev, pb->dev, pb->dSolveListF64.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), trustF64 ? pb->sHess2F64.as<double>() : nullptr, s));
   return MMX_OK;
 }
 

@@ -489,6 +489,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     FusedParams fp,
     double* __restrict__ Jg, // [B][n][M] scratch: the dense Jacobian (solved columns, column-major)
     double* __restrict__ Hg, // [B][n][n] scratch: H, then its Cholesky factor (lower triangle, column-major)
+    double* __restrict__ Hg2, // [B][n][n] scratch of MMX_STEP_TRUST_REGION: J^T J without damping, kept while the damping changes (else null)
     int rc) { // rows of J staged in LDS at a time
   extern __shared__ __attribute__((aligned(16))) double dmem[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -515,6 +516,9 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
   double* thg = theta + size_t(b) * P;
   double* Jb = Jg + size_t(b) * size_t(n) * size_t(M);
   double* Hb = Hg + size_t(b) * size_t(n) * size_t(n);
+  double* H0 = Hg2 != nullptr ? Hg2 + size_t(b) * size_t(n) * size_t(n) : nullptr;
+  const bool trust = fp.stepRule == MMX_STEP_TRUST_REGION; // TrustRegionQRT<double>::doIteration (trust_region_qr.cpp:52-270)
+  double trRadius = double(fp.trustRadius); // initializeSolver (:38-41); lives across the iterations
   for (int i = tid; i < P; i += 256) {
     s.th[i] = thg[i];
   }
@@ -578,6 +582,9 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       wi[0] = ct.tinParent, wi[1] = row, wi[2] = 3 | 16, wi[3] = ct.tinStop;
     }
     curError = blockSumF64(s, e, tid); // (not rounded: the value getJacobian returns)
+    if (trust) {
+      lambda = 0.0; // H is assembled without damping; the trust region adds its own per factorisation
+    }
     for (int item = tid; item < n * U; item += 256) {
       const int c = item / U, u = item - c * U;
       const int p = solveList[c];
@@ -771,6 +778,8 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     // ---- llt_.compute(H) (Eigen::LLT, lower): right-looking, one column per step; a non-positive pivot is
     // recorded (the reference never checks LLT::info(), gauss_newton_solver.cpp:251)
     bool notPd = false;
+    auto factorH = [&]() {
+    notPd = false;
     for (int k = 0; k < n; ++k) {
       const double dkk = Hb[size_t(k) * n + k];
       if (!(dkk > 0.0)) {
@@ -800,41 +809,48 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       __threadfence_block();
       __syncthreads();
     }
-    // ---- delta = llt_.solve(Jtr): wave 0, lanes over the already known entries
-    if (!notPd) {
+    };
+    // ---- x = llt_.solve(rhs): wave 0, lanes over the already known entries (x and rhs may be the same array)
+    auto solveLLt = [&](const double* rhs, double* x) {
       for (int c = tid; c < n; c += 256) {
-        s.d[c] = s.g[c];
+        x[c] = rhs[c];
       }
       __syncthreads();
       if (tid < 64) {
         for (int k = 0; k < n; ++k) { // L y = g
           double part = 0.0;
           for (int j = tid; j < k; j += 64) {
-            part += Hb[size_t(j) * n + k] * s.d[j];
+            part += Hb[size_t(j) * n + k] * x[j];
           }
           for (int off = 32; off > 0; off >>= 1) {
             part += __shfl_xor(part, off, 64);
           }
           if (tid == 0) {
-            s.d[k] = (s.d[k] - part) / Hb[size_t(k) * n + k];
+            x[k] = (x[k] - part) / Hb[size_t(k) * n + k];
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         for (int k = n - 1; k >= 0; --k) { // L^T x = y
           double part = 0.0;
           for (int j = k + 1 + tid; j < n; j += 64) {
-            part += Hb[size_t(k) * n + j] * s.d[j];
+            part += Hb[size_t(k) * n + j] * x[j];
           }
           for (int off = 32; off > 0; off >>= 1) {
             part += __shfl_xor(part, off, 64);
           }
           if (tid == 0) {
-            s.d[k] = (s.d[k] - part) / Hb[size_t(k) * n + k];
+            x[k] = (x[k] - part) / Hb[size_t(k) * n + k];
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
       }
       __syncthreads();
+    };
+    if (!trust) {
+      factorH();
+      if (!notPd) {
+        solveLLt(s.g, s.d);
+      }
     }
     // ---- updateParameters (gauss_newton_solver.cpp:283-313; subset_gauss_newton_solver.cpp:117-142) / LM schedule
     auto makeTrial = [&](double scale) {
@@ -853,7 +869,98 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       }
       __syncthreads();
     };
-    if (!notPd && fp.stepRule == 1) {
+    if (trust) {
+      // ---- TrustRegionQRT<double>::doIteration (trust_region_qr.cpp:52-270) on the normal equations: the reference
+      // seeds R with lambda = 1e-10 ON its diagonal (:86-87, online_householder_qr.cpp:133-140) and appends
+      // sqrt(lambda_new - lambda) I rows when the damping grows (:215-224), so R^T R = J^T J + (1e-20 + lambda - 1e-10) I;
+      // here H0 = J^T J (+ the parameter-space rows) is kept and every value of the damping is one LL^T of H0 + mu I.
+      for (int idx = tid; idx < n * n; idx += 256) { // (the lower triangle is what was assembled)
+        H0[idx] = Hb[idx];
+      }
+      __threadfence_block();
+      __syncthreads();
+      double lam = 1e-10;
+      bool haveStep = false; // s.d solves the system of the current damping
+      for (int trustStep = 0; trustStep < 10; ++trustStep) { // :157
+        double mu = 0.0, dn2 = 0.0, dg = 0.0;
+        bool noStep = false;
+        int pdRetries = 0;
+        for (int newton = 0;;) { // one pass per value of the damping (:180-231)
+          mu = 1e-20 + (lam - 1e-10);
+          if (!haveStep) {
+            for (int idx = tid; idx < n * n; idx += 256) {
+              const int i = idx % n, j = idx / n;
+              if (j <= i) {
+                Hb[idx] = H0[idx] + (i == j ? mu : 0.0);
+              }
+            }
+            __threadfence_block();
+            __syncthreads();
+            factorH();
+            if (notPd) { // (cannot happen in the reference's QR) more damping, a bounded number of times
+              lam = fmax(4.0 * lam, 1e-6);
+              if (++pdRetries > 16) {
+                noStep = true;
+                break;
+              }
+              continue;
+            }
+            solveLLt(s.g, s.d);
+            haveStep = true;
+          }
+          double p0 = 0.0, p1 = 0.0;
+          for (int c = tid; c < n; c += 256) {
+            p0 += s.d[c] * s.d[c];
+            p1 += s.d[c] * s.g[c];
+          }
+          dn2 = blockSumF64(s, p0, tid);
+          dg = blockSumF64(s, p1, tid);
+          if (newton == 0 && 2.0 * dg < double(FLT_EPSILON) * (1.0 + curError)) { // :164 (gradientSub_ = 2 J^T r): not worth a step
+            noStep = true;
+            break;
+          }
+          if (newton < 3 && sqrt(dn2) >= 1.05 * trRadius) { // :180-181
+            // Newton step on lambda (Nocedal & Wright eq. 4.44, :191-204): p_l = -(step), |q_l|^2 = p_l^T (R^T R)^-1 p_l
+            solveLLt(s.d, s.trial);
+            double pq = 0.0;
+            for (int c = tid; c < n; c += 256) {
+              pq += s.d[c] * s.trial[c];
+            }
+            const double q2 = blockSumF64(s, pq, tid);
+            if (q2 >= double(FLT_EPSILON)) { // :198
+              const double pn = sqrt(dn2);
+              const double deltaLambda = (dn2 / q2) * ((pn - trRadius) / trRadius);
+              if (deltaLambda > 0.0) { // :207: lambda only ever grows
+                lam += deltaLambda;
+                ++newton;
+                haveStep = false;
+                continue;
+              }
+            }
+          }
+          break;
+        }
+        if (noStep) {
+          break;
+        }
+        // trial step, gain ratio against the quadratic model e - 2 g.p + p^T (J^T J + 1e-20 I) p, where
+        // p^T J^T J p = g.p - mu |p|^2 because (J^T J + mu I) p = g  (:240-247)
+        makeTrial(1.0);
+        const double eNew = errorF64(rig, pb, s, s.trial, b, tid);
+        const double predicted = dg + (mu - 1e-20) * dn2; // e - model
+        const double rho = (curError - eNew) / predicted;
+        if (rho < 0.25) { // :256-262
+          trRadius = 0.25 * trRadius;
+        } else if (rho > 0.75 && lam > 0.0) {
+          trRadius = fmin(2.0 * trRadius, 10.0);
+        }
+        if (rho > 0.0) { // :265
+          acceptTrial();
+          break;
+        }
+      }
+      notPd = false; // (the rule's own retries dealt with it)
+    } else if (!notPd && fp.stepRule == 1) {
       double part = 0.0;
       for (int c = tid; c < n; c += 256) {
         part += s.d[c] * s.g[c] + lambda * s.d[c] * s.d[c];
@@ -978,6 +1085,7 @@ hipError_t launchSolveF64(
     const FusedParams& fp,
     double* Jg,
     double* Hg,
+    double* Hg2,
     hipStream_t stream) {
   const int genRows = pb.rowsJoint - 3 * pb.U;
   const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
@@ -991,7 +1099,7 @@ hipError_t launchSolveF64(
     }
   }
   hipLaunchKernelGGL(
-      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows));
+      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, Hg2, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows));
   return hipGetLastError();
 }
 

@@ -202,6 +202,7 @@ hipError_t launchSolveF64(
     const FusedParams& fp,
     double* Jg,
     double* Hg,
+    double* Hg2, // second [B][n][n] scratch, MMX_STEP_TRUST_REGION only (else null)
     hipStream_t stream);
 
 size_t fkJacobianLdsBytes(int J, int P, int U);

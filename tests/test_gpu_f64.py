@@ -244,14 +244,34 @@ def test_f64_solve_with_ellipsoid_limits(torch_cuda, orc, which, mode):
     assert np.abs(ref0["theta"] - ref["theta"]).max() > 1e-4
 
 
-def test_f64_refuses_the_trust_region(torch_cuda):
-    from momentum_amd import capi
+@pytest.mark.parametrize("radius", [1.0, 0.3])
+@pytest.mark.parametrize("which", ["reference_fixture", "humanoid72_all_joints"])
+def test_f64_trust_region_follows_the_oracle(torch_cuda, orc, which, radius):
+    """TrustRegionQRT<double>::doIteration (trust_region_qr.cpp:52-270) in the double instantiation: the reference's
+    TrustRegionTest.SanityCheck shape (solver_test.cpp:178-230: a constraint pair on every joint, random pose in
+    [-1, 1]^P, start at 0) and the 72-joint humanoid with every joint constrained -- J has full column rank on both, so
+    the LL^T of J^T J + (1e-20 + lambda - 1e-10) I IS the reference's QR with its appended sqrt(lambda) rows up to
+    rounding: same trial decisions, error history and pose parameters on the oracle's double run."""
     from momentum_amd._abi import MMX_STEP_TRUST_REGION
 
     torch = torch_cuda
-    rig = make_test_character(8)
-    cons, th0, _ = make_problem(rig, [7], [3], 2, seed=1)
-    rh, pb = _gpu(torch, rig, cons, 2)
-    with pytest.raises(capi.MmxError) as ei:
-        pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION))
-    assert "MMX_STEP_GN_FIXED_LAMBDA" in str(ei.value)
+    if which == "reference_fixture":
+        rig = make_test_character(5)
+        joints = list(range(rig.num_joints))
+        B, its, perturb = 16, 12, 1.0
+    else:
+        rig = make_humanoid72(variant="p219", unit=UNIT)
+        joints = list(range(rig.num_joints))
+        B, its, perturb = 6, 8, 0.3
+    cons, th0, _ = make_problem(rig, joints, joints, B, seed=900, perturb=perturb)
+    rh, pb = _gpu(torch, rig, cons, B)
+    opt = GnOptions.make(min_iterations=its, max_iterations=its, threshold=1000.0, step_rule=MMX_STEP_TRUST_REGION, trust_region_radius=radius)
+    out = pb.solve_f64(torch.from_numpy(th0.astype(np.float64)).to(pb.device), opt, want_history=True)
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"]) and np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.abs(h - href).max() <= 1e-7 * max(1.0, np.abs(href).max()), np.abs(h - href).max(axis=1)
+    th = out["theta"].cpu().numpy()
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert rel.max() <= 1e-7, rel
+    assert np.all(np.diff(h, axis=1) <= 1e-9 * np.abs(h[:, :-1]) + 1e-14)  # accepted steps only ever decrease the error
