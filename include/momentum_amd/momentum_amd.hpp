@@ -735,7 +735,8 @@ class BatchedGaussNewtonSolverQR : public BatchedSubsetGaussNewtonSolver {
   }
 };
 
-// TrustRegionQRT<float> for every element of the batch (trust_region_qr.cpp:52-270): the step rule
+// TrustRegionQRT<float> (and, through solve(std::vector<double>&), <double>) for every element of the batch
+// (trust_region_qr.cpp:52-270): the step rule
 // MMX_STEP_TRUST_REGION -- radius, up to ten trust steps per iteration, Newton updates of the damping, gain-ratio
 // radius update -- inside the one-launch solve where the problem fits it, on the wide route otherwise
 // (larger systems, further joint error functions, ellipsoid limits).

@@ -211,6 +211,19 @@ int main() {
     if (!differs || !(e_small[0] > e_wide[0]) || tr.getName() != "TrustRegionQR") {
       ++bad;
     }
+    // TrustRegionQRT<double>: the same solver object on double parameters (mmx_solve_f64 runs the rule in double).  The
+    // fixture is under-determined, so the two precisions part ways at some trial decision: the double run has to be as
+    // good a fit as the float one, not the same one (parity of the double rule with the oracle: tests/test_gpu_f64.py)
+    tr.setOptions(to);
+    std::vector<double> tdbl(B * P, 0.0);
+    const std::vector<double> etd = tr.solve(tdbl);
+    std::printf("  double instantiation: error %.6g (float %.6g)\n", etd[0], et[0]);
+    for (size_t b = 0; b < B; ++b) {
+      if (!(etd[b] < 0.1 * es[b]) || tr.getStatus()[b] != 0 || !(etd[b] <= 1.5 * et[b] + 1e-3)) {
+        std::printf("  instance %zu: double %.6g vs float %.6g, status %d\n", b, etd[b], et[b], tr.getStatus()[b]);
+        ++bad;
+      }
+    }
   }
   std::printf(bad == 0 ? "OK\n" : "FAIL\n");
   return bad == 0 ? 0 : 1;
