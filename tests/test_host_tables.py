@@ -157,3 +157,40 @@ def test_tile_structure_fill_in():
     ts = capi.host_tile_structure(rel)
     assert [int(ts["row_mask"][I]) for I in range(6)] == [1, 2, 4, 8, 16, 63]
     assert ts["products"] == 5  # the hub's diagonal tile: one product per earlier column
+
+
+@pytest.mark.parametrize("shape", ["bushy", "star", "chain"])
+@pytest.mark.parametrize("seed", range(4))
+def test_tile_structure_holds_the_real_normal_equations_of_random_rigs(orc, seed, shape):
+    """Random trees with shared parameters (one parameter driving rotations of several unrelated joints -- the case the
+    pattern's 'some joint of the one is an ancestor-or-self of some joint of the other' is written for): J^T J of the
+    oracle's double Jacobian at a random pose, in elimination order, has no entry outside the pattern, and its numerical
+    Cholesky factor no tile outside the symbolic structure."""
+    from tests.helpers import make_problem
+    from tests.test_gpu_fuzz import random_rig
+
+    rng = np.random.default_rng(1000 * seed + len(shape))
+    J = int(rng.integers(20, 90))
+    rig = random_rig(rng, J, shape)
+    anc = orc.ancestor_matrix(rig).astype(bool)
+    order = [int(p) for p in capi.host_tables(rig)["elimination_order"]]
+    assert sorted(order) == list(range(rig.num_params))
+    rel = _related(rig, order, anc)
+    ts = capi.host_tile_structure(rel)
+    n = len(order)
+    NB = (n + 15) // 16
+    pp = rng.choice(J, size=min(J, 12), replace=False)
+    op = rng.choice(J, size=min(J, 5), replace=False)
+    cons, th0, _ = make_problem(rig, pp, op, 1, seed=seed, perturb=0.3)
+    theta = rng.uniform(-0.3, 0.3, size=rig.num_params)
+    Jm, r, e = orc.eval_jacobian(rig, cons.instance(0), theta, dtype="f64")
+    H = (Jm.T @ Jm)[np.ix_(order, order)]
+    nz = np.abs(np.tril(H, -1)) > 1e-12 * max(1.0, np.abs(H).max())
+    assert not np.any(nz & ~rel.astype(bool))  # entry level: nothing outside the ancestor pattern
+    Lnz = np.abs(np.tril(np.linalg.cholesky(H + 0.05 * np.eye(n)))) > 1e-13 * max(1.0, np.abs(H).max())
+    for I in range(NB):
+        for Jc in range(I + 1):
+            if Lnz[16 * I : 16 * I + 16, 16 * Jc : 16 * Jc + 16].any():
+                assert ts["row_mask"][I] >> Jc & 1, (I, Jc)
+    if shape == "chain":  # every joint an ancestor of the ones below: wherever the parameters reach, the structure is dense
+        assert ts["products"] > 0 or NB == 1
