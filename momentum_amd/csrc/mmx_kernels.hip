@@ -3544,7 +3544,6 @@ hipError_t launchCholeskyStep(
     hipStream_t stream) {
   size_t lds = choleskyStepLdsBytes(pb.n, pb.M);
   if (lds > 160 * 1024 && factor != nullptr) { // large system: left-looking factor in its own tile-major scratch
-    const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
     // rows of J per refinement chunk: 32 (every column contributes one full 128-byte line per chunk) while the
     // chunk's loads fit the prefetch registers, else 16
     const int chunkRows = size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
