@@ -1834,34 +1834,42 @@ __device__ __forceinline__ void tiledPanelFactor(float* pan, int nt, int k, floa
   const bool active = diagLane || prow < 16 * nt;
   float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
   const int trow = diagLane ? lane : (prow & 15);
-  float a[16];
+  // a wave whose forty-eight rows all lie beyond the panel only takes part in the barriers: its copy of the chain would
+  // compete for the issue slots of its SIMD with the co-resident workgroup's wave (wave-uniform branch)
+  const bool waveWorks = wave == 0 || 16 + 48 * wave < 16 * nt;
+  float a[16] = {};
+  float bi = 0.f;
+  if (waveWorks) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
-    a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+      a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+    }
+    bi = g[16 * k + lrow]; // s_k
   }
-  float bi = g[16 * k + lrow]; // s_k
   __syncthreads();
   float invd = 0.f;
   bool bad = false;
+  if (waveWorks) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float djj = readLaneF(a[j], j);
-    bad = bad || !(djj > 0.f);
-    const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
-    a[j] *= inv;
-    if (lane == j) {
-      invd = inv;
-    }
-    // L_kk y_k = s_k rides along (lanes 0-15: row j's entry is final once column j is scaled; the other lanes carry a dummy)
-    const float yj = readLaneF(bi, j) * inv;
-    bi = (lane == j) ? yj : (lane > j ? bi - a[j] * yj : bi); // (a row's entries right of the diagonal are scratch)
+    for (int j = 0; j < 16; ++j) {
+      const float djj = readLaneF(a[j], j);
+      bad = bad || !(djj > 0.f);
+      const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
+      a[j] *= inv;
+      if (lane == j) {
+        invd = inv;
+      }
+      // L_kk y_k = s_k rides along (lanes 0-15: row j's entry is final once column j is scaled; the other lanes carry a dummy)
+      const float yj = readLaneF(bi, j) * inv;
+      bi = (lane == j) ? yj : (lane > j ? bi - a[j] * yj : bi); // (a row's entries right of the diagonal are scratch)
 #pragma unroll
-    for (int c = j + 1; c < 16; ++c) {
-      a[c] -= a[j] * readLaneF(a[j], c);
+      for (int c = j + 1; c < 16; ++c) {
+        a[c] -= a[j] * readLaneF(a[j], c);
+      }
     }
   }
-  if (diagLane) {
+  if (waveWorks && diagLane) {
     if (wave == 0) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -1872,7 +1880,7 @@ __device__ __forceinline__ void tiledPanelFactor(float* pan, int nt, int k, floa
         flags[0] = 1;
       }
     }
-  } else if (active) {
+  } else if (waveWorks && active) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       Tl[tileAddr(trow, c)] = a[c];
