@@ -194,3 +194,18 @@ def test_tile_structure_holds_the_real_normal_equations_of_random_rigs(orc, seed
                 assert ts["row_mask"][I] >> Jc & 1, (I, Jc)
     if shape == "chain":  # every joint an ancestor of the ones below: wherever the parameters reach, the structure is dense
         assert ts["products"] > 0 or NB == 1
+
+
+def test_tile_structure_argument_checks():
+    """n outside 0..512 is refused with a message (32 mask bits per block row); n = 0 is the empty structure."""
+    import ctypes as C
+
+    row, col = np.zeros(32, np.uint32), np.zeros(32, np.uint32)
+    prod = C.c_int64(-1)
+    rel = np.zeros((1, 1), np.uint8)
+    rc = capi.lib().mmx_host_tile_structure(C.c_int32(513), capi.as_ptr(rel, C.c_uint8), capi.as_ptr(row, C.c_uint32), capi.as_ptr(col, C.c_uint32), C.byref(prod))
+    assert rc != 0 and b"512" in capi.lib().mmx_last_error()
+    rc = capi.lib().mmx_host_tile_structure(C.c_int32(0), None, capi.as_ptr(row, C.c_uint32), capi.as_ptr(col, C.c_uint32), C.byref(prod))
+    assert rc == 0 and prod.value == 0 and not row.any() and not col.any()
+    ts = capi.host_tile_structure(np.zeros((512, 512), np.uint8))  # the largest system: 32 diagonal tiles, nothing else
+    assert [int(x) for x in ts["row_mask"]] == [1 << i for i in range(32)] and ts["products"] == 0
