@@ -209,3 +209,53 @@ def test_tile_structure_argument_checks():
     assert rc == 0 and prod.value == 0 and not row.any() and not col.any()
     ts = capi.host_tile_structure(np.zeros((512, 512), np.uint8))  # the largest system: 32 diagonal tiles, nothing else
     assert [int(x) for x in ts["row_mask"]] == [1 << i for i in range(32)] and ts["products"] == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tile_structure_is_closed_under_elimination(seed):
+    """What the masked factorisation relies on (tiledFactorPairs, choleskyFactorResidentKernel): if two tiles (I, k) and
+    (J, k), I >= J > k, of a block column exist, tile (I, J) exists -- so the product L(I,k) L(J,k)^T always has a home, and
+    column k + 1's missing term from column k's panel only ever touches rows column k + 1 holds.  Random patterns, and the
+    masked left-looking algorithm on the tile grid (only listed tiles are read or written) against a dense Cholesky."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(40, 200))
+    NB = (n + 15) // 16
+    rel = np.tril((rng.uniform(size=(n, n)) < rng.uniform(0.005, 0.05)).astype(np.uint8), -1)
+    ts = capi.host_tile_structure(rel)
+    M = np.array([[bool(ts["row_mask"][I] >> Jc & 1) for Jc in range(NB)] for I in range(NB)])
+    for k in range(NB):
+        rows = [I for I in range(k + 1, NB) if M[I, k]]
+        for I in rows:
+            for Jc in rows:
+                if Jc <= I:
+                    assert M[I, Jc], (k, I, Jc)
+        assert M[k, k] and bool(ts["col_mask"][k] >> k & 1)
+    # masked block algorithm in double on a padded SPD matrix with that pattern
+    NP = 16 * NB
+    A = np.zeros((NP, NP))
+    A[:n, :n] = np.tril(rel, -1) * rng.uniform(0.5, 1.0, size=(n, n))
+    A = A + A.T + np.eye(NP) * (n + 1.0)
+    tile = lambda X, I, Jc: X[16 * I : 16 * I + 16, 16 * Jc : 16 * Jc + 16]
+    L = np.full((NP, NP), np.nan)  # tiles outside the structure are never written: NaN would poison a wrong read
+    products = 0
+    for k in range(NB):
+        for I in range(k, NB):
+            if not M[I, k]:
+                continue
+            C = tile(A, I, k).copy()
+            for j in range(k):
+                if M[I, j] and M[k, j]:
+                    C -= tile(L, I, j) @ tile(L, k, j).T
+                    products += 1
+            if I == k:
+                tile(L, k, k)[:] = np.linalg.cholesky(C)
+            else:
+                tile(L, I, k)[:] = np.linalg.solve(tile(L, k, k), C.T).T
+    assert products == ts["products"]
+    Ld = np.linalg.cholesky(A)
+    for I in range(NB):
+        for Jc in range(I + 1):
+            if M[I, Jc]:
+                assert np.abs(tile(L, I, Jc) - tile(Ld, I, Jc)).max() <= 1e-10
+            else:
+                assert np.abs(tile(Ld, I, Jc)).max() <= 1e-12
