@@ -36,12 +36,16 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 8 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
+#define MMX_ABI_VERSION 9 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
                              trust_region_radius), mmx_comm_* (RCCL), MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J
                              7: mmx_tuning / mmx_problem_set_tuning / mmx_problem_last_route (replace the MMX_* environment
                              switches of earlier builds: the library reads no environment variable on the solve path)
                              8: columns in elimination order + tile-sparse factor on the wide route
-                                (mmx_host_elimination_order, mmx_host_tile_structure, mmx_problem_tile_structure) */
+                                (mmx_host_elimination_order, mmx_host_tile_structure, mmx_problem_tile_structure)
+                             9: status[] is a bit set (MMX_SOLVE_DAMPING_FLOORED, informational), sized form of the
+                                constraint call (mmx_problem_set_constraints_sized), mmx_eval_skeleton_state_host.
+                             A caller MUST compare mmx_abi_version() with the MMX_ABI_VERSION it was compiled against
+                             before any other call: the structs below grow at their end from version to version. */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
 #define MMX_INVALID_PARENT (-1) /* kInvalidIndex, momentum/character/types.h:182 */
 #define MMX_MAX_MODEL_PARAMS 2048 /* kMaxModelParams, momentum/math/types.h:426 */
@@ -72,6 +76,19 @@ typedef enum mmx_status {
                               FACTOR is damped by at least 1e-5 of the mean diagonal of J^T J (the refinement measures
                               its residual with the caller's lambda through J, so the step is the caller's wherever J
                               determines it): the drop rule is the last resort and this status is rare. */
+
+#define MMX_SOLVE_DAMPING_FLOORED 4 /* (bit, informational; since ABI 9 status[] is a bit set and MMX_SOLVE_NONFINITE /
+                                       MMX_SOLVE_NOT_PD are its error bits, MMX_SOLVE_ERROR_MASK) in at least one
+                                       iteration the caller's damping was below the floor of the single-precision
+                                       FACTOR, 1e-5 of the mean diagonal of J^T J (the note above): what was factored is
+                                       J^T J + floor I, the refinement pulled the step towards the caller's damping
+                                       wherever J determines it, and the predicted decrease of the LM schedule / trust
+                                       region was formed with the caller's value.  Where J is rank deficient or barely
+                                       determined (BASELINE configs[0], configs[1] below lambda ~ 1e-3) such a solve
+                                       is NOT within 1e-5 of the reference's double instantiation on the pose
+                                       parameters -- no single-precision normal-equation solver is; the answer there
+                                       is mmx_solve_f64.  mmx_solve_f64 never sets this bit. */
+#define MMX_SOLVE_ERROR_MASK 3 /* status & MMX_SOLVE_ERROR_MASK == 0: the solve of that element is sound */
 
 /* Where the caller's bulk arrays live. */
 #define MMX_MEM_HOST 0
@@ -397,8 +414,10 @@ int32_t mmx_problem_set_instance_parents(
  * test that wants every route exercised on the same inputs, or a benchmark -- can pin the route per problem handle.
  * A pinned route the problem does not fit makes mmx_solve return MMX_ERR_UNSUPPORTED; it never falls through silently.
  *   MMX_ROUTE_FUSED              one launch, one workgroup per instance, the system in LDS (<= 224 solved parameters)
- *   MMX_ROUTE_WIDE               normal equations from the tree moments, left-looking Cholesky with the factor in HBM,
- *                                refinement through the tree (<= 512 solved parameters; the default from 129 on)
+ *   MMX_ROUTE_WIDE               normal equations from the tree moments, left-looking blocked Cholesky over the
+ *                                structurally non-zero 16 x 16 tiles (columns in elimination order) -- the factor resident
+ *                                in LDS while its tiles fit half a CU (<= ~75 tiles), in HBM beyond --, refinement through
+ *                                the tree (<= 512 solved parameters; the default from 129 on)
  *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores) -> Cholesky step; the route for problems
  *                                outside the tree kernels' scope
  * The route does not change WHAT is computed (same algorithm, same refinement); results of different routes agree to
@@ -439,6 +458,16 @@ int32_t mmx_problem_set_enabled(mmx_problem* problem, const uint8_t* enabled);
 int32_t mmx_problem_set_constraints(
     mmx_problem* problem,
     const mmx_constraint_data* data,
+    void* stream);
+/* The same with sizeof(mmx_constraint_data) AS THE CALLER WAS COMPILED: mmx_constraint_data grows at its end (ABI 8
+ * appended function_weights / num_function_weights), and a caller built against an older header hands over a shorter
+ * struct.  Fields past data_size read as zero / NULL (= absent); a data_size larger than this library's struct is
+ * MMX_ERR_INVALID_ARGUMENT (the caller is newer than the library).  Bindings should call this form
+ * (the C++ shell and the ctypes plumbing do); mmx_problem_set_constraints trusts the full current layout. */
+int32_t mmx_problem_set_constraints_sized(
+    mmx_problem* problem,
+    const mmx_constraint_data* data,
+    size_t data_size,
     void* stream);
 
 /*
@@ -623,6 +652,8 @@ int32_t mmx_eval_jacobian_host(
     float* res_host,
     double* err_host,
     int32_t layout);
+/* mmx_eval_skeleton_state with host buffers: theta_host [B][P] -> state_host [B][J][8] (tx,ty,tz, qx,qy,qz,qw, s). */
+int32_t mmx_eval_skeleton_state_host(mmx_problem* problem, const float* theta_host, float* state_host);
 
 /*
  * Multi-GPU: instances are independent, so a batch shards into contiguous blocks, one problem handle per

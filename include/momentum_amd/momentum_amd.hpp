@@ -557,7 +557,7 @@ class BatchedSkeletonSolverFunction {
     d.joint_blocks = jb.empty() ? nullptr : jb.data();
     d.function_weights = fnWeights_.empty() ? nullptr : fnWeights_.data();
     d.num_function_weights = int32_t(fnCols_);
-    check(mmx_problem_set_constraints(handle_.get(), &d, nullptr));
+    check(mmx_problem_set_constraints_sized(handle_.get(), &d, sizeof(d), nullptr));
     // per-element parent lists only when some element departs from the constructor's lists
     auto departs = [&](const std::vector<int32_t>& all, const std::vector<int32_t>& shared) {
       for (size_t b = 0; b < batch_; ++b) {
@@ -588,6 +588,9 @@ class BatchedSkeletonSolverFunction {
   }
   mmx_problem* handle() const {
     return handle_.get();
+  }
+  const DeviceCharacter& character() const {
+    return character_;
   }
 
  private:
@@ -639,6 +642,79 @@ class BatchedSkeletonSolverFunction {
 };
 
 // GaussNewtonSolverT<float> for every element of the batch at once.
+// TransformT<float> (momentum/math/transform.h:36-42): p -> translation + rotation * (scale * p)
+struct Transform {
+  Vector3f translation{0.f, 0.f, 0.f};
+  Quaternionf rotation{0.f, 0.f, 0.f, 1.f}; // (x, y, z, w)
+  float scale = 1.f;
+  Vector3f transformPoint(const Vector3f& p) const { // transform.h:193 (Eigen's quaternion * vector: v + w uv + qv x uv, uv = 2 qv x v)
+    const float x = scale * p[0], y = scale * p[1], z = scale * p[2];
+    const float qx = rotation[0], qy = rotation[1], qz = rotation[2], qw = rotation[3];
+    const float ux = 2.f * (qy * z - qz * y), uy = 2.f * (qz * x - qx * z), uz = 2.f * (qx * y - qy * x);
+    return Vector3f{
+        translation[0] + x + qw * ux + (qy * uz - qz * uy),
+        translation[1] + y + qw * uy + (qz * ux - qx * uz),
+        translation[2] + z + qw * uz + (qx * uy - qy * ux)};
+  }
+};
+// the world-space part of JointStateT<float> (momentum/character/joint_state.h:50-74)
+struct JointState {
+  Transform transform;
+  const Vector3f& translation() const {
+    return transform.translation;
+  }
+  const Quaternionf& rotation() const {
+    return transform.rotation;
+  }
+  float scale() const {
+    return transform.scale;
+  }
+};
+// SkeletonStateT<float> (momentum/character/skeleton_state.h:45): jointState[j] of one character
+struct SkeletonState {
+  std::vector<JointState> jointState;
+};
+// SkeletonStateT<float>(parameterTransform.apply(modelParameters), skeleton) for every batch element
+// (skeleton_state.cpp:22-28,87-121; the forward pass only, call stack SURVEY 3.3): element b is evaluated on ITS
+// character when the function carries per-element characters.  modelParameters: [batch][numParameters].
+class BatchedSkeletonState {
+ public:
+  BatchedSkeletonState() = default;
+  BatchedSkeletonState(BatchedSkeletonSolverFunction& function, const std::vector<float>& modelParameters) {
+    set(function, modelParameters);
+  }
+  void set(BatchedSkeletonSolverFunction& function, const std::vector<float>& modelParameters) {
+    function.sync();
+    const size_t B = function.batchSize(), P = function.getNumParameters();
+    if (modelParameters.size() != B * P) {
+      throw std::runtime_error("momentum_amd: parameters.size() != batch * numParameters"); // parameter_transform.cpp:112-121
+    }
+    const size_t J = size_t(mmx_rig_num_joints(function.character().handle()));
+    std::vector<float> st(B * J * 8);
+    check(mmx_eval_skeleton_state_host(function.handle(), modelParameters.data(), st.data()));
+    states_.assign(B, SkeletonState{});
+    for (size_t b = 0; b < B; ++b) {
+      states_[b].jointState.resize(J);
+      for (size_t j = 0; j < J; ++j) {
+        const float* w = st.data() + (b * J + j) * 8;
+        Transform& t = states_[b].jointState[j].transform;
+        t.translation = Vector3f{w[0], w[1], w[2]};
+        t.rotation = Quaternionf{w[3], w[4], w[5], w[6]};
+        t.scale = w[7];
+      }
+    }
+  }
+  size_t batchSize() const {
+    return states_.size();
+  }
+  const SkeletonState& operator[](size_t b) const {
+    return states_.at(b);
+  }
+
+ private:
+  std::vector<SkeletonState> states_;
+};
+
 class BatchedGaussNewtonSolver {
  public:
   BatchedGaussNewtonSolver(const SolverOptions& options, BatchedSkeletonSolverFunction* function) : fn_(function) {

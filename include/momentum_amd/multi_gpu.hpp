@@ -38,8 +38,17 @@ struct RcclNormsComm {
     std::vector<mmx_comm*> comms(devices.size(), nullptr);
     check(mmx_comm_create_all(int32_t(devs.size()), devs.data(), comms.data()));
     std::vector<Handle> out;
-    for (mmx_comm* c : comms) {
-      out.emplace_back(c, [](mmx_comm* p) { mmx_comm_destroy(p); });
+    size_t wrapped = 0;
+    try {
+      out.reserve(comms.size());
+      for (; wrapped < comms.size(); ++wrapped) { // (shared_ptr's constructor runs the deleter itself when it throws)
+        out.emplace_back(comms[wrapped], [](mmx_comm* p) { mmx_comm_destroy(p); });
+      }
+    } catch (...) {
+      for (size_t i = wrapped + 1; i < comms.size(); ++i) { // the ones no handle owns yet
+        mmx_comm_destroy(comms[i]);
+      }
+      throw;
     }
     return out;
   }
@@ -154,7 +163,7 @@ class BatchedMultiGpuSolverT {
             for (size_t k = 0; k < err.size(); ++k) {
               local[0] += err[k];
               local[1] += double(sh.solver->getIterations()[k]);
-              local[2] += sh.solver->getStatus()[k] != 0 ? 1.0 : 0.0;
+              local[2] += (sh.solver->getStatus()[k] & MMX_SOLVE_ERROR_MASK) != 0 ? 1.0 : 0.0;
             }
           }
         } catch (...) {

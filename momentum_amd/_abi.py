@@ -14,9 +14,11 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-MMX_ABI_VERSION = 8
+MMX_ABI_VERSION = 9
 MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
+MMX_SOLVE_DAMPING_FLOORED = 4  # informational bit of status[] (include/mmx.h)
+MMX_SOLVE_ERROR_MASK = 3
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
 MMX_LAYOUT_COL_MAJOR, MMX_LAYOUT_ROW_MAJOR = 0, 1
 MMX_STEP_GN_FIXED_LAMBDA, MMX_STEP_LM_SCHEDULE, MMX_STEP_TRUST_REGION = 0, 1, 2

@@ -27,9 +27,9 @@ SYMBOLS = [
     "mmx_rig_create", "mmx_rig_destroy", "mmx_rig_num_joints", "mmx_rig_num_params",
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
     "mmx_problem_set_tuning", "mmx_problem_last_route",
-    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
+    "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_constraints_sized", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
-    "mmx_eval_jacobian_host", "mmx_host_tables", "mmx_debug_fused_normal_equations", "mmx_debug_tree_normal_equations",
+    "mmx_eval_jacobian_host", "mmx_eval_skeleton_state_host", "mmx_host_tables", "mmx_debug_fused_normal_equations", "mmx_debug_tree_normal_equations",
     "mmx_host_elimination_order", "mmx_host_tile_structure", "mmx_problem_tile_structure",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
     "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
     L.mmx_problem_set_tuning.argtypes = [vp, C.POINTER(_abi.Tuning)]
     L.mmx_problem_last_route.argtypes = [vp]
     L.mmx_problem_set_constraints.argtypes = [vp, C.POINTER(ConstraintData), vp]
+    L.mmx_problem_set_constraints_sized.argtypes = [vp, C.POINTER(ConstraintData), C.c_size_t, vp]
     L.mmx_problem_set_instance_rig.argtypes = [vp, vp, vp, i32, vp]
     L.mmx_problem_set_instance_parents.argtypes = [vp, vp, vp, i32, vp]
     L.mmx_eval_jacobian.argtypes = [vp, vp, vp, vp, vp, i32, vp]
@@ -87,6 +88,7 @@ def lib() -> C.CDLL:
     L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_solve_f64_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_eval_jacobian_host.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.mmx_eval_skeleton_state_host.argtypes = [vp, vp, vp]
     L.mmx_debug_tree_normal_equations.argtypes = [vp, vp, vp, vp, vp]
     L.mmx_debug_fused_normal_equations.argtypes = [vp, vp, vp, vp, _abi.c_int32_p, _abi.c_int32_p, vp]
     L.mmx_comm_unique_id.argtypes = [vp]
@@ -239,6 +241,12 @@ class Problem:
 
     # -- which kernels mmx_solve runs (mmx_tuning): "auto" | "fused" | "wide" | "explicit_jacobian"
     def set_route(self, route: str, max_refinement_steps: int = 0) -> None:
+        # a caller that pins a route means it: the sweep default (MMX_TEST_ROUTE=prefer_wide) steps back for this handle
+        # until the caller returns to "auto" (route-pinned tests then run what they name under a forced-route sweep)
+        self._prefer_wide = default_route == "prefer_wide" and route == "auto"
+        self._set_tuning(route, max_refinement_steps)
+
+    def _set_tuning(self, route: str, max_refinement_steps: int = 0) -> None:
         t = _abi.Tuning()
         t.route = _abi.ROUTES[route]
         t.max_refinement_steps = int(max_refinement_steps)  # 0 default (up to three), -1 none, 1..3
@@ -317,7 +325,7 @@ class Problem:
             len(ells), C.cast(earr, C.c_void_p) if ells else None,
             fw_ptr, fw_cols,
         )  # fmt: skip
-        _check(lib().mmx_problem_set_constraints(self._h, C.byref(cd), _stream_ptr()))
+        _check(lib().mmx_problem_set_constraints_sized(self._h, C.byref(cd), C.sizeof(cd), _stream_ptr()))
         self._keep = keep + bkeep if on_dev else []
         self.M = int(lib().mmx_problem_num_rows(self._h))
 
@@ -482,17 +490,25 @@ class Problem:
             self._prefer_wide = False
             keep = theta.clone()
             try:
-                self.set_route("wide")
+                self._set_tuning("wide")
                 return self.solve(theta, options, want_history, outputs, want_parameter_history)
             except MmxError as e:
                 if e.code != 4:  # MMX_ERR_UNSUPPORTED: outside the tree kernels' scope -> the library's own choice
                     raise
                 theta.copy_(keep)
-                self.set_route("auto")
+                self._set_tuning("auto")
             finally:
                 self._prefer_wide = True
-                if self.last_route() == "wide":
-                    self.set_route("auto")
+                import sys
+
+                if sys.exc_info()[0] is None:  # (an exception on its way out is not to be masked by a second library call)
+                    if self.last_route() == "wide":
+                        self._set_tuning("auto")
+                else:
+                    try:
+                        self._set_tuning("auto")
+                    except Exception:
+                        pass
         if outputs is None:
             outputs = dict(
                 error=torch.empty((self.B,), dtype=torch.float64, device=self.device),

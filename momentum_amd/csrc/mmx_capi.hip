@@ -1430,6 +1430,23 @@ int32_t mmx_problem_set_instance_parents(mmx_problem* pb, const int32_t* pos_par
   return MMX_OK;
 }
 
+int32_t mmx_problem_set_constraints_sized(mmx_problem* pb, const mmx_constraint_data* c, size_t dataSize, void* stream) {
+  if (c == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "constraint data is null");
+  }
+  // the layout every ABI since 1 shares ends with the `memory` field
+  if (dataSize < offsetof(mmx_constraint_data, memory) + sizeof(int32_t)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_problem_set_constraints_sized: data_size is smaller than any mmx_constraint_data");
+  }
+  if (dataSize > sizeof(mmx_constraint_data)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_problem_set_constraints_sized: data_size is larger than this library's mmx_constraint_data (caller built against a newer ABI)");
+  }
+  mmx_constraint_data full;
+  std::memset(&full, 0, sizeof(full)); // fields the caller's header did not have: absent
+  std::memcpy(&full, c, dataSize);
+  return mmx_problem_set_constraints(pb, &full, stream);
+}
+
 int32_t mmx_problem_set_constraints(mmx_problem* pb, const mmx_constraint_data* c, void* stream) {
   MMX_ZONE("mmx_problem_set_constraints");
   int32_t rc = checkProblem(pb, false);
@@ -2450,6 +2467,29 @@ int32_t mmx_solve_f64_host(
   if (status_host) {
     MMX_HIP(hipMemcpy(status_host, pb->sStatus.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
   }
+  return MMX_OK;
+}
+
+int32_t mmx_eval_skeleton_state_host(mmx_problem* pb, const float* theta_host, float* state_host) {
+  MMX_ZONE("mmx_eval_skeleton_state_host");
+  int32_t rc = checkProblem(pb, false);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_host == nullptr || state_host == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "theta / state is null");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P), J = size_t(pb->rig->J);
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  MMX_HIP(pb->sTheta.ensure(B * P * sizeof(float)));
+  MMX_HIP(pb->sRes.ensure(B * J * 8 * sizeof(float)));
+  MMX_HIP(hipMemcpy(pb->sTheta.p, theta_host, B * P * sizeof(float), hipMemcpyHostToDevice));
+  rc = mmx_eval_skeleton_state(pb, pb->sTheta.as<float>(), pb->sRes.as<float>(), nullptr);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  MMX_HIP(hipDeviceSynchronize());
+  MMX_HIP(hipMemcpy(state_host, pb->sRes.p, B * J * 8 * sizeof(float), hipMemcpyDeviceToHost));
   return MMX_OK;
 }
 

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) residualNormsKernel(
   for (int b = threadIdx.x; b < B; b += 256) {
     e += err != nullptr ? err[b] : 0.0;
     it += iters != nullptr ? double(iters[b]) : 0.0;
-    bad += (status != nullptr && status[b] != 0) ? 1.0 : 0.0;
+    bad += (status != nullptr && (status[b] & MMX_SOLVE_ERROR_MASK) != 0) ? 1.0 : 0.0; // (informational bits do not count)
   }
   red[0][threadIdx.x] = e, red[1][threadIdx.x] = it, red[2][threadIdx.x] = bad;
   __syncthreads();

@@ -21,7 +21,6 @@
 namespace mmx {
 
 constexpr int kJs = 21; // floats per joint in js[]: 17 used, odd stride (lanes = joints read a field without LDS bank conflicts)
-constexpr int kAlt = 9; // floats per joint in the second pointer-jumping buffer: 8 used, odd stride
 // Pivot threshold of every single-precision Cholesky in this library: when column j's pivot
 // d_jj = (H_jj + lambda) - sum_k l_jk^2 comes out at or below kPivotFloor * (H_jj + lambda), column j is DROPPED from this
 // iteration's step -- 1 / l_jj := 0, so l_ij = 0 below it and parameter j's step is exactly 0, as if the column were
@@ -343,42 +342,93 @@ __device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* _
   fkLocalSplit(rig, j, theta, o, o + 8);
 }
 
-// World transforms of all joints by double-buffered pointer jumping (see fkJacobianKernel for the
-// single-buffer form): `rounds` = ceil(log2(depth)) rounds, one workgroup barrier each.  Buffers:
-// js (stride kJs) and alt (stride kAlt), jump targets (+1) in jlA / jlB.  Precondition (barrier
-// done): the local transforms and the initial targets (= parents) are in js / jlA when `rounds`
-// is even, in alt / jlB when it is odd; the result always ends up in js.
-__device__ __forceinline__ void
-fkJumpRounds(float* js, float* alt, int* jlA, int* jlB, int J, int rounds, int tid, int nthreads) {
+// World transforms of all joints by double-buffered pointer jumping (see fkJacobianKernel for the single-buffer
+// single-precision form): `rounds` = ceil(log2(depth)) rounds, one workgroup barrier each, T_j <- T_a * T_j, a_j <- a_a.
+//
+// The partial products are carried in DOUBLE (round 4).  Pointer jumping re-associates SkeletonStateT::set's
+// parent-before-child product; in single precision every joint's world transform then carries its own rounding history
+// (each round rounds a different partial product), so the errors of a joint and of its parent are INDEPENDENT, where
+// the reference's sequential product hands the parent's error on to the child (child = fl(parent * local)).  Absolute
+// errors are the same (measured: 4.9e-8 m median either way on the 72-joint rig) but the relative geometry of
+// neighbouring joints -- what the finger angles are solved from -- is 2-3 x noisier: the solve's distance to the double
+// run sat at 1.5e-6 median / 8e-6 worst of 1024 instead of the float instantiation's 0.7e-6 / 2.6e-6
+// (scripts/diag_step_noise.py, diag_g_stages.py; profiles/r04_fk_noise.txt).  With the products in double the result is
+// the exact product of the single-precision local transforms rounded ONCE, which is tighter than the sequential
+// single-precision product.  gfx950 issues v_fma_f64 at the rate of v_fma_f32.
+//
+// Buffers: bufA / bufB, channel-major doubles [kFkCh][fkPad(J)]: t (3) q (4) s | jump target + 1 (an int in the
+// ninth 64-bit slot).  Precondition (barrier done): the local transforms and the parents are in bufA (fkStoreLocalD).  The last
+// round writes the world transform (t, q, s as floats) to js[kJs j + 0..7]; with rounds == 0 the caller writes js itself.
+constexpr int kFkCh = 9;
+__host__ __device__ __forceinline__ int fkPad(int J) {
+  return (J + 1) & ~1;
+}
+__host__ __device__ __forceinline__ size_t fkBufFloats(int J) { // one buffer, in floats (a multiple of 4)
+  return 2 * size_t(kFkCh) * size_t(fkPad(J));
+}
+struct FkXf {
+  double tx, ty, tz, qx, qy, qz, qw, s;
+  int jl;
+};
+__device__ __forceinline__ FkXf fkLoadD(const double* buf, int Jp, int j) {
+  FkXf x;
+  x.tx = buf[j], x.ty = buf[Jp + j], x.tz = buf[2 * Jp + j];
+  x.qx = buf[3 * Jp + j], x.qy = buf[4 * Jp + j], x.qz = buf[5 * Jp + j], x.qw = buf[6 * Jp + j];
+  x.s = buf[7 * Jp + j];
+  x.jl = reinterpret_cast<const int*>(buf + 8 * Jp)[2 * j];
+  return x;
+}
+__device__ __forceinline__ void fkStoreD(double* buf, int Jp, int j, const FkXf& x) {
+  buf[j] = x.tx, buf[Jp + j] = x.ty, buf[2 * Jp + j] = x.tz;
+  buf[3 * Jp + j] = x.qx, buf[4 * Jp + j] = x.qy, buf[5 * Jp + j] = x.qz, buf[6 * Jp + j] = x.qw;
+  buf[7 * Jp + j] = x.s;
+  reinterpret_cast<int*>(buf + 8 * Jp)[2 * j] = x.jl;
+}
+// the local transform o[0..7] = (t, q, s) of fkLocalFromParams and the joint's parent (+1) into bufA
+__device__ __forceinline__ void fkStoreLocalD(double* bufA, int Jp, int j, const float* o, int parentPlus1) {
+  FkXf x;
+  x.tx = o[0], x.ty = o[1], x.tz = o[2], x.qx = o[3], x.qy = o[4], x.qz = o[5], x.qw = o[6];
+  x.s = o[7], x.jl = parentPlus1;
+  fkStoreD(bufA, Jp, j, x);
+}
+// x <- p * x (transform.h:124-129: t = tp + qp (sp t), q = qp q, s = sp s) in double; Eigen's _transformVector form
+__device__ __forceinline__ void fkComposeD(const FkXf& p, FkXf& x) {
+  const double sp = p.s;
+  const double vx = sp * x.tx, vy = sp * x.ty, vz = sp * x.tz;
+  double ux = p.qy * vz - p.qz * vy, uy = p.qz * vx - p.qx * vz, uz = p.qx * vy - p.qy * vx;
+  ux += ux, uy += uy, uz += uz;
+  const double tx = p.tx + (vx + p.qw * ux + (p.qy * uz - p.qz * uy));
+  const double ty = p.ty + (vy + p.qw * uy + (p.qz * ux - p.qx * uz));
+  const double tz = p.tz + (vz + p.qw * uz + (p.qx * uy - p.qy * ux));
+  const double qx = p.qw * x.qx + p.qx * x.qw + p.qy * x.qz - p.qz * x.qy;
+  const double qy = p.qw * x.qy + p.qy * x.qw + p.qz * x.qx - p.qx * x.qz;
+  const double qz = p.qw * x.qz + p.qz * x.qw + p.qx * x.qy - p.qy * x.qx;
+  const double qw = p.qw * x.qw - p.qx * x.qx - p.qy * x.qy - p.qz * x.qz;
+  x.tx = tx, x.ty = ty, x.tz = tz, x.qx = qx, x.qy = qy, x.qz = qz, x.qw = qw;
+  x.s = p.s * x.s;
+  x.jl = p.jl;
+}
+__device__ __forceinline__ void fkJumpRoundsD(float* js, double* bufA, double* bufB, int J, int rounds, int tid, int nthreads) {
+  const int Jp = fkPad(J);
   for (int r = 0; r < rounds; ++r) {
-    const bool fromJs = ((rounds - r) & 1) == 0;
-    const float* src = fromJs ? js : alt;
-    float* dst = fromJs ? alt : js;
-    const int ss = fromJs ? kJs : kAlt, ds = fromJs ? kAlt : kJs;
-    const int* jlS = fromJs ? jlA : jlB;
-    int* jlD = fromJs ? jlB : jlA;
+    const double* src = (r & 1) ? bufB : bufA;
+    double* dst = (r & 1) ? bufA : bufB;
+    const bool last = r == rounds - 1;
     for (int j = tid; j < J; j += nthreads) {
-      const int a = jlS[j] - 1;
-      const float* o = src + ss * j;
-      F3 t{o[0], o[1], o[2]};
-      Q4 q{o[3], o[4], o[5], o[6]};
-      float sc = o[7];
-      int next = 0;
+      FkXf x = fkLoadD(src, Jp, j);
+      const int a = x.jl - 1;
       if (a >= 0) {
-        const float* p = src + ss * a;
-        const F3 tp{p[0], p[1], p[2]};
-        const Q4 qp{p[3], p[4], p[5], p[6]};
-        const float sp = p[7];
-        next = jlS[a];
-        t = tp + qrot(qp, sp * t); // transform.h:124-129
-        q = qmul(qp, q);
-        sc = sp * sc;
+        const FkXf p = fkLoadD(src, Jp, a);
+        fkComposeD(p, x);
       }
-      float* w = dst + ds * j;
-      w[0] = t.x, w[1] = t.y, w[2] = t.z;
-      w[3] = q.x, w[4] = q.y, w[5] = q.z, w[6] = q.w;
-      w[7] = sc;
-      jlD[j] = next;
+      if (last) {
+        float* w = js + kJs * j;
+        w[0] = float(x.tx), w[1] = float(x.ty), w[2] = float(x.tz);
+        w[3] = float(x.qx), w[4] = float(x.qy), w[5] = float(x.qz), w[6] = float(x.qw);
+        w[7] = float(x.s);
+      } else {
+        fkStoreD(dst, Jp, j, x);
+      }
     }
     __syncthreads();
   }

@@ -66,9 +66,8 @@ struct FusedLds {
   float* gW; // [rowsGp] r - J d of the refinement
   float* gJ; // [rowsGp][gst] their Jacobian rows over the solve columns (pad rows / columns zero)
   // ---- one region, two lives: assembly scratch (phases A-G), then the Cholesky factor (H-J)
-  float* alt; // [kAlt J] second transform buffer of the pointer-jumping FK
-  int* jlA; // [J] jump targets (+1), double-buffered
-  int* jlB;
+  double* fkA; // [kFkCh][fkPad(J)] the two buffers of the pointer-jumping FK (mmx_device.hpp fkJumpRoundsD); fkB lies over
+  double* fkB; // own2 / sub2, which phase D writes after FK is done
   float* own2; // [kC2 J]
   float* umom; // [kUmom U] per-unit moment contributions (phase D only)
   float* sub2; // [kC2 J]
@@ -300,7 +299,6 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
       *clkLast = now;
     }
   };
-  const bool odd = (rig.jumpRounds & 1) != 0;
   // joint parameters = transform * theta + offsets, one transform ROW per thread (parameter_transform.cpp:
   // 110-124; the same products in the same order as a per-joint walk): 7 J independent short CSR walks
   // instead of seven dependent ones per joint.  They land in the refinement scratch (jd), which is dead
@@ -333,18 +331,27 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   }
   __syncthreads();
   stamp(26);
+  const int Jp = fkPad(rig.J);
   for (int j = tid; j < rig.J; j += kT) {
     float* slot = s.js + kJs * j;
+    float loc[8];
     if (j == tid) {
-      fkLocalFromParams(s.jd + 7 * j, pre, off3, odd ? s.alt + kAlt * j : slot, slot + 8);
+      fkLocalFromParams(s.jd + 7 * j, pre, off3, loc, slot + 8);
     } else {
-      fkLocalFromParams(s.jd + 7 * j, rig.preRot + 4 * j, rig.offset + 3 * j, odd ? s.alt + kAlt * j : slot, slot + 8);
+      fkLocalFromParams(s.jd + 7 * j, rig.preRot + 4 * j, rig.offset + 3 * j, loc, slot + 8);
     }
-    (odd ? s.jlB : s.jlA)[j] = rig.parent[j] + 1;
+    if (rig.jumpRounds == 0) { // every joint is a root
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        slot[c] = loc[c];
+      }
+    } else {
+      fkStoreLocalD(s.fkA, Jp, j, loc, rig.parent[j] + 1);
+    }
   }
   __syncthreads();
   stamp(24);
-  fkJumpRounds(s.js, s.alt, s.jlA, s.jlB, rig.J, rig.jumpRounds, tid, kT);
+  fkJumpRoundsD(s.js, s.fkA, s.fkB, rig.J, rig.jumpRounds, tid, kT);
   stamp(25);
   if (withAxes) {
     for (int j = tid; j < rig.J; j += kT) {
@@ -870,9 +877,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       }
     }
     float* region = p;
-    s.alt = take(size_t(kAlt) * J);
-    s.jlA = reinterpret_cast<int*>(take(J));
-    s.jlB = reinterpret_cast<int*>(take(J));
+    s.fkA = reinterpret_cast<double*>(take(fkBufFloats(J)));
+    s.fkB = reinterpret_cast<double*>(p); // over own2 / sub2 (2 kC2 J >= fkBufFloats(J) floats)
     s.own2 = take(size_t(kC2) * J);
     s.sub2 = take(size_t(kC2) * J);
     s.umom = take(size_t(kUmom) * U);
@@ -950,7 +956,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   // through a joint -> position scratch map (alt is free until the first FK)
   int* lParentPos = lLevelOrder;
   {
-    int* posOf = reinterpret_cast<int*>(s.alt);
+    int* posOf = reinterpret_cast<int*>(s.fkA);
     for (int k = tid; k < J; k += 256) {
       posOf[fd.dfsJoint[k]] = k;
     }
@@ -1017,6 +1023,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     bool notPd = false; // (kept false since the pivot floor: the factorisation always completes and the step is always taken, as in
                         // the reference, which never looks at LLT::info(); the branches it guards are dead code the compiler removes)
     bool badPivot = false; // a raw pivot was not positive: reported as MMX_SOLVE_NOT_PD
+    bool floored = false; // the factor's damping floor exceeded the caller's damping: reported as MMX_SOLVE_DAMPING_FLOORED
     for (;;) {
     int tidT = tid;
     if (kTR) { // (no per-thread invariant of the body is to live across the re-solve loops either)
@@ -1357,6 +1364,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         tr += s.L[256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15)];
       }
       muFactor = fmaxf(mu, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
+      floored = floored || muFactor > mu;
     }
     for (int c = tid; c < NP; c += 256) {
       float* dg = s.L + 256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15);
@@ -1966,7 +1974,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       }
       itersDone = it + 1;
       if (badPivot) {
-        s.flags[2] = 2; // MMX_SOLVE_NOT_PD
+        s.flags[2] |= 2; // MMX_SOLVE_NOT_PD
+      }
+      if (floored) {
+        s.flags[2] |= 4; // MMX_SOLVE_DAMPING_FLOORED
       }
       const bool converged = fabs(lastError - e) / (fabs(e) + double(FLT_MIN)) <= double(fp.threshold) * double(FLT_EPSILON);
       s.flags[0] = (it >= fp.minIterations && converged) ? 1 : 0;
@@ -2027,8 +2038,9 @@ __host__ __device__ inline TreeStateLayout treeStateLayout(int J, int U) {
 }
 
 struct TreeNeLds {
-  float *th, *js, *alt, *up, *uy, *us, *own1, *own2, *sub1, *sub2, *umom, *jd, *srcT;
-  int *jlA, *jlB, *span; // span[slot] = tin | tout << 16
+  float *th, *js, *up, *uy, *us, *own1, *own2, *sub1, *sub2, *umom, *jd, *srcT;
+  double *fkA, *fkB; // buffers of the pointer-jumping FK; fkB lies over own1 / own2 (written in phase D, after FK)
+  int* span; // span[slot] = tin | tout << 16
   int *subSize, *loadedPos; // copies of the tables the subtree sums walk (read once per inner step)
   int *posUnitStart, *posUnits; // ... and of the units-per-joint lists the own sums walk
   int* kRange; // [2 rowTiles] treeSumRanges
@@ -2042,7 +2054,7 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
     off += alignUp4(count);
     return o;
   };
-  const size_t oTh = take(P), oJs = take(size_t(kJs) * J), oAlt = take(size_t(kAlt) * J), oJl = take(2 * size_t(J));
+  const size_t oTh = take(P), oJs = take(size_t(kJs) * J), oFk = take(fkBufFloats(J));
   const size_t oUp = take(3 * size_t(U)), oUy = take(3 * size_t(U)), oUs = take(U);
   const size_t oOwn1 = take(size_t(kC1) * J), oOwn2 = take(size_t(kC2) * J);
   // one region, two lives: joint parameters (FK) and the per-unit moments (D), then the subtree sums
@@ -2058,8 +2070,8 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
     out->kRange = reinterpret_cast<int*>(base + oKr);
     out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
     out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
-    out->th = base + oTh, out->js = base + oJs, out->alt = base + oAlt;
-    out->jlA = reinterpret_cast<int*>(base + oJl), out->jlB = out->jlA + J;
+    out->th = base + oTh, out->js = base + oJs;
+    out->fkA = reinterpret_cast<double*>(base + oFk), out->fkB = reinterpret_cast<double*>(base + oOwn1); // (kC1 + kC2) J >= fkBufFloats(J) from three joints on
     out->up = base + oUp, out->uy = base + oUy, out->us = base + oUs;
     out->own1 = base + oOwn1, out->own2 = base + oOwn2;
     out->jd = base + oR, out->umom = base + oR;
@@ -2151,7 +2163,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
   }
   // the fused kernel's helpers work on these views; here the tables stay where they are (L2)
   FusedLds s{};
-  s.th = t.th, s.js = t.js, s.alt = t.alt, s.jlA = t.jlA, s.jlB = t.jlB, s.jd = t.jd;
+  s.th = t.th, s.js = t.js, s.fkA = t.fkA, s.fkB = t.fkB, s.jd = t.jd;
   s.up = t.up, s.uy = t.uy, s.us = t.us, s.own1 = t.own1, s.own2 = t.own2, s.sub1 = t.sub1, s.sub2 = t.sub2, s.umom = t.umom;
   s.srcT = t.srcT, s.red = t.red;
   RigView rv;
@@ -2861,7 +2873,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
   const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
   const size_t srcT = size_t(kSrcCh) * size_t(srcStrideFor(nsrc));
   const size_t blockJ = refine > srcT ? refine : srcT;
-  const size_t scratch = a4(size_t(kAlt) * J) + 2 * a4(J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kUmom) * U);
+  const size_t scratch = fkBufFloats(J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kUmom) * U);
   const size_t region = scratch > T * 256 ? scratch : T * 256;
   const size_t rowsGp = (size_t(genRows) + 3) & ~size_t(3);
   const size_t gen = GT > 0 ? a4(size_t(kGenEv) * GT) + 2 * a4(rowsGp) + a4(rowsGp * size_t(srcStrideFor(int(NP)))) : 0;

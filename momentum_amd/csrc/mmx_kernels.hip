@@ -648,36 +648,43 @@ constexpr int kEvWords = 29; // vp(3) vn(3) sigma*dp(9) sigma*dn(9) tin row nrow
 
 struct SideLds {
   float* js; // [J][kJs]
-  float* alt; // [J][kAlt]
-  int* jlA; // [J]
-  int* jlB; // [J]
+  double* fkA; // [kFkCh][fkPad(J)] the two buffers of the pointer-jumping FK (mmx_device.hpp fkJumpRoundsD)
+  double* fkB;
 };
 
 __device__ __forceinline__ SideLds carveSideLds(float* smem, int J, float** next) {
   SideLds s;
   s.js = smem;
-  s.alt = s.js + ((kJs * J + 3) & ~3);
-  s.jlA = reinterpret_cast<int*>(s.alt + kAlt * J);
-  s.jlB = s.jlA + J;
-  *next = reinterpret_cast<float*>(s.jlB + J);
+  float* p = s.js + ((kJs * J + 3) & ~3);
+  s.fkA = reinterpret_cast<double*>(p);
+  s.fkB = reinterpret_cast<double*>(p + fkBufFloats(J));
+  *next = p + 2 * fkBufFloats(J);
   return s;
 }
 
 size_t sideFkLdsFloats(int J) {
-  return size_t((kJs * J + 3) & ~3) + size_t(kAlt + 2) * size_t(J);
+  return size_t((kJs * J + 3) & ~3) + 2 * fkBufFloats(J);
 }
 
 // forward kinematics of one instance by 256 threads: local transforms of all joints at once,
 // pointer-jumping composition, optionally the rotation axes (see fkJacobianKernel)
 __device__ __forceinline__ void sideFk(const RigDev& rig, const SideLds& s, const float* th, int tid, bool withAxes) {
-  const bool odd = (rig.jumpRounds & 1) != 0;
+  const int Jp = fkPad(rig.J);
   for (int j = tid; j < rig.J; j += 256) {
     float* slot = s.js + kJs * j;
-    fkLocalSplit(rig, j, th, odd ? s.alt + kAlt * j : slot, slot + 8);
-    (odd ? s.jlB : s.jlA)[j] = rig.parent[j] + 1;
+    float loc[8];
+    fkLocalSplit(rig, j, th, loc, slot + 8);
+    if (rig.jumpRounds == 0) { // every joint is a root
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        slot[c] = loc[c];
+      }
+    } else {
+      fkStoreLocalD(s.fkA, Jp, j, loc, rig.parent[j] + 1);
+    }
   }
   __syncthreads();
-  fkJumpRounds(s.js, s.alt, s.jlA, s.jlB, rig.J, rig.jumpRounds, tid, 256);
+  fkJumpRoundsD(s.js, s.fkA, s.fkB, rig.J, rig.jumpRounds, tid, 256);
   if (withAxes) {
     for (int j = tid; j < rig.J; j += 256) {
       fkAxesInPlaceP(rig, j, rig.parent[j], s.js);
@@ -1359,6 +1366,9 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
       tr += Hb[size_t(i) * n + i];
     }
     lambdaF = fmaxf(lambda, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
+    if (tid == 0 && lambdaF > lambda) {
+      st.status[b] |= 4; // MMX_SOLVE_DAMPING_FLOORED
+    }
   }
   for (int idx = tid; idx < n * n; idx += 256) {
     const int i = idx % n, j = idx / n;
@@ -1581,7 +1591,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
     st.iterations[b] = sp.iteration + 1;
     st.finalError[b] = e;
     if (badPivot) {
-      st.status[b] = 2; // MMX_SOLVE_NOT_PD
+      st.status[b] |= 2; // MMX_SOLVE_NOT_PD
     }
     const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
     if (sp.iteration >= sp.minIterations && converged) {
@@ -2289,7 +2299,7 @@ __device__ __forceinline__ void applyStepAndBook(
   }
   if (sp.stepRule == MMX_STEP_TRUST_REGION) { // several linear solves per iteration: trustEndKernel books it once
     if (tid == 0 && badPivot) {
-      st.status[b] = 2;
+      st.status[b] |= 2;
     }
     return;
   }
@@ -2302,7 +2312,7 @@ __device__ __forceinline__ void applyStepAndBook(
     st.iterations[b] = sp.iteration + 1;
     st.finalError[b] = e;
     if (badPivot) { // a raw pivot was not positive; floored (kPivotFloor), the step taken
-      st.status[b] = 2;
+      st.status[b] |= 2;
     }
     const bool converged = fabs(last - e) / (fabs(e) + double(FLT_MIN)) <= double(sp.threshold) * double(FLT_EPSILON);
     if (sp.iteration >= sp.minIterations && converged) {
@@ -2359,6 +2369,9 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
       tr += Hb[size_t(i) * n + i];
     }
     lambdaF = fmaxf(lambda, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
+    if (tid == 0 && lambdaF > lambda) {
+      st.status[b] |= 4; // MMX_SOLVE_DAMPING_FLOORED
+    }
   }
   tiledFactor(jtj + size_t(b) * n * n, L, n, lambdaF, t, sp, b, tid, tclk);
   const bool badPivot = t.flags[0] != 0;
@@ -2548,7 +2561,11 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
       t.rho[tid >> 6] = tr;
     }
     __syncthreads();
-    lambda = fmaxf(lambda, kFactorDamping * ((t.rho[0] + t.rho[1]) + (t.rho[2] + t.rho[3])) / float(n > 0 ? n : 1));
+    const float lambdaFloor = kFactorDamping * ((t.rho[0] + t.rho[1]) + (t.rho[2] + t.rho[3])) / float(n > 0 ? n : 1);
+    if (tid == 0 && lambdaFloor > lambda) {
+      st.status[b] |= 4; // MMX_SOLVE_DAMPING_FLOORED
+    }
+    lambda = fmaxf(lambda, lambdaFloor);
   }
   __syncthreads();
   long long tclk = clock64();
@@ -2574,7 +2591,7 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
   if (tid == 0) {
     refState[b] = 0;
     if (badPivot) { // (the finish stage books the iteration; the floored pivot is reported from here)
-      st.status[b] = 2;
+      st.status[b] |= 2;
     }
   }
 }
@@ -2733,7 +2750,11 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
       red[wave] = tr;
     }
     __syncthreads();
-    lambda = fmaxf(lambda, kFactorDamping * ((red[0] + red[1]) + (red[2] + red[3])) / float(n > 0 ? n : 1));
+    const float lambdaFloor = kFactorDamping * ((red[0] + red[1]) + (red[2] + red[3])) / float(n > 0 ? n : 1);
+    if (tid == 0 && lambdaFloor > lambda) {
+      st.status[b] |= 4; // MMX_SOLVE_DAMPING_FLOORED
+    }
+    lambda = fmaxf(lambda, lambdaFloor);
     for (int i = tid; i < NP; i += 256) {
       float* dg = tiles + 256 * int(maskWords[64 + (i >> 4)]) + tileAddr(i & 15, i & 15);
       const float hd = i < n ? *dg + lambda : 1.f;
@@ -2867,7 +2888,7 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   if (tid == 0) {
     refState[b] = 0;
     if (badPivot) { // (the finish stage books the iteration; the floored pivot is reported from here)
-      st.status[b] = 2;
+      st.status[b] |= 2;
     }
   }
 }

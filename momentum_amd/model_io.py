@@ -539,7 +539,8 @@ def load_gltf(data) -> Tuple[Rig, list]:
     for el in ext.get("parameterLimits", []):
         t, w = el.get("type", ""), float(el.get("weight", 0.0))
         if t == "minmax":
-            limits.append(ParameterLimit.minmax(pid(el["parameter"]), el["limits"][0], el["limits"][1], w))
+            lo, hi = np.ravel(np.asarray(el["limits"], np.float64))[:2]  # [lo, hi]; older files nest it: [[lo, hi]]
+            limits.append(ParameterLimit.minmax(pid(el["parameter"]), float(lo), float(hi), w))
         elif t in ("minmax_joint", "minmax_joint_passive"):
             j, a = jid[el["jointIndex"]], JOINT_PARAMETER_NAMES.index(el["jointParameter"])
             lim = ParameterLimit.minmax_joint(j, a, el["limits"][0], el["limits"][1], w)
@@ -561,6 +562,72 @@ def load_gltf(data) -> Tuple[Rig, list]:
         else:
             raise ModelFormatError(f"Unknown parameter limit type '{t}'")
     return rig, limits
+
+
+def _glb_binary_chunk(data) -> bytes:
+    """The BIN chunk of a GLB container (b"" when the document has none / is plain JSON)."""
+    if isinstance(data, (dict, str)):
+        return b""
+    b = bytes(data)
+    if b[:4] != b"glTF":
+        return b""
+    import struct
+
+    clen = struct.unpack("<I", b[12:16])[0]
+    pos = 20 + clen
+    while pos + 8 <= len(b):
+        n, ctype = struct.unpack("<I4s", b[pos : pos + 8])
+        if ctype == b"BIN\0":
+            return b[pos + 8 : pos + 8 + n]
+        pos += 8 + n
+    return b""
+
+
+def _float_accessor(doc: dict, binary: bytes, index: int) -> np.ndarray:
+    """Flat float32 contents of accessor `index` (copyAccessorBuffer<float>, momentum/io/gltf/utils/accessor_utils.h):
+    component type FLOAT, tightly packed or strided, from the GLB's own buffer."""
+    acc = doc["accessors"][index]
+    if acc.get("componentType") != 5126:
+        raise ModelFormatError("accessor is not of component type FLOAT")
+    ncomp = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT2": 4, "MAT3": 9, "MAT4": 16}[acc.get("type", "SCALAR")]
+    view = doc["bufferViews"][acc["bufferView"]]
+    if view.get("buffer", 0) != 0 or "uri" in doc["buffers"][0]:
+        raise ModelFormatError("only the GLB's embedded buffer is supported")
+    start = int(view.get("byteOffset", 0)) + int(acc.get("byteOffset", 0))
+    count, stride = int(acc["count"]), int(view.get("byteStride", 0)) or 4 * ncomp
+    raw = np.frombuffer(binary, np.uint8)
+    rows = np.lib.stride_tricks.as_strided(raw[start:], shape=(count, 4 * ncomp), strides=(stride, 1))
+    return np.ascontiguousarray(rows).view("<f4").reshape(-1).astype(np.float32)
+
+
+def load_gltf_motion(data):
+    """The motion a momentum GLB stores in its FB_momentum extension (getMotionFromModel,
+    momentum/io/gltf/gltf_animation_io.cpp:72-112): dict(parameter_names, poses [nframes, nparams] (the reference's
+    column-major nparams x nframes matrix, one row per frame here), joint_names, identity [7 J] joint-parameter offsets,
+    fps).  Empty dict when the file stores none."""
+    doc = _gltf_document(data)
+    ext = _momentum_ext(doc)
+    motion = ext.get("motion", {})
+    nframes = int(motion.get("nframes", 0))
+    pose_acc, off_acc = int(motion.get("poses", -1)), int(motion.get("offsets", -1))
+    if nframes == 0 or (pose_acc < 0 and off_acc < 0):
+        return {}
+    binary = _glb_binary_chunk(data)
+    out = dict(parameter_names=[], poses=np.zeros((nframes, 0), np.float32), joint_names=[], identity=np.zeros(0, np.float32),
+               fps=float(ext.get("fps", 0.0)))  # fmt: skip
+    if pose_acc >= 0:
+        names = list(motion.get("parameterNames", []))
+        v = _float_accessor(doc, binary, pose_acc)
+        if v.size != len(names) * nframes:
+            return {}
+        out["parameter_names"], out["poses"] = names, v.reshape(nframes, len(names))
+    if off_acc >= 0:
+        jn = list(motion.get("jointNames", []))
+        v = _float_accessor(doc, binary, off_acc)
+        if v.size != 7 * len(jn):
+            return {}
+        out["joint_names"], out["identity"] = jn, v
+    return out
 
 
 def write_gltf(rig: Rig, limits: Sequence = ()) -> dict:

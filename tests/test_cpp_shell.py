@@ -83,6 +83,34 @@ def test_cpp_shell_matches_golden_fixture_on_gpu():
     assert out.stdout.strip().endswith("OK"), out.stdout
 
 
+REAL_SRC = os.path.join(ROOT, "tests", "cpp", "test_real_rig.cpp")
+REAL_EXE = os.path.join(ROOT, "tests", "cpp", "test_real_rig")
+REAL_INC = os.path.join(ROOT, "tests", "cpp", "golden_real_rig.inc")
+
+
+def _compile_real_rig():
+    import sys
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "cpp", "make_golden_header.py"),
+                           os.path.join(ROOT, "tests", "golden", "real_rig_character_with_motion.npz"), REAL_INC])  # fmt: skip
+    _compile(REAL_SRC, REAL_EXE)
+
+
+def test_cpp_real_rig_program_compiles_and_links():
+    _compile_real_rig()
+    assert os.path.exists(REAL_EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_real_rig_skeleton_state_and_solve_on_gpu():
+    """The reference's character_with_motion.glb through the C++ shell: SkeletonState at the stored motion frames against the
+    oracle's double FK, then the solve towards them (tests/cpp/test_real_rig.cpp; the Python twin is tests/test_real_rig.py)."""
+    _compile_real_rig()
+    out = subprocess.run([REAL_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK"), out.stdout
+
+
 STUB_SRC = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu_stub.cpp")
 STUB_EXE = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu_stub")
 

@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 BOUND = 1e-5
 
 
-def _solve_and_check(torch, config, B, n_check, line_search=0, step_rule=None, iterations=10):
+def _solve_and_check(torch, config, B, n_check, line_search=0, step_rule=None, iterations=10, seed=20240611):
     rig, parents, _, cfg_rule, _ = bench.build_rig(config)
     rule = cfg_rule if step_rule is None else step_rule
-    db = bench.DeviceBatch(rig, parents, B, 0, 20240611)
+    db = bench.DeviceBatch(rig, parents, B, 0, seed)
     opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=0.05, step_rule=rule, do_line_search=line_search)
     out = db.pb.solve(db.theta0.clone(), opt)
     torch.cuda.synchronize()
@@ -36,23 +36,23 @@ def _solve_and_check(torch, config, B, n_check, line_search=0, step_rule=None, i
         ("cfg2", 4096, 1024, 2),  # the batched driver's default line search (SubsetGN / GN-QR rule)
         ("cfg2", 4096, 1024, 1),  # GaussNewtonSolverT's own line search
         ("cfg2_all", 2048, 1024, 0),  # P = 219, M = 864: the wide path (preferred over the fused NB = 14 instantiation)
-        ("cfg5", 1024, 1024, 0),  # 300-joint rig, wide J: MFMA normal equations + in-HBM Cholesky
     ],
 )
 def test_baseline_workloads_within_1e5_of_the_oracle(torch_cuda, orc, config, B, n_check, line_search):
     chk, _, _ = _solve_and_check(torch_cuda, config, B, n_check, line_search)
     assert chk["instances"] == n_check and chk["distinct"]
-    if config != "cfg5":
-        assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
-        return
-    # cfg5, 300 joints: one of the 1024 instances (325) is not converged after ten iterations (final error 8.5e-3, the
-    # oracle's own float instantiation ends 5.7e-4 from its double one on it) and lands at 5e-6 ... 1.3e-5 depending on the
-    # rounding of the factorisation -- 5.6e-6 with the columns in parameter order, 1.1e-5 in elimination order, 5.1e-6
-    # when every step takes a second refinement round (25 % slower).  Held to: everything else within the bound, that
-    # instance within 2x of it and at least 10x closer to the double answer than the reference's float arithmetic gets.
-    assert chk["num_above_bound"] <= 1 and chk["max_rel_theta_vs_oracle_f64"] <= 2 * BOUND, chk
-    if chk["num_above_bound"]:
-        assert chk["above_bound_float_oracle_rel"][0] >= 10 * chk["max_rel_theta_vs_oracle_f64"], chk
+    assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
+
+
+@pytest.mark.parametrize("seed", [20240611, 424242, 7])
+def test_config5_every_instance_within_1e5(torch_cuda, orc, seed):
+    """BASELINE configs[4] (300-joint rig, wide J: tree normal equations, tile-sparse factor, tree refinement): EVERY one of
+    4096 distinct instances within 1e-5 of the oracle's double solve, three seeds, no escape clause.  (Round 3 admitted one
+    instance of the first seed -- 325 -- up to 2e-5; the forward kinematics' re-associated single-precision products were the
+    cause, mmx_device.hpp fkJumpRoundsD.)"""
+    chk, _, _ = _solve_and_check(torch_cuda, "cfg5", 4096, 4096, seed=seed)
+    assert chk["instances"] == 4096 and chk["distinct"]
+    assert chk["num_above_bound"] == 0 and chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
 
 
 def test_cfg2_all_through_the_fused_instantiation(torch_cuda, orc, monkeypatch):

@@ -324,7 +324,7 @@ def test_random_wide_rig_with_extra_rows(torch_cuda, orc, seed):
         rel = np.linalg.norm(th[b] - ref["theta"]) / den
         tol = max(2e-5, 3.0 * np.linalg.norm(r32["theta"] - ref["theta"]) / den)
         assert rel <= tol, (seed, b, J, P, rel, tol)
-        assert int(out["iterations"][b]) == ref["iterations"] and int(out["status"][b]) == ref["status"]
+        assert int(out["iterations"][b]) == ref["iterations"] and int(out["status"][b]) & 3 == ref["status"]
         href = np.asarray(ref["error_history"])
         h = out["error_history"][b].cpu().numpy()[: len(href)]
         assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())

@@ -236,6 +236,7 @@ def test_plain_gauss_newton_instantiation_matches_the_general_one(torch_cuda, or
     cons, th0, ths = make_problem(rig, pp, op, B, seed=777, perturb=0.3)
     rh, pb = _gpu_problem(torch, rig, cons, B)
     rhg, pbg = _gpu_problem_with_vacuous_limit(torch, rig, cons, B)
+    pb.set_route("fused"), pbg.set_route("fused")  # (a statement about the one-launch solve's instantiations)
     opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
     general = pbg.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     plain = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)

@@ -47,7 +47,7 @@ def test_trust_region_matches_oracle_on_the_reference_fixture(torch_cuda, orc, r
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     assert pb.last_route() == route
     ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"]) and np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"]) and np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     same = np.all(np.abs(h - href) <= 2e-3 * np.abs(href) + 1e-6 * href[:, :1], axis=1)
     assert same.mean() >= 0.8, (same.mean(), np.abs(h - href).max(axis=1))
@@ -79,7 +79,7 @@ def test_trust_region_on_the_humanoid_does_at_least_as_well_as_gauss_newton(torc
     assert pb.last_route() == route
     out2 = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
     assert torch.equal(out["theta"], out2["theta"]) and torch.equal(out["error_history"], out2["error_history"])
-    assert int((out["status"] != 0).sum()) == 0
+    assert int((out["status"] & 3 != 0).sum()) == 0  # (bit 4, MMX_SOLVE_DAMPING_FLOORED, is set: the rule starts from lambda = 1e-10)
     th = out["theta"].cpu().numpy()
     gn = orc.solve_batch(rig, cons, th0, GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05), dtype="f64")
     h = out["error_history"].cpu().numpy()
@@ -110,7 +110,7 @@ def test_trust_region_on_systems_beyond_the_fused_solve(torch_cuda, orc, config,
     assert db.pb.last_route() == ("wide" if route == "auto" else route)
     out2 = db.pb.solve(db.theta0.clone(), opt, want_history=True)
     assert torch.equal(out["theta"], out2["theta"]) and torch.equal(out["error_history"], out2["error_history"])
-    assert int((out["status"] == 1).sum()) == 0
+    assert int((out["status"] & 1 != 0).sum()) == 0
     cons = db.host_constraints(B)
     th0 = np.zeros((B, rig.num_params), np.float32)
     ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=bench.usable_cores())
@@ -142,7 +142,7 @@ def test_trust_region_with_further_joint_blocks_and_limits(torch_cuda, orc):
     opt = GnOptions.make(min_iterations=8, max_iterations=8, threshold=1.0, step_rule=MMX_STEP_TRUST_REGION)
     out = db.pb.solve(db.theta0.clone(), opt, want_history=True)
     assert db.pb.last_route() == "wide"
-    assert int((out["status"] == 1).sum()) == 0
+    assert int((out["status"] & 1 != 0).sum()) == 0
     cons = db.host_constraints(B)
     th0 = np.zeros((B, rig.num_params), np.float32)
     h = out["error_history"].cpu().numpy()

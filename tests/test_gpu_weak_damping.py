@@ -7,8 +7,7 @@ where a small lambda bites, and the refinement step of the kernels is the defenc
 Three kinds of problems, three kinds of bounds (stated at each assert):
 
   * well-determined problems (a constraint on every joint): pose parameters within 1e-5 relative of the double solve
-    at EVERY lambda -- fused and wide routes (on the variant with shared short-lever parameters: 99.5 % of 1024
-    instances, the rest within 2e-5; see WELL_DETERMINED);
+    at EVERY lambda, every instance -- fused and wide routes;
   * the reference's 3-joint known-answer test: its own assertions (error <= 5e-7, end effector <= 5e-5);
   * the BASELINE shapes cfg1 (24-joint chain, 3 position constraints: 9 rows for 31 parameters) and cfg2 (16 landmark
     joints: as many independent rows as solved parameters): under-determined or marginally determined, so with a weak
@@ -78,13 +77,13 @@ def _rel(a, ref):
 WELL_DETERMINED = {
     # name: (variant, batch, share of the instances that must be within 1e-5, bound on the rest)
     # -- position + orientation constraint on every joint
-    # n = 128, the fused instantiation NB = 8.  Finger curls, fists and the spine twist are SHARED parameters here: their
-    # columns are sums over several short-lever joints, and the tree kernels take the first moments of the constraint
-    # forces about the world origin (that is what makes a subtree an index range), so a lever of a few centimetres at a
-    # metre from the origin costs ~5 bits of g: the HIP path's median distance to the double solve is 1.5e-6 where the
-    # oracle's float instantiation has 0.8e-6, and the tail of 1024 instances touches the bound (measured, every lambda:
-    # max 0.7 ... 1.4e-5, at most 5 instances above 1e-5).  Held to: 99.5 % within 1e-5, every instance within 2e-5.
-    "p128_all_joints": ("p128", 1024, 0.995, 2e-5),
+    # n = 128, the fused instantiation NB = 8.  Finger curls, fists and the spine twist are SHARED parameters here.  Rounds
+    # 2-3 held this variant to 99.5 % within 1e-5 / all within 2e-5 (median 1.5e-6 where the oracle's float instantiation has
+    # 0.7e-6, tail 0.7 ... 1.4e-5) and blamed the world-origin moments of the tree kernels; round 4 measured the cause
+    # (scripts/diag_step_noise.py, diag_g_stages.py): the re-associated single-precision products of the pointer-jumping
+    # forward kinematics.  With those in double (mmx_device.hpp fkJumpRoundsD) the median is 0.67e-6, the worst of 1024
+    # 2.9e-6: the plain bound on every instance.
+    "p128_all_joints": ("p128", 1024, 1.0, 1e-5),
     # n = 219: BASELINE's stress variant cfg2_all (three rotations per joint, nothing shared): the plain bound on every instance
     "p219_all_joints": ("p219", 512, 1.0, 1e-5),
 }
@@ -116,7 +115,7 @@ def test_well_determined_problems_hold_1e5_at_every_lambda(torch_cuda, orc, name
             "same_line_search_decisions": int(same.sum()), "max_rel_same_decisions": float(rel[same].max()),
             "bound": "1e-5 on every instance whose line-search decisions agree with the double run (all of them without a line search)"}  # fmt: skip
         _write_report()
-        assert np.all(out["status"] == 0) and np.array_equal(out["iterations"], ref["iterations"])
+        assert np.all(out["status"] & 3 == 0) and np.array_equal(out["iterations"], ref["iterations"])
         assert same.mean() >= 0.99, (name, lam, line_search, route, float(same.mean()))
         # north_star: 1e-5 relative on pose parameters
         assert (rel[same] <= BOUND).mean() >= share and rel[same].max() <= rest_bound, (name, lam, line_search, route, float(rel[same].max()), int((rel[same] > BOUND).sum()))
@@ -203,7 +202,7 @@ def test_baseline_shapes_at_weak_damping(torch_cuda, orc, name, line_search, rou
             "median_rel_float_oracle": float(np.median(rel32[sane])) if sane.any() else None,
             "p90_rel_hip": float(np.quantile(rel[sane], 0.9)) if sane.any() else None,
             "p90_rel_float_oracle": float(np.quantile(rel32[sane], 0.9)) if sane.any() else None,
-            "status_hip_nonzero": int((out["status"] != 0).sum()),
+            "status_hip_nonzero": int((out["status"] & 3 != 0).sum()), "status_hip_damping_floored": int((out["status"] & 4 != 0).sum()),
             "status_float_oracle_nonzero": int((r32["status"] != 0).sum()),
             "max_final_error_hip": float(np.nanmax(np.where(sane, out["error"], 0.0))),
             "max_final_error_double": float(np.nanmax(np.where(sane, r64["error"], 0.0))),
@@ -258,7 +257,7 @@ def test_solve_ik_defaults_full_batch(torch_cuda, orc):
     opt = GnOptions.make(min_iterations=4, max_iterations=50, threshold=10.0, regularization=0.01, do_line_search=2)
     out = db.pb.solve(db.theta0.clone(), opt)
     torch.cuda.synchronize()
-    assert int((out["status"] != 0).sum()) == 0
+    assert int((out["status"] & 3 != 0).sum()) == 0
     it = out["iterations"].cpu().numpy()
     assert it.min() >= 5 and it.max() <= 50
     cons = db.host_constraints(n)
@@ -303,7 +302,7 @@ def test_solve_matches_the_qr_solver(torch_cuda, orc, route):
                 "instances": B, "max_rel": float(rel.max()), "median_rel": float(np.median(rel)), "bound": "1e-5, no escape"}  # fmt: skip
             _write_report()
             assert rel.max() <= BOUND, (lam, ls, route, float(rel.max()))
-            assert np.array_equal(out["iterations"], ref["iterations"]) and np.all(out["status"] == 0)
+            assert np.array_equal(out["iterations"], ref["iterations"]) and np.all(out["status"] & 3 == 0)
 
 
 @pytest.mark.parametrize("name", sorted(BASELINE_SHAPES))
@@ -340,7 +339,7 @@ def test_double_instantiation_follows_the_double_solver_at_weak_damping(torch_cu
             "instances": B, "same_line_search_decisions": int(same.sum()), "max_rel_same_decisions": float(rel[same].max()) if same.any() else None,
             "max_final_error": float(e.max()), "max_final_error_double_oracle": float(ref["error"].max())}  # fmt: skip
         _write_report()
-        assert np.all(out["status"].cpu().numpy() == 0) and np.isfinite(th).all()
+        assert np.all(out["status"].cpu().numpy() & 3 == 0) and np.isfinite(th).all()
         # (an under-determined minimiser at lambda = 1e-7 amplifies a last-bit difference into another line-search branch on
         # many instances -- reported; the objective is what both reach)
         # (the oracle is built per host with the fastest of four flag sets -- another contraction of a*b+c is another last

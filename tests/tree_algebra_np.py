@@ -202,3 +202,70 @@ def jtj(tree, S):
                     h += w * wp * hj_entry(tree, tabs, r, rp)
             H[p, q] = H[q, p] = h
     return H
+
+
+# ---------------------------------------------------------------------------------------------
+# Local-lever forms (round 4): the same two passes with every moment taken about the joint it
+# belongs to instead of the world origin.  In exact arithmetic they equal jt_times / j_times; in
+# single precision the origin forms subtract two terms of size |t_a| |F| to get one of size
+# |lever| |F| (a finger joint a metre from the origin with a centimetre lever loses ~6.6 bits),
+# the local forms only ever multiply by physical levers (bone vectors, p_u - t_j).
+# ---------------------------------------------------------------------------------------------
+def jt_times_local(tree, units, y):
+    """J^T y: own sums about the unit's own joint, then leaves-to-root with the child's sums shifted to
+    the parent: N_a += N_c + (t_c - t_a) x F_c, D_a += D_c + (t_c - t_a) . F_c, F_a += F_c."""
+    T, J = tree.dtype, tree.J
+    F, N, D = np.zeros((J, 3), T), np.zeros((J, 3), T), np.zeros(J, T)
+    for i, u in enumerate(units):
+        j, yy = u["joint"], np.asarray(y[i], T)
+        if u["point"]:
+            lever = (u["p"] - tree.center).astype(T) - tree.t[j]
+            F[j] += yy
+            N[j] += np.cross(lever, yy)
+            D[j] += lever @ yy
+        else:
+            N[j] += np.cross(u["p"].astype(T), yy)
+    for j in range(J - 1, 0, -1):  # children before parents (parent < child)
+        pa = tree.parent[j]
+        if pa >= 0:
+            lever = tree.t[j] - tree.t[pa]
+            F[pa] += F[j]
+            N[pa] += N[j] + np.cross(lever, F[j])
+            D[pa] += D[j] + lever @ F[j]
+    gj = np.zeros(7 * J, T)
+    for a in range(J):
+        for d in range(3):
+            gj[7 * a + d] = tree.tau[a][:, d] @ F[a]
+            gj[7 * a + 3 + d] = tree.om[a][:, d] @ N[a]
+        gj[7 * a + 6] = tree.ln2 * D[a]
+    gj[~tree.active] = 0.0
+    return tree.A.T @ gj
+
+
+def j_times_local(tree, units, delta):
+    """J delta: V_a = velocity of the ancestors' motion AT t_a, root to leaves:
+    V_a = T_a + V_p + W_p x (t_a - t_p) + ln2 S_p (t_a - t_p); a unit adds W_a x (p - t_a) + ln2 S_a (p - t_a)."""
+    T, J = tree.dtype, tree.J
+    jd = tree.A @ np.asarray(delta, T)
+    V, W, Sd = np.zeros((J, 3), T), np.zeros((J, 3), T), np.zeros(J, T)
+    for a in range(J):
+        Tv = tree.tau[a] @ jd[7 * a : 7 * a + 3]
+        Om = tree.om[a] @ jd[7 * a + 3 : 7 * a + 6]
+        pa = tree.parent[a]
+        if pa >= 0:
+            lever = tree.t[a] - tree.t[pa]
+            V[a] = Tv + (V[pa] + np.cross(W[pa], lever) + tree.ln2 * Sd[pa] * lever)
+            W[a] = Om + W[pa]
+            Sd[a] = jd[7 * a + 6] + Sd[pa]
+        else:
+            V[a], W[a], Sd[a] = Tv, Om, jd[7 * a + 6]
+    out = np.zeros(3 * len(units), T)
+    for i, u in enumerate(units):
+        j = u["joint"]
+        if u["point"]:
+            lever = (u["p"] - tree.center).astype(T) - tree.t[j]
+            v = V[j] + np.cross(W[j], lever) + tree.ln2 * Sd[j] * lever
+        else:
+            v = np.cross(W[j], u["p"].astype(T))
+        out[3 * i : 3 * i + 3] = T(u["sigma"]) * v
+    return out
