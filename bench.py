@@ -232,6 +232,13 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n):
         out["above_bound_float_oracle_rel"] = [float(x) for x in rel32[:16]]
         out["above_bound_float_oracle_also_above"] = bool(np.all(~(rel32 <= PARITY_BOUND)))
         out["above_bound_final_error_double"] = [float(x) for x in ref["error"][idx][:16]]
+        # ... and whether the double run itself was converging on them: an iteration that has reduced its error by less than
+        # 1e3 after all its steps (a Gauss-Newton run without line search from a start where the step overshoots) amplifies
+        # every last-bit difference, in the reference's own float instantiation first of all
+        h0 = ref["error_history"][idx, 0]
+        diverging = ~(ref["error"][idx] <= 1e-3 * h0)
+        out["above_bound_initial_error_double"] = [float(x) for x in h0[:16]]
+        out["num_above_bound_on_converging_runs"] = int((~diverging).sum())
         out["pass_relaxed"] = bool(out["num_above_bound"] <= n // 100 and out["above_bound_float_oracle_also_above"])
         out["pass_relaxed_rule"] = ">= 99 % within the bound; every instance above it is above it in the oracle's float instantiation too"
     out["within_bound"] = f"{n - out['num_above_bound']}/{n}"

@@ -2306,11 +2306,14 @@ int32_t mmx_solve_f64(
   const int genRowsF64 = pb->dev.rowsJoint - 3 * pb->U;
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64) > 160 * 1024) {
-    return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: rig beyond the kernel's LDS budget");
+  const bool residentF64 = mmx::solveF64IsResident(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64);
+  if (!residentF64) { // the scratch form: dense J and H of every element in a global scratch of the problem
+    if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64) > 160 * 1024) {
+      return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: rig beyond the kernel's LDS budget");
+    }
+    MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));
+    MMX_HIP(pb->sHessF64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));
   }
-  MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));
-  MMX_HIP(pb->sHessF64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));
   const bool trustF64 = o->step_rule == MMX_STEP_TRUST_REGION;
   if (trustF64) {
     MMX_HIP(pb->sHess2F64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));

@@ -132,7 +132,17 @@ struct F64Lds {
   int* colOf; // [P] solve column of a model parameter, or -1
   double* jl; // [n][rc + 1] a chunk of J's rows, column-major (normal equations)
   double* gev; // [G][kGevD] the further joint error functions' evaluations (JointEvalD, rows scaled by sigma)
+  // ---- the resident instantiation (kRes): the system never leaves LDS
+  double* H; // [n (n + 1) / 2] lower triangle of H, then of its factor, packed by columns (hpos)
+  double* invd; // [n] 1 / L(k,k)
+  double* w1; // [n] work vectors of the substitutions
+  double* w2; // [n]
 };
+
+// position of H(i, j), i >= j, in the packed lower triangle (column j holds rows j .. n-1)
+__device__ __forceinline__ int hpos(int n, int i, int j) {
+  return j * n - ((j * (j - 1)) >> 1) + (i - j);
+}
 
 // ParameterTransformT<double>::apply + SkeletonStateT<double>::set (parameter_transform.cpp:110-124,
 // skeleton_state.cpp:87-121, joint_state.cpp:22-65): joint parameters one transform row per thread, then one
@@ -147,32 +157,45 @@ __device__ void fkF64(const RigDev& rig, const F64Lds& s, const double* th, int 
     s.jp[r] = acc + double(rig.ptOffsets[r]);
   }
   __syncthreads();
-  for (int lvl = 0; lvl < rig.numLevels; ++lvl) {
+  // the theta-only part of JointStateT<double>::set for all joints at once (the six sin / cos of a joint are the bulk of
+  // the arithmetic: inside the level sweep every tree level paid for them in turn): local (t, q, s) into the joint's
+  // world slot, the partial rotations pre * Rz, pre * Rz * Ry into the slots of the y / x axes (8 ..15)
+  for (int j = tid; j < rig.J; j += 256) {
+    const double* p = s.jp + 7 * j;
+    const float* pre = rig.preRot + 4 * j;
+    const float* off = rig.offset + 3 * j;
+    double sx, cx, sy, cy, sz, cz;
+    sincos(0.5 * p[3], &sx, &cx);
+    sincos(0.5 * p[4], &sy, &cy);
+    sincos(0.5 * p[5], &sz, &cz);
+    const DQ q0{double(pre[0]), double(pre[1]), double(pre[2]), double(pre[3])};
+    const DQ q1 = dqmul(q0, DQ{0.0, 0.0, sz, cz});
+    const DQ q2 = dqmul(q1, DQ{0.0, sy, 0.0, cy});
+    const DQ ql = dqmul(q2, DQ{sx, 0.0, 0.0, cx});
+    double* o = s.js + kDs * j;
+    o[0] = double(off[0]) + p[0], o[1] = double(off[1]) + p[1], o[2] = double(off[2]) + p[2];
+    o[3] = ql.x, o[4] = ql.y, o[5] = ql.z, o[6] = ql.w, o[7] = exp2(p[6]);
+    o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w, o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
+  }
+  __syncthreads();
+  for (int lvl = 0; lvl < rig.numLevels; ++lvl) { // parents before children (skeleton_state.cpp:100-121)
     const int i1 = rig.levelStart[lvl + 1];
     for (int i = rig.levelStart[lvl] + tid; i < i1; i += 256) {
       const int j = rig.levelOrder[i];
-      const double* p = s.jp + 7 * j;
       const float* pre = rig.preRot + 4 * j;
-      const float* off = rig.offset + 3 * j;
+      double* o = s.js + kDs * j;
       const DQ q0{double(pre[0]), double(pre[1]), double(pre[2]), double(pre[3])};
-      const DQ q1 = dqmul(q0, DQ{0.0, 0.0, sin(0.5 * p[5]), cos(0.5 * p[5])});
-      const DQ q2 = dqmul(q1, DQ{0.0, sin(0.5 * p[4]), 0.0, cos(0.5 * p[4])});
-      const DQ ql = dqmul(q2, DQ{sin(0.5 * p[3]), 0.0, 0.0, cos(0.5 * p[3])});
-      D3 t{double(off[0]) + p[0], double(off[1]) + p[1], double(off[2]) + p[2]};
-      DQ q = ql;
-      double sc = exp2(p[6]);
+      const DQ q1{o[8], o[9], o[10], o[11]}, q2{o[12], o[13], o[14], o[15]};
       DQ qp{0.0, 0.0, 0.0, 1.0};
       const int par = rig.parent[j];
       if (par >= 0) {
         const double* w = s.js + kDs * par;
         const D3 tp{w[0], w[1], w[2]};
         qp = DQ{w[3], w[4], w[5], w[6]};
-        t = tp + dqrot(qp, w[7] * t); // transform.h:124-129
-        q = dqmul(qp, ql);
-        sc = w[7] * sc;
+        const D3 t = tp + dqrot(qp, w[7] * D3{o[0], o[1], o[2]}); // transform.h:124-129
+        const DQ q = dqmul(qp, DQ{o[3], o[4], o[5], o[6]});
+        o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w, o[7] = w[7] * o[7];
       }
-      double* o = s.js + kDs * j;
-      o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = q.x, o[4] = q.y, o[5] = q.z, o[6] = q.w, o[7] = sc;
       if (withAxes) { // rotationAxis.col(i) = (q_parent * q_partial) * e_i (joint_state.cpp:53-54)
         const D3 az = dqrot(dqmul(qp, q0), D3{0.0, 0.0, 1.0});
         const D3 ay = dqrot(dqmul(qp, q1), D3{0.0, 1.0, 0.0});
@@ -479,7 +502,15 @@ __device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, cons
   return 0.693147180559945309417232121458176568 * (v - D3{a[0], a[1], a[2]});
 }
 
-__global__ void __launch_bounds__(256) solveF64Kernel(
+// kRes: the resident instantiation (round 4).  The system lives in LDS for the whole solve: J is assembled a chunk of
+// constraints at a time straight into LDS and consumed there (no dense J anywhere), H is the packed lower triangle in
+// LDS, factored by a right-looking blocked Cholesky (four columns per barrier pair) and solved by blocked substitutions
+// (one barrier per four unknowns), all in double.  Same arithmetic per entry as the scratch form below it (sums over the
+// rows in a different grouping: parity with the oracle's double run stays at the 1e-10 the tests hold).  Taken when the
+// packed H and a chunk of at least twelve rows fit a workgroup's LDS (n <= ~180 solved parameters); the scratch form
+// (J and H in a global scratch of the problem) is kept for the systems beyond.
+template <bool kRes>
+__global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     RigDev rig,
     ProblemDev pb,
     const int32_t* __restrict__ solveList, // [n] parameters of the dense system (enabled, structurally non-zero)
@@ -512,7 +543,14 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     s.colOf = reinterpret_cast<int*>(take((size_t(P) + 1) / 2));
     s.jl = take(size_t(n) * size_t(rc + 1));
     s.gev = take(size_t(kGevD) * size_t(G + pb.NE));
+    s.H = s.invd = s.w1 = s.w2 = nullptr;
+    if (kRes) {
+      s.H = take(size_t(n) * size_t(n + 1) / 2);
+      s.invd = take(n), s.w1 = take(n), s.w2 = take(n);
+    }
   }
+  // H(i, j), i >= j: the packed LDS triangle (kRes) or the column-major global scratch
+  auto Hat = [&](int i, int j) -> double& { return kRes ? s.H[hpos(n, i, j)] : Hg[size_t(b) * size_t(n) * size_t(n) + size_t(j) * n + i]; };
   double* thg = theta + size_t(b) * P;
   double* Jb = Jg + size_t(b) * size_t(n) * size_t(M);
   double* Hb = Hg + size_t(b) * size_t(n) * size_t(n);
@@ -585,6 +623,166 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     if (trust) {
       lambda = 0.0; // H is assembled without damping; the trust region adds its own per factorisation
     }
+    if (kRes) {
+      // ---- the resident form: H = lambda I, g = 0; then per chunk of constraints their rows of J straight into LDS
+      // (jl, column-major, ldj doubles per column) and from there into g and H
+      const int ldj = rc + 1;
+      for (int idx = tid; idx < n * (n + 1) / 2; idx += 256) {
+        s.H[idx] = 0.0;
+      }
+      for (int c = tid; c < n; c += 256) {
+        s.g[c] = 0.0;
+      }
+      __syncthreads();
+      for (int c = tid; c < n; c += 256) {
+        s.H[hpos(n, c, c)] = lambda;
+      }
+      // rows [r0, r0 + rows) of J are in jl: g += J^T r, H += J^T J (a thread owns 4 x 4 blocks of the lower triangle)
+      auto accumulate = [&](int r0, int rows) {
+        for (int c = tid; c < n; c += 256) {
+          double acc = s.g[c];
+          for (int r = 0; r < rows; ++r) {
+            acc += s.jl[c * ldj + r] * s.ur[r0 + r];
+          }
+          s.g[c] = acc;
+        }
+        const int nb4 = (n + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2;
+        for (int q = tid; q < nblk; q += 256) {
+          {
+            int bi = int((sqrt(8.0 * double(q) + 1.0) - 1.0) * 0.5); // q = bi (bi + 1) / 2 + bj, bj <= bi
+            while ((bi + 1) * (bi + 2) / 2 <= q) {
+              ++bi;
+            }
+            while (bi * (bi + 1) / 2 > q) {
+              --bi;
+            }
+            const int bj = q - bi * (bi + 1) / 2;
+            double acc[4][4] = {};
+            const double* ci[4];
+            const double* cj[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { // (columns beyond n read column n - 1: their entries are never stored)
+              ci[k] = s.jl + (4 * bi + k < n ? 4 * bi + k : n - 1) * ldj;
+              cj[k] = s.jl + (4 * bj + k < n ? 4 * bj + k : n - 1) * ldj;
+            }
+            for (int r = 0; r < rows; ++r) {
+              double av[4], bv[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                av[k] = ci[k][r], bv[k] = cj[k][r];
+              }
+#pragma unroll
+              for (int x = 0; x < 4; ++x) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                  acc[x][y] += av[x] * bv[y];
+                }
+              }
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+#pragma unroll
+              for (int y = 0; y < 4; ++y) {
+                const int i = 4 * bi + x, j = 4 * bj + y;
+                if (i < n && j <= i) {
+                  s.H[hpos(n, i, j)] += acc[x][y];
+                }
+              }
+            }
+          }
+        }
+      };
+      // position / orientation units, uc at a time
+      const int uc = rc / 3;
+      for (int u0 = 0; u0 < U; u0 += uc) {
+        const int nu = U - u0 < uc ? U - u0 : uc;
+        __syncthreads(); // (the previous chunk has been consumed)
+        for (int item = tid; item < n * nu; item += 256) {
+          const int c = item / nu, u = u0 + (item - c * nu);
+          const int p = solveList[c];
+          const D3 v{s.uv[3 * u], s.uv[3 * u + 1], s.uv[3 * u + 2]};
+          D3 acc{0.0, 0.0, 0.0};
+          const int e1 = pb.colStart[p + 1];
+          for (int k = pb.colStart[p]; k < e1; ++k) {
+            const ColumnSourceDev cs = pb.colSources[k];
+            bool applies;
+            const D3 gq = sourceDerivativeF64(cs, s.js, v, s.utin[u], u < pb.Kp, applies);
+            if (applies) { // jac.col(p) += derivScale * dfdv * jc * value (joint_error_function-inl.h:254-289)
+              const double w = double(cs.weight);
+              acc.x += (s.us[u] * gq.x) * w, acc.y += (s.us[u] * gq.y) * w, acc.z += (s.us[u] * gq.z) * w;
+            }
+          }
+          double* o = s.jl + c * ldj + 3 * (u - u0);
+          o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+        }
+        __syncthreads();
+        accumulate(3 * u0, 3 * nu);
+      }
+      // the further joint error functions / ellipsoid limits: consecutive constraints while their rows fit a chunk
+      const int GT = G + pb.NE;
+      for (int g0 = 0; g0 < GT;) {
+        const int rowFirst = reinterpret_cast<const int*>(s.gev + kGevD * g0 + 24)[1];
+        int g1 = g0, rowEnd = rowFirst;
+        while (g1 < GT) {
+          const int* wi = reinterpret_cast<const int*>(s.gev + kGevD * g1 + 24);
+          if (wi[1] + (wi[2] & 15) - rowFirst > rc) {
+            break;
+          }
+          rowEnd = wi[1] + (wi[2] & 15);
+          ++g1;
+        }
+        const int ng = g1 - g0;
+        __syncthreads();
+        for (int item = tid; item < n * ng; item += 256) {
+          const int c = item / ng, g = g0 + (item - c * ng);
+          const int p = solveList[c];
+          const double* w = s.gev + kGevD * g;
+          const int* wi = reinterpret_cast<const int*>(w + 24);
+          const int tin = wi[0], row = wi[1], nrows = wi[2] & 15, tinStop = wi[3];
+          const bool hasPoint = (wi[2] & 16) != 0, hasDir = (wi[2] & 32) != 0;
+          const D3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
+          double acc[3] = {0.0, 0.0, 0.0};
+          const int e1 = pb.colStart[p + 1];
+          for (int k = pb.colStart[p]; k < e1; ++k) {
+            const ColumnSourceDev cs = pb.colSources[k];
+            if (!(cs.tin <= tin && tin < cs.tout)) {
+              continue; // the source's joint is not an ancestor of the constraint's joint
+            }
+            if (tinStop >= 0 && cs.tin <= tinStop && tinStop < cs.tout) {
+              continue; // ellipsoid limit: the walk stopped before this joint
+            }
+            bool ap;
+            D3 gp{0.0, 0.0, 0.0}, gn{0.0, 0.0, 0.0};
+            if (hasPoint) {
+              gp = sourceDerivativeF64(cs, s.js, vp, tin, true, ap);
+              if (!ap) {
+                gp = D3{0.0, 0.0, 0.0};
+              }
+            }
+            if (hasDir) {
+              gn = sourceDerivativeF64(cs, s.js, vn, tin, false, ap);
+              if (!ap) {
+                gn = D3{0.0, 0.0, 0.0};
+              }
+            }
+            const double wt = double(cs.weight);
+            for (int q = 0; q < 3; ++q) {
+              const double jc = (w[6 + 3 * q] * gp.x + w[7 + 3 * q] * gp.y + w[8 + 3 * q] * gp.z) +
+                  (w[15 + 3 * q] * gn.x + w[16 + 3 * q] * gn.y + w[17 + 3 * q] * gn.z);
+              acc[q] += jc * wt;
+            }
+          }
+          double* o = s.jl + c * ldj + (row - rowFirst);
+          for (int q = 0; q < nrows; ++q) {
+            o[q] = acc[q];
+          }
+        }
+        __syncthreads();
+        accumulate(rowFirst, rowEnd - rowFirst);
+        g0 = g1;
+      }
+      __syncthreads();
+    } else {
     for (int item = tid; item < n * U; item += 256) {
       const int c = item / U, u = item - c * U;
       const int p = solveList[c];
@@ -721,7 +919,8 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     }
     __threadfence_block();
     __syncthreads();
-    if (M == 0) { // no joint-constraint rows at all (parameter-space rows only): H starts as lambda I
+    }
+    if (!kRes && M == 0) { // no joint-constraint rows at all (parameter-space rows only): H starts as lambda I
       for (int idx = tid; idx < n * n; idx += 256) {
         const int i = idx % n, j = idx / n;
         if (j <= i) {
@@ -751,7 +950,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
                 continue;
               }
               const int hi = cx > cy ? cx : cy, lo = cx > cy ? cy : cx;
-              Hb[size_t(lo) * n + hi] += row.coef[x] * row.coef[y]; // (a row's parameters are distinct: limitScatterRow merges)
+              Hat(hi, lo) += row.coef[x] * row.coef[y]; // (a row's parameters are distinct: limitScatterRow merges)
             }
           }
         }
@@ -767,7 +966,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
           const double w = double(tw[p]);
           if (pb.enabledMask[p] != 0 && w > 0.0) {
             const double jw = sW * w, r = (w * (s.th[p] - double(tp[p]))) * sW;
-            Hb[size_t(c) * n + c] += jw * jw;
+            Hat(c, c) += jw * jw;
             s.g[c] += jw * r;
           }
         }
@@ -778,7 +977,177 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     // ---- llt_.compute(H) (Eigen::LLT, lower): right-looking, one column per step; a non-positive pivot is
     // recorded (the reference never checks LLT::info(), gauss_newton_solver.cpp:251)
     bool notPd = false;
-    auto factorH = [&]() {
+    // the resident forms (kRes).  Rows are dealt one per thread (n <= 256).
+    auto factorRes = [&]() {
+      notPd = false;
+      for (int k0 = 0; k0 < n; k0 += 4) {
+        const int kb = n - k0 < 4 ? n - k0 : 4;
+        // the kb x kb diagonal block, factored by every thread for itself (ten broadcast reads)
+        double D[4][4], id[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int c = 0; c <= a; ++c) {
+            D[a][c] = a < kb ? s.H[hpos(n, k0 + a, k0 + c)] : (a == c ? 1.0 : 0.0);
+          }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int c = 0; c <= a; ++c) {
+            double v = D[a][c];
+#pragma unroll
+            for (int e = 0; e < c; ++e) {
+              v -= D[a][e] * D[c][e];
+            }
+            if (a == c) {
+              bad = bad || !(v > 0.0);
+              D[a][a] = sqrt(v);
+              id[a] = 1.0 / D[a][a];
+            } else {
+              D[a][c] = v * id[c];
+            }
+          }
+        }
+        if (bad) { // every thread has factored the same numbers
+          notPd = true;
+          break;
+        }
+        const int i = tid;
+        const bool below = i >= k0 + kb && i < n;
+        double x[4] = {0.0, 0.0, 0.0, 0.0};
+        if (below) { // this thread's row of the panel against the block
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              double v = s.H[hpos(n, i, k0 + c)];
+#pragma unroll
+              for (int e = 0; e < c; ++e) {
+                v -= x[e] * D[c][e];
+              }
+              x[c] = v * id[c];
+            }
+          }
+        }
+        __syncthreads(); // the block and the panel have been read
+        if (below) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              s.H[hpos(n, i, k0 + c)] = x[c];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) { // (static indices: D stays in registers)
+            if (a < kb && i == k0 + a) {
+#pragma unroll
+              for (int c = 0; c <= a; ++c) {
+                s.H[hpos(n, i, k0 + c)] = D[a][c];
+              }
+              s.invd[i] = id[a];
+            }
+          }
+        }
+        __syncthreads();
+        // trailing update H(i, j) -= sum_c L(i, k0 + c) L(j, k0 + c), i >= j >= k0 + kb: a 16 x 16 grid of threads over (i, j)
+        const int base = k0 + kb, rem = n - base, ti = tid >> 4;
+        for (int jj = tid & 15; jj < rem; jj += 16) {
+          const int j = base + jj;
+          double lj[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            lj[c] = c < kb ? s.H[hpos(n, j, k0 + c)] : 0.0;
+          }
+          int ii = ti;
+          if (ii < jj) {
+            ii += ((jj - ii + 15) >> 4) << 4;
+          }
+          for (; ii < rem; ii += 16) {
+            const int i2 = base + ii;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              acc += (c < kb ? s.H[hpos(n, i2, k0 + c)] : 0.0) * lj[c];
+            }
+            s.H[hpos(n, i2, j)] -= acc;
+          }
+        }
+        __syncthreads();
+      }
+    };
+    // x = (L L^T)^-1 rhs by blocked substitutions: every thread solves the four unknowns of a block for itself, the
+    // thread of a later row takes them out of its right-hand side; one barrier per block (x and rhs may be the same array)
+    auto solveRes = [&](const double* rhs, double* x) {
+      for (int c = tid; c < n; c += 256) {
+        s.w1[c] = rhs[c];
+      }
+      for (int k0 = 0; k0 < n; k0 += 4) { // L y = rhs: w1 is consumed, y lands in w2
+        const int kb = n - k0 < 4 ? n - k0 : 4;
+        __syncthreads();
+        double yb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (a < kb) {
+            double v = s.w1[k0 + a];
+#pragma unroll
+            for (int c = 0; c < a; ++c) {
+              v -= s.H[hpos(n, k0 + a, k0 + c)] * yb[c];
+            }
+            yb[a] = v * s.invd[k0 + a];
+          }
+        }
+        const int i = tid;
+        if (i >= k0 && i < k0 + kb) {
+          const int a = i - k0;
+          s.w2[i] = a == 0 ? yb[0] : (a == 1 ? yb[1] : (a == 2 ? yb[2] : yb[3]));
+        } else if (i >= k0 + kb && i < n) {
+          double v = s.w1[i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              v -= s.H[hpos(n, i, k0 + c)] * yb[c];
+            }
+          }
+          s.w1[i] = v;
+        }
+      }
+      for (int k0 = ((n - 1) >> 2) << 2; k0 >= 0; k0 -= 4) { // L^T x = y: w2 is consumed
+        const int kb = n - k0 < 4 ? n - k0 : 4;
+        __syncthreads();
+        double zb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 3; a >= 0; --a) {
+          if (a < kb) {
+            double v = s.w2[k0 + a];
+#pragma unroll
+            for (int c = 3; c > a; --c) {
+              if (c < kb) {
+                v -= s.H[hpos(n, k0 + c, k0 + a)] * zb[c];
+              }
+            }
+            zb[a] = v * s.invd[k0 + a];
+          }
+        }
+        const int i = tid;
+        if (i >= k0 && i < k0 + kb) {
+          const int a = i - k0;
+          x[i] = a == 0 ? zb[0] : (a == 1 ? zb[1] : (a == 2 ? zb[2] : zb[3]));
+        } else if (i < k0) {
+          double v = s.w2[i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              v -= s.H[hpos(n, k0 + c, i)] * zb[c];
+            }
+          }
+          s.w2[i] = v;
+        }
+      }
+      __syncthreads();
+    };
+    auto factorScratch = [&]() {
     notPd = false;
     for (int k = 0; k < n; ++k) {
       const double dkk = Hb[size_t(k) * n + k];
@@ -811,7 +1180,7 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
     }
     };
     // ---- x = llt_.solve(rhs): wave 0, lanes over the already known entries (x and rhs may be the same array)
-    auto solveLLt = [&](const double* rhs, double* x) {
+    auto solveScratch = [&](const double* rhs, double* x) {
       for (int c = tid; c < n; c += 256) {
         x[c] = rhs[c];
       }
@@ -846,6 +1215,20 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       }
       __syncthreads();
     };
+    auto factorH = [&]() {
+      if (kRes) {
+        factorRes();
+      } else {
+        factorScratch();
+      }
+    };
+    auto solveLLt = [&](const double* rhs, double* x) {
+      if (kRes) {
+        solveRes(rhs, x);
+      } else {
+        solveScratch(rhs, x);
+      }
+    };
     if (!trust) {
       factorH();
       if (!notPd) {
@@ -874,8 +1257,14 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
       // seeds R with lambda = 1e-10 ON its diagonal (:86-87, online_householder_qr.cpp:133-140) and appends
       // sqrt(lambda_new - lambda) I rows when the damping grows (:215-224), so R^T R = J^T J + (1e-20 + lambda - 1e-10) I;
       // here H0 = J^T J (+ the parameter-space rows) is kept and every value of the damping is one LL^T of H0 + mu I.
-      for (int idx = tid; idx < n * n; idx += 256) { // (the lower triangle is what was assembled)
-        H0[idx] = Hb[idx];
+      if (kRes) {
+        for (int idx = tid; idx < n * (n + 1) / 2; idx += 256) {
+          H0[idx] = s.H[idx];
+        }
+      } else {
+        for (int idx = tid; idx < n * n; idx += 256) { // (the lower triangle is what was assembled)
+          H0[idx] = Hb[idx];
+        }
       }
       __threadfence_block();
       __syncthreads();
@@ -888,10 +1277,20 @@ __global__ void __launch_bounds__(256) solveF64Kernel(
         for (int newton = 0;;) { // one pass per value of the damping (:180-231)
           mu = 1e-20 + (lam - 1e-10);
           if (!haveStep) {
-            for (int idx = tid; idx < n * n; idx += 256) {
-              const int i = idx % n, j = idx / n;
-              if (j <= i) {
-                Hb[idx] = H0[idx] + (i == j ? mu : 0.0);
+            if (kRes) {
+              for (int idx = tid; idx < n * (n + 1) / 2; idx += 256) {
+                s.H[idx] = H0[idx];
+              }
+              __syncthreads();
+              for (int c = tid; c < n; c += 256) {
+                s.H[hpos(n, c, c)] += mu;
+              }
+            } else {
+              for (int idx = tid; idx < n * n; idx += 256) {
+                const int i = idx % n, j = idx / n;
+                if (j <= i) {
+                  Hb[idx] = H0[idx] + (i == j ? mu : 0.0);
+                }
               }
             }
             __threadfence_block();
@@ -1075,6 +1474,31 @@ size_t solveF64LdsBytes(int J, int P, int U, int n, int G, int genRows) {
   return (solveF64BaseDoubles(J, P, U, n, G, genRows) + ((size_t(n) * size_t(rc + 1) + 1) & ~size_t(1))) * sizeof(double);
 }
 
+// the resident instantiation: rows of J per chunk (a multiple of three, >= 12) next to the packed H, or 0 when it does
+// not fit (then the scratch form runs).  Two workgroups per CU while that leaves a chunk of at least twelve rows.
+static int solveF64ResidentChunkRows(int J, int P, int U, int n, int G, int genRows) {
+  if (n <= 0 || n > 256) {
+    return 0;
+  }
+  auto e = [](size_t c) { return (c + 1) & ~size_t(1); };
+  const size_t base = (solveF64BaseDoubles(J, P, U, n, G, genRows) + e(size_t(n) * size_t(n + 1) / 2) + 3 * e(n)) * sizeof(double);
+  for (size_t budget : {size_t(79) * 1024, size_t(158) * 1024}) {
+    if (base + size_t(n) * 13 * sizeof(double) + 16 > budget) {
+      continue;
+    }
+    size_t rows = (budget - base - 16) / (size_t(n) * sizeof(double)) - 1;
+    rows = rows > 48 ? 48 : rows;
+    rows -= rows % 3;
+    if (rows >= 12) {
+      return int(rows);
+    }
+  }
+  return 0;
+}
+bool solveF64IsResident(int J, int P, int U, int n, int G, int genRows) {
+  return solveF64ResidentChunkRows(J, P, U, n, G, genRows) >= 12;
+}
+
 hipError_t launchSolveF64(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -1088,18 +1512,32 @@ hipError_t launchSolveF64(
     double* Hg2,
     hipStream_t stream) {
   const int genRows = pb.rowsJoint - 3 * pb.U;
+  const int rcRes = solveF64ResidentChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
+  if (rcRes >= 12) {
+    auto e = [](size_t c) { return (c + 1) & ~size_t(1); };
+    const size_t lds = (solveF64BaseDoubles(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows) + e(size_t(n) * size_t(rcRes + 1)) +
+                        e(size_t(n) * size_t(n + 1) / 2) + 3 * e(n)) * sizeof(double);
+    static LdsLimitCache ldsLimitRes;
+    hipError_t rc = ldsLimitRes.ensure(reinterpret_cast<const void*>(solveF64Kernel<true>), lds);
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    hipLaunchKernelGGL(solveF64Kernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, nullptr, nullptr, Hg2, rcRes);
+    return hipGetLastError();
+  }
   const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }
-  if (lds > 64 * 1024) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(solveF64Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  static LdsLimitCache ldsLimit;
+  {
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(solveF64Kernel<false>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
   }
   hipLaunchKernelGGL(
-      solveF64Kernel, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, Hg2, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows));
+      solveF64Kernel<false>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, Hg2, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows));
   return hipGetLastError();
 }
 

@@ -192,6 +192,7 @@ hipError_t launchFusedSolve(
 
 // double-precision solve (mmx_f64.hip)
 size_t solveF64LdsBytes(int J, int P, int U, int n, int G = 0, int genRows = 0);
+bool solveF64IsResident(int J, int P, int U, int n, int G = 0, int genRows = 0); // the system stays in LDS: no J / H scratch is read or written
 hipError_t launchSolveF64(
     const RigDev& rig,
     const ProblemDev& pb,

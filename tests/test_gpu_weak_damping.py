@@ -50,7 +50,7 @@ def _write_report():
         json.dump(_REPORT, f, indent=1, sort_keys=True)
 
 
-def _gpu_solve(torch, rig, cons, th0, opt, route):
+def _gpu_solve(torch, rig, cons, th0, opt, route, parameter_history=False):
     from momentum_amd import capi
 
     B = th0.shape[0]
@@ -63,11 +63,31 @@ def _gpu_solve(torch, rig, cons, th0, opt, route):
         t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
     )  # fmt: skip
     pb.set_route(route)
-    out = pb.solve(torch.from_numpy(th0.copy()).to(dev), opt, want_history=True)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(dev), opt, want_history=True, want_parameter_history=parameter_history)
     torch.cuda.synchronize()
     res = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
     res["route_taken"] = pb.last_route()
     return res
+
+
+def _backtracking_differs(orc, rig, cons, th0, opt_of, idx, parameter_history):
+    """For the instances idx: does some iteration's step of the HIP path (from its parameter history) differ in LENGTH from
+    the double run's -- a backtracking decision that went the other way (alpha is halved per trial, so the lengths then
+    differ by a power of two)?  A nearly converged instance takes steps whose decrease of the error is below what a
+    single-precision sum of squares resolves: the accept test then fails on noise and the step is halved where the double
+    run accepts it (measured: iteration 7 of 10, steps of 1e-5 |theta|, ratios 1/4 ... 1/16) -- the error history, flat to
+    ten digits there, cannot show it.  The double run's iterates come from re-running it for k = 1 ... iterations."""
+    sub = cons.subset(idx)
+    prev = th0[idx].astype(np.float64)
+    prev_g = prev.copy()
+    differs = np.zeros(len(idx), bool)
+    for k in range(1, parameter_history.shape[1] + 1):
+        rk = orc.solve_batch(rig, sub, th0[idx], opt_of(k), dtype="f64", nthreads=_cores())["theta"]
+        gk = parameter_history[idx, k - 1].astype(np.float64)
+        sr, sg = np.linalg.norm(rk - prev, axis=1), np.linalg.norm(gk - prev_g, axis=1)
+        differs |= ~differs & (np.abs(sg - sr) > 0.3 * sr)
+        prev, prev_g = rk, gk
+    return differs
 
 
 def _rel(a, ref):
@@ -99,7 +119,7 @@ def test_well_determined_problems_hold_1e5_at_every_lambda(torch_cuda, orc, name
     cons, th0, _ = make_problem(rig, allj, allj, B, seed=31337, perturb=0.3)
     for lam in LAMBDAS:
         opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=lam, do_line_search=line_search)
-        out = _gpu_solve(torch_cuda, rig, cons, th0, opt, route)
+        out = _gpu_solve(torch_cuda, rig, cons, th0, opt, route, parameter_history=bool(line_search))
         assert out["route_taken"] == route
         ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=_cores())
         rel = _rel(out["theta"].astype(np.float64), ref["theta"])
@@ -108,8 +128,21 @@ def test_well_determined_problems_hold_1e5_at_every_lambda(torch_cuda, orc, name
         # oracle's own float instantiation does, too -- and is then a different (equally valid) iteration, not a rounding
         # error.  Same decisions <=> the same error at every iterate (1e-3 relative, above the fp32 noise floor of a
         # converged fit): those instances are held to 1e-5; the few others must have converged as far as the double run.
-        h, href = out["error_history"], ref["error_history"]
-        same = np.all(np.abs(h - href) <= 1e-3 * np.abs(href) + 1e-7 * href[:, :1], axis=1) if line_search else np.ones(B, bool)
+        # The history holds the error at the START of each iteration, so the decision of the last iteration shows only in
+        # an eleventh entry: the same (deterministic) solves run for eleven iterations supply it -- a nearly converged
+        # instance whose last step is 1e-5 of theta moves by 0.5e-5 when that step is halved.
+        same = np.ones(B, bool)
+        if line_search:
+            opt11 = GnOptions.make(min_iterations=11, max_iterations=11, threshold=1.0, regularization=lam, do_line_search=line_search)
+            h = _gpu_solve(torch_cuda, rig, cons, th0, opt11, route)["error_history"]
+            href = orc.solve_batch(rig, cons, th0, opt11, dtype="f64", nthreads=_cores())["error_history"]
+            assert np.array_equal(h[:, :10], out["error_history"])
+            same = np.all(np.abs(h - href) <= 1e-3 * np.abs(href) + 1e-7 * href[:, :1], axis=1)
+            # ... and a decision taken on a decrease the error history cannot resolve: checked on the (few) instances it matters for
+            idx = np.flatnonzero(same & (rel > BOUND))
+            if 0 < len(idx) <= 32:
+                opt_of = lambda k: GnOptions.make(min_iterations=k, max_iterations=k, threshold=1.0, regularization=lam, do_line_search=line_search)
+                same[idx[_backtracking_differs(orc, rig, cons, th0, opt_of, idx, out["parameter_history"])]] = False
         _REPORT[f"{name} lambda={lam:g} line_search={line_search} route={route}"] = {
             "instances": B, "max_rel": float(rel.max()), "median_rel": float(np.median(rel)), "above_1e-5": int((rel > BOUND).sum()),
             "same_line_search_decisions": int(same.sum()), "max_rel_same_decisions": float(rel[same].max()),

@@ -110,7 +110,7 @@ def test_real_rig_solves_on_the_gpu(torch_cuda, orc, name):
         assert rel.max() <= 1e-5, (name, route, rel)
         assert np.array_equal(out["iterations"].cpu().numpy(), g["iterations"]) and np.all(out["status"].cpu().numpy() & 3 == 0)
         h = out["error_history"].cpu().numpy()
-        assert np.all(np.abs(h - g["error_history"]) <= 1e-4 * np.abs(g["error_history"]) + 1e-7 * g["error_history"][:, :1])  # (fp32 noise floor of a converged fit)
+        assert np.all(np.abs(h - g["error_history"]) <= 1e-4 * np.abs(g["error_history"]) + 1e-7 * g["error_history"][:, :1] + 1e-12)  # (fp32 noise floor of a converged fit; the rest-pose frame starts AT its solution)
     # the double instantiation: 1e-10
     out = pb.solve_f64(torch.from_numpy(g["theta0"].astype(np.float64)).to(dev), GnOptions.make(**OPT))
     torch.cuda.synchronize()
