@@ -395,6 +395,7 @@ def main() -> None:
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the other BASELINE configurations (N = 1 default run reports them)")
     ap.add_argument("--jac-launches", type=int, default=20)
     ap.add_argument("--line-search", type=int, default=0, choices=[0, 1, 2], help="MMX_LINE_SEARCH_*: 0 none (the BASELINE metric), 1 GaussNewtonSolverT's rule, 2 the rule of the batched driver's solvers (SubsetGN / GN-QR)")
+    ap.add_argument("--lambda", dest="regularization", type=float, default=0.05, help="GaussNewtonSolverOptions::regularization (the BASELINE metric: 0.05)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64: mmx_solve_f64 (SolverT<double>; built for exactness, see DESIGN.md)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
     args = ap.parse_args()
@@ -435,7 +436,7 @@ def main() -> None:
     seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
     db = DeviceBatch(rig, parents, B, local_rank, seed, tracker=CONFIGS[args.config][1].endswith("+tracker"))
     pb, theta_star = db.pb, db.theta_star
-    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=0.05, step_rule=step_rule, do_line_search=args.line_search)
+    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=args.regularization, step_rule=step_rule, do_line_search=args.line_search)
     dev = pb.device
     elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist, comm, args.dtype)
 
@@ -542,7 +543,7 @@ def main() -> None:
                 "solver": factor_structure(pb),
                 "gn_iterations": args.iterations,
                 "line_search": args.line_search,
-                "regularization": 0.05,
+                "regularization": args.regularization,
                 "sharding": f"{world} x {B} independent instances, one all-reduce of residual norms per solve",
                 "exchange": ("RCCL all-reduce of 3 doubles per solve, called from the C ABI (mmx_comm_all_reduce_norms), ranks seen by RCCL: " + str(comm.world_size)) if comm is not None else ("none (one GPU)" if world == 1 else "gloo (plumbing test)"),
                 # experiment switches in force (none in a default run): a number measured with one of them says so

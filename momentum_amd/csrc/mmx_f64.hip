@@ -502,6 +502,225 @@ __device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, cons
   return 0.693147180559945309417232121458176568 * (v - D3{a[0], a[1], a[2]});
 }
 
+// ---- the resident instantiation's three hot routines, each compiled on its own (not inlined: inside the kernel, whose
+// register file is full of the state of everything else, they were allocated around ~140 spilled registers)
+// g += J^T r, H += J^T J for the rows of J in jl (column-major, ldj doubles per column, rows padded with zeros to a multiple
+// of four).  H on the matrix cores: a 16 x 16 tile of the lower triangle takes one v_mfma_f64_16x16x4_f64 per four rows --
+// lane l feeds A[l % 16][l / 16] = J[row 4 s + l / 16][column 16 I + l % 16], likewise B for block column Jc, and register r
+// of lane l comes back as C[4 r + l / 16][l % 16] (measured: scripts/probes/mfma_f64_layout.hip; NOT the single-precision
+// 16x16x4 layout) -- and is added to the packed triangle once per chunk.  gfx950 issues the f64 matrix instruction at
+// the rate of the f32 one.
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ __noinline__ void residentAccumulate(const double* jl, int ldj, const double* ur, int rows, double* g, double* H, int n, int tid) {
+  for (int c = tid; c < n; c += 256) {
+    double acc = g[c];
+    for (int r = 0; r < rows; ++r) {
+      acc += jl[c * ldj + r] * ur[r];
+    }
+    g[c] = acc;
+  }
+  const int NB = (n + 15) >> 4, T = NB * (NB + 1) / 2, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, k = lane >> 4, steps = (rows + 3) >> 2;
+  int I = 0, Jc = 0;
+  for (int t = 0; t < T; ++t) { // tiles in row-major order of the lower triangle, dealt to the waves round robin
+    if ((t & 3) == wave) {
+      const double* pa = jl + (16 * I + i < n ? 16 * I + i : n - 1) * ldj + k;
+      const double* pb = jl + (16 * Jc + i < n ? 16 * Jc + i : n - 1) * ldj + k;
+      v4d c = {0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < steps; ++s) {
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pb[4 * s], c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + 4 * r + k, col = 16 * Jc + i;
+        if (row < n && col <= row) {
+          H[hpos(n, row, col)] += c[r];
+        }
+      }
+    }
+    if (++Jc > I) {
+      Jc = 0, ++I;
+    }
+  }
+}
+// right-looking blocked Cholesky of the packed lower triangle, four columns per barrier pair; true when a pivot was not positive
+__device__ __noinline__ bool residentFactor(double* H, double* invd, int n, int tid) {
+      bool notPd = false;
+      for (int k0 = 0; k0 < n; k0 += 4) {
+        const int kb = n - k0 < 4 ? n - k0 : 4;
+        // the kb x kb diagonal block, factored by every thread for itself (ten broadcast reads)
+        double D[4][4], id[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int c = 0; c <= a; ++c) {
+            D[a][c] = a < kb ? H[hpos(n, k0 + a, k0 + c)] : (a == c ? 1.0 : 0.0);
+          }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int c = 0; c <= a; ++c) {
+            double v = D[a][c];
+#pragma unroll
+            for (int e = 0; e < c; ++e) {
+              v -= D[a][e] * D[c][e];
+            }
+            if (a == c) {
+              bad = bad || !(v > 0.0);
+              // 1 / sqrt(v): the hardware's estimate and two Newton steps (each squares the error), then l = v / sqrt(v)
+              double y = __builtin_amdgcn_rsq(v);
+              y = y * (1.5 - 0.5 * v * y * y);
+              y = y * (1.5 - 0.5 * v * y * y);
+              id[a] = y;
+              D[a][a] = v * y;
+            } else {
+              D[a][c] = v * id[c];
+            }
+          }
+        }
+        if (bad) { // every thread has factored the same numbers
+          notPd = true;
+          break;
+        }
+        const int i = tid;
+        const bool below = i >= k0 + kb && i < n;
+        double x[4] = {0.0, 0.0, 0.0, 0.0};
+        if (below) { // this thread's row of the panel against the block
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              double v = H[hpos(n, i, k0 + c)];
+#pragma unroll
+              for (int e = 0; e < c; ++e) {
+                v -= x[e] * D[c][e];
+              }
+              x[c] = v * id[c];
+            }
+          }
+        }
+        __syncthreads(); // the block and the panel have been read
+        if (below) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              H[hpos(n, i, k0 + c)] = x[c];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) { // (static indices: D stays in registers)
+            if (a < kb && i == k0 + a) {
+#pragma unroll
+              for (int c = 0; c <= a; ++c) {
+                H[hpos(n, i, k0 + c)] = D[a][c];
+              }
+              invd[i] = id[a];
+            }
+          }
+        }
+        __syncthreads();
+        // trailing update H(i, j) -= sum_c L(i, k0 + c) L(j, k0 + c), i >= j >= k0 + kb: a rank-four update, i.e. ONE
+        // v_mfma_f64_16x16x4_f64 per 16 x 16 tile of the trailing triangle (rows / columns before k0 + kb are masked out)
+        const int base = k0 + kb;
+        if (base < n) {
+          const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+          const int NB = (n + 15) >> 4, I0 = base >> 4;
+          int t = 0;
+          for (int I = I0; I < NB; ++I) {
+            for (int Jc = I0; Jc <= I; ++Jc, ++t) {
+              if ((t & 3) != wave) {
+                continue;
+              }
+              const int ra = 16 * I + li, rb = 16 * Jc + li;
+              const double a = (ra >= base && ra < n && lk < kb) ? H[hpos(n, ra, k0 + lk)] : 0.0;
+              const double b2 = (rb >= base && rb < n && lk < kb) ? H[hpos(n, rb, k0 + lk)] : 0.0;
+              v4d c = {0.0, 0.0, 0.0, 0.0};
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, c, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + 4 * r + lk, col = 16 * Jc + li;
+                if (row < n && col <= row && col >= base) {
+                  H[hpos(n, row, col)] -= c[r];
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+      return notPd;
+}
+__device__ __noinline__ void residentSolve(const double* H, const double* invd, double* w1, double* w2, const double* rhs, double* x, int n, int tid) {
+      for (int c = tid; c < n; c += 256) {
+        w1[c] = rhs[c];
+      }
+      for (int k0 = 0; k0 < n; k0 += 4) { // L y = rhs: w1 is consumed, y lands in w2
+        const int kb = n - k0 < 4 ? n - k0 : 4;
+        __syncthreads();
+        double yb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (a < kb) {
+            double v = w1[k0 + a];
+#pragma unroll
+            for (int c = 0; c < a; ++c) {
+              v -= H[hpos(n, k0 + a, k0 + c)] * yb[c];
+            }
+            yb[a] = v * invd[k0 + a];
+          }
+        }
+        const int i = tid;
+        if (i >= k0 && i < k0 + kb) {
+          const int a = i - k0;
+          w2[i] = a == 0 ? yb[0] : (a == 1 ? yb[1] : (a == 2 ? yb[2] : yb[3]));
+        } else if (i >= k0 + kb && i < n) {
+          double v = w1[i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              v -= H[hpos(n, i, k0 + c)] * yb[c];
+            }
+          }
+          w1[i] = v;
+        }
+      }
+      for (int k0 = ((n - 1) >> 2) << 2; k0 >= 0; k0 -= 4) { // L^T x = y: w2 is consumed
+        const int kb = n - k0 < 4 ? n - k0 : 4;
+        __syncthreads();
+        double zb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 3; a >= 0; --a) {
+          if (a < kb) {
+            double v = w2[k0 + a];
+#pragma unroll
+            for (int c = 3; c > a; --c) {
+              if (c < kb) {
+                v -= H[hpos(n, k0 + c, k0 + a)] * zb[c];
+              }
+            }
+            zb[a] = v * invd[k0 + a];
+          }
+        }
+        const int i = tid;
+        if (i >= k0 && i < k0 + kb) {
+          const int a = i - k0;
+          x[i] = a == 0 ? zb[0] : (a == 1 ? zb[1] : (a == 2 ? zb[2] : zb[3]));
+        } else if (i < k0) {
+          double v = w2[i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < kb) {
+              v -= H[hpos(n, k0 + c, i)] * zb[c];
+            }
+          }
+          w2[i] = v;
+        }
+      }
+      __syncthreads();
+}
+
 // kRes: the resident instantiation (round 4).  The system lives in LDS for the whole solve: J is assembled a chunk of
 // constraints at a time straight into LDS and consumed there (no dense J anywhere), H is the packed lower triangle in
 // LDS, factored by a right-looking blocked Cholesky (four columns per barrier pair) and solved by blocked substitutions
@@ -572,12 +791,21 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
   }
   const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   __syncthreads();
+#ifdef MMX_EXP_F64CLK
+  long long clkAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long clkT = clock64();
+#define F64CLK(slot) { __syncthreads(); const long long now_ = clock64(); clkAcc[slot] += now_ - clkT; clkT = now_; }
+#else
+#define F64CLK(slot)
+#endif
   double lastError = DBL_MAX, curError = DBL_MAX; // solver.cpp:84-85
   double lambda = double(fp.lambda);
   int itersDone = 0;
   for (int it = 0; it < fp.maxIterations; ++it) {
     // ---- SkeletonSolverFunctionT::getJacobian: state, residual, Jacobian (skeleton_solver_function.cpp:200-261)
+    F64CLK(7)
     fkF64(rig, s, s.th, tid, true);
+    F64CLK(0)
     double e = 0.0;
     for (int u = tid; u < U; u += 256) {
       e += evalUnitF64(pb, s, b, u, true);
@@ -620,6 +848,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       wi[0] = ct.tinParent, wi[1] = row, wi[2] = 3 | 16, wi[3] = ct.tinStop;
     }
     curError = blockSumF64(s, e, tid); // (not rounded: the value getJacobian returns)
+    F64CLK(1)
     if (trust) {
       lambda = 0.0; // H is assembled without damping; the trust region adds its own per factorisation
     }
@@ -638,60 +867,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
         s.H[hpos(n, c, c)] = lambda;
       }
       // rows [r0, r0 + rows) of J are in jl: g += J^T r, H += J^T J (a thread owns 4 x 4 blocks of the lower triangle)
-      auto accumulate = [&](int r0, int rows) {
-        for (int c = tid; c < n; c += 256) {
-          double acc = s.g[c];
-          for (int r = 0; r < rows; ++r) {
-            acc += s.jl[c * ldj + r] * s.ur[r0 + r];
-          }
-          s.g[c] = acc;
-        }
-        const int nb4 = (n + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2;
-        for (int q = tid; q < nblk; q += 256) {
-          {
-            int bi = int((sqrt(8.0 * double(q) + 1.0) - 1.0) * 0.5); // q = bi (bi + 1) / 2 + bj, bj <= bi
-            while ((bi + 1) * (bi + 2) / 2 <= q) {
-              ++bi;
-            }
-            while (bi * (bi + 1) / 2 > q) {
-              --bi;
-            }
-            const int bj = q - bi * (bi + 1) / 2;
-            double acc[4][4] = {};
-            const double* ci[4];
-            const double* cj[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { // (columns beyond n read column n - 1: their entries are never stored)
-              ci[k] = s.jl + (4 * bi + k < n ? 4 * bi + k : n - 1) * ldj;
-              cj[k] = s.jl + (4 * bj + k < n ? 4 * bj + k : n - 1) * ldj;
-            }
-            for (int r = 0; r < rows; ++r) {
-              double av[4], bv[4];
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                av[k] = ci[k][r], bv[k] = cj[k][r];
-              }
-#pragma unroll
-              for (int x = 0; x < 4; ++x) {
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                  acc[x][y] += av[x] * bv[y];
-                }
-              }
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-#pragma unroll
-              for (int y = 0; y < 4; ++y) {
-                const int i = 4 * bi + x, j = 4 * bj + y;
-                if (i < n && j <= i) {
-                  s.H[hpos(n, i, j)] += acc[x][y];
-                }
-              }
-            }
-          }
-        }
-      };
+      auto accumulate = [&](int r0, int rows) { residentAccumulate(s.jl, ldj, s.ur + r0, rows, s.g, s.H, n, tid); };
       // position / orientation units, uc at a time
       const int uc = rc / 3;
       for (int u0 = 0; u0 < U; u0 += uc) {
@@ -714,6 +890,10 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
           }
           double* o = s.jl + c * ldj + 3 * (u - u0);
           o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+        }
+        for (int idx = tid; idx < n * ((4 - (3 * nu) % 4) % 4); idx += 256) { // rows up to a multiple of four: zeros (the matrix cores take four at a time)
+          const int pad = (4 - (3 * nu) % 4) % 4, c = idx / pad;
+          s.jl[c * ldj + 3 * nu + (idx - c * pad)] = 0.0;
         }
         __syncthreads();
         accumulate(3 * u0, 3 * nu);
@@ -776,6 +956,10 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
           for (int q = 0; q < nrows; ++q) {
             o[q] = acc[q];
           }
+        }
+        for (int idx = tid; idx < n * ((4 - (rowEnd - rowFirst) % 4) % 4); idx += 256) {
+          const int pad = (4 - (rowEnd - rowFirst) % 4) % 4, c = idx / pad;
+          s.jl[c * ldj + (rowEnd - rowFirst) + (idx - c * pad)] = 0.0;
         }
         __syncthreads();
         accumulate(rowFirst, rowEnd - rowFirst);
@@ -920,6 +1104,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     __threadfence_block();
     __syncthreads();
     }
+    F64CLK(2)
     if (!kRes && M == 0) { // no joint-constraint rows at all (parameter-space rows only): H starts as lambda I
       for (int idx = tid; idx < n * n; idx += 256) {
         const int i = idx % n, j = idx / n;
@@ -978,175 +1163,10 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     // recorded (the reference never checks LLT::info(), gauss_newton_solver.cpp:251)
     bool notPd = false;
     // the resident forms (kRes).  Rows are dealt one per thread (n <= 256).
-    auto factorRes = [&]() {
-      notPd = false;
-      for (int k0 = 0; k0 < n; k0 += 4) {
-        const int kb = n - k0 < 4 ? n - k0 : 4;
-        // the kb x kb diagonal block, factored by every thread for itself (ten broadcast reads)
-        double D[4][4], id[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-          for (int c = 0; c <= a; ++c) {
-            D[a][c] = a < kb ? s.H[hpos(n, k0 + a, k0 + c)] : (a == c ? 1.0 : 0.0);
-          }
-        }
-        bool bad = false;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-          for (int c = 0; c <= a; ++c) {
-            double v = D[a][c];
-#pragma unroll
-            for (int e = 0; e < c; ++e) {
-              v -= D[a][e] * D[c][e];
-            }
-            if (a == c) {
-              bad = bad || !(v > 0.0);
-              D[a][a] = sqrt(v);
-              id[a] = 1.0 / D[a][a];
-            } else {
-              D[a][c] = v * id[c];
-            }
-          }
-        }
-        if (bad) { // every thread has factored the same numbers
-          notPd = true;
-          break;
-        }
-        const int i = tid;
-        const bool below = i >= k0 + kb && i < n;
-        double x[4] = {0.0, 0.0, 0.0, 0.0};
-        if (below) { // this thread's row of the panel against the block
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              double v = s.H[hpos(n, i, k0 + c)];
-#pragma unroll
-              for (int e = 0; e < c; ++e) {
-                v -= x[e] * D[c][e];
-              }
-              x[c] = v * id[c];
-            }
-          }
-        }
-        __syncthreads(); // the block and the panel have been read
-        if (below) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              s.H[hpos(n, i, k0 + c)] = x[c];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int a = 0; a < 4; ++a) { // (static indices: D stays in registers)
-            if (a < kb && i == k0 + a) {
-#pragma unroll
-              for (int c = 0; c <= a; ++c) {
-                s.H[hpos(n, i, k0 + c)] = D[a][c];
-              }
-              s.invd[i] = id[a];
-            }
-          }
-        }
-        __syncthreads();
-        // trailing update H(i, j) -= sum_c L(i, k0 + c) L(j, k0 + c), i >= j >= k0 + kb: a 16 x 16 grid of threads over (i, j)
-        const int base = k0 + kb, rem = n - base, ti = tid >> 4;
-        for (int jj = tid & 15; jj < rem; jj += 16) {
-          const int j = base + jj;
-          double lj[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            lj[c] = c < kb ? s.H[hpos(n, j, k0 + c)] : 0.0;
-          }
-          int ii = ti;
-          if (ii < jj) {
-            ii += ((jj - ii + 15) >> 4) << 4;
-          }
-          for (; ii < rem; ii += 16) {
-            const int i2 = base + ii;
-            double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              acc += (c < kb ? s.H[hpos(n, i2, k0 + c)] : 0.0) * lj[c];
-            }
-            s.H[hpos(n, i2, j)] -= acc;
-          }
-        }
-        __syncthreads();
-      }
-    };
+    auto factorRes = [&]() { notPd = residentFactor(s.H, s.invd, n, tid); };
     // x = (L L^T)^-1 rhs by blocked substitutions: every thread solves the four unknowns of a block for itself, the
     // thread of a later row takes them out of its right-hand side; one barrier per block (x and rhs may be the same array)
-    auto solveRes = [&](const double* rhs, double* x) {
-      for (int c = tid; c < n; c += 256) {
-        s.w1[c] = rhs[c];
-      }
-      for (int k0 = 0; k0 < n; k0 += 4) { // L y = rhs: w1 is consumed, y lands in w2
-        const int kb = n - k0 < 4 ? n - k0 : 4;
-        __syncthreads();
-        double yb[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          if (a < kb) {
-            double v = s.w1[k0 + a];
-#pragma unroll
-            for (int c = 0; c < a; ++c) {
-              v -= s.H[hpos(n, k0 + a, k0 + c)] * yb[c];
-            }
-            yb[a] = v * s.invd[k0 + a];
-          }
-        }
-        const int i = tid;
-        if (i >= k0 && i < k0 + kb) {
-          const int a = i - k0;
-          s.w2[i] = a == 0 ? yb[0] : (a == 1 ? yb[1] : (a == 2 ? yb[2] : yb[3]));
-        } else if (i >= k0 + kb && i < n) {
-          double v = s.w1[i];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              v -= s.H[hpos(n, i, k0 + c)] * yb[c];
-            }
-          }
-          s.w1[i] = v;
-        }
-      }
-      for (int k0 = ((n - 1) >> 2) << 2; k0 >= 0; k0 -= 4) { // L^T x = y: w2 is consumed
-        const int kb = n - k0 < 4 ? n - k0 : 4;
-        __syncthreads();
-        double zb[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int a = 3; a >= 0; --a) {
-          if (a < kb) {
-            double v = s.w2[k0 + a];
-#pragma unroll
-            for (int c = 3; c > a; --c) {
-              if (c < kb) {
-                v -= s.H[hpos(n, k0 + c, k0 + a)] * zb[c];
-              }
-            }
-            zb[a] = v * s.invd[k0 + a];
-          }
-        }
-        const int i = tid;
-        if (i >= k0 && i < k0 + kb) {
-          const int a = i - k0;
-          x[i] = a == 0 ? zb[0] : (a == 1 ? zb[1] : (a == 2 ? zb[2] : zb[3]));
-        } else if (i < k0) {
-          double v = s.w2[i];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              v -= s.H[hpos(n, k0 + c, i)] * zb[c];
-            }
-          }
-          s.w2[i] = v;
-        }
-      }
-      __syncthreads();
-    };
+    auto solveRes = [&](const double* rhs, double* x) { residentSolve(s.H, s.invd, s.w1, s.w2, rhs, x, n, tid); };
     auto factorScratch = [&]() {
     notPd = false;
     for (int k = 0; k < n; ++k) {
@@ -1229,11 +1249,14 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
         solveScratch(rhs, x);
       }
     };
+    F64CLK(3)
     if (!trust) {
       factorH();
+      F64CLK(4)
       if (!notPd) {
         solveLLt(s.g, s.d);
       }
+      F64CLK(5)
     }
     // ---- updateParameters (gauss_newton_solver.cpp:283-313; subset_gauss_newton_solver.cpp:117-142) / LM schedule
     auto makeTrial = [&](double scale) {
@@ -1428,6 +1451,14 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       break;
     }
   }
+#ifdef MMX_EXP_F64CLK
+  F64CLK(6)
+  if (b == 0 && tid == 0 && st.errorHistory != nullptr && fp.maxIterations >= 8) {
+    for (int i = 0; i < 8; ++i) {
+      st.errorHistory[i] = double(clkAcc[i]);
+    }
+  }
+#endif
   // NaN / Inf: revert to the initial parameters (tensor_ik.cpp:168-173) = do not write
   int bad = 0;
   for (int i = tid; i < P; i += 256) {
@@ -1488,7 +1519,7 @@ static int solveF64ResidentChunkRows(int J, int P, int U, int n, int G, int genR
     }
     size_t rows = (budget - base - 16) / (size_t(n) * sizeof(double)) - 1;
     rows = rows > 48 ? 48 : rows;
-    rows -= rows % 3;
+    rows -= rows % 12; // whole units (3 rows) and whole steps of the matrix cores (4 rows)
     if (rows >= 12) {
       return int(rows);
     }
