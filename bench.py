@@ -48,6 +48,7 @@ CONFIGS = {
     # name: (rig variant, constraint joints, default batch per GPU, step rule, description)
     "cfg2": ("p128", "landmarks", 4096, 0, "BASELINE configs[1]: B x 72-joint humanoid (P=128), position+orientation on 16 landmark joints (M=192), GN lambda=0.05, 10 iterations"),
     "cfg3": ("p128", "landmarks", 65536, 1, "BASELINE configs[2]: 65536 x 72-joint humanoid (P=128, M=192), LM gain-ratio damping schedule (lambda0=0.05), 10 iterations"),
+    "cfg4": ("p128", "landmarks", 32768, 0, "BASELINE configs[3]: 262144 x 72-joint humanoid over 8 GPUs = 32768 per GPU (P=128, M=192), GN lambda=0.05, 10 iterations (weak scaling: the per-GPU shard of cfg2's problem)"),
     "cfg5": ("rig300", "cfg5", 8192, 0, "BASELINE configs[4]: 8192 x 300-joint hand+body rig (P=300), 150 position + 50 orientation constraints (M=900), GN lambda=0.05, 10 iterations"),
     "cfg2_all": ("p219", "all", 4096, 0, "BASELINE configs[1] stress variant: P=219, position+orientation on all 72 joints (M=864)"),
     "cfg2_p219": ("p219", "landmarks", 4096, 0, "P=219 parameter set, position+orientation on the 16 landmark joints (route selection probe)"),
@@ -57,13 +58,17 @@ CONFIGS = {
     "cfg2_tracker": ("p128", "landmarks+tracker", 4096, 0, "BASELINE configs[1] + PlaneErrorFunction (8 constraints) + 16 MinMax parameter limits (M=192+8+16)"),
 }
 
-# what the default single-GPU run reports besides the headline: (key, config, batch, line_search, timed steps, CPU sample, lambda)
+# what the default single-GPU run reports besides the headline: (key, config, batch, line_search, timed steps, CPU sample, lambda[, dtype])
 EXTRA_RUNS = [
     ("cfg3@65536", "cfg3", 65536, 0, 4, 8192, 0.05),
     ("cfg2@32768", "cfg2", 32768, 0, 6, 8192, 0.05),
     ("cfg2@4096 line_search=2", "cfg2", 4096, 2, 10, 4096, 0.05),
     ("cfg5@8192", "cfg5", 8192, 0, 3, 1024, 0.05),
     ("cfg2_tracker@4096", "cfg2_tracker", 4096, 0, 10, 4096, 0.05),
+    # the double instantiation (mmx_solve_f64, SolverT<double>) on the weak-damping case the single-precision line below
+    # cannot hold: checked against the oracle's double run on the instances whose line-search decisions agree, with the
+    # oracle's DOUBLE instantiation as its CPU baseline
+    ("cfg2@4096 lambda=1e-5 line_search=2 dtype=f64", "cfg2", 4096, 2, 3, 1024, 1e-5, "f64"),
     # weak damping (pymomentum's test_solver2.py value) with the batched driver's line search: on this shape -- as many
     # independent rows as solved parameters -- no single-precision Cholesky solver holds 1e-5 on theta (check.pass is
     # false by construction, the float oracle's figures stand beside it); tests/test_gpu_weak_damping.py has the table
@@ -116,6 +121,7 @@ class DeviceBatch:
         from momentum_amd import _abi, capi
 
         self.rig, self.parents, self.B = rig, parents, B
+        self.last_status, self.last_elapsed_rank = None, None  # of the last solve_loop on this batch
         pos_parents, ori_parents = parents
         self.rh = capi.RigHandle(rig, device_index)
         self.pb = pb = capi.Problem(self.rh, B, pos_parents, ori_parents)
@@ -190,7 +196,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def parity_check(db: DeviceBatch, theta_gpu, options, n):
+def parity_check(db: DeviceBatch, theta_gpu, options, n, line_search_aware=False):
     """Re-solves the first n (distinct) instances of the timed batch with the CPU oracle in double
     precision and compares the pose parameters (outside the timed region; the oracle is the checker)."""
     from oracle import oracle as orc
@@ -242,6 +248,8 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n):
         out["pass_relaxed"] = bool(out["num_above_bound"] <= n // 100 and out["above_bound_float_oracle_also_above"])
         out["pass_relaxed_rule"] = ">= 99 % within the bound; every instance above it is above it in the oracle's float instantiation too"
     out["within_bound"] = f"{n - out['num_above_bound']}/{n}"
+    if line_search_aware:
+        out["note"] = "backtracking takes discrete decisions: an instance whose accept test sits on its threshold goes the other, equally valid, way in another precision (tests/test_gpu_weak_damping.py separates those by step length); `pass` here is the plain bound on every checked instance"
     return out
 
 
@@ -315,7 +323,10 @@ def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None, comm=None, dtype=
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_rank = elapsed
     elapsed = D.reduce_max(dist, elapsed, dev)
+    db.last_status = outputs["status"]
+    db.last_elapsed_rank = elapsed_rank
     return elapsed, theta, [float(x) for x in norms.tolist()]
 
 
@@ -353,15 +364,16 @@ def fused_pmc():
         return None
 
 
-def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu, regularization=0.05):
+def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu, regularization=0.05, dtype="f32"):
     from momentum_amd._abi import GnOptions
 
     rig, parents, _, step_rule, desc = build_rig(config)
     db = DeviceBatch(rig, parents, B, device_index, 424242, tracker=CONFIGS[config][1].endswith("+tracker"))
     opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=regularization, step_rule=step_rule, do_line_search=line_search)
-    elapsed, theta, norms = solve_loop(db, opt, steps, 1)
+    elapsed, theta, norms = solve_loop(db, opt, steps, 1, dtype=dtype)
     out = {
         "workload": desc,
+        "dtype": dtype,
         "regularization": regularization,
         "batch": B,
         "line_search": line_search,
@@ -370,11 +382,14 @@ def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iter
         "ms_per_step": 1e3 * elapsed / steps,
         "steps": steps,
         "failed_instances": norms[2],
-        "check": parity_check(db, theta, opt, check_n),
-        "solver": factor_structure(db.pb),
+        # MMX_SOLVE_DAMPING_FLOORED (include/mmx.h): instances on which the single-precision factor's damping floor exceeded
+        # the caller's lambda in some iteration -- the caller's cue to take mmx_solve_f64 (never set by the double route)
+        "damping_floored_instances": int((db.last_status & 4 != 0).sum()) if db.last_status is not None else None,
+        "check": parity_check(db, theta, opt, check_n, line_search_aware=line_search != 0),
+        "solver": factor_structure(db.pb) if dtype == "f32" else {"route": "mmx_solve_f64", "solved_parameters": solved_parameters(db.pb)},
     }
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(db, cpu_sample, opt)
+        out["cpu_baseline"] = cpu_baseline(db, cpu_sample, opt, dtype)
         out["gpu_over_cpu"] = out["solves_per_s"] / out["cpu_baseline"]["value"]
     del db
     torch.cuda.empty_cache()
@@ -439,6 +454,8 @@ def main() -> None:
     opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=args.regularization, step_rule=step_rule, do_line_search=args.line_search)
     dev = pb.device
     elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist, comm, args.dtype)
+    # per-rank rates (each rank's own clock around the same K steps) next to the aggregate, which uses the slowest rank's time
+    rank_rate_min, rank_rate_max = D.reduce_min_max(dist, float(B) * args.steps / db.last_elapsed_rank, pb.device)
 
     # ---- roofline of the J-assembly kernel (mmx_eval_jacobian): HIP events on the launch stream
     M, P = pb.M, pb.P
@@ -545,11 +562,17 @@ def main() -> None:
                 "line_search": args.line_search,
                 "regularization": args.regularization,
                 "sharding": f"{world} x {B} independent instances, one all-reduce of residual norms per solve",
-                "exchange": ("RCCL all-reduce of 3 doubles per solve, called from the C ABI (mmx_comm_all_reduce_norms), ranks seen by RCCL: " + str(comm.world_size)) if comm is not None else ("none (one GPU)" if world == 1 else "gloo (plumbing test)"),
+                "exchange": {
+                    "what": "all-reduce of 3 doubles (sum of final errors, sum of iterations, failed instances) per solve; nothing else crosses GPUs",
+                    "backend": "RCCL called from the C ABI (mmx_comm_all_reduce_norms)" if comm is not None else ("none (one GPU)" if world == 1 else "gloo (plumbing test)"),
+                    "ranks_seen_by_rccl": comm.world_size if comm is not None else None,
+                    "per_rank_solves_per_s": {"min": rank_rate_min, "max": rank_rate_max},
+                },
                 # experiment switches in force (none in a default run): a number measured with one of them says so
                 "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMX_")},
             },
-            "check": {"sum_final_error": total_err, "sum_iterations": total_it, "failed_instances": failed},
+            "check": {"sum_final_error": total_err, "sum_iterations": total_it, "failed_instances": failed,
+                      "damping_floored_instances_rank0": int((db.last_status & 4 != 0).sum())},
             "roofline": {
                 "kernel": "fkJacobianKernel<true> (mmx_eval_jacobian: FK + dense J/r assembly)",
                 "bound": "hbm",
@@ -585,9 +608,9 @@ def main() -> None:
             del db, pb
             torch.cuda.empty_cache()
             line["configs"] = {}
-            for key, cfg, eb, ls, steps, sample, lam in EXTRA_RUNS:
+            for key, cfg, eb, ls, steps, sample, lam, *rest in EXTRA_RUNS:
                 try:
-                    line["configs"][key] = run_extra(key, cfg, eb, ls, steps, sample, local_rank, args.iterations, args.check_instances, not args.no_cpu_baseline, lam)
+                    line["configs"][key] = run_extra(key, cfg, eb, ls, steps, sample, local_rank, args.iterations, args.check_instances, not args.no_cpu_baseline, lam, *rest)
                 except Exception as ex:  # a failing side configuration must not lose the headline line
                     line["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(line), flush=True)

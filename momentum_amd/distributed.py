@@ -53,6 +53,15 @@ def reduce_norms(dist, norms: torch.Tensor) -> torch.Tensor:
     return norms
 
 
+def reduce_min_max(dist, value: float, device) -> Tuple[float, float]:
+    """(min, max) over ranks of a host scalar (the per-rank rates the bench reports next to the aggregate)."""
+    if dist is None:
+        return float(value), float(value)
+    t = torch.tensor([value, -value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t[0].item()), float(-t[1].item())
+
+
 def reduce_max(dist, value: float, device) -> float:
     """Max over ranks of a host scalar (the timed region of the bench)."""
     if dist is None:

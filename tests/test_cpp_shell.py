@@ -111,6 +111,35 @@ def test_cpp_real_rig_skeleton_state_and_solve_on_gpu():
     assert out.stdout.strip().endswith("OK"), out.stdout
 
 
+ADAPTER_EXE = os.path.join(ROOT, "integration", "adapter_check")
+
+
+def _compile_adapter():
+    """integration/tensor_ik_mmx_adapter.cpp (the binding a momentum maintainer adds next to
+    solveTensorIKProblem) against a stub of the reference types it touches: a drift of include/mmx.h breaks this build."""
+    mbuild.build()
+    libdir = os.path.join(ROOT, "momentum_amd")
+    idir = os.path.join(ROOT, "integration")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", idir,
+                           os.path.join(idir, "tensor_ik_mmx_adapter.cpp"), os.path.join(idir, "adapter_check.cpp"), "-L", libdir, "-lmmx_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", ADAPTER_EXE])  # fmt: skip
+
+
+def test_reference_side_adapter_compiles_and_converts_a_character():
+    _compile_adapter()
+    out = subprocess.run([ADAPTER_EXE], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK"), out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_side_adapter_solves_on_gpu():
+    _compile_adapter()
+    out = subprocess.run([ADAPTER_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "four elements on their targets" in out.stdout and out.stdout.strip().endswith("OK"), out.stdout
+
+
 STUB_SRC = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu_stub.cpp")
 STUB_EXE = os.path.join(ROOT, "tests", "cpp", "test_multi_gpu_stub")
 
