@@ -1132,6 +1132,10 @@ int32_t mmx_rig_create(const mmx_rig_desc* d, int32_t device, mmx_rig** out) {
   dv.ptInner = r->dPtInner.as<int32_t>();
   dv.ptValue = r->dPtValue.as<float>();
   dv.ptOffsets = r->dPtOffsets.as<float>();
+  dv.ptOffsetsNonZero = 0;
+  for (float v : r->ptOffsets) {
+    dv.ptOffsetsNonZero |= v != 0.f ? 1 : 0;
+  }
   dv.levelOrder = r->dLevelOrder.as<int32_t>();
   dv.levelStart = r->dLevelStart.as<int32_t>();
   *out = r;

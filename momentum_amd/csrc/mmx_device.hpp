@@ -138,6 +138,7 @@ struct RigDev {
   const int32_t* ptInner; // [nnz]
   const float* ptValue; // [nnz]
   const float* ptOffsets; // [R]
+  int32_t ptOffsetsNonZero; // 0: every entry of ptOffsets is zero (the usual case: the solve kernels then skip the load)
   const int32_t* levelOrder; // [J]
   const int32_t* levelStart; // [numLevels+1]
   // two (parameter index, value bits) pairs per joint-parameter row, index -1 = unused slot; null

@@ -88,6 +88,7 @@ struct RigView {
   const int32_t* ptInner;
   const float* ptValue;
   const float* ptOffsets; // "
+  bool hasOffsets; // some entry of ptOffsets is non-zero (RigDev::ptOffsetsNonZero)
   const int32_t* levelOrder;
   const int32_t* levelStart;
 };
@@ -305,10 +306,10 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   // whenever FK runs.
   if (kGlobalTables) {
     csrRowsPrefetched<kT>(
-        rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + rig.ptOffsets[r]; });
+        rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
   } else {
     for (int r = tid; r < rig.R; r += kT) {
-      const float off = rig.ptOffsets[r];
+      const float off = rig.hasOffsets ? rig.ptOffsets[r] : 0.f; // (a global load on the phase's critical path when it is taken)
       float acc = 0.f;
       const int k1 = rig.ptOuter[r + 1];
       for (int k = rig.ptOuter[r]; k < k1; ++k) {
@@ -782,14 +783,39 @@ __device__ __forceinline__ int buildInstanceUnitTables(
 // instead of 36 spilled vector registers, 352 / 380 instead of 456 spilled scalar registers).  (2 = a line search only:
 // compiles, but spills MORE than the generic instantiation -- 68 vector registers -- and is not instantiated.)
 // Round 3, one box: plain Gauss-Newton +2.1 %, LM schedule +2.5 % over the generic instantiation; parity unchanged.
+// Experiment (MMX_BUILD_VARIANT=argptr; round-3 verdict item 2a): the five descriptor structs in ONE device-resident struct
+// behind a single pointer, every field an s_load at its use, instead of ~200 SGPRs of kernel arguments that the register
+// allocator keeps in VGPR lanes (384 spilled SGPRs: v_writelane / v_readlane + s_nop).  Shared rig and weights only (the
+// per-element selections write into the by-value copies).  Measured: profiles/r04_exp_argptr.txt.
+struct FusedArgs {
+  RigDev rig;
+  ProblemDev pb;
+  FusedDev fd;
+  SolveStateDev st;
+  FusedParams fp;
+};
+#ifdef MMX_EXP_ARGPTR
+static __global__ void stashFusedArgsKernel(FusedArgs a, FusedArgs* dst) {
+  *dst = a;
+}
+#endif
 template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
+#ifdef MMX_EXP_OCC4
+__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 4 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
+#else
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
+#endif
+#ifdef MMX_EXP_ARGPTR
+    const FusedArgs* __restrict__ argsDev,
+    float* __restrict__ theta, // [B][P] in/out
+#else
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
     float* __restrict__ theta, // [B][P] in/out
     SolveStateDev st,
     FusedParams fp,
+#endif
     float* __restrict__ dbgH, // [B][n*n] or null: H = J^T J (no lambda) of the FIRST iteration
     float* __restrict__ dbgG, // [B][n] or null
     long long* __restrict__ dbgClk) { // [32] or null: per-phase cycle counts of block 0 (profiling aid)
@@ -808,8 +834,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+#ifdef MMX_EXP_ARGPTR
+#define rig (argsDev->rig)
+#define pb (argsDev->pb)
+#define fd (argsDev->fd)
+#define st (argsDev->st)
+#define fp (argsDev->fp)
+#else
   selectInstanceRig(rig, b);
   selectInstanceWeights(pb, b);
+#endif
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int kR = rig.R, kNnz = fd.nnz, kLevels = rig.numLevels;
 
@@ -971,6 +1005,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   rv.J = J, rv.P = P, rv.R = kR, rv.numLevels = kLevels, rv.jumpRounds = rig.jumpRounds;
   rv.parent = lParent, rv.preRot = rig.preRot, rv.offset = rig.offset;
   rv.ptOuter = lPtOuter, rv.ptInner = lPtInner, rv.ptValue = lPtValue, rv.ptOffsets = rig.ptOffsets;
+  rv.hasOffsets = rig.ptOffsetsNonZero != 0;
   rv.levelOrder = lLevelOrder, rv.levelStart = lLevelStart;
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp;
@@ -2009,6 +2044,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     st.finalError[b] = curError;
     st.status[b] = bad ? 1 : s.flags[2];
   }
+#ifdef MMX_EXP_ARGPTR
+#undef rig
+#undef pb
+#undef fd
+#undef st
+#undef fp
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2170,6 +2212,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
   rv.J = J, rv.P = P, rv.R = rig.R, rv.numLevels = rig.numLevels, rv.jumpRounds = rig.jumpRounds;
   rv.parent = rig.parent, rv.preRot = rig.preRot, rv.offset = rig.offset;
   rv.ptOuter = rig.ptOuter, rv.ptInner = rig.ptInner, rv.ptValue = rig.ptValue, rv.ptOffsets = rig.ptOffsets;
+  rv.hasOffsets = rig.ptOffsetsNonZero != 0;
   rv.levelOrder = rig.levelOrder, rv.levelStart = rig.levelStart;
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp, fv.subSize = t.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = t.loadedPos, fv.numLoaded = fd.numLoaded;
@@ -2904,7 +2947,19 @@ static hipError_t launchFusedMode(
       return rc;
     }
   }
+#ifdef MMX_EXP_ARGPTR
+  static FusedArgs* argsDev = nullptr; // (experiment: one problem at a time)
+  if (argsDev == nullptr) {
+    hipError_t rc = hipMalloc(&argsDev, sizeof(FusedArgs));
+    if (rc != hipSuccess) {
+      return rc;
+    }
+  }
+  hipLaunchKernelGGL(stashFusedArgsKernel, dim3(1), dim3(1), 0, stream, FusedArgs{rig, pb, fd, st, fp}, argsDev);
+  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule>), dim3(pb.B), dim3(256), lds, stream, argsDev, theta, dbgH, dbgG, dbgClk);
+#else
   hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+#endif
   return hipGetLastError();
 }
 

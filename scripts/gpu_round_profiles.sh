@@ -2,7 +2,7 @@
 # end-of-round evidence: full GPU suite, the default bench line, kernel traces and PMC passes of the headline (cfg2) and
 # of the wide solve (cfg5).  usage: bash scripts/gpu_round_profiles.sh r02   -> gpurun_out/round_r02/
 cd "$GRAFT_REPO_ROOT" || exit 1
-r=${1:-r02}
+r=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/round_$r
 mkdir -p $out
 export TMPDIR=/tmp
