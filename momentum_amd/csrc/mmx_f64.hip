@@ -24,6 +24,13 @@ namespace mmx {
 
 namespace {
 
+// Every working array of these kernels lives in LDS; the pointers say so in their TYPE (address space 3), so that each access
+// is a ds_read / ds_write wherever it sits -- in a helper that was not inlined, behind a struct that went to scratch.  (Round 4:
+// with generic pointers the resident kernel had 422 flat loads for 306 LDS reads; a flat access takes the long way through
+// the vector memory path and counts on both wait counters.)
+typedef __attribute__((address_space(3))) double ldsd;
+typedef __attribute__((address_space(3))) int ldsi;
+
 struct D3 {
   double x, y, z;
 };
@@ -117,26 +124,26 @@ __device__ __forceinline__ double dlossDeriv(const LossDev& l, double s) {
 constexpr int kDs = 17; // doubles per joint: world t(3) q(4) s(1) | rotation axes x, y, z (9)
 
 struct F64Lds {
-  double* th; // [P]
-  double* trial; // [P]
-  double* jp; // [7 J]
-  double* js; // [kDs J]
-  double* uv; // [3 U] unit world vector
-  double* ur; // [M] scaled residual rows: 3 U of the position / orientation blocks, then the further joint error functions'
-  double* us; // [U] derivScale
-  int* utin; // [U]
-  double* g; // [n]
-  double* d; // [n]
-  double* red; // [8]
-  int* flags; // [4]
-  int* colOf; // [P] solve column of a model parameter, or -1
-  double* jl; // [n][rc + 1] a chunk of J's rows, column-major (normal equations)
-  double* gev; // [G][kGevD] the further joint error functions' evaluations (JointEvalD, rows scaled by sigma)
+  ldsd* th; // [P]
+  ldsd* trial; // [P]
+  ldsd* jp; // [7 J]
+  ldsd* js; // [kDs J]
+  ldsd* uv; // [3 U] unit world vector
+  ldsd* ur; // [M] scaled residual rows: 3 U of the position / orientation blocks, then the further joint error functions'
+  ldsd* us; // [U] derivScale
+  ldsi* utin; // [U]
+  ldsd* g; // [n]
+  ldsd* d; // [n]
+  ldsd* red; // [8]
+  ldsi* flags; // [4]
+  ldsi* colOf; // [P] solve column of a model parameter, or -1
+  ldsd* jl; // [n][rc + 1] a chunk of J's rows, column-major (normal equations)
+  ldsd* gev; // [G][kGevD] the further joint error functions' evaluations (JointEvalD, rows scaled by sigma)
   // ---- the resident instantiation (kRes): the system never leaves LDS
-  double* H; // [n (n + 1) / 2] lower triangle of H, then of its factor, packed by columns (hpos)
-  double* invd; // [n] 1 / L(k,k)
-  double* w1; // [n] work vectors of the substitutions
-  double* w2; // [n]
+  ldsd* H; // [n (n + 1) / 2] lower triangle of H, then of its factor, packed by columns (hpos)
+  ldsd* invd; // [n] 1 / L(k,k)
+  ldsd* w1; // [n] work vectors of the substitutions
+  ldsd* w2; // [n]
 };
 
 // position of H(i, j), i >= j, in the packed lower triangle (column j holds rows j .. n-1)
@@ -147,7 +154,7 @@ __device__ __forceinline__ int hpos(int n, int i, int j) {
 // ParameterTransformT<double>::apply + SkeletonStateT<double>::set (parameter_transform.cpp:110-124,
 // skeleton_state.cpp:87-121, joint_state.cpp:22-65): joint parameters one transform row per thread, then one
 // tree level per barrier (parents before children), then the rotation axes of all joints at once.
-__device__ void fkF64(const RigDev& rig, const F64Lds& s, const double* th, int tid, bool withAxes) {
+__device__ void fkF64(const RigDev& rig, const F64Lds& s, const ldsd* th, int tid, bool withAxes) {
   for (int r = tid; r < rig.R; r += 256) {
     double acc = 0.0;
     const int k1 = rig.ptOuter[r + 1];
@@ -161,7 +168,7 @@ __device__ void fkF64(const RigDev& rig, const F64Lds& s, const double* th, int 
   // the arithmetic: inside the level sweep every tree level paid for them in turn): local (t, q, s) into the joint's
   // world slot, the partial rotations pre * Rz, pre * Rz * Ry into the slots of the y / x axes (8 ..15)
   for (int j = tid; j < rig.J; j += 256) {
-    const double* p = s.jp + 7 * j;
+    const ldsd* p = s.jp + 7 * j;
     const float* pre = rig.preRot + 4 * j;
     const float* off = rig.offset + 3 * j;
     double sx, cx, sy, cy, sz, cz;
@@ -172,7 +179,7 @@ __device__ void fkF64(const RigDev& rig, const F64Lds& s, const double* th, int 
     const DQ q1 = dqmul(q0, DQ{0.0, 0.0, sz, cz});
     const DQ q2 = dqmul(q1, DQ{0.0, sy, 0.0, cy});
     const DQ ql = dqmul(q2, DQ{sx, 0.0, 0.0, cx});
-    double* o = s.js + kDs * j;
+    ldsd* o = s.js + kDs * j;
     o[0] = double(off[0]) + p[0], o[1] = double(off[1]) + p[1], o[2] = double(off[2]) + p[2];
     o[3] = ql.x, o[4] = ql.y, o[5] = ql.z, o[6] = ql.w, o[7] = exp2(p[6]);
     o[8] = q1.x, o[9] = q1.y, o[10] = q1.z, o[11] = q1.w, o[12] = q2.x, o[13] = q2.y, o[14] = q2.z, o[15] = q2.w;
@@ -183,13 +190,13 @@ __device__ void fkF64(const RigDev& rig, const F64Lds& s, const double* th, int 
     for (int i = rig.levelStart[lvl] + tid; i < i1; i += 256) {
       const int j = rig.levelOrder[i];
       const float* pre = rig.preRot + 4 * j;
-      double* o = s.js + kDs * j;
+      ldsd* o = s.js + kDs * j;
       const DQ q0{double(pre[0]), double(pre[1]), double(pre[2]), double(pre[3])};
       const DQ q1{o[8], o[9], o[10], o[11]}, q2{o[12], o[13], o[14], o[15]};
       DQ qp{0.0, 0.0, 0.0, 1.0};
       const int par = rig.parent[j];
       if (par >= 0) {
-        const double* w = s.js + kDs * par;
+        const ldsd* w = s.js + kDs * par;
         const D3 tp{w[0], w[1], w[2]};
         qp = DQ{w[3], w[4], w[5], w[6]};
         const D3 t = tp + dqrot(qp, w[7] * D3{o[0], o[1], o[2]}); // transform.h:124-129
@@ -212,7 +219,7 @@ __device__ void fkF64(const RigDev& rig, const F64Lds& s, const double* th, int 
 // for unit u of instance b; returns the unit's share of the error (w * loss(|f|^2), once per constraint).
 __device__ double evalUnitF64(const ProblemDev& pb, const F64Lds& s, int b, int u, bool store) {
   const UnitInput in = loadUnitInput(pb, b, u);
-  const double* w = s.js + kDs * in.joint;
+  const ldsd* w = s.js + kDs * in.joint;
   const D3 t{w[0], w[1], w[2]};
   const DQ q{w[3], w[4], w[5], w[6]};
   const bool isPoint = u < pb.Kp;
@@ -272,12 +279,12 @@ __device__ double blockSumF64(const F64Lds& s, double v, int tid) {
 // (model_parameters_error_function.cpp:44-131).  kJacobianRows: the value getJacobian returns (model rows with weight
 // <= 0 are skipped, :113), else the one getError returns (:54-58).
 template <bool kJacobianRows>
-__device__ double paramRowsErrorF64(const RigDev& rig, const ProblemDev& pb, const double* th, int b, int tid) {
+__device__ double paramRowsErrorF64(const RigDev& rig, const ProblemDev& pb, const ldsd* th, int b, int tid) {
   double e = 0.0;
   if (pb.NL > 0 && pb.wLimit > 0.f) {
     const double tWeight = double(1e+1f * pb.wLimit); // kLimitWeight * weight_ (a float product in both instantiations)
     for (int l = tid; l < pb.NL; l += 256) {
-      e += evalLimit<double>(rig, pb.limits[l], th, pb.enabledMask, tWeight).err;
+      e += evalLimit<double>(rig, pb.limits[l], (const double*)th, pb.enabledMask, tWeight).err; // (cold path: generic pointer)
     }
   }
   if (pb.hasModel && pb.wModel > 0.f) {
@@ -317,7 +324,7 @@ __device__ __forceinline__ D3 dnormalizedOrSame(D3 a) { // Eigen normalized(): u
   return n2 > 0.0 ? (1.0 / sqrt(n2)) * a : a;
 }
 
-__device__ JointEvalD evalJointConstraintF64(const JointBlockDev& k, const double* js, int joint, size_t c) {
+__device__ JointEvalD evalJointConstraintF64(const JointBlockDev& k, const ldsd* js, int joint, size_t c) {
   JointEvalD o;
   o.vp = o.vn = D3{0.0, 0.0, 0.0};
   for (int i = 0; i < 9; ++i) {
@@ -328,7 +335,7 @@ __device__ JointEvalD evalJointConstraintF64(const JointBlockDev& k, const doubl
   o.nrows = jointBlockFuncDim(k.type);
   o.hasPoint = k.type != MMX_JC_FIXED_AXIS_DIFF && k.type != MMX_JC_FIXED_AXIS_COS && k.type != MMX_JC_FIXED_AXIS_ANGLE;
   o.hasDir = k.type != MMX_JC_PLANE && k.type != MMX_JC_HALF_PLANE;
-  const double* w = js + kDs * joint;
+  const ldsd* w = js + kDs * joint;
   const D3 t{w[0], w[1], w[2]};
   const DQ q{w[3], w[4], w[5], w[6]};
   const double sc = w[7];
@@ -432,9 +439,9 @@ struct EllipsoidEvalD {
   D3 position, diff;
   double jwgt, werr;
 };
-__device__ EllipsoidEvalD evalEllipsoidF64(const EllipsoidDev& ct, const double* js, float wLimit) {
-  const double* wp = js + kDs * ct.parent;
-  const double* we = js + kDs * ct.ellipsoidParent;
+__device__ EllipsoidEvalD evalEllipsoidF64(const EllipsoidDev& ct, const ldsd* js, float wLimit) {
+  const ldsd* wp = js + kDs * ct.parent;
+  const ldsd* we = js + kDs * ct.ellipsoidParent;
   const D3 te{we[0], we[1], we[2]};
   const DQ qe{we[3], we[4], we[5], we[6]};
   auto affine = [](const float* a, D3 p) { // 3 x 4 row-major
@@ -471,7 +478,7 @@ __device__ double jointBlocksErrorF64(const ProblemDev& pb, const F64Lds& s, int
   return e;
 }
 
-__device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds& s, const double* th, int b, int tid) {
+__device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds& s, const ldsd* th, int b, int tid) {
   fkF64(rig, s, th, tid, false);
   double e = 0.0;
   for (int u = tid; u < pb.U; u += 256) {
@@ -483,11 +490,11 @@ __device__ double errorF64(const RigDev& rig, const ProblemDev& pb, const F64Lds
 }
 
 // d(unit vector) / d(joint parameter (joint, dof)) (joint_error_function-inl.h:248-291, joint_state.cpp:68-82)
-__device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, const double* js, D3 v, int utin, bool isPoint, bool& applies) {
+__device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, const ldsd* js, D3 v, int utin, bool isPoint, bool& applies) {
   const bool anc = c.tin <= utin && utin < c.tout;
-  const double* a = js + kDs * c.joint;
+  const ldsd* a = js + kDs * c.joint;
   if (c.dof >= 3 && c.dof < 6) {
-    const double* ax = a + 8 + 3 * (c.dof - 3);
+    const ldsd* ax = a + 8 + 3 * (c.dof - 3);
     applies = anc;
     return dcross(D3{ax[0], ax[1], ax[2]}, isPoint ? v - D3{a[0], a[1], a[2]} : v);
   }
@@ -496,7 +503,7 @@ __device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, cons
     if (c.parent < 0) {
       return D3{c.dof == 0 ? 1.0 : 0.0, c.dof == 1 ? 1.0 : 0.0, c.dof == 2 ? 1.0 : 0.0};
     }
-    const double* p = js + kDs * c.parent;
+    const ldsd* p = js + kDs * c.parent;
     return p[7] * dqmatCol(DQ{p[3], p[4], p[5], p[6]}, c.dof);
   }
   return 0.693147180559945309417232121458176568 * (v - D3{a[0], a[1], a[2]});
@@ -511,7 +518,7 @@ __device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, cons
 // 16x16x4 layout) -- and is added to the packed triangle once per chunk.  gfx950 issues the f64 matrix instruction at
 // the rate of the f32 one.
 typedef double v4d __attribute__((ext_vector_type(4)));
-__device__ __noinline__ void residentAccumulate(const double* jl, int ldj, const double* ur, int rows, double* g, double* H, int n, int tid) {
+__device__ __noinline__ void residentAccumulate(const ldsd* jl, int ldj, const ldsd* ur, int rows, ldsd* g, ldsd* H, int n, int tid) {
   for (int c = tid; c < n; c += 256) {
     double acc = g[c];
     for (int r = 0; r < rows; ++r) {
@@ -524,8 +531,8 @@ __device__ __noinline__ void residentAccumulate(const double* jl, int ldj, const
   int I = 0, Jc = 0;
   for (int t = 0; t < T; ++t) { // tiles in row-major order of the lower triangle, dealt to the waves round robin
     if ((t & 3) == wave) {
-      const double* pa = jl + (16 * I + i < n ? 16 * I + i : n - 1) * ldj + k;
-      const double* pb = jl + (16 * Jc + i < n ? 16 * Jc + i : n - 1) * ldj + k;
+      const ldsd* pa = jl + (16 * I + i < n ? 16 * I + i : n - 1) * ldj + k;
+      const ldsd* pb = jl + (16 * Jc + i < n ? 16 * Jc + i : n - 1) * ldj + k;
       v4d c = {0.0, 0.0, 0.0, 0.0};
       for (int s = 0; s < steps; ++s) {
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pb[4 * s], c, 0, 0, 0);
@@ -544,7 +551,7 @@ __device__ __noinline__ void residentAccumulate(const double* jl, int ldj, const
   }
 }
 // right-looking blocked Cholesky of the packed lower triangle, four columns per barrier pair; true when a pivot was not positive
-__device__ __noinline__ bool residentFactor(double* H, double* invd, int n, int tid) {
+__device__ __noinline__ bool residentFactor(ldsd* H, ldsd* invd, int n, int tid) {
       bool notPd = false;
       for (int k0 = 0; k0 < n; k0 += 4) {
         const int kb = n - k0 < 4 ? n - k0 : 4;
@@ -652,7 +659,7 @@ __device__ __noinline__ bool residentFactor(double* H, double* invd, int n, int 
       }
       return notPd;
 }
-__device__ __noinline__ void residentSolve(const double* H, const double* invd, double* w1, double* w2, const double* rhs, double* x, int n, int tid) {
+__device__ __noinline__ void residentSolve(const ldsd* H, const ldsd* invd, ldsd* w1, ldsd* w2, const ldsd* rhs, ldsd* x, int n, int tid) {
       for (int c = tid; c < n; c += 256) {
         w1[c] = rhs[c];
       }
@@ -748,18 +755,18 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
   const int J = rig.J, P = rig.P, U = pb.U, G = pb.G, M = pb.rowsJoint; // (rowsJoint = 3 U + rows of the further joint error functions + 3 NE)
   F64Lds s;
   {
-    double* p = dmem;
+    ldsd* p = (ldsd*)dmem;
     auto take = [&](size_t c) {
-      double* r = p;
+      ldsd* r = p;
       p += (c + 1) & ~size_t(1);
       return r;
     };
     s.th = take(P), s.trial = take(P), s.jp = take(7 * size_t(J)), s.js = take(size_t(kDs) * J);
     s.uv = take(3 * size_t(U)), s.ur = take(size_t(M)), s.us = take(U);
     s.g = take(n), s.d = take(n), s.red = take(8);
-    s.utin = reinterpret_cast<int*>(take((U + 1) / 2 + 1));
-    s.flags = reinterpret_cast<int*>(take(2));
-    s.colOf = reinterpret_cast<int*>(take((size_t(P) + 1) / 2));
+    s.utin = reinterpret_cast<ldsi*>(take((U + 1) / 2 + 1));
+    s.flags = reinterpret_cast<ldsi*>(take(2));
+    s.colOf = reinterpret_cast<ldsi*>(take((size_t(P) + 1) / 2));
     s.jl = take(size_t(n) * size_t(rc + 1));
     s.gev = take(size_t(kGevD) * size_t(G + pb.NE));
     s.H = s.invd = s.w1 = s.w2 = nullptr;
@@ -769,7 +776,13 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     }
   }
   // H(i, j), i >= j: the packed LDS triangle (kRes) or the column-major global scratch
-  auto Hat = [&](int i, int j) -> double& { return kRes ? s.H[hpos(n, i, j)] : Hg[size_t(b) * size_t(n) * size_t(n) + size_t(j) * n + i]; };
+  auto addToH = [&](int i, int j, double v) {
+    if (kRes) {
+      s.H[hpos(n, i, j)] += v;
+    } else {
+      Hg[size_t(b) * size_t(n) * size_t(n) + size_t(j) * n + i] += v;
+    }
+  };
   double* thg = theta + size_t(b) * P;
   double* Jb = Jg + size_t(b) * size_t(n) * size_t(M);
   double* Hb = Hg + size_t(b) * size_t(n) * size_t(n);
@@ -823,13 +836,13 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
         s.ur[row + q] = o.sigma * o.f[q];
       }
       const double sg = fabs(o.sigma) <= 1e-9 ? 0.0 : o.sigma; // early termination (joint_error_function-inl.h:216): the rows stay zero
-      double* w = s.gev + kGevD * g;
+      ldsd* w = s.gev + kGevD * g;
       w[0] = o.vp.x, w[1] = o.vp.y, w[2] = o.vp.z, w[3] = o.vn.x, w[4] = o.vn.y, w[5] = o.vn.z;
       for (int q = 0; q < 9; ++q) {
         w[6 + q] = sg * o.dp[q];
         w[15 + q] = sg * o.dn[q];
       }
-      int* wi = reinterpret_cast<int*>(w + 24);
+      ldsi* wi = reinterpret_cast<ldsi*>(w + 24);
       wi[0] = pb.genTin[g], wi[1] = row, wi[2] = o.nrows | (o.hasPoint ? 16 : 0) | (o.hasDir ? 32 : 0), wi[3] = -1;
     }
     for (int q = tid; q < pb.NE; q += 256) { // ellipsoid limits: a point constraint whose walk stops at ellipsoidParent
@@ -838,13 +851,13 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       const int row = pb.rowsJoint - 3 * pb.NE + 3 * q;
       e += o.werr;
       s.ur[row] = o.diff.x * o.jwgt, s.ur[row + 1] = o.diff.y * o.jwgt, s.ur[row + 2] = o.diff.z * o.jwgt;
-      double* w = s.gev + kGevD * (G + q);
+      ldsd* w = s.gev + kGevD * (G + q);
       w[0] = o.position.x, w[1] = o.position.y, w[2] = o.position.z, w[3] = w[4] = w[5] = 0.0;
       for (int k = 0; k < 9; ++k) {
         w[6 + k] = (k == 0 || k == 4 || k == 8) ? o.jwgt : 0.0;
         w[15 + k] = 0.0;
       }
-      int* wi = reinterpret_cast<int*>(w + 24);
+      ldsi* wi = reinterpret_cast<ldsi*>(w + 24);
       wi[0] = ct.tinParent, wi[1] = row, wi[2] = 3 | 16, wi[3] = ct.tinStop;
     }
     curError = blockSumF64(s, e, tid); // (not rounded: the value getJacobian returns)
@@ -888,7 +901,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
               acc.x += (s.us[u] * gq.x) * w, acc.y += (s.us[u] * gq.y) * w, acc.z += (s.us[u] * gq.z) * w;
             }
           }
-          double* o = s.jl + c * ldj + 3 * (u - u0);
+          ldsd* o = s.jl + c * ldj + 3 * (u - u0);
           o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
         for (int idx = tid; idx < n * ((4 - (3 * nu) % 4) % 4); idx += 256) { // rows up to a multiple of four: zeros (the matrix cores take four at a time)
@@ -901,10 +914,10 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       // the further joint error functions / ellipsoid limits: consecutive constraints while their rows fit a chunk
       const int GT = G + pb.NE;
       for (int g0 = 0; g0 < GT;) {
-        const int rowFirst = reinterpret_cast<const int*>(s.gev + kGevD * g0 + 24)[1];
+        const int rowFirst = reinterpret_cast<const ldsi*>(s.gev + kGevD * g0 + 24)[1];
         int g1 = g0, rowEnd = rowFirst;
         while (g1 < GT) {
-          const int* wi = reinterpret_cast<const int*>(s.gev + kGevD * g1 + 24);
+          const ldsi* wi = reinterpret_cast<const ldsi*>(s.gev + kGevD * g1 + 24);
           if (wi[1] + (wi[2] & 15) - rowFirst > rc) {
             break;
           }
@@ -916,8 +929,8 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
         for (int item = tid; item < n * ng; item += 256) {
           const int c = item / ng, g = g0 + (item - c * ng);
           const int p = solveList[c];
-          const double* w = s.gev + kGevD * g;
-          const int* wi = reinterpret_cast<const int*>(w + 24);
+          const ldsd* w = s.gev + kGevD * g;
+          const ldsi* wi = reinterpret_cast<const ldsi*>(w + 24);
           const int tin = wi[0], row = wi[1], nrows = wi[2] & 15, tinStop = wi[3];
           const bool hasPoint = (wi[2] & 16) != 0, hasDir = (wi[2] & 32) != 0;
           const D3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
@@ -952,7 +965,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
               acc[q] += jc * wt;
             }
           }
-          double* o = s.jl + c * ldj + (row - rowFirst);
+          ldsd* o = s.jl + c * ldj + (row - rowFirst);
           for (int q = 0; q < nrows; ++q) {
             o[q] = acc[q];
           }
@@ -989,8 +1002,8 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     for (int item = tid; item < n * GT; item += 256) { // rows of the further joint error functions / ellipsoid limits (jointBlocksKernel in double)
       const int c = item / GT, g = item - c * GT;
       const int p = solveList[c];
-      const double* w = s.gev + kGevD * g;
-      const int* wi = reinterpret_cast<const int*>(w + 24);
+      const ldsd* w = s.gev + kGevD * g;
+      const ldsi* wi = reinterpret_cast<const ldsi*>(w + 24);
       const int tin = wi[0], row = wi[1], nrows = wi[2] & 15, tinStop = wi[3];
       const bool hasPoint = (wi[2] & 16) != 0, hasDir = (wi[2] & 32) != 0;
       const D3 vp{w[0], w[1], w[2]}, vn{w[3], w[4], w[5]};
@@ -1066,8 +1079,8 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
           }
           const int bj = q - bi * (bi + 1) / 2;
           double acc[4][4] = {};
-          const double* ci[4];
-          const double* cj[4];
+          const ldsd* ci[4];
+          const ldsd* cj[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { // (columns beyond n read column n - 1: their entries are never stored)
             ci[k] = s.jl + (4 * bi + k < n ? 4 * bi + k : n - 1) * ldj;
@@ -1122,7 +1135,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       if (tid == 0 && pb.NL > 0 && pb.wLimit > 0.f) {
         const double tWeight = double(1e+1f * pb.wLimit);
         for (int l = 0; l < pb.NL; ++l) {
-          const LimitRowT<double> row = evalLimit<double>(rig, pb.limits[l], s.th, pb.enabledMask, tWeight);
+          const LimitRowT<double> row = evalLimit<double>(rig, pb.limits[l], (const double*)s.th, pb.enabledMask, tWeight);
           for (int x = 0; x < kLimitEntries; ++x) {
             const int cx = row.idx[x] >= 0 ? s.colOf[row.idx[x]] : -1;
             if (cx < 0) {
@@ -1135,7 +1148,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
                 continue;
               }
               const int hi = cx > cy ? cx : cy, lo = cx > cy ? cy : cx;
-              Hat(hi, lo) += row.coef[x] * row.coef[y]; // (a row's parameters are distinct: limitScatterRow merges)
+              addToH(hi, lo, row.coef[x] * row.coef[y]); // (a row's parameters are distinct: limitScatterRow merges)
             }
           }
         }
@@ -1151,7 +1164,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
           const double w = double(tw[p]);
           if (pb.enabledMask[p] != 0 && w > 0.0) {
             const double jw = sW * w, r = (w * (s.th[p] - double(tp[p]))) * sW;
-            Hat(c, c) += jw * jw;
+            addToH(c, c, jw * jw);
             s.g[c] += jw * r;
           }
         }
@@ -1166,7 +1179,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     auto factorRes = [&]() { notPd = residentFactor(s.H, s.invd, n, tid); };
     // x = (L L^T)^-1 rhs by blocked substitutions: every thread solves the four unknowns of a block for itself, the
     // thread of a later row takes them out of its right-hand side; one barrier per block (x and rhs may be the same array)
-    auto solveRes = [&](const double* rhs, double* x) { residentSolve(s.H, s.invd, s.w1, s.w2, rhs, x, n, tid); };
+    auto solveRes = [&](const ldsd* rhs, ldsd* x) { residentSolve(s.H, s.invd, s.w1, s.w2, rhs, x, n, tid); };
     auto factorScratch = [&]() {
     notPd = false;
     for (int k = 0; k < n; ++k) {
@@ -1200,7 +1213,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     }
     };
     // ---- x = llt_.solve(rhs): wave 0, lanes over the already known entries (x and rhs may be the same array)
-    auto solveScratch = [&](const double* rhs, double* x) {
+    auto solveScratch = [&](const ldsd* rhs, ldsd* x) {
       for (int c = tid; c < n; c += 256) {
         x[c] = rhs[c];
       }
@@ -1242,7 +1255,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
         factorScratch();
       }
     };
-    auto solveLLt = [&](const double* rhs, double* x) {
+    auto solveLLt = [&](const ldsd* rhs, ldsd* x) {
       if (kRes) {
         solveRes(rhs, x);
       } else {
