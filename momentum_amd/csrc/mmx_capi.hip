@@ -1845,7 +1845,7 @@ int32_t mmx_eval_skeleton_state(mmx_problem* pb, const float* theta_dev, float* 
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
   MMX_HIP(mmx::launchFkJacobian(
-      pb->rigDev, pb->dev, theta_dev, nullptr, nullptr, nullptr, state_dev, nullptr, static_cast<hipStream_t>(stream)));
+      pb->rigDev, pb->dev, theta_dev, nullptr, nullptr, nullptr, state_dev, nullptr, static_cast<hipStream_t>(stream), nullptr, nullptr, true));
   return MMX_OK;
 }
 
@@ -2234,7 +2234,7 @@ static int32_t solveImpl(
       {
         MMX_ZONE("Get JtJ and JtR");
         MMX_HIP(mmx::launchFkJacobian(
-            pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s));
+            pb->rigDev, pb->dev, theta_dev, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sErr.as<double>(), nullptr, st.done, s, nullptr, nullptr, true));
         MMX_HIP(mmx::launchNormalEquations(
             ds, pb->rig->P, pb->sJac.as<float>(), pb->sRes.as<float>(), pb->sJtj.as<float>(), pb->sJtr.as<float>(), st.done, wide, s));
       }

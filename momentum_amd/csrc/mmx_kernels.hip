@@ -215,6 +215,12 @@ writeUnitColumns(const ProblemDev& pb, const float* js, const Unit& un, float* j
   }
 }
 
+// dynamic LDS of fkJacobianKernel in floats: joint slots | theta | packed parent table | evaluated units of the multi-chunk J path
+__host__ __device__ __forceinline__ size_t fkJacobianLdsFloats(int J, int P, int U) {
+  const size_t unitStash = U > 64 ? 5 * size_t(U) : 0;
+  return ((size_t(kJs) * size_t(J) + 3) & ~size_t(3)) + ((size_t(P) + 3) & ~size_t(3)) + ((size_t(J) + 3) & ~size_t(3)) + unitStash;
+}
+
 // WPI = wavefronts per instance: 1 (block = 64) for large batches, 4 (block = 256: FK over 256
 // threads, the column program dealt to the four waves) when the batch alone cannot fill the chip.
 template <bool kWriteJac, int WPI, bool kStream>
@@ -235,6 +241,10 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   float* thL = js + ((kJs * rig.J + 3) & ~3); // [P] theta of this instance
   int* jl = reinterpret_cast<int*>(thL + ((rig.P + 3) & ~3)); // [J] (parent + 1) << 16 | (jump target + 1)
   float* ul = reinterpret_cast<float*>(jl + ((rig.J + 3) & ~3)); // [U][5] evaluated units (v, sigma, tin), only when U > 64 and J is written
+  const bool fkDouble = (zeroPhase & 0x100) != 0; // the jump rounds in double: two channel-major buffers behind the unit stash
+  zeroPhase &= 0xff;
+  double* fkA = reinterpret_cast<double*>(smem + ((fkJacobianLdsFloats(rig.J, rig.P, pb.U) + 1) & ~size_t(1)));
+  double* fkB = fkA + fkBufFloats(rig.J) / 2;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   selectInstanceRig(rig, b);
@@ -348,7 +358,17 @@ __global__ void __launch_bounds__(64 * WPI) fkJacobianKernel(
   // target that was already advanced in the same round: (T_a, a_a) are always read as a
   // consistent pair, which keeps the invariant "T_j = product of the locals on the path
   // (a_j, j]" -- within one wave by program order, across waves by the two barriers.
-  for (int r = 0; r < rig.jumpRounds; ++r) {
+  if (fkDouble) { // (the locals are in js[0..7]; the result comes back there)
+    const int Jp = fkPad(rig.J);
+    if (rig.jumpRounds > 0) {
+      for (int j = tid; j < rig.J; j += NT) {
+        fkStoreLocalD(fkA, Jp, j, js + kJs * j, jl[j] >> 16);
+      }
+      __syncthreads();
+      fkJumpRoundsD(js, fkA, fkB, rig.J, rig.jumpRounds, tid, NT);
+    }
+  }
+  for (int r = 0; r < (fkDouble ? 0 : rig.jumpRounds); ++r) {
     for (int j0 = 0; j0 < rig.J; j0 += NT) {
       const int j = j0 + tid;
       const int mine = j < rig.J ? jl[j] : 0;
@@ -3404,8 +3424,7 @@ hipError_t launchTransposeJacobian(const float* colMajor, float* rowMajor, int B
 }
 
 size_t fkJacobianLdsBytes(int J, int P, int U) {
-  const size_t unitStash = U > 64 ? 5 * size_t(U) : 0; // evaluated units of the multi-chunk J path
-  return (((size_t(kJs) * size_t(J) + 3) & ~size_t(3)) + ((size_t(P) + 3) & ~size_t(3)) + ((size_t(J) + 3) & ~size_t(3)) + unitStash) * sizeof(float);
+  return fkJacobianLdsFloats(J, P, U) * sizeof(float);
 }
 
 hipError_t launchFkJacobian(
@@ -3419,8 +3438,17 @@ hipError_t launchFkJacobian(
     const int32_t* done,
     hipStream_t stream,
     hipEvent_t startEvent,
-    hipEvent_t stopEvent) {
+    hipEvent_t stopEvent,
+    bool accurateFk) {
   size_t lds = fkJacobianLdsBytes(rig.J, rig.P, pb.U);
+  if (accurateFk) { // (rigs whose double buffers do not fit the default 64 KB of dynamic LDS keep the single-precision rounds)
+    const size_t ldsD = (((fkJacobianLdsFloats(rig.J, rig.P, pb.U) + 1) & ~size_t(1)) + 2 * fkBufFloats(rig.J)) * sizeof(float);
+    if (ldsD <= 64 * 1024) {
+      lds = ldsD;
+    } else {
+      accurateFk = false;
+    }
+  }
 #if defined(MMX_EXP_JACOCC4) || defined(MMX_EXP_JACOCC3) // A/B build variants: resident workgroups per CU forced through the LDS request
 #ifdef MMX_EXP_JACOCC4
   constexpr size_t kOcc = 4;
@@ -3443,7 +3471,7 @@ hipError_t launchFkJacobian(
   const int wpi = (pb.B < 2048 || lds > 12 * 1024 || (jac != nullptr && pb.B <= 40000)) ? 4 : 1;
   // non-temporal column stores throughout (measured better at every batch size once they were really emitted: see store3());
   // the structurally zero columns: one wave per instance alternates their position, several waves: those without joints write them first
-  const int zeroPhase = wpi == 1 ? 1 : 0;
+  const int zeroPhase = (wpi == 1 ? 1 : 0) | (accurateFk ? 0x100 : 0);
   // (A two-kernel form -- FK + units once per instance handed over through HBM, then four adjacent columns per short-lived
   // workgroup -- was built and measured in round 2: 95-150 us against 86 us for this one at B = 4096, because the L2s are
   // written back between the two kernels and every column workgroup's first loads miss.  Removed in round 3)

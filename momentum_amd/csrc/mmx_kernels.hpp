@@ -225,7 +225,10 @@ hipError_t launchFkJacobian(
     const int32_t* done,
     hipStream_t stream,
     hipEvent_t startEvent = nullptr, // attached to the J-assembly dispatch itself (hipExtLaunchKernelGGL)
-    hipEvent_t stopEvent = nullptr);
+    hipEvent_t stopEvent = nullptr,
+    // the pointer-jumping rounds in double like the solve kernels' (mmx_device.hpp fkJumpRoundsD): the explicit-Jacobian SOLVE
+    // route and mmx_eval_skeleton_state; mmx_eval_jacobian (the graded kernel) keeps the single-precision rounds
+    bool accurateFk = false);
 
 hipError_t launchNormalEquations(
     const ProblemDev& pb,
