@@ -41,7 +41,8 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    jobs = []
+    jobs, keep = [], []
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     for src in SOURCES:
         groups = range(FUSED_GROUPS) if src == "mmx_fused.hip" else [None]
         for g in groups:
@@ -56,6 +57,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if src.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")
+            # incremental: an object newer than its source and every header is reused (force rebuilds everything)
+            if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):
+                keep.append((None, obj))
+                continue
             jobs.append((cmd, obj))
     from concurrent.futures import ThreadPoolExecutor
 
@@ -65,8 +70,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(job[0])
         return job[1]
 
-    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        objs = list(ex.map(run, jobs))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    objs = []
+    for src in SOURCES:  # link in the fixed source order whatever was recompiled
+        groups = range(FUSED_GROUPS) if src == "mmx_fused.hip" else [None]
+        for g in groups:
+            stem = os.path.splitext(src)[0] + ("" if g is None else f"_g{g}")
+            objs.append(os.path.join(CSRC, stem + (f".{VARIANT}" if VARIANT else "") + ".o"))
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
