@@ -238,12 +238,20 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n, line_search_aware=False
         out["above_bound_float_oracle_rel"] = [float(x) for x in rel32[:16]]
         out["above_bound_float_oracle_also_above"] = bool(np.all(~(rel32 <= PARITY_BOUND)))
         out["above_bound_final_error_double"] = [float(x) for x in ref["error"][idx][:16]]
-        # ... and whether the double run itself was converging on them: an iteration that has reduced its error by less than
-        # 1e3 after all its steps (a Gauss-Newton run without line search from a start where the step overshoots) amplifies
-        # every last-bit difference, in the reference's own float instantiation first of all
-        h0 = ref["error_history"][idx, 0]
-        diverging = ~(ref["error"][idx] <= 1e-3 * h0)
+        # ... and whether the double run itself was converging on them.  Plain Gauss-Newton (no line search) from a start where
+        # the undamped step overshoots RAISES its error at some iteration, or ends with less than 1e3 of reduction: such a run
+        # amplifies every last-bit difference (the reference's own float instantiation ends 1e-3 ... 0.4 from its double one
+        # on them, above_bound_float_oracle_rel).  num_above_bound_on_converging_runs counts the instances above the bound
+        # whose double run decreased its error at every iteration and by 1e3 overall; above_bound_closer_than_float_oracle
+        # says that on every instance above the bound the GPU answer is nearer to the double one than the float oracle's is.
+        hist = np.concatenate([ref["error_history"][idx], ref["error"][idx][:, None]], axis=1)
+        h0 = hist[:, 0]
+        its = np.asarray(ref["iterations"])[idx].astype(int)
+        raised = np.array([bool(np.any(np.diff(hist[k, : its[k]]) > 0.0) or hist[k, -1] > hist[k, its[k] - 1]) for k in range(len(idx))])
+        diverging = raised | ~(ref["error"][idx] <= 1e-3 * h0)
         out["above_bound_initial_error_double"] = [float(x) for x in h0[:16]]
+        out["above_bound_double_run_raised_its_error"] = [bool(x) for x in raised[:16]]
+        out["above_bound_closer_than_float_oracle"] = bool(np.all(rel[idx] <= rel32))
         out["num_above_bound_on_converging_runs"] = int((~diverging).sum())
         out["pass_relaxed"] = bool(out["num_above_bound"] <= n // 100 and out["above_bound_float_oracle_also_above"])
         out["pass_relaxed_rule"] = ">= 99 % within the bound; every instance above it is above it in the oracle's float instantiation too"
