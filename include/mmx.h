@@ -589,7 +589,9 @@ int32_t mmx_solve_f64(
  * (error_history is iterationHistory_["error"], `iterations` iterationHistory_["iterations"]).  The "jtj"
  * history of GaussNewtonSolverT (gauss_newton_solver.cpp:265-278) is not stored -- n^2 floats per element and
  * iteration --; it is J^T J at the parameters BEFORE iteration i, which mmx_eval_normal_equations returns for
- * row i-1 of parameter_history (theta_init for i = 0).
+ * row i-1 of parameter_history (theta_init for i = 0); the host mirror rebuilds it that way on request
+ * (momentum_amd/capi.py Problem.jtj_history: lower triangle + regularization on the diagonal, like :249 leaves
+ * hessianApprox_).
  */
 int32_t mmx_solve_with_history(
     mmx_problem* problem,

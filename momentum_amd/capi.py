@@ -421,6 +421,31 @@ class Problem:
         _check(lib().mmx_eval_normal_equations(self._h, _dev(theta), _dev(jtj), _dev(jtr), _dev(err), _stream_ptr()))
         return jtj, jtr, err
 
+    def jtj_history(self, theta_init, parameter_history, iterations, regularization, out=None):
+        """GaussNewtonSolverT's iterationHistory_["jtj"] (gauss_newton_solver.cpp:262-279) for a finished solve: entry i of
+        element b is hessianApprox_ of its iteration i -- the lower triangle of J^T J over the enabled parameters at the
+        parameters BEFORE that iteration (theta_init for i = 0, row i - 1 of parameter_history after), with the
+        regularisation on the diagonal (:249 adds it in place before the factorisation; the strict upper triangle is
+        never written and stays zero).  Entries from an element's iteration count on are zero (the reference leaves them
+        unset).  Rebuilt with mmx_eval_normal_equations, one launch per iteration, instead of being stored by the solve:
+        n^2 floats per element and iteration ([B, K, n, n]; `out` to bring the storage)."""
+        import torch
+
+        theta_init = self._theta(theta_init)
+        K = int(parameter_history.shape[1])
+        assert tuple(parameter_history.shape) == (self.B, K, self.P) and parameter_history.is_cuda
+        if out is None:
+            out = torch.zeros((self.B, K, self.n, self.n), dtype=torch.float32, device=self.device)
+        assert tuple(out.shape) == (self.B, K, self.n, self.n) and out.dtype == torch.float32 and out.is_cuda
+        its = iterations.to(self.device).to(torch.int64)
+        eye = torch.eye(self.n, dtype=torch.float32, device=self.device) * float(regularization)
+        for i in range(K):
+            th = theta_init if i == 0 else parameter_history[:, i - 1].contiguous()
+            jtj, _, _ = self.normal_equations(th)
+            h = torch.tril(jtj) + eye
+            out[:, i] = torch.where((its > i)[:, None, None], h, torch.zeros_like(h))
+        return out
+
     def tree_normal_equations(self, theta):
         """Parity hook: (JtJ [B,n,n] lower triangle, Jtr [B,n]) from the tree moments (the wide route's first stage)."""
         import torch

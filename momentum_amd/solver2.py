@@ -482,6 +482,19 @@ class Solver:
         self.options = options if options is not None else GaussNewtonSolverOptions()
         self._enabled = None
         self._history = None
+        self._store_history = False
+        self._iteration_history = {}
+
+    def set_store_history(self, b: bool) -> None:
+        """SolverT::setStoreHistory (solver.h / solver.cpp:53-72)"""
+        self._store_history = bool(b)
+
+    def get_history(self):
+        """SolverT::getHistory: {"parameters" [B, K, P], "error" [B, K], "iterations" [B], and for the Gauss-Newton solver
+        "jtj" [B, K, n, n]} of the last solve (gauss_newton_solver.cpp:262-279: the damped lower triangle of every
+        iteration's normal equations); empty unless set_store_history(True) was called before it.  Numpy arrays, without
+        the batch axis for a single parameter vector."""
+        return self._iteration_history
 
     def set_enabled_parameters(self, active_parameters) -> None:
         a = np.asarray(active_parameters).astype(bool).reshape(-1)
@@ -502,9 +515,15 @@ class Solver:
         o = self.options
         opt = GnOptions.make(min_iterations=o.min_iterations, max_iterations=o.max_iterations, threshold=o.threshold,
                              regularization=getattr(o, "regularization", 0.05), do_line_search=self._line_search_rule if getattr(o, "do_line_search", False) else 0)  # fmt: skip
-        out = pb.solve(torch.from_numpy(mp.copy()).to(pb.device), opt, want_history=True)
+        t0 = torch.from_numpy(mp.copy()).to(pb.device)
+        out = pb.solve(t0.clone(), opt, want_history=True, want_parameter_history=self._store_history)
         it = out["iterations"].cpu().numpy()
         h = out["error_history"].cpu().numpy()
+        self._iteration_history = {}
+        if self._store_history:
+            jtj = pb.jtj_history(t0, out["parameter_history"], out["iterations"], opt.regularization)
+            full = {"parameters": out["parameter_history"].cpu().numpy(), "error": h, "iterations": it, "jtj": jtj.cpu().numpy()}
+            self._iteration_history = {k: (v[0] if single else v) for k, v in full.items()}
         hist = [[float(x) for x in h[b, : it[b]]] for b in range(mp.shape[0])]
         self._history = hist[0] if single else hist
         th = out["theta"].cpu().numpy()

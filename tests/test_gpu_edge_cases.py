@@ -288,3 +288,37 @@ def test_parameter_history_matches_the_iterates(torch_cuda, orc, solver, monkeyp
     assert np.array_equal(iters, ref["iterations"])
     rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
     assert rel.max() <= 5e-5
+
+
+def test_jtj_history_is_the_damped_lower_triangle_of_every_iteration(torch_cuda, orc):
+    """GaussNewtonSolverT's iterationHistory_["jtj"] (gauss_newton_solver.cpp:262-279): block i of the history is
+    hessianApprox_ of iteration i -- the lower triangle of J^T J over the enabled parameters with the regularisation already on
+    its diagonal (:249 adds it in place), the upper triangle never written.  Problem.jtj_history rebuilds it from the
+    parameter history (mmx_eval_normal_equations at the parameters each iteration started from); checked against the
+    oracle's compacted system of solves truncated at i + 1 iterations, enabled subset, an element that stops early."""
+    torch = torch_cuda
+    rig = make_test_character(8)
+    B, lam = 4, 0.05
+    cons, th0, _ = make_problem(rig, [7, 3], [6], B, seed=5, theta0_scale=0.2)
+    enabled = np.ones(rig.num_params, np.uint8)
+    enabled[[1, 4]] = 0
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    pb.set_enabled(enabled)
+    _upload(torch, pb, cons, B)
+    opt = GnOptions.make(min_iterations=2, max_iterations=6, threshold=1e9, regularization=lam)
+    t0 = torch.from_numpy(th0.copy()).to(pb.device)
+    out = pb.solve(t0.clone(), opt, want_history=True, want_parameter_history=True)
+    iters = out["iterations"].cpu().numpy()
+    H = pb.jtj_history(t0, out["parameter_history"], out["iterations"], lam).cpu().numpy()
+    n = int(enabled.sum())
+    assert H.shape == (B, 6, n, n) and iters.min() < 6
+    for b in range(B):
+        assert np.all(H[b, iters[b] :] == 0)
+        sub = cons.subset(np.array([b]))
+        for i in range(iters[b]):
+            o2 = GnOptions.make(min_iterations=i + 1, max_iterations=i + 1, threshold=1e9, regularization=lam)
+            ref = orc.solve(rig, sub, th0[b], o2, enabled=enabled, dtype="f64")["jtj"]
+            want = np.tril(ref) + lam * np.eye(n)
+            assert np.all(np.triu(H[b, i], 1) == 0)
+            assert np.abs(H[b, i] - want).max() <= 2e-5 * np.abs(want).max(), (b, i)

@@ -75,6 +75,19 @@ def test_ik_basic_like_the_reference_python_test():
     assert J.shape == (3 * n_joints, n_params) and r.shape == (3 * n_joints,)
     assert np.isclose(r @ r, solver_function.get_error(model_params_init), rtol=1e-5)
     assert np.allclose(solver_function.get_gradient(model_params_init), 2 * J.T @ r)
+    # SolverT::setStoreHistory / getHistory (solver.cpp:53-72; "jtj": gauss_newton_solver.cpp:262-279): the first block
+    # of the jtj history is the damped lower triangle of J^T J at the initial parameters
+    assert solver.get_history() == {}
+    solver_options.max_iterations = 5
+    solver = pym_solver2.GaussNewtonSolver(solver_function, solver_options)
+    solver.set_store_history(True)
+    final = solver.solve(model_params_init)
+    hist = solver.get_history()
+    its = int(hist["iterations"])
+    assert hist["parameters"].shape == (5, n_params) and hist["jtj"].shape == (5, n_params, n_params) and 1 <= its <= 5
+    assert np.array_equal(hist["parameters"][its - 1], final)
+    want = np.tril(J.T @ J) + 1e-5 * np.eye(n_params)
+    assert np.allclose(hist["jtj"][0], want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
 @pytest.mark.gpu
