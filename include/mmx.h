@@ -418,8 +418,10 @@ int32_t mmx_problem_set_instance_parents(
  *                                structurally non-zero 16 x 16 tiles (columns in elimination order) -- the factor resident
  *                                in LDS while its tiles fit half a CU (<= ~75 tiles), in HBM beyond --, refinement through
  *                                the tree (<= 512 solved parameters; the default from 129 on)
- *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores) -> Cholesky step; the route for problems
- *                                outside the tree kernels' scope
+ *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores; VALU beyond 384 columns) -> Cholesky step; the route
+ *                                for problems outside the tree kernels' scope, among them systems of 513 ... 1536 solved
+ *                                parameters (more: MMX_ERR_UNSUPPORTED; the reference's kMaxModelParams is 2048,
+ *                                momentum/math/types.h:426-429)
  * The route does not change WHAT is computed (same algorithm, same refinement); results of different routes agree to
  * rounding (tests/test_gpu_weak_damping.py, tests/test_gpu_fuzz.py).
  */

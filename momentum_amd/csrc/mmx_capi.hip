@@ -1878,8 +1878,8 @@ int32_t mmx_eval_normal_equations(
   if (theta_dev == nullptr || jtj_dev == nullptr || jtr_dev == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "theta / jtj / jtr is null");
   }
-  if (pb->dev.n > 512) {
-    return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
+  if (pb->dev.n > mmx::kMaxSolved) {
+    return fail(MMX_ERR_UNSUPPORTED, "more than 1536 enabled parameters");
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2073,8 +2073,8 @@ static int32_t solveImpl(
   if (trust && !(preferWide && treeNormalEquationsUsable(pb) && route != MMX_ROUTE_EXPLICIT_JACOBIAN)) {
     return fail(MMX_ERR_UNSUPPORTED, "MMX_STEP_TRUST_REGION: available in the one-launch solve and on the wide route (tree kernels); this problem takes neither (MMX_ROUTE_EXPLICIT_JACOBIAN, or outside the tree kernels' scope)");
   }
-  if (n > 512) {
-    return fail(MMX_ERR_UNSUPPORTED, "more than 512 enabled parameters");
+  if (n > mmx::kMaxSolved) {
+    return fail(MMX_ERR_UNSUPPORTED, "more than 1536 solved parameters (512 on the tree routes; the explicit-Jacobian route takes up to 1536)");
   }
   // Wide systems (the in-LDS Cholesky step does not fit) inside the tree kernels' scope: normal equations from the tree
   // moments, left-looking factor in HBM, refinement through the tree.  No dense J is written or read.

@@ -889,7 +889,8 @@ size_t jointBlocksLdsBytes(int J, int P, int G) { // G = constraints of the bloc
 // lower triangle in registers over ALL rows (tile loop outside, chunk loop inside would re-stage J,
 // so tiles are kept in a small register set and the matrix is swept once per tile batch).
 // =============================================================================================
-constexpr int kNeChunk = 32; // rows of J staged per step
+constexpr int kNeChunk = 32; // rows of J staged per step (16 when 32 rows of a very wide system do not fit the LDS)
+constexpr int kNeCols = 6; // columns of g per thread: n <= 256 * kNeCols = kMaxSolved (mmx_kernels.hpp)
 // a further refinement step is taken while |correction|^2 > kRefineTol2 |step|^2 (at most three steps)
 constexpr float kRefineTol2 = 1e-6f;
 // ... and a correction is only TAKEN when it is a contraction: |correction|^2 <= kRefineMax2 |step|^2, and not larger than
@@ -908,7 +909,8 @@ __global__ void __launch_bounds__(256) normalEquationsKernel(
     const float* __restrict__ res, // [B][M]
     float* __restrict__ jtj, // [B][n*n]
     float* __restrict__ jtr, // [B][n]
-    const int32_t* __restrict__ done) {
+    const int32_t* __restrict__ done,
+    int chunk) { // rows of J per staged chunk: kNeChunk or half of it (normalEquationsChunkRows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (done != nullptr && done[b] != 0) {
@@ -917,8 +919,8 @@ __global__ void __launch_bounds__(256) normalEquationsKernel(
   const int n = pb.n, M = pb.M;
   const int nT = (n + 3) >> 2; // tiles per dimension
   const int ld = 4 * nT + 4; // padded row length of the staged chunk (multiple of 4 for b128 reads)
-  float* Jc = smem; // [kNeChunk][ld]
-  float* rc = smem + kNeChunk * ld; // [kNeChunk]
+  float* Jc = smem; // [chunk][ld]
+  float* rc = smem + chunk * ld; // [chunk]
   const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
   const float* rb = res + size_t(b) * size_t(M);
   const int numTiles = nT * (nT + 1) / 2;
@@ -947,20 +949,24 @@ __global__ void __launch_bounds__(256) normalEquationsKernel(
         acc[q][e] = 0.f;
       }
     }
-    float gacc[2] = {0.f, 0.f}; // threads accumulate g[tid], g[tid+256] (first tile batch only)
-    for (int k0 = 0; k0 < M; k0 += kNeChunk) {
-      const int kc = min(kNeChunk, M - k0);
+    float gacc[kNeCols]; // threads accumulate g[tid], g[tid + 256], ... (first tile batch only)
+#pragma unroll
+    for (int h = 0; h < kNeCols; ++h) {
+      gacc[h] = 0.f;
+    }
+    for (int k0 = 0; k0 < M; k0 += chunk) {
+      const int kc = min(chunk, M - k0);
       __syncthreads();
       // stage rows k0..k0+kc of the compacted Jacobian: element (k, s) = J[k0+k + E[s]*M]
-      for (int idx = tid; idx < kNeChunk * 4 * nT; idx += 256) {
-        const int k = idx % kNeChunk, s = idx / kNeChunk;
+      for (int idx = tid; idx < chunk * 4 * nT; idx += 256) {
+        const int k = idx % chunk, s = idx / chunk;
         float v = 0.f;
         if (k < kc && s < n) {
           v = Jb[size_t(pb.enabledList[s]) * M + k0 + k];
         }
         Jc[k * ld + s] = v;
       }
-      if (tid < kNeChunk) {
+      if (tid < chunk) {
         rc[tid] = tid < kc ? rb[k0 + tid] : 0.f;
       }
       __syncthreads();
@@ -969,7 +975,7 @@ __global__ void __launch_bounds__(256) normalEquationsKernel(
         if (base + q * 256 + tid < numTiles) {
           const float* pa = Jc + 4 * ti[q];
           const float* pbb = Jc + 4 * tj[q];
-          for (int k = 0; k < kNeChunk; ++k) {
+          for (int k = 0; k < chunk; ++k) {
             const float4 a = *reinterpret_cast<const float4*>(pa + k * ld);
             const float4 c = *reinterpret_cast<const float4*>(pbb + k * ld);
             const float av[4] = {a.x, a.y, a.z, a.w};
@@ -986,10 +992,10 @@ __global__ void __launch_bounds__(256) normalEquationsKernel(
       }
       if (base == 0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kNeCols; ++h) {
           const int s = tid + 256 * h;
           if (s < n) {
-            for (int k = 0; k < kNeChunk; ++k) {
+            for (int k = 0; k < chunk; ++k) {
               gacc[h] += Jc[k * ld + s] * rc[k];
             }
           }
@@ -1016,7 +1022,7 @@ __global__ void __launch_bounds__(256) normalEquationsKernel(
     }
     if (base == 0) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < kNeCols; ++h) {
         if (tid + 256 * h < n) {
           jtr[size_t(b) * n + tid + 256 * h] = gacc[h];
         }
@@ -1227,7 +1233,7 @@ __global__ void __launch_bounds__(256, 1) normalEquationsMfmaKernel(
     }
     if (base == 0) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < kNeCols; ++h) {
         if (tid + 256 * h < n) {
           jtr[size_t(b) * n + tid + 256 * h] = gacc[h];
         }
@@ -1622,7 +1628,7 @@ __global__ void __launch_bounds__(256) choleskyStepKernel(
 }
 
 // =============================================================================================
-// Kernel 3c: the large-system GN step (n up to 512 solved parameters), left-looking: the same step as
+// Kernel 3c: the large-system GN step (n up to kMaxSolved solved parameters), left-looking: the same step as
 // choleskyStepKernel with H and the factor in HBM.  (Round 1's right-looking form, factored in place, re-read
 // every trailing tile right after writing it -- ~40 dependent round trips per block column -- and was removed in
 // round 3.)  The order of the memory traffic:
@@ -2201,14 +2207,15 @@ __device__ __forceinline__ void tiledFactorPairs(
 // factor kernel's sweep over the tiles it has just written wants: 1.53 against 1.95 ms for the stage on cfg5), false: it reads
 // the diagonal tile instead (in cache) and takes zeros (uniform control flow; what the finish kernel's sweeps over a factor
 // coming from HBM want: 0.53 against 0.67 ms)
-template <bool forward, bool kSkip = false>
+// (kM: 256-row slabs a thread covers below / left of a block -- 2 up to 512 solved parameters, kNeCols beyond)
+template <bool forward, bool kSkip = false, int kM = 2>
 __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, float* x, int tid, uint32_t vMask = 0xffffffffu) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NP = 16 * NB, lrow = lane & 15;
   {
-    float dg[16] = {}, dgNext[16] = {}, pv[2][16] = {}, pvNext[2][16] = {};
+    float dg[16] = {}, dgNext[16] = {}, pv[kM][16] = {}, pvNext[kM][16] = {};
     float di = 1.f, diNext = 1.f; // L(i,i) of the lane's row / column of the diagonal tile
-    auto request = [&](int k, float (&dgo)[16], float (&pvo)[2][16], float& dio) {
+    auto request = [&](int k, float (&dgo)[16], float (&pvo)[kM][16], float& dio) {
       if (k < 0 || k >= NB) {
         return;
       }
@@ -2223,7 +2230,7 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
       // column k's tiles below the diagonal (forward) / row k's tiles left of it (backward) that are structurally non-zero
       const uint32_t present = uint32_t(__builtin_amdgcn_readlane(int(vMask), k));
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < kM; ++m) {
         if (forward) {
           const int r = 16 * (k + 1) + tid + 256 * m;
           const int rb = min(r, NP - 1) >> 4;
@@ -2278,7 +2285,7 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
       }
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < kM; ++m) {
         const int idx = tid + 256 * m;
         const int target = forward ? 16 * (k + 1) + idx : idx;
         if (forward ? target < NP : target < 16 * k) {
@@ -2293,7 +2300,11 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
       __syncthreads();
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        dg[c] = dgNext[c], pv[0][c] = pvNext[0][c], pv[1][c] = pvNext[1][c];
+        dg[c] = dgNext[c];
+#pragma unroll
+        for (int m = 0; m < kM; ++m) {
+          pv[m][c] = pvNext[m][c];
+        }
       }
       di = diNext;
     }
@@ -2342,7 +2353,8 @@ __device__ __forceinline__ void applyStepAndBook(
   }
 }
 
-__global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
+template <int kM> // 256-column slabs per thread: 2 (n <= 512, three workgroups per CU) or kNeCols (to kMaxSolved, one)
+__global__ void __launch_bounds__(256, kM == 2 ? 3 : 1) choleskyStepTiledKernel(
     ProblemDev pb,
     int P,
     const float* __restrict__ jac, // [B][M*P]
@@ -2402,7 +2414,7 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
   __syncthreads();
   MMX_SCLK(0)
   if (!bad) {
-    tiledSweep<false>(L, NB, d0, tid);
+    tiledSweep<false, false, kM>(L, NB, d0, tid);
   }
   MMX_SCLK(2)
   float prevCorr2 = FLT_MAX;
@@ -2415,10 +2427,12 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
     const int slices = 256 >> rowShift, wRow = tid & (chunkRows - 1), wSlice = tid >> rowShift;
     float4 nx[kChunkLoads];
     float rNext = 0.f;
-    auto requestChunk = [&](int m0) {
+    // the 16-byte pieces base + tid + 256 i of chunk m0 into nx (base = 0: the part that is prefetched a chunk ahead;
+    // systems of more than 256 kChunkLoads pieces per chunk -- beyond 640 solved parameters -- fetch the rest in place)
+    auto requestItems = [&](int m0, int base) {
 #pragma unroll
       for (int i = 0; i < kChunkLoads; ++i) {
-        const int it = tid + 256 * i;
+        const int it = base + tid + 256 * i;
         if (it < items) {
           const int col = it >> quadShift, row = m0 + 4 * (it & quadMask);
           const float* src = Jb + size_t(pb.enabledList[col]) * M;
@@ -2432,20 +2446,34 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
           }
         }
       }
-      if (tid < chunkRows) {
-        rNext = m0 + tid < M ? rb[m0 + tid] : 0.f;
-      }
     };
-    float racc[2] = {0.f, 0.f};
-    requestChunk(0);
-    for (int m0 = 0; m0 < M; m0 += chunkRows) {
+    auto commitItems = [&](int base) {
 #pragma unroll
       for (int i = 0; i < kChunkLoads; ++i) {
-        const int it = tid + 256 * i;
+        const int it = base + tid + 256 * i;
         if (it < items) {
           float* dst = pan + (it >> quadShift) * cs + 4 * (it & quadMask);
           dst[0] = nx[i].x, dst[1] = nx[i].y, dst[2] = nx[i].z, dst[3] = nx[i].w;
         }
+      }
+    };
+    auto requestChunk = [&](int m0) {
+      requestItems(m0, 0);
+      if (tid < chunkRows) {
+        rNext = m0 + tid < M ? rb[m0 + tid] : 0.f;
+      }
+    };
+    float racc[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) {
+      racc[m] = 0.f;
+    }
+    requestChunk(0);
+    for (int m0 = 0; m0 < M; m0 += chunkRows) {
+      commitItems(0);
+      for (int base = 256 * kChunkLoads; base < items; base += 256 * kChunkLoads) {
+        requestItems(m0, base);
+        commitItems(base);
       }
       const float rCur = rNext;
       __syncthreads();
@@ -2471,7 +2499,7 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
       }
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < kM; ++m) {
         const int col = tid + 256 * m;
         if (col < n) {
           float acc = racc[m];
@@ -2484,7 +2512,7 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
       __syncthreads();
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < kM; ++m) {
       const int col = tid + 256 * m;
       if (col < NP) {
         rho[col] = col < n ? racc[m] - lambda * d0[col] : 0.f;
@@ -2492,8 +2520,8 @@ __global__ void __launch_bounds__(256, 3) choleskyStepTiledKernel(
     }
     __syncthreads();
     MMX_SCLK(3)
-    tiledSweep<true>(L, NB, rho, tid);
-    tiledSweep<false>(L, NB, rho, tid);
+    tiledSweep<true, false, kM>(L, NB, rho, tid);
+    tiledSweep<false, false, kM>(L, NB, rho, tid);
     MMX_SCLK(5)
     float c2 = 0.f, d2 = 0.f;
     for (int i = tid; i < n; i += 256) {
@@ -3516,9 +3544,13 @@ hipError_t launchFkJacobian(
   return hipGetLastError();
 }
 
-size_t normalEquationsLdsBytes(int n) {
+int normalEquationsChunkRows(int n) { // 32 rows of J per staged chunk while they fit the LDS, else 16
   const int nT = (n + 3) >> 2;
-  return size_t(kNeChunk) * size_t(4 * nT + 4) * sizeof(float) + kNeChunk * sizeof(float);
+  return size_t(kNeChunk) * size_t(4 * nT + 5) * sizeof(float) <= 160 * 1024 - 64 ? kNeChunk : kNeChunk / 2;
+}
+size_t normalEquationsLdsBytes(int n) {
+  const int nT = (n + 3) >> 2, chunk = normalEquationsChunkRows(n);
+  return size_t(chunk) * size_t(4 * nT + 4) * sizeof(float) + chunk * sizeof(float);
 }
 
 hipError_t launchNormalEquations(
@@ -3577,8 +3609,20 @@ hipError_t launchNormalEquations(
 #undef MMX_NE_LAUNCH_V
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(
-      normalEquationsKernel, dim3(pb.B), dim3(256), normalEquationsLdsBytes(pb.n), stream, pb, P, jac, res, jtj, jtr, done);
+  if (pb.n > kMaxSolved) {
+    return hipErrorInvalidValue;
+  }
+  {
+    static LdsLimitCache ldsLimit;
+    const size_t lds = normalEquationsLdsBytes(pb.n);
+    if (lds > 64 * 1024) {
+      hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(normalEquationsKernel), 160 * 1024 - 64);
+      if (rc != hipSuccess) {
+        return rc;
+      }
+    }
+    hipLaunchKernelGGL(normalEquationsKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, done, normalEquationsChunkRows(pb.n));
+  }
   return hipGetLastError();
 }
 
@@ -3605,15 +3649,27 @@ hipError_t launchCholeskyStep(
     // chunk's loads fit the prefetch registers, else 16
     const int chunkRows = size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
     lds = tiledLdsFloats(pb.n, chunkRows, nullptr, nullptr) * sizeof(float);
-    if (lds > 64 * 1024) {
-      hipError_t rc = hipFuncSetAttribute(
-          reinterpret_cast<const void*>(choleskyStepTiledKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      if (rc != hipSuccess) {
-        return rc;
-      }
+    if (pb.n > kMaxSolved || lds > 160 * 1024 - 64) {
+      return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(
-        choleskyStepTiledKernel, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, factor, errIter, theta, st, sp, chunkRows);
+#define MMX_TILED_STEP(KM_)                                                                                          \
+  do {                                                                                                               \
+    if (lds > 64 * 1024) {                                                                                           \
+      static LdsLimitCache ldsLimit;                                                                                 \
+      hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(choleskyStepTiledKernel<KM_>), 160 * 1024 - 64); \
+      if (rc != hipSuccess) {                                                                                        \
+        return rc;                                                                                                   \
+      }                                                                                                              \
+    }                                                                                                                \
+    hipLaunchKernelGGL(                                                                                              \
+        choleskyStepTiledKernel<KM_>, dim3(pb.B), dim3(256), lds, stream, pb, P, jac, res, jtj, jtr, factor, errIter, theta, st, sp, chunkRows); \
+  } while (0)
+    if (pb.n <= 512) {
+      MMX_TILED_STEP(2);
+    } else {
+      MMX_TILED_STEP(kNeCols);
+    }
+#undef MMX_TILED_STEP
     return hipGetLastError();
   }
   if (lds > 160 * 1024) {

@@ -1,0 +1,126 @@
+"""More than 512 solved parameters (the reference's kMaxModelParams is 2048, momentum/math/types.h:426-429): the
+explicit-Jacobian route takes systems of 513 ... 1536 -- dense J, normal equations on the VALU, unmasked left-looking factor
+in HBM, refinement through J (mmx_kernels.hpp kMaxSolved) -- held to the oracle's double solve like every other route;
+beyond that the library refuses (MMX_ERR_UNSUPPORTED), it does not fall back."""
+import numpy as np
+import pytest
+
+from momentum_amd import capi, make_rig300
+from momentum_amd._abi import GnOptions
+from momentum_amd.rigs import RX, RZ, _build_rig
+from tests.helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _many_parameter_rig(extra_dofs, unit=0.01):
+    """make_rig300 (BASELINE configs[4]) with `extra_dofs` rotation parameters on every joint beyond the 72-joint body
+    instead of one on 172 of them: 128 + 228 * extra_dofs parameters."""
+    base = make_rig300(unit=unit)  # (metres: lambda = 0.05 stays above the factor's damping floor, kFactorDamping x the mean diagonal)
+    J0, J = 72, base.num_joints
+    trip = []
+    for r in range(7 * J0):
+        for k in range(base.pt_outer[r], base.pt_outer[r + 1]):
+            trip.append((r, int(base.pt_inner[k]), float(base.pt_value[k])))
+    names = list(base.param_names[:128])
+    assert max(c for _, c, _ in trip) == 127
+    for j in range(J0, J):
+        for d in [RX, RX + 1, RZ, 0, 1, 2, 6][:extra_dofs]:  # rotations first, then translations, then the scale
+            trip.append((j * 7 + d, len(names), 1.0))
+            names.append(f"{base.joint_names[j]}_d{d}")
+    return _build_rig(base.parent, base.pre_rotation, base.translation_offset, trip, len(names), list(base.joint_names), names)
+
+
+def _upload(torch, pb, cons, B):
+    dev = pb.device
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(dev)
+    pb.set_constraints(
+        t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+        t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)),
+        cons.pos_function_weight, cons.ori_function_weight,
+    )  # fmt: skip
+
+
+@pytest.fixture(scope="module")
+def problem812(torch_cuda, orc):
+    torch = torch_cuda
+    rig = _many_parameter_rig(3)  # 128 + 684 = 812 parameters
+    assert rig.num_params == 812
+    joints = np.arange(rig.num_joints, dtype=np.int32)  # a position and an orientation constraint on every joint: M = 3600 rows
+    B = 3
+    cons, th0, _ = make_problem(rig, joints, joints, B, seed=77, perturb=0.1)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, B, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, B)
+    return torch, rig, cons, th0, pb, B
+
+
+def test_normal_equations_of_812_parameters(problem812, orc):
+    torch, rig, cons, th0, pb, B = problem812
+    assert pb.n > 512
+    jtj, jtr, err = pb.normal_equations(torch.from_numpy(th0.copy()).to(pb.device))
+    jtj, jtr = jtj.cpu().numpy(), jtr.cpu().numpy()
+    opt1 = GnOptions.make(min_iterations=1, max_iterations=1, threshold=1.0, regularization=0.05)
+    for b in range(B):
+        ref = orc.solve(rig, cons.subset(np.array([b])), th0[b], opt1, dtype="f64")
+        H, g = ref["jtj"], ref["jtr"]
+        assert H.shape == jtj[b].shape == (812, 812)
+        scale = np.abs(H).max()
+        assert np.abs(jtj[b] - H).max() <= 2e-5 * scale
+        assert np.abs(jtr[b] - g).max() <= 2e-5 * np.abs(g).max()
+
+
+def test_solve_with_812_parameters_matches_the_double_oracle(problem812, orc):
+    torch, rig, cons, th0, pb, B = problem812
+    opt = GnOptions.make(min_iterations=5, max_iterations=5, threshold=1.0, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert pb.last_route() == "explicit_jacobian"
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=4)
+    th = out["theta"].cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    assert np.all((out["status"].cpu().numpy() & 3) == 0)
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.all(np.abs(h - href) <= 1e-4 * np.abs(href) + 1e-7 * href[:, :1])
+    assert rel.max() <= 1e-5, rel
+
+
+def test_solve_with_1496_parameters_near_the_limit(torch_cuda, orc):
+    """128 + 228 x 6 parameters (rotations and translations of every extra joint): the normal equations' 16-row chunks,
+    the factor's 94-tile panel and the refinement's chunk of J at the edge of one workgroup's LDS."""
+    torch = torch_cuda
+    rig = _many_parameter_rig(6)
+    assert rig.num_params == 1496
+    joints = np.arange(rig.num_joints, dtype=np.int32)
+    cons, th0, _ = make_problem(rig, joints, joints, 1, seed=78, perturb=0.05)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, 1, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, 1)
+    opt = GnOptions.make(min_iterations=3, max_iterations=3, threshold=1.0, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert pb.last_route() == "explicit_jacobian" and pb.n == 1496
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    r32 = orc.solve_batch(rig, cons, th0, opt, dtype="f32")
+    dist = lambda th: np.linalg.norm(th.astype(np.float64) - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    rel, rel32 = dist(out["theta"].cpu().numpy()), dist(r32["theta"])
+    print("rel", rel, "float oracle", rel32)
+    assert np.all((out["status"].cpu().numpy() & 3) == 0)
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.all(np.abs(h - href) <= 1e-4 * np.abs(href) + 1e-7 * href[:, :1])
+    assert rel.max() <= 1e-5, (rel, rel32)
+
+
+def test_more_than_1536_solved_parameters_are_refused(torch_cuda):
+    torch = torch_cuda
+    rig = _many_parameter_rig(7)  # 128 + 228 * 7 = 1724 parameters
+    assert rig.num_params == 1724
+    joints = np.arange(rig.num_joints, dtype=np.int32)
+    cons, th0, _ = make_problem(rig, joints, joints, 1, seed=3, perturb=0.05)
+    rh = capi.RigHandle(rig, 0)
+    pb = capi.Problem(rh, 1, cons.pos_parent, cons.ori_parent)
+    _upload(torch, pb, cons, 1)
+    assert pb.n > 1536
+    opt = GnOptions.make(min_iterations=1, max_iterations=1, threshold=1.0, regularization=0.05)
+    with pytest.raises(capi.MmxError) as e:
+        pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)
+    assert e.value.code == 4  # MMX_ERR_UNSUPPORTED
