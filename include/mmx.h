@@ -419,9 +419,8 @@ int32_t mmx_problem_set_instance_parents(
  *                                in LDS while its tiles fit half a CU (<= ~75 tiles), in HBM beyond --, refinement through
  *                                the tree (<= 512 solved parameters; the default from 129 on)
  *   MMX_ROUTE_EXPLICIT_JACOBIAN  dense J in HBM -> J^T J (matrix cores; VALU beyond 384 columns) -> Cholesky step; the route
- *                                for problems outside the tree kernels' scope, among them systems of 513 ... 1536 solved
- *                                parameters (more: MMX_ERR_UNSUPPORTED; the reference's kMaxModelParams is 2048,
- *                                momentum/math/types.h:426-429)
+ *                                for problems outside the tree kernels' scope, among them systems of 513 ... 2048 solved
+ *                                parameters (kMaxModelParams, momentum/math/types.h:426-429: a rig cannot have more)
  * The route does not change WHAT is computed (same algorithm, same refinement); results of different routes agree to
  * rounding (tests/test_gpu_weak_damping.py, tests/test_gpu_fuzz.py).
  */

@@ -1879,7 +1879,7 @@ int32_t mmx_eval_normal_equations(
     return fail(MMX_ERR_INVALID_ARGUMENT, "theta / jtj / jtr is null");
   }
   if (pb->dev.n > mmx::kMaxSolved) {
-    return fail(MMX_ERR_UNSUPPORTED, "more than 1536 enabled parameters");
+    return fail(MMX_ERR_UNSUPPORTED, "more than 2048 enabled parameters (kMaxModelParams)");
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2074,7 +2074,7 @@ static int32_t solveImpl(
     return fail(MMX_ERR_UNSUPPORTED, "MMX_STEP_TRUST_REGION: available in the one-launch solve and on the wide route (tree kernels); this problem takes neither (MMX_ROUTE_EXPLICIT_JACOBIAN, or outside the tree kernels' scope)");
   }
   if (n > mmx::kMaxSolved) {
-    return fail(MMX_ERR_UNSUPPORTED, "more than 1536 solved parameters (512 on the tree routes; the explicit-Jacobian route takes up to 1536)");
+    return fail(MMX_ERR_UNSUPPORTED, "more than 2048 solved parameters (kMaxModelParams; 512 on the tree routes, the explicit-Jacobian route takes the rest)");
   }
   // Wide systems (the in-LDS Cholesky step does not fit) inside the tree kernels' scope: normal equations from the tree
   // moments, left-looking factor in HBM, refinement through the tree.  No dense J is written or read.

@@ -890,7 +890,7 @@ size_t jointBlocksLdsBytes(int J, int P, int G) { // G = constraints of the bloc
 // so tiles are kept in a small register set and the matrix is swept once per tile batch).
 // =============================================================================================
 constexpr int kNeChunk = 32; // rows of J staged per step (16 when 32 rows of a very wide system do not fit the LDS)
-constexpr int kNeCols = 6; // columns of g per thread: n <= 256 * kNeCols = kMaxSolved (mmx_kernels.hpp)
+constexpr int kNeCols = 8; // columns of g per thread: n <= 256 * kNeCols = kMaxSolved (mmx_kernels.hpp)
 // a further refinement step is taken while |correction|^2 > kRefineTol2 |step|^2 (at most three steps)
 constexpr float kRefineTol2 = 1e-6f;
 // ... and a correction is only TAKEN when it is a contraction: |correction|^2 <= kRefineMax2 |step|^2, and not larger than
@@ -1660,7 +1660,7 @@ __host__ __device__ inline size_t tiledLdsFloats(int n, int chunkRows, TiledLds*
   const size_t chunk = chunkRows > 0 ? size_t(n) * size_t(chunkRows + 1) : 0;
   const size_t panels = chunkRows > 0 ? NP * 16 : 2 * NP * 16; // (chunkRows = 0: the factor stage alone, two panels)
   const size_t panFloats = ((panels > chunk ? panels : chunk) + 3) & ~size_t(3);
-  const size_t oG = panFloats, oD = oG + NP, oRho = oD + NP, oInv = oRho + NP, oW = oInv + NP;
+  const size_t oG = panFloats, oD = oG, oRho = oD + NP, oInv = oRho + NP, oW = oInv + NP; // (d0 = g: y = L^-1 g is solved in place)
   const size_t oPart = oW + ((size_t(chunkRows) + 3) & ~size_t(3)); // doubles: even float offset
   const size_t oFlags = oPart + (chunkRows > 0 ? 512 : 16);
   if (out != nullptr) {
@@ -2366,7 +2366,7 @@ __global__ void __launch_bounds__(256, kM == 2 ? 3 : 1) choleskyStepTiledKernel(
     float* __restrict__ theta,
     SolveStateDev st,
     StepParams sp,
-    int chunkRows) { // 16 or 32
+    int chunkRows) { // 8, 16 or 32
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2408,11 +2408,7 @@ __global__ void __launch_bounds__(256, kM == 2 ? 3 : 1) choleskyStepTiledKernel(
   tiledFactor(jtj + size_t(b) * n * n, L, n, lambdaF, t, sp, b, tid, tclk);
   const bool badPivot = t.flags[0] != 0;
   constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
-  for (int i = tid; i < NP; i += 256) {
-    d0[i] = t.g[i];
-  }
-  __syncthreads();
-  MMX_SCLK(0)
+  MMX_SCLK(0) // (d0 is t.g: tiledFactor left y = L^-1 g there, behind its last barrier)
   if (!bad) {
     tiledSweep<false, false, kM>(L, NB, d0, tid);
   }
@@ -2422,7 +2418,7 @@ __global__ void __launch_bounds__(256, kM == 2 ? 3 : 1) choleskyStepTiledKernel(
     const float* Jb = jac + size_t(b) * size_t(M) * size_t(P);
     const float* rb = res + size_t(b) * size_t(M);
     const bool vec4 = (M & 3) == 0 && (reinterpret_cast<uintptr_t>(jac) & 15) == 0;
-    const int rowShift = chunkRows == 32 ? 5 : 4, quadShift = rowShift - 2, quadMask = (1 << quadShift) - 1;
+    const int rowShift = chunkRows == 32 ? 5 : (chunkRows == 16 ? 4 : 3), quadShift = rowShift - 2, quadMask = (1 << quadShift) - 1;
     const int items = n << quadShift; // (column, 16-byte row group) pairs of one chunk
     const int slices = 256 >> rowShift, wRow = tid & (chunkRows - 1), wSlice = tid >> rowShift;
     float4 nx[kChunkLoads];
@@ -3647,8 +3643,12 @@ hipError_t launchCholeskyStep(
   if (lds > 160 * 1024 && factor != nullptr) { // large system: left-looking factor in its own tile-major scratch
     // rows of J per refinement chunk: 32 (every column contributes one full 128-byte line per chunk) while the
     // chunk's loads fit the prefetch registers, else 16
-    const int chunkRows = size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
+    int chunkRows = size_t(pb.n) * 8 <= 256 * size_t(kChunkLoads) ? 32 : 16;
     lds = tiledLdsFloats(pb.n, chunkRows, nullptr, nullptr) * sizeof(float);
+    if (lds > 160 * 1024 - 64) { // (beyond ~1900 solved parameters the factor's panel leaves room for eight rows only)
+      chunkRows = 8;
+      lds = tiledLdsFloats(pb.n, chunkRows, nullptr, nullptr) * sizeof(float);
+    }
     if (pb.n > kMaxSolved || lds > 160 * 1024 - 64) {
       return hipErrorInvalidValue;
     }

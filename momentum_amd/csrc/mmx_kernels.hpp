@@ -213,9 +213,9 @@ hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t strea
 hipError_t launchTransposeJacobian(const float* colMajor, float* rowMajor, int B, int M, int P, hipStream_t stream);
 // Most solved parameters of a problem: up to 512 on every route (tile masks of 32 blocks); 513 ... kMaxSolved on the
 // explicit-Jacobian route only (dense J, VALU normal equations, unmasked left-looking factor in HBM, refinement through J)
-// -- the reference's kMaxModelParams is 2048 (momentum/math/types.h:426-429); what bounds this route is the factor's panel
-// + the refinement's chunk of J in one workgroup's LDS.
-constexpr int kMaxSolved = 1536;
+// -- the reference's kMaxModelParams (momentum/math/types.h:426-429).  What bounds this route is the factor's panel
+// (16 columns x n rows) + the refinement's chunk of J in one workgroup's LDS: 154 KB at 2048.
+constexpr int kMaxSolved = 2048;
 size_t normalEquationsLdsBytes(int n);
 size_t choleskyStepLdsBytes(int n, int M);
 

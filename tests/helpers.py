@@ -42,6 +42,7 @@ def make_problem(
     random_offsets: bool = False,
     theta0_scale: float = 0.0,
     weights: str = "ones",
+    offset_scale: float = 1.0,
 ):
     """Synthetic batch as in SURVEY.md section 8d: instance i is seeded with seed+i; targets are
     FK(theta*) with theta* = theta0 + U[-perturb, perturb]^P.  Returns (Constraints [B,...],
@@ -63,7 +64,7 @@ def make_problem(
         th0[b] = (theta0_scale * rng.uniform(-1, 1, size=P)).astype(np.float32)
         ths[b] = (th0[b] + rng.uniform(-perturb, perturb, size=P)).astype(np.float32)
         if random_offsets:
-            po[b] = rng.uniform(-1, 1, size=(Kp, 3))
+            po[b] = offset_scale * rng.uniform(-1, 1, size=(Kp, 3))
             oo[b] = rand_quat(rng, Ko)
         if weights == "random":
             pw[b] = rng.uniform(0.2, 2.0, size=Kp)

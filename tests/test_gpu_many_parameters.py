@@ -1,5 +1,5 @@
 """More than 512 solved parameters (the reference's kMaxModelParams is 2048, momentum/math/types.h:426-429): the
-explicit-Jacobian route takes systems of 513 ... 1536 -- dense J, normal equations on the VALU, unmasked left-looking factor
+explicit-Jacobian route takes systems of 513 ... 2048 -- dense J, normal equations on the VALU, unmasked left-looking factor
 in HBM, refinement through J (mmx_kernels.hpp kMaxSolved) -- held to the oracle's double solve like every other route;
 beyond that the library refuses (MMX_ERR_UNSUPPORTED), it does not fall back."""
 import numpy as np
@@ -110,17 +110,51 @@ def test_solve_with_1496_parameters_near_the_limit(torch_cuda, orc):
     assert rel.max() <= 1e-5, (rel, rel32)
 
 
-def test_more_than_1536_solved_parameters_are_refused(torch_cuda):
+def _every_joint_dof_rig(skip=()):
+    """make_rig300's skeleton with one model parameter per joint parameter (300 x 7 = 2100) except the rows in `skip`."""
+    base = make_rig300(unit=0.01)
+    J = base.num_joints
+    rows = [r for r in range(7 * J) if r not in set(skip)]
+    trip = [(r, c, 1.0) for c, r in enumerate(rows)]
+    names = [f"{base.joint_names[r // 7]}_{'tx ty tz rx ry rz sc'.split()[r % 7]}" for r in rows]
+    return _build_rig(base.parent, base.pre_rotation, base.translation_offset, trip, len(rows), list(base.joint_names), names)
+
+
+@pytest.fixture(scope="module")
+def problem2048(torch_cuda):
     torch = torch_cuda
-    rig = _many_parameter_rig(7)  # 128 + 228 * 7 = 1724 parameters
-    assert rig.num_params == 1724
+    rig = _every_joint_dof_rig(skip=[40 * i + 6 for i in range(52)])  # without 52 of the scales: 2048 = kMaxModelParams
+    assert rig.num_params == 2048
     joints = np.arange(rig.num_joints, dtype=np.int32)
-    cons, th0, _ = make_problem(rig, joints, joints, 1, seed=3, perturb=0.05)
+    # (offsets of a few centimetres: with a point off the joint's origin its scale is observable)
+    cons, th0, _ = make_problem(rig, joints, joints, 1, seed=79, perturb=0.03, random_offsets=True, offset_scale=0.03)
     rh = capi.RigHandle(rig, 0)
     pb = capi.Problem(rh, 1, cons.pos_parent, cons.ori_parent)
     _upload(torch, pb, cons, 1)
-    assert pb.n > 1536
-    opt = GnOptions.make(min_iterations=1, max_iterations=1, threshold=1.0, regularization=0.05)
+    return torch, rig, cons, th0, pb
+
+
+def test_solve_with_2048_parameters_the_reference_maximum(problem2048, orc):
+    """kMaxModelParams (momentum/math/types.h:426-429) solved parameters.  The factor's 128-tile panel leaves the refinement
+    eight rows of J per chunk."""
+    torch, rig, cons, th0, pb = problem2048
+    assert pb.n == 2048
+    opt = GnOptions.make(min_iterations=3, max_iterations=3, threshold=1.0, regularization=0.05)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert pb.last_route() == "explicit_jacobian"
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+    r32 = orc.solve_batch(rig, cons, th0, opt, dtype="f32")
+    dist = lambda th: np.linalg.norm(th.astype(np.float64) - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    rel, rel32 = dist(out["theta"].cpu().numpy()), dist(r32["theta"])
+    print("rel", rel, "float oracle", rel32, "history", ref["error_history"])
+    assert np.all((out["status"].cpu().numpy() & 3) == 0)
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.all(np.abs(h - href) <= 1e-4 * np.abs(href) + 1e-7 * href[:, :1])
+    assert rel.max() <= 1e-5, (rel, rel32)
+
+
+def test_a_rig_of_more_than_2048_parameters_is_refused(torch_cuda):
+    """... like the reference's own bound on a parameter transform (kMaxModelParams): no solve ever sees more."""
     with pytest.raises(capi.MmxError) as e:
-        pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)
-    assert e.value.code == 4  # MMX_ERR_UNSUPPORTED
+        capi.RigHandle(_every_joint_dof_rig(), 0)  # 2100 parameters
+    assert e.value.code == 1 and "kMaxModelParams" in str(e.value)  # MMX_ERR_INVALID_ARGUMENT
