@@ -550,182 +550,191 @@ __device__ __noinline__ void residentAccumulate(const ldsd* jl, int ldj, const l
     }
   }
 }
-// right-looking blocked Cholesky of the packed lower triangle, four columns per barrier pair; true when a pivot was not positive
-__device__ __noinline__ bool residentFactor(ldsd* H, ldsd* invd, int n, int tid) {
-      bool notPd = false;
-      for (int k0 = 0; k0 < n; k0 += 4) {
-        const int kb = n - k0 < 4 ? n - k0 : 4;
-        // the kb x kb diagonal block, factored by every thread for itself (ten broadcast reads)
-        double D[4][4], id[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-          for (int c = 0; c <= a; ++c) {
-            D[a][c] = a < kb ? H[hpos(n, k0 + a, k0 + c)] : (a == c ? 1.0 : 0.0);
-          }
-        }
-        bool bad = false;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-          for (int c = 0; c <= a; ++c) {
-            double v = D[a][c];
-#pragma unroll
-            for (int e = 0; e < c; ++e) {
-              v -= D[a][e] * D[c][e];
-            }
-            if (a == c) {
-              bad = bad || !(v > 0.0);
-              // 1 / sqrt(v): the hardware's estimate and two Newton steps (each squares the error), then l = v / sqrt(v)
-              double y = __builtin_amdgcn_rsq(v);
-              y = y * (1.5 - 0.5 * v * y * y);
-              y = y * (1.5 - 0.5 * v * y * y);
-              id[a] = y;
-              D[a][a] = v * y;
-            } else {
-              D[a][c] = v * id[c];
-            }
-          }
-        }
-        if (bad) { // every thread has factored the same numbers
-          notPd = true;
-          break;
-        }
-        const int i = tid;
-        const bool below = i >= k0 + kb && i < n;
-        double x[4] = {0.0, 0.0, 0.0, 0.0};
-        if (below) { // this thread's row of the panel against the block
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              double v = H[hpos(n, i, k0 + c)];
-#pragma unroll
-              for (int e = 0; e < c; ++e) {
-                v -= x[e] * D[c][e];
-              }
-              x[c] = v * id[c];
-            }
-          }
-        }
-        __syncthreads(); // the block and the panel have been read
-        if (below) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              H[hpos(n, i, k0 + c)] = x[c];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int a = 0; a < 4; ++a) { // (static indices: D stays in registers)
-            if (a < kb && i == k0 + a) {
-#pragma unroll
-              for (int c = 0; c <= a; ++c) {
-                H[hpos(n, i, k0 + c)] = D[a][c];
-              }
-              invd[i] = id[a];
-            }
-          }
-        }
-        __syncthreads();
-        // trailing update H(i, j) -= sum_c L(i, k0 + c) L(j, k0 + c), i >= j >= k0 + kb: a rank-four update, i.e. ONE
-        // v_mfma_f64_16x16x4_f64 per 16 x 16 tile of the trailing triangle (rows / columns before k0 + kb are masked out)
-        const int base = k0 + kb;
-        if (base < n) {
-          const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-          const int NB = (n + 15) >> 4, I0 = base >> 4;
-          int t = 0;
-          for (int I = I0; I < NB; ++I) {
-            for (int Jc = I0; Jc <= I; ++Jc, ++t) {
-              if ((t & 3) != wave) {
-                continue;
-              }
-              const int ra = 16 * I + li, rb = 16 * Jc + li;
-              const double a = (ra >= base && ra < n && lk < kb) ? H[hpos(n, ra, k0 + lk)] : 0.0;
-              const double b2 = (rb >= base && rb < n && lk < kb) ? H[hpos(n, rb, k0 + lk)] : 0.0;
-              v4d c = {0.0, 0.0, 0.0, 0.0};
-              c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, c, 0, 0, 0);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + 4 * r + lk, col = 16 * Jc + li;
-                if (row < n && col <= row && col >= base) {
-                  H[hpos(n, row, col)] -= c[r];
-                }
-              }
-            }
-          }
-        }
-        __syncthreads();
-      }
-      return notPd;
+// a double of another lane (uniform lane index): two v_readlane_b32
+__device__ __forceinline__ double readLaneD(double v, int srcLane) {
+  const long long bits = __double_as_longlong(v);
+  const unsigned lo = unsigned(__builtin_amdgcn_readlane(int(bits), srcLane));
+  const unsigned hi = unsigned(__builtin_amdgcn_readlane(int(bits >> 32), srcLane));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __noinline__ void residentSolve(const ldsd* H, const ldsd* invd, ldsd* w1, ldsd* w2, const ldsd* rhs, ldsd* x, int n, int tid) {
-      for (int c = tid; c < n; c += 256) {
-        w1[c] = rhs[c];
+// 1 / sqrt(v): the hardware's estimate and two Newton steps (each squares the error)
+__device__ __forceinline__ double rsqrtNewton(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  y = y * (1.5 - 0.5 * v * y * y);
+  y = y * (1.5 - 0.5 * v * y * y);
+  return y;
+}
+// Right-looking blocked Cholesky of the packed lower triangle, SIXTEEN columns per panel (the shape of the single-precision
+// tiledPanelFactor, mmx_kernels.hip): a lane holds one row of the panel in registers -- lanes 0-15 of every wave the
+// diagonal block (redundantly, so that the pivots travel by v_readlane inside a wave), lanes 16-63 the 4 x 48 rows below
+// it -- and the sixteen column steps run without a barrier; the rank-16 trailing update is four v_mfma_f64_16x16x4_f64 per
+// 16 x 16 tile.  Three barriers per panel (n / 16 panels) where the four-column form took three per four columns: the
+// factor of a 96-parameter system went from 173 k to ~45 k cycles.  Column-packed storage makes "a lane = a row" reads
+// consecutive in LDS.  Rows covered per panel: 16 + 192 (the resident form is taken up to n = 208).  True when a pivot was
+// not positive (nothing of that panel is written).
+__device__ __noinline__ bool residentFactor(ldsd* H, ldsd* invd, int n, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool diagLane = lane < 16;
+  const int NB = (n + 15) >> 4;
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    const int row = diagLane ? k0 + lane : k0 + 16 + 48 * wave + (lane - 16);
+    const bool active = row < n;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = k0 + c;
+      a[c] = (active && col < n && col <= row) ? H[hpos(n, row, col)] : (row == col ? 1.0 : 0.0); // (rows / columns beyond n: identity)
+    }
+    double invMine = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double djj = readLaneD(a[j], j);
+      bad = bad || !(djj > 0.0);
+      const double y = rsqrtNewton(djj);
+      a[j] *= y; // the diagonal lane: l_jj = v / sqrt(v)
+      if (lane == j) {
+        invMine = y;
       }
-      for (int k0 = 0; k0 < n; k0 += 4) { // L y = rhs: w1 is consumed, y lands in w2
-        const int kb = n - k0 < 4 ? n - k0 : 4;
-        __syncthreads();
-        double yb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          if (a < kb) {
-            double v = w1[k0 + a];
-#pragma unroll
-            for (int c = 0; c < a; ++c) {
-              v -= H[hpos(n, k0 + a, k0 + c)] * yb[c];
-            }
-            yb[a] = v * invd[k0 + a];
-          }
-        }
-        const int i = tid;
-        if (i >= k0 && i < k0 + kb) {
-          const int a = i - k0;
-          w2[i] = a == 0 ? yb[0] : (a == 1 ? yb[1] : (a == 2 ? yb[2] : yb[3]));
-        } else if (i >= k0 + kb && i < n) {
-          double v = w1[i];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              v -= H[hpos(n, i, k0 + c)] * yb[c];
-            }
-          }
-          w1[i] = v;
-        }
+      for (int c = j + 1; c < 16; ++c) {
+        a[c] -= a[j] * readLaneD(a[j], c); // L(k0 + c, k0 + j) sits in diagonal lane c
       }
-      for (int k0 = ((n - 1) >> 2) << 2; k0 >= 0; k0 -= 4) { // L^T x = y: w2 is consumed
-        const int kb = n - k0 < 4 ? n - k0 : 4;
-        __syncthreads();
-        double zb[4] = {0.0, 0.0, 0.0, 0.0};
+    }
+    if (bad) { // (every wave has factored the same diagonal block: uniform)
+      return true;
+    }
+    __syncthreads(); // the panel has been read by everybody
+    if (diagLane) {
+      if (wave == 0 && active) {
 #pragma unroll
-        for (int a = 3; a >= 0; --a) {
-          if (a < kb) {
-            double v = w2[k0 + a];
-#pragma unroll
-            for (int c = 3; c > a; --c) {
-              if (c < kb) {
-                v -= H[hpos(n, k0 + c, k0 + a)] * zb[c];
-              }
-            }
-            zb[a] = v * invd[k0 + a];
+        for (int c = 0; c < 16; ++c) {
+          if (c <= lane) {
+            H[hpos(n, row, k0 + c)] = a[c];
           }
         }
-        const int i = tid;
-        if (i >= k0 && i < k0 + kb) {
-          const int a = i - k0;
-          x[i] = a == 0 ? zb[0] : (a == 1 ? zb[1] : (a == 2 ? zb[2] : zb[3]));
-        } else if (i < k0) {
-          double v = w2[i];
+        invd[row] = invMine;
+      }
+    } else if (active) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < kb) {
-              v -= H[hpos(n, k0 + c, i)] * zb[c];
+      for (int c = 0; c < 16; ++c) {
+        H[hpos(n, row, k0 + c)] = a[c]; // (row >= k0 + 16: every column of the panel exists)
+      }
+    }
+    __syncthreads();
+    // trailing update H(i, j) -= sum_c L(i, k0 + c) L(j, k0 + c), i >= j >= k0 + 16
+    const int base = k0 + 16;
+    if (base < n) {
+      const int li = lane & 15, lk = lane >> 4, I0 = base >> 4;
+      int t = 0;
+      for (int I = I0; I < NB; ++I) {
+        for (int Jc = I0; Jc <= I; ++Jc, ++t) {
+          if ((t & 3) != wave) {
+            continue;
+          }
+          const int ra = 16 * I + li, rb = 16 * Jc + li;
+          double av[4], bv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = k0 + 4 * q + lk;
+            av[q] = ra < n ? H[hpos(n, ra, col)] : 0.0;
+            bv[q] = rb < n ? H[hpos(n, rb, col)] : 0.0;
+          }
+          v4d c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * I + 4 * r + lk, cc = 16 * Jc + li;
+            if (rr < n && cc <= rr) {
+              H[hpos(n, rr, cc)] -= c[r];
             }
           }
-          w2[i] = v;
         }
       }
       __syncthreads();
+    }
+  }
+  return false;
+}
+// L y = rhs, L^T x = y on the packed factor, sixteen unknowns per barrier pair: wave 0 solves the diagonal block with its
+// rows (columns) in registers and the unknowns travelling by v_readlane, then every thread takes the block out of its own
+// row.  w1 / w2: work vectors.  n <= 256 (one row per thread).
+__device__ __noinline__ void residentSolve(const ldsd* H, const ldsd* invd, ldsd* w1, ldsd* w2, const ldsd* rhs, ldsd* x, int n, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, lrow = lane & 15;
+  const int NB = (n + 15) >> 4;
+  for (int c = tid; c < n; c += 256) {
+    w1[c] = rhs[c];
+  }
+  for (int k = 0; k < NB; ++k) { // L y = rhs: w1 is consumed, y lands in w2
+    const int k0 = 16 * k;
+    __syncthreads();
+    if (wave == 0) {
+      const int row = k0 + lrow;
+      double dg[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        dg[c] = (row < n && c < lrow) ? H[hpos(n, row, k0 + c)] : 0.0;
+      }
+      double bi = row < n ? w1[row] : 0.0;
+      const double iv = row < n ? invd[row] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double yj = readLaneD(bi, j) * readLaneD(iv, j);
+        bi = (lrow == j) ? yj : bi - dg[j] * yj; // (dg[j] = 0 for the rows above j)
+      }
+      if (lane < 16 && row < n) {
+        w2[row] = bi;
+      }
+    }
+    __syncthreads();
+    const int i = tid;
+    if (i >= k0 + 16 && i < n) {
+      double v = w1[i];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        v -= H[hpos(n, i, k0 + c)] * w2[k0 + c];
+      }
+      w1[i] = v;
+    }
+  }
+  for (int k = NB - 1; k >= 0; --k) { // L^T x = y: w2 is consumed
+    const int k0 = 16 * k;
+    __syncthreads();
+    if (wave == 0) {
+      const int col = k0 + lrow;
+      double dg[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        dg[c] = (col < n && k0 + c < n && c > lrow) ? H[hpos(n, k0 + c, col)] : 0.0; // L(k0 + c, col)
+      }
+      double bi = col < n ? w2[col] : 0.0;
+      const double iv = col < n ? invd[col] : 0.0;
+#pragma unroll
+      for (int j = 15; j >= 0; --j) {
+        const double xj = readLaneD(bi, j) * readLaneD(iv, j);
+        bi = (lrow == j) ? xj : bi - dg[j] * xj; // (dg[j] = 0 for the columns right of j)
+      }
+      if (lane < 16 && col < n) {
+        x[col] = bi;
+      }
+    }
+    __syncthreads();
+    const int i = tid;
+    if (i < k0) {
+      double v = w2[i];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (k0 + c < n) {
+          v -= H[hpos(n, k0 + c, i)] * x[k0 + c];
+        }
+      }
+      w2[i] = v;
+    }
+  }
+  __syncthreads();
 }
 
 // kRes: the resident instantiation (round 4).  The system lives in LDS for the whole solve: J is assembled a chunk of
@@ -1521,7 +1530,7 @@ size_t solveF64LdsBytes(int J, int P, int U, int n, int G, int genRows) {
 // the resident instantiation: rows of J per chunk (a multiple of three, >= 12) next to the packed H, or 0 when it does
 // not fit (then the scratch form runs).  Two workgroups per CU while that leaves a chunk of at least twelve rows.
 static int solveF64ResidentChunkRows(int J, int P, int U, int n, int G, int genRows) {
-  if (n <= 0 || n > 256) {
+  if (n <= 0 || n > 208) { // (residentFactor's panel: 16 + 4 x 48 rows)
     return 0;
   }
   auto e = [](size_t c) { return (c + 1) & ~size_t(1); };
