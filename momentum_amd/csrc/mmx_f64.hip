@@ -144,6 +144,7 @@ struct F64Lds {
   ldsd* invd; // [n] 1 / L(k,k)
   ldsd* w1; // [n] work vectors of the substitutions
   ldsd* w2; // [n]
+  ldsi* srcTab; // the solved columns' sources packed into LDS ([n + 1] offsets, then three words per source), or null
 };
 
 // position of H(i, j), i >= j, in the packed lower triangle (column j holds rows j .. n-1)
@@ -517,36 +518,231 @@ __device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, cons
 // of lane l comes back as C[4 r + l / 16][l % 16] (measured: scripts/probes/mfma_f64_layout.hip; NOT the single-precision
 // 16x16x4 layout) -- and is added to the packed triangle once per chunk.  gfx950 issues the f64 matrix instruction at
 // the rate of the f32 one.
+// The rows of J of the position / orientation units u0 .. u0 + nu - 1 into jl (column-major, ldj doubles per column, rows
+// padded with zeros to a multiple of four): a thread per entry (column, unit).  The column's sources come from the table
+// staged in LDS (srcTab; F64Lds) -- from L2 (solveList -> colStart -> colSources: three dependent round trips per entry,
+// one more per further source) when it did not fit -- and the ancestor test comes first: five of six (source, unit)
+// pairs of the 72-joint rig fail it and cost two LDS reads.  Compiled on its own like the routines below (inlined into
+// the kernel the same loop ran on registers spilled to scratch).
+__device__ __noinline__ void residentAssembleUnits(
+    const ldsi* srcTab, const ColumnSourceDev* __restrict__ colSources, const int32_t* __restrict__ colStart, const int32_t* __restrict__ solveList,
+    const ldsd* js, const ldsd* uv, const ldsd* us, const ldsi* utin, ldsd* jl, int ldj, int n, int u0, int nu, int Kp, int tid) {
+  for (int item = tid; item < n * nu; item += 256) {
+    const int c = item / nu, u = u0 + (item - c * nu);
+    const int ut = utin[u];
+    const bool isPoint = u < Kp;
+    const D3 v{uv[3 * u], uv[3 * u + 1], uv[3 * u + 2]};
+    const double sc = us[u];
+    D3 acc{0.0, 0.0, 0.0};
+    auto add = [&](const ColumnSourceDev& cs) { // jac.col(p) += derivScale * dfdv * jc * value (joint_error_function-inl.h:254-289)
+      bool applies;
+      const D3 gq = sourceDerivativeF64(cs, js, v, ut, isPoint, applies);
+      if (applies) {
+        const double w = double(cs.weight);
+        acc.x += (sc * gq.x) * w, acc.y += (sc * gq.y) * w, acc.z += (sc * gq.z) * w;
+      }
+    };
+    if (srcTab != nullptr) {
+      const ldsi* rec = srcTab + n + 1;
+      const int k1 = srcTab[c + 1];
+      for (int k = srcTab[c]; k < k1; ++k) {
+        const int w1 = rec[3 * k + 1];
+        const int tin = w1 & 0xffff, tout = int(unsigned(w1) >> 16);
+        if (!(tin <= ut && ut < tout)) {
+          continue; // the source's joint is not an ancestor of the unit's joint
+        }
+        const int w0 = rec[3 * k];
+        add(ColumnSourceDev{w0 & 0xfff, (w0 >> 12) & 7, tin, tout, (w0 >> 15) - 1, __int_as_float(rec[3 * k + 2])});
+      }
+    } else {
+      const int p = solveList[c];
+      const int e1 = colStart[p + 1];
+      for (int k = colStart[p]; k < e1; ++k) {
+        const ColumnSourceDev cs = colSources[k];
+        if (cs.tin <= ut && ut < cs.tout) {
+          add(cs);
+        }
+      }
+    }
+    ldsd* o = jl + c * ldj + 3 * (u - u0);
+    o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+  }
+  const int pad = (4 - (3 * nu) % 4) % 4; // rows up to a multiple of four: zeros (the matrix cores take four at a time)
+  for (int idx = tid; idx < n * pad; idx += 256) {
+    const int c = idx / pad;
+    jl[c * ldj + 3 * nu + (idx - c * pad)] = 0.0;
+  }
+}
 typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __noinline__ void residentAccumulate(const ldsd* jl, int ldj, const ldsd* ur, int rows, ldsd* g, ldsd* H, int n, int tid) {
+  const int rows4 = (rows + 3) & ~3; // (the pad rows of jl are zero; ur is read past `rows` only against those zeros)
   for (int c = tid; c < n; c += 256) {
+    const ldsd* col = jl + c * ldj;
     double acc = g[c];
-    for (int r = 0; r < rows; ++r) {
-      acc += jl[c * ldj + r] * ur[r];
+    for (int r = 0; r < rows4; r += 4) { // four rows per trip: eight reads in flight
+      const double j0 = col[r], j1 = col[r + 1], j2 = col[r + 2], j3 = col[r + 3];
+      const double r0 = ur[r], r1 = r + 1 < rows ? ur[r + 1] : 0.0, r2 = r + 2 < rows ? ur[r + 2] : 0.0, r3 = r + 3 < rows ? ur[r + 3] : 0.0;
+      acc += j0 * r0;
+      acc += j1 * r1;
+      acc += j2 * r2;
+      acc += j3 * r3;
     }
     g[c] = acc;
   }
   const int NB = (n + 15) >> 4, T = NB * (NB + 1) / 2, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, k = lane >> 4, steps = (rows + 3) >> 2;
-  int I = 0, Jc = 0;
-  for (int t = 0; t < T; ++t) { // tiles in row-major order of the lower triangle, dealt to the waves round robin
-    if ((t & 3) == wave) {
-      const ldsd* pa = jl + (16 * I + i < n ? 16 * I + i : n - 1) * ldj + k;
-      const ldsd* pb = jl + (16 * Jc + i < n ? 16 * Jc + i : n - 1) * ldj + k;
-      v4d c = {0.0, 0.0, 0.0, 0.0};
-      for (int s = 0; s < steps; ++s) {
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pb[4 * s], c, 0, 0, 0);
+  const int i = lane & 15, k = lane >> 4, steps = rows4 >> 2;
+  // the wave's tiles (row-major order of the lower triangle, round robin), two at a time: two independent accumulator
+  // chains, and per trip the operands of four steps (= sixteen rows) of both tiles are in flight together
+  auto tileOf = [](int t, int& I, int& Jc) {
+    I = int((sqrtf(8.f * float(t) + 1.f) - 1.f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= t) {
+      ++I;
+    }
+    while (I * (I + 1) / 2 > t) {
+      --I;
+    }
+    Jc = t - I * (I + 1) / 2;
+  };
+  for (int t0 = wave; t0 < T; t0 += 8) {
+    const int t1 = t0 + 4;
+    const bool two = t1 < T;
+    int I0, J0, I1, J1;
+    tileOf(t0, I0, J0);
+    tileOf(two ? t1 : t0, I1, J1);
+    const ldsd* pa0 = jl + (16 * I0 + i < n ? 16 * I0 + i : n - 1) * ldj + k;
+    const ldsd* pb0 = jl + (16 * J0 + i < n ? 16 * J0 + i : n - 1) * ldj + k;
+    const ldsd* pa1 = jl + (16 * I1 + i < n ? 16 * I1 + i : n - 1) * ldj + k;
+    const ldsd* pb1 = jl + (16 * J1 + i < n ? 16 * J1 + i : n - 1) * ldj + k;
+    v4d c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < steps; s0 += 4) {
+      double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int st = s0 + q < steps ? s0 + q : steps - 1;
+        a0[q] = pa0[4 * st], b0[q] = pb0[4 * st], a1[q] = pa1[4 * st], b1[q] = pb1[4 * st];
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (s0 + q < steps) {
+          c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], c1, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row0 = 16 * I0 + 4 * r + k, col0 = 16 * J0 + i;
+      if (row0 < n && col0 <= row0) {
+        H[hpos(n, row0, col0)] += c0[r];
+      }
+      const int row1 = 16 * I1 + 4 * r + k, col1 = 16 * J1 + i;
+      if (two && row1 < n && col1 <= row1) {
+        H[hpos(n, row1, col1)] += c1[r];
+      }
+    }
+  }
+}
+// The whole sweep over the position / orientation units for systems of at most 4 kTW tiles (n <= 96 with kTW = 6): chunk by
+// chunk residentAssembleUnits, g += J^T r, and H's tiles accumulated IN REGISTERS across the chunks (a wave owns tiles
+// t = wave, wave + 4, ...; eight registers each) -- added to the packed triangle once per iteration instead of once per
+// chunk (the read-modify-write of the tiles and the tile bookkeeping were a quarter of the accumulation's 30 k cycles per
+// chunk; the v_mfma_f64 themselves issue at 64 cycles per instruction, half the f32 rate: scripts/probes/mfma_f64_rate.hip).
+template <int kTW>
+__device__ __noinline__ void residentUnitsNormalEquations(
+    const ldsi* srcTab, const ColumnSourceDev* __restrict__ colSources, const int32_t* __restrict__ colStart, const int32_t* __restrict__ solveList,
+    const ldsd* js, const ldsd* uv, const ldsd* us, const ldsi* utin, const ldsd* ur, ldsd* jl, int ldj, int n, int U, int uc, int Kp, ldsd* g,
+    ldsd* H, int tid) {
+  const int NB = (n + 15) >> 4, T = NB * (NB + 1) / 2, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, k = lane >> 4;
+  int offA[kTW], offB[kTW]; // LDS offsets of the lane's operands of tile q (doubles)
+  v4d acc[kTW];
+#pragma unroll
+  for (int q = 0; q < kTW; ++q) {
+    const int t = wave + 4 * q < T ? wave + 4 * q : 0;
+    int I = int((sqrtf(8.f * float(t) + 1.f) - 1.f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= t) {
+      ++I;
+    }
+    while (I * (I + 1) / 2 > t) {
+      --I;
+    }
+    const int Jc = t - I * (I + 1) / 2;
+    offA[q] = (16 * I + i < n ? 16 * I + i : n - 1) * ldj + k;
+    offB[q] = (16 * Jc + i < n ? 16 * Jc + i : n - 1) * ldj + k;
+    acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+  }
+  for (int u0 = 0; u0 < U; u0 += uc) {
+    const int nu = U - u0 < uc ? U - u0 : uc;
+    __syncthreads(); // (the previous chunk has been consumed)
+    residentAssembleUnits(srcTab, colSources, colStart, solveList, js, uv, us, utin, jl, ldj, n, u0, nu, Kp, tid);
+    __syncthreads();
+    const int rows = 3 * nu, rows4 = (rows + 3) & ~3, steps = rows4 >> 2;
+    const ldsd* urc = ur + 3 * u0;
+    for (int c = tid; c < n; c += 256) {
+      const ldsd* col = jl + c * ldj;
+      double a = g[c];
+      for (int r = 0; r < rows4; r += 4) { // four rows per trip: eight reads in flight (the pad rows of jl are zero)
+        const double j0 = col[r], j1 = col[r + 1], j2 = col[r + 2], j3 = col[r + 3];
+        const double r0 = urc[r], r1 = r + 1 < rows ? urc[r + 1] : 0.0, r2 = r + 2 < rows ? urc[r + 2] : 0.0, r3 = r + 3 < rows ? urc[r + 3] : 0.0;
+        a += j0 * r0;
+        a += j1 * r1;
+        a += j2 * r2;
+        a += j3 * r3;
+      }
+      g[c] = a;
+    }
+#pragma unroll
+    for (int q = 0; q < kTW; q += 2) { // two tiles at a time: two independent accumulator chains
+      if (wave + 4 * q >= T) {
+        break;
+      }
+      const bool two = q + 1 < kTW && wave + 4 * (q + 1) < T;
+      const ldsd *pa0 = jl + offA[q], *pb0 = jl + offB[q];
+      const ldsd *pa1 = jl + offA[q + 1 < kTW ? q + 1 : q], *pb1 = jl + offB[q + 1 < kTW ? q + 1 : q];
+      v4d c0 = acc[q], c1 = acc[q + 1 < kTW ? q + 1 : q];
+      for (int s0 = 0; s0 < steps; s0 += 4) {
+        double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int st = s0 + e < steps ? s0 + e : steps - 1;
+          a0[e] = pa0[4 * st], b0[e] = pb0[4 * st], a1[e] = pa1[4 * st], b1[e] = pb1[4 * st];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (s0 + e < steps) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], c0, 0, 0, 0);
+            if (two) {
+              c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b1[e], c1, 0, 0, 0);
+            }
+          }
+        }
+      }
+      acc[q] = c0;
+      if (q + 1 < kTW) {
+        acc[q + 1] = c1;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kTW; ++q) {
+    const int t = wave + 4 * q;
+    if (t < T) {
+      int I = int((sqrtf(8.f * float(t) + 1.f) - 1.f) * 0.5f);
+      while ((I + 1) * (I + 2) / 2 <= t) {
+        ++I;
+      }
+      while (I * (I + 1) / 2 > t) {
+        --I;
+      }
+      const int Jc = t - I * (I + 1) / 2;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * I + 4 * r + k, col = 16 * Jc + i;
         if (row < n && col <= row) {
-          H[hpos(n, row, col)] += c[r];
+          H[hpos(n, row, col)] += acc[q][r];
         }
       }
-    }
-    if (++Jc > I) {
-      Jc = 0, ++I;
     }
   }
 }
@@ -779,10 +975,49 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     s.jl = take(size_t(n) * size_t(rc + 1));
     s.gev = take(size_t(kGevD) * size_t(G + pb.NE));
     s.H = s.invd = s.w1 = s.w2 = nullptr;
+    s.srcTab = nullptr;
     if (kRes) {
       s.H = take(size_t(n) * size_t(n + 1) / 2);
       s.invd = take(n), s.w1 = take(n), s.w2 = take(n);
     }
+  }
+  if (kRes && J < 4096 && size_t(7) * size_t(J) <= size_t(n) * size_t(rc + 1)) {
+    // The joint parameters (FK's scratch) move into the chunk buffer, which is dead whenever FK runs; their own 7 J
+    // doubles hold the solved columns' sources for the whole solve, packed to three words each -- when they fit
+    // (n + 1 + 3 nsrc <= 14 J words; else the assembly reads them from L2 as before).  residentAssembleUnits reads them
+    // once per entry of J: from L2 that was three dependent round trips per entry.
+    ldsi* tab = reinterpret_cast<ldsi*>(s.jp);
+    for (int c = tid; c < n; c += 256) {
+      const int p = solveList[c];
+      tab[c + 1] = pb.colStart[p + 1] - pb.colStart[p];
+    }
+    if (tid == 0) {
+      tab[0] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int c = 0; c < n; ++c) {
+        tab[c + 1] += tab[c];
+      }
+    }
+    __syncthreads();
+    const int nsrc = tab[n];
+    if (n + 1 + 3 * nsrc <= 14 * J) { // (uniform)
+      for (int c = tid; c < n; c += 256) {
+        const int p = solveList[c];
+        const int k0 = pb.colStart[p], cnt = tab[c + 1] - tab[c];
+        ldsi* o = tab + n + 1 + 3 * tab[c];
+        for (int e = 0; e < cnt; ++e) {
+          const ColumnSourceDev cs = pb.colSources[k0 + e];
+          o[3 * e] = cs.joint | cs.dof << 12 | (cs.parent + 1) << 15;
+          o[3 * e + 1] = cs.tin | cs.tout << 16;
+          o[3 * e + 2] = __float_as_int(cs.weight);
+        }
+      }
+      s.srcTab = tab;
+      s.jp = s.jl;
+    }
+    __syncthreads();
   }
   // H(i, j), i >= j: the packed LDS triangle (kRes) or the column-major global scratch
   auto addToH = [&](int i, int j, double v) {
@@ -814,7 +1049,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
   const bool hasParamRows = pb.M > pb.rowsJoint; // limit / model-parameter rows present (uniform)
   __syncthreads();
 #ifdef MMX_EXP_F64CLK
-  long long clkAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long clkAcc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // (8, 9: assembly / accumulation of the J chunks, parts of 2)
   long long clkT = clock64();
 #define F64CLK(slot) { __syncthreads(); const long long now_ = clock64(); clkAcc[slot] += now_ - clkT; clkT = now_; }
 #else
@@ -892,33 +1127,22 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       auto accumulate = [&](int r0, int rows) { residentAccumulate(s.jl, ldj, s.ur + r0, rows, s.g, s.H, n, tid); };
       // position / orientation units, uc at a time
       const int uc = rc / 3;
-      for (int u0 = 0; u0 < U; u0 += uc) {
-        const int nu = U - u0 < uc ? U - u0 : uc;
-        __syncthreads(); // (the previous chunk has been consumed)
-        for (int item = tid; item < n * nu; item += 256) {
-          const int c = item / nu, u = u0 + (item - c * nu);
-          const int p = solveList[c];
-          const D3 v{s.uv[3 * u], s.uv[3 * u + 1], s.uv[3 * u + 2]};
-          D3 acc{0.0, 0.0, 0.0};
-          const int e1 = pb.colStart[p + 1];
-          for (int k = pb.colStart[p]; k < e1; ++k) {
-            const ColumnSourceDev cs = pb.colSources[k];
-            bool applies;
-            const D3 gq = sourceDerivativeF64(cs, s.js, v, s.utin[u], u < pb.Kp, applies);
-            if (applies) { // jac.col(p) += derivScale * dfdv * jc * value (joint_error_function-inl.h:254-289)
-              const double w = double(cs.weight);
-              acc.x += (s.us[u] * gq.x) * w, acc.y += (s.us[u] * gq.y) * w, acc.z += (s.us[u] * gq.z) * w;
-            }
+      {
+        const int NBt = (n + 15) >> 4;
+        if (NBt * (NBt + 1) / 2 <= 24) { // (n <= 96: the tiles of H stay in registers across the chunks)
+          residentUnitsNormalEquations<6>(s.srcTab, pb.colSources, pb.colStart, solveList, s.js, s.uv, s.us, s.utin, s.ur, s.jl, ldj, n, U, uc, pb.Kp, s.g, s.H, tid);
+          F64CLK(9)
+        } else {
+          for (int u0 = 0; u0 < U; u0 += uc) {
+            const int nu = U - u0 < uc ? U - u0 : uc;
+            __syncthreads(); // (the previous chunk has been consumed)
+            residentAssembleUnits(s.srcTab, pb.colSources, pb.colStart, solveList, s.js, s.uv, s.us, s.utin, s.jl, ldj, n, u0, nu, pb.Kp, tid);
+            __syncthreads();
+            F64CLK(8)
+            accumulate(3 * u0, 3 * nu);
+            F64CLK(9)
           }
-          ldsd* o = s.jl + c * ldj + 3 * (u - u0);
-          o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
-        for (int idx = tid; idx < n * ((4 - (3 * nu) % 4) % 4); idx += 256) { // rows up to a multiple of four: zeros (the matrix cores take four at a time)
-          const int pad = (4 - (3 * nu) % 4) % 4, c = idx / pad;
-          s.jl[c * ldj + 3 * nu + (idx - c * pad)] = 0.0;
-        }
-        __syncthreads();
-        accumulate(3 * u0, 3 * nu);
       }
       // the further joint error functions / ellipsoid limits: consecutive constraints while their rows fit a chunk
       const int GT = G + pb.NE;
@@ -1475,8 +1699,8 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
   }
 #ifdef MMX_EXP_F64CLK
   F64CLK(6)
-  if (b == 0 && tid == 0 && st.errorHistory != nullptr && fp.maxIterations >= 8) {
-    for (int i = 0; i < 8; ++i) {
+  if (b == 0 && tid == 0 && st.errorHistory != nullptr && fp.maxIterations >= 10) {
+    for (int i = 0; i < 10; ++i) {
       st.errorHistory[i] = double(clkAcc[i]);
     }
   }

@@ -12,8 +12,8 @@ th = db.theta0.double().clone()
 out = db.pb.solve_f64(th, opt, want_history=True)
 torch.cuda.synchronize()
 h = out["error_history"][0].cpu().numpy()
-names = ["FK", "units + error", "J chunks + J^T J", "parameter rows", "factor", "solve", "update / bookkeeping", "loop top"]
-tot = h[:8].sum()
+names = ["FK", "units + error", "J chunks: rest", "parameter rows", "factor", "solve", "update / bookkeeping", "loop top", "J chunks: assembly (n > 96)", "units: assembly + g, H accumulation"]
+tot = h[:10].sum()
 print(f"B = {B}: cycles of workgroup 0 over 10 iterations: total {tot:.0f}")
-for n_, v in zip(names, h[:8]):
+for n_, v in zip(names, h[:10]):
     print(f"  {n_:24s} {v:12.0f}  {100 * v / tot:5.1f} %")
