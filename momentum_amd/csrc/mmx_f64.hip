@@ -678,7 +678,8 @@ __device__ __noinline__ void residentUnitsNormalEquations(
     __syncthreads();
     const int rows = 3 * nu, rows4 = (rows + 3) & ~3, steps = rows4 >> 2;
     const ldsd* urc = ur + 3 * u0;
-    for (int c = tid; c < n; c += 256) {
+    // g on the two waves with the fewer tiles (wave 0 owns the 4 q-th tiles: one more whenever T is not a multiple of four)
+    for (int c = tid - 128; c >= 0 && c < n; c += 128) {
       const ldsd* col = jl + c * ldj;
       double a = g[c];
       for (int r = 0; r < rows4; r += 4) { // four rows per trip: eight reads in flight (the pad rows of jl are zero)
@@ -768,13 +769,23 @@ __device__ __forceinline__ double rsqrtNewton(double v) {
 // factor of a 96-parameter system went from 173 k to ~45 k cycles.  Column-packed storage makes "a lane = a row" reads
 // consecutive in LDS.  Rows covered per panel: 16 + 192 (the resident form is taken up to n = 208).  True when a pivot was
 // not positive (nothing of that panel is written).
-__device__ __noinline__ bool residentFactor(ldsd* H, ldsd* invd, int n, int tid) {
+// With rhs (and the work vectors w1, w2) the forward substitution L y = rhs rides along, y in w2: the rows of a panel are
+// in registers when its block of y is known, so taking the block out of the right-hand sides below costs no further read
+// of the factor and no barrier of its own (the separate forward sweep was 6 x 3.6 k cycles on a 96-parameter system).
+__device__ __noinline__ bool residentFactor(ldsd* H, ldsd* invd, int n, int tid, const ldsd* rhs = nullptr, ldsd* w1 = nullptr, ldsd* w2 = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
   const bool diagLane = lane < 16;
   const int NB = (n + 15) >> 4;
+  if (rhs != nullptr) {
+    for (int c = tid; c < n; c += 256) {
+      w1[c] = rhs[c];
+    }
+    __syncthreads();
+  }
   for (int k0 = 0; k0 < n; k0 += 16) {
     const int row = diagLane ? k0 + lane : k0 + 16 + 48 * wave + (lane - 16);
     const bool active = row < n;
+    double bi = (rhs != nullptr && active) ? w1[row] : 0.0;
     double a[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -800,7 +811,25 @@ __device__ __noinline__ bool residentFactor(ldsd* H, ldsd* invd, int n, int tid)
     if (bad) { // (every wave has factored the same diagonal block: uniform)
       return true;
     }
-    __syncthreads(); // the panel has been read by everybody
+    if (rhs != nullptr && wave == 0) { // L_kk y_k = s_k with the block's rows in registers (lanes 0-15 matter)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double yj = readLaneD(bi, j) * readLaneD(invMine, j);
+        bi = (lane == j) ? yj : ((diagLane && lane > j) ? bi - a[j] * yj : bi); // (lanes 16-63 keep their rows' right-hand sides)
+      }
+      if (diagLane && active) {
+        w2[row] = bi;
+      }
+    }
+    __syncthreads(); // the panel has been read by everybody (and y_k is visible)
+    if (rhs != nullptr && !diagLane && active) { // the block out of this row's right-hand side
+      double v = bi;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        v -= a[c] * w2[k0 + c];
+      }
+      w1[row] = v;
+    }
     if (diagLane) {
       if (wave == 0 && active) {
 #pragma unroll
@@ -855,6 +884,7 @@ __device__ __noinline__ bool residentFactor(ldsd* H, ldsd* invd, int n, int tid)
   }
   return false;
 }
+__device__ __noinline__ void residentBackward(const ldsd* H, const ldsd* invd, ldsd* w2, ldsd* x, int n, int tid);
 // L y = rhs, L^T x = y on the packed factor, sixteen unknowns per barrier pair: wave 0 solves the diagonal block with its
 // rows (columns) in registers and the unknowns travelling by v_readlane, then every thread takes the block out of its own
 // row.  w1 / w2: work vectors.  n <= 256 (one row per thread).
@@ -896,7 +926,13 @@ __device__ __noinline__ void residentSolve(const ldsd* H, const ldsd* invd, ldsd
       w1[i] = v;
     }
   }
-  for (int k = NB - 1; k >= 0; --k) { // L^T x = y: w2 is consumed
+  residentBackward(H, invd, w2, x, n, tid);
+}
+// L^T x = y on the packed factor (y in w2, consumed), sixteen unknowns per barrier pair
+__device__ __noinline__ void residentBackward(const ldsd* H, const ldsd* invd, ldsd* w2, ldsd* x, int n, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, lrow = lane & 15;
+  const int NB = (n + 15) >> 4;
+  for (int k = NB - 1; k >= 0; --k) {
     const int k0 = 16 * k;
     __syncthreads();
     if (wave == 0) {
@@ -1497,10 +1533,18 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     };
     F64CLK(3)
     if (!trust) {
-      factorH();
-      F64CLK(4)
-      if (!notPd) {
-        solveLLt(s.g, s.d);
+      if (kRes) { // factor with the forward substitution riding along, then the backward sweep
+        notPd = residentFactor(s.H, s.invd, n, tid, s.g, s.w1, s.w2);
+        F64CLK(4)
+        if (!notPd) {
+          residentBackward(s.H, s.invd, s.w2, s.d, n, tid);
+        }
+      } else {
+        factorH();
+        F64CLK(4)
+        if (!notPd) {
+          solveLLt(s.g, s.d);
+        }
       }
       F64CLK(5)
     }
