@@ -2250,6 +2250,9 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
   }
   treeSumRanges(t.subSize, t.loadedPos, fv.numLoaded, J, tid, t.kRange); // (barriers follow before the first tree sum)
   MMX_TCLK(0)
+  // the thread's first unit: its payload is requested before the forward kinematics (an HBM round trip in the shadow of
+  // phase B instead of in the open at the head of phase C)
+  const UnitInput uin0 = loadUnitInput(pb, b, tid < U ? tid : U);
   // ---- A, B: forward kinematics with rotation axes
   blockFk<true, kT>(rv, s, s.th, tid, true);
   MMX_TCLK(1)
@@ -2259,7 +2262,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
     float* stb = state != nullptr ? state + size_t(b) * sl.total : nullptr;
     double e = 0.0;
     for (int u = tid; u < U; u += kT) {
-      const Unit un = evalUnit(pb, s.js, b, u);
+      const Unit un = evalUnitFrom(pb, u == tid ? uin0 : loadUnitInput(pb, b, u), s.js, u);
       s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
       const float sg2 = un.sigma * un.sigma;
       s.uy[3 * u] = sg2 * un.f.x, s.uy[3 * u + 1] = sg2 * un.f.y, s.uy[3 * u + 2] = sg2 * un.f.z;
