@@ -54,6 +54,7 @@ def test_config5_every_instance_within_1e5(torch_cuda, orc, seed):
     difference: the oracle's float instantiation (the restatement of SolverT<float>) ends 7e-4 ... 0.4 from its double one on
     them, the GPU 1.3e-5 ... 2e-4, and which side of 1e-5 instance 325 lands on changes with the compiler's instruction
     selection (round 3: 2e-5; double FK: 0.9e-5; the FK's axis pass fed from registers, same arithmetic: 1.35e-5).
+    (scripts/diag_cfg5_tail.py prints those instances with the double run's error history.)
     The rule, with nothing else exempt: an instance above the bound must be one on which the float oracle is at least fifty
     times above the bound AND further from the double answer than the GPU is, and there may be at most one in a thousand."""
     chk, _, _ = _solve_and_check(torch_cuda, "cfg5", 4096, 4096, seed=seed)
