@@ -827,6 +827,11 @@ int32_t uploadProblemTables(mmx_problem* pb) {
         }
       }
     }
+    // ... and behind the slots the level schedule of the factorisation (TileMasks::levelSteps; [96 + tiles]: numSteps, then
+    // four words per step)
+    for (int32_t w : pb->tileMasks.levelSteps) {
+      masks.push_back(uint32_t(w));
+    }
     MMX_HIP(upload(pb->dTileMasks, masks));
     MMX_HIP(upload(pb->dTileList, pb->tileMasks.tiles));
     pb->fdev.tileList = pb->dTileList.as<int32_t>();

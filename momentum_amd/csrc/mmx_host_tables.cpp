@@ -402,6 +402,61 @@ TileMasks eliminationTileMasks(int32_t n, const std::vector<uint8_t>& related, b
       }
     }
   }
+  // level schedule (TileMasks::levelSteps)
+  {
+    int32_t level[32] = {};
+    int32_t maxLevel = -1;
+    for (int32_t k = 0; k < NB; ++k) {
+      int32_t lv = 0;
+      for (int32_t j = 0; j < k; ++j) {
+        if (m.rowMask[k] >> j & 1u) {
+          lv = std::max(lv, level[j] + 1);
+        }
+      }
+      level[k] = lv;
+      maxLevel = std::max(maxLevel, lv);
+    }
+    std::vector<int32_t> steps;
+    for (int32_t lv = 0; lv <= maxLevel; ++lv) {
+      int32_t used = 0, inStep = 0;
+      auto flush = [&]() {
+        while (inStep > 0 && inStep < 4) {
+          steps.push_back(-1);
+          ++inStep;
+        }
+        used = 0, inStep = 0;
+      };
+      // the widest panels first: they take the low waves, the narrow ones fill up
+      std::vector<int32_t> cols;
+      for (int32_t k = 0; k < NB; ++k) {
+        if (level[k] == lv) {
+          cols.push_back(k);
+        }
+      }
+      std::stable_sort(cols.begin(), cols.end(), [&](int32_t a, int32_t b2) { return __builtin_popcount(m.colMask[a]) > __builtin_popcount(m.colMask[b2]); });
+      for (int32_t k : cols) {
+        const int32_t nt = __builtin_popcount(m.colMask[k]);
+        const int32_t rowsBelow = 16 * (nt - 1);
+        if (rowsBelow > 192) { // the whole workgroup (tiledPanelFactor's tail substitution takes the rows beyond 208)
+          flush();
+          steps.push_back(k | (0 << 8) | (0xf << 12));
+          inStep = 1;
+          flush();
+          continue;
+        }
+        const int32_t nw = std::max(1, (rowsBelow + 47) / 48);
+        if (used + nw > 4 || inStep == 4) {
+          flush();
+        }
+        steps.push_back(k | (used << 8) | (nw << 12));
+        used += nw, ++inStep;
+      }
+      flush();
+    }
+    m.levelSteps.clear();
+    m.levelSteps.push_back(int32_t(steps.size() / 4));
+    m.levelSteps.insert(m.levelSteps.end(), steps.begin(), steps.end());
+  }
   return m;
 }
 

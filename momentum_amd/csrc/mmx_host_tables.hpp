@@ -113,6 +113,13 @@ struct TileMasks {
   uint32_t colMask[32] = {};
   std::vector<int32_t> tiles; // the non-zero tiles, I | J << 8, in tile-index order (I (I + 1) / 2 + J ascending)
   int64_t products = 0; // tile products L(I,j) L(k,j)^T of the masked factorisation (dense: NB (NB^2 - 1) / 6)
+  // Level schedule of the factorisation (the resident factor kernel): block column k can be factored once every column j
+  // with a tile (k, j) is -- level[k] = 1 + max level[j] --, so the columns of one level are independent (the subtrees of
+  // the skeleton's elimination tree: finger chains next to the spine's).  steps: [numSteps, then 4 words per step], a word
+  // = k | firstWave << 8 | numWaves << 12 (a column's panel of nt tiles takes ceil((16 nt - 16) / 48) of the workgroup's
+  // four waves, at least one; 0xf = the whole workgroup, for panels beyond 208 rows) or -1; the columns of a step are
+  // factored side by side.
+  std::vector<int32_t> levelSteps;
 };
 TileMasks eliminationTileMasks(int32_t n, const std::vector<uint8_t>& related /* [n][n], lower triangle used */, bool dense);
 

@@ -1953,6 +1953,75 @@ __device__ __forceinline__ void tiledPanelFactor(float* pan, int nt, int k, floa
   }
 }
 
+// tiledPanelFactor for a GROUP of waves: several independent block columns (one level of TileMasks::levelSteps) are factored
+// side by side, each by its own waves of the workgroup -- `mine`: this wave has a column; wrel: its index inside the
+// column's group (0: writes the diagonal block and y_k); lanes 16-63 of wave wrel carry rows 16 + 48 wrel ... of the panel.
+// The same arithmetic per column as tiledPanelFactor (the results are bit-identical); every wave of the workgroup takes
+// part in the two barriers.  The group's waves must cover the panel (16 + 48 x waves rows).
+__device__ __forceinline__ void
+tiledPanelFactorGroup(float* pan, int nt, int k, float* g, float* invDiag, int* flags, float floorRow, int lane, int wrel, bool mine) {
+  const int lrow = lane & 15;
+  float* Dk = pan;
+  const bool diagLane = lane < 16;
+  const int prow = 16 + 48 * wrel + (lane - 16);
+  const bool active = mine && (diagLane || prow < 16 * nt);
+  float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
+  const int trow = diagLane ? lane : (prow & 15);
+  const bool waveWorks = mine && (wrel == 0 || 16 + 48 * wrel < 16 * nt);
+  float a[16] = {};
+  float bi = 0.f;
+  if (waveWorks) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = active ? ldsRow4(Tl, trow, q) : float4{0.f, 0.f, 0.f, 0.f};
+      a[4 * q] = v.x, a[4 * q + 1] = v.y, a[4 * q + 2] = v.z, a[4 * q + 3] = v.w;
+    }
+    bi = g[16 * k + lrow]; // s_k
+  }
+  __syncthreads();
+  float invd = 0.f;
+  bool bad = false;
+  if (waveWorks) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float djj = readLaneF(a[j], j);
+      bad = bad || !(djj > 0.f);
+      const float inv = djj > readLaneF(floorRow, j) ? __builtin_amdgcn_rsqf(djj) : 0.f; // see kPivotFloor
+      a[j] *= inv;
+      if (lane == j) {
+        invd = inv;
+      }
+      const float yj = readLaneF(bi, j) * inv;
+      bi = (lane == j) ? yj : (lane > j ? bi - a[j] * yj : bi);
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) {
+        a[c] -= a[j] * readLaneF(a[j], c);
+      }
+    }
+  }
+  if (waveWorks && diagLane) {
+    if (wrel == 0) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        Dk[tileAddr(lane, c)] = c <= lane ? a[c] : 0.f;
+      }
+      invDiag[16 * k + lane] = invd;
+      if (bad) {
+        flags[0] = 1;
+      }
+    }
+  } else if (waveWorks && active) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      Tl[tileAddr(trow, c)] = a[c];
+    }
+  }
+  if (mine && wrel == 0 && lane < 16) {
+    g[16 * k + lane] = bi;
+  }
+  __syncthreads();
+}
+
 // The 2 x 32 mask words of mmx::TileMasks in the lanes of two registers (lane i, i + 32: block i's word): a v_readlane picks one.
 struct TileMaskLanes {
   uint32_t row, col;
@@ -2808,17 +2877,40 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   }
   __syncthreads();
   MMX_SCLK(6)
-  // ---- left-looking factorisation, one block column at a time, everything in LDS
-  for (int k = 0; k < NB; ++k) {
-    const uint32_t cm = colMask(k), rk = rowMask(k) & below(k);
-    float* pan = tiles + 256 * colBase(k);
-    if (rk != 0u) {
+  // ---- left-looking factorisation in LDS, one LEVEL of independent block columns per step (TileMasks::levelSteps behind
+  // the slot list: the columns of a step have no tile in each other's rows, e.g. the finger chains of the two hands
+  // next to the spine's; cfg5: 17 columns in 11 steps).  Per step: the left-looking updates of all its columns (tiles dealt
+  // to the waves round robin), one barrier, then the panels side by side, each on its own waves.
+  const uint32_t* sched = sp.tileMasks + 96 + numTiles;
+  const int numSteps = int(sched[0]);
+  for (int st = 0; st < numSteps; ++st) {
+    int ent[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ent[e] = int(sched[1 + 4 * st + e]); // (uniform)
+    }
+    bool anyUpdate = false;
+    int rr = 0; // round robin over the step's (column, tile) pairs
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (ent[e] < 0) {
+        continue;
+      }
+      const int k = ent[e] & 0xff;
+      const uint32_t cm = colMask(k), rk = rowMask(k) & below(k);
+      float* pan = tiles + 256 * colBase(k);
+      if (rk == 0u) {
+        continue;
+      }
+      anyUpdate = true;
       uint32_t rem = cm;
       for (int idx = 0; rem != 0u; ++idx) {
         const int I = __builtin_ctz(rem);
         rem &= rem - 1u;
         uint32_t m = rowMask(I) & rk;
-        if ((idx & 3) != wave || m == 0u) {
+        const bool take = (rr & 3) == wave;
+        ++rr;
+        if (!take || m == 0u) {
           continue;
         }
         float* Tc = pan + 256 * idx;
@@ -2892,11 +2984,27 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
           g[16 * k + lane] -= acc;
         }
       }
+    }
+    if (anyUpdate) {
       __syncthreads();
     }
     MMX_SCLK(7)
-    {
-      tiledPanelFactor(pan, __builtin_popcount(cm), k, g, invDiag, flags, floorAll[16 * k + lrow], tid);
+    if (((ent[0] >> 12) & 0xf) == 0xf) { // a panel beyond 208 rows: the whole workgroup, with the tail substitution
+      const int k = ent[0] & 0xff;
+      tiledPanelFactor(tiles + 256 * colBase(k), __builtin_popcount(colMask(k)), k, g, invDiag, flags, floorAll[16 * k + lrow], tid);
+    } else {
+      int myK = 0, myRel = 0;
+      bool mine = false;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ent[e] >= 0) {
+          const int w0 = (ent[e] >> 8) & 0xf, nw = (ent[e] >> 12) & 0xf;
+          if (wave >= w0 && wave < w0 + nw) {
+            mine = true, myK = ent[e] & 0xff, myRel = wave - w0;
+          }
+        }
+      }
+      tiledPanelFactorGroup(tiles + 256 * colBase(myK), __builtin_popcount(colMask(myK)), myK, g, invDiag, flags, floorAll[16 * myK + lrow], lane, myRel, mine);
     }
     MMX_SCLK(1)
   }
