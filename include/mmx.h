@@ -724,6 +724,14 @@ int32_t mmx_host_tables(
 int32_t mmx_host_elimination_order(const mmx_rig_desc* desc, const uint8_t* enabled, int32_t* order, int32_t* num_enabled);
 int32_t mmx_host_tile_structure(int32_t n, const uint8_t* related, uint32_t* row_mask, uint32_t* col_mask, int64_t* products);
 int32_t mmx_problem_tile_structure(mmx_problem* problem, uint32_t* row_mask, uint32_t* col_mask, int32_t* num_blocks, int32_t* num_tiles, int64_t* products);
+/*
+ *   mmx_host_tile_level_schedule: the order the resident factor kernel takes the block columns of that structure in --
+ *     steps of mutually independent columns (no tile in each other's rows: different subtrees of the elimination tree),
+ *     each column on its own waves of the 4-wave workgroup.  steps[0] = number of steps S, then 4 words per step:
+ *     k | first_wave << 8 | num_waves << 12 (num_waves = 15: the whole workgroup, a panel beyond 208 rows) or -1.
+ *     steps must hold 1 + 4 * 32 words.  Host-only bookkeeping (additive in ABI 9).
+ */
+int32_t mmx_host_tile_level_schedule(int32_t n, const uint8_t* related, int32_t* steps);
 
 #ifdef __cplusplus
 } /* extern "C" */

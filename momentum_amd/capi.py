@@ -30,7 +30,7 @@ SYMBOLS = [
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_constraints_sized", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_eval_skeleton_state_host", "mmx_host_tables", "mmx_debug_fused_normal_equations", "mmx_debug_tree_normal_equations",
-    "mmx_host_elimination_order", "mmx_host_tile_structure", "mmx_problem_tile_structure",
+    "mmx_host_elimination_order", "mmx_host_tile_structure", "mmx_host_tile_level_schedule", "mmx_problem_tile_structure",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
     "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
 ]  # fmt: skip
@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
     u32p, i64p = C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
     L.mmx_host_elimination_order.argtypes = [C.POINTER(RigDesc), _abi.c_uint8_p, _abi.c_int32_p, _abi.c_int32_p]
     L.mmx_host_tile_structure.argtypes = [i32, _abi.c_uint8_p, u32p, u32p, i64p]
+    L.mmx_host_tile_level_schedule.argtypes = [i32, _abi.c_uint8_p, C.POINTER(C.c_int32)]
     L.mmx_problem_tile_structure.argtypes = [vp, u32p, u32p, _abi.c_int32_p, _abi.c_int32_p, i64p]
     _lib = L
     return L
@@ -157,6 +158,20 @@ def host_tile_structure(related: np.ndarray):
     prod = C.c_int64(0)
     _check(lib().mmx_host_tile_structure(C.c_int32(n), as_ptr(rel, C.c_uint8), as_ptr(row, C.c_uint32), as_ptr(col, C.c_uint32), C.byref(prod)))
     return dict(row_mask=row, col_mask=col, products=prod.value)
+
+
+def host_tile_level_schedule(related: np.ndarray):
+    """The resident factor kernel's level schedule for that structure (mmx_host_tile_level_schedule): list of steps, a step =
+    list of (block column, first wave, number of waves; 15 = the whole workgroup)."""
+    rel = np.ascontiguousarray(related, dtype=np.uint8)
+    n = rel.shape[0]
+    assert rel.shape == (n, n)
+    words = np.zeros(1 + 4 * 32, np.int32)
+    _check(lib().mmx_host_tile_level_schedule(C.c_int32(n), as_ptr(rel, C.c_uint8), as_ptr(words, C.c_int32)))
+    steps = []
+    for s in range(int(words[0])):
+        steps.append([(int(w) & 0xff, (int(w) >> 8) & 0xf, (int(w) >> 12) & 0xf) for w in words[1 + 4 * s : 5 + 4 * s] if w >= 0])
+    return steps
 
 
 def _stream_ptr() -> C.c_void_p:

@@ -1003,6 +1003,19 @@ int32_t mmx_host_tile_structure(int32_t n, const uint8_t* related, uint32_t* row
   return MMX_OK;
 }
 
+int32_t mmx_host_tile_level_schedule(int32_t n, const uint8_t* related, int32_t* steps) {
+  if (n < 0 || n > 512 || (n > 0 && related == nullptr) || steps == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_host_tile_level_schedule: n outside 0..512, or related / steps is null");
+  }
+  const std::vector<uint8_t> rel(related, related + size_t(n) * size_t(n));
+  const mmx::TileMasks m = mmx::eliminationTileMasks(n, rel, false);
+  if (m.levelSteps.size() > size_t(1 + 4 * 32)) {
+    return fail(MMX_ERR_UNSUPPORTED, "mmx_host_tile_level_schedule: more than 32 steps");
+  }
+  std::copy(m.levelSteps.begin(), m.levelSteps.end(), steps);
+  return MMX_OK;
+}
+
 int32_t mmx_problem_tile_structure(mmx_problem* pb, uint32_t* row_mask, uint32_t* col_mask, int32_t* num_blocks, int32_t* num_tiles, int64_t* products) {
   if (pb == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "problem is null");

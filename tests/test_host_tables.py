@@ -259,3 +259,72 @@ def test_tile_structure_is_closed_under_elimination(seed):
                 assert np.abs(tile(L, I, Jc) - tile(Ld, I, Jc)).max() <= 1e-10
             else:
                 assert np.abs(tile(Ld, I, Jc)).max() <= 1e-12
+
+
+def _check_level_schedule(rel):
+    """The resident factor kernel's level schedule (TileMasks::levelSteps, mmx_host_tile_level_schedule): every block column
+    exactly once; a column only after every column it has a tile in the row of (its left-looking update reads those); the
+    columns of a step on disjoint waves of the 4-wave workgroup, each with enough of them for its panel (16 + 48 x waves
+    rows); a panel beyond 208 rows alone in its step."""
+    ts = capi.host_tile_structure(rel)
+    steps = capi.host_tile_level_schedule(rel)
+    n = rel.shape[0]
+    NB = (n + 15) // 16
+    done_before = {}
+    seen = []
+    for s, step in enumerate(steps):
+        assert 1 <= len(step) <= 4
+        waves_used = set()
+        for k, w0, nw in step:
+            assert 0 <= k < NB
+            seen.append(k)
+            nt = bin(int(ts["col_mask"][k])).count("1")
+            if nw == 15:
+                assert len(step) == 1 and 16 * nt > 208
+            else:
+                assert nw >= 1 and w0 + nw <= 4 and 16 + 48 * nw >= 16 * nt
+                ws = set(range(w0, w0 + nw))
+                assert not (ws & waves_used)
+                waves_used |= ws
+            deps = [j for j in range(k) if int(ts["row_mask"][k]) >> j & 1]
+            assert all(j in done_before and done_before[j] < s for j in deps), (k, deps, s)
+        for k, _, _ in step:
+            done_before[k] = s
+    assert sorted(seen) == list(range(NB))
+    return len(steps), NB
+
+
+@pytest.mark.parametrize("name", ["humanoid72", "humanoid72_p219", "rig300"])
+def test_level_schedule_of_the_rigs(orc, name):
+    rig = RIGS[name]()
+    anc = orc.ancestor_matrix(rig).astype(bool)
+    t = capi.host_tables(rig)
+    rel = _related(rig, [int(p) for p in t["elimination_order"]], anc)
+    steps, NB = _check_level_schedule(rel)
+    assert steps <= NB
+    if name == "rig300":
+        assert steps <= NB - 5  # the finger chains go side by side with the spine's: 19 block columns in at most 14 steps
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_level_schedule_of_random_patterns(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(17, 512))
+    rel = np.zeros((n, n), np.uint8)
+    # a random forest on the 16-blocks: a block couples to its ancestors' blocks (plus a few stray entries)
+    NB = (n + 15) // 16
+    parent = [-1] + [int(rng.integers(0, i)) if rng.random() < 0.8 else -1 for i in range(1, NB)]
+    order = list(range(NB))[::-1]  # children before parents: block i's ancestors have smaller index -> reverse numbering
+    pos = {b: i for i, b in enumerate(order)}
+    for b in range(NB):
+        a = parent[b]
+        while a >= 0:
+            lo, hi = sorted((pos[b], pos[a]))
+            rel[16 * hi : min(16 * hi + 16, n), 16 * lo : min(16 * lo + 16, n)] = 1
+            a = parent[a]
+    for _ in range(3):
+        i, j = sorted(rng.integers(0, n, size=2))
+        if i != j:
+            rel[j, i] = 1
+    _check_level_schedule(np.tril(rel, -1))
+    _check_level_schedule(np.tril(np.ones((n, n), np.uint8), -1))  # dense: one column per step
