@@ -158,3 +158,19 @@ def test_a_rig_of_more_than_2048_parameters_is_refused(torch_cuda):
     with pytest.raises(capi.MmxError) as e:
         capi.RigHandle(_every_joint_dof_rig(), 0)  # 2100 parameters
     assert e.value.code == 1 and "kMaxModelParams" in str(e.value)  # MMX_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("line_search", [1, 2])
+def test_line_search_with_812_parameters(problem812, orc, line_search):
+    """stepUpdateKernel (both backtracking rules) on the explicit-Jacobian route beyond 512 solved parameters."""
+    torch, rig, cons, th0, pb, B = problem812
+    opt = GnOptions.make(min_iterations=4, max_iterations=4, threshold=1.0, regularization=0.05, do_line_search=line_search)
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+    assert pb.last_route() == "explicit_jacobian"
+    ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=4)
+    th = out["theta"].cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    assert np.all((out["status"].cpu().numpy() & 3) == 0)
+    assert np.all(np.abs(h - href) <= 1e-4 * np.abs(href) + 1e-7 * href[:, :1])
+    assert rel.max() <= 1e-5, rel
