@@ -355,7 +355,8 @@ __device__ __forceinline__ void fkLocalTo(const RigT& rig, int j, const float* _
 // run sat at 1.5e-6 median / 8e-6 worst of 1024 instead of the float instantiation's 0.7e-6 / 2.6e-6
 // (scripts/diag_step_noise.py, diag_g_stages.py; profiles/r04_fk_noise.txt).  With the products in double the result is
 // the exact product of the single-precision local transforms rounded ONCE, which is tighter than the sequential
-// single-precision product.  gfx950 issues v_fma_f64 at the rate of v_fma_f32.
+// single-precision product.  (v_fma_f64 issues at half the rate of v_fma_f32 on gfx950; the rounds are bound by the LDS
+// round trips and the barriers, not by the arithmetic: +2.8 % on the whole solve, profiles/r04_exp_fused.txt.)
 //
 // Buffers: bufA / bufB, channel-major doubles [kFkCh][fkPad(J)]: t (3) q (4) s | jump target + 1 (an int in the
 // ninth 64-bit slot).  Precondition (barrier done): the local transforms and the parents are in bufA (fkStoreLocalD).  The last

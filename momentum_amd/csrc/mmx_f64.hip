@@ -517,7 +517,7 @@ __device__ __forceinline__ D3 sourceDerivativeF64(const ColumnSourceDev& c, cons
 // lane l feeds A[l % 16][l / 16] = J[row 4 s + l / 16][column 16 I + l % 16], likewise B for block column Jc, and register r
 // of lane l comes back as C[4 r + l / 16][l % 16] (measured: scripts/probes/mfma_f64_layout.hip; NOT the single-precision
 // 16x16x4 layout) -- and is added to the packed triangle once per chunk.  gfx950 issues the f64 matrix instruction at
-// the rate of the f32 one.
+// 64 cycles per wave-instruction, HALF the rate of the f32 16x16x4 one (scripts/probes/mfma_f64_rate.hip).
 // The rows of J of the position / orientation units u0 .. u0 + nu - 1 into jl (column-major, ldj doubles per column, rows
 // padded with zeros to a multiple of four): a thread per entry (column, unit).  The column's sources come from the table
 // staged in LDS (srcTab; F64Lds) -- from L2 (solveList -> colStart -> colSources: three dependent round trips per entry,
