@@ -2773,7 +2773,8 @@ __device__ __forceinline__ void residentSweepBackward(
 // contiguous and tiledPanelFactor works on it in place); the left-looking update takes its operands L(I,j), L(k,j) from
 // LDS (~100 cycles instead of a dependent HBM round trip per column), every finished column is stored to the tile-major
 // factor in HBM without anybody waiting for it (the finish stage and the trust region read it there), and the backward
-// substitution of the first solve runs on the resident tiles.
+// substitution of the first solve runs on the resident tiles.  The block columns are taken a LEVEL of the elimination tree
+// at a time (TileMasks::levelSteps: independent columns side by side, each panel on its own waves).
 __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
     ProblemDev pb,
     int P,
