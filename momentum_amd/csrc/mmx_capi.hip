@@ -210,6 +210,7 @@ struct mmx_problem {
   DevBuf dSolveListV1; // [solveN]
   DevBuf sHess2F64; // mmx_solve_f64 under MMX_STEP_TRUST_REGION: J^T J without damping
   DevBuf dSolveListF64; // [solveN] the same parameters in index order: the double instantiation follows the reference's column order
+  std::vector<int32_t> solveListF64;
   std::vector<std::pair<int32_t, int32_t>> limitPairs; // (row, col) solve columns of the off-diagonal H entries limits add
   DevBuf dTileMasks, dTileList; // tile structure of the factor in elimination order (mmx::TileMasks): [64] masks, the non-zero tiles
   mmx::TileMasks tileMasks;
@@ -219,6 +220,10 @@ struct mmx_problem {
   DevBuf sTreeState, sDvec, sRhoVec, sRefState, sGenState; // wide systems refined through the tree (no dense J)
   DevBuf sJacColMajor; // column-major J of an MMX_LAYOUT_ROW_MAJOR request, before its transposition
   DevBuf sJacF64, sHessF64; // scratch of the double-precision solve
+  // mmx_solve_f64's assembly list (mmx::F64AssemblyList): built on first use for the launch's chunking, dropped when the
+  // tables change (uploadProblemTables)
+  DevBuf dF64Groups, dF64Extra, dF64ChunkStart;
+  int32_t f64ListUnitsPerChunk = 0; // 0: not built
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda, sTrust;
   mmx_tuning tuning{}; // mmx_problem_set_tuning
   int32_t lastRoute = MMX_ROUTE_AUTO;
@@ -767,6 +772,8 @@ int32_t uploadProblemTables(mmx_problem* pb) {
     pb->solveListV1 = list;
     std::sort(list.begin(), list.end());
     MMX_HIP(upload(pb->dSolveListF64, list));
+    pb->solveListF64 = list;
+    pb->f64ListUnitsPerChunk = 0;
   }
   // Tile structure of the wide solve's factor (HostTables::eliminationList): entry (row, col) of H can be non-zero when
   // a source joint of the one column is an ancestor-or-self of a source joint of the other (their columns of J overlap
@@ -2297,6 +2304,79 @@ static int32_t solveImpl(
   return MMX_OK;
 }
 
+namespace {
+// mmx::F64AssemblyList for chunks of `uc` units: every entry (solved column, unit) of J with an applicable source --
+// the source's joint an ancestor-or-self of the unit's joint (DFS interval) and, for translation / scale dofs, a point
+// unit (joint_error_function-inl.h:248-291) -- with the indices of those sources in the kernel's packed table (columns in
+// solve-list order, a column's sources in colSources order: the prefix sums the kernel forms itself).
+int32_t buildF64AssemblyList(mmx_problem* pb, int32_t uc) {
+  const mmx::HostTables& t = pb->tables;
+  const int32_t n = pb->solveN, U = pb->U;
+  std::vector<int32_t> prefix(size_t(n) + 1, 0);
+  for (int32_t c = 0; c < n; ++c) {
+    const int32_t p = pb->solveListF64[size_t(c)];
+    prefix[size_t(c) + 1] = prefix[size_t(c)] + (t.colStart[size_t(p) + 1] - t.colStart[size_t(p)]);
+  }
+  std::vector<int32_t> unitTin(size_t(std::max(U, 1)));
+  for (int32_t c = 0; c < pb->Kp; ++c) {
+    unitTin[size_t(c)] = t.tin[size_t(pb->posParent[size_t(c)])];
+  }
+  for (int32_t c = 0; c < pb->Ko; ++c) {
+    for (int k = 0; k < 3; ++k) {
+      unitTin[size_t(pb->Kp + 3 * c + k)] = t.tin[size_t(pb->oriParent[size_t(c)])];
+    }
+  }
+  std::vector<uint32_t> groups; // two words per group
+  std::vector<int32_t> extra, chunkStart;
+  for (int32_t u0 = 0; u0 < U; u0 += uc) {
+    chunkStart.push_back(int32_t(groups.size() / 2));
+    for (int32_t u = u0; u < std::min(U, u0 + uc); ++u) {
+      const bool isPoint = u < pb->Kp;
+      for (int32_t c = 0; c < n; ++c) {
+        const int32_t p = pb->solveListF64[size_t(c)];
+        int32_t count = 0, first = -1;
+        const size_t extraAt = extra.size();
+        for (int32_t e = t.colStart[size_t(p)]; e < t.colStart[size_t(p) + 1]; ++e) {
+          const mmx::ColumnSource& cs = t.colSources[size_t(e)];
+          const bool rot = cs.dof >= 3 && cs.dof < 6;
+          if (cs.tin <= unitTin[size_t(u)] && unitTin[size_t(u)] < cs.tout && (rot || isPoint)) {
+            const int32_t k = prefix[size_t(c)] + (e - t.colStart[size_t(p)]);
+            if (count == 0) {
+              first = k;
+            }
+            extra.push_back(k);
+            ++count;
+          }
+        }
+        if (count == 0) {
+          continue;
+        }
+        if (count > 8191) {
+          return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: more than 8191 sources of one column apply to one constraint");
+        }
+        if (count == 1) {
+          extra.resize(extraAt); // (a single source rides in the group word)
+        }
+        groups.push_back(uint32_t(c) | uint32_t(u - u0) << 12 | uint32_t(count) << 18);
+        groups.push_back(uint32_t(count == 1 ? first : int32_t(extraAt)));
+      }
+    }
+  }
+  chunkStart.push_back(int32_t(groups.size() / 2));
+  if (groups.empty()) {
+    groups.assign(2, 0u);
+  }
+  if (extra.empty()) {
+    extra.push_back(0);
+  }
+  MMX_HIP(upload(pb->dF64Groups, groups));
+  MMX_HIP(upload(pb->dF64Extra, extra));
+  MMX_HIP(upload(pb->dF64ChunkStart, chunkStart));
+  pb->f64ListUnitsPerChunk = uc;
+  return MMX_OK;
+}
+} // namespace
+
 int32_t mmx_solve_f64(
     mmx_problem* pb,
     const mmx_gn_options* o,
@@ -2363,8 +2443,21 @@ int32_t mmx_solve_f64(
   fp.lmUp = o->lm_up;
   fp.lmDown = o->lm_down;
   fp.trustRadius = o->trust_region_radius > 0.f ? o->trust_region_radius : 1.f;
+  mmx::F64AssemblyList alist{nullptr, nullptr, nullptr, 0};
+  if (residentF64 && pb->dev.instPosParent == nullptr && pb->dev.instOriParent == nullptr && pb->rig->J < 4096 && pb->solveN <= 4096) {
+    const int32_t uc = mmx::solveF64ResidentChunkRows(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64) / 3;
+    if (uc > 0 && uc <= 64) {
+      if (pb->f64ListUnitsPerChunk != uc) {
+        rc = buildF64AssemblyList(pb, uc);
+        if (rc != MMX_OK) {
+          return rc;
+        }
+      }
+      alist = mmx::F64AssemblyList{pb->dF64Groups.as<uint2>(), pb->dF64Extra.as<int32_t>(), pb->dF64ChunkStart.as<int32_t>(), uc};
+    }
+  }
   MMX_HIP(mmx::launchSolveF64(
-      pb->rigDev, pb->dev, pb->dSolveListF64.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), trustF64 ? pb->sHess2F64.as<double>() : nullptr, s));
+      pb->rigDev, pb->dev, pb->dSolveListF64.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), trustF64 ? pb->sHess2F64.as<double>() : nullptr, s, alist));
   return MMX_OK;
 }
 

@@ -573,6 +573,56 @@ __device__ __noinline__ void residentAssembleUnits(
     jl[c * ldj + 3 * nu + (idx - c * pad)] = 0.0;
   }
 }
+// The same rows from the host's assembly list (F64AssemblyList): the chunk is zeroed, then a thread takes whole entries
+// (column, unit) that HAVE an applicable source -- perfectly balanced, no ancestor test, two entries' list words requested
+// together.  Needs the packed source table (srcTab).
+__device__ __noinline__ void residentAssembleUnitsList(
+    const ldsi* srcTab, const uint2* __restrict__ groups, const int32_t* __restrict__ extra, int g0, int g1, const ldsd* js, const ldsd* uv,
+    const ldsd* us, const ldsi* utin, ldsd* jl, int ldj, int n, int u0, int nu, int Kp, int tid) {
+  const int rows4 = (3 * nu + 3) & ~3;
+  for (int idx = tid; idx < n * rows4; idx += 256) {
+    const int c = idx / rows4;
+    jl[c * ldj + (idx - c * rows4)] = 0.0;
+  }
+  __syncthreads();
+  const ldsi* rec = srcTab + n + 1;
+  for (int base = g0; base < g1; base += 512) {
+    uint2 w[2];
+    bool valid[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int g = base + 256 * e + tid;
+      valid[e] = g < g1;
+      w[e] = groups[valid[e] ? g : g0];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (!valid[e]) {
+        continue;
+      }
+      const int c = int(w[e].x & 0xfffu), ul = int((w[e].x >> 12) & 0x3fu), count = int(w[e].x >> 18);
+      const int u = u0 + ul;
+      const int ut = utin[u];
+      const bool isPoint = u < Kp;
+      const D3 v{uv[3 * u], uv[3 * u + 1], uv[3 * u + 2]};
+      const double sc = us[u];
+      D3 acc{0.0, 0.0, 0.0};
+      for (int si = 0; si < count; ++si) {
+        const int k = count == 1 ? int(w[e].y) : extra[int(w[e].y) + si];
+        const int w0 = rec[3 * k], w1 = rec[3 * k + 1];
+        const ColumnSourceDev cs{w0 & 0xfff, (w0 >> 12) & 7, w1 & 0xffff, int(unsigned(w1) >> 16), (w0 >> 15) - 1, __int_as_float(rec[3 * k + 2])};
+        bool applies;
+        const D3 gq = sourceDerivativeF64(cs, js, v, ut, isPoint, applies);
+        if (applies) { // jac.col(p) += derivScale * dfdv * jc * value (joint_error_function-inl.h:254-289)
+          const double wt = double(cs.weight);
+          acc.x += (sc * gq.x) * wt, acc.y += (sc * gq.y) * wt, acc.z += (sc * gq.z) * wt;
+        }
+      }
+      ldsd* o = jl + c * ldj + 3 * ul;
+      o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+    }
+  }
+}
 typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __noinline__ void residentAccumulate(const ldsd* jl, int ldj, const ldsd* ur, int rows, ldsd* g, ldsd* H, int n, int tid) {
   const int rows4 = (rows + 3) & ~3; // (the pad rows of jl are zero; ur is read past `rows` only against those zeros)
@@ -651,7 +701,7 @@ template <int kTW>
 __device__ __noinline__ void residentUnitsNormalEquations(
     const ldsi* srcTab, const ColumnSourceDev* __restrict__ colSources, const int32_t* __restrict__ colStart, const int32_t* __restrict__ solveList,
     const ldsd* js, const ldsd* uv, const ldsd* us, const ldsi* utin, const ldsd* ur, ldsd* jl, int ldj, int n, int U, int uc, int Kp, ldsd* g,
-    ldsd* H, int tid) {
+    ldsd* H, int tid, F64AssemblyList list) {
   const int NB = (n + 15) >> 4, T = NB * (NB + 1) / 2, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, k = lane >> 4;
   int offA[kTW], offB[kTW]; // LDS offsets of the lane's operands of tile q (doubles)
@@ -674,7 +724,12 @@ __device__ __noinline__ void residentUnitsNormalEquations(
   for (int u0 = 0; u0 < U; u0 += uc) {
     const int nu = U - u0 < uc ? U - u0 : uc;
     __syncthreads(); // (the previous chunk has been consumed)
-    residentAssembleUnits(srcTab, colSources, colStart, solveList, js, uv, us, utin, jl, ldj, n, u0, nu, Kp, tid);
+    if (list.groups != nullptr && srcTab != nullptr) {
+      const int ch = u0 / uc;
+      residentAssembleUnitsList(srcTab, list.groups, list.extra, list.chunkStart[ch], list.chunkStart[ch + 1], js, uv, us, utin, jl, ldj, n, u0, nu, Kp, tid);
+    } else {
+      residentAssembleUnits(srcTab, colSources, colStart, solveList, js, uv, us, utin, jl, ldj, n, u0, nu, Kp, tid);
+    }
     __syncthreads();
     const int rows = 3 * nu, rows4 = (rows + 3) & ~3, steps = rows4 >> 2;
     const ldsd* urc = ur + 3 * u0;
@@ -988,7 +1043,8 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     double* __restrict__ Jg, // [B][n][M] scratch: the dense Jacobian (solved columns, column-major)
     double* __restrict__ Hg, // [B][n][n] scratch: H, then its Cholesky factor (lower triangle, column-major)
     double* __restrict__ Hg2, // [B][n][n] scratch of MMX_STEP_TRUST_REGION: J^T J without damping, kept while the damping changes (else null)
-    int rc) { // rows of J staged in LDS at a time
+    int rc, // rows of J staged in LDS at a time
+    F64AssemblyList alist) { // the resident form's assembly list, or null pointers
   extern __shared__ __attribute__((aligned(16))) double dmem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   selectInstanceRig(rig, b);
@@ -1166,13 +1222,18 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       {
         const int NBt = (n + 15) >> 4;
         if (NBt * (NBt + 1) / 2 <= 24) { // (n <= 96: the tiles of H stay in registers across the chunks)
-          residentUnitsNormalEquations<6>(s.srcTab, pb.colSources, pb.colStart, solveList, s.js, s.uv, s.us, s.utin, s.ur, s.jl, ldj, n, U, uc, pb.Kp, s.g, s.H, tid);
+          residentUnitsNormalEquations<6>(s.srcTab, pb.colSources, pb.colStart, solveList, s.js, s.uv, s.us, s.utin, s.ur, s.jl, ldj, n, U, uc, pb.Kp, s.g, s.H, tid, alist);
           F64CLK(9)
         } else {
           for (int u0 = 0; u0 < U; u0 += uc) {
             const int nu = U - u0 < uc ? U - u0 : uc;
             __syncthreads(); // (the previous chunk has been consumed)
-            residentAssembleUnits(s.srcTab, pb.colSources, pb.colStart, solveList, s.js, s.uv, s.us, s.utin, s.jl, ldj, n, u0, nu, pb.Kp, tid);
+            if (alist.groups != nullptr && s.srcTab != nullptr) {
+              const int ch = u0 / uc;
+              residentAssembleUnitsList(s.srcTab, alist.groups, alist.extra, alist.chunkStart[ch], alist.chunkStart[ch + 1], s.js, s.uv, s.us, s.utin, s.jl, ldj, n, u0, nu, pb.Kp, tid);
+            } else {
+              residentAssembleUnits(s.srcTab, pb.colSources, pb.colStart, solveList, s.js, s.uv, s.us, s.utin, s.jl, ldj, n, u0, nu, pb.Kp, tid);
+            }
             __syncthreads();
             F64CLK(8)
             accumulate(3 * u0, 3 * nu);
@@ -1797,7 +1858,7 @@ size_t solveF64LdsBytes(int J, int P, int U, int n, int G, int genRows) {
 
 // the resident instantiation: rows of J per chunk (a multiple of three, >= 12) next to the packed H, or 0 when it does
 // not fit (then the scratch form runs).  Two workgroups per CU while that leaves a chunk of at least twelve rows.
-static int solveF64ResidentChunkRows(int J, int P, int U, int n, int G, int genRows) {
+int solveF64ResidentChunkRows(int J, int P, int U, int n, int G, int genRows) {
   if (n <= 0 || n > 208) { // (residentFactor's panel: 16 + 4 x 48 rows)
     return 0;
   }
@@ -1831,9 +1892,11 @@ hipError_t launchSolveF64(
     double* Jg,
     double* Hg,
     double* Hg2,
-    hipStream_t stream) {
+    hipStream_t stream,
+    const F64AssemblyList& list) {
   const int genRows = pb.rowsJoint - 3 * pb.U;
   const int rcRes = solveF64ResidentChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
+  const F64AssemblyList none{nullptr, nullptr, nullptr, 0};
   if (rcRes >= 12) {
     auto e = [](size_t c) { return (c + 1) & ~size_t(1); };
     const size_t lds = (solveF64BaseDoubles(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows) + e(size_t(n) * size_t(rcRes + 1)) +
@@ -1843,7 +1906,9 @@ hipError_t launchSolveF64(
     if (rc != hipSuccess) {
       return rc;
     }
-    hipLaunchKernelGGL(solveF64Kernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, nullptr, nullptr, Hg2, rcRes);
+    // (the list is only good for the chunking it was built for; per-instance constraint parents have none)
+    const bool useList = list.groups != nullptr && list.unitsPerChunk == rcRes / 3 && pb.instPosParent == nullptr && pb.instOriParent == nullptr;
+    hipLaunchKernelGGL(solveF64Kernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, nullptr, nullptr, Hg2, rcRes, useList ? list : none);
     return hipGetLastError();
   }
   const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
@@ -1858,7 +1923,7 @@ hipError_t launchSolveF64(
     }
   }
   hipLaunchKernelGGL(
-      solveF64Kernel<false>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, Hg2, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows));
+      solveF64Kernel<false>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, Hg2, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows), none);
   return hipGetLastError();
 }
 

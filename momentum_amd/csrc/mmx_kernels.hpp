@@ -193,6 +193,19 @@ hipError_t launchFusedSolve(
 // double-precision solve (mmx_f64.hip)
 size_t solveF64LdsBytes(int J, int P, int U, int n, int G = 0, int genRows = 0);
 bool solveF64IsResident(int J, int P, int U, int n, int G = 0, int genRows = 0); // the system stays in LDS: no J / H scratch is read or written
+// rows of J the resident form assembles per chunk (a multiple of twelve; 0: the scratch form runs)
+int solveF64ResidentChunkRows(int J, int P, int U, int n, int G = 0, int genRows = 0);
+// The resident form's assembly list (batch-shared, iteration-invariant; built on the host, mmx_capi.hip): per chunk of
+// units the entries (column, unit) of J that have an applicable source at all -- one in six on the 72-joint rig -- each
+// with the indices of those sources in the kernel's packed source table.  groups[g] = {column | unit-in-chunk << 12 |
+// count << 18, count == 1 ? the source : offset into extra}; chunkStart[chunk] .. chunkStart[chunk + 1] the chunk's groups.
+// Null pointers: the kernel tests every (column, unit) pair itself.
+struct F64AssemblyList {
+  const uint2* groups;
+  const int32_t* extra;
+  const int32_t* chunkStart;
+  int32_t unitsPerChunk; // the chunking the list was built for (must equal the launch's)
+};
 hipError_t launchSolveF64(
     const RigDev& rig,
     const ProblemDev& pb,
@@ -204,7 +217,8 @@ hipError_t launchSolveF64(
     double* Jg,
     double* Hg,
     double* Hg2, // second [B][n][n] scratch, MMX_STEP_TRUST_REGION only (else null)
-    hipStream_t stream);
+    hipStream_t stream,
+    const F64AssemblyList& list = F64AssemblyList{nullptr, nullptr, nullptr, 0});
 
 size_t fkJacobianLdsBytes(int J, int P, int U);
 // store-only counterpart of the J-assembly kernel (profiling aid; see storePatternKernel)
