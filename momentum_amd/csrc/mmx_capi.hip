@@ -2327,9 +2327,10 @@ int32_t buildF64AssemblyList(mmx_problem* pb, int32_t uc) {
     }
   }
   std::vector<uint32_t> groups; // two words per group
-  std::vector<int32_t> extra, chunkStart;
+  std::vector<int32_t> extra, chunkStart, blockMasks;
   for (int32_t u0 = 0; u0 < U; u0 += uc) {
     chunkStart.push_back(int32_t(groups.size() / 2));
+    blockMasks.push_back(0);
     for (int32_t u = u0; u < std::min(U, u0 + uc); ++u) {
       const bool isPoint = u < pb->Kp;
       for (int32_t c = 0; c < n; ++c) {
@@ -2357,12 +2358,14 @@ int32_t buildF64AssemblyList(mmx_problem* pb, int32_t uc) {
         if (count == 1) {
           extra.resize(extraAt); // (a single source rides in the group word)
         }
+        blockMasks.back() |= int32_t(1u << std::min(c >> 4, 31)); // (blocks beyond 31 share the last bit: n <= 208 has 13)
         groups.push_back(uint32_t(c) | uint32_t(u - u0) << 12 | uint32_t(count) << 18);
         groups.push_back(uint32_t(count == 1 ? first : int32_t(extraAt)));
       }
     }
   }
   chunkStart.push_back(int32_t(groups.size() / 2));
+  chunkStart.insert(chunkStart.end(), blockMasks.begin(), blockMasks.end()); // [chunks + 1 ..]: the chunks' block masks
   if (groups.empty()) {
     groups.assign(2, 0u);
   }

@@ -705,6 +705,7 @@ __device__ __noinline__ void residentUnitsNormalEquations(
   const int NB = (n + 15) >> 4, T = NB * (NB + 1) / 2, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, k = lane >> 4;
   int offA[kTW], offB[kTW]; // LDS offsets of the lane's operands of tile q (doubles)
+  uint32_t tileBlocks[kTW]; // 1 << I | 1 << J of tile q
   v4d acc[kTW];
 #pragma unroll
   for (int q = 0; q < kTW; ++q) {
@@ -719,13 +720,17 @@ __device__ __noinline__ void residentUnitsNormalEquations(
     const int Jc = t - I * (I + 1) / 2;
     offA[q] = (16 * I + i < n ? 16 * I + i : n - 1) * ldj + k;
     offB[q] = (16 * Jc + i < n ? 16 * Jc + i : n - 1) * ldj + k;
+    tileBlocks[q] = (1u << I) | (1u << Jc);
     acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
   }
+  const int numChunks = (U + uc - 1) / uc;
   for (int u0 = 0; u0 < U; u0 += uc) {
     const int nu = U - u0 < uc ? U - u0 : uc;
     __syncthreads(); // (the previous chunk has been consumed)
+    uint32_t blockMask = 0xffffffffu; // column blocks with an entry in this chunk (all, without the list)
     if (list.groups != nullptr && srcTab != nullptr) {
       const int ch = u0 / uc;
+      blockMask = uint32_t(list.chunkStart[numChunks + 1 + ch]);
       residentAssembleUnitsList(srcTab, list.groups, list.extra, list.chunkStart[ch], list.chunkStart[ch + 1], js, uv, us, utin, jl, ldj, n, u0, nu, Kp, tid);
     } else {
       residentAssembleUnits(srcTab, colSources, colStart, solveList, js, uv, us, utin, jl, ldj, n, u0, nu, Kp, tid);
@@ -735,6 +740,9 @@ __device__ __noinline__ void residentUnitsNormalEquations(
     const ldsd* urc = ur + 3 * u0;
     // g on the two waves with the fewer tiles (wave 0 owns the 4 q-th tiles: one more whenever T is not a multiple of four)
     for (int c = tid - 128; c >= 0 && c < n; c += 128) {
+      if ((blockMask >> (c >> 4) & 1u) == 0u) {
+        continue; // (the column is zero in this chunk)
+      }
       const ldsd* col = jl + c * ldj;
       double a = g[c];
       for (int r = 0; r < rows4; r += 4) { // four rows per trip: eight reads in flight (the pad rows of jl are zero)
@@ -752,7 +760,13 @@ __device__ __noinline__ void residentUnitsNormalEquations(
       if (wave + 4 * q >= T) {
         break;
       }
-      const bool two = q + 1 < kTW && wave + 4 * (q + 1) < T;
+      // a tile whose row block or column block has no entry in this chunk gets nothing from it: J^T J over zero columns
+      const bool need0 = (tileBlocks[q] & ~blockMask) == 0u;
+      const bool need1 = q + 1 < kTW && wave + 4 * (q + 1) < T && (tileBlocks[q + 1 < kTW ? q + 1 : q] & ~blockMask) == 0u;
+      if (!need0 && !need1) {
+        continue;
+      }
+      const bool two = need1;
       const ldsd *pa0 = jl + offA[q], *pb0 = jl + offB[q];
       const ldsd *pa1 = jl + offA[q + 1 < kTW ? q + 1 : q], *pb1 = jl + offB[q + 1 < kTW ? q + 1 : q];
       v4d c0 = acc[q], c1 = acc[q + 1 < kTW ? q + 1 : q];
@@ -766,7 +780,9 @@ __device__ __noinline__ void residentUnitsNormalEquations(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (s0 + e < steps) {
-            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], c0, 0, 0, 0);
+            if (need0) {
+              c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], c0, 0, 0, 0);
+            }
             if (two) {
               c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b1[e], c1, 0, 0, 0);
             }

@@ -203,7 +203,8 @@ int solveF64ResidentChunkRows(int J, int P, int U, int n, int G = 0, int genRows
 struct F64AssemblyList {
   const uint2* groups;
   const int32_t* extra;
-  const int32_t* chunkStart;
+  const int32_t* chunkStart; // [chunks + 1], then [chunks] the chunk's BLOCK MASK: bit I set when some entry of the chunk lies in
+                             // the 16-column block I -- a tile of H whose row or column block is empty in a chunk gets nothing from it
   int32_t unitsPerChunk; // the chunking the list was built for (must equal the launch's)
 };
 hipError_t launchSolveF64(
