@@ -580,9 +580,11 @@ __device__ __noinline__ void residentAssembleUnitsList(
     const ldsi* srcTab, const uint2* __restrict__ groups, const int32_t* __restrict__ extra, int g0, int g1, const ldsd* js, const ldsd* uv,
     const ldsd* us, const ldsi* utin, ldsd* jl, int ldj, int n, int u0, int nu, int Kp, int tid) {
   const int rows4 = (3 * nu + 3) & ~3;
-  for (int idx = tid; idx < n * rows4; idx += 256) {
-    const int c = idx / rows4;
-    jl[c * ldj + (idx - c * rows4)] = 0.0;
+  for (int c = tid >> 2; c < n; c += 64) { // four threads per column (no division by the runtime row count)
+    ldsd* col = jl + c * ldj;
+    for (int r = tid & 3; r < rows4; r += 4) {
+      col[r] = 0.0;
+    }
   }
   __syncthreads();
   const ldsi* rec = srcTab + n + 1;
