@@ -732,6 +732,31 @@ int32_t mmx_problem_tile_structure(mmx_problem* problem, uint32_t* row_mask, uin
  *     steps must hold 1 + 4 * 32 words.  Host-only bookkeeping (additive in ABI 9).
  */
 int32_t mmx_host_tile_level_schedule(int32_t n, const uint8_t* related, int32_t* steps);
+/*
+ *   mmx_host_f64_assembly_list: what mmx_solve_f64 builds once per problem for its resident form -- per chunk of
+ *     units_per_chunk constraint vectors (num_pos points, then three per orientation constraint) the entries (column c of
+ *     solve_list, unit) of J that have an applicable source, with those sources' indices in the kernel's packed table
+ *     (prefix sums of the columns' source counts in solve_list order + position in the column).  groups: two words per
+ *     entry, c | unit-in-chunk << 12 | count << 18 and (count == 1 ? the source index : offset into extra);
+ *     chunk_start: [chunks + 1] first group of a chunk, then [chunks] the chunk's mask of 16-column blocks with an entry.
+ *     In: *num_groups / *num_extra = capacities of groups (in entries) / extra; out: the sizes (arrays are filled when
+ *     they fit; call with null arrays to query).  chunk_start must hold 2 * chunks + 1 words.  Host-only (additive in ABI 9).
+ */
+int32_t mmx_host_f64_assembly_list(
+    const mmx_rig_desc* desc,
+    const int32_t* solve_list,
+    int32_t n,
+    const int32_t* pos_parent,
+    int32_t num_pos,
+    const int32_t* ori_parent,
+    int32_t num_ori,
+    int32_t units_per_chunk,
+    uint32_t* groups,
+    int32_t* num_groups,
+    int32_t* extra,
+    int32_t* num_extra,
+    int32_t* chunk_start,
+    int32_t* num_chunks);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_constraints_sized", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
     "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_eval_skeleton_state_host", "mmx_host_tables", "mmx_debug_fused_normal_equations", "mmx_debug_tree_normal_equations",
-    "mmx_host_elimination_order", "mmx_host_tile_structure", "mmx_host_tile_level_schedule", "mmx_problem_tile_structure",
+    "mmx_host_elimination_order", "mmx_host_tile_structure", "mmx_host_tile_level_schedule", "mmx_host_f64_assembly_list", "mmx_problem_tile_structure",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
     "mmx_comm_all_reduce_norms", "mmx_comm_all_reduce_norms_host", "mmx_residual_norms", "mmx_comm_destroy",
 ]  # fmt: skip
@@ -172,6 +172,35 @@ def host_tile_level_schedule(related: np.ndarray):
     for s in range(int(words[0])):
         steps.append([(int(w) & 0xff, (int(w) >> 8) & 0xf, (int(w) >> 12) & 0xf) for w in words[1 + 4 * s : 5 + 4 * s] if w >= 0])
     return steps
+
+
+def host_f64_assembly_list(rig: Rig, solve_list, pos_parent, ori_parent, units_per_chunk: int):
+    """mmx_solve_f64's assembly list (mmx_host_f64_assembly_list): list of chunks, a chunk = dict(block_mask, entries) with
+    entries = list of (column, unit in chunk, [source indices])."""
+    sl = np.ascontiguousarray(solve_list, dtype=np.int32)
+    pp = np.ascontiguousarray(pos_parent, dtype=np.int32)
+    op = np.ascontiguousarray(ori_parent, dtype=np.int32)
+    d = rig.desc()
+    ng, ne, nc = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    i32p = C.POINTER(C.c_int32)
+    args = lambda g, e, cs: (C.byref(d), as_ptr(sl, C.c_int32), C.c_int32(len(sl)), as_ptr(pp, C.c_int32), C.c_int32(len(pp)), as_ptr(op, C.c_int32),
+                             C.c_int32(len(op)), C.c_int32(units_per_chunk), g, C.byref(ng), e, C.byref(ne), cs, C.byref(nc))  # fmt: skip
+    f = lib().mmx_host_f64_assembly_list
+    f.restype = C.c_int32
+    _check(f(*args(None, None, None)))
+    groups = np.zeros(2 * max(ng.value, 1), np.uint32)
+    extra = np.zeros(max(ne.value, 1), np.int32)
+    cstart = np.zeros(2 * nc.value + 1, np.int32)
+    _check(f(*args(groups.ctypes.data_as(C.POINTER(C.c_uint32)), extra.ctypes.data_as(i32p), cstart.ctypes.data_as(i32p))))
+    chunks = []
+    for ch in range(nc.value):
+        entries = []
+        for g in range(cstart[ch], cstart[ch + 1]):
+            w0, w1 = int(groups[2 * g]), int(groups[2 * g + 1])
+            c, ul, count = w0 & 0xfff, (w0 >> 12) & 0x3f, w0 >> 18
+            entries.append((c, ul, [w1] if count == 1 else [int(x) for x in extra[w1 : w1 + count]]))
+        chunks.append(dict(block_mask=int(cstart[nc.value + 1 + ch]), entries=entries))
+    return chunks
 
 
 def _stream_ptr() -> C.c_void_p:

@@ -1023,6 +1023,70 @@ int32_t mmx_host_tile_level_schedule(int32_t n, const uint8_t* related, int32_t*
   return MMX_OK;
 }
 
+int32_t mmx_host_f64_assembly_list(
+    const mmx_rig_desc* desc,
+    const int32_t* solve_list,
+    int32_t n,
+    const int32_t* pos_parent,
+    int32_t num_pos,
+    const int32_t* ori_parent,
+    int32_t num_ori,
+    int32_t units_per_chunk,
+    uint32_t* groups,
+    int32_t* num_groups,
+    int32_t* extra,
+    int32_t* num_extra,
+    int32_t* chunk_start,
+    int32_t* num_chunks) {
+  if (n < 0 || num_pos < 0 || num_ori < 0 || units_per_chunk <= 0 || units_per_chunk > 64 || (n > 0 && solve_list == nullptr) ||
+      (num_pos > 0 && pos_parent == nullptr) || (num_ori > 0 && ori_parent == nullptr)) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_host_f64_assembly_list: sizes / pointers");
+  }
+  mmx::HostTables t;
+  std::string err;
+  const int32_t rc = mmx::buildHostTables(desc, nullptr, t, err);
+  if (rc != MMX_OK) {
+    return fail(rc, err);
+  }
+  for (int32_t i = 0; i < n; ++i) {
+    if (solve_list[i] < 0 || solve_list[i] >= t.P) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_host_f64_assembly_list: parameter index out of range");
+    }
+  }
+  for (int32_t i = 0; i < num_pos + num_ori; ++i) {
+    const int32_t j = i < num_pos ? pos_parent[i] : ori_parent[i - num_pos];
+    if (j < 0 || j >= t.J) {
+      return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_host_f64_assembly_list: joint index out of range");
+    }
+  }
+  mmx::F64AssemblyListHost h;
+  if (!mmx::buildF64AssemblyListHost(t, std::vector<int32_t>(solve_list, solve_list + n), pos_parent, num_pos, ori_parent, num_ori, units_per_chunk, h)) {
+    return fail(MMX_ERR_UNSUPPORTED, "mmx_host_f64_assembly_list: more than 8191 sources of one column apply to one constraint");
+  }
+  const int32_t chunks = (num_pos + 3 * num_ori + units_per_chunk - 1) / units_per_chunk;
+  // sizes first (null arrays: a query), then the arrays when the caller's capacities (passed in the counters) suffice
+  const int32_t capG = num_groups ? *num_groups : 0, capE = num_extra ? *num_extra : 0;
+  if (num_groups) {
+    *num_groups = int32_t(h.groups.size() / 2);
+  }
+  if (num_extra) {
+    *num_extra = int32_t(h.extra.size());
+  }
+  if (num_chunks) {
+    *num_chunks = chunks;
+  }
+  if (groups != nullptr && capG >= int32_t(h.groups.size() / 2)) {
+    std::copy(h.groups.begin(), h.groups.end(), groups);
+  }
+  if (extra != nullptr && capE >= int32_t(h.extra.size())) {
+    std::copy(h.extra.begin(), h.extra.end(), extra);
+  }
+  if (chunk_start != nullptr) {
+    std::copy(h.chunkStart.begin(), h.chunkStart.end(), chunk_start); // [2 chunks + 1]
+  }
+  return MMX_OK;
+}
+
 int32_t mmx_problem_tile_structure(mmx_problem* pb, uint32_t* row_mask, uint32_t* col_mask, int32_t* num_blocks, int32_t* num_tiles, int64_t* products) {
   if (pb == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "problem is null");
@@ -2305,76 +2369,21 @@ static int32_t solveImpl(
 }
 
 namespace {
-// mmx::F64AssemblyList for chunks of `uc` units: every entry (solved column, unit) of J with an applicable source --
-// the source's joint an ancestor-or-self of the unit's joint (DFS interval) and, for translation / scale dofs, a point
-// unit (joint_error_function-inl.h:248-291) -- with the indices of those sources in the kernel's packed table (columns in
-// solve-list order, a column's sources in colSources order: the prefix sums the kernel forms itself).
+// mmx::F64AssemblyList for chunks of `uc` units (mmx::buildF64AssemblyListHost), uploaded
 int32_t buildF64AssemblyList(mmx_problem* pb, int32_t uc) {
-  const mmx::HostTables& t = pb->tables;
-  const int32_t n = pb->solveN, U = pb->U;
-  std::vector<int32_t> prefix(size_t(n) + 1, 0);
-  for (int32_t c = 0; c < n; ++c) {
-    const int32_t p = pb->solveListF64[size_t(c)];
-    prefix[size_t(c) + 1] = prefix[size_t(c)] + (t.colStart[size_t(p) + 1] - t.colStart[size_t(p)]);
+  mmx::F64AssemblyListHost h;
+  if (!mmx::buildF64AssemblyListHost(pb->tables, pb->solveListF64, pb->posParent.data(), pb->Kp, pb->oriParent.data(), pb->Ko, uc, h)) {
+    return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: more than 8191 sources of one column apply to one constraint");
   }
-  std::vector<int32_t> unitTin(size_t(std::max(U, 1)));
-  for (int32_t c = 0; c < pb->Kp; ++c) {
-    unitTin[size_t(c)] = t.tin[size_t(pb->posParent[size_t(c)])];
+  if (h.groups.empty()) {
+    h.groups.assign(2, 0u);
   }
-  for (int32_t c = 0; c < pb->Ko; ++c) {
-    for (int k = 0; k < 3; ++k) {
-      unitTin[size_t(pb->Kp + 3 * c + k)] = t.tin[size_t(pb->oriParent[size_t(c)])];
-    }
+  if (h.extra.empty()) {
+    h.extra.push_back(0);
   }
-  std::vector<uint32_t> groups; // two words per group
-  std::vector<int32_t> extra, chunkStart, blockMasks;
-  for (int32_t u0 = 0; u0 < U; u0 += uc) {
-    chunkStart.push_back(int32_t(groups.size() / 2));
-    blockMasks.push_back(0);
-    for (int32_t u = u0; u < std::min(U, u0 + uc); ++u) {
-      const bool isPoint = u < pb->Kp;
-      for (int32_t c = 0; c < n; ++c) {
-        const int32_t p = pb->solveListF64[size_t(c)];
-        int32_t count = 0, first = -1;
-        const size_t extraAt = extra.size();
-        for (int32_t e = t.colStart[size_t(p)]; e < t.colStart[size_t(p) + 1]; ++e) {
-          const mmx::ColumnSource& cs = t.colSources[size_t(e)];
-          const bool rot = cs.dof >= 3 && cs.dof < 6;
-          if (cs.tin <= unitTin[size_t(u)] && unitTin[size_t(u)] < cs.tout && (rot || isPoint)) {
-            const int32_t k = prefix[size_t(c)] + (e - t.colStart[size_t(p)]);
-            if (count == 0) {
-              first = k;
-            }
-            extra.push_back(k);
-            ++count;
-          }
-        }
-        if (count == 0) {
-          continue;
-        }
-        if (count > 8191) {
-          return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: more than 8191 sources of one column apply to one constraint");
-        }
-        if (count == 1) {
-          extra.resize(extraAt); // (a single source rides in the group word)
-        }
-        blockMasks.back() |= int32_t(1u << std::min(c >> 4, 31)); // (blocks beyond 31 share the last bit: n <= 208 has 13)
-        groups.push_back(uint32_t(c) | uint32_t(u - u0) << 12 | uint32_t(count) << 18);
-        groups.push_back(uint32_t(count == 1 ? first : int32_t(extraAt)));
-      }
-    }
-  }
-  chunkStart.push_back(int32_t(groups.size() / 2));
-  chunkStart.insert(chunkStart.end(), blockMasks.begin(), blockMasks.end()); // [chunks + 1 ..]: the chunks' block masks
-  if (groups.empty()) {
-    groups.assign(2, 0u);
-  }
-  if (extra.empty()) {
-    extra.push_back(0);
-  }
-  MMX_HIP(upload(pb->dF64Groups, groups));
-  MMX_HIP(upload(pb->dF64Extra, extra));
-  MMX_HIP(upload(pb->dF64ChunkStart, chunkStart));
+  MMX_HIP(upload(pb->dF64Groups, h.groups));
+  MMX_HIP(upload(pb->dF64Extra, h.extra));
+  MMX_HIP(upload(pb->dF64ChunkStart, h.chunkStart));
   pb->f64ListUnitsPerChunk = uc;
   return MMX_OK;
 }

@@ -460,4 +460,65 @@ TileMasks eliminationTileMasks(int32_t n, const std::vector<uint8_t>& related, b
   return m;
 }
 
+bool buildF64AssemblyListHost(
+    const HostTables& t, const std::vector<int32_t>& solveList, const int32_t* posParent, int32_t Kp, const int32_t* oriParent, int32_t Ko,
+    int32_t uc, F64AssemblyListHost& out) {
+  const int32_t n = int32_t(solveList.size()), U = Kp + 3 * Ko;
+  std::vector<int32_t> prefix(size_t(n) + 1, 0);
+  for (int32_t c = 0; c < n; ++c) {
+    const int32_t p = solveList[size_t(c)];
+    prefix[size_t(c) + 1] = prefix[size_t(c)] + (t.colStart[size_t(p) + 1] - t.colStart[size_t(p)]);
+  }
+  std::vector<int32_t> unitTin(size_t(std::max(U, 1)));
+  for (int32_t c = 0; c < Kp; ++c) {
+    unitTin[size_t(c)] = t.tin[size_t(posParent[size_t(c)])];
+  }
+  for (int32_t c = 0; c < Ko; ++c) {
+    for (int k = 0; k < 3; ++k) {
+      unitTin[size_t(Kp + 3 * c + k)] = t.tin[size_t(oriParent[size_t(c)])];
+    }
+  }
+  out.groups.clear(), out.extra.clear(), out.chunkStart.clear();
+  std::vector<int32_t> blockMasks;
+  for (int32_t u0 = 0; u0 < U; u0 += uc) {
+    out.chunkStart.push_back(int32_t(out.groups.size() / 2));
+    blockMasks.push_back(0);
+    for (int32_t u = u0; u < std::min(U, u0 + uc); ++u) {
+      const bool isPoint = u < Kp;
+      for (int32_t c = 0; c < n; ++c) {
+        const int32_t p = solveList[size_t(c)];
+        int32_t count = 0, first = -1;
+        const size_t extraAt = out.extra.size();
+        for (int32_t e = t.colStart[size_t(p)]; e < t.colStart[size_t(p) + 1]; ++e) {
+          const ColumnSource& cs = t.colSources[size_t(e)];
+          const bool rot = cs.dof >= 3 && cs.dof < 6;
+          if (cs.tin <= unitTin[size_t(u)] && unitTin[size_t(u)] < cs.tout && (rot || isPoint)) {
+            const int32_t k = prefix[size_t(c)] + (e - t.colStart[size_t(p)]);
+            if (count == 0) {
+              first = k;
+            }
+            out.extra.push_back(k);
+            ++count;
+          }
+        }
+        if (count == 0) {
+          continue;
+        }
+        if (count > 8191) {
+          return false;
+        }
+        if (count == 1) {
+          out.extra.resize(extraAt); // (a single source rides in the group word)
+        }
+        blockMasks.back() |= int32_t(1u << std::min(c >> 4, 31)); // (blocks beyond 31 share the last bit: n <= 208 has 13)
+        out.groups.push_back(uint32_t(c) | uint32_t(u - u0) << 12 | uint32_t(count) << 18);
+        out.groups.push_back(uint32_t(count == 1 ? first : int32_t(extraAt)));
+      }
+    }
+  }
+  out.chunkStart.push_back(int32_t(out.groups.size() / 2));
+  out.chunkStart.insert(out.chunkStart.end(), blockMasks.begin(), blockMasks.end());
+  return true;
+}
+
 } // namespace mmx

@@ -123,6 +123,21 @@ struct TileMasks {
 };
 TileMasks eliminationTileMasks(int32_t n, const std::vector<uint8_t>& related /* [n][n], lower triangle used */, bool dense);
 
+// mmx_solve_f64's assembly list (mmx::F64AssemblyList, mmx_kernels.hpp) for chunks of `unitsPerChunk` units: every entry
+// (solved column, unit) of J with an applicable source -- the source's joint an ancestor-or-self of the unit's joint (DFS
+// interval) and, for translation / scale dofs, a point unit (joint_error_function-inl.h:248-291) -- with the indices of
+// those sources in the kernel's packed table (columns in solve-list order, a column's sources in colSources order).
+// groups: two words per entry, column | unit-in-chunk << 12 | count << 18 and (count == 1 ? the source : offset into
+// extra); chunkStart: [chunks + 1] first group of a chunk, then [chunks] the chunk's mask of 16-column blocks with an entry.
+// Units: Kp position constraints (points), then three per orientation constraint.  False when a count does not fit.
+struct F64AssemblyListHost {
+  std::vector<uint32_t> groups;
+  std::vector<int32_t> extra, chunkStart;
+};
+bool buildF64AssemblyListHost(
+    const HostTables& t, const std::vector<int32_t>& solveList, const int32_t* posParent, int32_t Kp, const int32_t* oriParent, int32_t Ko,
+    int32_t unitsPerChunk, F64AssemblyListHost& out);
+
 // Validates the descriptor the way the reference's constructors / MT_CHECKs do
 // (skeleton.cpp:16-22 parent-before-child; parameter_transform.cpp:112-121 sizes).
 // Returns MMX_OK or an error code with a message in `err`.

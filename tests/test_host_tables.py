@@ -328,3 +328,43 @@ def test_level_schedule_of_random_patterns(seed):
             rel[j, i] = 1
     _check_level_schedule(np.tril(rel, -1))
     _check_level_schedule(np.tril(np.ones((n, n), np.uint8), -1))  # dense: one column per step
+
+
+@pytest.mark.parametrize("name,uc", [("humanoid72", 16), ("test_character_8", 5), ("rig300", 16)])
+def test_f64_assembly_list_against_a_numpy_restatement(orc, name, uc):
+    """mmx_solve_f64's assembly list (mmx_host_f64_assembly_list / buildF64AssemblyListHost): exactly the entries (column,
+    unit) of J that have an applicable source -- the source's joint an ancestor-or-self of the unit's joint; translation and
+    scale dofs only for points (joint_error_function-inl.h:248-291) --, each with its sources' positions in the packed
+    table, and per chunk the mask of 16-column blocks that have an entry.  Restated from the parameter transform and the
+    ancestor matrix."""
+    rig = RIGS[name]() if name in RIGS else make_test_character(8)
+    J, P = rig.num_joints, rig.num_params
+    anc = orc.ancestor_matrix(rig).astype(bool)  # anc[a, j]: a is an ancestor-or-self of j
+    rng = np.random.default_rng(3)
+    pos_parent = rng.integers(0, J, size=min(J, 21)).astype(np.int32)
+    ori_parent = rng.integers(0, J, size=min(J, 9)).astype(np.int32)
+    solve_list = np.sort(rng.choice(P, size=max(1, (3 * P) // 4), replace=False)).astype(np.int32)
+    chunks = capi.host_f64_assembly_list(rig, solve_list, pos_parent, ori_parent, uc)
+    # sources of a parameter: the non-zeros of its column of the parameter transform, in row order (= colSources order)
+    src = [[] for _ in range(P)]
+    for r in range(7 * J):
+        for k in range(rig.pt_outer[r], rig.pt_outer[r + 1]):
+            src[int(rig.pt_inner[k])].append((r // 7, r % 7))
+    prefix = np.concatenate([[0], np.cumsum([len(src[p]) for p in solve_list])])
+    Kp, U = len(pos_parent), len(pos_parent) + 3 * len(ori_parent)
+    unit_joint = [int(pos_parent[u]) if u < Kp else int(ori_parent[(u - Kp) // 3]) for u in range(U)]
+    assert len(chunks) == (U + uc - 1) // uc
+    for ch, chunk in enumerate(chunks):
+        want, mask = [], 0
+        for ul in range(min(uc, U - ch * uc)):
+            u = ch * uc + ul
+            for c, p in enumerate(solve_list):
+                ks = []
+                for e, (joint, dof) in enumerate(src[int(p)]):
+                    if anc[joint, unit_joint[u]] and (3 <= dof < 6 or u < Kp):
+                        ks.append(int(prefix[c]) + e)
+                if ks:
+                    want.append((c, ul, ks))
+                    mask |= 1 << min(c >> 4, 31)
+        assert chunk["entries"] == want, (name, ch)
+        assert chunk["block_mask"] == mask
