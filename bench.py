@@ -69,6 +69,9 @@ EXTRA_RUNS = [
     # cannot hold: checked against the oracle's double run on the instances whose line-search decisions agree, with the
     # oracle's DOUBLE instantiation as its CPU baseline
     ("cfg2@4096 lambda=1e-5 line_search=2 dtype=f64", "cfg2", 4096, 2, 3, 1024, 1e-5, "f64"),
+    # MMX_PRECISION_AUTO at a damping where single precision loses the bound on part of the batch (profiles/r05_weak_damping.json):
+    # single precision first, the elements its precision estimate marks re-solved in double on the same stream
+    ("cfg2@4096 lambda=1e-3 precision=auto", "cfg2", 4096, 0, 6, 2048, 1e-3, "f32", 2),
     # weak damping (pymomentum's test_solver2.py value) with the batched driver's line search: on this shape -- as many
     # independent rows as solved parameters -- no single-precision Cholesky solver holds 1e-5 on theta (check.pass is
     # false by construction, the float oracle's figures stand beside it); tests/test_gpu_weak_damping.py has the table
@@ -261,35 +264,58 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n, line_search_aware=False
     return out
 
 
-def lm_decisions(db: DeviceBatch, opt, iterations, regularization, chk):
-    """LM schedule (BASELINE configs[2]): for the instances above the bound, whether the GPU run took the double run's
-    DECISIONS -- the gain ratio against 0 / 0.25 / 0.75 accepts or rejects a step and scales lambda; an instance whose ratio
-    sits on a threshold goes the other, equally valid, way in single precision (the oracle's float instantiation does, too:
-    above_bound_float_oracle_rel) and, once lambda has been scaled down the other branch, moves by percents along the
-    directions sixteen landmarks barely determine while its error agrees to six digits.  Same decisions <=> the same error at
-    every iterate (the final one = entry `iterations` of the same solve run one iteration longer) and the same accept /
-    reject pattern (a rejected step leaves the error exactly where it was); tests/test_gpu_baseline_parity.py holds every
-    same-decision instance of this batch to the bound."""
-    from momentum_amd._abi import GnOptions
-    from oracle import oracle as orc
+def lm_branch_analysis(gpu_steps, gpu_err, ref, rel, bound=PARITY_BOUND):
+    """LM schedule (BASELINE configs[2]): the GPU run's DECISIONS against the double oracle's, exactly.  Per iteration the
+    schedule decides twice on the gain ratio rho = actual / predicted decrease (the quantity TrustRegionQRT compares with its
+    thresholds, momentum/character_solver/trust_region_qr.cpp:244-268): accept iff rho > 0; lambda x lm_up iff not
+    rho >= 0.25, x lm_down iff rho > 0.75.  gpu_steps [n][K][2] = (lambda, rho) per iteration from mmx_solve_with_step_history,
+    ref = the oracle's double run with step_history.  An instance has the SAME decisions when every iteration's (accept,
+    scale class) pair agrees -- its lambda sequence is then the double run's, checked to 1e-6 -- and is held to `bound` on theta.
+    Every other instance is a BRANCH FLIP: at its first diverging iteration the two gain ratios lie on opposite sides of a
+    threshold; reported with the double run's distance to that threshold and the two ratios' difference."""
+    lam_g, rho_g = gpu_steps[..., 0], gpu_steps[..., 1]
+    lam_r, rho_r = np.asarray(ref["lambda_history"]), np.asarray(ref["gain_ratio_history"])
+    cls = lambda r: np.where(~(r >= 0.25), 0, np.where(r > 0.75, 2, 1))
+    same_it = ((rho_g > 0) == (rho_r > 0)) & (cls(rho_g) == cls(rho_r))
+    same = same_it.all(axis=1)
+    lam_ok = np.all(np.abs(lam_g - lam_r) <= 1e-6 * np.abs(lam_r), axis=1)
+    flips = np.flatnonzero(~same)
+    first = np.argmax(~same_it[flips], axis=1) if len(flips) else np.zeros(0, int)
+    rg, rr = rho_g[flips, first], rho_r[flips, first]
+    thr = np.array([0.0, 0.25, 0.75])
+    lo, hi = np.minimum(rg, rr), np.maximum(rg, rr)
+    straddled = (thr[None, :] >= lo[:, None]) & (thr[None, :] <= hi[:, None])
+    dist = np.where(straddled, np.abs(rr[:, None] - thr[None, :]), np.inf).min(axis=1) if len(flips) else np.zeros(0)
+    above = rel > bound
+    out = {
+        "instances": int(len(rel)),
+        "same_decisions": int(same.sum()),
+        "lm_branch_flips": int(len(flips)),
+        "same_decisions_lambda_sequences_equal": bool(lam_ok[same].all()) if same.any() else True,
+        "max_rel_same_decisions": float(rel[same].max()) if same.any() else None,
+        "num_above_bound": int(above.sum()),
+        "num_above_bound_with_same_decisions": int((above & same).sum()),
+        "num_above_bound_that_are_branch_flips": int((above & ~same).sum()),
+        "flips_double_rho_within_1e-3_of_threshold": int((dist <= 1e-3).sum()),
+        "flips_double_rho_within_1e-2_of_threshold": int((dist <= 1e-2).sum()),
+        "flip_max_distance_of_double_rho_to_threshold": float(dist.max()) if len(flips) else 0.0,
+        "flip_max_abs_rho_difference": float(np.abs(rg - rr).max()) if len(flips) else 0.0,
+        # (for the side file: the flips themselves)
+        "flip_instances": [int(i) for i in flips[:64]],
+        "flip_iteration": [int(i) for i in first[:64]],
+        "flip_rho_gpu": [float(x) for x in rg[:64]],
+        "flip_rho_double": [float(x) for x in rr[:64]],
+        "flip_rel_theta": [float(x) for x in rel[flips][:64]],
+        "flip_final_error_gpu_over_double": [float(a / b) if b > 0 else None for a, b in zip(gpu_err[flips, -1][:64], np.asarray(ref["error_history"])[flips, -1][:64])],
+    }
+    # pass: theta within the bound wherever the decisions are the double run's, and nothing above the bound that is not a flip
+    out["pass"] = bool(out["num_above_bound_with_same_decisions"] == 0 and out["same_decisions_lambda_sequences_equal"])
+    return out
 
-    idx = np.asarray(chk["above_bound_instances"], dtype=np.int64)
-    o11 = GnOptions.make(min_iterations=iterations + 1, max_iterations=iterations + 1, threshold=1.0, regularization=regularization, step_rule=1)
-    g = db.pb.solve(db.theta0.clone(), o11, want_history=True)
-    h = g["error_history"][idx].cpu().numpy()
-    n = int(chk["instances"])
-    cons = db.host_constraints(n).subset(idx)
-    href = orc.solve_batch(db.rig, cons, db.theta0[:n].cpu().numpy()[idx], o11, dtype="f64", nthreads=usable_cores())["error_history"]
-    same = np.all(np.abs(h - href) <= 1e-3 * np.abs(href) + 1e-7 * href[:, :1], axis=1)
-    same &= np.all((h[:, 1:] == h[:, :-1]) == (href[:, 1:] == href[:, :-1]), axis=1)
-    chk["above_bound_same_lm_decisions"] = [bool(x) for x in same[:16]]
-    chk["num_above_bound_with_the_same_lm_decisions"] = int(same.sum())
-    chk["above_bound_final_error_gpu_over_double"] = [float(a / b) if b > 0 else None for a, b in zip(h[:16, -1], href[:16, -1])]
-    chk["note"] = "LM schedule: the gain ratio's thresholds are discrete decisions; an instance on a threshold takes the other, equally valid, branch in single precision (so does the oracle's float instantiation). `pass` is the plain bound on every checked instance; num_above_bound_with_the_same_lm_decisions counts the instances above it whose ACCEPT / REJECT sequence and errors agree with the double run's -- the other decision, scaling lambda at rho = 0.25 / 0.75, leaves no trace in the error history of a converged fit (errors at the single-precision floor, 1e-7 of the initial one) yet sends the following steps along the directions sixteen landmarks barely determine: above_bound_final_error_gpu_over_double shows such an instance ending a few percent off in error and in pose (bench.lm_decisions)"
 
-
-def cpu_baseline(db: DeviceBatch, sample, options, dtype="f32"):
-    """The CPU oracle timed on the host cores (same precision as the GPU run) on the first `sample` instances of the SAME batch."""
+def cpu_baseline(db: DeviceBatch, sample, options, dtype="f32", dense_flops_per_solve=None):
+    """The CPU oracle timed on the host cores (same precision as the GPU run) on the first `sample` instances of the SAME batch.
+    Returns (compact, details): the compact part goes into the bench line, the details into the side file."""
     from oracle import oracle as orc
 
     cores = usable_cores()
@@ -305,14 +331,20 @@ def cpu_baseline(db: DeviceBatch, sample, options, dtype="f32"):
     t1 = time.perf_counter()
     orc.solve_batch(db.rig, db.host_constraints(n1), th0[:n1], options, dtype=dtype, nthreads=1)
     dt1 = time.perf_counter() - t1
-    return {
+    compact = {
         "value": sample / dt,
         "unit": "solves/s",
         "cores": cores,
+        "cores_total": os.cpu_count(),
         "kind": "port",
-        "sample": f"the first {sample} instances of the timed batch, {dtype}, oracle build: {orc.build_info()}, one solver per task over {cores} std::threads (= usable cores: affinity mask and cgroup quota; os.cpu_count() = {os.cpu_count()}; mirrors tensor_ik.cpp:127); single-thread: {n1 / dt1:.1f} solves/s",
+        "sample": f"first {sample} instances of the timed batch, {dtype}, one solver per task over {cores} threads",
         "single_thread_value": n1 / dt1,
     }
+    if dense_flops_per_solve:
+        # dense-equivalent flops of a solve x single-thread solves/s: what one core of the baseline sustains
+        compact["gflops_per_thread"] = dense_flops_per_solve * (n1 / dt1) / 1e9
+    details = dict(compact, build=orc.build_info(), note="usable cores = affinity mask and cgroup quota; mirrors tensor_ik.cpp:127 (one task per batch element)")
+    return compact, details
 
 
 def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None, comm=None, dtype="f32"):
@@ -399,38 +431,136 @@ def fused_pmc():
         return None
 
 
-def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu, regularization=0.05, dtype="f32"):
+def compact_check(chk):
+    """What the bench line keeps of a parity check (the rest goes to the side file)."""
+    if not chk:
+        return {}
+    out = {"within_bound": chk["within_bound"], "max_rel": chk["max_rel_theta_vs_oracle_f64"], "median_rel": chk["median_rel_theta_vs_oracle_f64"], "pass": chk["pass"]}
+    for k in ("pass_relaxed", "lm_branch_flips", "same_decisions", "num_above_bound_with_same_decisions", "max_rel_same_decisions",
+              "flips_double_rho_within_1e-2_of_threshold", "flip_max_abs_rho_difference"):  # fmt: skip
+        if k in chk:
+            out[k] = chk[k]
+    return out
+
+
+def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu, regularization=0.05, dtype="f32", precision=0):
+    """One side configuration: (compact entry of the bench line, details for the side file)."""
     from momentum_amd._abi import GnOptions
 
     rig, parents, _, step_rule, desc = build_rig(config)
     db = DeviceBatch(rig, parents, B, device_index, 424242, tracker=CONFIGS[config][1].endswith("+tracker"))
-    opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=regularization, step_rule=step_rule, do_line_search=line_search)
+    opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=regularization, step_rule=step_rule,
+                         do_line_search=line_search, precision=precision)  # fmt: skip
     elapsed, theta, norms = solve_loop(db, opt, steps, 1, dtype=dtype)
-    out = {
+    status = db.last_status
+    chk = parity_check(db, theta, opt, check_n, line_search_aware=line_search != 0)
+    n_solved = solved_parameters(db.pb)
+    dense_flops = dense_equivalent_flops_per_iteration(db.pb.M, n_solved, rig.num_joints) * iterations
+    details = {
         "workload": desc,
         "dtype": dtype,
         "regularization": regularization,
         "batch": B,
         "line_search": line_search,
+        "precision": ["f32", "f64", "auto"][precision],
         "step_rule": "lm_schedule" if step_rule == 1 else "gn_fixed_lambda",
         "solves_per_s": B * steps / elapsed,
         "ms_per_step": 1e3 * elapsed / steps,
         "steps": steps,
         "failed_instances": norms[2],
-        # MMX_SOLVE_DAMPING_FLOORED (include/mmx.h): instances on which the single-precision factor's damping floor exceeded
-        # the caller's lambda in some iteration -- the caller's cue to take mmx_solve_f64 (never set by the double route)
-        "damping_floored_instances": int((db.last_status & 4 != 0).sum()) if db.last_status is not None else None,
-        "check": parity_check(db, theta, opt, check_n, line_search_aware=line_search != 0),
-        "solver": factor_structure(db.pb) if dtype == "f32" else {"route": "mmx_solve_f64", "solved_parameters": solved_parameters(db.pb)},
+        # informational status bits (include/mmx.h): the factor's damping floor engaged / the precision estimate exceeded the
+        # bound / MMX_PRECISION_AUTO re-solved the element in double
+        "damping_floored_instances": int((status & 4 != 0).sum()) if status is not None else None,
+        "precision_suspect_instances": int((status & 8 != 0).sum()) if status is not None else None,
+        "escalated_f64_instances": int((status & 16 != 0).sum()) if status is not None else None,
+        "check": chk,
+        "solver": factor_structure(db.pb) if dtype == "f32" else {"route": "mmx_solve_f64", "solved_parameters": n_solved},
+        "dense_equivalent_tflops": B * steps / elapsed * dense_flops / 1e12,
     }
-    if step_rule == 1 and dtype == "f32" and out["check"] and out["check"].get("num_above_bound", 0) > 0:
-        lm_decisions(db, opt, iterations, regularization, out["check"])
+    if step_rule == 1 and dtype == "f32" and chk:
+        # the LM schedule's decisions, exactly: (lambda, rho) per iteration from the GPU against the double oracle's
+        n = int(chk["instances"])
+        g = db.pb.solve(db.theta0.clone(), opt, want_history=True, want_step_history=True)
+        from oracle import oracle as orc
+
+        ref = orc.solve_batch(db.rig, db.host_constraints(n), db.theta0[:n].cpu().numpy(), opt, dtype="f64", nthreads=usable_cores(), step_history=True)
+        th = g["theta"][:n].cpu().numpy().astype(np.float64)
+        rel = np.linalg.norm(th - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-30)
+        lm = lm_branch_analysis(g["step_history"][:n].cpu().numpy(), g["error_history"][:n].cpu().numpy(), ref, rel)
+        chk.update(lm)  # (`pass` becomes: 1e-5 wherever the decisions are the double run's)
+    compact = {
+        "solves_per_s": details["solves_per_s"],
+        "ms_per_step": details["ms_per_step"],
+        "route": details["solver"]["route"],
+        **compact_check(chk),
+    }
+    if precision == 2:
+        compact["escalated_f64"] = details["escalated_f64_instances"]
+    if dtype == "f32" and precision == 0:
+        compact["precision_suspect"] = details["precision_suspect_instances"]
+    if config == "cfg5":
+        compact["jtj_dense_equivalent_tflops"] = B * steps / elapsed * iterations * float(db.pb.M) * n_solved * n_solved / 1e12  # BASELINE.md row 5
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(db, cpu_sample, opt, dtype)
-        out["gpu_over_cpu"] = out["solves_per_s"] / out["cpu_baseline"]["value"]
+        c, d = cpu_baseline(db, cpu_sample, opt, dtype, dense_flops)
+        details["cpu_baseline"] = d
+        details["gpu_over_cpu"] = details["solves_per_s"] / c["value"]
+        compact["cpu_value"], compact["cpu_cores"], compact["gpu_over_cpu"] = c["value"], c["cores"], details["gpu_over_cpu"]
     del db
     torch.cuda.empty_cache()
-    return out
+    return compact, details
+
+
+def measure_traffic(config, B):
+    """HBM bytes per launch of the J-assembly kernel from the PMC counters, measured now: two separate rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE; no trace options beside them) over scripts/pmc_traffic.py, which launches mmx_eval_jacobian
+    on this shape a few times; unit and gfx950 correction as MI355X_MICROARCH.md's HBM section prescribes (counters in KiB-
+    like 1024-byte units here; FETCH_SIZE under-reports 2x on gfx950): bytes = 1024 x (WRITE_SIZE + 2 FETCH_SIZE).
+    None when rocprofv3 is not available or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic.py"), config, str(B)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            except Exception:
+                return None
+            per = []
+            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if "fkJacobianKernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        per.append(float(row["Counter_Value"]))
+            if not per:
+                return None
+            vals[counter] = float(np.mean(per[1:] if len(per) > 1 else per))  # (the first launch warms the L2s)
+    return 1024.0 * (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"])
+
+
+SHORT = {  # compact workload names of the bench line (the full descriptions: CONFIGS / the details file)
+    "cfg2": "BASELINE configs[1]: B x 72-joint humanoid, P=128, pos+ori on 16 landmarks (M=192), GN lambda=0.05, 10 it",
+    "cfg3": "BASELINE configs[2]: 65536 x 72-joint, LM schedule, 10 it",
+    "cfg4": "BASELINE configs[3]: 32768 x 72-joint per GPU (weak scaling), GN lambda=0.05, 10 it",
+    "cfg5": "BASELINE configs[4]: 8192 x 300-joint rig, P=300, M=900, GN lambda=0.05, 10 it",
+}
+
+
+def round_floats(x, digits=6):
+    """Floats of the bench line to `digits` significant digits (a compact line; nothing is compared at more)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: round_floats(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [round_floats(v, digits) for v in x]
+    return x
 
 
 def main() -> None:
@@ -446,9 +576,12 @@ def main() -> None:
     ap.add_argument("--check-instances", type=int, default=1024, help="distinct instances of the timed batch re-solved by the oracle (0 = skip)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the other BASELINE configurations (N = 1 default run reports them)")
     ap.add_argument("--jac-launches", type=int, default=20)
+    ap.add_argument("--measure-traffic", action="store_true", help="measure roofline.traffic in this run (rocprofv3 --pmc over a child process; adds about a minute)")
     ap.add_argument("--line-search", type=int, default=0, choices=[0, 1, 2], help="MMX_LINE_SEARCH_*: 0 none (the BASELINE metric), 1 GaussNewtonSolverT's rule, 2 the rule of the batched driver's solvers (SubsetGN / GN-QR)")
     ap.add_argument("--lambda", dest="regularization", type=float, default=0.05, help="GaussNewtonSolverOptions::regularization (the BASELINE metric: 0.05)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64: mmx_solve_f64 (SolverT<double>; built for exactness, see DESIGN.md)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64", "auto"], help="mmx_gn_options::precision of mmx_solve (auto: the elements the single-precision solve marks are re-solved in double)")
+    ap.add_argument("--details", default="", help="where the details of the run go (default gpurun_out/bench_details.json)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
     args = ap.parse_args()
 
@@ -488,7 +621,8 @@ def main() -> None:
     seed = 12345 + 1000003 * rank  # every rank solves different instances (its shard of the batch)
     db = DeviceBatch(rig, parents, B, local_rank, seed, tracker=CONFIGS[args.config][1].endswith("+tracker"))
     pb, theta_star = db.pb, db.theta_star
-    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=args.regularization, step_rule=step_rule, do_line_search=args.line_search)
+    opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=args.regularization, step_rule=step_rule,
+                         do_line_search=args.line_search, precision=["f32", "f64", "auto"].index(args.precision))  # fmt: skip
     dev = pb.device
     elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist, comm, args.dtype)
     # per-rank rates (each rank's own clock around the same K steps) next to the aggregate, which uses the slowest rank's time
@@ -517,13 +651,20 @@ def main() -> None:
     jac_ms_recorded = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     bytes_per_launch = B * algorithmic_bytes_per_instance(M, P, Kp_, Ko_)
     achieved = bytes_per_launch / (jac_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic of the kernel: measured in THIS run when --measure-traffic is given (two rocprofv3 --pmc passes over a child
+    # process that launches the same kernel on the same shape, scripts/pmc_traffic.py); otherwise the committed pass of the
+    # same shape (profiles/pmc_jacobian.json), and the line says which
+    traffic, traffic_source = None, None
+    if args.measure_traffic and rank == 0 and world == 1:
+        traffic = measure_traffic(args.config, B)
+        traffic_source = "rocprofv3 --pmc in this run" if traffic is not None else None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_jacobian.json")
-    if os.path.exists(pmc_path):
+    if traffic is None and os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path))
             if pm.get("batch") == B and pm.get("config") == args.config:
                 traffic = pm.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_jacobian.json (committed rocprofv3 --pmc pass of this shape)"
         except Exception:
             traffic = None
     del jac
@@ -554,25 +695,32 @@ def main() -> None:
             sp_ms = float(np.mean([pb.store_pattern_kernel_ms(fill) for _ in range(5)]))
             extra["store_pattern_gbs"] = B * 4 * M * P / (sp_ms * 1e-3) / 1e9
         del fill
-        BL = 32768
-        if args.config == "cfg2" and B < BL:
-            dbL = DeviceBatch(rig, parents, BL, local_rank, seed + 1)
-            jacL = torch.empty((BL, P, M), dtype=torch.float32, device=dev)
-            resL = torch.empty((BL, M), dtype=torch.float32, device=dev)
-            errL = torch.empty((BL,), dtype=torch.float64, device=dev)
-            for _ in range(2):
-                dbL.pb.eval_jacobian(dbL.theta_star, jacL, resL, errL)
-            msL = float(np.mean([dbL.pb.eval_jacobian_kernel_ms(dbL.theta_star, jacL, resL, errL) for _ in range(5)]))
-            gbsL = BL * algorithmic_bytes_per_instance(M, P, Kp_, Ko_) / (msL * 1e-3) / 1e9
-            extra["at_batch_32768"] = {"achieved": gbsL, "frac": gbsL / HBM_PEAK_GBS, "ms_per_launch": msL}
-            del jacL, resL, errL, dbL
-            torch.cuda.empty_cache()
+        if args.config == "cfg2":
+            for BL in (32768, 65536):  # the weak-scaling shard of BASELINE configs[3] and north_star's target size
+                if B >= BL:
+                    continue
+                dbL = DeviceBatch(rig, parents, BL, local_rank, seed + 1)
+                jacL = torch.empty((BL, P, M), dtype=torch.float32, device=dev)
+                resL = torch.empty((BL, M), dtype=torch.float32, device=dev)
+                errL = torch.empty((BL,), dtype=torch.float64, device=dev)
+                for _ in range(2):
+                    dbL.pb.eval_jacobian(dbL.theta_star, jacL, resL, errL)
+                msL = float(np.mean([dbL.pb.eval_jacobian_kernel_ms(dbL.theta_star, jacL, resL, errL) for _ in range(5)]))
+                gbsL = BL * algorithmic_bytes_per_instance(M, P, Kp_, Ko_) / (msL * 1e-3) / 1e9
+                extra[f"at_batch_{BL}"] = {"achieved": gbsL, "frac": gbsL / HBM_PEAK_GBS, "ms_per_launch": msL}
+                del jacL, resL, errL, dbL
+                torch.cuda.empty_cache()
 
     if rank == 0:
         solves = float(B) * world * args.steps
         n_solved = solved_parameters(pb)
         dense_flops = dense_equivalent_flops_per_iteration(M, n_solved, rig.num_joints) * args.iterations
         per_gpu_solves_per_s = float(B) * args.steps / elapsed
+        status = db.last_status
+        # ONE compact JSON line (the driver keeps its tail): per configuration the rate, the parity figures and the CPU figure;
+        # everything else -- above-bound arrays, branch-flip lists, oracle build sweeps, notes -- goes to `details`, written to
+        # gpurun_out/bench_details.json (or --details) and summarised on stderr.
+        details = {"workload": desc, "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMX_")}, "configs": {}}
         line = {
             "metric": f"character IK solves/sec ({rig.num_joints}-joint, {args.iterations} GN iters)",
             "value": solves / elapsed,
@@ -587,70 +735,81 @@ def main() -> None:
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": desc,
+                "workload": SHORT.get(args.config, args.config),
                 "batch_per_gpu": B,
                 "global_batch": B * world,
                 "joints": rig.num_joints,
                 "params": P,
                 "rows": M,
                 "solved_parameters": n_solved,
-                "solver": factor_structure(pb),
+                "route": factor_structure(pb)["route"],
                 "gn_iterations": args.iterations,
                 "line_search": args.line_search,
                 "regularization": args.regularization,
-                "sharding": f"{world} x {B} independent instances, one all-reduce of residual norms per solve",
+                "precision": args.precision,
                 "exchange": {
-                    "what": "all-reduce of 3 doubles (sum of final errors, sum of iterations, failed instances) per solve; nothing else crosses GPUs",
-                    "backend": "RCCL called from the C ABI (mmx_comm_all_reduce_norms)" if comm is not None else ("none (one GPU)" if world == 1 else "gloo (plumbing test)"),
+                    "what": "one all-reduce of 3 doubles per solve (sum error, sum iterations, failed)",
+                    "backend": "rccl" if comm is not None else ("none" if world == 1 else "gloo"),
                     "ranks_seen_by_rccl": comm.world_size if comm is not None else None,
-                    "per_rank_solves_per_s": {"min": rank_rate_min, "max": rank_rate_max},
+                    "per_rank_solves_per_s": [rank_rate_min, rank_rate_max],
                 },
-                # experiment switches in force (none in a default run): a number measured with one of them says so
-                "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMX_")},
             },
             "check": {"sum_final_error": total_err, "sum_iterations": total_it, "failed_instances": failed,
-                      "damping_floored_instances_rank0": int((db.last_status & 4 != 0).sum())},
+                      "damping_floored": int((status & 4 != 0).sum()), "precision_suspect": int((status & 8 != 0).sum()),
+                      "escalated_f64": int((status & 16 != 0).sum())},
             "roofline": {
-                "kernel": "fkJacobianKernel<true> (mmx_eval_jacobian: FK + dense J/r assembly)",
+                "kernel": "fkJacobianKernel<true> (mmx_eval_jacobian)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "bytes_per_launch": bytes_per_launch,
                 "ms_per_launch": jac_ms,
-                "timing": "HIP events attached to the kernel's dispatch packet on the launch stream (hipExtLaunchKernelGGL)",
-                "ms_per_launch_recorded_events": jac_ms_recorded,
                 "batch": B,
                 **extra,
             },
             "roofline_fused": {
-                "kernel": "fusedSolveKernel (mmx_solve: the kernel `value` times; the Jacobian is never formed)",
-                "bound": "latency (LDS round trips / barriers of one workgroup per instance); priced against the fp32 peak of a dense implementation",
+                "kernel": "fusedSolveKernel (mmx_solve; latency-bound, no J formed)",
                 "dense_equivalent_flops_per_solve": dense_flops,
                 "achieved": per_gpu_solves_per_s * dense_flops / 1e12,
                 "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s (dense-equivalent, per GPU)",
+                "unit": "TFLOP/s (dense-equivalent)",
                 "frac": per_gpu_solves_per_s * dense_flops / 1e12 / FP32_PEAK_TFLOPS,
-                "pmc": fused_pmc(),
             },
         }
+        details["roofline_fused_pmc"] = fused_pmc()
+        details["roofline_timing"] = {"ms_per_launch_recorded_events": jac_ms_recorded, "how": "HIP events attached to the kernel's dispatch packet on the launch stream (hipExtLaunchKernelGGL)"}
         if args.check_instances > 0:
-            line["check"].update(parity_check(db, theta_final, opt, args.check_instances))
+            chk = parity_check(db, theta_final, opt, args.check_instances)
+            details["check"] = chk
+            line["check"].update(compact_check(chk))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(db, args.cpu_sample, opt, args.dtype)
-        default_run = world == 1 and args.config == "cfg2" and args.batch == 0 and args.line_search == 0 and args.dtype == "f32"
+            line["cpu_baseline"], details["cpu_baseline"] = cpu_baseline(db, args.cpu_sample, opt, args.dtype, dense_flops)
+        default_run = world == 1 and args.config == "cfg2" and args.batch == 0 and args.line_search == 0 and args.dtype == "f32" and args.precision == "f32"
         if default_run and not args.no_extra_configs:
             del db, pb
             torch.cuda.empty_cache()
             line["configs"] = {}
             for key, cfg, eb, ls, steps, sample, lam, *rest in EXTRA_RUNS:
                 try:
-                    line["configs"][key] = run_extra(key, cfg, eb, ls, steps, sample, local_rank, args.iterations, args.check_instances, not args.no_cpu_baseline, lam, *rest)
+                    line["configs"][key], details["configs"][key] = run_extra(key, cfg, eb, ls, steps, sample, local_rank, args.iterations, args.check_instances, not args.no_cpu_baseline, lam, *rest)
                 except Exception as ex:  # a failing side configuration must not lose the headline line
-                    line["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"}
-        print(json.dumps(line), flush=True)
+                    line["configs"][key] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        line = round_floats(line)
+        try:
+            path = args.details or os.path.join(ROOT, "gpurun_out", "bench_details.json")
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(dict(details, line=line), f, indent=1)
+            print(f"[bench] details: {path}", file=sys.stderr)
+        except OSError as ex:
+            print(f"[bench] details not written: {ex}", file=sys.stderr)
+        for key, c in line.get("configs", {}).items():
+            print(f"[bench] {key:52s} {c.get('solves_per_s', 0):.4g} solves/s  within {c.get('within_bound')}  max_rel {c.get('max_rel')}  pass {c.get('pass')}", file=sys.stderr)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if comm is not None:
         comm.close()
     if dist is not None:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 9 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
+#define MMX_ABI_VERSION 10 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
                              trust_region_radius), mmx_comm_* (RCCL), MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J
                              7: mmx_tuning / mmx_problem_set_tuning / mmx_problem_last_route (replace the MMX_* environment
                              switches of earlier builds: the library reads no environment variable on the solve path)
@@ -44,6 +44,11 @@ extern "C" {
                                 (mmx_host_elimination_order, mmx_host_tile_structure, mmx_problem_tile_structure)
                              9: status[] is a bit set (MMX_SOLVE_DAMPING_FLOORED, informational), sized form of the
                                 constraint call (mmx_problem_set_constraints_sized), mmx_eval_skeleton_state_host.
+                             10: mmx_gn_options grows by `precision` / `precision_bound` (MMX_PRECISION_*: single, double, or
+                                single with the elements whose precision estimate exceeds the bound re-solved in double),
+                                status bits MMX_SOLVE_PRECISION_SUSPECT / MMX_SOLVE_ESCALATED_F64, MMX_SOLVE_FAILED(),
+                                mmx_solve_with_step_history (damping and gain ratio per iteration of the LM schedule),
+                                mmx_problem_solve_diagnostics.
                              A caller MUST compare mmx_abi_version() with the MMX_ABI_VERSION it was compiled against
                              before any other call: the structs below grow at their end from version to version. */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
@@ -88,7 +93,32 @@ typedef enum mmx_status {
                                        is NOT within 1e-5 of the reference's double instantiation on the pose
                                        parameters -- no single-precision normal-equation solver is; the answer there
                                        is mmx_solve_f64.  mmx_solve_f64 never sets this bit. */
-#define MMX_SOLVE_ERROR_MASK 3 /* status & MMX_SOLVE_ERROR_MASK == 0: the solve of that element is sound */
+#define MMX_SOLVE_PRECISION_SUSPECT 8 /* (bit, informational, ABI 10) the single-precision solve's own estimate of its
+                                         distance from the same solve in double -- eps * sum over the iterations of |step| /
+                                         sqrt(smallest Cholesky pivot ratio d_jj / (H_jj + lambda)), relative to |theta|;
+                                         mmx_problem_solve_diagnostics returns it -- exceeds mmx_gn_options::precision_bound
+                                         (default 1e-5, north_star's parity bound).  Unlike MMX_SOLVE_DAMPING_FLOORED, which
+                                         only says that the factor's damping floor engaged, this follows the conditioning
+                                         that loses the digits.  With MMX_PRECISION_AUTO such elements (and the ones with an
+                                         error bit) are solved again by the double instantiation from the initial parameters.
+                                         One-launch and wide routes; the explicit-Jacobian route keeps
+                                         MMX_SOLVE_DAMPING_FLOORED as its cue. */
+#define MMX_SOLVE_ESCALATED_F64 16 /* (bit, informational, ABI 10) MMX_PRECISION_AUTO: this element's result comes from the
+                                      double instantiation (its other status bits are that run's, plus the
+                                      MMX_SOLVE_PRECISION_SUSPECT that sent it there) */
+#define MMX_SOLVE_ERROR_MASK 3 /* (status & MMX_SOLVE_ERROR_MASK) == 0: the solve of that element is sound.  Mind the
+                                  parentheses: in C `status & MMX_SOLVE_ERROR_MASK == 0` parses as status & (3 == 0). */
+#define MMX_SOLVE_FAILED(status) (((status) & MMX_SOLVE_ERROR_MASK) != 0)
+
+/* mmx_gn_options::precision (ABI 10). */
+#define MMX_PRECISION_F32 0 /* the single-precision kernels (GaussNewtonSolverT<float>; what BASELINE's metric times) */
+#define MMX_PRECISION_F64 1 /* mmx_solve with float parameters in and out, every element solved by the double instantiation
+                               (GaussNewtonSolverT<double>, momentum/solver/gauss_newton_solver.cpp:315-316) */
+#define MMX_PRECISION_AUTO 2 /* single precision first; the elements it marks MMX_SOLVE_PRECISION_SUSPECT (or whose solve
+                                failed) are compacted and solved again in double from the initial parameters, on the same
+                                stream, without a host round trip.  The batched driver's defaults (lambda = 0.01,
+                                pymomentum/tensor_ik/solver_options.h:28-37) on marginally determined problems are where this
+                                matters (profiles/r05_weak_damping.json). */
 
 /* Where the caller's bulk arrays live. */
 #define MMX_MEM_HOST 0
@@ -333,6 +363,11 @@ typedef struct mmx_gn_options {
   float lm_down; /* lambda *= lm_down when rho > 0.75 (default 0.5) */
   /* trust region (only read when step_rule == MMX_STEP_TRUST_REGION) */
   float trust_region_radius; /* TrustRegionQROptions::trustRegionRadius_ (default 1; <= 0 selects the default) */
+  /* ABI 10 */
+  int32_t precision; /* MMX_PRECISION_* (default MMX_PRECISION_F32); read by mmx_solve / mmx_solve_with_history /
+                        mmx_solve_with_step_history / mmx_solve_host, not by mmx_solve_f64 */
+  float precision_bound; /* estimate above which an element is MMX_SOLVE_PRECISION_SUSPECT (default 1e-5; <= 0 selects the
+                            default) */
 } mmx_gn_options;
 
 typedef struct mmx_rig mmx_rig; /* opaque: device-resident rig constants */
@@ -548,7 +583,7 @@ int32_t mmx_eval_normal_equations(
  *   final_error[B]   double  the value solve() returns (error at the theta
  *                            before the last step, solver.cpp:126-127)
  *   iterations[B]    int32   errorHistory_.size()
- *   status[B]        int32   MMX_SOLVE_*
+ *   status[B]        int32   MMX_SOLVE_* (a bit set; MMX_SOLVE_FAILED(status[b]) tests the error bits)
  *   error_history    double [B][max_iterations] (unused tail = 0)
  */
 int32_t mmx_solve(
@@ -604,6 +639,41 @@ int32_t mmx_solve_with_history(
     double* error_history,
     float* parameter_history,
     void* stream);
+
+/*
+ * mmx_solve_with_history + the LM schedule's decisions (MMX_STEP_LM_SCHEDULE; MMX_ERR_INVALID_ARGUMENT for the other step
+ * rules when step_history is not null):
+ *   step_history  double [B][max_iterations][2]  (lambda iteration i factored with, its gain ratio rho = actual / predicted
+ *                 decrease -- the quantity TrustRegionQRT compares with 0.25 / 0.75 / nu,
+ *                 momentum/character_solver/trust_region_qr.cpp:244-268; -1 when no step could be computed); rows from an
+ *                 element's iteration count on stay zero.
+ * A step is accepted iff rho > 0; lambda is multiplied by lm_up when !(rho >= 0.25), by lm_down when rho > 0.75.  With this
+ * output a caller (and tests/test_gpu_baseline_parity.py) can tell an element whose answer differs from another precision's
+ * because a gain ratio sat on a threshold from one that differs for any other reason.  Every route; parameter_history may be
+ * null.
+ */
+int32_t mmx_solve_with_step_history(
+    mmx_problem* problem,
+    const mmx_gn_options* options,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    double* step_history,
+    void* stream);
+
+/*
+ * Numerical diagnostics of the LAST single-precision solve on this handle (one-launch and wide routes;
+ * MMX_ERR_UNSUPPORTED after a solve on the explicit-Jacobian route or before the first solve): diag_dev [B][4] floats
+ *   [0] the precision estimate MMX_SOLVE_PRECISION_SUSPECT is decided on (relative to |theta|)
+ *   [1] smallest Cholesky pivot ratio d_jj / (H_jj + lambda) met in any iteration (~ 1 / cond(J^T J + lambda I))
+ *   [2] largest |last refinement correction| / |step| of any iteration
+ *   [3] |theta| of the result
+ * Elements that MMX_PRECISION_AUTO re-solved in double keep the single-precision run's figures.
+ */
+int32_t mmx_problem_solve_diagnostics(mmx_problem* problem, float* diag_dev, void* stream);
 
 /*
  * Parity hook of the fused solve kernel: its normal equations at theta (first iteration), over
@@ -682,7 +752,7 @@ int32_t mmx_comm_all_reduce_norms(mmx_comm* comm, double* norms_dev, void* strea
 /* The same for three HOST doubles: staged through a device buffer and a stream the communicator owns;
  * returns when norms_host holds the sums.  (Callers without device code, e.g. the C++ shell's threads.) */
 int32_t mmx_comm_all_reduce_norms_host(mmx_comm* comm, double norms_host[3]);
-/* (sum final_error, sum iterations, #status != 0) of a solve's outputs -> norms_dev[3], on `stream`. */
+/* (sum final_error, sum iterations, #elements with MMX_SOLVE_FAILED(status)) of a solve's outputs -> norms_dev[3], on `stream`. */
 int32_t mmx_residual_norms(int32_t batch, const double* final_error, const int32_t* iterations, const int32_t* status, double* norms_dev, void* stream);
 void mmx_comm_destroy(mmx_comm* comm);
 

@@ -14,11 +14,14 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-MMX_ABI_VERSION = 9
+MMX_ABI_VERSION = 10
 MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
 MMX_SOLVE_DAMPING_FLOORED = 4  # informational bit of status[] (include/mmx.h)
+MMX_SOLVE_PRECISION_SUSPECT = 8  # informational: the single-precision solve's precision estimate exceeds options.precision_bound
+MMX_SOLVE_ESCALATED_F64 = 16  # informational: MMX_PRECISION_AUTO re-solved the element in double
 MMX_SOLVE_ERROR_MASK = 3
+MMX_PRECISION_F32, MMX_PRECISION_F64, MMX_PRECISION_AUTO = 0, 1, 2
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
 MMX_LAYOUT_COL_MAJOR, MMX_LAYOUT_ROW_MAJOR = 0, 1
 MMX_STEP_GN_FIXED_LAMBDA, MMX_STEP_LM_SCHEDULE, MMX_STEP_TRUST_REGION = 0, 1, 2
@@ -279,6 +282,8 @@ class GnOptions(C.Structure):
         ("lm_up", C.c_float),
         ("lm_down", C.c_float),
         ("trust_region_radius", C.c_float),
+        ("precision", C.c_int32),
+        ("precision_bound", C.c_float),
     ]
 
     @classmethod
@@ -295,6 +300,8 @@ class GnOptions(C.Structure):
         lm_up=4.0,
         lm_down=0.5,
         trust_region_radius=1.0,
+        precision=MMX_PRECISION_F32,
+        precision_bound=1e-5,
     ) -> "GnOptions":
         return cls(
             int(min_iterations),
@@ -308,6 +315,8 @@ class GnOptions(C.Structure):
             float(lm_up),
             float(lm_down),
             float(trust_region_radius),
+            int(precision),
+            float(precision_bound),
         )
 
 

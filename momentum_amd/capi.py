@@ -28,7 +28,7 @@ SYMBOLS = [
     "mmx_problem_create", "mmx_problem_destroy", "mmx_problem_num_rows", "mmx_problem_batch",
     "mmx_problem_set_tuning", "mmx_problem_last_route",
     "mmx_problem_set_enabled", "mmx_problem_set_constraints", "mmx_problem_set_constraints_sized", "mmx_problem_set_instance_rig", "mmx_problem_set_instance_parents", "mmx_eval_jacobian", "mmx_eval_jacobian_timed", "mmx_debug_store_pattern",
-    "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
+    "mmx_eval_skeleton_state", "mmx_eval_normal_equations", "mmx_solve", "mmx_solve_with_history", "mmx_solve_with_step_history", "mmx_problem_solve_diagnostics", "mmx_solve_f64", "mmx_solve_f64_host", "mmx_solve_host",
     "mmx_eval_jacobian_host", "mmx_eval_skeleton_state_host", "mmx_host_tables", "mmx_debug_fused_normal_equations", "mmx_debug_tree_normal_equations",
     "mmx_host_elimination_order", "mmx_host_tile_structure", "mmx_host_tile_level_schedule", "mmx_host_f64_assembly_list", "mmx_problem_tile_structure",
     "mmx_comm_unique_id", "mmx_comm_create", "mmx_comm_create_all", "mmx_comm_world_size", "mmx_comm_rank",
@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
     L.mmx_eval_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mmx_solve.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
     L.mmx_solve_with_history.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp, vp]
+    L.mmx_solve_with_step_history.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mmx_problem_solve_diagnostics.argtypes = [vp, vp, vp]
     L.mmx_solve_f64.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp, vp, vp]
     L.mmx_solve_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
     L.mmx_solve_f64_host.argtypes = [vp, C.POINTER(GnOptions), vp, vp, vp, vp]
@@ -549,9 +551,19 @@ class Problem:
         out["theta"] = theta
         return out
 
-    def solve(self, theta, options: GnOptions, want_history: bool = False, outputs=None, want_parameter_history: bool = False):
+    def solve_diagnostics(self):
+        """[B, 4] float tensor of the last single-precision solve (mmx_problem_solve_diagnostics): precision estimate,
+        smallest pivot ratio, largest refinement ratio, |theta|."""
+        import torch
+
+        out = torch.empty((self.B, 4), dtype=torch.float32, device=self.device)
+        _check(lib().mmx_problem_solve_diagnostics(self._h, _dev(out), _stream_ptr()))
+        return out
+
+    def solve(self, theta, options: GnOptions, want_history: bool = False, outputs=None, want_parameter_history: bool = False, want_step_history: bool = False):
         """In-place batched SolverT::solve.  Returns dict(theta, error, iterations, status[, error_history]
-        [, parameter_history [B, max_iterations, P]])."""
+        [, parameter_history [B, max_iterations, P]][, step_history [B, max_iterations, 2]: (lambda, gain ratio) per iteration
+        of the LM schedule])."""
         import torch
 
         theta = self._theta(theta)
@@ -560,7 +572,7 @@ class Problem:
             keep = theta.clone()
             try:
                 self._set_tuning("wide")
-                return self.solve(theta, options, want_history, outputs, want_parameter_history)
+                return self.solve(theta, options, want_history, outputs, want_parameter_history, want_step_history)
             except MmxError as e:
                 if e.code != 4:  # MMX_ERR_UNSUPPORTED: outside the tree kernels' scope -> the library's own choice
                     raise
@@ -588,6 +600,18 @@ class Problem:
                 outputs["error_history"] = torch.empty((self.B, max(1, options.max_iterations)), dtype=torch.float64, device=self.device)
         if want_parameter_history and "parameter_history" not in outputs:
             outputs["parameter_history"] = torch.empty((self.B, max(1, options.max_iterations), self.P), dtype=torch.float32, device=self.device)
+        if want_step_history and "step_history" not in outputs:
+            outputs["step_history"] = torch.empty((self.B, max(1, options.max_iterations), 2), dtype=torch.float64, device=self.device)
+        if outputs.get("step_history") is not None:
+            _check(
+                lib().mmx_solve_with_step_history(
+                    self._h, C.byref(options), _dev(theta), _dev(outputs["error"]), _dev(outputs["iterations"]),
+                    _dev(outputs["status"]), _dev(outputs.get("error_history")), _dev(outputs.get("parameter_history")),
+                    _dev(outputs["step_history"]), _stream_ptr(),
+                )
+            )  # fmt: skip
+            outputs["theta"] = theta
+            return outputs
         if outputs.get("parameter_history") is not None:
             _check(
                 lib().mmx_solve_with_history(

@@ -225,6 +225,10 @@ struct mmx_problem {
   DevBuf dF64Groups, dF64Extra, dF64ChunkStart;
   int32_t f64ListUnitsPerChunk = 0; // 0: not built
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda, sTrust;
+  DevBuf sDiag; // [B][4] diagnostics of the last single-precision solve (mmx_problem_solve_diagnostics)
+  DevBuf sDiagAcc; // [B][4] the wide route's accumulators behind it (mmx::StepParams::diagAcc)
+  bool diagValid = false;
+  DevBuf sThetaAuto, sAutoMap, sAutoCount; // MMX_PRECISION_AUTO: initial parameters, the elements to escalate, their number
   mmx_tuning tuning{}; // mmx_problem_set_tuning
   int32_t lastRoute = MMX_ROUTE_AUTO;
 };
@@ -919,6 +923,8 @@ void mmx_gn_options_default(mmx_gn_options* o) {
   o->lm_up = 4.0f;
   o->lm_down = 0.5f;
   o->trust_region_radius = 1.0f; // TrustRegionQROptions::trustRegionRadius_ (trust_region_qr.h:24)
+  o->precision = MMX_PRECISION_F32;
+  o->precision_bound = 1e-5f;
 }
 
 int32_t mmx_abi_version(void) {
@@ -2011,6 +2017,7 @@ static int32_t solveImpl(
     int32_t* status,
     double* error_history,
     float* parameter_history,
+    double* step_history,
     void* stream);
 
 int32_t mmx_solve(
@@ -2022,7 +2029,7 @@ int32_t mmx_solve(
     int32_t* status,
     double* error_history,
     void* stream) {
-  return solveImpl(pb, o, theta_dev, final_error, iterations, status, error_history, nullptr, stream);
+  return solveImpl(pb, o, theta_dev, final_error, iterations, status, error_history, nullptr, nullptr, stream);
 }
 
 int32_t mmx_solve_with_history(
@@ -2035,9 +2042,67 @@ int32_t mmx_solve_with_history(
     double* error_history,
     float* parameter_history,
     void* stream) {
-  return solveImpl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, stream);
+  return solveImpl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, nullptr, stream);
 }
 
+int32_t mmx_solve_with_step_history(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    double* step_history,
+    void* stream) {
+  if (step_history != nullptr && o != nullptr && o->step_rule != MMX_STEP_LM_SCHEDULE) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_solve_with_step_history: step_history is the LM schedule's (MMX_STEP_LM_SCHEDULE)");
+  }
+  return solveImpl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, step_history, stream);
+}
+
+int32_t mmx_problem_solve_diagnostics(mmx_problem* pb, float* diag_dev, void* stream) {
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (diag_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "diag_dev is null");
+  }
+  if (!pb->diagValid) {
+    return fail(MMX_ERR_UNSUPPORTED, "mmx_problem_solve_diagnostics: no single-precision solve on the one-launch or wide route has run on this handle");
+  }
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  MMX_HIP(hipMemcpyAsync(diag_dev, pb->sDiag.p, size_t(pb->B) * 4 * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return MMX_OK;
+}
+
+static int32_t solveF32Impl(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    double* step_history,
+    void* stream);
+static int32_t solveF64Impl(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    double* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    double* step_history,
+    const mmx::F64Select& select,
+    void* stream);
+
+// mmx_gn_options::precision: the single-precision routes, the double instantiation on float parameters, or the first
+// followed by the second on the elements it marked
 static int32_t solveImpl(
     mmx_problem* pb,
     const mmx_gn_options* o,
@@ -2047,6 +2112,59 @@ static int32_t solveImpl(
     int32_t* status,
     double* error_history,
     float* parameter_history,
+    double* step_history,
+    void* stream) {
+  if (o == nullptr || o->precision == MMX_PRECISION_F32) {
+    return solveF32Impl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, step_history, stream);
+  }
+  if (o->precision != MMX_PRECISION_F64 && o->precision != MMX_PRECISION_AUTO) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown precision (MMX_PRECISION_*)");
+  }
+  int32_t rc = checkProblem(pb, true);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  if (theta_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "options / theta is null");
+  }
+  if (parameter_history != nullptr) {
+    return fail(MMX_ERR_UNSUPPORTED, "parameter_history is single precision's (MMX_PRECISION_F32): the double instantiation does not record it");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (o->precision == MMX_PRECISION_F64) {
+    // every workgroup reads its element's parameters before it writes them: in place on the caller's float array
+    return solveF64Impl(pb, o, nullptr, final_error, iterations, status, error_history, step_history, mmx::F64Select{nullptr, nullptr, theta_dev, theta_dev}, stream);
+  }
+  MMX_HIP(pb->sThetaAuto.ensure(B * P * sizeof(float)));
+  MMX_HIP(pb->sAutoMap.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sAutoCount.ensure(sizeof(int32_t)));
+  MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+  MMX_HIP(hipMemcpyAsync(pb->sThetaAuto.p, theta_dev, B * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+  int32_t* st = status != nullptr ? status : pb->sStatus.as<int32_t>();
+  rc = solveF32Impl(pb, o, theta_dev, final_error, iterations, st, error_history, nullptr, step_history, stream);
+  if (rc != MMX_OK) {
+    return rc;
+  }
+  // a solve without the estimate (explicit-Jacobian route, the wide route's host-driven trust region): the cue stays the damping floor
+  const int32_t mask = MMX_SOLVE_ERROR_MASK | MMX_SOLVE_PRECISION_SUSPECT | (pb->diagValid ? 0 : MMX_SOLVE_DAMPING_FLOORED);
+  MMX_HIP(mmx::launchSelectSuspect(st, pb->B, mask, pb->sAutoMap.as<int32_t>(), pb->sAutoCount.as<int32_t>(), s));
+  return solveF64Impl(
+      pb, o, nullptr, final_error, iterations, st, error_history, step_history,
+      mmx::F64Select{pb->sAutoMap.as<int32_t>(), pb->sAutoCount.as<int32_t>(), pb->sThetaAuto.as<float>(), theta_dev}, stream);
+}
+
+static int32_t solveF32Impl(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    double* step_history,
     void* stream) {
   MMX_ZONE("mmx_solve (SolverT::solve)");
   int32_t rc = checkProblem(pb, true);
@@ -2110,6 +2228,14 @@ static int32_t solveImpl(
     fst.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
     fst.errorHistory = error_history;
     fst.paramHistory = parameter_history;
+    fst.stepHistory = step_history;
+    MMX_HIP(pb->sDiag.ensure(B * 4 * sizeof(float)));
+    fst.diag = pb->sDiag.as<float>();
+    fst.precisionBound = o->precision_bound > 0.f ? o->precision_bound : 1e-5f;
+    pb->diagValid = true;
+    if (step_history != nullptr && o->max_iterations > 0) {
+      MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
+    }
     if (error_history != nullptr && o->max_iterations > 0) {
       MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
     }
@@ -2193,6 +2319,11 @@ static int32_t solveImpl(
   st.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
   st.errorHistory = error_history;
   st.paramHistory = nullptr; // (explicit-Jacobian path: the history is copied after every iteration, below)
+  st.stepHistory = step_history;
+  pb->diagValid = false; // (the wide route's estimate: below, where its kernels are set up)
+  if (step_history != nullptr && o->max_iterations > 0) {
+    MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
+  }
   if (error_history != nullptr && o->max_iterations > 0) {
     MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
   }
@@ -2207,8 +2338,19 @@ static int32_t solveImpl(
   if (schedule) {
     MMX_HIP(pb->sLambda.ensure(B * sizeof(float)));
   }
-  MMX_HIP(mmx::launchSolveInit(st, pb->B, schedule ? pb->sLambda.as<float>() : nullptr, o->regularization, s));
+  // the precision estimate on the wide route (tree kernels + tile factor + finish stage); the trust region's host-driven
+  // re-factorisations and the explicit-Jacobian route keep MMX_SOLVE_DAMPING_FLOORED as their cue
+  const bool wideDiag = treeRefine && !trust && refineSteps(pb) > 0;
+  if (wideDiag) {
+    MMX_HIP(pb->sDiag.ensure(B * 4 * sizeof(float)));
+    MMX_HIP(pb->sDiagAcc.ensure(B * 4 * sizeof(float)));
+    st.diag = pb->sDiag.as<float>();
+    st.precisionBound = o->precision_bound > 0.f ? o->precision_bound : 1e-5f;
+    pb->diagValid = true;
+  }
+  MMX_HIP(mmx::launchSolveInit(st, pb->B, schedule ? pb->sLambda.as<float>() : nullptr, o->regularization, s, wideDiag ? pb->sDiagAcc.as<float>() : nullptr));
   mmx::StepParams sp{};
+  sp.diagAcc = wideDiag ? pb->sDiagAcc.as<float>() : nullptr;
   sp.lambda = o->regularization;
   sp.threshold = o->threshold;
   sp.minIterations = o->min_iterations;
@@ -2219,6 +2361,7 @@ static int32_t solveImpl(
   sp.delta = deferred ? pb->sDelta.as<float>() : nullptr;
   sp.stepIter = deferred ? pb->sStepIter.as<int32_t>() : nullptr;
   sp.lambdaPer = schedule ? pb->sLambda.as<float>() : nullptr;
+  sp.stepHistory = step_history;
   sp.doLineSearch = trust ? 0 : o->do_line_search; // (the trust region reads neither do_line_search nor regularization)
   sp.stepRule = o->step_rule;
   if (trust) {
@@ -2347,7 +2490,7 @@ static int32_t solveImpl(
   if (parameter_history != nullptr) {
     MMX_HIP(mmx::launchParamHistoryFinalize(parameter_history, st.iterations, pb->B, o->max_iterations, pb->rig->P, s));
   }
-  MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s));
+  MMX_HIP(mmx::launchSolveFinalize(theta_dev, pb->sThetaInit.as<float>(), pb->rig->P, st, pb->B, s, sp.diagAcc));
   if (sp.clk != nullptr) {
     long long h[16];
     MMX_HIP(hipMemcpyAsync(h, sp.clk, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -2398,12 +2541,30 @@ int32_t mmx_solve_f64(
     int32_t* status,
     double* error_history,
     void* stream) {
+  if (theta_dev == nullptr) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "options / theta is null");
+  }
+  return solveF64Impl(pb, o, theta_dev, final_error, iterations, status, error_history, nullptr, mmx::F64Select{nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+// theta_dev: double [B][P] in / out, or null when `select` carries float arrays (MMX_PRECISION_F64 / AUTO of mmx_solve)
+static int32_t solveF64Impl(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    double* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    double* step_history,
+    const mmx::F64Select& select,
+    void* stream) {
   MMX_ZONE("mmx_solve_f64 (SolverT<double>::solve)");
   int32_t rc = checkProblem(pb, true);
   if (rc != MMX_OK) {
     return rc;
   }
-  if (o == nullptr || theta_dev == nullptr) {
+  if (o == nullptr || (theta_dev == nullptr && select.thetaInit == nullptr)) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "options / theta is null");
   }
   if (o->max_iterations < 0 || o->min_iterations < 0) {
@@ -2440,8 +2601,13 @@ int32_t mmx_solve_f64(
   st.status = status != nullptr ? status : pb->sStatus.as<int32_t>();
   st.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
   st.errorHistory = error_history;
-  if (error_history != nullptr && o->max_iterations > 0) {
+  st.stepHistory = step_history;
+  const bool escalation = select.map != nullptr; // (the single-precision solve's outputs stay for the other elements)
+  if (error_history != nullptr && o->max_iterations > 0 && !escalation) {
     MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+  }
+  if (step_history != nullptr && o->max_iterations > 0 && !escalation) {
+    MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
   }
   mmx::FusedParams fp{};
   fp.lambda = o->regularization;
@@ -2469,7 +2635,7 @@ int32_t mmx_solve_f64(
     }
   }
   MMX_HIP(mmx::launchSolveF64(
-      pb->rigDev, pb->dev, pb->dSolveListF64.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), trustF64 ? pb->sHess2F64.as<double>() : nullptr, s, alist));
+      pb->rigDev, pb->dev, pb->dSolveListF64.as<int32_t>(), pb->solveN, theta_dev, st, fp, pb->sJacF64.as<double>(), pb->sHessF64.as<double>(), trustF64 ? pb->sHess2F64.as<double>() : nullptr, s, alist, select));
   return MMX_OK;
 }
 

@@ -50,6 +50,11 @@ constexpr float kPivotFloor = 3.814697265625e-6f; // 2^-18
 // directions J does not determine the step is the more damped one (the reference's QR returns the minimum-norm-like
 // step there, the objective decreases the same).  The trust-region solver used the same device from the start.
 constexpr float kFactorDamping = 1e-5f;
+// Precision estimate of the single-precision solves (mmx_problem_solve_diagnostics; MMX_SOLVE_PRECISION_SUSPECT): gain of
+// eps * sum_it |step_it| / sqrt(smallest pivot ratio_it) / |theta|, calibrated on the BASELINE shapes against the double oracle
+constexpr float kPrecisionGain = 1.f;
+constexpr float kPivotFloorOrOne = kPivotFloor > 0.f ? kPivotFloor : 1.f;
+
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40
 
 struct F3 {
@@ -1064,6 +1069,15 @@ __device__ __forceinline__ float waveReduceSumF(float v) {
   const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
   const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float waveReduceMaxF(float v) { // (the same four DPP steps; a NaN does not survive fmaxf: callers that care test it first)
+  v = fmaxf(v, dppMoveF<0xB1>(v));
+  v = fmaxf(v, dppMoveF<0x4E>(v));
+  v = fmaxf(v, dppMoveF<0x141>(v));
+  v = fmaxf(v, dppMoveF<0x140>(v));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 template <int kCtrl>
 __device__ __forceinline__ double dppMoveD(double v) {

@@ -1062,9 +1062,17 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     double* __restrict__ Hg, // [B][n][n] scratch: H, then its Cholesky factor (lower triangle, column-major)
     double* __restrict__ Hg2, // [B][n][n] scratch of MMX_STEP_TRUST_REGION: J^T J without damping, kept while the damping changes (else null)
     int rc, // rows of J staged in LDS at a time
-    F64AssemblyList alist) { // the resident form's assembly list, or null pointers
+    F64AssemblyList alist, // the resident form's assembly list, or null pointers
+    F64Select sel) { // MMX_PRECISION_AUTO: the elements to solve (null map: all of them)
   extern __shared__ __attribute__((aligned(16))) double dmem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  if (sel.map != nullptr) { // (uniform)
+    if (b >= *sel.count) {
+      return;
+    }
+    b = sel.map[b];
+  }
   selectInstanceRig(rig, b);
   selectInstanceWeights(pb, b);
   const int J = rig.J, P = rig.P, U = pb.U, G = pb.G, M = pb.rowsJoint; // (rowsJoint = 3 U + rows of the further joint error functions + 3 NE)
@@ -1144,7 +1152,7 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
   const bool trust = fp.stepRule == MMX_STEP_TRUST_REGION; // TrustRegionQRT<double>::doIteration (trust_region_qr.cpp:52-270)
   double trRadius = double(fp.trustRadius); // initializeSolver (:38-41); lives across the iterations
   for (int i = tid; i < P; i += 256) {
-    s.th[i] = thg[i];
+    s.th[i] = sel.thetaInit != nullptr ? double(sel.thetaInit[size_t(b) * P + i]) : thg[i];
   }
   if (tid == 0) {
     s.flags[0] = 0, s.flags[1] = 0, s.flags[2] = 0;
@@ -1760,6 +1768,11 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       makeTrial(1.0);
       const double eNew = errorF64(rig, pb, s, s.trial, b, tid);
       const double rho = predicted > 0.0 ? (curError - eNew) / predicted : -1.0;
+      if (st.stepHistory != nullptr && tid == 0) {
+        double* sh = st.stepHistory + (size_t(b) * fp.maxIterations + it) * 2;
+        sh[0] = lambda;
+        sh[1] = rho;
+      }
       if (rho > 0.0) {
         acceptTrial();
       }
@@ -1769,6 +1782,11 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
         lambda = fmax(lambda * double(fp.lmDown), double(fp.lmLambdaMin));
       }
     } else if (notPd && fp.stepRule == 1) {
+      if (st.stepHistory != nullptr && tid == 0) {
+        double* sh = st.stepHistory + (size_t(b) * fp.maxIterations + it) * 2;
+        sh[0] = lambda;
+        sh[1] = -1.0;
+      }
       lambda = fmin(lambda * double(fp.lmUp), double(fp.lmLambdaMax));
     } else if (!notPd && fp.doLineSearch == 2) {
       double part = 0.0;
@@ -1835,8 +1853,26 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
       bad = 1;
     }
   }
+  if (tid == 0) {
+    s.flags[3] = itersDone; // (thread 0 keeps the count)
+  }
   bad = __syncthreads_or(bad);
-  if (!bad) {
+  if (sel.thetaInit != nullptr) { // float parameters in and out (mmx_solve's MMX_PRECISION_F64 / AUTO); a non-finite answer: the initial ones
+    for (int i = tid; i < P; i += 256) {
+      sel.thetaOut[size_t(b) * P + i] = bad ? sel.thetaInit[size_t(b) * P + i] : float(s.th[i]);
+    }
+    if (sel.map != nullptr) { // the rows of the histories past this run's last iteration still hold the single-precision run's
+      for (int i = s.flags[3] + tid; i < fp.maxIterations; i += 256) {
+        if (st.errorHistory != nullptr) {
+          st.errorHistory[size_t(b) * fp.maxIterations + i] = 0.0;
+        }
+        if (st.stepHistory != nullptr) {
+          st.stepHistory[(size_t(b) * fp.maxIterations + i) * 2] = 0.0;
+          st.stepHistory[(size_t(b) * fp.maxIterations + i) * 2 + 1] = 0.0;
+        }
+      }
+    }
+  } else if (!bad) {
     for (int i = tid; i < P; i += 256) {
       thg[i] = s.th[i];
     }
@@ -1844,7 +1880,45 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
   if (tid == 0) {
     st.iterations[b] = itersDone;
     st.finalError[b] = curError;
-    st.status[b] = bad ? 1 : s.flags[2];
+    // (escalated: the double run's status + why the element was taken + MMX_SOLVE_ESCALATED_F64)
+    st.status[b] = (bad ? 1 : s.flags[2]) | (sel.map != nullptr ? ((st.status[b] & 8) | 16) : 0);
+  }
+}
+
+// MMX_PRECISION_AUTO: the elements the single-precision solve marked (MMX_SOLVE_PRECISION_SUSPECT, or an error bit), in
+// index order -- one workgroup, a 256-wide scan over the batch in strides
+__global__ void __launch_bounds__(256) selectSuspectKernel(const int32_t* __restrict__ status, int B, int32_t mask, int32_t* __restrict__ map, int32_t* __restrict__ count) {
+  __shared__ int waveTot[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    base = 0;
+  }
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    const int b = b0 + tid;
+    const bool take = b < B && (status[b] & mask) != 0;
+    const unsigned long long m = __ballot(take);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) {
+      waveTot[wave] = __popcll(m);
+    }
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) {
+      off += waveTot[w];
+    }
+    if (take) {
+      map[off + before] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      base += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *count = base;
   }
 }
 
@@ -1911,7 +1985,8 @@ hipError_t launchSolveF64(
     double* Hg,
     double* Hg2,
     hipStream_t stream,
-    const F64AssemblyList& list) {
+    const F64AssemblyList& list,
+    const F64Select& select) {
   const int genRows = pb.rowsJoint - 3 * pb.U;
   const int rcRes = solveF64ResidentChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
   const F64AssemblyList none{nullptr, nullptr, nullptr, 0};
@@ -1926,7 +2001,7 @@ hipError_t launchSolveF64(
     }
     // (the list is only good for the chunking it was built for; per-instance constraint parents have none)
     const bool useList = list.groups != nullptr && list.unitsPerChunk == rcRes / 3 && pb.instPosParent == nullptr && pb.instOriParent == nullptr;
-    hipLaunchKernelGGL(solveF64Kernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, nullptr, nullptr, Hg2, rcRes, useList ? list : none);
+    hipLaunchKernelGGL(solveF64Kernel<true>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, nullptr, nullptr, Hg2, rcRes, useList ? list : none, select);
     return hipGetLastError();
   }
   const size_t lds = solveF64LdsBytes(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows);
@@ -1941,7 +2016,12 @@ hipError_t launchSolveF64(
     }
   }
   hipLaunchKernelGGL(
-      solveF64Kernel<false>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, Hg2, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows), none);
+      solveF64Kernel<false>, dim3(pb.B), dim3(256), lds, stream, rig, pb, solveList, n, theta, st, fp, Jg, Hg, Hg2, solveF64ChunkRows(rig.J, rig.P, pb.U, n, pb.G + pb.NE, genRows), none, select);
+  return hipGetLastError();
+}
+
+hipError_t launchSelectSuspect(const int32_t* status, int B, int32_t mask, int32_t* map, int32_t* count, hipStream_t stream) {
+  hipLaunchKernelGGL(selectSuspectKernel, dim3(1), dim3(256), 0, stream, status, B, mask, map, count);
   return hipGetLastError();
 }
 

@@ -2684,6 +2684,18 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
   long long tclk = clock64();
   tiledFactorPairs(jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256, L, n, lambda, t, sp, b, tid, tclk, ml);
   const bool badPivot = t.flags[0] != 0;
+  if (sp.diagAcc != nullptr) { // the precision estimate's input (as in choleskyFactorResidentKernel)
+    const float* Hd = jtj + size_t(b) * size_t(NB * (NB + 1) / 2) * 256;
+    float w = 0.f;
+    for (int i = tid; i < n; i += 256) {
+      const float hd = Hd[size_t(tileIndex(i >> 4, i >> 4)) * 256 + (i & 15) * 17] + lambda;
+      w = fmaxf(w, kPivotFloor * hd * t.invDiag[i] * t.invDiag[i]);
+    }
+    w = waveReduceMaxF(w);
+    if ((tid & 63) == 0) {
+      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 3), __float_as_int(w));
+    }
+  }
   constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
   float* d0 = t.g; // y = L^-1 g, solved in place
   MMX_SCLK(0)
@@ -3010,6 +3022,16 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
     MMX_SCLK(1)
   }
   const bool badPivot = flags[0] != 0;
+  if (sp.diagAcc != nullptr) { // the precision estimate's input: the largest kPivotFloor (H_jj + mu) / d_jj of this factorisation
+    float w = 0.f;
+    for (int i = tid; i < n; i += 256) {
+      w = fmaxf(w, floorAll[i] * invDiag[i] * invDiag[i]);
+    }
+    w = waveReduceMaxF(w);
+    if (lane == 0) {
+      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 3), __float_as_int(w)); // (non-negative floats order like their bits)
+    }
+  }
   float* d0 = g; // y = L^-1 g; solved in place: L^T d = y on the resident tiles
   MMX_SCLK(0)
   residentSweepBackward(tiles, maskWords, vRowMask, vColBase, NB, d0, invDiag, tid);
@@ -3108,6 +3130,14 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
     }
     return;
   }
+  if (sp.diagAcc != nullptr && tid == 0) { // this iteration's share of the precision estimate (as fusedSolveKernel's phase K)
+    float* a = sp.diagAcc + 4 * size_t(b);
+    const float worst = a[3];
+    a[0] += sqrtf(step2 * worst * (1.f / kPivotFloorOrOne));
+    a[1] = fmaxf(a[1], worst);
+    a[2] = fmaxf(a[2], step2 > 0.f ? sqrtf(corr2 / step2) : 0.f);
+    a[3] = 0.f;
+  }
   applyStepAndBook(pb, P, b, d0, false, errIter, theta, st, sp, tid);
   if (tid == 0) {
     refState[b] = 1;
@@ -3151,7 +3181,13 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
     }
     if (mark < 0) { // H was not positive definite: no step; the schedule raises the damping
       if (sp.stepRule == MMX_STEP_LM_SCHEDULE && tid == 0) {
-        sp.lambdaPer[b] = fminf((sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda) * sp.lmUp, sp.lmLambdaMax);
+        const float lam = sp.lambdaPer != nullptr ? sp.lambdaPer[b] : sp.lambda;
+        if (sp.stepHistory != nullptr) {
+          double* sh = sp.stepHistory + (size_t(b) * sp.maxIterations + sp.iteration) * 2;
+          sh[0] = double(lam);
+          sh[1] = -1.0; // no step was taken: the schedule treats it as a rejected one
+        }
+        sp.lambdaPer[b] = fminf(lam * sp.lmUp, sp.lmLambdaMax);
       }
       return;
     }
@@ -3276,6 +3312,11 @@ __global__ void __launch_bounds__(256) stepUpdateKernel(
       }
     }
     if (tid == 0) {
+      if (sp.stepHistory != nullptr) {
+        double* sh = sp.stepHistory + (size_t(b) * sp.maxIterations + sp.iteration) * 2;
+        sh[0] = double(lambda);
+        sh[1] = double(rho);
+      }
       if (!(rho >= 0.25f)) {
         lambda = fminf(lambda * sp.lmUp, sp.lmLambdaMax);
       } else if (rho > 0.75f) {
@@ -3451,11 +3492,14 @@ hipError_t launchTrustEnd(const SolveStateDev& st, const StepParams& sp, const d
 // ---------------------------------------------------------------------------------------------
 // small bookkeeping kernels
 // ---------------------------------------------------------------------------------------------
-__global__ void solveInitKernel(SolveStateDev st, int B, float* lambdaPer, float lambda0) {
+__global__ void solveInitKernel(SolveStateDev st, int B, float* lambdaPer, float lambda0, float* diagAcc) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) {
     if (lambdaPer != nullptr) {
       lambdaPer[b] = lambda0;
+    }
+    if (diagAcc != nullptr) {
+      *reinterpret_cast<float4*>(diagAcc + 4 * size_t(b)) = float4{0.f, 0.f, 0.f, 0.f};
     }
     st.done[b] = 0;
     st.iterations[b] = 0;
@@ -3468,17 +3512,36 @@ __global__ void solveInitKernel(SolveStateDev st, int B, float* lambdaPer, float
 // NaN/Inf guard of the batched driver: revert to the initial parameters
 // (pymomentum/tensor_ik/tensor_ik.cpp:168-173).  One wavefront per instance.
 __global__ void __launch_bounds__(64)
-solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaInit, int P, SolveStateDev st) {
+solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaInit, int P, SolveStateDev st, const float* __restrict__ diagAcc) {
   const int b = blockIdx.x, lane = threadIdx.x;
   float* th = theta + size_t(b) * P;
   const float* ti = thetaInit + size_t(b) * P;
   int bad = 0;
+  float th2 = 0.f;
   for (int i = lane; i < P; i += 64) {
-    if (!isfinite(th[i])) {
+    const float v = th[i];
+    if (!isfinite(v)) {
       bad = 1;
     }
+    th2 += v * v;
   }
   bad = __any(bad);
+  if (diagAcc != nullptr && st.diag != nullptr) { // the wide route's precision estimate (fusedSolveKernel's epilogue has the formula)
+    th2 = waveReduceSumF(th2);
+    if (lane == 0) {
+      const float* a = diagAcc + 4 * size_t(b);
+      const float thn = sqrtf(th2);
+      const float est = kPrecisionGain * FLT_EPSILON * a[0] / fmaxf(thn, 1e-30f);
+      if (!bad && st.precisionBound > 0.f && !(est <= st.precisionBound)) {
+        st.status[b] |= 8; // MMX_SOLVE_PRECISION_SUSPECT
+      }
+      float* dg = st.diag + 4 * size_t(b);
+      dg[0] = est;
+      dg[1] = a[1] > 0.f ? kPivotFloorOrOne / a[1] : 1.f;
+      dg[2] = a[2];
+      dg[3] = bad ? 0.f : thn;
+    }
+  }
   if (bad) {
     for (int i = lane; i < P; i += 64) {
       th[i] = ti[i];
@@ -3861,8 +3924,8 @@ hipError_t launchCholeskyFinishTiled(
   return hipGetLastError();
 }
 
-hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream) {
-  hipLaunchKernelGGL(solveInitKernel, dim3((B + 255) / 256), dim3(256), 0, stream, st, B, lambdaPer, lambda0);
+hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream, float* diagAcc) {
+  hipLaunchKernelGGL(solveInitKernel, dim3((B + 255) / 256), dim3(256), 0, stream, st, B, lambdaPer, lambda0, diagAcc);
   return hipGetLastError();
 }
 
@@ -3901,8 +3964,8 @@ hipError_t launchParamHistoryFinalize(float* paramHistory, const int32_t* iterat
   return hipGetLastError();
 }
 
-hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(solveFinalizeKernel, dim3(B), dim3(64), 0, stream, theta, thetaInit, P, st);
+hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream, const float* diagAcc) {
+  hipLaunchKernelGGL(solveFinalizeKernel, dim3(B), dim3(64), 0, stream, theta, thetaInit, P, st, diagAcc);
   return hipGetLastError();
 }
 

@@ -21,6 +21,20 @@ struct SolveStateDev {
   double* finalError; // [B] error_ (what solve() returns)
   double* errorHistory; // [B][maxIterations] or null
   float* paramHistory; // [B][maxIterations][P] or null: the parameters after iteration i (iterationHistory_["parameters"], solver.cpp:101-106)
+  double* stepHistory; // [B][maxIterations][2] or null, MMX_STEP_LM_SCHEDULE: (lambda the iteration factored with, its gain ratio rho)
+  float* diag; // [B][4] or null: numerical diagnostics of a single-precision solve (mmx_problem_solve_diagnostics, include/mmx.h):
+               // estimated relative error of theta, smallest pivot ratio, largest refinement ratio, |theta|
+  float precisionBound; // status |= MMX_SOLVE_PRECISION_SUSPECT when the estimate exceeds it (<= 0: never)
+};
+
+// mmx_gn_options::precision == MMX_PRECISION_AUTO: the double solve runs on the elements map[0 .. *count - 1] only (workgroup
+// i takes element map[i]; workgroups beyond *count leave at once), reads their initial parameters from the float copy taken
+// before the single-precision solve and writes the result back rounded to float.
+struct F64Select {
+  const int32_t* map; // [B] or null: every element, theta in double in place
+  const int32_t* count; // [1]
+  const float* thetaInit; // [B][P]
+  float* thetaOut; // [B][P]
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: the largest value requested so far is
@@ -76,6 +90,10 @@ struct StepParams {
   float* delta; // [B][n] step of this iteration
   int32_t* stepIter; // [B] iteration + 1 when `delta` holds a step, -(iteration + 1) when H was not positive definite
   float* lambdaPer; // [B] per-instance damping (LM schedule, trust region) or null: `lambda` for everyone
+  double* stepHistory; // SolveStateDev::stepHistory for stepUpdateKernel (which applies the schedule on the wide / explicit routes)
+  float* diagAcc; // [B][4] or null: the wide route's precision estimate in the making -- path sum, largest pivot-floor ratio of
+                  // the solve, largest refinement ratio, largest pivot-floor ratio of the current iteration (fusedSolveKernel
+                  // keeps the same four in LDS); solveFinalizeKernel turns them into SolveStateDev::diag and the status bit
   TrustStateDev tr; // MMX_STEP_TRUST_REGION on the wide route (all null otherwise)
   int32_t doLineSearch; // GaussNewtonSolverOptions::doLineSearch
   int32_t stepRule; // MMX_STEP_*
@@ -219,7 +237,10 @@ hipError_t launchSolveF64(
     double* Hg,
     double* Hg2, // second [B][n][n] scratch, MMX_STEP_TRUST_REGION only (else null)
     hipStream_t stream,
-    const F64AssemblyList& list = F64AssemblyList{nullptr, nullptr, nullptr, 0});
+    const F64AssemblyList& list = F64AssemblyList{nullptr, nullptr, nullptr, 0},
+    const F64Select& select = F64Select{nullptr, nullptr, nullptr, nullptr});
+// elements whose status has a bit of `mask` set, in index order: map[0 .. *count - 1]
+hipError_t launchSelectSuspect(const int32_t* status, int B, int32_t mask, int32_t* map, int32_t* count, hipStream_t stream);
 
 size_t fkJacobianLdsBytes(int J, int P, int U);
 // store-only counterpart of the J-assembly kernel (profiling aid; see storePatternKernel)
@@ -318,7 +339,7 @@ hipError_t launchStepUpdate(
     const StepParams& sp,
     hipStream_t stream);
 
-hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream);
+hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream, float* diagAcc = nullptr);
 // TrustRegionQRT on the wide route: state of a solve / of an iteration, the decision after a linear solve (is the step
 // within the radius, or does lambda take a Newton update first), the bookkeeping at the end of an iteration
 hipError_t launchTrustInit(const TrustStateDev& tr, int B, float radius0, hipStream_t stream);
@@ -327,6 +348,6 @@ hipError_t launchTrustDecide(const ProblemDev& pb, const float* factor, const fl
 hipError_t launchTrustEnd(const SolveStateDev& st, const StepParams& sp, const double* errIter, int B, hipStream_t stream);
 // zeroes the rows of paramHistory [B][maxIterations][P] from iterations[b] on (the reference leaves them at setZero())
 hipError_t launchParamHistoryFinalize(float* paramHistory, const int32_t* iterations, int B, int maxIterations, int P, hipStream_t stream);
-hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream);
+hipError_t launchSolveFinalize(float* theta, const float* thetaInit, int P, const SolveStateDev& st, int B, hipStream_t stream, const float* diagAcc = nullptr);
 
 } // namespace mmx

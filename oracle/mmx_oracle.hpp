@@ -1331,6 +1331,10 @@ struct SolveResult {
   int iterations = 0; // errorHistory_.size()
   bool notPD = false;
   std::vector<double> errorHistory;
+  // LM gain-ratio schedule (stepRule 1) only, one entry per iteration: the damping the iteration's system was factored
+  // with, and the gain ratio rho = actual / predicted decrease its accept / scale decisions were taken on (the quantity
+  // TrustRegionQRT compares with 0.25 / 0.75 / nu, momentum/character_solver/trust_region_qr.cpp:247-268)
+  std::vector<double> lambdaHistory, gainRatioHistory;
   std::vector<T> lastJtJ, lastJtr; // compacted system of the last iteration (for parity hooks)
 };
 
@@ -1712,6 +1716,8 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
       }
       const double errorNew = fn.getError(trial.data());
       const T rho = predicted > T(0) ? T((error - errorNew) / double(predicted)) : T(-1);
+      out.lambdaHistory.push_back(double(lambda));
+      out.gainRatioHistory.push_back(double(rho));
       if (rho > T(0)) {
         params = trial;
       }

@@ -210,7 +210,9 @@ int solveOne(
     int32_t* status,
     double* hist,
     T* jtj,
-    T* jtr) {
+    T* jtr,
+    double* lamHist = nullptr, // [maxIterations] LM schedule: damping of iteration i (0 beyond the run / other step rules)
+    double* rhoHist = nullptr) { // [maxIterations] LM schedule: gain ratio of iteration i
   SolverFunction<T> fn(rig, cs);
   if (enabled) {
     fn.setEnabledParameters(enabled);
@@ -249,6 +251,14 @@ int solveOne(
   if (jtr) {
     std::copy(r.lastJtr.begin(), r.lastJtr.end(), jtr);
   }
+  for (int i = 0; i < opt.maxIterations; ++i) {
+    if (lamHist) {
+      lamHist[i] = size_t(i) < r.lambdaHistory.size() ? r.lambdaHistory[i] : 0.0;
+    }
+    if (rhoHist) {
+      rhoHist[i] = size_t(i) < r.gainRatioHistory.size() ? r.gainRatioHistory[i] : 0.0;
+    }
+  }
   return 0;
 }
 
@@ -269,7 +279,9 @@ int solveBatch(
     int32_t* iters,
     int32_t* status,
     double* hist, // [B][maxIter] or null
-    int nthreads) {
+    int nthreads,
+    double* lamHist = nullptr, // [B][maxIter] or null (LM schedule)
+    double* rhoHist = nullptr) {
   const Rig rig = makeRig(d);
   const Options opt = makeOptions(o, useBlockJtJ);
   // one independent solver + function per task, like dispenso::parallel_for(0, nBatch, ...) in
@@ -292,7 +304,9 @@ int solveBatch(
           status ? status + b : nullptr,
           hist ? hist + size_t(b) * opt.maxIterations : nullptr,
           nullptr,
-          nullptr);
+          nullptr,
+          lamHist ? lamHist + size_t(b) * opt.maxIterations : nullptr,
+          rhoHist ? rhoHist + size_t(b) * opt.maxIterations : nullptr);
     }
   };
   if (nthreads <= 1) {
@@ -414,6 +428,28 @@ extern "C" {
       double* hist,                                                                                      \
       int nthreads) {                                                                                    \
     return solveBatch<T>(d, B, Kp, pp, Ko, op, c, en, o, useBlockJtJ, theta, err, iters, status, hist, nthreads); \
+  }                                                                                                      \
+  /* orc_solve_batch + the LM schedule's per-iteration damping and gain ratio ([B][maxIterations] doubles) */ \
+  int orc_solve_batch_steps_##SUF(                                                                       \
+      const mmx_rig_desc* d,                                                                             \
+      int B,                                                                                             \
+      int Kp,                                                                                            \
+      const int32_t* pp,                                                                                 \
+      int Ko,                                                                                            \
+      const int32_t* op,                                                                                 \
+      const mmx_constraint_data* c,                                                                      \
+      const uint8_t* en,                                                                                 \
+      const mmx_gn_options* o,                                                                           \
+      int useBlockJtJ,                                                                                   \
+      T* theta,                                                                                          \
+      double* err,                                                                                       \
+      int32_t* iters,                                                                                    \
+      int32_t* status,                                                                                   \
+      double* hist,                                                                                      \
+      int nthreads,                                                                                      \
+      double* lamHist,                                                                                   \
+      double* rhoHist) {                                                                                 \
+    return solveBatch<T>(d, B, Kp, pp, Ko, op, c, en, o, useBlockJtJ, theta, err, iters, status, hist, nthreads, lamHist, rhoHist); \
   }                                                                                                      \
   int orc_mock_solve_##SUF(                                                                              \
       int P, const uint8_t* en, const mmx_gn_options* o, int useBlockJtJ, T* theta, double* err, int32_t* iters, double* hist) { \

@@ -92,6 +92,16 @@ def build(force: bool = False) -> str:
     is rebuilt for this one, with the fastest of the ISA candidates above."""
     cpu = host_cpu()
     stamp = build_info()
+
+    def stale():  # a source newer than the library (the library travels with the snapshot; its sources may have moved on)
+        try:
+            t = os.path.getmtime(_LIB_PATH)
+            srcs = [os.path.join(_HERE, "mmx_oracle_capi.cpp"), os.path.join(_HERE, "mmx_oracle.hpp"), os.path.join(os.path.dirname(_HERE), "include", "mmx.h")]
+            return any(os.path.getmtime(p) > t for p in srcs)
+        except OSError:
+            return True
+
+    force = force or stale()
     if force or not os.path.exists(_LIB_PATH) or not stamp.startswith(cpu + " | "):
         import fcntl
 
@@ -359,9 +369,11 @@ def solve(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None,
     )  # fmt: skip
 
 
-def solve_batch(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f32", nthreads=1, use_block_jtj=False, use_qr=False):
+def solve_batch(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled=None, dtype="f32", nthreads=1, use_block_jtj=False, use_qr=False, step_history=False):
     """The reference's batched driver shape (pymomentum/tensor_ik/tensor_ik.cpp:127-177): one
-    independent solver per instance, `nthreads` std::threads.  cons arrays are [B,K,...]."""
+    independent solver per instance, `nthreads` std::threads.  cons arrays are [B,K,...].
+    step_history (LM schedule, step_rule 1): also `lambda_history`, `gain_ratio_history` [B][max_iterations] -- the damping
+    iteration i factored with and the gain ratio its accept / scale decisions were taken on."""
     T = _np(dtype)
     P = rig.num_params
     th = np.array(theta0, dtype=T).reshape(-1, P).copy()
@@ -373,14 +385,21 @@ def solve_batch(rig: Rig, cons: Constraints, theta0, options: GnOptions, enabled
     hist = np.zeros((B, max(1, options.max_iterations)), np.float64)
     d, cd = rig.desc(), cons.data()
     ct = _ct(dtype)
-    fn = getattr(lib(), f"orc_solve_batch_{_suf(dtype)}")
-    rc = fn(
+    args = (
         C.byref(d), B, cons.Kp, as_ptr(cons.pos_parent, C.c_int32), cons.Ko, as_ptr(cons.ori_parent, C.c_int32),
         C.byref(cd), eptr, C.byref(options), int(bool(use_block_jtj)) | (2 if use_qr else 0), as_ptr(th, ct), as_ptr(err, C.c_double),
         as_ptr(iters, C.c_int32), as_ptr(status, C.c_int32), as_ptr(hist, C.c_double), int(nthreads),
     )  # fmt: skip
+    out = dict(theta=th, error=err, iterations=iters, status=status, error_history=hist)
+    if step_history:
+        lam = np.zeros_like(hist)
+        rho = np.zeros_like(hist)
+        rc = getattr(lib(), f"orc_solve_batch_steps_{_suf(dtype)}")(*args, as_ptr(lam, C.c_double), as_ptr(rho, C.c_double))
+        out.update(lambda_history=lam, gain_ratio_history=rho)
+    else:
+        rc = getattr(lib(), f"orc_solve_batch_{_suf(dtype)}")(*args)
     assert rc == 0
-    return dict(theta=th, error=err, iterations=iters, status=status, error_history=hist)
+    return out
 
 
 def mock_solve(P: int, theta0, options: GnOptions, enabled=None, dtype="f64", use_block_jtj=False):

@@ -1,0 +1,176 @@
+"""mmx_gn_options::precision (ABI 10) and the step history of the LM schedule, through the C ABI.
+
+  * MMX_PRECISION_F64 on float parameters = the double instantiation (GaussNewtonSolverT<double>,
+    momentum/solver/gauss_newton_solver.cpp:315-316) rounded to float on the way out;
+  * MMX_PRECISION_AUTO = single precision + the elements its own precision estimate marks (MMX_SOLVE_PRECISION_SUSPECT)
+    re-solved in double: with a bound nothing passes every element is escalated and the result is MMX_PRECISION_F64's bit
+    for bit; at BASELINE's damping nothing is escalated and the result is the single-precision one bit for bit; on the
+    shapes and dampings where single precision leaves the 1e-5 bound (BASELINE configs[0] / configs[1] at the batched
+    driver's lambda = 0.01 and below, pymomentum/tensor_ik/solver_options.h:28-37) every element the double oracle solves
+    is within the bound again;
+  * mmx_solve_with_step_history: (lambda, gain ratio) per iteration of the LM schedule obey the schedule's rule exactly
+    and agree with the oracle's double run on all but a few elements (branch flips).
+"""
+import numpy as np
+import pytest
+
+from momentum_amd import capi, humanoid72_landmark_joints, make_humanoid72, make_test_character
+from momentum_amd._abi import (
+    MMX_PRECISION_AUTO,
+    MMX_PRECISION_F64,
+    MMX_SOLVE_ESCALATED_F64,
+    MMX_SOLVE_PRECISION_SUSPECT,
+    MMX_STEP_LM_SCHEDULE,
+    GnOptions,
+)
+from tests.helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+UNIT = 0.01
+BOUND = 1e-5
+
+
+def _cores():
+    import bench
+
+    return bench.usable_cores()
+
+
+def _rel(a, ref):
+    return np.linalg.norm(a - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)
+
+
+def _problem(torch, rig, cons, B):
+    pb = capi.Problem(capi.RigHandle(rig, 0), B, cons.pos_parent, cons.ori_parent)
+    t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+    pb.set_constraints(t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
+                       t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)))  # fmt: skip
+    return pb
+
+
+def _solve(torch, pb, th0, opt, **kw):
+    out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items() if v is not None}
+
+
+def _cfg2(B, seed=777):
+    rig = make_humanoid72(seed=12345, variant="p128", unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    cons, th0, _ = make_problem(rig, lm, lm, B, seed=seed, perturb=0.3)
+    return rig, cons, th0
+
+
+@pytest.mark.parametrize("line_search", [0, 2])
+def test_precision_f64_is_the_double_instantiation_on_float_parameters(torch_cuda, orc, line_search):
+    B = 256
+    rig, cons, th0 = _cfg2(B)
+    pb = _problem(torch_cuda, rig, cons, B)
+    for lam in (0.05, 1e-5):
+        opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=lam, do_line_search=line_search, precision=MMX_PRECISION_F64)
+        out = _solve(torch_cuda, pb, th0, opt, want_history=True)
+        d = pb.solve_f64(torch_cuda.from_numpy(th0.astype(np.float64)).to(pb.device), opt, want_history=True)
+        torch_cuda.cuda.synchronize()
+        # the same kernel on the same values: the float result is the double one rounded once
+        assert np.array_equal(out["theta"], d["theta"].cpu().numpy().astype(np.float32))
+        assert np.array_equal(out["error_history"], d["error_history"].cpu().numpy())
+        assert np.array_equal(out["iterations"], d["iterations"].cpu().numpy()) and np.all(out["status"] == 0)
+        if lam == 0.05 and not line_search:
+            ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=_cores())
+            assert _rel(out["theta"].astype(np.float64), ref["theta"]).max() <= 2e-7  # (float rounding of theta: 6e-8)
+
+
+def test_auto_with_a_bound_nothing_passes_escalates_every_element(torch_cuda, orc):
+    B = 300  # (not a multiple of the selection kernel's stride)
+    rig, cons, th0 = _cfg2(B)
+    pb = _problem(torch_cuda, rig, cons, B)
+    mk = lambda prec, bound=1e-5: GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE,
+                                                 precision=prec, precision_bound=bound)  # fmt: skip
+    a = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_AUTO, 1e-30), want_history=True, want_step_history=True)
+    d = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_F64), want_history=True, want_step_history=True)
+    assert np.all(a["status"] & MMX_SOLVE_ESCALATED_F64 != 0) and np.all(a["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0)
+    assert np.all(a["status"] & 3 == 0)
+    for k in ("theta", "error", "iterations", "error_history", "step_history"):
+        assert np.array_equal(a[k], d[k]), k
+
+
+def test_auto_at_the_baseline_damping_escalates_nothing(torch_cuda, orc):
+    B = 1024
+    rig, cons, th0 = _cfg2(B)
+    pb = _problem(torch_cuda, rig, cons, B)
+    mk = lambda prec: GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, precision=prec)
+    a = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_AUTO))
+    f = _solve(torch_cuda, pb, th0, mk(0))
+    assert int((a["status"] & (MMX_SOLVE_ESCALATED_F64 | MMX_SOLVE_PRECISION_SUSPECT) != 0).sum()) == 0
+    assert np.array_equal(a["theta"], f["theta"]) and np.array_equal(a["status"], f["status"])
+    diag = pb.solve_diagnostics().cpu().numpy()
+    assert diag.shape == (B, 4) and np.isfinite(diag).all()
+    assert np.all(diag[:, 0] <= BOUND) and np.all((diag[:, 1] > 0) & (diag[:, 1] <= 1.0 + 1e-6))
+    assert np.allclose(diag[:, 3], np.linalg.norm(f["theta"], axis=1), rtol=1e-5)
+
+
+SHAPES = {
+    "cfg1": (lambda: make_test_character(24), [23, 12, 5], []),
+    "cfg2": (lambda: make_humanoid72(seed=12345, variant="p128", unit=UNIT), "lm", "lm"),
+}
+
+
+@pytest.mark.parametrize("route", ["fused", "wide"])
+@pytest.mark.parametrize("line_search", [0, 2])
+@pytest.mark.parametrize("name", sorted(SHAPES))
+def test_auto_holds_the_bound_where_single_precision_does_not(torch_cuda, orc, name, line_search, route):
+    """{above 1e-5} is a subset of {marked} u {another discrete decision}: under MMX_PRECISION_AUTO every element whose double run
+    converges and whose line-search decisions are the double run's is within 1e-5 -- at the batched driver's default damping
+    (0.01) and below it."""
+    mk, pp, op = SHAPES[name]
+    rig = mk()
+    if pp == "lm":
+        pp = op = humanoid72_landmark_joints(rig)
+    B = 1024
+    cons, th0, _ = make_problem(rig, pp, op, B, seed=777, perturb=0.3)
+    pb = _problem(torch_cuda, rig, cons, B)
+    pb.set_route(route)
+    e0 = np.array([orc.get_error(rig, cons.instance(b), th0[b].astype(np.float64), "f64") for b in range(0, B, 64)]).max()
+    for lam in (1e-2, 1e-3, 1e-5):
+        opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=lam, do_line_search=line_search, precision=MMX_PRECISION_AUTO)
+        out = _solve(torch_cuda, pb, th0, opt, want_history=True)
+        with np.errstate(all="ignore"):
+            ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=_cores())
+        sane = (ref["status"] == 0) & np.isfinite(ref["theta"]).all(axis=1) & (ref["error"] <= e0)
+        rel = _rel(out["theta"].astype(np.float64), ref["theta"])
+        esc = out["status"] & MMX_SOLVE_ESCALATED_F64 != 0
+        # an escalated element IS the double solver's run (1e-10 in tests/test_gpu_f64.py) rounded to float; with a line search
+        # an element whose accept test sits on its threshold may take the other branch: same decisions <=> same error history
+        h, href = out["error_history"], ref["error_history"]
+        same = np.all(np.abs(h - href) <= np.where(esc[:, None], 1e-6, 1e-3) * np.abs(href) + 1e-7 * href[:, :1], axis=1) if line_search else np.ones(B, bool)
+        held = sane & same
+        assert held.sum() >= 0.5 * sane.sum()
+        assert rel[held].max() <= BOUND, (name, lam, line_search, route, float(rel[held].max()), int((rel[held] > BOUND).sum()), int(esc.sum()))
+        assert np.isfinite(out["theta"]).all()
+
+
+def test_step_history_obeys_the_schedule_and_follows_the_double_run(torch_cuda, orc):
+    B = 512
+    rig, cons, th0 = _cfg2(B, seed=99)
+    pb = _problem(torch_cuda, rig, cons, B)
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
+    for route in ("fused", "wide"):
+        pb.set_route(route)
+        out = _solve(torch_cuda, pb, th0, opt, want_history=True, want_step_history=True)
+        lam, rho, h = out["step_history"][..., 0], out["step_history"][..., 1], out["error_history"]
+        assert np.allclose(lam[:, 0], 0.05, rtol=1e-6)
+        # lambda_{i+1} from (lambda_i, rho_i): x 4 when not rho >= 0.25, x 0.5 when rho > 0.75 (single-precision products)
+        nxt = np.where(~(rho >= 0.25), np.float32(4.0) * lam.astype(np.float32), np.where(rho > 0.75, np.float32(0.5) * lam.astype(np.float32), lam.astype(np.float32)))
+        assert np.array_equal(nxt[:, :-1].astype(np.float64), lam[:, 1:])
+        # a rejected step (rho <= 0) leaves the error exactly where it was, an accepted one changes it
+        rejected = ~(rho[:, :-1] > 0)
+        assert np.array_equal(rejected, h[:, 1:] == h[:, :-1])
+        ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=_cores(), step_history=True)
+        import bench
+
+        rel = _rel(out["theta"].astype(np.float64), ref["theta"])
+        res = bench.lm_branch_analysis(out["step_history"], h, ref, rel)
+        assert res["same_decisions"] >= 0.95 * B and res["same_decisions_lambda_sequences_equal"], res
+        assert res["num_above_bound_with_same_decisions"] == 0 and res["max_rel_same_decisions"] <= BOUND, res
+    with pytest.raises(capi.MmxError):  # the fixed-lambda rule has no schedule to record
+        _solve(torch_cuda, pb, th0, GnOptions.make(min_iterations=2, max_iterations=2), want_step_history=True)
