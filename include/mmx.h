@@ -94,12 +94,15 @@ typedef enum mmx_status {
                                        parameters -- no single-precision normal-equation solver is; the answer there
                                        is mmx_solve_f64.  mmx_solve_f64 never sets this bit. */
 #define MMX_SOLVE_PRECISION_SUSPECT 8 /* (bit, informational, ABI 10) the single-precision solve's own estimate of its
-                                         distance from the same solve in double -- eps * sum over the iterations of |step| /
-                                         sqrt(smallest Cholesky pivot ratio d_jj / (H_jj + lambda)), relative to |theta|;
+                                         distance from the same solve in double -- 0.042 eps / (smallest Cholesky pivot
+                                         ratio d_jj / (H_jj + lambda) of any iteration) ~ eps x cond(J^T J + lambda I),
+                                         calibrated as the 98th percentile of the relative distance on the BASELINE shapes;
                                          mmx_problem_solve_diagnostics returns it -- exceeds mmx_gn_options::precision_bound
-                                         (default 1e-5, north_star's parity bound).  Unlike MMX_SOLVE_DAMPING_FLOORED, which
-                                         only says that the factor's damping floor engaged, this follows the conditioning
-                                         that loses the digits.  With MMX_PRECISION_AUTO such elements (and the ones with an
+                                         (default 1e-5, north_star's parity bound: 1 / ratio = 4000).  Unlike
+                                         MMX_SOLVE_DAMPING_FLOORED, which only says that the factor's damping floor engaged,
+                                         this follows the conditioning that loses the digits; it is a property of the problem
+                                         class (rig, constraint set, lambda) more than of the instance: a class in which a
+                                         few per cent of the instances leave the bound is marked as a whole.  With MMX_PRECISION_AUTO such elements (and the ones with an
                                          error bit) are solved again by the double instantiation from the initial parameters.
                                          One-launch and wide routes; the explicit-Jacobian route keeps
                                          MMX_SOLVE_DAMPING_FLOORED as its cue. */

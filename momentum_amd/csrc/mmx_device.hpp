@@ -50,9 +50,21 @@ constexpr float kPivotFloor = 3.814697265625e-6f; // 2^-18
 // directions J does not determine the step is the more damped one (the reference's QR returns the minimum-norm-like
 // step there, the objective decreases the same).  The trust-region solver used the same device from the start.
 constexpr float kFactorDamping = 1e-5f;
-// Precision estimate of the single-precision solves (mmx_problem_solve_diagnostics; MMX_SOLVE_PRECISION_SUSPECT): gain of
-// eps * sum_it |step_it| / sqrt(smallest pivot ratio_it) / |theta|, calibrated on the BASELINE shapes against the double oracle
-constexpr float kPrecisionGain = 1.f;
+// Precision estimate of the single-precision solves (mmx_problem_solve_diagnostics; MMX_SOLVE_PRECISION_SUSPECT):
+//   est = kPrecisionGain * eps / min over every factorisation of the solve of the pivot ratio d_jj / (H_jj + lambda)
+// -- eps x an estimate of cond(J^T J + lambda I): what the rounding of g = J^T r is amplified by on its way into theta,
+// whatever the refinement through J does for the step.  Calibrated against the oracle's double run on 1024 instances per
+// row of (BASELINE configs[0] chain / configs[1] humanoid / the all-joints variant) x lambda {5e-2, 1e-2, 1e-3, 1e-5} x
+// {no line search, the driver's} x {one-launch, wide route} (scripts/diag_precision.py, profiles/r05_precision_estimate.txt):
+// the smallest pivot ratio is a property of the PROBLEM CLASS (rig, constraint set, lambda) -- it varies by 10 % inside a
+// batch and by decades between the rows --, and the share of instances further than 1e-5 from the double run follows it:
+//   1 / ratio   3.1e2 (configs[1], 0.05)  1.0e3  1.5e3 (configs[1], 0.01)  | 7.3e3 (configs[0], 0.05)  1.5e4 (configs[1], 1e-3)  3.6e4   >= 1.7e5
+//   above 1e-5  0 (worst 1.0e-6)          0      0 (worst 1.9e-6)          | 1-2 %                     1-4 %                      2-4 %   all
+// The gain puts the bound's default (1e-5) at 1 / ratio = 4000, between the last row without and the first row with
+// instances above it: est ~ the 98th percentile of the relative distance.  Which instances of a marked class end above the
+// bound is not predictable from the conditioning (a discrete line-search decision, an overshooting step): the whole class
+// is marked, which is what MMX_PRECISION_AUTO needs -- {above the bound} is a subset of {marked}.
+constexpr float kPrecisionGain = 0.042f;
 constexpr float kPivotFloorOrOne = kPivotFloor > 0.f ? kPivotFloor : 1.f;
 
 constexpr float kLn2 = 0.693147180559945309417232121458176568f; // momentum/math/constants.h:30,40

@@ -59,8 +59,7 @@ struct FusedLds {
   float* tanOwn; // [kTan J]
   float* tanPre; // [kTan J]
   double* red; // [8]
-  int* flags; // [12]: stop | not positive definite (this iteration) | status | largest pivot-floor ratio of this iteration (float bits)
-              // | float: |step|^2, |last correction|^2 of this iteration's refinement, path sum, largest refinement ratio
+  int* flags; // [4]: stop | not positive definite (this iteration) | status | unused
   // ---- rows of the further joint error functions and ellipsoid limits (kGen instantiations): dense in LDS
   float* gEv; // [GT][kGenEv] per constraint: vp(3) vn(3) sigma*dp(9) sigma*dn(9) tin row flags tinStop
   float* gRes; // [rowsGp] residual rows
@@ -890,7 +889,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     s.rho = take(NP);
     s.invDiag = take(NP);
     s.red = reinterpret_cast<double*>(take(16));
-    s.flags = reinterpret_cast<int*>(take(12));
+    s.flags = reinterpret_cast<int*>(take(4));
     s.gEv = s.gRes = s.gW = s.gJ = nullptr;
     if (kGen) {
       const int rowsGp = (fd.genRows + 3) & ~3;
@@ -1017,10 +1016,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     s.flags[0] = 0; // stop
     s.flags[1] = 0; // not positive definite (this iteration)
     s.flags[2] = 0; // status
-    s.flags[3] = 0; // largest kPivotFloor * (H_jj + mu) / d_jj met by this iteration's factorisations (float bits, >= 0)
-    s.flags[4] = 0, s.flags[5] = 0; // |step|^2 and |last correction|^2 of this iteration's refinement (floats)
-    s.flags[8] = 0;
-    s.flags[6] = 0, s.flags[7] = 0; // sum over the iterations of |step| / sqrt(smallest pivot ratio); largest refinement ratio (floats)
   }
   const bool hasParamRows = kRule >= 0 ? false : (pb.M > pb.rowsJoint); // limit / model-parameter rows present (uniform)
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
@@ -1028,6 +1023,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   float trRadius = fp.trustRadius; // TrustRegionQRT::curTrustRegionRadius_ (initializeSolver, trust_region_qr.cpp:38-41)
   double curError = DBL_MAX;
   int itersDone = 0;
+  float pivotWorst = 0.f; // largest kPivotFloor (H_jj + mu) / d_jj of the solve, per diagonal lane (the precision estimate's input)
+  float refineWorst = 0.f; // largest |last correction|^2 / |step|^2 of a refinement
   // the joint states / units in LDS already belong to s.th (left by an accepted trial of the line search or the LM
   // schedule, blockError<kStore>); stateError = the error an evaluation of phases A-C would report for it
   // (measured: line search 1.39 -> 1.52e6, LM schedule 1.41 -> 1.53e6 solves/s at cfg2 / cfg3)
@@ -1547,12 +1544,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           chain(false, 0.f);
 #ifndef MMX_EXP_NOPIVOT // (A/B build variant: no threshold at all)
           const float floorRow = s.invDiag[16 * k + (lane & 15)]; // kPivotFloor * (H_rr + lambda) of the diagonal lanes' rows
-          if (wave == 0 && diagLane) {
-            // the precision estimate's input: the smallest d_jj / (H_jj + mu) of the iteration, kept as the largest
-            // kPivotFloor (H_jj + mu) / d_jj (positive floats order like their bit patterns; a NaN sorts above everything).
-            // A store without a return value: nothing on the chain waits for it.
-            atomicMax(&s.flags[3], __float_as_int(floorRow * invd * invd));
-          }
+#ifndef MMX_EXP_NODIAG
+          // the precision estimate's input: the smallest d_jj / (H_jj + mu) of the solve, kept per lane as the largest
+          // kPivotFloor (H_jj + mu) / d_jj (one instruction off the chain; the lanes are joined once, after the last
+          // iteration).  Every wave factors the diagonal block redundantly: wave 0's lanes 0..15 are the ones read.
+          pivotWorst = floorRow * invd * invd > pivotWorst ? floorRow * invd * invd : pivotWorst; // (a NaN pivot keeps the old value: MMX_SOLVE_NOT_PD reports it)
+#endif
           if (__any(diagLane && !(floorRow * invd * invd < 1.f))) {
             loadRows();
             chain(true, floorRow);
@@ -1827,10 +1824,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       __syncthreads();
       const float corr2 = float((s.red[4] + s.red[5]) + (s.red[6] + s.red[7]));
       const float step2 = float((s.red[0] + s.red[1]) + (s.red[2] + s.red[3]));
-      if (tid == 0) { // (the precision estimate's inputs, read by thread 0 in phase K)
-        reinterpret_cast<float*>(s.flags)[4] = step2;
-        reinterpret_cast<float*>(s.flags)[5] = corr2;
-      }
+#ifndef MMX_EXP_NODIAG
+      refineWorst = fmaxf(refineWorst, corr2 * __builtin_amdgcn_rcpf(fmaxf(step2, 1e-37f))); // (mmx_problem_solve_diagnostics; uniform)
+#endif
       __syncthreads();
       // a correction is only taken when it is a contraction (kRefineMax2, mmx_kernels.hip: where the fp32 factor is no
       // preconditioner any more -- pivots at rounding level -- the refinement diverges): undo it and stop
@@ -2039,16 +2035,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       if (floored) {
         s.flags[2] |= 4; // MMX_SOLVE_DAMPING_FLOORED
       }
-      { // precision estimate (mmx_problem_solve_diagnostics): this iteration's share of the path sum
-        float* fs = reinterpret_cast<float*>(s.flags);
-        const float worst = __int_as_float(s.flags[3]); // kPivotFloor / (smallest pivot ratio of the iteration)
-        const float step2 = fs[4], corr2 = fs[5];
-        fs[6] += sqrtf(step2 * worst * (1.f / kPivotFloorOrOne));
-        fs[7] = fmaxf(fs[7], step2 > 0.f ? sqrtf(corr2 / step2) : 0.f);
-        fs[4] = 0.f, fs[5] = 0.f;
-        s.flags[3] = 0;
-        fs[8] = fmaxf(fs[8], worst); // ... and over the whole solve
-      }
+
       const bool converged = fabs(lastError - e) / (fabs(e) + double(FLT_MIN)) <= double(fp.threshold) * double(FLT_EPSILON);
       s.flags[0] = (it >= fp.minIterations && converged) ? 1 : 0;
       lastError = e;
@@ -2077,15 +2064,25 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       th2 += v * v;
     }
   }
-  th2 = blockSumF(s, th2, tid);
+#ifdef MMX_EXP_NODIAG
   if (tid == 0) {
-    // Estimated distance of theta from the same solve in double, relative to |theta|: every iteration's step carries a
-    // relative error of about eps * cond(J) = eps / sqrt(smallest pivot ratio) after the refinement through J; what the
-    // following iterations do not pull back (the weakly determined directions -- the ones a small pivot ratio reports) adds
-    // up along the path.  kPrecisionGain is calibrated on the BASELINE shapes (profiles/r05_precision_estimate.txt).
-    const float* fs = reinterpret_cast<const float*>(s.flags);
-    const float thn = sqrtf(th2);
-    const float est = kPrecisionGain * FLT_EPSILON * fs[6] / fmaxf(thn, 1e-30f);
+    st.iterations[b] = itersDone;
+    st.finalError[b] = curError;
+    st.status[b] = bad ? 1 : s.flags[2];
+  }
+#else
+  th2 = blockSumF(s, th2, tid);
+  pivotWorst = fmaxf(pivotWorst, dppMoveF<0xB1>(pivotWorst)); // the sixteen diagonal lanes of wave 0: four DPP steps inside their row
+  pivotWorst = fmaxf(pivotWorst, dppMoveF<0x4E>(pivotWorst));
+  pivotWorst = fmaxf(pivotWorst, dppMoveF<0x141>(pivotWorst));
+  pivotWorst = fmaxf(pivotWorst, dppMoveF<0x140>(pivotWorst));
+  if (tid == 0) {
+    // Estimated distance of theta from the same solve in double, relative to |theta|: kPrecisionGain * eps / (smallest pivot
+    // ratio d_jj / (H_jj + mu) of any factorisation of the solve) ~ eps * cond(J^T J + mu I) -- the rounding of g = J^T r is
+    // amplified by |H^-1| whatever the refinement through J does for the step (mmx_device.hpp has the calibration).
+    const float worst = pivotWorst;
+    const float ratio = worst > 0.f ? kPivotFloorOrOne / worst : 1.f;
+    const float est = kPrecisionGain * FLT_EPSILON / ratio;
     int stt = bad ? 1 : s.flags[2];
     if (!bad && st.precisionBound > 0.f && !(est <= st.precisionBound)) {
       stt |= 8; // MMX_SOLVE_PRECISION_SUSPECT
@@ -2093,14 +2090,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     if (st.diag != nullptr) {
       float* dg = st.diag + 4 * size_t(b);
       dg[0] = est;
-      dg[1] = fs[8] > 0.f ? kPivotFloorOrOne / fs[8] : 1.f;
-      dg[2] = fs[7];
-      dg[3] = thn;
+      dg[1] = ratio;
+      dg[2] = sqrtf(refineWorst);
+      dg[3] = sqrtf(th2);
     }
     st.iterations[b] = itersDone;
     st.finalError[b] = curError;
     st.status[b] = stt;
   }
+#endif
 #ifdef MMX_EXP_ARGPTR
 #undef rig
 #undef pb
@@ -2972,7 +2970,7 @@ size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int 
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
   const size_t meta = a4(NP + 1) + 3 * a4(nsrc) + 2 * a4(J) + a4(numLevels + 1) + a4(7 * size_t(J) + 1) + 2 * a4(nnz) + a4(J) +
       a4(J + 1) + 2 * a4(U) + a4(n) + 2 * a4(J) + a4(P);
-  const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 12;
+  const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 4;
   const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
   const size_t srcT = size_t(kSrcCh) * size_t(srcStrideFor(nsrc));
   const size_t blockJ = refine > srcT ? refine : srcT;

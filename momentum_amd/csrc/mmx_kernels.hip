@@ -2693,7 +2693,7 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
     }
     w = waveReduceMaxF(w);
     if ((tid & 63) == 0) {
-      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 3), __float_as_int(w));
+      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 1), __float_as_int(w));
     }
   }
   constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
@@ -3029,7 +3029,7 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
     }
     w = waveReduceMaxF(w);
     if (lane == 0) {
-      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 3), __float_as_int(w)); // (non-negative floats order like their bits)
+      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 1), __float_as_int(w)); // (non-negative floats order like their bits)
     }
   }
   float* d0 = g; // y = L^-1 g; solved in place: L^T d = y on the resident tiles
@@ -3130,13 +3130,9 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
     }
     return;
   }
-  if (sp.diagAcc != nullptr && tid == 0) { // this iteration's share of the precision estimate (as fusedSolveKernel's phase K)
+  if (sp.diagAcc != nullptr && tid == 0 && step2 > 0.f) { // the largest refinement ratio of the solve (squared)
     float* a = sp.diagAcc + 4 * size_t(b);
-    const float worst = a[3];
-    a[0] += sqrtf(step2 * worst * (1.f / kPivotFloorOrOne));
-    a[1] = fmaxf(a[1], worst);
-    a[2] = fmaxf(a[2], step2 > 0.f ? sqrtf(corr2 / step2) : 0.f);
-    a[3] = 0.f;
+    a[2] = fmaxf(a[2], corr2 / step2);
   }
   applyStepAndBook(pb, P, b, d0, false, errIter, theta, st, sp, tid);
   if (tid == 0) {
@@ -3530,16 +3526,16 @@ solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaIn
     th2 = waveReduceSumF(th2);
     if (lane == 0) {
       const float* a = diagAcc + 4 * size_t(b);
-      const float thn = sqrtf(th2);
-      const float est = kPrecisionGain * FLT_EPSILON * a[0] / fmaxf(thn, 1e-30f);
+      const float ratio = a[1] > 0.f ? kPivotFloorOrOne / a[1] : 1.f;
+      const float est = kPrecisionGain * FLT_EPSILON / ratio;
       if (!bad && st.precisionBound > 0.f && !(est <= st.precisionBound)) {
         st.status[b] |= 8; // MMX_SOLVE_PRECISION_SUSPECT
       }
       float* dg = st.diag + 4 * size_t(b);
       dg[0] = est;
-      dg[1] = a[1] > 0.f ? kPivotFloorOrOne / a[1] : 1.f;
-      dg[2] = a[2];
-      dg[3] = bad ? 0.f : thn;
+      dg[1] = ratio;
+      dg[2] = sqrtf(a[2]);
+      dg[3] = bad ? 0.f : sqrtf(th2);
     }
   }
   if (bad) {

@@ -91,9 +91,9 @@ struct StepParams {
   int32_t* stepIter; // [B] iteration + 1 when `delta` holds a step, -(iteration + 1) when H was not positive definite
   float* lambdaPer; // [B] per-instance damping (LM schedule, trust region) or null: `lambda` for everyone
   double* stepHistory; // SolveStateDev::stepHistory for stepUpdateKernel (which applies the schedule on the wide / explicit routes)
-  float* diagAcc; // [B][4] or null: the wide route's precision estimate in the making -- path sum, largest pivot-floor ratio of
-                  // the solve, largest refinement ratio, largest pivot-floor ratio of the current iteration (fusedSolveKernel
-                  // keeps the same four in LDS); solveFinalizeKernel turns them into SolveStateDev::diag and the status bit
+  float* diagAcc; // [B][4] or null: the wide route's precision estimate in the making -- [1] largest kPivotFloor (H_jj + mu) / d_jj
+                  // of the solve (float bits, by atomicMax), [2] largest squared refinement ratio (fusedSolveKernel keeps
+                  // the same two in LDS); solveFinalizeKernel turns them into SolveStateDev::diag and the status bit
   TrustStateDev tr; // MMX_STEP_TRUST_REGION on the wide route (all null otherwise)
   int32_t doLineSearch; // GaussNewtonSolverOptions::doLineSearch
   int32_t stepRule; // MMX_STEP_*

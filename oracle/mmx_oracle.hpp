@@ -1149,70 +1149,127 @@ inline T dot8(const T* a, const T* b, int n) {
 }
 
 // H (n x n column-major, lower triangle) += Jc^T Jc ; g += Jc^T r   with Jc = M x n column-major.
-// Register-blocked like a GEMM micro-kernel (4 x 2 entries of H per sweep over the rows, every entry
-// with the same 8 partial sums and the same summation order as dot8): the reference gets this
-// product from Eigen's blocked kernels (gauss_newton_solver.cpp:215), so the timed CPU baseline
-// should not re-read every column of J once per entry either.  Results are identical to the
-// entry-at-a-time form.
+// The reference gets this product from Eigen's blocked kernels (`rankUpdate`, gauss_newton_solver.cpp:215-216), which run
+// near a core's FMA peak; the timed CPU baseline must not be a strawman beside them, so this is a
+// register-blocked rank-M update in the shape of a GEMM micro-kernel: J is transposed once into a row-major copy (rows
+// padded with zeros), and a block of NJ columns x NV vectors of rows of H stays in vector registers for the whole sweep
+// over the M rows of J -- per row NV vector loads, NJ scalar broadcasts, NJ x NV fused multiply-adds, no horizontal sums.
+// 256-bit vectors (4 x 3 = 12 accumulators of 16 registers) or 512-bit ones (6 x 2 of 32) as the build's ISA offers; GCC
+// vector extensions, so every -march candidate of oracle.py's build sweep gets the same loop structure.  An entry of H is
+// the plain left-to-right sum over the rows (deterministic; another order than Eigen's, like every blocked product).
+#if defined(__AVX512F__)
+constexpr int kOrcVecBytes = 64;
+#else
+constexpr int kOrcVecBytes = 32;
+#endif
 template <class T>
-inline void accumulateNormalEquations(const T* Jc, const T* r, int M, int ld, int n, T* H, T* g) {
-  constexpr int BI = 4, BJ = 2;
-  const int M8 = M & ~7;
-  for (int j0 = 0; j0 < n; j0 += BJ) {
-    const int nj = std::min(BJ, n - j0);
-    for (int i0 = j0; i0 < n; i0 += BI) {
-      const int ni = std::min(BI, n - i0);
-      if (ni == BI && nj == BJ) {
-        T acc[BJ][BI][8];
-        for (int jj = 0; jj < BJ; ++jj) {
-          for (int ii = 0; ii < BI; ++ii) {
-            for (int l = 0; l < 8; ++l) {
-              acc[jj][ii][l] = T(0);
-            }
-          }
+struct OrcVec {
+  typedef T type __attribute__((vector_size(kOrcVecBytes), aligned(alignof(T))));
+};
+// The micro-kernel both dense products of the path run on:  H(i, j) += sign * sum_{k < K} A[k * lda + i] * A[k * lda + j]
+// for r0 <= j <= i < n (lower triangle, H column-major with leading dimension ldh).  A's "rows" k are contiguous in i:
+// the transposed copy of J (accumulateNormalEquations) or the finished columns of L themselves (choleskyLower's trailing
+// update).  Rows up to kOrcBlockRows - 1 past n are READ (never used): the caller guarantees they are addressable.
+template <class T>
+struct OrcBlock {
+  static constexpr int W = kOrcVecBytes / int(sizeof(T));
+  static constexpr int NV = kOrcVecBytes == 64 ? 2 : 3;
+  static constexpr int NJ = kOrcVecBytes == 64 ? 6 : 4;
+  static constexpr int IB = NV * W; // rows of H per block
+};
+template <class T, bool kSubtract>
+inline void syrkLower(const T* A, size_t lda, int K, int r0, int n, T* H, size_t ldh) {
+  using V = typename OrcVec<T>::type;
+  constexpr int W = OrcBlock<T>::W, NV = OrcBlock<T>::NV, NJ = OrcBlock<T>::NJ, IB = OrcBlock<T>::IB;
+  for (int j0 = r0; j0 < n; j0 += NJ) {
+    for (int i0 = r0 + (j0 - r0) / W * W; i0 < n; i0 += IB) { // (from the vector that holds the diagonal)
+      V acc[NJ][NV];
+      for (int jj = 0; jj < NJ; ++jj) {
+        for (int v = 0; v < NV; ++v) {
+          acc[jj][v] = V{};
         }
-        const T* cj0 = Jc + size_t(j0) * ld;
-        const T* cj1 = cj0 + ld;
-        const T* ci[BI];
-        for (int ii = 0; ii < BI; ++ii) {
-          ci[ii] = Jc + size_t(i0 + ii) * ld;
+      }
+      const T* row = A;
+      for (int k = 0; k < K; ++k, row += lda) {
+        V a[NV];
+        for (int v = 0; v < NV; ++v) {
+          a[v] = *reinterpret_cast<const V*>(row + i0 + v * W);
         }
-        for (int k = 0; k < M8; k += 8) {
-          for (int ii = 0; ii < BI; ++ii) {
-            for (int l = 0; l < 8; ++l) {
-              const T a = ci[ii][k + l];
-              acc[0][ii][l] += a * cj0[k + l];
-              acc[1][ii][l] += a * cj1[k + l];
-            }
-          }
-        }
-        for (int jj = 0; jj < BJ; ++jj) {
-          const T* cj = jj == 0 ? cj0 : cj1;
-          for (int ii = 0; ii < BI; ++ii) {
-            if (i0 + ii < j0 + jj) {
-              continue; // above the diagonal (only inside the diagonal block)
-            }
-            const T* s = acc[jj][ii];
-            T tail = T(0);
-            for (int k = M8; k < M; ++k) {
-              tail += ci[ii][k] * cj[k];
-            }
-            H[size_t(j0 + jj) * n + i0 + ii] += ((s[0] + s[4]) + (s[1] + s[5])) + ((s[2] + s[6]) + (s[3] + s[7])) + tail;
-          }
-        }
-      } else {
-        for (int jj = 0; jj < nj; ++jj) {
-          const T* cj = Jc + size_t(j0 + jj) * ld;
-          for (int ii = 0; ii < ni; ++ii) {
-            if (i0 + ii >= j0 + jj) {
-              H[size_t(j0 + jj) * n + i0 + ii] += dot8(Jc + size_t(i0 + ii) * ld, cj, M);
-            }
+        for (int jj = 0; jj < NJ; ++jj) {
+          const T bj = row[j0 + jj];
+          for (int v = 0; v < NV; ++v) {
+            acc[jj][v] += a[v] * bj;
           }
         }
       }
+      // (the accumulators leave through a copy: indexing their lanes in place would keep the array in memory for the whole
+      // sweep -- twelve stores per row of A, measured 18 instead of 30 GFLOP/s)
+      T out[NJ][IB];
+      for (int jj = 0; jj < NJ; ++jj) {
+        for (int v = 0; v < NV; ++v) {
+          const V t = acc[jj][v];
+          std::memcpy(&out[jj][v * W], &t, sizeof(V));
+        }
+      }
+      for (int jj = 0; jj < NJ && j0 + jj < n; ++jj) {
+        T* Hc = H + size_t(j0 + jj) * ldh;
+        const int lo = std::max(i0, j0 + jj), hi = std::min(i0 + IB, n);
+        for (int i = lo; i < hi; ++i) {
+          Hc[i] = kSubtract ? Hc[i] - out[jj][i - i0] : Hc[i] + out[jj][i - i0];
+        }
+      }
     }
-    for (int jj = 0; jj < nj; ++jj) {
-      g[j0 + jj] += dot8(Jc + size_t(j0 + jj) * ld, r, M);
+  }
+}
+
+template <class T>
+inline void accumulateNormalEquations(const T* Jc, const T* r, int M, int ld, int n, T* H, T* g) {
+  using V = typename OrcVec<T>::type;
+  constexpr int W = OrcBlock<T>::W, NV = OrcBlock<T>::NV, NJ = OrcBlock<T>::NJ, IB = OrcBlock<T>::IB;
+  const int np = (n + IB - 1) / IB * IB + IB + NJ; // row stride of the transposed copy: whole blocks + the kernel's overhang
+  static thread_local std::vector<T> scratch;
+  if (scratch.size() < size_t(M) * size_t(np)) {
+    scratch.resize(size_t(M) * size_t(np));
+  }
+  T* Jt = scratch.data();
+  // transposition, 8 x 8 element blocks (both sides touch whole cache lines); pad columns zero
+  for (int k0 = 0; k0 < M; k0 += 8) {
+    const int k1 = std::min(k0 + 8, M);
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      const int i1 = std::min(i0 + 8, n);
+      for (int k = k0; k < k1; ++k) {
+        for (int i = i0; i < i1; ++i) {
+          Jt[size_t(k) * np + i] = Jc[size_t(i) * ld + k];
+        }
+      }
+    }
+    for (int k = k0; k < k1; ++k) {
+      for (int i = n; i < np; ++i) {
+        Jt[size_t(k) * np + i] = T(0);
+      }
+    }
+  }
+  syrkLower<T, false>(Jt, size_t(np), M, 0, n, H, size_t(n));
+  // g += J^T r: the same sweep with r as the broadcast operand
+  for (int i0 = 0; i0 < n; i0 += IB) {
+    V acc[NV];
+    for (int v = 0; v < NV; ++v) {
+      acc[v] = V{};
+    }
+    const T* row = Jt;
+    for (int k = 0; k < M; ++k, row += np) {
+      const T rk = r[k];
+      for (int v = 0; v < NV; ++v) {
+        acc[v] += *reinterpret_cast<const V*>(row + i0 + v * W) * rk;
+      }
+    }
+    T out[IB];
+    for (int v = 0; v < NV; ++v) {
+      const V t = acc[v];
+      std::memcpy(&out[v * W], &t, sizeof(V));
+    }
+    for (int i = i0; i < std::min(i0 + IB, n); ++i) {
+      g[i] += out[i - i0];
     }
   }
 }
@@ -1225,17 +1282,27 @@ inline void accumulateNormalEquations(const T* Jc, const T* r, int M, int ld, in
 // that case.  (Eigen switches to a blocked variant for n >= 32: same mathematics, different
 // summation order; not bit-pinned by any reference test.)
 template <class T>
-inline bool choleskyLower(T* H, int n) {
-  // column k takes the contributions of the finished columns p = 0..k-1 one after the other (each
-  // a contiguous axpy over the rows k..n-1): the same sums in the same order as the textbook
-  // "s -= L(i,p) L(k,p) for p < k", walked along the storage instead of across it
-  std::vector<T> col(static_cast<size_t>(n));
-  for (int k = 0; k < n; ++k) {
+inline bool choleskyLowerUnblocked(T* H, int n, int c0, int c1, T* col) {
+  // columns c0 .. c1 - 1 (rows down to n), left-looking over the columns of THIS panel only: column k takes the contributions
+  // of the finished panel columns p = c0 .. k - 1 one after the other (each a contiguous axpy over the rows k .. n - 1) --
+  // the sums in the order of the textbook "s -= L(i,p) L(k,p) for p < k", walked along the storage instead of across it
+  for (int k = c0; k < c1; ++k) {
     T* ck = H + size_t(k) * n;
     for (int i = k; i < n; ++i) {
       col[i] = ck[i];
     }
-    for (int p = 0; p < k; ++p) {
+    int p = c0;
+    for (; p + 4 <= k; p += 4) { // four finished columns per sweep over the rows (one load / store of col per four updates)
+      const T* q0 = H + size_t(p) * n;
+      const T* q1 = q0 + n;
+      const T* q2 = q1 + n;
+      const T* q3 = q2 + n;
+      const T l0 = q0[k], l1 = q1[k], l2 = q2[k], l3 = q3[k];
+      for (int i = k; i < n; ++i) {
+        col[i] = (((col[i] - q0[i] * l0) - q1[i] * l1) - q2[i] * l2) - q3[i] * l3; // (the order of the one-at-a-time form)
+      }
+    }
+    for (; p < k; ++p) {
       const T* cp = H + size_t(p) * n;
       const T l = cp[k];
       for (int i = k; i < n; ++i) {
@@ -1244,12 +1311,35 @@ inline bool choleskyLower(T* H, int n) {
     }
     const T d = col[k];
     if (!(d > T(0))) {
-      return false; // column k and everything after it stay as they were (see above)
+      return false; // column k and everything after it stay as they are (see above)
     }
     const T lkk = std::sqrt(d);
     ck[k] = lkk;
     for (int i = k + 1; i < n; ++i) {
       ck[i] = col[i] / lkk;
+    }
+  }
+  return true;
+}
+
+// Blocked right-looking form for n >= 32, like Eigen's llt_inplace<Lower>::blocked (Eigen/src/Cholesky/LLT.h: unblocked
+// factor of the diagonal block and its panel, then A22.rankUpdate(A21, -1)): panels of sixteen columns, the trailing
+// update on syrkLower (the J^T J micro-kernel; the finished columns of L are its operand as they lie).  A failing pivot
+// stops inside its panel; like in Eigen the trailing matrix then carries the finished panels' updates.
+template <class T>
+inline bool choleskyLower(T* H, int n) {
+  std::vector<T> col(static_cast<size_t>(n));
+  constexpr int kPanel = 16;
+  if (n < 32 || n < 2 * OrcBlock<T>::IB) {
+    return choleskyLowerUnblocked<T>(H, n, 0, n, col.data());
+  }
+  for (int k0 = 0; k0 < n; k0 += kPanel) {
+    const int k1 = std::min(k0 + kPanel, n);
+    if (!choleskyLowerUnblocked<T>(H, n, k0, k1, col.data())) {
+      return false;
+    }
+    if (k1 < n) { // (the kernel reads up to IB - 1 rows past n of the panel's columns: they lie inside the matrix, k1 < n)
+      syrkLower<T, true>(H + size_t(k0) * n, size_t(n), k1 - k0, k1, n, H, size_t(n));
     }
   }
   return true;
@@ -1324,6 +1414,13 @@ struct Options {
   float lmLambdaMin = 1e-6f, lmLambdaMax = 1e6f, lmUp = 4.f, lmDown = 0.5f;
   float trustRegionRadius = 1.f; // TrustRegionQROptions::trustRegionRadius_ (trust_region_qr.h:24)
 };
+
+#ifdef ORC_PHASE_TIMERS
+inline unsigned long long* orcPhaseCycles() { // getJacobian | compaction + zeroing | J^T J, J^T r | copies of the system | factor, solve, update | loop bookkeeping
+  static thread_local unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return c;
+}
+#endif
 
 template <class T>
 struct SolveResult {
@@ -1472,9 +1569,17 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
   const T maxTrustRegionRadius = T(10); // trust_region_qr.h:83
 
   int it = 0;
+#ifdef ORC_PHASE_TIMERS // (diagnostic build: where a solve's time goes; cycles of the time-stamp counter per phase)
+#define ORC_T(slot) { const unsigned long long now_ = __builtin_ia32_rdtsc(); orcPhaseCycles()[slot] += now_ - tPrev_; tPrev_ = now_; }
+  unsigned long long tPrev_ = __builtin_ia32_rdtsc();
+#else
+#define ORC_T(slot)
+#endif
   for (; it < opt.maxIterations; ++it) { // solver.cpp:89
     // ---- doIteration (:224) / computeJtJFromJacobianBlocks (:110-221)
+    ORC_T(5)
     error = fn.getJacobian(params.data(), jac.data(), res.data());
+    ORC_T(0)
     // column compaction to the enabled subset (:204-209), in place
     for (int s = 0; s < n; ++s) {
       if (E[s] > s) {
@@ -1483,8 +1588,10 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
     }
     std::fill(H.begin(), H.end(), T(0));
     std::fill(g.begin(), g.end(), T(0));
+    ORC_T(1)
     if (!opt.useBlockJtJ) {
       accumulateNormalEquations<T>(jac.data(), res.data(), M, M, n, H.data(), g.data()); // :215-216
+      ORC_T(2)
     } else {
       // SolverFunctionT::getJtJR default (solver_function.cpp:74-121): one rank update per block
       // (= per error function), then compaction (:69-107) -- mathematically the same system,
@@ -1499,6 +1606,7 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
     }
     out.lastJtJ = H;
     out.lastJtr = g;
+    ORC_T(3)
 
     if (opt.stepRule == 2) {
       // ---- TrustRegionQRT<T>::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270).  jac
@@ -1728,6 +1836,7 @@ inline SolveResult<T> solveGaussNewton(Fn& fn, const Options& opt, T* theta) {
       }
     }
 
+    ORC_T(4)
     out.errorHistory.push_back(error); // solver.cpp:92
     // convergence (solver.cpp:96-115)
     const bool converged = std::fabs(lastError - error) / (std::fabs(error) + double(FLT_MIN)) <=

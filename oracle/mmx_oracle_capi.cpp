@@ -480,6 +480,18 @@ int orc_active_joint_params(const mmx_rig_desc* d, const uint8_t* enabled, uint8
   return 0;
 }
 
+#ifdef ORC_PHASE_TIMERS
+// cycles per phase accumulated by THIS thread's solves since the last call (single-threaded diagnostic runs); clears them
+int orc_phase_cycles(unsigned long long out[8]) {
+  unsigned long long* c = orcPhaseCycles();
+  for (int i = 0; i < 8; ++i) {
+    out[i] = c[i];
+    c[i] = 0;
+  }
+  return 0;
+}
+#endif
+
 int orc_hardware_threads(void) {
   return int(std::thread::hardware_concurrency());
 }

@@ -12,7 +12,7 @@ for v in "$@"; do
 import json,sys
 try:
     d=json.load(open(sys.argv[2]))
-    print("%-10s value %.4g solves/s  ms/step %.3f  parity max %.3g  failed %s" % (sys.argv[1], d["value"], d["ms_per_step"], d["check"].get("max_rel_theta_vs_oracle_f64",-1), d["check"]["failed_instances"]))
+    print("%-10s value %.4g solves/s  ms/step %.3f  parity max %.3g  failed %s" % (sys.argv[1], d["value"], d["ms_per_step"], d["check"].get("max_rel",-1), d["check"]["failed_instances"]))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY

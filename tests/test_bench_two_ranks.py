@@ -37,9 +37,9 @@ def test_bench_two_ranks_over_gloo():
     assert d["config"]["global_batch"] == 2048 and d["config"]["batch_per_gpu"] == 1024
     # both shards were solved and reduced: 2 x 1024 instances x 10 iterations, nobody failed
     assert d["check"]["sum_iterations"] == 2 * 1024 * 10 and d["check"]["failed_instances"] == 0
-    assert d["value"] > 0 and abs(d["value"] - 2048 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+    assert d["value"] > 0 and abs(d["value"] - 2048 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-4 * d["value"]  # (the line carries six significant digits)
     ex = d["config"]["exchange"]
-    assert ex["per_rank_solves_per_s"]["min"] <= ex["per_rank_solves_per_s"]["max"] and ex["per_rank_solves_per_s"]["min"] * 2 >= d["value"] * 0.999
+    assert ex["per_rank_solves_per_s"][0] <= ex["per_rank_solves_per_s"][1] and ex["per_rank_solves_per_s"][0] * 2 >= d["value"] * 0.999
     # the N = 1 line of the same command carries the same workload and per-GPU batch: what a scaling run compares
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "1024", "--no-cpu-baseline",
                           "--no-extra-configs", "--check-instances", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)  # fmt: skip

@@ -23,7 +23,7 @@ def _solve_and_check(torch, config, B, n_check, line_search=0, step_rule=None, i
     opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=0.05, step_rule=rule, do_line_search=line_search)
     out = db.pb.solve(db.theta0.clone(), opt)
     torch.cuda.synchronize()
-    assert int((out["status"] != 0).sum()) == 0
+    assert int((out["status"] & 3 != 0).sum()) == 0  # (MMX_SOLVE_ERROR_MASK: the informational bits may be set)
     assert int((out["iterations"] != iterations).sum()) == 0
     chk = bench.parity_check(db, out["theta"], opt, n_check)
     return chk, out, db
@@ -84,7 +84,7 @@ def test_config3_gauss_newton_part_at_full_size(torch_cuda, orc):
     opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05)
     out = db.pb.solve(db.theta0.clone(), opt)
     torch.cuda.synchronize()
-    assert int((out["status"] != 0).sum()) == 0
+    assert int((out["status"] & 3 != 0).sum()) == 0  # (MMX_SOLVE_ERROR_MASK: the informational bits may be set)
     from oracle import oracle as o
 
     idx = np.concatenate([np.arange(0, 683), np.arange(B // 2, B // 2 + 683), np.arange(B - 682, B)])

@@ -167,7 +167,7 @@ def test_three_kernel_path_system_sizes(torch_cuda, orc, count, monkeypatch):
         sens = np.linalg.norm(pert["theta"] - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-12)
         tol = np.maximum(1e-5, 3.0 * sens)
         assert (rel <= tol).all(), (count, ls, rel, tol)
-        assert (out["status"].cpu().numpy() == 0).all()
+        assert (out["status"].cpu().numpy() & 3 == 0).all()
         h = out["error_history"].cpu().numpy()
         assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
 

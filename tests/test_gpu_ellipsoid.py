@@ -96,7 +96,7 @@ def test_solve_with_ellipsoid_limits_matches_oracle(orc, which, line_search):
     assert (rel <= tol).all(), (rel, tol)
     h = out["error_history"].cpu().numpy()
     assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
-    assert (out["status"].cpu().numpy() == 0).all()
+    assert (out["status"].cpu().numpy() & 3 == 0).all()
 
 
 @pytest.mark.parametrize("which", ["chain8", "humanoid72"])
@@ -140,7 +140,7 @@ def test_fused_solve_carries_blocks_and_ellipsoids(orc, which, monkeypatch):
             th = out["theta"].cpu().numpy()
             rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
             assert (rel <= tol).all(), (general, rel, tol)
-            assert (out["status"].cpu().numpy() == 0).all()
+            assert (out["status"].cpu().numpy() & 3 == 0).all()
             h = out["error_history"].cpu().numpy()
             assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
             assert pb.last_route() == general
@@ -222,6 +222,6 @@ def test_wide_solve_carries_blocks_and_ellipsoids(orc, route, monkeypatch):
         rel = np.linalg.norm(out["theta"].cpu().numpy() - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
         tol = np.maximum(3e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
         assert (rel <= tol).all(), (route, rel, tol)
-        assert (out["status"].cpu().numpy() == 0).all()
+        assert (out["status"].cpu().numpy() & 3 == 0).all()
         h = out["error_history"].cpu().numpy()
         assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())

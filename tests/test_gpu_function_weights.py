@@ -97,7 +97,7 @@ def test_solve_with_per_element_weights_matches_the_oracle(torch_cuda, orc, with
         rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
         tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
         assert np.all(rel <= tol), (route, rel, tol)
-        assert np.all(out["status"].cpu().numpy() == 0)
+        assert np.all(out["status"].cpu().numpy() & 3 == 0)
         h = out["error_history"].cpu().numpy()
         assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
     # the weights matter: without them the answer differs

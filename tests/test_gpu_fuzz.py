@@ -134,7 +134,7 @@ def test_random_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
         tol = np.maximum(tol, 3.0 * np.linalg.norm(ref32["theta"] - ref["theta"], axis=1) / dnorm)
     assert np.all(rel <= tol), (seed, rel, tol)
     assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     assert np.all(th[:, en == 0] == th0[:, en == 0])  # disabled parameters are never touched
@@ -245,7 +245,7 @@ def test_random_wide_rig_matches_oracle(torch_cuda, orc, seed, monkeypatch):
     tol = np.maximum(2e-5, 3.0 * np.linalg.norm(ref32["theta"] - ref["theta"], axis=1) / den)
     assert np.all(rel <= tol), (seed, J, P, rel, tol)
     assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     assert np.all(th[:, en == 0] == th0[:, en == 0])
@@ -359,5 +359,5 @@ def test_random_rig_double_solve_matches_oracle(torch_cuda, orc, seed):
     th = out["theta"].cpu().numpy()
     rel = np.linalg.norm(th - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
     assert np.all(rel <= 1e-8), (seed, J, P, rel)
-    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]) and np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]) and np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
     assert np.all(th[:, en == 0] == th0[:, en == 0].astype(np.float64))

@@ -144,7 +144,7 @@ def test_solve_with_blocks_matches_oracle(torch_cuda, orc, which, mode):
     th = out["theta"].cpu().numpy()
     ref = orc.solve_batch(rig, full, th0, opt, dtype="f64")
     assert (out["iterations"].cpu().numpy() == ref["iterations"]).all()
-    assert (out["status"].cpu().numpy() == 0).all()
+    assert (out["status"].cpu().numpy() & 3 == 0).all()
     rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
     sens = _sensitivity(orc, rig, full, th0, opt, ref)
     # explicit-J path on a large-residual problem (unsatisfiable planes / aims): fp32 storage of J bounds

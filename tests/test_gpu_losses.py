@@ -83,4 +83,4 @@ def test_solve_with_robust_loss_matches_oracle(torch_cuda, orc, name, solver, mo
     assert np.all(rel <= tol), (name, rel, tol)
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])  # (MMX_SOLVE_ERROR_MASK: the oracle has no informational bits)

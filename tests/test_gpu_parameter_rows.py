@@ -142,7 +142,7 @@ def test_solve_with_limits_and_model_prior_matches_oracle(torch_cuda, orc, which
         tol = np.maximum(tol, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
     assert np.all(rel <= tol), (rel, tol)
     assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
 
@@ -192,6 +192,6 @@ def test_wide_solve_with_limits_and_the_model_prior(torch_cuda, orc, route, monk
         rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
         tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, full, th0, opt, ref))
         assert np.all(rel <= tol), (route, rel, tol)
-        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
         h = out["error_history"].cpu().numpy()
         assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())

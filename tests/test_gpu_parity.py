@@ -198,7 +198,7 @@ def test_solve_matches_oracle_pose_parameters(torch_cuda, orc, name):
         tol = np.maximum(tol, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
     assert np.all(rel <= tol), (rel, tol)
     assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])  # integer bookkeeping: exact
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
     e, eref = out["error"].cpu().numpy(), ref["error"]
     assert np.abs(e - eref).max() <= 1e-4 * np.maximum(1e-3, np.abs(eref)).max()
     h, href = out["error_history"].cpu().numpy(), ref["error_history"]
@@ -293,7 +293,7 @@ def test_line_search_and_lm_schedule_match_oracle(torch_cuda, orc, mode, path, m
     assert np.abs(h - href).max() <= 1e-4 * max(1.0, np.abs(href).max())
     if mode.startswith("line_search"):
         assert np.all(np.diff(h, axis=1) <= 1e-6 * np.abs(h[:, :-1]) + 1e-12)  # monotone
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
 
 
 @pytest.mark.parametrize("path", ["fused", "three_kernel"])
@@ -364,7 +364,7 @@ def test_nonfinite_input_reverts_to_initial_parameters(torch_cuda):
     opt = GnOptions.make(min_iterations=3, max_iterations=3)
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt)
     st = out["status"].cpu().numpy()
-    assert st[1] != 0 and np.all(np.delete(st, 1) == 0)
+    assert st[1] & 3 != 0 and np.all(np.delete(st, 1) & 3 == 0)
     assert np.array_equal(out["theta"].cpu().numpy()[1], th0[1])
     assert np.isfinite(out["theta"].cpu().numpy()).all()
 
@@ -394,7 +394,7 @@ def test_full_size_batch_properties(torch_cuda):
     assert torch.equal(th[0].expand_as(th), th)  # position in the batch does not matter
     h = out["error_history"]
     assert torch.all(h[:, -1] < 1e-3 * h[:, 0])
-    assert torch.all(out["status"] == 0) and torch.all(out["iterations"] == 10)
+    assert torch.all(out["status"] & 3 == 0) and torch.all(out["iterations"] == 10)
 
 
 @pytest.mark.parametrize("kp,ko", [(60, 2), (130, 90), (250, 100)])
@@ -456,7 +456,7 @@ def test_large_rig_config5_solve_matches_oracle(torch_cuda, orc):
     tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
     assert np.all(rel <= tol), (rel, tol)
     assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
     # the driver's default doLineSearch on the large system: Cholesky step in HBM + stepUpdateKernel
     opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=True)
     out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
@@ -487,7 +487,7 @@ def test_config3_full_size_lm_schedule_properties(torch_cuda, orc):
     out = pb.solve(torch.from_numpy(rep(th0)).to(pb.device), opt, want_history=True)
     th = out["theta"].view(B // Bs, Bs, -1)
     assert torch.equal(th[0].expand_as(th), th)
-    assert torch.isfinite(out["theta"]).all() and torch.all(out["status"] == 0) and torch.all(out["iterations"] == 10)
+    assert torch.isfinite(out["theta"]).all() and torch.all(out["status"] & 3 == 0) and torch.all(out["iterations"] == 10)
     h = out["error_history"]
     assert torch.all(h[:, -1] < 1e-3 * h[:, 0])
     ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
@@ -535,7 +535,7 @@ def test_tensor_ik_default_options(torch_cuda, orc):
     assert np.all(np.abs(e - eref) <= 1e-3 * eref + 1e-9), (e, eref)
     h = out["error_history"].cpu().numpy()
     assert np.all(np.diff(h[:, : it.min()], axis=1) <= 1e-6 * np.abs(h[:, : it.min() - 1]) + 1e-12)  # line search: monotone
-    assert np.all(out["status"].cpu().numpy() == 0)
+    assert np.all(out["status"].cpu().numpy() & 3 == 0)
     del th
 
 
@@ -619,7 +619,7 @@ def test_wide_solve_variants_agree_with_the_oracle(torch_cuda, orc, variant, mon
         rel = np.linalg.norm(th - ref["theta"], axis=1) / den
         tol = np.maximum(1e-5, 3.0 * _sensitivity(orc, rig, cons, th0, opt, ref))
         assert np.all(rel <= tol), (variant, rel, tol)
-        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        assert np.array_equal(out["status"].cpu().numpy() & 3, ref["status"])
         if opt.step_rule != MMX_STEP_LM_SCHEDULE:
             assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"]), (out["iterations"], ref["iterations"])
 
@@ -642,7 +642,7 @@ def test_wide_path_on_a_small_skeleton_with_many_units(torch_cuda, orc, monkeypa
         th = out["theta"].cpu().numpy()
         rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
         assert rel.max() <= 1e-5, (ls, rel.max())
-        assert int((out["status"] != 0).sum()) == 0
+        assert int((out["status"] & 3 != 0).sum()) == 0
         h = out["error_history"].cpu().numpy()
         assert np.abs(h - ref["error_history"]).max() <= 1e-4 * max(1.0, np.abs(ref["error_history"]).max())
     # iterationHistory_["parameters"] on this route: row i = the parameters after iteration i (the solve is deterministic)

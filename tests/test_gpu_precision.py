@@ -74,7 +74,10 @@ def test_precision_f64_is_the_double_instantiation_on_float_parameters(torch_cud
         # the same kernel on the same values: the float result is the double one rounded once
         assert np.array_equal(out["theta"], d["theta"].cpu().numpy().astype(np.float32))
         assert np.array_equal(out["error_history"], d["error_history"].cpu().numpy())
-        assert np.array_equal(out["iterations"], d["iterations"].cpu().numpy()) and np.all(out["status"] == 0)
+        # (lambda = 1e-5 without a line search: an overshooting Gauss-Newton run meets a non-positive pivot even in double --
+        # MMX_SOLVE_NOT_PD on both paths alike)
+        assert np.array_equal(out["iterations"], d["iterations"].cpu().numpy()) and np.array_equal(out["status"], d["status"].cpu().numpy())
+        assert np.all(out["status"] & 1 == 0) and (lam < 0.05 or np.all(out["status"] == 0))
         if lam == 0.05 and not line_search:
             ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=_cores())
             assert _rel(out["theta"].astype(np.float64), ref["theta"]).max() <= 2e-7  # (float rounding of theta: 6e-8)
@@ -120,8 +123,14 @@ SHAPES = {
 @pytest.mark.parametrize("name", sorted(SHAPES))
 def test_auto_holds_the_bound_where_single_precision_does_not(torch_cuda, orc, name, line_search, route):
     """{above 1e-5} is a subset of {marked} u {another discrete decision}: under MMX_PRECISION_AUTO every element whose double run
-    converges and whose line-search decisions are the double run's is within 1e-5 -- at the batched driver's default damping
-    (0.01) and below it."""
+    converges, is itself a stable computation, and whose line-search decisions are the double run's is within 1e-5 -- at the
+    batched driver's default damping (0.01) and below it.
+
+    Stable: without a line search an undamped Gauss-Newton step overshoots on these marginally determined shapes and the
+    iteration becomes chaotic IN DOUBLE -- the oracle's double run started from theta0 + 1e-12 ends 1e-7 ... O(1) from its
+    run started at theta0 on a few per cent of the elements (measured: cfg1 0.4 %, cfg2 at lambda = 1e-5 a third of the
+    elements whose run stays finite at all).  Two correct double implementations (the kernel's and the oracle's differ in the
+    order of their sums) part the same way there; such elements are counted, not compared."""
     mk, pp, op = SHAPES[name]
     rig = mk()
     if pp == "lm":
@@ -136,15 +145,18 @@ def test_auto_holds_the_bound_where_single_precision_does_not(torch_cuda, orc, n
         out = _solve(torch_cuda, pb, th0, opt, want_history=True)
         with np.errstate(all="ignore"):
             ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64", nthreads=_cores())
+            pert = orc.solve_batch(rig, cons, th0.astype(np.float64) + 1e-12, opt, dtype="f64", nthreads=_cores())
         sane = (ref["status"] == 0) & np.isfinite(ref["theta"]).all(axis=1) & (ref["error"] <= e0)
+        with np.errstate(all="ignore"):
+            stable = _rel(pert["theta"], ref["theta"]) <= 1e-7  # (amplification of a 1e-12 perturbation by at most 1e5)
         rel = _rel(out["theta"].astype(np.float64), ref["theta"])
         esc = out["status"] & MMX_SOLVE_ESCALATED_F64 != 0
         # an escalated element IS the double solver's run (1e-10 in tests/test_gpu_f64.py) rounded to float; with a line search
         # an element whose accept test sits on its threshold may take the other branch: same decisions <=> same error history
         h, href = out["error_history"], ref["error_history"]
         same = np.all(np.abs(h - href) <= np.where(esc[:, None], 1e-6, 1e-3) * np.abs(href) + 1e-7 * href[:, :1], axis=1) if line_search else np.ones(B, bool)
-        held = sane & same
-        assert held.sum() >= 0.5 * sane.sum()
+        held = sane & same & stable
+        assert held.sum() >= 0.5 * sane.sum(), (name, lam, line_search, route, int(sane.sum()), int(same.sum()), int(stable.sum()))
         assert rel[held].max() <= BOUND, (name, lam, line_search, route, float(rel[held].max()), int((rel[held] > BOUND).sum()), int(esc.sum()))
         assert np.isfinite(out["theta"]).all()
 
