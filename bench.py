@@ -70,8 +70,9 @@ EXTRA_RUNS = [
     # oracle's DOUBLE instantiation as its CPU baseline
     ("cfg2@4096 lambda=1e-5 line_search=2 dtype=f64", "cfg2", 4096, 2, 3, 1024, 1e-5, "f64"),
     # MMX_PRECISION_AUTO at a damping where single precision loses the bound on part of the batch (profiles/r05_weak_damping.json):
-    # single precision first, the elements its precision estimate marks re-solved in double on the same stream
-    ("cfg2@4096 lambda=1e-3 precision=auto", "cfg2", 4096, 0, 6, 2048, 1e-3, "f32", 2),
+    # single precision first, the elements its precision estimate marks re-solved in double on the same stream (with the batched
+    # driver's line search: without one the undamped iteration is chaotic in double on a few per cent of these instances)
+    ("cfg2@4096 lambda=1e-3 line_search=2 precision=auto", "cfg2", 4096, 2, 6, 2048, 1e-3, "f32", 2),
     # weak damping (pymomentum's test_solver2.py value) with the batched driver's line search: on this shape -- as many
     # independent rows as solved parameters -- no single-precision Cholesky solver holds 1e-5 on theta (check.pass is
     # false by construction, the float oracle's figures stand beside it); tests/test_gpu_weak_damping.py has the table
@@ -277,6 +278,7 @@ def lm_branch_analysis(gpu_steps, gpu_err, ref, rel, bound=PARITY_BOUND):
     lam_r, rho_r = np.asarray(ref["lambda_history"]), np.asarray(ref["gain_ratio_history"])
     cls = lambda r: np.where(~(r >= 0.25), 0, np.where(r > 0.75, 2, 1))
     same_it = ((rho_g > 0) == (rho_r > 0)) & (cls(rho_g) == cls(rho_r))
+    same_it[:, -1] = (rho_g[:, -1] > 0) == (rho_r[:, -1] > 0)  # (the last iteration's scaling of lambda acts on nothing)
     same = same_it.all(axis=1)
     lam_ok = np.all(np.abs(lam_g - lam_r) <= 1e-6 * np.abs(lam_r), axis=1)
     flips = np.flatnonzero(~same)
@@ -308,8 +310,13 @@ def lm_branch_analysis(gpu_steps, gpu_err, ref, rel, bound=PARITY_BOUND):
         "flip_rel_theta": [float(x) for x in rel[flips][:64]],
         "flip_final_error_gpu_over_double": [float(a / b) if b > 0 else None for a, b in zip(gpu_err[flips, -1][:64], np.asarray(ref["error_history"])[flips, -1][:64])],
     }
-    # pass: theta within the bound wherever the decisions are the double run's, and nothing above the bound that is not a flip
-    out["pass"] = bool(out["num_above_bound_with_same_decisions"] == 0 and out["same_decisions_lambda_sequences_equal"])
+    # pass: theta within the bound wherever the decisions are the double run's, and every other instance a genuine threshold
+    # case: at its first diverging iteration the double run's gain ratio within 1e-2 of the threshold the two ratios straddle
+    # (measured on 16 384 instances of the cfg3 batch: 31 flips, all within 4.7e-3, 23 within 1e-3; the ones further than
+    # 1e-3 sit at iterations 8-9 of a converged fit, where e - e_new is a difference at the noise floor of a float error sum;
+    # the oracle's own FLOAT instantiation flips on 263 of the same instances, ratios up to 0.12 apart)
+    out["pass"] = bool(out["num_above_bound_with_same_decisions"] == 0 and out["same_decisions_lambda_sequences_equal"]
+                       and out["flip_max_distance_of_double_rho_to_threshold"] <= 1e-2)
     return out
 
 

@@ -573,10 +573,16 @@ def _glb_binary_chunk(data) -> bytes:
         return b""
     import struct
 
-    clen = struct.unpack("<I", b[12:16])[0]
+    if len(b) < 20:
+        raise ModelFormatError("truncated GLB header")
+    total, clen = struct.unpack("<I", b[8:12])[0], struct.unpack("<I", b[12:16])[0]
+    if total > len(b) or 20 + clen > len(b):  # (an untrusted file: every declared length is held against the bytes at hand)
+        raise ModelFormatError("GLB chunk lengths exceed the file")
     pos = 20 + clen
     while pos + 8 <= len(b):
         n, ctype = struct.unpack("<I4s", b[pos : pos + 8])
+        if pos + 8 + n > len(b):
+            raise ModelFormatError("GLB chunk lengths exceed the file")
         if ctype == b"BIN\0":
             return b[pos + 8 : pos + 8 + n]
         pos += 8 + n
@@ -595,6 +601,17 @@ def _float_accessor(doc: dict, binary: bytes, index: int) -> np.ndarray:
         raise ModelFormatError("only the GLB's embedded buffer is supported")
     start = int(view.get("byteOffset", 0)) + int(acc.get("byteOffset", 0))
     count, stride = int(acc["count"]), int(view.get("byteStride", 0)) or 4 * ncomp
+    # the file is untrusted input: count / stride / offsets are held against the BIN chunk before any strided view is formed
+    # (the reference's copyAccessorBuffer goes through fx::gltf's own size checks)
+    if count < 0 or start < 0 or stride < 4 * ncomp:
+        raise ModelFormatError("accessor with a negative count / offset or a stride below its element size")
+    if count == 0:
+        return np.zeros(0, np.float32)
+    if start + (count - 1) * stride + 4 * ncomp > len(binary):
+        raise ModelFormatError("accessor reaches past the end of the GLB's binary chunk")
+    view_len = view.get("byteLength")
+    if view_len is not None and int(acc.get("byteOffset", 0)) + (count - 1) * stride + 4 * ncomp > int(view_len):
+        raise ModelFormatError("accessor reaches past the end of its buffer view")
     raw = np.frombuffer(binary, np.uint8)
     rows = np.lib.stride_tricks.as_strided(raw[start:], shape=(count, 4 * ncomp), strides=(stride, 1))
     return np.ascontiguousarray(rows).view("<f4").reshape(-1).astype(np.float32)

@@ -98,41 +98,38 @@ def test_config3_gauss_newton_part_at_full_size(torch_cuda, orc):
 
 
 def test_config3_lm_schedule_distinct_instances(torch_cuda, orc):
-    """The LM gain-ratio schedule on 1024 distinct instances of the cfg3 batch.  The schedule takes discrete
-    decisions (rho against 0 / 0.25 / 0.75); an instance whose gain ratio sits on a threshold goes a
-    different -- equally valid -- way in single and in double precision (the oracle's own float
-    instantiation does, too).  So: every instance whose decisions agree with the double solve (same error
-    history to 1e-4) is held to 1e-5, and the others must be few and still be good solutions."""
+    """BASELINE configs[2] at north_star's size on the batch bench.py times (65 536 instances, seed 424242), every instance
+    checked, decisions compared EXACTLY.  The LM schedule decides on the gain ratio rho = actual / predicted decrease (the
+    quantity TrustRegionQRT holds against its thresholds, momentum/character_solver/trust_region_qr.cpp:244-268): accept iff
+    rho > 0, lambda x 4 iff not rho >= 0.25, x 0.5 iff rho > 0.75.  mmx_solve_with_step_history returns (lambda, rho) per
+    iteration, the oracle's double run does the same:
+      * an instance whose (accept, scale) decisions equal the double run's at every iteration -- its lambda sequence is then the
+        double run's, asserted -- is held to 1e-5 on the pose parameters, no exception;
+      * every other instance is a branch flip and must prove it: at its first diverging iteration the two gain ratios straddle
+        a threshold, the double run's within 1e-2 of it and the two ratios within 2e-2 of each other (measured: 31 of 16 384, all
+        within 4.7e-3 / 5.8e-3; the oracle's own float instantiation flips on 263 of the same instances, ratios up to 0.12
+        apart); at most 0.5 % of the batch, and every one of them still converges."""
     torch = torch_cuda
     from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
     from oracle import oracle as o
 
     rig, parents, _, _, _ = bench.build_rig("cfg3")
-    B, n = 8192, 1024
-    db = bench.DeviceBatch(rig, parents, B, 0, 99)
+    B = 65536
+    db = bench.DeviceBatch(rig, parents, B, 0, 424242)
     opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
-    out = db.pb.solve(db.theta0.clone(), opt, want_history=True)
+    out = db.pb.solve(db.theta0.clone(), opt, want_history=True, want_step_history=True)
     torch.cuda.synchronize()
-    cons = db.host_constraints(n)
-    ref = o.solve_batch(rig, cons, np.zeros((n, rig.num_params), np.float32), opt, dtype="f64", nthreads=bench.usable_cores())
-    th = out["theta"][:n].cpu().numpy().astype(np.float64)
+    assert int((out["status"] & 3 != 0).sum()) == 0 and int((out["iterations"] != 10).sum()) == 0
+    ref = o.solve_batch(rig, db.host_constraints(B), np.zeros((B, rig.num_params), np.float32), opt, dtype="f64", nthreads=bench.usable_cores(), step_history=True)
+    th = out["theta"].cpu().numpy().astype(np.float64)
     rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
-    # same decisions <=> the same error at EVERY iterate, the final one included (relative, per entry: the
-    # late errors are 1e4 times smaller than the first one, so a difference there hides in a max-norm over
-    # the history).  The error of the final iterate is entry 10 of the same (deterministic) solve run for
-    # eleven iterations.
-    opt11 = GnOptions.make(min_iterations=11, max_iterations=11, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE)
-    out11 = db.pb.solve(db.theta0.clone(), opt11, want_history=True)
-    ref11 = o.solve_batch(rig, cons, np.zeros((n, rig.num_params), np.float32), opt11, dtype="f64", nthreads=bench.usable_cores())
-    h, href = out11["error_history"][:n].cpu().numpy(), ref11["error_history"]
-    assert np.array_equal(h[:, :10], out["error_history"][:n].cpu().numpy())
-    # (errors below 1e-7 of the initial one are the fp32 noise floor of a converged fit, not a decision)
-    same_path = np.all(np.abs(h - href) <= 1e-3 * np.abs(href) + 1e-7 * href[:, :1], axis=1)
-    # ... and the same accept / reject sequence: a rejected step leaves the error EXACTLY where it was (both implementations
-    # restore the state), an accepted one lowers it -- near convergence by less than the 1e-3 above can see, while the
-    # parameters move by percents along the directions the sixteen landmarks barely determine
-    same_path &= np.all((h[:, 1:] == h[:, :-1]) == (href[:, 1:] == href[:, :-1]), axis=1)
-    assert same_path.mean() >= 0.95, same_path.mean()
-    assert rel[same_path].max() <= BOUND, (rel[same_path].max(), int((rel[same_path] > BOUND).sum()))
-    # the instances that took another branch still converged
+    h = out["error_history"].cpu().numpy()
+    res = bench.lm_branch_analysis(out["step_history"].cpu().numpy(), h, ref, rel)
+    summary = {k: v for k, v in res.items() if not isinstance(v, list)}
+    assert res["same_decisions"] + res["lm_branch_flips"] == B and res["lm_branch_flips"] <= B // 200, summary
+    assert res["same_decisions_lambda_sequences_equal"], summary
+    assert res["num_above_bound_with_same_decisions"] == 0 and res["max_rel_same_decisions"] <= BOUND, summary
+    assert res["num_above_bound"] == res["num_above_bound_that_are_branch_flips"], summary
+    assert res["flip_max_distance_of_double_rho_to_threshold"] <= 1e-2 and res["flip_max_abs_rho_difference"] <= 2e-2, summary
+    # the instances that took the other branch still converged
     assert np.all(h[:, -1] <= 1e-3 * h[:, 0])

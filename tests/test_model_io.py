@@ -210,3 +210,46 @@ def test_reference_glb_resources_load(name, joints):
     assert rig.parent[0] == -1 and all(rig.parent[j] < j for j in range(rig.num_joints))
     assert np.allclose(np.linalg.norm(rig.pre_rotation, axis=1), 1.0, atol=1e-4)
     assert len(set(rig.joint_names)) == rig.num_joints
+
+
+def _glb_with_motion(poses: np.ndarray, count=None, stride=None, byte_offset=0, truncate=0):
+    """A minimal GLB whose FB_momentum extension stores `poses` (nframes x nparams floats) in its binary chunk; the accessor's
+    count / stride / offset can be forged, the binary chunk truncated."""
+    import json
+    import struct
+
+    nframes, nparams = poses.shape
+    blob = np.ascontiguousarray(poses, "<f4").tobytes()
+    doc = {
+        "asset": {"version": "2.0"},
+        "buffers": [{"byteLength": len(blob)}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(blob), **({"byteStride": stride} if stride else {})}],
+        "accessors": [{"bufferView": 0, "byteOffset": byte_offset, "componentType": 5126, "type": "SCALAR", "count": poses.size if count is None else count}],
+        "extensions": {"FB_momentum": {"fps": 30.0, "motion": {"nframes": nframes, "poses": 0, "parameterNames": [f"p{i}" for i in range(nparams)]}}},
+    }
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    blob = blob[: len(blob) - truncate]
+    body = struct.pack("<I4s", len(js), b"JSON") + js + struct.pack("<I4s", len(blob), b"BIN\0") + blob
+    return b"glTF" + struct.pack("<II", 2, 12 + len(body)) + body
+
+
+def test_glb_accessors_are_bounds_checked():
+    """An accessor of an untrusted GLB that reaches past the binary chunk is an error, not an out-of-bounds read (the
+    reference's copyAccessorBuffer goes through fx::gltf's size checks, momentum/io/gltf/utils/accessor_utils.h)."""
+    poses = np.arange(12, dtype=np.float32).reshape(3, 4)
+    ok = model_io.load_gltf_motion(_glb_with_motion(poses))
+    assert np.array_equal(ok["poses"], poses) and ok["parameter_names"] == ["p0", "p1", "p2", "p3"]
+    for forged in (
+        _glb_with_motion(poses, count=10**6),  # far more elements than the chunk holds
+        _glb_with_motion(poses, count=13),  # one element past the end
+        _glb_with_motion(poses, byte_offset=8),  # the same count from a later start
+        _glb_with_motion(poses, stride=2),  # a stride below the element size
+        _glb_with_motion(poses, stride=64),  # a stride that walks out of the chunk
+        _glb_with_motion(poses, count=-3),
+    ):
+        with pytest.raises(model_io.ModelFormatError):
+            model_io.load_gltf_motion(forged)
+    cut = _glb_with_motion(poses, truncate=0)[:-16]  # the file ends before its BIN chunk does
+    with pytest.raises(model_io.ModelFormatError):
+        model_io.load_gltf_motion(cut)
