@@ -734,9 +734,21 @@ class BatchedGaussNewtonSolver {
       opt_.do_line_search = d->doLineSearch ? lineSearchRule() : MMX_LINE_SEARCH_NONE;
     }
     applyDerivedOptions(options, opt_);
+    opt_.precision = precision_;
+    opt_.precision_bound = precisionBound_;
   }
   void setEnabledParameters(const ParameterSet& ps) {
     fn_->setEnabledParameters(ps);
+  }
+  // mmx_gn_options::precision (ABI 10) of solve(std::vector<float>&): MMX_PRECISION_F32 (default), MMX_PRECISION_F64 (every
+  // element by the double instantiation, float parameters in and out), MMX_PRECISION_AUTO (the elements the single-precision
+  // solve marks MMX_SOLVE_PRECISION_SUSPECT are solved again in double); bound <= 0 keeps the default (1e-5).  Kept across
+  // setOptions().
+  void setPrecision(int32_t precision, float bound = 0.f) {
+    precision_ = precision;
+    precisionBound_ = bound;
+    opt_.precision = precision;
+    opt_.precision_bound = bound;
   }
   // parameters [batch * P] in/out; returns the value SolverT::solve returns, per element
   std::vector<double> solve(std::vector<float>& parameters) {
@@ -781,6 +793,8 @@ class BatchedGaussNewtonSolver {
  private:
   BatchedSkeletonSolverFunction* fn_; // raw pointer like SolverT::solverFunction_ (solver.h:106)
   mmx_gn_options opt_{};
+  int32_t precision_ = MMX_PRECISION_F32;
+  float precisionBound_ = 0.f;
   std::vector<int32_t> iterations_, status_;
 };
 
@@ -835,5 +849,66 @@ class BatchedTrustRegionQR : public BatchedGaussNewtonSolver {
     }
   }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-instance forms under momentum's own names and signatures -- what a per-frame caller holds
+// (momentum/marker_tracking/marker_tracker.cpp:905-913: one SkeletonSolverFunction, one solver, solve(parameters) per
+// frame): a batch of one element behind momentum/character_solver/skeleton_solver_function.h:21-95 and
+// momentum/solver/solver.h:41-106.  (A GPU launch per frame is latency, not throughput: 0.5 ms per solve whatever the
+// batch up to ~768 elements; callers with many frames at hand should batch them.)
+// ---------------------------------------------------------------------------------------------------------------------
+class SkeletonSolverFunction : public BatchedSkeletonSolverFunction {
+ public:
+  SkeletonSolverFunction(const DeviceCharacter& character, const std::vector<size_t>& positionParents, const std::vector<size_t>& orientationParents)
+      : BatchedSkeletonSolverFunction(character, 1, positionParents, orientationParents) {}
+  using BatchedSkeletonSolverFunction::setConstraints;
+  void setPositionConstraints(const std::vector<PositionData>& c) {
+    BatchedSkeletonSolverFunction::setPositionConstraints(0, c);
+  }
+  void setOrientationConstraints(const std::vector<OrientationData>& c) {
+    BatchedSkeletonSolverFunction::setOrientationConstraints(0, c);
+  }
+  void setTargetParameters(const std::vector<float>& params, const std::vector<float>& weights, float weight = 1.f) {
+    BatchedSkeletonSolverFunction::setTargetParameters(0, params, weights, weight);
+  }
+  template <class Data>
+  void setConstraints(size_t block, const std::vector<Data>& c) {
+    BatchedSkeletonSolverFunction::setConstraints(block, 0, c);
+  }
+  // SolverFunctionT::getJacobian (momentum/solver/solver_function.h): Jacobian [rows x P] column-major, residual, returns the error
+  double getJacobian(const std::vector<float>& parameters, std::vector<float>& jacobian, std::vector<float>& residual) {
+    std::vector<double> e;
+    BatchedSkeletonSolverFunction::getJacobian(parameters, jacobian, residual, e);
+    return e.at(0);
+  }
+  // SolverFunctionT::getError: the same evaluation without keeping the Jacobian
+  double getError(const std::vector<float>& parameters) {
+    std::vector<float> j, r;
+    return getJacobian(parameters, j, r);
+  }
+};
+
+// SolverT::solve(Eigen::VectorX<T>& params) -> double (momentum/solver/solver.h:62) over the batched solvers: one element
+template <class BatchedSolver>
+class SingleInstanceSolverT : public BatchedSolver {
+ public:
+  SingleInstanceSolverT(const SolverOptions& options, SkeletonSolverFunction* function) : BatchedSolver(options, function) {}
+  double solve(std::vector<float>& parameters) {
+    return BatchedSolver::solve(parameters).at(0);
+  }
+  double solve(std::vector<double>& parameters) {
+    return BatchedSolver::solve(parameters).at(0);
+  }
+  int32_t iterations() const {
+    return this->getIterations().at(0);
+  }
+  int32_t status() const {
+    return this->getStatus().at(0);
+  }
+};
+using GaussNewtonSolver = SingleInstanceSolverT<BatchedGaussNewtonSolver>;
+using SubsetGaussNewtonSolver = SingleInstanceSolverT<BatchedSubsetGaussNewtonSolver>;
+using GaussNewtonSolverQR = SingleInstanceSolverT<BatchedGaussNewtonSolverQR>;
+using TrustRegionQR = SingleInstanceSolverT<BatchedTrustRegionQR>;
 
 } // namespace momentum_amd

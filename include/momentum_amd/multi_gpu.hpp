@@ -36,11 +36,11 @@ struct RcclNormsComm {
   static std::vector<Handle> createAll(const std::vector<int>& devices) {
     std::vector<int32_t> devs(devices.begin(), devices.end());
     std::vector<mmx_comm*> comms(devices.size(), nullptr);
-    check(mmx_comm_create_all(int32_t(devs.size()), devs.data(), comms.data()));
     std::vector<Handle> out;
+    out.reserve(comms.size()); // before any communicator exists: a failing allocation then has nothing to leak
+    check(mmx_comm_create_all(int32_t(devs.size()), devs.data(), comms.data()));
     size_t wrapped = 0;
     try {
-      out.reserve(comms.size());
       for (; wrapped < comms.size(); ++wrapped) { // (shared_ptr's constructor runs the deleter itself when it throws)
         out.emplace_back(comms[wrapped], [](mmx_comm* p) { mmx_comm_destroy(p); });
       }

@@ -2179,6 +2179,53 @@ __host__ __device__ inline size_t treeNeLdsFloats(int J, int P, int U, int nsrc,
   return off;
 }
 
+// The COMPACT carve (round 5): the same buffers placed by their lifetimes instead of side by side, so that two workgroups
+// of the plain instantiation share a CU (BASELINE configs[4], J = U = 300: 79.7 KB instead of 140).  Phases and what lives:
+//   FK      js | fkA | fkB (the joint parameters jd in its head: read before the first jump round writes there)
+//   C       js | up uy us (over fkA)
+//   D own   up uy us | umom | own2 (over js: the joint states have left for the hand-over buffer in HBM, phase E reads
+//           them from there) | own1 (behind umom)
+//   D sub   own1 own2 | sub2 sub1 (over up uy us / umom)
+//   E, G    sub1 sub2 | srcT (over own2) ; own1 stays the scratch of the split term records
+// Usable when the joint-state block covers own2 and srcT and sub1 ends before own1 begins (checked here: 0 = not usable).
+__host__ __device__ inline size_t treeNeCompactLdsFloats(int J, int P, int U, int nsrc, TreeNeLds* out, float* base) {
+  size_t off = 0;
+  auto take = [&](size_t count) {
+    const size_t o = off;
+    off += alignUp4(count);
+    return o;
+  };
+  const size_t oTh = take(P), oSpan = take(nsrc);
+  const size_t oSub = take(J), oLoaded = take(J), oPus = take(size_t(J) + 1), oPu = take(U), oKr = take(2 * ((size_t(J) + 15) / 16));
+  const size_t oRed = take(32);
+  const size_t X = off; // the persistent part; the scratch plan follows
+  const size_t a = alignUp4(size_t(kJs) * J), f = alignUp4(fkBufFloats(J)), u3 = alignUp4(3 * size_t(U)), u1 = alignUp4(U);
+  const size_t m = alignUp4(size_t(kUmom) * U), o1 = alignUp4(size_t(kC1) * J), o2 = alignUp4(size_t(kC2) * J);
+  const size_t st = size_t(kSrcCh) * size_t(srcStrideFor(nsrc));
+  const size_t endU = a + 2 * u3 + u1, endM = endU + m;
+  const size_t oOwn1 = endM > a + o2 + o1 ? endM : a + o2 + o1;
+  if (o2 > a || st > a || alignUp4(7 * size_t(J)) > f) {
+    return 0;
+  }
+  size_t S = a + 2 * f;
+  S = oOwn1 + o1 > S ? oOwn1 + o1 : S;
+  if (out != nullptr) {
+    float* sc = base + X;
+    out->th = base + oTh, out->span = reinterpret_cast<int*>(base + oSpan);
+    out->subSize = reinterpret_cast<int*>(base + oSub), out->loadedPos = reinterpret_cast<int*>(base + oLoaded);
+    out->posUnitStart = reinterpret_cast<int*>(base + oPus), out->posUnits = reinterpret_cast<int*>(base + oPu);
+    out->kRange = reinterpret_cast<int*>(base + oKr), out->red = reinterpret_cast<double*>(base + oRed);
+    out->js = sc;
+    out->fkA = reinterpret_cast<double*>(sc + a), out->fkB = reinterpret_cast<double*>(sc + a + f), out->jd = sc + a + f;
+    out->up = sc + a, out->uy = sc + a + u3, out->us = sc + a + 2 * u3;
+    out->umom = sc + endU;
+    out->own2 = sc, out->own1 = sc + oOwn1;
+    out->sub2 = sc + a, out->sub1 = sc + a + o2;
+    out->srcT = sc;
+  }
+  return X + S;
+}
+
 // LDS of the kExtraRows instantiation, carved behind the tables above (kept out of TreeNeLds: the plain kernel's carve
 // stays the small all-in-registers struct it was)
 struct TreeNeExtraLds {
@@ -2205,8 +2252,10 @@ __host__ __device__ inline size_t treeNeExtraLdsFloats(int P, int n, int GT, int
 // kWaves: wavefronts of the workgroup (4; 16 for the instantiation without extra rows: one workgroup per CU is all the
 // LDS allows, so four waves are ONE per SIMD -- sixteen give every phase that deals work by thread or by wave four times
 // the lanes and each SIMD three more waves to switch to; the term records stay with the first 256 threads)
-template <bool kExtraRows, int kWaves = 4>
-__global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
+// kCompact: the lifetime-packed LDS carve (treeNeCompactLdsFloats), two workgroups per CU; needs the hand-over buffer
+// (`state`), from which phase E reads the joint states back
+template <bool kExtraRows, int kWaves = 4, bool kCompact = false>
+__global__ void __launch_bounds__(64 * kWaves, kCompact ? 2 : 1) treeNormalEquationsKernel(
     RigDev rig,
     ProblemDev pb,
     FusedDev fd,
@@ -2231,8 +2280,9 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
   selectInstanceWeights(pb, b);
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int NB = (n + 15) >> 4, NP = 16 * NB, T = NB * (NB + 1) / 2;
+  static_assert(!kCompact || !kExtraRows, "the compact carve is the plain instantiation's");
   TreeNeLds t;
-  const size_t baseFloats = treeNeLdsFloats(J, P, U, nsrc, &t, smem);
+  const size_t baseFloats = kCompact ? treeNeCompactLdsFloats(J, P, U, nsrc, &t, smem) : treeNeLdsFloats(J, P, U, nsrc, &t, smem);
   TreeNeExtraLds x{};
   if (kExtraRows) {
     treeNeExtraLdsFloats(P, n, fd.GT, fd.genRows, U, &x, smem + baseFloats);
@@ -2381,9 +2431,12 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
   float* srcD = s.srcT;
   float* srcA = s.srcT + 7 * sst;
   float* srcG = s.srcT + 14 * sst;
+  // (compact carve: the joint states left LDS after phase C -- own2 and srcT lie over them -- and come back from the
+  // hand-over buffer this workgroup wrote in phase C: L2 hits, one round trip per slot, all its loads independent)
+  const float* jsE = kCompact ? state + size_t(b) * treeStateLayout(J, U).total + treeStateLayout(J, U).js : s.js;
   for (int e = tid; e < nsrc; e += kT) {
     const ColumnSourceDev cs = fd.srcs[e];
-    const float* a = s.js + kJs * cs.joint;
+    const float* a = jsE + kJs * cs.joint;
     const float* sb = s.sub2 + kC2 * cs.tin;
     const F3 ta{a[0], a[1], a[2]};
     const float m0 = sb[0];
@@ -2391,7 +2444,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
     F3 al, bv{0.f, 0.f, 0.f}, g0, ax;
     float bs = 0.f, tr;
     if (cs.dof < 3) {
-      al = transAxisCol(s.js, cs.parent, cs.dof);
+      al = transAxisCol(jsE, cs.parent, cs.dof);
       g0 = m0 * al;
       ax = cross(m1, al);
       tr = dot(al, m1);
@@ -2424,7 +2477,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) treeNormalEquationsKernel(
     o[0] = w * al.x, o[sst] = w * al.y, o[2 * sst] = w * al.z;
     o[3 * sst] = w * bv.x, o[4 * sst] = w * bv.y, o[5 * sst] = w * bv.z;
     o[6 * sst] = w * bs;
-    srcG[e] = w * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
+    srcG[e] = w * sourceGradient(cs.joint, cs.dof, cs.parent, jsE, s.sub1 + kC1 * cs.tin);
   }
   __syncthreads();
   MMX_TCLK(5)
@@ -2652,6 +2705,23 @@ hipError_t launchTreeNormalEquations(
     return hipErrorInvalidValue;
   }
   const bool extra = pb.M > pb.rowsJoint || fd.GT > 0 || pb.instPosParent != nullptr || pb.instOriParent != nullptr;
+#ifndef MMX_EXP_NECOMPACT_OFF
+  if (!extra && state != nullptr) {
+    // two workgroups of eight waves per CU when the lifetime-packed carve fits half a CU's LDS (BASELINE configs[4]: 79.7 KB):
+    // every phase of this kernel is a latency chain of one workgroup (VALU active 8.5 % of the wave cycles at one workgroup of
+    // sixteen waves per CU, profiles/r04_pmc_cfg5.txt) -- a second, independent workgroup fills the waits
+    const size_t compact = treeNeCompactLdsFloats(rig.J, rig.P, fd.U, fd.nsrc, nullptr, nullptr) * sizeof(float);
+    if (compact > 0 && compact <= 80 * 1024 - 64) {
+      static LdsLimitCache ldsLimitC;
+      hipError_t rc = ldsLimitC.ensure(reinterpret_cast<const void*>(treeNormalEquationsKernel<false, 8, true>), compact);
+      if (rc != hipSuccess) {
+        return rc;
+      }
+      hipLaunchKernelGGL((treeNormalEquationsKernel<false, 8, true>), dim3(pb.B), dim3(512), compact, stream, rig, pb, fd, theta, jtj, jtr, done, errOut, state, clk, genState, tileMajor ? 1 : 0);
+      return hipGetLastError();
+    }
+  }
+#endif
   if (!extra) { // many waves per workgroup (one workgroup per CU either way: the LDS footprint decides)
     // sixteen waves = four per SIMD (93 VGPRs: no spill under the 128 of that occupancy).  cfg5, one box, solves/s:
     // four waves 1.476e5, eight 1.626e5, sixteen 1.704e5 (round 3)

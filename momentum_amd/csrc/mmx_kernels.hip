@@ -2296,14 +2296,17 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
         }
         dio = Dt[lrow * 17];
       }
-      // column k's tiles below the diagonal (forward) / row k's tiles left of it (backward) that are structurally non-zero
-      const uint32_t present = uint32_t(__builtin_amdgcn_readlane(int(vMask), k));
+      // column k's tiles below the diagonal (forward) / row k's tiles left of it (backward) that are structurally non-zero.
+      // The mask words cover 32 blocks (512 solved parameters: the tree routes); the kM > 2 instantiation runs the
+      // explicit-Jacobian route's systems of up to 128 blocks, always dense: no word is looked up there (a shift by a block
+      // index >= 32 would be undefined, and so would a v_readlane of lane k >= 64)
+      const uint32_t present = kM > 2 ? 0xffffffffu : uint32_t(__builtin_amdgcn_readlane(int(vMask), k));
 #pragma unroll
       for (int m = 0; m < kM; ++m) {
         if (forward) {
           const int r = 16 * (k + 1) + tid + 256 * m;
           const int rb = min(r, NP - 1) >> 4;
-          const bool have = (present >> rb & 1u) != 0u;
+          const bool have = kM > 2 || (present >> (rb & 31) & 1u) != 0u;
           const float* Tr = L + size_t(tileIndex(kSkip || have ? rb : k, k)) * 256 + (r & 15) * 16;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -2315,7 +2318,7 @@ __device__ __forceinline__ void tiledSweep(const float* __restrict__ L, int NB, 
           }
         } else {
           const int cidx = min(tid + 256 * m, max(16 * k - 1, 0));
-          const bool have = (present >> (cidx >> 4) & 1u) != 0u;
+          const bool have = kM > 2 || (present >> ((cidx >> 4) & 31) & 1u) != 0u;
           const float* Tc = L + size_t(tileIndex(k, kSkip || have ? cidx >> 4 : k)) * 256 + (cidx & 15);
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) {

@@ -225,6 +225,69 @@ int main() {
       }
     }
   }
+  // the single-instance forms under momentum's own names (solver.h:41-106, skeleton_solver_function.h:21-95): a batch of one
+  // gives the batched solve's element 0 bit for bit; MMX_PRECISION_F64 / AUTO through the shell's setPrecision
+  {
+    BatchedSkeletonSolverFunction fnB(dev, B, {23, 12, 5}, {}); // (a fresh function: `fn` carries limits and a prior by now)
+    {
+      std::mt19937 rngB(12345);
+      std::uniform_real_distribution<float> UB(-1.f, 1.f);
+      for (size_t b = 0; b < B; ++b) {
+        std::vector<PositionData> cons(3);
+        const size_t parents[3] = {23, 12, 5};
+        for (int i = 0; i < 3; ++i) {
+          cons[i].parent = parents[i];
+          cons[i].offset = {0.f, 0.f, 0.f};
+          cons[i].target = {0.5f * UB(rngB), float(parents[i]) * 0.9f + 0.3f * UB(rngB), 0.5f * UB(rngB)};
+          cons[i].weight = 1.f;
+        }
+        fnB.setPositionConstraints(b, cons);
+      }
+    }
+    BatchedGaussNewtonSolver solverB(opt, &fnB);
+    std::vector<float> thB(B * P, 0.f);
+    const std::vector<double> eB = solverB.solve(thB);
+    SkeletonSolverFunction one(dev, {23, 12, 5}, {});
+    {
+      std::mt19937 rng1(12345); // element 0's constraints again
+      std::uniform_real_distribution<float> U1(-1.f, 1.f);
+      std::vector<PositionData> cons(3);
+      const size_t parents[3] = {23, 12, 5};
+      for (int i = 0; i < 3; ++i) {
+        cons[i].parent = parents[i];
+        cons[i].offset = {0.f, 0.f, 0.f};
+        cons[i].target = {0.5f * U1(rng1), float(parents[i]) * 0.9f + 0.3f * U1(rng1), 0.5f * U1(rng1)};
+        cons[i].weight = 1.f;
+      }
+      one.setPositionConstraints(cons);
+    }
+    GaussNewtonSolver single(opt, &one);
+    std::vector<float> th1(P, 0.f);
+    const double e1 = one.getError(th1);
+    const double eS = single.solve(th1);
+    bool same = eS == eB[0] && single.iterations() == 10 && !MMX_SOLVE_FAILED(single.status());
+    for (size_t i = 0; i < P; ++i) {
+      same = same && th1[i] == thB[i];
+    }
+    std::printf("single instance: error %.6g -> %.3g (batched element 0: %.3g), identical %d\n", e1, eS, eB[0], int(same));
+    if (!same || !(e1 > 0.0)) {
+      ++bad;
+    }
+    single.setPrecision(MMX_PRECISION_F64);
+    std::vector<float> thD(P, 0.f);
+    const double eD = single.solve(thD);
+    single.setPrecision(MMX_PRECISION_AUTO, 1e-30f); // a bound nothing passes: the element is escalated
+    std::vector<float> thA(P, 0.f);
+    const double eA = single.solve(thA);
+    bool okp = (single.status() & MMX_SOLVE_ESCALATED_F64) != 0 && eA == eD;
+    for (size_t i = 0; i < P; ++i) {
+      okp = okp && thA[i] == thD[i] && std::fabs(thD[i] - th1[i]) <= 1e-2f * (1.f + std::fabs(th1[i]));
+    }
+    std::printf("precision: double on float parameters %.3g, AUTO (escalated) %.3g, identical %d\n", eD, eA, int(okp));
+    if (!okp) {
+      ++bad;
+    }
+  }
   std::printf(bad == 0 ? "OK\n" : "FAIL\n");
   return bad == 0 ? 0 : 1;
 }
