@@ -642,6 +642,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
       MMX_HIP(upload(pb->dComb, comb));
       fd.comb = pb->dComb.as<int32_t>();
       fd.numComb = int32_t(combDest.size());
+      fd.numCells = numCells;
       MMX_HIP(upload(pb->dTerms, inter));
       fd.gTerms = pb->dTerms.as<uint4>();
       fd.termRounds = int32_t(rounds);
@@ -860,7 +861,7 @@ bool fusedUsable(const mmx_problem* pb) {
   // (the further joint-constraint blocks and ellipsoid limits ride along as a dense block of rows in LDS -- fdev.GT /
   // genRows -- while they fit; MMX_ROUTE_EXPLICIT_JACOBIAN sends them to the explicit-Jacobian kernels)
   return pb->rig->J < 4096 &&
-      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.nnz, pb->rigDev.numLevels, pb->fdev.GT, pb->fdev.genRows) +
+      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.numCells, true, pb->fdev.GT, pb->fdev.genRows, true) +
           size_t(8) * size_t(pb->rig->J + pb->rig->P) <=
       160 * 1024;
 }

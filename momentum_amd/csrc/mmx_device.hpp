@@ -2,7 +2,7 @@
 //
 // Data layout in LDS for ONE skeleton instance (all fp32):
 //   jp[10*J]  per joint: tx,ty,tz, sin(rx/2),cos(rx/2), sin(ry/2),cos(ry/2), sin(rz/2),cos(rz/2), exp2(sc)
-//   js[20*J]  per joint: world t(3) q(4, xyzw) s(1) | rotationAxis columns x,y,z (3x3) | pad(3)
+//   js[kJs*J] per joint: world t(3) q(4, xyzw) s(1) | rotationAxis columns x,y,z (3x3)
 // Math follows momentum's JointStateT::set (momentum/character/joint_state.cpp:22-65),
 // TransformT::operator* (momentum/math/transform.h:124-129) and the Position / Orientation
 // evalFunction + ancestor walk (momentum/character_solver/position_error_function.cpp:15-27,
@@ -20,7 +20,9 @@
 
 namespace mmx {
 
-constexpr int kJs = 21; // floats per joint in js[]: 17 used, odd stride (lanes = joints read a field without LDS bank conflicts)
+constexpr int kJs = 17; // floats per joint in js[]: t(3) q(4) s | axes (9); odd stride (lanes = joints read a field without LDS bank
+                      // conflicts).  21 until round 5: the four pad floats per joint were what stood between the one-launch solve and a
+                      // fourth workgroup per CU (288 of the 180 floats it is under the 40 KB mark now)
 // Pivot threshold of every single-precision Cholesky in this library: when column j's pivot
 // d_jj = (H_jj + lambda) - sum_k l_jk^2 comes out at or below kPivotFloor * (H_jj + lambda), column j is DROPPED from this
 // iteration's step -- 1 / l_jj := 0, so l_ij = 0 below it and parameter j's step is exactly 0, as if the column were

@@ -37,13 +37,13 @@ struct FusedLds {
   // ---- loaded once per launch (batch-shared integer tables and the parameter-transform CSR)
   // source SLOTS: slot c < NP is the primary source of column c (pad columns: weight 0), slots >= NP are
   // the further sources of multi-source columns: extras of column c = NP + mStart[c] .. NP + mStart[c+1] - 1
-  int* mStart; // [NP+1] column -> number of extra slots before it
+  int16_t* mStart; // [NP+1] column -> number of extra slots before it
   int* mTin; // [nsrc] DFS interval of the slot's joint: tin | tout << 16
   int* mInfo; // [nsrc] joint | dof << 12 | (parent + 1) << 16
   float* mW; // [nsrc]
   // ---- per iteration
   float* th; // [P] theta (full parameter space)
-  float* js; // [20 J] world t(3) q(4) s(1) | rotation axes (9) | pad
+  float* js; // [kJs J] world t(3) q(4) s(1) | rotation axes (9)
   float* up; // [3 U] unit world vector
   float* ur; // [3 U] scaled residual rows r
   float* uy; // [3 U] sigma * (r or w): input of the adjoint pass
@@ -92,18 +92,23 @@ struct RigView {
   const int32_t* levelOrder;
   const int32_t* levelStart;
 };
-struct FusedView {
+// I: int32_t where the tables stay in global memory or are LDS copies of the tree kernels; int16_t in the one-launch solve,
+// whose LDS budget is what decides between three and four workgroups per CU (every index of a fused problem is below 4096)
+template <class I>
+struct FusedViewT {
   int32_t U, Kp;
-  const int32_t* subSize;
-  const int32_t* dfsJoint;
-  const int32_t* loadedPos;
+  const I* subSize;
+  const I* dfsJoint;
+  const I* loadedPos;
   int32_t numLoaded;
-  const int32_t* colToSolve; // [P] compacted index of a parameter or -1
-  const int32_t* unitPos; // [U] DFS position of the joint a unit hangs on
-  const int32_t* posUnitStart;
-  const int32_t* posUnits;
-  const int32_t* solveList;
+  const I* colToSolve; // [P] compacted index of a parameter or -1
+  const I* unitPos; // [U] DFS position of the joint a unit hangs on
+  const I* posUnitStart;
+  const I* posUnits;
+  const I* solveList;
 };
+using FusedView = FusedViewT<int32_t>;
+using FusedViewS = FusedViewT<int16_t>;
 
 __host__ __device__ __forceinline__ size_t alignUp4(size_t x) {
   return (x + 3) & ~size_t(3);
@@ -114,7 +119,7 @@ __host__ __device__ __forceinline__ int srcStrideFor(int nsrc) {
   int x = (nsrc + 15) & ~15;
   return (x & 31) == 16 ? x : x + 16;
 }
-constexpr int kSrcCh = 15; // D(7) | A(7) | g share
+constexpr int kSrcCh = 15; // D(7) | A(7) | g share (the tree kernels; the one-launch solve keeps the g share in uy's place: 14)
 
 // ---------------------------------------------------------------------------------------------
 // adjoint machinery: sums over a joint's own units, then over its subtree (= a DFS index range)
@@ -135,8 +140,8 @@ __device__ __forceinline__ void firstOrderMoments(float* o, F3 p, float yx, floa
 }
 
 // NCH channels per unit (kC1 first-order, then kC2Used second-order ones), stored with stride STRIDE (odd)
-template <int NCH, int STRIDE, int kT = 256>
-__device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLds& s, const float* umom, int tid) {
+template <int NCH, int STRIDE, int kT = 256, class FV = FusedView>
+__device__ __forceinline__ void gatherOwnSums(const FV& fd, const FusedLds& s, const float* umom, int tid) {
   for (int item = tid; item < fd.numLoaded * NCH; item += kT) {
     const int li = item / NCH, c = item - li * NCH;
     const int k = fd.loadedPos[li];
@@ -155,8 +160,8 @@ __device__ __forceinline__ void gatherOwnSums(const FusedView& fd, const FusedLd
 constexpr int kUmom = 25; // stride of the per-unit moment scratch: 7 + 16 channels, odd
 
 // phase D: first- and second-order own sums from up / uy / us
-template <int kT = 256>
-__device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, float* umom, int U, int tid) {
+template <int kT = 256, class FV = FusedView>
+__device__ __forceinline__ void ownSums(const FV& fd, const FusedLds& s, float* umom, int U, int tid) {
   constexpr int NCH = kC1 + kC2Used;
   for (int u = tid; u < U; u += kT) {
     const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
@@ -185,13 +190,13 @@ __device__ __forceinline__ void ownSums(const FusedView& fd, const FusedLds& s, 
     }
   }
   __syncthreads();
-  gatherOwnSums<NCH, kUmom, kT>(fd, s, umom, tid);
+  gatherOwnSums<NCH, kUmom, kT, FV>(fd, s, umom, tid);
 }
 
 constexpr int kFusedTreeUn = 4; // k-steps per trip of the tree sums (measured on BASELINE configs[1]: 1 -> 1.575e6, 4 -> 1.60e6, 8 -> 1.54e6 solves/s)
-template <int NC, bool kSubtree, int STRIDE = NC, int UN = kFusedTreeUn>
-__device__ __forceinline__ void treeSum(const FusedView& fd, const float* in, float* out, int J, int wave, int lane, const int32_t* kRange = nullptr) {
-  treeSumT<NC, kSubtree, STRIDE, UN>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane, kRange);
+template <int NC, bool kSubtree, int STRIDE = NC, int UN = kFusedTreeUn, class I = int32_t>
+__device__ __forceinline__ void treeSum(const FusedViewT<I>& fd, const float* in, float* out, int J, int wave, int lane, const int32_t* kRange = nullptr) {
+  treeSumT<NC, kSubtree, STRIDE, UN, I>(fd.subSize, fd.loadedPos, fd.numLoaded, in, out, J, wave, 4, lane, kRange);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -205,13 +210,14 @@ struct ParamCol {
 
 // contributions of the rows to solve column c = parameter p: g_c = sum_l J(l,c) r_l and
 // H_cc = sum_l J(l,c)^2.  With a step `d0` the residual is replaced by r - J d0 (refinement).
+template <class I = int32_t>
 __device__ __forceinline__ ParamCol paramRowsColumn(
     const RigDev& rig,
     const ProblemDev& pb,
     const FusedDev& fd,
     const float* th,
     const float* d0,
-    const int* colToSolve,
+    const I* colToSolve,
     int P,
     int b,
     int c,
@@ -286,13 +292,65 @@ __device__ __forceinline__ void csrRowsPrefetched(const int32_t* outer, const in
   }
 }
 
+// The same walk for a matrix of at most 2 kT rows, software-pipelined over the iterations of a solve (the one-launch solve,
+// round 5: its LDS has no room for the transform's CSR any more): a thread's two rows r = tid, tid + kT have iteration-
+// invariant bounds (csrRowBounds, once per solve) and first entries; the first entries are REQUESTED a phase ahead
+// (csrRequestFirst: four independent loads that fly under the phase in between -- the end of phase K for the forward
+// kinematics, the first triangular solve for the refinement's joint-parameter step) and consumed by csrRowsFromFirst.
+// Rows with more than one entry (a joint parameter driven by several model parameters) walk their tail from global memory.
+struct CsrBounds2 {
+  int ka[2], cnt[2];
+};
+struct CsrFirst2 {
+  int in0[2];
+  float v0[2];
+};
+template <int kT = 256>
+__device__ __forceinline__ CsrBounds2 csrRowBounds(const int32_t* outer, int R, int tid) {
+  CsrBounds2 b;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = tid + kT * i;
+    const int lo = outer[min(r, R - 1)], hi = outer[min(r, R - 1) + 1];
+    b.ka[i] = lo, b.cnt[i] = r < R ? hi - lo : 0;
+  }
+  return b;
+}
+__device__ __forceinline__ CsrFirst2 csrRequestFirst(const int32_t* inner, const float* value, const CsrBounds2& b) {
+  CsrFirst2 f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f.in0[i] = b.cnt[i] > 0 ? inner[b.ka[i]] : 0, f.v0[i] = b.cnt[i] > 0 ? value[b.ka[i]] : 0.f;
+  }
+  return f;
+}
+template <int kT = 256, typename Gather, typename Store>
+__device__ __forceinline__ void
+csrRowsFromFirst(const int32_t* inner, const float* value, int R, int tid, const CsrBounds2& b, const CsrFirst2& f, Gather x, Store out) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = tid + kT * i;
+    if (r < R) {
+      float acc = 0.f;
+      if (b.cnt[i] > 0) {
+        acc += f.v0[i] * x(f.in0[i]);
+        for (int k = b.ka[i] + 1; k < b.ka[i] + b.cnt[i]; ++k) {
+          acc += value[k] * x(inner[k]);
+        }
+      }
+      out(r, acc);
+    }
+  }
+}
+
 // Forward kinematics of the whole skeleton from the parameters in `th` into s.js: local transforms
 // of all joints at once (parameter_transform.cpp:110-124, joint_state.cpp:44-62), world transforms
 // by pointer jumping (skeleton_state.cpp:100-121 re-associated), optionally the rotation axes.
 // Ends with a barrier.  Clobbers alt / jlA / jlB (assembly scratch = the Cholesky region).
 template <bool kGlobalTables = false, int kT = 256> // the rig's CSR tables are read from global memory (prefetching walk); kT threads
 __device__ __forceinline__ void
-blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes, long long* clk = nullptr, long long* clkLast = nullptr) {
+blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes, long long* clk = nullptr, long long* clkLast = nullptr,
+        const CsrBounds2* csrB = nullptr, const CsrFirst2* csrF = nullptr) { // (csrB / csrF: the pipelined walk, rig.R <= 2 kT)
   auto stamp = [&](int slot) { // profiling aid (MMX_PHASE_CLOCKS): sub-phases of FK
     if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
       const long long now = clock64();
@@ -304,7 +362,10 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   // 110-124; the same products in the same order as a per-joint walk): 7 J independent short CSR walks
   // instead of seven dependent ones per joint.  They land in the refinement scratch (jd), which is dead
   // whenever FK runs.
-  if (kGlobalTables) {
+  if (kGlobalTables && csrB != nullptr) {
+    csrRowsFromFirst<kT>(
+        rig.ptInner, rig.ptValue, rig.R, tid, *csrB, *csrF, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
+  } else if (kGlobalTables) {
     csrRowsPrefetched<kT>(
         rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
   } else {
@@ -363,6 +424,43 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
 }
 
 constexpr int kGenEv = 29; // words per constraint record (odd stride)
+
+// Sizes of the one-launch solve's lifetime-shared LDS areas (fusedSolveKernel's carve and fusedLdsBytes agree through this)
+struct FusedLayout {
+  size_t uyFloats; // uy (C-D) | slots' gradient shares (E-F) | partial cells (G) | rho, invDiag (end of G .. K)
+  size_t auxOff; // where the latter three start inside it: 0, or behind uy when uy must survive the factorisation (separateUy)
+  size_t cellOff; // where the partial cells start (counted from auxOff)
+  size_t t9; // aligned kTan J: tanOwn at 0, jd and tanPre at t9, dfull at 2 t9 of the arena
+  size_t arenaFloats; // srcT (E-G, 14 channels) | the refinement's buffers + dfull (J-K)
+  size_t umomFloats; // the unit moments' place, also the first-order subtree sums' (D-E)
+  size_t regionFloats; // assembly scratch (A-G) | the factor's tiles
+  size_t genFloats; // kGen: records, residual rows, w, J_g
+  size_t total;
+};
+// separateUy: the trust region re-runs phases D-G for every value of its damping WITHOUT re-evaluating the units (phase C), so
+// its uy must outlive rho / invDiag
+__host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy = false) {
+  auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
+  auto h4 = [&](size_t x) { return a4((x + 1) / 2); }; // 16-bit entries
+  auto mx = [](size_t x, size_t y) { return x > y ? x : y; };
+  const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
+  FusedLayout l;
+  l.cellOff = cellsBehindRho ? 2 * NP : 0;
+  const size_t aux = a4(mx(2 * NP, mx(size_t(nsrc), l.cellOff + size_t(numCells))));
+  l.auxOff = separateUy ? a4(3 * size_t(U)) : 0;
+  l.uyFloats = separateUy ? l.auxOff + aux : mx(a4(3 * size_t(U)), aux);
+  l.t9 = a4(size_t(kTan) * J);
+  l.arenaFloats = mx(size_t(kSrcCh - 1) * size_t(srcStrideFor(nsrc)), 2 * l.t9 + a4(P));
+  l.umomFloats = mx(a4(size_t(kUmom) * U), a4(size_t(kC1) * J));
+  const size_t scratch = fkBufFloats(J) + 2 * a4(size_t(kC2) * J) + l.umomFloats;
+  l.regionFloats = mx(scratch, T * 256);
+  const size_t rowsGp = a4(size_t(genRows));
+  l.genFloats = GT > 0 ? a4(size_t(kGenEv) * GT) + 2 * a4(rowsGp) + a4(rowsGp * size_t(srcStrideFor(int(NP)))) : 0;
+  const size_t meta = h4(NP + 1) + 3 * a4(nsrc) + a4(J) + 4 * h4(J) + h4(size_t(J) + 1) + 2 * h4(U) + h4(n) + h4(P);
+  const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 2 * a4(3 * size_t(U)) + a4(U) + 2 * a4(NP) + l.uyFloats + 16 + 4;
+  l.total = meta + fixed + l.genFloats + l.arenaFloats + l.regionFloats;
+  return l;
+}
 
 // error of the further joint error functions + ellipsoid limits at the joint states in js (this thread's share)
 __device__ __forceinline__ double generalRowsError(const ProblemDev& pb, const float* js, int b, int tid) {
@@ -501,19 +599,19 @@ __device__ __forceinline__ void generalRowsGather(const float* js, const float* 
 // kStore: the evaluation also leaves everything phases A-C of an iteration would leave for `th` (rotation axes, the
 // units' vectors / residuals / weights) and reports the unrounded sum -- when the trial is accepted, the next iteration
 // starts from it instead of repeating forward kinematics and the unit evaluation.
-template <bool kGen = false, bool kStore = false>
+template <bool kGen = false, bool kStore = false, class FV = FusedViewS>
 __device__ __forceinline__ double blockError(
     const RigDev& rigDev,
     const RigView& rig,
     const ProblemDev& pb,
-    const FusedView& fd,
+    const FV& fd,
     const FusedLds& s,
     const float* th,
     int b,
     int tid,
     double* unrounded = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
-  blockFk(rig, s, th, tid, kStore);
+  blockFk<true>(rig, s, th, tid, kStore); // (the transform's CSR is read from global memory: the one-launch solve keeps no LDS copy)
   double e = 0.0;
   for (int u = tid; u < fd.U; u += 256) {
     const Unit un = evalUnit(pb, s.js, b, u);
@@ -721,8 +819,9 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
 // joint, built per element instead of copied from the batch-shared ones -- units sorted by (DFS position of their joint,
 // unit index) with a counting rank, so that the own sums add in the same deterministic order as in the shared case.
 // All four tables in LDS; returns the number of loaded positions (the same value in every thread); ends with a barrier.
+template <class I>
 __device__ __forceinline__ int buildInstanceUnitTables(
-    const ProblemDev& pb, const FusedDev& fd, int b, int J, int U, int tid, int* unitPos, int* posUnitStart, int* posUnits, int* loadedPos) {
+    const ProblemDev& pb, const FusedDev& fd, int b, int J, int U, int tid, I* unitPos, I* posUnitStart, I* posUnits, I* loadedPos) {
   for (int u = tid; u < U; u += 256) {
     int joint;
     if (u < fd.Kp) {
@@ -731,7 +830,7 @@ __device__ __forceinline__ int buildInstanceUnitTables(
       const int co = (u - fd.Kp) / 3;
       joint = pb.instOriParent != nullptr ? pb.instOriParent[size_t(b) * pb.Ko + co] : fd.unitJoint[u];
     }
-    unitPos[u] = pb.jointTin[joint];
+    unitPos[u] = I(pb.jointTin[joint]);
   }
   __syncthreads();
   for (int k = tid; k <= J; k += 256) { // units on positions before k
@@ -739,7 +838,7 @@ __device__ __forceinline__ int buildInstanceUnitTables(
     for (int u = 0; u < U; ++u) {
       cnt += unitPos[u] < k ? 1 : 0;
     }
-    posUnitStart[k] = cnt;
+    posUnitStart[k] = I(cnt);
   }
   for (int u = tid; u < U; u += 256) {
     const int pu = unitPos[u];
@@ -748,7 +847,7 @@ __device__ __forceinline__ int buildInstanceUnitTables(
       const int pv = unitPos[v];
       rank += (pv < pu || (pv == pu && v < u)) ? 1 : 0;
     }
-    posUnits[rank] = u;
+    posUnits[rank] = I(u);
   }
   __syncthreads();
   for (int k = tid; k < J; k += 256) { // loaded positions, ascending
@@ -757,7 +856,7 @@ __device__ __forceinline__ int buildInstanceUnitTables(
       for (int q = 0; q < k; ++q) {
         rank += posUnitStart[q + 1] > posUnitStart[q] ? 1 : 0;
       }
-      loadedPos[rank] = k;
+      loadedPos[rank] = I(k);
     }
   }
   int numLoaded = 0; // every thread computes the same value
@@ -800,10 +899,15 @@ static __global__ void stashFusedArgsKernel(FusedArgs a, FusedArgs* dst) {
 }
 #endif
 template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
-#ifdef MMX_EXP_OCC4
-__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 4 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
-#else
+// Workgroups per CU the register budget is set for (the LDS footprint decides what actually runs): FOUR for the per-rule
+// instantiations up to six blocks (round 5: the lifetime-shared carve brings BASELINE configs[1] to 40.2 KB; 128 VGPRs cost
+// a workgroup 4.6 % of its latency -- measured with the LDS still at 52 KB, profiles/r05_exp_fused.txt -- and buy a third
+// more of them per CU), three for the generic ones (their trial evaluations spill at 128), two up to eight blocks and for
+// the general rows, one beyond.  MMX_EXP_OCC3: the A/B variant with three everywhere.
+#ifdef MMX_EXP_OCC3
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
+#else
+__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
 #endif
 #ifdef MMX_EXP_ARGPTR
     const FusedArgs* __restrict__ argsDev,
@@ -845,12 +949,23 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   selectInstanceWeights(pb, b);
 #endif
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
-  const int kR = rig.R, kNnz = fd.nnz, kLevels = rig.numLevels;
+  const int kR = rig.R;
 
-  // ---- LDS carve (every offset a multiple of 4 floats); must match fusedLdsBytes()
+  // ---- LDS carve (every offset a multiple of 4 floats); must match fusedLdsBytes().  Round 5: laid out by LIFETIME so that
+  // the 72-joint problems fit a quarter of a CU's LDS (BASELINE configs[1]: 52.2 -> 40.2 KB, four workgroups per CU):
+  //   * the integer tables are 16-bit (every index of a fused problem is below 4096), the parameter transform's CSR stays
+  //     in global memory (read by the prefetching walk csrRowsPrefetched: one L2 round trip per use);
+  //   * first-order own / subtree sums of phases D-E live in the assembly scratch (over the FK buffer / the unit moments),
+  //     those of the refinement in the refinement's arena;
+  //   * the arena (phases J-K: jd | tanOwn | tanPre | own sums | subtree sums | per-slot gradients, each over a dead
+  //     predecessor; dfull) shares its place with the slot tables srcT of phases E-G;
+  //   * uy (dead after phase D) shares its place with the slots' gradient shares (E-F), the split entries' partial
+  //     cells (G) and rho | invDiag (from the end of G on).
   FusedLds s;
-  int *lParent, *lLevelOrder, *lLevelStart, *lPtOuter, *lPtInner, *lSubSize, *lPosUnitStart, *lPosUnits, *lUnitJoint, *lSolveList, *lDfsJoint, *lLoadedPos, *lColToSolve;
-  float* lPtValue;
+  int16_t *lParentPos, *lSubSize, *lPosUnitStart, *lPosUnits, *lUnitJoint, *lSolveList, *lDfsJoint, *lLoadedPos, *lColToSolve;
+  int* lParent;
+  float *srcGu, *cells, *arena;
+  const FusedLayout lay = fusedLayout(NB, J, P, U, nsrc, n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR);
   {
     float* p = smem;
     auto take = [&](size_t count) {
@@ -858,36 +973,30 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       p += alignUp4(count);
       return r;
     };
-    s.mStart = reinterpret_cast<int*>(take(NP + 1));
+    auto takeS = [&](size_t count) { return reinterpret_cast<int16_t*>(take((count + 1) / 2)); };
+    s.mStart = takeS(NP + 1);
     s.mTin = reinterpret_cast<int*>(take(nsrc));
     s.mInfo = reinterpret_cast<int*>(take(nsrc));
     s.mW = take(nsrc);
     lParent = reinterpret_cast<int*>(take(J));
-    lLevelOrder = reinterpret_cast<int*>(take(J));
-    lLevelStart = reinterpret_cast<int*>(take(kLevels + 1));
-    lPtOuter = reinterpret_cast<int*>(take(kR + 1));
-    lPtInner = reinterpret_cast<int*>(take(kNnz));
-    lPtValue = take(kNnz);
-    lSubSize = reinterpret_cast<int*>(take(J));
-    lPosUnitStart = reinterpret_cast<int*>(take(J + 1));
-    lPosUnits = reinterpret_cast<int*>(take(U));
-    lUnitJoint = reinterpret_cast<int*>(take(U));
-    lSolveList = reinterpret_cast<int*>(take(n));
-    lDfsJoint = reinterpret_cast<int*>(take(J));
-    lLoadedPos = reinterpret_cast<int*>(take(J));
-    lColToSolve = reinterpret_cast<int*>(take(P));
+    lParentPos = takeS(J);
+    lSubSize = takeS(J);
+    lPosUnitStart = takeS(J + 1);
+    lPosUnits = takeS(U);
+    lUnitJoint = takeS(U);
+    lSolveList = takeS(n);
+    lDfsJoint = takeS(J);
+    lLoadedPos = takeS(J);
+    lColToSolve = takeS(P);
     s.th = take(P);
     s.js = take(size_t(kJs) * J);
     s.up = take(3 * size_t(U));
     s.ur = take(3 * size_t(U));
-    s.uy = take(3 * size_t(U));
     s.us = take(U);
-    s.own1 = take(size_t(kC1) * J);
-    s.sub1 = take(size_t(kC1) * J);
     s.g = take(NP);
     s.d0 = take(NP);
-    s.rho = take(NP);
-    s.invDiag = take(NP);
+    s.uy = take(lay.uyFloats);
+    s.rho = s.uy + lay.auxOff, s.invDiag = s.rho + NP, srcGu = s.rho, cells = s.rho + lay.cellOff;
     s.red = reinterpret_cast<double*>(take(16));
     s.flags = reinterpret_cast<int*>(take(4));
     s.gEv = s.gRes = s.gW = s.gJ = nullptr;
@@ -898,24 +1007,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       s.gW = take(rowsGp);
       s.gJ = take(size_t(rowsGp) * size_t(srcStrideFor(NP)));
     }
-    float* blockJ = p; // srcT (phases E-G)  |  dfull, jd, tanOwn, tanPre (phases J-K)
-    s.dfull = take(P);
-    s.jd = take(7 * size_t(J));
-    s.tanOwn = take(size_t(kTan) * J);
-    s.tanPre = take(size_t(kTan) * J);
-    s.srcT = blockJ;
-    {
-      float* endSrc = blockJ + size_t(kSrcCh) * srcStrideFor(nsrc);
-      if (endSrc > p) {
-        p = endSrc;
-      }
-    }
+    arena = take(lay.arenaFloats); // srcT (phases E-G)  |  the refinement's buffers and dfull (phases J-K)
+    s.srcT = arena;
+    s.tanOwn = arena, s.jd = arena + lay.t9, s.tanPre = arena + lay.t9, s.dfull = arena + 2 * lay.t9;
     float* region = p;
     s.fkA = reinterpret_cast<double*>(take(fkBufFloats(J)));
     s.fkB = reinterpret_cast<double*>(p); // over own2 / sub2 (2 kC2 J >= fkBufFloats(J) floats)
     s.own2 = take(size_t(kC2) * J);
     s.sub2 = take(size_t(kC2) * J);
-    s.umom = take(size_t(kUmom) * U);
+    s.umom = take(lay.umomFloats);
+    s.own1 = region, s.sub1 = s.umom; // phases D-E: over the FK buffer (dead after FK) / the unit moments (dead after the own sums)
     s.L = region;
   }
 
@@ -924,7 +1025,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     s.th[i] = thg[i];
   }
   for (int c = tid; c <= NP; c += 256) {
-    s.mStart[c] = fd.srcStart[c];
+    s.mStart[c] = int16_t(fd.srcStart[c]);
   }
   for (int e = tid; e < nsrc; e += 256) {
     const ColumnSourceDev cs = fd.srcs[e];
@@ -934,31 +1035,21 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   }
   for (int i = tid; i < J; i += 256) {
     lParent[i] = rig.parent[i];
-    lSubSize[i] = fd.subSize[i];
-  }
-  for (int i = tid; i <= kLevels; i += 256) {
-    lLevelStart[i] = rig.levelStart[i];
-  }
-  for (int i = tid; i <= kR; i += 256) {
-    lPtOuter[i] = rig.ptOuter[i];
-  }
-  for (int i = tid; i < kNnz; i += 256) {
-    lPtInner[i] = rig.ptInner[i];
-    lPtValue[i] = rig.ptValue[i];
+    lSubSize[i] = int16_t(fd.subSize[i]);
   }
   for (int i = tid; i <= J; i += 256) {
-    lPosUnitStart[i] = fd.posUnitStart[i];
+    lPosUnitStart[i] = int16_t(fd.posUnitStart[i]);
   }
   for (int i = tid; i < U; i += 256) {
-    lPosUnits[i] = fd.posUnits[i];
-    lUnitJoint[i] = pb.unitTin[i]; // DFS position of the unit's joint
+    lPosUnits[i] = int16_t(fd.posUnits[i]);
+    lUnitJoint[i] = int16_t(pb.unitTin[i]); // DFS position of the unit's joint
   }
   for (int i = tid; i < n; i += 256) {
-    lSolveList[i] = fd.solveList[i];
+    lSolveList[i] = int16_t(fd.solveList[i]);
   }
   for (int i = tid; i < J; i += 256) {
-    lDfsJoint[i] = fd.dfsJoint[i];
-    lLoadedPos[i] = i < fd.numLoaded ? fd.loadedPos[i] : 0;
+    lDfsJoint[i] = int16_t(fd.dfsJoint[i]);
+    lLoadedPos[i] = int16_t(i < fd.numLoaded ? fd.loadedPos[i] : 0);
   }
   for (int i = tid; i < P; i += 256) {
     lColToSolve[i] = -1;
@@ -975,7 +1066,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   }
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
-    lColToSolve[fd.solveList[i]] = i;
+    lColToSolve[fd.solveList[i]] = int16_t(i);
   }
   // Per-instance constraint parents (mmx_problem_set_instance_parents): the tables that say which units
   // hang on which joint are built here, per element, instead of copied from the batch-shared ones --
@@ -988,7 +1079,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   }
   // parentPos[k] = DFS position of the parent of the joint at DFS position k (-1 for a root), built
   // through a joint -> position scratch map (alt is free until the first FK)
-  int* lParentPos = lLevelOrder;
   {
     int* posOf = reinterpret_cast<int*>(s.fkA);
     for (int k = tid; k < J; k += 256) {
@@ -997,17 +1087,17 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     __syncthreads();
     for (int k = tid; k < J; k += 256) {
       const int par = rig.parent[fd.dfsJoint[k]];
-      lParentPos[k] = par >= 0 ? posOf[par] : -1;
+      lParentPos[k] = int16_t(par >= 0 ? posOf[par] : -1);
     }
   }
   // from here on the kernel reads the batch-shared tables through these LDS-backed views
   RigView rv;
-  rv.J = J, rv.P = P, rv.R = kR, rv.numLevels = kLevels, rv.jumpRounds = rig.jumpRounds;
+  rv.J = J, rv.P = P, rv.R = kR, rv.numLevels = rig.numLevels, rv.jumpRounds = rig.jumpRounds;
   rv.parent = lParent, rv.preRot = rig.preRot, rv.offset = rig.offset;
-  rv.ptOuter = lPtOuter, rv.ptInner = lPtInner, rv.ptValue = lPtValue, rv.ptOffsets = rig.ptOffsets;
+  rv.ptOuter = rig.ptOuter, rv.ptInner = rig.ptInner, rv.ptValue = rig.ptValue, rv.ptOffsets = rig.ptOffsets; // (global: csrRowsPrefetched)
   rv.hasOffsets = rig.ptOffsetsNonZero != 0;
-  rv.levelOrder = lLevelOrder, rv.levelStart = lLevelStart;
-  FusedView fv;
+  rv.levelOrder = nullptr, rv.levelStart = nullptr; // (the pointer-jumping FK needs neither)
+  FusedViewS fv;
   fv.U = U, fv.Kp = fd.Kp;
   fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = numLoadedInst, fv.colToSolve = lColToSolve;
   fv.subSize = lSubSize, fv.unitPos = lUnitJoint, fv.posUnitStart = lPosUnitStart, fv.posUnits = lPosUnits;
@@ -1033,6 +1123,38 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
   const int doLineSearch = kRule < 0 || kRule == 2 ? fp.doLineSearch : 0;
   bool stateValid = false;
   double stateError = 0.0;
+  // the parameter transform's CSR in global memory, walked twice per iteration: pipelined when a thread's two rows cover it
+  // (built and measured, round 5: 1.588e6 against 1.715e6 solves/s without it on BASELINE configs[1] -- the six registers the
+  // requests hold across the phases raise the spills at 128 VGPRs from 92 to 119, which costs more than the two L2 round
+  // trips per iteration it hides; profiles/r05_exp_fused.txt.  MMX_BUILD_VARIANT=csrpipe builds it.)
+#ifdef MMX_EXP_CSRPIPE
+  const bool csrPipe = kR <= 512;
+#else
+  const bool csrPipe = false;
+#endif
+  // ... and the lighter form: only the rows' bounds are kept (packed, two registers), the first entries are requested where
+  // they are needed -- one L2 round trip per walk instead of two.  MMX_BUILD_VARIANT=csrbounds.
+#ifdef MMX_EXP_CSRBOUNDS
+  const bool csrKeep = kR <= 512;
+#else
+  const bool csrKeep = false;
+#endif
+  int csrPacked[2] = {0, 0}; // ka | cnt << 20
+  if (csrKeep) {
+    const CsrBounds2 b0 = csrRowBounds<256>(rig.ptOuter, kR, tid);
+    csrPacked[0] = b0.ka[0] | (b0.cnt[0] << 20), csrPacked[1] = b0.ka[1] | (b0.cnt[1] << 20);
+  }
+  auto csrUnpack = [&]() {
+    CsrBounds2 b1;
+    b1.ka[0] = csrPacked[0] & 0xfffff, b1.cnt[0] = csrPacked[0] >> 20, b1.ka[1] = csrPacked[1] & 0xfffff, b1.cnt[1] = csrPacked[1] >> 20;
+    return b1;
+  };
+  CsrBounds2 csrB{};
+  CsrFirst2 csrFk{}, csrJd{};
+  if (csrPipe) {
+    csrB = csrRowBounds<256>(rig.ptOuter, kR, tid);
+    csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
+  }
   __syncthreads();
 
   if (MODE == 2) {
@@ -1074,7 +1196,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
       curError = stateError;
     } else {
     // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
-    blockFk(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast);
+    if (csrKeep) {
+      csrB = csrUnpack();
+      csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
+    }
+    blockFk<true>(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast, csrPipe || csrKeep ? &csrB : nullptr, &csrFk);
     MMX_CLK(1)
     // ================= C: units (need only the world transforms, not the axes)
     {
@@ -1138,7 +1264,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     const int sst = srcStrideFor(nsrc);
     float* srcD = s.srcT; // [7][sst]  G0(3) AX(3) TR
     float* srcA = s.srcT + 7 * sst; // [7][sst]  AL(3) BV(3) BS
-    float* srcG = s.srcT + 14 * sst; // [sst]     the slot's share of g = J^T r
+    float* srcG = srcGu; // [nsrc]    the slot's share of g = J^T r (in uy's place: dead since phase D, rho / invDiag not yet written)
     for (int e = tid; e < nsrc; e += 256) {
       ColumnSourceDev cs;
       {
@@ -1315,7 +1441,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
             if (x & (1u << 25)) {
               const uint32_t y = rec[k].y;
               if (y & (1u << 30)) {
-                s.sub1[y & 0xffff] = h; // partial cell of a split entry (sub1 is free between E and the refinement)
+                cells[y & 0xffff] = h; // partial cell of a split entry (in uy's place; the gradient shares are consumed)
               } else {
                 s.L[y] += h; // one thread per entry
               }
@@ -1331,7 +1457,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         const int dest = fd.comb[3 * i], first = fd.comb[3 * i + 1], cnt = fd.comb[3 * i + 2];
         float v = s.L[dest];
         for (int c = 0; c < cnt; ++c) {
-          v += s.sub1[first + c];
+          v += cells[first + c];
         }
         s.L[dest] = v;
       }
@@ -1619,6 +1745,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     MMX_CLK(7)
 
     // ================= I: d0 = (L L^T)^-1 g
+    if (csrPipe) { // the refinement's walk of the transform: its loads fly under the solve
+      csrJd = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
+    }
     if (!notPd) {
       solveLLt<NB>(s.L, s.invDiag, s.d0, tid);
     }
@@ -1633,14 +1762,21 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     float prevCorr2 = FLT_MAX;
     for (int rf = 0; rf < nRefine; ++rf) {
       // joint-parameter delta jd = transform * delta (delta gathered through the solve map)
-      for (int r = tid; r < rv.R; r += 256) {
-        float a = 0.f;
-        const int k1 = rv.ptOuter[r + 1];
-        for (int k = rv.ptOuter[r]; k < k1; ++k) {
-          const int cs = fv.colToSolve[rv.ptInner[k]];
-          a += rv.ptValue[k] * (cs >= 0 ? s.d0[cs] : 0.f);
+      {
+        auto xd = [&](int c) {
+          const int cs = fv.colToSolve[c];
+          return cs >= 0 ? s.d0[cs] : 0.f;
+        };
+        auto od = [&](int r, float a) { s.jd[r] = a; };
+        if (csrPipe && rf == 0) { // (first entries requested before the triangular solve of phase I)
+          csrRowsFromFirst<256>(rv.ptInner, rv.ptValue, rv.R, tid, csrB, csrJd, xd, od);
+        } else if (csrKeep) {
+          const CsrBounds2 b2 = csrUnpack();
+          const CsrFirst2 f2 = csrRequestFirst(rig.ptInner, rig.ptValue, b2);
+          csrRowsFromFirst<256>(rv.ptInner, rv.ptValue, rv.R, tid, b2, f2, xd, od);
+        } else {
+          csrRowsPrefetched<256>(rv.ptOuter, rv.ptInner, rv.ptValue, rv.R, tid, xd, od);
         }
-        s.jd[r] = a;
       }
       __syncthreads();
       MMX_CLK(16)
@@ -1716,9 +1852,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         treeSum<7, false, kTan>(fv, s.tanOwn, s.tanPre, J, wave, lane);
         __syncthreads();
       }
-      // w = r - J d, y = sigma w per unit, then the first-order own sums.  sub1 (free until the
-      // subtree sums are written) holds the per-unit contributions when it is large enough.
-      if (U <= J) {
+      // w = r - J d, y = sigma w per unit, then the first-order own sums.  The arena's two halves take turns (each buffer
+      // over a dead predecessor): with U <= J the per-unit contributions go where tanOwn was, their per-joint sums where
+      // tanPre was, the subtree sums over the contributions, the per-slot gradients over the own sums; with U > J the own
+      // sums are formed directly where tanOwn was and the two halves swap roles.
+      const bool unitPath = U <= J;
+      float* refOwn = unitPath ? arena + lay.t9 : arena;
+      float* refSub = unitPath ? arena : arena + lay.t9;
+      FusedLds sr = s;
+      sr.own1 = refOwn;
+      if (unitPath) {
         for (int u = tid; u < U; u += 256) {
           const float* pre = s.tanPre + kTan * fv.unitPos[u];
           const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
@@ -1729,10 +1872,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           }
           const float sg = s.us[u];
           firstOrderMoments(
-              s.sub1 + kC1 * u, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
+              refSub + kC1 * u, p, sg * (s.ur[3 * u] - sg * v.x), sg * (s.ur[3 * u + 1] - sg * v.y), sg * (s.ur[3 * u + 2] - sg * v.z), point);
         }
         __syncthreads();
-        gatherOwnSums<kC1, kC1>(fv, s, s.sub1, tid);
+        gatherOwnSums<kC1, kC1, 256, FusedViewS>(fv, sr, refSub, tid);
       } else {
         for (int k = tid; k < J; k += 256) {
           const int e0 = fv.posUnitStart[k], e1 = fv.posUnitStart[k + 1];
@@ -1758,21 +1901,22 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
           }
 #pragma unroll
           for (int c = 0; c < kC1; ++c) {
-            s.own1[kC1 * k + c] = a1[c];
+            refOwn[kC1 * k + c] = a1[c];
           }
         }
       }
       __syncthreads();
       MMX_CLK(17)
-      treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
+      treeSum<kC1, true>(fv, refOwn, refSub, J, wave, lane);
       __syncthreads();
       MMX_CLK(18)
-      // J^T w per slot in parallel (tanOwn is free again), then per column the sum of its slots
+      // J^T w per slot in parallel (where the own sums were: consumed), then per column the sum of its slots
       const bool perSource = nsrc <= kTan * J;
+      float* perS = refOwn;
       if (perSource) {
         for (int e = tid; e < nsrc; e += 256) {
           const int info = s.mInfo[e];
-          s.tanOwn[e] = s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * (s.mTin[e] & 0xffff));
+          perS[e] = s.mW[e] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, refSub + kC1 * (s.mTin[e] & 0xffff));
         }
         __syncthreads();
       }
@@ -1781,10 +1925,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
         if (c < n) {
           auto slotShare = [&](int sl) {
             if (perSource) {
-              return s.tanOwn[sl];
+              return perS[sl];
             }
             const int info = s.mInfo[sl];
-            return s.mW[sl] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, s.sub1 + kC1 * (s.mTin[sl] & 0xffff));
+            return s.mW[sl] * sourceGradient(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, s.js, refSub + kC1 * (s.mTin[sl] & 0xffff));
           };
           a = slotShare(c); // the primary slot, then the extras
           const int e1 = NP + s.mStart[c + 1];
@@ -1895,6 +2039,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
     }
     } // linear solves
     // ================= K: theta -= delta ; bookkeeping of SolverT::solve (solver.cpp:92-119)
+    if (csrPipe) { // the next forward kinematics' walk of the transform: its loads fly under this phase and the barrier
+      csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
+    }
     if (kTR) {
       if (trNoStep) {
         break;
@@ -3035,20 +3182,8 @@ hipError_t launchTreeRefine(
 
 // ---------------------------------------------------------------------------------------------
 #if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels, int GT, int genRows) {
-  const size_t T = size_t(NB) * (NB + 1) / 2, NP = 16 * size_t(NB);
-  auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
-  const size_t meta = a4(NP + 1) + 3 * a4(nsrc) + 2 * a4(J) + a4(numLevels + 1) + a4(7 * size_t(J) + 1) + 2 * a4(nnz) + a4(J) +
-      a4(J + 1) + 2 * a4(U) + a4(n) + 2 * a4(J) + a4(P);
-  const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 3 * a4(3 * size_t(U)) + a4(U) + 2 * a4(size_t(kC1) * J) + 4 * a4(NP) + 16 + 4;
-  const size_t refine = a4(P) + a4(7 * size_t(J)) + 2 * a4(size_t(kTan) * J);
-  const size_t srcT = size_t(kSrcCh) * size_t(srcStrideFor(nsrc));
-  const size_t blockJ = refine > srcT ? refine : srcT;
-  const size_t scratch = fkBufFloats(J) + 2 * a4(size_t(kC2) * J) + a4(size_t(kUmom) * U);
-  const size_t region = scratch > T * 256 ? scratch : T * 256;
-  const size_t rowsGp = (size_t(genRows) + 3) & ~size_t(3);
-  const size_t gen = GT > 0 ? a4(size_t(kGenEv) * GT) + 2 * a4(rowsGp) + a4(rowsGp * size_t(srcStrideFor(int(NP)))) : 0;
-  return (meta + fixed + gen + blockJ + region) * sizeof(float);
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy) {
+  return fusedLayout(NB, J, P, U, nsrc, n, numCells, cellsBehindRho, GT, genRows, separateUy).total * sizeof(float);
 }
 #endif
 
@@ -3064,7 +3199,7 @@ static hipError_t launchFusedMode(
     float* dbgG,
     long long* dbgClk,
     hipStream_t stream) {
-  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.nnz, rig.numLevels, kGen ? fd.GT : 0, kGen ? fd.genRows : 0);
+  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR);
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }

@@ -131,6 +131,7 @@ struct FusedDev {
   int32_t termRounds16;
   const int32_t* comb; // [numComb][3] (tile-region offset, first partial cell, cell count) of split entries
   int32_t numComb;
+  int32_t numCells; // partial cells of the split entries (the kernels park them in a scratch array)
   // parameter-space rows (limits on model parameters, model-parameter targets): which limits touch
   // a solve column, and which share an off-diagonal H entry
   int32_t numLimits;
@@ -161,7 +162,9 @@ struct FusedParams {
   float trustRadius; // TrustRegionQROptions::trustRegionRadius_
 };
 
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int nnz, int numLevels, int GT = 0, int genRows = 0);
+// cellsBehindRho: the instantiations that carry parameter-space rows park their diagonal in rho while the term records run,
+// so the split entries' partial cells lie behind rho / invDiag there (numCells floats more)
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT = 0, int genRows = 0, bool separateUy = false);
 // H = J^T J, g = J^T r from the tree moments for the explicit-Jacobian solver (mmx_fused.hip, treeNormalEquationsKernel)
 size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n, int GT = 0, int genRows = 0);
 size_t treeRefineLdsBytes(int J, int P, int U, int n, int genRows);

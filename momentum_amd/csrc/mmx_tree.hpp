@@ -32,10 +32,12 @@ constexpr int kC1 = 7; // first-order channels per joint: F(3) | N(3) | D (odd s
 // hundreds of joints; the 72-joint fused solve is faster with 1)
 // kRange (subtree sums, optional): per row tile the range [lo, hi) of loaded-position indices that can fall into a
 // subtree of one of the tile's rows (treeSumRanges below); everything outside multiplies by an exact zero.
-template <int NC, bool kSubtree, int STRIDE = NC, int UN = 1> // NC channels per row, rows STRIDE floats apart
+// I: element type of the two integer tables (int32_t in global memory / the tree kernels' LDS, int16_t in the one-launch
+// solve's LDS, where every float counts towards a fourth workgroup per CU)
+template <int NC, bool kSubtree, int STRIDE = NC, int UN = 1, class I = int32_t> // NC channels per row, rows STRIDE floats apart
 __device__ __forceinline__ void treeSumT(
-    const int32_t* subSize,
-    const int32_t* loadedPos,
+    const I* subSize,
+    const I* loadedPos,
     int numLoaded,
     const float* in,
     float* out,
@@ -91,7 +93,8 @@ __device__ __forceinline__ void treeSumT(
 // kRange of treeSumT: row tile rt covers DFS positions 16 rt .. 16 rt + 15; a loaded position p contributes to one of its
 // rows r iff r <= p < r + subSize[r], hence 16 rt <= p < max_r (r + subSize[r]).  One thread per row tile, two binary
 // searches in the ascending loadedPos.  Call by >= (J + 15) / 16 threads; barrier afterwards.
-__device__ __forceinline__ void treeSumRanges(const int32_t* subSize, const int32_t* loadedPos, int numLoaded, int J, int tid, int32_t* kRange) {
+template <class I = int32_t>
+__device__ __forceinline__ void treeSumRanges(const I* subSize, const I* loadedPos, int numLoaded, int J, int tid, int32_t* kRange) {
   const int rowTiles = (J + 15) >> 4;
   if (tid < rowTiles) {
     int hi = 0;
