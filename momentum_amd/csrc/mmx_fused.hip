@@ -1171,8 +1171,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the constraint payload of this thread's unit is requested before FK so that its HBM latency
-    // hides behind it (one round trip per iteration instead of two)
-    const UnitInput uin0 = loadUnitInput(pb, b, tid < U ? tid : U);
+    // hides behind it (one round trip per iteration instead of two) -- except in the instantiations that run four
+    // workgroups per CU at 128 registers: eleven registers across FK cost them more than the round trip (an L2 hit from the
+    // second iteration on): 1.716 -> 1.726e6 solves/s on BASELINE configs[1], profiles/r05_exp_fused.txt
+    constexpr bool kLateUnit = NB <= 6 && !kGen && kRule >= 0 && !kTR;
+    const UnitInput uin0 = kLateUnit ? UnitInput{} : loadUnitInput(pb, b, tid < U ? tid : U);
     // TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270) wraps what follows
     // in up to ten trial steps (:157); every other step rule passes through once.
     float trLambda = 1e-10f; // :86, only grows within an iteration (:213-224)
@@ -1206,7 +1209,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
     {
       double e = 0.0;
       for (int u = tid; u < U; u += 256) {
-        const Unit un = evalUnitFrom(pb, u == tid ? uin0 : loadUnitInput(pb, b, u), s.js, u);
+        const Unit un = evalUnitFrom(pb, (!kLateUnit && u == tid) ? uin0 : loadUnitInput(pb, b, u), s.js, u);
         s.up[3 * u] = un.v.x, s.up[3 * u + 1] = un.v.y, s.up[3 * u + 2] = un.v.z;
         const float rx = un.sigma * un.f.x, ry = un.sigma * un.f.y, rz = un.sigma * un.f.z;
         s.ur[3 * u] = rx, s.ur[3 * u + 1] = ry, s.ur[3 * u + 2] = rz;

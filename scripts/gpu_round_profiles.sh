@@ -2,12 +2,12 @@
 # end-of-round evidence: full GPU suite, the default bench line, kernel traces and PMC passes of the headline (cfg2) and
 # of the wide solve (cfg5).  usage: bash scripts/gpu_round_profiles.sh r02   -> gpurun_out/round_r02/
 cd "$GRAFT_REPO_ROOT" || exit 1
-r=${1:-r04}
+r=${1:-r05}
 out=$GRAFT_REPO_ROOT/gpurun_out/round_$r
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 700 python -m pytest tests -m gpu -q < /dev/null 2>&1 | grep -E "passed|failed|FAILED|rror" | tail -6 > $out/pytest_gpu.txt
-timeout 900 python bench.py < /dev/null > $out/${r}_bench_default.json 2> $out/bench_default.err
+timeout 900 python -m pytest tests -m gpu -q < /dev/null 2>&1 | grep -E "passed|failed|FAILED|rror" | tail -6 > $out/pytest_gpu.txt
+timeout 1200 python bench.py --measure-traffic < /dev/null > $out/${r}_bench_default.json 2> $out/bench_default.err
 cd /tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 0"
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace2 -o t -- $B < /dev/null > /dev/null 2> $out/trace2.err
@@ -73,10 +73,12 @@ open(f"{out}/{r}_roofline.txt","w").write("\n".join(rows)+"\n")
 print("\n".join(rows))
 PY
 cat $out/pytest_gpu.txt; head -8 $out/${r}_bench_kernel_stats.txt | cut -c1-140; head -8 $out/${r}_cfg5_kernel_stats.txt | cut -c1-140
+cp $GRAFT_REPO_ROOT/gpurun_out/bench_details.json $out/${r}_bench_details.json 2> /dev/null
 python - $out/${r}_bench_default.json < /dev/null <<'PY'
 import json,sys
-d=json.load(open(sys.argv[1]))
-print("value", d["value"], "roofline", d["roofline"]["frac"], "cpu", d["cpu_baseline"]["value"])
+raw=open(sys.argv[1]).read()
+d=json.loads(raw)
+print("bytes", len(raw), "value", d["value"], "roofline", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["single_thread_value"])
 for k,v in d["configs"].items():
-    print(k, round(v["solves_per_s"]), v["check"].get("max_rel_theta_vs_oracle_f64"), round(v.get("gpu_over_cpu",0),1))
+    print(" ", k, v.get("solves_per_s"), v.get("within_bound"), v.get("max_rel"), v.get("pass"), v.get("gpu_over_cpu"))
 PY
