@@ -98,7 +98,7 @@ typedef enum mmx_status {
                                          ratio d_jj / (H_jj + lambda) of any iteration) ~ eps x cond(J^T J + lambda I),
                                          calibrated as the 98th percentile of the relative distance on the BASELINE shapes;
                                          mmx_problem_solve_diagnostics returns it -- exceeds mmx_gn_options::precision_bound
-                                         (default 1e-5, north_star's parity bound: 1 / ratio = 4000).  Unlike
+                                         (default 1e-5, north_star's parity bound: 1 / ratio = 2000).  Unlike
                                          MMX_SOLVE_DAMPING_FLOORED, which only says that the factor's damping floor engaged,
                                          this follows the conditioning that loses the digits; it is a property of the problem
                                          class (rig, constraint set, lambda) more than of the instance: a class in which a

@@ -861,7 +861,7 @@ bool fusedUsable(const mmx_problem* pb) {
   // (the further joint-constraint blocks and ellipsoid limits ride along as a dense block of rows in LDS -- fdev.GT /
   // genRows -- while they fit; MMX_ROUTE_EXPLICIT_JACOBIAN sends them to the explicit-Jacobian kernels)
   return pb->rig->J < 4096 &&
-      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.numCells, true, pb->fdev.GT, pb->fdev.genRows, true) +
+      mmx::fusedLdsBytes(nb, pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.numCells, true, pb->fdev.GT, pb->fdev.genRows, true, mmx::fusedCsrFloats(pb->rig->J, pb->fdev.nnz)) +
           size_t(8) * size_t(pb->rig->J + pb->rig->P) <=
       160 * 1024;
 }

@@ -62,8 +62,8 @@ constexpr float kFactorDamping = 1e-5f;
 // batch and by decades between the rows --, and the share of instances further than 1e-5 from the double run follows it:
 //   1 / ratio   3.1e2 (configs[1], 0.05)  1.0e3  1.5e3 (configs[1], 0.01)  | 7.3e3 (configs[0], 0.05)  1.5e4 (configs[1], 1e-3)  3.6e4   >= 1.7e5
 //   above 1e-5  0 (worst 1.0e-6)          0      0 (worst 1.9e-6)          | 1-2 %                     1-4 %                      2-4 %   all
-// The gain puts the bound's default (1e-5) at 1 / ratio = 4000, between the last row without and the first row with
-// instances above it: est ~ the 98th percentile of the relative distance.  Which instances of a marked class end above the
+// The gain puts the bound's default (1e-5) at 1 / ratio = 2000 (eps = FLT_EPSILON = 1.19e-7), between the last row without
+// and the first row with instances above it: est ~ the 98th percentile of the relative distance.  Which instances of a marked class end above the
 // bound is not predictable from the conditioning (a discrete line-search decision, an overshooting step): the whole class
 // is marked, which is what MMX_PRECISION_AUTO needs -- {above the bound} is a subset of {marked}.
 constexpr float kPrecisionGain = 0.042f;

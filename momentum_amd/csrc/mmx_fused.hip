@@ -439,7 +439,9 @@ struct FusedLayout {
 };
 // separateUy: the trust region re-runs phases D-G for every value of its damping WITHOUT re-evaluating the units (phase C), so
 // its uy must outlive rho / invDiag
-__host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy = false) {
+// csrFloats: LDS copy of the parameter transform's CSR (row pointer, columns, values as 32-bit words) in the instantiations
+// that run three or fewer workgroups per CU -- they have the room, and an L2 walk costs them 4 %; 0: read from global memory
+__host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy = false, size_t csrFloats = 0) {
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
   auto h4 = [&](size_t x) { return a4((x + 1) / 2); }; // 16-bit entries
   auto mx = [](size_t x, size_t y) { return x > y ? x : y; };
@@ -458,7 +460,7 @@ __host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, 
   l.genFloats = GT > 0 ? a4(size_t(kGenEv) * GT) + 2 * a4(rowsGp) + a4(rowsGp * size_t(srcStrideFor(int(NP)))) : 0;
   const size_t meta = h4(NP + 1) + 3 * a4(nsrc) + a4(J) + 4 * h4(J) + h4(size_t(J) + 1) + 2 * h4(U) + h4(n) + h4(P);
   const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 2 * a4(3 * size_t(U)) + a4(U) + 2 * a4(NP) + l.uyFloats + 16 + 4;
-  l.total = meta + fixed + l.genFloats + l.arenaFloats + l.regionFloats;
+  l.total = meta + fixed + l.genFloats + l.arenaFloats + l.regionFloats + csrFloats;
   return l;
 }
 
@@ -599,7 +601,7 @@ __device__ __forceinline__ void generalRowsGather(const float* js, const float* 
 // kStore: the evaluation also leaves everything phases A-C of an iteration would leave for `th` (rotation axes, the
 // units' vectors / residuals / weights) and reports the unrounded sum -- when the trial is accepted, the next iteration
 // starts from it instead of repeating forward kinematics and the unit evaluation.
-template <bool kGen = false, bool kStore = false, class FV = FusedViewS>
+template <bool kGen = false, bool kStore = false, bool kGlobalCsr = true, class FV = FusedViewS>
 __device__ __forceinline__ double blockError(
     const RigDev& rigDev,
     const RigView& rig,
@@ -611,7 +613,7 @@ __device__ __forceinline__ double blockError(
     int tid,
     double* unrounded = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
-  blockFk<true>(rig, s, th, tid, kStore); // (the transform's CSR is read from global memory: the one-launch solve keeps no LDS copy)
+  blockFk<kGlobalCsr>(rig, s, th, tid, kStore); // (the transform's CSR: from global memory where the instantiation keeps no LDS copy)
   double e = 0.0;
   for (int u = tid; u < fd.U; u += 256) {
     const Unit un = evalUnit(pb, s.js, b, u);
@@ -963,8 +965,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
   //     cells (G) and rho | invDiag (from the end of G on).
   FusedLds s;
   int16_t *lParentPos, *lSubSize, *lPosUnitStart, *lPosUnits, *lUnitJoint, *lSolveList, *lDfsJoint, *lLoadedPos, *lColToSolve;
-  int* lParent;
-  float *srcGu, *cells, *arena;
+  int *lParent, *lPtOuter = nullptr, *lPtInner = nullptr;
+  float *srcGu, *cells, *arena, *lPtValue = nullptr;
+  // the instantiations whose register budget is set for four workgroups per CU read the transform's CSR from global memory
+  // (their LDS has no room for it); the others keep their LDS copy
+  constexpr bool kFour = NB <= 6 && !kGen && kRule >= 0 && !kTR;
+  constexpr bool kCsrLds = !kFour;
+  const int kNnz = fd.nnz;
   const FusedLayout lay = fusedLayout(NB, J, P, U, nsrc, n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR);
   {
     float* p = smem;
@@ -988,6 +995,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
     lDfsJoint = takeS(J);
     lLoadedPos = takeS(J);
     lColToSolve = takeS(P);
+    if (kCsrLds) {
+      lPtOuter = reinterpret_cast<int*>(take(kR + 1));
+      lPtInner = reinterpret_cast<int*>(take(kNnz));
+      lPtValue = take(kNnz);
+    }
     s.th = take(P);
     s.js = take(size_t(kJs) * J);
     s.up = take(3 * size_t(U));
@@ -1039,6 +1051,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
   }
   for (int i = tid; i <= J; i += 256) {
     lPosUnitStart[i] = int16_t(fd.posUnitStart[i]);
+  }
+  if (kCsrLds) {
+    for (int i = tid; i <= kR; i += 256) {
+      lPtOuter[i] = rig.ptOuter[i];
+    }
+    for (int i = tid; i < kNnz; i += 256) {
+      lPtInner[i] = rig.ptInner[i];
+      lPtValue[i] = rig.ptValue[i];
+    }
   }
   for (int i = tid; i < U; i += 256) {
     lPosUnits[i] = int16_t(fd.posUnits[i]);
@@ -1094,7 +1115,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
   RigView rv;
   rv.J = J, rv.P = P, rv.R = kR, rv.numLevels = rig.numLevels, rv.jumpRounds = rig.jumpRounds;
   rv.parent = lParent, rv.preRot = rig.preRot, rv.offset = rig.offset;
-  rv.ptOuter = rig.ptOuter, rv.ptInner = rig.ptInner, rv.ptValue = rig.ptValue, rv.ptOffsets = rig.ptOffsets; // (global: csrRowsPrefetched)
+  rv.ptOuter = kCsrLds ? lPtOuter : rig.ptOuter, rv.ptInner = kCsrLds ? lPtInner : rig.ptInner, rv.ptValue = kCsrLds ? lPtValue : rig.ptValue; // (LDS copy, or global: csrRowsPrefetched)
+  rv.ptOffsets = rig.ptOffsets;
   rv.hasOffsets = rig.ptOffsetsNonZero != 0;
   rv.levelOrder = nullptr, rv.levelStart = nullptr; // (the pointer-jumping FK needs neither)
   FusedViewS fv;
@@ -1203,7 +1225,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
       csrB = csrUnpack();
       csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
     }
-    blockFk<true>(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast, csrPipe || csrKeep ? &csrB : nullptr, &csrFk);
+    blockFk<!kCsrLds>(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast, csrPipe || csrKeep ? &csrB : nullptr, &csrFk);
     MMX_CLK(1)
     // ================= C: units (need only the world transforms, not the axes)
     {
@@ -1532,6 +1554,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
       muFactor = fmaxf(mu, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
       floored = floored || muFactor > mu;
     }
+    // Every wave has summed the UNDAMPED diagonal before any thread damps its entry in place (round 5: without this barrier a
+    // fast wave's writes below raced a slow wave's trace reads above -- harmless while lambda exceeds the floor, since
+    // muFactor is then lambda whatever the trace, but under weak damping the waves could factor with floors that differed in
+    // the last bits from run to run: scripts/diag_determinism.py found 586 of 11 264 instance-solves of BASELINE configs[1]'s
+    // shape at lambda = 1e-7 not bit-reproducible, none from lambda = 1e-3 up)
+    __syncthreads();
     for (int c = tid; c < NP; c += 256) {
       float* dg = s.L + 256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15);
       const float hd = c < n ? *dg + muFactor : 1.f;
@@ -1771,7 +1799,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
           return cs >= 0 ? s.d0[cs] : 0.f;
         };
         auto od = [&](int r, float a) { s.jd[r] = a; };
-        if (csrPipe && rf == 0) { // (first entries requested before the triangular solve of phase I)
+        if (kCsrLds) { // one transform row per thread from the LDS copy
+          for (int r = tid; r < rv.R; r += 256) {
+            float a = 0.f;
+            const int k1 = rv.ptOuter[r + 1];
+            for (int k = rv.ptOuter[r]; k < k1; ++k) {
+              a += rv.ptValue[k] * xd(rv.ptInner[k]);
+            }
+            od(r, a);
+          }
+        } else if (csrPipe && rf == 0) { // (first entries requested before the triangular solve of phase I)
           csrRowsFromFirst<256>(rv.ptInner, rv.ptValue, rv.R, tid, csrB, csrJd, xd, od);
         } else if (csrKeep) {
           const CsrBounds2 b2 = csrUnpack();
@@ -2059,7 +2096,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
         s.dfull[fv.solveList[c]] -= s.d0[c];
       }
       __syncthreads();
-      const double eNew = blockError<kGen>(rig, rv, pb, fv, s, s.dfull, b, tid);
+      const double eNew = blockError<kGen, false, !kCsrLds>(rig, rv, pb, fv, s, s.dfull, b, tid);
       const float predicted = trDg + (trMu - 1e-20f) * trDn2; // e - model
       const float rho = float((curError - eNew) / double(predicted));
       if (rho < 0.25f) { // :256-262 (lambda > 0 always holds: it starts at 1e-10)
@@ -2097,7 +2134,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
       }
       __syncthreads();
       double eFull = 0.0;
-      const double eNew = blockError<kGen, kReuse>(rig, rv, pb, fv, s, s.dfull, b, tid, &eFull);
+      const double eNew = blockError<kGen, kReuse, !kCsrLds>(rig, rv, pb, fv, s, s.dfull, b, tid, &eFull);
       const float rho = predicted > 0.f ? float((curError - eNew) / double(predicted)) : -1.f;
       if (st.stepHistory != nullptr && tid == 0) {
         double* sh = st.stepHistory + (size_t(b) * fp.maxIterations + it) * 2;
@@ -2148,7 +2185,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
           s.dfull[fv.solveList[c]] -= scale * s.d0[c];
         }
         __syncthreads();
-        const double eNew = blockError<kGen, kReuse>(rig, rv, pb, fv, s, s.dfull, b, tid, &stateError);
+        const double eNew = blockError<kGen, kReuse, !kCsrLds>(rig, rv, pb, fv, s, s.dfull, b, tid, &stateError);
         if ((curError - eNew) >= (doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale * scaledError))) {
           break;
         }
@@ -3185,8 +3222,12 @@ hipError_t launchTreeRefine(
 
 // ---------------------------------------------------------------------------------------------
 #if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy) {
-  return fusedLayout(NB, J, P, U, nsrc, n, numCells, cellsBehindRho, GT, genRows, separateUy).total * sizeof(float);
+size_t fusedCsrFloats(int J, int nnz) {
+  auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
+  return a4(7 * size_t(J) + 1) + 2 * a4(nnz);
+}
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy, size_t csrFloats) {
+  return fusedLayout(NB, J, P, U, nsrc, n, numCells, cellsBehindRho, GT, genRows, separateUy, csrFloats).total * sizeof(float);
 }
 #endif
 
@@ -3202,7 +3243,8 @@ static hipError_t launchFusedMode(
     float* dbgG,
     long long* dbgClk,
     hipStream_t stream) {
-  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR);
+  constexpr bool kFourL = NB <= 6 && !kGen && kRule >= 0 && !kTR; // (fusedSolveKernel's kFour)
+  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR, kFourL ? 0 : fusedCsrFloats(rig.J, fd.nnz));
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }

@@ -164,7 +164,8 @@ struct FusedParams {
 
 // cellsBehindRho: the instantiations that carry parameter-space rows park their diagonal in rho while the term records run,
 // so the split entries' partial cells lie behind rho / invDiag there (numCells floats more)
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT = 0, int genRows = 0, bool separateUy = false);
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT = 0, int genRows = 0, bool separateUy = false, size_t csrFloats = 0);
+size_t fusedCsrFloats(int J, int nnz); // LDS copy of the transform's CSR (the instantiations below four workgroups per CU)
 // H = J^T J, g = J^T r from the tree moments for the explicit-Jacobian solver (mmx_fused.hip, treeNormalEquationsKernel)
 size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n, int GT = 0, int genRows = 0);
 size_t treeRefineLdsBytes(int J, int P, int U, int n, int genRows);
