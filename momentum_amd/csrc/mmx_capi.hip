@@ -152,7 +152,7 @@ struct mmx_rig {
   std::vector<int32_t> parent, ptOuter, ptInner;
   std::vector<float> preRot, offset, ptValue, ptOffsets;
   mmx::HostTables topo; // built with all parameters enabled
-  DevBuf dParent, dPreRot, dOffset, dPtOuter, dPtInner, dPtValue, dPtOffsets, dLevelOrder, dLevelStart, dPtEll, dJumpParent;
+  DevBuf dParent, dPreRot, dOffset, dPtOuter, dPtInner, dPtValue, dPtOffsets, dLevelOrder, dLevelStart, dPtEll, dJumpParent, dPtRowRec;
   mmx::RigDev dev{};
 
   mmx_rig_desc desc() const {
@@ -1209,8 +1209,30 @@ int32_t mmx_rig_create(const mmx_rig_desc* d, int32_t device, mmx_rig** out) {
     UP(r->dPtEll, ell);
   }
   UP(r->dJumpParent, jumpParent);
+  // records of the non-empty transform rows (RigDev::ptRowRec)
+  std::vector<int32_t> rowRec;
+  if (R < 65536) {
+    std::vector<int32_t> rows;
+    for (int32_t row = 0; row < R; ++row) {
+      if (r->ptOuter[row + 1] > r->ptOuter[row]) {
+        rows.push_back(row);
+      }
+    }
+    for (size_t t = 0; t < rows.size(); ++t) {
+      const int32_t row = rows[t], next = t + 1 < rows.size() ? rows[t + 1] : R;
+      const int32_t k0 = r->ptOuter[row], cnt = std::min(r->ptOuter[row + 1] - k0, 65535);
+      int32_t bits = 0;
+      std::memcpy(&bits, &r->ptValue[k0], 4);
+      rowRec.insert(rowRec.end(), {row | ((next - row) << 16), r->ptInner[k0] | (cnt << 16), bits, k0});
+    }
+    if (!rowRec.empty()) {
+      UP(r->dPtRowRec, rowRec);
+    }
+  }
 #undef UP
   mmx::RigDev& dv = r->dev;
+  dv.ptRowRec = rowRec.empty() ? nullptr : r->dPtRowRec.as<int4>();
+  dv.numRowRec = int32_t(rowRec.size() / 4);
   dv.ptEll = ellOk ? r->dPtEll.as<int4>() : nullptr;
   dv.jumpParent = r->dJumpParent.as<int32_t>();
   dv.jumpRounds = 0;

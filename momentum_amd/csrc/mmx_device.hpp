@@ -163,6 +163,12 @@ struct RigDev {
   // two (parameter index, value bits) pairs per joint-parameter row, index -1 = unused slot; null
   // when some row of the transform has more than two entries (then the CSR arrays are walked)
   const int4* ptEll; // [R]
+  // the NON-EMPTY rows of the transform, ascending (round 5; the one-launch solve's four-workgroup instantiations, whose LDS
+  // has no room for the CSR): record t = { row | rows until the next record's row << 16 (the last record: until R), first
+  // column | entries << 16, first value (float bits), offset of the first entry in ptInner / ptValue } -- ONE 16-byte load
+  // per thread and walk; thread t writes its row and the (empty) rows up to the next record's, thread 0 also rows 0 .. row_0 - 1
+  const int4* ptRowRec; // [numRowRec] or null (no non-empty row, or R >= 65536)
+  int32_t numRowRec;
   const int32_t* jumpParent; // [J] (parent + 1) << 16 | (parent + 1): parent and initial jump target
   int32_t jumpRounds; // ceil(log2(numLevels)): pointer-jumping rounds that finish every joint
   // per-instance characters of the same topology (mmx_problem_set_instance_rig): [B][J][4] / [B][J][3] or null

@@ -91,6 +91,8 @@ struct RigView {
   bool hasOffsets; // some entry of ptOffsets is non-zero (RigDev::ptOffsetsNonZero)
   const int32_t* levelOrder;
   const int32_t* levelStart;
+  const int4* rowRec; // RigDev::ptRowRec (null: walk the CSR)
+  int32_t numRowRec;
 };
 // I: int32_t where the tables stay in global memory or are LDS copies of the tree kernels; int16_t in the one-launch solve,
 // whose LDS budget is what decides between three and four workgroups per CU (every index of a fused problem is below 4096)
@@ -343,6 +345,30 @@ csrRowsFromFirst(const int32_t* inner, const float* value, int R, int tid, const
   }
 }
 
+// y = A x from the records of A's non-empty rows (RigDev::ptRowRec): one 16-byte load per thread, then a row's first product
+// from the record itself; the rare further entries of a row from the CSR arrays.  out(r, value) is called for EVERY row r < R
+// exactly once (the empty ones with 0) by the thread that owns the record before it -- no zero-fill pass, no barrier.
+template <int kT = 256, typename Gather, typename Store>
+__device__ __forceinline__ void csrRowsFromRecords(const int4* rec, int numRec, const int32_t* inner, const float* value, int R, int tid, Gather x, Store out) {
+  for (int t = tid; t < numRec; t += kT) {
+    const int4 q = rec[t];
+    const int row = q.x & 0xffff, span = q.x >> 16, in0 = q.y & 0xffff, cnt = q.y >> 16;
+    float acc = __int_as_float(q.z) * x(in0);
+    for (int k = q.w + 1; k < q.w + cnt; ++k) {
+      acc += value[k] * x(inner[k]);
+    }
+    out(row, acc);
+    for (int r = row + 1; r < row + span; ++r) {
+      out(r, 0.f);
+    }
+    if (t == 0) {
+      for (int r = 0; r < row; ++r) {
+        out(r, 0.f);
+      }
+    }
+  }
+}
+
 // Forward kinematics of the whole skeleton from the parameters in `th` into s.js: local transforms
 // of all joints at once (parameter_transform.cpp:110-124, joint_state.cpp:44-62), world transforms
 // by pointer jumping (skeleton_state.cpp:100-121 re-associated), optionally the rotation axes.
@@ -362,7 +388,10 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   // 110-124; the same products in the same order as a per-joint walk): 7 J independent short CSR walks
   // instead of seven dependent ones per joint.  They land in the refinement scratch (jd), which is dead
   // whenever FK runs.
-  if (kGlobalTables && csrB != nullptr) {
+  if (kGlobalTables && rig.rowRec != nullptr && csrB == nullptr) {
+    csrRowsFromRecords<kT>(
+        rig.rowRec, rig.numRowRec, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
+  } else if (kGlobalTables && csrB != nullptr) {
     csrRowsFromFirst<kT>(
         rig.ptInner, rig.ptValue, rig.R, tid, *csrB, *csrF, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
   } else if (kGlobalTables) {
@@ -1119,6 +1148,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
   rv.ptOffsets = rig.ptOffsets;
   rv.hasOffsets = rig.ptOffsetsNonZero != 0;
   rv.levelOrder = nullptr, rv.levelStart = nullptr; // (the pointer-jumping FK needs neither)
+#ifdef MMX_EXP_NOROWREC // (A/B variant: the CSR walk, two dependent L2 round trips)
+  rv.rowRec = nullptr, rv.numRowRec = 0;
+#else
+  rv.rowRec = rig.ptRowRec, rv.numRowRec = rig.numRowRec;
+#endif
   FusedViewS fv;
   fv.U = U, fv.Kp = fd.Kp;
   fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = numLoadedInst, fv.colToSolve = lColToSolve;
@@ -1814,6 +1848,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
           const CsrBounds2 b2 = csrUnpack();
           const CsrFirst2 f2 = csrRequestFirst(rig.ptInner, rig.ptValue, b2);
           csrRowsFromFirst<256>(rv.ptInner, rv.ptValue, rv.R, tid, b2, f2, xd, od);
+        } else if (rv.rowRec != nullptr) {
+          csrRowsFromRecords<256>(rv.rowRec, rv.numRowRec, rv.ptInner, rv.ptValue, rv.R, tid, xd, od);
         } else {
           csrRowsPrefetched<256>(rv.ptOuter, rv.ptInner, rv.ptValue, rv.R, tid, xd, od);
         }
@@ -2506,6 +2542,7 @@ __global__ void __launch_bounds__(64 * kWaves, kCompact ? 2 : 1) treeNormalEquat
   rv.ptOuter = rig.ptOuter, rv.ptInner = rig.ptInner, rv.ptValue = rig.ptValue, rv.ptOffsets = rig.ptOffsets;
   rv.hasOffsets = rig.ptOffsetsNonZero != 0;
   rv.levelOrder = rig.levelOrder, rv.levelStart = rig.levelStart;
+  rv.rowRec = rig.ptRowRec, rv.numRowRec = rig.numRowRec; // (the transform's non-empty rows: one load per thread and walk)
   FusedView fv;
   fv.U = U, fv.Kp = fd.Kp, fv.subSize = t.subSize, fv.dfsJoint = fd.dfsJoint, fv.loadedPos = t.loadedPos, fv.numLoaded = fd.numLoaded;
   fv.colToSolve = nullptr, fv.unitPos = pb.unitTin, fv.posUnitStart = t.posUnitStart, fv.posUnits = t.posUnits, fv.solveList = fd.solveList;

@@ -22,15 +22,13 @@ _lib: Optional[C.CDLL] = None
 
 
 _STAMP = os.path.join(_HERE, ".built_for")
-# ISA / tuning candidates of the CPU baseline.  SURVEY.md 8d asks for the host's own ISA (-march=native); with this
-# compiler (gcc 11) that is not the fastest build of the oracle on either host this has run on, and on one it is
-# disastrous -- measured, solves/s/thread, float, 72-joint humanoid:
-#   Cooper Lake (this container): -march=native 320 | native, 256-bit vectors 457 | x86-64-v3 438
-#   EPYC 9575F (the MI355X box):  -march=native 208 | -march=znver3 167 | x86-64-v3 -mtune=native 166 | x86-64-v3 746-775
-# (gcc 11 does not know Zen 5: `native` resolves to a znver tuning whose cost model wrecks the oracle's short inner
-# loops, with or without AVX-512).  So build() compiles every candidate below, times a fixed single-thread workload with
-# each, and keeps the fastest: the baseline is the best this code does on the box at hand, and cpu_baseline.sample says
-# which flags won and what the others reached.
+# ISA / tuning candidates of the CPU baseline.  SURVEY.md 8d asks for the host's own ISA (-march=native); gcc 11 does not know
+# the GPU box's Zen 5 (`native` resolves to znver3 + the AVX-512 feature flags), so build() compiles every candidate below,
+# times a fixed single-thread solve workload with each (_selftime) and keeps the fastest: the baseline is the best this code
+# does on the box at hand, and cpu_baseline's details say which flags won and what the others reached.  Since round 5 the
+# dense kernels are written with explicit vector types (mmx_oracle.hpp syrkLower), so the candidates differ by < 15 % on a
+# converging solve (EPYC 9575F: 1155 ... 1321 solves/s/thread; profiles/r05_cpu_baseline.txt has the per-phase split and
+# why rounds 3-4 saw a 4-5 x spread).
 _CANDIDATES = [
     "-march=native",
     "-march=native -mtune=generic",
@@ -66,17 +64,21 @@ def build_info() -> str:
 
 
 def _selftime() -> float:
-    """Seconds for a fixed single-thread workload (32 x 72-joint solves, 10 iterations, float) with the library on disk;
-    run in a fresh interpreter so that every candidate is loaded from scratch."""
+    """Seconds for a fixed single-thread workload with the library on disk: 32 solves of BASELINE configs[1]'s shape (72-joint
+    humanoid, position + orientation on the 16 landmarks, targets = FK(theta*) like bench.py's batches, 10 iterations, float);
+    run in a fresh interpreter so that every candidate is loaded from scratch.  (Until round 5 the workload had random,
+    unreachable targets: its undamped iterations ran into Inf / NaN, and how slow THAT arithmetic is differs several-fold
+    between the ISA candidates -- 312 against 1219 solves/s on the GPU box's EPYC 9575F -- while on a converging solve the same
+    candidates are within 15 % of each other: the sweep picked by the pathology, profiles/r05_cpu_baseline.txt.)"""
     import sys
 
     code = (
         "import sys,time;sys.path.insert(0,%r);import numpy as np;"
         "from oracle import oracle as o;o._lib=__import__('ctypes').CDLL(o._LIB_PATH);"
         "from momentum_amd import humanoid72_landmark_joints as lj, make_humanoid72 as mk;from momentum_amd._abi import GnOptions as G;"
-        "r=mk(seed=12345,variant='p128',unit=0.01);l=lj(r);rng=np.random.default_rng(0);B=32;"
-        "z=np.zeros;c=o.Constraints(l,z((B,16,3)),rng.uniform(-1,1,(B,16,3)),np.ones((B,16)),l,np.tile([0,0,0,1.],(B,16,1)),np.tile([0,0,0,1.],(B,16,1)),np.ones((B,16)));"
-        "op=G.make(10,10);th=z((B,r.num_params),np.float32);o.solve_batch(r,c,th[:4],op,dtype='f32');"
+        "from tests.helpers import make_problem as mp;"
+        "r=mk(seed=12345,variant='p128',unit=0.01);l=lj(r);B=32;c,th,_=mp(r,l,l,B,seed=1,perturb=0.3);"
+        "op=G.make(10,10);o.solve_batch(r,c,th[:4],op,dtype='f32');"
         "t=time.perf_counter();o.solve_batch(r,c,th,op,dtype='f32');print(time.perf_counter()-t)"
     ) % os.path.dirname(_HERE)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip().split("\n")[-1]
