@@ -74,6 +74,12 @@ print("\n".join(rows))
 PY
 cat $out/pytest_gpu.txt; head -8 $out/${r}_bench_kernel_stats.txt | cut -c1-140; head -8 $out/${r}_cfg5_kernel_stats.txt | cut -c1-140
 cp $GRAFT_REPO_ROOT/gpurun_out/bench_details.json $out/${r}_bench_details.json 2> /dev/null
+cd $GRAFT_REPO_ROOT
+timeout 600 python scripts/diag_auto_table.py 1024 < /dev/null 2>&1 | grep -v amdgpu.ids > $out/auto_table.txt
+timeout 300 python scripts/diag_precision.py lm 65536 16384 < /dev/null 2>&1 | grep -v amdgpu.ids | tail -2 > $out/lm_steps.txt
+timeout 300 python bench.py --config cfg4 --steps 6 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 256 < /dev/null > $out/${r}_bench_cfg4.json 2> /dev/null
+timeout 200 python scripts/diag_determinism.py 6 < /dev/null 2>&1 | grep -v amdgpu.ids > $out/determinism.txt
+bash scripts/resource_usage.sh > $out/${r}_kernel_resource_usage.txt 2>&1
 python - $out/${r}_bench_default.json < /dev/null <<'PY'
 import json,sys
 raw=open(sys.argv[1]).read()
