@@ -474,7 +474,10 @@ class Problem:
         regularisation on the diagonal (:249 adds it in place before the factorisation; the strict upper triangle is
         never written and stays zero).  Entries from an element's iteration count on are zero (the reference leaves them
         unset).  Rebuilt with mmx_eval_normal_equations, one launch per iteration, instead of being stored by the solve:
-        n^2 floats per element and iteration ([B, K, n, n]; `out` to bring the storage)."""
+        n^2 floats per element and iteration ([B, K, n, n]; `out` to bring the storage).  The rebuilt system comes from the
+        explicit Jacobian with the single-precision pointer-jumping forward kinematics of mmx_eval_normal_equations; the solve
+        kernels carry the jump rounds' partial products in double, so an entry can differ from the system the solve
+        actually factored by a few ulp -- the tolerance of tests/test_gpu_edge_cases.py, not bit-exact."""
         import torch
 
         theta_init = self._theta(theta_init)

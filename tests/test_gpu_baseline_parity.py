@@ -44,6 +44,11 @@ def test_baseline_workloads_within_1e5_of_the_oracle(torch_cuda, orc, config, B,
     assert chk["max_rel_theta_vs_oracle_f64"] <= BOUND, chk
 
 
+# the overshooting Gauss-Newton runs among the 3 x 4096 starts (scripts/diag_cfg5_ids.py, round 5: 1715 at 3.9e-4 / 3557 at 4.2e-5
+# where the float oracle is 0.34 / 0.018 off; 325 sits at 0.9 ... 1.35e-5 depending on the compiler's contraction choices)
+CFG5_OVERSHOOTING_RUNS = {20240611: {325, 1715, 3557}, 424242: set(), 7: set()}
+
+
 @pytest.mark.parametrize("seed", [20240611, 424242, 7])
 def test_config5_every_instance_within_1e5(torch_cuda, orc, seed):
     """BASELINE configs[4] (300-joint rig, wide J: tree normal equations, tile-sparse factor, tree refinement): every one of
@@ -59,6 +64,9 @@ def test_config5_every_instance_within_1e5(torch_cuda, orc, seed):
     times above the bound AND further from the double answer than the GPU is, and there may be at most one in a thousand."""
     chk, _, _ = _solve_and_check(torch_cuda, "cfg5", 4096, 4096, seed=seed)
     assert chk["instances"] == 4096 and chk["distinct"]
+    # the instances the rule below may exempt are PINNED per seed (the overshooting runs found in rounds 3-4): a new outlier
+    # fails even if it satisfied the rule
+    assert set(chk.get("above_bound_instances", [])) <= CFG5_OVERSHOOTING_RUNS[seed], (seed, chk.get("above_bound_instances"), chk.get("above_bound_rel"))
     if chk["num_above_bound"]:
         assert chk["num_above_bound"] <= 4 and chk["above_bound_float_oracle_also_above"], chk
         assert min(chk["above_bound_float_oracle_rel"]) >= 50 * BOUND and chk["above_bound_closer_than_float_oracle"], chk
