@@ -454,6 +454,18 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
 
 constexpr int kGenEv = 29; // words per constraint record (odd stride)
 
+// Which instantiations of the one-launch solve are set up for FOUR workgroups per CU (128 registers, the transform's CSR walked
+// from global memory, the register-lean forms of the triangular solves / tile products): the per-rule ones up to six blocks.
+// MMX_EXP_GEN4 (A/B variant): the generic rule (line searches, parameter-space rows) as well.
+template <int NB, bool kTR, bool kGen, int kRule>
+struct FusedFour {
+#ifdef MMX_EXP_GEN4
+  static constexpr bool value = NB <= 6 && !kGen && !kTR;
+#else
+  static constexpr bool value = NB <= 6 && !kGen && kRule >= 0 && !kTR;
+#endif
+};
+
 // Sizes of the one-launch solve's lifetime-shared LDS areas (fusedSolveKernel's carve and fusedLdsBytes agree through this)
 struct FusedLayout {
   size_t uyFloats; // uy (C-D) | slots' gradient shares (E-F) | partial cells (G) | rho, invDiag (end of G .. K)
@@ -837,9 +849,16 @@ __device__ __forceinline__ void solveLLtRight(const float* L, const float* invDi
   __syncthreads();
 }
 
-template <int NB>
+// kLeft: the left-looking form also for the small systems -- the instantiations that run four workgroups per CU at 128 registers
+// (round 5: the right-looking form's 2 NB partial sums are what the allocator spills there; 1.73 -> 1.80e6 solves/s on BASELINE
+// configs[1], profiles/r05_exp_fused.txt; at three workgroups per CU and 168 registers the right-looking form stays ahead)
+template <int NB, bool kLeft = false>
 __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, float* x, int tid) {
-  if (NB <= 8) {
+#ifdef MMX_EXP_LEFTALL // (A/B variant: the left-looking form everywhere)
+  if (false) {
+#else
+  if (NB <= 8 && !kLeft) {
+#endif
     solveLLtRight<NB>(L, invDiag, x, tid);
   } else {
     solveLLtLeft<NB>(L, invDiag, x, tid);
@@ -938,7 +957,7 @@ template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
 #ifdef MMX_EXP_OCC3
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
 #else
-__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
+__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, kGen, kRule>::value ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
 #endif
 #ifdef MMX_EXP_ARGPTR
     const FusedArgs* __restrict__ argsDev,
@@ -958,7 +977,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
   constexpr int NP = 16 * NB; // padded system size
   // lookahead: the left-looking updates of block column k + 1 by the columns before k ride under panel k's elimination
   // chain (waves without a panel row); NB <= 8: wave 3 never holds one (round 3, measured on one box: +2.2 % on cfg2)
+#ifdef MMX_EXP_NOLOOK // (A/B variant: no lookahead in the instantiations that run four workgroups per CU)
+  constexpr bool kLook = NB <= 8 && !FusedFour<NB, kTR, kGen, kRule>::value;
+#else
   constexpr bool kLook = NB <= 8;
+#endif
   long long clkLast = 0;
 #define MMX_CLK(slot)                                             \
   if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) {         \
@@ -998,7 +1021,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
   float *srcGu, *cells, *arena, *lPtValue = nullptr;
   // the instantiations whose register budget is set for four workgroups per CU read the transform's CSR from global memory
   // (their LDS has no room for it); the others keep their LDS copy
-  constexpr bool kFour = NB <= 6 && !kGen && kRule >= 0 && !kTR;
+  constexpr bool kFour = FusedFour<NB, kTR, kGen, kRule>::value;
   constexpr bool kCsrLds = !kFour;
   const int kNnz = fd.nnz;
   const FusedLayout lay = fusedLayout(NB, J, P, U, nsrc, n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR);
@@ -1230,7 +1253,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
     // hides behind it (one round trip per iteration instead of two) -- except in the instantiations that run four
     // workgroups per CU at 128 registers: eleven registers across FK cost them more than the round trip (an L2 hit from the
     // second iteration on): 1.716 -> 1.726e6 solves/s on BASELINE configs[1], profiles/r05_exp_fused.txt
-    constexpr bool kLateUnit = NB <= 6 && !kGen && kRule >= 0 && !kTR;
+    constexpr bool kLateUnit = kFour;
     const UnitInput uin0 = kLateUnit ? UnitInput{} : loadUnitInput(pb, b, tid < U ? tid : U);
     // TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270) wraps what follows
     // in up to ten trial steps (:157); every other step rule passes through once.
@@ -1315,8 +1338,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
     ownSums(fv, s, s.umom, U, tid);
     __syncthreads();
     MMX_CLK(15)
-    treeSum<kC1, true>(fv, s.own1, s.sub1, J, wave, lane);
-    treeSum<kC2Used, true, kC2>(fv, s.own2, s.sub2, J, wave, lane);
+#ifdef MMX_EXP_TUN2 // (A/B variant: two k-steps per trip of the tree sums at four workgroups per CU)
+    constexpr int kUnD = kFour ? 2 : kFusedTreeUn;
+#elif defined(MMX_EXP_TUN1)
+    constexpr int kUnD = kFour ? 1 : kFusedTreeUn;
+#else
+    constexpr int kUnD = kFusedTreeUn;
+#endif
+    treeSum<kC1, true, kC1, kUnD>(fv, s.own1, s.sub1, J, wave, lane);
+    treeSum<kC2Used, true, kC2, kUnD>(fv, s.own2, s.sub2, J, wave, lane);
     __syncthreads();
     MMX_CLK(3)
     // ================= E: per-slot tables (weight folded in), channel-major
@@ -1446,7 +1476,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
         Jc += 4;
         normalise();
         const bool more = t + 4 < T; // wave-uniform
-        TileOps nxt = loadOps(more ? I : tI, more ? Jc : tJ); // the next tile's LDS reads fly while this one multiplies
+        // the next tile's LDS reads fly while this one multiplies -- except at four workgroups per CU, where the thirteen registers
+        // of a second operand set cost more than the reads' latency (other workgroups fill it): + 0.4 % (r05_exp_fused.txt)
+        TileOps nxt;
+        if (!kFour) {
+          nxt = loadOps(more ? I : tI, more ? Jc : tJ);
+        }
         const float z = gq == 3 ? 0.f : 1.f;
         v4f P{0.f, 0.f, 0.f, 0.f}, Q{0.f, 0.f, 0.f, 0.f};
         P = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dI0, cur.aJ0, P, 0, 0, 0); // P[r][c] = D_r . A_c : row slot deep
@@ -1462,6 +1497,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
           const bool colDeep = tinR <= tinC && tinC < toutR;
           Tc[tileAddr(4 * gq + q, i)] = rowDeep ? P[q] : (colDeep ? Q[q] : 0.f);
         }
+        if (kFour) {
+          nxt = loadOps(more ? I : tI, more ? Jc : tJ);
+        }
         cur = nxt;
       }
     }
@@ -1469,10 +1507,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
     MMX_CLK(12)
     if (fd.termRounds > 0) {
       float h = 0.f;
-      for (int k0 = 0; k0 < fd.termRounds; k0 += 8) {
-        uint2 rec[8];
+#ifdef MMX_EXP_REC4 // (A/B variant: four records per trip at four workgroups per CU -- eight registers less)
+      constexpr int kRecTrip = kFour ? 4 : 8;
+#else
+      constexpr int kRecTrip = 8;
+#endif
+      for (int k0 = 0; k0 < fd.termRounds; k0 += kRecTrip) {
+        uint2 rec[kRecTrip];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < kRecTrip; ++k) {
           const uint4* rp = fd.gTerms + (k0 + k) * 256 + tid;
           rec[k] = *reinterpret_cast<const uint2*>(rp); // x: deep | anc << 12 | flags ; y: destination
         }
@@ -1481,7 +1524,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
           MMX_CLK(21)
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < kRecTrip; ++k) {
           const uint32_t x = rec[k].x;
           if (x & (1u << 26)) {
             const int deep = x & 0xfff, anc = (x >> 12) & 0xfff;
@@ -1626,7 +1669,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
         for (int j = j0; j < j1; ++j) {
           const float4 av = ldsRow4(s.L + 256 * tileIndex(I, j), lane & 15, lane >> 4);
           const float4 bv = ldsRow4(s.L + 256 * tileIndex(kc, j), lane & 15, lane >> 4);
-          if (j & 1) {
+          if ((j & 1) && !kFour) { // (one accumulator at four workgroups per CU: four registers less, + 1.5 %; r05_exp_fused.txt)
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c1, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c1, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c1, 0, 0, 0);
@@ -1814,7 +1857,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
       csrJd = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
     }
     if (!notPd) {
-      solveLLt<NB>(s.L, s.invDiag, s.d0, tid);
+      solveLLt<NB, kFour>(s.L, s.invDiag, s.d0, tid);
     }
     MMX_CLK(8)
     // ================= J: one refinement step through the tree (tangent + adjoint passes)
@@ -2026,7 +2069,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
       }
       __syncthreads();
       MMX_CLK(19)
-      solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
+      solveLLt<NB, kFour>(s.L, s.invDiag, s.rho, tid);
       MMX_CLK(20)
       float c2 = 0.f, d2 = 0.f;
       for (int c = tid; c < n; c += 256) {
@@ -2095,7 +2138,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (kRule >= 0 && !kTR ?
         s.rho[c] = c < n ? s.d0[c] : 0.f;
       }
       __syncthreads();
-      solveLLt<NB>(s.L, s.invDiag, s.rho, tid);
+      solveLLt<NB, kFour>(s.L, s.invDiag, s.rho, tid);
       float pq = 0.f;
       for (int c = tid; c < n; c += 256) {
         pq += s.d0[c] * s.rho[c];
@@ -3280,7 +3323,7 @@ static hipError_t launchFusedMode(
     float* dbgG,
     long long* dbgClk,
     hipStream_t stream) {
-  constexpr bool kFourL = NB <= 6 && !kGen && kRule >= 0 && !kTR; // (fusedSolveKernel's kFour)
+  constexpr bool kFourL = FusedFour<NB, kTR, kGen, kRule>::value; // (fusedSolveKernel's kFour)
   const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR, kFourL ? 0 : fusedCsrFloats(rig.J, fd.nnz));
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
