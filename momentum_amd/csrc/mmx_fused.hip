@@ -455,14 +455,14 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
 constexpr int kGenEv = 29; // words per constraint record (odd stride)
 
 // Which instantiations of the one-launch solve are set up for FOUR workgroups per CU (128 registers, the transform's CSR walked
-// from global memory, the register-lean forms of the triangular solves / tile products): the per-rule ones up to six blocks.
-// MMX_EXP_GEN4 (A/B variant): the generic rule (line searches, parameter-space rows) as well.
+// from global memory, the register-lean forms of the triangular solves / tile products): up to six blocks, reference rows, no
+// trust region -- the per-rule ones and the generic rule (line searches).  MMX_EXP_GEN3 (A/B variant): the generic rule at three.
 template <int NB, bool kTR, bool kGen, int kRule>
 struct FusedFour {
-#ifdef MMX_EXP_GEN4
-  static constexpr bool value = NB <= 6 && !kGen && !kTR;
-#else
+#ifdef MMX_EXP_GEN3
   static constexpr bool value = NB <= 6 && !kGen && kRule >= 0 && !kTR;
+#else
+  static constexpr bool value = NB <= 6 && !kGen && !kTR;
 #endif
 };
 
