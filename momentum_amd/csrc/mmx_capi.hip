@@ -225,6 +225,7 @@ struct mmx_problem {
   DevBuf dF64Groups, dF64Extra, dF64ChunkStart;
   int32_t f64ListUnitsPerChunk = 0; // 0: not built
   DevBuf sDone, sIters, sStatus, sLastErr, sFinalErr, sHist, sClk, sDelta, sStepIter, sLambda, sTrust;
+  DevBuf sFusedArgs; // the one-launch solve's descriptors, stashed per solve (mmx_fused.hip, kArgLazy)
   DevBuf sDiag; // [B][4] diagnostics of the last single-precision solve (mmx_problem_solve_diagnostics)
   DevBuf sDiagAcc; // [B][4] the wide route's accumulators behind it (mmx::StepParams::diagAcc)
   bool diagValid = false;
@@ -2286,7 +2287,8 @@ static int32_t solveF32Impl(
     }
     {
       MMX_ZONE("fused solve: all iterations of GaussNewtonSolverT::doIteration in one launch");
-      MMX_HIP(mmx::launchFusedSolve(pb->rigDev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, s));
+      MMX_HIP(pb->sFusedArgs.ensure(mmx::fusedArgsBytes()));
+      MMX_HIP(mmx::launchFusedSolve(pb->rigDev, pb->dev, pb->fdev, theta_dev, fst, fp, nullptr, nullptr, clk, pb->sFusedArgs.p, s));
     }
     if (clk != nullptr) {
       long long h[32];
@@ -2705,7 +2707,7 @@ int32_t mmx_debug_fused_normal_equations(
   fp.minIterations = 1;
   fp.maxIterations = 1;
   fp.refine = 0;
-  MMX_HIP(mmx::launchFusedSolve(pb->rigDev, pb->dev, pb->fdev, pb->sTheta.as<float>(), fst, fp, jtj_dev, jtr_dev, nullptr, s));
+  MMX_HIP(mmx::launchFusedSolve(pb->rigDev, pb->dev, pb->fdev, pb->sTheta.as<float>(), fst, fp, jtj_dev, jtr_dev, nullptr, nullptr, s));
   return MMX_OK;
 }
 

@@ -932,10 +932,15 @@ __device__ __forceinline__ int buildInstanceUnitTables(
 // instead of 36 spilled vector registers, 352 / 380 instead of 456 spilled scalar registers).  (2 = a line search only:
 // compiles, but spills MORE than the generic instantiation -- 68 vector registers -- and is not instantiated.)
 // Round 3, one box: plain Gauss-Newton +2.1 %, LM schedule +2.5 % over the generic instantiation; parity unchanged.
-// Experiment (MMX_BUILD_VARIANT=argptr; round-3 verdict item 2a): the five descriptor structs in ONE device-resident struct
-// behind a single pointer, every field an s_load at its use, instead of ~200 SGPRs of kernel arguments that the register
-// allocator keeps in VGPR lanes (384 spilled SGPRs: v_writelane / v_readlane + s_nop).  Shared rig and weights only (the
-// per-element selections write into the by-value copies).  Measured: profiles/r04_exp_argptr.txt.
+// kArgLazy: the five descriptor structs in ONE device-resident struct behind a single pointer (the problem's, written by
+// stashFusedArgsKernel in stream order before the solve), every field an s_load where it is used, instead of ~200 SGPRs of
+// by-value arguments loaded at the entry and kept in VGPR lanes across the whole kernel (444 spilled SGPRs: v_writelane /
+// v_readlane).  At 168 registers the form lost 2 % (round 4: profiles/r04_exp_argptr.txt); at 128 it frees vector registers:
+// spilled VGPRs 75 -> 36 (LM schedule), 129 -> 94 (generic rule), and the line-search line gains 4 %, the LM one 1 %, plain
+// Gauss-Newton nothing (profiles/r05_exp_fused.txt).  (Reading them through the kernel-argument segment's own pointer instead
+// was tried: the compiler knows that segment dereferenceable and hoists the loads back to the entry -- 50 / 67 / 104 spilled.)
+// The four-workgroup production instantiations take it for problems with a shared rig and shared weights (the per-element
+// selections write into the by-value copies: those problems keep the by-value form).
 struct FusedArgs {
   RigDev rig;
   ProblemDev pb;
@@ -943,12 +948,10 @@ struct FusedArgs {
   SolveStateDev st;
   FusedParams fp;
 };
-#ifdef MMX_EXP_ARGPTR
 static __global__ void stashFusedArgsKernel(FusedArgs a, FusedArgs* dst) {
   *dst = a;
 }
-#endif
-template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1>
+template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1, bool kArgLazy = false>
 // Workgroups per CU the register budget is set for (the LDS footprint decides what actually runs): FOUR for the per-rule
 // instantiations up to six blocks (round 5: the lifetime-shared carve brings BASELINE configs[1] to 40.2 KB; 128 VGPRs cost
 // a workgroup 4.6 % of its latency -- measured with the LDS still at 52 KB, profiles/r05_exp_fused.txt -- and buy a third
@@ -959,17 +962,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1)
 #else
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, kGen, kRule>::value ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
 #endif
-#ifdef MMX_EXP_ARGPTR
-    const FusedArgs* __restrict__ argsDev,
+    const FusedArgs* __restrict__ argsDev, // kArgLazy: the descriptors (the by-value ones are not read); else unused
+    RigDev rigV,
+    ProblemDev pbV,
+    FusedDev fdV,
     float* __restrict__ theta, // [B][P] in/out
-#else
-    RigDev rig,
-    ProblemDev pb,
-    FusedDev fd,
-    float* __restrict__ theta, // [B][P] in/out
-    SolveStateDev st,
-    FusedParams fp,
-#endif
+    SolveStateDev stV,
+    FusedParams fpV,
     float* __restrict__ dbgH, // [B][n*n] or null: H = J^T J (no lambda) of the FIRST iteration
     float* __restrict__ dbgG, // [B][n] or null
     long long* __restrict__ dbgClk) { // [32] or null: per-phase cycle counts of block 0 (profiling aid)
@@ -992,16 +991,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-#ifdef MMX_EXP_ARGPTR
-#define rig (argsDev->rig)
-#define pb (argsDev->pb)
-#define fd (argsDev->fd)
-#define st (argsDev->st)
-#define fp (argsDev->fp)
-#else
-  selectInstanceRig(rig, b);
-  selectInstanceWeights(pb, b);
-#endif
+  if (!kArgLazy) { // (the element's selections go into the by-value copies)
+    selectInstanceRig(rigV, b);
+    selectInstanceWeights(pbV, b);
+  }
+  const RigDev& rig = kArgLazy ? argsDev->rig : rigV;
+  const ProblemDev& pb = kArgLazy ? argsDev->pb : pbV;
+  const FusedDev& fd = kArgLazy ? argsDev->fd : fdV;
+  const SolveStateDev& st = kArgLazy ? argsDev->st : stV;
+  const FusedParams& fp = kArgLazy ? argsDev->fp : fpV;
   const int J = rig.J, P = rig.P, U = fd.U, n = fd.n, nsrc = fd.nsrc;
   const int kR = rig.R;
 
@@ -2365,13 +2363,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     st.status[b] = stt;
   }
 #endif
-#ifdef MMX_EXP_ARGPTR
-#undef rig
-#undef pb
-#undef fd
-#undef st
-#undef fp
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3322,32 +3313,37 @@ static hipError_t launchFusedMode(
     float* dbgH,
     float* dbgG,
     long long* dbgClk,
+    void* argsBuf,
     hipStream_t stream) {
   constexpr bool kFourL = FusedFour<NB, kTR, kGen, kRule>::value; // (fusedSolveKernel's kFour)
   const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR, kFourL ? 0 : fusedCsrFloats(rig.J, fd.nnz));
   if (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   }
-  static LdsLimitCache ldsLimit; // (one per instantiation)
-  {
-    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen, kRule>), lds);
-    if (rc != hipSuccess) {
-      return rc;
-    }
-  }
-#ifdef MMX_EXP_ARGPTR
-  static FusedArgs* argsDev = nullptr; // (experiment: one problem at a time)
-  if (argsDev == nullptr) {
-    hipError_t rc = hipMalloc(&argsDev, sizeof(FusedArgs));
-    if (rc != hipSuccess) {
-      return rc;
-    }
-  }
-  hipLaunchKernelGGL(stashFusedArgsKernel, dim3(1), dim3(1), 0, stream, FusedArgs{rig, pb, fd, st, fp}, argsDev);
-  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule>), dim3(pb.B), dim3(256), lds, stream, argsDev, theta, dbgH, dbgG, dbgClk);
+  // the lazy-argument form (kArgLazy): four-workgroup production instantiations, shared rig and weights, a buffer to stash into
+#ifdef MMX_EXP_ARGVALUE // (A/B variant: by-value arguments everywhere)
+  constexpr bool kLazyBuilt = false;
 #else
-  hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule>), dim3(pb.B), dim3(256), lds, stream, rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+  constexpr bool kLazyBuilt = kFourL && MODE == 0;
 #endif
+  const bool lazy = kLazyBuilt && argsBuf != nullptr && rig.instPreRot == nullptr && rig.instOffset == nullptr && pb.fnWeights == nullptr;
+  if (lazy) {
+    static LdsLimitCache ldsLimit; // (one per instantiation)
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen, kRule, kLazyBuilt>), lds);
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    FusedArgs* dst = static_cast<FusedArgs*>(argsBuf);
+    hipLaunchKernelGGL(stashFusedArgsKernel, dim3(1), dim3(1), 0, stream, FusedArgs{rig, pb, fd, st, fp}, dst);
+    hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule, kLazyBuilt>), dim3(pb.B), dim3(256), lds, stream, dst, RigDev{}, ProblemDev{}, FusedDev{}, theta, SolveStateDev{}, FusedParams{}, dbgH, dbgG, dbgClk);
+  } else {
+    static LdsLimitCache ldsLimit;
+    hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen, kRule, false>), lds);
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule, false>), dim3(pb.B), dim3(256), lds, stream, static_cast<const FusedArgs*>(nullptr), rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+  }
   return hipGetLastError();
 }
 
@@ -3362,34 +3358,35 @@ static hipError_t launchFusedNB(
     float* dbgH,
     float* dbgG,
     long long* dbgClk,
+    void* argsBuf,
     hipStream_t stream) {
   if (fd.GT > 0) { // further joint error functions / ellipsoid limits: the production and the parity-dump instantiations only
     if (fp.stepRule == 2) {
       return hipErrorInvalidValue;
     }
     if (dbgH != nullptr || dbgG != nullptr) {
-      return launchFusedMode<NB, 1, false, true>(rig, pb, fd, theta, st, fp, dbgH, dbgG, nullptr, stream);
+      return launchFusedMode<NB, 1, false, true>(rig, pb, fd, theta, st, fp, dbgH, dbgG, nullptr, argsBuf, stream);
     }
-    return launchFusedMode<NB, 0, false, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+    return launchFusedMode<NB, 0, false, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, argsBuf, stream);
   }
   if (fp.stepRule == 2) { // MMX_STEP_TRUST_REGION: its own instantiation (no clocks / parity dump in it)
-    return launchFusedMode<NB, 0, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+    return launchFusedMode<NB, 0, true>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, argsBuf, stream);
   }
   if (dbgClk != nullptr) {
-    return launchFusedMode<NB, 2, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+    return launchFusedMode<NB, 2, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, argsBuf, stream);
   }
   if (dbgH != nullptr || dbgG != nullptr) {
-    return launchFusedMode<NB, 1, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+    return launchFusedMode<NB, 1, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, argsBuf, stream);
   }
   if (pb.M == pb.rowsJoint) { // no parameter-space rows: the instantiations per step rule (kRule)
     if (fp.stepRule == 0 && fp.doLineSearch == 0) {
-      return launchFusedMode<NB, 0, false, false, 0>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+      return launchFusedMode<NB, 0, false, false, 0>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, argsBuf, stream);
     }
     if (fp.stepRule == 1) {
-      return launchFusedMode<NB, 0, false, false, 1>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, stream);
+      return launchFusedMode<NB, 0, false, false, 1>(rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, argsBuf, stream);
     }
   }
-  return launchFusedMode<NB, 0, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream);
+  return launchFusedMode<NB, 0, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, argsBuf, stream);
 }
 
 // The instantiations are split over four translation units (build.py compiles this file once per
@@ -3400,8 +3397,8 @@ static hipError_t launchFusedNB(
 
 #define MMX_FUSED_ARGS \
   const RigDev &rig, const ProblemDev &pb, const FusedDev &fd, float *theta, const SolveStateDev &st, const FusedParams &fp, \
-      float *dbgH, float *dbgG, long long *dbgClk, hipStream_t stream
-#define MMX_FUSED_PASS rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, stream
+      float *dbgH, float *dbgG, long long *dbgClk, void *argsBuf, hipStream_t stream
+#define MMX_FUSED_PASS rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, argsBuf, stream
 
 hipError_t launchFusedGroup0(int nb, MMX_FUSED_ARGS);
 hipError_t launchFusedGroup1(int nb, MMX_FUSED_ARGS);
@@ -3449,6 +3446,10 @@ int fusedBlocksFor(int n) {
     }
   }
   return -1;
+}
+
+size_t fusedArgsBytes() {
+  return sizeof(FusedArgs);
 }
 
 hipError_t launchFusedSolve(MMX_FUSED_ARGS) {

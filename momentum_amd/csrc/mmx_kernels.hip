@@ -1860,19 +1860,20 @@ __device__ __forceinline__ void tiledFactor(
 // Panel factorisation of block column k whose nt tiles sit contiguously in `pan` (LDS; mmx_fused.hip phase H): lanes 0-15 of
 // every wave the diagonal block, redundantly; lanes 16-63 forty-eight rows below it; pivots by v_readlane.  Wave 0 also
 // finishes y_k (L_kk y_k = s_k with the rows still in registers).  floorRow: the pivot floor of row 16 k + (lane & 15)
-// (kPivotFloor x the original diagonal).  Ends with the panel complete and a barrier.  256 threads.
+// (kPivotFloor x the original diagonal).  Ends with the panel complete and a barrier.  256 threads -- or more: the waves
+// beyond the fourth only take part in the barriers (the rows' assignment, and with it every bit of the result, stays).
 __device__ __forceinline__ void tiledPanelFactor(float* pan, int nt, int k, float* g, float* invDiag, int* flags, float floorRow, int tid) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15;
   float* Dk = pan;
   const bool diagLane = lane < 16;
   const int prow = 16 + 48 * wave + (lane - 16);
-  const bool active = diagLane || prow < 16 * nt;
+  const bool active = wave < 4 && (diagLane || prow < 16 * nt);
   float* Tl = diagLane ? Dk : pan + 256 * ((active ? prow : 0) >> 4);
   const int trow = diagLane ? lane : (prow & 15);
   // a wave whose forty-eight rows all lie beyond the panel only takes part in the barriers: its copy of the chain would
   // compete for the issue slots of its SIMD with the co-resident workgroup's wave (wave-uniform branch)
-  const bool waveWorks = wave == 0 || 16 + 48 * wave < 16 * nt;
+  const bool waveWorks = wave == 0 || (wave < 4 && 16 + 48 * wave < 16 * nt);
   float a[16] = {};
   float bi = 0.f;
   if (waveWorks) {
@@ -1927,7 +1928,7 @@ __device__ __forceinline__ void tiledPanelFactor(float* pan, int nt, int k, floa
   }
   __syncthreads();
   if (16 * nt > 16 + 192) { // rows beyond 4 x 48: substitution against the finished diagonal block
-    for (int pr = 16 + 192 + tid; pr < 16 * nt; pr += 256) {
+    for (int pr = 16 + 192 + tid; pr < (tid < 256 ? 16 * nt : 0); pr += 256) {
       float* Tr = pan + 256 * (pr >> 4);
       float x[16];
 #pragma unroll
@@ -2729,7 +2730,8 @@ constexpr int kResidentLoads = 20; // 16-byte requests a lane of the resident ke
 // Substitutions on a factor whose structurally non-zero tiles are resident in LDS (column-compact slots, swizzled tiles:
 // choleskyFactorResidentKernel).  maskWords: the 96 words of StepParams::tileMasks in LDS (per-lane lookups), vRowMask /
 // vColMask / vColBase: the same words in the lanes of registers (uniform lookups by v_readlane).  invDiag: 1 / l_jj per
-// row (LDS) or null: taken from the diagonal tiles.  x: LDS, in place.  256 threads.
+// row (LDS) or null: taken from the diagonal tiles.  x: LDS, in place.  kW waves.
+template <int kW = 4>
 __device__ __forceinline__ void residentSweepBackward(
     const float* tiles, const uint32_t* maskWords, uint32_t vRowMask, uint32_t vColBase, int NB, float* x, const float* invDiag, int tid) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 15;
@@ -2763,7 +2765,7 @@ __device__ __forceinline__ void residentSweepBackward(
     const uint32_t present = uint32_t(__builtin_amdgcn_readlane(int(vRowMask), k)) & below(k); // row block k's tiles left of the diagonal
     // x[c] -= sum_r L(16k + r, c) x_k[r] for the columns c < 16 k whose tile (k, c >> 4) exists: a thread per column
     if (present != 0u) {
-      for (int c = tid; c < 16 * k; c += 256) {
+      for (int c = tid; c < 16 * k; c += 64 * kW) {
         const int jb = c >> 4;
         if ((present >> jb & 1u) == 0u) {
           continue;
@@ -2790,7 +2792,11 @@ __device__ __forceinline__ void residentSweepBackward(
 // factor in HBM without anybody waiting for it (the finish stage and the trust region read it there), and the backward
 // substitution of the first solve runs on the resident tiles.  The block columns are taken a LEVEL of the elimination tree
 // at a time (TileMasks::levelSteps: independent columns side by side, each panel on its own waves).
-__global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
+//   kW waves per workgroup: 4, or 8 (MMX_EXP_FACT8 decides in the launcher): the matrix comes in, the left-looking updates are
+// dealt, the sweep's columns and the factor's stores are spread over eight waves; the panels' rows and the damping's trace stay
+// on the first four (same sums in the same order: bit-identical results).
+template <int kW>
+__global__ void __launch_bounds__(64 * kW, kW == 8 ? 4 : 2) choleskyFactorResidentKernel(
     ProblemDev pb,
     int P,
     const float* __restrict__ jtj,
@@ -2837,23 +2843,24 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   if (tid < 96) {
     maskWords[tid] = sp.tileMasks[tid];
   }
-  for (int i = tid; i < NP; i += 256) {
+  for (int i = tid; i < NP; i += 64 * kW) {
     g[i] = i < n ? jtr[size_t(b) * n + i] : 0.f;
   }
   long long tclk = clock64();
   // ---- H into the slots: the wave's tiles (every fourth slot), ALL its requests in flight together -- one HBM round trip
   // for the whole matrix (4 x kResidentLoads >= the tiles that fit the kernel's LDS budget)
-  for (int s0 = 0; s0 < numTiles; s0 += 4 * kResidentLoads) {
-    float4 hv[kResidentLoads];
+  constexpr int kLoads = 4 * kResidentLoads / kW;
+  for (int s0 = 0; s0 < numTiles; s0 += kW * kLoads) {
+    float4 hv[kLoads];
 #pragma unroll
-    for (int u = 0; u < kResidentLoads; ++u) {
-      const int sl = min(s0 + 4 * u + wave, numTiles - 1); // (clamped: unconditional, independent requests)
+    for (int u = 0; u < kLoads; ++u) {
+      const int sl = min(s0 + kW * u + wave, numTiles - 1); // (clamped: unconditional, independent requests)
       const int code = int(sp.tileMasks[96 + sl]); // I | k << 8 (uniform)
       hv[u] = *reinterpret_cast<const float4*>(H + size_t(tileIndex(code & 0xff, code >> 8)) * 256 + opOff);
     }
 #pragma unroll
-    for (int u = 0; u < kResidentLoads; ++u) {
-      const int sl = s0 + 4 * u + wave;
+    for (int u = 0; u < kLoads; ++u) {
+      const int sl = s0 + kW * u + wave;
       if (sl < numTiles) {
         const int code = int(sp.tileMasks[96 + sl]);
         const int tI = code & 0xff, tK = code >> 8;
@@ -2871,11 +2878,11 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   { // damping of the FACTOR: at least kFactorDamping of the mean diagonal (mmx_device.hpp), from the resident diagonal
     // tiles; then the diagonal gets it and every row its pivot floor
     float tr = 0.f;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < (tid < 256 ? n : 0); i += 256) { // (the first four waves: the sum keeps its order)
       tr += tiles[256 * int(maskWords[64 + (i >> 4)]) + tileAddr(i & 15, i & 15)];
     }
     tr = waveReduceSumF(tr);
-    if (lane == 0) {
+    if (lane == 0 && wave < 4) {
       red[wave] = tr;
     }
     __syncthreads();
@@ -2884,7 +2891,7 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
       st.status[b] |= 4; // MMX_SOLVE_DAMPING_FLOORED
     }
     lambda = fmaxf(lambda, lambdaFloor);
-    for (int i = tid; i < NP; i += 256) {
+    for (int i = tid; i < NP; i += 64 * kW) {
       float* dg = tiles + 256 * int(maskWords[64 + (i >> 4)]) + tileAddr(i & 15, i & 15);
       const float hd = i < n ? *dg + lambda : 1.f;
       *dg = hd;
@@ -2924,7 +2931,7 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
         const int I = __builtin_ctz(rem);
         rem &= rem - 1u;
         uint32_t m = rowMask(I) & rk;
-        const bool take = (rr & 3) == wave;
+        const bool take = (rr & (kW - 1)) == wave;
         ++rr;
         if (!take || m == 0u) {
           continue;
@@ -2970,8 +2977,8 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
           Tc[tileAddr(4 * lkg + q, lrow)] = c0[q] + c1[q];
         }
       }
-      // the forward substitution rides along: s_k = g_k - sum_{j<k} L(k,j) y_j (wave 3)
-      if (wave == 3) {
+      // the forward substitution rides along: s_k = g_k - sum_{j<k} L(k,j) y_j (the last wave)
+      if (wave == kW - 1) {
         float acc = 0.f;
         uint32_t m = rk;
         while (m != 0u) { // four blocks per trip, reads in flight together
@@ -3027,7 +3034,7 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   const bool badPivot = flags[0] != 0;
   if (sp.diagAcc != nullptr) { // the precision estimate's input: the largest kPivotFloor (H_jj + mu) / d_jj of this factorisation
     float w = 0.f;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += 64 * kW) {
       w = fmaxf(w, floorAll[i] * invDiag[i] * invDiag[i]);
     }
     w = waveReduceMaxF(w);
@@ -3037,7 +3044,7 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
   }
   float* d0 = g; // y = L^-1 g; solved in place: L^T d = y on the resident tiles
   MMX_SCLK(0)
-  residentSweepBackward(tiles, maskWords, vRowMask, vColBase, NB, d0, invDiag, tid);
+  residentSweepBackward<kW>(tiles, maskWords, vRowMask, vColBase, NB, d0, invDiag, tid);
   MMX_SCLK(2)
   // the factor goes to its tile-major home in HBM (the finish stage and the trust region read it there) -- only now: a
   // __syncthreads() waits for every outstanding global store of the wave, so stores issued per finished column would put
@@ -3048,19 +3055,21 @@ __global__ void __launch_bounds__(256, 2) choleskyFactorResidentKernel(
     for (int idx = 0; rem != 0u; ++idx) {
       const int I = __builtin_ctz(rem);
       rem &= rem - 1u;
-      if ((idx & 3) == wave) {
+      if ((idx & (kW - 1)) == wave) {
         *reinterpret_cast<float4*>(L + size_t(tileIndex(I, k)) * 256 + opOff) = ldsRow4(pan + 256 * idx, lrow, lkg);
       }
     }
   }
   if (!sp.refine) {
-    applyStepAndBook(pb, P, b, d0, badPivot, errIter, theta, st, sp, tid);
+    if (tid < 256) {
+      applyStepAndBook(pb, P, b, d0, badPivot, errIter, theta, st, sp, tid);
+    }
     if (tid == 0) {
       refState[b] = 1;
     }
     return;
   }
-  for (int i = tid; i < NP; i += 256) {
+  for (int i = tid; i < NP; i += 64 * kW) {
     dvec[size_t(b) * NP + i] = d0[i];
   }
   if (tid == 0) {
@@ -3884,12 +3893,17 @@ hipError_t launchCholeskyFactorTiled(
     const bool useResident = sp.numTiles > 0 && resident <= 80 * 1024 - 64;
 #endif
     if (useResident) {
+#ifdef MMX_EXP_FACT8 // A/B build variant: eight waves per workgroup
+      constexpr int kW = 8;
+#else
+      constexpr int kW = 4;
+#endif
       static LdsLimitCache ldsLimit;
-      hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(choleskyFactorResidentKernel), resident);
+      hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(choleskyFactorResidentKernel<kW>), resident);
       if (rc != hipSuccess) {
         return rc;
       }
-      hipLaunchKernelGGL(choleskyFactorResidentKernel, dim3(pb.B), dim3(256), resident, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp, int(sp.numTiles));
+      hipLaunchKernelGGL(choleskyFactorResidentKernel<kW>, dim3(pb.B), dim3(64 * kW), resident, stream, pb, P, jtj, jtr, factor, dvec, refState, errIter, theta, st, sp, int(sp.numTiles));
       return hipGetLastError();
     }
   }

@@ -210,7 +210,9 @@ hipError_t launchFusedSolve(
     float* dbgH,
     float* dbgG,
     long long* dbgClk,
+    void* argsBuf, // fusedArgsBytes() of device memory owned by the problem, or null: where the descriptors are stashed for the lazy-argument instantiations (mmx_fused.hip, kArgLazy); written in stream order before the solve
     hipStream_t stream);
+size_t fusedArgsBytes();
 
 // double-precision solve (mmx_f64.hip)
 size_t solveF64LdsBytes(int J, int P, int U, int n, int G = 0, int genRows = 0);
