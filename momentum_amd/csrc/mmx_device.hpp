@@ -1062,6 +1062,34 @@ __device__ __forceinline__ float readLaneF(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// One elimination step of the panel chains (a lane holds a row of the panel, a[0..15]; column j is scaled): the row's entries
+// right of column j take their update, a[c] -= a[j] * L(c, j) with L(c, j) = lane c's a[j] (v_readlane).  TWO columns per
+// instruction (v_pk_fma_f32 with the two multipliers as an SGPR pair; the odd leftover of an even j on its own): 64 instead of
+// 120 multiply-adds per sixteen steps.  The chain is the longest VALU sequence of the solve kernels and its waves share a SIMD
+// with three others: BASELINE configs[1] 1.83e6 -> 1.91e6 solves/s, cfg3 + 2 % (profiles/r05_exp_fused.txt).
+typedef float v2f __attribute__((ext_vector_type(2)));
+// (j: the loop variable of an unrolled loop -- a constant where this is inlined)
+__device__ __forceinline__ void panelRowUpdate(float (&a)[16], int j) {
+#ifdef MMX_EXP_NOPKCHAIN
+#pragma unroll
+  for (int c = j + 1; c < 16; ++c) {
+    a[c] -= a[j] * readLaneF(a[j], c);
+  }
+#else
+  if ((j & 1) == 0) {
+    a[j + 1] -= a[j] * readLaneF(a[j], j + 1);
+  }
+#pragma unroll
+  for (int c = (j + 2) & ~1; c < 16; c += 2) {
+    const v2f mlt{readLaneF(a[j], c), readLaneF(a[j], c + 1)};
+    const v2f aj2{a[j], a[j]};
+    v2f acc{a[c], a[c + 1]};
+    acc = __builtin_elementwise_fma(-aj2, mlt, acc);
+    a[c] = acc.x, a[c + 1] = acc.y;
+  }
+#endif
+}
+
 __device__ __forceinline__ float4 ldsRow4(const float* tile, int row, int chunk) { // 4 consecutive columns
   return *reinterpret_cast<const float4*>(tile + row * 16 + (((chunk ^ (row >> 2)) & 3) << 2));
 }

@@ -778,6 +778,104 @@ __device__ __forceinline__ void solveLLtLeft(const float* L, const float* invDia
   __syncthreads();
 }
 
+// The left-looking form with the dependent chain cut to the NEWEST block: the sums over the blocks finished two steps ago
+// and earlier are formed a step ahead (their LDS reads fly under the current step's chain), the newest block's solution comes
+// over in registers (ds_bpermute from its quads) instead of through its store -- one partial sum and four values more than the
+// plain form, against the 2 NB partial sums of the right-looking one.  Forward: the same sums in the same order as
+// solveLLtLeft; backward: the blocks are added from the last one down (the plain form: from k + 1 up).
+template <int NB>
+__device__ __forceinline__ void solveLLtLeftAhead(const float* L, const float* invDiag, float* x, int tid) {
+  if (tid < 64) {
+    const int i = tid >> 2, g = tid & 3;
+    float pre = 0.f; // block k's sum over j < k - 1
+    float4 yq{0.f, 0.f, 0.f, 0.f}; // y_{k-1}[4g .. 4g+3]
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { // forward
+      float preNext = 0.f; // block k + 1's sum over j < k: independent of this step
+      if (k + 1 < NB) {
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+          preNext = dot4(ldsRow4(L + 256 * tileIndex(k + 1, j), i, g), *reinterpret_cast<const float4*>(x + 16 * j + 4 * g), preNext);
+        }
+      }
+      float acc = pre;
+      if (k > 0) {
+        acc = dot4(ldsRow4(L + 256 * tileIndex(k, k - 1), i, g), yq, acc);
+      }
+      acc = quadSum(acc);
+      float* xk = x + 16 * k;
+      const float rhs = xk[i] - acc; // the same value in the four lanes of quad i
+      const float invd = invDiag[16 * k + i];
+      const float* Dk = L + 256 * tileIndex(k, k);
+      float p = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g; // L_kk^-1 (i, c) = L_kk^-T (c, i)
+        const float m = Dk[tileAddr(c, i)];
+        const float rc = __shfl(rhs, 4 * c, 64); // right-hand side of row c straight from its quad
+        p += (c < i ? m : (c == i ? invd : 0.f)) * rc;
+      }
+      p = quadSum(p);
+      if (g == 0) {
+        xk[i] = p;
+      }
+      if (k + 1 < NB) {
+        yq = float4{__shfl(p, 16 * g, 64), __shfl(p, 16 * g + 4, 64), __shfl(p, 16 * g + 8, 64), __shfl(p, 16 * g + 12, 64)};
+      }
+      pre = preNext;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    pre = 0.f; // block k's sum over j > k + 1
+    float xq[4] = {0.f, 0.f, 0.f, 0.f}; // x_{k+1}[4t + g]
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k) { // backward
+      float preNext = 0.f; // block k - 1's sum over j > k
+      if (k > 0) {
+#pragma unroll
+        for (int j = NB - 1; j > k; --j) {
+          const float* Tj = L + 256 * tileIndex(j, k - 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c = 4 * t + g;
+            preNext += Tj[tileAddr(c, i)] * x[16 * j + c]; // L(16 j + c, 16 (k - 1) + i)
+          }
+        }
+      }
+      float acc = pre;
+      if (k + 1 < NB) {
+        const float* Tj = L + 256 * tileIndex(k + 1, k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc += Tj[tileAddr(4 * t + g, i)] * xq[t];
+        }
+      }
+      acc = quadSum(acc);
+      float* xk = x + 16 * k;
+      const float rhs = xk[i] - acc;
+      const float invd = invDiag[16 * k + i];
+      const float4 row = ldsRow4(L + 256 * tileIndex(k, k), i, g); // L_kk^-T (i, 4g..4g+3)
+      const int c0 = 4 * g;
+      float p = (c0 > i ? row.x : (c0 == i ? invd : 0.f)) * __shfl(rhs, 4 * c0, 64);
+      p += (c0 + 1 > i ? row.y : (c0 + 1 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 1), 64);
+      p += (c0 + 2 > i ? row.z : (c0 + 2 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 2), 64);
+      p += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 3), 64);
+      p = quadSum(p);
+      if (g == 0) {
+        xk[i] = p;
+      }
+      if (k > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          xq[t] = __shfl(p, 4 * (4 * t + g), 64);
+        }
+      }
+      pre = preNext;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  __syncthreads();
+}
+
 template <int NB>
 __device__ __forceinline__ void solveLLtRight(const float* L, const float* invDiag, float* x, int tid) {
   if (tid < 64) {
@@ -860,6 +958,10 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
   if (NB <= 8 && !kLeft) {
 #endif
     solveLLtRight<NB>(L, invDiag, x, tid);
+#ifdef MMX_EXP_AHEAD // (A/B variant: the chain cut to the newest block, see solveLLtLeftAhead)
+  } else if (NB <= 8) {
+    solveLLtLeftAhead<NB>(L, invDiag, x, tid);
+#endif
   } else {
     solveLLtLeft<NB>(L, invDiag, x, tid);
   }
@@ -1761,10 +1863,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
               if (lane == j) {
                 invd = inv;
               }
-#pragma unroll
-              for (int c = j + 1; c < 16; ++c) {
-                a[c] -= a[j] * readLaneF(a[j], c);
-              }
+              panelRowUpdate(a, j);
             }
           };
           // The threshold costs three instructions per step on the kernel's longest dependent chain (measured: 3 % of the
