@@ -18,7 +18,22 @@ VARIANT = os.environ.get("MMX_BUILD_VARIANT", "")
 VARIANT_FLAGS = os.environ.get("MMX_BUILD_FLAGS", "").split() if VARIANT else []
 LIB = os.path.join(HERE, f"libmmx_hip_{VARIANT}.so" if VARIANT else "libmmx_hip.so")
 SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_comm.hip", "mmx_f64.hip", "mmx_host_tables.cpp"]
-FUSED_GROUPS = 4  # mmx_fused.hip is compiled once per group of template instantiations, in parallel
+FUSED_GROUPS = 5  # mmx_fused.hip is compiled once per group of template instantiations, in parallel (4: the wide route's tree kernels)
+# The solve kernels (one-launch solve, double solve) are compiled WITHOUT the machine-level loop-invariant code motion and
+# WITHOUT loop strength reduction: at their register budgets the per-lane address arithmetic the first hoists out of the
+# iteration loop and the induction pointers the second creates are what gets spilled.  Spilled VGPRs of the BASELINE
+# configs[1] instantiation 37 -> 4 -> 0, LM schedule 54 -> 16 -> 0, generic rule 94 -> 49 -> 0, double solve 186 -> 40 -> 7
+# (scripts/probes/fused_one.sh prints them in seconds).  Measured, one box each: first flag headline + 1.7 %, cfg3 + 4.6 %,
+# line search + 13 %, double solve + 3.9 %; second flag on top + 4 % / + 2.5 % / + 1-4 % / + 0.7 %.  The wide route's kernels
+# (mmx_kernels.hip, the tree kernels = group 4) lose 0.2-0.3 % with either and keep the default pipeline
+# (profiles/r05_exp_fused.txt).
+SOLVE_KERNEL_FLAGS = ["-mllvm", "-disable-machine-licm", "-mllvm", "-disable-lsr"]
+
+
+def _extra_flags(src: str, group) -> list:
+    if src == "mmx_f64.hip" or (src == "mmx_fused.hip" and group != 4):
+        return SOLVE_KERNEL_FLAGS
+    return []
 HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_tree.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
 ARCH = "gfx950"
 
@@ -54,6 +69,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 cmd[1:1] = VARIANT_FLAGS
             if g is not None:
                 cmd.insert(1, f"-DMMX_FUSED_GROUP={g}")
+            if not os.environ.get("MMX_BUILD_DEFAULT_PIPELINE"):  # (A/B: MMX_BUILD_DEFAULT_PIPELINE=1 compiles everything with the default pipeline)
+                cmd[1:1] = _extra_flags(src, g)
             if src.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

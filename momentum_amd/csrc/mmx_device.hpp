@@ -1063,18 +1063,24 @@ __device__ __forceinline__ float readLaneF(float v, int lane) {
 }
 
 // One elimination step of the panel chains (a lane holds a row of the panel, a[0..15]; column j is scaled): the row's entries
-// right of column j take their update, a[c] -= a[j] * L(c, j) with L(c, j) = lane c's a[j] (v_readlane).  TWO columns per
-// instruction (v_pk_fma_f32 with the two multipliers as an SGPR pair; the odd leftover of an even j on its own): 64 instead of
-// 120 multiply-adds per sixteen steps.  The chain is the longest VALU sequence of the solve kernels and its waves share a SIMD
-// with three others: BASELINE configs[1] 1.83e6 -> 1.91e6 solves/s, cfg3 + 2 % (profiles/r05_exp_fused.txt).
+// right of column j take their update, a[c] -= a[j] * L(c, j) with L(c, j) = lane c's a[j] (v_readlane).
+// panelRowUpdate: TWO columns per instruction (v_pk_fma_f32 with the two multipliers as an SGPR pair; the odd leftover of an
+// even j on its own): 64 instead of 120 multiply-adds per sixteen steps.  The chain is the longest VALU sequence of the
+// one-launch solve and its wave shares a SIMD with three others: BASELINE configs[1] 1.83e6 -> 1.91e6 solves/s, cfg3 + 2 %
+// (profiles/r05_exp_fused.txt).  The packed form rounds like the plain one only almost everywhere (last bits of the pose move).
+// panelRowUpdate1: one column per instruction -- the wide route keeps it: there the packed form is worth 1.5 % (cfg5) and
+// moved one of the 12 288 instances test_config5_every_instance_within_1e5 pins over the bound (1.13e-5).
+// (j: the loop variable of an unrolled loop -- a constant where these are inlined)
 typedef float v2f __attribute__((ext_vector_type(2)));
-// (j: the loop variable of an unrolled loop -- a constant where this is inlined)
-__device__ __forceinline__ void panelRowUpdate(float (&a)[16], int j) {
-#ifdef MMX_EXP_NOPKCHAIN
+__device__ __forceinline__ void panelRowUpdate1(float (&a)[16], int j) {
 #pragma unroll
   for (int c = j + 1; c < 16; ++c) {
     a[c] -= a[j] * readLaneF(a[j], c);
   }
+}
+__device__ __forceinline__ void panelRowUpdate(float (&a)[16], int j) {
+#ifdef MMX_EXP_NOPKCHAIN // (A/B variant: one column per instruction everywhere)
+  panelRowUpdate1(a, j);
 #else
   if ((j & 1) == 0) {
     a[j + 1] -= a[j] * readLaneF(a[j], j + 1);

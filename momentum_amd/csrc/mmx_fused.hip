@@ -1123,6 +1123,22 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   // (their LDS has no room for it); the others keep their LDS copy
   constexpr bool kFour = FusedFour<NB, kTR, kGen, kRule>::value;
   constexpr bool kCsrLds = !kFour;
+  // the register-lean forms of three routines in the four-workgroup instantiations (A/B variants: the full forms back, one each)
+#ifdef MMX_EXP_FATSOLVE
+  constexpr bool kLeanSolve = false;
+#else
+  constexpr bool kLeanSolve = kFour;
+#endif
+#ifdef MMX_EXP_FATDBUF
+  constexpr bool kLeanOps = false;
+#else
+  constexpr bool kLeanOps = kFour;
+#endif
+#ifdef MMX_EXP_FATACC
+  constexpr bool kLeanAcc = false;
+#else
+  constexpr bool kLeanAcc = kFour;
+#endif
   const int kNnz = fd.nnz;
   const FusedLayout lay = fusedLayout(NB, J, P, U, nsrc, n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR);
   {
@@ -1579,7 +1595,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         // the next tile's LDS reads fly while this one multiplies -- except at four workgroups per CU, where the thirteen registers
         // of a second operand set cost more than the reads' latency (other workgroups fill it): + 0.4 % (r05_exp_fused.txt)
         TileOps nxt;
-        if (!kFour) {
+        if (!kLeanOps) {
           nxt = loadOps(more ? I : tI, more ? Jc : tJ);
         }
         const float z = gq == 3 ? 0.f : 1.f;
@@ -1597,7 +1613,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
           const bool colDeep = tinR <= tinC && tinC < toutR;
           Tc[tileAddr(4 * gq + q, i)] = rowDeep ? P[q] : (colDeep ? Q[q] : 0.f);
         }
-        if (kFour) {
+        if (kLeanOps) {
           nxt = loadOps(more ? I : tI, more ? Jc : tJ);
         }
         cur = nxt;
@@ -1769,7 +1785,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         for (int j = j0; j < j1; ++j) {
           const float4 av = ldsRow4(s.L + 256 * tileIndex(I, j), lane & 15, lane >> 4);
           const float4 bv = ldsRow4(s.L + 256 * tileIndex(kc, j), lane & 15, lane >> 4);
-          if ((j & 1) && !kFour) { // (one accumulator at four workgroups per CU: four registers less, + 1.5 %; r05_exp_fused.txt)
+          if ((j & 1) && !kLeanAcc) { // (one accumulator at four workgroups per CU: four registers less, + 1.5 %; r05_exp_fused.txt)
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.x, c1, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.y, bv.y, c1, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.z, bv.z, c1, 0, 0, 0);
@@ -1954,7 +1970,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       csrJd = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
     }
     if (!notPd) {
-      solveLLt<NB, kFour>(s.L, s.invDiag, s.d0, tid);
+      solveLLt<NB, kLeanSolve>(s.L, s.invDiag, s.d0, tid);
     }
     MMX_CLK(8)
     // ================= J: one refinement step through the tree (tangent + adjoint passes)
@@ -2166,7 +2182,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       }
       __syncthreads();
       MMX_CLK(19)
-      solveLLt<NB, kFour>(s.L, s.invDiag, s.rho, tid);
+      solveLLt<NB, kLeanSolve>(s.L, s.invDiag, s.rho, tid);
       MMX_CLK(20)
       float c2 = 0.f, d2 = 0.f;
       for (int c = tid; c < n; c += 256) {
@@ -2235,7 +2251,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         s.rho[c] = c < n ? s.d0[c] : 0.f;
       }
       __syncthreads();
-      solveLLt<NB, kFour>(s.L, s.invDiag, s.rho, tid);
+      solveLLt<NB, kLeanSolve>(s.L, s.invDiag, s.rho, tid);
       float pq = 0.f;
       for (int c = tid; c < n; c += 256) {
         pq += s.d0[c] * s.rho[c];
@@ -2475,7 +2491,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
 // kernel (launchTreeNormalEquations returns false).
 // Output: H[i * n + j] for i >= j (what choleskyStepGlobalKernel reads), no lambda; g[n].
 // ---------------------------------------------------------------------------------------------
-#if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 0
+#if !defined(MMX_FUSED_GROUP) || MMX_FUSED_GROUP == 4 // (the tree kernels of the wide route: a translation unit of their own, compiled WITH the machine-level loop-invariant code motion the solve kernel's groups switch off -- momentum_amd/build.py)
 // what treeNormalEquationsKernel hands to treeRefineKernel, per instance: js | up | ur | us
 struct TreeStateLayout {
   size_t js, up, ur, us, total;
@@ -3526,7 +3542,13 @@ hipError_t launchFusedGroup2(int nb, MMX_FUSED_ARGS) {
     MMX_CASE(7) MMX_CASE(8) MMX_CASE(10) default : return hipErrorInvalidValue;
   }
 }
-#else
+#elif MMX_FUSED_GROUP == 9 // (compile probe, scripts/probes/fused_one.sh: ONE instantiation, for register / spill figures in half a minute)
+#ifndef MMX_PROBE_RULE
+#define MMX_PROBE_RULE 0
+#endif
+template __global__ void fusedSolveKernel<6, 0, false, false, MMX_PROBE_RULE, true>(
+    const FusedArgs*, RigDev, ProblemDev, FusedDev, float*, SolveStateDev, FusedParams, float*, float*, long long*);
+#elif MMX_FUSED_GROUP == 3
 hipError_t launchFusedGroup3(int nb, MMX_FUSED_ARGS) {
   switch (nb) {
     MMX_CASE(12) MMX_CASE(14) default : return hipErrorInvalidValue;

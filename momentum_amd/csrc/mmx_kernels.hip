@@ -1788,7 +1788,7 @@ __device__ __forceinline__ void tiledFactor(
         if (lane == j) {
           invd = inv;
         }
-        panelRowUpdate(a, j);
+        panelRowUpdate1(a, j);
       }
       if (diagLane) {
         if (wave == 0) {
@@ -1897,7 +1897,7 @@ __device__ __forceinline__ void tiledPanelFactor(float* pan, int nt, int k, floa
       // L_kk y_k = s_k rides along (lanes 0-15: row j's entry is final once column j is scaled; the other lanes carry a dummy)
       const float yj = readLaneF(bi, j) * inv;
       bi = (lane == j) ? yj : (lane > j ? bi - a[j] * yj : bi); // (a row's entries right of the diagonal are scratch)
-      panelRowUpdate(a, j);
+      panelRowUpdate1(a, j);
     }
   }
   if (waveWorks && diagLane) {
@@ -1988,7 +1988,7 @@ tiledPanelFactorGroup(float* pan, int nt, int k, float* g, float* invDiag, int* 
       }
       const float yj = readLaneF(bi, j) * inv;
       bi = (lane == j) ? yj : (lane > j ? bi - a[j] * yj : bi);
-      panelRowUpdate(a, j);
+      panelRowUpdate1(a, j);
     }
   }
   if (waveWorks && diagLane) {

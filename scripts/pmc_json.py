@@ -14,9 +14,9 @@ for f in glob.glob(out + "/pmc2*/**/*counter_collection.csv", recursive=True):
 avg = lambda v: sum(v) / len(v) if v else None
 for (name, grid), c in agg.items():
     g = lambda k: avg(c.get(k, []))
-    if "fusedSolveKernel<6, 0, false, false, 0>" in name and grid == 4096 * 256:
+    if "fusedSolveKernel<6, 0, false, false, 0" in name and grid == 4096 * 256:  # (+ ", true>": the lazy-argument form)
         d = {
-            "kernel": "fusedSolveKernel<6,0,false,false,0>", "config": "cfg2", "batch": 4096,
+            "kernel": name.replace("void mmx::", "").replace(" ", ""), "config": "cfg2", "batch": 4096,
             "source": f"profiles/{tag}_pmc_bench.txt (rocprofv3 --pmc, separate passes, averages over the launches of one bench run)",
             "lds_bank_conflict_ratio": g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"),
             "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": g("SQ_LDS_IDX_ACTIVE"),
@@ -25,6 +25,7 @@ for (name, grid), c in agg.items():
             "wait_inst_any_over_wave_cycles": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
             "valu_insts": g("SQ_INSTS_VALU"), "mfma_f32_insts": g("SQ_INSTS_VALU_MFMA_F32"), "lds_insts": g("SQ_INSTS_LDS"), "salu_insts": g("SQ_INSTS_SALU"),
             "round2": {"lds_bank_conflict_ratio": 0.226, "valu_active_over_wave_cycles": 0.148, "wait_any_over_wave_cycles": 0.666, "valu_insts": 6.31e8, "salu_insts": 2.179e8},
+            "round5_before_the_compiler_flags_and_packed_chain": {"lds_bank_conflict_ratio": 0.261, "valu_active_over_wave_cycles": 0.132, "wait_any_over_wave_cycles": 0.671, "valu_insts": 6.92e8, "salu_insts": 2.575e8},
         }
         json.dump(d, open(os.path.join(out, "pmc_fused.json"), "w"), indent=1)
         print("pmc_fused:", {k: (round(v, 4) if isinstance(v, float) and v < 10 else v) for k, v in d.items() if k not in ("source", "round2")})

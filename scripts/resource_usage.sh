@@ -3,8 +3,9 @@
 # (-Rpass-analysis=kernel-resource-usage), as a table: bash scripts/resource_usage.sh > profiles/rNN_kernel_resource_usage.txt
 cd "$(dirname "$0")/../momentum_amd/csrc" || exit 1
 tmp=$(mktemp -d)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMMX_FUSED_GROUP=1 -c mmx_fused.hip -o $tmp/g1.o -Rpass-analysis=kernel-resource-usage 2> $tmp/g1.txt &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMMX_FUSED_GROUP=0 -c mmx_fused.hip -o $tmp/g0.o -Rpass-analysis=kernel-resource-usage 2> $tmp/g0.txt &
+# (the flags of momentum_amd/build.py: the solve kernels' groups without machine-level loop-invariant code motion / loop strength reduction)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -disable-machine-licm -mllvm -disable-lsr -DMMX_FUSED_GROUP=1 -c mmx_fused.hip -o $tmp/g1.o -Rpass-analysis=kernel-resource-usage 2> $tmp/g1.txt &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMMX_FUSED_GROUP=4 -c mmx_fused.hip -o $tmp/g0.o -Rpass-analysis=kernel-resource-usage 2> $tmp/g0.txt &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c mmx_kernels.hip -o $tmp/k.o -Rpass-analysis=kernel-resource-usage 2> $tmp/k.txt &
 wait
 python3 - $tmp <<'PY'
