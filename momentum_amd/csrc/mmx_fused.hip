@@ -782,7 +782,9 @@ __device__ __forceinline__ void solveLLtLeft(const float* L, const float* invDia
 // and earlier are formed a step ahead (their LDS reads fly under the current step's chain), the newest block's solution comes
 // over in registers (ds_bpermute from its quads) instead of through its store -- one partial sum and four values more than the
 // plain form, against the 2 NB partial sums of the right-looking one.  Forward: the same sums in the same order as
-// solveLLtLeft; backward: the blocks are added from the last one down (the plain form: from k + 1 up).
+// solveLLtLeft; backward: the blocks are added from the last one down (the plain form: from k + 1 up).  While the kernel spilled
+// (default code generation, 128 registers) this lost 0-5 %; without spills (momentum_amd/build.py SOLVE_KERNEL_FLAGS) it gains
+// 0.6 % on BASELINE configs[1] and 1.4 % on cfg3 (profiles/r05_exp_fused.txt).
 template <int NB>
 __device__ __forceinline__ void solveLLtLeftAhead(const float* L, const float* invDiag, float* x, int tid) {
   if (tid < 64) {
@@ -958,8 +960,8 @@ __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, f
   if (NB <= 8 && !kLeft) {
 #endif
     solveLLtRight<NB>(L, invDiag, x, tid);
-#ifdef MMX_EXP_AHEAD // (A/B variant: the chain cut to the newest block, see solveLLtLeftAhead)
-  } else if (NB <= 8) {
+#ifndef MMX_EXP_NOAHEAD // (A/B variant: the plain left-looking form in the four-workgroup instantiations)
+  } else if (NB <= 8) { // (kLeft: the chain cut to the newest block, see solveLLtLeftAhead)
     solveLLtLeftAhead<NB>(L, invDiag, x, tid);
 #endif
   } else {
@@ -1369,7 +1371,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     // hides behind it (one round trip per iteration instead of two) -- except in the instantiations that run four
     // workgroups per CU at 128 registers: eleven registers across FK cost them more than the round trip (an L2 hit from the
     // second iteration on): 1.716 -> 1.726e6 solves/s on BASELINE configs[1], profiles/r05_exp_fused.txt
+#ifdef MMX_EXP_EARLYUNIT // (A/B variant: the unit payload requested before FK in the four-workgroup instantiations too)
+    constexpr bool kLateUnit = false;
+#else
     constexpr bool kLateUnit = kFour;
+#endif
     const UnitInput uin0 = kLateUnit ? UnitInput{} : loadUnitInput(pb, b, tid < U ? tid : U);
     // TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270) wraps what follows
     // in up to ten trial steps (:157); every other step rule passes through once.
