@@ -132,3 +132,42 @@ def test_adapter_fold_for_the_joint_constraint_blocks_is_exact(torch_cuda, orc):
     a = run(cons.pos_weight, cons.ori_weight, fw)
     b = run(cons.pos_weight * fw[:, :1], cons.ori_weight * fw[:, 1:2], None)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("line_search,step_rule", [(0, 0), (2, 0), (0, 1)])
+def test_lazy_and_by_value_argument_forms_of_the_solve_agree(torch_cuda, orc, line_search, step_rule):
+    """The four-workgroup instantiations of the one-launch solve exist twice (mmx_fused.hip, kArgLazy): descriptors read lazily
+    from the problem's device struct (shared rig, shared weights: the production form), or passed by value (per-element rigs /
+    weights: the selections write into the copies).  Unit function weights send the same problem down the by-value form; the
+    two must give the same answer -- same source, same arithmetic: bit for bit -- for the plain, the line-search (generic) and
+    the LM instantiation."""
+    torch = torch_cuda
+    from momentum_amd._abi import MMX_STEP_LM_SCHEDULE
+
+    B = 64
+    rig = make_humanoid72(unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    cons, th0, _ = make_problem(rig, lm, lm, B, seed=11, perturb=0.3, weights="random")
+    opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, do_line_search=line_search,
+                         step_rule=MMX_STEP_LM_SCHEDULE if step_rule else 0)  # fmt: skip
+    t = lambda pb, a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
+
+    def run(fwt):
+        pb = capi.Problem(capi.RigHandle(rig, 0), B, cons.pos_parent, cons.ori_parent)
+        pb.set_route("fused")
+        pb.set_constraints(t(pb, cons.pos_offset, (B, cons.Kp, 3)), t(pb, cons.pos_target, (B, cons.Kp, 3)), t(pb, cons.pos_weight, (B, cons.Kp)),
+                           t(pb, cons.ori_offset, (B, cons.Ko, 4)), t(pb, cons.ori_target, (B, cons.Ko, 4)), t(pb, cons.ori_weight, (B, cons.Ko)),
+                           function_weights=None if fwt is None else t(pb, fwt, (B, 2)))  # fmt: skip
+        out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+        torch.cuda.synchronize()
+        return out["theta"].cpu().numpy(), out["error_history"].cpu().numpy(), out["status"].cpu().numpy()
+
+    lazy = run(None)
+    by_value = run(np.ones((B, 2), np.float32))
+    assert np.all(lazy[2] & 3 == 0) and np.array_equal(lazy[2], by_value[2])
+    assert np.array_equal(lazy[0], by_value[0]), float(np.abs(lazy[0] - by_value[0]).max())
+    assert np.array_equal(lazy[1], by_value[1])
+    if not line_search and not step_rule:  # ... and it is the right answer (no discrete decisions in the plain rule)
+        ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+        rel = np.linalg.norm(lazy[0] - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+        assert rel.max() <= 1e-5, rel.max()
