@@ -178,6 +178,18 @@ struct RigDev {
 
 // element b's view of the rig: the per-instance constants replace the shared ones (a kernel calls this
 // once on its by-value copy of the descriptor)
+// A pointer known to point into global memory.  Pointers read out of a descriptor struct in memory (the one-launch solve's lazily
+// loaded arguments) are generic to the compiler and their loads flat; through an integer the address space sticks (a plain cast
+// pair is folded away): + 0.5-1 % on the one-launch solve's lines (r05_exp_fused.txt).  A/B variant noglobalptr: identity.
+template <class T>
+__device__ __forceinline__ T* asGlobal(T* p) {
+#ifdef MMX_EXP_NOGLOBALPTR
+  return p;
+#else
+  return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
+#endif
+}
+
 __device__ __forceinline__ void selectInstanceRig(RigDev& rig, int b) {
   if (rig.instPreRot != nullptr) {
     rig.preRot = rig.instPreRot + size_t(b) * 4 * size_t(rig.J);
@@ -576,19 +588,19 @@ __device__ __forceinline__ UnitInput loadUnitInput(const ProblemDev& pb, int b, 
   if (u >= pb.U) {
     return in;
   }
-  in.joint = pb.unitJoint[u];
-  in.tin = pb.unitTin[u];
+  in.joint = asGlobal(pb.unitJoint)[u];
+  in.tin = asGlobal(pb.unitTin)[u];
   if (u < pb.Kp) {
     const size_t c = size_t(b) * pb.Kp + u;
     if (pb.instPosParent != nullptr) { // ConstraintData::parent of THIS element
       in.joint = pb.instPosParent[c];
       in.tin = pb.jointTin[in.joint];
     }
-    const float* po = pb.posOffset + 3 * c;
-    const float* pt = pb.posTarget + 3 * c;
+    const float* po = asGlobal(pb.posOffset) + 3 * c;
+    const float* pt = asGlobal(pb.posTarget) + 3 * c;
     in.a[0] = po[0], in.a[1] = po[1], in.a[2] = po[2];
     in.t[0] = pt[0], in.t[1] = pt[1], in.t[2] = pt[2];
-    in.cw = pb.posWeight[c];
+    in.cw = asGlobal(pb.posWeight)[c];
   } else {
     const int co = (u - pb.Kp) / 3;
     const size_t c = size_t(b) * pb.Ko + co;
@@ -596,11 +608,11 @@ __device__ __forceinline__ UnitInput loadUnitInput(const ProblemDev& pb, int b, 
       in.joint = pb.instOriParent[c];
       in.tin = pb.jointTin[in.joint];
     }
-    const float* oo = pb.oriOffset + 4 * c; // caller-owned pointers: no alignment assumed
-    const float* ot = pb.oriTarget + 4 * c;
+    const float* oo = asGlobal(pb.oriOffset) + 4 * c; // caller-owned pointers: no alignment assumed
+    const float* ot = asGlobal(pb.oriTarget) + 4 * c;
     in.a[0] = oo[0], in.a[1] = oo[1], in.a[2] = oo[2], in.a[3] = oo[3];
     in.t[0] = ot[0], in.t[1] = ot[1], in.t[2] = ot[2], in.t[3] = ot[3];
-    in.cw = pb.oriWeight[c];
+    in.cw = asGlobal(pb.oriWeight)[c];
   }
   return in;
 }
@@ -1098,6 +1110,22 @@ __device__ __forceinline__ void panelRowUpdate(float (&a)[16], int j) {
 
 __device__ __forceinline__ float4 ldsRow4(const float* tile, int row, int chunk) { // 4 consecutive columns
   return *reinterpret_cast<const float4*>(tile + row * 16 + (((chunk ^ (row >> 2)) & 3) << 2));
+}
+// the four products as two packed multiply-adds + one add (the sum's order differs from dot4's): the one-launch solve's
+// single-wave triangular solves, where the instruction count is the time (+ 2.3 % on BASELINE configs[1], r05_exp_fused.txt)
+__device__ __forceinline__ float dot4pk(float4 a, float4 b, float acc) {
+#ifdef MMX_EXP_NOPKDOT // (A/B variant)
+  acc += a.x * b.x;
+  acc += a.y * b.y;
+  acc += a.z * b.z;
+  acc += a.w * b.w;
+  return acc;
+#else
+  v2f s{acc, 0.f};
+  s = __builtin_elementwise_fma(v2f{a.x, a.y}, v2f{b.x, b.y}, s);
+  s = __builtin_elementwise_fma(v2f{a.z, a.w}, v2f{b.z, b.w}, s);
+  return s.x + s.y;
+#endif
 }
 __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
   acc += a.x * b.x;

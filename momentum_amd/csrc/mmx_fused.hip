@@ -781,8 +781,8 @@ __device__ __forceinline__ void solveLLtLeft(const float* L, const float* invDia
 // The left-looking form with the dependent chain cut to the NEWEST block: the sums over the blocks finished two steps ago
 // and earlier are formed a step ahead (their LDS reads fly under the current step's chain), the newest block's solution comes
 // over in registers (ds_bpermute from its quads) instead of through its store -- one partial sum and four values more than the
-// plain form, against the 2 NB partial sums of the right-looking one.  Forward: the same sums in the same order as
-// solveLLtLeft; backward: the blocks are added from the last one down (the plain form: from k + 1 up).  While the kernel spilled
+// plain form, against the 2 NB partial sums of the right-looking one.  Forward: the blocks in solveLLtLeft's order (each block's
+// four products packed: dot4pk); backward: the blocks are added from the last one down (the plain form: from k + 1 up).  While the kernel spilled
 // (default code generation, 128 registers) this lost 0-5 %; without spills (momentum_amd/build.py SOLVE_KERNEL_FLAGS) it gains
 // 0.6 % on BASELINE configs[1] and 1.4 % on cfg3 (profiles/r05_exp_fused.txt).
 template <int NB>
@@ -797,12 +797,12 @@ __device__ __forceinline__ void solveLLtLeftAhead(const float* L, const float* i
       if (k + 1 < NB) {
 #pragma unroll
         for (int j = 0; j < k; ++j) {
-          preNext = dot4(ldsRow4(L + 256 * tileIndex(k + 1, j), i, g), *reinterpret_cast<const float4*>(x + 16 * j + 4 * g), preNext);
+          preNext = dot4pk(ldsRow4(L + 256 * tileIndex(k + 1, j), i, g), *reinterpret_cast<const float4*>(x + 16 * j + 4 * g), preNext);
         }
       }
       float acc = pre;
       if (k > 0) {
-        acc = dot4(ldsRow4(L + 256 * tileIndex(k, k - 1), i, g), yq, acc);
+        acc = dot4pk(ldsRow4(L + 256 * tileIndex(k, k - 1), i, g), yq, acc);
       }
       acc = quadSum(acc);
       float* xk = x + 16 * k;
@@ -1284,15 +1284,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   // from here on the kernel reads the batch-shared tables through these LDS-backed views
   RigView rv;
   rv.J = J, rv.P = P, rv.R = kR, rv.numLevels = rig.numLevels, rv.jumpRounds = rig.jumpRounds;
-  rv.parent = lParent, rv.preRot = rig.preRot, rv.offset = rig.offset;
-  rv.ptOuter = kCsrLds ? lPtOuter : rig.ptOuter, rv.ptInner = kCsrLds ? lPtInner : rig.ptInner, rv.ptValue = kCsrLds ? lPtValue : rig.ptValue; // (LDS copy, or global: csrRowsPrefetched)
-  rv.ptOffsets = rig.ptOffsets;
+  rv.parent = lParent, rv.preRot = asGlobal(rig.preRot), rv.offset = asGlobal(rig.offset);
+  // (asGlobal: read out of the lazily loaded descriptors the pointers are generic and their loads flat)
+  rv.ptOuter = kCsrLds ? lPtOuter : asGlobal(rig.ptOuter), rv.ptInner = kCsrLds ? lPtInner : asGlobal(rig.ptInner), rv.ptValue = kCsrLds ? lPtValue : asGlobal(rig.ptValue); // (LDS copy, or global: csrRowsPrefetched)
+  rv.ptOffsets = asGlobal(rig.ptOffsets);
   rv.hasOffsets = rig.ptOffsetsNonZero != 0;
   rv.levelOrder = nullptr, rv.levelStart = nullptr; // (the pointer-jumping FK needs neither)
 #ifdef MMX_EXP_NOROWREC // (A/B variant: the CSR walk, two dependent L2 round trips)
   rv.rowRec = nullptr, rv.numRowRec = 0;
 #else
-  rv.rowRec = rig.ptRowRec, rv.numRowRec = rig.numRowRec;
+  rv.rowRec = asGlobal(rig.ptRowRec), rv.numRowRec = rig.numRowRec;
 #endif
   FusedViewS fv;
   fv.U = U, fv.Kp = fd.Kp;
@@ -1638,7 +1639,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         uint2 rec[kRecTrip];
 #pragma unroll
         for (int k = 0; k < kRecTrip; ++k) {
-          const uint4* rp = fd.gTerms + (k0 + k) * 256 + tid;
+          const uint4* rp = asGlobal(fd.gTerms) + (k0 + k) * 256 + tid;
           rec[k] = *reinterpret_cast<const uint2*>(rp); // x: deep | anc << 12 | flags ; y: destination
         }
         if (MODE == 2) {
