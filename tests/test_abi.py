@@ -114,3 +114,23 @@ def test_product_package_never_touches_the_oracle():
     assert not bad, bad
     out = subprocess.check_output(["readelf", "-d", capi.LIB_PATH]).decode()
     assert "oracle" not in out
+
+
+def test_build_recipe_flags_per_translation_unit():
+    """momentum_amd/build.py: the solve kernels' translation units (mmx_fused.hip groups 0-3, mmx_f64.hip) are compiled without
+    machine-level LICM and loop strength reduction (the kernels spill otherwise: profiles/r05_exp_fused.txt item 14), the wide
+    route's (mmx_kernels.hip, the tree kernels = group 4 of mmx_fused.hip) and the host-side files with the default pipeline;
+    every group the source dispatches to is built."""
+    import re
+
+    from momentum_amd import build as mbuild
+
+    solve = ["-mllvm", "-disable-machine-licm", "-mllvm", "-disable-lsr"]
+    for g in range(4):
+        assert mbuild._extra_flags("mmx_fused.hip", g) == solve
+    assert mbuild._extra_flags("mmx_f64.hip", None) == solve
+    for src, g in (("mmx_fused.hip", 4), ("mmx_kernels.hip", None), ("mmx_capi.hip", None), ("mmx_comm.hip", None), ("mmx_host_tables.cpp", None)):
+        assert mbuild._extra_flags(src, g) == []
+    text = open(os.path.join(os.path.dirname(mbuild.__file__), "csrc", "mmx_fused.hip")).read()
+    groups = {int(g) for g in re.findall(r"MMX_FUSED_GROUP == (\d+)", text)} - {9}  # (9: the one-instantiation compile probe)
+    assert groups == set(range(mbuild.FUSED_GROUPS))
