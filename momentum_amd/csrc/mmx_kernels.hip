@@ -2684,7 +2684,10 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
     float w = 0.f;
     for (int i = tid; i < n; i += 256) {
       const float hd = Hd[size_t(tileIndex(i >> 4, i >> 4)) * 256 + (i & 15) * 17] + lambda;
-      w = fmaxf(w, kPivotFloor * hd * t.invDiag[i] * t.invDiag[i]);
+      // (a column the pivot floor DROPPED leaves 1 / l_jj = 0 here: its pivot ratio is at or below kPivotFloor, i.e. w >= 1 --
+      // without this an element whose only small pivots were dropped reported ratio 1 and went unmarked; the one-launch solve
+      // counts such columns because it reads the unguarded 1 / l_jj)
+      w = fmaxf(w, t.invDiag[i] > 0.f ? kPivotFloor * hd * t.invDiag[i] * t.invDiag[i] : 1.f);
     }
     w = waveReduceMaxF(w);
     if ((tid & 63) == 0) {
@@ -3026,7 +3029,7 @@ __global__ void __launch_bounds__(64 * kW, kW == 8 ? 4 : 2) choleskyFactorReside
   if (sp.diagAcc != nullptr) { // the precision estimate's input: the largest kPivotFloor (H_jj + mu) / d_jj of this factorisation
     float w = 0.f;
     for (int i = tid; i < n; i += 64 * kW) {
-      w = fmaxf(w, floorAll[i] * invDiag[i] * invDiag[i]);
+      w = fmaxf(w, invDiag[i] > 0.f ? floorAll[i] * invDiag[i] * invDiag[i] : 1.f); // (a dropped column -- 1 / l_jj = 0 -- counts as a pivot ratio at the floor)
     }
     w = waveReduceMaxF(w);
     if (lane == 0) {

@@ -134,3 +134,40 @@ def test_build_recipe_flags_per_translation_unit():
     text = open(os.path.join(os.path.dirname(mbuild.__file__), "csrc", "mmx_fused.hip")).read()
     groups = {int(g) for g in re.findall(r"MMX_FUSED_GROUP == (\d+)", text)} - {9}  # (9: the one-instantiation compile probe)
     assert groups == set(range(mbuild.FUSED_GROUPS))
+
+
+def test_production_instantiations_do_not_spill():
+    """The RESULT the recipe's two -mllvm switches exist for, not the flag list: the three production instantiations of the
+    one-launch solve (BASELINE configs[1]'s six blocks: plain Gauss-Newton, LM schedule, generic rule), compiled the way
+    build.py compiles them on this toolchain (scripts/probes/fused_one.sh), keep at most 8 spilled vector registers at 128
+    registers = four workgroups per CU.  A ROCm that drops, renames or re-tunes either switch fails HERE instead of silently
+    giving the speed back (default pipeline: 54 / 354 spilled, 6-13 % slower; profiles/r05_exp_fused.txt item 14).  When the
+    compiler rejects the switches build.py falls back to the default pipeline and says so in build_info.json: the test then
+    checks that the stamp admits it."""
+    import json
+    from concurrent.futures import ThreadPoolExecutor
+
+    from momentum_amd import build as mbuild
+
+    flags = mbuild.SOLVE_KERNEL_FLAGS if mbuild.solve_flags_accepted() else []
+    probe = os.path.join(ROOT, "scripts", "probes", "fused_one.sh")
+
+    def one(rule):
+        out = subprocess.run(["bash", probe, f"-DMMX_PROBE_RULE={rule}"] + flags, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900).stdout.decode()
+        m = re.search(r"VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+)", out, flags=re.S)  # (the first kernel listed: the solve)
+        assert m, out
+        return rule, tuple(int(x) for x in m.groups())
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        got = dict(ex.map(one, (0, 1, -1)))
+    info = mbuild.build_info()
+    if not flags:
+        assert info.get("solve_kernel_pipeline") == "default", info
+        pytest.skip(f"hipcc rejects {mbuild.SOLVE_KERNEL_FLAGS}: default pipeline (stamped), figures {got}")
+    for rule, (vgprs, occ, sspill, vspill) in got.items():
+        assert vgprs <= 128 and occ == 4, (rule, got)
+        assert vspill <= 8, (rule, got)
+        assert sspill <= 320, (rule, got)
+    if os.path.exists(mbuild.LIB) and info:
+        assert info.get("solve_kernel_pipeline") == "no-machine-licm,no-lsr", info
+        json.dumps(info)

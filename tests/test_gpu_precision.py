@@ -188,3 +188,30 @@ def test_step_history_obeys_the_schedule_and_follows_the_double_run(torch_cuda, 
         assert res["num_above_bound_with_same_decisions"] == 0 and res["max_rel_same_decisions"] <= BOUND, res
     with pytest.raises(capi.MmxError):  # the fixed-lambda rule has no schedule to record
         _solve(torch_cuda, pb, th0, GnOptions.make(min_iterations=2, max_iterations=2), want_step_history=True)
+
+
+@pytest.mark.parametrize("lam", [1e-7, 1e-9])
+def test_rank_deficient_elements_are_marked_on_both_routes(torch_cuda, lam):
+    """An element whose small pivots were DROPPED by the pivot floor (1 / l_jj = 0) must still be marked: the wide route's factor
+    kernels used to skip such columns in the precision estimate (ratio 1, estimate 5e-9: neither MMX_SOLVE_PRECISION_SUSPECT nor
+    an escalation), while the one-launch solve counted them.  BASELINE configs[0]'s chain (nine rows for 31 parameters: 22 null
+    directions) with a damping far below the rounding of H: every element is marked on either route, the estimates agree in
+    magnitude, and MMX_PRECISION_AUTO escalates every one."""
+    rig = make_test_character(24)
+    B = 128
+    cons, th0, _ = make_problem(rig, [23, 12, 5], [], B, seed=4242, perturb=0.3)
+    pb = _problem(torch_cuda, rig, cons, B)
+    opt = GnOptions.make(min_iterations=4, max_iterations=4, threshold=1.0, regularization=lam)
+    est = {}
+    for route in ("fused", "wide"):
+        pb.set_route(route)
+        out = _solve(torch_cuda, pb, th0, opt)
+        assert np.all(out["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0), (route, int((out["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0).sum()))
+        diag = pb.solve_diagnostics().cpu().numpy()
+        assert np.all(diag[:, 0] > BOUND) and np.all(diag[:, 1] < 1.0 / 2000.0), (route, diag[:, :2].min(axis=0), diag[:, :2].max(axis=0))
+        est[route] = diag[:, 1]
+        a = _solve(torch_cuda, pb, th0, GnOptions.make(min_iterations=4, max_iterations=4, threshold=1.0, regularization=lam, precision=MMX_PRECISION_AUTO))
+        assert np.all(a["status"] & MMX_SOLVE_ESCALATED_F64 != 0), route
+    # the same class bound from either route (the pivot ratio is a property of the problem class: within a decade)
+    r = np.median(est["wide"]) / np.median(est["fused"])
+    assert 0.1 <= r <= 10.0, (np.median(est["wide"]), np.median(est["fused"]))
