@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 10 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
+#define MMX_ABI_VERSION 11 /* 6: per-instance characters and constraint parents, MMX_STEP_TRUST_REGION (+ mmx_gn_options::
                              trust_region_radius), mmx_comm_* (RCCL), MMX_LIMIT_MINMAX_JOINT_PASSIVE, row-major J
                              7: mmx_tuning / mmx_problem_set_tuning / mmx_problem_last_route (replace the MMX_* environment
                              switches of earlier builds: the library reads no environment variable on the solve path)
@@ -49,6 +49,11 @@ extern "C" {
                                 status bits MMX_SOLVE_PRECISION_SUSPECT / MMX_SOLVE_ESCALATED_F64, MMX_SOLVE_FAILED(),
                                 mmx_solve_with_step_history (damping and gain ratio per iteration of the LM schedule),
                                 mmx_problem_solve_diagnostics.
+                             11: MMX_PRECISION_MIXED (double forward kinematics / residuals / g = J^T r / linear-solve
+                                residual around the single-precision factor: the double instantiation's answers at close to
+                                the single-precision rate), which is also what MMX_PRECISION_AUTO now escalates to where it
+                                applies; status bit MMX_SOLVE_MIXED; mmx_tuning grows mixed_tolerance / mixed_max_cg out of
+                                its reserved words (same size).
                              A caller MUST compare mmx_abi_version() with the MMX_ABI_VERSION it was compiled against
                              before any other call: the structs below grow at their end from version to version. */
 #define MMX_PARAMS_PER_JOINT 7 /* momentum/character/types.h:21 */
@@ -109,6 +114,10 @@ typedef enum mmx_status {
 #define MMX_SOLVE_ESCALATED_F64 16 /* (bit, informational, ABI 10) MMX_PRECISION_AUTO: this element's result comes from the
                                       double instantiation (its other status bits are that run's, plus the
                                       MMX_SOLVE_PRECISION_SUSPECT that sent it there) */
+#define MMX_SOLVE_MIXED 32 /* (bit, informational, ABI 11) this element's result comes from the mixed-precision instantiation
+                              (MMX_PRECISION_MIXED, or MMX_PRECISION_AUTO's second pass).  With it, MMX_SOLVE_PRECISION_SUSPECT
+                              means that some iteration's conjugate gradients ran into mixed_max_cg before they met
+                              mixed_tolerance (the single-precision factor was no preconditioner any more: cond x eps ~ 1). */
 #define MMX_SOLVE_ERROR_MASK 3 /* (status & MMX_SOLVE_ERROR_MASK) == 0: the solve of that element is sound.  Mind the
                                   parentheses: in C `status & MMX_SOLVE_ERROR_MASK == 0` parses as status & (3 == 0). */
 #define MMX_SOLVE_FAILED(status) (((status) & MMX_SOLVE_ERROR_MASK) != 0)
@@ -121,7 +130,21 @@ typedef enum mmx_status {
                                 failed) are compacted and solved again in double from the initial parameters, on the same
                                 stream, without a host round trip.  The batched driver's defaults (lambda = 0.01,
                                 pymomentum/tensor_ik/solver_options.h:28-37) on marginally determined problems are where this
-                                matters (profiles/r05_weak_damping.json). */
+                                matters (profiles/r05_weak_damping.json).  ABI 11: the second pass is the
+                                mixed-precision instantiation wherever that applies (MMX_SOLVE_MIXED instead of
+                                MMX_SOLVE_ESCALATED_F64), and a problem class the FIRST factorisation already marks leaves the
+                                single-precision pass at once (no ten iterations thrown away). */
+#define MMX_PRECISION_MIXED 3 /* (ABI 11) one launch per solve like MMX_PRECISION_F32, with everything the answer's digits
+                                 depend on in double: theta, forward kinematics, residual rows, g = J^T r and the residual of
+                                 the linear solve -- all O(joints + constraints) tree passes -- while H = J^T J, its Cholesky
+                                 factor and the triangular solves stay single precision and act as the preconditioner of a
+                                 conjugate-gradient iteration whose operator is applied in double through the tree (classic
+                                 mixed-precision iterative refinement; accurate while cond(J^T J + lambda I) x 6e-8 < 1).
+                                 Follows GaussNewtonSolverT<double> (momentum/solver/gauss_newton_solver.cpp:315-316) to ~1e-7
+                                 on theta -- at the batched driver's lambda = 0.01 and far below -- at a multiple of the double
+                                 instantiation's rate.  Scope: the one-launch route's problems (up to 128 solved parameters,
+                                 256 joints) with position / orientation constraints, every step rule but the trust region;
+                                 anything else is solved by the double instantiation (MMX_SOLVE_ESCALATED_F64). */
 
 /* Where the caller's bulk arrays live. */
 #define MMX_MEM_HOST 0
@@ -472,7 +495,12 @@ typedef struct mmx_tuning {
                                    solve (each measures its residual through J itself): 0 = the default, up to three (a
                                    further one only while the last correction exceeded 1e-3 of the step); 1..3 = at most
                                    that many; -1 = none (a measurement switch: north_star's 1e-5 needs the refinement) */
-  int32_t reserved[6]; /* must be zero */
+  float mixed_tolerance; /* (ABI 11) MMX_PRECISION_MIXED: the conjugate gradients of an iteration stop when the predicted size of
+                            the next correction falls below this fraction of the step (0 = the default, 1e-9: north_star's 1e-5
+                            then holds on every element whose double run amplifies a 1e-12 perturbation by less than 1e5; 1e-7
+                            costs 15 % less and holds it where the amplification stays below 1e2) */
+  int32_t mixed_max_cg; /* ... and after at most this many operator applications (0 = the default, 12) */
+  int32_t reserved[4]; /* must be zero */
 } mmx_tuning;
 int32_t mmx_problem_set_tuning(mmx_problem* problem, const mmx_tuning* tuning);
 /* MMX_ROUTE_* the last mmx_solve / mmx_solve_with_history on this handle took (MMX_ROUTE_AUTO before the first). */

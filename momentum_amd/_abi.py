@@ -14,14 +14,15 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-MMX_ABI_VERSION = 10
+MMX_ABI_VERSION = 11
 MMX_OK = 0
 MMX_SOLVE_OK, MMX_SOLVE_NONFINITE, MMX_SOLVE_NOT_PD = 0, 1, 2
 MMX_SOLVE_DAMPING_FLOORED = 4  # informational bit of status[] (include/mmx.h)
 MMX_SOLVE_PRECISION_SUSPECT = 8  # informational: the single-precision solve's precision estimate exceeds options.precision_bound
 MMX_SOLVE_ESCALATED_F64 = 16  # informational: MMX_PRECISION_AUTO re-solved the element in double
+MMX_SOLVE_MIXED = 32  # informational: the element was solved by the mixed-precision instantiation (MMX_PRECISION_MIXED / AUTO)
 MMX_SOLVE_ERROR_MASK = 3
-MMX_PRECISION_F32, MMX_PRECISION_F64, MMX_PRECISION_AUTO = 0, 1, 2
+MMX_PRECISION_F32, MMX_PRECISION_F64, MMX_PRECISION_AUTO, MMX_PRECISION_MIXED = 0, 1, 2, 3
 MMX_MEM_HOST, MMX_MEM_DEVICE = 0, 1
 MMX_LAYOUT_COL_MAJOR, MMX_LAYOUT_ROW_MAJOR = 0, 1
 MMX_STEP_GN_FIXED_LAMBDA, MMX_STEP_LM_SCHEDULE, MMX_STEP_TRUST_REGION = 0, 1, 2
@@ -326,7 +327,7 @@ ROUTES = {"auto": 0, "fused": 1, "wide": 2, "explicit_jacobian": 3}  # MMX_ROUTE
 class Tuning(C.Structure):
     """mmx_tuning: which kernels mmx_solve runs (include/mmx.h)."""
 
-    _fields_ = [("route", C.c_int32), ("max_refinement_steps", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("route", C.c_int32), ("max_refinement_steps", C.c_int32), ("mixed_tolerance", C.c_float), ("mixed_max_cg", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 def as_ptr(a: np.ndarray, ctype):

@@ -18,7 +18,7 @@ VARIANT = os.environ.get("MMX_BUILD_VARIANT", "")
 VARIANT_FLAGS = os.environ.get("MMX_BUILD_FLAGS", "").split() if VARIANT else []
 LIB = os.path.join(HERE, f"libmmx_hip_{VARIANT}.so" if VARIANT else "libmmx_hip.so")
 SOURCES = ["mmx_kernels.hip", "mmx_fused.hip", "mmx_capi.hip", "mmx_comm.hip", "mmx_f64.hip", "mmx_host_tables.cpp"]
-FUSED_GROUPS = 5  # mmx_fused.hip is compiled once per group of template instantiations, in parallel (4: the wide route's tree kernels)
+FUSED_GROUPS = 7  # mmx_fused.hip is compiled once per group of template instantiations, in parallel (4: the wide route's tree kernels; 5, 6: the mixed-precision instantiations)
 # The solve kernels (one-launch solve, double solve) are compiled WITHOUT the machine-level loop-invariant code motion and
 # WITHOUT loop strength reduction: at their register budgets the per-lane address arithmetic the first hoists out of the
 # iteration loop and the induction pointers the second creates are what gets spilled.  Spilled VGPRs of the BASELINE
@@ -80,7 +80,7 @@ def build_info() -> dict:
             return json.load(f)
     except (OSError, ValueError):
         return {}
-HEADERS = ["mmx_device.hpp", "mmx_kernels.hpp", "mmx_tree.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
+HEADERS = ["mmx_device.hpp", "mmx_device_d.hpp", "mmx_kernels.hpp", "mmx_tree.hpp", "mmx_host_tables.hpp", os.path.join("..", "..", "include", "mmx.h")]
 ARCH = "gfx950"
 
 

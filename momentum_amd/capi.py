@@ -296,7 +296,14 @@ class Problem:
         t = _abi.Tuning()
         t.route = _abi.ROUTES[route]
         t.max_refinement_steps = int(max_refinement_steps)  # 0 default (up to three), -1 none, 1..3
+        t.mixed_tolerance, t.mixed_max_cg = getattr(self, "_mixed", (0.0, 0))  # MMX_PRECISION_MIXED: 0 = defaults (1e-7, 12)
+        self._route_args = (route, int(max_refinement_steps))
         _check(lib().mmx_problem_set_tuning(self._h, C.byref(t)))
+
+    def set_mixed(self, tolerance: float = 0.0, max_cg: int = 0) -> None:
+        """mmx_tuning::mixed_tolerance / mixed_max_cg (MMX_PRECISION_MIXED); the route setting is kept."""
+        self._mixed = (float(tolerance), int(max_cg))
+        self._set_tuning(*getattr(self, "_route_args", ("auto", 0)))
 
     def last_route(self) -> str:
         r = int(lib().mmx_problem_last_route(self._h))

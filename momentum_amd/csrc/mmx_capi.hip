@@ -230,6 +230,7 @@ struct mmx_problem {
   DevBuf sDiagAcc; // [B][4] the wide route's accumulators behind it (mmx::StepParams::diagAcc)
   bool diagValid = false;
   DevBuf sThetaAuto, sAutoMap, sAutoCount; // MMX_PRECISION_AUTO: initial parameters, the elements to escalate, their number
+  bool autoAbort = false; // ... its single-precision pass may leave a marked element after the first factorisation
   mmx_tuning tuning{}; // mmx_problem_set_tuning
   int32_t lastRoute = MMX_ROUTE_AUTO;
 };
@@ -1212,7 +1213,7 @@ int32_t mmx_rig_create(const mmx_rig_desc* d, int32_t device, mmx_rig** out) {
   UP(r->dJumpParent, jumpParent);
   // records of the non-empty transform rows (RigDev::ptRowRec)
   std::vector<int32_t> rowRec;
-  if (R < 65536) {
+  if (R < 65536 && r->P <= 65535) { // (every field of a record is an unsigned 16-bit number: row, rows to the next record, first column, entries)
     std::vector<int32_t> rows;
     for (int32_t row = 0; row < R; ++row) {
       if (r->ptOuter[row + 1] > r->ptOuter[row]) {
@@ -1221,7 +1222,11 @@ int32_t mmx_rig_create(const mmx_rig_desc* d, int32_t device, mmx_rig** out) {
     }
     for (size_t t = 0; t < rows.size(); ++t) {
       const int32_t row = rows[t], next = t + 1 < rows.size() ? rows[t + 1] : R;
-      const int32_t k0 = r->ptOuter[row], cnt = std::min(r->ptOuter[row + 1] - k0, 65535);
+      const int32_t k0 = r->ptOuter[row], cnt = r->ptOuter[row + 1] - k0;
+      if (cnt > 65535 || next - row > 65535) { // (does not fit: no records at all, the kernels walk the CSR)
+        rowRec.clear();
+        break;
+      }
       int32_t bits = 0;
       std::memcpy(&bits, &r->ptValue[k0], 4);
       rowRec.insert(rowRec.end(), {row | ((next - row) << 16), r->ptInner[k0] | (cnt << 16), bits, k0});
@@ -1368,6 +1373,9 @@ int32_t mmx_problem_set_tuning(mmx_problem* pb, const mmx_tuning* tuning) {
   }
   if (tuning->max_refinement_steps < -1 || tuning->max_refinement_steps > 3) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_tuning::max_refinement_steps: -1 (none), 0 (default) or 1..3");
+  }
+  if (!(tuning->mixed_tolerance >= 0.f) || tuning->mixed_tolerance > 1e-2f || tuning->mixed_max_cg < 0 || tuning->mixed_max_cg > 64) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "mmx_tuning::mixed_tolerance: 0 (default) or (0, 1e-2]; mixed_max_cg: 0 (default) or 1..64");
   }
   for (int32_t r : tuning->reserved) {
     if (r != 0) {
@@ -2125,6 +2133,112 @@ static int32_t solveF64Impl(
     const mmx::F64Select& select,
     void* stream);
 
+// MMX_PRECISION_MIXED (and MMX_PRECISION_AUTO's second pass): does the mixed-precision instantiation of the one-launch solve
+// take this problem with these options?  Position / orientation constraints only, no parameter-space rows, not the trust region,
+// the route not pinned away from the one-launch solve.
+static bool mixedUsable(const mmx_problem* pb, const mmx_gn_options* o) {
+  if (o == nullptr || pb == nullptr || pb->rig == nullptr) {
+    return false;
+  }
+  const int32_t route = pb->tuning.route;
+  return (route == MMX_ROUTE_AUTO || route == MMX_ROUTE_FUSED) && o->step_rule != MMX_STEP_TRUST_REGION && pb->fdev.GT == 0 && pb->dev.M == pb->dev.rowsJoint &&
+      pb->U > 0 && pb->fdev.n > 0 && fusedUsable(pb) &&
+      mmx::fusedMixedUsable(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.numCells);
+}
+
+static int32_t solveMixedImpl(
+    mmx_problem* pb,
+    const mmx_gn_options* o,
+    float* theta_dev,
+    double* final_error,
+    int32_t* iterations,
+    int32_t* status,
+    double* error_history,
+    float* parameter_history,
+    double* step_history,
+    const mmx::MixSelect& sel,
+    void* stream) {
+  MMX_ZONE("mmx_solve, mixed precision (SolverT<double>::solve around a single-precision factor)");
+  if (o->max_iterations < 0 || o->min_iterations < 0) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "iteration counts must be >= 0");
+  }
+  if (o->step_rule != MMX_STEP_GN_FIXED_LAMBDA && o->step_rule != MMX_STEP_LM_SCHEDULE) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown step_rule");
+  }
+  if (o->do_line_search != MMX_LINE_SEARCH_NONE && o->do_line_search != MMX_LINE_SEARCH_GAUSS_NEWTON && o->do_line_search != MMX_LINE_SEARCH_DIRECTIONAL) {
+    return fail(MMX_ERR_INVALID_ARGUMENT, "unknown do_line_search rule");
+  }
+  const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool escalation = sel.map != nullptr; // (the single-precision pass's outputs stay for the other elements)
+  pb->lastRoute = MMX_ROUTE_FUSED;
+  MMX_HIP(pb->sIters.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
+  MMX_HIP(pb->sFinalErr.ensure(B * sizeof(double)));
+  mmx::SolveStateDev fst{};
+  fst.iterations = iterations != nullptr ? iterations : pb->sIters.as<int32_t>();
+  fst.status = status != nullptr ? status : pb->sStatus.as<int32_t>();
+  fst.finalError = final_error != nullptr ? final_error : pb->sFinalErr.as<double>();
+  fst.errorHistory = error_history;
+  fst.paramHistory = parameter_history;
+  fst.stepHistory = step_history;
+  if (!escalation) {
+    MMX_HIP(pb->sDiag.ensure(B * 4 * sizeof(float)));
+    fst.diag = pb->sDiag.as<float>();
+    pb->diagValid = true;
+    if (step_history != nullptr && o->max_iterations > 0) {
+      MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
+    }
+    if (error_history != nullptr && o->max_iterations > 0) {
+      MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+    }
+    if (parameter_history != nullptr && o->max_iterations > 0) {
+      MMX_HIP(hipMemsetAsync(parameter_history, 0, B * size_t(o->max_iterations) * P * sizeof(float), s));
+    }
+  }
+  fst.precisionBound = o->precision_bound > 0.f ? o->precision_bound : 1e-5f;
+  mmx::FusedParams fp{};
+  fp.lambda = o->regularization;
+  fp.threshold = o->threshold;
+  fp.minIterations = o->min_iterations;
+  fp.maxIterations = o->max_iterations;
+  fp.refine = 0;
+  fp.doLineSearch = o->do_line_search;
+  fp.stepRule = o->step_rule;
+  fp.lmLambdaMin = o->lm_lambda_min;
+  fp.lmLambdaMax = o->lm_lambda_max;
+  fp.lmUp = o->lm_up;
+  fp.lmDown = o->lm_down;
+  fp.trustRadius = 1.f;
+  fp.mixTol = pb->tuning.mixed_tolerance > 0.f ? pb->tuning.mixed_tolerance : 1e-9f;
+  fp.mixMaxCg = pb->tuning.mixed_max_cg > 0 ? pb->tuning.mixed_max_cg : 12;
+  long long* clk = nullptr;
+  if (phaseClocksWanted()) { // profiling aid: per-phase cycles of block 0
+    MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
+    MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
+    clk = pb->sClk.as<long long>();
+  }
+  MMX_HIP(mmx::launchFusedMixed(pb->rigDev, pb->dev, pb->fdev, theta_dev, fst, fp, sel, pb->B, clk, s));
+  if (clk != nullptr) {
+    long long h[32];
+    MMX_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, s));
+    MMX_HIP(hipStreamSynchronize(s));
+    static const char* names[24] = {"-", "A-C fk + units (double)", "(reused state)", "D subtree sums", "E srcTables", "F g (double adjoint)",
+                                    "G combine + pull", "H cholesky(tail)", "-", "-", "K update",
+                                    "G extras: records", "G term records", "H.bc panel", "H.d mfma", "D own sums", "CG z0 solve + rz",
+                                    "CG operator (double)", "CG decide + direction", "CG dots + update", "CG solve", "G extras: loads", "H.b load+barrier", "H.b chain"};
+    long long tot = 0;
+    for (int i = 0; i < 24; ++i) {
+      tot += h[i];
+    }
+    fprintf(stderr, "[mmx phase clocks, MIXED, block 0, all iterations] total %lld\n", tot);
+    for (int i = 0; i < 24; ++i) {
+      fprintf(stderr, "  %-26s %10lld  %5.1f%%\n", names[i], h[i], 100.0 * double(h[i]) / double(tot > 0 ? tot : 1));
+    }
+  }
+  return MMX_OK;
+}
+
 // mmx_gn_options::precision: the single-precision routes, the double instantiation on float parameters, or the first
 // followed by the second on the elements it marked
 static int32_t solveImpl(
@@ -2141,7 +2255,7 @@ static int32_t solveImpl(
   if (o == nullptr || o->precision == MMX_PRECISION_F32) {
     return solveF32Impl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, step_history, stream);
   }
-  if (o->precision != MMX_PRECISION_F64 && o->precision != MMX_PRECISION_AUTO) {
+  if (o->precision != MMX_PRECISION_F64 && o->precision != MMX_PRECISION_AUTO && o->precision != MMX_PRECISION_MIXED) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "unknown precision (MMX_PRECISION_*)");
   }
   int32_t rc = checkProblem(pb, true);
@@ -2151,13 +2265,17 @@ static int32_t solveImpl(
   if (theta_dev == nullptr) {
     return fail(MMX_ERR_INVALID_ARGUMENT, "options / theta is null");
   }
-  if (parameter_history != nullptr) {
-    return fail(MMX_ERR_UNSUPPORTED, "parameter_history is single precision's (MMX_PRECISION_F32): the double instantiation does not record it");
+  const bool mixedOk = mixedUsable(pb, o);
+  if (parameter_history != nullptr && !(o->precision == MMX_PRECISION_MIXED && mixedOk)) {
+    return fail(MMX_ERR_UNSUPPORTED, "parameter_history is single precision's (MMX_PRECISION_F32) and the mixed-precision instantiation's: the double instantiation does not record it");
   }
   const size_t B = size_t(pb->B), P = size_t(pb->rig->P);
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (o->precision == MMX_PRECISION_F64) {
+  if (o->precision == MMX_PRECISION_MIXED && mixedOk) {
+    return solveMixedImpl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, step_history, mmx::MixSelect{nullptr, nullptr, nullptr}, stream);
+  }
+  if (o->precision == MMX_PRECISION_F64 || o->precision == MMX_PRECISION_MIXED) { // (MIXED outside the mixed instantiation's scope: the double one)
     // every workgroup reads its element's parameters before it writes them: in place on the caller's float array
     return solveF64Impl(pb, o, nullptr, final_error, iterations, status, error_history, step_history, mmx::F64Select{nullptr, nullptr, theta_dev, theta_dev}, stream);
   }
@@ -2167,13 +2285,26 @@ static int32_t solveImpl(
   MMX_HIP(pb->sStatus.ensure(B * sizeof(int32_t)));
   MMX_HIP(hipMemcpyAsync(pb->sThetaAuto.p, theta_dev, B * P * sizeof(float), hipMemcpyDeviceToDevice, s));
   int32_t* st = status != nullptr ? status : pb->sStatus.as<int32_t>();
+  pb->autoAbort = mixedOk; // (the single-precision pass leaves a class its first factorisation marks: the second pass starts over anyway)
   rc = solveF32Impl(pb, o, theta_dev, final_error, iterations, st, error_history, nullptr, step_history, stream);
+  pb->autoAbort = false;
   if (rc != MMX_OK) {
     return rc;
   }
   // a solve without the estimate (explicit-Jacobian route, the wide route's host-driven trust region): the cue stays the damping floor
   const int32_t mask = MMX_SOLVE_ERROR_MASK | MMX_SOLVE_PRECISION_SUSPECT | (pb->diagValid ? 0 : MMX_SOLVE_DAMPING_FLOORED);
   MMX_HIP(mmx::launchSelectSuspect(st, pb->B, mask, pb->sAutoMap.as<int32_t>(), pb->sAutoCount.as<int32_t>(), s));
+  if (mixedOk) { // the marked elements again, from the initial parameters, by the mixed-precision instantiation ...
+    rc = solveMixedImpl(
+        pb, o, theta_dev, final_error, iterations, st, error_history, nullptr, step_history,
+        mmx::MixSelect{pb->sAutoMap.as<int32_t>(), pb->sAutoCount.as<int32_t>(), pb->sThetaAuto.as<float>()}, stream);
+    if (rc != MMX_OK) {
+      return rc;
+    }
+    // ... and the ones whose conjugate gradients ran into the step limit there (the single-precision factor is no preconditioner
+    // any more: cond x eps ~ 1 -- BASELINE configs[1] at lambda = 1e-5) or that failed, by the double instantiation
+    MMX_HIP(mmx::launchSelectSuspect(st, pb->B, MMX_SOLVE_ERROR_MASK | MMX_SOLVE_PRECISION_SUSPECT, pb->sAutoMap.as<int32_t>(), pb->sAutoCount.as<int32_t>(), s, MMX_SOLVE_MIXED));
+  }
   return solveF64Impl(
       pb, o, nullptr, final_error, iterations, st, error_history, step_history,
       mmx::F64Select{pb->sAutoMap.as<int32_t>(), pb->sAutoCount.as<int32_t>(), pb->sThetaAuto.as<float>(), theta_dev}, stream);
@@ -2279,6 +2410,7 @@ static int32_t solveF32Impl(
     fp.lmUp = o->lm_up;
     fp.lmDown = o->lm_down;
     fp.trustRadius = o->trust_region_radius > 0.f ? o->trust_region_radius : 1.f;
+    fp.autoAbort = pb->autoAbort ? 1 : 0;
     long long* clk = nullptr;
     if (phaseClocksWanted()) { // profiling aid: per-phase cycles of block 0
       MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));

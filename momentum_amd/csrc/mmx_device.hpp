@@ -447,7 +447,8 @@ __device__ __forceinline__ void fkComposeD(const FkXf& p, FkXf& x) {
   x.s = p.s * x.s;
   x.jl = p.jl;
 }
-__device__ __forceinline__ void fkJumpRoundsD(float* js, double* bufA, double* bufB, int J, int rounds, int tid, int nthreads) {
+template <class T, int kStride = kJs> // T: what the joint states are stored as (float; double in the mixed-precision solve)
+__device__ __forceinline__ void fkJumpRoundsT(T* js, double* bufA, double* bufB, int J, int rounds, int tid, int nthreads) {
   const int Jp = fkPad(J);
   for (int r = 0; r < rounds; ++r) {
     const double* src = (r & 1) ? bufB : bufA;
@@ -461,16 +462,19 @@ __device__ __forceinline__ void fkJumpRoundsD(float* js, double* bufA, double* b
         fkComposeD(p, x);
       }
       if (last) {
-        float* w = js + kJs * j;
-        w[0] = float(x.tx), w[1] = float(x.ty), w[2] = float(x.tz);
-        w[3] = float(x.qx), w[4] = float(x.qy), w[5] = float(x.qz), w[6] = float(x.qw);
-        w[7] = float(x.s);
+        T* w = js + kStride * j;
+        w[0] = T(x.tx), w[1] = T(x.ty), w[2] = T(x.tz);
+        w[3] = T(x.qx), w[4] = T(x.qy), w[5] = T(x.qz), w[6] = T(x.qw);
+        w[7] = T(x.s);
       } else {
         fkStoreD(dst, Jp, j, x);
       }
     }
     __syncthreads();
   }
+}
+__device__ __forceinline__ void fkJumpRoundsD(float* js, double* bufA, double* bufB, int J, int rounds, int tid, int nthreads) {
+  fkJumpRoundsT<float, kJs>(js, bufA, bufB, J, rounds, tid, nthreads);
 }
 
 // the seven joint parameters of a joint from its two-slot ELL transform rows (in registers) and theta

@@ -26,6 +26,7 @@
 // tests/tree_algebra_np.py / tests/test_tree_algebra.py.
 #include "mmx_device.hpp"
 #include "mmx_kernels.hpp"
+#include "mmx_mixed.hpp"
 #include "mmx_tree.hpp"
 
 #include <cfloat>
@@ -142,7 +143,7 @@ __device__ __forceinline__ void firstOrderMoments(float* o, F3 p, float yx, floa
 }
 
 // NCH channels per unit (kC1 first-order, then kC2Used second-order ones), stored with stride STRIDE (odd)
-template <int NCH, int STRIDE, int kT = 256, class FV = FusedView>
+template <int NCH, int STRIDE, int kT = 256, class FV = FusedView, bool kSecondOnly = false>
 __device__ __forceinline__ void gatherOwnSums(const FV& fd, const FusedLds& s, const float* umom, int tid) {
   for (int item = tid; item < fd.numLoaded * NCH; item += kT) {
     const int li = item / NCH, c = item - li * NCH;
@@ -152,7 +153,9 @@ __device__ __forceinline__ void gatherOwnSums(const FV& fd, const FusedLds& s, c
     for (int e = fd.posUnitStart[k]; e < e1; ++e) {
       acc += umom[STRIDE * fd.posUnits[e] + c];
     }
-    if (c < kC1) {
+    if (kSecondOnly) { // (the channels are the second-order ones only)
+      s.own2[kC2 * k + c] = acc;
+    } else if (c < kC1) {
       s.own1[kC1 * k + c] = acc;
     } else {
       s.own2[kC2 * k + (c - kC1)] = acc;
@@ -162,17 +165,22 @@ __device__ __forceinline__ void gatherOwnSums(const FV& fd, const FusedLds& s, c
 constexpr int kUmom = 25; // stride of the per-unit moment scratch: 7 + 16 channels, odd
 
 // phase D: first- and second-order own sums from up / uy / us
-template <int kT = 256, class FV = FusedView>
-__device__ __forceinline__ void ownSums(const FV& fd, const FusedLds& s, float* umom, int U, int tid) {
-  constexpr int NCH = kC1 + kC2Used;
+// kSecondOnly: the second-order channels only (the mixed-precision solve: g = J^T r is formed in double, mmx_mixed.hpp; uy is
+// not read)
+// (upD / usD: the units' vectors and weights in double, rounded here -- the mixed route keeps no single-precision copies)
+template <int kT = 256, class FV = FusedView, bool kSecondOnly = false>
+__device__ __forceinline__ void ownSums(const FV& fd, const FusedLds& s, float* umom, int U, int tid, const double* upD = nullptr, const double* usD = nullptr) {
+  constexpr int NCH = kSecondOnly ? kC2Used : kC1 + kC2Used;
   for (int u = tid; u < U; u += kT) {
-    const F3 p{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
+    const F3 p = kSecondOnly ? F3{float(upD[3 * u]), float(upD[3 * u + 1]), float(upD[3 * u + 2])} : F3{s.up[3 * u], s.up[3 * u + 1], s.up[3 * u + 2]};
     const bool point = u < fd.Kp;
     float* o = umom + kUmom * u;
-    firstOrderMoments(o, p, s.uy[3 * u], s.uy[3 * u + 1], s.uy[3 * u + 2], point);
-    const float sg = s.us[u];
+    if (!kSecondOnly) {
+      firstOrderMoments(o, p, s.uy[3 * u], s.uy[3 * u + 1], s.uy[3 * u + 2], point);
+    }
+    const float sg = kSecondOnly ? float(usD[u]) : s.us[u];
     const float s2 = sg * sg;
-    float* o2 = o + kC1;
+    float* o2 = kSecondOnly ? o : o + kC1;
 #pragma unroll
     for (int c = 0; c < kC2Used; ++c) {
       o2[c] = 0.f;
@@ -192,7 +200,7 @@ __device__ __forceinline__ void ownSums(const FV& fd, const FusedLds& s, float* 
     }
   }
   __syncthreads();
-  gatherOwnSums<NCH, kUmom, kT, FV>(fd, s, umom, tid);
+  gatherOwnSums<NCH, kUmom, kT, FV, kSecondOnly>(fd, s, umom, tid);
 }
 
 constexpr int kFusedTreeUn = 4; // k-steps per trip of the tree sums (measured on BASELINE configs[1]: 1 -> 1.575e6, 4 -> 1.60e6, 8 -> 1.54e6 solves/s)
@@ -281,7 +289,7 @@ __device__ __forceinline__ void csrRowsPrefetched(const int32_t* outer, const in
     for (int i = 0; i < 4; ++i) {
       const int r = r0 + kT * i;
       if (r < R) {
-        float acc = 0.f;
+        decltype(x(0)) acc = 0; // (float; double in the mixed-precision solve)
         if (kb[i] > ka[i]) {
           acc += v0[i] * x(in0[i]);
           for (int k = ka[i] + 1; k < kb[i]; ++k) {
@@ -352,18 +360,18 @@ template <int kT = 256, typename Gather, typename Store>
 __device__ __forceinline__ void csrRowsFromRecords(const int4* rec, int numRec, const int32_t* inner, const float* value, int R, int tid, Gather x, Store out) {
   for (int t = tid; t < numRec; t += kT) {
     const int4 q = rec[t];
-    const int row = q.x & 0xffff, span = q.x >> 16, in0 = q.y & 0xffff, cnt = q.y >> 16;
-    float acc = __int_as_float(q.z) * x(in0);
+    const int row = q.x & 0xffff, span = int(uint32_t(q.x) >> 16), in0 = q.y & 0xffff, cnt = int(uint32_t(q.y) >> 16); // (unsigned fields: mmx_rig_create builds no records when one would not fit 16 bits)
+    auto acc = __int_as_float(q.z) * x(in0); // (float; double in the mixed-precision solve)
     for (int k = q.w + 1; k < q.w + cnt; ++k) {
       acc += value[k] * x(inner[k]);
     }
     out(row, acc);
     for (int r = row + 1; r < row + span; ++r) {
-      out(r, 0.f);
+      out(r, decltype(acc)(0));
     }
     if (t == 0) {
       for (int r = 0; r < row; ++r) {
-        out(r, 0.f);
+        out(r, decltype(acc)(0));
       }
     }
   }
@@ -452,6 +460,227 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The double passes of the mixed-precision instantiation (kMix; mmx_mixed.hpp has the primitives and the rationale).
+// ---------------------------------------------------------------------------------------------
+// y = transform * x in double: one transform row per thread from the rig's row records, else the prefetching CSR walk
+// (the tables in global memory either way); out(r, value) for every row r < R
+template <typename Gather, typename Store>
+__device__ __forceinline__ void mixTransformRows(const RigView& rig, int tid, Gather x, Store out) {
+  if (rig.rowRec != nullptr) {
+    csrRowsFromRecords<256>(rig.rowRec, rig.numRowRec, rig.ptInner, rig.ptValue, rig.R, tid, x, out);
+  } else {
+    csrRowsPrefetched<256>(rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, x, out);
+  }
+}
+
+// Forward kinematics of `th` (double) into m.js: joint parameters (m.X), local transforms of all joints at once, then the
+// world transforms ONE TREE LEVEL PER BARRIER in the reference's own association order, world_j = world_parent o local_j
+// (skeleton_state.cpp:100-121) -- NOT the pointer jumping of the single-precision kernels: the joints' pre-rotations are
+// float quaternions (|q|^2 = 1 +- 6e-8), and Eigen's q * v (transform.h:124-129) is a homomorphism only for unit quaternions, so
+// a re-associated product of the same transforms differs from the sequential one by ~1e-7 -- invisible in single precision,
+// the largest term left in double (measured: BASELINE configs[1] sat at 1.5e-7 ... 5e-7 of the oracle's double run whatever
+// the CG tolerance, the 24-joint chain with identity pre-rotations at 2.5e-8 = the rounding of the float result).
+// myLevel: the tree level of joint `tid` (one joint per thread, J <= 256); optionally the rotation axes.  Ends with a barrier.
+__device__ __forceinline__ void blockFkD(const RigView& rig, const MixLds& m, const double* th, int tid, int myLevel, bool withAxes) {
+  mixTransformRows(
+      rig, tid, [&](int c) { return th[c]; }, [&](int r, double acc) { m.X[r] = acc + (rig.hasOffsets ? double(rig.ptOffsets[r]) : 0.0); });
+  __syncthreads();
+  double loc[8];
+  const int j = tid;
+  double* slot = m.js + kJsD * (j < rig.J ? j : 0);
+  if (j < rig.J) {
+    fkLocalFromParamsD(m.X + 7 * j, rig.preRot + 4 * j, rig.offset + 3 * j, loc, slot + 8);
+    if (myLevel == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        slot[c] = loc[c];
+      }
+    }
+  }
+  __syncthreads();
+  for (int lvl = 1; lvl < rig.numLevels; ++lvl) {
+    if (j < rig.J && myLevel == lvl) {
+      const double* w = m.js + kJsD * rig.parent[j];
+      const DQ qp{w[3], w[4], w[5], w[6]};
+      const D3 t = D3{w[0], w[1], w[2]} + dqrot(qp, w[7] * D3{loc[0], loc[1], loc[2]}); // transform.h:124-129
+      const DQ q = dqmul(qp, DQ{loc[3], loc[4], loc[5], loc[6]});
+      slot[0] = t.x, slot[1] = t.y, slot[2] = t.z, slot[3] = q.x, slot[4] = q.y, slot[5] = q.z, slot[6] = q.w, slot[7] = w[7] * loc[7];
+    }
+    __syncthreads();
+  }
+  if (withAxes) {
+    if (j < rig.J) {
+      fkAxesInPlaceD(rig.preRot + 4 * j, j, rig.parent[j], m.js);
+    }
+    __syncthreads();
+  }
+}
+
+// phase C in double: units from the joint states in m.js (stored: m.up / m.uf / m.us); returns this thread's share of the error
+template <bool kStore>
+__device__ __forceinline__ double mixUnits(const ProblemDev& pb, const FusedLds& s, const MixLds& m, int b, int U, int tid) {
+  double e = 0.0;
+  for (int u = tid; u < U; u += 256) {
+    const UnitD un = evalUnitD(pb, loadUnitInput(pb, b, u), m.js, u);
+    if (kStore) {
+      m.up[3 * u] = un.v.x, m.up[3 * u + 1] = un.v.y, m.up[3 * u + 2] = un.v.z;
+      m.uf[3 * u] = un.f.x, m.uf[3 * u + 1] = un.f.y, m.uf[3 * u + 2] = un.f.z;
+      m.us[u] = un.sigma;
+    }
+    e += un.werr;
+  }
+  return e;
+}
+
+// SkeletonSolverFunctionT<double>::getError of `th` (skeleton_solver_function.cpp:64-83: rounded through float, :82); every
+// thread returns the same value.  kStore: also leaves what phases A-C of an iteration would leave (see blockError).
+template <bool kStore>
+__device__ __forceinline__ double blockErrorD(
+    const RigView& rig, const ProblemDev& pb, const FusedLds& s, const MixLds& m, const double* th, int b, int U, int tid, int myLevel, double* unrounded = nullptr) {
+  blockFkD(rig, m, th, tid, myLevel, kStore);
+  double e = mixUnits<kStore>(pb, s, m, b, U, tid);
+  const double tot = blockSumD(s.red, e, tid);
+  if (unrounded != nullptr) {
+    *unrounded = tot;
+  }
+  return double(float(tot));
+}
+
+// Adjoint pass in double: out[c] = (J^T y)_c for the solve columns c < n (0 for the pad columns), y_u = yOf(u, k) the adjoint
+// input of unit u (k: DFS position of its joint).  Own sums per loaded joint (m.X) -> subtree sums (m.Y; the loaded positions
+// inside a subtree are the index range lo..hi of the ascending loadedPos) -> per-slot gradients (m.X) -> columns.
+// Clobbers m.X and m.Y; yOf may read m.Y (the tangent pass's prefixes: consumed before the first barrier).  Ends WITHOUT a barrier.
+template <class FV, typename YFn>
+__device__ __forceinline__ void mixAdjoint(const FV& fd, const FusedLds& s, const MixLds& m, int J, int NP, int n, int nsrc, int tid, YFn yOf, double* out) {
+  for (int li = tid; li < fd.numLoaded; li += 256) {
+    const int k = fd.loadedPos[li];
+    D3 Fv{0.0, 0.0, 0.0}, Nv{0.0, 0.0, 0.0};
+    double Dd = 0.0;
+    const int e1 = fd.posUnitStart[k + 1];
+    for (int e = fd.posUnitStart[k]; e < e1; ++e) {
+      const int u = fd.posUnits[e];
+      const D3 pu{m.up[3 * u], m.up[3 * u + 1], m.up[3 * u + 2]};
+      const D3 y = yOf(u, k, pu);
+      Nv = Nv + dcross(pu, y); // points and directions share the channel (jt_times)
+      if (u < fd.Kp) {
+        Fv = Fv + y;
+        Dd += ddot(pu, y);
+      }
+    }
+    double* o = m.X + 7 * li;
+    o[0] = Fv.x, o[1] = Fv.y, o[2] = Fv.z, o[3] = Nv.x, o[4] = Nv.y, o[5] = Nv.z, o[6] = Dd;
+  }
+  __syncthreads();
+  for (int item = tid; item < 7 * J; item += 256) {
+    const int k = item / 7, c = item - 7 * k;
+    double acc = 0.0;
+    const int l1 = m.hi[k];
+    for (int li = m.lo[k]; li < l1; ++li) {
+      acc += m.X[7 * li + c];
+    }
+    m.Y[7 * k + c] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < nsrc; e += 256) {
+    const int info = s.mInfo[e];
+    m.X[e] = double(s.mW[e]) * sourceGradientD(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, m.js, m.Y + 7 * (s.mTin[e] & 0xffff));
+  }
+  __syncthreads();
+  for (int c = tid; c < NP; c += 256) {
+    double a = 0.0;
+    if (c < n) {
+      a = m.X[c]; // the primary slot, then the extras
+      const int e1 = NP + s.mStart[c + 1];
+      for (int e = NP + s.mStart[c]; e < e1; ++e) {
+        a += m.X[e];
+      }
+    }
+    out[c] = a;
+  }
+}
+
+// Tangent pass in double for the step x (solve columns; xOf(model parameter) -> its entry or 0): joint-parameter step (m.X),
+// per joint C = T - Om x t - ln2 sd t, W = Om, S = sd summed over the ancestor chain by pointer jumping -> m.Y[kTanD k ..]
+// by DFS position k.  J <= 256.  Ends with a barrier.
+template <class FV, typename XFn>
+__device__ __forceinline__ void mixTangent(const RigView& rig, const FV& fd, const MixLds& m, const int16_t* parentPos, int J, int tid, XFn xOf) {
+  mixTransformRows(rig, tid, xOf, [&](int r, double a) { m.X[r] = a; });
+  __syncthreads();
+  double acc[7];
+  int target = -1;
+  if (tid < J) {
+    const int q = fd.dfsJoint[tid];
+    const double* ja = m.js + kJsD * q;
+    const double* d = m.X + 7 * q;
+    const D3 ta{ja[0], ja[1], ja[2]};
+    D3 Tv{0.0, 0.0, 0.0};
+    if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) {
+      const int par = rig.parent[q];
+      Tv = d[0] * transAxisColD(m.js, par, 0) + d[1] * transAxisColD(m.js, par, 1) + d[2] * transAxisColD(m.js, par, 2);
+    }
+    const D3 Om = d[3] * D3{ja[8], ja[9], ja[10]} + d[4] * D3{ja[11], ja[12], ja[13]} + d[5] * D3{ja[14], ja[15], ja[16]};
+    const D3 C = Tv - dcross(Om, ta) - (kLn2D * d[6]) * ta;
+    acc[0] = C.x, acc[1] = C.y, acc[2] = C.z, acc[3] = Om.x, acc[4] = Om.y, acc[5] = Om.z, acc[6] = d[6];
+    target = parentPos[tid];
+    double* o = m.Y + kTanD * tid;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      o[c] = acc[c];
+    }
+    reinterpret_cast<int*>(o + 7)[0] = target;
+  }
+  __syncthreads();
+  for (int r = 0; r < rig.jumpRounds; ++r) {
+    int next = -1;
+    if (target >= 0) {
+      const double* t = m.Y + kTanD * target;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        acc[c] += t[c];
+      }
+      next = reinterpret_cast<const int*>(t + 7)[0];
+    }
+    __syncthreads();
+    if (target >= 0) {
+      double* o = m.Y + kTanD * tid;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        o[c] = acc[c];
+      }
+      reinterpret_cast<int*>(o + 7)[0] = next;
+    }
+    target = next;
+    __syncthreads();
+  }
+}
+
+// q = (J^T S^2 J + mu I) p in double (tangent pass down, adjoint pass up); p, q: [NP] over the solve columns.  Ends with a barrier.
+template <class FV>
+__device__ __forceinline__ void mixApply(
+    const RigView& rig, const FV& fd, const FusedLds& s, const MixLds& m, const int16_t* parentPos, int J, int NP, int n, int nsrc, double mu, const double* p, double* q, int tid) {
+  mixTangent(rig, fd, m, parentPos, J, tid, [&](int c) {
+    const int cs = fd.colToSolve[c];
+    return cs >= 0 ? p[cs] : 0.0;
+  });
+  mixAdjoint(
+      fd, s, m, J, NP, n, nsrc, tid,
+      [&](int u, int k, const D3& pu) {
+        const double* pre = m.Y + kTanD * k;
+        D3 v = dcross(D3{pre[3], pre[4], pre[5]}, pu);
+        if (u < fd.Kp) {
+          v = D3{pre[0], pre[1], pre[2]} + v + (kLn2D * pre[6]) * pu;
+        }
+        const double sg = m.us[u];
+        return (sg * sg) * v;
+      },
+      q);
+  for (int c = tid; c < n; c += 256) { // (the thread that wrote q[c])
+    q[c] += mu * p[c];
+  }
+  __syncthreads();
+}
+
 constexpr int kGenEv = 29; // words per constraint record (odd stride)
 
 // Which instantiations of the one-launch solve are set up for FOUR workgroups per CU (128 registers, the transform's CSR walked
@@ -482,7 +711,9 @@ struct FusedLayout {
 // its uy must outlive rho / invDiag
 // csrFloats: LDS copy of the parameter transform's CSR (row pointer, columns, values as 32-bit words) in the instantiations
 // that run three or fewer workgroups per CU -- they have the room, and an L2 walk costs them 4 %; 0: read from global memory
-__host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy = false, size_t csrFloats = 0) {
+// mix: the mixed-precision instantiation (kMix; mmx_mixed.hpp): theta, joint states, units, g and the CG vectors in double
+// INSTEAD of their single-precision twins, the double scratch X | Y in the arena
+__host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy = false, size_t csrFloats = 0, bool mix = false) {
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
   auto h4 = [&](size_t x) { return a4((x + 1) / 2); }; // 16-bit entries
   auto mx = [](size_t x, size_t y) { return x > y ? x : y; };
@@ -494,13 +725,19 @@ __host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, 
   l.uyFloats = separateUy ? l.auxOff + aux : mx(a4(3 * size_t(U)), aux);
   l.t9 = a4(size_t(kTan) * J);
   l.arenaFloats = mx(size_t(kSrcCh - 1) * size_t(srcStrideFor(nsrc)), 2 * l.t9 + a4(P));
+  if (mix) {
+    l.arenaFloats = mx(size_t(kSrcCh - 1) * size_t(srcStrideFor(nsrc)), a4(2 * (mixXDoubles(J, nsrc) + mixYDoubles(J, P))));
+  }
   l.umomFloats = mx(a4(size_t(kUmom) * U), a4(size_t(kC1) * J));
   const size_t scratch = fkBufFloats(J) + 2 * a4(size_t(kC2) * J) + l.umomFloats;
   l.regionFloats = mx(scratch, T * 256);
   const size_t rowsGp = a4(size_t(genRows));
   l.genFloats = GT > 0 ? a4(size_t(kGenEv) * GT) + 2 * a4(rowsGp) + a4(rowsGp * size_t(srcStrideFor(int(NP)))) : 0;
   const size_t meta = h4(NP + 1) + 3 * a4(nsrc) + a4(J) + 4 * h4(J) + h4(size_t(J) + 1) + 2 * h4(U) + h4(n) + h4(P);
-  const size_t fixed = a4(P) + a4(size_t(kJs) * J) + 2 * a4(3 * size_t(U)) + a4(U) + 2 * a4(NP) + l.uyFloats + 16 + 4;
+  size_t fixed = a4(P) + a4(size_t(kJs) * J) + 2 * a4(3 * size_t(U)) + a4(U) + 2 * a4(NP) + l.uyFloats + 16 + 4;
+  if (mix) { // uy's place | red, flags | the double arrays | lo, hi
+    fixed = l.uyFloats + 40 + 4 + a4(2 * mixPersistentDoubles(J, P, U, int(NP))) + 2 * h4(J);
+  }
   l.total = meta + fixed + l.genFloats + l.arenaFloats + l.regionFloats + csrFloats;
   return l;
 }
@@ -1055,7 +1292,11 @@ struct FusedArgs {
 static __global__ void stashFusedArgsKernel(FusedArgs a, FusedArgs* dst) {
   *dst = a;
 }
-template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1, bool kArgLazy = false>
+// kMix: the MIXED-precision instantiation (mmx_gn_options::precision == MMX_PRECISION_MIXED; mmx_mixed.hpp): theta, forward
+// kinematics, units, g = J^T r and the linear solve's residual in double -- all O(J + U) tree passes --, H / factor / triangular
+// solves in single precision as the preconditioner of a conjugate-gradient iteration in double.  Generic rule only (kRule = -1,
+// no parameter-space rows, no trust region, no general rows); three workgroups per CU up to six blocks.
+template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1, bool kArgLazy = false, bool kMix = false>
 // Workgroups per CU the register budget is set for (the LDS footprint decides what actually runs): FOUR for the per-rule
 // instantiations up to six blocks (round 5: the lifetime-shared carve brings BASELINE configs[1] to 40.2 KB; 128 VGPRs cost
 // a workgroup 4.6 % of its latency -- measured with the LDS still at 52 KB, profiles/r05_exp_fused.txt -- and buy a third
@@ -1064,7 +1305,7 @@ template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1, bool kA
 #ifdef MMX_EXP_OCC3
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
 #else
-__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, kGen, kRule>::value ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
+__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, kGen, kRule>::value && !kMix ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
 #endif
     const FusedArgs* __restrict__ argsDev, // kArgLazy: the descriptors (the by-value ones are not read); else unused
     RigDev rigV,
@@ -1075,13 +1316,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     FusedParams fpV,
     float* __restrict__ dbgH, // [B][n*n] or null: H = J^T J (no lambda) of the FIRST iteration
     float* __restrict__ dbgG, // [B][n] or null
-    long long* __restrict__ dbgClk) { // [32] or null: per-phase cycle counts of block 0 (profiling aid)
+    long long* __restrict__ dbgClk, // [32] or null: per-phase cycle counts of block 0 (profiling aid)
+    MixSelect sel) { // kMix: the elements to solve and where their initial parameters are (MMX_PRECISION_AUTO's second pass); else unused
+  static_assert(!kMix || (!kTR && !kGen && kRule == -1 && !kArgLazy), "the mixed-precision instantiation: generic rule, reference rows");
   constexpr int T = NB * (NB + 1) / 2; // lower-triangle tiles
   constexpr int NP = 16 * NB; // padded system size
   // lookahead: the left-looking updates of block column k + 1 by the columns before k ride under panel k's elimination
   // chain (waves without a panel row); NB <= 8: wave 3 never holds one (round 3, measured on one box: +2.2 % on cfg2)
 #ifdef MMX_EXP_NOLOOK // (A/B variant: no lookahead in the instantiations that run four workgroups per CU)
-  constexpr bool kLook = NB <= 8 && !FusedFour<NB, kTR, kGen, kRule>::value;
+  constexpr bool kLook = NB <= 8 && !(FusedFour<NB, kTR, kGen, kRule>::value && !kMix);
 #else
   constexpr bool kLook = NB <= 8;
 #endif
@@ -1093,7 +1336,14 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     clkLast = now_;                                               \
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  int bSel = blockIdx.x;
+  if (kMix && sel.map != nullptr) { // MMX_PRECISION_AUTO: workgroup i takes element map[i]; the ones beyond *count leave at once
+    if (int(blockIdx.x) >= *sel.count) {
+      return;
+    }
+    bSel = sel.map[blockIdx.x];
+  }
+  const int b = bSel, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   if (!kArgLazy) { // (the element's selections go into the by-value copies)
     selectInstanceRig(rigV, b);
@@ -1123,8 +1373,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   float *srcGu, *cells, *arena, *lPtValue = nullptr;
   // the instantiations whose register budget is set for four workgroups per CU read the transform's CSR from global memory
   // (their LDS has no room for it); the others keep their LDS copy
-  constexpr bool kFour = FusedFour<NB, kTR, kGen, kRule>::value;
-  constexpr bool kCsrLds = !kFour;
+  constexpr bool kFour = FusedFour<NB, kTR, kGen, kRule>::value && !kMix;
+  constexpr bool kCsrLds = !kFour && !kMix; // (the mixed instantiation walks the transform in double from global memory: mixTransformRows)
   // the register-lean forms of three routines in the four-workgroup instantiations (A/B variants: the full forms back, one each)
 #ifdef MMX_EXP_FATSOLVE
   constexpr bool kLeanSolve = false;
@@ -1142,7 +1392,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   constexpr bool kLeanAcc = kFour;
 #endif
   const int kNnz = fd.nnz;
-  const FusedLayout lay = fusedLayout(NB, J, P, U, nsrc, n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR);
+  const FusedLayout lay = fusedLayout(NB, J, P, U, nsrc, n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR, 0, kMix);
+  MixLds m{};
   {
     float* p = smem;
     auto take = [&](size_t count) {
@@ -1170,16 +1421,22 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       lPtInner = reinterpret_cast<int*>(take(kNnz));
       lPtValue = take(kNnz);
     }
-    s.th = take(P);
-    s.js = take(size_t(kJs) * J);
-    s.up = take(3 * size_t(U));
-    s.ur = take(3 * size_t(U));
-    s.us = take(U);
-    s.g = take(NP);
-    s.d0 = take(NP);
+    if (kMix) { // (theta, joint states, residual rows, g and the step live in double: below)
+      s.th = s.js = s.up = s.us = s.ur = s.g = s.d0 = nullptr;
+      m.lo = takeS(J);
+      m.hi = takeS(J);
+    } else {
+      s.th = take(P);
+      s.js = take(size_t(kJs) * J);
+      s.up = take(3 * size_t(U));
+      s.ur = take(3 * size_t(U));
+      s.us = take(U);
+      s.g = take(NP);
+      s.d0 = take(NP);
+    }
     s.uy = take(lay.uyFloats);
     s.rho = s.uy + lay.auxOff, s.invDiag = s.rho + NP, srcGu = s.rho, cells = s.rho + lay.cellOff;
-    s.red = reinterpret_cast<double*>(take(16));
+    s.red = reinterpret_cast<double*>(take(kMix ? 40 : 16)); // (kMix: five sums per reduction round)
     s.flags = reinterpret_cast<int*>(take(4));
     s.gEv = s.gRes = s.gW = s.gJ = nullptr;
     if (kGen) {
@@ -1190,6 +1447,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       s.gJ = take(size_t(rowsGp) * size_t(srcStrideFor(NP)));
     }
     arena = take(lay.arenaFloats); // srcT (phases E-G)  |  the refinement's buffers and dfull (phases J-K)
+    if (kMix) { // ... | the double scratch X, Y (everywhere else)
+      m.X = reinterpret_cast<double*>(arena);
+      m.Y = m.X + mixXDoubles(J, nsrc);
+    }
     s.srcT = arena;
     s.tanOwn = arena, s.jd = arena + lay.t9, s.tanPre = arena + lay.t9, s.dfull = arena + 2 * lay.t9;
     float* region = p;
@@ -1200,11 +1461,31 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     s.umom = take(lay.umomFloats);
     s.own1 = region, s.sub1 = s.umom; // phases D-E: over the FK buffer (dead after FK) / the unit moments (dead after the own sums)
     s.L = region;
+    if (kMix) { // the double arrays, behind everything else (every offset so far is a multiple of 16 bytes)
+      double* d = reinterpret_cast<double*>(smem + (lay.total - alignUp4(2 * mixPersistentDoubles(J, P, U, NP))));
+      m.th = d, d += P;
+      m.js = d, d += size_t(kJsD) * J;
+      m.up = d, d += 3 * size_t(U);
+      m.uf = d, d += 3 * size_t(U);
+      m.us = d, d += U;
+      m.g = d, d += NP;
+      m.x = d, d += NP;
+      m.r = d, d += NP;
+      m.p = d, d += NP;
+      m.q = d;
+    }
   }
 
   float* thg = theta + size_t(b) * P;
-  for (int i = tid; i < P; i += 256) {
-    s.th[i] = thg[i];
+  if (kMix) {
+    const float* th0 = sel.thetaInit != nullptr ? sel.thetaInit + size_t(b) * P : thg;
+    for (int i = tid; i < P; i += 256) {
+      m.th[i] = double(th0[i]);
+    }
+  } else {
+    for (int i = tid; i < P; i += 256) {
+      s.th[i] = thg[i];
+    }
   }
   for (int c = tid; c <= NP; c += 256) {
     s.mStart[c] = int16_t(fd.srcStart[c]);
@@ -1305,9 +1586,30 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     s.flags[1] = 0; // not positive definite (this iteration)
     s.flags[2] = 0; // status
   }
-  const bool hasParamRows = kRule >= 0 ? false : (pb.M > pb.rowsJoint); // limit / model-parameter rows present (uniform)
+  int mixLevel = 0; // kMix: the tree level of joint `tid` (blockFkD composes one level per barrier)
+  if (kMix && tid < J) {
+    for (int a = lParent[tid]; a >= 0; a = lParent[a]) {
+      ++mixLevel;
+    }
+  }
+  if (kMix) { // per DFS position: the index range of the (ascending) loaded positions inside the joint's subtree
+    for (int k = tid; k < J; k += 256) {
+      const int end = k + lSubSize[k];
+      int lo = 0, hi = 0;
+      for (int li = 0; li < numLoadedInst; ++li) {
+        const int pp = lLoadedPos[li];
+        lo += pp < k ? 1 : 0;
+        hi += pp < end ? 1 : 0;
+      }
+      m.lo[k] = int16_t(lo), m.hi[k] = int16_t(hi);
+    }
+  }
+  const bool hasParamRows = (kRule >= 0 || kMix) ? false : (pb.M > pb.rowsJoint); // limit / model-parameter rows present (uniform)
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
   float lambda = fp.lambda; // constant for GaussNewtonSolverT, adapted by the LM schedule
+  double lambdaD = double(fp.lambda); // kMix: the schedule's damping as GaussNewtonSolverT<double> carries it (lambda = its rounding: what is factored)
+  bool mixUnconverged = false; // kMix: some iteration's conjugate gradients stopped at the step limit
+  int mixApplied = 0; // kMix: operator applications of the whole solve (mmx_problem_solve_diagnostics [2]: per iteration)
   float trRadius = fp.trustRadius; // TrustRegionQRT::curTrustRegionRadius_ (initializeSolver, trust_region_qr.cpp:38-41)
   double curError = DBL_MAX;
   int itersDone = 0;
@@ -1375,7 +1677,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
 #ifdef MMX_EXP_EARLYUNIT // (A/B variant: the unit payload requested before FK in the four-workgroup instantiations too)
     constexpr bool kLateUnit = false;
 #else
-    constexpr bool kLateUnit = kFour;
+    constexpr bool kLateUnit = kFour || kMix;
 #endif
     const UnitInput uin0 = kLateUnit ? UnitInput{} : loadUnitInput(pb, b, tid < U ? tid : U);
     // TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270) wraps what follows
@@ -1399,6 +1701,17 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (kReuse && stateValid) {
       curError = stateError;
+    } else if (kMix) {
+      // ================= A-C in double (mmx_mixed.hpp)
+      blockFkD(rv, m, m.th, tid, mixLevel, true);
+      double e = mixUnits<true>(pb, s, m, b, U, tid);
+      e = waveReduceSum(e);
+      if (lane == 0) {
+        s.red[wave] = e;
+      }
+      __syncthreads();
+      curError = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+      MMX_CLK(1)
     } else {
     // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
     if (csrKeep) {
@@ -1444,6 +1757,18 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       __syncthreads();
     }
     MMX_CLK(2)
+    if (kMix) { // ================= F first, in double: g = J^T S^2 f (the arena is free: the slot tables come later)
+      __syncthreads(); // (s.red of the error sum / a reused trial state: every thread is past its reads)
+      mixAdjoint(
+          fv, s, m, J, NP, n, nsrc, tid,
+          [&](int u, int, const D3&) {
+            const double sg = m.us[u];
+            return (sg * sg) * D3{m.uf[3 * u], m.uf[3 * u + 1], m.uf[3 * u + 2]};
+          },
+          m.g);
+      __syncthreads();
+      MMX_CLK(5)
+    }
     int newtonIter = 0, pdRetries = 0;
     for (;;) { // one pass per value of the damping (the trust region's Newton updates change it, :180-231)
     int tidS = tid;
@@ -1458,7 +1783,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     // sqrt(lambda_new - lambda) I rows: R^T R = J^T J + (1e-20 + lambda - 1e-10) I
     const float mu = kTR ? 1e-20f + (trLambda - 1e-10f) : lambda;
     // ================= D: own + subtree sums
-    ownSums(fv, s, s.umom, U, tid);
+    if (kMix) {
+      ownSums<256, FusedViewS, true>(fv, s, s.umom, U, tid, m.up, m.us); // (second moments only: they feed H, the preconditioner)
+    } else {
+      ownSums(fv, s, s.umom, U, tid);
+    }
     __syncthreads();
     MMX_CLK(15)
 #ifdef MMX_EXP_TUN2 // (A/B variant: two k-steps per trip of the tree sums at four workgroups per CU)
@@ -1468,7 +1797,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
 #else
     constexpr int kUnD = kFusedTreeUn;
 #endif
-    treeSum<kC1, true, kC1, kUnD>(fv, s.own1, s.sub1, J, wave, lane);
+    if (!kMix) {
+      treeSum<kC1, true, kC1, kUnD>(fv, s.own1, s.sub1, J, wave, lane);
+    }
     treeSum<kC2Used, true, kC2, kUnD>(fv, s.own2, s.sub2, J, wave, lane);
     __syncthreads();
     MMX_CLK(3)
@@ -1486,7 +1817,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         cs.parent = (info >> 16) - 1;
         cs.tin = s.mTin[e] & 0xffff;
       }
-      const float* a = s.js + kJs * cs.joint;
+      float jaMix[kJs]; // kMix: the slot's joint state rounded to single precision (H is the preconditioner)
+      if (kMix) {
+        const double* ad = m.js + kJsD * cs.joint;
+#pragma unroll
+        for (int q = 0; q < kJs; ++q) {
+          jaMix[q] = float(ad[q]);
+        }
+      }
+      const float* a = kMix ? jaMix : s.js + kJs * cs.joint;
       const float* sb = s.sub2 + kC2 * cs.tin;
       const F3 ta{a[0], a[1], a[2]};
       const float m0 = sb[0];
@@ -1494,7 +1833,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       F3 al, bv{0.f, 0.f, 0.f}, g0, ax;
       float bs = 0.f, tr;
       if (cs.dof < 3) {
-        al = transAxisCol(s.js, cs.parent, cs.dof);
+        if (kMix) {
+          const D3 ad = transAxisColD(m.js, cs.parent, cs.dof);
+          al = F3{float(ad.x), float(ad.y), float(ad.z)};
+        } else {
+          al = transAxisCol(s.js, cs.parent, cs.dof);
+        }
         g0 = m0 * al;
         ax = cross(m1, al);
         tr = dot(al, m1);
@@ -1528,12 +1872,14 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       o[0] = w * al.x, o[sst] = w * al.y, o[2 * sst] = w * al.z;
       o[3 * sst] = w * bv.x, o[4 * sst] = w * bv.y, o[5 * sst] = w * bv.z;
       o[6 * sst] = w * bs;
-      srcG[e] = w * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
+      if (!kMix) {
+        srcG[e] = w * sourceGradient(cs.joint, cs.dof, cs.parent, s.js, s.sub1 + kC1 * cs.tin);
+      }
     }
     __syncthreads();
     MMX_CLK(4)
-    // ================= F: g = J^T r (compacted), padded with zeros
-    for (int c = tid; c < NP; c += 256) {
+    // ================= F: g = J^T r (compacted), padded with zeros  (kMix: done above, in double)
+    for (int c = tid; c < (kMix ? 0 : NP); c += 256) {
       float acc = srcG[c]; // pad columns: weight 0
       const int e1 = NP + s.mStart[c + 1];
       for (int e = NP + s.mStart[c]; e < e1; ++e) {
@@ -1751,7 +2097,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       for (int c = tid & 63; c < n; c += 64) {
         tr += s.L[256 * tileIndex(c >> 4, c >> 4) + tileAddr(c & 15, c & 15)];
       }
-      muFactor = fmaxf(mu, kFactorDamping * waveReduceSumF(tr) / float(n > 0 ? n : 1));
+      muFactor = fmaxf(mu, (kMix ? kMixFactorDamping : kFactorDamping) * waveReduceSumF(tr) / float(n > 0 ? n : 1));
       floored = floored || muFactor > mu;
     }
     // Every wave has summed the UNDAMPED diagonal before any thread damps its entry in place (round 5: without this barrier a
@@ -1880,7 +2226,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
               bad = bad || !(djj > 0.f);
               float inv = __builtin_amdgcn_rsqf(djj); // 1 / l_jj ; l_jj = d_jj * inv
               if (kGuard) {
-                inv = djj > readLaneF(floorRow, j) ? inv : 0.f;
+                // (kMix: what is factored is only the PRECONDITIONER of the conjugate gradients: a pivot at rounding level is
+                // FLOORED, not dropped -- a dropped column would take its parameter out of the Krylov space, and the noise a
+                // floored pivot lets through is the iteration's to remove)
+                const float fl = readLaneF(floorRow, j);
+                inv = djj > fl ? inv : (kMix ? __builtin_amdgcn_rsqf(fl) : 0.f);
               }
               a[j] *= inv;
               if (lane == j) {
@@ -1976,7 +2326,107 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     if (csrPipe) { // the refinement's walk of the transform: its loads fly under the solve
       csrJd = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
     }
-    if (!notPd) {
+    if (kMix) {
+      // ---- I + J in mixed precision: (J^T S^2 J + mu I) x = g by conjugate gradients in double, preconditioned by the
+      // single-precision factor (z = (L L^T)^-1 r, rounded through float on the way in and out); the operator goes through the
+      // tree in double (mixApply), never through the rounded H.  With a good preconditioner (mu well above the rounding of H:
+      // BASELINE's damping) the first direction is the single-precision step itself and the loop ends after ONE operator
+      // application with x = alpha z_0 + z_1 -- the single-precision solve's refinement step with an exact residual; where the
+      // factor is a poor preconditioner (damping floor above mu, cond x eps ~ 1e-2) the iteration continues as flexible
+      // (Polak-Ribiere) CG.  Stop: the predicted size of the NEXT correction, |z|^2 / |last step| x |z|, below mixTol |x|.
+      for (int c = tid; c < NP; c += 256) {
+        const double gc = c < n ? m.g[c] : 0.0;
+        m.x[c] = 0.0;
+        m.r[c] = gc;
+        s.rho[c] = float(gc);
+      }
+      __syncthreads();
+      solveLLt<NB, false>(s.L, s.invDiag, s.rho, tid);
+      double rz = 0.0;
+      for (int c = tid; c < n; c += 256) {
+        const double z = double(s.rho[c]);
+        m.p[c] = z;
+        rz += m.r[c] * z;
+      }
+      rz = blockSumD(s.red, rz, tid);
+      MMX_CLK(16)
+      const double tol2 = double(fp.mixTol) * double(fp.mixTol);
+      bool converged = !(rz > 0.0); // (g = 0: the step is zero)
+      for (int k = 0; k < fp.mixMaxCg && !converged; ++k) {
+        mixApply(rv, fv, s, m, lParentPos, J, NP, n, nsrc, double(mu), m.p, m.q, tid);
+        ++mixApplied;
+        MMX_CLK(17)
+        double pq = 0.0;
+        for (int c = tid; c < n; c += 256) {
+          pq += m.p[c] * m.q[c];
+        }
+        pq = blockSumD(s.red, pq, tid);
+        if (!(pq > 0.0)) {
+          break;
+        }
+        const double alpha = rz / pq;
+        double sums[5] = {0.0, 0.0, 0.0, 0.0, 0.0}; // |alpha p|^2, |x|^2, r.z, z.q, |z|^2
+        for (int c = tid; c < NP; c += 256) {
+          float rc = 0.f;
+          if (c < n) {
+            const double dx = alpha * m.p[c], xn = m.x[c] + dx, rn = m.r[c] - alpha * m.q[c];
+            m.x[c] = xn, m.r[c] = rn;
+            sums[0] += dx * dx, sums[1] += xn * xn;
+            rc = float(rn);
+          }
+          s.rho[c] = rc;
+        }
+        __syncthreads();
+        MMX_CLK(19)
+        solveLLt<NB, false>(s.L, s.invDiag, s.rho, tid);
+        MMX_CLK(20)
+        for (int c = tid; c < n; c += 256) {
+          const double z = double(s.rho[c]);
+          sums[2] += m.r[c] * z, sums[3] += z * m.q[c], sums[4] += z * z;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          sums[q] = waveReduceSum(sums[q]);
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            s.red[4 * q + wave] = sums[q];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          sums[q] = (s.red[4 * q] + s.red[4 * q + 1]) + (s.red[4 * q + 2] + s.red[4 * q + 3]);
+        }
+        __syncthreads();
+        // the correction z (x alpha when the factor over-damps the directions the iteration is moving in: alpha > 1) would be
+        // followed by one of about |z| x (|z| / |last step|): small enough => take z and stop
+        const double am2 = alpha > 1.0 ? alpha * alpha : 1.0;
+        if (am2 * sums[4] * am2 * sums[4] <= tol2 * sums[1] * sums[0]) {
+          for (int c = tid; c < n; c += 256) {
+            m.x[c] += double(s.rho[c]);
+          }
+          converged = true;
+        } else {
+          const double beta = -alpha * sums[3] / rz; // Polak-Ribiere: z'.(r' - r) / (z.r), r' - r = -alpha q
+          for (int c = tid; c < n; c += 256) {
+            m.p[c] = double(s.rho[c]) + beta * m.p[c];
+          }
+          rz = sums[2];
+          converged = !(rz > 0.0);
+          // no prospect of meeting the tolerance within the step limit (six applications in and the next correction still above
+          // 1e-3 of the step: cond x eps ~ 1, the factor is no preconditioner): stop here, the element is reported
+          if (k >= 5 && am2 * sums[4] > 1e-6 * sums[1]) {
+            __syncthreads();
+            break;
+          }
+        }
+        __syncthreads();
+        MMX_CLK(18)
+      }
+      mixUnconverged = mixUnconverged || !converged;
+    } else if (!notPd) {
       solveLLt<NB, kLeanSolve>(s.L, s.invDiag, s.d0, tid);
     }
     MMX_CLK(8)
@@ -1986,7 +2436,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     // weaker preconditioner, so a further step is taken while the last correction was still
     // larger than 1e-3 of the step (error after k steps ~ ratio^(k+1)).  The test is on block-wide
     // sums, hence uniform.
-    const int nRefine = !notPd ? fp.refine : 0; // refinement steps allowed (default 3, mmx_tuning::max_refinement_steps)
+    const int nRefine = (!notPd && !kMix) ? fp.refine : 0; // refinement steps allowed (default 3, mmx_tuning::max_refinement_steps)
     float prevCorr2 = FLT_MAX;
     for (int rf = 0; rf < nRefine; ++rf) {
       // joint-parameter delta jd = transform * delta (delta gathered through the solve map)
@@ -2281,6 +2731,83 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     if (csrPipe) { // the next forward kinematics' walk of the transform: its loads fly under this phase and the barrier
       csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
     }
+    if (kMix) {
+      // ---- the step rules of phase K as the DOUBLE instantiation takes them (oracle: solveGaussNewton<double>): theta, the
+      // trial parameters (m.Y) and the errors in double; the LM schedule's damping in double, its rounding is what is factored
+      if (stepRule == 1) {
+        double part = 0.0;
+        for (int c = tid; c < n; c += 256) {
+          part += m.x[c] * m.g[c] + lambdaD * m.x[c] * m.x[c];
+        }
+        const double predicted = blockSumD(s.red, part, tid); // decrease of |r - J d|^2 = d.g + lambda d.d
+        for (int i = tid; i < P; i += 256) {
+          m.Y[i] = m.th[i];
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += 256) {
+          m.Y[fv.solveList[c]] -= m.x[c];
+        }
+        __syncthreads();
+        double eFull = 0.0;
+        const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &eFull);
+        const double rho = predicted > 0.0 ? (curError - eNew) / predicted : -1.0;
+        if (st.stepHistory != nullptr && tid == 0) {
+          double* sh = st.stepHistory + (size_t(b) * fp.maxIterations + it) * 2;
+          sh[0] = lambdaD;
+          sh[1] = rho;
+        }
+        stateValid = false; // (a rejected trial leaves the trial's joint states behind: this theta is evaluated again)
+        if (rho > 0.0) {
+          for (int i = tid; i < P; i += 256) {
+            m.th[i] = m.Y[i];
+          }
+          stateValid = true;
+          stateError = eFull;
+        }
+        if (!(rho >= 0.25)) {
+          lambdaD = fmin(lambdaD * double(fp.lmUp), double(fp.lmLambdaMax));
+        } else if (rho > 0.75) {
+          lambdaD = fmax(lambdaD * double(fp.lmDown), double(fp.lmLambdaMin));
+        }
+        lambda = float(lambdaD);
+      } else if (doLineSearch) { // both backtracking rules (gauss_newton_solver.cpp:283-313, subset_gauss_newton_solver.cpp:117-142)
+        const double scaledError = 1e-3 * curError;
+        double gd = 0.0;
+        if (doLineSearch == 2) {
+          double part = 0.0;
+          for (int c = tid; c < n; c += 256) {
+            part += m.g[c] * m.x[c];
+          }
+          gd = blockSumD(s.red, part, tid);
+        }
+        float scale = 1.f;
+        for (int ls = 0; ls < 10; ++ls) {
+          for (int i = tid; i < P; i += 256) {
+            m.Y[i] = m.th[i];
+          }
+          __syncthreads();
+          for (int c = tid; c < n; c += 256) {
+            m.Y[fv.solveList[c]] -= double(scale) * m.x[c];
+          }
+          __syncthreads();
+          const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &stateError);
+          if ((curError - eNew) >= (doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale) * scaledError)) {
+            break;
+          }
+          scale *= 0.5f;
+        }
+        for (int i = tid; i < P; i += 256) {
+          m.th[i] = m.Y[i];
+        }
+        stateValid = true; // the last trial evaluated IS the new theta
+      } else {
+        for (int c = tid; c < n; c += 256) {
+          m.th[fv.solveList[c]] -= m.x[c]; // skeleton_solver_function.cpp:158
+        }
+        stateValid = false;
+      }
+      break;
+    }
     if (kTR) {
       if (trNoStep) {
         break;
@@ -2406,8 +2933,20 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     if (st.paramHistory != nullptr) { // iterationHistory_["parameters"].col(iteration_) = parameters_ (solver.cpp:101-106)
       float* ph = st.paramHistory + (size_t(b) * fp.maxIterations + it) * size_t(P);
       for (int i = tid; i < P; i += 256) {
-        ph[i] = s.th[i];
+        ph[i] = kMix ? float(m.th[i]) : s.th[i];
       }
+    }
+    // MMX_PRECISION_AUTO with a mixed-precision second pass (fp.autoAbort): an element one of this iteration's factorisations
+    // marks (precision estimate above the bound) will be solved again from its initial parameters anyway -- it stops here,
+    // its parameters are not written back.  The pivot ratio is a property of the problem class: a marked class pays ONE
+    // iteration of the single-precision pass instead of all of them.
+    float abortW = 0.f;
+    if (!kMix && !kTR && fp.autoAbort != 0 && wave == 0) {
+      abortW = pivotWorst;
+      abortW = fmaxf(abortW, dppMoveF<0xB1>(abortW));
+      abortW = fmaxf(abortW, dppMoveF<0x4E>(abortW));
+      abortW = fmaxf(abortW, dppMoveF<0x141>(abortW));
+      abortW = fmaxf(abortW, dppMoveF<0x140>(abortW));
     }
     if (tid == 0) {
       const double e = curError;
@@ -2415,7 +2954,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         st.errorHistory[size_t(b) * fp.maxIterations + it] = e;
       }
       itersDone = it + 1;
-      if (badPivot) {
+      if (badPivot && !kMix) { // (kMix: the factor is the preconditioner -- a floored pivot costs CG steps, and those are what is reported)
         s.flags[2] |= 2; // MMX_SOLVE_NOT_PD
       }
       if (floored) {
@@ -2425,6 +2964,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       const bool converged = fabs(lastError - e) / (fabs(e) + double(FLT_MIN)) <= double(fp.threshold) * double(FLT_EPSILON);
       s.flags[0] = (it >= fp.minIterations && converged) ? 1 : 0;
       lastError = e;
+      if (!kMix && !kTR && fp.autoAbort != 0 && st.precisionBound > 0.f &&
+          !(kPrecisionGain * FLT_EPSILON * (abortW > 0.f ? abortW / kPivotFloorOrOne : 1.f) <= st.precisionBound)) {
+        s.flags[0] = 2; // marked: leave
+      }
     }
     __syncthreads();
     MMX_CLK(10)
@@ -2437,15 +2980,16 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   // global memory still holds the initial parameters, so "revert" = do not write
   int bad = 0;
   for (int i = tid; i < P; i += 256) {
-    if (!isfinite(s.th[i])) {
+    if (!isfinite(kMix ? float(m.th[i]) : s.th[i])) {
       bad = 1;
     }
   }
   bad = __syncthreads_or(bad);
+  const bool aborted = !kMix && !kTR && s.flags[0] == 2; // (fp.autoAbort: the element is MMX_PRECISION_AUTO's second pass's)
   float th2 = 0.f;
-  if (!bad) {
+  if (!bad && !aborted) {
     for (int i = tid; i < P; i += 256) {
-      const float v = s.th[i];
+      const float v = kMix ? float(m.th[i]) : s.th[i];
       thg[i] = v;
       th2 += v * v;
     }
@@ -2470,14 +3014,19 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     const float ratio = worst > 0.f ? kPivotFloorOrOne / worst : 1.f;
     const float est = kPrecisionGain * FLT_EPSILON / ratio;
     int stt = bad ? 1 : s.flags[2];
-    if (!bad && st.precisionBound > 0.f && !(est <= st.precisionBound)) {
+    if (kMix) { // the estimate is the single-precision solves' (informational here): marked only when the CG did not converge
+      if (!bad && mixUnconverged) {
+        stt |= 8;
+      }
+      stt |= 32; // MMX_SOLVE_MIXED
+    } else if (!bad && st.precisionBound > 0.f && !(est <= st.precisionBound)) {
       stt |= 8; // MMX_SOLVE_PRECISION_SUSPECT
     }
     if (st.diag != nullptr) {
       float* dg = st.diag + 4 * size_t(b);
       dg[0] = est;
       dg[1] = ratio;
-      dg[2] = sqrtf(refineWorst);
+      dg[2] = kMix ? float(mixApplied) / float(itersDone > 0 ? itersDone : 1) : sqrtf(refineWorst);
       dg[3] = sqrtf(th2);
     }
     st.iterations[b] = itersDone;
@@ -3419,8 +3968,8 @@ size_t fusedCsrFloats(int J, int nnz) {
   auto a4 = [](size_t x) { return (x + 3) & ~size_t(3); };
   return a4(7 * size_t(J) + 1) + 2 * a4(nnz);
 }
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy, size_t csrFloats) {
-  return fusedLayout(NB, J, P, U, nsrc, n, numCells, cellsBehindRho, GT, genRows, separateUy, csrFloats).total * sizeof(float);
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT, int genRows, bool separateUy, size_t csrFloats, bool mix) {
+  return fusedLayout(NB, J, P, U, nsrc, n, numCells, cellsBehindRho, GT, genRows, separateUy, csrFloats, mix).total * sizeof(float);
 }
 #endif
 
@@ -3457,14 +4006,14 @@ static hipError_t launchFusedMode(
     }
     FusedArgs* dst = static_cast<FusedArgs*>(argsBuf);
     hipLaunchKernelGGL(stashFusedArgsKernel, dim3(1), dim3(1), 0, stream, FusedArgs{rig, pb, fd, st, fp}, dst);
-    hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule, kLazyBuilt>), dim3(pb.B), dim3(256), lds, stream, dst, RigDev{}, ProblemDev{}, FusedDev{}, theta, SolveStateDev{}, FusedParams{}, dbgH, dbgG, dbgClk);
+    hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule, kLazyBuilt>), dim3(pb.B), dim3(256), lds, stream, dst, RigDev{}, ProblemDev{}, FusedDev{}, theta, SolveStateDev{}, FusedParams{}, dbgH, dbgG, dbgClk, MixSelect{});
   } else {
     static LdsLimitCache ldsLimit;
     hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, MODE, kTR, kGen, kRule, false>), lds);
     if (rc != hipSuccess) {
       return rc;
     }
-    hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule, false>), dim3(pb.B), dim3(256), lds, stream, static_cast<const FusedArgs*>(nullptr), rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk);
+    hipLaunchKernelGGL((fusedSolveKernel<NB, MODE, kTR, kGen, kRule, false>), dim3(pb.B), dim3(256), lds, stream, static_cast<const FusedArgs*>(nullptr), rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, MixSelect{});
   }
   return hipGetLastError();
 }
@@ -3511,6 +4060,31 @@ static hipError_t launchFusedNB(
   return launchFusedMode<NB, 0, false>(rig, pb, fd, theta, st, fp, dbgH, dbgG, dbgClk, argsBuf, stream);
 }
 
+// the mixed-precision instantiation (generic rule; by-value arguments)
+template <int NB>
+static hipError_t launchFusedMixedNB(const RigDev& rig, const ProblemDev& pb, const FusedDev& fd, float* theta, const SolveStateDev& st, const FusedParams& fp, const MixSelect& sel, int blocks, long long* dbgClk, hipStream_t stream) {
+  const size_t lds = fusedLdsBytes(NB, rig.J, rig.P, fd.U, fd.nsrc, fd.n, fd.numCells, true, 0, 0, false, 0, true);
+  if (lds > 160 * 1024) {
+    return hipErrorInvalidValue;
+  }
+  if (NB == 6 && dbgClk != nullptr) { // profiling aid (MMX_PHASE_CLOCKS): the clocked instantiation, BASELINE configs[1]'s block count only
+    static LdsLimitCache ldsLimitClk;
+    hipError_t rc = ldsLimitClk.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB == 6 ? 6 : 1, 2, false, false, -1, false, true>), lds);
+    if (rc != hipSuccess) {
+      return rc;
+    }
+    hipLaunchKernelGGL((fusedSolveKernel<NB == 6 ? 6 : 1, 2, false, false, -1, false, true>), dim3(blocks), dim3(256), lds, stream, static_cast<const FusedArgs*>(nullptr), rig, pb, fd, theta, st, fp, nullptr, nullptr, dbgClk, sel);
+    return hipGetLastError();
+  }
+  static LdsLimitCache ldsLimit;
+  hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(fusedSolveKernel<NB, 0, false, false, -1, false, true>), lds);
+  if (rc != hipSuccess) {
+    return rc;
+  }
+  hipLaunchKernelGGL((fusedSolveKernel<NB, 0, false, false, -1, false, true>), dim3(blocks), dim3(256), lds, stream, static_cast<const FusedArgs*>(nullptr), rig, pb, fd, theta, st, fp, nullptr, nullptr, nullptr, sel);
+  return hipGetLastError();
+}
+
 // The instantiations are split over four translation units (build.py compiles this file once per
 // MMX_FUSED_GROUP, in parallel): group g provides launchFusedGroup<g>() for its block counts.
 #ifndef MMX_FUSED_GROUP
@@ -3526,6 +4100,13 @@ hipError_t launchFusedGroup0(int nb, MMX_FUSED_ARGS);
 hipError_t launchFusedGroup1(int nb, MMX_FUSED_ARGS);
 hipError_t launchFusedGroup2(int nb, MMX_FUSED_ARGS);
 hipError_t launchFusedGroup3(int nb, MMX_FUSED_ARGS);
+#define MMX_MIXED_ARGS \
+  const RigDev &rig, const ProblemDev &pb, const FusedDev &fd, float *theta, const SolveStateDev &st, const FusedParams &fp, const MixSelect &sel, int blocks, long long *dbgClk, hipStream_t stream
+hipError_t launchFusedMixedGroup5(int nb, MMX_MIXED_ARGS);
+hipError_t launchFusedMixedGroup6(int nb, MMX_MIXED_ARGS);
+#define MMX_MIXED_CASE(NB_) \
+  case NB_:                 \
+    return launchFusedMixedNB<NB_>(rig, pb, fd, theta, st, fp, sel, blocks, dbgClk, stream);
 
 #define MMX_CASE(NB_) \
   case NB_:           \
@@ -3554,15 +4135,31 @@ hipError_t launchFusedGroup2(int nb, MMX_FUSED_ARGS) {
 #define MMX_PROBE_RULE 0
 #endif
 template __global__ void fusedSolveKernel<6, 0, false, false, MMX_PROBE_RULE, true>(
-    const FusedArgs*, RigDev, ProblemDev, FusedDev, float*, SolveStateDev, FusedParams, float*, float*, long long*);
+    const FusedArgs*, RigDev, ProblemDev, FusedDev, float*, SolveStateDev, FusedParams, float*, float*, long long*, MixSelect);
+#elif MMX_FUSED_GROUP == 8 // (compile probe of the mixed-precision instantiation, six blocks)
+template __global__ void fusedSolveKernel<6, 0, false, false, -1, false, true>(
+    const FusedArgs*, RigDev, ProblemDev, FusedDev, float*, SolveStateDev, FusedParams, float*, float*, long long*, MixSelect);
 #elif MMX_FUSED_GROUP == 3
 hipError_t launchFusedGroup3(int nb, MMX_FUSED_ARGS) {
   switch (nb) {
     MMX_CASE(12) MMX_CASE(14) default : return hipErrorInvalidValue;
   }
 }
+#elif MMX_FUSED_GROUP == 5
+hipError_t launchFusedMixedGroup5(int nb, MMX_MIXED_ARGS) {
+  switch (nb) {
+    MMX_MIXED_CASE(1) MMX_MIXED_CASE(2) MMX_MIXED_CASE(3) MMX_MIXED_CASE(4) default : return hipErrorInvalidValue;
+  }
+}
+#elif MMX_FUSED_GROUP == 6
+hipError_t launchFusedMixedGroup6(int nb, MMX_MIXED_ARGS) {
+  switch (nb) {
+    MMX_MIXED_CASE(5) MMX_MIXED_CASE(6) MMX_MIXED_CASE(7) MMX_MIXED_CASE(8) default : return hipErrorInvalidValue;
+  }
+}
 #endif
 #undef MMX_CASE
+#undef MMX_MIXED_CASE
 
 #if MMX_FUSED_GROUP == 0
 int fusedBlocksFor(int n) {
@@ -3578,6 +4175,19 @@ int fusedBlocksFor(int n) {
 
 size_t fusedArgsBytes() {
   return sizeof(FusedArgs);
+}
+
+// MMX_PRECISION_MIXED: up to eight blocks (128 solved parameters), at most 256 joints (the tangent pass keeps a joint per thread)
+bool fusedMixedUsable(int J, int P, int U, int nsrc, int n, int numCells) {
+  const int nb = fusedBlocksFor(n);
+  return nb >= 1 && nb <= 8 && J <= 256 && fusedLdsBytes(nb, J, P, U, nsrc, n, numCells, true, 0, 0, false, 0, true) <= 160 * 1024;
+}
+hipError_t launchFusedMixed(MMX_MIXED_ARGS) {
+  const int nb = fusedBlocksFor(fd.n);
+  if (nb < 1 || nb > 8) {
+    return hipErrorInvalidValue;
+  }
+  return nb <= 4 ? launchFusedMixedGroup5(nb, rig, pb, fd, theta, st, fp, sel, blocks, dbgClk, stream) : launchFusedMixedGroup6(nb, rig, pb, fd, theta, st, fp, sel, blocks, dbgClk, stream);
 }
 
 hipError_t launchFusedSolve(MMX_FUSED_ARGS) {

@@ -160,11 +160,25 @@ struct FusedParams {
   int32_t stepRule; // MMX_STEP_*
   float lmLambdaMin, lmLambdaMax, lmUp, lmDown;
   float trustRadius; // TrustRegionQROptions::trustRegionRadius_
+  // the mixed-precision instantiation (MMX_PRECISION_MIXED): stop the conjugate gradients when the predicted next correction
+  // falls below mixTol |step|; at most mixMaxCg operator applications per iteration
+  float mixTol;
+  int32_t mixMaxCg;
+  int32_t autoAbort; // single-precision instantiations: leave an element as soon as a factorisation marks it MMX_SOLVE_PRECISION_SUSPECT (MMX_PRECISION_AUTO's first pass)
+};
+
+// mmx_gn_options::precision == MMX_PRECISION_AUTO with the mixed-precision instantiation as its second pass: workgroup i takes
+// element map[i] (the ones beyond *count leave at once) and starts from the float copy of the initial parameters taken before
+// the single-precision pass.  All null: every element, in place.
+struct MixSelect {
+  const int32_t* map; // [B] or null
+  const int32_t* count; // [1]
+  const float* thetaInit; // [B][P] or null: theta itself
 };
 
 // cellsBehindRho: the instantiations that carry parameter-space rows park their diagonal in rho while the term records run,
 // so the split entries' partial cells lie behind rho / invDiag there (numCells floats more)
-size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT = 0, int genRows = 0, bool separateUy = false, size_t csrFloats = 0);
+size_t fusedLdsBytes(int NB, int J, int P, int U, int nsrc, int n, int numCells, bool cellsBehindRho, int GT = 0, int genRows = 0, bool separateUy = false, size_t csrFloats = 0, bool mix = false);
 size_t fusedCsrFloats(int J, int nnz); // LDS copy of the transform's CSR (the instantiations below four workgroups per CU)
 // H = J^T J, g = J^T r from the tree moments for the explicit-Jacobian solver (mmx_fused.hip, treeNormalEquationsKernel)
 size_t treeNormalEquationsLdsBytes(int J, int P, int U, int nsrc, int n, int GT = 0, int genRows = 0);
@@ -213,6 +227,11 @@ hipError_t launchFusedSolve(
     void* argsBuf, // fusedArgsBytes() of device memory owned by the problem, or null: where the descriptors are stashed for the lazy-argument instantiations (mmx_fused.hip, kArgLazy); written in stream order before the solve
     hipStream_t stream);
 size_t fusedArgsBytes();
+// the mixed-precision instantiation of the one-launch solve (mmx_gn_options::precision == MMX_PRECISION_MIXED): usable for
+// problems without parameter-space rows / further joint error functions / the trust region, up to 128 solved parameters
+bool fusedMixedUsable(int J, int P, int U, int nsrc, int n, int numCells);
+hipError_t launchFusedMixed(
+    const RigDev& rig, const ProblemDev& pb, const FusedDev& fd, float* theta, const SolveStateDev& st, const FusedParams& fp, const MixSelect& sel, int blocks, long long* dbgClk, hipStream_t stream);
 
 // double-precision solve (mmx_f64.hip)
 size_t solveF64LdsBytes(int J, int P, int U, int n, int G = 0, int genRows = 0);
@@ -246,7 +265,7 @@ hipError_t launchSolveF64(
     const F64AssemblyList& list = F64AssemblyList{nullptr, nullptr, nullptr, 0},
     const F64Select& select = F64Select{nullptr, nullptr, nullptr, nullptr});
 // elements whose status has a bit of `mask` set, in index order: map[0 .. *count - 1]
-hipError_t launchSelectSuspect(const int32_t* status, int B, int32_t mask, int32_t* map, int32_t* count, hipStream_t stream);
+hipError_t launchSelectSuspect(const int32_t* status, int B, int32_t mask, int32_t* map, int32_t* count, hipStream_t stream, int32_t require = 0);
 
 size_t fkJacobianLdsBytes(int J, int P, int U);
 // store-only counterpart of the J-assembly kernel (profiling aid; see storePatternKernel)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 6 GPU call script: bash scripts/gpu_r06.sh <step> [args]   (run through gpurun; outputs under gpurun_out/)
+set -u
+mkdir -p gpurun_out
+step=${1:-mixed}
+shift || true
+case "$step" in
+  mixed)  # the mixed-precision table (B instances per row, default 1024)
+    timeout 1500 python scripts/diag_mixed_table.py "${1:-1024}" > gpurun_out/mixed_table.log 2>&1; tail -40 gpurun_out/mixed_table.log ;;
+  mixedvar)  # the same table for A/B libraries: mixedvar <variant> ... (momentum_amd/libmmx_hip_<variant>.so)
+    for v in "$@"; do
+      MMX_LIB=$PWD/momentum_amd/libmmx_hip_$v.so MMX_TABLE_TAG=_$v timeout 900 python scripts/diag_mixed_table.py 1024 > gpurun_out/mixed_table_$v.log 2>&1
+      echo "== $v"; grep -E "^cfg" gpurun_out/mixed_table_$v.log | cut -c1-60 | head -3
+    done ;;
+  mixedtol)  # the table for a list of CG tolerances: mixedtol <tol> ...
+    for t in "$@"; do
+      MMX_MIXED_TOL=$t MMX_TABLE_TAG=_tol$t timeout 900 python scripts/diag_mixed_table.py 1024 > gpurun_out/mixed_table_tol$t.log 2>&1
+      echo "== tol $t"; grep -cE "^cfg" gpurun_out/mixed_table_tol$t.log
+    done ;;
+  mixedrate)  # rates of the precision routes + the mixed kernel's phase clocks
+    timeout 900 python scripts/diag_mixed_rate.py > gpurun_out/mixed_rate.log 2>&1; cat gpurun_out/mixed_rate.log
+    MMX_PHASE_CLOCKS=1 timeout 300 python scripts/diag_mixed_rate.py > gpurun_out/mixed_clocks.log 2>&1; cat gpurun_out/mixed_clocks.log ;;
+  tests)  # the GPU suite (optionally -k expression)
+    timeout 2400 python -m pytest tests -m gpu -x -q "$@" > gpurun_out/pytest_gpu.log 2>&1; tail -15 gpurun_out/pytest_gpu.log ;;
+  bench)
+    timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 3000 gpurun_out/bench.json; tail -20 gpurun_out/bench.err ;;
+  *) echo "unknown step $step"; exit 2 ;;
+esac

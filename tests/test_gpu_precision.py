@@ -18,7 +18,9 @@ from momentum_amd import capi, humanoid72_landmark_joints, make_humanoid72, make
 from momentum_amd._abi import (
     MMX_PRECISION_AUTO,
     MMX_PRECISION_F64,
+    MMX_PRECISION_MIXED,
     MMX_SOLVE_ESCALATED_F64,
+    MMX_SOLVE_MIXED,
     MMX_SOLVE_PRECISION_SUSPECT,
     MMX_STEP_LM_SCHEDULE,
     GnOptions,
@@ -83,15 +85,23 @@ def test_precision_f64_is_the_double_instantiation_on_float_parameters(torch_cud
             assert _rel(out["theta"].astype(np.float64), ref["theta"]).max() <= 2e-7  # (float rounding of theta: 6e-8)
 
 
-def test_auto_with_a_bound_nothing_passes_escalates_every_element(torch_cuda, orc):
+@pytest.mark.parametrize("route", ["auto", "wide"])
+def test_auto_with_a_bound_nothing_passes_escalates_every_element(torch_cuda, orc, route):
+    """ABI 11: the second pass is the mixed-precision instantiation where it applies (the one-launch route's problems:
+    MMX_SOLVE_MIXED), the double one elsewhere (here: the wide route pinned -- MMX_SOLVE_ESCALATED_F64); either way the result is
+    that instantiation's own, bit for bit, on every element."""
     B = 300  # (not a multiple of the selection kernel's stride)
     rig, cons, th0 = _cfg2(B)
     pb = _problem(torch_cuda, rig, cons, B)
+    pb.set_route(route)
     mk = lambda prec, bound=1e-5: GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE,
                                                  precision=prec, precision_bound=bound)  # fmt: skip
     a = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_AUTO, 1e-30), want_history=True, want_step_history=True)
-    d = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_F64), want_history=True, want_step_history=True)
-    assert np.all(a["status"] & MMX_SOLVE_ESCALATED_F64 != 0) and np.all(a["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0)
+    d = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_MIXED if route == "auto" else MMX_PRECISION_F64), want_history=True, want_step_history=True)
+    bit = MMX_SOLVE_MIXED if route == "auto" else MMX_SOLVE_ESCALATED_F64
+    assert np.all(a["status"] & bit != 0) and np.all(a["status"] & (MMX_SOLVE_MIXED | MMX_SOLVE_ESCALATED_F64) == bit)
+    if route == "wide":
+        assert np.all(a["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0) and np.all(d["status"] & MMX_SOLVE_ESCALATED_F64 != 0)  # (MIXED outside its scope = the double instantiation)
     assert np.all(a["status"] & 3 == 0)
     for k in ("theta", "error", "iterations", "error_history", "step_history"):
         assert np.array_equal(a[k], d[k]), k
@@ -150,7 +160,7 @@ def test_auto_holds_the_bound_where_single_precision_does_not(torch_cuda, orc, n
         with np.errstate(all="ignore"):
             stable = _rel(pert["theta"], ref["theta"]) <= 1e-7  # (amplification of a 1e-12 perturbation by at most 1e5)
         rel = _rel(out["theta"].astype(np.float64), ref["theta"])
-        esc = out["status"] & MMX_SOLVE_ESCALATED_F64 != 0
+        esc = out["status"] & (MMX_SOLVE_ESCALATED_F64 | MMX_SOLVE_MIXED) != 0
         # an escalated element IS the double solver's run (1e-10 in tests/test_gpu_f64.py) rounded to float; with a line search
         # an element whose accept test sits on its threshold may take the other branch: same decisions <=> same error history
         h, href = out["error_history"], ref["error_history"]
@@ -211,7 +221,7 @@ def test_rank_deficient_elements_are_marked_on_both_routes(torch_cuda, lam):
         assert np.all(diag[:, 0] > BOUND) and np.all(diag[:, 1] < 1.0 / 2000.0), (route, diag[:, :2].min(axis=0), diag[:, :2].max(axis=0))
         est[route] = diag[:, 1]
         a = _solve(torch_cuda, pb, th0, GnOptions.make(min_iterations=4, max_iterations=4, threshold=1.0, regularization=lam, precision=MMX_PRECISION_AUTO))
-        assert np.all(a["status"] & MMX_SOLVE_ESCALATED_F64 != 0), route
+        assert np.all(a["status"] & (MMX_SOLVE_ESCALATED_F64 | MMX_SOLVE_MIXED) != 0), route
     # the same class bound from either route (the pivot ratio is a property of the problem class: within a decade)
     r = np.median(est["wide"]) / np.median(est["fused"])
     assert 0.1 <= r <= 10.0, (np.median(est["wide"]), np.median(est["fused"]))
