@@ -144,7 +144,8 @@ typedef enum mmx_status {
                                  on theta -- at the batched driver's lambda = 0.01 and far below -- at a multiple of the double
                                  instantiation's rate.  Scope: the one-launch route's problems (up to 128 solved parameters,
                                  256 joints) with position / orientation constraints, every step rule but the trust region;
-                                 anything else is solved by the double instantiation (MMX_SOLVE_ESCALATED_F64). */
+                                 anything else is solved by the double instantiation exactly as under MMX_PRECISION_F64 (no
+                                 MMX_SOLVE_MIXED bit on the status). */
 
 /* Where the caller's bulk arrays live. */
 #define MMX_MEM_HOST 0

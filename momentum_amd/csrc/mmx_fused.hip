@@ -550,38 +550,42 @@ __device__ __forceinline__ double blockErrorD(
 // Adjoint pass in double: out[c] = (J^T y)_c for the solve columns c < n (0 for the pad columns), y_u = yOf(u, k) the adjoint
 // input of unit u (k: DFS position of its joint).  Own sums per loaded joint (m.X) -> subtree sums (m.Y; the loaded positions
 // inside a subtree are the index range lo..hi of the ascending loadedPos) -> per-slot gradients (m.X) -> columns.
+// (Measured and not kept, round 6: one thread per UNIT writing its moments and the subtree sums walking the position-sorted unit
+// list -- a root joint's sum is then a chain of 64 dependent LDS round trips: the operator went from 20 k to 35 k cycles.)
 // Clobbers m.X and m.Y; yOf may read m.Y (the tangent pass's prefixes: consumed before the first barrier).  Ends WITHOUT a barrier.
 template <class FV, typename YFn>
 __device__ __forceinline__ void mixAdjoint(const FV& fd, const FusedLds& s, const MixLds& m, int J, int NP, int n, int nsrc, int tid, YFn yOf, double* out) {
-  for (int li = tid; li < fd.numLoaded; li += 256) {
-    const int k = fd.loadedPos[li];
-    D3 Fv{0.0, 0.0, 0.0}, Nv{0.0, 0.0, 0.0};
-    double Dd = 0.0;
-    const int e1 = fd.posUnitStart[k + 1];
-    for (int e = fd.posUnitStart[k]; e < e1; ++e) {
-      const int u = fd.posUnits[e];
-      const D3 pu{m.up[3 * u], m.up[3 * u + 1], m.up[3 * u + 2]};
-      const D3 y = yOf(u, k, pu);
-      Nv = Nv + dcross(pu, y); // points and directions share the channel (jt_times)
-      if (u < fd.Kp) {
-        Fv = Fv + y;
-        Dd += ddot(pu, y);
+  {
+    for (int li = tid; li < fd.numLoaded; li += 256) {
+      const int k = fd.loadedPos[li];
+      D3 Fv{0.0, 0.0, 0.0}, Nv{0.0, 0.0, 0.0};
+      double Dd = 0.0;
+      const int e1 = fd.posUnitStart[k + 1];
+      for (int e = fd.posUnitStart[k]; e < e1; ++e) {
+        const int u = fd.posUnits[e];
+        const D3 pu{m.up[3 * u], m.up[3 * u + 1], m.up[3 * u + 2]};
+        const D3 y = yOf(u, k, pu);
+        Nv = Nv + dcross(pu, y);
+        if (u < fd.Kp) {
+          Fv = Fv + y;
+          Dd += ddot(pu, y);
+        }
       }
+      double* o = m.X + 7 * li;
+      o[0] = Fv.x, o[1] = Fv.y, o[2] = Fv.z, o[3] = Nv.x, o[4] = Nv.y, o[5] = Nv.z, o[6] = Dd;
     }
-    double* o = m.X + 7 * li;
-    o[0] = Fv.x, o[1] = Fv.y, o[2] = Fv.z, o[3] = Nv.x, o[4] = Nv.y, o[5] = Nv.z, o[6] = Dd;
-  }
-  __syncthreads();
-  for (int item = tid; item < 7 * J; item += 256) {
-    const int k = item / 7, c = item - 7 * k;
-    double acc = 0.0;
-    const int l1 = m.hi[k];
-    for (int li = m.lo[k]; li < l1; ++li) {
-      acc += m.X[7 * li + c];
+    __syncthreads();
+    for (int item = tid; item < 7 * J; item += 256) {
+      const int k = item / 7, c = item - 7 * k;
+      double acc = 0.0;
+      const int l1 = m.hi[k];
+      for (int li = m.lo[k]; li < l1; ++li) {
+        acc += m.X[7 * li + c];
+      }
+      m.Y[7 * k + c] = acc;
     }
-    m.Y[7 * k + c] = acc;
+    __syncthreads();
   }
-  __syncthreads();
   for (int e = tid; e < nsrc; e += 256) {
     const int info = s.mInfo[e];
     m.X[e] = double(s.mW[e]) * sourceGradientD(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, m.js, m.Y + 7 * (s.mTin[e] & 0xffff));

@@ -71,11 +71,33 @@ __host__ __device__ inline size_t mixPersistentDoubles(int J, int P, int U, int 
 // (parameter_transform.cpp:110-124, joint_state.cpp:22-65, skeleton_state.cpp:87-121; pointer-jumping composition as in
 // the single-precision kernels, whose partial products are double already)
 // ---------------------------------------------------------------------------------------------
+// sin and cos of a joint half-angle in double without the library's large-argument path (its Payne-Hanek tables live in
+// scratch memory: 464 bytes per lane of the kernel).  Two-term Cody-Waite reduction by pi/2 -- n * pio2_1 is exact for |n| < 2^20 --
+// then fdlibm's kernel polynomials on [-pi/4, pi/4] (k_sin.c / k_cos.c, < 1 ulp; 1.1e-16 absolute against libm over |x| < 9e4).
+// Beyond |x| = 1e5 (no pose parameter is; a diverged run can be) the argument is first folded by 2 pi in plain double.
+__device__ __forceinline__ void mixSinCos(double x, double* sOut, double* cOut) {
+  if (!(fabs(x) < 1e5)) { // (a diverged run: bounded values of the right period, not the library's last-bit accuracy; NaN / Inf stay NaN)
+    x = fma(-rint(x * 1.59154943091895335769e-01), 6.28318530717958647693e+00, x);
+  }
+  const double fn = rint(x * 6.36619772367581382433e-01); // 2 / pi
+  double r = fma(-fn, 1.57079632673412561417e+00, x); // first 33 bits of pi / 2
+  r = fma(-fn, 6.07710050650619224932e-11, r); // pi / 2 - pio2_1
+  const int q = int(fn) & 3;
+  const double z = r * r;
+  const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sn = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+  const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cs = w + (((1.0 - w) - hz) + z * pc);
+  const double sv = (q & 1) ? cs : sn, cv = (q & 1) ? sn : cs;
+  *sOut = (q & 2) ? -sv : sv;
+  *cOut = ((q + 1) & 2) ? -cv : cv;
+}
 __device__ __forceinline__ void fkLocalFromParamsD(const double* p, const float* pre, const float* off, double* o, double* oq) {
   double sx, cx, sy, cy, sz, cz;
-  sincos(0.5 * p[3], &sx, &cx);
-  sincos(0.5 * p[4], &sy, &cy);
-  sincos(0.5 * p[5], &sz, &cz);
+  mixSinCos(0.5 * p[3], &sx, &cx);
+  mixSinCos(0.5 * p[4], &sy, &cy);
+  mixSinCos(0.5 * p[5], &sz, &cz);
   const DQ q0{double(pre[0]), double(pre[1]), double(pre[2]), double(pre[3])};
   const DQ q1 = dqmul(q0, DQ{0.0, 0.0, sz, cz});
   const DQ q2 = dqmul(q1, DQ{0.0, sy, 0.0, cy});

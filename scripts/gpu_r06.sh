@@ -21,7 +21,8 @@ case "$step" in
     timeout 900 python scripts/diag_mixed_rate.py > gpurun_out/mixed_rate.log 2>&1; cat gpurun_out/mixed_rate.log
     MMX_PHASE_CLOCKS=1 timeout 300 python scripts/diag_mixed_rate.py > gpurun_out/mixed_clocks.log 2>&1; cat gpurun_out/mixed_clocks.log ;;
   tests)  # the GPU suite (optionally -k expression)
-    timeout 2400 python -m pytest tests -m gpu -x -q "$@" > gpurun_out/pytest_gpu.log 2>&1; tail -15 gpurun_out/pytest_gpu.log ;;
+    if [ $# -eq 0 ]; then set -- tests; fi
+    timeout 2400 python -m pytest "$@" -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -25 gpurun_out/pytest_gpu.log ;;
   bench)
     timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 3000 gpurun_out/bench.json; tail -20 gpurun_out/bench.err ;;
   *) echo "unknown step $step"; exit 2 ;;

@@ -276,14 +276,19 @@ int main() {
     single.setPrecision(MMX_PRECISION_F64);
     std::vector<float> thD(P, 0.f);
     const double eD = single.solve(thD);
-    single.setPrecision(MMX_PRECISION_AUTO, 1e-30f); // a bound nothing passes: the element is escalated
+    single.setPrecision(MMX_PRECISION_MIXED); // ABI 11: double theta / FK / residuals / g around the single-precision factor
+    std::vector<float> thM(P, 0.f);
+    const double eM = single.solve(thM);
+    bool okp = (single.status() & MMX_SOLVE_MIXED) != 0 && (single.status() & MMX_SOLVE_ESCALATED_F64) == 0;
+    single.setPrecision(MMX_PRECISION_AUTO, 1e-30f); // a bound nothing passes: the element is solved again -- by the mixed instantiation
     std::vector<float> thA(P, 0.f);
     const double eA = single.solve(thA);
-    bool okp = (single.status() & MMX_SOLVE_ESCALATED_F64) != 0 && eA == eD;
+    okp = okp && (single.status() & MMX_SOLVE_MIXED) != 0 && eA == eM;
     for (size_t i = 0; i < P; ++i) {
-      okp = okp && thA[i] == thD[i] && std::fabs(thD[i] - th1[i]) <= 1e-2f * (1.f + std::fabs(th1[i]));
+      okp = okp && thA[i] == thM[i] && std::fabs(thD[i] - th1[i]) <= 1e-2f * (1.f + std::fabs(th1[i]));
+      okp = okp && std::fabs(thM[i] - thD[i]) <= 1e-5f * (1.f + std::fabs(thD[i])); // the mixed run follows the double one
     }
-    std::printf("precision: double on float parameters %.3g, AUTO (escalated) %.3g, identical %d\n", eD, eA, int(okp));
+    std::printf("precision: double on float parameters %.3g, mixed %.3g, AUTO (second pass: mixed) %.3g, identical %d\n", eD, eM, eA, int(okp));
     if (!okp) {
       ++bad;
     }

@@ -122,8 +122,6 @@ def test_mixed_holds_the_bound_where_single_precision_does_not(torch_cuda, orc, 
     pb = _problem(torch_cuda, rig, cons, B)
     e0 = np.array([orc.get_error(rig, cons.instance(b), th0[b].astype(np.float64), "f64") for b in range(0, B, 64)]).max()
     for lam in lams:
-        if lam <= 1e-5 and not line_search:
-            continue  # (undamped, no line search: the double run itself is chaotic on three quarters of the batch -- r06_weak_damping.json has the row)
         opt = GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=lam, do_line_search=line_search, precision=MMX_PRECISION_MIXED)
         out = _solve(torch_cuda, pb, th0, opt, want_history=True)
         with np.errstate(all="ignore"):
@@ -136,8 +134,17 @@ def test_mixed_holds_the_bound_where_single_precision_does_not(torch_cuda, orc, 
         same = np.all(np.abs(h - href) <= 1e-6 * np.abs(href) + 1e-7 * href[:, :1], axis=1) if line_search else np.ones(B, bool)
         held = sane & same & stable & (out["status"] & MMX_SOLVE_PRECISION_SUSPECT == 0)
         assert np.all(out["status"] & MMX_SOLVE_MIXED != 0) and np.all(out["status"] & MMX_SOLVE_ESCALATED_F64 == 0)
-        assert held.sum() >= 0.9 * (sane & stable).sum(), (name, lam, line_search, int(sane.sum()), int(stable.sum()), int(same.sum()), int(held.sum()))
-        assert rel[held].max() <= BOUND, (name, lam, line_search, float(rel[held].max()), int((rel[held] > BOUND).sum()))
+        flagged = out["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0
+        if name == "cfg2" and lam <= 1e-5:
+            # cond(J^T J + lambda I) = 1.4e7 here: cond x eps_f32 ~ 1, the single-precision factor is no preconditioner any more and
+            # the conjugate gradients run into their step limit -- the route SAYS so (MMX_SOLVE_PRECISION_SUSPECT on the element;
+            # MMX_PRECISION_AUTO then takes it to the double kernel, tests/test_gpu_precision.py); nothing unflagged is above the bound
+            assert flagged.mean() >= 0.9, float(flagged.mean())
+        else:
+            assert held.sum() >= 0.9 * (sane & stable).sum(), (name, lam, line_search, int(sane.sum()), int(stable.sum()), int(same.sum()), int(held.sum()))
+            assert flagged.mean() <= 0.02, float(flagged.mean())
+        if held.any():
+            assert rel[held].max() <= BOUND, (name, lam, line_search, float(rel[held].max()), int((rel[held] > BOUND).sum()))
         assert np.isfinite(out["theta"]).all()
 
 
@@ -174,12 +181,12 @@ def test_mixed_with_an_enabled_subset_and_per_instance_weights(torch_cuda, orc):
 
 def test_mixed_outside_its_scope_is_the_double_instantiation(torch_cuda):
     """The trust region is not built into the mixed instantiation: MMX_PRECISION_MIXED then runs the double kernel on every
-    element (MMX_SOLVE_ESCALATED_F64), bit for bit MMX_PRECISION_F64's result."""
+    element: MMX_PRECISION_F64's result bit for bit (no MMX_SOLVE_MIXED bit on the status)."""
     B = 64
     rig, cons, th0 = _cfg2(B)
     pb = _problem(torch_cuda, rig, cons, B)
     mk = lambda prec: GnOptions.make(min_iterations=5, max_iterations=5, threshold=1.0, step_rule=MMX_STEP_TRUST_REGION, precision=prec)
     a = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_MIXED))
     d = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_F64))
-    assert np.all(a["status"] & MMX_SOLVE_ESCALATED_F64 != 0) and np.all(a["status"] & MMX_SOLVE_MIXED == 0)
+    assert np.all(a["status"] & MMX_SOLVE_MIXED == 0)
     assert np.array_equal(a["theta"], d["theta"]) and np.array_equal(a["status"], d["status"])

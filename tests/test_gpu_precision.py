@@ -101,7 +101,7 @@ def test_auto_with_a_bound_nothing_passes_escalates_every_element(torch_cuda, or
     bit = MMX_SOLVE_MIXED if route == "auto" else MMX_SOLVE_ESCALATED_F64
     assert np.all(a["status"] & bit != 0) and np.all(a["status"] & (MMX_SOLVE_MIXED | MMX_SOLVE_ESCALATED_F64) == bit)
     if route == "wide":
-        assert np.all(a["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0) and np.all(d["status"] & MMX_SOLVE_ESCALATED_F64 != 0)  # (MIXED outside its scope = the double instantiation)
+        assert np.all(a["status"] & MMX_SOLVE_PRECISION_SUSPECT != 0)
     assert np.all(a["status"] & 3 == 0)
     for k in ("theta", "error", "iterations", "error_history", "step_history"):
         assert np.array_equal(a[k], d[k]), k
