@@ -56,7 +56,17 @@ CONFIGS = {
     # production-shaped: what marker_tracker.cpp:916-960 adds to the marker constraints -- a plane block (8 floor contacts,
     # PlaneErrorFunction) and MinMax limits on 16 parameters (LimitErrorFunction); takes the fused solve's general rows
     "cfg2_tracker": ("p128", "landmarks+tracker", 4096, 0, "BASELINE configs[1] + PlaneErrorFunction (8 constraints) + 16 MinMax parameter limits (M=192+8+16)"),
+    # the reference's own asset: examples/convert_model/test_data/character_with_motion.glb (skeleton + parameter transform read from
+    # the FB_momentum extension by momentum_amd.model_io; the committed fixture tests/golden/real_rig_character_with_motion.npz
+    # carries what the loader extracted -- the GPU box has no reference checkout), constraints as momentum/test/character_solver/
+    # solver_test.cpp:90-103 places them: position + orientation on every joint
+    "glb": ("fixture:real_rig_character_with_motion.npz", "all", 4096, 0, "the reference's character_with_motion.glb (3 joints, 10 parameters), position+orientation on every joint (M=36)"),
 }
+
+# pymomentum's batched driver as it is called without arguments (pymomentum/tensor_ik/solver_options.h:28-37: lambda = 0.01, at least 4
+# and at most 50 iterations, threshold 10, line search on -- the rule of the solvers it selects, SubsetGN / GN-QR): a
+# convergence-driven exit per element instead of BASELINE's ten fixed iterations
+DRIVER_DEFAULTS = dict(regularization=0.01, min_iterations=4, max_iterations=50, threshold=10.0, do_line_search=2)
 
 # what the default single-GPU run reports besides the headline: (key, config, batch, line_search, timed steps, CPU sample, lambda[, dtype])
 EXTRA_RUNS = [
@@ -64,7 +74,17 @@ EXTRA_RUNS = [
     ("cfg2@32768", "cfg2", 32768, 0, 6, 8192, 0.05),
     ("cfg2@4096 line_search=2", "cfg2", 4096, 2, 10, 4096, 0.05),
     ("cfg5@8192", "cfg5", 8192, 0, 3, 1024, 0.05),
+    # SURVEY 8(d)'s stress variant (the shape of solver_test.cpp:90-103): P = 219, both constraints on all 72 joints, M = 864
+    ("cfg2_all@4096", "cfg2_all", 4096, 0, 4, 1024, 0.05),
     ("cfg2_tracker@4096", "cfg2_tracker", 4096, 0, 10, 4096, 0.05),
+    # the batched driver's real defaults (DRIVER_DEFAULTS): what a solve_ik caller sees, on BASELINE's rig and on the reference's own
+    ("cfg2@4096 solve_ik defaults", "cfg2", 4096, 2, 6, 1024, 0.01, "f32", 0, True),
+    ("glb@4096 solve_ik defaults", "glb", 4096, 2, 6, 2048, 0.01, "f32", 0, True),
+    # MMX_PRECISION_MIXED (ABI 11): double theta / FK / residuals / g / linear-solve residual around the single-precision factor
+    # (with the batched driver's line search, like the AUTO line below: without one the undamped iteration is chaotic in double on a
+    # few per cent of these instances -- profiles/r06_weak_damping.json has both)
+    ("cfg2@4096 lambda=1e-3 line_search=2 precision=mixed", "cfg2", 4096, 2, 6, 1024, 1e-3, "f32", 3),
+    ("cfg3@65536 precision=mixed", "cfg3", 65536, 0, 3, 4096, 0.05, "f32", 3),
     # the double instantiation (mmx_solve_f64, SolverT<double>) on the weak-damping case the single-precision line below
     # cannot hold: checked against the oracle's double run on the instances whose line-search decisions agree, with the
     # oracle's DOUBLE instantiation as its CPU baseline
@@ -98,6 +118,14 @@ def build_rig(config: str):
     from momentum_amd import humanoid72_landmark_joints, make_humanoid72
 
     variant, which, defB, step_rule, desc = CONFIGS[config]
+    if variant.startswith("fixture:"):
+        from momentum_amd.rigs import Rig
+
+        g = np.load(os.path.join(ROOT, "tests", "golden", variant.split(":", 1)[1]))
+        rig = Rig(g["parent"], g["pre_rotation"], g["translation_offset"], g["pt_outer"], g["pt_inner"], g["pt_value"], g["pt_offsets"],
+                  len(g["param_names"]), [str(x) for x in g["joint_names"]], [str(x) for x in g["param_names"]])  # fmt: skip
+        allj = np.arange(rig.num_joints, dtype=np.int32)
+        return rig, (allj, allj), defB, step_rule, desc
     if variant == "rig300":
         from momentum_amd import make_rig300
 
@@ -224,6 +252,8 @@ def parity_check(db: DeviceBatch, theta_gpu, options, n, line_search_aware=False
         "bound": PARITY_BOUND,
         "pass": bool(rel.max() <= PARITY_BOUND),
     }
+    if options.min_iterations != options.max_iterations:
+        out["oracle_iterations"] = [int(x) for x in ref["iterations"]]
     if out["num_above_bound"] > 0:
         # `pass` is the strict bound.  Beside it, for the instances above the bound: what the oracle's own FLOAT instantiation
         # (the restatement of the reference's SolverT<float>) loses on them.  Three things put an instance there without any
@@ -400,6 +430,7 @@ def solve_loop(db: DeviceBatch, opt, steps, warmup, dist=None, comm=None, dtype=
     elapsed_rank = elapsed
     elapsed = D.reduce_max(dist, elapsed, dev)
     db.last_status = outputs["status"]
+    db.pb_last_iterations = outputs["iterations"]
     db.last_elapsed_rank = elapsed_rank
     return elapsed, theta, [float(x) for x in norms.tolist()]
 
@@ -450,14 +481,21 @@ def compact_check(chk):
     return out
 
 
-def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu, regularization=0.05, dtype="f32", precision=0):
+PRECISIONS = ["f32", "f64", "auto", "mixed"]  # MMX_PRECISION_*
+
+
+def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iterations, check_n, with_cpu, regularization=0.05, dtype="f32", precision=0, driver_defaults=False):
     """One side configuration: (compact entry of the bench line, details for the side file)."""
     from momentum_amd._abi import GnOptions
 
     rig, parents, _, step_rule, desc = build_rig(config)
     db = DeviceBatch(rig, parents, B, device_index, 424242, tracker=CONFIGS[config][1].endswith("+tracker"))
-    opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=regularization, step_rule=step_rule,
-                         do_line_search=line_search, precision=precision)  # fmt: skip
+    if driver_defaults:
+        opt = GnOptions.make(step_rule=step_rule, precision=precision, **DRIVER_DEFAULTS)
+        iterations = DRIVER_DEFAULTS["max_iterations"]
+    else:
+        opt = GnOptions.make(min_iterations=iterations, max_iterations=iterations, threshold=1.0, regularization=regularization, step_rule=step_rule,
+                             do_line_search=line_search, precision=precision)  # fmt: skip
     elapsed, theta, norms = solve_loop(db, opt, steps, 1, dtype=dtype)
     status = db.last_status
     chk = parity_check(db, theta, opt, check_n, line_search_aware=line_search != 0)
@@ -469,7 +507,7 @@ def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iter
         "regularization": regularization,
         "batch": B,
         "line_search": line_search,
-        "precision": ["f32", "f64", "auto"][precision],
+        "precision": PRECISIONS[precision],
         "step_rule": "lm_schedule" if step_rule == 1 else "gn_fixed_lambda",
         "solves_per_s": B * steps / elapsed,
         "ms_per_step": 1e3 * elapsed / steps,
@@ -480,6 +518,7 @@ def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iter
         "damping_floored_instances": int((status & 4 != 0).sum()) if status is not None else None,
         "precision_suspect_instances": int((status & 8 != 0).sum()) if status is not None else None,
         "escalated_f64_instances": int((status & 16 != 0).sum()) if status is not None else None,
+        "mixed_instances": int((status & 32 != 0).sum()) if status is not None else None,
         "check": chk,
         "solver": factor_structure(db.pb) if dtype == "f32" else {"route": "mmx_solve_f64", "solved_parameters": n_solved},
         "dense_equivalent_tflops": B * steps / elapsed * dense_flops / 1e12,
@@ -501,10 +540,24 @@ def run_extra(key, config, B, line_search, steps, cpu_sample, device_index, iter
         "route": details["solver"]["route"],
         **compact_check(chk),
     }
-    if precision == 2:
-        compact["escalated_f64"] = details["escalated_f64_instances"]
+    if precision in (2, 3):
+        compact["escalated_f64"], compact["mixed"] = details["escalated_f64_instances"], details["mixed_instances"]
+        compact["precision_suspect"] = details["precision_suspect_instances"]  # (mixed: conjugate gradients that met their step limit)
     if dtype == "f32" and precision == 0:
         compact["precision_suspect"] = details["precision_suspect_instances"]
+    if driver_defaults:
+        # convergence-driven exits: how many iterations the elements took (solver.cpp:96-119), and whether the oracle's double run
+        # took the same number on the checked ones
+        its = db.pb_last_iterations.cpu().numpy() if getattr(db, "pb_last_iterations", None) is not None else None
+        if its is not None:
+            vals, cnt = np.unique(its, return_counts=True)
+            compact["iterations_mean"] = float(its.mean())
+            compact["iterations_histogram"] = [[int(v), int(c)] for v, c in zip(vals, cnt)]
+            compact["options"] = "lambda=0.01 min=4 max=50 threshold=10 line_search=2 (solver_options.h:28-37)"
+            if chk and "oracle_iterations" in chk:
+                compact["iterations_equal_oracle"] = f"{int((its[: len(chk['oracle_iterations'])] == np.asarray(chk['oracle_iterations'])).sum())}/{len(chk['oracle_iterations'])}"
+                details["oracle_iterations_histogram"] = [[int(v), int(c)] for v, c in zip(*np.unique(chk["oracle_iterations"], return_counts=True))]
+                del chk["oracle_iterations"]
     if config == "cfg5":
         compact["jtj_dense_equivalent_tflops"] = B * steps / elapsed * iterations * float(db.pb.M) * n_solved * n_solved / 1e12
     if with_cpu:
@@ -559,6 +612,18 @@ SHORT = {  # compact workload names of the bench line (the full descriptions: CO
 }
 
 
+def build_stamp():
+    """Which pipeline the solve kernels of the loaded library were compiled with (momentum_amd/build_info.json): the headline
+    depends on two internal -mllvm switches; a toolchain that rejects them gets the default pipeline, and the line says so."""
+    try:
+        from momentum_amd import build as mbuild
+
+        info = mbuild.build_info()
+        return {"solve_kernel_pipeline": info.get("solve_kernel_pipeline", "unknown"), "flags_rejected_by_compiler": info.get("flags_rejected_by_compiler")}
+    except Exception:
+        return {"solve_kernel_pipeline": "unknown"}
+
+
 def round_floats(x, digits=6):
     """Floats of the bench line to `digits` significant digits (a compact line; nothing is compared at more)."""
     if isinstance(x, float):
@@ -583,11 +648,13 @@ def main() -> None:
     ap.add_argument("--check-instances", type=int, default=1024, help="distinct instances of the timed batch re-solved by the oracle (0 = skip)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the other BASELINE configurations (N = 1 default run reports them)")
     ap.add_argument("--jac-launches", type=int, default=20)
-    ap.add_argument("--measure-traffic", action="store_true", help="measure roofline.traffic in this run (rocprofv3 --pmc over a child process; adds about a minute)")
+    ap.add_argument("--measure-traffic", action="store_true", help="measure roofline.traffic in this run (rocprofv3 --pmc over a child process; adds about a minute).  ON by default for the default single-GPU run when rocprofv3 is on the path")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="never run the rocprofv3 passes: roofline.traffic then comes from the committed pass (profiles/pmc_jacobian.json) and the line says so")
     ap.add_argument("--line-search", type=int, default=0, choices=[0, 1, 2], help="MMX_LINE_SEARCH_*: 0 none (the BASELINE metric), 1 GaussNewtonSolverT's rule, 2 the rule of the batched driver's solvers (SubsetGN / GN-QR)")
     ap.add_argument("--lambda", dest="regularization", type=float, default=0.05, help="GaussNewtonSolverOptions::regularization (the BASELINE metric: 0.05)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64: mmx_solve_f64 (SolverT<double>; built for exactness, see DESIGN.md)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64", "auto"], help="mmx_gn_options::precision of mmx_solve (auto: the elements the single-precision solve marks are re-solved in double)")
+    ap.add_argument("--precision", default="f32", choices=PRECISIONS, help="mmx_gn_options::precision of mmx_solve (mixed: double theta / FK / residuals / g around the single-precision factor; auto: the elements the single-precision solve marks are solved again by the mixed instantiation, what that cannot converge by the double one)")
+    ap.add_argument("--driver-defaults", action="store_true", help="the batched driver's real defaults instead of ten fixed iterations (lambda 0.01, 4..50 iterations, threshold 10, line search 2)")
     ap.add_argument("--details", default="", help="where the details of the run go (default gpurun_out/bench_details.json)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for the plumbing test)")
     args = ap.parse_args()
@@ -629,7 +696,9 @@ def main() -> None:
     db = DeviceBatch(rig, parents, B, local_rank, seed, tracker=CONFIGS[args.config][1].endswith("+tracker"))
     pb, theta_star = db.pb, db.theta_star
     opt = GnOptions.make(min_iterations=args.iterations, max_iterations=args.iterations, threshold=1.0, regularization=args.regularization, step_rule=step_rule,
-                         do_line_search=args.line_search, precision=["f32", "f64", "auto"].index(args.precision))  # fmt: skip
+                         do_line_search=args.line_search, precision=PRECISIONS.index(args.precision))  # fmt: skip
+    if args.driver_defaults:
+        opt = GnOptions.make(step_rule=step_rule, precision=PRECISIONS.index(args.precision), **DRIVER_DEFAULTS)
     dev = pb.device
     elapsed, theta_final, (total_err, total_it, failed) = solve_loop(db, opt, args.steps, args.warmup, dist, comm, args.dtype)
     # per-rank rates (each rank's own clock around the same K steps) next to the aggregate, which uses the slowest rank's time
@@ -662,7 +731,9 @@ def main() -> None:
     # process that launches the same kernel on the same shape, scripts/pmc_traffic.py); otherwise the committed pass of the
     # same shape (profiles/pmc_jacobian.json), and the line says which
     traffic, traffic_source = None, None
-    if args.measure_traffic and rank == 0 and world == 1:
+    default_shape = world == 1 and args.config == "cfg2" and args.batch == 0
+    want_traffic = (args.measure_traffic or default_shape) and not args.no_measure_traffic
+    if want_traffic and rank == 0 and world == 1:
         traffic = measure_traffic(args.config, B)
         traffic_source = "rocprofv3 --pmc in this run" if traffic is not None else None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_jacobian.json")
@@ -717,6 +788,21 @@ def main() -> None:
                 extra[f"at_batch_{BL}"] = {"achieved": gbsL, "frac": gbsL / HBM_PEAK_GBS, "ms_per_launch": msL}
                 del jacL, resL, errL, dbL
                 torch.cuda.empty_cache()
+            # ... and on SURVEY 8(d)'s stress variant (P = 219, both constraints on all 72 joints: M = 864, 766 380 B per instance)
+            rigA, parA, _, _, _ = build_rig("cfg2_all")
+            dbA = DeviceBatch(rigA, parA, 4096, local_rank, seed + 2)
+            MA, PA = dbA.pb.M, dbA.pb.P
+            jacA = torch.empty((4096, PA, MA), dtype=torch.float32, device=dev)
+            resA = torch.empty((4096, MA), dtype=torch.float32, device=dev)
+            errA = torch.empty((4096,), dtype=torch.float64, device=dev)
+            for _ in range(2):
+                dbA.pb.eval_jacobian(dbA.theta_star, jacA, resA, errA)
+            msA = float(np.mean([dbA.pb.eval_jacobian_kernel_ms(dbA.theta_star, jacA, resA, errA) for _ in range(5)]))
+            bpiA = algorithmic_bytes_per_instance(MA, PA, len(parA[0]), len(parA[1]))
+            gbsA = 4096 * bpiA / (msA * 1e-3) / 1e9
+            extra["cfg2_all_at_batch_4096"] = {"achieved": gbsA, "frac": gbsA / HBM_PEAK_GBS, "ms_per_launch": msA, "bytes_per_instance": bpiA}
+            del jacA, resA, errA, dbA
+            torch.cuda.empty_cache()
 
     if rank == 0:
         solves = float(B) * world * args.steps
@@ -763,7 +849,8 @@ def main() -> None:
             },
             "check": {"sum_final_error": total_err, "sum_iterations": total_it, "failed_instances": failed,
                       "damping_floored": int((status & 4 != 0).sum()), "precision_suspect": int((status & 8 != 0).sum()),
-                      "escalated_f64": int((status & 16 != 0).sum())},
+                      "escalated_f64": int((status & 16 != 0).sum()), "mixed": int((status & 32 != 0).sum())},
+            "build": build_stamp(),
             "roofline": {
                 "kernel": "fkJacobianKernel<true> (mmx_eval_jacobian)",
                 "bound": "hbm",
@@ -795,7 +882,7 @@ def main() -> None:
             line["check"].update(compact_check(chk))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], details["cpu_baseline"] = cpu_baseline(db, args.cpu_sample, opt, args.dtype, dense_flops)
-        default_run = world == 1 and args.config == "cfg2" and args.batch == 0 and args.line_search == 0 and args.dtype == "f32" and args.precision == "f32"
+        default_run = world == 1 and args.config == "cfg2" and args.batch == 0 and args.line_search == 0 and args.dtype == "f32" and args.precision == "f32" and not args.driver_defaults
         if default_run and not args.no_extra_configs:
             del db, pb
             torch.cuda.empty_cache()

@@ -23,7 +23,13 @@ case "$step" in
   tests)  # the GPU suite (optionally -k expression)
     if [ $# -eq 0 ]; then set -- tests; fi
     timeout 2400 python -m pytest "$@" -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -25 gpurun_out/pytest_gpu.log ;;
-  bench)
-    timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 3000 gpurun_out/bench.json; tail -20 gpurun_out/bench.err ;;
+  bench)  # the driver's command (no arguments = the default run: its line and side file are the ones profiles/ keeps)
+    if [ $# -eq 0 ]; then
+      SECONDS=0; timeout 1500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+      echo "Elapsed ${SECONDS}s" >> gpurun_out/bench_default.err; cp gpurun_out/bench_details.json gpurun_out/bench_default_details.json
+      wc -c gpurun_out/bench_default.json; tail -c 1500 gpurun_out/bench_default.json; grep -E "^\[bench\]|Elapsed|Error|Traceback" gpurun_out/bench_default.err
+    else
+      timeout 900 python bench.py --details gpurun_out/bench_other_details.json "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 3000 gpurun_out/bench.json; tail -20 gpurun_out/bench.err
+    fi ;;
   *) echo "unknown step $step"; exit 2 ;;
 esac
