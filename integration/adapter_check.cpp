@@ -71,7 +71,29 @@ int main() {
   o.linearSolverType = pymomentum::LinearSolverType::QR, o.levmar_lambda = 0.01f, o.minIter = 4, o.maxIter = 50, o.threshold = 10.f, o.lineSearch = true;
   momentum::ParameterSet all;
   all.set();
-  mmx_adapter::solveBatch(rig, all, t, o, theta.data());
+  std::vector<int32_t> status(B, 0);
+  t.status = status.data();
+  const mmx_adapter::SolveReport rep = mmx_adapter::solveBatch(rig, all, t, o, theta.data()); // solveTensorIKProblem<float>: MMX_PRECISION_AUTO
+  // whatever the policy decided per element (single precision where its own estimate holds 1e-5, the mixed-precision
+  // instantiation or the double kernel elsewhere), nothing may have failed and the counts must add up
+  if (rep.failed != 0 || rep.mixed + rep.escalatedF64 > B) {
+    std::printf("FAIL: AUTO report: suspect %lld mixed %lld f64 %lld failed %lld\n", (long long)rep.precisionSuspect, (long long)rep.mixed, (long long)rep.escalatedF64, (long long)rep.failed);
+    return 1;
+  }
+  // solveTensorIKProblem<double> through the same adapter: the double instantiation on double parameters; the float answer follows it
+  std::vector<double> thetaD(B * 10, 0.0);
+  const mmx_adapter::SolveReport repD = mmx_adapter::solveBatch(rig, all, t, o, thetaD.data());
+  if (repD.failed != 0 || repD.mixed != 0) {
+    std::printf("FAIL: double report\n");
+    return 1;
+  }
+  for (int i = 0; i < B * 10; ++i) {
+    if (!(std::fabs(double(theta[i]) - thetaD[i]) <= 1e-5 * (1.0 + std::fabs(thetaD[i])))) {
+      std::printf("FAIL: parameter %d: float/AUTO %.9g, double %.9g\n", i, double(theta[i]), thetaD[i]);
+      return 1;
+    }
+  }
+  std::printf("AUTO: %lld of %d elements by the mixed-precision instantiation, %lld by the double kernel; within 1e-5 of solveBatch<double>\n", (long long)rep.mixed, B, (long long)rep.escalatedF64);
   // the solved pose puts joint 2's UnitY point on its target: check through the forward pass of the library
   mmx_problem* pb = nullptr;
   if (mmx_problem_create(rig, B, 0, nullptr, 0, nullptr, &pb) != MMX_OK) {

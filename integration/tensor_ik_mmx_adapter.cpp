@@ -43,25 +43,23 @@ mmx_rig* makeRig(const momentum::Character& c, int device) {
   return rig;
 }
 
-// the body of solveTensorIKProblem<float> when the GPU path applies: what the dispenso::parallel_for over the batch
-// elements (tensor_ik.cpp:127-177) does, for all elements at once.  modelParameters: [nBatch][P], initial values in,
-// solution out (an element whose result is not finite keeps its initial values, :168-173).
-void solveBatch(
-    mmx_rig* rig,
-    const momentum::ParameterSet& activeParams,
-    const BatchTensors& t,
-    const pymomentum::SolverOptions& options,
-    float* modelParameters) {
+namespace {
+
+// problem handle + constraints + options of one batch (what both scalar types share)
+struct Prepared {
   mmx_problem* pb = nullptr;
-  MT_THROW_IF(mmx_problem_create(rig, int32_t(t.nBatch), t.numPositions, t.positionParents, t.numOrientations, t.orientationParents, &pb) != MMX_OK, mmx_last_error());
-  struct Guard {
-    mmx_problem* p;
-    ~Guard() { mmx_problem_destroy(p); }
-  } guard{pb};
+  mmx_gn_options o{};
+  std::vector<float> fw;
+  ~Prepared() { mmx_problem_destroy(pb); }
+};
+
+void prepare(Prepared& p, mmx_rig* rig, const momentum::ParameterSet& activeParams, const BatchTensors& t, const pymomentum::SolverOptions& options) {
+  MT_THROW_IF(mmx_problem_create(rig, int32_t(t.nBatch), t.numPositions, t.positionParents, t.numOrientations, t.orientationParents, &p.pb) != MMX_OK, mmx_last_error());
+  mmx_problem* pb = p.pb;
   const int32_t P = mmx_rig_num_params(rig);
   std::vector<uint8_t> enabled(size_t(P), 0);
-  for (int32_t p = 0; p < P; ++p) {
-    enabled[size_t(p)] = activeParams.test(size_t(p)) ? 1 : 0;
+  for (int32_t q = 0; q < P; ++q) {
+    enabled[size_t(q)] = activeParams.test(size_t(q)) ? 1 : 0;
   }
   MT_THROW_IF(mmx_problem_set_enabled(pb, enabled.data()) != MMX_OK, mmx_last_error());
   if (t.perElementTranslationOffsets != nullptr || t.perElementPreRotations != nullptr) { // characters[iBatch] (:129,140)
@@ -77,36 +75,81 @@ void solveBatch(
   cd.memory = MMX_MEM_HOST;
   // errorFunctionWeights [nBatch][numWeightColumns] + weightsMap (tensor_ik.cpp:100-101): one column per block in the ABI's
   // order (position, orientation); weightsMap[iErr] < 0 means weight 0 (tensor_ik_utility.cpp:176)
-  std::vector<float> fw(size_t(t.nBatch) * 2, 1.f);
+  p.fw.assign(size_t(t.nBatch) * 2, 1.f);
   if (t.errorFunctionWeights != nullptr) {
     for (int64_t b = 0; b < t.nBatch; ++b) {
       for (int k = 0; k < 2; ++k) {
         const int col = t.weightsMap[k];
-        fw[size_t(2 * b + k)] = col < 0 ? 0.f : t.errorFunctionWeights[size_t(b) * size_t(t.numWeightColumns) + size_t(col)];
+        p.fw[size_t(2 * b + k)] = col < 0 ? 0.f : t.errorFunctionWeights[size_t(b) * size_t(t.numWeightColumns) + size_t(col)];
       }
     }
-    cd.function_weights = fw.data();
+    cd.function_weights = p.fw.data();
     cd.num_function_weights = 2;
   }
   MT_THROW_IF(mmx_problem_set_constraints_sized(pb, &cd, sizeof(cd), nullptr) != MMX_OK, mmx_last_error());
-  mmx_gn_options o;
-  mmx_gn_options_default(&o);
-  o.min_iterations = int32_t(options.minIter);
-  o.max_iterations = int32_t(options.maxIter);
-  o.threshold = options.threshold;
-  o.regularization = options.levmar_lambda;
+  mmx_gn_options_default(&p.o);
+  p.o.min_iterations = int32_t(options.minIter);
+  p.o.max_iterations = int32_t(options.maxIter);
+  p.o.threshold = options.threshold;
+  p.o.regularization = options.levmar_lambda;
   // SubsetGaussNewtonSolver / GaussNewtonSolverQR share one backtracking rule (tensor_ik.cpp:142-158)
-  o.do_line_search = options.lineSearch ? MMX_LINE_SEARCH_DIRECTIONAL : MMX_LINE_SEARCH_NONE;
+  p.o.do_line_search = options.lineSearch ? MMX_LINE_SEARCH_DIRECTIONAL : MMX_LINE_SEARCH_NONE;
   if (options.linearSolverType == pymomentum::LinearSolverType::TrustRegionQR) {
-    o.step_rule = MMX_STEP_TRUST_REGION;
+    p.o.step_rule = MMX_STEP_TRUST_REGION;
   }
-  std::vector<int32_t> status(size_t(t.nBatch), 0);
-  MT_THROW_IF(mmx_solve_host(pb, &o, modelParameters, nullptr, nullptr, status.data()) != MMX_OK, mmx_last_error());
-  if (t.dampingFloored != nullptr) { // informational: elements whose damping sat below the single-precision factor's floor
-    for (int64_t b = 0; b < t.nBatch; ++b) {
-      t.dampingFloored[b] = (status[size_t(b)] & MMX_SOLVE_DAMPING_FLOORED) != 0;
+}
+
+SolveReport report(const BatchTensors& t, const std::vector<int32_t>& status) {
+  SolveReport r;
+  for (int64_t b = 0; b < t.nBatch; ++b) {
+    const int32_t s = status[size_t(b)];
+    r.precisionSuspect += (s & MMX_SOLVE_PRECISION_SUSPECT) != 0;
+    r.mixed += (s & MMX_SOLVE_MIXED) != 0;
+    r.escalatedF64 += (s & MMX_SOLVE_ESCALATED_F64) != 0;
+    r.dampingFloored += (s & MMX_SOLVE_DAMPING_FLOORED) != 0;
+    r.failed += MMX_SOLVE_FAILED(s) ? 1 : 0;
+    if (t.dampingFloored != nullptr) { // informational: elements whose damping sat below the single-precision factor's floor
+      t.dampingFloored[b] = (s & MMX_SOLVE_DAMPING_FLOORED) != 0;
+    }
+    if (t.status != nullptr) {
+      t.status[b] = s;
     }
   }
+  return r;
+}
+
+} // namespace
+
+// the body of solveTensorIKProblem<float> when the GPU path applies: what the dispenso::parallel_for over the batch
+// elements (tensor_ik.cpp:127-177) does, for all elements at once.  modelParameters: [nBatch][P], initial values in,
+// solution out (an element whose result is not finite keeps its initial values, :168-173).
+SolveReport solveBatch(
+    mmx_rig* rig,
+    const momentum::ParameterSet& activeParams,
+    const BatchTensors& t,
+    const pymomentum::SolverOptions& options,
+    float* modelParameters,
+    int32_t precision) {
+  Prepared p;
+  prepare(p, rig, activeParams, t, options);
+  p.o.precision = precision; // (ABI 10 / 11; precision_bound keeps its default: north_star's 1e-5)
+  std::vector<int32_t> status(size_t(t.nBatch), 0);
+  MT_THROW_IF(mmx_solve_host(p.pb, &p.o, modelParameters, nullptr, nullptr, status.data()) != MMX_OK, mmx_last_error());
+  return report(t, status);
+}
+
+// solveTensorIKProblem<double>: the double instantiation on double parameters
+SolveReport solveBatch(
+    mmx_rig* rig,
+    const momentum::ParameterSet& activeParams,
+    const BatchTensors& t,
+    const pymomentum::SolverOptions& options,
+    double* modelParameters) {
+  Prepared p;
+  prepare(p, rig, activeParams, t, options);
+  std::vector<int32_t> status(size_t(t.nBatch), 0);
+  MT_THROW_IF(mmx_solve_f64_host(p.pb, &p.o, modelParameters, nullptr, nullptr, status.data()) != MMX_OK, mmx_last_error());
+  return report(t, status);
 }
 
 } // namespace mmx_adapter

@@ -39,7 +39,21 @@ struct BatchTensors {
   const int32_t* perElementPositionParents = nullptr; // [B][numPositions] or null
   const int32_t* perElementOrientationParents = nullptr; // [B][numOrientations] or null
   bool* dampingFloored = nullptr; // [B] out, or null
+  int32_t* status = nullptr; // [B] out, or null: the elements' MMX_SOLVE_* bit sets
 };
-void solveBatch(mmx_rig* rig, const momentum::ParameterSet& activeParams, const BatchTensors& t, const pymomentum::SolverOptions& options, float* modelParameters);
+// what a batch's precision policy did (ABI 11): how many elements the single-precision solve marked, how many the
+// mixed-precision instantiation and the double kernel solved again, how many failed (MMX_SOLVE_FAILED: non-finite -> reverted)
+struct SolveReport {
+  int64_t precisionSuspect = 0, mixed = 0, escalatedF64 = 0, failed = 0, dampingFloored = 0;
+};
+// solveTensorIKProblem<float>: float parameters in and out.  precision: MMX_PRECISION_AUTO by default -- single precision where its
+// own estimate holds north_star's 1e-5 against the double instantiation, the mixed-precision instantiation (double theta / forward
+// kinematics / residuals / g around the single-precision factor) on the elements it marks, the double kernel on what that cannot
+// converge; MMX_PRECISION_F32 is BASELINE's metric, MMX_PRECISION_MIXED / F64 follow GaussNewtonSolverT<double> everywhere.
+SolveReport solveBatch(mmx_rig* rig, const momentum::ParameterSet& activeParams, const BatchTensors& t, const pymomentum::SolverOptions& options, float* modelParameters,
+                       int32_t precision = MMX_PRECISION_AUTO);
+// solveTensorIKProblem<double> (tensor_ik.cpp is templated on T; gauss_newton_solver.cpp:315-316 instantiates both): double
+// parameters in and out through mmx_solve_f64_host, every element by the double instantiation
+SolveReport solveBatch(mmx_rig* rig, const momentum::ParameterSet& activeParams, const BatchTensors& t, const pymomentum::SolverOptions& options, double* modelParameters);
 
 } // namespace mmx_adapter

@@ -2275,7 +2275,12 @@ static int32_t solveImpl(
   if (o->precision == MMX_PRECISION_MIXED && mixedOk) {
     return solveMixedImpl(pb, o, theta_dev, final_error, iterations, status, error_history, parameter_history, step_history, mmx::MixSelect{nullptr, nullptr, nullptr}, stream);
   }
-  if (o->precision == MMX_PRECISION_F64 || o->precision == MMX_PRECISION_MIXED) { // (MIXED outside the mixed instantiation's scope: the double one)
+  // MMX_PRECISION_AUTO with the trust region: the rule's elements are marginal by construction (it starts from lambda = 1e-10, the
+  // factor's damping floor engages on every element, and its Newton updates of lambda divide two fp32 quadratic forms: the
+  // single-precision instantiation is held to 1e-4, tests/test_gpu_trust_region.py) and the mixed instantiation does not carry the
+  // rule -- the policy's answer is the double kernel for every element, without a single-precision pass thrown away first
+  const bool autoTrust = o->precision == MMX_PRECISION_AUTO && o->step_rule == MMX_STEP_TRUST_REGION;
+  if (o->precision == MMX_PRECISION_F64 || o->precision == MMX_PRECISION_MIXED || autoTrust) { // (MIXED outside the mixed instantiation's scope: the double one)
     // every workgroup reads its element's parameters before it writes them: in place on the caller's float array
     return solveF64Impl(pb, o, nullptr, final_error, iterations, status, error_history, step_history, mmx::F64Select{nullptr, nullptr, theta_dev, theta_dev}, stream);
   }

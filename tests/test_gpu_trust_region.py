@@ -166,3 +166,57 @@ def test_trust_region_is_refused_on_the_explicit_jacobian_route(torch_cuda):
     with pytest.raises(capi.MmxError) as ei:
         pb.solve(torch.from_numpy(th0.copy()).to(pb.device), GnOptions.make(step_rule=MMX_STEP_TRUST_REGION))
     assert "MMX_STEP_TRUST_REGION" in str(ei.value)
+
+
+@pytest.mark.parametrize("precision", ["auto", "mixed"])
+def test_trust_region_under_auto_and_mixed_holds_1e5_on_the_reference_fixture(torch_cuda, orc, precision):
+    """TrustRegionQR is one of the three solvers solveTensorIKProblem can pick (tensor_ik.cpp:150-152).  The single-precision
+    instantiation of the rule is held to 1e-4 on >= 80 % same-path elements (above): the Newton updates of lambda divide two fp32
+    quadratic forms.  The rule's elements are marginal by construction (it starts from lambda = 1e-10: the factor's damping floor
+    engages on every one) and the mixed instantiation does not carry the rule, so both policies run it in the double kernel:
+    north_star's 1e-5 on EVERY element of the reference's TrustRegionTest shape (solver_test.cpp:178-230), iteration counts and
+    error histories the oracle's double run's."""
+    from momentum_amd._abi import MMX_PRECISION_AUTO, MMX_PRECISION_MIXED, MMX_SOLVE_MIXED
+
+    torch = torch_cuda
+    rig = make_test_character(5)
+    J = rig.num_joints
+    B = 64
+    cons, th0, ths = make_problem(rig, list(range(J)), list(range(J)), B, seed=900, perturb=1.0)
+    rh, pb = _gpu(torch, rig, cons, B)
+    for radius in (1.0, 0.3):
+        opt = GnOptions.make(min_iterations=12, max_iterations=12, threshold=1000.0, step_rule=MMX_STEP_TRUST_REGION, trust_region_radius=radius,
+                             precision=MMX_PRECISION_AUTO if precision == "auto" else MMX_PRECISION_MIXED)  # fmt: skip
+        out = pb.solve(torch.from_numpy(th0.copy()).to(pb.device), opt, want_history=True)
+        ref = orc.solve_batch(rig, cons, th0, opt, dtype="f64")
+        st = out["status"].cpu().numpy()
+        assert np.all(st & MMX_SOLVE_MIXED == 0) and np.all(st & 3 == 0)
+        assert np.array_equal(out["iterations"].cpu().numpy(), ref["iterations"])
+        h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+        assert np.all(np.abs(h - href) <= 1e-6 * np.abs(href) + 1e-9 * href[:, :1])
+        th = out["theta"].cpu().numpy().astype(np.float64)
+        rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+        assert rel.max() <= 1e-5, rel.max()
+
+
+def test_trust_region_under_auto_holds_1e5_on_the_all_joints_humanoid(torch_cuda, orc):
+    """The same statement on SURVEY 8(d)'s stress variant (P = 219, both constraints on all 72 joints: J has full column rank, so the
+    double run is a meaningful reference): MMX_PRECISION_AUTO runs the rule in the double kernel."""
+    import bench
+    from momentum_amd._abi import MMX_PRECISION_AUTO
+
+    torch = torch_cuda
+    rig, parents, _, _, _ = bench.build_rig("cfg2_all")
+    B = 24
+    db = bench.DeviceBatch(rig, parents, B, 0, 4321)
+    opt = GnOptions.make(min_iterations=8, max_iterations=8, threshold=1.0, step_rule=MMX_STEP_TRUST_REGION, precision=MMX_PRECISION_AUTO)
+    out = db.pb.solve(db.theta0.clone(), opt, want_history=True)
+    st = out["status"].cpu().numpy()
+    assert np.all(st & 3 == 0)
+    ref = orc.solve_batch(rig, db.host_constraints(B), np.zeros((B, rig.num_params), np.float32), opt, dtype="f64", nthreads=bench.usable_cores())
+    th = out["theta"].cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(th - ref["theta"], axis=1) / np.linalg.norm(ref["theta"], axis=1)
+    h, href = out["error_history"].cpu().numpy(), ref["error_history"]
+    same = np.all(np.abs(h - href) <= 1e-6 * np.abs(href) + 1e-9 * href[:, :1], axis=1)  # (a trial decision on its threshold may differ between two double implementations)
+    assert same.mean() >= 0.9, same.mean()
+    assert rel[same].max() <= 1e-5, rel
