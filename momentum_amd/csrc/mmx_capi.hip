@@ -789,11 +789,7 @@ int32_t uploadProblemTables(mmx_problem* pb) {
   {
     const mmx::FusedTables& f = pb->fused;
     const int32_t n = int32_t(f.solveList.size());
-#ifdef MMX_EXP_DENSE // A/B build variant (MMX_BUILD_VARIANT=dense): what the tile structure buys
-    const bool dense = true;
-#else
     const bool dense = f.solveList != pb->solveListV1 || n > 512 || pb->fdev.GT > 0 || n == 0;
-#endif
     std::vector<uint8_t> related;
     if (!dense) {
       const size_t J = size_t(rig->J);

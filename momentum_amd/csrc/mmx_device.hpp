@@ -37,11 +37,7 @@ constexpr int kJs = 17; // floats per joint in js[]: t(3) q(4) s | axes (9); odd
 // float tolerances), only the undetermined components of theta differ from the double solver's minimum-norm ones.
 // Pivots above the threshold -- every problem whose H + lambda I is numerically positive definite -- are untouched bit
 // for bit.  2^-18 = 64 ulp: a kept pivot amplifies the rounding of its column by at most ~1 / 64.
-#ifdef MMX_EXP_NOFLOOR // A/B build variant (MMX_BUILD_VARIANT=nofloor): what the threshold costs, what it changes
-constexpr float kPivotFloor = 0.f;
-#else
 constexpr float kPivotFloor = 3.814697265625e-6f; // 2^-18
-#endif
 // Damping floor of every single-precision FACTOR in this library: what is factored is J^T J + max(lambda, kFactorDamping *
 // mean diag(J^T J)) I.  1e-5 ~ n eps: the level at which the pivots of an fp32 Cholesky of a rank-deficient J^T J are
 // rounding noise -- above it the factorisation completes whatever the column order (with the columns in elimination
@@ -183,11 +179,7 @@ struct RigDev {
 // pair is folded away): + 0.5-1 % on the one-launch solve's lines (r05_exp_fused.txt).  A/B variant noglobalptr: identity.
 template <class T>
 __device__ __forceinline__ T* asGlobal(T* p) {
-#ifdef MMX_EXP_NOGLOBALPTR
-  return p;
-#else
   return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
-#endif
 }
 
 __device__ __forceinline__ void selectInstanceRig(RigDev& rig, int b) {
@@ -1095,9 +1087,6 @@ __device__ __forceinline__ void panelRowUpdate1(float (&a)[16], int j) {
   }
 }
 __device__ __forceinline__ void panelRowUpdate(float (&a)[16], int j) {
-#ifdef MMX_EXP_NOPKCHAIN // (A/B variant: one column per instruction everywhere)
-  panelRowUpdate1(a, j);
-#else
   if ((j & 1) == 0) {
     a[j + 1] -= a[j] * readLaneF(a[j], j + 1);
   }
@@ -1109,7 +1098,6 @@ __device__ __forceinline__ void panelRowUpdate(float (&a)[16], int j) {
     acc = __builtin_elementwise_fma(-aj2, mlt, acc);
     a[c] = acc.x, a[c + 1] = acc.y;
   }
-#endif
 }
 
 __device__ __forceinline__ float4 ldsRow4(const float* tile, int row, int chunk) { // 4 consecutive columns
@@ -1118,18 +1106,10 @@ __device__ __forceinline__ float4 ldsRow4(const float* tile, int row, int chunk)
 // the four products as two packed multiply-adds + one add (the sum's order differs from dot4's): the one-launch solve's
 // single-wave triangular solves, where the instruction count is the time (+ 2.3 % on BASELINE configs[1], r05_exp_fused.txt)
 __device__ __forceinline__ float dot4pk(float4 a, float4 b, float acc) {
-#ifdef MMX_EXP_NOPKDOT // (A/B variant)
-  acc += a.x * b.x;
-  acc += a.y * b.y;
-  acc += a.z * b.z;
-  acc += a.w * b.w;
-  return acc;
-#else
   v2f s{acc, 0.f};
   s = __builtin_elementwise_fma(v2f{a.x, a.y}, v2f{b.x, b.y}, s);
   s = __builtin_elementwise_fma(v2f{a.z, a.w}, v2f{b.z, b.w}, s);
   return s.x + s.y;
-#endif
 }
 __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
   acc += a.x * b.x;

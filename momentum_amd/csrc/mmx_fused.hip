@@ -302,57 +302,6 @@ __device__ __forceinline__ void csrRowsPrefetched(const int32_t* outer, const in
   }
 }
 
-// The same walk for a matrix of at most 2 kT rows, software-pipelined over the iterations of a solve (the one-launch solve,
-// round 5: its LDS has no room for the transform's CSR any more): a thread's two rows r = tid, tid + kT have iteration-
-// invariant bounds (csrRowBounds, once per solve) and first entries; the first entries are REQUESTED a phase ahead
-// (csrRequestFirst: four independent loads that fly under the phase in between -- the end of phase K for the forward
-// kinematics, the first triangular solve for the refinement's joint-parameter step) and consumed by csrRowsFromFirst.
-// Rows with more than one entry (a joint parameter driven by several model parameters) walk their tail from global memory.
-struct CsrBounds2 {
-  int ka[2], cnt[2];
-};
-struct CsrFirst2 {
-  int in0[2];
-  float v0[2];
-};
-template <int kT = 256>
-__device__ __forceinline__ CsrBounds2 csrRowBounds(const int32_t* outer, int R, int tid) {
-  CsrBounds2 b;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = tid + kT * i;
-    const int lo = outer[min(r, R - 1)], hi = outer[min(r, R - 1) + 1];
-    b.ka[i] = lo, b.cnt[i] = r < R ? hi - lo : 0;
-  }
-  return b;
-}
-__device__ __forceinline__ CsrFirst2 csrRequestFirst(const int32_t* inner, const float* value, const CsrBounds2& b) {
-  CsrFirst2 f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    f.in0[i] = b.cnt[i] > 0 ? inner[b.ka[i]] : 0, f.v0[i] = b.cnt[i] > 0 ? value[b.ka[i]] : 0.f;
-  }
-  return f;
-}
-template <int kT = 256, typename Gather, typename Store>
-__device__ __forceinline__ void
-csrRowsFromFirst(const int32_t* inner, const float* value, int R, int tid, const CsrBounds2& b, const CsrFirst2& f, Gather x, Store out) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = tid + kT * i;
-    if (r < R) {
-      float acc = 0.f;
-      if (b.cnt[i] > 0) {
-        acc += f.v0[i] * x(f.in0[i]);
-        for (int k = b.ka[i] + 1; k < b.ka[i] + b.cnt[i]; ++k) {
-          acc += value[k] * x(inner[k]);
-        }
-      }
-      out(r, acc);
-    }
-  }
-}
-
 // y = A x from the records of A's non-empty rows (RigDev::ptRowRec): one 16-byte load per thread, then a row's first product
 // from the record itself; the rare further entries of a row from the CSR arrays.  out(r, value) is called for EVERY row r < R
 // exactly once (the empty ones with 0) by the thread that owns the record before it -- no zero-fill pass, no barrier.
@@ -383,8 +332,7 @@ __device__ __forceinline__ void csrRowsFromRecords(const int4* rec, int numRec, 
 // Ends with a barrier.  Clobbers alt / jlA / jlB (assembly scratch = the Cholesky region).
 template <bool kGlobalTables = false, int kT = 256> // the rig's CSR tables are read from global memory (prefetching walk); kT threads
 __device__ __forceinline__ void
-blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes, long long* clk = nullptr, long long* clkLast = nullptr,
-        const CsrBounds2* csrB = nullptr, const CsrFirst2* csrF = nullptr) { // (csrB / csrF: the pipelined walk, rig.R <= 2 kT)
+blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool withAxes, long long* clk = nullptr, long long* clkLast = nullptr) {
   auto stamp = [&](int slot) { // profiling aid (MMX_PHASE_CLOCKS): sub-phases of FK
     if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
       const long long now = clock64();
@@ -396,12 +344,9 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
   // 110-124; the same products in the same order as a per-joint walk): 7 J independent short CSR walks
   // instead of seven dependent ones per joint.  They land in the refinement scratch (jd), which is dead
   // whenever FK runs.
-  if (kGlobalTables && rig.rowRec != nullptr && csrB == nullptr) {
+  if (kGlobalTables && rig.rowRec != nullptr) {
     csrRowsFromRecords<kT>(
         rig.rowRec, rig.numRowRec, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
-  } else if (kGlobalTables && csrB != nullptr) {
-    csrRowsFromFirst<kT>(
-        rig.ptInner, rig.ptValue, rig.R, tid, *csrB, *csrF, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
   } else if (kGlobalTables) {
     csrRowsPrefetched<kT>(
         rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, [&](int c) { return th[c]; }, [&](int r, float acc) { s.jd[r] = acc + (rig.hasOffsets ? rig.ptOffsets[r] : 0.f); });
@@ -689,14 +634,10 @@ constexpr int kGenEv = 29; // words per constraint record (odd stride)
 
 // Which instantiations of the one-launch solve are set up for FOUR workgroups per CU (128 registers, the transform's CSR walked
 // from global memory, the register-lean forms of the triangular solves / tile products): up to six blocks, reference rows, no
-// trust region -- the per-rule ones and the generic rule (line searches).  MMX_EXP_GEN3 (A/B variant): the generic rule at three.
+// trust region -- the per-rule ones and the generic rule (line searches).
 template <int NB, bool kTR, bool kGen, int kRule>
 struct FusedFour {
-#ifdef MMX_EXP_GEN3
-  static constexpr bool value = NB <= 6 && !kGen && kRule >= 0 && !kTR;
-#else
   static constexpr bool value = NB <= 6 && !kGen && !kTR;
-#endif
 };
 
 // Sizes of the one-launch solve's lifetime-shared LDS areas (fusedSolveKernel's carve and fusedLdsBytes agree through this)
@@ -1195,16 +1136,10 @@ __device__ __forceinline__ void solveLLtRight(const float* L, const float* invDi
 // configs[1], profiles/r05_exp_fused.txt; at three workgroups per CU and 168 registers the right-looking form stays ahead)
 template <int NB, bool kLeft = false>
 __device__ __forceinline__ void solveLLt(const float* L, const float* invDiag, float* x, int tid) {
-#ifdef MMX_EXP_LEFTALL // (A/B variant: the left-looking form everywhere)
-  if (false) {
-#else
   if (NB <= 8 && !kLeft) {
-#endif
     solveLLtRight<NB>(L, invDiag, x, tid);
-#ifndef MMX_EXP_NOAHEAD // (A/B variant: the plain left-looking form in the four-workgroup instantiations)
   } else if (NB <= 8) { // (kLeft: the chain cut to the newest block, see solveLLtLeftAhead)
     solveLLtLeftAhead<NB>(L, invDiag, x, tid);
-#endif
   } else {
     solveLLtLeft<NB>(L, invDiag, x, tid);
   }
@@ -1305,12 +1240,8 @@ template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1, bool kA
 // instantiations up to six blocks (round 5: the lifetime-shared carve brings BASELINE configs[1] to 40.2 KB; 128 VGPRs cost
 // a workgroup 4.6 % of its latency -- measured with the LDS still at 52 KB, profiles/r05_exp_fused.txt -- and buy a third
 // more of them per CU), three for the generic ones (their trial evaluations spill at 128), two up to eight blocks and for
-// the general rows, one beyond.  MMX_EXP_OCC3: the A/B variant with three everywhere.
-#ifdef MMX_EXP_OCC3
-__global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? 3 : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
-#else
+// the general rows, one beyond.
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, kGen, kRule>::value && !kMix ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
-#endif
     const FusedArgs* __restrict__ argsDev, // kArgLazy: the descriptors (the by-value ones are not read); else unused
     RigDev rigV,
     ProblemDev pbV,
@@ -1327,11 +1258,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   constexpr int NP = 16 * NB; // padded system size
   // lookahead: the left-looking updates of block column k + 1 by the columns before k ride under panel k's elimination
   // chain (waves without a panel row); NB <= 8: wave 3 never holds one (round 3, measured on one box: +2.2 % on cfg2)
-#ifdef MMX_EXP_NOLOOK // (A/B variant: no lookahead in the instantiations that run four workgroups per CU)
-  constexpr bool kLook = NB <= 8 && !(FusedFour<NB, kTR, kGen, kRule>::value && !kMix);
-#else
   constexpr bool kLook = NB <= 8;
-#endif
   long long clkLast = 0;
 #define MMX_CLK(slot)                                             \
   if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) {         \
@@ -1380,21 +1307,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   constexpr bool kFour = FusedFour<NB, kTR, kGen, kRule>::value && !kMix;
   constexpr bool kCsrLds = !kFour && !kMix; // (the mixed instantiation walks the transform in double from global memory: mixTransformRows)
   // the register-lean forms of three routines in the four-workgroup instantiations (A/B variants: the full forms back, one each)
-#ifdef MMX_EXP_FATSOLVE
-  constexpr bool kLeanSolve = false;
-#else
   constexpr bool kLeanSolve = kFour;
-#endif
-#ifdef MMX_EXP_FATDBUF
-  constexpr bool kLeanOps = false;
-#else
   constexpr bool kLeanOps = kFour;
-#endif
-#ifdef MMX_EXP_FATACC
-  constexpr bool kLeanAcc = false;
-#else
   constexpr bool kLeanAcc = kFour;
-#endif
   const int kNnz = fd.nnz;
   const FusedLayout lay = fusedLayout(NB, J, P, U, nsrc, n, fd.numCells, kRule < 0, kGen ? fd.GT : 0, kGen ? fd.genRows : 0, kTR, 0, kMix);
   MixLds m{};
@@ -1575,11 +1490,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   rv.ptOffsets = asGlobal(rig.ptOffsets);
   rv.hasOffsets = rig.ptOffsetsNonZero != 0;
   rv.levelOrder = nullptr, rv.levelStart = nullptr; // (the pointer-jumping FK needs neither)
-#ifdef MMX_EXP_NOROWREC // (A/B variant: the CSR walk, two dependent L2 round trips)
-  rv.rowRec = nullptr, rv.numRowRec = 0;
-#else
   rv.rowRec = asGlobal(rig.ptRowRec), rv.numRowRec = rig.numRowRec;
-#endif
   FusedViewS fv;
   fv.U = U, fv.Kp = fd.Kp;
   fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = numLoadedInst, fv.colToSolve = lColToSolve;
@@ -1627,38 +1538,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   const int doLineSearch = kRule < 0 || kRule == 2 ? fp.doLineSearch : 0;
   bool stateValid = false;
   double stateError = 0.0;
-  // the parameter transform's CSR in global memory, walked twice per iteration: pipelined when a thread's two rows cover it
-  // (built and measured, round 5: 1.588e6 against 1.715e6 solves/s without it on BASELINE configs[1] -- the six registers the
-  // requests hold across the phases raise the spills at 128 VGPRs from 92 to 119, which costs more than the two L2 round
-  // trips per iteration it hides; profiles/r05_exp_fused.txt.  MMX_BUILD_VARIANT=csrpipe builds it.)
-#ifdef MMX_EXP_CSRPIPE
-  const bool csrPipe = kR <= 512;
-#else
-  const bool csrPipe = false;
-#endif
-  // ... and the lighter form: only the rows' bounds are kept (packed, two registers), the first entries are requested where
-  // they are needed -- one L2 round trip per walk instead of two.  MMX_BUILD_VARIANT=csrbounds.
-#ifdef MMX_EXP_CSRBOUNDS
-  const bool csrKeep = kR <= 512;
-#else
-  const bool csrKeep = false;
-#endif
-  int csrPacked[2] = {0, 0}; // ka | cnt << 20
-  if (csrKeep) {
-    const CsrBounds2 b0 = csrRowBounds<256>(rig.ptOuter, kR, tid);
-    csrPacked[0] = b0.ka[0] | (b0.cnt[0] << 20), csrPacked[1] = b0.ka[1] | (b0.cnt[1] << 20);
-  }
-  auto csrUnpack = [&]() {
-    CsrBounds2 b1;
-    b1.ka[0] = csrPacked[0] & 0xfffff, b1.cnt[0] = csrPacked[0] >> 20, b1.ka[1] = csrPacked[1] & 0xfffff, b1.cnt[1] = csrPacked[1] >> 20;
-    return b1;
-  };
-  CsrBounds2 csrB{};
-  CsrFirst2 csrFk{}, csrJd{};
-  if (csrPipe) {
-    csrB = csrRowBounds<256>(rig.ptOuter, kR, tid);
-    csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
-  }
+  // (the parameter transform's CSR in global memory is walked twice per iteration by the instantiations without an LDS copy.  Two
+  // ways of hiding the walk's L2 latency in registers -- the rows' bounds kept and the first entries requested a phase ahead;
+  // the bounds only -- were built and measured in round 5 and each LOST 7 % at 128 registers: profiles/r05_exp_fused.txt item 4.)
   __syncthreads();
 
   if (MODE == 2) {
@@ -1678,11 +1560,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     // hides behind it (one round trip per iteration instead of two) -- except in the instantiations that run four
     // workgroups per CU at 128 registers: eleven registers across FK cost them more than the round trip (an L2 hit from the
     // second iteration on): 1.716 -> 1.726e6 solves/s on BASELINE configs[1], profiles/r05_exp_fused.txt
-#ifdef MMX_EXP_EARLYUNIT // (A/B variant: the unit payload requested before FK in the four-workgroup instantiations too)
-    constexpr bool kLateUnit = false;
-#else
     constexpr bool kLateUnit = kFour || kMix;
-#endif
     const UnitInput uin0 = kLateUnit ? UnitInput{} : loadUnitInput(pb, b, tid < U ? tid : U);
     // TrustRegionQRT::doIteration (momentum/character_solver/trust_region_qr.cpp:52-270) wraps what follows
     // in up to ten trial steps (:157); every other step rule passes through once.
@@ -1718,11 +1596,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       MMX_CLK(1)
     } else {
     // ================= A+B: forward kinematics (local transforms, pointer-jumping composition, rotation axes)
-    if (csrKeep) {
-      csrB = csrUnpack();
-      csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
-    }
-    blockFk<!kCsrLds>(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast, csrPipe || csrKeep ? &csrB : nullptr, &csrFk);
+    blockFk<!kCsrLds>(rv, s, s.th, tid, true, MODE == 2 ? dbgClk : nullptr, &clkLast);
     MMX_CLK(1)
     // ================= C: units (need only the world transforms, not the axes)
     {
@@ -1794,13 +1668,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     }
     __syncthreads();
     MMX_CLK(15)
-#ifdef MMX_EXP_TUN2 // (A/B variant: two k-steps per trip of the tree sums at four workgroups per CU)
-    constexpr int kUnD = kFour ? 2 : kFusedTreeUn;
-#elif defined(MMX_EXP_TUN1)
-    constexpr int kUnD = kFour ? 1 : kFusedTreeUn;
-#else
     constexpr int kUnD = kFusedTreeUn;
-#endif
     if (!kMix) {
       treeSum<kC1, true, kC1, kUnD>(fv, s.own1, s.sub1, J, wave, lane);
     }
@@ -1980,11 +1848,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     MMX_CLK(12)
     if (fd.termRounds > 0) {
       float h = 0.f;
-#ifdef MMX_EXP_REC4 // (A/B variant: four records per trip at four workgroups per CU -- eight registers less)
-      constexpr int kRecTrip = kFour ? 4 : 8;
-#else
       constexpr int kRecTrip = 8;
-#endif
       for (int k0 = 0; k0 < fd.termRounds; k0 += kRecTrip) {
         uint2 rec[kRecTrip];
 #pragma unroll
@@ -2250,19 +2114,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
           // in LDS) and eliminated again with the guard.  Every wave factors the diagonal block redundantly from the same
           // values, so all of them take the same branch.
           chain(false, 0.f);
-#ifndef MMX_EXP_NOPIVOT // (A/B build variant: no threshold at all)
           const float floorRow = s.invDiag[16 * k + (lane & 15)]; // kPivotFloor * (H_rr + lambda) of the diagonal lanes' rows
-#ifndef MMX_EXP_NODIAG
           // the precision estimate's input: the smallest d_jj / (H_jj + mu) of the solve, kept per lane as the largest
           // kPivotFloor (H_jj + mu) / d_jj (one instruction off the chain; the lanes are joined once, after the last
           // iteration).  Every wave factors the diagonal block redundantly: wave 0's lanes 0..15 are the ones read.
           pivotWorst = floorRow * invd * invd > pivotWorst ? floorRow * invd * invd : pivotWorst; // (a NaN pivot keeps the old value: MMX_SOLVE_NOT_PD reports it)
-#endif
           if (__any(diagLane && !(floorRow * invd * invd < 1.f))) {
             loadRows();
             chain(true, floorRow);
           }
-#endif
         }
         __syncthreads(); // every wave has read the diagonal block (long ago) before wave 0 overwrites it
         if (waveWorks) {
@@ -2327,9 +2187,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     MMX_CLK(7)
 
     // ================= I: d0 = (L L^T)^-1 g
-    if (csrPipe) { // the refinement's walk of the transform: its loads fly under the solve
-      csrJd = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
-    }
     if (kMix) {
       // ---- I + J in mixed precision: (J^T S^2 J + mu I) x = g by conjugate gradients in double, preconditioned by the
       // single-precision factor (z = (L L^T)^-1 r, rounded through float on the way in and out); the operator goes through the
@@ -2459,12 +2316,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
             }
             od(r, a);
           }
-        } else if (csrPipe && rf == 0) { // (first entries requested before the triangular solve of phase I)
-          csrRowsFromFirst<256>(rv.ptInner, rv.ptValue, rv.R, tid, csrB, csrJd, xd, od);
-        } else if (csrKeep) {
-          const CsrBounds2 b2 = csrUnpack();
-          const CsrFirst2 f2 = csrRequestFirst(rig.ptInner, rig.ptValue, b2);
-          csrRowsFromFirst<256>(rv.ptInner, rv.ptValue, rv.R, tid, b2, f2, xd, od);
         } else if (rv.rowRec != nullptr) {
           csrRowsFromRecords<256>(rv.rowRec, rv.numRowRec, rv.ptInner, rv.ptValue, rv.R, tid, xd, od);
         } else {
@@ -2661,9 +2512,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       __syncthreads();
       const float corr2 = float((s.red[4] + s.red[5]) + (s.red[6] + s.red[7]));
       const float step2 = float((s.red[0] + s.red[1]) + (s.red[2] + s.red[3]));
-#ifndef MMX_EXP_NODIAG
       refineWorst = fmaxf(refineWorst, corr2 * __builtin_amdgcn_rcpf(fmaxf(step2, 1e-37f))); // (mmx_problem_solve_diagnostics; uniform)
-#endif
       __syncthreads();
       // a correction is only taken when it is a contraction (kRefineMax2, mmx_kernels.hip: where the fp32 factor is no
       // preconditioner any more -- pivots at rounding level -- the refinement diverges): undo it and stop
@@ -2732,9 +2581,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     }
     } // linear solves
     // ================= K: theta -= delta ; bookkeeping of SolverT::solve (solver.cpp:92-119)
-    if (csrPipe) { // the next forward kinematics' walk of the transform: its loads fly under this phase and the barrier
-      csrFk = csrRequestFirst(rig.ptInner, rig.ptValue, csrB);
-    }
     if (kMix) {
       // ---- the step rules of phase K as the DOUBLE instantiation takes them (oracle: solveGaussNewton<double>): theta, the
       // trial parameters (m.Y) and the errors in double; the LM schedule's damping in double, its rounding is what is factored
@@ -2998,13 +2844,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       th2 += v * v;
     }
   }
-#ifdef MMX_EXP_NODIAG
-  if (tid == 0) {
-    st.iterations[b] = itersDone;
-    st.finalError[b] = curError;
-    st.status[b] = bad ? 1 : s.flags[2];
-  }
-#else
   th2 = blockSumF(s, th2, tid);
   pivotWorst = fmaxf(pivotWorst, dppMoveF<0xB1>(pivotWorst)); // the sixteen diagonal lanes of wave 0: four DPP steps inside their row
   pivotWorst = fmaxf(pivotWorst, dppMoveF<0x4E>(pivotWorst));
@@ -3037,7 +2876,6 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     st.finalError[b] = curError;
     st.status[b] = stt;
   }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3638,7 +3476,6 @@ hipError_t launchTreeNormalEquations(
     return hipErrorInvalidValue;
   }
   const bool extra = pb.M > pb.rowsJoint || fd.GT > 0 || pb.instPosParent != nullptr || pb.instOriParent != nullptr;
-#ifndef MMX_EXP_NECOMPACT_OFF
   if (!extra && state != nullptr) {
     // two workgroups of eight waves per CU when the lifetime-packed carve fits half a CU's LDS (BASELINE configs[4]: 79.7 KB):
     // every phase of this kernel is a latency chain of one workgroup (VALU active 8.5 % of the wave cycles at one workgroup of
@@ -3654,7 +3491,6 @@ hipError_t launchTreeNormalEquations(
       return hipGetLastError();
     }
   }
-#endif
   if (!extra) { // many waves per workgroup (one workgroup per CU either way: the LDS footprint decides)
     // sixteen waves = four per SIMD (93 VGPRs: no spill under the 128 of that occupancy).  cfg5, one box, solves/s:
     // four waves 1.476e5, eight 1.626e5, sixteen 1.704e5 (round 3)
@@ -3996,11 +3832,7 @@ static hipError_t launchFusedMode(
     return hipErrorInvalidValue;
   }
   // the lazy-argument form (kArgLazy): four-workgroup production instantiations, shared rig and weights, a buffer to stash into
-#ifdef MMX_EXP_ARGVALUE // (A/B variant: by-value arguments everywhere)
-  constexpr bool kLazyBuilt = false;
-#else
   constexpr bool kLazyBuilt = kFourL && MODE == 0;
-#endif
   const bool lazy = kLazyBuilt && argsBuf != nullptr && rig.instPreRot == nullptr && rig.instOffset == nullptr && pb.fnWeights == nullptr;
   if (lazy) {
     static LdsLimitCache ldsLimit; // (one per instantiation)

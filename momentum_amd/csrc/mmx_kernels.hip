@@ -2786,7 +2786,7 @@ __device__ __forceinline__ void residentSweepBackward(
 // factor in HBM without anybody waiting for it (the finish stage and the trust region read it there), and the backward
 // substitution of the first solve runs on the resident tiles.  The block columns are taken a LEVEL of the elimination tree
 // at a time (TileMasks::levelSteps: independent columns side by side, each panel on its own waves).
-//   kW waves per workgroup: 4, or 8 (MMX_EXP_FACT8 decides in the launcher): the matrix comes in, the left-looking updates are
+//   kW waves per workgroup: 4 (8 was measured in round 5 and is 1.1 % slower on BASELINE configs[4]: profiles/r05_exp_fused.txt): the matrix comes in, the left-looking updates are
 // dealt, the sweep's columns and the factor's stores are spread over eight waves; the panels' rows and the damping's trace stay
 // on the first four (same sums in the same order: bit-identical results).
 template <int kW>
@@ -3647,16 +3647,6 @@ hipError_t launchFkJacobian(
       accurateFk = false;
     }
   }
-#if defined(MMX_EXP_JACOCC4) || defined(MMX_EXP_JACOCC3) // A/B build variants: resident workgroups per CU forced through the LDS request
-#ifdef MMX_EXP_JACOCC4
-  constexpr size_t kOcc = 4;
-#else
-  constexpr size_t kOcc = 3;
-#endif
-  if (jac != nullptr && lds < (160 * 1024 / kOcc) - 1024) {
-    lds = (160 * 1024 / kOcc) - 1024;
-  }
-#endif
   // Wavefronts per instance.  J-assembly: four waves share one instance (FK over 256 threads, the
   // column program dealt to the waves) up to 40 000 instances per launch -- fewer instances are then
   // in flight at a time (5 workgroups per CU instead of 20), and write bandwidth on this part
@@ -3881,17 +3871,9 @@ hipError_t launchCholeskyFactorTiled(
   {
     const size_t NP = (size_t(pb.n) + 15) & ~size_t(15);
     const size_t resident = (size_t(sp.numTiles) * 256 + 3 * NP + 8 + 96) * sizeof(float);
-#ifdef MMX_EXP_NORESIDENT // A/B build variant (MMX_BUILD_VARIANT=noresident): the in-HBM pairs form for every system
-    const bool useResident = false;
-#else
     const bool useResident = sp.numTiles > 0 && resident <= 80 * 1024 - 64;
-#endif
     if (useResident) {
-#ifdef MMX_EXP_FACT8 // A/B build variant: eight waves per workgroup
-      constexpr int kW = 8;
-#else
       constexpr int kW = 4;
-#endif
       static LdsLimitCache ldsLimit;
       hipError_t rc = ldsLimit.ensure(reinterpret_cast<const void*>(choleskyFactorResidentKernel<kW>), resident);
       if (rc != hipSuccess) {

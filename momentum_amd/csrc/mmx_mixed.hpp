@@ -23,17 +23,7 @@ constexpr int kJsD = 17; // doubles per joint: world t(3) q(4) s(1) | rotation a
 constexpr int kTanD = 8; // tangent-pass doubles per joint: C(3) W(3) S(1) | jump target (int bits)
 // damping floor of the mixed route's single-precision factor (fraction of the mean diagonal of J^T J; kFactorDamping of
 // mmx_device.hpp for the single-precision routes).  The factor is only the preconditioner here: A/B variants mixf6 / mixf7
-#if defined(MMX_EXP_MIXF6)
 constexpr float kMixFactorDamping = 1e-6f;
-#elif defined(MMX_EXP_MIXF7)
-constexpr float kMixFactorDamping = 1e-7f;
-#elif defined(MMX_EXP_MIXF4)
-constexpr float kMixFactorDamping = 1e-4f;
-#elif defined(MMX_EXP_MIXF5)
-constexpr float kMixFactorDamping = 1e-5f;
-#else
-constexpr float kMixFactorDamping = 1e-6f;
-#endif
 constexpr double kLn2D = 0.693147180559945309417232121458176568; // momentum/math/constants.h:30,40
 
 // the double arrays of one instance in LDS

@@ -2,14 +2,16 @@
 # end-of-round evidence: full GPU suite, the default bench line, kernel traces and PMC passes of the headline (cfg2) and
 # of the wide solve (cfg5).  usage: bash scripts/gpu_round_profiles.sh r02   -> gpurun_out/round_r02/
 cd "$GRAFT_REPO_ROOT" || exit 1
-r=${1:-r05}
+r=${1:-r06}
 out=$GRAFT_REPO_ROOT/gpurun_out/round_$r
 mkdir -p $out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q < /dev/null 2>&1 | grep -E "passed|failed|FAILED|rror" | tail -6 > $out/pytest_gpu.txt
-timeout 1200 python bench.py --measure-traffic < /dev/null > $out/${r}_bench_default.json 2> $out/bench_default.err
+# the DRIVER's command (no arguments): its line and ITS side file are the ones profiles/ keeps (round 5's committed side file was
+# a later profiling pass's: every other bench.py call below writes its details elsewhere)
+timeout 1200 python bench.py --details $out/${r}_bench_details.json < /dev/null > $out/${r}_bench_default.json 2> $out/bench_default.err
 cd /tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 0"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 0 --no-measure-traffic --details $out/profiling_pass_details.json"
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace2 -o t -- $B < /dev/null > /dev/null 2> $out/trace2.err
 db=$(find $out/trace2 -name "*.db" | head -1)
 [ -n "$db" ] && timeout 120 python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py "$db" < /dev/null > $out/${r}_bench_kernel_stats.txt

@@ -64,5 +64,47 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(torch_cuda):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 2 and "ranks seen by RCCL: 2" in d["config"]["exchange"]
+    assert d["n_gpus"] == 2 and d["config"]["exchange"]["ranks_seen_by_rccl"] == 2 and d["config"]["exchange"]["backend"] == "rccl"
     assert d["check"]["sum_iterations"] == 2 * 1024 * 10 and d["check"]["failed_instances"] == 0
+
+
+def test_two_rank_communicator_on_one_device_runs_or_is_refused_by_rccl(torch_cuda):
+    """The N > 1 code path of mmx_comm_create_all on a one-GPU box: ncclCommInitAll with the same device twice.  RCCL either
+    builds the two-rank communicator -- then the all-reduce of the norms runs with TWO ranks (each on its own stream, enqueued
+    back to back: neither call blocks the host) and both ranks end with the sum -- or refuses duplicate devices at
+    initialisation, in which case the library must hand the RCCL error on (MMX_ERR_DEVICE with ncclCommInitAll in the message)
+    and leave no handle behind.  Either outcome is asserted; which one this RCCL takes is recorded in the test's output
+    (DESIGN.md 7 quotes it).  With two GPUs visible the same call is made on devices 0 and 1 and must succeed."""
+    import ctypes as C
+
+    from momentum_amd import capi
+
+    torch = torch_cuda
+    two = torch.cuda.device_count() >= 2
+    devs = (C.c_int32 * 2)(0, 1 if two else 0)
+    handles = (C.c_void_p * 2)()
+    L = capi.lib()
+    rc = L.mmx_comm_create_all(2, devs, handles)
+    if rc != 0:
+        msg = L.mmx_last_error().decode() if isinstance(L.mmx_last_error(), bytes) else str(L.mmx_last_error())
+        assert not two, f"two GPUs visible and ncclCommInitAll failed: {msg}"
+        assert "ncclCommInitAll" in msg, msg
+        assert not handles[0] and not handles[1]
+        print(f"RCCL refuses two ranks on one device: {msg}")
+        return
+    try:
+        assert L.mmx_comm_world_size(C.c_void_p(handles[0])) == 2 and L.mmx_comm_rank(C.c_void_p(handles[1])) == 1
+        streams = [torch.cuda.Stream(device=int(devs[i])) for i in range(2)]
+        norms = [torch.tensor([1.5 + i, 10.0 * (i + 1), float(i)], dtype=torch.float64, device=f"cuda:{int(devs[i])}") for i in range(2)]
+        torch.cuda.synchronize()
+        for i in range(2):
+            capi._check(L.mmx_comm_all_reduce_norms(C.c_void_p(handles[i]), C.c_void_p(norms[i].data_ptr()), C.c_void_p(streams[i].cuda_stream)))
+        for st in streams:
+            st.synchronize()
+        for i in range(2):
+            assert norms[i].cpu().tolist() == [4.0, 30.0, 1.0], norms[i]
+        print("two-rank RCCL communicator ran the all-reduce of the norms" + ("" if two else " on ONE device"))
+    finally:
+        for i in range(2):
+            if handles[i]:
+                L.mmx_comm_destroy(C.c_void_p(handles[i]))
