@@ -497,7 +497,7 @@ typedef struct mmx_tuning {
                                    further one only while the last correction exceeded 1e-3 of the step); 1..3 = at most
                                    that many; -1 = none (a measurement switch: north_star's 1e-5 needs the refinement) */
   float mixed_tolerance; /* (ABI 11) MMX_PRECISION_MIXED: the conjugate gradients of an iteration stop when the predicted size of
-                            the next correction falls below this fraction of the step (0 = the default, 1e-9: north_star's 1e-5
+                            the next correction falls below this fraction of the step (0 = the default, 3e-9: north_star's 1e-5
                             then holds on every element whose double run amplifies a 1e-12 perturbation by less than 1e5; 1e-7
                             costs 15 % less and holds it where the amplification stays below 1e2) */
   int32_t mixed_max_cg; /* ... and after at most this many operator applications (0 = the default, 12) */

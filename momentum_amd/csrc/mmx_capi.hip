@@ -2206,7 +2206,7 @@ static int32_t solveMixedImpl(
   fp.lmUp = o->lm_up;
   fp.lmDown = o->lm_down;
   fp.trustRadius = 1.f;
-  fp.mixTol = pb->tuning.mixed_tolerance > 0.f ? pb->tuning.mixed_tolerance : 1e-9f;
+  fp.mixTol = pb->tuning.mixed_tolerance > 0.f ? pb->tuning.mixed_tolerance : 3e-9f;
   fp.mixMaxCg = pb->tuning.mixed_max_cg > 0 ? pb->tuning.mixed_max_cg : 12;
   long long* clk = nullptr;
   if (phaseClocksWanted()) { // profiling aid: per-phase cycles of block 0

@@ -410,9 +410,29 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
 // ---------------------------------------------------------------------------------------------
 // y = transform * x in double: one transform row per thread from the rig's row records, else the prefetching CSR walk
 // (the tables in global memory either way); out(r, value) for every row r < R
+// regRec: this thread's row record, loaded once per solve (rig.numRowRec <= 256: a record per thread; the walk's L2 round trip
+// -- twice per operator application and once per forward pass -- then only remains for rows with more than one entry)
 template <typename Gather, typename Store>
-__device__ __forceinline__ void mixTransformRows(const RigView& rig, int tid, Gather x, Store out) {
-  if (rig.rowRec != nullptr) {
+__device__ __forceinline__ void mixTransformRows(const RigView& rig, int tid, Gather x, Store out, const int4* regRec = nullptr) {
+  if (regRec != nullptr) {
+    if (tid < rig.numRowRec) {
+      const int4 q = *regRec;
+      const int row = q.x & 0xffff, span = int(uint32_t(q.x) >> 16), in0 = q.y & 0xffff, cnt = int(uint32_t(q.y) >> 16);
+      auto acc = __int_as_float(q.z) * x(in0);
+      for (int k = q.w + 1; k < q.w + cnt; ++k) {
+        acc += rig.ptValue[k] * x(rig.ptInner[k]);
+      }
+      out(row, acc);
+      for (int r = row + 1; r < row + span; ++r) {
+        out(r, decltype(acc)(0));
+      }
+      if (tid == 0) {
+        for (int r = 0; r < row; ++r) {
+          out(r, decltype(acc)(0));
+        }
+      }
+    }
+  } else if (rig.rowRec != nullptr) {
     csrRowsFromRecords<256>(rig.rowRec, rig.numRowRec, rig.ptInner, rig.ptValue, rig.R, tid, x, out);
   } else {
     csrRowsPrefetched<256>(rig.ptOuter, rig.ptInner, rig.ptValue, rig.R, tid, x, out);
@@ -427,9 +447,9 @@ __device__ __forceinline__ void mixTransformRows(const RigView& rig, int tid, Ga
 // the largest term left in double (measured: BASELINE configs[1] sat at 1.5e-7 ... 5e-7 of the oracle's double run whatever
 // the CG tolerance, the 24-joint chain with identity pre-rotations at 2.5e-8 = the rounding of the float result).
 // myLevel: the tree level of joint `tid` (one joint per thread, J <= 256); optionally the rotation axes.  Ends with a barrier.
-__device__ __forceinline__ void blockFkD(const RigView& rig, const MixLds& m, const double* th, int tid, int myLevel, bool withAxes) {
+__device__ __forceinline__ void blockFkD(const RigView& rig, const MixLds& m, const double* th, int tid, int myLevel, bool withAxes, const int4* regRec = nullptr) {
   mixTransformRows(
-      rig, tid, [&](int c) { return th[c]; }, [&](int r, double acc) { m.X[r] = acc + (rig.hasOffsets ? double(rig.ptOffsets[r]) : 0.0); });
+      rig, tid, [&](int c) { return th[c]; }, [&](int r, double acc) { m.X[r] = acc + (rig.hasOffsets ? double(rig.ptOffsets[r]) : 0.0); }, regRec);
   __syncthreads();
   double loc[8];
   const int j = tid;
@@ -482,8 +502,8 @@ __device__ __forceinline__ double mixUnits(const ProblemDev& pb, const FusedLds&
 // thread returns the same value.  kStore: also leaves what phases A-C of an iteration would leave (see blockError).
 template <bool kStore>
 __device__ __forceinline__ double blockErrorD(
-    const RigView& rig, const ProblemDev& pb, const FusedLds& s, const MixLds& m, const double* th, int b, int U, int tid, int myLevel, double* unrounded = nullptr) {
-  blockFkD(rig, m, th, tid, myLevel, kStore);
+    const RigView& rig, const ProblemDev& pb, const FusedLds& s, const MixLds& m, const double* th, int b, int U, int tid, int myLevel, double* unrounded = nullptr, const int4* regRec = nullptr) {
+  blockFkD(rig, m, th, tid, myLevel, kStore, regRec);
   double e = mixUnits<kStore>(pb, s, m, b, U, tid);
   const double tot = blockSumD(s.red, e, tid);
   if (unrounded != nullptr) {
@@ -495,12 +515,48 @@ __device__ __forceinline__ double blockErrorD(
 // Adjoint pass in double: out[c] = (J^T y)_c for the solve columns c < n (0 for the pad columns), y_u = yOf(u, k) the adjoint
 // input of unit u (k: DFS position of its joint).  Own sums per loaded joint (m.X) -> subtree sums (m.Y; the loaded positions
 // inside a subtree are the index range lo..hi of the ascending loadedPos) -> per-slot gradients (m.X) -> columns.
-// (Measured and not kept, round 6: one thread per UNIT writing its moments and the subtree sums walking the position-sorted unit
-// list -- a root joint's sum is then a chain of 64 dependent LDS round trips: the operator went from 20 k to 35 k cycles.)
+// (Measured and not kept, round 6: the subtree sums walking the position-sorted UNIT list directly -- a root joint's sum is then
+// a chain of 64 dependent LDS round trips: the operator went from 20 k to 35 k cycles.)
 // Clobbers m.X and m.Y; yOf may read m.Y (the tangent pass's prefixes: consumed before the first barrier).  Ends WITHOUT a barrier.
 template <class FV, typename YFn>
 __device__ __forceinline__ void mixAdjoint(const FV& fd, const FusedLds& s, const MixLds& m, int J, int NP, int n, int nsrc, int tid, YFn yOf, double* out) {
-  {
+  double *sub, *slot; // where the subtree sums / the per-slot gradients end up
+  if (size_t(7 * fd.U) <= mixXDoubles(J, nsrc) && size_t(nsrc) <= mixYDoubles(J, 0)) {
+    // one thread per UNIT writes its seven moments (the unit evaluation is the arithmetic of this pass: all units at once instead of
+    // a loaded joint's units one after the other), then one thread per (loaded joint, channel) adds the joint's few units
+    for (int u = tid; u < fd.U; u += 256) {
+      const D3 pu{m.up[3 * u], m.up[3 * u + 1], m.up[3 * u + 2]};
+      const D3 y = yOf(u, fd.unitPos[u], pu);
+      const D3 Nv = dcross(pu, y); // points and directions share the channel (jt_times)
+      const bool point = u < fd.Kp;
+      double* o = m.X + 7 * u;
+      o[0] = point ? y.x : 0.0, o[1] = point ? y.y : 0.0, o[2] = point ? y.z : 0.0;
+      o[3] = Nv.x, o[4] = Nv.y, o[5] = Nv.z;
+      o[6] = point ? ddot(pu, y) : 0.0;
+    }
+    __syncthreads();
+    for (int item = tid; item < 7 * fd.numLoaded; item += 256) {
+      const int li = item / 7, c = item - 7 * li;
+      const int k = fd.loadedPos[li];
+      double acc = 0.0;
+      const int e1 = fd.posUnitStart[k + 1];
+      for (int e = fd.posUnitStart[k]; e < e1; ++e) {
+        acc += m.X[7 * fd.posUnits[e] + c];
+      }
+      m.Y[item] = acc;
+    }
+    __syncthreads();
+    for (int item = tid; item < 7 * J; item += 256) {
+      const int k = item / 7, c = item - 7 * k;
+      double acc = 0.0;
+      const int l1 = m.hi[k];
+      for (int li = m.lo[k]; li < l1; ++li) {
+        acc += m.Y[7 * li + c];
+      }
+      m.X[item] = acc;
+    }
+    sub = m.X, slot = m.Y;
+  } else {
     for (int li = tid; li < fd.numLoaded; li += 256) {
       const int k = fd.loadedPos[li];
       D3 Fv{0.0, 0.0, 0.0}, Nv{0.0, 0.0, 0.0};
@@ -529,20 +585,21 @@ __device__ __forceinline__ void mixAdjoint(const FV& fd, const FusedLds& s, cons
       }
       m.Y[7 * k + c] = acc;
     }
-    __syncthreads();
+    sub = m.Y, slot = m.X;
   }
+  __syncthreads();
   for (int e = tid; e < nsrc; e += 256) {
     const int info = s.mInfo[e];
-    m.X[e] = double(s.mW[e]) * sourceGradientD(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, m.js, m.Y + 7 * (s.mTin[e] & 0xffff));
+    slot[e] = double(s.mW[e]) * sourceGradientD(info & 0xfff, (info >> 12) & 7, (info >> 16) - 1, m.js, sub + 7 * (s.mTin[e] & 0xffff));
   }
   __syncthreads();
   for (int c = tid; c < NP; c += 256) {
     double a = 0.0;
     if (c < n) {
-      a = m.X[c]; // the primary slot, then the extras
+      a = slot[c]; // the primary slot, then the extras
       const int e1 = NP + s.mStart[c + 1];
       for (int e = NP + s.mStart[c]; e < e1; ++e) {
-        a += m.X[e];
+        a += slot[e];
       }
     }
     out[c] = a;
@@ -553,8 +610,8 @@ __device__ __forceinline__ void mixAdjoint(const FV& fd, const FusedLds& s, cons
 // per joint C = T - Om x t - ln2 sd t, W = Om, S = sd summed over the ancestor chain by pointer jumping -> m.Y[kTanD k ..]
 // by DFS position k.  J <= 256.  Ends with a barrier.
 template <class FV, typename XFn>
-__device__ __forceinline__ void mixTangent(const RigView& rig, const FV& fd, const MixLds& m, const int16_t* parentPos, int J, int tid, XFn xOf) {
-  mixTransformRows(rig, tid, xOf, [&](int r, double a) { m.X[r] = a; });
+__device__ __forceinline__ void mixTangent(const RigView& rig, const FV& fd, const MixLds& m, const int16_t* parentPos, int J, int tid, XFn xOf, const int4* regRec = nullptr) {
+  mixTransformRows(rig, tid, xOf, [&](int r, double a) { m.X[r] = a; }, regRec);
   __syncthreads();
   double acc[7];
   int target = -1;
@@ -607,11 +664,14 @@ __device__ __forceinline__ void mixTangent(const RigView& rig, const FV& fd, con
 // q = (J^T S^2 J + mu I) p in double (tangent pass down, adjoint pass up); p, q: [NP] over the solve columns.  Ends with a barrier.
 template <class FV>
 __device__ __forceinline__ void mixApply(
-    const RigView& rig, const FV& fd, const FusedLds& s, const MixLds& m, const int16_t* parentPos, int J, int NP, int n, int nsrc, double mu, const double* p, double* q, int tid) {
-  mixTangent(rig, fd, m, parentPos, J, tid, [&](int c) {
-    const int cs = fd.colToSolve[c];
-    return cs >= 0 ? p[cs] : 0.0;
-  });
+    const RigView& rig, const FV& fd, const FusedLds& s, const MixLds& m, const int16_t* parentPos, int J, int NP, int n, int nsrc, double mu, const double* p, double* q, int tid, const int4* regRec = nullptr) {
+  mixTangent(
+      rig, fd, m, parentPos, J, tid,
+      [&](int c) {
+        const int cs = fd.colToSolve[c];
+        return cs >= 0 ? p[cs] : 0.0;
+      },
+      regRec);
   mixAdjoint(
       fd, s, m, J, NP, n, nsrc, tid,
       [&](int u, int k, const D3& pu) {
@@ -1501,6 +1561,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     s.flags[1] = 0; // not positive definite (this iteration)
     s.flags[2] = 0; // status
   }
+  int4 mixRec{0, 0, 0, 0}; // kMix: this thread's transform-row record (RigDev::ptRowRec), kept for the whole solve
+  const bool mixHasRec = kMix && rv.rowRec != nullptr && rv.numRowRec <= 256;
+  if (mixHasRec && tid < rv.numRowRec) {
+    mixRec = rv.rowRec[tid];
+  }
+  const int4* mixRecP = mixHasRec ? &mixRec : nullptr;
   int mixLevel = 0; // kMix: the tree level of joint `tid` (blockFkD composes one level per barrier)
   if (kMix && tid < J) {
     for (int a = lParent[tid]; a >= 0; a = lParent[a]) {
@@ -1585,7 +1651,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       curError = stateError;
     } else if (kMix) {
       // ================= A-C in double (mmx_mixed.hpp)
-      blockFkD(rv, m, m.th, tid, mixLevel, true);
+      blockFkD(rv, m, m.th, tid, mixLevel, true, mixRecP);
       double e = mixUnits<true>(pb, s, m, b, U, tid);
       e = waveReduceSum(e);
       if (lane == 0) {
@@ -2214,7 +2280,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       const double tol2 = double(fp.mixTol) * double(fp.mixTol);
       bool converged = !(rz > 0.0); // (g = 0: the step is zero)
       for (int k = 0; k < fp.mixMaxCg && !converged; ++k) {
-        mixApply(rv, fv, s, m, lParentPos, J, NP, n, nsrc, double(mu), m.p, m.q, tid);
+        mixApply(rv, fv, s, m, lParentPos, J, NP, n, nsrc, double(mu), m.p, m.q, tid, mixRecP);
         ++mixApplied;
         MMX_CLK(17)
         double pq = 0.0;
@@ -2599,7 +2665,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         }
         __syncthreads();
         double eFull = 0.0;
-        const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &eFull);
+        const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &eFull, mixRecP);
         const double rho = predicted > 0.0 ? (curError - eNew) / predicted : -1.0;
         if (st.stepHistory != nullptr && tid == 0) {
           double* sh = st.stepHistory + (size_t(b) * fp.maxIterations + it) * 2;
@@ -2640,7 +2706,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
             m.Y[fv.solveList[c]] -= double(scale) * m.x[c];
           }
           __syncthreads();
-          const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &stateError);
+          const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &stateError, mixRecP);
           if ((curError - eNew) >= (doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale) * scaledError)) {
             break;
           }
