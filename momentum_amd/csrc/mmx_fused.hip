@@ -1120,6 +1120,99 @@ __device__ __forceinline__ void solveLLtLeftAhead(const float* L, const float* i
   __syncthreads();
 }
 
+// solveLLtLeftAhead in two pieces (round 6): the forward substitution of block k by ONE wave without a workgroup barrier --
+// the same operations in the same order as solveLLtLeftAhead's k-th forward step (the older blocks' sum, then the newest
+// block's products, each as packed pairs), the previous blocks' solutions read from x in LDS instead of coming over in
+// registers: bit-identical results -- and the backward sweep on its own.  Block k needs the block rows 0..k of the factor only,
+// so a wave the panel factorisation leaves idle solves block k - 1 while the others eliminate panel k (phase H): the forward
+// half of the first solve of an iteration disappears from the critical path.
+template <int NB>
+__device__ __forceinline__ void solveForwardBlockAhead(const float* L, const float* invDiag, float* x, int k, int lane) {
+  const int i = lane >> 2, g = lane & 3;
+  float acc = 0.f;
+  for (int j = 0; j + 1 < k; ++j) {
+    acc = dot4pk(ldsRow4(L + 256 * tileIndex(k, j), i, g), *reinterpret_cast<const float4*>(x + 16 * j + 4 * g), acc);
+  }
+  if (k > 0) {
+    acc = dot4pk(ldsRow4(L + 256 * tileIndex(k, k - 1), i, g), *reinterpret_cast<const float4*>(x + 16 * (k - 1) + 4 * g), acc);
+  }
+  acc = quadSum(acc);
+  float* xk = x + 16 * k;
+  const float rhs = xk[i] - acc; // the same value in the four lanes of quad i
+  const float invd = invDiag[16 * k + i];
+  const float* Dk = L + 256 * tileIndex(k, k);
+  float p = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = 4 * t + g; // L_kk^-1 (i, c) = L_kk^-T (c, i)
+    const float m = Dk[tileAddr(c, i)];
+    const float rc = __shfl(rhs, 4 * c, 64); // right-hand side of row c straight from its quad
+    p += (c < i ? m : (c == i ? invd : 0.f)) * rc;
+  }
+  p = quadSum(p);
+  if (g == 0) {
+    xk[i] = p;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+// the last forward block (kFirst = NB - 1: the ones before it were solved during the factorisation) and the backward sweep of
+// solveLLtLeftAhead, by wave 0; ends with a barrier
+template <int NB>
+__device__ __forceinline__ void solveLLtAheadTail(const float* L, const float* invDiag, float* x, int tid) {
+  if (tid < 64) {
+    solveForwardBlockAhead<NB>(L, invDiag, x, NB - 1, tid);
+    const int i = tid >> 2, g = tid & 3;
+    float pre = 0.f; // block k's sum over j > k + 1
+    float xq[4] = {0.f, 0.f, 0.f, 0.f}; // x_{k+1}[4t + g]
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k) { // backward
+      float preNext = 0.f; // block k - 1's sum over j > k
+      if (k > 0) {
+#pragma unroll
+        for (int j = NB - 1; j > k; --j) {
+          const float* Tj = L + 256 * tileIndex(j, k - 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c = 4 * t + g;
+            preNext += Tj[tileAddr(c, i)] * x[16 * j + c]; // L(16 j + c, 16 (k - 1) + i)
+          }
+        }
+      }
+      float acc = pre;
+      if (k + 1 < NB) {
+        const float* Tj = L + 256 * tileIndex(k + 1, k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc += Tj[tileAddr(4 * t + g, i)] * xq[t];
+        }
+      }
+      acc = quadSum(acc);
+      float* xk = x + 16 * k;
+      const float rhs = xk[i] - acc;
+      const float invd = invDiag[16 * k + i];
+      const float4 row = ldsRow4(L + 256 * tileIndex(k, k), i, g); // L_kk^-T (i, 4g..4g+3)
+      const int c0 = 4 * g;
+      float p = (c0 > i ? row.x : (c0 == i ? invd : 0.f)) * __shfl(rhs, 4 * c0, 64);
+      p += (c0 + 1 > i ? row.y : (c0 + 1 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 1), 64);
+      p += (c0 + 2 > i ? row.z : (c0 + 2 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 2), 64);
+      p += (c0 + 3 > i ? row.w : (c0 + 3 == i ? invd : 0.f)) * __shfl(rhs, 4 * (c0 + 3), 64);
+      p = quadSum(p);
+      if (g == 0) {
+        xk[i] = p;
+      }
+      if (k > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          xq[t] = __shfl(p, 4 * (4 * t + g), 64);
+        }
+      }
+      pre = preNext;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  __syncthreads();
+}
+
 template <int NB>
 __device__ __forceinline__ void solveLLtRight(const float* L, const float* invDiag, float* x, int tid) {
   if (tid < 64) {
@@ -1368,6 +1461,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   constexpr bool kCsrLds = !kFour && !kMix; // (the mixed instantiation walks the transform in double from global memory: mixTransformRows)
   // the register-lean forms of three routines in the four-workgroup instantiations (A/B variants: the full forms back, one each)
   constexpr bool kLeanSolve = kFour;
+#ifdef MMX_EXP_NORIDE // (A/B variant: the first solve whole, after the factorisation)
+  constexpr bool kRide = false;
+#else
+  constexpr bool kRide = kFour && NB >= 2; // the first solve's forward substitution rides under the panel factorisation (wave 3)
+#endif
   constexpr bool kLeanOps = kFour;
   constexpr bool kLeanAcc = kFour;
   const int kNnz = fd.nnz;
@@ -2116,6 +2214,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         const bool panelLane = !diagLane && !identLane && prow < NP;
         // waves whose 48 virtual rows all lie beyond the matrix only wait (wave-uniform branch)
         const bool waveWorks = wave == 0 || 16 * k + 48 * wave < NP;
+        if (kRide && wave == 3 && k >= 1) {
+          // (round 6) the first solve's forward substitution rides along: block k - 1 of y = L^-1 g needs the block rows 0 .. k - 1
+          // of the factor, final since the barrier after panel k - 1 -- wave 3 never holds a panel row up to six blocks
+          solveForwardBlockAhead<NB>(s.L, s.invDiag, s.d0, k - 1, lane);
+        }
         if (kLook && !waveWorks && k >= 1 && k + 1 < NB) {
           // lookahead: the waves without a panel row bring block column k + 1 up to date with the finished columns
           // j < k while the others run the elimination chain (disjoint tiles: column k is the chain's)
@@ -2353,6 +2456,8 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         MMX_CLK(18)
       }
       mixUnconverged = mixUnconverged || !converged;
+    } else if (kRide) { // (blocks 0 .. NB - 2 of the forward substitution were solved under the panels: the last block and the backward sweep)
+      solveLLtAheadTail<NB>(s.L, s.invDiag, s.d0, tid);
     } else if (!notPd) {
       solveLLt<NB, kLeanSolve>(s.L, s.invDiag, s.d0, tid);
     }
@@ -2363,7 +2468,10 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     // weaker preconditioner, so a further step is taken while the last correction was still
     // larger than 1e-3 of the step (error after k steps ~ ratio^(k+1)).  The test is on block-wide
     // sums, hence uniform.
-    const int nRefine = (!notPd && !kMix) ? fp.refine : 0; // refinement steps allowed (default 3, mmx_tuning::max_refinement_steps)
+    // (refinement steps allowed: default 3, mmx_tuning::max_refinement_steps.  Round 6 measured leaving the refinement out of the
+    // FIRST three / five iterations only -- + 5.6 % / + 10 % -- and every instance left the bound, median 3.4e-5: ten damped
+    // iterations do not attenuate an early step's error at all; profiles/r06_exp_fused.txt)
+    const int nRefine = (!notPd && !kMix) ? fp.refine : 0;
     float prevCorr2 = FLT_MAX;
     for (int rf = 0; rf < nRefine; ++rf) {
       // joint-parameter delta jd = transform * delta (delta gathered through the solve map)

@@ -20,6 +20,19 @@ case "$step" in
   mixedrate)  # rates of the precision routes + the mixed kernel's phase clocks
     timeout 900 python scripts/diag_mixed_rate.py > gpurun_out/mixed_rate.log 2>&1; cat gpurun_out/mixed_rate.log
     MMX_PHASE_CLOCKS=1 timeout 300 python scripts/diag_mixed_rate.py > gpurun_out/mixed_clocks.log 2>&1; cat gpurun_out/mixed_clocks.log ;;
+  ab)  # A/B on one box: ab <variant> [more bench args]: the default library against momentum_amd/libmmx_hip_<variant>.so, alternating
+    v=$1; shift
+    B="python bench.py --no-extra-configs --no-cpu-baseline --no-measure-traffic --check-instances 1024 --steps 30 --warmup 3 --details gpurun_out/ab_details.json"
+    for rep in 1 2; do
+      for lib in default $v; do
+        if [ $lib = default ]; then unset MMX_LIB; else export MMX_LIB=$PWD/momentum_amd/libmmx_hip_$v.so; fi
+        for cfg in "--config cfg2" "--config cfg3 --steps 4" "--config cfg2 --line-search 2" "--config cfg2 --batch 32768 --steps 8"; do
+          timeout 300 $B $cfg "$@" 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); print('$lib', '$cfg', 'value %.4g' % l['value'], 'max_rel', l['check'].get('max_rel'), 'median', l['check'].get('median_rel'), l['check'].get('within_bound'))"
+        done
+      done
+    done ;;
   tests)  # the GPU suite (optionally -k expression)
     if [ $# -eq 0 ]; then set -- tests; fi
     timeout 2400 python -m pytest "$@" -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -25 gpurun_out/pytest_gpu.log ;;
