@@ -788,7 +788,9 @@ def main() -> None:
                 extra[f"at_batch_{BL}"] = {"achieved": gbsL, "frac": gbsL / HBM_PEAK_GBS, "ms_per_launch": msL}
                 del jacL, resL, errL, dbL
                 torch.cuda.empty_cache()
-            # ... and on SURVEY 8(d)'s stress variant (P = 219, both constraints on all 72 joints: M = 864, 766 380 B per instance)
+        if args.config == "cfg2" and not args.no_extra_configs:
+            # ... and on SURVEY 8(d)'s stress variant (P = 219, both constraints on all 72 joints: M = 864, 766 380 B per instance);
+            # (not in the profiling passes, --no-extra-configs: the same kernel name at the same grid size would blur their averages)
             rigA, parA, _, _, _ = build_rig("cfg2_all")
             dbA = DeviceBatch(rigA, parA, 4096, local_rank, seed + 2)
             MA, PA = dbA.pb.M, dbA.pb.P

@@ -75,9 +75,12 @@ open(f"{out}/{r}_roofline.txt","w").write("\n".join(rows)+"\n")
 print("\n".join(rows))
 PY
 cat $out/pytest_gpu.txt; head -8 $out/${r}_bench_kernel_stats.txt | cut -c1-140; head -8 $out/${r}_cfg5_kernel_stats.txt | cut -c1-140
-cp $GRAFT_REPO_ROOT/gpurun_out/bench_details.json $out/${r}_bench_details.json 2> /dev/null
 cd $GRAFT_REPO_ROOT
-timeout 600 python scripts/diag_auto_table.py 1024 < /dev/null 2>&1 | grep -v amdgpu.ids > $out/auto_table.txt
+MMX_TABLE_TAG=_round timeout 900 python scripts/diag_mixed_table.py 1024 < /dev/null 2>&1 | grep -v amdgpu.ids > $out/mixed_table.txt
+cp gpurun_out/mixed_table_round.json $out/${r}_weak_damping.json 2> /dev/null
+timeout 600 python scripts/diag_mixed_rate.py < /dev/null 2>&1 | grep -v amdgpu.ids > $out/${r}_mixed_rate.txt
+MMX_PHASE_CLOCKS=1 timeout 300 python scripts/diag_mixed_rate.py < /dev/null 2>&1 | grep -v amdgpu.ids > $out/${r}_mixed_phase_clocks.txt
+MMX_PHASE_CLOCKS=1 timeout 300 python bench.py --no-extra-configs --no-cpu-baseline --no-measure-traffic --check-instances 0 --steps 1 --warmup 0 --line-search 2 --details $out/profiling_pass_details.json < /dev/null 2>&1 | grep -v "amdgpu.ids\|^{" > $out/${r}_phase_clocks.txt
 timeout 300 python scripts/diag_precision.py lm 65536 16384 < /dev/null 2>&1 | grep -v amdgpu.ids | tail -2 > $out/lm_steps.txt
 timeout 300 python bench.py --config cfg4 --steps 6 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 256 < /dev/null > $out/${r}_bench_cfg4.json 2> /dev/null
 timeout 200 python scripts/diag_determinism.py 6 < /dev/null 2>&1 | grep -v amdgpu.ids > $out/determinism.txt
