@@ -46,6 +46,8 @@ def _problem(torch, rig, cons, B):
     t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(shp)).to(pb.device)
     pb.set_constraints(t(cons.pos_offset, (B, cons.Kp, 3)), t(cons.pos_target, (B, cons.Kp, 3)), t(cons.pos_weight, (B, cons.Kp)),
                        t(cons.ori_offset, (B, cons.Ko, 4)), t(cons.ori_target, (B, cons.Ko, 4)), t(cons.ori_weight, (B, cons.Ko)))  # fmt: skip
+    if capi.default_route == "prefer_wide":
+        pb.set_route("fused")  # (the forced-wide sweep of scripts/gpu_cross_checks.sh: this file is about the one-launch route's instantiation)
     return pb
 
 
@@ -190,3 +192,49 @@ def test_mixed_outside_its_scope_is_the_double_instantiation(torch_cuda):
     d = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_F64))
     assert np.all(a["status"] & MMX_SOLVE_MIXED == 0)
     assert np.array_equal(a["theta"], d["theta"]) and np.array_equal(a["status"], d["status"])
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_mixed_on_random_rigs_follows_the_double_run(torch_cuda, orc, seed):
+    """The randomised rigs of tests/test_gpu_fuzz.py (chains, stars, bushy trees; shared parameters, translation / scale dofs,
+    transform rows with three entries, non-zero transform offsets, random pre-rotations, random constraint sets, weights and
+    enabled masks) through the mixed-precision instantiation: every block count from one to eight, every step rule it carries, at a
+    damping where single precision is held to 2e-5 only -- within 2e-6 of the oracle's double run, iteration counts and error
+    histories the double run's."""
+    from tests.test_gpu_fuzz import random_rig
+
+    torch = torch_cuda
+    rng = np.random.default_rng(7000 + seed)
+    J = int(rng.integers(2, 110))
+    rig = random_rig(rng, J, ["chain", "star", "bushy"][seed % 3])
+    P = rig.num_params
+    Kp, Ko = int(rng.integers(0, 9)), int(rng.integers(0, 6))
+    if Kp + Ko == 0:
+        Kp = 1
+    pp = rng.integers(0, J, size=Kp).astype(np.int32)
+    op = rng.integers(0, J, size=Ko).astype(np.int32)
+    B = 3
+    cons, th0, _ = make_problem(rig, pp, op, B, seed=seed, perturb=0.25, random_offsets=True, weights="random")
+    pb = _problem(torch, rig, cons, B)
+    en = (rng.uniform(size=P) < 0.8).astype(np.uint8)
+    en[:3] = 1
+    pb.set_enabled(en)
+    rule = seed % 4  # plain, GaussNewtonSolverT's line search, the driver's, the LM schedule
+    opt = GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.1, do_line_search=rule if rule < 3 else 0,
+                         step_rule=MMX_STEP_LM_SCHEDULE if rule == 3 else 0, precision=MMX_PRECISION_MIXED)  # fmt: skip
+    try:
+        out = _solve(torch, pb, th0, opt, want_history=True)
+    except capi.MmxError as e:  # (more than 128 solved parameters: the wide route's problem -- the double kernel takes MIXED there)
+        pytest.skip(str(e))
+    ref = orc.solve_batch(rig, cons, th0, opt, enabled=en, dtype="f64")
+    st = out["status"]
+    if not np.all(st & MMX_SOLVE_MIXED != 0):
+        assert np.all(st & MMX_SOLVE_MIXED == 0)  # outside the instantiation's scope (block count): the double kernel, all or nothing
+    assert np.all(st & 3 == 0) and np.all(st & MMX_SOLVE_PRECISION_SUSPECT == 0), st
+    assert np.array_equal(out["iterations"], ref["iterations"])
+    h, href = out["error_history"], ref["error_history"]
+    same = np.all(np.abs(h - href) <= 1e-6 * np.abs(href) + 1e-9 * href[:, :1], axis=1)
+    assert same.sum() >= B - 1, (seed, h, href)  # (a line-search / gain-ratio decision on its threshold may go the other way on one)
+    rel = np.linalg.norm(out["theta"].astype(np.float64) - ref["theta"], axis=1) / np.maximum(np.linalg.norm(ref["theta"], axis=1), 1e-3)
+    assert rel[same].max() <= 2e-6, (seed, rel)
+    assert np.all(out["theta"][:, en == 0] == th0[:, en == 0])  # disabled parameters are never touched

@@ -93,7 +93,7 @@ def test_auto_with_a_bound_nothing_passes_escalates_every_element(torch_cuda, or
     B = 300  # (not a multiple of the selection kernel's stride)
     rig, cons, th0 = _cfg2(B)
     pb = _problem(torch_cuda, rig, cons, B)
-    pb.set_route(route)
+    pb.set_route("fused" if route == "auto" and capi.default_route == "prefer_wide" else route)  # (under the forced-wide sweep "auto" would be wide)
     mk = lambda prec, bound=1e-5: GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE,
                                                  precision=prec, precision_bound=bound)  # fmt: skip
     a = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_AUTO, 1e-30), want_history=True, want_step_history=True)
