@@ -1796,41 +1796,24 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
   }
 }
 
-// MMX_PRECISION_AUTO: the elements the single-precision solve marked (MMX_SOLVE_PRECISION_SUSPECT, or an error bit), in
-// index order -- one workgroup, a 256-wide scan over the batch in strides
-// require: bits that must ALL be set as well (0: none) -- the third stage takes only elements the mixed pass has solved
+// MMX_PRECISION_AUTO: the elements the last pass marked (status & mask, and all of `require` set), compacted into map[0 .. *count - 1].
+// One thread per element, one atomic per wave (*count zeroed by the launcher): the ORDER of the list depends on the waves' arrival
+// and is not reproducible -- it only decides which workgroup of the next pass solves which element; every element's result is
+// its own.  (Round 5's single-workgroup scan kept index order and took 0.4 ms per 65 536 elements.)
 __global__ void __launch_bounds__(256) selectSuspectKernel(const int32_t* __restrict__ status, int B, int32_t mask, int32_t require, int32_t* __restrict__ map, int32_t* __restrict__ count) {
-  __shared__ int waveTot[4];
-  __shared__ int base;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) {
-    base = 0;
+  const int b = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool take = b < B && (status[b] & mask) != 0 && (status[b] & require) == require;
+  const unsigned long long m = __ballot(take);
+  if (m == 0ull) {
+    return;
   }
-  __syncthreads();
-  for (int b0 = 0; b0 < B; b0 += 256) {
-    const int b = b0 + tid;
-    const bool take = b < B && (status[b] & mask) != 0 && (status[b] & require) == require;
-    const unsigned long long m = __ballot(take);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) {
-      waveTot[wave] = __popcll(m);
-    }
-    __syncthreads();
-    int off = base;
-    for (int w = 0; w < wave; ++w) {
-      off += waveTot[w];
-    }
-    if (take) {
-      map[off + before] = b;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      base += waveTot[0] + waveTot[1] + waveTot[2] + waveTot[3];
-    }
-    __syncthreads();
+  int base = 0;
+  if (lane == 0) {
+    base = atomicAdd(count, __popcll(m));
   }
-  if (tid == 0) {
-    *count = base;
+  base = __shfl(base, 0, 64);
+  if (take) {
+    map[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
   }
 }
 
@@ -1933,7 +1916,11 @@ hipError_t launchSolveF64(
 }
 
 hipError_t launchSelectSuspect(const int32_t* status, int B, int32_t mask, int32_t* map, int32_t* count, hipStream_t stream, int32_t require) {
-  hipLaunchKernelGGL(selectSuspectKernel, dim3(1), dim3(256), 0, stream, status, B, mask, require, map, count);
+  hipError_t rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
+  if (rc != hipSuccess) {
+    return rc;
+  }
+  hipLaunchKernelGGL(selectSuspectKernel, dim3((B + 255) / 256), dim3(256), 0, stream, status, B, mask, require, map, count);
   return hipGetLastError();
 }
 

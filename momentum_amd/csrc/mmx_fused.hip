@@ -1420,8 +1420,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     clkLast = now_;                                               \
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // MMX_PRECISION_AUTO's second pass (kMix with an element list): workgroup i takes element map[i]; the ones beyond *count leave at
+  // once.  (Round 6 measured a FIXED grid walking the list instead -- nothing to pay when the list is empty: AUTO on an unmarked
+  // batch - 3.5 % instead of - 7 % at 65 536 --, but the kernel arguments then stay live across the whole body for the next element:
+  // 34 instead of 8 spilled VGPRs, 504 instead of 309 spilled SGPRs, and MMX_PRECISION_MIXED itself 3.5 % slower.  Not kept.)
   int bSel = blockIdx.x;
-  if (kMix && sel.map != nullptr) { // MMX_PRECISION_AUTO: workgroup i takes element map[i]; the ones beyond *count leave at once
+  if (kMix && sel.map != nullptr) {
     if (int(blockIdx.x) >= *sel.count) {
       return;
     }
@@ -1461,11 +1465,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   constexpr bool kCsrLds = !kFour && !kMix; // (the mixed instantiation walks the transform in double from global memory: mixTransformRows)
   // the register-lean forms of three routines in the four-workgroup instantiations (A/B variants: the full forms back, one each)
   constexpr bool kLeanSolve = kFour;
-#ifdef MMX_EXP_NORIDE // (A/B variant: the first solve whole, after the factorisation)
-  constexpr bool kRide = false;
-#else
-  constexpr bool kRide = kFour && NB >= 2; // the first solve's forward substitution rides under the panel factorisation (wave 3)
-#endif
+  constexpr bool kRide = kFour && NB >= 2; // the first solve's forward substitution rides under the panel factorisation (wave 3); A/B: r06_exp_fused.txt item 1
   constexpr bool kLeanOps = kFour;
   constexpr bool kLeanAcc = kFour;
   const int kNnz = fd.nnz;
@@ -3049,6 +3049,19 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     st.iterations[b] = itersDone;
     st.finalError[b] = curError;
     st.status[b] = stt;
+    s.flags[3] = itersDone;
+  }
+  if (kMix && sel.map != nullptr) { // (list mode) the rows of the histories past this run's last iteration still hold the single-precision pass's
+    __syncthreads();
+    for (int i = s.flags[3] + tid; i < fp.maxIterations; i += 256) {
+      if (st.errorHistory != nullptr) {
+        st.errorHistory[size_t(b) * fp.maxIterations + i] = 0.0;
+      }
+      if (st.stepHistory != nullptr) {
+        st.stepHistory[(size_t(b) * fp.maxIterations + i) * 2] = 0.0;
+        st.stepHistory[(size_t(b) * fp.maxIterations + i) * 2 + 1] = 0.0;
+      }
+    }
   }
 }
 
