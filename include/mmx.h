@@ -99,8 +99,10 @@ typedef enum mmx_status {
                                        parameters -- no single-precision normal-equation solver is; the answer there
                                        is mmx_solve_f64.  mmx_solve_f64 never sets this bit. */
 #define MMX_SOLVE_PRECISION_SUSPECT 8 /* (bit, informational, ABI 10) the single-precision solve's own estimate of its
-                                         distance from the same solve in double -- 0.042 eps / (smallest Cholesky pivot
-                                         ratio d_jj / (H_jj + lambda) of any iteration) ~ eps x cond(J^T J + lambda I),
+                                         distance from the same solve in double -- 0.042 eps x max over the iterations of
+                                         sqrt(error of the iteration / error of the first) / (smallest Cholesky pivot
+                                         ratio d_jj / (H_jj + lambda) of the iteration) ~ eps x cond(J^T J + lambda I) x the
+                                         residual's share (ABI 11; ABI 10 weighted every iteration with 1),
                                          calibrated as the 98th percentile of the relative distance on the BASELINE shapes;
                                          mmx_problem_solve_diagnostics returns it -- exceeds mmx_gn_options::precision_bound
                                          (default 1e-5, north_star's parity bound: 1 / ratio = 2000).  Unlike

@@ -228,6 +228,7 @@ struct mmx_problem {
   DevBuf sFusedArgs; // the one-launch solve's descriptors, stashed per solve (mmx_fused.hip, kArgLazy)
   DevBuf sDiag; // [B][4] diagnostics of the last single-precision solve (mmx_problem_solve_diagnostics)
   DevBuf sDiagAcc; // [B][4] the wide route's accumulators behind it (mmx::StepParams::diagAcc)
+  DevBuf sDiagErr0; // [B] ... and the first iteration's error (mmx::StepParams::diagErr0)
   bool diagValid = false;
   DevBuf sThetaAuto, sAutoMap, sAutoCount; // MMX_PRECISION_AUTO: initial parameters, the elements to escalate, their number
   bool autoAbort = false; // ... its single-precision pass may leave a marked element after the first factorisation
@@ -2502,6 +2503,7 @@ static int32_t solveF32Impl(
   if (wideDiag) {
     MMX_HIP(pb->sDiag.ensure(B * 4 * sizeof(float)));
     MMX_HIP(pb->sDiagAcc.ensure(B * 4 * sizeof(float)));
+    MMX_HIP(pb->sDiagErr0.ensure(B * sizeof(float)));
     st.diag = pb->sDiag.as<float>();
     st.precisionBound = o->precision_bound > 0.f ? o->precision_bound : 1e-5f;
     pb->diagValid = true;
@@ -2509,6 +2511,7 @@ static int32_t solveF32Impl(
   MMX_HIP(mmx::launchSolveInit(st, pb->B, schedule ? pb->sLambda.as<float>() : nullptr, o->regularization, s, wideDiag ? pb->sDiagAcc.as<float>() : nullptr));
   mmx::StepParams sp{};
   sp.diagAcc = wideDiag ? pb->sDiagAcc.as<float>() : nullptr;
+  sp.diagErr0 = wideDiag ? pb->sDiagErr0.as<float>() : nullptr;
   sp.lambda = o->regularization;
   sp.threshold = o->threshold;
   sp.minIterations = o->min_iterations;

@@ -739,9 +739,9 @@ __host__ __device__ inline FusedLayout fusedLayout(int NB, int J, int P, int U, 
   const size_t rowsGp = a4(size_t(genRows));
   l.genFloats = GT > 0 ? a4(size_t(kGenEv) * GT) + 2 * a4(rowsGp) + a4(rowsGp * size_t(srcStrideFor(int(NP)))) : 0;
   const size_t meta = h4(NP + 1) + 3 * a4(nsrc) + a4(J) + 4 * h4(J) + h4(size_t(J) + 1) + 2 * h4(U) + h4(n) + h4(P);
-  size_t fixed = a4(P) + a4(size_t(kJs) * J) + 2 * a4(3 * size_t(U)) + a4(U) + 2 * a4(NP) + l.uyFloats + 16 + 4;
+  size_t fixed = a4(P) + a4(size_t(kJs) * J) + 2 * a4(3 * size_t(U)) + a4(U) + 2 * a4(NP) + l.uyFloats + 16 + 8;
   if (mix) { // uy's place | red, flags | the double arrays | lo, hi
-    fixed = l.uyFloats + 40 + 4 + a4(2 * mixPersistentDoubles(J, P, U, int(NP))) + 2 * h4(J);
+    fixed = l.uyFloats + 40 + 8 + a4(2 * mixPersistentDoubles(J, P, U, int(NP))) + 2 * h4(J);
   }
   l.total = meta + fixed + l.genFloats + l.arenaFloats + l.regionFloats + csrFloats;
   return l;
@@ -1514,7 +1514,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     s.uy = take(lay.uyFloats);
     s.rho = s.uy + lay.auxOff, s.invDiag = s.rho + NP, srcGu = s.rho, cells = s.rho + lay.cellOff;
     s.red = reinterpret_cast<double*>(take(kMix ? 40 : 16)); // (kMix: five sums per reduction round)
-    s.flags = reinterpret_cast<int*>(take(4));
+    s.flags = reinterpret_cast<int*>(take(8)); // [4 .. 6] as floats: the precision estimate's accumulators (estAcc below)
     s.gEv = s.gRes = s.gW = s.gJ = nullptr;
     if (kGen) {
       const int rowsGp = (fd.genRows + 3) & ~3;
@@ -1654,10 +1654,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   fv.dfsJoint = lDfsJoint, fv.loadedPos = lLoadedPos, fv.numLoaded = numLoadedInst, fv.colToSolve = lColToSolve;
   fv.subSize = lSubSize, fv.unitPos = lUnitJoint, fv.posUnitStart = lPosUnitStart, fv.posUnits = lPosUnits;
   fv.solveList = lSolveList;
+  // the precision estimate's accumulators, kept by thread 0 in LDS (not in registers: they are touched once per iteration):
+  // [0] largest w = kPivotFloor (H_jj + mu) / d_jj of the solve, [1] largest w x sqrt(error of the iteration / error of the
+  // first) over the iterations, [2] the first iteration's error (< 0: none yet)
+  float* estAcc = reinterpret_cast<float*>(s.flags + 4);
   if (tid == 0) {
     s.flags[0] = 0; // stop
     s.flags[1] = 0; // not positive definite (this iteration)
     s.flags[2] = 0; // status
+    estAcc[0] = estAcc[1] = 0.f, estAcc[2] = -1.f;
   }
   int4 mixRec{0, 0, 0, 0}; // kMix: this thread's transform-row record (RigDev::ptRowRec), kept for the whole solve
   const bool mixHasRec = kMix && rv.rowRec != nullptr && rv.numRowRec <= 256;
@@ -2964,13 +2969,28 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     // marks (precision estimate above the bound) will be solved again from its initial parameters anyway -- it stops here,
     // its parameters are not written back.  The pivot ratio is a property of the problem class: a marked class pays ONE
     // iteration of the single-precision pass instead of all of them.
-    float abortW = 0.f;
-    if (!kMix && !kTR && fp.autoAbort != 0 && wave == 0) {
-      abortW = pivotWorst;
-      abortW = fmaxf(abortW, dppMoveF<0xB1>(abortW));
-      abortW = fmaxf(abortW, dppMoveF<0x4E>(abortW));
-      abortW = fmaxf(abortW, dppMoveF<0x141>(abortW));
-      abortW = fmaxf(abortW, dppMoveF<0x140>(abortW));
+    // The precision estimate, iteration by iteration (round 6): what the rounding of g = J^T r contributes to theta in THIS
+    // iteration is ~ eps x cond(iteration) x |r| / |J| -- the noise of g scales with the RESIDUAL.  Round 5 took the worst pivot
+    // ratio of the whole solve at full weight, which is the first iteration's weight; an iteration whose residual has fallen to a
+    // thousandth (the LM schedule's last ones, whose small lambda gives them the worst pivot ratios of the solve) contributes a
+    // thirtieth of that.  With a fixed lambda the pivot ratio is the same in every iteration and the largest weight is the first
+    // iteration's 1: the estimate -- and its calibration (mmx_device.hpp) -- are round 5's.  Wave 0 joins its sixteen diagonal
+    // lanes' w of this iteration; thread 0 keeps max w and max w sqrt(e_it / e_0).
+    if (wave == 0) {
+      float w = pivotWorst;
+      w = fmaxf(w, dppMoveF<0xB1>(w));
+      w = fmaxf(w, dppMoveF<0x4E>(w));
+      w = fmaxf(w, dppMoveF<0x141>(w));
+      w = fmaxf(w, dppMoveF<0x140>(w));
+      pivotWorst = 0.f; // (per iteration from here on)
+      if (lane == 0) {
+        float e0 = estAcc[2];
+        if (e0 < 0.f) {
+          e0 = estAcc[2] = float(curError);
+        }
+        estAcc[0] = fmaxf(estAcc[0], w);
+        estAcc[1] = fmaxf(estAcc[1], w * (e0 > 0.f ? sqrtf(float(curError) / e0) : 1.f));
+      }
     }
     if (tid == 0) {
       const double e = curError;
@@ -2988,9 +3008,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       const bool converged = fabs(lastError - e) / (fabs(e) + double(FLT_MIN)) <= double(fp.threshold) * double(FLT_EPSILON);
       s.flags[0] = (it >= fp.minIterations && converged) ? 1 : 0;
       lastError = e;
-      if (!kMix && !kTR && fp.autoAbort != 0 && st.precisionBound > 0.f &&
-          !(kPrecisionGain * FLT_EPSILON * (abortW > 0.f ? abortW / kPivotFloorOrOne : 1.f) <= st.precisionBound)) {
-        s.flags[0] = 2; // marked: leave
+      if (!kMix && !kTR && fp.autoAbort != 0 && st.precisionBound > 0.f) {
+        // MMX_PRECISION_AUTO with a mixed-precision second pass: an element whose estimate SO FAR exceeds the bound will be solved
+        // again from its initial parameters anyway -- it stops here, its parameters are not written back
+        const float estNow = kPrecisionGain * FLT_EPSILON * estAcc[1] / kPivotFloorOrOne;
+        if (!(estNow <= st.precisionBound)) {
+          s.flags[0] = 2; // marked: leave
+        }
       }
     }
     __syncthreads();
@@ -3019,17 +3043,15 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
     }
   }
   th2 = blockSumF(s, th2, tid);
-  pivotWorst = fmaxf(pivotWorst, dppMoveF<0xB1>(pivotWorst)); // the sixteen diagonal lanes of wave 0: four DPP steps inside their row
-  pivotWorst = fmaxf(pivotWorst, dppMoveF<0x4E>(pivotWorst));
-  pivotWorst = fmaxf(pivotWorst, dppMoveF<0x141>(pivotWorst));
-  pivotWorst = fmaxf(pivotWorst, dppMoveF<0x140>(pivotWorst));
   if (tid == 0) {
-    // Estimated distance of theta from the same solve in double, relative to |theta|: kPrecisionGain * eps / (smallest pivot
-    // ratio d_jj / (H_jj + mu) of any factorisation of the solve) ~ eps * cond(J^T J + mu I) -- the rounding of g = J^T r is
-    // amplified by |H^-1| whatever the refinement through J does for the step (mmx_device.hpp has the calibration).
-    const float worst = pivotWorst;
+    // Estimated distance of theta from the same solve in double, relative to |theta|: kPrecisionGain * eps * max over the
+    // iterations of sqrt(e_it / e_0) / (smallest pivot ratio d_jj / (H_jj + mu) of the iteration's factorisations) ~ eps x cond
+    // x the residual's share -- the rounding of g = J^T r is amplified by |H^-1| ~ cond on its way into the step, whatever the
+    // refinement through J does for the linear solve (mmx_device.hpp has the calibration).  [1] of the diagnostics stays the
+    // smallest pivot ratio of the whole solve.
+    const float worst = estAcc[0], wS = estAcc[1];
     const float ratio = worst > 0.f ? kPivotFloorOrOne / worst : 1.f;
-    const float est = kPrecisionGain * FLT_EPSILON / ratio;
+    const float est = wS > 0.f ? kPrecisionGain * FLT_EPSILON * wS / kPivotFloorOrOne : kPrecisionGain * FLT_EPSILON;
     int stt = bad ? 1 : s.flags[2];
     if (kMix) { // the estimate is the single-precision solves' (informational here): marked only when the CG did not converge
       if (!bad && mixUnconverged) {

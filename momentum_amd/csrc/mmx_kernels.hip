@@ -2692,6 +2692,7 @@ __global__ void __launch_bounds__(256, 3) choleskyFactorTiledKernel(
     w = waveReduceMaxF(w);
     if ((tid & 63) == 0) {
       atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 1), __float_as_int(w));
+      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 3), __float_as_int(w)); // (this iteration's: the finish stage weights it with the step)
     }
   }
   constexpr bool bad = false; // (pivot floor: the factorisation always completes, the step is always taken)
@@ -3034,6 +3035,7 @@ __global__ void __launch_bounds__(64 * kW, kW == 8 ? 4 : 2) choleskyFactorReside
     w = waveReduceMaxF(w);
     if (lane == 0) {
       atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 1), __float_as_int(w)); // (non-negative floats order like their bits)
+      atomicMax(reinterpret_cast<int*>(sp.diagAcc + 4 * size_t(b) + 3), __float_as_int(w)); // (this iteration's: the finish stage weights it with the step)
     }
   }
   float* d0 = g; // y = L^-1 g; solved in place: L^T d = y on the resident tiles
@@ -3136,9 +3138,20 @@ __global__ void __launch_bounds__(256, 3) choleskyFinishTiledKernel(
     }
     return;
   }
-  if (sp.diagAcc != nullptr && tid == 0 && step2 > 0.f) { // the largest refinement ratio of the solve (squared)
+  if (sp.diagAcc != nullptr && tid == 0) {
     float* a = sp.diagAcc + 4 * size_t(b);
-    a[2] = fmaxf(a[2], corr2 / step2);
+    if (step2 > 0.f) { // the largest refinement ratio of the solve (squared)
+      a[2] = fmaxf(a[2], corr2 / step2);
+    }
+    // the precision estimate, iteration by iteration (fusedSolveKernel has the rationale): this iteration's largest
+    // kPivotFloor (H_jj + mu) / d_jj weighted with the residual's share sqrt(e_it / e_0)
+    const float eNow = float(errIter[b]);
+    if (sp.iteration == 0) {
+      sp.diagErr0[b] = eNow;
+    }
+    const float e0 = sp.diagErr0[b];
+    a[0] = fmaxf(a[0], a[3] * (e0 > 0.f ? sqrtf(eNow / e0) : 1.f));
+    a[3] = 0.f;
   }
   applyStepAndBook(pb, P, b, d0, false, errIter, theta, st, sp, tid);
   if (tid == 0) {
@@ -3533,7 +3546,7 @@ solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaIn
     if (lane == 0) {
       const float* a = diagAcc + 4 * size_t(b);
       const float ratio = a[1] > 0.f ? kPivotFloorOrOne / a[1] : 1.f;
-      const float est = kPrecisionGain * FLT_EPSILON / ratio;
+      const float est = a[0] > 0.f ? kPrecisionGain * FLT_EPSILON * a[0] / kPivotFloorOrOne : kPrecisionGain * FLT_EPSILON / ratio;
       if (!bad && st.precisionBound > 0.f && !(est <= st.precisionBound)) {
         st.status[b] |= 8; // MMX_SOLVE_PRECISION_SUSPECT
       }

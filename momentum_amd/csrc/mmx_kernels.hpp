@@ -91,7 +91,8 @@ struct StepParams {
   int32_t* stepIter; // [B] iteration + 1 when `delta` holds a step, -(iteration + 1) when H was not positive definite
   float* lambdaPer; // [B] per-instance damping (LM schedule, trust region) or null: `lambda` for everyone
   double* stepHistory; // SolveStateDev::stepHistory for stepUpdateKernel (which applies the schedule on the wide / explicit routes)
-  float* diagAcc; // [B][4] or null: the wide route's precision estimate in the making -- [1] largest kPivotFloor (H_jj + mu) / d_jj
+  float* diagErr0; // [B] with diagAcc: the first iteration's error (the estimate weights an iteration with sqrt(e_it / e_0))
+  float* diagAcc; // [B][4] or null: the wide route's precision estimate in the making -- [0] largest (w of an iteration) x sqrt(e_it / e_0), [3] w of the iteration under way, [1] largest kPivotFloor (H_jj + mu) / d_jj
                   // of the solve (float bits, by atomicMax), [2] largest squared refinement ratio (fusedSolveKernel keeps
                   // the same two in LDS); solveFinalizeKernel turns them into SolveStateDev::diag and the status bit
   TrustStateDev tr; // MMX_STEP_TRUST_REGION on the wide route (all null otherwise)

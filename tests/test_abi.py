@@ -166,7 +166,7 @@ def test_production_instantiations_do_not_spill():
         pytest.skip(f"hipcc rejects {mbuild.SOLVE_KERNEL_FLAGS}: default pipeline (stamped), figures {got}")
     for rule, (vgprs, occ, sspill, vspill) in got.items():
         assert vgprs <= 128 and occ == 4, (rule, got)
-        assert vspill <= (8 if rule >= 0 else 12), (rule, got)  # (the generic rule: 12 since the forward substitution rides under the panels; default pipeline: 94)
+        assert vspill <= (10 if rule >= 0 else 12), (rule, got)  # (round 6: 9 / 6 / 12 -- the ride-along forward substitution, the per-iteration estimate; default pipeline: 37 / 54 / 94)
         assert sspill <= 340, (rule, got)
     if os.path.exists(mbuild.LIB) and info:
         assert info.get("solve_kernel_pipeline") == "no-machine-licm,no-lsr", info

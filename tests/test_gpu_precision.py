@@ -225,3 +225,24 @@ def test_rank_deficient_elements_are_marked_on_both_routes(torch_cuda, lam):
     # the same class bound from either route (the pivot ratio is a property of the problem class: within a decade)
     r = np.median(est["wide"]) / np.median(est["fused"])
     assert 0.1 <= r <= 10.0, (np.median(est["wide"]), np.median(est["fused"]))
+
+
+@pytest.mark.parametrize("route", ["fused", "wide"])
+def test_lm_schedule_is_not_marked_for_the_small_dampings_of_its_last_iterations(torch_cuda, route):
+    """BASELINE configs[2]'s class (round 6).  The LM schedule halves lambda while the fit converges (0.05 -> 1e-4 after nine accepted
+    steps), so the LAST iterations have the worst pivot ratios of the solve -- round 5's estimate took the worst ratio at full
+    weight and marked all 65 536 elements of a class whose answers hold 1e-5 (bench line of round 5: precision_suspect = 65536).
+    What the rounding of g = J^T r contributes in an iteration scales with that iteration's RESIDUAL: the estimate now weights an
+    iteration's pivot ratio with sqrt(e_it / e_0) -- 1 for the first, which is what a fixed lambda is calibrated on.  The class is
+    unmarked (its smallest pivot ratio alone would still mark it), and MMX_PRECISION_AUTO is the single-precision solve bit for bit."""
+    B = 512
+    rig, cons, th0 = _cfg2(B, seed=99)
+    pb = _problem(torch_cuda, rig, cons, B)
+    pb.set_route(route)
+    mk = lambda prec: GnOptions.make(min_iterations=10, max_iterations=10, threshold=1.0, regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE, precision=prec)
+    f = _solve(torch_cuda, pb, th0, mk(0))
+    diag = pb.solve_diagnostics().cpu().numpy()
+    assert np.all(f["status"] & MMX_SOLVE_PRECISION_SUSPECT == 0)
+    assert np.all(diag[:, 0] <= BOUND) and np.median(diag[:, 1]) < 1.0 / 2000.0, (diag[:, 0].max(), np.median(diag[:, 1]))
+    a = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_AUTO))
+    assert np.array_equal(a["theta"], f["theta"]) and np.all(a["status"] & (MMX_SOLVE_MIXED | MMX_SOLVE_ESCALATED_F64) == 0)
