@@ -145,7 +145,8 @@ typedef enum mmx_status {
                                  Follows GaussNewtonSolverT<double> (momentum/solver/gauss_newton_solver.cpp:315-316) to ~1e-7
                                  on theta -- at the batched driver's lambda = 0.01 and far below -- at a multiple of the double
                                  instantiation's rate.  Scope: the one-launch route's problems (up to 128 solved parameters,
-                                 256 joints) with position / orientation constraints, every step rule but the trust region;
+                                 256 joints) with position / orientation constraints, limits on model / joint parameters and
+                                 the model-parameter prior, every step rule but the trust region;
                                  anything else is solved by the double instantiation exactly as under MMX_PRECISION_F64 (no
                                  MMX_SOLVE_MIXED bit on the status). */
 

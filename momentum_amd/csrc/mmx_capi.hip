@@ -2131,14 +2131,15 @@ static int32_t solveF64Impl(
     void* stream);
 
 // MMX_PRECISION_MIXED (and MMX_PRECISION_AUTO's second pass): does the mixed-precision instantiation of the one-launch solve
-// take this problem with these options?  Position / orientation constraints only, no parameter-space rows, not the trust region,
-// the route not pinned away from the one-launch solve.
+// take this problem with these options?  Position / orientation constraints and the parameter-space rows (limits on model / joint
+// parameters, the model-parameter prior); not the further joint error functions / ellipsoid limits, not the trust region, the route
+// not pinned away from the one-launch solve.
 static bool mixedUsable(const mmx_problem* pb, const mmx_gn_options* o) {
   if (o == nullptr || pb == nullptr || pb->rig == nullptr) {
     return false;
   }
   const int32_t route = pb->tuning.route;
-  return (route == MMX_ROUTE_AUTO || route == MMX_ROUTE_FUSED) && o->step_rule != MMX_STEP_TRUST_REGION && pb->fdev.GT == 0 && pb->dev.M == pb->dev.rowsJoint &&
+  return (route == MMX_ROUTE_AUTO || route == MMX_ROUTE_FUSED) && o->step_rule != MMX_STEP_TRUST_REGION && pb->fdev.GT == 0 &&
       pb->U > 0 && pb->fdev.n > 0 && fusedUsable(pb) &&
       mmx::fusedMixedUsable(pb->rig->J, pb->rig->P, pb->U, pb->fdev.nsrc, pb->fdev.n, pb->fdev.numCells);
 }

@@ -267,6 +267,73 @@ __device__ __forceinline__ ParamCol paramRowsColumn(
   return o;
 }
 
+// The same in double for the mixed-precision instantiation (LimitErrorFunctionT<double>, ModelParametersErrorFunctionT<double>):
+// kOp = false: g_c = sum_l J(l,c) r_l and H_cc = sum_l J(l,c)^2 of the rows at theta `th`; kOp = true: the rows' part of the
+// operator, (J_p^T J_p x)_c for the vector x over the solve columns (g) -- h unused.
+struct ParamColD {
+  double g, h;
+};
+template <bool kOp, class I>
+__device__ __forceinline__ ParamColD paramRowsColumnD(
+    const RigDev& rig, const ProblemDev& pb, const FusedDev& fd, const double* th, const double* x, const I* colToSolve, int P, int b, int c, int p) {
+  ParamColD o{0.0, 0.0};
+  if (fd.numLimits > 0 && pb.wLimit > 0.f) {
+    const double tWeight = double(1e+1f * pb.wLimit); // kLimitWeight * weight_ (a float product in both instantiations)
+    const int k1 = fd.limStart[c + 1];
+    for (int k = fd.limStart[c]; k < k1; ++k) {
+      const LimitRowT<double> row = evalLimit<double>(rig, pb.limits[fd.limOf[k]], th, pb.enabledMask, tWeight);
+      double coef = 0.0, jx = 0.0;
+#pragma unroll
+      for (int e = 0; e < kLimitEntries; ++e) {
+        coef += row.idx[e] == p ? row.coef[e] : 0.0;
+        if (kOp) {
+          const int sc = row.idx[e] >= 0 ? colToSolve[row.idx[e]] : -1;
+          jx += row.coef[e] * (sc >= 0 ? x[sc] : 0.0); // parameters outside the solve list do not move
+        }
+      }
+      o.g += coef * (kOp ? jx : row.r);
+      o.h += coef * coef;
+    }
+  }
+  if (pb.hasModel && pb.wModel > 0.f) {
+    const double w = double(pb.mpWeights[size_t(b) * P + p]);
+    if (w > 0.0) {
+      const double sWeight = double(sqrtf(pb.wModel * 1e-1f)); // sWeight: a float in both instantiations (model_parameters_error_function.cpp:109)
+      const double a = sWeight * w;
+      o.g += a * (kOp ? a * x[c] : (w * (th[p] - double(pb.mpTarget[size_t(b) * P + p]))) * sWeight);
+      o.h += a * a;
+    }
+  }
+  return o;
+}
+// this thread's share of the parameter-space blocks' error at `th` in double (paramRowsError of mmx_device.hpp with T = double)
+template <bool kJacobianRows>
+__device__ __forceinline__ double paramRowsErrorD(const RigDev& rig, const ProblemDev& pb, int P, const double* th, int b, int tid) {
+  double e = 0.0;
+  if (pb.NL > 0 && pb.wLimit > 0.f) {
+    const double tWeight = double(1e+1f * pb.wLimit);
+    for (int l = tid; l < pb.NL; l += 256) {
+      e += evalLimit<double>(rig, pb.limits[l], th, pb.enabledMask, tWeight).err;
+    }
+  }
+  if (pb.hasModel && pb.wModel > 0.f) {
+    const float* tp = pb.mpTarget + size_t(b) * P;
+    const float* tw = pb.mpWeights + size_t(b) * P;
+    double em = 0.0;
+    for (int i = tid; i < P; i += 256) {
+      if (pb.enabledMask[i] != 0) {
+        const double w = double(tw[i]);
+        if (!kJacobianRows || w > 0.0) {
+          const double pd = w * (th[i] - double(tp[i]));
+          em += pd * pd;
+        }
+      }
+    }
+    e += em * double(pb.wModel) * 1e-1;
+  }
+  return e;
+}
+
 // y = A x for a CSR matrix whose tables live in GLOBAL memory (the wide kernels; the fused solve keeps them in LDS):
 // four rows per trip with their row bounds, then their first entries, requested together -- a row's walk is a chain
 // of dependent L2 round trips otherwise.  Same products in the same order as the plain walk.
@@ -502,9 +569,13 @@ __device__ __forceinline__ double mixUnits(const ProblemDev& pb, const FusedLds&
 // thread returns the same value.  kStore: also leaves what phases A-C of an iteration would leave (see blockError).
 template <bool kStore>
 __device__ __forceinline__ double blockErrorD(
-    const RigView& rig, const ProblemDev& pb, const FusedLds& s, const MixLds& m, const double* th, int b, int U, int tid, int myLevel, double* unrounded = nullptr, const int4* regRec = nullptr) {
+    const RigView& rig, const ProblemDev& pb, const FusedLds& s, const MixLds& m, const double* th, int b, int U, int tid, int myLevel, double* unrounded = nullptr, const int4* regRec = nullptr,
+    const RigDev* rowsRig = nullptr) { // rowsRig: the rig descriptor when the problem has parameter-space rows (their getError share), else null
   blockFkD(rig, m, th, tid, myLevel, kStore, regRec);
   double e = mixUnits<kStore>(pb, s, m, b, U, tid);
+  if (rowsRig != nullptr) {
+    e += paramRowsErrorD<false>(*rowsRig, pb, rig.P, th, b, tid);
+  }
   const double tot = blockSumD(s.red, e, tid);
   if (unrounded != nullptr) {
     *unrounded = tot;
@@ -1688,7 +1759,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       m.lo[k] = int16_t(lo), m.hi[k] = int16_t(hi);
     }
   }
-  const bool hasParamRows = (kRule >= 0 || kMix) ? false : (pb.M > pb.rowsJoint); // limit / model-parameter rows present (uniform)
+  const bool hasParamRows = kRule >= 0 ? false : (pb.M > pb.rowsJoint); // limit / model-parameter rows present (uniform)
   double lastError = DBL_MAX; // solver.cpp:84-85 (kept by thread 0)
   float lambda = fp.lambda; // constant for GaussNewtonSolverT, adapted by the LM schedule
   double lambdaD = double(fp.lambda); // kMix: the schedule's damping as GaussNewtonSolverT<double> carries it (lambda = its rounding: what is factored)
@@ -1756,6 +1827,9 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       // ================= A-C in double (mmx_mixed.hpp)
       blockFkD(rv, m, m.th, tid, mixLevel, true, mixRecP);
       double e = mixUnits<true>(pb, s, m, b, U, tid);
+      if (hasParamRows) {
+        e += paramRowsErrorD<true>(rig, pb, P, m.th, b, tid);
+      }
       e = waveReduceSum(e);
       if (lane == 0) {
         s.red[wave] = e;
@@ -1940,6 +2014,13 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       s.g[c] = acc;
       s.d0[c] = acc;
     }
+    if (kMix && hasParamRows) { // the parameter-space rows' share of g in double; their diagonal parked (rounded) until the tiles of H exist
+      for (int c = tid; c < n; c += 256) {
+        const ParamColD pc = paramRowsColumnD<false>(rig, pb, fd, m.th, nullptr, lColToSolve, P, b, c, lSolveList[c]);
+        m.g[c] += pc.g;
+        s.rho[c] = float(pc.h);
+      }
+    }
     MMX_CLK(5)
     // ================= G: H = J^T J from the moment contractions.  Entry (r, c) of the primary slots is
     //   w_r w_c (G0.AL + AX.BV + TR BS)(deep, ancestor),   deep = the slot whose joint lies below the other's,
@@ -2081,13 +2162,23 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
           float accp = 0.f;
           const int k1 = fd.pairStart[d + 1];
           for (int k = fd.pairStart[d]; k < k1; ++k) {
-            const LimitRow row = evalLimit(rig, pb.limits[fd.pairLim[k]], s.th, pb.enabledMask, tWeight);
             float ca = 0.f, cb = 0.f; // the row's entries in the two columns of this H entry
+            if (kMix) { // (theta lives in double there; H is the preconditioner: rounded)
+              const LimitRowT<double> row = evalLimit<double>(rig, pb.limits[fd.pairLim[k]], m.th, pb.enabledMask, double(tWeight));
 #pragma unroll
-            for (int e = 0; e < kLimitEntries; ++e) {
-              const int sc = row.idx[e] >= 0 ? lColToSolve[row.idx[e]] : -1;
-              ca += sc == fd.pairCols[2 * d] ? row.coef[e] : 0.f;
-              cb += sc == fd.pairCols[2 * d + 1] ? row.coef[e] : 0.f;
+              for (int e = 0; e < kLimitEntries; ++e) {
+                const int sc = row.idx[e] >= 0 ? lColToSolve[row.idx[e]] : -1;
+                ca += sc == fd.pairCols[2 * d] ? float(row.coef[e]) : 0.f;
+                cb += sc == fd.pairCols[2 * d + 1] ? float(row.coef[e]) : 0.f;
+              }
+            } else {
+              const LimitRow row = evalLimit(rig, pb.limits[fd.pairLim[k]], s.th, pb.enabledMask, tWeight);
+#pragma unroll
+              for (int e = 0; e < kLimitEntries; ++e) {
+                const int sc = row.idx[e] >= 0 ? lColToSolve[row.idx[e]] : -1;
+                ca += sc == fd.pairCols[2 * d] ? row.coef[e] : 0.f;
+                cb += sc == fd.pairCols[2 * d + 1] ? row.coef[e] : 0.f;
+              }
             }
             accp += ca * cb;
           }
@@ -2389,6 +2480,12 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
       bool converged = !(rz > 0.0); // (g = 0: the step is zero)
       for (int k = 0; k < fp.mixMaxCg && !converged; ++k) {
         mixApply(rv, fv, s, m, lParentPos, J, NP, n, nsrc, double(mu), m.p, m.q, tid, mixRecP);
+        if (hasParamRows) { // + J_p^T J_p p of the parameter-space rows (the thread that wrote q[c])
+          for (int c = tid; c < n; c += 256) {
+            m.q[c] += paramRowsColumnD<true>(rig, pb, fd, m.th, m.p, lColToSolve, P, b, c, lSolveList[c]).g;
+          }
+          __syncthreads();
+        }
         ++mixApplied;
         MMX_CLK(17)
         double pq = 0.0;
@@ -2778,7 +2875,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         }
         __syncthreads();
         double eFull = 0.0;
-        const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &eFull, mixRecP);
+        const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &eFull, mixRecP, hasParamRows ? &rig : nullptr);
         const double rho = predicted > 0.0 ? (curError - eNew) / predicted : -1.0;
         if (st.stepHistory != nullptr && tid == 0) {
           double* sh = st.stepHistory + (size_t(b) * fp.maxIterations + it) * 2;
@@ -2790,7 +2887,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
           for (int i = tid; i < P; i += 256) {
             m.th[i] = m.Y[i];
           }
-          stateValid = true;
+          stateValid = !hasParamRows; // (the trial's error is getError's: with parameter-space rows the iteration's is getJacobian's)
           stateError = eFull;
         }
         if (!(rho >= 0.25)) {
@@ -2819,7 +2916,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
             m.Y[fv.solveList[c]] -= double(scale) * m.x[c];
           }
           __syncthreads();
-          const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &stateError, mixRecP);
+          const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &stateError, mixRecP, hasParamRows ? &rig : nullptr);
           if ((curError - eNew) >= (doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale) * scaledError)) {
             break;
           }
@@ -2828,7 +2925,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         for (int i = tid; i < P; i += 256) {
           m.th[i] = m.Y[i];
         }
-        stateValid = true; // the last trial evaluated IS the new theta
+        stateValid = !hasParamRows; // the last trial evaluated IS the new theta
       } else {
         for (int c = tid; c < n; c += 256) {
           m.th[fv.solveList[c]] -= m.x[c]; // skeleton_solver_function.cpp:158
