@@ -11,7 +11,7 @@ import pytest
 from momentum_amd import capi  # noqa: E402  (default_route: which kernels the problems of a test run)
 
 from momentum_amd import humanoid72_landmark_joints, make_humanoid72, make_test_character
-from momentum_amd._abi import GnOptions
+from momentum_amd._abi import MMX_PRECISION_MIXED, GnOptions
 from tests.helpers import make_problem
 
 pytestmark = pytest.mark.gpu
@@ -109,6 +109,8 @@ def test_per_instance_characters(torch_cuda, orc, solver, memory, monkeypatch):
     th0 = np.zeros((B, rig.num_params), np.float32)
     _check_solve(torch, orc, pb, rigs, cons, th0, parents, parents, GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05))
     _check_solve(torch, orc, pb, rigs, cons, th0, parents, parents, GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=2))
+    if solver == "fused":  # the mixed-precision instantiation on every element's own constants: the double run's answer to the float result's last bit
+        _check_solve(torch, orc, pb, rigs, cons, th0, parents, parents, GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, precision=MMX_PRECISION_MIXED), 2e-7)
     # offsets only (pre-rotations of the shared rig), then back to the shared rig
     pb.set_instance_rig(off, None)
     rigs2 = []
@@ -155,6 +157,8 @@ def test_per_instance_constraint_parents(torch_cuda, orc, solver, which, monkeyp
     tol = 1e-5 if which == "humanoid72" else 5e-5  # (the under-determined chain fixture amplifies fp32 input rounding, see test_gpu_parity)
     _check_solve(torch, orc, pb, rigs, cons, th0, pos_parents, ori_parents, GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05), tol)
     _check_solve(torch, orc, pb, rigs, cons, th0, pos_parents, ori_parents, GnOptions.make(min_iterations=6, max_iterations=6, regularization=0.05, do_line_search=1), tol)
+    if solver == "fused":  # per-element unit tables (buildInstanceUnitTables) under the mixed-precision instantiation's double adjoint pass
+        _check_solve(torch, orc, pb, rigs, cons, th0, pos_parents, ori_parents, GnOptions.make(min_iterations=10, max_iterations=10, regularization=0.05, precision=MMX_PRECISION_MIXED), 2e-7)
     # a disabled parameter set on top, then host lists for the positions only (orientation back to shared)
     en = np.ones(rig.num_params, np.uint8)
     en[[1, 4]] = 0
