@@ -27,13 +27,20 @@ pass pmc2b "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_F32 SQ_I
 pass pmc2c "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE"
 pass pmc2d "FETCH_SIZE"
 pass pmc2e "WRITE_SIZE"
+# the mixed-precision instantiation (fusedSolveKernel<6,0,false,false,-1,false,true>): utilisation counters and a kernel trace
+pass pmcMa "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" --precision mixed
+pass pmcMb "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT" --precision mixed
+pass pmcMc "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE" --precision mixed
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/traceM -o t -- $B --precision mixed < /dev/null > /dev/null 2> $out/traceM.err
+db=$(find $out/traceM -name "*.db" | head -1)
+[ -n "$db" ] && timeout 120 python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py "$db" < /dev/null > $out/${r}_mixed_kernel_stats.txt
 pass pmc5a "FETCH_SIZE" --config cfg5 --batch 2048 --steps 2 --warmup 1
 pass pmc5b "WRITE_SIZE" --config cfg5 --batch 2048 --steps 2 --warmup 1
 pass pmc5c "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_F32 SQ_LDS_BANK_CONFLICT" --config cfg5 --batch 2048 --steps 2 --warmup 1
 timeout 120 python - $out $r < /dev/null <<'PY'
 import csv,sys,glob,collections
 out,r=sys.argv[1],sys.argv[2]
-for tag,pat in (("pmc_bench","pmc2"),("pmc_cfg5","pmc5")):
+for tag,pat in (("pmc_bench","pmc2"),("pmc_cfg5","pmc5"),("pmc_mixed","pmcM")):
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out+"/"+pat+"*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
@@ -82,6 +89,7 @@ timeout 600 python scripts/diag_mixed_rate.py < /dev/null 2>&1 | grep -v amdgpu.
 MMX_PHASE_CLOCKS=1 timeout 300 python scripts/diag_mixed_rate.py < /dev/null 2>&1 | grep -v amdgpu.ids > $out/${r}_mixed_phase_clocks.txt
 MMX_PHASE_CLOCKS=1 timeout 300 python bench.py --no-extra-configs --no-cpu-baseline --no-measure-traffic --check-instances 0 --steps 1 --warmup 0 --line-search 2 --details $out/profiling_pass_details.json < /dev/null 2>&1 | grep -v "amdgpu.ids\|^{" > $out/${r}_phase_clocks.txt
 timeout 300 python scripts/diag_precision.py lm 65536 16384 < /dev/null 2>&1 | grep -v amdgpu.ids | tail -2 > $out/lm_steps.txt
+(timeout 120 python scripts/diag_lm_estimate.py < /dev/null 2>&1 | grep cfg3; timeout 900 python scripts/diag_precision.py estimate < /dev/null 2>&1 | grep -E "^cfg|^p128") > $out/${r}_precision_estimate.txt
 timeout 300 python bench.py --config cfg4 --steps 6 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 256 < /dev/null > $out/${r}_bench_cfg4.json 2> /dev/null
 timeout 200 python scripts/diag_determinism.py 6 < /dev/null 2>&1 | grep -v amdgpu.ids > $out/determinism.txt
 bash scripts/resource_usage.sh > $out/${r}_kernel_resource_usage.txt 2>&1
