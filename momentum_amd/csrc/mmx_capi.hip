@@ -890,6 +890,13 @@ bool phaseClocksWanted() {
   return wanted;
 }
 
+// MMX_PHASE_STOP=<stamp> beside MMX_PHASE_CLOCKS: the clocked instantiation's workgroups end at that stamp of their first
+// iteration (slot 31 of the clock array carries stamp + 1) -- the solve's outputs are then meaningless; for counter passes only
+hipError_t armPhaseStop(long long* clk, hipStream_t s) {
+  static const long long stop = getenv("MMX_PHASE_STOP") != nullptr ? atoll(getenv("MMX_PHASE_STOP")) + 1 : 0;
+  return stop > 0 ? hipMemcpyAsync(clk + 31, &stop, sizeof(long long), hipMemcpyHostToDevice, s) : hipSuccess;
+}
+
 int32_t checkProblem(const mmx_problem* pb, bool needConstraints) {
   // hipGetLastError() is per thread and shared with every other user of the runtime in this
   // process (torch probes devices / pointers and leaves benign errors behind): start clean so that
@@ -2215,6 +2222,7 @@ static int32_t solveMixedImpl(
     MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
     MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
     clk = pb->sClk.as<long long>();
+    MMX_HIP(armPhaseStop(clk, s));
   }
   MMX_HIP(mmx::launchFusedMixed(pb->rigDev, pb->dev, pb->fdev, theta_dev, fst, fp, sel, pb->B, clk, s));
   if (clk != nullptr) {
@@ -2419,6 +2427,7 @@ static int32_t solveF32Impl(
       MMX_HIP(pb->sClk.ensure(32 * sizeof(long long)));
       MMX_HIP(hipMemsetAsync(pb->sClk.p, 0, 32 * sizeof(long long), s));
       clk = pb->sClk.as<long long>();
+      MMX_HIP(armPhaseStop(clk, s));
     }
     {
       MMX_ZONE("fused solve: all iterations of GaussNewtonSolverT::doIteration in one launch");

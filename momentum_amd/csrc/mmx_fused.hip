@@ -1484,11 +1484,18 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   // chain (waves without a panel row); NB <= 8: wave 3 never holds one (round 3, measured on one box: +2.2 % on cfg2)
   constexpr bool kLook = NB <= 8;
   long long clkLast = 0;
+  // (the clocked instantiation only) dbgClk[31] = slot + 1: every workgroup ENDS the first time it reaches that stamp -- counter
+  // passes over launches cut after successive phases attribute a per-kernel PMC (LDS bank conflicts) to the phases by
+  // difference (scripts/lds_conflicts_by_phase.sh; the stamps used are the workgroup-uniform ones)
+  const int dbgStop = (MODE == 2 && dbgClk != nullptr) ? int(dbgClk[31]) : 0;
 #define MMX_CLK(slot)                                             \
   if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) {         \
     const long long now_ = clock64();                             \
     dbgClk[slot] += now_ - clkLast;                               \
     clkLast = now_;                                               \
+  }                                                               \
+  if (MODE == 2 && dbgStop == (slot) + 1) {                       \
+    __builtin_amdgcn_endpgm();                                    \
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // MMX_PRECISION_AUTO's second pass (kMix with an element list): workgroup i takes element map[i]; the ones beyond *count leave at
