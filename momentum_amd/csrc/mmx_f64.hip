@@ -962,8 +962,8 @@ __device__ __noinline__ void residentBackward(const ldsd* H, const ldsd* invd, l
 // (J and H in a global scratch of the problem) is kept for the systems beyond.
 template <bool kRes>
 __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
-    RigDev rig,
-    ProblemDev pb,
+    const RigDev rigArg, // (read-only: the per-element copies are taken below the element-list gate -- a modified by-value argument
+    const ProblemDev pbArg, // is copied to scratch at entry, which every workgroup beyond *sel.count paid before it left)
     const int32_t* __restrict__ solveList, // [n] parameters of the dense system (enabled, structurally non-zero)
     int n,
     double* __restrict__ theta, // [B][P] in/out
@@ -984,6 +984,8 @@ __global__ void __launch_bounds__(256, kRes ? 2 : 1) solveF64Kernel(
     }
     b = sel.map[b];
   }
+  RigDev rig = rigArg;
+  ProblemDev pb = pbArg;
   selectInstanceRig(rig, b);
   selectInstanceWeights(pb, b);
   const int J = rig.J, P = rig.P, U = pb.U, G = pb.G, M = pb.rowsJoint; // (rowsJoint = 3 U + rows of the further joint error functions + 3 NE)

@@ -1467,8 +1467,8 @@ template <int NB, int MODE, bool kTR, bool kGen = false, int kRule = -1, bool kA
 // the general rows, one beyond.
 __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, kGen, kRule>::value && !kMix ? 4 : 3) : (NB <= 8 ? 2 : 1))) fusedSolveKernel(
     const FusedArgs* __restrict__ argsDev, // kArgLazy: the descriptors (the by-value ones are not read); else unused
-    RigDev rigV,
-    ProblemDev pbV,
+    const RigDev rigArg, // (by value, read-only: the per-element copies are taken BELOW the element-list gate -- a modified by-value
+    const ProblemDev pbArg, // argument is copied to scratch at entry, 90 KB of stores per workgroup that an empty one paid too)
     FusedDev fdV,
     float* __restrict__ theta, // [B][P] in/out
     SolveStateDev stV,
@@ -1511,7 +1511,11 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   }
   const int b = bSel, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  if (!kArgLazy) { // (the element's selections go into the by-value copies)
+  RigDev rigV;
+  ProblemDev pbV;
+  if (!kArgLazy) { // (the element's selections go into copies of the by-value descriptors)
+    rigV = rigArg;
+    pbV = pbArg;
     selectInstanceRig(rigV, b);
     selectInstanceWeights(pbV, b);
   }
