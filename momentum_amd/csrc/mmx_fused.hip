@@ -475,15 +475,21 @@ blockFk(const RigView& rig, const FusedLds& s, const float* th, int tid, bool wi
 // ---------------------------------------------------------------------------------------------
 // The double passes of the mixed-precision instantiation (kMix; mmx_mixed.hpp has the primitives and the rationale).
 // ---------------------------------------------------------------------------------------------
+// this thread's transform-row record when the rig has at most one record per thread (a value and a flag, not a nullable pointer:
+// `has ? &rec : nullptr` keeps the record in scratch)
+struct MixRowRec {
+  int4 q{0, 0, 0, 0};
+  bool has = false;
+};
 // y = transform * x in double: one transform row per thread from the rig's row records, else the prefetching CSR walk
 // (the tables in global memory either way); out(r, value) for every row r < R
 // regRec: this thread's row record, loaded once per solve (rig.numRowRec <= 256: a record per thread; the walk's L2 round trip
 // -- twice per operator application and once per forward pass -- then only remains for rows with more than one entry)
 template <typename Gather, typename Store>
-__device__ __forceinline__ void mixTransformRows(const RigView& rig, int tid, Gather x, Store out, const int4* regRec = nullptr) {
-  if (regRec != nullptr) {
+__device__ __forceinline__ void mixTransformRows(const RigView& rig, int tid, Gather x, Store out, const MixRowRec& regRec = MixRowRec{}) {
+  if (regRec.has) {
     if (tid < rig.numRowRec) {
-      const int4 q = *regRec;
+      const int4 q = regRec.q;
       const int row = q.x & 0xffff, span = int(uint32_t(q.x) >> 16), in0 = q.y & 0xffff, cnt = int(uint32_t(q.y) >> 16);
       auto acc = __int_as_float(q.z) * x(in0);
       for (int k = q.w + 1; k < q.w + cnt; ++k) {
@@ -514,7 +520,7 @@ __device__ __forceinline__ void mixTransformRows(const RigView& rig, int tid, Ga
 // the largest term left in double (measured: BASELINE configs[1] sat at 1.5e-7 ... 5e-7 of the oracle's double run whatever
 // the CG tolerance, the 24-joint chain with identity pre-rotations at 2.5e-8 = the rounding of the float result).
 // myLevel: the tree level of joint `tid` (one joint per thread, J <= 256); optionally the rotation axes.  Ends with a barrier.
-__device__ __forceinline__ void blockFkD(const RigView& rig, const MixLds& m, const double* th, int tid, int myLevel, bool withAxes, const int4* regRec = nullptr) {
+__device__ __forceinline__ void blockFkD(const RigView& rig, const MixLds& m, const double* th, int tid, int myLevel, bool withAxes, const MixRowRec& regRec = MixRowRec{}) {
   mixTransformRows(
       rig, tid, [&](int c) { return th[c]; }, [&](int r, double acc) { m.X[r] = acc + (rig.hasOffsets ? double(rig.ptOffsets[r]) : 0.0); }, regRec);
   __syncthreads();
@@ -569,11 +575,12 @@ __device__ __forceinline__ double mixUnits(const ProblemDev& pb, const FusedLds&
 // thread returns the same value.  kStore: also leaves what phases A-C of an iteration would leave (see blockError).
 template <bool kStore>
 __device__ __forceinline__ double blockErrorD(
-    const RigView& rig, const ProblemDev& pb, const FusedLds& s, const MixLds& m, const double* th, int b, int U, int tid, int myLevel, double* unrounded = nullptr, const int4* regRec = nullptr,
-    const RigDev* rowsRig = nullptr) { // rowsRig: the rig descriptor when the problem has parameter-space rows (their getError share), else null
+    const RigView& rig, const ProblemDev& pb, const FusedLds& s, const MixLds& m, const double* th, int b, int U, int tid, int myLevel, double* unrounded = nullptr, const MixRowRec& regRec = MixRowRec{},
+    const RigDev* rowsRig = nullptr, bool hasRows = false) { // hasRows: the problem has parameter-space rows (their getError share; rowsRig = the rig descriptor.
+  // A separate flag, not a null pointer: `cond ? &rig : nullptr` at the call keeps the whole by-value descriptor in scratch)
   blockFkD(rig, m, th, tid, myLevel, kStore, regRec);
   double e = mixUnits<kStore>(pb, s, m, b, U, tid);
-  if (rowsRig != nullptr) {
+  if (hasRows) {
     e += paramRowsErrorD<false>(*rowsRig, pb, rig.P, th, b, tid);
   }
   const double tot = blockSumD(s.red, e, tid);
@@ -681,7 +688,7 @@ __device__ __forceinline__ void mixAdjoint(const FV& fd, const FusedLds& s, cons
 // per joint C = T - Om x t - ln2 sd t, W = Om, S = sd summed over the ancestor chain by pointer jumping -> m.Y[kTanD k ..]
 // by DFS position k.  J <= 256.  Ends with a barrier.
 template <class FV, typename XFn>
-__device__ __forceinline__ void mixTangent(const RigView& rig, const FV& fd, const MixLds& m, const int16_t* parentPos, int J, int tid, XFn xOf, const int4* regRec = nullptr) {
+__device__ __forceinline__ void mixTangent(const RigView& rig, const FV& fd, const MixLds& m, const int16_t* parentPos, int J, int tid, XFn xOf, const MixRowRec& regRec = MixRowRec{}) {
   mixTransformRows(rig, tid, xOf, [&](int r, double a) { m.X[r] = a; }, regRec);
   __syncthreads();
   double acc[7];
@@ -735,7 +742,7 @@ __device__ __forceinline__ void mixTangent(const RigView& rig, const FV& fd, con
 // q = (J^T S^2 J + mu I) p in double (tangent pass down, adjoint pass up); p, q: [NP] over the solve columns.  Ends with a barrier.
 template <class FV>
 __device__ __forceinline__ void mixApply(
-    const RigView& rig, const FV& fd, const FusedLds& s, const MixLds& m, const int16_t* parentPos, int J, int NP, int n, int nsrc, double mu, const double* p, double* q, int tid, const int4* regRec = nullptr) {
+    const RigView& rig, const FV& fd, const FusedLds& s, const MixLds& m, const int16_t* parentPos, int J, int NP, int n, int nsrc, double mu, const double* p, double* q, int tid, const MixRowRec& regRec = MixRowRec{}) {
   mixTangent(
       rig, fd, m, parentPos, J, tid,
       [&](int c) {
@@ -1751,7 +1758,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
   if (mixHasRec && tid < rv.numRowRec) {
     mixRec = rv.rowRec[tid];
   }
-  const int4* mixRecP = mixHasRec ? &mixRec : nullptr;
+  const MixRowRec mixRecP{mixRec, mixHasRec};
   int mixLevel = 0; // kMix: the tree level of joint `tid` (blockFkD composes one level per barrier)
   if (kMix && tid < J) {
     for (int a = lParent[tid]; a >= 0; a = lParent[a]) {
@@ -2886,7 +2893,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
         }
         __syncthreads();
         double eFull = 0.0;
-        const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &eFull, mixRecP, hasParamRows ? &rig : nullptr);
+        const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &eFull, mixRecP, &rig, hasParamRows);
         const double rho = predicted > 0.0 ? (curError - eNew) / predicted : -1.0;
         if (st.stepHistory != nullptr && tid == 0) {
           double* sh = st.stepHistory + (size_t(b) * fp.maxIterations + it) * 2;
@@ -2927,7 +2934,7 @@ __global__ void __launch_bounds__(256, (NB <= 6 && !kGen ? (FusedFour<NB, kTR, k
             m.Y[fv.solveList[c]] -= double(scale) * m.x[c];
           }
           __syncthreads();
-          const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &stateError, mixRecP, hasParamRows ? &rig : nullptr);
+          const double eNew = blockErrorD<true>(rv, pb, s, m, m.Y, b, U, tid, mixLevel, &stateError, mixRecP, &rig, hasParamRows);
           if ((curError - eNew) >= (doLineSearch == 2 ? double(1e-4f * scale) * gd : double(scale) * scaledError)) {
             break;
           }

@@ -147,12 +147,17 @@ __device__ __forceinline__ UnitD evalUnitD(const ProblemDev& pb, const UnitInput
   const bool isPoint = u < pb.Kp;
   double sqr, fw;
   bool first = true;
-  const LossDev& ls = isPoint ? pb.lossPos : pb.lossOri;
+  // (both members read up front and SELECTED BY VALUE: a reference chosen between two members -- or loads of them in the two
+  // branches below, which the optimiser merges into one load of a chosen address -- is a dynamic offset into the by-value
+  // descriptor, and the whole 344-byte ProblemDev then lives in scratch)
+  const LossDev lsP = pb.lossPos, lsO = pb.lossOri;
+  const float fwP = pb.wPos, fwO = pb.wOri;
+  const LossDev ls{isPoint ? lsP.type : lsO.type, isPoint ? lsP.alpha : lsO.alpha, isPoint ? lsP.invC2 : lsO.invC2, isPoint ? lsP.c : lsO.c};
   if (isPoint) {
     o.v = t + dqrot(q, w[7] * D3{double(in.a[0]), double(in.a[1]), double(in.a[2])});
     o.f = o.v - D3{double(in.t[0]), double(in.t[1]), double(in.t[2])};
     sqr = ddot(o.f, o.f);
-    fw = double(pb.wPos);
+    fw = double(fwP);
   } else {
     const int uo = u - pb.Kp, k = uo - 3 * (uo / 3);
     // OrientationDataT<double>'s constructor normalises in double (orientation_error_function.h:33-35)
@@ -170,7 +175,7 @@ __device__ __forceinline__ UnitD evalUnitD(const ProblemDev& pb, const UnitInput
         }
       }
     }
-    fw = double(pb.wOri);
+    fw = double(fwO);
   }
   if (in.cw != 0.f && fw > 0.0) {
     const double wgt = double(in.cw) * fw;
