@@ -2039,7 +2039,7 @@ int32_t mmx_debug_tree_normal_equations(mmx_problem* pb, const float* theta_dev,
   }
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  MMX_HIP(hipMemsetAsync(jtj_dev, 0, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
+  MMX_HIP(mmx::zeroAsync(jtj_dev, size_t(pb->B) * size_t(pb->dev.n) * size_t(pb->dev.n) * sizeof(float), s));
   MMX_HIP(mmx::launchTreeNormalEquations(pb->rigDev, pb->dev, pb->fdev, theta_dev, jtj_dev, jtr_dev, nullptr, nullptr, nullptr, nullptr, nullptr, false, s));
   return MMX_OK;
 }
@@ -2192,13 +2192,13 @@ static int32_t solveMixedImpl(
     fst.diag = pb->sDiag.as<float>();
     pb->diagValid = true;
     if (step_history != nullptr && o->max_iterations > 0) {
-      MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
+      MMX_HIP(mmx::zeroAsync(step_history, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
     }
     if (error_history != nullptr && o->max_iterations > 0) {
-      MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+      MMX_HIP(mmx::zeroAsync(error_history, B * size_t(o->max_iterations) * sizeof(double), s));
     }
     if (parameter_history != nullptr && o->max_iterations > 0) {
-      MMX_HIP(hipMemsetAsync(parameter_history, 0, B * size_t(o->max_iterations) * P * sizeof(float), s));
+      MMX_HIP(mmx::zeroAsync(parameter_history, B * size_t(o->max_iterations) * P * sizeof(float), s));
     }
   }
   fst.precisionBound = o->precision_bound > 0.f ? o->precision_bound : 1e-5f;
@@ -2400,13 +2400,13 @@ static int32_t solveF32Impl(
     fst.precisionBound = o->precision_bound > 0.f ? o->precision_bound : 1e-5f;
     pb->diagValid = true;
     if (step_history != nullptr && o->max_iterations > 0) {
-      MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
+      MMX_HIP(mmx::zeroAsync(step_history, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
     }
     if (error_history != nullptr && o->max_iterations > 0) {
-      MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+      MMX_HIP(mmx::zeroAsync(error_history, B * size_t(o->max_iterations) * sizeof(double), s));
     }
     if (parameter_history != nullptr && o->max_iterations > 0) {
-      MMX_HIP(hipMemsetAsync(parameter_history, 0, B * size_t(o->max_iterations) * P * sizeof(float), s));
+      MMX_HIP(mmx::zeroAsync(parameter_history, B * size_t(o->max_iterations) * P * sizeof(float), s));
     }
     mmx::FusedParams fp{};
     fp.lambda = o->regularization;
@@ -2491,10 +2491,10 @@ static int32_t solveF32Impl(
   st.stepHistory = step_history;
   pb->diagValid = false; // (the wide route's estimate: below, where its kernels are set up)
   if (step_history != nullptr && o->max_iterations > 0) {
-    MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
+    MMX_HIP(mmx::zeroAsync(step_history, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
   }
   if (error_history != nullptr && o->max_iterations > 0) {
-    MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+    MMX_HIP(mmx::zeroAsync(error_history, B * size_t(o->max_iterations) * sizeof(double), s));
   }
   MMX_HIP(hipMemcpyAsync(pb->sThetaInit.p, theta_dev, B * P * sizeof(float), hipMemcpyDeviceToDevice, s));
   const bool deferred = trust || o->do_line_search != 0 || o->step_rule == MMX_STEP_LM_SCHEDULE;
@@ -2502,7 +2502,7 @@ static int32_t solveF32Impl(
   if (deferred) {
     MMX_HIP(pb->sDelta.ensure(B * size_t(std::max(n, 1)) * sizeof(float)));
     MMX_HIP(pb->sStepIter.ensure(B * sizeof(int32_t)));
-    MMX_HIP(hipMemsetAsync(pb->sStepIter.p, 0, B * sizeof(int32_t), s));
+    MMX_HIP(mmx::zeroAsync(pb->sStepIter.p, B * sizeof(int32_t), s));
   }
   if (schedule) {
     MMX_HIP(pb->sLambda.ensure(B * sizeof(float)));
@@ -2617,7 +2617,7 @@ static int32_t solveF32Impl(
             return rc;
           }
           MMX_HIP(mmx::launchTrustDecide(ds, factorScratch, pb->sJtr.as<float>(), pb->sErr.as<double>(), st, sp, s));
-          MMX_HIP(hipMemsetAsync(sp.tr.active, 0, sizeof(int32_t), s));
+          MMX_HIP(mmx::zeroAsync(sp.tr.active, sizeof(int32_t), s));
           MMX_HIP(mmx::launchStepUpdate(pb->rigDev, ds, theta_dev, pb->sJtr.as<float>(), pb->sErr.as<double>(), sp, s));
           int32_t active = 0;
           MMX_HIP(hipMemcpyAsync(&active, sp.tr.active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -2775,10 +2775,10 @@ static int32_t solveF64Impl(
   st.stepHistory = step_history;
   const bool escalation = select.map != nullptr; // (the single-precision solve's outputs stay for the other elements)
   if (error_history != nullptr && o->max_iterations > 0 && !escalation) {
-    MMX_HIP(hipMemsetAsync(error_history, 0, B * size_t(o->max_iterations) * sizeof(double), s));
+    MMX_HIP(mmx::zeroAsync(error_history, B * size_t(o->max_iterations) * sizeof(double), s));
   }
   if (step_history != nullptr && o->max_iterations > 0 && !escalation) {
-    MMX_HIP(hipMemsetAsync(step_history, 0, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
+    MMX_HIP(mmx::zeroAsync(step_history, B * size_t(o->max_iterations) * 2 * sizeof(double), s));
   }
   mmx::FusedParams fp{};
   fp.lambda = o->regularization;

@@ -1918,7 +1918,7 @@ hipError_t launchSolveF64(
 }
 
 hipError_t launchSelectSuspect(const int32_t* status, int B, int32_t mask, int32_t* map, int32_t* count, hipStream_t stream, int32_t require) {
-  hipError_t rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
+  hipError_t rc = zeroAsync(count, sizeof(int32_t), stream); // (a kernel, not a memset node: mmx_kernels.hpp)
   if (rc != hipSuccess) {
     return rc;
   }

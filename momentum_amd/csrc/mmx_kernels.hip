@@ -17,6 +17,7 @@
 #include "mmx_device.hpp"
 #include "mmx_kernels.hpp"
 
+#include <algorithm>
 #include <cfloat>
 #include <type_traits>
 #include <cstdlib>
@@ -3923,6 +3924,24 @@ hipError_t launchCholeskyFinishTiled(
   // (the sweeps on a factor brought into LDS in one round trip -- the form choleskyFactorResidentKernel's first solve uses --
   // were built for this stage too and measured slower: 0.61 against 0.53 ms on cfg5; two workgroups per CU instead of four)
   hipLaunchKernelGGL(choleskyFinishTiledKernel, dim3(pb.B), dim3(256), 0, stream, pb, P, factor, dvec, rhoVec, refState, errIter, theta, st, sp, round);
+  return hipGetLastError();
+}
+
+static __global__ void __launch_bounds__(256) zeroFillKernel(uint32_t* __restrict__ p, size_t words) {
+  for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < words; i += size_t(gridDim.x) * 256) {
+    p[i] = 0u;
+  }
+}
+hipError_t zeroAsync(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0 || p == nullptr) {
+    return hipSuccess;
+  }
+  if ((bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(p) & 3) != 0) {
+    return hipErrorInvalidValue;
+  }
+  const size_t words = bytes / 4;
+  const unsigned grid = unsigned(std::min<size_t>((words + 255) / 256, 8192));
+  hipLaunchKernelGGL(zeroFillKernel, dim3(grid), dim3(256), 0, stream, static_cast<uint32_t*>(p), words);
   return hipGetLastError();
 }
 

@@ -365,6 +365,11 @@ hipError_t launchStepUpdate(
     const StepParams& sp,
     hipStream_t stream);
 
+// bytes (a multiple of four) of zeros at p, by a KERNEL: the solve paths use no memset nodes.  Inside a captured graph (torch's
+// CUDAGraph around mmx_solve) a 4-byte hipMemsetAsync between dependent kernels -- the element count of MMX_PRECISION_AUTO's
+// compaction -- brought the replay down on ROCm 7.2 (abort in the runtime once the second and the third pass both had
+// elements; tests/test_gpu_graph.py); a kernel node in its place replays bit for bit.
+hipError_t zeroAsync(void* p, size_t bytes, hipStream_t stream);
 hipError_t launchSolveInit(const SolveStateDev& st, int B, float* lambdaPer, float lambda0, hipStream_t stream, float* diagAcc = nullptr);
 // TrustRegionQRT on the wide route: state of a solve / of an iteration, the decision after a linear solve (is the step
 // within the radius, or does lambda take a Newton update first), the bookkeeping at the end of an iteration
