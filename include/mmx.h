@@ -25,6 +25,15 @@
  * Threading: one handle = one device + caller-provided stream; calls on one
  * handle must be serialised by the caller (the reference's solver objects are
  * not thread-safe either, momentum/math/resizeable_matrix.h:36-38).
+ *
+ * Streams and graphs: mmx_solve* / mmx_eval_* enqueue kernels and device-to-device
+ * copies on `stream` and return; they neither wait for the stream nor read results
+ * back (exceptions, each said at its declaration: the *_host conveniences, the
+ * timed debug entry points, MMX_STEP_TRUST_REGION on the wide route).  After one
+ * warm-up call on a handle (scratch buffers, LDS limits) such a call may therefore
+ * be recorded into a HIP graph (hipStreamBeginCapture / torch.cuda.CUDAGraph) and
+ * replayed on new values in the same buffers -- tests/test_gpu_graph.py; the
+ * library issues kernel nodes only, no memset nodes.
  */
 #ifndef MMX_H_
 #define MMX_H_

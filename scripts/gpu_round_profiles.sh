@@ -93,6 +93,12 @@ timeout 300 python scripts/diag_precision.py lm 65536 16384 < /dev/null 2>&1 | g
 timeout 300 python bench.py --config cfg4 --steps 6 --warmup 2 --no-extra-configs --no-cpu-baseline --check-instances 256 < /dev/null > $out/${r}_bench_cfg4.json 2> /dev/null
 timeout 200 python scripts/diag_determinism.py 6 < /dev/null 2>&1 | grep -v amdgpu.ids > $out/determinism.txt
 bash scripts/resource_usage.sh > $out/${r}_kernel_resource_usage.txt 2>&1
+# LDS bank conflicts by phase (counter passes over launches cut after successive stamps), eager against graph replay, AUTO's trace
+bash scripts/lds_conflicts_by_phase.sh f32 > /dev/null 2>&1; cp gpurun_out/lds_phase/lds_conflicts_by_phase.txt $out/${r}_lds_conflicts_by_phase.txt 2> /dev/null
+rm -rf gpurun_out/lds_phase/p_*
+timeout 600 python scripts/diag_graph_rate.py < /dev/null 2>&1 | grep -v amdgpu.ids > $out/${r}_graph_rate.txt
+(cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats -d $out/traceA -o t -- $B --precision auto < /dev/null > /dev/null 2> $out/traceA.err
+ db=$(find $out/traceA -name "*.db" | head -1); [ -n "$db" ] && timeout 120 python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py "$db" < /dev/null > $out/${r}_auto_kernel_stats_after.txt)
 python - $out/${r}_bench_default.json < /dev/null <<'PY'
 import json,sys
 raw=open(sys.argv[1]).read()
