@@ -99,6 +99,8 @@ rm -rf gpurun_out/lds_phase/p_*
 timeout 600 python scripts/diag_graph_rate.py < /dev/null 2>&1 | grep -v amdgpu.ids > $out/${r}_graph_rate.txt
 (cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats -d $out/traceA -o t -- $B --precision auto < /dev/null > /dev/null 2> $out/traceA.err
  db=$(find $out/traceA -name "*.db" | head -1); [ -n "$db" ] && timeout 120 python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py "$db" < /dev/null > $out/${r}_auto_kernel_stats_after.txt)
+# gpurun copies back at most 64 MiB: the raw traces and counter CSVs stay on the box, their summaries above are what is kept
+rm -rf $out/trace2 $out/trace5 $out/traceM $out/traceA $out/pmc2? $out/pmcM? $out/pmc5? gpurun_out/lds_phase/p_*
 python - $out/${r}_bench_default.json < /dev/null <<'PY'
 import json,sys
 raw=open(sys.argv[1]).read()
