@@ -2848,17 +2848,20 @@ __global__ void __launch_bounds__(64 * kW, kW == 8 ? 4 : 2) choleskyFactorReside
   constexpr int kLoads = 4 * kResidentLoads / kW;
   for (int s0 = 0; s0 < numTiles; s0 += kW * kLoads) {
     float4 hv[kLoads];
+    // the slots' (I, k) codes of this wave's tiles: ONE load, lane u the code of tile u (read one by one they were twenty
+    // dependent global round trips in front of the matrix's own: each a vector load the wave waited for before it could form
+    // the next address -- a tenth of the kernel, profiles/r06_exp_fused.txt)
+    const uint32_t vCode = sp.tileMasks[96 + min(s0 + kW * min(lane, kLoads - 1) + wave, numTiles - 1)];
 #pragma unroll
     for (int u = 0; u < kLoads; ++u) {
-      const int sl = min(s0 + kW * u + wave, numTiles - 1); // (clamped: unconditional, independent requests)
-      const int code = int(sp.tileMasks[96 + sl]); // I | k << 8 (uniform)
+      const int code = __builtin_amdgcn_readlane(int(vCode), u); // I | k << 8 (clamped to the last slot: unconditional, independent requests)
       hv[u] = *reinterpret_cast<const float4*>(H + size_t(tileIndex(code & 0xff, code >> 8)) * 256 + opOff);
     }
 #pragma unroll
     for (int u = 0; u < kLoads; ++u) {
       const int sl = s0 + kW * u + wave;
       if (sl < numTiles) {
-        const int code = int(sp.tileMasks[96 + sl]);
+        const int code = __builtin_amdgcn_readlane(int(vCode), u);
         const int tI = code & 0xff, tK = code >> 8;
         const float hq[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
         float* T = tiles + 256 * sl;
@@ -2871,6 +2874,7 @@ __global__ void __launch_bounds__(64 * kW, kW == 8 ? 4 : 2) choleskyFactorReside
     }
   }
   __syncthreads();
+  MMX_SCLK(3)
   { // damping of the FACTOR: at least kFactorDamping of the mean diagonal (mmx_device.hpp), from the resident diagonal
     // tiles; then the diagonal gets it and every row its pivot floor
     float tr = 0.f;
@@ -2902,11 +2906,15 @@ __global__ void __launch_bounds__(64 * kW, kW == 8 ? 4 : 2) choleskyFactorReside
   // to the waves round robin), one barrier, then the panels side by side, each on its own waves.
   const uint32_t* sched = sp.tileMasks + 96 + numTiles;
   const int numSteps = int(sched[0]);
+  // the schedule's entries (four per step, at most 32 steps) in the lanes of two registers: one round trip for all of them
+  // instead of one per step in front of its updates
+  const uint32_t vSched0 = lane < 4 * numSteps ? sched[1 + lane] : 0u, vSched1 = 64 + lane < 4 * numSteps ? sched[1 + 64 + lane] : 0u;
   for (int st = 0; st < numSteps; ++st) {
     int ent[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      ent[e] = int(sched[1 + 4 * st + e]); // (uniform)
+      const int idx = 4 * st + e; // (uniform)
+      ent[e] = idx < 64 ? __builtin_amdgcn_readlane(int(vSched0), idx) : __builtin_amdgcn_readlane(int(vSched1), idx - 64);
     }
     bool anyUpdate = false;
     int rr = 0; // round robin over the step's (column, tile) pairs
