@@ -2136,6 +2136,7 @@ static int32_t solveF64Impl(
     double* step_history,
     const mmx::F64Select& select,
     void* stream);
+static int32_t preflightF64(mmx_problem* pb);
 
 // MMX_PRECISION_MIXED (and MMX_PRECISION_AUTO's second pass): does the mixed-precision instantiation of the one-launch solve
 // take this problem with these options?  Position / orientation constraints and the parameter-space rows (limits on model / joint
@@ -2289,6 +2290,12 @@ static int32_t solveImpl(
   if (o->precision == MMX_PRECISION_F64 || o->precision == MMX_PRECISION_MIXED || autoTrust) { // (MIXED outside the mixed instantiation's scope: the double one)
     // every workgroup reads its element's parameters before it writes them: in place on the caller's float array
     return solveF64Impl(pb, o, nullptr, final_error, iterations, status, error_history, step_history, mmx::F64Select{nullptr, nullptr, theta_dev, theta_dev}, stream);
+  }
+  // (everything that can refuse or fail in the LATER stages is settled before the single-precision pass touches theta, status
+  // and the histories: the double kernel's LDS budget, its scratch, the element lists)
+  rc = preflightF64(pb);
+  if (rc != MMX_OK) {
+    return rc;
   }
   MMX_HIP(pb->sThetaAuto.ensure(B * P * sizeof(float)));
   MMX_HIP(pb->sAutoMap.ensure(B * sizeof(int32_t)));
@@ -2719,6 +2726,23 @@ int32_t mmx_solve_f64(
 }
 
 // theta_dev: double [B][P] in / out, or null when `select` carries float arrays (MMX_PRECISION_F64 / AUTO of mmx_solve)
+// What the double kernel needs before it can run on this problem: its LDS budget and, in the scratch form, the problem's global
+// scratch for J and H.  solveF64Impl calls it first; MMX_PRECISION_AUTO calls it before its single-precision pass, so that a
+// refusal or an allocation failure of the later stage leaves the caller's theta / status / histories untouched.
+static int32_t preflightF64(mmx_problem* pb) {
+  const size_t B = size_t(pb->B), n = size_t(pb->solveN), M = size_t(pb->dev.rowsJoint);
+  const int genRowsF64 = pb->dev.rowsJoint - 3 * pb->U;
+  MMX_HIP(hipSetDevice(pb->rig->device));
+  if (!mmx::solveF64IsResident(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64)) {
+    if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64) > 160 * 1024) {
+      return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: rig beyond the kernel's LDS budget");
+    }
+    MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));
+    MMX_HIP(pb->sHessF64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));
+  }
+  return MMX_OK;
+}
+
 static int32_t solveF64Impl(
     mmx_problem* pb,
     const mmx_gn_options* o,
@@ -2753,12 +2777,9 @@ static int32_t solveF64Impl(
   MMX_HIP(hipSetDevice(pb->rig->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool residentF64 = mmx::solveF64IsResident(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64);
-  if (!residentF64) { // the scratch form: dense J and H of every element in a global scratch of the problem
-    if (mmx::solveF64LdsBytes(pb->rig->J, pb->rig->P, pb->U, pb->solveN, pb->dev.G + pb->dev.NE, genRowsF64) > 160 * 1024) {
-      return fail(MMX_ERR_UNSUPPORTED, "mmx_solve_f64: rig beyond the kernel's LDS budget");
-    }
-    MMX_HIP(pb->sJacF64.ensure(std::max<size_t>(B * n * M, 1) * sizeof(double)));
-    MMX_HIP(pb->sHessF64.ensure(std::max<size_t>(B * n * n, 1) * sizeof(double)));
+  rc = preflightF64(pb); // (the scratch form: dense J and H of every element in a global scratch of the problem)
+  if (rc != MMX_OK) {
+    return rc;
   }
   const bool trustF64 = o->step_rule == MMX_STEP_TRUST_REGION;
   if (trustF64) {

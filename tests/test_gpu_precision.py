@@ -246,3 +246,29 @@ def test_lm_schedule_is_not_marked_for_the_small_dampings_of_its_last_iterations
     assert np.all(diag[:, 0] <= BOUND) and np.median(diag[:, 1]) < 1.0 / 2000.0, (diag[:, 0].max(), np.median(diag[:, 1]))
     a = _solve(torch_cuda, pb, th0, mk(MMX_PRECISION_AUTO))
     assert np.array_equal(a["theta"], f["theta"]) and np.all(a["status"] & (MMX_SOLVE_MIXED | MMX_SOLVE_ESCALATED_F64) == 0)
+
+
+def test_auto_refuses_before_it_touches_theta_when_the_double_stage_cannot_run(torch_cuda):
+    """MMX_PRECISION_AUTO settles everything its later stages can refuse BEFORE the single-precision pass runs:
+    a 1000-joint chain is inside the explicit-Jacobian route's scope but beyond the double kernel's LDS budget -- the call
+    returns MMX_ERR_UNSUPPORTED with the caller's theta and status untouched; MMX_PRECISION_F32 solves the same problem."""
+    B = 4
+    rig = make_test_character(1000)
+    cons, th0, _ = make_problem(rig, [999, 500, 250], [], B, seed=5, perturb=0.05)
+    pb = _problem(torch_cuda, rig, cons, B)
+    theta = torch_cuda.from_numpy(th0.copy()).to(pb.device)
+    status = torch_cuda.full((B,), -77, dtype=torch_cuda.int32, device=pb.device)
+    outputs = dict(error=torch_cuda.zeros((B,), dtype=torch_cuda.float64, device=pb.device),
+                   iterations=torch_cuda.zeros((B,), dtype=torch_cuda.int32, device=pb.device), status=status)  # fmt: skip
+    opt = GnOptions.make(min_iterations=2, max_iterations=2, threshold=1.0, regularization=0.05, precision=MMX_PRECISION_AUTO)
+    with pytest.raises(capi.MmxError) as e:
+        pb.solve(theta, opt, outputs=outputs)
+    assert e.value.code == 4  # MMX_ERR_UNSUPPORTED
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(theta.cpu().numpy(), th0)
+    assert (status.cpu().numpy() == -77).all()
+    out = pb.solve(theta, GnOptions.make(min_iterations=2, max_iterations=2, threshold=1.0, regularization=0.05), outputs=outputs)
+    torch_cuda.cuda.synchronize()
+    # (three constraints on a thousand-joint chain: the factor's damping floor engages, one element may report a floored pivot --
+    # what matters here is that the single-precision route takes the problem and moves theta)
+    assert (out["status"].cpu().numpy() & 1 == 0).all() and not np.array_equal(out["theta"].cpu().numpy(), th0)
