@@ -26,8 +26,8 @@ for B in ((4096,) if clocks else (4096, 32768, 65536)):
     pb = capi.Problem(capi.RigHandle(rig, 0), B, cons.pos_parent, cons.ori_parent)
     t = lambda a: torch.from_numpy(rep(np.asarray(a, np.float32))).to(pb.device)
     pb.set_constraints(t(cons.pos_offset), t(cons.pos_target), t(cons.pos_weight), t(cons.ori_offset), t(cons.ori_target), t(cons.ori_weight))
-    if os.environ.get("MMX_MIXED_TOL"):
-        pb.set_mixed(float(os.environ["MMX_MIXED_TOL"]), 0)
+    if os.environ.get("MMX_MIXED_TOL") or os.environ.get("MMX_MIXED_MAXCG"):
+        pb.set_mixed(float(os.environ.get("MMX_MIXED_TOL", "0")), int(os.environ.get("MMX_MIXED_MAXCG", "0")))
     th0d = t(th0)
     cases = [("gn lambda=0.05", dict(regularization=0.05)), ("gn lambda=0.01", dict(regularization=0.01)), ("gn lambda=1e-3", dict(regularization=1e-3)),
              ("driver line search lambda=0.01", dict(regularization=0.01, do_line_search=2)), ("lm schedule", dict(regularization=0.05, step_rule=MMX_STEP_LM_SCHEDULE))]  # fmt: skip
