@@ -1,3 +1,4 @@
+"""cfg5 (wide route), three seeds: which instance ids leave the 1e-5 bound (the ids tests/test_gpu_baseline_parity.py pins)."""
 import sys; sys.path.insert(0,'.')
 import torch, numpy as np, bench
 from momentum_amd._abi import GnOptions

@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""cfg3 (LM schedule), both routes: quantiles of the precision estimate, its ratio to the measured error and the number of marked elements
+(-> profiles/rNN_precision_estimate.txt, first lines)."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from momentum_amd._abi import MMX_STEP_LM_SCHEDULE, GnOptions
 rig, parents, _, _, _ = bench.build_rig("cfg3")
