@@ -11,7 +11,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-extra-configs --no-cpu-baseline --check-instances 0 --no-measure-traffic --precision $prec --details $out/details.json"
-C="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
+C=${MMX_PHASE_COUNTERS:-"SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"}
 # stamps in program order: 1 FK | 2 units | 15 own sums | 3 subtree sums | 4 slot tables | 5 g | 6 H assembly (records, terms, pull) |
 # 7 factor | 8 first solve | 9 refinement | 10 update (end of iteration 1)
 for stop in 1 2 15 3 4 5 6 7 8 9 10 none; do
