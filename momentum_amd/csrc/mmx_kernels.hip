@@ -3598,7 +3598,7 @@ __global__ void __launch_bounds__(256) storePatternKernel(float* __restrict__ ja
 }
 
 hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent) {
-  const int waves = B <= 40000 ? 4 : 1; // launchFkJacobian's choice for J-assembly
+  const int waves = B < 12288 ? 4 : 3; // launchFkJacobian's choice for J-assembly
   if (M / 3 <= 64) {
     hipExtLaunchKernelGGL((storePatternKernel<true>), dim3(B), dim3(64 * waves), 0, stream, startEvent, stopEvent, 0, jac, M, P, waves);
   } else {
@@ -3678,7 +3678,12 @@ hipError_t launchFkJacobian(
   // eight waves leave too few workgroups per CU to overlap FK with stores (4096: 113 us).
   // Large rigs are LDS-bound (a 300-joint instance needs 25 KB), so they take four waves too.
   // FK only (no J): one wave per instance from 2048 instances on (16 vs 23 us at 4096).
-  const int wpi = (pb.B < 2048 || lds > 12 * 1024 || (jac != nullptr && pb.B <= 40000)) ? 4 : 1;
+  // Round 6, J-assembly at THREE waves per instance (never tried before: one, four and eight were), one box, 20 launches each, two
+  // sweeps, fraction of the 8 TB/s peak at one / three / four waves: B = 4096: 0.517 / 0.543 / 0.582; 8192: 0.58 / 0.614 / 0.611;
+  // 16 384: 0.63 / 0.65 / 0.63; 32 768: 0.66 / 0.70 / 0.67; 40 000: 0.68 / 0.70 / 0.67; 65 536: 0.69 / 0.70 / 0.68 -- three from
+  // 12 288 instances on (small rigs; the LDS-bound large rigs keep four).
+  const bool smallRig = lds <= 12 * 1024;
+  const int wpi = (pb.B < 2048 || !smallRig) ? 4 : (jac != nullptr ? (pb.B < 12288 ? 4 : 3) : 1);
   // non-temporal column stores throughout (measured better at every batch size once they were really emitted: see store3());
   // the structurally zero columns: one wave per instance alternates their position, several waves: those without joints write them first
   const int zeroPhase = (wpi == 1 ? 1 : 0) | (accurateFk ? 0x100 : 0);
@@ -3689,7 +3694,9 @@ hipError_t launchFkJacobian(
   hipExtLaunchKernelGGL(                                                                                                       \
       (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done, zeroPhase)
   if (jac != nullptr) {
-    if (wpi == 4) {
+    if (wpi == 3) {
+      MMX_FKJ(true, 3, true);
+    } else if (wpi == 4) {
       MMX_FKJ(true, 4, true);
     } else {
       MMX_FKJ(true, 1, true);

@@ -397,6 +397,35 @@ def test_full_size_batch_properties(torch_cuda):
     assert torch.all(out["status"] & 3 == 0) and torch.all(out["iterations"] == 10)
 
 
+def test_jacobian_is_the_same_whatever_the_waves_per_instance(torch_cuda):
+    """J-assembly deals an instance's columns to four waves below 12 288 instances per launch, to three from there on
+    (launchFkJacobian, mmx_kernels.hip: measured per batch size) and to one wave per instance when only FK / r are asked for:
+    the same instances give bit-identical J, r and errors in every launch shape."""
+    torch = torch_cuda
+    rig = make_humanoid72(unit=UNIT)
+    lm = humanoid72_landmark_joints(rig)
+    Bs = 64
+    cons, th0, _ = make_problem(rig, lm, lm, Bs, seed=4711, perturb=0.3)
+    from oracle import oracle as o
+
+    got = {}
+    for B in (Bs, 2048, 12288):
+        rep = lambda a: np.ascontiguousarray(np.tile(a, (B // Bs,) + (1,) * (a.ndim - 1)))
+        big = o.Constraints(cons.pos_parent, rep(cons.pos_offset), rep(cons.pos_target), rep(cons.pos_weight),
+                            cons.ori_parent, rep(cons.ori_offset), rep(cons.ori_target), rep(cons.ori_weight))  # fmt: skip
+        rh, pb = _gpu_problem(torch, rig, big, B)
+        jac, res, err = pb.eval_jacobian(torch.from_numpy(rep(th0)).to(pb.device))
+        torch.cuda.synchronize()
+        assert torch.equal(jac[:Bs].expand(B // Bs, *jac[:Bs].shape).reshape(jac.shape), jac)  # (every copy of the 64 instances alike)
+        got[B] = (jac[:Bs].cpu().numpy(), res[:Bs].cpu().numpy(), err[:Bs].cpu().numpy())
+        del jac, res, err, pb, rh
+        torch.cuda.empty_cache()
+    for B in (2048, 12288):
+        for a, b in zip(got[Bs], got[B]):
+            assert np.array_equal(a, b)
+    assert np.isfinite(got[Bs][0]).all() and np.abs(got[Bs][0]).max() > 0
+
+
 @pytest.mark.parametrize("kp,ko", [(60, 2), (130, 90), (250, 100)])
 def test_jacobian_unit_chunks_match_oracle(torch_cuda, orc, kp, ko):
     """J-assembly with more units than lanes: 66 units (a second, nearly empty chunk), 400 (the last
