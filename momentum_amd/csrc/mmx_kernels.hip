@@ -3585,7 +3585,7 @@ solveFinalizeKernel(float* __restrict__ theta, const float* __restrict__ thetaIn
 // chunk after chunk otherwise, like fkJacobianKernel).  What this reaches is the ceiling the write
 // pattern itself sets for the graded kernel on the box at hand (bench.py: roofline.store_pattern_gbs).
 template <bool kNt>
-__global__ void __launch_bounds__(256) storePatternKernel(float* __restrict__ jac, int M, int P, int waves) {
+__global__ void __launch_bounds__(1024) storePatternKernel(float* __restrict__ jac, int M, int P, int waves) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* jb = jac + size_t(blockIdx.x) * size_t(M) * size_t(P);
   const float v = float(blockIdx.x);
@@ -3602,7 +3602,8 @@ hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t strea
   if (M / 3 <= 64) {
     hipExtLaunchKernelGGL((storePatternKernel<true>), dim3(B), dim3(64 * waves), 0, stream, startEvent, stopEvent, 0, jac, M, P, waves);
   } else {
-    hipExtLaunchKernelGGL((storePatternKernel<false>), dim3(B), dim3(256), 0, stream, startEvent, stopEvent, 0, jac, M, P, 4);
+    const int wavesLarge = B >= 8192 ? 16 : 8; // (launchFkJacobian's choice for the large rigs)
+    hipExtLaunchKernelGGL((storePatternKernel<false>), dim3(B), dim3(64 * wavesLarge), 0, stream, startEvent, stopEvent, 0, jac, M, P, wavesLarge);
   }
   return hipGetLastError();
 }
@@ -3682,8 +3683,11 @@ hipError_t launchFkJacobian(
   // sweeps, fraction of the 8 TB/s peak at one / three / four waves: B = 4096: 0.517 / 0.543 / 0.582; 8192: 0.58 / 0.614 / 0.611;
   // 16 384: 0.63 / 0.65 / 0.63; 32 768: 0.66 / 0.70 / 0.67; 40 000: 0.68 / 0.70 / 0.67; 65 536: 0.69 / 0.70 / 0.68 -- three from
   // 12 288 instances on (small rigs; the LDS-bound large rigs keep four).
+  // The LDS-bound large rigs (a 300-joint instance needs 25 KB; BASELINE configs[4], 1.09 MB of J per instance), same sweep:
+  // B = 2048: four / eight / sixteen waves 0.516 / 0.534 / 0.515; B = 8192: 0.554-0.571 / 0.574-0.590 / 0.589 (two boxes) --
+  // eight, sixteen from 8192 instances on.
   const bool smallRig = lds <= 12 * 1024;
-  const int wpi = (pb.B < 2048 || !smallRig) ? 4 : (jac != nullptr ? (pb.B < 12288 ? 4 : 3) : 1);
+  const int wpi = !smallRig ? (jac != nullptr ? (pb.B >= 8192 ? 16 : 8) : 4) : (pb.B < 2048 ? 4 : (jac != nullptr ? (pb.B < 12288 ? 4 : 3) : 1));
   // non-temporal column stores throughout (measured better at every batch size once they were really emitted: see store3());
   // the structurally zero columns: one wave per instance alternates their position, several waves: those without joints write them first
   const int zeroPhase = (wpi == 1 ? 1 : 0) | (accurateFk ? 0x100 : 0);
@@ -3694,7 +3698,11 @@ hipError_t launchFkJacobian(
   hipExtLaunchKernelGGL(                                                                                                       \
       (fkJacobianKernel<W_, WPI_, S_>), dim3(pb.B), dim3(64 * WPI_), lds, stream, startEvent, stopEvent, 0, rig, pb, theta, jac, res, err, state, done, zeroPhase)
   if (jac != nullptr) {
-    if (wpi == 3) {
+    if (wpi == 16) {
+      MMX_FKJ(true, 16, true);
+    } else if (wpi == 8) {
+      MMX_FKJ(true, 8, true);
+    } else if (wpi == 3) {
       MMX_FKJ(true, 3, true);
     } else if (wpi == 4) {
       MMX_FKJ(true, 4, true);

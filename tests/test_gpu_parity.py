@@ -397,19 +397,29 @@ def test_full_size_batch_properties(torch_cuda):
     assert torch.all(out["status"] & 3 == 0) and torch.all(out["iterations"] == 10)
 
 
-def test_jacobian_is_the_same_whatever_the_waves_per_instance(torch_cuda):
-    """J-assembly deals an instance's columns to four waves below 12 288 instances per launch, to three from there on
-    (launchFkJacobian, mmx_kernels.hip: measured per batch size) and to one wave per instance when only FK / r are asked for:
-    the same instances give bit-identical J, r and errors in every launch shape."""
+@pytest.mark.parametrize("shape", ["humanoid72", "rig300"])
+def test_jacobian_is_the_same_whatever_the_waves_per_instance(torch_cuda, shape):
+    """J-assembly deals an instance's columns to four waves below 12 288 instances per launch and to three from there on; the
+    LDS-bound large rigs take eight, sixteen from 8192 instances on (launchFkJacobian, mmx_kernels.hip: measured per batch
+    size): the same instances give bit-identical J, r and errors in every launch shape."""
     torch = torch_cuda
-    rig = make_humanoid72(unit=UNIT)
-    lm = humanoid72_landmark_joints(rig)
-    Bs = 64
-    cons, th0, _ = make_problem(rig, lm, lm, Bs, seed=4711, perturb=0.3)
+    if shape == "humanoid72":
+        rig = make_humanoid72(unit=UNIT)
+        lm = humanoid72_landmark_joints(rig)
+        pos, ori, Bs, sizes = lm, lm, 64, (64, 2048, 12288)
+    else:
+        from momentum_amd import make_rig300
+
+        rig = make_rig300(unit=UNIT)
+        rng = np.random.default_rng(3)
+        pos = np.sort(rng.choice(rig.num_joints, 150, replace=False))
+        ori = np.sort(rng.choice(rig.num_joints, 50, replace=False))
+        Bs, sizes = 8, (8, 512, 8192)
+    cons, th0, _ = make_problem(rig, pos, ori, Bs, seed=4711, perturb=0.3)
     from oracle import oracle as o
 
     got = {}
-    for B in (Bs, 2048, 12288):
+    for B in sizes:
         rep = lambda a: np.ascontiguousarray(np.tile(a, (B // Bs,) + (1,) * (a.ndim - 1)))
         big = o.Constraints(cons.pos_parent, rep(cons.pos_offset), rep(cons.pos_target), rep(cons.pos_weight),
                             cons.ori_parent, rep(cons.ori_offset), rep(cons.ori_target), rep(cons.ori_weight))  # fmt: skip
@@ -420,7 +430,7 @@ def test_jacobian_is_the_same_whatever_the_waves_per_instance(torch_cuda):
         got[B] = (jac[:Bs].cpu().numpy(), res[:Bs].cpu().numpy(), err[:Bs].cpu().numpy())
         del jac, res, err, pb, rh
         torch.cuda.empty_cache()
-    for B in (2048, 12288):
+    for B in sizes[1:]:
         for a, b in zip(got[Bs], got[B]):
             assert np.array_equal(a, b)
     assert np.isfinite(got[Bs][0]).all() and np.abs(got[Bs][0]).max() > 0
