@@ -64,7 +64,8 @@ def avg_us(path, wg):
         if line.startswith(f"[{wg} wg]") and "fkJacobianKernel<true" in line:
             f=line.split()
             # columns: ... calls total_ms avg_us min_us max_us pct (from the right)
-            return int(f[-6]), float(f[-4])
+            m=re.search(r"fkJacobianKernel<[^>]*>", line)
+            return int(f[-6]), float(f[-4]), (m.group(0).replace(" ", "") if m else "fkJacobianKernel<true,...>")
     return None
 rows=[]
 for tag,path,wg,M,P,Kp,Ko in (("cfg2 (BASELINE configs[1], B = 4096)", f"{out}/{r}_bench_kernel_stats.txt", 4096, 192, 128, 16, 16),
@@ -74,10 +75,10 @@ for tag,path,wg,M,P,Kp,Ko in (("cfg2 (BASELINE configs[1], B = 4096)", f"{out}/{
     except OSError:
         got=None
     if not got: continue
-    calls,us=got
+    calls,us,kname=got
     bpi=4*(M*P+M)+4*P+4*(7*Kp+9*Ko)+4*(Kp+Ko)
     gbs=bpi*wg/(us*1e-6)/1e9
-    rows.append(f"{tag}: fkJacobianKernel<true,4,true> at {wg} workgroups: {calls} launches, average {us:.2f} us; {bpi} B per instance x {wg} = {bpi*wg} B per launch -> {gbs:.0f} GB/s = {gbs/8000:.3f} of the 8 TB/s HBM peak")
+    rows.append(f"{tag}: {kname} at {wg} workgroups: {calls} launches, average {us:.2f} us; {bpi} B per instance x {wg} = {bpi*wg} B per launch -> {gbs:.0f} GB/s = {gbs/8000:.3f} of the 8 TB/s HBM peak")
 open(f"{out}/{r}_roofline.txt","w").write("\n".join(rows)+"\n")
 print("\n".join(rows))
 PY
