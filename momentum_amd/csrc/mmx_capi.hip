@@ -1949,7 +1949,7 @@ int32_t mmx_debug_store_pattern(mmx_problem* pb, float* jac_dev, void* stream, f
   MMX_HIP(hipEventCreate(&e0));
   hipError_t err = hipEventCreate(&e1);
   if (err == hipSuccess) {
-    err = mmx::launchStorePattern(jac_dev, pb->B, pb->dev.M, pb->rig->dev.P, static_cast<hipStream_t>(stream), e0, e1);
+    err = mmx::launchStorePattern(jac_dev, pb->B, pb->dev.M, pb->rig->dev.P, mmx::fkJacobianWavesPerInstance(pb->rigDev, pb->dev, true), static_cast<hipStream_t>(stream), e0, e1);
   }
   if (err == hipSuccess) {
     err = hipEventSynchronize(e1);

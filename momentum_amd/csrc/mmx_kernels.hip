@@ -3597,15 +3597,36 @@ __global__ void __launch_bounds__(1024) storePatternKernel(float* __restrict__ j
   }
 }
 
-hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent) {
-  const int waves = B < 12288 ? 4 : 3; // launchFkJacobian's choice for J-assembly
+hipError_t launchStorePattern(float* jac, int B, int M, int P, int waves, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent) {
+  if (waves < 1 || waves > 16) {
+    return hipErrorInvalidValue;
+  }
   if (M / 3 <= 64) {
     hipExtLaunchKernelGGL((storePatternKernel<true>), dim3(B), dim3(64 * waves), 0, stream, startEvent, stopEvent, 0, jac, M, P, waves);
   } else {
-    const int wavesLarge = B >= 8192 ? 16 : 8; // (launchFkJacobian's choice for the large rigs)
-    hipExtLaunchKernelGGL((storePatternKernel<false>), dim3(B), dim3(64 * wavesLarge), 0, stream, startEvent, stopEvent, 0, jac, M, P, wavesLarge);
+    hipExtLaunchKernelGGL((storePatternKernel<false>), dim3(B), dim3(64 * waves), 0, stream, startEvent, stopEvent, 0, jac, M, P, waves);
   }
   return hipGetLastError();
+}
+
+int fkJacobianWavesPerInstance(const RigDev& rig, const ProblemDev& pb, bool withJacobian) {
+  // Wavefronts per instance.  J-assembly: several waves share one instance (FK over all threads, the column program dealt to
+  // the waves) -- fewer instances are then in flight at a time, and write bandwidth on this part falls with the footprint of
+  // the concurrently written regions (scripts/probes/store_k.hip: 6.7 TB/s when a workgroup writes 4 KB and ends, 5.4 TB/s at
+  // 96 KB per workgroup).  Round 6 sweep, one box, 20 launches each, two sweeps, fraction of the 8 TB/s peak at one / three /
+  // four waves (two and eight lose everywhere): B = 4096: 0.517 / 0.543 / 0.582; 8192: 0.58 / 0.614 / 0.611; 16 384: 0.63 / 0.65 /
+  // 0.63; 32 768: 0.66 / 0.70 / 0.67; 40 000: 0.68 / 0.70 / 0.67; 65 536: 0.69 / 0.70 / 0.68 -- four below 12 288 instances, three
+  // from there on.  The LDS-bound large rigs (a 300-joint instance needs 25 KB; BASELINE configs[4], 1.09 MB of J per instance):
+  // B = 2048: four / eight / sixteen waves 0.516 / 0.534 / 0.515; B = 8192: 0.554-0.571 / 0.574-0.590 / 0.589 (two boxes) -- eight,
+  // sixteen from 8192 instances on.  FK only (no J): one wave per instance from 2048 instances on (16 against 23 us at 4096).
+  const bool smallRig = fkJacobianLdsBytes(rig.J, rig.P, pb.U) <= 12 * 1024;
+  if (!smallRig) {
+    return withJacobian ? (pb.B >= 8192 ? 16 : 8) : 4;
+  }
+  if (pb.B < 2048) {
+    return 4;
+  }
+  return withJacobian ? (pb.B < 12288 ? 4 : 3) : 1;
 }
 
 // =============================================================================================
@@ -3670,24 +3691,7 @@ hipError_t launchFkJacobian(
       accurateFk = false;
     }
   }
-  // Wavefronts per instance.  J-assembly: four waves share one instance (FK over 256 threads, the
-  // column program dealt to the waves) up to 40 000 instances per launch -- fewer instances are then
-  // in flight at a time (5 workgroups per CU instead of 20), and write bandwidth on this part
-  // falls with the footprint of the concurrently written regions (scripts/store_k.hip: 6.7 TB/s
-  // when a workgroup writes 4 KB and ends, 5.4 TB/s at 96 KB per workgroup).  Measured, same box:
-  // B = 4096: 95 -> 88 us, 16384: 335 -> 309 us, 32768: 632 -> 617 us, 65536: 1232 -> 1245 us;
-  // eight waves leave too few workgroups per CU to overlap FK with stores (4096: 113 us).
-  // Large rigs are LDS-bound (a 300-joint instance needs 25 KB), so they take four waves too.
-  // FK only (no J): one wave per instance from 2048 instances on (16 vs 23 us at 4096).
-  // Round 6, J-assembly at THREE waves per instance (never tried before: one, four and eight were), one box, 20 launches each, two
-  // sweeps, fraction of the 8 TB/s peak at one / three / four waves: B = 4096: 0.517 / 0.543 / 0.582; 8192: 0.58 / 0.614 / 0.611;
-  // 16 384: 0.63 / 0.65 / 0.63; 32 768: 0.66 / 0.70 / 0.67; 40 000: 0.68 / 0.70 / 0.67; 65 536: 0.69 / 0.70 / 0.68 -- three from
-  // 12 288 instances on (small rigs; the LDS-bound large rigs keep four).
-  // The LDS-bound large rigs (a 300-joint instance needs 25 KB; BASELINE configs[4], 1.09 MB of J per instance), same sweep:
-  // B = 2048: four / eight / sixteen waves 0.516 / 0.534 / 0.515; B = 8192: 0.554-0.571 / 0.574-0.590 / 0.589 (two boxes) --
-  // eight, sixteen from 8192 instances on.
-  const bool smallRig = lds <= 12 * 1024;
-  const int wpi = !smallRig ? (jac != nullptr ? (pb.B >= 8192 ? 16 : 8) : 4) : (pb.B < 2048 ? 4 : (jac != nullptr ? (pb.B < 12288 ? 4 : 3) : 1));
+  const int wpi = fkJacobianWavesPerInstance(rig, pb, jac != nullptr);
   // non-temporal column stores throughout (measured better at every batch size once they were really emitted: see store3());
   // the structurally zero columns: one wave per instance alternates their position, several waves: those without joints write them first
   const int zeroPhase = (wpi == 1 ? 1 : 0) | (accurateFk ? 0x100 : 0);

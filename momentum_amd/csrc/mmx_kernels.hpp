@@ -270,7 +270,10 @@ hipError_t launchSelectSuspect(const int32_t* status, int B, int32_t mask, int32
 
 size_t fkJacobianLdsBytes(int J, int P, int U);
 // store-only counterpart of the J-assembly kernel (profiling aid; see storePatternKernel)
-hipError_t launchStorePattern(float* jac, int B, int M, int P, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent);
+// wavefronts per instance launchFkJacobian takes for this problem (J-assembly when withJacobian, else FK / r / error only)
+int fkJacobianWavesPerInstance(const RigDev& rig, const ProblemDev& pb, bool withJacobian);
+// (waves: fkJacobianWavesPerInstance of the problem the pattern stands for -- the probe keeps the graded kernel's launch shape)
+hipError_t launchStorePattern(float* jac, int B, int M, int P, int waves, hipStream_t stream, hipEvent_t startEvent, hipEvent_t stopEvent);
 // column-major [B][P][M] -> row-major [B][M][P] (MMX_LAYOUT_ROW_MAJOR)
 hipError_t launchTransposeJacobian(const float* colMajor, float* rowMajor, int B, int M, int P, hipStream_t stream);
 // Most solved parameters of a problem: up to 512 on every route (tile masks of 32 blocks); 513 ... kMaxSolved on the
